@@ -1,0 +1,54 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see hal_oracle.hpp).
+#pragma once
+#include "oracle_mapper.hpp"
+#include <istream>
+#include <ostream>
+
+namespace orc {
+
+// liftover/inc/halBedLine.h:48-82
+struct BedLine {
+    std::string _chrName;
+    i64 _start = NULL_INDEX, _end = NULL_INDEX;
+    std::string _name;
+    i64 _score = 0;
+    char _strand = '+';
+    i64 _thickStart = 0, _thickEnd = 0, _itemR = 0, _itemG = 0, _itemB = 0;
+    std::vector<std::string> _extra;
+    int _bedType = -1;
+    i64 _srcStart = NULL_INDEX;
+    char _srcStrand = '+';
+    std::istream &read(std::istream &is, std::string &lineBuffer, int bedType);
+    std::ostream &write(std::ostream &os) const;
+};
+
+void extractSegment(MSegSet::iterator start, const MSegSet &paraSet, std::vector<MSegPtr> &fragments, MSegSet *startSet,
+                    const std::set<i64> &targetCutPoints, std::set<i64> &queryCutPoints);
+
+// liftover/inc/halLiftover.h + halBlockLiftover.h, flattened
+struct Liftover {
+    const Alignment *al = nullptr;
+    int srcGenome = -1, tgtGenome = -1, coalescenceLimit = -1, mrca = -1;
+    bool traverseDupes = true;
+    std::ostream *outStream = nullptr;
+    BedLine bedLine;
+    const Sequence *srcSequence = nullptr;
+    std::set<std::string> missedSet;
+    std::list<BedLine> outBedLines, mappedBlocks;
+    SegIt refSeg;
+    i64 lastIndex = 0;
+    std::set<int> downwardPath;
+    MSegSet mappedSegments;
+    // statistics for bench.py's cpu_baseline leg
+    double mapSeconds = 0;
+    size_t numIntervals = 0, numRecords = 0, numMappedPieces = 0;
+
+    void convert(const Alignment *alignment, int src, std::istream *bedIn, int tgt, std::ostream *bedOut, int bedType = 0,
+                 bool doDupes = true, int coalLimit = -1);
+    void visitBegin();
+    void visitLine();
+    void liftInterval(std::list<BedLine> &mappedBedLines);
+    void cleanResults();
+};
+
+} // namespace orc
