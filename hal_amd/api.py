@@ -1,0 +1,271 @@
+"""Python mirror of the reference interfaces this library stands behind (argument names and meaning
+follow Liftover::convert, liftover/inc/halLiftover.h:25-28, and the Alignment/Genome getters)."""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib, HgxError, hgx_interval, hgx_record, hgx_liftover_opts, hgx_liftover_stats, hgx_rand_opts, take_error
+
+RECORD_DTYPE = np.dtype([("query", "<i8"), ("tgt_start", "<i8"), ("tgt_end", "<i8"), ("src_start", "<i8"),
+                         ("tgt_seq", "<i4"), ("strand", "S1"), ("_pad", "S3")])
+assert RECORD_DTYPE.itemsize == C.sizeof(hgx_record) == 40
+INTERVAL_DTYPE = np.dtype([("start", "<i8"), ("end", "<i8"), ("seq", "<i4"), ("strand", "S1"), ("_pad", "S3")])
+assert INTERVAL_DTYPE.itemsize == C.sizeof(hgx_interval) == 24
+
+
+@dataclass
+class Interval:
+    seq: int
+    start: int
+    end: int
+    strand: str = "+"
+
+
+@dataclass
+class Record:
+    query: int
+    tgt_seq: int
+    tgt_start: int
+    tgt_end: int
+    strand: str
+    src_start: int
+
+
+@dataclass
+class RandOptions:
+    """halRandGen options (randgen/halRandGen.cpp:39-56)."""
+    mean_degree: float = 1.25
+    max_branch_length: float = 0.7
+    min_genomes: int = 8
+    max_genomes: int = 20
+    min_segment_length: int = 500
+    max_segment_length: int = 2000
+    min_segments: int = 100
+    max_segments: int = 500
+    seed: int = -1
+    with_dna: bool = True
+
+    @staticmethod
+    def preset(name, seed=-1, with_dna=True):
+        o = hgx_rand_opts()
+        o.seed = seed
+        o.with_dna = 1 if with_dna else 0
+        if lib.hgx_rand_preset(name.encode(), C.byref(o)) != 0:
+            raise HgxError("invalid --preset value: %s" % name)
+        return RandOptions(o.mean_degree, o.max_branch_length, o.min_genomes, o.max_genomes, o.min_segment_length,
+                           o.max_segment_length, o.min_segments, o.max_segments, seed, with_dna)
+
+    def _c(self):
+        o = hgx_rand_opts()
+        (o.mean_degree, o.max_branch_length, o.min_genomes, o.max_genomes, o.min_segment_length, o.max_segment_length,
+         o.min_segments, o.max_segments, o.seed, o.with_dna) = (
+            self.mean_degree, self.max_branch_length, self.min_genomes, self.max_genomes, self.min_segment_length,
+            self.max_segment_length, self.min_segments, self.max_segments, self.seed, 1 if self.with_dna else 0)
+        return o
+
+
+class Alignment:
+    """An open alignment (openHalAlignment, api/impl/halAlignmentInstance.cpp:133-165).  device=-1 keeps the
+    tables on the host (metadata only); device>=0 uploads them to that GPU."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @staticmethod
+    def open(path, device=0):
+        h, err = C.c_void_p(), C.c_void_p()
+        if lib.hgx_open(str(path).encode(), device, C.byref(h), C.byref(err)) != 0:
+            raise HgxError(take_error(err))
+        return Alignment(h)
+
+    @staticmethod
+    def random(opts, device=0):
+        h, err = C.c_void_p(), C.c_void_p()
+        o = opts._c()
+        if lib.hgx_create_random(C.byref(o), device, C.byref(h), C.byref(err)) != 0:
+            raise HgxError(take_error(err))
+        return Alignment(h)
+
+    def close(self):
+        if self._h:
+            lib.hgx_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def save(self, path):
+        err = C.c_void_p()
+        if lib.hgx_save_image(self._h, str(path).encode(), C.byref(err)) != 0:
+            raise HgxError(take_error(err))
+
+    # --- Alignment / Genome / Sequence getters ---
+    @property
+    def num_genomes(self):
+        return lib.hgx_num_genomes(self._h)
+
+    @property
+    def newick(self):
+        return lib.hgx_newick(self._h).decode()
+
+    def genome_name(self, g):
+        n = lib.hgx_genome_name(self._h, g)
+        if n is None:
+            raise HgxError("genome id out of range")
+        return n.decode()
+
+    def genome_id(self, name):
+        return lib.hgx_genome_id(self._h, name.encode())
+
+    def genome_parent(self, g):
+        return lib.hgx_genome_parent(self._h, g)
+
+    def genome_children(self, g):
+        return [lib.hgx_genome_child(self._h, g, k) for k in range(lib.hgx_genome_num_children(self._h, g))]
+
+    def genome_length(self, g):
+        return lib.hgx_genome_length(self._h, g)
+
+    def num_top_segments(self, g):
+        return lib.hgx_genome_num_top(self._h, g)
+
+    def num_bottom_segments(self, g):
+        return lib.hgx_genome_num_bottom(self._h, g)
+
+    def sequences(self, g):
+        out = []
+        for s in range(lib.hgx_genome_num_sequences(self._h, g)):
+            name, start, length = C.c_char_p(), C.c_int64(), C.c_int64()
+            lib.hgx_sequence_info(self._h, g, s, C.byref(name), C.byref(start), C.byref(length))
+            out.append((name.value.decode(), start.value, length.value))
+        return out
+
+    def sequence_lookup(self, g, name):
+        start, length = C.c_int64(), C.c_int64()
+        s = lib.hgx_sequence_lookup(self._h, g, name.encode(), C.byref(start), C.byref(length))
+        return (s, start.value, length.value) if s >= 0 else None
+
+    def mrca(self, a, b):
+        return lib.hgx_mrca(self._h, a, b)
+
+    # --- liftover, host-buffer form ---
+    def liftover_batch(self, src, tgt, intervals, traverse_dupes=True, min_length=0, coalescence_limit=-1):
+        """intervals: numpy array of INTERVAL_DTYPE or list of Interval.  Returns a numpy array of RECORD_DTYPE."""
+        if not isinstance(intervals, np.ndarray):
+            arr = np.zeros(len(intervals), dtype=INTERVAL_DTYPE)
+            for i, q in enumerate(intervals):
+                arr[i] = (q.start, q.end, q.seq, q.strand.encode(), b"")
+            intervals = arr
+        intervals = np.ascontiguousarray(intervals, dtype=INTERVAL_DTYPE)
+        opts = hgx_liftover_opts(1 if traverse_dupes else 0, coalescence_limit, min_length)
+        out, n, err = C.POINTER(hgx_record)(), C.c_size_t(), C.c_void_p()
+        rc = lib.hgx_liftover_batch(self._h, src, tgt, len(intervals),
+                                    intervals.ctypes.data_as(C.POINTER(hgx_interval)), C.byref(opts), C.byref(out),
+                                    C.byref(n), C.byref(err))
+        if rc != 0:
+            raise HgxError(take_error(err))
+        try:
+            res = np.frombuffer(C.string_at(out, n.value * 40), dtype=RECORD_DTYPE).copy() if n.value else np.zeros(0, RECORD_DTYPE)
+        finally:
+            lib.hgx_free(out)
+        return res
+
+
+def liftover_convert(alignment, src_genome, bed_text, tgt_genome, bed_type=0, traverse_dupes=True, out_psl=False,
+                     out_psl_with_name=False, coalescence_limit=-1):
+    """Liftover::convert (liftover/impl/halLiftover.cpp:23-41) on BED text; returns the output BED text.
+    Raises HgxError with the reference's message on malformed input (after lifting the preceding lines)."""
+    data = bed_text.encode() if isinstance(bed_text, str) else bed_text
+    out, n, err = C.c_void_p(), C.c_size_t(), C.c_void_p()
+    rc = lib.hgx_liftover_convert(alignment._h, src_genome, data, len(data), tgt_genome, bed_type, 1 if traverse_dupes else 0,
+                                  1 if out_psl else 0, 1 if out_psl_with_name else 0, coalescence_limit, C.byref(out),
+                                  C.byref(n), C.byref(err))
+    text = C.string_at(out, n.value).decode() if out.value else ""
+    if out.value:
+        lib.hgx_free(out)
+    if rc != 0:
+        e = HgxError(take_error(err))
+        e.partial_output = text
+        raise e
+    return text
+
+
+class LiftoverPlan:
+    """Device-resident liftover: queries and records stay in HBM (hgx_liftover_run_device)."""
+
+    def __init__(self, alignment, src, tgt, max_queries, traverse_dupes=True, min_length=0):
+        self._al = alignment
+        opts = hgx_liftover_opts(1 if traverse_dupes else 0, -1, min_length)
+        p, err = C.c_void_p(), C.c_void_p()
+        if lib.hgx_liftover_plan_create(alignment._h, src, tgt, C.byref(opts), max_queries, C.byref(p), C.byref(err)) != 0:
+            raise HgxError(take_error(err))
+        self._p = p
+
+    def close(self):
+        if self._p:
+            lib.hgx_liftover_plan_destroy(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run_ptr(self, n, d_gstart, d_gend, d_strand, stream=0):
+        """Raw-pointer form: device pointers (ints) of int64 start/end (inclusive genome coordinates) and uint8
+        strand.  Returns (device pointer of hgx_record[n_records], n_records)."""
+        out, nrec, err = C.c_void_p(), C.c_size_t(), C.c_void_p()
+        rc = lib.hgx_liftover_run_device(self._p, n, d_gstart, d_gend, d_strand, stream, C.byref(out), C.byref(nrec), C.byref(err))
+        if rc != 0:
+            raise HgxError(take_error(err))
+        return out.value or 0, nrec.value
+
+    def run(self, gstart, gend, strand):
+        """torch tensors on the alignment's device: int64 gstart/gend, uint8 strand; runs on torch's current stream."""
+        import torch
+        assert gstart.is_cuda and gstart.dtype == torch.int64 and gend.dtype == torch.int64 and strand.dtype == torch.uint8
+        stream = torch.cuda.current_stream(gstart.device).cuda_stream
+        return self.run_ptr(gstart.numel(), gstart.data_ptr(), gend.data_ptr(), strand.data_ptr(), stream)
+
+    def records_to_tensor(self, ptr, n):
+        """Copy the plan-owned device records into a fresh torch uint8 tensor [n, 40] (device to device)."""
+        import torch
+        t = torch.empty((n, 40), dtype=torch.uint8, device="cuda")
+        if n:
+            _hip_memcpy_dtod(t.data_ptr(), ptr, n * 40)
+        return t
+
+    def stats(self):
+        s = hgx_liftover_stats()
+        lib.hgx_liftover_last_stats(self._p, C.byref(s))
+        return {k: getattr(s, k) for k, _ in hgx_liftover_stats._fields_}
+
+    def kernel_times(self):
+        import json
+        js = C.c_void_p()
+        if lib.hgx_liftover_kernel_times(self._p, C.byref(js)) != 0:
+            return {}
+        try:
+            return json.loads(C.string_at(js.value).decode())
+        finally:
+            lib.hgx_free(js)
+
+
+_hip = None
+
+
+def _hip_memcpy_dtod(dst, src, nbytes):
+    global _hip
+    if _hip is None:
+        _hip = C.CDLL("libamdhip64.so")
+        _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        _hip.hipMemcpy.restype = C.c_int
+    rc = _hip.hipMemcpy(dst, src, nbytes, 3)  # hipMemcpyDeviceToDevice
+    if rc != 0:
+        raise HgxError("hipMemcpy failed with code %d" % rc)

@@ -1,0 +1,68 @@
+// Device-resident alignment tables (HBM layout) and the handle behind the C ABI.
+//
+// Per genome the image is narrowed to the fields one hop of the segment graph touches together, so that
+// a random hop costs one 16-byte record (one 64-byte sector) instead of one sector per field:
+//   TopRec<C>[numTop+1]   { C start; i32 parentEnc; i32 paralogy; i32 botParse }   (sentinel: start = length)
+//   BotRec<C>[numBot+1]   { C start; i32 topParse }
+//   childEnc[slot][numBot] i32
+// link encoding: (index << 1) | reversedBit, NULL_INDEX -> -1.  C is int32 when every genome is shorter
+// than 2^31 bases, else int64 (tables are re-instantiated, kernels are templates on C).
+// Source layouts: api/mmap_impl/mmapTopSegmentData.h:40-44, mmapBottomSegmentData.h:35-52.
+#pragma once
+#include "hgx_image.hpp"
+#include <memory>
+
+namespace hgx {
+
+template <typename C> struct alignas(16) TopRec;
+template <> struct alignas(16) TopRec<int32_t> {
+    int32_t start;
+    int32_t parentEnc;
+    int32_t paralogy;
+    int32_t botParse;
+};
+template <> struct alignas(16) TopRec<int64_t> {
+    int64_t start;
+    int32_t parentEnc;
+    int32_t paralogy;
+    int32_t botParse;
+    int32_t _pad[3];
+};
+template <typename C> struct BotRec;
+template <> struct alignas(8) BotRec<int32_t> {
+    int32_t start;
+    int32_t topParse;
+};
+template <> struct alignas(16) BotRec<int64_t> {
+    int64_t start;
+    int32_t topParse;
+    int32_t _pad;
+};
+
+struct DeviceGenome {
+    void *top = nullptr;                // TopRec<C>[numTop+1]
+    void *bot = nullptr;                // BotRec<C>[numBot+1]
+    std::vector<int32_t *> childEnc;    // per child slot, int32[numBot]
+    int64_t *seqStart = nullptr;        // int64[numSeq+1] (sentinel = genome length)
+    int32_t numSeq = 0;
+    int64_t numTop = 0, numBot = 0;
+};
+
+struct DeviceImage {
+    int device = -1;
+    bool wide = false; // C == int64_t
+    std::vector<DeviceGenome> genomes;
+    size_t bytes = 0;
+    ~DeviceImage();
+};
+
+// uploads img to `device`; throws std::runtime_error on any HIP failure or unsupported size
+std::unique_ptr<DeviceImage> uploadImage(const Image &img, int device);
+
+} // namespace hgx
+
+// the opaque handle of include/hgx.h
+struct hgx_alignment {
+    hgx::Image img;
+    std::unique_ptr<hgx::DeviceImage> dev;
+};

@@ -1,0 +1,542 @@
+// Per-interval finishing kernel: turns the unordered bag of mapped pieces of one query interval into
+// the reference's output lines.  One wavefront per interval, data staged in LDS.
+//
+//  1. order pieces like the reference's MappedSegmentSet: by target, then source, in forward
+//     coordinates (MappedSegment::lessThan / fastComp, api/impl/halMappedSegment.cpp:36-43,167-206);
+//  2. break overlaps: insertAndBreakOverlaps (api/impl/halSegmentMapper.cpp:475-520) leaves a set in which
+//     any two members have identical or disjoint target ranges, i.e. every piece cut at every boundary of
+//     every piece overlapping it — computed here directly as that common refinement (order independent),
+//     source side sliced in lock-step (MappedSegment::slice, halMappedSegment.cpp:395-402);
+//  3. merge runs: BlockMapper::extractSegment (liftover/impl/halBlockMapper.cpp:331-394) with
+//     canMergeRightWith (halMappedSegment.cpp:109-161) and the query cut-point set, walking the set in
+//     target order exactly as liftInterval does (liftover/impl/halBlockLiftover.cpp:79-105);
+//  4. stable sort of the lines by source start (Liftover::visitLine, liftover/impl/halLiftover.cpp:90).
+// Queries whose working set exceeds the staging capacity are deferred to the same code running on a
+// global-memory scratch area (template parameter); nothing is approximated.
+#pragma once
+#include "../../include/hgx.h"
+#include "hgx_liftover_kernels.hpp"
+
+namespace hgx {
+
+template <typename C> struct FinishStore {
+    // piece arrays, two banks (A = current, B = scratch / refinement output)
+    C *tLo, *tHi, *sLo, *sHi;
+    uint8_t *fl;
+    C *tLo2, *tHi2, *sLo2, *sHi2;
+    uint8_t *fl2;
+    int32_t *seq;   // target sequence index of each piece
+    uint32_t *ord;  // permutation / offsets scratch, capacity cap2 (power of two >= 2*cap)
+    C *bnd, *bnd2;  // boundary coordinates (raw / sorted unique), capacity cap2 each
+    uint8_t *alive; // set membership during extraction
+    C *cut;         // query cut points
+    // output lines
+    C *lStart, *lEnd, *lSrc;
+    int32_t *lSeq;
+    uint8_t *lStrand;
+    int cap, cap2, cutCap;
+};
+
+__device__ __forceinline__ void wsync() {
+    __syncthreads(); // block == one wavefront
+}
+
+// bitonic sort of ord[0..n2) (n2 power of two) by a strict weak order on the indices
+template <typename Less> __device__ __forceinline__ void wave_bitonic(uint32_t *ord, int n2, Less less) {
+    const int lane = lane_id();
+    for (int k = 2; k <= n2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = lane; t < (n2 >> 1); t += 64) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int p = i + j;
+                const bool up = (i & k) == 0;
+                const uint32_t a = ord[i], b = ord[p];
+                const bool swap = up ? less(b, a) : less(a, b);
+                if (swap) {
+                    ord[i] = b;
+                    ord[p] = a;
+                }
+            }
+            wsync();
+        }
+    }
+}
+
+__device__ __forceinline__ int pow2_at_least(int n) {
+    int p = 1;
+    while (p < n)
+        p <<= 1;
+    return p;
+}
+
+// sort bank A by (tLo, tHi, sLo, sHi) into bank B, then swap the banks
+template <typename C> __device__ __forceinline__ void sort_pieces(FinishStore<C> &S, int n) {
+    const int lane = lane_id();
+    const int n2 = pow2_at_least(n);
+    for (int i = lane; i < n2; i += 64)
+        S.ord[i] = (uint32_t)i;
+    wsync();
+    const C *tLo = S.tLo, *tHi = S.tHi, *sLo = S.sLo, *sHi = S.sHi;
+    wave_bitonic(S.ord, n2, [=](uint32_t a, uint32_t b) {
+        if ((int)a >= n)
+            return false;
+        if ((int)b >= n)
+            return true;
+        if (tLo[a] != tLo[b])
+            return tLo[a] < tLo[b];
+        if (tHi[a] != tHi[b])
+            return tHi[a] < tHi[b];
+        if (sLo[a] != sLo[b])
+            return sLo[a] < sLo[b];
+        return sHi[a] < sHi[b];
+    });
+    for (int i = lane; i < n; i += 64) {
+        const uint32_t o = S.ord[i];
+        S.tLo2[i] = S.tLo[o];
+        S.tHi2[i] = S.tHi[o];
+        S.sLo2[i] = S.sLo[o];
+        S.sHi2[i] = S.sHi[o];
+        S.fl2[i] = S.fl[o];
+    }
+    wsync();
+    C *t;
+    uint8_t *u;
+    t = S.tLo, S.tLo = S.tLo2, S.tLo2 = t;
+    t = S.tHi, S.tHi = S.tHi2, S.tHi2 = t;
+    t = S.sLo, S.sLo = S.sLo2, S.sLo2 = t;
+    t = S.sHi, S.sHi = S.sHi2, S.sHi2 = t;
+    u = S.fl, S.fl = S.fl2, S.fl2 = u;
+}
+
+// Returns the number of output lines written to S.l* (ordered for printing through S.ord), or -need
+// (need > 0) when the staging capacity is insufficient; `need` is a lower bound of the capacity to retry with.
+template <typename C>
+__device__ __forceinline__ int finish_query(FinishStore<C> &S, const Mapped &in, uint32_t base, int n, const int64_t *__restrict__ seqStart,
+                                            int numSeq) {
+    const int lane = lane_id();
+    if (n > S.cap)
+        return -n;
+    for (int i = lane; i < n; i += 64) {
+        S.tLo[i] = (C)in.tLo[base + i];
+        S.tHi[i] = (C)in.tHi[base + i];
+        S.sLo[i] = (C)in.sLo[base + i];
+        S.sHi[i] = (C)in.sHi[base + i];
+        S.fl[i] = in.flags[base + i];
+    }
+    wsync();
+    sort_pieces(S, n);
+
+    // does any pair of neighbours (in target order) overlap without having the same target range?
+    // (if any two pieces do, two neighbours do); are there exact duplicates?
+    bool refine = false, dup = false;
+    for (int i = lane; i + 1 < n; i += 64) {
+        const bool same = S.tLo[i + 1] == S.tLo[i] && S.tHi[i + 1] == S.tHi[i];
+        if (S.tLo[i + 1] <= S.tHi[i] && !same)
+            refine = true;
+        if (same && S.sLo[i + 1] == S.sLo[i] && S.sHi[i + 1] == S.sHi[i])
+            dup = true;
+    }
+    refine = __any(refine);
+    dup = __any(dup);
+
+    if (refine) {
+        // cut coordinates: every piece start and every piece end + 1
+        if (2 * n > S.cap2)
+            return -(2 * n);
+        const int nb2 = pow2_at_least(2 * n);
+        for (int i = lane; i < n; i += 64) {
+            S.bnd[2 * i] = S.tLo[i];
+            S.bnd[2 * i + 1] = S.tHi[i] + 1;
+        }
+        for (int i = lane; i < nb2; i += 64)
+            S.ord[i] = (uint32_t)i;
+        wsync();
+        {
+            const C *bnd = S.bnd;
+            const int nn = 2 * n;
+            wave_bitonic(S.ord, nb2, [=](uint32_t a, uint32_t b) {
+                if ((int)a >= nn)
+                    return false;
+                if ((int)b >= nn)
+                    return true;
+                return bnd[a] < bnd[b];
+            });
+        }
+        // sorted copy, then drop repeats (serial; this path is rare)
+        for (int i = lane; i < 2 * n; i += 64)
+            S.bnd2[i] = S.bnd[S.ord[i]];
+        wsync();
+        if (lane == 0) {
+            int w = 0;
+            for (int i = 0; i < 2 * n; ++i) {
+                const C v = S.bnd2[i];
+                if (w == 0 || v != S.bnd2[w - 1])
+                    S.bnd2[w++] = v;
+            }
+            S.ord[0] = (uint32_t)w;
+        }
+        wsync();
+        const int nbu = (int)S.ord[0];
+        wsync();
+        // number of sub-pieces of piece i = 1 + #{x in bnd : tLo < x <= tHi}
+        auto upper = [&](C v) { // first index with bnd[idx] > v
+            int lo = 0, hi = nbu;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (S.bnd2[mid] <= v)
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            return lo;
+        };
+        for (int i = lane; i < n; i += 64)
+            S.ord[i] = (uint32_t)(1 + upper(S.tHi[i]) - upper(S.tLo[i]));
+        wsync();
+        int m = 0;
+        if (lane == 0) {
+            for (int i = 0; i < n; ++i) {
+                const uint32_t c = S.ord[i];
+                S.ord[i] = (uint32_t)m;
+                m += (int)c;
+            }
+            S.ord[n] = (uint32_t)m;
+        }
+        wsync();
+        m = (int)S.ord[n];
+        if (m > S.cap)
+            return -m;
+        // emit the refined pieces into bank B
+        for (int i = lane; i < n; i += 64) {
+            int o = (int)S.ord[i];
+            const C tl = S.tLo[i], th = S.tHi[i], sl = S.sLo[i], sh = S.sHi[i];
+            const uint8_t f = S.fl[i];
+            const bool opposite = ((f & F_SREV) != 0) != ((f & F_TREV) != 0);
+            int k = upper(tl);
+            C lo = tl;
+            for (;;) {
+                const C hi = (k < nbu && S.bnd2[k] <= th) ? (C)(S.bnd2[k] - 1) : th;
+                S.tLo2[o] = lo;
+                S.tHi2[o] = hi;
+                if (!opposite) {
+                    S.sLo2[o] = sl + (lo - tl);
+                    S.sHi2[o] = sl + (hi - tl);
+                } else {
+                    S.sLo2[o] = sh - (hi - tl);
+                    S.sHi2[o] = sh - (lo - tl);
+                }
+                S.fl2[o] = f;
+                ++o;
+                if (hi == th)
+                    break;
+                lo = hi + 1;
+                ++k;
+            }
+        }
+        wsync();
+        {
+            C *t;
+            uint8_t *u;
+            t = S.tLo, S.tLo = S.tLo2, S.tLo2 = t;
+            t = S.tHi, S.tHi = S.tHi2, S.tHi2 = t;
+            t = S.sLo, S.sLo = S.sLo2, S.sLo2 = t;
+            t = S.sHi, S.sHi = S.sHi2, S.sHi2 = t;
+            u = S.fl, S.fl = S.fl2, S.fl2 = u;
+        }
+        n = m;
+        sort_pieces(S, n);
+        dup = false;
+        for (int i = lane; i + 1 < n; i += 64)
+            if (S.tLo[i + 1] == S.tLo[i] && S.tHi[i + 1] == S.tHi[i] && S.sLo[i + 1] == S.sLo[i] && S.sHi[i + 1] == S.sHi[i])
+                dup = true;
+        dup = __any(dup);
+    }
+    if (dup) { // std::set keeps the first of equal keys
+        if (lane == 0) {
+            int w = 0;
+            for (int i = 0; i < n; ++i) {
+                if (w > 0 && S.tLo[i] == S.tLo[w - 1] && S.tHi[i] == S.tHi[w - 1] && S.sLo[i] == S.sLo[w - 1] &&
+                    S.sHi[i] == S.sHi[w - 1])
+                    continue;
+                S.tLo[w] = S.tLo[i];
+                S.tHi[w] = S.tHi[i];
+                S.sLo[w] = S.sLo[i];
+                S.sHi[w] = S.sHi[i];
+                S.fl[w] = S.fl[i];
+                ++w;
+            }
+            S.ord[0] = (uint32_t)w;
+        }
+        wsync();
+        n = (int)S.ord[0];
+        wsync();
+    }
+
+    // target sequence of each piece (Segment::getSequence: site -> sequence, binary search on start[])
+    for (int i = lane; i < n; i += 64) {
+        int s = 0;
+        if (numSeq > 1) {
+            int lo = 0, hi = numSeq;
+            const int64_t pos = (int64_t)S.tLo[i];
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (seqStart[mid] <= pos)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+            s = lo;
+        }
+        S.seq[i] = s;
+        S.alive[i] = 1;
+    }
+    wsync();
+
+    // ---- extractSegment over the set in target order (serial: lane 0) ----
+    int nl = 0;
+    int fail = 0;
+    if (lane == 0) {
+        int ncut = 0;
+        auto nextAlive = [&](int i) {
+            while (i < n && !S.alive[i])
+                ++i;
+            return i;
+        };
+        auto canMergeRight = [&](int a, int b) { // halMappedSegment.cpp:109-161 in forward coordinates
+            const uint8_t fa = S.fl[a], fb = S.fl[b];
+            if (((fa ^ fb) & (F_SREV | F_TREV)) != 0)
+                return false;
+            if (S.tLo[b] - S.tHi[a] != 1)
+                return false;
+            const bool same = ((fa & F_SREV) != 0) == ((fa & F_TREV) != 0);
+            const bool rOk = same ? (S.sLo[b] - S.sHi[a] == 1) : (S.sLo[a] - S.sHi[b] == 1);
+            if (!rOk)
+                return false;
+            const C cutPos = S.tHi[a];
+            for (int c = 0; c < ncut; ++c)
+                if (S.cut[c] == cutPos)
+                    return false;
+            return true;
+        };
+        for (int i = 0; i < n && !fail; ++i) {
+            if (!S.alive[i])
+                continue;
+            int v1s = i, v1n = 1, back = i;
+            int nxt = nextAlive(i + 1);
+            while (nxt < n && S.tLo[back] == S.tLo[nxt]) {
+                back = nxt;
+                ++v1n;
+                nxt = nextAlive(nxt + 1);
+            }
+            int fragBack = i;
+            while (nxt < n) {
+                const int v2s = nxt;
+                int v2n = 0, b2 = -1;
+                while (nxt < n && (v2n == 0 || S.tLo[b2] == S.tLo[nxt]) && v2n < v1n) {
+                    b2 = nxt;
+                    ++v2n;
+                    nxt = nextAlive(nxt + 1);
+                }
+                bool can = v1n == v2n;
+                int a = v1s, b = v2s;
+                for (int k = 0; k < v1n && can; ++k) {
+                    can = S.seq[b] == S.seq[i] && canMergeRight(a, b);
+                    a = nextAlive(a + 1);
+                    b = nextAlive(b + 1);
+                }
+                if (!can)
+                    break;
+                fragBack = v2s;
+                S.alive[v2s] = 0; // erased from the set (halBlockMapper.cpp:389-391)
+                v1s = v2s;
+                v1n = v2n;
+            }
+            if (v1n > 1) {
+                if (ncut == S.cutCap) {
+                    fail = 1;
+                    break;
+                }
+                S.cut[ncut++] = S.tHi[fragBack];
+            }
+            // halBlockLiftover.cpp:82-105
+            const C a0 = S.tLo[i] < S.tLo[fragBack] ? S.tLo[i] : S.tLo[fragBack];
+            const C a1 = S.tHi[i] > S.tHi[fragBack] ? S.tHi[i] : S.tHi[fragBack];
+            S.lStart[nl] = a0;
+            S.lEnd[nl] = a1 + 1;
+            S.lSrc[nl] = S.sLo[i] < S.sLo[fragBack] ? S.sLo[i] : S.sLo[fragBack];
+            S.lSeq[nl] = S.seq[i];
+            S.lStrand[nl] = (S.fl[i] & F_DOT) ? '.' : ((S.fl[i] & F_TREV) ? '-' : '+');
+            ++nl;
+        }
+        S.ord[0] = (uint32_t)nl;
+        S.ord[1] = (uint32_t)fail;
+    }
+    wsync();
+    nl = (int)S.ord[0];
+    fail = (int)S.ord[1];
+    wsync();
+    if (fail)
+        return -(4 * S.cap);
+    // stable sort by source start: key (lSrc, line index)
+    const int l2 = pow2_at_least(nl);
+    for (int i = lane; i < l2; i += 64)
+        S.ord[i] = (uint32_t)i;
+    wsync();
+    {
+        const C *lSrc = S.lSrc;
+        const int nn = nl;
+        wave_bitonic(S.ord, l2, [=](uint32_t a, uint32_t b) {
+            if ((int)a >= nn)
+                return false;
+            if ((int)b >= nn)
+                return true;
+            if (lSrc[a] != lSrc[b])
+                return lSrc[a] < lSrc[b];
+            return a < b;
+        });
+    }
+    return nl;
+}
+
+template <typename C>
+__device__ __forceinline__ void write_records(const FinishStore<C> &S, int nl, int32_t q, hgx_record *__restrict__ dst,
+                                              const int64_t *__restrict__ seqStart) {
+    for (int k = lane_id(); k < nl; k += 64) {
+        const uint32_t o = S.ord[k];
+        hgx_record r;
+        const int32_t s = S.lSeq[o];
+        const int64_t ss = seqStart[s];
+        r.query = q;
+        r.tgt_start = (int64_t)S.lStart[o] - ss;
+        r.tgt_end = (int64_t)S.lEnd[o] - ss;
+        r.src_start = (int64_t)S.lSrc[o];
+        r.tgt_seq = s;
+        r.strand = (char)S.lStrand[o];
+        r._pad[0] = r._pad[1] = r._pad[2] = 0;
+        dst[k] = r;
+    }
+}
+
+// LDS-staged variant: capacity CAP pieces per query.
+template <typename C, int CAP>
+__global__ void __launch_bounds__(64) k_finish_lds(Mapped in, const uint32_t *__restrict__ offset, const uint32_t *__restrict__ count, uint32_t nq,
+                                                   const int64_t *__restrict__ seqStart, int numSeq, hgx_record *__restrict__ records,
+                                                   uint32_t *__restrict__ nOut, uint32_t *__restrict__ deferredList, uint32_t *__restrict__ needCap,
+                                                   unsigned long long *counters) {
+    constexpr int CAP2 = 2 * CAP;
+    __shared__ C s_tLo[CAP], s_tHi[CAP], s_sLo[CAP], s_sHi[CAP], s_tLo2[CAP], s_tHi2[CAP], s_sLo2[CAP], s_sHi2[CAP];
+    __shared__ C s_bnd[CAP2], s_bnd2[CAP2], s_lStart[CAP], s_lEnd[CAP], s_lSrc[CAP], s_cut[32];
+    __shared__ uint32_t s_ord[CAP2];
+    __shared__ int32_t s_seq[CAP], s_lSeq[CAP];
+    __shared__ uint8_t s_fl[CAP], s_fl2[CAP], s_alive[CAP], s_lStrand[CAP];
+    for (uint32_t q = blockIdx.x; q < nq; q += gridDim.x) {
+        const int n = (int)count[q];
+        if (n == 0) {
+            if (threadIdx.x == 0)
+                nOut[q] = 0;
+            continue;
+        }
+        FinishStore<C> S;
+        S.tLo = s_tLo, S.tHi = s_tHi, S.sLo = s_sLo, S.sHi = s_sHi, S.fl = s_fl;
+        S.tLo2 = s_tLo2, S.tHi2 = s_tHi2, S.sLo2 = s_sLo2, S.sHi2 = s_sHi2, S.fl2 = s_fl2;
+        S.seq = s_seq, S.ord = s_ord, S.bnd = s_bnd, S.bnd2 = s_bnd2, S.alive = s_alive, S.cut = s_cut;
+        S.lStart = s_lStart, S.lEnd = s_lEnd, S.lSrc = s_lSrc, S.lSeq = s_lSeq, S.lStrand = s_lStrand;
+        S.cap = CAP, S.cap2 = CAP2, S.cutCap = 32;
+        const uint32_t base = offset[q];
+        int nl = finish_query(S, in, base, n, seqStart, numSeq);
+        if (nl >= 0 && nl > n)
+            nl = -nl; // records are written into the query's own slice of the grouped buffer (n slots)
+        if (nl < 0) {
+            if (threadIdx.x == 0) {
+                const unsigned long long slot = atomicAdd(&counters[CNT_DEFERRED], 1ull);
+                deferredList[slot] = q;
+                needCap[q] = (uint32_t)(-nl);
+                atomicMax(&counters[CNT_MAXNEED], (unsigned long long)(-nl));
+                nOut[q] = 0;
+            }
+        } else {
+            write_records(S, nl, (int32_t)q, records + base, seqStart);
+            if (threadIdx.x == 0)
+                nOut[q] = (uint32_t)nl;
+        }
+        wsync();
+    }
+}
+
+// Global-scratch variant for deferred queries: slice k of `scratch` serves deferredList[k].
+template <typename C>
+__global__ void __launch_bounds__(64) k_finish_big(Mapped in, const uint32_t *__restrict__ offset, const uint32_t *__restrict__ count,
+                                                   const uint32_t *__restrict__ deferredList, uint32_t nDeferred, int cap,
+                                                   unsigned char *__restrict__ scratch, size_t sliceBytes,
+                                                   const int64_t *__restrict__ seqStart, int numSeq, hgx_record *__restrict__ bigRecords,
+                                                   uint32_t *__restrict__ nOut, unsigned long long *counters) {
+    for (uint32_t k = blockIdx.x; k < nDeferred; k += gridDim.x) {
+        const uint32_t q = deferredList[k];
+        const int n = (int)count[q];
+        unsigned char *p = scratch + (size_t)k * sliceBytes;
+        auto carve = [&](size_t bytes) {
+            unsigned char *r = p;
+            p += (bytes + 15) & ~(size_t)15;
+            return r;
+        };
+        const int cap2 = pow2_at_least(2 * cap);
+        FinishStore<C> S;
+        S.tLo = (C *)carve(sizeof(C) * cap), S.tHi = (C *)carve(sizeof(C) * cap), S.sLo = (C *)carve(sizeof(C) * cap),
+        S.sHi = (C *)carve(sizeof(C) * cap);
+        S.tLo2 = (C *)carve(sizeof(C) * cap), S.tHi2 = (C *)carve(sizeof(C) * cap), S.sLo2 = (C *)carve(sizeof(C) * cap),
+        S.sHi2 = (C *)carve(sizeof(C) * cap);
+        S.bnd = (C *)carve(sizeof(C) * cap2), S.bnd2 = (C *)carve(sizeof(C) * cap2);
+        S.lStart = (C *)carve(sizeof(C) * cap), S.lEnd = (C *)carve(sizeof(C) * cap), S.lSrc = (C *)carve(sizeof(C) * cap);
+        S.cut = (C *)carve(sizeof(C) * cap);
+        S.ord = (uint32_t *)carve(4 * (size_t)cap2);
+        S.seq = (int32_t *)carve(4 * (size_t)cap), S.lSeq = (int32_t *)carve(4 * (size_t)cap);
+        S.fl = carve(cap), S.fl2 = carve(cap), S.alive = carve(cap), S.lStrand = carve(cap);
+        S.cap = cap, S.cap2 = cap2, S.cutCap = cap;
+        __threadfence_block();
+        const int nl = finish_query(S, in, offset[q], n, seqStart, numSeq);
+        if (nl < 0) {
+            if (threadIdx.x == 0) {
+                counters[CNT_BIGFAIL] = 1;
+                atomicMax(&counters[CNT_MAXNEED], (unsigned long long)(-nl));
+                nOut[q] = 0;
+            }
+        } else {
+            write_records(S, nl, (int32_t)q, bigRecords + (size_t)k * cap, seqStart);
+            if (threadIdx.x == 0)
+                nOut[q] = (uint32_t)nl;
+        }
+        wsync();
+    }
+}
+
+// bytes of scratch per deferred query for capacity cap (must match the carving above)
+template <typename C> inline size_t finishSliceBytes(int cap) {
+    int cap2 = 1;
+    while (cap2 < 2 * cap)
+        cap2 <<= 1;
+    auto r = [](size_t b) { return (b + 15) & ~(size_t)15; };
+    return 8 * r(sizeof(C) * cap) + 2 * r(sizeof(C) * cap2) + 3 * r(sizeof(C) * cap) + r(sizeof(C) * cap) + r(4 * (size_t)cap2) +
+           2 * r(4 * (size_t)cap) + 4 * r(cap);
+}
+
+// dense output: out[outOffset[q] + k] = records of q (from its grouped slice, or from the big-records area)
+__global__ void __launch_bounds__(256) k_compact_records(const hgx_record *__restrict__ grouped, const uint32_t *__restrict__ offset,
+                                                         const hgx_record *__restrict__ big, const int32_t *__restrict__ bigSlot, int bigCap,
+                                                         const uint32_t *__restrict__ nOut, const uint32_t *__restrict__ outOffset, uint32_t nq,
+                                                         hgx_record *__restrict__ out) {
+    // one wavefront per query (records per query are few)
+    const uint32_t wavesTotal = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    for (uint32_t q = wave; q < nq; q += wavesTotal) {
+        const uint32_t n = nOut[q];
+        if (n == 0)
+            continue;
+        const int32_t bs = bigSlot ? bigSlot[q] : -1;
+        const hgx_record *src = bs >= 0 ? big + (size_t)bs * bigCap : grouped + offset[q];
+        hgx_record *dst = out + outOffset[q];
+        for (uint32_t k = lane_id(); k < n; k += 64)
+            dst[k] = src[k];
+    }
+}
+
+} // namespace hgx

@@ -1,0 +1,581 @@
+// Liftover engine: device image upload, the per-(source,target) walk schedule, workspaces, and the
+// launch sequence behind hgx_liftover_run_device / hgx_liftover_batch (include/hgx.h).
+#include "hgx_finish_kernel.hpp"
+#include "hgx_liftover_engine.hpp"
+#include <algorithm>
+#include <cstring>
+#include <map>
+
+namespace hgx {
+
+#define HIP_OK(expr)                                                                                                   \
+    do {                                                                                                               \
+        hipError_t e_ = (expr);                                                                                        \
+        if (e_ != hipSuccess)                                                                                          \
+            throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e_) + " at " #expr);               \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// device image
+DeviceImage::~DeviceImage() {
+    if (device < 0)
+        return;
+    (void)hipSetDevice(device);
+    for (DeviceGenome &g : genomes) {
+        if (g.top)
+            (void)hipFree(g.top);
+        if (g.bot)
+            (void)hipFree(g.bot);
+        for (int32_t *c : g.childEnc)
+            if (c)
+                (void)hipFree(c);
+        if (g.seqStart)
+            (void)hipFree(g.seqStart);
+    }
+}
+
+static inline int32_t encLink(int64_t idx, bool rev) {
+    return idx < 0 ? -1 : (int32_t)((idx << 1) | (rev ? 1 : 0));
+}
+
+template <typename C> static void uploadGenome(const GenomeTables &G, DeviceGenome &D, size_t &bytes) {
+    std::vector<TopRec<C>> top((size_t)G.numTop + 1);
+    memset(top.data(), 0, top.size() * sizeof(TopRec<C>));
+    for (int64_t i = 0; i < G.numTop; ++i) {
+        TopRec<C> &r = top[(size_t)i];
+        r.start = (C)G.tStart[(size_t)i];
+        r.parentEnc = encLink(G.tParent[(size_t)i], G.tParentRev[(size_t)i] != 0);
+        r.paralogy = (int32_t)G.tParalogy[(size_t)i];
+        r.botParse = (int32_t)G.tBotParse[(size_t)i];
+    }
+    top[(size_t)G.numTop].start = (C)G.totalLength;
+    top[(size_t)G.numTop].parentEnc = -1;
+    top[(size_t)G.numTop].paralogy = -1;
+    top[(size_t)G.numTop].botParse = -1;
+    std::vector<BotRec<C>> bot((size_t)G.numBot + 1);
+    memset(bot.data(), 0, bot.size() * sizeof(BotRec<C>));
+    for (int64_t i = 0; i < G.numBot; ++i) {
+        bot[(size_t)i].start = (C)G.bStart[(size_t)i];
+        bot[(size_t)i].topParse = (int32_t)G.bTopParse[(size_t)i];
+    }
+    bot[(size_t)G.numBot].start = (C)G.totalLength;
+    bot[(size_t)G.numBot].topParse = -1;
+    HIP_OK(hipMalloc(&D.top, top.size() * sizeof(TopRec<C>)));
+    HIP_OK(hipMemcpy(D.top, top.data(), top.size() * sizeof(TopRec<C>), hipMemcpyHostToDevice));
+    HIP_OK(hipMalloc(&D.bot, bot.size() * sizeof(BotRec<C>)));
+    HIP_OK(hipMemcpy(D.bot, bot.data(), bot.size() * sizeof(BotRec<C>), hipMemcpyHostToDevice));
+    bytes += top.size() * sizeof(TopRec<C>) + bot.size() * sizeof(BotRec<C>);
+}
+
+std::unique_ptr<DeviceImage> uploadImage(const Image &img, int device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        throw std::runtime_error("no HIP device available: the liftover/column kernels require a GPU (gfx950)");
+    if (device < 0 || device >= ndev)
+        throw std::runtime_error("invalid HIP device ordinal " + std::to_string(device));
+    HIP_OK(hipSetDevice(device));
+    std::unique_ptr<DeviceImage> D(new DeviceImage);
+    D->device = device;
+    for (const GenomeTables &G : img.genomes) {
+        if (G.totalLength >= (int64_t)1 << 31)
+            D->wide = true;
+        if (G.numTop >= ((int64_t)1 << 30) - 1 || G.numBot >= ((int64_t)1 << 30) - 1)
+            throw std::runtime_error("genome " + G.name + " has more than 2^30 segments; 32-bit link tables cannot hold it");
+        for (int64_t i = 0; i < G.numTop; ++i)
+            if (G.tStart[(size_t)i + 1] - G.tStart[(size_t)i] >= (int64_t)1 << 31)
+                throw std::runtime_error("genome " + G.name + " has a segment of 2^31 bases or more");
+    }
+    D->genomes.resize(img.genomes.size());
+    for (size_t g = 0; g < img.genomes.size(); ++g) {
+        const GenomeTables &G = img.genomes[g];
+        DeviceGenome &dg = D->genomes[g];
+        dg.numTop = G.numTop;
+        dg.numBot = G.numBot;
+        if (D->wide)
+            uploadGenome<int64_t>(G, dg, D->bytes);
+        else
+            uploadGenome<int32_t>(G, dg, D->bytes);
+        dg.childEnc.assign(G.children.size(), nullptr);
+        std::vector<int32_t> enc((size_t)G.numBot);
+        for (size_t k = 0; k < G.children.size(); ++k) {
+            for (int64_t i = 0; i < G.numBot; ++i)
+                enc[(size_t)i] = encLink(G.bChild[k][(size_t)i], G.bChildRev[k][(size_t)i] != 0);
+            HIP_OK(hipMalloc(&dg.childEnc[k], std::max<size_t>(4, enc.size() * 4)));
+            HIP_OK(hipMemcpy(dg.childEnc[k], enc.data(), enc.size() * 4, hipMemcpyHostToDevice));
+            D->bytes += enc.size() * 4;
+        }
+        std::vector<int64_t> ss;
+        for (const SeqInfo &S : G.seqs)
+            ss.push_back(S.start);
+        ss.push_back(G.totalLength);
+        dg.numSeq = (int32_t)G.seqs.size();
+        HIP_OK(hipMalloc(&dg.seqStart, ss.size() * 8));
+        HIP_OK(hipMemcpy(dg.seqStart, ss.data(), ss.size() * 8, hipMemcpyHostToDevice));
+    }
+    return D;
+}
+
+// ---------------------------------------------------------------------------------------------
+// plan
+struct DevBuf {
+    void *p = nullptr;
+    size_t n = 0;
+    void ensure(size_t bytes) {
+        if (bytes <= n)
+            return;
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+        HIP_OK(hipMalloc(&p, bytes));
+        n = bytes;
+    }
+    ~DevBuf() {
+        if (p)
+            (void)hipFree(p);
+    }
+};
+
+struct KernelTimer {
+    struct Rec {
+        std::string name;
+        hipEvent_t a, b;
+    };
+    std::vector<Rec> recs;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    size_t used = 0;
+    std::map<std::string, std::pair<double, int>> totals; // name -> (ms, launches) of the last run
+    void begin(const char *name, hipStream_t s) {
+        if (used == pool.size()) {
+            hipEvent_t a, b;
+            HIP_OK(hipEventCreate(&a));
+            HIP_OK(hipEventCreate(&b));
+            pool.emplace_back(a, b);
+        }
+        recs.push_back({name, pool[used].first, pool[used].second});
+        ++used;
+        HIP_OK(hipEventRecord(recs.back().a, s));
+    }
+    void end(hipStream_t s) {
+        HIP_OK(hipEventRecord(recs.back().b, s));
+    }
+    void resolve(bool reset) {
+        if (reset)
+            totals.clear();
+        for (Rec &r : recs) {
+            float ms = 0;
+            HIP_OK(hipEventElapsedTime(&ms, r.a, r.b));
+            auto &t = totals[r.name];
+            t.first += ms;
+            t.second += 1;
+        }
+        recs.clear();
+        used = 0;
+    }
+    ~KernelTimer() {
+        for (auto &p : pool) {
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
+        }
+    }
+};
+
+} // namespace hgx
+
+using namespace hgx;
+
+struct hgx_liftover_plan {
+    hgx_alignment *h = nullptr;
+    int src = -1, tgt = -1, mrca = -1;
+    hgx_liftover_opts opts{};
+    std::vector<int> up;                        // src ... mrca
+    std::vector<std::pair<int, int>> down;      // (parent genome, child slot) per downward hop
+    bool srcTop = true;
+    size_t maxQueries = 0;
+    uint32_t cap = 0; // piece capacity of every frontier / mapped / record buffer
+    DevBuf fr[2][6], mp[2][6], counters, perQuery, offset, cursor, nOut, outOffset, blockSums, total, grouped, outRecords,
+        deferredList, needCap, bigSlot, scratch, bigRecords;
+    KernelTimer timer;
+    hgx_liftover_stats stats{};
+    hipEvent_t evStart = nullptr, evWalk = nullptr, evEnd = nullptr;
+    ~hgx_liftover_plan() {
+        if (evStart)
+            (void)hipEventDestroy(evStart);
+        if (evWalk)
+            (void)hipEventDestroy(evWalk);
+        if (evEnd)
+            (void)hipEventDestroy(evEnd);
+    }
+    Frontier frontier(int k) {
+        return Frontier{(int32_t *)fr[k][0].p, (int64_t *)fr[k][1].p, (int32_t *)fr[k][2].p,
+                        (int32_t *)fr[k][3].p, (int32_t *)fr[k][4].p, (uint8_t *)fr[k][5].p};
+    }
+    Mapped mapped(int k) {
+        return Mapped{(int32_t *)mp[k][0].p, (int64_t *)mp[k][1].p, (int64_t *)mp[k][2].p,
+                      (int64_t *)mp[k][3].p, (int64_t *)mp[k][4].p, (uint8_t *)mp[k][5].p};
+    }
+    void allocate(uint32_t newCap) {
+        cap = newCap;
+        static const size_t fsz[6] = {4, 8, 4, 4, 4, 1}, msz[6] = {4, 8, 8, 8, 8, 1};
+        for (int k = 0; k < 2; ++k)
+            for (int a = 0; a < 6; ++a) {
+                fr[k][a].ensure(fsz[a] * (size_t)cap);
+                mp[k][a].ensure(msz[a] * (size_t)cap);
+            }
+        grouped.ensure(sizeof(hgx_record) * (size_t)cap);
+        outRecords.ensure(sizeof(hgx_record) * (size_t)cap);
+        const size_t nq = std::max<size_t>(maxQueries, 1);
+        counters.ensure(8 * CNT_SLOTS);
+        perQuery.ensure(4 * (nq + 1));
+        offset.ensure(4 * (nq + 1));
+        cursor.ensure(4 * (nq + 1));
+        nOut.ensure(4 * (nq + 1));
+        outOffset.ensure(4 * (nq + 1));
+        blockSums.ensure(4 * (nq / SCAN_BLOCK + 2));
+        total.ensure(16);
+        deferredList.ensure(4 * (nq + 1));
+        needCap.ensure(4 * (nq + 1));
+        bigSlot.ensure(4 * (nq + 1));
+    }
+};
+
+namespace hgx {
+
+static constexpr int GRID = 2048; // 256 CUs x 8 resident 256-thread blocks, grid-stride beyond
+
+static void exclusiveScan(hgx_liftover_plan &P, const uint32_t *in, uint32_t n, uint32_t *out, uint32_t *total, hipStream_t s) {
+    const uint32_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    P.timer.begin("scan", s);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(256), 0, s, in, n, (uint32_t *)P.blockSums.p);
+    hipLaunchKernelGGL(k_scan_sums_serial, dim3(1), dim3(64), 0, s, (uint32_t *)P.blockSums.p, nb, total);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, s, in, n, (const uint32_t *)P.blockSums.p, out);
+    P.timer.end(s);
+}
+
+template <typename C>
+static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int64_t *dE, const uint8_t *dStrand, hipStream_t s,
+                    unsigned long long *hostCounters) {
+    const DeviceImage &D = *P.h->dev;
+    unsigned long long *cnt = (unsigned long long *)P.counters.p;
+    const uint32_t cap = P.cap;
+    const uint32_t nq = (uint32_t)n;
+    HIP_OK(hipMemsetAsync(cnt, 0, 8 * CNT_SLOTS, s));
+    HIP_OK(hipMemsetAsync(P.perQuery.p, 0, 4 * (n + 1), s));
+    HIP_OK(hipMemsetAsync(P.cursor.p, 0, 4 * (n + 1), s));
+    HIP_OK(hipMemsetAsync(P.bigSlot.p, 0xFF, 4 * (n + 1), s));
+    HIP_OK(hipEventRecord(P.evStart, s));
+
+    int level = 0;
+    int cur = 0; // frontier buffer holding the current pieces
+    auto inCnt = [&]() { return cnt + CNT_FRONT0 + level; };
+    auto outCnt = [&]() { return cnt + CNT_FRONT0 + level + 1; };
+    const int64_t minLen = P.opts.min_length;
+
+    // stage 0
+    const DeviceGenome &SG = D.genomes[(size_t)P.src];
+    P.timer.begin("k_locate_expand", s);
+    if (P.srcTop)
+        hipLaunchKernelGGL((k_locate_expand<TopRec<C>>), dim3(GRID), dim3(256), 0, s, (const TopRec<C> *)SG.top, SG.numTop, dS, dE,
+                           dStrand, nq, P.frontier(cur), cap, cnt);
+    else
+        hipLaunchKernelGGL((k_locate_expand<BotRec<C>>), dim3(GRID), dim3(256), 0, s, (const BotRec<C> *)SG.bot, SG.numBot, dS, dE,
+                           dStrand, nq, P.frontier(cur), cap, cnt);
+    P.timer.end(s);
+
+    bool curTop = P.srcTop;
+    int curGenome = P.src;
+    if (P.src != P.mrca) {
+        // first hop: top pieces of the source -> bottom pieces of its parent
+        P.timer.begin("k_up_top", s);
+        hipLaunchKernelGGL((k_up_top<C>), dim3(GRID), dim3(256), 0, s, (const TopRec<C> *)D.genomes[(size_t)curGenome].top,
+                           P.frontier(cur), inCnt(), cap, P.frontier(cur ^ 1), outCnt(), minLen, cnt);
+        P.timer.end(s);
+        cur ^= 1;
+        ++level;
+        curGenome = P.up[1];
+        curTop = false;
+        for (size_t k = 1; k + 1 < P.up.size(); ++k) {
+            const DeviceGenome &G = D.genomes[(size_t)P.up[k]];
+            P.timer.begin("k_parse_up_then_up", s);
+            hipLaunchKernelGGL((k_parse_up_then_up<C>), dim3(GRID), dim3(256), 0, s, (const BotRec<C> *)G.bot,
+                               (const TopRec<C> *)G.top, P.frontier(cur), inCnt(), cap, P.frontier(cur ^ 1), outCnt(), minLen,
+                               cnt);
+            P.timer.end(s);
+            cur ^= 1;
+            ++level;
+            curGenome = P.up[k + 1];
+        }
+    }
+    if (P.tgt != P.mrca) {
+        if (curTop) { // source is the MRCA itself and is walked through its top tiling
+            const DeviceGenome &G = D.genomes[(size_t)curGenome];
+            P.timer.begin("k_parse_down", s);
+            hipLaunchKernelGGL((k_parse_down<C>), dim3(GRID), dim3(256), 0, s, (const TopRec<C> *)G.top, (const BotRec<C> *)G.bot,
+                               P.frontier(cur), inCnt(), cap, P.frontier(cur ^ 1), outCnt(), cnt);
+            P.timer.end(s);
+            cur ^= 1;
+            ++level;
+            curTop = false;
+        }
+        for (size_t k = 0; k < P.down.size(); ++k) {
+            const int parent = P.down[k].first, slot = P.down[k].second;
+            const int child = P.h->img.genomes[(size_t)parent].children[(size_t)slot];
+            const DeviceGenome &PG = D.genomes[(size_t)parent];
+            const DeviceGenome &CG = D.genomes[(size_t)child];
+            P.timer.begin("k_down_ring", s);
+            hipLaunchKernelGGL((k_down_ring<C>), dim3(GRID), dim3(256), 0, s, (const int32_t *)PG.childEnc[(size_t)slot],
+                               (const TopRec<C> *)CG.top, P.frontier(cur), inCnt(), cap, P.frontier(cur ^ 1), outCnt(), minLen,
+                               (int)(P.opts.traverse_dupes != 0), cnt);
+            P.timer.end(s);
+            cur ^= 1;
+            ++level;
+            curTop = true;
+            curGenome = child;
+            if (child != P.tgt) {
+                P.timer.begin("k_parse_down", s);
+                hipLaunchKernelGGL((k_parse_down<C>), dim3(GRID), dim3(256), 0, s, (const TopRec<C> *)CG.top,
+                                   (const BotRec<C> *)CG.bot, P.frontier(cur), inCnt(), cap, P.frontier(cur ^ 1), outCnt(), cnt);
+                P.timer.end(s);
+                cur ^= 1;
+                ++level;
+                curTop = false;
+            }
+        }
+    }
+    // final pieces live in the target genome
+    const DeviceGenome &TG = D.genomes[(size_t)P.tgt];
+    P.timer.begin("k_finalize", s);
+    if (curTop)
+        hipLaunchKernelGGL((k_finalize<TopRec<C>>), dim3(GRID), dim3(256), 0, s, (const TopRec<C> *)TG.top, P.frontier(cur), inCnt(),
+                           cap, P.mapped(0), (uint32_t *)P.perQuery.p, cnt, 1);
+    else
+        hipLaunchKernelGGL((k_finalize<BotRec<C>>), dim3(GRID), dim3(256), 0, s, (const BotRec<C> *)TG.bot, P.frontier(cur), inCnt(),
+                           cap, P.mapped(0), (uint32_t *)P.perQuery.p, cnt, 0);
+    P.timer.end(s);
+    HIP_OK(hipEventRecord(P.evWalk, s));
+
+    exclusiveScan(P, (const uint32_t *)P.perQuery.p, nq, (uint32_t *)P.offset.p, (uint32_t *)P.total.p, s);
+    P.timer.begin("k_scatter", s);
+    hipLaunchKernelGGL(k_scatter, dim3(GRID), dim3(256), 0, s, P.mapped(0), inCnt(), cap, (const uint32_t *)P.offset.p,
+                       (uint32_t *)P.cursor.p, P.mapped(1));
+    P.timer.end(s);
+    P.timer.begin("k_finish_lds", s);
+    hipLaunchKernelGGL((k_finish_lds<C, 256>), dim3(std::min<uint32_t>(std::max<uint32_t>(nq, 1), 1u << 16)), dim3(64), 0, s, P.mapped(1),
+                       (const uint32_t *)P.offset.p, (const uint32_t *)P.perQuery.p, nq, (const int64_t *)TG.seqStart, (int)TG.numSeq,
+                       (hgx_record *)P.grouped.p, (uint32_t *)P.nOut.p, (uint32_t *)P.deferredList.p, (uint32_t *)P.needCap.p, cnt);
+    P.timer.end(s);
+    HIP_OK(hipMemcpyAsync(hostCounters, cnt, 8 * CNT_SLOTS, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+}
+
+__global__ void k_fill_big_slot(const uint32_t *deferredList, uint32_t nd, int32_t *bigSlot) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nd)
+        bigSlot[deferredList[i]] = (int32_t)i;
+}
+
+template <typename C>
+static void runPlan(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int64_t *dE, const uint8_t *dStrand, hipStream_t s,
+                    const hgx_record **dOut, size_t *nOut) {
+    if (n > P.maxQueries)
+        throw std::runtime_error("batch larger than the plan's max_queries");
+    if (n >= ((size_t)1 << 31))
+        throw std::runtime_error("batch of 2^31 or more intervals; split it");
+    unsigned long long hc[CNT_SLOTS];
+    const DeviceImage &D = *P.h->dev;
+    HIP_OK(hipSetDevice(D.device));
+    P.stats = hgx_liftover_stats{};
+    if (n == 0) {
+        *dOut = (const hgx_record *)P.outRecords.p;
+        *nOut = 0;
+        return;
+    }
+    for (;;) {
+        runOnce<C>(P, n, dS, dE, dStrand, s, hc);
+        if (!hc[CNT_OVERFLOW])
+            break;
+        // a frontier outgrew the workspace: size it from the largest count seen and run again
+        unsigned long long need = 0;
+        for (int k = CNT_FRONT0; k < CNT_SLOTS; ++k)
+            need = std::max(need, hc[k]);
+        need = std::max<unsigned long long>(need + need / 4, 2ull * P.cap);
+        if (need >= (1ull << 32))
+            throw std::runtime_error("liftover batch expands to more than 2^32 pieces; submit smaller batches");
+        P.timer.resolve(true);
+        P.allocate((uint32_t)need);
+    }
+    const uint32_t nq = (uint32_t)n;
+    const DeviceGenome &TG = D.genomes[(size_t)P.tgt];
+    unsigned long long *cnt = (unsigned long long *)P.counters.p;
+    const uint32_t nDef = (uint32_t)hc[CNT_DEFERRED];
+    int bigCap = 0;
+    if (nDef > 0) {
+        bigCap = (int)std::max<unsigned long long>(512, 2 * hc[CNT_MAXNEED]);
+        hipLaunchKernelGGL(k_fill_big_slot, dim3((nDef + 255) / 256), dim3(256), 0, s, (const uint32_t *)P.deferredList.p, nDef,
+                           (int32_t *)P.bigSlot.p);
+        for (;;) {
+            const size_t slice = finishSliceBytes<C>(bigCap);
+            P.scratch.ensure(slice * nDef);
+            P.bigRecords.ensure(sizeof(hgx_record) * (size_t)bigCap * nDef);
+            unsigned long long zero[2] = {0, 0};
+            HIP_OK(hipMemcpyAsync(cnt + CNT_MAXNEED, zero, 16, hipMemcpyHostToDevice, s)); // MAXNEED, BIGFAIL
+            P.timer.begin("k_finish_big", s);
+            hipLaunchKernelGGL((k_finish_big<C>), dim3(nDef), dim3(64), 0, s, P.mapped(1), (const uint32_t *)P.offset.p,
+                               (const uint32_t *)P.perQuery.p, (const uint32_t *)P.deferredList.p, nDef, bigCap,
+                               (unsigned char *)P.scratch.p, slice, (const int64_t *)TG.seqStart, (int)TG.numSeq,
+                               (hgx_record *)P.bigRecords.p, (uint32_t *)P.nOut.p, cnt);
+            P.timer.end(s);
+            unsigned long long r[2];
+            HIP_OK(hipMemcpyAsync(r, cnt + CNT_MAXNEED, 16, hipMemcpyDeviceToHost, s));
+            HIP_OK(hipStreamSynchronize(s));
+            if (!r[1])
+                break;
+            bigCap = (int)std::max<unsigned long long>(2ull * bigCap, 2 * r[0]);
+            if (bigCap > (1 << 26))
+                throw std::runtime_error("an interval maps to more than 2^26 pieces; not supported");
+        }
+    }
+    exclusiveScan(P, (const uint32_t *)P.nOut.p, nq, (uint32_t *)P.outOffset.p, (uint32_t *)P.total.p, s);
+    uint32_t totalRecords = 0;
+    HIP_OK(hipMemcpyAsync(&totalRecords, P.total.p, 4, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    P.outRecords.ensure(sizeof(hgx_record) * std::max<size_t>(totalRecords, 1));
+    P.timer.begin("k_compact_records", s);
+    hipLaunchKernelGGL(k_compact_records, dim3(GRID), dim3(256), 0, s, (const hgx_record *)P.grouped.p, (const uint32_t *)P.offset.p,
+                       (const hgx_record *)P.bigRecords.p, nDef ? (const int32_t *)P.bigSlot.p : (const int32_t *)nullptr, bigCap,
+                       (const uint32_t *)P.nOut.p, (const uint32_t *)P.outOffset.p, nq, (hgx_record *)P.outRecords.p);
+    P.timer.end(s);
+    HIP_OK(hipEventRecord(P.evEnd, s));
+    HIP_OK(hipStreamSynchronize(s));
+    P.timer.resolve(true);
+    float walk = 0, tot = 0;
+    HIP_OK(hipEventElapsedTime(&walk, P.evStart, P.evWalk));
+    HIP_OK(hipEventElapsedTime(&tot, P.evStart, P.evEnd));
+    P.stats.queries = n;
+    P.stats.source_pieces = hc[CNT_SRC_PIECES];
+    P.stats.top_derefs = hc[CNT_TOP_DEREF] + (P.srcTop ? hc[CNT_SRC_PIECES] : 0);
+    P.stats.bottom_derefs = hc[CNT_BOT_DEREF] + (P.srcTop ? 0 : hc[CNT_SRC_PIECES]);
+    P.stats.mapped_pieces = hc[CNT_MAPPED];
+    P.stats.records = totalRecords;
+    P.stats.deferred_queries = nDef;
+    P.stats.walk_ms = walk;
+    P.stats.total_ms = tot;
+    *dOut = (const hgx_record *)P.outRecords.p;
+    *nOut = totalRecords;
+}
+
+hgx_liftover_plan *createLiftoverPlan(hgx_alignment *h, int src, int tgt, const hgx_liftover_opts &opts, size_t maxQueries) {
+    if (!h->dev)
+        throw std::runtime_error("alignment was opened without a device (device = -1); liftover needs the HIP path");
+    const Image &img = h->img;
+    if (src < 0 || tgt < 0 || src >= (int)img.genomes.size() || tgt >= (int)img.genomes.size())
+        throw std::runtime_error("genome id out of range");
+    std::unique_ptr<hgx_liftover_plan> P(new hgx_liftover_plan);
+    P->h = h;
+    P->src = src;
+    P->tgt = tgt;
+    P->opts = opts;
+    P->mrca = img.lca(src, tgt);
+    if (opts.coalescence_limit >= 0 && opts.coalescence_limit != P->mrca)
+        throw std::runtime_error("coalescenceLimit other than the MRCA is not supported yet (SURVEY 8(f) item 3)");
+    for (int g = src;; g = img.genomes[(size_t)g].parent) {
+        P->up.push_back(g);
+        if (g == P->mrca)
+            break;
+    }
+    std::vector<int> chain; // tgt ... mrca
+    for (int g = tgt; g != P->mrca; g = img.genomes[(size_t)g].parent)
+        chain.push_back(g);
+    int parent = P->mrca;
+    for (size_t k = chain.size(); k-- > 0;) {
+        // mapRecursiveDown picks the first child that is the target or lies on the path to it
+        // (halSegmentMapper.cpp:208-219); on a tree that is the unique child towards the target
+        const int slot = img.genomes[(size_t)parent].childSlotOf(chain[k]);
+        P->down.emplace_back(parent, slot);
+        parent = chain[k];
+    }
+    // BlockLiftover::visitBegin (halBlockLiftover.cpp:24-30): walk the source through its top tiling when it has one
+    P->srcTop = img.genomes[(size_t)src].numTop > 0;
+    P->maxQueries = std::max<size_t>(maxQueries, 1);
+    HIP_OK(hipSetDevice(h->dev->device));
+    HIP_OK(hipEventCreate(&P->evStart));
+    HIP_OK(hipEventCreate(&P->evWalk));
+    HIP_OK(hipEventCreate(&P->evEnd));
+    const unsigned long long want = std::max<unsigned long long>(1ull << 16, 48ull * P->maxQueries);
+    P->allocate((uint32_t)std::min<unsigned long long>(want, (1ull << 32) - 2));
+    return P.release();
+}
+
+void runLiftoverPlan(hgx_liftover_plan *p, size_t n, const int64_t *dS, const int64_t *dE, const uint8_t *dStrand, void *stream,
+                     const hgx_record **dOut, size_t *nOut) {
+    if (p->h->dev->wide)
+        runPlan<int64_t>(*p, n, dS, dE, dStrand, (hipStream_t)stream, dOut, nOut);
+    else
+        runPlan<int32_t>(*p, n, dS, dE, dStrand, (hipStream_t)stream, dOut, nOut);
+}
+
+void destroyLiftoverPlan(hgx_liftover_plan *p) {
+    if (!p)
+        return;
+    (void)hipSetDevice(p->h->dev->device);
+    delete p;
+}
+
+const hgx_liftover_stats &liftoverPlanStats(const hgx_liftover_plan *p) {
+    return p->stats;
+}
+
+std::string liftoverPlanKernelTimes(const hgx_liftover_plan *p) {
+    std::string s = "{";
+    bool first = true;
+    for (auto &kv : p->timer.totals) {
+        if (!first)
+            s += ", ";
+        first = false;
+        char buf[256];
+        snprintf(buf, sizeof buf, "\"%s\": {\"ms\": %.6f, \"launches\": %d}", kv.first.c_str(), kv.second.first, kv.second.second);
+        s += buf;
+    }
+    s += "}";
+    return s;
+}
+
+// host-buffer batch: H2D, run, D2H
+void liftoverBatchHost(hgx_alignment *h, int src, int tgt, size_t n, const hgx_interval *iv, const hgx_liftover_opts &opts,
+                       std::vector<hgx_record> &out, hgx_liftover_stats *stats) {
+    std::unique_ptr<hgx_liftover_plan, void (*)(hgx_liftover_plan *)> P(createLiftoverPlan(h, src, tgt, opts, n), destroyLiftoverPlan);
+    const GenomeTables &G = h->img.genomes[(size_t)src];
+    std::vector<int64_t> gs(n), ge(n);
+    std::vector<uint8_t> st(n);
+    for (size_t i = 0; i < n; ++i) {
+        const hgx_interval &q = iv[i];
+        bool ok = q.seq >= 0 && q.seq < (int32_t)G.seqs.size() && q.start >= 0 && q.start < q.end;
+        if (ok)
+            ok = q.end <= G.seqs[(size_t)q.seq].length; // halLiftover.cpp:62-66: skipped, not an error
+        if (ok) {
+            gs[i] = q.start + G.seqs[(size_t)q.seq].start;       // halBlockLiftover.cpp:48
+            ge[i] = q.end - 1 + G.seqs[(size_t)q.seq].start;     // :49
+        } else {
+            gs[i] = 0;
+            ge[i] = -1;
+        }
+        st[i] = (uint8_t)q.strand;
+    }
+    DevBuf dS, dE, dT;
+    dS.ensure(8 * std::max<size_t>(n, 1));
+    dE.ensure(8 * std::max<size_t>(n, 1));
+    dT.ensure(std::max<size_t>(n, 1));
+    HIP_OK(hipMemcpy(dS.p, gs.data(), 8 * n, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dE.p, ge.data(), 8 * n, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dT.p, st.data(), n, hipMemcpyHostToDevice));
+    const hgx_record *dOut = nullptr;
+    size_t nOut = 0;
+    runLiftoverPlan(P.get(), n, (const int64_t *)dS.p, (const int64_t *)dE.p, (const uint8_t *)dT.p, nullptr, &dOut, &nOut);
+    out.resize(nOut);
+    if (nOut)
+        HIP_OK(hipMemcpy(out.data(), dOut, sizeof(hgx_record) * nOut, hipMemcpyDeviceToHost));
+    if (stats)
+        *stats = P->stats;
+}
+
+} // namespace hgx

@@ -1,0 +1,19 @@
+// Internal C++ interface of the liftover engine (implemented in hgx_liftover.hip).
+#pragma once
+#include "../../include/hgx.h"
+#include "hgx_device.hpp"
+#include <string>
+#include <vector>
+
+namespace hgx {
+
+hgx_liftover_plan *createLiftoverPlan(hgx_alignment *h, int src, int tgt, const hgx_liftover_opts &opts, size_t maxQueries);
+void runLiftoverPlan(hgx_liftover_plan *p, size_t n, const int64_t *dStart, const int64_t *dEnd, const uint8_t *dStrand, void *stream,
+                     const hgx_record **dOut, size_t *nOut);
+void destroyLiftoverPlan(hgx_liftover_plan *p);
+const hgx_liftover_stats &liftoverPlanStats(const hgx_liftover_plan *p);
+std::string liftoverPlanKernelTimes(const hgx_liftover_plan *p);
+void liftoverBatchHost(hgx_alignment *h, int src, int tgt, size_t n, const hgx_interval *iv, const hgx_liftover_opts &opts,
+                       std::vector<hgx_record> &out, hgx_liftover_stats *stats);
+
+} // namespace hgx

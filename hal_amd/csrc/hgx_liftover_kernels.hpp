@@ -1,0 +1,586 @@
+// Device kernels of the liftover walk (gfx950).  Included only by hgx_liftover.hip.
+//
+// The reference maps one BED interval with a recursive, heap-allocating walk
+// (api/impl/halSegmentMapper.cpp:25-330).  Here a batch of intervals is advanced level-synchronously:
+// the frontier is a Structure-of-Arrays of "pieces" (query id, source start + strand, current segment
+// index, offset inside it, length, strand) in HBM; one kernel per tree hop reads the 16-byte link record
+// of each piece's segment, splits pieces where the top and bottom tilings disagree, and appends the
+// results to the next frontier with one atomic per wavefront (ballot + popcount prefix).  Integer only.
+#pragma once
+#include "hgx_device.hpp"
+#include <hip/hip_runtime.h>
+
+namespace hgx {
+
+// frontier / piece flags
+static constexpr uint8_t F_SREV = 1; // source iterator reversed
+static constexpr uint8_t F_TREV = 2; // current (target-side) iterator reversed
+static constexpr uint8_t F_DOT = 4;  // input strand was '.'
+
+struct Frontier {
+    int32_t *qid;
+    int64_t *sPos; // source position of the piece's first base in iteration order
+    int32_t *idx;  // segment index in the current genome
+    int32_t *so;   // start offset in iteration order (api/inc/halSegmentIterator.h:115)
+    int32_t *len;
+    uint8_t *flags;
+};
+
+// final mapped pieces in forward coordinates (what MappedSegment::lessThan orders by,
+// api/impl/halMappedSegment.cpp:36-43,167-206)
+struct Mapped {
+    int32_t *qid;
+    int64_t *tLo, *tHi, *sLo, *sHi;
+    uint8_t *flags;
+};
+
+// counters[] slots
+enum {
+    CNT_OVERFLOW = 0, // set when any append ran past capacity
+    CNT_TOP_DEREF = 1,
+    CNT_BOT_DEREF = 2,
+    CNT_SRC_PIECES = 3,
+    CNT_MAPPED = 4,
+    CNT_DEFERRED = 5,
+    CNT_MAXNEED = 6,
+    CNT_BIGFAIL = 7,
+    CNT_FRONT0 = 8, // + level: element count of frontier after each step
+    CNT_SLOTS = 64
+};
+
+__device__ __forceinline__ int lane_id() {
+    return (int)(threadIdx.x & 63);
+}
+
+// Append slots for the active lanes of a wavefront with one atomic: ballot the lanes that emit, give
+// each its popcount prefix, lane `leader` adds the wave total.  Must be called by all lanes of the
+// wave in converged control flow.
+__device__ __forceinline__ unsigned long long wave_append(unsigned long long *counter, bool emit) {
+    const unsigned long long mask = __ballot(emit);
+    if (mask == 0)
+        return ~0ull;
+    const int lane = lane_id();
+    const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    const int leader = __ffsll((long long)mask) - 1;
+    unsigned long long base = 0;
+    if (lane == leader)
+        base = atomicAdd(counter, (unsigned long long)__popcll(mask));
+    base = __shfl(base, leader);
+    return base + rank;
+}
+
+__device__ __forceinline__ void wave_count_add(unsigned long long *counter, uint32_t v) {
+    // wave reduction through DPP-free shuffles, one atomic per wave
+    for (int o = 32; o > 0; o >>= 1)
+        v += __shfl_down(v, o);
+    if (lane_id() == 0 && v)
+        atomicAdd(counter, (unsigned long long)v);
+}
+
+__device__ __forceinline__ void put(const Frontier &f, unsigned long long slot, int32_t qid, int64_t sPos, int32_t idx, int32_t so,
+                                    int32_t len, uint8_t flags) {
+    f.qid[slot] = qid;
+    f.sPos[slot] = sPos;
+    f.idx[slot] = idx;
+    f.so[slot] = so;
+    f.len[slot] = len;
+    f.flags[slot] = flags;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage 0: locate + expand.  BlockLiftover::liftInterval, liftover/impl/halBlockLiftover.cpp:46-72:
+// toSite(globalStart) (api/impl/halSegmentIterator.cpp:240-299, here a binary search on start[]), slice,
+// then one halMapSegment call per source segment until globalEnd; '-' intervals flip each piece in place
+// (:64-70, toReverseInPlace = flip strand and swap offsets, halSegmentIterator.cpp:149-153).
+// One lane per interval; the lanes of a wave walk their source segments in lockstep and append.
+template <typename REC>
+__global__ void __launch_bounds__(256) k_locate_expand(const REC *__restrict__ segs, int64_t numSegs, const int64_t *__restrict__ gStart,
+                                                       const int64_t *__restrict__ gEnd, const uint8_t *__restrict__ strand,
+                                                       uint32_t nq, Frontier out, uint32_t cap, unsigned long long *counters) {
+    const uint32_t wavesTotal = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    uint32_t derefs = 0;
+    for (uint32_t base = wave * 64; base < nq; base += wavesTotal * 64) {
+        const uint32_t q = base + lane_id();
+        bool act = q < nq;
+        int64_t gs = 0, ge = -1;
+        uint8_t fl = 0;
+        bool minus = false;
+        int64_t j = 0;
+        if (act) {
+            gs = gStart[q];
+            ge = gEnd[q];
+            const uint8_t st = strand[q];
+            minus = st == '-';
+            if (st == '.')
+                fl |= F_DOT;
+            act = ge >= gs && gs >= 0 && numSegs > 0 && gs < (int64_t)segs[numSegs].start;
+            // largest j with start[j] <= gs
+            int64_t lo = 0, hi = numSegs; // invariant start[lo] <= gs < start[hi]
+            if (act) {
+                while (hi - lo > 1) {
+                    const int64_t mid = (lo + hi) >> 1;
+                    if ((int64_t)segs[mid].start <= gs)
+                        lo = mid;
+                    else
+                        hi = mid;
+                }
+            }
+            j = lo;
+        }
+        int64_t curStart = act ? (int64_t)segs[j].start : 0;
+        while (__any(act)) {
+            int64_t nextStart = 0;
+            bool emit = false;
+            int64_t plo = 0, phi = 0;
+            if (act) {
+                nextStart = (int64_t)segs[j + 1].start;
+                ++derefs;
+                plo = gs > curStart ? gs : curStart;
+                phi = ge < nextStart - 1 ? ge : nextStart - 1;
+                emit = true;
+            }
+            const unsigned long long slot = wave_append(&counters[CNT_FRONT0], emit);
+            if (emit) {
+                if (slot < cap) {
+                    const int32_t len = (int32_t)(phi - plo + 1);
+                    if (!minus)
+                        put(out, slot, (int32_t)q, plo, (int32_t)j, (int32_t)(plo - curStart), len, fl);
+                    else
+                        put(out, slot, (int32_t)q, phi, (int32_t)j, (int32_t)(nextStart - 1 - phi), len,
+                            (uint8_t)(fl | F_SREV | F_TREV));
+                } else {
+                    counters[CNT_OVERFLOW] = 1;
+                }
+                ++j;
+                curStart = nextStart;
+                act = j < numSegs && curStart <= ge;
+            }
+        }
+    }
+    wave_count_add(&counters[CNT_SRC_PIECES], derefs);
+}
+
+// ---------------------------------------------------------------------------------------------
+// U: top piece -> parent's bottom piece.  mapUp, top branch (halSegmentMapper.cpp:29-38) with
+// BottomSegmentIterator::toParent (api/impl/halBottomSegmentIterator.cpp:40-49): index = parentIndex,
+// offsets copied, strand ^= parentReversed; dropped when there is no parent or len < minLength.
+// (doDupes is always true on the way up, halSegmentMapper.cpp:108.)
+template <typename C>
+__global__ void __launch_bounds__(256) k_up_top(const TopRec<C> *__restrict__ top, Frontier in, const unsigned long long *inCount, uint32_t cap,
+                                                Frontier out, unsigned long long *outCount, int64_t minLength,
+                                                unsigned long long *counters) {
+    const uint32_t n = (uint32_t)min((unsigned long long)cap, *inCount);
+    const uint32_t wavesTotal = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    uint32_t derefs = 0;
+    for (uint32_t base = wave * 64; base < n; base += wavesTotal * 64) {
+        const uint32_t i = base + lane_id();
+        bool emit = false;
+        int32_t qid = 0, idx = 0, so = 0, len = 0;
+        int64_t sPos = 0;
+        uint8_t fl = 0;
+        if (i < n) {
+            idx = in.idx[i];
+            len = in.len[i];
+            const int32_t enc = top[idx].parentEnc;
+            ++derefs;
+            if (enc >= 0 && (int64_t)len >= minLength) {
+                emit = true;
+                qid = in.qid[i];
+                sPos = in.sPos[i];
+                so = in.so[i];
+                fl = in.flags[i];
+                if (enc & 1)
+                    fl ^= F_TREV;
+                idx = enc >> 1;
+            }
+        }
+        const unsigned long long slot = wave_append(outCount, emit);
+        if (emit) {
+            if (slot < cap)
+                put(out, slot, qid, sPos, idx, so, len, fl);
+            else
+                counters[CNT_OVERFLOW] = 1;
+        }
+    }
+    wave_count_add(&counters[CNT_TOP_DEREF], derefs);
+}
+
+// ---------------------------------------------------------------------------------------------
+// PU+U: bottom piece in genome P -> pieces of P's top tiling -> each to the bottom tiling of P's parent.
+// mapUp, bottom branch (halSegmentMapper.cpp:39-78): TopSegmentIterator::toParseUp
+// (api/impl/halTopSegmentIterator.cpp:55-81) starts at topParseIndex, steps right until the top segment
+// contains the piece's first base, truncates the piece to that segment, and the caller loops
+// toRight(rightCutoff) over the rest; the source is sliced by the same deltas (:52-62).  Each resulting
+// top piece then takes the U hop above.  In forward coordinates: split [lo,hi] at P's top-segment starts.
+template <typename C>
+__global__ void __launch_bounds__(256) k_parse_up_then_up(const BotRec<C> *__restrict__ bot, const TopRec<C> *__restrict__ top, Frontier in,
+                                                          const unsigned long long *inCount, uint32_t cap, Frontier out,
+                                                          unsigned long long *outCount, int64_t minLength,
+                                                          unsigned long long *counters) {
+    const uint32_t n = (uint32_t)min((unsigned long long)cap, *inCount);
+    const uint32_t wavesTotal = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    uint32_t topDerefs = 0, botDerefs = 0;
+    for (uint32_t base = wave * 64; base < n; base += wavesTotal * 64) {
+        const uint32_t i = base + lane_id();
+        bool act = i < n;
+        int32_t qid = 0;
+        int64_t sPos = 0, lo = 0, hi = -1;
+        uint8_t fl = 0;
+        int64_t j = 0, curStart = 0;
+        if (act) {
+            const int32_t b = in.idx[i];
+            const int32_t so = in.so[i], len = in.len[i];
+            qid = in.qid[i];
+            sPos = in.sPos[i];
+            fl = in.flags[i];
+            const BotRec<C> br = bot[b];
+            ++botDerefs;
+            if (!(fl & F_TREV)) {
+                lo = (int64_t)br.start + so;
+            } else {
+                const int64_t bEnd = (int64_t)bot[b + 1].start; // segment end (exclusive)
+                lo = bEnd - so - len;
+            }
+            hi = lo + len - 1;
+            j = br.topParse;
+            ++topDerefs;
+            // toParseUp's "while startPos >= segStart+segLen ++index" (halTopSegmentIterator.cpp:64-66),
+            // applied to the piece's left end (the right end is reached by the toRight loop)
+            for (;;) {
+                const int64_t nextStart = (int64_t)top[j + 1].start;
+                if (nextStart > lo)
+                    break;
+                ++j;
+                ++topDerefs;
+            }
+            curStart = (int64_t)top[j].start;
+        }
+        while (__any(act)) {
+            bool emit = false;
+            int32_t oIdx = 0, oSo = 0, oLen = 0;
+            int64_t oSPos = 0;
+            uint8_t oFl = fl;
+            int64_t nextStart = 0;
+            if (act) {
+                const TopRec<C> tr = top[j];
+                nextStart = (int64_t)top[j + 1].start;
+                const int64_t plo = lo > curStart ? lo : curStart;
+                const int64_t phi = hi < nextStart - 1 ? hi : nextStart - 1;
+                oLen = (int32_t)(phi - plo + 1);
+                const int32_t enc = tr.parentEnc;
+                if (enc >= 0 && (int64_t)oLen >= minLength) {
+                    emit = true;
+                    int64_t d; // distance of the sub-piece's first base from the piece's first base
+                    if (!(fl & F_TREV)) {
+                        oSo = (int32_t)(plo - curStart);
+                        d = plo - lo;
+                    } else {
+                        oSo = (int32_t)(nextStart - 1 - phi);
+                        d = hi - phi;
+                    }
+                    oSPos = (fl & F_SREV) ? sPos - d : sPos + d;
+                    if (enc & 1)
+                        oFl ^= F_TREV;
+                    oIdx = enc >> 1;
+                }
+            }
+            const unsigned long long slot = wave_append(outCount, emit);
+            if (emit) {
+                if (slot < cap)
+                    put(out, slot, qid, oSPos, oIdx, oSo, oLen, oFl);
+                else
+                    counters[CNT_OVERFLOW] = 1;
+            }
+            if (act) {
+                ++j;
+                curStart = nextStart;
+                act = curStart <= hi;
+                if (act)
+                    ++topDerefs;
+            }
+        }
+    }
+    wave_count_add(&counters[CNT_TOP_DEREF], topDerefs);
+    wave_count_add(&counters[CNT_BOT_DEREF], botDerefs);
+}
+
+// ---------------------------------------------------------------------------------------------
+// D (+R): bottom piece -> child's top piece through child slot `slot` (mapDown bottom branch,
+// halSegmentMapper.cpp:133-143; TopSegmentIterator::toChild, api/impl/halTopSegmentIterator.cpp:36-45),
+// then, when traversing duplications, the paralogy ring of that top segment (mapSelf top branch,
+// halSegmentMapper.cpp:265-288; toNextParalogy, halTopSegmentIterator.cpp:99-107: follow paralogyIndex,
+// flip strand iff the two segments' parentReversed differ; emit-then-test do/while).
+template <typename C>
+__global__ void __launch_bounds__(256) k_down_ring(const int32_t *__restrict__ childEnc, const TopRec<C> *__restrict__ ctop, Frontier in,
+                                                   const unsigned long long *inCount, uint32_t cap, Frontier out,
+                                                   unsigned long long *outCount, int64_t minLength, int doDupes,
+                                                   unsigned long long *counters) {
+    const uint32_t n = (uint32_t)min((unsigned long long)cap, *inCount);
+    const uint32_t wavesTotal = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    uint32_t topDerefs = 0, botDerefs = 0;
+    for (uint32_t base = wave * 64; base < n; base += wavesTotal * 64) {
+        const uint32_t i = base + lane_id();
+        bool act = false;
+        int32_t qid = 0, so = 0, len = 0, t0 = 0, cur = 0;
+        int64_t sPos = 0;
+        uint8_t fl = 0;
+        if (i < n) {
+            const int32_t b = in.idx[i];
+            len = in.len[i];
+            const int32_t enc = childEnc[b];
+            ++botDerefs;
+            if (enc >= 0 && (int64_t)len >= minLength) {
+                act = true;
+                qid = in.qid[i];
+                sPos = in.sPos[i];
+                so = in.so[i];
+                fl = in.flags[i];
+                if (enc & 1)
+                    fl ^= F_TREV;
+                t0 = cur = enc >> 1;
+            }
+        }
+        bool haveRec = false;
+        int32_t rcPar = -1, rcEnc = 0; // paralogy link and parentEnc of `cur`
+        while (__any(act)) {
+            const unsigned long long slot = wave_append(outCount, act);
+            if (act) {
+                if (slot < cap)
+                    put(out, slot, qid, sPos, cur, so, len, fl);
+                else
+                    counters[CNT_OVERFLOW] = 1;
+                if (!doDupes) {
+                    act = false;
+                } else {
+                    if (!haveRec) {
+                        const TopRec<C> rc = ctop[cur];
+                        ++topDerefs;
+                        rcPar = rc.paralogy;
+                        rcEnc = rc.parentEnc;
+                        haveRec = true;
+                    }
+                    if (rcPar < 0) {
+                        act = false; // no next paralogy: the do/while exits after the first emit
+                    } else {
+                        const TopRec<C> nr = ctop[rcPar];
+                        ++topDerefs;
+                        if ((nr.parentEnc & 1) != (rcEnc & 1))
+                            fl ^= F_TREV;
+                        cur = rcPar;
+                        rcPar = nr.paralogy;
+                        rcEnc = nr.parentEnc;
+                        act = rcPar >= 0 && cur != t0; // while (hasNextParalogy && index != start)
+                    }
+                }
+            }
+        }
+    }
+    wave_count_add(&counters[CNT_TOP_DEREF], topDerefs);
+    wave_count_add(&counters[CNT_BOT_DEREF], botDerefs);
+}
+
+// ---------------------------------------------------------------------------------------------
+// PD: top piece in genome G -> pieces of G's bottom tiling.  mapDown, top branch
+// (halSegmentMapper.cpp:144-184) with BottomSegmentIterator::toParseDown
+// (api/impl/halBottomSegmentIterator.cpp:51-76); mirror image of the PU step.
+template <typename C>
+__global__ void __launch_bounds__(256) k_parse_down(const TopRec<C> *__restrict__ top, const BotRec<C> *__restrict__ bot, Frontier in,
+                                                    const unsigned long long *inCount, uint32_t cap, Frontier out,
+                                                    unsigned long long *outCount, unsigned long long *counters) {
+    const uint32_t n = (uint32_t)min((unsigned long long)cap, *inCount);
+    const uint32_t wavesTotal = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    uint32_t topDerefs = 0, botDerefs = 0;
+    for (uint32_t base = wave * 64; base < n; base += wavesTotal * 64) {
+        const uint32_t i = base + lane_id();
+        bool act = i < n;
+        int32_t qid = 0;
+        int64_t sPos = 0, lo = 0, hi = -1;
+        uint8_t fl = 0;
+        int64_t j = 0, curStart = 0;
+        if (act) {
+            const int32_t t = in.idx[i];
+            const int32_t so = in.so[i], len = in.len[i];
+            qid = in.qid[i];
+            sPos = in.sPos[i];
+            fl = in.flags[i];
+            const TopRec<C> tr = top[t];
+            ++topDerefs;
+            if (!(fl & F_TREV))
+                lo = (int64_t)tr.start + so;
+            else
+                lo = (int64_t)top[t + 1].start - so - len;
+            hi = lo + len - 1;
+            j = tr.botParse;
+            ++botDerefs;
+            for (;;) {
+                const int64_t nextStart = (int64_t)bot[j + 1].start;
+                if (nextStart > lo)
+                    break;
+                ++j;
+                ++botDerefs;
+            }
+            curStart = (int64_t)bot[j].start;
+        }
+        while (__any(act)) {
+            bool emit = false;
+            int32_t oSo = 0, oLen = 0;
+            int64_t oSPos = 0;
+            int64_t nextStart = 0;
+            if (act) {
+                nextStart = (int64_t)bot[j + 1].start;
+                const int64_t plo = lo > curStart ? lo : curStart;
+                const int64_t phi = hi < nextStart - 1 ? hi : nextStart - 1;
+                oLen = (int32_t)(phi - plo + 1);
+                emit = true;
+                int64_t d;
+                if (!(fl & F_TREV)) {
+                    oSo = (int32_t)(plo - curStart);
+                    d = plo - lo;
+                } else {
+                    oSo = (int32_t)(nextStart - 1 - phi);
+                    d = hi - phi;
+                }
+                oSPos = (fl & F_SREV) ? sPos - d : sPos + d;
+            }
+            const unsigned long long slot = wave_append(outCount, emit);
+            if (emit) {
+                if (slot < cap)
+                    put(out, slot, qid, oSPos, (int32_t)j, oSo, oLen, fl);
+                else
+                    counters[CNT_OVERFLOW] = 1;
+            }
+            if (act) {
+                ++j;
+                curStart = nextStart;
+                act = curStart <= hi;
+                if (act)
+                    ++botDerefs;
+            }
+        }
+    }
+    wave_count_add(&counters[CNT_TOP_DEREF], topDerefs);
+    wave_count_add(&counters[CNT_BOT_DEREF], botDerefs);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Final: pieces in the target genome -> forward coordinates, and count pieces per query.
+// Positions per SegmentIterator::getStartPosition/getEndPosition (halSegmentIterator.cpp:46-67).
+template <typename REC>
+__global__ void __launch_bounds__(256) k_finalize(const REC *__restrict__ segs, Frontier in, const unsigned long long *inCount, uint32_t cap,
+                                                  Mapped out, uint32_t *__restrict__ perQuery, unsigned long long *counters, int isTop) {
+    const uint32_t n = (uint32_t)min((unsigned long long)cap, *inCount);
+    uint32_t derefs = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int32_t idx = in.idx[i];
+        const int32_t so = in.so[i], len = in.len[i];
+        const uint8_t fl = in.flags[i];
+        const int64_t sPos = in.sPos[i];
+        const int32_t q = in.qid[i];
+        int64_t lo;
+        if (!(fl & F_TREV))
+            lo = (int64_t)segs[idx].start + so;
+        else
+            lo = (int64_t)segs[idx + 1].start - so - len;
+        ++derefs;
+        out.qid[i] = q;
+        out.tLo[i] = lo;
+        out.tHi[i] = lo + len - 1;
+        if (!(fl & F_SREV)) {
+            out.sLo[i] = sPos;
+            out.sHi[i] = sPos + len - 1;
+        } else {
+            out.sLo[i] = sPos - len + 1;
+            out.sHi[i] = sPos;
+        }
+        out.flags[i] = fl;
+        atomicAdd(&perQuery[q], 1u);
+    }
+    wave_count_add(&counters[isTop ? CNT_TOP_DEREF : CNT_BOT_DEREF], derefs);
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        counters[CNT_MAPPED] = n;
+}
+
+// group pieces by query: slot = offset[q] + cursor[q]++
+__global__ void __launch_bounds__(256) k_scatter(Mapped in, const unsigned long long *inCount, uint32_t cap, const uint32_t *__restrict__ offset,
+                                                 uint32_t *__restrict__ cursor, Mapped out) {
+    const uint32_t n = (uint32_t)min((unsigned long long)cap, *inCount);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int32_t q = in.qid[i];
+        const uint32_t s = offset[q] + atomicAdd(&cursor[q], 1u);
+        out.qid[s] = q;
+        out.tLo[s] = in.tLo[i];
+        out.tHi[s] = in.tHi[i];
+        out.sLo[s] = in.sLo[i];
+        out.sHi[s] = in.sHi[i];
+        out.flags[s] = in.flags[i];
+    }
+}
+
+// ---- exclusive scan of uint32 (three small kernels; n up to 2^32-1) ----
+static constexpr int SCAN_BLOCK = 1024; // elements per block (256 threads x 4)
+__global__ void __launch_bounds__(256) k_scan_block_sums(const uint32_t *__restrict__ in, uint32_t n, uint32_t *__restrict__ blockSums) {
+    __shared__ uint32_t red[256];
+    const uint32_t base = blockIdx.x * SCAN_BLOCK;
+    uint32_t s = 0;
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t i = base + threadIdx.x * 4 + k;
+        if (i < n)
+            s += in[i];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o)
+            red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        blockSums[blockIdx.x] = red[0];
+}
+__global__ void k_scan_sums_serial(uint32_t *blockSums, uint32_t nb, uint32_t *total) {
+    // one thread; nb = n/1024 is at most a few thousand for the batches this library sees
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (uint32_t i = 0; i < nb; ++i) {
+            const uint32_t v = blockSums[i];
+            blockSums[i] = acc;
+            acc += v;
+        }
+        *total = acc;
+    }
+}
+__global__ void __launch_bounds__(256) k_scan_apply(const uint32_t *__restrict__ in, uint32_t n, const uint32_t *__restrict__ blockSums,
+                                                    uint32_t *__restrict__ out) {
+    __shared__ uint32_t part[256];
+    const uint32_t base = blockIdx.x * SCAN_BLOCK + threadIdx.x * 4;
+    uint32_t v[4];
+    uint32_t s = 0;
+    for (int k = 0; k < 4; ++k) {
+        v[k] = (base + k < n) ? in[base + k] : 0;
+        s += v[k];
+    }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over 256 partials
+    for (int o = 1; o < 256; o <<= 1) {
+        uint32_t t = 0;
+        if ((int)threadIdx.x >= o)
+            t = part[threadIdx.x - o];
+        __syncthreads();
+        part[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint32_t acc = blockSums[blockIdx.x] + part[threadIdx.x] - s;
+    for (int k = 0; k < 4; ++k) {
+        if (base + k < n)
+            out[base + k] = acc;
+        acc += v[k];
+    }
+}
+
+} // namespace hgx

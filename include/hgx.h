@@ -1,0 +1,155 @@
+/* hgx.h — C ABI of libhgx: MI355X-native replacement for the traversal hot path of HAL
+ * (halLiftover's block mapper; hal2maf / halAlignmentDepth's column engine).
+ *
+ * The reference (ComparativeGenomicsToolkit/hal, paths below are relative to its root) has no FFI on
+ * this path: tools link libHal.a + libHalLiftover.a and call C++ classes.  Each entry point here names
+ * the C++ interface it stands behind; conventions follow the one C API the reference does ship,
+ * blockViz/inc/halBlockViz.h:134-225: int status (0 = ok, <0 = error), message returned through
+ * `char **err` (malloc'd, release with hgx_free; pass NULL to ignore), results allocated by the
+ * library and released with hgx_free.  No exceptions cross this boundary.  A handle may be used from
+ * one host thread at a time (same as the reference's stateful Liftover object).
+ */
+#ifndef HGX_H
+#define HGX_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HGX_OK 0
+#define HGX_ERR (-1)
+#define HGX_NULL_INDEX (-1) /* api/impl/halCommon.cpp:18 */
+
+typedef struct hgx_alignment hgx_alignment;
+
+/* ---- opening an alignment: replaces openHalAlignment (api/impl/halAlignmentInstance.cpp:133-165) ----
+ * path: mmap-format HAL file (api/mmap_impl; versions 1.0/1.1; dirty files refused like
+ * mmapFile.cpp:96-98) or an HGX flat image.  device >= 0: HIP device ordinal the segment tables are
+ * uploaded to (kernels then run there); device == -1: host tables only (metadata queries; any compute
+ * entry point fails). */
+int hgx_open(const char *path, int device, hgx_alignment **out, char **err);
+void hgx_close(hgx_alignment *h);
+
+/* Build an alignment from caller-owned flat arrays instead of a file (the route for HDF5-backed
+ * alignments: the maintainer-side loop over Genome::getTopSegmentIterator/getBottomSegmentIterator is
+ * shown in INTEGRATION.md).  Usage: begin, add every genome parent-before-child (children of one parent
+ * in child-index order, api/inc/halGenome.h:247-256), finish.
+ *   top arrays have num_top entries, top_start additionally a sentinel (= genome length);
+ *   child_index/child_reversed are [num_children][num_bottom], row-major. */
+typedef struct hgx_builder hgx_builder;
+int hgx_builder_begin(hgx_builder **out, char **err);
+int hgx_builder_add_genome(hgx_builder *b, const char *name, const char *parent_name /* NULL for root */,
+                           double branch_length, int64_t num_sequences, const char *const *seq_names,
+                           const int64_t *seq_lengths, const int64_t *seq_num_top, const int64_t *seq_num_bottom,
+                           int64_t num_top, const int64_t *top_start, const int64_t *top_parent_index,
+                           const uint8_t *top_parent_reversed, const int64_t *top_next_paralogy,
+                           const int64_t *top_bottom_parse, int64_t num_bottom, const int64_t *bottom_start,
+                           const int64_t *bottom_top_parse, int64_t num_children, const int64_t *child_index,
+                           const uint8_t *child_reversed, const char *dna /* may be NULL */, char **err);
+int hgx_builder_finish(hgx_builder *b, int device, hgx_alignment **out, char **err); /* consumes b */
+void hgx_builder_abort(hgx_builder *b);
+
+/* ---- metadata: Alignment / Genome / Sequence getters (api/inc/halAlignment.h, halGenome.h) ---- */
+int hgx_num_genomes(const hgx_alignment *h);
+const char *hgx_newick(const hgx_alignment *h);                    /* Alignment::getNewickTree */
+const char *hgx_genome_name(const hgx_alignment *h, int genome);   /* Genome::getName */
+int hgx_genome_id(const hgx_alignment *h, const char *name);       /* Alignment::openGenome; -1 if absent */
+int hgx_genome_parent(const hgx_alignment *h, int genome);         /* Genome::getParent; -1 for root */
+int hgx_genome_num_children(const hgx_alignment *h, int genome);   /* Genome::getNumChildren */
+int hgx_genome_child(const hgx_alignment *h, int genome, int k);   /* Genome::getChild */
+int64_t hgx_genome_length(const hgx_alignment *h, int genome);     /* Genome::getSequenceLength */
+int64_t hgx_genome_num_top(const hgx_alignment *h, int genome);    /* Genome::getNumTopSegments */
+int64_t hgx_genome_num_bottom(const hgx_alignment *h, int genome); /* Genome::getNumBottomSegments */
+int hgx_genome_num_sequences(const hgx_alignment *h, int genome);  /* Genome::getNumSequences */
+/* Sequence::getName / getStartPosition / getSequenceLength by index */
+int hgx_sequence_info(const hgx_alignment *h, int genome, int seq, const char **name, int64_t *start, int64_t *length);
+/* Genome::getSequence(name) (api/mmap_impl/mmapGenome.cpp:186-196); returns the sequence index or -1 */
+int hgx_sequence_lookup(const hgx_alignment *h, int genome, const char *name, int64_t *start, int64_t *length);
+/* getLowestCommonAncestor (api/impl/halCommon.cpp:123-152) of two genomes */
+int hgx_mrca(const hgx_alignment *h, int genome_a, int genome_b);
+
+/* ---- halLiftover hot path: BlockLiftover::liftInterval (liftover/impl/halBlockLiftover.cpp:46-113) =
+ * halMapSegment per source segment (api/impl/halSegmentMapper.cpp:639-670) + insertAndBreakOverlaps
+ * (:475-520) + BlockMapper::extractSegment (liftover/impl/halBlockMapper.cpp:331-394) + the stable sort by
+ * source start of Liftover::visitLine (liftover/impl/halLiftover.cpp:90). ---- */
+typedef struct hgx_interval {
+    int64_t start; /* BED chromStart, sequence-relative, 0-based */
+    int64_t end;   /* BED chromEnd, exclusive */
+    int32_t seq;   /* sequence index in the source genome */
+    char strand;   /* '+', '-' or '.' */
+    char _pad[3];
+} hgx_interval;
+
+typedef struct hgx_record { /* one lifted output interval = one output BED line */
+    int64_t query;     /* index of the input interval this line came from */
+    int64_t tgt_start; /* sequence-relative, 0-based */
+    int64_t tgt_end;   /* exclusive */
+    int64_t src_start; /* genome coordinate in the source; the reference's hidden sort key (_srcStart) */
+    int32_t tgt_seq;   /* sequence index in the target genome */
+    char strand;       /* '+', '-' ('.' when the input strand was '.') */
+    char _pad[3];
+} hgx_record;
+
+typedef struct hgx_liftover_opts {
+    int32_t traverse_dupes;    /* Liftover::convert traverseDupes (halLiftover.h:25-28); --noDupes => 0 */
+    int32_t coalescence_limit; /* genome id or -1 (= MRCA, the default; anything else: not yet supported) */
+    int64_t min_length;        /* halMapSegment minLength; halLiftover passes 0 */
+} hgx_liftover_opts;
+
+/* Host-buffer form.  Records come back grouped by input interval in input order and, inside one
+ * interval, in the reference's print order.  Intervals with end > sequence length are skipped (no
+ * records), like halLiftover.cpp:62-66.  *out is released with hgx_free. */
+int hgx_liftover_batch(hgx_alignment *h, int src_genome, int tgt_genome, size_t n, const hgx_interval *intervals,
+                       const hgx_liftover_opts *opts, hgx_record **out, size_t *n_out, char **err);
+
+/* Device-resident form: the query table is already in HBM and the records stay there.
+ * A plan owns the per-(src,tgt) walk schedule and all device workspaces, sized for max_queries. */
+typedef struct hgx_liftover_plan hgx_liftover_plan;
+int hgx_liftover_plan_create(hgx_alignment *h, int src_genome, int tgt_genome, const hgx_liftover_opts *opts,
+                             size_t max_queries, hgx_liftover_plan **out, char **err);
+void hgx_liftover_plan_destroy(hgx_liftover_plan *p);
+/* d_gstart / d_gend: device int64[n], inclusive GENOME coordinates (start + sequence start, end - 1 +
+ * sequence start: halBlockLiftover.cpp:48-49); d_strand: device uint8[n] ('+','-','.').
+ * hip_stream: hipStream_t (NULL = default stream).  On return the run is complete and
+ * *d_records (device, owned by the plan, valid until the next run) holds *n_records hgx_record. */
+int hgx_liftover_run_device(hgx_liftover_plan *p, size_t n, const int64_t *d_gstart, const int64_t *d_gend,
+                            const uint8_t *d_strand, void *hip_stream, const hgx_record **d_records,
+                            size_t *n_records, char **err);
+/* Counters of the last run (for roofline accounting): queries, source pieces, top-segment records
+ * dereferenced, bottom-segment records dereferenced, mapped pieces before merging, output records,
+ * and the accumulated device time in ms of the walk kernels / all kernels of the run. */
+typedef struct hgx_liftover_stats {
+    uint64_t queries, source_pieces, top_derefs, bottom_derefs, mapped_pieces, records, deferred_queries;
+    double walk_ms, total_ms;
+} hgx_liftover_stats;
+int hgx_liftover_last_stats(const hgx_liftover_plan *p, hgx_liftover_stats *out);
+/* Per-kernel device time of the last run, measured with HIP events on the run's stream, as a JSON
+ * object {"kernel": {"ms": total, "launches": n}, ...}; release *json with hgx_free. */
+int hgx_liftover_kernel_times(const hgx_liftover_plan *p, char **json);
+
+/* Text-level drop-in for Liftover::convert (liftover/inc/halLiftover.h:25-28): BED text in, BED text
+ * out, byte-identical to halLiftover for BED3..BED9 (+ extra columns).  bed_type 0 = auto
+ * (halBedLine.cpp:36-38).  *out_text is released with hgx_free. */
+int hgx_liftover_convert(hgx_alignment *h, int src_genome, const char *bed_text, size_t bed_len, int tgt_genome,
+                         int bed_type, int traverse_dupes, int out_psl, int out_psl_with_name, int coalescence_limit,
+                         char **out_text, size_t *out_len, char **err);
+
+/* ---- synthetic workloads: halRandGen (randgen/halRandGen.cpp) ---- */
+typedef struct hgx_rand_opts {
+    double mean_degree, max_branch_length;
+    uint64_t min_genomes, max_genomes, min_segment_length, max_segment_length, min_segments, max_segments;
+    int32_t seed;
+    int32_t with_dna; /* 1 = seed-compatible with halRandGen; 0 = skip DNA draws (faster, different stream) */
+} hgx_rand_opts;
+int hgx_rand_preset(const char *preset, hgx_rand_opts *opts); /* small | medium | big | large */
+int hgx_create_random(const hgx_rand_opts *opts, int device, hgx_alignment **out, char **err);
+int hgx_save_image(const hgx_alignment *h, const char *path, char **err);
+
+void hgx_free(void *p);
+const char *hgx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HGX_H */

@@ -1,0 +1,98 @@
+"""Golden vectors transcribed from the reference's liftover unit test
+(liftover/tests/halLiftoverTests.cpp): the hand-built 5-genome alignment of setupSharedAlignment
+(:15-252; inversions, an insertion, paralogy rings, incommensurate tilings) expressed as tables, and the
+literal input/expected BED strings of testOneBranchLifts (:272-317) and testMultiBranchLifts (:319-343).
+Data only."""
+from halfix import NULL, simple_genome
+
+T, F = True, False
+DNA100 = "CAAAAGCTGCCTCGGCGTAGCCAGGTGTAAGCTGGTATTGTTCTTGTGCATCTGGGCACCATTCTCTTGTTCGTAAATAGGCGACGCTGTCTTTTGGCCG"
+DNA70 = "ATGTGTATGCTTGGGTCAACTCTCTTTTCAGATCCGGGCGGTCGTCCGTAATTATGTGCCGAATCTCCAC"
+
+def genomes():
+    # ids: 0 root, 1 child1, 2 leaf1, 3 leaf2, 4 leaf3 (addLeafGenome order: child slots root=[child1,leaf1],
+    # child1=[leaf2,leaf3])
+    root = simple_genome("root", -1, [1, 2], 100, [], [
+        (0, 20, [(0, T), (0, T)]),
+        (20, 20, [(NULL, F), (2, T)]),
+        (40, 20, [(2, F), (1, F)]),
+        (60, 20, [(3, T), (NULL, F)]),
+        (80, 20, [(NULL, F), (4, F)]),
+    ], DNA100)
+    child1 = simple_genome("child1", 0, [3, 4], 100, [
+        (0, 20, 0, T, 4),
+        (20, 20, NULL, F, NULL),
+        (40, 20, 2, F, NULL),
+        (60, 20, 3, T, NULL),
+        (80, 20, 0, F, 0),
+    ], [
+        (0, 20, [(0, T), (NULL, F)]),
+        (20, 10, [(NULL, F), (0, T)]),
+        (30, 5, [(1, F), (NULL, F)]),
+        (35, 15, [(NULL, F), (2, F)]),
+        (50, 20, [(4, T), (1, T)]),
+        (70, 20, [(3, F), (3, T)]),
+        (90, 10, [(NULL, F), (4, F)]),
+    ], DNA100)
+    leaf1 = simple_genome("leaf1", 0, [], 100, [
+        (0, 20, 0, T, NULL),
+        (20, 20, 2, F, NULL),
+        (40, 20, 1, T, NULL),
+        (60, 20, NULL, F, NULL),
+        (80, 20, 4, F, NULL),
+    ], [], DNA100)
+    leaf2 = simple_genome("leaf2", 1, [], 70, [
+        (0, 20, 0, T, NULL),
+        (20, 5, 2, F, 2),
+        (25, 5, 2, F, 1),
+        (30, 20, 5, F, NULL),
+        (50, 20, 4, T, NULL),
+    ], [], DNA70)
+    leaf3 = simple_genome("leaf3", 1, [], 100, [
+        (0, 10, 1, T, NULL),
+        (10, 20, 4, T, NULL),
+        (30, 15, 3, F, NULL),
+        (45, 20, 5, T, NULL),
+        (65, 10, 6, F, NULL),
+        (75, 25, NULL, F, NULL),
+    ], [], DNA100)
+    return [root, child1, leaf1, leaf2, leaf3]
+
+# (srcGenome, tgtGenome, input BED, expected BED) — BED6 cases of the reference test
+CASES = [
+    ("child1", "root",
+     "Sequence\t0\t20\tPARALOGY1REV\t0\t+\n"
+     "Sequence\t60\t80\tREV\t0\t+\n"
+     "Sequence\t20\t40\tINSERTION\t0\t+\n"
+     "Sequence\t80\t100\tPARALOGY2\t0\t+\n",
+     "Sequence\t0\t20\tPARALOGY1REV\t0\t-\n"
+     "Sequence\t60\t80\tREV\t0\t-\n"
+     "Sequence\t0\t20\tPARALOGY2\t0\t+\n"),
+    ("leaf1", "root",
+     "Sequence\t0\t5\tNORMALREV\t0\t+\n"
+     "Sequence\t10\t30\tOVERLAP\t0\t+\n"
+     "Sequence\t50\t70\tOVERLAPINSERTION\t0\t+\n"
+     "Sequence\t70\t100\tOVERLAPINSERTION2\t0\t+\n",
+     "Sequence\t15\t20\tNORMALREV\t0\t-\n"
+     "Sequence\t0\t10\tOVERLAP\t0\t-\n"
+     "Sequence\t40\t50\tOVERLAP\t0\t+\n"
+     "Sequence\t20\t30\tOVERLAPINSERTION\t0\t-\n"
+     "Sequence\t80\t100\tOVERLAPINSERTION2\t0\t+\n"),
+    ("root", "child1",
+     "Sequence\t0\t10\tPARALOGY\t0\t+\n"
+     "Sequence\t30\t50\tOVERLAPINSERTION\t0\t+\n",
+     "Sequence\t10\t20\tPARALOGY\t0\t-\n"
+     "Sequence\t80\t90\tPARALOGY\t0\t+\n"
+     "Sequence\t40\t50\tOVERLAPINSERTION\t0\t+\n"),
+    ("leaf2", "leaf3",
+     "Sequence\t30\t35\tREV\t0\t+\n"
+     "Sequence\t40\t60\tOVERLAP\t0\t+\n",
+     "Sequence\t60\t65\tREV\t0\t-\n"
+     "Sequence\t45\t55\tOVERLAP\t0\t-\n"
+     "Sequence\t10\t20\tOVERLAP\t0\t+\n"),
+    ("root", "leaf2",
+     "Sequence\t0\t20\tBLOCK_A\t0\t+\n"
+     "Sequence\t30\t50\tBLOCK_B\t0\t+\n",
+     "Sequence\t0\t20\tBLOCK_A\t0\t+\n"
+     "Sequence\t40\t50\tBLOCK_A\t0\t+\n"),
+]

@@ -1,0 +1,240 @@
+"""Parity of the HIP liftover path (through the C ABI) with the oracle and the reference's golden vectors.
+Integer/byte work: the bar is bit-exact text."""
+import bz2
+import os
+
+import numpy as np
+import pytest
+
+import halfix
+import handbuilt_liftover as hb
+from util import random_bed, oracle_liftover
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _rand_alignment(hal, tmp_path, seed, max_branch=3.0, min_seg=10, max_seg=60, min_segs=200, max_segs=600, max_genomes=10,
+                    mean_degree=1.5, name="rnd"):
+    opts = hal.RandOptions(mean_degree=mean_degree, max_branch_length=max_branch, min_genomes=2, max_genomes=max_genomes,
+                           min_segment_length=min_seg, max_segment_length=max_seg, min_segments=min_segs,
+                           max_segments=max_segs, seed=seed, with_dna=False)
+    al = hal.Alignment.random(opts, device=0)
+    img = str(tmp_path / ("%s_%d.hgx" % (name, seed)))
+    al.save(img)
+    return al, img
+
+
+def _check_pair(hal, oracle_bin, al, img, src, tgt, tmp_path, n=300, min_len=1, max_len=300, seed=0, no_dupes=False,
+                strands="+-", bed6=True):
+    name, _, length = al.sequences(src)[0]
+    if length == 0:
+        return 0
+    bed = random_bed(name, length, n, min_len, max_len, seed, strands=strands, bed6=bed6)
+    got = hal.liftover_convert(al, src, bed, tgt, traverse_dupes=not no_dupes)
+    want = oracle_liftover(oracle_bin, img, al.genome_name(src), al.genome_name(tgt), bed, tmp_path, no_dupes=no_dupes)
+    assert got == want, "src=%s tgt=%s noDupes=%s" % (al.genome_name(src), al.genome_name(tgt), no_dupes)
+    return got.count("\n")
+
+
+def test_reference_unit_test_handbuilt(hal, tmp_path):
+    img = str(tmp_path / "hand.hgx")
+    halfix.write_hgx(img, hb.genomes())
+    al = hal.Alignment.open(img, device=0)
+    for src, tgt, bed, want in hb.CASES:
+        assert hal.liftover_convert(al, al.genome_id(src), bed, al.genome_id(tgt)) == want, (src, tgt)
+
+
+def test_handbuilt_all_pairs_vs_oracle(hal, oracle_bin, tmp_path):
+    img = str(tmp_path / "hand.hgx")
+    halfix.write_hgx(img, hb.genomes())
+    al = hal.Alignment.open(img, device=0)
+    total = 0
+    for s in range(al.num_genomes):
+        for t in range(al.num_genomes):
+            for nd in (False, True):
+                total += _check_pair(hal, oracle_bin, al, img, s, t, tmp_path, n=200, max_len=100, seed=s * 7 + t, no_dupes=nd,
+                                     strands="+-.")
+    assert total > 1000
+
+
+def test_reference_cli_goldens(hal, tmp_path):
+    al = hal.Alignment.random(hal.RandOptions.preset("small", seed=0), device=0)
+    g0, g2 = al.genome_id("Genome_0"), al.genome_id("Genome_2")
+    bed = open(os.path.join(GOLD, "ref_liftover", "test1.bed3")).read()
+    assert hal.liftover_convert(al, g0, bed, g2) == open(os.path.join(GOLD, "ref_liftover", "halLiftoverBed3Test.bed")).read()
+    bed = open(os.path.join(GOLD, "ref_liftover", "test1.bed4+2")).read()
+    assert hal.liftover_convert(al, g0, bed, g2, bed_type=4) == \
+        open(os.path.join(GOLD, "ref_liftover", "halLiftoverBed4ExtraTest.bed")).read()
+
+
+def test_reference_mmap_file_all_pairs(hal, oracle_bin, tmp_path):
+    raw = bz2.decompress(open(os.path.join(GOLD, "ref_mmap", "small.mmap1.0.hal.bz2"), "rb").read())
+    p = tmp_path / "small.mmap1.0.hal"
+    p.write_bytes(raw)
+    al = hal.Alignment.open(str(p), device=0)
+    img = str(tmp_path / "mm.hgx")
+    al.save(img)
+    for s in range(al.num_genomes):
+        for t in range(al.num_genomes):
+            _check_pair(hal, oracle_bin, al, img, s, t, tmp_path, n=200, max_len=6000, seed=s + 10 * t)
+
+
+@pytest.mark.parametrize("seed", [2, 5, 6])
+def test_random_alignments_all_pairs(hal, oracle_bin, tmp_path, seed):
+    """Inversions, transpositions, paralogy rings, incommensurate tilings (maxBranchLength 3)."""
+    al, img = _rand_alignment(hal, tmp_path, seed)
+    n = al.num_genomes
+    lines = 0
+    for s in range(n):
+        for t in range(n):
+            lines += _check_pair(hal, oracle_bin, al, img, s, t, tmp_path, n=150, max_len=250, seed=seed * 100 + s * n + t,
+                                 no_dupes=((s + t) % 3 == 0), strands="+-.")
+    assert lines > 5000
+
+
+def test_wide_fanout_deferred_path(hal, oracle_bin, tmp_path):
+    """Intervals spanning hundreds of tiny segments: pieces per interval exceed the LDS staging capacity, so
+    the global-scratch finishing path runs."""
+    al, img = _rand_alignment(hal, tmp_path, 2, min_seg=4, max_seg=12, min_segs=3000, max_segs=5000, name="tiny")
+    src, tgt = al.genome_id("Genome_9"), al.genome_id("Genome_8")
+    name, _, length = al.sequences(src)[0]
+    bed = random_bed(name, length, 60, 2000, 6000, 3)
+    got = hal.liftover_convert(al, src, bed, tgt)
+    want = oracle_liftover(oracle_bin, img, "Genome_9", "Genome_8", bed, tmp_path)
+    assert got == want and got.count("\n") > 1000
+    # and down a long branch from the root with duplications
+    src, tgt = al.genome_id("Genome_0"), al.genome_id("Genome_9")
+    name, _, length = al.sequences(src)[0]
+    bed = random_bed(name, length, 40, 3000, 8000, 4)
+    assert hal.liftover_convert(al, src, bed, tgt) == oracle_liftover(oracle_bin, img, "Genome_0", "Genome_9", bed, tmp_path)
+
+
+def test_overlap_breaking_paralogous_sources(hal, oracle_bin, tmp_path):
+    """Long intervals on a heavily duplicated child: several source segments of one interval share ancestors, so the
+    mapped set needs insertAndBreakOverlaps' refinement and extractSegment's equivalence classes."""
+    al, img = _rand_alignment(hal, tmp_path, 6, max_branch=3.0, min_seg=5, max_seg=9, min_segs=40, max_segs=60, name="dup")
+    hits = 0
+    for s in range(al.num_genomes):
+        for t in range(al.num_genomes):
+            name, _, length = al.sequences(s)[0]
+            if length == 0:
+                continue
+            bed = "".join("%s\t%d\t%d\tw%d\t0\t%s\n" % (name, a, min(length, a + w), a, st)
+                          for a in range(0, length - 1, max(1, length // 7)) for w in (length, length // 2, 37)
+                          for st in "+-")
+            got = hal.liftover_convert(al, s, bed, t)
+            want = oracle_liftover(oracle_bin, img, al.genome_name(s), al.genome_name(t), bed, tmp_path)
+            assert got == want, (al.genome_name(s), al.genome_name(t))
+            hits += got.count("\n")
+    assert hits > 2000
+
+
+def test_bed_columns_and_skips(hal, oracle_bin, tmp_path):
+    al, img = _rand_alignment(hal, tmp_path, 5)
+    src, tgt = al.genome_id("Genome_4"), al.genome_id("Genome_2")
+    name, _, length = al.sequences(src)[0]
+    bed = ("%s\t10\t200\n" % name +                                            # BED3
+           "\n  \n" +                                                         # blank lines are skipped
+           "%s\t10\t200\tn\t5\t-\t10\t200\t1,2,3\n" % name +                   # BED9, thick fields rewritten
+           "%s\t50\t90\tn2\t7\t+\t0\t0\t9\textraA\textraB\n" % name +          # BED9 + extras, thick 0/0 kept
+           "nosuch\t1\t5\tx\t0\t+\n" +                                         # unknown sequence: skipped
+           "%s\t5\t%d\ty\t0\t+\n" % (name, length + 10) +                      # end beyond the sequence: skipped
+           "%s\t300\t420\tshort\n" % name)                                     # BED4 inherits the previous strand
+    got = hal.liftover_convert(al, src, bed, tgt)
+    want = oracle_liftover(oracle_bin, img, "Genome_4", "Genome_2", bed, tmp_path)
+    assert got == want and got.count("\n") > 3
+
+
+def test_malformed_line_reports_like_reference(hal, tmp_path):
+    al, _ = _rand_alignment(hal, tmp_path, 5)
+    src, tgt = al.genome_id("Genome_4"), al.genome_id("Genome_2")
+    name = al.sequences(src)[0][0]
+    good = "%s\t10\t200\ta\t0\t+\n" % name
+    with pytest.raises(hal.HgxError, match=r"Error zero or negative length BED range: .* in input bed line 2") as ei:
+        hal.liftover_convert(al, src, good + "%s\t50\t50\tb\t0\t+\n" % name + good, tgt)
+    assert ei.value.partial_output == hal.liftover_convert(al, src, good, tgt)  # line 1 was already written
+    with pytest.raises(hal.HgxError, match="Expected at least three columns in BED record"):
+        hal.liftover_convert(al, src, "%s\t5\n" % name, tgt)
+    with pytest.raises(hal.HgxError, match="Strand character must be"):
+        hal.liftover_convert(al, src, "%s\t5\t9\tn\t0\t*\n" % name, tgt)
+
+
+def test_batch_records_grouped_in_input_order(hal, oracle_bin, tmp_path):
+    al, img = _rand_alignment(hal, tmp_path, 2)
+    src, tgt = al.genome_id("Genome_9"), al.genome_id("Genome_2")
+    name, _, length = al.sequences(src)[0]
+    rng = np.random.default_rng(7)
+    n = 500
+    iv = np.zeros(n, dtype=hal.api.INTERVAL_DTYPE)
+    iv["start"] = rng.integers(0, length - 300, n)
+    iv["end"] = iv["start"] + rng.integers(1, 300, n)
+    iv["strand"] = rng.choice([b"+", b"-"], n)
+    iv["end"][5] = length + 1  # skipped like halLiftover.cpp:62-66
+    recs = al.liftover_batch(src, tgt, iv)
+    assert np.all(np.diff(recs["query"]) >= 0) and 5 not in set(recs["query"])
+    for q in np.unique(recs["query"]):
+        r = recs[recs["query"] == q]
+        assert np.all(np.diff(r["src_start"]) >= 0)  # Liftover::visitLine's sort by source start
+    tname = al.sequences(tgt)[0][0]
+    bed = "".join("%s\t%d\t%d\tq\t0\t%s\n" % (name, a["start"], a["end"], a["strand"].decode()) for a in iv if a["end"] <= length)
+    text = "".join("%s\t%d\t%d\tq\t0\t%s\n" % (tname, r["tgt_start"], r["tgt_end"], r["strand"].decode()) for r in recs)
+    assert text == oracle_liftover(oracle_bin, img, "Genome_9", "Genome_2", bed, tmp_path)
+
+
+def test_device_resident_plan_and_stats(hal, oracle_bin, tmp_path):
+    import torch
+    al, img = _rand_alignment(hal, tmp_path, 2)
+    src, tgt = al.genome_id("Genome_9"), al.genome_id("Genome_8")
+    name, sstart, length = al.sequences(src)[0]
+    n = 4000
+    g = torch.Generator().manual_seed(1)
+    starts = torch.randint(0, length - 400, (n,), generator=g)
+    lens = torch.randint(1, 400, (n,), generator=g)
+    strand = torch.where(torch.rand(n, generator=g) < 0.5, ord("+"), ord("-")).to(torch.uint8)
+    plan = hal.LiftoverPlan(al, src, tgt, max_queries=n)
+    for _ in range(2):  # plans are reusable; results identical
+        ptr, nrec = plan.run((starts + sstart).cuda(), (starts + lens - 1 + sstart).cuda(), strand.cuda())
+        recs = plan.records_to_tensor(ptr, nrec).cpu().numpy().view(hal.RECORD_DTYPE).reshape(-1)
+        tname = al.sequences(tgt)[0][0]
+        bed = "".join("%s\t%d\t%d\tq\t0\t%s\n" % (name, int(s), int(s + l), chr(int(c))) for s, l, c in zip(starts, lens, strand))
+        text = "".join("%s\t%d\t%d\tq\t0\t%s\n" % (tname, r["tgt_start"], r["tgt_end"], r["strand"].decode()) for r in recs)
+        want, stats = oracle_liftover(oracle_bin, img, "Genome_9", "Genome_8", bed, tmp_path, stats=True)
+        assert text == want
+    st = plan.stats()
+    assert st["queries"] == n and st["records"] == nrec and st["mapped_pieces"] >= nrec
+    assert st["top_derefs"] > 0 and st["bottom_derefs"] > 0 and st["total_ms"] >= st["walk_ms"] > 0
+    kt = plan.kernel_times()
+    assert "k_parse_up_then_up" in kt and "k_finish_lds" in kt
+
+
+def test_strand_symmetry_property_at_scale(hal, tmp_path):
+    """Size-independent property: lifting an interval on '-' gives the same target intervals as on '+', strands
+    flipped, in the same order (the source flip is undone by the strand-aware merge).  Run at 200k intervals on a
+    10-genome alignment of ~10 Mb genomes, too big for the oracle to check in seconds."""
+    opts = hal.RandOptions(mean_degree=1.5, max_branch_length=3.0, min_genomes=2, max_genomes=10, min_segment_length=50,
+                           max_segment_length=200, min_segments=70000, max_segments=140000, seed=2, with_dna=False)
+    al = hal.Alignment.random(opts, device=0)
+    src, tgt = al.genome_id("Genome_9"), al.genome_id("Genome_2")
+    name, _, length = al.sequences(src)[0]
+    rng = np.random.default_rng(11)
+    n = 200000
+    iv = np.zeros(n, dtype=hal.api.INTERVAL_DTYPE)
+    iv["start"] = rng.integers(0, length - 1000, n)
+    iv["end"] = iv["start"] + rng.integers(50, 1000, n)
+    iv["strand"] = b"+"
+    plus = al.liftover_batch(src, tgt, iv)
+    again = al.liftover_batch(src, tgt, iv)
+    assert plus.tobytes() == again.tobytes()  # deterministic
+    iv["strand"] = b"-"
+    minus = al.liftover_batch(src, tgt, iv)
+    assert len(plus) == len(minus) > n
+    for f in ("query", "tgt_start", "tgt_end", "src_start", "tgt_seq"):
+        assert np.array_equal(plus[f], minus[f]), f
+    assert np.all((plus["strand"] == b"+") == (minus["strand"] == b"-"))
+    # every record lies inside the target genome and has positive length
+    tlen = al.sequences(tgt)[0][2]
+    assert plus["tgt_start"].min() >= 0 and plus["tgt_end"].max() <= tlen and np.all(plus["tgt_end"] > plus["tgt_start"])
+    # merged lines never exceed the query length
+    qlen = (iv["end"] - iv["start"])[plus["query"]]
+    assert np.all(plus["tgt_end"] - plus["tgt_start"] <= qlen)

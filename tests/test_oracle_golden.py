@@ -1,0 +1,68 @@
+"""The oracle (CPU restatement) against the reference's own golden vectors.  CPU only."""
+import os
+import subprocess
+
+import halfix
+import handbuilt_liftover as hb
+from util import oracle_liftover
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _small_seed0(hal, tmp_path):
+    # liftover/Makefile:62-64: halRandGen --preset small --seed 0 (storage format is irrelevant here)
+    opts = hal.RandOptions.preset("small", seed=0)
+    al = hal.Alignment.random(opts, device=-1)
+    img = str(tmp_path / "small0.hgx")
+    al.save(img)
+    return al, img
+
+
+def test_generator_tree_matches_reference_seed0(hal, tmp_path):
+    al, _ = _small_seed0(hal, tmp_path)
+    # halRandGen --preset small --seed 0 tree as written into maf/tests/expected/hal2mafSmallTest.maf's header
+    assert al.newick == "((Genome_3:0)Genome_1:0,Genome_2:0)Genome_0;"
+
+
+def test_generator_tree_matches_reference_seed2_config2(hal):
+    # tree printed by the reference for these options (probe run of halRandGen)
+    opts = hal.RandOptions(mean_degree=1.5, max_branch_length=3.0, min_genomes=2, max_genomes=10, min_segment_length=50,
+                           max_segment_length=200, min_segments=70, max_segments=140, seed=2, with_dna=True)
+    al = hal.Alignment.random(opts, device=-1)
+    assert al.newick == ("(((((Genome_9:0)Genome_6:2)Genome_4:0,(Genome_7:1,Genome_8:1)Genome_5:1)Genome_3:0)Genome_1:2,"
+                         "Genome_2:2)Genome_0;")
+
+
+def test_reference_cli_golden_bed3(hal, oracle_bin, tmp_path):
+    # liftover/Makefile:46-48 halLiftoverBed3Test
+    _, img = _small_seed0(hal, tmp_path)
+    bed = open(os.path.join(GOLD, "ref_liftover", "test1.bed3")).read()
+    want = open(os.path.join(GOLD, "ref_liftover", "halLiftoverBed3Test.bed")).read()
+    assert oracle_liftover(oracle_bin, img, "Genome_0", "Genome_2", bed, tmp_path) == want
+
+
+def test_reference_cli_golden_bed4_extra(hal, oracle_bin, tmp_path):
+    # liftover/Makefile:59-61 halLiftoverBed4ExtraTest (--bedType 4, two pass-through columns, paralogous hits)
+    _, img = _small_seed0(hal, tmp_path)
+    bed = open(os.path.join(GOLD, "ref_liftover", "test1.bed4+2")).read()
+    want = open(os.path.join(GOLD, "ref_liftover", "halLiftoverBed4ExtraTest.bed")).read()
+    assert oracle_liftover(oracle_bin, img, "Genome_0", "Genome_2", bed, tmp_path, bed_type=4) == want
+
+
+def test_reference_unit_test_handbuilt(oracle_bin, tmp_path):
+    # liftover/tests/halLiftoverTests.cpp:272-343 (BED6 cases): inversions, insertion, paralogy, overlap breaking
+    img = str(tmp_path / "hand.hgx")
+    halfix.write_hgx(img, hb.genomes())
+    for src, tgt, bed, want in hb.CASES:
+        assert oracle_liftover(oracle_bin, img, src, tgt, bed, tmp_path) == want, (src, tgt)
+
+
+def test_oracle_asan_clean(tmp_path):
+    """Reference CI runs an ASan build (.travis.yml:23-30); do the same for the restatement on a paralog-rich case."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), "asan"])
+    img = str(tmp_path / "hand.hgx")
+    halfix.write_hgx(img, hb.genomes())
+    asan = os.path.join(root, "oracle", "_build", "hal_oracle_asan")
+    for src, tgt, bed, want in hb.CASES:
+        assert oracle_liftover(asan, img, src, tgt, bed, tmp_path) == want
