@@ -80,6 +80,13 @@ SYMBOLS = {
 
 
 def _load():
+    # PyTorch-ROCm bundles its own HIP/HSA runtime (torch/lib/libamdhip64.so, same SONAME as /opt/rocm's).  Two
+    # runtimes in one process cannot both own the GPU, so when torch is installed it is imported first and
+    # libhgx.so binds to the runtime torch loaded; device pointers and streams are then shared with torch.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise HgxError(
             "%s is missing: the HIP extension has not been built (run `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -185,7 +185,8 @@ struct KernelTimer {
 using namespace hgx;
 
 struct hgx_liftover_plan {
-    hgx_alignment *h = nullptr;
+    hgx_alignment *h = nullptr; // not owned; must outlive every run (destroying the plan does not touch it)
+    int device = 0;
     int src = -1, tgt = -1, mrca = -1;
     hgx_liftover_opts opts{};
     std::vector<int> up;                        // src ... mrca
@@ -472,6 +473,7 @@ hgx_liftover_plan *createLiftoverPlan(hgx_alignment *h, int src, int tgt, const 
         throw std::runtime_error("genome id out of range");
     std::unique_ptr<hgx_liftover_plan> P(new hgx_liftover_plan);
     P->h = h;
+    P->device = h->dev->device;
     P->src = src;
     P->tgt = tgt;
     P->opts = opts;
@@ -517,7 +519,7 @@ void runLiftoverPlan(hgx_liftover_plan *p, size_t n, const int64_t *dS, const in
 void destroyLiftoverPlan(hgx_liftover_plan *p) {
     if (!p)
         return;
-    (void)hipSetDevice(p->h->dev->device);
+    (void)hipSetDevice(p->device);
     delete p;
 }
 

@@ -137,13 +137,17 @@ def test_bed_columns_and_skips(hal, oracle_bin, tmp_path):
     bed = ("%s\t10\t200\n" % name +                                            # BED3
            "\n  \n" +                                                         # blank lines are skipped
            "%s\t10\t200\tn\t5\t-\t10\t200\t1,2,3\n" % name +                   # BED9, thick fields rewritten
-           "%s\t50\t90\tn2\t7\t+\t0\t0\t9\textraA\textraB\n" % name +          # BED9 + extras, thick 0/0 kept
+           "%s\t50\t90\tn2\t7\t+\t0\t0\t9\n" % name +                          # BED9, thick 0/0 kept, rgb "9" -> 9,9,9
            "nosuch\t1\t5\tx\t0\t+\n" +                                         # unknown sequence: skipped
            "%s\t5\t%d\ty\t0\t+\n" % (name, length + 10) +                      # end beyond the sequence: skipped
            "%s\t300\t420\tshort\n" % name)                                     # BED4 inherits the previous strand
     got = hal.liftover_convert(al, src, bed, tgt)
     want = oracle_liftover(oracle_bin, img, "Genome_4", "Genome_2", bed, tmp_path)
     assert got == want and got.count("\n") > 3
+    # explicit --bedType with pass-through columns (liftover/Makefile:59-61)
+    bed = "%s\t50\t290\tn2\t7\t-\textraA\textraB\n%s\t1\t99\tn3\t8\t.\tC\n" % (name, name)
+    got = hal.liftover_convert(al, src, bed, tgt, bed_type=6)
+    assert got == oracle_liftover(oracle_bin, img, "Genome_4", "Genome_2", bed, tmp_path, bed_type=6) and "extraB" in got
 
 
 def test_malformed_line_reports_like_reference(hal, tmp_path):
