@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py — halLiftover block-mapping hot path on MI355X (BASELINE.json configs[1]).
+
+Workload (synthetic, generated in-process by hal_amd's restatement of halRandGen):
+  10-genome alignment, ~100 Mb and ~1 M segments per genome (halRandGen --seed 2 --minGenomes 2 --maxGenomes 10
+  --meanDegree 1.5 --minSegmentLength 50 --maxSegmentLength 200 --minSegments 700000 --maxSegments 1400000
+  --maxBranchLength 3, DNA draws skipped), 1 M BED6 intervals of 50..1000 bp, random strand, lifted from the
+  deepest leaf Genome_9 to Genome_2 (5 hops up, 1 down), duplications traversed.
+A "step" = one pass of the device-resident liftover over the whole interval batch (inputs already in HBM):
+locate/expand, the per-level walk kernels, grouping, per-interval overlap breaking + merging + ordering, record
+compaction.  With --gpus N every rank lifts its own 1 M-interval shard against a replicated image (weak scaling)
+and the ranks' records are collated with an all-gather (RCCL) inside the timed step.
+
+Prints one JSON line (rank 0).  `roofline` is for the kernel with the largest device time; `cpu_baseline` times the
+oracle (bit-identical CPU restatement of the reference, oracle/) on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+
+def workload_options(scale):
+    import hal_amd
+    return hal_amd.RandOptions(mean_degree=1.5, max_branch_length=3.0, min_genomes=2, max_genomes=10, min_segment_length=50,
+                               max_segment_length=200, min_segments=int(700000 * scale), max_segments=int(1400000 * scale),
+                               seed=2, with_dna=False)
+
+
+def make_queries(length, n, seed):
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(50, 1001, (n,), generator=g, dtype=torch.int64)
+    starts = (torch.rand(n, generator=g, dtype=torch.float64) * (length - 1001)).to(torch.int64)
+    strand = torch.where(torch.rand(n, generator=g) < 0.5, ord("+"), ord("-")).to(torch.uint8)
+    return starts, lens, strand
+
+
+def cpu_baseline(al, src_name, tgt_name, starts, lens, strand, seq_name, sample):
+    """Oracle (oracle/_build/hal_oracle, single thread) on the first `sample` intervals of this rank's batch."""
+    oracle = os.path.join(ROOT, "oracle", "_build", "hal_oracle")
+    if not os.path.exists(oracle):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    with tempfile.TemporaryDirectory() as tmp:
+        img = os.path.join(tmp, "bench.hgx")
+        al.save(img)
+        bed = os.path.join(tmp, "in.bed")
+        with open(bed, "w") as f:
+            for i in range(sample):
+                s, l = int(starts[i]), int(lens[i])
+                f.write("%s\t%d\t%d\tq\t0\t%s\n" % (seq_name, s, s + l, chr(int(strand[i]))))
+        out = subprocess.run([oracle, "liftover", img, src_name, bed, tgt_name, os.path.join(tmp, "out.bed"), "--stats"],
+                             check=True, stdout=subprocess.PIPE).stdout.decode()
+        st = json.loads(out)
+        with open(os.path.join(tmp, "out.bed")) as f:
+            text = f.read()
+    return st, text
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--queries", type=int, default=1000000, help="intervals per GPU")
+    ap.add_argument("--scale", type=float, default=1.0, help="genome size multiplier (1.0 = ~100 Mb/genome)")
+    ap.add_argument("--target", default="Genome_2")
+    ap.add_argument("--cpu-sample", type=int, default=300000, help="intervals timed on the CPU oracle (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import hal_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    t0 = time.time()
+    al = hal_amd.Alignment.random(workload_options(args.scale), device=local)
+    gen_s = time.time() - t0
+    src_name, tgt_name = "Genome_9", args.target
+    src, tgt = al.genome_id(src_name), al.genome_id(tgt_name)
+    seq_name, seq_start, length = al.sequences(src)[0]
+    nq = args.queries
+    starts, lens, strand = make_queries(length, nq, 1234 + rank)  # disjoint shards: every rank has its own intervals
+    d_gs = (starts + seq_start).to(dev)
+    d_ge = (starts + lens - 1 + seq_start).to(dev)
+    d_st = strand.to(dev)
+    plan = hal_amd.LiftoverPlan(al, src, tgt, max_queries=nq)
+
+    def step():
+        ptr, nrec = plan.run(d_gs, d_ge, d_st)
+        if world > 1:
+            # all-gatherv of the fixed-width records: counts first, then padded payloads
+            cnt = torch.tensor([nrec], dtype=torch.int64, device=dev)
+            counts = torch.empty(world, dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(counts, cnt)
+            mx = int(counts.max().item())
+            mine = torch.zeros((mx, 40), dtype=torch.uint8, device=dev)
+            if nrec:
+                mine[:nrec] = plan.records_to_tensor(ptr, nrec)
+            allrec = torch.empty((world * mx, 40), dtype=torch.uint8, device=dev)
+            dist.all_gather_into_tensor(allrec, mine)
+            return nrec, int(counts.sum().item())
+        return nrec, nrec
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kt_acc = {}
+    walk_ms = total_ms = 0.0
+    for _ in range(args.steps):
+        nrec, nrec_all = step()
+        st = plan.stats()
+        walk_ms += st["walk_ms"]
+        total_ms += st["total_ms"]
+        for k, v in plan.kernel_times().items():
+            a = kt_acc.setdefault(k, {"ms": 0.0, "launches": 0})
+            a["ms"] += v["ms"]
+            a["launches"] += v["launches"]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        st = plan.stats()
+        value = world * nq * args.steps / elapsed
+        # --- roofline of the dominant kernel (device time from HIP events on the launch stream) ---
+        dom = max(kt_acc.items(), key=lambda kv: kv[1]["ms"])
+        dom_name, dom_ms, dom_launches = dom[0], dom[1]["ms"], dom[1]["launches"]
+        Q, T, B, R = st["queries"], st["top_derefs"], st["bottom_derefs"], st["records"]
+        alg_total = 24 * Q + 25 * T + 25 * B + 40 * R  # SURVEY 8(d), per step
+        kern_ms_total = sum(v["ms"] for v in kt_acc.values()) / args.steps
+        per_kernel_alg = plan_kernel_bytes(plan, st)
+        dom_bytes_per_launch = per_kernel_alg.get(dom_name, 0.0)
+        dom_avg_ms = dom_ms / max(1, dom_launches)
+        achieved = dom_bytes_per_launch / (dom_avg_ms * 1e-3) / 1e9 if dom_avg_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(dom_name)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "lifted BED intervals/sec", "value": value, "unit": "intervals/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int64" if al.genome_length(src) >= 2 ** 31 else "int32", "data": "synthetic",
+            "config": {"workload": "halRandGen 10-genome ~100 Mb/genome HAL (seed 2, scale %g), halLiftover of %d BED6 intervals "
+                                   "per GPU, %s -> %s, dupes on" % (args.scale, nq, src_name, tgt_name),
+                       "intervals_per_gpu": nq, "records_per_step": nrec_all, "parallelism": "query-shard x%d" % world,
+                       "newick": al.newick, "generate_s": round(gen_s, 2)},
+            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel_avg_ms": dom_avg_ms, "kernel_launches_per_step": dom_launches / args.steps,
+                         "algorithmic_bytes_per_launch": dom_bytes_per_launch,
+                         "whole_path": {"algorithmic_bytes_per_step": alg_total, "kernel_ms_per_step": kern_ms_total,
+                                        "achieved_GBs": alg_total / (kern_ms_total * 1e-3) / 1e9 if kern_ms_total > 0 else 0.0}},
+            "kernels_ms_per_step": {k: round(v["ms"] / args.steps, 4) for k, v in sorted(kt_acc.items())},
+            "counts_per_step": {"queries": Q, "source_pieces": st["source_pieces"], "top_derefs": T, "bottom_derefs": B,
+                                "mapped_pieces": st["mapped_pieces"], "records": R, "deferred_queries": st["deferred_queries"]},
+        }
+        if args.cpu_sample > 0:
+            sample = min(args.cpu_sample, nq)
+            cst, text = cpu_baseline(al, src_name, tgt_name, starts, lens, strand, seq_name, sample)
+            # parity spot check of the timed configuration: GPU records of the sampled intervals vs the oracle's text
+            ptr, n = plan.run(d_gs[:sample].contiguous(), d_ge[:sample].contiguous(), d_st[:sample].contiguous())
+            import numpy as np
+            recs = plan.records_to_tensor(ptr, n).cpu().numpy().view(hal_amd.RECORD_DTYPE).reshape(-1)
+            tname = al.sequences(tgt)[0][0]
+            gpu_text = "".join("%s\t%d\t%d\tq\t0\t%s\n" % (tname, r["tgt_start"], r["tgt_end"], r["strand"].decode()) for r in recs)
+            out["cpu_baseline"] = {"value": cst["intervals"] / cst["map_seconds"], "unit": "intervals/s", "cores": 1,
+                                   "kind": "port",
+                                   "sample": "first %d intervals of rank 0's batch, oracle liftInterval+sort time only "
+                                             "(BED parse/print and image load excluded)" % sample,
+                                   "parity_with_gpu": gpu_text == text}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def plan_kernel_bytes(plan, st):
+    """Algorithmic bytes per launch of each kernel: 25 B per segment record logically
+    dereferenced by that kernel, 24 B per query for the locate kernel, 40 B per record written by the finishing kernel."""
+    kt = plan.kernel_times()
+    out = {}
+    for name, v in kt.items():
+        launches = max(1, v["launches"])
+        t, b = v.get("top_derefs", 0), v.get("bot_derefs", 0)
+        bytes_ = 25.0 * (t + b)
+        if name == "k_locate_expand":
+            bytes_ += 24.0 * st["queries"]
+        if name in ("k_finish_lds", "k_finish_big"):
+            bytes_ += 40.0 * st["records"]
+        if name == "k_compact_records":
+            bytes_ += 80.0 * st["records"]
+        out[name] = bytes_ / launches
+    return out
+
+
+if __name__ == "__main__":
+    main()

@@ -140,34 +140,44 @@ struct KernelTimer {
     struct Rec {
         std::string name;
         hipEvent_t a, b;
+        int launch; // index of this launch's {top, bottom} deref counters, or -1
+    };
+    struct Total {
+        double ms = 0;
+        int launches = 0;
+        unsigned long long top = 0, bot = 0;
     };
     std::vector<Rec> recs;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
     size_t used = 0;
-    std::map<std::string, std::pair<double, int>> totals; // name -> (ms, launches) of the last run
-    void begin(const char *name, hipStream_t s) {
+    std::map<std::string, Total> totals; // per kernel name, last run
+    void begin(const char *name, hipStream_t s, int launch = -1) {
         if (used == pool.size()) {
             hipEvent_t a, b;
             HIP_OK(hipEventCreate(&a));
             HIP_OK(hipEventCreate(&b));
             pool.emplace_back(a, b);
         }
-        recs.push_back({name, pool[used].first, pool[used].second});
+        recs.push_back({name, pool[used].first, pool[used].second, launch});
         ++used;
         HIP_OK(hipEventRecord(recs.back().a, s));
     }
     void end(hipStream_t s) {
         HIP_OK(hipEventRecord(recs.back().b, s));
     }
-    void resolve(bool reset) {
+    void resolve(bool reset, const unsigned long long *hostCounters = nullptr) {
         if (reset)
             totals.clear();
         for (Rec &r : recs) {
             float ms = 0;
             HIP_OK(hipEventElapsedTime(&ms, r.a, r.b));
-            auto &t = totals[r.name];
-            t.first += ms;
-            t.second += 1;
+            Total &t = totals[r.name];
+            t.ms += ms;
+            t.launches += 1;
+            if (hostCounters && r.launch >= 0) {
+                t.top += hostCounters[CNT_KSTAT0 + 2 * r.launch];
+                t.bot += hostCounters[CNT_KSTAT0 + 2 * r.launch + 1];
+            }
         }
         recs.clear();
         used = 0;
@@ -267,6 +277,8 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
     HIP_OK(hipEventRecord(P.evStart, s));
 
     int level = 0;
+    int launch = 0; // per-launch deref counter slot
+    auto kstat = [&]() { return cnt + CNT_KSTAT0 + 2 * launch; };
     int cur = 0; // frontier buffer holding the current pieces
     auto inCnt = [&]() { return cnt + CNT_FRONT0 + level; };
     auto outCnt = [&]() { return cnt + CNT_FRONT0 + level + 1; };
@@ -274,34 +286,37 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
 
     // stage 0
     const DeviceGenome &SG = D.genomes[(size_t)P.src];
-    P.timer.begin("k_locate_expand", s);
+    P.timer.begin("k_locate_expand", s, launch);
     if (P.srcTop)
         hipLaunchKernelGGL((k_locate_expand<TopRec<C>>), dim3(GRID), dim3(256), 0, s, (const TopRec<C> *)SG.top, SG.numTop, dS, dE,
-                           dStrand, nq, P.frontier(cur), cap, cnt);
+                           dStrand, nq, P.frontier(cur), cap, cnt, kstat() + 0);
     else
         hipLaunchKernelGGL((k_locate_expand<BotRec<C>>), dim3(GRID), dim3(256), 0, s, (const BotRec<C> *)SG.bot, SG.numBot, dS, dE,
-                           dStrand, nq, P.frontier(cur), cap, cnt);
+                           dStrand, nq, P.frontier(cur), cap, cnt, kstat() + 1);
     P.timer.end(s);
+    ++launch;
 
     bool curTop = P.srcTop;
     int curGenome = P.src;
     if (P.src != P.mrca) {
         // first hop: top pieces of the source -> bottom pieces of its parent
-        P.timer.begin("k_up_top", s);
+        P.timer.begin("k_up_top", s, launch);
         hipLaunchKernelGGL((k_up_top<C>), dim3(GRID), dim3(256), 0, s, (const TopRec<C> *)D.genomes[(size_t)curGenome].top,
-                           P.frontier(cur), inCnt(), cap, P.frontier(cur ^ 1), outCnt(), minLen, cnt);
+                           P.frontier(cur), inCnt(), cap, P.frontier(cur ^ 1), outCnt(), minLen, cnt, kstat());
         P.timer.end(s);
+        ++launch;
         cur ^= 1;
         ++level;
         curGenome = P.up[1];
         curTop = false;
         for (size_t k = 1; k + 1 < P.up.size(); ++k) {
             const DeviceGenome &G = D.genomes[(size_t)P.up[k]];
-            P.timer.begin("k_parse_up_then_up", s);
+            P.timer.begin("k_parse_up_then_up", s, launch);
             hipLaunchKernelGGL((k_parse_up_then_up<C>), dim3(GRID), dim3(256), 0, s, (const BotRec<C> *)G.bot,
                                (const TopRec<C> *)G.top, P.frontier(cur), inCnt(), cap, P.frontier(cur ^ 1), outCnt(), minLen,
-                               cnt);
+                               cnt, kstat());
             P.timer.end(s);
+            ++launch;
             cur ^= 1;
             ++level;
             curGenome = P.up[k + 1];
@@ -310,10 +325,11 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
     if (P.tgt != P.mrca) {
         if (curTop) { // source is the MRCA itself and is walked through its top tiling
             const DeviceGenome &G = D.genomes[(size_t)curGenome];
-            P.timer.begin("k_parse_down", s);
+            P.timer.begin("k_parse_down", s, launch);
             hipLaunchKernelGGL((k_parse_down<C>), dim3(GRID), dim3(256), 0, s, (const TopRec<C> *)G.top, (const BotRec<C> *)G.bot,
-                               P.frontier(cur), inCnt(), cap, P.frontier(cur ^ 1), outCnt(), cnt);
+                               P.frontier(cur), inCnt(), cap, P.frontier(cur ^ 1), outCnt(), cnt, kstat());
             P.timer.end(s);
+            ++launch;
             cur ^= 1;
             ++level;
             curTop = false;
@@ -323,20 +339,23 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
             const int child = P.h->img.genomes[(size_t)parent].children[(size_t)slot];
             const DeviceGenome &PG = D.genomes[(size_t)parent];
             const DeviceGenome &CG = D.genomes[(size_t)child];
-            P.timer.begin("k_down_ring", s);
+            P.timer.begin("k_down_ring", s, launch);
             hipLaunchKernelGGL((k_down_ring<C>), dim3(GRID), dim3(256), 0, s, (const int32_t *)PG.childEnc[(size_t)slot],
                                (const TopRec<C> *)CG.top, P.frontier(cur), inCnt(), cap, P.frontier(cur ^ 1), outCnt(), minLen,
-                               (int)(P.opts.traverse_dupes != 0), cnt);
+                               (int)(P.opts.traverse_dupes != 0), cnt, kstat());
             P.timer.end(s);
+            ++launch;
             cur ^= 1;
             ++level;
             curTop = true;
             curGenome = child;
             if (child != P.tgt) {
-                P.timer.begin("k_parse_down", s);
+                P.timer.begin("k_parse_down", s, launch);
                 hipLaunchKernelGGL((k_parse_down<C>), dim3(GRID), dim3(256), 0, s, (const TopRec<C> *)CG.top,
-                                   (const BotRec<C> *)CG.bot, P.frontier(cur), inCnt(), cap, P.frontier(cur ^ 1), outCnt(), cnt);
+                                   (const BotRec<C> *)CG.bot, P.frontier(cur), inCnt(), cap, P.frontier(cur ^ 1), outCnt(), cnt,
+                                   kstat());
                 P.timer.end(s);
+                ++launch;
                 cur ^= 1;
                 ++level;
                 curTop = false;
@@ -345,13 +364,13 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
     }
     // final pieces live in the target genome
     const DeviceGenome &TG = D.genomes[(size_t)P.tgt];
-    P.timer.begin("k_finalize", s);
+    P.timer.begin("k_finalize", s, launch);
     if (curTop)
         hipLaunchKernelGGL((k_finalize<TopRec<C>>), dim3(GRID), dim3(256), 0, s, (const TopRec<C> *)TG.top, P.frontier(cur), inCnt(),
-                           cap, P.mapped(0), (uint32_t *)P.perQuery.p, cnt, 1);
+                           cap, P.mapped(0), (uint32_t *)P.perQuery.p, cnt, kstat(), 1);
     else
         hipLaunchKernelGGL((k_finalize<BotRec<C>>), dim3(GRID), dim3(256), 0, s, (const BotRec<C> *)TG.bot, P.frontier(cur), inCnt(),
-                           cap, P.mapped(0), (uint32_t *)P.perQuery.p, cnt, 0);
+                           cap, P.mapped(0), (uint32_t *)P.perQuery.p, cnt, kstat(), 0);
     P.timer.end(s);
     HIP_OK(hipEventRecord(P.evWalk, s));
 
@@ -397,7 +416,7 @@ static void runPlan(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
             break;
         // a frontier outgrew the workspace: size it from the largest count seen and run again
         unsigned long long need = 0;
-        for (int k = CNT_FRONT0; k < CNT_SLOTS; ++k)
+        for (int k = CNT_FRONT0; k < CNT_FRONT0 + MAX_LEVELS; ++k)
             need = std::max(need, hc[k]);
         need = std::max<unsigned long long>(need + need / 4, 2ull * P.cap);
         if (need >= (1ull << 32))
@@ -448,14 +467,19 @@ static void runPlan(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
     P.timer.end(s);
     HIP_OK(hipEventRecord(P.evEnd, s));
     HIP_OK(hipStreamSynchronize(s));
-    P.timer.resolve(true);
+    P.timer.resolve(true, hc);
+    unsigned long long topAll = 0, botAll = 0;
+    for (int k = 0; k < MAX_LAUNCHES; ++k) {
+        topAll += hc[CNT_KSTAT0 + 2 * k];
+        botAll += hc[CNT_KSTAT0 + 2 * k + 1];
+    }
     float walk = 0, tot = 0;
     HIP_OK(hipEventElapsedTime(&walk, P.evStart, P.evWalk));
     HIP_OK(hipEventElapsedTime(&tot, P.evStart, P.evEnd));
     P.stats.queries = n;
     P.stats.source_pieces = hc[CNT_SRC_PIECES];
-    P.stats.top_derefs = hc[CNT_TOP_DEREF] + (P.srcTop ? hc[CNT_SRC_PIECES] : 0);
-    P.stats.bottom_derefs = hc[CNT_BOT_DEREF] + (P.srcTop ? 0 : hc[CNT_SRC_PIECES]);
+    P.stats.top_derefs = topAll;
+    P.stats.bottom_derefs = botAll;
     P.stats.mapped_pieces = hc[CNT_MAPPED];
     P.stats.records = totalRecords;
     P.stats.deferred_queries = nDef;
@@ -496,6 +520,8 @@ hgx_liftover_plan *createLiftoverPlan(hgx_alignment *h, int src, int tgt, const 
         P->down.emplace_back(parent, slot);
         parent = chain[k];
     }
+    if ((int)(P->up.size() + 2 * P->down.size()) + 3 >= MAX_LEVELS || (int)(P->up.size() + 2 * P->down.size()) + 3 >= MAX_LAUNCHES)
+        throw std::runtime_error("tree path between the genomes is too long for the counter block");
     // BlockLiftover::visitBegin (halBlockLiftover.cpp:24-30): walk the source through its top tiling when it has one
     P->srcTop = img.genomes[(size_t)src].numTop > 0;
     P->maxQueries = std::max<size_t>(maxQueries, 1);
@@ -535,7 +561,8 @@ std::string liftoverPlanKernelTimes(const hgx_liftover_plan *p) {
             s += ", ";
         first = false;
         char buf[256];
-        snprintf(buf, sizeof buf, "\"%s\": {\"ms\": %.6f, \"launches\": %d}", kv.first.c_str(), kv.second.first, kv.second.second);
+        snprintf(buf, sizeof buf, "\"%s\": {\"ms\": %.6f, \"launches\": %d, \"top_derefs\": %llu, \"bot_derefs\": %llu}",
+                 kv.first.c_str(), kv.second.ms, kv.second.launches, kv.second.top, kv.second.bot);
         s += buf;
     }
     s += "}";

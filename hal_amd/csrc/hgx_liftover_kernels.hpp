@@ -44,8 +44,11 @@ enum {
     CNT_DEFERRED = 5,
     CNT_MAXNEED = 6,
     CNT_BIGFAIL = 7,
-    CNT_FRONT0 = 8, // + level: element count of frontier after each step
-    CNT_SLOTS = 64
+    CNT_FRONT0 = 8,    // + level: element count of the frontier after each step (up to MAX_LEVELS)
+    MAX_LEVELS = 200,
+    CNT_KSTAT0 = 208,  // + 2*launch: {top, bottom} segment records dereferenced by that launch
+    MAX_LAUNCHES = 152,
+    CNT_SLOTS = 512
 };
 
 __device__ __forceinline__ int lane_id() {
@@ -96,7 +99,8 @@ __device__ __forceinline__ void put(const Frontier &f, unsigned long long slot, 
 template <typename REC>
 __global__ void __launch_bounds__(256) k_locate_expand(const REC *__restrict__ segs, int64_t numSegs, const int64_t *__restrict__ gStart,
                                                        const int64_t *__restrict__ gEnd, const uint8_t *__restrict__ strand,
-                                                       uint32_t nq, Frontier out, uint32_t cap, unsigned long long *counters) {
+                                                       uint32_t nq, Frontier out, uint32_t cap, unsigned long long *counters,
+                                                       unsigned long long *kstat) {
     const uint32_t wavesTotal = (gridDim.x * blockDim.x) >> 6;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     uint32_t derefs = 0;
@@ -159,6 +163,7 @@ __global__ void __launch_bounds__(256) k_locate_expand(const REC *__restrict__ s
         }
     }
     wave_count_add(&counters[CNT_SRC_PIECES], derefs);
+    wave_count_add(kstat, derefs);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -169,7 +174,7 @@ __global__ void __launch_bounds__(256) k_locate_expand(const REC *__restrict__ s
 template <typename C>
 __global__ void __launch_bounds__(256) k_up_top(const TopRec<C> *__restrict__ top, Frontier in, const unsigned long long *inCount, uint32_t cap,
                                                 Frontier out, unsigned long long *outCount, int64_t minLength,
-                                                unsigned long long *counters) {
+                                                unsigned long long *counters, unsigned long long *kstat) {
     const uint32_t n = (uint32_t)min((unsigned long long)cap, *inCount);
     const uint32_t wavesTotal = (gridDim.x * blockDim.x) >> 6;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -204,7 +209,7 @@ __global__ void __launch_bounds__(256) k_up_top(const TopRec<C> *__restrict__ to
                 counters[CNT_OVERFLOW] = 1;
         }
     }
-    wave_count_add(&counters[CNT_TOP_DEREF], derefs);
+    wave_count_add(&kstat[0], derefs);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -218,7 +223,7 @@ template <typename C>
 __global__ void __launch_bounds__(256) k_parse_up_then_up(const BotRec<C> *__restrict__ bot, const TopRec<C> *__restrict__ top, Frontier in,
                                                           const unsigned long long *inCount, uint32_t cap, Frontier out,
                                                           unsigned long long *outCount, int64_t minLength,
-                                                          unsigned long long *counters) {
+                                                          unsigned long long *counters, unsigned long long *kstat) {
     const uint32_t n = (uint32_t)min((unsigned long long)cap, *inCount);
     const uint32_t wavesTotal = (gridDim.x * blockDim.x) >> 6;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -303,8 +308,8 @@ __global__ void __launch_bounds__(256) k_parse_up_then_up(const BotRec<C> *__res
             }
         }
     }
-    wave_count_add(&counters[CNT_TOP_DEREF], topDerefs);
-    wave_count_add(&counters[CNT_BOT_DEREF], botDerefs);
+    wave_count_add(&kstat[0], topDerefs);
+    wave_count_add(&kstat[1], botDerefs);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -317,7 +322,7 @@ template <typename C>
 __global__ void __launch_bounds__(256) k_down_ring(const int32_t *__restrict__ childEnc, const TopRec<C> *__restrict__ ctop, Frontier in,
                                                    const unsigned long long *inCount, uint32_t cap, Frontier out,
                                                    unsigned long long *outCount, int64_t minLength, int doDupes,
-                                                   unsigned long long *counters) {
+                                                   unsigned long long *counters, unsigned long long *kstat) {
     const uint32_t n = (uint32_t)min((unsigned long long)cap, *inCount);
     const uint32_t wavesTotal = (gridDim.x * blockDim.x) >> 6;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -379,8 +384,8 @@ __global__ void __launch_bounds__(256) k_down_ring(const int32_t *__restrict__ c
             }
         }
     }
-    wave_count_add(&counters[CNT_TOP_DEREF], topDerefs);
-    wave_count_add(&counters[CNT_BOT_DEREF], botDerefs);
+    wave_count_add(&kstat[0], topDerefs);
+    wave_count_add(&kstat[1], botDerefs);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -390,7 +395,8 @@ __global__ void __launch_bounds__(256) k_down_ring(const int32_t *__restrict__ c
 template <typename C>
 __global__ void __launch_bounds__(256) k_parse_down(const TopRec<C> *__restrict__ top, const BotRec<C> *__restrict__ bot, Frontier in,
                                                     const unsigned long long *inCount, uint32_t cap, Frontier out,
-                                                    unsigned long long *outCount, unsigned long long *counters) {
+                                                    unsigned long long *outCount, unsigned long long *counters,
+                                                    unsigned long long *kstat) {
     const uint32_t n = (uint32_t)min((unsigned long long)cap, *inCount);
     const uint32_t wavesTotal = (gridDim.x * blockDim.x) >> 6;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -463,8 +469,8 @@ __global__ void __launch_bounds__(256) k_parse_down(const TopRec<C> *__restrict_
             }
         }
     }
-    wave_count_add(&counters[CNT_TOP_DEREF], topDerefs);
-    wave_count_add(&counters[CNT_BOT_DEREF], botDerefs);
+    wave_count_add(&kstat[0], topDerefs);
+    wave_count_add(&kstat[1], botDerefs);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -472,7 +478,8 @@ __global__ void __launch_bounds__(256) k_parse_down(const TopRec<C> *__restrict_
 // Positions per SegmentIterator::getStartPosition/getEndPosition (halSegmentIterator.cpp:46-67).
 template <typename REC>
 __global__ void __launch_bounds__(256) k_finalize(const REC *__restrict__ segs, Frontier in, const unsigned long long *inCount, uint32_t cap,
-                                                  Mapped out, uint32_t *__restrict__ perQuery, unsigned long long *counters, int isTop) {
+                                                  Mapped out, uint32_t *__restrict__ perQuery, unsigned long long *counters,
+                                                  unsigned long long *kstat, int isTop) {
     const uint32_t n = (uint32_t)min((unsigned long long)cap, *inCount);
     uint32_t derefs = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -500,7 +507,7 @@ __global__ void __launch_bounds__(256) k_finalize(const REC *__restrict__ segs, 
         out.flags[i] = fl;
         atomicAdd(&perQuery[q], 1u);
     }
-    wave_count_add(&counters[isTop ? CNT_TOP_DEREF : CNT_BOT_DEREF], derefs);
+    wave_count_add(&kstat[isTop ? 0 : 1], derefs);
     if (blockIdx.x == 0 && threadIdx.x == 0)
         counters[CNT_MAPPED] = n;
 }
