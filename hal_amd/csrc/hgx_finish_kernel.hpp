@@ -417,9 +417,175 @@ __device__ __forceinline__ void write_records(const FinishStore<C> &S, int nl, i
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Size classes.  Most intervals map to a handful of pieces; those are finished in registers by a sub-wave
+// group of G lanes (k_finish_fast), G the smallest of 8/16/32/64 that holds them.  Larger ones, and any interval
+// whose pieces overlap or tie on the target (the cases that need overlap breaking / equivalence classes), go to
+// the general LDS kernel through `generalList`.
+enum { CLS_8 = 0, CLS_16 = 1, CLS_32 = 2, CLS_64 = 3, CLS_GENERAL = 4, CLS_COUNT = 5 };
+
+__global__ void __launch_bounds__(256) k_classify(const uint32_t *__restrict__ count, uint32_t nq, uint32_t *__restrict__ lists /* [CLS_COUNT][nq] */,
+                                                  unsigned long long *__restrict__ listCount /* [CLS_COUNT] */, uint32_t *__restrict__ nOut) {
+    const uint32_t wavesTotal = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    for (uint32_t base = wave * 64; base < nq; base += wavesTotal * 64) {
+        const uint32_t q = base + lane_id();
+        int cls = -1;
+        if (q < nq) {
+            const uint32_t n = count[q];
+            if (n == 0)
+                nOut[q] = 0;
+            else
+                cls = n <= 8 ? CLS_8 : n <= 16 ? CLS_16 : n <= 32 ? CLS_32 : n <= 64 ? CLS_64 : CLS_GENERAL;
+        }
+        for (int c = 0; c < CLS_COUNT; ++c) {
+            const unsigned long long slot = wave_append(&listCount[c], cls == c);
+            if (cls == c)
+                lists[(size_t)c * nq + slot] = q;
+        }
+    }
+}
+
+// bitonic sort of one 64-bit key per lane inside aligned groups of G lanes (ascending), shuffles only
+template <int G> __device__ __forceinline__ unsigned long long group_sort(unsigned long long key, int li) {
+#pragma unroll
+    for (int k = 2; k <= G; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const unsigned long long other = __shfl_xor(key, j);
+            const bool up = (li & k) == 0;
+            const bool lower = (li & j) == 0;
+            const bool takeMin = lower == up;
+            const unsigned long long mn = key < other ? key : other, mx = key < other ? other : key;
+            key = takeMin ? mn : mx;
+        }
+    }
+    return key;
+}
+
+// Register-resident finishing for intervals with at most G pieces and no target overlaps or ties:
+// in that case the MappedSegmentSet is just the pieces sorted by target start, every equivalence class of
+// extractSegment (liftover/impl/halBlockMapper.cpp:348-352) has one member, no cut point is ever recorded
+// (:385-387 needs a class of size > 1), so an output line is a maximal run of neighbours that
+// canMergeRightWith (api/impl/halMappedSegment.cpp:109-161), and lines are then stably sorted by source start
+// (liftover/impl/halLiftover.cpp:90).  One sub-wave group of G lanes per interval, one piece per lane.
+template <typename C, int G>
+__global__ void __launch_bounds__(256) k_finish_fast(Mapped in, const uint32_t *__restrict__ offset, const uint32_t *__restrict__ count,
+                                                     const uint32_t *__restrict__ qlist, const unsigned long long *__restrict__ qcount,
+                                                     const int64_t *__restrict__ seqStart, int numSeq, hgx_record *__restrict__ records,
+                                                     uint32_t *__restrict__ nOut, uint32_t *__restrict__ generalList,
+                                                     unsigned long long *__restrict__ generalCount) {
+    constexpr int PER_WAVE = 64 / G;
+    const uint32_t nlist = (uint32_t)*qcount;
+    const uint32_t wavesTotal = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = lane_id();
+    const int li = lane & (G - 1);       // lane inside the group
+    const int gbase = lane & ~(G - 1);   // first lane of the group
+    const unsigned long long gmask = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << gbase;
+    const unsigned long long INF = ~0ull;
+    for (uint32_t wbase = wave * PER_WAVE; wbase < nlist; wbase += wavesTotal * PER_WAVE) {
+        const uint32_t k = wbase + (uint32_t)(lane / G);
+        const bool gvalid = k < nlist;
+        uint32_t q = 0, base = 0;
+        int n = 0;
+        if (gvalid) {
+            q = qlist[k];
+            n = (int)count[q];
+            base = offset[q];
+        }
+        const bool have = li < n;
+        int64_t tLo = 0, tHi = 0, sLo = 0, sHi = 0;
+        uint8_t fl = 0;
+        if (have) {
+            tLo = in.tLo[base + li];
+            tHi = in.tHi[base + li];
+            sLo = in.sLo[base + li];
+            sHi = in.sHi[base + li];
+            fl = in.flags[base + li];
+        }
+        // 1. order by target start
+        unsigned long long key = have ? (((unsigned long long)tLo << 6) | (unsigned long long)lane) : INF;
+        key = group_sort<G>(key, li);
+        const int srcLane = (int)(key & 63ull);
+        const bool occ = key != INF; // sorted position li holds a piece
+        tLo = __shfl(tLo, srcLane);
+        tHi = __shfl(tHi, srcLane);
+        sLo = __shfl(sLo, srcLane);
+        sHi = __shfl(sHi, srcLane);
+        fl = (uint8_t)__shfl((int)fl, srcLane);
+        int seq = 0;
+        if (numSeq > 1 && occ) {
+            int lo = 0, hi = numSeq;
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (seqStart[mid] <= tLo)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+            seq = lo;
+        }
+        // 2. neighbour relations (previous piece in target order)
+        const int64_t pTHi = __shfl_up(tHi, 1), pSLo = __shfl_up(sLo, 1), pSHi = __shfl_up(sHi, 1);
+        const int pFl = __shfl_up((int)fl, 1), pSeq = __shfl_up(seq, 1);
+        const bool hasPrev = occ && li > 0;
+        const bool complex_ = hasPrev && tLo <= pTHi; // overlap or tie: needs the general algorithm
+        bool mergePrev = false;
+        if (hasPrev) {
+            const bool sameStrands = (((int)fl ^ pFl) & (F_SREV | F_TREV)) == 0;
+            const bool same = ((fl & F_SREV) != 0) == ((fl & F_TREV) != 0);
+            const bool rOk = same ? (sLo - pSHi == 1) : (pSLo - sHi == 1);
+            mergePrev = sameStrands && (tLo - pTHi == 1) && rOk && seq == pSeq;
+        }
+        const unsigned long long complexMask = __ballot(complex_) & gmask;
+        const bool head = occ && !mergePrev;
+        const unsigned long long headMask = __ballot(head) & gmask;
+        if (gvalid && complexMask != 0) {
+            if (li == 0) {
+                const unsigned long long slot = atomicAdd(generalCount, 1ull);
+                generalList[slot] = q;
+            }
+        }
+        const bool doGroup = gvalid && complexMask == 0;
+        // 3. a line runs from its head to the piece before the next head
+        int back = li;
+        if (head) {
+            const unsigned long long above = (li + 1 < 64) ? ((headMask >> gbase) >> (li + 1)) : 0ull; // heads after me, group-relative
+            const int nextHead = above ? li + 1 + (__ffsll((long long)above) - 1) : n;
+            back = nextHead - 1;
+        }
+        const int64_t bTHi = __shfl(tHi, gbase + back), bSLo = __shfl(sLo, gbase + back);
+        const int64_t lStart = tLo, lEnd = bTHi + 1, lSrc = sLo < bSLo ? sLo : bSLo;
+        // 4. stable sort of the lines by source start
+        unsigned long long lkey = (head && doGroup) ? (((unsigned long long)lSrc << 6) | (unsigned long long)lane) : INF;
+        lkey = group_sort<G>(lkey, li);
+        const int lLane = (int)(lkey & 63ull);
+        const bool isLine = lkey != INF;
+        const int64_t oStart = __shfl(lStart, lLane), oEnd = __shfl(lEnd, lLane), oSrc = __shfl(lSrc, lLane);
+        const int oSeq = __shfl(seq, lLane), oFl = __shfl((int)fl, lLane);
+        if (isLine) {
+            hgx_record r;
+            const int64_t ss = seqStart[oSeq];
+            r.query = q;
+            r.tgt_start = oStart - ss;
+            r.tgt_end = oEnd - ss;
+            r.src_start = oSrc;
+            r.tgt_seq = oSeq;
+            r.strand = (oFl & F_DOT) ? '.' : ((oFl & F_TREV) ? '-' : '+');
+            r._pad[0] = r._pad[1] = r._pad[2] = 0;
+            records[base + li] = r;
+        }
+        if (doGroup && li == 0)
+            nOut[q] = (uint32_t)__popcll(headMask);
+    }
+}
+
 // LDS-staged variant: capacity CAP pieces per query.
 template <typename C, int CAP>
-__global__ void __launch_bounds__(64) k_finish_lds(Mapped in, const uint32_t *__restrict__ offset, const uint32_t *__restrict__ count, uint32_t nq,
+__global__ void __launch_bounds__(64) k_finish_lds(Mapped in, const uint32_t *__restrict__ offset, const uint32_t *__restrict__ count,
+                                                   const uint32_t *__restrict__ qlist, const unsigned long long *__restrict__ qcount,
                                                    const int64_t *__restrict__ seqStart, int numSeq, hgx_record *__restrict__ records,
                                                    uint32_t *__restrict__ nOut, uint32_t *__restrict__ deferredList, uint32_t *__restrict__ needCap,
                                                    unsigned long long *counters) {
@@ -429,13 +595,10 @@ __global__ void __launch_bounds__(64) k_finish_lds(Mapped in, const uint32_t *__
     __shared__ uint32_t s_ord[CAP2];
     __shared__ int32_t s_seq[CAP], s_lSeq[CAP];
     __shared__ uint8_t s_fl[CAP], s_fl2[CAP], s_alive[CAP], s_lStrand[CAP];
-    for (uint32_t q = blockIdx.x; q < nq; q += gridDim.x) {
+    const uint32_t nlist = (uint32_t)*qcount;
+    for (uint32_t k = blockIdx.x; k < nlist; k += gridDim.x) {
+        const uint32_t q = qlist[k];
         const int n = (int)count[q];
-        if (n == 0) {
-            if (threadIdx.x == 0)
-                nOut[q] = 0;
-            continue;
-        }
         FinishStore<C> S;
         S.tLo = s_tLo, S.tHi = s_tHi, S.sLo = s_sLo, S.sHi = s_sHi, S.fl = s_fl;
         S.tLo2 = s_tLo2, S.tHi2 = s_tHi2, S.sLo2 = s_sLo2, S.sHi2 = s_sHi2, S.fl2 = s_fl2;

@@ -205,7 +205,7 @@ struct hgx_liftover_plan {
     size_t maxQueries = 0;
     uint32_t cap = 0; // piece capacity of every frontier / mapped / record buffer
     DevBuf fr[2][6], mp[2][6], counters, perQuery, offset, cursor, nOut, outOffset, blockSums, total, grouped, outRecords,
-        deferredList, needCap, bigSlot, scratch, bigRecords;
+        deferredList, needCap, bigSlot, scratch, bigRecords, classLists, classCounts;
     KernelTimer timer;
     hgx_liftover_stats stats{};
     hipEvent_t evStart = nullptr, evWalk = nullptr, evEnd = nullptr;
@@ -247,6 +247,8 @@ struct hgx_liftover_plan {
         deferredList.ensure(4 * (nq + 1));
         needCap.ensure(4 * (nq + 1));
         bigSlot.ensure(4 * (nq + 1));
+        classLists.ensure(4 * (size_t)CLS_COUNT * (nq + 1));
+        classCounts.ensure(8 * CLS_COUNT);
     }
 };
 
@@ -379,9 +381,32 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
     hipLaunchKernelGGL(k_scatter, dim3(GRID), dim3(256), 0, s, P.mapped(0), inCnt(), cap, (const uint32_t *)P.offset.p,
                        (uint32_t *)P.cursor.p, P.mapped(1));
     P.timer.end(s);
+    // finishing: classify by piece count, register-resident fast path per class, general LDS path for the rest
+    uint32_t *lists = (uint32_t *)P.classLists.p;
+    unsigned long long *listCount = (unsigned long long *)P.classCounts.p;
+    HIP_OK(hipMemsetAsync(listCount, 0, 8 * CLS_COUNT, s));
+    P.timer.begin("k_classify", s);
+    hipLaunchKernelGGL(k_classify, dim3(GRID), dim3(256), 0, s, (const uint32_t *)P.perQuery.p, nq, lists, listCount,
+                       (uint32_t *)P.nOut.p);
+    P.timer.end(s);
+    uint32_t *generalList = lists + (size_t)CLS_GENERAL * nq;
+    unsigned long long *generalCount = listCount + CLS_GENERAL;
+    P.timer.begin("k_finish_fast", s);
+#define HGX_FAST(G, CLS)                                                                                               \
+    hipLaunchKernelGGL((k_finish_fast<C, G>), dim3(GRID), dim3(256), 0, s, P.mapped(1), (const uint32_t *)P.offset.p,  \
+                       (const uint32_t *)P.perQuery.p, (const uint32_t *)(lists + (size_t)CLS * nq),                  \
+                       (const unsigned long long *)(listCount + CLS), (const int64_t *)TG.seqStart, (int)TG.numSeq,    \
+                       (hgx_record *)P.grouped.p, (uint32_t *)P.nOut.p, generalList, generalCount)
+    HGX_FAST(8, CLS_8);
+    HGX_FAST(16, CLS_16);
+    HGX_FAST(32, CLS_32);
+    HGX_FAST(64, CLS_64);
+#undef HGX_FAST
+    P.timer.end(s);
     P.timer.begin("k_finish_lds", s);
-    hipLaunchKernelGGL((k_finish_lds<C, 256>), dim3(std::min<uint32_t>(std::max<uint32_t>(nq, 1), 1u << 16)), dim3(64), 0, s, P.mapped(1),
-                       (const uint32_t *)P.offset.p, (const uint32_t *)P.perQuery.p, nq, (const int64_t *)TG.seqStart, (int)TG.numSeq,
+    hipLaunchKernelGGL((k_finish_lds<C, 256>), dim3(std::min<uint32_t>(std::max<uint32_t>(nq, 1), 1u << 14)), dim3(64), 0, s, P.mapped(1),
+                       (const uint32_t *)P.offset.p, (const uint32_t *)P.perQuery.p, (const uint32_t *)generalList,
+                       (const unsigned long long *)generalCount, (const int64_t *)TG.seqStart, (int)TG.numSeq,
                        (hgx_record *)P.grouped.p, (uint32_t *)P.nOut.p, (uint32_t *)P.deferredList.p, (uint32_t *)P.needCap.p, cnt);
     P.timer.end(s);
     HIP_OK(hipMemcpyAsync(hostCounters, cnt, 8 * CNT_SLOTS, hipMemcpyDeviceToHost, s));

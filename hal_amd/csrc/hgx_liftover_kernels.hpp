@@ -90,6 +90,94 @@ __device__ __forceinline__ void put(const Frontier &f, unsigned long long slot, 
     f.flags[slot] = flags;
 }
 
+// LDS-staged append.  Appending straight to the next frontier costs one device-scope atomic on a single
+// counter per wavefront per emit round, and that one word saturates near 90 atomics/us on MI355X — the
+// first profile of this path was bound by exactly that.  Each wavefront therefore compacts its emitted
+// pieces (ballot + popcount prefix) into a private LDS window and only when the window is nearly full
+// reserves a contiguous range of the global frontier with ONE atomic and copies the window out with
+// coalesced stores.  Order inside a frontier is irrelevant (the result is re-grouped by query later).
+static constexpr int STAGE_CAP = 192;   // pieces per wavefront window (4 waves x 192 x 25 B = 19 KB per block)
+static constexpr int STAGE_FLUSH = STAGE_CAP - 64;
+
+struct StageMem { // one per block, declared __shared__ by the kernel
+    int64_t sPos[4 * STAGE_CAP];
+    int32_t qid[4 * STAGE_CAP];
+    int32_t idx[4 * STAGE_CAP];
+    int32_t so[4 * STAGE_CAP];
+    int32_t len[4 * STAGE_CAP];
+    uint8_t fl[4 * STAGE_CAP];
+};
+
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+struct Stage {
+    StageMem *m;
+    int base;  // this wave's window inside the block's StageMem
+    int count; // wave-uniform
+    Frontier out;
+    unsigned long long *outCount;
+    unsigned long long *counters;
+    uint32_t cap;
+
+    __device__ __forceinline__ void init(StageMem *mem, const Frontier &o, unsigned long long *oc, unsigned long long *c, uint32_t cp) {
+        m = mem;
+        base = (int)(threadIdx.x >> 6) * STAGE_CAP;
+        count = 0;
+        out = o;
+        outCount = oc;
+        counters = c;
+        cap = cp;
+    }
+    __device__ __forceinline__ void flush() {
+        wave_lds_fence();
+        const int n = count;
+        if (n > 0) {
+            const int lane = lane_id();
+            unsigned long long b = 0;
+            if (lane == 0)
+                b = atomicAdd(outCount, (unsigned long long)n);
+            b = __shfl(b, 0);
+            for (int i = lane; i < n; i += 64) {
+                const unsigned long long slot = b + (unsigned long long)i;
+                if (slot < cap) {
+                    out.qid[slot] = m->qid[base + i];
+                    out.sPos[slot] = m->sPos[base + i];
+                    out.idx[slot] = m->idx[base + i];
+                    out.so[slot] = m->so[base + i];
+                    out.len[slot] = m->len[base + i];
+                    out.flags[slot] = m->fl[base + i];
+                } else {
+                    counters[CNT_OVERFLOW] = 1;
+                }
+            }
+            count = 0;
+        }
+        wave_lds_fence();
+    }
+    // all lanes of the wave call this together; lanes with emit == true contribute one piece
+    __device__ __forceinline__ void emit(bool doEmit, int32_t qid, int64_t sPos, int32_t idx, int32_t so, int32_t len, uint8_t fl) {
+        const unsigned long long mask = __ballot(doEmit);
+        if (mask == 0)
+            return;
+        if (doEmit) {
+            const int p = base + count + (int)__popcll(mask & ((1ull << lane_id()) - 1ull));
+            m->qid[p] = qid;
+            m->sPos[p] = sPos;
+            m->idx[p] = idx;
+            m->so[p] = so;
+            m->len[p] = len;
+            m->fl[p] = fl;
+        }
+        count += (int)__popcll(mask);
+        if (count > STAGE_FLUSH)
+            flush();
+    }
+};
+
 // ---------------------------------------------------------------------------------------------
 // Stage 0: locate + expand.  BlockLiftover::liftInterval, liftover/impl/halBlockLiftover.cpp:46-72:
 // toSite(globalStart) (api/impl/halSegmentIterator.cpp:240-299, here a binary search on start[]), slice,
@@ -104,6 +192,9 @@ __global__ void __launch_bounds__(256) k_locate_expand(const REC *__restrict__ s
     const uint32_t wavesTotal = (gridDim.x * blockDim.x) >> 6;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     uint32_t derefs = 0;
+    __shared__ StageMem stageMem;
+    Stage stage;
+    stage.init(&stageMem, out, &counters[CNT_FRONT0], counters, cap);
     for (uint32_t base = wave * 64; base < nq; base += wavesTotal * 64) {
         const uint32_t q = base + lane_id();
         bool act = q < nq;
@@ -144,24 +235,17 @@ __global__ void __launch_bounds__(256) k_locate_expand(const REC *__restrict__ s
                 phi = ge < nextStart - 1 ? ge : nextStart - 1;
                 emit = true;
             }
-            const unsigned long long slot = wave_append(&counters[CNT_FRONT0], emit);
+            // one converged call: emit() ballots the whole wavefront
+            stage.emit(emit, (int32_t)q, minus ? phi : plo, (int32_t)j, (int32_t)(minus ? nextStart - 1 - phi : plo - curStart),
+                       (int32_t)(phi - plo + 1), minus ? (uint8_t)(fl | F_SREV | F_TREV) : fl);
             if (emit) {
-                if (slot < cap) {
-                    const int32_t len = (int32_t)(phi - plo + 1);
-                    if (!minus)
-                        put(out, slot, (int32_t)q, plo, (int32_t)j, (int32_t)(plo - curStart), len, fl);
-                    else
-                        put(out, slot, (int32_t)q, phi, (int32_t)j, (int32_t)(nextStart - 1 - phi), len,
-                            (uint8_t)(fl | F_SREV | F_TREV));
-                } else {
-                    counters[CNT_OVERFLOW] = 1;
-                }
                 ++j;
                 curStart = nextStart;
                 act = j < numSegs && curStart <= ge;
             }
         }
     }
+    stage.flush();
     wave_count_add(&counters[CNT_SRC_PIECES], derefs);
     wave_count_add(kstat, derefs);
 }
@@ -179,6 +263,9 @@ __global__ void __launch_bounds__(256) k_up_top(const TopRec<C> *__restrict__ to
     const uint32_t wavesTotal = (gridDim.x * blockDim.x) >> 6;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     uint32_t derefs = 0;
+    __shared__ StageMem stageMem;
+    Stage stage;
+    stage.init(&stageMem, out, outCount, counters, cap);
     for (uint32_t base = wave * 64; base < n; base += wavesTotal * 64) {
         const uint32_t i = base + lane_id();
         bool emit = false;
@@ -201,14 +288,9 @@ __global__ void __launch_bounds__(256) k_up_top(const TopRec<C> *__restrict__ to
                 idx = enc >> 1;
             }
         }
-        const unsigned long long slot = wave_append(outCount, emit);
-        if (emit) {
-            if (slot < cap)
-                put(out, slot, qid, sPos, idx, so, len, fl);
-            else
-                counters[CNT_OVERFLOW] = 1;
-        }
+        stage.emit(emit, qid, sPos, idx, so, len, fl);
     }
+    stage.flush();
     wave_count_add(&kstat[0], derefs);
 }
 
@@ -228,6 +310,9 @@ __global__ void __launch_bounds__(256) k_parse_up_then_up(const BotRec<C> *__res
     const uint32_t wavesTotal = (gridDim.x * blockDim.x) >> 6;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     uint32_t topDerefs = 0, botDerefs = 0;
+    __shared__ StageMem stageMem;
+    Stage stage;
+    stage.init(&stageMem, out, outCount, counters, cap);
     for (uint32_t base = wave * 64; base < n; base += wavesTotal * 64) {
         const uint32_t i = base + lane_id();
         bool act = i < n;
@@ -292,13 +377,7 @@ __global__ void __launch_bounds__(256) k_parse_up_then_up(const BotRec<C> *__res
                     oIdx = enc >> 1;
                 }
             }
-            const unsigned long long slot = wave_append(outCount, emit);
-            if (emit) {
-                if (slot < cap)
-                    put(out, slot, qid, oSPos, oIdx, oSo, oLen, oFl);
-                else
-                    counters[CNT_OVERFLOW] = 1;
-            }
+            stage.emit(emit, qid, oSPos, oIdx, oSo, oLen, oFl);
             if (act) {
                 ++j;
                 curStart = nextStart;
@@ -308,6 +387,7 @@ __global__ void __launch_bounds__(256) k_parse_up_then_up(const BotRec<C> *__res
             }
         }
     }
+    stage.flush();
     wave_count_add(&kstat[0], topDerefs);
     wave_count_add(&kstat[1], botDerefs);
 }
@@ -327,6 +407,9 @@ __global__ void __launch_bounds__(256) k_down_ring(const int32_t *__restrict__ c
     const uint32_t wavesTotal = (gridDim.x * blockDim.x) >> 6;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     uint32_t topDerefs = 0, botDerefs = 0;
+    __shared__ StageMem stageMem;
+    Stage stage;
+    stage.init(&stageMem, out, outCount, counters, cap);
     for (uint32_t base = wave * 64; base < n; base += wavesTotal * 64) {
         const uint32_t i = base + lane_id();
         bool act = false;
@@ -352,12 +435,8 @@ __global__ void __launch_bounds__(256) k_down_ring(const int32_t *__restrict__ c
         bool haveRec = false;
         int32_t rcPar = -1, rcEnc = 0; // paralogy link and parentEnc of `cur`
         while (__any(act)) {
-            const unsigned long long slot = wave_append(outCount, act);
+            stage.emit(act, qid, sPos, cur, so, len, fl);
             if (act) {
-                if (slot < cap)
-                    put(out, slot, qid, sPos, cur, so, len, fl);
-                else
-                    counters[CNT_OVERFLOW] = 1;
                 if (!doDupes) {
                     act = false;
                 } else {
@@ -384,6 +463,7 @@ __global__ void __launch_bounds__(256) k_down_ring(const int32_t *__restrict__ c
             }
         }
     }
+    stage.flush();
     wave_count_add(&kstat[0], topDerefs);
     wave_count_add(&kstat[1], botDerefs);
 }
@@ -401,6 +481,9 @@ __global__ void __launch_bounds__(256) k_parse_down(const TopRec<C> *__restrict_
     const uint32_t wavesTotal = (gridDim.x * blockDim.x) >> 6;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     uint32_t topDerefs = 0, botDerefs = 0;
+    __shared__ StageMem stageMem;
+    Stage stage;
+    stage.init(&stageMem, out, outCount, counters, cap);
     for (uint32_t base = wave * 64; base < n; base += wavesTotal * 64) {
         const uint32_t i = base + lane_id();
         bool act = i < n;
@@ -453,13 +536,7 @@ __global__ void __launch_bounds__(256) k_parse_down(const TopRec<C> *__restrict_
                 }
                 oSPos = (fl & F_SREV) ? sPos - d : sPos + d;
             }
-            const unsigned long long slot = wave_append(outCount, emit);
-            if (emit) {
-                if (slot < cap)
-                    put(out, slot, qid, oSPos, (int32_t)j, oSo, oLen, fl);
-                else
-                    counters[CNT_OVERFLOW] = 1;
-            }
+            stage.emit(emit, qid, oSPos, (int32_t)j, oSo, oLen, fl);
             if (act) {
                 ++j;
                 curStart = nextStart;
@@ -469,6 +546,7 @@ __global__ void __launch_bounds__(256) k_parse_down(const TopRec<C> *__restrict_
             }
         }
     }
+    stage.flush();
     wave_count_add(&kstat[0], topDerefs);
     wave_count_add(&kstat[1], botDerefs);
 }
