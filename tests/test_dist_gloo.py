@@ -1,0 +1,72 @@
+"""World-size-2 CPU test (gloo) of the multi-GPU host logic: contiguous query sharding and the all-gatherv of
+fixed-width records (counts, then padded payloads) that bench.py and a multi-GPU driver use.  No GPU: the
+per-rank "lift" is replaced by a deterministic stand-in producing a data-dependent number of records."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def shard_bounds(n, world, rank):
+    """Rank r owns [r*n/world, (r+1)*n/world): rank-major concatenation is input order."""
+    return (rank * n) // world, ((rank + 1) * n) // world
+
+
+def all_gather_records(recs, world):
+    """recs: uint8 [n, 40] tensor of hgx_record.  Returns the rank-major concatenation on every rank."""
+    cnt = torch.tensor([recs.shape[0]], dtype=torch.int64, device=recs.device)
+    counts = [torch.zeros(1, dtype=torch.int64, device=recs.device) for _ in range(world)]
+    dist.all_gather(counts, cnt)
+    counts = [int(c.item()) for c in counts]
+    mx = max(counts) if counts else 0
+    mine = torch.zeros((mx, 40), dtype=torch.uint8, device=recs.device)
+    mine[:recs.shape[0]] = recs
+    bufs = [torch.empty((mx, 40), dtype=torch.uint8, device=recs.device) for _ in range(world)]
+    dist.all_gather(bufs, mine)
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0), counts
+
+
+def fake_lift(q_lo, q_hi):
+    """query i yields (i % 4) records whose bytes encode (i, k)."""
+    out = []
+    for i in range(q_lo, q_hi):
+        for k in range(i % 4):
+            r = np.zeros(40, dtype=np.uint8)
+            r[:8] = np.frombuffer(np.int64(i).tobytes(), dtype=np.uint8)
+            r[8] = k
+            out.append(r)
+    return torch.from_numpy(np.stack(out)) if out else torch.zeros((0, 40), dtype=torch.uint8)
+
+
+def _worker(rank, world, port, n, result):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_bounds(n, world, rank)
+    gathered, counts = all_gather_records(fake_lift(lo, hi), world)
+    want = fake_lift(0, n)
+    ok = gathered.shape == want.shape and bool(torch.equal(gathered, want)) and sum(counts) == want.shape[0]
+    result[rank] = ok
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_and_allgatherv_world2():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mgr = mp.Manager()
+    result = mgr.dict()
+    mp.spawn(_worker, args=(2, port, 1001, result), nprocs=2, join=True)
+    assert result[0] and result[1]
+
+
+def test_shard_bounds_cover_everything():
+    for n in (0, 1, 7, 1000, 1000003):
+        for world in (1, 2, 4, 8):
+            b = [shard_bounds(n, world, r) for r in range(world)]
+            assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(world - 1))
