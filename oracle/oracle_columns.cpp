@@ -1,0 +1,515 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see hal_oracle.hpp).
+#include "oracle_columns.hpp"
+#include <chrono>
+
+namespace orc {
+
+static const char dnaUnpackMap[16] = {'a', 'c', 'g', 't', 'n', '\0', '\0', '\0', 'A', 'C', 'G', 'T', 'N', '\0', '\0', '\0'};
+
+// api/inc/halCommon.h:45-75
+static char reverseComplement(char c) {
+    switch (c) {
+    case 'A':
+        return 'T';
+    case 'a':
+        return 't';
+    case 'C':
+        return 'G';
+    case 'c':
+        return 'g';
+    case 'G':
+        return 'C';
+    case 'g':
+        return 'c';
+    case 'T':
+        return 'A';
+    case 't':
+        return 'a';
+    default:
+        break;
+    }
+    return c;
+}
+
+char dnaBase(const Alignment &al, const Dna &d) {
+    const std::vector<u8> &p = al.genomes[(size_t)d.g].dna;
+    u8 b = p[(size_t)(d.pos >> 1)];
+    char c = dnaUnpackMap[(d.pos & 1) ? (b & 0x0F) : (b >> 4)]; // halCommon.h:187-190
+    return d.rev ? reverseComplement(c) : c;
+}
+
+static int seqIndexBySite(const Genome &G, i64 pos) {
+    const Sequence *s = G.seqBySite(pos);
+    return s ? (int)(s - G.seqs.data()) : -1;
+}
+
+// halColumnIterator.cpp:18-57
+ColumnIterator::ColumnIterator(const Alignment *a, int reference, const std::set<int> *tgts, i64 columnIndex, i64 lastColumnIndex,
+                               bool noDupes_, bool noAncestors_, bool onlyOrthologs_)
+    : al(a), refGenome(reference), noDupes(noDupes_), noAncestors(noAncestors_), onlyOrthologs(onlyOrthologs_) {
+    seqIdx = seqIndexBySite(al->genomes[(size_t)reference], columnIndex);
+    if (tgts != nullptr && !tgts->empty()) {
+        targets = *tgts;
+        targets.insert(reference);
+        getGenomesInSpanningTree(*al, targets, scope);
+    }
+    firstIndex = index = columnIndex;
+    lastIndex = lastColumnIndex;
+    prevRefSeq = seqIdx;
+    prevRefIndex = 0;
+    toRight();
+}
+
+// halColumnIterator.cpp:65-144 with a one-entry stack and no visit cache
+void ColumnIterator::toRight() {
+    const Genome &G = al->genomes[(size_t)refGenome];
+    prevRefSeq = seqIdx;
+    prevRefIndex = index - G.seqs[(size_t)seqIdx].start;
+    if (!(index >= firstIndex && index <= lastIndex))
+        return;
+    recursiveUpdate();
+    index++;
+    const Sequence &seq = G.seqs[(size_t)seqIdx];
+    if (index < seq.start || (index >= seq.start + seq.length && index < G.totalLength))
+        seqIdx = seqIndexBySite(G, index);
+}
+
+// halColumnIterator.cpp:193-208
+void ColumnIterator::defragment() {
+    for (auto i = colMap.begin(); i != colMap.end();) {
+        if (i->second.empty())
+            i = colMap.erase(i);
+        else
+            ++i;
+    }
+}
+
+// halColumnIterator.cpp:766-819 (visit cache neither built nor consulted: unique == false, no indels)
+void ColumnIterator::colMapInsert(const SegIt &it) {
+    const int g = it.g;
+    if ((!noAncestors || al->genomes[(size_t)g].children.empty()) && (targets.empty() || targets.count(g))) {
+        const i64 pos = it.getStartPosition();
+        SeqKey k{al, g, seqIndexBySite(al->genomes[(size_t)g], pos)};
+        colMap[k].push_back(Dna{g, pos, it.rev});
+    }
+}
+
+// halColumnIterator.cpp:246-355
+void ColumnIterator::recursiveUpdate() {
+    for (auto &kv : colMap) // resetColMap :821-825 (keys persist)
+        kv.second.clear();
+    const Genome &G = al->genomes[(size_t)refGenome];
+    const Sequence &refSeq = G.seqs[(size_t)seqIdx];
+    SegIt it;
+    it.al = al;
+    it.g = refGenome;
+    if (refSeq.numTop > 0) {
+        it.top = true;
+        it.toSite(index, true);
+        colMapInsert(it);
+        updateParent(it);
+        if (!onlyOrthologs)
+            updateNextTopDup(it);
+        updateParseDown(it);
+    } else {
+        it.top = false;
+        it.toSite(index, true);
+        colMapInsert(it);
+        for (size_t child = 0; child < G.children.size(); ++child)
+            updateChild(it, (i64)child);
+    }
+}
+
+// halColumnIterator.cpp:556-605
+void ColumnIterator::updateParent(const SegIt &top) {
+    const int genome = top.g;
+    if (top.hasParent() && parentInScope(genome) && (!noDupes || top.isCanonicalParalog())) {
+        SegIt parent;
+        parent.toParent(top);
+        colMapInsert(parent);
+        updateParseUp(parent);
+        const Genome &P = al->genomes[(size_t)parent.g];
+        for (size_t i = 0; i < P.children.size(); ++i) {
+            if (P.children[i] != genome)
+                updateChild(parent, (i64)i);
+        }
+    }
+}
+
+// halColumnIterator.cpp:607-640
+void ColumnIterator::updateChild(const SegIt &bot, i64 slot) {
+    if (bot.hasChild(slot) && childInScope(bot.g, slot)) {
+        SegIt child;
+        child.toChild(bot, slot);
+        colMapInsert(child);
+        updateNextTopDup(child);
+        updateParseDown(child);
+    }
+}
+
+// halColumnIterator.cpp:642-681
+void ColumnIterator::updateNextTopDup(const SegIt &top) {
+    const Genome &G = top.G();
+    if (noDupes || G.tParalogy[(size_t)top.idx] == NULL_INDEX || G.parent < 0 || !parentInScope(top.g))
+        return;
+    const i64 firstIndexSeg = top.idx;
+    SegIt cur = top;
+    do {
+        SegIt dup = cur;
+        dup.toNextParalogy();
+        colMapInsert(dup);
+        updateParseDown(dup);
+        cur = dup;
+    } while (G.tParalogy[(size_t)cur.idx] != NULL_INDEX && G.tParalogy[(size_t)cur.idx] != firstIndexSeg);
+}
+
+// halColumnIterator.cpp:683-709
+void ColumnIterator::updateParseUp(const SegIt &bot) {
+    if (bot.G().bTopParse[(size_t)bot.idx] != NULL_INDEX) { // hasParseUp
+        SegIt top;
+        top.toParseUp(bot);
+        updateParent(top);
+        if (!onlyOrthologs)
+            updateNextTopDup(top);
+    }
+}
+
+// halColumnIterator.cpp:711-744
+void ColumnIterator::updateParseDown(const SegIt &top) {
+    if (top.G().tBotParse[(size_t)top.idx] != NULL_INDEX) { // hasParseDown
+        SegIt bot;
+        bot.toParseDown(top);
+        const Genome &G = bot.G();
+        for (size_t i = 0; i < G.children.size(); ++i)
+            updateChild(bot, (i64)i);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// alignmentDepth/halAlignmentDepth.cpp:215-308
+static void printDepthSequence(std::ostream &os, const Alignment &al, int genome, int seqIdx, const std::set<int> &targetSet,
+                               i64 start, i64 length, i64 step, bool countDupes, bool noAncestors) {
+    const Sequence &sequence = al.genomes[(size_t)genome].seqs[(size_t)seqIdx];
+    i64 seqLen = sequence.length;
+    if (seqLen == 0)
+        return;
+    if (length == 0)
+        length = seqLen - start;
+    i64 last = start + length;
+    if (last > seqLen)
+        throw std::runtime_error("Specified range is out of range for sequence " + sequence.name);
+    i64 pos = start;
+    ColumnIterator colIt(&al, genome, &targetSet, pos + sequence.start, last - 1 + sequence.start, false, noAncestors, false);
+    os << "fixedStep chrom=" << sequence.name << " start=" << start + 1 << " step=" << step << "\n";
+    pos += sequence.start;
+    last += sequence.start;
+    std::set<int> genomeSet;
+    while (pos <= last) {
+        genomeSet.clear();
+        i64 count = 0;
+        for (auto &kv : colIt.colMap) {
+            if (countDupes)
+                count += (i64)kv.second.size();
+            else if (!kv.second.empty())
+                genomeSet.insert(kv.first.g);
+        }
+        if (!countDupes)
+            count = (i64)genomeSet.size();
+        --count;
+        os << count << '\n';
+        if (colIt.lastColumn())
+            break;
+        pos += step;
+        if (step == 1) {
+            colIt.toRight();
+            if (pos % 1000 == 0)
+                colIt.defragment();
+        } else {
+            // ColumnIterator::toSite(pos, last) (halColumnIterator.cpp:146-165): restart at a non-contiguous site
+            if (pos > last || pos >= al.genomes[(size_t)genome].totalLength) // past the range: the loop test ends it
+                break;
+            colIt.seqIdx = seqIndexBySite(al.genomes[(size_t)genome], pos);
+            colIt.defragment();
+            colIt.firstIndex = colIt.index = pos;
+            colIt.lastIndex = last;
+            colIt.toRight();
+        }
+    }
+}
+
+// alignmentDepth/halAlignmentDepth.cpp:318-347
+void printDepthGenome(std::ostream &os, const Alignment &al, int genome, int sequence, const std::set<int> &targetSet, i64 start,
+                      i64 length, i64 step, bool countDupes, bool noAncestors) {
+    const Genome &G = al.genomes[(size_t)genome];
+    if (sequence >= 0) {
+        printDepthSequence(os, al, genome, sequence, targetSet, start, length, step, countDupes, noAncestors);
+        return;
+    }
+    if (start + length > G.totalLength)
+        throw std::runtime_error("Specified range is out of range for genome " + G.name);
+    if (length == 0)
+        length = G.totalLength - start;
+    i64 runningLength = 0;
+    for (size_t s = 0; s < G.seqs.size(); ++s) {
+        const Sequence &seq = G.seqs[s];
+        i64 seqLen = seq.length, seqStart = seq.start;
+        if (start + length >= seqStart && start < seqStart + seqLen && runningLength < length) {
+            i64 readStart = seqStart >= start ? 0 : start - seqStart;
+            i64 readLen = std::min(seqLen - readStart, length);
+            readLen = std::min(readLen, length - runningLength);
+            printDepthSequence(os, al, genome, (int)s, targetSet, readStart, readLen, step, countDupes, noAncestors);
+            runningLength += readLen;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// MAF
+MafExport::~MafExport() {
+    for (auto &kv : entries)
+        delete kv.second;
+}
+
+std::string MafExport::getName(const SeqKey &k) const { // halMafBlock.h:128-130
+    const Genome &G = k.al->genomes[(size_t)k.g];
+    return ucscNames ? G.name + "." + k.seq().name : k.seq().name; // Sequence::getFullName = genome.sequence
+}
+
+// halMafBlock.cpp:36-82
+void MafExport::resetEntries() {
+    reference = nullptr;
+    refIndex = NULL_INDEX;
+    for (auto i = entries.begin(); i != entries.end();) {
+        auto next = i;
+        ++next;
+        MafBlockEntry *e = i->second;
+        bool deleted = false;
+        if (e->start == NULL_INDEX) {
+            if (e->lastUsed > 10) {
+                delete e;
+                entries.erase(i);
+                deleted = true;
+            } else {
+                ++e->lastUsed;
+            }
+        } else {
+            e->lastUsed = 0;
+        }
+        if (!deleted) {
+            e->start = NULL_INDEX;
+            e->strand = '+';
+            e->length = 0;
+            e->sequence.clear();
+        }
+        i = next;
+    }
+}
+
+// halMafBlock.cpp:84-112
+void MafExport::initEntry(MafBlockEntry *entry, const SeqKey &k, const Dna *dna, bool clearSequence) {
+    std::string sequenceName = getName(k);
+    if (entry->name != sequenceName || k.g != entry->genome) {
+        entry->name = sequenceName;
+        entry->genome = k.g;
+        entry->srcLength = k.seq().length;
+    }
+    if (dna) {
+        entry->start = dna->pos - k.seq().start;
+        entry->length = 0;
+        entry->strand = dna->rev ? '-' : '+';
+        if (dna->rev)
+            entry->start = entry->srcLength - 1 - entry->start;
+    } else {
+        entry->start = NULL_INDEX;
+        entry->length = 0;
+        entry->strand = '+';
+    }
+    if (clearSequence)
+        entry->sequence.clear();
+}
+
+// halMafBlock.cpp:114-138
+void MafExport::updateEntry(MafBlockEntry *entry, const SeqKey *k, const Dna *dna) {
+    if (dna != nullptr) {
+        if (entry->start == NULL_INDEX)
+            initEntry(entry, *k, dna, false);
+        ++entry->length;
+        entry->sequence.push_back(dnaBase(*alp, *dna));
+    } else {
+        entry->sequence.push_back('-');
+    }
+}
+
+// halMafBlock.cpp:294-367
+void MafExport::initBlock(ColumnIterator &col) {
+    resetEntries();
+    Entries::iterator e = entries.begin();
+    for (auto c = col.colMap.begin(); c != col.colMap.end(); ++c) {
+        const SeqKey &sequence = c->first;
+        if (c->second.empty()) {
+            e = entries.lower_bound(sequence);
+            if (e == entries.end() || e->first != sequence) {
+                MafBlockEntry *entry = new MafBlockEntry;
+                initEntry(entry, sequence, nullptr);
+                e = entries.insert(Entries::value_type(sequence, entry));
+            } else {
+                initEntry(e->second, sequence, nullptr);
+            }
+        } else {
+            for (auto d = c->second.begin(); d != c->second.end(); ++d) {
+                if (e == entries.begin()) {
+                    e = entries.lower_bound(sequence);
+                    if (e == entries.end() || e->first != sequence)
+                        e = entries.end();
+                } else {
+                    // the reference dereferences e before testing for end(); order swapped to stay defined
+                    while (e != entries.end() && e->first != c->first)
+                        ++e;
+                }
+                if (e == entries.end()) {
+                    MafBlockEntry *entry = new MafBlockEntry;
+                    initEntry(entry, sequence, &*d);
+                    e = entries.insert(Entries::value_type(sequence, entry));
+                } else {
+                    initEntry(e->second, sequence, &*d);
+                }
+                ++e;
+            }
+        }
+    }
+    if (reference == nullptr) {
+        const SeqKey referenceSequence = col.refSequenceKey();
+        e = entries.lower_bound(referenceSequence);
+        if (e == entries.end() || e->first != referenceSequence)
+            e = entries.begin();
+        reference = e->second;
+        if (e->first == referenceSequence)
+            refIndex = col.refSequencePosition();
+    }
+}
+
+// halMafBlock.cpp:370-395
+void MafExport::appendColumn(ColumnIterator &col) {
+    Entries::iterator e = entries.begin();
+    for (auto c = col.colMap.begin(); c != col.colMap.end(); ++c) {
+        const SeqKey &sequence = c->first;
+        for (auto d = c->second.begin(); d != c->second.end(); ++d) {
+            while (e != entries.end() && e->first != sequence) {
+                updateEntry(e->second, nullptr, nullptr);
+                ++e;
+            }
+            updateEntry(e->second, &sequence, &*d);
+            ++e;
+        }
+    }
+    for (; e != entries.end(); ++e)
+        updateEntry(e->second, nullptr, nullptr);
+}
+
+// halMafBlock.cpp:401-452
+bool MafExport::canAppendColumn(ColumnIterator &col) {
+    Entries::iterator e = entries.begin();
+    for (auto c = col.colMap.begin(); c != col.colMap.end(); ++c) {
+        const SeqKey &sequence = c->first;
+        i64 sequenceStart = sequence.seq().start;
+        for (auto d = c->second.begin(); d != c->second.end(); ++d) {
+            while (e != entries.end() && e->first != sequence)
+                ++e;
+            if (e == entries.end())
+                return false;
+            MafBlockEntry *entry = e->second;
+            if (entry->start != NULL_INDEX) {
+                if (entry->length >= maxBlockLength || (entry->length > 0 && (entry->strand == '-') != d->rev))
+                    return false;
+                i64 pos = d->pos - sequenceStart;
+                if (d->rev)
+                    pos = entry->srcLength - 1 - pos;
+                if (pos - entry->start != entry->length)
+                    return false;
+            }
+            ++e;
+        }
+    }
+    return true;
+}
+
+bool MafExport::referenceIsAllGaps() const { // halMafBlock.h:95-102,136-138
+    if (reference == nullptr)
+        return false;
+    for (char c : reference->sequence)
+        if (c != '-')
+            return false;
+    return true;
+}
+
+static void printEntry(std::ostream &os, const MafBlockEntry &e) { // halMafBlock.cpp:454-458
+    os << "s\t" << e.name << '\t' << e.start << '\t' << e.length << '\t' << e.strand << '\t' << e.srcLength << '\t' << e.sequence << '\n';
+}
+
+// halMafBlock.cpp:499-519
+void MafExport::printBlock(std::ostream &os) const {
+    os << "a\n";
+    if (reference->start == NULL_INDEX) {
+        if (refIndex != NULL_INDEX) {
+            reference->start = refIndex;
+            printEntry(os, *reference);
+            reference->start = NULL_INDEX;
+        }
+    } else {
+        printEntry(os, *reference);
+    }
+    for (auto e = entries.begin(); e != entries.end(); ++e)
+        if (e->second->start != NULL_INDEX && e->second != reference)
+            printEntry(os, *e->second);
+}
+
+// halMafExport.cpp:15-88
+void MafExport::convertSequence(std::ostream &os, const Alignment &al, int genome, int seqIdx, i64 startPosition, i64 length,
+                                const std::set<int> &targets) {
+    alp = &al;
+    const Sequence &seq = al.genomes[(size_t)genome].seqs[(size_t)seqIdx];
+    if (startPosition >= seq.length || startPosition + length > seq.length)
+        throw std::runtime_error("Invalid range specified for convertGenome");
+    if (length == 0)
+        length = seq.length - startPosition;
+    if (length == 0)
+        throw std::runtime_error("Cannot convert zero length sequence");
+    i64 lastPosition = startPosition + (length - 1);
+    if (!append && !headerWritten) { // writeHeader: only when nothing has been written to the stream yet (:15-23)
+        os << "##maf version=1 scoring=N/A\n"
+           << "# hal " << al.newick << std::endl
+           << std::endl;
+        headerWritten = true;
+    }
+    auto t0 = std::chrono::steady_clock::now();
+    // Sequence::getColumnIterator (api/mmap_impl/mmapSequence.cpp:41-52): sequence-relative -> genome coordinates
+    ColumnIterator colIt(&al, genome, &targets, startPosition + seq.start, lastPosition + seq.start, noDupes, noAncestors, onlyOrthologs);
+    size_t appendCount = 0;
+    initBlock(colIt);
+    appendColumn(colIt);
+    ++appendCount;
+    ++numColumns;
+    size_t numBlocks = 0;
+    while (!colIt.lastColumn()) {
+        colIt.toRight();
+        ++numColumns;
+        if (!canAppendColumn(colIt)) {
+            if (numBlocks++ % 1000 == 0)
+                colIt.defragment();
+            if (appendCount > 0 && (keepEmptyRefBlocks || !referenceIsAllGaps())) {
+                printBlock(os);
+                os << '\n';
+            }
+            initBlock(colIt);
+        }
+        appendColumn(colIt);
+        ++appendCount;
+    }
+    if (appendCount > 0 && (keepEmptyRefBlocks || !referenceIsAllGaps())) {
+        printBlock(os);
+        os << std::endl;
+    }
+    seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+} // namespace orc

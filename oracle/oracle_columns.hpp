@@ -1,0 +1,130 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see hal_oracle.hpp).
+// Restatement of the column engine: api/impl/halColumnIterator.cpp (maxInsertLength == 0, unique == false:
+// the configuration of hal2maf's and halAlignmentDepth's defaults, where columns are independent,
+// halColumnIterator.cpp:785-787), maf/impl/halMafBlock.cpp, maf/impl/halMafExport.cpp and
+// alignmentDepth/halAlignmentDepth.cpp:215-347.
+#pragma once
+#include "oracle_mapper.hpp"
+#include <map>
+#include <ostream>
+
+namespace orc {
+
+// DnaIterator state (api/inc/halDnaIterator.h): genome position + strand
+struct Dna {
+    int g;
+    i64 pos;
+    bool rev;
+};
+
+// api/inc/halColumnIterator.h:45-50
+struct SeqKey {
+    const Alignment *al;
+    int g, s;
+    bool operator<(const SeqKey &o) const {
+        int diff = al->genomes[(size_t)g].name.compare(al->genomes[(size_t)o.g].name);
+        return diff < 0 || (diff == 0 && s < o.s);
+    }
+    bool operator==(const SeqKey &o) const {
+        return g == o.g && s == o.s;
+    }
+    bool operator!=(const SeqKey &o) const {
+        return !(*this == o);
+    }
+    const Sequence &seq() const {
+        return al->genomes[(size_t)g].seqs[(size_t)s];
+    }
+};
+
+struct ColumnIterator {
+    typedef std::vector<Dna> DNASet;
+    typedef std::map<SeqKey, DNASet> ColumnMap;
+
+    const Alignment *al;
+    int refGenome;
+    bool noDupes, noAncestors, onlyOrthologs;
+    std::set<int> targets, scope;
+    // the single stack entry of the maxInsertLength == 0 case (halColumnIteratorStack.h:47-107)
+    int seqIdx;
+    i64 firstIndex, index, lastIndex;
+    ColumnMap colMap;
+    int prevRefSeq;
+    i64 prevRefIndex;
+
+    ColumnIterator(const Alignment *a, int reference, const std::set<int> *tgts, i64 columnIndex, i64 lastColumnIndex, bool noDupes_,
+                   bool noAncestors_, bool onlyOrthologs_);
+    void toRight();
+    bool lastColumn() const {
+        return index > lastIndex;
+    }
+    void defragment();
+    SeqKey refSequenceKey() const {
+        return SeqKey{al, refGenome, prevRefSeq};
+    }
+    i64 refSequencePosition() const {
+        return prevRefIndex;
+    }
+
+  private:
+    bool parentInScope(int g) const {
+        return scope.empty() || scope.count(al->genomes[(size_t)g].parent);
+    }
+    bool childInScope(int g, i64 slot) const {
+        return scope.empty() || scope.count(al->genomes[(size_t)g].children[(size_t)slot]);
+    }
+    void recursiveUpdate();
+    void colMapInsert(const SegIt &it);
+    void updateParent(const SegIt &top);
+    void updateChild(const SegIt &bot, i64 slot);
+    void updateNextTopDup(const SegIt &top);
+    void updateParseUp(const SegIt &bot);
+    void updateParseDown(const SegIt &top);
+};
+
+char dnaBase(const Alignment &al, const Dna &d); // DnaIterator::getBase, halDnaIterator.h:131-138
+
+// alignmentDepth/halAlignmentDepth.cpp:318-347 printGenome / :215-308 printSequence
+void printDepthGenome(std::ostream &os, const Alignment &al, int genome, int sequence /* -1 = all */, const std::set<int> &targetSet,
+                      i64 start, i64 length, i64 step, bool countDupes, bool noAncestors);
+
+// maf/impl/halMafBlock.cpp + halMafExport.cpp
+struct MafBlockEntry {
+    int genome = -1;
+    std::string name;
+    i64 start = NULL_INDEX, length = 0, srcLength = 0;
+    char strand = '+';
+    std::string sequence;
+    short lastUsed = 0;
+};
+
+struct MafExport {
+    bool noDupes = false, noAncestors = false, ucscNames = true /* Genome.Sequence */, onlyOrthologs = false, keepEmptyRefBlocks = false,
+         append = false;
+    i64 maxBlockLength = 1000; // MafBlock::defaultMaxLength, halMafBlock.cpp:16
+    void convertSequence(std::ostream &os, const Alignment &al, int genome, int seq, i64 startPosition, i64 length,
+                         const std::set<int> &targets);
+    size_t numColumns = 0;
+    double seconds = 0;
+
+  private:
+    typedef std::multimap<SeqKey, MafBlockEntry *> Entries;
+    Entries entries;
+    MafBlockEntry *reference = nullptr;
+    i64 refIndex = NULL_INDEX;
+    bool headerWritten = false;
+    const Alignment *alp = nullptr;
+    std::string getName(const SeqKey &k) const;
+    void resetEntries();
+    void initEntry(MafBlockEntry *e, const SeqKey &k, const Dna *dna, bool clearSequence = true);
+    void updateEntry(MafBlockEntry *e, const SeqKey *k, const Dna *dna);
+    void initBlock(ColumnIterator &col);
+    void appendColumn(ColumnIterator &col);
+    bool canAppendColumn(ColumnIterator &col);
+    void printBlock(std::ostream &os) const;
+    bool referenceIsAllGaps() const;
+
+  public:
+    ~MafExport();
+};
+
+} // namespace orc

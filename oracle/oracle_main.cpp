@@ -1,9 +1,12 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY (see hal_oracle.hpp).  Command-line front end used by tests/ and by
 // bench.py's cpu_baseline leg.
 //   hal_oracle liftover <img.hgx> <srcGenome> <in.bed> <tgtGenome> <out.bed> [--noDupes] [--bedType N] [--stats]
+#include "oracle_columns.hpp"
 #include "oracle_liftover.hpp"
+#include <chrono>
 #include <fstream>
 #include <iostream>
+#include <limits>
 #include <sstream>
 
 using namespace orc;
@@ -47,10 +50,139 @@ static int cmdLiftover(int argc, char **argv) {
     return 0;
 }
 
+static std::vector<std::string> splitCommas(const std::string &s) {
+    std::vector<std::string> out;
+    size_t a = 0, b;
+    while ((b = s.find(',', a)) != std::string::npos) {
+        out.push_back(s.substr(a, b - a));
+        a = b + 1;
+    }
+    if (a < s.size())
+        out.push_back(s.substr(a));
+    return out;
+}
+
+// halAlignmentDepth (alignmentDepth/halAlignmentDepth.cpp:52-213) and hal2maf (maf/impl/hal2maf.cpp:18-217) front ends
+static int cmdColumns(bool maf, int argc, char **argv) {
+    std::vector<std::string> pos;
+    std::string refGenome, refSequence, targetGenomes, rootGenome;
+    i64 start = 0, length = 0, step = 1, maxBlockLen = 1000;
+    bool countDupes = false, noAncestors = false, noDupes = false, onlySequenceNames = false, onlyOrthologs = false, stats = false;
+    for (int i = 0; i < argc; ++i) {
+        std::string a = argv[i];
+        if (a == "--refGenome")
+            refGenome = argv[++i];
+        else if (a == "--refSequence")
+            refSequence = argv[++i];
+        else if (a == "--targetGenomes")
+            targetGenomes = argv[++i];
+        else if (a == "--rootGenome")
+            rootGenome = argv[++i];
+        else if (a == "--start")
+            start = atoll(argv[++i]);
+        else if (a == "--length")
+            length = atoll(argv[++i]);
+        else if (a == "--step")
+            step = atoll(argv[++i]);
+        else if (a == "--maxBlockLen")
+            maxBlockLen = atoll(argv[++i]);
+        else if (a == "--countDupes")
+            countDupes = true;
+        else if (a == "--noAncestors")
+            noAncestors = true;
+        else if (a == "--noDupes")
+            noDupes = true;
+        else if (a == "--onlySequenceNames")
+            onlySequenceNames = true;
+        else if (a == "--onlyOrthologs")
+            onlyOrthologs = true;
+        else if (a == "--stats")
+            stats = true;
+        else
+            pos.push_back(a);
+    }
+    // depth: <img> <refGenome> <out.wig>;  maf: <img> <out.maf>
+    if ((maf && pos.size() != 2) || (!maf && pos.size() != 3)) {
+        std::cerr << "usage: hal_oracle depth <img> <refGenome> <out.wig> [opts] | hal_oracle maf <img> <out.maf> [opts]" << std::endl;
+        return 1;
+    }
+    Alignment al = loadImage(pos[0]);
+    if (!maf)
+        refGenome = pos[1];
+    int ref = refGenome.empty() ? al.root() : al.genomeByName(refGenome);
+    if (ref < 0)
+        throw std::runtime_error("Reference genome, " + refGenome + ", not found in alignment");
+    std::set<int> targetSet;
+    if (!rootGenome.empty()) {
+        int rg = al.genomeByName(rootGenome);
+        if (rg < 0)
+            throw std::runtime_error("Root genome " + rootGenome + ", not found in alignment");
+        if (rg != al.root()) { // getGenomesInSubTree, api/impl/halCommon.cpp:189-195
+            std::vector<int> st(1, rg);
+            while (!st.empty()) {
+                int g = st.back();
+                st.pop_back();
+                targetSet.insert(g);
+                for (int c : al.genomes[(size_t)g].children)
+                    st.push_back(c);
+            }
+        }
+    }
+    for (const std::string &n : splitCommas(targetGenomes)) {
+        int g = al.genomeByName(n);
+        if (g < 0)
+            throw std::runtime_error("Target genome, " + n + ", not found in alignment");
+        targetSet.insert(g);
+    }
+    int seq = -1;
+    if (!refSequence.empty()) {
+        const Sequence *s = al.genomes[(size_t)ref].seqByName(refSequence);
+        if (!s)
+            throw std::runtime_error("Reference sequence, " + refSequence + ", not found in reference genome");
+        seq = (int)(s - al.genomes[(size_t)ref].seqs.data());
+    }
+    if (noAncestors && !al.genomes[(size_t)ref].children.empty())
+        throw std::runtime_error("--noAncestors cannot be used when the reference genome is ancestral");
+    std::ofstream out(maf ? pos[1] : pos[2]);
+    std::ostringstream buf;
+    double seconds = 0;
+    size_t columns = 0;
+    if (!maf) {
+        auto t0 = std::chrono::steady_clock::now();
+        printDepthGenome(buf, al, ref, seq, targetSet, start, length, step, countDupes, noAncestors);
+        seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        for (char c : buf.str())
+            columns += c == '\n';
+    } else {
+        MafExport me;
+        me.noDupes = noDupes;
+        me.noAncestors = noAncestors;
+        me.ucscNames = !onlySequenceNames;
+        me.onlyOrthologs = onlyOrthologs;
+        me.maxBlockLength = maxBlockLen <= 0 ? std::numeric_limits<i64>::max() : maxBlockLen;
+        if (seq >= 0) {
+            me.convertSequence(buf, al, ref, seq, start, length, targetSet);
+        } else {
+            for (size_t s = 0; s < al.genomes[(size_t)ref].seqs.size(); ++s)
+                me.convertSequence(buf, al, ref, (int)s, start, length, targetSet);
+        }
+        seconds = me.seconds;
+        columns = me.numColumns;
+    }
+    out << buf.str();
+    if (stats)
+        std::cout << "{\"columns\": " << columns << ", \"seconds\": " << seconds << "}" << std::endl;
+    return 0;
+}
+
 int main(int argc, char **argv) {
     try {
         if (argc >= 2 && std::string(argv[1]) == "liftover")
             return cmdLiftover(argc - 2, argv + 2);
+        if (argc >= 2 && std::string(argv[1]) == "depth")
+            return cmdColumns(false, argc - 2, argv + 2);
+        if (argc >= 2 && std::string(argv[1]) == "maf")
+            return cmdColumns(true, argc - 2, argv + 2);
         std::cerr << "usage: hal_oracle liftover ..." << std::endl;
         return 1;
     } catch (std::exception &e) {

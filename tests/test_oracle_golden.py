@@ -66,3 +66,23 @@ def test_oracle_asan_clean(tmp_path):
     asan = os.path.join(root, "oracle", "_build", "hal_oracle_asan")
     for src, tgt, bed, want in hb.CASES:
         assert oracle_liftover(asan, img, src, tgt, bed, tmp_path) == want
+
+
+def _oracle_maf(oracle_bin, img, tmp_path, *args):
+    out = str(tmp_path / "o.maf")
+    subprocess.check_call([oracle_bin, "maf", img, out] + list(args))
+    return open(out).read()
+
+
+def test_reference_cli_golden_hal2maf_small(hal, oracle_bin, tmp_path):
+    # maf/Makefile:40-42 hal2mafSmallMMapTest: root reference, every column, DNA text, paralogous rows
+    _, img = _small_seed0(hal, tmp_path)
+    assert _oracle_maf(oracle_bin, img, tmp_path) == open(os.path.join(GOLD, "ref_maf", "hal2mafSmallTest.maf")).read()
+
+
+def test_reference_cli_golden_hal2maf_seq_part(hal, oracle_bin, tmp_path):
+    # maf/Makefile:52-54 hal2mafSeqPartTest: leaf reference, --start 1000 --length 2000
+    _, img = _small_seed0(hal, tmp_path)
+    got = _oracle_maf(oracle_bin, img, tmp_path, "--refGenome", "Genome_2", "--refSequence", "Genome_2_seq", "--start", "1000",
+                      "--length", "2000")
+    assert got == open(os.path.join(GOLD, "ref_maf", "hal2mafSeqPartTest.maf")).read()
