@@ -28,6 +28,21 @@ class hgx_liftover_stats(C.Structure):
                 ("deferred_queries", C.c_uint64), ("walk_ms", C.c_double), ("total_ms", C.c_double)]
 
 
+class hgx_column_opts(C.Structure):
+    _fields_ = [("no_dupes", C.c_int32), ("no_ancestors", C.c_int32), ("only_orthologs", C.c_int32), ("n_targets", C.c_int32),
+                ("targets", C.POINTER(C.c_int32))]
+
+
+class hgx_column_row(C.Structure):
+    _fields_ = [("pos", C.c_int64), ("genome", C.c_int32), ("reversed", C.c_uint8), ("base", C.c_char), ("_pad", C.c_uint8 * 2)]
+
+
+class hgx_maf_opts(C.Structure):
+    _fields_ = [("no_dupes", C.c_int32), ("no_ancestors", C.c_int32), ("only_sequence_names", C.c_int32),
+                ("only_orthologs", C.c_int32), ("keep_empty_ref_blocks", C.c_int32), ("_pad", C.c_int32),
+                ("max_block_len", C.c_int64)]
+
+
 class hgx_rand_opts(C.Structure):
     _fields_ = [("mean_degree", C.c_double), ("max_branch_length", C.c_double), ("min_genomes", C.c_uint64),
                 ("max_genomes", C.c_uint64), ("min_segment_length", C.c_uint64), ("max_segment_length", C.c_uint64),
@@ -71,6 +86,15 @@ SYMBOLS = {
     "hgx_liftover_kernel_times": (C.c_int, [VP, P(VP)]),
     "hgx_liftover_convert": (C.c_int, [VP, C.c_int, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_int, P(VP), P(C.c_size_t), P(VP)]),
+    "hgx_columns_depth": (C.c_int, [VP, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int, P(hgx_column_opts), P(C.c_int32), P(VP)]),
+    "hgx_columns_depth_device": (C.c_int, [VP, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int, P(hgx_column_opts), VP, VP,
+                                           P(C.c_double), P(VP)]),
+    "hgx_column_rows": (C.c_int, [VP, C.c_int, C.c_int64, C.c_int64, P(hgx_column_opts), P(P(C.c_uint64)), P(P(hgx_column_row)),
+                                  P(C.c_size_t), P(VP)]),
+    "hgx_alignment_depth": (C.c_int, [VP, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, P(C.c_int32), C.c_int32,
+                                      P(VP), P(C.c_size_t), P(VP)]),
+    "hgx_maf_export": (C.c_int, [VP, C.c_int, C.c_int, C.c_int64, C.c_int64, P(hgx_maf_opts), P(C.c_int32), C.c_int32, P(VP),
+                                 P(C.c_size_t), P(VP)]),
     "hgx_rand_preset": (C.c_int, [C.c_char_p, P(hgx_rand_opts)]),
     "hgx_create_random": (C.c_int, [P(hgx_rand_opts), C.c_int, P(VP), P(VP)]),
     "hgx_save_image": (C.c_int, [VP, C.c_char_p, P(VP)]),

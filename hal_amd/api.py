@@ -6,7 +6,8 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _lib
-from ._lib import lib, HgxError, hgx_interval, hgx_record, hgx_liftover_opts, hgx_liftover_stats, hgx_rand_opts, take_error
+from ._lib import (lib, HgxError, hgx_interval, hgx_record, hgx_liftover_opts, hgx_liftover_stats, hgx_rand_opts, hgx_column_opts,
+                   hgx_column_row, hgx_maf_opts, take_error)
 
 RECORD_DTYPE = np.dtype([("query", "<i8"), ("tgt_start", "<i8"), ("tgt_end", "<i8"), ("src_start", "<i8"),
                          ("tgt_seq", "<i4"), ("strand", "S1"), ("_pad", "S3")])
@@ -174,6 +175,79 @@ class Alignment:
         finally:
             lib.hgx_free(out)
         return res
+
+
+    # --- column engine (ColumnIterator defaults: halAlignmentDepth, hal2maf) ---
+    @staticmethod
+    def _column_opts(no_dupes=False, no_ancestors=False, only_orthologs=False, targets=None):
+        o = hgx_column_opts(1 if no_dupes else 0, 1 if no_ancestors else 0, 1 if only_orthologs else 0, 0, None)
+        keep = None
+        if targets:
+            keep = (C.c_int32 * len(targets))(*targets)
+            o.n_targets = len(targets)
+            o.targets = C.cast(keep, C.POINTER(C.c_int32))
+        return o, keep
+
+    def columns_depth(self, ref, first, count, step=1, count_dupes=False, **kw):
+        """Per-column halAlignmentDepth value for columns first, first+step, ... (genome coordinates)."""
+        o, keep = self._column_opts(**kw)
+        out = np.empty(count, dtype=np.int32)
+        err = C.c_void_p()
+        if lib.hgx_columns_depth(self._h, ref, first, count, step, 1 if count_dupes else 0, C.byref(o),
+                                 out.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(err)) != 0:
+            raise HgxError(take_error(err))
+        return out
+
+    def columns_depth_device(self, ref, first, count, d_out_ptr, step=1, count_dupes=False, stream=0, **kw):
+        """Result left in HBM at d_out_ptr (int32[count]); returns the kernel's device time in ms."""
+        o, keep = self._column_opts(**kw)
+        ms, err = C.c_double(), C.c_void_p()
+        if lib.hgx_columns_depth_device(self._h, ref, first, count, step, 1 if count_dupes else 0, C.byref(o), d_out_ptr, stream,
+                                        C.byref(ms), C.byref(err)) != 0:
+            raise HgxError(take_error(err))
+        return ms.value
+
+    def column_rows(self, ref, first, count, **kw):
+        """(row_offset[count+1], rows) in ColumnMap insertion order."""
+        o, keep = self._column_opts(**kw)
+        off, rows, n, err = C.POINTER(C.c_uint64)(), C.POINTER(hgx_column_row)(), C.c_size_t(), C.c_void_p()
+        if lib.hgx_column_rows(self._h, ref, first, count, C.byref(o), C.byref(off), C.byref(rows), C.byref(n), C.byref(err)) != 0:
+            raise HgxError(take_error(err))
+        try:
+            offsets = np.frombuffer(C.string_at(off, (count + 1) * 8), dtype="<u8").copy()
+            dt = np.dtype([("pos", "<i8"), ("genome", "<i4"), ("reversed", "u1"), ("base", "S1"), ("_pad", "S2")])
+            r = np.frombuffer(C.string_at(rows, n.value * 16), dtype=dt).copy() if n.value else np.zeros(0, dt)
+        finally:
+            lib.hgx_free(off)
+            lib.hgx_free(rows)
+        return offsets, r
+
+    def alignment_depth(self, ref, ref_sequence=-1, start=0, length=0, step=1, count_dupes=False, no_ancestors=False, targets=None):
+        """halAlignmentDepth's wig text (alignmentDepth/halAlignmentDepth.cpp:318-347)."""
+        tg = (C.c_int32 * len(targets))(*targets) if targets else None
+        out, n, err = C.c_void_p(), C.c_size_t(), C.c_void_p()
+        if lib.hgx_alignment_depth(self._h, ref, ref_sequence, start, length, step, 1 if count_dupes else 0, 1 if no_ancestors else 0,
+                                   tg, len(targets) if targets else 0, C.byref(out), C.byref(n), C.byref(err)) != 0:
+            raise HgxError(take_error(err))
+        try:
+            return C.string_at(out, n.value).decode()
+        finally:
+            lib.hgx_free(out)
+
+    def maf_export(self, ref, ref_sequence=-1, start=0, length=0, no_dupes=False, no_ancestors=False, only_sequence_names=False,
+                   only_orthologs=False, keep_empty_ref_blocks=False, max_block_len=1000, targets=None):
+        """hal2maf's MAF text (maf/impl/halMafExport.cpp:25-88, maf/impl/hal2maf.cpp:196-206)."""
+        o = hgx_maf_opts(1 if no_dupes else 0, 1 if no_ancestors else 0, 1 if only_sequence_names else 0,
+                         1 if only_orthologs else 0, 1 if keep_empty_ref_blocks else 0, 0, max_block_len)
+        tg = (C.c_int32 * len(targets))(*targets) if targets else None
+        out, n, err = C.c_void_p(), C.c_size_t(), C.c_void_p()
+        if lib.hgx_maf_export(self._h, ref, ref_sequence, start, length, C.byref(o), tg, len(targets) if targets else 0,
+                              C.byref(out), C.byref(n), C.byref(err)) != 0:
+            raise HgxError(take_error(err))
+        try:
+            return C.string_at(out, n.value).decode()
+        finally:
+            lib.hgx_free(out)
 
 
 def liftover_convert(alignment, src_genome, bed_text, tgt_genome, bed_type=0, traverse_dupes=True, out_psl=False,

@@ -1,5 +1,6 @@
 // extern "C" boundary of libhgx (include/hgx.h).  No exception crosses it.
 #include "../../include/hgx.h"
+#include "hgx_columns_host.hpp"
 #include "hgx_liftover_host.hpp"
 #include <cstdlib>
 #include <cstring>
@@ -336,6 +337,123 @@ int hgx_liftover_convert(hgx_alignment *h, int src, const char *bed_text, size_t
         }
     }
     return rc;
+}
+
+static ColumnOptions columnOptions(const hgx_column_opts *o) {
+    ColumnOptions c;
+    if (o) {
+        c.noDupes = o->no_dupes != 0;
+        c.noAncestors = o->no_ancestors != 0;
+        c.onlyOrthologs = o->only_orthologs != 0;
+        if (o->n_targets > 0 && o->targets)
+            c.targets.assign(o->targets, o->targets + o->n_targets);
+    }
+    return c;
+}
+
+int hgx_columns_depth(hgx_alignment *h, int ref, int64_t first, int64_t count, int64_t step, int count_dupes,
+                      const hgx_column_opts *opts, int32_t *out, char **err) {
+    HGX_TRY
+    if (!h || (count > 0 && !out))
+        throw std::runtime_error("hgx_columns_depth: null argument");
+    columnsDepthHost(h, ref, first, count, step, count_dupes ? 1 : 0, columnOptions(opts), out, nullptr);
+    return HGX_OK;
+    HGX_CATCH
+}
+
+int hgx_columns_depth_device(hgx_alignment *h, int ref, int64_t first, int64_t count, int64_t step, int count_dupes,
+                             const hgx_column_opts *opts, int32_t *d_out, void *hip_stream, double *kernel_ms, char **err) {
+    HGX_TRY
+    if (!h || (count > 0 && !d_out))
+        throw std::runtime_error("hgx_columns_depth_device: null argument");
+    if (!h->dev)
+        throw std::runtime_error("alignment was opened without a device (device = -1); the column engine needs the HIP path");
+    ColumnStats st;
+    columnsDepthDevice(h, ref, first, count, step, count_dupes ? 1 : 0, columnOptions(opts), d_out, hip_stream, &st);
+    if (kernel_ms)
+        *kernel_ms = st.depth_ms;
+    return HGX_OK;
+    HGX_CATCH
+}
+
+int hgx_column_rows(hgx_alignment *h, int ref, int64_t first, int64_t count, const hgx_column_opts *opts, uint64_t **row_offset,
+                    hgx_column_row **rows, size_t *n_rows, char **err) {
+    HGX_TRY
+    static_assert(sizeof(hgx_column_row) == sizeof(ColumnRowHost), "row layouts must match");
+    if (!h || !row_offset || !rows || !n_rows)
+        throw std::runtime_error("hgx_column_rows: null argument");
+    std::vector<uint64_t> off;
+    std::vector<ColumnRowHost> r;
+    columnsRowsHost(h, ref, first, count, columnOptions(opts), !h->img.genomes[(size_t)ref].dna.empty(), off, r, nullptr);
+    *row_offset = (uint64_t *)malloc(off.size() * 8);
+    *rows = (hgx_column_row *)malloc(std::max<size_t>(1, r.size()) * sizeof(hgx_column_row));
+    if (!*row_offset || !*rows)
+        throw std::runtime_error("out of memory");
+    memcpy(*row_offset, off.data(), off.size() * 8);
+    if (!r.empty())
+        memcpy(*rows, r.data(), r.size() * sizeof(hgx_column_row));
+    *n_rows = r.size();
+    return HGX_OK;
+    HGX_CATCH
+}
+
+static int textOut(const std::string &s, char **out_text, size_t *out_len) {
+    *out_text = (char *)malloc(s.size() + 1);
+    if (!*out_text)
+        return HGX_ERR;
+    memcpy(*out_text, s.c_str(), s.size() + 1);
+    *out_len = s.size();
+    return HGX_OK;
+}
+
+int hgx_alignment_depth(hgx_alignment *h, int ref, int ref_sequence, int64_t start, int64_t length, int64_t step, int count_dupes,
+                        int no_ancestors, const int32_t *targets, int32_t n_targets, char **out_text, size_t *out_len, char **err) {
+    HGX_TRY
+    if (!h || !out_text || !out_len)
+        throw std::runtime_error("hgx_alignment_depth: null argument");
+    const GenomeTables *G = genomeOf(h, ref);
+    if (!G || ref_sequence >= (int)G->seqs.size())
+        throw std::runtime_error("hgx_alignment_depth: genome or sequence out of range");
+    if (!G->children.empty() && no_ancestors) // halAlignmentDepth.cpp:182-187
+        throw std::runtime_error("--noAncestors cannot be used when reference genome (" + G->name + ") is ancetral");
+    std::set<int> tset(targets, targets + (targets ? n_targets : 0));
+    std::ostringstream os;
+    alignmentDepth(os, h, ref, ref_sequence, tset, start, length, step, count_dupes != 0, no_ancestors != 0);
+    return textOut(os.str(), out_text, out_len);
+    HGX_CATCH
+}
+
+int hgx_maf_export(hgx_alignment *h, int ref, int ref_sequence, int64_t start, int64_t length, const hgx_maf_opts *o,
+                   const int32_t *targets, int32_t n_targets, char **out_text, size_t *out_len, char **err) {
+    HGX_TRY
+    if (!h || !out_text || !out_len)
+        throw std::runtime_error("hgx_maf_export: null argument");
+    const GenomeTables *G = genomeOf(h, ref);
+    if (!G || ref_sequence >= (int)G->seqs.size())
+        throw std::runtime_error("hgx_maf_export: genome or sequence out of range");
+    MafExport me;
+    if (o) {
+        me.setNoDupes(o->no_dupes != 0);
+        me.setNoAncestors(o->no_ancestors != 0);
+        me.setUcscNames(o->only_sequence_names == 0);
+        me.setOnlyOrthologs(o->only_orthologs != 0);
+        me.setKeepEmptyRefBlocks(o->keep_empty_ref_blocks != 0);
+        me.setMaxBlockLength(o->max_block_len == 0 ? 1000 : o->max_block_len);
+        if (o->no_ancestors && !G->children.empty()) // hal2maf.cpp:153-159
+            throw std::runtime_error("Since the reference genome to be used for the MAF is ancestral (" + G->name +
+                                     "), the --noAncestors option is invalid.  The --refGenome option can be used to specify a "
+                                     "different reference.");
+    }
+    std::set<int> tset(targets, targets + (targets ? n_targets : 0));
+    std::ostringstream os;
+    if (ref_sequence >= 0) {
+        me.convertSequence(os, h, ref, ref_sequence, start, length, tset);
+    } else {
+        for (size_t s = 0; s < G->seqs.size(); ++s)
+            me.convertSequence(os, h, ref, (int)s, start, length, tset);
+    }
+    return textOut(os.str(), out_text, out_len);
+    HGX_CATCH
 }
 
 int hgx_rand_preset(const char *preset, hgx_rand_opts *o) {

@@ -1,0 +1,291 @@
+// Column engine kernels (gfx950): the per-base closure of the reference's ColumnIterator
+// (api/impl/halColumnIterator.cpp, maxInsertLength == 0 and unique == false, where columns are independent,
+// :785-787).  The reference redoes a recursive walk with heap-allocated linked iterators for every base; here
+// one lane owns one reference base and runs the same depth-first walk with an explicit frame stack.  The 64
+// lanes of a wavefront hold 64 consecutive bases, which sit in the same segments almost everywhere, so their
+// table reads collapse into broadcast loads and the lanes stay converged; they diverge only at segment
+// boundaries.  The walk order is the reference's (updateParent, then paralogs, then the parse-down subtree;
+// :246-355, :556-744) so that rows come out in ColumnMap insertion order for the MAF writer.
+#pragma once
+#include "hgx_device.hpp"
+#include <hip/hip_runtime.h>
+
+namespace hgx {
+
+struct ColumnParams {
+    const GenomeDesc *desc;
+    int32_t numGenomes;
+    int32_t ref;
+    int64_t first; // genome coordinate of the first column
+    int64_t count; // number of columns
+    int64_t step;  // distance between consecutive columns (halAlignmentDepth --step)
+    int32_t noDupes, noAncestors, onlyOrthologs;
+    unsigned long long scopeMask[4];  // genomes the walk may enter (all ones when no targets)
+    unsigned long long targetMask[4]; // genomes whose bases are reported
+    unsigned int *error;              // set to 1 on frame-stack overflow
+};
+
+static constexpr int COL_STACK = 64;
+
+enum : uint32_t { FR_UP = 0, FR_PARSEUP = 1, FR_CHILD = 2, FR_RING = 3, FR_PARSEDOWN = 4 };
+
+struct Frame {
+    int32_t idx;   // segment index (top for UP/RING/PARSEDOWN, bottom for PARSEUP/CHILD)
+    int32_t so;    // offset of the base inside the segment, in iteration order
+    int32_t extra; // CHILD: slot; RING: index of the ring's first member
+    uint32_t meta; // kind | rev << 3 | genome << 4
+};
+
+__device__ __forceinline__ bool bit(const unsigned long long *m, int g) {
+    return (m[g >> 6] >> (g & 63)) & 1ull;
+}
+
+template <typename C> struct ColumnWalker {
+    const ColumnParams &P;
+    Frame stack[COL_STACK];
+    int sp = 0;
+    bool overflow = false;
+    __device__ ColumnWalker(const ColumnParams &p) : P(p) {
+    }
+    __device__ __forceinline__ const TopRec<C> *top(int g) const {
+        return (const TopRec<C> *)P.desc[g].top;
+    }
+    __device__ __forceinline__ const BotRec<C> *bot(int g) const {
+        return (const BotRec<C> *)P.desc[g].bot;
+    }
+    __device__ __forceinline__ void push(uint32_t kind, int g, int32_t idx, int32_t so, bool rev, int32_t extra) {
+        if (sp >= COL_STACK) {
+            overflow = true;
+            return;
+        }
+        stack[sp].idx = idx;
+        stack[sp].so = so;
+        stack[sp].extra = extra;
+        stack[sp].meta = kind | ((uint32_t)rev << 3) | ((uint32_t)g << 4);
+        ++sp;
+    }
+    // position of a base given its segment and iteration-order offset (halSegmentIterator.cpp:46-52)
+    template <typename REC> __device__ __forceinline__ int64_t posOf(const REC *segs, int32_t idx, int32_t so, bool rev) const {
+        return !rev ? (int64_t)segs[idx].start + so : (int64_t)segs[idx + 1].start - 1 - so;
+    }
+    // V: visitor with  void operator()(int genome, int64_t pos, bool rev)
+    template <typename V> __device__ __forceinline__ void insert(V &visit, int g, int64_t pos, bool rev) const {
+        // colMapInsert (halColumnIterator.cpp:802-812): noAncestors / targets filters
+        if ((!P.noAncestors || P.desc[g].numChildren == 0) && bit(P.targetMask, g))
+            visit(g, pos, rev);
+    }
+
+    template <typename V> __device__ void run(int64_t p, V &visit) {
+        const int R = P.ref;
+        const GenomeDesc &RD = P.desc[R];
+        sp = 0;
+        if (RD.numTop > 0) {
+            // recursiveUpdate, top branch (:252-300): toSite, insert, updateParent, updateNextTopDup, updateParseDown
+            const TopRec<C> *T = top(R);
+            int64_t lo = 0, hi = RD.numTop;
+            while (hi - lo > 1) {
+                const int64_t mid = (lo + hi) >> 1;
+                if ((int64_t)T[mid].start <= p)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+            const int32_t t = (int32_t)lo, so = (int32_t)(p - (int64_t)T[t].start);
+            insert(visit, R, p, false);
+            push(FR_PARSEDOWN, R, t, so, false, 0);
+            if (!P.onlyOrthologs)
+                push(FR_RING, R, t, so, false, t);
+            push(FR_UP, R, t, so, false, 0);
+        } else {
+            // bottom branch (:302-353): the root: insert, then every child
+            const BotRec<C> *B = bot(R);
+            int64_t lo = 0, hi = RD.numBot;
+            while (hi - lo > 1) {
+                const int64_t mid = (lo + hi) >> 1;
+                if ((int64_t)B[mid].start <= p)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+            const int32_t b = (int32_t)lo, so = (int32_t)(p - (int64_t)B[b].start);
+            insert(visit, R, p, false);
+            for (int i = RD.numChildren - 1; i >= 0; --i)
+                push(FR_CHILD, R, b, so, false, i);
+        }
+        while (sp > 0) {
+            const Frame f = stack[--sp];
+            const uint32_t kind = f.meta & 7u;
+            const bool rev = (f.meta >> 3) & 1u;
+            const int g = (int)(f.meta >> 4);
+            const GenomeDesc &D = P.desc[g];
+            if (kind == FR_UP) {
+                // updateParent (:556-605)
+                const TopRec<C> tr = top(g)[f.idx];
+                if (tr.parentEnc >= 0 && D.parent >= 0 && bit(P.scopeMask, D.parent)) {
+                    const int pg = D.parent;
+                    const GenomeDesc &PD = P.desc[pg];
+                    const int32_t b = tr.parentEnc >> 1;
+                    // noDupes: only the canonical paralog goes up (mmapTopSegment.cpp:30-40)
+                    if (!P.noDupes || (PD.child[D.slotInParent][b] >> 1) == f.idx) {
+                        const bool brev = rev ^ ((tr.parentEnc & 1) != 0);
+                        insert(visit, pg, posOf(bot(pg), b, f.so, brev), brev);
+                        for (int i = PD.numChildren - 1; i >= 0; --i) // siblings, executed after the parse-up branch
+                            if (i != D.slotInParent)
+                                push(FR_CHILD, pg, b, f.so, brev, i);
+                        push(FR_PARSEUP, pg, b, f.so, brev, 0);
+                    }
+                }
+            } else if (kind == FR_PARSEUP) {
+                // updateParseUp (:683-709): same base seen through the genome's top tiling
+                const BotRec<C> *B = bot(g);
+                const int32_t tp = B[f.idx].topParse;
+                if (tp >= 0) {
+                    const int64_t pos = posOf(B, f.idx, f.so, rev);
+                    const TopRec<C> *T = top(g);
+                    int32_t j = tp;
+                    while ((int64_t)T[j + 1].start <= pos)
+                        ++j;
+                    const int32_t so = !rev ? (int32_t)(pos - (int64_t)T[j].start) : (int32_t)((int64_t)T[j + 1].start - 1 - pos);
+                    if (!P.onlyOrthologs)
+                        push(FR_RING, g, j, so, rev, j);
+                    push(FR_UP, g, j, so, rev, 0);
+                }
+            } else if (kind == FR_CHILD) {
+                // updateChild (:607-640)
+                const int slot = f.extra;
+                const int32_t enc = D.child[slot][f.idx];
+                const int cg = D.childGenome[slot];
+                if (enc >= 0 && bit(P.scopeMask, cg)) {
+                    const int32_t t = enc >> 1;
+                    const bool crev = rev ^ ((enc & 1) != 0);
+                    insert(visit, cg, posOf(top(cg), t, f.so, crev), crev);
+                    push(FR_PARSEDOWN, cg, t, f.so, crev, 0);
+                    push(FR_RING, cg, t, f.so, crev, t);
+                }
+            } else if (kind == FR_RING) {
+                // updateNextTopDup (:642-681), one ring member per frame: emit the next paralog, walk its subtree,
+                // then continue round the ring
+                const TopRec<C> *T = top(g);
+                const TopRec<C> cur = T[f.idx];
+                const int32_t first = f.extra;
+                const bool startOfRing = f.idx == first;
+                bool go = !P.noDupes && cur.paralogy >= 0 && D.parent >= 0 && bit(P.scopeMask, D.parent);
+                if (go && !startOfRing)
+                    go = cur.paralogy != first; // do/while test (:679-680)
+                if (go) {
+                    const int32_t nxt = cur.paralogy;
+                    const TopRec<C> nr = T[nxt];
+                    const bool nrev = rev ^ ((nr.parentEnc & 1) != (cur.parentEnc & 1));
+                    insert(visit, g, posOf(T, nxt, f.so, nrev), nrev);
+                    push(FR_RING, g, nxt, f.so, nrev, first);
+                    push(FR_PARSEDOWN, g, nxt, f.so, nrev, 0);
+                }
+            } else { // FR_PARSEDOWN
+                // updateParseDown (:711-744)
+                const TopRec<C> *T = top(g);
+                const int32_t bp = T[f.idx].botParse;
+                if (bp >= 0) {
+                    const int64_t pos = posOf(T, f.idx, f.so, rev);
+                    const BotRec<C> *B = bot(g);
+                    int32_t j = bp;
+                    while ((int64_t)B[j + 1].start <= pos)
+                        ++j;
+                    const int32_t so = !rev ? (int32_t)(pos - (int64_t)B[j].start) : (int32_t)((int64_t)B[j + 1].start - 1 - pos);
+                    for (int i = D.numChildren - 1; i >= 0; --i)
+                        push(FR_CHILD, g, j, so, rev, i);
+                }
+            }
+        }
+    }
+};
+
+// depth visitor: genomes seen (bit set) and bases seen
+struct DepthVisitor {
+    unsigned long long mask[4] = {0, 0, 0, 0};
+    uint32_t bases = 0;
+    __device__ __forceinline__ void operator()(int g, int64_t, bool) {
+        mask[g >> 6] |= 1ull << (g & 63);
+        ++bases;
+    }
+};
+
+// halAlignmentDepth's per-column value (alignmentDepth/halAlignmentDepth.cpp:258-281): number of genomes with at
+// least one base in the column (or, with countDupes, number of bases) minus the reference base.
+// Also usable as the row-count pass of the MAF path (countDupes = 2: bases, without the -1).
+template <typename C>
+__global__ void __launch_bounds__(256) k_column_depth(ColumnParams P, int countMode, int32_t *__restrict__ out) {
+    ColumnWalker<C> w(P);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P.count; i += (int64_t)gridDim.x * blockDim.x) {
+        DepthVisitor v;
+        w.run(P.first + i * P.step, v);
+        int32_t val;
+        if (countMode == 0)
+            val = (int32_t)(__popcll(v.mask[0]) + __popcll(v.mask[1]) + __popcll(v.mask[2]) + __popcll(v.mask[3])) - 1;
+        else if (countMode == 1)
+            val = (int32_t)v.bases - 1;
+        else
+            val = (int32_t)v.bases;
+        out[i] = val;
+    }
+    if (w.overflow)
+        *P.error = 1;
+}
+
+// MAF rows: every reported base of every column, in ColumnMap insertion order
+struct ColumnRow {
+    int64_t pos;     // genome coordinate
+    int32_t genome;
+    uint8_t rev;
+    char base;       // DnaIterator::getBase: complemented when rev (halDnaIterator.h:131-138)
+    uint8_t _pad[2];
+};
+
+struct RowVisitor {
+    ColumnRow *dst;
+    const GenomeDesc *desc;
+    uint32_t n = 0;
+    __device__ __forceinline__ void operator()(int g, int64_t pos, bool rev) {
+        ColumnRow r;
+        r.pos = pos;
+        r.genome = g;
+        r.rev = rev;
+        char c = 'N';
+        const uint8_t *dna = desc[g].dna;
+        if (dna) {
+            const uint8_t b = dna[pos >> 1];
+            const uint32_t code = (pos & 1) ? (b & 0x0F) : (b >> 4); // dnaUnpack, halCommon.h:187-190
+            c = "acgtn\0\0\0ACGTN\0\0"[code];                       // dnaUnpackMap, halCommon.cpp:233-235
+            if (rev) { // reverseComplement (halCommon.h:45-75)
+                switch (c) {
+                case 'A': c = 'T'; break;
+                case 'a': c = 't'; break;
+                case 'C': c = 'G'; break;
+                case 'c': c = 'g'; break;
+                case 'G': c = 'C'; break;
+                case 'g': c = 'c'; break;
+                case 'T': c = 'A'; break;
+                case 't': c = 'a'; break;
+                default: break;
+                }
+            }
+        }
+        r.base = c;
+        r._pad[0] = r._pad[1] = 0;
+        dst[n++] = r;
+    }
+};
+
+template <typename C>
+__global__ void __launch_bounds__(256) k_column_rows(ColumnParams P, const uint64_t *__restrict__ rowOffset, ColumnRow *__restrict__ rows) {
+    ColumnWalker<C> w(P);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P.count; i += (int64_t)gridDim.x * blockDim.x) {
+        RowVisitor v;
+        v.dst = rows + rowOffset[i];
+        v.desc = P.desc;
+        w.run(P.first + i * P.step, v);
+    }
+    if (w.overflow)
+        *P.error = 1;
+}
+
+} // namespace hgx

@@ -1,0 +1,40 @@
+// Internal C++ interface of the column engine (implemented in hgx_columns.hip).
+#pragma once
+#include "../../include/hgx.h"
+#include "hgx_device.hpp"
+#include <string>
+#include <vector>
+
+namespace hgx {
+
+struct ColumnRowHost { // mirrors ColumnRow of hgx_column_kernels.hpp
+    int64_t pos;
+    int32_t genome;
+    uint8_t rev;
+    char base;
+    uint8_t _pad[2];
+};
+
+struct ColumnOptions {
+    bool noDupes = false, noAncestors = false, onlyOrthologs = false;
+    std::vector<int> targets; // genome ids; empty = everything (halColumnIterator.cpp:45-51)
+};
+
+struct ColumnStats {
+    double depth_ms = 0, rows_ms = 0;
+    uint64_t columns = 0, rows = 0;
+};
+
+// per-column values of halAlignmentDepth: mode 0 = distinct genomes - 1, 1 = bases - 1 (--countDupes), 2 = bases
+// first: genome coordinate; results for columns first, first+step, ... (count of them)
+void columnsDepthHost(hgx_alignment *h, int ref, int64_t first, int64_t count, int64_t step, int mode, const ColumnOptions &opt,
+                      int32_t *out, ColumnStats *stats);
+// same, results left on the device (d_out: device int32[count]); stream = hipStream_t
+void columnsDepthDevice(hgx_alignment *h, int ref, int64_t first, int64_t count, int64_t step, int mode, const ColumnOptions &opt,
+                        int32_t *d_out, void *stream, ColumnStats *stats);
+// every reported base of columns [first, first+count), in the reference's ColumnMap insertion order;
+// rowOffset gets count+1 entries
+void columnsRowsHost(hgx_alignment *h, int ref, int64_t first, int64_t count, const ColumnOptions &opt, bool withDna,
+                     std::vector<uint64_t> &rowOffset, std::vector<ColumnRowHost> &rows, ColumnStats *stats);
+
+} // namespace hgx

@@ -1,0 +1,361 @@
+#include "hgx_columns_host.hpp"
+#include <algorithm>
+#include <climits>
+
+namespace hgx {
+
+// ---------------------------------------------------------------------------------------------
+// halAlignmentDepth
+static void depthSequence(std::ostream &os, hgx_alignment *h, int genome, int seqIdx, const std::set<int> &targetSet, int64_t start,
+                          int64_t length, int64_t step, bool countDupes, bool noAncestors, ColumnStats *stats) {
+    // printSequence, alignmentDepth/halAlignmentDepth.cpp:215-308
+    const GenomeTables &G = h->img.genomes[(size_t)genome];
+    const SeqInfo &S = G.seqs[(size_t)seqIdx];
+    const int64_t seqLen = S.length;
+    if (seqLen == 0)
+        return;
+    if (length == 0)
+        length = seqLen - start;
+    const int64_t last = start + length;
+    if (last > seqLen)
+        throw std::runtime_error("Specified range [" + std::to_string(start) + "," + std::to_string(length) + "] is" +
+                                 "out of range for sequence " + S.name + ", which has length " + std::to_string(seqLen));
+    if (step < 1)
+        throw std::runtime_error("step must be positive");
+    os << "fixedStep chrom=" << S.name << " start=" << start + 1 << " step=" << step << "\n";
+    // positions the reference loop visits (:243-307): start, start+step, ... while inside [start, last); with step > 1 the
+    // iterator is re-seated by toSite(pos, last) whose last column is `last` itself, so a position landing exactly on
+    // `last` is also printed when it exists in the genome
+    int64_t count = 0;
+    if (step == 1) {
+        count = length;
+    } else if (length >= 1) {
+        count = 1;
+        if (length > 1) {
+            int64_t p = start + step;
+            while (p <= last && p + S.start < G.totalLength) {
+                ++count;
+                if (p >= last)
+                    break;
+                p += step;
+            }
+        }
+    }
+    ColumnOptions opt;
+    opt.noAncestors = noAncestors;
+    opt.targets.assign(targetSet.begin(), targetSet.end());
+    std::vector<int32_t> vals((size_t)count);
+    columnsDepthHost(h, genome, start + S.start, count, step, countDupes ? 1 : 0, opt, vals.data(), stats);
+    std::string buf;
+    buf.reserve((size_t)count * 3);
+    char tmp[16];
+    for (int64_t i = 0; i < count; ++i) {
+        int n = snprintf(tmp, sizeof tmp, "%d\n", vals[(size_t)i]);
+        buf.append(tmp, (size_t)n);
+    }
+    os << buf;
+}
+
+void alignmentDepth(std::ostream &os, hgx_alignment *h, int genome, int sequence, const std::set<int> &targetSet, int64_t start,
+                    int64_t length, int64_t step, bool countDupes, bool noAncestors, ColumnStats *stats) {
+    // printGenome, :318-347
+    const GenomeTables &G = h->img.genomes[(size_t)genome];
+    if (sequence >= 0) {
+        depthSequence(os, h, genome, sequence, targetSet, start, length, step, countDupes, noAncestors, stats);
+        return;
+    }
+    if (start + length > G.totalLength)
+        throw std::runtime_error("Specified range [" + std::to_string(start) + "," + std::to_string(length) + "] is" +
+                                 "out of range for genome " + G.name + ", which has length " + std::to_string(G.totalLength));
+    if (length == 0)
+        length = G.totalLength - start;
+    int64_t runningLength = 0;
+    for (size_t s = 0; s < G.seqs.size(); ++s) {
+        const SeqInfo &S = G.seqs[s];
+        if (start + length >= S.start && start < S.start + S.length && runningLength < length) {
+            const int64_t readStart = S.start >= start ? 0 : start - S.start;
+            int64_t readLen = std::min(S.length - readStart, length);
+            readLen = std::min(readLen, length - runningLength);
+            depthSequence(os, h, genome, (int)s, targetSet, readStart, readLen, step, countDupes, noAncestors, stats);
+            runningLength += readLen;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// hal2maf
+MafExport::~MafExport() {
+    for (auto &kv : _entries)
+        delete kv.second;
+}
+
+void MafExport::buildRanks() {
+    // ColumnIterator::SequenceLess (api/inc/halColumnIterator.h:45-50): genome name, then sequence index
+    const Image &img = _al->img;
+    std::vector<int> order(img.genomes.size());
+    for (size_t i = 0; i < order.size(); ++i)
+        order[i] = (int)i;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return img.genomes[(size_t)a].name < img.genomes[(size_t)b].name; });
+    _rank.assign(img.genomes.size(), std::vector<int>());
+    int r = 0;
+    for (int g : order) {
+        _rank[(size_t)g].resize(img.genomes[(size_t)g].seqs.size());
+        for (size_t s = 0; s < img.genomes[(size_t)g].seqs.size(); ++s)
+            _rank[(size_t)g][s] = r++;
+    }
+}
+
+MafExport::Key MafExport::keyOf(int genome, int64_t pos) const {
+    const GenomeTables &G = _al->img.genomes[(size_t)genome];
+    const int s = G.seqs.size() == 1 ? 0 : G.seqIndexBySite(pos);
+    return Key{_rank[(size_t)genome][(size_t)s], genome, s};
+}
+
+// halMafBlock.cpp:36-82
+void MafExport::resetEntries() {
+    _reference = nullptr;
+    _refIndex = NULL_INDEX;
+    for (auto i = _entries.begin(); i != _entries.end();) {
+        Entry *e = i->second;
+        if (e->start == NULL_INDEX) {
+            if (e->lastUsed > 10) { // unused for more than 10 consecutive blocks: dropped
+                delete e;
+                i = _entries.erase(i);
+                continue;
+            }
+            ++e->lastUsed;
+        } else {
+            e->lastUsed = 0;
+        }
+        e->start = NULL_INDEX;
+        e->strand = '+';
+        e->length = 0;
+        e->sequence.clear();
+        ++i;
+    }
+}
+
+// halMafBlock.cpp:84-112
+void MafExport::initEntry(Entry *e, const Key &k, const ColumnRowHost *row, bool clearSequence) {
+    const GenomeTables &G = _al->img.genomes[(size_t)k.genome];
+    const SeqInfo &S = G.seqs[(size_t)k.seq];
+    if (e->genome != k.genome || e->srcLength != S.length || e->name.empty()) {
+        e->name = _ucscNames ? G.name + "." + S.name : S.name; // Sequence::getFullName / getName (halMafBlock.h:128-130)
+        e->genome = k.genome;
+        e->srcLength = S.length;
+    }
+    if (row) {
+        e->start = row->pos - S.start;
+        e->length = 0;
+        e->strand = row->rev ? '-' : '+';
+        if (row->rev)
+            e->start = e->srcLength - 1 - e->start;
+    } else {
+        e->start = NULL_INDEX;
+        e->length = 0;
+        e->strand = '+';
+    }
+    if (clearSequence)
+        e->sequence.clear();
+}
+
+// halMafBlock.cpp:114-138
+void MafExport::updateEntry(Entry *e, const Key *k, const ColumnRowHost *row) {
+    if (row) {
+        if (e->start == NULL_INDEX)
+            initEntry(e, *k, row, false);
+        ++e->length;
+        e->sequence.push_back(row->base);
+    } else {
+        e->sequence.push_back('-');
+    }
+}
+
+// halMafBlock.cpp:294-367
+void MafExport::initBlock(const ColumnMap &col, const Key &refKey, int64_t refPos) {
+    resetEntries();
+    Entries::iterator e = _entries.begin();
+    for (auto c = col.begin(); c != col.end(); ++c) {
+        const Key &k = c->first;
+        if (c->second.empty()) {
+            e = _entries.lower_bound(k);
+            if (e == _entries.end() || e->first.rank != k.rank) {
+                Entry *ne = new Entry;
+                initEntry(ne, k, nullptr);
+                e = _entries.insert(Entries::value_type(k, ne));
+            } else {
+                initEntry(e->second, k, nullptr);
+            }
+        } else {
+            for (const ColumnRowHost *row : c->second) {
+                if (e == _entries.begin()) {
+                    e = _entries.lower_bound(k);
+                    if (e == _entries.end() || e->first.rank != k.rank)
+                        e = _entries.end();
+                } else {
+                    while (e != _entries.end() && e->first.rank != k.rank)
+                        ++e;
+                }
+                if (e == _entries.end()) {
+                    Entry *ne = new Entry;
+                    initEntry(ne, k, row);
+                    e = _entries.insert(Entries::value_type(k, ne));
+                } else {
+                    initEntry(e->second, k, row);
+                }
+                ++e;
+            }
+        }
+    }
+    if (_reference == nullptr) {
+        e = _entries.lower_bound(refKey);
+        if (e == _entries.end() || e->first.rank != refKey.rank)
+            e = _entries.begin();
+        _reference = e->second;
+        if (e->first.rank == refKey.rank)
+            _refIndex = refPos;
+    }
+}
+
+// halMafBlock.cpp:370-395
+void MafExport::appendColumn(const ColumnMap &col) {
+    Entries::iterator e = _entries.begin();
+    for (auto c = col.begin(); c != col.end(); ++c) {
+        for (const ColumnRowHost *row : c->second) {
+            while (e != _entries.end() && e->first.rank != c->first.rank) {
+                updateEntry(e->second, nullptr, nullptr);
+                ++e;
+            }
+            updateEntry(e->second, &c->first, row);
+            ++e;
+        }
+    }
+    for (; e != _entries.end(); ++e)
+        updateEntry(e->second, nullptr, nullptr);
+}
+
+// halMafBlock.cpp:401-452
+bool MafExport::canAppendColumn(const ColumnMap &col) {
+    Entries::iterator e = _entries.begin();
+    for (auto c = col.begin(); c != col.end(); ++c) {
+        if (c->second.empty())
+            continue;
+        const int64_t sequenceStart = _al->img.genomes[(size_t)c->first.genome].seqs[(size_t)c->first.seq].start;
+        for (const ColumnRowHost *row : c->second) {
+            while (e != _entries.end() && e->first.rank != c->first.rank)
+                ++e;
+            if (e == _entries.end())
+                return false;
+            const Entry *entry = e->second;
+            if (entry->start != NULL_INDEX) {
+                if (entry->length >= _maxBlockLength || (entry->length > 0 && (entry->strand == '-') != (row->rev != 0)))
+                    return false;
+                int64_t pos = row->pos - sequenceStart;
+                if (row->rev)
+                    pos = entry->srcLength - 1 - pos;
+                if (pos - entry->start != entry->length)
+                    return false;
+            }
+            ++e;
+        }
+    }
+    return true;
+}
+
+bool MafExport::referenceIsAllGaps() const {
+    if (!_reference)
+        return false;
+    for (char c : _reference->sequence)
+        if (c != '-')
+            return false;
+    return true;
+}
+
+// halMafBlock.cpp:454-458, 499-519
+void MafExport::printBlock(std::ostream &os) const {
+    auto printEntry = [&](const Entry &e, int64_t start) {
+        os << "s\t" << e.name << '\t' << start << '\t' << e.length << '\t' << e.strand << '\t' << e.srcLength << '\t' << e.sequence << '\n';
+    };
+    os << "a\n";
+    if (_reference->start == NULL_INDEX) {
+        if (_refIndex != NULL_INDEX)
+            printEntry(*_reference, _refIndex);
+    } else {
+        printEntry(*_reference, _reference->start);
+    }
+    for (auto e = _entries.begin(); e != _entries.end(); ++e)
+        if (e->second->start != NULL_INDEX && e->second != _reference)
+            printEntry(*e->second, e->second->start);
+}
+
+// halMafExport.cpp:25-88
+void MafExport::convertSequence(std::ostream &mafStream, hgx_alignment *alignment, int genome, int seq, int64_t startPosition,
+                                int64_t length, const std::set<int> &targets) {
+    if (_unique || _maxRefGap > 0)
+        throw std::runtime_error("--unique and --maxRefGap are not built yet (SURVEY 8(f) item 2)");
+    if (_al != alignment) {
+        _al = alignment;
+        buildRanks();
+    }
+    const GenomeTables &G = alignment->img.genomes[(size_t)genome];
+    const SeqInfo &S = G.seqs[(size_t)seq];
+    if (startPosition >= S.length || startPosition + length > S.length)
+        throw std::runtime_error("Invalid range specified for convertGenome");
+    if (length == 0)
+        length = S.length - startPosition;
+    if (length == 0)
+        throw std::runtime_error("Cannot convert zero length sequence");
+    if (!_append && !_headerWritten) { // writeHeader (:15-23): only at the very start of the stream
+        mafStream << "##maf version=1 scoring=N/A\n"
+                  << "# hal " << alignment->img.newick << std::endl
+                  << std::endl;
+        _headerWritten = true;
+    }
+    ColumnOptions opt;
+    opt.noDupes = _noDupes;
+    opt.noAncestors = _noAncestors;
+    opt.onlyOrthologs = _onlyOrthologs;
+    opt.targets.assign(targets.begin(), targets.end());
+    const Key refKey{_rank[(size_t)genome][(size_t)seq], genome, seq};
+
+    ColumnMap colMap; // keys persist between columns like ColumnIterator::_colMap (resetColMap only empties the vectors)
+    std::vector<uint64_t> off;
+    std::vector<ColumnRowHost> rows;
+    size_t appendCount = 0, numBlocks = 0;
+    const int64_t first = startPosition + S.start;
+    for (int64_t done = 0; done < length;) {
+        const int64_t n = std::min<int64_t>((int64_t)chunkColumns, length - done);
+        columnsRowsHost(alignment, genome, first + done, n, opt, true, off, rows, &stats);
+        for (int64_t i = 0; i < n; ++i) {
+            for (auto &kv : colMap)
+                kv.second.clear();
+            for (uint64_t r = off[(size_t)i]; r < off[(size_t)i + 1]; ++r) {
+                const ColumnRowHost &row = rows[r];
+                colMap[keyOf(row.genome, row.pos)].push_back(&row);
+            }
+            const int64_t refPos = startPosition + done + i;
+            if (appendCount == 0) {
+                initBlock(colMap, refKey, refPos);
+            } else if (!canAppendColumn(colMap)) {
+                if (numBlocks++ % 1000 == 0) { // ColumnIterator::defragment (halColumnIterator.cpp:193-208)
+                    for (auto it = colMap.begin(); it != colMap.end();)
+                        it = it->second.empty() ? colMap.erase(it) : std::next(it);
+                }
+                if (_keepEmptyRefBlocks || !referenceIsAllGaps()) {
+                    printBlock(mafStream);
+                    mafStream << '\n';
+                }
+                initBlock(colMap, refKey, refPos);
+            }
+            appendColumn(colMap);
+            ++appendCount;
+        }
+        done += n;
+    }
+    if (appendCount > 0 && (_keepEmptyRefBlocks || !referenceIsAllGaps())) {
+        printBlock(mafStream);
+        mafStream << std::endl;
+    }
+}
+
+} // namespace hgx

@@ -1,0 +1,71 @@
+// Host adapters with the reference's interfaces for the column engine: MafExport (maf/inc/halMafExport.h:30-68)
+// and halAlignmentDepth's printGenome (alignmentDepth/halAlignmentDepth.cpp:318-347).  Column contents come from
+// the GPU (hgx_columns.hip); block assembly and text formatting are sequential by definition in the reference
+// (the block state depends on every earlier column) and stay on the host.
+#pragma once
+#include "hgx_columns_engine.hpp"
+#include <map>
+#include <ostream>
+#include <set>
+
+namespace hgx {
+
+// halAlignmentDepth: writes the wig text of printGenome.  sequence = -1: all sequences of the genome.
+void alignmentDepth(std::ostream &os, hgx_alignment *h, int genome, int sequence, const std::set<int> &targetSet, int64_t start,
+                    int64_t length, int64_t step, bool countDupes, bool noAncestors, ColumnStats *stats = nullptr);
+
+class MafExport {
+  public:
+    // maf/inc/halMafExport.h:36-58
+    void setNoDupes(bool v) { _noDupes = v; }
+    void setNoAncestors(bool v) { _noAncestors = v; }
+    void setUcscNames(bool v) { _ucscNames = v; }
+    void setAppend(bool v) { _append = v; }
+    void setMaxBlockLength(int64_t v) { _maxBlockLength = v <= 0 ? INT64_MAX : v; }
+    void setOnlyOrthologs(bool v) { _onlyOrthologs = v; }
+    void setKeepEmptyRefBlocks(bool v) { _keepEmptyRefBlocks = v; }
+    void setMaxRefGap(int64_t v) { _maxRefGap = v; }
+    void setUnique(bool v) { _unique = v; }
+    // maf/impl/halMafExport.cpp:25-88; positions are sequence-relative, length 0 = to the end
+    void convertSequence(std::ostream &mafStream, hgx_alignment *alignment, int genome, int seq, int64_t startPosition, int64_t length,
+                         const std::set<int> &targets);
+    ~MafExport();
+    ColumnStats stats;
+    size_t chunkColumns = 1u << 21;
+
+  private:
+    struct Entry { // MafBlockEntry, maf/inc/halMafBlock.h:60-118
+        int genome = -1;
+        std::string name;
+        int64_t start = NULL_INDEX, length = 0, srcLength = 0;
+        char strand = '+';
+        std::string sequence;
+        short lastUsed = 0;
+    };
+    struct Key {
+        int rank, genome, seq;
+        bool operator<(const Key &o) const { return rank < o.rank; }
+    };
+    typedef std::multimap<Key, Entry *> Entries;
+    typedef std::map<Key, std::vector<const ColumnRowHost *>> ColumnMap;
+    bool _noDupes = false, _noAncestors = false, _ucscNames = true, _append = false, _onlyOrthologs = false, _keepEmptyRefBlocks = false,
+         _unique = false, _headerWritten = false;
+    int64_t _maxBlockLength = 1000, _maxRefGap = 0;
+    Entries _entries;
+    Entry *_reference = nullptr;
+    int64_t _refIndex = NULL_INDEX;
+    hgx_alignment *_al = nullptr;
+    std::vector<std::vector<int>> _rank; // [genome][sequence] -> order of ColumnIterator::SequenceLess
+    void buildRanks();
+    Key keyOf(int genome, int64_t pos) const;
+    void resetEntries();
+    void initEntry(Entry *e, const Key &k, const ColumnRowHost *row, bool clearSequence = true);
+    void updateEntry(Entry *e, const Key *k, const ColumnRowHost *row);
+    void initBlock(const ColumnMap &col, const Key &refKey, int64_t refPos);
+    void appendColumn(const ColumnMap &col);
+    bool canAppendColumn(const ColumnMap &col);
+    bool referenceIsAllGaps() const;
+    void printBlock(std::ostream &os) const;
+};
+
+} // namespace hgx

@@ -48,13 +48,32 @@ struct DeviceGenome {
     int64_t numTop = 0, numBot = 0;
 };
 
+// Per-genome descriptor readable from device code (the column kernels walk the whole tree, so they need
+// every genome's tables, not just the two or three a liftover launch is given).
+static constexpr int MAX_CHILD_SLOTS = 16;
+struct GenomeDesc {
+    const void *top;      // TopRec<C>[numTop+1]
+    const void *bot;      // BotRec<C>[numBot+1]
+    const int32_t *child[MAX_CHILD_SLOTS];
+    int32_t childGenome[MAX_CHILD_SLOTS];
+    const uint8_t *dna;   // nibble-packed bases, or null when the alignment carries no DNA
+    const int64_t *seqStart;
+    int64_t numTop, numBot, length;
+    int32_t parent, slotInParent, numChildren, numSeq;
+};
+
 struct DeviceImage {
     int device = -1;
     bool wide = false; // C == int64_t
     std::vector<DeviceGenome> genomes;
+    GenomeDesc *desc = nullptr;          // device array, one per genome
+    std::vector<uint8_t *> dna;          // device copies of the packed DNA (uploaded on first use)
     size_t bytes = 0;
     ~DeviceImage();
 };
+
+// uploads the packed DNA of every genome (idempotent); needed only by the MAF path
+void ensureDeviceDna(const Image &img, DeviceImage &D);
 
 // uploads img to `device`; throws std::runtime_error on any HIP failure or unsupported size
 std::unique_ptr<DeviceImage> uploadImage(const Image &img, int device);

@@ -32,6 +32,56 @@ DeviceImage::~DeviceImage() {
         if (g.seqStart)
             (void)hipFree(g.seqStart);
     }
+    if (desc)
+        (void)hipFree(desc);
+    for (uint8_t *p : dna)
+        if (p)
+            (void)hipFree(p);
+}
+
+static void uploadDescs(const Image &img, DeviceImage &D) {
+    std::vector<GenomeDesc> descs(img.genomes.size());
+    for (size_t g = 0; g < img.genomes.size(); ++g) {
+        const GenomeTables &G = img.genomes[g];
+        GenomeDesc &d = descs[g];
+        memset(&d, 0, sizeof d);
+        d.top = D.genomes[g].top;
+        d.bot = D.genomes[g].bot;
+        if (G.children.size() > (size_t)MAX_CHILD_SLOTS)
+            throw std::runtime_error("genome " + G.name + " has more than 16 children; the column kernels support at most 16");
+        for (size_t k = 0; k < G.children.size(); ++k) {
+            d.child[k] = D.genomes[g].childEnc[k];
+            d.childGenome[k] = G.children[k];
+        }
+        d.dna = g < D.dna.size() ? D.dna[g] : nullptr;
+        d.seqStart = D.genomes[g].seqStart;
+        d.numTop = G.numTop;
+        d.numBot = G.numBot;
+        d.length = G.totalLength;
+        d.parent = G.parent;
+        d.slotInParent = G.parent >= 0 ? img.genomes[(size_t)G.parent].childSlotOf((int)g) : -1;
+        d.numChildren = (int32_t)G.children.size();
+        d.numSeq = (int32_t)G.seqs.size();
+    }
+    if (!D.desc)
+        HIP_OK(hipMalloc(&D.desc, std::max<size_t>(1, descs.size()) * sizeof(GenomeDesc)));
+    HIP_OK(hipMemcpy(D.desc, descs.data(), descs.size() * sizeof(GenomeDesc), hipMemcpyHostToDevice));
+}
+
+void ensureDeviceDna(const Image &img, DeviceImage &D) {
+    if (!D.dna.empty())
+        return;
+    HIP_OK(hipSetDevice(D.device));
+    D.dna.assign(img.genomes.size(), nullptr);
+    for (size_t g = 0; g < img.genomes.size(); ++g) {
+        const std::vector<uint8_t> &p = img.genomes[g].dna;
+        if (p.empty())
+            continue;
+        HIP_OK(hipMalloc(&D.dna[g], p.size()));
+        HIP_OK(hipMemcpy(D.dna[g], p.data(), p.size(), hipMemcpyHostToDevice));
+        D.bytes += p.size();
+    }
+    uploadDescs(img, D);
 }
 
 static inline int32_t encLink(int64_t idx, bool rev) {
@@ -112,6 +162,7 @@ std::unique_ptr<DeviceImage> uploadImage(const Image &img, int device) {
         HIP_OK(hipMalloc(&dg.seqStart, ss.size() * 8));
         HIP_OK(hipMemcpy(dg.seqStart, ss.data(), ss.size() * 8, hipMemcpyHostToDevice));
     }
+    uploadDescs(img, *D);
     return D;
 }
 

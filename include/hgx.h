@@ -135,6 +135,56 @@ int hgx_liftover_convert(hgx_alignment *h, int src_genome, const char *bed_text,
                          int bed_type, int traverse_dupes, int out_psl, int out_psl_with_name, int coalescence_limit,
                          char **out_text, size_t *out_len, char **err);
 
+/* ---- column engine: ColumnIterator (api/impl/halColumnIterator.cpp) in its default configuration
+ * (maxInsertLength 0, unique false — columns are independent, :785-787), as used by halAlignmentDepth
+ * (alignmentDepth/halAlignmentDepth.cpp:215-308) and hal2maf (maf/impl/halMafExport.cpp:25-88). ---- */
+typedef struct hgx_column_opts {
+    int32_t no_dupes;       /* ColumnIterator noDupes */
+    int32_t no_ancestors;   /* ColumnIterator noAncestors */
+    int32_t only_orthologs; /* ColumnIterator onlyOrthologs */
+    int32_t n_targets;      /* 0 = visit everything */
+    const int32_t *targets; /* genome ids (the reference genome is added, halColumnIterator.cpp:47) */
+} hgx_column_opts;
+
+/* One value per column for columns first, first+step, ... (count of them; `first` is a GENOME coordinate of
+ * ref_genome): count_dupes == 0: genomes with a base in the column - 1; 1: bases in the column - 1
+ * (halAlignmentDepth.cpp:258-281).  out: host int32[count]. */
+int hgx_columns_depth(hgx_alignment *h, int ref_genome, int64_t first, int64_t count, int64_t step, int count_dupes,
+                      const hgx_column_opts *opts, int32_t *out, char **err);
+/* Same with the result left in HBM (d_out: device int32[count]); kernel_ms (may be NULL) receives the kernel's
+ * device time measured with HIP events on `hip_stream`. */
+int hgx_columns_depth_device(hgx_alignment *h, int ref_genome, int64_t first, int64_t count, int64_t step, int count_dupes,
+                             const hgx_column_opts *opts, int32_t *d_out, void *hip_stream, double *kernel_ms, char **err);
+
+/* Every reported base of columns [first, first+count) in ColumnMap insertion order: what a loop over
+ * Sequence::getColumnIterator()/toRight()/getColumnMap() sees.  *row_offset has count+1 entries. */
+typedef struct hgx_column_row {
+    int64_t pos;    /* genome coordinate */
+    int32_t genome;
+    uint8_t reversed;
+    char base;      /* DnaIterator::getBase (complemented when reversed); 'N' when the alignment has no DNA */
+    uint8_t _pad[2];
+} hgx_column_row;
+int hgx_column_rows(hgx_alignment *h, int ref_genome, int64_t first, int64_t count, const hgx_column_opts *opts,
+                    uint64_t **row_offset, hgx_column_row **rows, size_t *n_rows, char **err);
+
+/* halAlignmentDepth's printGenome (alignmentDepth/halAlignmentDepth.cpp:318-347): wig text.
+ * ref_sequence: sequence index or -1 for the whole genome; start/length as --start/--length (0 = to the end). */
+int hgx_alignment_depth(hgx_alignment *h, int ref_genome, int ref_sequence, int64_t start, int64_t length, int64_t step,
+                        int count_dupes, int no_ancestors, const int32_t *targets, int32_t n_targets, char **out_text,
+                        size_t *out_len, char **err);
+
+/* hal2maf: MafExport::convertSequence (maf/impl/halMafExport.cpp:25-88) over one sequence, or over every
+ * sequence of the reference genome when ref_sequence == -1 (maf/impl/hal2maf.cpp:196-206).  MAF text, header
+ * included, byte-identical to hal2maf for the options below. */
+typedef struct hgx_maf_opts {
+    int32_t no_dupes, no_ancestors, only_sequence_names, only_orthologs, keep_empty_ref_blocks;
+    int32_t _pad;
+    int64_t max_block_len; /* --maxBlockLen, default 1000 (halMafBlock.cpp:16); <= 0: unlimited */
+} hgx_maf_opts;
+int hgx_maf_export(hgx_alignment *h, int ref_genome, int ref_sequence, int64_t start, int64_t length, const hgx_maf_opts *opts,
+                   const int32_t *targets, int32_t n_targets, char **out_text, size_t *out_len, char **err);
+
 /* ---- synthetic workloads: halRandGen (randgen/halRandGen.cpp) ---- */
 typedef struct hgx_rand_opts {
     double mean_degree, max_branch_length;

@@ -1,0 +1,122 @@
+"""Parity of the HIP column engine (halAlignmentDepth, hal2maf) with the oracle and the reference's goldens."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import halfix
+import handbuilt_liftover as hb
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _oracle(oracle_bin, cmd, img, tmp_path, *args):
+    out = str(tmp_path / ("o." + cmd))
+    if cmd == "maf":
+        subprocess.check_call([oracle_bin, "maf", img, out] + list(args))
+    else:
+        subprocess.check_call([oracle_bin, "depth", img, args[0], out] + list(args[1:]))
+    return open(out).read()
+
+
+def _rand(hal, tmp_path, seed, dna=True, **kw):
+    o = dict(mean_degree=1.5, max_branch_length=3.0, min_genomes=2, max_genomes=10, min_segment_length=10, max_segment_length=60,
+             min_segments=60, max_segments=160, seed=seed, with_dna=dna)
+    o.update(kw)
+    al = hal.Alignment.random(hal.RandOptions(**o), device=0)
+    img = str(tmp_path / ("c%d.hgx" % seed))
+    al.save(img)
+    return al, img
+
+
+def test_reference_cli_goldens_hal2maf(hal, tmp_path):
+    al = hal.Alignment.random(hal.RandOptions.preset("small", seed=0), device=0)
+    assert al.maf_export(al.genome_id("Genome_0")) == open(os.path.join(GOLD, "ref_maf", "hal2mafSmallTest.maf")).read()
+    g2 = al.genome_id("Genome_2")
+    assert al.maf_export(g2, 0, start=1000, length=2000) == open(os.path.join(GOLD, "ref_maf", "hal2mafSeqPartTest.maf")).read()
+
+
+@pytest.mark.parametrize("seed", [2, 5, 6])
+def test_depth_all_genomes_vs_oracle(hal, oracle_bin, tmp_path, seed):
+    al, img = _rand(hal, tmp_path, seed, dna=False)
+    for g in range(al.num_genomes):
+        name = al.genome_name(g)
+        if al.genome_length(g) == 0:
+            continue
+        assert al.alignment_depth(g) == _oracle(oracle_bin, "depth", img, tmp_path, name), name
+        assert al.alignment_depth(g, count_dupes=True) == _oracle(oracle_bin, "depth", img, tmp_path, name, "--countDupes"), name
+        if not al.genome_children(g):
+            assert al.alignment_depth(g, no_ancestors=True) == _oracle(oracle_bin, "depth", img, tmp_path, name, "--noAncestors")
+
+
+def test_depth_options_vs_oracle(hal, oracle_bin, tmp_path):
+    al, img = _rand(hal, tmp_path, 2, dna=False)
+    g9, g8, g2, g5 = (al.genome_id(n) for n in ("Genome_9", "Genome_8", "Genome_2", "Genome_5"))
+    assert al.alignment_depth(g9, 0, start=100, length=777) == \
+        _oracle(oracle_bin, "depth", img, tmp_path, "Genome_9", "--refSequence", "Genome_9_seq", "--start", "100", "--length", "777")
+    assert al.alignment_depth(g9, step=7) == _oracle(oracle_bin, "depth", img, tmp_path, "Genome_9", "--step", "7")
+    assert al.alignment_depth(g9, 0, start=5, length=70, step=10) == \
+        _oracle(oracle_bin, "depth", img, tmp_path, "Genome_9", "--refSequence", "Genome_9_seq", "--start", "5", "--length", "70",
+                "--step", "10")
+    assert al.alignment_depth(g9, targets=[g8, g2]) == \
+        _oracle(oracle_bin, "depth", img, tmp_path, "Genome_9", "--targetGenomes", "Genome_8,Genome_2")
+    assert al.alignment_depth(g5, targets=[g8]) == _oracle(oracle_bin, "depth", img, tmp_path, "Genome_5", "--targetGenomes", "Genome_8")
+
+
+def test_depth_handbuilt_and_columns_api(hal, oracle_bin, tmp_path):
+    img = str(tmp_path / "hand.hgx")
+    halfix.write_hgx(img, hb.genomes())
+    al = hal.Alignment.open(img, device=0)
+    for g in range(al.num_genomes):
+        assert al.alignment_depth(g) == _oracle(oracle_bin, "depth", img, tmp_path, al.genome_name(g))
+    # raw per-column API agrees with the wig text
+    g = al.genome_id("leaf2")
+    vals = al.columns_depth(g, 0, 70)
+    assert "\n".join(map(str, vals)) + "\n" == al.alignment_depth(g).split("\n", 1)[1]
+    off, rows = al.column_rows(g, 0, 70)
+    assert len(off) == 71 and off[-1] == len(rows)
+    assert np.array_equal(np.diff(off).astype(np.int32) - 1, al.columns_depth(g, 0, 70, count_dupes=True))
+    # the first row of every column is the reference base itself
+    assert np.all(rows["genome"][off[:-1]] == g) and np.array_equal(rows["pos"][off[:-1]], np.arange(70))
+
+
+@pytest.mark.parametrize("seed", [2, 5])
+def test_maf_vs_oracle(hal, oracle_bin, tmp_path, seed):
+    al, img = _rand(hal, tmp_path, seed, dna=True)
+    for name in ("Genome_0", "Genome_1", "Genome_2", al.genome_name(al.num_genomes - 1)):
+        g = al.genome_id(name)
+        assert al.maf_export(g) == _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", name), name
+    leaf = al.genome_name(al.num_genomes - 1)
+    g = al.genome_id(leaf)
+    assert al.maf_export(g, no_ancestors=True) == _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", leaf, "--noAncestors")
+    assert al.maf_export(g, no_dupes=True) == _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", leaf, "--noDupes")
+    assert al.maf_export(g, only_orthologs=True, only_sequence_names=True, max_block_len=50) == \
+        _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", leaf, "--onlyOrthologs", "--onlySequenceNames", "--maxBlockLen", "50")
+    assert al.maf_export(g, targets=[0, 2]) == _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", leaf, "--targetGenomes",
+                                                        "Genome_0,Genome_2")
+
+
+def test_maf_handbuilt_inversions(hal, oracle_bin, tmp_path):
+    img = str(tmp_path / "hand.hgx")
+    halfix.write_hgx(img, hb.genomes())
+    al = hal.Alignment.open(img, device=0)
+    for g in range(al.num_genomes):
+        assert al.maf_export(g) == _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", al.genome_name(g)), al.genome_name(g)
+
+
+def test_depth_properties_at_scale(hal):
+    """2 M columns on a 10-genome alignment: depth is bounded by the genome count, countDupes >= unique count,
+    restricting targets never raises the count, and results are deterministic."""
+    o = hal.RandOptions(mean_degree=1.5, max_branch_length=3.0, min_genomes=2, max_genomes=10, min_segment_length=50,
+                        max_segment_length=200, min_segments=20000, max_segments=40000, seed=2, with_dna=False)
+    al = hal.Alignment.random(o, device=0)
+    g = al.genome_id("Genome_9")
+    n = min(2000000, al.genome_length(g))
+    d = al.columns_depth(g, 0, n)
+    dd = al.columns_depth(g, 0, n, count_dupes=True)
+    dt = al.columns_depth(g, 0, n, targets=[al.genome_id("Genome_2"), al.genome_id("Genome_8")])
+    assert d.min() >= 0 and d.max() <= al.num_genomes - 1 and np.all(dd >= d) and np.all(dt <= d)
+    assert np.array_equal(d, al.columns_depth(g, 0, n)) and d.max() > 3
+    assert np.array_equal(al.columns_depth(g, 0, n, step=1)[::5][: n // 5], al.columns_depth(g, 0, n // 5, step=5))
