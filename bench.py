@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="genome size multiplier (1.0 = ~100 Mb/genome)")
     ap.add_argument("--target", default="Genome_2")
     ap.add_argument("--cpu-sample", type=int, default=300000, help="intervals timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--columns", type=int, default=1, help="also time the column-depth kernel over the whole source genome (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -182,6 +183,16 @@ def main():
             "counts_per_step": {"queries": Q, "source_pieces": st["source_pieces"], "top_derefs": T, "bottom_derefs": B,
                                 "mapped_pieces": st["mapped_pieces"], "records": R, "deferred_queries": st["deferred_queries"]},
         }
+        if args.columns:
+            # secondary metric of BASELINE.json ("MAF columns/sec"): halAlignmentDepth's per-column closure over the whole
+            # source genome (ColumnIterator path), device-resident output, kernel time from HIP events
+            ncol = al.genome_length(src)
+            dcol = torch.empty(ncol, dtype=torch.int32, device=dev)
+            al.columns_depth_device(src, 0, ncol, dcol.data_ptr())
+            col_ms = min(al.columns_depth_device(src, 0, ncol, dcol.data_ptr()) for _ in range(3))
+            out["columns"] = {"metric": "alignment-depth columns/sec (ColumnIterator closure per reference base)",
+                              "value": ncol / (col_ms * 1e-3), "unit": "columns/s", "columns": ncol, "kernel_ms": col_ms,
+                              "reference_genome": src_name, "mean_depth": float(dcol.float().mean().item())}
         if args.cpu_sample > 0:
             sample = min(args.cpu_sample, nq)
             cst, text = cpu_baseline(al, src_name, tgt_name, starts, lens, strand, seq_name, sample)

@@ -1,0 +1,145 @@
+// hal2maf — command-line twin of the reference tool (maf/impl/hal2maf.cpp:18-279) for the options the column
+// engine implements; columns come from the GPU through libhgx.
+#include "../hgx_columns_host.hpp"
+#include <cstring>
+#include <fstream>
+#include <iostream>
+
+static std::vector<std::string> chop(const std::string &s, char sep) {
+    std::vector<std::string> out;
+    size_t a = 0, b;
+    while ((b = s.find(sep, a)) != std::string::npos) {
+        out.push_back(s.substr(a, b - a));
+        a = b + 1;
+    }
+    if (a < s.size())
+        out.push_back(s.substr(a));
+    return out;
+}
+
+int main(int argc, char **argv) {
+    std::vector<std::string> pos;
+    std::string refGenomeName, refSequenceName, rootGenomeName, targetGenomes;
+    int64_t start = 0, length = 0, maxBlockLen = 1000, maxRefGap = 0;
+    bool noDupes = false, noAncestors = false, onlySequenceNames = false, unique = false, append = false, onlyOrthologs = false,
+         keepEmptyRefBlocks = false;
+    int device = 0;
+    try {
+        for (int i = 1; i < argc; ++i) {
+            std::string a = argv[i];
+            auto val = [&]() -> std::string {
+                if (i + 1 >= argc)
+                    throw std::runtime_error("missing value for " + a);
+                return argv[++i];
+            };
+            if (a == "--refGenome") refGenomeName = val();
+            else if (a == "--refSequence") refSequenceName = val();
+            else if (a == "--rootGenome") rootGenomeName = val();
+            else if (a == "--targetGenomes") targetGenomes = val();
+            else if (a == "--start") start = atoll(val().c_str());
+            else if (a == "--length") length = atoll(val().c_str());
+            else if (a == "--maxBlockLen") maxBlockLen = atoll(val().c_str());
+            else if (a == "--maxRefGap") maxRefGap = atoll(val().c_str());
+            else if (a == "--device") device = atoi(val().c_str());
+            else if (a == "--noDupes") noDupes = true;
+            else if (a == "--noAncestors") noAncestors = true;
+            else if (a == "--onlySequenceNames") onlySequenceNames = true;
+            else if (a == "--unique") unique = true;
+            else if (a == "--append") append = true;
+            else if (a == "--onlyOrthologs") onlyOrthologs = true;
+            else if (a == "--keepEmptyRefBlocks") keepEmptyRefBlocks = true;
+            else if (a == "--refTargets" || a == "--global" || a == "--printTree")
+                throw std::runtime_error(a + " is not built in this implementation");
+            else if (a.rfind("--", 0) == 0) throw std::runtime_error("unknown option " + a);
+            else pos.push_back(a);
+        }
+        if (pos.size() != 2)
+            throw std::runtime_error("Too few (or many) arguments");
+    } catch (std::exception &e) {
+        std::cerr << e.what() << "\nusage: hal2maf [options] <halFile> <mafFile|stdout>" << std::endl;
+        return 1;
+    }
+    hgx_alignment *h = nullptr;
+    int rc = 0;
+    try {
+        char *err = nullptr;
+        if (hgx_open(pos[0].c_str(), device, &h, &err) != HGX_OK) {
+            std::string m = err ? err : "open failed";
+            hgx_free(err);
+            throw std::runtime_error(m);
+        }
+        if (hgx_num_genomes(h) == 0)
+            throw std::runtime_error("hal alignment is empty");
+        std::set<int> targetSet;
+        if (!rootGenomeName.empty()) { // hal2maf.cpp:124-131
+            int rg = hgx_genome_id(h, rootGenomeName.c_str());
+            if (rg < 0)
+                throw std::runtime_error("Root genome " + rootGenomeName + ", not found in alignment");
+            if (hgx_genome_parent(h, rg) >= 0) {
+                std::vector<int> st(1, rg);
+                while (!st.empty()) {
+                    int g = st.back();
+                    st.pop_back();
+                    targetSet.insert(g);
+                    for (int k = 0; k < hgx_genome_num_children(h, g); ++k)
+                        st.push_back(hgx_genome_child(h, g, k));
+                }
+            }
+        }
+        for (const std::string &n : chop(targetGenomes, ',')) {
+            int g = hgx_genome_id(h, n.c_str());
+            if (g < 0)
+                throw std::runtime_error("Target genome, " + n + ", not found in alignment");
+            targetSet.insert(g);
+        }
+        int ref = 0;
+        if (!refGenomeName.empty()) {
+            ref = hgx_genome_id(h, refGenomeName.c_str());
+            if (ref < 0)
+                throw std::runtime_error("Reference genome, " + refGenomeName + ", not found in alignment");
+        } else {
+            for (int g = 0; g < hgx_num_genomes(h); ++g)
+                if (hgx_genome_parent(h, g) < 0)
+                    ref = g;
+        }
+        if (noAncestors && hgx_genome_num_children(h, ref) != 0)
+            throw std::runtime_error(std::string("Since the reference genome to be used for the MAF is ancestral (") +
+                                     hgx_genome_name(h, ref) + "), the --noAncestors option is invalid.  The --refGenome option can be "
+                                     "used to specify a different reference.");
+        int refSeq = -1;
+        if (!refSequenceName.empty()) {
+            refSeq = hgx_sequence_lookup(h, ref, refSequenceName.c_str(), nullptr, nullptr);
+            if (refSeq < 0)
+                throw std::runtime_error("Reference sequence, " + refSequenceName + ", not found in reference genome, " +
+                                         hgx_genome_name(h, ref));
+        }
+        std::ofstream mafFile;
+        if (pos[1] != "stdout") {
+            mafFile.open(pos[1].c_str(), append ? std::ios::out | std::ios::app : std::ios::out);
+            if (!mafFile)
+                throw std::runtime_error("Error opening " + pos[1]);
+        }
+        std::ostream &mafStream = pos[1] != "stdout" ? mafFile : std::cout;
+        hgx::MafExport me;
+        me.setMaxRefGap(maxRefGap);
+        me.setNoDupes(noDupes);
+        me.setNoAncestors(noAncestors);
+        me.setUcscNames(!onlySequenceNames);
+        me.setUnique(unique);
+        me.setAppend(append);
+        me.setMaxBlockLength(maxBlockLen);
+        me.setOnlyOrthologs(onlyOrthologs);
+        me.setKeepEmptyRefBlocks(keepEmptyRefBlocks);
+        if (refSeq >= 0) {
+            me.convertSequence(mafStream, h, ref, refSeq, start, length, targetSet);
+        } else {
+            for (int s = 0; s < hgx_genome_num_sequences(h, ref); ++s)
+                me.convertSequence(mafStream, h, ref, s, start, length, targetSet);
+        }
+    } catch (std::exception &e) {
+        std::cerr << "hal exception caught: " << e.what() << std::endl;
+        rc = 1;
+    }
+    hgx_close(h);
+    return rc;
+}
