@@ -420,33 +420,10 @@ __device__ __forceinline__ void write_records(const FinishStore<C> &S, int nl, i
 
 // ---------------------------------------------------------------------------------------------
 // Size classes.  Most intervals map to a handful of pieces; those are finished in registers by a sub-wave
-// group of G lanes (k_finish_fast), G the smallest of 8/16/32/64 that holds them.  Larger ones, and any interval
-// whose pieces overlap or tie on the target (the cases that need overlap breaking / equivalence classes), go to
-// the general LDS kernel through `generalList`.
-enum { CLS_8 = 0, CLS_16 = 1, CLS_32 = 2, CLS_64 = 3, CLS_GENERAL = 4, CLS_COUNT = 5 };
-
-__global__ void __launch_bounds__(256) k_classify(const uint32_t *__restrict__ count, uint32_t nq, uint32_t *__restrict__ lists /* [CLS_COUNT][nq] */,
-                                                  unsigned long long *__restrict__ listCount /* [CLS_COUNT] */, uint32_t *__restrict__ nOut) {
-    const uint32_t wavesTotal = (gridDim.x * blockDim.x) >> 6;
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    for (uint32_t base = wave * 64; base < nq; base += wavesTotal * 64) {
-        const uint32_t q = base + lane_id();
-        int cls = -1;
-        if (q < nq) {
-            const uint32_t n = count[q];
-            if (n == 0)
-                nOut[q] = 0;
-            else
-                cls = n <= 8 ? CLS_8 : n <= 16 ? CLS_16 : n <= 32 ? CLS_32 : n <= 64 ? CLS_64 : CLS_GENERAL;
-        }
-        for (int c = 0; c < CLS_COUNT; ++c) {
-            const unsigned long long slot = wave_append(&listCount[c], cls == c);
-            if (cls == c)
-                lists[(size_t)c * nq + slot] = q;
-        }
-    }
-}
-
+// group of G lanes (k_finish_fast<G>), G the smallest of 8/16/32/64 that holds them: each instantiation scans
+// all intervals and handles the ones of its class.  Larger intervals, and any interval whose pieces overlap or
+// tie on the target (the cases that need overlap breaking / equivalence classes), are appended to `generalList`
+// for the general LDS kernel.
 // bitonic sort of one 64-bit key per lane inside aligned groups of G lanes (ascending), shuffles only
 template <int G> __device__ __forceinline__ unsigned long long group_sort(unsigned long long key, int li) {
 #pragma unroll
@@ -472,12 +449,11 @@ template <int G> __device__ __forceinline__ unsigned long long group_sort(unsign
 // (liftover/impl/halLiftover.cpp:90).  One sub-wave group of G lanes per interval, one piece per lane.
 template <typename C, int G>
 __global__ void __launch_bounds__(256) k_finish_fast(Mapped in, const uint32_t *__restrict__ offset, const uint32_t *__restrict__ count,
-                                                     const uint32_t *__restrict__ qlist, const unsigned long long *__restrict__ qcount,
-                                                     const int64_t *__restrict__ seqStart, int numSeq, hgx_record *__restrict__ records,
-                                                     uint32_t *__restrict__ nOut, uint32_t *__restrict__ generalList,
-                                                     unsigned long long *__restrict__ generalCount) {
+                                                     uint32_t nq, const int64_t *__restrict__ seqStart, int numSeq,
+                                                     hgx_record *__restrict__ records, uint32_t *__restrict__ nOut,
+                                                     uint32_t *__restrict__ generalList, unsigned long long *__restrict__ generalCount) {
     constexpr int PER_WAVE = 64 / G;
-    const uint32_t nlist = (uint32_t)*qcount;
+    const uint32_t nlist = nq;
     const uint32_t wavesTotal = (gridDim.x * blockDim.x) >> 6;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = lane_id();
@@ -486,15 +462,28 @@ __global__ void __launch_bounds__(256) k_finish_fast(Mapped in, const uint32_t *
     const unsigned long long gmask = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << gbase;
     const unsigned long long INF = ~0ull;
     for (uint32_t wbase = wave * PER_WAVE; wbase < nlist; wbase += wavesTotal * PER_WAVE) {
-        const uint32_t k = wbase + (uint32_t)(lane / G);
-        const bool gvalid = k < nlist;
-        uint32_t q = 0, base = 0;
+        const uint32_t q = wbase + (uint32_t)(lane / G);
+        bool gvalid = q < nlist;
+        uint32_t base = 0;
         int n = 0;
         if (gvalid) {
-            q = qlist[k];
             n = (int)count[q];
-            base = offset[q];
+            // this instantiation owns the intervals whose piece count needs exactly G lanes
+            const bool mine = G == 8 ? n <= 8 : (n > G / 2 && n <= G);
+            if (G == 8 && n == 0 && li == 0)
+                nOut[q] = 0;
+            if (G == 64 && n > 64 && li == 0) { // too many pieces for a wavefront: general path
+                const unsigned long long slot = atomicAdd(generalCount, 1ull);
+                generalList[slot] = q;
+            }
+            gvalid = mine && n > 0;
+            if (gvalid)
+                base = offset[q];
+            else
+                n = 0;
         }
+        if (!__any(gvalid))
+            continue; // no interval of this class among this wavefront's candidates
         const bool have = li < n;
         int64_t tLo = 0, tHi = 0, sLo = 0, sHi = 0;
         uint8_t fl = 0;

@@ -298,8 +298,8 @@ struct hgx_liftover_plan {
         deferredList.ensure(4 * (nq + 1));
         needCap.ensure(4 * (nq + 1));
         bigSlot.ensure(4 * (nq + 1));
-        classLists.ensure(4 * (size_t)CLS_COUNT * (nq + 1));
-        classCounts.ensure(8 * CLS_COUNT);
+        classLists.ensure(4 * (nq + 1));
+        classCounts.ensure(16);
     }
 };
 
@@ -333,8 +333,8 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
     int launch = 0; // per-launch deref counter slot
     auto kstat = [&]() { return cnt + CNT_KSTAT0 + 2 * launch; };
     int cur = 0; // frontier buffer holding the current pieces
-    auto inCnt = [&]() { return cnt + CNT_FRONT0 + level; };
-    auto outCnt = [&]() { return cnt + CNT_FRONT0 + level + 1; };
+    auto inCnt = [&]() { return cnt + CNT_FRONT0 + (size_t)level * NSEG; };
+    auto outCnt = [&]() { return cnt + CNT_FRONT0 + (size_t)(level + 1) * NSEG; };
     const int64_t minLen = P.opts.min_length;
 
     // stage 0
@@ -429,29 +429,23 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
 
     exclusiveScan(P, (const uint32_t *)P.perQuery.p, nq, (uint32_t *)P.offset.p, (uint32_t *)P.total.p, s);
     P.timer.begin("k_scatter", s);
-    hipLaunchKernelGGL(k_scatter, dim3(GRID), dim3(256), 0, s, P.mapped(0), inCnt(), cap, (const uint32_t *)P.offset.p,
+    hipLaunchKernelGGL(k_scatter, dim3(GRID), dim3(256), 0, s, P.mapped(0), cnt + CNT_MAPPED, cap, (const uint32_t *)P.offset.p,
                        (uint32_t *)P.cursor.p, P.mapped(1));
     P.timer.end(s);
-    // finishing: classify by piece count, register-resident fast path per class, general LDS path for the rest
-    uint32_t *lists = (uint32_t *)P.classLists.p;
-    unsigned long long *listCount = (unsigned long long *)P.classCounts.p;
-    HIP_OK(hipMemsetAsync(listCount, 0, 8 * CLS_COUNT, s));
-    P.timer.begin("k_classify", s);
-    hipLaunchKernelGGL(k_classify, dim3(GRID), dim3(256), 0, s, (const uint32_t *)P.perQuery.p, nq, lists, listCount,
-                       (uint32_t *)P.nOut.p);
-    P.timer.end(s);
-    uint32_t *generalList = lists + (size_t)CLS_GENERAL * nq;
-    unsigned long long *generalCount = listCount + CLS_GENERAL;
+    // finishing: register-resident fast path per size class (each kernel picks the intervals of its class),
+    // general LDS path for the rest
+    uint32_t *generalList = (uint32_t *)P.classLists.p;
+    unsigned long long *generalCount = (unsigned long long *)P.classCounts.p;
+    HIP_OK(hipMemsetAsync(generalCount, 0, 8, s));
     P.timer.begin("k_finish_fast", s);
-#define HGX_FAST(G, CLS)                                                                                               \
+#define HGX_FAST(G)                                                                                                    \
     hipLaunchKernelGGL((k_finish_fast<C, G>), dim3(GRID), dim3(256), 0, s, P.mapped(1), (const uint32_t *)P.offset.p,  \
-                       (const uint32_t *)P.perQuery.p, (const uint32_t *)(lists + (size_t)CLS * nq),                  \
-                       (const unsigned long long *)(listCount + CLS), (const int64_t *)TG.seqStart, (int)TG.numSeq,    \
+                       (const uint32_t *)P.perQuery.p, nq, (const int64_t *)TG.seqStart, (int)TG.numSeq,               \
                        (hgx_record *)P.grouped.p, (uint32_t *)P.nOut.p, generalList, generalCount)
-    HGX_FAST(8, CLS_8);
-    HGX_FAST(16, CLS_16);
-    HGX_FAST(32, CLS_32);
-    HGX_FAST(64, CLS_64);
+    HGX_FAST(8);
+    HGX_FAST(16);
+    HGX_FAST(32);
+    HGX_FAST(64);
 #undef HGX_FAST
     P.timer.end(s);
     P.timer.begin("k_finish_lds", s);
@@ -477,7 +471,8 @@ static void runPlan(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
         throw std::runtime_error("batch larger than the plan's max_queries");
     if (n >= ((size_t)1 << 31))
         throw std::runtime_error("batch of 2^31 or more intervals; split it");
-    unsigned long long hc[CNT_SLOTS];
+    std::vector<unsigned long long> hcv(CNT_SLOTS);
+    unsigned long long *hc = hcv.data();
     const DeviceImage &D = *P.h->dev;
     HIP_OK(hipSetDevice(D.device));
     P.stats = hgx_liftover_stats{};
@@ -492,8 +487,14 @@ static void runPlan(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
             break;
         // a frontier outgrew the workspace: size it from the largest count seen and run again
         unsigned long long need = 0;
-        for (int k = CNT_FRONT0; k < CNT_FRONT0 + MAX_LEVELS; ++k)
-            need = std::max(need, hc[k]);
+        for (int lv = 0; lv < MAX_LEVELS; ++lv) {
+            unsigned long long tot = 0, mx = 0;
+            for (int sgm = 0; sgm < NSEG; ++sgm) {
+                tot += hc[CNT_FRONT0 + lv * NSEG + sgm];
+                mx = std::max(mx, hc[CNT_FRONT0 + lv * NSEG + sgm]);
+            }
+            need = std::max(need, std::max(tot, mx * NSEG)); // the fullest segment sets the capacity
+        }
         need = std::max<unsigned long long>(need + need / 4, 2ull * P.cap);
         if (need >= (1ull << 32))
             throw std::runtime_error("liftover batch expands to more than 2^32 pieces; submit smaller batches");
@@ -596,7 +597,7 @@ hgx_liftover_plan *createLiftoverPlan(hgx_alignment *h, int src, int tgt, const 
         P->down.emplace_back(parent, slot);
         parent = chain[k];
     }
-    if ((int)(P->up.size() + 2 * P->down.size()) + 3 >= MAX_LEVELS || (int)(P->up.size() + 2 * P->down.size()) + 3 >= MAX_LAUNCHES)
+    if ((int)(P->up.size() + 2 * P->down.size()) + 3 >= MAX_LEVELS - 1 || (int)(P->up.size() + 2 * P->down.size()) + 3 >= MAX_LAUNCHES)
         throw std::runtime_error("tree path between the genomes is too long for the counter block");
     // BlockLiftover::visitBegin (halBlockLiftover.cpp:24-30): walk the source through its top tiling when it has one
     P->srcTop = img.genomes[(size_t)src].numTop > 0;

@@ -39,16 +39,17 @@ enum {
     CNT_OVERFLOW = 0, // set when any append ran past capacity
     CNT_TOP_DEREF = 1,
     CNT_BOT_DEREF = 2,
-    CNT_SRC_PIECES = 3,
-    CNT_MAPPED = 4,
+    CNT_SRC_PIECES = 4,
     CNT_DEFERRED = 5,
     CNT_MAXNEED = 6,
     CNT_BIGFAIL = 7,
-    CNT_FRONT0 = 8,    // + level: element count of the frontier after each step (up to MAX_LEVELS)
-    MAX_LEVELS = 200,
-    CNT_KSTAT0 = 208,  // + 2*launch: {top, bottom} segment records dereferenced by that launch
+    CNT_MAPPED = 3,    // pieces in the final frontier (written by k_finalize)
+    NSEG = 64,         // independent append segments per frontier (one counter word each)
+    CNT_FRONT0 = 8,    // + level*NSEG + segment: pieces appended to that segment of the level's frontier
+    MAX_LEVELS = 120,
+    CNT_KSTAT0 = CNT_FRONT0 + MAX_LEVELS * NSEG, // + 2*launch: {top, bottom} segment records dereferenced by that launch
     MAX_LAUNCHES = 152,
-    CNT_SLOTS = 512
+    CNT_SLOTS = CNT_KSTAT0 + 2 * MAX_LAUNCHES
 };
 
 __device__ __forceinline__ int lane_id() {
@@ -95,7 +96,9 @@ __device__ __forceinline__ void put(const Frontier &f, unsigned long long slot, 
 // first profile of this path was bound by exactly that.  Each wavefront therefore compacts its emitted
 // pieces (ballot + popcount prefix) into a private LDS window and only when the window is nearly full
 // reserves a contiguous range of the global frontier with ONE atomic and copies the window out with
-// coalesced stores.  Order inside a frontier is irrelevant (the result is re-grouped by query later).
+// coalesced stores.  The frontier itself is split into NSEG independent segments (block b appends to segment
+// b mod NSEG, each with its own counter word), so the remaining atomics spread over 64 addresses instead of
+// serialising on one.  Order inside a frontier is irrelevant (the result is re-grouped by query later).
 static constexpr int STAGE_CAP = 192;   // pieces per wavefront window (4 waves x 192 x 25 B = 19 KB per block)
 static constexpr int STAGE_FLUSH = STAGE_CAP - 64;
 
@@ -119,18 +122,22 @@ struct Stage {
     int base;  // this wave's window inside the block's StageMem
     int count; // wave-uniform
     Frontier out;
-    unsigned long long *outCount;
+    unsigned long long *outCount; // this block's segment counter
     unsigned long long *counters;
-    uint32_t cap;
+    uint32_t segCap;              // capacity of one segment
+    unsigned long long segBase;   // first slot of this block's segment
 
+    // oc: the NSEG counters of the output frontier; cp: total capacity of the frontier buffers
     __device__ __forceinline__ void init(StageMem *mem, const Frontier &o, unsigned long long *oc, unsigned long long *c, uint32_t cp) {
         m = mem;
         base = (int)(threadIdx.x >> 6) * STAGE_CAP;
         count = 0;
         out = o;
-        outCount = oc;
+        const uint32_t seg = blockIdx.x % NSEG;
+        outCount = oc + seg;
         counters = c;
-        cap = cp;
+        segCap = cp / NSEG;
+        segBase = (unsigned long long)seg * segCap;
     }
     __device__ __forceinline__ void flush() {
         wave_lds_fence();
@@ -142,8 +149,9 @@ struct Stage {
                 b = atomicAdd(outCount, (unsigned long long)n);
             b = __shfl(b, 0);
             for (int i = lane; i < n; i += 64) {
-                const unsigned long long slot = b + (unsigned long long)i;
-                if (slot < cap) {
+                const unsigned long long off = b + (unsigned long long)i;
+                const unsigned long long slot = segBase + off;
+                if (off < segCap) {
                     out.qid[slot] = m->qid[base + i];
                     out.sPos[slot] = m->sPos[base + i];
                     out.idx[slot] = m->idx[base + i];
@@ -177,6 +185,43 @@ struct Stage {
             flush();
     }
 };
+
+
+// Reading a segmented frontier: linear work index -> physical slot.  Each block scans the NSEG segment counts
+// once into LDS; a work item finds its segment by binary search over the 65 prefix sums.
+struct FrontView {
+    uint32_t prefix[NSEG + 1];
+};
+__device__ __forceinline__ uint32_t front_view_init(FrontView *v, const unsigned long long *segCount, uint32_t cap) {
+    const uint32_t segCap = cap / NSEG;
+    if (threadIdx.x < NSEG) {
+        const unsigned long long c = segCount[threadIdx.x];
+        v->prefix[threadIdx.x + 1] = (uint32_t)(c < segCap ? c : segCap);
+    }
+    if (threadIdx.x == 0)
+        v->prefix[0] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (int k = 1; k <= NSEG; ++k) {
+            acc += v->prefix[k];
+            v->prefix[k] = acc;
+        }
+    }
+    __syncthreads();
+    return v->prefix[NSEG];
+}
+__device__ __forceinline__ uint32_t front_slot(const FrontView *v, uint32_t i, uint32_t cap) {
+    int lo = 0, hi = NSEG; // prefix[lo] <= i < prefix[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (v->prefix[mid] <= i)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return (uint32_t)lo * (cap / NSEG) + (i - v->prefix[lo]);
+}
 
 // ---------------------------------------------------------------------------------------------
 // Stage 0: locate + expand.  BlockLiftover::liftInterval, liftover/impl/halBlockLiftover.cpp:46-72:
@@ -259,7 +304,8 @@ template <typename C>
 __global__ void __launch_bounds__(256) k_up_top(const TopRec<C> *__restrict__ top, Frontier in, const unsigned long long *inCount, uint32_t cap,
                                                 Frontier out, unsigned long long *outCount, int64_t minLength,
                                                 unsigned long long *counters, unsigned long long *kstat) {
-    const uint32_t n = (uint32_t)min((unsigned long long)cap, *inCount);
+    __shared__ FrontView fview;
+    const uint32_t n = front_view_init(&fview, inCount, cap);
     const uint32_t wavesTotal = (gridDim.x * blockDim.x) >> 6;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     uint32_t derefs = 0;
@@ -267,12 +313,13 @@ __global__ void __launch_bounds__(256) k_up_top(const TopRec<C> *__restrict__ to
     Stage stage;
     stage.init(&stageMem, out, outCount, counters, cap);
     for (uint32_t base = wave * 64; base < n; base += wavesTotal * 64) {
-        const uint32_t i = base + lane_id();
+        const uint32_t li = base + lane_id();
+        const uint32_t i = li < n ? front_slot(&fview, li, cap) : 0;
         bool emit = false;
         int32_t qid = 0, idx = 0, so = 0, len = 0;
         int64_t sPos = 0;
         uint8_t fl = 0;
-        if (i < n) {
+        if (li < n) {
             idx = in.idx[i];
             len = in.len[i];
             const int32_t enc = top[idx].parentEnc;
@@ -306,7 +353,8 @@ __global__ void __launch_bounds__(256) k_parse_up_then_up(const BotRec<C> *__res
                                                           const unsigned long long *inCount, uint32_t cap, Frontier out,
                                                           unsigned long long *outCount, int64_t minLength,
                                                           unsigned long long *counters, unsigned long long *kstat) {
-    const uint32_t n = (uint32_t)min((unsigned long long)cap, *inCount);
+    __shared__ FrontView fview;
+    const uint32_t n = front_view_init(&fview, inCount, cap);
     const uint32_t wavesTotal = (gridDim.x * blockDim.x) >> 6;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     uint32_t topDerefs = 0, botDerefs = 0;
@@ -314,8 +362,9 @@ __global__ void __launch_bounds__(256) k_parse_up_then_up(const BotRec<C> *__res
     Stage stage;
     stage.init(&stageMem, out, outCount, counters, cap);
     for (uint32_t base = wave * 64; base < n; base += wavesTotal * 64) {
-        const uint32_t i = base + lane_id();
-        bool act = i < n;
+        const uint32_t li = base + lane_id();
+        const uint32_t i = li < n ? front_slot(&fview, li, cap) : 0;
+        bool act = li < n;
         int32_t qid = 0;
         int64_t sPos = 0, lo = 0, hi = -1;
         uint8_t fl = 0;
@@ -403,7 +452,8 @@ __global__ void __launch_bounds__(256) k_down_ring(const int32_t *__restrict__ c
                                                    const unsigned long long *inCount, uint32_t cap, Frontier out,
                                                    unsigned long long *outCount, int64_t minLength, int doDupes,
                                                    unsigned long long *counters, unsigned long long *kstat) {
-    const uint32_t n = (uint32_t)min((unsigned long long)cap, *inCount);
+    __shared__ FrontView fview;
+    const uint32_t n = front_view_init(&fview, inCount, cap);
     const uint32_t wavesTotal = (gridDim.x * blockDim.x) >> 6;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     uint32_t topDerefs = 0, botDerefs = 0;
@@ -411,12 +461,13 @@ __global__ void __launch_bounds__(256) k_down_ring(const int32_t *__restrict__ c
     Stage stage;
     stage.init(&stageMem, out, outCount, counters, cap);
     for (uint32_t base = wave * 64; base < n; base += wavesTotal * 64) {
-        const uint32_t i = base + lane_id();
+        const uint32_t li = base + lane_id();
+        const uint32_t i = li < n ? front_slot(&fview, li, cap) : 0;
         bool act = false;
         int32_t qid = 0, so = 0, len = 0, t0 = 0, cur = 0;
         int64_t sPos = 0;
         uint8_t fl = 0;
-        if (i < n) {
+        if (li < n) {
             const int32_t b = in.idx[i];
             len = in.len[i];
             const int32_t enc = childEnc[b];
@@ -477,7 +528,8 @@ __global__ void __launch_bounds__(256) k_parse_down(const TopRec<C> *__restrict_
                                                     const unsigned long long *inCount, uint32_t cap, Frontier out,
                                                     unsigned long long *outCount, unsigned long long *counters,
                                                     unsigned long long *kstat) {
-    const uint32_t n = (uint32_t)min((unsigned long long)cap, *inCount);
+    __shared__ FrontView fview;
+    const uint32_t n = front_view_init(&fview, inCount, cap);
     const uint32_t wavesTotal = (gridDim.x * blockDim.x) >> 6;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     uint32_t topDerefs = 0, botDerefs = 0;
@@ -485,8 +537,9 @@ __global__ void __launch_bounds__(256) k_parse_down(const TopRec<C> *__restrict_
     Stage stage;
     stage.init(&stageMem, out, outCount, counters, cap);
     for (uint32_t base = wave * 64; base < n; base += wavesTotal * 64) {
-        const uint32_t i = base + lane_id();
-        bool act = i < n;
+        const uint32_t li = base + lane_id();
+        const uint32_t i = li < n ? front_slot(&fview, li, cap) : 0;
+        bool act = li < n;
         int32_t qid = 0;
         int64_t sPos = 0, lo = 0, hi = -1;
         uint8_t fl = 0;
@@ -558,14 +611,16 @@ template <typename REC>
 __global__ void __launch_bounds__(256) k_finalize(const REC *__restrict__ segs, Frontier in, const unsigned long long *inCount, uint32_t cap,
                                                   Mapped out, uint32_t *__restrict__ perQuery, unsigned long long *counters,
                                                   unsigned long long *kstat, int isTop) {
-    const uint32_t n = (uint32_t)min((unsigned long long)cap, *inCount);
+    __shared__ FrontView fview;
+    const uint32_t n = front_view_init(&fview, inCount, cap);
     uint32_t derefs = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int32_t idx = in.idx[i];
-        const int32_t so = in.so[i], len = in.len[i];
-        const uint8_t fl = in.flags[i];
-        const int64_t sPos = in.sPos[i];
-        const int32_t q = in.qid[i];
+        const uint32_t p = front_slot(&fview, i, cap);
+        const int32_t idx = in.idx[p];
+        const int32_t so = in.so[p], len = in.len[p];
+        const uint8_t fl = in.flags[p];
+        const int64_t sPos = in.sPos[p];
+        const int32_t q = in.qid[p];
         int64_t lo;
         if (!(fl & F_TREV))
             lo = (int64_t)segs[idx].start + so;
@@ -593,7 +648,7 @@ __global__ void __launch_bounds__(256) k_finalize(const REC *__restrict__ segs, 
 // group pieces by query: slot = offset[q] + cursor[q]++
 __global__ void __launch_bounds__(256) k_scatter(Mapped in, const unsigned long long *inCount, uint32_t cap, const uint32_t *__restrict__ offset,
                                                  uint32_t *__restrict__ cursor, Mapped out) {
-    const uint32_t n = (uint32_t)min((unsigned long long)cap, *inCount);
+    const uint32_t n = (uint32_t)min((unsigned long long)cap, *inCount); // CNT_MAPPED: dense count written by k_finalize
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int32_t q = in.qid[i];
         const uint32_t s = offset[q] + atomicAdd(&cursor[q], 1u);
