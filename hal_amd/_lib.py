@@ -15,7 +15,7 @@ class hgx_interval(C.Structure):
 
 class hgx_record(C.Structure):
     _fields_ = [("query", C.c_int64), ("tgt_start", C.c_int64), ("tgt_end", C.c_int64), ("src_start", C.c_int64),
-                ("tgt_seq", C.c_int32), ("strand", C.c_char), ("_pad", C.c_char * 3)]
+                ("tgt_seq", C.c_int32), ("strand", C.c_char), ("tgt_reversed", C.c_uint8), ("_pad", C.c_char * 2)]
 
 
 class hgx_liftover_opts(C.Structure):

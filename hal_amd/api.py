@@ -10,7 +10,7 @@ from ._lib import (lib, HgxError, hgx_interval, hgx_record, hgx_liftover_opts, h
                    hgx_column_row, hgx_maf_opts, take_error)
 
 RECORD_DTYPE = np.dtype([("query", "<i8"), ("tgt_start", "<i8"), ("tgt_end", "<i8"), ("src_start", "<i8"),
-                         ("tgt_seq", "<i4"), ("strand", "S1"), ("_pad", "S3")])
+                         ("tgt_seq", "<i4"), ("strand", "S1"), ("tgt_reversed", "u1"), ("_pad", "S2")])
 assert RECORD_DTYPE.itemsize == C.sizeof(hgx_record) == 40
 INTERVAL_DTYPE = np.dtype([("start", "<i8"), ("end", "<i8"), ("seq", "<i4"), ("strand", "S1"), ("_pad", "S3")])
 assert INTERVAL_DTYPE.itemsize == C.sizeof(hgx_interval) == 24

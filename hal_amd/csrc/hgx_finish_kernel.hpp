@@ -365,7 +365,8 @@ __device__ __forceinline__ int finish_query(FinishStore<C> &S, const Mapped &in,
             S.lEnd[nl] = a1 + 1;
             S.lSrc[nl] = S.sLo[i] < S.sLo[fragBack] ? S.sLo[i] : S.sLo[fragBack];
             S.lSeq[nl] = S.seq[i];
-            S.lStrand[nl] = (S.fl[i] & F_DOT) ? '.' : ((S.fl[i] & F_TREV) ? '-' : '+');
+            // strand character in the low 7 bits, the piece's own orientation in bit 7
+            S.lStrand[nl] = (uint8_t)(((S.fl[i] & F_DOT) ? '.' : ((S.fl[i] & F_TREV) ? '-' : '+')) | ((S.fl[i] & F_TREV) ? 0x80 : 0));
             ++nl;
         }
         S.ord[0] = (uint32_t)nl;
@@ -411,8 +412,9 @@ __device__ __forceinline__ void write_records(const FinishStore<C> &S, int nl, i
         r.tgt_end = (int64_t)S.lEnd[o] - ss;
         r.src_start = (int64_t)S.lSrc[o];
         r.tgt_seq = s;
-        r.strand = (char)S.lStrand[o];
-        r._pad[0] = r._pad[1] = r._pad[2] = 0;
+        r.strand = (char)(S.lStrand[o] & 0x7F);
+        r.tgt_reversed = (uint8_t)(S.lStrand[o] >> 7);
+        r._pad[0] = r._pad[1] = 0;
         dst[k] = r;
     }
 }
@@ -563,7 +565,8 @@ __global__ void __launch_bounds__(256) k_finish_fast(Mapped in, const uint32_t *
             r.src_start = oSrc;
             r.tgt_seq = oSeq;
             r.strand = (oFl & F_DOT) ? '.' : ((oFl & F_TREV) ? '-' : '+');
-            r._pad[0] = r._pad[1] = r._pad[2] = 0;
+            r.tgt_reversed = (oFl & F_TREV) ? 1 : 0;
+            r._pad[0] = r._pad[1] = 0;
             records[base + li] = r;
         }
         if (doGroup && li == 0)

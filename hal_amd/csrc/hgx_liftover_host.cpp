@@ -1,4 +1,6 @@
 #include "hgx_liftover_host.hpp"
+#include <algorithm>
+#include <climits>
 #include <iostream>
 #include <sstream>
 #include <unordered_map>
@@ -64,9 +66,25 @@ void BedLine::parse(const std::string &lineBuffer, int type) {
         if (rgb.size() == 3)
             itemB = strToInt(rgb[2]);
     }
-    if (bedType > 9)
-        throw std::runtime_error("BED12 block lifting (and PSL output) is not built yet; use --bedType 9 or fewer columns: " +
-                                 lineBuffer);
+    if (bedType > 9) {
+        if (bedType < 12)
+            throw std::runtime_error("Error parsing BED, insufficient columns for blocks: " + lineBuffer);
+        const size_t numBlocks = (size_t)strToInt(row[9]);
+        std::vector<std::string> sizes, starts;
+        chopString(row[10], ',', sizes);
+        if (sizes.size() != numBlocks)
+            throw std::runtime_error("Error parsing BED blockSizes: " + lineBuffer);
+        chopString(row[11], ',', starts);
+        if (starts.size() != numBlocks)
+            throw std::runtime_error("Error parsing BED blockStarts: " + lineBuffer);
+        blocks.resize(numBlocks);
+        for (size_t i = 0; i < numBlocks; ++i) {
+            blocks[i].length = strToInt(sizes[i]);
+            blocks[i].start = strToInt(starts[i]);
+            if (start + blocks[i].start + blocks[i].length > end)
+                throw std::runtime_error("Error BED block out of range: " + lineBuffer);
+        }
+    }
     extra.clear();
     for (size_t i = (size_t)bedType; i < row.size(); i++)
         extra.push_back(row[i]);
@@ -86,15 +104,228 @@ void BedLine::write(std::ostream &os) const {
         os << '\t' << thickEnd;
     if (bedType > 8)
         os << '\t' << itemR << ',' << itemG << ',' << itemB;
+    if (bedType > 9) {
+        os << '\t' << blocks.size();
+        for (size_t i = 0; i < blocks.size(); ++i)
+            os << (i == 0 ? '\t' : ',') << blocks[i].length;
+        for (size_t i = 0; i < blocks.size(); ++i)
+            os << (i == 0 ? '\t' : ',') << blocks[i].start;
+    }
     for (const std::string &e : extra)
         os << '\t' << e;
     os << '\n';
 }
 
+void BedLine::expandToBed12() {
+    if (bedType <= 3)
+        name = "";
+    if (bedType <= 4)
+        score = 0;
+    if (bedType <= 5)
+        strand = '+';
+    if (bedType <= 6)
+        thickStart = start;
+    if (bedType <= 7)
+        thickEnd = end;
+    if (bedType <= 8)
+        itemR = itemG = itemB = 0;
+    if (bedType <= 9) {
+        blocks.resize(1);
+        blocks[0].start = 0;
+        blocks[0].length = end - start;
+    }
+    bedType = 12;
+}
+
+void BedLine::writePSL(std::ostream &os, bool prefixWithName) const {
+    if (!validatePSL())
+        throw std::runtime_error("Internal error: PSL does not validate");
+    const PSLInfo &p = psl[0];
+    if (prefixWithName)
+        os << name << '\t';
+    os << p.matches << '\t' << p.misMatches << '\t' << p.repMatches << '\t' << p.nCount << '\t' << p.qNumInsert << '\t' << p.qBaseInsert
+       << '\t' << p.tNumInsert << '\t' << p.tBaseInsert << '\t' << p.qStrand << strand << '\t' << p.qSeqName << '\t' << p.qSeqSize << '\t'
+       << (srcStart - (int64_t)p.qChromOffset) << '\t' << (p.qEnd - p.qChromOffset) << '\t' << chrName << '\t' << p.tSeqSize << '\t'
+       << start << '\t' << end << '\t' << blocks.size() << '\t';
+    for (const BedBlock &b : blocks)
+        os << b.length << ',';
+    os << '\t';
+    for (size_t i = 0; i < p.qBlockStarts.size(); ++i) {
+        int64_t s = p.qBlockStarts[i] - (int64_t)p.qChromOffset;
+        if (p.qStrand == '-')
+            s = (int64_t)p.qSeqSize - s - blocks[i].length;
+        os << s << ',';
+    }
+    os << '\t';
+    for (const BedBlock &b : blocks) {
+        int64_t s = b.start + start;
+        if (strand == '-')
+            s = (int64_t)p.tSeqSize - s - b.length;
+        os << s << ',';
+    }
+    os << '\n';
+}
+
+bool BedLine::validatePSL() const {
+    if (psl.size() != 1 || blocks.empty())
+        return false;
+    const PSLInfo &p = psl[0];
+    if (blocks.size() != p.qBlockStarts.size())
+        return false;
+    uint64_t tot = 0;
+    for (const BedBlock &b : blocks)
+        tot += (uint64_t)b.length;
+    if (tot != p.matches + p.misMatches + p.repMatches + p.nCount)
+        return false;
+    if (tot + p.qBaseInsert != p.qEnd - (uint64_t)srcStart)
+        return false;
+    if (tot + p.tBaseInsert != (uint64_t)end - (uint64_t)start)
+        return false;
+    if (strand != '-') {
+        if (blocks[0].start != 0 || blocks.back().start + blocks.back().length + start != end)
+            return false;
+    } else {
+        if (blocks.back().start != 0 || blocks[0].start + blocks[0].length + start != end)
+            return false;
+    }
+    if (p.qStrand != '-') {
+        if (p.qBlockStarts[0] != srcStart || (uint64_t)(p.qBlockStarts.back() + blocks.back().length) != p.qEnd)
+            return false;
+    } else {
+        if (p.qBlockStarts.back() != srcStart || (uint64_t)(p.qBlockStarts[0] + blocks[0].length) != p.qEnd)
+            return false;
+    }
+    return true;
+}
+
+// halLiftover.cpp:169-195
+bool Liftover::compatible(const BedLine &tgtBed, const BedLine &newBlock) const {
+    if (tgtBed.strand != newBlock.strand || tgtBed.srcStart == newBlock.srcStart)
+        return false;
+    const BedBlock &tb = tgtBed.blocks.back();
+    const int64_t delta = tgtBed.strand != _inStrand ? tb.start - newBlock.end : newBlock.start - (tb.start + tb.length);
+    return delta >= 0 && tgtBed.chrName == newBlock.chrName;
+}
+
+// halLiftover.cpp:197-234
+void Liftover::flipBlocks(std::vector<BedLine> &lines) const {
+    for (BedLine &b : lines) {
+        if (b.blocks.size() > 1) {
+            const int64_t delta = b.blocks[1].start - (b.blocks[0].start + b.blocks[0].length);
+            const bool mustFlip = !_outPSL ? delta < 0 : ((b.strand == '-' && delta >= 0) || (b.strand != '-' && delta < 0));
+            if (mustFlip) {
+                std::reverse(b.blocks.begin(), b.blocks.end());
+                if (_outPSL)
+                    std::reverse(b.psl[0].qBlockStarts.begin(), b.psl[0].qBlockStarts.end());
+            }
+        }
+    }
+}
+
+// halLiftover.cpp:236-290 (the iterator swaps of the reference written as index selection)
+void Liftover::computePSLInserts(std::vector<BedLine> &lines) const {
+    for (BedLine &bed : lines) {
+        PSLInfo &p = bed.psl[0];
+        p.qNumInsert = p.qBaseInsert = p.tNumInsert = p.tBaseInsert = 0;
+        for (size_t i = 1; i < bed.blocks.size(); ++i) {
+            // target gap: previous block in target order, then the next one
+            const BedBlock &tA = bed.strand == '-' ? bed.blocks[i] : bed.blocks[i - 1];
+            const BedBlock &tB = bed.strand == '-' ? bed.blocks[i - 1] : bed.blocks[i];
+            uint64_t gap = (uint64_t)(tB.start - (tA.start + tA.length));
+            if (gap > 0) {
+                ++p.tNumInsert;
+                p.tBaseInsert += gap;
+            }
+            // query gap
+            const size_t a = p.qStrand == '-' ? i : i - 1, b = p.qStrand == '-' ? i - 1 : i;
+            const int64_t qa = p.qBlockStarts[a], qb = p.qBlockStarts[b], la = bed.blocks[a].length;
+            gap = qb >= qa + la ? (uint64_t)(qb - (qa + la)) : 0; // duplicated blocks can overlap
+            if (gap > 0) {
+                ++p.qNumInsert;
+                p.qBaseInsert += gap;
+            }
+        }
+    }
+}
+
+// halLiftover.cpp:108-167; mappedBlocks arrive stably sorted by source start
+void Liftover::assignBlocksToIntervals(std::vector<BedLine> &mappedBlocks, std::vector<BedLine> &out) {
+    int64_t prevSrcBlockEnd = NULL_INDEX;
+    for (size_t k = 0; k < mappedBlocks.size(); ++k) {
+        BedLine &blk = mappedBlocks[k];
+        const int64_t srcBlockEnd = blk.srcStart + (blk.end - blk.start);
+        const bool dupe = blk.srcStart < prevSrcBlockEnd || (k + 1 < mappedBlocks.size() && mappedBlocks[k + 1].srcStart < srcBlockEnd);
+        if (out.empty() || (_outPSL && dupe) || !compatible(out.back(), blk))
+            out.push_back(blk);
+        prevSrcBlockEnd = srcBlockEnd;
+        BedLine &tgt = out.back();
+        tgt.start = std::min(tgt.start, blk.start);
+        tgt.end = std::max(tgt.end, blk.end);
+        tgt.blocks.push_back(BedBlock{blk.start, blk.end - blk.start}); // absolute for now
+        if (_outPSL) {
+            tgt.psl[0].qBlockStarts.push_back(blk.srcStart);
+            if (tgt.blocks.size() > 1) {
+                tgt.psl[0].matches += blk.psl[0].matches;
+                tgt.psl[0].misMatches += blk.psl[0].misMatches;
+                tgt.psl[0].repMatches += blk.psl[0].repMatches;
+                tgt.psl[0].nCount += blk.psl[0].nCount;
+            }
+        }
+    }
+    for (BedLine &b : out)
+        for (BedBlock &bb : b.blocks)
+            bb.start -= b.start;
+    if (!out.empty())
+        flipBlocks(out);
+    if (_outPSL)
+        computePSLInserts(out);
+}
+
+// BlockLiftover::readPSLInfo (halBlockLiftover.cpp:115-162).  A lifted line is a run of fragments that are
+// consecutive on both genomes (canMergeRightWith), so its base pairs follow one linear map: target offset d pairs
+// with source offset d (same relative strand) or len-1-d (opposite); each side is complemented when its iterator
+// is reversed.
+static void pslCounts(const GenomeTables &S, const GenomeTables &T, int64_t sLo, int64_t tLo, int64_t len, bool srcRev, bool tgtRev,
+                      PSLInfo &p) {
+    if (S.dna.empty() || T.dna.empty())
+        throw std::runtime_error("PSL output needs DNA, and this alignment image carries none");
+    auto comp = [](char c) {
+        switch (c) {
+        case 'A': return 'T';
+        case 'a': return 't';
+        case 'C': return 'G';
+        case 'c': return 'g';
+        case 'G': return 'C';
+        case 'g': return 'c';
+        case 'T': return 'A';
+        case 't': return 'a';
+        default: return c;
+        }
+    };
+    const bool opposite = srcRev != tgtRev;
+    for (int64_t d = 0; d < len; ++d) {
+        char sc = dnaAt(S.dna, opposite ? sLo + len - 1 - d : sLo + d), tc = dnaAt(T.dna, tLo + d);
+        if (srcRev)
+            sc = comp(sc);
+        if (tgtRev)
+            tc = comp(tc);
+        if (sc == tc) {
+            if (!(sc >= 'a') && !(tc >= 'a')) // isMasked (halCommon.h:130-132)
+                ++p.matches;
+            else
+                ++p.repMatches;
+        } else if (tc == 'n' || tc == 'N') { // isMissingData (:126-128)
+            ++p.nCount;
+        } else {
+            ++p.misMatches;
+        }
+    }
+}
+
 void Liftover::convert(hgx_alignment *al, int srcGenome, std::istream *in, int tgtGenome, std::ostream *out, int bedType,
                        bool traverseDupes, bool outPSL, bool outPSLWithName, int coalescenceLimit) {
-    if (outPSL || outPSLWithName)
-        throw std::runtime_error("PSL output is not built yet (SURVEY 8(f) item 1)");
+    _outPSL = outPSL || outPSLWithName; // halLiftoverMain.cpp:82-84
+    _outPSLWithName = outPSLWithName;
     const GenomeTables &S = al->img.genomes[(size_t)srcGenome];
     const GenomeTables &T = al->img.genomes[(size_t)tgtGenome];
     std::unordered_map<std::string, int> seqByName;
@@ -117,15 +348,19 @@ void Liftover::convert(hgx_alignment *al, int srcGenome, std::istream *in, int t
     std::string lineBuffer;
     size_t lineNumber = 0;
     std::string pendingError;
-    std::vector<BedLine> lines;
+    struct Job {
+        BedLine line;
+        size_t firstQuery, numQueries;
+    };
+    std::vector<Job> jobs;
     std::vector<hgx_interval> ivs;
     std::vector<hgx_record> recs;
     skipWhiteSpaces(in);
     bool more = in->good();
     while (more || !pendingError.empty()) {
-        lines.clear();
+        jobs.clear();
         ivs.clear();
-        while (more && lines.size() < batchLines) {
+        while (more && ivs.size() < batchLines) {
             ++lineNumber;
             try {
                 std::getline(*in, lineBuffer);
@@ -135,7 +370,9 @@ void Liftover::convert(hgx_alignment *al, int srcGenome, std::istream *in, int t
                 more = false;
                 break;
             }
-            // Liftover::visitLine, halLiftover.cpp:51-66
+            // Liftover::visitLine, halLiftover.cpp:46-70
+            if (_outPSL && bedLine.bedType < 12)
+                bedLine.expandToBed12(); // forcing to BED12 makes PSL code simpler
             auto it = seqByName.find(bedLine.chrName);
             if (it == seqByName.end()) {
                 if (_missedSet.insert(bedLine.chrName).second)
@@ -143,20 +380,37 @@ void Liftover::convert(hgx_alignment *al, int srcGenome, std::istream *in, int t
             } else if (bedLine.end > S.seqs[(size_t)it->second].length) {
                 std::cerr << "Skipping interval with endpoint " << bedLine.end << "because sequence " << bedLine.chrName
                           << " has length " << S.seqs[(size_t)it->second].length << std::endl;
+            } else if (bedLine.bedType > 9 && bedLine.blocks.empty()) {
+                std::cerr << "Skipping input line with 0 blocks" << std::endl;
             } else {
+                Job job;
+                job.firstQuery = ivs.size();
                 hgx_interval q;
-                q.start = bedLine.start;
-                q.end = bedLine.end;
                 q.seq = it->second;
                 q.strand = bedLine.strand;
                 q._pad[0] = q._pad[1] = q._pad[2] = 0;
-                ivs.push_back(q);
-                lines.push_back(bedLine);
+                if (bedLine.bedType <= 9) {
+                    q.start = bedLine.start;
+                    q.end = bedLine.end;
+                    ivs.push_back(q);
+                } else {
+                    // liftBlockIntervals, halLiftover.cpp:296-309: blocks sorted by start, one lift per non-empty block
+                    std::sort(bedLine.blocks.begin(), bedLine.blocks.end());
+                    for (const BedBlock &b : bedLine.blocks) {
+                        q.start = b.start + bedLine.start;
+                        q.end = q.start + b.length;
+                        if (q.end > q.start)
+                            ivs.push_back(q);
+                    }
+                }
+                job.numQueries = ivs.size() - job.firstQuery;
+                job.line = bedLine;
+                jobs.push_back(std::move(job));
             }
             skipWhiteSpaces(in);
             more = in->good();
         }
-        if (!ivs.empty()) {
+        if (!jobs.empty()) {
             hgx_liftover_stats st{};
             liftoverBatchHost(al, srcGenome, tgtGenome, ivs.size(), ivs.data(), opts, recs, &st);
             lastStats.queries += st.queries;
@@ -168,20 +422,87 @@ void Liftover::convert(hgx_alignment *al, int srcGenome, std::istream *in, int t
             lastStats.deferred_queries += st.deferred_queries;
             lastStats.walk_ms += st.walk_ms;
             lastStats.total_ms += st.total_ms;
+            size_t r = 0; // records are grouped by query in input order
             BedLine o;
-            for (const hgx_record &r : recs) {
-                // halBlockLiftover.cpp:82-105 (fields other than chrom/start/end/strand echo the input line)
-                o = lines[(size_t)r.query];
-                o.chrName = T.seqs[(size_t)r.tgt_seq].name;
-                o.start = r.tgt_start;
-                o.end = r.tgt_end;
-                o.strand = r.strand;
-                // Liftover::cleanResults, halLiftover.cpp:313-331
-                if (o.bedType > 6 && (lines[(size_t)r.query].thickStart != 0 || lines[(size_t)r.query].thickEnd != 0)) {
-                    o.thickStart = o.start;
-                    o.thickEnd = o.end;
+            std::vector<BedLine> mapped, outLines;
+            for (const Job &job : jobs) {
+                const BedLine &src = job.line;
+                const size_t qEnd = job.firstQuery + job.numQueries;
+                const size_t r0 = r;
+                while (r < recs.size() && (size_t)recs[r].query < qEnd)
+                    ++r;
+                if (src.bedType <= 9) {
+                    for (size_t k = r0; k < r; ++k) {
+                        const hgx_record &rec = recs[k];
+                        // halBlockLiftover.cpp:82-105 (fields other than chrom/start/end/strand echo the input line)
+                        o = src;
+                        o.chrName = T.seqs[(size_t)rec.tgt_seq].name;
+                        o.start = rec.tgt_start;
+                        o.end = rec.tgt_end;
+                        o.strand = rec.strand;
+                        // Liftover::cleanResults, halLiftover.cpp:313-331
+                        if (o.bedType > 6 && (src.thickStart != 0 || src.thickEnd != 0)) {
+                            o.thickStart = o.start;
+                            o.thickEnd = o.end;
+                        }
+                        o.write(*out);
+                    }
+                    continue;
                 }
-                o.write(*out);
+                // BED12 / PSL: mapped blocks of all of the line's block intervals, stably sorted by source start
+                // (assignBlocksToIntervals' first step; per interval they already are)
+                _inStrand = src.strand;
+                mapped.clear();
+                outLines.clear();
+                for (size_t k = r0; k < r; ++k) {
+                    const hgx_record &rec = recs[k];
+                    mapped.push_back(src);
+                    BedLine &m = mapped.back();
+                    m.blocks.clear();
+                    m.chrName = T.seqs[(size_t)rec.tgt_seq].name;
+                    m.start = rec.tgt_start;
+                    m.end = rec.tgt_end;
+                    m.strand = rec.strand;
+                    m.srcStart = rec.src_start;
+                    if (_outPSL) {
+                        const SeqInfo &qs = S.seqs[(size_t)ivs[(size_t)rec.query].seq];
+                        const SeqInfo &ts = T.seqs[(size_t)rec.tgt_seq];
+                        m.psl.assign(1, PSLInfo());
+                        PSLInfo &p = m.psl[0];
+                        p.qSeqName = qs.name;
+                        p.qSeqSize = (uint64_t)qs.length;
+                        p.qStrand = src.strand == '-' ? '-' : '+'; // source pieces are flipped for '-' input (halBlockLiftover.cpp:64-70)
+                        p.qChromOffset = (uint64_t)qs.start;
+                        p.qEnd = (uint64_t)(m.srcStart + (m.end - m.start));
+                        p.tSeqSize = (uint64_t)ts.length;
+                        pslCounts(S, T, m.srcStart, m.start + ts.start, m.end - m.start, src.strand == '-', rec.tgt_reversed != 0, p);
+                    }
+                }
+                std::stable_sort(mapped.begin(), mapped.end(), [](const BedLine &a, const BedLine &b) { return a.srcStart < b.srcStart; });
+                if (!mapped.empty())
+                    assignBlocksToIntervals(mapped, outLines);
+                // cleanResults (halLiftover.cpp:313-355)
+                for (BedLine &b : outLines) {
+                    if (src.thickStart != 0 || src.thickEnd != 0) {
+                        b.thickStart = b.start;
+                        b.thickEnd = b.end;
+                    }
+                    if (_outPSL) {
+                        b.srcStart = INT64_MAX;
+                        b.psl[0].qEnd = 0;
+                        for (size_t k = 0; k < b.psl[0].qBlockStarts.size(); ++k) {
+                            b.srcStart = std::min(b.srcStart, b.psl[0].qBlockStarts[k]);
+                            b.psl[0].qEnd = std::max(b.psl[0].qEnd, (uint64_t)b.psl[0].qBlockStarts[k] + (uint64_t)b.blocks[k].length);
+                        }
+                    }
+                }
+                std::stable_sort(outLines.begin(), outLines.end(), [](const BedLine &a, const BedLine &b) { return a.srcStart < b.srcStart; });
+                for (const BedLine &b : outLines) {
+                    if (!_outPSL)
+                        b.write(*out);
+                    else
+                        b.writePSL(*out, _outPSLWithName);
+                }
             }
         }
         if (!pendingError.empty()) {

@@ -8,7 +8,21 @@
 
 namespace hgx {
 
-// One BED line: liftover/inc/halBedLine.h:48-82 (blocks / PSL fields belong to the BED12 path, not built yet)
+// liftover/inc/halBedLine.h:19-46
+struct BedBlock {
+    int64_t start, length;
+    bool operator<(const BedBlock &o) const { return start < o.start; }
+};
+struct PSLInfo {
+    uint64_t matches = 0, misMatches = 0, repMatches = 0, nCount = 0, qNumInsert = 0, qBaseInsert = 0, tNumInsert = 0, tBaseInsert = 0;
+    std::string qSeqName;
+    uint64_t qSeqSize = 0;
+    char qStrand = '+';
+    uint64_t qEnd = 0, qChromOffset = 0, tSeqSize = 0;
+    std::vector<int64_t> qBlockStarts;
+};
+
+// One BED line: liftover/inc/halBedLine.h:48-82
 struct BedLine {
     std::string chrName;
     int64_t start = NULL_INDEX, end = NULL_INDEX;
@@ -16,12 +30,19 @@ struct BedLine {
     int64_t score = 0;
     char strand = '+'; // halBedLine.cpp:19
     int64_t thickStart = 0, thickEnd = 0, itemR = 0, itemG = 0, itemB = 0;
+    std::vector<BedBlock> blocks;
     std::vector<std::string> extra;
+    std::vector<PSLInfo> psl; // at most one element (halBedLine.h:79-81)
     int bedType = -1;
+    int64_t srcStart = NULL_INDEX; // hidden sort key (halBedLine.h:74)
     // halBedLine.cpp:27-102; throws std::runtime_error with the reference's messages
     void parse(const std::string &lineBuffer, int bedType);
     // halBedLine.cpp:104-151
     void write(std::ostream &os) const;
+    // halBedLine.cpp:153-178, 206-250, 252-334
+    void expandToBed12();
+    void writePSL(std::ostream &os, bool prefixWithName) const;
+    bool validatePSL() const;
 };
 
 class Liftover {
@@ -37,6 +58,13 @@ class Liftover {
 
   private:
     std::set<std::string> _missedSet;
+    bool _outPSL = false, _outPSLWithName = false;
+    char _inStrand = '+';
+    // halLiftover.cpp:108-290
+    void assignBlocksToIntervals(std::vector<BedLine> &mappedBlocks, std::vector<BedLine> &out);
+    bool compatible(const BedLine &tgtBed, const BedLine &newBlock) const;
+    void flipBlocks(std::vector<BedLine> &lines) const;
+    void computePSLInserts(std::vector<BedLine> &lines) const;
 };
 
 } // namespace hgx

@@ -88,7 +88,8 @@ typedef struct hgx_record { /* one lifted output interval = one output BED line 
     int64_t src_start; /* genome coordinate in the source; the reference's hidden sort key (_srcStart) */
     int32_t tgt_seq;   /* sequence index in the target genome */
     char strand;       /* '+', '-' ('.' when the input strand was '.') */
-    char _pad[3];
+    uint8_t tgt_reversed; /* orientation of the mapped piece itself (also set when strand is '.'); needed for PSL */
+    char _pad[2];
 } hgx_record;
 
 typedef struct hgx_liftover_opts {

@@ -6,6 +6,23 @@
 
 namespace orc {
 
+// liftover/inc/halBedLine.h:19-46
+struct BedBlock {
+    i64 _start, _length;
+    bool operator<(const BedBlock &o) const {
+        return _start < o._start;
+    }
+};
+struct PSLInfo {
+    u64 _matches = 0, _misMatches = 0, _repMatches = 0, _nCount = 0, _qNumInsert = 0, _qBaseInsert = 0, _tNumInsert = 0,
+        _tBaseInsert = 0;
+    std::string _qSeqName;
+    u64 _qSeqSize = 0;
+    char _qStrand = '+';
+    u64 _qEnd = 0, _qChromOffset = 0, _tSeqSize = 0;
+    std::vector<i64> _qBlockStarts;
+};
+
 // liftover/inc/halBedLine.h:48-82
 struct BedLine {
     std::string _chrName;
@@ -14,12 +31,17 @@ struct BedLine {
     i64 _score = 0;
     char _strand = '+';
     i64 _thickStart = 0, _thickEnd = 0, _itemR = 0, _itemG = 0, _itemB = 0;
+    std::vector<BedBlock> _blocks;
     std::vector<std::string> _extra;
+    std::vector<PSLInfo> _psl;
     int _bedType = -1;
     i64 _srcStart = NULL_INDEX;
     char _srcStrand = '+';
     std::istream &read(std::istream &is, std::string &lineBuffer, int bedType);
     std::ostream &write(std::ostream &os) const;
+    std::ostream &writePSL(std::ostream &os, bool prefixWithName) const;
+    bool validatePSL() const;
+    void expandToBed12();
 };
 
 void extractSegment(MSegSet::iterator start, const MSegSet &paraSet, std::vector<MSegPtr> &fragments, MSegSet *startSet,
@@ -29,7 +51,7 @@ void extractSegment(MSegSet::iterator start, const MSegSet &paraSet, std::vector
 struct Liftover {
     const Alignment *al = nullptr;
     int srcGenome = -1, tgtGenome = -1, coalescenceLimit = -1, mrca = -1;
-    bool traverseDupes = true;
+    bool traverseDupes = true, outPSL = false, outPSLWithName = false;
     std::ostream *outStream = nullptr;
     BedLine bedLine;
     const Sequence *srcSequence = nullptr;
@@ -44,11 +66,17 @@ struct Liftover {
     size_t numIntervals = 0, numRecords = 0, numMappedPieces = 0;
 
     void convert(const Alignment *alignment, int src, std::istream *bedIn, int tgt, std::ostream *bedOut, int bedType = 0,
-                 bool doDupes = true, int coalLimit = -1);
+                 bool doDupes = true, int coalLimit = -1, bool outPSL = false, bool outPSLWithName = false);
     void visitBegin();
     void visitLine();
     void liftInterval(std::list<BedLine> &mappedBedLines);
     void cleanResults();
+    void liftBlockIntervals();
+    void assignBlocksToIntervals();
+    bool compatible(const BedLine &tgtBed, const BedLine &newBlock);
+    void flipBlocks(std::list<BedLine> &bedList);
+    void computePSLInserts(std::list<BedLine> &bedList);
+    void readPSLInfo(std::vector<MSegPtr> &fragments, BedLine &outBedLine);
 };
 
 } // namespace orc

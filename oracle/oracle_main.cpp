@@ -13,7 +13,7 @@ using namespace orc;
 
 static int cmdLiftover(int argc, char **argv) {
     std::vector<std::string> pos;
-    bool noDupes = false, stats = false;
+    bool noDupes = false, stats = false, outPSL = false, outPSLWithName = false;
     int bedType = 0;
     for (int i = 0; i < argc; ++i) {
         std::string a = argv[i];
@@ -21,6 +21,10 @@ static int cmdLiftover(int argc, char **argv) {
             noDupes = true;
         else if (a == "--stats")
             stats = true;
+        else if (a == "--outPSL")
+            outPSL = true;
+        else if (a == "--outPSLWithName")
+            outPSLWithName = true;
         else if (a == "--bedType")
             bedType = atoi(argv[++i]);
         else
@@ -41,7 +45,7 @@ static int cmdLiftover(int argc, char **argv) {
     inBuf << in.rdbuf();
     std::ostringstream outBuf;
     Liftover lo;
-    lo.convert(&al, src, &inBuf, tgt, &outBuf, bedType, !noDupes);
+    lo.convert(&al, src, &inBuf, tgt, &outBuf, bedType, !noDupes, -1, outPSL, outPSLWithName);
     std::ofstream out(pos[4]);
     out << outBuf.str();
     if (stats)

@@ -96,3 +96,29 @@ CASES = [
      "Sequence\t0\t20\tBLOCK_A\t0\t+\n"
      "Sequence\t40\t50\tBLOCK_A\t0\t+\n"),
 ]
+
+# leaf3 -> leaf1 (up 2, down 1) with BED12 blocks: liftover/tests/halLiftoverTests.cpp:345-373
+CASE3_BED12 = ("Sequence\t0\t10\tSEGMENT_0\t0\t+\t0\t10\t128,0,0\t1\t10\t0,\n"
+               "Sequence\t10\t30\tSEGMENT_1\t0\t+\t10\t30\t128,0,0\t1\t20\t0,\n"
+               "Sequence\t30\t45\tSEGMENT_2\t0\t+\t30\t45\t128,0,0\t1\t15\t0,\n"
+               "Sequence\t45\t65\tSEGMENT_3\t0\t+\t45\t65\t128,0,0\t1\t20\t0,\n"
+               "Sequence\t65\t75\tSEGMENT_4\t0\t+\t65\t75\t128,0,0\t1\t10\t0,\n"
+               "Sequence\t75\t100\tSEGMENT_5\t0\t+\t75\t100\t128,0,0\t1\t25\t0,\n")
+# (srcGenome, tgtGenome, input, expected, outPSL, outPSLWithName)
+CASES12 = [
+    ("leaf3", "leaf1", CASE3_BED12,
+     "Sequence\t30\t40\tSEGMENT_1\t0\t-\t30\t40\t128,0,0\t1\t10\t0\n"
+     "Sequence\t20\t30\tSEGMENT_2\t0\t+\t20\t30\t128,0,0\t1\t10\t0\n"
+     "Sequence\t10\t20\tSEGMENT_3\t0\t+\t10\t20\t128,0,0\t1\t10\t0\n"
+     "Sequence\t0\t10\tSEGMENT_4\t0\t-\t0\t10\t128,0,0\t1\t10\t0\n", False, False),
+    ("leaf3", "leaf1", CASE3_BED12,
+     "2\t8\t0\t0\t0\t0\t0\t0\t+-\tSequence\t100\t20\t30\tSequence\t100\t30\t40\t1\t10,\t20,\t60,\n"
+     "2\t8\t0\t0\t0\t0\t0\t0\t++\tSequence\t100\t35\t45\tSequence\t100\t20\t30\t1\t10,\t35,\t20,\n"
+     "3\t7\t0\t0\t0\t0\t0\t0\t++\tSequence\t100\t45\t55\tSequence\t100\t10\t20\t1\t10,\t45,\t10,\n"
+     "3\t7\t0\t0\t0\t0\t0\t0\t+-\tSequence\t100\t65\t75\tSequence\t100\t0\t10\t1\t10,\t65,\t90,\n", True, False),
+    ("leaf3", "leaf1", CASE3_BED12,
+     "SEGMENT_1\t2\t8\t0\t0\t0\t0\t0\t0\t+-\tSequence\t100\t20\t30\tSequence\t100\t30\t40\t1\t10,\t20,\t60,\n"
+     "SEGMENT_2\t2\t8\t0\t0\t0\t0\t0\t0\t++\tSequence\t100\t35\t45\tSequence\t100\t20\t30\t1\t10,\t35,\t20,\n"
+     "SEGMENT_3\t3\t7\t0\t0\t0\t0\t0\t0\t++\tSequence\t100\t45\t55\tSequence\t100\t10\t20\t1\t10,\t45,\t10,\n"
+     "SEGMENT_4\t3\t7\t0\t0\t0\t0\t0\t0\t+-\tSequence\t100\t65\t75\tSequence\t100\t0\t10\t1\t10,\t65,\t90,\n", True, True),
+]

@@ -242,3 +242,69 @@ def test_strand_symmetry_property_at_scale(hal, tmp_path):
     # merged lines never exceed the query length
     qlen = (iv["end"] - iv["start"])[plus["query"]]
     assert np.all(plus["tgt_end"] - plus["tgt_start"] <= qlen)
+
+
+def test_bed12_and_psl_reference_goldens(hal, tmp_path):
+    """liftover/Makefile:38-57 goldens and the BED12 / PSL literal strings of halLiftoverTests.cpp:345-373."""
+    al = hal.Alignment.random(hal.RandOptions.preset("small", seed=0), device=0)
+    g0, g2 = al.genome_id("Genome_0"), al.genome_id("Genome_2")
+    d = os.path.join(GOLD, "ref_liftover")
+    rd = lambda n: open(os.path.join(d, n)).read()
+    assert hal.liftover_convert(al, g0, rd("test1.bed12"), g2) == rd("halLiftoverBed12Test.bed")
+    assert hal.liftover_convert(al, g0, rd("test1.bed12+2"), g2) == rd("halLiftoverBed12ExtraTest.bed")
+    assert hal.liftover_convert(al, g0, rd("test1.bed12"), g2, out_psl=True) == rd("halLiftoverPsl12Test.psl")
+    assert hal.liftover_convert(al, g0, rd("test1.bed3"), g2, out_psl=True) == rd("halLiftoverPsl3Test.psl")
+    img = str(tmp_path / "hand.hgx")
+    halfix.write_hgx(img, hb.genomes())
+    hand = hal.Alignment.open(img, device=0)
+    for src, tgt, bed, want, psl, pslname in hb.CASES12:
+        got = hal.liftover_convert(hand, hand.genome_id(src), bed, hand.genome_id(tgt), out_psl=psl, out_psl_with_name=pslname)
+        assert got == want, (psl, pslname)
+
+
+def _random_bed12(seq_name, seq_len, n, seed, strands="+-"):
+    rng = np.random.default_rng(seed)
+    lines = []
+    for i in range(n):
+        nb = int(rng.integers(1, 6))
+        span = int(rng.integers(nb * 4, min(seq_len, 900)))
+        start = int(rng.integers(0, seq_len - span))
+        cuts = np.sort(rng.choice(np.arange(1, span), size=2 * nb - 1, replace=False)) if span > 2 * nb else np.arange(1, 2 * nb)
+        edges = [0] + list(map(int, cuts)) + [span]
+        sizes = [edges[2 * k + 1] - edges[2 * k] for k in range(nb)]
+        starts = [edges[2 * k] for k in range(nb)]
+        order = rng.permutation(nb)  # blocks need not be sorted in the input
+        st = strands[int(rng.integers(0, len(strands)))]
+        lines.append("%s\t%d\t%d\tt%d\t0\t%s\t%d\t%d\t1,2,3\t%d\t%s\t%s\n" % (
+            seq_name, start, start + span, i, st, start, start + span, nb, ",".join(str(sizes[k]) for k in order) + ",",
+            ",".join(str(starts[k]) for k in order) + ","))
+    return "".join(lines)
+
+
+@pytest.mark.parametrize("seed", [2, 6])
+def test_bed12_and_psl_vs_oracle(hal, oracle_bin, tmp_path, seed):
+    opts = hal.RandOptions(mean_degree=1.5, max_branch_length=3.0, min_genomes=2, max_genomes=10, min_segment_length=10,
+                           max_segment_length=60, min_segments=200, max_segments=600, seed=seed, with_dna=True)
+    al = hal.Alignment.random(opts, device=0)
+    img = str(tmp_path / "d.hgx")
+    al.save(img)
+    n = al.num_genomes
+    pairs = [(n - 1, 2), (n - 1, n - 2), (0, n - 1), (n - 1, 0), (1, 1), (3, n - 1)]
+    total = 0
+    for s, t in pairs:
+        name, _, length = al.sequences(s)[0]
+        bed = _random_bed12(name, length, 120, seed * 10 + s, strands="+-.")
+        for psl, pslname in ((False, False), (True, False), (True, True)):
+            if psl:
+                bed_in = bed.replace("\t.\t", "\t+\t")
+            else:
+                bed_in = bed
+            got = hal.liftover_convert(al, s, bed_in, t, out_psl=psl, out_psl_with_name=pslname)
+            want = oracle_liftover(oracle_bin, img, al.genome_name(s), al.genome_name(t), bed_in, tmp_path, psl=psl, psl_with_name=pslname)
+            assert got == want, (al.genome_name(s), al.genome_name(t), psl, pslname)
+            total += got.count("\n")
+        # PSL from BED6 input (expandToBed12)
+        bed6 = random_bed(name, length, 150, 5, 300, seed, strands="+-")
+        assert hal.liftover_convert(al, s, bed6, t, out_psl=True) == \
+            oracle_liftover(oracle_bin, img, al.genome_name(s), al.genome_name(t), bed6, tmp_path, psl=True)
+    assert total > 500

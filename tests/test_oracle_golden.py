@@ -86,3 +86,26 @@ def test_reference_cli_golden_hal2maf_seq_part(hal, oracle_bin, tmp_path):
     got = _oracle_maf(oracle_bin, img, tmp_path, "--refGenome", "Genome_2", "--refSequence", "Genome_2_seq", "--start", "1000",
                       "--length", "2000")
     assert got == open(os.path.join(GOLD, "ref_maf", "hal2mafSeqPartTest.maf")).read()
+
+
+def test_reference_cli_goldens_bed12_and_psl(hal, oracle_bin, tmp_path):
+    # liftover/Makefile:38-57: halLiftoverBed12Test, Psl12Test, Psl3Test, Bed12ExtraTest
+    _, img = _small_seed0(hal, tmp_path)
+    d = os.path.join(GOLD, "ref_liftover")
+    for inp, exp, extra in (("test1.bed12", "halLiftoverBed12Test.bed", []), ("test1.bed12+2", "halLiftoverBed12ExtraTest.bed", []),
+                            ("test1.bed12", "halLiftoverPsl12Test.psl", ["--outPSL"]), ("test1.bed3", "halLiftoverPsl3Test.psl", ["--outPSL"])):
+        out = str(tmp_path / "o.txt")
+        subprocess.check_call([oracle_bin, "liftover", img, "Genome_0", os.path.join(d, inp), "Genome_2", out] + extra)
+        assert open(out).read() == open(os.path.join(d, exp)).read(), exp
+
+
+def test_reference_unit_test_bed12_psl_literals(oracle_bin, tmp_path):
+    # liftover/tests/halLiftoverTests.cpp:345-373: BED12, --outPSL and --outPSLWithName literal strings
+    img = str(tmp_path / "hand.hgx")
+    halfix.write_hgx(img, hb.genomes())
+    for src, tgt, bed, want, psl, pslname in hb.CASES12:
+        inp, out = str(tmp_path / "i.bed"), str(tmp_path / "o.txt")
+        open(inp, "w").write(bed)
+        extra = ["--outPSLWithName"] if pslname else (["--outPSL"] if psl else [])
+        subprocess.check_call([oracle_bin, "liftover", img, src, inp, tgt, out] + extra)
+        assert open(out).read() == want

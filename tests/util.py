@@ -20,7 +20,8 @@ def random_bed(seq_name, seq_len, n, min_len, max_len, seed, strands="+-", bed6=
     return "".join(lines)
 
 
-def oracle_liftover(oracle_bin, image_path, src, tgt, bed_text, tmpdir, no_dupes=False, bed_type=0, stats=False):
+def oracle_liftover(oracle_bin, image_path, src, tgt, bed_text, tmpdir, no_dupes=False, bed_type=0, stats=False, psl=False,
+                    psl_with_name=False):
     inp = os.path.join(str(tmpdir), "oracle_in.bed")
     out = os.path.join(str(tmpdir), "oracle_out.bed")
     with open(inp, "w") as f:
@@ -32,6 +33,10 @@ def oracle_liftover(oracle_bin, image_path, src, tgt, bed_text, tmpdir, no_dupes
         cmd += ["--bedType", str(bed_type)]
     if stats:
         cmd.append("--stats")
+    if psl_with_name:
+        cmd.append("--outPSLWithName")
+    elif psl:
+        cmd.append("--outPSL")
     res = subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     with open(out) as f:
         text = f.read()
