@@ -438,6 +438,7 @@ int hgx_maf_export(hgx_alignment *h, int ref, int ref_sequence, int64_t start, i
         me.setUcscNames(o->only_sequence_names == 0);
         me.setOnlyOrthologs(o->only_orthologs != 0);
         me.setKeepEmptyRefBlocks(o->keep_empty_ref_blocks != 0);
+        me.setUnique(o->unique != 0);
         me.setMaxBlockLength(o->max_block_len == 0 ? 1000 : o->max_block_len);
         if (o->no_ancestors && !G->children.empty()) // hal2maf.cpp:153-159
             throw std::runtime_error("Since the reference genome to be used for the MAF is ancestral (" + G->name +

@@ -291,8 +291,8 @@ void MafExport::printBlock(std::ostream &os) const {
 // halMafExport.cpp:25-88
 void MafExport::convertSequence(std::ostream &mafStream, hgx_alignment *alignment, int genome, int seq, int64_t startPosition,
                                 int64_t length, const std::set<int> &targets) {
-    if (_unique || _maxRefGap > 0)
-        throw std::runtime_error("--unique and --maxRefGap are not built yet (SURVEY 8(f) item 2)");
+    if (_maxRefGap > 0)
+        throw std::runtime_error("--maxRefGap > 0 (indel stacks) is not built yet (SURVEY 8(f) item 2)");
     if (_al != alignment) {
         _al = alignment;
         buildRanks();
@@ -322,35 +322,109 @@ void MafExport::convertSequence(std::ostream &mafStream, hgx_alignment *alignmen
     std::vector<uint64_t> off;
     std::vector<ColumnRowHost> rows;
     size_t appendCount = 0, numBlocks = 0;
-    const int64_t first = startPosition + S.start;
-    for (int64_t done = 0; done < length;) {
-        const int64_t n = std::min<int64_t>((int64_t)chunkColumns, length - done);
-        columnsRowsHost(alignment, genome, first + done, n, opt, true, off, rows, &stats);
-        for (int64_t i = 0; i < n; ++i) {
+    const int64_t first = startPosition + S.start, last = first + length - 1;
+
+    // The GPU delivers every column of a chunk; the iterator state that is sequential by definition in the reference —
+    // the visit cache of --unique (halColumnIterator.cpp:749-819) and the MAF block state — is replayed here.
+    std::map<int64_t, int64_t> cache; // PositionCache of the reference genome (halPositionCache.cpp): last -> first
+    auto cacheFind = [&](int64_t pos) {
+        auto i = cache.lower_bound(pos);
+        return i != cache.end() && i->second <= pos;
+    };
+    auto cacheInsert = [&](int64_t pos) {
+        if (cacheFind(pos))
+            return false;
+        int64_t lo = pos, hi = pos;
+        auto right = cache.lower_bound(pos);
+        if (right != cache.end() && right->second == pos + 1) {
+            hi = right->first;
+            cache.erase(right);
+        }
+        auto left = cache.find(pos - 1);
+        if (left != cache.end()) {
+            lo = left->second;
+            cache.erase(left);
+        }
+        cache[hi] = lo;
+        return true;
+    };
+    int64_t chunkFirst = 0, chunkCount = 0; // genome coordinates covered by off/rows
+    auto fetch = [&](int64_t pos) {
+        if (pos < chunkFirst || pos >= chunkFirst + chunkCount) {
+            chunkFirst = pos;
+            chunkCount = std::min<int64_t>((int64_t)chunkColumns, last - pos + 1);
+            for (auto &kv : colMap)
+                kv.second.clear(); // they point into the buffer about to be replaced
+            columnsRowsHost(alignment, genome, chunkFirst, chunkCount, opt, true, off, rows, &stats);
+        }
+        return (size_t)(pos - chunkFirst);
+    };
+
+    int64_t index = first;         // ColumnIterator's stack entry (_index), genome coordinates
+    int64_t leftmostRefPos = first; // _leftmostRefPos
+    int64_t prevRefIndex = 0;       // getReferenceSequencePosition()
+    // ColumnIterator::toRight (halColumnIterator.cpp:65-144), one-entry stack
+    auto toRight = [&]() {
+        prevRefIndex = index - S.start;
+        if (index < first || index > last)
+            return;
+        bool brk;
+        do {
+            if (_unique)
+                while (cacheFind(index) && index <= last) // nextFreeIndex
+                    ++index;
+            if (index < first || index > last)
+                return; // the column map keeps whatever the last walk left in it
+            // recursiveUpdate + colMapInsert (:246-355, :766-819)
+            const size_t i = fetch(index);
             for (auto &kv : colMap)
                 kv.second.clear();
-            for (uint64_t r = off[(size_t)i]; r < off[(size_t)i + 1]; ++r) {
+            brk = false;
+            leftmostRefPos = index;
+            for (uint64_t r = off[i]; r < off[i + 1]; ++r) {
                 const ColumnRowHost &row = rows[r];
-                colMap[keyOf(row.genome, row.pos)].push_back(&row);
+                bool found = false;
+                if (_unique && row.genome == genome)
+                    found = first < row.pos ? !cacheInsert(row.pos) : cacheFind(row.pos);
+                if (!found)
+                    colMap[keyOf(row.genome, row.pos)].push_back(&row);
+                if (row.genome == genome)
+                    leftmostRefPos = std::min(leftmostRefPos, row.pos);
+                if (found) {
+                    brk = true; // the walk stops at the first base already visited
+                    break;
+                }
             }
-            const int64_t refPos = startPosition + done + i;
-            if (appendCount == 0) {
-                initBlock(colMap, refKey, refPos);
-            } else if (!canAppendColumn(colMap)) {
+            ++index;
+        } while (brk);
+    };
+    auto canonicalOnRef = [&]() { return leftmostRefPos >= first && leftmostRefPos <= last; }; // :210-214
+
+    toRight(); // the constructor's first step
+    if (!_unique || canonicalOnRef()) {
+        initBlock(colMap, refKey, prevRefIndex);
+        appendColumn(colMap);
+        ++appendCount;
+    }
+    while (!(index > last)) { // lastColumn()
+        toRight();
+        if (!_unique || canonicalOnRef()) {
+            if (appendCount == 0)
+                initBlock(colMap, refKey, prevRefIndex);
+            if (!canAppendColumn(colMap)) {
                 if (numBlocks++ % 1000 == 0) { // ColumnIterator::defragment (halColumnIterator.cpp:193-208)
                     for (auto it = colMap.begin(); it != colMap.end();)
                         it = it->second.empty() ? colMap.erase(it) : std::next(it);
                 }
-                if (_keepEmptyRefBlocks || !referenceIsAllGaps()) {
+                if (appendCount > 0 && (_keepEmptyRefBlocks || !referenceIsAllGaps())) {
                     printBlock(mafStream);
                     mafStream << '\n';
                 }
-                initBlock(colMap, refKey, refPos);
+                initBlock(colMap, refKey, prevRefIndex);
             }
             appendColumn(colMap);
             ++appendCount;
         }
-        done += n;
     }
     if (appendCount > 0 && (_keepEmptyRefBlocks || !referenceIsAllGaps())) {
         printBlock(mafStream);

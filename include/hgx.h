@@ -180,7 +180,7 @@ int hgx_alignment_depth(hgx_alignment *h, int ref_genome, int ref_sequence, int6
  * included, byte-identical to hal2maf for the options below. */
 typedef struct hgx_maf_opts {
     int32_t no_dupes, no_ancestors, only_sequence_names, only_orthologs, keep_empty_ref_blocks;
-    int32_t _pad;
+    int32_t unique; /* --unique: a column is written once, by its left-most reference base (halColumnIterator.cpp:210-214) */
     int64_t max_block_len; /* --maxBlockLen, default 1000 (halMafBlock.cpp:16); <= 0: unlimited */
 } hgx_maf_opts;
 int hgx_maf_export(hgx_alignment *h, int ref_genome, int ref_sequence, int64_t start, int64_t length, const hgx_maf_opts *opts,

@@ -45,8 +45,8 @@ static int seqIndexBySite(const Genome &G, i64 pos) {
 
 // halColumnIterator.cpp:18-57
 ColumnIterator::ColumnIterator(const Alignment *a, int reference, const std::set<int> *tgts, i64 columnIndex, i64 lastColumnIndex,
-                               bool noDupes_, bool noAncestors_, bool onlyOrthologs_)
-    : al(a), refGenome(reference), noDupes(noDupes_), noAncestors(noAncestors_), onlyOrthologs(onlyOrthologs_) {
+                               bool noDupes_, bool noAncestors_, bool onlyOrthologs_, bool unique_)
+    : al(a), refGenome(reference), noDupes(noDupes_), noAncestors(noAncestors_), onlyOrthologs(onlyOrthologs_), unique(unique_) {
     seqIdx = seqIndexBySite(al->genomes[(size_t)reference], columnIndex);
     if (tgts != nullptr && !tgts->empty()) {
         targets = *tgts;
@@ -60,18 +60,37 @@ ColumnIterator::ColumnIterator(const Alignment *a, int reference, const std::set
     toRight();
 }
 
-// halColumnIterator.cpp:65-144 with a one-entry stack and no visit cache
+// halColumnIterator.cpp:749-764 (one-entry stack: the cache is consulted only with --unique)
+void ColumnIterator::nextFreeIndex() {
+    if (unique) {
+        auto it = visitCache.find(refGenome);
+        if (it != visitCache.end()) {
+            bool found = it->second.find(index);
+            while (found && index <= lastIndex) {
+                ++index;
+                found = it->second.find(index);
+            }
+        }
+    }
+}
+
+// halColumnIterator.cpp:65-144 with a one-entry stack (maxInsertLength == 0)
 void ColumnIterator::toRight() {
     const Genome &G = al->genomes[(size_t)refGenome];
     prevRefSeq = seqIdx;
     prevRefIndex = index - G.seqs[(size_t)seqIdx].start;
     if (!(index >= firstIndex && index <= lastIndex))
         return;
-    recursiveUpdate();
-    index++;
-    const Sequence &seq = G.seqs[(size_t)seqIdx];
-    if (index < seq.start || (index >= seq.start + seq.length && index < G.totalLength))
-        seqIdx = seqIndexBySite(G, index);
+    do {
+        nextFreeIndex();
+        if (!(index >= firstIndex && index <= lastIndex))
+            return;
+        recursiveUpdate();
+        index++;
+        const Sequence &seq = G.seqs[(size_t)seqIdx];
+        if (index < seq.start || (index >= seq.start + seq.length && index < G.totalLength))
+            seqIdx = seqIndexBySite(G, index);
+    } while (brk);
 }
 
 // halColumnIterator.cpp:193-208
@@ -84,20 +103,37 @@ void ColumnIterator::defragment() {
     }
 }
 
-// halColumnIterator.cpp:766-819 (visit cache neither built nor consulted: unique == false, no indels)
-void ColumnIterator::colMapInsert(const SegIt &it) {
+// halColumnIterator.cpp:766-819 (maxInsertLength == 0, one-entry stack)
+bool ColumnIterator::colMapInsert(const SegIt &it) {
     const int g = it.g;
-    if ((!noAncestors || al->genomes[(size_t)g].children.empty()) && (targets.empty() || targets.count(g))) {
-        const i64 pos = it.getStartPosition();
+    const i64 pos = it.getStartPosition();
+    bool updateCache = g == refGenome && firstIndex < pos;
+    if (!unique)
+        updateCache = false;
+    bool found = false;
+    auto cacheIt = visitCache.find(g);
+    if (updateCache) {
+        if (cacheIt == visitCache.end())
+            cacheIt = visitCache.emplace(g, PositionCache()).first;
+        found = !cacheIt->second.insert(pos);
+    } else {
+        found = cacheIt != visitCache.end() && cacheIt->second.find(pos);
+    }
+    if (!found && (!noAncestors || al->genomes[(size_t)g].children.empty()) && (targets.empty() || targets.count(g))) {
         SeqKey k{al, g, seqIndexBySite(al->genomes[(size_t)g], pos)};
         colMap[k].push_back(Dna{g, pos, it.rev});
     }
+    if (g == refGenome)
+        leftmostRefPos = std::min(leftmostRefPos, pos);
+    return !found;
 }
 
 // halColumnIterator.cpp:246-355
 void ColumnIterator::recursiveUpdate() {
     for (auto &kv : colMap) // resetColMap :821-825 (keys persist)
         kv.second.clear();
+    brk = false;
+    leftmostRefPos = index;
     const Genome &G = al->genomes[(size_t)refGenome];
     const Sequence &refSeq = G.seqs[(size_t)seqIdx];
     SegIt it;
@@ -106,7 +142,10 @@ void ColumnIterator::recursiveUpdate() {
     if (refSeq.numTop > 0) {
         it.top = true;
         it.toSite(index, true);
-        colMapInsert(it);
+        if (!colMapInsert(it)) {
+            brk = true;
+            return;
+        }
         updateParent(it);
         if (!onlyOrthologs)
             updateNextTopDup(it);
@@ -114,7 +153,10 @@ void ColumnIterator::recursiveUpdate() {
     } else {
         it.top = false;
         it.toSite(index, true);
-        colMapInsert(it);
+        if (!colMapInsert(it)) {
+            brk = true;
+            return;
+        }
         for (size_t child = 0; child < G.children.size(); ++child)
             updateChild(it, (i64)child);
     }
@@ -123,10 +165,13 @@ void ColumnIterator::recursiveUpdate() {
 // halColumnIterator.cpp:556-605
 void ColumnIterator::updateParent(const SegIt &top) {
     const int genome = top.g;
-    if (top.hasParent() && parentInScope(genome) && (!noDupes || top.isCanonicalParalog())) {
+    if (!brk && top.hasParent() && parentInScope(genome) && (!noDupes || top.isCanonicalParalog())) {
         SegIt parent;
         parent.toParent(top);
-        colMapInsert(parent);
+        if (!colMapInsert(parent)) {
+            brk = true;
+            return;
+        }
         updateParseUp(parent);
         const Genome &P = al->genomes[(size_t)parent.g];
         for (size_t i = 0; i < P.children.size(); ++i) {
@@ -138,10 +183,13 @@ void ColumnIterator::updateParent(const SegIt &top) {
 
 // halColumnIterator.cpp:607-640
 void ColumnIterator::updateChild(const SegIt &bot, i64 slot) {
-    if (bot.hasChild(slot) && childInScope(bot.g, slot)) {
+    if (!brk && bot.hasChild(slot) && childInScope(bot.g, slot)) {
         SegIt child;
         child.toChild(bot, slot);
-        colMapInsert(child);
+        if (!colMapInsert(child)) {
+            brk = true;
+            return;
+        }
         updateNextTopDup(child);
         updateParseDown(child);
     }
@@ -150,14 +198,17 @@ void ColumnIterator::updateChild(const SegIt &bot, i64 slot) {
 // halColumnIterator.cpp:642-681
 void ColumnIterator::updateNextTopDup(const SegIt &top) {
     const Genome &G = top.G();
-    if (noDupes || G.tParalogy[(size_t)top.idx] == NULL_INDEX || G.parent < 0 || !parentInScope(top.g))
+    if (brk || noDupes || G.tParalogy[(size_t)top.idx] == NULL_INDEX || G.parent < 0 || !parentInScope(top.g))
         return;
     const i64 firstIndexSeg = top.idx;
     SegIt cur = top;
     do {
         SegIt dup = cur;
         dup.toNextParalogy();
-        colMapInsert(dup);
+        if (!colMapInsert(dup)) {
+            brk = true;
+            return;
+        }
         updateParseDown(dup);
         cur = dup;
     } while (G.tParalogy[(size_t)cur.idx] != NULL_INDEX && G.tParalogy[(size_t)cur.idx] != firstIndexSeg);
@@ -165,7 +216,7 @@ void ColumnIterator::updateNextTopDup(const SegIt &top) {
 
 // halColumnIterator.cpp:683-709
 void ColumnIterator::updateParseUp(const SegIt &bot) {
-    if (bot.G().bTopParse[(size_t)bot.idx] != NULL_INDEX) { // hasParseUp
+    if (!brk && bot.G().bTopParse[(size_t)bot.idx] != NULL_INDEX) { // hasParseUp
         SegIt top;
         top.toParseUp(bot);
         updateParent(top);
@@ -176,7 +227,7 @@ void ColumnIterator::updateParseUp(const SegIt &bot) {
 
 // halColumnIterator.cpp:711-744
 void ColumnIterator::updateParseDown(const SegIt &top) {
-    if (top.G().tBotParse[(size_t)top.idx] != NULL_INDEX) { // hasParseDown
+    if (!brk && top.G().tBotParse[(size_t)top.idx] != NULL_INDEX) { // hasParseDown
         SegIt bot;
         bot.toParseDown(top);
         const Genome &G = bot.G();
@@ -483,27 +534,34 @@ void MafExport::convertSequence(std::ostream &os, const Alignment &al, int genom
     }
     auto t0 = std::chrono::steady_clock::now();
     // Sequence::getColumnIterator (api/mmap_impl/mmapSequence.cpp:41-52): sequence-relative -> genome coordinates
-    ColumnIterator colIt(&al, genome, &targets, startPosition + seq.start, lastPosition + seq.start, noDupes, noAncestors, onlyOrthologs);
+    ColumnIterator colIt(&al, genome, &targets, startPosition + seq.start, lastPosition + seq.start, noDupes, noAncestors, onlyOrthologs,
+                         unique);
     size_t appendCount = 0;
-    initBlock(colIt);
-    appendColumn(colIt);
-    ++appendCount;
+    if (!unique || colIt.isCanonicalOnRef()) {
+        initBlock(colIt);
+        appendColumn(colIt);
+        ++appendCount;
+    }
     ++numColumns;
     size_t numBlocks = 0;
     while (!colIt.lastColumn()) {
         colIt.toRight();
         ++numColumns;
-        if (!canAppendColumn(colIt)) {
-            if (numBlocks++ % 1000 == 0)
-                colIt.defragment();
-            if (appendCount > 0 && (keepEmptyRefBlocks || !referenceIsAllGaps())) {
-                printBlock(os);
-                os << '\n';
+        if (!unique || colIt.isCanonicalOnRef()) {
+            if (appendCount == 0)
+                initBlock(colIt);
+            if (!canAppendColumn(colIt)) {
+                if (numBlocks++ % 1000 == 0)
+                    colIt.defragment();
+                if (appendCount > 0 && (keepEmptyRefBlocks || !referenceIsAllGaps())) {
+                    printBlock(os);
+                    os << '\n';
+                }
+                initBlock(colIt);
             }
-            initBlock(colIt);
+            appendColumn(colIt);
+            ++appendCount;
         }
-        appendColumn(colIt);
-        ++appendCount;
     }
     if (appendCount > 0 && (keepEmptyRefBlocks || !referenceIsAllGaps())) {
         printBlock(os);

@@ -36,13 +36,42 @@ struct SeqKey {
     }
 };
 
+// api/impl/halPositionCache.cpp:12-78: set of positions kept as merged intervals (map: last -> first)
+struct PositionCache {
+    std::map<i64, i64> set;
+    bool find(i64 pos) const {
+        auto i = set.lower_bound(pos);
+        return i != set.end() && i->second <= pos;
+    }
+    bool insert(i64 pos) { // false if already present
+        if (find(pos))
+            return false;
+        i64 first = pos, last = pos;
+        auto right = set.lower_bound(pos); // interval starting after pos (its first == pos + 1 merges)
+        if (right != set.end() && right->second == pos + 1) {
+            last = right->first;
+            set.erase(right);
+        }
+        auto left = set.find(pos - 1); // interval ending at pos - 1 merges
+        if (left != set.end()) {
+            first = left->second;
+            set.erase(left);
+        }
+        set[last] = first;
+        return true;
+    }
+};
+
 struct ColumnIterator {
     typedef std::vector<Dna> DNASet;
     typedef std::map<SeqKey, DNASet> ColumnMap;
 
     const Alignment *al;
     int refGenome;
-    bool noDupes, noAncestors, onlyOrthologs;
+    bool noDupes, noAncestors, onlyOrthologs, unique = false;
+    std::map<int, PositionCache> visitCache; // halColumnIterator.h: VisitCache (per genome)
+    bool brk = false;                        // _break
+    i64 leftmostRefPos = 0;
     std::set<int> targets, scope;
     // the single stack entry of the maxInsertLength == 0 case (halColumnIteratorStack.h:47-107)
     int seqIdx;
@@ -52,7 +81,10 @@ struct ColumnIterator {
     i64 prevRefIndex;
 
     ColumnIterator(const Alignment *a, int reference, const std::set<int> *tgts, i64 columnIndex, i64 lastColumnIndex, bool noDupes_,
-                   bool noAncestors_, bool onlyOrthologs_);
+                   bool noAncestors_, bool onlyOrthologs_, bool unique_ = false);
+    bool isCanonicalOnRef() const { // halColumnIterator.cpp:210-214
+        return leftmostRefPos >= firstIndex && leftmostRefPos <= lastIndex;
+    }
     void toRight();
     bool lastColumn() const {
         return index > lastIndex;
@@ -73,7 +105,8 @@ struct ColumnIterator {
         return scope.empty() || scope.count(al->genomes[(size_t)g].children[(size_t)slot]);
     }
     void recursiveUpdate();
-    void colMapInsert(const SegIt &it);
+    bool colMapInsert(const SegIt &it);
+    void nextFreeIndex();
     void updateParent(const SegIt &top);
     void updateChild(const SegIt &bot, i64 slot);
     void updateNextTopDup(const SegIt &top);
@@ -99,7 +132,7 @@ struct MafBlockEntry {
 
 struct MafExport {
     bool noDupes = false, noAncestors = false, ucscNames = true /* Genome.Sequence */, onlyOrthologs = false, keepEmptyRefBlocks = false,
-         append = false;
+         append = false, unique = false;
     i64 maxBlockLength = 1000; // MafBlock::defaultMaxLength, halMafBlock.cpp:16
     void convertSequence(std::ostream &os, const Alignment &al, int genome, int seq, i64 startPosition, i64 length,
                          const std::set<int> &targets);

@@ -71,7 +71,8 @@ static int cmdColumns(bool maf, int argc, char **argv) {
     std::vector<std::string> pos;
     std::string refGenome, refSequence, targetGenomes, rootGenome;
     i64 start = 0, length = 0, step = 1, maxBlockLen = 1000;
-    bool countDupes = false, noAncestors = false, noDupes = false, onlySequenceNames = false, onlyOrthologs = false, stats = false;
+    bool countDupes = false, noAncestors = false, noDupes = false, onlySequenceNames = false, onlyOrthologs = false, stats = false,
+         unique = false;
     for (int i = 0; i < argc; ++i) {
         std::string a = argv[i];
         if (a == "--refGenome")
@@ -100,6 +101,8 @@ static int cmdColumns(bool maf, int argc, char **argv) {
             onlySequenceNames = true;
         else if (a == "--onlyOrthologs")
             onlyOrthologs = true;
+        else if (a == "--unique")
+            unique = true;
         else if (a == "--stats")
             stats = true;
         else
@@ -163,6 +166,7 @@ static int cmdColumns(bool maf, int argc, char **argv) {
         me.noAncestors = noAncestors;
         me.ucscNames = !onlySequenceNames;
         me.onlyOrthologs = onlyOrthologs;
+        me.unique = unique;
         me.maxBlockLength = maxBlockLen <= 0 ? std::numeric_limits<i64>::max() : maxBlockLen;
         if (seq >= 0) {
             me.convertSequence(buf, al, ref, seq, start, length, targetSet);

@@ -36,6 +36,8 @@ def test_reference_cli_goldens_hal2maf(hal, tmp_path):
     assert al.maf_export(al.genome_id("Genome_0")) == open(os.path.join(GOLD, "ref_maf", "hal2mafSmallTest.maf")).read()
     g2 = al.genome_id("Genome_2")
     assert al.maf_export(g2, 0, start=1000, length=2000) == open(os.path.join(GOLD, "ref_maf", "hal2mafSeqPartTest.maf")).read()
+    # maf/Makefile:48-50 hal2mafSeqTest: --unique
+    assert al.maf_export(g2, 0, unique=True) == open(os.path.join(GOLD, "ref_maf", "hal2mafSeqTest.maf")).read()
 
 
 @pytest.mark.parametrize("seed", [2, 5, 6])
@@ -96,6 +98,16 @@ def test_maf_vs_oracle(hal, oracle_bin, tmp_path, seed):
         _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", leaf, "--onlyOrthologs", "--onlySequenceNames", "--maxBlockLen", "50")
     assert al.maf_export(g, targets=[0, 2]) == _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", leaf, "--targetGenomes",
                                                         "Genome_0,Genome_2")
+    # --unique on whole sequences and on sub-ranges (what hal2mafMP's slices run, maf/hal2mafMP.py:63-79)
+    for name in ("Genome_0", "Genome_1", leaf):
+        gg = al.genome_id(name)
+        assert al.maf_export(gg, unique=True) == _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", name, "--unique"), name
+        n = al.genome_length(gg)
+        sname = al.sequences(gg)[0][0]
+        for a, ln in ((0, n // 3), (n // 3, n // 3), (2 * (n // 3), n - 2 * (n // 3))):
+            assert al.maf_export(gg, 0, start=a, length=ln, unique=True) == \
+                _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", name, "--refSequence", sname, "--start", str(a), "--length",
+                        str(ln), "--unique"), (name, a, ln)
 
 
 def test_maf_handbuilt_inversions(hal, oracle_bin, tmp_path):

@@ -109,3 +109,10 @@ def test_reference_unit_test_bed12_psl_literals(oracle_bin, tmp_path):
         extra = ["--outPSLWithName"] if pslname else (["--outPSL"] if psl else [])
         subprocess.check_call([oracle_bin, "liftover", img, src, inp, tgt, out] + extra)
         assert open(out).read() == want
+
+
+def test_reference_cli_golden_hal2maf_unique(hal, oracle_bin, tmp_path):
+    # maf/Makefile:48-50 hal2mafSeqTest: --refGenome Genome_2 --refSequence Genome_2_seq --unique (visit cache)
+    _, img = _small_seed0(hal, tmp_path)
+    got = _oracle_maf(oracle_bin, img, tmp_path, "--refGenome", "Genome_2", "--refSequence", "Genome_2_seq", "--unique")
+    assert got == open(os.path.join(GOLD, "ref_maf", "hal2mafSeqTest.maf")).read()
