@@ -104,3 +104,102 @@ def simple_genome(name, parent, children, length, tops, bots, dna=None, seqname=
         g["dna"] = dna
     fix_parse_info(g)
     return g
+
+
+def random_multiseq_alignment(seed, n_genomes=6, max_children=3, root_len=400, max_seqs=4):
+    """Independent random alignment generator for tests (not halRandGen): irregular segment lengths, several
+    sequences per genome, inversions, insertions, deletions, duplications (paralogy rings).  Returns the genome
+    dict list for write_hgx.  Invariants kept: segments never span sequences, child top segment length == parent
+    bottom segment length, bottom child slot points at one (canonical) member of the ring."""
+    import random
+    rnd = random.Random(seed)
+    parents = [-1]
+    children = [[]]
+    for g in range(1, n_genomes):
+        cands = [p for p in range(g) if len(children[p]) < max_children]
+        p = rnd.choice(cands)
+        parents.append(p)
+        children.append([])
+        children[p].append(g)
+
+    def cut(total, lo, hi):
+        out, pos = [], 0
+        while pos < total:
+            l = min(total - pos, rnd.randint(lo, hi))
+            out.append(l)
+            pos += l
+        return out
+
+    genomes = [None] * n_genomes
+    bot_lens = {}
+    for g in range(n_genomes):
+        p = parents[g]
+        top = []  # (len, parentIdx, rev)
+        if p < 0:
+            total = root_len
+        else:
+            pl = bot_lens[p]
+            k = max(3, int(len(pl) * rnd.uniform(0.7, 1.4)))
+            i = 0
+            for _ in range(k):
+                r = rnd.random()
+                if r < 0.15:
+                    top.append((rnd.randint(1, 25), NULL, False))      # insertion
+                elif r < 0.35:
+                    j = rnd.randrange(len(pl))
+                    top.append((pl[j], j, rnd.random() < 0.4))         # transposition / duplication
+                else:
+                    top.append((pl[i % len(pl)], i % len(pl), rnd.random() < 0.3))
+                    i += rnd.choice([1, 1, 1, 2])                      # occasional deletion
+            total = sum(t[0] for t in top)
+        tb = [0]
+        for t in top:
+            tb.append(tb[-1] + t[0])
+        nseq = rnd.randint(1, max_seqs)
+        if p < 0:
+            sb = sorted(set([0, total] + [rnd.randrange(1, total) for _ in range(nseq - 1)]))
+        else:
+            inner = tb[1:-1]
+            sb = sorted(set([0, total] + (rnd.sample(inner, min(len(inner), nseq - 1)) if inner else [])))
+        bstarts = []
+        if children[g]:
+            for a, b in zip(sb[:-1], sb[1:]):
+                pos = a
+                for l in cut(b - a, 3, 30):
+                    bstarts.append(pos)
+                    pos += l
+        bl = [(bstarts[i + 1] if i + 1 < len(bstarts) else total) - bstarts[i] for i in range(len(bstarts))]
+        bot_lens[g] = bl
+        name = "G%d" % g
+        gd = {"name": name, "parent": p, "children": children[g], "branch": rnd.randint(0, 2)}
+        gd["tStart"] = tb if top else [total]
+        gd["tParent"] = [t[1] for t in top]
+        gd["tParentRev"] = [1 if t[2] else 0 for t in top]
+        gd["tParalogy"] = [NULL] * len(top)
+        gd["bStart"] = bstarts + [total]
+        gd["bChild"] = [[NULL] * len(bstarts) for _ in children[g]]
+        gd["bChildRev"] = [[0] * len(bstarts) for _ in children[g]]
+        seqs = []
+        for si, (a, b) in enumerate(zip(sb[:-1], sb[1:])):
+            ti = [i for i in range(len(top)) if a <= tb[i] < b]
+            bi = [i for i in range(len(bstarts)) if a <= bstarts[i] < b]
+            seqs.append(("%s_chr%d" % (name, si), a, b - a, ti[0] if ti else 0, len(ti), bi[0] if bi else 0, len(bi)))
+        gd["seqs"] = seqs
+        gd["dna"] = "".join(rnd.choice("ACGTacgtN") for _ in range(total))
+        genomes[g] = gd
+        if p >= 0:
+            P = genomes[p]
+            slot = P["children"].index(g)
+            ring = {}
+            for i, (l, pi, rev) in enumerate(top):
+                if pi != NULL:
+                    ring.setdefault(pi, []).append(i)
+            for pi, members in ring.items():
+                canon = rnd.choice(members)
+                P["bChild"][slot][pi] = canon
+                P["bChildRev"][slot][pi] = gd["tParentRev"][canon]
+                if len(members) > 1:
+                    for a, b in zip(members, members[1:] + members[:1]):
+                        gd["tParalogy"][a] = b
+        fix_parse_info(gd)
+    return genomes
