@@ -28,6 +28,23 @@ template <> struct alignas(16) TopRec<int64_t> {
     int32_t botParse;
     int32_t _pad[3];
 };
+// Up-walk record of a top segment: what the next level of the walk needs from the PARENT's bottom segment (its start
+// and its top-parse index) is copied next to the child's own start and link, so going up one level never touches the
+// parent's bottom table.
+template <typename C> struct UpRec;
+template <> struct alignas(16) UpRec<int32_t> {
+    int32_t start;
+    int32_t parentEnc;
+    int32_t parentStart;    // start coordinate of the parent bottom segment (undefined when parentEnc < 0)
+    int32_t parentTopParse; // its topParseIndex (-1 when the parent genome has no top tiling)
+};
+template <> struct alignas(16) UpRec<int64_t> {
+    int64_t start;
+    int64_t parentStart;
+    int32_t parentEnc;
+    int32_t parentTopParse;
+    int64_t _pad;
+};
 template <typename C> struct BotRec;
 template <> struct alignas(8) BotRec<int32_t> {
     int32_t start;
@@ -41,6 +58,7 @@ template <> struct alignas(16) BotRec<int64_t> {
 
 struct DeviceGenome {
     void *top = nullptr;                // TopRec<C>[numTop+1]
+    void *up = nullptr;                 // UpRec<C>[numTop+1] (genomes with a parent)
     void *bot = nullptr;                // BotRec<C>[numBot+1]
     std::vector<int32_t *> childEnc;    // per child slot, int32[numBot]
     int64_t *seqStart = nullptr;        // int64[numSeq+1] (sentinel = genome length)

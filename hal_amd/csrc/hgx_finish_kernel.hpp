@@ -679,17 +679,18 @@ __global__ void __launch_bounds__(256) k_compact_records(const hgx_record *__res
                                                          const hgx_record *__restrict__ big, const int32_t *__restrict__ bigSlot, int bigCap,
                                                          const uint32_t *__restrict__ nOut, const uint32_t *__restrict__ outOffset, uint32_t nq,
                                                          hgx_record *__restrict__ out) {
-    // one wavefront per query (records per query are few)
-    const uint32_t wavesTotal = (gridDim.x * blockDim.x) >> 6;
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    for (uint32_t q = wave; q < nq; q += wavesTotal) {
+    // eight lanes per query: most intervals produce a handful of records
+    const uint32_t groupsTotal = (gridDim.x * blockDim.x) >> 3;
+    const uint32_t group = (blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    const uint32_t li = threadIdx.x & 7;
+    for (uint32_t q = group; q < nq; q += groupsTotal) {
         const uint32_t n = nOut[q];
         if (n == 0)
             continue;
         const int32_t bs = bigSlot ? bigSlot[q] : -1;
         const hgx_record *src = bs >= 0 ? big + (size_t)bs * bigCap : grouped + offset[q];
         hgx_record *dst = out + outOffset[q];
-        for (uint32_t k = lane_id(); k < n; k += 64)
+        for (uint32_t k = li; k < n; k += 8)
             dst[k] = src[k];
     }
 }

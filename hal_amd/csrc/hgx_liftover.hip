@@ -24,6 +24,8 @@ DeviceImage::~DeviceImage() {
     for (DeviceGenome &g : genomes) {
         if (g.top)
             (void)hipFree(g.top);
+        if (g.up)
+            (void)hipFree(g.up);
         if (g.bot)
             (void)hipFree(g.bot);
         for (int32_t *c : g.childEnc)
@@ -88,6 +90,25 @@ static inline int32_t encLink(int64_t idx, bool rev) {
     return idx < 0 ? -1 : (int32_t)((idx << 1) | (rev ? 1 : 0));
 }
 
+template <typename C> static void uploadUpTable(const GenomeTables &G, const GenomeTables &P, DeviceGenome &D, size_t &bytes) {
+    std::vector<UpRec<C>> up((size_t)G.numTop + 1);
+    memset(up.data(), 0, up.size() * sizeof(UpRec<C>));
+    for (int64_t i = 0; i < G.numTop; ++i) {
+        UpRec<C> &r = up[(size_t)i];
+        const int64_t p = G.tParent[(size_t)i];
+        r.start = (C)G.tStart[(size_t)i];
+        r.parentEnc = p < 0 ? -1 : (int32_t)((p << 1) | (G.tParentRev[(size_t)i] ? 1 : 0));
+        r.parentStart = p < 0 ? 0 : (C)P.bStart[(size_t)p];
+        r.parentTopParse = p < 0 ? -1 : (int32_t)P.bTopParse[(size_t)p];
+    }
+    up[(size_t)G.numTop].start = (C)G.totalLength;
+    up[(size_t)G.numTop].parentEnc = -1;
+    up[(size_t)G.numTop].parentTopParse = -1;
+    HIP_OK(hipMalloc(&D.up, up.size() * sizeof(UpRec<C>)));
+    HIP_OK(hipMemcpy(D.up, up.data(), up.size() * sizeof(UpRec<C>), hipMemcpyHostToDevice));
+    bytes += up.size() * sizeof(UpRec<C>);
+}
+
 template <typename C> static void uploadGenome(const GenomeTables &G, DeviceGenome &D, size_t &bytes) {
     std::vector<TopRec<C>> top((size_t)G.numTop + 1);
     memset(top.data(), 0, top.size() * sizeof(TopRec<C>));
@@ -145,6 +166,12 @@ std::unique_ptr<DeviceImage> uploadImage(const Image &img, int device) {
             uploadGenome<int64_t>(G, dg, D->bytes);
         else
             uploadGenome<int32_t>(G, dg, D->bytes);
+        if (G.parent >= 0 && G.numTop > 0) {
+            if (D->wide)
+                uploadUpTable<int64_t>(G, img.genomes[(size_t)G.parent], dg, D->bytes);
+            else
+                uploadUpTable<int32_t>(G, img.genomes[(size_t)G.parent], dg, D->bytes);
+        }
         dg.childEnc.assign(G.children.size(), nullptr);
         std::vector<int32_t> enc((size_t)G.numBot);
         for (size_t k = 0; k < G.children.size(); ++k) {
@@ -270,7 +297,7 @@ struct hgx_liftover_plan {
     }
     Frontier frontier(int k) {
         return Frontier{(int32_t *)fr[k][0].p, (int64_t *)fr[k][1].p, (int32_t *)fr[k][2].p,
-                        (int32_t *)fr[k][3].p, (int32_t *)fr[k][4].p, (uint8_t *)fr[k][5].p};
+                        (int64_t *)fr[k][3].p, (int32_t *)fr[k][4].p, (uint8_t *)fr[k][5].p};
     }
     Mapped mapped(int k) {
         return Mapped{(int32_t *)mp[k][0].p, (int64_t *)mp[k][1].p, (int64_t *)mp[k][2].p,
@@ -278,7 +305,7 @@ struct hgx_liftover_plan {
     }
     void allocate(uint32_t newCap) {
         cap = newCap;
-        static const size_t fsz[6] = {4, 8, 4, 4, 4, 1}, msz[6] = {4, 8, 8, 8, 8, 1};
+        static const size_t fsz[6] = {4, 8, 4, 8, 4, 1}, msz[6] = {4, 8, 8, 8, 8, 1};
         for (int k = 0; k < 2; ++k)
             for (int a = 0; a < 6; ++a) {
                 fr[k][a].ensure(fsz[a] * (size_t)cap);
@@ -311,7 +338,7 @@ static void exclusiveScan(hgx_liftover_plan &P, const uint32_t *in, uint32_t n, 
     const uint32_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
     P.timer.begin("scan", s);
     hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(256), 0, s, in, n, (uint32_t *)P.blockSums.p);
-    hipLaunchKernelGGL(k_scan_sums_serial, dim3(1), dim3(64), 0, s, (uint32_t *)P.blockSums.p, nb, total);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, (uint32_t *)P.blockSums.p, nb, total);
     hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, s, in, n, (const uint32_t *)P.blockSums.p, out);
     P.timer.end(s);
 }
@@ -352,28 +379,32 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
     bool curTop = P.srcTop;
     int curGenome = P.src;
     if (P.src != P.mrca) {
-        // first hop: top pieces of the source -> bottom pieces of its parent
-        P.timer.begin("k_up_top", s, launch);
-        hipLaunchKernelGGL((k_up_top<C>), dim3(GRID), dim3(256), 0, s, (const TopRec<C> *)D.genomes[(size_t)curGenome].top,
-                           P.frontier(cur), inCnt(), cap, P.frontier(cur ^ 1), outCnt(), minLen, cnt, kstat());
-        P.timer.end(s);
-        ++launch;
-        cur ^= 1;
-        ++level;
-        curGenome = P.up[1];
-        curTop = false;
-        for (size_t k = 1; k + 1 < P.up.size(); ++k) {
-            const DeviceGenome &G = D.genomes[(size_t)P.up[k]];
-            P.timer.begin("k_parse_up_then_up", s, launch);
-            hipLaunchKernelGGL((k_parse_up_then_up<C>), dim3(GRID), dim3(256), 0, s, (const BotRec<C> *)G.bot,
-                               (const TopRec<C> *)G.top, P.frontier(cur), inCnt(), cap, P.frontier(cur ^ 1), outCnt(), minLen,
-                               cnt, kstat());
+        // up phase: P.up = [src, ..., mrca].  k_up_first lifts the source's top pieces to its parent; every further level
+        // is one k_up_walk launch.  The last launch emits ordinary bottom pieces (index, offset) in the MRCA, the
+        // others emit positional pieces (forward start in the parent + its top-parse hint).
+        const size_t nUp = P.up.size() - 1; // number of hops
+        {
+            const bool last = nUp == 1;
+            P.timer.begin("k_up_first", s, launch);
+            hipLaunchKernelGGL((k_up_first<C>), dim3(GRID), dim3(256), 0, s, (const UpRec<C> *)D.genomes[(size_t)P.src].up,
+                               P.frontier(cur), inCnt(), cap, P.frontier(cur ^ 1), outCnt(), minLen, (int)last, cnt, kstat());
             P.timer.end(s);
             ++launch;
             cur ^= 1;
             ++level;
-            curGenome = P.up[k + 1];
         }
+        for (size_t k = 1; k < nUp; ++k) {
+            const bool last = k + 1 == nUp;
+            P.timer.begin("k_up_walk", s, launch);
+            hipLaunchKernelGGL((k_up_walk<C>), dim3(GRID), dim3(256), 0, s, (const UpRec<C> *)D.genomes[(size_t)P.up[k]].up,
+                               P.frontier(cur), inCnt(), cap, P.frontier(cur ^ 1), outCnt(), minLen, (int)last, cnt, kstat());
+            P.timer.end(s);
+            ++launch;
+            cur ^= 1;
+            ++level;
+        }
+        curGenome = P.mrca;
+        curTop = false;
     }
     if (P.tgt != P.mrca) {
         if (curTop) { // source is the MRCA itself and is walked through its top tiling

@@ -21,7 +21,7 @@ struct Frontier {
     int32_t *qid;
     int64_t *sPos; // source position of the piece's first base in iteration order
     int32_t *idx;  // segment index in the current genome
-    int32_t *so;   // start offset in iteration order (api/inc/halSegmentIterator.h:115)
+    int64_t *so;   // start offset in iteration order (api/inc/halSegmentIterator.h:115); positional pieces: forward start
     int32_t *len;
     uint8_t *flags;
 };
@@ -99,14 +99,14 @@ __device__ __forceinline__ void put(const Frontier &f, unsigned long long slot, 
 // coalesced stores.  The frontier itself is split into NSEG independent segments (block b appends to segment
 // b mod NSEG, each with its own counter word), so the remaining atomics spread over 64 addresses instead of
 // serialising on one.  Order inside a frontier is irrelevant (the result is re-grouped by query later).
-static constexpr int STAGE_CAP = 192;   // pieces per wavefront window (4 waves x 192 x 25 B = 19 KB per block)
+static constexpr int STAGE_CAP = 160;   // pieces per wavefront window (4 waves x 160 x 29 B = 18.5 KB per block)
 static constexpr int STAGE_FLUSH = STAGE_CAP - 64;
 
 struct StageMem { // one per block, declared __shared__ by the kernel
     int64_t sPos[4 * STAGE_CAP];
     int32_t qid[4 * STAGE_CAP];
     int32_t idx[4 * STAGE_CAP];
-    int32_t so[4 * STAGE_CAP];
+    int64_t so[4 * STAGE_CAP];
     int32_t len[4 * STAGE_CAP];
     uint8_t fl[4 * STAGE_CAP];
 };
@@ -167,7 +167,7 @@ struct Stage {
         wave_lds_fence();
     }
     // all lanes of the wave call this together; lanes with emit == true contribute one piece
-    __device__ __forceinline__ void emit(bool doEmit, int32_t qid, int64_t sPos, int32_t idx, int32_t so, int32_t len, uint8_t fl) {
+    __device__ __forceinline__ void emit(bool doEmit, int32_t qid, int64_t sPos, int32_t idx, int64_t so, int32_t len, uint8_t fl) {
         const unsigned long long mask = __ballot(doEmit);
         if (mask == 0)
             return;
@@ -296,19 +296,26 @@ __global__ void __launch_bounds__(256) k_locate_expand(const REC *__restrict__ s
 }
 
 // ---------------------------------------------------------------------------------------------
-// U: top piece -> parent's bottom piece.  mapUp, top branch (halSegmentMapper.cpp:29-38) with
-// BottomSegmentIterator::toParent (api/impl/halBottomSegmentIterator.cpp:40-49): index = parentIndex,
-// offsets copied, strand ^= parentReversed; dropped when there is no parent or len < minLength.
-// (doDupes is always true on the way up, halSegmentMapper.cpp:108.)
+// Up phase.  mapUp (halSegmentMapper.cpp:25-80) alternates two steps per level: a top piece goes to its parent's
+// bottom segment (toParent, api/impl/halBottomSegmentIterator.cpp:40-49: index = parentIndex, offsets copied,
+// strand ^= parentReversed; dropped without a parent or below minLength; doDupes is always true on the way up, :108),
+// and the resulting bottom piece is re-expressed on the parent genome's top tiling (toParseUp,
+// api/impl/halTopSegmentIterator.cpp:55-81, + the toRight(rightCutoff) loop of :46-77), which splits it wherever the
+// two tilings disagree, the source being sliced by the same deltas (:52-62).
+// With UpRec the parent's start and top-parse index come with the child's record, so a piece travels between levels
+// as "forward start in the parent genome + length + top-parse hint" and one level costs only the walk over the
+// parent genome's UpRec table.  The hop into the MRCA emits ordinary bottom pieces (index + offset) instead.
+
+// source top pieces -> parent (positional, or ordinary when the parent is the MRCA)
 template <typename C>
-__global__ void __launch_bounds__(256) k_up_top(const TopRec<C> *__restrict__ top, Frontier in, const unsigned long long *inCount, uint32_t cap,
-                                                Frontier out, unsigned long long *outCount, int64_t minLength,
-                                                unsigned long long *counters, unsigned long long *kstat) {
+__global__ void __launch_bounds__(256) k_up_first(const UpRec<C> *__restrict__ up, Frontier in, const unsigned long long *inCount, uint32_t cap,
+                                                  Frontier out, unsigned long long *outCount, int64_t minLength, int last,
+                                                  unsigned long long *counters, unsigned long long *kstat) {
     __shared__ FrontView fview;
     const uint32_t n = front_view_init(&fview, inCount, cap);
     const uint32_t wavesTotal = (gridDim.x * blockDim.x) >> 6;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    uint32_t derefs = 0;
+    uint32_t topDerefs = 0, botDerefs = 0;
     __shared__ StageMem stageMem;
     Stage stage;
     stage.init(&stageMem, out, outCount, counters, cap);
@@ -316,43 +323,44 @@ __global__ void __launch_bounds__(256) k_up_top(const TopRec<C> *__restrict__ to
         const uint32_t li = base + lane_id();
         const uint32_t i = li < n ? front_slot(&fview, li, cap) : 0;
         bool emit = false;
-        int32_t qid = 0, idx = 0, so = 0, len = 0;
-        int64_t sPos = 0;
+        int32_t qid = 0, oIdx = 0, len = 0;
+        int64_t sPos = 0, oSo = 0;
         uint8_t fl = 0;
         if (li < n) {
-            idx = in.idx[i];
+            const int32_t t = in.idx[i];
             len = in.len[i];
-            const int32_t enc = top[idx].parentEnc;
-            ++derefs;
-            if (enc >= 0 && (int64_t)len >= minLength) {
+            const UpRec<C> r = up[t];
+            ++topDerefs;
+            if (r.parentEnc >= 0 && (int64_t)len >= minLength) {
                 emit = true;
                 qid = in.qid[i];
                 sPos = in.sPos[i];
-                so = in.so[i];
+                const int32_t so = (int32_t)in.so[i];
                 fl = in.flags[i];
-                if (enc & 1)
+                if (r.parentEnc & 1)
                     fl ^= F_TREV;
-                idx = enc >> 1;
+                if (last) {
+                    oIdx = r.parentEnc >> 1;
+                    oSo = so;
+                } else {
+                    const int64_t segLen = (int64_t)up[t + 1].start - (int64_t)r.start;
+                    oIdx = r.parentTopParse;
+                    oSo = !(fl & F_TREV) ? (int64_t)r.parentStart + so : (int64_t)r.parentStart + segLen - so - len;
+                }
             }
         }
-        stage.emit(emit, qid, sPos, idx, so, len, fl);
+        stage.emit(emit, qid, sPos, oIdx, oSo, len, fl);
     }
     stage.flush();
-    wave_count_add(&kstat[0], derefs);
+    wave_count_add(&kstat[0], topDerefs);
+    wave_count_add(&kstat[1], botDerefs);
 }
 
-// ---------------------------------------------------------------------------------------------
-// PU+U: bottom piece in genome P -> pieces of P's top tiling -> each to the bottom tiling of P's parent.
-// mapUp, bottom branch (halSegmentMapper.cpp:39-78): TopSegmentIterator::toParseUp
-// (api/impl/halTopSegmentIterator.cpp:55-81) starts at topParseIndex, steps right until the top segment
-// contains the piece's first base, truncates the piece to that segment, and the caller loops
-// toRight(rightCutoff) over the rest; the source is sliced by the same deltas (:52-62).  Each resulting
-// top piece then takes the U hop above.  In forward coordinates: split [lo,hi] at P's top-segment starts.
+// positional pieces in genome P -> split on P's top tiling -> P's parent (positional, or ordinary when that is the MRCA)
 template <typename C>
-__global__ void __launch_bounds__(256) k_parse_up_then_up(const BotRec<C> *__restrict__ bot, const TopRec<C> *__restrict__ top, Frontier in,
-                                                          const unsigned long long *inCount, uint32_t cap, Frontier out,
-                                                          unsigned long long *outCount, int64_t minLength,
-                                                          unsigned long long *counters, unsigned long long *kstat) {
+__global__ void __launch_bounds__(256) k_up_walk(const UpRec<C> *__restrict__ up, Frontier in, const unsigned long long *inCount, uint32_t cap,
+                                                 Frontier out, unsigned long long *outCount, int64_t minLength, int last,
+                                                 unsigned long long *counters, unsigned long long *kstat) {
     __shared__ FrontView fview;
     const uint32_t n = front_view_init(&fview, inCount, cap);
     const uint32_t wavesTotal = (gridDim.x * blockDim.x) >> 6;
@@ -368,69 +376,69 @@ __global__ void __launch_bounds__(256) k_parse_up_then_up(const BotRec<C> *__res
         int32_t qid = 0;
         int64_t sPos = 0, lo = 0, hi = -1;
         uint8_t fl = 0;
-        int64_t j = 0, curStart = 0;
+        int64_t j = 0;
+        UpRec<C> cur;
+        cur.start = 0;
+        cur.parentEnc = -1;
+        cur.parentStart = 0;
+        cur.parentTopParse = -1;
         if (act) {
-            const int32_t b = in.idx[i];
-            const int32_t so = in.so[i], len = in.len[i];
             qid = in.qid[i];
             sPos = in.sPos[i];
             fl = in.flags[i];
-            const BotRec<C> br = bot[b];
-            ++botDerefs;
-            if (!(fl & F_TREV)) {
-                lo = (int64_t)br.start + so;
-            } else {
-                const int64_t bEnd = (int64_t)bot[b + 1].start; // segment end (exclusive)
-                lo = bEnd - so - len;
-            }
-            hi = lo + len - 1;
-            j = br.topParse;
-            ++topDerefs;
-            // toParseUp's "while startPos >= segStart+segLen ++index" (halTopSegmentIterator.cpp:64-66),
-            // applied to the piece's left end (the right end is reached by the toRight loop)
-            for (;;) {
-                const int64_t nextStart = (int64_t)top[j + 1].start;
-                if (nextStart > lo)
-                    break;
+            lo = in.so[i];
+            hi = lo + in.len[i] - 1;
+            j = in.idx[i];
+            // toParseUp's "while startPos >= segStart+segLen ++index" (halTopSegmentIterator.cpp:64-66), applied to the
+            // piece's left end (the right end is reached by the toRight loop)
+            while ((int64_t)up[j + 1].start <= lo) {
                 ++j;
                 ++topDerefs;
             }
-            curStart = (int64_t)top[j].start;
+            cur = up[j];
+            ++topDerefs;
+            ++botDerefs; // logical dereference of the bottom segment this piece came from
         }
         while (__any(act)) {
             bool emit = false;
-            int32_t oIdx = 0, oSo = 0, oLen = 0;
-            int64_t oSPos = 0;
+            int32_t oIdx = 0, oLen = 0;
+            int64_t oSPos = 0, oSo = 0;
             uint8_t oFl = fl;
-            int64_t nextStart = 0;
+            UpRec<C> nxt = cur;
             if (act) {
-                const TopRec<C> tr = top[j];
-                nextStart = (int64_t)top[j + 1].start;
+                nxt = up[j + 1];
+                const int64_t curStart = (int64_t)cur.start, nextStart = (int64_t)nxt.start;
                 const int64_t plo = lo > curStart ? lo : curStart;
                 const int64_t phi = hi < nextStart - 1 ? hi : nextStart - 1;
                 oLen = (int32_t)(phi - plo + 1);
-                const int32_t enc = tr.parentEnc;
-                if (enc >= 0 && (int64_t)oLen >= minLength) {
+                if (cur.parentEnc >= 0 && (int64_t)oLen >= minLength) {
                     emit = true;
-                    int64_t d; // distance of the sub-piece's first base from the piece's first base
+                    int64_t so, d; // offset in the top segment, and distance from the piece's first base (iteration order)
                     if (!(fl & F_TREV)) {
-                        oSo = (int32_t)(plo - curStart);
+                        so = plo - curStart;
                         d = plo - lo;
                     } else {
-                        oSo = (int32_t)(nextStart - 1 - phi);
+                        so = nextStart - 1 - phi;
                         d = hi - phi;
                     }
                     oSPos = (fl & F_SREV) ? sPos - d : sPos + d;
-                    if (enc & 1)
+                    if (cur.parentEnc & 1)
                         oFl ^= F_TREV;
-                    oIdx = enc >> 1;
+                    if (last) {
+                        oIdx = cur.parentEnc >> 1;
+                        oSo = so;
+                    } else {
+                        oIdx = cur.parentTopParse;
+                        const int64_t segLen = nextStart - curStart;
+                        oSo = !(oFl & F_TREV) ? (int64_t)cur.parentStart + so : (int64_t)cur.parentStart + segLen - so - oLen;
+                    }
                 }
             }
             stage.emit(emit, qid, oSPos, oIdx, oSo, oLen, oFl);
             if (act) {
                 ++j;
-                curStart = nextStart;
-                act = curStart <= hi;
+                cur = nxt;
+                act = (int64_t)cur.start <= hi;
                 if (act)
                     ++topDerefs;
             }
@@ -476,7 +484,7 @@ __global__ void __launch_bounds__(256) k_down_ring(const int32_t *__restrict__ c
                 act = true;
                 qid = in.qid[i];
                 sPos = in.sPos[i];
-                so = in.so[i];
+                so = (int32_t)in.so[i];
                 fl = in.flags[i];
                 if (enc & 1)
                     fl ^= F_TREV;
@@ -546,7 +554,7 @@ __global__ void __launch_bounds__(256) k_parse_down(const TopRec<C> *__restrict_
         int64_t j = 0, curStart = 0;
         if (act) {
             const int32_t t = in.idx[i];
-            const int32_t so = in.so[i], len = in.len[i];
+            const int32_t so = (int32_t)in.so[i], len = in.len[i];
             qid = in.qid[i];
             sPos = in.sPos[i];
             fl = in.flags[i];
@@ -617,7 +625,7 @@ __global__ void __launch_bounds__(256) k_finalize(const REC *__restrict__ segs, 
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t p = front_slot(&fview, i, cap);
         const int32_t idx = in.idx[p];
-        const int32_t so = in.so[p], len = in.len[p];
+        const int32_t so = (int32_t)in.so[p], len = in.len[p];
         const uint8_t fl = in.flags[p];
         const int64_t sPos = in.sPos[p];
         const int32_t q = in.qid[p];
@@ -682,17 +690,32 @@ __global__ void __launch_bounds__(256) k_scan_block_sums(const uint32_t *__restr
     if (threadIdx.x == 0)
         blockSums[blockIdx.x] = red[0];
 }
-__global__ void k_scan_sums_serial(uint32_t *blockSums, uint32_t nb, uint32_t *total) {
-    // one thread; nb = n/1024 is at most a few thousand for the batches this library sees
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        uint32_t acc = 0;
-        for (uint32_t i = 0; i < nb; ++i) {
-            const uint32_t v = blockSums[i];
-            blockSums[i] = acc;
-            acc += v;
-        }
-        *total = acc;
+// exclusive scan of the per-block sums by one 1024-thread block (each thread owns a contiguous run)
+__global__ void __launch_bounds__(1024) k_scan_sums(uint32_t *blockSums, uint32_t nb, uint32_t *total) {
+    __shared__ uint32_t part[1024];
+    const uint32_t per = (nb + 1023) / 1024;
+    const uint32_t lo = threadIdx.x * per, hi = min(nb, lo + per);
+    uint32_t s = 0;
+    for (uint32_t i = lo; i < hi; ++i)
+        s += blockSums[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        uint32_t t = 0;
+        if ((int)threadIdx.x >= o)
+            t = part[threadIdx.x - o];
+        __syncthreads();
+        part[threadIdx.x] += t;
+        __syncthreads();
     }
+    uint32_t acc = part[threadIdx.x] - s;
+    for (uint32_t i = lo; i < hi; ++i) {
+        const uint32_t v = blockSums[i];
+        blockSums[i] = acc;
+        acc += v;
+    }
+    if (threadIdx.x == 1023)
+        *total = part[1023];
 }
 __global__ void __launch_bounds__(256) k_scan_apply(const uint32_t *__restrict__ in, uint32_t n, const uint32_t *__restrict__ blockSums,
                                                     uint32_t *__restrict__ out) {

@@ -209,7 +209,7 @@ def test_device_resident_plan_and_stats(hal, oracle_bin, tmp_path):
     assert st["queries"] == n and st["records"] == nrec and st["mapped_pieces"] >= nrec
     assert st["top_derefs"] > 0 and st["bottom_derefs"] > 0 and st["total_ms"] >= st["walk_ms"] > 0
     kt = plan.kernel_times()
-    assert "k_parse_up_then_up" in kt and "k_finish_lds" in kt
+    assert "k_up_walk" in kt and "k_finish_fast" in kt
 
 
 def test_strand_symmetry_property_at_scale(hal, tmp_path):
