@@ -308,11 +308,13 @@ class LiftoverPlan:
         return self.run_ptr(gstart.numel(), gstart.data_ptr(), gend.data_ptr(), strand.data_ptr(), stream)
 
     def records_to_tensor(self, ptr, n):
-        """Copy the plan-owned device records into a fresh torch uint8 tensor [n, 40] (device to device)."""
+        """Copy the plan-owned device records of the last run into a fresh torch uint8 tensor [n, 40] (device to device)."""
         import torch
         t = torch.empty((n, 40), dtype=torch.uint8, device="cuda")
-        if n:
-            _hip_memcpy_dtod(t.data_ptr(), ptr, n * 40)
+        err = C.c_void_p()
+        stream = torch.cuda.current_stream().cuda_stream
+        if lib.hgx_liftover_copy_records(self._p, t.data_ptr(), n, stream, C.byref(err)) != 0:
+            raise HgxError(take_error(err))
         return t
 
     def stats(self):
@@ -329,17 +331,3 @@ class LiftoverPlan:
             return json.loads(C.string_at(js.value).decode())
         finally:
             lib.hgx_free(js)
-
-
-_hip = None
-
-
-def _hip_memcpy_dtod(dst, src, nbytes):
-    global _hip
-    if _hip is None:
-        _hip = C.CDLL("libamdhip64.so")
-        _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-        _hip.hipMemcpy.restype = C.c_int
-    rc = _hip.hipMemcpy(dst, src, nbytes, 3)  # hipMemcpyDeviceToDevice
-    if rc != 0:
-        raise HgxError("hipMemcpy failed with code %d" % rc)

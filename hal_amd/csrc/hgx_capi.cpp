@@ -293,6 +293,15 @@ int hgx_liftover_last_stats(const hgx_liftover_plan *p, hgx_liftover_stats *out)
     return HGX_OK;
 }
 
+int hgx_liftover_copy_records(const hgx_liftover_plan *p, void *d_dst, size_t n_records, void *hip_stream, char **err) {
+    HGX_TRY
+    if (!p || (n_records && !d_dst))
+        throw std::runtime_error("hgx_liftover_copy_records: null argument");
+    liftoverPlanCopyRecords(p, d_dst, n_records, hip_stream);
+    return HGX_OK;
+    HGX_CATCH
+}
+
 int hgx_liftover_kernel_times(const hgx_liftover_plan *p, char **json) {
     if (!p || !json)
         return HGX_ERR;

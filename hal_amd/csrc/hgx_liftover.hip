@@ -3,6 +3,7 @@
 #include "hgx_finish_kernel.hpp"
 #include "hgx_liftover_engine.hpp"
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 
@@ -156,6 +157,11 @@ std::unique_ptr<DeviceImage> uploadImage(const Image &img, int device) {
             if (G.tStart[(size_t)i + 1] - G.tStart[(size_t)i] >= (int64_t)1 << 31)
                 throw std::runtime_error("genome " + G.name + " has a segment of 2^31 bases or more");
     }
+    // HGX_FORCE_WIDE=1 selects the int64 coordinate tables regardless of genome size (exercises the path that
+    // genomes of 2^31 bases or more take)
+    if (const char *fw = getenv("HGX_FORCE_WIDE"))
+        if (fw[0] == '1')
+            D->wide = true;
     D->genomes.resize(img.genomes.size());
     for (size_t g = 0; g < img.genomes.size(); ++g) {
         const GenomeTables &G = img.genomes[g];
@@ -659,6 +665,15 @@ void destroyLiftoverPlan(hgx_liftover_plan *p) {
 
 const hgx_liftover_stats &liftoverPlanStats(const hgx_liftover_plan *p) {
     return p->stats;
+}
+
+void liftoverPlanCopyRecords(const hgx_liftover_plan *p, void *dDst, size_t nRecords, void *stream) {
+    if (nRecords > p->stats.records)
+        throw std::runtime_error("more records requested than the last run produced");
+    HIP_OK(hipSetDevice(p->device));
+    if (nRecords)
+        HIP_OK(hipMemcpyAsync(dDst, p->outRecords.p, nRecords * sizeof(hgx_record), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    HIP_OK(hipStreamSynchronize((hipStream_t)stream));
 }
 
 std::string liftoverPlanKernelTimes(const hgx_liftover_plan *p) {

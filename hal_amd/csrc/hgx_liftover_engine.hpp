@@ -13,6 +13,7 @@ void runLiftoverPlan(hgx_liftover_plan *p, size_t n, const int64_t *dStart, cons
 void destroyLiftoverPlan(hgx_liftover_plan *p);
 const hgx_liftover_stats &liftoverPlanStats(const hgx_liftover_plan *p);
 std::string liftoverPlanKernelTimes(const hgx_liftover_plan *p);
+void liftoverPlanCopyRecords(const hgx_liftover_plan *p, void *dDst, size_t nRecords, void *stream);
 void liftoverBatchHost(hgx_alignment *h, int src, int tgt, size_t n, const hgx_interval *iv, const hgx_liftover_opts &opts,
                        std::vector<hgx_record> &out, hgx_liftover_stats *stats);
 

@@ -129,6 +129,9 @@ int hgx_liftover_last_stats(const hgx_liftover_plan *p, hgx_liftover_stats *out)
  * object {"kernel": {"ms": total, "launches": n}, ...}; release *json with hgx_free. */
 int hgx_liftover_kernel_times(const hgx_liftover_plan *p, char **json);
 
+/* Copy the plan-owned records of the last run into caller-owned device memory (device to device, on hip_stream). */
+int hgx_liftover_copy_records(const hgx_liftover_plan *p, void *d_dst, size_t n_records, void *hip_stream, char **err);
+
 /* Text-level drop-in for Liftover::convert (liftover/inc/halLiftover.h:25-28): BED text in, BED text
  * out, byte-identical to halLiftover for BED3..BED9 (+ extra columns).  bed_type 0 = auto
  * (halBedLine.cpp:36-38).  *out_text is released with hgx_free. */
