@@ -44,25 +44,48 @@ def make_queries(length, n, seed):
     return starts, lens, strand
 
 
-def cpu_baseline(al, src_name, tgt_name, starts, lens, strand, seq_name, sample):
-    """Oracle (oracle/_build/hal_oracle, single thread) on the first `sample` intervals of this rank's batch."""
+def cpu_baseline(al, src_name, tgt_name, starts, lens, strand, seq_name, sample, all_cores_sample=0):
+    """Oracle (oracle/_build/hal_oracle) on the first `sample` intervals of this rank's batch, single thread; and, as a
+    fairness row, `all_cores_sample` intervals split over one oracle process per host core (the reference's own way of
+    scaling: a pool of processes, stats/halStats.py:16,38)."""
     oracle = os.path.join(ROOT, "oracle", "_build", "hal_oracle")
     if not os.path.exists(oracle):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
     with tempfile.TemporaryDirectory() as tmp:
         img = os.path.join(tmp, "bench.hgx")
         al.save(img)
+
+        def write_bed(path, lo, hi):
+            with open(path, "w") as f:
+                for i in range(lo, hi):
+                    s, l = int(starts[i]), int(lens[i])
+                    f.write("%s\t%d\t%d\tq\t0\t%s\n" % (seq_name, s, s + l, chr(int(strand[i]))))
+
         bed = os.path.join(tmp, "in.bed")
-        with open(bed, "w") as f:
-            for i in range(sample):
-                s, l = int(starts[i]), int(lens[i])
-                f.write("%s\t%d\t%d\tq\t0\t%s\n" % (seq_name, s, s + l, chr(int(strand[i]))))
+        write_bed(bed, 0, sample)
         out = subprocess.run([oracle, "liftover", img, src_name, bed, tgt_name, os.path.join(tmp, "out.bed"), "--stats"],
                              check=True, stdout=subprocess.PIPE).stdout.decode()
         st = json.loads(out)
         with open(os.path.join(tmp, "out.bed")) as f:
             text = f.read()
-    return st, text
+        multi = None
+        cores = os.cpu_count() or 1
+        if all_cores_sample > 0 and cores > 1:
+            per = all_cores_sample // cores
+            procs = []
+            for c in range(cores):
+                b = os.path.join(tmp, "in%d.bed" % c)
+                write_bed(b, c * per, (c + 1) * per)
+                procs.append(subprocess.Popen([oracle, "liftover", img, src_name, b, tgt_name, os.path.join(tmp, "out%d.bed" % c),
+                                               "--stats"], stdout=subprocess.PIPE))
+            secs = []
+            for pr in procs:
+                o, _ = pr.communicate()
+                secs.append(json.loads(o.decode())["map_seconds"])
+            # every process maps `per` intervals concurrently; the slowest one bounds the pool
+            multi = {"value": per * cores / max(secs), "unit": "intervals/s", "cores": cores,
+                     "sample": "%d intervals over %d oracle processes (mapping time of the slowest process)" % (per * cores, cores)}
+    return st, text, multi
 
 
 def main():
@@ -74,6 +97,7 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="genome size multiplier (1.0 = ~100 Mb/genome)")
     ap.add_argument("--target", default="Genome_2")
     ap.add_argument("--cpu-sample", type=int, default=300000, help="intervals timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-all-cores", type=int, default=1, help="also time the oracle sharded over every host core")
     ap.add_argument("--columns", type=int, default=1, help="also time the column-depth kernel over the whole source genome (0 = skip)")
     args = ap.parse_args()
 
@@ -195,7 +219,8 @@ def main():
                               "reference_genome": src_name, "mean_depth": float(dcol.float().mean().item())}
         if args.cpu_sample > 0:
             sample = min(args.cpu_sample, nq)
-            cst, text = cpu_baseline(al, src_name, tgt_name, starts, lens, strand, seq_name, sample)
+            cst, text, multi = cpu_baseline(al, src_name, tgt_name, starts, lens, strand, seq_name, sample,
+                                            all_cores_sample=min(nq, 4 * sample) if args.cpu_all_cores else 0)
             # parity spot check of the timed configuration: GPU records of the sampled intervals vs the oracle's text
             ptr, n = plan.run(d_gs[:sample].contiguous(), d_ge[:sample].contiguous(), d_st[:sample].contiguous())
             import numpy as np
@@ -207,6 +232,8 @@ def main():
                                    "sample": "first %d intervals of rank 0's batch, oracle liftInterval+sort time only "
                                              "(BED parse/print and image load excluded)" % sample,
                                    "parity_with_gpu": gpu_text == text}
+            if multi:
+                out["cpu_baseline"]["all_cores"] = multi
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -117,11 +117,12 @@ __device__ __forceinline__ int finish_query(FinishStore<C> &S, const Mapped &in,
     if (n > S.cap)
         return -n;
     for (int i = lane; i < n; i += 64) {
-        S.tLo[i] = (C)in.tLo[base + i];
-        S.tHi[i] = (C)in.tHi[base + i];
-        S.sLo[i] = (C)in.sLo[base + i];
-        S.sHi[i] = (C)in.sHi[base + i];
-        S.fl[i] = in.flags[base + i];
+        const MappedRec r = in.rec[base + i];
+        S.tLo[i] = (C)r.tLo;
+        S.tHi[i] = (C)(r.tLo + r.len - 1);
+        S.sLo[i] = (C)r.sLo;
+        S.sHi[i] = (C)(r.sLo + r.len - 1);
+        S.fl[i] = (uint8_t)r.flags;
     }
     wsync();
     sort_pieces(S, n);
@@ -490,11 +491,12 @@ __global__ void __launch_bounds__(256) k_finish_fast(Mapped in, const uint32_t *
         int64_t tLo = 0, tHi = 0, sLo = 0, sHi = 0;
         uint8_t fl = 0;
         if (have) {
-            tLo = in.tLo[base + li];
-            tHi = in.tHi[base + li];
-            sLo = in.sLo[base + li];
-            sHi = in.sHi[base + li];
-            fl = in.flags[base + li];
+            const MappedRec r = in.rec[base + li];
+            tLo = r.tLo;
+            tHi = r.tLo + r.len - 1;
+            sLo = r.sLo;
+            sHi = r.sLo + r.len - 1;
+            fl = (uint8_t)r.flags;
         }
         // 1. order by target start
         unsigned long long key = have ? (((unsigned long long)tLo << 6) | (unsigned long long)lane) : INF;

@@ -306,17 +306,17 @@ struct hgx_liftover_plan {
                         (int64_t *)fr[k][3].p, (int32_t *)fr[k][4].p, (uint8_t *)fr[k][5].p};
     }
     Mapped mapped(int k) {
-        return Mapped{(int32_t *)mp[k][0].p, (int64_t *)mp[k][1].p, (int64_t *)mp[k][2].p,
-                      (int64_t *)mp[k][3].p, (int64_t *)mp[k][4].p, (uint8_t *)mp[k][5].p};
+        return Mapped{(MappedRec *)mp[k][0].p};
     }
     void allocate(uint32_t newCap) {
         cap = newCap;
-        static const size_t fsz[6] = {4, 8, 4, 8, 4, 1}, msz[6] = {4, 8, 8, 8, 8, 1};
+        static const size_t fsz[6] = {4, 8, 4, 8, 4, 1};
         for (int k = 0; k < 2; ++k)
-            for (int a = 0; a < 6; ++a) {
+        {
+            for (int a = 0; a < 6; ++a)
                 fr[k][a].ensure(fsz[a] * (size_t)cap);
-                mp[k][a].ensure(msz[a] * (size_t)cap);
-            }
+            mp[k][0].ensure(sizeof(MappedRec) * (size_t)cap);
+        }
         grouped.ensure(sizeof(hgx_record) * (size_t)cap);
         outRecords.ensure(sizeof(hgx_record) * (size_t)cap);
         const size_t nq = std::max<size_t>(maxQueries, 1);

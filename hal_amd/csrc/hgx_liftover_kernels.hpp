@@ -28,17 +28,20 @@ struct Frontier {
 
 // final mapped pieces in forward coordinates (what MappedSegment::lessThan orders by,
 // api/impl/halMappedSegment.cpp:36-43,167-206)
+// One 32-byte record per piece (a mapped piece has equal source and target length, so the high ends are implied):
+// finalize writes them densely, the grouping scatter moves each with two 16-byte stores into one sector.
+struct alignas(16) MappedRec {
+    int64_t tLo, sLo;
+    int32_t len, qid;
+    uint32_t flags, _pad;
+};
 struct Mapped {
-    int32_t *qid;
-    int64_t *tLo, *tHi, *sLo, *sHi;
-    uint8_t *flags;
+    MappedRec *rec;
 };
 
 // counters[] slots
 enum {
     CNT_OVERFLOW = 0, // set when any append ran past capacity
-    CNT_TOP_DEREF = 1,
-    CNT_BOT_DEREF = 2,
     CNT_SRC_PIECES = 4,
     CNT_DEFERRED = 5,
     CNT_MAXNEED = 6,
@@ -79,16 +82,6 @@ __device__ __forceinline__ void wave_count_add(unsigned long long *counter, uint
         v += __shfl_down(v, o);
     if (lane_id() == 0 && v)
         atomicAdd(counter, (unsigned long long)v);
-}
-
-__device__ __forceinline__ void put(const Frontier &f, unsigned long long slot, int32_t qid, int64_t sPos, int32_t idx, int32_t so,
-                                    int32_t len, uint8_t flags) {
-    f.qid[slot] = qid;
-    f.sPos[slot] = sPos;
-    f.idx[slot] = idx;
-    f.so[slot] = so;
-    f.len[slot] = len;
-    f.flags[slot] = flags;
 }
 
 // LDS-staged append.  Appending straight to the next frontier costs one device-scope atomic on a single
@@ -635,17 +628,14 @@ __global__ void __launch_bounds__(256) k_finalize(const REC *__restrict__ segs, 
         else
             lo = (int64_t)segs[idx + 1].start - so - len;
         ++derefs;
-        out.qid[i] = q;
-        out.tLo[i] = lo;
-        out.tHi[i] = lo + len - 1;
-        if (!(fl & F_SREV)) {
-            out.sLo[i] = sPos;
-            out.sHi[i] = sPos + len - 1;
-        } else {
-            out.sLo[i] = sPos - len + 1;
-            out.sHi[i] = sPos;
-        }
-        out.flags[i] = fl;
+        MappedRec r;
+        r.tLo = lo;
+        r.sLo = !(fl & F_SREV) ? sPos : sPos - len + 1;
+        r.len = len;
+        r.qid = q;
+        r.flags = fl;
+        r._pad = 0;
+        out.rec[i] = r;
         atomicAdd(&perQuery[q], 1u);
     }
     wave_count_add(&kstat[isTop ? 0 : 1], derefs);
@@ -658,14 +648,9 @@ __global__ void __launch_bounds__(256) k_scatter(Mapped in, const unsigned long 
                                                  uint32_t *__restrict__ cursor, Mapped out) {
     const uint32_t n = (uint32_t)min((unsigned long long)cap, *inCount); // CNT_MAPPED: dense count written by k_finalize
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int32_t q = in.qid[i];
-        const uint32_t s = offset[q] + atomicAdd(&cursor[q], 1u);
-        out.qid[s] = q;
-        out.tLo[s] = in.tLo[i];
-        out.tHi[s] = in.tHi[i];
-        out.sLo[s] = in.sLo[i];
-        out.sHi[s] = in.sHi[i];
-        out.flags[s] = in.flags[i];
+        const MappedRec r = in.rec[i];
+        const uint32_t s = offset[r.qid] + atomicAdd(&cursor[r.qid], 1u);
+        out.rec[s] = r;
     }
 }
 
