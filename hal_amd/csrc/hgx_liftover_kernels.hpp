@@ -59,23 +59,6 @@ __device__ __forceinline__ int lane_id() {
     return (int)(threadIdx.x & 63);
 }
 
-// Append slots for the active lanes of a wavefront with one atomic: ballot the lanes that emit, give
-// each its popcount prefix, lane `leader` adds the wave total.  Must be called by all lanes of the
-// wave in converged control flow.
-__device__ __forceinline__ unsigned long long wave_append(unsigned long long *counter, bool emit) {
-    const unsigned long long mask = __ballot(emit);
-    if (mask == 0)
-        return ~0ull;
-    const int lane = lane_id();
-    const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-    const int leader = __ffsll((long long)mask) - 1;
-    unsigned long long base = 0;
-    if (lane == leader)
-        base = atomicAdd(counter, (unsigned long long)__popcll(mask));
-    base = __shfl(base, leader);
-    return base + rank;
-}
-
 __device__ __forceinline__ void wave_count_add(unsigned long long *counter, uint32_t v) {
     // wave reduction through DPP-free shuffles, one atomic per wave
     for (int o = 32; o > 0; o >>= 1)
