@@ -25,7 +25,7 @@ struct ColumnParams {
     unsigned int *error;              // set to 1 on frame-stack overflow
 };
 
-static constexpr int COL_STACK = 64;
+static constexpr int COL_STACK = 64; // frames per lane (scratch; an LDS-resident lower part was measured slower: occupancy)
 
 enum : uint32_t { FR_UP = 0, FR_PARSEUP = 1, FR_CHILD = 2, FR_RING = 3, FR_PARSEDOWN = 4 };
 
@@ -58,11 +58,15 @@ template <typename C> struct ColumnWalker {
             overflow = true;
             return;
         }
-        stack[sp].idx = idx;
-        stack[sp].so = so;
-        stack[sp].extra = extra;
-        stack[sp].meta = kind | ((uint32_t)rev << 3) | ((uint32_t)g << 4);
-        ++sp;
+        Frame f;
+        f.idx = idx;
+        f.so = so;
+        f.extra = extra;
+        f.meta = kind | ((uint32_t)rev << 3) | ((uint32_t)g << 4);
+        stack[sp++] = f;
+    }
+    __device__ __forceinline__ Frame pop() {
+        return stack[--sp];
     }
     // position of a base given its segment and iteration-order offset (halSegmentIterator.cpp:46-52)
     template <typename REC> __device__ __forceinline__ int64_t posOf(const REC *segs, int32_t idx, int32_t so, bool rev) const {
@@ -90,12 +94,17 @@ template <typename C> struct ColumnWalker {
                 else
                     hi = mid;
             }
-            const int32_t t = (int32_t)lo, so = (int32_t)(p - (int64_t)T[t].start);
+            const int32_t t = (int32_t)lo;
+            const TopRec<C> tr = T[t];
+            const int32_t so = (int32_t)(p - (int64_t)tr.start);
             insert(visit, R, p, false);
-            push(FR_PARSEDOWN, R, t, so, false, 0);
-            if (!P.onlyOrthologs)
+            // frames that could only fall through are not pushed (fewer scratch round trips); each frame re-checks
+            if (tr.botParse >= 0)
+                push(FR_PARSEDOWN, R, t, so, false, 0);
+            if (!P.onlyOrthologs && tr.paralogy >= 0)
                 push(FR_RING, R, t, so, false, t);
-            push(FR_UP, R, t, so, false, 0);
+            if (tr.parentEnc >= 0)
+                push(FR_UP, R, t, so, false, 0);
         } else {
             // bottom branch (:302-353): the root: insert, then every child
             const BotRec<C> *B = bot(R);
@@ -110,10 +119,11 @@ template <typename C> struct ColumnWalker {
             const int32_t b = (int32_t)lo, so = (int32_t)(p - (int64_t)B[b].start);
             insert(visit, R, p, false);
             for (int i = RD.numChildren - 1; i >= 0; --i)
-                push(FR_CHILD, R, b, so, false, i);
+                if (RD.child[i][b] >= 0)
+                    push(FR_CHILD, R, b, so, false, i);
         }
         while (sp > 0) {
-            const Frame f = stack[--sp];
+            const Frame f = pop();
             const uint32_t kind = f.meta & 7u;
             const bool rev = (f.meta >> 3) & 1u;
             const int g = (int)(f.meta >> 4);
@@ -130,9 +140,10 @@ template <typename C> struct ColumnWalker {
                         const bool brev = rev ^ ((tr.parentEnc & 1) != 0);
                         insert(visit, pg, posOf(bot(pg), b, f.so, brev), brev);
                         for (int i = PD.numChildren - 1; i >= 0; --i) // siblings, executed after the parse-up branch
-                            if (i != D.slotInParent)
+                            if (i != D.slotInParent && PD.child[i][b] >= 0)
                                 push(FR_CHILD, pg, b, f.so, brev, i);
-                        push(FR_PARSEUP, pg, b, f.so, brev, 0);
+                        if (PD.parent >= 0)
+                            push(FR_PARSEUP, pg, b, f.so, brev, 0);
                     }
                 }
             } else if (kind == FR_PARSEUP) {
@@ -145,10 +156,12 @@ template <typename C> struct ColumnWalker {
                     int32_t j = tp;
                     while ((int64_t)T[j + 1].start <= pos)
                         ++j;
-                    const int32_t so = !rev ? (int32_t)(pos - (int64_t)T[j].start) : (int32_t)((int64_t)T[j + 1].start - 1 - pos);
-                    if (!P.onlyOrthologs)
+                    const TopRec<C> tj = T[j];
+                    const int32_t so = !rev ? (int32_t)(pos - (int64_t)tj.start) : (int32_t)((int64_t)T[j + 1].start - 1 - pos);
+                    if (!P.onlyOrthologs && tj.paralogy >= 0)
                         push(FR_RING, g, j, so, rev, j);
-                    push(FR_UP, g, j, so, rev, 0);
+                    if (tj.parentEnc >= 0)
+                        push(FR_UP, g, j, so, rev, 0);
                 }
             } else if (kind == FR_CHILD) {
                 // updateChild (:607-640)
@@ -158,9 +171,12 @@ template <typename C> struct ColumnWalker {
                 if (enc >= 0 && bit(P.scopeMask, cg)) {
                     const int32_t t = enc >> 1;
                     const bool crev = rev ^ ((enc & 1) != 0);
-                    insert(visit, cg, posOf(top(cg), t, f.so, crev), crev);
-                    push(FR_PARSEDOWN, cg, t, f.so, crev, 0);
-                    push(FR_RING, cg, t, f.so, crev, t);
+                    const TopRec<C> ct = top(cg)[t];
+                    insert(visit, cg, !crev ? (int64_t)ct.start + f.so : (int64_t)top(cg)[t + 1].start - 1 - f.so, crev);
+                    if (ct.botParse >= 0)
+                        push(FR_PARSEDOWN, cg, t, f.so, crev, 0);
+                    if (ct.paralogy >= 0)
+                        push(FR_RING, cg, t, f.so, crev, t);
                 }
             } else if (kind == FR_RING) {
                 // updateNextTopDup (:642-681), one ring member per frame: emit the next paralog, walk its subtree,
@@ -177,8 +193,10 @@ template <typename C> struct ColumnWalker {
                     const TopRec<C> nr = T[nxt];
                     const bool nrev = rev ^ ((nr.parentEnc & 1) != (cur.parentEnc & 1));
                     insert(visit, g, posOf(T, nxt, f.so, nrev), nrev);
-                    push(FR_RING, g, nxt, f.so, nrev, first);
-                    push(FR_PARSEDOWN, g, nxt, f.so, nrev, 0);
+                    if (nr.paralogy >= 0 && nr.paralogy != first)
+                        push(FR_RING, g, nxt, f.so, nrev, first);
+                    if (nr.botParse >= 0)
+                        push(FR_PARSEDOWN, g, nxt, f.so, nrev, 0);
                 }
             } else { // FR_PARSEDOWN
                 // updateParseDown (:711-744)
@@ -192,7 +210,8 @@ template <typename C> struct ColumnWalker {
                         ++j;
                     const int32_t so = !rev ? (int32_t)(pos - (int64_t)B[j].start) : (int32_t)((int64_t)B[j + 1].start - 1 - pos);
                     for (int i = D.numChildren - 1; i >= 0; --i)
-                        push(FR_CHILD, g, j, so, rev, i);
+                        if (D.child[i][j] >= 0)
+                            push(FR_CHILD, g, j, so, rev, i);
                 }
             }
         }
