@@ -96,6 +96,8 @@ SYMBOLS = {
                                       P(VP), P(C.c_size_t), P(VP)]),
     "hgx_maf_export": (C.c_int, [VP, C.c_int, C.c_int, C.c_int64, C.c_int64, P(hgx_maf_opts), P(C.c_int32), C.c_int32, P(VP),
                                  P(C.c_size_t), P(VP)]),
+    "hgx_maf_export_bed": (C.c_int, [VP, C.c_int, C.c_char_p, C.c_size_t, P(hgx_maf_opts), P(C.c_int32), C.c_int32, P(VP), P(C.c_size_t),
+                                     P(VP)]),
     "hgx_rand_preset": (C.c_int, [C.c_char_p, P(hgx_rand_opts)]),
     "hgx_create_random": (C.c_int, [P(hgx_rand_opts), C.c_int, P(VP), P(VP)]),
     "hgx_save_image": (C.c_int, [VP, C.c_char_p, P(VP)]),

@@ -432,15 +432,27 @@ int hgx_alignment_depth(hgx_alignment *h, int ref, int ref_sequence, int64_t sta
     HGX_CATCH
 }
 
-int hgx_maf_export(hgx_alignment *h, int ref, int ref_sequence, int64_t start, int64_t length, const hgx_maf_opts *o,
-                   const int32_t *targets, int32_t n_targets, char **out_text, size_t *out_len, char **err) {
+static void configureMaf(MafExport &me, const hgx_maf_opts *o, const GenomeTables *G);
+
+int hgx_maf_export_bed(hgx_alignment *h, int ref, const char *bed_text, size_t bed_len, const hgx_maf_opts *o, const int32_t *targets,
+                       int32_t n_targets, char **out_text, size_t *out_len, char **err) {
     HGX_TRY
-    if (!h || !out_text || !out_len)
-        throw std::runtime_error("hgx_maf_export: null argument");
+    if (!h || !out_text || !out_len || (bed_len && !bed_text))
+        throw std::runtime_error("hgx_maf_export_bed: null argument");
     const GenomeTables *G = genomeOf(h, ref);
-    if (!G || ref_sequence >= (int)G->seqs.size())
-        throw std::runtime_error("hgx_maf_export: genome or sequence out of range");
+    if (!G)
+        throw std::runtime_error("hgx_maf_export_bed: genome out of range");
     MafExport me;
+    configureMaf(me, o, G);
+    std::set<int> tset(targets, targets + (targets ? n_targets : 0));
+    std::istringstream is(std::string(bed_text ? bed_text : "", bed_len));
+    std::ostringstream os;
+    me.convertBed(os, h, ref, is, tset);
+    return textOut(os.str(), out_text, out_len);
+    HGX_CATCH
+}
+
+static void configureMaf(MafExport &me, const hgx_maf_opts *o, const GenomeTables *G) {
     if (o) {
         me.setNoDupes(o->no_dupes != 0);
         me.setNoAncestors(o->no_ancestors != 0);
@@ -454,6 +466,18 @@ int hgx_maf_export(hgx_alignment *h, int ref, int ref_sequence, int64_t start, i
                                      "), the --noAncestors option is invalid.  The --refGenome option can be used to specify a "
                                      "different reference.");
     }
+}
+
+int hgx_maf_export(hgx_alignment *h, int ref, int ref_sequence, int64_t start, int64_t length, const hgx_maf_opts *o,
+                   const int32_t *targets, int32_t n_targets, char **out_text, size_t *out_len, char **err) {
+    HGX_TRY
+    if (!h || !out_text || !out_len)
+        throw std::runtime_error("hgx_maf_export: null argument");
+    const GenomeTables *G = genomeOf(h, ref);
+    if (!G || ref_sequence >= (int)G->seqs.size())
+        throw std::runtime_error("hgx_maf_export: genome or sequence out of range");
+    MafExport me;
+    configureMaf(me, o, G);
     std::set<int> tset(targets, targets + (targets ? n_targets : 0));
     std::ostringstream os;
     if (ref_sequence >= 0) {

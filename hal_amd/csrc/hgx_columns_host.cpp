@@ -1,4 +1,6 @@
 #include "hgx_columns_host.hpp"
+#include "hgx_liftover_host.hpp"
+#include <iostream>
 #include <algorithm>
 #include <climits>
 
@@ -429,6 +431,46 @@ void MafExport::convertSequence(std::ostream &mafStream, hgx_alignment *alignmen
     if (appendCount > 0 && (_keepEmptyRefBlocks || !referenceIsAllGaps())) {
         printBlock(mafStream);
         mafStream << std::endl;
+    }
+}
+
+// maf/impl/halMafBed.cpp:24-52 driven by BedScanner::scan (liftover/impl/halBedScanner.cpp:40-61)
+void MafExport::convertBed(std::ostream &mafStream, hgx_alignment *alignment, int genome, std::istream &in, const std::set<int> &targets) {
+    const GenomeTables &G = alignment->img.genomes[(size_t)genome];
+    auto skipWhiteSpaces = [](std::istream &s) {
+        while (s.good() && std::isspace((char)s.peek()))
+            s.get();
+    };
+    BedLine bedLine;
+    std::string lineBuffer;
+    size_t lineNumber = 0;
+    skipWhiteSpaces(in);
+    while (in.good()) {
+        ++lineNumber;
+        try {
+            std::getline(in, lineBuffer);
+            bedLine.parse(lineBuffer, 0);
+        } catch (std::runtime_error &e) {
+            throw std::runtime_error(std::string(e.what()) + " in input bed line " + std::to_string(lineNumber));
+        }
+        const int seq = G.seqIndexByName(bedLine.chrName);
+        if (seq < 0) {
+            std::cerr << "Line " << lineNumber << ": BED sequence " << bedLine.chrName << " not found in genome " << G.name << '\n';
+        } else if (bedLine.bedType <= 9) {
+            if (bedLine.end <= bedLine.start || bedLine.end > G.seqs[(size_t)seq].length)
+                std::cerr << "Line " << lineNumber << ": BED coordinates invalid\n";
+            else
+                convertSequence(mafStream, alignment, genome, seq, bedLine.start, bedLine.end - bedLine.start, targets);
+        } else {
+            for (size_t i = 0; i < bedLine.blocks.size(); ++i) {
+                const BedBlock &b = bedLine.blocks[i];
+                if (b.length == 0 || bedLine.start + b.start + b.length >= G.seqs[(size_t)seq].length)
+                    std::cerr << "Line " << lineNumber << ", block " << i << ": BED coordinates invalid\n";
+                else
+                    convertSequence(mafStream, alignment, genome, seq, bedLine.start + b.start, b.length, targets);
+            }
+        }
+        skipWhiteSpaces(in);
     }
 }
 

@@ -29,6 +29,8 @@ class MafExport {
     // maf/impl/halMafExport.cpp:25-88; positions are sequence-relative, length 0 = to the end
     void convertSequence(std::ostream &mafStream, hgx_alignment *alignment, int genome, int seq, int64_t startPosition, int64_t length,
                          const std::set<int> &targets);
+    // hal2maf --refTargets: MafBed::visitLine (maf/impl/halMafBed.cpp:24-52) over a BED stream of reference intervals
+    void convertBed(std::ostream &mafStream, hgx_alignment *alignment, int genome, std::istream &bedStream, const std::set<int> &targets);
     ~MafExport();
     ColumnStats stats;
     size_t chunkColumns = 1u << 21;

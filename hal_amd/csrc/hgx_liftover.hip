@@ -643,7 +643,7 @@ hgx_liftover_plan *createLiftoverPlan(hgx_alignment *h, int src, int tgt, const 
     HIP_OK(hipEventCreate(&P->evStart));
     HIP_OK(hipEventCreate(&P->evWalk));
     HIP_OK(hipEventCreate(&P->evEnd));
-    const unsigned long long want = std::max<unsigned long long>(1ull << 16, 48ull * P->maxQueries);
+    const unsigned long long want = std::max<unsigned long long>(1ull << 16, 16ull * P->maxQueries); // grown on demand
     P->allocate((uint32_t)std::min<unsigned long long>(want, (1ull << 32) - 2));
     return P.release();
 }

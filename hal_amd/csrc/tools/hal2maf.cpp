@@ -19,7 +19,7 @@ static std::vector<std::string> chop(const std::string &s, char sep) {
 
 int main(int argc, char **argv) {
     std::vector<std::string> pos;
-    std::string refGenomeName, refSequenceName, rootGenomeName, targetGenomes;
+    std::string refGenomeName, refSequenceName, rootGenomeName, targetGenomes, refTargetsPath;
     int64_t start = 0, length = 0, maxBlockLen = 1000, maxRefGap = 0;
     bool noDupes = false, noAncestors = false, onlySequenceNames = false, unique = false, append = false, onlyOrthologs = false,
          keepEmptyRefBlocks = false;
@@ -48,7 +48,8 @@ int main(int argc, char **argv) {
             else if (a == "--append") append = true;
             else if (a == "--onlyOrthologs") onlyOrthologs = true;
             else if (a == "--keepEmptyRefBlocks") keepEmptyRefBlocks = true;
-            else if (a == "--refTargets" || a == "--global" || a == "--printTree")
+            else if (a == "--refTargets") refTargetsPath = val();
+            else if (a == "--global" || a == "--printTree")
                 throw std::runtime_error(a + " is not built in this implementation");
             else if (a.rfind("--", 0) == 0) throw std::runtime_error("unknown option " + a);
             else pos.push_back(a);
@@ -130,7 +131,15 @@ int main(int argc, char **argv) {
         me.setMaxBlockLength(maxBlockLen);
         me.setOnlyOrthologs(onlyOrthologs);
         me.setKeepEmptyRefBlocks(keepEmptyRefBlocks);
-        if (refSeq >= 0) {
+        if (!refTargetsPath.empty()) { // hal2mafWithTargets, hal2maf.cpp:105-119
+            std::ifstream bedFile;
+            if (refTargetsPath != "stdin") {
+                bedFile.open(refTargetsPath);
+                if (!bedFile)
+                    throw std::runtime_error("Error opening " + refTargetsPath);
+            }
+            me.convertBed(mafStream, h, ref, refTargetsPath != "stdin" ? bedFile : std::cin, targetSet);
+        } else if (refSeq >= 0) {
             me.convertSequence(mafStream, h, ref, refSeq, start, length, targetSet);
         } else {
             for (int s = 0; s < hgx_genome_num_sequences(h, ref); ++s)

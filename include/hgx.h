@@ -188,6 +188,10 @@ typedef struct hgx_maf_opts {
 } hgx_maf_opts;
 int hgx_maf_export(hgx_alignment *h, int ref_genome, int ref_sequence, int64_t start, int64_t length, const hgx_maf_opts *opts,
                    const int32_t *targets, int32_t n_targets, char **out_text, size_t *out_len, char **err);
+/* hal2maf --refTargets: one convertSequence per BED interval (or BED12 block) of the reference genome, sharing one
+ * MafExport (MafBed::visitLine, maf/impl/halMafBed.cpp:24-52). */
+int hgx_maf_export_bed(hgx_alignment *h, int ref_genome, const char *bed_text, size_t bed_len, const hgx_maf_opts *opts,
+                       const int32_t *targets, int32_t n_targets, char **out_text, size_t *out_len, char **err);
 
 /* ---- synthetic workloads: halRandGen (randgen/halRandGen.cpp) ---- */
 typedef struct hgx_rand_opts {

@@ -69,7 +69,7 @@ static std::vector<std::string> splitCommas(const std::string &s) {
 // halAlignmentDepth (alignmentDepth/halAlignmentDepth.cpp:52-213) and hal2maf (maf/impl/hal2maf.cpp:18-217) front ends
 static int cmdColumns(bool maf, int argc, char **argv) {
     std::vector<std::string> pos;
-    std::string refGenome, refSequence, targetGenomes, rootGenome;
+    std::string refGenome, refSequence, targetGenomes, rootGenome, refTargets;
     i64 start = 0, length = 0, step = 1, maxBlockLen = 1000;
     bool countDupes = false, noAncestors = false, noDupes = false, onlySequenceNames = false, onlyOrthologs = false, stats = false,
          unique = false;
@@ -83,6 +83,8 @@ static int cmdColumns(bool maf, int argc, char **argv) {
             targetGenomes = argv[++i];
         else if (a == "--rootGenome")
             rootGenome = argv[++i];
+        else if (a == "--refTargets")
+            refTargets = argv[++i];
         else if (a == "--start")
             start = atoll(argv[++i]);
         else if (a == "--length")
@@ -168,7 +170,43 @@ static int cmdColumns(bool maf, int argc, char **argv) {
         me.onlyOrthologs = onlyOrthologs;
         me.unique = unique;
         me.maxBlockLength = maxBlockLen <= 0 ? std::numeric_limits<i64>::max() : maxBlockLen;
-        if (seq >= 0) {
+        if (!refTargets.empty()) {
+            // MafBed::visitLine (maf/impl/halMafBed.cpp:24-52) over BedScanner::scan
+            std::ifstream bedIn(refTargets);
+            BedLine bedLine;
+            std::string lineBuffer;
+            size_t lineNumber = 0;
+            auto skipWs = [&]() {
+                while (bedIn.good() && std::isspace((char)bedIn.peek()))
+                    bedIn.get();
+            };
+            skipWs();
+            while (bedIn.good()) {
+                ++lineNumber;
+                bedLine.read(bedIn, lineBuffer, 0);
+                const Sequence *rs = al.genomes[(size_t)ref].seqByName(bedLine._chrName);
+                if (rs == nullptr) {
+                    std::cerr << "Line " << lineNumber << ": BED sequence " << bedLine._chrName << " not found" << std::endl;
+                } else {
+                    const int si = (int)(rs - al.genomes[(size_t)ref].seqs.data());
+                    if (bedLine._bedType <= 9) {
+                        if (bedLine._end <= bedLine._start || bedLine._end > rs->length)
+                            std::cerr << "Line " << lineNumber << ": BED coordinates invalid\n";
+                        else
+                            me.convertSequence(buf, al, ref, si, bedLine._start, bedLine._end - bedLine._start, targetSet);
+                    } else {
+                        for (size_t k = 0; k < bedLine._blocks.size(); ++k) {
+                            const BedBlock &b = bedLine._blocks[k];
+                            if (b._length == 0 || bedLine._start + b._start + b._length >= rs->length)
+                                std::cerr << "Line " << lineNumber << ", block " << k << ": BED coordinates invalid\n";
+                            else
+                                me.convertSequence(buf, al, ref, si, bedLine._start + b._start, b._length, targetSet);
+                        }
+                    }
+                }
+                skipWs();
+            }
+        } else if (seq >= 0) {
             me.convertSequence(buf, al, ref, seq, start, length, targetSet);
         } else {
             for (size_t s = 0; s < al.genomes[(size_t)ref].seqs.size(); ++s)

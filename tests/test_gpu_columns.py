@@ -132,3 +132,18 @@ def test_depth_properties_at_scale(hal):
     assert d.min() >= 0 and d.max() <= al.num_genomes - 1 and np.all(dd >= d) and np.all(dt <= d)
     assert np.array_equal(d, al.columns_depth(g, 0, n)) and d.max() > 3
     assert np.array_equal(al.columns_depth(g, 0, n, step=1)[::5][: n // 5], al.columns_depth(g, 0, n // 5, step=5))
+
+
+def test_maf_ref_targets_vs_oracle(hal, oracle_bin, tmp_path):
+    """hal2maf --refTargets (maf/impl/halMafBed.cpp): BED3 intervals and BED12 blocks of the reference, one shared MafExport."""
+    al, img = _rand(hal, tmp_path, 5, dna=True)
+    leaf = al.genome_name(al.num_genomes - 1)
+    g = al.genome_id(leaf)
+    sname, _, n = al.sequences(g)[0]
+    bed = ("%s\t10\t300\n" % sname + "%s\t250\t900\tx\t0\t-\n" % sname + "nosuch\t1\t5\n" + "%s\t5\t%d\n" % (sname, n + 5) +
+           "%s\t1000\t1600\tb\t0\t+\t1000\t1600\t0\t3\t50,70,0,\t0,200,400,\n" % sname)
+    bedfile = tmp_path / "t.bed"
+    bedfile.write_text(bed)
+    assert al.maf_export(g, ref_targets_bed=bed) == _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", leaf, "--refTargets", str(bedfile))
+    assert al.maf_export(g, ref_targets_bed=bed, unique=True, no_ancestors=True) == \
+        _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", leaf, "--refTargets", str(bedfile), "--unique", "--noAncestors")
