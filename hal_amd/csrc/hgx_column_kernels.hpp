@@ -294,8 +294,8 @@ struct RowVisitor {
     }
 };
 
-template <typename C>
-__global__ void __launch_bounds__(256) k_column_rows(ColumnParams P, const uint64_t *__restrict__ rowOffset, ColumnRow *__restrict__ rows) {
+template <typename C, typename OFF>
+__global__ void __launch_bounds__(256) k_column_rows(ColumnParams P, const OFF *__restrict__ rowOffset, ColumnRow *__restrict__ rows) {
     ColumnWalker<C> w(P);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P.count; i += (int64_t)gridDim.x * blockDim.x) {
         RowVisitor v;
@@ -305,6 +305,41 @@ __global__ void __launch_bounds__(256) k_column_rows(ColumnParams P, const uint6
     }
     if (w.overflow)
         *P.error = 1;
+}
+
+// ---- run detection for the MAF writer ----
+// A column "continues" its left neighbour when it has the same rows (same genomes and strands, in the same
+// insertion order) each advanced by one base along its strand.  Inside such a run the MAF block state machine of
+// the reference does nothing but append one character per row, so only the first column of every run ("head")
+// needs its rows shipped to the host.
+static __global__ void __launch_bounds__(256) k_column_heads(const uint32_t *__restrict__ rowOffset, const ColumnRow *__restrict__ rows, int64_t count,
+                                                      uint8_t *__restrict__ head, uint32_t *__restrict__ headRows /* rows of heads, else 0 */) {
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < count; c += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t a = rowOffset[c], n = rowOffset[c + 1] - a;
+        bool isHead = c == 0;
+        if (!isHead) {
+            const uint32_t pa = rowOffset[c - 1];
+            isHead = (a - pa) != n;
+            for (uint32_t k = 0; k < n && !isHead; ++k) {
+                const ColumnRow r = rows[a + k], q = rows[pa + k];
+                isHead = r.genome != q.genome || r.rev != q.rev || r.pos != (q.rev ? q.pos - 1 : q.pos + 1);
+            }
+        }
+        head[c] = isHead ? 1 : 0;
+        headRows[c] = isHead ? n : 0;
+    }
+}
+
+static __global__ void __launch_bounds__(256) k_gather_head_rows(const uint32_t *__restrict__ rowOffset, const ColumnRow *__restrict__ rows, int64_t count,
+                                                          const uint8_t *__restrict__ head, const uint32_t *__restrict__ headOffset,
+                                                          ColumnRow *__restrict__ out) {
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < count; c += (int64_t)gridDim.x * blockDim.x) {
+        if (!head[c])
+            continue;
+        const uint32_t a = rowOffset[c], n = rowOffset[c + 1] - a, o = headOffset[c];
+        for (uint32_t k = 0; k < n; ++k)
+            out[o + k] = rows[a + k];
+    }
 }
 
 } // namespace hgx

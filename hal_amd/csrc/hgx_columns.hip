@@ -1,6 +1,7 @@
 // Column engine: launches of the per-base closure kernels behind hgx_columns_depth / hgx_alignment_depth /
 // hgx_maf_export (include/hgx.h).
 #include "hgx_column_kernels.hpp"
+#include "hgx_liftover_kernels.hpp"
 #include "hgx_columns_engine.hpp"
 #include <algorithm>
 #include <cstring>
@@ -161,9 +162,11 @@ void columnsRowsHost(hgx_alignment *h, int ref, int64_t first, int64_t count, co
     HIP_OK(hipEventRecord(a.e, nullptr));
     const int grid = (int)std::min<int64_t>(COL_GRID, (count + 255) / 256);
     if (h->dev->wide)
-        hipLaunchKernelGGL((k_column_rows<int64_t>), dim3(grid), dim3(256), 0, nullptr, P, (const uint64_t *)dOff.p, (ColumnRow *)dRows.p);
+        hipLaunchKernelGGL((k_column_rows<int64_t, uint64_t>), dim3(grid), dim3(256), 0, nullptr, P, (const uint64_t *)dOff.p,
+                           (ColumnRow *)dRows.p);
     else
-        hipLaunchKernelGGL((k_column_rows<int32_t>), dim3(grid), dim3(256), 0, nullptr, P, (const uint64_t *)dOff.p, (ColumnRow *)dRows.p);
+        hipLaunchKernelGGL((k_column_rows<int32_t, uint64_t>), dim3(grid), dim3(256), 0, nullptr, P, (const uint64_t *)dOff.p,
+                           (ColumnRow *)dRows.p);
     HIP_OK(hipEventRecord(b.e, nullptr));
     unsigned int e = 0;
     HIP_OK(hipMemcpy(&e, err.p, 4, hipMemcpyDeviceToHost));
@@ -176,6 +179,84 @@ void columnsRowsHost(hgx_alignment *h, int ref, int64_t first, int64_t count, co
         HIP_OK(hipEventElapsedTime(&ms, a.e, b.e));
         stats->rows_ms += ms;
         stats->rows += total;
+    }
+}
+
+// exclusive scan of n uint32 on the device (out[n] = total); scratch: (n / 1024 + 2) uint32
+static uint32_t deviceScan(const uint32_t *in, uint32_t n, uint32_t *out, uint32_t *blockSums) {
+    const uint32_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(256), 0, nullptr, in, n, blockSums);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, nullptr, blockSums, nb, out + n);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, nullptr, in, n, (const uint32_t *)blockSums, out);
+    uint32_t total = 0;
+    HIP_OK(hipMemcpy(&total, out + n, 4, hipMemcpyDeviceToHost));
+    return total;
+}
+
+void columnsHeadRowsHost(hgx_alignment *h, int ref, int64_t first, int64_t count, const ColumnOptions &opt, bool withDna,
+                         std::vector<uint8_t> &head, std::vector<uint32_t> &headOffset, std::vector<ColumnRowHost> &headRows,
+                         ColumnStats *stats) {
+    if (!h->dev)
+        throw std::runtime_error("alignment was opened without a device (device = -1); the column engine needs the HIP path");
+    HIP_OK(hipSetDevice(h->dev->device));
+    if (withDna)
+        ensureDeviceDna(h->img, *h->dev);
+    head.clear();
+    headOffset.assign(1, 0);
+    headRows.clear();
+    if (count == 0)
+        return;
+    if (count >= ((int64_t)1 << 31))
+        throw std::runtime_error("column chunk too large");
+    const uint32_t n = (uint32_t)count;
+    Buf dCnt((size_t)n * 4), dOff(((size_t)n + 1) * 4), dSums(((size_t)n / SCAN_BLOCK + 2) * 4), err(4);
+    Ev e0, e1;
+    HIP_OK(hipEventRecord(e0.e, nullptr));
+    // 1. rows per column, 2. offsets, 3. all rows (device only)
+    columnsDepthDevice(h, ref, first, count, 1, 2, opt, (int32_t *)dCnt.p, nullptr, nullptr);
+    const uint32_t totalRows = deviceScan((const uint32_t *)dCnt.p, n, (uint32_t *)dOff.p, (uint32_t *)dSums.p);
+    Buf dRows((size_t)totalRows * sizeof(ColumnRow));
+    HIP_OK(hipMemset(err.p, 0, 4));
+    ColumnParams P = makeParams(h, ref, first, count, 1, opt, (unsigned int *)err.p);
+    const int grid = (int)std::min<int64_t>(COL_GRID, (count + 255) / 256);
+    if (h->dev->wide)
+        hipLaunchKernelGGL((k_column_rows<int64_t, uint32_t>), dim3(grid), dim3(256), 0, nullptr, P, (const uint32_t *)dOff.p,
+                           (ColumnRow *)dRows.p);
+    else
+        hipLaunchKernelGGL((k_column_rows<int32_t, uint32_t>), dim3(grid), dim3(256), 0, nullptr, P, (const uint32_t *)dOff.p,
+                           (ColumnRow *)dRows.p);
+    // 4. run heads, 5. offsets of the heads' rows, 6. gather them
+    Buf dHead(n), dHeadCnt((size_t)n * 4), dHeadOff(((size_t)n + 1) * 4);
+    hipLaunchKernelGGL(k_column_heads, dim3(grid), dim3(256), 0, nullptr, (const uint32_t *)dOff.p, (const ColumnRow *)dRows.p, count,
+                       (uint8_t *)dHead.p, (uint32_t *)dHeadCnt.p);
+    const uint32_t totalHeadRows = deviceScan((const uint32_t *)dHeadCnt.p, n, (uint32_t *)dHeadOff.p, (uint32_t *)dSums.p);
+    Buf dOut((size_t)totalHeadRows * sizeof(ColumnRow));
+    hipLaunchKernelGGL(k_gather_head_rows, dim3(grid), dim3(256), 0, nullptr, (const uint32_t *)dOff.p, (const ColumnRow *)dRows.p, count,
+                       (const uint8_t *)dHead.p, (const uint32_t *)dHeadOff.p, (ColumnRow *)dOut.p);
+    HIP_OK(hipEventRecord(e1.e, nullptr));
+    unsigned int e = 0;
+    HIP_OK(hipMemcpy(&e, err.p, 4, hipMemcpyDeviceToHost));
+    if (e)
+        throw std::runtime_error("column walk exceeded the frame stack (more than 64 pending branches for one base)");
+    head.resize(n);
+    HIP_OK(hipMemcpy(head.data(), dHead.p, n, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> headCnt(n);
+    HIP_OK(hipMemcpy(headCnt.data(), dHeadCnt.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    headRows.resize(totalHeadRows);
+    if (totalHeadRows)
+        HIP_OK(hipMemcpy(headRows.data(), dOut.p, (size_t)totalHeadRows * sizeof(ColumnRow), hipMemcpyDeviceToHost));
+    uint32_t acc = 0;
+    for (uint32_t c = 0; c < n; ++c)
+        if (head[c]) {
+            acc += headCnt[c];
+            headOffset.push_back(acc);
+        }
+    if (stats) {
+        float ms = 0;
+        HIP_OK(hipEventElapsedTime(&ms, e0.e, e1.e));
+        stats->rows_ms += ms;
+        stats->rows += totalRows;
+        stats->columns += (uint64_t)count;
     }
 }
 

@@ -37,4 +37,10 @@ void columnsDepthDevice(hgx_alignment *h, int ref, int64_t first, int64_t count,
 void columnsRowsHost(hgx_alignment *h, int ref, int64_t first, int64_t count, const ColumnOptions &opt, bool withDna,
                      std::vector<uint64_t> &rowOffset, std::vector<ColumnRowHost> &rows, ColumnStats *stats);
 
+// Run-compressed form for the MAF writer: head[c] == 1 when column c does not simply continue column c-1 (same rows
+// advanced by one base); only heads have their rows returned (headOffset: one entry per head, + 1).
+void columnsHeadRowsHost(hgx_alignment *h, int ref, int64_t first, int64_t count, const ColumnOptions &opt, bool withDna,
+                         std::vector<uint8_t> &head, std::vector<uint32_t> &headOffset, std::vector<ColumnRowHost> &headRows,
+                         ColumnStats *stats);
+
 } // namespace hgx

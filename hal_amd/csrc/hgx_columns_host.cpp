@@ -2,7 +2,10 @@
 #include "hgx_liftover_host.hpp"
 #include <iostream>
 #include <algorithm>
+#include <chrono>
 #include <climits>
+#include <cstdlib>
+#include <cstring>
 
 namespace hgx {
 
@@ -401,6 +404,169 @@ void MafExport::convertSequence(std::ostream &mafStream, hgx_alignment *alignmen
         } while (brk);
     };
     auto canonicalOnRef = [&]() { return leftmostRefPos >= first && leftmostRefPos <= last; }; // :210-214
+
+    // ---- fast path (no --unique): run-compressed columns ----
+    // Inside a run every column has the rows of its left neighbour advanced by one base, so canAppendColumn can only
+    // fail on the block-length limit and appendColumn only appends one character per entry; the run is therefore
+    // appended in bulk, falling back to single columns at sequence ends and block-length breaks.
+    if (!_unique && !getenv("HGX_MAF_PER_COLUMN")) {
+        double fetchSeconds = 0;
+        size_t numHeads = 0;
+        std::vector<uint8_t> head;
+        std::vector<uint32_t> headOff;
+        std::vector<ColumnRowHost> headRows, curRows;
+        struct Pair {
+            Entry *e;
+            ColumnRowHost *row; // null: entry gets a gap
+        };
+        std::vector<Pair> pairs;
+        auto comp = [](char c) {
+            switch (c) {
+            case 'A': return 'T';
+            case 'a': return 't';
+            case 'C': return 'G';
+            case 'c': return 'g';
+            case 'G': return 'C';
+            case 'g': return 'c';
+            case 'T': return 'A';
+            case 't': return 'a';
+            default: return c;
+            }
+        };
+        auto baseAt = [&](const ColumnRowHost &r, int64_t pos) {
+            const std::vector<uint8_t> &d = alignment->img.genomes[(size_t)r.genome].dna;
+            if (d.empty())
+                return 'N';
+            const char c = dnaAt(d, pos);
+            return r.rev ? comp(c) : c;
+        };
+        auto rebuildColMap = [&]() {
+            for (auto &kv : colMap)
+                kv.second.clear();
+            for (ColumnRowHost &r : curRows)
+                colMap[keyOf(r.genome, r.pos)].push_back(&r);
+        };
+        auto buildPairs = [&]() { // the pairing appendColumn performs (halMafBlock.cpp:370-395)
+            pairs.clear();
+            Entries::iterator e = _entries.begin();
+            for (auto c = colMap.begin(); c != colMap.end(); ++c)
+                for (const ColumnRowHost *row : c->second) {
+                    while (e != _entries.end() && e->first.rank != c->first.rank) {
+                        pairs.push_back(Pair{e->second, nullptr});
+                        ++e;
+                    }
+                    pairs.push_back(Pair{e->second, const_cast<ColumnRowHost *>(row)});
+                    ++e;
+                }
+            for (; e != _entries.end(); ++e)
+                pairs.push_back(Pair{e->second, nullptr});
+        };
+        auto stepColumn = [&](int64_t refPos) { // one column through the reference's per-column logic
+            if (appendCount == 0) {
+                initBlock(colMap, refKey, refPos);
+            } else if (!canAppendColumn(colMap)) {
+                if (numBlocks++ % 1000 == 0)
+                    for (auto it = colMap.begin(); it != colMap.end();)
+                        it = it->second.empty() ? colMap.erase(it) : std::next(it);
+                if (_keepEmptyRefBlocks || !referenceIsAllGaps()) {
+                    printBlock(mafStream);
+                    mafStream << '\n';
+                }
+                initBlock(colMap, refKey, refPos);
+            }
+            appendColumn(colMap);
+            ++appendCount;
+        };
+        for (int64_t done = 0; done < length;) {
+            const int64_t n = std::min<int64_t>((int64_t)chunkColumns, length - done);
+            const auto tFetch0 = std::chrono::steady_clock::now();
+            columnsHeadRowsHost(alignment, genome, first + done, n, opt, true, head, headOff, headRows, &stats);
+            fetchSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - tFetch0).count();
+            numHeads += headOff.size() - 1;
+            size_t hk = 0;
+            for (int64_t i = 0; i < n;) {
+                // head column i: its rows come from the GPU
+                curRows.assign(headRows.begin() + headOff[hk], headRows.begin() + headOff[hk + 1]);
+                ++hk;
+                rebuildColMap();
+                stepColumn(startPosition + done + i);
+                int64_t run = 0; // continuation columns that follow
+                while (i + 1 + run < n && !head[(size_t)(i + 1 + run)])
+                    ++run;
+                int64_t col = i + 1;
+                while (run > 0) {
+                    buildPairs();
+                    int64_t t = run;
+                    for (const Pair &pr : pairs) {
+                        if (!pr.row)
+                            continue;
+                        t = std::min(t, _maxBlockLength - pr.e->length); // canAppendColumn: length >= maxLength breaks
+                        const GenomeTables &RG = alignment->img.genomes[(size_t)pr.row->genome];
+                        const SeqInfo &RS = RG.seqs.size() == 1 ? RG.seqs[0] : RG.seqs[(size_t)RG.seqIndexBySite(pr.row->pos)];
+                        t = std::min(t, pr.row->rev ? pr.row->pos - RS.start : RS.start + RS.length - 1 - pr.row->pos);
+                    }
+                    if (t > 0) {
+                        for (const Pair &pr : pairs) {
+                            if (!pr.row) {
+                                pr.e->sequence.append((size_t)t, '-');
+                                continue;
+                            }
+                            ColumnRowHost &r = *pr.row;
+                            const size_t at = pr.e->sequence.size();
+                            pr.e->sequence.resize(at + (size_t)t);
+                            char *dst = &pr.e->sequence[at];
+                            const std::vector<uint8_t> &d = alignment->img.genomes[(size_t)r.genome].dna;
+                            if (d.empty()) {
+                                memset(dst, 'N', (size_t)t);
+                            } else if (!r.rev) { // dnaUnpack (halCommon.h:187-190) over a forward run
+                                static const char fwd[17] = "acgtn\0\0\0ACGTN\0\0\0";
+                                const uint8_t *pk = d.data();
+                                int64_t p0 = r.pos + 1;
+                                for (int64_t k = 0; k < t; ++k, ++p0) {
+                                    const uint8_t b = pk[p0 >> 1];
+                                    dst[k] = fwd[(p0 & 1) ? (b & 0x0F) : (b >> 4)];
+                                }
+                            } else { // reverse strand: walk left, complemented (reverseComplement, halCommon.h:45-75)
+                                static const char rc[17] = "tgcan\0\0\0TGCAN\0\0\0";
+                                const uint8_t *pk = d.data();
+                                int64_t p0 = r.pos - 1;
+                                for (int64_t k = 0; k < t; ++k, --p0) {
+                                    const uint8_t b = pk[p0 >> 1];
+                                    dst[k] = rc[(p0 & 1) ? (b & 0x0F) : (b >> 4)];
+                                }
+                            }
+                            pr.e->length += t;
+                            r.pos += r.rev ? -t : t;
+                            r.base = pr.e->sequence.back();
+                        }
+                        appendCount += (size_t)t;
+                        run -= t;
+                        col += t;
+                    }
+                    if (run > 0) { // a block-length break or a sequence end: one ordinary column
+                        for (ColumnRowHost &r : curRows) {
+                            r.pos += r.rev ? -1 : 1;
+                            r.base = baseAt(r, r.pos);
+                        }
+                        rebuildColMap();
+                        stepColumn(startPosition + done + col);
+                        --run;
+                        ++col;
+                    }
+                }
+                i = col;
+            }
+            done += n;
+        }
+        if (appendCount > 0 && (_keepEmptyRefBlocks || !referenceIsAllGaps())) {
+            printBlock(mafStream);
+            mafStream << std::endl;
+        }
+        if (getenv("HGX_MAF_TIMING"))
+            std::cerr << "[hgx maf] columns " << length << " heads " << numHeads << " blocks " << numBlocks << " fetch(GPU+copy) "
+                      << fetchSeconds << " s, device " << stats.rows_ms + stats.depth_ms << " ms" << std::endl;
+        return;
+    }
 
     toRight(); // the constructor's first step
     if (!_unique || canonicalOnRef()) {

@@ -627,7 +627,7 @@ __global__ void __launch_bounds__(256) k_finalize(const REC *__restrict__ segs, 
 }
 
 // group pieces by query: slot = offset[q] + cursor[q]++
-__global__ void __launch_bounds__(256) k_scatter(Mapped in, const unsigned long long *inCount, uint32_t cap, const uint32_t *__restrict__ offset,
+static __global__ void __launch_bounds__(256) k_scatter(Mapped in, const unsigned long long *inCount, uint32_t cap, const uint32_t *__restrict__ offset,
                                                  uint32_t *__restrict__ cursor, Mapped out) {
     const uint32_t n = (uint32_t)min((unsigned long long)cap, *inCount); // CNT_MAPPED: dense count written by k_finalize
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -639,7 +639,7 @@ __global__ void __launch_bounds__(256) k_scatter(Mapped in, const unsigned long 
 
 // ---- exclusive scan of uint32 (three small kernels; n up to 2^32-1) ----
 static constexpr int SCAN_BLOCK = 1024; // elements per block (256 threads x 4)
-__global__ void __launch_bounds__(256) k_scan_block_sums(const uint32_t *__restrict__ in, uint32_t n, uint32_t *__restrict__ blockSums) {
+static __global__ void __launch_bounds__(256) k_scan_block_sums(const uint32_t *__restrict__ in, uint32_t n, uint32_t *__restrict__ blockSums) {
     __shared__ uint32_t red[256];
     const uint32_t base = blockIdx.x * SCAN_BLOCK;
     uint32_t s = 0;
@@ -659,7 +659,7 @@ __global__ void __launch_bounds__(256) k_scan_block_sums(const uint32_t *__restr
         blockSums[blockIdx.x] = red[0];
 }
 // exclusive scan of the per-block sums by one 1024-thread block (each thread owns a contiguous run)
-__global__ void __launch_bounds__(1024) k_scan_sums(uint32_t *blockSums, uint32_t nb, uint32_t *total) {
+static __global__ void __launch_bounds__(1024) k_scan_sums(uint32_t *blockSums, uint32_t nb, uint32_t *total) {
     __shared__ uint32_t part[1024];
     const uint32_t per = (nb + 1023) / 1024;
     const uint32_t lo = threadIdx.x * per, hi = min(nb, lo + per);
@@ -685,7 +685,7 @@ __global__ void __launch_bounds__(1024) k_scan_sums(uint32_t *blockSums, uint32_
     if (threadIdx.x == 1023)
         *total = part[1023];
 }
-__global__ void __launch_bounds__(256) k_scan_apply(const uint32_t *__restrict__ in, uint32_t n, const uint32_t *__restrict__ blockSums,
+static __global__ void __launch_bounds__(256) k_scan_apply(const uint32_t *__restrict__ in, uint32_t n, const uint32_t *__restrict__ blockSums,
                                                     uint32_t *__restrict__ out) {
     __shared__ uint32_t part[256];
     const uint32_t base = blockIdx.x * SCAN_BLOCK + threadIdx.x * 4;
