@@ -104,6 +104,7 @@ def main():
     import torch
     import torch.distributed as dist
     import hal_amd
+    from hal_amd import shard
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -130,17 +131,9 @@ def main():
     def step():
         ptr, nrec = plan.run(d_gs, d_ge, d_st)
         if world > 1:
-            # all-gatherv of the fixed-width records: counts first, then padded payloads
-            cnt = torch.tensor([nrec], dtype=torch.int64, device=dev)
-            counts = torch.empty(world, dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(counts, cnt)
-            mx = int(counts.max().item())
-            mine = torch.zeros((mx, 40), dtype=torch.uint8, device=dev)
-            if nrec:
-                mine[:nrec] = plan.records_to_tensor(ptr, nrec)
-            allrec = torch.empty((world * mx, 40), dtype=torch.uint8, device=dev)
-            dist.all_gather_into_tensor(allrec, mine)
-            return nrec, int(counts.sum().item())
+            # the one exchange step of the path: all-gatherv of the fixed-width records (hal_amd/shard.py)
+            _, counts = shard.all_gather_records(plan.records_to_tensor(ptr, nrec), trim=False)
+            return nrec, sum(counts)
         return nrec, nrec
 
     for _ in range(args.warmup):
@@ -189,6 +182,18 @@ def main():
                 traffic = json.load(open(pmc)).get(dom_name)
             except Exception:
                 traffic = None
+        # measured device-copy rate on this GPU (read + write bytes of a 1 GiB device-to-device copy), SURVEY 8(d)
+        cp_src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+        cp_dst = torch.empty_like(cp_src)
+        cp_dst.copy_(cp_src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            cp_dst.copy_(cp_src)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 5 * 2 * cp_src.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del cp_src, cp_dst
         out = {
             "metric": "lifted BED intervals/sec", "value": value, "unit": "intervals/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
@@ -199,6 +204,7 @@ def main():
                        "newick": al.newick, "generate_s": round(gen_s, 2)},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "measured_copy_GBs": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs,
                          "kernel_avg_ms": dom_avg_ms, "kernel_launches_per_step": dom_launches / args.steps,
                          "algorithmic_bytes_per_launch": dom_bytes_per_launch,
                          "whole_path": {"algorithmic_bytes_per_step": alg_total, "kernel_ms_per_step": kern_ms_total,

@@ -1,0 +1,63 @@
+"""Multi-GPU host logic of the hot path: one process per GPU, contiguous shards of independent units (query
+intervals: liftover/impl/halLiftover.cpp:46-92 clears all per-line state; reference columns:
+api/impl/halColumnIterator.cpp:785-787), and the single exchange step that collates fixed-width output records
+(SURVEY 8(e)): an all-gather of per-rank counts, then an all-gather of payloads padded to the largest shard.
+torch.distributed is the transport (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests)."""
+import torch
+import torch.distributed as dist
+
+RECORD_BYTES = 40  # sizeof(hgx_record), include/hgx.h
+
+
+def shard_bounds(n, world, rank):
+    """Rank r owns [r*n/world, (r+1)*n/world): rank-major concatenation of the shards is input order."""
+    return (rank * n) // world, ((rank + 1) * n) // world
+
+
+def all_gather_counts(n, device):
+    """Every rank's record count, as a python list, on every rank."""
+    world = dist.get_world_size()
+    cnt = torch.tensor([n], dtype=torch.int64, device=device)
+    counts = torch.empty(world, dtype=torch.int64, device=device)
+    if device.type == "cuda":
+        dist.all_gather_into_tensor(counts, cnt)
+    else:  # gloo has no all_gather_into_tensor on every build
+        parts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(parts, cnt)
+        counts = torch.cat(parts)
+    return [int(c) for c in counts.tolist()]
+
+
+def all_gather_records(recs, trim=True):
+    """recs: uint8 [n, 40] tensor of hgx_record (any device).  Returns (records, counts): with trim the rank-major
+    concatenation [sum(counts), 40] on every rank; without it the padded [world * max(counts), 40] buffer, which
+    avoids the device-side compaction when the caller only forwards the bytes."""
+    world = dist.get_world_size()
+    dev = recs.device
+    counts = all_gather_counts(recs.shape[0], dev)
+    mx = max(counts) if counts else 0
+    mine = recs
+    if recs.shape[0] != mx:
+        mine = torch.zeros((mx, RECORD_BYTES), dtype=torch.uint8, device=dev)
+        mine[:recs.shape[0]] = recs
+    if dev.type == "cuda":
+        allrec = torch.empty((world * mx, RECORD_BYTES), dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(allrec, mine.contiguous())
+        bufs = list(allrec.view(world, mx, RECORD_BYTES).unbind(0))
+    else:
+        bufs = [torch.empty((mx, RECORD_BYTES), dtype=torch.uint8) for _ in range(world)]
+        dist.all_gather(bufs, mine.contiguous())
+        allrec = None
+    if not trim:
+        return (allrec if allrec is not None else torch.cat(bufs, dim=0)), counts
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0), counts
+
+
+def offset_query_index(recs, first_query):
+    """Records carry the query index within the shard (hgx_record.query, first 8 bytes, little endian); add the shard's
+    first global index so that the gathered stream reads as one batch."""
+    if recs.shape[0]:
+        q = recs[:, :8].contiguous().view(torch.int64)
+        q += first_query
+        recs[:, :8] = q.view(torch.uint8).view(-1, 8)
+    return recs

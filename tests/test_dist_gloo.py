@@ -10,32 +10,17 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 
-def shard_bounds(n, world, rank):
-    """Rank r owns [r*n/world, (r+1)*n/world): rank-major concatenation is input order."""
-    return (rank * n) // world, ((rank + 1) * n) // world
+from hal_amd.shard import all_gather_records, shard_bounds, offset_query_index
 
 
-def all_gather_records(recs, world):
-    """recs: uint8 [n, 40] tensor of hgx_record.  Returns the rank-major concatenation on every rank."""
-    cnt = torch.tensor([recs.shape[0]], dtype=torch.int64, device=recs.device)
-    counts = [torch.zeros(1, dtype=torch.int64, device=recs.device) for _ in range(world)]
-    dist.all_gather(counts, cnt)
-    counts = [int(c.item()) for c in counts]
-    mx = max(counts) if counts else 0
-    mine = torch.zeros((mx, 40), dtype=torch.uint8, device=recs.device)
-    mine[:recs.shape[0]] = recs
-    bufs = [torch.empty((mx, 40), dtype=torch.uint8, device=recs.device) for _ in range(world)]
-    dist.all_gather(bufs, mine)
-    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0), counts
-
-
-def fake_lift(q_lo, q_hi):
-    """query i yields (i % 4) records whose bytes encode (i, k)."""
+def fake_lift(q_lo, q_hi, base=0):
+    """query i yields (i % 4) records whose bytes encode (i - base, k): base = q_lo imitates a rank that numbers
+    its queries from 0, as the plan does."""
     out = []
     for i in range(q_lo, q_hi):
         for k in range(i % 4):
             r = np.zeros(40, dtype=np.uint8)
-            r[:8] = np.frombuffer(np.int64(i).tobytes(), dtype=np.uint8)
+            r[:8] = np.frombuffer(np.int64(i - base).tobytes(), dtype=np.uint8)
             r[8] = k
             out.append(r)
     return torch.from_numpy(np.stack(out)) if out else torch.zeros((0, 40), dtype=torch.uint8)
@@ -46,7 +31,7 @@ def _worker(rank, world, port, n, result):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lo, hi = shard_bounds(n, world, rank)
-    gathered, counts = all_gather_records(fake_lift(lo, hi), world)
+    gathered, counts = all_gather_records(offset_query_index(fake_lift(lo, hi, base=lo), lo))
     want = fake_lift(0, n)
     ok = gathered.shape == want.shape and bool(torch.equal(gathered, want)) and sum(counts) == want.shape[0]
     result[rank] = ok
