@@ -45,6 +45,47 @@ template <> struct alignas(16) UpRec<int64_t> {
     int32_t parentTopParse;
     int64_t _pad;
 };
+// Record of the chained up kernel (k_up_chain): everything one step over one top segment needs in ONE 16-byte load
+// (the gather rate of that kernel is bound by the number of L1 misses in flight per CU, so a step must not cost two).
+// The segment's length replaces the look at the next record's start.  Two tables per genome: "mid" for a hop whose
+// parent is walked further (link = the parent bottom segment's top-parse index) and "last" for the hop into the
+// MRCA (link = the parent bottom segment's index).
+#ifdef __HIPCC__
+#define HGX_HD __host__ __device__
+#else
+#define HGX_HD // this header is also read by the g++-compiled host files
+#endif
+template <typename C> struct ChainRec;
+template <> struct alignas(16) ChainRec<int32_t> {
+    int32_t start;
+    int32_t parentStart;  // start coordinate of the parent bottom segment
+    uint32_t lenHas;      // (length << 1) | hasParent
+    uint32_t linkRev;     // (link << 1) | parentReversed
+    HGX_HD int64_t len() const { return (int64_t)(lenHas >> 1); }
+    HGX_HD bool hasParent() const { return lenHas & 1u; }
+    HGX_HD void set(int64_t s, int64_t ps, int64_t l, bool has, int64_t link, bool rev) {
+        start = (int32_t)s;
+        parentStart = (int32_t)ps;
+        lenHas = ((uint32_t)l << 1) | (has ? 1u : 0u);
+        linkRev = ((uint32_t)link << 1) | (rev ? 1u : 0u);
+    }
+};
+template <> struct alignas(16) ChainRec<int64_t> {
+    int64_t start;
+    int64_t parentStart;
+    int64_t length;
+    uint32_t linkRev;
+    uint32_t has;
+    HGX_HD int64_t len() const { return length; }
+    HGX_HD bool hasParent() const { return has != 0; }
+    HGX_HD void set(int64_t s, int64_t ps, int64_t l, bool h, int64_t link, bool rev) {
+        start = s;
+        parentStart = ps;
+        length = l;
+        has = h ? 1u : 0u;
+        linkRev = ((uint32_t)link << 1) | (rev ? 1u : 0u);
+    }
+};
 template <typename C> struct BotRec;
 template <> struct alignas(8) BotRec<int32_t> {
     int32_t start;
@@ -59,6 +100,8 @@ template <> struct alignas(16) BotRec<int64_t> {
 struct DeviceGenome {
     void *top = nullptr;                // TopRec<C>[numTop+1]
     void *up = nullptr;                 // UpRec<C>[numTop+1] (genomes with a parent)
+    void *chainMid = nullptr;           // ChainRec<C>[numTop], built on first use by a plan (ensureChainTables)
+    void *chainLast = nullptr;          // ChainRec<C>[numTop]
     void *bot = nullptr;                // BotRec<C>[numBot+1]
     std::vector<int32_t *> childEnc;    // per child slot, int32[numBot]
     int64_t *seqStart = nullptr;        // int64[numSeq+1] (sentinel = genome length)
@@ -89,6 +132,9 @@ struct DeviceImage {
     size_t bytes = 0;
     ~DeviceImage();
 };
+
+// builds the k_up_chain tables of `genome` (idempotent, serialised by an internal mutex)
+void ensureChainTables(const Image &img, DeviceImage &D, int genome, bool mid, bool last);
 
 // uploads the packed DNA of every genome (idempotent); needed only by the MAF path
 void ensureDeviceDna(const Image &img, DeviceImage &D);

@@ -4,6 +4,7 @@
 #include "hgx_liftover_engine.hpp"
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 #include <cstring>
 #include <map>
 
@@ -27,6 +28,10 @@ DeviceImage::~DeviceImage() {
             (void)hipFree(g.top);
         if (g.up)
             (void)hipFree(g.up);
+        if (g.chainMid)
+            (void)hipFree(g.chainMid);
+        if (g.chainLast)
+            (void)hipFree(g.chainLast);
         if (g.bot)
             (void)hipFree(g.bot);
         for (int32_t *c : g.childEnc)
@@ -108,6 +113,41 @@ template <typename C> static void uploadUpTable(const GenomeTables &G, const Gen
     HIP_OK(hipMalloc(&D.up, up.size() * sizeof(UpRec<C>)));
     HIP_OK(hipMemcpy(D.up, up.data(), up.size() * sizeof(UpRec<C>), hipMemcpyHostToDevice));
     bytes += up.size() * sizeof(UpRec<C>);
+}
+
+template <typename C> static void *uploadChainTable(const GenomeTables &G, const GenomeTables &P, bool last, size_t &bytes) {
+    std::vector<ChainRec<C>> t((size_t)std::max<int64_t>(1, G.numTop));
+    memset(t.data(), 0, t.size() * sizeof(ChainRec<C>));
+    for (int64_t i = 0; i < G.numTop; ++i) {
+        const int64_t p = G.tParent[(size_t)i];
+        const int64_t start = G.tStart[(size_t)i];
+        const int64_t len = (i + 1 < G.numTop ? G.tStart[(size_t)i + 1] : G.totalLength) - start;
+        if (p < 0)
+            t[(size_t)i].set(start, 0, len, false, 0, false);
+        else
+            t[(size_t)i].set(start, P.bStart[(size_t)p], len, true, last ? p : std::max<int64_t>(0, P.bTopParse[(size_t)p]),
+                             G.tParentRev[(size_t)i] != 0);
+    }
+    void *d = nullptr;
+    HIP_OK(hipMalloc(&d, t.size() * sizeof(ChainRec<C>)));
+    HIP_OK(hipMemcpy(d, t.data(), t.size() * sizeof(ChainRec<C>), hipMemcpyHostToDevice));
+    bytes += t.size() * sizeof(ChainRec<C>);
+    return d;
+}
+
+void ensureChainTables(const Image &img, DeviceImage &D, int genome, bool mid, bool last) {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    const GenomeTables &G = img.genomes[(size_t)genome];
+    if (G.parent < 0)
+        throw std::runtime_error("ensureChainTables: genome has no parent");
+    const GenomeTables &P = img.genomes[(size_t)G.parent];
+    DeviceGenome &dg = D.genomes[(size_t)genome];
+    HIP_OK(hipSetDevice(D.device));
+    if (mid && !dg.chainMid)
+        dg.chainMid = D.wide ? uploadChainTable<int64_t>(G, P, false, D.bytes) : uploadChainTable<int32_t>(G, P, false, D.bytes);
+    if (last && !dg.chainLast)
+        dg.chainLast = D.wide ? uploadChainTable<int64_t>(G, P, true, D.bytes) : uploadChainTable<int32_t>(G, P, true, D.bytes);
 }
 
 template <typename C> static void uploadGenome(const GenomeTables &G, DeviceGenome &D, size_t &bytes) {
@@ -286,6 +326,7 @@ struct hgx_liftover_plan {
     std::vector<int> up;                        // src ... mrca
     std::vector<std::pair<int, int>> down;      // (parent genome, child slot) per downward hop
     bool srcTop = true;
+    bool levelSyncUp = getenv("HGX_LEVEL_SYNC_UP") != nullptr; // one launch per up level instead of k_up_chain (kept for deep trees and as a cross-check)
     size_t maxQueries = 0;
     uint32_t cap = 0; // piece capacity of every frontier / mapped / record buffer
     DevBuf fr[2][6], mp[2][6], counters, perQuery, offset, cursor, nOut, outOffset, blockSums, total, grouped, outRecords,
@@ -389,25 +430,43 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
         // is one k_up_walk launch.  The last launch emits ordinary bottom pieces (index, offset) in the MRCA, the
         // others emit positional pieces (forward start in the parent + its top-parse hint).
         const size_t nUp = P.up.size() - 1; // number of hops
-        {
-            const bool last = nUp == 1;
-            P.timer.begin("k_up_first", s, launch);
-            hipLaunchKernelGGL((k_up_first<C>), dim3(GRID), dim3(256), 0, s, (const UpRec<C> *)D.genomes[(size_t)P.src].up,
-                               P.frontier(cur), inCnt(), cap, P.frontier(cur ^ 1), outCnt(), minLen, (int)last, cnt, kstat());
+        if (nUp >= 2 && nUp <= (size_t)MAX_CHAIN && !P.levelSyncUp) {
+            // the whole up phase depth first in one launch (no intermediate frontiers)
+            UpTables<C> tabs;
+            for (int k = 0; k < MAX_CHAIN; ++k) {
+                const size_t kk = (size_t)k < nUp ? (size_t)k : 0;
+                const DeviceGenome &UG = D.genomes[(size_t)P.up[kk]];
+                tabs.t[k] = (const ChainRec<C> *)(kk + 1 == nUp ? UG.chainLast : UG.chainMid);
+            }
+            tabs.n = (int)nUp;
+            P.timer.begin("k_up_chain", s, launch);
+            hipLaunchKernelGGL((k_up_chain<C>), dim3(GRID), dim3(256), upChainLdsBytes((int)nUp), s, tabs, P.frontier(cur), inCnt(), cap, P.frontier(cur ^ 1),
+                               outCnt(), minLen, cnt, kstat());
             P.timer.end(s);
             ++launch;
             cur ^= 1;
             ++level;
-        }
-        for (size_t k = 1; k < nUp; ++k) {
-            const bool last = k + 1 == nUp;
-            P.timer.begin("k_up_walk", s, launch);
-            hipLaunchKernelGGL((k_up_walk<C>), dim3(GRID), dim3(256), 0, s, (const UpRec<C> *)D.genomes[(size_t)P.up[k]].up,
-                               P.frontier(cur), inCnt(), cap, P.frontier(cur ^ 1), outCnt(), minLen, (int)last, cnt, kstat());
-            P.timer.end(s);
-            ++launch;
-            cur ^= 1;
-            ++level;
+        } else {
+            {
+                const bool last = nUp == 1;
+                P.timer.begin("k_up_first", s, launch);
+                hipLaunchKernelGGL((k_up_first<C>), dim3(GRID), dim3(256), 0, s, (const UpRec<C> *)D.genomes[(size_t)P.src].up,
+                                   P.frontier(cur), inCnt(), cap, P.frontier(cur ^ 1), outCnt(), minLen, (int)last, cnt, kstat());
+                P.timer.end(s);
+                ++launch;
+                cur ^= 1;
+                ++level;
+            }
+            for (size_t k = 1; k < nUp; ++k) {
+                const bool last = k + 1 == nUp;
+                P.timer.begin("k_up_walk", s, launch);
+                hipLaunchKernelGGL((k_up_walk<C>), dim3(GRID), dim3(256), 0, s, (const UpRec<C> *)D.genomes[(size_t)P.up[k]].up,
+                                   P.frontier(cur), inCnt(), cap, P.frontier(cur ^ 1), outCnt(), minLen, (int)last, cnt, kstat());
+                P.timer.end(s);
+                ++launch;
+                cur ^= 1;
+                ++level;
+            }
         }
         curGenome = P.mrca;
         curTop = false;
@@ -622,6 +681,12 @@ hgx_liftover_plan *createLiftoverPlan(hgx_alignment *h, int src, int tgt, const 
         P->up.push_back(g);
         if (g == P->mrca)
             break;
+    }
+    {
+        const size_t nUp = P->up.size() - 1;
+        if (nUp >= 2 && nUp <= (size_t)MAX_CHAIN && !P->levelSyncUp)
+            for (size_t k = 0; k < nUp; ++k)
+                ensureChainTables(img, *h->dev, P->up[k], k + 1 < nUp, k + 1 == nUp);
     }
     std::vector<int> chain; // tgt ... mrca
     for (int g = tgt; g != P->mrca; g = img.genomes[(size_t)g].parent)

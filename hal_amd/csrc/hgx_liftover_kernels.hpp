@@ -425,6 +425,187 @@ __global__ void __launch_bounds__(256) k_up_walk(const UpRec<C> *__restrict__ up
     wave_count_add(&kstat[1], botDerefs);
 }
 
+// The whole up phase in one launch.  With k_up_first/k_up_walk every level writes its pieces to HBM and the next launch
+// reads them back (29 B each way per piece per level) although a piece's way up depends on nothing but itself.  Here a
+// lane takes one source piece and follows it to the MRCA depth first: a step looks at one top segment of the current
+// level (one UpRec gather), cuts the piece against it, and either emits the cut (last level), descends with it to the
+// next level, or moves right; a level that still has bases to the right is parked on a small per-lane stack.  The
+// results are the same set of pieces k_up_walk produces level by level (the order inside a frontier is irrelevant).
+// Lanes that finish refill from the wavefront's private slice of the input, so the wave stays full until its slice
+// is exhausted.  Dereference counters follow the same rules as k_up_first / k_up_walk.
+static constexpr int MAX_CHAIN = 16; // up hops handled by the chained kernel (deeper paths use one launch per level)
+template <typename C> struct UpTables {
+    const ChainRec<C> *t[MAX_CHAIN]; // t[k] = chain table of the k-th genome on the way up (t[0] = source); "last" flavour for t[n-1]
+    int n;                           // number of hops
+};
+
+// anchor of the affine map forward position -> source position of a piece whose first base (iteration order) has
+// source position sPos: first base is at lo on the forward target strand, at hi on the reverse one
+__device__ __forceinline__ int64_t make_anchor(int64_t sPos, int64_t lo, int64_t hi, uint8_t fl) {
+    const int64_t first = !(fl & F_TREV) ? lo : hi;
+    const bool neg = ((fl & F_SREV) != 0) != ((fl & F_TREV) != 0);
+    return neg ? sPos + first : sPos - first;
+}
+// What bounds this kernel (PMC, profiles/r01i_*): the number of cache-line requests a CU's L1 keeps in flight — about
+// 60 at ~630 cycles each, TCP pending-stall ~75 % of the time — so the cost of a step is its number of L1 requests,
+// and a step is exactly one 16-byte gather (ChainRec).  Tried and measured slower: a register window of 4-5 records
+// per step (more requests per step than scan steps saved), and 4 lanes per piece sharing one 64-byte request (fewer
+// requests, but four times the wave-steps made it issue-bound: 3.1 ms against 1.2 ms).
+static inline size_t upChainLdsBytes(int hops) {
+    const int slots = hops - 1 > 1 ? hops - 2 : 1;
+    return (size_t)slots * 256 * (8 + 8 + 4 + 1);
+}
+
+template <typename C>
+__global__ void __launch_bounds__(256) k_up_chain(UpTables<C> tabs, Frontier in, const unsigned long long *inCount, uint32_t cap,
+                                                  Frontier out, unsigned long long *outCount, int64_t minLength,
+                                                  unsigned long long *counters, unsigned long long *kstat) {
+    __shared__ FrontView fview;
+    __shared__ const ChainRec<C> *sTab[MAX_CHAIN];
+    if (threadIdx.x < MAX_CHAIN)
+        sTab[threadIdx.x] = tabs.t[threadIdx.x];
+    const uint32_t n = front_view_init(&fview, inCount, cap); // contains the block barriers that publish sTab
+    const int lastLvl = tabs.n - 1;
+    const uint32_t wavesTotal = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t per = (n + wavesTotal - 1) / wavesTotal;
+    uint32_t next = wave * per; // wave-uniform cursor into this wave's slice
+    const uint32_t endItem = (uint64_t)next + per < n ? next + per : n;
+    uint32_t topDerefs = 0, botDerefs = 0;
+    __shared__ StageMem stageMem;
+    Stage stage;
+    stage.init(&stageMem, out, outCount, counters, cap);
+
+    // parked levels live in dynamic LDS, [slot][thread]: slot = level - 1, levels 1 .. lastLvl-1 can park.
+    // A parked level keeps what its remaining segments need: the right clip, the next segment, the flags and the
+    // affine map from a forward position to the source position (see make_anchor).
+    extern __shared__ __align__(16) unsigned char dynLds[];
+    const int slots = lastLvl > 1 ? lastLvl - 1 : 1;
+    int64_t *stAnchor = (int64_t *)dynLds;
+    int64_t *stHi = stAnchor + slots * 256;
+    int32_t *stJ = (int32_t *)(stHi + slots * 256);
+    uint8_t *stFl = (uint8_t *)(stJ + slots * 256);
+    uint32_t pending = 0;
+
+    bool busy = false, fresh = false;
+    int lvl = 0;
+    int32_t qid = 0;
+    int64_t j = 0, lo = 0, hi = -1, anchor = 0;
+    uint8_t fl = 0;
+    for (;;) {
+        // refill idle lanes from the slice: level 0 is the source piece itself (never splits: it lies inside one top
+        // segment), mapped to its parent here
+        const unsigned long long idle = __ballot(!busy);
+        if (idle != 0 && next < endItem) {
+            const uint32_t mine = next + (uint32_t)__popcll(idle & ((1ull << lane_id()) - 1ull));
+            if (!busy && mine < endItem) {
+                const uint32_t i = front_slot(&fview, mine, cap);
+                const int32_t t = in.idx[i];
+                const int32_t len = in.len[i];
+                const ChainRec<C> r = sTab[0][t];
+                ++topDerefs;
+                if (r.hasParent() && (int64_t)len >= minLength) {
+                    qid = in.qid[i];
+                    const int64_t so = in.so[i];
+                    fl = in.flags[i];
+                    if (r.linkRev & 1u)
+                        fl ^= F_TREV;
+                    lo = !(fl & F_TREV) ? (int64_t)r.parentStart + so : (int64_t)r.parentStart + r.len() - so - len;
+                    hi = lo + len - 1;
+                    anchor = make_anchor(in.sPos[i], lo, hi, fl);
+                    j = (int64_t)(r.linkRev >> 1);
+                    lvl = 1;
+                    fresh = true;
+                    busy = true;
+                    pending = 0;
+                }
+            }
+            next += (uint32_t)__popcll(idle);
+            if (next > endItem)
+                next = endItem;
+        }
+        if (!__any(busy)) {
+            if (next >= endItem)
+                break;
+            continue;
+        }
+        bool emit = false;
+        int32_t oIdx = 0, oLen = 0;
+        int64_t oSPos = 0, oSo = 0;
+        uint8_t oFl = 0;
+        if (busy) {
+            const ChainRec<C> r = sTab[lvl][j]; // the step's only memory access
+            const int64_t curStart = (int64_t)r.start, nextStart = curStart + r.len();
+            ++topDerefs;
+            if (fresh && nextStart <= lo) {
+                ++j; // toParseUp's linear scan to the segment holding the piece's left end (halTopSegmentIterator.cpp:64-66)
+            } else {
+                if (fresh) {
+                    fresh = false;
+                    ++botDerefs; // logical dereference of the bottom segment this piece came from
+                }
+                const int64_t plo = lo > curStart ? lo : curStart;
+                const int64_t phi = hi < nextStart - 1 ? hi : nextStart - 1;
+                oLen = (int32_t)(phi - plo + 1);
+                const bool more = nextStart <= hi;
+                const bool valid = r.hasParent() && (int64_t)oLen >= minLength;
+                ++j;
+                bool descended = false;
+                if (valid) {
+                    // source position of the cut's first base in iteration order: srcPos(p) = anchor +- p
+                    const int64_t so = !(fl & F_TREV) ? plo - curStart : nextStart - 1 - phi;
+                    const int64_t edge = !(fl & F_TREV) ? plo : phi;
+                    const bool neg = ((fl & F_SREV) != 0) != ((fl & F_TREV) != 0);
+                    oSPos = neg ? anchor - edge : anchor + edge;
+                    oFl = fl;
+                    if (r.linkRev & 1u)
+                        oFl ^= F_TREV;
+                    if (lvl == lastLvl) {
+                        emit = true;
+                        oIdx = (int32_t)(r.linkRev >> 1);
+                        oSo = so;
+                    } else {
+                        if (more) {
+                            const int at = (lvl - 1) * 256 + (int)threadIdx.x;
+                            stJ[at] = (int32_t)j;
+                            stAnchor[at] = anchor;
+                            stHi[at] = hi;
+                            stFl[at] = fl;
+                            pending |= 1u << lvl;
+                        }
+                        lo = !(oFl & F_TREV) ? (int64_t)r.parentStart + so : (int64_t)r.parentStart + r.len() - so - oLen;
+                        hi = lo + oLen - 1;
+                        fl = oFl;
+                        anchor = make_anchor(oSPos, lo, hi, fl);
+                        j = (int64_t)(r.linkRev >> 1);
+                        ++lvl;
+                        fresh = true;
+                        descended = true;
+                    }
+                }
+                if (!descended && !more) {
+                    if (pending) {
+                        lvl = 31 - __clz((int)pending);
+                        pending &= ~(1u << lvl);
+                        const int at = (lvl - 1) * 256 + (int)threadIdx.x;
+                        j = stJ[at];
+                        anchor = stAnchor[at];
+                        hi = stHi[at];
+                        fl = stFl[at];
+                        lo = INT64_MIN; // a resumed level starts at a segment boundary: plo = curStart
+                    } else {
+                        busy = false;
+                    }
+                }
+            }
+        }
+        stage.emit(emit, qid, oSPos, oIdx, oSo, oLen, oFl);
+    }
+    stage.flush();
+    wave_count_add(&kstat[0], topDerefs);
+    wave_count_add(&kstat[1], botDerefs);
+}
+
 // ---------------------------------------------------------------------------------------------
 // D (+R): bottom piece -> child's top piece through child slot `slot` (mapDown bottom branch,
 // halSegmentMapper.cpp:133-143; TopSegmentIterator::toChild, api/impl/halTopSegmentIterator.cpp:36-45),

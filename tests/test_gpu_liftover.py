@@ -209,7 +209,19 @@ def test_device_resident_plan_and_stats(hal, oracle_bin, tmp_path):
     assert st["queries"] == n and st["records"] == nrec and st["mapped_pieces"] >= nrec
     assert st["top_derefs"] > 0 and st["bottom_derefs"] > 0 and st["total_ms"] >= st["walk_ms"] > 0
     kt = plan.kernel_times()
-    assert "k_up_walk" in kt and "k_finish_fast" in kt
+    assert "k_up_chain" in kt and "k_finish_fast" in kt
+    # the chained up kernel against one launch per level: same records, same logical dereference counts
+    os.environ["HGX_LEVEL_SYNC_UP"] = "1"
+    try:
+        plan2 = hal.LiftoverPlan(al, src, tgt, max_queries=n)
+    finally:
+        del os.environ["HGX_LEVEL_SYNC_UP"]
+    ptr2, nrec2 = plan2.run((starts + sstart).cuda(), (starts + lens - 1 + sstart).cuda(), strand.cuda())
+    recs2 = plan2.records_to_tensor(ptr2, nrec2).cpu().numpy().view(hal.RECORD_DTYPE).reshape(-1)
+    assert nrec2 == nrec and recs2.tobytes() == recs.tobytes()
+    st2 = plan2.stats()
+    assert "k_up_walk" in plan2.kernel_times()
+    assert st2["top_derefs"] == st["top_derefs"] and st2["bottom_derefs"] == st["bottom_derefs"]
 
 
 def test_strand_symmetry_property_at_scale(hal, tmp_path):
