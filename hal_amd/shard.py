@@ -61,3 +61,45 @@ def offset_query_index(recs, first_query):
         q += first_query
         recs[:, :8] = q.view(torch.uint8).view(-1, 8)
     return recs
+
+
+class RecordCollator:
+    """The all-gatherv of one batch overlapped with the mapping of the next: submit() exchanges the counts (a few bytes,
+    synchronous) and starts the payload all-gather asynchronously on the communicator's own stream; wait() returns the
+    previous batch.  At most one exchange is in flight, its buffers are kept alive here until it has completed."""
+
+    def __init__(self):
+        self._pending = None
+
+    def submit(self, recs):
+        world = dist.get_world_size()
+        dev = recs.device
+        counts = all_gather_counts(recs.shape[0], dev)
+        mx = max(counts) if counts else 0
+        mine = recs
+        if recs.shape[0] != mx:
+            mine = torch.zeros((mx, RECORD_BYTES), dtype=torch.uint8, device=dev)
+            mine[:recs.shape[0]] = recs
+        mine = mine.contiguous()
+        if dev.type == "cuda":
+            out = torch.empty((world * mx, RECORD_BYTES), dtype=torch.uint8, device=dev)
+            work = dist.all_gather_into_tensor(out, mine, async_op=True)
+            bufs = None
+        else:
+            bufs = [torch.empty((mx, RECORD_BYTES), dtype=torch.uint8) for _ in range(world)]
+            work = dist.all_gather(bufs, mine, async_op=True)
+            out = None
+        self._pending = (work, out, bufs, mine, counts, mx)
+
+    def wait(self, trim=True):
+        """(records, counts) of the submitted batch, or None when nothing is in flight."""
+        if self._pending is None:
+            return None
+        work, out, bufs, _mine, counts, mx = self._pending
+        self._pending = None
+        work.wait()
+        if bufs is None:
+            if not trim:
+                return out, counts
+            bufs = list(out.view(len(counts), mx, RECORD_BYTES).unbind(0))
+        return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0), counts

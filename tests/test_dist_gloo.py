@@ -10,7 +10,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 
-from hal_amd.shard import all_gather_records, shard_bounds, offset_query_index
+from hal_amd.shard import RecordCollator, all_gather_records, shard_bounds, offset_query_index
 
 
 def fake_lift(q_lo, q_hi, base=0):
@@ -34,6 +34,16 @@ def _worker(rank, world, port, n, result):
     gathered, counts = all_gather_records(offset_query_index(fake_lift(lo, hi, base=lo), lo))
     want = fake_lift(0, n)
     ok = gathered.shape == want.shape and bool(torch.equal(gathered, want)) and sum(counts) == want.shape[0]
+    # the overlapped form: two batches in flight one after the other
+    col = RecordCollator()
+    assert col.wait() is None
+    col.submit(offset_query_index(fake_lift(lo, hi, base=lo), lo))
+    first = col.wait()
+    col.submit(fake_lift(0, 3 + rank))
+    second = col.wait()
+    ok = ok and bool(torch.equal(first[0], want)) and first[1] == counts
+    ok = ok and second[1] == [fake_lift(0, 3 + r).shape[0] for r in range(world)]
+    ok = ok and bool(torch.equal(second[0], torch.cat([fake_lift(0, 3 + r) for r in range(world)], dim=0)))
     result[rank] = ok
     dist.barrier()
     dist.destroy_process_group()
