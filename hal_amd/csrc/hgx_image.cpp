@@ -313,7 +313,7 @@ Image openAlignmentFile(const std::string &path) {
     if (memcmp(head, "HAL-MMAP", 8) == 0)
         return readMmapHal(path);
     if (memcmp(head, "\x89HDF\r\n\x1a\n", 8) == 0)
-        throw std::runtime_error(path + ": HDF5-format HAL is not supported; convert with `halExtract --outputFormat mmap`");
+        return readHdf5Hal(path);
     throw std::runtime_error(path + ": unknown alignment file format");
 }
 

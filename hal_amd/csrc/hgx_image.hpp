@@ -125,7 +125,57 @@ void writeImage(const Image &img, const std::string &path);
 Image readImage(const std::string &path);
 
 // mmap-format HAL reader (api/mmap_impl/*, versions 1.0 and 1.1)
+// Newick subset written by the reference (sonLib stTree_getNewickTreeString): "(a,b)label:len;".
+struct NewickNode {
+    std::string label;
+    double len = 0;
+    std::vector<int> kids;
+};
+struct NewickParser {
+    const std::string &s;
+    size_t i = 0;
+    std::vector<NewickNode> nodes;
+    explicit NewickParser(const std::string &str) : s(str) {
+    }
+    int parse() {
+        int id = (int)nodes.size();
+        nodes.emplace_back();
+        if (i < s.size() && s[i] == '(') {
+            ++i;
+            for (;;) {
+                int k = parse();
+                nodes[(size_t)id].kids.push_back(k);
+                if (i < s.size() && s[i] == ',') {
+                    ++i;
+                    continue;
+                }
+                if (i < s.size() && s[i] == ')') {
+                    ++i;
+                    break;
+                }
+                throw std::runtime_error("malformed Newick tree in the alignment file");
+            }
+        }
+        size_t b = i;
+        while (i < s.size() && s[i] != ':' && s[i] != ',' && s[i] != ')' && s[i] != ';')
+            ++i;
+        nodes[(size_t)id].label = s.substr(b, i - b);
+        if (i < s.size() && s[i] == ':') {
+            ++i;
+            size_t e = i;
+            while (e < s.size() && s[e] != ',' && s[e] != ')' && s[e] != ';')
+                ++e;
+            nodes[(size_t)id].len = atof(s.substr(i, e - i).c_str());
+            i = e;
+        }
+        return id;
+    }
+};
+
+
 Image readMmapHal(const std::string &path);
+// HDF5-format HAL (api/hdf5_impl); needs libhdf5 at run time (hgx_hdf5_reader.cpp)
+Image readHdf5Hal(const std::string &path);
 // auto-detect by magic: "HGXIMG01" or "HAL-MMAP"
 Image openAlignmentFile(const std::string &path);
 
