@@ -67,7 +67,7 @@ def test_open_rejects_bad_files(hal, tmp_path):
         hal.Alignment.open(str(tmp_path / "missing.hal"), device=-1)
     h5 = tmp_path / "x.hal"
     h5.write_bytes(b"\x89HDF\r\n\x1a\n" + b"\0" * 64)
-    with pytest.raises(hal.HgxError, match="HDF5"):
+    with pytest.raises(hal.HgxError, match="Unable to open|HDF5 C library"):  # a truncated HDF5 file (hdf5Alignment.cpp:181)
         hal.Alignment.open(str(h5), device=-1)
 
 
