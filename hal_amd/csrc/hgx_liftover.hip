@@ -326,10 +326,12 @@ struct hgx_liftover_plan {
     std::vector<int> up;                        // src ... mrca
     std::vector<std::pair<int, int>> down;      // (parent genome, child slot) per downward hop
     bool srcTop = true;
+    std::vector<int> climb;                     // mrca ... coalescenceLimit when the limit lies above the MRCA (and dupes are on), else empty
+    int numFrontiers = 2;
     bool levelSyncUp = getenv("HGX_LEVEL_SYNC_UP") != nullptr; // one launch per up level instead of k_up_chain (kept for deep trees and as a cross-check)
     size_t maxQueries = 0;
     uint32_t cap = 0; // piece capacity of every frontier / mapped / record buffer
-    DevBuf fr[2][6], mp[2][6], counters, perQuery, offset, cursor, nOut, outOffset, blockSums, total, grouped, outRecords,
+    DevBuf fr[6][6], mp[2][6], counters, perQuery, offset, cursor, nOut, outOffset, blockSums, total, grouped, outRecords,
         deferredList, needCap, bigSlot, scratch, bigRecords, classLists, classCounts;
     KernelTimer timer;
     hgx_liftover_stats stats{};
@@ -352,12 +354,11 @@ struct hgx_liftover_plan {
     void allocate(uint32_t newCap) {
         cap = newCap;
         static const size_t fsz[6] = {4, 8, 4, 8, 4, 1};
-        for (int k = 0; k < 2; ++k)
-        {
+        for (int k = 0; k < numFrontiers; ++k)
             for (int a = 0; a < 6; ++a)
                 fr[k][a].ensure(fsz[a] * (size_t)cap);
+        for (int k = 0; k < 2; ++k)
             mp[k][0].ensure(sizeof(MappedRec) * (size_t)cap);
-        }
         grouped.ensure(sizeof(hgx_record) * (size_t)cap);
         outRecords.ensure(sizeof(hgx_record) * (size_t)cap);
         const size_t nq = std::max<size_t>(maxQueries, 1);
@@ -408,7 +409,8 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
     auto kstat = [&]() { return cnt + CNT_KSTAT0 + 2 * launch; };
     int cur = 0; // frontier buffer holding the current pieces
     auto inCnt = [&]() { return cnt + CNT_FRONT0 + (size_t)level * NSEG; };
-    auto outCnt = [&]() { return cnt + CNT_FRONT0 + (size_t)(level + 1) * NSEG; };
+    int outLevel = 1; // counter block of the frontier the next launch writes; every launch gets a fresh one
+    auto outCnt = [&]() { return cnt + CNT_FRONT0 + (size_t)outLevel * NSEG; };
     const int64_t minLen = P.opts.min_length;
 
     // stage 0
@@ -445,7 +447,7 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
             P.timer.end(s);
             ++launch;
             cur ^= 1;
-            ++level;
+            level = outLevel++;
         } else {
             {
                 const bool last = nUp == 1;
@@ -455,7 +457,7 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
                 P.timer.end(s);
                 ++launch;
                 cur ^= 1;
-                ++level;
+                level = outLevel++;
             }
             for (size_t k = 1; k < nUp; ++k) {
                 const bool last = k + 1 == nUp;
@@ -465,11 +467,100 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
                 P.timer.end(s);
                 ++launch;
                 cur ^= 1;
-                ++level;
+                level = outLevel++;
             }
         }
         curGenome = P.mrca;
         curTop = false;
+    }
+    if (!P.climb.empty()) {
+        // mapRecursiveParalogies (halSegmentMapper.cpp:525-576), coalescenceLimit above the MRCA: at every genome c_i from
+        // the MRCA up to the child of the limit, the pieces (walked through c_i's top tiling) are expanded to their paralogy
+        // rings (mapSelf) and the ring members are mapped back DOWN to the MRCA without dupes; the pieces themselves (not
+        // their paralogs) go up one more level (mapUp, always with dupes).  The union R of what came back down (top pieces
+        // in the MRCA) replaces the frontier.  Exact duplicates the reference removes with sort+unique at every level
+        // are removed here by the set semantics of the finishing step.
+        // Buffers: F = pieces in c_i, T = F on the top tiling, N = pieces in c_{i+1}, A/B = the way down, R = result.
+        const int rBuf = cur ^ 1;
+        int rot[3] = {cur, 2, 3}; // F, T, N
+        const int aBuf = 4, bBuf = 5;
+        int nextLevel = outLevel;
+        auto cntOf = [&](int lv) { return cnt + CNT_FRONT0 + (size_t)lv * NSEG; };
+        const int rLevel = nextLevel++;
+        int fLevel = level;
+        bool fTop = curTop;
+        for (size_t i = 0; i + 1 < P.climb.size(); ++i) {
+            const int g = P.climb[i];
+            const DeviceGenome &G = D.genomes[(size_t)g];
+            const int fBuf = rot[0], tBuf = rot[1], nBuf = rot[2];
+            int tLevel = fLevel, tb = fBuf;
+            if (!fTop) {
+                tLevel = nextLevel++;
+                tb = tBuf;
+                P.timer.begin("k_parse_up", s, launch);
+                hipLaunchKernelGGL((k_parse_up<C>), dim3(GRID), dim3(256), 0, s, (const BotRec<C> *)G.bot, (const TopRec<C> *)G.top,
+                                   P.frontier(fBuf), cntOf(fLevel), cap, P.frontier(tb), cntOf(tLevel), cnt, kstat());
+                P.timer.end(s);
+                ++launch;
+            }
+            // ring members of c_i; for i == 0 they already live in the MRCA
+            const int pLevel = i == 0 ? rLevel : nextLevel++;
+            const int pb = i == 0 ? rBuf : aBuf;
+            P.timer.begin("k_ring", s, launch);
+            hipLaunchKernelGGL((k_ring<C>), dim3(GRID), dim3(256), 0, s, (const TopRec<C> *)G.top, P.frontier(tb), cntOf(tLevel), cap,
+                               P.frontier(pb), cntOf(pLevel), minLen, cnt, kstat());
+            P.timer.end(s);
+            ++launch;
+            // the pieces themselves one level up (before the buffers of the way down are reused)
+            int nLevel = -1;
+            if (i + 2 < P.climb.size()) {
+                nLevel = nextLevel++;
+                P.timer.begin("k_up_first", s, launch);
+                hipLaunchKernelGGL((k_up_first<C>), dim3(GRID), dim3(256), 0, s, (const UpRec<C> *)G.up, P.frontier(tb), cntOf(tLevel), cap,
+                                   P.frontier(nBuf), cntOf(nLevel), minLen, 1, cnt, kstat());
+                P.timer.end(s);
+                ++launch;
+            }
+            // ring members back down to the MRCA: c_i -> c_{i-1} -> ... -> c_0, no dupes (mapRecursiveDown(..., false, ...))
+            int dBuf = pb, dLevel = pLevel;
+            for (size_t j = i; j > 0; --j) {
+                const int pg = P.climb[j], cg = P.climb[j - 1];
+                const DeviceGenome &PG = D.genomes[(size_t)pg];
+                const DeviceGenome &CG = D.genomes[(size_t)cg];
+                const int slot = P.h->img.genomes[(size_t)pg].childSlotOf(cg);
+                const int xBuf = dBuf == aBuf ? bBuf : aBuf;
+                const int xLevel = nextLevel++;
+                P.timer.begin("k_parse_down", s, launch);
+                hipLaunchKernelGGL((k_parse_down<C>), dim3(GRID), dim3(256), 0, s, (const TopRec<C> *)PG.top, (const BotRec<C> *)PG.bot,
+                                   P.frontier(dBuf), cntOf(dLevel), cap, P.frontier(xBuf), cntOf(xLevel), cnt, kstat());
+                P.timer.end(s);
+                ++launch;
+                const bool intoR = j == 1;
+                const int yBuf = intoR ? rBuf : (xBuf == aBuf ? bBuf : aBuf);
+                const int yLevel = intoR ? rLevel : nextLevel++;
+                P.timer.begin("k_down_ring", s, launch);
+                hipLaunchKernelGGL((k_down_ring<C>), dim3(GRID), dim3(256), 0, s, (const int32_t *)PG.childEnc[(size_t)slot],
+                                   (const TopRec<C> *)CG.top, P.frontier(xBuf), cntOf(xLevel), cap, P.frontier(yBuf), cntOf(yLevel), minLen,
+                                   0, cnt, kstat());
+                P.timer.end(s);
+                ++launch;
+                dBuf = yBuf;
+                dLevel = yLevel;
+            }
+            if (nLevel < 0)
+                break;
+            // next level: N becomes F; the old F and T buffers are free again
+            rot[0] = nBuf;
+            rot[1] = fBuf;
+            rot[2] = tBuf;
+            fLevel = nLevel;
+            fTop = false;
+        }
+        cur = rBuf;
+        level = rLevel;
+        outLevel = nextLevel;
+        curTop = true;
+        curGenome = P.mrca;
     }
     if (P.tgt != P.mrca) {
         if (curTop) { // source is the MRCA itself and is walked through its top tiling
@@ -480,7 +571,7 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
             P.timer.end(s);
             ++launch;
             cur ^= 1;
-            ++level;
+            level = outLevel++;
             curTop = false;
         }
         for (size_t k = 0; k < P.down.size(); ++k) {
@@ -495,7 +586,7 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
             P.timer.end(s);
             ++launch;
             cur ^= 1;
-            ++level;
+            level = outLevel++;
             curTop = true;
             curGenome = child;
             if (child != P.tgt) {
@@ -506,7 +597,7 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
                 P.timer.end(s);
                 ++launch;
                 cur ^= 1;
-                ++level;
+                level = outLevel++;
                 curTop = false;
             }
         }
@@ -675,8 +766,20 @@ hgx_liftover_plan *createLiftoverPlan(hgx_alignment *h, int src, int tgt, const 
     P->tgt = tgt;
     P->opts = opts;
     P->mrca = img.lca(src, tgt);
-    if (opts.coalescence_limit >= 0 && opts.coalescence_limit != P->mrca)
-        throw std::runtime_error("coalescenceLimit other than the MRCA is not supported yet (SURVEY 8(f) item 3)");
+    if (opts.coalescence_limit >= (int)img.genomes.size())
+        throw std::runtime_error("coalescenceLimit: no such genome");
+    if (opts.coalescence_limit >= 0 && opts.coalescence_limit != P->mrca && opts.traverse_dupes) {
+        // mapSource (halSegmentMapper.cpp:616-621): the paralogy phase runs only with dupes on.  The limit has to be an
+        // ancestor of the MRCA; the reference finds out while climbing (":541 Hit root genome ..."), here it is checked up front.
+        for (int g = P->mrca;; g = img.genomes[(size_t)g].parent) {
+            if (g < 0)
+                throw std::runtime_error("Hit root genome when attempting to map paralogies");
+            P->climb.push_back(g);
+            if (g == opts.coalescence_limit)
+                break;
+        }
+        P->numFrontiers = 6;
+    }
     for (int g = src;; g = img.genomes[(size_t)g].parent) {
         P->up.push_back(g);
         if (g == P->mrca)
@@ -699,7 +802,10 @@ hgx_liftover_plan *createLiftoverPlan(hgx_alignment *h, int src, int tgt, const 
         P->down.emplace_back(parent, slot);
         parent = chain[k];
     }
-    if ((int)(P->up.size() + 2 * P->down.size()) + 3 >= MAX_LEVELS - 1 || (int)(P->up.size() + 2 * P->down.size()) + 3 >= MAX_LAUNCHES)
+    const size_t climbHops = P->climb.empty() ? 0 : P->climb.size() - 1;
+    const size_t climbLaunches = 3 * climbHops + climbHops * climbHops; // parse-up, ring, up + two per level of the way back down
+    if ((int)(P->up.size() + 2 * P->down.size() + climbLaunches) + 4 >= MAX_LEVELS - 1 ||
+        (int)(P->up.size() + 2 * P->down.size() + climbLaunches) + 4 >= MAX_LAUNCHES)
         throw std::runtime_error("tree path between the genomes is too long for the counter block");
     // BlockLiftover::visitBegin (halBlockLiftover.cpp:24-30): walk the source through its top tiling when it has one
     P->srcTop = img.genomes[(size_t)src].numTop > 0;

@@ -685,25 +685,32 @@ __global__ void __launch_bounds__(256) k_down_ring(const int32_t *__restrict__ c
 }
 
 // ---------------------------------------------------------------------------------------------
-// PD: top piece in genome G -> pieces of G's bottom tiling.  mapDown, top branch
-// (halSegmentMapper.cpp:144-184) with BottomSegmentIterator::toParseDown
-// (api/impl/halBottomSegmentIterator.cpp:51-76); mirror image of the PU step.
-template <typename C>
-__global__ void __launch_bounds__(256) k_parse_down(const TopRec<C> *__restrict__ top, const BotRec<C> *__restrict__ bot, Frontier in,
-                                                    const unsigned long long *inCount, uint32_t cap, Frontier out,
-                                                    unsigned long long *outCount, unsigned long long *counters,
-                                                    unsigned long long *kstat) {
-    __shared__ FrontView fview;
-    const uint32_t n = front_view_init(&fview, inCount, cap);
+// PD / PU: a piece on one tiling of genome G -> pieces on G's other tiling.
+// PD, top -> bottom: mapDown, top branch (halSegmentMapper.cpp:144-184) with BottomSegmentIterator::toParseDown
+// (api/impl/halBottomSegmentIterator.cpp:51-76).  PU, bottom -> top: mapUp / mapSelf, bottom branch
+// (halSegmentMapper.cpp:40-78, :289-328) with TopSegmentIterator::toParseUp (api/impl/halTopSegmentIterator.cpp:55-81).
+// Both: start at the parse index, scan right to the segment holding the piece's first base, then one output piece per
+// overlapped segment (the toRight(rightCutoff) loop); the source side is sliced by the same deltas.
+template <typename C> __device__ __forceinline__ int32_t parse_link(const TopRec<C> &r) {
+    return r.botParse;
+}
+template <typename C> __device__ __forceinline__ int32_t parse_link(const BotRec<C> &r) {
+    return r.topParse;
+}
+// FROM_TOP: statistics slot of the `from` table (0 = top records, 1 = bottom records)
+template <typename FROM, typename TO, int FROM_SLOT>
+__device__ __forceinline__ void parse_body(const FROM *__restrict__ from, const TO *__restrict__ to, Frontier in,
+                                           const unsigned long long *inCount, uint32_t cap, Frontier out, unsigned long long *outCount,
+                                           unsigned long long *counters, unsigned long long *kstat, StageMem *stageMem, FrontView *fview) {
+    const uint32_t n = front_view_init(fview, inCount, cap);
     const uint32_t wavesTotal = (gridDim.x * blockDim.x) >> 6;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    uint32_t topDerefs = 0, botDerefs = 0;
-    __shared__ StageMem stageMem;
+    uint32_t fromDerefs = 0, toDerefs = 0;
     Stage stage;
-    stage.init(&stageMem, out, outCount, counters, cap);
+    stage.init(stageMem, out, outCount, counters, cap);
     for (uint32_t base = wave * 64; base < n; base += wavesTotal * 64) {
         const uint32_t li = base + lane_id();
-        const uint32_t i = li < n ? front_slot(&fview, li, cap) : 0;
+        const uint32_t i = li < n ? front_slot(fview, li, cap) : 0;
         bool act = li < n;
         int32_t qid = 0;
         int64_t sPos = 0, lo = 0, hi = -1;
@@ -715,23 +722,23 @@ __global__ void __launch_bounds__(256) k_parse_down(const TopRec<C> *__restrict_
             qid = in.qid[i];
             sPos = in.sPos[i];
             fl = in.flags[i];
-            const TopRec<C> tr = top[t];
-            ++topDerefs;
+            const FROM tr = from[t];
+            ++fromDerefs;
             if (!(fl & F_TREV))
                 lo = (int64_t)tr.start + so;
             else
-                lo = (int64_t)top[t + 1].start - so - len;
+                lo = (int64_t)from[t + 1].start - so - len;
             hi = lo + len - 1;
-            j = tr.botParse;
-            ++botDerefs;
+            j = parse_link(tr);
+            ++toDerefs;
             for (;;) {
-                const int64_t nextStart = (int64_t)bot[j + 1].start;
+                const int64_t nextStart = (int64_t)to[j + 1].start;
                 if (nextStart > lo)
                     break;
                 ++j;
-                ++botDerefs;
+                ++toDerefs;
             }
-            curStart = (int64_t)bot[j].start;
+            curStart = (int64_t)to[j].start;
         }
         while (__any(act)) {
             bool emit = false;
@@ -739,7 +746,7 @@ __global__ void __launch_bounds__(256) k_parse_down(const TopRec<C> *__restrict_
             int64_t oSPos = 0;
             int64_t nextStart = 0;
             if (act) {
-                nextStart = (int64_t)bot[j + 1].start;
+                nextStart = (int64_t)to[j + 1].start;
                 const int64_t plo = lo > curStart ? lo : curStart;
                 const int64_t phi = hi < nextStart - 1 ? hi : nextStart - 1;
                 oLen = (int32_t)(phi - plo + 1);
@@ -760,13 +767,92 @@ __global__ void __launch_bounds__(256) k_parse_down(const TopRec<C> *__restrict_
                 curStart = nextStart;
                 act = curStart <= hi;
                 if (act)
-                    ++botDerefs;
+                    ++toDerefs;
+            }
+        }
+    }
+    stage.flush();
+    wave_count_add(&kstat[FROM_SLOT], fromDerefs);
+    wave_count_add(&kstat[1 - FROM_SLOT], toDerefs);
+}
+
+template <typename C>
+__global__ void __launch_bounds__(256) k_parse_down(const TopRec<C> *__restrict__ top, const BotRec<C> *__restrict__ bot, Frontier in,
+                                                    const unsigned long long *inCount, uint32_t cap, Frontier out,
+                                                    unsigned long long *outCount, unsigned long long *counters,
+                                                    unsigned long long *kstat) {
+    __shared__ FrontView fview;
+    __shared__ StageMem stageMem;
+    parse_body<TopRec<C>, BotRec<C>, 0>(top, bot, in, inCount, cap, out, outCount, counters, kstat, &stageMem, &fview);
+}
+
+template <typename C>
+__global__ void __launch_bounds__(256) k_parse_up(const BotRec<C> *__restrict__ bot, const TopRec<C> *__restrict__ top, Frontier in,
+                                                  const unsigned long long *inCount, uint32_t cap, Frontier out,
+                                                  unsigned long long *outCount, unsigned long long *counters,
+                                                  unsigned long long *kstat) {
+    __shared__ FrontView fview;
+    __shared__ StageMem stageMem;
+    parse_body<BotRec<C>, TopRec<C>, 1>(bot, top, in, inCount, cap, out, outCount, counters, kstat, &stageMem, &fview);
+}
+
+// ---------------------------------------------------------------------------------------------
+// R: top piece -> itself and the other members of its paralogy ring (mapSelf, top branch, halSegmentMapper.cpp:265-288;
+// toNextParalogy, halTopSegmentIterator.cpp:99-107).  The do/while emits before it tests, follows the ring while the
+// segment it moved to has a next paralogy, the piece is at least minLength long and the walk is not back at its start.
+// (k_down_ring carries the same loop after its child hop; this kernel is the stand-alone form mapRecursiveParalogies needs.)
+template <typename C>
+__global__ void __launch_bounds__(256) k_ring(const TopRec<C> *__restrict__ top, Frontier in, const unsigned long long *inCount, uint32_t cap,
+                                              Frontier out, unsigned long long *outCount, int64_t minLength, unsigned long long *counters,
+                                              unsigned long long *kstat) {
+    __shared__ FrontView fview;
+    const uint32_t n = front_view_init(&fview, inCount, cap);
+    const uint32_t wavesTotal = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    uint32_t topDerefs = 0;
+    __shared__ StageMem stageMem;
+    Stage stage;
+    stage.init(&stageMem, out, outCount, counters, cap);
+    for (uint32_t base = wave * 64; base < n; base += wavesTotal * 64) {
+        const uint32_t li = base + lane_id();
+        const uint32_t i = li < n ? front_slot(&fview, li, cap) : 0;
+        bool act = li < n;
+        int32_t qid = 0, len = 0, t0 = 0, cur = 0;
+        int64_t sPos = 0, so = 0;
+        uint8_t fl = 0;
+        int32_t rcPar = -1, rcEnc = 0;
+        if (act) {
+            qid = in.qid[i];
+            sPos = in.sPos[i];
+            so = in.so[i];
+            len = in.len[i];
+            fl = in.flags[i];
+            t0 = cur = in.idx[i];
+            const TopRec<C> rc = top[cur];
+            ++topDerefs;
+            rcPar = rc.paralogy;
+            rcEnc = rc.parentEnc;
+        }
+        while (__any(act)) {
+            stage.emit(act, qid, sPos, cur, so, len, fl);
+            if (act) {
+                if (rcPar < 0) {
+                    act = false;
+                } else {
+                    const TopRec<C> nr = top[rcPar];
+                    ++topDerefs;
+                    if ((nr.parentEnc & 1) != (rcEnc & 1))
+                        fl ^= F_TREV;
+                    cur = rcPar;
+                    rcPar = nr.paralogy;
+                    rcEnc = nr.parentEnc;
+                    act = rcPar >= 0 && (int64_t)len >= minLength && cur != t0;
+                }
             }
         }
     }
     stage.flush();
     wave_count_add(&kstat[0], topDerefs);
-    wave_count_add(&kstat[1], botDerefs);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -94,7 +94,8 @@ typedef struct hgx_record { /* one lifted output interval = one output BED line 
 
 typedef struct hgx_liftover_opts {
     int32_t traverse_dupes;    /* Liftover::convert traverseDupes (halLiftover.h:25-28); --noDupes => 0 */
-    int32_t coalescence_limit; /* genome id or -1 (= MRCA, the default; anything else: not yet supported) */
+    int32_t coalescence_limit; /* --coalescenceLimit: genome id of an ancestor of the MRCA, or -1 (= the MRCA, the default);
+                                  paralogs coalescing up to that genome are followed (halSegmentMapper.cpp:525-576) */
     int64_t min_length;        /* halMapSegment minLength; halLiftover passes 0 */
 } hgx_liftover_opts;
 

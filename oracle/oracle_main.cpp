@@ -1,6 +1,6 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY (see hal_oracle.hpp).  Command-line front end used by tests/ and by
 // bench.py's cpu_baseline leg.
-//   hal_oracle liftover <img.hgx> <srcGenome> <in.bed> <tgtGenome> <out.bed> [--noDupes] [--bedType N] [--stats]
+//   hal_oracle liftover <img.hgx> <srcGenome> <in.bed> <tgtGenome> <out.bed> [--noDupes] [--bedType N] [--coalescenceLimit G] [--stats]
 #include "oracle_columns.hpp"
 #include "oracle_liftover.hpp"
 #include <chrono>
@@ -15,10 +15,13 @@ static int cmdLiftover(int argc, char **argv) {
     std::vector<std::string> pos;
     bool noDupes = false, stats = false, outPSL = false, outPSLWithName = false;
     int bedType = 0;
+    std::string coalName;
     for (int i = 0; i < argc; ++i) {
         std::string a = argv[i];
         if (a == "--noDupes")
             noDupes = true;
+        else if (a == "--coalescenceLimit")
+            coalName = argv[++i];
         else if (a == "--stats")
             stats = true;
         else if (a == "--outPSL")
@@ -45,7 +48,15 @@ static int cmdLiftover(int argc, char **argv) {
     inBuf << in.rdbuf();
     std::ostringstream outBuf;
     Liftover lo;
-    lo.convert(&al, src, &inBuf, tgt, &outBuf, bedType, !noDupes, -1, outPSL, outPSLWithName);
+    int coal = -1;
+    if (!coalName.empty()) {
+        coal = al.genomeByName(coalName);
+        if (coal < 0) {
+            std::cerr << "coalescence limit genome not found" << std::endl;
+            return 1;
+        }
+    }
+    lo.convert(&al, src, &inBuf, tgt, &outBuf, bedType, !noDupes, coal, outPSL, outPSLWithName);
     std::ofstream out(pos[4]);
     out << outBuf.str();
     if (stats)

@@ -21,7 +21,7 @@ def random_bed(seq_name, seq_len, n, min_len, max_len, seed, strands="+-", bed6=
 
 
 def oracle_liftover(oracle_bin, image_path, src, tgt, bed_text, tmpdir, no_dupes=False, bed_type=0, stats=False, psl=False,
-                    psl_with_name=False):
+                    psl_with_name=False, coalescence_limit=None):
     inp = os.path.join(str(tmpdir), "oracle_in.bed")
     out = os.path.join(str(tmpdir), "oracle_out.bed")
     with open(inp, "w") as f:
@@ -31,6 +31,8 @@ def oracle_liftover(oracle_bin, image_path, src, tgt, bed_text, tmpdir, no_dupes
         cmd.append("--noDupes")
     if bed_type:
         cmd += ["--bedType", str(bed_type)]
+    if coalescence_limit:
+        cmd += ["--coalescenceLimit", coalescence_limit]
     if stats:
         cmd.append("--stats")
     if psl_with_name:
