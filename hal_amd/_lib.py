@@ -19,7 +19,8 @@ class hgx_record(C.Structure):
 
 
 class hgx_liftover_opts(C.Structure):
-    _fields_ = [("traverse_dupes", C.c_int32), ("coalescence_limit", C.c_int32), ("min_length", C.c_int64)]
+    _fields_ = [("traverse_dupes", C.c_int32), ("coalescence_limit", C.c_int32), ("min_length", C.c_int64),
+                ("emit_blocks", C.c_int32), ("block_mapper_source", C.c_int32)]
 
 
 class hgx_liftover_stats(C.Structure):
@@ -79,6 +80,8 @@ SYMBOLS = {
     "hgx_mrca": (C.c_int, [VP, C.c_int, C.c_int]),
     "hgx_liftover_batch": (C.c_int, [VP, C.c_int, C.c_int, C.c_size_t, P(hgx_interval), P(hgx_liftover_opts),
                                      P(P(hgx_record)), P(C.c_size_t), P(VP)]),
+    "hgx_block_map": (C.c_int, [VP, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int, P(P(hgx_record)),
+                                P(C.c_size_t), P(VP)]),
     "hgx_liftover_plan_create": (C.c_int, [VP, C.c_int, C.c_int, P(hgx_liftover_opts), C.c_size_t, P(VP), P(VP)]),
     "hgx_liftover_plan_destroy": (None, [VP]),
     "hgx_liftover_run_device": (C.c_int, [VP, C.c_size_t, VP, VP, VP, VP, P(VP), P(C.c_size_t), P(VP)]),

@@ -155,6 +155,19 @@ class Alignment:
         return lib.hgx_mrca(self._h, a, b)
 
     # --- liftover, host-buffer form ---
+    def block_map(self, ref, query, abs_first, abs_last, target_reversed=False, do_dupes=True, min_length=0, coalescence_limit=-1):
+        """BlockMapper init + map + getMap without adjacencies (liftover/inc/halBlockMapper.h:30-40): the members of the mapped
+        set for the reference range [abs_first, abs_last] (genome coordinates, inclusive), in set order, as a numpy record
+        array (RECORD_DTYPE; see hgx_liftover_opts.emit_blocks in include/hgx.h for the field meaning)."""
+        out, n, err = C.POINTER(hgx_record)(), C.c_size_t(), C.c_void_p()
+        if lib.hgx_block_map(self._h, ref, query, abs_first, abs_last, 1 if target_reversed else 0, 1 if do_dupes else 0, min_length,
+                             coalescence_limit, C.byref(out), C.byref(n), C.byref(err)) != 0:
+            raise HgxError(take_error(err))
+        try:
+            return np.frombuffer(C.string_at(out, n.value * C.sizeof(hgx_record)), dtype=RECORD_DTYPE).copy()
+        finally:
+            lib.hgx_free(out)
+
     def liftover_batch(self, src, tgt, intervals, traverse_dupes=True, min_length=0, coalescence_limit=-1):
         """intervals: numpy array of INTERVAL_DTYPE or list of Interval.  Returns a numpy array of RECORD_DTYPE."""
         if not isinstance(intervals, np.ndarray):

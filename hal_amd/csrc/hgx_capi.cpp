@@ -237,6 +237,8 @@ static hgx_liftover_opts defaultOpts(const hgx_liftover_opts *o) {
     d.traverse_dupes = 1;
     d.coalescence_limit = -1;
     d.min_length = 0;
+    d.emit_blocks = 0;
+    d.block_mapper_source = 0;
     return o ? *o : d;
 }
 
@@ -249,6 +251,29 @@ int hgx_liftover_batch(hgx_alignment *h, int src, int tgt, size_t n, const hgx_i
         throw std::runtime_error("hgx_liftover_batch: genome id out of range");
     std::vector<hgx_record> recs;
     liftoverBatchHost(h, src, tgt, n, iv, defaultOpts(opts), recs, nullptr);
+    *out = (hgx_record *)malloc(std::max<size_t>(1, recs.size()) * sizeof(hgx_record));
+    if (!*out)
+        throw std::runtime_error("out of memory");
+    if (!recs.empty())
+        memcpy(*out, recs.data(), recs.size() * sizeof(hgx_record));
+    *n_out = recs.size();
+    return HGX_OK;
+    HGX_CATCH
+}
+
+int hgx_block_map(hgx_alignment *h, int ref, int query, int64_t abs_ref_first, int64_t abs_ref_last, int target_reversed, int do_dupes,
+                  int64_t min_length, int coalescence_limit, hgx_record **out, size_t *n_out, char **err) {
+    HGX_TRY
+    if (!h || !out || !n_out)
+        throw std::runtime_error("hgx_block_map: null argument");
+    if (!genomeOf(h, ref) || !genomeOf(h, query))
+        throw std::runtime_error("hgx_block_map: genome id out of range");
+    hgx_liftover_opts o = defaultOpts(nullptr);
+    o.traverse_dupes = do_dupes ? 1 : 0;
+    o.min_length = min_length;
+    o.coalescence_limit = coalescence_limit;
+    std::vector<hgx_record> recs;
+    blockMapHost(h, ref, query, abs_ref_first, abs_ref_last, target_reversed != 0, o, recs);
     *out = (hgx_record *)malloc(std::max<size_t>(1, recs.size()) * sizeof(hgx_record));
     if (!*out)
         throw std::runtime_error("out of memory");

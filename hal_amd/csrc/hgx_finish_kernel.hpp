@@ -35,6 +35,7 @@ template <typename C> struct FinishStore {
     int32_t *lSeq;
     uint8_t *lStrand;
     int cap, cap2, cutCap;
+    int blocks = 0; // 1: return the refined set itself (BlockMapper::getMap), no extractSegment merging
 };
 
 __device__ __forceinline__ void wsync() {
@@ -292,6 +293,21 @@ __device__ __forceinline__ int finish_query(FinishStore<C> &S, const Mapped &in,
         S.alive[i] = 1;
     }
     wsync();
+
+    if (S.blocks) {
+        // BlockMapper::getMap (liftover/inc/halBlockMapper.h:36): the set after insertAndBreakOverlaps, in set order
+        // (target, then source).  One line per member: forward target range, forward source start, both orientations.
+        for (int i = lane; i < n; i += 64) {
+            S.lStart[i] = S.tLo[i];
+            S.lEnd[i] = S.tHi[i] + 1;
+            S.lSrc[i] = S.sLo[i];
+            S.lSeq[i] = S.seq[i];
+            S.lStrand[i] = (uint8_t)(((S.fl[i] & F_SREV) ? '-' : '+') | ((S.fl[i] & F_TREV) ? 0x80 : 0));
+            S.ord[i] = (uint32_t)i;
+        }
+        wsync();
+        return n;
+    }
 
     // ---- extractSegment over the set in target order (serial: lane 0) ----
     int nl = 0;
@@ -582,7 +598,7 @@ __global__ void __launch_bounds__(64) k_finish_lds(Mapped in, const uint32_t *__
                                                    const uint32_t *__restrict__ qlist, const unsigned long long *__restrict__ qcount,
                                                    const int64_t *__restrict__ seqStart, int numSeq, hgx_record *__restrict__ records,
                                                    uint32_t *__restrict__ nOut, uint32_t *__restrict__ deferredList, uint32_t *__restrict__ needCap,
-                                                   unsigned long long *counters) {
+                                                   unsigned long long *counters, int blocks) {
     constexpr int CAP2 = 2 * CAP;
     __shared__ C s_tLo[CAP], s_tHi[CAP], s_sLo[CAP], s_sHi[CAP], s_tLo2[CAP], s_tHi2[CAP], s_sLo2[CAP], s_sHi2[CAP];
     __shared__ C s_bnd[CAP2], s_bnd2[CAP2], s_lStart[CAP], s_lEnd[CAP], s_lSrc[CAP], s_cut[32];
@@ -599,6 +615,7 @@ __global__ void __launch_bounds__(64) k_finish_lds(Mapped in, const uint32_t *__
         S.seq = s_seq, S.ord = s_ord, S.bnd = s_bnd, S.bnd2 = s_bnd2, S.alive = s_alive, S.cut = s_cut;
         S.lStart = s_lStart, S.lEnd = s_lEnd, S.lSrc = s_lSrc, S.lSeq = s_lSeq, S.lStrand = s_lStrand;
         S.cap = CAP, S.cap2 = CAP2, S.cutCap = 32;
+        S.blocks = blocks;
         const uint32_t base = offset[q];
         int nl = finish_query(S, in, base, n, seqStart, numSeq);
         if (nl >= 0 && nl > n)
@@ -626,7 +643,7 @@ __global__ void __launch_bounds__(64) k_finish_big(Mapped in, const uint32_t *__
                                                    const uint32_t *__restrict__ deferredList, uint32_t nDeferred, int cap,
                                                    unsigned char *__restrict__ scratch, size_t sliceBytes,
                                                    const int64_t *__restrict__ seqStart, int numSeq, hgx_record *__restrict__ bigRecords,
-                                                   uint32_t *__restrict__ nOut, unsigned long long *counters) {
+                                                   uint32_t *__restrict__ nOut, unsigned long long *counters, int blocks) {
     for (uint32_t k = blockIdx.x; k < nDeferred; k += gridDim.x) {
         const uint32_t q = deferredList[k];
         const int n = (int)count[q];
@@ -649,6 +666,7 @@ __global__ void __launch_bounds__(64) k_finish_big(Mapped in, const uint32_t *__
         S.seq = (int32_t *)carve(4 * (size_t)cap), S.lSeq = (int32_t *)carve(4 * (size_t)cap);
         S.fl = carve(cap), S.fl2 = carve(cap), S.alive = carve(cap), S.lStrand = carve(cap);
         S.cap = cap, S.cap2 = cap2, S.cutCap = cap;
+        S.blocks = blocks;
         __threadfence_block();
         const int nl = finish_query(S, in, offset[q], n, seqStart, numSeq);
         if (nl < 0) {
@@ -663,6 +681,17 @@ __global__ void __launch_bounds__(64) k_finish_big(Mapped in, const uint32_t *__
                 nOut[q] = (uint32_t)nl;
         }
         wsync();
+    }
+}
+
+// blocks mode: every interval with pieces goes to the general kernel
+static __global__ void __launch_bounds__(256) k_all_general(const uint32_t *__restrict__ count, uint32_t nq, uint32_t *__restrict__ nOut,
+                                                            uint32_t *__restrict__ generalList, unsigned long long *__restrict__ generalCount) {
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
+        if (count[q] == 0)
+            nOut[q] = 0;
+        else
+            generalList[atomicAdd(generalCount, 1ull)] = q;
     }
 }
 

@@ -624,6 +624,11 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
     uint32_t *generalList = (uint32_t *)P.classLists.p;
     unsigned long long *generalCount = (unsigned long long *)P.classCounts.p;
     HIP_OK(hipMemsetAsync(generalCount, 0, 8, s));
+    const int blocks = P.opts.emit_blocks ? 1 : 0;
+    if (blocks) {
+        hipLaunchKernelGGL(k_all_general, dim3(GRID), dim3(256), 0, s, (const uint32_t *)P.perQuery.p, nq, (uint32_t *)P.nOut.p, generalList,
+                           generalCount);
+    } else {
     P.timer.begin("k_finish_fast", s);
 #define HGX_FAST(G)                                                                                                    \
     hipLaunchKernelGGL((k_finish_fast<C, G>), dim3(GRID), dim3(256), 0, s, P.mapped(1), (const uint32_t *)P.offset.p,  \
@@ -635,11 +640,12 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
     HGX_FAST(64);
 #undef HGX_FAST
     P.timer.end(s);
+    }
     P.timer.begin("k_finish_lds", s);
     hipLaunchKernelGGL((k_finish_lds<C, 256>), dim3(std::min<uint32_t>(std::max<uint32_t>(nq, 1), 1u << 14)), dim3(64), 0, s, P.mapped(1),
                        (const uint32_t *)P.offset.p, (const uint32_t *)P.perQuery.p, (const uint32_t *)generalList,
                        (const unsigned long long *)generalCount, (const int64_t *)TG.seqStart, (int)TG.numSeq,
-                       (hgx_record *)P.grouped.p, (uint32_t *)P.nOut.p, (uint32_t *)P.deferredList.p, (uint32_t *)P.needCap.p, cnt);
+                       (hgx_record *)P.grouped.p, (uint32_t *)P.nOut.p, (uint32_t *)P.deferredList.p, (uint32_t *)P.needCap.p, cnt, blocks);
     P.timer.end(s);
     HIP_OK(hipMemcpyAsync(hostCounters, cnt, 8 * CNT_SLOTS, hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
@@ -707,7 +713,7 @@ static void runPlan(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
             hipLaunchKernelGGL((k_finish_big<C>), dim3(nDef), dim3(64), 0, s, P.mapped(1), (const uint32_t *)P.offset.p,
                                (const uint32_t *)P.perQuery.p, (const uint32_t *)P.deferredList.p, nDef, bigCap,
                                (unsigned char *)P.scratch.p, slice, (const int64_t *)TG.seqStart, (int)TG.numSeq,
-                               (hgx_record *)P.bigRecords.p, (uint32_t *)P.nOut.p, cnt);
+                               (hgx_record *)P.bigRecords.p, (uint32_t *)P.nOut.p, cnt, P.opts.emit_blocks ? 1 : 0);
             P.timer.end(s);
             unsigned long long r[2];
             HIP_OK(hipMemcpyAsync(r, cnt + CNT_MAXNEED, 16, hipMemcpyDeviceToHost, s));
@@ -809,6 +815,10 @@ hgx_liftover_plan *createLiftoverPlan(hgx_alignment *h, int src, int tgt, const 
         throw std::runtime_error("tree path between the genomes is too long for the counter block");
     // BlockLiftover::visitBegin (halBlockLiftover.cpp:24-30): walk the source through its top tiling when it has one
     P->srcTop = img.genomes[(size_t)src].numTop > 0;
+    // BlockMapper::map (halBlockMapper.cpp:79-86) chooses differently: bottom segments iff the reference genome is the MRCA
+    // and not the query genome itself, top segments otherwise
+    if (opts.block_mapper_source)
+        P->srcTop = !(P->mrca == src && src != tgt);
     P->maxQueries = std::max<size_t>(maxQueries, 1);
     HIP_OK(hipSetDevice(h->dev->device));
     HIP_OK(hipEventCreate(&P->evStart));
@@ -864,6 +874,24 @@ std::string liftoverPlanKernelTimes(const hgx_liftover_plan *p) {
 }
 
 // host-buffer batch: H2D, run, D2H
+static void runHostArrays(hgx_liftover_plan *P, const std::vector<int64_t> &gs, const std::vector<int64_t> &ge, const std::vector<uint8_t> &st,
+                          std::vector<hgx_record> &out) {
+    const size_t n = gs.size();
+    DevBuf dS, dE, dT;
+    dS.ensure(8 * std::max<size_t>(n, 1));
+    dE.ensure(8 * std::max<size_t>(n, 1));
+    dT.ensure(std::max<size_t>(n, 1));
+    HIP_OK(hipMemcpy(dS.p, gs.data(), 8 * n, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dE.p, ge.data(), 8 * n, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dT.p, st.data(), n, hipMemcpyHostToDevice));
+    const hgx_record *dOut = nullptr;
+    size_t nOut = 0;
+    runLiftoverPlan(P, n, (const int64_t *)dS.p, (const int64_t *)dE.p, (const uint8_t *)dT.p, nullptr, &dOut, &nOut);
+    out.resize(nOut);
+    if (nOut)
+        HIP_OK(hipMemcpy(out.data(), dOut, sizeof(hgx_record) * nOut, hipMemcpyDeviceToHost));
+}
+
 void liftoverBatchHost(hgx_alignment *h, int src, int tgt, size_t n, const hgx_interval *iv, const hgx_liftover_opts &opts,
                        std::vector<hgx_record> &out, hgx_liftover_stats *stats) {
     std::unique_ptr<hgx_liftover_plan, void (*)(hgx_liftover_plan *)> P(createLiftoverPlan(h, src, tgt, opts, n), destroyLiftoverPlan);
@@ -884,21 +912,23 @@ void liftoverBatchHost(hgx_alignment *h, int src, int tgt, size_t n, const hgx_i
         }
         st[i] = (uint8_t)q.strand;
     }
-    DevBuf dS, dE, dT;
-    dS.ensure(8 * std::max<size_t>(n, 1));
-    dE.ensure(8 * std::max<size_t>(n, 1));
-    dT.ensure(std::max<size_t>(n, 1));
-    HIP_OK(hipMemcpy(dS.p, gs.data(), 8 * n, hipMemcpyHostToDevice));
-    HIP_OK(hipMemcpy(dE.p, ge.data(), 8 * n, hipMemcpyHostToDevice));
-    HIP_OK(hipMemcpy(dT.p, st.data(), n, hipMemcpyHostToDevice));
-    const hgx_record *dOut = nullptr;
-    size_t nOut = 0;
-    runLiftoverPlan(P.get(), n, (const int64_t *)dS.p, (const int64_t *)dE.p, (const uint8_t *)dT.p, nullptr, &dOut, &nOut);
-    out.resize(nOut);
-    if (nOut)
-        HIP_OK(hipMemcpy(out.data(), dOut, sizeof(hgx_record) * nOut, hipMemcpyDeviceToHost));
+    runHostArrays(P.get(), gs, ge, st, out);
     if (stats)
         *stats = P->stats;
+}
+
+void blockMapHost(hgx_alignment *h, int ref, int query, int64_t absFirst, int64_t absLast, bool targetReversed,
+                  const hgx_liftover_opts &optsIn, std::vector<hgx_record> &out) {
+    hgx_liftover_opts opts = optsIn;
+    opts.emit_blocks = 1;
+    opts.block_mapper_source = 1;
+    const GenomeTables &G = h->img.genomes[(size_t)ref];
+    if (absFirst < 0 || absLast < absFirst || absLast >= G.totalLength)
+        throw std::runtime_error("hgx_block_map: reference range out of bounds");
+    std::unique_ptr<hgx_liftover_plan, void (*)(hgx_liftover_plan *)> P(createLiftoverPlan(h, ref, query, opts, 1), destroyLiftoverPlan);
+    std::vector<int64_t> gs{absFirst}, ge{absLast};
+    std::vector<uint8_t> st{(uint8_t)(targetReversed ? '-' : '+')};
+    runHostArrays(P.get(), gs, ge, st, out);
 }
 
 } // namespace hgx

@@ -16,5 +16,8 @@ std::string liftoverPlanKernelTimes(const hgx_liftover_plan *p);
 void liftoverPlanCopyRecords(const hgx_liftover_plan *p, void *dDst, size_t nRecords, void *stream);
 void liftoverBatchHost(hgx_alignment *h, int src, int tgt, size_t n, const hgx_interval *iv, const hgx_liftover_opts &opts,
                        std::vector<hgx_record> &out, hgx_liftover_stats *stats);
+// BlockMapper::init + map + getMap without adjacencies (liftover/impl/halBlockMapper.cpp:33-110)
+void blockMapHost(hgx_alignment *h, int ref, int query, int64_t absFirst, int64_t absLast, bool targetReversed,
+                  const hgx_liftover_opts &opts, std::vector<hgx_record> &out);
 
 } // namespace hgx

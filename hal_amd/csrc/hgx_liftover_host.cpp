@@ -331,7 +331,7 @@ void Liftover::convert(hgx_alignment *al, int srcGenome, std::istream *in, int t
     std::unordered_map<std::string, int> seqByName;
     for (size_t i = 0; i < S.seqs.size(); ++i)
         seqByName.emplace(S.seqs[i].name, (int)i);
-    hgx_liftover_opts opts;
+    hgx_liftover_opts opts{};
     opts.traverse_dupes = traverseDupes ? 1 : 0;
     opts.coalescence_limit = coalescenceLimit;
     opts.min_length = 0;

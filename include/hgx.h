@@ -97,6 +97,12 @@ typedef struct hgx_liftover_opts {
     int32_t coalescence_limit; /* --coalescenceLimit: genome id of an ancestor of the MRCA, or -1 (= the MRCA, the default);
                                   paralogs coalescing up to that genome are followed (halSegmentMapper.cpp:525-576) */
     int64_t min_length;        /* halMapSegment minLength; halLiftover passes 0 */
+    int32_t emit_blocks;       /* 1: records are the members of the mapped set itself, in set order (BlockMapper::getMap,
+                                  liftover/inc/halBlockMapper.h:36) instead of merged output lines: tgt_start/tgt_end = the
+                                  member's forward target range, src_start = its forward source start, strand = orientation
+                                  of its source side ('+'/'-'), tgt_reversed = orientation of its target side */
+    int32_t block_mapper_source; /* 1: walk the source genome the way BlockMapper::map does (halBlockMapper.cpp:79-86: bottom
+                                    segments iff it is the MRCA and not the target) instead of BlockLiftover's rule */
 } hgx_liftover_opts;
 
 /* Host-buffer form.  Records come back grouped by input interval in input order and, inside one
@@ -104,6 +110,14 @@ typedef struct hgx_liftover_opts {
  * records), like halLiftover.cpp:62-66.  *out is released with hgx_free. */
 int hgx_liftover_batch(hgx_alignment *h, int src_genome, int tgt_genome, size_t n, const hgx_interval *intervals,
                        const hgx_liftover_opts *opts, hgx_record **out, size_t *n_out, char **err);
+
+/* BlockMapper (liftover/inc/halBlockMapper.h:30-40) without adjacencies: init(refGenome, queryGenome, absRefFirst,
+ * absRefLast, targetReversed, doDupes, minLength, false, coalescenceLimit); map(); getMap().  abs_ref_first/last are
+ * genome coordinates, last inclusive.  Records as described at hgx_liftover_opts.emit_blocks, query = 0; the source
+ * range of a record is [src_start, src_start + (tgt_end - tgt_start)).  Released with hgx_free. */
+int hgx_block_map(hgx_alignment *h, int ref_genome, int query_genome, int64_t abs_ref_first, int64_t abs_ref_last,
+                  int target_reversed, int do_dupes, int64_t min_length, int coalescence_limit, hgx_record **out, size_t *n_out,
+                  char **err);
 
 /* Device-resident form: the query table is already in HBM and the records stay there.
  * A plan owns the per-(src,tgt) walk schedule and all device workspaces, sized for max_queries. */

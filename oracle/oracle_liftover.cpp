@@ -634,4 +634,49 @@ void Liftover::convert(const Alignment *alignment, int src, std::istream *bedIn,
     }
 }
 
+// liftover/impl/halBlockMapper.cpp:36-110 (mapTargetAdjacencies == false)
+void blockMap(const Alignment &al, int refGenome, int queryGenome, i64 absRefFirst, i64 absRefLast, bool targetReversed, bool doDupes,
+              i64 minLength, int coalescenceLimit, MSegSet &segSet) {
+    std::set<int> in;
+    in.insert(refGenome);
+    in.insert(queryGenome);
+    const int mrca = getLowestCommonAncestor(al, in);
+    if (coalescenceLimit < 0)
+        coalescenceLimit = mrca;
+    in.clear();
+    in.insert(queryGenome);
+    in.insert(coalescenceLimit);
+    std::set<int> downwardPath;
+    getGenomesInSpanningTree(al, in, downwardPath);
+    const Genome &R = al.genomes[(size_t)refGenome];
+    SegIt refSeg;
+    refSeg.al = &al;
+    refSeg.g = refGenome;
+    i64 lastIndex;
+    if (mrca == refGenome && refGenome != queryGenome) { // :79-86
+        refSeg.top = false;
+        lastIndex = R.numBot;
+    } else {
+        refSeg.top = true;
+        lastIndex = R.numTop;
+    }
+    if (lastIndex == 0)
+        return;
+    refSeg.rev = false;
+    refSeg.toSite(absRefFirst, false);
+    i64 startOffset = absRefFirst - refSeg.getStartPosition();
+    i64 endOffset = 0;
+    if (absRefLast <= refSeg.getEndPosition())
+        endOffset = refSeg.getEndPosition() - absRefLast;
+    refSeg.slice(startOffset, endOffset);
+    while (refSeg.idx < lastIndex && refSeg.getStartPosition() <= absRefLast) {
+        if (targetReversed)
+            refSeg.toReverseInPlace();
+        halMapSegment(refSeg, segSet, queryGenome, &downwardPath, doDupes, minLength, coalescenceLimit, mrca);
+        if (targetReversed)
+            refSeg.toReverseInPlace();
+        refSeg.toRight(absRefLast);
+    }
+}
+
 } // namespace orc

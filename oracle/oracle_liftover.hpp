@@ -79,4 +79,8 @@ struct Liftover {
     void readPSLInfo(std::vector<MSegPtr> &fragments, BedLine &outBedLine);
 };
 
+// liftover/impl/halBlockMapper.cpp:36-110: BlockMapper::init + map without adjacencies; fills the set getMap() returns
+void blockMap(const Alignment &al, int refGenome, int queryGenome, i64 absRefFirst, i64 absRefLast, bool targetReversed, bool doDupes,
+              i64 minLength, int coalescenceLimit, MSegSet &segSet);
+
 } // namespace orc

@@ -232,8 +232,56 @@ static int cmdColumns(bool maf, int argc, char **argv) {
     return 0;
 }
 
+// hal_oracle blocks <img.hgx> <refGenome> <queryGenome> <absFirst> <absLast> [--reversed] [--noDupes] [--minLength N]
+//                   [--coalescenceLimit G]
+// prints the members of BlockMapper::getMap() in set order: target sequence, target range (sequence relative, forward,
+// end exclusive), forward source start (genome coordinate), source strand, target strand
+static int cmdBlocks(int argc, char **argv) {
+    std::vector<std::string> pos;
+    bool reversed = false, noDupes = false;
+    i64 minLength = 0;
+    std::string coalName;
+    for (int i = 0; i < argc; ++i) {
+        std::string a = argv[i];
+        if (a == "--reversed")
+            reversed = true;
+        else if (a == "--noDupes")
+            noDupes = true;
+        else if (a == "--minLength")
+            minLength = atoll(argv[++i]);
+        else if (a == "--coalescenceLimit")
+            coalName = argv[++i];
+        else
+            pos.push_back(a);
+    }
+    if (pos.size() != 5) {
+        std::cerr << "usage: hal_oracle blocks <img.hgx> <refGenome> <queryGenome> <absFirst> <absLast>" << std::endl;
+        return 1;
+    }
+    Alignment al = loadImage(pos[0]);
+    int ref = al.genomeByName(pos[1]), query = al.genomeByName(pos[2]);
+    int coal = coalName.empty() ? -1 : al.genomeByName(coalName);
+    if (ref < 0 || query < 0 || (!coalName.empty() && coal < 0)) {
+        std::cerr << "genome not found" << std::endl;
+        return 1;
+    }
+    MSegSet segs;
+    blockMap(al, ref, query, atoll(pos[3].c_str()), atoll(pos[4].c_str()), reversed, !noDupes, minLength, coal, segs);
+    for (MSegSet::iterator i = segs.begin(); i != segs.end(); ++i) {
+        const SegIt &t = (*i)->tgt, &s = (*i)->src;
+        const Sequence *seq = t.getSequence();
+        const i64 tLo = std::min(t.getStartPosition(), t.getEndPosition()), tHi = std::max(t.getStartPosition(), t.getEndPosition());
+        const i64 sLo = std::min(s.getStartPosition(), s.getEndPosition());
+        std::cout << seq->name << '\t' << tLo - seq->start << '\t' << tHi + 1 - seq->start << '\t' << sLo << '\t' << (s.rev ? '-' : '+')
+                  << '\t' << (t.rev ? '-' : '+') << '\n';
+    }
+    return 0;
+}
+
 int main(int argc, char **argv) {
     try {
+        if (argc >= 2 && std::string(argv[1]) == "blocks")
+            return cmdBlocks(argc - 2, argv + 2);
         if (argc >= 2 && std::string(argv[1]) == "liftover")
             return cmdLiftover(argc - 2, argv + 2);
         if (argc >= 2 && std::string(argv[1]) == "depth")
