@@ -28,8 +28,12 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
 
 
-def workload_options(scale):
+def workload_options(scale, workload="cfg2"):
     import hal_amd
+    if workload == "cfg4":  # BASELINE configs 4/5: the 50-genome alignment (--seed 0 --meanDegree 2 --maxGenomes 50)
+        return hal_amd.RandOptions(mean_degree=2.0, max_branch_length=3.0, min_genomes=2, max_genomes=50, min_segment_length=50,
+                                   max_segment_length=200, min_segments=int(700000 * scale), max_segments=int(1400000 * scale),
+                                   seed=0, with_dna=False)
     return hal_amd.RandOptions(mean_degree=1.5, max_branch_length=3.0, min_genomes=2, max_genomes=10, min_segment_length=50,
                                max_segment_length=200, min_segments=int(700000 * scale), max_segments=int(1400000 * scale),
                                seed=2, with_dna=False)
@@ -95,6 +99,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--queries", type=int, default=1000000, help="intervals per GPU")
     ap.add_argument("--scale", type=float, default=1.0, help="genome size multiplier (1.0 = ~100 Mb/genome)")
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4"],
+                    help="cfg2: 10-genome alignment, Genome_9 -> Genome_2 (the metric's configuration); cfg4: 50-genome alignment, "
+                         "Genome_44 -> Genome_2 (BASELINE configs 4 and 5, one GPU's shard)")
     ap.add_argument("--target", default="Genome_2")
     ap.add_argument("--cpu-sample", type=int, default=300000, help="intervals timed on the CPU oracle (0 = skip)")
     ap.add_argument("--cpu-all-cores", type=int, default=1, help="also time the oracle sharded over every host core")
@@ -116,9 +123,9 @@ def main():
     dev = torch.device("cuda", local)
 
     t0 = time.time()
-    al = hal_amd.Alignment.random(workload_options(args.scale), device=local)
+    al = hal_amd.Alignment.random(workload_options(args.scale, args.workload), device=local)
     gen_s = time.time() - t0
-    src_name, tgt_name = "Genome_9", args.target
+    src_name, tgt_name = ("Genome_9" if args.workload == "cfg2" else "Genome_44"), args.target
     src, tgt = al.genome_id(src_name), al.genome_id(tgt_name)
     seq_name, seq_start, length = al.sequences(src)[0]
     nq = args.queries
@@ -206,8 +213,10 @@ def main():
             "metric": "lifted BED intervals/sec", "value": value, "unit": "intervals/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int64" if al.genome_length(src) >= 2 ** 31 else "int32", "data": "synthetic",
-            "config": {"workload": "halRandGen 10-genome ~100 Mb/genome HAL (seed 2, scale %g), halLiftover of %d BED6 intervals "
-                                   "per GPU, %s -> %s, dupes on" % (args.scale, nq, src_name, tgt_name),
+            "config": {"workload": "halRandGen %s ~100 Mb/genome HAL (%s, scale %g), halLiftover of %d BED6 intervals "
+                                   "per GPU, %s -> %s, dupes on" % ("10-genome" if args.workload == "cfg2" else "50-genome",
+                                                                     "seed 2" if args.workload == "cfg2" else "seed 0", args.scale, nq,
+                                                                     src_name, tgt_name),
                        "intervals_per_gpu": nq, "records_per_step": nrec_all, "parallelism": "query-shard x%d" % world,
                        "newick": al.newick, "generate_s": round(gen_s, 2)},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -228,9 +237,20 @@ def main():
             dcol = torch.empty(ncol, dtype=torch.int32, device=dev)
             al.columns_depth_device(src, 0, ncol, dcol.data_ptr())
             col_ms = min(al.columns_depth_device(src, 0, ncol, dcol.data_ptr()) for _ in range(3))
+            cst = al.columns_depth_stats(src, 0, ncol)
+            # algorithmic bytes of the column path: 25 B per segment record of the closure, computed once per
+            # reference piece (= per run of columns with one walk, which is how the kernel works), + the 4-byte result
+            col_bytes = 25.0 * (cst["top_derefs"] + cst["bottom_derefs"]) + 4.0 * ncol
+            col_gbs = col_bytes / (col_ms * 1e-3) / 1e9
             out["columns"] = {"metric": "alignment-depth columns/sec (ColumnIterator closure per reference base)",
                               "value": ncol / (col_ms * 1e-3), "unit": "columns/s", "columns": ncol, "kernel_ms": col_ms,
-                              "reference_genome": src_name, "mean_depth": float(dcol.float().mean().item())}
+                              "reference_genome": src_name, "mean_depth": float(dcol.float().mean().item()),
+                              "roofline": {"bound": "hbm", "kernel": "k_column_depth", "achieved": col_gbs, "peak": HBM_PEAK_GBS,
+                                           "unit": "GB/s", "frac": col_gbs / HBM_PEAK_GBS, "traffic": (json.load(open(pmc)).get("k_column_depth") if os.path.exists(pmc) else None),
+                                           "algorithmic_bytes_per_launch": col_bytes,
+                                           "top_derefs": cst["top_derefs"], "bottom_derefs": cst["bottom_derefs"],
+                                           "note": "the kernel is bound by the scratch traffic of its frame stacks, not by these bytes "
+                                                   "(DESIGN.md 4.1)"}}
         if args.cpu_sample > 0:
             sample = min(args.cpu_sample, nq)
             cst, text, multi = cpu_baseline(al, src_name, tgt_name, starts, lens, strand, seq_name, sample,

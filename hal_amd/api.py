@@ -155,6 +155,14 @@ class Alignment:
         return lib.hgx_mrca(self._h, a, b)
 
     # --- liftover, host-buffer form ---
+    def columns_depth_stats(self, ref, first, count, step=1, **col_opts):
+        """{top_derefs, bottom_derefs}: segment records the column walks of columns_depth(...) logically dereference."""
+        o, keep = self._column_opts(**col_opts)
+        t, b, err = C.c_uint64(), C.c_uint64(), C.c_void_p()
+        if lib.hgx_columns_depth_stats(self._h, ref, first, count, step, C.byref(o), C.byref(t), C.byref(b), C.byref(err)) != 0:
+            raise HgxError(take_error(err))
+        return {"top_derefs": t.value, "bottom_derefs": b.value}
+
     def block_map(self, ref, query, abs_first, abs_last, target_reversed=False, do_dupes=True, min_length=0, coalescence_limit=-1):
         """BlockMapper init + map + getMap without adjacencies (liftover/inc/halBlockMapper.h:30-40): the members of the mapped
         set for the reference range [abs_first, abs_last] (genome coordinates, inclusive), in set order, as a numpy record

@@ -410,6 +410,24 @@ int hgx_columns_depth_device(hgx_alignment *h, int ref, int64_t first, int64_t c
     HGX_CATCH
 }
 
+int hgx_columns_depth_stats(hgx_alignment *h, int ref, int64_t first, int64_t count, int64_t step, const hgx_column_opts *opts,
+                            uint64_t *top_derefs, uint64_t *bottom_derefs, char **err) {
+    HGX_TRY
+    if (!h)
+        throw std::runtime_error("hgx_columns_depth_stats: null argument");
+    if (!h->dev)
+        throw std::runtime_error("alignment was opened without a device (device = -1); the column engine needs the HIP path");
+    ColumnStats st;
+    std::vector<int32_t> scratch((size_t)std::max<int64_t>(count, 0));
+    columnsDepthHost(h, ref, first, count, step, 0, columnOptions(opts), scratch.data(), &st, true);
+    if (top_derefs)
+        *top_derefs = st.top_derefs;
+    if (bottom_derefs)
+        *bottom_derefs = st.bottom_derefs;
+    return HGX_OK;
+    HGX_CATCH
+}
+
 int hgx_column_rows(hgx_alignment *h, int ref, int64_t first, int64_t count, const hgx_column_opts *opts, uint64_t **row_offset,
                     hgx_column_row **rows, size_t *n_rows, char **err) {
     HGX_TRY

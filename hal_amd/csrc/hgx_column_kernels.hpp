@@ -23,6 +23,7 @@ struct ColumnParams {
     unsigned long long scopeMask[4];  // genomes the walk may enter (all ones when no targets)
     unsigned long long targetMask[4]; // genomes whose bases are reported
     unsigned int *error;              // set to 1 on frame-stack overflow
+    unsigned long long *derefs;       // optional {top, bottom} segment records logically dereferenced (roofline accounting)
 };
 
 static constexpr int COL_STACK = 64; // frames per lane (scratch; an LDS-resident lower part was measured slower: occupancy)
@@ -40,11 +41,16 @@ __device__ __forceinline__ bool bit(const unsigned long long *m, int g) {
     return (m[g >> 6] >> (g & 63)) & 1ull;
 }
 
-template <typename C> struct ColumnWalker {
+template <typename C, bool STATS = false> struct ColumnWalker {
     const ColumnParams &P;
     Frame stack[COL_STACK];
     int sp = 0;
     bool overflow = false;
+    uint32_t nTop = 0, nBot = 0; // records the reference's walk dereferences (one per segment looked at)
+    // Columns p+1 .. p+remain have the walk of column p with every base advanced by one along its strand: going to a
+    // parent, child or paralog keeps the offset inside segments of equal length, so only the reference segment and the
+    // segments a parse step lands in can end the run; remain = the fewest bases left (iteration order) in any of them.
+    int64_t remain = 0;
     __device__ ColumnWalker(const ColumnParams &p) : P(p) {
     }
     __device__ __forceinline__ const TopRec<C> *top(int g) const {
@@ -53,6 +59,7 @@ template <typename C> struct ColumnWalker {
     __device__ __forceinline__ const BotRec<C> *bot(int g) const {
         return (const BotRec<C> *)P.desc[g].bot;
     }
+    // (keeping the most recently pushed frame in registers instead of on the scratch stack was measured 17 % slower)
     __device__ __forceinline__ void push(uint32_t kind, int g, int32_t idx, int32_t so, bool rev, int32_t extra) {
         if (sp >= COL_STACK) {
             overflow = true;
@@ -79,14 +86,13 @@ template <typename C> struct ColumnWalker {
             visit(g, pos, rev);
     }
 
-    template <typename V> __device__ void run(int64_t p, V &visit) {
-        const int R = P.ref;
-        const GenomeDesc &RD = P.desc[R];
-        sp = 0;
+    // index of the reference segment (top tiling, or bottom for a genome without one) holding position p
+    __device__ __forceinline__ int32_t locate(int64_t p) const {
+        const GenomeDesc &RD = P.desc[P.ref];
+        int64_t lo = 0, hi;
         if (RD.numTop > 0) {
-            // recursiveUpdate, top branch (:252-300): toSite, insert, updateParent, updateNextTopDup, updateParseDown
-            const TopRec<C> *T = top(R);
-            int64_t lo = 0, hi = RD.numTop;
+            const TopRec<C> *T = top(P.ref);
+            hi = RD.numTop;
             while (hi - lo > 1) {
                 const int64_t mid = (lo + hi) >> 1;
                 if ((int64_t)T[mid].start <= p)
@@ -94,9 +100,36 @@ template <typename C> struct ColumnWalker {
                 else
                     hi = mid;
             }
-            const int32_t t = (int32_t)lo;
+        } else {
+            const BotRec<C> *B = bot(P.ref);
+            hi = RD.numBot;
+            while (hi - lo > 1) {
+                const int64_t mid = (lo + hi) >> 1;
+                if ((int64_t)B[mid].start <= p)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+        }
+        return (int32_t)lo;
+    }
+    template <typename V> __device__ __forceinline__ void run(int64_t p, V &visit) {
+        runAt(locate(p), p, visit);
+    }
+    // the walk of column p, which lies in reference segment seg
+    template <typename V> __device__ void runAt(int32_t seg, int64_t p, V &visit) {
+        const int R = P.ref;
+        const GenomeDesc &RD = P.desc[R];
+        sp = 0;
+        if (RD.numTop > 0) {
+            // recursiveUpdate, top branch (:252-300): toSite, insert, updateParent, updateNextTopDup, updateParseDown
+            const TopRec<C> *T = top(R);
+            const int32_t t = seg;
             const TopRec<C> tr = T[t];
+            if (STATS)
+                ++nTop;
             const int32_t so = (int32_t)(p - (int64_t)tr.start);
+            remain = (int64_t)T[t + 1].start - 1 - p;
             insert(visit, R, p, false);
             // frames that could only fall through are not pushed (fewer scratch round trips); each frame re-checks
             if (tr.botParse >= 0)
@@ -108,15 +141,10 @@ template <typename C> struct ColumnWalker {
         } else {
             // bottom branch (:302-353): the root: insert, then every child
             const BotRec<C> *B = bot(R);
-            int64_t lo = 0, hi = RD.numBot;
-            while (hi - lo > 1) {
-                const int64_t mid = (lo + hi) >> 1;
-                if ((int64_t)B[mid].start <= p)
-                    lo = mid;
-                else
-                    hi = mid;
-            }
-            const int32_t b = (int32_t)lo, so = (int32_t)(p - (int64_t)B[b].start);
+            const int32_t b = seg, so = (int32_t)(p - (int64_t)B[b].start);
+            if (STATS)
+                ++nBot;
+            remain = (int64_t)B[b + 1].start - 1 - p;
             insert(visit, R, p, false);
             for (int i = RD.numChildren - 1; i >= 0; --i)
                 if (RD.child[i][b] >= 0)
@@ -131,7 +159,11 @@ template <typename C> struct ColumnWalker {
             if (kind == FR_UP) {
                 // updateParent (:556-605)
                 const TopRec<C> tr = top(g)[f.idx];
+                if (STATS)
+                    ++nTop;
                 if (tr.parentEnc >= 0 && D.parent >= 0 && bit(P.scopeMask, D.parent)) {
+                    if (STATS)
+                        ++nBot;
                     const int pg = D.parent;
                     const GenomeDesc &PD = P.desc[pg];
                     const int32_t b = tr.parentEnc >> 1;
@@ -157,6 +189,14 @@ template <typename C> struct ColumnWalker {
                     while ((int64_t)T[j + 1].start <= pos)
                         ++j;
                     const TopRec<C> tj = T[j];
+                    if (STATS)
+                        ++nBot;
+                    if (STATS)
+                        nTop += (uint32_t)(j - tp + 1);
+                    {
+                        const int64_t left = !rev ? (int64_t)T[j + 1].start - 1 - pos : pos - (int64_t)tj.start;
+                        remain = left < remain ? left : remain;
+                    }
                     const int32_t so = !rev ? (int32_t)(pos - (int64_t)tj.start) : (int32_t)((int64_t)T[j + 1].start - 1 - pos);
                     if (!P.onlyOrthologs && tj.paralogy >= 0)
                         push(FR_RING, g, j, so, rev, j);
@@ -168,7 +208,11 @@ template <typename C> struct ColumnWalker {
                 const int slot = f.extra;
                 const int32_t enc = D.child[slot][f.idx];
                 const int cg = D.childGenome[slot];
+                if (STATS)
+                    ++nBot;
                 if (enc >= 0 && bit(P.scopeMask, cg)) {
+                    if (STATS)
+                        ++nTop;
                     const int32_t t = enc >> 1;
                     const bool crev = rev ^ ((enc & 1) != 0);
                     const TopRec<C> ct = top(cg)[t];
@@ -183,6 +227,8 @@ template <typename C> struct ColumnWalker {
                 // then continue round the ring
                 const TopRec<C> *T = top(g);
                 const TopRec<C> cur = T[f.idx];
+                if (STATS)
+                    ++nTop;
                 const int32_t first = f.extra;
                 const bool startOfRing = f.idx == first;
                 bool go = !P.noDupes && cur.paralogy >= 0 && D.parent >= 0 && bit(P.scopeMask, D.parent);
@@ -191,6 +237,8 @@ template <typename C> struct ColumnWalker {
                 if (go) {
                     const int32_t nxt = cur.paralogy;
                     const TopRec<C> nr = T[nxt];
+                    if (STATS)
+                        ++nTop;
                     const bool nrev = rev ^ ((nr.parentEnc & 1) != (cur.parentEnc & 1));
                     insert(visit, g, posOf(T, nxt, f.so, nrev), nrev);
                     if (nr.paralogy >= 0 && nr.paralogy != first)
@@ -208,6 +256,14 @@ template <typename C> struct ColumnWalker {
                     int32_t j = bp;
                     while ((int64_t)B[j + 1].start <= pos)
                         ++j;
+                    if (STATS)
+                        ++nTop;
+                    if (STATS)
+                        nBot += (uint32_t)(j - bp + 1);
+                    {
+                        const int64_t left = !rev ? (int64_t)B[j + 1].start - 1 - pos : pos - (int64_t)B[j].start;
+                        remain = left < remain ? left : remain;
+                    }
                     const int32_t so = !rev ? (int32_t)(pos - (int64_t)B[j].start) : (int32_t)((int64_t)B[j + 1].start - 1 - pos);
                     for (int i = D.numChildren - 1; i >= 0; --i)
                         if (D.child[i][j] >= 0)
@@ -231,9 +287,9 @@ struct DepthVisitor {
 // halAlignmentDepth's per-column value (alignmentDepth/halAlignmentDepth.cpp:258-281): number of genomes with at
 // least one base in the column (or, with countDupes, number of bases) minus the reference base.
 // Also usable as the row-count pass of the MAF path (countDupes = 2: bases, without the -1).
-template <typename C>
+template <typename C, bool STATS>
 __global__ void __launch_bounds__(256) k_column_depth(ColumnParams P, int countMode, int32_t *__restrict__ out) {
-    ColumnWalker<C> w(P);
+    ColumnWalker<C, STATS> w(P);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P.count; i += (int64_t)gridDim.x * blockDim.x) {
         DepthVisitor v;
         w.run(P.first + i * P.step, v);
@@ -248,6 +304,17 @@ __global__ void __launch_bounds__(256) k_column_depth(ColumnParams P, int countM
     }
     if (w.overflow)
         *P.error = 1;
+    if (STATS && P.derefs) { // wave reduction, one atomic per counter per wave
+        uint32_t a = w.nTop, b = w.nBot;
+        for (int o = 32; o > 0; o >>= 1) {
+            a += __shfl_down(a, o);
+            b += __shfl_down(b, o);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&P.derefs[0], (unsigned long long)a);
+            atomicAdd(&P.derefs[1], (unsigned long long)b);
+        }
+    }
 }
 
 // MAF rows: every reported base of every column, in ColumnMap insertion order
@@ -339,6 +406,103 @@ static __global__ void __launch_bounds__(256) k_gather_head_rows(const uint32_t 
         const uint32_t a = rowOffset[c], n = rowOffset[c + 1] - a, o = headOffset[c];
         for (uint32_t k = 0; k < n; ++k)
             out[o + k] = rows[a + k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Run-compressed column engine.  One lane owns one reference SEGMENT and walks only the first column of every run
+// (ColumnWalker::remain tells where the next run starts); the columns inside a run differ from its first column by
+// a shift, so depth is constant along a run and MAF rows advance by one base per column.  This is "the closure
+// computed once per reference piece" of SURVEY 8(d): ~24x fewer walks than one per column on the cfg2 alignment.
+struct LongRun { // a run too long for its lane to fill alone
+    int64_t first, count; // output index range
+    int32_t value, _pad;
+};
+static constexpr int64_t LANE_FILL_MAX = 256;
+
+__device__ __forceinline__ int32_t depth_value(const DepthVisitor &v, int countMode) {
+    if (countMode == 0)
+        return (int32_t)(__popcll(v.mask[0]) + __popcll(v.mask[1]) + __popcll(v.mask[2]) + __popcll(v.mask[3])) - 1;
+    if (countMode == 1)
+        return (int32_t)v.bases - 1;
+    return (int32_t)v.bases;
+}
+
+template <typename W> __device__ __forceinline__ void ref_segment_bounds(const W &w, int32_t s, int64_t &lo, int64_t &hi) {
+    const GenomeDesc &RD = w.P.desc[w.P.ref];
+    if (RD.numTop > 0) {
+        lo = (int64_t)w.top(w.P.ref)[s].start;
+        hi = (int64_t)w.top(w.P.ref)[s + 1].start - 1;
+    } else {
+        lo = (int64_t)w.bot(w.P.ref)[s].start;
+        hi = (int64_t)w.bot(w.P.ref)[s + 1].start - 1;
+    }
+}
+
+// out[i] for the columns first + i*step (i < count); segFirst .. segFirst+segCount-1 are the reference segments they lie in
+template <typename C, bool STATS>
+__global__ void __launch_bounds__(256) k_depth_runs(ColumnParams P, int countMode, int32_t segFirst, int64_t segCount, int32_t *__restrict__ out,
+                                                    LongRun *__restrict__ longRuns, unsigned long long *__restrict__ longCount,
+                                                    unsigned long long longCap) {
+    ColumnWalker<C, STATS> w(P);
+    const int64_t lastPos = P.first + (P.count - 1) * P.step;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < segCount; k += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t s = segFirst + (int32_t)k;
+        int64_t lo, hi;
+        ref_segment_bounds(w, s, lo, hi);
+        int64_t p = lo > P.first ? lo : P.first;
+        const int64_t end = hi < lastPos ? hi : lastPos;
+        if (P.step > 1) { // first sampled column at or after p
+            const int64_t r = (p - P.first) % P.step;
+            if (r)
+                p += P.step - r;
+        }
+        while (p <= end) {
+            DepthVisitor v;
+            w.runAt(s, p, v);
+            const int32_t val = depth_value(v, countMode);
+            const int64_t q = p + w.remain < end ? p + w.remain : end; // last column of the run (inside this segment)
+            const int64_t i0 = (p - P.first) / P.step, i1 = (q - P.first) / P.step;
+            const int64_t n = i1 - i0 + 1;
+            if (n <= LANE_FILL_MAX) {
+                for (int64_t i = i0; i <= i1; ++i)
+                    out[i] = val;
+            } else {
+                const unsigned long long slot = atomicAdd(longCount, 1ull);
+                if (slot < longCap) {
+                    LongRun lr;
+                    lr.first = i0;
+                    lr.count = n;
+                    lr.value = val;
+                    lr._pad = 0;
+                    longRuns[slot] = lr;
+                }
+            }
+            p = P.first + (i1 + 1) * P.step;
+        }
+    }
+    if (w.overflow)
+        *P.error = 1;
+    if (STATS && P.derefs) {
+        uint32_t a = w.nTop, b = w.nBot;
+        for (int o = 32; o > 0; o >>= 1) {
+            a += __shfl_down(a, o);
+            b += __shfl_down(b, o);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&P.derefs[0], (unsigned long long)a);
+            atomicAdd(&P.derefs[1], (unsigned long long)b);
+        }
+    }
+}
+
+static __global__ void __launch_bounds__(256) k_fill_long_runs(const LongRun *__restrict__ runs, const unsigned long long *__restrict__ nRuns,
+                                                               int32_t *__restrict__ out) {
+    const unsigned long long n = *nRuns;
+    for (unsigned long long r = blockIdx.x; r < n; r += gridDim.x) {
+        const LongRun lr = runs[r];
+        for (int64_t i = threadIdx.x; i < lr.count; i += blockDim.x)
+            out[lr.first + i] = lr.value;
     }
 }
 

@@ -20,7 +20,14 @@ namespace hgx {
 namespace {
 struct Buf {
     void *p = nullptr;
+    Buf() = default;
     explicit Buf(size_t bytes) {
+        HIP_OK(hipMalloc(&p, std::max<size_t>(bytes, 16)));
+    }
+    void resize(size_t bytes) { // contents are not kept
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
         HIP_OK(hipMalloc(&p, std::max<size_t>(bytes, 16)));
     }
     ~Buf() {
@@ -65,6 +72,7 @@ static ColumnParams makeParams(hgx_alignment *h, int ref, int64_t first, int64_t
     P.noAncestors = opt.noAncestors;
     P.onlyOrthologs = opt.onlyOrthologs;
     P.error = dErr;
+    P.derefs = nullptr;
     if (opt.targets.empty()) {
         for (int w = 0; w < 4; ++w)
             P.scopeMask[w] = P.targetMask[w] = ~0ull;
@@ -93,23 +101,76 @@ static ColumnParams makeParams(hgx_alignment *h, int ref, int64_t first, int64_t
     return P;
 }
 
-static constexpr int COL_GRID = 2048;
+static const int COL_GRID = getenv("HGX_COL_GRID") ? atoi(getenv("HGX_COL_GRID")) : 2048;
+
+static bool perBaseColumns() {
+    static const bool v = getenv("HGX_COLUMNS_PER_BASE") != nullptr;
+    return v;
+}
+
+// reference segments (top tiling, or bottom for a genome without one) holding positions firstPos .. lastPos
+static void refSegmentRange(hgx_alignment *h, int ref, int64_t firstPos, int64_t lastPos, int32_t &segFirst, int64_t &segCount) {
+    const GenomeTables &G = h->img.genomes[(size_t)ref];
+    const std::vector<int64_t> &st = G.numTop > 0 ? G.tStart : G.bStart;
+    const int64_t nseg = G.numTop > 0 ? G.numTop : G.numBot;
+    if (nseg <= 0 || firstPos < 0 || lastPos >= G.totalLength || lastPos < firstPos)
+        throw std::runtime_error("column range outside the reference genome");
+    auto find = [&](int64_t p) { return (int64_t)(std::upper_bound(st.begin(), st.begin() + nseg, p) - st.begin()) - 1; };
+    const int64_t a = find(firstPos), b = find(lastPos);
+    segFirst = (int32_t)a;
+    segCount = b - a + 1;
+}
+
+// the dereference counters cost ~10 % of the kernel, so they are a separate instantiation
+#define LAUNCH_DEPTH(K, CT, ...)                                                                                       \
+    do {                                                                                                               \
+        if (countDerefs)                                                                                               \
+            hipLaunchKernelGGL((K<CT, true>), dim3(grid), dim3(256), 0, s, __VA_ARGS__);                               \
+        else                                                                                                           \
+            hipLaunchKernelGGL((K<CT, false>), dim3(grid), dim3(256), 0, s, __VA_ARGS__);                              \
+    } while (0)
 
 void columnsDepthDevice(hgx_alignment *h, int ref, int64_t first, int64_t count, int64_t step, int mode, const ColumnOptions &opt,
-                        int32_t *d_out, void *stream, ColumnStats *stats) {
+                        int32_t *d_out, void *stream, ColumnStats *stats, bool countDerefs, bool perBase) {
     HIP_OK(hipSetDevice(h->dev->device));
     hipStream_t s = (hipStream_t)stream;
     Buf err(4);
     HIP_OK(hipMemsetAsync(err.p, 0, 4, s));
     ColumnParams P = makeParams(h, ref, first, count, step, opt, (unsigned int *)err.p);
+    Buf der(16);
+    if (stats && countDerefs) {
+        HIP_OK(hipMemsetAsync(der.p, 0, 16, s));
+        P.derefs = (unsigned long long *)der.p;
+    }
     Ev a, b;
+    Buf longRuns, longCount(8);
     HIP_OK(hipEventRecord(a.e, s));
-    if (count > 0) {
+    if (count > 0 && (perBase || perBaseColumns())) {
+        // one walk per column: 64 neighbouring columns per wavefront walk in lockstep.  Used for the row counts of the MAF
+        // path (short chunks: one lane per reference SEGMENT would leave the GPU empty) and as a cross-check of the run
+        // kernel (HGX_COLUMNS_PER_BASE=1)
         const int grid = (int)std::min<int64_t>(COL_GRID, (count + 255) / 256);
         if (h->dev->wide)
-            hipLaunchKernelGGL((k_column_depth<int64_t>), dim3(grid), dim3(256), 0, s, P, mode, d_out);
+            LAUNCH_DEPTH(k_column_depth, int64_t, P, mode, d_out);
         else
-            hipLaunchKernelGGL((k_column_depth<int32_t>), dim3(grid), dim3(256), 0, s, P, mode, d_out);
+            LAUNCH_DEPTH(k_column_depth, int32_t, P, mode, d_out);
+    } else if (count > 0) {
+        // one walk per run, one lane per reference segment
+        int32_t segFirst;
+        int64_t segCount;
+        refSegmentRange(h, ref, first, first + (count - 1) * step, segFirst, segCount);
+        const unsigned long long longCap = (unsigned long long)(count / LANE_FILL_MAX + 1);
+        longRuns.resize((size_t)longCap * sizeof(LongRun));
+        HIP_OK(hipMemsetAsync(longCount.p, 0, 8, s));
+        const int grid = (int)std::min<int64_t>(COL_GRID, (segCount + 255) / 256);
+        if (h->dev->wide)
+            LAUNCH_DEPTH(k_depth_runs, int64_t, P, mode, segFirst, segCount, d_out, (LongRun *)longRuns.p, (unsigned long long *)longCount.p,
+                         longCap);
+        else
+            LAUNCH_DEPTH(k_depth_runs, int32_t, P, mode, segFirst, segCount, d_out, (LongRun *)longRuns.p, (unsigned long long *)longCount.p,
+                         longCap);
+        hipLaunchKernelGGL(k_fill_long_runs, dim3(1024), dim3(256), 0, s, (const LongRun *)longRuns.p, (const unsigned long long *)longCount.p,
+                           d_out);
     }
     HIP_OK(hipEventRecord(b.e, s));
     unsigned int e = 0;
@@ -122,16 +183,22 @@ void columnsDepthDevice(hgx_alignment *h, int ref, int64_t first, int64_t count,
         HIP_OK(hipEventElapsedTime(&ms, a.e, b.e));
         stats->depth_ms += ms;
         stats->columns += (uint64_t)count;
+        if (countDerefs) {
+            unsigned long long d[2] = {0, 0};
+            HIP_OK(hipMemcpy(d, der.p, 16, hipMemcpyDeviceToHost));
+            stats->top_derefs += d[0];
+            stats->bottom_derefs += d[1];
+        }
     }
 }
 
 void columnsDepthHost(hgx_alignment *h, int ref, int64_t first, int64_t count, int64_t step, int mode, const ColumnOptions &opt,
-                      int32_t *out, ColumnStats *stats) {
+                      int32_t *out, ColumnStats *stats, bool countDerefs) {
     if (!h->dev)
         throw std::runtime_error("alignment was opened without a device (device = -1); the column engine needs the HIP path");
     HIP_OK(hipSetDevice(h->dev->device));
     Buf d((size_t)count * 4);
-    columnsDepthDevice(h, ref, first, count, step, mode, opt, (int32_t *)d.p, nullptr, stats);
+    columnsDepthDevice(h, ref, first, count, step, mode, opt, (int32_t *)d.p, nullptr, stats, countDerefs);
     if (count > 0)
         HIP_OK(hipMemcpy(out, d.p, (size_t)count * 4, hipMemcpyDeviceToHost));
 }
@@ -213,7 +280,7 @@ void columnsHeadRowsHost(hgx_alignment *h, int ref, int64_t first, int64_t count
     Ev e0, e1;
     HIP_OK(hipEventRecord(e0.e, nullptr));
     // 1. rows per column, 2. offsets, 3. all rows (device only)
-    columnsDepthDevice(h, ref, first, count, 1, 2, opt, (int32_t *)dCnt.p, nullptr, nullptr);
+    columnsDepthDevice(h, ref, first, count, 1, 2, opt, (int32_t *)dCnt.p, nullptr, nullptr, false, true);
     const uint32_t totalRows = deviceScan((const uint32_t *)dCnt.p, n, (uint32_t *)dOff.p, (uint32_t *)dSums.p);
     Buf dRows((size_t)totalRows * sizeof(ColumnRow));
     HIP_OK(hipMemset(err.p, 0, 4));

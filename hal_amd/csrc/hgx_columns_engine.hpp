@@ -23,15 +23,16 @@ struct ColumnOptions {
 struct ColumnStats {
     double depth_ms = 0, rows_ms = 0;
     uint64_t columns = 0, rows = 0;
+    uint64_t top_derefs = 0, bottom_derefs = 0; // segment records the walks logically dereferenced (depth kernel only)
 };
 
 // per-column values of halAlignmentDepth: mode 0 = distinct genomes - 1, 1 = bases - 1 (--countDupes), 2 = bases
 // first: genome coordinate; results for columns first, first+step, ... (count of them)
 void columnsDepthHost(hgx_alignment *h, int ref, int64_t first, int64_t count, int64_t step, int mode, const ColumnOptions &opt,
-                      int32_t *out, ColumnStats *stats);
+                      int32_t *out, ColumnStats *stats, bool countDerefs = false);
 // same, results left on the device (d_out: device int32[count]); stream = hipStream_t
 void columnsDepthDevice(hgx_alignment *h, int ref, int64_t first, int64_t count, int64_t step, int mode, const ColumnOptions &opt,
-                        int32_t *d_out, void *stream, ColumnStats *stats);
+                        int32_t *d_out, void *stream, ColumnStats *stats, bool countDerefs = false, bool perBase = false);
 // every reported base of columns [first, first+count), in the reference's ColumnMap insertion order;
 // rowOffset gets count+1 entries
 void columnsRowsHost(hgx_alignment *h, int ref, int64_t first, int64_t count, const ColumnOptions &opt, bool withDna,

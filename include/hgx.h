@@ -174,6 +174,11 @@ int hgx_columns_depth(hgx_alignment *h, int ref_genome, int64_t first, int64_t c
  * device time measured with HIP events on `hip_stream`. */
 int hgx_columns_depth_device(hgx_alignment *h, int ref_genome, int64_t first, int64_t count, int64_t step, int count_dupes,
                              const hgx_column_opts *opts, int32_t *d_out, void *hip_stream, double *kernel_ms, char **err);
+/* Roofline accounting of the same computation: the segment records the column walks logically dereference (one per
+ * top / bottom segment looked at; 25 bytes each).  Runs the kernel's counting instantiation (about 10 %
+ * slower than the plain one, which is why the counts are not a by-product of hgx_columns_depth_device). */
+int hgx_columns_depth_stats(hgx_alignment *h, int ref_genome, int64_t first, int64_t count, int64_t step, const hgx_column_opts *opts,
+                            uint64_t *top_derefs, uint64_t *bottom_derefs, char **err);
 
 /* Every reported base of columns [first, first+count) in ColumnMap insertion order: what a loop over
  * Sequence::getColumnIterator()/toRight()/getColumnMap() sees.  *row_offset has count+1 entries. */
