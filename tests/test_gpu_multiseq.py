@@ -65,3 +65,30 @@ def test_columns_all_genomes(hal, oracle_bin, tmp_path, seed):
         assert al.maf_export(g, len(al.sequences(g)) - 1, start=slen // 4, length=slen // 2) == \
             _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", name, "--refSequence", sname, "--start", str(slen // 4), "--length",
                     str(slen // 2)), name
+
+
+@pytest.mark.parametrize("seed,n", [(0, 22), (1, 19)])
+def test_deep_caterpillar_tree(hal, oracle_bin, tmp_path, seed, n):
+    """A chain of n genomes (every genome has one child): paths of up to n-1 hops.  More than 16 upward hops leave the
+    chained up kernel for one launch per level; 15/16 hops sit on its limit; the way down doubles the launches."""
+    img = str(tmp_path / "deep.hgx")
+    halfix.write_hgx(img, halfix.random_multiseq_alignment(seed, n_genomes=n, max_children=1, root_len=600))
+    al = hal.Alignment.open(img, device=0)
+    ids = {al.genome_name(i): i for i in range(al.num_genomes)}
+    leaf, root = ids["G%d" % (n - 1)], ids["G0"]
+    pairs = [(leaf, root), (root, leaf), (leaf, ids["G2"]), (ids["G%d" % (n - 2)], ids["G%d" % (n - 2 - 16)]),
+             (ids["G%d" % (n - 2)], ids["G%d" % (n - 2 - 15)]), (ids["G%d" % (n - 1)], ids["G%d" % (n - 1 - 17)]), (ids["G5"], ids["G5"])]
+    lines = 0
+    for s, t in pairs:
+        bed = _bed(al, s, 80, seed * 7 + s + t)
+        for nd in (False, True):
+            got = hal.liftover_convert(al, s, bed, t, traverse_dupes=not nd)
+            want = oracle_liftover(oracle_bin, img, al.genome_name(s), al.genome_name(t), bed, tmp_path, no_dupes=nd)
+            assert got == want, (al.genome_name(s), al.genome_name(t), nd)
+            lines += got.count("\n")
+    assert lines > 100
+    # columns through the whole chain
+    for g in (leaf, root, ids["G7"]):
+        name = al.genome_name(g)
+        assert al.alignment_depth(g) == _oracle(oracle_bin, "depth", img, tmp_path, name), name
+        assert al.maf_export(g) == _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", name), name
