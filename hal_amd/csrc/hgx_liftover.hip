@@ -334,9 +334,12 @@ struct hgx_liftover_plan {
     DevBuf fr[6][6], mp[2][6], counters, perQuery, offset, cursor, nOut, outOffset, blockSums, total, grouped, outRecords,
         deferredList, needCap, bigSlot, scratch, bigRecords, classLists, classCounts;
     KernelTimer timer;
+    unsigned long long *pinned = nullptr; // host-pinned copy of the counter block + the record total (one readback per run)
     hgx_liftover_stats stats{};
     hipEvent_t evStart = nullptr, evWalk = nullptr, evEnd = nullptr;
     ~hgx_liftover_plan() {
+        if (pinned)
+            (void)hipHostFree(pinned);
         if (evStart)
             (void)hipEventDestroy(evStart);
         if (evWalk)
@@ -361,6 +364,8 @@ struct hgx_liftover_plan {
             mp[k][0].ensure(sizeof(MappedRec) * (size_t)cap);
         grouped.ensure(sizeof(hgx_record) * (size_t)cap);
         outRecords.ensure(sizeof(hgx_record) * (size_t)cap);
+        if (!pinned)
+            HIP_OK(hipHostMalloc((void **)&pinned, 8 * (CNT_SLOTS + 1)));
         const size_t nq = std::max<size_t>(maxQueries, 1);
         counters.ensure(8 * CNT_SLOTS);
         perQuery.ensure(4 * (nq + 1));
@@ -415,13 +420,17 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
 
     // stage 0
     const DeviceGenome &SG = D.genomes[(size_t)P.src];
+    // `order` = the batch sorted by start position: measured -14 % on the walk kernels (neighbouring lanes share cache
+    // lines) but +0.17 ms in k_finalize / k_scatter (their per-interval atomics then collide on the same lines) and 0.19 ms
+    // for the radix sort itself: no net gain on cfg2, so batches are processed in the order they arrive.
+    const uint32_t *order = nullptr;
     P.timer.begin("k_locate_expand", s, launch);
     if (P.srcTop)
         hipLaunchKernelGGL((k_locate_expand<TopRec<C>>), dim3(GRID), dim3(256), 0, s, (const TopRec<C> *)SG.top, SG.numTop, dS, dE,
-                           dStrand, nq, P.frontier(cur), cap, cnt, kstat() + 0);
+                           dStrand, nq, order, P.frontier(cur), cap, cnt, kstat() + 0);
     else
         hipLaunchKernelGGL((k_locate_expand<BotRec<C>>), dim3(GRID), dim3(256), 0, s, (const BotRec<C> *)SG.bot, SG.numBot, dS, dE,
-                           dStrand, nq, P.frontier(cur), cap, cnt, kstat() + 1);
+                           dStrand, nq, order, P.frontier(cur), cap, cnt, kstat() + 1);
     P.timer.end(s);
     ++launch;
 
@@ -647,8 +656,19 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
                        (const unsigned long long *)generalCount, (const int64_t *)TG.seqStart, (int)TG.numSeq,
                        (hgx_record *)P.grouped.p, (uint32_t *)P.nOut.p, (uint32_t *)P.deferredList.p, (uint32_t *)P.needCap.p, cnt, blocks);
     P.timer.end(s);
-    HIP_OK(hipMemcpyAsync(hostCounters, cnt, 8 * CNT_SLOTS, hipMemcpyDeviceToHost, s));
+    // The common case has no deferred interval: number the output and compact it right away, and read the counters and
+    // the record total back with ONE synchronisation.  runPlan redoes the tail when an interval was deferred.
+    exclusiveScan(P, (const uint32_t *)P.nOut.p, nq, (uint32_t *)P.outOffset.p, (uint32_t *)P.total.p, s);
+    P.timer.begin("k_compact_records", s);
+    hipLaunchKernelGGL(k_compact_records, dim3(GRID), dim3(256), 0, s, (const hgx_record *)P.grouped.p, (const uint32_t *)P.offset.p,
+                       (const hgx_record *)nullptr, (const int32_t *)nullptr, 0, (const uint32_t *)P.nOut.p, (const uint32_t *)P.outOffset.p, nq,
+                       (hgx_record *)P.outRecords.p);
+    P.timer.end(s);
+    HIP_OK(hipEventRecord(P.evEnd, s));
+    HIP_OK(hipMemcpyAsync(P.pinned, cnt, 8 * CNT_SLOTS, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipMemcpyAsync(P.pinned + CNT_SLOTS, P.total.p, 4, hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
+    memcpy(hostCounters, P.pinned, 8 * CNT_SLOTS);
 }
 
 __global__ void k_fill_big_slot(const uint32_t *deferredList, uint32_t nd, int32_t *bigSlot) {
@@ -725,18 +745,21 @@ static void runPlan(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
                 throw std::runtime_error("an interval maps to more than 2^26 pieces; not supported");
         }
     }
-    exclusiveScan(P, (const uint32_t *)P.nOut.p, nq, (uint32_t *)P.outOffset.p, (uint32_t *)P.total.p, s);
-    uint32_t totalRecords = 0;
-    HIP_OK(hipMemcpyAsync(&totalRecords, P.total.p, 4, hipMemcpyDeviceToHost, s));
-    HIP_OK(hipStreamSynchronize(s));
-    P.outRecords.ensure(sizeof(hgx_record) * std::max<size_t>(totalRecords, 1));
-    P.timer.begin("k_compact_records", s);
-    hipLaunchKernelGGL(k_compact_records, dim3(GRID), dim3(256), 0, s, (const hgx_record *)P.grouped.p, (const uint32_t *)P.offset.p,
-                       (const hgx_record *)P.bigRecords.p, nDef ? (const int32_t *)P.bigSlot.p : (const int32_t *)nullptr, bigCap,
-                       (const uint32_t *)P.nOut.p, (const uint32_t *)P.outOffset.p, nq, (hgx_record *)P.outRecords.p);
-    P.timer.end(s);
-    HIP_OK(hipEventRecord(P.evEnd, s));
-    HIP_OK(hipStreamSynchronize(s));
+    uint32_t totalRecords = (uint32_t)(P.pinned[CNT_SLOTS] & 0xFFFFFFFFull);
+    if (nDef > 0) {
+        // the deferred intervals' records live in bigRecords: number and compact again
+        exclusiveScan(P, (const uint32_t *)P.nOut.p, nq, (uint32_t *)P.outOffset.p, (uint32_t *)P.total.p, s);
+        HIP_OK(hipMemcpyAsync(&totalRecords, P.total.p, 4, hipMemcpyDeviceToHost, s));
+        HIP_OK(hipStreamSynchronize(s));
+        P.outRecords.ensure(sizeof(hgx_record) * std::max<size_t>(totalRecords, 1));
+        P.timer.begin("k_compact_records", s);
+        hipLaunchKernelGGL(k_compact_records, dim3(GRID), dim3(256), 0, s, (const hgx_record *)P.grouped.p, (const uint32_t *)P.offset.p,
+                           (const hgx_record *)P.bigRecords.p, (const int32_t *)P.bigSlot.p, bigCap, (const uint32_t *)P.nOut.p,
+                           (const uint32_t *)P.outOffset.p, nq, (hgx_record *)P.outRecords.p);
+        P.timer.end(s);
+        HIP_OK(hipEventRecord(P.evEnd, s));
+        HIP_OK(hipStreamSynchronize(s));
+    }
     P.timer.resolve(true, hc);
     unsigned long long topAll = 0, botAll = 0;
     for (int k = 0; k < MAX_LAUNCHES; ++k) {

@@ -208,8 +208,8 @@ __device__ __forceinline__ uint32_t front_slot(const FrontView *v, uint32_t i, u
 template <typename REC>
 __global__ void __launch_bounds__(256) k_locate_expand(const REC *__restrict__ segs, int64_t numSegs, const int64_t *__restrict__ gStart,
                                                        const int64_t *__restrict__ gEnd, const uint8_t *__restrict__ strand,
-                                                       uint32_t nq, Frontier out, uint32_t cap, unsigned long long *counters,
-                                                       unsigned long long *kstat) {
+                                                       uint32_t nq, const uint32_t *__restrict__ order, Frontier out, uint32_t cap,
+                                                       unsigned long long *counters, unsigned long long *kstat) {
     const uint32_t wavesTotal = (gridDim.x * blockDim.x) >> 6;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     uint32_t derefs = 0;
@@ -217,8 +217,11 @@ __global__ void __launch_bounds__(256) k_locate_expand(const REC *__restrict__ s
     Stage stage;
     stage.init(&stageMem, out, &counters[CNT_FRONT0], counters, cap);
     for (uint32_t base = wave * 64; base < nq; base += wavesTotal * 64) {
-        const uint32_t q = base + lane_id();
-        bool act = q < nq;
+        // `order` (optional): the intervals sorted by start position, so that neighbouring lanes search, expand and later
+        // walk neighbouring segments; a piece keeps its interval's own index, nothing downstream depends on the order
+        const uint32_t qi = base + lane_id();
+        bool act = qi < nq;
+        const uint32_t q = act && order ? order[qi] : qi;
         int64_t gs = 0, ge = -1;
         uint8_t fl = 0;
         bool minus = false;
@@ -858,6 +861,21 @@ __global__ void __launch_bounds__(256) k_ring(const TopRec<C> *__restrict__ top,
 // ---------------------------------------------------------------------------------------------
 // Final: pieces in the target genome -> forward coordinates, and count pieces per query.
 // Positions per SegmentIterator::getStartPosition/getEndPosition (halSegmentIterator.cpp:46-67).
+// runs of equal interval index among the lanes of a wavefront (neighbouring pieces usually belong to one interval, the
+// more so once the batch is sorted): one atomic per run instead of one per lane.  q < 0 marks an idle lane.
+// Returns the run's first lane and its length.
+__device__ __forceinline__ void wave_run_of(int32_t q, int &start, int &len) {
+    const int lane = lane_id();
+    const int32_t prev = __shfl_up(q, 1);
+    const bool leader = lane == 0 || q != prev;
+    const unsigned long long mask = __ballot(leader);
+    const unsigned long long upto = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+    start = 63 - __clzll((long long)(mask & upto));
+    const unsigned long long above = mask & ~upto;
+    const int end = above ? __ffsll((long long)above) - 1 : 64;
+    len = end - start;
+}
+
 template <typename REC>
 __global__ void __launch_bounds__(256) k_finalize(const REC *__restrict__ segs, Frontier in, const unsigned long long *inCount, uint32_t cap,
                                                   Mapped out, uint32_t *__restrict__ perQuery, unsigned long long *counters,
@@ -865,28 +883,36 @@ __global__ void __launch_bounds__(256) k_finalize(const REC *__restrict__ segs, 
     __shared__ FrontView fview;
     const uint32_t n = front_view_init(&fview, inCount, cap);
     uint32_t derefs = 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t p = front_slot(&fview, i, cap);
-        const int32_t idx = in.idx[p];
-        const int32_t so = (int32_t)in.so[p], len = in.len[p];
-        const uint8_t fl = in.flags[p];
-        const int64_t sPos = in.sPos[p];
-        const int32_t q = in.qid[p];
-        int64_t lo;
-        if (!(fl & F_TREV))
-            lo = (int64_t)segs[idx].start + so;
-        else
-            lo = (int64_t)segs[idx + 1].start - so - len;
-        ++derefs;
-        MappedRec r;
-        r.tLo = lo;
-        r.sLo = !(fl & F_SREV) ? sPos : sPos - len + 1;
-        r.len = len;
-        r.qid = q;
-        r.flags = fl;
-        r._pad = 0;
-        out.rec[i] = r;
-        atomicAdd(&perQuery[q], 1u);
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += stride) { // whole wavefronts iterate together
+        const uint32_t i = base + threadIdx.x;
+        int32_t q = -1;
+        if (i < n) {
+            const uint32_t p = front_slot(&fview, i, cap);
+            const int32_t idx = in.idx[p];
+            const int32_t so = (int32_t)in.so[p], len = in.len[p];
+            const uint8_t fl = in.flags[p];
+            const int64_t sPos = in.sPos[p];
+            q = in.qid[p];
+            int64_t lo;
+            if (!(fl & F_TREV))
+                lo = (int64_t)segs[idx].start + so;
+            else
+                lo = (int64_t)segs[idx + 1].start - so - len;
+            ++derefs;
+            MappedRec r;
+            r.tLo = lo;
+            r.sLo = !(fl & F_SREV) ? sPos : sPos - len + 1;
+            r.len = len;
+            r.qid = q;
+            r.flags = fl;
+            r._pad = 0;
+            out.rec[i] = r;
+        }
+        int start, len;
+        wave_run_of(q, start, len);
+        if (q >= 0 && lane_id() == start)
+            atomicAdd(&perQuery[q], (uint32_t)len);
     }
     wave_count_add(&kstat[isTop ? 0 : 1], derefs);
     if (blockIdx.x == 0 && threadIdx.x == 0)
@@ -897,12 +923,29 @@ __global__ void __launch_bounds__(256) k_finalize(const REC *__restrict__ segs, 
 static __global__ void __launch_bounds__(256) k_scatter(Mapped in, const unsigned long long *inCount, uint32_t cap, const uint32_t *__restrict__ offset,
                                                  uint32_t *__restrict__ cursor, Mapped out) {
     const uint32_t n = (uint32_t)min((unsigned long long)cap, *inCount); // CNT_MAPPED: dense count written by k_finalize
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const MappedRec r = in.rec[i];
-        const uint32_t s = offset[r.qid] + atomicAdd(&cursor[r.qid], 1u);
-        out.rec[s] = r;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += stride) {
+        const uint32_t i = base + threadIdx.x;
+        MappedRec r;
+        r.qid = -1;
+        if (i < n)
+            r = in.rec[i];
+        int start, len;
+        wave_run_of(r.qid, start, len);
+        uint32_t b = 0;
+        if (r.qid >= 0 && lane_id() == start)
+            b = atomicAdd(&cursor[r.qid], (uint32_t)len);
+        b = __shfl(b, start);
+        if (i < n)
+            out.rec[offset[r.qid] + b + (uint32_t)(lane_id() - start)] = r;
     }
 }
+
+static __global__ void __launch_bounds__(256) k_iota(uint32_t *__restrict__ v, uint32_t n) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        v[i] = i;
+}
+
 
 // ---- exclusive scan of uint32 (three small kernels; n up to 2^32-1) ----
 static constexpr int SCAN_BLOCK = 1024; // elements per block (256 threads x 4)
