@@ -149,8 +149,20 @@ def main():
             return nrec, (sum(prev[1]) if prev else nrec * world)
         return nrec, nrec
 
+    # settle: the first runs of a fresh process pay for lazy code-object loads, event pools and workspace growth (observed:
+    # 5-12 ms for the first one or two runs against 2.9 ms steady state); run untimed until two consecutive runs agree
+    prev = None
+    for _ in range(12):
+        t_s = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t_s
+        if prev is not None and abs(dt - prev) <= 0.05 * prev:
+            break
+        prev = dt
     for _ in range(args.warmup):
         step()
+    plan.set_timing(2)  # kernel events accumulate over the timed steps and are read once, after the timed region
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -162,16 +174,16 @@ def main():
         st = plan.stats()
         walk_ms += st["walk_ms"]
         total_ms += st["total_ms"]
-        for k, v in plan.kernel_times().items():
-            a = kt_acc.setdefault(k, {"ms": 0.0, "launches": 0})
-            a["ms"] += v["ms"]
-            a["launches"] += v["launches"]
     if world > 1:
         collator.wait(trim=False)  # the last exchange belongs to the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    kt_total = plan.kernel_times()
+    for k, v in kt_total.items():
+        kt_acc[k] = {"ms": v["ms"], "launches": v["launches"]}
+    plan.set_timing(1)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -186,7 +198,7 @@ def main():
         Q, T, B, R = st["queries"], st["top_derefs"], st["bottom_derefs"], st["records"]
         alg_total = 24 * Q + 25 * T + 25 * B + 40 * R  # SURVEY 8(d), per step
         kern_ms_total = sum(v["ms"] for v in kt_acc.values()) / args.steps
-        per_kernel_alg = plan_kernel_bytes(plan, st)
+        per_kernel_alg = plan_kernel_bytes(kt_total, st, args.steps)
         dom_bytes_per_launch = per_kernel_alg.get(dom_name, 0.0)
         dom_avg_ms = dom_ms / max(1, dom_launches)
         achieved = dom_bytes_per_launch / (dom_avg_ms * 1e-3) / 1e9 if dom_avg_ms > 0 else 0.0
@@ -273,21 +285,21 @@ def main():
         dist.destroy_process_group()
 
 
-def plan_kernel_bytes(plan, st):
+def plan_kernel_bytes(kt, st, steps):
     """Algorithmic bytes per launch of each kernel: 25 B per segment record logically
-    dereferenced by that kernel, 24 B per query for the locate kernel, 40 B per record written by the finishing kernel."""
-    kt = plan.kernel_times()
+    dereferenced by that kernel, 24 B per query for the locate kernel, 40 B per record written by the finishing kernel.
+    kt: kernel times and dereference counts accumulated over `steps` runs; st: the counts of one run."""
     out = {}
     for name, v in kt.items():
         launches = max(1, v["launches"])
         t, b = v.get("top_derefs", 0), v.get("bot_derefs", 0)
         bytes_ = 25.0 * (t + b)
         if name == "k_locate_expand":
-            bytes_ += 24.0 * st["queries"]
+            bytes_ += 24.0 * st["queries"] * steps
         if name in ("k_finish_lds", "k_finish_big"):
-            bytes_ += 40.0 * st["records"]
+            bytes_ += 40.0 * st["records"] * steps
         if name == "k_compact_records":
-            bytes_ += 80.0 * st["records"]
+            bytes_ += 80.0 * st["records"] * steps
         out[name] = bytes_ / launches
     return out
 

@@ -358,6 +358,11 @@ class LiftoverPlan:
         lib.hgx_liftover_last_stats(self._p, C.byref(s))
         return {k: getattr(s, k) for k, _ in hgx_liftover_stats._fields_}
 
+    def set_timing(self, mode):
+        """0: no per-kernel events; 1: kernel_times() covers the last run (default); 2: every run since the previous read."""
+        if lib.hgx_liftover_plan_set_timing(self._p, mode) != 0:
+            raise HgxError("set_timing failed")
+
     def kernel_times(self):
         import json
         js = C.c_void_p()

@@ -327,15 +327,30 @@ int hgx_liftover_copy_records(const hgx_liftover_plan *p, void *d_dst, size_t n_
     HGX_CATCH
 }
 
-int hgx_liftover_kernel_times(const hgx_liftover_plan *p, char **json) {
+int hgx_liftover_kernel_times(hgx_liftover_plan *p, char **json) {
     if (!p || !json)
         return HGX_ERR;
-    const std::string s = liftoverPlanKernelTimes(p);
-    *json = (char *)malloc(s.size() + 1);
-    if (!*json)
+    try {
+        const std::string s = liftoverPlanKernelTimes(p);
+        *json = (char *)malloc(s.size() + 1);
+        if (!*json)
+            return HGX_ERR;
+        memcpy(*json, s.c_str(), s.size() + 1);
+        return HGX_OK;
+    } catch (...) {
         return HGX_ERR;
-    memcpy(*json, s.c_str(), s.size() + 1);
-    return HGX_OK;
+    }
+}
+
+int hgx_liftover_plan_set_timing(hgx_liftover_plan *p, int mode) {
+    if (!p)
+        return HGX_ERR;
+    try {
+        liftoverPlanSetTiming(p, mode);
+        return HGX_OK;
+    } catch (...) {
+        return HGX_ERR;
+    }
 }
 
 int hgx_liftover_convert(hgx_alignment *h, int src, const char *bed_text, size_t bed_len, int tgt, int bed_type, int traverse_dupes,

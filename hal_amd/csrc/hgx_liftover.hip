@@ -265,17 +265,30 @@ struct KernelTimer {
         std::string name;
         hipEvent_t a, b;
         int launch; // index of this launch's {top, bottom} deref counters, or -1
+        unsigned long long top = 0, bot = 0;
     };
     struct Total {
         double ms = 0;
         int launches = 0;
         unsigned long long top = 0, bot = 0;
     };
+    // mode 0: no events at all; 1: the kernel times of the last run (default); 2: accumulated over all runs since the last
+    // read.  Elapsed times are only queried when somebody asks (hipEventElapsedTime per launch is host time inside a step).
+    int mode = 1;
     std::vector<Rec> recs;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
-    size_t used = 0;
-    std::map<std::string, Total> totals; // per kernel name, last run
+    size_t used = 0, runStart = 0;
+    std::map<std::string, Total> totals;
+    void beginRun() {
+        if (mode != 2) { // forget the previous run
+            recs.clear();
+            used = 0;
+        }
+        runStart = recs.size();
+    }
     void begin(const char *name, hipStream_t s, int launch = -1) {
+        if (mode == 0)
+            return;
         if (used == pool.size()) {
             hipEvent_t a, b;
             HIP_OK(hipEventCreate(&a));
@@ -287,24 +300,38 @@ struct KernelTimer {
         HIP_OK(hipEventRecord(recs.back().a, s));
     }
     void end(hipStream_t s) {
+        if (mode == 0)
+            return;
         HIP_OK(hipEventRecord(recs.back().b, s));
     }
-    void resolve(bool reset, const unsigned long long *hostCounters = nullptr) {
-        if (reset)
-            totals.clear();
+    void dropRun() { // the run is repeated (workspace regrown)
+        recs.resize(runStart);
+        used = runStart;
+    }
+    void endRun(const unsigned long long *hostCounters) { // keep this run's dereference counts with its launches
+        for (size_t i = runStart; i < recs.size(); ++i)
+            if (recs[i].launch >= 0) {
+                recs[i].top = hostCounters[CNT_KSTAT0 + 2 * recs[i].launch];
+                recs[i].bot = hostCounters[CNT_KSTAT0 + 2 * recs[i].launch + 1];
+            }
+    }
+    const std::map<std::string, Total> &read() { // resolves what is pending; in mode 2 the window restarts
+        totals.clear();
         for (Rec &r : recs) {
             float ms = 0;
             HIP_OK(hipEventElapsedTime(&ms, r.a, r.b));
             Total &t = totals[r.name];
             t.ms += ms;
             t.launches += 1;
-            if (hostCounters && r.launch >= 0) {
-                t.top += hostCounters[CNT_KSTAT0 + 2 * r.launch];
-                t.bot += hostCounters[CNT_KSTAT0 + 2 * r.launch + 1];
-            }
+            t.top += r.top;
+            t.bot += r.bot;
         }
-        recs.clear();
-        used = 0;
+        if (mode == 2) {
+            recs.clear();
+            used = 0;
+            runStart = 0;
+        }
+        return totals;
     }
     ~KernelTimer() {
         for (auto &p : pool) {
@@ -548,9 +575,9 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
                 const int yBuf = intoR ? rBuf : (xBuf == aBuf ? bBuf : aBuf);
                 const int yLevel = intoR ? rLevel : nextLevel++;
                 P.timer.begin("k_down_ring", s, launch);
-                hipLaunchKernelGGL((k_down_ring<C>), dim3(GRID), dim3(256), 0, s, (const int32_t *)PG.childEnc[(size_t)slot],
+                hipLaunchKernelGGL((k_down_ring<C, false>), dim3(GRID), dim3(256), 0, s, (const int32_t *)PG.childEnc[(size_t)slot],
                                    (const TopRec<C> *)CG.top, P.frontier(xBuf), cntOf(xLevel), cap, P.frontier(yBuf), cntOf(yLevel), minLen,
-                                   0, cnt, kstat());
+                                   0, cnt, kstat(), (uint32_t *)nullptr);
                 P.timer.end(s);
                 ++launch;
                 dBuf = yBuf;
@@ -571,6 +598,7 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
         curTop = true;
         curGenome = P.mrca;
     }
+    bool finalized = false; // the last walk kernel already produced final pieces and the per-interval counts
     if (P.tgt != P.mrca) {
         if (curTop) { // source is the MRCA itself and is walked through its top tiling
             const DeviceGenome &G = D.genomes[(size_t)curGenome];
@@ -589,9 +617,16 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
             const DeviceGenome &PG = D.genomes[(size_t)parent];
             const DeviceGenome &CG = D.genomes[(size_t)child];
             P.timer.begin("k_down_ring", s, launch);
-            hipLaunchKernelGGL((k_down_ring<C>), dim3(GRID), dim3(256), 0, s, (const int32_t *)PG.childEnc[(size_t)slot],
-                               (const TopRec<C> *)CG.top, P.frontier(cur), inCnt(), cap, P.frontier(cur ^ 1), outCnt(), minLen,
-                               (int)(P.opts.traverse_dupes != 0), cnt, kstat());
+            if (child == P.tgt) {
+                hipLaunchKernelGGL((k_down_ring<C, true>), dim3(GRID), dim3(256), 0, s, (const int32_t *)PG.childEnc[(size_t)slot],
+                                   (const TopRec<C> *)CG.top, P.frontier(cur), inCnt(), cap, P.frontier(cur ^ 1), outCnt(), minLen,
+                                   (int)(P.opts.traverse_dupes != 0), cnt, kstat(), (uint32_t *)P.perQuery.p);
+                finalized = true;
+            } else {
+                hipLaunchKernelGGL((k_down_ring<C, false>), dim3(GRID), dim3(256), 0, s, (const int32_t *)PG.childEnc[(size_t)slot],
+                                   (const TopRec<C> *)CG.top, P.frontier(cur), inCnt(), cap, P.frontier(cur ^ 1), outCnt(), minLen,
+                                   (int)(P.opts.traverse_dupes != 0), cnt, kstat(), (uint32_t *)nullptr);
+            }
             P.timer.end(s);
             ++launch;
             cur ^= 1;
@@ -613,6 +648,7 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
     }
     // final pieces live in the target genome
     const DeviceGenome &TG = D.genomes[(size_t)P.tgt];
+    if (!finalized) {
     P.timer.begin("k_finalize", s, launch);
     if (curTop)
         hipLaunchKernelGGL((k_finalize<TopRec<C>>), dim3(GRID), dim3(256), 0, s, (const TopRec<C> *)TG.top, P.frontier(cur), inCnt(),
@@ -621,12 +657,17 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
         hipLaunchKernelGGL((k_finalize<BotRec<C>>), dim3(GRID), dim3(256), 0, s, (const BotRec<C> *)TG.bot, P.frontier(cur), inCnt(),
                            cap, P.mapped(0), (uint32_t *)P.perQuery.p, cnt, kstat(), 0);
     P.timer.end(s);
+    }
     HIP_OK(hipEventRecord(P.evWalk, s));
 
     exclusiveScan(P, (const uint32_t *)P.perQuery.p, nq, (uint32_t *)P.offset.p, (uint32_t *)P.total.p, s);
     P.timer.begin("k_scatter", s);
-    hipLaunchKernelGGL(k_scatter, dim3(GRID), dim3(256), 0, s, P.mapped(0), cnt + CNT_MAPPED, cap, (const uint32_t *)P.offset.p,
-                       (uint32_t *)P.cursor.p, P.mapped(1));
+    if (finalized)
+        hipLaunchKernelGGL(k_scatter_front, dim3(GRID), dim3(256), 0, s, P.frontier(cur), inCnt(), cap, (const uint32_t *)P.offset.p,
+                           (uint32_t *)P.cursor.p, P.mapped(1), cnt);
+    else
+        hipLaunchKernelGGL(k_scatter, dim3(GRID), dim3(256), 0, s, P.mapped(0), cnt + CNT_MAPPED, cap, (const uint32_t *)P.offset.p,
+                           (uint32_t *)P.cursor.p, P.mapped(1));
     P.timer.end(s);
     // finishing: register-resident fast path per size class (each kernel picks the intervals of its class),
     // general LDS path for the rest
@@ -694,6 +735,7 @@ static void runPlan(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
         *nOut = 0;
         return;
     }
+    P.timer.beginRun();
     for (;;) {
         runOnce<C>(P, n, dS, dE, dStrand, s, hc);
         if (!hc[CNT_OVERFLOW])
@@ -711,7 +753,7 @@ static void runPlan(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
         need = std::max<unsigned long long>(need + need / 4, 2ull * P.cap);
         if (need >= (1ull << 32))
             throw std::runtime_error("liftover batch expands to more than 2^32 pieces; submit smaller batches");
-        P.timer.resolve(true);
+        P.timer.dropRun();
         P.allocate((uint32_t)need);
     }
     const uint32_t nq = (uint32_t)n;
@@ -760,7 +802,7 @@ static void runPlan(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
         HIP_OK(hipEventRecord(P.evEnd, s));
         HIP_OK(hipStreamSynchronize(s));
     }
-    P.timer.resolve(true, hc);
+    P.timer.endRun(hc);
     unsigned long long topAll = 0, botAll = 0;
     for (int k = 0; k < MAX_LAUNCHES; ++k) {
         topAll += hc[CNT_KSTAT0 + 2 * k];
@@ -880,10 +922,22 @@ void liftoverPlanCopyRecords(const hgx_liftover_plan *p, void *dDst, size_t nRec
     HIP_OK(hipStreamSynchronize((hipStream_t)stream));
 }
 
-std::string liftoverPlanKernelTimes(const hgx_liftover_plan *p) {
+void liftoverPlanSetTiming(hgx_liftover_plan *p, int mode) {
+    if (mode < 0 || mode > 2)
+        throw std::runtime_error("timing mode must be 0 (off), 1 (last run) or 2 (accumulate)");
+    HIP_OK(hipSetDevice(p->device));
+    p->timer.read(); // closes whatever was pending
+    p->timer.recs.clear();
+    p->timer.used = 0;
+    p->timer.runStart = 0;
+    p->timer.mode = mode;
+}
+
+std::string liftoverPlanKernelTimes(hgx_liftover_plan *p) {
+    HIP_OK(hipSetDevice(p->device));
     std::string s = "{";
     bool first = true;
-    for (auto &kv : p->timer.totals) {
+    for (auto &kv : p->timer.read()) {
         if (!first)
             s += ", ";
         first = false;

@@ -12,7 +12,8 @@ void runLiftoverPlan(hgx_liftover_plan *p, size_t n, const int64_t *dStart, cons
                      const hgx_record **dOut, size_t *nOut);
 void destroyLiftoverPlan(hgx_liftover_plan *p);
 const hgx_liftover_stats &liftoverPlanStats(const hgx_liftover_plan *p);
-std::string liftoverPlanKernelTimes(const hgx_liftover_plan *p);
+std::string liftoverPlanKernelTimes(hgx_liftover_plan *p);
+void liftoverPlanSetTiming(hgx_liftover_plan *p, int mode);
 void liftoverPlanCopyRecords(const hgx_liftover_plan *p, void *dDst, size_t nRecords, void *stream);
 void liftoverBatchHost(hgx_alignment *h, int src, int tgt, size_t n, const hgx_interval *iv, const hgx_liftover_opts &opts,
                        std::vector<hgx_record> &out, hgx_liftover_stats *stats);

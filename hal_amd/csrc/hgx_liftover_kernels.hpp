@@ -102,6 +102,8 @@ struct Stage {
     unsigned long long *counters;
     uint32_t segCap;              // capacity of one segment
     unsigned long long segBase;   // first slot of this block's segment
+    uint32_t *perQuery = nullptr; // final pieces: per-interval count of the pieces actually stored (an overflowing append drops
+                                  // pieces; counting at emit time would leave offsets pointing past the buffers)
 
     // oc: the NSEG counters of the output frontier; cp: total capacity of the frontier buffers
     __device__ __forceinline__ void init(StageMem *mem, const Frontier &o, unsigned long long *oc, unsigned long long *c, uint32_t cp) {
@@ -134,6 +136,8 @@ struct Stage {
                     out.so[slot] = m->so[base + i];
                     out.len[slot] = m->len[base + i];
                     out.flags[slot] = m->fl[base + i];
+                    if (perQuery)
+                        atomicAdd(&perQuery[m->qid[base + i]], 1u);
                 } else {
                     counters[CNT_OVERFLOW] = 1;
                 }
@@ -615,11 +619,16 @@ __global__ void __launch_bounds__(256) k_up_chain(UpTables<C> tabs, Frontier in,
 // then, when traversing duplications, the paralogy ring of that top segment (mapSelf top branch,
 // halSegmentMapper.cpp:265-288; toNextParalogy, halTopSegmentIterator.cpp:99-107: follow paralogyIndex,
 // flip strand iff the two segments' parentReversed differ; emit-then-test do/while).
-template <typename C>
+// FINAL (the hop into the target genome): the pieces leave as final mapped pieces instead of (index, offset) pieces — the
+// child's top record is in registers anyway for the ring walk, so the forward target coordinate costs nothing (one more
+// load for a reversed piece), and the per-interval piece count is taken here; this replaces a k_finalize pass over the
+// frontier (29 B written and read back per piece plus a gather).  In that form a frontier entry carries the forward
+// source start in sPos and the forward target start in so (k_scatter_front turns it into a MappedRec).
+template <typename C, bool FINAL>
 __global__ void __launch_bounds__(256) k_down_ring(const int32_t *__restrict__ childEnc, const TopRec<C> *__restrict__ ctop, Frontier in,
                                                    const unsigned long long *inCount, uint32_t cap, Frontier out,
                                                    unsigned long long *outCount, int64_t minLength, int doDupes,
-                                                   unsigned long long *counters, unsigned long long *kstat) {
+                                                   unsigned long long *counters, unsigned long long *kstat, uint32_t *__restrict__ perQuery) {
     __shared__ FrontView fview;
     const uint32_t n = front_view_init(&fview, inCount, cap);
     const uint32_t wavesTotal = (gridDim.x * blockDim.x) >> 6;
@@ -628,6 +637,8 @@ __global__ void __launch_bounds__(256) k_down_ring(const int32_t *__restrict__ c
     __shared__ StageMem stageMem;
     Stage stage;
     stage.init(&stageMem, out, outCount, counters, cap);
+    if (FINAL)
+        stage.perQuery = perQuery;
     for (uint32_t base = wave * 64; base < n; base += wavesTotal * 64) {
         const uint32_t li = base + lane_id();
         const uint32_t i = li < n ? front_slot(&fview, li, cap) : 0;
@@ -653,8 +664,29 @@ __global__ void __launch_bounds__(256) k_down_ring(const int32_t *__restrict__ c
         }
         bool haveRec = false;
         int32_t rcPar = -1, rcEnc = 0; // paralogy link and parentEnc of `cur`
+        int64_t rcStart = 0;
+        if (FINAL && act) {
+            const TopRec<C> rc = ctop[cur];
+            rcPar = rc.paralogy;
+            rcEnc = rc.parentEnc;
+            rcStart = (int64_t)rc.start;
+            haveRec = true;
+            if (doDupes)
+                ++topDerefs; // the ring walk's look at the segment (counted there in the two-pass form)
+        }
         while (__any(act)) {
-            stage.emit(act, qid, sPos, cur, so, len, fl);
+            if (FINAL) {
+                int64_t tLo = 0, sLo = 0;
+                if (act) {
+                    // SegmentIterator::getStartPosition / getEndPosition in forward coordinates (halSegmentIterator.cpp:46-67)
+                    tLo = !(fl & F_TREV) ? rcStart + so : (int64_t)ctop[cur + 1].start - so - len;
+                    sLo = !(fl & F_SREV) ? sPos : sPos - len + 1;
+                    ++topDerefs; // k_finalize's share
+                }
+                stage.emit(act, qid, sLo, 0, tLo, len, fl);
+            } else {
+                stage.emit(act, qid, sPos, cur, so, len, fl);
+            }
             if (act) {
                 if (!doDupes) {
                     act = false;
@@ -676,6 +708,7 @@ __global__ void __launch_bounds__(256) k_down_ring(const int32_t *__restrict__ c
                         cur = rcPar;
                         rcPar = nr.paralogy;
                         rcEnc = nr.parentEnc;
+                        rcStart = (int64_t)nr.start;
                         act = rcPar >= 0 && cur != t0; // while (hasNextParalogy && index != start)
                     }
                 }
@@ -939,6 +972,39 @@ static __global__ void __launch_bounds__(256) k_scatter(Mapped in, const unsigne
         if (i < n)
             out.rec[offset[r.qid] + b + (uint32_t)(lane_id() - start)] = r;
     }
+}
+
+// the same from a frontier of FINAL pieces (k_down_ring<C, true>)
+static __global__ void __launch_bounds__(256) k_scatter_front(Frontier in, const unsigned long long *inCount, uint32_t cap,
+                                                              const uint32_t *__restrict__ offset, uint32_t *__restrict__ cursor, Mapped out,
+                                                              unsigned long long *counters) {
+    __shared__ FrontView fview;
+    const uint32_t n = front_view_init(&fview, inCount, cap);
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += stride) {
+        const uint32_t i = base + threadIdx.x;
+        MappedRec r;
+        r.qid = -1;
+        if (i < n) {
+            const uint32_t p = front_slot(&fview, i, cap);
+            r.tLo = in.so[p];
+            r.sLo = in.sPos[p];
+            r.len = in.len[p];
+            r.qid = in.qid[p];
+            r.flags = in.flags[p];
+            r._pad = 0;
+        }
+        int start, len;
+        wave_run_of(r.qid, start, len);
+        uint32_t b = 0;
+        if (r.qid >= 0 && lane_id() == start)
+            b = atomicAdd(&cursor[r.qid], (uint32_t)len);
+        b = __shfl(b, start);
+        if (i < n)
+            out.rec[offset[r.qid] + b + (uint32_t)(lane_id() - start)] = r;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        counters[CNT_MAPPED] = n;
 }
 
 static __global__ void __launch_bounds__(256) k_iota(uint32_t *__restrict__ v, uint32_t n) {

@@ -140,9 +140,12 @@ typedef struct hgx_liftover_stats {
     double walk_ms, total_ms;
 } hgx_liftover_stats;
 int hgx_liftover_last_stats(const hgx_liftover_plan *p, hgx_liftover_stats *out);
-/* Per-kernel device time of the last run, measured with HIP events on the run's stream, as a JSON
- * object {"kernel": {"ms": total, "launches": n}, ...}; release *json with hgx_free. */
-int hgx_liftover_kernel_times(const hgx_liftover_plan *p, char **json);
+/* Per-kernel device time, measured with HIP events on the run's stream, as a JSON object
+ * {"kernel": {"ms": total, "launches": n, "top_derefs": t, "bot_derefs": b}, ...}; release *json with hgx_free.
+ * hgx_liftover_plan_set_timing chooses what it covers: 1 = the last run (default), 2 = every run since the previous
+ * read (for a benchmark loop: the elapsed-time queries then happen once, outside the loop), 0 = no events at all. */
+int hgx_liftover_kernel_times(hgx_liftover_plan *p, char **json);
+int hgx_liftover_plan_set_timing(hgx_liftover_plan *p, int mode);
 
 /* Copy the plan-owned records of the last run into caller-owned device memory (device to device, on hip_stream). */
 int hgx_liftover_copy_records(const hgx_liftover_plan *p, void *d_dst, size_t n_records, void *hip_stream, char **err);
