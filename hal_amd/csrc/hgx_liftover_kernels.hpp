@@ -457,7 +457,8 @@ __device__ __forceinline__ int64_t make_anchor(int64_t sPos, int64_t lo, int64_t
 // 60 at ~630 cycles each, TCP pending-stall ~75 % of the time — so the cost of a step is its number of L1 requests,
 // and a step is exactly one 16-byte gather (ChainRec).  Tried and measured slower: a register window of 4-5 records
 // per step (more requests per step than scan steps saved), and 4 lanes per piece sharing one 64-byte request (fewer
-// requests, but four times the wave-steps made it issue-bound: 3.1 ms against 1.2 ms).
+// requests, but four times the wave-steps made it issue-bound: 3.1 ms against 1.2 ms), and fetching the right-hand
+// neighbour together with the record when a piece has just arrived at a level, to save the first scan step (1.23 ms against 1.20 ms).
 static inline size_t upChainLdsBytes(int hops) {
     const int slots = hops - 1 > 1 ? hops - 2 : 1;
     return (size_t)slots * 256 * (8 + 8 + 4 + 1);
