@@ -5,6 +5,7 @@
 #include <chrono>
 #include <climits>
 #include <cstdlib>
+#include <charconv>
 #include <cstring>
 
 namespace hgx {
@@ -277,11 +278,47 @@ bool MafExport::referenceIsAllGaps() const {
 }
 
 // halMafBlock.cpp:454-458, 499-519
+namespace {
+// packed byte -> its two bases as text; reversed: low nibble first (walking the reverse strand)
+struct PairTable {
+    uint16_t v[256];
+    PairTable(const char *map, bool reversed) {
+        for (int b = 0; b < 256; ++b) {
+            const char hi = map[b >> 4], lo = map[b & 15];
+            char two[2] = {reversed ? lo : hi, reversed ? hi : lo};
+            memcpy(&v[b], two, 2);
+        }
+    }
+};
+} // namespace
+
 void MafExport::printBlock(std::ostream &os) const {
-    auto printEntry = [&](const Entry &e, int64_t start) {
-        os << "s\t" << e.name << '\t' << start << '\t' << e.length << '\t' << e.strand << '\t' << e.srcLength << '\t' << e.sequence << '\n';
+    // MafBlock's operator<< (halMafBlock.cpp:499-520) prints field by field through the stream; formatting a block into
+    // one buffer and writing it once is the same bytes at a fifth of the cost (the stream formatting was half of hal2maf's
+    // run time here)
+    static thread_local std::string buf;
+    buf.clear();
+    auto num = [&](int64_t v) {
+        char tmp[24];
+        auto r = std::to_chars(tmp, tmp + sizeof tmp, v);
+        buf.append(tmp, (size_t)(r.ptr - tmp));
     };
-    os << "a\n";
+    auto printEntry = [&](const Entry &e, int64_t start) {
+        buf += "s\t";
+        buf += e.name;
+        buf += '\t';
+        num(start);
+        buf += '\t';
+        num(e.length);
+        buf += '\t';
+        buf += e.strand;
+        buf += '\t';
+        num(e.srcLength);
+        buf += '\t';
+        buf += e.sequence;
+        buf += '\n';
+    };
+    buf += "a\n";
     if (_reference->start == NULL_INDEX) {
         if (_refIndex != NULL_INDEX)
             printEntry(*_reference, _refIndex);
@@ -291,6 +328,7 @@ void MafExport::printBlock(std::ostream &os) const {
     for (auto e = _entries.begin(); e != _entries.end(); ++e)
         if (e->second->start != NULL_INDEX && e->second != _reference)
             printEntry(*e->second, e->second->start);
+    os.write(buf.data(), (std::streamsize)buf.size());
 }
 
 // halMafExport.cpp:25-88
@@ -461,20 +499,37 @@ void MafExport::convertSequence(std::ostream &mafStream, hgx_alignment *alignmen
             for (; e != _entries.end(); ++e)
                 pairs.push_back(Pair{e->second, nullptr});
         };
+        double tCan = 0, tPrint = 0, tInit = 0, tAppend = 0, tMap = 0, tPairs = 0, tBulk = 0;
+        const bool timing = getenv("HGX_MAF_TIMING") != nullptr;
+        auto now = [&]() { return timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point(); };
+        auto since = [&](std::chrono::steady_clock::time_point t0) {
+            return timing ? std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() : 0.0;
+        };
         auto stepColumn = [&](int64_t refPos) { // one column through the reference's per-column logic
             if (appendCount == 0) {
                 initBlock(colMap, refKey, refPos);
-            } else if (!canAppendColumn(colMap)) {
-                if (numBlocks++ % 1000 == 0)
-                    for (auto it = colMap.begin(); it != colMap.end();)
-                        it = it->second.empty() ? colMap.erase(it) : std::next(it);
-                if (_keepEmptyRefBlocks || !referenceIsAllGaps()) {
-                    printBlock(mafStream);
-                    mafStream << '\n';
+            } else {
+                auto t0 = now();
+                const bool can = canAppendColumn(colMap);
+                tCan += since(t0);
+                if (!can) {
+                    if (numBlocks++ % 1000 == 0)
+                        for (auto it = colMap.begin(); it != colMap.end();)
+                            it = it->second.empty() ? colMap.erase(it) : std::next(it);
+                    if (_keepEmptyRefBlocks || !referenceIsAllGaps()) {
+                        t0 = now();
+                        printBlock(mafStream);
+                        mafStream << '\n';
+                        tPrint += since(t0);
+                    }
+                    t0 = now();
+                    initBlock(colMap, refKey, refPos);
+                    tInit += since(t0);
                 }
-                initBlock(colMap, refKey, refPos);
             }
+            auto t1 = now();
             appendColumn(colMap);
+            tAppend += since(t1);
             ++appendCount;
         };
         for (int64_t done = 0; done < length;) {
@@ -486,16 +541,21 @@ void MafExport::convertSequence(std::ostream &mafStream, hgx_alignment *alignmen
             size_t hk = 0;
             for (int64_t i = 0; i < n;) {
                 // head column i: its rows come from the GPU
+                auto tm0 = now();
                 curRows.assign(headRows.begin() + headOff[hk], headRows.begin() + headOff[hk + 1]);
                 ++hk;
                 rebuildColMap();
+                tMap += since(tm0);
                 stepColumn(startPosition + done + i);
                 int64_t run = 0; // continuation columns that follow
                 while (i + 1 + run < n && !head[(size_t)(i + 1 + run)])
                     ++run;
                 int64_t col = i + 1;
                 while (run > 0) {
+                    auto tp0 = now();
                     buildPairs();
+                    tPairs += since(tp0);
+                    auto tb0 = now();
                     int64_t t = run;
                     for (const Pair &pr : pairs) {
                         if (!pr.row)
@@ -518,22 +578,32 @@ void MafExport::convertSequence(std::ostream &mafStream, hgx_alignment *alignmen
                             const std::vector<uint8_t> &d = alignment->img.genomes[(size_t)r.genome].dna;
                             if (d.empty()) {
                                 memset(dst, 'N', (size_t)t);
-                            } else if (!r.rev) { // dnaUnpack (halCommon.h:187-190) over a forward run
+                            } else if (!r.rev) { // dnaUnpack (halCommon.h:187-190) over a forward run, two bases per packed byte
                                 static const char fwd[17] = "acgtn\0\0\0ACGTN\0\0\0";
+                                static const PairTable fwd2(fwd, false);
                                 const uint8_t *pk = d.data();
-                                int64_t p0 = r.pos + 1;
-                                for (int64_t k = 0; k < t; ++k, ++p0) {
-                                    const uint8_t b = pk[p0 >> 1];
-                                    dst[k] = fwd[(p0 & 1) ? (b & 0x0F) : (b >> 4)];
+                                int64_t p0 = r.pos + 1, k = 0;
+                                if (k < t && (p0 & 1)) { // odd start: low nibble of its byte
+                                    dst[k++] = fwd[pk[p0 >> 1] & 0x0F];
+                                    ++p0;
                                 }
+                                for (; k + 1 < t; k += 2, p0 += 2)
+                                    memcpy(dst + k, &fwd2.v[pk[p0 >> 1]], 2);
+                                if (k < t)
+                                    dst[k] = fwd[pk[p0 >> 1] >> 4];
                             } else { // reverse strand: walk left, complemented (reverseComplement, halCommon.h:45-75)
                                 static const char rc[17] = "tgcan\0\0\0TGCAN\0\0\0";
+                                static const PairTable rc2(rc, true);
                                 const uint8_t *pk = d.data();
-                                int64_t p0 = r.pos - 1;
-                                for (int64_t k = 0; k < t; ++k, --p0) {
-                                    const uint8_t b = pk[p0 >> 1];
-                                    dst[k] = rc[(p0 & 1) ? (b & 0x0F) : (b >> 4)];
+                                int64_t p0 = r.pos - 1, k = 0;
+                                if (k < t && !(p0 & 1)) { // even start: high nibble of its byte, its partner lies to the right
+                                    dst[k++] = rc[pk[p0 >> 1] >> 4];
+                                    --p0;
                                 }
+                                for (; k + 1 < t; k += 2, p0 -= 2) // p0 odd: (low nibble, then high nibble) of one byte
+                                    memcpy(dst + k, &rc2.v[pk[p0 >> 1]], 2);
+                                if (k < t)
+                                    dst[k] = rc[pk[p0 >> 1] & 0x0F];
                             }
                             pr.e->length += t;
                             r.pos += r.rev ? -t : t;
@@ -543,6 +613,7 @@ void MafExport::convertSequence(std::ostream &mafStream, hgx_alignment *alignmen
                         run -= t;
                         col += t;
                     }
+                    tBulk += since(tb0);
                     if (run > 0) { // a block-length break or a sequence end: one ordinary column
                         for (ColumnRowHost &r : curRows) {
                             r.pos += r.rev ? -1 : 1;
@@ -564,7 +635,9 @@ void MafExport::convertSequence(std::ostream &mafStream, hgx_alignment *alignmen
         }
         if (getenv("HGX_MAF_TIMING"))
             std::cerr << "[hgx maf] columns " << length << " heads " << numHeads << " blocks " << numBlocks << " fetch(GPU+copy) "
-                      << fetchSeconds << " s, device " << stats.rows_ms + stats.depth_ms << " ms" << std::endl;
+                      << fetchSeconds << " s, device " << stats.rows_ms + stats.depth_ms << " ms; host: colMap " << tMap << " canAppend " << tCan
+                      << " print " << tPrint << " initBlock " << tInit << " appendColumn " << tAppend << " pairs " << tPairs << " bulk " << tBulk
+                      << " s" << std::endl;
         return;
     }
 

@@ -1,6 +1,7 @@
 // hal2maf — command-line twin of the reference tool (maf/impl/hal2maf.cpp:18-279) for the options the column
 // engine implements; columns come from the GPU through libhgx.
 #include "../hgx_columns_host.hpp"
+#include <vector>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -114,7 +115,9 @@ int main(int argc, char **argv) {
                 throw std::runtime_error("Reference sequence, " + refSequenceName + ", not found in reference genome, " +
                                          hgx_genome_name(h, ref));
         }
+        std::vector<char> fileBuffer(4 << 20); // a few large writes instead of one system call per block / line
         std::ofstream mafFile;
+        mafFile.rdbuf()->pubsetbuf(fileBuffer.data(), (std::streamsize)fileBuffer.size());
         if (pos[1] != "stdout") {
             mafFile.open(pos[1].c_str(), append ? std::ios::out | std::ios::app : std::ios::out);
             if (!mafFile)

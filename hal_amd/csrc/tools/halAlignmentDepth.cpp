@@ -1,6 +1,7 @@
 // halAlignmentDepth — command-line twin of the reference tool (alignmentDepth/halAlignmentDepth.cpp:52-213);
 // per-column depths come from the GPU through libhgx.
 #include "../hgx_columns_host.hpp"
+#include <vector>
 #include <fstream>
 #include <iostream>
 
@@ -89,7 +90,9 @@ int main(int argc, char **argv) {
         }
         if (hgx_genome_num_children(h, ref) != 0 && noAncestors)
             throw std::runtime_error("--noAncestors cannot be used when reference genome (" + pos[1] + ") is ancetral");
+        std::vector<char> fileBuffer(4 << 20); // a few large writes instead of one system call per block / line
         std::ofstream ofile;
+        ofile.rdbuf()->pubsetbuf(fileBuffer.data(), (std::streamsize)fileBuffer.size());
         if (wigPath != "stdout") {
             ofile.open(wigPath.c_str());
             if (!ofile)

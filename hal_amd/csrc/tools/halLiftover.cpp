@@ -1,6 +1,7 @@
 // halLiftover — command-line twin of the reference tool (liftover/impl/halLiftoverMain.cpp:17-152):
 // same arguments, options and messages; the mapping runs on the GPU through libhgx.
 #include "../hgx_liftover_host.hpp"
+#include <vector>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -89,7 +90,9 @@ int main(int argc, char **argv) {
             if (!srcBed)
                 throw std::runtime_error("Error opening srcBed, " + pos[2]);
         }
+        std::vector<char> fileBuffer(4 << 20); // a few large writes instead of one system call per block / line
         std::ofstream tgtBed;
+        tgtBed.rdbuf()->pubsetbuf(fileBuffer.data(), (std::streamsize)fileBuffer.size());
         std::ostream *tgtBedPtr = &std::cout;
         if (pos[4] != "stdout") {
             tgtBed.open(pos[4].c_str(), append ? std::ios::out | std::ios::app : std::ios::out);
