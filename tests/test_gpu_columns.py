@@ -147,3 +147,26 @@ def test_maf_ref_targets_vs_oracle(hal, oracle_bin, tmp_path):
     assert al.maf_export(g, ref_targets_bed=bed) == _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", leaf, "--refTargets", str(bedfile))
     assert al.maf_export(g, ref_targets_bed=bed, unique=True, no_ancestors=True) == \
         _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", leaf, "--refTargets", str(bedfile), "--unique", "--noAncestors")
+
+
+def test_reference_goldens_of_the_multiprocess_driver(hal, tmp_path):
+    """Product path against the expected files of the reference's sliced runner (hal2mafMP.py, maf/Makefile:62-72): target
+    genomes, --refTargets, and 250-base slices exported separately and concatenated."""
+    from test_oracle_golden import _mp_slices
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_maf")
+    al = hal.Alignment.random(hal.RandOptions.preset("small", seed=0), device=0)
+    g3 = al.genome_id("Genome_3")
+    name, _, ln = al.sequences(g3)[0]
+    got = al.maf_export(g3, 0, start=0, length=ln, unique=True, targets=[al.genome_id("Genome_1"), al.genome_id("Genome_2")])
+    assert got == open(os.path.join(gold, "hal2mafMPTargetGenomesTest.maf")).read()
+    g0 = al.genome_id("Genome_0")
+    got = al.maf_export(g0, unique=True, ref_targets_bed=open(os.path.join(gold, "small-Genome_0.bed")).read())
+    assert got == open(os.path.join(gold, "hal2mafMPRefTargetsGenomesTest.maf")).read()
+    name, _, ln = al.sequences(g0)[0]
+    got = _mp_slices(lambda s, l: al.maf_export(g0, 0, start=s, length=l, unique=True), name, ln, 250)
+    assert got == open(os.path.join(gold, "hal2mafMPBySeqTest_Genome_0_seq.maf")).read()
+    # and without --unique the slices of a run-compressed export still concatenate to the unsliced export's columns
+    whole = al.maf_export(g0, 0)
+    sliced = _mp_slices(lambda s, l: al.maf_export(g0, 0, start=s, length=l), name, ln, 250)
+    cols = lambda t: sum(len(x.split("\t")[6]) for x in t.splitlines() if x.startswith("s\tGenome_0."))
+    assert cols(whole) == cols(sliced) == ln

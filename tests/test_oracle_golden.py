@@ -116,3 +116,36 @@ def test_reference_cli_golden_hal2maf_unique(hal, oracle_bin, tmp_path):
     _, img = _small_seed0(hal, tmp_path)
     got = _oracle_maf(oracle_bin, img, tmp_path, "--refGenome", "Genome_2", "--refSequence", "Genome_2_seq", "--unique")
     assert got == open(os.path.join(GOLD, "ref_maf", "hal2mafSeqTest.maf")).read()
+
+
+def _mp_slices(run, seq_name, seq_len, slice_size):
+    """What hal2mafMP.py does with --sliceSize (maf/hal2mafMP.py:63-79 computeSlices, :81-102 concatenateSlices): one
+    hal2maf --unique run per slice of the reference sequence; the first slice's file is kept whole, of the others the
+    lines starting with '#' are dropped."""
+    parts = []
+    for i, s in enumerate(range(0, seq_len, slice_size)):
+        t = run(s, min(slice_size, seq_len - s))
+        if i > 0:
+            t = "".join(x for x in t.splitlines(True) if not x.startswith("#"))
+        parts.append(t)
+    return "".join(parts)
+
+
+def test_reference_goldens_of_the_multiprocess_driver(hal, oracle_bin, tmp_path):
+    """The expected files of hal2mafMP.py's tests (maf/Makefile:62-72; the driver is deprecated, its goldens are still in
+    the tree): --targetGenomes, --refTargets, and a reference sequence cut into 250-base slices that are exported
+    separately and concatenated — the reference's own way of sharding the column path."""
+    al, img = _small_seed0(hal, tmp_path)
+    d = os.path.join(GOLD, "ref_maf")
+    g3 = al.genome_id("Genome_3")
+    name, _, ln = al.sequences(g3)[0]
+    got = _oracle_maf(oracle_bin, img, tmp_path, "--refGenome", "Genome_3", "--targetGenomes", "Genome_1,Genome_2", "--refSequence", name,
+                      "--start", "0", "--length", str(ln), "--unique")
+    assert got == open(os.path.join(d, "hal2mafMPTargetGenomesTest.maf")).read()
+    got = _oracle_maf(oracle_bin, img, tmp_path, "--refTargets", os.path.join(d, "small-Genome_0.bed"), "--unique")
+    assert got == open(os.path.join(d, "hal2mafMPRefTargetsGenomesTest.maf")).read()
+    g0 = al.genome_id("Genome_0")
+    name, _, ln = al.sequences(g0)[0]
+    got = _mp_slices(lambda s, l: _oracle_maf(oracle_bin, img, tmp_path, "--refGenome", "Genome_0", "--refSequence", name, "--start", str(s),
+                                              "--length", str(l), "--unique"), name, ln, 250)
+    assert got == open(os.path.join(d, "hal2mafMPBySeqTest_Genome_0_seq.maf")).read()
