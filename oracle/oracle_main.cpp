@@ -278,8 +278,38 @@ static int cmdBlocks(int argc, char **argv) {
     return 0;
 }
 
+// hal_oracle columns <img.hgx> <refGenome>: every column of the reference genome's first sequence, one line per
+// column: "<col>" then " <genome>:<position>:<+|->" per base in ColumnMap order (sequences in SequenceLess order,
+// bases of a sequence in insertion order); what a loop over getColumnIterator() / toRight() / getColumnMap() sees.
+static int cmdColumnRows(int argc, char **argv) {
+    if (argc != 2) {
+        std::cerr << "usage: hal_oracle columns <img.hgx> <refGenome>" << std::endl;
+        return 1;
+    }
+    Alignment al = loadImage(argv[0]);
+    const int ref = al.genomeByName(argv[1]);
+    if (ref < 0) {
+        std::cerr << "genome not found" << std::endl;
+        return 1;
+    }
+    const Sequence &S = al.genomes[(size_t)ref].seqs[0];
+    ColumnIterator col(&al, ref, nullptr, S.start, S.start + S.length - 1, false, false, false);
+    for (i64 c = 0; c < S.length; ++c) {
+        std::cout << c;
+        for (auto &kv : col.colMap)
+            for (const Dna &d : kv.second)
+                std::cout << ' ' << al.genomes[(size_t)d.g].name << ':' << d.pos << ':' << (d.rev ? '-' : '+');
+        std::cout << '\n';
+        if (c + 1 < S.length)
+            col.toRight();
+    }
+    return 0;
+}
+
 int main(int argc, char **argv) {
     try {
+        if (argc >= 2 && std::string(argv[1]) == "columns")
+            return cmdColumnRows(argc - 2, argv + 2);
         if (argc >= 2 && std::string(argv[1]) == "blocks")
             return cmdBlocks(argc - 2, argv + 2);
         if (argc >= 2 && std::string(argv[1]) == "liftover")

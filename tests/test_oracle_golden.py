@@ -149,3 +149,20 @@ def test_reference_goldens_of_the_multiprocess_driver(hal, oracle_bin, tmp_path)
     got = _mp_slices(lambda s, l: _oracle_maf(oracle_bin, img, tmp_path, "--refGenome", "Genome_0", "--refSequence", name, "--start", str(s),
                                               "--length", str(l), "--unique"), name, ln, 250)
     assert got == open(os.path.join(d, "hal2mafMPBySeqTest_Genome_0_seq.maf")).read()
+
+
+def test_reference_unit_tests_of_the_column_iterator(oracle_bin, tmp_path):
+    """api/tests/halColumnIteratorTest.cpp: the Depth, Dup and Inv hand-built alignments and what the reference asserts about
+    every column of them (tests/golden/handbuilt_columns.py)."""
+    import handbuilt_columns as hc
+    for name, build, check, refs in hc.CASES:
+        img = str(tmp_path / (name + ".hgx"))
+        halfix.write_hgx(img, build())
+        for ref in refs:
+            out = subprocess.run([oracle_bin, "columns", img, ref], check=True, stdout=subprocess.PIPE).stdout.decode()
+            lines = out.splitlines()
+            assert len(lines) == 100
+            for line in lines:
+                f = line.split()
+                rows = [(x.split(":")[0], int(x.split(":")[1]), x.split(":")[2] == "-") for x in f[1:]]
+                check(ref, int(f[0]), rows)
