@@ -122,3 +122,24 @@ CASES12 = [
      "SEGMENT_3\t3\t7\t0\t0\t0\t0\t0\t0\t++\tSequence\t100\t45\t55\tSequence\t100\t10\t20\t1\t10,\t45,\t10,\n"
      "SEGMENT_4\t3\t7\t0\t0\t0\t0\t0\t0\t+-\tSequence\t100\t65\t75\tSequence\t100\t0\t10\t1\t10,\t65,\t90,\n", True, True),
 ]
+
+
+def extra_paralogs_genomes():
+    """The alignment of MappedSegmentMapExtraParalogsTest (api/tests/halMappedSegmentTest.cpp:478-566): every segment of
+    grandChild1 coalesces with the first segment of grandChild2, but only above the MRCA (in `root`)."""
+    from halfix import simple_genome
+    root = simple_genome("root", -1, [1], 3, [], [(0, 3, [(0, False)])], dna="CCC")
+    parent = simple_genome("parent", 0, [2, 3], 9, [(0, 3, 0, False, 1), (3, 3, 0, False, 2), (6, 3, 0, False, 0)],
+                           [(0, 3, [(0, True), (0, False)]), (3, 3, [(1, True), (-1, True)]), (6, 3, [(2, True), (-1, False)])],
+                           dna="CCCTACGTG")
+    gc1 = simple_genome("grandChild1", 1, [], 9, [(0, 3, 0, True, -1), (3, 3, 1, True, -1), (6, 3, 2, True, -1)], [], dna="CCCTACGTG")
+    gc2 = simple_genome("grandChild2", 1, [], 9, [(0, 3, 0, False, -1), (3, 3, -1, True, -1), (6, 3, -1, False, -1)], [], dna="CCCTACGTG")
+    return [root, parent, gc1, gc2]
+
+
+# :568-611: mapping grandChild2's first top segment to grandChild1: by default only the homology inside the MRCA
+# (target start position 2, length 3, reversed = forward range [0, 3)); with the root as coalescence limit all three
+# paralogs (start positions 2, 5, 8, reversed).  Lines of `hal_oracle blocks` / hgx_block_map: target sequence, forward
+# target range, forward source start, source strand, target strand.
+EXTRA_PARALOGS_DEFAULT = "Sequence\t0\t3\t0\t+\t-\n"
+EXTRA_PARALOGS_ROOT_LIMIT = "Sequence\t0\t3\t0\t+\t-\nSequence\t3\t6\t0\t+\t-\nSequence\t6\t9\t0\t+\t-\n"

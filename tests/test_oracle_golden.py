@@ -166,3 +166,14 @@ def test_reference_unit_tests_of_the_column_iterator(oracle_bin, tmp_path):
                 f = line.split()
                 rows = [(x.split(":")[0], int(x.split(":")[1]), x.split(":")[2] == "-") for x in f[1:]]
                 check(ref, int(f[0]), rows)
+
+
+def test_reference_unit_test_extra_paralogs_coalescence_limit(oracle_bin, tmp_path):
+    """api/tests/halMappedSegmentTest.cpp:478-611: the known answer for a coalescence limit above the MRCA."""
+    img = str(tmp_path / "xp.hgx")
+    halfix.write_hgx(img, hb.extra_paralogs_genomes())
+    run = lambda *a: subprocess.run([oracle_bin, "blocks", img, "grandChild2", "grandChild1", "0", "2"] + list(a), check=True,
+                                    stdout=subprocess.PIPE).stdout.decode()
+    assert run() == hb.EXTRA_PARALOGS_DEFAULT
+    assert run("--coalescenceLimit", "root") == hb.EXTRA_PARALOGS_ROOT_LIMIT
+    assert run("--coalescenceLimit", "parent") == hb.EXTRA_PARALOGS_DEFAULT
