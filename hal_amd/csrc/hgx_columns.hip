@@ -1,7 +1,7 @@
 // Column engine: launches of the per-base closure kernels behind hgx_columns_depth / hgx_alignment_depth /
 // hgx_maf_export (include/hgx.h).
 #include "hgx_column_kernels.hpp"
-#include "hgx_liftover_kernels.hpp"
+#include "hgx_scan_kernels.hpp"
 #include "hgx_columns_engine.hpp"
 #include <algorithm>
 #include <cstring>
