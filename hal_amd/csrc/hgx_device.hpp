@@ -86,6 +86,24 @@ template <> struct alignas(16) ChainRec<int64_t> {
         linkRev = ((uint32_t)link << 1) | (rev ? 1u : 0u);
     }
 };
+// Record of the down hop (k_down_ring), one per bottom segment and child slot: the child link together with what the hop
+// needs from the child's top segment (its start, its length, its paralogy link), so that the hop costs one 16-byte
+// gather instead of a gather of the link followed by a gather of the child's record (and of its right neighbour for a
+// reversed piece).  Built on first use by a plan (ensureDownTables).
+template <typename C> struct DownRec;
+template <> struct alignas(16) DownRec<int32_t> {
+    int32_t childEnc;   // (child top index << 1) | reversed, -1 = no child
+    int32_t childStart; // start coordinate of the child's top segment
+    int32_t len;        // its length (= the bottom segment's)
+    int32_t paralogy;   // its next paralogy index, -1 = none
+};
+template <> struct alignas(16) DownRec<int64_t> {
+    int64_t childStart;
+    int64_t len;
+    int32_t childEnc;
+    int32_t paralogy;
+    int64_t _pad;
+};
 template <typename C> struct BotRec;
 template <> struct alignas(8) BotRec<int32_t> {
     int32_t start;
@@ -104,6 +122,7 @@ struct DeviceGenome {
     void *chainLast = nullptr;          // ChainRec<C>[numTop]
     void *bot = nullptr;                // BotRec<C>[numBot+1]
     std::vector<int32_t *> childEnc;    // per child slot, int32[numBot]
+    std::vector<void *> downRec;        // per child slot, DownRec<C>[numBot], built on first use by a plan
     int64_t *seqStart = nullptr;        // int64[numSeq+1] (sentinel = genome length)
     int32_t numSeq = 0;
     int64_t numTop = 0, numBot = 0;
@@ -135,6 +154,8 @@ struct DeviceImage {
 
 // builds the k_up_chain tables of `genome` (idempotent, serialised by an internal mutex)
 void ensureChainTables(const Image &img, DeviceImage &D, int genome, bool mid, bool last);
+// builds the k_down_ring table of (parent genome, child slot) (idempotent, serialised)
+void ensureDownTable(const Image &img, DeviceImage &D, int parent, int slot);
 
 // uploads the packed DNA of every genome (idempotent); needed only by the MAF path
 void ensureDeviceDna(const Image &img, DeviceImage &D);

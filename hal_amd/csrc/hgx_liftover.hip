@@ -37,6 +37,9 @@ DeviceImage::~DeviceImage() {
         for (int32_t *c : g.childEnc)
             if (c)
                 (void)hipFree(c);
+        for (void *c : g.downRec)
+            if (c)
+                (void)hipFree(c);
         if (g.seqStart)
             (void)hipFree(g.seqStart);
     }
@@ -148,6 +151,41 @@ void ensureChainTables(const Image &img, DeviceImage &D, int genome, bool mid, b
         dg.chainMid = D.wide ? uploadChainTable<int64_t>(G, P, false, D.bytes) : uploadChainTable<int32_t>(G, P, false, D.bytes);
     if (last && !dg.chainLast)
         dg.chainLast = D.wide ? uploadChainTable<int64_t>(G, P, true, D.bytes) : uploadChainTable<int32_t>(G, P, true, D.bytes);
+}
+
+template <typename C> static void *uploadDownTable(const GenomeTables &P, const GenomeTables &G, int slot, size_t &bytes) {
+    std::vector<DownRec<C>> t((size_t)std::max<int64_t>(1, P.numBot));
+    memset(t.data(), 0, t.size() * sizeof(DownRec<C>));
+    for (int64_t i = 0; i < P.numBot; ++i) {
+        DownRec<C> &r = t[(size_t)i];
+        const int64_t c = P.bChild[(size_t)slot][(size_t)i];
+        r.childEnc = encLink(c, P.bChildRev[(size_t)slot][(size_t)i] != 0);
+        r.paralogy = -1;
+        if (c >= 0) {
+            r.childStart = (C)G.tStart[(size_t)c];
+            r.len = (C)(G.tStart[(size_t)c + 1] - G.tStart[(size_t)c]);
+            r.paralogy = (int32_t)G.tParalogy[(size_t)c];
+        }
+    }
+    void *d = nullptr;
+    HIP_OK(hipMalloc(&d, t.size() * sizeof(DownRec<C>)));
+    HIP_OK(hipMemcpy(d, t.data(), t.size() * sizeof(DownRec<C>), hipMemcpyHostToDevice));
+    bytes += t.size() * sizeof(DownRec<C>);
+    return d;
+}
+
+void ensureDownTable(const Image &img, DeviceImage &D, int parent, int slot) {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    const GenomeTables &P = img.genomes[(size_t)parent];
+    DeviceGenome &dg = D.genomes[(size_t)parent];
+    if (dg.downRec.size() < P.children.size())
+        dg.downRec.resize(P.children.size(), nullptr);
+    if (dg.downRec[(size_t)slot])
+        return;
+    HIP_OK(hipSetDevice(D.device));
+    const GenomeTables &G = img.genomes[(size_t)P.children[(size_t)slot]];
+    dg.downRec[(size_t)slot] = D.wide ? uploadDownTable<int64_t>(P, G, slot, D.bytes) : uploadDownTable<int32_t>(P, G, slot, D.bytes);
 }
 
 template <typename C> static void uploadGenome(const GenomeTables &G, DeviceGenome &D, size_t &bytes) {
@@ -575,7 +613,7 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
                 const int yBuf = intoR ? rBuf : (xBuf == aBuf ? bBuf : aBuf);
                 const int yLevel = intoR ? rLevel : nextLevel++;
                 P.timer.begin("k_down_ring", s, launch);
-                hipLaunchKernelGGL((k_down_ring<C, false>), dim3(GRID), dim3(256), 0, s, (const int32_t *)PG.childEnc[(size_t)slot],
+                hipLaunchKernelGGL((k_down_ring<C, false>), dim3(GRID), dim3(256), 0, s, (const DownRec<C> *)PG.downRec[(size_t)slot],
                                    (const TopRec<C> *)CG.top, P.frontier(xBuf), cntOf(xLevel), cap, P.frontier(yBuf), cntOf(yLevel), minLen,
                                    0, cnt, kstat(), (uint32_t *)nullptr);
                 P.timer.end(s);
@@ -618,12 +656,12 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
             const DeviceGenome &CG = D.genomes[(size_t)child];
             P.timer.begin("k_down_ring", s, launch);
             if (child == P.tgt) {
-                hipLaunchKernelGGL((k_down_ring<C, true>), dim3(GRID), dim3(256), 0, s, (const int32_t *)PG.childEnc[(size_t)slot],
+                hipLaunchKernelGGL((k_down_ring<C, true>), dim3(GRID), dim3(256), 0, s, (const DownRec<C> *)PG.downRec[(size_t)slot],
                                    (const TopRec<C> *)CG.top, P.frontier(cur), inCnt(), cap, P.frontier(cur ^ 1), outCnt(), minLen,
                                    (int)(P.opts.traverse_dupes != 0), cnt, kstat(), (uint32_t *)P.perQuery.p);
                 finalized = true;
             } else {
-                hipLaunchKernelGGL((k_down_ring<C, false>), dim3(GRID), dim3(256), 0, s, (const int32_t *)PG.childEnc[(size_t)slot],
+                hipLaunchKernelGGL((k_down_ring<C, false>), dim3(GRID), dim3(256), 0, s, (const DownRec<C> *)PG.downRec[(size_t)slot],
                                    (const TopRec<C> *)CG.top, P.frontier(cur), inCnt(), cap, P.frontier(cur ^ 1), outCnt(), minLen,
                                    (int)(P.opts.traverse_dupes != 0), cnt, kstat(), (uint32_t *)nullptr);
             }
@@ -862,6 +900,8 @@ hgx_liftover_plan *createLiftoverPlan(hgx_alignment *h, int src, int tgt, const 
             for (size_t k = 0; k < nUp; ++k)
                 ensureChainTables(img, *h->dev, P->up[k], k + 1 < nUp, k + 1 == nUp);
     }
+    for (size_t j = 1; j < P->climb.size(); ++j) // the paralogy phase maps ring members back down the climb path
+        ensureDownTable(img, *h->dev, P->climb[j], img.genomes[(size_t)P->climb[j]].childSlotOf(P->climb[j - 1]));
     std::vector<int> chain; // tgt ... mrca
     for (int g = tgt; g != P->mrca; g = img.genomes[(size_t)g].parent)
         chain.push_back(g);
@@ -871,6 +911,7 @@ hgx_liftover_plan *createLiftoverPlan(hgx_alignment *h, int src, int tgt, const 
         // (halSegmentMapper.cpp:208-219); on a tree that is the unique child towards the target
         const int slot = img.genomes[(size_t)parent].childSlotOf(chain[k]);
         P->down.emplace_back(parent, slot);
+        ensureDownTable(img, *h->dev, parent, slot);
         parent = chain[k];
     }
     const size_t climbHops = P->climb.empty() ? 0 : P->climb.size() - 1;

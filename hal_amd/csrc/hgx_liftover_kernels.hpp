@@ -622,12 +622,12 @@ __global__ void __launch_bounds__(256) k_up_chain(UpTables<C> tabs, Frontier in,
 // halSegmentMapper.cpp:265-288; toNextParalogy, halTopSegmentIterator.cpp:99-107: follow paralogyIndex,
 // flip strand iff the two segments' parentReversed differ; emit-then-test do/while).
 // FINAL (the hop into the target genome): the pieces leave as final mapped pieces instead of (index, offset) pieces — the
-// child's top record is in registers anyway for the ring walk, so the forward target coordinate costs nothing (one more
-// load for a reversed piece), and the per-interval piece count is taken here; this replaces a k_finalize pass over the
+// child segment's start and length come with the DownRec, so the forward target coordinate costs nothing, and the
+// per-interval piece count is taken here (when a piece is stored); this replaces a k_finalize pass over the
 // frontier (29 B written and read back per piece plus a gather).  In that form a frontier entry carries the forward
 // source start in sPos and the forward target start in so (k_scatter_front turns it into a MappedRec).
 template <typename C, bool FINAL>
-__global__ void __launch_bounds__(256) k_down_ring(const int32_t *__restrict__ childEnc, const TopRec<C> *__restrict__ ctop, Frontier in,
+__global__ void __launch_bounds__(256) k_down_ring(const DownRec<C> *__restrict__ down, const TopRec<C> *__restrict__ ctop, Frontier in,
                                                    const unsigned long long *inCount, uint32_t cap, Frontier out,
                                                    unsigned long long *outCount, int64_t minLength, int doDupes,
                                                    unsigned long long *counters, unsigned long long *kstat, uint32_t *__restrict__ perQuery) {
@@ -648,40 +648,36 @@ __global__ void __launch_bounds__(256) k_down_ring(const int32_t *__restrict__ c
         int32_t qid = 0, so = 0, len = 0, t0 = 0, cur = 0;
         int64_t sPos = 0;
         uint8_t fl = 0;
+        int32_t rcPar = -1, rcEnc = 0; // paralogy link and parentEnc (only its strand bit is used) of `cur`
+        int64_t rcStart = 0, rcLen = 0; // start and length of `cur` (ring members have one length: they share a parent segment)
         if (li < n) {
             const int32_t b = in.idx[i];
             len = in.len[i];
-            const int32_t enc = childEnc[b];
+            const DownRec<C> d = down[b]; // link, start, length and paralogy of the child segment in one gather
             ++botDerefs;
-            if (enc >= 0 && (int64_t)len >= minLength) {
+            if (d.childEnc >= 0 && (int64_t)len >= minLength) {
                 act = true;
                 qid = in.qid[i];
                 sPos = in.sPos[i];
                 so = (int32_t)in.so[i];
                 fl = in.flags[i];
-                if (enc & 1)
+                if (d.childEnc & 1)
                     fl ^= F_TREV;
-                t0 = cur = enc >> 1;
+                t0 = cur = d.childEnc >> 1;
+                rcPar = d.paralogy;
+                rcEnc = d.childEnc; // a top segment's parentReversed equals its parent's childReversed
+                rcStart = (int64_t)d.childStart;
+                rcLen = (int64_t)d.len;
+                if (doDupes)
+                    ++topDerefs; // the ring walk's look at the child segment
             }
-        }
-        bool haveRec = false;
-        int32_t rcPar = -1, rcEnc = 0; // paralogy link and parentEnc of `cur`
-        int64_t rcStart = 0;
-        if (FINAL && act) {
-            const TopRec<C> rc = ctop[cur];
-            rcPar = rc.paralogy;
-            rcEnc = rc.parentEnc;
-            rcStart = (int64_t)rc.start;
-            haveRec = true;
-            if (doDupes)
-                ++topDerefs; // the ring walk's look at the segment (counted there in the two-pass form)
         }
         while (__any(act)) {
             if (FINAL) {
                 int64_t tLo = 0, sLo = 0;
                 if (act) {
                     // SegmentIterator::getStartPosition / getEndPosition in forward coordinates (halSegmentIterator.cpp:46-67)
-                    tLo = !(fl & F_TREV) ? rcStart + so : (int64_t)ctop[cur + 1].start - so - len;
+                    tLo = !(fl & F_TREV) ? rcStart + so : rcStart + rcLen - so - len;
                     sLo = !(fl & F_SREV) ? sPos : sPos - len + 1;
                     ++topDerefs; // k_finalize's share
                 }
@@ -693,13 +689,6 @@ __global__ void __launch_bounds__(256) k_down_ring(const int32_t *__restrict__ c
                 if (!doDupes) {
                     act = false;
                 } else {
-                    if (!haveRec) {
-                        const TopRec<C> rc = ctop[cur];
-                        ++topDerefs;
-                        rcPar = rc.paralogy;
-                        rcEnc = rc.parentEnc;
-                        haveRec = true;
-                    }
                     if (rcPar < 0) {
                         act = false; // no next paralogy: the do/while exits after the first emit
                     } else {
