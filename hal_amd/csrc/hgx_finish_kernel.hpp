@@ -466,43 +466,76 @@ template <int G> __device__ __forceinline__ unsigned long long group_sort(unsign
 // (:385-387 needs a class of size > 1), so an output line is a maximal run of neighbours that
 // canMergeRightWith (api/impl/halMappedSegment.cpp:109-161), and lines are then stably sorted by source start
 // (liftover/impl/halLiftover.cpp:90).  One sub-wave group of G lanes per interval, one piece per lane.
+static constexpr int FAST_LIST_CAP = 1024; // intervals per block of the G == 8 instantiation (its class lists live in LDS)
+
 template <typename C, int G>
 __global__ void __launch_bounds__(256) k_finish_fast(Mapped in, const uint32_t *__restrict__ offset, const uint32_t *__restrict__ count,
                                                      uint32_t nq, const int64_t *__restrict__ seqStart, int numSeq,
                                                      hgx_record *__restrict__ records, uint32_t *__restrict__ nOut,
-                                                     uint32_t *__restrict__ generalList, unsigned long long *__restrict__ generalCount) {
+                                                     uint32_t *__restrict__ generalList, unsigned long long *__restrict__ generalCount,
+                                                     uint32_t *__restrict__ classLists, unsigned long long *__restrict__ classCounts) {
+    // G == 8 looks at every interval: it finishes the ones with up to 8 pieces and sorts the others into three lists
+    // (9-16, 17-32, 33-64 pieces; classLists + k*nq, classCounts[k]) that the wider instantiations then work through
+    // densely.  The lists are gathered in LDS per block (one global atomic per block and class: a single counter word
+    // takes ~90 atomics per microsecond); a block owns a contiguous range of intervals for that.
     constexpr int PER_WAVE = 64 / G;
-    const uint32_t nlist = nq;
-    const uint32_t wavesTotal = (gridDim.x * blockDim.x) >> 6;
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    constexpr int CLS = G == 16 ? 0 : G == 32 ? 1 : 2;
+    constexpr int LIST_CAP = FAST_LIST_CAP;
+    __shared__ uint32_t sList[G == 8 ? 3 * LIST_CAP : 1];
+    __shared__ uint32_t sCount[3];
+    if (G == 8) {
+        if (threadIdx.x < 3)
+            sCount[threadIdx.x] = 0;
+        __syncthreads();
+    }
+    const uint32_t nlist = G == 8 ? nq : (uint32_t)classCounts[CLS];
+    const uint32_t *myList = classLists + (size_t)CLS * nq;
     const int lane = lane_id();
     const int li = lane & (G - 1);       // lane inside the group
     const int gbase = lane & ~(G - 1);   // first lane of the group
     const unsigned long long gmask = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << gbase;
     const unsigned long long INF = ~0ull;
-    for (uint32_t wbase = wave * PER_WAVE; wbase < nlist; wbase += wavesTotal * PER_WAVE) {
-        const uint32_t q = wbase + (uint32_t)(lane / G);
-        bool gvalid = q < nlist;
+    // G == 8: block b takes intervals [b * chunk, (b + 1) * chunk), its waves interleaved inside; else grid-stride over the list
+    const uint32_t chunk = G == 8 ? (nq + gridDim.x - 1) / gridDim.x : 0;
+    const uint32_t first = G == 8 ? blockIdx.x * chunk + (threadIdx.x >> 6) * PER_WAVE
+                                  : ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * PER_WAVE;
+    const uint32_t limit = G == 8 ? (blockIdx.x * chunk + chunk < nq ? blockIdx.x * chunk + chunk : nq) : nlist;
+    const uint32_t stride = G == 8 ? (blockDim.x >> 6) * PER_WAVE : ((gridDim.x * blockDim.x) >> 6) * PER_WAVE;
+    for (uint32_t wbase = first; wbase < limit; wbase += stride) {
+        const uint32_t slotIdx = wbase + (uint32_t)(lane / G);
+        bool gvalid = slotIdx < limit;
+        const uint32_t q = gvalid ? (G == 8 ? slotIdx : myList[slotIdx]) : 0;
         uint32_t base = 0;
         int n = 0;
         if (gvalid) {
             n = (int)count[q];
-            // this instantiation owns the intervals whose piece count needs exactly G lanes
-            const bool mine = G == 8 ? n <= 8 : (n > G / 2 && n <= G);
-            if (G == 8 && n == 0 && li == 0)
-                nOut[q] = 0;
-            if (G == 64 && n > 64 && li == 0) { // too many pieces for a wavefront: general path
-                const unsigned long long slot = atomicAdd(generalCount, 1ull);
-                generalList[slot] = q;
+            if (G == 8) {
+                if (n == 0 && li == 0)
+                    nOut[q] = 0;
+                if (n > 8 && li == 0) {
+                    if (n > 64) { // too many pieces for a wavefront: general path
+                        const unsigned long long slot = atomicAdd(generalCount, 1ull);
+                        generalList[slot] = q;
+                    } else {
+                        const int c = n <= 16 ? 0 : n <= 32 ? 1 : 2;
+                        const uint32_t at = atomicAdd(&sCount[c], 1u);
+                        if (at < (uint32_t)LIST_CAP) {
+                            sList[c * LIST_CAP + at] = q;
+                        } else { // the block's window is full (cannot happen with chunk <= LIST_CAP; kept as a guard)
+                            const unsigned long long slot = atomicAdd(&classCounts[c], 1ull);
+                            classLists[(size_t)c * nq + slot] = q;
+                        }
+                    }
+                }
+                gvalid = n > 0 && n <= 8;
             }
-            gvalid = mine && n > 0;
             if (gvalid)
                 base = offset[q];
             else
                 n = 0;
         }
         if (!__any(gvalid))
-            continue; // no interval of this class among this wavefront's candidates
+            continue; // nothing for this instantiation among this wavefront's candidates
         const bool have = li < n;
         int64_t tLo = 0, tHi = 0, sLo = 0, sHi = 0;
         uint8_t fl = 0;
@@ -589,6 +622,20 @@ __global__ void __launch_bounds__(256) k_finish_fast(Mapped in, const uint32_t *
         }
         if (doGroup && li == 0)
             nOut[q] = (uint32_t)__popcll(headMask);
+    }
+    if (G == 8) {
+        __syncthreads();
+        __shared__ unsigned long long sBase[3];
+        if (threadIdx.x < 3) {
+            const uint32_t c = sCount[threadIdx.x] < (uint32_t)LIST_CAP ? sCount[threadIdx.x] : (uint32_t)LIST_CAP;
+            sBase[threadIdx.x] = c ? atomicAdd(&classCounts[threadIdx.x], (unsigned long long)c) : 0ull;
+        }
+        __syncthreads();
+        for (int c = 0; c < 3; ++c) {
+            const uint32_t cnt = sCount[c] < (uint32_t)LIST_CAP ? sCount[c] : (uint32_t)LIST_CAP;
+            for (uint32_t k = threadIdx.x; k < cnt; k += blockDim.x)
+                classLists[(size_t)c * nq + sBase[c] + k] = sList[c * LIST_CAP + k];
+        }
     }
 }
 

@@ -443,8 +443,8 @@ struct hgx_liftover_plan {
         deferredList.ensure(4 * (nq + 1));
         needCap.ensure(4 * (nq + 1));
         bigSlot.ensure(4 * (nq + 1));
-        classLists.ensure(4 * (nq + 1));
-        classCounts.ensure(16);
+        classLists.ensure(4 * 4 * (nq + 1));
+        classCounts.ensure(32);
     }
 };
 
@@ -709,19 +709,23 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
     P.timer.end(s);
     // finishing: register-resident fast path per size class (each kernel picks the intervals of its class),
     // general LDS path for the rest
+    // classLists: [general | 9-16 | 17-32 | 33-64 pieces], nq entries each; classCounts: [general, 3 classes]
     uint32_t *generalList = (uint32_t *)P.classLists.p;
     unsigned long long *generalCount = (unsigned long long *)P.classCounts.p;
-    HIP_OK(hipMemsetAsync(generalCount, 0, 8, s));
+    uint32_t *classLists = generalList + nq;
+    unsigned long long *classCounts = generalCount + 1;
+    HIP_OK(hipMemsetAsync(generalCount, 0, 32, s));
     const int blocks = P.opts.emit_blocks ? 1 : 0;
     if (blocks) {
         hipLaunchKernelGGL(k_all_general, dim3(GRID), dim3(256), 0, s, (const uint32_t *)P.perQuery.p, nq, (uint32_t *)P.nOut.p, generalList,
                            generalCount);
     } else {
     P.timer.begin("k_finish_fast", s);
+    const int gridG8 = (int)std::max<uint32_t>((uint32_t)GRID, (nq + FAST_LIST_CAP - 1) / FAST_LIST_CAP); // a block's share fits its LDS lists
 #define HGX_FAST(G)                                                                                                    \
-    hipLaunchKernelGGL((k_finish_fast<C, G>), dim3(GRID), dim3(256), 0, s, P.mapped(1), (const uint32_t *)P.offset.p,  \
+    hipLaunchKernelGGL((k_finish_fast<C, G>), dim3(G == 8 ? gridG8 : GRID), dim3(256), 0, s, P.mapped(1), (const uint32_t *)P.offset.p,  \
                        (const uint32_t *)P.perQuery.p, nq, (const int64_t *)TG.seqStart, (int)TG.numSeq,               \
-                       (hgx_record *)P.grouped.p, (uint32_t *)P.nOut.p, generalList, generalCount)
+                       (hgx_record *)P.grouped.p, (uint32_t *)P.nOut.p, generalList, generalCount, classLists, classCounts)
     HGX_FAST(8);
     HGX_FAST(16);
     HGX_FAST(32);
