@@ -136,6 +136,7 @@ def main():
     plan = hal_amd.LiftoverPlan(al, src, tgt, max_queries=nq)
 
     collator = shard.RecordCollator()
+    packed_wire = shard.can_pack(max(al.genome_length(src), al.genome_length(tgt)), nq, len(al.sequences(tgt)))
 
     def step():
         ptr, nrec = plan.run(d_gs, d_ge, d_st)
@@ -144,6 +145,8 @@ def main():
             # payload exchange of this batch runs on RCCL's stream while the next batch is mapped; the previous
             # batch's exchange is completed first, so every timed step pays for one whole exchange.
             recs = plan.records_to_tensor(ptr, nrec)
+            if packed_wire:
+                recs = shard.pack_records(recs)  # 20-byte wire records: half the bytes over xGMI
             prev = collator.wait(trim=False)
             collator.submit(recs)
             return nrec, (sum(prev[1]) if prev else nrec * world)
@@ -232,6 +235,8 @@ def main():
                                                                      "seed 2" if args.workload == "cfg2" else "seed 0", args.scale, nq,
                                                                      src_name, tgt_name),
                        "intervals_per_gpu": nq, "records_per_step": nrec_all, "parallelism": "query-shard x%d" % world,
+                       "exchange": ("all-gatherv of %d-byte records, overlapped with the next batch" % (20 if packed_wire else 40))
+                       if world > 1 else "none (one GPU)",
                        "newick": al.newick, "generate_s": round(gen_s, 2)},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

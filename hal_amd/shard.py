@@ -63,6 +63,38 @@ def offset_query_index(recs, first_query):
     return recs
 
 
+PACKED_BYTES = 20
+
+
+def can_pack(max_position, num_queries, num_target_sequences):
+    """The 20-byte wire form holds 31-bit coordinates and query indices and a 16-bit sequence index."""
+    return max_position < (1 << 31) and num_queries < (1 << 31) and num_target_sequences < (1 << 16)
+
+
+def pack_records(recs):
+    """hgx_record (40 bytes: four int64, an int32 and two bytes) -> 20 bytes (five int32): query, tgt_start, tgt_end,
+    src_start, tgt_seq << 16 | strand << 8 | tgt_reversed.  Halves what the all-gatherv moves over xGMI; valid under
+    can_pack().  uint8 [n, 40] in, uint8 [n, 20] out, same device."""
+    n = recs.shape[0]
+    r64 = recs.contiguous().view(torch.int64).view(n, 5)
+    out = torch.empty((n, 5), dtype=torch.int32, device=recs.device)
+    out[:, :4] = r64[:, :4]
+    tail = r64[:, 4]
+    out[:, 4] = ((tail & 0xFFFF) << 16) | (((tail >> 32) & 0xFF) << 8) | ((tail >> 40) & 0xFF)
+    return out.view(torch.uint8).view(n, PACKED_BYTES)
+
+
+def unpack_records(packed):
+    """inverse of pack_records"""
+    n = packed.shape[0]
+    p = packed.contiguous().view(torch.int32).view(n, 5).to(torch.int64)
+    out = torch.zeros((n, 5), dtype=torch.int64, device=packed.device)
+    out[:, :4] = p[:, :4]
+    w = p[:, 4] & 0xFFFFFFFF
+    out[:, 4] = ((w >> 16) & 0xFFFF) | (((w >> 8) & 0xFF) << 32) | ((w & 0xFF) << 40)
+    return out.view(torch.uint8).view(n, RECORD_BYTES)
+
+
 class RecordCollator:
     """The all-gatherv of one batch overlapped with the mapping of the next: submit() exchanges the counts (a few bytes,
     synchronous) and starts the payload all-gather asynchronously on the communicator's own stream; wait() returns the
@@ -74,32 +106,33 @@ class RecordCollator:
     def submit(self, recs):
         world = dist.get_world_size()
         dev = recs.device
+        width = recs.shape[1]  # 40 (hgx_record) or 20 (pack_records)
         counts = all_gather_counts(recs.shape[0], dev)
         mx = max(counts) if counts else 0
         mine = recs
         if recs.shape[0] != mx:
-            mine = torch.zeros((mx, RECORD_BYTES), dtype=torch.uint8, device=dev)
+            mine = torch.zeros((mx, width), dtype=torch.uint8, device=dev)
             mine[:recs.shape[0]] = recs
         mine = mine.contiguous()
         if dev.type == "cuda":
-            out = torch.empty((world * mx, RECORD_BYTES), dtype=torch.uint8, device=dev)
+            out = torch.empty((world * mx, width), dtype=torch.uint8, device=dev)
             work = dist.all_gather_into_tensor(out, mine, async_op=True)
             bufs = None
         else:
-            bufs = [torch.empty((mx, RECORD_BYTES), dtype=torch.uint8) for _ in range(world)]
+            bufs = [torch.empty((mx, width), dtype=torch.uint8) for _ in range(world)]
             work = dist.all_gather(bufs, mine, async_op=True)
             out = None
-        self._pending = (work, out, bufs, mine, counts, mx)
+        self._pending = (work, out, bufs, mine, counts, mx, width)
 
     def wait(self, trim=True):
         """(records, counts) of the submitted batch, or None when nothing is in flight."""
         if self._pending is None:
             return None
-        work, out, bufs, _mine, counts, mx = self._pending
+        work, out, bufs, _mine, counts, mx, width = self._pending
         self._pending = None
         work.wait()
         if bufs is None:
             if not trim:
                 return out, counts
-            bufs = list(out.view(len(counts), mx, RECORD_BYTES).unbind(0))
+            bufs = list(out.view(len(counts), mx, width).unbind(0))
         return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0), counts

@@ -10,7 +10,8 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 
-from hal_amd.shard import RecordCollator, all_gather_records, shard_bounds, offset_query_index
+from hal_amd.shard import (RecordCollator, all_gather_records, can_pack, offset_query_index, pack_records, shard_bounds,
+                           unpack_records)
 
 
 def fake_lift(q_lo, q_hi, base=0):
@@ -24,6 +25,29 @@ def fake_lift(q_lo, q_hi, base=0):
             r[8] = k
             out.append(r)
     return torch.from_numpy(np.stack(out)) if out else torch.zeros((0, 40), dtype=torch.uint8)
+
+
+def _real_records(n, seed):
+    """n well-formed hgx_record rows (RECORD_DTYPE layout) with values near the limits of the packed form"""
+    rng = np.random.default_rng(seed)
+    dt = np.dtype([("query", "<i8"), ("tgt_start", "<i8"), ("tgt_end", "<i8"), ("src_start", "<i8"), ("tgt_seq", "<i4"), ("strand", "S1"),
+                   ("tgt_reversed", "u1"), ("_pad", "S2")])
+    r = np.zeros(n, dtype=dt)
+    r["query"] = rng.integers(0, 2 ** 31 - 1, n)
+    r["tgt_start"] = rng.integers(0, 2 ** 31 - 1, n)
+    r["tgt_end"] = rng.integers(0, 2 ** 31 - 1, n)
+    r["src_start"] = rng.integers(0, 2 ** 31 - 1, n)
+    r["tgt_seq"] = rng.integers(0, 2 ** 16 - 1, n)
+    r["strand"] = rng.choice([b"+", b"-", b"."], n)
+    r["tgt_reversed"] = rng.integers(0, 2, n)
+    return torch.from_numpy(r.view(np.uint8).reshape(n, 40).copy())
+
+
+def test_pack_roundtrip_and_limits():
+    r = _real_records(1000, 7)
+    assert torch.equal(unpack_records(pack_records(r)), r)
+    assert pack_records(r).shape == (1000, 20)
+    assert can_pack(2 ** 31 - 1, 10 ** 6, 100) and not can_pack(2 ** 31, 10, 1) and not can_pack(10, 2 ** 31, 1) and not can_pack(10, 10, 2 ** 16)
 
 
 def _worker(rank, world, port, n, result):
@@ -44,6 +68,13 @@ def _worker(rank, world, port, n, result):
     ok = ok and bool(torch.equal(first[0], want)) and first[1] == counts
     ok = ok and second[1] == [fake_lift(0, 3 + r).shape[0] for r in range(world)]
     ok = ok and bool(torch.equal(second[0], torch.cat([fake_lift(0, 3 + r) for r in range(world)], dim=0)))
+    # the 20-byte wire form through the same exchange
+    mine = _real_records(200 + 50 * rank, rank)
+    col.submit(pack_records(mine))
+    packed, pcounts = col.wait()
+    back = unpack_records(packed)
+    expect = torch.cat([_real_records(200 + 50 * r, r) for r in range(world)], dim=0)
+    ok = ok and packed.shape[1] == 20 and pcounts == [200 + 50 * r for r in range(world)] and bool(torch.equal(back, expect))
     result[rank] = ok
     dist.barrier()
     dist.destroy_process_group()

@@ -320,3 +320,24 @@ def test_bed12_and_psl_vs_oracle(hal, oracle_bin, tmp_path, seed):
         assert hal.liftover_convert(al, s, bed6, t, out_psl=True) == \
             oracle_liftover(oracle_bin, img, al.genome_name(s), al.genome_name(t), bed6, tmp_path, psl=True)
     assert total > 500
+
+
+def test_packed_wire_records_on_device(hal, tmp_path):
+    """hal_amd.shard.pack_records / unpack_records on real device-resident records (the multi-GPU exchange format)."""
+    import torch
+    from hal_amd import shard
+    al, _ = _rand_alignment(hal, tmp_path, 2)
+    src, tgt = al.genome_id("Genome_9"), al.genome_id("Genome_2")
+    _, sstart, length = al.sequences(src)[0]
+    n = 3000
+    g = torch.Generator().manual_seed(3)
+    starts = torch.randint(0, length - 300, (n,), generator=g)
+    lens = torch.randint(1, 300, (n,), generator=g)
+    strand = torch.where(torch.rand(n, generator=g) < 0.5, ord("+"), ord("-")).to(torch.uint8)
+    plan = hal.LiftoverPlan(al, src, tgt, max_queries=n)
+    ptr, nrec = plan.run((starts + sstart).cuda(), (starts + lens - 1 + sstart).cuda(), strand.cuda())
+    recs = plan.records_to_tensor(ptr, nrec)
+    assert nrec > 1000 and shard.can_pack(max(al.genome_length(src), al.genome_length(tgt)), n, len(al.sequences(tgt)))
+    packed = shard.pack_records(recs)
+    assert packed.shape == (nrec, 20) and packed.is_cuda
+    assert torch.equal(shard.unpack_records(packed), recs)
