@@ -144,9 +144,7 @@ def main():
             # the one exchange step of the path: all-gatherv of the fixed-width records (hal_amd/shard.py).  The
             # payload exchange of this batch runs on RCCL's stream while the next batch is mapped; the previous
             # batch's exchange is completed first, so every timed step pays for one whole exchange.
-            recs = plan.records_to_tensor(ptr, nrec)
-            if packed_wire:
-                recs = shard.pack_records(recs)  # 20-byte wire records: half the bytes over xGMI
+            recs = plan.records_to_tensor(ptr, nrec, packed=packed_wire)  # 20-byte wire records: half the bytes over xGMI
             prev = collator.wait(trim=False)
             collator.submit(recs)
             return nrec, (sum(prev[1]) if prev else nrec * world)

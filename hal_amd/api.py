@@ -343,13 +343,15 @@ class LiftoverPlan:
         stream = torch.cuda.current_stream(gstart.device).cuda_stream
         return self.run_ptr(gstart.numel(), gstart.data_ptr(), gend.data_ptr(), strand.data_ptr(), stream)
 
-    def records_to_tensor(self, ptr, n):
-        """Copy the plan-owned device records of the last run into a fresh torch uint8 tensor [n, 40] (device to device)."""
+    def records_to_tensor(self, ptr, n, packed=False):
+        """Copy the plan-owned device records of the last run into a fresh torch uint8 tensor (device to device): [n, 40]
+        hgx_record rows, or with packed=True [n, 20] rows in the wire form of hal_amd.shard.pack_records."""
         import torch
-        t = torch.empty((n, 40), dtype=torch.uint8, device="cuda")
+        t = torch.empty((n, 20 if packed else 40), dtype=torch.uint8, device="cuda")
         err = C.c_void_p()
         stream = torch.cuda.current_stream().cuda_stream
-        if lib.hgx_liftover_copy_records(self._p, t.data_ptr(), n, stream, C.byref(err)) != 0:
+        f = lib.hgx_liftover_copy_records_packed if packed else lib.hgx_liftover_copy_records
+        if f(self._p, t.data_ptr(), n, stream, C.byref(err)) != 0:
             raise HgxError(take_error(err))
         return t
 

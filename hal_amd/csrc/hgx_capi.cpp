@@ -327,6 +327,15 @@ int hgx_liftover_copy_records(const hgx_liftover_plan *p, void *d_dst, size_t n_
     HGX_CATCH
 }
 
+int hgx_liftover_copy_records_packed(const hgx_liftover_plan *p, void *d_dst, size_t n_records, void *hip_stream, char **err) {
+    HGX_TRY
+    if (!p || (n_records && !d_dst))
+        throw std::runtime_error("hgx_liftover_copy_records_packed: null argument");
+    liftoverPlanCopyRecordsPacked(p, d_dst, n_records, hip_stream);
+    return HGX_OK;
+    HGX_CATCH
+}
+
 int hgx_liftover_kernel_times(hgx_liftover_plan *p, char **json) {
     if (!p || !json)
         return HGX_ERR;

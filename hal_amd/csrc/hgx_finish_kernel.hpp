@@ -773,4 +773,18 @@ __global__ void __launch_bounds__(256) k_compact_records(const hgx_record *__res
     }
 }
 
+// hgx_record (40 B) -> the 20-byte wire form of the multi-GPU exchange (hal_amd/shard.py: pack_records): query, tgt_start,
+// tgt_end, src_start as int32, then tgt_seq << 16 | strand << 8 | tgt_reversed
+static __global__ void __launch_bounds__(256) k_pack_records(const hgx_record *__restrict__ in, uint32_t n, int32_t *__restrict__ out) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const hgx_record r = in[i];
+        int32_t *o = out + (size_t)i * 5;
+        o[0] = (int32_t)r.query;
+        o[1] = (int32_t)r.tgt_start;
+        o[2] = (int32_t)r.tgt_end;
+        o[3] = (int32_t)r.src_start;
+        o[4] = (int32_t)(((uint32_t)r.tgt_seq << 16) | ((uint32_t)(uint8_t)r.strand << 8) | (uint32_t)r.tgt_reversed);
+    }
+}
+
 } // namespace hgx

@@ -978,6 +978,16 @@ void liftoverPlanSetTiming(hgx_liftover_plan *p, int mode) {
     p->timer.mode = mode;
 }
 
+void liftoverPlanCopyRecordsPacked(const hgx_liftover_plan *p, void *dDst, size_t nRecords, void *stream) {
+    if (nRecords > p->stats.records)
+        throw std::runtime_error("more records requested than the last run produced");
+    HIP_OK(hipSetDevice(p->device));
+    if (nRecords)
+        hipLaunchKernelGGL(k_pack_records, dim3(GRID), dim3(256), 0, (hipStream_t)stream, (const hgx_record *)p->outRecords.p, (uint32_t)nRecords,
+                           (int32_t *)dDst);
+    HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+}
+
 std::string liftoverPlanKernelTimes(hgx_liftover_plan *p) {
     HIP_OK(hipSetDevice(p->device));
     std::string s = "{";

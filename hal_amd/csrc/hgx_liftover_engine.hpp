@@ -15,6 +15,7 @@ const hgx_liftover_stats &liftoverPlanStats(const hgx_liftover_plan *p);
 std::string liftoverPlanKernelTimes(hgx_liftover_plan *p);
 void liftoverPlanSetTiming(hgx_liftover_plan *p, int mode);
 void liftoverPlanCopyRecords(const hgx_liftover_plan *p, void *dDst, size_t nRecords, void *stream);
+void liftoverPlanCopyRecordsPacked(const hgx_liftover_plan *p, void *dDst, size_t nRecords, void *stream);
 void liftoverBatchHost(hgx_alignment *h, int src, int tgt, size_t n, const hgx_interval *iv, const hgx_liftover_opts &opts,
                        std::vector<hgx_record> &out, hgx_liftover_stats *stats);
 // BlockMapper::init + map + getMap without adjacencies (liftover/impl/halBlockMapper.cpp:33-110)

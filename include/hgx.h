@@ -149,6 +149,10 @@ int hgx_liftover_plan_set_timing(hgx_liftover_plan *p, int mode);
 
 /* Copy the plan-owned records of the last run into caller-owned device memory (device to device, on hip_stream). */
 int hgx_liftover_copy_records(const hgx_liftover_plan *p, void *d_dst, size_t n_records, void *hip_stream, char **err);
+/* Same in the 20-byte wire form of the multi-GPU exchange: five int32 per record — query, tgt_start, tgt_end, src_start,
+ * tgt_seq << 16 | strand << 8 | tgt_reversed.  Only meaningful when every coordinate and the batch size fit 31 bits and the
+ * target genome has fewer than 65536 sequences (the caller checks: hal_amd.shard.can_pack). */
+int hgx_liftover_copy_records_packed(const hgx_liftover_plan *p, void *d_dst, size_t n_records, void *hip_stream, char **err);
 
 /* Text-level drop-in for Liftover::convert (liftover/inc/halLiftover.h:25-28): BED text in, BED text
  * out, byte-identical to halLiftover for BED3..BED9 (+ extra columns).  bed_type 0 = auto

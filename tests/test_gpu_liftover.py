@@ -341,3 +341,5 @@ def test_packed_wire_records_on_device(hal, tmp_path):
     packed = shard.pack_records(recs)
     assert packed.shape == (nrec, 20) and packed.is_cuda
     assert torch.equal(shard.unpack_records(packed), recs)
+    # the library's own kernel writes the same bytes
+    assert torch.equal(plan.records_to_tensor(ptr, nrec, packed=True), packed)
