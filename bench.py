@@ -192,6 +192,36 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    col_result = None
+    if args.columns:
+        # secondary metric of BASELINE.json ("MAF columns/sec", configs 3 and 5): halAlignmentDepth's per-column closure over
+        # the whole source genome (ColumnIterator path).  Columns are independent (api/impl/halColumnIterator.cpp:785-787):
+        # rank r scans the contiguous range shard_bounds(ncol, world, r) and the int32 results are all-gathered.
+        ncol = al.genome_length(src)
+        lo, hi = shard.shard_bounds(ncol, world, rank)
+        mine = torch.empty(max(hi - lo, 1), dtype=torch.int32, device=dev)
+        al.columns_depth_device(src, lo, hi - lo, mine.data_ptr())
+        col_ms = min(al.columns_depth_device(src, lo, hi - lo, mine.data_ptr()) for _ in range(3))
+        gather_ms = 0.0
+        depth_sum = float(mine[:hi - lo].double().sum().item())
+        if world > 1:
+            per = (ncol + world - 1) // world
+            padded = torch.zeros(per, dtype=torch.int32, device=dev)
+            padded[:hi - lo] = mine[:hi - lo]
+            allv = torch.empty(per * world, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t_g = time.perf_counter()
+            dist.all_gather_into_tensor(allv, padded)
+            torch.cuda.synchronize()
+            gather_ms = (time.perf_counter() - t_g) * 1e3
+            t = torch.tensor([col_ms, gather_ms, depth_sum], dtype=torch.float64, device=dev)
+            tmax = t.clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            col_ms, gather_ms, depth_sum = float(tmax[0].item()), float(tmax[1].item()), float(t[2].item())
+        col_result = (ncol, col_ms, gather_ms, depth_sum / ncol)
+
     if rank == 0:
         st = plan.stats()
         value = world * nq * args.steps / elapsed
@@ -247,27 +277,23 @@ def main():
             "counts_per_step": {"queries": Q, "source_pieces": st["source_pieces"], "top_derefs": T, "bottom_derefs": B,
                                 "mapped_pieces": st["mapped_pieces"], "records": R, "deferred_queries": st["deferred_queries"]},
         }
-        if args.columns:
-            # secondary metric of BASELINE.json ("MAF columns/sec"): halAlignmentDepth's per-column closure over the whole
-            # source genome (ColumnIterator path), device-resident output, kernel time from HIP events
-            ncol = al.genome_length(src)
-            dcol = torch.empty(ncol, dtype=torch.int32, device=dev)
-            al.columns_depth_device(src, 0, ncol, dcol.data_ptr())
-            col_ms = min(al.columns_depth_device(src, 0, ncol, dcol.data_ptr()) for _ in range(3))
+        if col_result:
+            ncol, col_ms, gather_ms, mean_depth = col_result
             cst = al.columns_depth_stats(src, 0, ncol)
             # algorithmic bytes of the column path: 25 B per segment record of the closure, computed once per
             # reference piece (= per run of columns with one walk, which is how the kernel works), + the 4-byte result
             col_bytes = 25.0 * (cst["top_derefs"] + cst["bottom_derefs"]) + 4.0 * ncol
-            col_gbs = col_bytes / (col_ms * 1e-3) / 1e9
+            col_gbs = col_bytes / world / (col_ms * 1e-3) / 1e9
             out["columns"] = {"metric": "alignment-depth columns/sec (ColumnIterator closure per reference base)",
                               "value": ncol / (col_ms * 1e-3), "unit": "columns/s", "columns": ncol, "kernel_ms": col_ms,
-                              "reference_genome": src_name, "mean_depth": float(dcol.float().mean().item()),
-                              "roofline": {"bound": "hbm", "kernel": "k_column_depth", "achieved": col_gbs, "peak": HBM_PEAK_GBS,
+                              "n_gpus": world, "all_gather_ms": gather_ms,
+                              "reference_genome": src_name, "mean_depth": mean_depth,
+                              "roofline": {"bound": "hbm", "kernel": "k_depth_runs", "achieved": col_gbs, "peak": HBM_PEAK_GBS,
                                            "unit": "GB/s", "frac": col_gbs / HBM_PEAK_GBS, "traffic": (json.load(open(pmc)).get("k_column_depth") if os.path.exists(pmc) else None),
-                                           "algorithmic_bytes_per_launch": col_bytes,
+                                           "algorithmic_bytes_per_launch": col_bytes / world,
                                            "top_derefs": cst["top_derefs"], "bottom_derefs": cst["bottom_derefs"],
                                            "note": "the kernel is bound by the scratch traffic of its frame stacks, not by these bytes "
-                                                   "(DESIGN.md 4.1)"}}
+                                                   "(DESIGN.md 4.1); per-GPU figures when n_gpus > 1"}}
         if args.cpu_sample > 0:
             sample = min(args.cpu_sample, nq)
             cst, text, multi = cpu_baseline(al, src_name, tgt_name, starts, lens, strand, seq_name, sample,
