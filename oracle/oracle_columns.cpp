@@ -33,6 +33,8 @@ static char reverseComplement(char c) {
 
 char dnaBase(const Alignment &al, const Dna &d) {
     const std::vector<u8> &p = al.genomes[(size_t)d.g].dna;
+    if (p.empty()) // an HGX image written without DNA (not a reference format): every base reads as N, as in the product
+        return 'N';
     u8 b = p[(size_t)(d.pos >> 1)];
     char c = dnaUnpackMap[(d.pos & 1) ? (b & 0x0F) : (b >> 4)]; // halCommon.h:187-190
     return d.rev ? reverseComplement(c) : c;
