@@ -123,6 +123,8 @@ struct DeviceGenome {
     void *bot = nullptr;                // BotRec<C>[numBot+1]
     std::vector<int32_t *> childEnc;    // per child slot, int32[numBot]
     std::vector<void *> downRec;        // per child slot, DownRec<C>[numBot], built on first use by a plan
+    int32_t *locate[2] = {nullptr, nullptr}; // coarse position -> segment index table of the {top, bottom} tiling (ensureLocateTable)
+    int locateShift[2] = {0, 0};
     int64_t *seqStart = nullptr;        // int64[numSeq+1] (sentinel = genome length)
     int32_t numSeq = 0;
     int64_t numTop = 0, numBot = 0;
@@ -154,6 +156,8 @@ struct DeviceImage {
 
 // builds the k_up_chain tables of `genome` (idempotent, serialised by an internal mutex)
 void ensureChainTables(const Image &img, DeviceImage &D, int genome, bool mid, bool last);
+// builds the coarse locate table of a genome's top (which = 0) or bottom (1) tiling (idempotent, serialised)
+void ensureLocateTable(const Image &img, DeviceImage &D, int genome, int which);
 // builds the k_down_ring table of (parent genome, child slot) (idempotent, serialised)
 void ensureDownTable(const Image &img, DeviceImage &D, int parent, int slot);
 

@@ -40,6 +40,9 @@ DeviceImage::~DeviceImage() {
         for (void *c : g.downRec)
             if (c)
                 (void)hipFree(c);
+        for (int32_t *c : g.locate)
+            if (c)
+                (void)hipFree(c);
         if (g.seqStart)
             (void)hipFree(g.seqStart);
     }
@@ -172,6 +175,41 @@ template <typename C> static void *uploadDownTable(const GenomeTables &P, const 
     HIP_OK(hipMemcpy(d, t.data(), t.size() * sizeof(DownRec<C>), hipMemcpyHostToDevice));
     bytes += t.size() * sizeof(DownRec<C>);
     return d;
+}
+
+// coarse[b] = index of the segment holding position b << shift; ~4 segments per bucket, at most 2^22 buckets
+void ensureLocateTable(const Image &img, DeviceImage &D, int genome, int which) {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    DeviceGenome &dg = D.genomes[(size_t)genome];
+    if (dg.locate[which])
+        return;
+    const GenomeTables &G = img.genomes[(size_t)genome];
+    const std::vector<int64_t> &st = which == 0 ? G.tStart : G.bStart;
+    const int64_t nseg = which == 0 ? G.numTop : G.numBot;
+    if (nseg <= 0 || G.totalLength <= 0)
+        return;
+    int64_t buckets = 1;
+    while (buckets < nseg / 4 && buckets < ((int64_t)1 << 22))
+        buckets <<= 1;
+    int shift = 0;
+    while (((G.totalLength - 1) >> shift) >= buckets)
+        ++shift;
+    const int64_t nb = ((G.totalLength - 1) >> shift) + 1;
+    std::vector<int32_t> coarse((size_t)nb + 1);
+    int64_t j = 0;
+    for (int64_t b = 0; b < nb; ++b) {
+        const int64_t pos = b << shift;
+        while (j + 1 < nseg && st[(size_t)j + 1] <= pos)
+            ++j;
+        coarse[(size_t)b] = (int32_t)j;
+    }
+    coarse[(size_t)nb] = (int32_t)(nseg - 1);
+    HIP_OK(hipSetDevice(D.device));
+    HIP_OK(hipMalloc((void **)&dg.locate[which], coarse.size() * 4));
+    HIP_OK(hipMemcpy(dg.locate[which], coarse.data(), coarse.size() * 4, hipMemcpyHostToDevice));
+    dg.locateShift[which] = shift;
+    D.bytes += coarse.size() * 4;
 }
 
 void ensureDownTable(const Image &img, DeviceImage &D, int parent, int slot) {
@@ -492,10 +530,10 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
     P.timer.begin("k_locate_expand", s, launch);
     if (P.srcTop)
         hipLaunchKernelGGL((k_locate_expand<TopRec<C>>), dim3(GRID), dim3(256), 0, s, (const TopRec<C> *)SG.top, SG.numTop, dS, dE,
-                           dStrand, nq, order, P.frontier(cur), cap, cnt, kstat() + 0);
+                           dStrand, nq, order, (const int32_t *)SG.locate[0], SG.locateShift[0], P.frontier(cur), cap, cnt, kstat() + 0);
     else
         hipLaunchKernelGGL((k_locate_expand<BotRec<C>>), dim3(GRID), dim3(256), 0, s, (const BotRec<C> *)SG.bot, SG.numBot, dS, dE,
-                           dStrand, nq, order, P.frontier(cur), cap, cnt, kstat() + 1);
+                           dStrand, nq, order, (const int32_t *)SG.locate[1], SG.locateShift[1], P.frontier(cur), cap, cnt, kstat() + 1);
     P.timer.end(s);
     ++launch;
 
@@ -929,6 +967,7 @@ hgx_liftover_plan *createLiftoverPlan(hgx_alignment *h, int src, int tgt, const 
     // and not the query genome itself, top segments otherwise
     if (opts.block_mapper_source)
         P->srcTop = !(P->mrca == src && src != tgt);
+    ensureLocateTable(img, *h->dev, src, P->srcTop ? 0 : 1);
     P->maxQueries = std::max<size_t>(maxQueries, 1);
     HIP_OK(hipSetDevice(h->dev->device));
     HIP_OK(hipEventCreate(&P->evStart));

@@ -213,7 +213,8 @@ __device__ __forceinline__ uint32_t front_slot(const FrontView *v, uint32_t i, u
 template <typename REC>
 __global__ void __launch_bounds__(256) k_locate_expand(const REC *__restrict__ segs, int64_t numSegs, const int64_t *__restrict__ gStart,
                                                        const int64_t *__restrict__ gEnd, const uint8_t *__restrict__ strand,
-                                                       uint32_t nq, const uint32_t *__restrict__ order, Frontier out, uint32_t cap,
+                                                       uint32_t nq, const uint32_t *__restrict__ order, const int32_t *__restrict__ coarse, int coarseShift, Frontier out,
+                                                       uint32_t cap,
                                                        unsigned long long *counters, unsigned long long *kstat) {
     const uint32_t wavesTotal = (gridDim.x * blockDim.x) >> 6;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -239,8 +240,18 @@ __global__ void __launch_bounds__(256) k_locate_expand(const REC *__restrict__ s
             if (st == '.')
                 fl |= F_DOT;
             act = ge >= gs && gs >= 0 && numSegs > 0 && gs < (int64_t)segs[numSegs].start;
-            // largest j with start[j] <= gs
+            // largest j with start[j] <= gs: toSite (halSegmentIterator.cpp:240-299; interpolation search there).  The coarse
+            // table (segment index at every 2^shift-th position, ~4 segments per bucket) narrows the binary search to a few
+            // probes on neighbouring records instead of ~20 probes all over a 16 MB table
             int64_t lo = 0, hi = numSegs; // invariant start[lo] <= gs < start[hi]
+            if (act && coarse) {
+                const int64_t b = gs >> coarseShift;
+                lo = coarse[b];
+                const int64_t up = (int64_t)coarse[b + 1] + 1;
+                hi = up < numSegs ? up : numSegs;
+                if (hi <= lo)
+                    hi = lo + 1;
+            }
             if (act) {
                 while (hi - lo > 1) {
                     const int64_t mid = (lo + hi) >> 1;
