@@ -1,6 +1,9 @@
 #include "hgx_liftover_host.hpp"
 #include <algorithm>
+#include <cerrno>
+#include <charconv>
 #include <climits>
+#include <cstdlib>
 #include <iostream>
 #include <sstream>
 #include <unordered_map>
@@ -19,13 +22,16 @@ static void chopString(const std::string &in, char sep, std::vector<std::string>
         out.push_back(in.substr(start));
 }
 // api/impl/halCommon.cpp:44-52 (operator>> semantics: leading blanks skipped, trailing junk ignored)
+// strtoll has the same reading (blanks, optional sign, decimal digits, stop at the first other character; nothing read or
+// out of range = failure) at a tenth of the cost of a stringstream per field.
 static int64_t strToInt(const std::string &s) {
-    std::stringstream ss(s);
-    int64_t i;
-    ss >> i;
-    if (ss.bad() || ss.fail())
+    const char *b = s.c_str();
+    char *e = nullptr;
+    errno = 0;
+    const long long v = strtoll(b, &e, 10);
+    if (e == b || errno == ERANGE)
         throw std::runtime_error("Error converting string to int: " + s);
-    return i;
+    return (int64_t)v;
 }
 
 void BedLine::parse(const std::string &lineBuffer, int type) {
@@ -90,30 +96,71 @@ void BedLine::parse(const std::string &lineBuffer, int type) {
         extra.push_back(row[i]);
 }
 
-void BedLine::write(std::ostream &os) const {
-    os << chrName << '\t' << start << '\t' << end;
-    if (bedType > 3)
-        os << '\t' << name;
-    if (bedType > 4)
-        os << '\t' << score;
-    if (bedType > 5)
-        os << '\t' << strand;
-    if (bedType > 6)
-        os << '\t' << thickStart;
-    if (bedType > 7)
-        os << '\t' << thickEnd;
-    if (bedType > 8)
-        os << '\t' << itemR << ',' << itemG << ',' << itemB;
-    if (bedType > 9) {
-        os << '\t' << blocks.size();
-        for (size_t i = 0; i < blocks.size(); ++i)
-            os << (i == 0 ? '\t' : ',') << blocks[i].length;
-        for (size_t i = 0; i < blocks.size(); ++i)
-            os << (i == 0 ? '\t' : ',') << blocks[i].start;
+static inline void appendInt(std::string &buf, int64_t v) {
+    char tmp[24];
+    auto r = std::to_chars(tmp, tmp + sizeof tmp, v);
+    buf.append(tmp, (size_t)(r.ptr - tmp));
+}
+
+// BedLine::write (halBedLine.cpp:104-151) into a text buffer.  The lifted form substitutes chromosome, range, strand and
+// thick range for the line's own (what BlockLiftover::liftInterval and Liftover::cleanResults change) without copying the line.
+void BedLine::append(std::string &buf, const std::string &chrom, int64_t s, int64_t e, char str, int64_t tStart, int64_t tEnd) const {
+    buf += chrom;
+    buf += '\t';
+    appendInt(buf, s);
+    buf += '\t';
+    appendInt(buf, e);
+    if (bedType > 3) {
+        buf += '\t';
+        buf += name;
     }
-    for (const std::string &e : extra)
-        os << '\t' << e;
-    os << '\n';
+    if (bedType > 4) {
+        buf += '\t';
+        appendInt(buf, score);
+    }
+    if (bedType > 5) {
+        buf += '\t';
+        buf += str;
+    }
+    if (bedType > 6) {
+        buf += '\t';
+        appendInt(buf, tStart);
+    }
+    if (bedType > 7) {
+        buf += '\t';
+        appendInt(buf, tEnd);
+    }
+    if (bedType > 8) {
+        buf += '\t';
+        appendInt(buf, itemR);
+        buf += ',';
+        appendInt(buf, itemG);
+        buf += ',';
+        appendInt(buf, itemB);
+    }
+    if (bedType > 9) {
+        buf += '\t';
+        appendInt(buf, (int64_t)blocks.size());
+        for (size_t i = 0; i < blocks.size(); ++i) {
+            buf += (i == 0 ? '\t' : ',');
+            appendInt(buf, blocks[i].length);
+        }
+        for (size_t i = 0; i < blocks.size(); ++i) {
+            buf += (i == 0 ? '\t' : ',');
+            appendInt(buf, blocks[i].start);
+        }
+    }
+    for (const std::string &x : extra) {
+        buf += '\t';
+        buf += x;
+    }
+    buf += '\n';
+}
+
+void BedLine::write(std::ostream &os) const {
+    std::string buf;
+    append(buf, chrName, start, end, strand, thickStart, thickEnd);
+    os.write(buf.data(), (std::streamsize)buf.size());
 }
 
 void BedLine::expandToBed12() {
@@ -423,7 +470,7 @@ void Liftover::convert(hgx_alignment *al, int srcGenome, std::istream *in, int t
             lastStats.walk_ms += st.walk_ms;
             lastStats.total_ms += st.total_ms;
             size_t r = 0; // records are grouped by query in input order
-            BedLine o;
+            std::string outBuf;
             std::vector<BedLine> mapped, outLines;
             for (const Job &job : jobs) {
                 const BedLine &src = job.line;
@@ -434,20 +481,21 @@ void Liftover::convert(hgx_alignment *al, int srcGenome, std::istream *in, int t
                 if (src.bedType <= 9) {
                     for (size_t k = r0; k < r; ++k) {
                         const hgx_record &rec = recs[k];
-                        // halBlockLiftover.cpp:82-105 (fields other than chrom/start/end/strand echo the input line)
-                        o = src;
-                        o.chrName = T.seqs[(size_t)rec.tgt_seq].name;
-                        o.start = rec.tgt_start;
-                        o.end = rec.tgt_end;
-                        o.strand = rec.strand;
-                        // Liftover::cleanResults, halLiftover.cpp:313-331
-                        if (o.bedType > 6 && (src.thickStart != 0 || src.thickEnd != 0)) {
-                            o.thickStart = o.start;
-                            o.thickEnd = o.end;
-                        }
-                        o.write(*out);
+                        // halBlockLiftover.cpp:82-105 (fields other than chrom/start/end/strand echo the input line);
+                        // Liftover::cleanResults, halLiftover.cpp:313-331: a set thick range becomes the lifted range
+                        const bool thick = src.bedType > 6 && (src.thickStart != 0 || src.thickEnd != 0);
+                        src.append(outBuf, T.seqs[(size_t)rec.tgt_seq].name, rec.tgt_start, rec.tgt_end, rec.strand,
+                                   thick ? rec.tgt_start : src.thickStart, thick ? rec.tgt_end : src.thickEnd);
+                    }
+                    if (outBuf.size() > (1u << 20)) {
+                        out->write(outBuf.data(), (std::streamsize)outBuf.size());
+                        outBuf.clear();
                     }
                     continue;
+                }
+                if (!outBuf.empty()) { // keep the order of the output when line types are mixed
+                    out->write(outBuf.data(), (std::streamsize)outBuf.size());
+                    outBuf.clear();
                 }
                 // BED12 / PSL: mapped blocks of all of the line's block intervals, stably sorted by source start
                 // (assignBlocksToIntervals' first step; per interval they already are)
@@ -504,6 +552,8 @@ void Liftover::convert(hgx_alignment *al, int srcGenome, std::istream *in, int t
                         b.writePSL(*out, _outPSLWithName);
                 }
             }
+            if (!outBuf.empty())
+                out->write(outBuf.data(), (std::streamsize)outBuf.size());
         }
         if (!pendingError.empty()) {
             std::string e = pendingError;

@@ -39,6 +39,7 @@ struct BedLine {
     void parse(const std::string &lineBuffer, int bedType);
     // halBedLine.cpp:104-151
     void write(std::ostream &os) const;
+    void append(std::string &buf, const std::string &chrom, int64_t s, int64_t e, char str, int64_t tStart, int64_t tEnd) const;
     // halBedLine.cpp:153-178, 206-250, 252-334
     void expandToBed12();
     void writePSL(std::ostream &os, bool prefixWithName) const;
