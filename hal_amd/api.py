@@ -192,7 +192,9 @@ class Alignment:
         if rc != 0:
             raise HgxError(take_error(err))
         try:
-            res = np.frombuffer(C.string_at(out, n.value * 40), dtype=RECORD_DTYPE).copy() if n.value else np.zeros(0, RECORD_DTYPE)
+            # one copy out of the library's buffer (string_at + frombuffer().copy() would be two)
+            res = (np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(n.value * 40,)).view(RECORD_DTYPE).copy()
+                   if n.value else np.zeros(0, RECORD_DTYPE))
         finally:
             lib.hgx_free(out)
         return res

@@ -249,14 +249,14 @@ int hgx_liftover_batch(hgx_alignment *h, int src, int tgt, size_t n, const hgx_i
         throw std::runtime_error("hgx_liftover_batch: null argument");
     if (!genomeOf(h, src) || !genomeOf(h, tgt))
         throw std::runtime_error("hgx_liftover_batch: genome id out of range");
-    std::vector<hgx_record> recs;
-    liftoverBatchHost(h, src, tgt, n, iv, defaultOpts(opts), recs, nullptr);
-    *out = (hgx_record *)malloc(std::max<size_t>(1, recs.size()) * sizeof(hgx_record));
-    if (!*out)
-        throw std::runtime_error("out of memory");
-    if (!recs.empty())
-        memcpy(*out, recs.data(), recs.size() * sizeof(hgx_record));
-    *n_out = recs.size();
+    *out = nullptr;
+    liftoverBatchHostRaw(h, src, tgt, n, iv, defaultOpts(opts), [&](size_t nrec) {
+        *out = (hgx_record *)malloc(std::max<size_t>(1, nrec) * sizeof(hgx_record));
+        if (!*out)
+            throw std::runtime_error("out of memory");
+        *n_out = nrec;
+        return *out;
+    });
     return HGX_OK;
     HGX_CATCH
 }

@@ -9,6 +9,8 @@
 // than 2^31 bases, else int64 (tables are re-instantiated, kernels are templates on C).
 // Source layouts: api/mmap_impl/mmapTopSegmentData.h:40-44, mmapBottomSegmentData.h:35-52.
 #pragma once
+#include <mutex>
+#include "../../include/hgx.h"
 #include "hgx_image.hpp"
 #include <memory>
 
@@ -170,7 +172,18 @@ std::unique_ptr<DeviceImage> uploadImage(const Image &img, int device);
 } // namespace hgx
 
 // the opaque handle of include/hgx.h
+struct hgx_liftover_plan;
 struct hgx_alignment {
     hgx::Image img;
     std::unique_ptr<hgx::DeviceImage> dev;
+    // the host-buffer entry points (hgx_liftover_batch, hgx_liftover_convert) keep their last plan: creating one means
+    // gigabytes of device allocations, and a BED file is lifted in several batches with the same genomes and options
+    struct CachedPlan {
+        int src = -1, tgt = -1;
+        hgx_liftover_opts opts{};
+        size_t maxQueries = 0;
+        hgx_liftover_plan *plan = nullptr;
+    } cachedPlan;
+    std::mutex planMutex;
+    ~hgx_alignment();
 };

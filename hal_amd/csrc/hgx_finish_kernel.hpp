@@ -493,7 +493,7 @@ __global__ void __launch_bounds__(256) k_finish_fast(Mapped in, const uint32_t *
     const int lane = lane_id();
     const int li = lane & (G - 1);       // lane inside the group
     const int gbase = lane & ~(G - 1);   // first lane of the group
-    const unsigned long long gmask = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << gbase;
+    const unsigned long long gmask = (G == 64 ? ~0ull : ((1ull << (G & 63)) - 1ull)) << gbase;
     const unsigned long long INF = ~0ull;
     // G == 8: block b takes intervals [b * chunk, (b + 1) * chunk), its waves interleaved inside; else grid-stride over the list
     const uint32_t chunk = G == 8 ? (nq + gridDim.x - 1) / gridDim.x : 0;

@@ -3,6 +3,7 @@
 #include "hgx_finish_kernel.hpp"
 #include "hgx_liftover_engine.hpp"
 #include <algorithm>
+#include <functional>
 #include <cstdlib>
 #include <mutex>
 #include <cstring>
@@ -1045,6 +1046,25 @@ std::string liftoverPlanKernelTimes(hgx_liftover_plan *p) {
 }
 
 // host-buffer batch: H2D, run, D2H
+// alloc(n) returns the host memory the n records are copied into (straight from the device: no staging copy)
+static void runHostArraysInto(hgx_liftover_plan *P, const std::vector<int64_t> &gs, const std::vector<int64_t> &ge, const std::vector<uint8_t> &st,
+                              const std::function<hgx_record *(size_t)> &alloc) {
+    const size_t n = gs.size();
+    DevBuf dS, dE, dT;
+    dS.ensure(8 * std::max<size_t>(n, 1));
+    dE.ensure(8 * std::max<size_t>(n, 1));
+    dT.ensure(std::max<size_t>(n, 1));
+    HIP_OK(hipMemcpy(dS.p, gs.data(), 8 * n, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dE.p, ge.data(), 8 * n, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dT.p, st.data(), n, hipMemcpyHostToDevice));
+    const hgx_record *dOut = nullptr;
+    size_t nOut = 0;
+    runLiftoverPlan(P, n, (const int64_t *)dS.p, (const int64_t *)dE.p, (const uint8_t *)dT.p, nullptr, &dOut, &nOut);
+    hgx_record *dst = alloc(nOut);
+    if (nOut)
+        HIP_OK(hipMemcpy(dst, dOut, sizeof(hgx_record) * nOut, hipMemcpyDeviceToHost));
+}
+
 static void runHostArrays(hgx_liftover_plan *P, const std::vector<int64_t> &gs, const std::vector<int64_t> &ge, const std::vector<uint8_t> &st,
                           std::vector<hgx_record> &out) {
     const size_t n = gs.size();
@@ -1063,12 +1083,21 @@ static void runHostArrays(hgx_liftover_plan *P, const std::vector<int64_t> &gs, 
         HIP_OK(hipMemcpy(out.data(), dOut, sizeof(hgx_record) * nOut, hipMemcpyDeviceToHost));
 }
 
-void liftoverBatchHost(hgx_alignment *h, int src, int tgt, size_t n, const hgx_interval *iv, const hgx_liftover_opts &opts,
-                       std::vector<hgx_record> &out, hgx_liftover_stats *stats) {
-    std::unique_ptr<hgx_liftover_plan, void (*)(hgx_liftover_plan *)> P(createLiftoverPlan(h, src, tgt, opts, n), destroyLiftoverPlan);
-    const GenomeTables &G = h->img.genomes[(size_t)src];
-    std::vector<int64_t> gs(n), ge(n);
-    std::vector<uint8_t> st(n);
+} // namespace hgx
+
+hgx_alignment::~hgx_alignment() {
+    if (cachedPlan.plan)
+        hgx::destroyLiftoverPlan(cachedPlan.plan);
+}
+
+namespace hgx {
+
+// sequence-relative half-open intervals -> inclusive genome coordinates; invalid ones become empty (gs = 0, ge = -1)
+static void intervalsToGenomeCoordinates(const GenomeTables &G, size_t n, const hgx_interval *iv, std::vector<int64_t> &gs,
+                                         std::vector<int64_t> &ge, std::vector<uint8_t> &st) {
+    gs.resize(n);
+    ge.resize(n);
+    st.resize(n);
     for (size_t i = 0; i < n; ++i) {
         const hgx_interval &q = iv[i];
         bool ok = q.seq >= 0 && q.seq < (int32_t)G.seqs.size() && q.start >= 0 && q.start < q.end;
@@ -1083,9 +1112,46 @@ void liftoverBatchHost(hgx_alignment *h, int src, int tgt, size_t n, const hgx_i
         }
         st[i] = (uint8_t)q.strand;
     }
-    runHostArrays(P.get(), gs, ge, st, out);
+}
+
+// the alignment's cached plan for (src, tgt, opts), recreated when the key changes or the batch outgrows it; the
+// caller holds h->planMutex while it uses the plan
+static hgx_liftover_plan *cachedPlanFor(hgx_alignment *h, int src, int tgt, const hgx_liftover_opts &opts, size_t n) {
+    hgx_alignment::CachedPlan &c = h->cachedPlan;
+    const bool same = c.plan && c.src == src && c.tgt == tgt && memcmp(&c.opts, &opts, sizeof opts) == 0 && n <= c.maxQueries;
+    if (!same) {
+        if (c.plan)
+            destroyLiftoverPlan(c.plan);
+        c.plan = nullptr;
+        c.plan = createLiftoverPlan(h, src, tgt, opts, n);
+        c.src = src;
+        c.tgt = tgt;
+        c.opts = opts;
+        c.maxQueries = std::max<size_t>(n, 1);
+    }
+    return c.plan;
+}
+
+void liftoverBatchHost(hgx_alignment *h, int src, int tgt, size_t n, const hgx_interval *iv, const hgx_liftover_opts &opts,
+                       std::vector<hgx_record> &out, hgx_liftover_stats *stats) {
+    std::lock_guard<std::mutex> lock(h->planMutex);
+    hgx_liftover_plan *P = cachedPlanFor(h, src, tgt, opts, n);
+    std::vector<int64_t> gs, ge;
+    std::vector<uint8_t> st;
+    intervalsToGenomeCoordinates(h->img.genomes[(size_t)src], n, iv, gs, ge, st);
+    runHostArrays(P, gs, ge, st, out);
     if (stats)
         *stats = P->stats;
+}
+
+void liftoverBatchHostRaw(hgx_alignment *h, int src, int tgt, size_t n, const hgx_interval *iv, const hgx_liftover_opts &opts,
+                          const std::function<hgx_record *(size_t)> &alloc) {
+    std::lock_guard<std::mutex> lock(h->planMutex);
+    hgx_liftover_plan *P = cachedPlanFor(h, src, tgt, opts, n);
+    std::vector<int64_t> gs, ge;
+    std::vector<uint8_t> st;
+    intervalsToGenomeCoordinates(h->img.genomes[(size_t)src], n, iv, gs, ge, st);
+    runHostArraysInto(P, gs, ge, st, alloc);
 }
 
 void blockMapHost(hgx_alignment *h, int ref, int query, int64_t absFirst, int64_t absLast, bool targetReversed,

@@ -2,6 +2,7 @@
 #pragma once
 #include "../../include/hgx.h"
 #include "hgx_device.hpp"
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -18,6 +19,9 @@ void liftoverPlanCopyRecords(const hgx_liftover_plan *p, void *dDst, size_t nRec
 void liftoverPlanCopyRecordsPacked(const hgx_liftover_plan *p, void *dDst, size_t nRecords, void *stream);
 void liftoverBatchHost(hgx_alignment *h, int src, int tgt, size_t n, const hgx_interval *iv, const hgx_liftover_opts &opts,
                        std::vector<hgx_record> &out, hgx_liftover_stats *stats);
+// same, the records copied from the device straight into the memory alloc(n) returns
+void liftoverBatchHostRaw(hgx_alignment *h, int src, int tgt, size_t n, const hgx_interval *iv, const hgx_liftover_opts &opts,
+                          const std::function<hgx_record *(size_t)> &alloc);
 // BlockMapper::init + map + getMap without adjacencies (liftover/impl/halBlockMapper.cpp:33-110)
 void blockMapHost(hgx_alignment *h, int ref, int query, int64_t absFirst, int64_t absLast, bool targetReversed,
                   const hgx_liftover_opts &opts, std::vector<hgx_record> &out);
