@@ -6,6 +6,8 @@
 #include <climits>
 #include <cstdlib>
 #include <charconv>
+#include <climits>
+#include <thread>
 #include <cstring>
 
 namespace hgx {
@@ -137,6 +139,7 @@ void MafExport::resetEntries() {
         e->strand = '+';
         e->length = 0;
         e->sequence.clear();
+        e->segs.clear();
         ++i;
     }
 }
@@ -147,6 +150,12 @@ void MafExport::initEntry(Entry *e, const Key &k, const ColumnRowHost *row, bool
     const SeqInfo &S = G.seqs[(size_t)k.seq];
     if (e->genome != k.genome || e->srcLength != S.length || e->name.empty()) {
         e->name = _ucscNames ? G.name + "." + S.name : S.name; // Sequence::getFullName / getName (halMafBlock.h:128-130)
+        auto it = _nameIds.find(e->name);
+        if (it == _nameIds.end()) {
+            it = _nameIds.emplace(e->name, (uint32_t)_names.size()).first;
+            _names.push_back(e->name);
+        }
+        e->nameId = it->second;
         e->genome = k.genome;
         e->srcLength = S.length;
     }
@@ -161,8 +170,10 @@ void MafExport::initEntry(Entry *e, const Key &k, const ColumnRowHost *row, bool
         e->length = 0;
         e->strand = '+';
     }
-    if (clearSequence)
+    if (clearSequence) {
         e->sequence.clear();
+        e->segs.clear();
+    }
 }
 
 // halMafBlock.cpp:114-138
@@ -171,9 +182,33 @@ void MafExport::updateEntry(Entry *e, const Key *k, const ColumnRowHost *row) {
         if (e->start == NULL_INDEX)
             initEntry(e, *k, row, false);
         ++e->length;
-        e->sequence.push_back(row->base);
+        if (_segMode)
+            appendRun(e, row, row->pos, 1);
+        else
+            e->sequence.push_back(row->base);
+    } else if (_segMode) {
+        appendRun(e, nullptr, 0, 1);
     } else {
         e->sequence.push_back('-');
+    }
+}
+
+// run mode: n more columns of this row starting at genome position pos (a gap when row is null); contiguous runs merge
+void MafExport::appendRun(Entry *e, const ColumnRowHost *row, int64_t pos, int64_t n) {
+    const uint8_t kind = !row ? 0 : (row->rev ? 2 : 1);
+    if (!e->segs.empty()) {
+        Entry::Seg &l = e->segs.back();
+        if (l.kind == kind && (int64_t)l.n + n < INT32_MAX &&
+            (kind == 0 || (kind == 1 ? pos == l.pos + l.n : pos == l.pos - l.n))) {
+            l.n += (int32_t)n;
+            return;
+        }
+    }
+    while (n > 0) { // a run longer than 2^31 - 1 columns is split (not reachable with a block length limit, kept for safety)
+        const int64_t m = std::min<int64_t>(n, INT32_MAX - 1);
+        e->segs.push_back(Entry::Seg{pos, (int32_t)m, kind});
+        pos += kind == 2 ? -m : m;
+        n -= m;
     }
 }
 
@@ -271,6 +306,12 @@ bool MafExport::canAppendColumn(const ColumnMap &col) {
 bool MafExport::referenceIsAllGaps() const {
     if (!_reference)
         return false;
+    if (_segMode) {
+        for (const Entry::Seg &g : _reference->segs)
+            if (g.kind != 0)
+                return false;
+        return true;
+    }
     for (char c : _reference->sequence)
         if (c != '-')
             return false;
@@ -291,6 +332,156 @@ struct PairTable {
     }
 };
 } // namespace
+
+// run mode: the rows of the block as data (MafBlock's operator<< order: the reference row first, then the entries that have a
+// start, halMafBlock.cpp:499-520); text is made later, by flushSnapshots
+void MafExport::snapshotBlock() {
+    BlockSnap b{(uint32_t)_snapRows.size(), 0};
+    auto add = [&](const Entry &e, int64_t start) {
+        RowSnap r;
+        r.nameId = e.nameId;
+        r.firstSeg = (uint32_t)_snapSegs.size();
+        r.numSegs = (uint32_t)e.segs.size();
+        _snapSegs.insert(_snapSegs.end(), e.segs.begin(), e.segs.end());
+        r.start = start;
+        r.length = e.length;
+        r.srcLength = e.srcLength;
+        r.genome = e.genome;
+        r.strand = e.strand;
+        _snapRows.push_back(r);
+        ++b.numRows;
+    };
+    if (_reference->start == NULL_INDEX) {
+        if (_refIndex != NULL_INDEX)
+            add(*_reference, _refIndex);
+    } else {
+        add(*_reference, _reference->start);
+    }
+    for (auto e = _entries.begin(); e != _entries.end(); ++e)
+        if (e->second->start != NULL_INDEX && e->second != _reference)
+            add(*e->second, e->second->start);
+    _snapBlocks.push_back(b);
+}
+
+// renders the pending blocks ("a\n", the rows, one blank line each) on several threads and writes them in order
+// — in the background: the batch is moved out, the state machine goes on filling the next one while this one is rendered
+// and written (the previous batch is waited for first, so the stream sees the batches in order).
+void MafExport::flushSnapshots(std::ostream &os) {
+    waitPendingWrite();
+    if (_snapBlocks.empty())
+        return;
+    struct Batch {
+        std::vector<BlockSnap> blocks;
+        std::vector<RowSnap> rows;
+        std::vector<Entry::Seg> segs;
+    };
+    auto batch = std::make_shared<Batch>();
+    batch->blocks.swap(_snapBlocks);
+    batch->rows.swap(_snapRows);
+    batch->segs.swap(_snapSegs);
+    const std::deque<std::string> *names = &_names;
+    const hgx_alignment *al = _al;
+    std::ostream *out = &os;
+    _pendingWrite = std::async(std::launch::async, [batch, names, al, out]() {
+    const std::vector<BlockSnap> &_snapBlocks = batch->blocks;
+    const std::vector<RowSnap> &_snapRows = batch->rows;
+    const std::vector<Entry::Seg> &_snapSegs = batch->segs;
+    const std::deque<std::string> &_names = *names;
+    const hgx_alignment *_al = al;
+    std::ostream &os = *out;
+    static const char fwd[17] = "acgtn\0\0\0ACGTN\0\0\0";
+    static const char rc[17] = "tgcan\0\0\0TGCAN\0\0\0";
+    static const PairTable fwd2(fwd, false), rc2(rc, true);
+    const size_t nb = _snapBlocks.size();
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = std::max(1u, std::min(nt ? nt : 1u, 16u));
+    if (nb < 256)
+        nt = 1;
+    std::vector<std::string> text(nt);
+    auto render = [&](unsigned t) {
+        std::string &buf = text[t];
+        const size_t b0 = nb * t / nt, b1 = nb * (t + 1) / nt;
+        size_t bytes = 0;
+        for (size_t b = b0; b < b1; ++b)
+            for (uint32_t k = 0; k < _snapBlocks[b].numRows; ++k) {
+                const RowSnap &r = _snapRows[_snapBlocks[b].firstRow + k];
+                bytes += _names[r.nameId].size() + 80;
+                for (uint32_t g = 0; g < r.numSegs; ++g)
+                    bytes += (size_t)_snapSegs[r.firstSeg + g].n;
+            }
+        buf.resize(bytes + 3 * (b1 - b0));
+        char *o = &buf[0];
+        auto num = [&](int64_t v) { o = std::to_chars(o, o + 24, v).ptr; };
+        for (size_t b = b0; b < b1; ++b) {
+            *o++ = 'a';
+            *o++ = '\n';
+            for (uint32_t k = 0; k < _snapBlocks[b].numRows; ++k) {
+                const RowSnap &r = _snapRows[_snapBlocks[b].firstRow + k];
+                *o++ = 's';
+                *o++ = '\t';
+                const std::string &nm = _names[r.nameId];
+                memcpy(o, nm.data(), nm.size());
+                o += nm.size();
+                *o++ = '\t';
+                num(r.start);
+                *o++ = '\t';
+                num(r.length);
+                *o++ = '\t';
+                *o++ = r.strand;
+                *o++ = '\t';
+                num(r.srcLength);
+                *o++ = '\t';
+                const std::vector<uint8_t> &d = _al->img.genomes[(size_t)r.genome].dna;
+                const uint8_t *pk = d.data();
+                for (uint32_t g = 0; g < r.numSegs; ++g) {
+                    const Entry::Seg &sg = _snapSegs[r.firstSeg + g];
+                    const int64_t t = sg.n;
+                    if (sg.kind == 0) {
+                        memset(o, '-', (size_t)t);
+                    } else if (d.empty()) {
+                        memset(o, 'N', (size_t)t);
+                    } else if (sg.kind == 1) { // dnaUnpack (halCommon.h:187-190), two bases per packed byte
+                        int64_t p0 = sg.pos, i = 0;
+                        if (i < t && (p0 & 1)) {
+                            o[i++] = fwd[pk[p0 >> 1] & 0x0F];
+                            ++p0;
+                        }
+                        for (; i + 1 < t; i += 2, p0 += 2)
+                            memcpy(o + i, &fwd2.v[pk[p0 >> 1]], 2);
+                        if (i < t)
+                            o[i] = fwd[pk[p0 >> 1] >> 4];
+                    } else { // reverse strand: walk left, complemented (reverseComplement, halCommon.h:45-75)
+                        int64_t p0 = sg.pos, i = 0;
+                        if (i < t && !(p0 & 1)) {
+                            o[i++] = rc[pk[p0 >> 1] >> 4];
+                            --p0;
+                        }
+                        for (; i + 1 < t; i += 2, p0 -= 2)
+                            memcpy(o + i, &rc2.v[pk[p0 >> 1]], 2);
+                        if (i < t)
+                            o[i] = rc[pk[p0 >> 1] & 0x0F];
+                    }
+                    o += t;
+                }
+                *o++ = '\n';
+            }
+            *o++ = '\n';
+        }
+        buf.resize((size_t)(o - buf.data()));
+    };
+    if (nt == 1) {
+        render(0);
+    } else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; ++t)
+            th.emplace_back(render, t);
+        for (std::thread &x : th)
+            x.join();
+    }
+    for (const std::string &t : text)
+        os.write(t.data(), (std::streamsize)t.size());
+    });
+}
 
 void MafExport::printBlock(std::ostream &os) const {
     // MafBlock's operator<< (halMafBlock.cpp:499-520) prints field by field through the stream; formatting a block into
@@ -448,6 +639,14 @@ void MafExport::convertSequence(std::ostream &mafStream, hgx_alignment *alignmen
     // fail on the block-length limit and appendColumn only appends one character per entry; the run is therefore
     // appended in bulk, falling back to single columns at sequence ends and block-length breaks.
     if (!_unique && !getenv("HGX_MAF_PER_COLUMN")) {
+        struct SegModeGuard {
+            bool &f;
+            explicit SegModeGuard(bool &x) : f(x) { f = true; }
+            ~SegModeGuard() { f = false; }
+        } segModeGuard(_segMode);
+        _snapBlocks.clear();
+        _snapRows.clear();
+        _snapSegs.clear();
         double fetchSeconds = 0;
         size_t numHeads = 0;
         std::vector<uint8_t> head;
@@ -458,26 +657,6 @@ void MafExport::convertSequence(std::ostream &mafStream, hgx_alignment *alignmen
             ColumnRowHost *row; // null: entry gets a gap
         };
         std::vector<Pair> pairs;
-        auto comp = [](char c) {
-            switch (c) {
-            case 'A': return 'T';
-            case 'a': return 't';
-            case 'C': return 'G';
-            case 'c': return 'g';
-            case 'G': return 'C';
-            case 'g': return 'c';
-            case 'T': return 'A';
-            case 't': return 'a';
-            default: return c;
-            }
-        };
-        auto baseAt = [&](const ColumnRowHost &r, int64_t pos) {
-            const std::vector<uint8_t> &d = alignment->img.genomes[(size_t)r.genome].dna;
-            if (d.empty())
-                return 'N';
-            const char c = dnaAt(d, pos);
-            return r.rev ? comp(c) : c;
-        };
         auto rebuildColMap = [&]() {
             for (auto &kv : colMap)
                 kv.second.clear();
@@ -518,8 +697,9 @@ void MafExport::convertSequence(std::ostream &mafStream, hgx_alignment *alignmen
                             it = it->second.empty() ? colMap.erase(it) : std::next(it);
                     if (_keepEmptyRefBlocks || !referenceIsAllGaps()) {
                         t0 = now();
-                        printBlock(mafStream);
-                        mafStream << '\n';
+                        snapshotBlock();
+                        if (_snapBlocks.size() >= 32768)
+                            flushSnapshots(mafStream);
                         tPrint += since(t0);
                     }
                     t0 = now();
@@ -568,46 +748,13 @@ void MafExport::convertSequence(std::ostream &mafStream, hgx_alignment *alignmen
                     if (t > 0) {
                         for (const Pair &pr : pairs) {
                             if (!pr.row) {
-                                pr.e->sequence.append((size_t)t, '-');
+                                appendRun(pr.e, nullptr, 0, t);
                                 continue;
                             }
                             ColumnRowHost &r = *pr.row;
-                            const size_t at = pr.e->sequence.size();
-                            pr.e->sequence.resize(at + (size_t)t);
-                            char *dst = &pr.e->sequence[at];
-                            const std::vector<uint8_t> &d = alignment->img.genomes[(size_t)r.genome].dna;
-                            if (d.empty()) {
-                                memset(dst, 'N', (size_t)t);
-                            } else if (!r.rev) { // dnaUnpack (halCommon.h:187-190) over a forward run, two bases per packed byte
-                                static const char fwd[17] = "acgtn\0\0\0ACGTN\0\0\0";
-                                static const PairTable fwd2(fwd, false);
-                                const uint8_t *pk = d.data();
-                                int64_t p0 = r.pos + 1, k = 0;
-                                if (k < t && (p0 & 1)) { // odd start: low nibble of its byte
-                                    dst[k++] = fwd[pk[p0 >> 1] & 0x0F];
-                                    ++p0;
-                                }
-                                for (; k + 1 < t; k += 2, p0 += 2)
-                                    memcpy(dst + k, &fwd2.v[pk[p0 >> 1]], 2);
-                                if (k < t)
-                                    dst[k] = fwd[pk[p0 >> 1] >> 4];
-                            } else { // reverse strand: walk left, complemented (reverseComplement, halCommon.h:45-75)
-                                static const char rc[17] = "tgcan\0\0\0TGCAN\0\0\0";
-                                static const PairTable rc2(rc, true);
-                                const uint8_t *pk = d.data();
-                                int64_t p0 = r.pos - 1, k = 0;
-                                if (k < t && !(p0 & 1)) { // even start: high nibble of its byte, its partner lies to the right
-                                    dst[k++] = rc[pk[p0 >> 1] >> 4];
-                                    --p0;
-                                }
-                                for (; k + 1 < t; k += 2, p0 -= 2) // p0 odd: (low nibble, then high nibble) of one byte
-                                    memcpy(dst + k, &rc2.v[pk[p0 >> 1]], 2);
-                                if (k < t)
-                                    dst[k] = rc[pk[p0 >> 1] & 0x0F];
-                            }
+                            appendRun(pr.e, &r, r.rev ? r.pos - 1 : r.pos + 1, t); // the text is rendered when the block is printed
                             pr.e->length += t;
                             r.pos += r.rev ? -t : t;
-                            r.base = pr.e->sequence.back();
                         }
                         appendCount += (size_t)t;
                         run -= t;
@@ -615,10 +762,8 @@ void MafExport::convertSequence(std::ostream &mafStream, hgx_alignment *alignmen
                     }
                     tBulk += since(tb0);
                     if (run > 0) { // a block-length break or a sequence end: one ordinary column
-                        for (ColumnRowHost &r : curRows) {
-                            r.pos += r.rev ? -1 : 1;
-                            r.base = baseAt(r, r.pos);
-                        }
+                        for (ColumnRowHost &r : curRows)
+                            r.pos += r.rev ? -1 : 1; // (the base itself is not needed: rows are kept as runs)
                         rebuildColMap();
                         stepColumn(startPosition + done + col);
                         --run;
@@ -629,9 +774,14 @@ void MafExport::convertSequence(std::ostream &mafStream, hgx_alignment *alignmen
             }
             done += n;
         }
-        if (appendCount > 0 && (_keepEmptyRefBlocks || !referenceIsAllGaps())) {
-            printBlock(mafStream);
-            mafStream << std::endl;
+        if (appendCount > 0 && (_keepEmptyRefBlocks || !referenceIsAllGaps()))
+            snapshotBlock();
+        {
+            auto t0 = now();
+            flushSnapshots(mafStream);
+            waitPendingWrite();
+            mafStream.flush();
+            tPrint += since(t0);
         }
         if (getenv("HGX_MAF_TIMING"))
             std::cerr << "[hgx maf] columns " << length << " heads " << numHeads << " blocks " << numBlocks << " fetch(GPU+copy) "

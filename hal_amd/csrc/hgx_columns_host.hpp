@@ -4,6 +4,8 @@
 // (the block state depends on every earlier column) and stay on the host.
 #pragma once
 #include "hgx_columns_engine.hpp"
+#include <deque>
+#include <future>
 #include <map>
 #include <ostream>
 #include <set>
@@ -43,6 +45,15 @@ class MafExport {
         char strand = '+';
         std::string sequence;
         short lastUsed = 0;
+        // run mode (the default export path): the row's text is not built column by column; the entry keeps the runs it
+        // consists of and the text is rendered from the packed DNA when the block is printed
+        struct Seg {
+            int64_t pos; // genome coordinate of the run's first base (kind 2: the run walks left from there)
+            int32_t n;
+            uint8_t kind; // 0 gap, 1 forward bases, 2 reverse-strand bases (complemented)
+        };
+        std::vector<Seg> segs;
+        uint32_t nameId = 0; // index into _names (run mode snapshots refer to names by id)
     };
     struct Key {
         int rank, genome, seq;
@@ -68,6 +79,30 @@ class MafExport {
     bool canAppendColumn(const ColumnMap &col);
     bool referenceIsAllGaps() const;
     void printBlock(std::ostream &os) const;
+    // run mode: blocks are snapshotted (rows as runs) and rendered to text in batches by several threads
+    bool _segMode = false;
+    struct RowSnap {
+        uint32_t nameId, firstSeg, numSegs;
+        int64_t start, length, srcLength;
+        int32_t genome;
+        char strand;
+    };
+    struct BlockSnap {
+        uint32_t firstRow, numRows;
+    };
+    std::vector<BlockSnap> _snapBlocks;
+    std::vector<RowSnap> _snapRows;
+    std::vector<Entry::Seg> _snapSegs;
+    std::deque<std::string> _names;               // every row name handed out so far (a deque: rendering threads keep references)
+    std::map<std::string, uint32_t> _nameIds;
+    void snapshotBlock();
+    void flushSnapshots(std::ostream &os);
+    std::future<void> _pendingWrite;              // rendering + writing of the previous batch, running beside the state machine
+    void waitPendingWrite() {
+        if (_pendingWrite.valid())
+            _pendingWrite.get();
+    }
+    void appendRun(Entry *e, const ColumnRowHost *row, int64_t pos, int64_t n);
 };
 
 } // namespace hgx
