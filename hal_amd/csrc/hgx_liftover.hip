@@ -524,17 +524,15 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
 
     // stage 0
     const DeviceGenome &SG = D.genomes[(size_t)P.src];
-    // `order` = the batch sorted by start position: measured -14 % on the walk kernels (neighbouring lanes share cache
-    // lines) but +0.17 ms in k_finalize / k_scatter (their per-interval atomics then collide on the same lines) and 0.19 ms
-    // for the radix sort itself: no net gain on cfg2, so batches are processed in the order they arrive.
-    const uint32_t *order = nullptr;
+    // (processing the batch sorted by start position was measured: -14 % on the walk kernels, but +0.17 ms in the per-interval
+    // atomics of the grouping step and 0.19 ms for the sort itself — no net gain, so batches run in arrival order)
     P.timer.begin("k_locate_expand", s, launch);
     if (P.srcTop)
         hipLaunchKernelGGL((k_locate_expand<TopRec<C>>), dim3(GRID), dim3(256), 0, s, (const TopRec<C> *)SG.top, SG.numTop, dS, dE,
-                           dStrand, nq, order, (const int32_t *)SG.locate[0], SG.locateShift[0], P.frontier(cur), cap, cnt, kstat() + 0);
+                           dStrand, nq, (const int32_t *)SG.locate[0], SG.locateShift[0], P.frontier(cur), cap, cnt, kstat() + 0);
     else
         hipLaunchKernelGGL((k_locate_expand<BotRec<C>>), dim3(GRID), dim3(256), 0, s, (const BotRec<C> *)SG.bot, SG.numBot, dS, dE,
-                           dStrand, nq, order, (const int32_t *)SG.locate[1], SG.locateShift[1], P.frontier(cur), cap, cnt, kstat() + 1);
+                           dStrand, nq, (const int32_t *)SG.locate[1], SG.locateShift[1], P.frontier(cur), cap, cnt, kstat() + 1);
     P.timer.end(s);
     ++launch;
 

@@ -213,7 +213,7 @@ __device__ __forceinline__ uint32_t front_slot(const FrontView *v, uint32_t i, u
 template <typename REC>
 __global__ void __launch_bounds__(256) k_locate_expand(const REC *__restrict__ segs, int64_t numSegs, const int64_t *__restrict__ gStart,
                                                        const int64_t *__restrict__ gEnd, const uint8_t *__restrict__ strand,
-                                                       uint32_t nq, const uint32_t *__restrict__ order, const int32_t *__restrict__ coarse, int coarseShift, Frontier out,
+                                                       uint32_t nq, const int32_t *__restrict__ coarse, int coarseShift, Frontier out,
                                                        uint32_t cap,
                                                        unsigned long long *counters, unsigned long long *kstat) {
     const uint32_t wavesTotal = (gridDim.x * blockDim.x) >> 6;
@@ -223,11 +223,8 @@ __global__ void __launch_bounds__(256) k_locate_expand(const REC *__restrict__ s
     Stage stage;
     stage.init(&stageMem, out, &counters[CNT_FRONT0], counters, cap);
     for (uint32_t base = wave * 64; base < nq; base += wavesTotal * 64) {
-        // `order` (optional): the intervals sorted by start position, so that neighbouring lanes search, expand and later
-        // walk neighbouring segments; a piece keeps its interval's own index, nothing downstream depends on the order
-        const uint32_t qi = base + lane_id();
-        bool act = qi < nq;
-        const uint32_t q = act && order ? order[qi] : qi;
+        const uint32_t q = base + lane_id();
+        bool act = q < nq;
         int64_t gs = 0, ge = -1;
         uint8_t fl = 0;
         bool minus = false;
