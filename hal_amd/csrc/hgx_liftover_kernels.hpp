@@ -468,6 +468,9 @@ __device__ __forceinline__ int64_t make_anchor(int64_t sPos, int64_t lo, int64_t
 // per step (more requests per step than scan steps saved), and 4 lanes per piece sharing one 64-byte request (fewer
 // requests, but four times the wave-steps made it issue-bound: 3.1 ms against 1.2 ms), and fetching the right-hand
 // neighbour together with the record when a piece has just arrived at a level, to save the first scan step (1.23 ms against 1.20 ms).
+// Doing the single down hop into the target inside this kernel as well (a lane that has cut a piece at the last level gathers
+// the DownRec in its next step and walks the ring) was also measured: 1.68 ms against 1.21 + 0.48 ms for the two launches — the
+// frontier between them is coalesced traffic, the gathers are what costs, and fusing does not remove any.
 static inline size_t upChainLdsBytes(int hops) {
     const int slots = hops - 1 > 1 ? hops - 2 : 1;
     return (size_t)slots * 256 * (8 + 8 + 4 + 1);
