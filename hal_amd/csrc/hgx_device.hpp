@@ -12,6 +12,7 @@
 #include <mutex>
 #include "../../include/hgx.h"
 #include "hgx_image.hpp"
+#include <map>
 #include <memory>
 
 namespace hgx {
@@ -106,6 +107,24 @@ template <> struct alignas(16) DownRec<int64_t> {
     int32_t paralogy;
     int64_t _pad;
 };
+// Composed up table of a (source genome, ancestor) pair: the pieces the whole up walk (k_up_chain) produces for every
+// source top segment, in source order — what a chain file is to a pairwise alignment.  A batch's intervals are then clipped
+// against these records instead of walking level by level (k_locate_composed).  Built on the GPU by the walk kernels
+// themselves when a plan is created for a large batch (ensureComposedUp).
+template <typename C> struct alignas(16) ComposedRec {
+    C sLo;        // source genome position of the piece's first base (the source side runs forward)
+    C len;
+    C so, eo;     // offsets of the piece inside the ancestor's bottom segment, in iteration order, before and after it
+    int32_t mEnc; // (ancestor bottom segment index << 1) | target-reversed
+    int32_t seg;  // source top segment the piece came from
+    int32_t _pad[2];
+};
+struct ComposedUp {
+    void *recs = nullptr;      // ComposedRec<C>[numRecs], sorted by sLo
+    uint32_t *pstart = nullptr; // [numTop(src) + 1]: first record of every source top segment
+    uint64_t numRecs = 0;
+    double buildMs = 0;
+};
 template <typename C> struct BotRec;
 template <> struct alignas(8) BotRec<int32_t> {
     int32_t start;
@@ -152,6 +171,7 @@ struct DeviceImage {
     std::vector<DeviceGenome> genomes;
     GenomeDesc *desc = nullptr;          // device array, one per genome
     std::vector<uint8_t *> dna;          // device copies of the packed DNA (uploaded on first use)
+    std::map<std::pair<int, int>, ComposedUp> composed; // (source genome, ancestor) -> composed up table
     size_t bytes = 0;
     ~DeviceImage();
 };

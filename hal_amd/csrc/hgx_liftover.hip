@@ -3,6 +3,7 @@
 #include "hgx_finish_kernel.hpp"
 #include "hgx_liftover_engine.hpp"
 #include <algorithm>
+#include <chrono>
 #include <functional>
 #include <cstdlib>
 #include <mutex>
@@ -46,6 +47,12 @@ DeviceImage::~DeviceImage() {
                 (void)hipFree(c);
         if (g.seqStart)
             (void)hipFree(g.seqStart);
+    }
+    for (auto &kv : composed) {
+        if (kv.second.recs)
+            (void)hipFree(kv.second.recs);
+        if (kv.second.pstart)
+            (void)hipFree(kv.second.pstart);
     }
     if (desc)
         (void)hipFree(desc);
@@ -430,6 +437,14 @@ struct hgx_liftover_plan {
     std::vector<int> up;                        // src ... mrca
     std::vector<std::pair<int, int>> down;      // (parent genome, child slot) per downward hop
     bool srcTop = true;
+    const ComposedUp *composed = nullptr;       // composed up table src -> mrca (large plans; see ensureComposedUp), or null
+    bool captureUp = false;                     // table builder: keep the pieces that arrive in the MRCA
+    struct CapturedPiece {
+        int32_t qid, idx, len;
+        int64_t sPos, so;
+        uint8_t fl;
+    };
+    std::vector<CapturedPiece> captured;
     std::vector<int> climb;                     // mrca ... coalescenceLimit when the limit lies above the MRCA (and dupes are on), else empty
     int numFrontiers = 2;
     bool levelSyncUp = getenv("HGX_LEVEL_SYNC_UP") != nullptr; // one launch per up level instead of k_up_chain (kept for deep trees and as a cross-check)
@@ -526,6 +541,16 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
     const DeviceGenome &SG = D.genomes[(size_t)P.src];
     // (processing the batch sorted by start position was measured: -14 % on the walk kernels, but +0.17 ms in the per-interval
     // atomics of the grouping step and 0.19 ms for the sort itself — no net gain, so batches run in arrival order)
+    const bool useComposed = P.composed != nullptr;
+    if (useComposed) {
+        // locate + the whole up phase from the composed table: the pieces arrive in the MRCA directly
+        P.timer.begin("k_locate_composed", s, launch);
+        hipLaunchKernelGGL((k_locate_composed<C, TopRec<C>>), dim3(GRID), dim3(256), 0, s, (const TopRec<C> *)SG.top, SG.numTop, dS, dE, dStrand,
+                           nq, (const int32_t *)SG.locate[0], SG.locateShift[0], (const uint32_t *)P.composed->pstart,
+                           (const ComposedRec<C> *)P.composed->recs, (uint64_t)P.composed->numRecs, P.frontier(cur), cap, inCnt(), cnt);
+        P.timer.end(s);
+        ++launch;
+    } else {
     P.timer.begin("k_locate_expand", s, launch);
     if (P.srcTop)
         hipLaunchKernelGGL((k_locate_expand<TopRec<C>>), dim3(GRID), dim3(256), 0, s, (const TopRec<C> *)SG.top, SG.numTop, dS, dE,
@@ -535,10 +560,14 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
                            dStrand, nq, (const int32_t *)SG.locate[1], SG.locateShift[1], P.frontier(cur), cap, cnt, kstat() + 1);
     P.timer.end(s);
     ++launch;
+    }
 
     bool curTop = P.srcTop;
     int curGenome = P.src;
-    if (P.src != P.mrca) {
+    if (useComposed) {
+        curGenome = P.mrca;
+        curTop = false;
+    } else if (P.src != P.mrca) {
         // up phase: P.up = [src, ..., mrca].  k_up_first lifts the source's top pieces to its parent; every further level
         // is one k_up_walk launch.  The last launch emits ordinary bottom pieces (index, offset) in the MRCA, the
         // others emit positional pieces (forward start in the parent + its top-parse hint).
@@ -583,6 +612,45 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
         }
         curGenome = P.mrca;
         curTop = false;
+    }
+    if (P.captureUp) { // table builder: bring the pieces that reached the MRCA to the host
+        HIP_OK(hipStreamSynchronize(s));
+        unsigned long long segCount[NSEG];
+        HIP_OK(hipMemcpy(segCount, inCnt(), 8 * NSEG, hipMemcpyDeviceToHost));
+        const uint32_t segCap = cap / NSEG;
+        const Frontier F = P.frontier(cur);
+        P.captured.clear();
+        std::vector<int32_t> a32;
+        std::vector<int64_t> a64;
+        std::vector<uint8_t> a8;
+        for (int sg = 0; sg < NSEG; ++sg) {
+            const size_t c = (size_t)std::min<unsigned long long>(segCount[sg], segCap);
+            if (!c)
+                continue;
+            const size_t at = P.captured.size(), off = (size_t)sg * segCap;
+            P.captured.resize(at + c);
+            a32.resize(c);
+            a64.resize(c);
+            a8.resize(c);
+            HIP_OK(hipMemcpy(a32.data(), F.qid + off, 4 * c, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < c; ++i)
+                P.captured[at + i].qid = a32[i];
+            HIP_OK(hipMemcpy(a32.data(), F.idx + off, 4 * c, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < c; ++i)
+                P.captured[at + i].idx = a32[i];
+            HIP_OK(hipMemcpy(a32.data(), F.len + off, 4 * c, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < c; ++i)
+                P.captured[at + i].len = a32[i];
+            HIP_OK(hipMemcpy(a64.data(), F.sPos + off, 8 * c, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < c; ++i)
+                P.captured[at + i].sPos = a64[i];
+            HIP_OK(hipMemcpy(a64.data(), F.so + off, 8 * c, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < c; ++i)
+                P.captured[at + i].so = a64[i];
+            HIP_OK(hipMemcpy(a8.data(), F.flags + off, c, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < c; ++i)
+                P.captured[at + i].fl = a8[i];
+        }
     }
     if (!P.climb.empty()) {
         // mapRecursiveParalogies (halSegmentMapper.cpp:525-576), coalescenceLimit above the MRCA: at every genome c_i from
@@ -899,11 +967,18 @@ static void runPlan(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
     P.stats.deferred_queries = nDef;
     P.stats.walk_ms = walk;
     P.stats.total_ms = tot;
+    P.stats.composed_records = P.composed ? P.composed->numRecs : 0;
+    P.stats.composed_build_ms = P.composed ? P.composed->buildMs : 0;
     *dOut = (const hgx_record *)P.outRecords.p;
     *nOut = totalRecords;
 }
 
-hgx_liftover_plan *createLiftoverPlan(hgx_alignment *h, int src, int tgt, const hgx_liftover_opts &opts, size_t maxQueries) {
+static const ComposedUp *ensureComposedUp(hgx_alignment *h, int src, int mrca);
+static void runHostArrays(hgx_liftover_plan *P, const std::vector<int64_t> &gs, const std::vector<int64_t> &ge, const std::vector<uint8_t> &st,
+                          std::vector<hgx_record> &out);
+
+hgx_liftover_plan *createLiftoverPlan(hgx_alignment *h, int src, int tgt, const hgx_liftover_opts &opts, size_t maxQueries,
+                                      bool allowComposed) {
     if (!h->dev)
         throw std::runtime_error("alignment was opened without a device (device = -1); liftover needs the HIP path");
     const Image &img = h->img;
@@ -974,7 +1049,89 @@ hgx_liftover_plan *createLiftoverPlan(hgx_alignment *h, int src, int tgt, const 
     HIP_OK(hipEventCreate(&P->evEnd));
     const unsigned long long want = std::max<unsigned long long>(1ull << 16, 16ull * P->maxQueries); // grown on demand
     P->allocate((uint32_t)std::min<unsigned long long>(want, (1ull << 32) - 2));
+    // A plan for a batch that is large against the source genome serves the up phase from the composed table (building it
+    // costs one walk over every source segment).  HGX_COMPOSED_UP=1 forces it, =0 forbids it.
+    if (allowComposed && src != P->mrca && P->srcTop && opts.min_length == 0) {
+        const char *e = getenv("HGX_COMPOSED_UP");
+        const bool force = e && e[0] == '1', forbid = e && e[0] == '0';
+        const bool big = P->maxQueries * 8 >= (size_t)img.genomes[(size_t)src].numTop;
+        if (!forbid && (force || big))
+            P->composed = ensureComposedUp(h, src, P->mrca);
+    }
     return P.release();
+}
+
+// Builds (once per alignment and pair) the composed up table of src -> mrca: every source top segment is lifted to the MRCA
+// as one interval by the ordinary walk (a plan with captureUp), the pieces are sorted by source position and stored with
+// the per-segment index.  Serialised; the table lives as long as the device image.
+template <typename C> static void buildComposedUp(hgx_alignment *h, int src, int mrca, ComposedUp &out) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const GenomeTables &S = h->img.genomes[(size_t)src];
+    const GenomeTables &M = h->img.genomes[(size_t)mrca];
+    const size_t nt = (size_t)S.numTop;
+    hgx_liftover_opts o{};
+    o.traverse_dupes = 1;
+    o.coalescence_limit = -1;
+    std::unique_ptr<hgx_liftover_plan, void (*)(hgx_liftover_plan *)> P(createLiftoverPlan(h, src, mrca, o, nt, /*allowComposed=*/false),
+                                                                       destroyLiftoverPlan);
+    P->captureUp = true;
+    P->timer.mode = 0;
+    std::vector<int64_t> gs(nt), ge(nt);
+    std::vector<uint8_t> st(nt, (uint8_t)'+');
+    for (size_t i = 0; i < nt; ++i) {
+        gs[i] = S.tStart[i];
+        ge[i] = S.tStart[i + 1] - 1;
+    }
+    std::vector<hgx_record> ignored;
+    runHostArrays(P.get(), gs, ge, st, ignored);
+    std::vector<hgx_liftover_plan::CapturedPiece> &cp = P->captured;
+    std::sort(cp.begin(), cp.end(), [](const hgx_liftover_plan::CapturedPiece &a, const hgx_liftover_plan::CapturedPiece &b) {
+        return a.sPos < b.sPos; // source positions of distinct pieces are disjoint; qid (= segment) order follows
+    });
+    std::vector<ComposedRec<C>> recs(std::max<size_t>(cp.size(), 1));
+    memset(recs.data(), 0, recs.size() * sizeof(ComposedRec<C>));
+    std::vector<uint32_t> pstart(nt + 1, 0);
+    if (cp.size() >= ((size_t)1 << 32) - 1)
+        throw std::runtime_error("composed up table too large");
+    for (size_t k = 0; k < cp.size(); ++k) {
+        const hgx_liftover_plan::CapturedPiece &p = cp[k];
+        if (p.fl & F_SREV)
+            throw std::runtime_error("internal: a forward source segment produced a source-reversed piece");
+        ComposedRec<C> &r = recs[k];
+        const int64_t segLen = M.bStart[(size_t)p.idx + 1] - M.bStart[(size_t)p.idx];
+        r.sLo = (C)p.sPos;
+        r.len = (C)p.len;
+        r.so = (C)p.so;
+        r.eo = (C)(segLen - p.so - p.len);
+        r.mEnc = (int32_t)((p.idx << 1) | ((p.fl & F_TREV) ? 1 : 0));
+        r.seg = p.qid;
+        ++pstart[(size_t)p.qid + 1];
+    }
+    for (size_t i = 0; i < nt; ++i)
+        pstart[i + 1] += pstart[i];
+    HIP_OK(hipSetDevice(h->dev->device));
+    HIP_OK(hipMalloc(&out.recs, recs.size() * sizeof(ComposedRec<C>)));
+    HIP_OK(hipMemcpy(out.recs, recs.data(), recs.size() * sizeof(ComposedRec<C>), hipMemcpyHostToDevice));
+    HIP_OK(hipMalloc((void **)&out.pstart, pstart.size() * 4));
+    HIP_OK(hipMemcpy(out.pstart, pstart.data(), pstart.size() * 4, hipMemcpyHostToDevice));
+    out.numRecs = cp.size();
+    h->dev->bytes += recs.size() * sizeof(ComposedRec<C>) + pstart.size() * 4;
+    out.buildMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+static const ComposedUp *ensureComposedUp(hgx_alignment *h, int src, int mrca) {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    auto key = std::make_pair(src, mrca);
+    auto it = h->dev->composed.find(key);
+    if (it != h->dev->composed.end())
+        return &it->second;
+    ComposedUp c;
+    if (h->dev->wide)
+        buildComposedUp<int64_t>(h, src, mrca, c);
+    else
+        buildComposedUp<int32_t>(h, src, mrca, c);
+    return &h->dev->composed.emplace(key, c).first->second;
 }
 
 void runLiftoverPlan(hgx_liftover_plan *p, size_t n, const int64_t *dS, const int64_t *dE, const uint8_t *dStrand, void *stream,

@@ -288,6 +288,108 @@ __global__ void __launch_bounds__(256) k_locate_expand(const REC *__restrict__ s
 }
 
 // ---------------------------------------------------------------------------------------------
+// Stage 0 + the whole up phase from the composed table (ComposedRec, hgx_device.hpp): the records of consecutive source
+// segments are contiguous, so an interval is one binary search, one look at pstart[] and a scan over the few records it
+// overlaps; each is clipped to the interval and leaves as an ordinary bottom piece in the ancestor — the same pieces
+// k_locate_expand + k_up_chain produce (a source segment's pieces are cut at the same places whatever part of the segment
+// an interval covers, so clipping the whole segment's pieces is the same as walking the part).  A '-' interval is the
+// forward result reversed in place: source first base = the high end, both strand bits flipped, offsets from the other end
+// (toReverseInPlace commutes with every hop: parent / child hops copy the offsets, parse steps are symmetric).
+template <typename C, typename REC>
+__global__ void __launch_bounds__(256) k_locate_composed(const REC *__restrict__ segs, int64_t numSegs, const int64_t *__restrict__ gStart,
+                                                         const int64_t *__restrict__ gEnd, const uint8_t *__restrict__ strand, uint32_t nq,
+                                                         const int32_t *__restrict__ coarse, int coarseShift,
+                                                         const uint32_t *__restrict__ pstart, const ComposedRec<C> *__restrict__ recs,
+                                                         uint64_t numRecs, Frontier out, uint32_t cap, unsigned long long *outCount,
+                                                         unsigned long long *counters) {
+    const uint32_t wavesTotal = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    uint32_t srcPieces = 0;
+    __shared__ StageMem stageMem;
+    Stage stage;
+    stage.init(&stageMem, out, outCount, counters, cap);
+    for (uint32_t base = wave * 64; base < nq; base += wavesTotal * 64) {
+        const uint32_t q = base + lane_id();
+        bool act = q < nq;
+        int64_t gs = 0, ge = -1;
+        uint8_t dot = 0;
+        bool minus = false;
+        uint64_t k = 0;
+        int32_t lastSeg = -1;
+        if (act) {
+            gs = gStart[q];
+            ge = gEnd[q];
+            const uint8_t st = strand[q];
+            minus = st == '-';
+            if (st == '.')
+                dot = F_DOT;
+            act = ge >= gs && gs >= 0 && numSegs > 0 && gs < (int64_t)segs[numSegs].start;
+            if (act) {
+                int64_t lo = 0, hi = numSegs; // invariant start[lo] <= gs < start[hi]
+                if (coarse) {
+                    const int64_t b = gs >> coarseShift;
+                    lo = coarse[b];
+                    const int64_t up = (int64_t)coarse[b + 1] + 1;
+                    hi = up < numSegs ? up : numSegs;
+                    if (hi <= lo)
+                        hi = lo + 1;
+                }
+                while (hi - lo > 1) {
+                    const int64_t mid = (lo + hi) >> 1;
+                    if ((int64_t)segs[mid].start <= gs)
+                        lo = mid;
+                    else
+                        hi = mid;
+                }
+                k = pstart[lo];
+            }
+        }
+        while (__any(act)) {
+            bool emit = false;
+            int32_t oIdx = 0, oLen = 0;
+            int64_t oSPos = 0, oSo = 0;
+            uint8_t oFl = 0;
+            if (act) {
+                if (k >= numRecs) {
+                    act = false;
+                } else {
+                    const ComposedRec<C> r = recs[k];
+                    const int64_t pLo = (int64_t)r.sLo, pHi = pLo + (int64_t)r.len - 1;
+                    if (pLo > ge) {
+                        act = false;
+                    } else {
+                        ++k;
+                        if (pHi >= gs) {
+                            const int64_t c = pLo > gs ? pLo : gs, d = pHi < ge ? pHi : ge;
+                            const int64_t n = d - c + 1, delta = c - pLo;
+                            emit = true;
+                            oLen = (int32_t)n;
+                            oIdx = r.mEnc >> 1;
+                            oFl = (uint8_t)(((r.mEnc & 1) ? F_TREV : 0) | dot);
+                            if (!minus) {
+                                oSPos = c;
+                                oSo = (int64_t)r.so + delta;
+                            } else {
+                                oSPos = d;
+                                oSo = (int64_t)r.eo + ((int64_t)r.len - delta - n);
+                                oFl ^= (uint8_t)(F_SREV | F_TREV);
+                            }
+                            if (r.seg != lastSeg) {
+                                lastSeg = r.seg;
+                                ++srcPieces;
+                            }
+                        }
+                    }
+                }
+            }
+            stage.emit(emit, (int32_t)q, oSPos, oIdx, oSo, oLen, oFl);
+        }
+    }
+    stage.flush();
+    wave_count_add(&counters[CNT_SRC_PIECES], srcPieces);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Up phase.  mapUp (halSegmentMapper.cpp:25-80) alternates two steps per level: a top piece goes to its parent's
 // bottom segment (toParent, api/impl/halBottomSegmentIterator.cpp:40-49: index = parentIndex, offsets copied,
 // strand ^= parentReversed; dropped without a parent or below minLength; doDupes is always true on the way up, :108),

@@ -138,6 +138,12 @@ int hgx_liftover_run_device(hgx_liftover_plan *p, size_t n, const int64_t *d_gst
 typedef struct hgx_liftover_stats {
     uint64_t queries, source_pieces, top_derefs, bottom_derefs, mapped_pieces, records, deferred_queries;
     double walk_ms, total_ms;
+    /* Plans for batches that are large against the source genome serve locate + the whole up phase from a composed table
+     * (every source top segment lifted to the MRCA once, by the walk kernels, when the first such plan is created): its size
+     * and build time, or zeros when this plan walks level by level.  With the table the dereference counters above cover
+     * the down phase only.  HGX_COMPOSED_UP=1 / =0 in the environment forces / forbids the table. */
+    uint64_t composed_records;
+    double composed_build_ms;
 } hgx_liftover_stats;
 int hgx_liftover_last_stats(const hgx_liftover_plan *p, hgx_liftover_stats *out);
 /* Per-kernel device time, measured with HIP events on the run's stream, as a JSON object

@@ -1,5 +1,5 @@
 """The alternative code paths behind environment switches give the same bytes as the defaults: one launch per up level
-(HGX_LEVEL_SYNC_UP), the per-column depth kernel (HGX_COLUMNS_PER_BASE), the per-column MAF path (HGX_MAF_PER_COLUMN), the
+(HGX_LEVEL_SYNC_UP), the composed up table forced on small batches (HGX_COMPOSED_UP), the per-column depth kernel (HGX_COLUMNS_PER_BASE), the per-column MAF path (HGX_MAF_PER_COLUMN), the
 64-bit instantiations (HGX_FORCE_WIDE).  Each switch is read once per process, so every variant runs in its own process."""
 import hashlib
 import os
@@ -47,7 +47,8 @@ def _digest(**env):
 def test_switchable_paths_agree():
     base = _digest()
     assert len(base) == 64
-    for env in ({"HGX_LEVEL_SYNC_UP": "1"}, {"HGX_COLUMNS_PER_BASE": "1"}, {"HGX_MAF_PER_COLUMN": "1"}, {"HGX_FORCE_WIDE": "1"}):
+    for env in ({"HGX_LEVEL_SYNC_UP": "1"}, {"HGX_COLUMNS_PER_BASE": "1"}, {"HGX_MAF_PER_COLUMN": "1"}, {"HGX_FORCE_WIDE": "1"},
+                {"HGX_COMPOSED_UP": "1"}, {"HGX_COMPOSED_UP": "1", "HGX_FORCE_WIDE": "1"}):
         assert _digest(**env) == base, env
 
 
@@ -64,16 +65,17 @@ def test_plan_timing_modes(hal, tmp_path):
     plan = hal.LiftoverPlan(al, src, tgt, max_queries=n)
     plan.run(gs, ge, st)
     last = plan.kernel_times()
-    assert last["k_up_chain"]["launches"] == 1
+    walk = "k_up_chain" if "k_up_chain" in last else "k_locate_composed"  # a batch this large against the genome uses the table
+    assert last[walk]["launches"] == 1 and last["k_down_ring"]["top_derefs"] > 0
     plan.set_timing(2)  # accumulate
     for _ in range(3):
         plan.run(gs, ge, st)
     acc = plan.kernel_times()
-    assert acc["k_up_chain"]["launches"] == 3 and acc["k_up_chain"]["top_derefs"] == 3 * last["k_up_chain"]["top_derefs"]
+    assert acc[walk]["launches"] == 3 and acc["k_down_ring"]["top_derefs"] == 3 * last["k_down_ring"]["top_derefs"]
     assert plan.kernel_times() == {}  # the window restarts after a read
     plan.set_timing(0)
     plan.run(gs, ge, st)
     assert plan.kernel_times() == {}
     plan.set_timing(1)
     plan.run(gs, ge, st)
-    assert plan.kernel_times()["k_up_chain"]["launches"] == 1
+    assert plan.kernel_times()[walk]["launches"] == 1

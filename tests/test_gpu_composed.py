@@ -1,0 +1,106 @@
+"""The composed up table (large plans: locate + the whole up phase from one table, k_locate_composed) against the oracle:
+forced with HGX_COMPOSED_UP=1 on small batches, every genome pair, both strands and '.', dupes on and off, BED12 / PSL,
+the coalescence limit, real data; and at scale against the walk kernels (HGX_COMPOSED_UP=0)."""
+import os
+
+import numpy as np
+import pytest
+
+import halfix
+from util import oracle_liftover, random_bed
+from test_gpu_liftover import _rand_alignment
+from test_gpu_multiseq import _bed
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(autouse=True)
+def _forced(monkeypatch):
+    monkeypatch.setenv("HGX_COMPOSED_UP", "1")
+
+
+@pytest.mark.parametrize("seed", [2, 5, 9])
+def test_randgen_all_pairs(hal, oracle_bin, tmp_path, seed):
+    al, img = _rand_alignment(hal, tmp_path, seed)
+    n = al.num_genomes
+    lines = 0
+    for s in range(n):
+        name, _, length = al.sequences(s)[0]
+        if length == 0:
+            continue
+        for t in range(n):
+            bed = random_bed(name, length, 120, 1, 400, seed * 100 + s * n + t, strands="+-.")
+            nd = (s + t) % 3 == 0
+            got = hal.liftover_convert(al, s, bed, t, traverse_dupes=not nd)
+            assert got == oracle_liftover(oracle_bin, img, al.genome_name(s), al.genome_name(t), bed, tmp_path, no_dupes=nd), \
+                (al.genome_name(s), al.genome_name(t), nd)
+            lines += got.count("\n")
+            m = al.mrca(s, t)
+            if (s + 2 * t) % 5 == 0 and al.genome_parent(m) >= 0:
+                lim = al.genome_parent(m)
+                assert hal.liftover_convert(al, s, bed, t, coalescence_limit=lim) == \
+                    oracle_liftover(oracle_bin, img, al.genome_name(s), al.genome_name(t), bed, tmp_path, coalescence_limit=al.genome_name(lim))
+    assert lines > 2000
+
+
+@pytest.mark.parametrize("seed", [0, 3])
+def test_multiseq_bed12_psl(hal, oracle_bin, tmp_path, seed):
+    img = str(tmp_path / "ms.hgx")
+    halfix.write_hgx(img, halfix.random_multiseq_alignment(seed, n_genomes=7))
+    al = hal.Alignment.open(img, device=0)
+    n = al.num_genomes
+    for s in range(n):
+        for t in range(n):
+            bed = _bed(al, s, 50, seed * 100 + s * n + t)
+            assert hal.liftover_convert(al, s, bed, t) == oracle_liftover(oracle_bin, img, al.genome_name(s), al.genome_name(t), bed, tmp_path)
+            if (s + t) % 4 == 0:
+                bedp = bed.replace("\t.\n", "\t+\n")
+                assert hal.liftover_convert(al, s, bedp, t, out_psl=True) == \
+                    oracle_liftover(oracle_bin, img, al.genome_name(s), al.genome_name(t), bedp, tmp_path, psl=True)
+
+
+def test_real_data(hal, oracle_bin, tmp_path):
+    try:
+        al = hal.Alignment.open(os.path.join(GOLD, "ref_hdf5", "mr.hal"), device=0)
+    except hal.HgxError as e:
+        if "HDF5 C library" in str(e):
+            pytest.skip("libhdf5 not loadable here")
+        raise
+    img = str(tmp_path / "mr.hgx")
+    al.save(img)
+    for src, tgt in (("simMouse_chr6", "simRat_chr6"), ("simRat_chr6", "mr"), ("simRat_chr6", "simMouse_chr6")):
+        s, t = al.genome_id(src), al.genome_id(tgt)
+        bed = _bed(al, s, 2000, 3 + s + t)
+        name, _, length = al.sequences(s)[0]
+        rng = np.random.default_rng(8)
+        for _ in range(60):
+            ln = int(rng.integers(1000, 30000))
+            st = int(rng.integers(0, length - ln))
+            bed += "%s\t%d\t%d\tlong\t0\t%s\n" % (name, st, st + ln, "+-"[int(rng.integers(0, 2))])
+        assert hal.liftover_convert(al, s, bed, t) == oracle_liftover(oracle_bin, img, src, tgt, bed, tmp_path), (src, tgt)
+
+
+def test_at_scale_against_the_walk_kernels(hal, monkeypatch):
+    """200 k intervals on ~10 Mb genomes: composed table vs level walk, record for record."""
+    import torch
+    opts = hal.RandOptions(mean_degree=1.5, max_branch_length=3.0, min_genomes=2, max_genomes=10, min_segment_length=50,
+                           max_segment_length=200, min_segments=70000, max_segments=140000, seed=2, with_dna=False)
+    al = hal.Alignment.random(opts, device=0)
+    src, tgt = al.genome_id("Genome_9"), al.genome_id("Genome_8")
+    _, ss, length = al.sequences(src)[0]
+    n = 200000
+    g = torch.Generator().manual_seed(4)
+    starts = torch.randint(0, length - 1100, (n,), generator=g)
+    lens = torch.randint(50, 1000, (n,), generator=g)
+    strand = torch.where(torch.rand(n, generator=g) < 0.5, ord("+"), ord("-")).to(torch.uint8)
+    gs, ge, st = (starts + ss).cuda(), (starts + lens - 1 + ss).cuda(), strand.cuda()
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("HGX_COMPOSED_UP", mode)
+        plan = hal.LiftoverPlan(al, src, tgt, max_queries=n)
+        ptr, nrec = plan.run(gs, ge, st)
+        out[mode] = plan.records_to_tensor(ptr, nrec).cpu()
+        kt = plan.kernel_times()
+        assert ("k_locate_composed" in kt) == (mode == "1") and ("k_up_chain" in kt) == (mode == "0")
+    assert out["1"].shape[0] > n and torch.equal(out["1"], out["0"])
