@@ -286,7 +286,7 @@ def main():
                        "intervals_per_gpu": nq, "records_per_step": nrec_all, "parallelism": "query-shard x%d" % world,
                        "up_phase": ("composed table src->MRCA: %d records (%.0f MB), built once by the walk kernels in %.0f ms at plan "
                                     "creation, untimed; set HGX_COMPOSED_UP=0 for the level-by-level walk"
-                                    % (st["composed_records"], st["composed_records"] * 32 / 1e6, st["composed_build_ms"]))
+                                    % (st["composed_records"], st["composed_records"] * 20 / 1e6, st["composed_build_ms"]))
                        if st["composed_records"] else "level-by-level walk (k_up_chain)",
                        "exchange": ("all-gatherv of %d-byte records, overlapped with the next batch" % (20 if packed_wire else 40))
                        if world > 1 else "none (one GPU)",

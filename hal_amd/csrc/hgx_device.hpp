@@ -111,17 +111,23 @@ template <> struct alignas(16) DownRec<int64_t> {
 // source top segment, in source order — what a chain file is to a pairwise alignment.  A batch's intervals are then clipped
 // against these records instead of walking level by level (k_locate_composed).  Built on the GPU by the walk kernels
 // themselves when a plan is created for a large batch (ensureComposedUp).
-template <typename C> struct alignas(16) ComposedRec {
-    C sLo;        // source genome position of the piece's first base (the source side runs forward)
-    C len;
-    C so, eo;     // offsets of the piece inside the ancestor's bottom segment, in iteration order, before and after it
-    int32_t mEnc; // (ancestor bottom segment index << 1) | target-reversed
-    int32_t seg;  // source top segment the piece came from
-    int32_t _pad[2];
+template <typename C> struct ComposedRec;
+template <> struct alignas(16) ComposedRec<int32_t> { // 16 bytes: one gather per record (the kernel is bound by gathers in flight)
+    int32_t sLo;    // source genome position of the piece's first base (the source side runs forward)
+    int32_t len;
+    int32_t so;     // offset of the piece inside the ancestor's bottom segment, in iteration order
+    uint32_t mEncF; // (ancestor bottom segment index << 2) | (first piece of its source segment << 1) | target-reversed
+};
+template <> struct alignas(16) ComposedRec<int64_t> {
+    int64_t sLo, so, len;
+    uint32_t mEncF;
+    uint32_t _pad;
 };
 struct ComposedUp {
-    void *recs = nullptr;      // ComposedRec<C>[numRecs], sorted by sLo
-    uint32_t *pstart = nullptr; // [numTop(src) + 1]: first record of every source top segment
+    void *recs = nullptr;       // ComposedRec<C>[numRecs], sorted by sLo
+    void *eo = nullptr;         // C[numRecs]: bases of the ancestor's bottom segment after the piece (needed by '-' intervals only)
+    uint32_t *coarse = nullptr; // [buckets + 1]: first record that does not end before position bucket << shift
+    int shift = 0;
     uint64_t numRecs = 0;
     double buildMs = 0;
 };

@@ -51,8 +51,10 @@ DeviceImage::~DeviceImage() {
     for (auto &kv : composed) {
         if (kv.second.recs)
             (void)hipFree(kv.second.recs);
-        if (kv.second.pstart)
-            (void)hipFree(kv.second.pstart);
+        if (kv.second.eo)
+            (void)hipFree(kv.second.eo);
+        if (kv.second.coarse)
+            (void)hipFree(kv.second.coarse);
     }
     if (desc)
         (void)hipFree(desc);
@@ -532,9 +534,9 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
     int launch = 0; // per-launch deref counter slot
     auto kstat = [&]() { return cnt + CNT_KSTAT0 + 2 * launch; };
     int cur = 0; // frontier buffer holding the current pieces
-    auto inCnt = [&]() { return cnt + CNT_FRONT0 + (size_t)level * NSEG; };
+    auto inCnt = [&]() { return cnt + CNT_FRONT0 + (size_t)level; };
     int outLevel = 1; // counter block of the frontier the next launch writes; every launch gets a fresh one
-    auto outCnt = [&]() { return cnt + CNT_FRONT0 + (size_t)outLevel * NSEG; };
+    auto outCnt = [&]() { return cnt + CNT_FRONT0 + (size_t)outLevel; };
     const int64_t minLen = P.opts.min_length;
 
     // stage 0
@@ -545,9 +547,9 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
     if (useComposed) {
         // locate + the whole up phase from the composed table: the pieces arrive in the MRCA directly
         P.timer.begin("k_locate_composed", s, launch);
-        hipLaunchKernelGGL((k_locate_composed<C, TopRec<C>>), dim3(GRID), dim3(256), 0, s, (const TopRec<C> *)SG.top, SG.numTop, dS, dE, dStrand,
-                           nq, (const int32_t *)SG.locate[0], SG.locateShift[0], (const uint32_t *)P.composed->pstart,
-                           (const ComposedRec<C> *)P.composed->recs, (uint64_t)P.composed->numRecs, P.frontier(cur), cap, inCnt(), cnt);
+        hipLaunchKernelGGL((k_locate_composed<C>), dim3(GRID), dim3(256), 0, s, dS, dE, dStrand, nq, P.h->img.genomes[(size_t)P.src].totalLength,
+                           (const uint32_t *)P.composed->coarse, P.composed->shift, (const ComposedRec<C> *)P.composed->recs,
+                           (const C *)P.composed->eo, (uint64_t)P.composed->numRecs, P.frontier(cur), cap, inCnt(), cnt);
         P.timer.end(s);
         ++launch;
     } else {
@@ -616,7 +618,7 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
     if (P.captureUp) { // table builder: bring the pieces that reached the MRCA to the host
         HIP_OK(hipStreamSynchronize(s));
         unsigned long long segCount[NSEG];
-        HIP_OK(hipMemcpy(segCount, inCnt(), 8 * NSEG, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy2D(segCount, 8, inCnt(), 8 * SEG_PITCH, 8, NSEG, hipMemcpyDeviceToHost));
         const uint32_t segCap = cap / NSEG;
         const Frontier F = P.frontier(cur);
         P.captured.clear();
@@ -664,7 +666,7 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
         int rot[3] = {cur, 2, 3}; // F, T, N
         const int aBuf = 4, bBuf = 5;
         int nextLevel = outLevel;
-        auto cntOf = [&](int lv) { return cnt + CNT_FRONT0 + (size_t)lv * NSEG; };
+        auto cntOf = [&](int lv) { return cnt + CNT_FRONT0 + (size_t)lv; };
         const int rLevel = nextLevel++;
         int fLevel = level;
         bool fTop = curTop;
@@ -892,8 +894,8 @@ static void runPlan(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
         for (int lv = 0; lv < MAX_LEVELS; ++lv) {
             unsigned long long tot = 0, mx = 0;
             for (int sgm = 0; sgm < NSEG; ++sgm) {
-                tot += hc[CNT_FRONT0 + lv * NSEG + sgm];
-                mx = std::max(mx, hc[CNT_FRONT0 + lv * NSEG + sgm]);
+                tot += hc[CNT_FRONT0 + sgm * SEG_PITCH + lv];
+                mx = std::max(mx, hc[CNT_FRONT0 + sgm * SEG_PITCH + lv]);
             }
             need = std::max(need, std::max(tot, mx * NSEG)); // the fullest segment sets the capacity
         }
@@ -1089,10 +1091,11 @@ template <typename C> static void buildComposedUp(hgx_alignment *h, int src, int
         return a.sPos < b.sPos; // source positions of distinct pieces are disjoint; qid (= segment) order follows
     });
     std::vector<ComposedRec<C>> recs(std::max<size_t>(cp.size(), 1));
+    std::vector<C> eo(std::max<size_t>(cp.size(), 1));
     memset(recs.data(), 0, recs.size() * sizeof(ComposedRec<C>));
-    std::vector<uint32_t> pstart(nt + 1, 0);
     if (cp.size() >= ((size_t)1 << 32) - 1)
         throw std::runtime_error("composed up table too large");
+    int32_t lastSeg = -1;
     for (size_t k = 0; k < cp.size(); ++k) {
         const hgx_liftover_plan::CapturedPiece &p = cp[k];
         if (p.fl & F_SREV)
@@ -1102,20 +1105,39 @@ template <typename C> static void buildComposedUp(hgx_alignment *h, int src, int
         r.sLo = (C)p.sPos;
         r.len = (C)p.len;
         r.so = (C)p.so;
-        r.eo = (C)(segLen - p.so - p.len);
-        r.mEnc = (int32_t)((p.idx << 1) | ((p.fl & F_TREV) ? 1 : 0));
-        r.seg = p.qid;
-        ++pstart[(size_t)p.qid + 1];
+        eo[k] = (C)(segLen - p.so - p.len);
+        r.mEncF = ((uint32_t)p.idx << 2) | (p.qid != lastSeg ? 2u : 0u) | ((p.fl & F_TREV) ? 1u : 0u);
+        lastSeg = p.qid;
     }
-    for (size_t i = 0; i < nt; ++i)
-        pstart[i + 1] += pstart[i];
+    // coarse[b] = first record that does not end before position b << shift (~4 records per bucket)
+    int64_t buckets = 1;
+    while (buckets < (int64_t)cp.size() / 4 && buckets < ((int64_t)1 << 22))
+        buckets <<= 1;
+    int shift = 0;
+    while (((S.totalLength - 1) >> shift) >= buckets)
+        ++shift;
+    const int64_t nb = ((S.totalLength - 1) >> shift) + 1;
+    std::vector<uint32_t> coarse((size_t)nb + 1);
+    {
+        size_t k = 0;
+        for (int64_t b = 0; b < nb; ++b) {
+            const int64_t pos = b << shift;
+            while (k < cp.size() && cp[k].sPos + cp[k].len - 1 < pos)
+                ++k;
+            coarse[(size_t)b] = (uint32_t)k;
+        }
+        coarse[(size_t)nb] = (uint32_t)cp.size();
+    }
     HIP_OK(hipSetDevice(h->dev->device));
     HIP_OK(hipMalloc(&out.recs, recs.size() * sizeof(ComposedRec<C>)));
     HIP_OK(hipMemcpy(out.recs, recs.data(), recs.size() * sizeof(ComposedRec<C>), hipMemcpyHostToDevice));
-    HIP_OK(hipMalloc((void **)&out.pstart, pstart.size() * 4));
-    HIP_OK(hipMemcpy(out.pstart, pstart.data(), pstart.size() * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMalloc(&out.eo, eo.size() * sizeof(C)));
+    HIP_OK(hipMemcpy(out.eo, eo.data(), eo.size() * sizeof(C), hipMemcpyHostToDevice));
+    HIP_OK(hipMalloc((void **)&out.coarse, coarse.size() * 4));
+    HIP_OK(hipMemcpy(out.coarse, coarse.data(), coarse.size() * 4, hipMemcpyHostToDevice));
+    out.shift = shift;
     out.numRecs = cp.size();
-    h->dev->bytes += recs.size() * sizeof(ComposedRec<C>) + pstart.size() * 4;
+    h->dev->bytes += recs.size() * sizeof(ComposedRec<C>) + eo.size() * sizeof(C) + coarse.size() * 4;
     out.buildMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 

@@ -49,12 +49,17 @@ enum {
     CNT_BIGFAIL = 7,
     CNT_MAPPED = 3,    // pieces in the final frontier (written by k_finalize)
     NSEG = 64,         // independent append segments per frontier (one counter word each)
-    CNT_FRONT0 = 8,    // + level*NSEG + segment: pieces appended to that segment of the level's frontier
+    SEG_PITCH = 128,   // words between the counters of two segments: every segment's counters sit in their own 1 KB, so the
+                       // appends of one level land on 64 different cache lines (and memory channels).  Atomics on words that
+                       // share a line serialise at the memory side: with the 64 counters packed into four lines the up-phase
+                       // kernels spent about a third of their time queueing on them
+    CNT_FRONT0 = 8,    // + segment*SEG_PITCH + level: pieces appended to that segment of the level's frontier
     MAX_LEVELS = 120,
-    CNT_KSTAT0 = CNT_FRONT0 + MAX_LEVELS * NSEG, // + 2*launch: {top, bottom} segment records dereferenced by that launch
+    CNT_KSTAT0 = CNT_FRONT0 + NSEG * SEG_PITCH, // + 2*launch: {top, bottom} segment records dereferenced by that launch
     MAX_LAUNCHES = 152,
     CNT_SLOTS = CNT_KSTAT0 + 2 * MAX_LAUNCHES
 };
+static_assert(MAX_LEVELS <= SEG_PITCH, "a segment's counter block holds one word per level");
 
 __device__ __forceinline__ int lane_id() {
     return (int)(threadIdx.x & 63);
@@ -106,14 +111,14 @@ struct Stage {
     uint32_t *perQuery = nullptr; // final pieces: per-interval count of the pieces actually stored (an overflowing append drops
                                   // pieces; counting at emit time would leave offsets pointing past the buffers)
 
-    // oc: the NSEG counters of the output frontier; cp: total capacity of the frontier buffers
+    // oc: segment 0's counter of the output frontier (segment s at oc + s*SEG_PITCH); cp: total capacity of the frontier buffers
     __device__ __forceinline__ void init(StageMem *mem, const Frontier &o, unsigned long long *oc, unsigned long long *c, uint32_t cp) {
         m = mem;
         base = (int)(threadIdx.x >> 6) * STAGE_CAP;
         count = 0;
         out = o;
         const uint32_t seg = blockIdx.x % NSEG;
-        outCount = oc + seg;
+        outCount = oc + (size_t)seg * SEG_PITCH;
         counters = c;
         segCap = cp / NSEG;
         segBase = (unsigned long long)seg * segCap;
@@ -175,18 +180,29 @@ struct FrontView {
 };
 __device__ __forceinline__ uint32_t front_view_init(FrontView *v, const unsigned long long *segCount, uint32_t cap) {
     const uint32_t segCap = cap / NSEG;
-    if (threadIdx.x < NSEG) {
-        const unsigned long long c = segCount[threadIdx.x];
-        v->prefix[threadIdx.x + 1] = (uint32_t)(c < segCap ? c : segCap);
-    }
-    if (threadIdx.x == 0)
-        v->prefix[0] = 0;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t acc = 0;
-        for (int k = 1; k <= NSEG; ++k) {
-            acc += v->prefix[k];
-            v->prefix[k] = acc;
+    constexpr int PER = NSEG / 64; // the first wavefront scans the counts, PER consecutive segments per lane
+    if (threadIdx.x < 64) {
+        uint32_t c[PER], sum = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const unsigned long long x = segCount[(size_t)(threadIdx.x * PER + k) * SEG_PITCH];
+            c[k] = (uint32_t)(x < segCap ? x : segCap);
+            sum += c[k];
+        }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o);
+            if ((int)threadIdx.x >= o)
+                incl += up;
+        }
+        uint32_t acc = incl - sum;
+        if (threadIdx.x == 0)
+            v->prefix[0] = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            acc += c[k];
+            v->prefix[threadIdx.x * PER + k + 1] = acc;
         }
     }
     __syncthreads();
@@ -295,27 +311,35 @@ __global__ void __launch_bounds__(256) k_locate_expand(const REC *__restrict__ s
 // an interval covers, so clipping the whole segment's pieces is the same as walking the part).  A '-' interval is the
 // forward result reversed in place: source first base = the high end, both strand bits flipped, offsets from the other end
 // (toReverseInPlace commutes with every hop: parent / child hops copy the offsets, parse steps are symmetric).
-template <typename C, typename REC>
-__global__ void __launch_bounds__(256) k_locate_composed(const REC *__restrict__ segs, int64_t numSegs, const int64_t *__restrict__ gStart,
-                                                         const int64_t *__restrict__ gEnd, const uint8_t *__restrict__ strand, uint32_t nq,
-                                                         const int32_t *__restrict__ coarse, int coarseShift,
-                                                         const uint32_t *__restrict__ pstart, const ComposedRec<C> *__restrict__ recs,
-                                                         uint64_t numRecs, Frontier out, uint32_t cap, unsigned long long *outCount,
+// The kernel is bound, like the walk kernels, by the number of gathers a CU keeps in flight (PMC: 21.6 M L1 requests per
+// 1 M intervals with 32-byte records found through a binary search on the source tiling and a per-segment index), so a
+// record is 16 bytes and one gather, the bases after the piece (needed to reverse it) live in a side array read by '-'
+// intervals only, and a coarse table over source positions leads straight to the first record that can overlap.
+// Eight lanes work on one interval: they load eight consecutive records (one 128-byte line) per round, clip them in
+// parallel and emit together, so an interval with twenty pieces takes three rounds instead of twenty dependent gathers in
+// one lane while its neighbours wait (one lane per interval ran at 0.43-0.46 ms, this at a third of it).
+template <typename C>
+__global__ void __launch_bounds__(256) k_locate_composed(const int64_t *__restrict__ gStart, const int64_t *__restrict__ gEnd,
+                                                         const uint8_t *__restrict__ strand, uint32_t nq, int64_t genomeLength,
+                                                         const uint32_t *__restrict__ coarse, int coarseShift,
+                                                         const ComposedRec<C> *__restrict__ recs, const C *__restrict__ eoOf, uint64_t numRecs,
+                                                         Frontier out, uint32_t cap, unsigned long long *outCount,
                                                          unsigned long long *counters) {
+    constexpr int G = 4, PER_WAVE = 64 / G;
     const uint32_t wavesTotal = (gridDim.x * blockDim.x) >> 6;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = lane_id(), li = lane & (G - 1);
     uint32_t srcPieces = 0;
     __shared__ StageMem stageMem;
     Stage stage;
     stage.init(&stageMem, out, outCount, counters, cap);
-    for (uint32_t base = wave * 64; base < nq; base += wavesTotal * 64) {
-        const uint32_t q = base + lane_id();
-        bool act = q < nq;
+    for (uint32_t base = wave * PER_WAVE; base < nq; base += wavesTotal * PER_WAVE) {
+        const uint32_t q = base + (uint32_t)(lane / G);
+        bool act = q < nq; // the same in all lanes of a group
         int64_t gs = 0, ge = -1;
         uint8_t dot = 0;
-        bool minus = false;
+        bool minus = false, first = true;
         uint64_t k = 0;
-        int32_t lastSeg = -1;
         if (act) {
             gs = gStart[q];
             ge = gEnd[q];
@@ -323,66 +347,60 @@ __global__ void __launch_bounds__(256) k_locate_composed(const REC *__restrict__
             minus = st == '-';
             if (st == '.')
                 dot = F_DOT;
-            act = ge >= gs && gs >= 0 && numSegs > 0 && gs < (int64_t)segs[numSegs].start;
-            if (act) {
-                int64_t lo = 0, hi = numSegs; // invariant start[lo] <= gs < start[hi]
-                if (coarse) {
-                    const int64_t b = gs >> coarseShift;
-                    lo = coarse[b];
-                    const int64_t up = (int64_t)coarse[b + 1] + 1;
-                    hi = up < numSegs ? up : numSegs;
-                    if (hi <= lo)
-                        hi = lo + 1;
-                }
-                while (hi - lo > 1) {
-                    const int64_t mid = (lo + hi) >> 1;
-                    if ((int64_t)segs[mid].start <= gs)
-                        lo = mid;
-                    else
-                        hi = mid;
-                }
-                k = pstart[lo];
-            }
+            act = ge >= gs && gs >= 0 && gs < genomeLength && numRecs > 0;
+            if (act)
+                k = coarse[gs >> coarseShift];
         }
         while (__any(act)) {
-            bool emit = false;
+            bool emit = false, beyond = false, startsSegment = false;
             int32_t oIdx = 0, oLen = 0;
             int64_t oSPos = 0, oSo = 0;
             uint8_t oFl = 0;
             if (act) {
-                if (k >= numRecs) {
-                    act = false;
+                const uint64_t at = k + (uint64_t)li;
+                if (at >= numRecs) {
+                    beyond = true;
                 } else {
-                    const ComposedRec<C> r = recs[k];
+                    const ComposedRec<C> r = recs[at];
                     const int64_t pLo = (int64_t)r.sLo, pHi = pLo + (int64_t)r.len - 1;
                     if (pLo > ge) {
-                        act = false;
-                    } else {
-                        ++k;
-                        if (pHi >= gs) {
-                            const int64_t c = pLo > gs ? pLo : gs, d = pHi < ge ? pHi : ge;
-                            const int64_t n = d - c + 1, delta = c - pLo;
-                            emit = true;
-                            oLen = (int32_t)n;
-                            oIdx = r.mEnc >> 1;
-                            oFl = (uint8_t)(((r.mEnc & 1) ? F_TREV : 0) | dot);
-                            if (!minus) {
-                                oSPos = c;
-                                oSo = (int64_t)r.so + delta;
-                            } else {
-                                oSPos = d;
-                                oSo = (int64_t)r.eo + ((int64_t)r.len - delta - n);
-                                oFl ^= (uint8_t)(F_SREV | F_TREV);
-                            }
-                            if (r.seg != lastSeg) {
-                                lastSeg = r.seg;
-                                ++srcPieces;
-                            }
+                        beyond = true;
+                    } else if (pHi >= gs) {
+                        const int64_t c = pLo > gs ? pLo : gs, d = pHi < ge ? pHi : ge;
+                        const int64_t n = d - c + 1, delta = c - pLo;
+                        emit = true;
+                        oLen = (int32_t)n;
+                        oIdx = (int32_t)(r.mEncF >> 2);
+                        oFl = (uint8_t)(((r.mEncF & 1u) ? F_TREV : 0) | dot);
+                        if (!minus) {
+                            oSPos = c;
+                            oSo = (int64_t)r.so + delta;
+                        } else {
+                            oSPos = d;
+                            oSo = (int64_t)eoOf[at] + ((int64_t)r.len - delta - n);
+                            oFl ^= (uint8_t)(F_SREV | F_TREV);
                         }
+                        startsSegment = (r.mEncF & 2u) != 0;
                     }
                 }
             }
+            // the interval is finished once any of its lanes saw a record beyond its end (records are in source order)
+            const unsigned long long bmask = __ballot(beyond);
+            const unsigned long long gmask = ((1ull << G) - 1ull) << (lane & ~(G - 1));
+            // source segments that contribute (the statistics' "source pieces"): every emitted record that starts its segment,
+            // and the interval's very first emitted record if it does not
+            const unsigned long long emask = __ballot(emit) & gmask;
+            if (emit && (startsSegment || (first && (emask & ((1ull << lane) - 1ull)) == 0)))
+                ++srcPieces;
+            if (emask)
+                first = false;
             stage.emit(emit, (int32_t)q, oSPos, oIdx, oSo, oLen, oFl);
+            if (act) {
+                if (bmask & gmask)
+                    act = false;
+                else
+                    k += G;
+            }
         }
     }
     stage.flush();
