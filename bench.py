@@ -239,12 +239,9 @@ def main():
             walk_kt = walk_plan.kernel_times()
             wst = walk_plan.stats()
             assert wst["records"] == st["records"] and wst["mapped_pieces"] == st["mapped_pieces"]
+            table_kernel = "k_locate_through" if st["composed_kind"] == 2 else "k_locate_composed"
+            table_records = kt_total[table_kernel]["top_derefs"] // args.steps  # composed records dereferenced per step
             st = dict(st, top_derefs=wst["top_derefs"], bottom_derefs=wst["bottom_derefs"], source_pieces=wst["source_pieces"])
-            # the composed kernel stands for the locate and up kernels of the walk
-            share = sum(walk_kt[k]["top_derefs"] + walk_kt[k]["bot_derefs"] for k in ("k_locate_expand", "k_up_chain", "k_up_first", "k_up_walk")
-                        if k in walk_kt)
-            kt_total["k_locate_composed"]["top_derefs"] = share * args.steps  # (top and bottom together; only the sum is used)
-            kt_total["k_locate_composed"]["bot_derefs"] = 0
             del walk_plan
         # --- roofline of the dominant kernel (device time from HIP events on the launch stream) ---
         dom = max(kt_acc.items(), key=lambda kv: kv[1]["ms"])
@@ -284,9 +281,12 @@ def main():
                                                                      "seed 2" if args.workload == "cfg2" else "seed 0", args.scale, nq,
                                                                      src_name, tgt_name),
                        "intervals_per_gpu": nq, "records_per_step": nrec_all, "parallelism": "query-shard x%d" % world,
-                       "up_phase": ("composed table src->MRCA: %d records (%.0f MB), built once by the walk kernels in %.0f ms at plan "
-                                    "creation, untimed; set HGX_COMPOSED_UP=0 for the level-by-level walk"
-                                    % (st["composed_records"], st["composed_records"] * 20 / 1e6, st["composed_build_ms"]))
+                       "up_phase": ("composed table of the %s: %d records (%.0f MB), built once per alignment and genome pair by the walk "
+                                    "kernels in %.0f ms at plan creation, untimed; %d table records dereferenced per step; "
+                                    "HGX_COMPOSED_UP=0 gives the level-by-level walk (profiles/r01r_bench_walk.log)"
+                                    % ("whole path src->MRCA->target" if st["composed_kind"] == 2 else "up phase src->MRCA",
+                                       st["composed_records"], st["composed_records"] * (16 if st["composed_kind"] == 2 else 20) / 1e6,
+                                       st["composed_build_ms"], table_records))
                        if st["composed_records"] else "level-by-level walk (k_up_chain)",
                        "exchange": ("all-gatherv of %d-byte records, overlapped with the next batch" % (20 if packed_wire else 40))
                        if world > 1 else "none (one GPU)",
@@ -297,7 +297,10 @@ def main():
                          "kernel_avg_ms": dom_avg_ms, "kernel_launches_per_step": dom_launches / args.steps,
                          "algorithmic_bytes_per_launch": dom_bytes_per_launch,
                          "whole_path": {"algorithmic_bytes_per_step": alg_total, "kernel_ms_per_step": kern_ms_total,
-                                        "achieved_GBs": alg_total / (kern_ms_total * 1e-3) / 1e9 if kern_ms_total > 0 else 0.0}},
+                                        "achieved_GBs": alg_total / (kern_ms_total * 1e-3) / 1e9 if kern_ms_total > 0 else 0.0,
+                                        "note": "SURVEY 8(d) bytes of the reference's walk (24Q+25T+25B+40R, counted by an untimed "
+                                                "level-by-level run of the same batch); a composed table dereferences far fewer "
+                                                "records, so this figure is not bounded by the HBM peak when a table is in use"}},
             "kernels_ms_per_step": {k: round(v["ms"] / args.steps, 4) for k, v in sorted(kt_acc.items())},
             "counts_per_step": {"queries": Q, "source_pieces": st["source_pieces"], "top_derefs": T, "bottom_derefs": B,
                                 "mapped_pieces": st["mapped_pieces"], "records": R, "deferred_queries": st["deferred_queries"]},
@@ -350,7 +353,14 @@ def plan_kernel_bytes(kt, st, steps):
         launches = max(1, v["launches"])
         t, b = v.get("top_derefs", 0), v.get("bot_derefs", 0)
         bytes_ = 25.0 * (t + b)
-        if name in ("k_locate_expand", "k_locate_composed"):
+        if name in ("k_locate_composed", "k_locate_through"):
+            # the table kernels' own figure: 16 B per composed record that overlaps its interval (counted in the top slot)
+            # and the piece it leaves (29 B in a frontier, a 32-byte MappedRec from the whole-path kernel, which also writes
+            # 8 B of offset and count per interval), instead of the segment records of the walk they replace
+            bytes_ = (16.0 + (29.0 if name == "k_locate_composed" else 32.0)) * t
+            if name == "k_locate_through":
+                bytes_ += 8.0 * st["queries"] * steps
+        if name in ("k_locate_expand", "k_locate_composed", "k_locate_through"):
             bytes_ += 24.0 * st["queries"] * steps
         if name in ("k_finish_lds", "k_finish_big"):
             bytes_ += 40.0 * st["records"] * steps

@@ -12,6 +12,7 @@
 #include <mutex>
 #include "../../include/hgx.h"
 #include "hgx_image.hpp"
+#include <array>
 #include <map>
 #include <memory>
 
@@ -127,9 +128,12 @@ struct ComposedUp {
     void *recs = nullptr;       // ComposedRec<C>[numRecs], sorted by sLo
     void *eo = nullptr;         // C[numRecs]: bases of the ancestor's bottom segment after the piece (needed by '-' intervals only)
     uint32_t *coarse = nullptr; // [buckets + 1]: first record that does not end before position bucket << shift
+    uint32_t *starts = nullptr; // [buckets + 1] (whole-path tables): first record that begins at or after bucket << shift
     int shift = 0;
     uint64_t numRecs = 0;
     double buildMs = 0;
+    bool through = false;       // records hold FINAL pieces in the target genome (so = forward target start, no segment index):
+                                // the table composes the whole path source -> MRCA -> target, paralogy rings included
 };
 template <typename C> struct BotRec;
 template <> struct alignas(8) BotRec<int32_t> {
@@ -177,7 +181,9 @@ struct DeviceImage {
     std::vector<DeviceGenome> genomes;
     GenomeDesc *desc = nullptr;          // device array, one per genome
     std::vector<uint8_t *> dna;          // device copies of the packed DNA (uploaded on first use)
-    std::map<std::pair<int, int>, ComposedUp> composed; // (source genome, ancestor) -> composed up table
+    // composed tables: (source genome, ancestor, -1, -1) -> up table; (source, target, dupes, coalescence limit + 1) with
+    // through = true -> table of the whole path
+    std::map<std::array<int, 4>, ComposedUp> composed;
     size_t bytes = 0;
     ~DeviceImage();
 };

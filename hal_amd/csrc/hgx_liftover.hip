@@ -55,6 +55,8 @@ DeviceImage::~DeviceImage() {
             (void)hipFree(kv.second.eo);
         if (kv.second.coarse)
             (void)hipFree(kv.second.coarse);
+        if (kv.second.starts)
+            (void)hipFree(kv.second.starts);
     }
     if (desc)
         (void)hipFree(desc);
@@ -441,6 +443,7 @@ struct hgx_liftover_plan {
     bool srcTop = true;
     const ComposedUp *composed = nullptr;       // composed up table src -> mrca (large plans; see ensureComposedUp), or null
     bool captureUp = false;                     // table builder: keep the pieces that arrive in the MRCA
+    bool captureFinal = false;                  // table builder: keep the FINAL pieces (after the last down hop)
     struct CapturedPiece {
         int32_t qid, idx, len;
         int64_t sPos, so;
@@ -544,12 +547,20 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
     // (processing the batch sorted by start position was measured: -14 % on the walk kernels, but +0.17 ms in the per-interval
     // atomics of the grouping step and 0.19 ms for the sort itself — no net gain, so batches run in arrival order)
     const bool useComposed = P.composed != nullptr;
+    const bool through = useComposed && P.composed->through; // the table's pieces are final: straight to the grouping step
     if (useComposed) {
         // locate + the whole up phase from the composed table: the pieces arrive in the MRCA directly
-        P.timer.begin("k_locate_composed", s, launch);
-        hipLaunchKernelGGL((k_locate_composed<C>), dim3(GRID), dim3(256), 0, s, dS, dE, dStrand, nq, P.h->img.genomes[(size_t)P.src].totalLength,
-                           (const uint32_t *)P.composed->coarse, P.composed->shift, (const ComposedRec<C> *)P.composed->recs,
-                           (const C *)P.composed->eo, (uint64_t)P.composed->numRecs, P.frontier(cur), cap, inCnt(), cnt);
+        P.timer.begin(through ? "k_locate_through" : "k_locate_composed", s, launch);
+        if (through)
+            hipLaunchKernelGGL((k_locate_through<C>), dim3(GRID), dim3(256), 0, s, dS, dE, dStrand, nq,
+                               P.h->img.genomes[(size_t)P.src].totalLength, (const uint32_t *)P.composed->coarse,
+                               (const uint32_t *)P.composed->starts, P.composed->shift, (const ComposedRec<C> *)P.composed->recs, P.mapped(1), cap,
+                               inCnt(), cnt, kstat(), (uint32_t *)P.offset.p, (uint32_t *)P.perQuery.p);
+        else
+            hipLaunchKernelGGL((k_locate_composed<C>), dim3(GRID), dim3(256), 0, s, dS, dE, dStrand, nq,
+                               P.h->img.genomes[(size_t)P.src].totalLength, (const uint32_t *)P.composed->coarse, P.composed->shift,
+                               (const ComposedRec<C> *)P.composed->recs, (const C *)P.composed->eo, (uint64_t)P.composed->numRecs, P.frontier(cur),
+                               cap, inCnt(), cnt, kstat());
         P.timer.end(s);
         ++launch;
     } else {
@@ -615,7 +626,7 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
         curGenome = P.mrca;
         curTop = false;
     }
-    if (P.captureUp) { // table builder: bring the pieces that reached the MRCA to the host
+    auto capture = [&]() { // table builder: bring the current frontier to the host
         HIP_OK(hipStreamSynchronize(s));
         unsigned long long segCount[NSEG];
         HIP_OK(hipMemcpy2D(segCount, 8, inCnt(), 8 * SEG_PITCH, 8, NSEG, hipMemcpyDeviceToHost));
@@ -653,8 +664,10 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
             for (size_t i = 0; i < c; ++i)
                 P.captured[at + i].fl = a8[i];
         }
-    }
-    if (!P.climb.empty()) {
+    };
+    if (P.captureUp)
+        capture();
+    if (!P.climb.empty() && !through) {
         // mapRecursiveParalogies (halSegmentMapper.cpp:525-576), coalescenceLimit above the MRCA: at every genome c_i from
         // the MRCA up to the child of the limit, the pieces (walked through c_i's top tiling) are expanded to their paralogy
         // rings (mapSelf) and the ring members are mapped back DOWN to the MRCA without dupes; the pieces themselves (not
@@ -743,8 +756,8 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
         curTop = true;
         curGenome = P.mrca;
     }
-    bool finalized = false; // the last walk kernel already produced final pieces and the per-interval counts
-    if (P.tgt != P.mrca) {
+    bool finalized = through; // the last walk kernel already produced final pieces and the per-interval counts
+    if (P.tgt != P.mrca && !through) {
         if (curTop) { // source is the MRCA itself and is walked through its top tiling
             const DeviceGenome &G = D.genomes[(size_t)curGenome];
             P.timer.begin("k_parse_down", s, launch);
@@ -791,6 +804,11 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
             }
         }
     }
+    if (P.captureFinal) {
+        if (!finalized)
+            throw std::runtime_error("internal: captureFinal on a path without a final down hop");
+        capture();
+    }
     // final pieces live in the target genome
     const DeviceGenome &TG = D.genomes[(size_t)P.tgt];
     if (!finalized) {
@@ -805,6 +823,7 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
     }
     HIP_OK(hipEventRecord(P.evWalk, s));
 
+    if (!through) { // (the whole-path table kernel wrote its pieces grouped, with offset[] and perQuery[])
     exclusiveScan(P, (const uint32_t *)P.perQuery.p, nq, (uint32_t *)P.offset.p, (uint32_t *)P.total.p, s);
     P.timer.begin("k_scatter", s);
     if (finalized)
@@ -814,6 +833,7 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
         hipLaunchKernelGGL(k_scatter, dim3(GRID), dim3(256), 0, s, P.mapped(0), cnt + CNT_MAPPED, cap, (const uint32_t *)P.offset.p,
                            (uint32_t *)P.cursor.p, P.mapped(1));
     P.timer.end(s);
+    }
     // finishing: register-resident fast path per size class (each kernel picks the intervals of its class),
     // general LDS path for the rest
     // classLists: [general | 9-16 | 17-32 | 33-64 pieces], nq entries each; classCounts: [general, 3 classes]
@@ -971,11 +991,12 @@ static void runPlan(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
     P.stats.total_ms = tot;
     P.stats.composed_records = P.composed ? P.composed->numRecs : 0;
     P.stats.composed_build_ms = P.composed ? P.composed->buildMs : 0;
+    P.stats.composed_kind = P.composed ? (P.composed->through ? 2 : 1) : 0;
     *dOut = (const hgx_record *)P.outRecords.p;
     *nOut = totalRecords;
 }
 
-static const ComposedUp *ensureComposedUp(hgx_alignment *h, int src, int mrca);
+static const ComposedUp *ensureComposed(hgx_alignment *h, int src, int dst, bool through, const hgx_liftover_opts &opts);
 static void runHostArrays(hgx_liftover_plan *P, const std::vector<int64_t> &gs, const std::vector<int64_t> &ge, const std::vector<uint8_t> &st,
                           std::vector<hgx_record> &out);
 
@@ -1051,32 +1072,42 @@ hgx_liftover_plan *createLiftoverPlan(hgx_alignment *h, int src, int tgt, const 
     HIP_OK(hipEventCreate(&P->evEnd));
     const unsigned long long want = std::max<unsigned long long>(1ull << 16, 16ull * P->maxQueries); // grown on demand
     P->allocate((uint32_t)std::min<unsigned long long>(want, (1ull << 32) - 2));
-    // A plan for a batch that is large against the source genome serves the up phase from the composed table (building it
-    // costs one walk over every source segment).  HGX_COMPOSED_UP=1 forces it, =0 forbids it.
+    // A plan for a batch that is large against the source genome is served from a composed table (building it costs one
+    // walk over every source segment): the table of the whole path when the target lies below the MRCA, the up table
+    // otherwise.  HGX_COMPOSED_UP=1 forces a table, =0 forbids it; HGX_COMPOSED_THROUGH=0 keeps to the up table.
     if (allowComposed && src != P->mrca && P->srcTop && opts.min_length == 0) {
         const char *e = getenv("HGX_COMPOSED_UP");
         const bool force = e && e[0] == '1', forbid = e && e[0] == '0';
         const bool big = P->maxQueries * 8 >= (size_t)img.genomes[(size_t)src].numTop;
+        const char *t = getenv("HGX_COMPOSED_THROUGH");
+        const bool through = tgt != P->mrca && !(t && t[0] == '0');
         if (!forbid && (force || big))
-            P->composed = ensureComposedUp(h, src, P->mrca);
+            P->composed = ensureComposed(h, src, through ? tgt : P->mrca, through, opts);
     }
     return P.release();
 }
 
-// Builds (once per alignment and pair) the composed up table of src -> mrca: every source top segment is lifted to the MRCA
-// as one interval by the ordinary walk (a plan with captureUp), the pieces are sorted by source position and stored with
-// the per-segment index.  Serialised; the table lives as long as the device image.
-template <typename C> static void buildComposedUp(hgx_alignment *h, int src, int mrca, ComposedUp &out) {
+// Builds (once per alignment and pair) a composed table.  Up table (src -> mrca): every source top segment is lifted to the
+// MRCA as one interval by the ordinary walk (a plan with captureUp).  Table of the whole path (src -> tgt, through): the
+// same batch runs the complete walk with the plan's own options (dupes, coalescenceLimit) and the FINAL pieces are kept.
+// The pieces are sorted by source position.  Serialised; the table lives as long as the device image.
+template <typename C>
+static void buildComposed(hgx_alignment *h, int src, int dst, bool through, const hgx_liftover_opts &opts, ComposedUp &out) {
     const auto t0 = std::chrono::steady_clock::now();
     const GenomeTables &S = h->img.genomes[(size_t)src];
-    const GenomeTables &M = h->img.genomes[(size_t)mrca];
+    const GenomeTables &M = h->img.genomes[(size_t)dst];
     const size_t nt = (size_t)S.numTop;
     hgx_liftover_opts o{};
     o.traverse_dupes = 1;
     o.coalescence_limit = -1;
-    std::unique_ptr<hgx_liftover_plan, void (*)(hgx_liftover_plan *)> P(createLiftoverPlan(h, src, mrca, o, nt, /*allowComposed=*/false),
+    if (through) {
+        o.traverse_dupes = opts.traverse_dupes;
+        o.coalescence_limit = opts.coalescence_limit;
+        o.block_mapper_source = opts.block_mapper_source;
+    }
+    std::unique_ptr<hgx_liftover_plan, void (*)(hgx_liftover_plan *)> P(createLiftoverPlan(h, src, dst, o, nt, /*allowComposed=*/false),
                                                                        destroyLiftoverPlan);
-    P->captureUp = true;
+    (through ? P->captureFinal : P->captureUp) = true;
     P->timer.mode = 0;
     std::vector<int64_t> gs(nt), ge(nt);
     std::vector<uint8_t> st(nt, (uint8_t)'+');
@@ -1088,28 +1119,33 @@ template <typename C> static void buildComposedUp(hgx_alignment *h, int src, int
     runHostArrays(P.get(), gs, ge, st, ignored);
     std::vector<hgx_liftover_plan::CapturedPiece> &cp = P->captured;
     std::sort(cp.begin(), cp.end(), [](const hgx_liftover_plan::CapturedPiece &a, const hgx_liftover_plan::CapturedPiece &b) {
-        return a.sPos < b.sPos; // source positions of distinct pieces are disjoint; qid (= segment) order follows
+        // pieces of one segment (= qid) stay together; inside the up table the source ranges of distinct pieces are disjoint,
+        // the pieces of a whole path may repeat a range (paralogs)
+        return a.sPos != b.sPos ? a.sPos < b.sPos : a.so < b.so;
     });
     std::vector<ComposedRec<C>> recs(std::max<size_t>(cp.size(), 1));
-    std::vector<C> eo(std::max<size_t>(cp.size(), 1));
+    std::vector<C> eo(std::max<size_t>(through ? 0 : cp.size(), 1));
     memset(recs.data(), 0, recs.size() * sizeof(ComposedRec<C>));
     if (cp.size() >= ((size_t)1 << 32) - 1)
-        throw std::runtime_error("composed up table too large");
+        throw std::runtime_error("composed table too large");
     int32_t lastSeg = -1;
     for (size_t k = 0; k < cp.size(); ++k) {
         const hgx_liftover_plan::CapturedPiece &p = cp[k];
         if (p.fl & F_SREV)
             throw std::runtime_error("internal: a forward source segment produced a source-reversed piece");
         ComposedRec<C> &r = recs[k];
-        const int64_t segLen = M.bStart[(size_t)p.idx + 1] - M.bStart[(size_t)p.idx];
         r.sLo = (C)p.sPos;
         r.len = (C)p.len;
-        r.so = (C)p.so;
-        eo[k] = (C)(segLen - p.so - p.len);
-        r.mEncF = ((uint32_t)p.idx << 2) | (p.qid != lastSeg ? 2u : 0u) | ((p.fl & F_TREV) ? 1u : 0u);
+        r.so = (C)p.so; // through: the forward start in the target genome
+        if (!through) {
+            const int64_t segLen = M.bStart[(size_t)p.idx + 1] - M.bStart[(size_t)p.idx];
+            eo[k] = (C)(segLen - p.so - p.len);
+        }
+        r.mEncF = (through ? 0u : ((uint32_t)p.idx << 2)) | (p.qid != lastSeg ? 2u : 0u) | ((p.fl & F_TREV) ? 1u : 0u);
         lastSeg = p.qid;
     }
-    // coarse[b] = first record that does not end before position b << shift (~4 records per bucket)
+    // coarse[b] = first record that reaches position b << shift or starts after it (~4 records per bucket): no earlier
+    // record overlaps anything at or after that position
     int64_t buckets = 1;
     while (buckets < (int64_t)cp.size() / 4 && buckets < ((int64_t)1 << 22))
         buckets <<= 1;
@@ -1117,42 +1153,63 @@ template <typename C> static void buildComposedUp(hgx_alignment *h, int src, int
     while (((S.totalLength - 1) >> shift) >= buckets)
         ++shift;
     const int64_t nb = ((S.totalLength - 1) >> shift) + 1;
-    std::vector<uint32_t> coarse((size_t)nb + 1);
-    {
-        size_t k = 0;
-        for (int64_t b = 0; b < nb; ++b) {
-            const int64_t pos = b << shift;
-            while (k < cp.size() && cp[k].sPos + cp[k].len - 1 < pos)
-                ++k;
-            coarse[(size_t)b] = (uint32_t)k;
-        }
-        coarse[(size_t)nb] = (uint32_t)cp.size();
+    const uint32_t UNSET = 0xFFFFFFFFu;
+    std::vector<uint32_t> coarse((size_t)nb + 1, UNSET);
+    for (size_t k = 0; k < cp.size(); ++k) {
+        const int64_t bLo = cp[k].sPos >> shift, bHi = (cp[k].sPos + cp[k].len - 1) >> shift;
+        for (int64_t b = bLo; b <= bHi; ++b)
+            if (coarse[(size_t)b] == UNSET)
+                coarse[(size_t)b] = (uint32_t)k; // records come in source order: the first to touch a bucket is the smallest
     }
+    coarse[(size_t)nb] = (uint32_t)cp.size();
+    for (int64_t b = nb; b-- > 0;)
+        if (coarse[(size_t)b] == UNSET)
+            coarse[(size_t)b] = coarse[(size_t)b + 1];
     HIP_OK(hipSetDevice(h->dev->device));
     HIP_OK(hipMalloc(&out.recs, recs.size() * sizeof(ComposedRec<C>)));
     HIP_OK(hipMemcpy(out.recs, recs.data(), recs.size() * sizeof(ComposedRec<C>), hipMemcpyHostToDevice));
-    HIP_OK(hipMalloc(&out.eo, eo.size() * sizeof(C)));
-    HIP_OK(hipMemcpy(out.eo, eo.data(), eo.size() * sizeof(C), hipMemcpyHostToDevice));
+    size_t bytes = recs.size() * sizeof(ComposedRec<C>) + coarse.size() * 4;
+    if (!through) {
+        HIP_OK(hipMalloc(&out.eo, eo.size() * sizeof(C)));
+        HIP_OK(hipMemcpy(out.eo, eo.data(), eo.size() * sizeof(C), hipMemcpyHostToDevice));
+        bytes += eo.size() * sizeof(C);
+    }
     HIP_OK(hipMalloc((void **)&out.coarse, coarse.size() * 4));
     HIP_OK(hipMemcpy(out.coarse, coarse.data(), coarse.size() * 4, hipMemcpyHostToDevice));
+    if (through) { // starts[b] = first record that begins at or after b << shift
+        std::vector<uint32_t> starts((size_t)nb + 1);
+        size_t k = 0;
+        for (int64_t b = 0; b <= nb; ++b) {
+            while (k < cp.size() && cp[k].sPos < (b << shift))
+                ++k;
+            starts[(size_t)b] = (uint32_t)k;
+        }
+        HIP_OK(hipMalloc((void **)&out.starts, starts.size() * 4));
+        HIP_OK(hipMemcpy(out.starts, starts.data(), starts.size() * 4, hipMemcpyHostToDevice));
+        bytes += starts.size() * 4;
+    }
     out.shift = shift;
     out.numRecs = cp.size();
-    h->dev->bytes += recs.size() * sizeof(ComposedRec<C>) + eo.size() * sizeof(C) + coarse.size() * 4;
+    out.through = through;
+    h->dev->bytes += bytes;
     out.buildMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
-static const ComposedUp *ensureComposedUp(hgx_alignment *h, int src, int mrca) {
+static const ComposedUp *ensureComposed(hgx_alignment *h, int src, int dst, bool through, const hgx_liftover_opts &opts) {
     static std::mutex mu;
     std::lock_guard<std::mutex> lock(mu);
-    auto key = std::make_pair(src, mrca);
+    const bool climbs = opts.coalescence_limit >= 0 && opts.traverse_dupes; // createLiftoverPlan ignores the limit without dupes
+    const std::array<int, 4> key = through ? std::array<int, 4>{src, dst, (opts.traverse_dupes ? 1 : 0) | (opts.block_mapper_source ? 2 : 0),
+                                                                  climbs ? opts.coalescence_limit + 1 : 0}
+                                           : std::array<int, 4>{src, dst, -1, -1};
     auto it = h->dev->composed.find(key);
     if (it != h->dev->composed.end())
         return &it->second;
     ComposedUp c;
     if (h->dev->wide)
-        buildComposedUp<int64_t>(h, src, mrca, c);
+        buildComposed<int64_t>(h, src, dst, through, opts, c);
     else
-        buildComposedUp<int32_t>(h, src, mrca, c);
+        buildComposed<int32_t>(h, src, dst, through, opts, c);
     return &h->dev->composed.emplace(key, c).first->second;
 }
 

@@ -324,12 +324,12 @@ __global__ void __launch_bounds__(256) k_locate_composed(const int64_t *__restri
                                                          const uint32_t *__restrict__ coarse, int coarseShift,
                                                          const ComposedRec<C> *__restrict__ recs, const C *__restrict__ eoOf, uint64_t numRecs,
                                                          Frontier out, uint32_t cap, unsigned long long *outCount,
-                                                         unsigned long long *counters) {
+                                                         unsigned long long *counters, unsigned long long *kstat) {
     constexpr int G = 4, PER_WAVE = 64 / G;
     const uint32_t wavesTotal = (gridDim.x * blockDim.x) >> 6;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = lane_id(), li = lane & (G - 1);
-    uint32_t srcPieces = 0;
+    uint32_t srcPieces = 0, used = 0; // used: table records that overlap their interval (one piece each)
     __shared__ StageMem stageMem;
     Stage stage;
     stage.init(&stageMem, out, outCount, counters, cap);
@@ -394,6 +394,7 @@ __global__ void __launch_bounds__(256) k_locate_composed(const int64_t *__restri
                 ++srcPieces;
             if (emask)
                 first = false;
+            used += emit ? 1u : 0u;
             stage.emit(emit, (int32_t)q, oSPos, oIdx, oSo, oLen, oFl);
             if (act) {
                 if (bmask & gmask)
@@ -405,6 +406,147 @@ __global__ void __launch_bounds__(256) k_locate_composed(const int64_t *__restri
     }
     stage.flush();
     wave_count_add(&counters[CNT_SRC_PIECES], srcPieces);
+    wave_count_add(&kstat[0], used); // reported in the "top" slot of this launch: records of the composed table dereferenced
+}
+
+// ---------------------------------------------------------------------------------------------
+// The whole path from one table.  The records are the FINAL pieces of every source top segment (source -> MRCA -> target
+// with the paralogy rings and, if asked for, the coalescenceLimit phase; built by running each segment through the walk
+// kernels once, buildComposed): (source start, length, forward target start, target strand).  Records of one source segment
+// may overlap each other in the source (paralogs), so the coarse table gives the first record that can overlap a position
+// and `starts` the first record that begins at or after it; an interval's pieces are among records
+// [coarse[start bucket], starts[end bucket + 1]) — an upper bound on its piece count known before any record is read.
+// That bound lets the kernel write the pieces grouped by interval straight away: a wavefront (16 intervals, four lanes
+// each) reserves the sum of its bounds with one atomic on its block's segment counter and every interval writes its
+// MappedRecs contiguously from its own offset.  offset[] and perQuery[] are then exactly what the finishing kernels read —
+// no frontier, no per-interval atomics, no scan and no grouping scatter; the price is holes in the piece buffer (about
+// as many slots as pieces), which nothing reads.
+template <typename C>
+__global__ void __launch_bounds__(256) k_locate_through(const int64_t *__restrict__ gStart, const int64_t *__restrict__ gEnd,
+                                                        const uint8_t *__restrict__ strand, uint32_t nq, int64_t genomeLength,
+                                                        const uint32_t *__restrict__ coarse, const uint32_t *__restrict__ starts, int coarseShift,
+                                                        const ComposedRec<C> *__restrict__ recs, Mapped out, uint32_t cap,
+                                                        unsigned long long *segCounters, unsigned long long *counters,
+                                                        unsigned long long *kstat, uint32_t *__restrict__ offset,
+                                                        uint32_t *__restrict__ perQuery) {
+    constexpr int G = 4, PER_WAVE = 64 / G;
+    const uint32_t wavesTotal = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = lane_id(), li = lane & (G - 1);
+    const uint32_t seg = blockIdx.x % NSEG, segCap = cap / NSEG;
+    const uint32_t segBase = seg * segCap;
+    unsigned long long *segCount = segCounters + (size_t)seg * SEG_PITCH;
+    const unsigned long long gmask = ((1ull << G) - 1ull) << (lane & ~(G - 1));
+    uint32_t srcPieces = 0, used = 0;
+    for (uint32_t base = wave * PER_WAVE; base < nq; base += wavesTotal * PER_WAVE) {
+        const uint32_t q = base + (uint32_t)(lane / G);
+        bool act = q < nq; // the same in all lanes of a group
+        int64_t gs = 0, ge = -1;
+        uint32_t dot = 0;
+        bool minus = false, first = true;
+        uint32_t k = 0, kEnd = 0;
+        if (act) {
+            gs = gStart[q];
+            ge = gEnd[q];
+            const uint8_t st = strand[q];
+            minus = st == '-';
+            if (st == '.')
+                dot = F_DOT;
+            act = ge >= gs && gs >= 0 && gs < genomeLength;
+            if (act) {
+                const int64_t geIn = ge < genomeLength ? ge : genomeLength - 1;
+                k = coarse[gs >> coarseShift];
+                kEnd = starts[(geIn >> coarseShift) + 1];
+                act = kEnd > k;
+            }
+        }
+        // the first round's records are requested before the reservation, so the gathers do not wait for the atomic
+        ComposedRec<C> r{};
+        bool inRange = act && k + (uint32_t)li < kEnd;
+        if (inRange)
+            r = recs[k + (uint32_t)li];
+        // reserve room for the wavefront's intervals: prefix sum of the bounds over the groups, one atomic
+        const uint32_t bound = act ? kEnd - k : 0u;
+        uint32_t incl = li == 0 ? bound : 0u;
+        const uint32_t own = incl;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o);
+            if (lane >= o)
+                incl += up;
+        }
+        const uint32_t total = __shfl(incl, 63);
+        uint32_t myOff = __shfl(incl - own, lane & ~(G - 1)); // the group leader's exclusive prefix
+        if (total) {
+            unsigned long long b = 0;
+            if (lane == 0)
+                b = atomicAdd(segCount, (unsigned long long)total);
+            b = __shfl(b, 0);
+            if (b + total > segCap) { // the retry sizes the buffer from the counters
+                if (lane == 0)
+                    counters[CNT_OVERFLOW] = 1;
+                act = false;
+                k = kEnd;
+            }
+            myOff += segBase + (uint32_t)b;
+        }
+        uint32_t written = 0; // pieces of this interval so far (the same in all lanes of a group)
+        while (__any(act)) {
+            bool emit = false, beyond = false, startsSegment = false;
+            MappedRec m;
+            if (act) {
+                if (!inRange) {
+                    beyond = true;
+                } else {
+                    const int64_t pLo = (int64_t)r.sLo, pHi = pLo + (int64_t)r.len - 1;
+                    if (pLo > ge) {
+                        beyond = true;
+                    } else if (pHi >= gs) {
+                        const int64_t c = pLo > gs ? pLo : gs, d = pHi < ge ? pHi : ge;
+                        const int64_t n = d - c + 1, delta = c - pLo;
+                        emit = true;
+                        // forward low ends (what the FINAL down hop emits); a reversed target counts from the other end.
+                        // A '-' interval is the same piece with both strand bits flipped.
+                        m.sLo = c;
+                        m.tLo = (int64_t)r.so + ((r.mEncF & 1u) ? (int64_t)r.len - delta - n : delta);
+                        m.len = (int32_t)n;
+                        m.qid = (int32_t)q;
+                        m.flags = (((r.mEncF & 1u) ? F_TREV : 0u) | dot) ^ (minus ? (uint32_t)(F_SREV | F_TREV) : 0u);
+                        m._pad = 0;
+                        startsSegment = (r.mEncF & 2u) != 0;
+                    }
+                }
+            }
+            const unsigned long long bmask = __ballot(beyond);
+            const unsigned long long emask = __ballot(emit) & gmask;
+            if (emit) {
+                if (startsSegment || (first && (emask & ((1ull << lane) - 1ull)) == 0))
+                    ++srcPieces;
+                ++used;
+                out.rec[myOff + written + (uint32_t)__popcll(emask & ((1ull << lane) - 1ull))] = m;
+            }
+            if (emask)
+                first = false;
+            written += (uint32_t)__popcll(emask);
+            if (act) {
+                if (bmask & gmask) {
+                    act = false;
+                } else {
+                    k += G;
+                    inRange = k + (uint32_t)li < kEnd;
+                    if (inRange)
+                        r = recs[k + (uint32_t)li];
+                }
+            }
+        }
+        if (li == 0 && q < nq) {
+            offset[q] = written ? myOff : 0u;
+            perQuery[q] = written;
+        }
+    }
+    wave_count_add(&counters[CNT_SRC_PIECES], srcPieces);
+    wave_count_add(&counters[CNT_MAPPED], used);
+    wave_count_add(&kstat[0], used); // reported in the "top" slot of this launch: records of the composed table dereferenced
 }
 
 // ---------------------------------------------------------------------------------------------

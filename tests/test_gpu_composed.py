@@ -1,4 +1,5 @@
-"""The composed up table (large plans: locate + the whole up phase from one table, k_locate_composed) against the oracle:
+"""The composed tables (large plans; k_locate_composed) against the oracle — the table of the whole path source -> target
+("through") and the up table source -> MRCA ("up", HGX_COMPOSED_THROUGH=0):
 forced with HGX_COMPOSED_UP=1 on small batches, every genome pair, both strands and '.', dupes on and off, BED12 / PSL,
 the coalescence limit, real data; and at scale against the walk kernels (HGX_COMPOSED_UP=0)."""
 import os
@@ -15,9 +16,11 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-@pytest.fixture(autouse=True)
-def _forced(monkeypatch):
+@pytest.fixture(autouse=True, params=["through", "up"])
+def _forced(monkeypatch, request):
     monkeypatch.setenv("HGX_COMPOSED_UP", "1")
+    monkeypatch.setenv("HGX_COMPOSED_THROUGH", "1" if request.param == "through" else "0")
+    return request.param
 
 
 @pytest.mark.parametrize("seed", [2, 5, 9])
@@ -81,7 +84,7 @@ def test_real_data(hal, oracle_bin, tmp_path):
         assert hal.liftover_convert(al, s, bed, t) == oracle_liftover(oracle_bin, img, src, tgt, bed, tmp_path), (src, tgt)
 
 
-def test_at_scale_against_the_walk_kernels(hal, monkeypatch):
+def test_at_scale_against_the_walk_kernels(hal, monkeypatch, _forced):
     """200 k intervals on ~10 Mb genomes: composed table vs level walk, record for record."""
     import torch
     opts = hal.RandOptions(mean_degree=1.5, max_branch_length=3.0, min_genomes=2, max_genomes=10, min_segment_length=50,
@@ -102,5 +105,8 @@ def test_at_scale_against_the_walk_kernels(hal, monkeypatch):
         ptr, nrec = plan.run(gs, ge, st)
         out[mode] = plan.records_to_tensor(ptr, nrec).cpu()
         kt = plan.kernel_times()
-        assert ("k_locate_composed" in kt) == (mode == "1") and ("k_up_chain" in kt) == (mode == "0")
+        table_kernel = "k_locate_through" if _forced == "through" else "k_locate_composed"
+        assert (table_kernel in kt) == (mode == "1") and ("k_up_chain" in kt) == (mode == "0")
+        if mode == "1":  # the table of the whole path replaces the down hop and the grouping scatter as well
+            assert ("k_down_ring" in kt) == (_forced == "up") and ("k_scatter" in kt) == (_forced == "up")
     assert out["1"].shape[0] > n and torch.equal(out["1"], out["0"])
