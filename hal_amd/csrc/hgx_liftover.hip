@@ -2,6 +2,8 @@
 // launch sequence behind hgx_liftover_run_device / hgx_liftover_batch (include/hgx.h).
 #include "hgx_finish_kernel.hpp"
 #include "hgx_liftover_engine.hpp"
+#include "hgx_table_kernels.hpp"
+#include <hipcub/hipcub.hpp>
 #include <algorithm>
 #include <chrono>
 #include <functional>
@@ -444,12 +446,10 @@ struct hgx_liftover_plan {
     const ComposedUp *composed = nullptr;       // composed up table src -> mrca (large plans; see ensureComposedUp), or null
     bool captureUp = false;                     // table builder: keep the pieces that arrive in the MRCA
     bool captureFinal = false;                  // table builder: keep the FINAL pieces (after the last down hop)
-    struct CapturedPiece {
-        int32_t qid, idx, len;
-        int64_t sPos, so;
-        uint8_t fl;
-    };
-    std::vector<CapturedPiece> captured;
+    bool composedThrough = false;               // which table this plan would use
+    unsigned long long composedAfter = ~0ull;   // switch to the table once this many intervals have been walked (~0: never)
+    unsigned long long walked = 0;
+    int capturedBuf = -1, capturedLevel = -1;   // frontier and counter block of the captured pieces (the run stops there)
     std::vector<int> climb;                     // mrca ... coalescenceLimit when the limit lies above the MRCA (and dupes are on), else empty
     int numFrontiers = 2;
     bool levelSyncUp = getenv("HGX_LEVEL_SYNC_UP") != nullptr; // one launch per up level instead of k_up_chain (kept for deep trees and as a cross-check)
@@ -519,6 +519,8 @@ static void exclusiveScan(hgx_liftover_plan &P, const uint32_t *in, uint32_t n, 
     hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, s, in, n, (const uint32_t *)P.blockSums.p, out);
     P.timer.end(s);
 }
+
+static const ComposedUp *ensureComposed(hgx_alignment *h, int src, int dst, bool through, const hgx_liftover_opts &opts);
 
 template <typename C>
 static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int64_t *dE, const uint8_t *dStrand, hipStream_t s,
@@ -626,47 +628,24 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
         curGenome = P.mrca;
         curTop = false;
     }
-    auto capture = [&]() { // table builder: bring the current frontier to the host
+    // table builder: the run stops at the captured frontier, which stays in the plan's buffers
+    auto endRun = [&]() {
+        HIP_OK(hipEventRecord(P.evEnd, s));
+        HIP_OK(hipMemcpyAsync(P.pinned, cnt, 8 * CNT_SLOTS, hipMemcpyDeviceToHost, s));
+        HIP_OK(hipMemcpyAsync(P.pinned + CNT_SLOTS, P.total.p, 4, hipMemcpyDeviceToHost, s));
         HIP_OK(hipStreamSynchronize(s));
-        unsigned long long segCount[NSEG];
-        HIP_OK(hipMemcpy2D(segCount, 8, inCnt(), 8 * SEG_PITCH, 8, NSEG, hipMemcpyDeviceToHost));
-        const uint32_t segCap = cap / NSEG;
-        const Frontier F = P.frontier(cur);
-        P.captured.clear();
-        std::vector<int32_t> a32;
-        std::vector<int64_t> a64;
-        std::vector<uint8_t> a8;
-        for (int sg = 0; sg < NSEG; ++sg) {
-            const size_t c = (size_t)std::min<unsigned long long>(segCount[sg], segCap);
-            if (!c)
-                continue;
-            const size_t at = P.captured.size(), off = (size_t)sg * segCap;
-            P.captured.resize(at + c);
-            a32.resize(c);
-            a64.resize(c);
-            a8.resize(c);
-            HIP_OK(hipMemcpy(a32.data(), F.qid + off, 4 * c, hipMemcpyDeviceToHost));
-            for (size_t i = 0; i < c; ++i)
-                P.captured[at + i].qid = a32[i];
-            HIP_OK(hipMemcpy(a32.data(), F.idx + off, 4 * c, hipMemcpyDeviceToHost));
-            for (size_t i = 0; i < c; ++i)
-                P.captured[at + i].idx = a32[i];
-            HIP_OK(hipMemcpy(a32.data(), F.len + off, 4 * c, hipMemcpyDeviceToHost));
-            for (size_t i = 0; i < c; ++i)
-                P.captured[at + i].len = a32[i];
-            HIP_OK(hipMemcpy(a64.data(), F.sPos + off, 8 * c, hipMemcpyDeviceToHost));
-            for (size_t i = 0; i < c; ++i)
-                P.captured[at + i].sPos = a64[i];
-            HIP_OK(hipMemcpy(a64.data(), F.so + off, 8 * c, hipMemcpyDeviceToHost));
-            for (size_t i = 0; i < c; ++i)
-                P.captured[at + i].so = a64[i];
-            HIP_OK(hipMemcpy(a8.data(), F.flags + off, c, hipMemcpyDeviceToHost));
-            for (size_t i = 0; i < c; ++i)
-                P.captured[at + i].fl = a8[i];
-        }
+        memcpy(hostCounters, P.pinned, 8 * CNT_SLOTS);
     };
-    if (P.captureUp)
+    auto capture = [&]() {
+        P.capturedBuf = cur;
+        P.capturedLevel = level;
+        HIP_OK(hipEventRecord(P.evWalk, s));
+        endRun();
+    };
+    if (P.captureUp) {
         capture();
+        return;
+    }
     if (!P.climb.empty() && !through) {
         // mapRecursiveParalogies (halSegmentMapper.cpp:525-576), coalescenceLimit above the MRCA: at every genome c_i from
         // the MRCA up to the child of the limit, the pieces (walked through c_i's top tiling) are expanded to their paralogy
@@ -808,6 +787,7 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
         if (!finalized)
             throw std::runtime_error("internal: captureFinal on a path without a final down hop");
         capture();
+        return;
     }
     // final pieces live in the target genome
     const DeviceGenome &TG = D.genomes[(size_t)P.tgt];
@@ -874,11 +854,7 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
                        (const hgx_record *)nullptr, (const int32_t *)nullptr, 0, (const uint32_t *)P.nOut.p, (const uint32_t *)P.outOffset.p, nq,
                        (hgx_record *)P.outRecords.p);
     P.timer.end(s);
-    HIP_OK(hipEventRecord(P.evEnd, s));
-    HIP_OK(hipMemcpyAsync(P.pinned, cnt, 8 * CNT_SLOTS, hipMemcpyDeviceToHost, s));
-    HIP_OK(hipMemcpyAsync(P.pinned + CNT_SLOTS, P.total.p, 4, hipMemcpyDeviceToHost, s));
-    HIP_OK(hipStreamSynchronize(s));
-    memcpy(hostCounters, P.pinned, 8 * CNT_SLOTS);
+    endRun();
 }
 
 __global__ void k_fill_big_slot(const uint32_t *deferredList, uint32_t nd, int32_t *bigSlot) {
@@ -903,6 +879,12 @@ static void runPlan(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
         *dOut = (const hgx_record *)P.outRecords.p;
         *nOut = 0;
         return;
+    }
+    if (!P.composed && P.composedAfter != ~0ull) {
+        if (P.walked >= P.composedAfter)
+            P.composed = ensureComposed(P.h, P.src, P.composedThrough ? P.tgt : P.mrca, P.composedThrough, P.opts);
+        else
+            P.walked += n;
     }
     P.timer.beginRun();
     for (;;) {
@@ -996,7 +978,6 @@ static void runPlan(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
     *nOut = totalRecords;
 }
 
-static const ComposedUp *ensureComposed(hgx_alignment *h, int src, int dst, bool through, const hgx_liftover_opts &opts);
 static void runHostArrays(hgx_liftover_plan *P, const std::vector<int64_t> &gs, const std::vector<int64_t> &ge, const std::vector<uint8_t> &st,
                           std::vector<hgx_record> &out);
 
@@ -1072,17 +1053,18 @@ hgx_liftover_plan *createLiftoverPlan(hgx_alignment *h, int src, int tgt, const 
     HIP_OK(hipEventCreate(&P->evEnd));
     const unsigned long long want = std::max<unsigned long long>(1ull << 16, 16ull * P->maxQueries); // grown on demand
     P->allocate((uint32_t)std::min<unsigned long long>(want, (1ull << 32) - 2));
-    // A plan for a batch that is large against the source genome is served from a composed table (building it costs one
-    // walk over every source segment): the table of the whole path when the target lies below the MRCA, the up table
-    // otherwise.  HGX_COMPOSED_UP=1 forces a table, =0 forbids it; HGX_COMPOSED_THROUGH=0 keeps to the up table.
+    // A plan that has walked a few times as many intervals as the source genome has segments switches to a composed table
+    // (runPlan): building one costs about as much as walking one interval per source segment, a table lookup a third of a
+    // walk.  The table of the whole path when the target lies below the MRCA, the up table otherwise.
+    // HGX_COMPOSED_UP=1 builds it right away, =0 forbids it; HGX_COMPOSED_THROUGH=0 keeps to the up table.
     if (allowComposed && src != P->mrca && P->srcTop && opts.min_length == 0) {
         const char *e = getenv("HGX_COMPOSED_UP");
         const bool force = e && e[0] == '1', forbid = e && e[0] == '0';
-        const bool big = P->maxQueries * 8 >= (size_t)img.genomes[(size_t)src].numTop;
         const char *t = getenv("HGX_COMPOSED_THROUGH");
-        const bool through = tgt != P->mrca && !(t && t[0] == '0');
-        if (!forbid && (force || big))
-            P->composed = ensureComposed(h, src, through ? tgt : P->mrca, through, opts);
+        P->composedThrough = tgt != P->mrca && !(t && t[0] == '0');
+        P->composedAfter = forbid ? ~0ull : (force ? 0ull : 4ull * (unsigned long long)img.genomes[(size_t)src].numTop);
+        if (force)
+            P->composed = ensureComposed(h, src, P->composedThrough ? tgt : P->mrca, P->composedThrough, opts);
     }
     return P.release();
 }
@@ -1095,7 +1077,7 @@ template <typename C>
 static void buildComposed(hgx_alignment *h, int src, int dst, bool through, const hgx_liftover_opts &opts, ComposedUp &out) {
     const auto t0 = std::chrono::steady_clock::now();
     const GenomeTables &S = h->img.genomes[(size_t)src];
-    const GenomeTables &M = h->img.genomes[(size_t)dst];
+    const DeviceImage &D = *h->dev;
     const size_t nt = (size_t)S.numTop;
     hgx_liftover_opts o{};
     o.traverse_dupes = 1;
@@ -1109,87 +1091,89 @@ static void buildComposed(hgx_alignment *h, int src, int dst, bool through, cons
                                                                        destroyLiftoverPlan);
     (through ? P->captureFinal : P->captureUp) = true;
     P->timer.mode = 0;
-    std::vector<int64_t> gs(nt), ge(nt);
-    std::vector<uint8_t> st(nt, (uint8_t)'+');
-    for (size_t i = 0; i < nt; ++i) {
-        gs[i] = S.tStart[i];
-        ge[i] = S.tStart[i + 1] - 1;
+    HIP_OK(hipSetDevice(D.device));
+    hipStream_t s = nullptr;
+    // every source top segment as one forward interval, walked to the capture point
+    DevBuf dS, dE, dT;
+    dS.ensure(8 * std::max<size_t>(nt, 1));
+    dE.ensure(8 * std::max<size_t>(nt, 1));
+    dT.ensure(std::max<size_t>(nt, 1));
+    if (nt)
+        hipLaunchKernelGGL((k_table_queries<C>), dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, (const TopRec<C> *)D.genomes[(size_t)src].top,
+                           (uint32_t)nt, (int64_t *)dS.p, (int64_t *)dE.p, (uint8_t *)dT.p);
+    const hgx_record *ignoredRecords = nullptr;
+    size_t ignoredCount = 0;
+    runLiftoverPlan(P.get(), nt, (const int64_t *)dS.p, (const int64_t *)dE.p, (const uint8_t *)dT.p, s, &ignoredRecords, &ignoredCount);
+    size_t n = 0;
+    if (nt) {
+        if (P->capturedBuf < 0)
+            throw std::runtime_error("internal: the table builder's run did not reach its capture point");
+        const uint32_t segCap = P->cap / NSEG;
+        for (int sg = 0; sg < NSEG; ++sg)
+            n += (size_t)std::min<unsigned long long>(P->pinned[CNT_FRONT0 + (size_t)sg * SEG_PITCH + (size_t)P->capturedLevel], segCap);
     }
-    std::vector<hgx_record> ignored;
-    runHostArrays(P.get(), gs, ge, st, ignored);
-    std::vector<hgx_liftover_plan::CapturedPiece> &cp = P->captured;
-    std::sort(cp.begin(), cp.end(), [](const hgx_liftover_plan::CapturedPiece &a, const hgx_liftover_plan::CapturedPiece &b) {
-        // pieces of one segment (= qid) stay together; inside the up table the source ranges of distinct pieces are disjoint,
-        // the pieces of a whole path may repeat a range (paralogs)
-        return a.sPos != b.sPos ? a.sPos < b.sPos : a.so < b.so;
-    });
-    std::vector<ComposedRec<C>> recs(std::max<size_t>(cp.size(), 1));
-    std::vector<C> eo(std::max<size_t>(through ? 0 : cp.size(), 1));
-    memset(recs.data(), 0, recs.size() * sizeof(ComposedRec<C>));
-    if (cp.size() >= ((size_t)1 << 32) - 1)
+    if (n >= ((size_t)1 << 32) - 1)
         throw std::runtime_error("composed table too large");
-    int32_t lastSeg = -1;
-    for (size_t k = 0; k < cp.size(); ++k) {
-        const hgx_liftover_plan::CapturedPiece &p = cp[k];
-        if (p.fl & F_SREV)
-            throw std::runtime_error("internal: a forward source segment produced a source-reversed piece");
-        ComposedRec<C> &r = recs[k];
-        r.sLo = (C)p.sPos;
-        r.len = (C)p.len;
-        r.so = (C)p.so; // through: the forward start in the target genome
-        if (!through) {
-            const int64_t segLen = M.bStart[(size_t)p.idx + 1] - M.bStart[(size_t)p.idx];
-            eo[k] = (C)(segLen - p.so - p.len);
-        }
-        r.mEncF = (through ? 0u : ((uint32_t)p.idx << 2)) | (p.qid != lastSeg ? 2u : 0u) | ((p.fl & F_TREV) ? 1u : 0u);
-        lastSeg = p.qid;
-    }
-    // coarse[b] = first record that reaches position b << shift or starts after it (~4 records per bucket): no earlier
-    // record overlaps anything at or after that position
+    // ~4 records per bucket
     int64_t buckets = 1;
-    while (buckets < (int64_t)cp.size() / 4 && buckets < ((int64_t)1 << 22))
+    while (buckets < (int64_t)n / 4 && buckets < ((int64_t)1 << 22))
         buckets <<= 1;
     int shift = 0;
     while (((S.totalLength - 1) >> shift) >= buckets)
         ++shift;
-    const int64_t nb = ((S.totalLength - 1) >> shift) + 1;
-    const uint32_t UNSET = 0xFFFFFFFFu;
-    std::vector<uint32_t> coarse((size_t)nb + 1, UNSET);
-    for (size_t k = 0; k < cp.size(); ++k) {
-        const int64_t bLo = cp[k].sPos >> shift, bHi = (cp[k].sPos + cp[k].len - 1) >> shift;
-        for (int64_t b = bLo; b <= bHi; ++b)
-            if (coarse[(size_t)b] == UNSET)
-                coarse[(size_t)b] = (uint32_t)k; // records come in source order: the first to touch a bucket is the smallest
-    }
-    coarse[(size_t)nb] = (uint32_t)cp.size();
-    for (int64_t b = nb; b-- > 0;)
-        if (coarse[(size_t)b] == UNSET)
-            coarse[(size_t)b] = coarse[(size_t)b + 1];
-    HIP_OK(hipSetDevice(h->dev->device));
-    HIP_OK(hipMalloc(&out.recs, recs.size() * sizeof(ComposedRec<C>)));
-    HIP_OK(hipMemcpy(out.recs, recs.data(), recs.size() * sizeof(ComposedRec<C>), hipMemcpyHostToDevice));
-    size_t bytes = recs.size() * sizeof(ComposedRec<C>) + coarse.size() * 4;
+    const uint32_t nb = (uint32_t)(((S.totalLength - 1) >> shift) + 1);
+    const size_t nAlloc = std::max<size_t>(n, 1);
+    HIP_OK(hipMalloc(&out.recs, nAlloc * sizeof(ComposedRec<C>)));
+    HIP_OK(hipMemsetAsync(out.recs, 0, nAlloc * sizeof(ComposedRec<C>), s));
+    HIP_OK(hipMalloc((void **)&out.coarse, ((size_t)nb + 1) * 4));
+    HIP_OK(hipMemsetAsync(out.coarse, 0xFF, ((size_t)nb + 1) * 4, s));
+    HIP_OK(hipMalloc((void **)&out.starts, ((size_t)nb + 1) * 4));
+    size_t bytes = nAlloc * sizeof(ComposedRec<C>) + ((size_t)nb + 1) * 8;
     if (!through) {
-        HIP_OK(hipMalloc(&out.eo, eo.size() * sizeof(C)));
-        HIP_OK(hipMemcpy(out.eo, eo.data(), eo.size() * sizeof(C), hipMemcpyHostToDevice));
-        bytes += eo.size() * sizeof(C);
+        HIP_OK(hipMalloc(&out.eo, nAlloc * sizeof(C)));
+        bytes += nAlloc * sizeof(C);
     }
-    HIP_OK(hipMalloc((void **)&out.coarse, coarse.size() * 4));
-    HIP_OK(hipMemcpy(out.coarse, coarse.data(), coarse.size() * 4, hipMemcpyHostToDevice));
-    if (through) { // starts[b] = first record that begins at or after b << shift
-        std::vector<uint32_t> starts((size_t)nb + 1);
-        size_t k = 0;
-        for (int64_t b = 0; b <= nb; ++b) {
-            while (k < cp.size() && cp[k].sPos < (b << shift))
-                ++k;
-            starts[(size_t)b] = (uint32_t)k;
+    if (n) {
+        const Frontier F = P->frontier(P->capturedBuf);
+        const unsigned long long *levelCount = (const unsigned long long *)P->counters.p + CNT_FRONT0 + (size_t)P->capturedLevel;
+        DevBuf keys[2], slots[2], tmp, bad;
+        for (int k = 0; k < 2; ++k) {
+            keys[k].ensure(8 * n);
+            slots[k].ensure(4 * n);
         }
-        HIP_OK(hipMalloc((void **)&out.starts, starts.size() * 4));
-        HIP_OK(hipMemcpy(out.starts, starts.data(), starts.size() * 4, hipMemcpyHostToDevice));
-        bytes += starts.size() * 4;
+        bad.ensure(8);
+        HIP_OK(hipMemsetAsync(bad.p, 0, 8, s));
+        hipLaunchKernelGGL(k_table_keys, dim3(GRID), dim3(256), 0, s, F, levelCount, P->cap, (uint64_t *)keys[0].p, (uint32_t *)slots[0].p);
+        int endBit = 1;
+        while (endBit < 64 && (S.totalLength >> endBit) != 0)
+            ++endBit;
+        size_t tmpBytes = 0;
+        HIP_OK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmpBytes, (const uint64_t *)keys[0].p, (uint64_t *)keys[1].p, (const uint32_t *)slots[0].p,
+                                                  (uint32_t *)slots[1].p, (int)n, 0, endBit, s));
+        tmp.ensure(std::max<size_t>(tmpBytes, 16));
+        HIP_OK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmpBytes, (const uint64_t *)keys[0].p, (uint64_t *)keys[1].p, (const uint32_t *)slots[0].p,
+                                                  (uint32_t *)slots[1].p, (int)n, 0, endBit, s));
+        const unsigned gridN = (unsigned)((n + 255) / 256);
+        hipLaunchKernelGGL((k_table_records<C>), dim3(gridN), dim3(256), 0, s, F, (const uint32_t *)slots[1].p, (uint32_t)n, through ? 1 : 0,
+                           (const BotRec<C> *)D.genomes[(size_t)dst].bot, (ComposedRec<C> *)out.recs, (C *)out.eo, (unsigned long long *)bad.p);
+        hipLaunchKernelGGL((k_table_touch<C>), dim3(gridN), dim3(256), 0, s, (const ComposedRec<C> *)out.recs, (uint32_t)n, shift, out.coarse);
+        unsigned long long isBad = 0;
+        HIP_OK(hipMemcpyAsync(&isBad, bad.p, 8, hipMemcpyDeviceToHost, s));
+        HIP_OK(hipStreamSynchronize(s));
+        if (isBad)
+            throw std::runtime_error("internal: a forward source segment produced a source-reversed piece");
+    }
+    const unsigned gridB = (unsigned)(((size_t)nb + 1 + 255) / 256);
+    hipLaunchKernelGGL((k_table_starts<C>), dim3(gridB), dim3(256), 0, s, (const ComposedRec<C> *)out.recs, (uint32_t)n, shift, nb, out.starts);
+    hipLaunchKernelGGL(k_table_fill, dim3(gridB), dim3(256), 0, s, out.coarse, (const uint32_t *)out.starts, nb);
+    HIP_OK(hipStreamSynchronize(s));
+    if (!through) { // the up table's kernel has no use for starts[]
+        (void)hipFree(out.starts);
+        out.starts = nullptr;
+        bytes -= ((size_t)nb + 1) * 4;
     }
     out.shift = shift;
-    out.numRecs = cp.size();
+    out.numRecs = n;
     out.through = through;
     h->dev->bytes += bytes;
     out.buildMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

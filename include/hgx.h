@@ -138,9 +138,10 @@ int hgx_liftover_run_device(hgx_liftover_plan *p, size_t n, const int64_t *d_gst
 typedef struct hgx_liftover_stats {
     uint64_t queries, source_pieces, top_derefs, bottom_derefs, mapped_pieces, records, deferred_queries;
     double walk_ms, total_ms;
-    /* Plans for batches that are large against the source genome are served from a composed table, built once per
-     * alignment and genome pair by the walk kernels themselves when the first such plan is created (every source top
-     * segment runs through the walk as one interval and its pieces are kept, sorted by source position):
+    /* A plan that has walked four times as many intervals as the source genome has top segments switches to a composed
+     * table, built once per alignment, genome pair and options on the device (every source top segment runs through the
+     * walk kernels as one interval, the pieces are radix-sorted by source position; about the cost of walking one interval
+     * per source segment):
      *   composed_kind 2 — the table of the whole path source -> MRCA -> target (paralogy rings and coalescenceLimit
      *                     included): an interval is one lookup plus the grouping / merging step;
      *   composed_kind 1 — the up table source -> MRCA (when the target is the MRCA itself, or HGX_COMPOSED_THROUGH=0):
@@ -148,7 +149,7 @@ typedef struct hgx_liftover_stats {
      *   composed_kind 0 — this plan walks level by level.
      * composed_records / composed_build_ms: size and build time of the table.  With a table, top_derefs counts the table
      * records dereferenced plus the segment records of whatever part of the walk still runs.
-     * HGX_COMPOSED_UP=1 / =0 in the environment forces / forbids the table. */
+     * HGX_COMPOSED_UP=1 in the environment builds the table when the plan is created, =0 forbids it. */
     uint64_t composed_records;
     double composed_build_ms;
     uint64_t composed_kind;

@@ -11,4 +11,5 @@ gs = (starts + ss).cuda(); ge = (starts + lens - 1 + ss).cuda(); st = strand.cud
 plan = hal_amd.LiftoverPlan(al, src, tgt, max_queries=n)
 for _ in range(5):
     plan.run(gs, ge, st)
-print({k: round(v["ms"], 4) for k, v in plan.kernel_times().items()}, plan.stats()["total_ms"])
+st = plan.stats()
+print({k: round(v["ms"], 4) for k, v in plan.kernel_times().items()}, st["total_ms"], "table:", st["composed_kind"], st["composed_records"], round(st["composed_build_ms"], 2), "ms")

@@ -52,8 +52,9 @@ def test_switchable_paths_agree():
         assert _digest(**env) == base, env
 
 
-def test_plan_timing_modes(hal, tmp_path):
+def test_plan_timing_modes(hal, tmp_path, monkeypatch):
     import torch
+    monkeypatch.setenv("HGX_COMPOSED_UP", "1")  # (a walking plan would switch to its table in the middle of the test)
     opts = hal.RandOptions(mean_degree=1.5, max_branch_length=3.0, min_genomes=2, max_genomes=10, min_segment_length=10, max_segment_length=60,
                            min_segments=200, max_segments=600, seed=2, with_dna=False)
     al = hal.Alignment.random(opts, device=0)
@@ -65,7 +66,6 @@ def test_plan_timing_modes(hal, tmp_path):
     plan = hal.LiftoverPlan(al, src, tgt, max_queries=n)
     plan.run(gs, ge, st)
     last = plan.kernel_times()
-    # a batch this large against the genome uses the table of the whole path (one kernel in front of the finishing step)
     walk = "k_up_chain" if "k_up_chain" in last else "k_locate_through"
     ctr = "k_down_ring" if walk == "k_up_chain" else walk
     assert last[walk]["launches"] == 1 and last[ctr]["top_derefs"] > 0

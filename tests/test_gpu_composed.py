@@ -110,3 +110,33 @@ def test_at_scale_against_the_walk_kernels(hal, monkeypatch, _forced):
         if mode == "1":  # the table of the whole path replaces the down hop and the grouping scatter as well
             assert ("k_down_ring" in kt) == (_forced == "up") and ("k_scatter" in kt) == (_forced == "up")
     assert out["1"].shape[0] > n and torch.equal(out["1"], out["0"])
+
+
+def test_a_walking_plan_switches_to_its_table(hal, monkeypatch, _forced):
+    """Without HGX_COMPOSED_UP a plan walks until it has seen four intervals per source segment, then builds and uses the
+    table; the records before and after the switch are the same."""
+    import torch
+    monkeypatch.delenv("HGX_COMPOSED_UP")
+    opts = hal.RandOptions(mean_degree=1.5, max_branch_length=3.0, min_genomes=2, max_genomes=10, min_segment_length=20,
+                           max_segment_length=80, min_segments=2000, max_segments=4000, seed=2, with_dna=False)
+    al = hal.Alignment.random(opts, device=0)
+    src, tgt = al.genome_id("Genome_9"), al.genome_id("Genome_8")
+    _, ss, length = al.sequences(src)[0]
+    n = 3000
+    g = torch.Generator().manual_seed(11)
+    starts = torch.randint(0, length - 400, (n,), generator=g)
+    lens = torch.randint(1, 300, (n,), generator=g)
+    gs, ge = (starts + ss).cuda(), (starts + lens - 1 + ss).cuda()
+    st = torch.where(torch.rand(n, generator=g) < 0.5, ord("+"), ord("-")).to(torch.uint8).cuda()
+    plan = hal.LiftoverPlan(al, src, tgt, max_queries=n)
+    table_kernel = "k_locate_through" if _forced == "through" else "k_locate_composed"
+    first, kinds = None, []
+    for _ in range(12):
+        ptr, nrec = plan.run(gs, ge, st)
+        recs = plan.records_to_tensor(ptr, nrec).cpu()
+        if first is None:
+            first = recs
+        assert torch.equal(recs, first)
+        kinds.append(table_kernel in plan.kernel_times())
+    assert kinds[0] is False and kinds[-1] is True and sorted(kinds) == kinds  # walks first, one switch, the table afterwards
+    assert plan.stats()["composed_kind"] == (2 if _forced == "through" else 1)
