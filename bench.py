@@ -281,9 +281,9 @@ def main():
                                                                      "seed 2" if args.workload == "cfg2" else "seed 0", args.scale, nq,
                                                                      src_name, tgt_name),
                        "intervals_per_gpu": nq, "records_per_step": nrec_all, "parallelism": "query-shard x%d" % world,
-                       "up_phase": ("composed table of the %s: %d records (%.0f MB), built once per alignment and genome pair by the walk "
-                                    "kernels in %.0f ms at plan creation, untimed; %d table records dereferenced per step; "
-                                    "HGX_COMPOSED_UP=0 gives the level-by-level walk (profiles/r01r_bench_walk.log)"
+                       "up_phase": ("composed table of the %s: %d records (%.0f MB), built once per alignment and genome pair on the device "
+                                    "in %.0f ms when the plan changed over during warm-up (after 4 intervals per source segment), untimed; %d table records dereferenced per step; "
+                                    "HGX_COMPOSED_UP=0 gives the level-by-level walk (profiles/r01q_bench_walk.log)"
                                     % ("whole path src->MRCA->target" if st["composed_kind"] == 2 else "up phase src->MRCA",
                                        st["composed_records"], st["composed_records"] * (16 if st["composed_kind"] == 2 else 20) / 1e6,
                                        st["composed_build_ms"], table_records))
@@ -362,7 +362,9 @@ def plan_kernel_bytes(kt, st, steps):
                 bytes_ += 8.0 * st["queries"] * steps
         if name in ("k_locate_expand", "k_locate_composed", "k_locate_through"):
             bytes_ += 24.0 * st["queries"] * steps
-        if name in ("k_finish_lds", "k_finish_big"):
+        if name in ("k_finish_fast", "k_finish_lds", "k_finish_big"):
+            # 40 B per output record.  The fast kernels write nearly all of them; the split between the fast and
+            # the general kernel is not counted, so each is credited with all records (an upper bound for either)
             bytes_ += 40.0 * st["records"] * steps
         if name == "k_compact_records":
             bytes_ += 80.0 * st["records"] * steps

@@ -491,7 +491,7 @@ struct hgx_liftover_plan {
         if (!pinned)
             HIP_OK(hipHostMalloc((void **)&pinned, 8 * (CNT_SLOTS + 1)));
         const size_t nq = std::max<size_t>(maxQueries, 1);
-        counters.ensure(8 * CNT_SLOTS);
+        counters.ensure(8 * CNT_DEV_SLOTS);
         perQuery.ensure(4 * (nq + 1));
         offset.ensure(4 * (nq + 1));
         cursor.ensure(4 * (nq + 1));
@@ -511,6 +511,27 @@ namespace hgx {
 
 static constexpr int GRID = 2048; // 256 CUs x 8 resident 256-thread blocks, grid-stride beyond
 
+// Grid of a grid-stride kernel that does not fit eight blocks per CU (more than 64 VGPRs): exactly the resident blocks.
+// With GRID blocks the ones that do not fit start when the first ones finish and run their whole share on a nearly idle
+// chip — k_locate_through (68 VGPRs, 7 blocks per CU) took twice the lifetime of its wavefronts (PMC, profiles/r01q_pmc.txt).
+template <typename K> static int residentGrid(K kernel, size_t dynLds = 0) {
+    static std::mutex mu;
+    static std::map<std::pair<const void *, size_t>, int> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    const auto key = std::make_pair((const void *)kernel, dynLds);
+    auto it = cache.find(key);
+    if (it != cache.end())
+        return it->second;
+    int perCu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    HIP_OK(hipGetDevice(&dev));
+    HIP_OK(hipGetDeviceProperties(&prop, dev));
+    HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kernel, 256, dynLds));
+    const int g = std::min(GRID, std::max(1, perCu) * prop.multiProcessorCount);
+    cache.emplace(key, g);
+    return g;
+}
+
 static void exclusiveScan(hgx_liftover_plan &P, const uint32_t *in, uint32_t n, uint32_t *out, uint32_t *total, hipStream_t s) {
     const uint32_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
     P.timer.begin("scan", s);
@@ -529,15 +550,16 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
     unsigned long long *cnt = (unsigned long long *)P.counters.p;
     const uint32_t cap = P.cap;
     const uint32_t nq = (uint32_t)n;
-    HIP_OK(hipMemsetAsync(cnt, 0, 8 * CNT_SLOTS, s));
-    HIP_OK(hipMemsetAsync(P.perQuery.p, 0, 4 * (n + 1), s));
-    HIP_OK(hipMemsetAsync(P.cursor.p, 0, 4 * (n + 1), s));
-    HIP_OK(hipMemsetAsync(P.bigSlot.p, 0xFF, 4 * (n + 1), s));
+    HIP_OK(hipMemsetAsync(cnt, 0, 8 * CNT_DEV_SLOTS, s));
+    if (!(P.composed && P.composed->through)) { // (k_locate_through writes every interval's count itself and has no grouping scatter)
+        HIP_OK(hipMemsetAsync(P.perQuery.p, 0, 4 * (n + 1), s));
+        HIP_OK(hipMemsetAsync(P.cursor.p, 0, 4 * (n + 1), s));
+    }
     HIP_OK(hipEventRecord(P.evStart, s));
 
     int level = 0;
     int launch = 0; // per-launch deref counter slot
-    auto kstat = [&]() { return cnt + CNT_KSTAT0 + 2 * launch; };
+    auto kstat = [&]() { return cnt + CNT_DSTAT0 + STAT_LAUNCH0 + 2 * launch; }; // (copy 0; a block adds to its own copy)
     int cur = 0; // frontier buffer holding the current pieces
     auto inCnt = [&]() { return cnt + CNT_FRONT0 + (size_t)level; };
     int outLevel = 1; // counter block of the frontier the next launch writes; every launch gets a fresh one
@@ -554,7 +576,7 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
         // locate + the whole up phase from the composed table: the pieces arrive in the MRCA directly
         P.timer.begin(through ? "k_locate_through" : "k_locate_composed", s, launch);
         if (through)
-            hipLaunchKernelGGL((k_locate_through<C>), dim3(GRID), dim3(256), 0, s, dS, dE, dStrand, nq,
+            hipLaunchKernelGGL((k_locate_through<C>), dim3(residentGrid(k_locate_through<C>)), dim3(256), 0, s, dS, dE, dStrand, nq,
                                P.h->img.genomes[(size_t)P.src].totalLength, (const uint32_t *)P.composed->coarse,
                                (const uint32_t *)P.composed->starts, P.composed->shift, (const ComposedRec<C> *)P.composed->recs, P.mapped(1), cap,
                                inCnt(), cnt, kstat(), (uint32_t *)P.offset.p, (uint32_t *)P.perQuery.p);
@@ -597,7 +619,7 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
             }
             tabs.n = (int)nUp;
             P.timer.begin("k_up_chain", s, launch);
-            hipLaunchKernelGGL((k_up_chain<C>), dim3(GRID), dim3(256), upChainLdsBytes((int)nUp), s, tabs, P.frontier(cur), inCnt(), cap, P.frontier(cur ^ 1),
+            hipLaunchKernelGGL((k_up_chain<C>), dim3(residentGrid(k_up_chain<C>, upChainLdsBytes((int)nUp))), dim3(256), upChainLdsBytes((int)nUp), s, tabs, P.frontier(cur), inCnt(), cap, P.frontier(cur ^ 1),
                                outCnt(), minLen, cnt, kstat());
             P.timer.end(s);
             ++launch;
@@ -631,10 +653,25 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
     // table builder: the run stops at the captured frontier, which stays in the plan's buffers
     auto endRun = [&]() {
         HIP_OK(hipEventRecord(P.evEnd, s));
-        HIP_OK(hipMemcpyAsync(P.pinned, cnt, 8 * CNT_SLOTS, hipMemcpyDeviceToHost, s));
+        const int words = STAT_LAUNCH0 + 2 * std::min(launch + 1, (int)MAX_LAUNCHES);
+        hipLaunchKernelGGL(k_fold_stats, dim3(1), dim3(STAT_PITCH), 0, s, cnt, words);
+        // one readback: the scalar slots, the per-launch statistics and the record total; the 64 KB of frontier counters
+        // only when somebody needs them (the table builder, or below after an overflow)
+        if (P.captureUp || P.captureFinal) {
+            HIP_OK(hipMemcpyAsync(P.pinned, cnt, 8 * CNT_SLOTS, hipMemcpyDeviceToHost, s));
+        } else {
+            HIP_OK(hipMemcpyAsync(P.pinned, cnt, 8 * CNT_FRONT0, hipMemcpyDeviceToHost, s));
+            HIP_OK(hipMemcpyAsync(P.pinned + CNT_KSTAT0, cnt + CNT_KSTAT0, 8 * (size_t)(words - STAT_LAUNCH0), hipMemcpyDeviceToHost, s));
+        }
         HIP_OK(hipMemcpyAsync(P.pinned + CNT_SLOTS, P.total.p, 4, hipMemcpyDeviceToHost, s));
         HIP_OK(hipStreamSynchronize(s));
+        if (P.pinned[CNT_OVERFLOW] && !(P.captureUp || P.captureFinal)) { // the retry sizes the buffers from the frontier counters
+            HIP_OK(hipMemcpyAsync(P.pinned, cnt, 8 * CNT_SLOTS, hipMemcpyDeviceToHost, s));
+            HIP_OK(hipStreamSynchronize(s));
+        }
         memcpy(hostCounters, P.pinned, 8 * CNT_SLOTS);
+        const size_t usedStats = (size_t)(words - STAT_LAUNCH0); // launches this run did not make count nothing
+        memset(hostCounters + CNT_KSTAT0 + usedStats, 0, 8 * (2 * (size_t)MAX_LAUNCHES - usedStats));
     };
     auto capture = [&]() {
         P.capturedBuf = cur;
@@ -817,6 +854,8 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
     // finishing: register-resident fast path per size class (each kernel picks the intervals of its class),
     // general LDS path for the rest
     // classLists: [general | 9-16 | 17-32 | 33-64 pieces], nq entries each; classCounts: [general, 3 classes]
+    // (splitting every list into sub-lists with their counters on separate cache lines was measured: no gain — the blocks of
+    // k_finish_fast<C, 8> reach their bulk appends at different times, unlike the statistics all wavefronts add at their end)
     uint32_t *generalList = (uint32_t *)P.classLists.p;
     unsigned long long *generalCount = (unsigned long long *)P.classCounts.p;
     uint32_t *classLists = generalList + nq;
@@ -914,6 +953,7 @@ static void runPlan(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
     int bigCap = 0;
     if (nDef > 0) {
         bigCap = (int)std::max<unsigned long long>(512, 2 * hc[CNT_MAXNEED]);
+        HIP_OK(hipMemsetAsync(P.bigSlot.p, 0xFF, 4 * (n + 1), s)); // -1: not deferred
         hipLaunchKernelGGL(k_fill_big_slot, dim3((nDef + 255) / 256), dim3(256), 0, s, (const uint32_t *)P.deferredList.p, nDef,
                            (int32_t *)P.bigSlot.p);
         for (;;) {

@@ -57,20 +57,48 @@ enum {
     MAX_LEVELS = 120,
     CNT_KSTAT0 = CNT_FRONT0 + NSEG * SEG_PITCH, // + 2*launch: {top, bottom} segment records dereferenced by that launch
     MAX_LAUNCHES = 152,
-    CNT_SLOTS = CNT_KSTAT0 + 2 * MAX_LAUNCHES
+    CNT_SLOTS = CNT_KSTAT0 + 2 * MAX_LAUNCHES,
+    // Statistics (dereference counts per launch, source pieces) are summed by every wavefront at the end of a kernel.
+    // Atomics on one cache line complete one after the other at the memory side, about 12 ns each: with 8192 wavefronts
+    // adding two or three words of one line every kernel carried a tail of 0.2-0.3 ms (k_locate_through ran 0.21 ms with
+    // 1024 blocks and 1.5 ms with 16384).  The sums are therefore spread over STAT_LINES copies, 4 KB apart, chosen by the
+    // block index; k_fold_stats adds the copies up at the end of the run into the compact slots above.  Device-only words, after the compact block:
+    STAT_LINES = 32,
+    STAT_PITCH = 512,      // words between two copies
+    STAT_SRC_PIECES = 0,   // word inside a copy
+    STAT_MAPPED = 1,       // pieces written by k_locate_through
+    STAT_LAUNCH0 = 2,      // + 2*launch: {top, bottom}
+    CNT_DSTAT0 = CNT_SLOTS,
+    CNT_DEV_SLOTS = CNT_SLOTS + STAT_LINES * STAT_PITCH
 };
+static_assert(STAT_LAUNCH0 + 2 * MAX_LAUNCHES <= STAT_PITCH, "a copy of the statistics holds two words per launch");
+// adds a wavefront's count to this block's copy of a statistics word (word0: the word in copy 0)
+__device__ __forceinline__ void stat_add(unsigned long long *word0, uint32_t v) {
+    for (int o = 32; o > 0; o >>= 1)
+        v += __shfl_down(v, o);
+    if ((threadIdx.x & 63) == 0 && v)
+        atomicAdd(word0 + (size_t)(blockIdx.x & (STAT_LINES - 1)) * STAT_PITCH, (unsigned long long)v);
+}
 static_assert(MAX_LEVELS <= SEG_PITCH, "a segment's counter block holds one word per level");
 
 __device__ __forceinline__ int lane_id() {
     return (int)(threadIdx.x & 63);
 }
 
-__device__ __forceinline__ void wave_count_add(unsigned long long *counter, uint32_t v) {
-    // wave reduction through DPP-free shuffles, one atomic per wave
-    for (int o = 32; o > 0; o >>= 1)
-        v += __shfl_down(v, o);
-    if (lane_id() == 0 && v)
-        atomicAdd(counter, (unsigned long long)v);
+// adds the copies of the statistics words up into the compact slots (one small launch at the end of a run)
+static __global__ void k_fold_stats(unsigned long long *counters, int words) {
+    const int w = (int)threadIdx.x;
+    if (w >= words)
+        return;
+    unsigned long long sum = 0;
+    for (int l = 0; l < STAT_LINES; ++l)
+        sum += counters[CNT_DSTAT0 + (size_t)l * STAT_PITCH + w];
+    if (w == STAT_SRC_PIECES)
+        counters[CNT_SRC_PIECES] = sum;
+    else if (w == STAT_MAPPED)
+        counters[CNT_MAPPED] += sum;
+    else
+        counters[CNT_KSTAT0 + (w - STAT_LAUNCH0)] = sum;
 }
 
 // LDS-staged append.  Appending straight to the next frontier costs one device-scope atomic on a single
@@ -299,8 +327,8 @@ __global__ void __launch_bounds__(256) k_locate_expand(const REC *__restrict__ s
         }
     }
     stage.flush();
-    wave_count_add(&counters[CNT_SRC_PIECES], derefs);
-    wave_count_add(kstat, derefs);
+    stat_add(&counters[CNT_DSTAT0 + STAT_SRC_PIECES], derefs);
+    stat_add(kstat, derefs);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -405,8 +433,8 @@ __global__ void __launch_bounds__(256) k_locate_composed(const int64_t *__restri
         }
     }
     stage.flush();
-    wave_count_add(&counters[CNT_SRC_PIECES], srcPieces);
-    wave_count_add(&kstat[0], used); // reported in the "top" slot of this launch: records of the composed table dereferenced
+    stat_add(&counters[CNT_DSTAT0 + STAT_SRC_PIECES], srcPieces);
+    stat_add(&kstat[0], used); // reported in the "top" slot of this launch: records of the composed table dereferenced
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -544,9 +572,9 @@ __global__ void __launch_bounds__(256) k_locate_through(const int64_t *__restric
             perQuery[q] = written;
         }
     }
-    wave_count_add(&counters[CNT_SRC_PIECES], srcPieces);
-    wave_count_add(&counters[CNT_MAPPED], used);
-    wave_count_add(&kstat[0], used); // reported in the "top" slot of this launch: records of the composed table dereferenced
+    stat_add(&counters[CNT_DSTAT0 + STAT_SRC_PIECES], srcPieces);
+    stat_add(&counters[CNT_DSTAT0 + STAT_MAPPED], used);
+    stat_add(&kstat[0], used); // reported in the "top" slot of this launch: records of the composed table dereferenced
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -606,8 +634,8 @@ __global__ void __launch_bounds__(256) k_up_first(const UpRec<C> *__restrict__ u
         stage.emit(emit, qid, sPos, oIdx, oSo, len, fl);
     }
     stage.flush();
-    wave_count_add(&kstat[0], topDerefs);
-    wave_count_add(&kstat[1], botDerefs);
+    stat_add(&kstat[0], topDerefs);
+    stat_add(&kstat[1], botDerefs);
 }
 
 // positional pieces in genome P -> split on P's top tiling -> P's parent (positional, or ordinary when that is the MRCA)
@@ -699,8 +727,8 @@ __global__ void __launch_bounds__(256) k_up_walk(const UpRec<C> *__restrict__ up
         }
     }
     stage.flush();
-    wave_count_add(&kstat[0], topDerefs);
-    wave_count_add(&kstat[1], botDerefs);
+    stat_add(&kstat[0], topDerefs);
+    stat_add(&kstat[1], botDerefs);
 }
 
 // The whole up phase in one launch.  With k_up_first/k_up_walk every level writes its pieces to HBM and the next launch
@@ -884,8 +912,8 @@ __global__ void __launch_bounds__(256) k_up_chain(UpTables<C> tabs, Frontier in,
         stage.emit(emit, qid, oSPos, oIdx, oSo, oLen, oFl);
     }
     stage.flush();
-    wave_count_add(&kstat[0], topDerefs);
-    wave_count_add(&kstat[1], botDerefs);
+    stat_add(&kstat[0], topDerefs);
+    stat_add(&kstat[1], botDerefs);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -980,8 +1008,8 @@ __global__ void __launch_bounds__(256) k_down_ring(const DownRec<C> *__restrict_
         }
     }
     stage.flush();
-    wave_count_add(&kstat[0], topDerefs);
-    wave_count_add(&kstat[1], botDerefs);
+    stat_add(&kstat[0], topDerefs);
+    stat_add(&kstat[1], botDerefs);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1072,8 +1100,8 @@ __device__ __forceinline__ void parse_body(const FROM *__restrict__ from, const 
         }
     }
     stage.flush();
-    wave_count_add(&kstat[FROM_SLOT], fromDerefs);
-    wave_count_add(&kstat[1 - FROM_SLOT], toDerefs);
+    stat_add(&kstat[FROM_SLOT], fromDerefs);
+    stat_add(&kstat[1 - FROM_SLOT], toDerefs);
 }
 
 template <typename C>
@@ -1152,7 +1180,7 @@ __global__ void __launch_bounds__(256) k_ring(const TopRec<C> *__restrict__ top,
         }
     }
     stage.flush();
-    wave_count_add(&kstat[0], topDerefs);
+    stat_add(&kstat[0], topDerefs);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1211,7 +1239,7 @@ __global__ void __launch_bounds__(256) k_finalize(const REC *__restrict__ segs, 
         if (q >= 0 && lane_id() == start)
             atomicAdd(&perQuery[q], (uint32_t)len);
     }
-    wave_count_add(&kstat[isTop ? 0 : 1], derefs);
+    stat_add(&kstat[isTop ? 0 : 1], derefs);
     if (blockIdx.x == 0 && threadIdx.x == 0)
         counters[CNT_MAPPED] = n;
 }
