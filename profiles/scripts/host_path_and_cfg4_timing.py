@@ -28,7 +28,14 @@ n = 1250000
 starts, lens, strand = bench.make_queries(length, n, 99)
 plan = hal_amd.LiftoverPlan(al, src, tgt, max_queries=n)
 gs, ge, st = (starts + ss).cuda(), (starts + lens - 1 + ss).cuda(), strand.cuda()
+def report(tag):
+    s = plan.stats()
+    print("cfg4 shard on 1 GPU, %s: %d intervals Genome_44->Genome_2 (7 up, 1 down): %.3f ms, %.1f M intervals/s, %d records, %d mapped pieces, table kind %d (%d records, built in %.1f ms)"
+          % (tag, n, s["total_ms"], n / s["total_ms"] / 1e3, nrec, s["mapped_pieces"], s["composed_kind"], s["composed_records"], s["composed_build_ms"]),
+          {k: round(v["ms"], 3) for k, v in plan.kernel_times().items()})
 for _ in range(3):
     ptr, nrec = plan.run(gs, ge, st)
-s = plan.stats()
-print("cfg4 shard on 1 GPU: %d intervals Genome_44->Genome_2 (7 up, 1 down): %.3f ms, %.1f M intervals/s, %d records, %d mapped pieces" % (n, s["total_ms"], n / s["total_ms"] / 1e3, nrec, s["mapped_pieces"]), {k: round(v["ms"], 3) for k, v in plan.kernel_times().items()})
+report("level walk (first runs of a plan)")
+for _ in range(12):  # the plan changes over to its table after 4 intervals per source segment
+    ptr, nrec = plan.run(gs, ge, st)
+report("after the change-over")
