@@ -106,6 +106,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=300000, help="intervals timed on the CPU oracle (0 = skip)")
     ap.add_argument("--cpu-all-cores", type=int, default=1, help="also time the oracle sharded over every host core")
     ap.add_argument("--columns", type=int, default=1, help="also time the column-depth kernel over the whole source genome (0 = skip)")
+    ap.add_argument("--exchange-selftest", type=int, default=0,
+                    help="1: with one GPU, run the multi-GPU code path (wire blob, overlapped all-gatherv, collective settle exit) on a "
+                         "one-rank RCCL group; the JSON line then says so in config.exchange")
     args = ap.parse_args()
 
     import torch
@@ -116,8 +119,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    exchanging = world > 1 or bool(args.exchange_selftest)  # the exchange step is part of the timed loop
+    if exchanging:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -136,26 +144,27 @@ def main():
     plan = hal_amd.LiftoverPlan(al, src, tgt, max_queries=nq)
 
     collator = shard.RecordCollator()
-    packed_wire = shard.can_pack(max(al.genome_length(src), al.genome_length(tgt)), nq, len(al.sequences(tgt)))
+    wire = {"format": None, "bytes": 0}
 
     def step():
         ptr, nrec = plan.run(d_gs, d_ge, d_st)
-        if world > 1:
-            # the one exchange step of the path: all-gatherv of the fixed-width records (hal_amd/shard.py).  The
-            # payload exchange of this batch runs on RCCL's stream while the next batch is mapped; the previous
-            # batch's exchange is completed first, so every timed step pays for one whole exchange.
-            recs = plan.records_to_tensor(ptr, nrec, packed=packed_wire)  # 20-byte wire records: half the bytes over xGMI
-            prev = collator.wait(trim=False)
-            collator.submit(recs)
-            return nrec, (sum(prev[1]) if prev else nrec * world)
-        return nrec, nrec
+        if exchanging:
+            # the one exchange step of the path: all-gatherv of the batch's records (hal_amd/shard.py) as a self-describing
+            # blob, 12 bytes per record + 2 per interval when every field fits (hgx_liftover_wire_blob).  The payload exchange
+            # of this batch runs on RCCL's stream while the next batch is mapped; the previous batch's exchange is completed
+            # first, so every timed step pays for one whole exchange.
+            blob, fmt = plan.wire_blob(first_query=rank * nq)
+            wire["format"], wire["bytes"] = fmt, int(blob.numel())
+            collator.wait(trim=False)
+            collator.submit(blob)
+        return nrec
 
     # settle (untimed): the first runs of a fresh process pay for lazy code-object loads, event pools and workspace growth
     # (5-12 ms against 2.9 ms), and a process that starts while the previous GPU process is still being torn down by the
     # driver sees ~1.3 ms of extra host time per run for a second or two.  Run until ten consecutive runs are within 5 %
     # of the fastest one seen, for at most 4 s.
     best, streak, t_settle = None, 0, time.perf_counter()
-    while streak < 10 and time.perf_counter() - t_settle < 4.0:
+    while True:
         t_s = time.perf_counter()
         step()
         torch.cuda.synchronize()
@@ -163,31 +172,43 @@ def main():
         if best is None or dt < best:
             best = dt
         streak = streak + 1 if dt <= 1.05 * best else 0
+        done = streak >= 10 or time.perf_counter() - t_settle >= 4.0
+        if exchanging:  # every step is a collective: the ranks leave the loop together
+            flag = torch.tensor([1 if done else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            done = bool(flag.item())
+        if done:
+            break
     for _ in range(args.warmup):
         step()
     plan.set_timing(2)  # kernel events accumulate over the timed steps and are read once, after the timed region
-    if world > 1:
+    if exchanging:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     kt_acc = {}
     walk_ms = total_ms = 0.0
     for _ in range(args.steps):
-        nrec, nrec_all = step()
+        nrec = step()
         st = plan.stats()
         walk_ms += st["walk_ms"]
         total_ms += st["total_ms"]
-    if world > 1:
+    if exchanging:
         collator.wait(trim=False)  # the last exchange belongs to the timed region
     torch.cuda.synchronize()
-    if world > 1:
+    if exchanging:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    nrec_all = nrec
+    if exchanging:
+        tot = torch.tensor([nrec], dtype=torch.int64, device=dev)
+        dist.all_reduce(tot)
+        nrec_all = int(tot.item())
     kt_total = plan.kernel_times()
     for k, v in kt_total.items():
         kt_acc[k] = {"ms": v["ms"], "launches": v["launches"]}
     plan.set_timing(1)
-    if world > 1:
+    if exchanging:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -204,7 +225,7 @@ def main():
         col_ms = min(al.columns_depth_device(src, lo, hi - lo, mine.data_ptr()) for _ in range(3))
         gather_ms = 0.0
         depth_sum = float(mine[:hi - lo].double().sum().item())
-        if world > 1:
+        if exchanging:
             per = (ncol + world - 1) // world
             padded = torch.zeros(per, dtype=torch.int32, device=dev)
             padded[:hi - lo] = mine[:hi - lo]
@@ -288,8 +309,9 @@ def main():
                                        st["composed_records"], st["composed_records"] * (16 if st["composed_kind"] == 2 else 20) / 1e6,
                                        st["composed_build_ms"], table_records))
                        if st["composed_records"] else "level-by-level walk (k_up_chain)",
-                       "exchange": ("all-gatherv of %d-byte records, overlapped with the next batch" % (20 if packed_wire else 40))
-                       if world > 1 else "none (one GPU)",
+                       "exchange": ("all-gatherv of wire blobs (format %s: %.1f MB per rank and step), overlapped with the next batch"
+                                    % (wire["format"], wire["bytes"] / 1e6))
+                       if exchanging else "none (one GPU)",
                        "newick": al.newick, "generate_s": round(gen_s, 2)},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -340,7 +362,7 @@ def main():
             if multi:
                 out["cpu_baseline"]["all_cores"] = multi
         print(json.dumps(out))
-    if world > 1:
+    if exchanging:
         dist.destroy_process_group()
 
 

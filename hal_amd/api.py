@@ -357,6 +357,19 @@ class LiftoverPlan:
             raise HgxError(take_error(err))
         return t
 
+    def wire_blob(self, first_query=0):
+        """The last run's records as one self-describing uint8 tensor for the multi-GPU exchange (hgx_liftover_wire_blob;
+        hal_amd.shard.decode_blob reads it): (blob, format) with format 12 or 20 bytes per record."""
+        import torch
+        err, nbytes, fmt = C.c_void_p(), C.c_size_t(), C.c_int()
+        stream = torch.cuda.current_stream().cuda_stream
+        st = self.stats()  # room for any of the three formats (the call chooses; only the bytes written are returned)
+        cap = 32 + (2 * st["queries"] + 7) // 8 * 8 + 40 * st["records"]
+        t = torch.empty(cap, dtype=torch.uint8, device="cuda")
+        if lib.hgx_liftover_wire_blob(self._p, t.data_ptr(), t.numel(), first_query, C.byref(nbytes), C.byref(fmt), stream, C.byref(err)) != 0:
+            raise HgxError(take_error(err))
+        return t[:nbytes.value], fmt.value
+
     def stats(self):
         s = hgx_liftover_stats()
         lib.hgx_liftover_last_stats(self._p, C.byref(s))

@@ -336,6 +336,16 @@ int hgx_liftover_copy_records_packed(const hgx_liftover_plan *p, void *d_dst, si
     HGX_CATCH
 }
 
+int hgx_liftover_wire_blob(hgx_liftover_plan *p, void *d_dst, size_t capacity, int64_t first_query, size_t *bytes, int *format, void *hip_stream,
+                           char **err) {
+    HGX_TRY
+    if (!p || !bytes)
+        throw std::runtime_error("hgx_liftover_wire_blob: null argument");
+    *bytes = liftoverPlanWireBlob(p, d_dst, capacity, first_query, format, hip_stream);
+    return HGX_OK;
+    HGX_CATCH
+}
+
 int hgx_liftover_kernel_times(hgx_liftover_plan *p, char **json) {
     if (!p || !json)
         return HGX_ERR;

@@ -787,4 +787,42 @@ static __global__ void __launch_bounds__(256) k_pack_records(const hgx_record *_
     }
 }
 
+// hgx_record (40 B) -> the 12-byte wire form: tgt_start, src_start (uint32) and (tgt_end - tgt_start) | tgt_seq << 22 |
+// strand code << 29 | tgt_reversed << 31; the query index is not sent, a uint16 record count per interval is
+// (k_wire12_counts).  *bad is set when a field does not fit (the caller then sends the 20-byte form).
+static __global__ void __launch_bounds__(256) k_wire12_records(const hgx_record *__restrict__ in, uint32_t n, uint32_t *__restrict__ out,
+                                                               unsigned int *bad) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const hgx_record r = in[i];
+        const int64_t len = r.tgt_end - r.tgt_start;
+        const uint32_t sc = r.strand == '+' ? 0u : r.strand == '-' ? 1u : r.strand == '.' ? 2u : 3u;
+        if (len < 0 || len >= (1 << 22) || (uint64_t)r.tgt_start >> 32 || (uint64_t)r.src_start >> 32 || (uint32_t)r.tgt_seq >= 128u || sc == 3u ||
+            r.tgt_reversed > 1)
+            *bad = 1;
+        uint32_t *o = out + (size_t)i * 3;
+        o[0] = (uint32_t)r.tgt_start;
+        o[1] = (uint32_t)r.src_start;
+        o[2] = (uint32_t)len | ((uint32_t)r.tgt_seq << 22) | (sc << 29) | ((uint32_t)r.tgt_reversed << 31);
+    }
+}
+static __global__ void __launch_bounds__(256) k_wire12_counts(const uint32_t *__restrict__ nOut, uint32_t nq, uint32_t nqPadded,
+                                                              uint16_t *__restrict__ out, unsigned int *bad) {
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nqPadded; q += gridDim.x * blockDim.x) {
+        const uint32_t c = q < nq ? nOut[q] : 0u; // (the padding up to a multiple of 8 bytes is zero)
+        if (c >> 16)
+            *bad = 1;
+        out[q] = (uint16_t)c;
+    }
+}
+struct WireHeader { // include/hgx.h: hgx_liftover_wire_blob
+    char magic[4];
+    uint32_t format;
+    int64_t firstQuery;
+    uint64_t nq, nrec;
+};
+static_assert(sizeof(WireHeader) == 32, "blob header");
+static __global__ void k_wire_header(WireHeader h, WireHeader *out) {
+    *out = h;
+}
+
 } // namespace hgx

@@ -458,12 +458,16 @@ struct hgx_liftover_plan {
     DevBuf fr[6][6], mp[2][6], counters, perQuery, offset, cursor, nOut, outOffset, blockSums, total, grouped, outRecords,
         deferredList, needCap, bigSlot, scratch, bigRecords, classLists, classCounts;
     KernelTimer timer;
+    DevBuf wireFlag;                      // hgx_liftover_wire_blob: "a field does not fit the 12-byte form"
+    unsigned int *wireFlagHost = nullptr;
     unsigned long long *pinned = nullptr; // host-pinned copy of the counter block + the record total (one readback per run)
     hgx_liftover_stats stats{};
     hipEvent_t evStart = nullptr, evWalk = nullptr, evEnd = nullptr;
     ~hgx_liftover_plan() {
         if (pinned)
             (void)hipHostFree(pinned);
+        if (wireFlagHost)
+            (void)hipHostFree(wireFlagHost);
         if (evStart)
             (void)hipEventDestroy(evStart);
         if (evWalk)
@@ -1284,6 +1288,56 @@ void liftoverPlanCopyRecordsPacked(const hgx_liftover_plan *p, void *dDst, size_
         hipLaunchKernelGGL(k_pack_records, dim3(GRID), dim3(256), 0, (hipStream_t)stream, (const hgx_record *)p->outRecords.p, (uint32_t)nRecords,
                            (int32_t *)dDst);
     HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+}
+
+// The last run's records as one self-describing blob for the multi-GPU exchange (include/hgx.h: hgx_liftover_wire_blob).
+size_t liftoverPlanWireBlob(hgx_liftover_plan *p, void *dDst, size_t capacity, int64_t firstQuery, int *format, void *stream) {
+    HIP_OK(hipSetDevice(p->device));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t nrec = (size_t)p->stats.records, nq = (size_t)p->stats.queries;
+    const size_t countsBytes = (2 * nq + 7) & ~(size_t)7;
+    const size_t need12 = 32 + countsBytes + 12 * nrec, need20 = 32 + 20 * nrec, need40 = 32 + sizeof(hgx_record) * nrec;
+    // the 20-byte form holds 31-bit coordinates and a 16-bit sequence index; beyond that the records travel as they are
+    const Image &img = p->h->img;
+    const bool fits20 = img.genomes[(size_t)p->src].totalLength < ((int64_t)1 << 31) && img.genomes[(size_t)p->tgt].totalLength < ((int64_t)1 << 31) &&
+                        img.genomes[(size_t)p->tgt].seqs.size() <= ((size_t)1 << 16);
+    const char *forced = getenv("HGX_WIRE_FORMAT"); // tests: the wider forms on data that would fit the narrow one
+    const size_t needFallback = (fits20 && !(forced && forced[0] == '4')) ? need20 : need40;
+    if (!dDst)
+        return std::max(need12, needFallback); // capacity query
+    if (capacity < std::max(need12, needFallback))
+        throw std::runtime_error("hgx_liftover_wire_blob: destination too small");
+    unsigned char *dst = (unsigned char *)dDst;
+    int fmt = 12;
+    {
+        p->wireFlag.ensure(4);
+        if (!p->wireFlagHost)
+            HIP_OK(hipHostMalloc((void **)&p->wireFlagHost, 4));
+        HIP_OK(hipMemsetAsync(p->wireFlag.p, 0, 4, s));
+        if (nq)
+            hipLaunchKernelGGL(k_wire12_counts, dim3(GRID), dim3(256), 0, s, (const uint32_t *)p->nOut.p, (uint32_t)nq, (uint32_t)(countsBytes / 2),
+                               (uint16_t *)(dst + 32), (unsigned int *)p->wireFlag.p);
+        if (nrec)
+            hipLaunchKernelGGL(k_wire12_records, dim3(GRID), dim3(256), 0, s, (const hgx_record *)p->outRecords.p, (uint32_t)nrec,
+                               (uint32_t *)(dst + 32 + countsBytes), (unsigned int *)p->wireFlag.p);
+        HIP_OK(hipMemcpyAsync(p->wireFlagHost, p->wireFlag.p, 4, hipMemcpyDeviceToHost, s));
+        HIP_OK(hipStreamSynchronize(s)); // the one synchronisation of the call: does the narrow form hold this batch?
+        if (*p->wireFlagHost)
+            fmt = fits20 ? 20 : 40;
+    }
+    if (forced && forced[0] == '4')
+        fmt = 40;
+    else if (forced && forced[0] == '2' && fits20)
+        fmt = 20;
+    if (fmt == 20 && nrec)
+        hipLaunchKernelGGL(k_pack_records, dim3(GRID), dim3(256), 0, s, (const hgx_record *)p->outRecords.p, (uint32_t)nrec, (int32_t *)(dst + 32));
+    if (fmt == 40 && nrec)
+        HIP_OK(hipMemcpyAsync(dst + 32, p->outRecords.p, sizeof(hgx_record) * nrec, hipMemcpyDeviceToDevice, s));
+    const WireHeader header = {{'H', 'G', 'X', 'W'}, (uint32_t)fmt, firstQuery, (uint64_t)nq, (uint64_t)nrec};
+    hipLaunchKernelGGL(k_wire_header, dim3(1), dim3(1), 0, s, header, (WireHeader *)dst); // (stream ordered: no further wait)
+    if (format)
+        *format = fmt;
+    return fmt == 12 ? need12 : fmt == 20 ? need20 : need40;
 }
 
 std::string liftoverPlanKernelTimes(hgx_liftover_plan *p) {

@@ -18,6 +18,7 @@ std::string liftoverPlanKernelTimes(hgx_liftover_plan *p);
 void liftoverPlanSetTiming(hgx_liftover_plan *p, int mode);
 void liftoverPlanCopyRecords(const hgx_liftover_plan *p, void *dDst, size_t nRecords, void *stream);
 void liftoverPlanCopyRecordsPacked(const hgx_liftover_plan *p, void *dDst, size_t nRecords, void *stream);
+size_t liftoverPlanWireBlob(hgx_liftover_plan *p, void *dDst, size_t capacity, int64_t firstQuery, int *format, void *stream);
 void liftoverBatchHost(hgx_alignment *h, int src, int tgt, size_t n, const hgx_interval *iv, const hgx_liftover_opts &opts,
                        std::vector<hgx_record> &out, hgx_liftover_stats *stats);
 // same, the records copied from the device straight into the memory alloc(n) returns

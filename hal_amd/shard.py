@@ -95,6 +95,86 @@ def unpack_records(packed):
     return out.view(torch.uint8).view(n, RECORD_BYTES)
 
 
+# ---- self-describing wire blobs (include/hgx.h: hgx_liftover_wire_blob) ------------------------------------------------
+BLOB_HEADER = 32
+_STRAND_CODES = (ord("+"), ord("-"), ord("."))
+
+
+def _header(fmt, first_query, nq, nrec):
+    import struct
+    return torch.frombuffer(bytearray(struct.pack("<4sIqQQ", b"HGXW", fmt, first_query, nq, nrec)), dtype=torch.uint8)
+
+
+def encode_blob(recs, num_queries, first_query=0, fmt=None):
+    """Reference encoder (torch ops, any device) of what hgx_liftover_wire_blob writes: recs uint8 [n, 40] hgx_record
+    rows grouped by query (query index relative to the shard), num_queries intervals in the batch.  fmt None picks 12
+    when every field fits, else 20 (the caller knows whether 31 bits hold its coordinates; 40 = raw rows)."""
+    n = recs.shape[0]
+    dev = recs.device
+    r64 = recs.contiguous().view(torch.int64).view(n, 5)
+    q, ts, te, ss, tail = r64[:, 0], r64[:, 1], r64[:, 2], r64[:, 3], r64[:, 4]
+    seq, strand, rev = tail & 0xFFFFFFFF, (tail >> 32) & 0xFF, (tail >> 40) & 0xFF
+    counts = torch.bincount(q, minlength=num_queries) if n else torch.zeros(num_queries, dtype=torch.int64, device=dev)
+    code = torch.full_like(strand, 3)
+    for k, ch in enumerate(_STRAND_CODES):
+        code = torch.where(strand == ch, torch.full_like(code, k), code)
+    fits = bool(n == 0 or (((te - ts) >= 0) & ((te - ts) < (1 << 22)) & (ts >= 0) & (ts < (1 << 32)) & (ss >= 0) & (ss < (1 << 32)) &
+                           (seq < 128) & (code < 3) & (rev <= 1)).all()) and bool(num_queries == 0 or (counts < 65536).all())
+    if fmt is None:
+        fmt = 12 if fits else 20
+    if fmt == 12:
+        assert fits, "fields do not fit the 12-byte form"
+        c16 = torch.zeros((2 * num_queries + 7) // 8 * 4, dtype=torch.int16, device=dev)
+        c16[:num_queries] = counts.to(torch.int32).to(torch.int16)  # (uint16 bit pattern)
+        w = torch.empty((n, 3), dtype=torch.int64, device=dev)
+        w[:, 0], w[:, 1] = ts, ss
+        w[:, 2] = (te - ts) | (seq << 22) | (code << 29) | (rev << 31)
+        body = torch.cat([c16.view(torch.uint8), (w & 0xFFFFFFFF).to(torch.int32).view(torch.uint8).view(-1) if n else
+                          torch.empty(0, dtype=torch.uint8, device=dev)])
+    elif fmt == 20:
+        body = pack_records(recs).view(-1)
+    else:
+        body = recs.contiguous().view(-1)
+    return torch.cat([_header(fmt, first_query, num_queries, n).to(dev), body])
+
+
+def decode_blob(blob):
+    """blob (uint8, any device) -> (records uint8 [n, 40] with GLOBAL query indices, first_query, num_queries)."""
+    import struct
+    magic, fmt, first_query, nq, nrec = struct.unpack("<4sIqQQ", bytes(blob[:BLOB_HEADER].cpu().numpy()))
+    if magic != b"HGXW":
+        raise ValueError("not a wire blob")
+    dev = blob.device
+    body = blob[BLOB_HEADER:]
+    if fmt == 20:
+        recs = unpack_records(body[:PACKED_BYTES * nrec].view(nrec, PACKED_BYTES))
+        return offset_query_index(recs, first_query), first_query, nq
+    if fmt == 40:
+        recs = body[:RECORD_BYTES * nrec].view(nrec, RECORD_BYTES).clone()
+        return offset_query_index(recs, first_query), first_query, nq
+    if fmt != 12:
+        raise ValueError("unknown wire format %d" % fmt)
+    cbytes = (2 * nq + 7) // 8 * 8
+    counts = body[:2 * nq].contiguous().view(torch.int16).to(torch.int64) & 0xFFFF
+    w = (body[cbytes:cbytes + 12 * nrec].contiguous().view(torch.int32).view(nrec, 3).to(torch.int64)) & 0xFFFFFFFF
+    out = torch.zeros((nrec, 5), dtype=torch.int64, device=dev)
+    out[:, 0] = torch.repeat_interleave(torch.arange(nq, dtype=torch.int64, device=dev), counts) + first_query
+    out[:, 1] = w[:, 0]
+    out[:, 2] = w[:, 0] + (w[:, 2] & ((1 << 22) - 1))
+    out[:, 3] = w[:, 1]
+    code = (w[:, 2] >> 29) & 3
+    strand = torch.tensor(_STRAND_CODES, dtype=torch.int64, device=dev)[code.clamp(max=2)]
+    out[:, 4] = ((w[:, 2] >> 22) & 127) | (strand << 32) | (((w[:, 2] >> 31) & 1) << 40)
+    return out.view(torch.uint8).view(nrec, RECORD_BYTES), first_query, nq
+
+
+def split_blobs(gathered, counts):
+    """The padded all-gather buffer of RecordCollator.wait(trim=False) -> the ranks' blobs."""
+    world = len(counts)
+    mx = gathered.numel() // world if world else 0
+    return [gathered.reshape(world, mx)[r, :counts[r]] for r in range(world)]
+
+
 class RecordCollator:
     """The all-gatherv of one batch overlapped with the mapping of the next: submit() exchanges the counts (a few bytes,
     synchronous) and starts the payload all-gather asynchronously on the communicator's own stream; wait() returns the
@@ -106,7 +186,9 @@ class RecordCollator:
     def submit(self, recs):
         world = dist.get_world_size()
         dev = recs.device
-        width = recs.shape[1]  # 40 (hgx_record) or 20 (pack_records)
+        if recs.dim() == 1:  # a wire blob: rows of one byte
+            recs = recs.view(-1, 1)
+        width = recs.shape[1]  # 40 (hgx_record), 20 (pack_records) or 1 (blob bytes)
         counts = all_gather_counts(recs.shape[0], dev)
         mx = max(counts) if counts else 0
         mine = recs
@@ -131,8 +213,8 @@ class RecordCollator:
         work, out, bufs, _mine, counts, mx, width = self._pending
         self._pending = None
         work.wait()
+        if not trim:
+            return (out if bufs is None else torch.cat(bufs, dim=0)), counts
         if bufs is None:
-            if not trim:
-                return out, counts
             bufs = list(out.view(len(counts), mx, width).unbind(0))
         return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0), counts

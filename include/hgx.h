@@ -169,6 +169,21 @@ int hgx_liftover_copy_records(const hgx_liftover_plan *p, void *d_dst, size_t n_
  * target genome has fewer than 65536 sequences (the caller checks: hal_amd.shard.can_pack). */
 int hgx_liftover_copy_records_packed(const hgx_liftover_plan *p, void *d_dst, size_t n_records, void *hip_stream, char **err);
 
+/* The last run's records as one self-describing blob for the all-gatherv of the multi-GPU path (hal_amd/shard.py decodes
+ * it): a 32-byte header {"HGXW", uint32 format, int64 first_query, uint64 n_queries, uint64 n_records} and then
+ *   format 12: uint16 record count per interval (padded to 8 bytes), then 12 bytes per record — tgt_start and src_start
+ *              as uint32, (tgt_end - tgt_start) | tgt_seq << 22 | strand code << 29 | tgt_reversed << 31 (strand code
+ *              0 '+', 1 '-', 2 '.'); the query index follows from the counts and first_query;
+ *   format 20: the records of hgx_liftover_copy_records_packed (query relative to first_query);
+ *   format 40: hgx_record rows as they are (query relative to first_query).
+ * Format 12 is used when every field fits (lengths < 2^22, positions < 2^32, < 128 target sequences, < 65536 records per
+ * interval), which the call checks on the device; otherwise format 20 when both genomes are shorter than 2^31 bases and
+ * the target has at most 65536 sequences, else format 40.  With d_dst == NULL only *bytes is set, to the
+ * capacity a destination needs; otherwise *bytes is what was written and *format which form.  first_query: global index of
+ * the batch's first interval (what shard_bounds gave this rank). */
+int hgx_liftover_wire_blob(hgx_liftover_plan *p, void *d_dst, size_t capacity, int64_t first_query, size_t *bytes, int *format,
+                           void *hip_stream, char **err);
+
 /* Text-level drop-in for Liftover::convert (liftover/inc/halLiftover.h:25-28): BED text in, BED text
  * out, byte-identical to halLiftover for BED3..BED9 (+ extra columns).  bed_type 0 = auto
  * (halBedLine.cpp:36-38).  *out_text is released with hgx_free. */

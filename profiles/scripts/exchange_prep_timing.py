@@ -1,9 +1,12 @@
-"""What a rank does per step besides mapping when N > 1 (measurable on one GPU): copy the records out of the plan and
-pack them to the 20-byte wire form."""
-import sys, time
+"""Host-side cost of the exchange step on one GPU (one-rank RCCL group): the wire blob, the count exchange, the payload
+all-gather, against the bare run."""
+import os, sys, time
 sys.path.insert(0, '.')
-import torch, hal_amd, bench
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29519")
+os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+import torch, torch.distributed as dist, hal_amd, bench
 from hal_amd import shard
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
 al = hal_amd.Alignment.random(bench.workload_options(1.0), device=0)
 src, tgt = al.genome_id("Genome_9"), al.genome_id("Genome_2")
 _, ss, length = al.sequences(src)[0]
@@ -11,14 +14,23 @@ n = 1000000
 starts, lens, strand = bench.make_queries(length, n, 1234)
 gs = (starts + ss).cuda(); ge = (starts + lens - 1 + ss).cuda(); st = strand.cuda()
 plan = hal_amd.LiftoverPlan(al, src, tgt, max_queries=n)
-for _ in range(5):
+for _ in range(12):
     ptr, nrec = plan.run(gs, ge, st)
-def t(f, k=20):
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(k):
-        r = f()
-    torch.cuda.synchronize(); return (time.perf_counter() - t0) / k * 1e3, r
-ms_copy, recs = t(lambda: plan.records_to_tensor(ptr, nrec))
-ms_pack, packed = t(lambda: shard.pack_records(recs), 3)
-ms_kpack, kp = t(lambda: plan.records_to_tensor(ptr, nrec, packed=True))
-print("records %d: records_to_tensor %.3f ms, torch pack_records %.3f ms, packed copy by the library %.3f ms (%d -> %d MB)" % (nrec, ms_copy, ms_pack, ms_kpack, recs.numel() >> 20, packed.numel() >> 20))
+col = shard.RecordCollator()
+def timed(f, reps=20):
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(reps):
+        f()
+    torch.cuda.synchronize(); return (time.perf_counter() - t) / reps * 1e3
+print("run                     %.3f ms" % timed(lambda: plan.run(gs, ge, st)))
+print("wire_blob               %.3f ms" % timed(lambda: plan.wire_blob(first_query=0)))
+blob, fmt = plan.wire_blob(first_query=0)
+print("all_gather_counts       %.3f ms" % timed(lambda: shard.all_gather_counts(blob.numel(), blob.device)))
+def ex():
+    col.wait(trim=False); col.submit(blob)
+print("collator wait+submit    %.3f ms  (%d bytes, format %d)" % (timed(ex), blob.numel(), fmt))
+def step():
+    plan.run(gs, ge, st); b, _ = plan.wire_blob(first_query=0); col.wait(trim=False); col.submit(b)
+print("whole step              %.3f ms" % timed(step))
+col.wait()
+dist.destroy_process_group()

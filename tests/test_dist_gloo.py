@@ -10,8 +10,8 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 
-from hal_amd.shard import (RecordCollator, all_gather_records, can_pack, offset_query_index, pack_records, shard_bounds,
-                           unpack_records)
+from hal_amd.shard import (RecordCollator, all_gather_records, can_pack, decode_blob, encode_blob, offset_query_index, pack_records,
+                           shard_bounds, split_blobs, unpack_records)
 
 
 def fake_lift(q_lo, q_hi, base=0):
@@ -41,6 +41,46 @@ def _real_records(n, seed):
     r["strand"] = rng.choice([b"+", b"-", b"."], n)
     r["tgt_reversed"] = rng.integers(0, 2, n)
     return torch.from_numpy(r.view(np.uint8).reshape(n, 40).copy())
+
+
+def _batch_records(nq, seed, wide=False):
+    """records of one batch as a plan returns them: grouped by interval, shard-relative query index, lengths and sequence
+    indices inside the 12-byte form unless wide"""
+    rng = np.random.default_rng(seed)
+    counts = rng.integers(0, 6, nq)
+    counts[rng.integers(0, nq)] = 300  # one interval with many records
+    n = int(counts.sum())
+    dt = np.dtype([("query", "<i8"), ("tgt_start", "<i8"), ("tgt_end", "<i8"), ("src_start", "<i8"), ("tgt_seq", "<i4"), ("strand", "S1"),
+                   ("tgt_reversed", "u1"), ("_pad", "S2")])
+    r = np.zeros(n, dtype=dt)
+    r["query"] = np.repeat(np.arange(nq), counts)
+    top = 2 ** 31 - 2 ** 23 if not wide else 2 ** 40
+    r["tgt_start"] = rng.integers(0, top, n)
+    r["tgt_end"] = r["tgt_start"] + rng.integers(1, 2 ** 22 if not wide else 2 ** 24, n)
+    r["tgt_end"][0] = r["tgt_start"][0] + (2 ** 22 - 1 if not wide else 2 ** 22)  # the longest length that fits / the first that does not
+    r["src_start"] = rng.integers(0, top, n)
+    r["tgt_seq"] = rng.integers(0, 128, n)
+    r["strand"] = rng.choice([b"+", b"-", b"."], n)
+    r["tgt_reversed"] = rng.integers(0, 2, n)
+    return torch.from_numpy(r.view(np.uint8).reshape(n, 40).copy()), n
+
+
+def test_wire_blob_roundtrip_and_format_choice():
+    recs, n = _batch_records(500, 3)
+    for fmt, per_record in ((None, 12), (12, 12), (20, 20), (40, 40)):
+        blob = encode_blob(recs, 500, first_query=12345, fmt=fmt)
+        assert blob.numel() == 32 + (1000 if per_record == 12 else 0) + per_record * n
+        out, first, nq = decode_blob(blob)
+        assert (first, nq) == (12345, 500) and torch.equal(out, offset_query_index(recs.clone(), 12345))
+    wide, n = _batch_records(100, 4, wide=True)
+    blob = encode_blob(wide, 100, first_query=7)  # a length of 2^22 does not fit: the encoder falls back
+    assert blob[4] == 20
+    raw = encode_blob(wide, 100, first_query=7, fmt=40)  # (coordinates beyond 31 bits: only the raw form is exact)
+    assert torch.equal(decode_blob(raw)[0], offset_query_index(wide.clone(), 7))
+    empty = encode_blob(torch.zeros((0, 40), dtype=torch.uint8), 0)
+    assert empty.numel() == 32 and decode_blob(empty)[0].shape == (0, 40)
+    none = encode_blob(torch.zeros((0, 40), dtype=torch.uint8), 9, first_query=3)  # intervals without records
+    assert decode_blob(none)[0].shape == (0, 40) and decode_blob(none)[1:] == (3, 9)
 
 
 def test_pack_roundtrip_and_limits():
@@ -75,6 +115,14 @@ def _worker(rank, world, port, n, result):
     back = unpack_records(packed)
     expect = torch.cat([_real_records(200 + 50 * r, r) for r in range(world)], dim=0)
     ok = ok and packed.shape[1] == 20 and pcounts == [200 + 50 * r for r in range(world)] and bool(torch.equal(back, expect))
+    # self-describing blobs of different formats and sizes through the same exchange
+    nq = 300 + 20 * rank
+    mine, _ = _batch_records(nq, 10 + rank)
+    col.submit(encode_blob(mine, nq, first_query=1000 * rank, fmt=12 if rank == 0 else 20))
+    gathered, sizes = col.wait(trim=False)
+    decoded = torch.cat([decode_blob(b)[0] for b in split_blobs(gathered, sizes)], dim=0)
+    expect = torch.cat([offset_query_index(_batch_records(300 + 20 * r, 10 + r)[0], 1000 * r) for r in range(world)], dim=0)
+    ok = ok and bool(torch.equal(decoded, expect))
     result[rank] = ok
     dist.barrier()
     dist.destroy_process_group()

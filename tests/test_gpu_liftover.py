@@ -344,3 +344,31 @@ def test_packed_wire_records_on_device(hal, tmp_path):
     assert torch.equal(shard.unpack_records(packed), recs)
     # the library's own kernel writes the same bytes
     assert torch.equal(plan.records_to_tensor(ptr, nrec, packed=True), packed)
+
+
+@pytest.mark.parametrize("forced", [None, "20", "40"])
+def test_wire_blob_matches_the_reference_encoder(hal, tmp_path, monkeypatch, forced):
+    """hgx_liftover_wire_blob (device kernels) writes byte for byte what hal_amd.shard.encode_blob builds from the plan's
+    records, in every format, and decode_blob gives the records back with global query indices."""
+    import torch
+    from hal_amd import shard
+    if forced:
+        monkeypatch.setenv("HGX_WIRE_FORMAT", forced)
+    al, _ = _rand_alignment(hal, tmp_path, 5)
+    src, tgt = al.genome_id("Genome_3"), al.genome_id("Genome_1")
+    _, ss, length = al.sequences(src)[0]
+    n = 777
+    g = torch.Generator().manual_seed(3)
+    starts = torch.randint(0, length - 300, (n,), generator=g)
+    lens = torch.randint(1, 300, (n,), generator=g)
+    strand = torch.tensor([ord(c) for c in "+-."], dtype=torch.uint8)[torch.randint(0, 3, (n,), generator=g)]
+    plan = hal.LiftoverPlan(al, src, tgt, max_queries=n)
+    ptr, nrec = plan.run((starts + ss).cuda(), (starts + lens - 1 + ss).cuda(), strand.cuda())
+    assert nrec > n // 2
+    recs = plan.records_to_tensor(ptr, nrec)
+    blob, fmt = plan.wire_blob(first_query=5000)
+    assert fmt == int(forced or 12)
+    assert torch.equal(blob.cpu(), shard.encode_blob(recs.cpu(), n, first_query=5000, fmt=fmt))
+    out, first, nq = shard.decode_blob(blob)
+    assert (first, nq) == (5000, n) and torch.equal(out, shard.offset_query_index(recs.clone(), 5000))
+    assert blob.numel() == 32 + (((2 * n + 7) // 8 * 8 + 12 * nrec) if fmt == 12 else fmt * nrec)
