@@ -150,9 +150,10 @@ def main():
         ptr, nrec = plan.run(d_gs, d_ge, d_st)
         if exchanging:
             # the one exchange step of the path: all-gatherv of the batch's records (hal_amd/shard.py) as a self-describing
-            # blob, 12 bytes per record + 2 per interval when every field fits (hgx_liftover_wire_blob).  The payload exchange
-            # of this batch runs on RCCL's stream while the next batch is mapped; the previous batch's exchange is completed
-            # first, so every timed step pays for one whole exchange.
+            # blob, 12 bytes per record + 2 per interval when every field fits (hgx_liftover_wire_blob).  RecordCollator
+            # exchanges this batch's sizes now and its payload during the next step, on RCCL's stream, while the following
+            # batches are mapped; wait() completes the oldest exchange under way, so every timed step pays for one whole
+            # exchange and the host never waits for a collective in the steady state.
             blob, fmt = plan.wire_blob(first_query=rank * nq)
             wire["format"], wire["bytes"] = fmt, int(blob.numel())
             collator.wait(trim=False)
@@ -194,7 +195,7 @@ def main():
         walk_ms += st["walk_ms"]
         total_ms += st["total_ms"]
     if exchanging:
-        collator.wait(trim=False)  # the last exchange belongs to the timed region
+        collator.drain(trim=False)  # the exchanges still under way belong to the timed region
     torch.cuda.synchronize()
     if exchanging:
         dist.barrier()

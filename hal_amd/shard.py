@@ -176,23 +176,62 @@ def split_blobs(gathered, counts):
 
 
 class RecordCollator:
-    """The all-gatherv of one batch overlapped with the mapping of the next: submit() exchanges the counts (a few bytes,
-    synchronous) and starts the payload all-gather asynchronously on the communicator's own stream; wait() returns the
-    previous batch.  At most one exchange is in flight, its buffers are kept alive here until it has completed."""
+    """The all-gatherv of a stream of batches, overlapped with the mapping of the following ones and free of host waits in
+    the steady state.  submit(batch k) starts the exchange of the ranks' sizes for batch k and the payload all-gather of
+    batch k-1, whose sizes have arrived in the meantime; wait() hands out the oldest batch whose payload is in flight
+    (batch k-2 in a wait(); submit() loop) after making the current stream wait for it.  Buffers are kept alive here until
+    their exchange has completed.  drain() completes everything that was submitted."""
 
     def __init__(self):
-        self._pending = None
+        self._staged = None   # sizes under way, payload not yet started
+        self._inflight = []   # payload all-gathers, oldest first
+        self._slots = None    # reusable (size, sizes, pinned host copy, event) sets: allocating them per batch costs more
+        self._turn = 0        # host time than the collective itself
 
-    def submit(self, recs):
+    # -- stage A: the sizes --------------------------------------------------------------------------------------------
+    def submit(self, recs, backing=None):
+        """recs: uint8 [n, width] rows or a 1-D blob.  backing: the allocation recs is a prefix of (wire_blob's), sent
+        without a padding copy when it is long enough for the largest rank."""
         world = dist.get_world_size()
         dev = recs.device
         if recs.dim() == 1:  # a wire blob: rows of one byte
+            if backing is None and recs._base is not None and recs._base.dim() == 1 and recs._base.dtype == torch.uint8:
+                backing = recs._base  # LiftoverPlan.wire_blob returns a prefix of a larger allocation
             recs = recs.view(-1, 1)
         width = recs.shape[1]  # 40 (hgx_record), 20 (pack_records) or 1 (blob bytes)
-        counts = all_gather_counts(recs.shape[0], dev)
+        stage = {"recs": recs, "backing": backing, "width": width, "world": world}
+        if dev.type == "cuda":
+            if self._slots is None:  # three sets: one staged, one being read by _launch, one free
+                self._slots = [(torch.zeros(1, dtype=torch.int64, device=dev), torch.empty(world, dtype=torch.int64, device=dev),
+                                torch.empty(world, dtype=torch.int64, pin_memory=True), torch.cuda.Event()) for _ in range(3)]
+            size, sizes, host, ev = self._slots[self._turn % 3]
+            self._turn += 1
+            size.fill_(recs.shape[0])
+            dist.all_gather_into_tensor(sizes, size)  # stream ordered; the host does not wait
+            host.copy_(sizes, non_blocking=True)
+            ev.record()
+            stage.update(host=host, event=ev)
+        else:
+            stage["counts"] = all_gather_counts(recs.shape[0], dev)
+        previous, self._staged = self._staged, stage
+        if previous is not None:
+            self._launch(previous)
+
+    # -- stage B: the payload ------------------------------------------------------------------------------------------
+    def _launch(self, stage):
+        recs, width, world = stage["recs"], stage["width"], stage["world"]
+        dev = recs.device
+        if "counts" not in stage:
+            stage["event"].synchronize()  # recorded one batch ago
+            stage["counts"] = [int(c) for c in stage["host"].tolist()]
+        counts = stage["counts"]
         mx = max(counts) if counts else 0
-        mine = recs
-        if recs.shape[0] != mx:
+        backing = stage["backing"]
+        if recs.shape[0] == mx:
+            mine = recs
+        elif backing is not None and width == 1 and backing.numel() >= mx and backing.data_ptr() == recs.data_ptr():
+            mine = backing[:mx].view(-1, 1)  # bytes after the blob are padding nobody reads
+        else:
             mine = torch.zeros((mx, width), dtype=torch.uint8, device=dev)
             mine[:recs.shape[0]] = recs
         mine = mine.contiguous()
@@ -204,17 +243,30 @@ class RecordCollator:
             bufs = [torch.empty((mx, width), dtype=torch.uint8) for _ in range(world)]
             work = dist.all_gather(bufs, mine, async_op=True)
             out = None
-        self._pending = (work, out, bufs, mine, counts, mx, width)
+        self._inflight.append((work, out, bufs, (mine, recs, backing), counts, mx, width))
 
-    def wait(self, trim=True):
-        """(records, counts) of the submitted batch, or None when nothing is in flight."""
-        if self._pending is None:
-            return None
-        work, out, bufs, _mine, counts, mx, width = self._pending
-        self._pending = None
+    def wait(self, trim=True, flush=False):
+        """(records, counts) of the oldest batch whose payload exchange is under way, or None when there is none.
+        flush: also start (and complete) the exchange of a batch whose sizes only have been exchanged so far — the last
+        batch of a stream, or the only one."""
+        if not self._inflight:
+            if self._staged is None or not flush:
+                return None
+            staged, self._staged = self._staged, None
+            self._launch(staged)
+        work, out, bufs, _keep, counts, mx, width = self._inflight.pop(0)
         work.wait()
         if not trim:
             return (out if bufs is None else torch.cat(bufs, dim=0)), counts
         if bufs is None:
             bufs = list(out.view(len(counts), mx, width).unbind(0))
         return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0), counts
+
+    def drain(self, trim=True):
+        """complete every submitted exchange; returns the batches in submission order"""
+        done = []
+        while True:
+            r = self.wait(trim=trim, flush=True)
+            if r is None:
+                return done
+            done.append(r)

@@ -32,5 +32,5 @@ print("collator wait+submit    %.3f ms  (%d bytes, format %d)" % (timed(ex), blo
 def step():
     plan.run(gs, ge, st); b, _ = plan.wire_blob(first_query=0); col.wait(trim=False); col.submit(b)
 print("whole step              %.3f ms" % timed(step))
-col.wait()
+col.drain()
 dist.destroy_process_group()

@@ -102,16 +102,16 @@ def _worker(rank, world, port, n, result):
     col = RecordCollator()
     assert col.wait() is None
     col.submit(offset_query_index(fake_lift(lo, hi, base=lo), lo))
-    first = col.wait()
+    first = col.wait(flush=True)
     col.submit(fake_lift(0, 3 + rank))
-    second = col.wait()
+    second = col.wait(flush=True)
     ok = ok and bool(torch.equal(first[0], want)) and first[1] == counts
     ok = ok and second[1] == [fake_lift(0, 3 + r).shape[0] for r in range(world)]
     ok = ok and bool(torch.equal(second[0], torch.cat([fake_lift(0, 3 + r) for r in range(world)], dim=0)))
     # the 20-byte wire form through the same exchange
     mine = _real_records(200 + 50 * rank, rank)
     col.submit(pack_records(mine))
-    packed, pcounts = col.wait()
+    packed, pcounts = col.wait(flush=True)
     back = unpack_records(packed)
     expect = torch.cat([_real_records(200 + 50 * r, r) for r in range(world)], dim=0)
     ok = ok and packed.shape[1] == 20 and pcounts == [200 + 50 * r for r in range(world)] and bool(torch.equal(back, expect))
@@ -119,10 +119,32 @@ def _worker(rank, world, port, n, result):
     nq = 300 + 20 * rank
     mine, _ = _batch_records(nq, 10 + rank)
     col.submit(encode_blob(mine, nq, first_query=1000 * rank, fmt=12 if rank == 0 else 20))
-    gathered, sizes = col.wait(trim=False)
+    gathered, sizes = col.wait(trim=False, flush=True)
     decoded = torch.cat([decode_blob(b)[0] for b in split_blobs(gathered, sizes)], dim=0)
     expect = torch.cat([offset_query_index(_batch_records(300 + 20 * r, 10 + r)[0], 1000 * r) for r in range(world)], dim=0)
     ok = ok and bool(torch.equal(decoded, expect))
+    # a stream of batches the way bench.py drives it: wait(); submit() per step, drain() at the end — the payload of a
+    # batch starts one submit later, nothing is lost or reordered, and a blob that is a prefix of a larger allocation
+    # travels without a padding copy
+    stream = RecordCollator()
+    got = []
+    for k in range(5):
+        r = stream.wait(trim=False)
+        if r is not None:
+            got.append(r)
+        nqk = 40 + 7 * k + 3 * rank
+        blob = encode_blob(_batch_records(nqk, 100 + 10 * k + rank)[0], nqk, first_query=10000 * k + 100 * rank)
+        room = torch.zeros(blob.numel() * 3, dtype=torch.uint8)
+        room[:blob.numel()] = blob
+        stream.submit(room[:blob.numel()])
+    assert len(got) == 3  # (batch k-2 comes out in step k)
+    got += stream.drain(trim=False)
+    ok = ok and len(got) == 5 and stream.wait() is None
+    for k, (gathered, sizes) in enumerate(got):
+        decoded = torch.cat([decode_blob(b)[0] for b in split_blobs(gathered, sizes)], dim=0)
+        expect = torch.cat([offset_query_index(_batch_records(40 + 7 * k + 3 * r, 100 + 10 * k + r)[0], 10000 * k + 100 * r)
+                            for r in range(world)], dim=0)
+        ok = ok and bool(torch.equal(decoded, expect))
     result[rank] = ok
     dist.barrier()
     dist.destroy_process_group()
