@@ -443,20 +443,79 @@ __device__ __forceinline__ void write_records(const FinishStore<C> &S, int nl, i
 // all intervals and handles the ones of its class.  Larger intervals, and any interval whose pieces overlap or
 // tie on the target (the cases that need overlap breaking / equivalence classes), are appended to `generalList`
 // for the general LDS kernel.
-// bitonic sort of one 64-bit key per lane inside aligned groups of G lanes (ascending), shuffles only
-template <int G> __device__ __forceinline__ unsigned long long group_sort(unsigned long long key, int li) {
-#pragma unroll
-    for (int k = 2; k <= G; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            const unsigned long long other = __shfl_xor(key, j);
-            const bool up = (li & k) == 0;
-            const bool lower = (li & j) == 0;
-            const bool takeMin = lower == up;
-            const unsigned long long mn = key < other ? key : other, mx = key < other ? other : key;
-            key = takeMin ? mn : mx;
-        }
+// Lane exchanges of the register-resident kernels.  ds_bpermute (what __shfl* compiles to) goes through the LDS crossbar;
+// the fixed patterns of a sorting network inside a quad or a row of 16 lanes, and the shift by one lane, are DPP modifiers
+// of an ordinary VALU move on gfx9-family parts: xor 1 / 2 / 3 = quad_perm, xor 7 = row_half_mirror, xor 15 = row_mirror,
+// previous lane = wave_shr:1.  k_finish_fast<C, 8> went from 53 ds_bpermute per iteration to 9 (with the narrower gathers
+// below) — and kept its 0.10 ms per 1 M intervals: the kernel is bound by the number of instructions its eight wavefronts
+// per SIMD issue (VALU 47 % busy plus scalar and LDS work, profiles/r01q_pmc.txt), not by the crossbar.
+template <int CTRL> __device__ __forceinline__ int dpp_move(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); // lanes without a source keep their own value
+}
+template <int CTRL> __device__ __forceinline__ unsigned long long dpp_move(unsigned long long v) {
+    const int lo = dpp_move<CTRL>((int)(uint32_t)v), hi = dpp_move<CTRL>((int)(uint32_t)(v >> 32));
+    return ((unsigned long long)(uint32_t)hi << 32) | (unsigned long long)(uint32_t)lo;
+}
+template <int CTRL> __device__ __forceinline__ int64_t dpp_move(int64_t v) {
+    return (int64_t)dpp_move<CTRL>((unsigned long long)v);
+}
+enum { DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_XOR3 = 0x1B, DPP_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140, DPP_WAVE_SHR1 = 0x138 };
+// value of lane ^ M
+template <int M> __device__ __forceinline__ unsigned long long lane_xor(unsigned long long v) {
+    if (M == 1)
+        return dpp_move<DPP_XOR1>(v);
+    if (M == 2)
+        return dpp_move<DPP_XOR2>(v);
+    if (M == 3)
+        return dpp_move<DPP_XOR3>(v);
+    if (M == 7)
+        return dpp_move<DPP_HALF_MIRROR>(v);
+    if (M == 15)
+        return dpp_move<DPP_ROW_MIRROR>(v);
+    return __shfl_xor(v, M);
+}
+// value of the previous lane (lane 0: its own)
+template <typename T> __device__ __forceinline__ T lane_prev(T v) {
+    return dpp_move<DPP_WAVE_SHR1>(v);
+}
+
+// a position (below 2^31 when C is int32) from another lane
+template <typename C> __device__ __forceinline__ int64_t shfl_pos(int64_t v, int srcLane) {
+    if (sizeof(C) == 4)
+        return (int64_t)__shfl((int)v, srcLane);
+    return __shfl(v, srcLane);
+}
+
+// one merge level of the sorting network: blocks of K lanes, each made of two ascending halves, become ascending.  The
+// first step compares lane i with lane i ^ (K - 1) (the mirror image inside the block), the others i with i ^ j.
+template <int K, int J> struct MergeSteps {
+    static __device__ __forceinline__ unsigned long long run(unsigned long long key, int li) {
+        const unsigned long long other = lane_xor<J>(key);
+        const unsigned long long mn = key < other ? key : other, mx = key < other ? other : key;
+        key = (li & J) == 0 ? mn : mx;
+        return MergeSteps<K, (J >> 1)>::run(key, li);
     }
+};
+template <int K> struct MergeSteps<K, 0> {
+    static __device__ __forceinline__ unsigned long long run(unsigned long long key, int) { return key; }
+};
+template <int K> __device__ __forceinline__ unsigned long long merge_level(unsigned long long key, int li) {
+    const unsigned long long other = lane_xor<K - 1>(key);
+    const unsigned long long mn = key < other ? key : other, mx = key < other ? other : key;
+    key = (li & (K >> 1)) == 0 ? mn : mx;
+    return MergeSteps<K, (K >> 2)>::run(key, li);
+}
+// sort of one 64-bit key per lane inside aligned groups of G lanes (ascending)
+template <int G> __device__ __forceinline__ unsigned long long group_sort(unsigned long long key, int li) {
+    key = merge_level<2>(key, li);
+    key = merge_level<4>(key, li);
+    key = merge_level<8>(key, li);
+    if (G >= 16)
+        key = merge_level<16>(key, li);
+    if (G >= 32)
+        key = merge_level<32>(key, li);
+    if (G >= 64)
+        key = merge_level<64>(key, li);
     return key;
 }
 
@@ -552,10 +611,12 @@ __global__ void __launch_bounds__(256) k_finish_fast(Mapped in, const uint32_t *
         key = group_sort<G>(key, li);
         const int srcLane = (int)(key & 63ull);
         const bool occ = key != INF; // sorted position li holds a piece
-        tLo = __shfl(tLo, srcLane);
-        tHi = __shfl(tHi, srcLane);
-        sLo = __shfl(sLo, srcLane);
-        sHi = __shfl(sHi, srcLane);
+        // the sorted key carries the target start; length, source start and flags come from the lane that loaded the piece
+        const int32_t len = __shfl((int32_t)(tHi - tLo + 1), srcLane);
+        tLo = (int64_t)(key >> 6);
+        tHi = tLo + len - 1;
+        sLo = shfl_pos<C>(sLo, srcLane);
+        sHi = sLo + len - 1;
         fl = (uint8_t)__shfl((int)fl, srcLane);
         int seq = 0;
         if (numSeq > 1 && occ) {
@@ -570,8 +631,8 @@ __global__ void __launch_bounds__(256) k_finish_fast(Mapped in, const uint32_t *
             seq = lo;
         }
         // 2. neighbour relations (previous piece in target order)
-        const int64_t pTHi = __shfl_up(tHi, 1), pSLo = __shfl_up(sLo, 1), pSHi = __shfl_up(sHi, 1);
-        const int pFl = __shfl_up((int)fl, 1), pSeq = __shfl_up(seq, 1);
+        const int64_t pTHi = lane_prev(tHi), pSLo = lane_prev(sLo), pSHi = lane_prev(sHi);
+        const int pFl = lane_prev((int)fl), pSeq = lane_prev(seq);
         const bool hasPrev = occ && li > 0;
         const bool complex_ = hasPrev && tLo <= pTHi; // overlap or tie: needs the general algorithm
         bool mergePrev = false;
@@ -598,15 +659,16 @@ __global__ void __launch_bounds__(256) k_finish_fast(Mapped in, const uint32_t *
             const int nextHead = above ? li + 1 + (__ffsll((long long)above) - 1) : n;
             back = nextHead - 1;
         }
-        const int64_t bTHi = __shfl(tHi, gbase + back), bSLo = __shfl(sLo, gbase + back);
+        const int64_t bTHi = shfl_pos<C>(tHi, gbase + back), bSLo = shfl_pos<C>(sLo, gbase + back);
         const int64_t lStart = tLo, lEnd = bTHi + 1, lSrc = sLo < bSLo ? sLo : bSLo;
         // 4. stable sort of the lines by source start
         unsigned long long lkey = (head && doGroup) ? (((unsigned long long)lSrc << 6) | (unsigned long long)lane) : INF;
         lkey = group_sort<G>(lkey, li);
         const int lLane = (int)(lkey & 63ull);
         const bool isLine = lkey != INF;
-        const int64_t oStart = __shfl(lStart, lLane), oEnd = __shfl(lEnd, lLane), oSrc = __shfl(lSrc, lLane);
-        const int oSeq = __shfl(seq, lLane), oFl = __shfl((int)fl, lLane);
+        const int64_t oStart = shfl_pos<C>(lStart, lLane), oEnd = shfl_pos<C>(lEnd, lLane);
+        const int64_t oSrc = (int64_t)(lkey >> 6); // (the sorted key carries the line's source start)
+        const int oSeq = numSeq > 1 ? __shfl(seq, lLane) : 0, oFl = __shfl((int)fl, lLane);
         if (isLine) {
             hgx_record r;
             const int64_t ss = seqStart[oSeq];
