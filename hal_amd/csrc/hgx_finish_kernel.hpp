@@ -596,34 +596,37 @@ __global__ void __launch_bounds__(256) k_finish_fast(Mapped in, const uint32_t *
         if (!__any(gvalid))
             continue; // nothing for this instantiation among this wavefront's candidates
         const bool have = li < n;
-        int64_t tLo = 0, tHi = 0, sLo = 0, sHi = 0;
+        // positions in the coordinate type of the alignment: 32-bit arithmetic when every genome is shorter than 2^31 bases
+        // (the kernel is bound by the instructions it issues, and every 64-bit add, compare or lane move is two)
+        typedef C P;
+        P tLo = 0, tHi = 0, sLo = 0, sHi = 0;
         uint8_t fl = 0;
         if (have) {
             const MappedRec r = in.rec[base + li];
-            tLo = r.tLo;
-            tHi = r.tLo + r.len - 1;
-            sLo = r.sLo;
-            sHi = r.sLo + r.len - 1;
+            tLo = (P)r.tLo;
+            tHi = (P)(r.tLo + r.len - 1);
+            sLo = (P)r.sLo;
+            sHi = (P)(r.sLo + r.len - 1);
             fl = (uint8_t)r.flags;
         }
         // 1. order by target start
-        unsigned long long key = have ? (((unsigned long long)tLo << 6) | (unsigned long long)lane) : INF;
+        unsigned long long key = have ? (((unsigned long long)(int64_t)tLo << 6) | (unsigned long long)lane) : INF;
         key = group_sort<G>(key, li);
         const int srcLane = (int)(key & 63ull);
         const bool occ = key != INF; // sorted position li holds a piece
         // the sorted key carries the target start; length, source start and flags come from the lane that loaded the piece
         const int32_t len = __shfl((int32_t)(tHi - tLo + 1), srcLane);
-        tLo = (int64_t)(key >> 6);
-        tHi = tLo + len - 1;
-        sLo = shfl_pos<C>(sLo, srcLane);
-        sHi = sLo + len - 1;
+        tLo = (P)(key >> 6);
+        tHi = (P)(tLo + len - 1);
+        sLo = (P)shfl_pos<C>((int64_t)sLo, srcLane);
+        sHi = (P)(sLo + len - 1);
         fl = (uint8_t)__shfl((int)fl, srcLane);
         int seq = 0;
         if (numSeq > 1 && occ) {
             int lo = 0, hi = numSeq;
             while (hi - lo > 1) {
                 const int mid = (lo + hi) >> 1;
-                if (seqStart[mid] <= tLo)
+                if (seqStart[mid] <= (int64_t)tLo)
                     lo = mid;
                 else
                     hi = mid;
@@ -631,7 +634,7 @@ __global__ void __launch_bounds__(256) k_finish_fast(Mapped in, const uint32_t *
             seq = lo;
         }
         // 2. neighbour relations (previous piece in target order)
-        const int64_t pTHi = lane_prev(tHi), pSLo = lane_prev(sLo), pSHi = lane_prev(sHi);
+        const P pTHi = lane_prev(tHi), pSLo = lane_prev(sLo), pSHi = lane_prev(sHi);
         const int pFl = lane_prev((int)fl), pSeq = lane_prev(seq);
         const bool hasPrev = occ && li > 0;
         const bool complex_ = hasPrev && tLo <= pTHi; // overlap or tie: needs the general algorithm
@@ -659,14 +662,15 @@ __global__ void __launch_bounds__(256) k_finish_fast(Mapped in, const uint32_t *
             const int nextHead = above ? li + 1 + (__ffsll((long long)above) - 1) : n;
             back = nextHead - 1;
         }
-        const int64_t bTHi = shfl_pos<C>(tHi, gbase + back), bSLo = shfl_pos<C>(sLo, gbase + back);
-        const int64_t lStart = tLo, lEnd = bTHi + 1, lSrc = sLo < bSLo ? sLo : bSLo;
+        const P bTHi = (P)shfl_pos<C>((int64_t)tHi, gbase + back), bSLo = (P)shfl_pos<C>((int64_t)sLo, gbase + back);
+        const P lStart = tLo, lSrc = sLo < bSLo ? sLo : bSLo;
+        const int64_t lEnd = (int64_t)bTHi + 1;
         // 4. stable sort of the lines by source start
-        unsigned long long lkey = (head && doGroup) ? (((unsigned long long)lSrc << 6) | (unsigned long long)lane) : INF;
+        unsigned long long lkey = (head && doGroup) ? (((unsigned long long)(int64_t)lSrc << 6) | (unsigned long long)lane) : INF;
         lkey = group_sort<G>(lkey, li);
         const int lLane = (int)(lkey & 63ull);
         const bool isLine = lkey != INF;
-        const int64_t oStart = shfl_pos<C>(lStart, lLane), oEnd = shfl_pos<C>(lEnd, lLane);
+        const int64_t oStart = shfl_pos<C>((int64_t)lStart, lLane), oEnd = shfl_pos<C>(lEnd - 1, lLane) + 1;
         const int64_t oSrc = (int64_t)(lkey >> 6); // (the sorted key carries the line's source start)
         const int oSeq = numSeq > 1 ? __shfl(seq, lLane) : 0, oFl = __shfl((int)fl, lLane);
         if (isLine) {
