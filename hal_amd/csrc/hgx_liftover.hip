@@ -1095,7 +1095,10 @@ hgx_liftover_plan *createLiftoverPlan(hgx_alignment *h, int src, int tgt, const 
     HIP_OK(hipEventCreate(&P->evStart));
     HIP_OK(hipEventCreate(&P->evWalk));
     HIP_OK(hipEventCreate(&P->evEnd));
-    const unsigned long long want = std::max<unsigned long long>(1ull << 16, 16ull * P->maxQueries); // grown on demand
+    // pieces per interval the workspace starts with (grown on demand); the table builder's intervals are single source
+    // segments, which yield a few pieces each, and its batch is the whole genome
+    const unsigned long long perQuery = allowComposed ? 16ull : 4ull;
+    const unsigned long long want = std::max<unsigned long long>(1ull << 16, perQuery * P->maxQueries);
     P->allocate((uint32_t)std::min<unsigned long long>(want, (1ull << 32) - 2));
     // A plan that has walked a few times as many intervals as the source genome has segments switches to a composed table
     // (runPlan): building one costs about as much as walking one interval per source segment, a table lookup a third of a
