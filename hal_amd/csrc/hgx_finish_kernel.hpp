@@ -448,7 +448,10 @@ __device__ __forceinline__ void write_records(const FinishStore<C> &S, int nl, i
 // of an ordinary VALU move on gfx9-family parts: xor 1 / 2 / 3 = quad_perm, xor 7 = row_half_mirror, xor 15 = row_mirror,
 // previous lane = wave_shr:1.  k_finish_fast<C, 8> went from 53 ds_bpermute per iteration to 9 (with the narrower gathers
 // below) — and kept its 0.10 ms per 1 M intervals: the kernel is bound by the number of instructions its eight wavefronts
-// per SIMD issue (VALU 47 % busy plus scalar and LDS work, profiles/r01q_pmc.txt), not by the crossbar.
+// per SIMD issue (VALU 47 % busy plus scalar and LDS work, profiles/r01q_pmc.txt), not by the crossbar.  (32-bit sort
+// keys — position << log2 G | lane when both fit — cut the static instruction count of the G = 16..64 instantiations by
+// 30-40 % and changed nothing either; not kept.  Prefetching the next iteration's count and offset: nothing.  What the
+// wavefronts wait for 70 % of their life is not settled; the 40-byte records leave as five 8-byte stores per lane.)
 template <int CTRL> __device__ __forceinline__ int dpp_move(int v) {
     return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); // lanes without a source keep their own value
 }
