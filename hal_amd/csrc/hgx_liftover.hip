@@ -592,15 +592,15 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
         P.timer.end(s);
         ++launch;
     } else {
-    P.timer.begin("k_locate_expand", s, launch);
-    if (P.srcTop)
-        hipLaunchKernelGGL((k_locate_expand<TopRec<C>>), dim3(GRID), dim3(256), 0, s, (const TopRec<C> *)SG.top, SG.numTop, dS, dE,
-                           dStrand, nq, (const int32_t *)SG.locate[0], SG.locateShift[0], P.frontier(cur), cap, cnt, kstat() + 0);
-    else
-        hipLaunchKernelGGL((k_locate_expand<BotRec<C>>), dim3(GRID), dim3(256), 0, s, (const BotRec<C> *)SG.bot, SG.numBot, dS, dE,
-                           dStrand, nq, (const int32_t *)SG.locate[1], SG.locateShift[1], P.frontier(cur), cap, cnt, kstat() + 1);
-    P.timer.end(s);
-    ++launch;
+        P.timer.begin("k_locate_expand", s, launch);
+        if (P.srcTop)
+            hipLaunchKernelGGL((k_locate_expand<TopRec<C>>), dim3(GRID), dim3(256), 0, s, (const TopRec<C> *)SG.top, SG.numTop, dS, dE,
+                               dStrand, nq, (const int32_t *)SG.locate[0], SG.locateShift[0], P.frontier(cur), cap, cnt, kstat() + 0);
+        else
+            hipLaunchKernelGGL((k_locate_expand<BotRec<C>>), dim3(GRID), dim3(256), 0, s, (const BotRec<C> *)SG.bot, SG.numBot, dS, dE,
+                               dStrand, nq, (const int32_t *)SG.locate[1], SG.locateShift[1], P.frontier(cur), cap, cnt, kstat() + 1);
+        P.timer.end(s);
+        ++launch;
     }
 
     bool curTop = P.srcTop;
@@ -833,27 +833,27 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
     // final pieces live in the target genome
     const DeviceGenome &TG = D.genomes[(size_t)P.tgt];
     if (!finalized) {
-    P.timer.begin("k_finalize", s, launch);
-    if (curTop)
-        hipLaunchKernelGGL((k_finalize<TopRec<C>>), dim3(GRID), dim3(256), 0, s, (const TopRec<C> *)TG.top, P.frontier(cur), inCnt(),
-                           cap, P.mapped(0), (uint32_t *)P.perQuery.p, cnt, kstat(), 1);
-    else
-        hipLaunchKernelGGL((k_finalize<BotRec<C>>), dim3(GRID), dim3(256), 0, s, (const BotRec<C> *)TG.bot, P.frontier(cur), inCnt(),
-                           cap, P.mapped(0), (uint32_t *)P.perQuery.p, cnt, kstat(), 0);
-    P.timer.end(s);
+        P.timer.begin("k_finalize", s, launch);
+        if (curTop)
+            hipLaunchKernelGGL((k_finalize<TopRec<C>>), dim3(GRID), dim3(256), 0, s, (const TopRec<C> *)TG.top, P.frontier(cur), inCnt(),
+                               cap, P.mapped(0), (uint32_t *)P.perQuery.p, cnt, kstat(), 1);
+        else
+            hipLaunchKernelGGL((k_finalize<BotRec<C>>), dim3(GRID), dim3(256), 0, s, (const BotRec<C> *)TG.bot, P.frontier(cur), inCnt(),
+                               cap, P.mapped(0), (uint32_t *)P.perQuery.p, cnt, kstat(), 0);
+        P.timer.end(s);
     }
     HIP_OK(hipEventRecord(P.evWalk, s));
 
     if (!through) { // (the whole-path table kernel wrote its pieces grouped, with offset[] and perQuery[])
-    exclusiveScan(P, (const uint32_t *)P.perQuery.p, nq, (uint32_t *)P.offset.p, (uint32_t *)P.total.p, s);
-    P.timer.begin("k_scatter", s);
-    if (finalized)
-        hipLaunchKernelGGL(k_scatter_front, dim3(GRID), dim3(256), 0, s, P.frontier(cur), inCnt(), cap, (const uint32_t *)P.offset.p,
-                           (uint32_t *)P.cursor.p, P.mapped(1), cnt);
-    else
-        hipLaunchKernelGGL(k_scatter, dim3(GRID), dim3(256), 0, s, P.mapped(0), cnt + CNT_MAPPED, cap, (const uint32_t *)P.offset.p,
-                           (uint32_t *)P.cursor.p, P.mapped(1));
-    P.timer.end(s);
+        exclusiveScan(P, (const uint32_t *)P.perQuery.p, nq, (uint32_t *)P.offset.p, (uint32_t *)P.total.p, s);
+        P.timer.begin("k_scatter", s);
+        if (finalized)
+            hipLaunchKernelGGL(k_scatter_front, dim3(GRID), dim3(256), 0, s, P.frontier(cur), inCnt(), cap, (const uint32_t *)P.offset.p,
+                               (uint32_t *)P.cursor.p, P.mapped(1), cnt);
+        else
+            hipLaunchKernelGGL(k_scatter, dim3(GRID), dim3(256), 0, s, P.mapped(0), cnt + CNT_MAPPED, cap, (const uint32_t *)P.offset.p,
+                               (uint32_t *)P.cursor.p, P.mapped(1));
+        P.timer.end(s);
     }
     // finishing: register-resident fast path per size class (each kernel picks the intervals of its class),
     // general LDS path for the rest
@@ -870,18 +870,18 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
         hipLaunchKernelGGL(k_all_general, dim3(GRID), dim3(256), 0, s, (const uint32_t *)P.perQuery.p, nq, (uint32_t *)P.nOut.p, generalList,
                            generalCount);
     } else {
-    P.timer.begin("k_finish_fast", s);
-    const int gridG8 = (int)std::max<uint32_t>((uint32_t)GRID, (nq + FAST_LIST_CAP - 1) / FAST_LIST_CAP); // a block's share fits its LDS lists
+        P.timer.begin("k_finish_fast", s);
+        const int gridG8 = (int)std::max<uint32_t>((uint32_t)GRID, (nq + FAST_LIST_CAP - 1) / FAST_LIST_CAP); // a block's share fits its LDS lists
 #define HGX_FAST(G)                                                                                                    \
-    hipLaunchKernelGGL((k_finish_fast<C, G>), dim3(G == 8 ? gridG8 : GRID), dim3(256), 0, s, P.mapped(1), (const uint32_t *)P.offset.p,  \
-                       (const uint32_t *)P.perQuery.p, nq, (const int64_t *)TG.seqStart, (int)TG.numSeq,               \
-                       (hgx_record *)P.grouped.p, (uint32_t *)P.nOut.p, generalList, generalCount, classLists, classCounts)
-    HGX_FAST(8);
-    HGX_FAST(16);
-    HGX_FAST(32);
-    HGX_FAST(64);
+        hipLaunchKernelGGL((k_finish_fast<C, G>), dim3(G == 8 ? gridG8 : GRID), dim3(256), 0, s, P.mapped(1), (const uint32_t *)P.offset.p,  \
+                           (const uint32_t *)P.perQuery.p, nq, (const int64_t *)TG.seqStart, (int)TG.numSeq,               \
+                           (hgx_record *)P.grouped.p, (uint32_t *)P.nOut.p, generalList, generalCount, classLists, classCounts)
+        HGX_FAST(8);
+        HGX_FAST(16);
+        HGX_FAST(32);
+        HGX_FAST(64);
 #undef HGX_FAST
-    P.timer.end(s);
+        P.timer.end(s);
     }
     P.timer.begin("k_finish_lds", s);
     hipLaunchKernelGGL((k_finish_lds<C, 256>), dim3(std::min<uint32_t>(std::max<uint32_t>(nq, 1), 1u << 14)), dim3(64), 0, s, P.mapped(1),
