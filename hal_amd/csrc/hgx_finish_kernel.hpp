@@ -563,49 +563,100 @@ __global__ void __launch_bounds__(256) k_finish_fast(Mapped in, const uint32_t *
                                   : ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * PER_WAVE;
     const uint32_t limit = G == 8 ? (blockIdx.x * chunk + chunk < nq ? blockIdx.x * chunk + chunk : nq) : nlist;
     const uint32_t stride = G == 8 ? (blockDim.x >> 6) * PER_WAVE : ((gridDim.x * blockDim.x) >> 6) * PER_WAVE;
-    for (uint32_t wbase = first; wbase < limit; wbase += stride) {
-        const uint32_t slotIdx = wbase + (uint32_t)(lane / G);
-        bool gvalid = slotIdx < limit;
-        const uint32_t q = gvalid ? (G == 8 ? slotIdx : myList[slotIdx]) : 0;
-        uint32_t base = 0;
-        int n = 0;
-        if (gvalid) {
-            n = (int)count[q];
-            if (G == 8) {
-                if (n == 0 && li == 0)
-                    nOut[q] = 0;
-                if (n > 8 && li == 0) {
-                    if (n > 64) { // too many pieces for a wavefront: general path
-                        const unsigned long long slot = atomicAdd(generalCount, 1ull);
-                        generalList[slot] = q;
-                    } else {
-                        const int c = n <= 16 ? 0 : n <= 32 ? 1 : 2;
-                        const uint32_t at = atomicAdd(&sCount[c], 1u);
-                        if (at < (uint32_t)LIST_CAP) {
-                            sList[c * LIST_CAP + at] = q;
-                        } else { // the block's window is full (cannot happen with chunk <= LIST_CAP; kept as a guard)
-                            const unsigned long long slot = atomicAdd(&classCounts[c], 1ull);
-                            classLists[(size_t)c * nq + slot] = q;
-                        }
+    // The loop is a chain of dependent memory round trips — list entry -> count and offset -> pieces -> (sequence start)
+    // -> stores, and on this hardware the wait for a load also waits for every older store — that cost ~20 k cycles per
+    // iteration whatever G (profiles/r01q_pmc.txt: a dozen reads in flight per CU).  It is therefore software-pipelined
+    // three deep: while iteration i is worked on, the pieces of i+1, the count and offset of i+2 and the list entry of
+    // i+3 are in flight, each requested before iteration i's stores so that no load ever waits for a store.
+    typedef C P; // positions in the coordinate type of the alignment (32-bit arithmetic on narrow alignments)
+    const int64_t ss0 = seqStart[0];
+    struct Entry { // list stage
+        uint32_t q;
+        bool valid;
+    };
+    struct Head { // count / offset stage
+        uint32_t q, base;
+        int n;
+        bool valid;
+    };
+    struct Pieces { // piece stage: one piece per lane
+        uint32_t q, base;
+        int n;
+        bool gvalid;
+        MappedRec r;
+    };
+    auto loadEntry = [&](uint32_t wb) {
+        Entry e;
+        const uint32_t slot = wb + (uint32_t)(lane / G);
+        e.valid = wb < limit && slot < limit;
+        e.q = e.valid ? (G == 8 ? slot : myList[slot]) : 0u;
+        return e;
+    };
+    auto loadHead = [&](const Entry &e) {
+        Head h;
+        h.q = e.q;
+        h.valid = e.valid;
+        h.n = e.valid ? (int)count[e.q] : 0;
+        h.base = e.valid ? offset[e.q] : 0u;
+        return h;
+    };
+    // classifies the interval (G == 8: hands the larger ones to the lists) and requests its pieces
+    auto loadPieces = [&](const Head &h) {
+        Pieces c;
+        c.q = h.q;
+        c.base = h.base;
+        c.n = h.n;
+        c.gvalid = h.valid;
+        if (h.valid && G == 8) {
+            const uint32_t q = h.q;
+            const int n = h.n;
+            if (n == 0 && li == 0)
+                nOut[q] = 0;
+            if (n > 8 && li == 0) {
+                if (n > 64) { // too many pieces for a wavefront: general path
+                    const unsigned long long slot = atomicAdd(generalCount, 1ull);
+                    generalList[slot] = q;
+                } else {
+                    const int cl = n <= 16 ? 0 : n <= 32 ? 1 : 2;
+                    const uint32_t at = atomicAdd(&sCount[cl], 1u);
+                    if (at < (uint32_t)LIST_CAP) {
+                        sList[cl * LIST_CAP + at] = q;
+                    } else { // the block's window is full (cannot happen with chunk <= LIST_CAP; kept as a guard)
+                        const unsigned long long slot = atomicAdd(&classCounts[cl], 1ull);
+                        classLists[(size_t)cl * nq + slot] = q;
                     }
                 }
-                gvalid = n > 0 && n <= 8;
             }
-            if (gvalid)
-                base = offset[q];
-            else
-                n = 0;
+            c.gvalid = n > 0 && n <= 8;
         }
+        if (!c.gvalid)
+            c.n = 0;
+        c.r = MappedRec{};
+        if (li < c.n)
+            c.r = in.rec[c.base + li];
+        return c;
+    };
+    Entry stageA = loadEntry(first);
+    Head stageB = loadHead(stageA);
+    stageA = loadEntry(first + stride);
+    Pieces stageC = loadPieces(stageB);
+    stageB = loadHead(stageA);
+    stageA = loadEntry(first + 2 * stride);
+    for (uint32_t wbase = first; wbase < limit; wbase += stride) {
+        const Pieces cur = stageC;
+        stageC = loadPieces(stageB);
+        stageB = loadHead(stageA);
+        stageA = loadEntry(wbase + 3 * stride);
+        const bool gvalid = cur.gvalid;
+        const uint32_t q = cur.q, base = cur.base;
+        const int n = cur.n;
         if (!__any(gvalid))
             continue; // nothing for this instantiation among this wavefront's candidates
         const bool have = li < n;
-        // positions in the coordinate type of the alignment: 32-bit arithmetic when every genome is shorter than 2^31 bases
-        // (the kernel is bound by the instructions it issues, and every 64-bit add, compare or lane move is two)
-        typedef C P;
         P tLo = 0, tHi = 0, sLo = 0, sHi = 0;
         uint8_t fl = 0;
         if (have) {
-            const MappedRec r = in.rec[base + li];
+            const MappedRec &r = cur.r;
             tLo = (P)r.tLo;
             tHi = (P)(r.tLo + r.len - 1);
             sLo = (P)r.sLo;
@@ -678,7 +729,7 @@ __global__ void __launch_bounds__(256) k_finish_fast(Mapped in, const uint32_t *
         const int oSeq = numSeq > 1 ? __shfl(seq, lLane) : 0, oFl = __shfl((int)fl, lLane);
         if (isLine) {
             hgx_record r;
-            const int64_t ss = seqStart[oSeq];
+            const int64_t ss = numSeq > 1 ? seqStart[oSeq] : ss0;
             r.query = q;
             r.tgt_start = oStart - ss;
             r.tgt_end = oEnd - ss;
