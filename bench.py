@@ -260,8 +260,8 @@ def main():
             walk_plan.run(d_gs, d_ge, d_st)
             walk_kt = walk_plan.kernel_times()
             wst = walk_plan.stats()
-            assert wst["records"] == st["records"] and wst["mapped_pieces"] == st["mapped_pieces"]
-            table_kernel = "k_locate_through" if st["composed_kind"] == 2 else "k_locate_composed"
+            assert wst["records"] == st["records"] and (st["composed_kind"] == 3 or wst["mapped_pieces"] == st["mapped_pieces"])
+            table_kernel = {3: "k_lift_merged", 2: "k_locate_through"}.get(st["composed_kind"], "k_locate_composed")
             table_records = kt_total[table_kernel]["top_derefs"] // args.steps  # composed records dereferenced per step
             st = dict(st, top_derefs=wst["top_derefs"], bottom_derefs=wst["bottom_derefs"], source_pieces=wst["source_pieces"])
             del walk_plan
@@ -306,8 +306,9 @@ def main():
                        "up_phase": ("composed table of the %s: %d records (%.0f MB), built once per alignment and genome pair on the device "
                                     "in %.0f ms when the plan changed over during warm-up (after 4 intervals per source segment), untimed; %d table records dereferenced per step; "
                                     "HGX_COMPOSED_UP=0 gives the level-by-level walk (profiles/r01q_bench_walk.log)"
-                                    % ("whole path src->MRCA->target" if st["composed_kind"] == 2 else "up phase src->MRCA",
-                                       st["composed_records"], st["composed_records"] * (16 if st["composed_kind"] == 2 else 20) / 1e6,
+                                    % ("whole path src->MRCA->target, merged into chains" if st["composed_kind"] == 3 else
+                                       "whole path src->MRCA->target" if st["composed_kind"] == 2 else "up phase src->MRCA",
+                                       st["composed_records"], st["composed_records"] * (16 if st["composed_kind"] >= 2 else 20) / 1e6,
                                        st["composed_build_ms"], table_records))
                        if st["composed_records"] else "level-by-level walk (k_up_chain)",
                        "exchange": ("all-gatherv of wire blobs (format %s: %.1f MB per rank and step), overlapped with the next batch"
@@ -383,6 +384,12 @@ def plan_kernel_bytes(kt, st, steps):
             bytes_ = (16.0 + (29.0 if name == "k_locate_composed" else 32.0)) * t
             if name == "k_locate_through":
                 bytes_ += 8.0 * st["queries"] * steps
+        if name == "k_lift_merged":
+            # the single-pass kernel: 24 B per interval + the 8 B k_lift_classify left for it, 16 B per merged record that
+            # overlaps its interval (top slot), 40 B per record written + 8 B of count and offset per interval
+            bytes_ = 16.0 * t + (24.0 + 8.0 + 8.0) * st["queries"] * steps + 40.0 * st["records"] * steps
+        if name == "k_lift_classify":
+            bytes_ = (16.0 + 16.0 + 8.0) * st["queries"] * steps  # interval ends, two 8-byte bucket entries, the 8-byte answer
         if name in ("k_locate_expand", "k_locate_composed", "k_locate_through"):
             bytes_ += 24.0 * st["queries"] * steps
         if name in ("k_finish_fast", "k_finish_lds", "k_finish_big"):

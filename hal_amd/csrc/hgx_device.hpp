@@ -134,6 +134,16 @@ struct ComposedUp {
     double buildMs = 0;
     bool through = false;       // records hold FINAL pieces in the target genome (so = forward target start, no segment index):
                                 // the table composes the whole path source -> MRCA -> target, paralogy rings included
+    // The merged form of a whole-path table (hgx_merged_kernels.hpp; 32-bit coordinates only): maximal chains of pieces that
+    // canMergeRightWith joins, in (source start, target start) order, with bucket tables that carry the number of flagged
+    // records before each entry.  Read by the single-pass kernels of hgx_lift_kernels.hpp.
+    void *mRecs = nullptr;      // ComposedRec<int32_t>[mNum]: sLo, len, so = forward target start, mEncF = target strand | sequence << 8
+    void *mCoarse = nullptr;    // uint2[mBuckets + 1]: {first record that touches the bucket, flagged records before it}
+    void *mStarts = nullptr;    // uint2[mBuckets + 1]: {first record that begins at or after the bucket, flagged records before it}
+    int mShift = 0;
+    uint64_t mNum = 0, mFlagged = 0;
+    int64_t mWindow = 0;        // intervals longer than this take the general path
+    double mBuildMs = 0;
 };
 template <typename C> struct BotRec;
 template <> struct alignas(8) BotRec<int32_t> {

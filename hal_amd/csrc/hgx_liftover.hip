@@ -3,6 +3,8 @@
 #include "hgx_finish_kernel.hpp"
 #include "hgx_liftover_engine.hpp"
 #include "hgx_table_kernels.hpp"
+#include "hgx_merged_kernels.hpp"
+#include "hgx_lift_kernels.hpp"
 #include <hipcub/hipcub.hpp>
 #include <algorithm>
 #include <chrono>
@@ -59,6 +61,12 @@ DeviceImage::~DeviceImage() {
             (void)hipFree(kv.second.coarse);
         if (kv.second.starts)
             (void)hipFree(kv.second.starts);
+        if (kv.second.mRecs)
+            (void)hipFree(kv.second.mRecs);
+        if (kv.second.mCoarse)
+            (void)hipFree(kv.second.mCoarse);
+        if (kv.second.mStarts)
+            (void)hipFree(kv.second.mStarts);
     }
     if (desc)
         (void)hipFree(desc);
@@ -457,6 +465,11 @@ struct hgx_liftover_plan {
     uint32_t cap = 0; // piece capacity of every frontier / mapped / record buffer
     DevBuf fr[6][6], mp[2][6], counters, perQuery, offset, cursor, nOut, outOffset, blockSums, total, grouped, outRecords,
         deferredList, needCap, bigSlot, scratch, bigRecords, classLists, classCounts;
+    // single-pass path over the merged table (hgx_lift_kernels.hpp)
+    DevBuf liftKb, liftBlockList, liftBlockCount, liftStatus;
+    bool mergedDisabled = false; // a look-back wait timed out once: this plan keeps to the multi-kernel path
+    bool mergedOffThisRun = false;
+    int liftGrid = 0;
     KernelTimer timer;
     DevBuf wireFlag;                      // hgx_liftover_wire_blob: "a field does not fit the 12-byte form"
     unsigned int *wireFlagHost = nullptr;
@@ -508,6 +521,10 @@ struct hgx_liftover_plan {
         bigSlot.ensure(4 * (nq + 1));
         classLists.ensure(4 * 4 * (nq + 1));
         classCounts.ensure(32);
+        liftKb.ensure(8 * (nq + 1));
+        liftBlockList.ensure(4 * (nq + 4096));
+        liftBlockCount.ensure(4 * 2048);
+        liftStatus.ensure(8 * ((nq + LIFT_TILE - 1) / LIFT_TILE + (nq + 64 * LIFT_TILE - 1) / (64 * LIFT_TILE) + 2));
     }
 };
 
@@ -547,6 +564,74 @@ static void exclusiveScan(hgx_liftover_plan &P, const uint32_t *in, uint32_t n, 
 
 static const ComposedUp *ensureComposed(hgx_alignment *h, int src, int dst, bool through, const hgx_liftover_opts &opts);
 
+// One batch on the single-pass path (32-bit tables): classify, the general intervals through the unmerged table and the
+// LDS finishing kernel, then k_lift_merged writes every record at its final place.  One host synchronisation at the end.
+static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int64_t *dE, const uint8_t *dStrand, hipStream_t s,
+                          unsigned long long *hostCounters) {
+    typedef int32_t C;
+    const DeviceImage &D = *P.h->dev;
+    const ComposedUp &T = *P.composed;
+    unsigned long long *cnt = (unsigned long long *)P.counters.p;
+    const uint32_t cap = P.cap, nq = (uint32_t)n;
+    const int64_t srcLength = P.h->img.genomes[(size_t)P.src].totalLength;
+    const DeviceGenome &TG = D.genomes[(size_t)P.tgt];
+    const uint32_t nTiles = (nq + LIFT_TILE - 1) / LIFT_TILE, nGroups = (nTiles + 63) / 64;
+    unsigned long long *tileStatus = (unsigned long long *)P.liftStatus.p, *groupStatus = tileStatus + nTiles;
+    HIP_OK(hipMemsetAsync(tileStatus, 0, 8 * ((size_t)nTiles + nGroups), s));
+    uint32_t *generalList = (uint32_t *)P.classLists.p;
+    unsigned long long *generalCount = (unsigned long long *)P.classCounts.p;
+    int launch = 0;
+    auto kstat = [&]() { return cnt + CNT_DSTAT0 + STAT_LAUNCH0 + 2 * launch; };
+    // k_lift_classify: a workgroup per contiguous chunk of intervals
+    const uint32_t cGrid = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)GRID, (nq + 255) / 256));
+    const uint32_t chunk = (nq + cGrid - 1) / cGrid;
+    P.timer.begin("k_lift_classify", s);
+    hipLaunchKernelGGL(k_lift_classify, dim3(cGrid), dim3(256), 0, s, dS, dE, nq, srcLength, (const uint2 *)T.mCoarse, (const uint2 *)T.mStarts, T.mShift,
+                       T.mWindow, (uint2 *)P.liftKb.p, (uint32_t *)P.liftBlockList.p, (uint32_t *)P.liftBlockCount.p, chunk);
+    hipLaunchKernelGGL(k_lift_gather, dim3(std::min<uint32_t>(cGrid, 256)), dim3(256), 0, s, (const uint32_t *)P.liftBlockList.p,
+                       (const uint32_t *)P.liftBlockCount.p, cGrid, chunk, generalList, generalCount);
+    P.timer.end(s);
+    // the general intervals: pieces from the unmerged table, grouped by interval, then the general finishing kernel
+    P.timer.begin("k_locate_through", s, launch);
+    hipLaunchKernelGGL((k_locate_through<C>), dim3(residentGrid(k_locate_through<C>)), dim3(256), 0, s, dS, dE, dStrand, nq, srcLength,
+                       (const uint32_t *)T.coarse, (const uint32_t *)T.starts, T.shift, (const ComposedRec<C> *)T.recs, P.mapped(1), cap,
+                       cnt + CNT_FRONT0, cnt, kstat(), (uint32_t *)P.offset.p, (uint32_t *)P.perQuery.p, (const uint32_t *)generalList,
+                       (const unsigned long long *)generalCount);
+    P.timer.end(s);
+    ++launch;
+    HIP_OK(hipEventRecord(P.evWalk, s));
+    P.timer.begin("k_finish_lds", s);
+    hipLaunchKernelGGL((k_finish_lds<C, 256>), dim3(std::min<uint32_t>(std::max<uint32_t>(nq, 1), 1u << 14)), dim3(64), 0, s, P.mapped(1),
+                       (const uint32_t *)P.offset.p, (const uint32_t *)P.perQuery.p, (const uint32_t *)generalList,
+                       (const unsigned long long *)generalCount, (const int64_t *)TG.seqStart, (int)TG.numSeq, (hgx_record *)P.grouped.p,
+                       (uint32_t *)P.nOut.p, (uint32_t *)P.deferredList.p, (uint32_t *)P.needCap.p, cnt, 0);
+    P.timer.end(s);
+    // everything else, and the dense output
+    if (!P.liftGrid)
+        P.liftGrid = residentGrid(k_lift_merged);
+    P.timer.begin("k_lift_merged", s, launch);
+    hipLaunchKernelGGL(k_lift_merged, dim3(std::min<uint32_t>((uint32_t)P.liftGrid, nTiles)), dim3(256), 0, s, dS, dE, dStrand, nq,
+                       (const uint2 *)P.liftKb.p, (const ComposedRec<C> *)T.mRecs, (const int64_t *)TG.seqStart, (int)TG.numSeq,
+                       (const uint32_t *)P.offset.p, (const hgx_record *)P.grouped.p, (hgx_record *)P.outRecords.p, cap, (uint32_t *)P.nOut.p,
+                       (uint32_t *)P.outOffset.p, tileStatus, groupStatus, nTiles, cnt, kstat(), (uint32_t *)P.total.p);
+    P.timer.end(s);
+    ++launch;
+    HIP_OK(hipEventRecord(P.evEnd, s));
+    const int words = STAT_LAUNCH0 + 2 * launch;
+    hipLaunchKernelGGL(k_fold_stats, dim3(1), dim3(STAT_PITCH), 0, s, cnt, words);
+    HIP_OK(hipMemcpyAsync(P.pinned, cnt, 8 * CNT_FRONT0, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipMemcpyAsync(P.pinned + CNT_KSTAT0, cnt + CNT_KSTAT0, 8 * (size_t)(words - STAT_LAUNCH0), hipMemcpyDeviceToHost, s));
+    HIP_OK(hipMemcpyAsync(P.pinned + CNT_SLOTS, P.total.p, 4, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    if (P.pinned[CNT_OVERFLOW]) { // the retry sizes the buffers from the frontier counters and CNT_LIFT_TOTAL
+        HIP_OK(hipMemcpyAsync(P.pinned, cnt, 8 * CNT_SLOTS, hipMemcpyDeviceToHost, s));
+        HIP_OK(hipStreamSynchronize(s));
+    }
+    memcpy(hostCounters, P.pinned, 8 * CNT_SLOTS);
+    const size_t usedStats = (size_t)(words - STAT_LAUNCH0);
+    memset(hostCounters + CNT_KSTAT0 + usedStats, 0, 8 * (2 * (size_t)MAX_LAUNCHES - usedStats));
+}
+
 template <typename C>
 static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int64_t *dE, const uint8_t *dStrand, hipStream_t s,
                     unsigned long long *hostCounters) {
@@ -561,6 +646,10 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
     }
     HIP_OK(hipEventRecord(P.evStart, s));
 
+    if (P.composed && P.composed->mRecs && !P.opts.emit_blocks && !P.mergedDisabled && !P.mergedOffThisRun && !P.captureUp && !P.captureFinal) {
+        runMergedOnce(P, n, dS, dE, dStrand, s, hostCounters);
+        return;
+    }
     int level = 0;
     int launch = 0; // per-launch deref counter slot
     auto kstat = [&]() { return cnt + CNT_DSTAT0 + STAT_LAUNCH0 + 2 * launch; }; // (copy 0; a block adds to its own copy)
@@ -924,16 +1013,32 @@ static void runPlan(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
         return;
     }
     if (!P.composed && P.composedAfter != ~0ull) {
-        if (P.walked >= P.composedAfter)
+        // the batch that takes the plan past its threshold is already served from the table
+        if (P.walked + n >= P.composedAfter)
             P.composed = ensureComposed(P.h, P.src, P.composedThrough ? P.tgt : P.mrca, P.composedThrough, P.opts);
         else
             P.walked += n;
     }
     P.timer.beginRun();
+    P.mergedOffThisRun = false;
     for (;;) {
         runOnce<C>(P, n, dS, dE, dStrand, s, hc);
-        if (!hc[CNT_OVERFLOW])
+        if (!hc[CNT_OVERFLOW]) {
+            const bool merged = P.composed && P.composed->mRecs && !P.opts.emit_blocks && !P.mergedDisabled && !P.mergedOffThisRun;
+            if (merged && (hc[CNT_LIFT_FAIL] || hc[CNT_DEFERRED])) {
+                // the single-pass kernel cannot place this batch: a look-back wait timed out (not expected; the plan then
+                // stays on the multi-kernel path), or an interval outgrew the LDS finishing kernel (its records come from
+                // k_finish_big, which runs behind a host synchronisation).  Repeat the batch on the multi-kernel path.
+                if (hc[CNT_LIFT_FAIL]) {
+                    P.mergedDisabled = true;
+                    fprintf(stderr, "hgx: single-pass liftover kernel gave up waiting for a neighbouring workgroup; this plan continues on the multi-kernel path\n");
+                }
+                P.mergedOffThisRun = true;
+                P.timer.dropRun();
+                continue;
+            }
             break;
+        }
         // a frontier outgrew the workspace: size it from the largest count seen and run again
         unsigned long long need = 0;
         for (int lv = 0; lv < MAX_LEVELS; ++lv) {
@@ -944,6 +1049,7 @@ static void runPlan(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
             }
             need = std::max(need, std::max(tot, mx * NSEG)); // the fullest segment sets the capacity
         }
+        need = std::max(need, hc[CNT_LIFT_TOTAL]); // (the single-pass kernel's output)
         need = std::max<unsigned long long>(need + need / 4, 2ull * P.cap);
         if (need >= (1ull << 32))
             throw std::runtime_error("liftover batch expands to more than 2^32 pieces; submit smaller batches");
@@ -1018,6 +1124,11 @@ static void runPlan(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
     P.stats.composed_records = P.composed ? P.composed->numRecs : 0;
     P.stats.composed_build_ms = P.composed ? P.composed->buildMs : 0;
     P.stats.composed_kind = P.composed ? (P.composed->through ? 2 : 1) : 0;
+    if (P.composed && P.composed->mRecs && !P.opts.emit_blocks && !P.mergedDisabled && !P.mergedOffThisRun) {
+        P.stats.composed_kind = 3;
+        P.stats.composed_records = P.composed->mNum;
+        P.stats.composed_build_ms = P.composed->buildMs + P.composed->mBuildMs;
+    }
     *dOut = (const hgx_record *)P.outRecords.p;
     *nOut = totalRecords;
 }
@@ -1109,7 +1220,13 @@ hgx_liftover_plan *createLiftoverPlan(hgx_alignment *h, int src, int tgt, const 
         const bool force = e && e[0] == '1', forbid = e && e[0] == '0';
         const char *t = getenv("HGX_COMPOSED_THROUGH");
         P->composedThrough = tgt != P->mrca && !(t && t[0] == '0');
-        P->composedAfter = forbid ? ~0ull : (force ? 0ull : 4ull * (unsigned long long)img.genomes[(size_t)src].numTop);
+        // A table costs about as much as walking one interval per source segment, and an interval covers a few segments:
+        // the plan changes over with the batch that brings its intervals to a quarter of the source's segments
+        // (HGX_COMPOSED_AFTER=<x>: to x times the source's segments).
+        double after = 0.25;
+        if (const char *a = getenv("HGX_COMPOSED_AFTER"))
+            after = atof(a);
+        P->composedAfter = forbid ? ~0ull : (force ? 0ull : (unsigned long long)std::max(1.0, after * (double)img.genomes[(size_t)src].numTop));
         if (force)
             P->composed = ensureComposed(h, src, P->composedThrough ? tgt : P->mrca, P->composedThrough, opts);
     }
@@ -1226,6 +1343,138 @@ static void buildComposed(hgx_alignment *h, int src, int dst, bool through, cons
     out.buildMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
+// radix sort of n (key, value) pairs into the second halves of the buffers
+static void sortPairs(DevBuf keys[2], DevBuf vals[2], DevBuf &tmp, size_t n, int endBit, hipStream_t s) {
+    size_t tmpBytes = 0;
+    HIP_OK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmpBytes, (const uint64_t *)keys[0].p, (uint64_t *)keys[1].p, (const uint32_t *)vals[0].p,
+                                              (uint32_t *)vals[1].p, (int)n, 0, endBit, s));
+    tmp.ensure(std::max<size_t>(tmpBytes, 16));
+    HIP_OK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmpBytes, (const uint64_t *)keys[0].p, (uint64_t *)keys[1].p, (const uint32_t *)vals[0].p,
+                                              (uint32_t *)vals[1].p, (int)n, 0, endBit, s));
+}
+
+// The merged form of a whole-path table (hgx_merged_kernels.hpp): chains of mergeable pieces, flags, bucket tables.  All on
+// the device: two radix sorts over the junction keys and the chains, pointer jumping, a third sort and a running maximum
+// for the flags.  window: HGX_MERGED_WINDOW (default 8192 bases).
+static void buildMerged(hgx_alignment *h, int src, int dst, ComposedUp &c) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const DeviceImage &D = *h->dev;
+    const GenomeTables &S = h->img.genomes[(size_t)src];
+    const DeviceGenome &SG = D.genomes[(size_t)src], &TG = D.genomes[(size_t)dst];
+    const size_t n = (size_t)c.numRecs;
+    if (n == 0 || n >= ((size_t)1 << 31) || h->img.genomes[(size_t)dst].seqs.size() >= ((size_t)1 << 24))
+        return;
+    HIP_OK(hipSetDevice(D.device));
+    hipStream_t s = nullptr;
+    int64_t window = 8192;
+    if (const char *e = getenv("HGX_MERGED_WINDOW"))
+        window = std::max<long long>(1, atoll(e));
+    const ComposedRec<int32_t> *recs = (const ComposedRec<int32_t> *)c.recs;
+    DevBuf keys[2], vals[2], tmp, root, minS, sumLen, scalars;
+    for (int k = 0; k < 2; ++k) {
+        keys[k].ensure(8 * 2 * n);
+        vals[k].ensure(4 * 2 * n);
+    }
+    root.ensure(4 * n);
+    minS.ensure(4 * n);
+    sumLen.ensure(4 * n);
+    scalars.ensure(16);
+    const unsigned gridN = (unsigned)((n + 255) / 256), grid2N = (unsigned)((2 * n + 255) / 256);
+    // 1. junctions: which piece continues which
+    hipLaunchKernelGGL(k_merge_keys, dim3(gridN), dim3(256), 0, s, recs, (uint32_t)n, (uint64_t *)keys[0].p, (uint32_t *)vals[0].p);
+    sortPairs(keys, vals, tmp, 2 * n, 64, s);
+    hipLaunchKernelGGL(k_merge_identity, dim3(gridN), dim3(256), 0, s, (uint32_t *)root.p, (uint32_t)n);
+    hipLaunchKernelGGL(k_merge_link, dim3(grid2N), dim3(256), 0, s, (const uint64_t *)keys[1].p, (const uint32_t *)vals[1].p, (uint32_t)(2 * n), recs,
+                       (const int64_t *)TG.seqStart, (int)TG.numSeq, (const int64_t *)SG.seqStart, (int)SG.numSeq, (uint32_t *)root.p);
+    // 2. chains: pointer jumping until nothing moves (the flag is read every fourth round)
+    for (int round = 0; round < 64; round += 4) {
+        HIP_OK(hipMemsetAsync(scalars.p, 0, 4, s));
+        for (int k = 0; k < 4; ++k)
+            hipLaunchKernelGGL(k_merge_jump, dim3(gridN), dim3(256), 0, s, (uint32_t *)root.p, (uint32_t)n, (unsigned int *)scalars.p);
+        unsigned int changed = 0;
+        HIP_OK(hipMemcpyAsync(&changed, scalars.p, 4, hipMemcpyDeviceToHost, s));
+        HIP_OK(hipStreamSynchronize(s));
+        if (!changed)
+            break;
+    }
+    HIP_OK(hipMemsetAsync(minS.p, 0xFF, 4 * n, s));
+    HIP_OK(hipMemsetAsync(sumLen.p, 0, 4 * n, s));
+    HIP_OK(hipMemsetAsync(scalars.p, 0, 16, s));
+    hipLaunchKernelGGL(k_merge_extent, dim3(gridN), dim3(256), 0, s, recs, (const uint32_t *)root.p, (uint32_t)n, (uint32_t *)minS.p, (uint32_t *)sumLen.p);
+    hipLaunchKernelGGL(k_merge_heads, dim3(gridN), dim3(256), 0, s, recs, (const uint32_t *)root.p, (uint32_t)n, (const uint32_t *)minS.p,
+                       (uint64_t *)keys[0].p, (uint32_t *)vals[0].p, (unsigned int *)scalars.p);
+    sortPairs(keys, vals, tmp, n, 64, s);
+    unsigned int m32 = 0;
+    HIP_OK(hipMemcpyAsync(&m32, scalars.p, 4, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    const size_t m = m32;
+    HIP_OK(hipMalloc(&c.mRecs, std::max<size_t>(m, 1) * sizeof(ComposedRec<int32_t>)));
+    ComposedRec<int32_t> *mrecs = (ComposedRec<int32_t> *)c.mRecs;
+    const unsigned gridM = (unsigned)((m + 255) / 256);
+    hipLaunchKernelGGL(k_merge_records, dim3(gridM), dim3(256), 0, s, recs, (const uint32_t *)vals[1].p, (uint32_t)m, (const uint32_t *)minS.p,
+                       (const uint32_t *)sumLen.p, (const int64_t *)TG.seqStart, (int)TG.numSeq, mrecs);
+    // 3. flags: records whose target range overlaps that of a record nearby in the source
+    DevBuf flag, flagPrefix, tHi, runMax;
+    flag.ensure(4 * (m + 1));
+    flagPrefix.ensure(4 * (m + 1));
+    tHi.ensure(4 * m);
+    runMax.ensure(4 * m);
+    HIP_OK(hipMemsetAsync(flag.p, 0, 4 * (m + 1), s));
+    hipLaunchKernelGGL(k_flag_keys, dim3(gridM), dim3(256), 0, s, (const ComposedRec<int32_t> *)mrecs, (uint32_t)m, (uint64_t *)keys[0].p);
+    {
+        size_t tmpBytes = 0;
+        HIP_OK(hipcub::DeviceRadixSort::SortKeys(nullptr, tmpBytes, (const uint64_t *)keys[0].p, (uint64_t *)keys[1].p, (int)m, 0, 64, s));
+        tmp.ensure(std::max<size_t>(tmpBytes, 16));
+        HIP_OK(hipcub::DeviceRadixSort::SortKeys(tmp.p, tmpBytes, (const uint64_t *)keys[0].p, (uint64_t *)keys[1].p, (int)m, 0, 64, s));
+    }
+    hipLaunchKernelGGL(k_flag_ends, dim3(gridM), dim3(256), 0, s, (const ComposedRec<int32_t> *)mrecs, (const uint64_t *)keys[1].p, (uint32_t)m,
+                       (uint32_t *)tHi.p);
+    {
+        size_t tmpBytes = 0;
+        HIP_OK(hipcub::DeviceScan::InclusiveScan(nullptr, tmpBytes, (const uint32_t *)tHi.p, (uint32_t *)runMax.p, MaxOp(), (int)m, s));
+        tmp.ensure(std::max<size_t>(tmpBytes, 16));
+        HIP_OK(hipcub::DeviceScan::InclusiveScan(tmp.p, tmpBytes, (const uint32_t *)tHi.p, (uint32_t *)runMax.p, MaxOp(), (int)m, s));
+    }
+    hipLaunchKernelGGL(k_flag_overlaps, dim3(gridM), dim3(256), 0, s, (const ComposedRec<int32_t> *)mrecs, (const uint64_t *)keys[1].p,
+                       (const uint32_t *)runMax.p, (uint32_t)m, window, (uint32_t *)flag.p);
+    {
+        size_t tmpBytes = 0;
+        HIP_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmpBytes, (const uint32_t *)flag.p, (uint32_t *)flagPrefix.p, (int)(m + 1), s));
+        tmp.ensure(std::max<size_t>(tmpBytes, 16));
+        HIP_OK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmpBytes, (const uint32_t *)flag.p, (uint32_t *)flagPrefix.p, (int)(m + 1), s));
+    }
+    // 4. bucket tables, about one record per bucket (an interval's reach is then a record or two wider than its records)
+    int64_t buckets = 1;
+    while (buckets < (int64_t)m && buckets < ((int64_t)1 << 22))
+        buckets <<= 1;
+    int shift = 0;
+    while (((S.totalLength - 1) >> shift) >= buckets)
+        ++shift;
+    const uint32_t nb = (uint32_t)(((S.totalLength - 1) >> shift) + 1);
+    DevBuf coarse, starts;
+    coarse.ensure(((size_t)nb + 1) * 4);
+    starts.ensure(((size_t)nb + 1) * 4);
+    HIP_OK(hipMemsetAsync(coarse.p, 0xFF, ((size_t)nb + 1) * 4, s));
+    HIP_OK(hipMalloc(&c.mCoarse, ((size_t)nb + 1) * 8));
+    HIP_OK(hipMalloc(&c.mStarts, ((size_t)nb + 1) * 8));
+    if (m)
+        hipLaunchKernelGGL((k_table_touch<int32_t>), dim3(gridM), dim3(256), 0, s, (const ComposedRec<int32_t> *)mrecs, (uint32_t)m, shift, (uint32_t *)coarse.p);
+    const unsigned gridB = (unsigned)(((size_t)nb + 1 + 255) / 256);
+    hipLaunchKernelGGL((k_table_starts<int32_t>), dim3(gridB), dim3(256), 0, s, (const ComposedRec<int32_t> *)mrecs, (uint32_t)m, shift, nb, (uint32_t *)starts.p);
+    hipLaunchKernelGGL(k_table_fill, dim3(gridB), dim3(256), 0, s, (uint32_t *)coarse.p, (const uint32_t *)starts.p, nb);
+    hipLaunchKernelGGL(k_merge_pack_buckets, dim3(gridB), dim3(256), 0, s, (const uint32_t *)coarse.p, (const uint32_t *)starts.p, nb,
+                       (const uint32_t *)flagPrefix.p, (uint2 *)c.mCoarse, (uint2 *)c.mStarts);
+    unsigned int flagged = 0;
+    HIP_OK(hipMemcpyAsync(&flagged, (const uint32_t *)flagPrefix.p + m, 4, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    c.mShift = shift;
+    c.mNum = m;
+    c.mFlagged = flagged;
+    c.mWindow = window;
+    h->dev->bytes += std::max<size_t>(m, 1) * sizeof(ComposedRec<int32_t>) + ((size_t)nb + 1) * 16;
+    c.mBuildMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
 static const ComposedUp *ensureComposed(hgx_alignment *h, int src, int dst, bool through, const hgx_liftover_opts &opts) {
     static std::mutex mu;
     std::lock_guard<std::mutex> lock(mu);
@@ -1241,6 +1490,10 @@ static const ComposedUp *ensureComposed(hgx_alignment *h, int src, int dst, bool
         buildComposed<int64_t>(h, src, dst, through, opts, c);
     else
         buildComposed<int32_t>(h, src, dst, through, opts, c);
+    // the merged form for the single-pass kernels (HGX_MERGED=0: keep to the multi-kernel path)
+    const char *me = getenv("HGX_MERGED");
+    if (through && !h->dev->wide && !(me && me[0] == '0'))
+        buildMerged(h, src, dst, c);
     return &h->dev->composed.emplace(key, c).first->second;
 }
 

@@ -456,7 +456,11 @@ __global__ void __launch_bounds__(256) k_locate_through(const int64_t *__restric
                                                         const ComposedRec<C> *__restrict__ recs, Mapped out, uint32_t cap,
                                                         unsigned long long *segCounters, unsigned long long *counters,
                                                         unsigned long long *kstat, uint32_t *__restrict__ offset,
-                                                        uint32_t *__restrict__ perQuery) {
+                                                        uint32_t *__restrict__ perQuery, const uint32_t *__restrict__ qlist = nullptr,
+                                                        const unsigned long long *__restrict__ qcount = nullptr) {
+    // qlist / qcount: work on these intervals only (the general intervals of the merged-table path, hgx_lift_kernels.hpp)
+    if (qlist)
+        nq = (uint32_t)*qcount;
     constexpr int G = 4, PER_WAVE = 64 / G;
     const uint32_t wavesTotal = (gridDim.x * blockDim.x) >> 6;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -467,8 +471,9 @@ __global__ void __launch_bounds__(256) k_locate_through(const int64_t *__restric
     const unsigned long long gmask = ((1ull << G) - 1ull) << (lane & ~(G - 1));
     uint32_t srcPieces = 0, used = 0;
     for (uint32_t base = wave * PER_WAVE; base < nq; base += wavesTotal * PER_WAVE) {
-        const uint32_t q = base + (uint32_t)(lane / G);
-        bool act = q < nq; // the same in all lanes of a group
+        const uint32_t slot = base + (uint32_t)(lane / G);
+        bool act = slot < nq; // the same in all lanes of a group
+        const uint32_t q = (qlist && act) ? qlist[slot] : slot;
         int64_t gs = 0, ge = -1;
         uint32_t dot = 0;
         bool minus = false, first = true;
@@ -567,7 +572,7 @@ __global__ void __launch_bounds__(256) k_locate_through(const int64_t *__restric
                 }
             }
         }
-        if (li == 0 && q < nq) {
+        if (li == 0 && slot < nq) {
             offset[q] = written ? myOff : 0u;
             perQuery[q] = written;
         }

@@ -66,7 +66,7 @@ def test_plan_timing_modes(hal, tmp_path, monkeypatch):
     plan = hal.LiftoverPlan(al, src, tgt, max_queries=n)
     plan.run(gs, ge, st)
     last = plan.kernel_times()
-    walk = "k_up_chain" if "k_up_chain" in last else "k_locate_through"
+    walk = "k_up_chain" if "k_up_chain" in last else "k_lift_merged" if "k_lift_merged" in last else "k_locate_through"
     ctr = "k_down_ring" if walk == "k_up_chain" else walk
     assert last[walk]["launches"] == 1 and last[ctr]["top_derefs"] > 0
     plan.set_timing(2)  # accumulate

@@ -1,5 +1,6 @@
-"""The composed tables (large plans; k_locate_composed) against the oracle — the table of the whole path source -> target
-("through") and the up table source -> MRCA ("up", HGX_COMPOSED_THROUGH=0):
+"""The composed tables (large plans) against the oracle — the merged table of the whole path with the single-pass kernels
+("merged", the default: k_lift_classify / k_lift_merged), the unmerged table of the whole path with the multi-kernel
+finishing step ("through", HGX_MERGED=0: k_locate_through) and the up table source -> MRCA ("up", HGX_COMPOSED_THROUGH=0):
 forced with HGX_COMPOSED_UP=1 on small batches, every genome pair, both strands and '.', dupes on and off, BED12 / PSL,
 the coalescence limit, real data; and at scale against the walk kernels (HGX_COMPOSED_UP=0)."""
 import os
@@ -16,11 +17,16 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-@pytest.fixture(autouse=True, params=["through", "up"])
+@pytest.fixture(autouse=True, params=["merged", "through", "up"])
 def _forced(monkeypatch, request):
     monkeypatch.setenv("HGX_COMPOSED_UP", "1")
-    monkeypatch.setenv("HGX_COMPOSED_THROUGH", "1" if request.param == "through" else "0")
+    monkeypatch.setenv("HGX_COMPOSED_THROUGH", "0" if request.param == "up" else "1")
+    monkeypatch.setenv("HGX_MERGED", "1" if request.param == "merged" else "0")
     return request.param
+
+
+TABLE_KERNEL = {"merged": "k_lift_merged", "through": "k_locate_through", "up": "k_locate_composed"}
+TABLE_KIND = {"merged": 3, "through": 2, "up": 1}
 
 
 @pytest.mark.parametrize("seed", [2, 5, 9])
@@ -105,18 +111,21 @@ def test_at_scale_against_the_walk_kernels(hal, monkeypatch, _forced):
         ptr, nrec = plan.run(gs, ge, st)
         out[mode] = plan.records_to_tensor(ptr, nrec).cpu()
         kt = plan.kernel_times()
-        table_kernel = "k_locate_through" if _forced == "through" else "k_locate_composed"
-        assert (table_kernel in kt) == (mode == "1") and ("k_up_chain" in kt) == (mode == "0")
+        assert (TABLE_KERNEL[_forced] in kt) == (mode == "1") and ("k_up_chain" in kt) == (mode == "0")
         if mode == "1":  # the table of the whole path replaces the down hop and the grouping scatter as well
             assert ("k_down_ring" in kt) == (_forced == "up") and ("k_scatter" in kt) == (_forced == "up")
+            assert plan.stats()["composed_kind"] == TABLE_KIND[_forced]
+            if _forced == "merged":  # one kernel writes the records: no register finishing step, no compaction
+                assert "k_finish_fast" not in kt and "k_compact_records" not in kt
     assert out["1"].shape[0] > n and torch.equal(out["1"], out["0"])
 
 
 def test_a_walking_plan_switches_to_its_table(hal, monkeypatch, _forced):
-    """Without HGX_COMPOSED_UP a plan walks until it has seen four intervals per source segment, then builds and uses the
-    table; the records before and after the switch are the same."""
+    """Without HGX_COMPOSED_UP a plan walks until its intervals reach a multiple of the source's segments (a quarter by
+    default, four times here), then builds and uses the table; the records before and after the switch are the same."""
     import torch
     monkeypatch.delenv("HGX_COMPOSED_UP")
+    monkeypatch.setenv("HGX_COMPOSED_AFTER", "4")
     opts = hal.RandOptions(mean_degree=1.5, max_branch_length=3.0, min_genomes=2, max_genomes=10, min_segment_length=20,
                            max_segment_length=80, min_segments=2000, max_segments=4000, seed=2, with_dna=False)
     al = hal.Alignment.random(opts, device=0)
@@ -129,7 +138,7 @@ def test_a_walking_plan_switches_to_its_table(hal, monkeypatch, _forced):
     gs, ge = (starts + ss).cuda(), (starts + lens - 1 + ss).cuda()
     st = torch.where(torch.rand(n, generator=g) < 0.5, ord("+"), ord("-")).to(torch.uint8).cuda()
     plan = hal.LiftoverPlan(al, src, tgt, max_queries=n)
-    table_kernel = "k_locate_through" if _forced == "through" else "k_locate_composed"
+    table_kernel = TABLE_KERNEL[_forced]
     first, kinds = None, []
     for _ in range(12):
         ptr, nrec = plan.run(gs, ge, st)
@@ -139,4 +148,4 @@ def test_a_walking_plan_switches_to_its_table(hal, monkeypatch, _forced):
         assert torch.equal(recs, first)
         kinds.append(table_kernel in plan.kernel_times())
     assert kinds[0] is False and kinds[-1] is True and sorted(kinds) == kinds  # walks first, one switch, the table afterwards
-    assert plan.stats()["composed_kind"] == (2 if _forced == "through" else 1)
+    assert plan.stats()["composed_kind"] == TABLE_KIND[_forced]
