@@ -28,15 +28,15 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
 
 
-def workload_options(scale, workload="cfg2"):
+def workload_options(scale, workload="cfg2", dna=False):
     import hal_amd
     if workload == "cfg4":  # BASELINE configs 4/5: the 50-genome alignment (--seed 0 --meanDegree 2 --maxGenomes 50)
         return hal_amd.RandOptions(mean_degree=2.0, max_branch_length=3.0, min_genomes=2, max_genomes=50, min_segment_length=50,
                                    max_segment_length=200, min_segments=int(700000 * scale), max_segments=int(1400000 * scale),
-                                   seed=0, with_dna=False)
+                                   seed=0, with_dna=dna)
     return hal_amd.RandOptions(mean_degree=1.5, max_branch_length=3.0, min_genomes=2, max_genomes=10, min_segment_length=50,
                                max_segment_length=200, min_segments=int(700000 * scale), max_segments=int(1400000 * scale),
-                               seed=2, with_dna=False)
+                               seed=2, with_dna=dna)
 
 
 def make_queries(length, n, seed):
@@ -92,6 +92,34 @@ def cpu_baseline(al, src_name, tgt_name, starts, lens, strand, seq_name, sample,
     return st, text, multi
 
 
+def lib_sha16():
+    import hashlib
+    with open(os.path.join(ROOT, "hal_amd", "libhgx.so"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the PMC passes of profiles/scripts/r02_pmc.sh (profiles/pmc_traffic.json), or
+    None when the file was made with another build of libhgx.so than the one running (the file records the library's hash)."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        d = json.load(open(path))
+    except Exception:
+        return None, "no profiles/pmc_traffic.json"
+    if d.get("libhgx_sha16") != lib_sha16():
+        return None, "profiles/pmc_traffic.json was measured on another build of libhgx.so (%s); rerun profiles/scripts/r02_pmc.sh" % d.get("libhgx_sha16")
+    return d.get("kernels", {}).get(kernel), d.get("source", "")
+
+
+def timed_steps(step, k, sync):
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(k):
+        r = step()
+    sync()
+    return time.perf_counter() - t0, r
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -106,6 +134,10 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=300000, help="intervals timed on the CPU oracle (0 = skip)")
     ap.add_argument("--cpu-all-cores", type=int, default=1, help="also time the oracle sharded over every host core")
     ap.add_argument("--columns", type=int, default=1, help="also time the column-depth kernel over the whole source genome (0 = skip)")
+    ap.add_argument("--maf-columns", type=int, default=8000000,
+                    help="hal2maf (BASELINE config 3) over the first N reference columns, end to end to MAF text (0 = skip; one GPU only)")
+    ap.add_argument("--text-path", type=int, default=1, help="also time Liftover::convert (BED text in, BED text out) on the batch (one GPU only)")
+    ap.add_argument("--sustained-seconds", type=float, default=2.0, help="extra leg: the same step repeated for about this long")
     ap.add_argument("--exchange-selftest", type=int, default=0,
                     help="1: with one GPU, run the multi-GPU code path (wire blob, overlapped all-gatherv, collective settle exit) on a "
                          "one-rank RCCL group; the JSON line then says so in config.exchange")
@@ -129,9 +161,12 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    sync = torch.cuda.synchronize
+    want_maf = args.maf_columns > 0 and world == 1 and not args.exchange_selftest
 
     t0 = time.time()
-    al = hal_amd.Alignment.random(workload_options(args.scale, args.workload), device=local)
+    # (DNA only for the hal2maf leg: "fast" gives the alignment of with_dna=False plus bases from a separate generator)
+    al = hal_amd.Alignment.random(workload_options(args.scale, args.workload, dna="fast" if want_maf else False), device=local)
     gen_s = time.time() - t0
     src_name, tgt_name = ("Genome_9" if args.workload == "cfg2" else "Genome_44"), args.target
     src, tgt = al.genome_id(src_name), al.genome_id(tgt_name)
@@ -141,7 +176,18 @@ def main():
     d_gs = (starts + seq_start).to(dev)
     d_ge = (starts + lens - 1 + seq_start).to(dev)
     d_st = strand.to(dev)
+
+    # ---- cold: a fresh plan with the default policy, one pass over the batch (whatever the policy does on its first
+    # batch — here it builds the table of the whole path and its merged form — is inside the time) ----
+    sync()
+    t0 = time.perf_counter()
     plan = hal_amd.LiftoverPlan(al, src, tgt, max_queries=nq)
+    t_plan = time.perf_counter() - t0
+    ptr, nrec = plan.run(d_gs, d_ge, d_st)
+    sync()
+    cold_s = time.perf_counter() - t0
+    cold_stats = plan.stats()
+    passes_before_timing = 1
 
     collator = shard.RecordCollator()
     wire = {"format": None, "bytes": 0}
@@ -160,15 +206,16 @@ def main():
             collator.submit(blob)
         return nrec
 
-    # settle (untimed): the first runs of a fresh process pay for lazy code-object loads, event pools and workspace growth
-    # (5-12 ms against 2.9 ms), and a process that starts while the previous GPU process is still being torn down by the
-    # driver sees ~1.3 ms of extra host time per run for a second or two.  Run until ten consecutive runs are within 5 %
-    # of the fastest one seen, for at most 4 s.
+    # settle (untimed): the first runs of a fresh process pay for lazy code-object loads and workspace growth, and a process
+    # that starts while the previous GPU process is still being torn down sees extra host time per run for a second or two.
+    # Run until ten consecutive runs are within 5 % of the fastest one seen, for at most 4 s.
+    plan.set_timing(0)  # no kernel events in the timed loop (the kernel times come from a separate loop below)
     best, streak, t_settle = None, 0, time.perf_counter()
     while True:
         t_s = time.perf_counter()
         step()
-        torch.cuda.synchronize()
+        sync()
+        passes_before_timing += 1
         dt = time.perf_counter() - t_s
         if best is None or dt < best:
             best = dt
@@ -182,21 +229,16 @@ def main():
             break
     for _ in range(args.warmup):
         step()
-    plan.set_timing(2)  # kernel events accumulate over the timed steps and are read once, after the timed region
+        passes_before_timing += 1
     if exchanging:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
-    kt_acc = {}
-    walk_ms = total_ms = 0.0
     for _ in range(args.steps):
         nrec = step()
-        st = plan.stats()
-        walk_ms += st["walk_ms"]
-        total_ms += st["total_ms"]
     if exchanging:
         collator.drain(trim=False)  # the exchanges still under way belong to the timed region
-    torch.cuda.synchronize()
+    sync()
     if exchanging:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -205,14 +247,24 @@ def main():
         tot = torch.tensor([nrec], dtype=torch.int64, device=dev)
         dist.all_reduce(tot)
         nrec_all = int(tot.item())
-    kt_total = plan.kernel_times()
-    for k, v in kt_total.items():
-        kt_acc[k] = {"ms": v["ms"], "launches": v["launches"]}
-    plan.set_timing(1)
-    if exchanging:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # ---- sustained: the same step for a couple of seconds (a region long enough for outside observers: rocm-smi, the driver) ----
+    sustained = None
+    if args.sustained_seconds > 0 and not exchanging:
+        k = max(args.steps, int(args.sustained_seconds / max(elapsed / args.steps, 1e-5)))
+        dt_s, _ = timed_steps(step, k, sync)
+        sustained = {"steps": k, "seconds": dt_s, "value": nq * k / dt_s, "ms_per_step": 1e3 * dt_s / k}
+
+    # ---- kernel times: the same steps again with HIP events around every launch (untimed) ----
+    plan.set_timing(2)
+    for _ in range(args.steps):
+        plan.run(d_gs, d_ge, d_st)
+    kt_total = plan.kernel_times()
+    kt_acc = {k: {"ms": v["ms"], "launches": v["launches"]} for k, v in kt_total.items()}
+    plan.set_timing(1)
 
     col_result = None
     if args.columns:
@@ -231,11 +283,11 @@ def main():
             padded = torch.zeros(per, dtype=torch.int32, device=dev)
             padded[:hi - lo] = mine[:hi - lo]
             allv = torch.empty(per * world, dtype=torch.int32, device=dev)
-            torch.cuda.synchronize()
+            sync()
             dist.barrier()
             t_g = time.perf_counter()
             dist.all_gather_into_tensor(allv, padded)
-            torch.cuda.synchronize()
+            sync()
             gather_ms = (time.perf_counter() - t_g) * 1e3
             t = torch.tensor([col_ms, gather_ms, depth_sum], dtype=torch.float64, device=dev)
             tmax = t.clone()
@@ -247,41 +299,52 @@ def main():
     if rank == 0:
         st = plan.stats()
         value = world * nq * args.steps / elapsed
-        # Algorithmic bytes are a property of the input, not of the implementation (counted by the restatement of
-        # the reference's walk): when the timed plan serves the up phase from its composed table, the segment records the
-        # reference's walk dereferences are counted by one untimed run of the level-by-level plan on the same batch.
-        walk_kt = None
-        if st["composed_records"]:
-            os.environ["HGX_COMPOSED_UP"] = "0"
-            try:
-                walk_plan = hal_amd.LiftoverPlan(al, src, tgt, max_queries=nq)
-            finally:
-                del os.environ["HGX_COMPOSED_UP"]
+        # ---- walk: the level-by-level kernels (HGX_COMPOSED_UP=0), the "per-query-interval graph chase" itself.  Its
+        # dereference counts are also the SURVEY 8(d) figure of the batch: algorithmic bytes are a property of the input,
+        # counted by the reference's own walk, whatever the timed plan reads instead. ----
+        os.environ["HGX_COMPOSED_UP"] = "0"
+        try:
+            walk_plan = hal_amd.LiftoverPlan(al, src, tgt, max_queries=nq)
+        finally:
+            del os.environ["HGX_COMPOSED_UP"]
+        for _ in range(3):
             walk_plan.run(d_gs, d_ge, d_st)
-            walk_kt = walk_plan.kernel_times()
-            wst = walk_plan.stats()
-            assert wst["records"] == st["records"] and (st["composed_kind"] == 3 or wst["mapped_pieces"] == st["mapped_pieces"])
+        walk_plan.set_timing(0)
+        walk_dt, _ = timed_steps(lambda: walk_plan.run(d_gs, d_ge, d_st), 5, sync)
+        walk_plan.set_timing(2)
+        for _ in range(5):
+            walk_plan.run(d_gs, d_ge, d_st)
+        walk_kt = walk_plan.kernel_times()
+        wst = walk_plan.stats()
+        assert wst["records"] == st["records"]
+        walk_bytes = plan_kernel_bytes(walk_kt, wst, 5)
+        walk_dom = max(walk_kt.items(), key=lambda kv: kv[1]["ms"])[0]
+        walk_dom_ms = walk_kt[walk_dom]["ms"] / max(1, walk_kt[walk_dom]["launches"])
+        walk_traffic, _ = pmc_traffic(walk_dom)
+        walk = {"ms_per_step": 1e3 * walk_dt / 5, "value": nq * 5 / walk_dt, "unit": "intervals/s",
+                "kernels_ms_per_step": {k: round(v["ms"] / 5, 4) for k, v in sorted(walk_kt.items())},
+                "roofline": {"bound": "hbm", "kernel": walk_dom, "achieved": walk_bytes[walk_dom] / (walk_dom_ms * 1e-3) / 1e9,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": walk_bytes[walk_dom] / (walk_dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "traffic": walk_traffic, "kernel_avg_ms": walk_dom_ms, "algorithmic_bytes_per_launch": walk_bytes[walk_dom]}}
+        table_records = 0
+        if st["composed_records"]:
             table_kernel = {3: "k_lift_merged", 2: "k_locate_through"}.get(st["composed_kind"], "k_locate_composed")
-            table_records = kt_total[table_kernel]["top_derefs"] // args.steps  # composed records dereferenced per step
-            st = dict(st, top_derefs=wst["top_derefs"], bottom_derefs=wst["bottom_derefs"], source_pieces=wst["source_pieces"])
-            del walk_plan
+            table_records = kt_total[table_kernel]["top_derefs"] // args.steps  # table records dereferenced per step
+        wcounts = dict(top_derefs=wst["top_derefs"], bottom_derefs=wst["bottom_derefs"], source_pieces=wst["source_pieces"],
+                       mapped_pieces=wst["mapped_pieces"])
+        del walk_plan
         # --- roofline of the dominant kernel (device time from HIP events on the launch stream) ---
         dom = max(kt_acc.items(), key=lambda kv: kv[1]["ms"])
         dom_name, dom_ms, dom_launches = dom[0], dom[1]["ms"], dom[1]["launches"]
-        Q, T, B, R = st["queries"], st["top_derefs"], st["bottom_derefs"], st["records"]
-        alg_total = 24 * Q + 25 * T + 25 * B + 40 * R  # SURVEY 8(d), per step
+        Q, T, B, R = st["queries"], wcounts["top_derefs"], wcounts["bottom_derefs"], st["records"]
+        alg_walk = 24 * Q + 25 * T + 25 * B + 40 * R  # SURVEY 8(d), per step, by the reference's walk
         kern_ms_total = sum(v["ms"] for v in kt_acc.values()) / args.steps
         per_kernel_alg = plan_kernel_bytes(kt_total, st, args.steps)
+        own_bytes = sum(per_kernel_alg[k] * v["launches"] for k, v in kt_acc.items()) / args.steps  # what the timed kernels must move
         dom_bytes_per_launch = per_kernel_alg.get(dom_name, 0.0)
         dom_avg_ms = dom_ms / max(1, dom_launches)
         achieved = dom_bytes_per_launch / (dom_avg_ms * 1e-3) / 1e9 if dom_avg_ms > 0 else 0.0
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get(dom_name)
-            except Exception:
-                traffic = None
+        traffic, traffic_source = pmc_traffic(dom_name)
         # measured device-copy rate on this GPU (read + write bytes of a 1 GiB device-to-device copy), SURVEY 8(d)
         cp_src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
         cp_dst = torch.empty_like(cp_src)
@@ -291,9 +354,11 @@ def main():
         for _ in range(5):
             cp_dst.copy_(cp_src)
         e1.record()
-        torch.cuda.synchronize()
+        sync()
         copy_gbs = 5 * 2 * cp_src.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del cp_src, cp_dst
+        kind_text = {3: "merged table of the whole path src->MRCA->target (chains of mergeable pieces), single-pass kernels",
+                     2: "table of the whole path src->MRCA->target", 1: "table of the up phase src->MRCA"}
         out = {
             "metric": "lifted BED intervals/sec", "value": value, "unit": "intervals/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
@@ -303,32 +368,42 @@ def main():
                                                                      "seed 2" if args.workload == "cfg2" else "seed 0", args.scale, nq,
                                                                      src_name, tgt_name),
                        "intervals_per_gpu": nq, "records_per_step": nrec_all, "parallelism": "query-shard x%d" % world,
-                       "up_phase": ("composed table of the %s: %d records (%.0f MB), built once per alignment and genome pair on the device "
-                                    "in %.0f ms when the plan changed over during warm-up (after 4 intervals per source segment), untimed; %d table records dereferenced per step; "
-                                    "HGX_COMPOSED_UP=0 gives the level-by-level walk (profiles/r01q_bench_walk.log)"
-                                    % ("whole path src->MRCA->target, merged into chains" if st["composed_kind"] == 3 else
-                                       "whole path src->MRCA->target" if st["composed_kind"] == 2 else "up phase src->MRCA",
-                                       st["composed_records"], st["composed_records"] * (16 if st["composed_kind"] >= 2 else 20) / 1e6,
-                                       st["composed_build_ms"], table_records))
+                       "regime": ("steady state: the timed steps are passes %d.. of this batch through one plan; the plan's first pass "
+                                  "(see `cold`) built its %s: %d records (%.0f MB) in %.1f ms on the device; %d table records "
+                                  "dereferenced per step, %d of the %d intervals took the general (overlap-breaking) route; "
+                                  "`walk` is the same batch without any table"
+                                  % (passes_before_timing + 1, kind_text.get(st["composed_kind"], "?"), st["composed_records"],
+                                     st["composed_records"] * 16 / 1e6, st["composed_build_ms"], table_records, st["general_queries"], nq))
                        if st["composed_records"] else "level-by-level walk (k_up_chain)",
                        "exchange": ("all-gatherv of wire blobs (format %s: %.1f MB per rank and step), overlapped with the next batch"
                                     % (wire["format"], wire["bytes"] / 1e6))
                        if exchanging else "none (one GPU)",
                        "newick": al.newick, "generate_s": round(gen_s, 2)},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "measured_copy_GBs": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs,
                          "kernel_avg_ms": dom_avg_ms, "kernel_launches_per_step": dom_launches / args.steps,
                          "algorithmic_bytes_per_launch": dom_bytes_per_launch,
-                         "whole_path": {"algorithmic_bytes_per_step": alg_total, "kernel_ms_per_step": kern_ms_total,
-                                        "achieved_GBs": alg_total / (kern_ms_total * 1e-3) / 1e9 if kern_ms_total > 0 else 0.0,
-                                        "note": "SURVEY 8(d) bytes of the reference's walk (24Q+25T+25B+40R, counted by an untimed "
-                                                "level-by-level run of the same batch); a composed table dereferences far fewer "
-                                                "records, so this figure is not bounded by the HBM peak when a table is in use"}},
+                         "whole_step": {"kernel_ms_per_step": kern_ms_total, "bytes_the_timed_kernels_must_move": own_bytes,
+                                        "achieved_GBs": own_bytes / (kern_ms_total * 1e-3) / 1e9 if kern_ms_total > 0 else 0.0,
+                                        "frac": own_bytes / (kern_ms_total * 1e-3) / 1e9 / HBM_PEAK_GBS if kern_ms_total > 0 else 0.0,
+                                        "reference_walk_bytes_per_step": alg_walk,
+                                        "note": "bytes_the_timed_kernels_must_move prices every timed kernel by its own inputs and outputs "
+                                                "(DESIGN.md 5); reference_walk_bytes_per_step is SURVEY 8(d)'s 24Q+25T+25B+40R counted by the "
+                                                "level walk of the same batch — a table reads far fewer records, so that figure divided by "
+                                                "the table path's time is not a bandwidth"}},
+            "cold": {"ms": 1e3 * cold_s, "value": nq / cold_s, "unit": "intervals/s", "plan_create_ms": 1e3 * t_plan,
+                     "table_build_ms": cold_stats["composed_build_ms"], "composed_kind": cold_stats["composed_kind"],
+                     "what": "fresh plan (default policy) + one pass over the batch, wall clock with the device synchronised; the first "
+                             "HIP module loads of the process are in it"},
+            "walk": walk,
             "kernels_ms_per_step": {k: round(v["ms"] / args.steps, 4) for k, v in sorted(kt_acc.items())},
-            "counts_per_step": {"queries": Q, "source_pieces": st["source_pieces"], "top_derefs": T, "bottom_derefs": B,
-                                "mapped_pieces": st["mapped_pieces"], "records": R, "deferred_queries": st["deferred_queries"]},
+            "counts_per_step": {"queries": Q, "source_pieces": wcounts["source_pieces"], "top_derefs": T, "bottom_derefs": B,
+                                "mapped_pieces": wcounts["mapped_pieces"], "records": R, "deferred_queries": st["deferred_queries"],
+                                "general_queries": st["general_queries"], "table_records_dereferenced": table_records},
         }
+        if sustained:
+            out["sustained"] = sustained
         if col_result:
             ncol, col_ms, gather_ms, mean_depth = col_result
             cst = al.columns_depth_stats(src, 0, ncol)
@@ -336,16 +411,39 @@ def main():
             # reference piece (= per run of columns with one walk, which is how the kernel works), + the 4-byte result
             col_bytes = 25.0 * (cst["top_derefs"] + cst["bottom_derefs"]) + 4.0 * ncol
             col_gbs = col_bytes / world / (col_ms * 1e-3) / 1e9
+            col_traffic, col_src = pmc_traffic("k_depth_runs")
             out["columns"] = {"metric": "alignment-depth columns/sec (ColumnIterator closure per reference base)",
                               "value": ncol / (col_ms * 1e-3), "unit": "columns/s", "columns": ncol, "kernel_ms": col_ms,
                               "n_gpus": world, "all_gather_ms": gather_ms,
                               "reference_genome": src_name, "mean_depth": mean_depth,
                               "roofline": {"bound": "hbm", "kernel": "k_depth_runs", "achieved": col_gbs, "peak": HBM_PEAK_GBS,
-                                           "unit": "GB/s", "frac": col_gbs / HBM_PEAK_GBS, "traffic": (json.load(open(pmc)).get("k_column_depth") if os.path.exists(pmc) else None),
+                                           "unit": "GB/s", "frac": col_gbs / HBM_PEAK_GBS, "traffic": col_traffic, "traffic_source": col_src,
                                            "algorithmic_bytes_per_launch": col_bytes / world,
                                            "top_derefs": cst["top_derefs"], "bottom_derefs": cst["bottom_derefs"],
-                                           "note": "the kernel is bound by the scratch traffic of its frame stacks, not by these bytes "
-                                                   "(DESIGN.md 4.1); per-GPU figures when n_gpus > 1"}}
+                                           "note": "per-GPU figures when n_gpus > 1"}}
+        if want_maf:
+            # BASELINE config 3: hal2maf --refGenome <leaf> --noAncestors, end to end (column kernels, row fetch, block state
+            # machine, text rendering) over the first N reference columns
+            ncols = min(args.maf_columns, al.genome_length(src))
+            al.maf_export_bytes(src, start=0, length=min(ncols, 200000), no_ancestors=True)  # (DNA upload, code objects)
+            t0 = time.perf_counter()
+            nbytes = al.maf_export_bytes(src, start=0, length=ncols, no_ancestors=True)
+            dt_m = time.perf_counter() - t0
+            out.setdefault("columns", {})["hal2maf"] = {"metric": "MAF columns/sec (hal2maf --refGenome %s --noAncestors, end to end to MAF text in host memory)" % src_name,
+                                                        "value": ncols / dt_m, "unit": "columns/s", "columns": ncols, "seconds": dt_m,
+                                                        "maf_bytes": nbytes}
+        if args.text_path and world == 1 and not args.exchange_selftest:
+            # Liftover::convert as halLiftover runs it: BED text in, BED text out (parse, H2D, kernels, D2H, format), PCIe inclusive
+            import numpy as np
+            sn, ln, tn = starts.numpy(), lens.numpy(), strand.numpy()
+            bed = "".join("%s\t%d\t%d\tq\t0\t%s\n" % (seq_name, int(a), int(a + b), chr(int(c))) for a, b, c in zip(sn, ln, tn))
+            hal_amd.liftover_convert(al, src, bed[:bed.index("\n", 4000000) + 1], tgt)  # (code objects, plan, pinned buffers)
+            t0 = time.perf_counter()
+            text_out = hal_amd.liftover_convert(al, src, bed, tgt)
+            dt_t = time.perf_counter() - t0
+            out["end_to_end"] = {"what": "hgx_liftover_convert = Liftover::convert: BED6 text of the batch in host memory -> lifted BED text "
+                                         "in host memory (parse, H2D, kernels, D2H, format; PCIe inclusive, never `value`)",
+                                 "value": nq / dt_t, "unit": "intervals/s", "seconds": dt_t, "lines_in": nq, "lines_out": text_out.count("\n")}
         if args.cpu_sample > 0:
             sample = min(args.cpu_sample, nq)
             cst, text, multi = cpu_baseline(al, src_name, tgt_name, starts, lens, strand, seq_name, sample,
@@ -356,8 +454,13 @@ def main():
             recs = plan.records_to_tensor(ptr, n).cpu().numpy().view(hal_amd.RECORD_DTYPE).reshape(-1)
             tname = al.sequences(tgt)[0][0]
             gpu_text = "".join("%s\t%d\t%d\tq\t0\t%s\n" % (tname, r["tgt_start"], r["tgt_end"], r["strand"].decode()) for r in recs)
+            cpu_model = ""
+            try:
+                cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+            except Exception:
+                pass
             out["cpu_baseline"] = {"value": cst["intervals"] / cst["map_seconds"], "unit": "intervals/s", "cores": 1,
-                                   "kind": "port",
+                                   "kind": "port", "host_cpu": cpu_model,
                                    "sample": "first %d intervals of rank 0's batch, oracle liftInterval+sort time only "
                                              "(BED parse/print and image load excluded)" % sample,
                                    "parity_with_gpu": gpu_text == text}

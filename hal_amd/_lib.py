@@ -28,7 +28,7 @@ class hgx_liftover_stats(C.Structure):
                 ("bottom_derefs", C.c_uint64), ("mapped_pieces", C.c_uint64), ("records", C.c_uint64),
                 ("deferred_queries", C.c_uint64), ("walk_ms", C.c_double), ("total_ms", C.c_double),
                 ("composed_records", C.c_uint64), ("composed_build_ms", C.c_double),
-                ("composed_kind", C.c_uint64)]
+                ("composed_kind", C.c_uint64), ("general_queries", C.c_uint64), ("composed_flagged", C.c_uint64)]
 
 
 class hgx_column_opts(C.Structure):

@@ -46,7 +46,7 @@ class RandOptions:
     min_segments: int = 100
     max_segments: int = 500
     seed: int = -1
-    with_dna: bool = True
+    with_dna: object = True  # True: halRandGen's stream; False: no DNA (different, faster stream); "fast": False's alignment + DNA from a fast generator
 
     @staticmethod
     def preset(name, seed=-1, with_dna=True):
@@ -63,7 +63,8 @@ class RandOptions:
         (o.mean_degree, o.max_branch_length, o.min_genomes, o.max_genomes, o.min_segment_length, o.max_segment_length,
          o.min_segments, o.max_segments, o.seed, o.with_dna) = (
             self.mean_degree, self.max_branch_length, self.min_genomes, self.max_genomes, self.min_segment_length,
-            self.max_segment_length, self.min_segments, self.max_segments, self.seed, 1 if self.with_dna else 0)
+            self.max_segment_length, self.min_segments, self.max_segments, self.seed,
+            2 if self.with_dna == "fast" else (1 if self.with_dna else 0))
         return o
 
 
@@ -256,6 +257,15 @@ class Alignment:
             return C.string_at(out, n.value).decode()
         finally:
             lib.hgx_free(out)
+
+    def maf_export_bytes(self, ref, ref_sequence=-1, start=0, length=0, no_ancestors=False, max_block_len=1000):
+        """hal2maf end to end, the text left in library memory and released: returns its size (benchmark use)."""
+        o = hgx_maf_opts(0, 1 if no_ancestors else 0, 0, 0, 0, 0, max_block_len)
+        out, n, err = C.c_void_p(), C.c_size_t(), C.c_void_p()
+        if lib.hgx_maf_export(self._h, ref, ref_sequence, start, length, C.byref(o), None, 0, C.byref(out), C.byref(n), C.byref(err)) != 0:
+            raise HgxError(take_error(err))
+        lib.hgx_free(out)
+        return n.value
 
     def maf_export(self, ref, ref_sequence=-1, start=0, length=0, no_dupes=False, no_ancestors=False, only_sequence_names=False,
                    only_orthologs=False, keep_empty_ref_blocks=False, max_block_len=1000, targets=None, unique=False,

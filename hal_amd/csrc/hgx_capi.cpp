@@ -572,7 +572,7 @@ int hgx_rand_preset(const char *preset, hgx_rand_opts *o) {
         return HGX_ERR;
     RandOptions r;
     r.seed = o->seed;
-    r.withDna = o->with_dna != 0;
+    r.withDna = o->with_dna == 2 ? 2 : (o->with_dna != 0 ? 1 : 0);
     if (!randPreset(preset, r))
         return HGX_ERR;
     o->mean_degree = r.meanDegree;
@@ -600,7 +600,7 @@ int hgx_create_random(const hgx_rand_opts *o, int device, hgx_alignment **out, c
     r.minSegments = o->min_segments;
     r.maxSegments = o->max_segments;
     r.seed = o->seed;
-    r.withDna = o->with_dna != 0;
+    r.withDna = o->with_dna == 2 ? 2 : (o->with_dna != 0 ? 1 : 0);
     return finishHandle(createRandomAlignment(r), device, out);
     HGX_CATCH
 }

@@ -810,7 +810,20 @@ __global__ void __launch_bounds__(64) k_finish_big(Mapped in, const uint32_t *__
                                                    const uint32_t *__restrict__ deferredList, uint32_t nDeferred, int cap,
                                                    unsigned char *__restrict__ scratch, size_t sliceBytes,
                                                    const int64_t *__restrict__ seqStart, int numSeq, hgx_record *__restrict__ bigRecords,
-                                                   uint32_t *__restrict__ nOut, unsigned long long *counters, int blocks) {
+                                                   uint32_t *__restrict__ nOut, unsigned long long *counters, int blocks,
+                                                   int countOnDevice = 0, uint32_t *__restrict__ offsetOut = nullptr, uint32_t recordBase = 0) {
+    // countOnDevice (single-pass runs, hgx_lift_kernels.hpp): the number of deferred intervals is read from the counter block
+    // (nDeferred = the slices the scratch area holds; more than that fails the run, the host grows the area and repeats it);
+    // offsetOut: the interval's records are slice k of an area that starts recordBase records into the grouped buffer
+    if (countOnDevice) {
+        const unsigned long long have = counters[CNT_DEFERRED];
+        if (have > (unsigned long long)nDeferred) {
+            if (threadIdx.x == 0 && blockIdx.x == 0)
+                counters[CNT_BIGFAIL] = 1;
+        } else {
+            nDeferred = (uint32_t)have;
+        }
+    }
     for (uint32_t k = blockIdx.x; k < nDeferred; k += gridDim.x) {
         const uint32_t q = deferredList[k];
         const int n = (int)count[q];
@@ -844,8 +857,11 @@ __global__ void __launch_bounds__(64) k_finish_big(Mapped in, const uint32_t *__
             }
         } else {
             write_records(S, nl, (int32_t)q, bigRecords + (size_t)k * cap, seqStart);
-            if (threadIdx.x == 0)
+            if (threadIdx.x == 0) {
                 nOut[q] = (uint32_t)nl;
+                if (offsetOut)
+                    offsetOut[q] = recordBase + k * (uint32_t)cap;
+            }
         }
         wsync();
     }

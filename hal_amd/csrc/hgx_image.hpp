@@ -195,7 +195,8 @@ struct RandOptions {
     uint64_t minGenomes = 8, maxGenomes = 20, minSegmentLength = 500, maxSegmentLength = 2000, minSegments = 100,
              maxSegments = 500;
     int seed = -1;
-    bool withDna = true; // false: skip DNA content (not seed-compatible with halRandGen; benchmark use)
+    int withDna = 1; // 0: skip DNA content (not seed-compatible with halRandGen; benchmark use); 2: the alignment of 0 with
+                     // DNA from a separate fast generator (hgx_randgen.cpp: FastDna)
 };
 bool randPreset(const std::string &name, RandOptions &opt);
 Image createRandomAlignment(const RandOptions &opt);

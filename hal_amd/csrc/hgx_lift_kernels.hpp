@@ -249,7 +249,8 @@ __device__ __forceinline__ uint32_t lift_wave_pass(const ComposedRec<int32_t> *_
 // kb: k_lift_classify's answer; genOffset / genRecords / nOut: where the general path left the records of the general
 // intervals (k_finish_lds: nOut[q] records at genRecords + genOffset[q]); out / outCap: the dense output; outOffset[q]:
 // first record of interval q in it.  tileStatus / groupStatus: zeroed look-back granules.
-static __global__ void __launch_bounds__(256) k_lift_merged(const int64_t *__restrict__ gStart, const int64_t *__restrict__ gEnd,
+template <int MINW>
+static __global__ void __launch_bounds__(256, MINW) k_lift_merged(const int64_t *__restrict__ gStart, const int64_t *__restrict__ gEnd,
                                                             const uint8_t *__restrict__ strand, uint32_t nq, const uint2 *__restrict__ kb,
                                                             const ComposedRec<int32_t> *__restrict__ recs, const int64_t *__restrict__ tSeqStart,
                                                             int tNumSeq, const uint32_t *__restrict__ genOffset,
@@ -407,6 +408,30 @@ static __global__ void __launch_bounds__(256) k_lift_merged(const int64_t *__res
     }
     stat_add(&kstat[0], used); // the "top" slot of this launch: merged records that overlap their interval
     stat_add(&counters[CNT_DSTAT0 + STAT_MAPPED], used);
+}
+
+// End of a single-pass run: folds the spread statistics words (hgx_liftover_kernels.hpp: stat_add) and gathers everything
+// the host reads back into LIFT_RB_WORDS consecutive words — one 128-byte copy per batch.
+// rb[0..7] = the scalar slots (CNT_MAPPED with the pieces of this run), rb[8 + l] = top-slot count of launch l (l < 4),
+// rb[12] = general intervals.
+static constexpr int LIFT_RB_WORDS = 16;
+static __global__ void k_lift_epilogue(unsigned long long *counters, const unsigned long long *generalCount, unsigned long long *rb) {
+    __shared__ unsigned long long sums[5];
+    const int w = (int)threadIdx.x;
+    if (w < 5) {
+        const int word = w == 0 ? STAT_MAPPED : STAT_LAUNCH0 + 2 * (w - 1);
+        unsigned long long sum = 0;
+        for (int l = 0; l < STAT_LINES; ++l)
+            sum += counters[CNT_DSTAT0 + (size_t)l * STAT_PITCH + word];
+        sums[w] = sum;
+    }
+    __syncthreads();
+    if (w < 8)
+        rb[w] = counters[w] + (w == CNT_MAPPED ? sums[0] : 0ull);
+    else if (w < 12)
+        rb[w] = sums[w - 7];
+    else if (w == 12)
+        rb[w] = *generalCount;
 }
 
 } // namespace hgx

@@ -469,7 +469,12 @@ struct hgx_liftover_plan {
     DevBuf liftKb, liftBlockList, liftBlockCount, liftStatus;
     bool mergedDisabled = false; // a look-back wait timed out once: this plan keeps to the multi-kernel path
     bool mergedOffThisRun = false;
-    int liftGrid = 0;
+    int liftGrid = 0, liftMinWaves = 1;
+    unsigned long long generalQueries = 0;
+    // scratch of the single-pass runs for intervals that outgrow the LDS finishing kernel (k_finish_big without a host
+    // synchronisation in between): liftBigSlots slices for liftBigCap pieces each, grown when a run needed more
+    uint32_t liftBigSlots = 0;
+    int liftBigCap = 0;
     KernelTimer timer;
     DevBuf wireFlag;                      // hgx_liftover_wire_blob: "a field does not fit the 12-byte form"
     unsigned int *wireFlagHost = nullptr;
@@ -503,12 +508,14 @@ struct hgx_liftover_plan {
                 fr[k][a].ensure(fsz[a] * (size_t)cap);
         for (int k = 0; k < 2; ++k)
             mp[k][0].ensure(sizeof(MappedRec) * (size_t)cap);
-        grouped.ensure(sizeof(hgx_record) * (size_t)cap);
+        grouped.ensure(sizeof(hgx_record) * ((size_t)cap + (size_t)liftBigSlots * (size_t)liftBigCap));
+        if (liftBigSlots)
+            scratch.ensure((h->dev->wide ? finishSliceBytes<int64_t>(liftBigCap) : finishSliceBytes<int32_t>(liftBigCap)) * (size_t)liftBigSlots);
         outRecords.ensure(sizeof(hgx_record) * (size_t)cap);
         if (!pinned)
-            HIP_OK(hipHostMalloc((void **)&pinned, 8 * (CNT_SLOTS + 1)));
+            HIP_OK(hipHostMalloc((void **)&pinned, 8 * (CNT_SLOTS + 1 + LIFT_RB_WORDS)));
         const size_t nq = std::max<size_t>(maxQueries, 1);
-        counters.ensure(8 * CNT_DEV_SLOTS);
+        counters.ensure(8 * (CNT_DEV_SLOTS + LIFT_RB_WORDS));
         perQuery.ensure(4 * (nq + 1));
         offset.ensure(4 * (nq + 1));
         cursor.ensure(4 * (nq + 1));
@@ -593,7 +600,8 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
     P.timer.end(s);
     // the general intervals: pieces from the unmerged table, grouped by interval, then the general finishing kernel
     P.timer.begin("k_locate_through", s, launch);
-    hipLaunchKernelGGL((k_locate_through<C>), dim3(residentGrid(k_locate_through<C>)), dim3(256), 0, s, dS, dE, dStrand, nq, srcLength,
+    // (the list's length is only known on the device; the grids are sized for a list that is a small part of the batch)
+    hipLaunchKernelGGL((k_locate_through<C>), dim3(std::min(512, residentGrid(k_locate_through<C>))), dim3(256), 0, s, dS, dE, dStrand, nq, srcLength,
                        (const uint32_t *)T.coarse, (const uint32_t *)T.starts, T.shift, (const ComposedRec<C> *)T.recs, P.mapped(1), cap,
                        cnt + CNT_FRONT0, cnt, kstat(), (uint32_t *)P.offset.p, (uint32_t *)P.perQuery.p, (const uint32_t *)generalList,
                        (const unsigned long long *)generalCount);
@@ -601,35 +609,58 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
     ++launch;
     HIP_OK(hipEventRecord(P.evWalk, s));
     P.timer.begin("k_finish_lds", s);
-    hipLaunchKernelGGL((k_finish_lds<C, 256>), dim3(std::min<uint32_t>(std::max<uint32_t>(nq, 1), 1u << 14)), dim3(64), 0, s, P.mapped(1),
+    hipLaunchKernelGGL((k_finish_lds<C, 256>), dim3(std::min<uint32_t>(std::max<uint32_t>(nq, 1), 1536u)), dim3(64), 0, s, P.mapped(1),
                        (const uint32_t *)P.offset.p, (const uint32_t *)P.perQuery.p, (const uint32_t *)generalList,
                        (const unsigned long long *)generalCount, (const int64_t *)TG.seqStart, (int)TG.numSeq, (hgx_record *)P.grouped.p,
                        (uint32_t *)P.nOut.p, (uint32_t *)P.deferredList.p, (uint32_t *)P.needCap.p, cnt, 0);
     P.timer.end(s);
+    if (P.liftBigSlots) { // intervals k_finish_lds deferred: same algorithm on global scratch; their records become slices behind the grouped buffer
+        P.timer.begin("k_finish_big", s);
+        hipLaunchKernelGGL((k_finish_big<C>), dim3(P.liftBigSlots), dim3(64), 0, s, P.mapped(1), (const uint32_t *)P.offset.p,
+                           (const uint32_t *)P.perQuery.p, (const uint32_t *)P.deferredList.p, P.liftBigSlots, P.liftBigCap,
+                           (unsigned char *)P.scratch.p, finishSliceBytes<C>(P.liftBigCap), (const int64_t *)TG.seqStart, (int)TG.numSeq,
+                           (hgx_record *)P.grouped.p + cap, (uint32_t *)P.nOut.p, cnt, 0, 1, (uint32_t *)P.offset.p, cap);
+        P.timer.end(s);
+    }
     // everything else, and the dense output
-    if (!P.liftGrid)
-        P.liftGrid = residentGrid(k_lift_merged);
+    if (!P.liftGrid) {
+        const char *v = getenv("HGX_LIFT_MINWAVES"); // 8: hold the kernel to 64 VGPRs (experiments)
+        P.liftMinWaves = v && atoi(v) == 8 ? 8 : 1;
+        P.liftGrid = P.liftMinWaves == 8 ? residentGrid(k_lift_merged<8>) : residentGrid(k_lift_merged<1>);
+        if (const char *b = getenv("HGX_LIFT_BLOCKS")) // workgroups per CU (experiments)
+            P.liftGrid = std::min(P.liftGrid, std::max(1, atoi(b)) * 256);
+    }
     P.timer.begin("k_lift_merged", s, launch);
-    hipLaunchKernelGGL(k_lift_merged, dim3(std::min<uint32_t>((uint32_t)P.liftGrid, nTiles)), dim3(256), 0, s, dS, dE, dStrand, nq,
-                       (const uint2 *)P.liftKb.p, (const ComposedRec<C> *)T.mRecs, (const int64_t *)TG.seqStart, (int)TG.numSeq,
-                       (const uint32_t *)P.offset.p, (const hgx_record *)P.grouped.p, (hgx_record *)P.outRecords.p, cap, (uint32_t *)P.nOut.p,
-                       (uint32_t *)P.outOffset.p, tileStatus, groupStatus, nTiles, cnt, kstat(), (uint32_t *)P.total.p);
+#define HGX_LIFT(W)                                                                                                                          \
+    hipLaunchKernelGGL(k_lift_merged<W>, dim3(std::min<uint32_t>((uint32_t)P.liftGrid, nTiles)), dim3(256), 0, s, dS, dE, dStrand, nq,           \
+                       (const uint2 *)P.liftKb.p, (const ComposedRec<C> *)T.mRecs, (const int64_t *)TG.seqStart, (int)TG.numSeq,               \
+                       (const uint32_t *)P.offset.p, (const hgx_record *)P.grouped.p, (hgx_record *)P.outRecords.p, cap, (uint32_t *)P.nOut.p, \
+                       (uint32_t *)P.outOffset.p, tileStatus, groupStatus, nTiles, cnt, kstat(), (uint32_t *)P.total.p)
+    if (P.liftMinWaves == 8)
+        HGX_LIFT(8);
+    else
+        HGX_LIFT(1);
+#undef HGX_LIFT
     P.timer.end(s);
     ++launch;
     HIP_OK(hipEventRecord(P.evEnd, s));
-    const int words = STAT_LAUNCH0 + 2 * launch;
-    hipLaunchKernelGGL(k_fold_stats, dim3(1), dim3(STAT_PITCH), 0, s, cnt, words);
-    HIP_OK(hipMemcpyAsync(P.pinned, cnt, 8 * CNT_FRONT0, hipMemcpyDeviceToHost, s));
-    HIP_OK(hipMemcpyAsync(P.pinned + CNT_KSTAT0, cnt + CNT_KSTAT0, 8 * (size_t)(words - STAT_LAUNCH0), hipMemcpyDeviceToHost, s));
-    HIP_OK(hipMemcpyAsync(P.pinned + CNT_SLOTS, P.total.p, 4, hipMemcpyDeviceToHost, s));
+    // one small copy brings back everything the host needs (k_lift_epilogue)
+    unsigned long long *rb = cnt + CNT_DEV_SLOTS;
+    hipLaunchKernelGGL(k_lift_epilogue, dim3(1), dim3(64), 0, s, cnt, (const unsigned long long *)generalCount, rb);
+    unsigned long long *hrb = P.pinned + CNT_SLOTS + 1;
+    HIP_OK(hipMemcpyAsync(hrb, rb, 8 * LIFT_RB_WORDS, hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
-    if (P.pinned[CNT_OVERFLOW]) { // the retry sizes the buffers from the frontier counters and CNT_LIFT_TOTAL
+    memset(hostCounters, 0, 8 * CNT_SLOTS);
+    if (hrb[CNT_OVERFLOW]) { // the retry sizes the buffers from the frontier counters and CNT_LIFT_TOTAL
         HIP_OK(hipMemcpyAsync(P.pinned, cnt, 8 * CNT_SLOTS, hipMemcpyDeviceToHost, s));
         HIP_OK(hipStreamSynchronize(s));
+        memcpy(hostCounters, P.pinned, 8 * CNT_SLOTS);
     }
-    memcpy(hostCounters, P.pinned, 8 * CNT_SLOTS);
-    const size_t usedStats = (size_t)(words - STAT_LAUNCH0);
-    memset(hostCounters + CNT_KSTAT0 + usedStats, 0, 8 * (2 * (size_t)MAX_LAUNCHES - usedStats));
+    memcpy(hostCounters, hrb, 8 * 8);
+    for (int l = 0; l < launch; ++l)
+        hostCounters[CNT_KSTAT0 + 2 * l] = hrb[8 + l];
+    P.pinned[CNT_SLOTS] = hrb[CNT_LIFT_TOTAL]; // the record total, where runPlan looks for it
+    P.generalQueries = hrb[12];
 }
 
 template <typename C>
@@ -1025,15 +1056,25 @@ static void runPlan(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
         runOnce<C>(P, n, dS, dE, dStrand, s, hc);
         if (!hc[CNT_OVERFLOW]) {
             const bool merged = P.composed && P.composed->mRecs && !P.opts.emit_blocks && !P.mergedDisabled && !P.mergedOffThisRun;
-            if (merged && (hc[CNT_LIFT_FAIL] || hc[CNT_DEFERRED])) {
-                // the single-pass kernel cannot place this batch: a look-back wait timed out (not expected; the plan then
-                // stays on the multi-kernel path), or an interval outgrew the LDS finishing kernel (its records come from
-                // k_finish_big, which runs behind a host synchronisation).  Repeat the batch on the multi-kernel path.
-                if (hc[CNT_LIFT_FAIL]) {
-                    P.mergedDisabled = true;
-                    fprintf(stderr, "hgx: single-pass liftover kernel gave up waiting for a neighbouring workgroup; this plan continues on the multi-kernel path\n");
+            if (merged && hc[CNT_DEFERRED] && (hc[CNT_BIGFAIL] || hc[CNT_DEFERRED] > P.liftBigSlots)) {
+                // intervals outgrew the LDS finishing kernel and the scratch area of k_finish_big was too small (or not there
+                // yet): size it from what this run needed and repeat the batch
+                const unsigned long long slots = std::max<unsigned long long>(64, 2 * hc[CNT_DEFERRED]);
+                const unsigned long long pieces = std::max<unsigned long long>(512, 2 * hc[CNT_MAXNEED]);
+                if (pieces > (1ull << 26) || slots * pieces >= (1ull << 31))
+                    P.mergedOffThisRun = true; // (the multi-kernel path sizes its scratch per run)
+                else {
+                    P.liftBigSlots = (uint32_t)std::max<unsigned long long>(P.liftBigSlots, slots);
+                    P.liftBigCap = (int)std::max<unsigned long long>((unsigned long long)P.liftBigCap, pieces);
+                    P.allocate(P.cap);
                 }
-                P.mergedOffThisRun = true;
+                P.timer.dropRun();
+                continue;
+            }
+            if (merged && hc[CNT_LIFT_FAIL]) {
+                // a look-back wait timed out (not expected): repeat the batch on the multi-kernel path and stay there
+                P.mergedDisabled = true;
+                fprintf(stderr, "hgx: single-pass liftover kernel gave up waiting for a neighbouring workgroup; this plan continues on the multi-kernel path\n");
                 P.timer.dropRun();
                 continue;
             }
@@ -1059,7 +1100,10 @@ static void runPlan(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
     const uint32_t nq = (uint32_t)n;
     const DeviceGenome &TG = D.genomes[(size_t)P.tgt];
     unsigned long long *cnt = (unsigned long long *)P.counters.p;
-    const uint32_t nDef = (uint32_t)hc[CNT_DEFERRED];
+    const bool mergedRun = P.composed && P.composed->mRecs && !P.opts.emit_blocks && !P.mergedDisabled && !P.mergedOffThisRun;
+    // (a single-pass run has finished its deferred intervals itself and placed their records)
+    const uint32_t nDeferredSeen = (uint32_t)hc[CNT_DEFERRED];
+    const uint32_t nDef = mergedRun ? 0u : nDeferredSeen;
     int bigCap = 0;
     if (nDef > 0) {
         bigCap = (int)std::max<unsigned long long>(512, 2 * hc[CNT_MAXNEED]);
@@ -1118,7 +1162,7 @@ static void runPlan(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
     P.stats.bottom_derefs = botAll;
     P.stats.mapped_pieces = hc[CNT_MAPPED];
     P.stats.records = totalRecords;
-    P.stats.deferred_queries = nDef;
+    P.stats.deferred_queries = nDeferredSeen;
     P.stats.walk_ms = walk;
     P.stats.total_ms = tot;
     P.stats.composed_records = P.composed ? P.composed->numRecs : 0;
@@ -1128,6 +1172,8 @@ static void runPlan(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
         P.stats.composed_kind = 3;
         P.stats.composed_records = P.composed->mNum;
         P.stats.composed_build_ms = P.composed->buildMs + P.composed->mBuildMs;
+        P.stats.general_queries = P.generalQueries;
+        P.stats.composed_flagged = P.composed->mFlagged;
     }
     *dOut = (const hgx_record *)P.outRecords.p;
     *nOut = totalRecords;
@@ -1444,8 +1490,11 @@ static void buildMerged(hgx_alignment *h, int src, int dst, ComposedUp &c) {
         HIP_OK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmpBytes, (const uint32_t *)flag.p, (uint32_t *)flagPrefix.p, (int)(m + 1), s));
     }
     // 4. bucket tables, about one record per bucket (an interval's reach is then a record or two wider than its records)
+    int64_t perBucket = 1;
+    if (const char *e = getenv("HGX_MERGED_BUCKET_RECS")) // records per bucket (experiments)
+        perBucket = std::max<long long>(1, atoll(e));
     int64_t buckets = 1;
-    while (buckets < (int64_t)m && buckets < ((int64_t)1 << 22))
+    while (buckets < (int64_t)m / perBucket && buckets < ((int64_t)1 << 22))
         buckets <<= 1;
     int shift = 0;
     while (((S.totalLength - 1) >> shift) >= buckets)

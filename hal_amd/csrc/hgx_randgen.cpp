@@ -5,6 +5,7 @@
 // tilings, parent/child/paralogy links and DNA as halRandGen (pinned through the reference's golden
 // liftover/MAF outputs in tests/).
 #include "hgx_image.hpp"
+#include <cstring>
 #include <cmath>
 #include <deque>
 #include <random>
@@ -56,6 +57,43 @@ inline char randDNA(Rng &rng) { // halRandomData.cpp:23-35
         return 'T';
     }
 }
+// withDna == 2: bases from a separate cheap generator (splitmix64), so that the main stream — and with it the tree, the
+// tilings and every link — is the one of withDna == 0, and a 1 Gb alignment gets its DNA in seconds.  Same model as
+// halRandomData.cpp (uniform bases, per-base substitution with probability 1 - exp(-branchLength), reverse complement on
+// inverted segments), not the same draws.
+struct FastDna {
+    uint64_t s;
+    explicit FastDna(uint64_t seed) : s(seed * 0x9E3779B97F4A7C15ull + 0x1234567ull) {}
+    uint64_t next() {
+        uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+    void fill(char *dst, int64_t n) {
+        static const char B[4] = {'A', 'C', 'G', 'T'};
+        int64_t i = 0;
+        while (i < n) {
+            uint64_t r = next();
+            for (int k = 0; k < 32 && i < n; ++k, r >>= 2)
+                dst[i++] = B[r & 3];
+        }
+    }
+    // substitutes each base with probability p (threshold on 32-bit draws)
+    void mutate(char *dst, int64_t n, double p) {
+        static const char B[4] = {'A', 'C', 'G', 'T'};
+        if (p <= 0)
+            return;
+        const uint64_t thr = p >= 1 ? (1ull << 32) : (uint64_t)(p * 4294967296.0);
+        for (int64_t i = 0; i < n; i += 2) {
+            const uint64_t r = next();
+            if ((r & 0xFFFFFFFFull) < thr)
+                dst[i] = B[(r >> 60) & 3];
+            if (i + 1 < n && ((r >> 28) & 0xFFFFFFFFull) < thr)
+                dst[i + 1] = B[(r >> 62) & 3];
+        }
+    }
+};
 inline char complement(char c) { // api/inc/halCommon.h:45-75
     switch (c) {
     case 'A':
@@ -87,7 +125,7 @@ struct Dim {
 
 bool randPreset(const std::string &name, RandOptions &o) { // halRandGen.cpp:34-37
     int seed = o.seed;
-    bool dna = o.withDna;
+    const int dna = o.withDna;
     if (name == "small")
         o = RandOptions{0.75, 0.1, 2, 5, 250, 1000, 5, 10};
     else if (name == "medium")
@@ -216,12 +254,16 @@ Image createRandomAlignment(const RandOptions &opt) {
             queue.pop_back();
             GenomeTables &G = img.genomes[(size_t)g];
             std::string &seq = dna[(size_t)g];
+            const bool slowDna = opt.withDna == 1, fastDna = opt.withDna == 2;
+            FastDna fd((uint64_t)opt.seed * 1000003ull + (uint64_t)g);
             if (opt.withDna)
                 seq.resize((size_t)G.totalLength);
             if (G.parent < 0) {
-                if (opt.withDna)
+                if (slowDna)
                     for (int64_t i = 0; i < G.totalLength; ++i)
                         seq[(size_t)i] = randDNA(rng);
+                else if (fastDna)
+                    fd.fill(&seq[0], G.totalLength);
             } else {
                 GenomeTables &P = img.genomes[(size_t)G.parent];
                 const std::string &pseq = dna[(size_t)G.parent];
@@ -241,13 +283,25 @@ Image createRandomAlignment(const RandOptions &opt) {
                     G.tParent[(size_t)i] = parentIdx;
                     int64_t tstart = G.tStart[(size_t)i], tlen = G.tStart[(size_t)i + 1] - tstart;
                     if (parentIdx == NULL_INDEX) {
-                        if (opt.withDna)
+                        if (slowDna)
                             for (int64_t j = 0; j < tlen; ++j)
                                 seq[(size_t)(tstart + j)] = randDNA(rng);
+                        else if (fastDna)
+                            fd.fill(&seq[(size_t)tstart], tlen);
                     } else {
                         bool reversed = exponEvent(rng, branchLength);
                         G.tParentRev[(size_t)i] = reversed;
-                        if (opt.withDna) {
+                        if (fastDna) {
+                            int64_t pstart = P.bStart[(size_t)parentIdx];
+                            char *d = &seq[(size_t)tstart];
+                            if (reversed)
+                                for (int64_t j = 0; j < tlen; ++j)
+                                    d[j] = complement(pseq[(size_t)(pstart + tlen - 1 - j)]);
+                            else
+                                memcpy(d, pseq.data() + pstart, (size_t)tlen);
+                            fd.mutate(d, tlen, 1.0 - exp(-branchLength));
+                        }
+                        if (slowDna) {
                             int64_t pstart = P.bStart[(size_t)parentIdx];
                             buffer.assign(pseq, (size_t)pstart, (size_t)tlen);
                             if (reversed) {

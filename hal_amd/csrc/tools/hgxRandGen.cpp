@@ -61,7 +61,7 @@ int main(int argc, char **argv) {
             } else if (a == "--testRand") {
                 // parsed but ignored by the reference too (halRandGen.cpp:110)
             } else if (a == "--noDna") {
-                opt.withDna = false;
+                opt.withDna = 0;
             } else if (a.rfind("--", 0) == 0) {
                 std::cerr << "unknown option " << a << std::endl;
                 return 1;

@@ -138,10 +138,15 @@ int hgx_liftover_run_device(hgx_liftover_plan *p, size_t n, const int64_t *d_gst
 typedef struct hgx_liftover_stats {
     uint64_t queries, source_pieces, top_derefs, bottom_derefs, mapped_pieces, records, deferred_queries;
     double walk_ms, total_ms;
-    /* A plan that has walked four times as many intervals as the source genome has top segments switches to a composed
-     * table, built once per alignment, genome pair and options on the device (every source top segment runs through the
-     * walk kernels as one interval, the pieces are radix-sorted by source position; about the cost of walking one interval
-     * per source segment):
+    /* A plan whose intervals have reached a quarter of the source genome's top segments (the batch that crosses the line
+     * included) is served from a composed table, built once per alignment, genome pair and options on the device (every
+     * source top segment runs through the walk kernels as one interval, the pieces are radix-sorted by source position;
+     * about the cost of walking one interval per source segment):
+     *   composed_kind 3 — the MERGED table of the whole path: the pieces of kind 2 joined into the maximal chains that
+     *                     canMergeRightWith would merge (rows of a chain file).  One kernel classifies the intervals, one
+     *                     writes every record at its final place; intervals that may need overlap breaking (a record in
+     *                     reach whose target overlaps that of a record nearby in the source; general_queries of them)
+     *                     take the kind-2 route inside the same run.  32-bit coordinates only; HGX_MERGED=0 forbids it;
      *   composed_kind 2 — the table of the whole path source -> MRCA -> target (paralogy rings and coalescenceLimit
      *                     included): an interval is one lookup plus the grouping / merging step;
      *   composed_kind 1 — the up table source -> MRCA (when the target is the MRCA itself, or HGX_COMPOSED_THROUGH=0):
@@ -149,10 +154,13 @@ typedef struct hgx_liftover_stats {
      *   composed_kind 0 — this plan walks level by level.
      * composed_records / composed_build_ms: size and build time of the table.  With a table, top_derefs counts the table
      * records dereferenced plus the segment records of whatever part of the walk still runs.
-     * HGX_COMPOSED_UP=1 in the environment builds the table when the plan is created, =0 forbids it. */
+     * HGX_COMPOSED_UP=1 in the environment builds the table when the plan is created, =0 forbids it;
+     * HGX_COMPOSED_AFTER=x moves the change-over to x times the source's segments. */
     uint64_t composed_records;
     double composed_build_ms;
     uint64_t composed_kind;
+    uint64_t general_queries;  /* kind 3: intervals of the last run that took the general route */
+    uint64_t composed_flagged; /* kind 3: flagged records of the table */
 } hgx_liftover_stats;
 int hgx_liftover_last_stats(const hgx_liftover_plan *p, hgx_liftover_stats *out);
 /* Per-kernel device time, measured with HIP events on the run's stream, as a JSON object
@@ -255,7 +263,8 @@ typedef struct hgx_rand_opts {
     double mean_degree, max_branch_length;
     uint64_t min_genomes, max_genomes, min_segment_length, max_segment_length, min_segments, max_segments;
     int32_t seed;
-    int32_t with_dna; /* 1 = seed-compatible with halRandGen; 0 = skip DNA draws (faster, different stream) */
+    int32_t with_dna; /* 1 = seed-compatible with halRandGen; 0 = skip DNA draws (faster, different stream); 2 = the
+                         alignment of 0 with DNA from a separate fast generator (same model, seconds for 1 Gb) */
 } hgx_rand_opts;
 int hgx_rand_preset(const char *preset, hgx_rand_opts *opts); /* small | medium | big | large */
 int hgx_create_random(const hgx_rand_opts *opts, int device, hgx_alignment **out, char **err);
