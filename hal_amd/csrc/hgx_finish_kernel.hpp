@@ -961,4 +961,388 @@ static __global__ void k_wire_header(WireHeader h, WireHeader *out) {
     *out = h;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The general algorithm of finish_query for intervals of at most 64 pieces, entirely in registers: one wavefront per
+// interval, one piece per lane.  finish_query's LDS version spends its time in chains of dependent LDS reads issued by one
+// lane (15-45 us per interval whatever its size); here
+//   * the two sorts are ranks by counting (every lane compares itself with piece j, read with v_readlane, j = 0..n-1);
+//   * overlap breaking is the common refinement computed from the ranks of the pieces' boundaries among the distinct
+//     boundary values: piece i becomes rank(tHi+1) - rank(tLo) pieces, the k-th of them from boundary rank(tLo)+k to the next
+//     (insertAndBreakOverlaps, api/impl/halSegmentMapper.cpp:475-520; the sorted boundaries are the only thing kept in LDS);
+//   * the sequential part — BlockMapper::extractSegment over the set in target order (liftover/impl/halBlockMapper.cpp:
+//     331-394: equivalence classes of equal target start, canMergeRightWith, cut points, erasure) — runs as scalar code that
+//     reads the pieces with v_readlane; the set membership is one 64-bit mask.
+// Intervals whose refined set has more than 64 members, or more than 64 cut points, are passed on (return false).
+template <typename C> __device__ __forceinline__ C wave_read(C v, int j);
+template <> __device__ __forceinline__ int32_t wave_read<int32_t>(int32_t v, int j) {
+    return __builtin_amdgcn_readlane(v, j);
+}
+template <> __device__ __forceinline__ int64_t wave_read<int64_t>(int64_t v, int j) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, j), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), j);
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+template <typename C> __device__ __forceinline__ C wave_push(C v, int dstLane);
+template <> __device__ __forceinline__ int32_t wave_push<int32_t>(int32_t v, int dstLane) {
+    return __builtin_amdgcn_ds_permute(dstLane << 2, v);
+}
+template <> __device__ __forceinline__ int64_t wave_push<int64_t>(int64_t v, int dstLane) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_permute(dstLane << 2, (int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_permute(dstLane << 2, (int)(uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+template <typename C> __device__ __forceinline__ C wave_pull(C v, int srcLane);
+template <> __device__ __forceinline__ int32_t wave_pull<int32_t>(int32_t v, int srcLane) {
+    return __shfl(v, srcLane);
+}
+template <> __device__ __forceinline__ int64_t wave_pull<int64_t>(int64_t v, int srcLane) {
+    return __shfl(v, srcLane);
+}
+
+template <typename C> struct WaveLines { // line l of the interval lives in lane l
+    C lStart, lEnd, lSrc;
+    int lSeq, lStrand; // strand character in the low 7 bits, the piece's own orientation in bit 7
+    int rank;          // position of the line in the output (stable order by source start)
+    int nl;
+};
+
+// the pieces of lanes 0..n-1 into MappedSegmentSet order: (target, then source) in forward coordinates
+template <typename C> __device__ __forceinline__ void wave_sort_pieces(int lane, int n, C &tLo, C &tHi, C &sLo, C &sHi, int &fl) {
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
+        const C jt = wave_read<C>(tLo, j), jh = wave_read<C>(tHi, j), js = wave_read<C>(sLo, j), jS = wave_read<C>(sHi, j);
+        const bool less = jt != tLo ? jt < tLo : jh != tHi ? jh < tHi : js != sLo ? js < sLo : jS != sHi ? jS < sHi : j < lane;
+        rank += less ? 1 : 0;
+    }
+    if (lane >= n)
+        rank = lane;
+    tLo = wave_push<C>(tLo, rank);
+    tHi = wave_push<C>(tHi, rank);
+    sLo = wave_push<C>(sLo, rank);
+    sHi = wave_push<C>(sHi, rank);
+    fl = __builtin_amdgcn_ds_permute(rank << 2, fl);
+}
+
+// n (wave-uniform, 1..64) pieces in lanes 0..n-1; sD: 128 coordinates of LDS, sOwn: 64 bytes of LDS, private to the wavefront
+template <typename C>
+__device__ __forceinline__ bool finish_wave(const int lane, int n, C tLo, C tHi, C sLo, C sHi, int fl, const int64_t *__restrict__ seqStart,
+                                            const int numSeq, C *sD, uint8_t *sOwn, WaveLines<C> &L) {
+    wave_sort_pieces<C>(lane, n, tLo, tHi, sLo, sHi, fl);
+    {
+        const C pTLo = lane_prev(tLo), pTHi = lane_prev(tHi);
+        const bool hasPrev = lane > 0 && lane < n;
+        const bool sameT = hasPrev && tLo == pTLo && tHi == pTHi;
+        if (__any(hasPrev && tLo <= pTHi && !sameT)) {
+            // ---- refinement: every piece cut at every boundary (a piece's start, a piece's end + 1) inside it ----
+            const bool valid = lane < n;
+            const C A = tLo, B = tHi + 1;
+            bool firstA = valid, firstB = valid; // this lane holds the canonical occurrence of the value
+            for (int j = 0; j < n; ++j) {
+                const C aj = wave_read<C>(A, j), bj = wave_read<C>(B, j);
+                if (j < lane && aj == A)
+                    firstA = false;
+                if (aj == B || (j < lane && bj == B))
+                    firstB = false;
+            }
+            int rA = 0, rB = 0; // number of distinct boundary values below mine
+            const int fa = firstA ? 1 : 0, fb = firstB ? 1 : 0;
+            for (int j = 0; j < n; ++j) {
+                const C aj = wave_read<C>(A, j), bj = wave_read<C>(B, j);
+                const int faj = __builtin_amdgcn_readlane(fa, j), fbj = __builtin_amdgcn_readlane(fb, j);
+                rA += (faj && aj < A ? 1 : 0) + (fbj && bj < A ? 1 : 0);
+                rB += (faj && aj < B ? 1 : 0) + (fbj && bj < B ? 1 : 0);
+            }
+            if (firstA)
+                sD[rA] = A;
+            if (firstB)
+                sD[rB] = B;
+            const int c = valid ? rB - rA : 0; // pieces this one becomes
+            int incl = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int up = __shfl_up(incl, o);
+                if (lane >= o)
+                    incl += up;
+            }
+            const int m = __builtin_amdgcn_readlane(incl, 63);
+            if (m > 64)
+                return false;
+            const int off = incl - c;
+            sOwn[lane] = 0;
+            wave_lds_fence();
+            if (c > 0)
+                sOwn[off] = (uint8_t)(lane + 1);
+            wave_lds_fence();
+            int mark = (int)sOwn[lane];
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int up = __shfl_up(mark, o);
+                if (lane >= o && up > mark)
+                    mark = up;
+            }
+            const int owner = mark > 0 ? mark - 1 : 0;
+            const int k = lane - __shfl(off, owner);
+            const int ra = __shfl(rA, owner);
+            const C otLo = wave_pull<C>(tLo, owner), osLo = wave_pull<C>(sLo, owner), osHi = wave_pull<C>(sHi, owner);
+            const int ofl = __shfl(fl, owner);
+            if (lane < m) {
+                const C lo = sD[ra + k], hi = sD[ra + k + 1] - 1;
+                const bool opposite = ((ofl & F_SREV) != 0) != ((ofl & F_TREV) != 0);
+                tLo = lo;
+                tHi = hi;
+                if (!opposite) { // the source side sliced in lock-step (MappedSegment::slice, halMappedSegment.cpp:395-402)
+                    sLo = osLo + (lo - otLo);
+                    sHi = osLo + (hi - otLo);
+                } else {
+                    sLo = osHi - (hi - otLo);
+                    sHi = osHi - (lo - otLo);
+                }
+                fl = ofl;
+            } else {
+                tLo = tHi = sLo = sHi = 0;
+                fl = 0;
+            }
+            wave_lds_fence();
+            n = m;
+            wave_sort_pieces<C>(lane, n, tLo, tHi, sLo, sHi, fl);
+        }
+    }
+    {   // equal keys: the set keeps one
+        const C pTLo = lane_prev(tLo), pTHi = lane_prev(tHi), pSLo = lane_prev(sLo), pSHi = lane_prev(sHi);
+        const bool dup = lane > 0 && lane < n && tLo == pTLo && tHi == pTHi && sLo == pSLo && sHi == pSHi;
+        if (__any(dup)) {
+            const unsigned long long keep = __ballot(lane < n && !dup);
+            // (the dropped lanes all aim at lane 63: with n <= 64 and at least one of them it is never a kept lane's place)
+            const int dest = (lane < n && !dup) ? (int)__popcll(keep & ((1ull << lane) - 1ull)) : 63;
+            tLo = wave_push<C>(tLo, dest);
+            tHi = wave_push<C>(tHi, dest);
+            sLo = wave_push<C>(sLo, dest);
+            sHi = wave_push<C>(sHi, dest);
+            fl = __builtin_amdgcn_ds_permute(dest << 2, fl);
+            n = (int)__popcll(keep);
+        }
+    }
+    int seq = 0;
+    if (numSeq > 1 && lane < n) {
+        int lo = 0, hi = numSeq;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (seqStart[mid] <= (int64_t)tLo)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        seq = lo;
+    }
+    // ---- extractSegment over the set in target order (scalar control flow; finish_query has the LDS original) ----
+    unsigned long long alive = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+    C cutv = 0; // cut point c lives in lane c
+    int ncut = 0, nl = 0;
+    L.lStart = L.lEnd = L.lSrc = 0;
+    L.lSeq = L.lStrand = 0;
+    auto nextAlive = [&](int i) -> int { // first member of the set at or after i, or n
+        if (i >= n)
+            return n;
+        const unsigned long long mm = alive >> i;
+        return mm ? i + (__ffsll((long long)mm) - 1) : n;
+    };
+    auto T = [&](int x) { return wave_read<C>(tLo, x); };
+    auto H = [&](int x) { return wave_read<C>(tHi, x); };
+    auto SL = [&](int x) { return wave_read<C>(sLo, x); };
+    auto SH = [&](int x) { return wave_read<C>(sHi, x); };
+    auto FL = [&](int x) { return __builtin_amdgcn_readlane(fl, x); };
+    auto SQ = [&](int x) { return __builtin_amdgcn_readlane(seq, x); };
+    auto canMergeRight = [&](int a, int b) -> bool { // halMappedSegment.cpp:109-161 in forward coordinates
+        const int fa = FL(a), fb = FL(b);
+        if (((fa ^ fb) & (F_SREV | F_TREV)) != 0)
+            return false;
+        if (T(b) - H(a) != 1)
+            return false;
+        const bool same = ((fa & F_SREV) != 0) == ((fa & F_TREV) != 0);
+        const bool rOk = same ? (SL(b) - SH(a) == 1) : (SL(a) - SH(b) == 1);
+        if (!rOk)
+            return false;
+        const C cutPos = H(a);
+        return __ballot(lane < ncut && cutv == cutPos) == 0;
+    };
+    for (int i = nextAlive(0); i < n; i = nextAlive(i + 1)) {
+        int v1s = i, v1n = 1, back = i;
+        int nxt = nextAlive(i + 1);
+        while (nxt < n && T(back) == T(nxt)) {
+            back = nxt;
+            ++v1n;
+            nxt = nextAlive(nxt + 1);
+        }
+        int fragBack = i;
+        const int seqI = SQ(i);
+        while (nxt < n) {
+            const int v2s = nxt;
+            int v2n = 0, b2 = -1;
+            while (nxt < n && (v2n == 0 || T(b2) == T(nxt)) && v2n < v1n) {
+                b2 = nxt;
+                ++v2n;
+                nxt = nextAlive(nxt + 1);
+            }
+            bool can = v1n == v2n;
+            int a = v1s, b = v2s;
+            for (int c = 0; c < v1n && can; ++c) {
+                can = SQ(b) == seqI && canMergeRight(a, b);
+                a = nextAlive(a + 1);
+                b = nextAlive(b + 1);
+            }
+            if (!can)
+                break;
+            fragBack = v2s;
+            alive &= ~(1ull << v2s); // erased from the set (halBlockMapper.cpp:389-391)
+            v1s = v2s;
+            v1n = v2n;
+        }
+        if (v1n > 1) {
+            if (ncut == 64)
+                return false;
+            const C cp = H(fragBack);
+            if (lane == ncut)
+                cutv = cp;
+            ++ncut;
+        }
+        // halBlockLiftover.cpp:82-105
+        const C ti = T(i), tf = T(fragBack), hi_ = H(i), hf = H(fragBack), si = SL(i), sf = SL(fragBack);
+        const int fi = FL(i);
+        if (lane == nl) {
+            L.lStart = ti < tf ? ti : tf;
+            L.lEnd = (hi_ > hf ? hi_ : hf) + 1;
+            L.lSrc = si < sf ? si : sf;
+            L.lSeq = seqI;
+            L.lStrand = ((fi & F_DOT) ? '.' : ((fi & F_TREV) ? '-' : '+')) | ((fi & F_TREV) ? 0x80 : 0);
+        }
+        ++nl;
+    }
+    // stable sort of the lines by source start (halLiftover.cpp:90), again a rank by counting
+    int lrank = 0;
+    for (int j = 0; j < nl; ++j) {
+        const C js = wave_read<C>(L.lSrc, j);
+        lrank += (js < L.lSrc || (js == L.lSrc && j < lane)) ? 1 : 0;
+    }
+    L.rank = lrank;
+    L.nl = nl;
+    return true;
+}
+
+// k_general_wave: the general intervals of a single-pass run (hgx_lift_kernels.hpp), one wavefront each, from the unmerged
+// table of the whole path to finished records without a round trip of the pieces through HBM: the interval's records
+// (at most 64 in reach; k_locate_through's rule for which they are) are clipped in the lanes that loaded them, compacted,
+// finished by finish_wave and written to a slice of the grouped buffer reserved from the same segment counters
+// k_locate_through appends through.  offset[q] / nOut[q] then say where k_lift_merged finds them.  Intervals with more records
+// in reach, or that finish_wave passes on, go to restList for k_locate_through + k_finish_lds (+ k_finish_big).
+template <typename C>
+__global__ void __launch_bounds__(256) k_general_wave(const int64_t *__restrict__ gStart, const int64_t *__restrict__ gEnd,
+                                                      const uint8_t *__restrict__ strand, int64_t genomeLength,
+                                                      const uint32_t *__restrict__ coarse, const uint32_t *__restrict__ starts, int coarseShift,
+                                                      const ComposedRec<C> *__restrict__ recs, const uint32_t *__restrict__ qlist,
+                                                      const unsigned long long *__restrict__ qcount, const int64_t *__restrict__ seqStart,
+                                                      int numSeq, hgx_record *__restrict__ records, uint32_t cap,
+                                                      unsigned long long *segCounters, unsigned long long *counters, unsigned long long *kstat,
+                                                      uint32_t *__restrict__ offset, uint32_t *__restrict__ nOut, uint32_t *__restrict__ restList,
+                                                      unsigned long long *__restrict__ restCount) {
+    __shared__ C sDAll[4][128];
+    __shared__ uint8_t sOwnAll[4][64];
+    const int lane = lane_id(), w = (int)(threadIdx.x >> 6);
+    const uint32_t nlist = (uint32_t)*qcount;
+    // (everything that steers control flow is made wave-uniform explicitly, so that the loops compile to scalar branches)
+    const uint32_t wavesTotal = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    const uint32_t seg = blockIdx.x % NSEG, segCap = cap / NSEG;
+    unsigned long long *segCount = segCounters + (size_t)seg * SEG_PITCH;
+    const int64_t ss0 = seqStart[0];
+    uint32_t used = 0;
+    for (uint32_t k = wave; k < nlist; k += wavesTotal) {
+        const uint32_t q = (uint32_t)__builtin_amdgcn_readfirstlane((int)qlist[k]);
+        const int64_t gs = gStart[q], ge = gEnd[q];
+        const uint8_t st = strand[q];
+        const int64_t geIn = ge < genomeLength ? ge : genomeLength - 1;
+        const uint32_t k0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)coarse[gs >> coarseShift]);
+        const uint32_t kEnd = (uint32_t)__builtin_amdgcn_readfirstlane((int)starts[(geIn >> coarseShift) + 1]);
+        bool pass = kEnd > k0 + 64u;
+        int n = 0;
+        C tLo = 0, tHi = 0, sLo = 0, sHi = 0;
+        int fl = 0;
+        if (!pass) {
+            bool have = false;
+            if (k0 + (uint32_t)lane < kEnd) {
+                const ComposedRec<C> r = recs[k0 + (uint32_t)lane];
+                const int64_t pLo = (int64_t)r.sLo, pHi = pLo + (int64_t)r.len - 1;
+                if (pLo <= ge && pHi >= gs) { // clipped to the interval (k_locate_through)
+                    const int64_t c = pLo > gs ? pLo : gs, d = pHi < ge ? pHi : ge;
+                    const int64_t len = d - c + 1, delta = c - pLo;
+                    have = true;
+                    sLo = (C)c;
+                    sHi = (C)d;
+                    tLo = (C)((int64_t)r.so + ((r.mEncF & 1u) ? (int64_t)r.len - delta - len : delta));
+                    tHi = (C)((int64_t)tLo + len - 1);
+                    fl = (int)((((r.mEncF & 1u) ? F_TREV : 0u) | (st == '.' ? (uint32_t)F_DOT : 0u)) ^ (st == '-' ? (uint32_t)(F_SREV | F_TREV) : 0u));
+                }
+            }
+            const unsigned long long hm = __ballot(have);
+            n = (int)__popcll(hm);
+            used += have ? 1u : 0u;
+            if (n > 0 && hm != (n >= 64 ? ~0ull : ((1ull << n) - 1ull))) { // close the gaps (the ones left out aim at lane 63, which is free then)
+                const int dest = have ? (int)__popcll(hm & ((1ull << lane) - 1ull)) : 63;
+                tLo = wave_push<C>(tLo, dest);
+                tHi = wave_push<C>(tHi, dest);
+                sLo = wave_push<C>(sLo, dest);
+                sHi = wave_push<C>(sHi, dest);
+                fl = __builtin_amdgcn_ds_permute(dest << 2, fl);
+            }
+        }
+        if (!pass && n == 0) {
+            if (lane == 0) {
+                nOut[q] = 0;
+                offset[q] = 0;
+            }
+            continue;
+        }
+        WaveLines<C> L;
+        L.nl = 0;
+        if (!pass)
+            pass = !finish_wave<C>(lane, n, tLo, tHi, sLo, sHi, fl, seqStart, numSeq, sDAll[w], sOwnAll[w], L);
+        if (pass) {
+            if (lane == 0)
+                restList[atomicAdd(restCount, 1ull)] = q;
+            continue;
+        }
+        // a slice of the grouped buffer for the records
+        unsigned long long b = 0;
+        if (lane == 0)
+            b = atomicAdd(segCount, (unsigned long long)L.nl);
+        b = __shfl(b, 0);
+        if (b + (unsigned long long)L.nl > segCap) { // the retry sizes the buffers from the counters
+            if (lane == 0) {
+                counters[CNT_OVERFLOW] = 1;
+                nOut[q] = 0;
+                offset[q] = 0;
+            }
+            continue;
+        }
+        const uint32_t base = seg * segCap + (uint32_t)b;
+        if (lane < L.nl) {
+            hgx_record r;
+            const int64_t ss = numSeq > 1 ? seqStart[L.lSeq] : ss0;
+            r.query = (int64_t)q;
+            r.tgt_start = (int64_t)L.lStart - ss;
+            r.tgt_end = (int64_t)L.lEnd - ss;
+            r.src_start = (int64_t)L.lSrc;
+            r.tgt_seq = L.lSeq;
+            r.strand = (char)(L.lStrand & 0x7F);
+            r.tgt_reversed = (uint8_t)((L.lStrand >> 7) & 1);
+            r._pad[0] = r._pad[1] = 0;
+            records[base + (uint32_t)L.rank] = r;
+        }
+        if (lane == 0) {
+            nOut[q] = (uint32_t)L.nl;
+            offset[q] = base;
+        }
+    }
+    stat_add(&kstat[0], used);
+    stat_add(&counters[CNT_DSTAT0 + STAT_MAPPED], used);
+}
+
 } // namespace hgx

@@ -598,21 +598,37 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
     hipLaunchKernelGGL(k_lift_gather, dim3(std::min<uint32_t>(cGrid, 256)), dim3(256), 0, s, (const uint32_t *)P.liftBlockList.p,
                        (const uint32_t *)P.liftBlockCount.p, cGrid, chunk, generalList, generalCount);
     P.timer.end(s);
-    // the general intervals: pieces from the unmerged table, grouped by interval, then the general finishing kernel
+    // the general intervals: look-up, clipping and the general algorithm in registers, a wavefront per interval
+    // (k_general_wave); what it cannot hold — more than 64 pieces — goes the old way: pieces from the unmerged table grouped
+    // by interval, the LDS finishing kernel, and k_finish_big behind it.  HGX_FINISH_WAVE=0: everything the old way.
+    uint32_t *restList = generalList + nq;
+    unsigned long long *restCount = generalCount + 1;
+    const bool waveFinish = !(getenv("HGX_FINISH_WAVE") && getenv("HGX_FINISH_WAVE")[0] == '0');
+    if (waveFinish) {
+        HIP_OK(hipMemsetAsync(restCount, 0, 8, s));
+        P.timer.begin("k_general_wave", s, launch);
+        hipLaunchKernelGGL((k_general_wave<C>), dim3(512), dim3(256), 0, s, dS, dE, dStrand, srcLength, (const uint32_t *)T.coarse,
+                           (const uint32_t *)T.starts, T.shift, (const ComposedRec<C> *)T.recs, (const uint32_t *)generalList,
+                           (const unsigned long long *)generalCount, (const int64_t *)TG.seqStart, (int)TG.numSeq, (hgx_record *)P.grouped.p, cap,
+                           cnt + CNT_FRONT0, cnt, kstat(), (uint32_t *)P.offset.p, (uint32_t *)P.nOut.p, restList, restCount);
+        P.timer.end(s);
+        ++launch;
+    }
+    const uint32_t *lateList = waveFinish ? restList : generalList;
+    const unsigned long long *lateCount = waveFinish ? restCount : generalCount;
     P.timer.begin("k_locate_through", s, launch);
     // (the list's length is only known on the device; the grids are sized for a list that is a small part of the batch)
     hipLaunchKernelGGL((k_locate_through<C>), dim3(std::min(512, residentGrid(k_locate_through<C>))), dim3(256), 0, s, dS, dE, dStrand, nq, srcLength,
                        (const uint32_t *)T.coarse, (const uint32_t *)T.starts, T.shift, (const ComposedRec<C> *)T.recs, P.mapped(1), cap,
-                       cnt + CNT_FRONT0, cnt, kstat(), (uint32_t *)P.offset.p, (uint32_t *)P.perQuery.p, (const uint32_t *)generalList,
-                       (const unsigned long long *)generalCount);
+                       cnt + CNT_FRONT0, cnt, kstat(), (uint32_t *)P.offset.p, (uint32_t *)P.perQuery.p, lateList, lateCount);
     P.timer.end(s);
     ++launch;
     HIP_OK(hipEventRecord(P.evWalk, s));
     P.timer.begin("k_finish_lds", s);
     hipLaunchKernelGGL((k_finish_lds<C, 256>), dim3(std::min<uint32_t>(std::max<uint32_t>(nq, 1), 1536u)), dim3(64), 0, s, P.mapped(1),
-                       (const uint32_t *)P.offset.p, (const uint32_t *)P.perQuery.p, (const uint32_t *)generalList,
-                       (const unsigned long long *)generalCount, (const int64_t *)TG.seqStart, (int)TG.numSeq, (hgx_record *)P.grouped.p,
-                       (uint32_t *)P.nOut.p, (uint32_t *)P.deferredList.p, (uint32_t *)P.needCap.p, cnt, 0);
+                       (const uint32_t *)P.offset.p, (const uint32_t *)P.perQuery.p, lateList, lateCount, (const int64_t *)TG.seqStart,
+                       (int)TG.numSeq, (hgx_record *)P.grouped.p, (uint32_t *)P.nOut.p, (uint32_t *)P.deferredList.p, (uint32_t *)P.needCap.p,
+                       cnt, 0);
     P.timer.end(s);
     if (P.liftBigSlots) { // intervals k_finish_lds deferred: same algorithm on global scratch; their records become slices behind the grouped buffer
         P.timer.begin("k_finish_big", s);
