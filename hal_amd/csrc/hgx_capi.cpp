@@ -87,8 +87,16 @@ int hgx_builder_add_genome(hgx_builder *b, const char *name, const char *parent_
     } else if (!img.genomes.empty()) {
         throw std::runtime_error("only the first genome added may be the root");
     }
+    if (num_sequences < 0 || num_top < 0 || num_bottom < 0 || num_children < 0)
+        throw std::runtime_error("hgx_builder_add_genome: negative count");
+    if ((num_sequences > 0 && (!seq_names || !seq_lengths)) ||
+        (num_top > 0 && (!top_start || !top_parent_index || !top_parent_reversed || !top_next_paralogy)) || (num_bottom > 0 && !bottom_start) ||
+        (num_children > 0 && num_bottom > 0 && (!child_index || !child_reversed)))
+        throw std::runtime_error("hgx_builder_add_genome: null array");
     int64_t pos = 0, ti = 0, bi = 0;
     for (int64_t s = 0; s < num_sequences; ++s) {
+        if (!seq_names[s] || seq_lengths[s] < 0 || (seq_num_top && seq_num_top[s] < 0) || (seq_num_bottom && seq_num_bottom[s] < 0))
+            throw std::runtime_error("hgx_builder_add_genome: bad sequence entry");
         SeqInfo S;
         S.name = seq_names[s];
         S.start = pos;
@@ -102,6 +110,8 @@ int hgx_builder_add_genome(hgx_builder *b, const char *name, const char *parent_
         bi += S.numBot;
         G.seqs.push_back(S);
     }
+    if ((seq_num_top && ti != num_top) || (seq_num_bottom && bi != num_bottom))
+        throw std::runtime_error("hgx_builder_add_genome: the sequences' segment counts do not add up to the genome's");
     G.totalLength = pos;
     G.numTop = num_top;
     G.numBot = num_bottom;
@@ -250,13 +260,21 @@ int hgx_liftover_batch(hgx_alignment *h, int src, int tgt, size_t n, const hgx_i
     if (!genomeOf(h, src) || !genomeOf(h, tgt))
         throw std::runtime_error("hgx_liftover_batch: genome id out of range");
     *out = nullptr;
-    liftoverBatchHostRaw(h, src, tgt, n, iv, defaultOpts(opts), [&](size_t nrec) {
-        *out = (hgx_record *)malloc(std::max<size_t>(1, nrec) * sizeof(hgx_record));
-        if (!*out)
-            throw std::runtime_error("out of memory");
-        *n_out = nrec;
-        return *out;
-    });
+    *n_out = 0;
+    try {
+        liftoverBatchHostRaw(h, src, tgt, n, iv, defaultOpts(opts), [&](size_t nrec) {
+            *out = (hgx_record *)malloc(std::max<size_t>(1, nrec) * sizeof(hgx_record));
+            if (!*out)
+                throw std::runtime_error("out of memory");
+            *n_out = nrec;
+            return *out;
+        });
+    } catch (...) { // (the copy from the device can still fail after the buffer was handed out)
+        free(*out);
+        *out = nullptr;
+        *n_out = 0;
+        throw;
+    }
     return HGX_OK;
     HGX_CATCH
 }
@@ -468,6 +486,10 @@ int hgx_column_rows(hgx_alignment *h, int ref, int64_t first, int64_t count, con
     static_assert(sizeof(hgx_column_row) == sizeof(ColumnRowHost), "row layouts must match");
     if (!h || !row_offset || !rows || !n_rows)
         throw std::runtime_error("hgx_column_rows: null argument");
+    if (!genomeOf(h, ref))
+        throw std::runtime_error("hgx_column_rows: reference genome id out of range");
+    if (count < 0 || first < 0)
+        throw std::runtime_error("hgx_column_rows: negative column range");
     std::vector<uint64_t> off;
     std::vector<ColumnRowHost> r;
     columnsRowsHost(h, ref, first, count, columnOptions(opts), !h->img.genomes[(size_t)ref].dna.empty(), off, r, nullptr);

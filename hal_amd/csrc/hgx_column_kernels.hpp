@@ -20,8 +20,8 @@ struct ColumnParams {
     int64_t count; // number of columns
     int64_t step;  // distance between consecutive columns (halAlignmentDepth --step)
     int32_t noDupes, noAncestors, onlyOrthologs;
-    unsigned long long scopeMask[4];  // genomes the walk may enter (all ones when no targets)
-    unsigned long long targetMask[4]; // genomes whose bases are reported
+    const unsigned long long *scopeMask;  // device, ceil(numGenomes / 64) words: genomes the walk may enter (all ones when no targets)
+    const unsigned long long *targetMask; // device: genomes whose bases are reported
     unsigned int *error;              // set to 1 on frame-stack overflow
     unsigned long long *derefs;       // optional {top, bottom} segment records logically dereferenced (roofline accounting)
 };
@@ -275,27 +275,40 @@ template <typename C, bool STATS = false> struct ColumnWalker {
 };
 
 // depth visitor: genomes seen (bit set) and bases seen
-struct DepthVisitor {
-    unsigned long long mask[4] = {0, 0, 0, 0};
+// (W words of 64 genomes: 4 for alignments of up to 256 genomes, 32 — in scratch — for up to 2048)
+template <int W> struct DepthVisitor {
+    unsigned long long mask[W];
     uint32_t bases = 0;
+    __device__ __forceinline__ DepthVisitor() {
+#pragma unroll
+        for (int i = 0; i < W; ++i)
+            mask[i] = 0;
+    }
     __device__ __forceinline__ void operator()(int g, int64_t, bool) {
         mask[g >> 6] |= 1ull << (g & 63);
         ++bases;
+    }
+    __device__ __forceinline__ int genomes() const {
+        int n = 0;
+#pragma unroll
+        for (int i = 0; i < W; ++i)
+            n += (int)__popcll(mask[i]);
+        return n;
     }
 };
 
 // halAlignmentDepth's per-column value (alignmentDepth/halAlignmentDepth.cpp:258-281): number of genomes with at
 // least one base in the column (or, with countDupes, number of bases) minus the reference base.
 // Also usable as the row-count pass of the MAF path (countDupes = 2: bases, without the -1).
-template <typename C, bool STATS>
+template <typename C, bool STATS, int W = 4>
 __global__ void __launch_bounds__(256) k_column_depth(ColumnParams P, int countMode, int32_t *__restrict__ out) {
     ColumnWalker<C, STATS> w(P);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P.count; i += (int64_t)gridDim.x * blockDim.x) {
-        DepthVisitor v;
+        DepthVisitor<W> v;
         w.run(P.first + i * P.step, v);
         int32_t val;
         if (countMode == 0)
-            val = (int32_t)(__popcll(v.mask[0]) + __popcll(v.mask[1]) + __popcll(v.mask[2]) + __popcll(v.mask[3])) - 1;
+            val = (int32_t)v.genomes() - 1;
         else if (countMode == 1)
             val = (int32_t)v.bases - 1;
         else
@@ -420,9 +433,9 @@ struct LongRun { // a run too long for its lane to fill alone
 };
 static constexpr int64_t LANE_FILL_MAX = 256;
 
-__device__ __forceinline__ int32_t depth_value(const DepthVisitor &v, int countMode) {
+template <int W> __device__ __forceinline__ int32_t depth_value(const DepthVisitor<W> &v, int countMode) {
     if (countMode == 0)
-        return (int32_t)(__popcll(v.mask[0]) + __popcll(v.mask[1]) + __popcll(v.mask[2]) + __popcll(v.mask[3])) - 1;
+        return (int32_t)v.genomes() - 1;
     if (countMode == 1)
         return (int32_t)v.bases - 1;
     return (int32_t)v.bases;
@@ -440,7 +453,7 @@ template <typename W> __device__ __forceinline__ void ref_segment_bounds(const W
 }
 
 // out[i] for the columns first + i*step (i < count); segFirst .. segFirst+segCount-1 are the reference segments they lie in
-template <typename C, bool STATS>
+template <typename C, bool STATS, int W = 4>
 __global__ void __launch_bounds__(256) k_depth_runs(ColumnParams P, int countMode, int32_t segFirst, int64_t segCount, int32_t *__restrict__ out,
                                                     LongRun *__restrict__ longRuns, unsigned long long *__restrict__ longCount,
                                                     unsigned long long longCap) {
@@ -458,7 +471,7 @@ __global__ void __launch_bounds__(256) k_depth_runs(ColumnParams P, int countMod
                 p += P.step - r;
         }
         while (p <= end) {
-            DepthVisitor v;
+            DepthVisitor<W> v;
             w.runAt(s, p, v);
             const int32_t val = depth_value(v, countMode);
             const int64_t q = p + w.remain < end ? p + w.remain : end; // last column of the run (inside this segment)

@@ -47,16 +47,17 @@ struct Ev {
 };
 } // namespace
 
+// masks: device memory of the call that holds the scope and target bit sets (ceil(genomes / 64) words each)
 static ColumnParams makeParams(hgx_alignment *h, int ref, int64_t first, int64_t count, int64_t step, const ColumnOptions &opt,
-                               unsigned int *dErr) {
+                               unsigned int *dErr, Buf &masks) {
     if (!h->dev)
         throw std::runtime_error("alignment was opened without a device (device = -1); the column engine needs the HIP path");
     const Image &img = h->img;
     const int ng = (int)img.genomes.size();
     if (ref < 0 || ref >= ng)
         throw std::runtime_error("reference genome id out of range");
-    if (ng > 256)
-        throw std::runtime_error("alignments with more than 256 genomes are not supported by the column kernels yet");
+    if (ng > 2048)
+        throw std::runtime_error("alignments with more than 2048 genomes are not supported by the column kernels (the depth kernels keep a 2048-bit genome set per column)");
     const GenomeTables &R = img.genomes[(size_t)ref];
     if (count < 0 || step < 1 || first < 0 || (count > 0 && first + (count - 1) * step >= R.totalLength))
         throw std::runtime_error("column range out of bounds for genome " + R.name);
@@ -73,9 +74,10 @@ static ColumnParams makeParams(hgx_alignment *h, int ref, int64_t first, int64_t
     P.onlyOrthologs = opt.onlyOrthologs;
     P.error = dErr;
     P.derefs = nullptr;
+    const size_t words = ((size_t)ng + 63) / 64;
+    std::vector<unsigned long long> m(2 * words, 0ull); // scope, then targets
     if (opt.targets.empty()) {
-        for (int w = 0; w < 4; ++w)
-            P.scopeMask[w] = P.targetMask[w] = ~0ull;
+        std::fill(m.begin(), m.end(), ~0ull);
     } else {
         // halColumnIterator.cpp:45-51: targets + reference, scope = their spanning tree (halCommon.cpp:156-187)
         std::set<int> tg(opt.targets.begin(), opt.targets.end());
@@ -83,7 +85,7 @@ static ColumnParams makeParams(hgx_alignment *h, int ref, int64_t first, int64_t
         for (int g : tg) {
             if (g < 0 || g >= ng)
                 throw std::runtime_error("target genome id out of range");
-            P.targetMask[g >> 6] |= 1ull << (g & 63);
+            m[words + (size_t)(g >> 6)] |= 1ull << (g & 63);
         }
         int lca = *tg.begin();
         for (int g : tg)
@@ -96,16 +98,19 @@ static ColumnParams makeParams(hgx_alignment *h, int ref, int64_t first, int64_t
                     break;
             }
         for (int g : scope)
-            P.scopeMask[g >> 6] |= 1ull << (g & 63);
+            m[(size_t)(g >> 6)] |= 1ull << (g & 63);
     }
+    masks.resize(16 * words);
+    HIP_OK(hipMemcpy(masks.p, m.data(), 16 * words, hipMemcpyHostToDevice));
+    P.scopeMask = (const unsigned long long *)masks.p;
+    P.targetMask = (const unsigned long long *)masks.p + words;
     return P;
 }
 
 static const int COL_GRID = getenv("HGX_COL_GRID") ? atoi(getenv("HGX_COL_GRID")) : 2048;
 
-static bool perBaseColumns() {
-    static const bool v = getenv("HGX_COLUMNS_PER_BASE") != nullptr;
-    return v;
+static bool perBaseColumns() { // (looked at on every call: tests compare the two depth kernels inside one process)
+    return getenv("HGX_COLUMNS_PER_BASE") != nullptr;
 }
 
 // reference segments (top tiling, or bottom for a genome without one) holding positions firstPos .. lastPos
@@ -122,9 +127,12 @@ static void refSegmentRange(hgx_alignment *h, int ref, int64_t firstPos, int64_t
 }
 
 // the dereference counters cost ~10 % of the kernel, so they are a separate instantiation
+// (alignments of more than 256 genomes take the instantiation with a 2048-bit genome set per column)
 #define LAUNCH_DEPTH(K, CT, ...)                                                                                       \
     do {                                                                                                               \
-        if (countDerefs)                                                                                               \
+        if (P.numGenomes > 256)                                                                                        \
+            hipLaunchKernelGGL((K<CT, false, 32>), dim3(grid), dim3(256), 0, s, __VA_ARGS__);                          \
+        else if (countDerefs)                                                                                          \
             hipLaunchKernelGGL((K<CT, true>), dim3(grid), dim3(256), 0, s, __VA_ARGS__);                               \
         else                                                                                                           \
             hipLaunchKernelGGL((K<CT, false>), dim3(grid), dim3(256), 0, s, __VA_ARGS__);                              \
@@ -136,7 +144,8 @@ void columnsDepthDevice(hgx_alignment *h, int ref, int64_t first, int64_t count,
     hipStream_t s = (hipStream_t)stream;
     Buf err(4);
     HIP_OK(hipMemsetAsync(err.p, 0, 4, s));
-    ColumnParams P = makeParams(h, ref, first, count, step, opt, (unsigned int *)err.p);
+    Buf masks;
+    ColumnParams P = makeParams(h, ref, first, count, step, opt, (unsigned int *)err.p, masks);
     Buf der(16);
     if (stats && countDerefs) {
         HIP_OK(hipMemsetAsync(der.p, 0, 16, s));
@@ -224,7 +233,8 @@ void columnsRowsHost(hgx_alignment *h, int ref, int64_t first, int64_t count, co
     Buf dOff(((size_t)count + 1) * 8), dRows(total * sizeof(ColumnRow)), err(4);
     HIP_OK(hipMemcpy(dOff.p, rowOffset.data(), ((size_t)count + 1) * 8, hipMemcpyHostToDevice));
     HIP_OK(hipMemset(err.p, 0, 4));
-    ColumnParams P = makeParams(h, ref, first, count, 1, opt, (unsigned int *)err.p);
+    Buf masks;
+    ColumnParams P = makeParams(h, ref, first, count, 1, opt, (unsigned int *)err.p, masks);
     Ev a, b;
     HIP_OK(hipEventRecord(a.e, nullptr));
     const int grid = (int)std::min<int64_t>(COL_GRID, (count + 255) / 256);
@@ -250,6 +260,26 @@ void columnsRowsHost(hgx_alignment *h, int ref, int64_t first, int64_t count, co
 }
 
 // exclusive scan of n uint32 on the device (out[n] = total); scratch: (n / 1024 + 2) uint32
+// 64-bit total of a uint32 array (the scan below wraps at 2^32: callers check the chunk before they trust its offsets)
+static __global__ void __launch_bounds__(256) k_sum64(const uint32_t *__restrict__ in, uint32_t n, unsigned long long *total) {
+    unsigned long long s = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        s += in[i];
+    for (int o = 32; o > 0; o >>= 1)
+        s += __shfl_down(s, o);
+    if ((threadIdx.x & 63) == 0 && s)
+        atomicAdd(total, s);
+}
+static void checkRowTotal(const uint32_t *counts, uint32_t n) {
+    Buf t(8);
+    HIP_OK(hipMemset(t.p, 0, 8));
+    hipLaunchKernelGGL(k_sum64, dim3(256), dim3(256), 0, nullptr, counts, n, (unsigned long long *)t.p);
+    unsigned long long total = 0;
+    HIP_OK(hipMemcpy(&total, t.p, 8, hipMemcpyDeviceToHost));
+    if (total >= (1ull << 32))
+        throw ColumnChunkTooLarge();
+}
+
 static uint32_t deviceScan(const uint32_t *in, uint32_t n, uint32_t *out, uint32_t *blockSums) {
     const uint32_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
     hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(256), 0, nullptr, in, n, blockSums);
@@ -281,10 +311,12 @@ void columnsHeadRowsHost(hgx_alignment *h, int ref, int64_t first, int64_t count
     HIP_OK(hipEventRecord(e0.e, nullptr));
     // 1. rows per column, 2. offsets, 3. all rows (device only)
     columnsDepthDevice(h, ref, first, count, 1, 2, opt, (int32_t *)dCnt.p, nullptr, nullptr, false, true);
+    checkRowTotal((const uint32_t *)dCnt.p, n);
     const uint32_t totalRows = deviceScan((const uint32_t *)dCnt.p, n, (uint32_t *)dOff.p, (uint32_t *)dSums.p);
     Buf dRows((size_t)totalRows * sizeof(ColumnRow));
     HIP_OK(hipMemset(err.p, 0, 4));
-    ColumnParams P = makeParams(h, ref, first, count, 1, opt, (unsigned int *)err.p);
+    Buf masks;
+    ColumnParams P = makeParams(h, ref, first, count, 1, opt, (unsigned int *)err.p, masks);
     const int grid = (int)std::min<int64_t>(COL_GRID, (count + 255) / 256);
     if (h->dev->wide)
         hipLaunchKernelGGL((k_column_rows<int64_t, uint32_t>), dim3(grid), dim3(256), 0, nullptr, P, (const uint32_t *)dOff.p,

@@ -2,6 +2,7 @@
 #pragma once
 #include "../../include/hgx.h"
 #include "hgx_device.hpp"
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -18,6 +19,12 @@ struct ColumnRowHost { // mirrors ColumnRow of hgx_column_kernels.hpp
 struct ColumnOptions {
     bool noDupes = false, noAncestors = false, onlyOrthologs = false;
     std::vector<int> targets; // genome ids; empty = everything (halColumnIterator.cpp:45-51)
+};
+
+// thrown by columnsHeadRowsHost when a chunk of columns holds 2^32 rows or more (its offsets are 32-bit): the caller halves
+// the chunk and asks again
+struct ColumnChunkTooLarge : std::runtime_error {
+    ColumnChunkTooLarge() : std::runtime_error("a chunk of columns holds 2^32 rows or more") {}
 };
 
 struct ColumnStats {

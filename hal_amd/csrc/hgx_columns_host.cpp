@@ -539,11 +539,13 @@ void MafExport::convertSequence(std::ostream &mafStream, hgx_alignment *alignmen
         length = S.length - startPosition;
     if (length == 0)
         throw std::runtime_error("Cannot convert zero length sequence");
-    if (!_append && !_headerWritten) { // writeHeader (:15-23): only at the very start of the stream
+    // writeHeader (halMafExport.cpp:15-23) as the reference has it: whenever the stream's position is not past its start —
+    // once for a file or a string stream, before every sequence on a stream that cannot tell its position (a pipe: tellp()
+    // is -1, and hal2maf to stdout repeats the header per sequence and per --refTargets interval)
+    if (!_append && mafStream.tellp() <= std::streampos(0)) {
         mafStream << "##maf version=1 scoring=N/A\n"
                   << "# hal " << alignment->img.newick << std::endl
                   << std::endl;
-        _headerWritten = true;
     }
     ColumnOptions opt;
     opt.noDupes = _noDupes;
@@ -713,9 +715,19 @@ void MafExport::convertSequence(std::ostream &mafStream, hgx_alignment *alignmen
             ++appendCount;
         };
         for (int64_t done = 0; done < length;) {
-            const int64_t n = std::min<int64_t>((int64_t)chunkColumns, length - done);
+            int64_t n = std::min<int64_t>((int64_t)chunkColumns, length - done);
             const auto tFetch0 = std::chrono::steady_clock::now();
-            columnsHeadRowsHost(alignment, genome, first + done, n, opt, true, head, headOff, headRows, &stats);
+            for (;;) { // (a chunk's row offsets are 32-bit: very wide alignments get smaller chunks)
+                try {
+                    columnsHeadRowsHost(alignment, genome, first + done, n, opt, true, head, headOff, headRows, &stats);
+                    break;
+                } catch (const ColumnChunkTooLarge &) {
+                    if (n <= 1)
+                        throw;
+                    chunkColumns = (size_t)std::max<int64_t>(1, n / 2);
+                    n = (int64_t)chunkColumns;
+                }
+            }
             fetchSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - tFetch0).count();
             numHeads += headOff.size() - 1;
             size_t hk = 0;

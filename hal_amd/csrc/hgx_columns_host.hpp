@@ -23,7 +23,8 @@ class MafExport {
     void setNoAncestors(bool v) { _noAncestors = v; }
     void setUcscNames(bool v) { _ucscNames = v; }
     void setAppend(bool v) { _append = v; }
-    void setMaxBlockLength(int64_t v) { _maxBlockLength = v <= 0 ? INT64_MAX : v; }
+    // stored as it is, like MafBlock::setMaxLength (maf/inc/halMafBlock.h:133): with 0 (or less) every column starts a block
+    void setMaxBlockLength(int64_t v) { _maxBlockLength = v < 0 ? 0 : v; }
     void setOnlyOrthologs(bool v) { _onlyOrthologs = v; }
     void setKeepEmptyRefBlocks(bool v) { _keepEmptyRefBlocks = v; }
     void setMaxRefGap(int64_t v) { _maxRefGap = v; }
@@ -62,7 +63,7 @@ class MafExport {
     typedef std::multimap<Key, Entry *> Entries;
     typedef std::map<Key, std::vector<const ColumnRowHost *>> ColumnMap;
     bool _noDupes = false, _noAncestors = false, _ucscNames = true, _append = false, _onlyOrthologs = false, _keepEmptyRefBlocks = false,
-         _unique = false, _headerWritten = false;
+         _unique = false;
     int64_t _maxBlockLength = 1000, _maxRefGap = 0;
     Entries _entries;
     Entry *_reference = nullptr;

@@ -173,12 +173,11 @@ struct DeviceGenome {
 
 // Per-genome descriptor readable from device code (the column kernels walk the whole tree, so they need
 // every genome's tables, not just the two or three a liftover launch is given).
-static constexpr int MAX_CHILD_SLOTS = 16;
 struct GenomeDesc {
     const void *top;      // TopRec<C>[numTop+1]
     const void *bot;      // BotRec<C>[numBot+1]
-    const int32_t *child[MAX_CHILD_SLOTS];
-    int32_t childGenome[MAX_CHILD_SLOTS];
+    const int32_t *const *child; // [numChildren] child link arrays (a slice of DeviceImage::childPtrs: no limit on the child count)
+    const int32_t *childGenome;  // [numChildren] genome ids of the children (a slice of DeviceImage::childGenomes)
     const uint8_t *dna;   // nibble-packed bases, or null when the alignment carries no DNA
     const int64_t *seqStart;
     int64_t numTop, numBot, length;
@@ -190,6 +189,8 @@ struct DeviceImage {
     bool wide = false; // C == int64_t
     std::vector<DeviceGenome> genomes;
     GenomeDesc *desc = nullptr;          // device array, one per genome
+    const int32_t **childPtrs = nullptr; // device: every genome's child link arrays, one after the other
+    int32_t *childGenomes = nullptr;     // device: the children's genome ids, same order
     std::vector<uint8_t *> dna;          // device copies of the packed DNA (uploaded on first use)
     // composed tables: (source genome, ancestor, -1, -1) -> up table; (source, target, dupes, coalescence limit + 1) with
     // through = true -> table of the whole path

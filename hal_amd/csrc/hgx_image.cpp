@@ -1,5 +1,6 @@
 // HGX flat image I/O, Newick text, structural validation.  See hgx_image.hpp.
 #include "hgx_image.hpp"
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <functional>
@@ -54,10 +55,70 @@ std::string Image::buildNewick() const {
 
 void Image::validate() const {
     auto fail = [](const std::string &m) { throw std::runtime_error("invalid alignment image: " + m); };
+    // the tree first: every index below is used as a subscript (a corrupt file must end here, not in a crash, an
+    // out-of-bounds read on the device or a ring walk that never comes back)
+    const int ng = (int)genomes.size();
+    int roots = 0;
+    for (int gi = 0; gi < ng; ++gi) {
+        const GenomeTables &G = genomes[(size_t)gi];
+        if (G.parent < -1 || G.parent >= ng || G.parent == gi)
+            fail(G.name + ": parent genome out of range");
+        roots += G.parent < 0 ? 1 : 0;
+        for (int c : G.children)
+            if (c < 0 || c >= ng || c == gi || genomes[(size_t)c].parent != gi)
+                fail(G.name + ": child genome out of range or not pointing back");
+        if (G.parent >= 0 && genomes[(size_t)G.parent].childSlotOf(gi) < 0)
+            fail(G.name + ": not a child of its parent");
+        if (G.numTop < 0 || G.numBot < 0 || G.totalLength < 0)
+            fail(G.name + ": negative size");
+    }
+    if (ng > 0 && roots != 1)
+        fail("the tree needs exactly one root genome");
+    for (int gi = 0; gi < ng; ++gi) { // no cycles: every genome reaches the root
+        int steps = 0;
+        for (int x = gi; x >= 0; x = genomes[(size_t)x].parent)
+            if (++steps > ng)
+                fail(genomes[(size_t)gi].name + ": parent links form a cycle");
+    }
     for (size_t gi = 0; gi < genomes.size(); ++gi) {
         const GenomeTables &G = genomes[gi];
         if ((int64_t)G.tStart.size() != G.numTop + 1 || (int64_t)G.bStart.size() != G.numBot + 1)
             fail(G.name + ": start table size");
+        if ((int64_t)G.tParent.size() != G.numTop || (int64_t)G.tParalogy.size() != G.numTop || (int64_t)G.tBotParse.size() != G.numTop ||
+            (int64_t)G.tParentRev.size() != G.numTop || (int64_t)G.bTopParse.size() != G.numBot)
+            fail(G.name + ": segment table size");
+        for (size_t k = 0; k < G.bChild.size(); ++k)
+            if ((int64_t)G.bChild[k].size() != G.numBot || k >= G.bChildRev.size() || (int64_t)G.bChildRev[k].size() != G.numBot)
+                fail(G.name + ": child link table size");
+        if (!G.dna.empty() && (int64_t)G.dna.size() != (G.totalLength + 1) / 2)
+            fail(G.name + ": DNA is not (length + 1) / 2 bytes");
+        if (G.parent < 0)
+            for (int64_t i = 0; i < G.numTop; ++i)
+                if (G.tParent[(size_t)i] != NULL_INDEX)
+                    fail(G.name + ": the root genome has a parent link");
+        // paralogy rings: in range for every top segment (with or without a parent link) and closed — following the links
+        // from any member comes back to it (the ring walks on the device have no other way to stop)
+        {
+            std::vector<uint8_t> seen((size_t)G.numTop, 0);
+            for (int64_t i = 0; i < G.numTop; ++i) {
+                const int64_t n = G.tParalogy[(size_t)i];
+                if (n == NULL_INDEX)
+                    continue;
+                if (n < 0 || n >= G.numTop)
+                    fail(G.name + ": paralogy index out of range");
+                if (seen[(size_t)i])
+                    continue;
+                int64_t x = i, steps = 0;
+                do {
+                    seen[(size_t)x] = 1;
+                    x = G.tParalogy[(size_t)x];
+                    if (x == NULL_INDEX || x < 0 || x >= G.numTop || ++steps > G.numTop)
+                        fail(G.name + ": paralogy ring is not closed");
+                } while (x != i && !seen[(size_t)x]);
+                if (x != i)
+                    fail(G.name + ": paralogy ring is not closed");
+            }
+        }
         if (G.numTop > 0 && (G.tStart[0] != 0 || G.tStart[(size_t)G.numTop] != G.totalLength))
             fail(G.name + ": top tiling does not cover the genome");
         if (G.numBot > 0 && (G.bStart[0] != 0 || G.bStart[(size_t)G.numBot] != G.totalLength))
@@ -116,14 +177,27 @@ void Image::validate() const {
             }
         }
         // halValidate.cpp:174-221: sequences tile the genome and own whole segments
-        int64_t pos = 0;
+        int64_t pos = 0, topAt = 0, botAt = 0;
         for (const SeqInfo &S : G.seqs) {
-            if (S.start != pos)
+            if (S.start != pos || S.length < 0)
                 fail(G.name + ": sequences not laid end to end");
+            if (S.numTop < 0 || S.numBot < 0 || S.topStart < 0 || S.botStart < 0 || S.topStart + S.numTop > G.numTop ||
+                S.botStart + S.numBot > G.numBot)
+                fail(G.name + ": sequence segment range out of bounds");
+            if (S.numTop > 0 && (S.topStart != topAt || G.tStart[(size_t)S.topStart] != S.start ||
+                                 G.tStart[(size_t)(S.topStart + S.numTop)] != S.start + S.length))
+                fail(G.name + ": top segments of sequence " + S.name + " do not tile it");
+            if (S.numBot > 0 && (S.botStart != botAt || G.bStart[(size_t)S.botStart] != S.start ||
+                                 G.bStart[(size_t)(S.botStart + S.numBot)] != S.start + S.length))
+                fail(G.name + ": bottom segments of sequence " + S.name + " do not tile it");
+            topAt += S.numTop;
+            botAt += S.numBot;
             pos += S.length;
         }
         if (pos != G.totalLength)
             fail(G.name + ": sequence lengths do not sum to the genome length");
+        if (!G.seqs.empty() && ((G.numTop > 0 && topAt != G.numTop) || (G.numBot > 0 && botAt != G.numBot)))
+            fail(G.name + ": segments outside every sequence");
     }
 }
 
@@ -254,20 +328,46 @@ Image readImage(const std::string &path) {
     if (memcmp(magic, "HGXIMG01", 8) != 0)
         throw std::runtime_error(path + ": not an HGX image");
     Image img;
+    // counts are checked against the file's size before anything is resized by them
+    int64_t fileSize = 0;
+    {
+        const long at = ftell(r.f);
+        fseek(r.f, 0, SEEK_END);
+        fileSize = (int64_t)ftell(r.f);
+        fseek(r.f, at, SEEK_SET);
+    }
+    auto sane = [&](int64_t n, int64_t bytesEach, const char *what) {
+        if (n < 0 || n > fileSize / std::max<int64_t>(1, bytesEach))
+            throw std::runtime_error(path + ": corrupt HGX image (" + what + ")");
+    };
     int64_t ng = r.s64();
+    sane(ng, 64, "genome count");
     img.newick = r.str();
     img.genomes.resize((size_t)ng);
     for (GenomeTables &G : img.genomes) {
         G.name = r.str();
-        G.parent = (int)r.s64();
+        const int64_t parent = r.s64();
+        if (parent < -1 || parent >= ng)
+            throw std::runtime_error(path + ": corrupt HGX image (parent genome)");
+        G.parent = (int)parent;
         int64_t nc = r.s64();
+        sane(nc, 8, "child count");
         G.children.resize((size_t)nc);
-        for (int &c : G.children)
-            c = (int)r.s64();
+        for (int &c : G.children) {
+            const int64_t v = r.s64();
+            if (v < 0 || v >= ng)
+                throw std::runtime_error(path + ": corrupt HGX image (child genome)");
+            c = (int)v;
+        }
         G.totalLength = r.s64();
         int64_t ns = r.s64();
         G.numTop = r.s64();
         G.numBot = r.s64();
+        sane(ns, 56, "sequence count");
+        sane(G.numTop, 33, "top segment count");
+        sane(G.numBot, 16, "bottom segment count");
+        if (G.totalLength < 0)
+            throw std::runtime_error(path + ": corrupt HGX image (genome length)");
         G.seqs.resize((size_t)ns);
         for (SeqInfo &S : G.seqs) {
             S.name = r.str();
@@ -292,6 +392,7 @@ Image readImage(const std::string &path) {
             r.a8(G.bChildRev[(size_t)k], (size_t)G.numBot);
         }
         int64_t nd = r.s64();
+        sane(nd, 1, "DNA size");
         r.a8(G.dna, (size_t)nd);
     }
     return img;

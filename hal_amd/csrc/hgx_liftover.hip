@@ -70,6 +70,10 @@ DeviceImage::~DeviceImage() {
     }
     if (desc)
         (void)hipFree(desc);
+    if (childPtrs)
+        (void)hipFree((void *)childPtrs);
+    if (childGenomes)
+        (void)hipFree(childGenomes);
     for (uint8_t *p : dna)
         if (p)
             (void)hipFree(p);
@@ -77,18 +81,32 @@ DeviceImage::~DeviceImage() {
 
 static void uploadDescs(const Image &img, DeviceImage &D) {
     std::vector<GenomeDesc> descs(img.genomes.size());
+    std::vector<const int32_t *> ptrs;
+    std::vector<int32_t> ids;
+    std::vector<size_t> firstChild(img.genomes.size());
+    for (size_t g = 0; g < img.genomes.size(); ++g) {
+        firstChild[g] = ptrs.size();
+        for (size_t k = 0; k < img.genomes[g].children.size(); ++k) {
+            ptrs.push_back(D.genomes[g].childEnc[k]);
+            ids.push_back(img.genomes[g].children[k]);
+        }
+    }
+    if (!D.childPtrs) {
+        HIP_OK(hipMalloc((void **)&D.childPtrs, std::max<size_t>(1, ptrs.size()) * sizeof(int32_t *)));
+        HIP_OK(hipMalloc((void **)&D.childGenomes, std::max<size_t>(1, ids.size()) * 4));
+    }
+    if (!ptrs.empty()) {
+        HIP_OK(hipMemcpy(D.childPtrs, ptrs.data(), ptrs.size() * sizeof(int32_t *), hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(D.childGenomes, ids.data(), ids.size() * 4, hipMemcpyHostToDevice));
+    }
     for (size_t g = 0; g < img.genomes.size(); ++g) {
         const GenomeTables &G = img.genomes[g];
         GenomeDesc &d = descs[g];
         memset(&d, 0, sizeof d);
         d.top = D.genomes[g].top;
         d.bot = D.genomes[g].bot;
-        if (G.children.size() > (size_t)MAX_CHILD_SLOTS)
-            throw std::runtime_error("genome " + G.name + " has more than 16 children; the column kernels support at most 16");
-        for (size_t k = 0; k < G.children.size(); ++k) {
-            d.child[k] = D.genomes[g].childEnc[k];
-            d.childGenome[k] = G.children[k];
-        }
+        d.child = (const int32_t *const *)(D.childPtrs + firstChild[g]);
+        d.childGenome = D.childGenomes + firstChild[g];
         d.dna = g < D.dna.size() ? D.dna[g] : nullptr;
         d.seqStart = D.genomes[g].seqStart;
         d.numTop = G.numTop;

@@ -249,7 +249,9 @@ int hgx_alignment_depth(hgx_alignment *h, int ref_genome, int ref_sequence, int6
 typedef struct hgx_maf_opts {
     int32_t no_dupes, no_ancestors, only_sequence_names, only_orthologs, keep_empty_ref_blocks;
     int32_t unique; /* --unique: a column is written once, by its left-most reference base (halColumnIterator.cpp:210-214) */
-    int64_t max_block_len; /* --maxBlockLen, default 1000 (halMafBlock.cpp:16); <= 0: unlimited */
+    int64_t max_block_len; /* --maxBlockLen; 0 = the default, 1000 (halMafBlock.cpp:16).  A negative value is what the
+                              reference makes of --maxBlockLen 0 (MafBlock::setMaxLength keeps the value, halMafBlock.h:133):
+                              every column starts a block; the hal2maf twin passes the option through unchanged */
 } hgx_maf_opts;
 int hgx_maf_export(hgx_alignment *h, int ref_genome, int ref_sequence, int64_t start, int64_t length, const hgx_maf_opts *opts,
                    const int32_t *targets, int32_t n_targets, char **out_text, size_t *out_len, char **err);

@@ -106,7 +106,7 @@ def simple_genome(name, parent, children, length, tops, bots, dna=None, seqname=
     return g
 
 
-def random_multiseq_alignment(seed, n_genomes=6, max_children=3, root_len=400, max_seqs=4):
+def random_multiseq_alignment(seed, n_genomes=6, max_children=3, root_len=400, max_seqs=4, root_children=0):
     """Independent random alignment generator for tests (not halRandGen): irregular segment lengths, several
     sequences per genome, inversions, insertions, deletions, duplications (paralogy rings).  Returns the genome
     dict list for write_hgx.  Invariants kept: segments never span sequences, child top segment length == parent
@@ -117,7 +117,7 @@ def random_multiseq_alignment(seed, n_genomes=6, max_children=3, root_len=400, m
     children = [[]]
     for g in range(1, n_genomes):
         cands = [p for p in range(g) if len(children[p]) < max_children]
-        p = rnd.choice(cands)
+        p = 0 if g <= root_children else rnd.choice(cands)  # (root_children: a star at the root, beyond max_children)
         parents.append(p)
         children.append([])
         children[p].append(g)

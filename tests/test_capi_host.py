@@ -71,6 +71,53 @@ def test_open_rejects_bad_files(hal, tmp_path):
         hal.Alignment.open(str(h5), device=-1)
 
 
+def test_corrupt_images_are_refused(hal, tmp_path):
+    """Every index an image carries is used as a subscript on the host or on the device: validate() must stop a corrupt image
+    (genome ids, table sizes, paralogy rings that do not close, DNA size, sequence / segment ownership) with an error."""
+    import copy
+    import halfix
+    good = halfix.random_multiseq_alignment(3, n_genomes=6)
+
+    def refused(mutate, match):
+        g = copy.deepcopy(good)
+        mutate(g)
+        p = str(tmp_path / "bad.hgx")
+        try:
+            halfix.write_hgx(p, g)
+        except Exception:
+            return  # the fixture writer itself cannot express it
+        with pytest.raises(hal.HgxError, match=match):
+            hal.Alignment.open(p, device=-1)
+
+    hal.Alignment.open(_write(tmp_path, good), device=-1)
+    ring_genome = next(i for i, x in enumerate(good) if any(v >= 0 for v in x["tParalogy"]))
+    ring_at = next(i for i, v in enumerate(good[ring_genome]["tParalogy"]) if v >= 0)
+
+    def break_ring(g):
+        t = g[ring_genome]["tParalogy"]
+        members, x = [ring_at], t[ring_at]
+        while x != ring_at:
+            members.append(x)
+            x = t[x]
+        t[members[-1]] = members[-1] if len(members) > 1 else -1  # the last member points at itself: the walk never returns to the start
+        if len(members) == 1:
+            t[ring_at] = ring_at + 10 ** 6
+    refused(break_ring, "paralogy")
+    refused(lambda g: g[2].__setitem__("parent", 17), "corrupt HGX image|parent genome")
+    refused(lambda g: g[1]["tParalogy"].__setitem__(0, 10 ** 9), "paralogy")
+    refused(lambda g: g[1].__setitem__("dna", g[1]["dna"][:-4]), "DNA")
+    refused(lambda g: g[3]["tParent"].__setitem__(0, 10 ** 7), "invalid alignment image")
+    child = next(i for i, x in enumerate(good) if x["parent"] == 0)
+    refused(lambda g: g[0]["children"].remove(child), "invalid alignment image")
+
+
+def _write(tmp_path, genomes):
+    import halfix
+    p = str(tmp_path / "ok.hgx")
+    halfix.write_hgx(p, genomes)
+    return p
+
+
 def _real_mmap(tmp_path):
     raw = bz2.decompress(open(os.path.join(GOLD, "ref_mmap", "small.mmap1.0.hal.bz2"), "rb").read())
     p = tmp_path / "small.mmap1.0.hal"
