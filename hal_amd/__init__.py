@@ -12,5 +12,6 @@ from .api import (  # noqa: F401
     Record,
     RandOptions,
     liftover_convert,
+    liftover_convert_bytes,
     RECORD_DTYPE,
 )

@@ -394,16 +394,16 @@ int hgx_liftover_convert(hgx_alignment *h, int src, const char *bed_text, size_t
                          int out_psl, int out_psl_with_name, int coalescence_limit, char **out_text, size_t *out_len, char **err) {
     // Output produced before a failing input line is still returned (the reference has already written it
     // to the stream when it throws, halBedScanner.cpp:49-58).
-    std::ostringstream os;
+    std::string text;
     int rc = HGX_OK;
     try {
         if (!h || !out_text || !out_len || (bed_len && !bed_text))
             throw std::runtime_error("hgx_liftover_convert: null argument");
         if (!genomeOf(h, src) || !genomeOf(h, tgt))
             throw std::runtime_error("hgx_liftover_convert: genome id out of range");
-        std::istringstream is(std::string(bed_text ? bed_text : "", bed_len));
         Liftover lo;
-        lo.convert(h, src, &is, tgt, &os, bed_type, traverse_dupes != 0, out_psl != 0, out_psl_with_name != 0, coalescence_limit);
+        lo.convertBuffer(h, src, bed_text ? bed_text : "", bed_len, tgt, &text, bed_type, traverse_dupes != 0, out_psl != 0, out_psl_with_name != 0,
+                         coalescence_limit);
     } catch (std::exception &e) {
         setErr(err, e.what());
         rc = HGX_ERR;
@@ -412,11 +412,10 @@ int hgx_liftover_convert(hgx_alignment *h, int src, const char *bed_text, size_t
         rc = HGX_ERR;
     }
     if (out_text && out_len) {
-        const std::string s = os.str();
-        *out_text = (char *)malloc(s.size() + 1);
+        *out_text = (char *)malloc(text.size() + 1);
         if (*out_text) {
-            memcpy(*out_text, s.c_str(), s.size() + 1);
-            *out_len = s.size();
+            memcpy(*out_text, text.c_str(), text.size() + 1);
+            *out_len = text.size();
         } else {
             *out_len = 0;
             rc = HGX_ERR;

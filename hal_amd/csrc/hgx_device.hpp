@@ -228,5 +228,16 @@ struct hgx_alignment {
         hgx_liftover_plan *plan = nullptr;
     } cachedPlan;
     std::mutex planMutex;
+    // pinned host staging of the text path (Liftover::convert): genome coordinates and strands of a batch on the way in, its
+    // records on the way out, and the device copy of the former; grown on demand, freed with the alignment
+    struct Stage {
+        int64_t *gs = nullptr, *ge = nullptr;
+        uint8_t *st = nullptr;
+        size_t capQ = 0;
+        hgx_record *recs = nullptr;
+        size_t capR = 0;
+        void *dS = nullptr, *dE = nullptr, *dT = nullptr;
+        size_t capD = 0;
+    } stage;
     ~hgx_alignment();
 };

@@ -1739,6 +1739,20 @@ static void runHostArrays(hgx_liftover_plan *P, const std::vector<int64_t> &gs, 
 hgx_alignment::~hgx_alignment() {
     if (cachedPlan.plan)
         hgx::destroyLiftoverPlan(cachedPlan.plan);
+    if (stage.gs)
+        (void)hipHostFree(stage.gs);
+    if (stage.ge)
+        (void)hipHostFree(stage.ge);
+    if (stage.st)
+        (void)hipHostFree(stage.st);
+    if (stage.recs)
+        (void)hipHostFree(stage.recs);
+    if (stage.dS)
+        (void)hipFree(stage.dS);
+    if (stage.dE)
+        (void)hipFree(stage.dE);
+    if (stage.dT)
+        (void)hipFree(stage.dT);
 }
 
 namespace hgx {
@@ -1803,6 +1817,80 @@ void liftoverBatchHostRaw(hgx_alignment *h, int src, int tgt, size_t n, const hg
     std::vector<uint8_t> st;
     intervalsToGenomeCoordinates(h->img.genomes[(size_t)src], n, iv, gs, ge, st);
     runHostArraysInto(P, gs, ge, st, alloc);
+}
+
+void liftoverStageQueries(hgx_alignment *h, size_t n, int64_t **gs, int64_t **ge, uint8_t **strand) {
+    if (!h->dev)
+        throw std::runtime_error("alignment was opened without a device (device = -1); liftover needs the HIP path");
+    HIP_OK(hipSetDevice(h->dev->device));
+    hgx_alignment::Stage &S = h->stage;
+    if (n > S.capQ) {
+        const size_t cap = std::max<size_t>(n + n / 4, 1u << 16);
+        if (S.gs)
+            (void)hipHostFree(S.gs);
+        if (S.ge)
+            (void)hipHostFree(S.ge);
+        if (S.st)
+            (void)hipHostFree(S.st);
+        S.gs = S.ge = nullptr;
+        S.st = nullptr;
+        S.capQ = 0;
+        HIP_OK(hipHostMalloc((void **)&S.gs, 8 * cap));
+        HIP_OK(hipHostMalloc((void **)&S.ge, 8 * cap));
+        HIP_OK(hipHostMalloc((void **)&S.st, cap));
+        S.capQ = cap;
+    }
+    *gs = S.gs;
+    *ge = S.ge;
+    *strand = S.st;
+}
+
+void liftoverBatchStaged(hgx_alignment *h, int src, int tgt, size_t n, const hgx_liftover_opts &opts, const hgx_record **recs, size_t *nRecs,
+                         hgx_liftover_stats *stats) {
+    std::lock_guard<std::mutex> lock(h->planMutex);
+    hgx_alignment::Stage &S = h->stage;
+    if (n > S.capQ)
+        throw std::runtime_error("liftoverBatchStaged: more intervals than were staged");
+    hgx_liftover_plan *P = cachedPlanFor(h, src, tgt, opts, n);
+    HIP_OK(hipSetDevice(h->dev->device));
+    if (n > S.capD) {
+        if (S.dS)
+            (void)hipFree(S.dS);
+        if (S.dE)
+            (void)hipFree(S.dE);
+        if (S.dT)
+            (void)hipFree(S.dT);
+        S.dS = S.dE = S.dT = nullptr;
+        S.capD = 0;
+        HIP_OK(hipMalloc(&S.dS, 8 * S.capQ));
+        HIP_OK(hipMalloc(&S.dE, 8 * S.capQ));
+        HIP_OK(hipMalloc(&S.dT, S.capQ));
+        S.capD = S.capQ;
+    }
+    hipStream_t s = nullptr;
+    HIP_OK(hipMemcpyAsync(S.dS, S.gs, 8 * n, hipMemcpyHostToDevice, s));
+    HIP_OK(hipMemcpyAsync(S.dE, S.ge, 8 * n, hipMemcpyHostToDevice, s));
+    HIP_OK(hipMemcpyAsync(S.dT, S.st, n, hipMemcpyHostToDevice, s));
+    const hgx_record *dOut = nullptr;
+    size_t nOut = 0;
+    runLiftoverPlan(P, n, (const int64_t *)S.dS, (const int64_t *)S.dE, (const uint8_t *)S.dT, s, &dOut, &nOut);
+    if (nOut > S.capR) {
+        if (S.recs)
+            (void)hipHostFree(S.recs);
+        S.recs = nullptr;
+        S.capR = 0;
+        const size_t cap = nOut + nOut / 4;
+        HIP_OK(hipHostMalloc((void **)&S.recs, sizeof(hgx_record) * cap));
+        S.capR = cap;
+    }
+    if (nOut) {
+        HIP_OK(hipMemcpyAsync(S.recs, dOut, sizeof(hgx_record) * nOut, hipMemcpyDeviceToHost, s));
+        HIP_OK(hipStreamSynchronize(s));
+    }
+    *recs = S.recs;
+    *nRecs = nOut;
+    if (stats)
+        *stats = P->stats;
 }
 
 void blockMapHost(hgx_alignment *h, int ref, int query, int64_t absFirst, int64_t absLast, bool targetReversed,

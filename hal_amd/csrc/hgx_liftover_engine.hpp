@@ -24,6 +24,12 @@ void liftoverBatchHost(hgx_alignment *h, int src, int tgt, size_t n, const hgx_i
 // same, the records copied from the device straight into the memory alloc(n) returns
 void liftoverBatchHostRaw(hgx_alignment *h, int src, int tgt, size_t n, const hgx_interval *iv, const hgx_liftover_opts &opts,
                           const std::function<hgx_record *(size_t)> &alloc);
+// The text path's batch: pinned arrays for n intervals' inclusive genome coordinates and strands (empty interval: start 0,
+// end -1) ...
+void liftoverStageQueries(hgx_alignment *h, size_t n, int64_t **gs, int64_t **ge, uint8_t **strand);
+// ... and the run over what was written into them: *recs (pinned, owned by the alignment, valid until the next staged run)
+void liftoverBatchStaged(hgx_alignment *h, int src, int tgt, size_t n, const hgx_liftover_opts &opts, const hgx_record **recs, size_t *nRecs,
+                         hgx_liftover_stats *stats);
 // BlockMapper::init + map + getMap without adjacencies (liftover/impl/halBlockMapper.cpp:33-110)
 void blockMapHost(hgx_alignment *h, int ref, int query, int64_t absFirst, int64_t absLast, bool targetReversed,
                   const hgx_liftover_opts &opts, std::vector<hgx_record> &out);

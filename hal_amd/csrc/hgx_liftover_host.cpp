@@ -42,6 +42,8 @@ void BedLine::parse(const std::string &lineBuffer, int type) {
         throw std::runtime_error("Expected at least three columns in BED record: " + lineBuffer);
     if (bedType == 0)
         bedType = std::min(int(row.size()), 12);
+    if ((size_t)bedType > row.size()) // (an explicit --bedType beyond the line's columns: the reference indexes past its row here)
+        throw std::runtime_error("Expected at least " + std::to_string(bedType) + " columns in BED record: " + lineBuffer);
     chrName = row[0];
     start = strToInt(row[1]);
     end = strToInt(row[2]);
@@ -371,6 +373,45 @@ static void pslCounts(const GenomeTables &S, const GenomeTables &T, int64_t sLo,
 
 void Liftover::convert(hgx_alignment *al, int srcGenome, std::istream *in, int tgtGenome, std::ostream *out, int bedType,
                        bool traverseDupes, bool outPSL, bool outPSLWithName, int coalescenceLimit) {
+    if (in->bad())
+        throw std::runtime_error("Error reading bed input stream");
+    // the whole input in memory: the common shapes are parsed, lifted and printed by all cores at once
+    std::string text((std::istreambuf_iterator<char>(*in)), std::istreambuf_iterator<char>());
+    std::string lifted;
+    try {
+        convertBuffer(al, srcGenome, text.data(), text.size(), tgtGenome, &lifted, bedType, traverseDupes, outPSL, outPSLWithName, coalescenceLimit);
+    } catch (...) { // what was lifted before the failing line has been written by then in the reference, too
+        out->write(lifted.data(), (std::streamsize)lifted.size());
+        throw;
+    }
+    out->write(lifted.data(), (std::streamsize)lifted.size());
+}
+
+void Liftover::convertBuffer(hgx_alignment *al, int srcGenome, const char *text, size_t len, int tgtGenome, std::string *out, int bedType,
+                             bool traverseDupes, bool outPSL, bool outPSLWithName, int coalescenceLimit) {
+    out->clear();
+    if (!(outPSL || outPSLWithName) && !getenv("HGX_TEXT_GENERAL")) {
+        std::string error;
+        _missedSet.clear();
+        if (liftoverTextFast(al, srcGenome, text, len, tgtGenome, bedType, traverseDupes, coalescenceLimit, *out, error, _missedSet, lastStats)) {
+            if (!error.empty())
+                throw std::runtime_error(error);
+            return;
+        }
+    }
+    std::istringstream is(std::string(text, len));
+    std::ostringstream os;
+    try {
+        convertGeneral(al, srcGenome, &is, tgtGenome, &os, bedType, traverseDupes, outPSL, outPSLWithName, coalescenceLimit);
+    } catch (...) {
+        *out = os.str();
+        throw;
+    }
+    *out = os.str();
+}
+
+void Liftover::convertGeneral(hgx_alignment *al, int srcGenome, std::istream *in, int tgtGenome, std::ostream *out, int bedType,
+                              bool traverseDupes, bool outPSL, bool outPSLWithName, int coalescenceLimit) {
     _outPSL = outPSL || outPSLWithName; // halLiftoverMain.cpp:82-84
     _outPSLWithName = outPSLWithName;
     const GenomeTables &S = al->img.genomes[(size_t)srcGenome];

@@ -53,11 +53,19 @@ class Liftover {
     void convert(hgx_alignment *alignment, int srcGenome, std::istream *inBedStream, int tgtGenome, std::ostream *outBedStream,
                  int bedType = 0, bool traverseDupes = true, bool outPSL = false, bool outPSLWithName = false,
                  int coalescenceLimit = -1);
+    // The same over text in memory; *out receives the lifted text (also what was written before a malformed line, which is
+    // then reported by an exception like convert's).  This is what hgx_liftover_convert calls: inputs of up to nine columns,
+    // the same number on every line, BED out, take the parallel path of hgx_liftover_text.cpp.
+    void convertBuffer(hgx_alignment *alignment, int srcGenome, const char *text, size_t len, int tgtGenome, std::string *out, int bedType = 0,
+                       bool traverseDupes = true, bool outPSL = false, bool outPSLWithName = false, int coalescenceLimit = -1);
     // intervals per device batch (memory bound only)
     size_t batchLines = 1u << 22;
     hgx_liftover_stats lastStats{};
 
   private:
+    // every shape of input: BED12 blocks, PSL output, lines of different column counts (one line at a time on the host)
+    void convertGeneral(hgx_alignment *alignment, int srcGenome, std::istream *inBedStream, int tgtGenome, std::ostream *outBedStream, int bedType,
+                        bool traverseDupes, bool outPSL, bool outPSLWithName, int coalescenceLimit);
     std::set<std::string> _missedSet;
     bool _outPSL = false, _outPSLWithName = false;
     char _inStrand = '+';
@@ -67,5 +75,9 @@ class Liftover {
     void flipBlocks(std::vector<BedLine> &lines) const;
     void computePSLInserts(std::vector<BedLine> &lines) const;
 };
+
+// hgx_liftover_text.cpp; false: not an input for the fast path (nothing was done)
+bool liftoverTextFast(hgx_alignment *al, int srcGenome, const char *text, size_t len, int tgtGenome, int bedType, bool traverseDupes,
+                      int coalescenceLimit, std::string &out, std::string &error, std::set<std::string> &missedSet, hgx_liftover_stats &stats);
 
 } // namespace hgx

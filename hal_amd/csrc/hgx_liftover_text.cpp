@@ -1,0 +1,403 @@
+// The text path of Liftover::convert (liftover/impl/halLiftover.cpp:23-92) for what halLiftover is mostly fed: BED files whose
+// lines all have the same number of columns, up to nine, lifted to BED.  One pass over the input buffer per stage, every stage
+// spread over the host's cores:
+//   1. the buffer is cut into chunks at line ends; every chunk is tokenised in place (no copies of lines or fields): sequence
+//      look-up, coordinates, strand, the numeric fields the output re-prints, and where the fields start that it echoes;
+//   2. the intervals go into pinned arrays in genome coordinates, one H2D copy, the kernels, one D2H copy of the records into
+//      pinned memory (liftoverBatchStaged);
+//   3. every chunk's output lines are rendered from its records into the chunk's own slice of the one output buffer.
+// Semantics are those of BedScanner::scan / BedLine::read / Liftover::visitLine / BedLine::write
+// (halBedScanner.cpp:40-61, halBedLine.cpp:27-151, halLiftover.cpp:46-92): blank space between lines is skipped and does not
+// count as a line, a line's fields are split at tabs (empty fields kept, a trailing tab adds none), integers read like
+// operator>> (leading blanks, optional sign, digits, the rest ignored), score / thick range / itemRgb are re-printed from
+// their values, every other field is echoed, skipped lines (unknown sequence, end past the sequence) produce nothing, and the
+// first malformed line ends the conversion with the reference's message after the lines before it have been written.
+// Anything else — BED12 lines, PSL output, files that mix column counts (the reference's line object then inherits fields from
+// earlier lines) — returns false and takes the general path of hgx_liftover_host.cpp.
+#include "hgx_liftover_host.hpp"
+#include <algorithm>
+#include <atomic>
+#include <charconv>
+#include <cstring>
+#include <iostream>
+#include <thread>
+#include <unordered_map>
+
+namespace hgx {
+
+namespace {
+
+struct Line {
+    const char *text;  // the line (without its newline)
+    uint32_t len;
+    uint32_t nameOff, nameLen;   // field 3
+    uint32_t extraOff, extraEnd; // the echoed fields after the parsed ones: text[extraOff, extraEnd); extraOff == NO_EXTRA: none
+    int32_t seq;                 // source sequence, or -1: skipped
+    int64_t start, end, score, thickStart, thickEnd, r, g, b;
+    char strand;
+    int64_t query;               // index of the interval in the batch, -1: skipped
+};
+
+constexpr uint32_t NO_EXTRA = 0xFFFFFFFFu;
+
+struct Chunk {
+    const char *begin, *end;
+    std::vector<Line> lines;
+    size_t numQueries = 0, firstQuery = 0, firstLine = 0;
+    std::string error;            // first malformed line of the chunk (then `lines` ends before it)
+    size_t errorLine = 0;         // its number inside the chunk, 1-based
+    size_t linesSeen = 0;
+    bool general = false;         // a line the fast path does not handle
+    int bedType = -1;             // column count of the chunk's lines
+    std::vector<std::string> notes; // what the reference writes to stderr, in order
+    std::string out;
+};
+
+inline bool isBlank(char c) { // std::isspace in the "C" locale
+    return c == ' ' || c == '\t' || c == '\n' || c == '\v' || c == '\f' || c == '\r';
+}
+
+// operator>>(int64) on a field: leading blanks, optional sign, digits; stops at the first other character
+bool readInt(const char *b, const char *e, int64_t &v) {
+    while (b < e && isBlank(*b))
+        ++b;
+    bool neg = false;
+    if (b < e && (*b == '+' || *b == '-')) {
+        neg = *b == '-';
+        ++b;
+    }
+    if (b >= e || *b < '0' || *b > '9')
+        return false;
+    uint64_t x = 0;
+    const uint64_t lim = neg ? (uint64_t)1 << 63 : ((uint64_t)1 << 63) - 1;
+    for (; b < e && *b >= '0' && *b <= '9'; ++b) {
+        const uint64_t d = (uint64_t)(*b - '0');
+        if (x > (lim - d) / 10)
+            return false; // out of range
+        x = x * 10 + d;
+    }
+    v = neg ? (int64_t)(0 - x) : (int64_t)x;
+    return true;
+}
+
+struct Fail {
+    std::string what;
+};
+
+inline int64_t intField(const char *b, const char *e) {
+    int64_t v;
+    if (!readInt(b, e, v))
+        throw Fail{"Error converting string to int: " + std::string(b, e)};
+    return v;
+}
+
+inline char *putInt(char *p, int64_t v) {
+    return std::to_chars(p, p + 24, v).ptr;
+}
+
+void parseChunk(Chunk &C, int forcedType, const std::unordered_map<std::string, int> &seqByName, const GenomeTables &S) {
+    const char *p = C.begin;
+    std::string key;
+    while (true) {
+        while (p < C.end && isBlank(*p)) // BedScanner::skipWhiteSpaces
+            ++p;
+        if (p >= C.end)
+            break;
+        const char *eol = (const char *)memchr(p, '\n', (size_t)(C.end - p));
+        if (!eol)
+            eol = C.end;
+        ++C.linesSeen;
+        Line L{};
+        L.text = p;
+        L.len = (uint32_t)(eol - p);
+        try {
+            // fields (chopString: empty fields kept, nothing after a trailing separator)
+            const char *fb[13], *fe[13];
+            int nf = 0;
+            const char *q = p;
+            bool moreFields = false; // more than twelve
+            while (q < eol) {
+                const char *t = (const char *)memchr(q, '\t', (size_t)(eol - q));
+                if (nf == 12) {
+                    moreFields = true;
+                    break;
+                }
+                fb[nf] = q;
+                fe[nf] = t ? t : eol;
+                ++nf;
+                if (!t)
+                    break;
+                q = t + 1;
+            }
+            auto whole = [&]() { return std::string(p, eol); };
+            if (nf < 3)
+                throw Fail{"Expected at least three columns in BED record: " + whole()};
+            const int bt = forcedType ? forcedType : nf; // (min(columns, 12): nf stops at twelve)
+            if (bt > 9 || bt == 7 || (C.bedType >= 0 && bt != C.bedType)) { // BED12, or fields inherited between lines: general path
+                C.general = true;
+                return;
+            }
+            C.bedType = bt;
+            if (bt > nf) // (the reference reads past the end of its row here)
+                throw Fail{"Expected at least " + std::to_string(bt) + " columns in BED record: " + whole()};
+            L.start = intField(fb[1], fe[1]);
+            L.end = intField(fb[2], fe[2]);
+            if (L.start >= L.end)
+                throw Fail{"Error zero or negative length BED range: " + whole()};
+            L.strand = '+';
+            if (bt > 3) {
+                L.nameOff = (uint32_t)(fb[3] - p);
+                L.nameLen = (uint32_t)(fe[3] - fb[3]);
+            }
+            if (bt > 4)
+                L.score = intField(fb[4], fe[4]);
+            if (bt > 5) {
+                L.strand = fb[5] < fe[5] ? *fb[5] : '\0';
+                if (L.strand != '.' && L.strand != '+' && L.strand != '-')
+                    throw Fail{"Strand character must be + or - or ." + whole()};
+            }
+            if (bt > 6)
+                L.thickStart = intField(fb[6], fe[6]);
+            if (bt > 7)
+                L.thickEnd = intField(fb[7], fe[7]);
+            if (bt > 8) {
+                const char *c1 = (const char *)memchr(fb[8], ',', (size_t)(fe[8] - fb[8]));
+                const char *c2 = c1 ? (const char *)memchr(c1 + 1, ',', (size_t)(fe[8] - c1 - 1)) : nullptr;
+                const char *c3 = c2 ? (const char *)memchr(c2 + 1, ',', (size_t)(fe[8] - c2 - 1)) : nullptr;
+                // chopString on ',': empty field, or more than three parts (a third comma followed by anything) is an error
+                if (fb[8] == fe[8] || (c3 && c3 + 1 < fe[8]))
+                    throw Fail{"Error parsing BED itemRGB: " + whole()};
+                L.r = intField(fb[8], c1 ? c1 : fe[8]);
+                L.g = L.b = L.r;
+                if (c1 && c1 + 1 < fe[8])
+                    L.g = intField(c1 + 1, c2 ? c2 : fe[8]);
+                if (c2 && c2 + 1 < fe[8])
+                    L.b = intField(c2 + 1, c3 ? c3 : fe[8]);
+            }
+            // the fields after the parsed ones are echoed as they are: from the start of field bt to the end of the last field
+            // (chopString: a tab at the very end of the line starts no field)
+            L.extraOff = NO_EXTRA;
+            if (bt < nf || moreFields) {
+                L.extraOff = (uint32_t)(fb[bt] - p);
+                L.extraEnd = (uint32_t)((eol[-1] == '\t' ? eol - 1 : eol) - p);
+            }
+            // Liftover::visitLine (halLiftover.cpp:52-66)
+            key.assign(fb[0], fe[0]);
+            auto it = seqByName.find(key);
+            L.seq = -1;
+            if (it == seqByName.end()) {
+                C.notes.push_back("?" + key);
+            } else if (L.end > S.seqs[(size_t)it->second].length) {
+                C.notes.push_back("Skipping interval with endpoint " + std::to_string(L.end) + "because sequence " + key + " has length " +
+                                  std::to_string(S.seqs[(size_t)it->second].length));
+            } else {
+                L.seq = it->second;
+                ++C.numQueries;
+            }
+        } catch (const Fail &f) {
+            C.error = f.what;
+            C.errorLine = C.linesSeen;
+            return;
+        }
+        C.lines.push_back(L);
+        p = eol < C.end ? eol + 1 : C.end;
+    }
+}
+
+// BedLine::write (halBedLine.cpp:104-151) with what BlockLiftover::liftInterval and Liftover::cleanResults substitute
+void renderChunk(Chunk &C, const hgx_record *recs, size_t nRecs, const GenomeTables &T) {
+    if (C.numQueries == 0)
+        return;
+    // the chunk's records: queries [firstQuery, firstQuery + numQueries), the records are sorted by query
+    const hgx_record *r = std::lower_bound(recs, recs + nRecs, (int64_t)C.firstQuery, [](const hgx_record &a, int64_t q) { return a.query < q; });
+    const hgx_record *rEnd = recs + nRecs;
+    const int bt = C.bedType;
+    std::string &out = C.out;
+    size_t used = 0;
+    out.resize(1 << 16);
+    for (const Line &L : C.lines) {
+        if (L.query < 0)
+            continue;
+        const bool thick = bt > 6 && (L.thickStart != 0 || L.thickEnd != 0);
+        for (; r < rEnd && r->query == L.query; ++r) {
+            const std::string &chrom = T.seqs[(size_t)r->tgt_seq].name;
+            const size_t need = chrom.size() + L.len + 200;
+            if (out.size() - used < need)
+                out.resize(std::max(out.size() * 2, used + need));
+            char *w = &out[used];
+            memcpy(w, chrom.data(), chrom.size());
+            w += chrom.size();
+            *w++ = '\t';
+            w = putInt(w, r->tgt_start);
+            *w++ = '\t';
+            w = putInt(w, r->tgt_end);
+            if (bt > 3) {
+                *w++ = '\t';
+                memcpy(w, L.text + L.nameOff, L.nameLen);
+                w += L.nameLen;
+            }
+            if (bt > 4) {
+                *w++ = '\t';
+                w = putInt(w, L.score);
+            }
+            if (bt > 5) {
+                *w++ = '\t';
+                *w++ = r->strand;
+            }
+            if (bt > 6) { // (bt == 7 never gets here)
+                *w++ = '\t';
+                w = putInt(w, thick ? r->tgt_start : L.thickStart);
+            }
+            if (bt > 7) {
+                *w++ = '\t';
+                w = putInt(w, thick ? r->tgt_end : L.thickEnd);
+            }
+            if (bt > 8) {
+                *w++ = '\t';
+                w = putInt(w, L.r);
+                *w++ = ',';
+                w = putInt(w, L.g);
+                *w++ = ',';
+                w = putInt(w, L.b);
+            }
+            if (L.extraOff != NO_EXTRA) {
+                *w++ = '\t';
+                memcpy(w, L.text + L.extraOff, L.extraEnd - L.extraOff);
+                w += L.extraEnd - L.extraOff;
+            }
+            *w++ = '\n';
+            used = (size_t)(w - out.data());
+        }
+    }
+    out.resize(used);
+}
+
+template <typename F> void forEachChunk(std::vector<Chunk> &chunks, unsigned threads, F f) {
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+        for (size_t i; (i = next.fetch_add(1)) < chunks.size();)
+            f(chunks[i]);
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < threads; ++t)
+        pool.emplace_back(work);
+    work();
+    for (std::thread &t : pool)
+        t.join();
+}
+
+} // namespace
+
+bool liftoverTextFast(hgx_alignment *al, int srcGenome, const char *text, size_t len, int tgtGenome, int bedType, bool traverseDupes,
+                      int coalescenceLimit, std::string &out, std::string &error, std::set<std::string> &missedSet, hgx_liftover_stats &stats) {
+    if (bedType > 9 || bedType == 7 || bedType < 0)
+        return false;
+    const GenomeTables &S = al->img.genomes[(size_t)srcGenome], &T = al->img.genomes[(size_t)tgtGenome];
+    std::unordered_map<std::string, int> seqByName;
+    for (size_t i = 0; i < S.seqs.size(); ++i)
+        seqByName.emplace(S.seqs[i].name, (int)i);
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned threads = (unsigned)std::min<size_t>(std::min(hw, 32u), len / (1u << 18) + 1);
+    // chunks: about four per thread, cut behind a newline
+    std::vector<Chunk> chunks;
+    {
+        const size_t want = (size_t)threads * 4, per = len / want + 1;
+        const char *p = text, *end = text + len;
+        while (p < end) {
+            const char *q = p + per < end ? p + per : end;
+            if (q < end) {
+                const char *nl = (const char *)memchr(q, '\n', (size_t)(end - q));
+                q = nl ? nl + 1 : end;
+            }
+            Chunk c;
+            c.begin = p;
+            c.end = q;
+            chunks.push_back(std::move(c));
+            p = q;
+        }
+    }
+    forEachChunk(chunks, threads, [&](Chunk &C) { parseChunk(C, bedType, seqByName, S); });
+    // one column count for the whole input, nothing for the general path; the first malformed line ends the input
+    int bt = -1;
+    size_t usable = chunks.size();
+    for (size_t i = 0; i < chunks.size(); ++i) {
+        Chunk &C = chunks[i];
+        if (C.general)
+            return false;
+        if (C.bedType >= 0) {
+            if (bt >= 0 && C.bedType != bt)
+                return false;
+            bt = C.bedType;
+        }
+        if (!C.error.empty()) {
+            usable = i + 1;
+            break;
+        }
+    }
+    size_t nq = 0, nlines = 0;
+    for (size_t i = 0; i < usable; ++i) {
+        Chunk &C = chunks[i];
+        C.bedType = bt;
+        C.firstQuery = nq;
+        C.firstLine = nlines;
+        nq += C.numQueries;
+        nlines += C.linesSeen;
+        for (const std::string &n : C.notes) { // (stderr, like the reference; unknown sequences once per name)
+            if (n[0] == '?') {
+                if (missedSet.insert(n.substr(1)).second)
+                    std::cerr << "Unable to find sequence " << n.substr(1) << " in genome " << S.name << std::endl;
+            } else {
+                std::cerr << n << std::endl;
+            }
+        }
+        if (!C.error.empty())
+            error = C.error + " in input bed line " + std::to_string(C.firstLine + C.errorLine);
+    }
+    chunks.resize(usable);
+    stats = hgx_liftover_stats{};
+    out.clear();
+    if (nq == 0)
+        return true;
+    int64_t *gs, *ge;
+    uint8_t *st;
+    liftoverStageQueries(al, nq, &gs, &ge, &st);
+    forEachChunk(chunks, threads, [&](Chunk &C) {
+        size_t q = C.firstQuery;
+        for (Line &L : C.lines) {
+            if (L.seq < 0) {
+                L.query = -1;
+                continue;
+            }
+            const int64_t s0 = S.seqs[(size_t)L.seq].start;
+            gs[q] = L.start + s0;      // halBlockLiftover.cpp:48
+            ge[q] = L.end - 1 + s0;    // :49
+            st[q] = (uint8_t)L.strand;
+            L.query = (int64_t)q++;
+        }
+    });
+    hgx_liftover_opts opts{};
+    opts.traverse_dupes = traverseDupes ? 1 : 0;
+    opts.coalescence_limit = coalescenceLimit;
+    const hgx_record *recs = nullptr;
+    size_t nRecs = 0;
+    try {
+        liftoverBatchStaged(al, srcGenome, tgtGenome, nq, opts, &recs, &nRecs, &stats);
+    } catch (std::exception &e) { // (the reference's scanner adds the line to whatever visitLine throws)
+        error = std::string(e.what()) + " in input bed line 1";
+        return true;
+    }
+    forEachChunk(chunks, threads, [&](Chunk &C) { renderChunk(C, recs, nRecs, T); });
+    size_t total = 0;
+    for (Chunk &C : chunks) {
+        C.firstLine = total; // (reused: the chunk's place in the output)
+        total += C.out.size();
+    }
+    out.resize(total);
+    forEachChunk(chunks, threads, [&](Chunk &C) {
+        if (!C.out.empty())
+            memcpy(&out[C.firstLine], C.out.data(), C.out.size());
+    });
+    return true;
+}
+
+} // namespace hgx
