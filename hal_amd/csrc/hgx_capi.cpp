@@ -394,7 +394,8 @@ int hgx_liftover_convert(hgx_alignment *h, int src, const char *bed_text, size_t
                          int out_psl, int out_psl_with_name, int coalescence_limit, char **out_text, size_t *out_len, char **err) {
     // Output produced before a failing input line is still returned (the reference has already written it
     // to the stream when it throws, halBedScanner.cpp:49-58).
-    std::string text;
+    char *text = nullptr;
+    size_t n = 0;
     int rc = HGX_OK;
     try {
         if (!h || !out_text || !out_len || (bed_len && !bed_text))
@@ -402,7 +403,7 @@ int hgx_liftover_convert(hgx_alignment *h, int src, const char *bed_text, size_t
         if (!genomeOf(h, src) || !genomeOf(h, tgt))
             throw std::runtime_error("hgx_liftover_convert: genome id out of range");
         Liftover lo;
-        lo.convertBuffer(h, src, bed_text ? bed_text : "", bed_len, tgt, &text, bed_type, traverse_dupes != 0, out_psl != 0, out_psl_with_name != 0,
+        lo.convertBuffer(h, src, bed_text ? bed_text : "", bed_len, tgt, &text, &n, bed_type, traverse_dupes != 0, out_psl != 0, out_psl_with_name != 0,
                          coalescence_limit);
     } catch (std::exception &e) {
         setErr(err, e.what());
@@ -412,14 +413,18 @@ int hgx_liftover_convert(hgx_alignment *h, int src, const char *bed_text, size_t
         rc = HGX_ERR;
     }
     if (out_text && out_len) {
-        *out_text = (char *)malloc(text.size() + 1);
-        if (*out_text) {
-            memcpy(*out_text, text.c_str(), text.size() + 1);
-            *out_len = text.size();
-        } else {
-            *out_len = 0;
-            rc = HGX_ERR;
+        if (!text) { // (nothing was lifted: an empty text, still released with hgx_free)
+            text = (char *)malloc(1);
+            if (text)
+                text[0] = '\0';
+            n = 0;
         }
+        *out_text = text;
+        *out_len = text ? n : 0;
+        if (!text)
+            rc = HGX_ERR;
+    } else {
+        free(text);
     }
     return rc;
 }

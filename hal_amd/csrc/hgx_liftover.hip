@@ -161,23 +161,14 @@ template <typename C> static void uploadUpTable(const GenomeTables &G, const Gen
     bytes += up.size() * sizeof(UpRec<C>);
 }
 
-template <typename C> static void *uploadChainTable(const GenomeTables &G, const GenomeTables &P, bool last, size_t &bytes) {
-    std::vector<ChainRec<C>> t((size_t)std::max<int64_t>(1, G.numTop));
-    memset(t.data(), 0, t.size() * sizeof(ChainRec<C>));
-    for (int64_t i = 0; i < G.numTop; ++i) {
-        const int64_t p = G.tParent[(size_t)i];
-        const int64_t start = G.tStart[(size_t)i];
-        const int64_t len = (i + 1 < G.numTop ? G.tStart[(size_t)i + 1] : G.totalLength) - start;
-        if (p < 0)
-            t[(size_t)i].set(start, 0, len, false, 0, false);
-        else
-            t[(size_t)i].set(start, P.bStart[(size_t)p], len, true, last ? p : std::max<int64_t>(0, P.bTopParse[(size_t)p]),
-                             G.tParentRev[(size_t)i] != 0);
-    }
+template <typename C> static void *makeChainTable(const DeviceGenome &G, const DeviceGenome &P, bool last, size_t &bytes) {
     void *d = nullptr;
-    HIP_OK(hipMalloc(&d, t.size() * sizeof(ChainRec<C>)));
-    HIP_OK(hipMemcpy(d, t.data(), t.size() * sizeof(ChainRec<C>), hipMemcpyHostToDevice));
-    bytes += t.size() * sizeof(ChainRec<C>);
+    const size_t n = (size_t)std::max<int64_t>(1, G.numTop);
+    HIP_OK(hipMalloc(&d, n * sizeof(ChainRec<C>)));
+    if (G.numTop > 0)
+        hipLaunchKernelGGL((k_make_chain<C>), dim3((unsigned)((G.numTop + 255) / 256)), dim3(256), 0, nullptr, (const TopRec<C> *)G.top,
+                           (const BotRec<C> *)P.bot, (uint32_t)G.numTop, last ? 1 : 0, (ChainRec<C> *)d);
+    bytes += n * sizeof(ChainRec<C>);
     return d;
 }
 
@@ -187,33 +178,23 @@ void ensureChainTables(const Image &img, DeviceImage &D, int genome, bool mid, b
     const GenomeTables &G = img.genomes[(size_t)genome];
     if (G.parent < 0)
         throw std::runtime_error("ensureChainTables: genome has no parent");
-    const GenomeTables &P = img.genomes[(size_t)G.parent];
     DeviceGenome &dg = D.genomes[(size_t)genome];
+    const DeviceGenome &pg = D.genomes[(size_t)G.parent];
     HIP_OK(hipSetDevice(D.device));
     if (mid && !dg.chainMid)
-        dg.chainMid = D.wide ? uploadChainTable<int64_t>(G, P, false, D.bytes) : uploadChainTable<int32_t>(G, P, false, D.bytes);
+        dg.chainMid = D.wide ? makeChainTable<int64_t>(dg, pg, false, D.bytes) : makeChainTable<int32_t>(dg, pg, false, D.bytes);
     if (last && !dg.chainLast)
-        dg.chainLast = D.wide ? uploadChainTable<int64_t>(G, P, true, D.bytes) : uploadChainTable<int32_t>(G, P, true, D.bytes);
+        dg.chainLast = D.wide ? makeChainTable<int64_t>(dg, pg, true, D.bytes) : makeChainTable<int32_t>(dg, pg, true, D.bytes);
 }
 
-template <typename C> static void *uploadDownTable(const GenomeTables &P, const GenomeTables &G, int slot, size_t &bytes) {
-    std::vector<DownRec<C>> t((size_t)std::max<int64_t>(1, P.numBot));
-    memset(t.data(), 0, t.size() * sizeof(DownRec<C>));
-    for (int64_t i = 0; i < P.numBot; ++i) {
-        DownRec<C> &r = t[(size_t)i];
-        const int64_t c = P.bChild[(size_t)slot][(size_t)i];
-        r.childEnc = encLink(c, P.bChildRev[(size_t)slot][(size_t)i] != 0);
-        r.paralogy = -1;
-        if (c >= 0) {
-            r.childStart = (C)G.tStart[(size_t)c];
-            r.len = (C)(G.tStart[(size_t)c + 1] - G.tStart[(size_t)c]);
-            r.paralogy = (int32_t)G.tParalogy[(size_t)c];
-        }
-    }
+template <typename C> static void *makeDownTable(const DeviceGenome &P, const DeviceGenome &G, int slot, size_t &bytes) {
     void *d = nullptr;
-    HIP_OK(hipMalloc(&d, t.size() * sizeof(DownRec<C>)));
-    HIP_OK(hipMemcpy(d, t.data(), t.size() * sizeof(DownRec<C>), hipMemcpyHostToDevice));
-    bytes += t.size() * sizeof(DownRec<C>);
+    const size_t n = (size_t)std::max<int64_t>(1, P.numBot);
+    HIP_OK(hipMalloc(&d, n * sizeof(DownRec<C>)));
+    if (P.numBot > 0)
+        hipLaunchKernelGGL((k_make_down<C>), dim3((unsigned)((P.numBot + 255) / 256)), dim3(256), 0, nullptr, (const int32_t *)P.childEnc[(size_t)slot],
+                           (const TopRec<C> *)G.top, (uint32_t)P.numBot, (DownRec<C> *)d);
+    bytes += n * sizeof(DownRec<C>);
     return d;
 }
 
@@ -225,7 +206,6 @@ void ensureLocateTable(const Image &img, DeviceImage &D, int genome, int which) 
     if (dg.locate[which])
         return;
     const GenomeTables &G = img.genomes[(size_t)genome];
-    const std::vector<int64_t> &st = which == 0 ? G.tStart : G.bStart;
     const int64_t nseg = which == 0 ? G.numTop : G.numBot;
     if (nseg <= 0 || G.totalLength <= 0)
         return;
@@ -236,20 +216,22 @@ void ensureLocateTable(const Image &img, DeviceImage &D, int genome, int which) 
     while (((G.totalLength - 1) >> shift) >= buckets)
         ++shift;
     const int64_t nb = ((G.totalLength - 1) >> shift) + 1;
-    std::vector<int32_t> coarse((size_t)nb + 1);
-    int64_t j = 0;
-    for (int64_t b = 0; b < nb; ++b) {
-        const int64_t pos = b << shift;
-        while (j + 1 < nseg && st[(size_t)j + 1] <= pos)
-            ++j;
-        coarse[(size_t)b] = (int32_t)j;
-    }
-    coarse[(size_t)nb] = (int32_t)(nseg - 1);
     HIP_OK(hipSetDevice(D.device));
-    HIP_OK(hipMalloc((void **)&dg.locate[which], coarse.size() * 4));
-    HIP_OK(hipMemcpy(dg.locate[which], coarse.data(), coarse.size() * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMalloc((void **)&dg.locate[which], ((size_t)nb + 1) * 4));
+    const unsigned grid = (unsigned)((nb + 1 + 255) / 256);
+    if (which == 0) {
+        if (D.wide)
+            hipLaunchKernelGGL((k_make_locate<TopRec<int64_t>>), dim3(grid), dim3(256), 0, nullptr, (const TopRec<int64_t> *)dg.top, nseg, shift, (uint32_t)nb, dg.locate[which]);
+        else
+            hipLaunchKernelGGL((k_make_locate<TopRec<int32_t>>), dim3(grid), dim3(256), 0, nullptr, (const TopRec<int32_t> *)dg.top, nseg, shift, (uint32_t)nb, dg.locate[which]);
+    } else {
+        if (D.wide)
+            hipLaunchKernelGGL((k_make_locate<BotRec<int64_t>>), dim3(grid), dim3(256), 0, nullptr, (const BotRec<int64_t> *)dg.bot, nseg, shift, (uint32_t)nb, dg.locate[which]);
+        else
+            hipLaunchKernelGGL((k_make_locate<BotRec<int32_t>>), dim3(grid), dim3(256), 0, nullptr, (const BotRec<int32_t> *)dg.bot, nseg, shift, (uint32_t)nb, dg.locate[which]);
+    }
     dg.locateShift[which] = shift;
-    D.bytes += coarse.size() * 4;
+    D.bytes += ((size_t)nb + 1) * 4;
 }
 
 void ensureDownTable(const Image &img, DeviceImage &D, int parent, int slot) {
@@ -262,8 +244,8 @@ void ensureDownTable(const Image &img, DeviceImage &D, int parent, int slot) {
     if (dg.downRec[(size_t)slot])
         return;
     HIP_OK(hipSetDevice(D.device));
-    const GenomeTables &G = img.genomes[(size_t)P.children[(size_t)slot]];
-    dg.downRec[(size_t)slot] = D.wide ? uploadDownTable<int64_t>(P, G, slot, D.bytes) : uploadDownTable<int32_t>(P, G, slot, D.bytes);
+    const DeviceGenome &cg = D.genomes[(size_t)P.children[(size_t)slot]];
+    dg.downRec[(size_t)slot] = D.wide ? makeDownTable<int64_t>(dg, cg, slot, D.bytes) : makeDownTable<int32_t>(dg, cg, slot, D.bytes);
 }
 
 template <typename C> static void uploadGenome(const GenomeTables &G, DeviceGenome &D, size_t &bytes) {
@@ -518,18 +500,33 @@ struct hgx_liftover_plan {
     Mapped mapped(int k) {
         return Mapped{(MappedRec *)mp[k][0].p};
     }
+    // The frontiers and the first mapped-piece buffer are only needed by runs that walk (level by level, the up table, the
+    // table builder); a plan served from a whole-path table never touches them, and they are most of a plan's memory —
+    // allocating gigabytes is what a fresh plan's first batch would otherwise wait for.
+    bool walkBuffers = false;
+    bool tableBuilder = false; // created by buildComposed: walks every source segment up to the capture point
+    void ensureWalkBuffers() {
+        if (walkBuffers)
+            return;
+        walkBuffers = true;
+        allocate(cap);
+    }
     void allocate(uint32_t newCap) {
         cap = newCap;
         static const size_t fsz[6] = {4, 8, 4, 8, 4, 1};
-        for (int k = 0; k < numFrontiers; ++k)
-            for (int a = 0; a < 6; ++a)
-                fr[k][a].ensure(fsz[a] * (size_t)cap);
-        for (int k = 0; k < 2; ++k)
-            mp[k][0].ensure(sizeof(MappedRec) * (size_t)cap);
-        grouped.ensure(sizeof(hgx_record) * ((size_t)cap + (size_t)liftBigSlots * (size_t)liftBigCap));
+        if (walkBuffers) {
+            for (int k = 0; k < numFrontiers; ++k)
+                for (int a = 0; a < 6; ++a)
+                    fr[k][a].ensure(fsz[a] * (size_t)cap);
+            mp[0][0].ensure(sizeof(MappedRec) * (size_t)cap);
+        }
+        if (!tableBuilder) { // (a table builder's run ends at the captured frontier: no pieces grouped by interval, no records)
+            mp[1][0].ensure(sizeof(MappedRec) * (size_t)cap);
+            grouped.ensure(sizeof(hgx_record) * ((size_t)cap + (size_t)liftBigSlots * (size_t)liftBigCap));
+            outRecords.ensure(sizeof(hgx_record) * (size_t)cap);
+        }
         if (liftBigSlots)
             scratch.ensure((h->dev->wide ? finishSliceBytes<int64_t>(liftBigCap) : finishSliceBytes<int32_t>(liftBigCap)) * (size_t)liftBigSlots);
-        outRecords.ensure(sizeof(hgx_record) * (size_t)cap);
         if (!pinned)
             HIP_OK(hipHostMalloc((void **)&pinned, 8 * (CNT_SLOTS + 1 + LIFT_RB_WORDS)));
         const size_t nq = std::max<size_t>(maxQueries, 1);
@@ -715,6 +712,8 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
         runMergedOnce(P, n, dS, dE, dStrand, s, hostCounters);
         return;
     }
+    if (!(P.composed && P.composed->through))
+        P.ensureWalkBuffers();
     int level = 0;
     int launch = 0; // per-launch deref counter slot
     auto kstat = [&]() { return cnt + CNT_DSTAT0 + STAT_LAUNCH0 + 2 * launch; }; // (copy 0; a block adds to its own copy)
@@ -1217,7 +1216,7 @@ static void runHostArrays(hgx_liftover_plan *P, const std::vector<int64_t> &gs, 
                           std::vector<hgx_record> &out);
 
 hgx_liftover_plan *createLiftoverPlan(hgx_alignment *h, int src, int tgt, const hgx_liftover_opts &opts, size_t maxQueries,
-                                      bool allowComposed) {
+                                      bool allowComposed, bool tableBuilder) {
     if (!h->dev)
         throw std::runtime_error("alignment was opened without a device (device = -1); liftover needs the HIP path");
     const Image &img = h->img;
@@ -1225,6 +1224,7 @@ hgx_liftover_plan *createLiftoverPlan(hgx_alignment *h, int src, int tgt, const 
         throw std::runtime_error("genome id out of range");
     std::unique_ptr<hgx_liftover_plan> P(new hgx_liftover_plan);
     P->h = h;
+    P->tableBuilder = tableBuilder;
     P->device = h->dev->device;
     P->src = src;
     P->tgt = tgt;
@@ -1288,9 +1288,7 @@ hgx_liftover_plan *createLiftoverPlan(hgx_alignment *h, int src, int tgt, const 
     HIP_OK(hipEventCreate(&P->evEnd));
     // pieces per interval the workspace starts with (grown on demand); the table builder's intervals are single source
     // segments, which yield a few pieces each, and its batch is the whole genome
-    const unsigned long long perQuery = allowComposed ? 16ull : 4ull;
-    const unsigned long long want = std::max<unsigned long long>(1ull << 16, perQuery * P->maxQueries);
-    P->allocate((uint32_t)std::min<unsigned long long>(want, (1ull << 32) - 2));
+    unsigned long long perQuery = allowComposed ? 16ull : 4ull;
     // A plan that has walked a few times as many intervals as the source genome has segments switches to a composed table
     // (runPlan): building one costs about as much as walking one interval per source segment, a table lookup a third of a
     // walk.  The table of the whole path when the target lies below the MRCA, the up table otherwise.
@@ -1307,9 +1305,14 @@ hgx_liftover_plan *createLiftoverPlan(hgx_alignment *h, int src, int tgt, const 
         if (const char *a = getenv("HGX_COMPOSED_AFTER"))
             after = atof(a);
         P->composedAfter = forbid ? ~0ull : (force ? 0ull : (unsigned long long)std::max(1.0, after * (double)img.genomes[(size_t)src].numTop));
+        // a plan whose first full batch already changes it over to a whole-path table holds output lines, not walked pieces
+        if (P->composedThrough && P->composedAfter <= P->maxQueries)
+            perQuery = 4ull;
         if (force)
             P->composed = ensureComposed(h, src, P->composedThrough ? tgt : P->mrca, P->composedThrough, opts);
     }
+    const unsigned long long want = std::max<unsigned long long>(1ull << 16, perQuery * P->maxQueries);
+    P->allocate((uint32_t)std::min<unsigned long long>(want, (1ull << 32) - 2));
     return P.release();
 }
 
@@ -1320,6 +1323,15 @@ hgx_liftover_plan *createLiftoverPlan(hgx_alignment *h, int src, int tgt, const 
 template <typename C>
 static void buildComposed(hgx_alignment *h, int src, int dst, bool through, const hgx_liftover_opts &opts, ComposedUp &out) {
     const auto t0 = std::chrono::steady_clock::now();
+    const bool timing = getenv("HGX_BUILD_TIMING") != nullptr;
+    auto lap = [&, last = t0](const char *what) mutable {
+        if (!timing)
+            return;
+        (void)hipDeviceSynchronize();
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[hgx build] pieces: %-28s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t - last).count());
+        last = t;
+    };
     const GenomeTables &S = h->img.genomes[(size_t)src];
     const DeviceImage &D = *h->dev;
     const size_t nt = (size_t)S.numTop;
@@ -1331,10 +1343,11 @@ static void buildComposed(hgx_alignment *h, int src, int dst, bool through, cons
         o.coalescence_limit = opts.coalescence_limit;
         o.block_mapper_source = opts.block_mapper_source;
     }
-    std::unique_ptr<hgx_liftover_plan, void (*)(hgx_liftover_plan *)> P(createLiftoverPlan(h, src, dst, o, nt, /*allowComposed=*/false),
+    std::unique_ptr<hgx_liftover_plan, void (*)(hgx_liftover_plan *)> P(createLiftoverPlan(h, src, dst, o, nt, /*allowComposed=*/false, /*tableBuilder=*/true),
                                                                        destroyLiftoverPlan);
     (through ? P->captureFinal : P->captureUp) = true;
     P->timer.mode = 0;
+    lap("builder plan");
     HIP_OK(hipSetDevice(D.device));
     hipStream_t s = nullptr;
     // every source top segment as one forward interval, walked to the capture point
@@ -1348,6 +1361,7 @@ static void buildComposed(hgx_alignment *h, int src, int dst, bool through, cons
     const hgx_record *ignoredRecords = nullptr;
     size_t ignoredCount = 0;
     runLiftoverPlan(P.get(), nt, (const int64_t *)dS.p, (const int64_t *)dE.p, (const uint8_t *)dT.p, s, &ignoredRecords, &ignoredCount);
+    lap("walk of every source segment");
     size_t n = 0;
     if (nt) {
         if (P->capturedBuf < 0)
@@ -1407,6 +1421,7 @@ static void buildComposed(hgx_alignment *h, int src, int dst, bool through, cons
         if (isBad)
             throw std::runtime_error("internal: a forward source segment produced a source-reversed piece");
     }
+    lap("sort + records");
     const unsigned gridB = (unsigned)(((size_t)nb + 1 + 255) / 256);
     hipLaunchKernelGGL((k_table_starts<C>), dim3(gridB), dim3(256), 0, s, (const ComposedRec<C> *)out.recs, (uint32_t)n, shift, nb, out.starts);
     hipLaunchKernelGGL(k_table_fill, dim3(gridB), dim3(256), 0, s, out.coarse, (const uint32_t *)out.starts, nb);
@@ -1416,6 +1431,7 @@ static void buildComposed(hgx_alignment *h, int src, int dst, bool through, cons
         out.starts = nullptr;
         bytes -= ((size_t)nb + 1) * 4;
     }
+    lap("bucket tables");
     out.shift = shift;
     out.numRecs = n;
     out.through = through;
@@ -1438,6 +1454,15 @@ static void sortPairs(DevBuf keys[2], DevBuf vals[2], DevBuf &tmp, size_t n, int
 // for the flags.  window: HGX_MERGED_WINDOW (default 8192 bases).
 static void buildMerged(hgx_alignment *h, int src, int dst, ComposedUp &c) {
     const auto t0 = std::chrono::steady_clock::now();
+    const bool timing = getenv("HGX_BUILD_TIMING") != nullptr;
+    auto lap = [&, last = t0](const char *what) mutable {
+        if (!timing)
+            return;
+        (void)hipDeviceSynchronize();
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[hgx build] merged: %-28s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t - last).count());
+        last = t;
+    };
     const DeviceImage &D = *h->dev;
     const GenomeTables &S = h->img.genomes[(size_t)src];
     const DeviceGenome &SG = D.genomes[(size_t)src], &TG = D.genomes[(size_t)dst];
@@ -1460,12 +1485,14 @@ static void buildMerged(hgx_alignment *h, int src, int dst, ComposedUp &c) {
     sumLen.ensure(4 * n);
     scalars.ensure(16);
     const unsigned gridN = (unsigned)((n + 255) / 256), grid2N = (unsigned)((2 * n + 255) / 256);
+    lap("allocations");
     // 1. junctions: which piece continues which
     hipLaunchKernelGGL(k_merge_keys, dim3(gridN), dim3(256), 0, s, recs, (uint32_t)n, (uint64_t *)keys[0].p, (uint32_t *)vals[0].p);
     sortPairs(keys, vals, tmp, 2 * n, 64, s);
     hipLaunchKernelGGL(k_merge_identity, dim3(gridN), dim3(256), 0, s, (uint32_t *)root.p, (uint32_t)n);
     hipLaunchKernelGGL(k_merge_link, dim3(grid2N), dim3(256), 0, s, (const uint64_t *)keys[1].p, (const uint32_t *)vals[1].p, (uint32_t)(2 * n), recs,
                        (const int64_t *)TG.seqStart, (int)TG.numSeq, (const int64_t *)SG.seqStart, (int)SG.numSeq, (uint32_t *)root.p);
+    lap("junction sort + links");
     // 2. chains: pointer jumping until nothing moves (the flag is read every fourth round)
     for (int round = 0; round < 64; round += 4) {
         HIP_OK(hipMemsetAsync(scalars.p, 0, 4, s));
@@ -1477,6 +1504,7 @@ static void buildMerged(hgx_alignment *h, int src, int dst, ComposedUp &c) {
         if (!changed)
             break;
     }
+    lap("pointer jumping");
     HIP_OK(hipMemsetAsync(minS.p, 0xFF, 4 * n, s));
     HIP_OK(hipMemsetAsync(sumLen.p, 0, 4 * n, s));
     HIP_OK(hipMemsetAsync(scalars.p, 0, 16, s));
@@ -1493,6 +1521,7 @@ static void buildMerged(hgx_alignment *h, int src, int dst, ComposedUp &c) {
     const unsigned gridM = (unsigned)((m + 255) / 256);
     hipLaunchKernelGGL(k_merge_records, dim3(gridM), dim3(256), 0, s, recs, (const uint32_t *)vals[1].p, (uint32_t)m, (const uint32_t *)minS.p,
                        (const uint32_t *)sumLen.p, (const int64_t *)TG.seqStart, (int)TG.numSeq, mrecs);
+    lap("chains sorted, records");
     // 3. flags: records whose target range overlaps that of a record nearby in the source
     DevBuf flag, flagPrefix, tHi, runMax;
     flag.ensure(4 * (m + 1));
@@ -1523,6 +1552,7 @@ static void buildMerged(hgx_alignment *h, int src, int dst, ComposedUp &c) {
         tmp.ensure(std::max<size_t>(tmpBytes, 16));
         HIP_OK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmpBytes, (const uint32_t *)flag.p, (uint32_t *)flagPrefix.p, (int)(m + 1), s));
     }
+    lap("flags");
     // 4. bucket tables, about one record per bucket (an interval's reach is then a record or two wider than its records)
     int64_t perBucket = 1;
     if (const char *e = getenv("HGX_MERGED_BUCKET_RECS")) // records per bucket (experiments)
@@ -1550,6 +1580,7 @@ static void buildMerged(hgx_alignment *h, int src, int dst, ComposedUp &c) {
     unsigned int flagged = 0;
     HIP_OK(hipMemcpyAsync(&flagged, (const uint32_t *)flagPrefix.p + m, 4, hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
+    lap("bucket tables");
     c.mShift = shift;
     c.mNum = m;
     c.mFlagged = flagged;

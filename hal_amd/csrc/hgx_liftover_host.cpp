@@ -4,6 +4,7 @@
 #include <charconv>
 #include <climits>
 #include <cstdlib>
+#include <cstring>
 #include <iostream>
 #include <sstream>
 #include <unordered_map>
@@ -377,23 +378,30 @@ void Liftover::convert(hgx_alignment *al, int srcGenome, std::istream *in, int t
         throw std::runtime_error("Error reading bed input stream");
     // the whole input in memory: the common shapes are parsed, lifted and printed by all cores at once
     std::string text((std::istreambuf_iterator<char>(*in)), std::istreambuf_iterator<char>());
-    std::string lifted;
+    char *lifted = nullptr;
+    size_t n = 0;
     try {
-        convertBuffer(al, srcGenome, text.data(), text.size(), tgtGenome, &lifted, bedType, traverseDupes, outPSL, outPSLWithName, coalescenceLimit);
+        convertBuffer(al, srcGenome, text.data(), text.size(), tgtGenome, &lifted, &n, bedType, traverseDupes, outPSL, outPSLWithName, coalescenceLimit);
     } catch (...) { // what was lifted before the failing line has been written by then in the reference, too
-        out->write(lifted.data(), (std::streamsize)lifted.size());
+        if (lifted)
+            out->write(lifted, (std::streamsize)n);
+        free(lifted);
         throw;
     }
-    out->write(lifted.data(), (std::streamsize)lifted.size());
+    if (lifted)
+        out->write(lifted, (std::streamsize)n);
+    free(lifted);
 }
 
-void Liftover::convertBuffer(hgx_alignment *al, int srcGenome, const char *text, size_t len, int tgtGenome, std::string *out, int bedType,
+void Liftover::convertBuffer(hgx_alignment *al, int srcGenome, const char *text, size_t len, int tgtGenome, char **outText, size_t *outLen, int bedType,
                              bool traverseDupes, bool outPSL, bool outPSLWithName, int coalescenceLimit) {
-    out->clear();
+    *outText = nullptr;
+    *outLen = 0;
     if (!(outPSL || outPSLWithName) && !getenv("HGX_TEXT_GENERAL")) {
         std::string error;
         _missedSet.clear();
-        if (liftoverTextFast(al, srcGenome, text, len, tgtGenome, bedType, traverseDupes, coalescenceLimit, *out, error, _missedSet, lastStats)) {
+        if (liftoverTextFast(al, srcGenome, text, len, tgtGenome, bedType, traverseDupes, coalescenceLimit, outText, outLen, error, _missedSet,
+                             lastStats)) {
             if (!error.empty())
                 throw std::runtime_error(error);
             return;
@@ -401,13 +409,21 @@ void Liftover::convertBuffer(hgx_alignment *al, int srcGenome, const char *text,
     }
     std::istringstream is(std::string(text, len));
     std::ostringstream os;
+    auto hand = [&]() {
+        const std::string s = os.str();
+        *outText = (char *)malloc(s.size() + 1);
+        if (!*outText)
+            throw std::runtime_error("out of memory");
+        memcpy(*outText, s.c_str(), s.size() + 1);
+        *outLen = s.size();
+    };
     try {
         convertGeneral(al, srcGenome, &is, tgtGenome, &os, bedType, traverseDupes, outPSL, outPSLWithName, coalescenceLimit);
     } catch (...) {
-        *out = os.str();
+        hand();
         throw;
     }
-    *out = os.str();
+    hand();
 }
 
 void Liftover::convertGeneral(hgx_alignment *al, int srcGenome, std::istream *in, int tgtGenome, std::ostream *out, int bedType,

@@ -56,8 +56,9 @@ class Liftover {
     // The same over text in memory; *out receives the lifted text (also what was written before a malformed line, which is
     // then reported by an exception like convert's).  This is what hgx_liftover_convert calls: inputs of up to nine columns,
     // the same number on every line, BED out, take the parallel path of hgx_liftover_text.cpp.
-    void convertBuffer(hgx_alignment *alignment, int srcGenome, const char *text, size_t len, int tgtGenome, std::string *out, int bedType = 0,
-                       bool traverseDupes = true, bool outPSL = false, bool outPSLWithName = false, int coalescenceLimit = -1);
+    // *outText: malloc'd, NUL-terminated, owned by the caller (also set when an exception reports a malformed line)
+    void convertBuffer(hgx_alignment *alignment, int srcGenome, const char *text, size_t len, int tgtGenome, char **outText, size_t *outLen,
+                       int bedType = 0, bool traverseDupes = true, bool outPSL = false, bool outPSLWithName = false, int coalescenceLimit = -1);
     // intervals per device batch (memory bound only)
     size_t batchLines = 1u << 22;
     hgx_liftover_stats lastStats{};
@@ -78,6 +79,7 @@ class Liftover {
 
 // hgx_liftover_text.cpp; false: not an input for the fast path (nothing was done)
 bool liftoverTextFast(hgx_alignment *al, int srcGenome, const char *text, size_t len, int tgtGenome, int bedType, bool traverseDupes,
-                      int coalescenceLimit, std::string &out, std::string &error, std::set<std::string> &missedSet, hgx_liftover_stats &stats);
+                      int coalescenceLimit, char **outText, size_t *outLen, std::string &error, std::set<std::string> &missedSet,
+                      hgx_liftover_stats &stats);
 
 } // namespace hgx

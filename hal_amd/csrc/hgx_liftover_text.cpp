@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <atomic>
 #include <charconv>
+#include <chrono>
 #include <cstring>
 #include <iostream>
 #include <thread>
@@ -289,13 +290,22 @@ template <typename F> void forEachChunk(std::vector<Chunk> &chunks, unsigned thr
 } // namespace
 
 bool liftoverTextFast(hgx_alignment *al, int srcGenome, const char *text, size_t len, int tgtGenome, int bedType, bool traverseDupes,
-                      int coalescenceLimit, std::string &out, std::string &error, std::set<std::string> &missedSet, hgx_liftover_stats &stats) {
+                      int coalescenceLimit, char **outText, size_t *outLen, std::string &error, std::set<std::string> &missedSet,
+                      hgx_liftover_stats &stats) {
+    *outText = nullptr;
+    *outLen = 0;
     if (bedType > 9 || bedType == 7 || bedType < 0)
         return false;
     const GenomeTables &S = al->img.genomes[(size_t)srcGenome], &T = al->img.genomes[(size_t)tgtGenome];
     std::unordered_map<std::string, int> seqByName;
     for (size_t i = 0; i < S.seqs.size(); ++i)
         seqByName.emplace(S.seqs[i].name, (int)i);
+    const bool timing = getenv("HGX_TEXT_TIMING") != nullptr;
+    auto now = []() { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    const auto t0 = now();
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     const unsigned threads = (unsigned)std::min<size_t>(std::min(hw, 32u), len / (1u << 18) + 1);
     // chunks: about four per thread, cut behind a newline
@@ -317,6 +327,7 @@ bool liftoverTextFast(hgx_alignment *al, int srcGenome, const char *text, size_t
         }
     }
     forEachChunk(chunks, threads, [&](Chunk &C) { parseChunk(C, bedType, seqByName, S); });
+    const auto t1 = now();
     // one column count for the whole input, nothing for the general path; the first malformed line ends the input
     int bt = -1;
     size_t usable = chunks.size();
@@ -355,7 +366,6 @@ bool liftoverTextFast(hgx_alignment *al, int srcGenome, const char *text, size_t
     }
     chunks.resize(usable);
     stats = hgx_liftover_stats{};
-    out.clear();
     if (nq == 0)
         return true;
     int64_t *gs, *ge;
@@ -375,6 +385,7 @@ bool liftoverTextFast(hgx_alignment *al, int srcGenome, const char *text, size_t
             L.query = (int64_t)q++;
         }
     });
+    const auto t2 = now();
     hgx_liftover_opts opts{};
     opts.traverse_dupes = traverseDupes ? 1 : 0;
     opts.coalescence_limit = coalescenceLimit;
@@ -386,17 +397,31 @@ bool liftoverTextFast(hgx_alignment *al, int srcGenome, const char *text, size_t
         error = std::string(e.what()) + " in input bed line 1";
         return true;
     }
+    const auto t3 = now();
     forEachChunk(chunks, threads, [&](Chunk &C) { renderChunk(C, recs, nRecs, T); });
+    const auto t4 = now();
     size_t total = 0;
     for (Chunk &C : chunks) {
         C.firstLine = total; // (reused: the chunk's place in the output)
         total += C.out.size();
     }
-    out.resize(total);
+    // the output buffer is handed to the caller as it is (malloc, untouched until the chunks copy themselves in: the
+    // first touch of its pages is spread over the threads as well)
+    char *buf = (char *)malloc(total + 1);
+    if (!buf)
+        throw std::runtime_error("out of memory");
+    buf[total] = '\0';
+    const auto t5 = now();
     forEachChunk(chunks, threads, [&](Chunk &C) {
         if (!C.out.empty())
-            memcpy(&out[C.firstLine], C.out.data(), C.out.size());
+            memcpy(buf + C.firstLine, C.out.data(), C.out.size());
     });
+    *outText = buf;
+    *outLen = total;
+    if (timing)
+        std::cerr << "[hgx text] " << threads << " threads, " << chunks.size() << " chunks: tokenise " << ms(t0, t1) << " ms, stage " << ms(t1, t2)
+                  << ", device (H2D, kernels, D2H) " << ms(t2, t3) << ", render " << ms(t3, t4) << ", allocate output " << ms(t4, t5) << ", gather "
+                  << ms(t5, now()) << std::endl;
     return true;
 }
 

@@ -97,4 +97,70 @@ static __global__ void __launch_bounds__(256) k_table_fill(uint32_t *__restrict_
         coarse[b] = starts[b];
 }
 
+// ---- per-genome side tables of the walk kernels, derived on the device from the uploaded TopRec / BotRec tables (a plan's
+// creation used to spend tens of milliseconds building them in host loops) ----
+// ChainRec of every top segment (hgx_device.hpp): `last` selects the parent bottom segment's own index as the link instead
+// of its top-parse index
+template <typename C>
+static __global__ void __launch_bounds__(256) k_make_chain(const TopRec<C> *__restrict__ top, const BotRec<C> *__restrict__ pbot, uint32_t numTop,
+                                                           int last, ChainRec<C> *__restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= numTop)
+        return;
+    const TopRec<C> t = top[i];
+    const int64_t len = (int64_t)top[i + 1].start - (int64_t)t.start;
+    ChainRec<C> r;
+    if (t.parentEnc < 0) {
+        r.set((int64_t)t.start, 0, len, false, 0, false);
+    } else {
+        const int32_t p = t.parentEnc >> 1;
+        const BotRec<C> b = pbot[p];
+        const int64_t link = last ? (int64_t)p : (int64_t)(b.topParse < 0 ? 0 : b.topParse);
+        r.set((int64_t)t.start, (int64_t)b.start, len, true, link, (t.parentEnc & 1) != 0);
+    }
+    out[i] = r;
+}
+// DownRec of every bottom segment for one child slot
+template <typename C>
+static __global__ void __launch_bounds__(256) k_make_down(const int32_t *__restrict__ childEnc, const TopRec<C> *__restrict__ ctop, uint32_t numBot,
+                                                          DownRec<C> *__restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= numBot)
+        return;
+    DownRec<C> r;
+    memset(&r, 0, sizeof r);
+    r.childEnc = childEnc[i];
+    r.paralogy = -1;
+    if (r.childEnc >= 0) {
+        const int32_t c = r.childEnc >> 1;
+        const TopRec<C> t = ctop[c];
+        r.childStart = t.start;
+        r.len = (C)((int64_t)ctop[c + 1].start - (int64_t)t.start);
+        r.paralogy = t.paralogy;
+    }
+    out[i] = r;
+}
+// coarse position -> segment table: out[b] = index of the segment that holds position b << shift (b < nb), out[nb] = last segment
+template <typename REC>
+static __global__ void __launch_bounds__(256) k_make_locate(const REC *__restrict__ segs, int64_t nseg, int shift, uint32_t nb,
+                                                            int32_t *__restrict__ out) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > nb)
+        return;
+    if (b == nb) {
+        out[b] = (int32_t)(nseg - 1);
+        return;
+    }
+    const int64_t pos = (int64_t)b << shift;
+    int64_t lo = 0, hi = nseg; // last segment with start <= pos
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)segs[mid].start <= pos)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    out[b] = (int32_t)lo;
+}
+
 } // namespace hgx
