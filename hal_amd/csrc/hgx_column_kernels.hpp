@@ -519,4 +519,95 @@ static __global__ void __launch_bounds__(256) k_fill_long_runs(const LongRun *__
     }
 }
 
+// ---- depth by two sweeps over the tree (hgx_columns.hip: columnsDepthSweep) ----
+// Every base has at most one parent base, so the column of a base — everything the walk of recursiveUpdate reaches
+// (api/impl/halColumnIterator.cpp:246-355: up to the parent, across to the siblings and paralogs, down into every child) — is the
+// whole descendant tree of the base's topmost ancestor.  With S_x[p] = the genomes below base p of genome x (a bit set; x's own
+// bit if x counts), the depth of a column is the size of S at that ancestor.  Two streaming sweeps, one track entry per base:
+//   bottom-up  S_x over a bottom segment = own bit | the S of every top segment of every child that hangs under it (the
+//              child slot's segment and its paralogy ring), read in the child's orientation;
+//   top-down   A_x[p] = size of S at p's topmost ancestor: copied from the parent's A where the top segment has a parent,
+//              the size of S_x[p] where it has none (or x is the top of the walk's scope).
+// halAlignmentDepth's value is A - 1 on the reference (alignmentDepth/halAlignmentDepth.cpp:258-281).  SUM = true counts
+// bases instead of genomes (--countDupes): the same sweeps with sums.  One wavefront per segment, lanes along its bases.
+template <typename M, bool SUM> __device__ __forceinline__ M track_join(M a, M b) {
+    return SUM ? (M)(a + b) : (M)(a | b);
+}
+struct SweepChild {
+    const int32_t *enc; // the parent's child link array for this slot
+    const void *top;    // the child's TopRec table
+    const void *track;  // the child's S
+};
+static constexpr int SWEEP_MAX_CHILDREN = 8;
+struct SweepChildren {
+    SweepChild c[SWEEP_MAX_CHILDREN];
+    int n;
+};
+template <typename C, typename M, bool SUM>
+static __global__ void __launch_bounds__(256) k_sweep_up(const BotRec<C> *__restrict__ bot, int64_t numBot, SweepChildren ch, M own, int accumulate,
+                                                         M *__restrict__ S) {
+    const int lane = (int)(threadIdx.x & 63);
+    const int64_t wavesTotal = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; b < numBot; b += wavesTotal) {
+        const int64_t start = (int64_t)bot[b].start, len = (int64_t)bot[b + 1].start - start;
+        for (int64_t o0 = 0; o0 < len; o0 += 64) {
+            const int64_t o = o0 + lane;
+            M v = accumulate && o < len ? S[start + o] : own; // (more than SWEEP_MAX_CHILDREN children: several launches)
+            for (int k = 0; k < ch.n; ++k) {
+                const int32_t enc = ch.c[k].enc[b];
+                if (enc < 0)
+                    continue;
+                const TopRec<C> *top = (const TopRec<C> *)ch.c[k].top;
+                const M *T = (const M *)ch.c[k].track;
+                const int32_t t0 = enc >> 1;
+                int32_t t = t0;
+                do { // the slot's segment and its paralogy ring (updateChild + updateNextTopDup, :607-681)
+                    const TopRec<C> tr = top[t];
+                    if (o < len)
+                        v = track_join<M, SUM>(v, T[(int64_t)tr.start + ((tr.parentEnc & 1) ? len - 1 - o : o)]);
+                    t = tr.paralogy;
+                } while (t >= 0 && t != t0);
+            }
+            if (o < len)
+                S[start + o] = v;
+        }
+    }
+}
+template <typename M> static __global__ void __launch_bounds__(256) k_sweep_fill(M *__restrict__ S, int64_t n, M v) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        S[i] = v;
+}
+template <typename M, bool SUM> __device__ __forceinline__ int32_t track_size(M v) {
+    return SUM ? (int32_t)v : (int32_t)__popcll((unsigned long long)v);
+}
+template <typename M, bool SUM>
+static __global__ void __launch_bounds__(256) k_sweep_top(const M *__restrict__ S, int64_t n, int32_t *__restrict__ A) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        A[i] = track_size<M, SUM>(S[i]);
+}
+template <typename C, typename M, bool SUM>
+static __global__ void __launch_bounds__(256) k_sweep_down(const TopRec<C> *__restrict__ top, int64_t numTop, const BotRec<C> *__restrict__ pbot,
+                                                           const int32_t *__restrict__ pA, const M *__restrict__ S, int32_t *__restrict__ A) {
+    const int lane = (int)(threadIdx.x & 63);
+    const int64_t wavesTotal = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; t < numTop; t += wavesTotal) {
+        const TopRec<C> tr = top[t];
+        const int64_t start = (int64_t)tr.start, len = (int64_t)top[t + 1].start - start;
+        if (tr.parentEnc >= 0) {
+            const int64_t pstart = (int64_t)pbot[tr.parentEnc >> 1].start;
+            const bool rev = (tr.parentEnc & 1) != 0;
+            for (int64_t o = lane; o < len; o += 64)
+                A[start + o] = pA[pstart + (rev ? len - 1 - o : o)];
+        } else {
+            for (int64_t o = lane; o < len; o += 64)
+                A[start + o] = track_size<M, SUM>(S[start + o]);
+        }
+    }
+}
+static __global__ void __launch_bounds__(256) k_sweep_out(const int32_t *__restrict__ A, int64_t first, int64_t count, int64_t step, int32_t sub,
+                                                          int32_t *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = A[first + i * step] - sub;
+}
+
 } // namespace hgx

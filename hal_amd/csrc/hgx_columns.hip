@@ -3,6 +3,8 @@
 #include "hgx_column_kernels.hpp"
 #include "hgx_scan_kernels.hpp"
 #include "hgx_columns_engine.hpp"
+#include "hgx_liftover_engine.hpp"
+#include <hipcub/hipcub.hpp>
 #include <algorithm>
 #include <cstring>
 #include <functional>
@@ -138,10 +140,170 @@ static void refSegmentRange(hgx_alignment *h, int ref, int64_t firstPos, int64_t
             hipLaunchKernelGGL((K<CT, false>), dim3(grid), dim3(256), 0, s, __VA_ARGS__);                              \
     } while (0)
 
+// halAlignmentDepth's per-column value by two streaming sweeps over the tree (hgx_column_kernels.hpp: k_sweep_up / k_sweep_down)
+// instead of one depth-first walk per run of columns: every in-scope genome gets a track with one entry per base.  Used for
+// requests that span a million columns or more (the sweeps always cover whole genomes) when at most 64 genomes count and
+// the tracks fit the device; otherwise (return false) the column walk runs.  HGX_DEPTH_SWEEP=0 forbids it, =1 lifts the
+// size threshold.  mode 0: genomes - 1, 1: bases - 1 (--countDupes), 2: bases.
+template <typename C, typename M, bool SUM>
+static void sweepTracks(hgx_alignment *h, const std::vector<int> &postOrder, const std::vector<int> &path, const std::vector<char> &inScope,
+                        const std::vector<long long> &ownValue, std::vector<Buf> &S, std::vector<Buf> &A, hipStream_t s) {
+    const Image &img = h->img;
+    const DeviceImage &D = *h->dev;
+    const int GRID = 4096;
+    for (int g : postOrder) {
+        const GenomeTables &G = img.genomes[(size_t)g];
+        const DeviceGenome &dg = D.genomes[(size_t)g];
+        if (G.totalLength <= 0)
+            continue;
+        std::vector<SweepChild> kids;
+        for (size_t k = 0; k < G.children.size(); ++k) {
+            const int c = G.children[k];
+            if (!inScope[(size_t)c] || img.genomes[(size_t)c].totalLength <= 0 || img.genomes[(size_t)c].numTop <= 0)
+                continue;
+            kids.push_back(SweepChild{dg.childEnc[k], D.genomes[(size_t)c].top, S[(size_t)c].p});
+        }
+        const M own = (M)ownValue[(size_t)g];
+        if (kids.empty() || G.numBot <= 0) {
+            hipLaunchKernelGGL((k_sweep_fill<M>), dim3(GRID), dim3(256), 0, s, (M *)S[(size_t)g].p, (int64_t)G.totalLength, own);
+            continue;
+        }
+        for (size_t at = 0; at < kids.size(); at += SWEEP_MAX_CHILDREN) {
+            SweepChildren ch;
+            ch.n = (int)std::min<size_t>(SWEEP_MAX_CHILDREN, kids.size() - at);
+            for (int k = 0; k < ch.n; ++k)
+                ch.c[k] = kids[at + (size_t)k];
+            hipLaunchKernelGGL((k_sweep_up<C, M, SUM>), dim3(GRID), dim3(256), 0, s, (const BotRec<C> *)dg.bot, (int64_t)G.numBot, ch, own, at ? 1 : 0,
+                               (M *)S[(size_t)g].p);
+        }
+    }
+    // top-down along the path from the top of the scope to the reference
+    const int top = path[0];
+    hipLaunchKernelGGL((k_sweep_top<M, SUM>), dim3(GRID), dim3(256), 0, s, (const M *)S[(size_t)top].p, (int64_t)img.genomes[(size_t)top].totalLength,
+                       (int32_t *)A[(size_t)top].p);
+    for (size_t i = 1; i < path.size(); ++i) {
+        const int c = path[i], p = path[i - 1];
+        hipLaunchKernelGGL((k_sweep_down<C, M, SUM>), dim3(GRID), dim3(256), 0, s, (const TopRec<C> *)D.genomes[(size_t)c].top,
+                           (int64_t)img.genomes[(size_t)c].numTop, (const BotRec<C> *)D.genomes[(size_t)p].bot, (const int32_t *)A[(size_t)p].p,
+                           (const M *)S[(size_t)c].p, (int32_t *)A[(size_t)c].p);
+    }
+}
+
+static bool columnsDepthSweep(hgx_alignment *h, int ref, int64_t first, int64_t count, int64_t step, int mode, const ColumnOptions &opt,
+                              int32_t *d_out, hipStream_t s, ColumnStats *stats) {
+    const char *env = getenv("HGX_DEPTH_SWEEP");
+    if (count <= 0 || (env && env[0] == '0') || opt.noDupes || opt.onlyOrthologs)
+        return false;
+    const int64_t span = (count - 1) * step + 1;
+    if (span < (1 << 20) && !(env && env[0] == '1'))
+        return false;
+    const Image &img = h->img;
+    const int ng = (int)img.genomes.size();
+    // the walk's scope (halColumnIterator.cpp:45-51) and the genomes whose bases are reported (:802-812)
+    std::vector<char> inScope((size_t)ng, 1), counted((size_t)ng, 1);
+    int scopeRoot = img.root();
+    if (!opt.targets.empty()) {
+        std::set<int> tg(opt.targets.begin(), opt.targets.end());
+        tg.insert(ref);
+        scopeRoot = ref;
+        for (int g : tg) {
+            if (g < 0 || g >= ng)
+                throw std::runtime_error("target genome id out of range");
+            scopeRoot = img.lca(scopeRoot, g);
+        }
+        std::fill(inScope.begin(), inScope.end(), 0);
+        std::fill(counted.begin(), counted.end(), 0);
+        for (int g : tg) {
+            counted[(size_t)g] = 1;
+            for (int x = g;; x = img.genomes[(size_t)x].parent) {
+                inScope[(size_t)x] = 1;
+                if (x == scopeRoot)
+                    break;
+            }
+        }
+    }
+    if (opt.noAncestors)
+        for (int g = 0; g < ng; ++g)
+            if (!img.genomes[(size_t)g].children.empty())
+                counted[(size_t)g] = 0;
+    // post-order of the scope's tree, the path to the reference, one bit per counted genome
+    std::vector<int> postOrder, stack{scopeRoot}, path;
+    while (!stack.empty()) { // reverse pre-order = a post-order
+        const int g = stack.back();
+        stack.pop_back();
+        postOrder.push_back(g);
+        for (int c : img.genomes[(size_t)g].children)
+            if (inScope[(size_t)c])
+                stack.push_back(c);
+    }
+    std::reverse(postOrder.begin(), postOrder.end());
+    for (int x = ref;; x = img.genomes[(size_t)x].parent) {
+        path.push_back(x);
+        if (x == scopeRoot)
+            break;
+    }
+    std::reverse(path.begin(), path.end());
+    const bool sum = mode != 0;
+    int bits = 0;
+    std::vector<long long> own((size_t)ng, 0);
+    for (int g : postOrder)
+        if (counted[(size_t)g]) {
+            own[(size_t)g] = sum ? 1ll : (long long)(1ull << (bits & 63));
+            ++bits;
+        }
+    if (!sum && bits > 64)
+        return false;
+    const size_t word = sum ? 4 : (bits <= 32 ? 4 : 8);
+    size_t need = 0;
+    for (int g : postOrder)
+        need += (size_t)img.genomes[(size_t)g].totalLength * word;
+    for (int g : path)
+        need += (size_t)img.genomes[(size_t)g].totalLength * 4;
+    size_t freeB = 0, totalB = 0;
+    HIP_OK(hipMemGetInfo(&freeB, &totalB));
+    if (need + (1ull << 30) > freeB)
+        return false;
+    std::vector<Buf> S((size_t)ng), A((size_t)ng);
+    for (int g : postOrder)
+        S[(size_t)g].resize((size_t)img.genomes[(size_t)g].totalLength * word);
+    for (int g : path)
+        A[(size_t)g].resize((size_t)img.genomes[(size_t)g].totalLength * 4);
+    Ev a, b;
+    HIP_OK(hipEventRecord(a.e, s));
+    if (h->dev->wide) {
+        if (sum)
+            sweepTracks<int64_t, int32_t, true>(h, postOrder, path, inScope, own, S, A, s);
+        else if (word == 4)
+            sweepTracks<int64_t, uint32_t, false>(h, postOrder, path, inScope, own, S, A, s);
+        else
+            sweepTracks<int64_t, unsigned long long, false>(h, postOrder, path, inScope, own, S, A, s);
+    } else {
+        if (sum)
+            sweepTracks<int32_t, int32_t, true>(h, postOrder, path, inScope, own, S, A, s);
+        else if (word == 4)
+            sweepTracks<int32_t, uint32_t, false>(h, postOrder, path, inScope, own, S, A, s);
+        else
+            sweepTracks<int32_t, unsigned long long, false>(h, postOrder, path, inScope, own, S, A, s);
+    }
+    hipLaunchKernelGGL(k_sweep_out, dim3(2048), dim3(256), 0, s, (const int32_t *)A[(size_t)ref].p, first, count, step, mode == 2 ? 0 : 1, d_out);
+    HIP_OK(hipEventRecord(b.e, s));
+    HIP_OK(hipStreamSynchronize(s));
+    if (stats) {
+        float ms = 0;
+        HIP_OK(hipEventElapsedTime(&ms, a.e, b.e));
+        stats->depth_ms += ms;
+        stats->columns += (uint64_t)count;
+        stats->sweep_bytes += (uint64_t)need;
+    }
+    return true;
+}
+
 void columnsDepthDevice(hgx_alignment *h, int ref, int64_t first, int64_t count, int64_t step, int mode, const ColumnOptions &opt,
                         int32_t *d_out, void *stream, ColumnStats *stats, bool countDerefs, bool perBase) {
     HIP_OK(hipSetDevice(h->dev->device));
     hipStream_t s = (hipStream_t)stream;
+    if (!perBase && !perBaseColumns() && !countDerefs && columnsDepthSweep(h, ref, first, count, step, mode, opt, d_out, s, stats))
+        return;
     Buf err(4);
     HIP_OK(hipMemsetAsync(err.p, 0, 4, s));
     Buf masks;

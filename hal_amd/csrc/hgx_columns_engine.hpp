@@ -31,6 +31,7 @@ struct ColumnStats {
     double depth_ms = 0, rows_ms = 0;
     uint64_t columns = 0, rows = 0;
     uint64_t top_derefs = 0, bottom_derefs = 0; // segment records the walks logically dereferenced (depth kernel only)
+    uint64_t sweep_bytes = 0;                   // depth by tree sweeps: bytes of the per-base tracks
 };
 
 // per-column values of halAlignmentDepth: mode 0 = distinct genomes - 1, 1 = bases - 1 (--countDupes), 2 = bases

@@ -144,6 +144,7 @@ struct ComposedUp {
     uint64_t mNum = 0, mFlagged = 0;
     int64_t mWindow = 0;        // intervals longer than this take the general path
     double mBuildMs = 0;
+    bool mTried = false;        // the merged form was attempted (it stays absent for tables it cannot hold)
 };
 template <typename C> struct BotRec;
 template <> struct alignas(8) BotRec<int32_t> {

@@ -584,7 +584,7 @@ static void exclusiveScan(hgx_liftover_plan &P, const uint32_t *in, uint32_t n, 
     P.timer.end(s);
 }
 
-static const ComposedUp *ensureComposed(hgx_alignment *h, int src, int dst, bool through, const hgx_liftover_opts &opts);
+static const ComposedUp *ensureComposed(hgx_alignment *h, int src, int dst, bool through, const hgx_liftover_opts &opts, bool wantMerged = true);
 
 // One batch on the single-pass path (32-bit tables): classify, the general intervals through the unmerged table and the
 // LDS finishing kernel, then k_lift_merged writes every record at its final place.  One host synchronisation at the end.
@@ -1079,7 +1079,7 @@ static void runPlan(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
     if (!P.composed && P.composedAfter != ~0ull) {
         // the batch that takes the plan past its threshold is already served from the table
         if (P.walked + n >= P.composedAfter)
-            P.composed = ensureComposed(P.h, P.src, P.composedThrough ? P.tgt : P.mrca, P.composedThrough, P.opts);
+            P.composed = ensureComposed(P.h, P.src, P.composedThrough ? P.tgt : P.mrca, P.composedThrough, P.opts, !P.opts.emit_blocks);
         else
             P.walked += n;
     }
@@ -1309,7 +1309,7 @@ hgx_liftover_plan *createLiftoverPlan(hgx_alignment *h, int src, int tgt, const 
         if (P->composedThrough && P->composedAfter <= P->maxQueries)
             perQuery = 4ull;
         if (force)
-            P->composed = ensureComposed(h, src, P->composedThrough ? tgt : P->mrca, P->composedThrough, opts);
+            P->composed = ensureComposed(h, src, P->composedThrough ? tgt : P->mrca, P->composedThrough, opts, !opts.emit_blocks);
     }
     const unsigned long long want = std::max<unsigned long long>(1ull << 16, perQuery * P->maxQueries);
     P->allocate((uint32_t)std::min<unsigned long long>(want, (1ull << 32) - 2));
@@ -1589,26 +1589,50 @@ static void buildMerged(hgx_alignment *h, int src, int dst, ComposedUp &c) {
     c.mBuildMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
-static const ComposedUp *ensureComposed(hgx_alignment *h, int src, int dst, bool through, const hgx_liftover_opts &opts) {
+static const ComposedUp *ensureComposed(hgx_alignment *h, int src, int dst, bool through, const hgx_liftover_opts &opts, bool wantMerged) {
     static std::mutex mu;
     std::lock_guard<std::mutex> lock(mu);
+    // the merged form for the single-pass kernels (HGX_MERGED=0: keep to the multi-kernel path), built when a plan asks for it
+    auto addMerged = [&](ComposedUp &c) {
+        const char *me = getenv("HGX_MERGED");
+        if (wantMerged && through && !h->dev->wide && !c.mRecs && !c.mTried && !(me && me[0] == '0')) {
+            c.mTried = true;
+            buildMerged(h, src, dst, c);
+        }
+    };
     const bool climbs = opts.coalescence_limit >= 0 && opts.traverse_dupes; // createLiftoverPlan ignores the limit without dupes
     const std::array<int, 4> key = through ? std::array<int, 4>{src, dst, (opts.traverse_dupes ? 1 : 0) | (opts.block_mapper_source ? 2 : 0),
                                                                   climbs ? opts.coalescence_limit + 1 : 0}
                                            : std::array<int, 4>{src, dst, -1, -1};
     auto it = h->dev->composed.find(key);
-    if (it != h->dev->composed.end())
+    if (it != h->dev->composed.end()) {
+        addMerged(it->second);
         return &it->second;
+    }
     ComposedUp c;
     if (h->dev->wide)
         buildComposed<int64_t>(h, src, dst, through, opts, c);
     else
         buildComposed<int32_t>(h, src, dst, through, opts, c);
-    // the merged form for the single-pass kernels (HGX_MERGED=0: keep to the multi-kernel path)
-    const char *me = getenv("HGX_MERGED");
-    if (through && !h->dev->wide && !(me && me[0] == '0'))
-        buildMerged(h, src, dst, c);
+    addMerged(c);
     return &h->dev->composed.emplace(key, c).first->second;
+}
+
+// The table of the whole path src -> dst (dupes on, paralogs followed up to `limit`, -1 = the MRCA) for users outside the
+// liftover plans (the depth of hgx_columns.hip); null when this pair cannot have one (the source is the MRCA or has no top
+// tiling — the conditions of createLiftoverPlan).
+const ComposedUp *wholePathTable(hgx_alignment *h, int src, int dst, int limit) {
+    const Image &img = h->img;
+    if (src == dst || img.lca(src, dst) == src || img.genomes[(size_t)src].numTop <= 0)
+        return nullptr;
+    hgx_liftover_opts o{};
+    o.traverse_dupes = 1;
+    o.coalescence_limit = (limit >= 0 && limit != img.lca(src, dst)) ? limit : -1;
+    // an ancestor of the source is reached by the up walk alone: the up table (its records are the pieces that arrive there;
+    // paralogs found higher up cannot add an image where the direct lineage has none)
+    if (img.lca(src, dst) == dst)
+        return ensureComposed(h, src, dst, false, o, false);
+    return ensureComposed(h, src, dst, true, o, /*wantMerged=*/false);
 }
 
 void runLiftoverPlan(hgx_liftover_plan *p, size_t n, const int64_t *dS, const int64_t *dE, const uint8_t *dStrand, void *stream,

@@ -30,6 +30,9 @@ void liftoverStageQueries(hgx_alignment *h, size_t n, int64_t **gs, int64_t **ge
 // ... and the run over what was written into them: *recs (pinned, owned by the alignment, valid until the next staged run)
 void liftoverBatchStaged(hgx_alignment *h, int src, int tgt, size_t n, const hgx_liftover_opts &opts, const hgx_record **recs, size_t *nRecs,
                          hgx_liftover_stats *stats);
+// the table of the whole path src -> dst with dupes (hgx_device.hpp: ComposedUp, through), built on first use; null when the
+// pair cannot have one
+const ComposedUp *wholePathTable(hgx_alignment *h, int src, int dst, int coalescenceLimit);
 // BlockMapper::init + map + getMap without adjacencies (liftover/impl/halBlockMapper.cpp:33-110)
 void blockMapHost(hgx_alignment *h, int ref, int query, int64_t absFirst, int64_t absLast, bool targetReversed,
                   const hgx_liftover_opts &opts, std::vector<hgx_record> &out);

@@ -191,3 +191,37 @@ def test_reference_unit_tests_of_the_column_iterator(hal, oracle_bin, tmp_path):
                 # the oracle prints ColumnMap order (by sequence), the rows API insertion order: same multiset
                 o = sorted((x.split(":")[0], int(x.split(":")[1]), x.split(":")[2] == "-") for x in want[c].split()[1:])
                 assert sorted(tuples) == o, (name, ref, c)
+
+
+@pytest.mark.parametrize("seed", [2, 5, 6, 11])
+def test_depth_by_tree_sweeps_vs_walk_and_oracle(hal, oracle_bin, tmp_path, seed, monkeypatch):
+    """halAlignmentDepth by the two tree sweeps (HGX_DEPTH_SWEEP=1 lifts the size threshold) against the column walk (=0) and
+    the oracle: every genome (leaves, ancestors, the root), whole genome and ranges, --step, --countDupes, --noAncestors,
+    --targetGenomes."""
+    al, img = _rand(hal, tmp_path, seed, dna=False, min_segments=120, max_segments=400)
+    for g in range(al.num_genomes):
+        n = al.genome_length(g)
+        if n == 0:
+            continue
+        name = al.genome_name(g)
+        leaf = not al.genome_children(g)
+        others = [x for x in range(al.num_genomes) if x != g]
+        cases = [dict(), dict(count_dupes=True), dict(targets=others[:2]), dict(targets=[others[-1]], count_dupes=True), dict(targets=others[1:4])]
+        if leaf:
+            cases += [dict(no_ancestors=True), dict(no_ancestors=True, targets=others[2:6])]
+        for kw in cases:
+            monkeypatch.setenv("HGX_DEPTH_SWEEP", "1")
+            a = al.columns_depth(g, 0, n, **kw)
+            b = al.columns_depth(g, n // 3, n // 2, **kw)
+            c = al.columns_depth(g, 5, (n - 5) // 7, step=7, **kw)
+            monkeypatch.setenv("HGX_DEPTH_SWEEP", "0")
+            assert np.array_equal(a, al.columns_depth(g, 0, n, **kw)), (name, kw)
+            assert np.array_equal(b, al.columns_depth(g, n // 3, n // 2, **kw)), (name, kw)
+            assert np.array_equal(c, al.columns_depth(g, 5, (n - 5) // 7, step=7, **kw)), (name, kw)
+        monkeypatch.setenv("HGX_DEPTH_SWEEP", "1")
+        assert al.alignment_depth(g) == _oracle(oracle_bin, "depth", img, tmp_path, name), name
+        assert al.alignment_depth(g, count_dupes=True) == _oracle(oracle_bin, "depth", img, tmp_path, name, "--countDupes"), name
+        if leaf:
+            assert al.alignment_depth(g, no_ancestors=True) == _oracle(oracle_bin, "depth", img, tmp_path, name, "--noAncestors"), name
+        assert al.alignment_depth(g, 0, start=7, length=n // 2, step=3) == \
+            _oracle(oracle_bin, "depth", img, tmp_path, name, "--refSequence", al.sequences(g)[0][0], "--start", "7", "--length", str(n // 2), "--step", "3")
