@@ -421,16 +421,19 @@ def main():
             # reference piece (= per run of columns with one walk, which is how the kernel works), + the 4-byte result
             col_bytes = 25.0 * (cst["top_derefs"] + cst["bottom_derefs"]) + 4.0 * ncol
             col_gbs = col_bytes / world / (col_ms * 1e-3) / 1e9
-            col_traffic, col_src = pmc_traffic("k_depth_runs")
+            col_kernel = "k_sweep_up"  # (requests of a million columns or more take the tree sweeps; k_depth_runs otherwise)
+            col_traffic, col_src = pmc_traffic(col_kernel)
             out["columns"] = {"metric": "alignment-depth columns/sec (ColumnIterator closure per reference base)",
                               "value": ncol / (col_ms * 1e-3), "unit": "columns/s", "columns": ncol, "kernel_ms": col_ms,
                               "n_gpus": world, "all_gather_ms": gather_ms,
                               "reference_genome": src_name, "mean_depth": mean_depth,
-                              "roofline": {"bound": "hbm", "kernel": "k_depth_runs", "achieved": col_gbs, "peak": HBM_PEAK_GBS,
+                              "roofline": {"bound": "hbm", "kernel": col_kernel, "achieved": col_gbs, "peak": HBM_PEAK_GBS,
                                            "unit": "GB/s", "frac": col_gbs / HBM_PEAK_GBS, "traffic": col_traffic, "traffic_source": col_src,
                                            "algorithmic_bytes_per_launch": col_bytes / world,
                                            "top_derefs": cst["top_derefs"], "bottom_derefs": cst["bottom_derefs"],
-                                           "note": "per-GPU figures when n_gpus > 1"}}
+                                           "note": "achieved = SURVEY 8(d)'s 25 B per segment record of the closure (counted by the column walk's "
+                                                   "counting instantiation) + 4 B per column, over the time of all sweep kernels of one call "
+                                                   "(k_sweep_fill/up/top/down/out); traffic: k_sweep_up launches only; per-GPU figures when n_gpus > 1"}}
         if want_maf:
             # BASELINE config 3: hal2maf --refGenome <leaf> --noAncestors, end to end (column kernels, row fetch, block state
             # machine, text rendering) over the first N reference columns

@@ -536,73 +536,102 @@ template <typename M, bool SUM> __device__ __forceinline__ M track_join(M a, M b
 struct SweepChild {
     const int32_t *enc; // the parent's child link array for this slot
     const void *top;    // the child's TopRec table
-    const void *track;  // the child's S
+    const void *track;  // the child's S, or null: the same value on every base (a genome without in-scope children)
+    long long constant; // that value
 };
 static constexpr int SWEEP_MAX_CHILDREN = 8;
 struct SweepChildren {
     SweepChild c[SWEEP_MAX_CHILDREN];
     int n;
 };
+// sixteen lanes per bottom segment, four bases per lane and round: four segments' dependent loads (segment bounds, child link,
+// child record, ring links) are in flight per wavefront instead of one
 template <typename C, typename M, bool SUM>
 static __global__ void __launch_bounds__(256) k_sweep_up(const BotRec<C> *__restrict__ bot, int64_t numBot, SweepChildren ch, M own, int accumulate,
                                                          M *__restrict__ S) {
-    const int lane = (int)(threadIdx.x & 63);
-    const int64_t wavesTotal = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    for (int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; b < numBot; b += wavesTotal) {
+    const int sub = (int)(threadIdx.x & 15);
+    const int64_t groupsTotal = ((int64_t)gridDim.x * blockDim.x) >> 4;
+    for (int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; b < numBot; b += groupsTotal) {
         const int64_t start = (int64_t)bot[b].start, len = (int64_t)bot[b + 1].start - start;
         for (int64_t o0 = 0; o0 < len; o0 += 64) {
-            const int64_t o = o0 + lane;
-            M v = accumulate && o < len ? S[start + o] : own; // (more than SWEEP_MAX_CHILDREN children: several launches)
+            M v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t o = o0 + sub + 16 * j;
+                v[j] = accumulate && o < len ? S[start + o] : own; // (more than SWEEP_MAX_CHILDREN children: several launches)
+            }
             for (int k = 0; k < ch.n; ++k) {
                 const int32_t enc = ch.c[k].enc[b];
                 if (enc < 0)
                     continue;
                 const TopRec<C> *top = (const TopRec<C> *)ch.c[k].top;
                 const M *T = (const M *)ch.c[k].track;
+                if (!T && !SUM) { // a child without tracks of its own: every base below carries the same set
+                    const M cst = (M)ch.c[k].constant;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        v[j] = track_join<M, SUM>(v[j], cst);
+                    continue;
+                }
                 const int32_t t0 = enc >> 1;
                 int32_t t = t0;
                 do { // the slot's segment and its paralogy ring (updateChild + updateNextTopDup, :607-681)
                     const TopRec<C> tr = top[t];
-                    if (o < len)
-                        v = track_join<M, SUM>(v, T[(int64_t)tr.start + ((tr.parentEnc & 1) ? len - 1 - o : o)]);
+                    if (T) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int64_t o = o0 + sub + 16 * j;
+                            if (o < len)
+                                v[j] = track_join<M, SUM>(v[j], T[(int64_t)tr.start + ((tr.parentEnc & 1) ? len - 1 - o : o)]);
+                        }
+                    } else { // (sums: one per ring member)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            v[j] = track_join<M, SUM>(v[j], (M)ch.c[k].constant);
+                    }
                     t = tr.paralogy;
                 } while (t >= 0 && t != t0);
             }
-            if (o < len)
-                S[start + o] = v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t o = o0 + sub + 16 * j;
+                if (o < len)
+                    S[start + o] = v[j];
+            }
         }
     }
-}
-template <typename M> static __global__ void __launch_bounds__(256) k_sweep_fill(M *__restrict__ S, int64_t n, M v) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        S[i] = v;
 }
 template <typename M, bool SUM> __device__ __forceinline__ int32_t track_size(M v) {
     return SUM ? (int32_t)v : (int32_t)__popcll((unsigned long long)v);
 }
-template <typename M, bool SUM>
-static __global__ void __launch_bounds__(256) k_sweep_top(const M *__restrict__ S, int64_t n, int32_t *__restrict__ A) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        A[i] = track_size<M, SUM>(S[i]);
-}
+// pS: the parent is the top of the scope — its A is the size of its own S (no separate pass); S null: the genome's own
+// track is the constant `own` (a genome without in-scope children)
 template <typename C, typename M, bool SUM>
 static __global__ void __launch_bounds__(256) k_sweep_down(const TopRec<C> *__restrict__ top, int64_t numTop, const BotRec<C> *__restrict__ pbot,
-                                                           const int32_t *__restrict__ pA, const M *__restrict__ S, int32_t *__restrict__ A) {
-    const int lane = (int)(threadIdx.x & 63);
-    const int64_t wavesTotal = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    for (int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; t < numTop; t += wavesTotal) {
+                                                           const int32_t *__restrict__ pA, const M *__restrict__ pS, const M *__restrict__ S, M own,
+                                                           int32_t *__restrict__ A) {
+    const int sub = (int)(threadIdx.x & 15);
+    const int64_t groupsTotal = ((int64_t)gridDim.x * blockDim.x) >> 4;
+    for (int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; t < numTop; t += groupsTotal) {
         const TopRec<C> tr = top[t];
         const int64_t start = (int64_t)tr.start, len = (int64_t)top[t + 1].start - start;
         if (tr.parentEnc >= 0) {
             const int64_t pstart = (int64_t)pbot[tr.parentEnc >> 1].start;
             const bool rev = (tr.parentEnc & 1) != 0;
-            for (int64_t o = lane; o < len; o += 64)
-                A[start + o] = pA[pstart + (rev ? len - 1 - o : o)];
+            for (int64_t o = sub; o < len; o += 16) {
+                const int64_t pp = pstart + (rev ? len - 1 - o : o);
+                A[start + o] = pS ? track_size<M, SUM>(pS[pp]) : pA[pp];
+            }
         } else {
-            for (int64_t o = lane; o < len; o += 64)
-                A[start + o] = track_size<M, SUM>(S[start + o]);
+            for (int64_t o = sub; o < len; o += 16)
+                A[start + o] = track_size<M, SUM>(S ? S[start + o] : own);
         }
     }
+}
+template <typename M, bool SUM>
+static __global__ void __launch_bounds__(256) k_sweep_top(const M *__restrict__ S, int64_t n, M own, int32_t *__restrict__ A) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        A[i] = track_size<M, SUM>(S ? S[i] : own);
 }
 static __global__ void __launch_bounds__(256) k_sweep_out(const int32_t *__restrict__ A, int64_t first, int64_t count, int64_t step, int32_t sub,
                                                           int32_t *__restrict__ out) {

@@ -147,27 +147,24 @@ static void refSegmentRange(hgx_alignment *h, int ref, int64_t firstPos, int64_t
 // size threshold.  mode 0: genomes - 1, 1: bases - 1 (--countDupes), 2: bases.
 template <typename C, typename M, bool SUM>
 static void sweepTracks(hgx_alignment *h, const std::vector<int> &postOrder, const std::vector<int> &path, const std::vector<char> &inScope,
-                        const std::vector<long long> &ownValue, std::vector<Buf> &S, std::vector<Buf> &A, hipStream_t s) {
+                        const std::vector<long long> &ownValue, const std::vector<char> &hasTrack, std::vector<Buf> &S, std::vector<Buf> &A,
+                        hipStream_t s) {
     const Image &img = h->img;
     const DeviceImage &D = *h->dev;
     const int GRID = 4096;
     for (int g : postOrder) {
         const GenomeTables &G = img.genomes[(size_t)g];
         const DeviceGenome &dg = D.genomes[(size_t)g];
-        if (G.totalLength <= 0)
-            continue;
+        if (G.totalLength <= 0 || !hasTrack[(size_t)g])
+            continue; // (a genome without in-scope children has the same value on every base: no track)
         std::vector<SweepChild> kids;
         for (size_t k = 0; k < G.children.size(); ++k) {
             const int c = G.children[k];
             if (!inScope[(size_t)c] || img.genomes[(size_t)c].totalLength <= 0 || img.genomes[(size_t)c].numTop <= 0)
                 continue;
-            kids.push_back(SweepChild{dg.childEnc[k], D.genomes[(size_t)c].top, S[(size_t)c].p});
+            kids.push_back(SweepChild{dg.childEnc[k], D.genomes[(size_t)c].top, hasTrack[(size_t)c] ? S[(size_t)c].p : nullptr, ownValue[(size_t)c]});
         }
         const M own = (M)ownValue[(size_t)g];
-        if (kids.empty() || G.numBot <= 0) {
-            hipLaunchKernelGGL((k_sweep_fill<M>), dim3(GRID), dim3(256), 0, s, (M *)S[(size_t)g].p, (int64_t)G.totalLength, own);
-            continue;
-        }
         for (size_t at = 0; at < kids.size(); at += SWEEP_MAX_CHILDREN) {
             SweepChildren ch;
             ch.n = (int)std::min<size_t>(SWEEP_MAX_CHILDREN, kids.size() - at);
@@ -177,15 +174,17 @@ static void sweepTracks(hgx_alignment *h, const std::vector<int> &postOrder, con
                                (M *)S[(size_t)g].p);
         }
     }
-    // top-down along the path from the top of the scope to the reference
+    // top-down along the path from the top of the scope to the reference (the top's own A is the size of its S: read from S)
     const int top = path[0];
-    hipLaunchKernelGGL((k_sweep_top<M, SUM>), dim3(GRID), dim3(256), 0, s, (const M *)S[(size_t)top].p, (int64_t)img.genomes[(size_t)top].totalLength,
-                       (int32_t *)A[(size_t)top].p);
+    if (path.size() == 1)
+        hipLaunchKernelGGL((k_sweep_top<M, SUM>), dim3(GRID), dim3(256), 0, s, hasTrack[(size_t)top] ? (const M *)S[(size_t)top].p : (const M *)nullptr,
+                           (int64_t)img.genomes[(size_t)top].totalLength, (M)ownValue[(size_t)top], (int32_t *)A[(size_t)top].p);
     for (size_t i = 1; i < path.size(); ++i) {
         const int c = path[i], p = path[i - 1];
         hipLaunchKernelGGL((k_sweep_down<C, M, SUM>), dim3(GRID), dim3(256), 0, s, (const TopRec<C> *)D.genomes[(size_t)c].top,
-                           (int64_t)img.genomes[(size_t)c].numTop, (const BotRec<C> *)D.genomes[(size_t)p].bot, (const int32_t *)A[(size_t)p].p,
-                           (const M *)S[(size_t)c].p, (int32_t *)A[(size_t)c].p);
+                           (int64_t)img.genomes[(size_t)c].numTop, (const BotRec<C> *)D.genomes[(size_t)p].bot,
+                           i == 1 ? (const int32_t *)nullptr : (const int32_t *)A[(size_t)p].p, i == 1 ? (const M *)S[(size_t)p].p : (const M *)nullptr,
+                           hasTrack[(size_t)c] ? (const M *)S[(size_t)c].p : (const M *)nullptr, (M)ownValue[(size_t)c], (int32_t *)A[(size_t)c].p);
     }
 }
 
@@ -254,36 +253,48 @@ static bool columnsDepthSweep(hgx_alignment *h, int ref, int64_t first, int64_t 
     if (!sum && bits > 64)
         return false;
     const size_t word = sum ? 4 : (bits <= 32 ? 4 : 8);
+    // a genome has a track of its own when something in scope hangs under it
+    std::vector<char> hasTrack((size_t)ng, 0);
+    for (int g : postOrder) {
+        const GenomeTables &G = img.genomes[(size_t)g];
+        if (G.numBot <= 0)
+            continue;
+        for (int c : G.children)
+            if (inScope[(size_t)c] && img.genomes[(size_t)c].totalLength > 0 && img.genomes[(size_t)c].numTop > 0)
+                hasTrack[(size_t)g] = 1;
+    }
     size_t need = 0;
     for (int g : postOrder)
-        need += (size_t)img.genomes[(size_t)g].totalLength * word;
-    for (int g : path)
-        need += (size_t)img.genomes[(size_t)g].totalLength * 4;
+        if (hasTrack[(size_t)g])
+            need += (size_t)img.genomes[(size_t)g].totalLength * word;
+    for (size_t i = path.size() == 1 ? 0 : 1; i < path.size(); ++i)
+        need += (size_t)img.genomes[(size_t)path[i]].totalLength * 4;
     size_t freeB = 0, totalB = 0;
     HIP_OK(hipMemGetInfo(&freeB, &totalB));
     if (need + (1ull << 30) > freeB)
         return false;
     std::vector<Buf> S((size_t)ng), A((size_t)ng);
     for (int g : postOrder)
-        S[(size_t)g].resize((size_t)img.genomes[(size_t)g].totalLength * word);
-    for (int g : path)
-        A[(size_t)g].resize((size_t)img.genomes[(size_t)g].totalLength * 4);
+        if (hasTrack[(size_t)g])
+            S[(size_t)g].resize((size_t)img.genomes[(size_t)g].totalLength * word);
+    for (size_t i = path.size() == 1 ? 0 : 1; i < path.size(); ++i)
+        A[(size_t)path[i]].resize((size_t)img.genomes[(size_t)path[i]].totalLength * 4);
     Ev a, b;
     HIP_OK(hipEventRecord(a.e, s));
     if (h->dev->wide) {
         if (sum)
-            sweepTracks<int64_t, int32_t, true>(h, postOrder, path, inScope, own, S, A, s);
+            sweepTracks<int64_t, int32_t, true>(h, postOrder, path, inScope, own, hasTrack, S, A, s);
         else if (word == 4)
-            sweepTracks<int64_t, uint32_t, false>(h, postOrder, path, inScope, own, S, A, s);
+            sweepTracks<int64_t, uint32_t, false>(h, postOrder, path, inScope, own, hasTrack, S, A, s);
         else
-            sweepTracks<int64_t, unsigned long long, false>(h, postOrder, path, inScope, own, S, A, s);
+            sweepTracks<int64_t, unsigned long long, false>(h, postOrder, path, inScope, own, hasTrack, S, A, s);
     } else {
         if (sum)
-            sweepTracks<int32_t, int32_t, true>(h, postOrder, path, inScope, own, S, A, s);
+            sweepTracks<int32_t, int32_t, true>(h, postOrder, path, inScope, own, hasTrack, S, A, s);
         else if (word == 4)
-            sweepTracks<int32_t, uint32_t, false>(h, postOrder, path, inScope, own, S, A, s);
+            sweepTracks<int32_t, uint32_t, false>(h, postOrder, path, inScope, own, hasTrack, S, A, s);
         else
-            sweepTracks<int32_t, unsigned long long, false>(h, postOrder, path, inScope, own, S, A, s);
+            sweepTracks<int32_t, unsigned long long, false>(h, postOrder, path, inScope, own, hasTrack, S, A, s);
     }
     hipLaunchKernelGGL(k_sweep_out, dim3(2048), dim3(256), 0, s, (const int32_t *)A[(size_t)ref].p, first, count, step, mode == 2 ? 0 : 1, d_out);
     HIP_OK(hipEventRecord(b.e, s));
