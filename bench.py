@@ -138,6 +138,9 @@ def main():
                     help="hal2maf (BASELINE config 3) over the first N reference columns, end to end to MAF text (0 = skip; one GPU only)")
     ap.add_argument("--text-path", type=int, default=1, help="also time Liftover::convert (BED text in, BED text out) on the batch (one GPU only)")
     ap.add_argument("--sustained-seconds", type=float, default=2.0, help="extra leg: the same step repeated for about this long")
+    ap.add_argument("--exchange", default="torch", choices=["torch", "c_abi"],
+                    help="who issues the batch's one all-gather: torch.distributed (the launcher's communicator, default) or the library "
+                         "itself through hgx_liftover_exchange (RCCL loaded by libhgx.so)")
     ap.add_argument("--exchange-selftest", type=int, default=0,
                     help="1: with one GPU, run the multi-GPU code path (wire blob, overlapped all-gatherv, collective settle exit) on a "
                          "one-rank RCCL group; the JSON line then says so in config.exchange")
@@ -198,21 +201,30 @@ def main():
     cold_stats = plan.stats()
     passes_before_timing = 1
 
-    collator = shard.RecordCollator()
+    # The one exchange step of the path: the batch's records of every rank, as self-describing wire blobs (12 bytes per record + 2
+    # per interval when every field fits: hgx_liftover_wire_blob) in equal slots of one buffer, ONE all-gather per batch
+    # (hal_amd/shard.py: SlotExchange) — issued by torch.distributed or, --exchange c_abi, by the library itself
+    # (hgx_liftover_exchange).  Three buffers rotate: wait() completes the oldest exchange under way, so every timed step pays for
+    # one whole exchange while the following batches are mapped.
+    exchange = None
+    if exchanging:
+        cap = torch.tensor([plan.wire_capacity()], dtype=torch.int64, device=dev)
+        dist.all_reduce(cap, op=dist.ReduceOp.MAX)  # (one slot size for all ranks, with room for batches that differ a little)
+        slot = int(cap.item()) * 5 // 4
+        comm = None
+        if args.exchange == "c_abi":
+            uid = torch.tensor(list(hal_amd.Comm.unique_id()) if rank == 0 else [0] * 128, dtype=torch.uint8, device=dev)
+            dist.broadcast(uid, 0)
+            comm = hal_amd.Comm(bytes(uid.cpu().tolist()), rank, world, local)
+        exchange = shard.SlotExchange(world, rank, slot, dev, backend=args.exchange, comm=comm)
     wire = {"format": None, "bytes": 0}
 
     def step():
         ptr, nrec = plan.run(d_gs, d_ge, d_st)
         if exchanging:
-            # the one exchange step of the path: all-gatherv of the batch's records (hal_amd/shard.py) as a self-describing
-            # blob, 12 bytes per record + 2 per interval when every field fits (hgx_liftover_wire_blob).  RecordCollator
-            # exchanges this batch's sizes now and its payload during the next step, on RCCL's stream, while the following
-            # batches are mapped; wait() completes the oldest exchange under way, so every timed step pays for one whole
-            # exchange and the host never waits for a collective in the steady state.
-            blob, fmt = plan.wire_blob(first_query=rank * nq)
-            wire["format"], wire["bytes"] = fmt, int(blob.numel())
-            collator.wait(trim=False)
-            collator.submit(blob)
+            exchange.wait()
+            exchange.submit(plan, first_query=rank * nq)
+            wire["format"], wire["bytes"] = exchange.last_format, exchange.last_bytes
         return nrec
 
     # settle (untimed): the first runs of a fresh process pay for lazy code-object loads and workspace growth, and a process
@@ -246,7 +258,7 @@ def main():
     for _ in range(args.steps):
         nrec = step()
     if exchanging:
-        collator.drain(trim=False)  # the exchanges still under way belong to the timed region
+        exchange.drain()  # the exchanges still under way belong to the timed region
     sync()
     if exchanging:
         dist.barrier()
@@ -384,8 +396,10 @@ def main():
                                   % (passes_before_timing + 1, kind_text.get(st["composed_kind"], "?"), st["composed_records"],
                                      st["composed_records"] * 16 / 1e6, st["composed_build_ms"], table_records, st["general_queries"], nq))
                        if st["composed_records"] else "level-by-level walk (k_up_chain)",
-                       "exchange": ("all-gatherv of wire blobs (format %s: %.1f MB per rank and step), overlapped with the next batch"
-                                    % (wire["format"], wire["bytes"] / 1e6))
+                       "exchange": ("one all-gather per batch of self-describing wire blobs in equal slots (%s; format %s, %.1f MB per rank and "
+                                    "step), overlapped with the next batches"
+                                    % ("hgx_liftover_exchange: RCCL from the library" if args.exchange == "c_abi" else "torch.distributed",
+                                       wire["format"], wire["bytes"] / 1e6))
                        if exchanging else "none (one GPU)",
                        "newick": al.newick, "generate_s": round(gen_s, 2)},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

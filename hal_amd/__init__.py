@@ -8,10 +8,12 @@ from ._lib import lib, HgxError, LIB_PATH  # noqa: F401
 from .api import (  # noqa: F401
     Alignment,
     LiftoverPlan,
+    Comm,
     Interval,
     Record,
     RandOptions,
     liftover_convert,
     liftover_convert_bytes,
+    liftover_convert_multi,
     RECORD_DTYPE,
 )

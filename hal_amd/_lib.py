@@ -91,6 +91,13 @@ SYMBOLS = {
     "hgx_liftover_plan_destroy": (None, [VP]),
     "hgx_liftover_run_device": (C.c_int, [VP, C.c_size_t, VP, VP, VP, VP, P(VP), P(C.c_size_t), P(VP)]),
     "hgx_liftover_last_stats": (C.c_int, [VP, P(hgx_liftover_stats)]),
+    "hgx_clone_to_device": (C.c_int, [VP, C.c_int, P(VP), P(VP)]),
+    "hgx_comm_unique_id": (C.c_int, [VP, P(VP)]),
+    "hgx_comm_create": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, P(VP), P(VP)]),
+    "hgx_comm_destroy": (None, [VP]),
+    "hgx_liftover_exchange": (C.c_int, [VP, VP, C.c_int64, VP, C.c_size_t, VP, P(C.c_size_t), P(VP)]),
+    "hgx_liftover_convert_multi": (C.c_int, [P(VP), C.c_int, C.c_int, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                             P(VP), P(C.c_size_t), P(VP)]),
     "hgx_liftover_kernel_times": (C.c_int, [VP, P(VP)]),
     "hgx_liftover_copy_records": (C.c_int, [VP, VP, C.c_size_t, VP, P(VP)]),
     "hgx_liftover_copy_records_packed": (C.c_int, [VP, VP, C.c_size_t, VP, P(VP)]),

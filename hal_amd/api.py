@@ -101,6 +101,13 @@ class Alignment:
         except Exception:
             pass
 
+    def clone_to_device(self, device):
+        """Another handle of this alignment with its tables on `device` (hgx_clone_to_device): the host image is shared."""
+        out, err = C.c_void_p(), C.c_void_p()
+        if lib.hgx_clone_to_device(self._h, device, C.byref(out), C.byref(err)) != 0:
+            raise HgxError(take_error(err))
+        return Alignment(out)
+
     def save(self, path):
         err = C.c_void_p()
         if lib.hgx_save_image(self._h, str(path).encode(), C.byref(err)) != 0:
@@ -317,6 +324,26 @@ def liftover_convert(alignment, src_genome, bed_text, tgt_genome, bed_type=0, tr
     return text
 
 
+def liftover_convert_multi(alignments, src_genome, bed_text, tgt_genome, bed_type=0, traverse_dupes=True, out_psl=False,
+                           out_psl_with_name=False, coalescence_limit=-1):
+    """hgx_liftover_convert_multi: Liftover::convert over several device clones of one alignment (Alignment.clone_to_device),
+    the input's lines shared out over them; same result as liftover_convert."""
+    data = bed_text.encode() if isinstance(bed_text, str) else bed_text
+    hs = (C.c_void_p * len(alignments))(*[a._h for a in alignments])
+    out, n, err = C.c_void_p(), C.c_size_t(), C.c_void_p()
+    rc = lib.hgx_liftover_convert_multi(hs, len(alignments), src_genome, data, len(data), tgt_genome, bed_type, 1 if traverse_dupes else 0,
+                                        1 if out_psl else 0, 1 if out_psl_with_name else 0, coalescence_limit, C.byref(out), C.byref(n),
+                                        C.byref(err))
+    text = C.string_at(out, n.value).decode() if out.value else ""
+    if out.value:
+        lib.hgx_free(out)
+    if rc != 0:
+        e = HgxError(take_error(err))
+        e.partial_output = text
+        raise e
+    return text
+
+
 def liftover_convert_bytes(alignment, src_genome, data, tgt_genome, bed_type=0, traverse_dupes=True, count_lines=True):
     """hgx_liftover_convert on BED bytes, the output left in library memory and released: (bytes, lines) of it (benchmark use:
     no decoding of a hundred megabytes of text in Python)."""
@@ -329,6 +356,33 @@ def liftover_convert_bytes(alignment, src_genome, data, tgt_genome, bed_type=0, 
     if rc != 0:
         raise HgxError(take_error(err))
     return n.value, lines
+
+
+class Comm:
+    """An RCCL communicator made by the library itself (hgx_comm_create): one process per GPU.  The 128-byte id comes from
+    Comm.unique_id() on one rank and reaches the others by whatever the launcher offers (torch.distributed, MPI, a file)."""
+
+    def __init__(self, unique_id, rank, n_ranks, device):
+        buf = (C.c_ubyte * 128).from_buffer_copy(bytes(unique_id))
+        c, err = C.c_void_p(), C.c_void_p()
+        if lib.hgx_comm_create(buf, rank, n_ranks, device, C.byref(c), C.byref(err)) != 0:
+            raise HgxError(take_error(err))
+        self._c, self.rank, self.n_ranks = c, rank, n_ranks
+
+    @staticmethod
+    def unique_id():
+        buf, err = (C.c_ubyte * 128)(), C.c_void_p()
+        if lib.hgx_comm_unique_id(buf, C.byref(err)) != 0:
+            raise HgxError(take_error(err))
+        return bytes(buf)
+
+    def close(self):
+        if self._c:
+            lib.hgx_comm_destroy(self._c)
+            self._c = None
+
+    def __del__(self):
+        self.close()
 
 
 class LiftoverPlan:
@@ -381,15 +435,29 @@ class LiftoverPlan:
             raise HgxError(take_error(err))
         return t
 
-    def wire_blob(self, first_query=0):
+    def wire_capacity(self):
+        """bytes a destination of wire_blob needs for the last run's records (any of the three formats)"""
+        st = self.stats()
+        return 32 + (2 * st["queries"] + 7) // 8 * 8 + 40 * st["records"]
+
+    def exchange(self, comm, first_query, gathered, slot_bytes):
+        """hgx_liftover_exchange: this rank's records of the last run into slot comm.rank of `gathered` (uint8 device tensor of
+        comm.n_ranks * slot_bytes) and one RCCL all-gather of the slots, ordered on the current stream.  Returns this rank's bytes."""
+        import torch
+        err, nbytes = C.c_void_p(), C.c_size_t()
+        if lib.hgx_liftover_exchange(self._p, comm._c, first_query, gathered.data_ptr(), slot_bytes, torch.cuda.current_stream().cuda_stream,
+                                     C.byref(nbytes), C.byref(err)) != 0:
+            raise HgxError(take_error(err))
+        return nbytes.value
+
+    def wire_blob(self, first_query=0, dst=None):
         """The last run's records as one self-describing uint8 tensor for the multi-GPU exchange (hgx_liftover_wire_blob;
-        hal_amd.shard.decode_blob reads it): (blob, format) with format 12 or 20 bytes per record."""
+        hal_amd.shard.decode_blob reads it): (blob, format) with format 12 or 20 bytes per record.  dst: write into this uint8
+        device tensor (a slot of an exchange buffer) instead of a fresh one."""
         import torch
         err, nbytes, fmt = C.c_void_p(), C.c_size_t(), C.c_int()
         stream = torch.cuda.current_stream().cuda_stream
-        st = self.stats()  # room for any of the three formats (the call chooses; only the bytes written are returned)
-        cap = 32 + (2 * st["queries"] + 7) // 8 * 8 + 40 * st["records"]
-        t = torch.empty(cap, dtype=torch.uint8, device="cuda")
+        t = dst if dst is not None else torch.empty(self.wire_capacity(), dtype=torch.uint8, device="cuda")
         if lib.hgx_liftover_wire_blob(self._p, t.data_ptr(), t.numel(), first_query, C.byref(nbytes), C.byref(fmt), stream, C.byref(err)) != 0:
             raise HgxError(take_error(err))
         return t[:nbytes.value], fmt.value

@@ -58,6 +58,19 @@ void hgx_close(hgx_alignment *h) {
     delete h;
 }
 
+int hgx_clone_to_device(const hgx_alignment *h, int device, hgx_alignment **out, char **err) {
+    HGX_TRY
+    if (!h || !out)
+        throw std::runtime_error("hgx_clone_to_device: null argument");
+    if (device < 0)
+        throw std::runtime_error("hgx_clone_to_device: a device ordinal is needed");
+    std::unique_ptr<hgx_alignment> c(new hgx_alignment(h->imgHolder));
+    c->dev = uploadImage(c->img, device);
+    *out = c.release();
+    return HGX_OK;
+    HGX_CATCH
+}
+
 int hgx_builder_begin(hgx_builder **out, char **err) {
     HGX_TRY
     *out = new hgx_builder;
@@ -390,8 +403,29 @@ int hgx_liftover_plan_set_timing(hgx_liftover_plan *p, int mode) {
     }
 }
 
+static int convertOver(hgx_alignment *const *handles, int n_handles, int src, const char *bed_text, size_t bed_len, int tgt, int bed_type,
+                       int traverse_dupes, int out_psl, int out_psl_with_name, int coalescence_limit, char **out_text, size_t *out_len, char **err);
+
 int hgx_liftover_convert(hgx_alignment *h, int src, const char *bed_text, size_t bed_len, int tgt, int bed_type, int traverse_dupes,
                          int out_psl, int out_psl_with_name, int coalescence_limit, char **out_text, size_t *out_len, char **err) {
+    return convertOver(&h, 1, src, bed_text, bed_len, tgt, bed_type, traverse_dupes, out_psl, out_psl_with_name, coalescence_limit, out_text, out_len,
+                       err);
+}
+
+int hgx_liftover_convert_multi(hgx_alignment *const *handles, int n_handles, int src, const char *bed_text, size_t bed_len, int tgt, int bed_type,
+                               int traverse_dupes, int out_psl, int out_psl_with_name, int coalescence_limit, char **out_text, size_t *out_len,
+                               char **err) {
+    if (!handles || n_handles < 1) {
+        setErr(err, "hgx_liftover_convert_multi: no handles");
+        return HGX_ERR;
+    }
+    return convertOver(handles, n_handles, src, bed_text, bed_len, tgt, bed_type, traverse_dupes, out_psl, out_psl_with_name, coalescence_limit,
+                       out_text, out_len, err);
+}
+
+static int convertOver(hgx_alignment *const *handles, int n_handles, int src, const char *bed_text, size_t bed_len, int tgt, int bed_type,
+                       int traverse_dupes, int out_psl, int out_psl_with_name, int coalescence_limit, char **out_text, size_t *out_len, char **err) {
+    hgx_alignment *h = handles[0];
     // Output produced before a failing input line is still returned (the reference has already written it
     // to the stream when it throws, halBedScanner.cpp:49-58).
     char *text = nullptr;
@@ -403,6 +437,11 @@ int hgx_liftover_convert(hgx_alignment *h, int src, const char *bed_text, size_t
         if (!genomeOf(h, src) || !genomeOf(h, tgt))
             throw std::runtime_error("hgx_liftover_convert: genome id out of range");
         Liftover lo;
+        for (int i = 1; i < n_handles; ++i) {
+            if (!handles[i] || handles[i]->imgHolder != h->imgHolder || !handles[i]->dev)
+                throw std::runtime_error("hgx_liftover_convert_multi: every handle must be a device clone of the first (hgx_clone_to_device)");
+            lo.moreDevices.push_back(handles[i]);
+        }
         lo.convertBuffer(h, src, bed_text ? bed_text : "", bed_len, tgt, &text, &n, bed_type, traverse_dupes != 0, out_psl != 0, out_psl_with_name != 0,
                          coalescence_limit);
     } catch (std::exception &e) {

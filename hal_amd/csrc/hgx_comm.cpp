@@ -1,0 +1,181 @@
+// The exchange step of the multi-GPU path from inside the library: RCCL (librccl.so, loaded at run time) called directly, one
+// process per GPU, ONE collective per batch.  Every rank writes the records of its plan's last run as a self-describing wire
+// blob (hgx_liftover_wire_blob) into its own slot of a buffer of n_ranks equal slots and a single in-place ncclAllGather fills
+// in the others: no exchange of sizes first — a blob carries its size in its header — and no host wait (the collective is
+// ordered on the caller's stream).  The reference has no counterpart (its parallelism is a pool of processes writing files:
+// maf/hal2mafMP.py:176-190); the semantics pinned by it are those of Liftover::visitLine's per-line independence
+// (liftover/impl/halLiftover.cpp:46-92): rank-major concatenation of the shards' records is the unsharded output.
+#include "../../include/hgx.h"
+#include "hgx_liftover_engine.hpp"
+#include <cstring>
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+
+namespace {
+
+struct UniqueId { // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128)
+    char internal[128];
+};
+typedef int (*GetUniqueIdFn)(UniqueId *);
+typedef int (*CommInitRankFn)(void **, int, UniqueId, int);
+typedef int (*AllGatherFn)(const void *, void *, size_t, int, void *, hipStream_t);
+typedef int (*CommDestroyFn)(void *);
+typedef const char *(*GetErrorStringFn)(int);
+
+struct Rccl {
+    void *lib = nullptr;
+    GetUniqueIdFn getUniqueId = nullptr;
+    CommInitRankFn commInitRank = nullptr;
+    AllGatherFn allGather = nullptr;
+    CommDestroyFn commDestroy = nullptr;
+    GetErrorStringFn getErrorString = nullptr;
+};
+
+Rccl &rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    static std::string failure;
+    std::call_once(once, [&]() {
+        // (a process that has loaded a librccl already — PyTorch's — gets that one back under the same soname)
+        const char *names[] = {getenv("HGX_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names) {
+            if (!n || !*n)
+                continue;
+            r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (r.lib)
+                break;
+        }
+        if (!r.lib) {
+            failure = "the RCCL library (librccl.so) could not be loaded; set HGX_RCCL_LIB to its path";
+            return;
+        }
+        r.getUniqueId = (GetUniqueIdFn)dlsym(r.lib, "ncclGetUniqueId");
+        r.commInitRank = (CommInitRankFn)dlsym(r.lib, "ncclCommInitRank");
+        r.allGather = (AllGatherFn)dlsym(r.lib, "ncclAllGather");
+        r.commDestroy = (CommDestroyFn)dlsym(r.lib, "ncclCommDestroy");
+        r.getErrorString = (GetErrorStringFn)dlsym(r.lib, "ncclGetErrorString");
+        if (!r.getUniqueId || !r.commInitRank || !r.allGather || !r.commDestroy)
+            failure = "librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy";
+    });
+    if (!failure.empty())
+        throw std::runtime_error(failure);
+    return r;
+}
+
+void check(int rc, const char *what) {
+    if (rc != 0) {
+        Rccl &r = rccl();
+        throw std::runtime_error(std::string(what) + ": " + (r.getErrorString ? r.getErrorString(rc) : "RCCL error") + " (" + std::to_string(rc) + ")");
+    }
+}
+
+void setErr(char **err, const std::string &m) {
+    if (err) {
+        *err = (char *)malloc(m.size() + 1);
+        if (*err)
+            memcpy(*err, m.c_str(), m.size() + 1);
+    }
+}
+
+} // namespace
+
+struct hgx_comm {
+    void *comm = nullptr;
+    int rank = 0, nRanks = 1, device = 0;
+};
+
+extern "C" {
+
+int hgx_comm_unique_id(unsigned char *id128, char **err) {
+    try {
+        if (!id128)
+            throw std::runtime_error("hgx_comm_unique_id: null argument");
+        UniqueId id;
+        memset(&id, 0, sizeof id);
+        check(rccl().getUniqueId(&id), "ncclGetUniqueId");
+        memcpy(id128, id.internal, 128);
+        return HGX_OK;
+    } catch (std::exception &e) {
+        setErr(err, e.what());
+        return HGX_ERR;
+    }
+}
+
+int hgx_comm_create(const unsigned char *id128, int rank, int n_ranks, int device, hgx_comm **out, char **err) {
+    try {
+        if (!id128 || !out || n_ranks < 1 || rank < 0 || rank >= n_ranks)
+            throw std::runtime_error("hgx_comm_create: bad argument");
+        if (hipSetDevice(device) != hipSuccess)
+            throw std::runtime_error("hgx_comm_create: invalid device ordinal " + std::to_string(device));
+        UniqueId id;
+        memcpy(id.internal, id128, 128);
+        hgx_comm *c = new hgx_comm;
+        c->rank = rank;
+        c->nRanks = n_ranks;
+        c->device = device;
+        const int rc = rccl().commInitRank(&c->comm, n_ranks, id, rank);
+        if (rc != 0) {
+            delete c;
+            check(rc, "ncclCommInitRank");
+        }
+        *out = c;
+        return HGX_OK;
+    } catch (std::exception &e) {
+        setErr(err, e.what());
+        return HGX_ERR;
+    }
+}
+
+void hgx_comm_destroy(hgx_comm *c) {
+    if (!c)
+        return;
+    if (c->comm) {
+        (void)hipSetDevice(c->device);
+        (void)rccl().commDestroy(c->comm);
+    }
+    delete c;
+}
+
+int hgx_liftover_exchange(hgx_liftover_plan *p, hgx_comm *c, int64_t first_query, void *d_gathered, size_t slot_bytes, void *hip_stream,
+                          size_t *my_bytes, char **err) {
+    try {
+        if (!p || !c || !d_gathered)
+            throw std::runtime_error("hgx_liftover_exchange: null argument");
+        if (slot_bytes < 64 || slot_bytes % 8)
+            throw std::runtime_error("hgx_liftover_exchange: the slot size must be a multiple of 8 and at least 64 bytes");
+        unsigned char *mine = (unsigned char *)d_gathered + (size_t)c->rank * slot_bytes;
+        const size_t need = hgx::liftoverPlanWireBlob(p, nullptr, 0, first_query, nullptr, hip_stream);
+        size_t wrote = 0;
+        bool fits = need <= slot_bytes;
+        if (fits) {
+            wrote = hgx::liftoverPlanWireBlob(p, mine, slot_bytes, first_query, nullptr, hip_stream);
+        } else {
+            // the collective still has to happen on every rank: this rank sends a header that says so (format 0, the bytes it
+            // would have needed in the record count) and reports the error after the exchange
+            struct {
+                char magic[4];
+                uint32_t format;
+                int64_t firstQuery;
+                uint64_t nq, nrec;
+            } h = {{'H', 'G', 'X', 'W'}, 0u, first_query, 0ull, (uint64_t)need};
+            if (hipMemcpyAsync(mine, &h, sizeof h, hipMemcpyHostToDevice, (hipStream_t)hip_stream) != hipSuccess ||
+                hipStreamSynchronize((hipStream_t)hip_stream) != hipSuccess)
+                throw std::runtime_error("hgx_liftover_exchange: could not write the slot header");
+        }
+        check(rccl().allGather(mine, d_gathered, slot_bytes, /*ncclUint8*/ 1, c->comm, (hipStream_t)hip_stream), "ncclAllGather");
+        if (my_bytes)
+            *my_bytes = wrote;
+        if (!fits)
+            throw std::runtime_error("hgx_liftover_exchange: this rank's records need " + std::to_string(need) + " bytes, the slot has " +
+                                     std::to_string(slot_bytes) + " (the exchange was carried out; the slot's header says so to the other ranks)");
+        return HGX_OK;
+    } catch (std::exception &e) {
+        setErr(err, e.what());
+        return HGX_ERR;
+    }
+}
+
+} // extern "C"

@@ -218,7 +218,12 @@ std::unique_ptr<DeviceImage> uploadImage(const Image &img, int device);
 // the opaque handle of include/hgx.h
 struct hgx_liftover_plan;
 struct hgx_alignment {
-    hgx::Image img;
+    // the host image is shared by the handles hgx_clone_to_device makes of one alignment (one copy in host memory, one set of
+    // tables per device); `img` is the name every user of a handle knows it by
+    std::shared_ptr<hgx::Image> imgHolder;
+    hgx::Image &img;
+    hgx_alignment() : imgHolder(std::make_shared<hgx::Image>()), img(*imgHolder) {}
+    explicit hgx_alignment(const std::shared_ptr<hgx::Image> &shared) : imgHolder(shared), img(*imgHolder) {}
     std::unique_ptr<hgx::DeviceImage> dev;
     // the host-buffer entry points (hgx_liftover_batch, hgx_liftover_convert) keep their last plan: creating one means
     // gigabytes of device allocations, and a BED file is lifted in several batches with the same genomes and options

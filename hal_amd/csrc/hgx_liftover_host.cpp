@@ -400,8 +400,10 @@ void Liftover::convertBuffer(hgx_alignment *al, int srcGenome, const char *text,
     if (!(outPSL || outPSLWithName) && !getenv("HGX_TEXT_GENERAL")) {
         std::string error;
         _missedSet.clear();
-        if (liftoverTextFast(al, srcGenome, text, len, tgtGenome, bedType, traverseDupes, coalescenceLimit, outText, outLen, error, _missedSet,
-                             lastStats)) {
+        std::vector<hgx_alignment *> als{al};
+        als.insert(als.end(), moreDevices.begin(), moreDevices.end());
+        if (liftoverTextFast(als.data(), (int)als.size(), srcGenome, text, len, tgtGenome, bedType, traverseDupes, coalescenceLimit, outText, outLen,
+                             error, _missedSet, lastStats)) {
             if (!error.empty())
                 throw std::runtime_error(error);
             return;

@@ -59,6 +59,9 @@ class Liftover {
     // *outText: malloc'd, NUL-terminated, owned by the caller (also set when an exception reports a malformed line)
     void convertBuffer(hgx_alignment *alignment, int srcGenome, const char *text, size_t len, int tgtGenome, char **outText, size_t *outLen,
                        int bedType = 0, bool traverseDupes = true, bool outPSL = false, bool outPSLWithName = false, int coalescenceLimit = -1);
+    // further handles of the same alignment on other devices (hgx_clone_to_device): convert / convertBuffer shard the lines
+    // of inputs the parallel text path takes over `alignment` and these
+    std::vector<hgx_alignment *> moreDevices;
     // intervals per device batch (memory bound only)
     size_t batchLines = 1u << 22;
     hgx_liftover_stats lastStats{};
@@ -78,8 +81,9 @@ class Liftover {
 };
 
 // hgx_liftover_text.cpp; false: not an input for the fast path (nothing was done)
-bool liftoverTextFast(hgx_alignment *al, int srcGenome, const char *text, size_t len, int tgtGenome, int bedType, bool traverseDupes,
-                      int coalescenceLimit, char **outText, size_t *outLen, std::string &error, std::set<std::string> &missedSet,
-                      hgx_liftover_stats &stats);
+// als: one handle per device (hgx_clone_to_device); the lines are dealt to them in contiguous shares
+bool liftoverTextFast(hgx_alignment *const *als, int nAls, int srcGenome, const char *text, size_t len, int tgtGenome, int bedType,
+                      bool traverseDupes, int coalescenceLimit, char **outText, size_t *outLen, std::string &error,
+                      std::set<std::string> &missedSet, hgx_liftover_stats &stats);
 
 } // namespace hgx

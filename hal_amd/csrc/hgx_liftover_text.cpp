@@ -45,6 +45,7 @@ struct Chunk {
     const char *begin, *end;
     std::vector<Line> lines;
     size_t numQueries = 0, firstQuery = 0, firstLine = 0;
+    int device = 0;               // which handle lifts the chunk's lines (firstQuery counts inside that handle's batch)
     std::string error;            // first malformed line of the chunk (then `lines` ends before it)
     size_t errorLine = 0;         // its number inside the chunk, 1-based
     size_t linesSeen = 0;
@@ -289,11 +290,12 @@ template <typename F> void forEachChunk(std::vector<Chunk> &chunks, unsigned thr
 
 } // namespace
 
-bool liftoverTextFast(hgx_alignment *al, int srcGenome, const char *text, size_t len, int tgtGenome, int bedType, bool traverseDupes,
-                      int coalescenceLimit, char **outText, size_t *outLen, std::string &error, std::set<std::string> &missedSet,
-                      hgx_liftover_stats &stats) {
+bool liftoverTextFast(hgx_alignment *const *als, int nAls, int srcGenome, const char *text, size_t len, int tgtGenome, int bedType,
+                      bool traverseDupes, int coalescenceLimit, char **outText, size_t *outLen, std::string &error,
+                      std::set<std::string> &missedSet, hgx_liftover_stats &stats) {
     *outText = nullptr;
     *outLen = 0;
+    hgx_alignment *al = als[0];
     if (bedType > 9 || bedType == 7 || bedType < 0)
         return false;
     const GenomeTables &S = al->img.genomes[(size_t)srcGenome], &T = al->img.genomes[(size_t)tgtGenome];
@@ -349,7 +351,6 @@ bool liftoverTextFast(hgx_alignment *al, int srcGenome, const char *text, size_t
     for (size_t i = 0; i < usable; ++i) {
         Chunk &C = chunks[i];
         C.bedType = bt;
-        C.firstQuery = nq;
         C.firstLine = nlines;
         nq += C.numQueries;
         nlines += C.linesSeen;
@@ -368,20 +369,37 @@ bool liftoverTextFast(hgx_alignment *al, int srcGenome, const char *text, size_t
     stats = hgx_liftover_stats{};
     if (nq == 0)
         return true;
-    int64_t *gs, *ge;
-    uint8_t *st;
-    liftoverStageQueries(al, nq, &gs, &ge, &st);
+    // contiguous shares of the chunks for the devices, about the same number of intervals each
+    std::vector<size_t> devQueries((size_t)nAls, 0);
+    {
+        const size_t share = (nq + (size_t)nAls - 1) / (size_t)nAls;
+        int d = 0;
+        for (Chunk &C : chunks) {
+            if (devQueries[(size_t)d] >= share && d + 1 < nAls)
+                ++d;
+            C.device = d;
+            C.firstQuery = devQueries[(size_t)d];
+            devQueries[(size_t)d] += C.numQueries;
+        }
+    }
+    std::vector<int64_t *> gs((size_t)nAls), ge((size_t)nAls);
+    std::vector<uint8_t *> st((size_t)nAls);
+    for (int d = 0; d < nAls; ++d)
+        if (devQueries[(size_t)d])
+            liftoverStageQueries(als[d], devQueries[(size_t)d], &gs[(size_t)d], &ge[(size_t)d], &st[(size_t)d]);
     forEachChunk(chunks, threads, [&](Chunk &C) {
         size_t q = C.firstQuery;
+        int64_t *s0 = gs[(size_t)C.device], *e0 = ge[(size_t)C.device];
+        uint8_t *t0 = st[(size_t)C.device];
         for (Line &L : C.lines) {
             if (L.seq < 0) {
                 L.query = -1;
                 continue;
             }
-            const int64_t s0 = S.seqs[(size_t)L.seq].start;
-            gs[q] = L.start + s0;      // halBlockLiftover.cpp:48
-            ge[q] = L.end - 1 + s0;    // :49
-            st[q] = (uint8_t)L.strand;
+            const int64_t off = S.seqs[(size_t)L.seq].start;
+            s0[q] = L.start + off;     // halBlockLiftover.cpp:48
+            e0[q] = L.end - 1 + off;   // :49
+            t0[q] = (uint8_t)L.strand;
             L.query = (int64_t)q++;
         }
     });
@@ -389,16 +407,46 @@ bool liftoverTextFast(hgx_alignment *al, int srcGenome, const char *text, size_t
     hgx_liftover_opts opts{};
     opts.traverse_dupes = traverseDupes ? 1 : 0;
     opts.coalescence_limit = coalescenceLimit;
-    const hgx_record *recs = nullptr;
-    size_t nRecs = 0;
-    try {
-        liftoverBatchStaged(al, srcGenome, tgtGenome, nq, opts, &recs, &nRecs, &stats);
-    } catch (std::exception &e) { // (the reference's scanner adds the line to whatever visitLine throws)
-        error = std::string(e.what()) + " in input bed line 1";
-        return true;
+    std::vector<const hgx_record *> recs((size_t)nAls, nullptr);
+    std::vector<size_t> nRecs((size_t)nAls, 0);
+    std::vector<hgx_liftover_stats> devStats((size_t)nAls);
+    std::vector<std::string> devError((size_t)nAls);
+    {
+        auto run = [&](int d) {
+            if (!devQueries[(size_t)d])
+                return;
+            try {
+                liftoverBatchStaged(als[d], srcGenome, tgtGenome, devQueries[(size_t)d], opts, &recs[(size_t)d], &nRecs[(size_t)d], &devStats[(size_t)d]);
+            } catch (std::exception &e) {
+                devError[(size_t)d] = e.what();
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int d = 1; d < nAls; ++d)
+            pool.emplace_back(run, d);
+        run(0);
+        for (std::thread &t : pool)
+            t.join();
+    }
+    for (int d = 0; d < nAls; ++d) {
+        if (!devError[(size_t)d].empty()) { // (the reference's scanner adds the line to whatever visitLine throws)
+            error = devError[(size_t)d] + " in input bed line 1";
+            return true;
+        }
+        stats.queries += devStats[(size_t)d].queries;
+        stats.records += devStats[(size_t)d].records;
+        stats.mapped_pieces += devStats[(size_t)d].mapped_pieces;
+        stats.top_derefs += devStats[(size_t)d].top_derefs;
+        stats.bottom_derefs += devStats[(size_t)d].bottom_derefs;
+        stats.deferred_queries += devStats[(size_t)d].deferred_queries;
+        stats.general_queries += devStats[(size_t)d].general_queries;
+        stats.total_ms = std::max(stats.total_ms, devStats[(size_t)d].total_ms);
+        stats.walk_ms = std::max(stats.walk_ms, devStats[(size_t)d].walk_ms);
+        stats.composed_kind = devStats[(size_t)d].composed_kind;
+        stats.composed_records = devStats[(size_t)d].composed_records;
     }
     const auto t3 = now();
-    forEachChunk(chunks, threads, [&](Chunk &C) { renderChunk(C, recs, nRecs, T); });
+    forEachChunk(chunks, threads, [&](Chunk &C) { renderChunk(C, recs[(size_t)C.device], nRecs[(size_t)C.device], T); });
     const auto t4 = now();
     size_t total = 0;
     for (Chunk &C : chunks) {
@@ -419,7 +467,7 @@ bool liftoverTextFast(hgx_alignment *al, int srcGenome, const char *text, size_t
     *outText = buf;
     *outLen = total;
     if (timing)
-        std::cerr << "[hgx text] " << threads << " threads, " << chunks.size() << " chunks: tokenise " << ms(t0, t1) << " ms, stage " << ms(t1, t2)
+        std::cerr << "[hgx text] " << threads << " threads, " << nAls << " device(s), " << chunks.size() << " chunks: tokenise " << ms(t0, t1) << " ms, stage " << ms(t1, t2)
                   << ", device (H2D, kernels, D2H) " << ms(t2, t3) << ", render " << ms(t3, t4) << ", allocate output " << ms(t4, t5) << ", gather "
                   << ms(t5, now()) << std::endl;
     return true;

@@ -270,3 +270,84 @@ class RecordCollator:
             if r is None:
                 return done
             done.append(r)
+
+
+class SlotExchange:
+    """ONE collective per batch.  Every rank owns a slot of `slot_bytes` in a buffer of world_size equal slots; its records
+    travel as a self-describing wire blob (hgx_liftover_wire_blob: the header carries the sizes, so no exchange of sizes comes
+    first) and one all-gather fills in the other slots.  backend "c_abi": hgx_liftover_exchange — RCCL called by the library
+    itself on the current stream; "torch": torch.distributed's all-gather of the same slots (the launcher's own communicator;
+    gloo on CPU for the tests).  submit() starts the exchange of the plan's last run, wait() hands out the oldest buffer under
+    way (three rotate, so the mapping of the next batches overlaps the exchange); slots(buf) views the ranks' blobs."""
+
+    def __init__(self, world, rank, slot_bytes, device, backend="torch", comm=None):
+        self.world, self.rank, self.slot = world, rank, (int(slot_bytes) + 7) // 8 * 8
+        self.backend, self.comm = backend, comm
+        self._bufs = [torch.zeros(world * self.slot, dtype=torch.uint8, device=device) for _ in range(3)]
+        self._turn, self._inflight = 0, []
+        self.last_bytes, self.last_format = 0, None
+
+    def _mine(self, buf):
+        return buf[self.rank * self.slot:(self.rank + 1) * self.slot]
+
+    def submit(self, plan=None, first_query=0, blob=None):
+        """plan: a LiftoverPlan whose last run is exchanged; blob: a ready blob instead (CPU tests)"""
+        buf = self._bufs[self._turn % 3]
+        self._turn += 1
+        work = None
+        if self.backend == "c_abi":
+            self.last_bytes = plan.exchange(self.comm, first_query, buf, self.slot)
+        else:
+            mine = self._mine(buf)
+            if blob is not None:
+                if blob.numel() > self.slot:
+                    raise ValueError("blob of %d bytes does not fit the slot of %d" % (blob.numel(), self.slot))
+                mine[:blob.numel()] = blob
+                self.last_bytes = int(blob.numel())
+            else:
+                if plan.wire_capacity() > self.slot:
+                    raise ValueError("this rank's records may need %d bytes, the slot has %d" % (plan.wire_capacity(), self.slot))
+                b, self.last_format = plan.wire_blob(first_query, dst=mine)
+                self.last_bytes = int(b.numel())
+            if buf.device.type == "cuda":
+                work = dist.all_gather_into_tensor(buf, mine, async_op=True)
+            else:
+                parts = list(buf.view(self.world, self.slot).unbind(0))
+                work = dist.all_gather(parts, mine.clone(), async_op=True)
+        self._inflight.append((work, buf))
+
+    def wait(self):
+        if not self._inflight:
+            return None
+        work, buf = self._inflight.pop(0)
+        if work is not None:
+            work.wait()
+        return buf
+
+    def drain(self):
+        out = []
+        while self._inflight:
+            out.append(self.wait())
+        return out
+
+    def slots(self, buf):
+        """the ranks' blobs (each trimmed to what its header says it holds), in rank order"""
+        out = []
+        for r in range(self.world):
+            s = buf[r * self.slot:(r + 1) * self.slot]
+            out.append(s[:blob_bytes(s)])
+        return out
+
+
+def blob_bytes(slot):
+    """length of the blob at the start of a slot, from its 32-byte header {"HGXW", u32 format, i64 first_query, u64 n_queries, u64 n_records}"""
+    h = slot[:32].cpu().numpy().tobytes()
+    if h[:4] != b"HGXW":
+        raise ValueError("not a wire blob")
+    fmt = int.from_bytes(h[4:8], "little")
+    nq, nrec = int.from_bytes(h[16:24], "little"), int.from_bytes(h[24:32], "little")
+    if fmt == 0:
+        raise ValueError("a rank's records did not fit its slot (it needed %d bytes)" % nrec)
+    if fmt == 12:
+        return 32 + (2 * nq + 7) // 8 * 8 + 12 * nrec
+    return 32 + (20 if fmt == 20 else 40) * nrec

@@ -30,6 +30,10 @@ typedef struct hgx_alignment hgx_alignment;
  * entry point fails). */
 int hgx_open(const char *path, int device, hgx_alignment **out, char **err);
 void hgx_close(hgx_alignment *h);
+/* A second handle of the same alignment with its tables on another device of this process (multi-GPU, one process): the
+ * host image is shared, everything device-side (tables, plans, staging) belongs to the new handle.  Released with hgx_close
+ * like any handle, in any order. */
+int hgx_clone_to_device(const hgx_alignment *h, int device, hgx_alignment **out, char **err);
 
 /* Build an alignment from caller-owned flat arrays instead of a file (the route for HDF5-backed
  * alignments: the maintainer-side loop over Genome::getTopSegmentIterator/getBottomSegmentIterator is
@@ -111,6 +115,15 @@ typedef struct hgx_liftover_opts {
 int hgx_liftover_batch(hgx_alignment *h, int src_genome, int tgt_genome, size_t n, const hgx_interval *intervals,
                        const hgx_liftover_opts *opts, hgx_record **out, size_t *n_out, char **err);
 
+/* Liftover::convert over several handles of one alignment (hgx_clone_to_device), one per GPU: the input's lines are dealt to
+ * the devices in contiguous shares, lifted at the same time, and the output is put together in input order on the host —
+ * the one-process form of sharding independent intervals (liftover/impl/halLiftover.cpp:46-92 clears all state per line).
+ * Same arguments, output and errors as hgx_liftover_convert; inputs the parallel text path does not take (BED12, PSL, mixed
+ * column counts) run on handles[0] alone. */
+int hgx_liftover_convert_multi(hgx_alignment *const *handles, int n_handles, int src_genome, const char *bed_text, size_t bed_len,
+                               int tgt_genome, int bed_type, int traverse_dupes, int out_psl, int out_psl_with_name, int coalescence_limit,
+                               char **out_text, size_t *out_len, char **err);
+
 /* BlockMapper (liftover/inc/halBlockMapper.h:30-40) without adjacencies: init(refGenome, queryGenome, absRefFirst,
  * absRefLast, targetReversed, doDupes, minLength, false, coalescenceLimit); map(); getMap().  abs_ref_first/last are
  * genome coordinates, last inclusive.  Records as described at hgx_liftover_opts.emit_blocks, query = 0; the source
@@ -191,6 +204,23 @@ int hgx_liftover_copy_records_packed(const hgx_liftover_plan *p, void *d_dst, si
  * the batch's first interval (what shard_bounds gave this rank). */
 int hgx_liftover_wire_blob(hgx_liftover_plan *p, void *d_dst, size_t capacity, int64_t first_query, size_t *bytes, int *format,
                            void *hip_stream, char **err);
+
+/* ---- the exchange step between the GPUs of a node, one process per GPU (RCCL, loaded by the library at run time) ----
+ * hgx_comm_unique_id: made by one rank and handed to all (file, MPI, torch.distributed ...: 128 bytes);
+ * hgx_comm_create: collective over the n_ranks ranks, each on its own device.
+ * hgx_liftover_exchange: ONE collective per batch — this rank's records of the plan's last run travel as a wire blob
+ * (hgx_liftover_wire_blob: self-describing, its header carries its sizes) in slot `rank` of d_gathered, a device buffer of
+ * n_ranks slots of slot_bytes each; on return (stream-ordered on hip_stream) every slot holds the blob of its rank, and the
+ * rank-major concatenation of their records is the unsharded output (intervals are independent: halLiftover.cpp:46-92).
+ * A rank whose blob does not fit still takes part (its slot's header has format 0 and the bytes it needed in n_records) and
+ * returns HGX_ERR. */
+typedef struct hgx_comm hgx_comm;
+int hgx_comm_unique_id(unsigned char *id128, char **err);
+int hgx_comm_create(const unsigned char *id128, int rank, int n_ranks, int device, hgx_comm **out, char **err);
+void hgx_comm_destroy(hgx_comm *c);
+int hgx_liftover_exchange(hgx_liftover_plan *p, hgx_comm *c, int64_t first_query, void *d_gathered, size_t slot_bytes, void *hip_stream,
+                          size_t *my_bytes, char **err);
+
 
 /* Text-level drop-in for Liftover::convert (liftover/inc/halLiftover.h:25-28): BED text in, BED text
  * out, byte-identical to halLiftover for BED3..BED9 (+ extra columns).  bed_type 0 = auto

@@ -166,3 +166,55 @@ def test_shard_bounds_cover_everything():
         for world in (1, 2, 4, 8):
             b = [shard_bounds(n, world, r) for r in range(world)]
             assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _slot_worker(rank, world, port, result):
+    """The one-collective exchange (hal_amd.shard.SlotExchange) on records of a real lift: tests/golden/lifted_records.npz holds
+    the hgx_record rows a GPU produced for 600 intervals (tests/golden/make_lifted_records.py), the rows of two uneven shards
+    of them as two ranks would lift them, and the wire blobs the DEVICE wrote for those shards."""
+    from hal_amd.shard import SlotExchange
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    z = np.load(os.path.join(GOLD, "lifted_records.npz"))
+    bounds = [int(b) for b in z["bounds"]]
+    mine = torch.from_numpy(z["shard%d" % rank].copy())
+    nq = bounds[rank + 1] - bounds[rank]
+    blob = encode_blob(mine, nq, first_query=bounds[rank])
+    # the torch encoder writes the bytes the device wrote (so what travels here is what travels between GPUs)
+    ok = bool(torch.equal(blob, torch.from_numpy(z["blob%d" % rank].copy()))) and int(z["formats"][rank]) == 12
+    slot = 16384
+    ex = SlotExchange(world, rank, slot, "cpu", backend="torch")
+    assert ex.wait() is None
+    for _ in range(4):  # a stream of batches: three buffers rotate
+        ex.submit(blob=blob)
+    bufs = ex.drain()
+    ok = ok and len(bufs) == 4
+    whole = torch.from_numpy(z["whole"].copy())
+    for buf in bufs:
+        parts = ex.slots(buf)
+        ok = ok and [p.numel() for p in parts] == [int(z["blob0"].shape[0]), int(z["blob1"].shape[0])]
+        decoded = torch.cat([decode_blob(p)[0] for p in parts], dim=0)
+        ok = ok and bool(torch.equal(decoded, whole))  # rank-major concatenation of the shards = the unsharded lift
+    try:
+        SlotExchange(world, rank, 64, "cpu", backend="torch").submit(blob=blob)
+        ok = False
+    except ValueError:
+        pass
+    result[rank] = ok
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_collective_exchange_of_real_lifted_records_world2():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mgr = mp.Manager()
+    result = mgr.dict()
+    mp.spawn(_slot_worker, args=(2, port, result), nprocs=2, join=True)
+    assert result[0] and result[1]

@@ -117,3 +117,33 @@ def test_a_million_lines(hal, tmp_path):
     bed = "".join("%s\t%d\t%d\tq%d\t%d\t%s\n" % (name, a, a + b, i, i % 1000, "+-"[i & 1]) for i, (a, b) in enumerate(zip(starts, lens)))
     status, text = _both(hal, al, src, bed, tgt)
     assert status == "ok" and text.count("\n") > 2 * n
+
+
+def test_lines_shared_out_over_device_clones(hal, oracle_bin, tmp_path):
+    """hgx_liftover_convert_multi: three handles of one alignment (clones on the one GPU of the test box: the sharding, staging
+    and collation are the same code as with three GPUs) give the bytes of the single handle and of the oracle, also with a
+    malformed line in the last share, and so does the CLI twin with --devices."""
+    import subprocess
+    al, img = _rand_alignment(hal, tmp_path, 2)
+    clones = [al, al.clone_to_device(0), al.clone_to_device(0)]
+    src, tgt = al.genome_id("Genome_9"), al.genome_id("Genome_2")
+    name, _, length = al.sequences(src)[0]
+    rng = np.random.default_rng(9)
+    body = _lines(name, length, 30000, 6, rng)
+    bed = "\n".join(body) + "\n"
+    one = hal.liftover_convert(al, src, bed, tgt)
+    assert hal.liftover_convert_multi(clones, src, bed, tgt) == one
+    assert one == oracle_liftover(oracle_bin, img, "Genome_9", "Genome_2", bed, tmp_path)
+    assert hal.liftover_convert_multi(clones, src, bed, tgt, traverse_dupes=False) == hal.liftover_convert(al, src, bed, tgt, traverse_dupes=False)
+    bad = body[:29000] + ["%s\t10\t5\tq\t0\t+" % name] + body[29000:]
+    with pytest.raises(hal.HgxError, match="in input bed line 29001") as e:
+        hal.liftover_convert_multi(clones, src, "\n".join(bad) + "\n", tgt)
+    assert e.value.partial_output == hal.liftover_convert(al, src, "\n".join(body[:29000]) + "\n", tgt)
+    # BED12 goes the general way on the first handle
+    b12 = "".join("%s\t%d\t%d\tn\t0\t+\t%d\t%d\t0\t2\t10,10,\t0,%d,\n" % (name, a, a + 60, a, a + 60, 50) for a in range(100, 20000, 700))
+    assert hal.liftover_convert_multi(clones, src, b12, tgt) == hal.liftover_convert(al, src, b12, tgt)
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hal_amd", "_build", "halLiftover")
+    inp, outp = str(tmp_path / "in.bed"), str(tmp_path / "out.bed")
+    open(inp, "w").write(bed)
+    subprocess.check_call([tool, "--devices", "0,0", img, "Genome_9", inp, "Genome_2", outp])
+    assert open(outp).read() == one
