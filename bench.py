@@ -497,9 +497,21 @@ def main():
                                    "parity_with_gpu": gpu_text == text}
             if multi:
                 out["cpu_baseline"]["all_cores"] = multi
-        print(json.dumps(out))
+        result_line = json.dumps(out)
+    else:
+        result_line = None
     if exchanging:
         dist.destroy_process_group()
+    # the JSON line is the last thing on stdout: whatever C libraries have buffered (RCCL prints its version banner through
+    # stdio) goes out first
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    if result_line is not None:
+        print(result_line, flush=True)
 
 
 def plan_kernel_bytes(kt, st, steps):

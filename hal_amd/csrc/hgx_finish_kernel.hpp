@@ -1304,9 +1304,12 @@ __global__ void __launch_bounds__(256) k_general_wave(const int64_t *__restrict_
         L.nl = 0;
         if (!pass)
             pass = !finish_wave<C>(lane, n, tLo, tHi, sLo, sHi, fl, seqStart, numSeq, sDAll[w], sOwnAll[w], L);
-        if (pass) {
-            if (lane == 0)
+        if (pass) { // (no records yet: a run that does not make the launches behind this one sees an empty interval and is repeated)
+            if (lane == 0) {
                 restList[atomicAdd(restCount, 1ull)] = q;
+                nOut[q] = 0;
+                offset[q] = 0;
+            }
             continue;
         }
         // a slice of the grouped buffer for the records

@@ -413,9 +413,10 @@ static __global__ void __launch_bounds__(256, MINW) k_lift_merged(const int64_t 
 // End of a single-pass run: folds the spread statistics words (hgx_liftover_kernels.hpp: stat_add) and gathers everything
 // the host reads back into LIFT_RB_WORDS consecutive words — one 128-byte copy per batch.
 // rb[0..7] = the scalar slots (CNT_MAPPED with the pieces of this run), rb[8 + l] = top-slot count of launch l (l < 4),
-// rb[12] = general intervals.
+// rb[12] = general intervals, rb[13] = the ones k_general_wave passed on.
 static constexpr int LIFT_RB_WORDS = 16;
-static __global__ void k_lift_epilogue(unsigned long long *counters, const unsigned long long *generalCount, unsigned long long *rb) {
+static __global__ void k_lift_epilogue(unsigned long long *counters, const unsigned long long *generalCount, const unsigned long long *restCount,
+                                       unsigned long long *rb) {
     __shared__ unsigned long long sums[5];
     const int w = (int)threadIdx.x;
     if (w < 5) {
@@ -432,6 +433,8 @@ static __global__ void k_lift_epilogue(unsigned long long *counters, const unsig
         rb[w] = sums[w - 7];
     else if (w == 12)
         rb[w] = *generalCount;
+    else if (w == 13)
+        rb[w] = restCount ? *restCount : 0ull; // intervals k_general_wave passed on
 }
 
 } // namespace hgx

@@ -470,7 +470,8 @@ struct hgx_liftover_plan {
     bool mergedDisabled = false; // a look-back wait timed out once: this plan keeps to the multi-kernel path
     bool mergedOffThisRun = false;
     int liftGrid = 0, liftMinWaves = 1;
-    unsigned long long generalQueries = 0;
+    unsigned long long generalQueries = 0, liftRestCount = 0;
+    bool liftRestSeen = false, liftRestSkipped = false; // (see runMergedOnce: the launches behind k_general_wave)
     // scratch of the single-pass runs for intervals that outgrow the LDS finishing kernel (k_finish_big without a host
     // synchronisation in between): liftBigSlots slices for liftBigCap pieces each, grown when a run needed more
     uint32_t liftBigSlots = 0;
@@ -631,6 +632,11 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
     }
     const uint32_t *lateList = waveFinish ? restList : generalList;
     const unsigned long long *lateCount = waveFinish ? restCount : generalCount;
+    // Two more launches for what k_general_wave passes on (more than 64 pieces) — made only once a run of this plan has passed
+    // something on: a run that skips them reads the count back with its counters and is repeated with them when it is not zero
+    // (runPlan), so batches without such intervals do not pay for two empty launches.
+    P.liftRestSkipped = waveFinish && !P.liftRestSeen;
+    if (!P.liftRestSkipped) {
     P.timer.begin("k_locate_through", s, launch);
     // (the list's length is only known on the device; the grids are sized for a list that is a small part of the batch)
     hipLaunchKernelGGL((k_locate_through<C>), dim3(std::min(512, residentGrid(k_locate_through<C>))), dim3(256), 0, s, dS, dE, dStrand, nq, srcLength,
@@ -645,7 +651,10 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
                        (int)TG.numSeq, (hgx_record *)P.grouped.p, (uint32_t *)P.nOut.p, (uint32_t *)P.deferredList.p, (uint32_t *)P.needCap.p,
                        cnt, 0);
     P.timer.end(s);
-    if (P.liftBigSlots) { // intervals k_finish_lds deferred: same algorithm on global scratch; their records become slices behind the grouped buffer
+    } else {
+        HIP_OK(hipEventRecord(P.evWalk, s));
+    }
+    if (P.liftBigSlots && !P.liftRestSkipped) { // intervals k_finish_lds deferred: same algorithm on global scratch; their records become slices behind the grouped buffer
         P.timer.begin("k_finish_big", s);
         hipLaunchKernelGGL((k_finish_big<C>), dim3(P.liftBigSlots), dim3(64), 0, s, P.mapped(1), (const uint32_t *)P.offset.p,
                            (const uint32_t *)P.perQuery.p, (const uint32_t *)P.deferredList.p, P.liftBigSlots, P.liftBigCap,
@@ -677,7 +686,8 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
     HIP_OK(hipEventRecord(P.evEnd, s));
     // one small copy brings back everything the host needs (k_lift_epilogue)
     unsigned long long *rb = cnt + CNT_DEV_SLOTS;
-    hipLaunchKernelGGL(k_lift_epilogue, dim3(1), dim3(64), 0, s, cnt, (const unsigned long long *)generalCount, rb);
+    hipLaunchKernelGGL(k_lift_epilogue, dim3(1), dim3(64), 0, s, cnt, (const unsigned long long *)generalCount,
+                       waveFinish ? (const unsigned long long *)restCount : (const unsigned long long *)nullptr, rb);
     unsigned long long *hrb = P.pinned + CNT_SLOTS + 1;
     HIP_OK(hipMemcpyAsync(hrb, rb, 8 * LIFT_RB_WORDS, hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
@@ -692,6 +702,7 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
         hostCounters[CNT_KSTAT0 + 2 * l] = hrb[8 + l];
     P.pinned[CNT_SLOTS] = hrb[CNT_LIFT_TOTAL]; // the record total, where runPlan looks for it
     P.generalQueries = hrb[12];
+    P.liftRestCount = hrb[13];
 }
 
 template <typename C>
@@ -1104,6 +1115,13 @@ static void runPlan(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
                 P.timer.dropRun();
                 continue;
             }
+            if (merged && P.liftRestCount && P.liftRestSkipped) { // intervals were passed on to launches this run did not make
+                P.liftRestSeen = true;
+                P.timer.dropRun();
+                continue;
+            }
+            if (merged && P.liftRestCount)
+                P.liftRestSeen = true;
             if (merged && hc[CNT_LIFT_FAIL]) {
                 // a look-back wait timed out (not expected): repeat the batch on the multi-kernel path and stay there
                 P.mergedDisabled = true;
