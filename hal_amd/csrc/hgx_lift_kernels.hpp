@@ -415,8 +415,11 @@ static __global__ void __launch_bounds__(256, MINW) k_lift_merged(const int64_t 
 // rb[0..7] = the scalar slots (CNT_MAPPED with the pieces of this run), rb[8 + l] = top-slot count of launch l (l < 4),
 // rb[12] = general intervals, rb[13] = the ones k_general_wave passed on.
 static constexpr int LIFT_RB_WORDS = 16;
-static __global__ void k_lift_epilogue(unsigned long long *counters, const unsigned long long *generalCount, const unsigned long long *restCount,
-                                       unsigned long long *rb) {
+// ... and leaves the words the next single-pass run counts in zeroed (the scalar slots, the level-0 append counters, the
+// statistics copies, the look-back granules of this run, the count of passed-on intervals): a batch then needs no memsets.
+static __global__ void __launch_bounds__(256) k_lift_epilogue(unsigned long long *counters, const unsigned long long *generalCount,
+                                                              unsigned long long *restCount, unsigned long long *rb, unsigned long long *granules,
+                                                              uint32_t numGranules) {
     __shared__ unsigned long long sums[5];
     const int w = (int)threadIdx.x;
     if (w < 5) {
@@ -435,6 +438,17 @@ static __global__ void k_lift_epilogue(unsigned long long *counters, const unsig
         rb[w] = *generalCount;
     else if (w == 13)
         rb[w] = restCount ? *restCount : 0ull; // intervals k_general_wave passed on
+    __syncthreads();
+    if (w < 8)
+        counters[w] = 0;
+    if (w < NSEG)
+        counters[CNT_FRONT0 + (size_t)w * SEG_PITCH] = 0;
+    for (int i = w; i < STAT_LINES * (STAT_LAUNCH0 + 8); i += (int)blockDim.x)
+        counters[CNT_DSTAT0 + (size_t)(i / (STAT_LAUNCH0 + 8)) * STAT_PITCH + (size_t)(i % (STAT_LAUNCH0 + 8))] = 0;
+    for (uint32_t i = (uint32_t)w; i < numGranules; i += blockDim.x)
+        granules[i] = 0;
+    if (w == 0 && restCount)
+        *restCount = 0;
 }
 
 } // namespace hgx

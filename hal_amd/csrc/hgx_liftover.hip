@@ -472,6 +472,7 @@ struct hgx_liftover_plan {
     int liftGrid = 0, liftMinWaves = 1;
     unsigned long long generalQueries = 0, liftRestCount = 0;
     bool liftRestSeen = false, liftRestSkipped = false; // (see runMergedOnce: the launches behind k_general_wave)
+    bool liftStateClean = false; // the counters and look-back granules are zero (left so by the last run's epilogue)
     // scratch of the single-pass runs for intervals that outgrow the LDS finishing kernel (k_finish_big without a host
     // synchronisation in between): liftBigSlots slices for liftBigCap pieces each, grown when a run needed more
     uint32_t liftBigSlots = 0;
@@ -514,6 +515,7 @@ struct hgx_liftover_plan {
     }
     void allocate(uint32_t newCap) {
         cap = newCap;
+        liftStateClean = false; // (buffers may move: their contents are not what the last run's epilogue left)
         static const size_t fsz[6] = {4, 8, 4, 8, 4, 1};
         if (walkBuffers) {
             for (int k = 0; k < numFrontiers; ++k)
@@ -600,9 +602,20 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
     const DeviceGenome &TG = D.genomes[(size_t)P.tgt];
     const uint32_t nTiles = (nq + LIFT_TILE - 1) / LIFT_TILE, nGroups = (nTiles + 63) / 64;
     unsigned long long *tileStatus = (unsigned long long *)P.liftStatus.p, *groupStatus = tileStatus + nTiles;
-    HIP_OK(hipMemsetAsync(tileStatus, 0, 8 * ((size_t)nTiles + nGroups), s));
     uint32_t *generalList = (uint32_t *)P.classLists.p;
     unsigned long long *generalCount = (unsigned long long *)P.classCounts.p;
+    // the words this run counts in were left zeroed by the previous single-pass run's epilogue; otherwise (first run, another
+    // path in between, a repeated run) they are cleared here
+    const bool wasClean = P.liftStateClean;
+    P.liftStateClean = false;
+    if (!wasClean) {
+        HIP_OK(hipMemsetAsync(cnt, 0, 8 * CNT_DEV_SLOTS, s));
+        HIP_OK(hipMemsetAsync(P.liftStatus.p, 0, P.liftStatus.n, s));
+        HIP_OK(hipMemsetAsync(generalCount, 0, 32, s));
+    }
+    const bool events = P.timer.mode != 0; // (walk_ms / total_ms of the statistics need three event records per run)
+    if (events)
+        HIP_OK(hipEventRecord(P.evStart, s));
     int launch = 0;
     auto kstat = [&]() { return cnt + CNT_DSTAT0 + STAT_LAUNCH0 + 2 * launch; };
     // k_lift_classify: a workgroup per contiguous chunk of intervals
@@ -621,7 +634,6 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
     unsigned long long *restCount = generalCount + 1;
     const bool waveFinish = !(getenv("HGX_FINISH_WAVE") && getenv("HGX_FINISH_WAVE")[0] == '0');
     if (waveFinish) {
-        HIP_OK(hipMemsetAsync(restCount, 0, 8, s));
         P.timer.begin("k_general_wave", s, launch);
         hipLaunchKernelGGL((k_general_wave<C>), dim3(512), dim3(256), 0, s, dS, dE, dStrand, srcLength, (const uint32_t *)T.coarse,
                            (const uint32_t *)T.starts, T.shift, (const ComposedRec<C> *)T.recs, (const uint32_t *)generalList,
@@ -644,14 +656,15 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
                        cnt + CNT_FRONT0, cnt, kstat(), (uint32_t *)P.offset.p, (uint32_t *)P.perQuery.p, lateList, lateCount);
     P.timer.end(s);
     ++launch;
-    HIP_OK(hipEventRecord(P.evWalk, s));
+    if (events)
+        HIP_OK(hipEventRecord(P.evWalk, s));
     P.timer.begin("k_finish_lds", s);
     hipLaunchKernelGGL((k_finish_lds<C, 256>), dim3(std::min<uint32_t>(std::max<uint32_t>(nq, 1), 1536u)), dim3(64), 0, s, P.mapped(1),
                        (const uint32_t *)P.offset.p, (const uint32_t *)P.perQuery.p, lateList, lateCount, (const int64_t *)TG.seqStart,
                        (int)TG.numSeq, (hgx_record *)P.grouped.p, (uint32_t *)P.nOut.p, (uint32_t *)P.deferredList.p, (uint32_t *)P.needCap.p,
                        cnt, 0);
     P.timer.end(s);
-    } else {
+    } else if (events) {
         HIP_OK(hipEventRecord(P.evWalk, s));
     }
     if (P.liftBigSlots && !P.liftRestSkipped) { // intervals k_finish_lds deferred: same algorithm on global scratch; their records become slices behind the grouped buffer
@@ -683,11 +696,12 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
 #undef HGX_LIFT
     P.timer.end(s);
     ++launch;
-    HIP_OK(hipEventRecord(P.evEnd, s));
+    if (events)
+        HIP_OK(hipEventRecord(P.evEnd, s));
     // one small copy brings back everything the host needs (k_lift_epilogue)
     unsigned long long *rb = cnt + CNT_DEV_SLOTS;
-    hipLaunchKernelGGL(k_lift_epilogue, dim3(1), dim3(64), 0, s, cnt, (const unsigned long long *)generalCount,
-                       waveFinish ? (const unsigned long long *)restCount : (const unsigned long long *)nullptr, rb);
+    hipLaunchKernelGGL(k_lift_epilogue, dim3(1), dim3(256), 0, s, cnt, (const unsigned long long *)generalCount,
+                       waveFinish ? restCount : (unsigned long long *)nullptr, rb, tileStatus, nTiles + nGroups);
     unsigned long long *hrb = P.pinned + CNT_SLOTS + 1;
     HIP_OK(hipMemcpyAsync(hrb, rb, 8 * LIFT_RB_WORDS, hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
@@ -701,6 +715,8 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
     for (int l = 0; l < launch; ++l)
         hostCounters[CNT_KSTAT0 + 2 * l] = hrb[8 + l];
     P.pinned[CNT_SLOTS] = hrb[CNT_LIFT_TOTAL]; // the record total, where runPlan looks for it
+    // (an overflowing or failing run may have left counters beyond the ones the epilogue clears)
+    P.liftStateClean = !hrb[CNT_OVERFLOW] && !hrb[CNT_LIFT_FAIL] && !hrb[CNT_DEFERRED] && !(getenv("HGX_LIFT_MEMSETS") != nullptr);
     P.generalQueries = hrb[12];
     P.liftRestCount = hrb[13];
 }
@@ -712,6 +728,11 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
     unsigned long long *cnt = (unsigned long long *)P.counters.p;
     const uint32_t cap = P.cap;
     const uint32_t nq = (uint32_t)n;
+    if (P.composed && P.composed->mRecs && !P.opts.emit_blocks && !P.mergedDisabled && !P.mergedOffThisRun && !P.captureUp && !P.captureFinal) {
+        runMergedOnce(P, n, dS, dE, dStrand, s, hostCounters);
+        return;
+    }
+    P.liftStateClean = false; // (this run counts in words a single-pass run expects zeroed)
     HIP_OK(hipMemsetAsync(cnt, 0, 8 * CNT_DEV_SLOTS, s));
     if (!(P.composed && P.composed->through)) { // (k_locate_through writes every interval's count itself and has no grouping scatter)
         HIP_OK(hipMemsetAsync(P.perQuery.p, 0, 4 * (n + 1), s));
@@ -719,10 +740,6 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
     }
     HIP_OK(hipEventRecord(P.evStart, s));
 
-    if (P.composed && P.composed->mRecs && !P.opts.emit_blocks && !P.mergedDisabled && !P.mergedOffThisRun && !P.captureUp && !P.captureFinal) {
-        runMergedOnce(P, n, dS, dE, dStrand, s, hostCounters);
-        return;
-    }
     if (!(P.composed && P.composed->through))
         P.ensureWalkBuffers();
     int level = 0;
@@ -1205,8 +1222,10 @@ static void runPlan(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
         botAll += hc[CNT_KSTAT0 + 2 * k + 1];
     }
     float walk = 0, tot = 0;
-    HIP_OK(hipEventElapsedTime(&walk, P.evStart, P.evWalk));
-    HIP_OK(hipEventElapsedTime(&tot, P.evStart, P.evEnd));
+    if (!(mergedRun && P.timer.mode == 0)) { // (a single-pass run without kernel events records none of its own either)
+        HIP_OK(hipEventElapsedTime(&walk, P.evStart, P.evWalk));
+        HIP_OK(hipEventElapsedTime(&tot, P.evStart, P.evEnd));
+    }
     P.stats.queries = n;
     P.stats.source_pieces = hc[CNT_SRC_PIECES];
     P.stats.top_derefs = topAll;
