@@ -2,7 +2,8 @@
 import ctypes as C
 import os
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libhgx.so")
+# (HGX_LIB_PATH: an instrumented build, e.g. hal_amd/libhgx_prof.so of `make profile-lib`)
+LIB_PATH = os.environ.get("HGX_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libhgx.so")
 
 
 class HgxError(RuntimeError):

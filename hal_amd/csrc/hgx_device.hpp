@@ -138,8 +138,7 @@ struct ComposedUp {
     // canMergeRightWith joins, in (source start, target start) order, with bucket tables that carry the number of flagged
     // records before each entry.  Read by the single-pass kernels of hgx_lift_kernels.hpp.
     void *mRecs = nullptr;      // ComposedRec<int32_t>[mNum]: sLo, len, so = forward target start, mEncF = target strand | sequence << 8
-    void *mCoarse = nullptr;    // uint2[mBuckets + 1]: {first record that touches the bucket, flagged records before it}
-    void *mStarts = nullptr;    // uint2[mBuckets + 1]: {first record that begins at or after the bucket, flagged records before it}
+    void *mBuckets = nullptr;   // uint32[buckets + 1]: the first merged record that touches the bucket
     int mShift = 0;
     uint64_t mNum = 0, mFlagged = 0;
     int64_t mWindow = 0;        // intervals longer than this take the general path

@@ -759,13 +759,22 @@ __global__ void __launch_bounds__(256) k_finish_fast(Mapped in, const uint32_t *
     }
 }
 
+// single-pass runs (hgx_lift_kernels.hpp) keep the number of output lines per 64 intervals (a wavefront's worth); an
+// interval finished after the counting launch adds its lines here
+static constexpr int LIFT_TILE_SHIFT = 8;
+__device__ __forceinline__ void lift_add_late_lines(uint32_t *waveTotal, uint32_t q, int nl) {
+    if (waveTotal && nl > 0)
+        atomicAdd(&waveTotal[q >> 6], (uint32_t)nl);
+}
+
 // LDS-staged variant: capacity CAP pieces per query.
 template <typename C, int CAP>
 __global__ void __launch_bounds__(64) k_finish_lds(Mapped in, const uint32_t *__restrict__ offset, const uint32_t *__restrict__ count,
                                                    const uint32_t *__restrict__ qlist, const unsigned long long *__restrict__ qcount,
                                                    const int64_t *__restrict__ seqStart, int numSeq, hgx_record *__restrict__ records,
                                                    uint32_t *__restrict__ nOut, uint32_t *__restrict__ deferredList, uint32_t *__restrict__ needCap,
-                                                   unsigned long long *counters, int blocks) {
+                                                   unsigned long long *counters, int blocks, uint32_t *waveTotal = nullptr) {
+    // waveTotal (single-pass runs, hgx_lift_kernels.hpp): the interval's lines are added to the line count of its 64 intervals
     constexpr int CAP2 = 2 * CAP;
     __shared__ C s_tLo[CAP], s_tHi[CAP], s_sLo[CAP], s_sHi[CAP], s_tLo2[CAP], s_tHi2[CAP], s_sLo2[CAP], s_sHi2[CAP];
     __shared__ C s_bnd[CAP2], s_bnd2[CAP2], s_lStart[CAP], s_lEnd[CAP], s_lSrc[CAP], s_cut[32];
@@ -797,8 +806,10 @@ __global__ void __launch_bounds__(64) k_finish_lds(Mapped in, const uint32_t *__
             }
         } else {
             write_records(S, nl, (int32_t)q, records + base, seqStart);
-            if (threadIdx.x == 0)
+            if (threadIdx.x == 0) {
                 nOut[q] = (uint32_t)nl;
+                lift_add_late_lines(waveTotal, q, nl);
+            }
         }
         wsync();
     }
@@ -811,7 +822,8 @@ __global__ void __launch_bounds__(64) k_finish_big(Mapped in, const uint32_t *__
                                                    unsigned char *__restrict__ scratch, size_t sliceBytes,
                                                    const int64_t *__restrict__ seqStart, int numSeq, hgx_record *__restrict__ bigRecords,
                                                    uint32_t *__restrict__ nOut, unsigned long long *counters, int blocks,
-                                                   int countOnDevice = 0, uint32_t *__restrict__ offsetOut = nullptr, uint32_t recordBase = 0) {
+                                                   int countOnDevice = 0, uint32_t *__restrict__ offsetOut = nullptr, uint32_t recordBase = 0,
+                                                   uint32_t *waveTotal = nullptr) {
     // countOnDevice (single-pass runs, hgx_lift_kernels.hpp): the number of deferred intervals is read from the counter block
     // (nDeferred = the slices the scratch area holds; more than that fails the run, the host grows the area and repeats it);
     // offsetOut: the interval's records are slice k of an area that starts recordBase records into the grouped buffer
@@ -859,6 +871,7 @@ __global__ void __launch_bounds__(64) k_finish_big(Mapped in, const uint32_t *__
             write_records(S, nl, (int32_t)q, bigRecords + (size_t)k * cap, seqStart);
             if (threadIdx.x == 0) {
                 nOut[q] = (uint32_t)nl;
+                lift_add_late_lines(waveTotal, q, nl);
                 if (offsetOut)
                     offsetOut[q] = recordBase + k * (uint32_t)cap;
             }
@@ -1227,125 +1240,126 @@ __device__ __forceinline__ bool finish_wave(const int lane, int n, C tLo, C tHi,
     return true;
 }
 
-// k_general_wave: the general intervals of a single-pass run (hgx_lift_kernels.hpp), one wavefront each, from the unmerged
-// table of the whole path to finished records without a round trip of the pieces through HBM: the interval's records
-// (at most 64 in reach; k_locate_through's rule for which they are) are clipped in the lanes that loaded them, compacted,
-// finished by finish_wave and written to a slice of the grouped buffer reserved from the same segment counters
-// k_locate_through appends through.  offset[q] / nOut[q] then say where k_lift_merged finds them.  Intervals with more records
-// in reach, or that finish_wave passes on, go to restList for k_locate_through + k_finish_lds (+ k_finish_big).
+// One general interval of a single-pass run (hgx_lift_kernels.hpp), by one wavefront, from the unmerged table of the whole path
+// to finished records without a round trip of the pieces through HBM: the interval's records (at most 64 in reach;
+// k_locate_through's rule for which they are) are clipped in the lanes that loaded them, compacted, finished by finish_wave and
+// written to a slice of the grouped buffer reserved from the same segment counters k_locate_through appends through.
+// Returns 1 with (nl, base) = where k_lift_merged finds the records, 0 when the interval has to go on to k_locate_through +
+// k_finish_lds (more records in reach, or finish_wave passes it on), -1 when the grouped buffer is full (the host repeats the
+// batch with larger buffers).  All arguments wave-uniform.
+// -DHGX_LIFT_PROFILE (make profile-lib: hal_amd/libhgx_prof.so, loaded with HGX_LIB_PATH): lane 0 of every wavefront of
+// k_lift_merged adds up the shader cycles it spends in each phase of its tiles; k_lift_epilogue prints the sums.
+#ifdef HGX_LIFT_PROFILE
+__device__ unsigned long long g_liftProfile[8192 * 4 * 8]; // [workgroup][wavefront][phase]: plain stores, summed by the epilogue
+#define LIFT_PROF_DECL unsigned long long profT = __builtin_readcyclecounter(), profAcc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define LIFT_PROF(i)                                                                                                                         \
+    {                                                                                                                                        \
+        const unsigned long long now = __builtin_readcyclecounter();                                                                         \
+        profAcc[i] += now - profT;                                                                                                           \
+        profT = now;                                                                                                                         \
+    }
+#define LIFT_PROF_FLUSH                                                                                                                      \
+    if (lane == 0 && blockIdx.x < 8192) {                                                                                                    \
+        profAcc[7] = 1;                                                                                                                      \
+        for (int i = 0; i < 8; ++i)                                                                                                          \
+            g_liftProfile[(blockIdx.x * 4 + w) * 8 + i] = profAcc[i];                                                                        \
+    }
+#define LIFT_PROF_ARG , profAcc, profT
+#define LIFT_PROF_PARAMS , unsigned long long *profAcc, unsigned long long &profT
+#else
+#define LIFT_PROF_ARG
+#define LIFT_PROF_PARAMS
+#define LIFT_PROF_DECL
+#define LIFT_PROF(i)
+#define LIFT_PROF_FLUSH
+#endif
+
+template <typename C> struct GeneralTable {
+    const uint32_t *coarse, *starts;
+    int shift;
+    const ComposedRec<C> *recs;
+    int64_t genomeLength;
+    const int64_t *seqStart;
+    int numSeq;
+    hgx_record *records; // the grouped buffer
+    uint32_t cap;
+    unsigned long long *segCounters, *counters;
+};
 template <typename C>
-__global__ void __launch_bounds__(256) k_general_wave(const int64_t *__restrict__ gStart, const int64_t *__restrict__ gEnd,
-                                                      const uint8_t *__restrict__ strand, int64_t genomeLength,
-                                                      const uint32_t *__restrict__ coarse, const uint32_t *__restrict__ starts, int coarseShift,
-                                                      const ComposedRec<C> *__restrict__ recs, const uint32_t *__restrict__ qlist,
-                                                      const unsigned long long *__restrict__ qcount, const int64_t *__restrict__ seqStart,
-                                                      int numSeq, hgx_record *__restrict__ records, uint32_t cap,
-                                                      unsigned long long *segCounters, unsigned long long *counters, unsigned long long *kstat,
-                                                      uint32_t *__restrict__ offset, uint32_t *__restrict__ nOut, uint32_t *__restrict__ restList,
-                                                      unsigned long long *__restrict__ restCount) {
-    __shared__ C sDAll[4][128];
-    __shared__ uint8_t sOwnAll[4][64];
-    const int lane = lane_id(), w = (int)(threadIdx.x >> 6);
-    const uint32_t nlist = (uint32_t)*qcount;
-    // (everything that steers control flow is made wave-uniform explicitly, so that the loops compile to scalar branches)
-    const uint32_t wavesTotal = (gridDim.x * blockDim.x) >> 6;
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
-    const uint32_t seg = blockIdx.x % NSEG, segCap = cap / NSEG;
-    unsigned long long *segCount = segCounters + (size_t)seg * SEG_PITCH;
-    const int64_t ss0 = seqStart[0];
-    uint32_t used = 0;
-    for (uint32_t k = wave; k < nlist; k += wavesTotal) {
-        const uint32_t q = (uint32_t)__builtin_amdgcn_readfirstlane((int)qlist[k]);
-        const int64_t gs = gStart[q], ge = gEnd[q];
-        const uint8_t st = strand[q];
-        const int64_t geIn = ge < genomeLength ? ge : genomeLength - 1;
-        const uint32_t k0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)coarse[gs >> coarseShift]);
-        const uint32_t kEnd = (uint32_t)__builtin_amdgcn_readfirstlane((int)starts[(geIn >> coarseShift) + 1]);
-        bool pass = kEnd > k0 + 64u;
-        int n = 0;
-        C tLo = 0, tHi = 0, sLo = 0, sHi = 0;
-        int fl = 0;
-        if (!pass) {
-            bool have = false;
-            if (k0 + (uint32_t)lane < kEnd) {
-                const ComposedRec<C> r = recs[k0 + (uint32_t)lane];
-                const int64_t pLo = (int64_t)r.sLo, pHi = pLo + (int64_t)r.len - 1;
-                if (pLo <= ge && pHi >= gs) { // clipped to the interval (k_locate_through)
-                    const int64_t c = pLo > gs ? pLo : gs, d = pHi < ge ? pHi : ge;
-                    const int64_t len = d - c + 1, delta = c - pLo;
-                    have = true;
-                    sLo = (C)c;
-                    sHi = (C)d;
-                    tLo = (C)((int64_t)r.so + ((r.mEncF & 1u) ? (int64_t)r.len - delta - len : delta));
-                    tHi = (C)((int64_t)tLo + len - 1);
-                    fl = (int)((((r.mEncF & 1u) ? F_TREV : 0u) | (st == '.' ? (uint32_t)F_DOT : 0u)) ^ (st == '-' ? (uint32_t)(F_SREV | F_TREV) : 0u));
-                }
-            }
-            const unsigned long long hm = __ballot(have);
-            n = (int)__popcll(hm);
-            used += have ? 1u : 0u;
-            if (n > 0 && hm != (n >= 64 ? ~0ull : ((1ull << n) - 1ull))) { // close the gaps (the ones left out aim at lane 63, which is free then)
-                const int dest = have ? (int)__popcll(hm & ((1ull << lane) - 1ull)) : 63;
-                tLo = wave_push<C>(tLo, dest);
-                tHi = wave_push<C>(tHi, dest);
-                sLo = wave_push<C>(sLo, dest);
-                sHi = wave_push<C>(sHi, dest);
-                fl = __builtin_amdgcn_ds_permute(dest << 2, fl);
-            }
-        }
-        if (!pass && n == 0) {
-            if (lane == 0) {
-                nOut[q] = 0;
-                offset[q] = 0;
-            }
-            continue;
-        }
-        WaveLines<C> L;
-        L.nl = 0;
-        if (!pass)
-            pass = !finish_wave<C>(lane, n, tLo, tHi, sLo, sHi, fl, seqStart, numSeq, sDAll[w], sOwnAll[w], L);
-        if (pass) { // (no records yet: a run that does not make the launches behind this one sees an empty interval and is repeated)
-            if (lane == 0) {
-                restList[atomicAdd(restCount, 1ull)] = q;
-                nOut[q] = 0;
-                offset[q] = 0;
-            }
-            continue;
-        }
-        // a slice of the grouped buffer for the records
-        unsigned long long b = 0;
-        if (lane == 0)
-            b = atomicAdd(segCount, (unsigned long long)L.nl);
-        b = __shfl(b, 0);
-        if (b + (unsigned long long)L.nl > segCap) { // the retry sizes the buffers from the counters
-            if (lane == 0) {
-                counters[CNT_OVERFLOW] = 1;
-                nOut[q] = 0;
-                offset[q] = 0;
-            }
-            continue;
-        }
-        const uint32_t base = seg * segCap + (uint32_t)b;
-        if (lane < L.nl) {
-            hgx_record r;
-            const int64_t ss = numSeq > 1 ? seqStart[L.lSeq] : ss0;
-            r.query = (int64_t)q;
-            r.tgt_start = (int64_t)L.lStart - ss;
-            r.tgt_end = (int64_t)L.lEnd - ss;
-            r.src_start = (int64_t)L.lSrc;
-            r.tgt_seq = L.lSeq;
-            r.strand = (char)(L.lStrand & 0x7F);
-            r.tgt_reversed = (uint8_t)((L.lStrand >> 7) & 1);
-            r._pad[0] = r._pad[1] = 0;
-            records[base + (uint32_t)L.rank] = r;
-        }
-        if (lane == 0) {
-            nOut[q] = (uint32_t)L.nl;
-            offset[q] = base;
+__device__ __forceinline__ int general_interval(const int lane, const GeneralTable<C> &G, const uint32_t q, const int64_t gs, const int64_t ge,
+                                                const uint8_t st, C *sD, uint8_t *sOwn, uint32_t &used, int &nlOut, uint32_t &baseOut LIFT_PROF_PARAMS) {
+    const int64_t geIn = ge < G.genomeLength ? ge : G.genomeLength - 1;
+    const uint32_t k0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)G.coarse[gs >> G.shift]);
+    const uint32_t kEnd = (uint32_t)__builtin_amdgcn_readfirstlane((int)G.starts[(geIn >> G.shift) + 1]);
+    nlOut = 0;
+    baseOut = 0;
+    if (kEnd > k0 + 64u)
+        return 0;
+    C tLo = 0, tHi = 0, sLo = 0, sHi = 0;
+    int fl = 0;
+    bool have = false;
+    if (k0 + (uint32_t)lane < kEnd) {
+        const ComposedRec<C> r = G.recs[k0 + (uint32_t)lane];
+        const int64_t pLo = (int64_t)r.sLo, pHi = pLo + (int64_t)r.len - 1;
+        if (pLo <= ge && pHi >= gs) { // clipped to the interval (k_locate_through)
+            const int64_t c = pLo > gs ? pLo : gs, d = pHi < ge ? pHi : ge;
+            const int64_t len = d - c + 1, delta = c - pLo;
+            have = true;
+            sLo = (C)c;
+            sHi = (C)d;
+            tLo = (C)((int64_t)r.so + ((r.mEncF & 1u) ? (int64_t)r.len - delta - len : delta));
+            tHi = (C)((int64_t)tLo + len - 1);
+            fl = (int)((((r.mEncF & 1u) ? F_TREV : 0u) | (st == '.' ? (uint32_t)F_DOT : 0u)) ^ (st == '-' ? (uint32_t)(F_SREV | F_TREV) : 0u));
         }
     }
-    stat_add(&kstat[0], used);
-    stat_add(&counters[CNT_DSTAT0 + STAT_MAPPED], used);
+    const unsigned long long hm = __ballot(have);
+    const int n = (int)__popcll(hm);
+    used += have ? 1u : 0u;
+    if (n == 0)
+        return 1;
+    if (hm != (n >= 64 ? ~0ull : ((1ull << n) - 1ull))) { // close the gaps (the ones left out aim at lane 63, which is free then)
+        const int dest = have ? (int)__popcll(hm & ((1ull << lane) - 1ull)) : 63;
+        tLo = wave_push<C>(tLo, dest);
+        tHi = wave_push<C>(tHi, dest);
+        sLo = wave_push<C>(sLo, dest);
+        sHi = wave_push<C>(sHi, dest);
+        fl = __builtin_amdgcn_ds_permute(dest << 2, fl);
+    }
+    WaveLines<C> L;
+    L.nl = 0;
+    LIFT_PROF(4) // table look-ups, records
+    if (!finish_wave<C>(lane, n, tLo, tHi, sLo, sHi, fl, G.seqStart, G.numSeq, sD, sOwn, L))
+        return 0;
+    LIFT_PROF(5) // the algorithm
+    // a slice of the grouped buffer for the records
+    const uint32_t seg = blockIdx.x % NSEG, segCap = G.cap / NSEG;
+    unsigned long long b = 0;
+    if (lane == 0)
+        b = atomicAdd(G.segCounters + (size_t)seg * SEG_PITCH, (unsigned long long)L.nl);
+    b = __shfl(b, 0);
+    if (b + (unsigned long long)L.nl > segCap) { // the retry sizes the buffers from the counters
+        if (lane == 0)
+            G.counters[CNT_OVERFLOW] = 1;
+        return -1;
+    }
+    const uint32_t base = seg * segCap + (uint32_t)b;
+    LIFT_PROF(6) // the reservation
+    if (lane < L.nl) {
+        hgx_record r;
+        const int64_t ss = G.numSeq > 1 ? G.seqStart[L.lSeq] : G.seqStart[0];
+        r.query = (int64_t)q;
+        r.tgt_start = (int64_t)L.lStart - ss;
+        r.tgt_end = (int64_t)L.lEnd - ss;
+        r.src_start = (int64_t)L.lSrc;
+        r.tgt_seq = L.lSeq;
+        r.strand = (char)(L.lStrand & 0x7F);
+        r.tgt_reversed = (uint8_t)((L.lStrand >> 7) & 1);
+        r._pad[0] = r._pad[1] = 0;
+        G.records[base + (uint32_t)L.rank] = r;
+    }
+    nlOut = L.nl;
+    baseOut = base;
+    return 1;
 }
 
 } // namespace hgx

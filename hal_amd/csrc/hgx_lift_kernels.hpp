@@ -1,9 +1,11 @@
 // The single-pass liftover kernels over the MERGED table (hgx_merged_kernels.hpp): BlockLiftover::liftInterval
 // (liftover/impl/halBlockLiftover.cpp:46-113) for a batch of intervals — toSite, the per-source-segment halMapSegment calls,
 // insertAndBreakOverlaps, extractSegment, the stable sort on the source start (liftover/impl/halLiftover.cpp:90) — as
-//   k_lift_classify   one bucket look-up per interval end: where its records start, how many can be in reach, and whether
-//                     the interval must go the general way (hgx_finish_kernel.hpp, over the unmerged table);
-//   k_lift_merged     everything else: reads an interval's merged records, clips them, orders them, and writes the
+//   k_lift_classify   per interval: one look at the bucket table (where its records start, how many can be in reach, whether
+//                     it must go the general way — hgx_finish_kernel.hpp, over the unmerged table, which the wavefront that
+//                     meets such an interval does on the spot) and a first walk over its records that counts its output
+//                     lines; per tile of 256 intervals and per group of 64 tiles: the number of lines;
+//   k_lift_merged     reads the records a second time (they are in the L2 by then), clips them, orders them, and writes the
 //                     hgx_records of the whole batch densely and in input order — once.
 // An unflagged interval's records have pairwise disjoint target ranges, so (see hgx_merged_kernels.hpp) its output lines
 // are exactly its records clipped to it.  The reference prints them stably sorted by source start, ties in target order:
@@ -11,262 +13,340 @@
 // ones that begin at or before the interval's first base — they all start at that base after clipping and are ordered by
 // target start among themselves (they are the first of the interval's records; usually there is one).
 //
-// Dense output in input order from one pass needs every interval's offset = the number of lines of all intervals before
-// it.  A workgroup owns a tile of 256 consecutive intervals; it counts its lines, publishes the count, obtains the sum of
-// the tiles before it by a two-level decoupled look-back (64 tiles form a group; a tile reads the counts of the tiles
-// before it in its own group and the totals of the groups before its own), then walks its records a second time (they are
-// in the L1/L2 by then) and stores the lines at their final place.  The words the workgroups exchange are 8-byte
-// {tag, value} granules written with one agent-scope store and polled with agent-scope loads (per-XCD L2s are not
-// coherent; see cdna_hip_programming.md Guideline 16): no fences, nothing else is shared.  Tiles are dealt round-robin to a
-// grid that is resident as a whole, so a tile only ever waits for workgroups that are running; every spin is bounded and a
-// time-out makes the host repeat the batch on the multi-kernel path.
+// Dense output in input order needs every interval's offset = the number of lines of all intervals before it.  The count
+// and the store are two launches, so the store knows every tile's count when it starts: a workgroup adds up the counts of
+// the groups before its tile's group and of the tiles before its tile in the group (two 64-wide reads) — no waiting.  (The
+// one-launch form of this — count, publish, decoupled look-back, store — spent 44 % of its wavefronts' cycles waiting for
+// the slowest of the 64 tiles in front: profiles/r02k_notes.md.)
 #pragma once
 #include "../../include/hgx.h"
-#include "hgx_liftover_kernels.hpp"
+#include "hgx_finish_kernel.hpp"
 
 namespace hgx {
 
-static constexpr int LIFT_TILE = 256;        // intervals per tile (= threads per workgroup)
+static constexpr int LIFT_TILE = 256;        // intervals per tile (= threads per workgroup; LIFT_TILE_SHIFT in hgx_finish_kernel.hpp)
 static constexpr uint32_t LIFT_MAX_BOUND = 64; // records in reach of an interval the wave-wide rounds can hold
 static constexpr uint32_t KB_GENERAL = 0x80000000u;
-enum { CNT_LIFT_TOTAL = 1, CNT_LIFT_FAIL = 2 }; // counters[] slots (hgx_liftover_kernels.hpp uses 0 and 3..7)
+enum { CNT_LIFT_TOTAL = 1 }; // counters[] slot (hgx_liftover_kernels.hpp uses 0 and 3..7)
+static_assert(LIFT_TILE == 1 << LIFT_TILE_SHIFT, "the finishing kernels add late counts to the tile totals");
 
-// ---------------------------------------------------------------------------------------------
-// k_lift_classify: kb[q] = {first record in reach, number of records in reach | KB_GENERAL}.  General intervals (a
-// flagged record in reach, more than LIFT_MAX_BOUND records in reach, longer than the table's window) are listed per
-// workgroup — a workgroup owns a contiguous range of intervals and a private slice of the list, so no atomics — and
-// gathered into one dense list by k_lift_gather.
-static __global__ void __launch_bounds__(256) k_lift_classify(const int64_t *__restrict__ gStart, const int64_t *__restrict__ gEnd, uint32_t nq,
-                                                              int64_t genomeLength, const uint2 *__restrict__ coarseF,
-                                                              const uint2 *__restrict__ startsF, int shift, int64_t window,
-                                                              uint2 *__restrict__ kb, uint32_t *__restrict__ blockList,
-                                                              uint32_t *__restrict__ blockCount, uint32_t chunk) {
-    __shared__ uint32_t sCount;
-    if (threadIdx.x == 0)
-        sCount = 0;
-    __syncthreads();
-    const uint32_t lo = blockIdx.x * chunk, hi = lo + chunk < nq ? lo + chunk : nq;
-    for (uint32_t q = lo + threadIdx.x; q < hi; q += blockDim.x) {
-        const int64_t gs = gStart[q], ge = gEnd[q];
-        uint2 out = make_uint2(0u, 0u);
-        if (ge >= gs && gs >= 0 && gs < genomeLength) {
-            const int64_t geIn = ge < genomeLength ? ge : genomeLength - 1;
-            const uint2 a = coarseF[gs >> shift], b = startsF[(geIn >> shift) + 1];
-            if (b.x > a.x) {
-                const uint32_t bound = b.x - a.x;
-                const bool general = bound > LIFT_MAX_BOUND || b.y != a.y || ge - gs >= window;
-                out = make_uint2(a.x, general ? KB_GENERAL : bound);
-                if (general)
-                    blockList[lo + atomicAdd(&sCount, 1u)] = q; // (LDS atomic; the slice holds the whole chunk)
-            }
-        }
-        kb[q] = out;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0)
-        blockCount[blockIdx.x] = sCount;
+// ---- wave-wide scans on the VALU: DPP row shifts and row broadcasts (gfx9 encodings), no trip through the LDS crossbar ----
+// (a ds_bpermute-based scan is six dependent LDS-pipe round trips; the kernel runs several per tile)
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint32_t lift_dpp(uint32_t ident, uint32_t v) {
+    // lanes whose source lies outside their row (or whose row is masked off) keep `ident`
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)ident, (int)v, CTRL, ROW_MASK, 0xF, false);
 }
-
-// dense general list: every workgroup scans the (at most 2048) per-workgroup counts itself and copies its share
-static __global__ void __launch_bounds__(256) k_lift_gather(const uint32_t *__restrict__ blockList, const uint32_t *__restrict__ blockCount,
-                                                            uint32_t numBlocks, uint32_t chunk, uint32_t *__restrict__ list,
-                                                            unsigned long long *__restrict__ listCount) {
-    __shared__ uint32_t sPrefix[2049];
-    __shared__ uint32_t sPart[256];
-    const uint32_t per = (numBlocks + 255) / 256;
-    uint32_t s = 0;
-    for (uint32_t k = 0; k < per; ++k) {
-        const uint32_t b = threadIdx.x * per + k;
-        s += b < numBlocks ? blockCount[b] : 0u;
-    }
-    sPart[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {
-        uint32_t t = 0;
-        if ((int)threadIdx.x >= o)
-            t = sPart[threadIdx.x - o];
-        __syncthreads();
-        sPart[threadIdx.x] += t;
-        __syncthreads();
-    }
-    uint32_t acc = sPart[threadIdx.x] - s;
-    for (uint32_t k = 0; k < per; ++k) {
-        const uint32_t b = threadIdx.x * per + k;
-        if (b < numBlocks) {
-            sPrefix[b] = acc;
-            acc += blockCount[b];
-        }
-    }
-    if (threadIdx.x == 255)
-        sPrefix[numBlocks] = sPart[255];
-    __syncthreads();
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-        *listCount = (unsigned long long)sPrefix[numBlocks];
-    for (uint32_t b = blockIdx.x; b < numBlocks; b += gridDim.x) {
-        const uint32_t n = sPrefix[b + 1] - sPrefix[b];
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x)
-            list[sPrefix[b] + i] = blockList[(size_t)b * chunk + i];
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// granules of the look-back: tag in the two top bits (0 = not there yet, 1 = the tile's / group's own count, 2 = count of
-// everything up to and including it), value below
-typedef __attribute__((address_space(1))) unsigned long long lift_gu64;
-static constexpr unsigned long long LIFT_TAG_OWN = 1ull << 62, LIFT_TAG_INCL = 2ull << 62, LIFT_VALUE = (1ull << 62) - 1ull;
-__device__ __forceinline__ void lift_publish(unsigned long long *p, unsigned long long v) {
-    __hip_atomic_store((lift_gu64 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ unsigned long long lift_peek(const unsigned long long *p) {
-    return __hip_atomic_load((lift_gu64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-static constexpr unsigned LIFT_SPIN_LIMIT = 1u << 17; // polls of one wait before the batch is given up (~0.1 s)
-// a wait also ends when another workgroup has given up (looked at every 256 polls)
-__device__ __forceinline__ bool lift_spin_over(unsigned spins, const unsigned long long *counters) {
-    return spins >= LIFT_SPIN_LIMIT || ((spins & 255u) == 255u && lift_peek(&counters[CNT_LIFT_FAIL]) != 0);
-}
-
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t up = __shfl_up(v, o);
-        if (lane >= o)
-            v += up;
-    }
+struct LiftSum {
+    static __device__ __forceinline__ uint32_t f(uint32_t a, uint32_t b) { return a + b; }
+};
+struct LiftMax {
+    static __device__ __forceinline__ uint32_t f(uint32_t a, uint32_t b) { return a > b ? a : b; }
+};
+// inclusive scan over the 64 lanes (identity 0 for both operations used here)
+template <typename Op> __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    v = Op::f(v, lift_dpp<0x111, 0xF>(0u, v)); // row_shr:1
+    v = Op::f(v, lift_dpp<0x112, 0xF>(0u, v)); // row_shr:2
+    v = Op::f(v, lift_dpp<0x114, 0xF>(0u, v)); // row_shr:4
+    v = Op::f(v, lift_dpp<0x118, 0xF>(0u, v)); // row_shr:8    -> every row of 16 scanned
+    v = Op::f(v, lift_dpp<0x142, 0xA>(0u, v)); // row_bcast:15 -> rows 1 and 3 add the row before them
+    v = Op::f(v, lift_dpp<0x143, 0xC>(0u, v)); // row_bcast:31 -> rows 2 and 3 add the lower half
     return v;
 }
+__device__ __forceinline__ uint32_t wave_total(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan<LiftSum>(v), 63);
+}
+// sum of 64 values below 2^62, in three limbs of at most 24 bits (64 of them stay below 2^30)
 __device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-        v += __shfl_down(v, o);
-    return __shfl(v, 0);
+    const unsigned long long a = wave_total((uint32_t)v & 0xFFFFFFu), b = wave_total((uint32_t)(v >> 24) & 0xFFFFFFu),
+                             c = wave_total((uint32_t)(v >> 48));
+    return a + (b << 24) + (c << 48);
 }
 
-// One wavefront's pass over the records in reach of its 64 intervals, in rounds of up to 64 records: consecutive
-// intervals share a round as long as their records fit.  EMIT = false counts every interval's lines, EMIT = true stores
-// them.  Interval data live in the lane that owns the interval (lane = interval index inside the wave's 64) and reach the
-// record lanes by ds_bpermute; sOwner is the wave's 64-byte LDS strip that maps a round's record slots to owner lanes.
-template <bool EMIT>
-__device__ __forceinline__ uint32_t lift_wave_pass(const ComposedRec<int32_t> *__restrict__ recs, uint8_t *sOwner, const int lane, const uint32_t k,
-                                                   const uint32_t b, const uint32_t p, const uint32_t totalSlots, const int32_t gs,
-                                                   const int32_t ge, const uint32_t flags /* bit 0 minus, bit 1 dot */, const uint32_t lineOff,
-                                                   const uint32_t firstQuery, const int64_t *__restrict__ tSeqStart, const int64_t ss0,
-                                                   const bool oneSeq, hgx_record *__restrict__ out, uint32_t &used) {
-    uint32_t cnt = 0;
+// ---------------------------------------------------------------------------------------------
+// quad helpers (DPP quad_perm: no LDS crossbar)
+template <int CTRL> __device__ __forceinline__ uint32_t quad_dpp(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+static constexpr int QUAD_XOR1 = 0xB1, QUAD_XOR2 = 0x4E, QUAD_LANE3 = 0xFF; // quad_perm:[1,0,3,2], [2,3,0,1], [3,3,3,3]
+struct LiftMin {
+    static __device__ __forceinline__ uint32_t f(uint32_t a, uint32_t b) { return a < b ? a : b; }
+};
+template <typename Op> __device__ __forceinline__ uint32_t quad_reduce(uint32_t v) {
+    v = Op::f(v, quad_dpp<QUAD_XOR1>(v));
+    return Op::f(v, quad_dpp<QUAD_XOR2>(v));
+}
+struct LiftOr {
+    static __device__ __forceinline__ uint32_t f(uint32_t a, uint32_t b) { return a | b; }
+};
+
+// what one lane of a quad has seen of its interval's records
+struct LiftScan {
+    uint32_t cnt = 0, flags = 0, first = 0xFFFFFFFFu, last = 0;
+    bool cont = false; // the quad's fourth record still begins inside the interval: four more
+    __device__ __forceinline__ void take(const ComposedRec<int32_t> &r, uint32_t idx, int32_t gs, int32_t ge) {
+        const bool more = r.sLo <= ge;
+        const bool ov = more && r.sLo + r.len - 1 >= gs;
+        if (ov) {
+            ++cnt;
+            flags |= (r.mEncF >> 1) & 1u;
+            first = idx < first ? idx : first;
+            last = idx > last ? idx : last;
+        }
+        cont = quad_dpp<QUAD_LANE3>(more ? 1u : 0u) != 0;
+    }
+};
+
+// k_lift_classify, a workgroup per tile: kb[q] = {first record that overlaps interval q, number of records from there to the
+// last one that overlaps | KB_GENERAL}, nOut[q] = the interval's lines, waveTotal[q / 64] = the lines of a wavefront's 64
+// intervals.
+// An interval's records are found by one look at the bucket table (the first record that touches the bucket of its first
+// base) and a scan from there to the first record that begins behind its last base (the table ends in sentinels).  Four
+// lanes scan for one interval, four records — one 64-byte line — per trip: the kernel is bound by the number of separate
+// lines its gathers touch, and this way an interval costs one or two besides the bucket entry.
+// General intervals (an overlapping record that carries the flag, more than LIFT_MAX_BOUND records, longer than the table's
+// window):
+//   INLINE: finished on the spot by the wavefront that meets them (general_interval, hgx_finish_kernel.hpp: the reference's
+//   general algorithm in registers over the unmerged table) — nOut[q] / offset[q] then say where k_lift_merged finds their
+//   records; the ones that passes on (more than 64 pieces) are listed in lateList for k_locate_through + k_finish_lds, which
+//   add their lines to the totals.  A general interval costs its own wavefront a handful of dependent memory round trips;
+//   in a launch of their own the same round trips were the batch's critical path.
+//   !INLINE (HGX_FINISH_WAVE=0, a cross-check): all of them are listed.
+template <bool INLINE>
+static __global__ void __launch_bounds__(256) k_lift_classify(const int64_t *__restrict__ gStart, const int64_t *__restrict__ gEnd,
+                                                              const uint8_t *__restrict__ strand, uint32_t nq, int64_t genomeLength,
+                                                              const uint32_t *__restrict__ coarse, int shift, int64_t window,
+                                                              const ComposedRec<int32_t> *__restrict__ recs, uint2 *__restrict__ kb,
+                                                              GeneralTable<int32_t> GT, unsigned long long *kstat, uint32_t *__restrict__ offset,
+                                                              uint32_t *__restrict__ nOut, uint32_t *__restrict__ lateList,
+                                                              unsigned long long *__restrict__ lateCount, uint32_t *__restrict__ waveTotal) {
+    __shared__ int32_t sDAll[INLINE ? 4 : 1][INLINE ? 128 : 1];
+    __shared__ uint8_t sOwnAll[INLINE ? 4 : 1][INLINE ? 64 : 1];
+    __shared__ uint4 sAsk[4][64], sAnswer[4][64];
+    const int lane = lane_id(), w = (int)(threadIdx.x >> 6);
+    const int quad = lane >> 2, c = lane & 3;
+    uint32_t generalSeen = 0, used = 0;
+    const uint32_t nTiles = (nq + (uint32_t)LIFT_TILE - 1) >> LIFT_TILE_SHIFT;
+    LIFT_PROF_DECL;
+    for (uint32_t tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
+        const uint32_t q = tile * (uint32_t)LIFT_TILE + threadIdx.x;
+        int64_t gs = 0, ge = -1;
+        if (q < nq) {
+            gs = gStart[q];
+            ge = gEnd[q];
+        }
+        const bool valid = ge >= gs && gs >= 0 && gs < genomeLength;
+        // (an interval that is not valid asks for nothing: no record begins at or before base -1)
+        const uint32_t k0 = valid ? coarse[gs >> shift] : 0u;
+        const int32_t gs32 = valid ? (int32_t)gs : 0, ge32 = valid ? (int32_t)(ge < 0x7FFFFFFFll ? ge : 0x7FFFFFFFll) : -1;
+        sAsk[w][lane] = make_uint4(k0, (uint32_t)gs32, (uint32_t)ge32, 0u);
+        wave_lds_fence();
+        LIFT_PROF(0) // the intervals and their bucket entries have arrived
+        // ---- the scan: quad `quad` of round `it` works for the interval of lane 16 * it + quad ----
+        uint4 ask[4];
+        ComposedRec<int32_t> r[4];
+        LiftScan sc[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            ask[it] = sAsk[w][16 * it + quad];
+            r[it] = recs[ask[it].x + (uint32_t)c];
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+            sc[it].take(r[it], ask[it].x + (uint32_t)c, (int32_t)ask[it].y, (int32_t)ask[it].z);
+        for (uint32_t trip = 1; trip < LIFT_MAX_BOUND / 4 && __any(sc[0].cont || sc[1].cont || sc[2].cont || sc[3].cont); ++trip) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+                if (sc[it].cont)
+                    r[it] = recs[ask[it].x + 4u * trip + (uint32_t)c];
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+                if (sc[it].cont) // (quad-uniform)
+                    sc[it].take(r[it], ask[it].x + 4u * trip + (uint32_t)c, (int32_t)ask[it].y, (int32_t)ask[it].z);
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const uint32_t n = quad_reduce<LiftSum>(sc[it].cnt), fl = quad_reduce<LiftOr>(sc[it].flags | (sc[it].cont ? 2u : 0u)),
+                           first = quad_reduce<LiftMin>(sc[it].first), last = quad_reduce<LiftMax>(sc[it].last);
+            if (c == 0)
+                sAnswer[w][16 * it + quad] = make_uint4(n, fl, first, last);
+        }
+        wave_lds_fence();
+        const uint4 ans = sAnswer[w][lane];
+        uint32_t cnt = ans.x;
+        // flags: 1 a record that overlaps the interval carries the table's flag, 2 the scan stopped at LIFT_MAX_BOUND records
+        // that begin inside the interval.  (Putting the flag's question — do two of the interval's records overlap on the
+        // target? — to the records of a quad themselves spares a quarter of the general intervals at cfg2 and costs every
+        // interval more than that saves: profiles/r02k_notes.md.)
+        const bool general = valid && (cnt > 0 || (ans.y & 2u)) && ((ans.y & 3u) != 0 || ge - gs >= window);
+        if (q < nq)
+            kb[q] = general ? make_uint2(0u, KB_GENERAL) : cnt ? make_uint2(ans.z, ans.w - ans.z + 1u) : make_uint2(0u, 0u);
+        generalSeen += general ? 1u : 0u;
+        LIFT_PROF(1) // counted
+        if (INLINE) {
+            unsigned long long gm = __ballot(general);
+            while (gm) { // (rare: about one wavefront in fifteen meets one at cfg2)
+                const int o = __ffsll((long long)gm) - 1;
+                gm &= gm - 1;
+                const uint32_t oq = (uint32_t)wave_read<int32_t>((int32_t)q, o); // (readlane: wave-uniform values keep general_interval's loops scalar)
+                const int64_t os = wave_read<int64_t>(gs, o), oe = wave_read<int64_t>(ge, o);
+                int nl = 0;
+                uint32_t base = 0;
+                const int rc = general_interval<int32_t>(lane, GT, oq, os, oe, strand[oq], sDAll[w], sOwnAll[w], used, nl, base LIFT_PROF_ARG);
+                if (lane == 0) {
+                    if (rc == 0) // (its lines come later, or not at all: a run that does not make the launches behind this one is repeated)
+                        lateList[atomicAdd(lateCount, 1ull)] = oq;
+                    offset[oq] = base;
+                }
+                if (lane == o)
+                    cnt = (uint32_t)nl;
+            }
+        } else if (general) {
+            lateList[atomicAdd(lateCount, 1ull)] = q;
+            cnt = 0;
+        }
+        if (q < nq)
+            nOut[q] = cnt;
+        // (no barrier: a wavefront that met a general interval does not keep the other three waiting)
+        const uint32_t waveLines = wave_total(cnt);
+        if (lane == 0)
+            waveTotal[tile * 4u + (uint32_t)w] = waveLines;
+        LIFT_PROF(2) // general intervals done
+        LIFT_PROF(3)
+    }
+    LIFT_PROF_FLUSH
+    stat_add(&kstat[0], used);         // the "top" slot of this launch: unmerged records the general intervals clipped
+    stat_add(&kstat[1], generalSeen);  // its "bottom" slot: general intervals
+    stat_add(&GT.counters[CNT_DSTAT0 + STAT_MAPPED], used);
+}
+
+// what a record lane needs to know about the interval that owns its slot (one ds_read_b128)
+//   x: first record of the interval - its first slot (so that record = x + slot), y: its first slot,
+//   z: first base | minus strand << 31, w: last base | '.' strand << 31
+static constexpr uint32_t LIFT_STRIP = 512 + 64; // slots whose owners are looked up from one scatter (bytes of LDS per wavefront)
+
+// Pass 2, one record per lane, in rounds of up to 64 record slots: consecutive intervals share a round as long as their
+// records fit.  sStrip maps record slots to owner lanes (owners mark their first slot — once per 512 slots, not per round —
+// and a running maximum spreads the marks to the right); sIv / sOff hold the owners' interval data and first output line.
+__device__ __forceinline__ void lift_wave_emit(const ComposedRec<int32_t> *__restrict__ recs, uint8_t *sStrip, const uint4 *sIv,
+                                               const uint32_t *sOff, const int lane, const uint32_t b, const uint32_t p,
+                                               const uint32_t totalSlots, const uint32_t firstQuery, const int64_t *__restrict__ tSeqStart,
+                                               const int64_t ss0, const bool oneSeq, hgx_record *__restrict__ out, uint32_t &used) {
     const unsigned long long below = (1ull << lane) - 1ull;
+    uint32_t windowBase = 0;
+    bool haveWindow = false;
     for (uint32_t base = 0; base < totalSlots;) {
         // intervals of this round: from the first one whose records start at `base` up to the first one that does not fit
         const bool started = p >= base;
         const bool fits = started && p + b <= base + 64;
         const unsigned long long stop = __ballot(started && !fits);
         const int qb = stop ? __ffsll((long long)stop) - 1 : 64;
-        const uint32_t nextBase = qb < 64 ? (uint32_t)__shfl((int)p, qb) : totalSlots;
-        const bool inRound = fits && lane < qb && b > 0;
-        // record slot -> owner lane: owners mark their first slot, a running maximum spreads the marks to the right
-        sOwner[lane] = 0;
-        wave_lds_fence();
-        if (inRound)
-            sOwner[p - base] = (uint8_t)(lane + 1);
-        wave_lds_fence();
-        int mark = (int)sOwner[lane];
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int up = __shfl_up(mark, o);
-            if (lane >= o && up > mark)
-                mark = up;
+        const uint32_t nextBase = qb < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)p, qb) : totalSlots;
+        if (!haveWindow || base - windowBase > 512u) { // (wave-uniform; usually once per tile)
+            windowBase = base;
+            haveWindow = true;
+            wave_lds_fence();
+            reinterpret_cast<unsigned long long *>(sStrip)[lane] = 0ull;
+            if (lane < 8)
+                reinterpret_cast<unsigned long long *>(sStrip)[64 + lane] = 0ull;
+            wave_lds_fence();
+            if (b > 0 && started && p - base < LIFT_STRIP)
+                sStrip[p - base] = (uint8_t)(lane + 1);
+            wave_lds_fence();
         }
+        const uint32_t mark = wave_incl_scan<LiftMax>((uint32_t)sStrip[base - windowBase + (uint32_t)lane]);
         const bool slotValid = base + (uint32_t)lane < nextBase && mark > 0;
-        const int owner = mark > 0 ? mark - 1 : 0;
-        const uint32_t oK = (uint32_t)__shfl((int)k, owner), oP = (uint32_t)__shfl((int)p, owner);
-        const int32_t oGs = __shfl(gs, owner), oGe = __shfl(ge, owner);
-        const uint32_t lo = (oP - base) & 63u; // first slot of my interval in this round
+        const int owner = mark > 0 ? (int)mark - 1 : 0;
+        const uint4 iv = sIv[owner];
+        const uint32_t oOff = sOff[owner];
+        const int32_t oGs = (int32_t)(iv.z & 0x7FFFFFFFu), oGe = (int32_t)(iv.w & 0x7FFFFFFFu);
+        const uint32_t lo = (iv.y - base) & 63u; // first slot of my interval in this round
         ComposedRec<int32_t> r{};
         if (slotValid)
-            r = recs[oK + (base + (uint32_t)lane - oP)];
+            r = recs[iv.x + base + (uint32_t)lane];
         const int32_t pLo = r.sLo, pHi = r.sLo + r.len - 1;
         const bool emit = slotValid && pLo <= oGe && pHi >= oGs;
         const unsigned long long em = __ballot(emit);
-        if (!EMIT) {
-            if (inRound) {
-                const uint32_t a = p - base, e = a + b; // my slots [a, e)
-                const unsigned long long mask = (e >= 64 ? ~0ull : ((1ull << e) - 1ull)) & ~((1ull << a) - 1ull);
-                cnt += (uint32_t)__popcll(em & mask);
+        used += emit ? 1u : 0u;
+        // lines of my interval before me (the table's order)
+        const unsigned long long mine = em & ~((1ull << lo) - 1ull); // (records of earlier intervals sit below lo)
+        uint32_t pos = (uint32_t)__popcll(mine & below);
+        const int32_t c = pLo > oGs ? pLo : oGs, d = pHi < oGe ? pHi : oGe;
+        const int32_t n = d - c + 1, delta = c - pLo;
+        const uint32_t trev = r.mEncF & 1u;
+        const int32_t tLo = r.so + (trev ? r.len - delta - n : delta);
+        // records that begin at or before the interval's first base all start there after clipping: among themselves
+        // they go by target start.  They are the first lines of the interval; more than one only with paralogs.
+        const bool inGroup = emit && pLo <= oGs;
+        if (__any(inGroup && pos > 0)) {
+            const int rel = (int)lane - (int)lo;
+            const int span = (int)__builtin_amdgcn_readlane((int)wave_incl_scan<LiftMax>(inGroup ? (uint32_t)(rel + 1) : 0u), 63);
+            const uint32_t oB = (uint32_t)__shfl((int)b, owner);
+            uint32_t rank = 0;
+            for (int jj = 0; jj < span; ++jj) {
+                const int partner = (int)lo + jj;
+                const int pGroup = __shfl((int)inGroup, partner & 63);
+                const int32_t pT = __shfl(tLo, partner & 63);
+                if (inGroup && (uint32_t)jj < oB && partner < 64 && pGroup && pT < tLo)
+                    ++rank;
             }
-        } else {
-            used += emit ? 1u : 0u;
-            // lines of my interval before me (the table's order)
-            const unsigned long long mine = em & ~((1ull << lo) - 1ull); // (records of earlier intervals sit below lo)
-            uint32_t pos = (uint32_t)__popcll(mine & below);
-            const int32_t c = pLo > oGs ? pLo : oGs, d = pHi < oGe ? pHi : oGe;
-            const int32_t n = d - c + 1, delta = c - pLo;
-            const uint32_t trev = r.mEncF & 1u;
-            const int32_t tLo = r.so + (trev ? r.len - delta - n : delta);
-            // records that begin at or before the interval's first base all start there after clipping: among themselves
-            // they go by target start.  They are the first lines of the interval; more than one only with paralogs.
-            const bool inGroup = emit && pLo <= oGs;
-            if (__any(inGroup && pos > 0)) {
-                const int rel = (int)lane - (int)lo;
-                int span = inGroup ? rel + 1 : 0; // slots of my interval up to and including me
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const int other = __shfl_xor(span, o);
-                    span = other > span ? other : span;
-                }
-                const uint32_t oB = (uint32_t)__shfl((int)b, owner);
-                uint32_t rank = 0;
-                for (int jj = 0; jj < span; ++jj) {
-                    const int partner = (int)lo + jj;
-                    const int pGroup = __shfl((int)inGroup, partner & 63);
-                    const int32_t pT = __shfl(tLo, partner & 63);
-                    if (inGroup && (uint32_t)jj < oB && partner < 64 && pGroup && pT < tLo)
-                        ++rank;
-                }
-                if (inGroup)
-                    pos = rank;
-            }
-            const uint32_t oOff = (uint32_t)__shfl((int)lineOff, owner), oFl = (uint32_t)__shfl((int)flags, owner);
-            if (emit) {
-                const uint32_t seq = r.mEncF >> 8;
-                const int64_t ss = oneSeq ? ss0 : tSeqStart[seq];
-                const uint32_t rev = trev ^ (oFl & 1u);
-                hgx_record rec;
-                rec.query = (int64_t)(firstQuery + (uint32_t)owner);
-                rec.tgt_start = (int64_t)tLo - ss;
-                rec.tgt_end = (int64_t)tLo + n - ss;
-                rec.src_start = (int64_t)c;
-                rec.tgt_seq = (int32_t)seq;
-                rec.strand = (oFl & 2u) ? '.' : (rev ? '-' : '+');
-                rec.tgt_reversed = (uint8_t)rev;
-                rec._pad[0] = rec._pad[1] = 0;
-                out[oOff + pos] = rec;
-            }
+            if (inGroup)
+                pos = rank;
+        }
+        if (emit) {
+            const uint32_t seq = r.mEncF >> 8;
+            const int64_t ss = oneSeq ? ss0 : tSeqStart[seq];
+            const uint32_t rev = trev ^ (iv.z >> 31);
+            hgx_record rec;
+            rec.query = (int64_t)(firstQuery + (uint32_t)owner);
+            rec.tgt_start = (int64_t)tLo - ss;
+            rec.tgt_end = (int64_t)tLo + n - ss;
+            rec.src_start = (int64_t)c;
+            rec.tgt_seq = (int32_t)seq;
+            rec.strand = (iv.w >> 31) ? '.' : (rev ? '-' : '+');
+            rec.tgt_reversed = (uint8_t)rev;
+            rec._pad[0] = rec._pad[1] = 0;
+            out[oOff + pos] = rec;
         }
         base = nextBase;
     }
-    return cnt;
 }
 
-// kb: k_lift_classify's answer; genOffset / genRecords / nOut: where the general path left the records of the general
-// intervals (k_finish_lds: nOut[q] records at genRecords + genOffset[q]); out / outCap: the dense output; outOffset[q]:
-// first record of interval q in it.  tileStatus / groupStatus: zeroed look-back granules.
+// k_lift_groups: groupTotal[g] = the lines of the 64 tiles (256 wavefronts' worth of intervals) of group g — after the
+// finishing kernels have added theirs to waveTotal
+static __global__ void __launch_bounds__(256) k_lift_groups(const uint32_t *__restrict__ waveTotal, uint32_t nWaves,
+                                                            unsigned long long *__restrict__ groupTotal) {
+    __shared__ uint32_t sPart[4];
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t t = wave_total(i < nWaves ? waveTotal[i] : 0u); // (a group has at most 2^14 intervals of at most ... lines: the sum of 64 stays far below 2^32)
+    if ((threadIdx.x & 63u) == 0)
+        sPart[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        groupTotal[blockIdx.x] = (unsigned long long)sPart[0] + sPart[1] + sPart[2] + sPart[3];
+}
+
+// kb, nOut, waveTotal, groupTotal: k_lift_classify's and k_lift_groups' answers; genOffset /
+// genRecords: where the general path left the records of the general intervals (nOut[q] records at genRecords +
+// genOffset[q]); out / outCap: the dense output; outOffset[q]: first record of interval q in it.
 template <int MINW>
 static __global__ void __launch_bounds__(256, MINW) k_lift_merged(const int64_t *__restrict__ gStart, const int64_t *__restrict__ gEnd,
                                                             const uint8_t *__restrict__ strand, uint32_t nq, const uint2 *__restrict__ kb,
                                                             const ComposedRec<int32_t> *__restrict__ recs, const int64_t *__restrict__ tSeqStart,
                                                             int tNumSeq, const uint32_t *__restrict__ genOffset,
                                                             const hgx_record *__restrict__ genRecords, hgx_record *__restrict__ out,
-                                                            uint32_t outCap, uint32_t *__restrict__ nOut, uint32_t *__restrict__ outOffset,
-                                                            unsigned long long *tileStatus, unsigned long long *groupStatus, uint32_t nTiles,
+                                                            uint32_t outCap, const uint32_t *__restrict__ nOut, uint32_t *__restrict__ outOffset,
+                                                            const uint32_t *__restrict__ waveTotal,
+                                                            const unsigned long long *__restrict__ groupTotal, uint32_t nTiles,
                                                             unsigned long long *counters, unsigned long long *kstat, uint32_t *__restrict__ total) {
-    __shared__ uint8_t sOwnerAll[4][64];
-    __shared__ uint32_t sWaveTotal[4];
-    __shared__ unsigned long long sTileBase;
-    __shared__ int sGiveUp;
+    __shared__ __attribute__((aligned(16))) uint8_t sStripAll[4][LIFT_STRIP];
+    __shared__ uint4 sIvAll[4][64];
+    __shared__ uint32_t sOffAll[4][64];
+    __shared__ uint32_t sWaveTotal[4], sFront[4];
     const int lane = lane_id(), w = (int)(threadIdx.x >> 6);
-    uint8_t *sOwner = sOwnerAll[w];
     const int64_t ss0 = tSeqStart[0];
     const bool oneSeq = tNumSeq <= 1;
     uint32_t used = 0;
+    LIFT_PROF_DECL;
     for (uint32_t tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
         // ---- the workgroup's intervals, one per thread ----
         const uint32_t q = tile * (uint32_t)LIFT_TILE + threadIdx.x;
@@ -274,140 +354,88 @@ static __global__ void __launch_bounds__(256, MINW) k_lift_merged(const int64_t 
         int32_t gs = 0, ge = -1;
         bool general = false;
         if (q < nq) {
+            const int64_t s64 = gStart[q], e64 = gEnd[q];
+            const uint8_t st = strand[q];
             const uint2 x = kb[q];
+            cnt = nOut[q];
+            gs = (int32_t)s64;
+            ge = (int32_t)(e64 < 0x7FFFFFFFll ? e64 : 0x7FFFFFFFll);
+            flags = (st == '-' ? 1u : 0u) | (st == '.' ? 2u : 0u);
             k = x.x;
             general = (x.y & KB_GENERAL) != 0;
             b = general ? 0u : x.y;
-            const int64_t s64 = gStart[q], e64 = gEnd[q];
-            gs = (int32_t)s64;
-            ge = (int32_t)(e64 < 0x7FFFFFFFll ? e64 : 0x7FFFFFFFll);
-            const uint8_t st = strand[q];
-            flags = (st == '-' ? 1u : 0u) | (st == '.' ? 2u : 0u);
-            if (general) {
-                cnt = nOut[q];
+            if (general)
                 gOff = genOffset[q];
-            }
         }
-        const uint32_t inclSlots = wave_incl_scan(b, lane);
-        const uint32_t p = inclSlots - b, totalSlots = (uint32_t)__shfl((int)inclSlots, 63);
-        // ---- pass 1: lines per interval ----
-        uint32_t dummy = 0;
-        const uint32_t fast = lift_wave_pass<false>(recs, sOwner, lane, k, b, p, totalSlots, gs, ge, flags, 0u, 0u, tSeqStart, ss0, oneSeq, out,
-                                                     dummy);
-        if (!general)
-            cnt = fast;
-        const uint32_t inclLines = wave_incl_scan(cnt, lane);
-        if (lane == 63)
-            sWaveTotal[w] = inclLines;
+        // ---- the tile's place in the output ----
+        // thread t looks at wavefront t of the tile's group: the ones in front of the tile, the ones of the tile in front of
+        // this wavefront; the groups in front are added up by every wavefront for itself
+        const uint32_t g = tile >> 6, j = tile & 63u;
+        const uint32_t nWaves = (nq + 63u) >> 6;
+        const uint32_t peer = (g << 8) + threadIdx.x;
+        const uint32_t peerLines = peer < nWaves && threadIdx.x < 4u * j + 4u ? waveTotal[peer] : 0u;
+        unsigned long long before = 0;
+        for (uint32_t g0 = 0; g0 < g; g0 += 64u)
+            before += g0 + (uint32_t)lane < g ? groupTotal[g0 + (uint32_t)lane] : 0ull;
+        const uint32_t inclSlots = wave_incl_scan<LiftSum>(b);
+        const uint32_t p = inclSlots - b, totalSlots = (uint32_t)__builtin_amdgcn_readlane((int)inclSlots, 63);
+        const uint32_t inclLines = wave_incl_scan<LiftSum>(cnt);
+        sIvAll[w][lane] = make_uint4(k - p, p, ((uint32_t)gs & 0x7FFFFFFFu) | ((flags & 1u) << 31), ((uint32_t)ge & 0x7FFFFFFFu) | ((flags & 2u) << 30));
+        const uint32_t inFront = wave_total(threadIdx.x < 4u * j ? peerLines : 0u); // of the tiles in front, as far as this wavefront's threads see them
+        if (lane == 0)
+            sFront[w] = inFront;
+        if (threadIdx.x >= 4u * j && threadIdx.x < 4u * j + 4u)
+            sWaveTotal[threadIdx.x - 4u * j] = peerLines;
+        const unsigned long long groupsBefore = wave_sum64(before);
+        LIFT_PROF(0) // the intervals, their reach and their place have arrived
         __syncthreads();
-        uint32_t wavePrefix = 0, tileTotal = 0;
+        LIFT_PROF(1)
+        const unsigned long long tileBase = groupsBefore + sFront[0] + sFront[1] + sFront[2] + sFront[3];
+        uint32_t wavePrefix = 0, tileLines = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint32_t t = sWaveTotal[i];
             wavePrefix += i < w ? t : 0u;
-            tileTotal += t;
+            tileLines += t;
         }
-        // ---- the tile's place in the output: two-level look-back by the first wavefront ----
-        if (w == 0) {
-            bool giveUp = false;
-            if (lane == 0)
-                lift_publish(&tileStatus[tile], LIFT_TAG_OWN | (unsigned long long)tileTotal);
-            const uint32_t g = tile >> 6, j = tile & 63u;
-            const uint32_t groupSize = nTiles - (g << 6) < 64u ? nTiles - (g << 6) : 64u;
-            // (a) the tiles before mine in my group
-            unsigned long long mine = 0;
-            for (unsigned spins = 0;; ++spins) {
-                const unsigned long long v = (uint32_t)lane < j ? lift_peek(&tileStatus[(g << 6) + (uint32_t)lane]) : LIFT_TAG_OWN;
-                if (__all((v & ~LIFT_VALUE) != 0)) {
-                    mine = wave_sum64((uint32_t)lane < j ? (v & LIFT_VALUE) : 0ull);
-                    break;
-                }
-                if (lift_spin_over(spins, counters)) {
-                    giveUp = true;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(2);
-            }
-            const bool lastOfGroup = j + 1 == groupSize;
-            if (lastOfGroup && lane == 0 && !giveUp)
-                lift_publish(&groupStatus[g], LIFT_TAG_OWN | (mine + tileTotal));
-            // (b) the groups before mine: 64 per step, stopping at the first one that knows its inclusive count
-            unsigned long long before = 0;
-            for (long long posn = (long long)g - 1; posn >= 0 && !giveUp;) {
-                const long long idx = posn - lane;
-                unsigned long long v = LIFT_TAG_INCL; // in front of group 0: inclusive count 0
-                bool done = false;
-                for (unsigned spins = 0;; ++spins) {
-                    v = idx >= 0 ? lift_peek(&groupStatus[idx]) : LIFT_TAG_INCL;
-                    const unsigned long long empty = __ballot((v & ~LIFT_VALUE) == 0);
-                    const unsigned long long incl = __ballot((v & ~LIFT_VALUE) == LIFT_TAG_INCL);
-                    // usable once every lane up to the nearest inclusive one (or all 64) has something
-                    const int firstIncl = incl ? __ffsll((long long)incl) - 1 : 63;
-                    const unsigned long long need = firstIncl >= 63 ? ~0ull : ((2ull << firstIncl) - 1ull);
-                    if ((empty & need) == 0) {
-                        before += wave_sum64(lane <= firstIncl ? (v & LIFT_VALUE) : 0ull);
-                        done = incl != 0;
-                        break;
-                    }
-                    if (lift_spin_over(spins, counters)) {
-                        giveUp = true;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(2);
-                }
-                if (done || giveUp)
-                    break;
-                posn -= 64;
-            }
-            if (lastOfGroup && lane == 0 && !giveUp)
-                lift_publish(&groupStatus[g], LIFT_TAG_INCL | (before + mine + tileTotal));
-            const unsigned long long tileBase = before + mine;
-            int state = giveUp ? 1 : 0; // 1: a wait timed out (the host repeats the batch on the multi-kernel path)
-            if (!giveUp && tileBase + tileTotal > (unsigned long long)outCap) { // the retry sizes the buffers from CNT_LIFT_TOTAL
-                state = 2;
-                if (lane == 0)
-                    counters[CNT_OVERFLOW] = 1;
-            }
-            if (lane == 0) {
-                sTileBase = tileBase;
-                sGiveUp = state;
-                if (tile + 1 == nTiles) {
-                    *total = (uint32_t)(tileBase + tileTotal);
-                    counters[CNT_LIFT_TOTAL] = tileBase + tileTotal;
-                }
-            }
+        if (tile + 1 == nTiles && threadIdx.x == 0) {
+            *total = (uint32_t)(tileBase + tileLines);
+            counters[CNT_LIFT_TOTAL] = tileBase + tileLines;
         }
-        __syncthreads();
-        const int state = sGiveUp;
-        const uint32_t tileBase = (uint32_t)sTileBase;
-        if (state != 0) {
-            if (threadIdx.x == 0 && state == 1)
-                lift_publish(&counters[CNT_LIFT_FAIL], 1ull);
+        if (tileBase + tileLines > (unsigned long long)outCap) { // (uniform over the workgroup) the retry sizes the buffers from CNT_LIFT_TOTAL
+            if (threadIdx.x == 0)
+                counters[CNT_OVERFLOW] = 1;
         } else {
-            // ---- pass 2: the lines, at their final place ----
-            const uint32_t lineOff = tileBase + wavePrefix + (inclLines - cnt);
-            lift_wave_pass<true>(recs, sOwner, lane, k, b, p, totalSlots, gs, ge, flags, lineOff, tile * (uint32_t)LIFT_TILE + (uint32_t)(w << 6),
-                                 tSeqStart, ss0, oneSeq, out, used);
+            // ---- the lines, at their final place ----
+            const uint32_t lineOff = (uint32_t)tileBase + wavePrefix + (inclLines - cnt);
+            sOffAll[w][lane] = lineOff; // (made visible to the wave by the fences in front of lift_wave_emit's first scatter)
+            lift_wave_emit(recs, sStripAll[w], sIvAll[w], sOffAll[w], lane, b, p, totalSlots, tile * (uint32_t)LIFT_TILE + (uint32_t)(w << 6),
+                           tSeqStart, ss0, oneSeq, out, used);
+            LIFT_PROF(2) // lines stored
             // general intervals: their records were made by the general path; copied in as 8-byte words
             unsigned long long gm = __ballot(general && cnt > 0);
             while (gm) {
                 const int o = __ffsll((long long)gm) - 1;
                 gm &= gm - 1;
-                const uint32_t n = (uint32_t)__shfl((int)cnt, o), from = (uint32_t)__shfl((int)gOff, o), to = (uint32_t)__shfl((int)lineOff, o);
+                const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)cnt, o), from = (uint32_t)__builtin_amdgcn_readlane((int)gOff, o),
+                               to = (uint32_t)__builtin_amdgcn_readlane((int)lineOff, o);
                 const unsigned long long *src = (const unsigned long long *)(genRecords + from);
                 unsigned long long *dst = (unsigned long long *)(out + to);
                 for (uint32_t i = (uint32_t)lane; i < n * 5u; i += 64u)
                     dst[i] = src[i];
             }
-            if (q < nq) {
-                nOut[q] = cnt;
+            if (q < nq)
                 outOffset[q] = lineOff;
-            }
+            LIFT_PROF(3)
         }
-        __syncthreads(); // (sWaveTotal, sTileBase are reused by the next tile)
+        if (tile + gridDim.x < nTiles)
+            __syncthreads(); // (sWaveTotal, sFront are rewritten for the next tile)
     }
     stat_add(&kstat[0], used); // the "top" slot of this launch: merged records that overlap their interval
     stat_add(&counters[CNT_DSTAT0 + STAT_MAPPED], used);
+#if defined(HGX_LIFT_PROFILE) && HGX_LIFT_PROFILE == 1
+    LIFT_PROF_FLUSH
+#endif
 }
 
 // End of a single-pass run: folds the spread statistics words (hgx_liftover_kernels.hpp: stat_add) and gathers everything
@@ -417,13 +445,13 @@ static __global__ void __launch_bounds__(256, MINW) k_lift_merged(const int64_t 
 static constexpr int LIFT_RB_WORDS = 16;
 // ... and leaves the words the next single-pass run counts in zeroed (the scalar slots, the level-0 append counters, the
 // statistics copies, the look-back granules of this run, the count of passed-on intervals): a batch then needs no memsets.
-static __global__ void __launch_bounds__(256) k_lift_epilogue(unsigned long long *counters, const unsigned long long *generalCount,
+static __global__ void __launch_bounds__(256) k_lift_epilogue(unsigned long long *counters, unsigned long long *generalCount,
                                                               unsigned long long *restCount, unsigned long long *rb, unsigned long long *granules,
                                                               uint32_t numGranules) {
-    __shared__ unsigned long long sums[5];
+    __shared__ unsigned long long sums[6];
     const int w = (int)threadIdx.x;
-    if (w < 5) {
-        const int word = w == 0 ? STAT_MAPPED : STAT_LAUNCH0 + 2 * (w - 1);
+    if (w < 6) {
+        const int word = w == 0 ? STAT_MAPPED : w == 5 ? STAT_LAUNCH0 + 1 : STAT_LAUNCH0 + 2 * (w - 1);
         unsigned long long sum = 0;
         for (int l = 0; l < STAT_LINES; ++l)
             sum += counters[CNT_DSTAT0 + (size_t)l * STAT_PITCH + word];
@@ -438,6 +466,8 @@ static __global__ void __launch_bounds__(256) k_lift_epilogue(unsigned long long
         rb[w] = *generalCount;
     else if (w == 13)
         rb[w] = restCount ? *restCount : 0ull; // intervals k_general_wave passed on
+    else if (w == 14)
+        rb[w] = sums[5]; // the "bottom" slot of launch 0 (single-kernel form: general intervals)
     __syncthreads();
     if (w < 8)
         counters[w] = 0;
@@ -449,6 +479,27 @@ static __global__ void __launch_bounds__(256) k_lift_epilogue(unsigned long long
         granules[i] = 0;
     if (w == 0 && restCount)
         *restCount = 0;
+    if (w == 1)
+        *generalCount = 0;
+#ifdef HGX_LIFT_PROFILE
+    __shared__ unsigned long long profSum[8];
+    if (w < 8)
+        profSum[w] = 0;
+    __syncthreads();
+    for (int i = w; i < 8192 * 4 * 8; i += (int)blockDim.x) {
+        atomicAdd(&profSum[i & 7], g_liftProfile[i]);
+        g_liftProfile[i] = 0;
+    }
+    __syncthreads();
+    if (w == 0) {
+        const double n = (double)profSum[7];
+        // (both kernels write the same slots: the later one, k_lift_merged, unless built with -DHGX_LIFT_PROFILE=2, which leaves
+        // it out: 1 = k_lift_merged: load+place, barrier, store, tail; 2 = k_lift_classify: classify, general, count, reduce,
+        // then inside general_interval: table look-ups and records, finish_wave, reservation, store)
+        printf("lift profile: waves %.0f, cycles per wave: %.0f %.0f %.0f %.0f | %.0f %.0f %.0f\n", n, (double)profSum[0] / n, (double)profSum[1] / n,
+               (double)profSum[2] / n, (double)profSum[3] / n, (double)profSum[4] / n, (double)profSum[5] / n, (double)profSum[6] / n);
+    }
+#endif
 }
 
 } // namespace hgx

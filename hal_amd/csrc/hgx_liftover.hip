@@ -63,10 +63,8 @@ DeviceImage::~DeviceImage() {
             (void)hipFree(kv.second.starts);
         if (kv.second.mRecs)
             (void)hipFree(kv.second.mRecs);
-        if (kv.second.mCoarse)
-            (void)hipFree(kv.second.mCoarse);
-        if (kv.second.mStarts)
-            (void)hipFree(kv.second.mStarts);
+        if (kv.second.mBuckets)
+            (void)hipFree(kv.second.mBuckets);
     }
     if (desc)
         (void)hipFree(desc);
@@ -549,7 +547,7 @@ struct hgx_liftover_plan {
         liftKb.ensure(8 * (nq + 1));
         liftBlockList.ensure(4 * (nq + 4096));
         liftBlockCount.ensure(4 * 2048);
-        liftStatus.ensure(8 * ((nq + LIFT_TILE - 1) / LIFT_TILE + (nq + 64 * LIFT_TILE - 1) / (64 * LIFT_TILE) + 2));
+        liftStatus.ensure(16 * ((nq + LIFT_TILE - 1) / LIFT_TILE) + 8 * ((nq + 64 * LIFT_TILE - 1) / (64 * LIFT_TILE)) + 16);
     }
 };
 
@@ -601,7 +599,9 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
     const int64_t srcLength = P.h->img.genomes[(size_t)P.src].totalLength;
     const DeviceGenome &TG = D.genomes[(size_t)P.tgt];
     const uint32_t nTiles = (nq + LIFT_TILE - 1) / LIFT_TILE, nGroups = (nTiles + 63) / 64;
-    unsigned long long *tileStatus = (unsigned long long *)P.liftStatus.p, *groupStatus = tileStatus + nTiles;
+    // lines per 64 intervals (k_lift_classify, + the finishing kernels) and per group of 64 tiles (k_lift_groups)
+    uint32_t *waveTotal = (uint32_t *)P.liftStatus.p;
+    unsigned long long *groupTotal = (unsigned long long *)P.liftStatus.p + 2 * (size_t)nTiles; // (behind the 4 * nTiles 32-bit words)
     uint32_t *generalList = (uint32_t *)P.classLists.p;
     unsigned long long *generalCount = (unsigned long long *)P.classCounts.p;
     // the words this run counts in were left zeroed by the previous single-pass run's epilogue; otherwise (first run, another
@@ -616,34 +616,29 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
     const bool events = P.timer.mode != 0; // (walk_ms / total_ms of the statistics need three event records per run)
     if (events)
         HIP_OK(hipEventRecord(P.evStart, s));
-    int launch = 0;
-    auto kstat = [&]() { return cnt + CNT_DSTAT0 + STAT_LAUNCH0 + 2 * launch; };
-    // k_lift_classify: a workgroup per contiguous chunk of intervals
-    const uint32_t cGrid = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)GRID, (nq + 255) / 256));
-    const uint32_t chunk = (nq + cGrid - 1) / cGrid;
-    P.timer.begin("k_lift_classify", s);
-    hipLaunchKernelGGL(k_lift_classify, dim3(cGrid), dim3(256), 0, s, dS, dE, nq, srcLength, (const uint2 *)T.mCoarse, (const uint2 *)T.mStarts, T.mShift,
-                       T.mWindow, (uint2 *)P.liftKb.p, (uint32_t *)P.liftBlockList.p, (uint32_t *)P.liftBlockCount.p, chunk);
-    hipLaunchKernelGGL(k_lift_gather, dim3(std::min<uint32_t>(cGrid, 256)), dim3(256), 0, s, (const uint32_t *)P.liftBlockList.p,
-                       (const uint32_t *)P.liftBlockCount.p, cGrid, chunk, generalList, generalCount);
-    P.timer.end(s);
-    // the general intervals: look-up, clipping and the general algorithm in registers, a wavefront per interval
-    // (k_general_wave); what it cannot hold — more than 64 pieces — goes the old way: pieces from the unmerged table grouped
-    // by interval, the LDS finishing kernel, and k_finish_big behind it.  HGX_FINISH_WAVE=0: everything the old way.
+    const GeneralTable<C> GT{(const uint32_t *)T.coarse, (const uint32_t *)T.starts, T.shift, (const ComposedRec<C> *)T.recs, srcLength,
+                             (const int64_t *)TG.seqStart, (int)TG.numSeq, (hgx_record *)P.grouped.p, cap, cnt + CNT_FRONT0, cnt};
     uint32_t *restList = generalList + nq;
     unsigned long long *restCount = generalCount + 1;
     const bool waveFinish = !(getenv("HGX_FINISH_WAVE") && getenv("HGX_FINISH_WAVE")[0] == '0');
-    if (waveFinish) {
-        P.timer.begin("k_general_wave", s, launch);
-        hipLaunchKernelGGL((k_general_wave<C>), dim3(512), dim3(256), 0, s, dS, dE, dStrand, srcLength, (const uint32_t *)T.coarse,
-                           (const uint32_t *)T.starts, T.shift, (const ComposedRec<C> *)T.recs, (const uint32_t *)generalList,
-                           (const unsigned long long *)generalCount, (const int64_t *)TG.seqStart, (int)TG.numSeq, (hgx_record *)P.grouped.p, cap,
-                           cnt + CNT_FRONT0, cnt, kstat(), (uint32_t *)P.offset.p, (uint32_t *)P.nOut.p, restList, restCount);
-        P.timer.end(s);
-        ++launch;
-    }
+    int launch = 0;
+    auto kstat = [&]() { return cnt + CNT_DSTAT0 + STAT_LAUNCH0 + 2 * launch; };
+    // k_lift_classify: every interval's reach and its number of lines; the general intervals are finished by the wavefronts that
+    // meet them (HGX_FINISH_WAVE=0: they are all listed instead and go the LDS way, the round-1 route, as a cross-check)
     const uint32_t *lateList = waveFinish ? restList : generalList;
-    const unsigned long long *lateCount = waveFinish ? restCount : generalCount;
+    unsigned long long *lateCount = waveFinish ? restCount : generalCount;
+    P.timer.begin("k_lift_classify", s, launch);
+#define HGX_CLASSIFY(INL)                                                                                                                    \
+    hipLaunchKernelGGL((k_lift_classify<INL>), dim3(std::max<uint32_t>(1, nTiles)), dim3(256), 0, s, dS, dE, dStrand, nq, srcLength,           \
+                       (const uint32_t *)T.mBuckets, T.mShift, T.mWindow, (const ComposedRec<C> *)T.mRecs, (uint2 *)P.liftKb.p, GT, kstat(),       \
+                       (uint32_t *)P.offset.p, (uint32_t *)P.nOut.p, (uint32_t *)lateList, lateCount, waveTotal)
+    if (waveFinish)
+        HGX_CLASSIFY(true);
+    else
+        HGX_CLASSIFY(false);
+#undef HGX_CLASSIFY
+    P.timer.end(s);
+    ++launch;
     // Two more launches for what k_general_wave passes on (more than 64 pieces) — made only once a run of this plan has passed
     // something on: a run that skips them reads the count back with its counters and is repeated with them when it is not zero
     // (runPlan), so batches without such intervals do not pay for two empty launches.
@@ -662,7 +657,7 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
     hipLaunchKernelGGL((k_finish_lds<C, 256>), dim3(std::min<uint32_t>(std::max<uint32_t>(nq, 1), 1536u)), dim3(64), 0, s, P.mapped(1),
                        (const uint32_t *)P.offset.p, (const uint32_t *)P.perQuery.p, lateList, lateCount, (const int64_t *)TG.seqStart,
                        (int)TG.numSeq, (hgx_record *)P.grouped.p, (uint32_t *)P.nOut.p, (uint32_t *)P.deferredList.p, (uint32_t *)P.needCap.p,
-                       cnt, 0);
+                       cnt, 0, waveTotal);
     P.timer.end(s);
     } else if (events) {
         HIP_OK(hipEventRecord(P.evWalk, s));
@@ -672,23 +667,26 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
         hipLaunchKernelGGL((k_finish_big<C>), dim3(P.liftBigSlots), dim3(64), 0, s, P.mapped(1), (const uint32_t *)P.offset.p,
                            (const uint32_t *)P.perQuery.p, (const uint32_t *)P.deferredList.p, P.liftBigSlots, P.liftBigCap,
                            (unsigned char *)P.scratch.p, finishSliceBytes<C>(P.liftBigCap), (const int64_t *)TG.seqStart, (int)TG.numSeq,
-                           (hgx_record *)P.grouped.p + cap, (uint32_t *)P.nOut.p, cnt, 0, 1, (uint32_t *)P.offset.p, cap);
+                           (hgx_record *)P.grouped.p + cap, (uint32_t *)P.nOut.p, cnt, 0, 1, (uint32_t *)P.offset.p, cap, waveTotal);
         P.timer.end(s);
     }
     // everything else, and the dense output
     if (!P.liftGrid) {
         const char *v = getenv("HGX_LIFT_MINWAVES"); // 8: hold the kernel to 64 VGPRs (experiments)
         P.liftMinWaves = v && atoi(v) == 8 ? 8 : 1;
-        P.liftGrid = P.liftMinWaves == 8 ? residentGrid(k_lift_merged<8>) : residentGrid(k_lift_merged<1>);
-        if (const char *b = getenv("HGX_LIFT_BLOCKS")) // workgroups per CU (experiments)
-            P.liftGrid = std::min(P.liftGrid, std::max(1, atoi(b)) * 256);
+        P.liftGrid = 1 << 20; // a workgroup per tile, the hardware deals them out (HGX_LIFT_BLOCKS: a looping grid of that many per CU)
+        if (const char *b = getenv("HGX_LIFT_BLOCKS"))
+            P.liftGrid = std::max(1, atoi(b)) * 256;
     }
+    P.timer.begin("k_lift_groups", s);
+    hipLaunchKernelGGL(k_lift_groups, dim3(std::max<uint32_t>(1, nGroups)), dim3(256), 0, s, (const uint32_t *)waveTotal, 4 * nTiles, groupTotal);
+    P.timer.end(s);
     P.timer.begin("k_lift_merged", s, launch);
 #define HGX_LIFT(W)                                                                                                                          \
-    hipLaunchKernelGGL(k_lift_merged<W>, dim3(std::min<uint32_t>((uint32_t)P.liftGrid, nTiles)), dim3(256), 0, s, dS, dE, dStrand, nq,           \
-                       (const uint2 *)P.liftKb.p, (const ComposedRec<C> *)T.mRecs, (const int64_t *)TG.seqStart, (int)TG.numSeq,               \
-                       (const uint32_t *)P.offset.p, (const hgx_record *)P.grouped.p, (hgx_record *)P.outRecords.p, cap, (uint32_t *)P.nOut.p, \
-                       (uint32_t *)P.outOffset.p, tileStatus, groupStatus, nTiles, cnt, kstat(), (uint32_t *)P.total.p)
+    hipLaunchKernelGGL((k_lift_merged<W>), dim3(std::min<uint32_t>((uint32_t)P.liftGrid, nTiles)), dim3(256), 0, s, dS, dE, dStrand, nq,        \
+                       (const uint2 *)P.liftKb.p, (const ComposedRec<C> *)T.mRecs, (const int64_t *)TG.seqStart, (int)TG.numSeq,             \
+                       (const uint32_t *)P.offset.p, (const hgx_record *)P.grouped.p, (hgx_record *)P.outRecords.p, cap,                     \
+                       (const uint32_t *)P.nOut.p, (uint32_t *)P.outOffset.p, waveTotal, groupTotal, nTiles, cnt, kstat(), (uint32_t *)P.total.p)
     if (P.liftMinWaves == 8)
         HGX_LIFT(8);
     else
@@ -700,8 +698,8 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
         HIP_OK(hipEventRecord(P.evEnd, s));
     // one small copy brings back everything the host needs (k_lift_epilogue)
     unsigned long long *rb = cnt + CNT_DEV_SLOTS;
-    hipLaunchKernelGGL(k_lift_epilogue, dim3(1), dim3(256), 0, s, cnt, (const unsigned long long *)generalCount,
-                       waveFinish ? restCount : (unsigned long long *)nullptr, rb, tileStatus, nTiles + nGroups);
+    hipLaunchKernelGGL(k_lift_epilogue, dim3(1), dim3(256), 0, s, cnt, generalCount, waveFinish ? restCount : (unsigned long long *)nullptr, rb,
+                       (unsigned long long *)nullptr, 0u);
     unsigned long long *hrb = P.pinned + CNT_SLOTS + 1;
     HIP_OK(hipMemcpyAsync(hrb, rb, 8 * LIFT_RB_WORDS, hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
@@ -716,8 +714,8 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
         hostCounters[CNT_KSTAT0 + 2 * l] = hrb[8 + l];
     P.pinned[CNT_SLOTS] = hrb[CNT_LIFT_TOTAL]; // the record total, where runPlan looks for it
     // (an overflowing or failing run may have left counters beyond the ones the epilogue clears)
-    P.liftStateClean = !hrb[CNT_OVERFLOW] && !hrb[CNT_LIFT_FAIL] && !hrb[CNT_DEFERRED] && !(getenv("HGX_LIFT_MEMSETS") != nullptr);
-    P.generalQueries = hrb[12];
+    P.liftStateClean = !hrb[CNT_OVERFLOW] && !hrb[CNT_DEFERRED] && !(getenv("HGX_LIFT_MEMSETS") != nullptr);
+    P.generalQueries = waveFinish ? hrb[14] : hrb[12];
     P.liftRestCount = hrb[13];
 }
 
@@ -1139,13 +1137,6 @@ static void runPlan(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
             }
             if (merged && P.liftRestCount)
                 P.liftRestSeen = true;
-            if (merged && hc[CNT_LIFT_FAIL]) {
-                // a look-back wait timed out (not expected): repeat the batch on the multi-kernel path and stay there
-                P.mergedDisabled = true;
-                fprintf(stderr, "hgx: single-pass liftover kernel gave up waiting for a neighbouring workgroup; this plan continues on the multi-kernel path\n");
-                P.timer.dropRun();
-                continue;
-            }
             break;
         }
         // a frontier outgrew the workspace: size it from the largest count seen and run again
@@ -1553,7 +1544,7 @@ static void buildMerged(hgx_alignment *h, int src, int dst, ComposedUp &c) {
     HIP_OK(hipMemcpyAsync(&m32, scalars.p, 4, hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
     const size_t m = m32;
-    HIP_OK(hipMalloc(&c.mRecs, std::max<size_t>(m, 1) * sizeof(ComposedRec<int32_t>)));
+    HIP_OK(hipMalloc(&c.mRecs, (m + LIFT_SENTINELS) * sizeof(ComposedRec<int32_t>)));
     ComposedRec<int32_t> *mrecs = (ComposedRec<int32_t> *)c.mRecs;
     const unsigned gridM = (unsigned)((m + 255) / 256);
     hipLaunchKernelGGL(k_merge_records, dim3(gridM), dim3(256), 0, s, recs, (const uint32_t *)vals[1].p, (uint32_t)m, (const uint32_t *)minS.p,
@@ -1605,15 +1596,14 @@ static void buildMerged(hgx_alignment *h, int src, int dst, ComposedUp &c) {
     coarse.ensure(((size_t)nb + 1) * 4);
     starts.ensure(((size_t)nb + 1) * 4);
     HIP_OK(hipMemsetAsync(coarse.p, 0xFF, ((size_t)nb + 1) * 4, s));
-    HIP_OK(hipMalloc(&c.mCoarse, ((size_t)nb + 1) * 8));
-    HIP_OK(hipMalloc(&c.mStarts, ((size_t)nb + 1) * 8));
+    HIP_OK(hipMalloc(&c.mBuckets, ((size_t)nb + 1) * 4));
     if (m)
         hipLaunchKernelGGL((k_table_touch<int32_t>), dim3(gridM), dim3(256), 0, s, (const ComposedRec<int32_t> *)mrecs, (uint32_t)m, shift, (uint32_t *)coarse.p);
     const unsigned gridB = (unsigned)(((size_t)nb + 1 + 255) / 256);
     hipLaunchKernelGGL((k_table_starts<int32_t>), dim3(gridB), dim3(256), 0, s, (const ComposedRec<int32_t> *)mrecs, (uint32_t)m, shift, nb, (uint32_t *)starts.p);
     hipLaunchKernelGGL(k_table_fill, dim3(gridB), dim3(256), 0, s, (uint32_t *)coarse.p, (const uint32_t *)starts.p, nb);
-    hipLaunchKernelGGL(k_merge_pack_buckets, dim3(gridB), dim3(256), 0, s, (const uint32_t *)coarse.p, (const uint32_t *)starts.p, nb,
-                       (const uint32_t *)flagPrefix.p, (uint2 *)c.mCoarse, (uint2 *)c.mStarts);
+    HIP_OK(hipMemcpyAsync(c.mBuckets, coarse.p, ((size_t)nb + 1) * 4, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_merge_mark, dim3((unsigned)((m + LIFT_SENTINELS + 255) / 256)), dim3(256), 0, s, mrecs, (const uint32_t *)flag.p, (uint32_t)m);
     unsigned int flagged = 0;
     HIP_OK(hipMemcpyAsync(&flagged, (const uint32_t *)flagPrefix.p + m, 4, hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
@@ -1622,7 +1612,7 @@ static void buildMerged(hgx_alignment *h, int src, int dst, ComposedUp &c) {
     c.mNum = m;
     c.mFlagged = flagged;
     c.mWindow = window;
-    h->dev->bytes += std::max<size_t>(m, 1) * sizeof(ComposedRec<int32_t>) + ((size_t)nb + 1) * 16;
+    h->dev->bytes += (m + LIFT_SENTINELS) * sizeof(ComposedRec<int32_t>) + ((size_t)nb + 1) * 4;
     c.mBuildMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 

@@ -14,9 +14,9 @@
 // looking at their pieces: a merged record is FLAGGED when its target range overlaps the target range of another record
 // whose source range lies within `window` bases of its own.  Two records that both touch an interval no longer than
 // `window` are that close, so an interval shorter than the window whose records carry no flag has pairwise disjoint target
-// ranges; everything else (a flagged record in reach, more than 64 records in reach, a longer interval) goes the general
-// way over the unmerged table.  F[k] = number of flagged records before record k rides in the bucket tables, so the
-// classification costs nothing beyond the two bucket look-ups the interval needs anyway.
+// ranges; everything else (a flagged record among the ones that overlap it, more than 64 records, a longer interval) goes
+// the general way over the unmerged table.  The flag rides in the record (bit 1 of mEncF), so the classification costs
+// nothing beyond the walk over the interval's records that counts its lines.
 //
 // 32-bit coordinates only (every genome < 2^31 bases); wider alignments keep to the unmerged table.
 #pragma once
@@ -221,16 +221,22 @@ static __global__ void __launch_bounds__(256) k_flag_overlaps(const ComposedRec<
         flag[i] = 1u;
 }
 
-// bucket tables with the flag counts riding along: {record index, flagged records before it}
-static __global__ void __launch_bounds__(256) k_merge_pack_buckets(const uint32_t *__restrict__ coarse, const uint32_t *__restrict__ starts, uint32_t nb,
-                                                                   const uint32_t *__restrict__ flagPrefix, uint2 *__restrict__ coarseF,
-                                                                   uint2 *__restrict__ startsF) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b > nb)
-        return;
-    const uint32_t c = coarse[b], s = starts[b];
-    coarseF[b] = make_uint2(c, flagPrefix[c]);
-    startsF[b] = make_uint2(s, flagPrefix[s]);
+// the flag rides in bit 1 of the record's mEncF; LIFT_SENTINELS records that begin behind every base end the table (the
+// scans of k_lift_classify stop at the first record that begins behind their interval and read four records at a time)
+static constexpr uint32_t LIFT_SENTINELS = 8;
+static __global__ void __launch_bounds__(256) k_merge_mark(ComposedRec<int32_t> *__restrict__ recs, const uint32_t *__restrict__ flag, uint32_t m) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < m) {
+        if (flag[j])
+            recs[j].mEncF |= 2u;
+    } else if (j < m + LIFT_SENTINELS) {
+        ComposedRec<int32_t> o;
+        o.sLo = 0x7FFFFFFF;
+        o.len = 0;
+        o.so = 0;
+        o.mEncF = 0;
+        recs[j] = o;
+    }
 }
 
 } // namespace hgx
