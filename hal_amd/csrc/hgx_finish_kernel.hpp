@@ -762,9 +762,12 @@ __global__ void __launch_bounds__(256) k_finish_fast(Mapped in, const uint32_t *
 // single-pass runs (hgx_lift_kernels.hpp) keep the number of output lines per 64 intervals (a wavefront's worth); an
 // interval finished after the counting launch adds its lines here
 static constexpr int LIFT_TILE_SHIFT = 8;
-__device__ __forceinline__ void lift_add_late_lines(uint32_t *waveTotal, uint32_t q, int nl) {
-    if (waveTotal && nl > 0)
+// (otherLines: the statistics word for lines that do not come from merged records, one of its copies)
+__device__ __forceinline__ void lift_add_late_lines(uint32_t *waveTotal, unsigned long long *otherLines, uint32_t q, int nl) {
+    if (waveTotal && nl > 0) {
         atomicAdd(&waveTotal[q >> 6], (uint32_t)nl);
+        atomicAdd(otherLines + (size_t)(blockIdx.x & (STAT_LINES - 1)) * STAT_PITCH, (unsigned long long)nl);
+    }
 }
 
 // LDS-staged variant: capacity CAP pieces per query.
@@ -773,7 +776,8 @@ __global__ void __launch_bounds__(64) k_finish_lds(Mapped in, const uint32_t *__
                                                    const uint32_t *__restrict__ qlist, const unsigned long long *__restrict__ qcount,
                                                    const int64_t *__restrict__ seqStart, int numSeq, hgx_record *__restrict__ records,
                                                    uint32_t *__restrict__ nOut, uint32_t *__restrict__ deferredList, uint32_t *__restrict__ needCap,
-                                                   unsigned long long *counters, int blocks, uint32_t *waveTotal = nullptr) {
+                                                   unsigned long long *counters, int blocks, uint32_t *waveTotal = nullptr,
+                                                   unsigned long long *otherLines = nullptr) {
     // waveTotal (single-pass runs, hgx_lift_kernels.hpp): the interval's lines are added to the line count of its 64 intervals
     constexpr int CAP2 = 2 * CAP;
     __shared__ C s_tLo[CAP], s_tHi[CAP], s_sLo[CAP], s_sHi[CAP], s_tLo2[CAP], s_tHi2[CAP], s_sLo2[CAP], s_sHi2[CAP];
@@ -808,7 +812,7 @@ __global__ void __launch_bounds__(64) k_finish_lds(Mapped in, const uint32_t *__
             write_records(S, nl, (int32_t)q, records + base, seqStart);
             if (threadIdx.x == 0) {
                 nOut[q] = (uint32_t)nl;
-                lift_add_late_lines(waveTotal, q, nl);
+                lift_add_late_lines(waveTotal, otherLines, q, nl);
             }
         }
         wsync();
@@ -823,7 +827,7 @@ __global__ void __launch_bounds__(64) k_finish_big(Mapped in, const uint32_t *__
                                                    const int64_t *__restrict__ seqStart, int numSeq, hgx_record *__restrict__ bigRecords,
                                                    uint32_t *__restrict__ nOut, unsigned long long *counters, int blocks,
                                                    int countOnDevice = 0, uint32_t *__restrict__ offsetOut = nullptr, uint32_t recordBase = 0,
-                                                   uint32_t *waveTotal = nullptr) {
+                                                   uint32_t *waveTotal = nullptr, unsigned long long *otherLines = nullptr) {
     // countOnDevice (single-pass runs, hgx_lift_kernels.hpp): the number of deferred intervals is read from the counter block
     // (nDeferred = the slices the scratch area holds; more than that fails the run, the host grows the area and repeats it);
     // offsetOut: the interval's records are slice k of an area that starts recordBase records into the grouped buffer
@@ -871,7 +875,7 @@ __global__ void __launch_bounds__(64) k_finish_big(Mapped in, const uint32_t *__
             write_records(S, nl, (int32_t)q, bigRecords + (size_t)k * cap, seqStart);
             if (threadIdx.x == 0) {
                 nOut[q] = (uint32_t)nl;
-                lift_add_late_lines(waveTotal, q, nl);
+                lift_add_late_lines(waveTotal, otherLines, q, nl);
                 if (offsetOut)
                     offsetOut[q] = recordBase + k * (uint32_t)cap;
             }
@@ -1281,6 +1285,7 @@ template <typename C> struct GeneralTable {
     int64_t genomeLength;
     const int64_t *seqStart;
     int numSeq;
+    int64_t seqStart0;   // seqStart[0] (known to the host: no load in front of the record store)
     hgx_record *records; // the grouped buffer
     uint32_t cap;
     unsigned long long *segCounters, *counters;
@@ -1346,7 +1351,7 @@ __device__ __forceinline__ int general_interval(const int lane, const GeneralTab
     LIFT_PROF(6) // the reservation
     if (lane < L.nl) {
         hgx_record r;
-        const int64_t ss = G.numSeq > 1 ? G.seqStart[L.lSeq] : G.seqStart[0];
+        const int64_t ss = G.numSeq > 1 ? G.seqStart[L.lSeq] : G.seqStart0;
         r.query = (int64_t)q;
         r.tgt_start = (int64_t)L.lStart - ss;
         r.tgt_end = (int64_t)L.lEnd - ss;

@@ -28,6 +28,7 @@ static constexpr int LIFT_TILE = 256;        // intervals per tile (= threads pe
 static constexpr uint32_t LIFT_MAX_BOUND = 64; // records in reach of an interval the wave-wide rounds can hold
 static constexpr uint32_t KB_GENERAL = 0x80000000u;
 enum { CNT_LIFT_TOTAL = 1 }; // counters[] slot (hgx_liftover_kernels.hpp uses 0 and 3..7)
+static_assert(STAT_LINES <= 64, "k_lift_totals folds the statistics copies with one lane each");
 static_assert(LIFT_TILE == 1 << LIFT_TILE_SHIFT, "the finishing kernels add late counts to the tile totals");
 
 // ---- wave-wide scans on the VALU: DPP row shifts and row broadcasts (gfx9 encodings), no trip through the LDS crossbar ----
@@ -111,12 +112,13 @@ struct LiftScan {
 //   add their lines to the totals.  A general interval costs its own wavefront a handful of dependent memory round trips;
 //   in a launch of their own the same round trips were the batch's critical path.
 //   !INLINE (HGX_FINISH_WAVE=0, a cross-check): all of them are listed.
-template <bool INLINE>
-static __global__ void __launch_bounds__(256) k_lift_classify(const int64_t *__restrict__ gStart, const int64_t *__restrict__ gEnd,
+template <bool INLINE, int MINW>
+static __global__ void __launch_bounds__(256, MINW) k_lift_classify(const int64_t *__restrict__ gStart, const int64_t *__restrict__ gEnd,
                                                               const uint8_t *__restrict__ strand, uint32_t nq, int64_t genomeLength,
                                                               const uint32_t *__restrict__ coarse, int shift, int64_t window,
                                                               const ComposedRec<int32_t> *__restrict__ recs, uint2 *__restrict__ kb,
-                                                              GeneralTable<int32_t> GT, unsigned long long *kstat, uint32_t *__restrict__ offset,
+                                                              GeneralTable<int32_t> GT, unsigned long long *kstat, unsigned long long *kstatStore,
+                                                              uint32_t *__restrict__ offset,
                                                               uint32_t *__restrict__ nOut, uint32_t *__restrict__ lateList,
                                                               unsigned long long *__restrict__ lateCount, uint32_t *__restrict__ waveTotal) {
     __shared__ int32_t sDAll[INLINE ? 4 : 1][INLINE ? 128 : 1];
@@ -124,7 +126,7 @@ static __global__ void __launch_bounds__(256) k_lift_classify(const int64_t *__r
     __shared__ uint4 sAsk[4][64], sAnswer[4][64];
     const int lane = lane_id(), w = (int)(threadIdx.x >> 6);
     const int quad = lane >> 2, c = lane & 3;
-    uint32_t generalSeen = 0, used = 0;
+    uint32_t generalSeen = 0, used = 0, generalLines = 0;
     const uint32_t nTiles = (nq + (uint32_t)LIFT_TILE - 1) >> LIFT_TILE_SHIFT;
     LIFT_PROF_DECL;
     for (uint32_t tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
@@ -197,8 +199,10 @@ static __global__ void __launch_bounds__(256) k_lift_classify(const int64_t *__r
                         lateList[atomicAdd(lateCount, 1ull)] = oq;
                     offset[oq] = base;
                 }
-                if (lane == o)
+                if (lane == o) {
                     cnt = (uint32_t)nl;
+                    generalLines += (uint32_t)nl;
+                }
             }
         } else if (general) {
             lateList[atomicAdd(lateCount, 1ull)] = q;
@@ -216,6 +220,9 @@ static __global__ void __launch_bounds__(256) k_lift_classify(const int64_t *__r
     LIFT_PROF_FLUSH
     stat_add(&kstat[0], used);         // the "top" slot of this launch: unmerged records the general intervals clipped
     stat_add(&kstat[1], generalSeen);  // its "bottom" slot: general intervals
+    // (the lines that come from merged records — nearly all — are not counted here: one or two atomics per wavefront on 32
+    // cache lines cost the launch 1-3 us; k_lift_totals has them as all lines minus these)
+    stat_add(&kstatStore[1], generalLines); // the "bottom" slot of the storing launch: lines that do not come from merged records
     stat_add(&GT.counters[CNT_DSTAT0 + STAT_MAPPED], used);
 }
 
@@ -230,7 +237,7 @@ static constexpr uint32_t LIFT_STRIP = 512 + 64; // slots whose owners are looke
 __device__ __forceinline__ void lift_wave_emit(const ComposedRec<int32_t> *__restrict__ recs, uint8_t *sStrip, const uint4 *sIv,
                                                const uint32_t *sOff, const int lane, const uint32_t b, const uint32_t p,
                                                const uint32_t totalSlots, const uint32_t firstQuery, const int64_t *__restrict__ tSeqStart,
-                                               const int64_t ss0, const bool oneSeq, hgx_record *__restrict__ out, uint32_t &used) {
+                                               const int64_t ss0, const bool oneSeq, hgx_record *__restrict__ out) {
     const unsigned long long below = (1ull << lane) - 1ull;
     uint32_t windowBase = 0;
     bool haveWindow = false;
@@ -266,7 +273,6 @@ __device__ __forceinline__ void lift_wave_emit(const ComposedRec<int32_t> *__res
         const int32_t pLo = r.sLo, pHi = r.sLo + r.len - 1;
         const bool emit = slotValid && pLo <= oGe && pHi >= oGs;
         const unsigned long long em = __ballot(emit);
-        used += emit ? 1u : 0u;
         // lines of my interval before me (the table's order)
         const unsigned long long mine = em & ~((1ull << lo) - 1ull); // (records of earlier intervals sit below lo)
         uint32_t pos = (uint32_t)__popcll(mine & below);
@@ -311,21 +317,7 @@ __device__ __forceinline__ void lift_wave_emit(const ComposedRec<int32_t> *__res
     }
 }
 
-// k_lift_groups: groupTotal[g] = the lines of the 64 tiles (256 wavefronts' worth of intervals) of group g — after the
-// finishing kernels have added theirs to waveTotal
-static __global__ void __launch_bounds__(256) k_lift_groups(const uint32_t *__restrict__ waveTotal, uint32_t nWaves,
-                                                            unsigned long long *__restrict__ groupTotal) {
-    __shared__ uint32_t sPart[4];
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t t = wave_total(i < nWaves ? waveTotal[i] : 0u); // (a group has at most 2^14 intervals of at most ... lines: the sum of 64 stays far below 2^32)
-    if ((threadIdx.x & 63u) == 0)
-        sPart[threadIdx.x >> 6] = t;
-    __syncthreads();
-    if (threadIdx.x == 0)
-        groupTotal[blockIdx.x] = (unsigned long long)sPart[0] + sPart[1] + sPart[2] + sPart[3];
-}
-
-// kb, nOut, waveTotal, groupTotal: k_lift_classify's and k_lift_groups' answers; genOffset /
+// kb, nOut, waveTotal, groupTotal: k_lift_classify's and k_lift_totals' answers; genOffset /
 // genRecords: where the general path left the records of the general intervals (nOut[q] records at genRecords +
 // genOffset[q]); out / outCap: the dense output; outOffset[q]: first record of interval q in it.
 template <int MINW>
@@ -336,8 +328,7 @@ static __global__ void __launch_bounds__(256, MINW) k_lift_merged(const int64_t 
                                                             const hgx_record *__restrict__ genRecords, hgx_record *__restrict__ out,
                                                             uint32_t outCap, const uint32_t *__restrict__ nOut, uint32_t *__restrict__ outOffset,
                                                             const uint32_t *__restrict__ waveTotal,
-                                                            const unsigned long long *__restrict__ groupTotal, uint32_t nTiles,
-                                                            unsigned long long *counters, unsigned long long *kstat, uint32_t *__restrict__ total) {
+                                                            const unsigned long long *__restrict__ groupTotal, uint32_t nTiles) {
     __shared__ __attribute__((aligned(16))) uint8_t sStripAll[4][LIFT_STRIP];
     __shared__ uint4 sIvAll[4][64];
     __shared__ uint32_t sOffAll[4][64];
@@ -345,7 +336,6 @@ static __global__ void __launch_bounds__(256, MINW) k_lift_merged(const int64_t 
     const int lane = lane_id(), w = (int)(threadIdx.x >> 6);
     const int64_t ss0 = tSeqStart[0];
     const bool oneSeq = tNumSeq <= 1;
-    uint32_t used = 0;
     LIFT_PROF_DECL;
     for (uint32_t tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
         // ---- the workgroup's intervals, one per thread ----
@@ -398,19 +388,12 @@ static __global__ void __launch_bounds__(256, MINW) k_lift_merged(const int64_t 
             wavePrefix += i < w ? t : 0u;
             tileLines += t;
         }
-        if (tile + 1 == nTiles && threadIdx.x == 0) {
-            *total = (uint32_t)(tileBase + tileLines);
-            counters[CNT_LIFT_TOTAL] = tileBase + tileLines;
-        }
-        if (tileBase + tileLines > (unsigned long long)outCap) { // (uniform over the workgroup) the retry sizes the buffers from CNT_LIFT_TOTAL
-            if (threadIdx.x == 0)
-                counters[CNT_OVERFLOW] = 1;
-        } else {
+        if (tileBase + tileLines <= (unsigned long long)outCap) { // (uniform over the workgroup; k_lift_totals has told the host otherwise)
             // ---- the lines, at their final place ----
             const uint32_t lineOff = (uint32_t)tileBase + wavePrefix + (inclLines - cnt);
             sOffAll[w][lane] = lineOff; // (made visible to the wave by the fences in front of lift_wave_emit's first scatter)
             lift_wave_emit(recs, sStripAll[w], sIvAll[w], sOffAll[w], lane, b, p, totalSlots, tile * (uint32_t)LIFT_TILE + (uint32_t)(w << 6),
-                           tSeqStart, ss0, oneSeq, out, used);
+                           tSeqStart, ss0, oneSeq, out);
             LIFT_PROF(2) // lines stored
             // general intervals: their records were made by the general path; copied in as 8-byte words
             unsigned long long gm = __ballot(general && cnt > 0);
@@ -431,43 +414,73 @@ static __global__ void __launch_bounds__(256, MINW) k_lift_merged(const int64_t 
         if (tile + gridDim.x < nTiles)
             __syncthreads(); // (sWaveTotal, sFront are rewritten for the next tile)
     }
-    stat_add(&kstat[0], used); // the "top" slot of this launch: merged records that overlap their interval
-    stat_add(&counters[CNT_DSTAT0 + STAT_MAPPED], used);
 #if defined(HGX_LIFT_PROFILE) && HGX_LIFT_PROFILE == 1
     LIFT_PROF_FLUSH
 #endif
 }
 
-// End of a single-pass run: folds the spread statistics words (hgx_liftover_kernels.hpp: stat_add) and gathers everything
-// the host reads back into LIFT_RB_WORDS consecutive words — one 128-byte copy per batch.
-// rb[0..7] = the scalar slots (CNT_MAPPED with the pieces of this run), rb[8 + l] = top-slot count of launch l (l < 4),
-// rb[12] = general intervals, rb[13] = the ones k_general_wave passed on.
+// k_lift_totals, one workgroup between the counting and the storing launch:
+//   groupTotal[g] = the lines of the 64 tiles (256 wavefronts' worth of intervals) of group g — after the finishing kernels have
+//   added theirs to waveTotal —, *total = all lines, CNT_OVERFLOW if they do not fit the output (k_lift_merged then leaves
+//   the tiles beyond it alone and the host repeats the batch with larger buffers);
+//   folds the spread statistics words (hgx_liftover_kernels.hpp: stat_add) and writes everything the host wants to know of
+//   the batch into LIFT_RB_WORDS words of host memory (rb is mapped pinned memory: no copy behind the last launch):
+//   rb[0..7] = the scalar slots (CNT_MAPPED with the pieces of this run), rb[8 + l] = top-slot count of launch l (l < 4),
+//   rb[12] = listed general intervals (HGX_FINISH_WAVE=0), rb[13] = the ones passed on to the finishing kernels,
+//   rb[14] = bottom-slot count of launch 0 (general intervals);
+//   leaves the words the next single-pass run counts in zeroed (the scalar slots, the level-0 append counters, the
+//   statistics copies, the list counts): a batch then needs no memsets.  (k_lift_merged counts nothing.)
 static constexpr int LIFT_RB_WORDS = 16;
-// ... and leaves the words the next single-pass run counts in zeroed (the scalar slots, the level-0 append counters, the
-// statistics copies, the look-back granules of this run, the count of passed-on intervals): a batch then needs no memsets.
-static __global__ void __launch_bounds__(256) k_lift_epilogue(unsigned long long *counters, unsigned long long *generalCount,
-                                                              unsigned long long *restCount, unsigned long long *rb, unsigned long long *granules,
-                                                              uint32_t numGranules) {
-    __shared__ unsigned long long sums[6];
-    const int w = (int)threadIdx.x;
-    if (w < 6) {
-        const int word = w == 0 ? STAT_MAPPED : w == 5 ? STAT_LAUNCH0 + 1 : STAT_LAUNCH0 + 2 * (w - 1);
-        unsigned long long sum = 0;
-        for (int l = 0; l < STAT_LINES; ++l)
-            sum += counters[CNT_DSTAT0 + (size_t)l * STAT_PITCH + word];
-        sums[w] = sum;
+static __global__ void __launch_bounds__(1024) k_lift_totals(const uint32_t *__restrict__ waveTotal, uint32_t nWaves, uint32_t nGroups,
+                                                             unsigned long long *__restrict__ groupTotal, uint32_t outCap,
+                                                             uint32_t *__restrict__ total, unsigned long long *counters,
+                                                             unsigned long long *generalCount, unsigned long long *restCount,
+                                                             int storeLaunch, unsigned long long *rb) {
+    __shared__ unsigned long long sums[7], sGrand[16], sFast;
+    const int w = (int)threadIdx.x, lane = lane_id(), wv = w >> 6;
+    unsigned long long grand = 0;
+    for (uint32_t g = (uint32_t)wv; g < nGroups; g += 16u) { // a wavefront per group
+        unsigned long long part = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i) {
+            const uint32_t idx = (g << 8) + (i << 6) + (uint32_t)lane;
+            part += idx < nWaves ? (unsigned long long)waveTotal[idx] : 0ull;
+        }
+        const unsigned long long t = wave_sum64(part);
+        if (lane == 0)
+            groupTotal[g] = t;
+        grand += t;
+    }
+    if (lane == 0)
+        sGrand[wv] = grand;
+    if (wv < 7) { // the copies of seven statistics words, a wavefront each
+        const int word = wv == 0 ? STAT_MAPPED : wv == 5 ? STAT_LAUNCH0 + 1 : wv == 6 ? STAT_LAUNCH0 + 2 * storeLaunch + 1 : STAT_LAUNCH0 + 2 * (wv - 1);
+        const unsigned long long sum = wave_sum64(lane < STAT_LINES ? counters[CNT_DSTAT0 + (size_t)lane * STAT_PITCH + word] : 0ull);
+        if (lane == 0)
+            sums[wv] = sum;
+    }
+    __syncthreads();
+    if (w == 0) {
+        unsigned long long all = 0;
+        for (int i = 0; i < 16; ++i)
+            all += sGrand[i];
+        sFast = all - sums[6]; // lines from merged records = merged records that overlap their interval
+        *total = (uint32_t)all;
+        counters[CNT_LIFT_TOTAL] = all;
+        if (all > (unsigned long long)outCap)
+            counters[CNT_OVERFLOW] = 1;
     }
     __syncthreads();
     if (w < 8)
-        rb[w] = counters[w] + (w == CNT_MAPPED ? sums[0] : 0ull);
+        rb[w] = counters[w] + (w == CNT_MAPPED ? sums[0] + sFast : 0ull);
     else if (w < 12)
-        rb[w] = sums[w - 7];
+        rb[w] = w - 8 == storeLaunch ? sFast : sums[w - 7];
     else if (w == 12)
         rb[w] = *generalCount;
     else if (w == 13)
-        rb[w] = restCount ? *restCount : 0ull; // intervals k_general_wave passed on
+        rb[w] = restCount ? *restCount : 0ull;
     else if (w == 14)
-        rb[w] = sums[5]; // the "bottom" slot of launch 0 (single-kernel form: general intervals)
+        rb[w] = sums[5];
     __syncthreads();
     if (w < 8)
         counters[w] = 0;
@@ -475,8 +488,6 @@ static __global__ void __launch_bounds__(256) k_lift_epilogue(unsigned long long
         counters[CNT_FRONT0 + (size_t)w * SEG_PITCH] = 0;
     for (int i = w; i < STAT_LINES * (STAT_LAUNCH0 + 8); i += (int)blockDim.x)
         counters[CNT_DSTAT0 + (size_t)(i / (STAT_LAUNCH0 + 8)) * STAT_PITCH + (size_t)(i % (STAT_LAUNCH0 + 8))] = 0;
-    for (uint32_t i = (uint32_t)w; i < numGranules; i += blockDim.x)
-        granules[i] = 0;
     if (w == 0 && restCount)
         *restCount = 0;
     if (w == 1)

@@ -479,6 +479,7 @@ struct hgx_liftover_plan {
     DevBuf wireFlag;                      // hgx_liftover_wire_blob: "a field does not fit the 12-byte form"
     unsigned int *wireFlagHost = nullptr;
     unsigned long long *pinned = nullptr; // host-pinned copy of the counter block + the record total (one readback per run)
+    unsigned long long *pinnedDev = nullptr; // the same memory as the device sees it (k_lift_totals writes its report there)
     hgx_liftover_stats stats{};
     hipEvent_t evStart = nullptr, evWalk = nullptr, evEnd = nullptr;
     ~hgx_liftover_plan() {
@@ -528,8 +529,10 @@ struct hgx_liftover_plan {
         }
         if (liftBigSlots)
             scratch.ensure((h->dev->wide ? finishSliceBytes<int64_t>(liftBigCap) : finishSliceBytes<int32_t>(liftBigCap)) * (size_t)liftBigSlots);
-        if (!pinned)
-            HIP_OK(hipHostMalloc((void **)&pinned, 8 * (CNT_SLOTS + 1 + LIFT_RB_WORDS)));
+        if (!pinned) {
+            HIP_OK(hipHostMalloc((void **)&pinned, 8 * (CNT_SLOTS + 1 + LIFT_RB_WORDS), hipHostMallocMapped));
+            HIP_OK(hipHostGetDevicePointer((void **)&pinnedDev, pinned, 0));
+        }
         const size_t nq = std::max<size_t>(maxQueries, 1);
         counters.ensure(8 * (CNT_DEV_SLOTS + LIFT_RB_WORDS));
         perQuery.ensure(4 * (nq + 1));
@@ -617,7 +620,9 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
     if (events)
         HIP_OK(hipEventRecord(P.evStart, s));
     const GeneralTable<C> GT{(const uint32_t *)T.coarse, (const uint32_t *)T.starts, T.shift, (const ComposedRec<C> *)T.recs, srcLength,
-                             (const int64_t *)TG.seqStart, (int)TG.numSeq, (hgx_record *)P.grouped.p, cap, cnt + CNT_FRONT0, cnt};
+                             (const int64_t *)TG.seqStart, (int)TG.numSeq,
+                             P.h->img.genomes[(size_t)P.tgt].seqs.empty() ? 0 : (int64_t)P.h->img.genomes[(size_t)P.tgt].seqs[0].start,
+                             (hgx_record *)P.grouped.p, cap, cnt + CNT_FRONT0, cnt};
     uint32_t *restList = generalList + nq;
     unsigned long long *restCount = generalCount + 1;
     const bool waveFinish = !(getenv("HGX_FINISH_WAVE") && getenv("HGX_FINISH_WAVE")[0] == '0');
@@ -627,22 +632,31 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
     // meet them (HGX_FINISH_WAVE=0: they are all listed instead and go the LDS way, the round-1 route, as a cross-check)
     const uint32_t *lateList = waveFinish ? restList : generalList;
     unsigned long long *lateCount = waveFinish ? restCount : generalCount;
+    // (the launches behind k_lift_classify for what it passes on are made only once a run of this plan has passed something on)
+    P.liftRestSkipped = waveFinish && !P.liftRestSeen;
+    const int storeLaunch = P.liftRestSkipped ? 1 : 2; // k_lift_merged's place among the launches that keep statistics
     P.timer.begin("k_lift_classify", s, launch);
-#define HGX_CLASSIFY(INL)                                                                                                                    \
-    hipLaunchKernelGGL((k_lift_classify<INL>), dim3(std::max<uint32_t>(1, nTiles)), dim3(256), 0, s, dS, dE, dStrand, nq, srcLength,           \
-                       (const uint32_t *)T.mBuckets, T.mShift, T.mWindow, (const ComposedRec<C> *)T.mRecs, (uint2 *)P.liftKb.p, GT, kstat(),       \
-                       (uint32_t *)P.offset.p, (uint32_t *)P.nOut.p, (uint32_t *)lateList, lateCount, waveTotal)
-    if (waveFinish)
-        HGX_CLASSIFY(true);
+#define HGX_CLASSIFY(INL, W)                                                                                                                 \
+    hipLaunchKernelGGL((k_lift_classify<INL, W>), dim3(std::max<uint32_t>(1, nTiles)), dim3(256), 0, s, dS, dE, dStrand, nq, srcLength,        \
+                       (const uint32_t *)T.mBuckets, T.mShift, T.mWindow, (const ComposedRec<C> *)T.mRecs, (uint2 *)P.liftKb.p, GT, kstat(),    \
+                       cnt + CNT_DSTAT0 + STAT_LAUNCH0 + 2 * storeLaunch, (uint32_t *)P.offset.p, (uint32_t *)P.nOut.p, (uint32_t *)lateList, lateCount, waveTotal)
+    static const int classifyWaves = getenv("HGX_CLASSIFY_MINWAVES") ? atoi(getenv("HGX_CLASSIFY_MINWAVES")) : 6; // (experiments: 1, 6, 7, 8)
+    if (!waveFinish)
+        HGX_CLASSIFY(false, 1);
+    else if (classifyWaves == 1)
+        HGX_CLASSIFY(true, 1);
+    else if (classifyWaves == 7)
+        HGX_CLASSIFY(true, 7);
+    else if (classifyWaves == 8)
+        HGX_CLASSIFY(true, 8);
     else
-        HGX_CLASSIFY(false);
+        HGX_CLASSIFY(true, 6);
 #undef HGX_CLASSIFY
     P.timer.end(s);
     ++launch;
     // Two more launches for what k_general_wave passes on (more than 64 pieces) — made only once a run of this plan has passed
     // something on: a run that skips them reads the count back with its counters and is repeated with them when it is not zero
     // (runPlan), so batches without such intervals do not pay for two empty launches.
-    P.liftRestSkipped = waveFinish && !P.liftRestSeen;
     if (!P.liftRestSkipped) {
     P.timer.begin("k_locate_through", s, launch);
     // (the list's length is only known on the device; the grids are sized for a list that is a small part of the batch)
@@ -657,7 +671,7 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
     hipLaunchKernelGGL((k_finish_lds<C, 256>), dim3(std::min<uint32_t>(std::max<uint32_t>(nq, 1), 1536u)), dim3(64), 0, s, P.mapped(1),
                        (const uint32_t *)P.offset.p, (const uint32_t *)P.perQuery.p, lateList, lateCount, (const int64_t *)TG.seqStart,
                        (int)TG.numSeq, (hgx_record *)P.grouped.p, (uint32_t *)P.nOut.p, (uint32_t *)P.deferredList.p, (uint32_t *)P.needCap.p,
-                       cnt, 0, waveTotal);
+                       cnt, 0, waveTotal, cnt + CNT_DSTAT0 + STAT_LAUNCH0 + 2 * storeLaunch + 1);
     P.timer.end(s);
     } else if (events) {
         HIP_OK(hipEventRecord(P.evWalk, s));
@@ -667,7 +681,8 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
         hipLaunchKernelGGL((k_finish_big<C>), dim3(P.liftBigSlots), dim3(64), 0, s, P.mapped(1), (const uint32_t *)P.offset.p,
                            (const uint32_t *)P.perQuery.p, (const uint32_t *)P.deferredList.p, P.liftBigSlots, P.liftBigCap,
                            (unsigned char *)P.scratch.p, finishSliceBytes<C>(P.liftBigCap), (const int64_t *)TG.seqStart, (int)TG.numSeq,
-                           (hgx_record *)P.grouped.p + cap, (uint32_t *)P.nOut.p, cnt, 0, 1, (uint32_t *)P.offset.p, cap, waveTotal);
+                           (hgx_record *)P.grouped.p + cap, (uint32_t *)P.nOut.p, cnt, 0, 1, (uint32_t *)P.offset.p, cap, waveTotal,
+                           cnt + CNT_DSTAT0 + STAT_LAUNCH0 + 2 * storeLaunch + 1);
         P.timer.end(s);
     }
     // everything else, and the dense output
@@ -678,15 +693,18 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
         if (const char *b = getenv("HGX_LIFT_BLOCKS"))
             P.liftGrid = std::max(1, atoi(b)) * 256;
     }
-    P.timer.begin("k_lift_groups", s);
-    hipLaunchKernelGGL(k_lift_groups, dim3(std::max<uint32_t>(1, nGroups)), dim3(256), 0, s, (const uint32_t *)waveTotal, 4 * nTiles, groupTotal);
+    // all lines, the groups' lines, the statistics — and everything the host wants to know goes to pinned memory from here
+    unsigned long long *hrb = P.pinned + CNT_SLOTS + 1;
+    P.timer.begin("k_lift_totals", s);
+    hipLaunchKernelGGL(k_lift_totals, dim3(1), dim3(1024), 0, s, (const uint32_t *)waveTotal, 4 * nTiles, nGroups, groupTotal, cap, (uint32_t *)P.total.p,
+                       cnt, generalCount, waveFinish ? restCount : (unsigned long long *)nullptr, storeLaunch, P.pinnedDev + CNT_SLOTS + 1);
     P.timer.end(s);
     P.timer.begin("k_lift_merged", s, launch);
 #define HGX_LIFT(W)                                                                                                                          \
     hipLaunchKernelGGL((k_lift_merged<W>), dim3(std::min<uint32_t>((uint32_t)P.liftGrid, nTiles)), dim3(256), 0, s, dS, dE, dStrand, nq,        \
                        (const uint2 *)P.liftKb.p, (const ComposedRec<C> *)T.mRecs, (const int64_t *)TG.seqStart, (int)TG.numSeq,             \
                        (const uint32_t *)P.offset.p, (const hgx_record *)P.grouped.p, (hgx_record *)P.outRecords.p, cap,                     \
-                       (const uint32_t *)P.nOut.p, (uint32_t *)P.outOffset.p, waveTotal, groupTotal, nTiles, cnt, kstat(), (uint32_t *)P.total.p)
+                       (const uint32_t *)P.nOut.p, (uint32_t *)P.outOffset.p, waveTotal, groupTotal, nTiles)
     if (P.liftMinWaves == 8)
         HGX_LIFT(8);
     else
@@ -696,12 +714,6 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
     ++launch;
     if (events)
         HIP_OK(hipEventRecord(P.evEnd, s));
-    // one small copy brings back everything the host needs (k_lift_epilogue)
-    unsigned long long *rb = cnt + CNT_DEV_SLOTS;
-    hipLaunchKernelGGL(k_lift_epilogue, dim3(1), dim3(256), 0, s, cnt, generalCount, waveFinish ? restCount : (unsigned long long *)nullptr, rb,
-                       (unsigned long long *)nullptr, 0u);
-    unsigned long long *hrb = P.pinned + CNT_SLOTS + 1;
-    HIP_OK(hipMemcpyAsync(hrb, rb, 8 * LIFT_RB_WORDS, hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
     memset(hostCounters, 0, 8 * CNT_SLOTS);
     if (hrb[CNT_OVERFLOW]) { // the retry sizes the buffers from the frontier counters and CNT_LIFT_TOTAL
