@@ -366,6 +366,14 @@ def main():
         dom_avg_ms = dom_ms / max(1, dom_launches)
         achieved = dom_bytes_per_launch / (dom_avg_ms * 1e-3) / 1e9 if dom_avg_ms > 0 else 0.0
         traffic, traffic_source = pmc_traffic(dom_name)
+        # every timed kernel of the step priced the same way (the object above is the one that takes the most time)
+        per_kernel_roofline = []
+        for kname, kv in sorted(kt_acc.items(), key=lambda kv: -kv[1]["ms"]):
+            k_avg_ms = kv["ms"] / max(1, kv["launches"])
+            k_bytes = per_kernel_alg.get(kname, 0.0)
+            k_gbs = k_bytes / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms > 0 else 0.0
+            per_kernel_roofline.append({"kernel": kname, "kernel_avg_ms": k_avg_ms, "algorithmic_bytes_per_launch": k_bytes,
+                                        "achieved": k_gbs, "frac": k_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic(kname)[0]})
         # measured device-copy rate on this GPU (read + write bytes of a 1 GiB device-to-device copy), SURVEY 8(d)
         cp_src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
         cp_dst = torch.empty_like(cp_src)
@@ -407,6 +415,7 @@ def main():
                          "measured_copy_GBs": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs,
                          "kernel_avg_ms": dom_avg_ms, "kernel_launches_per_step": dom_launches / args.steps,
                          "algorithmic_bytes_per_launch": dom_bytes_per_launch,
+                         "kernels": per_kernel_roofline,
                          "whole_step": {"kernel_ms_per_step": kern_ms_total, "bytes_the_timed_kernels_must_move": own_bytes,
                                         "achieved_GBs": own_bytes / (kern_ms_total * 1e-3) / 1e9 if kern_ms_total > 0 else 0.0,
                                         "frac": own_bytes / (kern_ms_total * 1e-3) / 1e9 / HBM_PEAK_GBS if kern_ms_total > 0 else 0.0,
@@ -531,11 +540,16 @@ def plan_kernel_bytes(kt, st, steps):
             if name == "k_locate_through":
                 bytes_ += 8.0 * st["queries"] * steps
         if name == "k_lift_merged":
-            # the single-pass kernel: 24 B per interval + the 8 B k_lift_classify left for it, 16 B per merged record that
-            # overlaps its interval (top slot), 40 B per record written + 8 B of count and offset per interval
-            bytes_ = 16.0 * t + (24.0 + 8.0 + 8.0) * st["queries"] * steps + 40.0 * st["records"] * steps
+            # the storing kernel: 37 B per interval (its two ends, the strand, the 8-byte answer and the line count
+            # k_lift_classify left, the 4-byte offset it writes), 16 B per merged record that overlaps its interval (top slot),
+            # 40 B per record written
+            bytes_ = 16.0 * t + (16.0 + 1.0 + 8.0 + 4.0 + 4.0 + 4.0) * st["queries"] * steps + 40.0 * st["records"] * steps
         if name == "k_lift_classify":
-            bytes_ = (16.0 + 16.0 + 8.0) * st["queries"] * steps  # interval ends, two 8-byte bucket entries, the 8-byte answer
+            # the counting kernel: interval ends, one 4-byte bucket entry, the 8-byte answer and the 4-byte line count, and 16 B
+            # per merged record that overlaps its interval (k_lift_merged's top slot: the same records) or unmerged record a
+            # general interval clips (its own top slot)
+            merged_records = kt.get("k_lift_merged", {}).get("top_derefs", 0)
+            bytes_ = (16.0 + 4.0 + 8.0 + 4.0) * st["queries"] * steps + 16.0 * (merged_records + t)
         if name in ("k_locate_expand", "k_locate_composed", "k_locate_through"):
             bytes_ += 24.0 * st["queries"] * steps
         if name in ("k_finish_fast", "k_finish_lds", "k_finish_big"):

@@ -7,8 +7,9 @@ over profiles/scripts/r02_pmc_driver.py, then writes profiles/pmc_traffic.json w
 bench.py only quotes the figures for the build they were measured on.
 FETCH_SIZE / WRITE_SIZE are in KiB.  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE counts a wide coalesced streaming read at
 half its bytes; profiles/r01l_fetch_size_calibration.txt: a random 16-byte gather is counted in full.  `traffic` therefore
-doubles FETCH_SIZE for the kernels that stream their inputs (STREAMING below) and takes it as it is for the gather-bound walk
-kernels; both raw values are kept in the file.
+doubles FETCH_SIZE for the kernels that stream their inputs (STREAMING below), takes it as it is for the gather-bound walk
+kernels, and for the two single-pass kernels — streamed per-interval inputs, gathered table records — adds the uncounted half of
+the streamed bytes (STREAMED_PER_INTERVAL x intervals); the raw values are kept in the file.
 usage: r02_pmc.py <outdir> [driver args]"""
 import csv
 import glob
@@ -20,7 +21,10 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-STREAMING = {"k_lift_merged", "k_lift_classify", "k_lift_gather", "k_compact_records", "k_depth_fill"}
+STREAMING = {"k_compact_records", "k_depth_fill"}
+# kernels that stream their per-interval inputs and gather the rest: the streamed bytes (per interval) are the part counted at half
+STREAMED_PER_INTERVAL = {"k_lift_classify": 16.0, "k_lift_merged": 33.0}
+NQ = float(sys.argv[3]) if len(sys.argv) > 3 else 1e6
 out = sys.argv[1]
 driver = [sys.executable, os.path.join(ROOT, "profiles", "scripts", "r02_pmc_driver.py")] + sys.argv[2:]
 os.makedirs(out, exist_ok=True)
@@ -70,8 +74,9 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
 kernels, detail = {}, {}
 for k in sorted(set(raw.get("FETCH_SIZE", {})) | set(raw.get("WRITE_SIZE", {}))):
     fe, wr = raw.get("FETCH_SIZE", {}).get(k, 0.0), raw.get("WRITE_SIZE", {}).get(k, 0.0)
-    kernels[k] = (2.0 * fe if k in STREAMING else fe) + wr
-    detail[k] = {"fetch_raw": fe, "write_raw": wr, "fetch_doubled": k in STREAMING, "avg_ns": dur.get(k)}
+    kernels[k] = (2.0 * fe if k in STREAMING else fe + 0.5 * STREAMED_PER_INTERVAL.get(k, 0.0) * NQ) + wr
+    detail[k] = {"fetch_raw": fe, "write_raw": wr, "fetch_doubled": k in STREAMING,
+                 "streamed_input_bytes_counted_at_half": STREAMED_PER_INTERVAL.get(k, 0.0) * NQ, "avg_ns": dur.get(k)}
 sha = hashlib.sha256(open(os.path.join(ROOT, "hal_amd", "libhgx.so"), "rb").read()).hexdigest()[:16]
 res = {"libhgx_sha16": sha, "kernels": kernels, "detail": detail,
        "source": "profiles/scripts/r02_pmc.py: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (KiB x 1024) over the cfg2 batch; "
