@@ -1015,6 +1015,46 @@ template <> __device__ __forceinline__ int64_t wave_pull<int64_t>(int64_t v, int
     return __shfl(v, srcLane);
 }
 
+// -DHGX_LIFT_PROFILE (make profile-lib: hal_amd/libhgx_prof.so, loaded with HGX_LIB_PATH): lane 0 of every wavefront of
+// k_lift_merged adds up the shader cycles it spends in each phase of its tiles; k_lift_epilogue prints the sums.
+#ifdef HGX_LIFT_PROFILE
+__device__ unsigned long long g_liftProfile[8192 * 4 * 8]; // [workgroup][wavefront][phase]: plain stores, summed by the epilogue
+#define LIFT_PROF_DECL unsigned long long profT = __builtin_readcyclecounter(), profAcc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define LIFT_PROF(i)                                                                                                                         \
+    {                                                                                                                                        \
+        const unsigned long long now = __builtin_readcyclecounter();                                                                         \
+        profAcc[i] += now - profT;                                                                                                           \
+        profT = now;                                                                                                                         \
+    }
+#if HGX_LIFT_PROFILE == 3 // the phases of finish_wave only (slots 0..6): LIFT_PROF moves the clock, LIFT_PROF3 books
+#define LIFT_PROF3(i)                                                                                                                        \
+    {                                                                                                                                        \
+        const unsigned long long now = __builtin_readcyclecounter();                                                                         \
+        profAcc[i] += now - profT;                                                                                                           \
+        profT = now;                                                                                                                         \
+    }
+#undef LIFT_PROF
+#define LIFT_PROF(i) profT = __builtin_readcyclecounter();
+#else
+#define LIFT_PROF3(i)
+#endif
+#define LIFT_PROF_FLUSH                                                                                                                      \
+    if (lane == 0 && blockIdx.x < 8192) {                                                                                                    \
+        profAcc[7] = 1;                                                                                                                      \
+        for (int i = 0; i < 8; ++i)                                                                                                          \
+            g_liftProfile[(blockIdx.x * 4 + w) * 8 + i] = profAcc[i];                                                                        \
+    }
+#define LIFT_PROF_ARG , profAcc, profT
+#define LIFT_PROF_PARAMS , unsigned long long *profAcc, unsigned long long &profT
+#else
+#define LIFT_PROF_ARG
+#define LIFT_PROF_PARAMS
+#define LIFT_PROF_DECL
+#define LIFT_PROF(i)
+#define LIFT_PROF3(i)
+#define LIFT_PROF_FLUSH
+#endif
+
 template <typename C> struct WaveLines { // line l of the interval lives in lane l
     C lStart, lEnd, lSrc;
     int lSeq, lStrand; // strand character in the low 7 bits, the piece's own orientation in bit 7
@@ -1042,8 +1082,10 @@ template <typename C> __device__ __forceinline__ void wave_sort_pieces(int lane,
 // n (wave-uniform, 1..64) pieces in lanes 0..n-1; sD: 128 coordinates of LDS, sOwn: 64 bytes of LDS, private to the wavefront
 template <typename C>
 __device__ __forceinline__ bool finish_wave(const int lane, int n, C tLo, C tHi, C sLo, C sHi, int fl, const int64_t *__restrict__ seqStart,
-                                            const int numSeq, C *sD, uint8_t *sOwn, WaveLines<C> &L) {
+                                            const int numSeq, C *sD, uint8_t *sOwn, WaveLines<C> &L LIFT_PROF_PARAMS) {
+    LIFT_PROF3(0) // (look-ups, records, compaction: everything in front of the algorithm)
     wave_sort_pieces<C>(lane, n, tLo, tHi, sLo, sHi, fl);
+    LIFT_PROF3(1) // first sort
     {
         const C pTLo = lane_prev(tLo), pTHi = lane_prev(tHi);
         const bool hasPrev = lane > 0 && lane < n;
@@ -1120,7 +1162,9 @@ __device__ __forceinline__ bool finish_wave(const int lane, int n, C tLo, C tHi,
             }
             wave_lds_fence();
             n = m;
+            LIFT_PROF3(2) // refinement
             wave_sort_pieces<C>(lane, n, tLo, tHi, sLo, sHi, fl);
+            LIFT_PROF3(3) // second sort
         }
     }
     {   // equal keys: the set keeps one
@@ -1150,6 +1194,7 @@ __device__ __forceinline__ bool finish_wave(const int lane, int n, C tLo, C tHi,
         }
         seq = lo;
     }
+    LIFT_PROF3(4) // duplicates, sequences
     // ---- extractSegment over the set in target order (scalar control flow; finish_query has the LDS original) ----
     unsigned long long alive = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
     C cutv = 0; // cut point c lives in lane c
@@ -1233,6 +1278,7 @@ __device__ __forceinline__ bool finish_wave(const int lane, int n, C tLo, C tHi,
         }
         ++nl;
     }
+    LIFT_PROF3(5) // extractSegment
     // stable sort of the lines by source start (halLiftover.cpp:90), again a rank by counting
     int lrank = 0;
     for (int j = 0; j < nl; ++j) {
@@ -1241,6 +1287,7 @@ __device__ __forceinline__ bool finish_wave(const int lane, int n, C tLo, C tHi,
     }
     L.rank = lrank;
     L.nl = nl;
+    LIFT_PROF3(6) // line order
     return true;
 }
 
@@ -1251,33 +1298,6 @@ __device__ __forceinline__ bool finish_wave(const int lane, int n, C tLo, C tHi,
 // Returns 1 with (nl, base) = where k_lift_merged finds the records, 0 when the interval has to go on to k_locate_through +
 // k_finish_lds (more records in reach, or finish_wave passes it on), -1 when the grouped buffer is full (the host repeats the
 // batch with larger buffers).  All arguments wave-uniform.
-// -DHGX_LIFT_PROFILE (make profile-lib: hal_amd/libhgx_prof.so, loaded with HGX_LIB_PATH): lane 0 of every wavefront of
-// k_lift_merged adds up the shader cycles it spends in each phase of its tiles; k_lift_epilogue prints the sums.
-#ifdef HGX_LIFT_PROFILE
-__device__ unsigned long long g_liftProfile[8192 * 4 * 8]; // [workgroup][wavefront][phase]: plain stores, summed by the epilogue
-#define LIFT_PROF_DECL unsigned long long profT = __builtin_readcyclecounter(), profAcc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#define LIFT_PROF(i)                                                                                                                         \
-    {                                                                                                                                        \
-        const unsigned long long now = __builtin_readcyclecounter();                                                                         \
-        profAcc[i] += now - profT;                                                                                                           \
-        profT = now;                                                                                                                         \
-    }
-#define LIFT_PROF_FLUSH                                                                                                                      \
-    if (lane == 0 && blockIdx.x < 8192) {                                                                                                    \
-        profAcc[7] = 1;                                                                                                                      \
-        for (int i = 0; i < 8; ++i)                                                                                                          \
-            g_liftProfile[(blockIdx.x * 4 + w) * 8 + i] = profAcc[i];                                                                        \
-    }
-#define LIFT_PROF_ARG , profAcc, profT
-#define LIFT_PROF_PARAMS , unsigned long long *profAcc, unsigned long long &profT
-#else
-#define LIFT_PROF_ARG
-#define LIFT_PROF_PARAMS
-#define LIFT_PROF_DECL
-#define LIFT_PROF(i)
-#define LIFT_PROF_FLUSH
-#endif
-
 template <typename C> struct GeneralTable {
     const uint32_t *coarse, *starts;
     int shift;
@@ -1333,7 +1353,7 @@ __device__ __forceinline__ int general_interval(const int lane, const GeneralTab
     WaveLines<C> L;
     L.nl = 0;
     LIFT_PROF(4) // table look-ups, records
-    if (!finish_wave<C>(lane, n, tLo, tHi, sLo, sHi, fl, G.seqStart, G.numSeq, sD, sOwn, L))
+    if (!finish_wave<C>(lane, n, tLo, tHi, sLo, sHi, fl, G.seqStart, G.numSeq, sD, sOwn, L LIFT_PROF_ARG))
         return 0;
     LIFT_PROF(5) // the algorithm
     // a slice of the grouped buffer for the records
