@@ -1016,7 +1016,8 @@ template <> __device__ __forceinline__ int64_t wave_pull<int64_t>(int64_t v, int
 }
 
 // -DHGX_LIFT_PROFILE (make profile-lib: hal_amd/libhgx_prof.so, loaded with HGX_LIB_PATH): lane 0 of every wavefront of
-// k_lift_merged adds up the shader cycles it spends in each phase of its tiles; k_lift_epilogue prints the sums.
+// k_lift_merged (PROFILE_KERNEL=1), of k_lift_classify (2) or inside finish_wave (3) adds up the shader cycles it spends in each
+// phase; k_lift_totals prints the sums.
 #ifdef HGX_LIFT_PROFILE
 __device__ unsigned long long g_liftProfile[8192 * 4 * 8]; // [workgroup][wavefront][phase]: plain stores, summed by the epilogue
 #define LIFT_PROF_DECL unsigned long long profT = __builtin_readcyclecounter(), profAcc[8] = {0, 0, 0, 0, 0, 0, 0, 0}

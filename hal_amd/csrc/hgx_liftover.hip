@@ -465,12 +465,12 @@ struct hgx_liftover_plan {
         deferredList, needCap, bigSlot, scratch, bigRecords, classLists, classCounts;
     // single-pass path over the merged table (hgx_lift_kernels.hpp)
     DevBuf liftKb, liftBlockList, liftBlockCount, liftStatus;
-    bool mergedDisabled = false; // a look-back wait timed out once: this plan keeps to the multi-kernel path
+    bool mergedDisabled = false; // (never set any more: the single-pass kernels wait for nothing)
     bool mergedOffThisRun = false;
     int liftGrid = 0, liftMinWaves = 1;
     unsigned long long generalQueries = 0, liftRestCount = 0;
-    bool liftRestSeen = false, liftRestSkipped = false; // (see runMergedOnce: the launches behind k_general_wave)
-    bool liftStateClean = false; // the counters and look-back granules are zero (left so by the last run's epilogue)
+    bool liftRestSeen = false, liftRestSkipped = false; // (see runMergedOnce: the launches behind k_lift_classify for what it passes on)
+    bool liftStateClean = false; // the counters are zero (left so by the last run's k_lift_totals)
     // scratch of the single-pass runs for intervals that outgrow the LDS finishing kernel (k_finish_big without a host
     // synchronisation in between): liftBigSlots slices for liftBigCap pieces each, grown when a run needed more
     uint32_t liftBigSlots = 0;
@@ -602,7 +602,7 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
     const int64_t srcLength = P.h->img.genomes[(size_t)P.src].totalLength;
     const DeviceGenome &TG = D.genomes[(size_t)P.tgt];
     const uint32_t nTiles = (nq + LIFT_TILE - 1) / LIFT_TILE, nGroups = (nTiles + 63) / 64;
-    // lines per 64 intervals (k_lift_classify, + the finishing kernels) and per group of 64 tiles (k_lift_groups)
+    // lines per 64 intervals (k_lift_classify, + the finishing kernels) and per group of 64 tiles (k_lift_totals)
     uint32_t *waveTotal = (uint32_t *)P.liftStatus.p;
     unsigned long long *groupTotal = (unsigned long long *)P.liftStatus.p + 2 * (size_t)nTiles; // (behind the 4 * nTiles 32-bit words)
     uint32_t *generalList = (uint32_t *)P.classLists.p;
@@ -654,7 +654,7 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
 #undef HGX_CLASSIFY
     P.timer.end(s);
     ++launch;
-    // Two more launches for what k_general_wave passes on (more than 64 pieces) — made only once a run of this plan has passed
+    // Two more launches for what k_lift_classify passes on (general intervals of more than 64 pieces) — made only once a run of this plan has passed
     // something on: a run that skips them reads the count back with its counters and is repeated with them when it is not zero
     // (runPlan), so batches without such intervals do not pay for two empty launches.
     if (!P.liftRestSkipped) {
