@@ -252,7 +252,8 @@ static bool columnsDepthSweep(hgx_alignment *h, int ref, int64_t first, int64_t 
         }
     if (!sum && bits > 64)
         return false;
-    const size_t word = sum ? 4 : (bits <= 32 ? 4 : 8);
+    // (a genome set per base is as wide as the counted genomes need: the sweeps are bound by the tracks' bytes)
+    const size_t word = sum ? 4 : bits <= 8 ? 1 : bits <= 16 ? 2 : bits <= 32 ? 4 : 8;
     // a genome has a track of its own when something in scope hangs under it
     std::vector<char> hasTrack((size_t)ng, 0);
     for (int g : postOrder) {
@@ -281,21 +282,23 @@ static bool columnsDepthSweep(hgx_alignment *h, int ref, int64_t first, int64_t 
         A[(size_t)path[i]].resize((size_t)img.genomes[(size_t)path[i]].totalLength * 4);
     Ev a, b;
     HIP_OK(hipEventRecord(a.e, s));
+#define HGX_SWEEP(C)                                                                                                                         \
+    if (sum)                                                                                                                                 \
+        sweepTracks<C, int32_t, true>(h, postOrder, path, inScope, own, hasTrack, S, A, s);                                                  \
+    else if (word == 1)                                                                                                                      \
+        sweepTracks<C, uint8_t, false>(h, postOrder, path, inScope, own, hasTrack, S, A, s);                                                 \
+    else if (word == 2)                                                                                                                      \
+        sweepTracks<C, uint16_t, false>(h, postOrder, path, inScope, own, hasTrack, S, A, s);                                                \
+    else if (word == 4)                                                                                                                      \
+        sweepTracks<C, uint32_t, false>(h, postOrder, path, inScope, own, hasTrack, S, A, s);                                                \
+    else                                                                                                                                     \
+        sweepTracks<C, unsigned long long, false>(h, postOrder, path, inScope, own, hasTrack, S, A, s)
     if (h->dev->wide) {
-        if (sum)
-            sweepTracks<int64_t, int32_t, true>(h, postOrder, path, inScope, own, hasTrack, S, A, s);
-        else if (word == 4)
-            sweepTracks<int64_t, uint32_t, false>(h, postOrder, path, inScope, own, hasTrack, S, A, s);
-        else
-            sweepTracks<int64_t, unsigned long long, false>(h, postOrder, path, inScope, own, hasTrack, S, A, s);
+        HGX_SWEEP(int64_t);
     } else {
-        if (sum)
-            sweepTracks<int32_t, int32_t, true>(h, postOrder, path, inScope, own, hasTrack, S, A, s);
-        else if (word == 4)
-            sweepTracks<int32_t, uint32_t, false>(h, postOrder, path, inScope, own, hasTrack, S, A, s);
-        else
-            sweepTracks<int32_t, unsigned long long, false>(h, postOrder, path, inScope, own, hasTrack, S, A, s);
+        HGX_SWEEP(int32_t);
     }
+#undef HGX_SWEEP
     hipLaunchKernelGGL(k_sweep_out, dim3(2048), dim3(256), 0, s, (const int32_t *)A[(size_t)ref].p, first, count, step, mode == 2 ? 0 : 1, d_out);
     HIP_OK(hipEventRecord(b.e, s));
     HIP_OK(hipStreamSynchronize(s));
