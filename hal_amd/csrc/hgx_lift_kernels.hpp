@@ -139,7 +139,8 @@ static __global__ void __launch_bounds__(256, MINW) k_lift_classify(const int64_
         const bool valid = ge >= gs && gs >= 0 && gs < genomeLength;
         // (an interval that is not valid asks for nothing: no record begins at or before base -1)
         const uint32_t k0 = valid ? coarse[gs >> shift] : 0u;
-        const int32_t gs32 = valid ? (int32_t)gs : 0, ge32 = valid ? (int32_t)(ge < 0x7FFFFFFFll ? ge : 0x7FFFFFFFll) : -1;
+        // (the scan stops at the first record that begins behind ge32: below the sentinels' 2^31 - 1 whatever the interval says)
+        const int32_t gs32 = valid ? (int32_t)gs : 0, ge32 = valid ? (int32_t)(ge < genomeLength ? ge : genomeLength - 1) : -1;
         sAsk[w][lane] = make_uint4(k0, (uint32_t)gs32, (uint32_t)ge32, 0u);
         wave_lds_fence();
         LIFT_PROF(0) // the intervals and their bucket entries have arrived

@@ -149,3 +149,30 @@ def test_a_walking_plan_switches_to_its_table(hal, monkeypatch, _forced):
         kinds.append(table_kernel in plan.kernel_times())
     assert kinds[0] is False and kinds[-1] is True and sorted(kinds) == kinds  # walks first, one switch, the table afterwards
     assert plan.stats()["composed_kind"] == TABLE_KIND[_forced]
+
+
+def test_intervals_at_and_over_the_edges(hal, monkeypatch, _forced):
+    """What the device entry point is handed unchecked: intervals that end behind the genome, begin in front of it, are empty,
+    are one base, cover the whole genome, sit on the first and the last base — table against walk, record for record."""
+    import torch
+    opts = hal.RandOptions(mean_degree=1.5, max_branch_length=3.0, min_genomes=2, max_genomes=10, min_segment_length=20,
+                           max_segment_length=80, min_segments=2000, max_segments=4000, seed=2, with_dna=False)
+    al = hal.Alignment.random(opts, device=0)
+    src, tgt = al.genome_id("Genome_9"), al.genome_id("Genome_8")
+    _, ss, length = al.sequences(src)[0]
+    edge = [(0, 0), (0, 99), (length - 1, length - 1), (length - 100, length - 1), (length - 100, length + 50), (length - 1, 2 ** 40),
+            (length, length + 10), (-5, 20), (50, 40), (0, length - 1), (0, 2 ** 31), (17, 17), (length // 2, length // 2 + 20000)]
+    g = torch.Generator().manual_seed(5)
+    n = 700
+    starts = torch.cat([torch.tensor([a for a, _ in edge]), torch.randint(0, length - 400, (n,), generator=g)])
+    ends = torch.cat([torch.tensor([b for _, b in edge]), torch.zeros(n, dtype=torch.int64)])
+    ends[len(edge):] = starts[len(edge):] + torch.randint(0, 300, (n,), generator=g)
+    st = torch.where(torch.rand(starts.numel(), generator=g) < 0.5, ord("+"), ord("-")).to(torch.uint8).cuda()
+    gs, ge = (starts + ss).cuda(), (ends + ss).cuda()
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("HGX_COMPOSED_UP", mode)
+        plan = hal.LiftoverPlan(al, src, tgt, max_queries=int(starts.numel()))
+        ptr, nrec = plan.run(gs, ge, st)
+        out[mode] = plan.records_to_tensor(ptr, nrec).cpu()
+    assert out["1"].shape[0] > n and torch.equal(out["1"], out["0"])
