@@ -440,17 +440,28 @@ static __global__ void __launch_bounds__(1024) k_lift_totals(const uint32_t *__r
     __shared__ unsigned long long sums[7], sGrand[16], sFast;
     const int w = (int)threadIdx.x, lane = lane_id(), wv = w >> 6;
     unsigned long long grand = 0;
-    for (uint32_t g = (uint32_t)wv; g < nGroups; g += 16u) { // a wavefront per group
-        unsigned long long part = 0;
+    // a wavefront per group, four groups' loads in flight at a time (the counts were written by other XCDs' workgroups: every
+    // trip is one to the memory side)
+    for (uint32_t g0 = (uint32_t)wv; g0 < nGroups; g0 += 64u) {
+        unsigned long long part[4];
 #pragma unroll
-        for (uint32_t i = 0; i < 4; ++i) {
-            const uint32_t idx = (g << 8) + (i << 6) + (uint32_t)lane;
-            part += idx < nWaves ? (unsigned long long)waveTotal[idx] : 0ull;
+        for (uint32_t b = 0; b < 4; ++b) {
+            const uint32_t g = g0 + 16u * b;
+            part[b] = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) {
+                const uint32_t idx = (g << 8) + (i << 6) + (uint32_t)lane;
+                part[b] += g < nGroups && idx < nWaves ? (unsigned long long)waveTotal[idx] : 0ull;
+            }
         }
-        const unsigned long long t = wave_sum64(part);
-        if (lane == 0)
-            groupTotal[g] = t;
-        grand += t;
+#pragma unroll
+        for (uint32_t b = 0; b < 4; ++b) {
+            const uint32_t g = g0 + 16u * b;
+            const unsigned long long t = wave_sum64(part[b]);
+            if (lane == 0 && g < nGroups)
+                groupTotal[g] = t;
+            grand += t;
+        }
     }
     if (lane == 0)
         sGrand[wv] = grand;
