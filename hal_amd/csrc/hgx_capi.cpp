@@ -548,14 +548,76 @@ int hgx_column_rows(hgx_alignment *h, int ref, int64_t first, int64_t count, con
     HGX_CATCH
 }
 
-static int textOut(const std::string &s, char **out_text, size_t *out_len) {
-    *out_text = (char *)malloc(s.size() + 1);
-    if (!*out_text)
-        return HGX_ERR;
-    memcpy(*out_text, s.c_str(), s.size() + 1);
-    *out_len = s.size();
-    return HGX_OK;
-}
+// The text the export entry points hand back: an ostream over a malloc'd buffer that grows by realloc (large blocks move by
+// remapping, not copying) and is handed to the caller as it stands.  (std::ostringstream + str() + a copy into malloc'd memory
+// moved the 264 MB of an 8 M-column MAF four times.)
+namespace {
+class MallocBuf : public std::streambuf {
+  public:
+    ~MallocBuf() override { free(_p); }
+    // NUL-terminated; the caller owns it (hgx_free)
+    bool release(char **out, size_t *len) {
+        if (!reserve(_n + 1))
+            return false;
+        _p[_n] = 0;
+        *out = _p;
+        *len = _n;
+        _p = nullptr;
+        _n = _cap = 0;
+        return true;
+    }
+
+  protected:
+    std::streamsize xsputn(const char *s, std::streamsize n) override {
+        if (n <= 0)
+            return 0;
+        if (!reserve(_n + (size_t)n + 1))
+            return 0;
+        memcpy(_p + _n, s, (size_t)n);
+        _n += (size_t)n;
+        return n;
+    }
+    // (tellp: MafExport writes its header when the stream is at position 0, halMafExport.cpp:147-156)
+    pos_type seekoff(off_type off, std::ios_base::seekdir dir, std::ios_base::openmode which) override {
+        if (off == 0 && dir == std::ios_base::cur && (which & std::ios_base::out))
+            return pos_type((off_type)_n);
+        return pos_type(off_type(-1));
+    }
+    int_type overflow(int_type c) override {
+        if (c == traits_type::eof())
+            return traits_type::not_eof(c);
+        const char ch = traits_type::to_char_type(c);
+        return xsputn(&ch, 1) == 1 ? c : traits_type::eof();
+    }
+
+  private:
+    bool reserve(size_t need) {
+        if (need <= _cap)
+            return true;
+        size_t cap = _cap ? _cap : (size_t)1 << 16;
+        while (cap < need)
+            cap += cap < ((size_t)1 << 28) ? cap : ((size_t)1 << 28);
+        char *q = (char *)realloc(_p, cap);
+        if (!q)
+            return false;
+        _p = q;
+        _cap = cap;
+        return true;
+    }
+    char *_p = nullptr;
+    size_t _n = 0, _cap = 0;
+};
+struct TextOut {
+    MallocBuf buf;
+    std::ostream os{&buf};
+    int finish(char **out_text, size_t *out_len) {
+        os.flush();
+        if (!os.good() || !buf.release(out_text, out_len))
+            throw std::runtime_error("out of memory for the output text");
+        return HGX_OK;
+    }
+};
+} // namespace
 
 int hgx_alignment_depth(hgx_alignment *h, int ref, int ref_sequence, int64_t start, int64_t length, int64_t step, int count_dupes,
                         int no_ancestors, const int32_t *targets, int32_t n_targets, char **out_text, size_t *out_len, char **err) {
@@ -568,9 +630,10 @@ int hgx_alignment_depth(hgx_alignment *h, int ref, int ref_sequence, int64_t sta
     if (!G->children.empty() && no_ancestors) // halAlignmentDepth.cpp:182-187
         throw std::runtime_error("--noAncestors cannot be used when reference genome (" + G->name + ") is ancetral");
     std::set<int> tset(targets, targets + (targets ? n_targets : 0));
-    std::ostringstream os;
+    TextOut T;
+    std::ostream &os = T.os;
     alignmentDepth(os, h, ref, ref_sequence, tset, start, length, step, count_dupes != 0, no_ancestors != 0);
-    return textOut(os.str(), out_text, out_len);
+    return T.finish(out_text, out_len);
     HGX_CATCH
 }
 
@@ -588,9 +651,10 @@ int hgx_maf_export_bed(hgx_alignment *h, int ref, const char *bed_text, size_t b
     configureMaf(me, o, G);
     std::set<int> tset(targets, targets + (targets ? n_targets : 0));
     std::istringstream is(std::string(bed_text ? bed_text : "", bed_len));
-    std::ostringstream os;
+    TextOut T;
+    std::ostream &os = T.os;
     me.convertBed(os, h, ref, is, tset);
-    return textOut(os.str(), out_text, out_len);
+    return T.finish(out_text, out_len);
     HGX_CATCH
 }
 
@@ -621,14 +685,15 @@ int hgx_maf_export(hgx_alignment *h, int ref, int ref_sequence, int64_t start, i
     MafExport me;
     configureMaf(me, o, G);
     std::set<int> tset(targets, targets + (targets ? n_targets : 0));
-    std::ostringstream os;
+    TextOut T;
+    std::ostream &os = T.os;
     if (ref_sequence >= 0) {
         me.convertSequence(os, h, ref, ref_sequence, start, length, tset);
     } else {
         for (size_t s = 0; s < G->seqs.size(); ++s)
             me.convertSequence(os, h, ref, (int)s, start, length, tset);
     }
-    return textOut(os.str(), out_text, out_len);
+    return T.finish(out_text, out_len);
     HGX_CATCH
 }
 
