@@ -123,8 +123,8 @@ def timed_steps(step, k, sync):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=100, help="timed steps (a step is 0.12 ms at config 2: a hundred of them are a stable mean)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--queries", type=int, default=1000000, help="intervals per GPU")
     ap.add_argument("--scale", type=float, default=1.0, help="genome size multiplier (1.0 = ~100 Mb/genome)")
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4"],

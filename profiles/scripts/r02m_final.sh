@@ -6,8 +6,8 @@ mkdir -p gpurun_out
 timeout 1200 python profiles/scripts/r02_pmc.py /tmp/r02m_pmc > gpurun_out/r02m_pmc.txt 2>&1
 cp /tmp/r02m_pmc/kernel_stats.txt gpurun_out/r02m_pmc_driver_kernel_stats.txt 2>/dev/null
 cp profiles/pmc_traffic.json gpurun_out/r02m_pmc_traffic.json
-( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/r02m_prof -- python "$GRAFT_REPO_ROOT/bench.py" --columns 0 --maf-columns 0 --text-path 0 --sustained-seconds 0 > /tmp/r02m_prof_bench.log 2>&1 )
+( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/r02m_prof -- python "$GRAFT_REPO_ROOT/bench.py" > /tmp/r02m_prof_bench.log 2>&1 )
 f=$(find /tmp/r02m_prof -name '*kernel_stats.csv' | head -1)
-[ -n "$f" ] && { echo "# rocprofv3 --kernel-trace --stats -- python bench.py --columns 0 --maf-columns 0 --text-path 0 --sustained-seconds 0" > gpurun_out/r02m_kernel_stats.txt; head -40 "$f" >> gpurun_out/r02m_kernel_stats.txt; }
+[ -n "$f" ] && { echo "# rocprofv3 --kernel-trace --stats -- python bench.py" > gpurun_out/r02m_kernel_stats.txt; head -40 "$f" >> gpurun_out/r02m_kernel_stats.txt; }
 timeout 900 python bench.py > gpurun_out/r02m_bench.log 2> gpurun_out/r02m_bench.err
 tail -c 1500 gpurun_out/r02m_pmc.txt; head -12 gpurun_out/r02m_kernel_stats.txt | cut -c1-160; tail -c 300 gpurun_out/r02m_bench.log
