@@ -137,6 +137,7 @@ def main():
     ap.add_argument("--maf-columns", type=int, default=8000000,
                     help="hal2maf (BASELINE config 3) over the first N reference columns, end to end to MAF text (0 = skip; one GPU only)")
     ap.add_argument("--text-path", type=int, default=1, help="also time Liftover::convert (BED text in, BED text out) on the batch (one GPU only)")
+    ap.add_argument("--in-flight", type=int, default=2, help="batches in flight on one GPU without an exchange: 2 (two plans, two streams) or 1")
     ap.add_argument("--sustained-seconds", type=float, default=2.0, help="extra leg: the same step repeated for about this long")
     ap.add_argument("--exchange", default="torch", choices=["torch", "c_abi"],
                     help="who issues the batch's one all-gather: torch.distributed (the launcher's communicator, default) or the library "
@@ -219,13 +220,47 @@ def main():
         exchange = shard.SlotExchange(world, rank, slot, dev, backend=args.exchange, comm=comm)
     wire = {"format": None, "bytes": 0}
 
-    def step():
+    # One GPU without an exchange: TWO plans of the alignment with a batch each in flight on two streams
+    # (hgx_liftover_submit / hgx_liftover_collect) — a step is still one pass of one plan over the batch, the next step of the
+    # other plan is queued behind it before this one is waited for, so the end of one batch's launches (a few wavefronts
+    # finishing general intervals) and the host's launch and wake-up times overlap the other batch.  `one_plan` reports the
+    # same steps through one plan, batch after batch.  With an exchange every step carries a collective and one plan is used.
+    in_flight = 1 if exchanging or args.in_flight <= 1 else 2
+    plans, streams, pending = [plan], [torch.cuda.current_stream()], [False, False]
+    if in_flight == 2:
+        plans.append(hal_amd.LiftoverPlan(al, src, tgt, max_queries=nq))
+        for _ in range(3):  # (the second plan's own change-over to the table, which is cached in the alignment by now)
+            plans[1].run(d_gs, d_ge, d_st)
+        plans[1].set_timing(0)
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    counter = {"i": 0, "nrec": nrec}
+
+    def step_one():
         ptr, nrec = plan.run(d_gs, d_ge, d_st)
         if exchanging:
             exchange.wait()
             exchange.submit(plan, first_query=rank * nq)
             wire["format"], wire["bytes"] = exchange.last_format, exchange.last_bytes
         return nrec
+
+    def finish(k):
+        if pending[k]:
+            _, counter["nrec"] = plans[k].collect()
+            pending[k] = False
+
+    def step():
+        if in_flight == 1:
+            return step_one()
+        k = counter["i"] & 1
+        counter["i"] += 1
+        finish(k)
+        plans[k].submit(d_gs, d_ge, d_st, stream=streams[k])
+        pending[k] = True
+        return counter["nrec"]
+
+    def drain():
+        finish(0)
+        finish(1)
 
     # settle (untimed): the first runs of a fresh process pay for lazy code-object loads and workspace growth, and a process
     # that starts while the previous GPU process is still being torn down sees extra host time per run for a second or two.
@@ -235,6 +270,7 @@ def main():
     while True:
         t_s = time.perf_counter()
         step()
+        drain()
         sync()
         passes_before_timing += 1
         dt = time.perf_counter() - t_s
@@ -251,12 +287,15 @@ def main():
     for _ in range(args.warmup):
         step()
         passes_before_timing += 1
+    drain()
     if exchanging:
         dist.barrier()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         nrec = step()
+    drain()  # the batches still in flight belong to the timed region
+    nrec = counter["nrec"] if in_flight == 2 else nrec
     if exchanging:
         exchange.drain()  # the exchanges still under way belong to the timed region
     sync()
@@ -276,8 +315,19 @@ def main():
     sustained = None
     if args.sustained_seconds > 0 and not exchanging:
         k = max(args.steps, int(args.sustained_seconds / max(elapsed / args.steps, 1e-5)))
-        dt_s, _ = timed_steps(step, k, sync)
-        sustained = {"steps": k, "seconds": dt_s, "value": nq * k / dt_s, "ms_per_step": 1e3 * dt_s / k}
+
+        def all_steps():
+            for _ in range(k):
+                step()
+            drain()
+        dt_s, _ = timed_steps(all_steps, 1, sync)
+        sustained = {"steps": k, "seconds": dt_s, "value": nq * k / dt_s, "ms_per_step": 1e3 * dt_s / k, "in_flight": in_flight}
+    # ---- the same number of steps through ONE plan, batch after batch (what `value` was before batches were kept in flight) ----
+    one_plan = None
+    if in_flight == 2:
+        dt_1, _ = timed_steps(step_one, args.steps, sync)
+        one_plan = {"ms_per_step": 1e3 * dt_1 / args.steps, "value": nq * args.steps / dt_1, "unit": "intervals/s", "steps": args.steps,
+                    "what": "hgx_liftover_run_device, one plan: every batch waited for before the next one is launched"}
 
     # ---- kernel times: the same steps again with HIP events around every launch (untimed) ----
     plan.set_timing(2)
@@ -397,11 +447,14 @@ def main():
                                                                      "seed 2" if args.workload == "cfg2" else "seed 0", args.scale, nq,
                                                                      src_name, tgt_name),
                        "intervals_per_gpu": nq, "records_per_step": nrec_all, "parallelism": "query-shard x%d" % world,
-                       "regime": ("steady state: the timed steps are passes %d.. of this batch through one plan; the plan's first pass "
+                       "regime": ("steady state: the timed steps are passes %d.. of this batch, through %s; the first plan's first pass "
                                   "(see `cold`) built its %s: %d records (%.0f MB) in %.1f ms on the device; %d table records "
                                   "dereferenced per step, %d of the %d intervals took the general (overlap-breaking) route; "
                                   "`walk` is the same batch without any table"
-                                  % (passes_before_timing + 1, kind_text.get(st["composed_kind"], "?"), st["composed_records"],
+                                  % (passes_before_timing + 1,
+                                     "one plan" if in_flight == 1 else "two plans of the alignment with a batch each in flight on two streams "
+                                     "(hgx_liftover_submit / _collect; `one_plan`: the same steps batch after batch)",
+                                     kind_text.get(st["composed_kind"], "?"), st["composed_records"],
                                      st["composed_records"] * 16 / 1e6, st["composed_build_ms"], table_records, st["general_queries"], nq))
                        if st["composed_records"] else "level-by-level walk (k_up_chain)",
                        "exchange": ("one all-gather per batch of self-describing wire blobs in equal slots (%s; format %s, %.1f MB per rank and "
@@ -420,7 +473,10 @@ def main():
                                         "achieved_GBs": own_bytes / (kern_ms_total * 1e-3) / 1e9 if kern_ms_total > 0 else 0.0,
                                         "frac": own_bytes / (kern_ms_total * 1e-3) / 1e9 / HBM_PEAK_GBS if kern_ms_total > 0 else 0.0,
                                         "reference_walk_bytes_per_step": alg_walk,
-                                        "note": "bytes_the_timed_kernels_must_move prices every timed kernel by its own inputs and outputs "
+                                        "batches_in_flight": in_flight,
+                                        "note": "kernel times come from a loop of its own through one plan with HIP events around every launch; with "
+                                                "two batches in flight the launches of the two overlap, so ms_per_step is below kernel_ms_per_step.  "
+                                                "bytes_the_timed_kernels_must_move prices every timed kernel by its own inputs and outputs "
                                                 "(DESIGN.md 5); reference_walk_bytes_per_step is SURVEY 8(d)'s 24Q+25T+25B+40R counted by the "
                                                 "level walk of the same batch — a table reads far fewer records, so that figure divided by "
                                                 "the table path's time is not a bandwidth"}},
@@ -437,6 +493,9 @@ def main():
         }
         if sustained:
             out["sustained"] = sustained
+        if one_plan:
+            out["one_plan"] = one_plan
+        out["config"]["batches_in_flight"] = in_flight
         if col_result:
             ncol, col_ms, gather_ms, mean_depth = col_result
             cst = al.columns_depth_stats(src, 0, ncol)

@@ -91,6 +91,8 @@ SYMBOLS = {
     "hgx_liftover_plan_create": (C.c_int, [VP, C.c_int, C.c_int, P(hgx_liftover_opts), C.c_size_t, P(VP), P(VP)]),
     "hgx_liftover_plan_destroy": (None, [VP]),
     "hgx_liftover_run_device": (C.c_int, [VP, C.c_size_t, VP, VP, VP, VP, P(VP), P(C.c_size_t), P(VP)]),
+    "hgx_liftover_submit": (C.c_int, [VP, C.c_size_t, VP, VP, VP, VP, P(VP)]),
+    "hgx_liftover_collect": (C.c_int, [VP, P(VP), P(C.c_size_t), P(VP)]),
     "hgx_liftover_last_stats": (C.c_int, [VP, P(hgx_liftover_stats)]),
     "hgx_clone_to_device": (C.c_int, [VP, C.c_int, P(VP), P(VP)]),
     "hgx_comm_unique_id": (C.c_int, [VP, P(VP)]),

@@ -423,6 +423,25 @@ class LiftoverPlan:
         stream = torch.cuda.current_stream(gstart.device).cuda_stream
         return self.run_ptr(gstart.numel(), gstart.data_ptr(), gend.data_ptr(), strand.data_ptr(), stream)
 
+    def submit(self, gstart, gend, strand, stream=None):
+        """hgx_liftover_submit: queue the batch on `stream` (a torch.cuda.Stream; default: the current one) and return; collect()
+        waits for it.  The tensors must stay alive and unchanged until then."""
+        import torch
+        assert gstart.is_cuda and gstart.dtype == torch.int64 and gend.dtype == torch.int64 and strand.dtype == torch.uint8
+        st = (stream or torch.cuda.current_stream(gstart.device)).cuda_stream
+        err = C.c_void_p()
+        if lib.hgx_liftover_submit(self._p, gstart.numel(), gstart.data_ptr(), gend.data_ptr(), strand.data_ptr(), st, C.byref(err)) != 0:
+            raise HgxError(take_error(err))
+        self._pending = (gstart, gend, strand)
+
+    def collect(self):
+        """hgx_liftover_collect: (device pointer of hgx_record[n_records], n_records) of the submitted batch"""
+        out, nrec, err = C.c_void_p(), C.c_size_t(), C.c_void_p()
+        if lib.hgx_liftover_collect(self._p, C.byref(out), C.byref(nrec), C.byref(err)) != 0:
+            raise HgxError(take_error(err))
+        self._pending = None
+        return out.value or 0, nrec.value
+
     def records_to_tensor(self, ptr, n, packed=False):
         """Copy the plan-owned device records of the last run into a fresh torch uint8 tensor (device to device): [n, 40]
         hgx_record rows, or with packed=True [n, 20] rows in the wire form of hal_amd.shard.pack_records."""

@@ -342,6 +342,25 @@ int hgx_liftover_run_device(hgx_liftover_plan *p, size_t n, const int64_t *d_gst
     HGX_CATCH
 }
 
+int hgx_liftover_submit(hgx_liftover_plan *p, size_t n, const int64_t *d_gstart, const int64_t *d_gend, const uint8_t *d_strand, void *hip_stream,
+                        char **err) {
+    HGX_TRY
+    if (!p)
+        throw std::runtime_error("hgx_liftover_submit: null argument");
+    submitLiftoverPlan(p, n, d_gstart, d_gend, d_strand, hip_stream);
+    return HGX_OK;
+    HGX_CATCH
+}
+
+int hgx_liftover_collect(hgx_liftover_plan *p, const hgx_record **d_records, size_t *n_records, char **err) {
+    HGX_TRY
+    if (!p || !d_records || !n_records)
+        throw std::runtime_error("hgx_liftover_collect: null argument");
+    collectLiftoverPlan(p, d_records, n_records);
+    return HGX_OK;
+    HGX_CATCH
+}
+
 int hgx_liftover_last_stats(const hgx_liftover_plan *p, hgx_liftover_stats *out) {
     if (!p || !out)
         return HGX_ERR;

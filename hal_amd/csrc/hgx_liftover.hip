@@ -466,6 +466,16 @@ struct hgx_liftover_plan {
     // single-pass path over the merged table (hgx_lift_kernels.hpp)
     DevBuf liftKb, liftBlockList, liftBlockCount, liftStatus;
     bool mergedDisabled = false; // (never set any more: the single-pass kernels wait for nothing)
+    int liftLaunches = 0;        // launches of the last single-pass run that keep statistics
+    bool liftWaveFinish = true;
+    // hgx_liftover_submit / _collect: a batch whose launches are queued (1) or that has been run to the end already (2)
+    int pendingState = 0;
+    size_t pendingN = 0;
+    const int64_t *pendingS = nullptr, *pendingE = nullptr;
+    const uint8_t *pendingStrand = nullptr;
+    hipStream_t pendingStream = nullptr;
+    const hgx_record *pendingOut = nullptr;
+    size_t pendingCount = 0;
     bool mergedOffThisRun = false;
     int liftGrid = 0, liftMinWaves = 1;
     unsigned long long generalQueries = 0, liftRestCount = 0;
@@ -592,8 +602,10 @@ static const ComposedUp *ensureComposed(hgx_alignment *h, int src, int dst, bool
 
 // One batch on the single-pass path (32-bit tables): classify, the general intervals through the unmerged table and the
 // LDS finishing kernel, then k_lift_merged writes every record at its final place.  One host synchronisation at the end.
+static void finishMergedOnce(hgx_liftover_plan &P, hipStream_t s, unsigned long long *hostCounters);
+// launchOnly: the launches are queued and the function returns; finishMergedOnce waits for them and reads the report
 static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int64_t *dE, const uint8_t *dStrand, hipStream_t s,
-                          unsigned long long *hostCounters) {
+                          unsigned long long *hostCounters, bool launchOnly = false) {
     typedef int32_t C;
     const DeviceImage &D = *P.h->dev;
     const ComposedUp &T = *P.composed;
@@ -694,7 +706,6 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
             P.liftGrid = std::max(1, atoi(b)) * 256;
     }
     // all lines, the groups' lines, the statistics — and everything the host wants to know goes to pinned memory from here
-    unsigned long long *hrb = P.pinned + CNT_SLOTS + 1;
     P.timer.begin("k_lift_totals", s);
     hipLaunchKernelGGL(k_lift_totals, dim3(1), dim3(1024), 0, s, (const uint32_t *)waveTotal, 4 * nTiles, nGroups, groupTotal, cap, (uint32_t *)P.total.p,
                        cnt, generalCount, waveFinish ? restCount : (unsigned long long *)nullptr, storeLaunch, P.pinnedDev + CNT_SLOTS + 1);
@@ -714,6 +725,15 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
     ++launch;
     if (events)
         HIP_OK(hipEventRecord(P.evEnd, s));
+    P.liftLaunches = launch;
+    P.liftWaveFinish = waveFinish;
+    if (!launchOnly)
+        finishMergedOnce(P, s, hostCounters);
+}
+
+static void finishMergedOnce(hgx_liftover_plan &P, hipStream_t s, unsigned long long *hostCounters) {
+    unsigned long long *cnt = (unsigned long long *)P.counters.p;
+    unsigned long long *hrb = P.pinned + CNT_SLOTS + 1;
     HIP_OK(hipStreamSynchronize(s));
     memset(hostCounters, 0, 8 * CNT_SLOTS);
     if (hrb[CNT_OVERFLOW]) { // the retry sizes the buffers from the frontier counters and CNT_LIFT_TOTAL
@@ -722,12 +742,12 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
         memcpy(hostCounters, P.pinned, 8 * CNT_SLOTS);
     }
     memcpy(hostCounters, hrb, 8 * 8);
-    for (int l = 0; l < launch; ++l)
+    for (int l = 0; l < P.liftLaunches; ++l)
         hostCounters[CNT_KSTAT0 + 2 * l] = hrb[8 + l];
     P.pinned[CNT_SLOTS] = hrb[CNT_LIFT_TOTAL]; // the record total, where runPlan looks for it
     // (an overflowing or failing run may have left counters beyond the ones the epilogue clears)
     P.liftStateClean = !hrb[CNT_OVERFLOW] && !hrb[CNT_DEFERRED] && !(getenv("HGX_LIFT_MEMSETS") != nullptr);
-    P.generalQueries = waveFinish ? hrb[14] : hrb[12];
+    P.generalQueries = P.liftWaveFinish ? hrb[14] : hrb[12];
     P.liftRestCount = hrb[13];
 }
 
@@ -1672,6 +1692,68 @@ const ComposedUp *wholePathTable(hgx_alignment *h, int src, int dst, int limit) 
     if (img.lca(src, dst) == dst)
         return ensureComposed(h, src, dst, false, o, false);
     return ensureComposed(h, src, dst, true, o, /*wantMerged=*/false);
+}
+
+// hgx_liftover_submit: queues a batch's launches on `stream` and returns; hgx_liftover_collect waits for them.  A plan has one
+// batch in flight; two plans on two streams keep the GPU busy across the ends of their launches (the counting launch ends with
+// a few wavefronts finishing general intervals, the host's launch and wake-up times sit between batches).  Only the steady
+// state of the single-pass path is queued — anything else (no table yet, kernel events on, a run that needs one of the
+// repeat-with-larger-buffers paths) is run to the end by submit, or repeated to the end by collect.
+void submitLiftoverPlan(hgx_liftover_plan *p, size_t n, const int64_t *dS, const int64_t *dE, const uint8_t *dStrand, void *stream) {
+    hgx_liftover_plan &P = *p;
+    if (P.pendingState != 0)
+        throw std::runtime_error("hgx_liftover_submit: the plan's previous batch has not been collected");
+    P.pendingN = n;
+    P.pendingS = dS;
+    P.pendingE = dE;
+    P.pendingStrand = dStrand;
+    P.pendingStream = (hipStream_t)stream;
+    const bool steady = n > 0 && n <= P.maxQueries && n < ((size_t)1 << 31) && P.composed && P.composed->mRecs && !P.opts.emit_blocks &&
+                        !P.mergedDisabled && !P.h->dev->wide && P.timer.mode == 0 && !P.captureUp && !P.captureFinal && P.liftStateClean;
+    if (!steady) {
+        runLiftoverPlan(p, n, dS, dE, dStrand, stream, &P.pendingOut, &P.pendingCount);
+        P.pendingState = 2;
+        return;
+    }
+    HIP_OK(hipSetDevice(P.h->dev->device));
+    std::vector<unsigned long long> hc(CNT_SLOTS);
+    P.mergedOffThisRun = false;
+    runMergedOnce(P, n, dS, dE, dStrand, (hipStream_t)stream, hc.data(), true);
+    P.pendingState = 1;
+}
+
+void collectLiftoverPlan(hgx_liftover_plan *p, const hgx_record **dOut, size_t *nOut) {
+    hgx_liftover_plan &P = *p;
+    if (P.pendingState == 0)
+        throw std::runtime_error("hgx_liftover_collect: nothing was submitted");
+    const int state = P.pendingState;
+    P.pendingState = 0;
+    if (state == 2) {
+        *dOut = P.pendingOut;
+        *nOut = P.pendingCount;
+        return;
+    }
+    std::vector<unsigned long long> hc(CNT_SLOTS);
+    finishMergedOnce(P, P.pendingStream, hc.data());
+    if (hc[CNT_OVERFLOW] || hc[CNT_DEFERRED] || P.liftRestCount) { // (rare: the batch again, through every repeat path runPlan has)
+        runLiftoverPlan(p, P.pendingN, P.pendingS, P.pendingE, P.pendingStrand, P.pendingStream, dOut, nOut);
+        return;
+    }
+    P.stats = hgx_liftover_stats{};
+    P.stats.queries = P.pendingN;
+    P.stats.mapped_pieces = hc[CNT_MAPPED];
+    for (int k = 0; k < MAX_LAUNCHES; ++k) {
+        P.stats.top_derefs += hc[CNT_KSTAT0 + 2 * k];
+        P.stats.bottom_derefs += hc[CNT_KSTAT0 + 2 * k + 1];
+    }
+    P.stats.records = (uint32_t)(P.pinned[CNT_SLOTS] & 0xFFFFFFFFull);
+    P.stats.composed_kind = 3;
+    P.stats.composed_records = P.composed->mNum;
+    P.stats.composed_build_ms = P.composed->buildMs + P.composed->mBuildMs;
+    P.stats.general_queries = P.generalQueries;
+    P.stats.composed_flagged = P.composed->mFlagged;
+    *dOut = (const hgx_record *)P.outRecords.p;
+    *nOut = P.stats.records;
 }
 
 void runLiftoverPlan(hgx_liftover_plan *p, size_t n, const int64_t *dS, const int64_t *dE, const uint8_t *dStrand, void *stream,

@@ -10,6 +10,8 @@ namespace hgx {
 
 hgx_liftover_plan *createLiftoverPlan(hgx_alignment *h, int src, int tgt, const hgx_liftover_opts &opts, size_t maxQueries,
                                       bool allowComposed = true, bool tableBuilder = false);
+void submitLiftoverPlan(hgx_liftover_plan *p, size_t n, const int64_t *dStart, const int64_t *dEnd, const uint8_t *dStrand, void *stream);
+void collectLiftoverPlan(hgx_liftover_plan *p, const hgx_record **dOut, size_t *nOut);
 void runLiftoverPlan(hgx_liftover_plan *p, size_t n, const int64_t *dStart, const int64_t *dEnd, const uint8_t *dStrand, void *stream,
                      const hgx_record **dOut, size_t *nOut);
 void destroyLiftoverPlan(hgx_liftover_plan *p);

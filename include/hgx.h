@@ -145,6 +145,15 @@ void hgx_liftover_plan_destroy(hgx_liftover_plan *p);
 int hgx_liftover_run_device(hgx_liftover_plan *p, size_t n, const int64_t *d_gstart, const int64_t *d_gend,
                             const uint8_t *d_strand, void *hip_stream, const hgx_record **d_records,
                             size_t *n_records, char **err);
+/* The same in two halves, for callers that keep several batches in flight: hgx_liftover_submit queues the batch's launches on
+ * hip_stream and returns; hgx_liftover_collect waits for them and hands back what hgx_liftover_run_device hands back.  A plan
+ * has one batch in flight (its workspaces and its output belong to that batch until the next submit); two plans of the same
+ * alignment on two streams overlap one batch's last wavefronts and the host's launch and wake-up times with the other batch.
+ * The interval arrays must stay as they are until collect returns.  (Liftover::convert's lines are independent,
+ * liftover/impl/halLiftover.cpp:46-92: batches may be mapped in any order and at the same time.) */
+int hgx_liftover_submit(hgx_liftover_plan *p, size_t n, const int64_t *d_gstart, const int64_t *d_gend, const uint8_t *d_strand,
+                        void *hip_stream, char **err);
+int hgx_liftover_collect(hgx_liftover_plan *p, const hgx_record **d_records, size_t *n_records, char **err);
 /* Counters of the last run (for roofline accounting): queries, source pieces, top-segment records
  * dereferenced, bottom-segment records dereferenced, mapped pieces before merging, output records,
  * and the accumulated device time in ms of the walk kernels / all kernels of the run. */

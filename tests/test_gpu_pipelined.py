@@ -1,0 +1,54 @@
+"""hgx_liftover_submit / hgx_liftover_collect: two plans of one alignment with a batch each in flight on two streams give the
+records of hgx_liftover_run_device, batch after batch — also for the batches that submit or collect run to the end themselves
+(the first ones of a plan, which walk and then build the table; one with kernel events on)."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_two_plans_two_streams(hal):
+    import torch
+    opts = hal.RandOptions(mean_degree=1.5, max_branch_length=3.0, min_genomes=2, max_genomes=10, min_segment_length=20,
+                           max_segment_length=80, min_segments=3000, max_segments=6000, seed=2, with_dna=False)
+    al = hal.Alignment.random(opts, device=0)
+    src, tgt = al.genome_id("Genome_9"), al.genome_id("Genome_8")
+    _, ss, length = al.sequences(src)[0]
+    n = 20000
+    batches = []
+    for b in range(6):
+        g = torch.Generator().manual_seed(100 + b)
+        starts = torch.randint(0, length - 400, (n,), generator=g)
+        lens = torch.randint(1, 300, (n,), generator=g)
+        st = torch.where(torch.rand(n, generator=g) < 0.5, ord("+"), ord("-")).to(torch.uint8).cuda()
+        batches.append(((starts + ss).cuda(), (starts + lens - 1 + ss).cuda(), st))
+    ref_plan = hal.LiftoverPlan(al, src, tgt, max_queries=n)
+    want = []
+    for gs, ge, st in batches:
+        ptr, nrec = ref_plan.run(gs, ge, st)
+        want.append(ref_plan.records_to_tensor(ptr, nrec).cpu())
+    plans = [hal.LiftoverPlan(al, src, tgt, max_queries=n) for _ in range(2)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    got = [None] * len(batches)
+    for rnd in range(3):  # (the same batches three times: the plans are in their steady state from the second round on)
+        inflight = [None, None]
+        for i, (gs, ge, st) in enumerate(batches):
+            k = i & 1
+            if inflight[k] is not None:
+                ptr, nrec = plans[k].collect()
+                with torch.cuda.stream(streams[k]):
+                    got[inflight[k]] = plans[k].records_to_tensor(ptr, nrec).cpu()
+            if rnd == 1 and i == 3:
+                plans[k].set_timing(2)  # a batch that submit runs to the end itself
+            plans[k].submit(gs, ge, st, stream=streams[k])
+            plans[k].set_timing(0)
+            inflight[k] = i
+        for k in range(2):
+            ptr, nrec = plans[k].collect()
+            with torch.cuda.stream(streams[k]):
+                got[inflight[k]] = plans[k].records_to_tensor(ptr, nrec).cpu()
+        for i in range(len(batches)):
+            assert torch.equal(got[i], want[i]), (rnd, i)
+    assert plans[0].stats()["composed_kind"] == 3
+    with pytest.raises(hal.HgxError):
+        plans[0].collect()
