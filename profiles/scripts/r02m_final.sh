@@ -9,5 +9,6 @@ cp profiles/pmc_traffic.json gpurun_out/r02m_pmc_traffic.json
 ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/r02m_prof -- python "$GRAFT_REPO_ROOT/bench.py" > /tmp/r02m_prof_bench.log 2>&1 )
 f=$(find /tmp/r02m_prof -name '*kernel_stats.csv' | head -1)
 [ -n "$f" ] && { echo "# rocprofv3 --kernel-trace --stats -- python bench.py" > gpurun_out/r02m_kernel_stats.txt; head -40 "$f" >> gpurun_out/r02m_kernel_stats.txt; }
+sleep 8  # (a process that starts while the previous GPU process is being torn down sees slow allocations: the cold leg would show them)
 timeout 900 python bench.py > gpurun_out/r02m_bench.log 2> gpurun_out/r02m_bench.err
 tail -c 1500 gpurun_out/r02m_pmc.txt; head -12 gpurun_out/r02m_kernel_stats.txt | cut -c1-160; tail -c 300 gpurun_out/r02m_bench.log
