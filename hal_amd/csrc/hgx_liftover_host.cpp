@@ -466,6 +466,7 @@ void Liftover::convertGeneral(hgx_alignment *al, int srcGenome, std::istream *in
     while (more || !pendingError.empty()) {
         jobs.clear();
         ivs.clear();
+        const size_t batchFirstLine = lineNumber + 1;
         while (more && ivs.size() < batchLines) {
             ++lineNumber;
             try {
@@ -518,7 +519,12 @@ void Liftover::convertGeneral(hgx_alignment *al, int srcGenome, std::istream *in
         }
         if (!jobs.empty()) {
             hgx_liftover_stats st{};
-            liftoverBatchHost(al, srcGenome, tgtGenome, ivs.size(), ivs.data(), opts, recs, &st);
+            try { // (BedScanner::scan wraps visitLine as well, halBedScanner.cpp:60-68: an error raised while lifting names a line — here
+                  // the first line of the batch it was lifted in)
+                liftoverBatchHost(al, srcGenome, tgtGenome, ivs.size(), ivs.data(), opts, recs, &st);
+            } catch (std::runtime_error &e) {
+                throw std::runtime_error(std::string(e.what()) + " in input bed line " + std::to_string(batchFirstLine));
+            }
             lastStats.queries += st.queries;
             lastStats.source_pieces += st.source_pieces;
             lastStats.top_derefs += st.top_derefs;
