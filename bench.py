@@ -98,16 +98,30 @@ def lib_sha16():
         return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
+def kernel_sources_sha16():
+    """identity of the device code: the .hip files and the headers they include (host-only changes leave it alone)"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "hal_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "hal_amd", "csrc", "*.hpp"))):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the PMC passes of profiles/scripts/r02_pmc.sh (profiles/pmc_traffic.json), or
-    None when the file was made with another build of libhgx.so than the one running (the file records the library's hash)."""
+    None when the file was made with other device code than the one running (the file records the hash of the library and of
+    the device sources it was built from; either one matching will do: a host-only change rebuilds the library without touching
+    a kernel)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         d = json.load(open(path))
     except Exception:
         return None, "no profiles/pmc_traffic.json"
-    if d.get("libhgx_sha16") != lib_sha16():
-        return None, "profiles/pmc_traffic.json was measured on another build of libhgx.so (%s); rerun profiles/scripts/r02_pmc.sh" % d.get("libhgx_sha16")
+    if d.get("libhgx_sha16") != lib_sha16() and d.get("kernel_sources_sha16") != kernel_sources_sha16():
+        return None, "profiles/pmc_traffic.json was measured on other device code (library %s); rerun profiles/scripts/r02_pmc.py" % d.get("libhgx_sha16")
     return d.get("kernels", {}).get(kernel), d.get("source", "")
 
 

@@ -78,7 +78,9 @@ for k in sorted(set(raw.get("FETCH_SIZE", {})) | set(raw.get("WRITE_SIZE", {})))
     detail[k] = {"fetch_raw": fe, "write_raw": wr, "fetch_doubled": k in STREAMING,
                  "streamed_input_bytes_counted_at_half": STREAMED_PER_INTERVAL.get(k, 0.0) * NQ, "avg_ns": dur.get(k)}
 sha = hashlib.sha256(open(os.path.join(ROOT, "hal_amd", "libhgx.so"), "rb").read()).hexdigest()[:16]
-res = {"libhgx_sha16": sha, "kernels": kernels, "detail": detail,
+sys.path.insert(0, ROOT)
+from bench import kernel_sources_sha16
+res = {"libhgx_sha16": sha, "kernel_sources_sha16": kernel_sources_sha16(), "kernels": kernels, "detail": detail,
        "source": "profiles/scripts/r02_pmc.py: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (KiB x 1024) over the cfg2 batch; "
                  "FETCH_SIZE doubled for the streaming kernels (MI355X_MICROARCH.md, gfx950), as counted for the gather-bound walk kernels "
                  "(profiles/r01l_fetch_size_calibration.txt); per launch"}
