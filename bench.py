@@ -488,8 +488,11 @@ def main():
                                         "frac": own_bytes / (kern_ms_total * 1e-3) / 1e9 / HBM_PEAK_GBS if kern_ms_total > 0 else 0.0,
                                         "reference_walk_bytes_per_step": alg_walk,
                                         "batches_in_flight": in_flight,
+                                        "achieved_GBs_at_step_rate": own_bytes / (elapsed / args.steps) / 1e9,
+                                        "frac_at_step_rate": own_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
                                         "note": "kernel times come from a loop of its own through one plan with HIP events around every launch; with "
-                                                "two batches in flight the launches of the two overlap, so ms_per_step is below kernel_ms_per_step.  "
+                                                "two batches in flight the launches of the two overlap, so ms_per_step is below kernel_ms_per_step; "
+                                                "achieved_GBs_at_step_rate = the same bytes over ms_per_step, what the GPU moves per second in the timed loop.  "
                                                 "bytes_the_timed_kernels_must_move prices every timed kernel by its own inputs and outputs "
                                                 "(DESIGN.md 5); reference_walk_bytes_per_step is SURVEY 8(d)'s 24Q+25T+25B+40R counted by the "
                                                 "level walk of the same batch — a table reads far fewer records, so that figure divided by "
