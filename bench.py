@@ -325,6 +325,23 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- with an exchange in the step: the same steps without it (what the ranks map when nobody collates) ----
+    mapping_only = None
+    if exchanging:
+        dist.barrier()
+        sync()
+        t0m = time.perf_counter()
+        for _ in range(args.steps):
+            plan.run(d_gs, d_ge, d_st)
+        sync()
+        dist.barrier()
+        tm = torch.tensor([time.perf_counter() - t0m], dtype=torch.float64, device=dev)
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        mapping_only = {"value": world * nq * args.steps / float(tm.item()), "unit": "intervals/s", "ms_per_step": 1e3 * float(tm.item()) / args.steps,
+                        "what": "the same steps without the all-gather of the records (one plan per rank, every batch waited for): the "
+                                "shards are independent, so this is what the ranks map; `value` includes collating every rank's records "
+                                "on every rank, which the links bound (%.1f MB per rank and step)" % (wire["bytes"] / 1e6)}
+
     # ---- sustained: the same step for a couple of seconds (a region long enough for outside observers: rocm-smi, the driver) ----
     sustained = None
     if args.sustained_seconds > 0 and not exchanging:
@@ -512,6 +529,8 @@ def main():
             out["sustained"] = sustained
         if one_plan:
             out["one_plan"] = one_plan
+        if mapping_only:
+            out["mapping_only"] = mapping_only
         out["config"]["batches_in_flight"] = in_flight
         if col_result:
             ncol, col_ms, gather_ms, mean_depth = col_result
