@@ -464,8 +464,7 @@ struct hgx_liftover_plan {
     DevBuf fr[6][6], mp[2][6], counters, perQuery, offset, cursor, nOut, outOffset, blockSums, total, grouped, outRecords,
         deferredList, needCap, bigSlot, scratch, bigRecords, classLists, classCounts;
     // single-pass path over the merged table (hgx_lift_kernels.hpp)
-    DevBuf liftKb, liftBlockList, liftBlockCount, liftStatus;
-    bool mergedDisabled = false; // (never set any more: the single-pass kernels wait for nothing)
+    DevBuf liftKb, liftStatus;
     int liftLaunches = 0;        // launches of the last single-pass run that keep statistics
     bool liftWaveFinish = true;
     // hgx_liftover_submit / _collect: a batch whose launches are queued (1) or that has been run to the end already (2)
@@ -558,8 +557,6 @@ struct hgx_liftover_plan {
         classLists.ensure(4 * 4 * (nq + 1));
         classCounts.ensure(32);
         liftKb.ensure(8 * (nq + 1));
-        liftBlockList.ensure(4 * (nq + 4096));
-        liftBlockCount.ensure(4 * 2048);
         liftStatus.ensure(16 * ((nq + LIFT_TILE - 1) / LIFT_TILE) + 8 * ((nq + 64 * LIFT_TILE - 1) / (64 * LIFT_TILE)) + 16);
     }
 };
@@ -652,17 +649,10 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
     hipLaunchKernelGGL((k_lift_classify<INL, W>), dim3(std::max<uint32_t>(1, nTiles)), dim3(256), 0, s, dS, dE, dStrand, nq, srcLength,        \
                        (const uint32_t *)T.mBuckets, T.mShift, T.mWindow, (const ComposedRec<C> *)T.mRecs, (uint2 *)P.liftKb.p, GT, kstat(),    \
                        cnt + CNT_DSTAT0 + STAT_LAUNCH0 + 2 * storeLaunch, (uint32_t *)P.offset.p, (uint32_t *)P.nOut.p, (uint32_t *)lateList, lateCount, waveTotal)
-    static const int classifyWaves = getenv("HGX_CLASSIFY_MINWAVES") ? atoi(getenv("HGX_CLASSIFY_MINWAVES")) : 6; // (experiments: 1, 6, 7, 8)
     if (!waveFinish)
         HGX_CLASSIFY(false, 1);
-    else if (classifyWaves == 1)
-        HGX_CLASSIFY(true, 1);
-    else if (classifyWaves == 7)
-        HGX_CLASSIFY(true, 7);
-    else if (classifyWaves == 8)
-        HGX_CLASSIFY(true, 8);
     else
-        HGX_CLASSIFY(true, 6);
+        HGX_CLASSIFY(true, 6); // (80 VGPRs; compiled for 1 / 7 / 8 wavefronts per SIMD it took 0.056 / 0.058 / 0.085 ms against 0.054)
 #undef HGX_CLASSIFY
     P.timer.end(s);
     ++launch;
@@ -758,7 +748,7 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
     unsigned long long *cnt = (unsigned long long *)P.counters.p;
     const uint32_t cap = P.cap;
     const uint32_t nq = (uint32_t)n;
-    if (P.composed && P.composed->mRecs && !P.opts.emit_blocks && !P.mergedDisabled && !P.mergedOffThisRun && !P.captureUp && !P.captureFinal) {
+    if (P.composed && P.composed->mRecs && !P.opts.emit_blocks && !P.mergedOffThisRun && !P.captureUp && !P.captureFinal) {
         runMergedOnce(P, n, dS, dE, dStrand, s, hostCounters);
         return;
     }
@@ -1146,7 +1136,7 @@ static void runPlan(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
     for (;;) {
         runOnce<C>(P, n, dS, dE, dStrand, s, hc);
         if (!hc[CNT_OVERFLOW]) {
-            const bool merged = P.composed && P.composed->mRecs && !P.opts.emit_blocks && !P.mergedDisabled && !P.mergedOffThisRun;
+            const bool merged = P.composed && P.composed->mRecs && !P.opts.emit_blocks && !P.mergedOffThisRun;
             if (merged && hc[CNT_DEFERRED] && (hc[CNT_BIGFAIL] || hc[CNT_DEFERRED] > P.liftBigSlots)) {
                 // intervals outgrew the LDS finishing kernel and the scratch area of k_finish_big was too small (or not there
                 // yet): size it from what this run needed and repeat the batch
@@ -1191,7 +1181,7 @@ static void runPlan(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
     const uint32_t nq = (uint32_t)n;
     const DeviceGenome &TG = D.genomes[(size_t)P.tgt];
     unsigned long long *cnt = (unsigned long long *)P.counters.p;
-    const bool mergedRun = P.composed && P.composed->mRecs && !P.opts.emit_blocks && !P.mergedDisabled && !P.mergedOffThisRun;
+    const bool mergedRun = P.composed && P.composed->mRecs && !P.opts.emit_blocks && !P.mergedOffThisRun;
     // (a single-pass run has finished its deferred intervals itself and placed their records)
     const uint32_t nDeferredSeen = (uint32_t)hc[CNT_DEFERRED];
     const uint32_t nDef = mergedRun ? 0u : nDeferredSeen;
@@ -1261,7 +1251,7 @@ static void runPlan(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
     P.stats.composed_records = P.composed ? P.composed->numRecs : 0;
     P.stats.composed_build_ms = P.composed ? P.composed->buildMs : 0;
     P.stats.composed_kind = P.composed ? (P.composed->through ? 2 : 1) : 0;
-    if (P.composed && P.composed->mRecs && !P.opts.emit_blocks && !P.mergedDisabled && !P.mergedOffThisRun) {
+    if (P.composed && P.composed->mRecs && !P.opts.emit_blocks && !P.mergedOffThisRun) {
         P.stats.composed_kind = 3;
         P.stats.composed_records = P.composed->mNum;
         P.stats.composed_build_ms = P.composed->buildMs + P.composed->mBuildMs;
@@ -1709,7 +1699,7 @@ void submitLiftoverPlan(hgx_liftover_plan *p, size_t n, const int64_t *dS, const
     P.pendingStrand = dStrand;
     P.pendingStream = (hipStream_t)stream;
     const bool steady = n > 0 && n <= P.maxQueries && n < ((size_t)1 << 31) && P.composed && P.composed->mRecs && !P.opts.emit_blocks &&
-                        !P.mergedDisabled && !P.h->dev->wide && P.timer.mode == 0 && !P.captureUp && !P.captureFinal && P.liftStateClean;
+                        !P.h->dev->wide && P.timer.mode == 0 && !P.captureUp && !P.captureFinal && P.liftStateClean;
     if (!steady) {
         runLiftoverPlan(p, n, dS, dE, dStrand, stream, &P.pendingOut, &P.pendingCount);
         P.pendingState = 2;
