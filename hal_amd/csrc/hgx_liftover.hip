@@ -1748,6 +1748,8 @@ void collectLiftoverPlan(hgx_liftover_plan *p, const hgx_record **dOut, size_t *
 
 void runLiftoverPlan(hgx_liftover_plan *p, size_t n, const int64_t *dS, const int64_t *dE, const uint8_t *dStrand, void *stream,
                      const hgx_record **dOut, size_t *nOut) {
+    if (p->pendingState == 1) // (its workspaces and its output belong to the batch in flight)
+        throw std::runtime_error("the plan has a submitted batch that has not been collected");
     if (p->h->dev->wide)
         runPlan<int64_t>(*p, n, dS, dE, dStrand, (hipStream_t)stream, dOut, nOut);
     else
@@ -1758,6 +1760,8 @@ void destroyLiftoverPlan(hgx_liftover_plan *p) {
     if (!p)
         return;
     (void)hipSetDevice(p->device);
+    if (p->pendingState == 1) // (a submitted batch nobody collected: its launches read and write the plan's workspaces)
+        (void)hipStreamSynchronize(p->pendingStream);
     delete p;
 }
 
