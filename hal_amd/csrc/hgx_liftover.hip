@@ -1699,7 +1699,7 @@ void submitLiftoverPlan(hgx_liftover_plan *p, size_t n, const int64_t *dS, const
     P.pendingStrand = dStrand;
     P.pendingStream = (hipStream_t)stream;
     const bool steady = n > 0 && n <= P.maxQueries && n < ((size_t)1 << 31) && P.composed && P.composed->mRecs && !P.opts.emit_blocks &&
-                        !P.h->dev->wide && P.timer.mode == 0 && !P.captureUp && !P.captureFinal && P.liftStateClean;
+                        !P.h->dev->wide && P.timer.mode == 0 && !P.captureUp && !P.captureFinal;
     if (!steady) {
         runLiftoverPlan(p, n, dS, dE, dStrand, stream, &P.pendingOut, &P.pendingCount);
         P.pendingState = 2;
@@ -1725,7 +1725,9 @@ void collectLiftoverPlan(hgx_liftover_plan *p, const hgx_record **dOut, size_t *
     }
     std::vector<unsigned long long> hc(CNT_SLOTS);
     finishMergedOnce(P, P.pendingStream, hc.data());
-    if (hc[CNT_OVERFLOW] || hc[CNT_DEFERRED] || P.liftRestCount) { // (rare: the batch again, through every repeat path runPlan has)
+    // (runPlan's conditions for repeating a batch: buffers too small, the scratch of k_finish_big too small, intervals passed on
+    // to launches that were not made — rare: the batch again, through every repeat path runPlan has)
+    if (hc[CNT_OVERFLOW] || (hc[CNT_DEFERRED] && (hc[CNT_BIGFAIL] || hc[CNT_DEFERRED] > P.liftBigSlots)) || (P.liftRestCount && P.liftRestSkipped)) {
         runLiftoverPlan(p, P.pendingN, P.pendingS, P.pendingE, P.pendingStrand, P.pendingStream, dOut, nOut);
         return;
     }
@@ -1737,6 +1739,9 @@ void collectLiftoverPlan(hgx_liftover_plan *p, const hgx_record **dOut, size_t *
         P.stats.bottom_derefs += hc[CNT_KSTAT0 + 2 * k + 1];
     }
     P.stats.records = (uint32_t)(P.pinned[CNT_SLOTS] & 0xFFFFFFFFull);
+    P.stats.deferred_queries = (uint32_t)hc[CNT_DEFERRED];
+    if (P.liftRestCount)
+        P.liftRestSeen = true;
     P.stats.composed_kind = 3;
     P.stats.composed_records = P.composed->mNum;
     P.stats.composed_build_ms = P.composed->buildMs + P.composed->mBuildMs;
