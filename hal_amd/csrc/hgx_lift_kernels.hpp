@@ -1,12 +1,13 @@
 // The single-pass liftover kernels over the MERGED table (hgx_merged_kernels.hpp): BlockLiftover::liftInterval
 // (liftover/impl/halBlockLiftover.cpp:46-113) for a batch of intervals — toSite, the per-source-segment halMapSegment calls,
 // insertAndBreakOverlaps, extractSegment, the stable sort on the source start (liftover/impl/halLiftover.cpp:90) — as
-//   k_lift_classify   per interval: one look at the bucket table (where its records start, how many can be in reach, whether
-//                     it must go the general way — hgx_finish_kernel.hpp, over the unmerged table, which the wavefront that
-//                     meets such an interval does on the spot) and a first walk over its records that counts its output
-//                     lines; per tile of 256 intervals and per group of 64 tiles: the number of lines;
-//   k_lift_merged     reads the records a second time (they are in the L2 by then), clips them, orders them, and writes the
-//                     hgx_records of the whole batch densely and in input order — once.
+//   k_lift_classify   per interval: one look at the bucket table (where its records start) and a walk over its records that
+//                     counts its output lines and finds out whether it must go the general way — hgx_finish_kernel.hpp, over
+//                     the unmerged table, which the wavefront that meets such an interval does on the spot; per wavefront:
+//                     the lines of its 64 intervals;
+//   k_lift_totals     one workgroup: the lines of every group of 64 tiles, all lines, the statistics, the host's report;
+//   k_lift_merged     reads the records a second time, clips them, orders them, and writes the hgx_records of the whole batch
+//                     densely and in input order — once.
 // An unflagged interval's records have pairwise disjoint target ranges, so (see hgx_merged_kernels.hpp) its output lines
 // are exactly its records clipped to it.  The reference prints them stably sorted by source start, ties in target order:
 // the table is sorted by (source start, target start), so the clipped records already come in that order except for the
@@ -14,8 +15,8 @@
 // target start among themselves (they are the first of the interval's records; usually there is one).
 //
 // Dense output in input order needs every interval's offset = the number of lines of all intervals before it.  The count
-// and the store are two launches, so the store knows every tile's count when it starts: a workgroup adds up the counts of
-// the groups before its tile's group and of the tiles before its tile in the group (two 64-wide reads) — no waiting.  (The
+// and the store are two launches, so the store knows every count when it starts: a workgroup adds up the counts of the groups
+// before its tile's group and of the wavefronts before its tile in the group (two reads, DPP sums) — no waiting.  (The
 // one-launch form of this — count, publish, decoupled look-back, store — spent 44 % of its wavefronts' cycles waiting for
 // the slowest of the 64 tiles in front: profiles/r02k_notes.md.)
 #pragma once
