@@ -52,3 +52,51 @@ def test_two_plans_two_streams(hal):
     assert plans[0].stats()["composed_kind"] == 3
     with pytest.raises(hal.HgxError):
         plans[0].collect()
+
+
+def test_batches_with_long_intervals_in_flight(hal):
+    """A 50-genome alignment whose intervals reach sets of more than 64 pieces (the LDS and global-scratch finishing kernels
+    run inside the single-pass launch sequence, and collect repeats a batch whose scratch was too small): submit / collect
+    against run_device."""
+    import torch
+    opts = hal.RandOptions(mean_degree=2.0, max_branch_length=3.0, min_genomes=2, max_genomes=50, min_segment_length=20,
+                           max_segment_length=80, min_segments=1500, max_segments=3000, seed=0, with_dna=False)
+    al = hal.Alignment.random(opts, device=0)
+    names = [al.genome_name(g) for g in range(al.num_genomes)]
+    src = al.genome_id("Genome_44") if "Genome_44" in names else al.num_genomes - 1
+    tgt = al.genome_id("Genome_2")
+    _, ss, length = al.sequences(src)[0]
+    n = 30000
+    batches = []
+    for b in range(4):
+        g = torch.Generator().manual_seed(200 + b)
+        maxlen = (300, 3000, 300, 12000)[b]
+        starts = torch.randint(0, max(1, length - maxlen - 1), (n,), generator=g)
+        lens = torch.randint(1, maxlen, (n,), generator=g)
+        st = torch.where(torch.rand(n, generator=g) < 0.5, ord("+"), ord("-")).to(torch.uint8).cuda()
+        batches.append(((starts + ss).cuda(), (starts + lens - 1 + ss).clamp(max=ss + length - 1).cuda(), st))
+    ref_plan = hal.LiftoverPlan(al, src, tgt, max_queries=n)
+    want = []
+    for gs, ge, st in batches * 2:
+        ptr, nrec = ref_plan.run(gs, ge, st)
+        want.append(ref_plan.records_to_tensor(ptr, nrec).cpu())
+    assert ref_plan.stats()["composed_kind"] == 3
+    plans = [hal.LiftoverPlan(al, src, tgt, max_queries=n) for _ in range(2)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    inflight = [None, None]
+    deferred = 0
+    for i, (gs, ge, st) in enumerate(batches * 2):
+        k = i & 1
+        if inflight[k] is not None:
+            ptr, nrec = plans[k].collect()
+            deferred += plans[k].stats()["deferred_queries"]
+            with torch.cuda.stream(streams[k]):
+                assert torch.equal(plans[k].records_to_tensor(ptr, nrec).cpu(), want[inflight[k]]), inflight[k]
+        plans[k].submit(gs, ge, st, stream=streams[k])
+        inflight[k] = i
+    for k in range(2):
+        ptr, nrec = plans[k].collect()
+        with torch.cuda.stream(streams[k]):
+            assert torch.equal(plans[k].records_to_tensor(ptr, nrec).cpu(), want[inflight[k]]), inflight[k]
+    assert ref_plan.stats()["general_queries"] > 0
