@@ -541,6 +541,7 @@ def main():
             col_gbs = col_bytes / world / (col_ms * 1e-3) / 1e9
             col_kernel = "k_sweep_up"  # (requests of a million columns or more take the tree sweeps; k_depth_runs otherwise)
             col_traffic, col_src = pmc_traffic(col_kernel)
+            sweep_bytes = sweep_design_bytes(al, src)
             out["columns"] = {"metric": "alignment-depth columns/sec (ColumnIterator closure per reference base)",
                               "value": ncol / (col_ms * 1e-3), "unit": "columns/s", "columns": ncol, "kernel_ms": col_ms,
                               "n_gpus": world, "all_gather_ms": gather_ms,
@@ -549,9 +550,16 @@ def main():
                                            "unit": "GB/s", "frac": col_gbs / HBM_PEAK_GBS, "traffic": col_traffic, "traffic_source": col_src,
                                            "algorithmic_bytes_per_launch": col_bytes / world,
                                            "top_derefs": cst["top_derefs"], "bottom_derefs": cst["bottom_derefs"],
+                                           "sweeps_own_bytes": sweep_bytes,
+                                           "sweeps_own_GBs": sweep_bytes / (col_ms * 1e-3) / 1e9 if world == 1 else None,
+                                           "sweeps_own_frac": sweep_bytes / (col_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if world == 1 else None,
                                            "note": "achieved = SURVEY 8(d)'s 25 B per segment record of the closure (counted by the column walk's "
                                                    "counting instantiation) + 4 B per column, over the time of all sweep kernels of one call "
-                                                   "(k_sweep_fill/up/top/down/out); traffic: k_sweep_up launches only; per-GPU figures when n_gpus > 1"}}
+                                                   "(k_sweep_fill/up/top/down/out) — the reference's per-column walk priced at the sweeps' time: an effective rate, "
+                                                   "above the peak where a sweep visits a segment record once and the walk visits it from every reference "
+                                                   "piece that reaches it (50-genome alignments).  sweeps_own_*: what the two sweeps themselves must move "
+                                                   "(bench.py: sweep_design_bytes: the per-base genome-set tracks written and read once, the segment "
+                                                   "records, the 4-byte depths).  traffic: k_sweep_up launches only; per-GPU figures when n_gpus > 1"}}
         if want_maf:
             # BASELINE config 3: hal2maf --refGenome <leaf> --noAncestors, end to end (column kernels, row fetch, block state
             # machine, text rendering) over the first N reference columns
@@ -616,6 +624,38 @@ def main():
     sys.stdout.flush()
     if result_line is not None:
         print(result_line, flush=True)
+
+
+def sweep_design_bytes(al, ref):
+    """What halAlignmentDepth's two tree sweeps (hgx_columns.hip: sweepTracks) must move for a scan of genome `ref` with every genome
+    in scope: bottom-up, every genome with children writes its per-base genome-set track once and reads its children's (a child
+    without children of its own carries a constant: no track), with one bottom-segment record and child link per segment and child
+    and one top-segment record per child segment; top-down along the path root -> ref, a genome reads its parent's and its own
+    track (or depth) and writes its 4-byte depth per base; the result is read and written once."""
+    n = al.num_genomes
+    word = 1 if n <= 8 else 2 if n <= 16 else 4 if n <= 32 else 8
+    has_track = [len(al.genome_children(g)) > 0 for g in range(n)]
+    total = 0.0
+    for g in range(n):
+        kids = al.genome_children(g)
+        if not kids:
+            continue
+        total += word * al.genome_length(g)  # its own track
+        total += al.num_bottom_segments(g) * (8.0 + 4.0 * len(kids))  # BotRec + child links
+        for c in kids:
+            total += 16.0 * al.num_top_segments(c)  # the child's TopRec
+            if has_track[c]:
+                total += word * al.genome_length(c)
+    path = [ref]
+    while al.genome_parent(path[-1]) >= 0:
+        path.append(al.genome_parent(path[-1]))
+    for c in path[:-1]:  # (every genome on the path below the root)
+        p = al.genome_parent(c)
+        total += 16.0 * al.num_top_segments(c) + 8.0 * al.num_top_segments(c)  # TopRec + the parent's BotRec behind it
+        total += (word if has_track[c] else 0) * al.genome_length(c) + 4.0 * al.genome_length(c)  # own track, depth written
+        total += (4.0 if al.genome_parent(p) >= 0 else word) * al.genome_length(c)  # the parent's depth (the root's: its track)
+    total += 8.0 * al.genome_length(ref)  # depth read, result written
+    return total
 
 
 def plan_kernel_bytes(kt, st, steps):
