@@ -165,10 +165,11 @@ typedef struct hgx_liftover_stats {
      * source top segment runs through the walk kernels as one interval, the pieces are radix-sorted by source position;
      * about the cost of walking one interval per source segment):
      *   composed_kind 3 — the MERGED table of the whole path: the pieces of kind 2 joined into the maximal chains that
-     *                     canMergeRightWith would merge (rows of a chain file).  One kernel classifies the intervals, one
-     *                     writes every record at its final place; intervals that may need overlap breaking (a record in
-     *                     reach whose target overlaps that of a record nearby in the source; general_queries of them)
-     *                     take the kind-2 route inside the same run.  32-bit coordinates only; HGX_MERGED=0 forbids it;
+     *                     canMergeRightWith would merge (rows of a chain file).  One launch counts every interval's
+     *                     lines, one writes every record at its final place; intervals that may need overlap breaking (one
+     *                     of their records overlaps on the target with a record nearby in the source; general_queries of
+     *                     them) are finished from the kind-2 table inside the counting launch.  32-bit coordinates only;
+     *                     HGX_MERGED=0 forbids it;
      *   composed_kind 2 — the table of the whole path source -> MRCA -> target (paralogy rings and coalescenceLimit
      *                     included): an interval is one lookup plus the grouping / merging step;
      *   composed_kind 1 — the up table source -> MRCA (when the target is the MRCA itself, or HGX_COMPOSED_THROUGH=0):
