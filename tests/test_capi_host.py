@@ -39,6 +39,20 @@ def test_compute_fails_loudly_without_device(hal, tmp_path):
         hal.liftover_convert(al, 1, "Sequence\t0\t20\n", 0)
 
 
+def test_submit_and_collect_refuse_null_plans(hal):
+    """the two halves of hgx_liftover_run_device report errors across the ABI like every other entry point"""
+    import ctypes as C
+    from hal_amd import _lib
+    err, out, n = C.c_void_p(), C.c_void_p(), C.c_size_t()
+    assert _lib.lib.hgx_liftover_submit(None, 0, None, None, None, None, C.byref(err)) != 0
+    assert b"null argument" in C.string_at(err.value)
+    _lib.lib.hgx_free(err)
+    err = C.c_void_p()
+    assert _lib.lib.hgx_liftover_collect(None, C.byref(out), C.byref(n), C.byref(err)) != 0
+    assert b"null argument" in C.string_at(err.value)
+    _lib.lib.hgx_free(err)
+
+
 def test_metadata_getters(hal, tmp_path):
     img = str(tmp_path / "hand.hgx")
     halfix.write_hgx(img, hb.genomes())
