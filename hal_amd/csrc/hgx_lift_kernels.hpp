@@ -82,10 +82,10 @@ struct LiftOr {
 };
 
 // what one lane of a quad has seen of its interval's records
-struct LiftScan {
+template <typename C> struct LiftScan {
     uint32_t cnt = 0, flags = 0, first = 0xFFFFFFFFu, last = 0;
     bool cont = false; // the quad's fourth record still begins inside the interval: four more
-    __device__ __forceinline__ void take(const ComposedRec<int32_t> &r, uint32_t idx, int32_t gs, int32_t ge) {
+    __device__ __forceinline__ void take(const ComposedRec<C> &r, uint32_t idx, C gs, C ge) {
         const bool more = r.sLo <= ge;
         const bool ov = more && r.sLo + r.len - 1 >= gs;
         if (ov) {
@@ -96,6 +96,12 @@ struct LiftScan {
         }
         cont = quad_dpp<QUAD_LANE3>(more ? 1u : 0u) != 0;
     }
+};
+// what the quads need to know of an interval: where its records start, its first and last base (one ds_read_b128 with 32-bit
+// coordinates, two with 64-bit ones)
+template <typename C> struct alignas(16) LiftAsk {
+    C gs, ge;
+    uint32_t k0, _pad;
 };
 
 // k_lift_classify, a workgroup per tile: kb[q] = {first record that overlaps interval q, number of records from there to the
@@ -113,18 +119,19 @@ struct LiftScan {
 //   add their lines to the totals.  A general interval costs its own wavefront a handful of dependent memory round trips;
 //   in a launch of their own the same round trips were the batch's critical path.
 //   !INLINE (HGX_FINISH_WAVE=0, a cross-check): all of them are listed.
-template <bool INLINE, int MINW>
+template <typename C, bool INLINE, int MINW>
 static __global__ void __launch_bounds__(256, MINW) k_lift_classify(const int64_t *__restrict__ gStart, const int64_t *__restrict__ gEnd,
                                                               const uint8_t *__restrict__ strand, uint32_t nq, int64_t genomeLength,
                                                               const uint32_t *__restrict__ coarse, int shift, int64_t window,
-                                                              const ComposedRec<int32_t> *__restrict__ recs, uint2 *__restrict__ kb,
-                                                              GeneralTable<int32_t> GT, unsigned long long *kstat, unsigned long long *kstatStore,
+                                                              const ComposedRec<C> *__restrict__ recs, uint2 *__restrict__ kb,
+                                                              GeneralTable<C> GT, unsigned long long *kstat, unsigned long long *kstatStore,
                                                               uint32_t *__restrict__ offset,
                                                               uint32_t *__restrict__ nOut, uint32_t *__restrict__ lateList,
                                                               unsigned long long *__restrict__ lateCount, uint32_t *__restrict__ waveTotal) {
-    __shared__ int32_t sDAll[INLINE ? 4 : 1][INLINE ? 128 : 1];
+    __shared__ C sDAll[INLINE ? 4 : 1][INLINE ? 128 : 1];
     __shared__ uint8_t sOwnAll[INLINE ? 4 : 1][INLINE ? 64 : 1];
-    __shared__ uint4 sAsk[4][64], sAnswer[4][64];
+    __shared__ LiftAsk<C> sAsk[4][64];
+    __shared__ uint4 sAnswer[4][64];
     const int lane = lane_id(), w = (int)(threadIdx.x >> 6);
     const int quad = lane >> 2, c = lane & 3;
     uint32_t generalSeen = 0, used = 0, generalLines = 0;
@@ -140,32 +147,32 @@ static __global__ void __launch_bounds__(256, MINW) k_lift_classify(const int64_
         const bool valid = ge >= gs && gs >= 0 && gs < genomeLength;
         // (an interval that is not valid asks for nothing: no record begins at or before base -1)
         const uint32_t k0 = valid ? coarse[gs >> shift] : 0u;
-        // (the scan stops at the first record that begins behind ge32: below the sentinels' 2^31 - 1 whatever the interval says)
-        const int32_t gs32 = valid ? (int32_t)gs : 0, ge32 = valid ? (int32_t)(ge < genomeLength ? ge : genomeLength - 1) : -1;
-        sAsk[w][lane] = make_uint4(k0, (uint32_t)gs32, (uint32_t)ge32, 0u);
+        // (the scan stops at the first record that begins behind geC: below the sentinels' start whatever the interval says)
+        const C gsC = valid ? (C)gs : (C)0, geC = valid ? (C)(ge < genomeLength ? ge : genomeLength - 1) : (C)-1;
+        sAsk[w][lane] = LiftAsk<C>{gsC, geC, k0, 0u};
         wave_lds_fence();
         LIFT_PROF(0) // the intervals and their bucket entries have arrived
         // ---- the scan: quad `quad` of round `it` works for the interval of lane 16 * it + quad ----
-        uint4 ask[4];
-        ComposedRec<int32_t> r[4];
-        LiftScan sc[4];
+        LiftAsk<C> ask[4];
+        ComposedRec<C> r[4];
+        LiftScan<C> sc[4];
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             ask[it] = sAsk[w][16 * it + quad];
-            r[it] = recs[ask[it].x + (uint32_t)c];
+            r[it] = recs[ask[it].k0 + (uint32_t)c];
         }
 #pragma unroll
         for (int it = 0; it < 4; ++it)
-            sc[it].take(r[it], ask[it].x + (uint32_t)c, (int32_t)ask[it].y, (int32_t)ask[it].z);
+            sc[it].take(r[it], ask[it].k0 + (uint32_t)c, ask[it].gs, ask[it].ge);
         for (uint32_t trip = 1; trip < LIFT_MAX_BOUND / 4 && __any(sc[0].cont || sc[1].cont || sc[2].cont || sc[3].cont); ++trip) {
 #pragma unroll
             for (int it = 0; it < 4; ++it)
                 if (sc[it].cont)
-                    r[it] = recs[ask[it].x + 4u * trip + (uint32_t)c];
+                    r[it] = recs[ask[it].k0 + 4u * trip + (uint32_t)c];
 #pragma unroll
             for (int it = 0; it < 4; ++it)
                 if (sc[it].cont) // (quad-uniform)
-                    sc[it].take(r[it], ask[it].x + 4u * trip + (uint32_t)c, (int32_t)ask[it].y, (int32_t)ask[it].z);
+                    sc[it].take(r[it], ask[it].k0 + 4u * trip + (uint32_t)c, ask[it].gs, ask[it].ge);
         }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
@@ -195,7 +202,7 @@ static __global__ void __launch_bounds__(256, MINW) k_lift_classify(const int64_
                 const int64_t os = wave_read<int64_t>(gs, o), oe = wave_read<int64_t>(ge, o);
                 int nl = 0;
                 uint32_t base = 0;
-                const int rc = general_interval<int32_t>(lane, GT, oq, os, oe, strand[oq], sDAll[w], sOwnAll[w], used, nl, base LIFT_PROF_ARG);
+                const int rc = general_interval<C>(lane, GT, oq, os, oe, strand[oq], sDAll[w], sOwnAll[w], used, nl, base LIFT_PROF_ARG);
                 if (lane == 0) {
                     if (rc == 0) // (its lines come later, or not at all: a run that does not make the launches behind this one is repeated)
                         lateList[atomicAdd(lateCount, 1ull)] = oq;
@@ -228,15 +235,39 @@ static __global__ void __launch_bounds__(256, MINW) k_lift_classify(const int64_
     stat_add(&GT.counters[CNT_DSTAT0 + STAT_MAPPED], used);
 }
 
-// what a record lane needs to know about the interval that owns its slot (one ds_read_b128)
+// what a record lane needs to know about the interval that owns its slot (one ds_read_b128 with 32-bit coordinates, two with
+// 64-bit ones)
 //   x: first record of the interval - its first slot (so that record = x + slot), y: its first slot,
-//   z: first base | minus strand << 31, w: last base | '.' strand << 31
+//   32-bit: z: first base | minus strand << 31, w: last base | '.' strand << 31;  64-bit: the bases and the two bits apart
+template <typename C> struct LiftIv;
+template <> struct alignas(16) LiftIv<int32_t> {
+    uint32_t x, y, z, w;
+    static __device__ __forceinline__ LiftIv make(uint32_t x, uint32_t y, int32_t gs, int32_t ge, uint32_t minus, uint32_t dot) {
+        return LiftIv{x, y, ((uint32_t)gs & 0x7FFFFFFFu) | (minus << 31), ((uint32_t)ge & 0x7FFFFFFFu) | (dot << 31)};
+    }
+    __device__ __forceinline__ int32_t gs() const { return (int32_t)(z & 0x7FFFFFFFu); }
+    __device__ __forceinline__ int32_t ge() const { return (int32_t)(w & 0x7FFFFFFFu); }
+    __device__ __forceinline__ uint32_t minus() const { return z >> 31; }
+    __device__ __forceinline__ uint32_t dot() const { return w >> 31; }
+};
+template <> struct alignas(16) LiftIv<int64_t> {
+    uint32_t x, y, fl, _pad;
+    int64_t s, e;
+    static __device__ __forceinline__ LiftIv make(uint32_t x, uint32_t y, int64_t gs, int64_t ge, uint32_t minus, uint32_t dot) {
+        return LiftIv{x, y, minus | (dot << 1), 0u, gs, ge};
+    }
+    __device__ __forceinline__ int64_t gs() const { return s; }
+    __device__ __forceinline__ int64_t ge() const { return e; }
+    __device__ __forceinline__ uint32_t minus() const { return fl & 1u; }
+    __device__ __forceinline__ uint32_t dot() const { return (fl >> 1) & 1u; }
+};
 static constexpr uint32_t LIFT_STRIP = 512 + 64; // slots whose owners are looked up from one scatter (bytes of LDS per wavefront)
 
 // Pass 2, one record per lane, in rounds of up to 64 record slots: consecutive intervals share a round as long as their
 // records fit.  sStrip maps record slots to owner lanes (owners mark their first slot — once per 512 slots, not per round —
 // and a running maximum spreads the marks to the right); sIv / sOff hold the owners' interval data and first output line.
-__device__ __forceinline__ void lift_wave_emit(const ComposedRec<int32_t> *__restrict__ recs, uint8_t *sStrip, const uint4 *sIv,
+template <typename C>
+__device__ __forceinline__ void lift_wave_emit(const ComposedRec<C> *__restrict__ recs, uint8_t *sStrip, const LiftIv<C> *sIv,
                                                const uint32_t *sOff, const int lane, const uint32_t b, const uint32_t p,
                                                const uint32_t totalSlots, const uint32_t firstQuery, const int64_t *__restrict__ tSeqStart,
                                                const int64_t ss0, const bool oneSeq, hgx_record *__restrict__ out) {
@@ -265,23 +296,23 @@ __device__ __forceinline__ void lift_wave_emit(const ComposedRec<int32_t> *__res
         const uint32_t mark = wave_incl_scan<LiftMax>((uint32_t)sStrip[base - windowBase + (uint32_t)lane]);
         const bool slotValid = base + (uint32_t)lane < nextBase && mark > 0;
         const int owner = mark > 0 ? (int)mark - 1 : 0;
-        const uint4 iv = sIv[owner];
+        const LiftIv<C> iv = sIv[owner];
         const uint32_t oOff = sOff[owner];
-        const int32_t oGs = (int32_t)(iv.z & 0x7FFFFFFFu), oGe = (int32_t)(iv.w & 0x7FFFFFFFu);
+        const C oGs = iv.gs(), oGe = iv.ge();
         const uint32_t lo = (iv.y - base) & 63u; // first slot of my interval in this round
-        ComposedRec<int32_t> r{};
+        ComposedRec<C> r{};
         if (slotValid)
             r = recs[iv.x + base + (uint32_t)lane];
-        const int32_t pLo = r.sLo, pHi = r.sLo + r.len - 1;
+        const C pLo = r.sLo, pHi = r.sLo + r.len - 1;
         const bool emit = slotValid && pLo <= oGe && pHi >= oGs;
         const unsigned long long em = __ballot(emit);
         // lines of my interval before me (the table's order)
         const unsigned long long mine = em & ~((1ull << lo) - 1ull); // (records of earlier intervals sit below lo)
         uint32_t pos = (uint32_t)__popcll(mine & below);
-        const int32_t c = pLo > oGs ? pLo : oGs, d = pHi < oGe ? pHi : oGe;
-        const int32_t n = d - c + 1, delta = c - pLo;
+        const C c = pLo > oGs ? pLo : oGs, d = pHi < oGe ? pHi : oGe;
+        const C n = d - c + 1, delta = c - pLo;
         const uint32_t trev = r.mEncF & 1u;
-        const int32_t tLo = r.so + (trev ? r.len - delta - n : delta);
+        const C tLo = r.so + (trev ? r.len - delta - n : delta);
         // records that begin at or before the interval's first base all start there after clipping: among themselves
         // they go by target start.  They are the first lines of the interval; more than one only with paralogs.
         const bool inGroup = emit && pLo <= oGs;
@@ -293,7 +324,7 @@ __device__ __forceinline__ void lift_wave_emit(const ComposedRec<int32_t> *__res
             for (int jj = 0; jj < span; ++jj) {
                 const int partner = (int)lo + jj;
                 const int pGroup = __shfl((int)inGroup, partner & 63);
-                const int32_t pT = __shfl(tLo, partner & 63);
+                const C pT = wave_pull<C>(tLo, partner & 63);
                 if (inGroup && (uint32_t)jj < oB && partner < 64 && pGroup && pT < tLo)
                     ++rank;
             }
@@ -303,14 +334,14 @@ __device__ __forceinline__ void lift_wave_emit(const ComposedRec<int32_t> *__res
         if (emit) {
             const uint32_t seq = r.mEncF >> 8;
             const int64_t ss = oneSeq ? ss0 : tSeqStart[seq];
-            const uint32_t rev = trev ^ (iv.z >> 31);
+            const uint32_t rev = trev ^ iv.minus();
             hgx_record rec;
             rec.query = (int64_t)(firstQuery + (uint32_t)owner);
             rec.tgt_start = (int64_t)tLo - ss;
             rec.tgt_end = (int64_t)tLo + n - ss;
             rec.src_start = (int64_t)c;
             rec.tgt_seq = (int32_t)seq;
-            rec.strand = (iv.w >> 31) ? '.' : (rev ? '-' : '+');
+            rec.strand = iv.dot() ? '.' : (rev ? '-' : '+');
             rec.tgt_reversed = (uint8_t)rev;
             rec._pad[0] = rec._pad[1] = 0;
             out[oOff + pos] = rec;
@@ -322,17 +353,17 @@ __device__ __forceinline__ void lift_wave_emit(const ComposedRec<int32_t> *__res
 // kb, nOut, waveTotal, groupTotal: k_lift_classify's and k_lift_totals' answers; genOffset /
 // genRecords: where the general path left the records of the general intervals (nOut[q] records at genRecords +
 // genOffset[q]); out / outCap: the dense output; outOffset[q]: first record of interval q in it.
-template <int MINW>
+template <typename C, int MINW>
 static __global__ void __launch_bounds__(256, MINW) k_lift_merged(const int64_t *__restrict__ gStart, const int64_t *__restrict__ gEnd,
                                                             const uint8_t *__restrict__ strand, uint32_t nq, const uint2 *__restrict__ kb,
-                                                            const ComposedRec<int32_t> *__restrict__ recs, const int64_t *__restrict__ tSeqStart,
+                                                            const ComposedRec<C> *__restrict__ recs, const int64_t *__restrict__ tSeqStart,
                                                             int tNumSeq, const uint32_t *__restrict__ genOffset,
                                                             const hgx_record *__restrict__ genRecords, hgx_record *__restrict__ out,
                                                             uint32_t outCap, const uint32_t *__restrict__ nOut, uint32_t *__restrict__ outOffset,
                                                             const uint32_t *__restrict__ waveTotal,
                                                             const unsigned long long *__restrict__ groupTotal, uint32_t nTiles) {
     __shared__ __attribute__((aligned(16))) uint8_t sStripAll[4][LIFT_STRIP];
-    __shared__ uint4 sIvAll[4][64];
+    __shared__ LiftIv<C> sIvAll[4][64];
     __shared__ uint32_t sOffAll[4][64];
     __shared__ uint32_t sWaveTotal[4], sFront[4];
     const int lane = lane_id(), w = (int)(threadIdx.x >> 6);
@@ -343,15 +374,15 @@ static __global__ void __launch_bounds__(256, MINW) k_lift_merged(const int64_t 
         // ---- the workgroup's intervals, one per thread ----
         const uint32_t q = tile * (uint32_t)LIFT_TILE + threadIdx.x;
         uint32_t k = 0, b = 0, flags = 0, cnt = 0, gOff = 0;
-        int32_t gs = 0, ge = -1;
+        C gs = 0, ge = -1;
         bool general = false;
         if (q < nq) {
             const int64_t s64 = gStart[q], e64 = gEnd[q];
             const uint8_t st = strand[q];
             const uint2 x = kb[q];
             cnt = nOut[q];
-            gs = (int32_t)s64;
-            ge = (int32_t)(e64 < 0x7FFFFFFFll ? e64 : 0x7FFFFFFFll);
+            gs = (C)s64;
+            ge = (C)(e64 < (int64_t)LiftCoord<C>::MAXV ? e64 : (int64_t)LiftCoord<C>::MAXV);
             flags = (st == '-' ? 1u : 0u) | (st == '.' ? 2u : 0u);
             k = x.x;
             general = (x.y & KB_GENERAL) != 0;
@@ -372,7 +403,7 @@ static __global__ void __launch_bounds__(256, MINW) k_lift_merged(const int64_t 
         const uint32_t inclSlots = wave_incl_scan<LiftSum>(b);
         const uint32_t p = inclSlots - b, totalSlots = (uint32_t)__builtin_amdgcn_readlane((int)inclSlots, 63);
         const uint32_t inclLines = wave_incl_scan<LiftSum>(cnt);
-        sIvAll[w][lane] = make_uint4(k - p, p, ((uint32_t)gs & 0x7FFFFFFFu) | ((flags & 1u) << 31), ((uint32_t)ge & 0x7FFFFFFFu) | ((flags & 2u) << 30));
+        sIvAll[w][lane] = LiftIv<C>::make(k - p, p, gs, ge, flags & 1u, (flags >> 1) & 1u);
         const uint32_t inFront = wave_total(threadIdx.x < 4u * j ? peerLines : 0u); // of the tiles in front, as far as this wavefront's threads see them
         if (lane == 0)
             sFront[w] = inFront;

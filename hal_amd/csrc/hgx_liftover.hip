@@ -597,13 +597,14 @@ static void exclusiveScan(hgx_liftover_plan &P, const uint32_t *in, uint32_t n, 
 
 static const ComposedUp *ensureComposed(hgx_alignment *h, int src, int dst, bool through, const hgx_liftover_opts &opts, bool wantMerged = true);
 
-// One batch on the single-pass path (32-bit tables): classify, the general intervals through the unmerged table and the
-// LDS finishing kernel, then k_lift_merged writes every record at its final place.  One host synchronisation at the end.
+// One batch on the single-pass path: classify, the general intervals through the unmerged table and the LDS finishing
+// kernel, then k_lift_merged writes every record at its final place.  One host synchronisation at the end.  C: the coordinate
+// type of the alignment's tables (int64 for alignments with a genome of 2^31 bases or more — hal_index_t, api/inc/halDefs.h:34).
 static void finishMergedOnce(hgx_liftover_plan &P, hipStream_t s, unsigned long long *hostCounters);
 // launchOnly: the launches are queued and the function returns; finishMergedOnce waits for them and reads the report
+template <typename C>
 static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int64_t *dE, const uint8_t *dStrand, hipStream_t s,
                           unsigned long long *hostCounters, bool launchOnly = false) {
-    typedef int32_t C;
     const DeviceImage &D = *P.h->dev;
     const ComposedUp &T = *P.composed;
     unsigned long long *cnt = (unsigned long long *)P.counters.p;
@@ -646,13 +647,16 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
     const int storeLaunch = P.liftRestSkipped ? 1 : 2; // k_lift_merged's place among the launches that keep statistics
     P.timer.begin("k_lift_classify", s, launch);
 #define HGX_CLASSIFY(INL, W)                                                                                                                 \
-    hipLaunchKernelGGL((k_lift_classify<INL, W>), dim3(std::max<uint32_t>(1, nTiles)), dim3(256), 0, s, dS, dE, dStrand, nq, srcLength,        \
+    hipLaunchKernelGGL((k_lift_classify<C, INL, W>), dim3(std::max<uint32_t>(1, nTiles)), dim3(256), 0, s, dS, dE, dStrand, nq, srcLength,     \
                        (const uint32_t *)T.mBuckets, T.mShift, T.mWindow, (const ComposedRec<C> *)T.mRecs, (uint2 *)P.liftKb.p, GT, kstat(),    \
                        cnt + CNT_DSTAT0 + STAT_LAUNCH0 + 2 * storeLaunch, (uint32_t *)P.offset.p, (uint32_t *)P.nOut.p, (uint32_t *)lateList, lateCount, waveTotal)
-    if (!waveFinish)
+    if (!waveFinish) {
         HGX_CLASSIFY(false, 1);
-    else
+    } else if constexpr (sizeof(C) == 8) {
+        HGX_CLASSIFY(true, 4); // (64-bit coordinates: twice the registers per record and per piece)
+    } else {
         HGX_CLASSIFY(true, 6); // (80 VGPRs; compiled for 1 / 7 / 8 wavefronts per SIMD it took 0.056 / 0.058 / 0.085 ms against 0.054)
+    }
 #undef HGX_CLASSIFY
     P.timer.end(s);
     ++launch;
@@ -702,7 +706,7 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
     P.timer.end(s);
     P.timer.begin("k_lift_merged", s, launch);
 #define HGX_LIFT(W)                                                                                                                          \
-    hipLaunchKernelGGL((k_lift_merged<W>), dim3(std::min<uint32_t>((uint32_t)P.liftGrid, nTiles)), dim3(256), 0, s, dS, dE, dStrand, nq,        \
+    hipLaunchKernelGGL((k_lift_merged<C, W>), dim3(std::min<uint32_t>((uint32_t)P.liftGrid, nTiles)), dim3(256), 0, s, dS, dE, dStrand, nq,     \
                        (const uint2 *)P.liftKb.p, (const ComposedRec<C> *)T.mRecs, (const int64_t *)TG.seqStart, (int)TG.numSeq,             \
                        (const uint32_t *)P.offset.p, (const hgx_record *)P.grouped.p, (hgx_record *)P.outRecords.p, cap,                     \
                        (const uint32_t *)P.nOut.p, (uint32_t *)P.outOffset.p, waveTotal, groupTotal, nTiles)
@@ -749,7 +753,7 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
     const uint32_t cap = P.cap;
     const uint32_t nq = (uint32_t)n;
     if (P.composed && P.composed->mRecs && !P.opts.emit_blocks && !P.mergedOffThisRun && !P.captureUp && !P.captureFinal) {
-        runMergedOnce(P, n, dS, dE, dStrand, s, hostCounters);
+        runMergedOnce<C>(P, n, dS, dE, dStrand, s, hostCounters);
         return;
     }
     P.liftStateClean = false; // (this run counts in words a single-pass run expects zeroed)
@@ -1499,10 +1503,20 @@ static void sortPairs(DevBuf keys[2], DevBuf vals[2], DevBuf &tmp, size_t n, int
                                               (uint32_t *)vals[1].p, (int)n, 0, endBit, s));
 }
 
+static int bitsOf(int64_t v) { // smallest b with v < 2^b
+    int b = 0;
+    while (b < 63 && (v >> b) != 0)
+        ++b;
+    return b;
+}
+
 // The merged form of a whole-path table (hgx_merged_kernels.hpp): chains of mergeable pieces, flags, bucket tables.  All on
-// the device: two radix sorts over the junction keys and the chains, pointer jumping, a third sort and a running maximum
-// for the flags.  window: HGX_MERGED_WINDOW (default 8192 bases).
-static void buildMerged(hgx_alignment *h, int src, int dst, ComposedUp &c) {
+// the device: radix sorts over the junction keys and the chains, pointer jumping, a sort by target start and a running maximum
+// for the flags.  window: HGX_MERGED_WINDOW (default 8192 bases).  C: the coordinate type of the alignment's tables; the
+// 64-bit tables sort their junctions and chains in two stable passes (a junction does not fit one 64-bit key there).
+template <typename C> static void buildMerged(hgx_alignment *h, int src, int dst, ComposedUp &c) {
+    typedef typename MergeWord<C>::U U;
+    constexpr bool WIDE = sizeof(C) == 8;
     const auto t0 = std::chrono::steady_clock::now();
     const bool timing = getenv("HGX_BUILD_TIMING") != nullptr;
     auto lap = [&, last = t0](const char *what) mutable {
@@ -1515,32 +1529,42 @@ static void buildMerged(hgx_alignment *h, int src, int dst, ComposedUp &c) {
     };
     const DeviceImage &D = *h->dev;
     const GenomeTables &S = h->img.genomes[(size_t)src];
+    const GenomeTables &T = h->img.genomes[(size_t)dst];
     const DeviceGenome &SG = D.genomes[(size_t)src], &TG = D.genomes[(size_t)dst];
     const size_t n = (size_t)c.numRecs;
-    if (n == 0 || n >= ((size_t)1 << 31) || h->img.genomes[(size_t)dst].seqs.size() >= ((size_t)1 << 24))
+    if (n == 0 || n >= ((size_t)1 << 30) || T.seqs.size() >= ((size_t)1 << 24))
         return;
     HIP_OK(hipSetDevice(D.device));
     hipStream_t s = nullptr;
     int64_t window = 8192;
     if (const char *e = getenv("HGX_MERGED_WINDOW"))
         window = std::max<long long>(1, atoll(e));
-    const ComposedRec<int32_t> *recs = (const ComposedRec<int32_t> *)c.recs;
+    const ComposedRec<C> *recs = (const ComposedRec<C> *)c.recs;
+    const int sBits = bitsOf(S.totalLength), tBits = bitsOf(T.totalLength);
     DevBuf keys[2], vals[2], tmp, root, minS, sumLen, scalars;
     for (int k = 0; k < 2; ++k) {
         keys[k].ensure(8 * 2 * n);
         vals[k].ensure(4 * 2 * n);
     }
     root.ensure(4 * n);
-    minS.ensure(4 * n);
-    sumLen.ensure(4 * n);
+    minS.ensure(sizeof(U) * n);
+    sumLen.ensure(sizeof(U) * n);
     scalars.ensure(16);
     const unsigned gridN = (unsigned)((n + 255) / 256), grid2N = (unsigned)((2 * n + 255) / 256);
     lap("allocations");
     // 1. junctions: which piece continues which
-    hipLaunchKernelGGL(k_merge_keys, dim3(gridN), dim3(256), 0, s, recs, (uint32_t)n, (uint64_t *)keys[0].p, (uint32_t *)vals[0].p);
-    sortPairs(keys, vals, tmp, 2 * n, 64, s);
+    if constexpr (!WIDE) {
+        hipLaunchKernelGGL(k_merge_keys, dim3(gridN), dim3(256), 0, s, recs, (uint32_t)n, sBits, (uint64_t *)keys[0].p, (uint32_t *)vals[0].p);
+        sortPairs(keys, vals, tmp, 2 * n, std::min(64, tBits + sBits + 2), s);
+    } else {
+        hipLaunchKernelGGL(k_merge_keys_low, dim3(gridN), dim3(256), 0, s, recs, (uint32_t)n, (uint64_t *)keys[0].p, (uint32_t *)vals[0].p);
+        sortPairs(keys, vals, tmp, 2 * n, std::min(64, sBits + 2), s);
+        hipLaunchKernelGGL(k_merge_keys_high, dim3(grid2N), dim3(256), 0, s, recs, (const uint32_t *)vals[1].p, (uint32_t)(2 * n), (uint64_t *)keys[0].p,
+                           (uint32_t *)vals[0].p);
+        sortPairs(keys, vals, tmp, 2 * n, std::min(64, tBits), s);
+    }
     hipLaunchKernelGGL(k_merge_identity, dim3(gridN), dim3(256), 0, s, (uint32_t *)root.p, (uint32_t)n);
-    hipLaunchKernelGGL(k_merge_link, dim3(grid2N), dim3(256), 0, s, (const uint64_t *)keys[1].p, (const uint32_t *)vals[1].p, (uint32_t)(2 * n), recs,
+    hipLaunchKernelGGL((k_merge_link<C>), dim3(grid2N), dim3(256), 0, s, (const uint32_t *)vals[1].p, (uint32_t)(2 * n), recs,
                        (const int64_t *)TG.seqStart, (int)TG.numSeq, (const int64_t *)SG.seqStart, (int)SG.numSeq, (uint32_t *)root.p);
     lap("junction sort + links");
     // 2. chains: pointer jumping until nothing moves (the flag is read every fourth round)
@@ -1555,47 +1579,50 @@ static void buildMerged(hgx_alignment *h, int src, int dst, ComposedUp &c) {
             break;
     }
     lap("pointer jumping");
-    HIP_OK(hipMemsetAsync(minS.p, 0xFF, 4 * n, s));
-    HIP_OK(hipMemsetAsync(sumLen.p, 0, 4 * n, s));
+    HIP_OK(hipMemsetAsync(minS.p, 0xFF, sizeof(U) * n, s));
+    HIP_OK(hipMemsetAsync(sumLen.p, 0, sizeof(U) * n, s));
     HIP_OK(hipMemsetAsync(scalars.p, 0, 16, s));
-    hipLaunchKernelGGL(k_merge_extent, dim3(gridN), dim3(256), 0, s, recs, (const uint32_t *)root.p, (uint32_t)n, (uint32_t *)minS.p, (uint32_t *)sumLen.p);
-    hipLaunchKernelGGL(k_merge_heads, dim3(gridN), dim3(256), 0, s, recs, (const uint32_t *)root.p, (uint32_t)n, (const uint32_t *)minS.p,
-                       (uint64_t *)keys[0].p, (uint32_t *)vals[0].p, (unsigned int *)scalars.p);
-    sortPairs(keys, vals, tmp, n, 64, s);
+    hipLaunchKernelGGL((k_merge_extent<C>), dim3(gridN), dim3(256), 0, s, recs, (const uint32_t *)root.p, (uint32_t)n, (U *)minS.p, (U *)sumLen.p);
+    if constexpr (!WIDE) {
+        hipLaunchKernelGGL(k_merge_heads, dim3(gridN), dim3(256), 0, s, recs, (const uint32_t *)root.p, (uint32_t)n, (const uint32_t *)minS.p,
+                           (uint64_t *)keys[0].p, (uint32_t *)vals[0].p, (unsigned int *)scalars.p);
+        sortPairs(keys, vals, tmp, n, 64, s);
+    } else {
+        hipLaunchKernelGGL(k_merge_heads_low, dim3(gridN), dim3(256), 0, s, recs, (const uint32_t *)root.p, (uint32_t)n, (uint64_t *)keys[0].p,
+                           (uint32_t *)vals[0].p, (unsigned int *)scalars.p);
+        sortPairs(keys, vals, tmp, n, 64, s);
+        hipLaunchKernelGGL(k_merge_heads_high, dim3(gridN), dim3(256), 0, s, (const uint32_t *)root.p, (const uint32_t *)vals[1].p, (uint32_t)n,
+                           (const unsigned long long *)minS.p, (uint64_t *)keys[0].p, (uint32_t *)vals[0].p);
+        sortPairs(keys, vals, tmp, n, 64, s);
+    }
     unsigned int m32 = 0;
     HIP_OK(hipMemcpyAsync(&m32, scalars.p, 4, hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
     const size_t m = m32;
-    HIP_OK(hipMalloc(&c.mRecs, (m + LIFT_SENTINELS) * sizeof(ComposedRec<int32_t>)));
-    ComposedRec<int32_t> *mrecs = (ComposedRec<int32_t> *)c.mRecs;
+    HIP_OK(hipMalloc(&c.mRecs, (m + LIFT_SENTINELS) * sizeof(ComposedRec<C>)));
+    ComposedRec<C> *mrecs = (ComposedRec<C> *)c.mRecs;
     const unsigned gridM = (unsigned)((m + 255) / 256);
-    hipLaunchKernelGGL(k_merge_records, dim3(gridM), dim3(256), 0, s, recs, (const uint32_t *)vals[1].p, (uint32_t)m, (const uint32_t *)minS.p,
-                       (const uint32_t *)sumLen.p, (const int64_t *)TG.seqStart, (int)TG.numSeq, mrecs);
+    hipLaunchKernelGGL((k_merge_records<C>), dim3(gridM), dim3(256), 0, s, recs, (const uint32_t *)vals[1].p, (uint32_t)m, (const U *)minS.p,
+                       (const U *)sumLen.p, (const int64_t *)TG.seqStart, (int)TG.numSeq, mrecs);
     lap("chains sorted, records");
     // 3. flags: records whose target range overlaps that of a record nearby in the source
     DevBuf flag, flagPrefix, tHi, runMax;
     flag.ensure(4 * (m + 1));
     flagPrefix.ensure(4 * (m + 1));
-    tHi.ensure(4 * m);
-    runMax.ensure(4 * m);
+    tHi.ensure(sizeof(U) * std::max<size_t>(m, 1));
+    runMax.ensure(sizeof(U) * std::max<size_t>(m, 1));
     HIP_OK(hipMemsetAsync(flag.p, 0, 4 * (m + 1), s));
-    hipLaunchKernelGGL(k_flag_keys, dim3(gridM), dim3(256), 0, s, (const ComposedRec<int32_t> *)mrecs, (uint32_t)m, (uint64_t *)keys[0].p);
+    hipLaunchKernelGGL((k_flag_keys<C>), dim3(gridM), dim3(256), 0, s, (const ComposedRec<C> *)mrecs, (uint32_t)m, (uint64_t *)keys[0].p, (uint32_t *)vals[0].p);
+    sortPairs(keys, vals, tmp, m, std::min(64, std::max(1, tBits)), s);
+    hipLaunchKernelGGL((k_flag_ends<C>), dim3(gridM), dim3(256), 0, s, (const ComposedRec<C> *)mrecs, (const uint32_t *)vals[1].p, (uint32_t)m, (U *)tHi.p);
     {
         size_t tmpBytes = 0;
-        HIP_OK(hipcub::DeviceRadixSort::SortKeys(nullptr, tmpBytes, (const uint64_t *)keys[0].p, (uint64_t *)keys[1].p, (int)m, 0, 64, s));
+        HIP_OK(hipcub::DeviceScan::InclusiveScan(nullptr, tmpBytes, (const U *)tHi.p, (U *)runMax.p, MaxOp(), (int)m, s));
         tmp.ensure(std::max<size_t>(tmpBytes, 16));
-        HIP_OK(hipcub::DeviceRadixSort::SortKeys(tmp.p, tmpBytes, (const uint64_t *)keys[0].p, (uint64_t *)keys[1].p, (int)m, 0, 64, s));
+        HIP_OK(hipcub::DeviceScan::InclusiveScan(tmp.p, tmpBytes, (const U *)tHi.p, (U *)runMax.p, MaxOp(), (int)m, s));
     }
-    hipLaunchKernelGGL(k_flag_ends, dim3(gridM), dim3(256), 0, s, (const ComposedRec<int32_t> *)mrecs, (const uint64_t *)keys[1].p, (uint32_t)m,
-                       (uint32_t *)tHi.p);
-    {
-        size_t tmpBytes = 0;
-        HIP_OK(hipcub::DeviceScan::InclusiveScan(nullptr, tmpBytes, (const uint32_t *)tHi.p, (uint32_t *)runMax.p, MaxOp(), (int)m, s));
-        tmp.ensure(std::max<size_t>(tmpBytes, 16));
-        HIP_OK(hipcub::DeviceScan::InclusiveScan(tmp.p, tmpBytes, (const uint32_t *)tHi.p, (uint32_t *)runMax.p, MaxOp(), (int)m, s));
-    }
-    hipLaunchKernelGGL(k_flag_overlaps, dim3(gridM), dim3(256), 0, s, (const ComposedRec<int32_t> *)mrecs, (const uint64_t *)keys[1].p,
-                       (const uint32_t *)runMax.p, (uint32_t)m, window, (uint32_t *)flag.p);
+    hipLaunchKernelGGL((k_flag_overlaps<C>), dim3(gridM), dim3(256), 0, s, (const ComposedRec<C> *)mrecs, (const uint64_t *)keys[1].p,
+                       (const uint32_t *)vals[1].p, (const U *)runMax.p, (uint32_t)m, window, (uint32_t *)flag.p);
     {
         size_t tmpBytes = 0;
         HIP_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmpBytes, (const uint32_t *)flag.p, (uint32_t *)flagPrefix.p, (int)(m + 1), s));
@@ -1620,12 +1647,12 @@ static void buildMerged(hgx_alignment *h, int src, int dst, ComposedUp &c) {
     HIP_OK(hipMemsetAsync(coarse.p, 0xFF, ((size_t)nb + 1) * 4, s));
     HIP_OK(hipMalloc(&c.mBuckets, ((size_t)nb + 1) * 4));
     if (m)
-        hipLaunchKernelGGL((k_table_touch<int32_t>), dim3(gridM), dim3(256), 0, s, (const ComposedRec<int32_t> *)mrecs, (uint32_t)m, shift, (uint32_t *)coarse.p);
+        hipLaunchKernelGGL((k_table_touch<C>), dim3(gridM), dim3(256), 0, s, (const ComposedRec<C> *)mrecs, (uint32_t)m, shift, (uint32_t *)coarse.p);
     const unsigned gridB = (unsigned)(((size_t)nb + 1 + 255) / 256);
-    hipLaunchKernelGGL((k_table_starts<int32_t>), dim3(gridB), dim3(256), 0, s, (const ComposedRec<int32_t> *)mrecs, (uint32_t)m, shift, nb, (uint32_t *)starts.p);
+    hipLaunchKernelGGL((k_table_starts<C>), dim3(gridB), dim3(256), 0, s, (const ComposedRec<C> *)mrecs, (uint32_t)m, shift, nb, (uint32_t *)starts.p);
     hipLaunchKernelGGL(k_table_fill, dim3(gridB), dim3(256), 0, s, (uint32_t *)coarse.p, (const uint32_t *)starts.p, nb);
     HIP_OK(hipMemcpyAsync(c.mBuckets, coarse.p, ((size_t)nb + 1) * 4, hipMemcpyDeviceToDevice, s));
-    hipLaunchKernelGGL(k_merge_mark, dim3((unsigned)((m + LIFT_SENTINELS + 255) / 256)), dim3(256), 0, s, mrecs, (const uint32_t *)flag.p, (uint32_t)m);
+    hipLaunchKernelGGL((k_merge_mark<C>), dim3((unsigned)((m + LIFT_SENTINELS + 255) / 256)), dim3(256), 0, s, mrecs, (const uint32_t *)flag.p, (uint32_t)m);
     unsigned int flagged = 0;
     HIP_OK(hipMemcpyAsync(&flagged, (const uint32_t *)flagPrefix.p + m, 4, hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
@@ -1634,7 +1661,7 @@ static void buildMerged(hgx_alignment *h, int src, int dst, ComposedUp &c) {
     c.mNum = m;
     c.mFlagged = flagged;
     c.mWindow = window;
-    h->dev->bytes += (m + LIFT_SENTINELS) * sizeof(ComposedRec<int32_t>) + ((size_t)nb + 1) * 4;
+    h->dev->bytes += (m + LIFT_SENTINELS) * sizeof(ComposedRec<C>) + ((size_t)nb + 1) * 4;
     c.mBuildMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
@@ -1644,9 +1671,12 @@ static const ComposedUp *ensureComposed(hgx_alignment *h, int src, int dst, bool
     // the merged form for the single-pass kernels (HGX_MERGED=0: keep to the multi-kernel path), built when a plan asks for it
     auto addMerged = [&](ComposedUp &c) {
         const char *me = getenv("HGX_MERGED");
-        if (wantMerged && through && !h->dev->wide && !c.mRecs && !c.mTried && !(me && me[0] == '0')) {
+        if (wantMerged && through && !c.mRecs && !c.mTried && !(me && me[0] == '0')) {
             c.mTried = true;
-            buildMerged(h, src, dst, c);
+            if (h->dev->wide)
+                buildMerged<int64_t>(h, src, dst, c);
+            else
+                buildMerged<int32_t>(h, src, dst, c);
         }
     };
     const bool climbs = opts.coalescence_limit >= 0 && opts.traverse_dupes; // createLiftoverPlan ignores the limit without dupes
@@ -1699,7 +1729,7 @@ void submitLiftoverPlan(hgx_liftover_plan *p, size_t n, const int64_t *dS, const
     P.pendingStrand = dStrand;
     P.pendingStream = (hipStream_t)stream;
     const bool steady = n > 0 && n <= P.maxQueries && n < ((size_t)1 << 31) && P.composed && P.composed->mRecs && !P.opts.emit_blocks &&
-                        !P.h->dev->wide && P.timer.mode == 0 && !P.captureUp && !P.captureFinal;
+                        P.timer.mode == 0 && !P.captureUp && !P.captureFinal;
     if (!steady) {
         runLiftoverPlan(p, n, dS, dE, dStrand, stream, &P.pendingOut, &P.pendingCount);
         P.pendingState = 2;
@@ -1708,7 +1738,10 @@ void submitLiftoverPlan(hgx_liftover_plan *p, size_t n, const int64_t *dS, const
     HIP_OK(hipSetDevice(P.h->dev->device));
     std::vector<unsigned long long> hc(CNT_SLOTS);
     P.mergedOffThisRun = false;
-    runMergedOnce(P, n, dS, dE, dStrand, (hipStream_t)stream, hc.data(), true);
+    if (P.h->dev->wide)
+        runMergedOnce<int64_t>(P, n, dS, dE, dStrand, (hipStream_t)stream, hc.data(), true);
+    else
+        runMergedOnce<int32_t>(P, n, dS, dE, dStrand, (hipStream_t)stream, hc.data(), true);
     P.pendingState = 1;
 }
 

@@ -203,3 +203,17 @@ def random_multiseq_alignment(seed, n_genomes=6, max_children=3, root_len=400, m
                         gd["tParalogy"][a] = b
         fix_parse_info(gd)
     return genomes
+
+
+def scale_alignment(genomes, k):
+    """The same alignment with every coordinate multiplied by k (segment and sequence boundaries; links are untouched) and
+    without DNA: a few thousand segments then cover genomes of more than 2^31 bases, the case the int64 tables exist for."""
+    out = []
+    for g in genomes:
+        h = dict(g)
+        h["tStart"] = [x * k for x in g["tStart"]]
+        h["bStart"] = [x * k for x in g["bStart"]]
+        h["seqs"] = [(s[0], s[1] * k, s[2] * k, s[3], s[4], s[5], s[6]) for s in g["seqs"]]
+        h["dna"] = ""
+        out.append(h)
+    return out
