@@ -134,6 +134,57 @@ def timed_steps(step, k, sync):
     return time.perf_counter() - t0, r
 
 
+def steady_legs(hal_amd, torch, al, src, tgt, d_gs, d_ge, d_st, steps, sync, rec_bytes=16):
+    """The timed configuration's three measurements on another alignment / another table width: two plans with a batch each in
+    flight (hgx_liftover_submit / _collect), one plan batch after batch (hgx_liftover_run_device), and the kernels of the latter
+    with HIP events around every launch, each priced by its own bytes (plan_kernel_bytes)."""
+    nq = d_gs.numel()
+    plans = [hal_amd.LiftoverPlan(al, src, tgt, max_queries=nq) for _ in range(2)]
+    for p in plans:
+        for _ in range(3):  # (change-over to the table, workspace growth, the launches for intervals passed on)
+            p.run(d_gs, d_ge, d_st)
+        p.set_timing(0)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    pending = [False, False]
+
+    def two(k_steps):
+        for i in range(k_steps):
+            k = i & 1
+            if pending[k]:
+                plans[k].collect()
+                pending[k] = False
+            plans[k].submit(d_gs, d_ge, d_st, stream=streams[k])
+            pending[k] = True
+        for k in (0, 1):
+            if pending[k]:
+                plans[k].collect()
+                pending[k] = False
+    two(10)
+    dt2, _ = timed_steps(lambda: two(steps), 1, sync)
+    for _ in range(5):
+        plans[0].run(d_gs, d_ge, d_st)
+    dt1, _ = timed_steps(lambda: plans[0].run(d_gs, d_ge, d_st), steps, sync)
+    plans[0].set_timing(2)
+    for _ in range(steps):
+        plans[0].run(d_gs, d_ge, d_st)
+    kt = plans[0].kernel_times()
+    st = plans[0].stats()
+    plans[0].set_timing(1)
+    per_alg = plan_kernel_bytes(kt, st, steps, rec_bytes)
+    kernels = []
+    for kname, kv in sorted(kt.items(), key=lambda kv: -kv[1]["ms"]):
+        avg = kv["ms"] / max(1, kv["launches"])
+        gbs = per_alg.get(kname, 0.0) / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
+        kernels.append({"kernel": kname, "kernel_avg_ms": avg, "launches_per_step": kv["launches"] / steps,
+                        "algorithmic_bytes_per_launch": per_alg.get(kname, 0.0), "achieved": gbs, "frac": gbs / HBM_PEAK_GBS})
+    return {"ms_per_step": 1e3 * dt2 / steps, "value": nq * steps / dt2, "unit": "intervals/s", "batches_in_flight": 2, "steps": steps,
+            "one_plan": {"ms_per_step": 1e3 * dt1 / steps, "value": nq * steps / dt1},
+            "kernels_ms_per_step": {k: round(v["ms"] / steps, 4) for k, v in sorted(kt.items())},
+            "roofline_kernels": kernels, "records_per_step": st["records"], "general_queries": st["general_queries"],
+            "deferred_queries": st["deferred_queries"], "composed_kind": st["composed_kind"], "table_records": st["composed_records"],
+            "table_build_ms": st["composed_build_ms"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -150,6 +201,11 @@ def main():
     ap.add_argument("--columns", type=int, default=1, help="also time the column-depth kernel over the whole source genome (0 = skip)")
     ap.add_argument("--maf-columns", type=int, default=8000000,
                     help="hal2maf (BASELINE config 3) over the first N reference columns, end to end to MAF text (0 = skip; one GPU only)")
+    ap.add_argument("--maf-full", type=int, default=1, help="hal2maf over the WHOLE reference genome (BASELINE config 3 as it is stated; one GPU only)")
+    ap.add_argument("--wide", type=int, default=1, help="the same steps on int64-coordinate tables (HGX_FORCE_WIDE=1 copy of the alignment; one GPU only)")
+    ap.add_argument("--cfg4", type=int, default=1,
+                    help="BASELINE configs 4 and 5 on one GPU: a 1.25 M-interval shard Genome_44 -> Genome_2 and the whole-genome depth scan of "
+                         "Genome_44 on the 50-genome alignment (generating it takes about a minute; 0 = skip; one GPU only)")
     ap.add_argument("--text-path", type=int, default=1, help="also time Liftover::convert (BED text in, BED text out) on the batch (one GPU only)")
     ap.add_argument("--in-flight", type=int, default=2, help="batches in flight on one GPU without an exchange: 2 (two plans, two streams) or 1")
     ap.add_argument("--sustained-seconds", type=float, default=2.0, help="extra leg: the same step repeated for about this long")
@@ -229,6 +285,28 @@ def main():
     if cold_b < cold_s:
         cold_s, t_plan, cold_stats = cold_b, t_plan_b, plan_b.stats()
     del plan_b, al2
+    # (a third time with a device synchronisation at every phase boundary — HGX_BUILD_TIMING=2 — for the breakdown: its phases
+    # add up to its own wall time, which is a little above the un-instrumented runs')
+    cold_phases = None
+    if rank == 0:
+        al3 = al.clone_to_device(local)
+        sync()
+        os.environ["HGX_BUILD_TIMING"] = "2"
+        try:
+            t0c = time.perf_counter()
+            plan_c = hal_amd.LiftoverPlan(al3, src, tgt, max_queries=nq)
+            sync()
+            t_plan_c = time.perf_counter() - t0c
+            plan_c.run(d_gs, d_ge, d_st)
+            sync()
+            cold_c = time.perf_counter() - t0c
+        finally:
+            del os.environ["HGX_BUILD_TIMING"]
+        ph = [("plan creation (schedule, chain / down / locate tables, workspaces)", 1e3 * t_plan_c)] + hal_amd.build_phases()
+        listed = sum(ms for _, ms in ph)
+        ph.append(("host side of the run outside the phases above", max(0.0, 1e3 * cold_c - listed)))
+        cold_phases = {"ms": 1e3 * cold_c, "phases_ms": [[k, round(v, 4)] for k, v in ph]}
+        del plan_c, al3
     passes_before_timing = 1
 
     # The one exchange step of the path: the batch's records of every rank, as self-describing wire blobs (12 bytes per record + 2
@@ -531,6 +609,7 @@ def main():
                                                 "the table path's time is not a bandwidth"}},
             "cold": {"ms": 1e3 * cold_s, "runs_ms": cold_runs, "value": nq / cold_s, "unit": "intervals/s", "plan_create_ms": 1e3 * t_plan,
                      "table_build_ms": cold_stats["composed_build_ms"], "composed_kind": cold_stats["composed_kind"],
+                     "instrumented": cold_phases,
                      "what": "fresh plan (default policy: the table is built when the first batch reaches a quarter of the source's segments) + "
                              "one pass over the batch, wall clock with the device synchronised, in a process that has loaded its HIP code "
                              "objects on a 1 %-scale alignment before (a fresh process adds ~120 ms of module loading once)"},
@@ -586,6 +665,57 @@ def main():
             out.setdefault("columns", {})["hal2maf"] = {"metric": "MAF columns/sec (hal2maf --refGenome %s --noAncestors, end to end to MAF text in host memory)" % src_name,
                                                         "value": ncols / dt_m, "unit": "columns/s", "columns": ncols, "seconds": dt_m,
                                                         "maf_bytes": nbytes}
+        if want_maf and args.maf_full:
+            # BASELINE config 3 as stated: the full reference genome
+            ncols = al.genome_length(src)
+            t0 = time.perf_counter()
+            nbytes = al.maf_export_bytes(src, no_ancestors=True)
+            dt_m = time.perf_counter() - t0
+            out.setdefault("columns", {})["hal2maf_full"] = {"metric": "MAF columns/sec (hal2maf --refGenome %s --noAncestors over the whole genome, end to end to MAF text "
+                                                        "in host memory)" % src_name,
+                                              "value": ncols / dt_m, "unit": "columns/s", "columns": ncols, "seconds": dt_m, "maf_bytes": nbytes}
+        if args.wide and world == 1 and not args.exchange_selftest:
+            # the reference's own coordinate width (hal_index_t = int64, api/inc/halDefs.h:34; what an alignment with a genome of
+            # 2^31 bases or more — every mammalian one — runs on): the same alignment, batch and steps on int64 tables
+            os.environ["HGX_FORCE_WIDE"] = "1"
+            try:
+                alw = al.clone_to_device(local)
+            finally:
+                del os.environ["HGX_FORCE_WIDE"]
+            w = steady_legs(hal_amd, torch, alw, src, tgt, d_gs, d_ge, d_st, args.steps, sync, rec_bytes=32)
+            w["what"] = ("the timed configuration on int64-coordinate tables (HGX_FORCE_WIDE=1 copy of the same alignment: 32-byte table "
+                         "records): same batch, same records")
+            w["records_match"] = w["records_per_step"] == nrec_all
+            w["ratio_to_int32_step"] = w["ms_per_step"] / (1e3 * elapsed / args.steps)
+            if one_plan:
+                w["one_plan"]["ratio_to_int32"] = w["one_plan"]["ms_per_step"] / one_plan["ms_per_step"]
+            out["wide"] = w
+            del alw
+        if args.cfg4 and world == 1 and not args.exchange_selftest and args.workload == "cfg2":
+            # BASELINE configs 4 and 5 on this GPU: one GPU's 1.25 M-interval shard of the 10 M intervals Genome_44 -> Genome_2 on the
+            # 50-genome alignment, and the whole-genome depth scan of Genome_44
+            t0 = time.time()
+            al4 = hal_amd.Alignment.random(workload_options(args.scale, "cfg4"), device=local)
+            gen4 = time.time() - t0
+            s4, t4 = al4.genome_id("Genome_44"), al4.genome_id("Genome_2")
+            _, ss4, len4 = al4.sequences(s4)[0]
+            nq4 = 1250000
+            st4, ln4, sd4 = make_queries(len4, nq4, 1234)
+            c4 = steady_legs(hal_amd, torch, al4, s4, t4, (st4 + ss4).to(dev), (st4 + ln4 - 1 + ss4).to(dev), sd4.to(dev), max(5, args.steps // 4), sync)
+            c4["what"] = ("BASELINE config 4, one GPU's shard: halRandGen 50-genome alignment (seed 0, meanDegree 2), %d BED6 intervals "
+                          "Genome_44 -> Genome_2" % nq4)
+            c4["generate_s"] = round(gen4, 2)
+            out["cfg4"] = c4
+            ncol4 = al4.genome_length(s4)
+            d4 = torch.empty(ncol4, dtype=torch.int32, device=dev)
+            al4.columns_depth_device(s4, 0, ncol4, d4.data_ptr())
+            ms4 = min(al4.columns_depth_device(s4, 0, ncol4, d4.data_ptr()) for _ in range(3))
+            sw4 = sweep_design_bytes(al4, s4)
+            out["cfg5"] = {"what": "BASELINE config 5 on one GPU: halAlignmentDepth of Genome_44 over its whole genome on the 50-genome alignment",
+                           "value": ncol4 / (ms4 * 1e-3), "unit": "columns/s", "columns": ncol4, "kernel_ms": ms4,
+                           "mean_depth": float(d4.double().mean().item()),
+                           "sweeps_own_bytes": sw4, "sweeps_own_GBs": sw4 / (ms4 * 1e-3) / 1e9, "sweeps_own_frac": sw4 / (ms4 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            del al4, d4
         if args.text_path and world == 1 and not args.exchange_selftest:
             # Liftover::convert as halLiftover runs it: BED text in, BED text out (parse, H2D, kernels, D2H, format), PCIe inclusive
             sn, ln, tn = starts.numpy(), lens.numpy(), strand.numpy()
@@ -673,10 +803,11 @@ def sweep_design_bytes(al, ref):
     return total
 
 
-def plan_kernel_bytes(kt, st, steps):
+def plan_kernel_bytes(kt, st, steps, rec_bytes=16):
     """Algorithmic bytes per launch of each kernel: 25 B per segment record logically
     dereferenced by that kernel, 24 B per query for the locate kernel, 40 B per record written by the finishing kernel.
-    kt: kernel times and dereference counts accumulated over `steps` runs; st: the counts of one run."""
+    kt: kernel times and dereference counts accumulated over `steps` runs; st: the counts of one run; rec_bytes: size of a
+    table record (16 with int32 coordinates, 32 with int64)."""
     out = {}
     for name, v in kt.items():
         launches = max(1, v["launches"])
@@ -686,20 +817,20 @@ def plan_kernel_bytes(kt, st, steps):
             # the table kernels' own figure: 16 B per composed record that overlaps its interval (counted in the top slot)
             # and the piece it leaves (29 B in a frontier, a 32-byte MappedRec from the whole-path kernel, which also writes
             # 8 B of offset and count per interval), instead of the segment records of the walk they replace
-            bytes_ = (16.0 + (29.0 if name == "k_locate_composed" else 32.0)) * t
+            bytes_ = (rec_bytes + (29.0 if name == "k_locate_composed" else 32.0)) * t
             if name == "k_locate_through":
                 bytes_ += 8.0 * st["queries"] * steps
         if name == "k_lift_merged":
             # the storing kernel: 37 B per interval (its two ends, the strand, the 8-byte answer and the line count
             # k_lift_classify left, the 4-byte offset it writes), 16 B per merged record that overlaps its interval (top slot),
             # 40 B per record written
-            bytes_ = 16.0 * t + (16.0 + 1.0 + 8.0 + 4.0 + 4.0 + 4.0) * st["queries"] * steps + 40.0 * st["records"] * steps
+            bytes_ = rec_bytes * t + (16.0 + 1.0 + 8.0 + 4.0 + 4.0 + 4.0) * st["queries"] * steps + 40.0 * st["records"] * steps
         if name == "k_lift_classify":
             # the counting kernel: interval ends, one 4-byte bucket entry, the 8-byte answer and the 4-byte line count, and 16 B
             # per merged record that overlaps its interval (k_lift_merged's top slot: the same records) or unmerged record a
             # general interval clips (its own top slot)
             merged_records = kt.get("k_lift_merged", {}).get("top_derefs", 0)
-            bytes_ = (16.0 + 4.0 + 8.0 + 4.0) * st["queries"] * steps + 16.0 * (merged_records + t)
+            bytes_ = (16.0 + 4.0 + 8.0 + 4.0) * st["queries"] * steps + rec_bytes * (merged_records + t)
         if name in ("k_locate_expand", "k_locate_composed", "k_locate_through"):
             bytes_ += 24.0 * st["queries"] * steps
         if name in ("k_finish_fast", "k_finish_lds", "k_finish_big"):

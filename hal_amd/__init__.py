@@ -8,6 +8,7 @@ from ._lib import lib, HgxError, LIB_PATH  # noqa: F401
 from .api import (  # noqa: F401
     Alignment,
     LiftoverPlan,
+    build_phases,
     Comm,
     Interval,
     Record,

@@ -102,6 +102,7 @@ SYMBOLS = {
     "hgx_liftover_convert_multi": (C.c_int, [P(VP), C.c_int, C.c_int, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                              P(VP), P(C.c_size_t), P(VP)]),
     "hgx_liftover_kernel_times": (C.c_int, [VP, P(VP)]),
+    "hgx_liftover_build_phases": (C.c_int, [P(VP)]),
     "hgx_liftover_copy_records": (C.c_int, [VP, VP, C.c_size_t, VP, P(VP)]),
     "hgx_liftover_copy_records_packed": (C.c_int, [VP, VP, C.c_size_t, VP, P(VP)]),
     "hgx_liftover_wire_blob": (C.c_int, [VP, VP, C.c_size_t, C.c_int64, P(C.c_size_t), P(C.c_int), VP, P(VP)]),

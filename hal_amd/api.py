@@ -385,6 +385,18 @@ class Comm:
         self.close()
 
 
+def build_phases():
+    """[(phase, ms), ...] of this process's last table build made with HGX_BUILD_TIMING set (hgx_liftover_build_phases)"""
+    import json
+    js = C.c_void_p()
+    if lib.hgx_liftover_build_phases(C.byref(js)) != 0:
+        return []
+    try:
+        return [tuple(x) for x in json.loads(C.string_at(js.value).decode())]
+    finally:
+        lib.hgx_free(js)
+
+
 class LiftoverPlan:
     """Device-resident liftover: queries and records stay in HBM (hgx_liftover_run_device)."""
 

@@ -411,6 +411,21 @@ int hgx_liftover_kernel_times(hgx_liftover_plan *p, char **json) {
     }
 }
 
+int hgx_liftover_build_phases(char **json) {
+    if (!json)
+        return HGX_ERR;
+    try {
+        const std::string s = liftoverBuildPhases();
+        *json = (char *)malloc(s.size() + 1);
+        if (!*json)
+            return HGX_ERR;
+        memcpy(*json, s.c_str(), s.size() + 1);
+        return HGX_OK;
+    } catch (...) {
+        return HGX_ERR;
+    }
+}
+
 int hgx_liftover_plan_set_timing(hgx_liftover_plan *p, int mode) {
     if (!p)
         return HGX_ERR;

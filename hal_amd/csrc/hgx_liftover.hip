@@ -437,6 +437,47 @@ struct KernelTimer {
     }
 };
 
+// Where the time of a plan's change-over to its table goes (HGX_BUILD_TIMING=1: printed to stderr, =2: kept for
+// hgx_liftover_build_phases): the device is synchronised at every lap, so the phases add up to the wall time of the instrumented
+// run (which is a little longer than an un-instrumented one).  One log per process; builds are serialised by ensureComposed's mutex.
+struct BuildPhases {
+    bool on = false, print = false;
+    std::chrono::steady_clock::time_point last;
+    std::vector<std::pair<std::string, double>> v;
+    void start() {
+        const char *e = getenv("HGX_BUILD_TIMING");
+        on = e != nullptr;
+        print = on && e[0] != '2';
+        v.clear();
+        if (on) {
+            (void)hipDeviceSynchronize();
+            last = std::chrono::steady_clock::now();
+        }
+    }
+    void lap(const char *what) {
+        if (!on)
+            return;
+        (void)hipDeviceSynchronize();
+        const auto t = std::chrono::steady_clock::now();
+        const double ms = std::chrono::duration<double, std::milli>(t - last).count();
+        if (print)
+            fprintf(stderr, "[hgx build] %-40s %.3f ms\n", what, ms);
+        v.emplace_back(what, ms);
+        last = t;
+    }
+};
+static BuildPhases g_phases;
+
+std::string liftoverBuildPhases() {
+    std::string s = "[";
+    for (size_t i = 0; i < g_phases.v.size(); ++i) {
+        char buf[256];
+        snprintf(buf, sizeof buf, "%s[\"%s\", %.4f]", i ? ", " : "", g_phases.v[i].first.c_str(), g_phases.v[i].second);
+        s += buf;
+    }
+    return s + "]";
+}
+
 } // namespace hgx
 
 using namespace hgx;
@@ -1128,12 +1169,17 @@ static void runPlan(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
         *nOut = 0;
         return;
     }
+    bool builtNow = false;
     if (!P.composed && P.composedAfter != ~0ull) {
         // the batch that takes the plan past its threshold is already served from the table
-        if (P.walked + n >= P.composedAfter)
+        if (P.walked + n >= P.composedAfter) {
+            g_phases.start();
             P.composed = ensureComposed(P.h, P.src, P.composedThrough ? P.tgt : P.mrca, P.composedThrough, P.opts, !P.opts.emit_blocks);
-        else
+            g_phases.lap("merged: workspaces released");
+            builtNow = true;
+        } else {
             P.walked += n;
+        }
     }
     P.timer.beginRun();
     P.mergedOffThisRun = false;
@@ -1243,6 +1289,8 @@ static void runPlan(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
         HIP_OK(hipEventElapsedTime(&walk, P.evStart, P.evWalk));
         HIP_OK(hipEventElapsedTime(&tot, P.evStart, P.evEnd));
     }
+    if (builtNow)
+        g_phases.lap("first batch from the table");
     P.stats.queries = n;
     P.stats.source_pieces = hc[CNT_SRC_PIECES];
     P.stats.top_derefs = topAll;
@@ -1377,15 +1425,7 @@ hgx_liftover_plan *createLiftoverPlan(hgx_alignment *h, int src, int tgt, const 
 template <typename C>
 static void buildComposed(hgx_alignment *h, int src, int dst, bool through, const hgx_liftover_opts &opts, ComposedUp &out) {
     const auto t0 = std::chrono::steady_clock::now();
-    const bool timing = getenv("HGX_BUILD_TIMING") != nullptr;
-    auto lap = [&, last = t0](const char *what) mutable {
-        if (!timing)
-            return;
-        (void)hipDeviceSynchronize();
-        const auto t = std::chrono::steady_clock::now();
-        fprintf(stderr, "[hgx build] pieces: %-28s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t - last).count());
-        last = t;
-    };
+    auto lap = [&](const char *what) { g_phases.lap((std::string("pieces: ") + what).c_str()); };
     const GenomeTables &S = h->img.genomes[(size_t)src];
     const DeviceImage &D = *h->dev;
     const size_t nt = (size_t)S.numTop;
@@ -1518,15 +1558,7 @@ template <typename C> static void buildMerged(hgx_alignment *h, int src, int dst
     typedef typename MergeWord<C>::U U;
     constexpr bool WIDE = sizeof(C) == 8;
     const auto t0 = std::chrono::steady_clock::now();
-    const bool timing = getenv("HGX_BUILD_TIMING") != nullptr;
-    auto lap = [&, last = t0](const char *what) mutable {
-        if (!timing)
-            return;
-        (void)hipDeviceSynchronize();
-        const auto t = std::chrono::steady_clock::now();
-        fprintf(stderr, "[hgx build] merged: %-28s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t - last).count());
-        last = t;
-    };
+    auto lap = [&](const char *what) { g_phases.lap((std::string("merged: ") + what).c_str()); };
     const DeviceImage &D = *h->dev;
     const GenomeTables &S = h->img.genomes[(size_t)src];
     const GenomeTables &T = h->img.genomes[(size_t)dst];
@@ -1693,6 +1725,7 @@ static const ComposedUp *ensureComposed(hgx_alignment *h, int src, int dst, bool
         buildComposed<int64_t>(h, src, dst, through, opts, c);
     else
         buildComposed<int32_t>(h, src, dst, through, opts, c);
+    g_phases.lap("pieces: builder plan and workspaces released");
     addMerged(c);
     return &h->dev->composed.emplace(key, c).first->second;
 }

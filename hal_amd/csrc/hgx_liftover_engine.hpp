@@ -17,6 +17,8 @@ void runLiftoverPlan(hgx_liftover_plan *p, size_t n, const int64_t *dStart, cons
 void destroyLiftoverPlan(hgx_liftover_plan *p);
 const hgx_liftover_stats &liftoverPlanStats(const hgx_liftover_plan *p);
 std::string liftoverPlanKernelTimes(hgx_liftover_plan *p);
+// phases of the last table build of this process (HGX_BUILD_TIMING), as a JSON list of [name, ms]
+std::string liftoverBuildPhases();
 void liftoverPlanSetTiming(hgx_liftover_plan *p, int mode);
 void liftoverPlanCopyRecords(const hgx_liftover_plan *p, void *dDst, size_t nRecords, void *stream);
 void liftoverPlanCopyRecordsPacked(const hgx_liftover_plan *p, void *dDst, size_t nRecords, void *stream);

@@ -192,6 +192,12 @@ int hgx_liftover_last_stats(const hgx_liftover_plan *p, hgx_liftover_stats *out)
  * read (for a benchmark loop: the elapsed-time queries then happen once, outside the loop), 0 = no events at all. */
 int hgx_liftover_kernel_times(hgx_liftover_plan *p, char **json);
 int hgx_liftover_plan_set_timing(hgx_liftover_plan *p, int mode);
+/* Where a plan's change-over to its table spent its time: with HGX_BUILD_TIMING=2 in the environment (1: also printed to
+ * stderr) the run that builds a table synchronises the device at every phase boundary and keeps the wall time of each phase —
+ * builder plan, walk of every source segment, sorts, records, bucket tables, junction sort, chains, flags, the releases of the
+ * workspaces, the first batch served from the table.  *json: the phases of this process's last such run as a JSON list of
+ * [name, ms] (they add up to that run's wall time, a little more than an un-instrumented run's); release with hgx_free. */
+int hgx_liftover_build_phases(char **json);
 
 /* Copy the plan-owned records of the last run into caller-owned device memory (device to device, on hip_stream). */
 int hgx_liftover_copy_records(const hgx_liftover_plan *p, void *d_dst, size_t n_records, void *hip_stream, char **err);
