@@ -24,17 +24,15 @@ struct Buf {
     void *p = nullptr;
     Buf() = default;
     explicit Buf(size_t bytes) {
-        HIP_OK(hipMalloc(&p, std::max<size_t>(bytes, 16)));
+        p = hgx::devAlloc(bytes);
     }
     void resize(size_t bytes) { // contents are not kept
-        if (p)
-            (void)hipFree(p);
+        hgx::devRelease(p);
         p = nullptr;
-        HIP_OK(hipMalloc(&p, std::max<size_t>(bytes, 16)));
+        p = hgx::devAlloc(bytes);
     }
     ~Buf() {
-        if (p)
-            (void)hipFree(p);
+        hgx::devRelease(p);
     }
     Buf(const Buf &) = delete;
 };

@@ -146,31 +146,38 @@ int hgx_liftover_exchange(hgx_liftover_plan *p, hgx_comm *c, int64_t first_query
             throw std::runtime_error("hgx_liftover_exchange: null argument");
         if (slot_bytes < 64 || slot_bytes % 8)
             throw std::runtime_error("hgx_liftover_exchange: the slot size must be a multiple of 8 and at least 64 bytes");
+        // (argument errors above are the caller's on every rank alike; from here on this rank takes part in the collective
+        // whatever happens to its own blob — the other ranks are waiting in theirs)
         unsigned char *mine = (unsigned char *)d_gathered + (size_t)c->rank * slot_bytes;
-        const size_t need = hgx::liftoverPlanWireBlob(p, nullptr, 0, first_query, nullptr, hip_stream);
-        size_t wrote = 0;
-        bool fits = need <= slot_bytes;
-        if (fits) {
-            wrote = hgx::liftoverPlanWireBlob(p, mine, slot_bytes, first_query, nullptr, hip_stream);
-        } else {
-            // the collective still has to happen on every rank: this rank sends a header that says so (format 0, the bytes it
-            // would have needed in the record count) and reports the error after the exchange
+        size_t need = 0, wrote = 0;
+        std::string failure;
+        try {
+            need = hgx::liftoverPlanWireBlob(p, nullptr, 0, first_query, nullptr, hip_stream);
+            if (need <= slot_bytes)
+                wrote = hgx::liftoverPlanWireBlob(p, mine, slot_bytes, first_query, nullptr, hip_stream);
+            else
+                failure = "hgx_liftover_exchange: this rank's records need " + std::to_string(need) + " bytes, the slot has " +
+                          std::to_string(slot_bytes);
+        } catch (std::exception &e) { // a plan with a batch in flight, a HIP error while the blob was made, no memory for its staging
+            failure = std::string("hgx_liftover_exchange: no blob from this rank: ") + e.what();
+        }
+        if (!failure.empty()) {
+            // the slot's header says so to the other ranks: format 0, and the bytes the blob would have needed in the record count
             struct {
                 char magic[4];
                 uint32_t format;
                 int64_t firstQuery;
                 uint64_t nq, nrec;
             } h = {{'H', 'G', 'X', 'W'}, 0u, first_query, 0ull, (uint64_t)need};
-            if (hipMemcpyAsync(mine, &h, sizeof h, hipMemcpyHostToDevice, (hipStream_t)hip_stream) != hipSuccess ||
-                hipStreamSynchronize((hipStream_t)hip_stream) != hipSuccess)
-                throw std::runtime_error("hgx_liftover_exchange: could not write the slot header");
+            // (best effort: when even this copy fails the slot keeps whatever it held — the collective is still posted)
+            if (hipMemcpyAsync(mine, &h, sizeof h, hipMemcpyHostToDevice, (hipStream_t)hip_stream) == hipSuccess)
+                (void)hipStreamSynchronize((hipStream_t)hip_stream); // (h lives on this stack frame)
         }
         check(rccl().allGather(mine, d_gathered, slot_bytes, /*ncclUint8*/ 1, c->comm, (hipStream_t)hip_stream), "ncclAllGather");
         if (my_bytes)
             *my_bytes = wrote;
-        if (!fits)
-            throw std::runtime_error("hgx_liftover_exchange: this rank's records need " + std::to_string(need) + " bytes, the slot has " +
-                                     std::to_string(slot_bytes) + " (the exchange was carried out; the slot's header says so to the other ranks)");
+        if (!failure.empty())
+            throw std::runtime_error(failure + " (the exchange was carried out; the slot's header says so to the other ranks)");
         return HGX_OK;
     } catch (std::exception &e) {
         setErr(err, e.what());

@@ -199,6 +199,16 @@ struct DeviceImage {
     ~DeviceImage();
 };
 
+// Device workspaces come from a per-device cache of released blocks: hipFree costs a device synchronisation and an unmap
+// (releasing the table builder's workspaces was 3.7 of the 8 ms a fresh plan's first batch took, profiles/r03a_bench.log), and the next
+// plan asks for the same sizes again.  Sizes are rounded up to a power of two or one and a half times one, so a released block
+// fits the next request of its class; blocks beyond HGX_CACHE_BYTES (default 24 GB per device) go back to the driver, and so does
+// the whole cache of a device when an alignment on it is closed.  Callers release a block only when no queued work uses it any
+// more (the places that used to call hipFree: after a run's synchronisation, when a plan is destroyed).
+void *devAlloc(size_t bytes);   // on the current device; throws std::runtime_error
+void devRelease(void *p);       // back to the cache of the device it came from (null: nothing)
+void devCacheTrim(int device);  // hipFree everything cached for `device`
+
 // builds the k_up_chain tables of `genome` (idempotent, serialised by an internal mutex)
 void ensureChainTables(const Image &img, DeviceImage &D, int genome, bool mid, bool last);
 // builds the coarse locate table of a genome's top (which = 0) or bottom (1) tiling (idempotent, serialised)

@@ -24,11 +24,126 @@ namespace hgx {
     } while (0)
 
 // ---------------------------------------------------------------------------------------------
+// workspace cache (hgx_device.hpp)
+namespace {
+struct DevCache {
+    std::mutex mu;
+    std::map<std::pair<int, size_t>, std::vector<void *>> free; // (device, size class) -> released blocks
+    std::map<void *, std::pair<int, size_t>> live;              // every block handed out: its device and size class
+    std::map<int, size_t> cachedBytes;
+};
+DevCache &devCache() {
+    static DevCache *c = new DevCache; // (never destroyed: blocks may be released from static destructors)
+    return *c;
+}
+size_t sizeClass(size_t bytes) {
+    size_t c = 256;
+    while (c < bytes) {
+        if (c + c / 2 >= bytes && c >= 4096)
+            return c + c / 2;
+        c <<= 1;
+    }
+    return c;
+}
+} // namespace
+
+void *devAlloc(size_t bytes) {
+    int dev = 0;
+    HIP_OK(hipGetDevice(&dev));
+    const size_t cls = sizeClass(std::max<size_t>(bytes, 16));
+    DevCache &C = devCache();
+    {
+        std::lock_guard<std::mutex> lock(C.mu);
+        auto it = C.free.find({dev, cls});
+        if (it != C.free.end() && !it->second.empty()) {
+            void *p = it->second.back();
+            it->second.pop_back();
+            C.cachedBytes[dev] -= cls;
+            C.live[p] = {dev, cls};
+            return p;
+        }
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, cls);
+    if (e != hipSuccess) { // out of memory with blocks in the cache: give them back and try once more
+        (void)hipGetLastError();
+        devCacheTrim(dev);
+        e = hipMalloc(&p, cls);
+    }
+    if (e != hipSuccess)
+        throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e) + " at hipMalloc of " + std::to_string(cls) + " bytes");
+    std::lock_guard<std::mutex> lock(C.mu);
+    C.live[p] = {dev, cls};
+    return p;
+}
+
+void devRelease(void *p) {
+    if (!p)
+        return;
+    static const size_t limit = []() {
+        const char *e = getenv("HGX_CACHE_BYTES");
+        return e ? (size_t)std::max<long long>(0, atoll(e)) : (size_t)24 << 30;
+    }();
+    DevCache &C = devCache();
+    int dev = -1;
+    size_t cls = 0;
+    bool keep = false;
+    {
+        std::lock_guard<std::mutex> lock(C.mu);
+        auto it = C.live.find(p);
+        if (it != C.live.end()) {
+            dev = it->second.first;
+            cls = it->second.second;
+            C.live.erase(it);
+            keep = C.cachedBytes[dev] + cls <= limit;
+            if (keep) {
+                C.free[{dev, cls}].push_back(p);
+                C.cachedBytes[dev] += cls;
+            }
+        }
+    }
+    if (!keep) {
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        if (dev >= 0 && dev != cur)
+            (void)hipSetDevice(dev);
+        (void)hipFree(p);
+        if (dev >= 0 && dev != cur)
+            (void)hipSetDevice(cur);
+    }
+}
+
+void devCacheTrim(int device) {
+    DevCache &C = devCache();
+    std::vector<void *> blocks;
+    {
+        std::lock_guard<std::mutex> lock(C.mu);
+        for (auto &kv : C.free)
+            if (kv.first.first == device) {
+                blocks.insert(blocks.end(), kv.second.begin(), kv.second.end());
+                kv.second.clear();
+            }
+        C.cachedBytes[device] = 0;
+    }
+    if (blocks.empty())
+        return;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    if (cur != device)
+        (void)hipSetDevice(device);
+    for (void *p : blocks)
+        (void)hipFree(p);
+    if (cur != device)
+        (void)hipSetDevice(cur);
+}
+
+// ---------------------------------------------------------------------------------------------
 // device image
 DeviceImage::~DeviceImage() {
     if (device < 0)
         return;
     (void)hipSetDevice(device);
+    devCacheTrim(device);
     for (DeviceGenome &g : genomes) {
         if (g.top)
             (void)hipFree(g.top);
@@ -337,22 +452,20 @@ std::unique_ptr<DeviceImage> uploadImage(const Image &img, int device) {
 
 // ---------------------------------------------------------------------------------------------
 // plan
-struct DevBuf {
+struct DevBuf { // a workspace from the device's block cache (devAlloc / devRelease, hgx_device.hpp)
     void *p = nullptr;
     size_t n = 0;
     void ensure(size_t bytes) {
         if (bytes <= n)
             return;
-        if (p)
-            (void)hipFree(p);
+        devRelease(p);
         p = nullptr;
         n = 0;
-        HIP_OK(hipMalloc(&p, bytes));
+        p = devAlloc(bytes);
         n = bytes;
     }
     ~DevBuf() {
-        if (p)
-            (void)hipFree(p);
+        devRelease(p);
     }
 };
 
@@ -1771,11 +1884,19 @@ void submitLiftoverPlan(hgx_liftover_plan *p, size_t n, const int64_t *dS, const
     HIP_OK(hipSetDevice(P.h->dev->device));
     std::vector<unsigned long long> hc(CNT_SLOTS);
     P.mergedOffThisRun = false;
-    if (P.h->dev->wide)
-        runMergedOnce<int64_t>(P, n, dS, dE, dStrand, (hipStream_t)stream, hc.data(), true);
-    else
-        runMergedOnce<int32_t>(P, n, dS, dE, dStrand, (hipStream_t)stream, hc.data(), true);
-    P.pendingState = 1;
+    P.pendingState = 1; // (from the first launch on the plan's workspaces belong to this batch)
+    try {
+        if (P.h->dev->wide)
+            runMergedOnce<int64_t>(P, n, dS, dE, dStrand, (hipStream_t)stream, hc.data(), true);
+        else
+            runMergedOnce<int32_t>(P, n, dS, dE, dStrand, (hipStream_t)stream, hc.data(), true);
+    } catch (...) {
+        // some launches may be queued: let them finish before anybody touches the workspaces again, and forget the batch
+        (void)hipStreamSynchronize((hipStream_t)stream);
+        P.pendingState = 0;
+        P.liftStateClean = false;
+        throw;
+    }
 }
 
 void collectLiftoverPlan(hgx_liftover_plan *p, const hgx_record **dOut, size_t *nOut) {
@@ -1784,6 +1905,7 @@ void collectLiftoverPlan(hgx_liftover_plan *p, const hgx_record **dOut, size_t *
         throw std::runtime_error("hgx_liftover_collect: nothing was submitted");
     const int state = P.pendingState;
     P.pendingState = 0;
+    HIP_OK(hipSetDevice(P.h->dev->device)); // (the caller's thread may be bound to another device; the rerun path launches)
     if (state == 2) {
         *dOut = P.pendingOut;
         *nOut = P.pendingCount;
@@ -1821,6 +1943,7 @@ void runLiftoverPlan(hgx_liftover_plan *p, size_t n, const int64_t *dS, const in
                      const hgx_record **dOut, size_t *nOut) {
     if (p->pendingState == 1) // (its workspaces and its output belong to the batch in flight)
         throw std::runtime_error("the plan has a submitted batch that has not been collected");
+    p->pendingState = 0; // (a batch submit ran to the end and nobody collected is superseded by this run: collect then has nothing)
     if (p->h->dev->wide)
         runPlan<int64_t>(*p, n, dS, dE, dStrand, (hipStream_t)stream, dOut, nOut);
     else
@@ -1840,7 +1963,15 @@ const hgx_liftover_stats &liftoverPlanStats(const hgx_liftover_plan *p) {
     return p->stats;
 }
 
+static void refuseWhileInFlight(const hgx_liftover_plan *p, const char *who) {
+    // (stats and outRecords belong to the batch in flight: its launches are still writing the records and k_lift_totals has not
+    // reported yet)
+    if (p->pendingState == 1)
+        throw std::runtime_error(std::string(who) + ": the plan has a submitted batch that has not been collected");
+}
+
 void liftoverPlanCopyRecords(const hgx_liftover_plan *p, void *dDst, size_t nRecords, void *stream) {
+    refuseWhileInFlight(p, "hgx_liftover_copy_records");
     if (nRecords > p->stats.records)
         throw std::runtime_error("more records requested than the last run produced");
     HIP_OK(hipSetDevice(p->device));
@@ -1861,6 +1992,7 @@ void liftoverPlanSetTiming(hgx_liftover_plan *p, int mode) {
 }
 
 void liftoverPlanCopyRecordsPacked(const hgx_liftover_plan *p, void *dDst, size_t nRecords, void *stream) {
+    refuseWhileInFlight(p, "hgx_liftover_copy_records_packed");
     if (nRecords > p->stats.records)
         throw std::runtime_error("more records requested than the last run produced");
     HIP_OK(hipSetDevice(p->device));
@@ -1872,6 +2004,7 @@ void liftoverPlanCopyRecordsPacked(const hgx_liftover_plan *p, void *dDst, size_
 
 // The last run's records as one self-describing blob for the multi-GPU exchange (include/hgx.h: hgx_liftover_wire_blob).
 size_t liftoverPlanWireBlob(hgx_liftover_plan *p, void *dDst, size_t capacity, int64_t firstQuery, int *format, void *stream) {
+    refuseWhileInFlight(p, "hgx_liftover_wire_blob");
     HIP_OK(hipSetDevice(p->device));
     hipStream_t s = (hipStream_t)stream;
     const size_t nrec = (size_t)p->stats.records, nq = (size_t)p->stats.queries;
@@ -2006,9 +2139,15 @@ static void intervalsToGenomeCoordinates(const GenomeTables &G, size_t n, const 
     st.resize(n);
     for (size_t i = 0; i < n; ++i) {
         const hgx_interval &q = iv[i];
-        bool ok = q.seq >= 0 && q.seq < (int32_t)G.seqs.size() && q.start >= 0 && q.start < q.end;
+        // (a negative start is not checked by the reference: Liftover::visitLine, halLiftover.cpp:52-66, only looks at the end, and
+        // liftInterval adds the sequence's start (halBlockLiftover.cpp:48) — the interval then begins in the sequence in front.
+        // Same arithmetic here and in the text path; only a start in front of the genome's first base, where the reference's
+        // toSite has nothing to stand on, makes the interval empty)
+        bool ok = q.seq >= 0 && q.seq < (int32_t)G.seqs.size() && q.start < q.end;
         if (ok)
             ok = q.end <= G.seqs[(size_t)q.seq].length; // halLiftover.cpp:62-66: skipped, not an error
+        if (ok)
+            ok = q.start + G.seqs[(size_t)q.seq].start >= 0;
         if (ok) {
             gs[i] = q.start + G.seqs[(size_t)q.seq].start;       // halBlockLiftover.cpp:48
             ge[i] = q.end - 1 + G.seqs[(size_t)q.seq].start;     // :49

@@ -402,8 +402,11 @@ void Liftover::convertBuffer(hgx_alignment *al, int srcGenome, const char *text,
         _missedSet.clear();
         std::vector<hgx_alignment *> als{al};
         als.insert(als.end(), moreDevices.begin(), moreDevices.end());
+        size_t lines = batchLines;
+        if (const char *e = getenv("HGX_BATCH_LINES"))
+            lines = (size_t)std::max<long long>(1, atoll(e));
         if (liftoverTextFast(als.data(), (int)als.size(), srcGenome, text, len, tgtGenome, bedType, traverseDupes, coalescenceLimit, outText, outLen,
-                             error, _missedSet, lastStats)) {
+                             error, _missedSet, lastStats, lines)) {
             if (!error.empty())
                 throw std::runtime_error(error);
             return;

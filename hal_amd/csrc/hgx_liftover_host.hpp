@@ -62,7 +62,7 @@ class Liftover {
     // further handles of the same alignment on other devices (hgx_clone_to_device): convert / convertBuffer shard the lines
     // of inputs the parallel text path takes over `alignment` and these
     std::vector<hgx_alignment *> moreDevices;
-    // intervals per device batch (memory bound only)
+    // intervals per device batch (memory bound only; HGX_BATCH_LINES in the environment overrides it: tests)
     size_t batchLines = 1u << 22;
     hgx_liftover_stats lastStats{};
 
@@ -84,6 +84,6 @@ class Liftover {
 // als: one handle per device (hgx_clone_to_device); the lines are dealt to them in contiguous shares
 bool liftoverTextFast(hgx_alignment *const *als, int nAls, int srcGenome, const char *text, size_t len, int tgtGenome, int bedType,
                       bool traverseDupes, int coalescenceLimit, char **outText, size_t *outLen, std::string &error,
-                      std::set<std::string> &missedSet, hgx_liftover_stats &stats);
+                      std::set<std::string> &missedSet, hgx_liftover_stats &stats, size_t batchLines);
 
 } // namespace hgx

@@ -292,7 +292,7 @@ template <typename F> void forEachChunk(std::vector<Chunk> &chunks, unsigned thr
 
 bool liftoverTextFast(hgx_alignment *const *als, int nAls, int srcGenome, const char *text, size_t len, int tgtGenome, int bedType,
                       bool traverseDupes, int coalescenceLimit, char **outText, size_t *outLen, std::string &error,
-                      std::set<std::string> &missedSet, hgx_liftover_stats &stats) {
+                      std::set<std::string> &missedSet, hgx_liftover_stats &stats, size_t batchLines) {
     *outText = nullptr;
     *outLen = 0;
     hgx_alignment *al = als[0];
@@ -310,10 +310,11 @@ bool liftoverTextFast(hgx_alignment *const *als, int nAls, int srcGenome, const 
     const auto t0 = now();
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     const unsigned threads = (unsigned)std::min<size_t>(std::min(hw, 32u), len / (1u << 18) + 1);
-    // chunks: about four per thread, cut behind a newline
+    // chunks: about four per thread, cut behind a newline; no chunk larger than 16 MB of text, so that a device batch (whole
+    // chunks, at most batchLines intervals: below) stays bounded on inputs of any size
     std::vector<Chunk> chunks;
     {
-        const size_t want = (size_t)threads * 4, per = len / want + 1;
+        const size_t want = std::max<size_t>((size_t)threads * 4, len / ((size_t)16 << 20) + 1), per = len / want + 1;
         const char *p = text, *end = text + len;
         while (p < end) {
             const char *q = p + per < end ? p + per : end;
@@ -382,71 +383,141 @@ bool liftoverTextFast(hgx_alignment *const *als, int nAls, int srcGenome, const 
             devQueries[(size_t)d] += C.numQueries;
         }
     }
-    std::vector<int64_t *> gs((size_t)nAls), ge((size_t)nAls);
-    std::vector<uint8_t *> st((size_t)nAls);
-    for (int d = 0; d < nAls; ++d)
-        if (devQueries[(size_t)d])
-            liftoverStageQueries(als[d], devQueries[(size_t)d], &gs[(size_t)d], &ge[(size_t)d], &st[(size_t)d]);
-    forEachChunk(chunks, threads, [&](Chunk &C) {
-        size_t q = C.firstQuery;
-        int64_t *s0 = gs[(size_t)C.device], *e0 = ge[(size_t)C.device];
-        uint8_t *t0 = st[(size_t)C.device];
-        for (Line &L : C.lines) {
-            if (L.seq < 0) {
-                L.query = -1;
-                continue;
-            }
-            const int64_t off = S.seqs[(size_t)L.seq].start;
-            s0[q] = L.start + off;     // halBlockLiftover.cpp:48
-            e0[q] = L.end - 1 + off;   // :49
-            t0[q] = (uint8_t)L.strand;
-            L.query = (int64_t)q++;
+    // Every device works through its share in groups of whole chunks of at most batchLines intervals (a chunk of more than
+    // that is a group of its own): stage, lift, render, next group — the plan, the pinned staging and the records in flight are
+    // sized by a group, not by the input.  Round r runs the r-th group of every device at the same time.
+    batchLines = std::max<size_t>(batchLines, 1);
+    struct Group {
+        size_t firstChunk, endChunk, numQueries;
+    };
+    std::vector<std::vector<Group>> groups((size_t)nAls);
+    for (size_t i = 0; i < chunks.size();) {
+        const int d = chunks[i].device;
+        Group g{i, i, 0};
+        while (g.endChunk < chunks.size() && chunks[g.endChunk].device == d &&
+               (g.endChunk == g.firstChunk || g.numQueries + chunks[g.endChunk].numQueries <= batchLines)) {
+            chunks[g.endChunk].firstQuery = g.numQueries; // (inside the group's batch)
+            g.numQueries += chunks[g.endChunk].numQueries;
+            ++g.endChunk;
         }
-    });
-    const auto t2 = now();
+        groups[(size_t)d].push_back(g);
+        i = g.endChunk;
+    }
+    size_t rounds = 0;
+    for (int d = 0; d < nAls; ++d)
+        rounds = std::max(rounds, groups[(size_t)d].size());
     hgx_liftover_opts opts{};
     opts.traverse_dupes = traverseDupes ? 1 : 0;
     opts.coalescence_limit = coalescenceLimit;
-    std::vector<const hgx_record *> recs((size_t)nAls, nullptr);
-    std::vector<size_t> nRecs((size_t)nAls, 0);
-    std::vector<hgx_liftover_stats> devStats((size_t)nAls);
-    std::vector<std::string> devError((size_t)nAls);
-    {
-        auto run = [&](int d) {
-            if (!devQueries[(size_t)d])
-                return;
-            try {
-                liftoverBatchStaged(als[d], srcGenome, tgtGenome, devQueries[(size_t)d], opts, &recs[(size_t)d], &nRecs[(size_t)d], &devStats[(size_t)d]);
-            } catch (std::exception &e) {
-                devError[(size_t)d] = e.what();
+    double msStage = 0, msDevice = 0, msRender = 0;
+    // a device error ends the input at the first line of the group that failed (below): groups behind it are not run, groups
+    // in front of it — other devices' later rounds — still are
+    size_t limit = chunks.size();
+    std::string devFailure;
+    for (size_t round = 0; round < rounds; ++round) {
+        const auto r0 = now();
+        std::vector<int64_t *> gs((size_t)nAls, nullptr), ge((size_t)nAls, nullptr);
+        std::vector<uint8_t *> st((size_t)nAls, nullptr);
+        std::vector<Chunk *> mine; // the chunks of this round
+        std::vector<const Group *> grp((size_t)nAls, nullptr);
+        for (int d = 0; d < nAls; ++d)
+            if (round < groups[(size_t)d].size() && groups[(size_t)d][round].firstChunk < limit) {
+                grp[(size_t)d] = &groups[(size_t)d][round];
+                if (grp[(size_t)d]->numQueries)
+                    liftoverStageQueries(als[d], grp[(size_t)d]->numQueries, &gs[(size_t)d], &ge[(size_t)d], &st[(size_t)d]);
+                for (size_t i = grp[(size_t)d]->firstChunk; i < grp[(size_t)d]->endChunk; ++i)
+                    mine.push_back(&chunks[i]);
             }
+        auto forMine = [&](auto f) {
+            std::atomic<size_t> next{0};
+            auto work = [&]() {
+                for (size_t i; (i = next.fetch_add(1)) < mine.size();)
+                    f(*mine[i]);
+            };
+            std::vector<std::thread> pool;
+            for (unsigned t = 1; t < threads && t < mine.size(); ++t)
+                pool.emplace_back(work);
+            work();
+            for (std::thread &t : pool)
+                t.join();
         };
-        std::vector<std::thread> pool;
-        for (int d = 1; d < nAls; ++d)
-            pool.emplace_back(run, d);
-        run(0);
-        for (std::thread &t : pool)
-            t.join();
-    }
-    for (int d = 0; d < nAls; ++d) {
-        if (!devError[(size_t)d].empty()) { // (the reference's scanner adds the line to whatever visitLine throws)
-            error = devError[(size_t)d] + " in input bed line 1";
-            return true;
+        forMine([&](Chunk &C) {
+            size_t q = C.firstQuery;
+            int64_t *s0 = gs[(size_t)C.device], *e0 = ge[(size_t)C.device];
+            uint8_t *t0 = st[(size_t)C.device];
+            for (Line &L : C.lines) {
+                if (L.seq < 0) {
+                    L.query = -1;
+                    continue;
+                }
+                const int64_t off = S.seqs[(size_t)L.seq].start;
+                s0[q] = L.start + off;     // halBlockLiftover.cpp:48
+                e0[q] = L.end - 1 + off;   // :49
+                t0[q] = (uint8_t)L.strand;
+                L.query = (int64_t)q++;
+            }
+        });
+        const auto r1 = now();
+        std::vector<const hgx_record *> recs((size_t)nAls, nullptr);
+        std::vector<size_t> nRecs((size_t)nAls, 0);
+        std::vector<hgx_liftover_stats> devStats((size_t)nAls);
+        std::vector<std::string> devError((size_t)nAls);
+        {
+            auto run = [&](int d) {
+                if (!grp[(size_t)d] || !grp[(size_t)d]->numQueries)
+                    return;
+                try {
+                    liftoverBatchStaged(als[d], srcGenome, tgtGenome, grp[(size_t)d]->numQueries, opts, &recs[(size_t)d], &nRecs[(size_t)d],
+                                        &devStats[(size_t)d]);
+                } catch (std::exception &e) {
+                    devError[(size_t)d] = e.what();
+                }
+            };
+            std::vector<std::thread> pool;
+            for (int d = 1; d < nAls; ++d)
+                pool.emplace_back(run, d);
+            run(0);
+            for (std::thread &t : pool)
+                t.join();
         }
-        stats.queries += devStats[(size_t)d].queries;
-        stats.records += devStats[(size_t)d].records;
-        stats.mapped_pieces += devStats[(size_t)d].mapped_pieces;
-        stats.top_derefs += devStats[(size_t)d].top_derefs;
-        stats.bottom_derefs += devStats[(size_t)d].bottom_derefs;
-        stats.deferred_queries += devStats[(size_t)d].deferred_queries;
-        stats.general_queries += devStats[(size_t)d].general_queries;
-        stats.total_ms = std::max(stats.total_ms, devStats[(size_t)d].total_ms);
-        stats.walk_ms = std::max(stats.walk_ms, devStats[(size_t)d].walk_ms);
-        stats.composed_kind = devStats[(size_t)d].composed_kind;
-        stats.composed_records = devStats[(size_t)d].composed_records;
+        for (int d = 0; d < nAls; ++d) {
+            if (!devError[(size_t)d].empty()) {
+                // (the reference's scanner adds the line to whatever visitLine throws: here the first line of the group that failed;
+                // what lies in front of it in input order keeps its output, like the lines in front of a malformed one)
+                if (grp[(size_t)d]->firstChunk < limit) {
+                    limit = grp[(size_t)d]->firstChunk;
+                    devFailure = devError[(size_t)d] + " in input bed line " + std::to_string(chunks[limit].firstLine + 1);
+                }
+                continue;
+            }
+            stats.queries += devStats[(size_t)d].queries;
+            stats.records += devStats[(size_t)d].records;
+            stats.mapped_pieces += devStats[(size_t)d].mapped_pieces;
+            stats.top_derefs += devStats[(size_t)d].top_derefs;
+            stats.bottom_derefs += devStats[(size_t)d].bottom_derefs;
+            stats.deferred_queries += devStats[(size_t)d].deferred_queries;
+            stats.general_queries += devStats[(size_t)d].general_queries;
+            stats.total_ms = std::max(stats.total_ms, devStats[(size_t)d].total_ms);
+            stats.walk_ms = std::max(stats.walk_ms, devStats[(size_t)d].walk_ms);
+            stats.composed_kind = devStats[(size_t)d].composed_kind;
+            stats.composed_records = devStats[(size_t)d].composed_records;
+        }
+        const auto r2 = now();
+        forMine([&](Chunk &C) {
+            if (C.numQueries && devError[(size_t)C.device].empty())
+                renderChunk(C, recs[(size_t)C.device], nRecs[(size_t)C.device], T);
+            std::vector<Line>().swap(C.lines); // (the tokens of a rendered chunk are not needed any more)
+        });
+        const auto r3 = now();
+        msStage += ms(r0, r1);
+        msDevice += ms(r1, r2);
+        msRender += ms(r2, r3);
     }
-    const auto t3 = now();
-    forEachChunk(chunks, threads, [&](Chunk &C) { renderChunk(C, recs[(size_t)C.device], nRecs[(size_t)C.device], T); });
+    if (!devFailure.empty()) {
+        error = devFailure; // (it lies in front of any malformed line, which ended the input)
+        for (size_t i = limit; i < chunks.size(); ++i)
+            chunks[i].out.clear();
+    }
     const auto t4 = now();
     size_t total = 0;
     for (Chunk &C : chunks) {
@@ -467,9 +538,9 @@ bool liftoverTextFast(hgx_alignment *const *als, int nAls, int srcGenome, const 
     *outText = buf;
     *outLen = total;
     if (timing)
-        std::cerr << "[hgx text] " << threads << " threads, " << nAls << " device(s), " << chunks.size() << " chunks: tokenise " << ms(t0, t1) << " ms, stage " << ms(t1, t2)
-                  << ", device (H2D, kernels, D2H) " << ms(t2, t3) << ", render " << ms(t3, t4) << ", allocate output " << ms(t4, t5) << ", gather "
-                  << ms(t5, now()) << std::endl;
+        std::cerr << "[hgx text] " << threads << " threads, " << nAls << " device(s), " << chunks.size() << " chunks, " << rounds << " round(s): tokenise "
+                  << ms(t0, t1) << " ms, stage " << msStage << ", device (H2D, kernels, D2H) " << msDevice << ", render " << msRender
+                  << ", allocate output " << ms(t4, t5) << ", gather " << ms(t5, now()) << std::endl;
     return true;
 }
 

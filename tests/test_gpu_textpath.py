@@ -147,3 +147,52 @@ def test_lines_shared_out_over_device_clones(hal, oracle_bin, tmp_path):
     open(inp, "w").write(bed)
     subprocess.check_call([tool, "--devices", "0,0", img, "Genome_9", inp, "Genome_2", outp])
     assert open(outp).read() == one
+
+
+def test_device_batches_of_bounded_size(hal, oracle_bin, tmp_path, monkeypatch):
+    """The text path lifts its chunks in groups of at most batchLines intervals per device (HGX_BATCH_LINES here): an input of many
+    groups — on one handle and dealt over three — gives the bytes of one batch, a malformed line in a later group ends the output
+    where it stands, and the plan that serves it was sized for a group, not for the input."""
+    al, img = _rand_alignment(hal, tmp_path, 2)
+    clones = [al, al.clone_to_device(0), al.clone_to_device(0)]
+    src, tgt = al.genome_id("Genome_9"), al.genome_id("Genome_2")
+    name, _, length = al.sequences(src)[0]
+    rng = np.random.default_rng(12)
+    body = _lines(name, length, 60000, 6, rng)
+    bed = "\n".join(body) + "\n"
+    one = hal.liftover_convert(al, src, bed, tgt)
+    assert one == oracle_liftover(oracle_bin, img, "Genome_9", "Genome_2", bed, tmp_path)
+    for lines in ("1", "700", "5000"):
+        monkeypatch.setenv("HGX_BATCH_LINES", lines)
+        assert hal.liftover_convert(al, src, bed, tgt) == one, lines
+        assert hal.liftover_convert_multi(clones, src, bed, tgt) == one, lines
+    monkeypatch.setenv("HGX_BATCH_LINES", "900")
+    bad = body[:41000] + ["%s\t10\t5\tq\t0\t+" % name] + body[41000:]
+    with pytest.raises(hal.HgxError, match="in input bed line 41001") as e:
+        hal.liftover_convert_multi(clones, src, "\n".join(bad) + "\n", tgt)
+    monkeypatch.delenv("HGX_BATCH_LINES")
+    assert e.value.partial_output == hal.liftover_convert(al, src, "\n".join(body[:41000]) + "\n", tgt)
+
+
+def test_negative_start_lands_in_the_sequence_in_front(hal, oracle_bin, tmp_path):
+    """chromStart < 0 is not checked by the reference (halLiftover.cpp:52-66 looks at the end only; halBlockLiftover.cpp:48 adds the
+    sequence's start): the interval begins in the sequence in front.  Text path, general path and oracle agree."""
+    import halfix
+    img = str(tmp_path / "ms.hgx")
+    halfix.write_hgx(img, halfix.random_multiseq_alignment(3, n_genomes=6, max_seqs=5))
+    al = hal.Alignment.open(img, device=0)
+    checked = 0
+    for s in range(al.num_genomes):
+        seqs = [q for q in al.sequences(s) if q[2] > 0]
+        for k in range(1, len(seqs)):
+            name, start, length = seqs[k]
+            back = min(7, start)
+            if back == 0:
+                continue
+            bed = "%s\t%d\t%d\tneg\t0\t+\n%s\t0\t%d\tpos\t0\t-\n" % (name, -back, min(length, 9), name, min(length, 9))
+            for t in range(al.num_genomes):
+                status, text = _both(hal, al, s, bed, t)
+                assert status == "ok"
+                assert text == oracle_liftover(oracle_bin, img, al.genome_name(s), al.genome_name(t), bed, tmp_path), (s, k, t)
+                checked += 1
+    assert checked > 10
