@@ -97,7 +97,7 @@ static __global__ void __launch_bounds__(256) k_merge_keys_high(const ComposedRe
 }
 
 // After the sort a junction with exactly one right end followed by exactly one left end links two pieces — if they lie on
-// the same target sequence (halBlockMapper.cpp:366) and the same source sequence.  Junctions claimed by more pieces are
+// the same target sequence (halBlockMapper.cpp:366).  Junctions claimed by more pieces are
 // left alone: those pieces tie or overlap on the target at distance zero, so they are flagged and never read as merged.
 // (The junctions are read back from the records: the sorted order is all the sort is needed for.)
 template <typename C>
@@ -131,8 +131,11 @@ static __global__ void __launch_bounds__(256) k_merge_link(const uint32_t *__res
     }
     if (tNumSeq > 1 && seq_of(tSeqStart, tNumSeq, (int64_t)ra.so) != seq_of(tSeqStart, tNumSeq, (int64_t)rb.so))
         return;
-    if (sNumSeq > 1 && seq_of(sSeqStart, sNumSeq, (int64_t)ra.sLo) != seq_of(sSeqStart, sNumSeq, (int64_t)rb.sLo))
-        return;
+    // (the source sequence is not looked at: canMergeRightWith only asserts that it is the same, halMappedSegment.cpp:118, and an
+    // interval that reaches into the sequence in front — a negative chromStart, which the reference does not check — is merged
+    // across the boundary there; intervals inside one sequence never see such a junction)
+    (void)sSeqStart;
+    (void)sNumSeq;
     root[B] = A; // B hangs under its left neighbour (root[] starts as the identity)
 }
 

@@ -174,10 +174,14 @@ def test_device_batches_of_bounded_size(hal, oracle_bin, tmp_path, monkeypatch):
     assert e.value.partial_output == hal.liftover_convert(al, src, "\n".join(body[:41000]) + "\n", tgt)
 
 
-def test_negative_start_lands_in_the_sequence_in_front(hal, oracle_bin, tmp_path):
+@pytest.mark.parametrize("table", [False, True])
+def test_negative_start_lands_in_the_sequence_in_front(hal, oracle_bin, tmp_path, monkeypatch, table):
     """chromStart < 0 is not checked by the reference (halLiftover.cpp:52-66 looks at the end only; halBlockLiftover.cpp:48 adds the
-    sequence's start): the interval begins in the sequence in front.  Text path, general path and oracle agree."""
+    sequence's start): the interval begins in the sequence in front.  Text path, general path and oracle agree — with the walk
+    and with the merged table (whose chains are not cut at the source's sequence boundaries for this reason)."""
     import halfix
+    if table:
+        monkeypatch.setenv("HGX_COMPOSED_UP", "1")
     img = str(tmp_path / "ms.hgx")
     halfix.write_hgx(img, halfix.random_multiseq_alignment(3, n_genomes=6, max_seqs=5))
     al = hal.Alignment.open(img, device=0)
