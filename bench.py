@@ -134,7 +134,7 @@ def timed_steps(step, k, sync):
     return time.perf_counter() - t0, r
 
 
-def steady_legs(hal_amd, torch, al, src, tgt, d_gs, d_ge, d_st, steps, sync, rec_bytes=16):
+def steady_legs(hal_amd, torch, al, src, tgt, d_gs, d_ge, d_st, steps, sync, rec_bytes=16, streams=None):
     """The timed configuration's three measurements on another alignment / another table width: two plans with a batch each in
     flight (hgx_liftover_submit / _collect), one plan batch after batch (hgx_liftover_run_device), and the kernels of the latter
     with HIP events around every launch, each priced by its own bytes (plan_kernel_bytes)."""
@@ -144,7 +144,9 @@ def steady_legs(hal_amd, torch, al, src, tgt, d_gs, d_ge, d_st, steps, sync, rec
         for _ in range(3):  # (change-over to the table, workspace growth, the launches for intervals passed on)
             p.run(d_gs, d_ge, d_st)
         p.set_timing(0)
-    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    # (the two streams of the main measurement where there are some: later streams of a process may share a hardware queue, and
+    # two batches on one queue do not overlap — seen as a wide leg with no gain from the second batch, profiles/r03a_bench.log)
+    streams = streams or [torch.cuda.Stream(), torch.cuda.Stream()]
     pending = [False, False]
 
     def two(k_steps):
@@ -682,7 +684,8 @@ def main():
                 alw = al.clone_to_device(local)
             finally:
                 del os.environ["HGX_FORCE_WIDE"]
-            w = steady_legs(hal_amd, torch, alw, src, tgt, d_gs, d_ge, d_st, args.steps, sync, rec_bytes=32)
+            w = steady_legs(hal_amd, torch, alw, src, tgt, d_gs, d_ge, d_st, args.steps, sync, rec_bytes=32,
+                            streams=streams if in_flight == 2 else None)
             w["what"] = ("the timed configuration on int64-coordinate tables (HGX_FORCE_WIDE=1 copy of the same alignment: 32-byte table "
                          "records): same batch, same records")
             w["records_match"] = w["records_per_step"] == nrec_all
@@ -701,7 +704,8 @@ def main():
             _, ss4, len4 = al4.sequences(s4)[0]
             nq4 = 1250000
             st4, ln4, sd4 = make_queries(len4, nq4, 1234)
-            c4 = steady_legs(hal_amd, torch, al4, s4, t4, (st4 + ss4).to(dev), (st4 + ln4 - 1 + ss4).to(dev), sd4.to(dev), max(5, args.steps // 4), sync)
+            c4 = steady_legs(hal_amd, torch, al4, s4, t4, (st4 + ss4).to(dev), (st4 + ln4 - 1 + ss4).to(dev), sd4.to(dev), max(5, args.steps // 4), sync,
+                             streams=streams if in_flight == 2 else None)
             c4["what"] = ("BASELINE config 4, one GPU's shard: halRandGen 50-genome alignment (seed 0, meanDegree 2), %d BED6 intervals "
                           "Genome_44 -> Genome_2" % nq4)
             c4["generate_s"] = round(gen4, 2)

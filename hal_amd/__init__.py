@@ -9,6 +9,7 @@ from .api import (  # noqa: F401
     Alignment,
     LiftoverPlan,
     build_phases,
+    format_block_results,
     Comm,
     Interval,
     Record,

@@ -85,6 +85,11 @@ SYMBOLS = {
                                      P(P(hgx_record)), P(C.c_size_t), P(VP)]),
     "hgx_block_map": (C.c_int, [VP, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int, P(P(hgx_record)),
                                 P(C.c_size_t), P(VP)]),
+    "hgx_get_blocks_in_target_range": (VP, [VP, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                            C.c_char_p, P(VP)]),
+    "hgx_get_blocks_in_target_ranges": (C.c_int, [VP, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, P(C.c_int64), P(C.c_int64), C.c_int64,
+                                                  C.c_int, C.c_int, C.c_int, C.c_char_p, P(VP), P(VP)]),
+    "hgx_free_block_results": (None, [VP]),
     "hgx_columns_depth_stats": (C.c_int, [VP, C.c_int, C.c_int64, C.c_int64, C.c_int64, P(hgx_column_opts), P(C.c_uint64), P(C.c_uint64),
                                           P(VP)]),
     "hgx_liftover_plan_set_timing": (C.c_int, [VP, C.c_int]),

@@ -49,14 +49,20 @@ class RandOptions:
     with_dna: object = True  # True: halRandGen's stream; False: no DNA (different, faster stream); "fast": False's alignment + DNA from a fast generator
 
     @staticmethod
-    def preset(name, seed=-1, with_dna=True):
+    def preset(name, seed=-1, with_dna=True, **overrides):
+        """halRandGen --preset <name> [--minSegmentLength ...]: the preset's values, then the options given (randgen/halRandGen.cpp:58-108)"""
         o = hgx_rand_opts()
         o.seed = seed
         o.with_dna = 1 if with_dna else 0
         if lib.hgx_rand_preset(name.encode(), C.byref(o)) != 0:
             raise HgxError("invalid --preset value: %s" % name)
-        return RandOptions(o.mean_degree, o.max_branch_length, o.min_genomes, o.max_genomes, o.min_segment_length,
-                           o.max_segment_length, o.min_segments, o.max_segments, seed, with_dna)
+        r = RandOptions(o.mean_degree, o.max_branch_length, o.min_genomes, o.max_genomes, o.min_segment_length,
+                        o.max_segment_length, o.min_segments, o.max_segments, seed, with_dna)
+        for k, v in overrides.items():
+            if not hasattr(r, k):
+                raise HgxError("no such halRandGen option: %s" % k)
+            setattr(r, k, v)
+        return r
 
     def _c(self):
         o = hgx_rand_opts()
@@ -183,6 +189,34 @@ class Alignment:
             return np.frombuffer(C.string_at(out, n.value * C.sizeof(hgx_record)), dtype=RECORD_DTYPE).copy()
         finally:
             lib.hgx_free(out)
+
+    def blocks_in_target_ranges(self, q_species, t_species, t_chrom, ranges, t_reversed=False, seq=False, dup_mode=2, adjacencies=True,
+                                coalescence_limit=None):
+        """halGetBlocksInTargetRange (blockViz/inc/halBlockViz.h:222-225) for every (t_start, t_end) of `ranges` in one call
+        (hgx_get_blocks_in_target_ranges).  Per range: (blocks, target_dupes) — blocks = list of dicts with the fields of
+        hal_block_t (qChrom, tStart, qStart, size, strand, qSequence, tSequence), target_dupes = list of (id, qChrom, [(tStart,
+        size), ...])."""
+        n = len(ranges)
+        starts = (C.c_int64 * max(n, 1))(*[r[0] for r in ranges])
+        ends = (C.c_int64 * max(n, 1))(*[r[1] for r in ranges])
+        res = (C.c_void_p * max(n, 1))()
+        err = C.c_void_p()
+        lim = coalescence_limit.encode() if coalescence_limit is not None else None
+        if lib.hgx_get_blocks_in_target_ranges(self._h, q_species.encode(), t_species.encode(), t_chrom.encode(), n, starts, ends,
+                                               1 if t_reversed else 0, 1 if seq else 0, dup_mode, 1 if adjacencies else 0, lim,
+                                               C.cast(res, C.POINTER(C.c_void_p)), C.byref(err)) != 0:
+            raise HgxError(take_error(err))
+        out = []
+        for k in range(n):
+            try:
+                out.append(_read_block_results(res[k]))
+            finally:
+                lib.hgx_free_block_results(res[k])
+        return out
+
+    def blocks_in_target_range(self, q_species, t_species, t_chrom, t_start, t_end, **kw):
+        """halGetBlocksInTargetRange for one range: (blocks, target_dupes)"""
+        return self.blocks_in_target_ranges(q_species, t_species, t_chrom, [(t_start, t_end)], **kw)[0]
 
     def liftover_batch(self, src, tgt, intervals, traverse_dupes=True, min_length=0, coalescence_limit=-1):
         """intervals: numpy array of INTERVAL_DTYPE or list of Interval.  Returns a numpy array of RECORD_DTYPE."""
@@ -383,6 +417,67 @@ class Comm:
 
     def __del__(self):
         self.close()
+
+
+class _TargetRange(C.Structure):
+    pass
+
+
+_TargetRange._fields_ = [("next", C.POINTER(_TargetRange)), ("tStart", C.c_int64), ("size", C.c_int64)]
+
+
+class _TargetDupe(C.Structure):
+    pass
+
+
+_TargetDupe._fields_ = [("next", C.POINTER(_TargetDupe)), ("id", C.c_int64), ("tRange", C.POINTER(_TargetRange)), ("qChrom", C.c_char_p)]
+
+
+class _Block(C.Structure):
+    pass
+
+
+_Block._fields_ = [("next", C.POINTER(_Block)), ("qChrom", C.c_char_p), ("tStart", C.c_int64), ("qStart", C.c_int64), ("size", C.c_int64),
+                   ("strand", C.c_char), ("qSequence", C.c_char_p), ("tSequence", C.c_char_p)]
+
+
+class _BlockResults(C.Structure):
+    _fields_ = [("mappedBlocks", C.POINTER(_Block)), ("targetDupeBlocks", C.POINTER(_TargetDupe))]
+
+
+def _read_block_results(ptr):
+    r = C.cast(ptr, C.POINTER(_BlockResults)).contents
+    blocks, dupes = [], []
+    b = r.mappedBlocks
+    while b:
+        x = b.contents
+        blocks.append({"qChrom": x.qChrom.decode(), "tStart": x.tStart, "qStart": x.qStart, "size": x.size, "strand": x.strand.decode(),
+                       "qSequence": x.qSequence.decode() if x.qSequence is not None else None,
+                       "tSequence": x.tSequence.decode() if x.tSequence is not None else None})
+        b = x.next
+    d = r.targetDupeBlocks
+    while d:
+        x = d.contents
+        ranges, t = [], x.tRange
+        while t:
+            ranges.append((t.contents.tStart, t.contents.size))
+            t = t.contents.next
+        dupes.append((x.id, x.qChrom.decode(), ranges))
+        d = x.next
+    return blocks, dupes
+
+
+def format_block_results(blocks, dupes):
+    """what blockVizTest --verbose prints for a result (blockViz/tests/blockVizTest.cpp:103-113)"""
+    out = []
+    for b in blocks:
+        out.append("chr:%s, tSt:%d, qSt:%d, size:%d, strand:%s: tgt : %s query: %s\n"
+                   % (b["qChrom"], b["tStart"], b["qStart"], b["size"], b["strand"],
+                      "(null)" if b["tSequence"] is None else b["tSequence"][:10], "(null)" if b["qSequence"] is None else b["qSequence"][:10]))
+    for did, chrom, ranges in dupes:
+        out.append("tDupe id:%d qCrhom:%s\n" % (did, chrom))
+        out += [" tSt:%d size:%d\n" % r for r in ranges]
+    return "".join(out)
 
 
 def build_phases():

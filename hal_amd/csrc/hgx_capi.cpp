@@ -315,6 +315,111 @@ int hgx_block_map(hgx_alignment *h, int ref, int query, int64_t abs_ref_first, i
     HGX_CATCH
 }
 
+void hgx_free_block_results(hgx_block_results *results) { // halFreeBlockResults (blockViz/impl/halBlockViz.cpp:207-241)
+    if (!results)
+        return;
+    for (hgx_block *b = results->mappedBlocks; b;) {
+        hgx_block *next = b->next;
+        free(b->qChrom);
+        free(b->qSequence);
+        free(b->tSequence);
+        free(b);
+        b = next;
+    }
+    for (hgx_target_dupe_list *d = results->targetDupeBlocks; d;) {
+        hgx_target_dupe_list *next = d->next;
+        for (hgx_target_range *r = d->tRange; r;) {
+            hgx_target_range *rn = r->next;
+            free(r);
+            r = rn;
+        }
+        free(d->qChrom);
+        free(d);
+        d = next;
+    }
+    free(results);
+}
+
+int hgx_get_blocks_in_target_ranges(hgx_alignment *h, const char *q_species, const char *t_species, const char *t_chrom, size_t n,
+                                    const int64_t *t_starts, const int64_t *t_ends, int64_t t_reversed, int seq_mode, int dup_mode,
+                                    int map_back_adjacencies, const char *coalescence_limit_name, hgx_block_results **results, char **err) {
+    std::vector<hgx_block_results *> out;
+    if (results)
+        for (size_t k = 0; k < n; ++k)
+            results[k] = nullptr;
+    try {
+        if (!h || !q_species || !t_species || !t_chrom || !results || (n && (!t_starts || !t_ends)))
+            throw std::runtime_error("hgx_get_blocks_in_target_ranges: null argument");
+        if (!h->dev)
+            throw std::runtime_error("alignment was opened without a device (device = -1); the block mapper needs the HIP path");
+        // halGetBlocksInTargetRange's own checks, with its messages (halBlockViz.cpp:251-302; checkGenomes :716-738)
+        if (t_reversed != 0 && map_back_adjacencies != 0)
+            throw std::runtime_error("halGetBlocksInTargetRange tReversed can only be set when mapBackAdjacencies is 0");
+        if (t_reversed != 0 && dup_mode == 2)
+            throw std::runtime_error("tReversed cannot be set in conjunction with dupMode=HAL_QUERY_AND_TARGET_DUPS");
+        const Image &img = h->img;
+        const int q = img.genomeByName(q_species), t = img.genomeByName(t_species);
+        if (q < 0)
+            throw std::runtime_error(std::string("Query species ") + q_species + " not found in alignment");
+        if (t < 0)
+            throw std::runtime_error(std::string("Reference species ") + t_species + " not found in alignment");
+        const GenomeTables &T = img.genomes[(size_t)t];
+        const int s = T.seqIndexByName(t_chrom);
+        if (s < 0)
+            throw std::runtime_error(std::string("Unable to locate sequence ") + t_chrom + " in genome " + t_species);
+        int limit = -1;
+        if (coalescence_limit_name) {
+            limit = img.genomeByName(coalescence_limit_name);
+            if (limit < 0)
+                throw std::runtime_error(std::string("Could not find coalescence limit ") + coalescence_limit_name + " in alignment");
+            // (the reference finds out while it climbs, halSegmentMapper.cpp:541; an ancestor of the MRCA is what it can use)
+            int g = img.lca(q, t);
+            while (g >= 0 && g != limit)
+                g = img.genomes[(size_t)g].parent;
+            if (g < 0)
+                throw std::runtime_error("Hit root genome when attempting to map paralogies");
+        }
+        const SeqInfo &S = T.seqs[(size_t)s];
+        std::vector<std::pair<int64_t, int64_t>> ranges;
+        for (size_t k = 0; k < n; ++k) {
+            const int64_t tStart = t_starts[k], tEnd = t_ends[k];
+            if (tEnd - tStart < 0)
+                throw std::runtime_error("halGetBlocksInTargetRange invalid query range [" + std::to_string(tStart) + "," + std::to_string(tEnd) + ")");
+            const int64_t myEnd = tEnd > 0 ? tEnd : S.length;
+            const int64_t absStart = S.start + tStart, absEnd = S.start + myEnd - 1;
+            if (absStart > absEnd || tStart < 0)
+                throw std::runtime_error("halGetBlocksInTargetRange invalid range");
+            if (absEnd > S.start + S.length - 1)
+                throw std::runtime_error("halGetBlocksInTargetRange target end position outside of target sequence");
+            ranges.emplace_back(absStart, absEnd);
+        }
+        hgx::blocksInTargetRanges(h, q, t, ranges, t_reversed != 0, seq_mode != 0, dup_mode != 0, dup_mode == 2, map_back_adjacencies != 0, limit, out);
+        for (size_t k = 0; k < n; ++k)
+            results[k] = out[k];
+        return HGX_OK;
+    } catch (std::exception &e) {
+        for (hgx_block_results *r : out)
+            hgx_free_block_results(r);
+        setErr(err, std::string("halGetBlocksInTargetRange error reading blocks: ") + e.what());
+        return HGX_ERR;
+    } catch (...) {
+        for (hgx_block_results *r : out)
+            hgx_free_block_results(r);
+        setErr(err, "halGetBlocksInTargetRange error reading blocks: unknown exception");
+        return HGX_ERR;
+    }
+}
+
+hgx_block_results *hgx_get_blocks_in_target_range(hgx_alignment *h, const char *q_species, const char *t_species, const char *t_chrom,
+                                                  int64_t t_start, int64_t t_end, int64_t t_reversed, int seq_mode, int dup_mode,
+                                                  int map_back_adjacencies, const char *coalescence_limit_name, char **err) {
+    hgx_block_results *r = nullptr;
+    if (hgx_get_blocks_in_target_ranges(h, q_species, t_species, t_chrom, 1, &t_start, &t_end, t_reversed, seq_mode, dup_mode, map_back_adjacencies,
+                                        coalescence_limit_name, &r, err) != HGX_OK)
+        return nullptr;
+    return r;
+}
+
 int hgx_liftover_plan_create(hgx_alignment *h, int src, int tgt, const hgx_liftover_opts *opts, size_t max_queries,
                              hgx_liftover_plan **out, char **err) {
     HGX_TRY

@@ -35,7 +35,8 @@ template <typename C> struct FinishStore {
     int32_t *lSeq;
     uint8_t *lStrand;
     int cap, cap2, cutCap;
-    int blocks = 0; // 1: return the refined set itself (BlockMapper::getMap), no extractSegment merging
+    int blocks = 0; // 1: return the refined set itself (BlockMapper::getMap), no extractSegment merging; 2: the same without
+                    // the refinement either (the mapped pieces, sorted, equal ones once)
 };
 
 __device__ __forceinline__ void wsync() {
@@ -138,7 +139,7 @@ __device__ __forceinline__ int finish_query(FinishStore<C> &S, const Mapped &in,
         if (same && S.sLo[i + 1] == S.sLo[i] && S.sHi[i + 1] == S.sHi[i])
             dup = true;
     }
-    refine = __any(refine);
+    refine = __any(refine) && S.blocks != 2; // (blocks == 2: the pieces as halMapSegment's walk leaves them, before insertAndBreakOverlaps)
     dup = __any(dup);
 
     if (refine) {

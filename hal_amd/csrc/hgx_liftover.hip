@@ -1224,7 +1224,7 @@ static void runOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
     uint32_t *classLists = generalList + nq;
     unsigned long long *classCounts = generalCount + 1;
     HIP_OK(hipMemsetAsync(generalCount, 0, 32, s));
-    const int blocks = P.opts.emit_blocks ? 1 : 0;
+    const int blocks = P.opts.emit_blocks;
     if (blocks) {
         hipLaunchKernelGGL(k_all_general, dim3(GRID), dim3(256), 0, s, (const uint32_t *)P.perQuery.p, nq, (uint32_t *)P.nOut.p, generalList,
                            generalCount);
@@ -1364,7 +1364,7 @@ static void runPlan(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
             hipLaunchKernelGGL((k_finish_big<C>), dim3(nDef), dim3(64), 0, s, P.mapped(1), (const uint32_t *)P.offset.p,
                                (const uint32_t *)P.perQuery.p, (const uint32_t *)P.deferredList.p, nDef, bigCap,
                                (unsigned char *)P.scratch.p, slice, (const int64_t *)TG.seqStart, (int)TG.numSeq,
-                               (hgx_record *)P.bigRecords.p, (uint32_t *)P.nOut.p, cnt, P.opts.emit_blocks ? 1 : 0);
+                               (hgx_record *)P.bigRecords.p, (uint32_t *)P.nOut.p, cnt, P.opts.emit_blocks);
             P.timer.end(s);
             unsigned long long r[2];
             HIP_OK(hipMemcpyAsync(r, cnt + CNT_MAXNEED, 16, hipMemcpyDeviceToHost, s));
@@ -1493,8 +1493,12 @@ hgx_liftover_plan *createLiftoverPlan(hgx_alignment *h, int src, int tgt, const 
     P->srcTop = img.genomes[(size_t)src].numTop > 0;
     // BlockMapper::map (halBlockMapper.cpp:79-86) chooses differently: bottom segments iff the reference genome is the MRCA
     // and not the query genome itself, top segments otherwise
-    if (opts.block_mapper_source)
+    if (opts.block_mapper_source == 1)
         P->srcTop = !(P->mrca == src && src != tgt);
+    else if (opts.block_mapper_source == 2 || opts.block_mapper_source == 3) // the caller names the tiling (hgx_blockviz.cpp)
+        P->srcTop = opts.block_mapper_source == 2;
+    if (P->srcTop ? img.genomes[(size_t)src].numTop <= 0 : img.genomes[(size_t)src].numBot <= 0)
+        throw std::runtime_error("the source genome has no segments of the tiling the walk was asked to start from");
     ensureLocateTable(img, *h->dev, src, P->srcTop ? 0 : 1);
     P->maxQueries = std::max<size_t>(maxQueries, 1);
     HIP_OK(hipSetDevice(h->dev->device));
@@ -2271,6 +2275,16 @@ void liftoverBatchStaged(hgx_alignment *h, int src, int tgt, size_t n, const hgx
     *nRecs = nOut;
     if (stats)
         *stats = P->stats;
+}
+
+// a batch of absolute intervals (inclusive genome coordinates of src) through a plan of its own, records to the host
+void liftoverBatchAbsolute(hgx_alignment *h, int src, int tgt, const std::vector<int64_t> &gs, const std::vector<int64_t> &ge,
+                           const std::vector<uint8_t> &strand, const hgx_liftover_opts &opts, std::vector<hgx_record> &out) {
+    out.clear();
+    if (gs.empty())
+        return;
+    std::unique_ptr<hgx_liftover_plan, void (*)(hgx_liftover_plan *)> P(createLiftoverPlan(h, src, tgt, opts, gs.size()), destroyLiftoverPlan);
+    runHostArrays(P.get(), gs, ge, strand, out);
 }
 
 void blockMapHost(hgx_alignment *h, int ref, int query, int64_t absFirst, int64_t absLast, bool targetReversed,

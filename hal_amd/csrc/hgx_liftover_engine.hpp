@@ -37,8 +37,16 @@ void liftoverBatchStaged(hgx_alignment *h, int src, int tgt, size_t n, const hgx
 // the table of the whole path src -> dst with dupes (hgx_device.hpp: ComposedUp, through), built on first use; null when the
 // pair cannot have one
 const ComposedUp *wholePathTable(hgx_alignment *h, int src, int dst, int coalescenceLimit);
+// a batch of absolute intervals (inclusive genome coordinates of src, strand '+' / '-' / '.') through a plan of its own
+void liftoverBatchAbsolute(hgx_alignment *h, int src, int tgt, const std::vector<int64_t> &gs, const std::vector<int64_t> &ge,
+                           const std::vector<uint8_t> &strand, const hgx_liftover_opts &opts, std::vector<hgx_record> &out);
 // BlockMapper::init + map + getMap without adjacencies (liftover/impl/halBlockMapper.cpp:33-110)
 void blockMapHost(hgx_alignment *h, int ref, int query, int64_t absFirst, int64_t absLast, bool targetReversed,
                   const hgx_liftover_opts &opts, std::vector<hgx_record> &out);
+
+// hgx_blockviz.cpp: halGetBlocksInTargetRange's readBlocks for every (absolute, inclusive) range of the target genome
+void blocksInTargetRanges(hgx_alignment *h, int qGenome, int tGenome, const std::vector<std::pair<int64_t, int64_t>> &ranges, bool tReversed,
+                          bool getSequenceString, bool doDupes, bool doTargetDupes, bool doAdjes, int coalescenceLimit,
+                          std::vector<hgx_block_results *> &results);
 
 } // namespace hgx

@@ -101,12 +101,16 @@ typedef struct hgx_liftover_opts {
     int32_t coalescence_limit; /* --coalescenceLimit: genome id of an ancestor of the MRCA, or -1 (= the MRCA, the default);
                                   paralogs coalescing up to that genome are followed (halSegmentMapper.cpp:525-576) */
     int64_t min_length;        /* halMapSegment minLength; halLiftover passes 0 */
-    int32_t emit_blocks;       /* 1: records are the members of the mapped set itself, in set order (BlockMapper::getMap,
+    int32_t emit_blocks;       /* 2: as 1 below, but the pieces as halMapSegment's walk leaves them, before insertAndBreakOverlaps
+                                  cuts them against each other (sorted in set order, equal ones once);
+                                  1: records are the members of the mapped set itself, in set order (BlockMapper::getMap,
                                   liftover/inc/halBlockMapper.h:36) instead of merged output lines: tgt_start/tgt_end = the
                                   member's forward target range, src_start = its forward source start, strand = orientation
                                   of its source side ('+'/'-'), tgt_reversed = orientation of its target side */
     int32_t block_mapper_source; /* 1: walk the source genome the way BlockMapper::map does (halBlockMapper.cpp:79-86: bottom
-                                    segments iff it is the MRCA and not the target) instead of BlockLiftover's rule */
+                                    segments iff it is the MRCA and not the target) instead of BlockLiftover's rule;
+                                    2 / 3: through its top / bottom tiling, whatever the rules say (what mapAdjacencies'
+                                    iterator does: it stands on the tiling its mapped segment lies on, :247-256) */
 } hgx_liftover_opts;
 
 /* Host-buffer form.  Records come back grouped by input interval in input order and, inside one
@@ -131,6 +135,52 @@ int hgx_liftover_convert_multi(hgx_alignment *const *handles, int n_handles, int
 int hgx_block_map(hgx_alignment *h, int ref_genome, int query_genome, int64_t abs_ref_first, int64_t abs_ref_last,
                   int target_reversed, int do_dupes, int64_t min_length, int coalescence_limit, hgx_record **out, size_t *n_out,
                   char **err);
+
+/* ---- the blockViz query: halGetBlocksInTargetRange (blockViz/inc/halBlockViz.h:222-225; impl/halBlockViz.cpp:243-330) =
+ * BlockMapper::init + map WITH adjacencies (liftover/impl/halBlockMapper.cpp:36-245: for every mapped segment the stretch of the
+ * query genome next to it on either side is mapped back to the target genome) + chainReferenceParalogies + extractSegment with the
+ * paralogy set and the range's ends as cut points + readBlock + processTargetDupes (halBlockViz.cpp:759-1178).
+ * The structs have the layout of hal_block_t / hal_target_range_t / hal_target_dupe_list_t / hal_block_results_t
+ * (halBlockViz.h:23-58: int64_t where the reference has `long`), so a maintainer's halGetBlocksInTargetRange can return the
+ * library's result as it is; every string and node is malloc'd, released by hgx_free_block_results.
+ * q_species / t_species / t_chrom: query genome, target (reference) genome and its sequence; [t_start, t_end) sequence-relative,
+ * t_end == 0: to the end of the sequence; t_reversed, seq_mode (0 none, otherwise DNA strings: there are no levels of detail
+ * here), dup_mode (0 none, 1 query dupes, 2 query and target dupes), map_back_adjacencies and coalescence_limit_name (NULL: the
+ * MRCA — the root for a self-alignment) as halGetBlocksInTargetRange's.  Returns NULL and *err (release with hgx_free) on failure,
+ * with the reference's messages for its own argument checks. */
+typedef struct hgx_target_range {
+    struct hgx_target_range *next;
+    int64_t tStart, size;
+} hgx_target_range;
+typedef struct hgx_target_dupe_list {
+    struct hgx_target_dupe_list *next;
+    int64_t id;
+    hgx_target_range *tRange;
+    char *qChrom;
+} hgx_target_dupe_list;
+typedef struct hgx_block { /* ALL COORDINATES ARE FORWARD-STRAND RELATIVE (halBlockViz.h:47-58) */
+    struct hgx_block *next;
+    char *qChrom;
+    int64_t tStart, qStart, size;
+    char strand;
+    char *qSequence, *tSequence; /* NULL unless asked for */
+} hgx_block;
+typedef struct hgx_block_results {
+    hgx_block *mappedBlocks;
+    hgx_target_dupe_list *targetDupeBlocks;
+} hgx_block_results;
+hgx_block_results *hgx_get_blocks_in_target_range(hgx_alignment *h, const char *q_species, const char *t_species, const char *t_chrom,
+                                                  int64_t t_start, int64_t t_end, int64_t t_reversed, int seq_mode, int dup_mode,
+                                                  int map_back_adjacencies, const char *coalescence_limit_name, char **err);
+/* The same for n ranges of one target sequence at once — one request per track window, or a genome browsed in tiles: the
+ * mapping of all ranges is one batch of device work, and so is the mapping back of all their adjacencies; the sequential part of
+ * BlockMapper::mapAdjacencies (every adjacency added changes what the next one is cut against) runs per range on the host.
+ * results[k] (caller's array of n pointers) receives what hgx_get_blocks_in_target_range returns for [t_starts[k], t_ends[k]);
+ * HGX_ERR with *err set and every results[k] NULL on failure. */
+int hgx_get_blocks_in_target_ranges(hgx_alignment *h, const char *q_species, const char *t_species, const char *t_chrom, size_t n,
+                                    const int64_t *t_starts, const int64_t *t_ends, int64_t t_reversed, int seq_mode, int dup_mode,
+                                    int map_back_adjacencies, const char *coalescence_limit_name, hgx_block_results **results, char **err);
+void hgx_free_block_results(hgx_block_results *results); /* halFreeBlockResults */
 
 /* Device-resident form: the query table is already in HBM and the records stay there.
  * A plan owns the per-(src,tgt) walk schedule and all device workspaces, sized for max_queries. */

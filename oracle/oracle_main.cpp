@@ -1,6 +1,7 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY (see hal_oracle.hpp).  Command-line front end used by tests/ and by
 // bench.py's cpu_baseline leg.
 //   hal_oracle liftover <img.hgx> <srcGenome> <in.bed> <tgtGenome> <out.bed> [--noDupes] [--bedType N] [--coalescenceLimit G] [--stats]
+#include "oracle_blockviz.hpp"
 #include "oracle_columns.hpp"
 #include "oracle_liftover.hpp"
 #include <chrono>
@@ -278,6 +279,46 @@ static int cmdBlocks(int argc, char **argv) {
     return 0;
 }
 
+// hal_oracle blockviz <img.hgx> <qSpecies> <tSpecies> <tChrom> <tStart> <tEnd> [--doSeq] [--dupMode 0|1|2] [--noAdj] [--tReversed]
+//                     [--coalescenceLimit G]
+// = blockVizTest --verbose (blockViz/tests/blockVizTest.cpp:200-236: dupMode HAL_QUERY_AND_TARGET_DUPS and mapBackAdjacencies 1
+// unless told otherwise): the blocks, then the target dupe lists, in that program's print format
+static int cmdBlockViz(int argc, char **argv) {
+    std::vector<std::string> pos;
+    bool doSeq = false, adj = true, tReversed = false;
+    int dupMode = VIZ_QUERY_AND_TARGET_DUPS;
+    std::string coalName;
+    for (int i = 0; i < argc; ++i) {
+        std::string a = argv[i];
+        if (a == "--doSeq")
+            doSeq = true;
+        else if (a == "--noAdj")
+            adj = false;
+        else if (a == "--tReversed")
+            tReversed = true;
+        else if (a == "--dupMode")
+            dupMode = atoi(argv[++i]);
+        else if (a == "--coalescenceLimit")
+            coalName = argv[++i];
+        else
+            pos.push_back(a);
+    }
+    if (pos.size() != 6) {
+        std::cerr << "usage: hal_oracle blockviz <img.hgx> <qSpecies> <tSpecies> <tChrom> <tStart> <tEnd>" << std::endl;
+        return 1;
+    }
+    Alignment al = loadImage(pos[0]);
+    const int q = al.genomeByName(pos[1]), t = al.genomeByName(pos[2]);
+    const int coal = coalName.empty() ? -1 : al.genomeByName(coalName);
+    if (q < 0 || t < 0 || (!coalName.empty() && coal < 0)) {
+        std::cerr << "genome not found" << std::endl;
+        return 1;
+    }
+    VizResults r = getBlocksInTargetRange(al, q, t, pos[3], atoll(pos[4].c_str()), atoll(pos[5].c_str()), tReversed, doSeq, dupMode, adj, coal);
+    printVizResults(std::cout, r, doSeq);
+    return 0;
+}
+
 // hal_oracle columns <img.hgx> <refGenome>: every column of the reference genome's first sequence, one line per
 // column: "<col>" then " <genome>:<position>:<+|->" per base in ColumnMap order (sequences in SequenceLess order,
 // bases of a sequence in insertion order); what a loop over getColumnIterator() / toRight() / getColumnMap() sees.
@@ -312,6 +353,8 @@ int main(int argc, char **argv) {
             return cmdColumnRows(argc - 2, argv + 2);
         if (argc >= 2 && std::string(argv[1]) == "blocks")
             return cmdBlocks(argc - 2, argv + 2);
+        if (argc >= 2 && std::string(argv[1]) == "blockviz")
+            return cmdBlockViz(argc - 2, argv + 2);
         if (argc >= 2 && std::string(argv[1]) == "liftover")
             return cmdLiftover(argc - 2, argv + 2);
         if (argc >= 2 && std::string(argv[1]) == "depth")

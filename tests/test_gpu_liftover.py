@@ -15,10 +15,10 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def _rand_alignment(hal, tmp_path, seed, max_branch=3.0, min_seg=10, max_seg=60, min_segs=200, max_segs=600, max_genomes=10,
-                    mean_degree=1.5, name="rnd"):
+                    mean_degree=1.5, name="rnd", with_dna=False):
     opts = hal.RandOptions(mean_degree=mean_degree, max_branch_length=max_branch, min_genomes=2, max_genomes=max_genomes,
                            min_segment_length=min_seg, max_segment_length=max_seg, min_segments=min_segs,
-                           max_segments=max_segs, seed=seed, with_dna=False)
+                           max_segments=max_segs, seed=seed, with_dna=with_dna)
     al = hal.Alignment.random(opts, device=0)
     img = str(tmp_path / ("%s_%d.hgx" % (name, seed)))
     al.save(img)

@@ -49,6 +49,21 @@ def test_reference_cli_golden_bed4_extra(hal, oracle_bin, tmp_path):
     assert oracle_liftover(oracle_bin, img, "Genome_0", "Genome_2", bed, tmp_path, bed_type=4) == want
 
 
+def test_reference_blockviz_golden(hal, oracle_bin, tmp_path):
+    # blockViz/Makefile:52-71: blockVizTest --verbose --doSeq on halRandGen --preset small --seed 0 --minSegmentLength 3000
+    # --maxSegmentLength 5000: halGetBlocksInTargetRange(Genome_2, Genome_0, Genome_0_seq, 0, 3000, HAL_QUERY_AND_TARGET_DUPS,
+    # mapBackAdjacencies = 1) — the second block lies outside the range: an adjacency mapped back
+    opts = hal.RandOptions.preset("small", seed=0, min_segment_length=3000, max_segment_length=5000)
+    al = hal.Alignment.random(opts, device=-1)
+    img = str(tmp_path / "bv.hgx")
+    al.save(img)
+    for name in ("blockVizMmapTests.out", "blockVizHdf5Tests.out"):
+        want = open(os.path.join(GOLD, "ref_blockviz", name)).read()
+        got = subprocess.run([oracle_bin, "blockviz", img, "Genome_2", "Genome_0", "Genome_0_seq", "0", "3000", "--doSeq"], check=True,
+                             stdout=subprocess.PIPE).stdout.decode()
+        assert got == want
+
+
 def test_reference_unit_test_handbuilt(oracle_bin, tmp_path):
     # liftover/tests/halLiftoverTests.cpp:272-343 (BED6 cases): inversions, insertion, paralogy, overlap breaking
     img = str(tmp_path / "hand.hgx")
