@@ -1497,7 +1497,9 @@ hgx_liftover_plan *createLiftoverPlan(hgx_alignment *h, int src, int tgt, const 
         P->srcTop = !(P->mrca == src && src != tgt);
     else if (opts.block_mapper_source == 2 || opts.block_mapper_source == 3) // the caller names the tiling (hgx_blockviz.cpp)
         P->srcTop = opts.block_mapper_source == 2;
-    if (P->srcTop ? img.genomes[(size_t)src].numTop <= 0 : img.genomes[(size_t)src].numBot <= 0)
+    // (a genome without the tiling its rule names — the root walked through its top segments by BlockMapper's rule for a
+    // self-alignment — maps nothing; a caller that names a tiling the genome does not have is mistaken)
+    if (opts.block_mapper_source >= 2 && (P->srcTop ? img.genomes[(size_t)src].numTop <= 0 : img.genomes[(size_t)src].numBot <= 0))
         throw std::runtime_error("the source genome has no segments of the tiling the walk was asked to start from");
     ensureLocateTable(img, *h->dev, src, P->srcTop ? 0 : 1);
     P->maxQueries = std::max<size_t>(maxQueries, 1);
