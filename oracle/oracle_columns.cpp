@@ -47,9 +47,12 @@ static int seqIndexBySite(const Genome &G, i64 pos) {
 
 // halColumnIterator.cpp:18-57
 ColumnIterator::ColumnIterator(const Alignment *a, int reference, const std::set<int> *tgts, i64 columnIndex, i64 lastColumnIndex,
-                               bool noDupes_, bool noAncestors_, bool onlyOrthologs_, bool unique_)
-    : al(a), refGenome(reference), noDupes(noDupes_), noAncestors(noAncestors_), onlyOrthologs(onlyOrthologs_), unique(unique_) {
+                               bool noDupes_, bool noAncestors_, bool onlyOrthologs_, bool unique_, i64 maxInsertLength_)
+    : al(a), refGenome(reference), noDupes(noDupes_), noAncestors(noAncestors_), onlyOrthologs(onlyOrthologs_), unique(unique_),
+      maxInsertLength(maxInsertLength_) {
+    base.g = reference;
     seqIdx = seqIndexBySite(al->genomes[(size_t)reference], columnIndex);
+    refSeqIdx = seqIdx;
     if (tgts != nullptr && !tgts->empty()) {
         targets = *tgts;
         targets.insert(reference);
@@ -62,37 +65,77 @@ ColumnIterator::ColumnIterator(const Alignment *a, int reference, const std::set
     toRight();
 }
 
-// halColumnIterator.cpp:749-764 (one-entry stack: the cache is consulted only with --unique)
+// ColumnIteratorStack::push (halColumnIteratorStack.h:112-121) on one of the indel stacks
+void ColumnIterator::pushEntry(std::vector<Entry> &st, int g, int seqIdx, i64 index, i64 lastIndex, bool reversed) {
+    Entry e;
+    e.g = g;
+    e.seqIdx = seqIdx;
+    e.cumulativeSize = st.empty() ? 0 : st.back().cumulativeSize + lastIndex - index + 1;
+    e.firstIndex = index;
+    e.index = reversed ? lastIndex : index;
+    e.lastIndex = lastIndex;
+    e.reversed = reversed;
+    st.push_back(e);
+}
+
+// halColumnIterator.cpp:749-764
 void ColumnIterator::nextFreeIndex() {
-    if (unique) {
-        auto it = visitCache.find(refGenome);
+    Entry &e = top();
+    i64 idx = e.index;
+    if (unique || !upper.empty()) {
+        auto it = visitCache.find(e.g);
         if (it != visitCache.end()) {
-            bool found = it->second.find(index);
-            while (found && index <= lastIndex) {
-                ++index;
-                found = it->second.find(index);
+            bool found = it->second.find(idx);
+            while (found && idx <= e.lastIndex) {
+                ++idx;
+                found = it->second.find(idx);
             }
         }
     }
+    e.index = idx;
 }
 
-// halColumnIterator.cpp:65-144 with a one-entry stack (maxInsertLength == 0)
+// halColumnIterator.cpp:65-144
 void ColumnIterator::toRight() {
     const Genome &G = al->genomes[(size_t)refGenome];
-    prevRefSeq = seqIdx;
-    prevRefIndex = index - G.seqs[(size_t)seqIdx].start;
-    if (!(index >= firstIndex && index <= lastIndex))
+    prevRefSeq = refSeqIdx;
+    prevRefIndex = index - G.seqs[(size_t)refSeqIdx].start;
+    if (upper.empty() && !topInBounds())
         return;
     do {
         nextFreeIndex();
-        if (!(index >= firstIndex && index <= lastIndex))
+        while (!upper.empty() && !topInBounds()) {
+            upper.pop_back();
+            nextFreeIndex();
+        }
+        if (upper.empty() && !topInBounds())
             return;
         recursiveUpdate();
-        index++;
-        const Sequence &seq = G.seqs[(size_t)seqIdx];
-        if (index < seq.start || (index >= seq.start + seq.length && index < G.totalLength))
-            seqIdx = seqIndexBySite(G, index);
+        Entry &e = top();
+        if (e.reversed)
+            e.index--;
+        else
+            e.index++;
+        if (upper.empty()) { // jump to the next sequence of the genome if necessary (:109-118)
+            const Sequence &seq = G.seqs[(size_t)seqIdx];
+            if (index < seq.start || (index >= seq.start + seq.length && index < G.totalLength)) {
+                seqIdx = seqIndexBySite(G, index);
+                refSeqIdx = seqIdx;
+            }
+        }
     } while (brk);
+    // push the indel stacks (:121-123)
+    for (size_t i = deletionStack.size(); i-- > 0;)
+        upper.push_back(deletionStack[i]);
+    deletionStack.clear();
+    for (size_t i = 0; i < insertionStack.size(); ++i)
+        upper.push_back(insertionStack[i]);
+    insertionStack.clear();
+    nextFreeIndex();
+    while (!upper.empty() && !topInBounds()) {
+        upper.pop_back();
+        nextFreeIndex();
+    }
 }
 
 // halColumnIterator.cpp:193-208
@@ -105,12 +148,17 @@ void ColumnIterator::defragment() {
     }
 }
 
-// halColumnIterator.cpp:766-819 (maxInsertLength == 0, one-entry stack)
+// halColumnIterator.cpp:766-819
 bool ColumnIterator::colMapInsert(const SegIt &it) {
     const int g = it.g;
     const i64 pos = it.getStartPosition();
-    bool updateCache = g == refGenome && firstIndex < pos;
-    if (!unique)
+    bool updateCache = g == refGenome; // all reference bases are added to the cache ...
+    if (maxInsertLength == 0)          // ... unless indels are not done: then only the ones right of the starting point
+        updateCache = updateCache && top().firstIndex < pos;
+    for (size_t i = 0; i < upper.size() && !updateCache; ++i)
+        if (g == upper[i].g)
+            updateCache = true;
+    if (!unique && maxInsertLength == 0)
         updateCache = false;
     bool found = false;
     auto cacheIt = visitCache.find(g);
@@ -136,25 +184,31 @@ void ColumnIterator::recursiveUpdate() {
         kv.second.clear();
     brk = false;
     leftmostRefPos = index;
-    const Genome &G = al->genomes[(size_t)refGenome];
-    const Sequence &refSeq = G.seqs[(size_t)seqIdx];
+    const Entry &e = top();
+    const Genome &G = al->genomes[(size_t)e.g];
+    const Sequence &refSeq = G.seqs[(size_t)e.seqIdx];
     SegIt it;
     it.al = al;
-    it.g = refGenome;
+    it.g = e.g;
     if (refSeq.numTop > 0) {
         it.top = true;
-        it.toSite(index, true);
+        it.toSite(e.index, true);
+        if (e.reversed)
+            it.toReverseInPlace();
         if (!colMapInsert(it)) {
             brk = true;
             return;
         }
+        handleDeletion(it);
         updateParent(it);
         if (!onlyOrthologs)
             updateNextTopDup(it);
         updateParseDown(it);
     } else {
         it.top = false;
-        it.toSite(index, true);
+        it.toSite(e.index, true);
+        if (e.reversed)
+            it.toReverseInPlace();
         if (!colMapInsert(it)) {
             brk = true;
             return;
@@ -162,6 +216,213 @@ void ColumnIterator::recursiveUpdate() {
         for (size_t child = 0; child < G.children.size(); ++child)
             updateChild(it, (i64)child);
     }
+}
+
+// ---- Segment::isFirst / isLast (api/mmap_impl/mmapTopSegment.h:102-111, mmapBottomSegment.h:111-120) through an iterator
+// (halSegmentIterator.cpp:110-116) ----
+static bool segIsFirst(const SegIt &s) {
+    const Sequence *q = s.getSequence();
+    return s.idx == 0 || s.idx == (s.top ? q->topStart : q->botStart);
+}
+static bool segIsLast(const SegIt &s) {
+    const Sequence *q = s.getSequence();
+    return s.idx == s.numSegs() || s.idx == (s.top ? q->topStart + q->numTop : q->botStart + q->numBot) - 1;
+}
+static bool itIsFirst(const SegIt &s) {
+    return !s.rev ? segIsFirst(s) : segIsLast(s);
+}
+static bool itIsLast(const SegIt &s) {
+    return !s.rev ? segIsLast(s) : segIsFirst(s);
+}
+
+// Rearrangement (api/impl/halRearrangement.cpp) as the column iterator holds it: getRearrangement(0, 0, 1., true)
+// (halColumnIterator.cpp:34-39) = gap threshold 0, atomic — every gapped iterator is one whole segment, the "next ungapped"
+// moves of halGappedTop/BottomSegmentIterator.cpp never step (no segment is shorter than one base) and extendLeft / extendRight
+// return at once.  What is left of the gapped iterators: a SegIt over a whole segment.
+namespace {
+struct AtomicRearrangement {
+    SegIt cur, next, left, right, leftParent, rightParent, curParent;
+    // GappedBottomSegmentIterator::adjacentTo (halGappedBottomSegmentIterator.cpp:293-337), one segment each
+    static bool adjacentTo(const SegIt &self, const SegIt &other) {
+        for (int pass = 0; pass < 2; ++pass) {
+            const SegIt t = self; // _left, then _right: the same segment
+            if (pass == 0 ? !itIsFirst(t) : !itIsLast(t)) {
+                SegIt t2 = other;
+                if (!itIsFirst(t2)) {
+                    t2.toLeft();
+                    if (t.idx == t2.idx)
+                        return true;
+                }
+                t2 = other;
+                if (!itIsLast(t2)) {
+                    t2.toRight();
+                    if (t.idx == t2.idx)
+                        return true;
+                }
+            }
+        }
+        return false;
+    }
+    void resetStatus(const SegIt &topSegment) { // :243-270
+        cur = next = left = right = topSegment;
+    }
+    // :458-516; true: leftParent holds the deletion candidate
+    bool scanDeletionCycle(const SegIt &topSegment) {
+        resetStatus(topSegment);
+        const bool first = itIsFirst(cur), last = itIsLast(cur);
+        if (!cur.hasParent() || (first && last))
+            return false;
+        if (last) {
+            leftParent.toParent(cur);
+            if (!itIsFirst(leftParent)) {
+                leftParent.toLeft();
+                return true;
+            }
+            if (!itIsLast(leftParent)) {
+                leftParent.toRight();
+                return true;
+            }
+        } else {
+            leftParent.toParent(cur);
+            right.toRight();
+            if (!right.hasParent())
+                return false;
+            rightParent.toParent(right);
+            if (leftParent.getSequence() == rightParent.getSequence()) {
+                if (leftParent.rev)
+                    leftParent.toReverse();
+                if (rightParent.rev)
+                    rightParent.toReverse();
+                if (rightParent.idx < leftParent.idx)
+                    std::swap(leftParent, rightParent);
+                if (itIsLast(leftParent))
+                    return false;
+                leftParent.toRight();
+                return adjacentTo(leftParent, rightParent);
+            }
+        }
+        return false;
+    }
+    // :133-140
+    bool identifyDeletionFromLeftBreakpoint(const SegIt &topSegment) {
+        if (!scanDeletionCycle(topSegment))
+            return false;
+        const i64 slot = leftParent.G().childSlotOf(topSegment.g); // the gapped bottom iterator's _childIndex (toParent)
+        return !leftParent.hasChild(slot);
+    }
+    std::pair<i64, i64> getDeletedRange() const { // :142-154 (left == right: one segment)
+        if (!leftParent.rev)
+            return std::make_pair(leftParent.getStartPosition(), leftParent.getEndPosition());
+        return std::make_pair(leftParent.getEndPosition(), leftParent.getStartPosition());
+    }
+    // :386-456; true: cur holds the insertion candidate
+    bool scanInsertionCycle(const SegIt &topSegment) {
+        resetStatus(topSegment);
+        while (!next.hasParent() && !itIsLast(next)) {
+            right = next;
+            right.toRight();
+            if (!right.hasParent())
+                next = right;
+            else
+                break;
+        }
+        right = next;
+        const bool first = itIsFirst(cur), last = itIsLast(right);
+        if (first && last)
+            return false;
+        if (first) {
+            right.toRight();
+            if (!cur.hasParent()) {
+                return true;
+            } else if (right.hasParent()) {
+                curParent.toParent(cur);
+                rightParent.toParent(right);
+                return !adjacentTo(rightParent, curParent);
+            }
+        } else if (last) {
+            left.toLeft();
+            if (!cur.hasParent()) {
+                return true;
+            } else if (left.hasParent()) {
+                curParent.toParent(cur);
+                leftParent.toParent(left);
+                return !adjacentTo(leftParent, curParent);
+            }
+        } else {
+            left.toLeft();
+            right.toRight();
+            if (left.hasParent() && right.hasParent()) {
+                leftParent.toParent(left);
+                rightParent.toParent(right);
+                if (adjacentTo(leftParent, rightParent))
+                    return true;
+                else if (itIsFirst(leftParent) || itIsLast(leftParent))
+                    return leftParent.getSequence() == rightParent.getSequence();
+                else if (itIsFirst(rightParent) || itIsLast(rightParent))
+                    return leftParent.getSequence() == rightParent.getSequence();
+            }
+        }
+        return false;
+    }
+    // :156-163
+    bool identifyInsertionFromLeftBreakpoint(const SegIt &topSegment) {
+        return scanInsertionCycle(topSegment) && !cur.hasParent();
+    }
+    std::pair<i64, i64> getInsertedRange() const { // :165-176, as written (left == right; a reversed iterator's "start" is its high end)
+        std::pair<i64, i64> range;
+        range.first = cur.getStartPosition();
+        range.second = cur.getStartPosition() + (cur.getLength() - 1);
+        if (range.first >= range.second)
+            std::swap(range.first, range.second);
+        return range;
+    }
+};
+} // namespace
+
+// halColumnIterator.cpp:357-382
+bool ColumnIterator::handleDeletion(const SegIt &inputTopSegIt) {
+    if (maxInsertLength > 0 && inputTopSegIt.hasParent()) {
+        SegIt topIt = inputTopSegIt;
+        if (topIt.eo == 0) { // only immediately left of the breakpoint
+            topIt.slice(0, 0);
+            AtomicRearrangement rea;
+            if (rea.identifyDeletionFromLeftBreakpoint(topIt) &&
+                rea.leftParent.getLength() + top().cumulativeSize <= maxInsertLength) {
+                const std::pair<i64, i64> deletedRange = rea.getDeletedRange();
+                SegIt botSegIt;
+                botSegIt.toParent(inputTopSegIt);
+                const Genome &P = botSegIt.G();
+                if (deletedRange.first < 0 || deletedRange.second >= P.totalLength)
+                    throw std::runtime_error("oracle: deleted range outside the genome");
+                pushEntry(deletionStack, botSegIt.g, seqIndexBySite(P, botSegIt.segStart()), deletedRange.first, deletedRange.second, botSegIt.rev);
+                return true;
+            }
+        }
+    }
+    return false;
+}
+
+// halColumnIterator.cpp:384-405
+bool ColumnIterator::handleInsertion(const SegIt &inputTopSegIt) {
+    if (maxInsertLength > 0 && inputTopSegIt.hasParent()) {
+        SegIt topIt = inputTopSegIt;
+        const bool reversed = topIt.rev;
+        if (topIt.eo == 0 && !itIsLast(topIt)) { // only immediately left of the break
+            topIt.slice(0, 0);
+            topIt.toRight();
+            AtomicRearrangement rea;
+            if (rea.identifyInsertionFromLeftBreakpoint(topIt) && rea.cur.getLength() + top().cumulativeSize <= maxInsertLength) {
+                const std::pair<i64, i64> insertedRange = rea.getInsertedRange();
+                const Genome &G = topIt.G();
+                // (the reference computes a reversed iterator's range from its high end upwards, :165-176; a range that leaves
+                // the genome is undefined behaviour there and an error here)
+                if (insertedRange.first < 0 || insertedRange.second >= G.totalLength)
+                    throw std::runtime_error("oracle: inserted range outside the genome (reference: undefined behaviour)");
+                pushEntry(insertionStack, topIt.g, seqIndexBySite(G, topIt.segStart()), insertedRange.first, insertedRange.second, reversed);
+            }
+        }
+    }
+    return false;
 }
 
 // halColumnIterator.cpp:556-605
@@ -175,6 +436,11 @@ void ColumnIterator::updateParent(const SegIt &top) {
             return;
         }
         updateParseUp(parent);
+        if (parent.G().bTopParse[(size_t)parent.idx] != NULL_INDEX) { // hasParseUp and its linked top iterator exists (:587-589)
+            SegIt topParse;
+            topParse.toParseUp(parent);
+            handleDeletion(topParse);
+        }
         const Genome &P = al->genomes[(size_t)parent.g];
         for (size_t i = 0; i < P.children.size(); ++i) {
             if (P.children[i] != genome)
@@ -192,6 +458,7 @@ void ColumnIterator::updateChild(const SegIt &bot, i64 slot) {
             brk = true;
             return;
         }
+        handleInsertion(child);
         updateNextTopDup(child);
         updateParseDown(child);
     }
@@ -211,6 +478,7 @@ void ColumnIterator::updateNextTopDup(const SegIt &top) {
             brk = true;
             return;
         }
+        handleInsertion(dup);
         updateParseDown(dup);
         cur = dup;
     } while (G.tParalogy[(size_t)cur.idx] != NULL_INDEX && G.tParalogy[(size_t)cur.idx] != firstIndexSeg);
@@ -282,6 +550,7 @@ static void printDepthSequence(std::ostream &os, const Alignment &al, int genome
             if (pos > last || pos >= al.genomes[(size_t)genome].totalLength) // past the range: the loop test ends it
                 break;
             colIt.seqIdx = seqIndexBySite(al.genomes[(size_t)genome], pos);
+            colIt.refSeqIdx = colIt.seqIdx;
             colIt.defragment();
             colIt.firstIndex = colIt.index = pos;
             colIt.lastIndex = last;
@@ -537,7 +806,7 @@ void MafExport::convertSequence(std::ostream &os, const Alignment &al, int genom
     auto t0 = std::chrono::steady_clock::now();
     // Sequence::getColumnIterator (api/mmap_impl/mmapSequence.cpp:41-52): sequence-relative -> genome coordinates
     ColumnIterator colIt(&al, genome, &targets, startPosition + seq.start, lastPosition + seq.start, noDupes, noAncestors, onlyOrthologs,
-                         unique);
+                         unique, maxRefGap);
     size_t appendCount = 0;
     if (!unique || colIt.isCanonicalOnRef()) {
         initBlock(colIt);

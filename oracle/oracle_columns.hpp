@@ -1,8 +1,10 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY (see hal_oracle.hpp).
-// Restatement of the column engine: api/impl/halColumnIterator.cpp (maxInsertLength == 0, unique == false:
-// the configuration of hal2maf's and halAlignmentDepth's defaults, where columns are independent,
-// halColumnIterator.cpp:785-787), maf/impl/halMafBlock.cpp, maf/impl/halMafExport.cpp and
-// alignmentDepth/halAlignmentDepth.cpp:215-347.
+// Restatement of the column engine: api/impl/halColumnIterator.cpp — the configuration of hal2maf's and halAlignmentDepth's
+// defaults (maxInsertLength == 0, unique == false: columns are independent, halColumnIterator.cpp:785-787), --unique (the visit
+// cache) and maxInsertLength > 0 (hal2maf --maxRefGap: the stack of inserted / deleted ranges the iterator walks between two
+// reference columns, :65-144, :357-401, api/inc/halColumnIteratorStack.h, with Rearrangement's deletion and insertion cycles in
+// the atomic, gap-threshold-0 form the iterator uses them in, api/impl/halRearrangement.cpp:133-160, 386-545) —,
+// maf/impl/halMafBlock.cpp, maf/impl/halMafExport.cpp and alignmentDepth/halAlignmentDepth.cpp:215-347.
 #pragma once
 #include "oracle_mapper.hpp"
 #include <map>
@@ -66,28 +68,51 @@ struct ColumnIterator {
     typedef std::vector<Dna> DNASet;
     typedef std::map<SeqKey, DNASet> ColumnMap;
 
+    // ColumnIteratorStack::Entry (halColumnIteratorStack.h:47-107) without its linked iterators (they only save the search for
+    // the site: every column is located afresh here)
+    struct Entry {
+        int g = -1, seqIdx = -1;
+        i64 firstIndex = 0, index = 0, lastIndex = 0, cumulativeSize = 0;
+        bool reversed = false;
+        bool pastEnd() const {
+            return reversed ? index < firstIndex : index > lastIndex;
+        }
+    };
     const Alignment *al;
     int refGenome;
     bool noDupes, noAncestors, onlyOrthologs, unique = false;
+    i64 maxInsertLength = 0;
     std::map<int, PositionCache> visitCache; // halColumnIterator.h: VisitCache (per genome)
     bool brk = false;                        // _break
     i64 leftmostRefPos = 0;
     std::set<int> targets, scope;
-    // the single stack entry of the maxInsertLength == 0 case (halColumnIteratorStack.h:47-107)
-    int seqIdx;
-    i64 firstIndex, index, lastIndex;
+    // _stack: entry 0 (the reference range; its fields keep their names from the one-entry case) and what lies on top of it;
+    // _insertionStack, _deletionStack: filled while a column is walked, moved onto _stack behind it (halColumnIterator.cpp:121-123)
+    Entry base;
+    int &seqIdx = base.seqIdx;
+    i64 &firstIndex = base.firstIndex, &index = base.index, &lastIndex = base.lastIndex;
+    std::vector<Entry> upper, insertionStack, deletionStack;
     ColumnMap colMap;
     int prevRefSeq;
     i64 prevRefIndex;
+    int refSeqIdx; // _ref: the reference sequence (follows entry 0 across sequence boundaries)
 
     ColumnIterator(const Alignment *a, int reference, const std::set<int> *tgts, i64 columnIndex, i64 lastColumnIndex, bool noDupes_,
-                   bool noAncestors_, bool onlyOrthologs_, bool unique_ = false);
+                   bool noAncestors_, bool onlyOrthologs_, bool unique_ = false, i64 maxInsertLength_ = 0);
+    ColumnIterator(const ColumnIterator &) = delete;
     bool isCanonicalOnRef() const { // halColumnIterator.cpp:210-214
         return leftmostRefPos >= firstIndex && leftmostRefPos <= lastIndex;
     }
     void toRight();
-    bool lastColumn() const {
-        return index > lastIndex;
+    bool lastColumn() const { // halColumnIterator.cpp:167-169
+        return upper.empty() && base.pastEnd();
+    }
+    Entry &top() {
+        return upper.empty() ? base : upper.back();
+    }
+    bool topInBounds() {
+        const Entry &e = top();
+        return e.index >= e.firstIndex && e.index <= e.lastIndex;
     }
     void defragment();
     SeqKey refSequenceKey() const {
@@ -112,6 +137,9 @@ struct ColumnIterator {
     void updateNextTopDup(const SegIt &top);
     void updateParseUp(const SegIt &bot);
     void updateParseDown(const SegIt &top);
+    bool handleDeletion(const SegIt &inputTop);
+    bool handleInsertion(const SegIt &inputTop);
+    static void pushEntry(std::vector<Entry> &st, int g, int seqIdx, i64 index, i64 lastIndex, bool reversed);
 };
 
 char dnaBase(const Alignment &al, const Dna &d); // DnaIterator::getBase, halDnaIterator.h:131-138
@@ -134,6 +162,7 @@ struct MafExport {
     bool noDupes = false, noAncestors = false, ucscNames = true /* Genome.Sequence */, onlyOrthologs = false, keepEmptyRefBlocks = false,
          append = false, unique = false;
     i64 maxBlockLength = 1000; // MafBlock::defaultMaxLength, halMafBlock.cpp:16
+    i64 maxRefGap = 0;         // MafExport::_maxRefGap = the column iterator's maxInsertLength (halMafExport.cpp:47)
     void convertSequence(std::ostream &os, const Alignment &al, int genome, int seq, i64 startPosition, i64 length,
                          const std::set<int> &targets);
     size_t numColumns = 0;

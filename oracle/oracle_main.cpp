@@ -82,7 +82,7 @@ static std::vector<std::string> splitCommas(const std::string &s) {
 static int cmdColumns(bool maf, int argc, char **argv) {
     std::vector<std::string> pos;
     std::string refGenome, refSequence, targetGenomes, rootGenome, refTargets;
-    i64 start = 0, length = 0, step = 1, maxBlockLen = 1000;
+    i64 start = 0, length = 0, step = 1, maxBlockLen = 1000, maxRefGap = 0;
     bool countDupes = false, noAncestors = false, noDupes = false, onlySequenceNames = false, onlyOrthologs = false, stats = false,
          unique = false;
     for (int i = 0; i < argc; ++i) {
@@ -105,6 +105,8 @@ static int cmdColumns(bool maf, int argc, char **argv) {
             step = atoll(argv[++i]);
         else if (a == "--maxBlockLen")
             maxBlockLen = atoll(argv[++i]);
+        else if (a == "--maxRefGap")
+            maxRefGap = atoll(argv[++i]);
         else if (a == "--countDupes")
             countDupes = true;
         else if (a == "--noAncestors")
@@ -181,6 +183,7 @@ static int cmdColumns(bool maf, int argc, char **argv) {
         me.ucscNames = !onlySequenceNames;
         me.onlyOrthologs = onlyOrthologs;
         me.unique = unique;
+        me.maxRefGap = maxRefGap;
         me.maxBlockLength = maxBlockLen <= 0 ? std::numeric_limits<i64>::max() : maxBlockLen;
         if (!refTargets.empty()) {
             // MafBed::visitLine (maf/impl/halMafBed.cpp:24-52) over BedScanner::scan
@@ -323,26 +326,44 @@ static int cmdBlockViz(int argc, char **argv) {
 // column: "<col>" then " <genome>:<position>:<+|->" per base in ColumnMap order (sequences in SequenceLess order,
 // bases of a sequence in insertion order); what a loop over getColumnIterator() / toRight() / getColumnMap() sees.
 static int cmdColumnRows(int argc, char **argv) {
-    if (argc != 2) {
-        std::cerr << "usage: hal_oracle columns <img.hgx> <refGenome>" << std::endl;
+    std::vector<std::string> pos;
+    i64 maxInsertLength = 0;
+    bool noDupes = false, noAncestors = false, unique = false;
+    for (int i = 0; i < argc; ++i) {
+        std::string a = argv[i];
+        if (a == "--maxRefGap")
+            maxInsertLength = atoll(argv[++i]);
+        else if (a == "--noDupes")
+            noDupes = true;
+        else if (a == "--noAncestors")
+            noAncestors = true;
+        else if (a == "--unique")
+            unique = true;
+        else
+            pos.push_back(a);
+    }
+    if (pos.size() != 2) {
+        std::cerr << "usage: hal_oracle columns <img.hgx> <refGenome> [--maxRefGap N] [--noDupes] [--noAncestors] [--unique]" << std::endl;
         return 1;
     }
-    Alignment al = loadImage(argv[0]);
-    const int ref = al.genomeByName(argv[1]);
+    Alignment al = loadImage(pos[0]);
+    const int ref = al.genomeByName(pos[1]);
     if (ref < 0) {
         std::cerr << "genome not found" << std::endl;
         return 1;
     }
     const Sequence &S = al.genomes[(size_t)ref].seqs[0];
-    ColumnIterator col(&al, ref, nullptr, S.start, S.start + S.length - 1, false, false, false);
-    for (i64 c = 0; c < S.length; ++c) {
+    ColumnIterator col(&al, ref, nullptr, S.start, S.start + S.length - 1, noDupes, noAncestors, false, unique, maxInsertLength);
+    // (with a stack — --maxRefGap — or a visit cache the number of columns is not the sequence's length: until lastColumn())
+    for (i64 c = 0;; ++c) {
         std::cout << c;
         for (auto &kv : col.colMap)
             for (const Dna &d : kv.second)
                 std::cout << ' ' << al.genomes[(size_t)d.g].name << ':' << d.pos << ':' << (d.rev ? '-' : '+');
         std::cout << '\n';
-        if (c + 1 < S.length)
-            col.toRight();
+        if (col.lastColumn())
+            break;
+        col.toRight();
     }
     return 0;
 }

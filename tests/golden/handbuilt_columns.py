@@ -5,6 +5,10 @@ as tables, and the facts those tests assert, as predicates over the rows of ever
   dup()    ColumnIteratorDupTest    :158-280  dad - (son1, son2); son1 is ten copies of dad's segment 0, son2 has segments 4
                                               and 8 both derived from dad's segment 4
   inv()    ColumnIteratorInvTest    :282-457  grandpa - dad - son1 with inversions on one and on both branches
+  gap()            ColumnIteratorGapTest          :459-540  grandpa - dad; dad lacks grandpa's middle segment (a deletion); iterated from
+                                                            dad with maxInsertLength 1000 the deleted bases come as columns of their own
+  multi_gap()      ColumnIteratorMultiGapTest     :542-732  adam - grandpa - dad, a deletion on either branch (nested stack entries)
+  multi_gap_inv()  ColumnIteratorMultiGapInvTest  :734-933  the same with adam's second segment inverted in grandpa
 """
 from halfix import NULL, fix_parse_info
 
@@ -90,6 +94,92 @@ def check_inv(ref_name, col, rows):
     else:
         assert by["son1"][0] == by["dad"][0] == by["grandpa"][0] == col, (col, rows)
 
+
+def _small(name, parent, children, length, tops, bots, dna, seq):
+    """4-base segments: tops = list of (parentIdx, parentRev), bots = list of per-child (idx, rev)"""
+    g = {"name": name, "parent": parent, "children": children}
+    g["tStart"] = [4 * i for i in range(len(tops))] + [length]
+    g["tParent"] = [t[0] for t in tops]
+    g["tParentRev"] = [1 if t[1] else 0 for t in tops]
+    g["tParalogy"] = [NULL] * len(tops)
+    g["bStart"] = [4 * i for i in range(len(bots))] + [length]
+    g["bChild"] = [[b[k][0] for b in bots] for k in range(len(children))]
+    g["bChildRev"] = [[1 if b[k][1] else 0 for b in bots] for k in range(len(children))]
+    g["seqs"] = [(seq, 0, length, 0, len(tops), 0, len(bots))]
+    g["dna"] = dna
+    fix_parse_info(g)
+    return g
+
+
+def gap():
+    # :476-507
+    return [_small("grandpa", -1, [1], 12, [], [[(0, False)], [(NULL, False)], [(1, False)]], "ACGTAAAAGGGG", "gseq"),
+            _small("dad", 0, [], 8, [(0, False), (2, False)], [], "ACGTGGGG", "dseq")]
+
+
+def check_gap(i, rows):
+    """:519-538: column i of the iteration from dad with maxInsertLength 1000 (12 columns)"""
+    by = {}
+    for g, p, _ in rows:
+        by.setdefault(g, []).append(p)
+    if i < 4 or i >= 8:
+        assert by.get("dad") == [i if i < 4 else i - 4], (i, rows)
+    assert by.get("grandpa") == [i], (i, rows)
+
+
+def _multi_gap(inverted):
+    # :566-640 / :758-838
+    adam = _small("adam", -1, [1], 16, [], [[(0, False)], [(1, inverted)], [(NULL, False)], [(2, False)]], "ACGTAAAATTTTGGGG", "aseq")
+    grandpa = _small("grandpa", 0, [2], 12, [(0, False), (1, inverted), (3, False)], [[(0, False)], [(NULL, False)], [(1, False)]],
+                     "ACGTAAAAGGGG", "gseq")
+    dad = _small("dad", 1, [], 8, [(0, False), (2, False)], [], "ACGTGGGG", "dseq")
+    return [adam, grandpa, dad]
+
+
+def multi_gap():
+    return _multi_gap(False)
+
+
+def multi_gap_inv():
+    return _multi_gap(True)
+
+
+def _by(rows):
+    by = {}
+    for g, p, _ in rows:
+        by.setdefault(g, []).append(p)
+    return by
+
+
+def check_multi_gap(i, rows):
+    """:660-729 (16 columns)"""
+    by = _by(rows)
+    if i < 4:
+        assert by == {"adam": [i], "grandpa": [i], "dad": [i]}, (i, rows)
+    elif i < 8:
+        assert by == {"adam": [i], "grandpa": [i]}, (i, rows)
+    elif i < 12:
+        assert by == {"adam": [i]}, (i, rows)
+    else:
+        assert by == {"adam": [i], "grandpa": [i - 4], "dad": [i - 8]}, (i, rows)
+
+
+def check_multi_gap_inv(i, rows):
+    """:854-930 (16 columns; the assertion on adam's position in columns 8..11 is disabled in the reference)"""
+    by = _by(rows)
+    if i < 4:
+        assert by == {"adam": [i], "grandpa": [i], "dad": [i]}, (i, rows)
+    elif i < 8:
+        assert by == {"adam": [11 - i], "grandpa": [i]}, (i, rows)
+    elif i < 12:
+        assert sorted(by) == ["adam"] and len(by["adam"]) == 1, (i, rows)
+    else:
+        assert by == {"adam": [i], "grandpa": [i - 4], "dad": [i - 8]}, (i, rows)
+
+
+# (name, alignment, check(column number in iteration order, rows), reference genome, number of columns) with maxInsertLength 1000
+GAP_CASES = [("gap", gap, check_gap, "dad", 12), ("multi_gap", multi_gap, check_multi_gap, "dad", 16),
+             ("multi_gap_inv", multi_gap_inv, check_multi_gap_inv, "dad", 16)]
 
 CASES = [("depth", depth, check_depth, ["grandpa", "dad", "son1", "son2"]), ("dup", dup, check_dup, ["dad", "son1", "son2"]),
          ("inv", inv, check_inv, ["son1"])]

@@ -183,6 +183,24 @@ def test_reference_unit_tests_of_the_column_iterator(oracle_bin, tmp_path):
                 check(ref, int(f[0]), rows)
 
 
+def test_reference_unit_tests_of_the_column_iterator_with_gaps(oracle_bin, tmp_path):
+    """api/tests/halColumnIteratorTest.cpp:459-933: Gap, MultiGap and MultiGapInv — the column iterator with maxInsertLength 1000
+    walks the deleted ranges of the ancestors as columns of their own between two reference columns (the indel stack)."""
+    import handbuilt_columns as hc
+    for name, build, check, ref, ncol in hc.GAP_CASES:
+        img = str(tmp_path / (name + ".hgx"))
+        halfix.write_hgx(img, build())
+        out = subprocess.run([oracle_bin, "columns", img, ref, "--maxRefGap", "1000"], check=True, stdout=subprocess.PIPE).stdout.decode()
+        lines = out.splitlines()
+        assert len(lines) == ncol, (name, len(lines))
+        for line in lines:
+            f = line.split()
+            check(int(f[0]), [(x.split(":")[0], int(x.split(":")[1]), x.split(":")[2] == "-") for x in f[1:]])
+        # without the stack the iterator gives the reference's own columns only
+        plain = subprocess.run([oracle_bin, "columns", img, ref], check=True, stdout=subprocess.PIPE).stdout.decode().splitlines()
+        assert len(plain) == 8
+
+
 def test_reference_unit_test_extra_paralogs_coalescence_limit(oracle_bin, tmp_path):
     """api/tests/halMappedSegmentTest.cpp:478-611: the known answer for a coalescence limit above the MRCA."""
     img = str(tmp_path / "xp.hgx")
