@@ -301,7 +301,7 @@ class Alignment:
 
     def maf_export_bytes(self, ref, ref_sequence=-1, start=0, length=0, no_ancestors=False, max_block_len=1000):
         """hal2maf end to end, the text left in library memory and released: returns its size (benchmark use)."""
-        o = hgx_maf_opts(0, 1 if no_ancestors else 0, 0, 0, 0, 0, max_block_len)
+        o = hgx_maf_opts(0, 1 if no_ancestors else 0, 0, 0, 0, 0, max_block_len, 0)
         out, n, err = C.c_void_p(), C.c_size_t(), C.c_void_p()
         if lib.hgx_maf_export(self._h, ref, ref_sequence, start, length, C.byref(o), None, 0, C.byref(out), C.byref(n), C.byref(err)) != 0:
             raise HgxError(take_error(err))
@@ -310,12 +310,12 @@ class Alignment:
 
     def maf_export(self, ref, ref_sequence=-1, start=0, length=0, no_dupes=False, no_ancestors=False, only_sequence_names=False,
                    only_orthologs=False, keep_empty_ref_blocks=False, max_block_len=1000, targets=None, unique=False,
-                   ref_targets_bed=None):
+                   ref_targets_bed=None, max_ref_gap=0):
         """hal2maf's MAF text (maf/impl/halMafExport.cpp:25-88, maf/impl/hal2maf.cpp:196-206); ref_targets_bed: BED text of
         reference intervals (--refTargets, maf/impl/halMafBed.cpp)."""
         if ref_targets_bed is not None:
             o = hgx_maf_opts(1 if no_dupes else 0, 1 if no_ancestors else 0, 1 if only_sequence_names else 0,
-                             1 if only_orthologs else 0, 1 if keep_empty_ref_blocks else 0, 1 if unique else 0, max_block_len)
+                             1 if only_orthologs else 0, 1 if keep_empty_ref_blocks else 0, 1 if unique else 0, max_block_len, max_ref_gap)
             tg = (C.c_int32 * len(targets))(*targets) if targets else None
             data = ref_targets_bed.encode() if isinstance(ref_targets_bed, str) else ref_targets_bed
             out, n, err = C.c_void_p(), C.c_size_t(), C.c_void_p()
@@ -327,7 +327,7 @@ class Alignment:
             finally:
                 lib.hgx_free(out)
         o = hgx_maf_opts(1 if no_dupes else 0, 1 if no_ancestors else 0, 1 if only_sequence_names else 0,
-                         1 if only_orthologs else 0, 1 if keep_empty_ref_blocks else 0, 1 if unique else 0, max_block_len)
+                         1 if only_orthologs else 0, 1 if keep_empty_ref_blocks else 0, 1 if unique else 0, max_block_len, max_ref_gap)
         tg = (C.c_int32 * len(targets))(*targets) if targets else None
         out, n, err = C.c_void_p(), C.c_size_t(), C.c_void_p()
         if lib.hgx_maf_export(self._h, ref, ref_sequence, start, length, C.byref(o), tg, len(targets) if targets else 0,

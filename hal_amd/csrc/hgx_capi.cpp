@@ -806,6 +806,7 @@ static void configureMaf(MafExport &me, const hgx_maf_opts *o, const GenomeTable
         me.setKeepEmptyRefBlocks(o->keep_empty_ref_blocks != 0);
         me.setUnique(o->unique != 0);
         me.setMaxBlockLength(o->max_block_len == 0 ? 1000 : o->max_block_len);
+        me.setMaxRefGap(o->max_ref_gap < 0 ? 0 : o->max_ref_gap);
         if (o->no_ancestors && !G->children.empty()) // hal2maf.cpp:153-159
             throw std::runtime_error("Since the reference genome to be used for the MAF is ancestral (" + G->name +
                                      "), the --noAncestors option is invalid.  The --refGenome option can be used to specify a "

@@ -1,6 +1,7 @@
 // Column engine: launches of the per-base closure kernels behind hgx_columns_depth / hgx_alignment_depth /
 // hgx_maf_export (include/hgx.h).
 #include "hgx_column_kernels.hpp"
+#include "hgx_gap_kernels.hpp"
 #include "hgx_scan_kernels.hpp"
 #include "hgx_columns_engine.hpp"
 #include "hgx_liftover_engine.hpp"
@@ -417,6 +418,63 @@ void columnsRowsHost(hgx_alignment *h, int ref, int64_t first, int64_t count, co
                            (ColumnRow *)dRows.p);
     else
         hipLaunchKernelGGL((k_column_rows<int32_t, uint64_t>), dim3(grid), dim3(256), 0, nullptr, P, (const uint64_t *)dOff.p,
+                           (ColumnRow *)dRows.p);
+    HIP_OK(hipEventRecord(b.e, nullptr));
+    unsigned int e = 0;
+    HIP_OK(hipMemcpy(&e, err.p, 4, hipMemcpyDeviceToHost));
+    if (e)
+        throw std::runtime_error("column walk exceeded the frame stack (more than 64 pending branches for one base)");
+    if (total)
+        HIP_OK(hipMemcpy(rows.data(), dRows.p, total * sizeof(ColumnRow), hipMemcpyDeviceToHost));
+    if (stats) {
+        float ms = 0;
+        HIP_OK(hipEventElapsedTime(&ms, a.e, b.e));
+        stats->rows_ms += ms;
+        stats->rows += total;
+    }
+}
+
+void columnsGapRowsHost(hgx_alignment *h, int ref, const std::vector<GapAskHost> &asks, const ColumnOptions &opt, bool withDna,
+                        std::vector<uint64_t> &rowOffset, std::vector<ColumnRowHost> &rows, ColumnStats *stats) {
+    static_assert(sizeof(GapAskHost) == sizeof(GapAsk), "ask layouts must match");
+    if (!h->dev)
+        throw std::runtime_error("alignment was opened without a device (device = -1); the column engine needs the HIP path");
+    HIP_OK(hipSetDevice(h->dev->device));
+    if (withDna)
+        ensureDeviceDna(h->img, *h->dev);
+    const size_t n = asks.size();
+    rowOffset.assign(n + 1, 0);
+    rows.clear();
+    if (n == 0)
+        return;
+    for (const GapAskHost &a : asks)
+        if (a.genome < 0 || a.genome >= (int)h->img.genomes.size() || a.pos < 0 || a.pos >= h->img.genomes[(size_t)a.genome].totalLength)
+            throw std::runtime_error("column asked for outside its genome");
+    Buf dAsk(n * sizeof(GapAsk)), dCnt(n * 4), dOff((n + 1) * 8), err(4), masks;
+    HIP_OK(hipMemcpy(dAsk.p, asks.data(), n * sizeof(GapAsk), hipMemcpyHostToDevice));
+    HIP_OK(hipMemset(err.p, 0, 4));
+    ColumnParams P = makeParams(h, ref, 0, 0, 1, opt, (unsigned int *)err.p, masks);
+    P.count = (int64_t)n;
+    Ev a, b;
+    HIP_OK(hipEventRecord(a.e, nullptr));
+    const int grid = (int)std::min<int64_t>(COL_GRID, ((int64_t)n + 255) / 256);
+    if (h->dev->wide)
+        hipLaunchKernelGGL((k_gap_count<int64_t>), dim3(grid), dim3(256), 0, nullptr, P, (const GapAsk *)dAsk.p, (uint32_t *)dCnt.p);
+    else
+        hipLaunchKernelGGL((k_gap_count<int32_t>), dim3(grid), dim3(256), 0, nullptr, P, (const GapAsk *)dAsk.p, (uint32_t *)dCnt.p);
+    std::vector<uint32_t> cnt(n);
+    HIP_OK(hipMemcpy(cnt.data(), dCnt.p, n * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i)
+        rowOffset[i + 1] = rowOffset[i] + cnt[i];
+    const uint64_t total = rowOffset[n];
+    rows.resize(total);
+    Buf dRows(std::max<uint64_t>(total, 1) * sizeof(ColumnRow));
+    HIP_OK(hipMemcpy(dOff.p, rowOffset.data(), (n + 1) * 8, hipMemcpyHostToDevice));
+    if (h->dev->wide)
+        hipLaunchKernelGGL((k_gap_rows<int64_t>), dim3(grid), dim3(256), 0, nullptr, P, (const GapAsk *)dAsk.p, (const uint64_t *)dOff.p,
+                           (ColumnRow *)dRows.p);
+    else
+        hipLaunchKernelGGL((k_gap_rows<int32_t>), dim3(grid), dim3(256), 0, nullptr, P, (const GapAsk *)dAsk.p, (const uint64_t *)dOff.p,
                            (ColumnRow *)dRows.p);
     HIP_OK(hipEventRecord(b.e, nullptr));
     unsigned int e = 0;

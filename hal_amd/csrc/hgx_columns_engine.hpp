@@ -46,6 +46,20 @@ void columnsDepthDevice(hgx_alignment *h, int ref, int64_t first, int64_t count,
 void columnsRowsHost(hgx_alignment *h, int ref, int64_t first, int64_t count, const ColumnOptions &opt, bool withDna,
                      std::vector<uint64_t> &rowOffset, std::vector<ColumnRowHost> &rows, ColumnStats *stats);
 
+// The columns of a ColumnIterator with maxInsertLength > 0 (hgx_gap_kernels.hpp): column i starts from base asks[i] — any genome,
+// either orientation — and comes back as EVERY base its walk visits, in the reference's order, with what the host's replay of the
+// iterator's sequential state needs: _pad[0] & 7 = 0 a reported base, 1 a base colMapInsert's filters keep out of the column, 2 / 3
+// a deleted / inserted range the walk met behind the previous base (pos = its first base, genome, rev = the orientation it is
+// to be walked in; the next row, kind 4, carries its last base); _pad[0] & 8: the base was reached by updateParent; _pad[1]: level
+// in the walk's upward chain.  ref: the iterator's reference genome (scope and targets are relative to it).
+struct GapAskHost {
+    int64_t pos;
+    int32_t genome;
+    int32_t reversed;
+};
+void columnsGapRowsHost(hgx_alignment *h, int ref, const std::vector<GapAskHost> &asks, const ColumnOptions &opt, bool withDna,
+                        std::vector<uint64_t> &rowOffset, std::vector<ColumnRowHost> &rows, ColumnStats *stats);
+
 // Run-compressed form for the MAF writer: head[c] == 1 when column c does not simply continue column c-1 (same rows
 // advanced by one base); only heads have their rows returned (headOffset: one entry per head, + 1).
 void columnsHeadRowsHost(hgx_alignment *h, int ref, int64_t first, int64_t count, const ColumnOptions &opt, bool withDna,

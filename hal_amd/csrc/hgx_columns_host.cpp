@@ -525,8 +525,6 @@ void MafExport::printBlock(std::ostream &os) const {
 // halMafExport.cpp:25-88
 void MafExport::convertSequence(std::ostream &mafStream, hgx_alignment *alignment, int genome, int seq, int64_t startPosition,
                                 int64_t length, const std::set<int> &targets) {
-    if (_maxRefGap > 0)
-        throw std::runtime_error("--maxRefGap > 0 (indel stacks) is not built yet (SURVEY 8(f) item 2)");
     if (_al != alignment) {
         _al = alignment;
         buildRanks();
@@ -554,6 +552,10 @@ void MafExport::convertSequence(std::ostream &mafStream, hgx_alignment *alignmen
     opt.targets.assign(targets.begin(), targets.end());
     const Key refKey{_rank[(size_t)genome][(size_t)seq], genome, seq};
 
+    if (_maxRefGap > 0) {
+        convertSequenceGapped(mafStream, alignment, genome, seq, startPosition + S.start, startPosition + S.start + length - 1, opt);
+        return;
+    }
     ColumnMap colMap; // keys persist between columns like ColumnIterator::_colMap (resetColMap only empties the vectors)
     std::vector<uint64_t> off;
     std::vector<ColumnRowHost> rows;
@@ -824,6 +826,302 @@ void MafExport::convertSequence(std::ostream &mafStream, hgx_alignment *alignmen
                     mafStream << '\n';
                 }
                 initBlock(colMap, refKey, prevRefIndex);
+            }
+            appendColumn(colMap);
+            ++appendCount;
+        }
+    }
+    if (appendCount > 0 && (_keepEmptyRefBlocks || !referenceIsAllGaps())) {
+        printBlock(mafStream);
+        mafStream << std::endl;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ColumnIterator with maxInsertLength > 0.  The device walks columns and reports what their walks meet (hgx_gap_kernels.hpp);
+// the iterator's sequential state — the stack of ranges (api/inc/halColumnIteratorStack.h), the visit cache of the reference
+// genome and of every genome a range lies in (halColumnIterator.cpp:749-819), the columns abandoned at a base seen before —
+// is replayed here, in the reference's order.
+namespace {
+
+struct PositionCache { // api/impl/halPositionCache.cpp:12-78: positions as merged intervals, last -> first
+    std::map<int64_t, int64_t> set;
+    bool find(int64_t pos) const {
+        auto i = set.lower_bound(pos);
+        return i != set.end() && i->second <= pos;
+    }
+    bool insert(int64_t pos) { // false: already there
+        if (find(pos))
+            return false;
+        int64_t lo = pos, hi = pos;
+        auto right = set.lower_bound(pos);
+        if (right != set.end() && right->second == pos + 1) {
+            hi = right->first;
+            set.erase(right);
+        }
+        auto left = set.find(pos - 1);
+        if (left != set.end()) {
+            lo = left->second;
+            set.erase(left);
+        }
+        set[hi] = lo;
+        return true;
+    }
+};
+
+struct StackEntry { // ColumnIteratorStack::Entry (halColumnIteratorStack.h:47-107)
+    int g = -1;
+    int64_t firstIndex = 0, index = 0, lastIndex = 0, cumulativeSize = 0;
+    bool reversed = false;
+    bool inBounds() const { return index >= firstIndex && index <= lastIndex; }
+};
+
+// ColumnIteratorStack::push on one of the indel stacks (:112-121)
+void pushEntry(std::vector<StackEntry> &st, int g, int64_t index, int64_t lastIndex, bool reversed) {
+    StackEntry e;
+    e.g = g;
+    e.cumulativeSize = st.empty() ? 0 : st.back().cumulativeSize + lastIndex - index + 1;
+    e.firstIndex = index;
+    e.index = reversed ? lastIndex : index;
+    e.lastIndex = lastIndex;
+    e.reversed = reversed;
+    st.push_back(e);
+}
+
+struct ColKey {
+    int64_t pos;
+    int32_t genome, reversed;
+    bool operator<(const ColKey &o) const {
+        if (genome != o.genome)
+            return genome < o.genome;
+        if (reversed != o.reversed)
+            return reversed < o.reversed;
+        return pos < o.pos;
+    }
+};
+
+// the columns the device has delivered: batches of (asks, row offsets, rows)
+struct GapColumns {
+    hgx_alignment *al;
+    int refGenome;
+    const ColumnOptions &opt;
+    int64_t maxInsert;
+    ColumnStats *stats;
+    struct Batch {
+        std::vector<GapAskHost> asks;
+        std::vector<uint64_t> off;
+        std::vector<ColumnRowHost> rows;
+    };
+    std::deque<Batch> batches, previous; // previous: the chunk before (the column map may still point into it)
+    std::map<ColKey, std::pair<uint32_t, uint32_t>> where;
+    GapColumns(hgx_alignment *a, int ref, const ColumnOptions &o, int64_t mi, ColumnStats *st) : al(a), refGenome(ref), opt(o), maxInsert(mi), stats(st) {}
+
+    void run(std::vector<GapAskHost> &&asks) {
+        batches.emplace_back();
+        Batch &B = batches.back();
+        B.asks = std::move(asks);
+        columnsGapRowsHost(al, refGenome, B.asks, opt, true, B.off, B.rows, stats);
+        for (size_t i = 0; i < B.asks.size(); ++i)
+            where[ColKey{B.asks[i].pos, B.asks[i].genome, B.asks[i].reversed}] = {(uint32_t)batches.size() - 1, (uint32_t)i};
+    }
+    bool usable(const ColumnRowHost &head, const ColumnRowHost &tail) const { // a range the iterator can walk (and may accept)
+        const int64_t first = head.pos, last = tail.pos;
+        return first >= 0 && last >= first && last < al->img.genomes[(size_t)head.genome].totalLength && last - first + 1 <= maxInsert;
+    }
+    // the reference columns [first, first + count) and, level by level, every column of every range their walks (and the walks of
+    // those columns ...) could push: a superset of what the replay will ask for
+    void prefetch(int64_t first, int64_t count) {
+        previous.swap(batches);
+        batches.clear();
+        where.clear();
+        std::vector<GapAskHost> asks((size_t)count);
+        for (int64_t i = 0; i < count; ++i)
+            asks[(size_t)i] = GapAskHost{first + i, refGenome, 0};
+        run(std::move(asks));
+        for (size_t level = 0; level < batches.size(); ++level) { // (a batch may add the next one)
+            const Batch &B = batches[level];
+            std::vector<GapAskHost> next;
+            std::set<ColKey> seen;
+            for (size_t r = 0; r + 1 < B.rows.size(); ++r) {
+                const int kind = B.rows[r]._pad[0] & 7;
+                if ((kind != 2 && kind != 3) || !usable(B.rows[r], B.rows[r + 1]))
+                    continue;
+                for (int64_t p = B.rows[r].pos; p <= B.rows[r + 1].pos; ++p) {
+                    const ColKey k{p, B.rows[r].genome, B.rows[r].rev ? 1 : 0};
+                    if (!where.count(k) && seen.insert(k).second)
+                        next.push_back(GapAskHost{p, k.genome, k.reversed});
+                }
+            }
+            if (!next.empty())
+                run(std::move(next));
+        }
+    }
+    // rows of the column that starts from (genome, pos, reversed): [begin, end)
+    void column(int g, int64_t pos, bool reversed, const ColumnRowHost *&begin, const ColumnRowHost *&end) {
+        auto it = where.find(ColKey{pos, g, reversed ? 1 : 0});
+        if (it == where.end()) { // (not foreseen by the prefetch: asked for by itself)
+            run(std::vector<GapAskHost>{GapAskHost{pos, g, reversed ? 1 : 0}});
+            it = where.find(ColKey{pos, g, reversed ? 1 : 0});
+        }
+        const Batch &B = batches[it->second.first];
+        begin = B.rows.data() + B.off[it->second.second];
+        end = B.rows.data() + B.off[it->second.second + 1];
+    }
+};
+
+} // namespace
+
+void MafExport::convertSequenceGapped(std::ostream &mafStream, hgx_alignment *alignment, int genome, int seq, int64_t first, int64_t last,
+                                      const ColumnOptions &opt) {
+    const GenomeTables &G = alignment->img.genomes[(size_t)genome];
+    GapColumns cols(alignment, genome, opt, _maxRefGap, &stats);
+    const int64_t gapChunk = (int64_t)std::min<size_t>(chunkColumns, (size_t)1 << 17); // (every visited base comes back: smaller chunks)
+    int64_t chunkFirst = 0, chunkCount = 0;
+
+    // ---- ColumnIterator state (halColumnIterator.h:140-165) ----
+    StackEntry base;
+    base.g = genome;
+    base.firstIndex = base.index = first;
+    base.lastIndex = last;
+    std::vector<StackEntry> upper, insertionStack, deletionStack;
+    std::map<int, PositionCache> visitCache;
+    ColumnMap colMap;
+    bool brk = false;
+    int64_t leftmostRefPos = first;
+    int refSeqIdx = seq, prevRefSeq = seq;
+    int64_t prevRefIndex = 0;
+    auto top = [&]() -> StackEntry & { return upper.empty() ? base : upper.back(); };
+    // nextFreeIndex (:749-764)
+    auto nextFreeIndex = [&]() {
+        StackEntry &e = top();
+        if (_unique || !upper.empty()) {
+            auto it = visitCache.find(e.g);
+            if (it != visitCache.end())
+                while (it->second.find(e.index) && e.index <= e.lastIndex)
+                    ++e.index;
+        }
+    };
+    // recursiveUpdate (:246-355) over the column the device walked: colMapInsert (:766-819) for every base in the walk's order,
+    // handleDeletion / handleInsertion (:357-405) for every range it met
+    auto recursiveUpdate = [&]() {
+        for (auto &kv : colMap)
+            kv.second.clear();
+        brk = false;
+        leftmostRefPos = base.index;
+        const StackEntry e = top();
+        if (upper.empty() && (e.index < chunkFirst || e.index >= chunkFirst + chunkCount)) {
+            chunkFirst = e.index;
+            chunkCount = std::min<int64_t>(gapChunk, last - e.index + 1);
+            cols.prefetch(chunkFirst, chunkCount);
+        }
+        const ColumnRowHost *r, *end;
+        cols.column(e.g, e.index, e.reversed, r, end);
+        unsigned long long open = 0; // levels of the upward chain whose parse-up branch is under way (their deletion check is still to come)
+        for (; r < end; ++r) {
+            const int kind = r->_pad[0] & 7, level = r->_pad[1];
+            if (kind == 4)
+                continue;
+            if (kind == 2 || kind == 3) {
+                const bool pendingDeletion = kind == 2 && level >= 1 && level < 64 && ((open >> level) & 1ull);
+                if (kind == 2 && level >= 1 && level < 64)
+                    open &= ~(1ull << level);
+                // after the walk was abandoned only the deletion checks of the updateParent calls it was inside are still made
+                // (:585-589 is not guarded by _break)
+                if (brk && !pendingDeletion)
+                    continue;
+                const ColumnRowHost &tail = r[1];
+                const int64_t lo = r->pos, hi = tail.pos;
+                if (lo < 0 || hi < lo || hi >= alignment->img.genomes[(size_t)r->genome].totalLength)
+                    continue; // (getInsertedRange's range of a reversed iterator can leave the genome: undefined in the reference, left out)
+                if (hi - lo + 1 + e.cumulativeSize <= _maxRefGap)
+                    pushEntry(kind == 2 ? deletionStack : insertionStack, r->genome, lo, hi, r->rev != 0);
+                continue;
+            }
+            if (brk)
+                continue;
+            bool updateCache = r->genome == genome;
+            for (size_t i = 0; i < upper.size() && !updateCache; ++i)
+                updateCache = r->genome == upper[i].g;
+            bool found;
+            if (updateCache) {
+                found = !visitCache[r->genome].insert(r->pos);
+            } else {
+                auto it = visitCache.find(r->genome);
+                found = it != visitCache.end() && it->second.find(r->pos);
+            }
+            if (!found && kind == 0)
+                colMap[keyOf(r->genome, r->pos)].push_back(r);
+            if (r->genome == genome)
+                leftmostRefPos = std::min(leftmostRefPos, r->pos);
+            if (found) {
+                brk = true;
+                continue;
+            }
+            if ((r->_pad[0] & 8) && level >= 1 && level < 64)
+                open |= 1ull << level;
+        }
+    };
+    // toRight (:65-144)
+    auto toRight = [&]() {
+        prevRefSeq = refSeqIdx;
+        prevRefIndex = base.index - G.seqs[(size_t)refSeqIdx].start;
+        if (upper.empty() && !top().inBounds())
+            return;
+        do {
+            nextFreeIndex();
+            while (!upper.empty() && !top().inBounds()) {
+                upper.pop_back();
+                nextFreeIndex();
+            }
+            if (upper.empty() && !top().inBounds())
+                return;
+            recursiveUpdate();
+            StackEntry &e = top();
+            e.index += e.reversed ? -1 : 1;
+            if (upper.empty()) {
+                const SeqInfo &S = G.seqs[(size_t)refSeqIdx];
+                if (base.index < S.start || (base.index >= S.start + S.length && base.index < G.totalLength))
+                    refSeqIdx = G.seqIndexBySite(base.index);
+            }
+        } while (brk);
+        for (size_t i = deletionStack.size(); i-- > 0;) // pushStackReversed (:121-123)
+            upper.push_back(deletionStack[i]);
+        deletionStack.clear();
+        for (const StackEntry &x : insertionStack)
+            upper.push_back(x);
+        insertionStack.clear();
+        nextFreeIndex();
+        while (!upper.empty() && !top().inBounds()) {
+            upper.pop_back();
+            nextFreeIndex();
+        }
+    };
+    auto lastColumn = [&]() { return upper.empty() && base.index > base.lastIndex; };                          // :167-169
+    auto canonicalOnRef = [&]() { return leftmostRefPos >= base.firstIndex && leftmostRefPos <= base.lastIndex; }; // :210-214
+    auto refKey = [&]() { return Key{_rank[(size_t)genome][(size_t)prevRefSeq], genome, prevRefSeq}; };
+
+    // ---- MafExport::convertSequence's loop (maf/impl/halMafExport.cpp:51-87) ----
+    size_t appendCount = 0, numBlocks = 0;
+    toRight(); // the constructor's first step
+    if (!_unique || canonicalOnRef()) {
+        initBlock(colMap, refKey(), prevRefIndex);
+        appendColumn(colMap);
+        ++appendCount;
+    }
+    while (!lastColumn()) {
+        toRight();
+        if (!_unique || canonicalOnRef()) {
+            if (appendCount == 0)
+                initBlock(colMap, refKey(), prevRefIndex);
+            if (!canAppendColumn(colMap)) {
+                if (numBlocks++ % 1000 == 0)
+                    for (auto it = colMap.begin(); it != colMap.end();)
+                        it = it->second.empty() ? colMap.erase(it) : std::next(it);
+                if (appendCount > 0 && (_keepEmptyRefBlocks || !referenceIsAllGaps())) {
+                    printBlock(mafStream);
+                    mafStream << '\n';
+                }
+                initBlock(colMap, refKey(), prevRefIndex);
             }
             appendColumn(colMap);
             ++appendCount;

@@ -348,6 +348,10 @@ typedef struct hgx_maf_opts {
     int64_t max_block_len; /* --maxBlockLen; 0 = the default, 1000 (halMafBlock.cpp:16).  A negative value is what the
                               reference makes of --maxBlockLen 0 (MafBlock::setMaxLength keeps the value, halMafBlock.h:133):
                               every column starts a block; the hal2maf twin passes the option through unchanged */
+    int64_t max_ref_gap; /* --maxRefGap = ColumnIterator's maxInsertLength (maf/impl/halMafExport.cpp:47): > 0: between two
+                            reference columns the bases the reference lacks — ranges deleted above it, inserted below it, up to
+                            this many bases — come as columns of their own (halColumnIterator.cpp:65-144, 357-405), and, as in
+                            the reference, every reference base is then written once (the visit cache is on) */
 } hgx_maf_opts;
 int hgx_maf_export(hgx_alignment *h, int ref_genome, int ref_sequence, int64_t start, int64_t length, const hgx_maf_opts *opts,
                    const int32_t *targets, int32_t n_targets, char **out_text, size_t *out_len, char **err);

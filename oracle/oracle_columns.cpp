@@ -393,7 +393,7 @@ bool ColumnIterator::handleDeletion(const SegIt &inputTopSegIt) {
                 botSegIt.toParent(inputTopSegIt);
                 const Genome &P = botSegIt.G();
                 if (deletedRange.first < 0 || deletedRange.second >= P.totalLength)
-                    throw std::runtime_error("oracle: deleted range outside the genome");
+                    return false;
                 pushEntry(deletionStack, botSegIt.g, seqIndexBySite(P, botSegIt.segStart()), deletedRange.first, deletedRange.second, botSegIt.rev);
                 return true;
             }
@@ -415,9 +415,10 @@ bool ColumnIterator::handleInsertion(const SegIt &inputTopSegIt) {
                 const std::pair<i64, i64> insertedRange = rea.getInsertedRange();
                 const Genome &G = topIt.G();
                 // (the reference computes a reversed iterator's range from its high end upwards, :165-176; a range that leaves
-                // the genome is undefined behaviour there and an error here)
+                // the genome is undefined behaviour there — a column iterator over positions that do not exist — and is left
+                // out here, as in the product)
                 if (insertedRange.first < 0 || insertedRange.second >= G.totalLength)
-                    throw std::runtime_error("oracle: inserted range outside the genome (reference: undefined behaviour)");
+                    return false;
                 pushEntry(insertionStack, topIt.g, seqIndexBySite(G, topIt.segStart()), insertedRange.first, insertedRange.second, reversed);
             }
         }
