@@ -85,6 +85,10 @@ SYMBOLS = {
                                      P(P(hgx_record)), P(C.c_size_t), P(VP)]),
     "hgx_block_map": (C.c_int, [VP, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int, P(P(hgx_record)),
                                 P(C.c_size_t), P(VP)]),
+    "hgx_alignment_depth_multi": (C.c_int, [P(VP), C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, P(C.c_int32), C.c_int32,
+                                             P(VP), P(C.c_size_t), P(VP)]),
+    "hgx_maf_export_multi": (C.c_int, [P(VP), C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, P(hgx_maf_opts), P(C.c_int32), C.c_int32,
+                                        P(VP), P(C.c_size_t), P(VP)]),
     "hgx_get_blocks_in_target_range": (VP, [VP, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int,
                                             C.c_char_p, P(VP)]),
     "hgx_get_blocks_in_target_ranges": (C.c_int, [VP, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, P(C.c_int64), P(C.c_int64), C.c_int64,

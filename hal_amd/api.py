@@ -378,6 +378,40 @@ def liftover_convert_multi(alignments, src_genome, bed_text, tgt_genome, bed_typ
     return text
 
 
+def alignment_depth_multi(alignments, ref, ref_sequence=-1, start=0, length=0, step=1, count_dupes=False, no_ancestors=False, targets=None):
+    """hgx_alignment_depth_multi: halAlignmentDepth's wig text, the columns scanned in contiguous shares on several device clones of
+    one alignment (Alignment.clone_to_device); same text as Alignment.alignment_depth."""
+    hs = (C.c_void_p * len(alignments))(*[a._h for a in alignments])
+    tg = (C.c_int32 * len(targets))(*targets) if targets else None
+    out, n, err = C.c_void_p(), C.c_size_t(), C.c_void_p()
+    if lib.hgx_alignment_depth_multi(hs, len(alignments), ref, ref_sequence, start, length, step, 1 if count_dupes else 0,
+                                     1 if no_ancestors else 0, tg, len(targets) if targets else 0, C.byref(out), C.byref(n), C.byref(err)) != 0:
+        raise HgxError(take_error(err))
+    try:
+        return C.string_at(out, n.value).decode()
+    finally:
+        lib.hgx_free(out)
+
+
+def maf_export_multi(alignments, ref, ref_sequence=-1, start=0, length=0, slice_size=0, no_dupes=False, no_ancestors=False,
+                     only_sequence_names=False, only_orthologs=False, keep_empty_ref_blocks=False, max_block_len=1000, targets=None,
+                     unique=False, max_ref_gap=0):
+    """hgx_maf_export_multi: hal2mafMP.py's slices (maf/hal2mafMP.py:63-79) — one export per slice of slice_size reference columns
+    (0: the range divided evenly over the handles), dealt to the device clones, the texts concatenated with the first header only."""
+    hs = (C.c_void_p * len(alignments))(*[a._h for a in alignments])
+    o = hgx_maf_opts(1 if no_dupes else 0, 1 if no_ancestors else 0, 1 if only_sequence_names else 0, 1 if only_orthologs else 0,
+                     1 if keep_empty_ref_blocks else 0, 1 if unique else 0, max_block_len, max_ref_gap)
+    tg = (C.c_int32 * len(targets))(*targets) if targets else None
+    out, n, err = C.c_void_p(), C.c_size_t(), C.c_void_p()
+    if lib.hgx_maf_export_multi(hs, len(alignments), ref, ref_sequence, start, length, slice_size, C.byref(o), tg,
+                                len(targets) if targets else 0, C.byref(out), C.byref(n), C.byref(err)) != 0:
+        raise HgxError(take_error(err))
+    try:
+        return C.string_at(out, n.value).decode()
+    finally:
+        lib.hgx_free(out)
+
+
 def liftover_convert_bytes(alignment, src_genome, data, tgt_genome, bed_type=0, traverse_dupes=True, count_lines=True):
     """hgx_liftover_convert on BED bytes, the output left in library memory and released: (bytes, lines) of it (benchmark use:
     no decoding of a hundred megabytes of text in Python)."""

@@ -778,6 +778,74 @@ int hgx_alignment_depth(hgx_alignment *h, int ref, int ref_sequence, int64_t sta
 
 static void configureMaf(MafExport &me, const hgx_maf_opts *o, const GenomeTables *G);
 
+// clones of handles[0] (the same host image), as hgx_liftover_convert_multi asks for
+static std::vector<hgx_alignment *> cloneList(hgx_alignment *const *handles, int n_handles, const char *who) {
+    if (!handles || n_handles < 1 || !handles[0])
+        throw std::runtime_error(std::string(who) + ": no handles");
+    std::vector<hgx_alignment *> hs;
+    for (int i = 0; i < n_handles; ++i) {
+        if (!handles[i] || handles[i]->imgHolder.get() != handles[0]->imgHolder.get())
+            throw std::runtime_error(std::string(who) + ": every handle must be a device clone of the first (hgx_clone_to_device)");
+        hs.push_back(handles[i]);
+    }
+    return hs;
+}
+
+int hgx_alignment_depth_multi(hgx_alignment *const *handles, int n_handles, int ref, int ref_sequence, int64_t start, int64_t length,
+                              int64_t step, int count_dupes, int no_ancestors, const int32_t *targets, int32_t n_targets, char **out_text,
+                              size_t *out_len, char **err) {
+    HGX_TRY
+    if (!out_text || !out_len)
+        throw std::runtime_error("hgx_alignment_depth_multi: null argument");
+    std::vector<hgx_alignment *> hs = cloneList(handles, n_handles, "hgx_alignment_depth_multi");
+    hgx_alignment *h = hs[0];
+    const GenomeTables *G = genomeOf(h, ref);
+    if (!G || ref_sequence >= (int)G->seqs.size())
+        throw std::runtime_error("hgx_alignment_depth_multi: genome or sequence out of range");
+    if (!G->children.empty() && no_ancestors)
+        throw std::runtime_error("--noAncestors cannot be used when reference genome (" + G->name + ") is ancetral");
+    std::set<int> tset(targets, targets + (targets ? n_targets : 0));
+    std::vector<hgx_alignment *> more(hs.begin() + 1, hs.end());
+    TextOut T;
+    std::ostream &os = T.os;
+    alignmentDepth(os, h, ref, ref_sequence, tset, start, length, step, count_dupes != 0, no_ancestors != 0, nullptr, &more);
+    return T.finish(out_text, out_len);
+    HGX_CATCH
+}
+
+int hgx_maf_export_multi(hgx_alignment *const *handles, int n_handles, int ref, int ref_sequence, int64_t start, int64_t length,
+                         int64_t slice_size, const hgx_maf_opts *o, const int32_t *targets, int32_t n_targets, char **out_text,
+                         size_t *out_len, char **err) {
+    HGX_TRY
+    if (!out_text || !out_len)
+        throw std::runtime_error("hgx_maf_export_multi: null argument");
+    std::vector<hgx_alignment *> hs = cloneList(handles, n_handles, "hgx_maf_export_multi");
+    const GenomeTables *G = genomeOf(hs[0], ref);
+    if (!G || ref_sequence >= (int)G->seqs.size())
+        throw std::runtime_error("hgx_maf_export_multi: genome or sequence out of range");
+    MafExportSettings cfg;
+    if (o) {
+        cfg.noDupes = o->no_dupes != 0;
+        cfg.noAncestors = o->no_ancestors != 0;
+        cfg.ucscNames = o->only_sequence_names == 0;
+        cfg.onlyOrthologs = o->only_orthologs != 0;
+        cfg.keepEmptyRefBlocks = o->keep_empty_ref_blocks != 0;
+        cfg.unique = o->unique != 0;
+        cfg.maxBlockLength = o->max_block_len == 0 ? 1000 : o->max_block_len;
+        cfg.maxRefGap = o->max_ref_gap < 0 ? 0 : o->max_ref_gap;
+        if (o->no_ancestors && !G->children.empty())
+            throw std::runtime_error("Since the reference genome to be used for the MAF is ancestral (" + G->name +
+                                     "), the --noAncestors option is invalid.  The --refGenome option can be used to specify a "
+                                     "different reference.");
+    }
+    std::set<int> tset(targets, targets + (targets ? n_targets : 0));
+    TextOut T;
+    std::ostream &os = T.os;
+    mafExportSliced(os, hs, ref, ref_sequence, start, length, slice_size, cfg, tset);
+    return T.finish(out_text, out_len);
+    HGX_CATCH
+}
+
 int hgx_maf_export_bed(hgx_alignment *h, int ref, const char *bed_text, size_t bed_len, const hgx_maf_opts *o, const int32_t *targets,
                        int32_t n_targets, char **out_text, size_t *out_len, char **err) {
     HGX_TRY

@@ -2,6 +2,8 @@
 #include "hgx_liftover_host.hpp"
 #include <iostream>
 #include <algorithm>
+#include <atomic>
+#include <sstream>
 #include <chrono>
 #include <climits>
 #include <cstdlib>
@@ -15,7 +17,8 @@ namespace hgx {
 // ---------------------------------------------------------------------------------------------
 // halAlignmentDepth
 static void depthSequence(std::ostream &os, hgx_alignment *h, int genome, int seqIdx, const std::set<int> &targetSet, int64_t start,
-                          int64_t length, int64_t step, bool countDupes, bool noAncestors, ColumnStats *stats) {
+                          int64_t length, int64_t step, bool countDupes, bool noAncestors, ColumnStats *stats,
+                          const std::vector<hgx_alignment *> *moreDevices) {
     // printSequence, alignmentDepth/halAlignmentDepth.cpp:215-308
     const GenomeTables &G = h->img.genomes[(size_t)genome];
     const SeqInfo &S = G.seqs[(size_t)seqIdx];
@@ -53,7 +56,35 @@ static void depthSequence(std::ostream &os, hgx_alignment *h, int genome, int se
     opt.noAncestors = noAncestors;
     opt.targets.assign(targetSet.begin(), targetSet.end());
     std::vector<int32_t> vals((size_t)count);
-    columnsDepthHost(h, genome, start + S.start, count, step, countDupes ? 1 : 0, opt, vals.data(), stats);
+    if (moreDevices && !moreDevices->empty() && count >= 2) {
+        // columns are independent (api/impl/halColumnIterator.cpp:785-787): contiguous shares of the sampled columns, one per
+        // device clone, scanned at the same time; the values land in their place of the one array
+        std::vector<hgx_alignment *> hs{h};
+        hs.insert(hs.end(), moreDevices->begin(), moreDevices->end());
+        const int64_t nd = (int64_t)hs.size();
+        std::vector<std::string> errors((size_t)nd);
+        std::vector<std::thread> pool;
+        for (int64_t d = 0; d < nd; ++d) {
+            const int64_t lo = count * d / nd, hi = count * (d + 1) / nd;
+            if (hi <= lo)
+                continue;
+            pool.emplace_back([&, d, lo, hi]() {
+                try {
+                    columnsDepthHost(hs[(size_t)d], genome, start + S.start + lo * step, hi - lo, step, countDupes ? 1 : 0, opt, vals.data() + lo,
+                                     nullptr);
+                } catch (std::exception &e) {
+                    errors[(size_t)d] = e.what();
+                }
+            });
+        }
+        for (std::thread &t : pool)
+            t.join();
+        for (const std::string &e : errors)
+            if (!e.empty())
+                throw std::runtime_error(e);
+    } else {
+        columnsDepthHost(h, genome, start + S.start, count, step, countDupes ? 1 : 0, opt, vals.data(), stats);
+    }
     std::string buf;
     buf.reserve((size_t)count * 3);
     char tmp[16];
@@ -65,11 +96,12 @@ static void depthSequence(std::ostream &os, hgx_alignment *h, int genome, int se
 }
 
 void alignmentDepth(std::ostream &os, hgx_alignment *h, int genome, int sequence, const std::set<int> &targetSet, int64_t start,
-                    int64_t length, int64_t step, bool countDupes, bool noAncestors, ColumnStats *stats) {
+                    int64_t length, int64_t step, bool countDupes, bool noAncestors, ColumnStats *stats,
+                    const std::vector<hgx_alignment *> *moreDevices) {
     // printGenome, :318-347
     const GenomeTables &G = h->img.genomes[(size_t)genome];
     if (sequence >= 0) {
-        depthSequence(os, h, genome, sequence, targetSet, start, length, step, countDupes, noAncestors, stats);
+        depthSequence(os, h, genome, sequence, targetSet, start, length, step, countDupes, noAncestors, stats, moreDevices);
         return;
     }
     if (start + length > G.totalLength)
@@ -84,7 +116,7 @@ void alignmentDepth(std::ostream &os, hgx_alignment *h, int genome, int sequence
             const int64_t readStart = S.start >= start ? 0 : start - S.start;
             int64_t readLen = std::min(S.length - readStart, length);
             readLen = std::min(readLen, length - runningLength);
-            depthSequence(os, h, genome, (int)s, targetSet, readStart, readLen, step, countDupes, noAncestors, stats);
+            depthSequence(os, h, genome, (int)s, targetSet, readStart, readLen, step, countDupes, noAncestors, stats, moreDevices);
             runningLength += readLen;
         }
     }
@@ -635,6 +667,11 @@ void MafExport::convertSequence(std::ostream &mafStream, hgx_alignment *alignmen
             }
             ++index;
         } while (brk);
+        // "clean stack again" (:125-130): the index moves on to the next base not visited yet before the caller asks
+        // lastColumn() — a range whose last bases were all seen in earlier columns ends here, not with one more column
+        if (_unique)
+            while (cacheFind(index) && index <= last)
+                ++index;
     };
     auto canonicalOnRef = [&]() { return leftmostRefPos >= first && leftmostRefPos <= last; }; // :210-214
 
@@ -1131,6 +1168,84 @@ void MafExport::convertSequenceGapped(std::ostream &mafStream, hgx_alignment *al
         printBlock(mafStream);
         mafStream << std::endl;
     }
+}
+
+// hal2mafMP.py (maf/hal2mafMP.py:63-79 computeSlices, :176-190 concatenateSlices) with devices in the place of processes
+void mafExportSliced(std::ostream &os, const std::vector<hgx_alignment *> &handles, int genome, int sequence, int64_t start, int64_t length,
+                     int64_t sliceSize, const MafExportSettings &cfg, const std::set<int> &targets) {
+    if (handles.empty())
+        throw std::runtime_error("mafExportSliced: no handles");
+    const GenomeTables &G = handles[0]->img.genomes[(size_t)genome];
+    struct Slice {
+        int seq;
+        int64_t start, length;
+        std::string text, error;
+    };
+    std::vector<Slice> slices;
+    for (int s = 0; s < (int)G.seqs.size(); ++s) {
+        if (sequence >= 0 && s != sequence)
+            continue;
+        const int64_t seqLen = G.seqs[(size_t)s].length;
+        if (seqLen == 0 && sequence < 0)
+            continue; // (hal2maf.cpp:200-205 skips nothing, but a zero-length sequence cannot be converted: halMafExport.cpp:35-37)
+        if (start >= seqLen || start + length > seqLen)
+            throw std::runtime_error("Invalid range specified for convertGenome");
+        const int64_t inLength = length < 1 ? seqLen - start : length;
+        int64_t size = sliceSize > 0 ? sliceSize : (inLength + (int64_t)handles.size() - 1) / (int64_t)handles.size();
+        if (size < 1 || size >= inLength) {
+            slices.push_back(Slice{s, start, inLength, "", ""});
+            continue;
+        }
+        for (int64_t i = 0; i < inLength / size; ++i)
+            slices.push_back(Slice{s, start + i * size, size, "", ""});
+        if (inLength % size > 0)
+            slices.push_back(Slice{s, start + (inLength / size) * size, inLength % size, "", ""});
+    }
+    std::atomic<size_t> next{0};
+    auto work = [&](hgx_alignment *h) {
+        for (size_t i; (i = next.fetch_add(1)) < slices.size();) {
+            Slice &sl = slices[i];
+            try {
+                MafExport me;
+                me.setNoDupes(cfg.noDupes);
+                me.setNoAncestors(cfg.noAncestors);
+                me.setUcscNames(cfg.ucscNames);
+                me.setOnlyOrthologs(cfg.onlyOrthologs);
+                me.setKeepEmptyRefBlocks(cfg.keepEmptyRefBlocks);
+                me.setUnique(cfg.unique);
+                me.setMaxBlockLength(cfg.maxBlockLength);
+                me.setMaxRefGap(cfg.maxRefGap);
+                std::ostringstream text;
+                me.convertSequence(text, h, genome, sl.seq, sl.start, sl.length, targets);
+                sl.text = text.str();
+                if (i != 0) { // concatenateSlices (hal2mafMP.py:176-190): of every slice but the first the lines that start with '#' are dropped
+                    std::string kept;
+                    kept.reserve(sl.text.size());
+                    for (size_t a = 0; a < sl.text.size();) {
+                        size_t b = sl.text.find('\n', a);
+                        b = b == std::string::npos ? sl.text.size() : b + 1;
+                        if (sl.text[a] != '#')
+                            kept.append(sl.text, a, b - a);
+                        a = b;
+                    }
+                    sl.text.swap(kept);
+                }
+            } catch (std::exception &e) {
+                sl.error = e.what();
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (size_t d = 1; d < handles.size(); ++d)
+        pool.emplace_back(work, handles[d]);
+    work(handles[0]);
+    for (std::thread &t : pool)
+        t.join();
+    for (const Slice &sl : slices)
+        if (!sl.error.empty())
+            throw std::runtime_error(sl.error);
+    for (const Slice &sl : slices)
+        os.write(sl.text.data(), (std::streamsize)sl.text.size());
 }
 
 // maf/impl/halMafBed.cpp:24-52 driven by BedScanner::scan (liftover/impl/halBedScanner.cpp:40-61)

@@ -14,7 +14,18 @@ namespace hgx {
 
 // halAlignmentDepth: writes the wig text of printGenome.  sequence = -1: all sequences of the genome.
 void alignmentDepth(std::ostream &os, hgx_alignment *h, int genome, int sequence, const std::set<int> &targetSet, int64_t start,
-                    int64_t length, int64_t step, bool countDupes, bool noAncestors, ColumnStats *stats = nullptr);
+                    int64_t length, int64_t step, bool countDupes, bool noAncestors, ColumnStats *stats = nullptr,
+                    const std::vector<hgx_alignment *> *moreDevices = nullptr);
+// hal2mafMP.py's slicing (maf/hal2mafMP.py:63-79, 176-190): the range of every reference sequence cut into slices of sliceSize
+// columns (0: the range divided evenly over the handles), every slice an export of its own, the texts put together in order
+// with the header of the first only.  handles: device clones of one alignment (hgx_clone_to_device); the slices are dealt to
+// them as they become free, one host thread per handle.
+struct MafExportSettings {
+    bool noDupes = false, noAncestors = false, ucscNames = true, onlyOrthologs = false, keepEmptyRefBlocks = false, unique = false;
+    int64_t maxBlockLength = 1000, maxRefGap = 0;
+};
+void mafExportSliced(std::ostream &os, const std::vector<hgx_alignment *> &handles, int genome, int sequence, int64_t start, int64_t length,
+                     int64_t sliceSize, const MafExportSettings &cfg, const std::set<int> &targets);
 
 class MafExport {
   public:

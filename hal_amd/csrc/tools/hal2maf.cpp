@@ -21,7 +21,8 @@ static std::vector<std::string> chop(const std::string &s, char sep) {
 int main(int argc, char **argv) {
     std::vector<std::string> pos;
     std::string refGenomeName, refSequenceName, rootGenomeName, targetGenomes, refTargetsPath;
-    int64_t start = 0, length = 0, maxBlockLen = 1000, maxRefGap = 0;
+    int64_t start = 0, length = 0, maxBlockLen = 1000, maxRefGap = 0, sliceSize = 0;
+    std::vector<int> devices; // --gpus n / --devices a,b,...: hal2mafMP.py's slices, dealt to these devices (one process)
     bool noDupes = false, noAncestors = false, onlySequenceNames = false, unique = false, append = false, onlyOrthologs = false,
          keepEmptyRefBlocks = false;
     int device = 0;
@@ -42,6 +43,20 @@ int main(int argc, char **argv) {
             else if (a == "--maxBlockLen") maxBlockLen = atoll(val().c_str());
             else if (a == "--maxRefGap") maxRefGap = atoll(val().c_str());
             else if (a == "--device") device = atoi(val().c_str());
+            else if (a == "--sliceSize") sliceSize = atoll(val().c_str()); // hal2mafMP.py --sliceSize
+            else if (a == "--gpus") {
+                const int n = atoi(val().c_str());
+                if (n < 1) throw std::runtime_error("--gpus must be at least 1");
+                for (int d = 0; d < n; ++d) devices.push_back(d);
+            } else if (a == "--devices") {
+                const std::string list = val();
+                for (size_t at = 0; at < list.size();) {
+                    const size_t comma = list.find(',', at);
+                    devices.push_back(atoi(list.substr(at, comma == std::string::npos ? std::string::npos : comma - at).c_str()));
+                    if (comma == std::string::npos) break;
+                    at = comma + 1;
+                }
+            }
             else if (a == "--noDupes") noDupes = true;
             else if (a == "--noAncestors") noAncestors = true;
             else if (a == "--onlySequenceNames") onlySequenceNames = true;
@@ -62,13 +77,25 @@ int main(int argc, char **argv) {
         return 1;
     }
     hgx_alignment *h = nullptr;
+    std::vector<hgx_alignment *> clones;
     int rc = 0;
     try {
         char *err = nullptr;
+        if (!devices.empty())
+            device = devices[0];
         if (hgx_open(pos[0].c_str(), device, &h, &err) != HGX_OK) {
             std::string m = err ? err : "open failed";
             hgx_free(err);
             throw std::runtime_error(m);
+        }
+        for (size_t d = 1; d < devices.size(); ++d) {
+            hgx_alignment *c = nullptr;
+            if (hgx_clone_to_device(h, devices[d], &c, &err) != HGX_OK) {
+                std::string m = err ? err : "clone failed";
+                hgx_free(err);
+                throw std::runtime_error(m);
+            }
+            clones.push_back(c);
         }
         if (hgx_num_genomes(h) == 0)
             throw std::runtime_error("hal alignment is empty");
@@ -142,6 +169,19 @@ int main(int argc, char **argv) {
                     throw std::runtime_error("Error opening " + refTargetsPath);
             }
             me.convertBed(mafStream, h, ref, refTargetsPath != "stdin" ? bedFile : std::cin, targetSet);
+        } else if (devices.size() > 1 || sliceSize > 0) { // hal2mafMP.py's way: slices of the reference, one export each, put together in order
+            std::vector<hgx_alignment *> hs{h};
+            hs.insert(hs.end(), clones.begin(), clones.end());
+            hgx::MafExportSettings cfg;
+            cfg.noDupes = noDupes;
+            cfg.noAncestors = noAncestors;
+            cfg.ucscNames = !onlySequenceNames;
+            cfg.onlyOrthologs = onlyOrthologs;
+            cfg.keepEmptyRefBlocks = keepEmptyRefBlocks;
+            cfg.unique = unique;
+            cfg.maxBlockLength = maxBlockLen;
+            cfg.maxRefGap = maxRefGap;
+            hgx::mafExportSliced(mafStream, hs, ref, refSeq, start, length, sliceSize, cfg, targetSet);
         } else if (refSeq >= 0) {
             me.convertSequence(mafStream, h, ref, refSeq, start, length, targetSet);
         } else {
@@ -152,6 +192,8 @@ int main(int argc, char **argv) {
         std::cerr << "hal exception caught: " << e.what() << std::endl;
         rc = 1;
     }
+    for (hgx_alignment *c : clones)
+        hgx_close(c);
     hgx_close(h);
     return rc;
 }

@@ -11,6 +11,7 @@ int main(int argc, char **argv) {
     int64_t start = 0, length = 0, step = 1;
     bool countDupes = false, noAncestors = false;
     int device = 0;
+    std::vector<int> devices; // --gpus n / --devices a,b,...
     try {
         for (int i = 1; i < argc; ++i) {
             std::string a = argv[i];
@@ -27,6 +28,19 @@ int main(int argc, char **argv) {
             else if (a == "--length") length = atoll(val().c_str());
             else if (a == "--step") step = atoll(val().c_str());
             else if (a == "--device") device = atoi(val().c_str());
+            else if (a == "--gpus") { // the scan shared out over the first n devices (one process; hgx_alignment_depth_multi's way)
+                const int n = atoi(val().c_str());
+                if (n < 1) throw std::runtime_error("--gpus must be at least 1");
+                for (int d = 0; d < n; ++d) devices.push_back(d);
+            } else if (a == "--devices") {
+                const std::string list = val();
+                for (size_t at = 0; at < list.size();) {
+                    const size_t comma = list.find(',', at);
+                    devices.push_back(atoi(list.substr(at, comma == std::string::npos ? std::string::npos : comma - at).c_str()));
+                    if (comma == std::string::npos) break;
+                    at = comma + 1;
+                }
+            }
             else if (a == "--countDupes") countDupes = true;
             else if (a == "--noAncestors") noAncestors = true;
             else if (a.rfind("--", 0) == 0) throw std::runtime_error("unknown option " + a);
@@ -41,13 +55,25 @@ int main(int argc, char **argv) {
         return 1;
     }
     hgx_alignment *h = nullptr;
+    std::vector<hgx_alignment *> clones;
     int rc = 0;
     try {
         char *err = nullptr;
+        if (!devices.empty())
+            device = devices[0];
         if (hgx_open(pos[0].c_str(), device, &h, &err) != HGX_OK) {
             std::string m = err ? err : "open failed";
             hgx_free(err);
             throw std::runtime_error(m);
+        }
+        for (size_t d = 1; d < devices.size(); ++d) { // the image once in host memory, its tables on every device
+            hgx_alignment *c = nullptr;
+            if (hgx_clone_to_device(h, devices[d], &c, &err) != HGX_OK) {
+                std::string m = err ? err : "clone failed";
+                hgx_free(err);
+                throw std::runtime_error(m);
+            }
+            clones.push_back(c);
         }
         if (hgx_num_genomes(h) == 0)
             throw std::runtime_error("input hal alignmenet is empty");
@@ -99,11 +125,13 @@ int main(int argc, char **argv) {
                 throw std::runtime_error("Error opening output file " + wigPath);
         }
         std::ostream &out = wigPath == "stdout" ? std::cout : ofile;
-        hgx::alignmentDepth(out, h, ref, refSeq, targetSet, start, length, step, countDupes, noAncestors);
+        hgx::alignmentDepth(out, h, ref, refSeq, targetSet, start, length, step, countDupes, noAncestors, nullptr, clones.empty() ? nullptr : &clones);
     } catch (std::exception &e) {
         std::cerr << "hal exception caught: " << e.what() << std::endl;
         rc = 1;
     }
+    for (hgx_alignment *c : clones)
+        hgx_close(c);
     hgx_close(h);
     return rc;
 }

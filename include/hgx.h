@@ -360,6 +360,21 @@ int hgx_maf_export(hgx_alignment *h, int ref_genome, int ref_sequence, int64_t s
 int hgx_maf_export_bed(hgx_alignment *h, int ref_genome, const char *bed_text, size_t bed_len, const hgx_maf_opts *opts,
                        const int32_t *targets, int32_t n_targets, char **out_text, size_t *out_len, char **err);
 
+/* The column tools over several handles of one alignment (hgx_clone_to_device), one per GPU of this process — columns are
+ * independent (api/impl/halColumnIterator.cpp:785-787), so contiguous ranges of the reference scan at the same time:
+ * hgx_alignment_depth_multi: the sampled columns of every sequence in contiguous shares, one per device; the wig text is the
+ *   one hgx_alignment_depth writes (BASELINE config 5: the whole-genome depth scan on 8 GPUs);
+ * hgx_maf_export_multi: the reference's own way of running hal2maf in parallel (maf/hal2mafMP.py:63-79, 176-190): every
+ *   sequence's range cut into slices of slice_size columns (0: the range divided evenly over the handles), every slice an export
+ *   of its own — blocks end at slice edges, as they do in hal2mafMP's output — dealt to the devices as they become free, the
+ *   texts put together in input order with the header of the first slice only. */
+int hgx_alignment_depth_multi(hgx_alignment *const *handles, int n_handles, int ref_genome, int ref_sequence, int64_t start,
+                              int64_t length, int64_t step, int count_dupes, int no_ancestors, const int32_t *targets, int32_t n_targets,
+                              char **out_text, size_t *out_len, char **err);
+int hgx_maf_export_multi(hgx_alignment *const *handles, int n_handles, int ref_genome, int ref_sequence, int64_t start, int64_t length,
+                         int64_t slice_size, const hgx_maf_opts *opts, const int32_t *targets, int32_t n_targets, char **out_text,
+                         size_t *out_len, char **err);
+
 /* ---- synthetic workloads: halRandGen (randgen/halRandGen.cpp) ---- */
 typedef struct hgx_rand_opts {
     double mean_degree, max_branch_length;

@@ -225,3 +225,46 @@ def test_depth_by_tree_sweeps_vs_walk_and_oracle(hal, oracle_bin, tmp_path, seed
             assert al.alignment_depth(g, no_ancestors=True) == _oracle(oracle_bin, "depth", img, tmp_path, name, "--noAncestors"), name
         assert al.alignment_depth(g, 0, start=7, length=n // 2, step=3) == \
             _oracle(oracle_bin, "depth", img, tmp_path, name, "--refSequence", al.sequences(g)[0][0], "--start", "7", "--length", str(n // 2), "--step", "3")
+
+
+def test_column_tools_over_device_clones(hal, oracle_bin, tmp_path):
+    """hgx_alignment_depth_multi / hgx_maf_export_multi over three handles of one alignment (clones on the test box's one GPU: the
+    sharing out, the threads and the collation are the code that runs with three GPUs): the depth text is the single handle's, the
+    sliced MAF is the expected file of the reference's own sliced runner (hal2mafMP.py, 250-base slices of Genome_0_seq with
+    --unique, maf/Makefile:70-72), and the CLI twins take --devices."""
+    from test_oracle_golden import _mp_slices
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_maf")
+    al = hal.Alignment.random(hal.RandOptions.preset("small", seed=0), device=0)
+    clones = [al, al.clone_to_device(0), al.clone_to_device(0)]
+    g0 = al.genome_id("Genome_0")
+    name, _, ln = al.sequences(g0)[0]
+    want = open(os.path.join(gold, "hal2mafMPBySeqTest_Genome_0_seq.maf")).read()
+    assert hal.maf_export_multi(clones, g0, 0, slice_size=250, unique=True) == want
+    assert hal.maf_export_multi(clones[:1], g0, 0, slice_size=250, unique=True) == want
+    # slice size 0: the range divided evenly over the handles, like hal2mafMP's default (ceil(length / numProc))
+    size = -(-ln // 3)
+    assert hal.maf_export_multi(clones, g0, 0) == _mp_slices(lambda s, l: al.maf_export(g0, 0, start=s, length=l), name, ln, size)
+    for g in range(al.num_genomes):
+        assert hal.alignment_depth_multi(clones, g) == al.alignment_depth(g)
+        leaf = not al.genome_children(g)
+        assert hal.alignment_depth_multi(clones, g, step=7, count_dupes=True, no_ancestors=leaf) == \
+            al.alignment_depth(g, step=7, count_dupes=True, no_ancestors=leaf)
+        sn, _, sl = al.sequences(g)[0]
+        assert hal.maf_export_multi(clones, g, 0, slice_size=97, no_dupes=True) == \
+            _mp_slices(lambda s, l: al.maf_export(g, 0, start=s, length=l, no_dupes=True), sn, sl, 97)
+    # a larger alignment: the shares of a whole-genome scan go through the tree sweeps or the walk as their sizes say
+    big, img = _rand(hal, tmp_path, 2, dna=False, min_segments=3000, max_segments=6000)
+    bclones = [big, big.clone_to_device(0)]
+    g9 = big.genome_id("Genome_9")
+    assert hal.alignment_depth_multi(bclones, g9) == big.alignment_depth(g9) == _oracle(oracle_bin, "depth", img, tmp_path, "Genome_9")
+    # CLI twins
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    small = str(tmp_path / "small.hgx")
+    al.save(small)
+    out = str(tmp_path / "d.wig")
+    subprocess.check_call([os.path.join(root, "hal_amd", "_build", "halAlignmentDepth"), "--devices", "0,0", "--outWiggle", out, small, "Genome_0"])
+    assert open(out).read() == al.alignment_depth(g0)
+    out = str(tmp_path / "m.maf")
+    subprocess.check_call([os.path.join(root, "hal_amd", "_build", "hal2maf"), "--devices", "0,0,0", "--sliceSize", "250", "--refGenome", "Genome_0",
+                           "--refSequence", name, "--unique", small, out])
+    assert open(out).read() == want
