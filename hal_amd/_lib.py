@@ -85,6 +85,7 @@ SYMBOLS = {
                                      P(P(hgx_record)), P(C.c_size_t), P(VP)]),
     "hgx_block_map": (C.c_int, [VP, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int, P(P(hgx_record)),
                                 P(C.c_size_t), P(VP)]),
+    "hgx_maf_export_global": (C.c_int, [VP, P(hgx_maf_opts), P(VP), P(C.c_size_t), P(VP)]),
     "hgx_alignment_depth_multi": (C.c_int, [P(VP), C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, P(C.c_int32), C.c_int32,
                                              P(VP), P(C.c_size_t), P(VP)]),
     "hgx_maf_export_multi": (C.c_int, [P(VP), C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, P(hgx_maf_opts), P(C.c_int32), C.c_int32,

@@ -308,6 +308,18 @@ class Alignment:
         lib.hgx_free(out)
         return n.value
 
+    def maf_export_global(self, no_dupes=False, no_ancestors=False, only_sequence_names=False, only_orthologs=False, max_block_len=1000):
+        """hal2maf --global (MafExport::convertEntireAlignment, maf/impl/halMafExport.cpp:90-153): every column of the alignment once"""
+        o = hgx_maf_opts(1 if no_dupes else 0, 1 if no_ancestors else 0, 1 if only_sequence_names else 0, 1 if only_orthologs else 0, 0, 0,
+                         max_block_len, 0)
+        out, n, err = C.c_void_p(), C.c_size_t(), C.c_void_p()
+        if lib.hgx_maf_export_global(self._h, C.byref(o), C.byref(out), C.byref(n), C.byref(err)) != 0:
+            raise HgxError(take_error(err))
+        try:
+            return C.string_at(out, n.value).decode()
+        finally:
+            lib.hgx_free(out)
+
     def maf_export(self, ref, ref_sequence=-1, start=0, length=0, no_dupes=False, no_ancestors=False, only_sequence_names=False,
                    only_orthologs=False, keep_empty_ref_blocks=False, max_block_len=1000, targets=None, unique=False,
                    ref_targets_bed=None, max_ref_gap=0):

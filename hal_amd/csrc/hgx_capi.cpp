@@ -778,6 +778,25 @@ int hgx_alignment_depth(hgx_alignment *h, int ref, int ref_sequence, int64_t sta
 
 static void configureMaf(MafExport &me, const hgx_maf_opts *o, const GenomeTables *G);
 
+int hgx_maf_export_global(hgx_alignment *h, const hgx_maf_opts *o, char **out_text, size_t *out_len, char **err) {
+    HGX_TRY
+    if (!h || !out_text || !out_len)
+        throw std::runtime_error("hgx_maf_export_global: null argument");
+    MafExport me;
+    if (o) {
+        me.setNoDupes(o->no_dupes != 0);
+        me.setNoAncestors(o->no_ancestors != 0);
+        me.setUcscNames(o->only_sequence_names == 0);
+        me.setOnlyOrthologs(o->only_orthologs != 0);
+        me.setMaxBlockLength(o->max_block_len == 0 ? 1000 : o->max_block_len);
+    }
+    TextOut T;
+    std::ostream &os = T.os;
+    me.convertEntireAlignment(os, h);
+    return T.finish(out_text, out_len);
+    HGX_CATCH
+}
+
 // clones of handles[0] (the same host image), as hgx_liftover_convert_multi asks for
 static std::vector<hgx_alignment *> cloneList(hgx_alignment *const *handles, int n_handles, const char *who) {
     if (!handles || n_handles < 1 || !handles[0])

@@ -1008,47 +1008,62 @@ struct GapColumns {
 
 } // namespace
 
-void MafExport::convertSequenceGapped(std::ostream &mafStream, hgx_alignment *alignment, int genome, int seq, int64_t first, int64_t last,
-                                      const ColumnOptions &opt) {
-    const GenomeTables &G = alignment->img.genomes[(size_t)genome];
-    GapColumns cols(alignment, genome, opt, _maxRefGap, &stats);
-    const int64_t gapChunk = (int64_t)std::min<size_t>(chunkColumns, (size_t)1 << 17); // (every visited base comes back: smaller chunks)
-    int64_t chunkFirst = 0, chunkCount = 0;
-
-    // ---- ColumnIterator state (halColumnIterator.h:140-165) ----
+// The ColumnIterator whose sequential state does not fit the device (maxInsertLength > 0, or a visit cache that looks at more
+// than the reference genome): api/impl/halColumnIterator.cpp:65-144 (toRight), :246-355 (recursiveUpdate) with :766-819
+// (colMapInsert), :357-405 (the indel handlers) over the columns GapColumns delivers.
+namespace {
+struct ReplayIterator {
+    hgx_alignment *al;
+    int genome;
+    const GenomeTables &G;
+    bool unique;
+    int64_t maxInsert;
+    GapColumns cols;
+    int64_t gapChunk, chunkFirst = 0, chunkCount = 0;
     StackEntry base;
-    base.g = genome;
-    base.firstIndex = base.index = first;
-    base.lastIndex = last;
     std::vector<StackEntry> upper, insertionStack, deletionStack;
-    std::map<int, PositionCache> visitCache;
-    ColumnMap colMap;
+    std::map<int, PositionCache> visitCache; // ColumnIterator::VisitCache
+    std::vector<const ColumnRowHost *> column; // the bases of the current column that pass colMapInsert's filters, in its order
     bool brk = false;
-    int64_t leftmostRefPos = first;
-    int refSeqIdx = seq, prevRefSeq = seq;
+    int64_t leftmostRefPos = 0;
+    int refSeqIdx = 0, prevRefSeq = 0;
     int64_t prevRefIndex = 0;
-    auto top = [&]() -> StackEntry & { return upper.empty() ? base : upper.back(); };
-    // nextFreeIndex (:749-764)
-    auto nextFreeIndex = [&]() {
+
+    ReplayIterator(hgx_alignment *a, int g, const ColumnOptions &opt, bool uniq, int64_t maxIns, size_t chunkColumns, ColumnStats *stats)
+        : al(a), genome(g), G(a->img.genomes[(size_t)g]), unique(uniq), maxInsert(maxIns), cols(a, g, opt, maxIns, stats),
+          gapChunk((int64_t)std::min<size_t>(chunkColumns, (size_t)1 << 17)) { // (every visited base comes back: smaller chunks)
+        base.g = g;
+    }
+    // the constructor's / toSite's part (:54-57, :146-165): the stack holds [first, last] of the reference, then the first column
+    void start(int64_t first, int64_t last) {
+        upper.clear();
+        insertionStack.clear();
+        deletionStack.clear();
+        base.firstIndex = base.index = first;
+        base.lastIndex = last;
+        base.reversed = false;
+        refSeqIdx = G.seqIndexBySite(first);
+        chunkFirst = chunkCount = 0;
+        toRight();
+    }
+    StackEntry &top() { return upper.empty() ? base : upper.back(); }
+    void nextFreeIndex() { // :749-764
         StackEntry &e = top();
-        if (_unique || !upper.empty()) {
+        if (unique || !upper.empty()) {
             auto it = visitCache.find(e.g);
             if (it != visitCache.end())
                 while (it->second.find(e.index) && e.index <= e.lastIndex)
                     ++e.index;
         }
-    };
-    // recursiveUpdate (:246-355) over the column the device walked: colMapInsert (:766-819) for every base in the walk's order,
-    // handleDeletion / handleInsertion (:357-405) for every range it met
-    auto recursiveUpdate = [&]() {
-        for (auto &kv : colMap)
-            kv.second.clear();
+    }
+    void recursiveUpdate() {
+        column.clear();
         brk = false;
         leftmostRefPos = base.index;
         const StackEntry e = top();
         if (upper.empty() && (e.index < chunkFirst || e.index >= chunkFirst + chunkCount)) {
             chunkFirst = e.index;
-            chunkCount = std::min<int64_t>(gapChunk, last - e.index + 1);
+            chunkCount = std::min<int64_t>(gapChunk, base.lastIndex - e.index + 1);
             cols.prefetch(chunkFirst, chunkCount);
         }
         const ColumnRowHost *r, *end;
@@ -1064,21 +1079,25 @@ void MafExport::convertSequenceGapped(std::ostream &mafStream, hgx_alignment *al
                     open &= ~(1ull << level);
                 // after the walk was abandoned only the deletion checks of the updateParent calls it was inside are still made
                 // (:585-589 is not guarded by _break)
-                if (brk && !pendingDeletion)
+                if (maxInsert <= 0 || (brk && !pendingDeletion))
                     continue;
-                const ColumnRowHost &tail = r[1];
-                const int64_t lo = r->pos, hi = tail.pos;
-                if (lo < 0 || hi < lo || hi >= alignment->img.genomes[(size_t)r->genome].totalLength)
+                const int64_t lo = r->pos, hi = r[1].pos;
+                if (lo < 0 || hi < lo || hi >= al->img.genomes[(size_t)r->genome].totalLength)
                     continue; // (getInsertedRange's range of a reversed iterator can leave the genome: undefined in the reference, left out)
-                if (hi - lo + 1 + e.cumulativeSize <= _maxRefGap)
+                if (hi - lo + 1 + e.cumulativeSize <= maxInsert)
                     pushEntry(kind == 2 ? deletionStack : insertionStack, r->genome, lo, hi, r->rev != 0);
                 continue;
             }
             if (brk)
                 continue;
+            // colMapInsert
             bool updateCache = r->genome == genome;
+            if (maxInsert == 0)
+                updateCache = updateCache && e.firstIndex < r->pos;
             for (size_t i = 0; i < upper.size() && !updateCache; ++i)
                 updateCache = r->genome == upper[i].g;
+            if (!unique && maxInsert == 0)
+                updateCache = false;
             bool found;
             if (updateCache) {
                 found = !visitCache[r->genome].insert(r->pos);
@@ -1087,7 +1106,7 @@ void MafExport::convertSequenceGapped(std::ostream &mafStream, hgx_alignment *al
                 found = it != visitCache.end() && it->second.find(r->pos);
             }
             if (!found && kind == 0)
-                colMap[keyOf(r->genome, r->pos)].push_back(r);
+                column.push_back(r);
             if (r->genome == genome)
                 leftmostRefPos = std::min(leftmostRefPos, r->pos);
             if (found) {
@@ -1097,9 +1116,8 @@ void MafExport::convertSequenceGapped(std::ostream &mafStream, hgx_alignment *al
             if ((r->_pad[0] & 8) && level >= 1 && level < 64)
                 open |= 1ull << level;
         }
-    };
-    // toRight (:65-144)
-    auto toRight = [&]() {
+    }
+    void toRight() { // :65-144
         prevRefSeq = refSeqIdx;
         prevRefIndex = base.index - G.seqs[(size_t)refSeqIdx].start;
         if (upper.empty() && !top().inBounds())
@@ -1132,39 +1150,131 @@ void MafExport::convertSequenceGapped(std::ostream &mafStream, hgx_alignment *al
             upper.pop_back();
             nextFreeIndex();
         }
-    };
-    auto lastColumn = [&]() { return upper.empty() && base.index > base.lastIndex; };                          // :167-169
-    auto canonicalOnRef = [&]() { return leftmostRefPos >= base.firstIndex && leftmostRefPos <= base.lastIndex; }; // :210-214
-    auto refKey = [&]() { return Key{_rank[(size_t)genome][(size_t)prevRefSeq], genome, prevRefSeq}; };
+    }
+    bool lastColumn() const { return upper.empty() && base.index > base.lastIndex; }                                    // :167-169
+    bool canonicalOnRef() const { return leftmostRefPos >= base.firstIndex && leftmostRefPos <= base.lastIndex; }       // :210-214
+};
+} // namespace
 
-    // ---- MafExport::convertSequence's loop (maf/impl/halMafExport.cpp:51-87) ----
+void MafExport::convertSequenceGapped(std::ostream &mafStream, hgx_alignment *alignment, int genome, int seq, int64_t first, int64_t last,
+                                      const ColumnOptions &opt) {
+    (void)seq;
+    ReplayIterator it(alignment, genome, opt, _unique, _maxRefGap, chunkColumns, &stats);
+    ColumnMap colMap; // keys persist between columns like ColumnIterator::_colMap (resetColMap only empties the vectors)
+    auto fill = [&]() {
+        for (auto &kv : colMap)
+            kv.second.clear();
+        for (const ColumnRowHost *r : it.column)
+            colMap[keyOf(r->genome, r->pos)].push_back(r);
+    };
+    auto refKey = [&]() { return Key{_rank[(size_t)genome][(size_t)it.prevRefSeq], genome, it.prevRefSeq}; };
+    // MafExport::convertSequence's loop (maf/impl/halMafExport.cpp:51-87)
     size_t appendCount = 0, numBlocks = 0;
-    toRight(); // the constructor's first step
-    if (!_unique || canonicalOnRef()) {
-        initBlock(colMap, refKey(), prevRefIndex);
+    it.start(first, last);
+    fill();
+    if (!_unique || it.canonicalOnRef()) {
+        initBlock(colMap, refKey(), it.prevRefIndex);
         appendColumn(colMap);
         ++appendCount;
     }
-    while (!lastColumn()) {
-        toRight();
-        if (!_unique || canonicalOnRef()) {
+    while (!it.lastColumn()) {
+        it.toRight();
+        fill();
+        if (!_unique || it.canonicalOnRef()) {
             if (appendCount == 0)
-                initBlock(colMap, refKey(), prevRefIndex);
+                initBlock(colMap, refKey(), it.prevRefIndex);
             if (!canAppendColumn(colMap)) {
                 if (numBlocks++ % 1000 == 0)
-                    for (auto it = colMap.begin(); it != colMap.end();)
-                        it = it->second.empty() ? colMap.erase(it) : std::next(it);
+                    for (auto k = colMap.begin(); k != colMap.end();)
+                        k = k->second.empty() ? colMap.erase(k) : std::next(k);
                 if (appendCount > 0 && (_keepEmptyRefBlocks || !referenceIsAllGaps())) {
                     printBlock(mafStream);
                     mafStream << '\n';
                 }
-                initBlock(colMap, refKey(), prevRefIndex);
+                initBlock(colMap, refKey(), it.prevRefIndex);
             }
             appendColumn(colMap);
             ++appendCount;
         }
     }
     if (appendCount > 0 && (_keepEmptyRefBlocks || !referenceIsAllGaps())) {
+        printBlock(mafStream);
+        mafStream << std::endl;
+    }
+}
+
+// hal2maf --global: MafExport::convertEntireAlignment (maf/impl/halMafExport.cpp:90-153) — every column of the alignment once: the
+// leaves in breadth-first order (getLeafGenomes, api/impl/halCommon.cpp:197-207), each walked over its whole genome by a --unique
+// iterator that is handed the visit cache of the leaves before it; a column with a base of an earlier leaf was written then.
+void MafExport::convertEntireAlignment(std::ostream &mafStream, hgx_alignment *alignment) {
+    if (_al != alignment) {
+        _al = alignment;
+        buildRanks();
+    }
+    const Image &img = alignment->img;
+    if (mafStream.tellp() <= std::streampos(0)) // writeHeader (:15-23), unconditionally here (:97)
+        mafStream << "##maf version=1 scoring=N/A\n"
+                  << "# hal " << img.newick << std::endl
+                  << std::endl;
+    std::vector<int> leaves; // Alignment::getLeafNamesBelow(root): breadth first, children in their order
+    {
+        std::deque<int> queue(1, img.root());
+        while (!queue.empty()) {
+            const int g = queue.front();
+            queue.pop_front();
+            if (img.genomes[(size_t)g].children.empty() && g != img.root())
+                leaves.push_back(g);
+            for (int c : img.genomes[(size_t)g].children)
+                queue.push_back(c);
+        }
+    }
+    ColumnOptions opt;
+    opt.noDupes = _noDupes;
+    opt.noAncestors = _noAncestors;
+    opt.onlyOrthologs = _onlyOrthologs;
+    std::map<int, PositionCache> visitCache;
+    ColumnMap colMap;
+    size_t appendCount = 0, numBlocks = 0;
+    for (int genome : leaves) {
+        const GenomeTables &G = img.genomes[(size_t)genome];
+        if (G.totalLength == 0)
+            continue;
+        ReplayIterator it(alignment, genome, opt, true, 0, chunkColumns, &stats);
+        // (the iterator's own first column, walked by its constructor before setVisitCache replaces its cache, leaves nothing behind)
+        it.visitCache.swap(visitCache);
+        it.start(0, G.totalLength - 1); // toSite(0, length - 1), :111-113
+        auto fill = [&]() {
+            for (auto &kv : colMap)
+                kv.second.clear();
+            for (const ColumnRowHost *r : it.column)
+                colMap[keyOf(r->genome, r->pos)].push_back(r);
+        };
+        auto refKey = [&]() { return Key{_rank[(size_t)genome][(size_t)it.prevRefSeq], genome, it.prevRefSeq}; };
+        for (;;) {
+            fill();
+            if (appendCount == 0)
+                initBlock(colMap, refKey(), it.prevRefIndex);
+            if (!canAppendColumn(colMap)) {
+                if (numBlocks++ % 1000 == 0)
+                    for (auto k = colMap.begin(); k != colMap.end();)
+                        k = k->second.empty() ? colMap.erase(k) : std::next(k);
+                if (appendCount > 0) {
+                    printBlock(mafStream);
+                    mafStream << '\n';
+                }
+                initBlock(colMap, refKey(), it.prevRefIndex);
+            }
+            appendColumn(colMap);
+            ++appendCount;
+            if (it.lastColumn())
+                break;
+            it.toRight();
+        }
+        for (auto &kv : colMap)
+            kv.second.clear(); // (the rows belong to the iterator that goes away)
+        visitCache.swap(it.visitCache);
+    }
+    if (appendCount > 0) {
         printBlock(mafStream);
         mafStream << std::endl;
     }

@@ -43,6 +43,8 @@ class MafExport {
     // maf/impl/halMafExport.cpp:25-88; positions are sequence-relative, length 0 = to the end
     void convertSequence(std::ostream &mafStream, hgx_alignment *alignment, int genome, int seq, int64_t startPosition, int64_t length,
                          const std::set<int> &targets);
+    // hal2maf --global: every column of the alignment once (maf/impl/halMafExport.cpp:90-153)
+    void convertEntireAlignment(std::ostream &mafStream, hgx_alignment *alignment);
     // hal2maf --refTargets: MafBed::visitLine (maf/impl/halMafBed.cpp:24-52) over a BED stream of reference intervals
     void convertBed(std::ostream &mafStream, hgx_alignment *alignment, int genome, std::istream &bedStream, const std::set<int> &targets);
     ~MafExport();

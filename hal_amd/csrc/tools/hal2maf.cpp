@@ -24,7 +24,7 @@ int main(int argc, char **argv) {
     int64_t start = 0, length = 0, maxBlockLen = 1000, maxRefGap = 0, sliceSize = 0;
     std::vector<int> devices; // --gpus n / --devices a,b,...: hal2mafMP.py's slices, dealt to these devices (one process)
     bool noDupes = false, noAncestors = false, onlySequenceNames = false, unique = false, append = false, onlyOrthologs = false,
-         keepEmptyRefBlocks = false;
+         keepEmptyRefBlocks = false, global = false;
     int device = 0;
     try {
         for (int i = 1; i < argc; ++i) {
@@ -65,7 +65,8 @@ int main(int argc, char **argv) {
             else if (a == "--onlyOrthologs") onlyOrthologs = true;
             else if (a == "--keepEmptyRefBlocks") keepEmptyRefBlocks = true;
             else if (a == "--refTargets") refTargetsPath = val();
-            else if (a == "--global" || a == "--printTree")
+            else if (a == "--global") global = true;
+            else if (a == "--printTree")
                 throw std::runtime_error(a + " is not built in this implementation");
             else if (a.rfind("--", 0) == 0) throw std::runtime_error("unknown option " + a);
             else pos.push_back(a);
@@ -131,7 +132,7 @@ int main(int argc, char **argv) {
                 if (hgx_genome_parent(h, g) < 0)
                     ref = g;
         }
-        if (noAncestors && hgx_genome_num_children(h, ref) != 0)
+        if (noAncestors && hgx_genome_num_children(h, ref) != 0 && !global) // hal2maf.cpp:154
             throw std::runtime_error(std::string("Since the reference genome to be used for the MAF is ancestral (") +
                                      hgx_genome_name(h, ref) + "), the --noAncestors option is invalid.  The --refGenome option can be "
                                      "used to specify a different reference.");
@@ -169,6 +170,8 @@ int main(int argc, char **argv) {
                     throw std::runtime_error("Error opening " + refTargetsPath);
             }
             me.convertBed(mafStream, h, ref, refTargetsPath != "stdin" ? bedFile : std::cin, targetSet);
+        } else if (global) { // hal2maf.cpp:198-199
+            me.convertEntireAlignment(mafStream, h);
         } else if (devices.size() > 1 || sliceSize > 0) { // hal2mafMP.py's way: slices of the reference, one export each, put together in order
             std::vector<hgx_alignment *> hs{h};
             hs.insert(hs.end(), clones.begin(), clones.end());

@@ -360,6 +360,11 @@ int hgx_maf_export(hgx_alignment *h, int ref_genome, int ref_sequence, int64_t s
 int hgx_maf_export_bed(hgx_alignment *h, int ref_genome, const char *bed_text, size_t bed_len, const hgx_maf_opts *opts,
                        const int32_t *targets, int32_t n_targets, char **out_text, size_t *out_len, char **err);
 
+/* hal2maf --global: MafExport::convertEntireAlignment (maf/impl/halMafExport.cpp:90-153) — every column of the alignment once, the
+ * leaves taken as the reference one after the other, each with the visit cache of the ones before it.  Of opts the fields that
+ * function reads: no_dupes, no_ancestors, only_sequence_names, only_orthologs, max_block_len. */
+int hgx_maf_export_global(hgx_alignment *h, const hgx_maf_opts *opts, char **out_text, size_t *out_len, char **err);
+
 /* The column tools over several handles of one alignment (hgx_clone_to_device), one per GPU of this process — columns are
  * independent (api/impl/halColumnIterator.cpp:785-787), so contiguous ranges of the reference scan at the same time:
  * hgx_alignment_depth_multi: the sampled columns of every sequence in contiguous shares, one per device; the wig text is the

@@ -1,5 +1,6 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY (see hal_oracle.hpp).
 #include "oracle_columns.hpp"
+#include <deque>
 #include <chrono>
 
 namespace orc {
@@ -840,6 +841,76 @@ void MafExport::convertSequence(std::ostream &os, const Alignment &al, int genom
         os << std::endl;
     }
     seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// halMafExport.cpp:90-153
+void MafExport::convertEntireAlignment(std::ostream &os, const Alignment &al) {
+    alp = &al;
+    size_t appendCount = 0, numBlocks = 0;
+    if (!headerWritten) {
+        os << "##maf version=1 scoring=N/A\n"
+           << "# hal " << al.newick << std::endl
+           << std::endl;
+        headerWritten = true;
+    }
+    // getLeafGenomes (api/impl/halCommon.cpp:197-207) over Alignment::getLeafNamesBelow (api/mmap_impl/mmapAlignment.h:155-171)
+    std::vector<int> leafGenomes;
+    {
+        std::deque<int> bfQueue;
+        bfQueue.push_front(al.root());
+        while (!bfQueue.empty()) {
+            const int current = bfQueue.back();
+            const std::vector<int> &children = al.genomes[(size_t)current].children;
+            if (children.empty() && current != al.root())
+                leafGenomes.push_back(current);
+            for (size_t i = 0; i < children.size(); ++i)
+                bfQueue.push_front(children[i]);
+            bfQueue.pop_back();
+        }
+    }
+    std::map<int, PositionCache> visitCache;
+    for (size_t i = 0; i < leafGenomes.size(); i++) {
+        const int genome = leafGenomes[i];
+        const Genome &G = al.genomes[(size_t)genome];
+        if (G.totalLength == 0)
+            continue;
+        ColumnIterator colIt(&al, genome, nullptr, 0, G.totalLength - 1, noDupes, noAncestors, onlyOrthologs, true, 0);
+        colIt.visitCache = visitCache; // setVisitCache: the iterator's own cache (its constructor's first column) is dropped
+        // toSite(0, length - 1) (halColumnIterator.cpp:146-165)
+        colIt.seqIdx = 0;
+        while (colIt.seqIdx + 1 < (int)G.seqs.size() && G.seqs[(size_t)colIt.seqIdx].length == 0)
+            ++colIt.seqIdx;
+        colIt.refSeqIdx = colIt.seqIdx;
+        colIt.upper.clear();
+        colIt.defragment();
+        colIt.firstIndex = colIt.index = 0;
+        colIt.lastIndex = G.totalLength - 1;
+        colIt.toRight();
+        for (;;) {
+            if (appendCount == 0)
+                initBlock(colIt);
+            if (!canAppendColumn(colIt)) {
+                if (numBlocks++ % 1000 == 0)
+                    colIt.defragment();
+                if (appendCount > 0) {
+                    printBlock(os);
+                    os << '\n';
+                }
+                initBlock(colIt);
+            }
+            appendColumn(colIt);
+            appendCount++;
+            ++numColumns;
+            if (colIt.lastColumn())
+                break;
+            colIt.toRight();
+        }
+        visitCache = colIt.visitCache;
+    }
+    if (appendCount > 0) {
+        printBlock(os);
+        os << std::endl;
+    }
 }
 
 } // namespace orc

@@ -165,6 +165,8 @@ struct MafExport {
     i64 maxRefGap = 0;         // MafExport::_maxRefGap = the column iterator's maxInsertLength (halMafExport.cpp:47)
     void convertSequence(std::ostream &os, const Alignment &al, int genome, int seq, i64 startPosition, i64 length,
                          const std::set<int> &targets);
+    // maf/impl/halMafExport.cpp:90-153 (hal2maf --global)
+    void convertEntireAlignment(std::ostream &os, const Alignment &al);
     size_t numColumns = 0;
     double seconds = 0;
 

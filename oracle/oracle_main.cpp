@@ -84,7 +84,7 @@ static int cmdColumns(bool maf, int argc, char **argv) {
     std::string refGenome, refSequence, targetGenomes, rootGenome, refTargets;
     i64 start = 0, length = 0, step = 1, maxBlockLen = 1000, maxRefGap = 0;
     bool countDupes = false, noAncestors = false, noDupes = false, onlySequenceNames = false, onlyOrthologs = false, stats = false,
-         unique = false;
+         unique = false, global = false;
     for (int i = 0; i < argc; ++i) {
         std::string a = argv[i];
         if (a == "--refGenome")
@@ -119,6 +119,8 @@ static int cmdColumns(bool maf, int argc, char **argv) {
             onlyOrthologs = true;
         else if (a == "--unique")
             unique = true;
+        else if (a == "--global")
+            global = true;
         else if (a == "--stats")
             stats = true;
         else
@@ -164,7 +166,7 @@ static int cmdColumns(bool maf, int argc, char **argv) {
             throw std::runtime_error("Reference sequence, " + refSequence + ", not found in reference genome");
         seq = (int)(s - al.genomes[(size_t)ref].seqs.data());
     }
-    if (noAncestors && !al.genomes[(size_t)ref].children.empty())
+    if (noAncestors && !al.genomes[(size_t)ref].children.empty() && !global) // hal2maf.cpp:154
         throw std::runtime_error("--noAncestors cannot be used when the reference genome is ancestral");
     std::ofstream out(maf ? pos[1] : pos[2]);
     std::ostringstream buf;
@@ -185,7 +187,9 @@ static int cmdColumns(bool maf, int argc, char **argv) {
         me.unique = unique;
         me.maxRefGap = maxRefGap;
         me.maxBlockLength = maxBlockLen <= 0 ? std::numeric_limits<i64>::max() : maxBlockLen;
-        if (!refTargets.empty()) {
+        if (global) { // hal2maf.cpp:198-199
+            me.convertEntireAlignment(buf, al);
+        } else if (!refTargets.empty()) {
             // MafBed::visitLine (maf/impl/halMafBed.cpp:24-52) over BedScanner::scan
             std::ifstream bedIn(refTargets);
             BedLine bedLine;

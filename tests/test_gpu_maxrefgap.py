@@ -107,3 +107,24 @@ def test_real_data_and_cli(hal, oracle_bin, tmp_path):
     subprocess.check_call([tool, "--refGenome", "simMouse_chr6", "--refSequence", name, "--start", "0", "--length", str(n), "--maxRefGap", "100",
                            "--noAncestors", img, out])
     assert open(out).read() == want
+
+
+def test_global_export_against_the_oracle(hal, oracle_bin, tmp_path):
+    """hal2maf --global (MafExport::convertEntireAlignment, maf/impl/halMafExport.cpp:90-153): the leaves one after the other, each
+    with the visit cache of the ones before; the replay over the device's unfiltered columns gives the oracle's bytes (the reference
+    holds no expected file for this option: oracle only)."""
+    import subprocess as sp
+    al, img = _rand(hal, tmp_path, 2)
+    assert al.maf_export_global() == _oracle(oracle_bin, "maf", img, tmp_path, "--global")
+    assert al.maf_export_global(no_ancestors=True, no_dupes=True) == _oracle(oracle_bin, "maf", img, tmp_path, "--global", "--noAncestors", "--noDupes")
+    for seed in (0, 4):
+        img2 = str(tmp_path / ("g%d.hgx" % seed))
+        halfix.write_hgx(img2, halfix.random_multiseq_alignment(seed, n_genomes=7))
+        al2 = hal.Alignment.open(img2, device=0)
+        assert al2.maf_export_global() == _oracle(oracle_bin, "maf", img2, tmp_path, "--global"), seed
+        assert al2.maf_export_global(no_ancestors=True, only_sequence_names=True, max_block_len=20) == \
+            _oracle(oracle_bin, "maf", img2, tmp_path, "--global", "--noAncestors", "--onlySequenceNames", "--maxBlockLen", "20"), seed
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hal_amd", "_build", "hal2maf")
+    out = str(tmp_path / "cli_global.maf")
+    sp.check_call([tool, "--global", "--noAncestors", img, out])
+    assert open(out).read() == _oracle(oracle_bin, "maf", img, tmp_path, "--global", "--noAncestors")
