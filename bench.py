@@ -104,14 +104,17 @@ def kernel_sources_sha16():
     import hashlib
     h = hashlib.sha256()
     for path in sorted(glob.glob(os.path.join(ROOT, "hal_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "hal_amd", "csrc", "*.hpp"))):
-        h.update(os.path.basename(path).encode())
         with open(path, "rb") as f:
-            h.update(f.read())
+            text = f.read()
+        if path.endswith(".hpp") and b"__global__" not in text and b"__device__" not in text:
+            continue  # a host-side header
+        h.update(os.path.basename(path).encode())
+        h.update(text)
     return h.hexdigest()[:16]
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the PMC passes of profiles/scripts/r02_pmc.sh (profiles/pmc_traffic.json), or
+    """HBM bytes per launch of `kernel` from the PMC passes of profiles/scripts/r03_pmc.py (profiles/pmc_traffic.json), or
     None when the file was made with other device code than the one running (the file records the hash of the library and of
     the device sources it was built from; either one matching will do: a host-only change rebuilds the library without touching
     a kernel)."""
@@ -121,7 +124,7 @@ def pmc_traffic(kernel):
     except Exception:
         return None, "no profiles/pmc_traffic.json"
     if d.get("libhgx_sha16") != lib_sha16() and d.get("kernel_sources_sha16") != kernel_sources_sha16():
-        return None, "profiles/pmc_traffic.json was measured on other device code (library %s); rerun profiles/scripts/r02_pmc.py" % d.get("libhgx_sha16")
+        return None, "profiles/pmc_traffic.json was measured on other device code (library %s); rerun profiles/scripts/r03_pmc.py" % d.get("libhgx_sha16")
     return d.get("kernels", {}).get(kernel), d.get("source", "")
 
 

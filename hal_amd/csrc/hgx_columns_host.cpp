@@ -1024,6 +1024,10 @@ struct ReplayIterator {
     std::vector<StackEntry> upper, insertionStack, deletionStack;
     std::map<int, PositionCache> visitCache; // ColumnIterator::VisitCache
     std::vector<const ColumnRowHost *> column; // the bases of the current column that pass colMapInsert's filters, in its order
+    // every base colMapInsert put into the column map since the caller last looked, the ones of abandoned walks included: their
+    // sequences stay behind as (empty) keys of the map (resetColMap, :821-825, only empties the sets), and MafBlock::initBlock gives
+    // every key an entry
+    std::vector<std::pair<int, int64_t>> inserted;
     bool brk = false;
     int64_t leftmostRefPos = 0;
     int refSeqIdx = 0, prevRefSeq = 0;
@@ -1043,7 +1047,6 @@ struct ReplayIterator {
         base.lastIndex = last;
         base.reversed = false;
         refSeqIdx = G.seqIndexBySite(first);
-        chunkFirst = chunkCount = 0;
         toRight();
     }
     StackEntry &top() { return upper.empty() ? base : upper.back(); }
@@ -1105,8 +1108,10 @@ struct ReplayIterator {
                 auto it = visitCache.find(r->genome);
                 found = it != visitCache.end() && it->second.find(r->pos);
             }
-            if (!found && kind == 0)
+            if (!found && kind == 0) {
                 column.push_back(r);
+                inserted.emplace_back(r->genome, r->pos);
+            }
             if (r->genome == genome)
                 leftmostRefPos = std::min(leftmostRefPos, r->pos);
             if (found) {
@@ -1164,6 +1169,9 @@ void MafExport::convertSequenceGapped(std::ostream &mafStream, hgx_alignment *al
     auto fill = [&]() {
         for (auto &kv : colMap)
             kv.second.clear();
+        for (const auto &gp : it.inserted)
+            colMap[keyOf(gp.first, gp.second)];
+        it.inserted.clear();
         for (const ColumnRowHost *r : it.column)
             colMap[keyOf(r->genome, r->pos)].push_back(r);
     };
@@ -1233,19 +1241,25 @@ void MafExport::convertEntireAlignment(std::ostream &mafStream, hgx_alignment *a
     opt.noAncestors = _noAncestors;
     opt.onlyOrthologs = _onlyOrthologs;
     std::map<int, PositionCache> visitCache;
-    ColumnMap colMap;
     size_t appendCount = 0, numBlocks = 0;
     for (int genome : leaves) {
         const GenomeTables &G = img.genomes[(size_t)genome];
         if (G.totalLength == 0)
             continue;
         ReplayIterator it(alignment, genome, opt, true, 0, chunkColumns, &stats);
-        // (the iterator's own first column, walked by its constructor before setVisitCache replaces its cache, leaves nothing behind)
+        // every leaf has an iterator of its own (:106-110), hence a column map of its own; the first column its constructor walks
+        // (with the iterator's own, empty cache, which setVisitCache then replaces) leaves its sequences behind as empty keys of that
+        // map (toSite's defragment, :160, sees them filled), and initBlock gives every empty key an entry (halMafBlock.cpp:311-322)
+        ColumnMap colMap;
+        it.start(0, G.totalLength - 1);
         it.visitCache.swap(visitCache);
         it.start(0, G.totalLength - 1); // toSite(0, length - 1), :111-113
         auto fill = [&]() {
             for (auto &kv : colMap)
                 kv.second.clear();
+            for (const auto &gp : it.inserted) // (the constructor's column among them)
+                colMap[keyOf(gp.first, gp.second)];
+            it.inserted.clear();
             for (const ColumnRowHost *r : it.column)
                 colMap[keyOf(r->genome, r->pos)].push_back(r);
         };
@@ -1270,8 +1284,6 @@ void MafExport::convertEntireAlignment(std::ostream &mafStream, hgx_alignment *a
                 break;
             it.toRight();
         }
-        for (auto &kv : colMap)
-            kv.second.clear(); // (the rows belong to the iterator that goes away)
         visitCache.swap(it.visitCache);
     }
     if (appendCount > 0) {

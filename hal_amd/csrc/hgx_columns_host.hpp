@@ -117,6 +117,11 @@ class MafExport {
             _pendingWrite.get();
     }
     void appendRun(Entry *e, const ColumnRowHost *row, int64_t pos, int64_t n);
+    // ---- the run-compressed export (hgx_columns_host.cpp: RunMachine): MafBlock's state on flat arrays ----
+    struct RunMachine;
+    friend struct RunMachine;
+    void convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alignment, int genome, int seq, int64_t startPosition, int64_t length,
+                             const ColumnOptions &opt);
     // --maxRefGap > 0: the column iterator with its stack of inserted / deleted ranges (halColumnIterator.cpp:65-144, 357-405),
     // replayed over the columns and indel events the device returns (hgx_gap_kernels.hpp)
     void convertSequenceGapped(std::ostream &mafStream, hgx_alignment *alignment, int genome, int seq, int64_t first, int64_t last,
