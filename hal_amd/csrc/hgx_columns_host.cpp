@@ -402,6 +402,14 @@ void MafExport::flushSnapshots(std::ostream &os) {
     waitPendingWrite();
     if (_snapBlocks.empty())
         return;
+#ifdef HGX_HOST_PROFILE
+    if (getenv("HGX_MAF_NO_RENDER")) { // (the state machine alone)
+        _snapBlocks.clear();
+        _snapRows.clear();
+        _snapSegs.clear();
+        return;
+    }
+#endif
     struct Batch {
         std::vector<BlockSnap> blocks;
         std::vector<RowSnap> rows;
@@ -411,14 +419,18 @@ void MafExport::flushSnapshots(std::ostream &os) {
     batch->blocks.swap(_snapBlocks);
     batch->rows.swap(_snapRows);
     batch->segs.swap(_snapSegs);
-    const std::deque<std::string> *names = &_names;
+    // (the names by address, taken here: the state machine may add names while the batch is rendered; a deque's elements stay put)
+    auto names = std::make_shared<std::vector<const std::string *>>();
+    names->reserve(_names.size());
+    for (const std::string &n : _names)
+        names->push_back(&n);
     const hgx_alignment *al = _al;
     std::ostream *out = &os;
     _pendingWrite = std::async(std::launch::async, [batch, names, al, out]() {
     const std::vector<BlockSnap> &_snapBlocks = batch->blocks;
     const std::vector<RowSnap> &_snapRows = batch->rows;
     const std::vector<Entry::Seg> &_snapSegs = batch->segs;
-    const std::deque<std::string> &_names = *names;
+    const std::vector<const std::string *> &_names = *names;
     const hgx_alignment *_al = al;
     std::ostream &os = *out;
     static const char fwd[17] = "acgtn\0\0\0ACGTN\0\0\0";
@@ -437,7 +449,7 @@ void MafExport::flushSnapshots(std::ostream &os) {
         for (size_t b = b0; b < b1; ++b)
             for (uint32_t k = 0; k < _snapBlocks[b].numRows; ++k) {
                 const RowSnap &r = _snapRows[_snapBlocks[b].firstRow + k];
-                bytes += _names[r.nameId].size() + 80;
+                bytes += _names[r.nameId]->size() + 80;
                 for (uint32_t g = 0; g < r.numSegs; ++g)
                     bytes += (size_t)_snapSegs[r.firstSeg + g].n;
             }
@@ -451,7 +463,7 @@ void MafExport::flushSnapshots(std::ostream &os) {
                 const RowSnap &r = _snapRows[_snapBlocks[b].firstRow + k];
                 *o++ = 's';
                 *o++ = '\t';
-                const std::string &nm = _names[r.nameId];
+                const std::string &nm = *_names[r.nameId];
                 memcpy(o, nm.data(), nm.size());
                 o += nm.size();
                 *o++ = '\t';
@@ -552,6 +564,457 @@ void MafExport::printBlock(std::ostream &os) const {
         if (e->second->start != NULL_INDEX && e->second != _reference)
             printEntry(*e->second, e->second->start);
     os.write(buf.data(), (std::streamsize)buf.size());
+}
+
+// The default export path (no --unique, no --maxRefGap): run-compressed columns from the device, MafBlock's state machine
+// (maf/impl/halMafBlock.cpp:36-82 resetEntries, :294-367 initBlock, :370-395 appendColumn, :401-450 canAppendColumn) on flat
+// arrays sorted by the rank of the sequence instead of the reference's multimap / map of vectors.  What the reference's
+// iterator-chasing loops amount to, stated once: the entries and the column's bases are both ordered by sequence; the i-th base
+// of a sequence goes with the i-th entry of that sequence; initBlock makes the entries that are missing (behind the ones the
+// sequence has), and gives every sequence the column map still has a key for (its bases are gone, the key stays until
+// defragment) one entry at least; canAppendColumn fails when a sequence has more bases than entries.
+#ifdef HGX_HOST_PROFILE
+static unsigned long long g_mafTicks[12];
+struct MafTick {
+    int slot;
+    unsigned long long t0;
+    explicit MafTick(int s) : slot(s), t0(__builtin_ia32_rdtsc()) {}
+    ~MafTick() { g_mafTicks[slot] += __builtin_ia32_rdtsc() - t0; }
+};
+#define MAF_TICK(slot) MafTick mafTick##slot(slot)
+#else
+#define MAF_TICK(slot)
+#endif
+struct MafExport::RunMachine {
+    struct Ent {
+        int rank, genome, seq;
+        Entry *e;
+    };
+    struct KeyRec {
+        int rank, genome, seq;
+    };
+    struct Row {
+        int rank, seq;
+        ColumnRowHost *row;
+    };
+    MafExport &M;
+    std::ostream &os;
+    const Image &img;
+    const int refRank;
+    std::vector<Ent> ents;
+    std::vector<KeyRec> keys; // the column map's keys, the ones without bases in the current column among them
+    std::vector<ColumnRowHost> curRows;
+    std::vector<Row> order;         // the current column's bases by rank, in the column's order within a rank
+    std::vector<const Row *> pairs; // per entry: the base appendColumn gives it (null: a gap)
+    std::vector<Entry *> pool;
+    std::vector<int64_t> nameIdOfRank;
+    size_t appendCount = 0, numBlocks = 0;
+
+    RunMachine(MafExport &m, std::ostream &o, int refRank_) : M(m), os(o), img(m._al->img), refRank(refRank_) {
+        for (auto &kv : M._entries)
+            ents.push_back(Ent{kv.first.rank, kv.first.genome, kv.first.seq, kv.second});
+        size_t ranks = 0;
+        for (const std::vector<int> &r : M._rank)
+            ranks += r.size();
+        nameIdOfRank.assign(ranks, -1);
+    }
+    ~RunMachine() { // the entries go back to the block the other paths (and the next sequence) go on with
+        M._entries.clear();
+        for (const Ent &x : ents)
+            M._entries.insert(M._entries.end(), Entries::value_type(Key{x.rank, x.genome, x.seq}, x.e));
+        for (Entry *e : pool)
+            delete e;
+    }
+    Ent newEnt(const KeyRec &k) {
+        Entry *e;
+        if (pool.empty()) {
+            e = new Entry;
+        } else {
+            e = pool.back();
+            pool.pop_back();
+        }
+        const GenomeTables &G = img.genomes[(size_t)k.genome];
+        const SeqInfo &S = G.seqs[(size_t)k.seq];
+        int64_t &id = nameIdOfRank[(size_t)k.rank];
+        if (id < 0) { // initEntry's name (halMafBlock.cpp:84-112)
+            const std::string name = M._ucscNames ? G.name + "." + S.name : S.name;
+            auto it = M._nameIds.find(name);
+            if (it == M._nameIds.end()) {
+                it = M._nameIds.emplace(name, (uint32_t)M._names.size()).first;
+                M._names.push_back(name);
+            }
+            id = it->second;
+        }
+        e->nameId = (uint32_t)id;
+        e->name = M._names[(size_t)id];
+        e->genome = k.genome;
+        e->srcLength = S.length;
+        e->start = NULL_INDEX;
+        e->length = 0;
+        e->strand = '+';
+        e->lastUsed = 0;
+        e->sequence.clear();
+        e->segs.clear();
+        return Ent{k.rank, k.genome, k.seq, e};
+    }
+    static void setFromRow(Entry *e, const SeqInfo &S, const ColumnRowHost *row) { // initEntry with a base
+        e->start = row->pos - S.start;
+        e->length = 0;
+        e->strand = row->rev ? '-' : '+';
+        if (row->rev)
+            e->start = e->srcLength - 1 - e->start;
+    }
+    // the rows of the current column (curRows) sorted the way the column map holds them; new keys into the map
+    void loadColumn() {
+        MAF_TICK(0);
+        order.resize(curRows.size());
+        for (size_t i = 0; i < curRows.size(); ++i) {
+            ColumnRowHost &r = curRows[i];
+            const GenomeTables &G = img.genomes[(size_t)r.genome];
+            const int s = G.seqs.size() == 1 ? 0 : G.seqIndexBySite(r.pos);
+            order[i] = Row{M._rank[(size_t)r.genome][(size_t)s], s, &r};
+        }
+        for (size_t i = 1; i < order.size(); ++i) { // (a handful of rows: insertion sort, stable)
+            const Row x = order[i];
+            size_t j = i;
+            for (; j > 0 && order[j - 1].rank > x.rank; --j)
+                order[j] = order[j - 1];
+            order[j] = x;
+        }
+        size_t ki = 0;
+        for (size_t o = 0; o < order.size(); ++o) {
+            if (o > 0 && order[o].rank == order[o - 1].rank)
+                continue;
+            while (ki < keys.size() && keys[ki].rank < order[o].rank)
+                ++ki;
+            if (ki == keys.size() || keys[ki].rank != order[o].rank)
+                keys.insert(keys.begin() + (std::ptrdiff_t)ki, KeyRec{order[o].rank, order[o].row->genome, order[o].seq});
+            ++ki;
+        }
+    }
+    void defragment() { // ColumnIterator::defragment (halColumnIterator.cpp:193-208): keys without bases go
+        keys.clear();
+        for (size_t o = 0; o < order.size(); ++o)
+            if (o == 0 || order[o].rank != order[o - 1].rank)
+                keys.push_back(KeyRec{order[o].rank, order[o].row->genome, order[o].seq});
+    }
+    void resetEntries() {
+        M._reference = nullptr;
+        M._refIndex = NULL_INDEX;
+        size_t w = 0;
+        for (size_t i = 0; i < ents.size(); ++i) {
+            Entry *e = ents[i].e;
+            if (e->start == NULL_INDEX) {
+                if (e->lastUsed > 10) {
+                    pool.push_back(e);
+                    continue;
+                }
+                ++e->lastUsed;
+            } else {
+                e->lastUsed = 0;
+            }
+            e->start = NULL_INDEX;
+            e->strand = '+';
+            e->length = 0;
+            e->segs.clear();
+            ents[w++] = ents[i];
+        }
+        ents.resize(w);
+    }
+    void initBlock(int64_t refPos) {
+        MAF_TICK(1);
+        resetEntries();
+        size_t oi = 0, ei = 0;
+        for (const KeyRec &k : keys) {
+            while (ei < ents.size() && ents[ei].rank < k.rank)
+                ++ei;
+            if (oi == order.size() || order[oi].rank != k.rank) { // a key without bases: an empty entry for it, if it has none
+                if (ei == ents.size() || ents[ei].rank != k.rank)
+                    ents.insert(ents.begin() + (std::ptrdiff_t)ei, newEnt(k));
+                continue;
+            }
+            const SeqInfo &S = img.genomes[(size_t)k.genome].seqs[(size_t)k.seq];
+            for (; oi < order.size() && order[oi].rank == k.rank; ++oi, ++ei) {
+                if (ei == ents.size() || ents[ei].rank != k.rank)
+                    ents.insert(ents.begin() + (std::ptrdiff_t)ei, newEnt(k));
+                setFromRow(ents[ei].e, S, order[oi].row);
+            }
+        }
+        if (ents.empty())
+            return;
+        size_t r = 0;
+        while (r < ents.size() && ents[r].rank < refRank)
+            ++r;
+        if (r == ents.size() || ents[r].rank != refRank)
+            r = 0;
+        M._reference = ents[r].e;
+        if (ents[r].rank == refRank)
+            M._refIndex = refPos;
+    }
+    bool canAppend() const {
+        MAF_TICK(2);
+        size_t ei = 0;
+        for (const Row &o : order) {
+            while (ei < ents.size() && ents[ei].rank != o.rank)
+                ++ei;
+            if (ei == ents.size())
+                return false;
+            const Entry *entry = ents[ei].e;
+            if (entry->start != NULL_INDEX) {
+                const ColumnRowHost *row = o.row;
+                if (entry->length >= M._maxBlockLength || (entry->length > 0 && (entry->strand == '-') != (row->rev != 0)))
+                    return false;
+                int64_t pos = row->pos - img.genomes[(size_t)row->genome].seqs[(size_t)o.seq].start;
+                if (row->rev)
+                    pos = entry->srcLength - 1 - pos;
+                if (pos - entry->start != entry->length)
+                    return false;
+            }
+            ++ei;
+        }
+        return true;
+    }
+    void buildPairs() {
+        MAF_TICK(3);
+        pairs.assign(ents.size(), nullptr);
+        size_t ei = 0;
+        for (const Row &o : order) {
+            while (ents[ei].rank != o.rank)
+                ++ei;
+            pairs[ei++] = &o;
+        }
+    }
+    void appendColumn() {
+        MAF_TICK(4);
+        for (size_t i = 0; i < ents.size(); ++i) {
+            Entry *e = ents[i].e;
+            if (const Row *o = pairs[i]) {
+                if (e->start == NULL_INDEX)
+                    setFromRow(e, img.genomes[(size_t)o->row->genome].seqs[(size_t)o->seq], o->row);
+                ++e->length;
+                M.appendRun(e, o->row, o->row->pos, 1);
+            } else {
+                M.appendRun(e, nullptr, 0, 1);
+            }
+        }
+    }
+    void snapshot() { // MafBlock's operator<< order (halMafBlock.cpp:499-520), the rows as runs
+        MAF_TICK(5);
+        BlockSnap b{(uint32_t)M._snapRows.size(), 0};
+        auto add = [&](const Entry &e, int64_t start) {
+            RowSnap r;
+            r.nameId = e.nameId;
+            r.firstSeg = (uint32_t)M._snapSegs.size();
+            r.numSegs = (uint32_t)e.segs.size();
+            M._snapSegs.insert(M._snapSegs.end(), e.segs.begin(), e.segs.end());
+            r.start = start;
+            r.length = e.length;
+            r.srcLength = e.srcLength;
+            r.genome = e.genome;
+            r.strand = e.strand;
+            M._snapRows.push_back(r);
+            ++b.numRows;
+        };
+        if (M._reference->start == NULL_INDEX) {
+            if (M._refIndex != NULL_INDEX)
+                add(*M._reference, M._refIndex);
+        } else {
+            add(*M._reference, M._reference->start);
+        }
+        for (const Ent &x : ents)
+            if (x.e->start != NULL_INDEX && x.e != M._reference)
+                add(*x.e, x.e->start);
+        M._snapBlocks.push_back(b);
+    }
+    // one column through MafExport::convertSequence's loop body (halMafExport.cpp:60-79)
+    void step(int64_t refPos) {
+        if (appendCount == 0) {
+            initBlock(refPos);
+        } else if (!canAppend()) {
+            if (numBlocks++ % 1000 == 0)
+                defragment();
+            if (M._keepEmptyRefBlocks || !M.referenceIsAllGaps()) {
+                snapshot();
+                if (M._snapBlocks.size() >= 32768)
+                    M.flushSnapshots(os);
+            }
+            initBlock(refPos);
+        }
+        buildPairs();
+        appendColumn();
+        ++appendCount;
+    }
+    // up to `run` columns that continue the current one base by base: as many as fit before a block-length limit or the end
+    // of a row's sequence, appended at once; returns how many
+    int64_t appendContinuation(int64_t run) {
+        MAF_TICK(6);
+        int64_t t = run;
+        for (size_t i = 0; i < ents.size(); ++i) {
+            const Row *o = pairs[i];
+            if (!o)
+                continue;
+            t = std::min(t, M._maxBlockLength - ents[i].e->length); // canAppendColumn: length >= maxLength breaks
+            const SeqInfo &S = img.genomes[(size_t)o->row->genome].seqs[(size_t)o->seq];
+            t = std::min(t, o->row->rev ? o->row->pos - S.start : S.start + S.length - 1 - o->row->pos);
+        }
+        if (t <= 0)
+            return 0;
+        for (size_t i = 0; i < ents.size(); ++i) {
+            const Row *o = pairs[i];
+            Entry *e = ents[i].e;
+            if (!o) {
+                M.appendRun(e, nullptr, 0, t);
+                continue;
+            }
+            ColumnRowHost &r = *o->row;
+            M.appendRun(e, &r, r.rev ? r.pos - 1 : r.pos + 1, t); // the text is rendered when the block is printed
+            e->length += t;
+            r.pos += r.rev ? -t : t;
+        }
+        appendCount += (size_t)t;
+        return t;
+    }
+};
+
+void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alignment, int genome, int seq, int64_t startPosition,
+                                    int64_t length, const ColumnOptions &opt) {
+    const GenomeTables &G = alignment->img.genomes[(size_t)genome];
+    const int64_t first = startPosition + G.seqs[(size_t)seq].start;
+    if (const char *e = getenv("HGX_MAF_CHUNK")) // (columns per device batch: tests cross batch ends with it)
+        chunkColumns = (size_t)std::max<long long>(1, atoll(e));
+    struct SegModeGuard {
+        bool &f;
+        explicit SegModeGuard(bool &x) : f(x) { f = true; }
+        ~SegModeGuard() { f = false; }
+    } segModeGuard(_segMode);
+    _snapBlocks.clear();
+    _snapRows.clear();
+    _snapSegs.clear();
+    struct Chunk { // one device batch: which columns are heads, the heads' rows
+        int64_t done = 0, n = 0;
+        std::vector<uint8_t> head;
+        std::vector<uint32_t> headOff;
+        std::vector<ColumnRowHost> headRows;
+        double seconds = 0;
+    };
+    // (the next batch is walked by the device and copied while the state machine goes through this one)
+    auto fetch = [&](int64_t done) {
+        std::unique_ptr<Chunk> c(new Chunk);
+        c->done = done;
+        c->n = std::min<int64_t>((int64_t)chunkColumns, length - done);
+        const auto t0 = std::chrono::steady_clock::now();
+#ifdef HGX_HOST_PROFILE
+        // profiling aid of the host state machine (make hostprof-lib, not part of libhgx.so): HGX_MAF_DUMP=file records the device's
+        // batches, HGX_MAF_REPLAY=file plays them back to the state machine on a machine without a GPU
+        static FILE *replay = getenv("HGX_MAF_REPLAY") ? fopen(getenv("HGX_MAF_REPLAY"), "rb") : nullptr;
+        static FILE *dump = getenv("HGX_MAF_DUMP") ? fopen(getenv("HGX_MAF_DUMP"), "wb") : nullptr;
+        if (replay) {
+            uint64_t hd[4];
+            if (fread(hd, 8, 4, replay) != 4 || (int64_t)hd[0] != done)
+                throw std::runtime_error("HGX_MAF_REPLAY: the file does not continue at this column");
+            c->n = (int64_t)hd[1];
+            c->head.resize((size_t)c->n);
+            c->headOff.resize((size_t)hd[2]);
+            c->headRows.resize((size_t)hd[3]);
+            if (fread(c->head.data(), 1, c->head.size(), replay) != c->head.size() ||
+                fread(c->headOff.data(), 4, c->headOff.size(), replay) != c->headOff.size() ||
+                fread(c->headRows.data(), sizeof(ColumnRowHost), c->headRows.size(), replay) != c->headRows.size())
+                throw std::runtime_error("HGX_MAF_REPLAY: short file");
+            return c;
+        }
+#endif
+        for (;;) { // (a chunk's row offsets are 32-bit: very wide alignments get smaller chunks)
+            try {
+                columnsHeadRowsHost(alignment, genome, first + done, c->n, opt, true, c->head, c->headOff, c->headRows, &stats);
+#ifdef HGX_HOST_PROFILE
+                if (dump) {
+                    const uint64_t hd[4] = {(uint64_t)done, (uint64_t)c->n, c->headOff.size(), c->headRows.size()};
+                    fwrite(hd, 8, 4, dump);
+                    fwrite(c->head.data(), 1, c->head.size(), dump);
+                    fwrite(c->headOff.data(), 4, c->headOff.size(), dump);
+                    fwrite(c->headRows.data(), sizeof(ColumnRowHost), c->headRows.size(), dump);
+                    fflush(dump);
+                }
+#endif
+                break;
+            } catch (const ColumnChunkTooLarge &) {
+                if (c->n <= 1)
+                    throw;
+                chunkColumns = (size_t)std::max<int64_t>(1, c->n / 2);
+                c->n = (int64_t)chunkColumns;
+            }
+        }
+        c->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return c;
+    };
+    double fetchSeconds = 0, waitSeconds = 0;
+    size_t numHeads = 0;
+    const auto tStart = std::chrono::steady_clock::now();
+    {
+        RunMachine R(*this, mafStream, _rank[(size_t)genome][(size_t)seq]);
+        std::future<std::unique_ptr<Chunk>> next = std::async(std::launch::async, fetch, (int64_t)0);
+        for (int64_t done = 0; done < length;) {
+            const auto tw = std::chrono::steady_clock::now();
+            std::unique_ptr<Chunk> c = next.get();
+            waitSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
+            const int64_t n = c->n;
+            if (done + n < length)
+                next = std::async(std::launch::async, fetch, done + n);
+            fetchSeconds += c->seconds;
+            numHeads += c->headOff.size() - 1;
+            size_t hk = 0;
+            for (int64_t i = 0; i < n;) {
+                // head column i: its rows come from the device
+                {
+                    MAF_TICK(7);
+                    R.curRows.assign(c->headRows.begin() + c->headOff[hk], c->headRows.begin() + c->headOff[hk + 1]);
+                }
+                ++hk;
+                R.loadColumn();
+                R.step(startPosition + done + i);
+                int64_t run = 0; // the columns that follow and continue it
+                {
+                    MAF_TICK(8);
+                    while (i + 1 + run < n && !c->head[(size_t)(i + 1 + run)])
+                        ++run;
+                }
+                int64_t col = i + 1;
+                while (run > 0) {
+                    const int64_t t = R.appendContinuation(run);
+                    run -= t;
+                    col += t;
+                    if (run > 0) { // a block-length break or a sequence end: one ordinary column
+                        for (ColumnRowHost &r : R.curRows)
+                            r.pos += r.rev ? -1 : 1; // (the base itself is not needed: rows are kept as runs)
+                        R.loadColumn();
+                        R.step(startPosition + done + col);
+                        --run;
+                        ++col;
+                    }
+                }
+                i = col;
+            }
+            done += n;
+        }
+        if (R.appendCount > 0 && (_keepEmptyRefBlocks || !referenceIsAllGaps()))
+            R.snapshot();
+        if (getenv("HGX_MAF_TIMING"))
+            std::cerr << "[hgx maf] columns " << length << " heads " << numHeads << " blocks " << R.numBlocks << " state machine + waits "
+                      << std::chrono::duration<double>(std::chrono::steady_clock::now() - tStart).count() << " s, of which waiting for the device "
+                      << waitSeconds << " s (fetches " << fetchSeconds << " s, device " << stats.rows_ms + stats.depth_ms << " ms)" << std::endl;
+    }
+    flushSnapshots(mafStream);
+    waitPendingWrite();
+    mafStream.flush();
+#ifdef HGX_HOST_PROFILE
+    if (getenv("HGX_MAF_TIMING")) {
+        static const char *what[] = {"loadColumn", "initBlock", "canAppend", "buildPairs", "appendColumn", "snapshot", "continuation", "rows copy", "run scan"};
+        for (int i = 0; i < 9; ++i)
+            std::cerr << "[hgx maf]   " << what[i] << " " << (double)g_mafTicks[i] / 1e6 << " Mticks" << std::endl;
+    }
+#endif
+    if (getenv("HGX_MAF_TIMING"))
+        std::cerr << "[hgx maf] written after " << std::chrono::duration<double>(std::chrono::steady_clock::now() - tStart).count() << " s" << std::endl;
 }
 
 // halMafExport.cpp:25-88
@@ -679,7 +1142,11 @@ void MafExport::convertSequence(std::ostream &mafStream, hgx_alignment *alignmen
     // Inside a run every column has the rows of its left neighbour advanced by one base, so canAppendColumn can only
     // fail on the block-length limit and appendColumn only appends one character per entry; the run is therefore
     // appended in bulk, falling back to single columns at sequence ends and block-length breaks.
-    if (!_unique && !getenv("HGX_MAF_PER_COLUMN")) {
+    if (!_unique && !getenv("HGX_MAF_PER_COLUMN") && !getenv("HGX_MAF_MAP_STATE")) {
+        convertSequenceRuns(mafStream, alignment, genome, seq, startPosition, length, opt);
+        return;
+    }
+    if (!_unique && !getenv("HGX_MAF_PER_COLUMN")) { // (the same path on MafBlock's own containers: kept as a cross-check, HGX_MAF_MAP_STATE=1)
         struct SegModeGuard {
             bool &f;
             explicit SegModeGuard(bool &x) : f(x) { f = true; }

@@ -1,5 +1,6 @@
 """The alternative code paths behind environment switches give the same bytes as the defaults: one launch per up level
-(HGX_LEVEL_SYNC_UP), the composed up table forced on small batches (HGX_COMPOSED_UP), the per-column depth kernel (HGX_COLUMNS_PER_BASE), the per-column MAF path (HGX_MAF_PER_COLUMN), the
+(HGX_LEVEL_SYNC_UP), the composed up table forced on small batches (HGX_COMPOSED_UP), the per-column depth kernel (HGX_COLUMNS_PER_BASE), the per-column MAF path (HGX_MAF_PER_COLUMN),
+the run-compressed MAF path on MafBlock's own containers (HGX_MAF_MAP_STATE) and in small device batches (HGX_MAF_CHUNK), the
 64-bit instantiations (HGX_FORCE_WIDE).  Each switch is read once per process, so every variant runs in its own process."""
 import hashlib
 import os
@@ -31,6 +32,17 @@ for g in ("Genome_9", "Genome_0", "Genome_3"):
     h.update(al.alignment_depth(gi, step=7, count_dupes=True).encode())
     h.update(al.maf_export(gi).encode())
     h.update(al.maf_export(gi, no_dupes=True, max_block_len=11).encode())
+import os, tempfile
+import halfix
+with tempfile.TemporaryDirectory() as T:  # several sequences per genome, duplications, short blocks
+    for seed in (0, 1, 3):
+        p = os.path.join(T, "ms%%d.hgx" %% seed)
+        halfix.write_hgx(p, halfix.random_multiseq_alignment(seed, n_genomes=6))
+        al2 = hal.Alignment.open(p, device=0)
+        for gi in range(al2.num_genomes):
+            h.update(al2.maf_export(gi).encode())
+            h.update(al2.maf_export(gi, max_block_len=5, keep_empty_ref_blocks=True).encode())
+            h.update(al2.maf_export(gi, only_orthologs=True, only_sequence_names=True).encode())
 st = al.columns_depth_stats(src, 0, al.genome_length(src))
 assert st["top_derefs"] > 0 and st["bottom_derefs"] > 0
 print(h.hexdigest())
@@ -47,7 +59,8 @@ def _digest(**env):
 def test_switchable_paths_agree():
     base = _digest()
     assert len(base) == 64
-    for env in ({"HGX_LEVEL_SYNC_UP": "1"}, {"HGX_COLUMNS_PER_BASE": "1"}, {"HGX_MAF_PER_COLUMN": "1"}, {"HGX_FORCE_WIDE": "1"},
+    for env in ({"HGX_LEVEL_SYNC_UP": "1"}, {"HGX_COLUMNS_PER_BASE": "1"}, {"HGX_MAF_PER_COLUMN": "1"}, {"HGX_MAF_MAP_STATE": "1"},
+                {"HGX_MAF_CHUNK": "97"}, {"HGX_FORCE_WIDE": "1"},
                 {"HGX_COMPOSED_UP": "1"}, {"HGX_COMPOSED_UP": "1", "HGX_FORCE_WIDE": "1"}):
         assert _digest(**env) == base, env
 
