@@ -573,6 +573,11 @@ void MafExport::printBlock(std::ostream &os) const {
 // of a sequence goes with the i-th entry of that sequence; initBlock makes the entries that are missing (behind the ones the
 // sequence has), and gives every sequence the column map still has a key for (its bases are gone, the key stays until
 // defragment) one entry at least; canAppendColumn fails when a sequence has more bases than entries.
+//
+// Only what decides where blocks begin is sequential: per entry its start, length, strand and age.  That is all the thread
+// that walks the columns keeps; of every block it leaves a log — the entries it had, and per appended stretch of columns which
+// base each entry was given — and the rows themselves (runs of gaps and bases, then text) are made from the log by the
+// rendering threads, a batch of blocks at a time, beside the walk.
 #ifdef HGX_HOST_PROFILE
 static unsigned long long g_mafTicks[12];
 struct MafTick {
@@ -586,16 +591,49 @@ struct MafTick {
 #define MAF_TICK(slot)
 #endif
 struct MafExport::RunMachine {
+    struct PRow { // a base of a column: what the walk and the renderers need of it
+        int64_t pos;      // genome coordinate
+        int64_t seqStart; // of its sequence
+        int64_t limit;    // columns the row can go on inside its sequence
+        int32_t rank, genome, seq;
+        uint8_t rev;
+    };
+    struct Chunk { // one device batch: which columns are heads, the heads' rows (sorted the way the column map holds them)
+        int64_t done = 0, n = 0;
+        std::vector<uint8_t> head;
+        std::vector<uint32_t> headOff;
+        std::vector<PRow> rows;
+        double seconds = 0;
+    };
     struct Ent {
-        int rank, genome, seq;
-        Entry *e;
+        int32_t rank, genome, seq;
+        bool rev;
+        short lastUsed;
+        int64_t start, length, srcLength;
     };
     struct KeyRec {
-        int rank, genome, seq;
+        int32_t rank, genome, seq;
     };
-    struct Row {
-        int rank, seq;
-        ColumnRowHost *row;
+    struct RankInfo {
+        int64_t nameId = -1, srcLength = 0;
+        int32_t genome = 0;
+    };
+    struct BlockLog {
+        uint32_t firstEnt, numEnts, firstEvent, numEvents;
+        int32_t refEnt;
+        int64_t refIndex;
+    };
+    struct EventLog {
+        int64_t k; // columns
+        uint32_t firstPair;
+    };
+    struct Batch {
+        std::vector<BlockLog> blocks;
+        std::vector<int32_t> entRank;
+        std::vector<EventLog> events;
+        std::vector<const PRow *> pairs; // per event and entry of the block: the base the entry was given at the event's first column
+        std::vector<std::shared_ptr<Chunk>> chunks; // (what the pairs point into)
+        std::vector<std::unique_ptr<PRow[]>> extra;
     };
     MafExport &M;
     std::ostream &os;
@@ -603,306 +641,454 @@ struct MafExport::RunMachine {
     const int refRank;
     std::vector<Ent> ents;
     std::vector<KeyRec> keys; // the column map's keys, the ones without bases in the current column among them
-    std::vector<ColumnRowHost> curRows;
-    std::vector<Row> order;         // the current column's bases by rank, in the column's order within a rank
-    std::vector<const Row *> pairs; // per entry: the base appendColumn gives it (null: a gap)
-    std::vector<Entry *> pool;
-    std::vector<int64_t> nameIdOfRank;
+    std::vector<uint8_t> inKeys;
+    std::shared_ptr<std::vector<RankInfo>> rankInfo;
+    std::unique_ptr<Batch> batch;
+    std::shared_ptr<Chunk> chunk;
+    BlockLog cur{};
     size_t appendCount = 0, numBlocks = 0;
 
-    RunMachine(MafExport &m, std::ostream &o, int refRank_) : M(m), os(o), img(m._al->img), refRank(refRank_) {
-        for (auto &kv : M._entries)
-            ents.push_back(Ent{kv.first.rank, kv.first.genome, kv.first.seq, kv.second});
+    RunMachine(MafExport &m, std::ostream &o, int refRank_) : M(m), os(o), img(m._al->img), refRank(refRank_), batch(new Batch) {
         size_t ranks = 0;
         for (const std::vector<int> &r : M._rank)
             ranks += r.size();
-        nameIdOfRank.assign(ranks, -1);
+        rankInfo = std::make_shared<std::vector<RankInfo>>(ranks);
+        inKeys.assign(ranks, 0);
+        for (auto &kv : M._entries) { // the block the other paths (and the sequence before) left
+            const Entry &e = *kv.second;
+            ents.push_back(Ent{kv.first.rank, kv.first.genome, kv.first.seq, e.strand == '-', e.lastUsed, e.start, e.length, e.srcLength});
+            info(KeyRec{kv.first.rank, kv.first.genome, kv.first.seq});
+            delete kv.second;
+        }
+        M._entries.clear();
+        M._reference = nullptr;
     }
     ~RunMachine() { // the entries go back to the block the other paths (and the next sequence) go on with
-        M._entries.clear();
-        for (const Ent &x : ents)
-            M._entries.insert(M._entries.end(), Entries::value_type(Key{x.rank, x.genome, x.seq}, x.e));
-        for (Entry *e : pool)
-            delete e;
-    }
-    Ent newEnt(const KeyRec &k) {
-        Entry *e;
-        if (pool.empty()) {
-            e = new Entry;
-        } else {
-            e = pool.back();
-            pool.pop_back();
+        for (const Ent &x : ents) {
+            Entry *e = new Entry;
+            e->genome = x.genome;
+            e->nameId = (uint32_t)(*rankInfo)[(size_t)x.rank].nameId;
+            e->name = M._names[e->nameId];
+            e->start = x.start;
+            e->length = x.length;
+            e->srcLength = x.srcLength;
+            e->strand = x.rev ? '-' : '+';
+            e->lastUsed = x.lastUsed;
+            M._entries.insert(M._entries.end(), Entries::value_type(Key{x.rank, x.genome, x.seq}, e));
         }
-        const GenomeTables &G = img.genomes[(size_t)k.genome];
-        const SeqInfo &S = G.seqs[(size_t)k.seq];
-        int64_t &id = nameIdOfRank[(size_t)k.rank];
-        if (id < 0) { // initEntry's name (halMafBlock.cpp:84-112)
+        M._reference = nullptr; // (the next block begins with resetEntries)
+        M._refIndex = NULL_INDEX;
+    }
+    const RankInfo &info(const KeyRec &k) {
+        RankInfo &ri = (*rankInfo)[(size_t)k.rank];
+        if (ri.nameId < 0) { // initEntry's name (halMafBlock.cpp:84-112)
+            const GenomeTables &G = img.genomes[(size_t)k.genome];
+            const SeqInfo &S = G.seqs[(size_t)k.seq];
             const std::string name = M._ucscNames ? G.name + "." + S.name : S.name;
             auto it = M._nameIds.find(name);
             if (it == M._nameIds.end()) {
                 it = M._nameIds.emplace(name, (uint32_t)M._names.size()).first;
                 M._names.push_back(name);
             }
-            id = it->second;
+            ri.nameId = it->second;
+            ri.srcLength = S.length;
+            ri.genome = k.genome;
         }
-        e->nameId = (uint32_t)id;
-        e->name = M._names[(size_t)id];
-        e->genome = k.genome;
-        e->srcLength = S.length;
-        e->start = NULL_INDEX;
-        e->length = 0;
-        e->strand = '+';
-        e->lastUsed = 0;
-        e->sequence.clear();
-        e->segs.clear();
-        return Ent{k.rank, k.genome, k.seq, e};
+        return ri;
     }
-    static void setFromRow(Entry *e, const SeqInfo &S, const ColumnRowHost *row) { // initEntry with a base
-        e->start = row->pos - S.start;
-        e->length = 0;
-        e->strand = row->rev ? '-' : '+';
-        if (row->rev)
-            e->start = e->srcLength - 1 - e->start;
+    Ent newEnt(const KeyRec &k) { return Ent{k.rank, k.genome, k.seq, false, 0, NULL_INDEX, 0, info(k).srcLength}; }
+    // device rows -> PRows, every column's sorted by rank (stable): done by the thread that fetches, beside the walk
+    static void describe(const Image &img, const std::vector<std::vector<int>> &rank, PRow &p, int genome, int64_t pos, bool rev) {
+        const GenomeTables &G = img.genomes[(size_t)genome];
+        const int s = G.seqs.size() == 1 ? 0 : G.seqIndexBySite(pos);
+        const SeqInfo &S = G.seqs[(size_t)s];
+        p.pos = pos;
+        p.seqStart = S.start;
+        p.limit = rev ? pos - S.start : S.start + S.length - 1 - pos;
+        p.rank = rank[(size_t)genome][(size_t)s];
+        p.genome = genome;
+        p.seq = s;
+        p.rev = rev ? 1 : 0;
     }
-    // the rows of the current column (curRows) sorted the way the column map holds them; new keys into the map
-    void loadColumn() {
-        MAF_TICK(0);
-        order.resize(curRows.size());
-        for (size_t i = 0; i < curRows.size(); ++i) {
-            ColumnRowHost &r = curRows[i];
-            const GenomeTables &G = img.genomes[(size_t)r.genome];
-            const int s = G.seqs.size() == 1 ? 0 : G.seqIndexBySite(r.pos);
-            order[i] = Row{M._rank[(size_t)r.genome][(size_t)s], s, &r};
-        }
-        for (size_t i = 1; i < order.size(); ++i) { // (a handful of rows: insertion sort, stable)
-            const Row x = order[i];
+    static void sortColumn(PRow *r, size_t n) { // (a handful of rows: insertion sort)
+        for (size_t i = 1; i < n; ++i) {
+            const PRow x = r[i];
             size_t j = i;
-            for (; j > 0 && order[j - 1].rank > x.rank; --j)
-                order[j] = order[j - 1];
-            order[j] = x;
+            for (; j > 0 && r[j - 1].rank > x.rank; --j)
+                r[j] = r[j - 1];
+            r[j] = x;
         }
-        size_t ki = 0;
-        for (size_t o = 0; o < order.size(); ++o) {
-            if (o > 0 && order[o].rank == order[o - 1].rank)
+    }
+    void addKeys(const PRow *rows, size_t n) {
+        for (size_t i = 0; i < n; ++i) {
+            if (inKeys[(size_t)rows[i].rank])
                 continue;
-            while (ki < keys.size() && keys[ki].rank < order[o].rank)
+            inKeys[(size_t)rows[i].rank] = 1;
+            size_t ki = 0;
+            while (ki < keys.size() && keys[ki].rank < rows[i].rank)
                 ++ki;
-            if (ki == keys.size() || keys[ki].rank != order[o].rank)
-                keys.insert(keys.begin() + (std::ptrdiff_t)ki, KeyRec{order[o].rank, order[o].row->genome, order[o].seq});
-            ++ki;
+            keys.insert(keys.begin() + (std::ptrdiff_t)ki, KeyRec{rows[i].rank, rows[i].genome, rows[i].seq});
         }
     }
-    void defragment() { // ColumnIterator::defragment (halColumnIterator.cpp:193-208): keys without bases go
+    void defragment(const PRow *rows, size_t n) { // ColumnIterator::defragment (halColumnIterator.cpp:193-208): keys without bases go
+        for (const KeyRec &k : keys)
+            inKeys[(size_t)k.rank] = 0;
         keys.clear();
-        for (size_t o = 0; o < order.size(); ++o)
-            if (o == 0 || order[o].rank != order[o - 1].rank)
-                keys.push_back(KeyRec{order[o].rank, order[o].row->genome, order[o].seq});
-    }
-    void resetEntries() {
-        M._reference = nullptr;
-        M._refIndex = NULL_INDEX;
-        size_t w = 0;
-        for (size_t i = 0; i < ents.size(); ++i) {
-            Entry *e = ents[i].e;
-            if (e->start == NULL_INDEX) {
-                if (e->lastUsed > 10) {
-                    pool.push_back(e);
-                    continue;
-                }
-                ++e->lastUsed;
-            } else {
-                e->lastUsed = 0;
+        for (size_t i = 0; i < n; ++i)
+            if (i == 0 || rows[i].rank != rows[i - 1].rank) {
+                keys.push_back(KeyRec{rows[i].rank, rows[i].genome, rows[i].seq});
+                inKeys[(size_t)rows[i].rank] = 1;
             }
-            e->start = NULL_INDEX;
-            e->strand = '+';
-            e->length = 0;
-            e->segs.clear();
-            ents[w++] = ents[i];
+    }
+    void initBlock(const PRow *rows, size_t n, int64_t refPos) {
+        MAF_TICK(1);
+        size_t w = 0; // resetEntries
+        for (size_t i = 0; i < ents.size(); ++i) {
+            Ent &e = ents[i];
+            if (e.start == NULL_INDEX) {
+                if (e.lastUsed > 10)
+                    continue; // unused for more than 10 consecutive blocks: dropped
+                ++e.lastUsed;
+            } else {
+                e.lastUsed = 0;
+            }
+            e.start = NULL_INDEX;
+            e.rev = false;
+            e.length = 0;
+            ents[w++] = e;
         }
         ents.resize(w);
-    }
-    void initBlock(int64_t refPos) {
-        MAF_TICK(1);
-        resetEntries();
         size_t oi = 0, ei = 0;
         for (const KeyRec &k : keys) {
             while (ei < ents.size() && ents[ei].rank < k.rank)
                 ++ei;
-            if (oi == order.size() || order[oi].rank != k.rank) { // a key without bases: an empty entry for it, if it has none
+            if (oi == n || rows[oi].rank != k.rank) { // a key without bases: an empty entry for it, if it has none
                 if (ei == ents.size() || ents[ei].rank != k.rank)
                     ents.insert(ents.begin() + (std::ptrdiff_t)ei, newEnt(k));
                 continue;
             }
-            const SeqInfo &S = img.genomes[(size_t)k.genome].seqs[(size_t)k.seq];
-            for (; oi < order.size() && order[oi].rank == k.rank; ++oi, ++ei) {
+            for (; oi < n && rows[oi].rank == k.rank; ++oi, ++ei) {
                 if (ei == ents.size() || ents[ei].rank != k.rank)
                     ents.insert(ents.begin() + (std::ptrdiff_t)ei, newEnt(k));
-                setFromRow(ents[ei].e, S, order[oi].row);
+                setFromRow(ents[ei], rows[oi]);
             }
         }
-        if (ents.empty())
-            return;
+#ifdef HGX_HOST_PROFILE
+        g_mafTicks[8] += ents.size();
+        g_mafTicks[9] += n;
+        g_mafTicks[10] += keys.size();
+#endif
+        cur.firstEnt = (uint32_t)batch->entRank.size();
+        cur.numEnts = (uint32_t)ents.size();
+        cur.firstEvent = (uint32_t)batch->events.size();
+        cur.numEvents = 0;
+        for (const Ent &e : ents)
+            batch->entRank.push_back(e.rank);
         size_t r = 0;
         while (r < ents.size() && ents[r].rank < refRank)
             ++r;
         if (r == ents.size() || ents[r].rank != refRank)
             r = 0;
-        M._reference = ents[r].e;
-        if (ents[r].rank == refRank)
-            M._refIndex = refPos;
+        cur.refEnt = ents.empty() ? -1 : (int32_t)r;
+        cur.refIndex = !ents.empty() && ents[r].rank == refRank ? refPos : NULL_INDEX;
     }
-    bool canAppend() const {
+    static void setFromRow(Ent &e, const PRow &row) { // initEntry with a base
+        e.start = row.pos - row.seqStart;
+        e.length = 0;
+        e.rev = row.rev != 0;
+        if (row.rev)
+            e.start = e.srcLength - 1 - e.start;
+    }
+    bool canAppend(const PRow *rows, size_t n) const {
         MAF_TICK(2);
         size_t ei = 0;
-        for (const Row &o : order) {
-            while (ei < ents.size() && ents[ei].rank != o.rank)
+        for (size_t i = 0; i < n; ++i) {
+            const PRow &row = rows[i];
+            while (ei < ents.size() && ents[ei].rank != row.rank)
                 ++ei;
             if (ei == ents.size())
                 return false;
-            const Entry *entry = ents[ei].e;
-            if (entry->start != NULL_INDEX) {
-                const ColumnRowHost *row = o.row;
-                if (entry->length >= M._maxBlockLength || (entry->length > 0 && (entry->strand == '-') != (row->rev != 0)))
+            const Ent &entry = ents[ei];
+            if (entry.start != NULL_INDEX) {
+                if (entry.length >= M._maxBlockLength || (entry.length > 0 && entry.rev != (row.rev != 0)))
                     return false;
-                int64_t pos = row->pos - img.genomes[(size_t)row->genome].seqs[(size_t)o.seq].start;
-                if (row->rev)
-                    pos = entry->srcLength - 1 - pos;
-                if (pos - entry->start != entry->length)
+                int64_t pos = row.pos - row.seqStart;
+                if (row.rev)
+                    pos = entry.srcLength - 1 - pos;
+                if (pos - entry.start != entry.length)
                     return false;
             }
             ++ei;
         }
         return true;
     }
-    void buildPairs() {
-        MAF_TICK(3);
-        pairs.assign(ents.size(), nullptr);
-        size_t ei = 0;
-        for (const Row &o : order) {
-            while (ents[ei].rank != o.rank)
-                ++ei;
-            pairs[ei++] = &o;
-        }
+    void endBlock() {
+        cur.numEvents = (uint32_t)batch->events.size() - cur.firstEvent;
+        batch->blocks.push_back(cur);
     }
-    void appendColumn() {
-        MAF_TICK(4);
-        for (size_t i = 0; i < ents.size(); ++i) {
-            Entry *e = ents[i].e;
-            if (const Row *o = pairs[i]) {
-                if (e->start == NULL_INDEX)
-                    setFromRow(e, img.genomes[(size_t)o->row->genome].seqs[(size_t)o->seq], o->row);
-                ++e->length;
-                M.appendRun(e, o->row, o->row->pos, 1);
-            } else {
-                M.appendRun(e, nullptr, 0, 1);
-            }
-        }
-    }
-    void snapshot() { // MafBlock's operator<< order (halMafBlock.cpp:499-520), the rows as runs
-        MAF_TICK(5);
-        BlockSnap b{(uint32_t)M._snapRows.size(), 0};
-        auto add = [&](const Entry &e, int64_t start) {
-            RowSnap r;
-            r.nameId = e.nameId;
-            r.firstSeg = (uint32_t)M._snapSegs.size();
-            r.numSegs = (uint32_t)e.segs.size();
-            M._snapSegs.insert(M._snapSegs.end(), e.segs.begin(), e.segs.end());
-            r.start = start;
-            r.length = e.length;
-            r.srcLength = e.srcLength;
-            r.genome = e.genome;
-            r.strand = e.strand;
-            M._snapRows.push_back(r);
-            ++b.numRows;
-        };
-        if (M._reference->start == NULL_INDEX) {
-            if (M._refIndex != NULL_INDEX)
-                add(*M._reference, M._refIndex);
-        } else {
-            add(*M._reference, M._reference->start);
-        }
-        for (const Ent &x : ents)
-            if (x.e->start != NULL_INDEX && x.e != M._reference)
-                add(*x.e, x.e->start);
-        M._snapBlocks.push_back(b);
-    }
-    // one column through MafExport::convertSequence's loop body (halMafExport.cpp:60-79)
-    void step(int64_t refPos) {
+    // the column with these bases at reference position refPos and up to left - 1 columns behind it that continue it base by base,
+    // through MafExport::convertSequence's loop body (halMafExport.cpp:60-79); returns how many columns were placed: as many
+    // as fit before a block-length limit (canAppendColumn: length >= maxLength breaks) or the end of a row's sequence
+    int64_t place(const PRow *rows, size_t n, int64_t left, int64_t refPos) {
         if (appendCount == 0) {
-            initBlock(refPos);
-        } else if (!canAppend()) {
+            initBlock(rows, n, refPos);
+        } else if (!canAppend(rows, n)) {
+            endBlock();
             if (numBlocks++ % 1000 == 0)
-                defragment();
-            if (M._keepEmptyRefBlocks || !M.referenceIsAllGaps()) {
-                snapshot();
-                if (M._snapBlocks.size() >= 32768)
-                    M.flushSnapshots(os);
-            }
-            initBlock(refPos);
+                defragment(rows, n);
+            if (batch->blocks.size() >= 32768)
+                flush(rows);
+            initBlock(rows, n, refPos);
         }
-        buildPairs();
-        appendColumn();
-        ++appendCount;
+        MAF_TICK(3);
+        const size_t firstPair = batch->pairs.size();
+        batch->pairs.resize(firstPair + ents.size(), nullptr);
+        const PRow **pairs = batch->pairs.data() + firstPair;
+        int64_t k = left;
+        size_t ei = 0;
+        for (size_t i = 0; i < n; ++i) { // the pairing appendColumn performs
+            while (ents[ei].rank != rows[i].rank)
+                ++ei;
+            pairs[ei] = &rows[i];
+            k = std::min(k, 1 + std::max<int64_t>(0, M._maxBlockLength - (ents[ei].length + 1)));
+            k = std::min(k, 1 + rows[i].limit);
+            ++ei;
+        }
+        for (size_t j = 0; j < ents.size(); ++j)
+            if (const PRow *p = pairs[j]) {
+                if (ents[j].start == NULL_INDEX)
+                    setFromRow(ents[j], *p);
+                ents[j].length += k;
+            }
+        batch->events.push_back(EventLog{k, (uint32_t)firstPair});
+        appendCount += (size_t)k;
+        return k;
     }
-    // up to `run` columns that continue the current one base by base: as many as fit before a block-length limit or the end
-    // of a row's sequence, appended at once; returns how many
-    int64_t appendContinuation(int64_t run) {
-        MAF_TICK(6);
-        int64_t t = run;
-        for (size_t i = 0; i < ents.size(); ++i) {
-            const Row *o = pairs[i];
-            if (!o)
-                continue;
-            t = std::min(t, M._maxBlockLength - ents[i].e->length); // canAppendColumn: length >= maxLength breaks
-            const SeqInfo &S = img.genomes[(size_t)o->row->genome].seqs[(size_t)o->seq];
-            t = std::min(t, o->row->rev ? o->row->pos - S.start : S.start + S.length - 1 - o->row->pos);
+    // the bases k columns on (a column that has to go through the per-column logic in the middle of a run)
+    const PRow *advance(const PRow *rows, size_t n, int64_t k) {
+        std::unique_ptr<PRow[]> next(new PRow[n]);
+        for (size_t i = 0; i < n; ++i)
+            describe(img, M._rank, next[i], rows[i].genome, rows[i].pos + (rows[i].rev ? -k : k), rows[i].rev != 0);
+        sortColumn(next.get(), n);
+        batch->extra.push_back(std::move(next));
+        return batch->extra.back().get();
+    }
+    // hands the batch to the rendering threads (beside the walk: the previous batch is waited for first); current: the column
+    // the next block begins with
+    void flush(const PRow *current = nullptr);
+};
+
+namespace {
+struct TextBuffer {
+    char *data = nullptr;
+    size_t len = 0, cap = 0;
+    ~TextBuffer() { free(data); }
+    char *room(size_t n) {
+        if (len + n > cap) {
+            cap = std::max(cap * 2, len + n + (1u << 20));
+            data = (char *)realloc(data, cap);
+            if (!data)
+                throw std::bad_alloc();
         }
-        if (t <= 0)
-            return 0;
-        for (size_t i = 0; i < ents.size(); ++i) {
-            const Row *o = pairs[i];
-            Entry *e = ents[i].e;
-            if (!o) {
-                M.appendRun(e, nullptr, 0, t);
-                continue;
-            }
-            ColumnRowHost &r = *o->row;
-            M.appendRun(e, &r, r.rev ? r.pos - 1 : r.pos + 1, t); // the text is rendered when the block is printed
-            e->length += t;
-            r.pos += r.rev ? -t : t;
-        }
-        appendCount += (size_t)t;
-        return t;
+        return data + len;
     }
 };
+} // namespace
+
+void MafExport::RunMachine::flush(const PRow *current) {
+    M.waitPendingWrite();
+    if (batch->blocks.empty())
+        return;
+    std::shared_ptr<Batch> work(batch.release());
+    batch.reset(new Batch);
+    if (chunk)
+        batch->chunks.push_back(chunk); // (still being walked)
+    if (!work->extra.empty() && work->extra.back().get() == current) { // (made by advance for the block to come: no event of this batch points to it)
+        batch->extra.push_back(std::move(work->extra.back()));
+        work->extra.pop_back();
+    }
+    // (the names by address, taken here: the walk may add names while the batch is rendered; a deque's elements stay put)
+    auto names = std::make_shared<std::vector<const std::string *>>();
+    names->reserve(M._names.size());
+    for (const std::string &n : M._names)
+        names->push_back(&n);
+    std::shared_ptr<std::vector<RankInfo>> ranks = rankInfo;
+    const hgx_alignment *al = M._al;
+    std::ostream *out = &os;
+    const bool keepEmptyRefBlocks = M._keepEmptyRefBlocks;
+#ifdef HGX_HOST_PROFILE
+    if (getenv("HGX_MAF_NO_RENDER"))
+        return;
+#endif
+    M._pendingWrite = std::async(std::launch::async, [work, names, ranks, al, out, keepEmptyRefBlocks]() {
+        static const char fwd[17] = "acgtn\0\0\0ACGTN\0\0\0";
+        static const char rc[17] = "tgcan\0\0\0TGCAN\0\0\0";
+        static const PairTable fwd2(fwd, false), rc2(rc, true);
+        const size_t nb = work->blocks.size();
+        unsigned nt = std::thread::hardware_concurrency();
+        nt = std::max(1u, std::min(nt ? nt : 1u, 16u));
+        if (nb < 256)
+            nt = 1;
+        std::vector<TextBuffer> text(nt);
+        auto render = [&](unsigned t) {
+            TextBuffer &buf = text[t];
+            struct RowOut {
+                int64_t start, length;
+                uint32_t firstSeg, numSegs;
+                bool rev;
+            };
+            std::vector<RowOut> rows;
+            std::vector<Entry::Seg> segs;
+            for (size_t b = nb * t / nt; b < nb * (t + 1) / nt; ++b) {
+                const BlockLog &B = work->blocks[b];
+                const EventLog *ev = work->events.data() + B.firstEvent;
+                rows.clear();
+                segs.clear();
+                int64_t columns = 0;
+                for (uint32_t e = 0; e < B.numEvents; ++e)
+                    columns += ev[e].k;
+                // appendColumn / updateEntry (halMafBlock.cpp:114-138, 370-395) for every entry, the row kept as runs
+                for (uint32_t j = 0; j < B.numEnts; ++j) {
+                    RowOut r{NULL_INDEX, 0, (uint32_t)segs.size(), 0, false};
+                    const int64_t srcLength = (*ranks)[(size_t)work->entRank[B.firstEnt + j]].srcLength;
+                    for (uint32_t e = 0; e < B.numEvents; ++e) {
+                        const PRow *p = work->pairs[ev[e].firstPair + j];
+                        const int64_t k = ev[e].k;
+                        const uint8_t kind = !p ? 0 : (p->rev ? 2 : 1);
+                        if (p) {
+                            if (r.start == NULL_INDEX) {
+                                r.start = p->pos - p->seqStart;
+                                r.rev = p->rev != 0;
+                                if (p->rev)
+                                    r.start = srcLength - 1 - r.start;
+                            }
+                            r.length += k;
+                        }
+                        const int64_t pos = p ? p->pos : 0;
+                        if (segs.size() > r.firstSeg) {
+                            Entry::Seg &l = segs.back();
+                            if (l.kind == kind && (int64_t)l.n + k < INT32_MAX &&
+                                (kind == 0 || (kind == 1 ? pos == l.pos + l.n : pos == l.pos - l.n))) {
+                                l.n += (int32_t)k;
+                                continue;
+                            }
+                        }
+                        for (int64_t left = k, at = pos; left > 0;) { // (a run longer than 2^31 - 1 columns is split)
+                            const int64_t m = std::min<int64_t>(left, INT32_MAX - 1);
+                            segs.push_back(Entry::Seg{at, (int32_t)m, kind});
+                            at += kind == 2 ? -m : m;
+                            left -= m;
+                        }
+                    }
+                    r.numSegs = (uint32_t)segs.size() - r.firstSeg;
+                    rows.push_back(r);
+                }
+                if (B.refEnt < 0)
+                    continue;
+                if (!keepEmptyRefBlocks && rows[(size_t)B.refEnt].start == NULL_INDEX)
+                    continue; // referenceIsAllGaps (halMafExport.cpp:70, 85)
+                // MafBlock's operator<< (halMafBlock.cpp:499-520): the reference row first, then the entries that have a start
+                auto row = [&](uint32_t j, int64_t start) {
+                    const RowOut &r = rows[j];
+                    const RankInfo &ri = (*ranks)[(size_t)work->entRank[B.firstEnt + j]];
+                    const std::string &nm = *(*names)[(size_t)ri.nameId];
+                    char *o = buf.room(nm.size() + 96 + (size_t)columns);
+                    char *const o0 = o;
+                    auto num = [&](int64_t v) { o = std::to_chars(o, o + 24, v).ptr; };
+                    *o++ = 's';
+                    *o++ = '\t';
+                    memcpy(o, nm.data(), nm.size());
+                    o += nm.size();
+                    *o++ = '\t';
+                    num(start);
+                    *o++ = '\t';
+                    num(r.length);
+                    *o++ = '\t';
+                    *o++ = r.rev ? '-' : '+';
+                    *o++ = '\t';
+                    num(ri.srcLength);
+                    *o++ = '\t';
+                    const std::vector<uint8_t> &d = al->img.genomes[(size_t)ri.genome].dna;
+                    const uint8_t *pk = d.data();
+                    for (uint32_t g = 0; g < r.numSegs; ++g) {
+                        const Entry::Seg &sg = segs[r.firstSeg + g];
+                        const int64_t n = sg.n;
+                        if (sg.kind == 0) {
+                            memset(o, '-', (size_t)n);
+                        } else if (d.empty()) {
+                            memset(o, 'N', (size_t)n);
+                        } else if (sg.kind == 1) { // dnaUnpack (halCommon.h:187-190), two bases per packed byte
+                            int64_t p0 = sg.pos, i = 0;
+                            if (i < n && (p0 & 1)) {
+                                o[i++] = fwd[pk[p0 >> 1] & 0x0F];
+                                ++p0;
+                            }
+                            for (; i + 1 < n; i += 2, p0 += 2)
+                                memcpy(o + i, &fwd2.v[pk[p0 >> 1]], 2);
+                            if (i < n)
+                                o[i] = fwd[pk[p0 >> 1] >> 4];
+                        } else { // reverse strand: walk left, complemented (reverseComplement, halCommon.h:45-75)
+                            int64_t p0 = sg.pos, i = 0;
+                            if (i < n && !(p0 & 1)) {
+                                o[i++] = rc[pk[p0 >> 1] >> 4];
+                                --p0;
+                            }
+                            for (; i + 1 < n; i += 2, p0 -= 2)
+                                memcpy(o + i, &rc2.v[pk[p0 >> 1]], 2);
+                            if (i < n)
+                                o[i] = rc[pk[p0 >> 1] & 0x0F];
+                        }
+                        o += n;
+                    }
+                    *o++ = '\n';
+                    buf.len += (size_t)(o - o0);
+                };
+                memcpy(buf.room(2), "a\n", 2);
+                buf.len += 2;
+                const uint32_t ref = (uint32_t)B.refEnt;
+                if (rows[ref].start == NULL_INDEX) {
+                    if (B.refIndex != NULL_INDEX)
+                        row(ref, B.refIndex);
+                } else {
+                    row(ref, rows[ref].start);
+                }
+                for (uint32_t j = 0; j < B.numEnts; ++j)
+                    if (rows[j].start != NULL_INDEX && j != ref)
+                        row(j, rows[j].start);
+                *buf.room(1) = '\n';
+                buf.len += 1;
+            }
+        };
+        if (nt == 1) {
+            render(0);
+        } else {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nt; ++t)
+                th.emplace_back(render, t);
+            for (std::thread &x : th)
+                x.join();
+        }
+        for (const TextBuffer &t : text)
+            out->write(t.data, (std::streamsize)t.len);
+    });
+}
 
 void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alignment, int genome, int seq, int64_t startPosition,
                                     int64_t length, const ColumnOptions &opt) {
+    typedef RunMachine::Chunk Chunk;
+    typedef RunMachine::PRow PRow;
     const GenomeTables &G = alignment->img.genomes[(size_t)genome];
     const int64_t first = startPosition + G.seqs[(size_t)seq].start;
     if (const char *e = getenv("HGX_MAF_CHUNK")) // (columns per device batch: tests cross batch ends with it)
         chunkColumns = (size_t)std::max<long long>(1, atoll(e));
-    struct SegModeGuard {
-        bool &f;
-        explicit SegModeGuard(bool &x) : f(x) { f = true; }
-        ~SegModeGuard() { f = false; }
-    } segModeGuard(_segMode);
-    _snapBlocks.clear();
-    _snapRows.clear();
-    _snapSegs.clear();
-    struct Chunk { // one device batch: which columns are heads, the heads' rows
-        int64_t done = 0, n = 0;
-        std::vector<uint8_t> head;
-        std::vector<uint32_t> headOff;
-        std::vector<ColumnRowHost> headRows;
-        double seconds = 0;
-    };
-    // (the next batch is walked by the device and copied while the state machine goes through this one)
+    // (the next batch is walked by the device, copied and sorted while the state machine goes through this one)
     auto fetch = [&](int64_t done) {
-        std::unique_ptr<Chunk> c(new Chunk);
+        std::shared_ptr<Chunk> c(new Chunk);
         c->done = done;
         c->n = std::min<int64_t>((int64_t)chunkColumns, length - done);
+        std::vector<ColumnRowHost> headRows;
         const auto t0 = std::chrono::steady_clock::now();
+        bool have = false;
 #ifdef HGX_HOST_PROFILE
         // profiling aid of the host state machine (make hostprof-lib, not part of libhgx.so): HGX_MAF_DUMP=file records the device's
         // batches, HGX_MAF_REPLAY=file plays them back to the state machine on a machine without a GPU
@@ -915,28 +1101,28 @@ void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alig
             c->n = (int64_t)hd[1];
             c->head.resize((size_t)c->n);
             c->headOff.resize((size_t)hd[2]);
-            c->headRows.resize((size_t)hd[3]);
+            headRows.resize((size_t)hd[3]);
             if (fread(c->head.data(), 1, c->head.size(), replay) != c->head.size() ||
                 fread(c->headOff.data(), 4, c->headOff.size(), replay) != c->headOff.size() ||
-                fread(c->headRows.data(), sizeof(ColumnRowHost), c->headRows.size(), replay) != c->headRows.size())
+                fread(headRows.data(), sizeof(ColumnRowHost), headRows.size(), replay) != headRows.size())
                 throw std::runtime_error("HGX_MAF_REPLAY: short file");
-            return c;
+            have = true;
         }
 #endif
-        for (;;) { // (a chunk's row offsets are 32-bit: very wide alignments get smaller chunks)
+        while (!have) { // (a chunk's row offsets are 32-bit: very wide alignments get smaller chunks)
             try {
-                columnsHeadRowsHost(alignment, genome, first + done, c->n, opt, true, c->head, c->headOff, c->headRows, &stats);
+                columnsHeadRowsHost(alignment, genome, first + done, c->n, opt, true, c->head, c->headOff, headRows, &stats);
 #ifdef HGX_HOST_PROFILE
                 if (dump) {
-                    const uint64_t hd[4] = {(uint64_t)done, (uint64_t)c->n, c->headOff.size(), c->headRows.size()};
+                    const uint64_t hd[4] = {(uint64_t)done, (uint64_t)c->n, c->headOff.size(), headRows.size()};
                     fwrite(hd, 8, 4, dump);
                     fwrite(c->head.data(), 1, c->head.size(), dump);
                     fwrite(c->headOff.data(), 4, c->headOff.size(), dump);
-                    fwrite(c->headRows.data(), sizeof(ColumnRowHost), c->headRows.size(), dump);
+                    fwrite(headRows.data(), sizeof(ColumnRowHost), headRows.size(), dump);
                     fflush(dump);
                 }
 #endif
-                break;
+                have = true;
             } catch (const ColumnChunkTooLarge &) {
                 if (c->n <= 1)
                     throw;
@@ -944,73 +1130,82 @@ void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alig
                 c->n = (int64_t)chunkColumns;
             }
         }
+        c->rows.resize(headRows.size());
+        const size_t heads = c->headOff.size() - 1;
+        auto convert = [&](size_t h0, size_t h1) {
+            for (size_t i = c->headOff[h0]; i < c->headOff[h1]; ++i)
+                RunMachine::describe(alignment->img, _rank, c->rows[i], headRows[i].genome, headRows[i].pos, headRows[i].rev != 0);
+            for (size_t h = h0; h < h1; ++h)
+                RunMachine::sortColumn(c->rows.data() + c->headOff[h], c->headOff[h + 1] - c->headOff[h]);
+        };
+        const size_t parts = heads >= 4096 ? 4 : 1;
+        std::vector<std::thread> helpers;
+        for (size_t t = 1; t < parts; ++t)
+            helpers.emplace_back(convert, heads * t / parts, heads * (t + 1) / parts);
+        convert(0, heads / parts);
+        for (std::thread &t : helpers)
+            t.join();
         c->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         return c;
     };
     double fetchSeconds = 0, waitSeconds = 0;
-    size_t numHeads = 0;
+    size_t numHeads = 0, numBlocks = 0;
     const auto tStart = std::chrono::steady_clock::now();
     {
         RunMachine R(*this, mafStream, _rank[(size_t)genome][(size_t)seq]);
-        std::future<std::unique_ptr<Chunk>> next = std::async(std::launch::async, fetch, (int64_t)0);
+        std::future<std::shared_ptr<Chunk>> next = std::async(std::launch::async, fetch, (int64_t)0);
         for (int64_t done = 0; done < length;) {
             const auto tw = std::chrono::steady_clock::now();
-            std::unique_ptr<Chunk> c = next.get();
+            std::shared_ptr<Chunk> c = next.get();
             waitSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
             const int64_t n = c->n;
             if (done + n < length)
                 next = std::async(std::launch::async, fetch, done + n);
             fetchSeconds += c->seconds;
             numHeads += c->headOff.size() - 1;
+            R.chunk = c;
+            R.batch->chunks.push_back(c);
             size_t hk = 0;
             for (int64_t i = 0; i < n;) {
-                // head column i: its rows come from the device
-                {
-                    MAF_TICK(7);
-                    R.curRows.assign(c->headRows.begin() + c->headOff[hk], c->headRows.begin() + c->headOff[hk + 1]);
-                }
+                // head column i: its rows come from the device; the columns up to the next head continue it
+                const PRow *rows = c->rows.data() + c->headOff[hk];
+                const size_t nr = c->headOff[hk + 1] - c->headOff[hk];
                 ++hk;
-                R.loadColumn();
-                R.step(startPosition + done + i);
-                int64_t run = 0; // the columns that follow and continue it
-                {
-                    MAF_TICK(8);
-                    while (i + 1 + run < n && !c->head[(size_t)(i + 1 + run)])
-                        ++run;
-                }
-                int64_t col = i + 1;
-                while (run > 0) {
-                    const int64_t t = R.appendContinuation(run);
-                    run -= t;
-                    col += t;
-                    if (run > 0) { // a block-length break or a sequence end: one ordinary column
-                        for (ColumnRowHost &r : R.curRows)
-                            r.pos += r.rev ? -1 : 1; // (the base itself is not needed: rows are kept as runs)
-                        R.loadColumn();
-                        R.step(startPosition + done + col);
-                        --run;
-                        ++col;
-                    }
+                int64_t left = 1;
+                while (i + left < n && !c->head[(size_t)(i + left)])
+                    ++left;
+                int64_t col = i;
+                for (;;) {
+                    R.addKeys(rows, nr);
+                    const int64_t k = R.place(rows, nr, left, startPosition + done + col);
+                    left -= k;
+                    col += k;
+                    if (left == 0)
+                        break;
+                    rows = R.advance(rows, nr, k); // a block-length break or a sequence end: an ordinary column next
                 }
                 i = col;
             }
             done += n;
         }
-        if (R.appendCount > 0 && (_keepEmptyRefBlocks || !referenceIsAllGaps()))
-            R.snapshot();
+        if (R.appendCount > 0)
+            R.endBlock();
+        R.flush();
+        numBlocks = R.numBlocks;
         if (getenv("HGX_MAF_TIMING"))
-            std::cerr << "[hgx maf] columns " << length << " heads " << numHeads << " blocks " << R.numBlocks << " state machine + waits "
+            std::cerr << "[hgx maf] columns " << length << " heads " << numHeads << " blocks " << numBlocks << " state machine + waits "
                       << std::chrono::duration<double>(std::chrono::steady_clock::now() - tStart).count() << " s, of which waiting for the device "
                       << waitSeconds << " s (fetches " << fetchSeconds << " s, device " << stats.rows_ms + stats.depth_ms << " ms)" << std::endl;
     }
-    flushSnapshots(mafStream);
     waitPendingWrite();
     mafStream.flush();
 #ifdef HGX_HOST_PROFILE
     if (getenv("HGX_MAF_TIMING")) {
-        static const char *what[] = {"loadColumn", "initBlock", "canAppend", "buildPairs", "appendColumn", "snapshot", "continuation", "rows copy", "run scan"};
-        for (int i = 0; i < 9; ++i)
+        static const char *what[] = {"", "initBlock", "canAppend", "pair + place"};
+        for (int i = 1; i < 4; ++i)
             std::cerr << "[hgx maf]   " << what[i] << " " << (double)g_mafTicks[i] / 1e6 << " Mticks" << std::endl;
+        std::cerr << "[hgx maf]   per block: entries " << (double)g_mafTicks[8] / numBlocks << " rows " << (double)g_mafTicks[9] / numBlocks << " keys "
+                  << (double)g_mafTicks[10] / numBlocks << std::endl;
     }
 #endif
     if (getenv("HGX_MAF_TIMING"))
