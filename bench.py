@@ -456,15 +456,35 @@ def main():
     if in_flight == 2:
         dt_1, _ = timed_steps(step_one, args.steps, sync)
         one_plan = {"ms_per_step": 1e3 * dt_1 / args.steps, "value": nq * args.steps / dt_1, "unit": "intervals/s", "steps": args.steps,
-                    "what": "hgx_liftover_run_device, one plan: every batch waited for before the next one is launched"}
+                    "what": "hgx_liftover_run_device, one plan: every batch waited for before the next one is launched.  A batch that "
+                            "runs by itself has its general intervals found by a pass of its own (k_lift_general_list) and finished by "
+                            "workgroups at the head of k_lift_classify's grid (hgx_liftover_plan_set_workers, the default); the batches "
+                            "kept in flight for `value` overlap their launches' tails and are spared that pass"}
+        # the kernels of these steps (HIP events around every launch, a loop of its own)
+        plan.set_timing(2)
+        for _ in range(args.steps):
+            plan.run(d_gs, d_ge, d_st)
+        kt_one = plan.kernel_times()
+        one_bytes = plan_kernel_bytes(kt_one, plan.stats(), args.steps)
+        one_plan["kernels_ms_per_step"] = {k: round(v["ms"] / args.steps, 4) for k, v in sorted(kt_one.items())}
+        one_plan["roofline_kernels"] = [
+            {"kernel": k, "kernel_avg_ms": v["ms"] / max(1, v["launches"]), "algorithmic_bytes_per_launch": one_bytes.get(k, 0.0),
+             "achieved": one_bytes.get(k, 0.0) / (v["ms"] / max(1, v["launches"]) * 1e-3) / 1e9 if v["ms"] > 0 else 0.0,
+             "frac": one_bytes.get(k, 0.0) / (v["ms"] / max(1, v["launches"]) * 1e-3) / 1e9 / HBM_PEAK_GBS if v["ms"] > 0 else 0.0}
+            for k, v in sorted(kt_one.items(), key=lambda kv: -kv[1]["ms"])]
+        plan.set_timing(1)
 
-    # ---- kernel times: the same steps again with HIP events around every launch (untimed) ----
+    # ---- kernel times: the steps of the timed region again with HIP events around every launch (untimed) — through one plan, in
+    # the form the batches in flight are launched in (no pass for the general intervals in front, see one_plan) ----
+    if in_flight == 2:
+        plan.set_workers(0)
     plan.set_timing(2)
     for _ in range(args.steps):
         plan.run(d_gs, d_ge, d_st)
     kt_total = plan.kernel_times()
     kt_acc = {k: {"ms": v["ms"], "launches": v["launches"]} for k, v in kt_total.items()}
     plan.set_timing(1)
+    plan.set_workers(-1)
 
     col_result = None
     if args.columns:
@@ -838,6 +858,9 @@ def plan_kernel_bytes(kt, st, steps, rec_bytes=16):
             # general interval clips (its own top slot)
             merged_records = kt.get("k_lift_merged", {}).get("top_derefs", 0)
             bytes_ = (16.0 + 4.0 + 8.0 + 4.0) * st["queries"] * steps + rec_bytes * (merged_records + t)
+        if name == "k_lift_general_list":
+            # the pass in front of k_lift_classify: interval ends, a bit per interval written
+            bytes_ = (16.0 + 0.125) * st["queries"] * steps
         if name in ("k_locate_expand", "k_locate_composed", "k_locate_through"):
             bytes_ += 24.0 * st["queries"] * steps
         if name in ("k_finish_fast", "k_finish_lds", "k_finish_big"):

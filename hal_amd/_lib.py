@@ -98,6 +98,7 @@ SYMBOLS = {
     "hgx_columns_depth_stats": (C.c_int, [VP, C.c_int, C.c_int64, C.c_int64, C.c_int64, P(hgx_column_opts), P(C.c_uint64), P(C.c_uint64),
                                           P(VP)]),
     "hgx_liftover_plan_set_timing": (C.c_int, [VP, C.c_int]),
+    "hgx_liftover_plan_set_workers": (C.c_int, [VP, C.c_int]),
     "hgx_liftover_plan_create": (C.c_int, [VP, C.c_int, C.c_int, P(hgx_liftover_opts), C.c_size_t, P(VP), P(VP)]),
     "hgx_liftover_plan_destroy": (None, [VP]),
     "hgx_liftover_run_device": (C.c_int, [VP, C.c_size_t, VP, VP, VP, VP, P(VP), P(C.c_size_t), P(VP)]),

@@ -644,11 +644,17 @@ class LiftoverPlan:
         if lib.hgx_liftover_plan_set_timing(self._p, mode) != 0:
             raise HgxError("set_timing failed")
 
+    def set_workers(self, n):
+        """hgx_liftover_plan_set_workers: < 0 the general intervals of a batch that runs by itself are found up front and finished by
+        workgroups at the head of the classifying launch when the last batch had few (default); 0 never; n > 0 always, n workgroups."""
+        if lib.hgx_liftover_plan_set_workers(self._p, n) != 0:
+            raise HgxError("set_workers failed")
+
     def kernel_times(self):
         import json
         js = C.c_void_p()
         if lib.hgx_liftover_kernel_times(self._p, C.byref(js)) != 0:
-            return {}
+            raise HgxError("kernel_times failed (the library says why on stderr)")
         try:
             return json.loads(C.string_at(js.value).decode())
         finally:

@@ -511,6 +511,9 @@ int hgx_liftover_kernel_times(hgx_liftover_plan *p, char **json) {
             return HGX_ERR;
         memcpy(*json, s.c_str(), s.size() + 1);
         return HGX_OK;
+    } catch (std::exception &e) { // (no error slot in this call's signature: the reason goes to stderr)
+        fprintf(stderr, "hgx_liftover_kernel_times: %s\n", e.what());
+        return HGX_ERR;
     } catch (...) {
         return HGX_ERR;
     }
@@ -537,9 +540,19 @@ int hgx_liftover_plan_set_timing(hgx_liftover_plan *p, int mode) {
     try {
         liftoverPlanSetTiming(p, mode);
         return HGX_OK;
+    } catch (std::exception &e) { // (no error slot in this call's signature: the reason goes to stderr)
+        fprintf(stderr, "hgx_liftover_plan_set_timing: %s\n", e.what());
+        return HGX_ERR;
     } catch (...) {
         return HGX_ERR;
     }
+}
+
+int hgx_liftover_plan_set_workers(hgx_liftover_plan *p, int n) {
+    if (!p)
+        return HGX_ERR;
+    liftoverPlanSetWorkers(p, n);
+    return HGX_OK;
 }
 
 static int convertOver(hgx_alignment *const *handles, int n_handles, int src, const char *bed_text, size_t bed_len, int tgt, int bed_type,

@@ -139,6 +139,7 @@ struct ComposedUp {
     // records before each entry.  Read by the single-pass kernels of hgx_lift_kernels.hpp.
     void *mRecs = nullptr;      // ComposedRec<int32_t>[mNum]: sLo, len, so = forward target start, mEncF = target strand | sequence << 8
     void *mBuckets = nullptr;   // uint32[buckets + 1]: the first merged record that touches the bucket
+    void *mFlagBits = nullptr;  // a bit per bucket: a flagged record touches it (k_lift_general_list)
     int mShift = 0;
     uint64_t mNum = 0, mFlagged = 0;
     int64_t mWindow = 0;        // intervals longer than this take the general path

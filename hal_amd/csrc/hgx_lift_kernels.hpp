@@ -104,6 +104,76 @@ template <typename C> struct alignas(16) LiftAsk {
     uint32_t k0, _pad;
 };
 
+// k_lift_general_list, in front of k_lift_classify when a plan's last run had few general intervals: which intervals must go the
+// general way, found from the batch alone — bits: a bit per bucket of the merged table, set where a flagged record touches the
+// bucket (hgx_merged_kernels.hpp: k_bucket_flag_bits); an interval with a flagged record among its own has such a bucket among
+// the ones it touches.  Yes as well for intervals longer than the table's window (general whatever their records), and for the
+// few that touch more buckets than two words of bits cover.  mask[q / 64]: those intervals as bits; list: the same as LIFT_LISTS
+// lists of listCap entries each, counts[l * LIFT_LIST_PITCH] long (a workgroup appends to the list of its index: one counter for
+// all of them is a queue of same-address atomics at the memory side, 15 ns each).  k_lift_classify's workers take the lists, its
+// tiles leave the intervals of the mask alone.  waveExtra / groupExtra: see k_lift_classify.
+static constexpr uint32_t LIFT_LISTS = 64, LIFT_LIST_PITCH = 16; // (counters 128 bytes apart)
+static __global__ void __launch_bounds__(256) k_lift_general_list(const int64_t *__restrict__ gStart, const int64_t *__restrict__ gEnd, uint32_t nq,
+                                                                  int64_t genomeLength, const uint32_t *__restrict__ bits, int shift, int64_t window,
+                                                                  unsigned long long *__restrict__ mask, uint32_t *__restrict__ list, uint32_t listCap,
+                                                                  unsigned long long *__restrict__ counts, uint32_t *__restrict__ waveExtra,
+                                                                  unsigned long long *__restrict__ groupExtra) {
+    // two intervals per thread (256 apart), their loads issued together: the kernel is two dependent round trips to memory and
+    // nothing else, and this way all its wavefronts are resident at once
+    const int lane = lane_id();
+    uint32_t q[2];
+    int64_t gs[2], ge[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        q[u] = blockIdx.x * 512u + (uint32_t)u * 256u + threadIdx.x;
+        gs[u] = 0;
+        ge[u] = -1;
+        if (q[u] < nq) {
+            gs[u] = gStart[q[u]];
+            ge[u] = gEnd[q[u]];
+        }
+    }
+    bool mine[2];
+    uint32_t w0[2], w1[2];
+    int64_t b0[2], nbk[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const bool valid = ge[u] >= gs[u] && gs[u] >= 0 && gs[u] < genomeLength;
+        b0[u] = valid ? gs[u] >> shift : 0;
+        nbk[u] = valid ? ((ge[u] < genomeLength ? ge[u] : genomeLength - 1) >> shift) - b0[u] + 1 : 0;
+        mine[u] = valid && (ge[u] - gs[u] >= window || nbk[u] > 32);
+        w0[u] = w1[u] = 0;
+        if (valid && !mine[u]) {
+            w0[u] = bits[b0[u] >> 5];
+            w1[u] = bits[(b0[u] >> 5) + 1];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if (nbk[u] > 0 && !mine[u]) {
+            const uint64_t both = ((uint64_t)w1[u] << 32) | w0[u];
+            mine[u] = (((uint32_t)(both >> (b0[u] & 31))) & (nbk[u] >= 32 ? 0xFFFFFFFFu : ((1u << nbk[u]) - 1u))) != 0;
+        }
+        // (the words the workers count their lines in, per 64 intervals and per group of 64 tiles: cleared here, in front of them)
+        if (q[u] < nq && lane == 0)
+            waveExtra[q[u] >> 6] = 0;
+        if (q[u] < nq && (q[u] & ((64u << LIFT_TILE_SHIFT) - 1u)) == 0)
+            groupExtra[q[u] >> (6 + LIFT_TILE_SHIFT)] = 0;
+        const unsigned long long m = __ballot(mine[u]);
+        if (q[u] < nq && lane == 0)
+            mask[q[u] >> 6] = m;
+        if (m) {
+            const uint32_t l = blockIdx.x % LIFT_LISTS;
+            unsigned long long at = 0;
+            if (lane == 0)
+                at = atomicAdd(&counts[l * LIFT_LIST_PITCH], (unsigned long long)__popcll(m));
+            at = __shfl(at, 0);
+            if (mine[u]) // (a list cannot run full: it holds every interval its workgroups look at)
+                list[(size_t)l * listCap + at + __popcll(m & ((1ull << lane) - 1ull))] = q[u];
+        }
+    }
+}
+
 // k_lift_classify, a workgroup per tile: kb[q] = {first record that overlaps interval q, number of records from there to the
 // last one that overlaps | KB_GENERAL}, nOut[q] = the interval's lines, waveTotal[q / 64] = the lines of a wavefront's 64
 // intervals.
@@ -119,6 +189,10 @@ template <typename C> struct alignas(16) LiftAsk {
 //   add their lines to the totals.  A general interval costs its own wavefront a handful of dependent memory round trips;
 //   in a launch of their own the same round trips were the batch's critical path.
 //   !INLINE (HGX_FINISH_WAVE=0, a cross-check): all of them are listed.
+//   workers > 0 (INLINE): the first `workers` workgroups of the grid are not tiles; they finish the general intervals
+//   k_lift_general_list found in the batch at the start of the launch (see there); the tiles leave those intervals alone (kb /
+//   nOut / offset are the workers' to write; their lines are counted in waveExtra and groupExtra, beside the tiles' waveTotal:
+//   k_lift_general_list has cleared them, k_lift_totals and k_lift_merged add them in).
 template <typename C, bool INLINE, int MINW>
 static __global__ void __launch_bounds__(256, MINW) k_lift_classify(const int64_t *__restrict__ gStart, const int64_t *__restrict__ gEnd,
                                                               const uint8_t *__restrict__ strand, uint32_t nq, int64_t genomeLength,
@@ -127,7 +201,11 @@ static __global__ void __launch_bounds__(256, MINW) k_lift_classify(const int64_
                                                               GeneralTable<C> GT, unsigned long long *kstat, unsigned long long *kstatStore,
                                                               uint32_t *__restrict__ offset,
                                                               uint32_t *__restrict__ nOut, uint32_t *__restrict__ lateList,
-                                                              unsigned long long *__restrict__ lateCount, uint32_t *__restrict__ waveTotal) {
+                                                              unsigned long long *__restrict__ lateCount, uint32_t *__restrict__ waveTotal,
+                                                              uint32_t workers, uint32_t *__restrict__ waveExtra,
+                                                              const unsigned long long *__restrict__ workMask, const uint32_t *__restrict__ workList,
+                                                              uint32_t workListCap, const unsigned long long *__restrict__ workCounts,
+                                                              unsigned long long *__restrict__ groupExtra) {
     __shared__ C sDAll[INLINE ? 4 : 1][INLINE ? 128 : 1];
     __shared__ uint8_t sOwnAll[INLINE ? 4 : 1][INLINE ? 64 : 1];
     __shared__ LiftAsk<C> sAsk[4][64];
@@ -137,7 +215,45 @@ static __global__ void __launch_bounds__(256, MINW) k_lift_classify(const int64_
     uint32_t generalSeen = 0, used = 0, generalLines = 0;
     const uint32_t nTiles = (nq + (uint32_t)LIFT_TILE - 1) >> LIFT_TILE_SHIFT;
     LIFT_PROF_DECL;
-    for (uint32_t tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
+    if (INLINE && blockIdx.x < workers) {
+        // ---- a worker: the general intervals k_lift_general_list found, a wavefront each, dealt round-robin.  The workgroups in
+        // front of the grid do this, so the general intervals of the whole batch are under way when the launch begins and not when
+        // their tile comes up (the last tiles' would otherwise end the launch one general interval's latency — two, three dependent
+        // round trips and finish_wave — after everything else).
+        // (lane l holds the length of list l and what is in the lists before it)
+        const uint32_t mine = (uint32_t)workCounts[(uint32_t)lane * LIFT_LIST_PITCH];
+        const uint32_t incl = wave_incl_scan<LiftSum>(mine);
+        const uint32_t nWork = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        for (uint32_t i = blockIdx.x * 4u + (uint32_t)w; i < nWork; i += workers * 4u) {
+            const int l = (int)__popcll(__ballot(incl <= i)); // the list item i is in
+            const uint32_t before = (uint32_t)__builtin_amdgcn_readlane((int)(incl - mine), l);
+            const uint32_t oq = (uint32_t)__builtin_amdgcn_readfirstlane((int)workList[(size_t)l * workListCap + (i - before)]);
+            const int64_t os = gStart[oq], oe = gEnd[oq];
+            int nl = 0;
+            uint32_t base = 0;
+            const int rc = general_interval<C>(lane, GT, oq, os, oe, strand[oq], sDAll[w], sOwnAll[w], used, nl, base LIFT_PROF_ARG);
+            if (lane == 0) {
+                if (rc == 0) // (its lines come later, or not at all: a run that does not make the launches behind this one is repeated)
+                    lateList[atomicAdd(lateCount, 1ull)] = oq;
+                kb[oq] = make_uint2(0u, KB_GENERAL);
+                offset[oq] = base;
+                nOut[oq] = (uint32_t)nl;
+                if (nl > 0) { // (the interval's tile counts its 64 without it)
+                    atomicAdd(&waveExtra[oq >> 6], (uint32_t)nl);
+                    atomicAdd(&groupExtra[oq >> (6 + LIFT_TILE_SHIFT)], (unsigned long long)nl);
+                }
+            }
+            generalSeen += lane == 0 ? 1u : 0u;
+            generalLines += lane == 0 ? (uint32_t)nl : 0u;
+        }
+        stat_add(&kstat[0], used);
+        stat_add(&kstat[1], generalSeen);
+        stat_add(&kstatStore[1], generalLines);
+        stat_add(&GT.counters[CNT_DSTAT0 + STAT_MAPPED], used);
+        return;
+    }
+    const uint32_t firstTile = INLINE ? blockIdx.x - workers : blockIdx.x;
+    for (uint32_t tile = firstTile; tile < nTiles; tile += gridDim.x - (INLINE ? workers : 0u)) {
         const uint32_t q = tile * (uint32_t)LIFT_TILE + threadIdx.x;
         int64_t gs = 0, ge = -1;
         if (q < nq) {
@@ -189,11 +305,19 @@ static __global__ void __launch_bounds__(256, MINW) k_lift_classify(const int64_
         // target? — to the records of a quad themselves spares a quarter of the general intervals at cfg2 and costs every
         // interval more than that saves: profiles/r02k_notes.md.)
         const bool general = valid && (cnt > 0 || (ans.y & 2u)) && ((ans.y & 3u) != 0 || ge - gs >= window);
-        if (q < nq)
+        // (with workers: the intervals they take — every one with a flagged record among its own, and then some — are theirs
+        // to answer; what is left for the tile is an interval with more records than the scan holds, which is listed)
+        const bool theirs = INLINE && workers != 0 && q < nq && ((workMask[q >> 6] >> lane) & 1ull) != 0;
+        if (q < nq && !theirs)
             kb[q] = general ? make_uint2(0u, KB_GENERAL) : cnt ? make_uint2(ans.z, ans.w - ans.z + 1u) : make_uint2(0u, 0u);
-        generalSeen += general ? 1u : 0u;
+        generalSeen += general && !theirs ? 1u : 0u;
         LIFT_PROF(1) // counted
-        if (INLINE) {
+        if (INLINE && workers != 0) {
+            if (general && !theirs)
+                lateList[atomicAdd(lateCount, 1ull)] = q;
+            if (general || theirs)
+                cnt = 0;
+        } else if (INLINE) {
             unsigned long long gm = __ballot(general);
             while (gm) { // (rare: about one wavefront in fifteen meets one at cfg2)
                 const int o = __ffsll((long long)gm) - 1;
@@ -217,7 +341,7 @@ static __global__ void __launch_bounds__(256, MINW) k_lift_classify(const int64_
             lateList[atomicAdd(lateCount, 1ull)] = q;
             cnt = 0;
         }
-        if (q < nq)
+        if (q < nq && !theirs)
             nOut[q] = cnt;
         // (no barrier: a wavefront that met a general interval does not keep the other three waiting)
         const uint32_t waveLines = wave_total(cnt);
@@ -350,7 +474,8 @@ __device__ __forceinline__ void lift_wave_emit(const ComposedRec<C> *__restrict_
     }
 }
 
-// kb, nOut, waveTotal, groupTotal: k_lift_classify's and k_lift_totals' answers; genOffset /
+// kb, nOut, waveTotal, groupTotal: k_lift_classify's and k_lift_totals' answers (waveExtra: the lines its workers counted, null
+// in a run without them); genOffset /
 // genRecords: where the general path left the records of the general intervals (nOut[q] records at genRecords +
 // genOffset[q]); out / outCap: the dense output; outOffset[q]: first record of interval q in it.
 template <typename C, int MINW>
@@ -360,7 +485,7 @@ static __global__ void __launch_bounds__(256, MINW) k_lift_merged(const int64_t 
                                                             int tNumSeq, const uint32_t *__restrict__ genOffset,
                                                             const hgx_record *__restrict__ genRecords, hgx_record *__restrict__ out,
                                                             uint32_t outCap, const uint32_t *__restrict__ nOut, uint32_t *__restrict__ outOffset,
-                                                            const uint32_t *__restrict__ waveTotal,
+                                                            const uint32_t *__restrict__ waveTotal, const uint32_t *__restrict__ waveExtra,
                                                             const unsigned long long *__restrict__ groupTotal, uint32_t nTiles) {
     __shared__ __attribute__((aligned(16))) uint8_t sStripAll[4][LIFT_STRIP];
     __shared__ LiftIv<C> sIvAll[4][64];
@@ -396,7 +521,7 @@ static __global__ void __launch_bounds__(256, MINW) k_lift_merged(const int64_t 
         const uint32_t g = tile >> 6, j = tile & 63u;
         const uint32_t nWaves = (nq + 63u) >> 6;
         const uint32_t peer = (g << 8) + threadIdx.x;
-        const uint32_t peerLines = peer < nWaves && threadIdx.x < 4u * j + 4u ? waveTotal[peer] : 0u;
+        const uint32_t peerLines = peer < nWaves && threadIdx.x < 4u * j + 4u ? waveTotal[peer] + (waveExtra ? waveExtra[peer] : 0u) : 0u;
         unsigned long long before = 0;
         for (uint32_t g0 = 0; g0 < g; g0 += 64u)
             before += g0 + (uint32_t)lane < g ? groupTotal[g0 + (uint32_t)lane] : 0ull;
@@ -454,7 +579,7 @@ static __global__ void __launch_bounds__(256, MINW) k_lift_merged(const int64_t 
 
 // k_lift_totals, one workgroup between the counting and the storing launch:
 //   groupTotal[g] = the lines of the 64 tiles (256 wavefronts' worth of intervals) of group g — after the finishing kernels have
-//   added theirs to waveTotal —, *total = all lines, CNT_OVERFLOW if they do not fit the output (k_lift_merged then leaves
+//   added theirs to waveTotal, and with what k_lift_classify's workers counted in waveExtra —, *total = all lines, CNT_OVERFLOW if they do not fit the output (k_lift_merged then leaves
 //   the tiles beyond it alone and the host repeats the batch with larger buffers);
 //   folds the spread statistics words (hgx_liftover_kernels.hpp: stat_add) and writes everything the host wants to know of
 //   the batch into LIFT_RB_WORDS words of host memory (rb is mapped pinned memory: no copy behind the last launch):
@@ -464,11 +589,12 @@ static __global__ void __launch_bounds__(256, MINW) k_lift_merged(const int64_t 
 //   leaves the words the next single-pass run counts in zeroed (the scalar slots, the level-0 append counters, the
 //   statistics copies, the list counts): a batch then needs no memsets.  (k_lift_merged counts nothing.)
 static constexpr int LIFT_RB_WORDS = 16;
-static __global__ void __launch_bounds__(1024) k_lift_totals(const uint32_t *__restrict__ waveTotal, uint32_t nWaves, uint32_t nGroups,
+static __global__ void __launch_bounds__(1024) k_lift_totals(const uint32_t *__restrict__ waveTotal, const unsigned long long *__restrict__ groupExtra,
+                                                             uint32_t nWaves, uint32_t nGroups,
                                                              unsigned long long *__restrict__ groupTotal, uint32_t outCap,
                                                              uint32_t *__restrict__ total, unsigned long long *counters,
                                                              unsigned long long *generalCount, unsigned long long *restCount,
-                                                             int storeLaunch, unsigned long long *rb) {
+                                                             unsigned long long *workCounts, int storeLaunch, unsigned long long *rb) {
     __shared__ unsigned long long sums[7], sGrand[16], sFast;
     const int w = (int)threadIdx.x, lane = lane_id(), wv = w >> 6;
     unsigned long long grand = 0;
@@ -489,7 +615,8 @@ static __global__ void __launch_bounds__(1024) k_lift_totals(const uint32_t *__r
 #pragma unroll
         for (uint32_t b = 0; b < 4; ++b) {
             const uint32_t g = g0 + 16u * b;
-            const unsigned long long t = wave_sum64(part[b]);
+            // (+ the lines k_lift_classify's workers made for intervals of the group)
+            const unsigned long long t = wave_sum64(part[b]) + (groupExtra && g < nGroups ? groupExtra[g] : 0ull);
             if (lane == 0 && g < nGroups)
                 groupTotal[g] = t;
             grand += t;
@@ -536,6 +663,8 @@ static __global__ void __launch_bounds__(1024) k_lift_totals(const uint32_t *__r
         *restCount = 0;
     if (w == 1)
         *generalCount = 0;
+    if (w >= 64 && w < 64 + (int)LIFT_LISTS && workCounts)
+        workCounts[(size_t)(w - 64) * LIFT_LIST_PITCH] = 0;
 #ifdef HGX_LIFT_PROFILE
     __shared__ unsigned long long profSum[8];
     if (w < 8)

@@ -180,6 +180,8 @@ DeviceImage::~DeviceImage() {
             (void)hipFree(kv.second.mRecs);
         if (kv.second.mBuckets)
             (void)hipFree(kv.second.mBuckets);
+        if (kv.second.mFlagBits)
+            (void)hipFree(kv.second.mFlagBits);
     }
     if (desc)
         (void)hipFree(desc);
@@ -618,7 +620,7 @@ struct hgx_liftover_plan {
     DevBuf fr[6][6], mp[2][6], counters, perQuery, offset, cursor, nOut, outOffset, blockSums, total, grouped, outRecords,
         deferredList, needCap, bigSlot, scratch, bigRecords, classLists, classCounts;
     // single-pass path over the merged table (hgx_lift_kernels.hpp)
-    DevBuf liftKb, liftStatus;
+    DevBuf liftKb, liftStatus, liftWorkMask, liftWorkCounts;
     int liftLaunches = 0;        // launches of the last single-pass run that keep statistics
     bool liftWaveFinish = true;
     // hgx_liftover_submit / _collect: a batch whose launches are queued (1) or that has been run to the end already (2)
@@ -634,6 +636,10 @@ struct hgx_liftover_plan {
     unsigned long long generalQueries = 0, liftRestCount = 0;
     bool liftRestSeen = false, liftRestSkipped = false; // (see runMergedOnce: the launches behind k_lift_classify for what it passes on)
     bool liftStateClean = false; // the counters are zero (left so by the last run's k_lift_totals)
+    size_t liftTilesCap = 0, liftGroupsCap = 0; // tiles, groups of 64 tiles liftStatus has room for
+    uint32_t liftWorkers = 0;    // workgroups of k_lift_classify that go for the general intervals first (from the last run's count)
+    unsigned long long liftLastQueries = 0;
+    int liftWorkersWanted = -1;  // hgx_liftover_plan_set_workers
     // scratch of the single-pass runs for intervals that outgrow the LDS finishing kernel (k_finish_big without a host
     // synchronisation in between): liftBigSlots slices for liftBigCap pieces each, grown when a run needed more
     uint32_t liftBigSlots = 0;
@@ -711,7 +717,12 @@ struct hgx_liftover_plan {
         classLists.ensure(4 * 4 * (nq + 1));
         classCounts.ensure(32);
         liftKb.ensure(8 * (nq + 1));
-        liftStatus.ensure(16 * ((nq + LIFT_TILE - 1) / LIFT_TILE) + 8 * ((nq + 64 * LIFT_TILE - 1) / (64 * LIFT_TILE)) + 16);
+        liftTilesCap = std::max(liftTilesCap, (nq + LIFT_TILE - 1) / LIFT_TILE);
+        // [lines k_lift_classify's workers add per 64 intervals | the same per group of 64 tiles | lines per 64 intervals | lines per group]
+        liftGroupsCap = std::max(liftGroupsCap, (nq + 64 * LIFT_TILE - 1) / (64 * LIFT_TILE));
+        liftStatus.ensure(32 * liftTilesCap + 16 * liftGroupsCap + 16);
+        liftWorkMask.ensure(8 * ((nq + 63) / 64 + 1));
+        liftWorkCounts.ensure(8 * LIFT_LISTS * LIFT_LIST_PITCH);
     }
 };
 
@@ -763,12 +774,16 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
     const ComposedUp &T = *P.composed;
     unsigned long long *cnt = (unsigned long long *)P.counters.p;
     const uint32_t cap = P.cap, nq = (uint32_t)n;
+    P.liftLastQueries = n;
     const int64_t srcLength = P.h->img.genomes[(size_t)P.src].totalLength;
     const DeviceGenome &TG = D.genomes[(size_t)P.tgt];
     const uint32_t nTiles = (nq + LIFT_TILE - 1) / LIFT_TILE, nGroups = (nTiles + 63) / 64;
     // lines per 64 intervals (k_lift_classify, + the finishing kernels) and per group of 64 tiles (k_lift_totals)
-    uint32_t *waveTotal = (uint32_t *)P.liftStatus.p;
-    unsigned long long *groupTotal = (unsigned long long *)P.liftStatus.p + 2 * (size_t)nTiles; // (behind the 4 * nTiles 32-bit words)
+    // (+ what k_lift_classify's workers count beside them, in a run that has workers)
+    uint32_t *waveExtra = (uint32_t *)P.liftStatus.p;
+    unsigned long long *groupExtra = (unsigned long long *)(waveExtra + 4 * P.liftTilesCap);
+    uint32_t *waveTotal = (uint32_t *)(groupExtra + P.liftGroupsCap);
+    unsigned long long *groupTotal = (unsigned long long *)waveTotal + 2 * (size_t)nTiles; // (behind the 4 * nTiles 32-bit words)
     uint32_t *generalList = (uint32_t *)P.classLists.p;
     unsigned long long *generalCount = (unsigned long long *)P.classCounts.p;
     // the words this run counts in were left zeroed by the previous single-pass run's epilogue; otherwise (first run, another
@@ -779,6 +794,7 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
         HIP_OK(hipMemsetAsync(cnt, 0, 8 * CNT_DEV_SLOTS, s));
         HIP_OK(hipMemsetAsync(P.liftStatus.p, 0, P.liftStatus.n, s));
         HIP_OK(hipMemsetAsync(generalCount, 0, 32, s));
+        HIP_OK(hipMemsetAsync(P.liftWorkCounts.p, 0, P.liftWorkCounts.n, s));
     }
     const bool events = P.timer.mode != 0; // (walk_ms / total_ms of the statistics need three event records per run)
     if (events)
@@ -799,11 +815,31 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
     // (the launches behind k_lift_classify for what it passes on are made only once a run of this plan has passed something on)
     P.liftRestSkipped = waveFinish && !P.liftRestSeen;
     const int storeLaunch = P.liftRestSkipped ? 1 : 2; // k_lift_merged's place among the launches that keep statistics
+    // workers: the last run's general intervals were few enough to be looked for up front (HGX_LIFT_WORKERS: their number, 0 = none)
+    // (a batch that is launched and left — others are in flight beside it — overlaps its launches' tails with theirs: the pass
+    // over its intervals would be work added, not time saved)
+    uint32_t workers = !waveFinish ? 0u : P.liftWorkersWanted >= 0 ? (uint32_t)P.liftWorkersWanted : launchOnly ? 0u : P.liftWorkers;
+    if (const char *e = getenv("HGX_LIFT_WORKERS"))
+        workers = waveFinish ? (uint32_t)std::max(0, atoi(e)) : 0u;
+    // (the lists: the third and fourth quarter of classLists, a list's room = what its workgroups look at and more)
+    uint32_t *workList = generalList + 2 * (size_t)nq;
+    const uint32_t workListCap = (((nq + 511) / 512 + LIFT_LISTS - 1) / LIFT_LISTS) * 512;
+    unsigned long long *workCounts = (unsigned long long *)P.liftWorkCounts.p;
+    if (workers && (size_t)workListCap * LIFT_LISTS > 2 * (size_t)nq + 2)
+        workers = 0; // (a batch of a few hundred intervals: no room for 64 lists, and nothing to gain)
+    if (workers) {
+        P.timer.begin("k_lift_general_list", s);
+        hipLaunchKernelGGL(k_lift_general_list, dim3((nq + 511) / 512), dim3(256), 0, s, dS, dE, nq, srcLength, (const uint32_t *)T.mFlagBits, T.mShift,
+                           T.mWindow, (unsigned long long *)P.liftWorkMask.p, workList, workListCap, workCounts, waveExtra, groupExtra);
+        P.timer.end(s);
+    }
     P.timer.begin("k_lift_classify", s, launch);
 #define HGX_CLASSIFY(INL, W)                                                                                                                 \
-    hipLaunchKernelGGL((k_lift_classify<C, INL, W>), dim3(std::max<uint32_t>(1, nTiles)), dim3(256), 0, s, dS, dE, dStrand, nq, srcLength,     \
-                       (const uint32_t *)T.mBuckets, T.mShift, T.mWindow, (const ComposedRec<C> *)T.mRecs, (uint2 *)P.liftKb.p, GT, kstat(),    \
-                       cnt + CNT_DSTAT0 + STAT_LAUNCH0 + 2 * storeLaunch, (uint32_t *)P.offset.p, (uint32_t *)P.nOut.p, (uint32_t *)lateList, lateCount, waveTotal)
+    hipLaunchKernelGGL((k_lift_classify<C, INL, W>), dim3(std::max<uint32_t>(1, nTiles) + workers), dim3(256), 0, s, dS, dE, dStrand, nq,     \
+                       srcLength, (const uint32_t *)T.mBuckets, T.mShift, T.mWindow, (const ComposedRec<C> *)T.mRecs, (uint2 *)P.liftKb.p, GT,\
+                       kstat(), cnt + CNT_DSTAT0 + STAT_LAUNCH0 + 2 * storeLaunch, (uint32_t *)P.offset.p, (uint32_t *)P.nOut.p,              \
+                       (uint32_t *)lateList, lateCount, waveTotal, workers, waveExtra, (const unsigned long long *)P.liftWorkMask.p,         \
+                       (const uint32_t *)workList, workListCap, (const unsigned long long *)workCounts, groupExtra)
     if (!waveFinish) {
         HGX_CLASSIFY(false, 1);
     } else if constexpr (sizeof(C) == 8) {
@@ -855,15 +891,17 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
     }
     // all lines, the groups' lines, the statistics — and everything the host wants to know goes to pinned memory from here
     P.timer.begin("k_lift_totals", s);
-    hipLaunchKernelGGL(k_lift_totals, dim3(1), dim3(1024), 0, s, (const uint32_t *)waveTotal, 4 * nTiles, nGroups, groupTotal, cap, (uint32_t *)P.total.p,
-                       cnt, generalCount, waveFinish ? restCount : (unsigned long long *)nullptr, storeLaunch, P.pinnedDev + CNT_SLOTS + 1);
+    hipLaunchKernelGGL(k_lift_totals, dim3(1), dim3(1024), 0, s, (const uint32_t *)waveTotal, workers ? (const unsigned long long *)groupExtra : nullptr, 4 * nTiles, nGroups,
+                       groupTotal, cap, (uint32_t *)P.total.p, cnt, generalCount, waveFinish ? restCount : (unsigned long long *)nullptr, workCounts,
+                       storeLaunch, P.pinnedDev + CNT_SLOTS + 1);
     P.timer.end(s);
     P.timer.begin("k_lift_merged", s, launch);
 #define HGX_LIFT(W)                                                                                                                          \
     hipLaunchKernelGGL((k_lift_merged<C, W>), dim3(std::min<uint32_t>((uint32_t)P.liftGrid, nTiles)), dim3(256), 0, s, dS, dE, dStrand, nq,     \
                        (const uint2 *)P.liftKb.p, (const ComposedRec<C> *)T.mRecs, (const int64_t *)TG.seqStart, (int)TG.numSeq,             \
                        (const uint32_t *)P.offset.p, (const hgx_record *)P.grouped.p, (hgx_record *)P.outRecords.p, cap,                     \
-                       (const uint32_t *)P.nOut.p, (uint32_t *)P.outOffset.p, waveTotal, groupTotal, nTiles)
+                       (const uint32_t *)P.nOut.p, (uint32_t *)P.outOffset.p, waveTotal, workers ? (const uint32_t *)waveExtra : nullptr, groupTotal, \
+                       nTiles)
     if (P.liftMinWaves == 8)
         HGX_LIFT(8);
     else
@@ -896,6 +934,12 @@ static void finishMergedOnce(hgx_liftover_plan &P, hipStream_t s, unsigned long 
     // (an overflowing or failing run may have left counters beyond the ones the epilogue clears)
     P.liftStateClean = !hrb[CNT_OVERFLOW] && !hrb[CNT_DEFERRED] && !(getenv("HGX_LIFT_MEMSETS") != nullptr);
     P.generalQueries = P.liftWaveFinish ? hrb[14] : hrb[12];
+    // the next run's workers: about a wavefront per general interval of this one, when they are a small part of the batch
+    // (a batch of long intervals is all general: the tiles' own wavefronts are the many hands then)
+    {
+        const unsigned long long g = P.generalQueries, nqLast = P.liftLastQueries;
+        P.liftWorkers = g > 0 && g * 64 <= nqLast ? (uint32_t)std::min<unsigned long long>(1024, std::max<unsigned long long>(32, (g * 3 / 2 + 3) / 4)) : 0u;
+    }
     P.liftRestCount = hrb[13];
 }
 
@@ -1797,12 +1841,18 @@ template <typename C> static void buildMerged(hgx_alignment *h, int src, int dst
     starts.ensure(((size_t)nb + 1) * 4);
     HIP_OK(hipMemsetAsync(coarse.p, 0xFF, ((size_t)nb + 1) * 4, s));
     HIP_OK(hipMalloc(&c.mBuckets, ((size_t)nb + 1) * 4));
+    const size_t flagBitsBytes = 4 * (((size_t)nb + 1) / 32 + 3);
+    HIP_OK(hipMalloc(&c.mFlagBits, flagBitsBytes));
+    HIP_OK(hipMemsetAsync(c.mFlagBits, 0, flagBitsBytes, s));
     if (m)
         hipLaunchKernelGGL((k_table_touch<C>), dim3(gridM), dim3(256), 0, s, (const ComposedRec<C> *)mrecs, (uint32_t)m, shift, (uint32_t *)coarse.p);
     const unsigned gridB = (unsigned)(((size_t)nb + 1 + 255) / 256);
     hipLaunchKernelGGL((k_table_starts<C>), dim3(gridB), dim3(256), 0, s, (const ComposedRec<C> *)mrecs, (uint32_t)m, shift, nb, (uint32_t *)starts.p);
     hipLaunchKernelGGL(k_table_fill, dim3(gridB), dim3(256), 0, s, (uint32_t *)coarse.p, (const uint32_t *)starts.p, nb);
     HIP_OK(hipMemcpyAsync(c.mBuckets, coarse.p, ((size_t)nb + 1) * 4, hipMemcpyDeviceToDevice, s));
+    if (m)
+        hipLaunchKernelGGL((k_bucket_flag_bits<C>), dim3(gridM), dim3(256), 0, s, (const ComposedRec<C> *)mrecs, (const uint32_t *)flag.p, (uint32_t)m, shift,
+                           (uint32_t *)c.mFlagBits);
     hipLaunchKernelGGL((k_merge_mark<C>), dim3((unsigned)((m + LIFT_SENTINELS + 255) / 256)), dim3(256), 0, s, mrecs, (const uint32_t *)flag.p, (uint32_t)m);
     unsigned int flagged = 0;
     HIP_OK(hipMemcpyAsync(&flagged, (const uint32_t *)flagPrefix.p + m, 4, hipMemcpyDeviceToHost, s));
@@ -1812,7 +1862,7 @@ template <typename C> static void buildMerged(hgx_alignment *h, int src, int dst
     c.mNum = m;
     c.mFlagged = flagged;
     c.mWindow = window;
-    h->dev->bytes += (m + LIFT_SENTINELS) * sizeof(ComposedRec<C>) + ((size_t)nb + 1) * 4;
+    h->dev->bytes += (m + LIFT_SENTINELS) * sizeof(ComposedRec<C>) + ((size_t)nb + 1) * 4 + flagBitsBytes;
     c.mBuildMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
@@ -1984,6 +2034,10 @@ void liftoverPlanCopyRecords(const hgx_liftover_plan *p, void *dDst, size_t nRec
     if (nRecords)
         HIP_OK(hipMemcpyAsync(dDst, p->outRecords.p, nRecords * sizeof(hgx_record), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+}
+
+void liftoverPlanSetWorkers(hgx_liftover_plan *p, int n) {
+    p->liftWorkersWanted = n;
 }
 
 void liftoverPlanSetTiming(hgx_liftover_plan *p, int mode) {

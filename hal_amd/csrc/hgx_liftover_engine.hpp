@@ -20,6 +20,7 @@ std::string liftoverPlanKernelTimes(hgx_liftover_plan *p);
 // phases of the last table build of this process (HGX_BUILD_TIMING), as a JSON list of [name, ms]
 std::string liftoverBuildPhases();
 void liftoverPlanSetTiming(hgx_liftover_plan *p, int mode);
+void liftoverPlanSetWorkers(hgx_liftover_plan *p, int n);
 void liftoverPlanCopyRecords(const hgx_liftover_plan *p, void *dDst, size_t nRecords, void *stream);
 void liftoverPlanCopyRecordsPacked(const hgx_liftover_plan *p, void *dDst, size_t nRecords, void *stream);
 size_t liftoverPlanWireBlob(hgx_liftover_plan *p, void *dDst, size_t capacity, int64_t firstQuery, int *format, void *stream);

@@ -346,4 +346,17 @@ static __global__ void __launch_bounds__(256) k_merge_mark(ComposedRec<C> *__res
     }
 }
 
+// ---- which buckets a flagged record touches: k_lift_general_list finds the intervals that must go the general way from these
+// bits alone (hgx_lift_kernels.hpp) ----
+// bits[b >> 5] bit (b & 31): a flagged record touches bucket b (two words of slack behind the last bucket's)
+template <typename C>
+static __global__ void __launch_bounds__(256) k_bucket_flag_bits(const ComposedRec<C> *__restrict__ recs, const uint32_t *__restrict__ flag,
+                                                                 uint32_t m, int shift, uint32_t *__restrict__ bits) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m || !flag[j])
+        return;
+    const int64_t lo = (int64_t)recs[j].sLo, hi = lo + (int64_t)recs[j].len - 1;
+    for (int64_t b = lo >> shift; b <= (hi >> shift); ++b)
+        atomicOr(&bits[b >> 5], 1u << (b & 31));
+}
 } // namespace hgx

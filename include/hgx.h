@@ -242,6 +242,13 @@ int hgx_liftover_last_stats(const hgx_liftover_plan *p, hgx_liftover_stats *out)
  * read (for a benchmark loop: the elapsed-time queries then happen once, outside the loop), 0 = no events at all. */
 int hgx_liftover_kernel_times(hgx_liftover_plan *p, char **json);
 int hgx_liftover_plan_set_timing(hgx_liftover_plan *p, int mode);
+/* The general intervals of a single-pass batch (kind 3; BlockMapper's general algorithm, liftover/impl/halBlockMapper.cpp:331-394,
+ * for the few intervals whose records overlap on the target) can be found in a pass of their own in front of the classifying
+ * launch and finished by workgroups at the head of its grid, so that the launch does not end one such interval's latency after
+ * its last tile.  n < 0 (default): done when a plan's last batch had few of them and the batch runs by itself
+ * (hgx_liftover_run_device) — batches kept in flight (hgx_liftover_submit_device) overlap their launches' tails anyway and are
+ * spared the extra pass over their intervals; 0: never; n > 0: always, with n workgroups.  Same records either way. */
+int hgx_liftover_plan_set_workers(hgx_liftover_plan *p, int n);
 /* Where a plan's change-over to its table spent its time: with HGX_BUILD_TIMING=2 in the environment (1: also printed to
  * stderr) the run that builds a table synchronises the device at every phase boundary and keeps the wall time of each phase —
  * builder plan, walk of every source segment, sorts, records, bucket tables, junction sort, chains, flags, the releases of the

@@ -100,3 +100,50 @@ def test_batches_with_long_intervals_in_flight(hal):
         with torch.cuda.stream(streams[k]):
             assert torch.equal(plans[k].records_to_tensor(ptr, nrec).cpu(), want[inflight[k]]), inflight[k]
     assert ref_plan.stats()["general_queries"] > 0
+
+
+def test_general_intervals_by_worker_workgroups(hal, monkeypatch):
+    """k_lift_classify's workers (hgx_lift_kernels.hpp): the workgroups in front of the grid find the general intervals of the whole
+    batch from the bucket entries and finish them while the tiles are classified.  Same records whether the general intervals
+    are finished by the wavefronts that meet them (no workers: a plan's first run), by few or many workers, or — what a plan
+    does by itself — by as many as its last run's count suggests."""
+    import torch
+    opts = hal.RandOptions(mean_degree=2.0, max_branch_length=3.0, min_genomes=2, max_genomes=50, min_segment_length=20,
+                           max_segment_length=80, min_segments=1500, max_segments=3000, seed=0, with_dna=False)
+    al = hal.Alignment.random(opts, device=0)
+    names = [al.genome_name(g) for g in range(al.num_genomes)]
+    src = al.genome_id("Genome_44") if "Genome_44" in names else al.num_genomes - 1
+    tgt = al.genome_id("Genome_2")
+    _, ss, length = al.sequences(src)[0]
+    n = 70000
+    batches = []
+    for b, maxlen in enumerate((300, 3000, 60, 12000)):
+        g = torch.Generator().manual_seed(300 + b)
+        starts = torch.randint(0, max(1, length - maxlen - 1), (n,), generator=g)
+        lens = torch.randint(1, maxlen, (n,), generator=g)
+        st = torch.where(torch.rand(n, generator=g) < 0.5, ord("+"), ord("-")).to(torch.uint8).cuda()
+        batches.append(((starts + ss).cuda(), (starts + lens - 1 + ss).clamp(max=ss + length - 1).cuda(), st))
+
+    def run(plan):
+        out = []
+        for gs, ge, st in batches:
+            ptr, nrec = plan.run(gs, ge, st)
+            out.append(plan.records_to_tensor(ptr, nrec).cpu())
+        return out
+
+    monkeypatch.setenv("HGX_LIFT_WORKERS", "0")
+    plan = hal.LiftoverPlan(al, src, tgt, max_queries=n)
+    want = run(plan)
+    assert plan.stats()["composed_kind"] == 3 and plan.stats()["general_queries"] > 0
+    for workers in ("3", "64", "1024"):
+        monkeypatch.setenv("HGX_LIFT_WORKERS", workers)
+        plan = hal.LiftoverPlan(al, src, tgt, max_queries=n)
+        got = run(plan)
+        assert plan.stats()["general_queries"] > 0
+        for a, b in zip(got, want):
+            assert torch.equal(a, b), workers
+    monkeypatch.delenv("HGX_LIFT_WORKERS")
+    plan = hal.LiftoverPlan(al, src, tgt, max_queries=n)
+    for _ in range(3):  # (the first run has no count to go by; the later ones do)
+        for a, b in zip(run(plan), want):
+            assert torch.equal(a, b)
