@@ -544,21 +544,41 @@ struct SweepChildren {
     SweepChild c[SWEEP_MAX_CHILDREN];
     int n;
 };
-// sixteen lanes per bottom segment, four bases per lane and round: four segments' dependent loads (segment bounds, child link,
-// child record, ring links) are in flight per wavefront instead of one
+// sixteen lanes per bottom segment — four segments' dependent loads (segment bounds, child link, child record, ring links) are
+// in flight per wavefront instead of one —, and every lane moves 8 bytes of consecutive bases of the track (16 of 64-bit sets) as one
+// word (a child in the other orientation: the word at the mirrored place, its elements taken back to front).  The tracks start
+// where their segments start: the words are not aligned (global accesses need not be); the last word of a segment goes
+// element by element.
+template <typename M> struct SweepVec {
+    static constexpr int N = sizeof(M) >= 8 ? 2 : 8 / (int)sizeof(M);
+    M e[N];
+};
+template <typename T> __device__ __forceinline__ T sweep_load(const void *p) {
+    T v;
+    __builtin_memcpy(&v, p, sizeof(T));
+    return v;
+}
+template <typename T> __device__ __forceinline__ void sweep_store(void *p, const T &v) {
+    __builtin_memcpy(p, &v, sizeof(T));
+}
 template <typename C, typename M, bool SUM>
 static __global__ void __launch_bounds__(256) k_sweep_up(const BotRec<C> *__restrict__ bot, int64_t numBot, SweepChildren ch, M own, int accumulate,
                                                          M *__restrict__ S) {
+    constexpr int V = SweepVec<M>::N;
     const int sub = (int)(threadIdx.x & 15);
     const int64_t groupsTotal = ((int64_t)gridDim.x * blockDim.x) >> 4;
     for (int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; b < numBot; b += groupsTotal) {
         const int64_t start = (int64_t)bot[b].start, len = (int64_t)bot[b + 1].start - start;
-        for (int64_t o0 = 0; o0 < len; o0 += 64) {
-            M v[4];
+        for (int64_t o0 = 0; o0 < len; o0 += 16 * V) {
+            const int64_t o = o0 + (int64_t)sub * V; // this lane's bases: o .. o + V - 1
+            const bool whole = o + V <= len;
+            SweepVec<M> v;
+            if (accumulate && whole) { // (more than SWEEP_MAX_CHILDREN children: several launches)
+                v = sweep_load<SweepVec<M>>(S + start + o);
+            } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int64_t o = o0 + sub + 16 * j;
-                v[j] = accumulate && o < len ? S[start + o] : own; // (more than SWEEP_MAX_CHILDREN children: several launches)
+                for (int j = 0; j < V; ++j)
+                    v.e[j] = accumulate && o + j < len ? S[start + o + j] : own;
             }
             for (int k = 0; k < ch.n; ++k) {
                 const int32_t enc = ch.c[k].enc[b];
@@ -569,8 +589,8 @@ static __global__ void __launch_bounds__(256) k_sweep_up(const BotRec<C> *__rest
                 if (!T && !SUM) { // a child without tracks of its own: every base below carries the same set
                     const M cst = (M)ch.c[k].constant;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        v[j] = track_join<M, SUM>(v[j], cst);
+                    for (int j = 0; j < V; ++j)
+                        v.e[j] = track_join<M, SUM>(v.e[j], cst);
                     continue;
                 }
                 const int32_t t0 = enc >> 1;
@@ -578,25 +598,40 @@ static __global__ void __launch_bounds__(256) k_sweep_up(const BotRec<C> *__rest
                 do { // the slot's segment and its paralogy ring (updateChild + updateNextTopDup, :607-681)
                     const TopRec<C> tr = top[t];
                     if (T) {
+                        const M *base = T + (int64_t)tr.start;
+                        if (whole) {
+                            if (tr.parentEnc & 1) {
+                                const SweepVec<M> x = sweep_load<SweepVec<M>>(base + (len - o - V));
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int64_t o = o0 + sub + 16 * j;
-                            if (o < len)
-                                v[j] = track_join<M, SUM>(v[j], T[(int64_t)tr.start + ((tr.parentEnc & 1) ? len - 1 - o : o)]);
+                                for (int j = 0; j < V; ++j)
+                                    v.e[j] = track_join<M, SUM>(v.e[j], x.e[V - 1 - j]);
+                            } else {
+                                const SweepVec<M> x = sweep_load<SweepVec<M>>(base + o);
+#pragma unroll
+                                for (int j = 0; j < V; ++j)
+                                    v.e[j] = track_join<M, SUM>(v.e[j], x.e[j]);
+                            }
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < V; ++j)
+                                if (o + j < len)
+                                    v.e[j] = track_join<M, SUM>(v.e[j], base[(tr.parentEnc & 1) ? len - 1 - o - j : o + j]);
                         }
                     } else { // (sums: one per ring member)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            v[j] = track_join<M, SUM>(v[j], (M)ch.c[k].constant);
+                        for (int j = 0; j < V; ++j)
+                            v.e[j] = track_join<M, SUM>(v.e[j], (M)ch.c[k].constant);
                     }
                     t = tr.paralogy;
                 } while (t >= 0 && t != t0);
             }
+            if (whole) {
+                sweep_store(S + start + o, v);
+            } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int64_t o = o0 + sub + 16 * j;
-                if (o < len)
-                    S[start + o] = v[j];
+                for (int j = 0; j < V; ++j)
+                    if (o + j < len)
+                        S[start + o + j] = v.e[j];
             }
         }
     }
@@ -610,21 +645,53 @@ template <typename C, typename M, bool SUM>
 static __global__ void __launch_bounds__(256) k_sweep_down(const TopRec<C> *__restrict__ top, int64_t numTop, const BotRec<C> *__restrict__ pbot,
                                                            const int32_t *__restrict__ pA, const M *__restrict__ pS, const M *__restrict__ S, M own,
                                                            int32_t *__restrict__ A) {
+    constexpr int V = 4; // bases per lane and round: a 16-byte word of A
+    struct AVec {
+        int32_t e[V];
+    };
+    struct MVec {
+        M e[V];
+    };
     const int sub = (int)(threadIdx.x & 15);
     const int64_t groupsTotal = ((int64_t)gridDim.x * blockDim.x) >> 4;
     for (int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; t < numTop; t += groupsTotal) {
         const TopRec<C> tr = top[t];
         const int64_t start = (int64_t)tr.start, len = (int64_t)top[t + 1].start - start;
-        if (tr.parentEnc >= 0) {
-            const int64_t pstart = (int64_t)pbot[tr.parentEnc >> 1].start;
-            const bool rev = (tr.parentEnc & 1) != 0;
-            for (int64_t o = sub; o < len; o += 16) {
-                const int64_t pp = pstart + (rev ? len - 1 - o : o);
-                A[start + o] = pS ? track_size<M, SUM>(pS[pp]) : pA[pp];
+        const bool hasParent = tr.parentEnc >= 0, rev = (tr.parentEnc & 1) != 0;
+        const int64_t pstart = hasParent ? (int64_t)pbot[tr.parentEnc >> 1].start : 0;
+        for (int64_t o = (int64_t)sub * V; o < len; o += 16 * V) {
+            AVec a;
+            if (o + V <= len) {
+                if (hasParent) {
+                    const int64_t pp = pstart + (rev ? len - o - V : o); // the V parent bases, in the parent's order
+                    if (pS) {
+                        const MVec x = sweep_load<MVec>(pS + pp);
+#pragma unroll
+                        for (int j = 0; j < V; ++j)
+                            a.e[j] = track_size<M, SUM>(x.e[rev ? V - 1 - j : j]);
+                    } else {
+                        const AVec x = sweep_load<AVec>(pA + pp);
+#pragma unroll
+                        for (int j = 0; j < V; ++j)
+                            a.e[j] = x.e[rev ? V - 1 - j : j];
+                    }
+                } else if (S) {
+                    const MVec x = sweep_load<MVec>(S + start + o);
+#pragma unroll
+                    for (int j = 0; j < V; ++j)
+                        a.e[j] = track_size<M, SUM>(x.e[j]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < V; ++j)
+                        a.e[j] = track_size<M, SUM>(own);
+                }
+                sweep_store(A + start + o, a);
+            } else {
+                for (int j = 0; j < V && o + j < len; ++j) {
+                    const int64_t pp = pstart + (rev ? len - 1 - o - j : o + j);
+                    A[start + o + j] = hasParent ? (pS ? track_size<M, SUM>(pS[pp]) : pA[pp]) : track_size<M, SUM>(S ? S[start + o + j] : own);
+                }
             }
-        } else {
-            for (int64_t o = sub; o < len; o += 16)
-                A[start + o] = track_size<M, SUM>(S ? S[start + o] : own);
         }
     }
 }
