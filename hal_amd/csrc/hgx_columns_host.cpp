@@ -596,7 +596,8 @@ struct MafExport::RunMachine {
         int64_t seqStart; // of its sequence
         int64_t limit;    // columns the row can go on inside its sequence
         int32_t rank, genome, seq;
-        uint8_t rev;
+        uint32_t ord : 31; // its place in the column as the walk delivers it (the order of a sequence's bases in the column map)
+        uint32_t rev : 1;
     };
     struct Chunk { // one device batch: which columns are heads, the heads' rows (sorted the way the column map holds them)
         int64_t done = 0, n = 0;
@@ -698,7 +699,7 @@ struct MafExport::RunMachine {
     }
     Ent newEnt(const KeyRec &k) { return Ent{k.rank, k.genome, k.seq, false, 0, NULL_INDEX, 0, info(k).srcLength}; }
     // device rows -> PRows, every column's sorted by rank (stable): done by the thread that fetches, beside the walk
-    static void describe(const Image &img, const std::vector<std::vector<int>> &rank, PRow &p, int genome, int64_t pos, bool rev) {
+    static void describe(const Image &img, const std::vector<std::vector<int>> &rank, PRow &p, int genome, int64_t pos, bool rev, uint32_t ord) {
         const GenomeTables &G = img.genomes[(size_t)genome];
         const int s = G.seqs.size() == 1 ? 0 : G.seqIndexBySite(pos);
         const SeqInfo &S = G.seqs[(size_t)s];
@@ -708,13 +709,15 @@ struct MafExport::RunMachine {
         p.rank = rank[(size_t)genome][(size_t)s];
         p.genome = genome;
         p.seq = s;
+        p.ord = ord;
         p.rev = rev ? 1 : 0;
     }
-    static void sortColumn(PRow *r, size_t n) { // (a handful of rows: insertion sort)
+    // by sequence, a sequence's bases in the walk's order (a handful of rows: insertion sort)
+    static void sortColumn(PRow *r, size_t n) {
         for (size_t i = 1; i < n; ++i) {
             const PRow x = r[i];
             size_t j = i;
-            for (; j > 0 && r[j - 1].rank > x.rank; --j)
+            for (; j > 0 && (r[j - 1].rank > x.rank || (r[j - 1].rank == x.rank && r[j - 1].ord > x.ord)); --j)
                 r[j] = r[j - 1];
             r[j] = x;
         }
@@ -868,7 +871,7 @@ struct MafExport::RunMachine {
     const PRow *advance(const PRow *rows, size_t n, int64_t k) {
         std::unique_ptr<PRow[]> next(new PRow[n]);
         for (size_t i = 0; i < n; ++i)
-            describe(img, M._rank, next[i], rows[i].genome, rows[i].pos + (rows[i].rev ? -k : k), rows[i].rev != 0);
+            describe(img, M._rank, next[i], rows[i].genome, rows[i].pos + (rows[i].rev ? -k : k), rows[i].rev != 0, rows[i].ord);
         sortColumn(next.get(), n);
         batch->extra.push_back(std::move(next));
         return batch->extra.back().get();
@@ -1133,10 +1136,12 @@ void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alig
         c->rows.resize(headRows.size());
         const size_t heads = c->headOff.size() - 1;
         auto convert = [&](size_t h0, size_t h1) {
-            for (size_t i = c->headOff[h0]; i < c->headOff[h1]; ++i)
-                RunMachine::describe(alignment->img, _rank, c->rows[i], headRows[i].genome, headRows[i].pos, headRows[i].rev != 0);
-            for (size_t h = h0; h < h1; ++h)
+            for (size_t h = h0; h < h1; ++h) {
+                for (size_t i = c->headOff[h]; i < c->headOff[h + 1]; ++i)
+                    RunMachine::describe(alignment->img, _rank, c->rows[i], headRows[i].genome, headRows[i].pos, headRows[i].rev != 0,
+                                         (uint32_t)(i - c->headOff[h]));
                 RunMachine::sortColumn(c->rows.data() + c->headOff[h], c->headOff[h + 1] - c->headOff[h]);
+            }
         };
         const size_t parts = heads >= 4096 ? 4 : 1;
         std::vector<std::thread> helpers;

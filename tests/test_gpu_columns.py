@@ -268,3 +268,20 @@ def test_column_tools_over_device_clones(hal, oracle_bin, tmp_path):
     subprocess.check_call([os.path.join(root, "hal_amd", "_build", "hal2maf"), "--devices", "0,0,0", "--sliceSize", "250", "--refGenome", "Genome_0",
                            "--refSequence", name, "--unique", small, out])
     assert open(out).read() == want
+
+
+@pytest.mark.parametrize("seed,n_genomes,max_children,root_len", [(412, 8, 1, 1108), (77, 9, 2, 600), (5, 6, 3, 300)])
+def test_maf_block_length_breaks_where_rows_change_sequence(hal, oracle_bin, tmp_path, seed, n_genomes, max_children, root_len):
+    """A block-length limit that falls into a run of columns makes the host go through the per-column logic in the middle of the run,
+    with the run's rows moved on — where a row has just crossed into its genome's next sequence its sequence's bases must still
+    come in the walk's order (seed 412: a soak run found two rows of one sequence swapped there).  Every genome as reference."""
+    import halfix
+    img = str(tmp_path / "ms.hgx")
+    halfix.write_hgx(img, halfix.random_multiseq_alignment(seed, n_genomes=n_genomes, max_children=max_children, root_len=root_len))
+    al = hal.Alignment.open(img, device=0)
+    for g in range(al.num_genomes):
+        if al.genome_length(g) == 0:
+            continue
+        nm = al.genome_name(g)
+        for mbl in (17, 3):
+            assert al.maf_export(g, max_block_len=mbl) == _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", nm, "--maxBlockLen", str(mbl)), (nm, mbl)
