@@ -625,7 +625,11 @@ def main():
                                         "batches_in_flight": in_flight,
                                         "achieved_GBs_at_step_rate": own_bytes / (elapsed / args.steps) / 1e9,
                                         "frac_at_step_rate": own_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
-                                        "note": "kernel times come from a loop of its own through one plan with HIP events around every launch; with "
+                                        "note": "kernel times come from a loop of its own through one plan with HIP events around every launch, in the "
+                                                "form the batches in flight are launched in (general intervals finished by the wavefronts that meet them: "
+                                                "k_lift_classify's launch then ends one such interval's latency after its last tile, a tail the other "
+                                                "batch's launches fill; one_plan.roofline_kernels has the form a batch that runs by itself takes, with "
+                                                "k_lift_classify at 0.036 ms); with "
                                                 "two batches in flight the launches of the two overlap, so ms_per_step is below kernel_ms_per_step; "
                                                 "achieved_GBs_at_step_rate = the same bytes over ms_per_step, what the GPU moves per second in the timed loop.  "
                                                 "bytes_the_timed_kernels_must_move prices every timed kernel by its own inputs and outputs "
