@@ -292,11 +292,16 @@ class SlotExchange:
 
     def submit(self, plan=None, first_query=0, blob=None):
         """plan: a LiftoverPlan whose last run is exchanged; blob: a ready blob instead (CPU tests)"""
+        while len(self._inflight) >= 3:  # (the buffer about to be reused may still be the target of an all-gather under way)
+            self.wait()
         buf = self._bufs[self._turn % 3]
         self._turn += 1
         work = None
         if self.backend == "c_abi":
             self.last_bytes = plan.exchange(self.comm, first_query, buf, self.slot)
+            if buf.device.type == "cuda":  # (the library queues its all-gather on the current stream: an event marks its end)
+                work = torch.cuda.Event()
+                work.record()
         else:
             mine = self._mine(buf)
             if blob is not None:
@@ -316,12 +321,20 @@ class SlotExchange:
                 work = dist.all_gather(parts, mine.clone(), async_op=True)
         self._inflight.append((work, buf))
 
+    @property
+    def in_flight(self):
+        """exchanges submitted and not waited for (at most three: a fourth submit waits for the oldest first)"""
+        return len(self._inflight)
+
     def wait(self):
         if not self._inflight:
             return None
         work, buf = self._inflight.pop(0)
         if work is not None:
-            work.wait()
+            if hasattr(work, "synchronize"):  # a CUDA event (c_abi): readers on other streams must see the gathered slots
+                work.synchronize()
+            else:
+                work.wait()
         return buf
 
     def drain(self):

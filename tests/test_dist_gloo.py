@@ -189,16 +189,27 @@ def _slot_worker(rank, world, port, result):
     slot = 16384
     ex = SlotExchange(world, rank, slot, "cpu", backend="torch")
     assert ex.wait() is None
-    for _ in range(4):  # a stream of batches: three buffers rotate
-        ex.submit(blob=blob)
-    bufs = ex.drain()
-    ok = ok and len(bufs) == 4
     whole = torch.from_numpy(z["whole"].copy())
-    for buf in bufs:
+
+    def check(buf):
         parts = ex.slots(buf)
-        ok = ok and [p.numel() for p in parts] == [int(z["blob0"].shape[0]), int(z["blob1"].shape[0])]
+        good = [p.numel() for p in parts] == [int(z["blob0"].shape[0]), int(z["blob1"].shape[0])]
         decoded = torch.cat([decode_blob(p)[0] for p in parts], dim=0)
-        ok = ok and bool(torch.equal(decoded, whole))  # rank-major concatenation of the shards = the unsharded lift
+        return good and bool(torch.equal(decoded, whole))  # rank-major concatenation of the shards = the unsharded lift
+
+    seen = 0
+    for _ in range(7):  # a stream of batches: three buffers rotate, a buffer is read before the exchange after next reuses it
+        if ex.in_flight == 3:
+            ok = ok and check(ex.wait())
+            seen += 1
+        ex.submit(blob=blob)
+    for buf in ex.drain():
+        ok = ok and check(buf)
+        seen += 1
+    ok = ok and seen == 7
+    for _ in range(4):  # (a fourth submit without a wait completes the oldest exchange itself instead of writing over its buffer)
+        ex.submit(blob=blob)
+    ok = ok and ex.in_flight == 3 and all(check(b) for b in ex.drain())
     try:
         SlotExchange(world, rank, 64, "cpu", backend="torch").submit(blob=blob)
         ok = False
