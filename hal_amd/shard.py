@@ -331,7 +331,7 @@ class SlotExchange:
             return None
         work, buf = self._inflight.pop(0)
         if work is not None:
-            if hasattr(work, "synchronize"):  # a CUDA event (c_abi): readers on other streams must see the gathered slots
+            if isinstance(work, torch.cuda.Event):  # (c_abi): readers on other streams must see the gathered slots
                 work.synchronize()
             else:
                 work.wait()
