@@ -1197,88 +1197,100 @@ __device__ __forceinline__ bool finish_wave(const int lane, int n, C tLo, C tHi,
         seq = lo;
     }
     LIFT_PROF3(4) // duplicates, sequences
-    // ---- extractSegment over the set in target order (scalar control flow; finish_query has the LDS original) ----
-    unsigned long long alive = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
-    C cutv = 0; // cut point c lives in lane c
-    int ncut = 0, nl = 0;
-    L.lStart = L.lEnd = L.lSrc = 0;
-    L.lSeq = L.lStrand = 0;
-    auto nextAlive = [&](int i) -> int { // first member of the set at or after i, or n
+    // ---- extractSegment over the set in target order (finish_query has the LDS original) ----
+    // After the refinement two members' target ranges are equal or disjoint, so "equal target start" (the classes the reference
+    // compares, halBlockMapper.cpp:340-352), "equal target end" (a cut point is a target end, :382-386) and "same class" are the
+    // same thing: a class is a run of neighbours, its members in source order.  Everything that looks at coordinates is done for
+    // all members at once — where classes begin (gb), and for every member a which members b of the class behind its own it
+    // could be merged with if no cut point forbade it (mergeable[a], canMergeRightWith: halMappedSegment.cpp:109-161) — and the
+    // sequential part (which classes a line swallows, what is erased, where cut points are) is left with 64-bit masks.
+    const unsigned long long all = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+    const C prevTLo = lane_prev(tLo); // (a DPP move: made by all lanes, not behind a condition that switches its source lane off)
+    const unsigned long long gb = __ballot(lane < n && (lane == 0 || tLo != prevTLo)); // first members of the classes
+    unsigned long long mergeable = 0;
+    {
+        const unsigned long long rest = lane < 63 ? (gb & all) >> (lane + 1) : 0ull; // class starts behind this member
+        int nb = n, gsz = 0;                                                           // the class behind this member's: [nb, nb + gsz)
+        if (lane < n && rest) {
+            const int z = __ffsll((long long)rest) - 1;
+            nb = lane + 1 + z;
+            const unsigned long long rest2 = z < 63 ? rest >> (z + 1) : 0ull;
+            gsz = (rest2 ? nb + __ffsll((long long)rest2) : n) - nb;
+        }
+        const bool same = ((fl & F_SREV) != 0) == ((fl & F_TREV) != 0);
+        for (int c = 0; __any(c < gsz); ++c) {
+            const int b = (nb + c) & 63;
+            const C bT = wave_pull<C>(tLo, b), bSL = wave_pull<C>(sLo, b), bSH = wave_pull<C>(sHi, b);
+            const int bFl = __shfl(fl, b), bSeq = __shfl(seq, b);
+            if (c < gsz && bSeq == seq && ((fl ^ bFl) & (F_SREV | F_TREV)) == 0 && bT - tHi == 1 && (same ? bSL - sHi == 1 : sLo - bSH == 1))
+                mergeable |= 1ull << b;
+        }
+    }
+    unsigned long long alive = all, cut = 0; // cut: the members whose target end is a cut point
+    int nl = 0, lineFirst = 0, lineBack = 0; // line l's first member and the first member of the last class it swallowed: lane l
+    auto firstFrom = [&](unsigned long long m, int i) -> int { // first member of m at or behind i, or n
         if (i >= n)
             return n;
-        const unsigned long long mm = alive >> i;
+        const unsigned long long mm = (m & all) >> i;
         return mm ? i + (__ffsll((long long)mm) - 1) : n;
     };
-    auto T = [&](int x) { return wave_read<C>(tLo, x); };
-    auto H = [&](int x) { return wave_read<C>(tHi, x); };
-    auto SL = [&](int x) { return wave_read<C>(sLo, x); };
-    auto SH = [&](int x) { return wave_read<C>(sHi, x); };
-    auto FL = [&](int x) { return __builtin_amdgcn_readlane(fl, x); };
-    auto SQ = [&](int x) { return __builtin_amdgcn_readlane(seq, x); };
-    auto canMergeRight = [&](int a, int b) -> bool { // halMappedSegment.cpp:109-161 in forward coordinates
-        const int fa = FL(a), fb = FL(b);
-        if (((fa ^ fb) & (F_SREV | F_TREV)) != 0)
-            return false;
-        if (T(b) - H(a) != 1)
-            return false;
-        const bool same = ((fa & F_SREV) != 0) == ((fa & F_TREV) != 0);
-        const bool rOk = same ? (SL(b) - SH(a) == 1) : (SL(a) - SH(b) == 1);
-        if (!rOk)
-            return false;
-        const C cutPos = H(a);
-        return __ballot(lane < ncut && cutv == cutPos) == 0;
+    auto span = [&](int lo, int hi) -> unsigned long long { // the members lo .. hi - 1
+        const unsigned long long upTo = hi >= 64 ? ~0ull : ((1ull << hi) - 1ull);
+        return upTo & ~((1ull << lo) - 1ull);
     };
-    for (int i = nextAlive(0); i < n; i = nextAlive(i + 1)) {
-        int v1s = i, v1n = 1, back = i;
-        int nxt = nextAlive(i + 1);
-        while (nxt < n && T(back) == T(nxt)) {
-            back = nxt;
-            ++v1n;
-            nxt = nextAlive(nxt + 1);
-        }
+    for (int i = firstFrom(alive, 0); i < n; i = firstFrom(alive, i + 1)) {
+        unsigned long long v1 = alive & span(i, firstFrom(gb, i + 1)); // what is left of i's class from i on
+        int v1n = (int)__popcll(v1);
+        int nxt = firstFrom(alive, firstFrom(gb, i + 1));
         int fragBack = i;
-        const int seqI = SQ(i);
         while (nxt < n) {
-            const int v2s = nxt;
-            int v2n = 0, b2 = -1;
-            while (nxt < n && (v2n == 0 || T(b2) == T(nxt)) && v2n < v1n) {
-                b2 = nxt;
+            // the next v1n members of the class nxt is in, as far as it has them
+            unsigned long long rest = alive & span(nxt, firstFrom(gb, nxt + 1)), v2 = 0;
+            int v2n = 0, last = nxt;
+            while (rest && v2n < v1n) {
+                last = __ffsll((long long)rest) - 1;
+                v2 |= 1ull << last;
+                rest &= rest - 1;
                 ++v2n;
-                nxt = nextAlive(nxt + 1);
             }
+            const int after = firstFrom(alive, last + 1);
             bool can = v1n == v2n;
-            int a = v1s, b = v2s;
-            for (int c = 0; c < v1n && can; ++c) {
-                can = SQ(b) == seqI && canMergeRight(a, b);
-                a = nextAlive(a + 1);
-                b = nextAlive(b + 1);
+            for (unsigned long long m1 = v1, m2 = v2; m1 && can; m1 &= m1 - 1, m2 &= m2 - 1) { // member by member
+                const int a = __ffsll((long long)m1) - 1, b = __ffsll((long long)m2) - 1;
+                const unsigned long long ma = (unsigned long long)wave_read<int64_t>((int64_t)mergeable, a);
+                can = ((ma >> b) & 1ull) != 0 && ((cut >> a) & 1ull) == 0;
             }
             if (!can)
                 break;
-            fragBack = v2s;
-            alive &= ~(1ull << v2s); // erased from the set (halBlockMapper.cpp:389-391)
-            v1s = v2s;
+            fragBack = __ffsll((long long)v2) - 1;
+            alive &= ~(1ull << fragBack); // erased from the set (halBlockMapper.cpp:389-391)
+            v1 = v2;
             v1n = v2n;
+            nxt = after;
         }
-        if (v1n > 1) {
-            if (ncut == 64)
-                return false;
-            const C cp = H(fragBack);
-            if (lane == ncut)
-                cutv = cp;
-            ++ncut;
+        if (v1n > 1) { // a cut point at the end of the last class (:382-386): no line merges across it any more
+            const int g0 = 63 - __clzll((long long)(gb & span(0, fragBack + 1)));
+            cut |= span(g0, firstFrom(gb, fragBack + 1));
         }
-        // halBlockLiftover.cpp:82-105
-        const C ti = T(i), tf = T(fragBack), hi_ = H(i), hf = H(fragBack), si = SL(i), sf = SL(fragBack);
-        const int fi = FL(i);
         if (lane == nl) {
+            lineFirst = i;
+            lineBack = fragBack;
+        }
+        ++nl;
+    }
+    {   // halBlockLiftover.cpp:82-105
+        const C ti = wave_pull<C>(tLo, lineFirst), tf = wave_pull<C>(tLo, lineBack), hi_ = wave_pull<C>(tHi, lineFirst),
+                hf = wave_pull<C>(tHi, lineBack), si = wave_pull<C>(sLo, lineFirst), sf = wave_pull<C>(sLo, lineBack);
+        const int fi = __shfl(fl, lineFirst), seqI = __shfl(seq, lineFirst);
+        L.lStart = L.lEnd = L.lSrc = 0;
+        L.lSeq = L.lStrand = 0;
+        if (lane < nl) {
             L.lStart = ti < tf ? ti : tf;
             L.lEnd = (hi_ > hf ? hi_ : hf) + 1;
             L.lSrc = si < sf ? si : sf;
             L.lSeq = seqI;
             L.lStrand = ((fi & F_DOT) ? '.' : ((fi & F_TREV) ? '-' : '+')) | ((fi & F_TREV) ? 0x80 : 0);
         }
-        ++nl;
     }
     LIFT_PROF3(5) // extractSegment
     // stable sort of the lines by source start (halLiftover.cpp:90), again a rank by counting
