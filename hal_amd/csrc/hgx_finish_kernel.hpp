@@ -1332,38 +1332,58 @@ __device__ __forceinline__ int general_interval(const int lane, const GeneralTab
     const uint32_t kEnd = (uint32_t)__builtin_amdgcn_readfirstlane((int)G.starts[(geIn >> G.shift) + 1]);
     nlOut = 0;
     baseOut = 0;
-    if (kEnd > k0 + 64u)
+    if (kEnd > k0 + 128u)
         return 0;
+    // up to 128 records in reach (the buckets of the interval's ends hold records that do not touch it), two rounds of 64; the ones
+    // that overlap the interval are clipped in the lanes that loaded them and packed into the lanes from 0 on — up to 64 of them
     C tLo = 0, tHi = 0, sLo = 0, sHi = 0;
-    int fl = 0;
-    bool have = false;
-    if (k0 + (uint32_t)lane < kEnd) {
-        const ComposedRec<C> r = G.recs[k0 + (uint32_t)lane];
-        const int64_t pLo = (int64_t)r.sLo, pHi = pLo + (int64_t)r.len - 1;
-        if (pLo <= ge && pHi >= gs) { // clipped to the interval (k_locate_through)
-            const int64_t c = pLo > gs ? pLo : gs, d = pHi < ge ? pHi : ge;
-            const int64_t len = d - c + 1, delta = c - pLo;
-            have = true;
-            sLo = (C)c;
-            sHi = (C)d;
-            tLo = (C)((int64_t)r.so + ((r.mEncF & 1u) ? (int64_t)r.len - delta - len : delta));
-            tHi = (C)((int64_t)tLo + len - 1);
-            fl = (int)((((r.mEncF & 1u) ? F_TREV : 0u) | (st == '.' ? (uint32_t)F_DOT : 0u)) ^ (st == '-' ? (uint32_t)(F_SREV | F_TREV) : 0u));
+    int fl = 0, n = 0;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (uint32_t round = 0; round < 2u && k0 + 64u * round < kEnd; ++round) { // (wave-uniform)
+        C rtLo = 0, rtHi = 0, rsLo = 0, rsHi = 0;
+        int rfl = 0;
+        bool have = false;
+        const uint32_t k = k0 + 64u * round + (uint32_t)lane;
+        if (k < kEnd) {
+            const ComposedRec<C> r = G.recs[k];
+            const int64_t pLo = (int64_t)r.sLo, pHi = pLo + (int64_t)r.len - 1;
+            if (pLo <= ge && pHi >= gs) { // clipped to the interval (k_locate_through)
+                const int64_t c = pLo > gs ? pLo : gs, d = pHi < ge ? pHi : ge;
+                const int64_t len = d - c + 1, delta = c - pLo;
+                have = true;
+                rsLo = (C)c;
+                rsHi = (C)d;
+                rtLo = (C)((int64_t)r.so + ((r.mEncF & 1u) ? (int64_t)r.len - delta - len : delta));
+                rtHi = (C)((int64_t)rtLo + len - 1);
+                rfl = (int)((((r.mEncF & 1u) ? F_TREV : 0u) | (st == '.' ? (uint32_t)F_DOT : 0u)) ^ (st == '-' ? (uint32_t)(F_SREV | F_TREV) : 0u));
+            }
         }
+        const unsigned long long hm = __ballot(have);
+        const int m = (int)__popcll(hm);
+        used += have ? 1u : 0u;
+        if (m == 0)
+            continue;
+        if (n + m > 64)
+            return 0; // more pieces than lanes: the LDS finishing kernel's
+        // to lanes n .. n + m - 1 (the ones left out aim at a lane that is not among them: if there is none, nobody is left out)
+        const int dump = n > 0 ? 0 : 63;
+        const int dest = have ? n + (int)__popcll(hm & below) : dump;
+        rtLo = wave_push<C>(rtLo, dest);
+        rtHi = wave_push<C>(rtHi, dest);
+        rsLo = wave_push<C>(rsLo, dest);
+        rsHi = wave_push<C>(rsHi, dest);
+        rfl = __builtin_amdgcn_ds_permute(dest << 2, rfl);
+        if (lane >= n && lane < n + m) {
+            tLo = rtLo;
+            tHi = rtHi;
+            sLo = rsLo;
+            sHi = rsHi;
+            fl = rfl;
+        }
+        n += m;
     }
-    const unsigned long long hm = __ballot(have);
-    const int n = (int)__popcll(hm);
-    used += have ? 1u : 0u;
     if (n == 0)
         return 1;
-    if (hm != (n >= 64 ? ~0ull : ((1ull << n) - 1ull))) { // close the gaps (the ones left out aim at lane 63, which is free then)
-        const int dest = have ? (int)__popcll(hm & ((1ull << lane) - 1ull)) : 63;
-        tLo = wave_push<C>(tLo, dest);
-        tHi = wave_push<C>(tHi, dest);
-        sLo = wave_push<C>(sLo, dest);
-        sHi = wave_push<C>(sHi, dest);
-        fl = __builtin_amdgcn_ds_permute(dest << 2, fl);
-    }
     WaveLines<C> L;
     L.nl = 0;
     LIFT_PROF(4) // table look-ups, records
