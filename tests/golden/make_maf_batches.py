@@ -1,0 +1,44 @@
+"""Makes tests/golden/maf_batches.bin: the device's batches (which columns are heads, the heads' rows: hgx_columns.hip,
+columnsHeadRowsHost) of a fixed list of hal2maf exports over small alignments of tests/halfix.py's generator, recorded on a GPU box
+by the profiling build of the library (make -C hal_amd/csrc hostprof-lib; HGX_MAF_DUMP).  tests/test_maf_replay.py plays them back
+to hal2maf's host side (the block state machine and the rendering) on a machine without a GPU and holds the text against the oracle.
+usage (GPU box): python tests/golden/make_maf_batches.py"""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+# (seed, n_genomes, max_children, root_len), then per genome the exports below, in this order
+ALIGNMENTS = [(3, 5, 2, 150), (8, 6, 1, 180), (21, 5, 3, 120)]
+EXPORTS = [({}, []), (dict(max_block_len=4, keep_empty_ref_blocks=True), ["--maxBlockLen", "4", "--keepEmptyRefBlocks"]),
+           (dict(no_dupes=True, only_sequence_names=True), ["--noDupes", "--onlySequenceNames"])]
+
+
+def cases(hal, device, tmp):
+    """yields (image path, genome name, text of the library, oracle arguments) for every export of the list"""
+    import halfix
+    for seed, ng, mc, rl in ALIGNMENTS:
+        img = os.path.join(tmp, "a%d.hgx" % seed)
+        halfix.write_hgx(img, halfix.random_multiseq_alignment(seed, n_genomes=ng, max_children=mc, root_len=rl))
+        al = hal.Alignment.open(img, device=device)
+        for g in range(al.num_genomes):
+            if al.genome_length(g) == 0:
+                continue
+            for kw, args in EXPORTS:
+                yield img, al.genome_name(g), al.maf_export(g, **kw), ["--refGenome", al.genome_name(g)] + args
+
+
+if __name__ == "__main__":
+    import tempfile
+    out = os.path.join(HERE, "maf_batches.bin")
+    if os.path.exists(out):
+        os.remove(out)
+    os.environ["HGX_MAF_DUMP"] = out
+    os.environ["HGX_LIB_PATH"] = os.path.join(ROOT, "hal_amd", "libhgx_hostprof.so")
+    import hal_amd as hal
+    with tempfile.TemporaryDirectory() as tmp:
+        n = sum(1 for _ in cases(hal, 0, tmp))
+    print("%d exports recorded, %d bytes" % (n, os.path.getsize(out)))

@@ -1,0 +1,41 @@
+"""hal2maf's host side — MafBlock's state machine on flat arrays, the log of pairings, the rendering threads
+(hal_amd/csrc/hgx_columns_host.cpp: MafExport::RunMachine; maf/impl/halMafBlock.cpp:36-82, 294-450, maf/impl/halMafExport.cpp:51-87) —
+without a GPU: the device's batches of a list of exports were recorded on a GPU box (tests/golden/make_maf_batches.py); the
+profiling build of the library (make hostprof-lib) plays them back to the host side, and the text must be the oracle's.  The
+product library has no such switch: it fails without a device (test_capi_host.py)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+SCRIPT = r'''
+import os, subprocess, sys, tempfile
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+import hal_amd as hal
+import make_maf_batches as mk
+oracle = %r
+bad = n = 0
+with tempfile.TemporaryDirectory() as tmp:
+    for img, name, got, args in mk.cases(hal, -1, tmp):
+        out = os.path.join(tmp, "o.maf")
+        subprocess.check_call([oracle, "maf", img, out] + args)
+        n += 1
+        if got != open(out).read():
+            bad += 1
+            print("DIFFERENT", img, name, args)
+print("exports %%d different %%d" %% (n, bad))
+''' % (ROOT, os.path.join(ROOT, "tests"), GOLD, os.path.join(ROOT, "oracle", "_build", "hal_oracle"))
+
+
+def test_recorded_device_batches_through_the_host_state_machine(oracle_bin):
+    lib = os.path.join(ROOT, "hal_amd", "libhgx_hostprof.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "hal_amd", "csrc"), "hostprof-lib"])
+    env = dict(os.environ, HGX_LIB_PATH=lib, HGX_MAF_REPLAY=os.path.join(GOLD, "maf_batches.bin"))
+    out = subprocess.run([sys.executable, "-c", SCRIPT], env=env, check=True, stdout=subprocess.PIPE).stdout.decode()
+    last = out.strip().splitlines()[-1].split()
+    assert last[0] == "exports" and int(last[1]) >= 40 and int(last[3]) == 0, out
