@@ -37,6 +37,11 @@ def test_compute_fails_loudly_without_device(hal, tmp_path):
         al.liftover_batch(1, 0, [hal.Interval(0, 0, 20)])
     with pytest.raises(hal.HgxError):
         hal.liftover_convert(al, 1, "Sequence\t0\t20\n", 0)
+    # the column tools, the block mapper and blockViz's entry point as well: nothing computes on the host
+    for call in (lambda: al.maf_export(0), lambda: al.maf_export(0, max_ref_gap=10), lambda: al.maf_export_global(),
+                 lambda: al.alignment_depth(0), lambda: al.blocks_in_target_range(al.genome_name(1), al.genome_name(0), "Sequence", 0, 20)):
+        with pytest.raises(hal.HgxError, match="without a device"):
+            call()
 
 
 def test_submit_and_collect_refuse_null_plans(hal):
