@@ -44,7 +44,7 @@ class hgx_column_row(C.Structure):
 class hgx_maf_opts(C.Structure):
     _fields_ = [("no_dupes", C.c_int32), ("no_ancestors", C.c_int32), ("only_sequence_names", C.c_int32),
                 ("only_orthologs", C.c_int32), ("keep_empty_ref_blocks", C.c_int32), ("unique", C.c_int32),
-                ("max_block_len", C.c_int64), ("max_ref_gap", C.c_int64)]
+                ("max_block_len", C.c_int64), ("max_ref_gap", C.c_int64), ("print_tree", C.c_int32)]
 
 
 class hgx_rand_opts(C.Structure):

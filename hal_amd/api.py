@@ -322,12 +322,13 @@ class Alignment:
 
     def maf_export(self, ref, ref_sequence=-1, start=0, length=0, no_dupes=False, no_ancestors=False, only_sequence_names=False,
                    only_orthologs=False, keep_empty_ref_blocks=False, max_block_len=1000, targets=None, unique=False,
-                   ref_targets_bed=None, max_ref_gap=0):
+                   ref_targets_bed=None, max_ref_gap=0, print_tree=False):
         """hal2maf's MAF text (maf/impl/halMafExport.cpp:25-88, maf/impl/hal2maf.cpp:196-206); ref_targets_bed: BED text of
         reference intervals (--refTargets, maf/impl/halMafBed.cpp)."""
         if ref_targets_bed is not None:
             o = hgx_maf_opts(1 if no_dupes else 0, 1 if no_ancestors else 0, 1 if only_sequence_names else 0,
-                             1 if only_orthologs else 0, 1 if keep_empty_ref_blocks else 0, 1 if unique else 0, max_block_len, max_ref_gap)
+                             1 if only_orthologs else 0, 1 if keep_empty_ref_blocks else 0, 1 if unique else 0, max_block_len, max_ref_gap,
+                             1 if print_tree else 0)
             tg = (C.c_int32 * len(targets))(*targets) if targets else None
             data = ref_targets_bed.encode() if isinstance(ref_targets_bed, str) else ref_targets_bed
             out, n, err = C.c_void_p(), C.c_size_t(), C.c_void_p()
@@ -339,7 +340,8 @@ class Alignment:
             finally:
                 lib.hgx_free(out)
         o = hgx_maf_opts(1 if no_dupes else 0, 1 if no_ancestors else 0, 1 if only_sequence_names else 0,
-                         1 if only_orthologs else 0, 1 if keep_empty_ref_blocks else 0, 1 if unique else 0, max_block_len, max_ref_gap)
+                         1 if only_orthologs else 0, 1 if keep_empty_ref_blocks else 0, 1 if unique else 0, max_block_len, max_ref_gap,
+                             1 if print_tree else 0)
         tg = (C.c_int32 * len(targets))(*targets) if targets else None
         out, n, err = C.c_void_p(), C.c_size_t(), C.c_void_p()
         if lib.hgx_maf_export(self._h, ref, ref_sequence, start, length, C.byref(o), tg, len(targets) if targets else 0,

@@ -802,6 +802,7 @@ int hgx_maf_export_global(hgx_alignment *h, const hgx_maf_opts *o, char **out_te
         me.setUcscNames(o->only_sequence_names == 0);
         me.setOnlyOrthologs(o->only_orthologs != 0);
         me.setMaxBlockLength(o->max_block_len == 0 ? 1000 : o->max_block_len);
+        me.setPrintTree(o->print_tree != 0);
     }
     TextOut T;
     std::ostream &os = T.os;
@@ -865,6 +866,7 @@ int hgx_maf_export_multi(hgx_alignment *const *handles, int n_handles, int ref, 
         cfg.unique = o->unique != 0;
         cfg.maxBlockLength = o->max_block_len == 0 ? 1000 : o->max_block_len;
         cfg.maxRefGap = o->max_ref_gap < 0 ? 0 : o->max_ref_gap;
+        cfg.printTree = o->print_tree != 0;
         if (o->no_ancestors && !G->children.empty())
             throw std::runtime_error("Since the reference genome to be used for the MAF is ancestral (" + G->name +
                                      "), the --noAncestors option is invalid.  The --refGenome option can be used to specify a "
@@ -907,6 +909,7 @@ static void configureMaf(MafExport &me, const hgx_maf_opts *o, const GenomeTable
         me.setUnique(o->unique != 0);
         me.setMaxBlockLength(o->max_block_len == 0 ? 1000 : o->max_block_len);
         me.setMaxRefGap(o->max_ref_gap < 0 ? 0 : o->max_ref_gap);
+        me.setPrintTree(o->print_tree != 0);
         if (o->no_ancestors && !G->children.empty()) // hal2maf.cpp:153-159
             throw std::runtime_error("Since the reference genome to be used for the MAF is ancestral (" + G->name +
                                      "), the --noAncestors option is invalid.  The --refGenome option can be used to specify a "

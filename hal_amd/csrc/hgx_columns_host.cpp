@@ -1,4 +1,5 @@
 #include "hgx_columns_host.hpp"
+#include <functional>
 #include "hgx_liftover_host.hpp"
 #include <iostream>
 #include <algorithm>
@@ -127,6 +128,7 @@ void alignmentDepth(std::ostream &os, hgx_alignment *h, int genome, int sequence
 MafExport::~MafExport() {
     for (auto &kv : _entries)
         delete kv.second;
+    delete _tree;
 }
 
 void MafExport::buildRanks() {
@@ -206,7 +208,146 @@ void MafExport::initEntry(Entry *e, const Key &k, const ColumnRowHost *row, bool
         e->sequence.clear();
         e->segs.clear();
     }
+    e->tree = nullptr;
 }
+
+// ---- hal2maf --printTree: the tree of a column's bases (halMafBlock.cpp:121-292), walked over the host's segment tables — a
+// handful of hops per block, on the path that goes column by column anyway ----
+namespace {
+int64_t segmentAt(const std::vector<int64_t> &starts, int64_t n, int64_t pos) { // the segment that holds pos
+    return (int64_t)(std::upper_bound(starts.begin(), starts.begin() + n, pos) - starts.begin()) - 1;
+}
+} // namespace
+// :159-200: a node for a base: the entry of its sequence that continues there (or has no start yet), or, for a sequence the
+// block has no entry of (an ancestor left out by --noAncestors), the genome's name
+MafExport::Tree *MafExport::getTreeNode(int genome, int64_t pos, bool modifyEntries) {
+    std::unique_ptr<Tree> ret(new Tree);
+    const Key key = keyOf(genome, pos);
+    const GenomeTables &G = _al->img.genomes[(size_t)genome];
+    auto it = _entries.lower_bound(key);
+    if (it != _entries.end() && it->first.rank == key.rank) {
+        Entry *entry = nullptr;
+        for (; it != _entries.end() && it->first.rank == key.rank; ++it) {
+            Entry *cur = it->second;
+            int64_t curPos = cur->start + cur->length;
+            if (cur->strand == '-')
+                curPos = cur->srcLength - 1 - curPos;
+            if (curPos == pos - G.seqs[(size_t)key.seq].start || cur->start == NULL_INDEX) {
+                entry = cur;
+                break;
+            }
+        }
+        if (!entry) // (an assertion in the reference: the column was found appendable before its tree is built)
+            throw std::runtime_error("printTree: no block entry continues at this base");
+        ret->entry = entry;
+        ret->label = entry->name;
+        if (modifyEntries)
+            entry->tree = ret.get();
+    } else {
+        ret->label = G.name;
+    }
+    return ret.release();
+}
+// :204-237: under the node of a bottom segment's base, a node for the base of every child segment and of its paralogs, and on
+// down through their parse links
+void MafExport::buildTreeR(int genome, int64_t b, int64_t pos, Tree *node, bool modifyEntries) {
+    const Image &img = _al->img;
+    const GenomeTables &G = img.genomes[(size_t)genome];
+    const int64_t off = pos - G.bStart[(size_t)b], len = G.bStart[(size_t)b + 1] - G.bStart[(size_t)b];
+    for (size_t i = 0; i < G.children.size(); ++i) {
+        const int64_t tc = G.bChild[i][(size_t)b];
+        if (tc == NULL_INDEX)
+            continue;
+        const int c = G.children[i];
+        const GenomeTables &CG = img.genomes[(size_t)c];
+        int64_t t = tc;
+        do { // the canonical paralog (the one the parent's link names) first, then the rest of the cycle
+            const int64_t cpos = CG.tStart[(size_t)t] + (CG.tParentRev[(size_t)t] ? len - 1 - off : off);
+            Tree *child = getTreeNode(c, cpos, modifyEntries);
+            child->parent = node;
+            node->children.push_back(child);
+            if (CG.tBotParse[(size_t)t] != NULL_INDEX)
+                buildTreeR(c, segmentAt(CG.bStart, CG.numBot, cpos), cpos, child, modifyEntries);
+            t = CG.tParalogy[(size_t)t];
+        } while (t != NULL_INDEX && t != tc);
+    }
+}
+// :239-292: from the column's first base up to the segment that is the ancestor of all of them, then down
+MafExport::Tree *MafExport::buildTree(const ColumnMap &col, bool modifyEntries) {
+    const ColumnRowHost *first = nullptr;
+    for (auto c = col.begin(); c != col.end() && !first; ++c)
+        if (!c->second.empty())
+            first = c->second[0];
+    if (!first)
+        throw std::runtime_error("printTree: empty column");
+    const Image &img = _al->img;
+    int g = first->genome;
+    int64_t pos = first->pos;
+    const GenomeTables &G0 = img.genomes[(size_t)g];
+    if (G0.numTop == 0) { // the root genome
+        std::unique_ptr<Tree> t(getTreeNode(g, pos, modifyEntries));
+        buildTreeR(g, segmentAt(G0.bStart, G0.numBot, pos), pos, t.get(), modifyEntries);
+        return t.release();
+    }
+    int64_t t = segmentAt(G0.tStart, G0.numTop, pos);
+    int botGenome = -1;
+    int64_t botPos = 0;
+    while (img.genomes[(size_t)g].tParent[(size_t)t] != NULL_INDEX) {
+        const GenomeTables &G = img.genomes[(size_t)g];
+        const GenomeTables &P = img.genomes[(size_t)G.parent];
+        const int64_t b = G.tParent[(size_t)t], off = pos - G.tStart[(size_t)t], len = G.tStart[(size_t)t + 1] - G.tStart[(size_t)t];
+        botGenome = G.parent;
+        botPos = P.bStart[(size_t)b] + (G.tParentRev[(size_t)t] ? len - 1 - off : off);
+        if (P.parent < 0 || P.bTopParse[(size_t)b] == NULL_INDEX)
+            break; // the root genome, or nothing above this segment
+        g = botGenome;
+        pos = botPos;
+        t = segmentAt(P.tStart, P.numTop, pos);
+    }
+    const GenomeTables &G = img.genomes[(size_t)g];
+    if (G.tParent[(size_t)t] == NULL_INDEX && g == first->genome && G.numBot == 0)
+        return getTreeNode(g, pos, modifyEntries); // an insertion in a leaf: no bottom segment anywhere
+    // (the reference dereferences a null bottom iterator here when the column's first base is an insertion in a genome that has
+    // bottom segments: undefined there, an error here)
+    if (botGenome < 0)
+        throw std::runtime_error("printTree: the column's first base has no parent in a genome with bottom segments");
+    const GenomeTables &B = img.genomes[(size_t)botGenome];
+    std::unique_ptr<Tree> root(getTreeNode(botGenome, botPos, modifyEntries));
+    buildTreeR(botGenome, segmentAt(B.bStart, B.numBot, botPos), botPos, root.get(), modifyEntries);
+    return root.release();
+}
+namespace {
+template <typename T> bool treeEquals(const T *a, const T *b) { // stTree_equals
+    if (a->label != b->label || a->children.size() != b->children.size())
+        return false;
+    for (size_t i = 0; i < a->children.size(); ++i)
+        if (!treeEquals(a->children[i], b->children[i]))
+            return false;
+    return true;
+}
+template <typename T> void treeNewick(const T *t, std::string &s) { // stTree_getNewickTreeString without the final ';'
+    if (!t->children.empty()) {
+        s += '(';
+        for (size_t i = 0; i < t->children.size(); ++i) {
+            if (i)
+                s += ',';
+            treeNewick(t->children[i], s);
+        }
+        s += ')';
+    }
+    s += t->label;
+}
+template <typename T> void prioritizeNodeInTree(T *node) { // :128-157: the node and its ancestors first among their siblings
+    T *parent = node->parent;
+    if (!parent)
+        return;
+    size_t at = 0;
+    while (parent->children[at] != node)
+        ++at;
+    std::swap(parent->children[0], parent->children[at]);
+    prioritizeNodeInTree(parent);
+}
+} // namespace
 
 // halMafBlock.cpp:114-138
 void MafExport::updateEntry(Entry *e, const Key *k, const ColumnRowHost *row) {
@@ -246,6 +387,10 @@ void MafExport::appendRun(Entry *e, const ColumnRowHost *row, int64_t pos, int64
 
 // halMafBlock.cpp:294-367
 void MafExport::initBlock(const ColumnMap &col, const Key &refKey, int64_t refPos) {
+    if (_printTree && _tree) {
+        delete _tree;
+        _tree = nullptr;
+    }
     resetEntries();
     Entries::iterator e = _entries.begin();
     for (auto c = col.begin(); c != col.end(); ++c) {
@@ -288,6 +433,8 @@ void MafExport::initBlock(const ColumnMap &col, const Key &refKey, int64_t refPo
         if (e->first.rank == refKey.rank)
             _refIndex = refPos;
     }
+    if (_printTree)
+        _tree = buildTree(col, true);
 }
 
 // halMafBlock.cpp:370-395
@@ -331,6 +478,10 @@ bool MafExport::canAppendColumn(const ColumnMap &col) {
             }
             ++e;
         }
+    }
+    if (_printTree) { // :443-448: the column's tree must be the block's
+        std::unique_ptr<Tree> t(buildTree(col, false));
+        return treeEquals(t.get(), _tree);
     }
     return true;
 }
@@ -553,6 +704,22 @@ void MafExport::printBlock(std::ostream &os) const {
         buf += e.sequence;
         buf += '\n';
     };
+    if (_printTree) { // printBlockWithTree (halMafBlock.cpp:485-497): the tree as a comment of the block, the rows in post order
+        if (_reference->tree)
+            prioritizeNodeInTree(_reference->tree); // the reference first
+        buf += "a tree=\"";
+        treeNewick(_tree, buf);
+        buf += ";\"\n";
+        std::function<void(const Tree *)> rows = [&](const Tree *t) {
+            for (const Tree *c : t->children)
+                rows(c);
+            if (t->entry) // (none for an ancestor left out by --noAncestors)
+                printEntry(*t->entry, t->entry->start);
+        };
+        rows(_tree);
+        os.write(buf.data(), (std::streamsize)buf.size());
+        return;
+    }
     buf += "a\n";
     if (_reference->start == NULL_INDEX) {
         if (_refIndex != NULL_INDEX)
@@ -579,6 +746,15 @@ void MafExport::printBlock(std::ostream &os) const {
 // base each entry was given — and the rows themselves (runs of gaps and bases, then text) are made from the log by the
 // rendering threads, a batch of blocks at a time, beside the walk.
 #ifdef HGX_HOST_PROFILE
+// the profiling build's record of the device's batches, one file for both export paths, in the order of the calls
+static FILE *mafReplayFile() {
+    static FILE *f = getenv("HGX_MAF_REPLAY") ? fopen(getenv("HGX_MAF_REPLAY"), "rb") : nullptr;
+    return f;
+}
+static FILE *mafDumpFile() {
+    static FILE *f = getenv("HGX_MAF_DUMP") ? fopen(getenv("HGX_MAF_DUMP"), "wb") : nullptr;
+    return f;
+}
 static unsigned long long g_mafTicks[12];
 struct MafTick {
     int slot;
@@ -1095,8 +1271,7 @@ void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alig
 #ifdef HGX_HOST_PROFILE
         // profiling aid of the host state machine (make hostprof-lib, not part of libhgx.so): HGX_MAF_DUMP=file records the device's
         // batches, HGX_MAF_REPLAY=file plays them back to the state machine on a machine without a GPU
-        static FILE *replay = getenv("HGX_MAF_REPLAY") ? fopen(getenv("HGX_MAF_REPLAY"), "rb") : nullptr;
-        static FILE *dump = getenv("HGX_MAF_DUMP") ? fopen(getenv("HGX_MAF_DUMP"), "wb") : nullptr;
+        FILE *replay = mafReplayFile(), *dump = mafDumpFile();
         if (replay) {
             uint64_t hd[4];
             if (fread(hd, 8, 4, replay) != 4 || (int64_t)hd[0] != done)
@@ -1288,7 +1463,30 @@ void MafExport::convertSequence(std::ostream &mafStream, hgx_alignment *alignmen
             chunkCount = std::min<int64_t>((int64_t)chunkColumns, last - pos + 1);
             for (auto &kv : colMap)
                 kv.second.clear(); // they point into the buffer about to be replaced
+#ifdef HGX_HOST_PROFILE
+            // (the profiling build's recording / playback of the device's batches, as in convertSequenceRuns: HGX_MAF_DUMP / HGX_MAF_REPLAY)
+            FILE *replay = mafReplayFile(), *dump = mafDumpFile();
+            if (replay) {
+                uint64_t hd[4];
+                if (fread(hd, 8, 4, replay) != 4 || (int64_t)hd[0] != chunkFirst || (int64_t)hd[1] != chunkCount)
+                    throw std::runtime_error("HGX_MAF_REPLAY: the file does not continue with these columns");
+                off.resize((size_t)hd[2]);
+                rows.resize((size_t)hd[3]);
+                if (fread(off.data(), 8, off.size(), replay) != off.size() || fread(rows.data(), sizeof(ColumnRowHost), rows.size(), replay) != rows.size())
+                    throw std::runtime_error("HGX_MAF_REPLAY: short file");
+                return (size_t)(pos - chunkFirst);
+            }
+#endif
             columnsRowsHost(alignment, genome, chunkFirst, chunkCount, opt, true, off, rows, &stats);
+#ifdef HGX_HOST_PROFILE
+            if (dump) {
+                const uint64_t hd[4] = {(uint64_t)chunkFirst, (uint64_t)chunkCount, off.size(), rows.size()};
+                fwrite(hd, 8, 4, dump);
+                fwrite(off.data(), 8, off.size(), dump);
+                fwrite(rows.data(), sizeof(ColumnRowHost), rows.size(), dump);
+                fflush(dump);
+            }
+#endif
         }
         return (size_t)(pos - chunkFirst);
     };
@@ -1342,11 +1540,11 @@ void MafExport::convertSequence(std::ostream &mafStream, hgx_alignment *alignmen
     // Inside a run every column has the rows of its left neighbour advanced by one base, so canAppendColumn can only
     // fail on the block-length limit and appendColumn only appends one character per entry; the run is therefore
     // appended in bulk, falling back to single columns at sequence ends and block-length breaks.
-    if (!_unique && !getenv("HGX_MAF_PER_COLUMN") && !getenv("HGX_MAF_MAP_STATE")) {
+    if (!_unique && !_printTree && !getenv("HGX_MAF_PER_COLUMN") && !getenv("HGX_MAF_MAP_STATE")) {
         convertSequenceRuns(mafStream, alignment, genome, seq, startPosition, length, opt);
         return;
     }
-    if (!_unique && !getenv("HGX_MAF_PER_COLUMN")) { // (the same path on MafBlock's own containers: kept as a cross-check, HGX_MAF_MAP_STATE=1)
+    if (!_unique && !_printTree && !getenv("HGX_MAF_PER_COLUMN")) { // (the same path on MafBlock's own containers: kept as a cross-check, HGX_MAF_MAP_STATE=1)
         struct SegModeGuard {
             bool &f;
             explicit SegModeGuard(bool &x) : f(x) { f = true; }
@@ -2004,6 +2202,7 @@ void mafExportSliced(std::ostream &os, const std::vector<hgx_alignment *> &handl
                 me.setUnique(cfg.unique);
                 me.setMaxBlockLength(cfg.maxBlockLength);
                 me.setMaxRefGap(cfg.maxRefGap);
+                me.setPrintTree(cfg.printTree);
                 std::ostringstream text;
                 me.convertSequence(text, h, genome, sl.seq, sl.start, sl.length, targets);
                 sl.text = text.str();

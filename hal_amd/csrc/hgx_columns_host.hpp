@@ -21,7 +21,8 @@ void alignmentDepth(std::ostream &os, hgx_alignment *h, int genome, int sequence
 // with the header of the first only.  handles: device clones of one alignment (hgx_clone_to_device); the slices are dealt to
 // them as they become free, one host thread per handle.
 struct MafExportSettings {
-    bool noDupes = false, noAncestors = false, ucscNames = true, onlyOrthologs = false, keepEmptyRefBlocks = false, unique = false;
+    bool noDupes = false, noAncestors = false, ucscNames = true, onlyOrthologs = false, keepEmptyRefBlocks = false, unique = false,
+         printTree = false;
     int64_t maxBlockLength = 1000, maxRefGap = 0;
 };
 void mafExportSliced(std::ostream &os, const std::vector<hgx_alignment *> &handles, int genome, int sequence, int64_t start, int64_t length,
@@ -40,6 +41,9 @@ class MafExport {
     void setKeepEmptyRefBlocks(bool v) { _keepEmptyRefBlocks = v; }
     void setMaxRefGap(int64_t v) { _maxRefGap = v; }
     void setUnique(bool v) { _unique = v; }
+    // hal2maf --printTree: every block with the tree of its rows (halMafBlock.cpp:121-292, 485-497); blocks also end where the
+    // column's tree changes (:443-448)
+    void setPrintTree(bool v) { _printTree = v; }
     // maf/impl/halMafExport.cpp:25-88; positions are sequence-relative, length 0 = to the end
     void convertSequence(std::ostream &mafStream, hgx_alignment *alignment, int genome, int seq, int64_t startPosition, int64_t length,
                          const std::set<int> &targets);
@@ -52,6 +56,20 @@ class MafExport {
     size_t chunkColumns = 1u << 21;
 
   private:
+    // the part of sonLib's stTree the block uses (sonLib is not in the reference tree; restated from its use in halMafBlock.cpp and
+    // its published behaviour: children in the order they were given their parent, Newick text "(child,child)label;" without
+    // lengths when none was set, two trees equal when labels and children, in order, are)
+    struct Entry;
+    struct Tree {
+        Tree *parent = nullptr;
+        std::vector<Tree *> children;
+        std::string label;
+        Entry *entry = nullptr;
+        ~Tree() {
+            for (Tree *c : children)
+                delete c;
+        }
+    };
     struct Entry { // MafBlockEntry, maf/inc/halMafBlock.h:60-118
         int genome = -1;
         std::string name;
@@ -68,6 +86,7 @@ class MafExport {
         };
         std::vector<Seg> segs;
         uint32_t nameId = 0; // index into _names (run mode snapshots refer to names by id)
+        Tree *tree = nullptr;
     };
     struct Key {
         int rank, genome, seq;
@@ -76,7 +95,11 @@ class MafExport {
     typedef std::multimap<Key, Entry *> Entries;
     typedef std::map<Key, std::vector<const ColumnRowHost *>> ColumnMap;
     bool _noDupes = false, _noAncestors = false, _ucscNames = true, _append = false, _onlyOrthologs = false, _keepEmptyRefBlocks = false,
-         _unique = false;
+         _unique = false, _printTree = false;
+    Tree *_tree = nullptr;
+    Tree *getTreeNode(int genome, int64_t pos, bool modifyEntries);
+    void buildTreeR(int genome, int64_t bottomSegment, int64_t pos, Tree *node, bool modifyEntries);
+    Tree *buildTree(const ColumnMap &col, bool modifyEntries);
     int64_t _maxBlockLength = 1000, _maxRefGap = 0;
     Entries _entries;
     Entry *_reference = nullptr;

@@ -24,7 +24,7 @@ int main(int argc, char **argv) {
     int64_t start = 0, length = 0, maxBlockLen = 1000, maxRefGap = 0, sliceSize = 0;
     std::vector<int> devices; // --gpus n / --devices a,b,...: hal2mafMP.py's slices, dealt to these devices (one process)
     bool noDupes = false, noAncestors = false, onlySequenceNames = false, unique = false, append = false, onlyOrthologs = false,
-         keepEmptyRefBlocks = false, global = false;
+         keepEmptyRefBlocks = false, global = false, printTree = false;
     int device = 0;
     try {
         for (int i = 1; i < argc; ++i) {
@@ -66,8 +66,7 @@ int main(int argc, char **argv) {
             else if (a == "--keepEmptyRefBlocks") keepEmptyRefBlocks = true;
             else if (a == "--refTargets") refTargetsPath = val();
             else if (a == "--global") global = true;
-            else if (a == "--printTree")
-                throw std::runtime_error(a + " is not built in this implementation");
+            else if (a == "--printTree") printTree = true;
             else if (a.rfind("--", 0) == 0) throw std::runtime_error("unknown option " + a);
             else pos.push_back(a);
         }
@@ -162,6 +161,7 @@ int main(int argc, char **argv) {
         me.setMaxBlockLength(maxBlockLen);
         me.setOnlyOrthologs(onlyOrthologs);
         me.setKeepEmptyRefBlocks(keepEmptyRefBlocks);
+        me.setPrintTree(printTree);
         if (!refTargetsPath.empty()) { // hal2mafWithTargets, hal2maf.cpp:105-119
             std::ifstream bedFile;
             if (refTargetsPath != "stdin") {
@@ -184,6 +184,7 @@ int main(int argc, char **argv) {
             cfg.unique = unique;
             cfg.maxBlockLength = maxBlockLen;
             cfg.maxRefGap = maxRefGap;
+            cfg.printTree = printTree;
             hgx::mafExportSliced(mafStream, hs, ref, refSeq, start, length, sliceSize, cfg, targetSet);
         } else if (refSeq >= 0) {
             me.convertSequence(mafStream, h, ref, refSeq, start, length, targetSet);

@@ -359,6 +359,10 @@ typedef struct hgx_maf_opts {
                             reference columns the bases the reference lacks — ranges deleted above it, inserted below it, up to
                             this many bases — come as columns of their own (halColumnIterator.cpp:65-144, 357-405), and, as in
                             the reference, every reference base is then written once (the visit cache is on) */
+    int32_t print_tree;  /* --printTree: every block begins "a tree=\"...\"" with the tree of its rows, the rows in the tree's post
+                            order; a block also ends where the column's tree changes (halMafBlock.cpp:121-292, 443-448, 485-497).
+                            As in the reference, a column whose first base (in sequence order) is an insertion in a genome that
+                            has bottom segments has no such tree: undefined behaviour there, an error here */
 } hgx_maf_opts;
 int hgx_maf_export(hgx_alignment *h, int ref_genome, int ref_sequence, int64_t start, int64_t length, const hgx_maf_opts *opts,
                    const int32_t *targets, int32_t n_targets, char **out_text, size_t *out_len, char **err);

@@ -590,6 +590,7 @@ void printDepthGenome(std::ostream &os, const Alignment &al, int genome, int seq
 // ---------------------------------------------------------------------------------------------
 // MAF
 MafExport::~MafExport() {
+    delete tree;
     for (auto &kv : entries)
         delete kv.second;
 }
@@ -650,9 +651,153 @@ void MafExport::initEntry(MafBlockEntry *entry, const SeqKey &k, const Dna *dna,
     }
     if (clearSequence)
         entry->sequence.clear();
+    entry->tree = nullptr;
 }
 
 // halMafBlock.cpp:114-138
+// ---- hal2maf --printTree: the tree of the column's bases (halMafBlock.cpp:121-292) ----
+static void treeSetParent(MafTree *node, MafTree *parent) { // stTree_setParent: appended to the parent's children
+    node->parent = parent;
+    parent->children.push_back(node);
+}
+static bool treeEquals(const MafTree *a, const MafTree *b) { // stTree_equals
+    if (a->label != b->label || a->children.size() != b->children.size())
+        return false;
+    for (size_t i = 0; i < a->children.size(); ++i)
+        if (!treeEquals(a->children[i], b->children[i]))
+            return false;
+    return true;
+}
+static std::string treeNewick(const MafTree *t) { // stTree_getNewickTreeString without its final ';'
+    std::string s;
+    if (!t->children.empty()) {
+        s += '(';
+        for (size_t i = 0; i < t->children.size(); ++i) {
+            if (i)
+                s += ',';
+            s += treeNewick(t->children[i]);
+        }
+        s += ')';
+    }
+    return s + t->label;
+}
+// :128-157: the node and its ancestors first among their siblings (first in a post-order walk)
+static void prioritizeNodeInTree(MafTree *node) {
+    MafTree *parent = node->parent;
+    if (parent == nullptr)
+        return;
+    size_t nodeIndex = 0;
+    while (parent->children[nodeIndex] != node)
+        ++nodeIndex;
+    std::swap(parent->children[0], parent->children[nodeIndex]);
+    prioritizeNodeInTree(parent);
+}
+// :159-200
+MafTree *MafExport::getTreeNode(const SegIt &segIt, bool modifyEntries) {
+    MafTree *ret = new MafTree;
+    const Genome &genome = alp->genomes[(size_t)segIt.g];
+    const i64 position = segIt.getStartPosition();
+    const SeqKey seq{alp, segIt.g, seqIndexBySite(genome, position)};
+    Entries::const_iterator entryIt = entries.lower_bound(seq);
+    if (entryIt != entries.end() && entryIt->first == seq) {
+        MafBlockEntry *entry = nullptr;
+        for (; entryIt != entries.end() && entryIt->first == seq; ++entryIt) {
+            MafBlockEntry *curEntry = entryIt->second;
+            i64 curEntryPos = curEntry->start + curEntry->length;
+            if (curEntry->strand == '-')
+                curEntryPos = curEntry->srcLength - 1 - curEntryPos;
+            if (curEntryPos == position - seq.seq().start || curEntry->start == NULL_INDEX) {
+                entry = curEntry;
+                break;
+            }
+        }
+        if (entry == nullptr) // (an assertion in the reference: the column was found appendable before its tree is built)
+            throw std::runtime_error("printTree: no block entry continues at this base");
+        ret->entry = entry;
+        ret->label = entry->name;
+        if (modifyEntries)
+            entry->tree = ret;
+    } else { // no entry for this sequence: an ancestor, ancestral sequence left out (--noAncestors)
+        ret->label = genome.name;
+    }
+    return ret;
+}
+// :204-237: a node for every child segment (and its paralogs) of this bottom segment, and on down
+void MafExport::buildTreeR(const SegIt &botIt, MafTree *node, bool modifyEntries) {
+    const Genome &genome = botIt.G();
+    for (size_t i = 0; i < genome.children.size(); ++i) {
+        if (!botIt.hasChild((i64)i))
+            continue;
+        SegIt topIt;
+        topIt.toChild(botIt, (i64)i);
+        MafTree *canonicalParalog = getTreeNode(topIt, modifyEntries);
+        treeSetParent(canonicalParalog, node);
+        if (topIt.G().tBotParse[(size_t)topIt.idx] != NULL_INDEX) { // hasParseDown
+            SegIt childBotIt;
+            childBotIt.toParseDown(topIt);
+            buildTreeR(childBotIt, canonicalParalog, modifyEntries);
+        }
+        if (topIt.hasNextParalogy()) { // the rest of the paralogy cycle hangs under the same parent node
+            topIt.toNextParalogy();
+            while (!topIt.isCanonicalParalog()) {
+                MafTree *paralog = getTreeNode(topIt, modifyEntries);
+                treeSetParent(paralog, node);
+                if (topIt.G().tBotParse[(size_t)topIt.idx] != NULL_INDEX) {
+                    SegIt childBotIt;
+                    childBotIt.toParseDown(topIt);
+                    buildTreeR(childBotIt, paralog, modifyEntries);
+                }
+                topIt.toNextParalogy();
+            }
+        }
+    }
+}
+// :239-292: from any base of the column up to the segment that is the ancestor of all of them, then down
+MafTree *MafExport::buildTree(ColumnIterator &col, bool modifyEntries) {
+    const Dna *first = nullptr;
+    for (auto c = col.colMap.begin(); c != col.colMap.end() && !first; ++c)
+        if (!c->second.empty())
+            first = &c->second[0];
+    if (!first)
+        throw std::runtime_error("printTree: empty column");
+    const Genome &genome = alp->genomes[(size_t)first->g];
+    SegIt topIt, botIt;
+    bool haveBot = false;
+    topIt.al = botIt.al = alp;
+    if (genome.numTop == 0) { // the reference is the root genome
+        botIt.g = first->g;
+        botIt.top = false;
+        botIt.toSite(first->pos);
+        haveBot = true;
+    } else {
+        topIt.g = first->g;
+        topIt.top = true;
+        topIt.toSite(first->pos);
+        while (topIt.hasParent()) {
+            const int parent = topIt.G().parent;
+            botIt.toParent(topIt);
+            haveBot = true;
+            if (alp->genomes[(size_t)parent].parent < 0 || botIt.G().bTopParse[(size_t)botIt.idx] == NULL_INDEX)
+                break; // the root genome, or nothing above this segment
+            SegIt up;
+            up.toParseUp(botIt);
+            topIt = up;
+        }
+    }
+    MafTree *t;
+    if (genome.numTop != 0 && !topIt.hasParent() && topIt.g == first->g && genome.numBot == 0) {
+        t = getTreeNode(topIt, modifyEntries); // an insertion in a leaf: no bottom segment anywhere
+    } else {
+        // (the reference dereferences a null bottom iterator here when the column's first base is an insertion in a genome
+        // that has bottom segments: undefined there, an error here)
+        if (!haveBot)
+            throw std::runtime_error("printTree: the column's first base has no parent in a genome with bottom segments");
+        t = getTreeNode(botIt, modifyEntries);
+        buildTreeR(botIt, t, modifyEntries);
+    }
+    return t;
+}
+
 void MafExport::updateEntry(MafBlockEntry *entry, const SeqKey *k, const Dna *dna) {
     if (dna != nullptr) {
         if (entry->start == NULL_INDEX)
@@ -666,6 +811,10 @@ void MafExport::updateEntry(MafBlockEntry *entry, const SeqKey *k, const Dna *dn
 
 // halMafBlock.cpp:294-367
 void MafExport::initBlock(ColumnIterator &col) {
+    if (printTree && tree != nullptr) {
+        delete tree;
+        tree = nullptr;
+    }
     resetEntries();
     Entries::iterator e = entries.begin();
     for (auto c = col.colMap.begin(); c != col.colMap.end(); ++c) {
@@ -710,6 +859,8 @@ void MafExport::initBlock(ColumnIterator &col) {
         if (e->first == referenceSequence)
             refIndex = col.refSequencePosition();
     }
+    if (printTree)
+        tree = buildTree(col, true);
 }
 
 // halMafBlock.cpp:370-395
@@ -754,6 +905,12 @@ bool MafExport::canAppendColumn(ColumnIterator &col) {
             ++e;
         }
     }
+    if (printTree) { // :443-448: the column's tree must be the block's
+        MafTree *t = buildTree(col, false);
+        const bool ret = treeEquals(t, tree);
+        delete t;
+        return ret;
+    }
     return true;
 }
 
@@ -771,7 +928,21 @@ static void printEntry(std::ostream &os, const MafBlockEntry &e) { // halMafBloc
 }
 
 // halMafBlock.cpp:499-519
+static void printTreeEntries(const MafTree *t, std::ostream &os) { // :472-483: post order
+    for (const MafTree *c : t->children)
+        printTreeEntries(c, os);
+    if (t->entry != nullptr) // (null for an ancestor left out by --noAncestors)
+        printEntry(os, *t->entry);
+}
+
 void MafExport::printBlock(std::ostream &os) const {
+    if (printTree) { // printBlockWithTree, :485-497
+        if (reference->tree != nullptr)
+            prioritizeNodeInTree(reference->tree); // the reference first
+        os << "a tree=\"" << treeNewick(tree) << ";\"\n";
+        printTreeEntries(tree, os);
+        return;
+    }
     os << "a\n";
     if (reference->start == NULL_INDEX) {
         if (refIndex != NULL_INDEX) {

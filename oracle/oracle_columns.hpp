@@ -149,6 +149,20 @@ void printDepthGenome(std::ostream &os, const Alignment &al, int genome, int seq
                       i64 start, i64 length, i64 step, bool countDupes, bool noAncestors);
 
 // maf/impl/halMafBlock.cpp + halMafExport.cpp
+// the part of sonLib's stTree the MAF block uses (hal2maf --printTree; sonLib is not in the reference tree: restated from its
+// use in maf/impl/halMafBlock.cpp:121-292, 472-496 and its published behaviour — children in the order they were given a parent,
+// Newick text "(child,child)label;" without lengths when none was set, equality = same label and equal children in order)
+struct MafBlockEntry;
+struct MafTree {
+    MafTree *parent = nullptr;
+    std::vector<MafTree *> children;
+    std::string label;
+    MafBlockEntry *entry = nullptr; // client data
+    ~MafTree() {
+        for (MafTree *c : children)
+            delete c;
+    }
+};
 struct MafBlockEntry {
     int genome = -1;
     std::string name;
@@ -156,6 +170,7 @@ struct MafBlockEntry {
     char strand = '+';
     std::string sequence;
     short lastUsed = 0;
+    MafTree *tree = nullptr;
 };
 
 struct MafExport {
@@ -163,6 +178,7 @@ struct MafExport {
          append = false, unique = false;
     i64 maxBlockLength = 1000; // MafBlock::defaultMaxLength, halMafBlock.cpp:16
     i64 maxRefGap = 0;         // MafExport::_maxRefGap = the column iterator's maxInsertLength (halMafExport.cpp:47)
+    bool printTree = false;    // hal2maf --printTree
     void convertSequence(std::ostream &os, const Alignment &al, int genome, int seq, i64 startPosition, i64 length,
                          const std::set<int> &targets);
     // maf/impl/halMafExport.cpp:90-153 (hal2maf --global)
@@ -186,6 +202,10 @@ struct MafExport {
     bool canAppendColumn(ColumnIterator &col);
     void printBlock(std::ostream &os) const;
     bool referenceIsAllGaps() const;
+    MafTree *tree = nullptr;
+    MafTree *getTreeNode(const SegIt &segIt, bool modifyEntries);
+    void buildTreeR(const SegIt &botIt, MafTree *node, bool modifyEntries);
+    MafTree *buildTree(ColumnIterator &col, bool modifyEntries);
 
   public:
     ~MafExport();

@@ -84,7 +84,7 @@ static int cmdColumns(bool maf, int argc, char **argv) {
     std::string refGenome, refSequence, targetGenomes, rootGenome, refTargets;
     i64 start = 0, length = 0, step = 1, maxBlockLen = 1000, maxRefGap = 0;
     bool countDupes = false, noAncestors = false, noDupes = false, onlySequenceNames = false, onlyOrthologs = false, stats = false,
-         unique = false, global = false, keepEmptyRefBlocks = false;
+         unique = false, global = false, keepEmptyRefBlocks = false, printTree = false;
     for (int i = 0; i < argc; ++i) {
         std::string a = argv[i];
         if (a == "--refGenome")
@@ -121,6 +121,8 @@ static int cmdColumns(bool maf, int argc, char **argv) {
             unique = true;
         else if (a == "--keepEmptyRefBlocks")
             keepEmptyRefBlocks = true;
+        else if (a == "--printTree")
+            printTree = true;
         else if (a == "--global")
             global = true;
         else if (a == "--stats")
@@ -187,6 +189,7 @@ static int cmdColumns(bool maf, int argc, char **argv) {
         me.ucscNames = !onlySequenceNames;
         me.onlyOrthologs = onlyOrthologs;
         me.keepEmptyRefBlocks = keepEmptyRefBlocks;
+        me.printTree = printTree;
         me.unique = unique;
         me.maxRefGap = maxRefGap;
         me.maxBlockLength = maxBlockLen <= 0 ? std::numeric_limits<i64>::max() : maxBlockLen;

@@ -12,23 +12,41 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 # (seed, n_genomes, max_children, root_len), then per genome the exports below, in this order
-ALIGNMENTS = [(3, 5, 2, 150), (8, 6, 1, 180), (21, 5, 3, 120)]
+ALIGNMENTS = [(3, 5, 2, 150), (8, 6, 1, 180), (21, 5, 3, 120), ("randgen", 0, 0, 0)]
 EXPORTS = [({}, []), (dict(max_block_len=4, keep_empty_ref_blocks=True), ["--maxBlockLen", "4", "--keepEmptyRefBlocks"]),
-           (dict(no_dupes=True, only_sequence_names=True), ["--noDupes", "--onlySequenceNames"])]
+           (dict(no_dupes=True, only_sequence_names=True), ["--noDupes", "--onlySequenceNames"]),
+           (dict(unique=True), ["--unique"]),                       # the column-by-column path: visit cache replayed on the host
+           (dict(print_tree=True), ["--printTree"]),                # the same path with the block's tree
+           (dict(print_tree=True, no_dupes=True, max_block_len=9), ["--printTree", "--noDupes", "--maxBlockLen", "9"])]
+# hal2maf --printTree has no tree for a column whose first base is an insertion in a genome with bottom segments (the reference
+# dereferences a null iterator there, maf/impl/halMafBlock.cpp:281-287), nor where a base of the tree is not in the column (with
+# --noDupes the paralogs the tree walks to were left out: the reference asserts, :180): the library and the oracle both say so
+NO_TREE = ("has no parent in a genome with bottom segments", "no block entry continues at this base")
 
 
 def cases(hal, device, tmp):
     """yields (image path, genome name, text of the library, oracle arguments) for every export of the list"""
     import halfix
     for seed, ng, mc, rl in ALIGNMENTS:
-        img = os.path.join(tmp, "a%d.hgx" % seed)
-        halfix.write_hgx(img, halfix.random_multiseq_alignment(seed, n_genomes=ng, max_children=mc, root_len=rl))
+        img = os.path.join(tmp, "a%s.hgx" % seed)
+        if seed == "randgen":  # the generator of the reference's own tests (halRandGen --preset small --seed 0: every top segment has a parent)
+            opts = hal.RandOptions(mean_degree=1.3, max_branch_length=2.0, min_genomes=3, max_genomes=5, min_segment_length=5,
+                                   max_segment_length=25, min_segments=8, max_segments=20, seed=4, with_dna=True)
+            hal.Alignment.random(opts, device=-1).save(img)
+        else:
+            halfix.write_hgx(img, halfix.random_multiseq_alignment(seed, n_genomes=ng, max_children=mc, root_len=rl))
         al = hal.Alignment.open(img, device=device)
         for g in range(al.num_genomes):
             if al.genome_length(g) == 0:
                 continue
             for kw, args in EXPORTS:
-                yield img, al.genome_name(g), al.maf_export(g, **kw), ["--refGenome", al.genome_name(g)] + args
+                try:
+                    text = al.maf_export(g, **kw)
+                except hal.HgxError as e:
+                    if not any(m in str(e) for m in NO_TREE):
+                        raise
+                    text = None
+                yield img, al.genome_name(g), text, ["--refGenome", al.genome_name(g)] + args
 
 
 if __name__ == "__main__":

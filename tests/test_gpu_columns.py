@@ -285,3 +285,39 @@ def test_maf_block_length_breaks_where_rows_change_sequence(hal, oracle_bin, tmp
         nm = al.genome_name(g)
         for mbl in (17, 3):
             assert al.maf_export(g, max_block_len=mbl) == _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", nm, "--maxBlockLen", str(mbl)), (nm, mbl)
+
+
+def test_maf_print_tree_against_the_oracle(hal, oracle_bin, tmp_path):
+    """hal2maf --printTree (maf/impl/halMafBlock.cpp:121-292, 443-448, 485-497): every block with the tree of its rows, blocks also
+    ending where the column's tree changes, rows in the tree's post order.  The reference holds no expected file for the option
+    and its tree code (sonLib) is not in the reference tree: held against the oracle's restatement only.  Where the reference has
+    no tree for a column (its first base an insertion in a genome with bottom segments; a paralog --noDupes left out) the library
+    and the oracle refuse with the same words."""
+    import halfix
+    import make_maf_batches as mk
+    trees = refused = 0
+    images = []
+    for seed in (2, 4):
+        al, img = _rand(hal, tmp_path, seed)
+        images.append((al, img))
+    img = str(tmp_path / "ms.hgx")
+    halfix.write_hgx(img, halfix.random_multiseq_alignment(3, n_genomes=5, max_children=2, root_len=150))
+    images.append((hal.Alignment.open(img, device=0), img))
+    for al, img in images:
+        for g in range(al.num_genomes):
+            if al.genome_length(g) == 0:
+                continue
+            nm = al.genome_name(g)
+            for kw, args in ((dict(), []), (dict(max_block_len=7), ["--maxBlockLen", "7"]), (dict(only_orthologs=True), ["--onlyOrthologs"])):
+                out = str(tmp_path / "o.maf")
+                r = subprocess.run([oracle_bin, "maf", img, out, "--refGenome", nm, "--printTree"] + args, stderr=subprocess.PIPE)
+                try:
+                    got = al.maf_export(g, print_tree=True, **kw)
+                except hal.HgxError as e:
+                    assert r.returncode != 0 and any(m in str(e) and m in r.stderr.decode() for m in mk.NO_TREE), (nm, kw, str(e))
+                    refused += 1
+                    continue
+                assert r.returncode == 0 and got == open(out).read(), (nm, kw)
+                assert 'a tree="' in got
+                trees += 1
+    assert trees >= 6 and refused >= 1
