@@ -20,6 +20,7 @@ struct ColumnParams {
     int64_t count; // number of columns
     int64_t step;  // distance between consecutive columns (halAlignmentDepth --step)
     int32_t noDupes, noAncestors, onlyOrthologs;
+    int32_t noGapEvents; // hgx_gap_kernels.hpp: the walk reports no deletions / insertions (maxInsertLength == 0)
     const unsigned long long *scopeMask;  // device, ceil(numGenomes / 64) words: genomes the walk may enter (all ones when no targets)
     const unsigned long long *targetMask; // device: genomes whose bases are reported
     unsigned int *error;              // set to 1 on frame-stack overflow

@@ -423,7 +423,7 @@ void columnsRowsHost(hgx_alignment *h, int ref, int64_t first, int64_t count, co
     unsigned int e = 0;
     HIP_OK(hipMemcpy(&e, err.p, 4, hipMemcpyDeviceToHost));
     if (e)
-        throw std::runtime_error("column walk exceeded the frame stack (more than 64 pending branches for one base)");
+        throw std::runtime_error("column walk exceeded the frame stack (more than 64 pending branches for one base, or a recursion deeper than 253)");
     if (total)
         HIP_OK(hipMemcpy(rows.data(), dRows.p, total * sizeof(ColumnRow), hipMemcpyDeviceToHost));
     if (stats) {
@@ -435,7 +435,7 @@ void columnsRowsHost(hgx_alignment *h, int ref, int64_t first, int64_t count, co
 }
 
 void columnsGapRowsHost(hgx_alignment *h, int ref, const std::vector<GapAskHost> &asks, const ColumnOptions &opt, bool withDna,
-                        std::vector<uint64_t> &rowOffset, std::vector<ColumnRowHost> &rows, ColumnStats *stats) {
+                        std::vector<uint64_t> &rowOffset, std::vector<ColumnRowHost> &rows, ColumnStats *stats, bool events) {
     static_assert(sizeof(GapAskHost) == sizeof(GapAsk), "ask layouts must match");
     if (!h->dev)
         throw std::runtime_error("alignment was opened without a device (device = -1); the column engine needs the HIP path");
@@ -455,6 +455,7 @@ void columnsGapRowsHost(hgx_alignment *h, int ref, const std::vector<GapAskHost>
     HIP_OK(hipMemset(err.p, 0, 4));
     ColumnParams P = makeParams(h, ref, 0, 0, 1, opt, (unsigned int *)err.p, masks);
     P.count = (int64_t)n;
+    P.noGapEvents = events ? 0 : 1;
     Ev a, b;
     HIP_OK(hipEventRecord(a.e, nullptr));
     const int grid = (int)std::min<int64_t>(COL_GRID, ((int64_t)n + 255) / 256);
@@ -480,7 +481,7 @@ void columnsGapRowsHost(hgx_alignment *h, int ref, const std::vector<GapAskHost>
     unsigned int e = 0;
     HIP_OK(hipMemcpy(&e, err.p, 4, hipMemcpyDeviceToHost));
     if (e)
-        throw std::runtime_error("column walk exceeded the frame stack (more than 64 pending branches for one base)");
+        throw std::runtime_error("column walk exceeded the frame stack (more than 64 pending branches for one base, or a recursion deeper than 253)");
     if (total)
         HIP_OK(hipMemcpy(rows.data(), dRows.p, total * sizeof(ColumnRow), hipMemcpyDeviceToHost));
     if (stats) {

@@ -57,8 +57,10 @@ struct GapAskHost {
     int32_t genome;
     int32_t reversed;
 };
+// _pad[0] & 16: a paralog inserted by updateNextTopDup's loop; _pad[1] of a base row: its depth in the recursion (the level, on
+// the upward chain).  events = false: no deleted / inserted ranges are looked for (maxInsertLength == 0).
 void columnsGapRowsHost(hgx_alignment *h, int ref, const std::vector<GapAskHost> &asks, const ColumnOptions &opt, bool withDna,
-                        std::vector<uint64_t> &rowOffset, std::vector<ColumnRowHost> &rows, ColumnStats *stats);
+                        std::vector<uint64_t> &rowOffset, std::vector<ColumnRowHost> &rows, ColumnStats *stats, bool events = true);
 
 // Run-compressed form for the MAF writer: head[c] == 1 when column c does not simply continue column c-1 (same rows
 // advanced by one base); only heads have their rows returned (headOffset: one entry per head, + 1).

@@ -1422,7 +1422,8 @@ void MafExport::convertSequence(std::ostream &mafStream, hgx_alignment *alignmen
     opt.targets.assign(targets.begin(), targets.end());
     const Key refKey{_rank[(size_t)genome][(size_t)seq], genome, seq};
 
-    if (_maxRefGap > 0) {
+    // (the iterator whose state is sequential — a visit cache, a stack of ranges — is replayed on the host over the device's columns)
+    if (_maxRefGap > 0 || _unique) {
         convertSequenceGapped(mafStream, alignment, genome, seq, startPosition + S.start, startPosition + S.start + length - 1, opt);
         return;
     }
@@ -1815,16 +1816,42 @@ struct GapColumns {
         std::vector<ColumnRowHost> rows;
     };
     std::deque<Batch> batches, previous; // previous: the chunk before (the column map may still point into it)
-    std::map<ColKey, std::pair<uint32_t, uint32_t>> where;
+    std::map<ColKey, std::pair<uint32_t, uint32_t>> where; // (the columns of the ranges; the reference columns are found by their index)
+    int64_t baseFirst = 0, baseCount = 0;
     GapColumns(hgx_alignment *a, int ref, const ColumnOptions &o, int64_t mi, ColumnStats *st) : al(a), refGenome(ref), opt(o), maxInsert(mi), stats(st) {}
 
-    void run(std::vector<GapAskHost> &&asks) {
+    void run(std::vector<GapAskHost> &&asks, bool index = true) {
         batches.emplace_back();
         Batch &B = batches.back();
         B.asks = std::move(asks);
-        columnsGapRowsHost(al, refGenome, B.asks, opt, true, B.off, B.rows, stats);
-        for (size_t i = 0; i < B.asks.size(); ++i)
-            where[ColKey{B.asks[i].pos, B.asks[i].genome, B.asks[i].reversed}] = {(uint32_t)batches.size() - 1, (uint32_t)i};
+        const bool events = maxInsert > 0;
+#ifdef HGX_HOST_PROFILE
+        // (the profiling build's recording / playback of the device's batches: HGX_MAF_DUMP / HGX_MAF_REPLAY)
+        if (FILE *replay = mafReplayFile()) {
+            uint64_t hd[4];
+            if (fread(hd, 8, 4, replay) != 4 || hd[0] != 0x4741505Full || hd[1] != B.asks.size())
+                throw std::runtime_error("HGX_MAF_REPLAY: the file does not continue with this batch of columns");
+            B.off.resize((size_t)hd[2]);
+            B.rows.resize((size_t)hd[3]);
+            if (fread(B.off.data(), 8, B.off.size(), replay) != B.off.size() ||
+                fread(B.rows.data(), sizeof(ColumnRowHost), B.rows.size(), replay) != B.rows.size())
+                throw std::runtime_error("HGX_MAF_REPLAY: short file");
+        } else {
+            columnsGapRowsHost(al, refGenome, B.asks, opt, true, B.off, B.rows, stats, events);
+            if (FILE *dump = mafDumpFile()) {
+                const uint64_t hd[4] = {0x4741505Full, B.asks.size(), B.off.size(), B.rows.size()};
+                fwrite(hd, 8, 4, dump);
+                fwrite(B.off.data(), 8, B.off.size(), dump);
+                fwrite(B.rows.data(), sizeof(ColumnRowHost), B.rows.size(), dump);
+                fflush(dump);
+            }
+        }
+#else
+        columnsGapRowsHost(al, refGenome, B.asks, opt, true, B.off, B.rows, stats, events);
+#endif
+        if (index)
+            for (size_t i = 0; i < B.asks.size(); ++i)
+                where[ColKey{B.asks[i].pos, B.asks[i].genome, B.asks[i].reversed}] = {(uint32_t)batches.size() - 1, (uint32_t)i};
     }
     bool usable(const ColumnRowHost &head, const ColumnRowHost &tail) const { // a range the iterator can walk (and may accept)
         const int64_t first = head.pos, last = tail.pos;
@@ -1839,8 +1866,10 @@ struct GapColumns {
         std::vector<GapAskHost> asks((size_t)count);
         for (int64_t i = 0; i < count; ++i)
             asks[(size_t)i] = GapAskHost{first + i, refGenome, 0};
-        run(std::move(asks));
-        for (size_t level = 0; level < batches.size(); ++level) { // (a batch may add the next one)
+        run(std::move(asks), false);
+        baseFirst = first;
+        baseCount = count;
+        for (size_t level = 0; maxInsert > 0 && level < batches.size(); ++level) { // (a batch may add the next one)
             const Batch &B = batches[level];
             std::vector<GapAskHost> next;
             std::set<ColKey> seen;
@@ -1850,7 +1879,8 @@ struct GapColumns {
                     continue;
                 for (int64_t p = B.rows[r].pos; p <= B.rows[r + 1].pos; ++p) {
                     const ColKey k{p, B.rows[r].genome, B.rows[r].rev ? 1 : 0};
-                    if (!where.count(k) && seen.insert(k).second)
+                    const bool base = k.genome == refGenome && !k.reversed && p >= baseFirst && p < baseFirst + baseCount;
+                    if (!base && !where.count(k) && seen.insert(k).second)
                         next.push_back(GapAskHost{p, k.genome, k.reversed});
                 }
             }
@@ -1860,6 +1890,12 @@ struct GapColumns {
     }
     // rows of the column that starts from (genome, pos, reversed): [begin, end)
     void column(int g, int64_t pos, bool reversed, const ColumnRowHost *&begin, const ColumnRowHost *&end) {
+        if (g == refGenome && !reversed && pos >= baseFirst && pos < baseFirst + baseCount && !batches.empty()) {
+            const Batch &B = batches[0];
+            begin = B.rows.data() + B.off[(size_t)(pos - baseFirst)];
+            end = B.rows.data() + B.off[(size_t)(pos - baseFirst) + 1];
+            return;
+        }
         auto it = where.find(ColKey{pos, g, reversed ? 1 : 0});
         if (it == where.end()) { // (not foreseen by the prefetch: asked for by itself)
             run(std::vector<GapAskHost>{GapAskHost{pos, g, reversed ? 1 : 0}});
@@ -1937,17 +1973,25 @@ struct ReplayIterator {
         const ColumnRowHost *r, *end;
         cols.column(e.g, e.index, e.reversed, r, end);
         unsigned long long open = 0; // levels of the upward chain whose parse-up branch is under way (their deletion check is still to come)
+        // After the walk is abandoned (a base seen before): updateNextTopDup's loop over a paralogy cycle does not look at _break
+        // (:653-680), so the cycles the abandoned base lies under — inside the subtree of one of their members — still insert
+        // their remaining members (colMapInsert and handleInsertion; the members' own subtrees are not walked).  ringAt[d]: the
+        // last base at depth d was such a member; after the break ringOn[d]: the cycle at depth d goes on.
+        bool ringAt[256], ringOn[256];
+        int breakDepth = -1;
+        bool memberInserted = false; // the base row before was a member inserted after the break: its insertion event counts
         for (; r < end; ++r) {
-            const int kind = r->_pad[0] & 7, level = r->_pad[1];
+            const int kind = r->_pad[0] & 7;
             if (kind == 4)
                 continue;
             if (kind == 2 || kind == 3) {
+                const int level = r->_pad[1];
                 const bool pendingDeletion = kind == 2 && level >= 1 && level < 64 && ((open >> level) & 1ull);
                 if (kind == 2 && level >= 1 && level < 64)
                     open &= ~(1ull << level);
                 // after the walk was abandoned only the deletion checks of the updateParent calls it was inside are still made
-                // (:585-589 is not guarded by _break)
-                if (maxInsert <= 0 || (brk && !pendingDeletion))
+                // (:585-589 is not guarded by _break), and the insertion checks of the cycle members that are still inserted
+                if (maxInsert <= 0 || (brk && !pendingDeletion && !(kind == 3 && memberInserted)))
                     continue;
                 const int64_t lo = r->pos, hi = r[1].pos;
                 if (lo < 0 || hi < lo || hi >= al->img.genomes[(size_t)r->genome].totalLength)
@@ -1956,8 +2000,20 @@ struct ReplayIterator {
                     pushEntry(kind == 2 ? deletionStack : insertionStack, r->genome, lo, hi, r->rev != 0);
                 continue;
             }
-            if (brk)
-                continue;
+            const int depth = r->_pad[1];
+            const bool ring = (r->_pad[0] & 16) != 0;
+            memberInserted = false;
+            if (brk) {
+                for (int k = depth + 1; k <= breakDepth; ++k)
+                    ringOn[k] = false; // (the calls deeper than this base have returned)
+                if (!(ring && depth <= breakDepth && ringOn[depth])) {
+                    if (depth <= breakDepth)
+                        ringOn[depth] = false; // (another call's base at this depth: whatever cycle was there is over)
+                    continue;
+                }
+            } else {
+                ringAt[depth] = ring;
+            }
             // colMapInsert
             bool updateCache = r->genome == genome;
             if (maxInsert == 0)
@@ -1973,18 +2029,34 @@ struct ReplayIterator {
                 auto it = visitCache.find(r->genome);
                 found = it != visitCache.end() && it->second.find(r->pos);
             }
+#ifdef HGX_HOST_PROFILE
+            if (getenv("HGX_REPLAY_TRACE"))
+                fprintf(stderr, "  col g%d idx %lld: row g%d pos %lld rev %d kind %d depth %d ring %d upd %d found %d brk %d\n", e.g, (long long)e.index,
+                        r->genome, (long long)r->pos, (int)r->rev, kind, depth, (int)ring, (int)updateCache, (int)found, (int)brk);
+#endif
             if (!found && kind == 0) {
                 column.push_back(r);
                 inserted.emplace_back(r->genome, r->pos);
             }
             if (r->genome == genome)
                 leftmostRefPos = std::min(leftmostRefPos, r->pos);
-            if (found) {
-                brk = true;
+            if (brk) { // a member of a cycle that goes on
+                if (found)
+                    ringOn[depth] = false; // (:669-672: the loop returns)
+                else
+                    memberInserted = true;
                 continue;
             }
-            if ((r->_pad[0] & 8) && level >= 1 && level < 64)
-                open |= 1ull << level;
+            if (found) {
+                brk = true;
+                breakDepth = depth;
+                for (int k = 0; k < depth; ++k)
+                    ringOn[k] = ringAt[k]; // the cycles whose member's subtree this base lies in
+                ringOn[depth] = false;     // (a member that is found itself ends its loop)
+                continue;
+            }
+            if ((r->_pad[0] & 8) && depth >= 1 && depth < 64)
+                open |= 1ull << depth; // (on the upward chain the depth is the level)
         }
     }
     void toRight() { // :65-144

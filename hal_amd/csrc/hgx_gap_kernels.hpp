@@ -38,7 +38,8 @@ struct GapAsk { // a column: the base its walk starts from (ColumnIteratorStack:
 // row kinds (ColumnRow::_pad[0]); _pad[1] = the level of the walk's upward chain the row belongs to (0: the column's own
 // genome; a parent base reached by updateParent: its level, 1 for the first; events of handleDeletion at a parse-up: the level
 // of the parent base they hang on) — the host needs it to know which deletions of an abandoned column were still made
-enum : uint8_t { GAP_ROW = 0, GAP_ROW_HIDDEN = 1, GAP_DELETION = 2, GAP_INSERTION = 3, GAP_EVENT_END = 4, GAP_ROW_UP = 8 /* flag: reached by updateParent */ };
+enum : uint8_t { GAP_ROW = 0, GAP_ROW_HIDDEN = 1, GAP_DELETION = 2, GAP_INSERTION = 3, GAP_EVENT_END = 4, GAP_ROW_UP = 8 /* flag: reached by updateParent */,
+                 GAP_ROW_RING = 16 /* flag: a paralog updateNextTopDup's loop inserts */ };
 
 // a whole segment seen through an iterator (what the atomic, gap-threshold-0 gapped iterators of Rearrangement degenerate to:
 // halGappedTopSegmentIterator.cpp / halGappedBottomSegmentIterator.cpp with _atomic and _gapThreshold == 0)
@@ -191,8 +192,14 @@ template <typename C> struct GapTables {
 
 enum : uint32_t { FR_DELETION = 5 };
 
-// V: visitor with  void row(int genome, int64_t pos, bool rev, bool reported, int level, bool up)
+// V: visitor with  void row(int genome, int64_t pos, bool rev, bool reported, int depth, bool up, bool ring)
 //                  void event(uint8_t kind, int level, int genome, int64_t first, int64_t last, bool reversed)
+// depth: how deep in the recursion the call that inserts the base sits — 0 the column's own base, one more for the parent base an
+// updateParent inserts (on the upward chain depth and level are the same number), for the child bases of updateChild, and for the
+// paralogs updateNextTopDup goes round (ring: they hang one deeper than the segment whose ring it is, their own children another
+// one deeper).  The host needs it where a walk is abandoned at a base seen before: the paralogy loop of updateNextTopDup does not
+// look at _break (halColumnIterator.cpp:653-680), so the rest of a ring whose member's subtree the walk was abandoned in is still
+// inserted — those bases, and only those, are the ring rows at the depth of a ring member the abandoned base lies under.
 template <typename C> struct GapWalker {
     const ColumnParams &P;
     GapTables<C> tab;
@@ -200,8 +207,9 @@ template <typename C> struct GapWalker {
     int sp = 0;
     bool overflow = false;
     __device__ GapWalker(const ColumnParams &p) : P(p) { tab.desc = p.desc; }
-    __device__ __forceinline__ void push(uint32_t kind, int g, int32_t idx, int32_t so, bool rev, int32_t extra) {
-        if (sp >= COL_STACK) {
+    // depth: of the base the frame belongs to (what it inserts lies one deeper)
+    __device__ __forceinline__ void push(uint32_t kind, int g, int32_t idx, int32_t so, bool rev, int32_t extra, int depth) {
+        if (sp >= COL_STACK || depth >= 254 || g >= 65536) {
             overflow = true;
             return;
         }
@@ -209,17 +217,19 @@ template <typename C> struct GapWalker {
         f.idx = idx;
         f.so = so;
         f.extra = extra;
-        f.meta = kind | ((uint32_t)rev << 3) | ((uint32_t)g << 4);
+        f.meta = kind | ((uint32_t)rev << 3) | ((uint32_t)g << 4) | ((uint32_t)depth << 20);
         stack[sp++] = f;
     }
     template <typename REC> __device__ __forceinline__ int64_t posOf(const REC *segs, int32_t idx, int32_t so, bool rev) const {
         return !rev ? (int64_t)segs[idx].start + so : (int64_t)segs[idx + 1].start - 1 - so;
     }
-    template <typename V> __device__ __forceinline__ void insert(V &visit, int g, int64_t pos, bool rev, int level, bool up) const {
-        visit.row(g, pos, rev, (!P.noAncestors || P.desc[g].numChildren == 0) && bit(P.targetMask, g), level, up);
+    template <typename V> __device__ __forceinline__ void insert(V &visit, int g, int64_t pos, bool rev, int depth, bool up, bool ring) const {
+        visit.row(g, pos, rev, (!P.noAncestors || P.desc[g].numChildren == 0) && bit(P.targetMask, g), depth, up, ring);
     }
     // handleDeletion (halColumnIterator.cpp:357-382) at the base with offset so (iteration order) of top segment t of genome g
     template <typename V> __device__ __forceinline__ void handleDeletion(V &visit, int g, int32_t t, int32_t so, bool rev, int level) const {
+        if (P.noGapEvents)
+            return; // (maxInsertLength == 0: the handlers do nothing, :358, :385)
         const TopRec<C> *T = tab.top(g);
         if (T[t].parentEnc < 0 || (int64_t)so != (int64_t)T[t + 1].start - (int64_t)T[t].start - 1)
             return; // no parent, or not immediately left of the breakpoint (end offset 0)
@@ -230,6 +240,8 @@ template <typename C> struct GapWalker {
     }
     // handleInsertion (:384-405)
     template <typename V> __device__ __forceinline__ void handleInsertion(V &visit, int g, int32_t t, int32_t so, bool rev, int level) const {
+        if (P.noGapEvents)
+            return;
         const TopRec<C> *T = tab.top(g);
         if (T[t].parentEnc < 0 || (int64_t)so != (int64_t)T[t + 1].start - (int64_t)T[t].start - 1)
             return;
@@ -257,14 +269,14 @@ template <typename C> struct GapWalker {
             const int32_t t = (int32_t)lo;
             const TopRec<C> tr = T[t];
             const int32_t so = !rrev ? (int32_t)(p - (int64_t)tr.start) : (int32_t)((int64_t)T[t + 1].start - 1 - p);
-            insert(visit, R, p, rrev, 0, false);
+            insert(visit, R, p, rrev, 0, false, false);
             handleDeletion(visit, R, t, so, rrev, 0);
             if (tr.botParse >= 0)
-                push(FR_PARSEDOWN, R, t, so, rrev, 0);
+                push(FR_PARSEDOWN, R, t, so, rrev, 0, 0);
             if (!P.onlyOrthologs && tr.paralogy >= 0)
-                push(FR_RING, R, t, so, rrev, t);
+                push(FR_RING, R, t, so, rrev, t, 0);
             if (tr.parentEnc >= 0)
-                push(FR_UP, R, t, so, rrev, 1);
+                push(FR_UP, R, t, so, rrev, 1, 0);
         } else {
             const BotRec<C> *B = tab.bot(R);
             int64_t lo = 0, hi = RD.numBot;
@@ -277,16 +289,17 @@ template <typename C> struct GapWalker {
             }
             const int32_t b = (int32_t)lo;
             const int32_t so = !rrev ? (int32_t)(p - (int64_t)B[b].start) : (int32_t)((int64_t)B[b + 1].start - 1 - p);
-            insert(visit, R, p, rrev, 0, false);
+            insert(visit, R, p, rrev, 0, false, false);
             for (int i = RD.numChildren - 1; i >= 0; --i)
                 if (RD.child[i][b] >= 0)
-                    push(FR_CHILD, R, b, so, rrev, i);
+                    push(FR_CHILD, R, b, so, rrev, i, 0);
         }
         while (sp > 0) {
             const Frame f = stack[--sp];
             const uint32_t kind = f.meta & 7u;
             const bool rev = (f.meta >> 3) & 1u;
-            const int g = (int)(f.meta >> 4);
+            const int g = (int)((f.meta >> 4) & 0xFFFFu);
+            const int depth = (int)(f.meta >> 20);
             const GenomeDesc &D = P.desc[g];
             if (kind == FR_UP) { // updateParent (:556-605); f.extra: the level of the parent base
                 const TopRec<C> tr = tab.top(g)[f.idx];
@@ -296,13 +309,13 @@ template <typename C> struct GapWalker {
                     const int32_t b = tr.parentEnc >> 1;
                     if (!P.noDupes || (PD.child[D.slotInParent][b] >> 1) == f.idx) {
                         const bool brev = rev ^ ((tr.parentEnc & 1) != 0);
-                        insert(visit, pg, posOf(tab.bot(pg), b, f.so, brev), brev, f.extra, true);
+                        insert(visit, pg, posOf(tab.bot(pg), b, f.so, brev), brev, depth + 1, true, false); // (depth + 1 == f.extra, the level)
                         for (int i = PD.numChildren - 1; i >= 0; --i) // siblings: after the parse-up branch and its deletion
                             if (i != D.slotInParent && PD.child[i][b] >= 0)
-                                push(FR_CHILD, pg, b, f.so, brev, i);
+                                push(FR_CHILD, pg, b, f.so, brev, i, depth + 1);
                         if (PD.parent >= 0) {
-                            push(FR_DELETION, pg, b, f.so, brev, f.extra); // handleDeletion(parent's top parse), :587-589
-                            push(FR_PARSEUP, pg, b, f.so, brev, f.extra);
+                            push(FR_DELETION, pg, b, f.so, brev, f.extra, depth + 1); // handleDeletion(parent's top parse), :587-589
+                            push(FR_PARSEUP, pg, b, f.so, brev, f.extra, depth + 1);
                         }
                     }
                 }
@@ -322,9 +335,9 @@ template <typename C> struct GapWalker {
                         handleDeletion(visit, g, j, so, rev, f.extra);
                     } else {
                         if (!P.onlyOrthologs && tj.paralogy >= 0)
-                            push(FR_RING, g, j, so, rev, j);
+                            push(FR_RING, g, j, so, rev, j, depth);
                         if (tj.parentEnc >= 0)
-                            push(FR_UP, g, j, so, rev, f.extra + 1);
+                            push(FR_UP, g, j, so, rev, f.extra + 1, depth);
                     }
                 }
             } else if (kind == FR_CHILD) { // updateChild (:607-640)
@@ -335,12 +348,12 @@ template <typename C> struct GapWalker {
                     const int32_t t = enc >> 1;
                     const bool crev = rev ^ ((enc & 1) != 0);
                     const TopRec<C> ct = tab.top(cg)[t];
-                    insert(visit, cg, !crev ? (int64_t)ct.start + f.so : (int64_t)tab.top(cg)[t + 1].start - 1 - f.so, crev, 0, false);
+                    insert(visit, cg, !crev ? (int64_t)ct.start + f.so : (int64_t)tab.top(cg)[t + 1].start - 1 - f.so, crev, depth + 1, false, false);
                     handleInsertion(visit, cg, t, f.so, crev, 0);
                     if (ct.botParse >= 0)
-                        push(FR_PARSEDOWN, cg, t, f.so, crev, 0);
+                        push(FR_PARSEDOWN, cg, t, f.so, crev, 0, depth + 1);
                     if (ct.paralogy >= 0)
-                        push(FR_RING, cg, t, f.so, crev, t);
+                        push(FR_RING, cg, t, f.so, crev, t, depth + 1);
                 }
             } else if (kind == FR_RING) { // updateNextTopDup (:642-681), one ring member per frame
                 const TopRec<C> *T = tab.top(g);
@@ -354,12 +367,12 @@ template <typename C> struct GapWalker {
                     const int32_t nxt = cur.paralogy;
                     const TopRec<C> nr = T[nxt];
                     const bool nrev = rev ^ ((nr.parentEnc & 1) != (cur.parentEnc & 1));
-                    insert(visit, g, posOf(T, nxt, f.so, nrev), nrev, 0, false);
+                    insert(visit, g, posOf(T, nxt, f.so, nrev), nrev, depth + 1, false, true);
                     handleInsertion(visit, g, nxt, f.so, nrev, 0);
                     if (nr.paralogy >= 0 && nr.paralogy != first)
-                        push(FR_RING, g, nxt, f.so, nrev, first);
+                        push(FR_RING, g, nxt, f.so, nrev, first, depth); // (the rest of the ring: the same loop)
                     if (nr.botParse >= 0)
-                        push(FR_PARSEDOWN, g, nxt, f.so, nrev, 0);
+                        push(FR_PARSEDOWN, g, nxt, f.so, nrev, 0, depth + 1);
                 }
             } else { // FR_PARSEDOWN: updateParseDown (:711-744)
                 const TopRec<C> *T = tab.top(g);
@@ -373,7 +386,7 @@ template <typename C> struct GapWalker {
                     const int32_t so = !rev ? (int32_t)(pos - (int64_t)B[j].start) : (int32_t)((int64_t)B[j + 1].start - 1 - pos);
                     for (int i = D.numChildren - 1; i >= 0; --i)
                         if (D.child[i][j] >= 0)
-                            push(FR_CHILD, g, j, so, rev, i);
+                            push(FR_CHILD, g, j, so, rev, i, depth);
                 }
             }
         }
@@ -382,14 +395,14 @@ template <typename C> struct GapWalker {
 
 struct GapCountVisitor {
     uint32_t n = 0;
-    __device__ __forceinline__ void row(int, int64_t, bool, bool, int, bool) { ++n; }
+    __device__ __forceinline__ void row(int, int64_t, bool, bool, int, bool, bool) { ++n; }
     __device__ __forceinline__ void event(uint8_t, int, int, int64_t, int64_t, bool) { n += 2; }
 };
 struct GapRowVisitor {
     ColumnRow *dst;
     const GenomeDesc *desc;
     uint32_t n = 0;
-    __device__ __forceinline__ void row(int g, int64_t pos, bool rev, bool reported, int level, bool up) {
+    __device__ __forceinline__ void row(int g, int64_t pos, bool rev, bool reported, int depth, bool up, bool ring) {
         ColumnRow r;
         r.pos = pos;
         r.genome = g;
@@ -414,8 +427,8 @@ struct GapRowVisitor {
             }
         }
         r.base = c;
-        r._pad[0] = (uint8_t)((reported ? GAP_ROW : GAP_ROW_HIDDEN) | (up ? GAP_ROW_UP : 0));
-        r._pad[1] = (uint8_t)level;
+        r._pad[0] = (uint8_t)((reported ? GAP_ROW : GAP_ROW_HIDDEN) | (up ? GAP_ROW_UP : 0) | (ring ? GAP_ROW_RING : 0));
+        r._pad[1] = (uint8_t)depth; // (on the upward chain: the level)
         dst[n++] = r;
     }
     __device__ __forceinline__ void event(uint8_t kind, int level, int g, int64_t first, int64_t last, bool reversed) {

@@ -1,5 +1,7 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY (see hal_oracle.hpp).
 #include "oracle_columns.hpp"
+#include <cstdio>
+#include <cstdlib>
 #include <deque>
 #include <chrono>
 
@@ -153,6 +155,9 @@ void ColumnIterator::defragment() {
 bool ColumnIterator::colMapInsert(const SegIt &it) {
     const int g = it.g;
     const i64 pos = it.getStartPosition();
+    static const bool trace = getenv("ORC_TRACE") != nullptr; // (debugging aid: the order bases reach the column map in)
+    if (trace)
+        fprintf(stderr, "  col g%d idx %lld: insert g%d pos %lld rev %d\n", refGenome, (long long)top().index, g, (long long)pos, (int)it.rev);
     bool updateCache = g == refGenome; // all reference bases are added to the cache ...
     if (maxInsertLength == 0)          // ... unless indels are not done: then only the ones right of the starting point
         updateCache = updateCache && top().firstIndex < pos;
@@ -170,6 +175,8 @@ bool ColumnIterator::colMapInsert(const SegIt &it) {
     } else {
         found = cacheIt != visitCache.end() && cacheIt->second.find(pos);
     }
+    if (trace)
+        fprintf(stderr, "      upd %d found %d cache-has-genome %d\n", (int)updateCache, (int)found, (int)(visitCache.find(g) != visitCache.end()));
     if (!found && (!noAncestors || al->genomes[(size_t)g].children.empty()) && (targets.empty() || targets.count(g))) {
         SeqKey k{al, g, seqIndexBySite(al->genomes[(size_t)g], pos)};
         colMap[k].push_back(Dna{g, pos, it.rev});
