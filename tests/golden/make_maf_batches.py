@@ -49,14 +49,29 @@ def cases(hal, device, tmp):
                 yield img, al.genome_name(g), text, ["--refGenome", al.genome_name(g)] + args
 
 
+# hal2maf --global over an alignment a randomised soak found (profiles/scripts/r03_features_soak.py): the last walk of a leaf's pass
+# is abandoned under a paralogy cycle that still inserts its remaining members (halColumnIterator.cpp:653-680)
+GLOBAL_CASE = (1431, 6, 2, 807)
+
+
+def global_case(hal, device, tmp):
+    import halfix
+    seed, ng, mc, rl = GLOBAL_CASE
+    img = os.path.join(tmp, "g%d.hgx" % seed)
+    halfix.write_hgx(img, halfix.random_multiseq_alignment(seed, n_genomes=ng, max_children=mc, root_len=rl))
+    return img, hal.Alignment.open(img, device=device).maf_export_global()
+
+
 if __name__ == "__main__":
+    # usage (GPU box): python tests/golden/make_maf_batches.py [global]   (one recording per process: the library opens its file once)
     import tempfile
-    out = os.path.join(HERE, "maf_batches.bin")
+    which = sys.argv[1] if len(sys.argv) > 1 else "exports"
+    out = os.path.join(HERE, "maf_batches.bin" if which == "exports" else "maf_global_batches.bin")
     if os.path.exists(out):
         os.remove(out)
     os.environ["HGX_MAF_DUMP"] = out
     os.environ["HGX_LIB_PATH"] = os.path.join(ROOT, "hal_amd", "libhgx_hostprof.so")
     import hal_amd as hal
     with tempfile.TemporaryDirectory() as tmp:
-        n = sum(1 for _ in cases(hal, 0, tmp))
-    print("%d exports recorded, %d bytes" % (n, os.path.getsize(out)))
+        n = sum(1 for _ in cases(hal, 0, tmp)) if which == "exports" else len(global_case(hal, 0, tmp)[1])
+    print("%s recorded (%d), %d bytes" % (which, n, os.path.getsize(out)))
