@@ -17,7 +17,9 @@ EXPORTS = [({}, []), (dict(max_block_len=4, keep_empty_ref_blocks=True), ["--max
            (dict(no_dupes=True, only_sequence_names=True), ["--noDupes", "--onlySequenceNames"]),
            (dict(unique=True), ["--unique"]),                       # the column-by-column path: visit cache replayed on the host
            (dict(print_tree=True), ["--printTree"]),                # the same path with the block's tree
-           (dict(print_tree=True, no_dupes=True, max_block_len=9), ["--printTree", "--noDupes", "--maxBlockLen", "9"])]
+           (dict(print_tree=True, no_dupes=True, max_block_len=9), ["--printTree", "--noDupes", "--maxBlockLen", "9"]),
+           (dict(max_ref_gap=9), ["--maxRefGap", "9"]),             # the iterator with its stack of inserted / deleted ranges
+           (dict(max_ref_gap=1000, no_dupes=True, max_block_len=13), ["--maxRefGap", "1000", "--noDupes", "--maxBlockLen", "13"])]
 # hal2maf --printTree has no tree for a column whose first base is an insertion in a genome with bottom segments (the reference
 # dereferences a null iterator there, maf/impl/halMafBlock.cpp:281-287), nor where a base of the tree is not in the column (with
 # --noDupes the paralogs the tree walks to were left out: the reference asserts, :180): the library and the oracle both say so

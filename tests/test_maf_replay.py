@@ -1,5 +1,5 @@
 """hal2maf's host side — MafBlock's state machine on flat arrays, the log of pairings, the rendering threads; the column-by-column
-path of --unique and --printTree (visit cache, the block's tree)
+paths of --unique, --maxRefGap and --printTree (visit caches, the stack of inserted and deleted ranges, the block's tree)
 (hal_amd/csrc/hgx_columns_host.cpp: MafExport::RunMachine; maf/impl/halMafBlock.cpp:36-82, 294-450, maf/impl/halMafExport.cpp:51-87) —
 without a GPU: the device's batches of a list of exports were recorded on a GPU box (tests/golden/make_maf_batches.py); the
 profiling build of the library (make hostprof-lib) plays them back to the host side, and the text must be the oracle's.  The
@@ -46,7 +46,7 @@ def test_recorded_device_batches_through_the_host_state_machine(oracle_bin):
     env = dict(os.environ, HGX_LIB_PATH=lib, HGX_MAF_REPLAY=os.path.join(GOLD, "maf_batches.bin"))
     out = subprocess.run([sys.executable, "-c", SCRIPT], env=env, check=True, stdout=subprocess.PIPE).stdout.decode()
     last = out.strip().splitlines()[-1].split()
-    assert last[0] == "exports" and int(last[1]) >= 80 and int(last[3]) == 0 and int(last[5]) >= 8, out  # (8+ exports with trees)
+    assert last[0] == "exports" and int(last[1]) >= 120 and int(last[3]) == 0 and int(last[5]) >= 8, out  # (8+ exports with trees)
 
 
 GLOBAL_SCRIPT = r'''
