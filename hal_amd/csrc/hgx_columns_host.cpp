@@ -815,7 +815,7 @@ struct MafExport::RunMachine {
     MafExport &M;
     std::ostream &os;
     const Image &img;
-    const int refRank;
+    int refRank; // the rank of the reference sequence of the column a block begins with (the column-by-column path sets it per column)
     std::vector<Ent> ents;
     std::vector<KeyRec> keys; // the column map's keys, the ones without bases in the current column among them
     std::vector<uint8_t> inKeys;
@@ -1747,27 +1747,69 @@ void MafExport::convertSequence(std::ostream &mafStream, hgx_alignment *alignmen
 // is replayed here, in the reference's order.
 namespace {
 
-struct PositionCache { // api/impl/halPositionCache.cpp:12-78: positions as merged intervals, last -> first
+struct PositionCache { // api/impl/halPositionCache.cpp:12-78: positions as merged intervals, first -> last
     std::map<int64_t, int64_t> set;
+    // (a walk along a sequence asks for, and adds, the position behind the one before: the interval touched last is tried first)
+    mutable std::map<int64_t, int64_t>::iterator hint = set.end();
+    PositionCache() = default;
+    PositionCache(const PositionCache &o) : set(o.set) { hint = set.end(); }
+    PositionCache(PositionCache &&o) noexcept : set(std::move(o.set)) { hint = set.end(); o.hint = o.set.end(); }
+    PositionCache &operator=(PositionCache o) {
+        set.swap(o.set);
+        hint = set.end();
+        return *this;
+    }
     bool find(int64_t pos) const {
-        auto i = set.lower_bound(pos);
-        return i != set.end() && i->second <= pos;
+        if (hint != set.end() && hint->first <= pos && pos <= hint->second)
+            return true;
+        std::map<int64_t, int64_t> &m = const_cast<std::map<int64_t, int64_t> &>(set);
+        auto i = m.upper_bound(pos); // the first interval that begins behind pos
+        if (i == m.begin())
+            return false;
+        --i;
+        if (i->second < pos)
+            return false;
+        hint = i;
+        return true;
     }
     bool insert(int64_t pos) { // false: already there
-        if (find(pos))
-            return false;
-        int64_t lo = pos, hi = pos;
-        auto right = set.lower_bound(pos);
-        if (right != set.end() && right->second == pos + 1) {
-            hi = right->first;
+        if (hint != set.end() && hint->first <= pos) {
+            if (pos <= hint->second)
+                return false;
+            if (pos == hint->second + 1) { // the common case: one more position at the end of the interval touched last
+                auto next = std::next(hint);
+                if (next == set.end() || next->first > pos + 1) {
+                    hint->second = pos;
+                    return true;
+                }
+            }
+        }
+        auto right = set.upper_bound(pos); // the first interval that begins behind pos
+        auto left = right;
+        bool haveLeft = false;
+        if (left != set.begin()) {
+            --left;
+            haveLeft = true;
+            if (left->second >= pos) {
+                hint = left;
+                return false;
+            }
+        }
+        const bool joinsLeft = haveLeft && left->second == pos - 1, joinsRight = right != set.end() && right->first == pos + 1;
+        if (joinsLeft && joinsRight) {
+            left->second = right->second;
             set.erase(right);
+            hint = left;
+        } else if (joinsLeft) {
+            left->second = pos;
+            hint = left;
+        } else if (joinsRight) {
+            const int64_t hi = right->second;
+            set.erase(right);
+            hint = set.emplace(pos, hi).first;
+        } else {
+            hint = set.emplace(pos, pos).first;
         }
-        auto left = set.find(pos - 1);
-        if (left != set.end()) {
-            lo = left->second;
-            set.erase(left);
-        }
-        set[hi] = lo;
         return true;
     }
 };
@@ -1860,6 +1902,7 @@ struct GapColumns {
     // the reference columns [first, first + count) and, level by level, every column of every range their walks (and the walks of
     // those columns ...) could push: a superset of what the replay will ask for
     void prefetch(int64_t first, int64_t count) {
+        MAF_TICK(6);
         previous.swap(batches);
         batches.clear();
         where.clear();
@@ -1923,7 +1966,7 @@ struct ReplayIterator {
     int64_t gapChunk, chunkFirst = 0, chunkCount = 0;
     StackEntry base;
     std::vector<StackEntry> upper, insertionStack, deletionStack;
-    std::map<int, PositionCache> visitCache; // ColumnIterator::VisitCache
+    std::vector<PositionCache> visitCache; // ColumnIterator::VisitCache, by genome (an empty set: the genome has none)
     std::vector<const ColumnRowHost *> column; // the bases of the current column that pass colMapInsert's filters, in its order
     // every base colMapInsert put into the column map since the caller last looked, the ones of abandoned walks included: their
     // sequences stay behind as (empty) keys of the map (resetColMap, :821-825, only empties the sets), and MafBlock::initBlock gives
@@ -1938,6 +1981,7 @@ struct ReplayIterator {
         : al(a), genome(g), G(a->img.genomes[(size_t)g]), unique(uniq), maxInsert(maxIns), cols(a, g, opt, maxIns, stats),
           gapChunk((int64_t)std::min<size_t>(chunkColumns, (size_t)1 << 17)) { // (every visited base comes back: smaller chunks)
         base.g = g;
+        visitCache.resize(a->img.genomes.size());
     }
     // the constructor's / toSite's part (:54-57, :146-165): the stack holds [first, last] of the reference, then the first column
     void start(int64_t first, int64_t last) {
@@ -1954,13 +1998,14 @@ struct ReplayIterator {
     void nextFreeIndex() { // :749-764
         StackEntry &e = top();
         if (unique || !upper.empty()) {
-            auto it = visitCache.find(e.g);
-            if (it != visitCache.end())
-                while (it->second.find(e.index) && e.index <= e.lastIndex)
+            const PositionCache &cache = visitCache[(size_t)e.g];
+            if (!cache.set.empty())
+                while (cache.find(e.index) && e.index <= e.lastIndex)
                     ++e.index;
         }
     }
     void recursiveUpdate() {
+        MAF_TICK(4);
         column.clear();
         brk = false;
         leftmostRefPos = base.index;
@@ -2024,13 +2069,14 @@ struct ReplayIterator {
                 updateCache = false;
             bool found;
             if (updateCache) {
-                found = !visitCache[r->genome].insert(r->pos);
+                found = !visitCache[(size_t)r->genome].insert(r->pos);
             } else {
-                auto it = visitCache.find(r->genome);
-                found = it != visitCache.end() && it->second.find(r->pos);
+                const PositionCache &cache = visitCache[(size_t)r->genome];
+                found = !cache.set.empty() && cache.find(r->pos);
             }
 #ifdef HGX_HOST_PROFILE
-            if (getenv("HGX_REPLAY_TRACE"))
+            static const bool trace = getenv("HGX_REPLAY_TRACE") != nullptr;
+            if (trace)
                 fprintf(stderr, "  col g%d idx %lld: row g%d pos %lld rev %d kind %d depth %d ring %d upd %d found %d brk %d\n", e.g, (long long)e.index,
                         r->genome, (long long)r->pos, (int)r->rev, kind, depth, (int)ring, (int)updateCache, (int)found, (int)brk);
 #endif
@@ -2101,7 +2147,114 @@ struct ReplayIterator {
 void MafExport::convertSequenceGapped(std::ostream &mafStream, hgx_alignment *alignment, int genome, int seq, int64_t first, int64_t last,
                                       const ColumnOptions &opt) {
     (void)seq;
+    const auto tStart = std::chrono::steady_clock::now();
+    struct Report { // HGX_MAF_TIMING: what the column-by-column path took
+        std::chrono::steady_clock::time_point t0;
+        const ColumnStats &st;
+        int64_t columns;
+        ~Report() {
+            if (getenv("HGX_MAF_TIMING"))
+                std::cerr << "[hgx maf] column by column: " << columns << " reference columns in "
+                          << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << " s (device " << st.rows_ms << " ms, "
+                          << st.rows << " rows)" << std::endl;
+        }
+    } report{tStart, stats, last - first + 1};
     ReplayIterator it(alignment, genome, opt, _unique, _maxRefGap, chunkColumns, &stats);
+    if (!_printTree && !getenv("HGX_MAF_MAP_STATE")) {
+        // The columns go through the same state machine as the run-compressed export (RunMachine): a column whose bases all continue
+        // the column before by one base on their strands — the reference's among them — is held back as one more column of a
+        // run, and the run goes through place() when something else comes (the per-column logic inside a run is place()'s:
+        // block-length limits, sequence ends).  The keys abandoned walks and unwritten columns leave in the column map go in
+        // between two runs, where the reference adds them.
+        typedef RunMachine::PRow PRow;
+        RunMachine R(*this, mafStream, -1);
+        struct Raw {
+            int64_t pos;
+            int32_t genome;
+            bool rev;
+        };
+        std::vector<Raw> lastRows;       // the bases of the run's last column, in the walk's order
+        std::unique_ptr<PRow[]> headRows; // the run's first column, sorted the way the column map holds it
+        size_t headCount = 0;
+        int64_t runColumns = 0, runRefPos = 0;
+        int runRefSeq = -1;
+        auto flushRun = [&]() {
+            if (runColumns == 0)
+                return;
+            const PRow *rows = headRows.get();
+            R.batch->extra.push_back(std::move(headRows)); // (the log points into it)
+            R.refRank = _rank[(size_t)genome][(size_t)runRefSeq];
+            int64_t left = runColumns, off = 0;
+            for (;;) {
+                R.addKeys(rows, headCount);
+                const int64_t k = R.place(rows, headCount, left, runRefPos + off);
+                left -= k;
+                off += k;
+                if (left == 0)
+                    break;
+                rows = R.advance(rows, headCount, k);
+            }
+            runColumns = 0;
+        };
+        auto column = [&]() {
+            MAF_TICK(5);
+            const bool written = !_unique || it.canonicalOnRef();
+            const bool otherKeys = it.inserted.size() != it.column.size(); // (bases of abandoned walks, or of a column that is not written)
+            bool continues = written && !otherKeys && runColumns > 0 && it.column.size() == lastRows.size() && it.prevRefSeq == runRefSeq &&
+                             it.prevRefIndex == runRefPos + runColumns;
+            for (size_t i = 0; continues && i < lastRows.size(); ++i) {
+                const ColumnRowHost *r = it.column[i];
+                continues = r->genome == lastRows[i].genome && (r->rev != 0) == lastRows[i].rev && r->pos == lastRows[i].pos + (lastRows[i].rev ? -1 : 1);
+            }
+            if (continues) {
+                ++runColumns;
+                for (Raw &x : lastRows)
+                    x.pos += x.rev ? -1 : 1;
+                it.inserted.clear();
+                return;
+            }
+            flushRun();
+            for (const auto &gp : it.inserted) { // every base colMapInsert put into the column map leaves its key there
+                PRow k;
+                RunMachine::describe(alignment->img, _rank, k, gp.first, gp.second, false, 0);
+                R.addKeys(&k, 1);
+            }
+            it.inserted.clear();
+            if (!written)
+                return;
+            headCount = it.column.size();
+            headRows.reset(new PRow[headCount ? headCount : 1]);
+            lastRows.resize(headCount);
+            for (size_t i = 0; i < headCount; ++i) {
+                const ColumnRowHost *r = it.column[i];
+                RunMachine::describe(alignment->img, _rank, headRows[i], r->genome, r->pos, r->rev != 0, (uint32_t)i);
+                lastRows[i] = Raw{r->pos, r->genome, r->rev != 0};
+            }
+            RunMachine::sortColumn(headRows.get(), headCount);
+            runColumns = 1;
+            runRefPos = it.prevRefIndex;
+            runRefSeq = it.prevRefSeq;
+        };
+        it.start(first, last);
+        column();
+        while (!it.lastColumn()) {
+            it.toRight();
+            column();
+        }
+        flushRun();
+        if (R.appendCount > 0)
+            R.endBlock();
+        R.flush();
+        waitPendingWrite();
+        mafStream.flush();
+#ifdef HGX_HOST_PROFILE
+        if (getenv("HGX_MAF_TIMING"))
+            std::cerr << "[hgx maf]   Mticks: recursiveUpdate " << g_mafTicks[4] / 1e6 << " (of which prefetch " << g_mafTicks[6] / 1e6 << "), column() "
+                      << g_mafTicks[5] / 1e6 << " (initBlock " << g_mafTicks[1] / 1e6 << " canAppend " << g_mafTicks[2] / 1e6 << " place " << g_mafTicks[3] / 1e6
+                      << ")" << std::endl;
+#endif
+        return;
+    }
     ColumnMap colMap; // keys persist between columns like ColumnIterator::_colMap (resetColMap only empties the vectors)
     auto fill = [&]() {
         for (auto &kv : colMap)
@@ -2177,7 +2330,7 @@ void MafExport::convertEntireAlignment(std::ostream &mafStream, hgx_alignment *a
     opt.noDupes = _noDupes;
     opt.noAncestors = _noAncestors;
     opt.onlyOrthologs = _onlyOrthologs;
-    std::map<int, PositionCache> visitCache;
+    std::vector<PositionCache> visitCache(img.genomes.size());
     size_t appendCount = 0, numBlocks = 0;
     for (int genome : leaves) {
         const GenomeTables &G = img.genomes[(size_t)genome];
