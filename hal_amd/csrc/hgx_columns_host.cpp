@@ -1901,15 +1901,50 @@ struct GapColumns {
     }
     // the reference columns [first, first + count) and, level by level, every column of every range their walks (and the walks of
     // those columns ...) could push: a superset of what the replay will ask for
-    void prefetch(int64_t first, int64_t count) {
+    // (without ranges to follow — maxInsert == 0 — the chunk behind this one is walked by the device and copied while this one is
+    // replayed: ahead = the columns it would have if the replay goes straight on, 0 for none)
+    std::future<std::unique_ptr<Batch>> coming;
+    int64_t comingFirst = 0, comingCount = 0;
+    std::unique_ptr<Batch> walk(int64_t first, int64_t count) const {
+        std::unique_ptr<Batch> B(new Batch);
+        B->asks.resize((size_t)count);
+        for (int64_t i = 0; i < count; ++i)
+            B->asks[(size_t)i] = GapAskHost{first + i, refGenome, 0};
+        columnsGapRowsHost(al, refGenome, B->asks, opt, true, B->off, B->rows, stats, false);
+        return B;
+    }
+    ~GapColumns() {
+        if (coming.valid())
+            coming.wait();
+    }
+    // first / count: in: the columns asked for; out: the columns delivered (the chunk foreseen, when it holds the first one asked for)
+    void prefetch(int64_t &first, int64_t &count, int64_t lastIndex) {
         MAF_TICK(6);
         previous.swap(batches);
         batches.clear();
         where.clear();
-        std::vector<GapAskHost> asks((size_t)count);
-        for (int64_t i = 0; i < count; ++i)
-            asks[(size_t)i] = GapAskHost{first + i, refGenome, 0};
-        run(std::move(asks), false);
+        bool async = maxInsert == 0;
+#ifdef HGX_HOST_PROFILE
+        async = async && !mafReplayFile() && !mafDumpFile(); // (a recording holds the batches in the order the replay asks for them)
+#endif
+        if (async && coming.valid() && first >= comingFirst && first < comingFirst + comingCount) {
+            batches.push_back(std::move(*coming.get()));
+            first = comingFirst;
+            count = comingCount;
+        } else {
+            if (coming.valid())
+                coming.get(); // (the replay jumped: not the chunk that was foreseen)
+            std::vector<GapAskHost> asks((size_t)count);
+            for (int64_t i = 0; i < count; ++i)
+                asks[(size_t)i] = GapAskHost{first + i, refGenome, 0};
+            run(std::move(asks), false);
+        }
+        const int64_t ahead = std::min<int64_t>(count, lastIndex - (first + count) + 1);
+        if (async && ahead > 0) {
+            comingFirst = first + count;
+            comingCount = ahead;
+            coming = std::async(std::launch::async, [this]() { return walk(comingFirst, comingCount); });
+        }
         baseFirst = first;
         baseCount = count;
         for (size_t level = 0; maxInsert > 0 && level < batches.size(); ++level) { // (a batch may add the next one)
@@ -2013,7 +2048,7 @@ struct ReplayIterator {
         if (upper.empty() && (e.index < chunkFirst || e.index >= chunkFirst + chunkCount)) {
             chunkFirst = e.index;
             chunkCount = std::min<int64_t>(gapChunk, base.lastIndex - e.index + 1);
-            cols.prefetch(chunkFirst, chunkCount);
+            cols.prefetch(chunkFirst, chunkCount, base.lastIndex);
         }
         const ColumnRowHost *r, *end;
         cols.column(e.g, e.index, e.reversed, r, end);
