@@ -7,9 +7,10 @@ Workload (synthetic, generated in-process by hal_amd's restatement of halRandGen
   --maxBranchLength 3, DNA draws skipped), 1 M BED6 intervals of 50..1000 bp, random strand, lifted from the
   deepest leaf Genome_9 to Genome_2 (5 hops up, 1 down), duplications traversed.
 A "step" = one pass of the device-resident liftover over the whole interval batch (inputs already in HBM):
-locate/expand, the per-level walk kernels, grouping, per-interval overlap breaking + merging + ordering, record
-compaction.  With --gpus N every rank lifts its own 1 M-interval shard against a replicated image (weak scaling)
-and the ranks' records are collated with an all-gather (RCCL) inside the timed step.
+classify against the merged whole-path table, per-interval overlap breaking + merging + ordering, totals, record
+compaction.  With --gpus N every rank lifts its own 1 M-interval shard against a replicated image (weak scaling,
+no collective on the mapping path); collating every rank's records on every rank with an all-gather (RCCL) is
+measured beside as `collated`, or inside the timed step with --exchange-in-step 1.
 
 Prints one JSON line (rank 0).  `roofline` is for the kernel with the largest device time; `cpu_baseline` times the
 oracle (bit-identical CPU restatement of the reference, oracle/) on a bounded sample of the same workload.
