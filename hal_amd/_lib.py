@@ -42,9 +42,18 @@ class hgx_column_row(C.Structure):
 
 
 class hgx_maf_opts(C.Structure):
-    _fields_ = [("no_dupes", C.c_int32), ("no_ancestors", C.c_int32), ("only_sequence_names", C.c_int32),
+    _fields_ = [("struct_size", C.c_uint32), ("no_dupes", C.c_int32), ("no_ancestors", C.c_int32), ("only_sequence_names", C.c_int32),
                 ("only_orthologs", C.c_int32), ("keep_empty_ref_blocks", C.c_int32), ("unique", C.c_int32),
                 ("max_block_len", C.c_int64), ("max_ref_gap", C.c_int64), ("print_tree", C.c_int32)]
+
+
+def maf_opts(**kw):
+    """hgx_maf_opts with struct_size set (HGX_MAF_OPTS_INIT) and the given fields; booleans become 0 / 1"""
+    o = hgx_maf_opts()
+    o.struct_size = C.sizeof(hgx_maf_opts)
+    for k, v in kw.items():
+        setattr(o, k, int(v))
+    return o
 
 
 class hgx_rand_opts(C.Structure):

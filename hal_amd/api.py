@@ -7,7 +7,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import (lib, HgxError, hgx_interval, hgx_record, hgx_liftover_opts, hgx_liftover_stats, hgx_rand_opts, hgx_column_opts,
-                   hgx_column_row, hgx_maf_opts, take_error)
+                   hgx_column_row, hgx_maf_opts, maf_opts, take_error)
 
 RECORD_DTYPE = np.dtype([("query", "<i8"), ("tgt_start", "<i8"), ("tgt_end", "<i8"), ("src_start", "<i8"),
                          ("tgt_seq", "<i4"), ("strand", "S1"), ("tgt_reversed", "u1"), ("_pad", "S2")])
@@ -301,17 +301,18 @@ class Alignment:
 
     def maf_export_bytes(self, ref, ref_sequence=-1, start=0, length=0, no_ancestors=False, max_block_len=1000):
         """hal2maf end to end, the text left in library memory and released: returns its size (benchmark use)."""
-        o = hgx_maf_opts(0, 1 if no_ancestors else 0, 0, 0, 0, 0, max_block_len, 0)
+        o = maf_opts(no_ancestors=no_ancestors, max_block_len=max_block_len)
         out, n, err = C.c_void_p(), C.c_size_t(), C.c_void_p()
         if lib.hgx_maf_export(self._h, ref, ref_sequence, start, length, C.byref(o), None, 0, C.byref(out), C.byref(n), C.byref(err)) != 0:
             raise HgxError(take_error(err))
         lib.hgx_free(out)
         return n.value
 
-    def maf_export_global(self, no_dupes=False, no_ancestors=False, only_sequence_names=False, only_orthologs=False, max_block_len=1000):
+    def maf_export_global(self, no_dupes=False, no_ancestors=False, only_sequence_names=False, only_orthologs=False, max_block_len=1000,
+                          print_tree=False):
         """hal2maf --global (MafExport::convertEntireAlignment, maf/impl/halMafExport.cpp:90-153): every column of the alignment once"""
-        o = hgx_maf_opts(1 if no_dupes else 0, 1 if no_ancestors else 0, 1 if only_sequence_names else 0, 1 if only_orthologs else 0, 0, 0,
-                         max_block_len, 0)
+        o = maf_opts(no_dupes=no_dupes, no_ancestors=no_ancestors, only_sequence_names=only_sequence_names, only_orthologs=only_orthologs,
+                     max_block_len=max_block_len, print_tree=print_tree)
         out, n, err = C.c_void_p(), C.c_size_t(), C.c_void_p()
         if lib.hgx_maf_export_global(self._h, C.byref(o), C.byref(out), C.byref(n), C.byref(err)) != 0:
             raise HgxError(take_error(err))
@@ -326,9 +327,9 @@ class Alignment:
         """hal2maf's MAF text (maf/impl/halMafExport.cpp:25-88, maf/impl/hal2maf.cpp:196-206); ref_targets_bed: BED text of
         reference intervals (--refTargets, maf/impl/halMafBed.cpp)."""
         if ref_targets_bed is not None:
-            o = hgx_maf_opts(1 if no_dupes else 0, 1 if no_ancestors else 0, 1 if only_sequence_names else 0,
-                             1 if only_orthologs else 0, 1 if keep_empty_ref_blocks else 0, 1 if unique else 0, max_block_len, max_ref_gap,
-                             1 if print_tree else 0)
+            o = maf_opts(no_dupes=no_dupes, no_ancestors=no_ancestors, only_sequence_names=only_sequence_names, only_orthologs=only_orthologs,
+                         keep_empty_ref_blocks=keep_empty_ref_blocks, unique=unique, max_block_len=max_block_len, max_ref_gap=max_ref_gap,
+                         print_tree=print_tree)
             tg = (C.c_int32 * len(targets))(*targets) if targets else None
             data = ref_targets_bed.encode() if isinstance(ref_targets_bed, str) else ref_targets_bed
             out, n, err = C.c_void_p(), C.c_size_t(), C.c_void_p()
@@ -339,9 +340,9 @@ class Alignment:
                 return C.string_at(out, n.value).decode()
             finally:
                 lib.hgx_free(out)
-        o = hgx_maf_opts(1 if no_dupes else 0, 1 if no_ancestors else 0, 1 if only_sequence_names else 0,
-                         1 if only_orthologs else 0, 1 if keep_empty_ref_blocks else 0, 1 if unique else 0, max_block_len, max_ref_gap,
-                             1 if print_tree else 0)
+        o = maf_opts(no_dupes=no_dupes, no_ancestors=no_ancestors, only_sequence_names=only_sequence_names, only_orthologs=only_orthologs,
+                         keep_empty_ref_blocks=keep_empty_ref_blocks, unique=unique, max_block_len=max_block_len, max_ref_gap=max_ref_gap,
+                         print_tree=print_tree)
         tg = (C.c_int32 * len(targets))(*targets) if targets else None
         out, n, err = C.c_void_p(), C.c_size_t(), C.c_void_p()
         if lib.hgx_maf_export(self._h, ref, ref_sequence, start, length, C.byref(o), tg, len(targets) if targets else 0,
@@ -409,12 +410,13 @@ def alignment_depth_multi(alignments, ref, ref_sequence=-1, start=0, length=0, s
 
 def maf_export_multi(alignments, ref, ref_sequence=-1, start=0, length=0, slice_size=0, no_dupes=False, no_ancestors=False,
                      only_sequence_names=False, only_orthologs=False, keep_empty_ref_blocks=False, max_block_len=1000, targets=None,
-                     unique=False, max_ref_gap=0):
+                     unique=False, max_ref_gap=0, print_tree=False):
     """hgx_maf_export_multi: hal2mafMP.py's slices (maf/hal2mafMP.py:63-79) — one export per slice of slice_size reference columns
     (0: the range divided evenly over the handles), dealt to the device clones, the texts concatenated with the first header only."""
     hs = (C.c_void_p * len(alignments))(*[a._h for a in alignments])
-    o = hgx_maf_opts(1 if no_dupes else 0, 1 if no_ancestors else 0, 1 if only_sequence_names else 0, 1 if only_orthologs else 0,
-                     1 if keep_empty_ref_blocks else 0, 1 if unique else 0, max_block_len, max_ref_gap)
+    o = maf_opts(no_dupes=no_dupes, no_ancestors=no_ancestors, only_sequence_names=only_sequence_names, only_orthologs=only_orthologs,
+                         keep_empty_ref_blocks=keep_empty_ref_blocks, unique=unique, max_block_len=max_block_len, max_ref_gap=max_ref_gap,
+                         print_tree=print_tree)
     tg = (C.c_int32 * len(targets))(*targets) if targets else None
     out, n, err = C.c_void_p(), C.c_size_t(), C.c_void_p()
     if lib.hgx_maf_export_multi(hs, len(alignments), ref, ref_sequence, start, length, slice_size, C.byref(o), tg,

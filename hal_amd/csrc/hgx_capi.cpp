@@ -340,6 +340,12 @@ void hgx_free_block_results(hgx_block_results *results) { // halFreeBlockResults
     free(results);
 }
 
+namespace {
+struct ArgumentMessage : std::runtime_error { // halGetBlocksInTargetRange's own argument checks: reported as they are (halBlockViz.cpp:251-265)
+    using std::runtime_error::runtime_error;
+};
+} // namespace
+
 int hgx_get_blocks_in_target_ranges(hgx_alignment *h, const char *q_species, const char *t_species, const char *t_chrom, size_t n,
                                     const int64_t *t_starts, const int64_t *t_ends, int64_t t_reversed, int seq_mode, int dup_mode,
                                     int map_back_adjacencies, const char *coalescence_limit_name, hgx_block_results **results, char **err) {
@@ -353,10 +359,13 @@ int hgx_get_blocks_in_target_ranges(hgx_alignment *h, const char *q_species, con
         if (!h->dev)
             throw std::runtime_error("alignment was opened without a device (device = -1); the block mapper needs the HIP path");
         // halGetBlocksInTargetRange's own checks, with its messages (halBlockViz.cpp:251-302; checkGenomes :716-738)
+        for (size_t k = 0; k < n; ++k) // (the range check comes first in the reference, :251-257)
+            if (t_ends[k] - t_starts[k] < 0)
+                throw ArgumentMessage("halGetBlocksInTargetRange invalid query range [" + std::to_string(t_starts[k]) + "," + std::to_string(t_ends[k]) + ")");
         if (t_reversed != 0 && map_back_adjacencies != 0)
-            throw std::runtime_error("halGetBlocksInTargetRange tReversed can only be set when mapBackAdjacencies is 0");
+            throw ArgumentMessage("halGetBlocksInTargetRange tReversed can only be set when mapBackAdjacencies is 0");
         if (t_reversed != 0 && dup_mode == 2)
-            throw std::runtime_error("tReversed cannot be set in conjunction with dupMode=HAL_QUERY_AND_TARGET_DUPS");
+            throw ArgumentMessage("tReversed cannot be set in conjunction with dupMode=HAL_QUERY_AND_TARGET_DUPS");
         const Image &img = h->img;
         const int q = img.genomeByName(q_species), t = img.genomeByName(t_species);
         if (q < 0)
@@ -383,20 +392,21 @@ int hgx_get_blocks_in_target_ranges(hgx_alignment *h, const char *q_species, con
         std::vector<std::pair<int64_t, int64_t>> ranges;
         for (size_t k = 0; k < n; ++k) {
             const int64_t tStart = t_starts[k], tEnd = t_ends[k];
-            if (tEnd - tStart < 0)
-                throw std::runtime_error("halGetBlocksInTargetRange invalid query range [" + std::to_string(tStart) + "," + std::to_string(tEnd) + ")");
             const int64_t myEnd = tEnd > 0 ? tEnd : S.length;
             const int64_t absStart = S.start + tStart, absEnd = S.start + myEnd - 1;
             if (absStart > absEnd || tStart < 0)
-                throw std::runtime_error("halGetBlocksInTargetRange invalid range");
+                throw ArgumentMessage("halGetBlocksInTargetRange invalid range");
             if (absEnd > S.start + S.length - 1)
-                throw std::runtime_error("halGetBlocksInTargetRange target end position outside of target sequence");
+                throw ArgumentMessage("halGetBlocksInTargetRange target end position outside of target sequence");
             ranges.emplace_back(absStart, absEnd);
         }
         hgx::blocksInTargetRanges(h, q, t, ranges, t_reversed != 0, seq_mode != 0, dup_mode != 0, dup_mode == 2, map_back_adjacencies != 0, limit, out);
         for (size_t k = 0; k < n; ++k)
             results[k] = out[k];
         return HGX_OK;
+    } catch (ArgumentMessage &e) {
+        setErr(err, e.what());
+        return HGX_ERR;
     } catch (std::exception &e) {
         for (hgx_block_results *r : out)
             hgx_free_block_results(r);
@@ -790,13 +800,28 @@ int hgx_alignment_depth(hgx_alignment *h, int ref, int ref_sequence, int64_t sta
 }
 
 static void configureMaf(MafExport &me, const hgx_maf_opts *o, const GenomeTables *G);
+// the caller's options as this build's struct: what the caller's header did not have yet reads as 0 (hgx_maf_opts.struct_size)
+static hgx_maf_opts mafOpts(const hgx_maf_opts *o) {
+    hgx_maf_opts x;
+    memset(&x, 0, sizeof x);
+    x.struct_size = (uint32_t)sizeof x;
+    if (!o)
+        return x;
+    const size_t first = offsetof(hgx_maf_opts, max_block_len) + sizeof(int64_t);
+    if (o->struct_size < first)
+        throw std::runtime_error("hgx_maf_opts.struct_size is not set (initialise the options with HGX_MAF_OPTS_INIT)");
+    memcpy(&x, o, std::min<size_t>(o->struct_size, sizeof x));
+    x.struct_size = (uint32_t)sizeof x;
+    return x;
+}
 
-int hgx_maf_export_global(hgx_alignment *h, const hgx_maf_opts *o, char **out_text, size_t *out_len, char **err) {
+int hgx_maf_export_global(hgx_alignment *h, const hgx_maf_opts *o_, char **out_text, size_t *out_len, char **err) {
     HGX_TRY
     if (!h || !out_text || !out_len)
         throw std::runtime_error("hgx_maf_export_global: null argument");
     MafExport me;
-    if (o) {
+    if (o_) {
+        const hgx_maf_opts opts = mafOpts(o_), *o = &opts;
         me.setNoDupes(o->no_dupes != 0);
         me.setNoAncestors(o->no_ancestors != 0);
         me.setUcscNames(o->only_sequence_names == 0);
@@ -847,7 +872,7 @@ int hgx_alignment_depth_multi(hgx_alignment *const *handles, int n_handles, int 
 }
 
 int hgx_maf_export_multi(hgx_alignment *const *handles, int n_handles, int ref, int ref_sequence, int64_t start, int64_t length,
-                         int64_t slice_size, const hgx_maf_opts *o, const int32_t *targets, int32_t n_targets, char **out_text,
+                         int64_t slice_size, const hgx_maf_opts *o_, const int32_t *targets, int32_t n_targets, char **out_text,
                          size_t *out_len, char **err) {
     HGX_TRY
     if (!out_text || !out_len)
@@ -857,7 +882,8 @@ int hgx_maf_export_multi(hgx_alignment *const *handles, int n_handles, int ref, 
     if (!G || ref_sequence >= (int)G->seqs.size())
         throw std::runtime_error("hgx_maf_export_multi: genome or sequence out of range");
     MafExportSettings cfg;
-    if (o) {
+    if (o_) {
+        const hgx_maf_opts opts = mafOpts(o_), *o = &opts;
         cfg.noDupes = o->no_dupes != 0;
         cfg.noAncestors = o->no_ancestors != 0;
         cfg.ucscNames = o->only_sequence_names == 0;
@@ -899,8 +925,9 @@ int hgx_maf_export_bed(hgx_alignment *h, int ref, const char *bed_text, size_t b
     HGX_CATCH
 }
 
-static void configureMaf(MafExport &me, const hgx_maf_opts *o, const GenomeTables *G) {
-    if (o) {
+static void configureMaf(MafExport &me, const hgx_maf_opts *o_, const GenomeTables *G) {
+    if (o_) {
+        const hgx_maf_opts opts = mafOpts(o_), *o = &opts;
         me.setNoDupes(o->no_dupes != 0);
         me.setNoAncestors(o->no_ancestors != 0);
         me.setUcscNames(o->only_sequence_names == 0);

@@ -151,24 +151,31 @@ int hgx_liftover_exchange(hgx_liftover_plan *p, hgx_comm *c, int64_t first_query
         unsigned char *mine = (unsigned char *)d_gathered + (size_t)c->rank * slot_bytes;
         size_t need = 0, wrote = 0;
         std::string failure;
+        // (the buffers rotate: the slot may hold a complete blob of an earlier batch.  Its header is cleared first, so that whatever
+        // goes wrong below the other ranks cannot take stale records for this batch's: a slot without the magic is not a blob)
+        (void)hipMemsetAsync(mine, 0, 32, (hipStream_t)hip_stream);
+        bool tooSmall = false;
         try {
             need = hgx::liftoverPlanWireBlob(p, nullptr, 0, first_query, nullptr, hip_stream);
             if (need <= slot_bytes)
                 wrote = hgx::liftoverPlanWireBlob(p, mine, slot_bytes, first_query, nullptr, hip_stream);
-            else
+            else {
+                tooSmall = true;
                 failure = "hgx_liftover_exchange: this rank's records need " + std::to_string(need) + " bytes, the slot has " +
                           std::to_string(slot_bytes);
+            }
         } catch (std::exception &e) { // a plan with a batch in flight, a HIP error while the blob was made, no memory for its staging
             failure = std::string("hgx_liftover_exchange: no blob from this rank: ") + e.what();
         }
         if (!failure.empty()) {
-            // the slot's header says so to the other ranks: format 0, and the bytes the blob would have needed in the record count
+            // the slot's header says so to the other ranks: format 0; n_queries 0 = the slot was too small, and the bytes the blob
+            // would have needed stand in the record count; n_queries 1 = no blob for another reason (a batch in flight, a HIP error)
             struct {
                 char magic[4];
                 uint32_t format;
                 int64_t firstQuery;
                 uint64_t nq, nrec;
-            } h = {{'H', 'G', 'X', 'W'}, 0u, first_query, 0ull, (uint64_t)need};
+            } h = {{'H', 'G', 'X', 'W'}, 0u, first_query, tooSmall ? 0ull : 1ull, (uint64_t)need};
             // (best effort: when even this copy fails the slot keeps whatever it held — the collective is still posted)
             if (hipMemcpyAsync(mine, &h, sizeof h, hipMemcpyHostToDevice, (hipStream_t)hip_stream) == hipSuccess)
                 (void)hipStreamSynchronize((hipStream_t)hip_stream); // (h lives on this stack frame)

@@ -37,6 +37,9 @@ DevCache &devCache() {
     return *c;
 }
 size_t sizeClass(size_t bytes) {
+    // (above 256 MiB the classes are 64 MiB apart: a 9 GB workspace must not become a 12 GB one)
+    if (bytes > ((size_t)256 << 20))
+        return (bytes + (((size_t)64 << 20) - 1)) & ~(((size_t)64 << 20) - 1);
     size_t c = 256;
     while (c < bytes) {
         if (c + c / 2 >= bytes && c >= 4096)
@@ -64,16 +67,22 @@ void *devAlloc(size_t bytes) {
         }
     }
     void *p = nullptr;
+    size_t got = cls;
     hipError_t e = hipMalloc(&p, cls);
     if (e != hipSuccess) { // out of memory with blocks in the cache: give them back and try once more
         (void)hipGetLastError();
         devCacheTrim(dev);
         e = hipMalloc(&p, cls);
     }
+    if (e != hipSuccess && bytes < cls) { // the class does not fit, the request itself may: an exact block (its own class when it comes back)
+        (void)hipGetLastError();
+        got = std::max<size_t>(bytes, 16);
+        e = hipMalloc(&p, got);
+    }
     if (e != hipSuccess)
-        throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e) + " at hipMalloc of " + std::to_string(cls) + " bytes");
+        throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e) + " at hipMalloc of " + std::to_string(bytes) + " bytes");
     std::lock_guard<std::mutex> lock(C.mu);
-    C.live[p] = {dev, cls};
+    C.live[p] = {dev, got};
     return p;
 }
 

@@ -292,8 +292,10 @@ class SlotExchange:
 
     def submit(self, plan=None, first_query=0, blob=None):
         """plan: a LiftoverPlan whose last run is exchanged; blob: a ready blob instead (CPU tests)"""
-        while len(self._inflight) >= 3:  # (the buffer about to be reused may still be the target of an all-gather under way)
-            self.wait()
+        if len(self._inflight) >= 3:
+            # (the buffer about to be reused is still the target — or the unread result — of an exchange under way: completing it
+            # here would throw its records away)
+            raise RuntimeError("three exchanges in flight: wait() before the next submit")
         buf = self._bufs[self._turn % 3]
         self._turn += 1
         work = None
@@ -323,7 +325,7 @@ class SlotExchange:
 
     @property
     def in_flight(self):
-        """exchanges submitted and not waited for (at most three: a fourth submit waits for the oldest first)"""
+        """exchanges submitted and not waited for (at most three: a fourth submit without a wait() is refused)"""
         return len(self._inflight)
 
     def wait(self):
@@ -359,8 +361,10 @@ def blob_bytes(slot):
         raise ValueError("not a wire blob")
     fmt = int.from_bytes(h[4:8], "little")
     nq, nrec = int.from_bytes(h[16:24], "little"), int.from_bytes(h[24:32], "little")
-    if fmt == 0:
-        raise ValueError("a rank's records did not fit its slot (it needed %d bytes)" % nrec)
+    if fmt == 0:  # (hgx_liftover_exchange: the rank took part in the collective without a blob)
+        if nq == 0:
+            raise ValueError("a rank's records did not fit its slot (it needed %d bytes)" % nrec)
+        raise ValueError("a rank had no blob for this batch (its own call reports the cause: a batch in flight, a HIP error)")
     if fmt == 12:
         return 32 + (2 * nq + 7) // 8 * 8 + 12 * nrec
     return 32 + (20 if fmt == 20 else 40) * nrec

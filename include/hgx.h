@@ -285,8 +285,10 @@ int hgx_liftover_wire_blob(hgx_liftover_plan *p, void *d_dst, size_t capacity, i
  * (hgx_liftover_wire_blob: self-describing, its header carries its sizes) in slot `rank` of d_gathered, a device buffer of
  * n_ranks slots of slot_bytes each; on return (stream-ordered on hip_stream) every slot holds the blob of its rank, and the
  * rank-major concatenation of their records is the unsharded output (intervals are independent: halLiftover.cpp:46-92).
- * A rank whose blob does not fit still takes part (its slot's header has format 0 and the bytes it needed in n_records) and
- * returns HGX_ERR. */
+ * A rank that has no blob for the batch still takes part and returns HGX_ERR: its slot's header has format 0, with n_queries 0
+ * and the bytes it needed in n_records when its blob did not fit the slot, n_queries 1 when it failed for another reason (a
+ * batch in flight, a HIP error).  The slot's header is cleared before the blob is built, so a slot never shows an earlier
+ * batch's blob as this one's. */
 typedef struct hgx_comm hgx_comm;
 int hgx_comm_unique_id(unsigned char *id128, char **err);
 int hgx_comm_create(const unsigned char *id128, int rank, int n_ranks, int device, hgx_comm **out, char **err);
@@ -350,6 +352,9 @@ int hgx_alignment_depth(hgx_alignment *h, int ref_genome, int ref_sequence, int6
  * sequence of the reference genome when ref_sequence == -1 (maf/impl/hal2maf.cpp:196-206).  MAF text, header
  * included, byte-identical to hal2maf for the options below. */
 typedef struct hgx_maf_opts {
+    uint32_t struct_size; /* sizeof(hgx_maf_opts) as the caller's header has it (HGX_MAF_OPTS_INIT sets it): fields the caller's
+                             struct does not reach read as 0, a size below the first version's (up to max_block_len) is an error.
+                             New options are added at the end only. */
     int32_t no_dupes, no_ancestors, only_sequence_names, only_orthologs, keep_empty_ref_blocks;
     int32_t unique; /* --unique: a column is written once, by its left-most reference base (halColumnIterator.cpp:210-214) */
     int64_t max_block_len; /* --maxBlockLen; 0 = the default, 1000 (halMafBlock.cpp:16).  A negative value is what the
@@ -364,6 +369,7 @@ typedef struct hgx_maf_opts {
                             As in the reference, a column whose first base (in sequence order) is an insertion in a genome that
                             has bottom segments has no such tree: undefined behaviour there, an error here */
 } hgx_maf_opts;
+#define HGX_MAF_OPTS_INIT {(uint32_t)sizeof(hgx_maf_opts), 0, 0, 0, 0, 0, 0, 0, 0, 0}
 int hgx_maf_export(hgx_alignment *h, int ref_genome, int ref_sequence, int64_t start, int64_t length, const hgx_maf_opts *opts,
                    const int32_t *targets, int32_t n_targets, char **out_text, size_t *out_len, char **err);
 /* hal2maf --refTargets: one convertSequence per BED interval (or BED12 block) of the reference genome, sharing one

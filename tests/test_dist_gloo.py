@@ -207,9 +207,15 @@ def _slot_worker(rank, world, port, result):
         ok = ok and check(buf)
         seen += 1
     ok = ok and seen == 7
-    for _ in range(4):  # (a fourth submit without a wait completes the oldest exchange itself instead of writing over its buffer)
+    for _ in range(3):
         ex.submit(blob=blob)
-    ok = ok and ex.in_flight == 3 and all(check(b) for b in ex.drain())
+    try:  # (a fourth submit without a wait would write over a buffer nobody has read: refused, nothing is lost)
+        ex.submit(blob=blob)
+        ok = False
+    except RuntimeError:
+        pass
+    done = ex.drain()
+    ok = ok and len(done) == 3 and all(check(b) for b in done)
     try:
         SlotExchange(world, rank, 64, "cpu", backend="torch").submit(blob=blob)
         ok = False
