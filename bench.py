@@ -114,8 +114,9 @@ def kernel_sources_sha16():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the PMC passes of profiles/scripts/r03_pmc.py (profiles/pmc_traffic.json), or
+def pmc_traffic(kernel, form="kernels"):
+    """HBM bytes per launch of `kernel` from the PMC passes of profiles/scripts/r04_pmc.py (profiles/pmc_traffic.json; form
+    "kernels": one batch repeated, "rotating": four batches in turn), or
     None when the file was made with other device code than the one running (the file records the hash of the library and of
     the device sources it was built from; either one matching will do: a host-only change rebuilds the library without touching
     a kernel)."""
@@ -125,8 +126,8 @@ def pmc_traffic(kernel):
     except Exception:
         return None, "no profiles/pmc_traffic.json"
     if d.get("libhgx_sha16") != lib_sha16() and d.get("kernel_sources_sha16") != kernel_sources_sha16():
-        return None, "profiles/pmc_traffic.json was measured on other device code (library %s); rerun profiles/scripts/r03_pmc.py" % d.get("libhgx_sha16")
-    return d.get("kernels", {}).get(kernel), d.get("source", "")
+        return None, "profiles/pmc_traffic.json was measured on other device code (library %s); rerun profiles/scripts/r04_pmc.py" % d.get("libhgx_sha16")
+    return d.get(form, {}).get(kernel), d.get("source", "")
 
 
 def timed_steps(step, k, sync):
@@ -215,6 +216,12 @@ def main():
     ap.add_argument("--text-path", type=int, default=1, help="also time Liftover::convert (BED text in, BED text out) on the batch (one GPU only)")
     ap.add_argument("--in-flight", type=int, default=2, help="batches in flight on one GPU without an exchange: 2 (two plans, two streams) or 1")
     ap.add_argument("--sustained-seconds", type=float, default=2.0, help="extra leg: the same step repeated for about this long")
+    ap.add_argument("--rotating", type=int, default=4,
+                    help="extra leg: this many DISTINCT batches (other seeds), each with a plan and output buffers of its own, taken in turn "
+                         "with two in flight — one rotation's working set (0.65 GB at 4) is past the 256 MiB Infinity Cache (0 = skip)")
+    ap.add_argument("--features", type=int, default=1,
+                    help="extra legs for the other entry points of the path: halGetBlocksInTargetRange (ranges/s), hal2maf --unique, "
+                         "--maxRefGap 100 and hgx_maf_export_multi over device clones (one GPU only)")
     ap.add_argument("--exchange", default="torch", choices=["torch", "c_abi"],
                     help="who issues the batch's one all-gather: torch.distributed (the launcher's communicator, default) or the library "
                          "itself through hgx_liftover_exchange (RCCL loaded by libhgx.so)")
@@ -488,6 +495,74 @@ def main():
             drain()
         dt_s, _ = timed_steps(all_steps, 1, sync)
         sustained = {"steps": k, "seconds": dt_s, "value": nq * k / dt_s, "ms_per_step": 1e3 * dt_s / k, "in_flight": in_flight}
+    # ---- rotating: K distinct batches, a plan (and so output, answer and count buffers) each, taken in turn with two in flight.
+    # The timed loop above passes ONE batch through two plans again and again: its inputs, tables and even the records it writes
+    # (165 MB per plan) can stay in the 256 MiB Infinity Cache, and FETCH_SIZE counts what is served from there.  Here a batch
+    # and its buffers come round again only after K - 1 others have gone through (K = 4: 0.65 GB per rotation). ----
+    rotating = None
+    if args.rotating > 1 and in_flight == 2 and not exchanging:
+        K = args.rotating
+        r_plans, r_batches = [], []
+        for k in range(K):
+            s_k, l_k, d_k = make_queries(length, nq, 5000 + 17 * k + 101 * rank)
+            r_batches.append(((s_k + seq_start).to(dev), (s_k + l_k - 1 + seq_start).to(dev), d_k.to(dev)))
+            pk = hal_amd.LiftoverPlan(al, src, tgt, max_queries=nq)
+            for _ in range(3):
+                pk.run(*r_batches[k])
+            pk.set_timing(0)
+            r_plans.append(pk)
+        r_pending = [False] * K
+        r_records = [0] * K
+
+        def r_finish(k):
+            if r_pending[k]:
+                _, r_records[k] = r_plans[k].collect()
+                r_pending[k] = False
+
+        def r_loop(n_steps):
+            for i in range(n_steps):
+                k = i % K
+                r_finish((i - 2) % K)  # (two in flight: the batch two steps back is waited for)
+                r_finish(k)
+                r_plans[k].submit(*r_batches[k], stream=streams[i & 1])
+                r_pending[k] = True
+            for k in range(K):
+                r_finish(k)
+        n_r = (max(args.steps, 4 * K) + K - 1) // K * K
+        r_loop(2 * K)
+        dt_r, _ = timed_steps(lambda: r_loop(n_r), 1, sync)
+        # the kernels of these steps: every plan in turn, one batch at a time, HIP events around every launch, in the form the
+        # batches in flight are launched in
+        for pk in r_plans:
+            pk.set_workers(0)
+            pk.set_timing(2)
+        for i in range(n_r):
+            r_plans[i % K].run(*r_batches[i % K])
+        r_kt = {}
+        r_stats = r_plans[0].stats()
+        for pk in r_plans:
+            for kname, kv in pk.kernel_times().items():
+                acc = r_kt.setdefault(kname, {"ms": 0.0, "launches": 0, "top_derefs": 0, "bot_derefs": 0})
+                for f in acc:
+                    acc[f] += kv.get(f, 0)
+        r_bytes = plan_kernel_bytes(r_kt, dict(r_stats, records=sum(r_records) // K), n_r)
+        rotating = {"value": nq * n_r / dt_r, "unit": "intervals/s", "ms_per_step": 1e3 * dt_r / n_r, "steps": n_r, "batches": K,
+                    "batches_in_flight": 2, "records_per_step": sum(r_records) / K,
+                    "working_set_bytes_per_rotation": K * (17 * nq + 12 * nq + 4 * nq) + 40 * sum(r_records) + 16 * r_stats["composed_records"],
+                    "kernels_ms_per_step": {k: round(v["ms"] / n_r, 4) for k, v in sorted(r_kt.items())},
+                    "roofline_kernels": [
+                        {"kernel": k, "kernel_avg_ms": v["ms"] / max(1, v["launches"]), "algorithmic_bytes_per_launch": r_bytes.get(k, 0.0),
+                         "achieved": r_bytes.get(k, 0.0) / (v["ms"] / max(1, v["launches"]) * 1e-3) / 1e9 if v["ms"] > 0 else 0.0,
+                         "frac": r_bytes.get(k, 0.0) / (v["ms"] / max(1, v["launches"]) * 1e-3) / 1e9 / HBM_PEAK_GBS if v["ms"] > 0 else 0.0,
+                         "traffic": pmc_traffic(k, "rotating")[0]}
+                        for k, v in sorted(r_kt.items(), key=lambda kv: -kv[1]["ms"])],
+                    "what": "%d distinct 1 M-interval batches (other seeds), each with its own plan — its own record, answer and count buffers "
+                            "— taken in turn, two in flight on the two streams of `value`: a batch's inputs and buffers are touched again after "
+                            "the %d others, past the Infinity Cache; `value` repeats one batch (its working set fits the cache).  Kernel times: "
+                            "the same rotation one batch at a time with HIP events; traffic: the PMC passes over this form "
+                            "(profiles/scripts/r04_pmc.py --form rotating)" % (K, K - 1)}
+        del r_plans, r_batches
+
     # ---- the same number of steps through ONE plan, batch after batch (what `value` was before batches were kept in flight) ----
     one_plan = None
     if in_flight == 2:
@@ -667,7 +742,7 @@ def main():
                                                 "form the batches in flight are launched in (general intervals finished by the wavefronts that meet them: "
                                                 "k_lift_classify's launch then ends one such interval's latency after its last tile, a tail the other "
                                                 "batch's launches fill; one_plan.roofline_kernels has the form a batch that runs by itself takes, with "
-                                                "k_lift_classify at 0.036 ms); with "
+                                                "k_lift_classify at " + ("%.3f" % (one_plan["kernels_ms_per_step"].get("k_lift_classify", float("nan"))) if one_plan else "?") + " ms); with "
                                                 "two batches in flight the launches of the two overlap, so ms_per_step is below kernel_ms_per_step; "
                                                 "achieved_GBs_at_step_rate = the same bytes over ms_per_step, what the GPU moves per second in the timed loop.  "
                                                 "bytes_the_timed_kernels_must_move prices every timed kernel by its own inputs and outputs "
@@ -690,10 +765,19 @@ def main():
             out["sustained"] = sustained
         if one_plan:
             out["one_plan"] = one_plan
+        if rotating:
+            out["rotating"] = rotating
+            out["roofline"]["form"] = ("`value`'s: one batch repeated (kernel_avg_ms from that loop); rotating.roofline_kernels prices the same "
+                                       "kernels when the batches rotate past the Infinity Cache")
         if mapping_only:
             out["mapping_only"] = mapping_only
         if collated:
             out["collated"] = collated
+            # BASELINE config 4 names the all-gatherv as part of its workload: its number is the collated one, quoted beside `value`
+            out["config4_as_stated"] = {"value": collated["value"], "unit": "intervals/s", "ms_per_step": collated["ms_per_step"],
+                                        "what": "`collated`: every step's records gathered on every rank (RCCL all-gather of wire blobs); "
+                                                "`value` is the same steps without it"}
+        out["timed_step"] = "map+allgather" if exchanging else "map_only"
         out["config"]["batches_in_flight"] = in_flight
         if col_result:
             ncol, col_ms, gather_ms, mean_depth = col_result
@@ -803,6 +887,74 @@ def main():
                                          "in host memory (tokenise, H2D, kernels, D2H, render; PCIe inclusive, never `value`); best of 3",
                                  "value": nq / best_t, "unit": "intervals/s", "seconds": best_t, "lines_in": nq, "lines_out": out_lines,
                                  "bytes_in": len(bed), "bytes_out": out_bytes, "host_threads": min(32, os.cpu_count() or 1)}
+        if args.features and want_maf:
+            # the other entry points of the path, each as a number: halGetBlocksInTargetRange (a browser's call: latency per call and
+            # ranges per second when a call carries many), hal2maf --unique (what hal2mafMP.py runs every slice with), --maxRefGap,
+            # and hgx_maf_export_multi's slices over two handles of this GPU
+            feats = {}
+            sn, ln = starts.numpy(), lens.numpy()
+            t_chrom = seq_name
+            r1k = [(int(a), int(a + b)) for a, b in zip(sn[:1000], ln[:1000])]
+            big = [(int(a), int(a) + 100000) for a in sn[:64] if int(a) + 100000 < length]
+            kwv = dict(dup_mode=2, adjacencies=True, decode=False)
+            al.blocks_in_target_ranges(tgt_name, src_name, t_chrom, r1k[:10], **kwv)  # (plans, tables, code objects)
+            al.blocks_in_target_ranges(tgt_name, src_name, t_chrom, r1k, **kwv)
+            lat = []
+            for r in r1k[:100]:
+                t0 = time.perf_counter()
+                al.blocks_in_target_ranges(tgt_name, src_name, t_chrom, [r], **kwv)
+                lat.append(time.perf_counter() - t0)
+            lat.sort()
+            lat_big = []
+            for r in big[:20]:
+                t0 = time.perf_counter()
+                al.blocks_in_target_ranges(tgt_name, src_name, t_chrom, [r], **kwv)
+                lat_big.append(time.perf_counter() - t0)
+            lat_big.sort()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                al.blocks_in_target_ranges(tgt_name, src_name, t_chrom, r1k, **kwv)
+            dt_b = (time.perf_counter() - t0) / 3
+            feats["blocks_in_target_range"] = {
+                "what": "hgx_get_blocks_in_target_range[s] = halGetBlocksInTargetRange (target %s, query %s, dupMode HAL_QUERY_AND_TARGET_DUPS, "
+                        "adjacencies mapped back): the batch's first intervals (50..1000 bases) as ranges, results left in library memory and "
+                        "released" % (src_name, tgt_name),
+                "one_range_per_call": {"median_us": 1e6 * lat[len(lat) // 2], "p90_us": 1e6 * lat[int(0.9 * len(lat))], "ranges_per_s": len(lat) / sum(lat),
+                                       "calls": len(lat)},
+                "one_100kb_range_per_call": {"median_us": 1e6 * lat_big[len(lat_big) // 2] if lat_big else None, "calls": len(lat_big)},
+                "thousand_ranges_per_call": {"ranges_per_s": len(r1k) / dt_b, "ms_per_call": 1e3 * dt_b}}
+            ncu = min(2000000, al.genome_length(src))
+            al.maf_export_bytes(src, 0, start=0, length=min(ncu, 200000), no_ancestors=True, unique=True)
+            t0 = time.perf_counter()
+            nb_u = al.maf_export_bytes(src, 0, start=0, length=ncu, no_ancestors=True, unique=True)
+            dt_u = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            nb_p = al.maf_export_bytes(src, 0, start=0, length=ncu, no_ancestors=True)
+            dt_p = time.perf_counter() - t0
+            feats["hal2maf_unique"] = {"what": "hal2maf --refGenome %s --noAncestors --unique over the first %d columns, to MAF text in host memory; "
+                                               "which columns the visit cache lets through is decided on the device (k_column_unique_count), "
+                                               "the written ones take the run-compressed path" % (src_name, ncu),
+                                       "value": ncu / dt_u, "unit": "columns/s", "seconds": dt_u, "maf_bytes": nb_u,
+                                       "same_range_without_unique": {"value": ncu / dt_p, "seconds": dt_p, "maf_bytes": nb_p}}
+            ncg = min(200000, al.genome_length(src))
+            al.maf_export_bytes(src, 0, start=0, length=20000, no_ancestors=True, max_ref_gap=100)
+            t0 = time.perf_counter()
+            nb_g = al.maf_export_bytes(src, 0, start=0, length=ncg, no_ancestors=True, max_ref_gap=100)
+            dt_g = time.perf_counter() - t0
+            feats["hal2maf_max_ref_gap"] = {"what": "hal2maf --noAncestors --maxRefGap 100 over the first %d columns (the iterator's stack of inserted and "
+                                                    "deleted ranges and its visit caches are replayed on the host over device columns: host-bound)" % ncg,
+                                            "value": ncg / dt_g, "unit": "columns/s", "seconds": dt_g, "maf_bytes": nb_g}
+            clones = [al, al.clone_to_device(local)]
+            ncm = min(8000000, al.genome_length(src))
+            hal_amd.maf_export_multi(clones, src, 0, start=0, length=min(ncm, 400000), slice_size=100000, no_ancestors=True, unique=True, size_only=True)
+            t0 = time.perf_counter()
+            nb_m = hal_amd.maf_export_multi(clones, src, 0, start=0, length=ncm, slice_size=1000000, no_ancestors=True, unique=True, size_only=True)
+            dt_m2 = time.perf_counter() - t0
+            feats["maf_export_multi"] = {"what": "hgx_maf_export_multi: hal2mafMP.py's recipe (slices of 1 M reference columns, --unique, an export each) over "
+                                                 "two handles of this one GPU, first %d columns" % ncm,
+                                         "value": ncm / dt_m2, "unit": "columns/s", "seconds": dt_m2, "maf_bytes": nb_m, "handles": 2, "gpus": 1}
+            del clones
+            out["features"] = feats
         if args.cpu_sample > 0:
             sample = min(args.cpu_sample, nq)
             cst, text, multi = cpu_baseline(al, src_name, tgt_name, starts, lens, strand, seq_name, sample,

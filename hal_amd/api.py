@@ -191,11 +191,11 @@ class Alignment:
             lib.hgx_free(out)
 
     def blocks_in_target_ranges(self, q_species, t_species, t_chrom, ranges, t_reversed=False, seq=False, dup_mode=2, adjacencies=True,
-                                coalescence_limit=None):
+                                coalescence_limit=None, decode=True):
         """halGetBlocksInTargetRange (blockViz/inc/halBlockViz.h:222-225) for every (t_start, t_end) of `ranges` in one call
         (hgx_get_blocks_in_target_ranges).  Per range: (blocks, target_dupes) — blocks = list of dicts with the fields of
         hal_block_t (qChrom, tStart, qStart, size, strand, qSequence, tSequence), target_dupes = list of (id, qChrom, [(tStart,
-        size), ...])."""
+        size), ...]).  decode=False: the results are released unread and None is returned (benchmark use: the library's time)."""
         n = len(ranges)
         starts = (C.c_int64 * max(n, 1))(*[r[0] for r in ranges])
         ends = (C.c_int64 * max(n, 1))(*[r[1] for r in ranges])
@@ -209,10 +209,11 @@ class Alignment:
         out = []
         for k in range(n):
             try:
-                out.append(_read_block_results(res[k]))
+                if decode:
+                    out.append(_read_block_results(res[k]))
             finally:
                 lib.hgx_free_block_results(res[k])
-        return out
+        return out if decode else None
 
     def blocks_in_target_range(self, q_species, t_species, t_chrom, t_start, t_end, **kw):
         """halGetBlocksInTargetRange for one range: (blocks, target_dupes)"""
@@ -299,9 +300,9 @@ class Alignment:
         finally:
             lib.hgx_free(out)
 
-    def maf_export_bytes(self, ref, ref_sequence=-1, start=0, length=0, no_ancestors=False, max_block_len=1000):
+    def maf_export_bytes(self, ref, ref_sequence=-1, start=0, length=0, no_ancestors=False, max_block_len=1000, unique=False, max_ref_gap=0):
         """hal2maf end to end, the text left in library memory and released: returns its size (benchmark use)."""
-        o = maf_opts(no_ancestors=no_ancestors, max_block_len=max_block_len)
+        o = maf_opts(no_ancestors=no_ancestors, max_block_len=max_block_len, unique=unique, max_ref_gap=max_ref_gap)
         out, n, err = C.c_void_p(), C.c_size_t(), C.c_void_p()
         if lib.hgx_maf_export(self._h, ref, ref_sequence, start, length, C.byref(o), None, 0, C.byref(out), C.byref(n), C.byref(err)) != 0:
             raise HgxError(take_error(err))
@@ -410,9 +411,10 @@ def alignment_depth_multi(alignments, ref, ref_sequence=-1, start=0, length=0, s
 
 def maf_export_multi(alignments, ref, ref_sequence=-1, start=0, length=0, slice_size=0, no_dupes=False, no_ancestors=False,
                      only_sequence_names=False, only_orthologs=False, keep_empty_ref_blocks=False, max_block_len=1000, targets=None,
-                     unique=False, max_ref_gap=0, print_tree=False):
+                     unique=False, max_ref_gap=0, print_tree=False, size_only=False):
     """hgx_maf_export_multi: hal2mafMP.py's slices (maf/hal2mafMP.py:63-79) — one export per slice of slice_size reference columns
-    (0: the range divided evenly over the handles), dealt to the device clones, the texts concatenated with the first header only."""
+    (0: the range divided evenly over the handles), dealt to the device clones, the texts concatenated with the first header only.
+    size_only: the text is released unread and its size returned (benchmark use)."""
     hs = (C.c_void_p * len(alignments))(*[a._h for a in alignments])
     o = maf_opts(no_dupes=no_dupes, no_ancestors=no_ancestors, only_sequence_names=only_sequence_names, only_orthologs=only_orthologs,
                          keep_empty_ref_blocks=keep_empty_ref_blocks, unique=unique, max_block_len=max_block_len, max_ref_gap=max_ref_gap,
@@ -423,7 +425,7 @@ def maf_export_multi(alignments, ref, ref_sequence=-1, start=0, length=0, slice_
                                 len(targets) if targets else 0, C.byref(out), C.byref(n), C.byref(err)) != 0:
         raise HgxError(take_error(err))
     try:
-        return C.string_at(out, n.value).decode()
+        return n.value if size_only else C.string_at(out, n.value).decode()
     finally:
         lib.hgx_free(out)
 

@@ -27,6 +27,12 @@ struct ColumnParams {
     unsigned long long *derefs;       // optional {top, bottom} segment records logically dereferenced (roofline accounting)
 };
 
+// a visitor that also wants every base the walk reaches, whatever the noAncestors / targets filters say of its genome
+// (UniqueVisitor below): specialise to true and give it  void raw(int genome, int64_t pos)
+template <typename V> struct VisitorWantsRaw {
+    static constexpr bool value = false;
+};
+
 static constexpr int COL_STACK = 64; // frames per lane (scratch; an LDS-resident lower part was measured slower: occupancy)
 
 enum : uint32_t { FR_UP = 0, FR_PARSEUP = 1, FR_CHILD = 2, FR_RING = 3, FR_PARSEDOWN = 4 };
@@ -83,6 +89,8 @@ template <typename C, bool STATS = false> struct ColumnWalker {
     // V: visitor with  void operator()(int genome, int64_t pos, bool rev)
     template <typename V> __device__ __forceinline__ void insert(V &visit, int g, int64_t pos, bool rev) const {
         // colMapInsert (halColumnIterator.cpp:802-812): noAncestors / targets filters
+        if constexpr (VisitorWantsRaw<V>::value)
+            visit.raw(g, pos);
         if ((!P.noAncestors || P.desc[g].numChildren == 0) && bit(P.targetMask, g))
             visit(g, pos, rev);
     }
@@ -375,14 +383,72 @@ struct RowVisitor {
     }
 };
 
+// cls (optional, --unique: k_column_unique_count): columns of class COL_SKIPPED are not walked (they have no rows)
 template <typename C, typename OFF>
-__global__ void __launch_bounds__(256) k_column_rows(ColumnParams P, const OFF *__restrict__ rowOffset, ColumnRow *__restrict__ rows) {
+__global__ void __launch_bounds__(256) k_column_rows(ColumnParams P, const OFF *__restrict__ rowOffset, ColumnRow *__restrict__ rows,
+                                                     const uint8_t *__restrict__ cls = nullptr) {
     ColumnWalker<C> w(P);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P.count; i += (int64_t)gridDim.x * blockDim.x) {
+        if (cls && cls[i] == 0)
+            continue;
         RowVisitor v;
         v.dst = rows + rowOffset[i];
         v.desc = P.desc;
         w.run(P.first + i * P.step, v);
+    }
+    if (w.overflow)
+        *P.error = 1;
+}
+
+// ---- hal2maf --unique without the visit cache ----
+// With unique set and maxInsertLength == 0 the iterator keeps a visit cache of the REFERENCE genome's bases: every reference
+// base a walk reaches right of the range's first column is entered (halColumnIterator.cpp:766-776), nextFreeIndex skips the
+// entered ones (:749-764), a walk that meets an entered base is abandoned (:779-800, _break), and hal2maf writes a column only if
+// none of its reference bases lies left of the range (isCanonicalOnRef, :210-214; maf/impl/halMafExport.cpp:52-64).  The cache
+// is sequential state; what it computes is not.  Every base has at most one parent base and a paralogy ring holds exactly the
+// top segments of one parent segment, so the walk of a base reaches the whole tree under the base's topmost in-scope ancestor
+// — the same set from whichever of its members it starts (the walk is symmetric under every option: noDupes cuts the same
+// edges in both directions, onlyOrthologs never reaches a second base of the reference genome, a scope cuts genomes).  Hence,
+// with f the range's first column and R(p) the reference bases of column p's walk:
+//   p is walked   <=>  no base of R(p) lies in [f, p)        (otherwise the walk of the smallest such base entered p);
+//   p is written  <=>  p is walked and no base of R(p) lies left of f  <=>  p = min R(p);
+//   no walk is ever abandoned (a base met a second time would have entered p itself the first time).
+// A column that is walked but not written still leaves its sequences as keys in the iterator's column map (resetColMap keeps
+// the keys, :822-826), which MafBlock::initBlock turns into empty entries that later columns may join: those columns are
+// delivered with their rows, marked.  One lane per column decides this in the pass that counts the rows.
+enum : uint8_t { COL_SKIPPED = 0, COL_WRITTEN = 1, COL_KEYS_ONLY = 2 };
+struct UniqueVisitor {
+    int64_t p, f;   // this column, the range's first column
+    int32_t ref;
+    uint32_t bases = 0;
+    bool inRange = false, leftOfRange = false; // a reference base of the walk in [f, p); one left of f
+    __device__ __forceinline__ void raw(int g, int64_t pos) {
+        if (g == ref && pos < p) {
+            if (pos >= f)
+                inRange = true;
+            else
+                leftOfRange = true;
+        }
+    }
+    __device__ __forceinline__ void operator()(int, int64_t, bool) {
+        ++bases;
+    }
+};
+template <> struct VisitorWantsRaw<UniqueVisitor> {
+    static constexpr bool value = true;
+};
+template <typename C>
+__global__ void __launch_bounds__(256) k_column_unique_count(ColumnParams P, int64_t rangeFirst, int32_t *__restrict__ cnt, uint8_t *__restrict__ cls) {
+    ColumnWalker<C> w(P);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P.count; i += (int64_t)gridDim.x * blockDim.x) {
+        UniqueVisitor v;
+        v.p = P.first + i * P.step;
+        v.f = rangeFirst;
+        v.ref = P.ref;
+        w.run(v.p, v);
+        const uint8_t c = v.inRange ? COL_SKIPPED : v.leftOfRange ? COL_KEYS_ONLY : COL_WRITTEN;
+        cls[i] = c;
+        cnt[i] = c == COL_SKIPPED ? 0 : (int32_t)v.bases;
     }
     if (w.overflow)
         *P.error = 1;
@@ -393,11 +459,19 @@ __global__ void __launch_bounds__(256) k_column_rows(ColumnParams P, const OFF *
 // insertion order) each advanced by one base along its strand.  Inside such a run the MAF block state machine of
 // the reference does nothing but append one character per row, so only the first column of every run ("head")
 // needs its rows shipped to the host.
+// head[c]: 0 the column continues its left neighbour, 1 a head; with cls (--unique): 2 a column that is not walked, 3 a column
+// that is walked but not written (its rows are shipped: they leave keys in the column map) — a written column behind either is a head
 static __global__ void __launch_bounds__(256) k_column_heads(const uint32_t *__restrict__ rowOffset, const ColumnRow *__restrict__ rows, int64_t count,
-                                                      uint8_t *__restrict__ head, uint32_t *__restrict__ headRows /* rows of heads, else 0 */) {
+                                                      uint8_t *__restrict__ head, uint32_t *__restrict__ headRows /* rows of heads, else 0 */,
+                                                      const uint8_t *__restrict__ cls = nullptr) {
     for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < count; c += (int64_t)gridDim.x * blockDim.x) {
         const uint32_t a = rowOffset[c], n = rowOffset[c + 1] - a;
-        bool isHead = c == 0;
+        if (cls && cls[c] != COL_WRITTEN) {
+            head[c] = cls[c] == COL_SKIPPED ? 2 : 3;
+            headRows[c] = cls[c] == COL_SKIPPED ? 0 : n;
+            continue;
+        }
+        bool isHead = c == 0 || (cls && cls[c - 1] != COL_WRITTEN);
         if (!isHead) {
             const uint32_t pa = rowOffset[c - 1];
             isHead = (a - pa) != n;
@@ -415,7 +489,7 @@ static __global__ void __launch_bounds__(256) k_gather_head_rows(const uint32_t 
                                                           const uint8_t *__restrict__ head, const uint32_t *__restrict__ headOffset,
                                                           ColumnRow *__restrict__ out) {
     for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < count; c += (int64_t)gridDim.x * blockDim.x) {
-        if (!head[c])
+        if (!(head[c] & 1))
             continue;
         const uint32_t a = rowOffset[c], n = rowOffset[c + 1] - a, o = headOffset[c];
         for (uint32_t k = 0; k < n; ++k)

@@ -415,10 +415,10 @@ void columnsRowsHost(hgx_alignment *h, int ref, int64_t first, int64_t count, co
     const int grid = (int)std::min<int64_t>(COL_GRID, (count + 255) / 256);
     if (h->dev->wide)
         hipLaunchKernelGGL((k_column_rows<int64_t, uint64_t>), dim3(grid), dim3(256), 0, nullptr, P, (const uint64_t *)dOff.p,
-                           (ColumnRow *)dRows.p);
+                           (ColumnRow *)dRows.p, (const uint8_t *)nullptr);
     else
         hipLaunchKernelGGL((k_column_rows<int32_t, uint64_t>), dim3(grid), dim3(256), 0, nullptr, P, (const uint64_t *)dOff.p,
-                           (ColumnRow *)dRows.p);
+                           (ColumnRow *)dRows.p, (const uint8_t *)nullptr);
     HIP_OK(hipEventRecord(b.e, nullptr));
     unsigned int e = 0;
     HIP_OK(hipMemcpy(&e, err.p, 4, hipMemcpyDeviceToHost));
@@ -525,7 +525,7 @@ static uint32_t deviceScan(const uint32_t *in, uint32_t n, uint32_t *out, uint32
 
 void columnsHeadRowsHost(hgx_alignment *h, int ref, int64_t first, int64_t count, const ColumnOptions &opt, bool withDna,
                          std::vector<uint8_t> &head, std::vector<uint32_t> &headOffset, std::vector<ColumnRowHost> &headRows,
-                         ColumnStats *stats) {
+                         ColumnStats *stats, int64_t uniqueFirst) {
     if (!h->dev)
         throw std::runtime_error("alignment was opened without a device (device = -1); the column engine needs the HIP path");
     HIP_OK(hipSetDevice(h->dev->device));
@@ -542,25 +542,38 @@ void columnsHeadRowsHost(hgx_alignment *h, int ref, int64_t first, int64_t count
     Buf dCnt((size_t)n * 4), dOff(((size_t)n + 1) * 4), dSums(((size_t)n / SCAN_BLOCK + 2) * 4), err(4);
     Ev e0, e1;
     HIP_OK(hipEventRecord(e0.e, nullptr));
-    // 1. rows per column, 2. offsets, 3. all rows (device only)
-    columnsDepthDevice(h, ref, first, count, 1, 2, opt, (int32_t *)dCnt.p, nullptr, nullptr, false, true);
-    checkRowTotal((const uint32_t *)dCnt.p, n);
-    const uint32_t totalRows = deviceScan((const uint32_t *)dCnt.p, n, (uint32_t *)dOff.p, (uint32_t *)dSums.p);
-    Buf dRows((size_t)totalRows * sizeof(ColumnRow));
+    // 1. rows per column (--unique: and which columns the iterator walks and writes), 2. offsets, 3. all rows (device only)
     HIP_OK(hipMemset(err.p, 0, 4));
     Buf masks;
     ColumnParams P = makeParams(h, ref, first, count, 1, opt, (unsigned int *)err.p, masks);
     const int grid = (int)std::min<int64_t>(COL_GRID, (count + 255) / 256);
+    const bool unique = uniqueFirst >= 0;
+    Buf dCls;
+    if (unique) {
+        if (uniqueFirst > first)
+            throw std::runtime_error("columnsHeadRowsHost: the range of --unique begins behind its columns");
+        dCls.resize(n);
+        if (h->dev->wide)
+            hipLaunchKernelGGL((k_column_unique_count<int64_t>), dim3(grid), dim3(256), 0, nullptr, P, uniqueFirst, (int32_t *)dCnt.p, (uint8_t *)dCls.p);
+        else
+            hipLaunchKernelGGL((k_column_unique_count<int32_t>), dim3(grid), dim3(256), 0, nullptr, P, uniqueFirst, (int32_t *)dCnt.p, (uint8_t *)dCls.p);
+    } else {
+        columnsDepthDevice(h, ref, first, count, 1, 2, opt, (int32_t *)dCnt.p, nullptr, nullptr, false, true);
+    }
+    const uint8_t *cls = unique ? (const uint8_t *)dCls.p : nullptr;
+    checkRowTotal((const uint32_t *)dCnt.p, n);
+    const uint32_t totalRows = deviceScan((const uint32_t *)dCnt.p, n, (uint32_t *)dOff.p, (uint32_t *)dSums.p);
+    Buf dRows((size_t)totalRows * sizeof(ColumnRow));
     if (h->dev->wide)
         hipLaunchKernelGGL((k_column_rows<int64_t, uint32_t>), dim3(grid), dim3(256), 0, nullptr, P, (const uint32_t *)dOff.p,
-                           (ColumnRow *)dRows.p);
+                           (ColumnRow *)dRows.p, cls);
     else
         hipLaunchKernelGGL((k_column_rows<int32_t, uint32_t>), dim3(grid), dim3(256), 0, nullptr, P, (const uint32_t *)dOff.p,
-                           (ColumnRow *)dRows.p);
+                           (ColumnRow *)dRows.p, cls);
     // 4. run heads, 5. offsets of the heads' rows, 6. gather them
     Buf dHead(n), dHeadCnt((size_t)n * 4), dHeadOff(((size_t)n + 1) * 4);
     hipLaunchKernelGGL(k_column_heads, dim3(grid), dim3(256), 0, nullptr, (const uint32_t *)dOff.p, (const ColumnRow *)dRows.p, count,
-                       (uint8_t *)dHead.p, (uint32_t *)dHeadCnt.p);
+                       (uint8_t *)dHead.p, (uint32_t *)dHeadCnt.p, cls);
     const uint32_t totalHeadRows = deviceScan((const uint32_t *)dHeadCnt.p, n, (uint32_t *)dHeadOff.p, (uint32_t *)dSums.p);
     Buf dOut((size_t)totalHeadRows * sizeof(ColumnRow));
     hipLaunchKernelGGL(k_gather_head_rows, dim3(grid), dim3(256), 0, nullptr, (const uint32_t *)dOff.p, (const ColumnRow *)dRows.p, count,
@@ -579,7 +592,7 @@ void columnsHeadRowsHost(hgx_alignment *h, int ref, int64_t first, int64_t count
         HIP_OK(hipMemcpy(headRows.data(), dOut.p, (size_t)totalHeadRows * sizeof(ColumnRow), hipMemcpyDeviceToHost));
     uint32_t acc = 0;
     for (uint32_t c = 0; c < n; ++c)
-        if (head[c]) {
+        if (head[c] & 1) { // (1: a head, 3: a column of --unique that is walked but not written; both have their rows here)
             acc += headCnt[c];
             headOffset.push_back(acc);
         }

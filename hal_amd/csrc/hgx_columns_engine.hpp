@@ -64,8 +64,12 @@ void columnsGapRowsHost(hgx_alignment *h, int ref, const std::vector<GapAskHost>
 
 // Run-compressed form for the MAF writer: head[c] == 1 when column c does not simply continue column c-1 (same rows
 // advanced by one base); only heads have their rows returned (headOffset: one entry per head, + 1).
+// uniqueFirst >= 0: hal2maf --unique over a range that begins at genome coordinate uniqueFirst (hgx_column_kernels.hpp:
+// k_column_unique_count) — head[c] == 2: column c is not walked by the reference's iterator (no rows, no entry in headOffset),
+// head[c] == 3: walked but not written (its rows are returned: their sequences become keys of the column map); a written
+// column is a head or a continuation of the written column before it, as above.
 void columnsHeadRowsHost(hgx_alignment *h, int ref, int64_t first, int64_t count, const ColumnOptions &opt, bool withDna,
                          std::vector<uint8_t> &head, std::vector<uint32_t> &headOffset, std::vector<ColumnRowHost> &headRows,
-                         ColumnStats *stats);
+                         ColumnStats *stats, int64_t uniqueFirst = -1);
 
 } // namespace hgx

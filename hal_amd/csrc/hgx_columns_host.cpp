@@ -1289,7 +1289,8 @@ void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alig
 #endif
         while (!have) { // (a chunk's row offsets are 32-bit: very wide alignments get smaller chunks)
             try {
-                columnsHeadRowsHost(alignment, genome, first + done, c->n, opt, true, c->head, c->headOff, headRows, &stats);
+                columnsHeadRowsHost(alignment, genome, first + done, c->n, opt, true, c->head, c->headOff, headRows, &stats,
+                                    _unique ? first : (int64_t)-1);
 #ifdef HGX_HOST_PROFILE
                 if (dump) {
                     const uint64_t hd[4] = {(uint64_t)done, (uint64_t)c->n, c->headOff.size(), headRows.size()};
@@ -1347,10 +1348,19 @@ void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alig
             R.batch->chunks.push_back(c);
             size_t hk = 0;
             for (int64_t i = 0; i < n;) {
+                if (c->head[(size_t)i] == 2) { // --unique: a column the iterator does not walk (nextFreeIndex passes over it)
+                    ++i;
+                    continue;
+                }
                 // head column i: its rows come from the device; the columns up to the next head continue it
                 const PRow *rows = c->rows.data() + c->headOff[hk];
                 const size_t nr = c->headOff[hk + 1] - c->headOff[hk];
                 ++hk;
+                if (c->head[(size_t)i] == 3) { // --unique: walked, not written (a reference base left of the range): its sequences stay
+                    R.addKeys(rows, nr);       // behind as keys of the column map (halColumnIterator.cpp:822-826)
+                    ++i;
+                    continue;
+                }
                 int64_t left = 1;
                 while (i + left < n && !c->head[(size_t)(i + left)])
                     ++left;
@@ -1422,6 +1432,13 @@ void MafExport::convertSequence(std::ostream &mafStream, hgx_alignment *alignmen
     opt.targets.assign(targets.begin(), targets.end());
     const Key refKey{_rank[(size_t)genome][(size_t)seq], genome, seq};
 
+    // --unique alone: which columns the iterator walks and writes is decided on the device, column by column (hgx_column_kernels.hpp:
+    // k_column_unique_count), and the written ones go through the run-compressed path; HGX_UNIQUE_REPLAY=1 keeps the replay of the
+    // visit cache on the host (below) as a cross-check
+    if (_unique && _maxRefGap == 0 && !_printTree && !getenv("HGX_UNIQUE_REPLAY") && !getenv("HGX_MAF_PER_COLUMN") && !getenv("HGX_MAF_MAP_STATE")) {
+        convertSequenceRuns(mafStream, alignment, genome, seq, startPosition, length, opt);
+        return;
+    }
     // (the iterator whose state is sequential — a visit cache, a stack of ranges — is replayed on the host over the device's columns)
     if (_maxRefGap > 0 || _unique) {
         convertSequenceGapped(mafStream, alignment, genome, seq, startPosition + S.start, startPosition + S.start + length - 1, opt);
