@@ -19,6 +19,23 @@
 
 namespace hgx {
 
+// -DHGX_LIFT_PROFILE=4 (make profile-lib PROFILE_KERNEL=4): the cycles finish_query spends in each of its phases, summed over all
+// intervals of the finishing kernels (lane 0 books; hgx_liftover.hip prints the sums after a single-pass run)
+#if defined(HGX_LIFT_PROFILE) && HGX_LIFT_PROFILE == 4
+__device__ unsigned long long g_finishProfile[16];
+#define FQ_PROF_DECL unsigned long long fqT = __builtin_readcyclecounter()
+#define FQ_PROF(i)                                                                                                                           \
+    {                                                                                                                                        \
+        const unsigned long long now = __builtin_readcyclecounter();                                                                         \
+        if (lane_id() == 0)                                                                                                                  \
+            atomicAdd(&g_finishProfile[i], now - fqT);                                                                                       \
+        fqT = now;                                                                                                                           \
+    }
+#else
+#define FQ_PROF_DECL
+#define FQ_PROF(i)
+#endif
+
 template <typename C> struct FinishStore {
     // piece arrays, two banks (A = current, B = scratch / refinement output)
     C *tLo, *tHi, *sLo, *sHi;
@@ -64,6 +81,8 @@ template <typename Less> __device__ __forceinline__ void wave_bitonic(uint32_t *
     }
 }
 
+static constexpr int RANK_SORT_MAX = 128; // sets up to this size are sorted by counting ranks (quadratic: beyond it the bitonic network)
+
 __device__ __forceinline__ int pow2_at_least(int n) {
     int p = 1;
     while (p < n)
@@ -71,9 +90,52 @@ __device__ __forceinline__ int pow2_at_least(int n) {
     return p;
 }
 
+// the two sorts by ranks counted in registers (defined behind the lane-exchange helpers, below)
+template <typename C, int REGS> __device__ __forceinline__ void rank_sort_regs(FinishStore<C> &S, int n);
+template <typename C, int REGS> __device__ __forceinline__ void rank_lines_regs(FinishStore<C> &S, int nl);
+
 // sort bank A by (tLo, tHi, sLo, sHi) into bank B, then swap the banks
-template <typename C> __device__ __forceinline__ void sort_pieces(FinishStore<C> &S, int n) {
+template <typename C, int REGS = 0> __device__ __forceinline__ void sort_pieces(FinishStore<C> &S, int n) {
     const int lane = lane_id();
+    if constexpr (REGS > 0) {
+        if (n <= 64 * REGS && n <= RANK_SORT_MAX) { // (wave-uniform)
+            rank_sort_regs<C, REGS>(S, n);
+            return;
+        }
+    }
+    if (n <= RANK_SORT_MAX) {
+        // a rank by counting: every lane compares its piece with piece j, read by all lanes at once (an LDS broadcast), j = 0 .. n - 1,
+        // and writes it at its rank (equal keys: by index) — for a hundred pieces a tenth of the bitonic network's LDS traffic and
+        // none of its 36 barriers (the sorts were 60 % of an interval's time once extractSegment was off the serial loop)
+        for (int c0 = 0; c0 < n; c0 += 64) {
+            const int i = c0 + lane;
+            const bool in = i < n;
+            const C mt = in ? S.tLo[i] : (C)0, mh = in ? S.tHi[i] : (C)0, ms = in ? S.sLo[i] : (C)0, me = in ? S.sHi[i] : (C)0;
+            const uint8_t mf = in ? S.fl[i] : (uint8_t)0;
+            int rank = 0;
+            for (int j = 0; j < n; ++j) {
+                const C a = S.tLo[j], b = S.tHi[j], c = S.sLo[j], d = S.sHi[j];
+                const bool less = a != mt ? a < mt : b != mh ? b < mh : c != ms ? c < ms : d != me ? d < me : j < i;
+                rank += less ? 1 : 0;
+            }
+            if (in) {
+                S.tLo2[rank] = mt;
+                S.tHi2[rank] = mh;
+                S.sLo2[rank] = ms;
+                S.sHi2[rank] = me;
+                S.fl2[rank] = mf;
+            }
+        }
+        wsync();
+        C *t;
+        uint8_t *u;
+        t = S.tLo, S.tLo = S.tLo2, S.tLo2 = t;
+        t = S.tHi, S.tHi = S.tHi2, S.tHi2 = t;
+        t = S.sLo, S.sLo = S.sLo2, S.sLo2 = t;
+        t = S.sHi, S.sHi = S.sHi2, S.sHi2 = t;
+        u = S.fl, S.fl = S.fl2, S.fl2 = u;
+        return;
+    }
     const int n2 = pow2_at_least(n);
     for (int i = lane; i < n2; i += 64)
         S.ord[i] = (uint32_t)i;
@@ -110,12 +172,18 @@ template <typename C> __device__ __forceinline__ void sort_pieces(FinishStore<C>
     u = S.fl, S.fl = S.fl2, S.fl2 = u;
 }
 
+// extractSegment with the set spread over the lanes' registers (defined behind the lane-exchange helpers, below)
+template <typename C, int REGS> __device__ __forceinline__ void extract_segment_regs(FinishStore<C> &S, int n, int &nlOut, int &failOut);
+
 // Returns the number of output lines written to S.l* (ordered for printing through S.ord), or -need
 // (need > 0) when the staging capacity is insufficient; `need` is a lower bound of the capacity to retry with.
-template <typename C>
+// REGS > 0: a set of up to 64 * REGS members goes through extractSegment in registers (extract_segment_regs) instead of the
+// serial loop over the staging arrays.
+template <typename C, int REGS = 0>
 __device__ __forceinline__ int finish_query(FinishStore<C> &S, const Mapped &in, uint32_t base, int n, const int64_t *__restrict__ seqStart,
                                             int numSeq) {
     const int lane = lane_id();
+    FQ_PROF_DECL;
     if (n > S.cap)
         return -n;
     for (int i = lane; i < n; i += 64) {
@@ -127,7 +195,9 @@ __device__ __forceinline__ int finish_query(FinishStore<C> &S, const Mapped &in,
         S.fl[i] = (uint8_t)r.flags;
     }
     wsync();
-    sort_pieces(S, n);
+    FQ_PROF(8) // load
+    sort_pieces<C, REGS>(S, n);
+    FQ_PROF(0) // first sort
 
     // does any pair of neighbours (in target order) overlap without having the same target range?
     // (if any two pieces do, two neighbours do); are there exact duplicates?
@@ -165,22 +235,29 @@ __device__ __forceinline__ int finish_query(FinishStore<C> &S, const Mapped &in,
                 return bnd[a] < bnd[b];
             });
         }
-        // sorted copy, then drop repeats (serial; this path is rare)
+        FQ_PROF(1) // boundaries sorted
+        // sorted copy, then the distinct values, 64 at a time: a value that differs from the one in front of it is kept, its
+        // place is the number of such values before it (ballot + popcount, a running base) — into the raw array, which is free
         for (int i = lane; i < 2 * n; i += 64)
             S.bnd2[i] = S.bnd[S.ord[i]];
         wsync();
-        if (lane == 0) {
-            int w = 0;
-            for (int i = 0; i < 2 * n; ++i) {
-                const C v = S.bnd2[i];
-                if (w == 0 || v != S.bnd2[w - 1])
-                    S.bnd2[w++] = v;
-            }
-            S.ord[0] = (uint32_t)w;
+        int nbu = 0;
+        for (int c0 = 0; c0 < 2 * n; c0 += 64) {
+            const int i = c0 + lane;
+            const bool in2 = i < 2 * n;
+            const C v = in2 ? S.bnd2[i] : (C)0;
+            const bool fresh = in2 && (i == 0 || v != S.bnd2[i - 1]);
+            const unsigned long long m = __ballot(fresh);
+            if (fresh)
+                S.bnd[nbu + (int)__popcll(m & ((1ull << lane) - 1ull))] = v;
+            nbu += (int)__popcll(m);
         }
         wsync();
-        const int nbu = (int)S.ord[0];
-        wsync();
+        {
+            C *t = S.bnd;
+            S.bnd = S.bnd2;
+            S.bnd2 = t;
+        }
         // number of sub-pieces of piece i = 1 + #{x in bnd : tLo < x <= tHi}
         auto upper = [&](C v) { // first index with bnd[idx] > v
             int lo = 0, hi = nbu;
@@ -196,19 +273,24 @@ __device__ __forceinline__ int finish_query(FinishStore<C> &S, const Mapped &in,
         for (int i = lane; i < n; i += 64)
             S.ord[i] = (uint32_t)(1 + upper(S.tHi[i]) - upper(S.tLo[i]));
         wsync();
-        int m = 0;
-        if (lane == 0) {
-            for (int i = 0; i < n; ++i) {
-                const uint32_t c = S.ord[i];
-                S.ord[i] = (uint32_t)m;
-                m += (int)c;
+        int m = 0; // exclusive prefix sums, 64 at a time with a running base
+        for (int c0 = 0; c0 < n; c0 += 64) {
+            const int i = c0 + lane;
+            const uint32_t c = i < n ? S.ord[i] : 0u;
+            uint32_t incl = c;
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+                if (lane >= o)
+                    incl += up;
             }
-            S.ord[n] = (uint32_t)m;
+            if (i < n)
+                S.ord[i] = (uint32_t)m + incl - c;
+            m += __builtin_amdgcn_readlane((int)incl, 63);
         }
         wsync();
-        m = (int)S.ord[n];
         if (m > S.cap)
             return -m;
+        FQ_PROF(2) // distinct boundaries, counts, prefix sums
         // emit the refined pieces into bank B
         for (int i = lane; i < n; i += 64) {
             int o = (int)S.ord[i];
@@ -247,32 +329,43 @@ __device__ __forceinline__ int finish_query(FinishStore<C> &S, const Mapped &in,
             u = S.fl, S.fl = S.fl2, S.fl2 = u;
         }
         n = m;
-        sort_pieces(S, n);
+        FQ_PROF(3) // refined pieces emitted
+        sort_pieces<C, REGS>(S, n);
+        FQ_PROF(4) // second sort
         dup = false;
         for (int i = lane; i + 1 < n; i += 64)
             if (S.tLo[i + 1] == S.tLo[i] && S.tHi[i + 1] == S.tHi[i] && S.sLo[i + 1] == S.sLo[i] && S.sHi[i + 1] == S.sHi[i])
                 dup = true;
         dup = __any(dup);
     }
-    if (dup) { // std::set keeps the first of equal keys
-        if (lane == 0) {
-            int w = 0;
-            for (int i = 0; i < n; ++i) {
-                if (w > 0 && S.tLo[i] == S.tLo[w - 1] && S.tHi[i] == S.tHi[w - 1] && S.sLo[i] == S.sLo[w - 1] &&
-                    S.sHi[i] == S.sHi[w - 1])
-                    continue;
-                S.tLo[w] = S.tLo[i];
-                S.tHi[w] = S.tHi[i];
-                S.sLo[w] = S.sLo[i];
-                S.sHi[w] = S.sHi[i];
-                S.fl[w] = S.fl[i];
-                ++w;
+    if (dup) { // std::set keeps the first of equal keys: a member equal to the one in front of it goes (equal keys are neighbours)
+        int w = 0;
+        for (int c0 = 0; c0 < n; c0 += 64) {
+            const int i = c0 + lane;
+            const bool keep = i < n && (i == 0 || S.tLo[i] != S.tLo[i - 1] || S.tHi[i] != S.tHi[i - 1] || S.sLo[i] != S.sLo[i - 1] ||
+                                        S.sHi[i] != S.sHi[i - 1]);
+            const unsigned long long km = __ballot(keep);
+            if (keep) {
+                const int o = w + (int)__popcll(km & ((1ull << lane) - 1ull));
+                S.tLo2[o] = S.tLo[i];
+                S.tHi2[o] = S.tHi[i];
+                S.sLo2[o] = S.sLo[i];
+                S.sHi2[o] = S.sHi[i];
+                S.fl2[o] = S.fl[i];
             }
-            S.ord[0] = (uint32_t)w;
+            w += (int)__popcll(km);
         }
         wsync();
-        n = (int)S.ord[0];
-        wsync();
+        {
+            C *t;
+            uint8_t *u;
+            t = S.tLo, S.tLo = S.tLo2, S.tLo2 = t;
+            t = S.tHi, S.tHi = S.tHi2, S.tHi2 = t;
+            t = S.sLo, S.sLo = S.sLo2, S.sLo2 = t;
+            t = S.sHi, S.sHi = S.sHi2, S.sHi2 = t;
+            u = S.fl, S.fl = S.fl2, S.fl2 = u;
+        }
+        n = w;
     }
 
     // target sequence of each piece (Segment::getSequence: site -> sequence, binary search on start[])
@@ -310,10 +403,20 @@ __device__ __forceinline__ int finish_query(FinishStore<C> &S, const Mapped &in,
         return n;
     }
 
-    // ---- extractSegment over the set in target order (serial: lane 0) ----
+    FQ_PROF(5) // duplicates, sequences
+    // ---- extractSegment over the set in target order (in registers when the set fits them, else serial: lane 0) ----
     int nl = 0;
     int fail = 0;
-    if (lane == 0) {
+    bool inRegs = false;
+    if constexpr (REGS > 0) {
+        if (n <= 64 * REGS) { // (wave-uniform)
+            extract_segment_regs<C, REGS>(S, n, nl, fail);
+            inRegs = fail != 2;
+            if (!inRegs)
+                nl = fail = 0;
+        }
+    }
+    if (!inRegs && lane == 0) {
         int ncut = 0;
         auto nextAlive = [&](int i) {
             while (i < n && !S.alive[i])
@@ -391,12 +494,38 @@ __device__ __forceinline__ int finish_query(FinishStore<C> &S, const Mapped &in,
         S.ord[1] = (uint32_t)fail;
     }
     wsync();
-    nl = (int)S.ord[0];
-    fail = (int)S.ord[1];
+    if (!inRegs) {
+        nl = (int)S.ord[0];
+        fail = (int)S.ord[1];
+    }
     wsync();
     if (fail)
         return -(4 * S.cap);
+    FQ_PROF(6) // extractSegment
     // stable sort by source start: key (lSrc, line index)
+    if constexpr (REGS > 0) {
+        if (nl <= 64 * REGS && nl <= RANK_SORT_MAX) {
+            rank_lines_regs<C, REGS>(S, nl);
+            FQ_PROF(7) // lines sorted
+            return nl;
+        }
+    }
+    if (nl <= RANK_SORT_MAX) { // (ranks by counting, as in sort_pieces: ord[rank] = line)
+        for (int c0 = 0; c0 < nl; c0 += 64) {
+            const int i = c0 + lane;
+            const C mine = i < nl ? S.lSrc[i] : (C)0;
+            int rank = 0;
+            for (int j = 0; j < nl; ++j) {
+                const C a = S.lSrc[j];
+                rank += (a != mine ? a < mine : j < i) ? 1 : 0;
+            }
+            if (i < nl)
+                S.ord[rank] = (uint32_t)i;
+        }
+        wsync();
+        FQ_PROF(7) // lines sorted
+        return nl;
+    }
     const int l2 = pow2_at_least(nl);
     for (int i = lane; i < l2; i += 64)
         S.ord[i] = (uint32_t)i;
@@ -414,6 +543,7 @@ __device__ __forceinline__ int finish_query(FinishStore<C> &S, const Mapped &in,
             return a < b;
         });
     }
+    FQ_PROF(7) // lines sorted
     return nl;
 }
 
@@ -798,7 +928,7 @@ __global__ void __launch_bounds__(64) k_finish_lds(Mapped in, const uint32_t *__
         S.cap = CAP, S.cap2 = CAP2, S.cutCap = 32;
         S.blocks = blocks;
         const uint32_t base = offset[q];
-        int nl = finish_query(S, in, base, n, seqStart, numSeq);
+        int nl = finish_query<C, CAP / 64>(S, in, base, n, seqStart, numSeq);
         if (nl >= 0 && nl > n)
             nl = -nl; // records are written into the query's own slice of the grouped buffer (n slots)
         if (nl < 0) {
@@ -828,7 +958,10 @@ __global__ void __launch_bounds__(64) k_finish_big(Mapped in, const uint32_t *__
                                                    const int64_t *__restrict__ seqStart, int numSeq, hgx_record *__restrict__ bigRecords,
                                                    uint32_t *__restrict__ nOut, unsigned long long *counters, int blocks,
                                                    int countOnDevice = 0, uint32_t *__restrict__ offsetOut = nullptr, uint32_t recordBase = 0,
-                                                   uint32_t *waveTotal = nullptr, unsigned long long *otherLines = nullptr) {
+                                                   uint32_t *waveTotal = nullptr, unsigned long long *otherLines = nullptr, int stageInLds = 0) {
+    // stageInLds: the launch has sliceBytes of dynamic LDS and the interval is staged there instead of in its slice of the global
+    // scratch (an interval of a few hundred pieces: the sorts and the sweeps are round trips to LDS, not to memory)
+    extern __shared__ __attribute__((aligned(16))) unsigned char bigLds[];
     // countOnDevice (single-pass runs, hgx_lift_kernels.hpp): the number of deferred intervals is read from the counter block
     // (nDeferred = the slices the scratch area holds; more than that fails the run, the host grows the area and repeats it);
     // offsetOut: the interval's records are slice k of an area that starts recordBase records into the grouped buffer
@@ -844,7 +977,7 @@ __global__ void __launch_bounds__(64) k_finish_big(Mapped in, const uint32_t *__
     for (uint32_t k = blockIdx.x; k < nDeferred; k += gridDim.x) {
         const uint32_t q = deferredList[k];
         const int n = (int)count[q];
-        unsigned char *p = scratch + (size_t)k * sliceBytes;
+        unsigned char *p = stageInLds ? bigLds : scratch + (size_t)k * sliceBytes;
         auto carve = [&](size_t bytes) {
             unsigned char *r = p;
             p += (bytes + 15) & ~(size_t)15;
@@ -865,7 +998,7 @@ __global__ void __launch_bounds__(64) k_finish_big(Mapped in, const uint32_t *__
         S.cap = cap, S.cap2 = cap2, S.cutCap = cap;
         S.blocks = blocks;
         __threadfence_block();
-        const int nl = finish_query(S, in, offset[q], n, seqStart, numSeq);
+        const int nl = finish_query<C, 8>(S, in, offset[q], n, seqStart, numSeq);
         if (nl < 0) {
             if (threadIdx.x == 0) {
                 counters[CNT_BIGFAIL] = 1;
@@ -999,6 +1132,9 @@ template <> __device__ __forceinline__ int64_t wave_read<int64_t>(int64_t v, int
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, j), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), j);
     return (int64_t)(((uint64_t)hi << 32) | lo);
 }
+template <> __device__ __forceinline__ unsigned long long wave_read<unsigned long long>(unsigned long long v, int j) {
+    return (unsigned long long)wave_read<int64_t>((int64_t)v, j);
+}
 template <typename C> __device__ __forceinline__ C wave_push(C v, int dstLane);
 template <> __device__ __forceinline__ int32_t wave_push<int32_t>(int32_t v, int dstLane) {
     return __builtin_amdgcn_ds_permute(dstLane << 2, v);
@@ -1014,6 +1150,394 @@ template <> __device__ __forceinline__ int32_t wave_pull<int32_t>(int32_t v, int
 }
 template <> __device__ __forceinline__ int64_t wave_pull<int64_t>(int64_t v, int srcLane) {
     return __shfl(v, srcLane);
+}
+
+// BlockMapper::extractSegment (liftover/impl/halBlockMapper.cpp:331-394) over a set of up to 64 * REGS members in target order — the
+// formulation of finish_wave (below) for sets of more than 64 members.  The serial loop of finish_query, one lane over the
+// staging arrays, spends an LDS round trip on every coordinate it looks at and looks at ten per pair of members: an interval of a
+// hundred pieces took 120 us, 100 of them there.  Here everything that looks at coordinates is done for all members at once —
+// where the classes of equal target start begin (gb), and for every member a which members of the class BEHIND its own it could
+// be merged with if no cut point forbade it (canMergeRightWith, halMappedSegment.cpp:109-161: a 64-bit mask relative to that
+// class's first member nb[a]; classes of more than 64 members go back to the serial loop) — and the sequential part (which
+// classes a line swallows, what is erased, where the cut points are) runs as wave-uniform scalar code on bit sets of REGS words:
+// the members still in the set, the class starts, the members whose target end is a cut point.  Same walk, same erasures, same
+// lines as the serial loop, which remains the statement of what this computes; it has room for 32 cut points and passes an
+// interval with more on to a larger staging area, this form has no such limit and gives the answer the larger area would.
+// (explicit members and compile-time selection: an array indexed through a loop, even an unrollable one inside a lambda, went to
+// scratch memory — and everything read back from there counts as divergent, which turns every v_readlane into a waterfall loop)
+template <typename T, int N> struct RegFile {
+    T r0, r1, r2, r3, r4, r5, r6, r7;
+    template <int K> __device__ __forceinline__ T &ref() {
+        static_assert(K < 8, "eight registers");
+        if constexpr (K == 0) return r0;
+        else if constexpr (K == 1) return r1;
+        else if constexpr (K == 2) return r2;
+        else if constexpr (K == 3) return r3;
+        else if constexpr (K == 4) return r4;
+        else if constexpr (K == 5) return r5;
+        else if constexpr (K == 6) return r6;
+        else return r7;
+    }
+    template <int K> __device__ __forceinline__ T get() const {
+        return const_cast<RegFile *>(this)->template ref<K>();
+    }
+};
+// a value per member, member j in lane j & 63 of register j >> 6; at(j) for a wave-uniform j
+template <typename T, int REGS> struct RegSet {
+    RegFile<T, REGS> f;
+    template <int K = 1> __device__ __forceinline__ T pick(T r, int hi, int lo) const {
+        if constexpr (K < REGS) {
+            if (hi == K)
+                r = wave_read<T>(f.template get<K>(), lo);
+            return pick<K + 1>(r, hi, lo);
+        } else {
+            return r;
+        }
+    }
+    __device__ __forceinline__ T at(int j) const {
+        const int lo = __builtin_amdgcn_readfirstlane(j & 63), hi = __builtin_amdgcn_readfirstlane(j >> 6);
+        return pick<1>(wave_read<T>(f.template get<0>(), lo), hi, lo);
+    }
+};
+// a set of members, W words of 64 (bits at or behind n are never set)
+template <int W> struct BitSet {
+    RegFile<unsigned long long, W> f;
+    template <int K = 0> __device__ __forceinline__ void zero() {
+        if constexpr (K < W) {
+            f.template ref<K>() = 0ull;
+            zero<K + 1>();
+        }
+    }
+    template <int K = 1> __device__ __forceinline__ unsigned long long pick(unsigned long long w, int k) const {
+        if constexpr (K < W) {
+            if (k == K)
+                w = f.template get<K>();
+            return pick<K + 1>(w, k);
+        } else {
+            return w;
+        }
+    }
+    __device__ __forceinline__ unsigned long long word(int k) const { // (0 behind the last word)
+        return k >= W ? 0ull : pick<1>(f.template get<0>(), k);
+    }
+    __device__ __forceinline__ bool get(int i) const {
+        return ((word(i >> 6) >> (i & 63)) & 1ull) != 0;
+    }
+    template <int K = 0> __device__ __forceinline__ void clear(int i) {
+        if constexpr (K < W) {
+            if ((i >> 6) == K)
+                f.template ref<K>() &= ~(1ull << (i & 63));
+            clear<K + 1>(i);
+        }
+    }
+    template <int K = 0> __device__ __forceinline__ void setSpan(int lo, int hi) { // members lo .. hi - 1
+        if constexpr (K < W) {
+            const int a = lo - 64 * K < 0 ? 0 : lo - 64 * K, b = hi - 64 * K > 64 ? 64 : hi - 64 * K;
+            if (a < b)
+                f.template ref<K>() |= (b >= 64 ? ~0ull : ((1ull << b) - 1ull)) & ~((1ull << a) - 1ull);
+            setSpan<K + 1>(lo, hi);
+        }
+    }
+    __device__ __forceinline__ int firstFrom(int i, int n) const { // the first member at or behind i, or n
+        if (i >= n)
+            return n;
+        int k = i >> 6;
+        unsigned long long w = word(k) & (~0ull << (i & 63));
+        while (!w && ++k < W)
+            w = word(k);
+        return w ? 64 * k + (int)__builtin_ctzll(w) : n;
+    }
+    __device__ __forceinline__ int lastAtOrBelow(int i) const { // the last member at or in front of i (0 if there is none)
+        int k = i >> 6;
+        unsigned long long w = word(k) & ((i & 63) == 63 ? ~0ull : ((1ull << ((i & 63) + 1)) - 1ull));
+        while (!w && k > 0)
+            w = word(--k);
+        return w ? 64 * k + 63 - (int)__builtin_clzll(w) : 0;
+    }
+    __device__ __forceinline__ unsigned long long window(int i) const { // members i .. i + 63 as bits 0 .. 63
+        const int k = i >> 6, sft = i & 63;
+        unsigned long long w = word(k) >> sft;
+        if (sft)
+            w |= word(k + 1) << (64 - sft);
+        return w;
+    }
+};
+__device__ __forceinline__ unsigned long long low_bits(int len) { // len in 0 .. 64
+    return len >= 64 ? ~0ull : ((1ull << len) - 1ull);
+}
+// The sorts of finish_query by ranks counted in registers: every lane holds its members (member j in lane j & 63 of register
+// j >> 6), piece j's key is read by all lanes at once with v_readlane, j = 0 .. n - 1, and every lane counts the pieces in front
+// of each of its own (equal keys: by index).  A hundred pieces: a few thousand instructions and one barrier, where the bitonic
+// network in LDS took 36 stages of LDS round trips with a barrier each (40 k cycles an interval).
+template <typename C, int REGS> struct RankSort {
+    RegFile<C, REGS> tLo, tHi, sLo, sHi;
+    RegFile<int32_t, REGS> rank;
+    template <int K = 0> __device__ __forceinline__ void load(const FinishStore<C> &S, int lane, int n) {
+        if constexpr (K < REGS) {
+            const int i = lane + 64 * K;
+            const bool in = i < n;
+            tLo.template ref<K>() = in ? S.tLo[i] : (C)0;
+            tHi.template ref<K>() = in ? S.tHi[i] : (C)0;
+            sLo.template ref<K>() = in ? S.sLo[i] : (C)0;
+            sHi.template ref<K>() = in ? S.sHi[i] : (C)0;
+            rank.template ref<K>() = 0;
+            load<K + 1>(S, lane, n);
+        }
+    }
+    template <int M = 0> __device__ __forceinline__ void count(C a, C b, C c, C d, int j, int lane, int n) {
+        if constexpr (M < REGS) {
+            if (64 * M < n) { // (wave-uniform)
+                const C mt = tLo.template get<M>(), mh = tHi.template get<M>(), ms = sLo.template get<M>(), me = sHi.template get<M>();
+                const bool less = a != mt ? a < mt : b != mh ? b < mh : c != ms ? c < ms : d != me ? d < me : j < lane + 64 * M;
+                rank.template ref<M>() += less ? 1 : 0;
+            }
+            count<M + 1>(a, b, c, d, j, lane, n);
+        }
+    }
+    template <int K = 0> __device__ __forceinline__ void sweep(int lane, int n) {
+        if constexpr (K < REGS) {
+            const int lim = n - 64 * K < 64 ? n - 64 * K : 64;
+            for (int jj = 0; jj < lim; ++jj)
+                count<0>(wave_read<C>(tLo.template get<K>(), jj), wave_read<C>(tHi.template get<K>(), jj), wave_read<C>(sLo.template get<K>(), jj),
+                         wave_read<C>(sHi.template get<K>(), jj), 64 * K + jj, lane, n);
+            sweep<K + 1>(lane, n);
+        }
+    }
+    template <int K = 0> __device__ __forceinline__ void store(FinishStore<C> &S, int lane, int n) {
+        if constexpr (K < REGS) {
+            const int i = lane + 64 * K;
+            if (i < n) {
+                const int r = rank.template get<K>();
+                S.tLo2[r] = tLo.template get<K>();
+                S.tHi2[r] = tHi.template get<K>();
+                S.sLo2[r] = sLo.template get<K>();
+                S.sHi2[r] = sHi.template get<K>();
+                S.fl2[r] = S.fl[i];
+            }
+            store<K + 1>(S, lane, n);
+        }
+    }
+};
+template <typename C, int REGS> __device__ __forceinline__ void rank_sort_regs(FinishStore<C> &S, int n) {
+    const int lane = lane_id();
+    RankSort<C, REGS> R;
+    R.load(S, lane, n);
+    R.sweep(lane, n);
+    R.store(S, lane, n);
+    wsync();
+    C *t;
+    uint8_t *u;
+    t = S.tLo, S.tLo = S.tLo2, S.tLo2 = t;
+    t = S.tHi, S.tHi = S.tHi2, S.tHi2 = t;
+    t = S.sLo, S.sLo = S.sLo2, S.sLo2 = t;
+    t = S.sHi, S.sHi = S.sHi2, S.sHi2 = t;
+    u = S.fl, S.fl = S.fl2, S.fl2 = u;
+}
+// the lines' order: stable by source start, S.ord[rank] = line
+template <typename C, int REGS> struct RankLines {
+    RegFile<C, REGS> src;
+    RegFile<int32_t, REGS> rank;
+    template <int K = 0> __device__ __forceinline__ void load(const FinishStore<C> &S, int lane, int nl) {
+        if constexpr (K < REGS) {
+            src.template ref<K>() = lane + 64 * K < nl ? S.lSrc[lane + 64 * K] : (C)0;
+            rank.template ref<K>() = 0;
+            load<K + 1>(S, lane, nl);
+        }
+    }
+    template <int M = 0> __device__ __forceinline__ void count(C a, int j, int lane, int nl) {
+        if constexpr (M < REGS) {
+            if (64 * M < nl) {
+                const C mine = src.template get<M>();
+                rank.template ref<M>() += (a != mine ? a < mine : j < lane + 64 * M) ? 1 : 0;
+            }
+            count<M + 1>(a, j, lane, nl);
+        }
+    }
+    template <int K = 0> __device__ __forceinline__ void sweep(int lane, int nl) {
+        if constexpr (K < REGS) {
+            const int lim = nl - 64 * K < 64 ? nl - 64 * K : 64;
+            for (int jj = 0; jj < lim; ++jj)
+                count<0>(wave_read<C>(src.template get<K>(), jj), 64 * K + jj, lane, nl);
+            sweep<K + 1>(lane, nl);
+        }
+    }
+    template <int K = 0> __device__ __forceinline__ void store(FinishStore<C> &S, int lane, int nl) {
+        if constexpr (K < REGS) {
+            if (lane + 64 * K < nl)
+                S.ord[rank.template get<K>()] = (uint32_t)(lane + 64 * K);
+            store<K + 1>(S, lane, nl);
+        }
+    }
+};
+template <typename C, int REGS> __device__ __forceinline__ void rank_lines_regs(FinishStore<C> &S, int nl) {
+    const int lane = lane_id();
+    RankLines<C, REGS> R;
+    R.load(S, lane, nl);
+    R.sweep(lane, nl);
+    R.store(S, lane, nl);
+    wsync();
+}
+template <typename C, int REGS> struct ExtractPrep { // the parallel part: one member per lane and register
+    BitSet<REGS> gb;
+    RegSet<unsigned long long, REGS> mergeRel;
+    RegSet<int32_t, REGS> nb;
+    bool tooWide = false;
+    template <int K = 0> __device__ __forceinline__ void starts(const FinishStore<C> &S, int lane, int n) {
+        if constexpr (K < REGS) {
+            const int j = lane + 64 * K;
+            gb.f.template ref<K>() = __ballot(j < n && (j == 0 || S.tLo[j] != S.tLo[j - 1]));
+            starts<K + 1>(S, lane, n);
+        }
+    }
+    template <int K = 0> __device__ __forceinline__ void partners(const FinishStore<C> &S, int lane, int n) {
+        if constexpr (K < REGS) {
+            const int j = lane + 64 * K;
+            unsigned long long mr = 0;
+            int first = n;
+            if (j < n) {
+                first = gb.firstFrom(j + 1, n); // the class behind this member's: [first, first + gsz)
+                const int gsz = gb.firstFrom(first + 1, n) - first;
+                if (gsz > 64 || (gb.get(j) && first - j > 64))
+                    tooWide = true;
+                const C tHi = S.tHi[j], sLo = S.sLo[j], sHi = S.sHi[j];
+                const int fl = (int)S.fl[j], seq = S.seq[j];
+                const bool same = ((fl & F_SREV) != 0) == ((fl & F_TREV) != 0);
+                for (int c = 0; c < gsz && c < 64; ++c) {
+                    const int b = first + c;
+                    const int bFl = (int)S.fl[b];
+                    if (S.seq[b] == seq && ((fl ^ bFl) & (F_SREV | F_TREV)) == 0 && S.tLo[b] - tHi == 1 &&
+                        (same ? S.sLo[b] - sHi == 1 : sLo - S.sHi[b] == 1))
+                        mr |= 1ull << c;
+                }
+            }
+            mergeRel.f.template ref<K>() = mr;
+            nb.f.template ref<K>() = first;
+            partners<K + 1>(S, lane, n);
+        }
+    }
+    template <int K = 0> __device__ __forceinline__ int classes() const {
+        if constexpr (K < REGS)
+            return (int)__popcll(gb.f.template get<K>()) + classes<K + 1>();
+        else
+            return 0;
+    }
+    __device__ __forceinline__ bool allSingle(int n) const {
+        return classes() == n;
+    }
+    // (all classes single) line starts: member 0 and every member whose left neighbour cannot be merged with it
+    template <int K = 0> __device__ __forceinline__ void lineStarts(BitSet<REGS> &L, int lane, int n, unsigned long long carry) {
+        if constexpr (K < REGS) {
+            const int j = lane + 64 * K;
+            const unsigned long long m0 = __ballot(j < n && (mergeRel.f.template get<K>() & 1ull) != 0); // mergeable with member j + 1
+            const unsigned long long valid = low_bits(n - 64 * K < 0 ? 0 : (n - 64 * K > 64 ? 64 : n - 64 * K));
+            L.f.template ref<K>() = ~((m0 << 1) | carry) & valid;
+            lineStarts<K + 1>(L, lane, n, m0 >> 63);
+        }
+    }
+    template <int K = 0> __device__ __forceinline__ void writeLines(const FinishStore<C> &S, const BitSet<REGS> &L, int lane, int n, int before) {
+        if constexpr (K < REGS) {
+            const int j = lane + 64 * K;
+            const unsigned long long w = L.f.template get<K>();
+            if (j < n && ((w >> lane) & 1ull)) {
+                const int l = before + (int)__popcll(w & ((1ull << lane) - 1ull));
+                const int fragBack = L.firstFrom(j + 1, n) - 1; // the member in front of the next line's first
+                const C iT = S.tLo[j], fT = S.tLo[fragBack], iH = S.tHi[j], fH = S.tHi[fragBack], iS = S.sLo[j], fS = S.sLo[fragBack];
+                const int iFl = (int)S.fl[j];
+                S.lStart[l] = iT < fT ? iT : fT; // halBlockLiftover.cpp:82-105
+                S.lEnd[l] = (iH > fH ? iH : fH) + 1;
+                S.lSrc[l] = iS < fS ? iS : fS;
+                S.lSeq[l] = S.seq[j];
+                S.lStrand[l] = (uint8_t)(((iFl & F_DOT) ? '.' : ((iFl & F_TREV) ? '-' : '+')) | ((iFl & F_TREV) ? 0x80 : 0));
+            }
+            writeLines<K + 1>(S, L, lane, n, before + (int)__popcll(w));
+        }
+    }
+    __device__ __forceinline__ void singles(const FinishStore<C> &S, int lane, int n, int &nl) {
+        BitSet<REGS> L;
+        lineStarts(L, lane, n, 0ull); // (carry 0: member 0 begins a line — bit 0 of ~(m0 << 1) is set)
+        nl = 0;
+        countLines(L, nl);
+        writeLines(S, L, lane, n, 0);
+    }
+    template <int K = 0> __device__ __forceinline__ void countLines(const BitSet<REGS> &L, int &nl) const {
+        if constexpr (K < REGS) {
+            nl += (int)__popcll(L.f.template get<K>());
+            countLines<K + 1>(L, nl);
+        }
+    }
+};
+template <typename C, int REGS> __device__ __forceinline__ void extract_segment_regs(FinishStore<C> &S, int n, int &nlOut, int &failOut) {
+    const int lane = lane_id();
+    ExtractPrep<C, REGS> P;
+    P.starts(S, lane, n);
+    P.partners(S, lane, n);
+    nlOut = 0;
+    failOut = 0;
+    if (__any(P.tooWide)) { // a class of more than 64 members: the serial loop's
+        failOut = 2;
+        return;
+    }
+    if (P.allSingle(n)) {
+        // Every class has one member (no two members with the same target range: the usual set).  Then a line swallows the member
+        // behind its last one exactly when the two can be merged (there is no cut point without a class of two), what it erases lies
+        // behind it, and the lines are the maximal runs of members each mergeable with its right neighbour: no loop at all — a
+        // line begins at member 0 and behind every member that cannot be merged with the next one.
+        P.singles(S, lane, n, nlOut);
+        return;
+    }
+    BitSet<REGS> alive, cut;
+    alive.zero();
+    cut.zero();
+    alive.setSpan(0, n);
+    int nl = 0;
+    for (int i = alive.firstFrom(0, n); i < n; i = alive.firstFrom(i + 1, n)) {
+        i = __builtin_amdgcn_readfirstlane(i);
+        const int ce = P.gb.firstFrom(i + 1, n);
+        unsigned long long v1 = alive.window(i) & low_bits(ce - i); // what is left of i's class from i on, bit 0 = member v1base
+        int v1base = i, v1n = (int)__popcll(v1);
+        int nxt = alive.firstFrom(ce, n);
+        int fragBack = i;
+        while (nxt < n) {
+            // the next v1n members of the class nxt is in, as far as it has them
+            unsigned long long rest = alive.window(nxt) & low_bits(P.gb.firstFrom(nxt + 1, n) - nxt), v2 = 0;
+            int v2n = 0, last = 0;
+            while (rest && v2n < v1n) {
+                last = (int)__builtin_ctzll(rest);
+                v2 |= 1ull << last;
+                rest &= rest - 1;
+                ++v2n;
+            }
+            const int after = alive.firstFrom(nxt + last + 1, n);
+            bool can = v1n == v2n;
+            for (unsigned long long m1 = v1, m2 = v2; m1 && can; m1 &= m1 - 1, m2 &= m2 - 1) { // member by member
+                const int a = v1base + (int)__builtin_ctzll(m1), b = nxt + (int)__builtin_ctzll(m2);
+                const int rel = b - P.nb.at(a);
+                can = rel >= 0 && rel < 64 && ((P.mergeRel.at(a) >> rel) & 1ull) != 0 && !cut.get(a);
+            }
+            if (!can)
+                break;
+            fragBack = nxt; // (the first of v2: nxt itself is in the set)
+            alive.clear(fragBack); // erased from the set (halBlockMapper.cpp:389-391)
+            v1 = v2;
+            v1base = nxt;
+            v1n = v2n;
+            nxt = after;
+        }
+        if (v1n > 1) // a cut point at the end of the last class (:382-386): no line merges across it any more
+            cut.setSpan(P.gb.lastAtOrBelow(fragBack), P.gb.firstFrom(fragBack + 1, n));
+        if (lane == 0) { // halBlockLiftover.cpp:82-105
+            const C iT = S.tLo[i], fT = S.tLo[fragBack], iH = S.tHi[i], fH = S.tHi[fragBack], iS = S.sLo[i], fS = S.sLo[fragBack];
+            const int iFl = (int)S.fl[i];
+            S.lStart[nl] = iT < fT ? iT : fT;
+            S.lEnd[nl] = (iH > fH ? iH : fH) + 1;
+            S.lSrc[nl] = iS < fS ? iS : fS;
+            S.lSeq[nl] = S.seq[i];
+            // strand character in the low 7 bits, the piece's own orientation in bit 7
+            S.lStrand[nl] = (uint8_t)(((iFl & F_DOT) ? '.' : ((iFl & F_TREV) ? '-' : '+')) | ((iFl & F_TREV) ? 0x80 : 0));
+        }
+        ++nl;
+    }
+    nlOut = nl;
 }
 
 // -DHGX_LIFT_PROFILE (make profile-lib: hal_amd/libhgx_prof.so, loaded with HGX_LIB_PATH): lane 0 of every wavefront of

@@ -760,6 +760,25 @@ template <typename K> static int residentGrid(K kernel, size_t dynLds = 0) {
     return g;
 }
 
+// may k_finish_big stage an interval's slice in LDS?  Up to the 160 KB a workgroup can have (beyond 64 KB the kernel is told once)
+template <typename C> static bool bigLdsOk(size_t sliceBytes) {
+    if (getenv("HGX_BIG_IN_LDS") && getenv("HGX_BIG_IN_LDS")[0] == '0')
+        return false;
+    if (sliceBytes > 160 * 1024 - 1024)
+        return false;
+    static std::mutex mu;
+    static size_t allowed = 64 * 1024;
+    std::lock_guard<std::mutex> lock(mu);
+    if (sliceBytes > allowed) {
+        if (hipFuncSetAttribute((const void *)k_finish_big<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - 1024)) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        allowed = 160 * 1024 - 1024;
+    }
+    return true;
+}
+
 static void exclusiveScan(hgx_liftover_plan &P, const uint32_t *in, uint32_t n, uint32_t *out, uint32_t *total, hipStream_t s) {
     const uint32_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
     P.timer.begin("scan", s);
@@ -873,7 +892,9 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
     if (events)
         HIP_OK(hipEventRecord(P.evWalk, s));
     P.timer.begin("k_finish_lds", s);
-    hipLaunchKernelGGL((k_finish_lds<C, 256>), dim3(std::min<uint32_t>(std::max<uint32_t>(nq, 1), 1536u)), dim3(64), 0, s, P.mapped(1),
+    // (128 pieces of staging — 10 KB of LDS: fifteen intervals a CU instead of seven; a wavefront alone on its SIMD leaves most of its
+    // issue slots empty, and the few intervals that outgrow 128 go on to k_finish_big, which stages in LDS as well)
+    hipLaunchKernelGGL((k_finish_lds<C, 128>), dim3(std::min<uint32_t>(std::max<uint32_t>(nq, 1), 3840u)), dim3(64), 0, s, P.mapped(1),
                        (const uint32_t *)P.offset.p, (const uint32_t *)P.perQuery.p, lateList, lateCount, (const int64_t *)TG.seqStart,
                        (int)TG.numSeq, (hgx_record *)P.grouped.p, (uint32_t *)P.nOut.p, (uint32_t *)P.deferredList.p, (uint32_t *)P.needCap.p,
                        cnt, 0, waveTotal, cnt + CNT_DSTAT0 + STAT_LAUNCH0 + 2 * storeLaunch + 1);
@@ -881,13 +902,49 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
     } else if (events) {
         HIP_OK(hipEventRecord(P.evWalk, s));
     }
+    if (!P.liftRestSkipped && getenv("HGX_LATE_HISTOGRAM")) { // diagnostics: how many pieces the intervals passed on have (stderr)
+        HIP_OK(hipStreamSynchronize(s));
+        unsigned long long nLate = 0;
+        HIP_OK(hipMemcpy(&nLate, lateCount, 8, hipMemcpyDeviceToHost));
+        std::vector<uint32_t> list((size_t)nLate), per((size_t)nq + 1);
+        if (nLate)
+            HIP_OK(hipMemcpy(list.data(), lateList, 4 * (size_t)nLate, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(per.data(), P.perQuery.p, 4 * ((size_t)nq + 1), hipMemcpyDeviceToHost));
+        unsigned long long hist[16] = {0}, pieces = 0, mx = 0;
+        for (uint32_t q : list) {
+            const uint32_t c = per[q];
+            int b = 0;
+            while ((1u << b) < c && b < 15)
+                ++b;
+            ++hist[b];
+            pieces += c;
+            mx = std::max<unsigned long long>(mx, c);
+        }
+        fprintf(stderr, "[hgx late] %llu intervals passed on, %llu pieces, largest %llu; by pieces <= 2^b:", nLate, pieces, mx);
+        for (int b = 0; b < 16; ++b)
+            fprintf(stderr, " %d:%llu", b, hist[b]);
+        fprintf(stderr, "\n");
+    }
+#if defined(HGX_LIFT_PROFILE) && HGX_LIFT_PROFILE == 4
+    if (!P.liftRestSkipped) {
+        HIP_OK(hipStreamSynchronize(s));
+        unsigned long long fp[16];
+        HIP_OK(hipMemcpyFromSymbol(fp, HIP_SYMBOL(g_finishProfile), sizeof fp));
+        fprintf(stderr, "(k_finish_lds) [hgx finish profile] Mcycles: sort %.2f | boundary sort %.2f | unique+prefix %.2f | emit %.2f | sort2 %.2f | dups+seq %.2f | extract %.2f | line sort %.2f | load %.2f\n",
+                fp[0] / 1e6, fp[1] / 1e6, fp[2] / 1e6, fp[3] / 1e6, fp[4] / 1e6, fp[5] / 1e6, fp[6] / 1e6, fp[7] / 1e6, fp[8] / 1e6);
+        memset(fp, 0, sizeof fp);
+        HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_finishProfile), fp, sizeof fp));
+    }
+#endif
     if (P.liftBigSlots && !P.liftRestSkipped) { // intervals k_finish_lds deferred: same algorithm on global scratch; their records become slices behind the grouped buffer
         P.timer.begin("k_finish_big", s);
-        hipLaunchKernelGGL((k_finish_big<C>), dim3(P.liftBigSlots), dim3(64), 0, s, P.mapped(1), (const uint32_t *)P.offset.p,
+        const size_t bigSlice = finishSliceBytes<C>(P.liftBigCap);
+        const int bigInLds = bigLdsOk<C>(bigSlice) ? 1 : 0; // (a few hundred pieces: staged in LDS, not in the global scratch)
+        hipLaunchKernelGGL((k_finish_big<C>), dim3(P.liftBigSlots), dim3(64), bigInLds ? bigSlice : 0, s, P.mapped(1), (const uint32_t *)P.offset.p,
                            (const uint32_t *)P.perQuery.p, (const uint32_t *)P.deferredList.p, P.liftBigSlots, P.liftBigCap,
-                           (unsigned char *)P.scratch.p, finishSliceBytes<C>(P.liftBigCap), (const int64_t *)TG.seqStart, (int)TG.numSeq,
+                           (unsigned char *)P.scratch.p, bigSlice, (const int64_t *)TG.seqStart, (int)TG.numSeq,
                            (hgx_record *)P.grouped.p + cap, (uint32_t *)P.nOut.p, cnt, 0, 1, (uint32_t *)P.offset.p, cap, waveTotal,
-                           cnt + CNT_DSTAT0 + STAT_LAUNCH0 + 2 * storeLaunch + 1);
+                           cnt + CNT_DSTAT0 + STAT_LAUNCH0 + 2 * storeLaunch + 1, bigInLds);
         P.timer.end(s);
     }
     // everything else, and the dense output
@@ -918,6 +975,18 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
 #undef HGX_LIFT
     P.timer.end(s);
     ++launch;
+#if defined(HGX_LIFT_PROFILE) && HGX_LIFT_PROFILE == 4
+    if (!P.liftRestSkipped) {
+        fprintf(stderr, "(k_finish_big) ");
+        HIP_OK(hipStreamSynchronize(s));
+        unsigned long long fp[16];
+        HIP_OK(hipMemcpyFromSymbol(fp, HIP_SYMBOL(g_finishProfile), sizeof fp));
+        fprintf(stderr, "[hgx finish profile] Mcycles: load+sort %.2f | boundary sort %.2f | unique+prefix %.2f | emit %.2f | sort2 %.2f | dups+seq %.2f | extract %.2f | line sort %.2f | load %.2f\n",
+                fp[0] / 1e6, fp[1] / 1e6, fp[2] / 1e6, fp[3] / 1e6, fp[4] / 1e6, fp[5] / 1e6, fp[6] / 1e6, fp[7] / 1e6, fp[8] / 1e6);
+        memset(fp, 0, sizeof fp);
+        HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_finishProfile), fp, sizeof fp));
+    }
+#endif
     if (events)
         HIP_OK(hipEventRecord(P.evEnd, s));
     P.liftLaunches = launch;
@@ -1414,10 +1483,12 @@ static void runPlan(hgx_liftover_plan &P, size_t n, const int64_t *dS, const int
             unsigned long long zero[2] = {0, 0};
             HIP_OK(hipMemcpyAsync(cnt + CNT_MAXNEED, zero, 16, hipMemcpyHostToDevice, s)); // MAXNEED, BIGFAIL
             P.timer.begin("k_finish_big", s);
-            hipLaunchKernelGGL((k_finish_big<C>), dim3(nDef), dim3(64), 0, s, P.mapped(1), (const uint32_t *)P.offset.p,
+            const int bigInLds = bigLdsOk<C>(slice) ? 1 : 0;
+            hipLaunchKernelGGL((k_finish_big<C>), dim3(nDef), dim3(64), bigInLds ? slice : 0, s, P.mapped(1), (const uint32_t *)P.offset.p,
                                (const uint32_t *)P.perQuery.p, (const uint32_t *)P.deferredList.p, nDef, bigCap,
                                (unsigned char *)P.scratch.p, slice, (const int64_t *)TG.seqStart, (int)TG.numSeq,
-                               (hgx_record *)P.bigRecords.p, (uint32_t *)P.nOut.p, cnt, P.opts.emit_blocks);
+                               (hgx_record *)P.bigRecords.p, (uint32_t *)P.nOut.p, cnt, P.opts.emit_blocks, 0, (uint32_t *)nullptr, 0u,
+                               (uint32_t *)nullptr, (unsigned long long *)nullptr, bigInLds);
             P.timer.end(s);
             unsigned long long r[2];
             HIP_OK(hipMemcpyAsync(r, cnt + CNT_MAXNEED, 16, hipMemcpyDeviceToHost, s));
