@@ -775,10 +775,12 @@ static __global__ void __launch_bounds__(256) k_sweep_top(const M *__restrict__ 
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         A[i] = track_size<M, SUM>(S ? S[i] : own);
 }
+// accumulate: more than 64 counted genomes go through the sweeps in groups of 64 (a group's genome sets are 64-bit words); the
+// depth of a column is the sum of the groups' set sizes at the column's topmost ancestor
 static __global__ void __launch_bounds__(256) k_sweep_out(const int32_t *__restrict__ A, int64_t first, int64_t count, int64_t step, int32_t sub,
-                                                          int32_t *__restrict__ out) {
+                                                          int32_t *__restrict__ out, int accumulate) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
-        out[i] = A[first + i * step] - sub;
+        out[i] = (accumulate ? out[i] : 0) + A[first + i * step] - sub;
 }
 
 } // namespace hgx

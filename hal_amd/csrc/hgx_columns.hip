@@ -244,12 +244,17 @@ static bool columnsDepthSweep(hgx_alignment *h, int ref, int64_t first, int64_t 
     const bool sum = mode != 0;
     int bits = 0;
     std::vector<long long> own((size_t)ng, 0);
+    std::vector<int> bitOf((size_t)ng, -1); // a counted genome's number among the counted ones
     for (int g : postOrder)
         if (counted[(size_t)g]) {
             own[(size_t)g] = sum ? 1ll : (long long)(1ull << (bits & 63));
+            bitOf[(size_t)g] = bits;
             ++bits;
         }
-    if (!sum && bits > 64)
+    // more than 64 counted genomes (cactus alignments have hundreds): the sweeps run once per group of 64 — the size of a
+    // column's genome set is the sum of the sizes of its parts — and the groups' depths are added up on the way out
+    const int groups = sum ? 1 : std::max(1, (bits + 63) / 64);
+    if (getenv("HGX_SWEEP_GROUPS_MAX") && groups > atoi(getenv("HGX_SWEEP_GROUPS_MAX")))
         return false;
     // (a genome set per base is as wide as the counted genomes need: the sweeps are bound by the tracks' bytes)
     const size_t word = sum ? 4 : bits <= 8 ? 1 : bits <= 16 ? 2 : bits <= 32 ? 4 : 8;
@@ -281,6 +286,10 @@ static bool columnsDepthSweep(hgx_alignment *h, int ref, int64_t first, int64_t 
         A[(size_t)path[i]].resize((size_t)img.genomes[(size_t)path[i]].totalLength * 4);
     Ev a, b;
     HIP_OK(hipEventRecord(a.e, s));
+    for (int group = 0; group < groups; ++group) {
+    if (groups > 1) // this group's genomes carry their bit, the others none
+        for (int g = 0; g < ng; ++g)
+            own[(size_t)g] = bitOf[(size_t)g] >= 0 && bitOf[(size_t)g] / 64 == group ? (long long)(1ull << (bitOf[(size_t)g] & 63)) : 0ll;
 #define HGX_SWEEP(C)                                                                                                                         \
     if (sum)                                                                                                                                 \
         sweepTracks<C, int32_t, true>(h, postOrder, path, inScope, own, hasTrack, S, A, s);                                                  \
@@ -298,7 +307,9 @@ static bool columnsDepthSweep(hgx_alignment *h, int ref, int64_t first, int64_t 
         HGX_SWEEP(int32_t);
     }
 #undef HGX_SWEEP
-    hipLaunchKernelGGL(k_sweep_out, dim3(2048), dim3(256), 0, s, (const int32_t *)A[(size_t)ref].p, first, count, step, mode == 2 ? 0 : 1, d_out);
+    hipLaunchKernelGGL(k_sweep_out, dim3(2048), dim3(256), 0, s, (const int32_t *)A[(size_t)ref].p, first, count, step,
+                       mode == 2 || group > 0 ? 0 : 1, d_out, group > 0 ? 1 : 0);
+    }
     HIP_OK(hipEventRecord(b.e, s));
     HIP_OK(hipStreamSynchronize(s));
     if (stats) {

@@ -54,3 +54,33 @@ def test_three_hundred_genomes(hal, oracle_bin, tmp_path):
     al = hal.Alignment.open(img, device=0)
     assert al.num_genomes == 300
     _check(hal, oracle_bin, tmp_path, al, img, [(299, 150), (150, 299), (0, 280), (270, 0)], [0, 299, 120])
+
+
+def test_depth_sweeps_with_more_than_64_counted_genomes(hal, oracle_bin, tmp_path, monkeypatch):
+    """the tree sweeps keep a 64-bit genome set per base: alignments with more counted genomes (300 here, 150 leaves with
+    --noAncestors, a hundred targets) go through them in groups of 64, the groups' set sizes added up — against the column walk
+    and the oracle"""
+    import numpy as np
+    img = str(tmp_path / "wide.hgx")
+    halfix.write_hgx(img, halfix.random_multiseq_alignment(7, n_genomes=300, max_children=3, root_len=300))
+    al = hal.Alignment.open(img, device=0)
+    leaves = [g for g in range(al.num_genomes) if not al.genome_children(g)]
+    assert len(leaves) > 64
+    for g in (0, 299, 120, leaves[0], leaves[-1]):
+        name = al.genome_name(g)
+        n = al.genome_length(g)
+        if n == 0:
+            continue
+        leaf = not al.genome_children(g)
+        cases = [dict(), dict(count_dupes=True), dict(targets=list(range(3, 290, 3)))]
+        if leaf:
+            cases.append(dict(no_ancestors=True))
+        for kw in cases:
+            monkeypatch.setenv("HGX_DEPTH_SWEEP", "1")
+            a = al.columns_depth(g, 0, n, **kw)
+            monkeypatch.setenv("HGX_DEPTH_SWEEP", "0")
+            assert np.array_equal(a, al.columns_depth(g, 0, n, **kw)), (name, kw)
+        monkeypatch.setenv("HGX_DEPTH_SWEEP", "1")
+        assert al.alignment_depth(g) == _oracle(oracle_bin, "depth", img, tmp_path, name), name
+        if leaf:
+            assert al.alignment_depth(g, no_ancestors=True) == _oracle(oracle_bin, "depth", img, tmp_path, name, "--noAncestors"), name
