@@ -1002,31 +1002,46 @@ def sweep_design_bytes(al, ref):
     """What halAlignmentDepth's two tree sweeps (hgx_columns.hip: sweepTracks) must move for a scan of genome `ref` with every genome
     in scope: bottom-up, every genome with children writes its per-base genome-set track once and reads its children's (a child
     without children of its own carries a constant: no track), with one bottom-segment record and child link per segment and child
-    and one top-segment record per child segment; top-down along the path root -> ref, a genome reads its parent's and its own
-    track (or depth) and writes its 4-byte depth per base; the result is read and written once."""
+    and one top-segment record per child segment; a genome's set holds the genomes of its own subtree, in a word just wide enough
+    for them.  Top-down along the path root -> ref, a genome reads its parent's depth (the root's: its track) and writes its
+    depth per base (a byte: at most 64 genomes are counted per group); the result is read and written once (int32)."""
     n = al.num_genomes
-    word = 1 if n <= 8 else 2 if n <= 16 else 4 if n <= 32 else 8
+    size = [0] * n
+
+    def subtree(g):
+        size[g] = 1 + sum(subtree(c) for c in al.genome_children(g))
+        return size[g]
+    roots = [g for g in range(n) if al.genome_parent(g) < 0]
+    for r in roots:
+        subtree(r)
+    if n > 64:  # (groups of 64 genomes: one numbering, 8-byte words, a pass per group)
+        word = [8.0] * n
+        passes = (n + 63) // 64
+    else:
+        word = [1.0 if size[g] <= 8 else 2.0 if size[g] <= 16 else 4.0 if size[g] <= 32 else 8.0 for g in range(n)]
+        passes = 1
     has_track = [len(al.genome_children(g)) > 0 for g in range(n)]
     total = 0.0
     for g in range(n):
         kids = al.genome_children(g)
         if not kids:
             continue
-        total += word * al.genome_length(g)  # its own track
+        total += word[g] * al.genome_length(g)  # its own track
         total += al.num_bottom_segments(g) * (8.0 + 4.0 * len(kids))  # BotRec + child links
         for c in kids:
             total += 16.0 * al.num_top_segments(c)  # the child's TopRec
             if has_track[c]:
-                total += word * al.genome_length(c)
+                total += word[c] * al.genome_length(c)
     path = [ref]
     while al.genome_parent(path[-1]) >= 0:
         path.append(al.genome_parent(path[-1]))
     for c in path[:-1]:  # (every genome on the path below the root)
         p = al.genome_parent(c)
         total += 16.0 * al.num_top_segments(c) + 8.0 * al.num_top_segments(c)  # TopRec + the parent's BotRec behind it
-        total += (word if has_track[c] else 0) * al.genome_length(c) + 4.0 * al.genome_length(c)  # own track, depth written
-        total += (4.0 if al.genome_parent(p) >= 0 else word) * al.genome_length(c)  # the parent's depth (the root's: its track)
-    total += 8.0 * al.genome_length(ref)  # depth read, result written
+        total += 1.0 * al.genome_length(c)  # depth written (a byte)
+        total += (1.0 if al.genome_parent(p) >= 0 else word[p]) * al.genome_length(c)  # the parent's depth (the root's: its track)
+    total *= passes
+    total += 5.0 * al.genome_length(ref)  # depth read (a byte), result written (int32)
     return total
 
 

@@ -608,11 +608,18 @@ static __global__ void __launch_bounds__(256) k_fill_long_runs(const LongRun *__
 template <typename M, bool SUM> __device__ __forceinline__ M track_join(M a, M b) {
     return SUM ? (M)(a + b) : (M)(a | b);
 }
+// A genome's set holds only the genomes of its own subtree, numbered from the subtree's first counted genome (post-order: a
+// subtree's genomes are consecutive), in a word just wide enough for them — most genomes of a large tree have a handful of
+// descendants, and the sweeps are bound by the tracks' bytes (the 50-genome alignment: 8 bytes a base for every genome moved
+// 69 GB, most of it for sets with three members).  A parent reads a child's word, of the child's width, and moves it up by the
+// child's place in its own numbering (shift).
 struct SweepChild {
     const int32_t *enc; // the parent's child link array for this slot
     const void *top;    // the child's TopRec table
     const void *track;  // the child's S, or null: the same value on every base (a genome without in-scope children)
-    long long constant; // that value
+    long long constant; // that value, in the parent's numbering
+    int wlog;           // log2 of the bytes of a word of the child's track
+    int shift;          // the child's first genome in the parent's numbering (0 for sums)
 };
 static constexpr int SWEEP_MAX_CHILDREN = 8;
 struct SweepChildren {
@@ -624,9 +631,15 @@ struct SweepChildren {
 // word (a child in the other orientation: the word at the mirrored place, its elements taken back to front).  The tracks start
 // where their segments start: the words are not aligned (global accesses need not be); the last word of a segment goes
 // element by element.
+#ifndef HGX_SWEEP_LPS_LOG
+#define HGX_SWEEP_LPS_LOG(V) ((V) >= 8 ? 3 : 4)
+#endif
 template <typename M> struct SweepVec {
     static constexpr int N = sizeof(M) >= 8 ? 2 : 8 / (int)sizeof(M);
     M e[N];
+};
+template <typename T, int N> struct SweepElems {
+    T e[N];
 };
 template <typename T> __device__ __forceinline__ T sweep_load(const void *p) {
     T v;
@@ -636,16 +649,49 @@ template <typename T> __device__ __forceinline__ T sweep_load(const void *p) {
 template <typename T> __device__ __forceinline__ void sweep_store(void *p, const T &v) {
     __builtin_memcpy(p, &v, sizeof(T));
 }
+// the bases o .. o + V - 1 of a parent segment of `len` bases under child segment `tr`, from the child's track T (words of MC)
+template <typename C, typename M, typename MC, bool SUM>
+__device__ __forceinline__ void sweep_join_child(SweepVec<M> &v, const MC *__restrict__ T, const TopRec<C> &tr, int64_t len, int64_t o, bool whole,
+                                                 int shift) {
+    constexpr int V = SweepVec<M>::N;
+    const MC *base = T + (int64_t)tr.start;
+    const bool rev = (tr.parentEnc & 1) != 0;
+    if (whole) {
+        const SweepElems<MC, V> x = sweep_load<SweepElems<MC, V>>(base + (rev ? len - o - V : o));
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const MC c = x.e[rev ? V - 1 - j : j];
+            v.e[j] = track_join<M, SUM>(v.e[j], SUM ? (M)c : (M)((unsigned long long)c << shift));
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < V; ++j)
+            if (o + j < len) {
+                const MC c = base[rev ? len - 1 - o - j : o + j];
+                v.e[j] = track_join<M, SUM>(v.e[j], SUM ? (M)c : (M)((unsigned long long)c << shift));
+            }
+    }
+}
 template <typename C, typename M, bool SUM>
 static __global__ void __launch_bounds__(256) k_sweep_up(const BotRec<C> *__restrict__ bot, int64_t numBot, SweepChildren ch, M own, int accumulate,
                                                          M *__restrict__ S) {
     constexpr int V = SweepVec<M>::N;
-    const int sub = (int)(threadIdx.x & 15);
-    const int64_t groupsTotal = ((int64_t)gridDim.x * blockDim.x) >> 4;
-    for (int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; b < numBot; b += groupsTotal) {
+    // (lanes per segment: a round of them covers 64 bases or more — eight lanes with byte-wide sets, so that eight segments'
+    // chains of dependent loads are in flight per wavefront)
+    constexpr int LPS_LOG = HGX_SWEEP_LPS_LOG(V);
+    constexpr int LPS = 1 << LPS_LOG;
+    const int sub = (int)(threadIdx.x & (LPS - 1));
+    const int64_t groupsTotal = ((int64_t)gridDim.x * blockDim.x) >> LPS_LOG;
+    for (int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> LPS_LOG; b < numBot; b += groupsTotal) {
         const int64_t start = (int64_t)bot[b].start, len = (int64_t)bot[b + 1].start - start;
-        for (int64_t o0 = 0; o0 < len; o0 += 16 * V) {
-            const int64_t o = o0 + (int64_t)sub * V; // this lane's bases: o .. o + V - 1
+        for (int64_t o0 = 0; o0 < len; o0 += LPS * V) {
+            int64_t o = o0 + (int64_t)sub * V; // this lane's bases: o .. o + V - 1
+            if (o >= len)
+                continue;
+            // (the lane at the segment's end takes the segment's last V bases — some of them its neighbour's as well, which come out
+            // the same: element by element it was the one lane the other fifteen waited for)
+            if (o + V > len && len >= V)
+                o = len - V;
             const bool whole = o + V <= len;
             SweepVec<M> v;
             if (accumulate && whole) { // (more than SWEEP_MAX_CHILDREN children: several launches)
@@ -660,7 +706,7 @@ static __global__ void __launch_bounds__(256) k_sweep_up(const BotRec<C> *__rest
                 if (enc < 0)
                     continue;
                 const TopRec<C> *top = (const TopRec<C> *)ch.c[k].top;
-                const M *T = (const M *)ch.c[k].track;
+                const void *T = ch.c[k].track;
                 if (!T && !SUM) { // a child without tracks of its own: every base below carries the same set
                     const M cst = (M)ch.c[k].constant;
 #pragma unroll
@@ -673,24 +719,20 @@ static __global__ void __launch_bounds__(256) k_sweep_up(const BotRec<C> *__rest
                 do { // the slot's segment and its paralogy ring (updateChild + updateNextTopDup, :607-681)
                     const TopRec<C> tr = top[t];
                     if (T) {
-                        const M *base = T + (int64_t)tr.start;
-                        if (whole) {
-                            if (tr.parentEnc & 1) {
-                                const SweepVec<M> x = sweep_load<SweepVec<M>>(base + (len - o - V));
-#pragma unroll
-                                for (int j = 0; j < V; ++j)
-                                    v.e[j] = track_join<M, SUM>(v.e[j], x.e[V - 1 - j]);
-                            } else {
-                                const SweepVec<M> x = sweep_load<SweepVec<M>>(base + o);
-#pragma unroll
-                                for (int j = 0; j < V; ++j)
-                                    v.e[j] = track_join<M, SUM>(v.e[j], x.e[j]);
-                            }
-                        } else {
-#pragma unroll
-                            for (int j = 0; j < V; ++j)
-                                if (o + j < len)
-                                    v.e[j] = track_join<M, SUM>(v.e[j], base[(tr.parentEnc & 1) ? len - 1 - o - j : o + j]);
+                        const int shift = ch.c[k].shift;
+                        switch (ch.c[k].wlog) {
+                        case 0:
+                            sweep_join_child<C, M, uint8_t, SUM>(v, (const uint8_t *)T, tr, len, o, whole, shift);
+                            break;
+                        case 1:
+                            sweep_join_child<C, M, uint16_t, SUM>(v, (const uint16_t *)T, tr, len, o, whole, shift);
+                            break;
+                        case 2:
+                            sweep_join_child<C, M, uint32_t, SUM>(v, (const uint32_t *)T, tr, len, o, whole, shift);
+                            break;
+                        default:
+                            sweep_join_child<C, M, unsigned long long, SUM>(v, (const unsigned long long *)T, tr, len, o, whole, shift);
+                            break;
                         }
                     } else { // (sums: one per ring member)
 #pragma unroll
@@ -714,15 +756,32 @@ static __global__ void __launch_bounds__(256) k_sweep_up(const BotRec<C> *__rest
 template <typename M, bool SUM> __device__ __forceinline__ int32_t track_size(M v) {
     return SUM ? (int32_t)v : (int32_t)__popcll((unsigned long long)v);
 }
-// pS: the parent is the top of the scope — its A is the size of its own S (no separate pass); S null: the genome's own
-// track is the constant `own` (a genome without in-scope children)
-template <typename C, typename M, bool SUM>
+// size of the set at base i of a track whose words have 1 << wlog bytes
+template <bool SUM> __device__ __forceinline__ int32_t track_size_at(const void *S, int64_t i, int wlog) {
+    if (SUM)
+        return ((const int32_t *)S)[i];
+    switch (wlog) {
+    case 0:
+        return (int32_t)__popc((unsigned)((const uint8_t *)S)[i]);
+    case 1:
+        return (int32_t)__popc((unsigned)((const uint16_t *)S)[i]);
+    case 2:
+        return (int32_t)__popc(((const uint32_t *)S)[i]);
+    default:
+        return (int32_t)__popcll(((const unsigned long long *)S)[i]);
+    }
+}
+// pS: the parent is the top of the scope — its A is the size of its own S (words of M; no separate pass); S (words of
+// 1 << sLog bytes): the genome's own track, read where a segment has no parent — null: the constant ownSize (a genome without
+// in-scope children).  AT: the type of a depth along the path — a byte when genome sets are counted (at most 64 genomes a
+// group), which is a quarter of what the top-down sweep moves with 32-bit depths.
+template <typename C, typename M, bool SUM, typename AT>
 static __global__ void __launch_bounds__(256) k_sweep_down(const TopRec<C> *__restrict__ top, int64_t numTop, const BotRec<C> *__restrict__ pbot,
-                                                           const int32_t *__restrict__ pA, const M *__restrict__ pS, const M *__restrict__ S, M own,
-                                                           int32_t *__restrict__ A) {
-    constexpr int V = 4; // bases per lane and round: a 16-byte word of A
+                                                           const AT *__restrict__ pA, const M *__restrict__ pS, const void *__restrict__ S, int sLog,
+                                                           int32_t ownSize, AT *__restrict__ A) {
+    constexpr int V = sizeof(AT) == 1 ? 8 : 4; // bases per lane and round: an 8- or 16-byte word of A
     struct AVec {
-        int32_t e[V];
+        AT e[V];
     };
     struct MVec {
         M e[V];
@@ -734,53 +793,45 @@ static __global__ void __launch_bounds__(256) k_sweep_down(const TopRec<C> *__re
         const int64_t start = (int64_t)tr.start, len = (int64_t)top[t + 1].start - start;
         const bool hasParent = tr.parentEnc >= 0, rev = (tr.parentEnc & 1) != 0;
         const int64_t pstart = hasParent ? (int64_t)pbot[tr.parentEnc >> 1].start : 0;
-        for (int64_t o = (int64_t)sub * V; o < len; o += 16 * V) {
+        for (int64_t o_ = (int64_t)sub * V; o_ < len; o_ += 16 * V) {
+            const int64_t o = o_ + V > len && len >= V ? len - V : o_; // (the last lane: the segment's last V bases, as in k_sweep_up)
             AVec a;
-            if (o + V <= len) {
-                if (hasParent) {
-                    const int64_t pp = pstart + (rev ? len - o - V : o); // the V parent bases, in the parent's order
-                    if (pS) {
-                        const MVec x = sweep_load<MVec>(pS + pp);
-#pragma unroll
-                        for (int j = 0; j < V; ++j)
-                            a.e[j] = track_size<M, SUM>(x.e[rev ? V - 1 - j : j]);
-                    } else {
-                        const AVec x = sweep_load<AVec>(pA + pp);
-#pragma unroll
-                        for (int j = 0; j < V; ++j)
-                            a.e[j] = x.e[rev ? V - 1 - j : j];
-                    }
-                } else if (S) {
-                    const MVec x = sweep_load<MVec>(S + start + o);
+            if (o + V <= len && hasParent) {
+                const int64_t pp = pstart + (rev ? len - o - V : o); // the V parent bases, in the parent's order
+                if (pS) {
+                    const MVec x = sweep_load<MVec>(pS + pp);
 #pragma unroll
                     for (int j = 0; j < V; ++j)
-                        a.e[j] = track_size<M, SUM>(x.e[j]);
+                        a.e[j] = (AT)track_size<M, SUM>(x.e[rev ? V - 1 - j : j]);
                 } else {
+                    const AVec x = sweep_load<AVec>(pA + pp);
 #pragma unroll
                     for (int j = 0; j < V; ++j)
-                        a.e[j] = track_size<M, SUM>(own);
+                        a.e[j] = x.e[rev ? V - 1 - j : j];
                 }
                 sweep_store(A + start + o, a);
-            } else {
+            } else { // (the end of a segment, or a segment without a parent — an insertion: its own set's size)
                 for (int j = 0; j < V && o + j < len; ++j) {
                     const int64_t pp = pstart + (rev ? len - 1 - o - j : o + j);
-                    A[start + o + j] = hasParent ? (pS ? track_size<M, SUM>(pS[pp]) : pA[pp]) : track_size<M, SUM>(S ? S[start + o + j] : own);
+                    A[start + o + j] = hasParent ? (pS ? (AT)track_size<M, SUM>(pS[pp]) : pA[pp])
+                                                 : (AT)(S ? track_size_at<SUM>(S, start + o + j, sLog) : ownSize);
                 }
             }
         }
     }
 }
-template <typename M, bool SUM>
-static __global__ void __launch_bounds__(256) k_sweep_top(const M *__restrict__ S, int64_t n, M own, int32_t *__restrict__ A) {
+template <typename M, bool SUM, typename AT>
+static __global__ void __launch_bounds__(256) k_sweep_top(const M *__restrict__ S, int64_t n, M own, AT *__restrict__ A) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        A[i] = track_size<M, SUM>(S ? S[i] : own);
+        A[i] = (AT)track_size<M, SUM>(S ? S[i] : own);
 }
 // accumulate: more than 64 counted genomes go through the sweeps in groups of 64 (a group's genome sets are 64-bit words); the
 // depth of a column is the sum of the groups' set sizes at the column's topmost ancestor
-static __global__ void __launch_bounds__(256) k_sweep_out(const int32_t *__restrict__ A, int64_t first, int64_t count, int64_t step, int32_t sub,
+template <typename AT>
+static __global__ void __launch_bounds__(256) k_sweep_out(const AT *__restrict__ A, int64_t first, int64_t count, int64_t step, int32_t sub,
                                                           int32_t *__restrict__ out, int accumulate) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
-        out[i] = (accumulate ? out[i] : 0) + A[first + i * step] - sub;
+        out[i] = (accumulate ? out[i] : 0) + (int32_t)A[first + i * step] - sub;
 }
 
 } // namespace hgx

@@ -144,9 +144,15 @@ static void refSegmentRange(hgx_alignment *h, int ref, int64_t firstPos, int64_t
 // requests that span a million columns or more (the sweeps always cover whole genomes) when at most 64 genomes count and
 // the tracks fit the device; otherwise (return false) the column walk runs.  HGX_DEPTH_SWEEP=0 forbids it, =1 lifts the
 // size threshold.  mode 0: genomes - 1, 1: bases - 1 (--countDupes), 2: bases.
-template <typename C, typename M, bool SUM>
+// what the sweeps need to know of a genome's track: the bytes of a word (1 << wlog), its first genome in the numbering of the
+// counted genomes (lo: a track's bit b is genome lo + b), its own bit (or 1 for sums; 0: not counted)
+struct SweepTrack {
+    int wlog = 0, lo = 0;
+    long long own = 0;
+};
+template <typename C, bool SUM, typename AT>
 static void sweepTracks(hgx_alignment *h, const std::vector<int> &postOrder, const std::vector<int> &path, const std::vector<char> &inScope,
-                        const std::vector<long long> &ownValue, const std::vector<char> &hasTrack, std::vector<Buf> &S, std::vector<Buf> &A,
+                        const std::vector<SweepTrack> &track, const std::vector<char> &hasTrack, std::vector<Buf> &S, std::vector<Buf> &A,
                         hipStream_t s) {
     const Image &img = h->img;
     const DeviceImage &D = *h->dev;
@@ -156,34 +162,78 @@ static void sweepTracks(hgx_alignment *h, const std::vector<int> &postOrder, con
         const DeviceGenome &dg = D.genomes[(size_t)g];
         if (G.totalLength <= 0 || !hasTrack[(size_t)g])
             continue; // (a genome without in-scope children has the same value on every base: no track)
+        const SweepTrack &tg = track[(size_t)g];
         std::vector<SweepChild> kids;
         for (size_t k = 0; k < G.children.size(); ++k) {
             const int c = G.children[k];
             if (!inScope[(size_t)c] || img.genomes[(size_t)c].totalLength <= 0 || img.genomes[(size_t)c].numTop <= 0)
                 continue;
-            kids.push_back(SweepChild{dg.childEnc[k], D.genomes[(size_t)c].top, hasTrack[(size_t)c] ? S[(size_t)c].p : nullptr, ownValue[(size_t)c]});
+            const SweepTrack &tc = track[(size_t)c];
+            const int shift = SUM ? 0 : tc.lo - tg.lo;
+            kids.push_back(SweepChild{dg.childEnc[k], D.genomes[(size_t)c].top, hasTrack[(size_t)c] ? S[(size_t)c].p : nullptr,
+                                      SUM ? tc.own : (long long)((unsigned long long)tc.own << shift), tc.wlog, shift});
         }
-        const M own = (M)ownValue[(size_t)g];
         for (size_t at = 0; at < kids.size(); at += SWEEP_MAX_CHILDREN) {
             SweepChildren ch;
             ch.n = (int)std::min<size_t>(SWEEP_MAX_CHILDREN, kids.size() - at);
             for (int k = 0; k < ch.n; ++k)
                 ch.c[k] = kids[at + (size_t)k];
-            hipLaunchKernelGGL((k_sweep_up<C, M, SUM>), dim3(GRID), dim3(256), 0, s, (const BotRec<C> *)dg.bot, (int64_t)G.numBot, ch, own, at ? 1 : 0,
-                               (M *)S[(size_t)g].p);
+#define HGX_UP(M)                                                                                                                            \
+    hipLaunchKernelGGL((k_sweep_up<C, M, SUM>), dim3(GRID), dim3(256), 0, s, (const BotRec<C> *)dg.bot, (int64_t)G.numBot, ch, (M)tg.own,     \
+                       at ? 1 : 0, (M *)S[(size_t)g].p)
+            if (SUM)
+                HGX_UP(int32_t);
+            else if (tg.wlog == 0)
+                HGX_UP(uint8_t);
+            else if (tg.wlog == 1)
+                HGX_UP(uint16_t);
+            else if (tg.wlog == 2)
+                HGX_UP(uint32_t);
+            else
+                HGX_UP(unsigned long long);
+#undef HGX_UP
         }
     }
     // top-down along the path from the top of the scope to the reference (the top's own A is the size of its S: read from S)
+    auto sizeOfOwn = [&](int g) { return SUM ? (int32_t)track[(size_t)g].own : (int32_t)__builtin_popcountll((unsigned long long)track[(size_t)g].own); };
     const int top = path[0];
-    if (path.size() == 1)
-        hipLaunchKernelGGL((k_sweep_top<M, SUM>), dim3(GRID), dim3(256), 0, s, hasTrack[(size_t)top] ? (const M *)S[(size_t)top].p : (const M *)nullptr,
-                           (int64_t)img.genomes[(size_t)top].totalLength, (M)ownValue[(size_t)top], (int32_t *)A[(size_t)top].p);
+    if (path.size() == 1) {
+        const void *St = hasTrack[(size_t)top] ? S[(size_t)top].p : nullptr;
+        const int64_t n = (int64_t)img.genomes[(size_t)top].totalLength;
+        const SweepTrack &tt = track[(size_t)top];
+#define HGX_TOP(M) hipLaunchKernelGGL((k_sweep_top<M, SUM, AT>), dim3(GRID), dim3(256), 0, s, (const M *)St, n, (M)tt.own, (AT *)A[(size_t)top].p)
+        if (SUM)
+            HGX_TOP(int32_t);
+        else if (tt.wlog == 0)
+            HGX_TOP(uint8_t);
+        else if (tt.wlog == 1)
+            HGX_TOP(uint16_t);
+        else if (tt.wlog == 2)
+            HGX_TOP(uint32_t);
+        else
+            HGX_TOP(unsigned long long);
+#undef HGX_TOP
+    }
     for (size_t i = 1; i < path.size(); ++i) {
         const int c = path[i], p = path[i - 1];
-        hipLaunchKernelGGL((k_sweep_down<C, M, SUM>), dim3(GRID), dim3(256), 0, s, (const TopRec<C> *)D.genomes[(size_t)c].top,
-                           (int64_t)img.genomes[(size_t)c].numTop, (const BotRec<C> *)D.genomes[(size_t)p].bot,
-                           i == 1 ? (const int32_t *)nullptr : (const int32_t *)A[(size_t)p].p, i == 1 ? (const M *)S[(size_t)p].p : (const M *)nullptr,
-                           hasTrack[(size_t)c] ? (const M *)S[(size_t)c].p : (const M *)nullptr, (M)ownValue[(size_t)c], (int32_t *)A[(size_t)c].p);
+        const void *Sc = hasTrack[(size_t)c] ? S[(size_t)c].p : nullptr;
+#define HGX_DOWN(M)                                                                                                                          \
+    hipLaunchKernelGGL((k_sweep_down<C, M, SUM, AT>), dim3(GRID), dim3(256), 0, s, (const TopRec<C> *)D.genomes[(size_t)c].top,               \
+                       (int64_t)img.genomes[(size_t)c].numTop, (const BotRec<C> *)D.genomes[(size_t)p].bot,                                   \
+                       i == 1 ? (const AT *)nullptr : (const AT *)A[(size_t)p].p, i == 1 ? (const M *)S[(size_t)p].p : (const M *)nullptr, Sc,  \
+                       track[(size_t)c].wlog, sizeOfOwn(c), (AT *)A[(size_t)c].p)
+        const int pl = track[(size_t)p].wlog;
+        if (SUM)
+            HGX_DOWN(int32_t);
+        else if (i > 1 || pl == 0) // (the parent's track is read by the first step only)
+            HGX_DOWN(uint8_t);
+        else if (pl == 1)
+            HGX_DOWN(uint16_t);
+        else if (pl == 2)
+            HGX_DOWN(uint32_t);
+        else
+            HGX_DOWN(unsigned long long);
+#undef HGX_DOWN
     }
 }
 
@@ -243,21 +293,52 @@ static bool columnsDepthSweep(hgx_alignment *h, int ref, int64_t first, int64_t 
     std::reverse(path.begin(), path.end());
     const bool sum = mode != 0;
     int bits = 0;
-    std::vector<long long> own((size_t)ng, 0);
-    std::vector<int> bitOf((size_t)ng, -1); // a counted genome's number among the counted ones
-    for (int g : postOrder)
+    std::vector<int> bitOf((size_t)ng, -1); // a counted genome's number among the counted ones: post-order, so a subtree's are consecutive
+    std::vector<int> firstBit((size_t)ng, 0), below((size_t)ng, 0); // a subtree's first number, and how many it holds
+    for (int g : postOrder) {
+        int f = bits, n = 0;
+        bool any = false;
+        for (int c : img.genomes[(size_t)g].children)
+            if (inScope[(size_t)c]) {
+                if (!any || firstBit[(size_t)c] < f)
+                    f = firstBit[(size_t)c];
+                any = true;
+                n += below[(size_t)c];
+            }
         if (counted[(size_t)g]) {
-            own[(size_t)g] = sum ? 1ll : (long long)(1ull << (bits & 63));
-            bitOf[(size_t)g] = bits;
-            ++bits;
+            bitOf[(size_t)g] = bits++;
+            ++n;
         }
+        firstBit[(size_t)g] = any ? f : (counted[(size_t)g] ? bitOf[(size_t)g] : bits);
+        below[(size_t)g] = n;
+    }
     // more than 64 counted genomes (cactus alignments have hundreds): the sweeps run once per group of 64 — the size of a
     // column's genome set is the sum of the sizes of its parts — and the groups' depths are added up on the way out
     const int groups = sum ? 1 : std::max(1, (bits + 63) / 64);
     if (getenv("HGX_SWEEP_GROUPS_MAX") && groups > atoi(getenv("HGX_SWEEP_GROUPS_MAX")))
         return false;
-    // (a genome set per base is as wide as the counted genomes need: the sweeps are bound by the tracks' bytes)
-    const size_t word = sum ? 4 : bits <= 8 ? 1 : bits <= 16 ? 2 : bits <= 32 ? 4 : 8;
+    // A genome's set holds the genomes of its subtree only, in a word just wide enough (HGX_SWEEP_LOCAL=0, and alignments that
+    // go in groups: one numbering and one width for all)
+    const bool local = !sum && groups == 1 && !(getenv("HGX_SWEEP_LOCAL") && getenv("HGX_SWEEP_LOCAL")[0] == '0');
+    const int globalLog = sum ? 2 : bits <= 8 ? 0 : bits <= 16 ? 1 : bits <= 32 ? 2 : 3;
+    std::vector<SweepTrack> track((size_t)ng);
+    auto setTracks = [&](int group) {
+        for (int g = 0; g < ng; ++g) {
+            SweepTrack &t = track[(size_t)g];
+            const int b = bitOf[(size_t)g];
+            if (sum) {
+                t = SweepTrack{2, 0, b >= 0 ? 1ll : 0ll};
+            } else if (local) {
+                const int n = below[(size_t)g];
+                t.wlog = n <= 8 ? 0 : n <= 16 ? 1 : n <= 32 ? 2 : 3;
+                t.lo = firstBit[(size_t)g];
+                t.own = b >= 0 ? (long long)(1ull << (b - t.lo)) : 0ll;
+            } else {
+                t = SweepTrack{globalLog, 0, b >= 0 && b / 64 == group ? (long long)(1ull << (b & 63)) : 0ll};
+            }
+        }
+    };
+    setTracks(0);
     // a genome has a track of its own when something in scope hangs under it
     std::vector<char> hasTrack((size_t)ng, 0);
     for (int g : postOrder) {
@@ -271,9 +352,11 @@ static bool columnsDepthSweep(hgx_alignment *h, int ref, int64_t first, int64_t 
     size_t need = 0;
     for (int g : postOrder)
         if (hasTrack[(size_t)g])
-            need += (size_t)img.genomes[(size_t)g].totalLength * word;
+            need += (size_t)img.genomes[(size_t)g].totalLength << track[(size_t)g].wlog;
+    // (a depth along the path is a byte when genome sets are counted: at most 64 of them a group)
+    const size_t depthBytes = sum ? 4 : 1;
     for (size_t i = path.size() == 1 ? 0 : 1; i < path.size(); ++i)
-        need += (size_t)img.genomes[(size_t)path[i]].totalLength * 4;
+        need += (size_t)img.genomes[(size_t)path[i]].totalLength * depthBytes;
     size_t freeB = 0, totalB = 0;
     HIP_OK(hipMemGetInfo(&freeB, &totalB));
     if (need + (1ull << 30) > freeB)
@@ -281,34 +364,31 @@ static bool columnsDepthSweep(hgx_alignment *h, int ref, int64_t first, int64_t 
     std::vector<Buf> S((size_t)ng), A((size_t)ng);
     for (int g : postOrder)
         if (hasTrack[(size_t)g])
-            S[(size_t)g].resize((size_t)img.genomes[(size_t)g].totalLength * word);
+            S[(size_t)g].resize((size_t)img.genomes[(size_t)g].totalLength << track[(size_t)g].wlog);
     for (size_t i = path.size() == 1 ? 0 : 1; i < path.size(); ++i)
-        A[(size_t)path[i]].resize((size_t)img.genomes[(size_t)path[i]].totalLength * 4);
+        A[(size_t)path[i]].resize((size_t)img.genomes[(size_t)path[i]].totalLength * depthBytes);
     Ev a, b;
     HIP_OK(hipEventRecord(a.e, s));
     for (int group = 0; group < groups; ++group) {
-    if (groups > 1) // this group's genomes carry their bit, the others none
-        for (int g = 0; g < ng; ++g)
-            own[(size_t)g] = bitOf[(size_t)g] >= 0 && bitOf[(size_t)g] / 64 == group ? (long long)(1ull << (bitOf[(size_t)g] & 63)) : 0ll;
-#define HGX_SWEEP(C)                                                                                                                         \
-    if (sum)                                                                                                                                 \
-        sweepTracks<C, int32_t, true>(h, postOrder, path, inScope, own, hasTrack, S, A, s);                                                  \
-    else if (word == 1)                                                                                                                      \
-        sweepTracks<C, uint8_t, false>(h, postOrder, path, inScope, own, hasTrack, S, A, s);                                                 \
-    else if (word == 2)                                                                                                                      \
-        sweepTracks<C, uint16_t, false>(h, postOrder, path, inScope, own, hasTrack, S, A, s);                                                \
-    else if (word == 4)                                                                                                                      \
-        sweepTracks<C, uint32_t, false>(h, postOrder, path, inScope, own, hasTrack, S, A, s);                                                \
-    else                                                                                                                                     \
-        sweepTracks<C, unsigned long long, false>(h, postOrder, path, inScope, own, hasTrack, S, A, s)
+    if (group > 0) // this group's genomes carry their bit, the others none
+        setTracks(group);
     if (h->dev->wide) {
-        HGX_SWEEP(int64_t);
+        if (sum)
+            sweepTracks<int64_t, true, int32_t>(h, postOrder, path, inScope, track, hasTrack, S, A, s);
+        else
+            sweepTracks<int64_t, false, uint8_t>(h, postOrder, path, inScope, track, hasTrack, S, A, s);
     } else {
-        HGX_SWEEP(int32_t);
+        if (sum)
+            sweepTracks<int32_t, true, int32_t>(h, postOrder, path, inScope, track, hasTrack, S, A, s);
+        else
+            sweepTracks<int32_t, false, uint8_t>(h, postOrder, path, inScope, track, hasTrack, S, A, s);
     }
-#undef HGX_SWEEP
-    hipLaunchKernelGGL(k_sweep_out, dim3(2048), dim3(256), 0, s, (const int32_t *)A[(size_t)ref].p, first, count, step,
-                       mode == 2 || group > 0 ? 0 : 1, d_out, group > 0 ? 1 : 0);
+    if (sum)
+        hipLaunchKernelGGL(k_sweep_out<int32_t>, dim3(2048), dim3(256), 0, s, (const int32_t *)A[(size_t)ref].p, first, count, step,
+                           mode == 2 || group > 0 ? 0 : 1, d_out, group > 0 ? 1 : 0);
+    else
+        hipLaunchKernelGGL(k_sweep_out<uint8_t>, dim3(2048), dim3(256), 0, s, (const uint8_t *)A[(size_t)ref].p, first, count, step,
+                           mode == 2 || group > 0 ? 0 : 1, d_out, group > 0 ? 1 : 0);
     }
     HIP_OK(hipEventRecord(b.e, s));
     HIP_OK(hipStreamSynchronize(s));
