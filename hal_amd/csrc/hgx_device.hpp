@@ -243,6 +243,9 @@ struct hgx_alignment {
         size_t maxQueries = 0;
         hgx_liftover_plan *plan = nullptr;
     } cachedPlan;
+    // halGetBlocksInTargetRange maps a range forward and the stretches next to its members back: two plans that a browser's
+    // calls alternate between, kept like the one above (creating a plan is a millisecond, a call's device work a tenth of it)
+    CachedPlan vizPlans[2];
     std::mutex planMutex;
     // pinned host staging of the text path (Liftover::convert): genome coordinates and strands of a batch on the way in, its
     // records on the way out, and the device copy of the former; grown on demand, freed with the alignment

@@ -2253,6 +2253,9 @@ static void runHostArrays(hgx_liftover_plan *P, const std::vector<int64_t> &gs, 
 hgx_alignment::~hgx_alignment() {
     if (cachedPlan.plan)
         hgx::destroyLiftoverPlan(cachedPlan.plan);
+    for (CachedPlan &c : vizPlans)
+        if (c.plan)
+            hgx::destroyLiftoverPlan(c.plan);
     if (stage.gs)
         (void)hipHostFree(stage.gs);
     if (stage.ge)
@@ -2301,8 +2304,8 @@ static void intervalsToGenomeCoordinates(const GenomeTables &G, size_t n, const 
 
 // the alignment's cached plan for (src, tgt, opts), recreated when the key changes or the batch outgrows it; the
 // caller holds h->planMutex while it uses the plan
-static hgx_liftover_plan *cachedPlanFor(hgx_alignment *h, int src, int tgt, const hgx_liftover_opts &opts, size_t n) {
-    hgx_alignment::CachedPlan &c = h->cachedPlan;
+static hgx_liftover_plan *cachedPlanFor(hgx_alignment *h, int src, int tgt, const hgx_liftover_opts &opts, size_t n, int vizSlot = -1) {
+    hgx_alignment::CachedPlan &c = vizSlot < 0 ? h->cachedPlan : h->vizPlans[vizSlot];
     const bool same = c.plan && c.src == src && c.tgt == tgt && memcmp(&c.opts, &opts, sizeof opts) == 0 && n <= c.maxQueries;
     if (!same) {
         if (c.plan)
@@ -2419,8 +2422,11 @@ void liftoverBatchAbsolute(hgx_alignment *h, int src, int tgt, const std::vector
     out.clear();
     if (gs.empty())
         return;
-    std::unique_ptr<hgx_liftover_plan, void (*)(hgx_liftover_plan *)> P(createLiftoverPlan(h, src, tgt, opts, gs.size()), destroyLiftoverPlan);
-    runHostArrays(P.get(), gs, ge, strand, out);
+    // (the two plans of halGetBlocksInTargetRange — emit_blocks 1: the range forward, 2: the neighbours back — are kept with the
+    // alignment; the calls are serialised as the reference's are, blockViz/impl/halBlockViz.cpp: halLock)
+    std::lock_guard<std::mutex> lock(h->planMutex);
+    hgx_liftover_plan *P = cachedPlanFor(h, src, tgt, opts, std::max<size_t>(gs.size(), 64), opts.emit_blocks == 2 ? 1 : 0);
+    runHostArrays(P, gs, ge, strand, out);
 }
 
 void blockMapHost(hgx_alignment *h, int ref, int query, int64_t absFirst, int64_t absLast, bool targetReversed,
