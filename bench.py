@@ -484,6 +484,37 @@ def main():
                             "rank (%s), overlapped with the next batches: bound by the links, not by the kernels; not part of `value`"
                             % ("hgx_liftover_exchange: RCCL from the library" if args.exchange == "c_abi" else "torch.distributed")}
 
+    # ---- the same steps with every rank's records gathered on rank 0 only, in the 8-byte form: what a writer of the BED file needs
+    # (a rank sends its blob once; nobody receives N of them) ----
+    to_writer = None
+    if synced and (world > 1 or args.exchange_selftest):
+        wx = shard.SlotExchange(world, rank, exchange.slot, dev, backend=args.exchange, comm=exchange.comm, root=0, bed_only=True)
+
+        def step_to_writer():
+            plan.run(d_gs, d_ge, d_st)
+            wx.wait()
+            wx.submit(plan, first_query=rank * nq)
+        for _ in range(3):
+            step_to_writer()
+        wx.drain()
+        dist.barrier()
+        sync()
+        t0w = time.perf_counter()
+        for _ in range(args.steps):
+            step_to_writer()
+        wx.drain()
+        sync()
+        dist.barrier()
+        tw = torch.tensor([time.perf_counter() - t0w], dtype=torch.float64, device=dev)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        to_writer = {"value": world * nq * args.steps / float(tw.item()), "unit": "intervals/s", "ms_per_step": 1e3 * float(tw.item()) / args.steps,
+                     "wire_format_bytes_per_record": wx.last_format, "wire_MB_per_rank_and_step": wx.last_bytes / 1e6,
+                     "what": "the same steps (one plan per rank) each followed by a gather of the ranks' records of the batch to rank 0 only "
+                             "(%s), 8 bytes a record (no source coordinates: what a writer of BED lines needs), overlapped with the next batches; "
+                             "not part of `value`" % ("hgx_liftover_gather: RCCL send / recv from the library" if args.exchange == "c_abi"
+                                                      else "torch.distributed.gather")}
+        del wx
+
     # ---- sustained: the same step for a couple of seconds (a region long enough for outside observers: rocm-smi, the driver) ----
     sustained = None
     if args.sustained_seconds > 0 and not exchanging:
@@ -781,6 +812,8 @@ def main():
             out["config4_as_stated"] = {"value": collated["value"], "unit": "intervals/s", "ms_per_step": collated["ms_per_step"],
                                         "what": "`collated`: every step's records gathered on every rank (RCCL all-gather of wire blobs); "
                                                 "`value` is the same steps without it"}
+        if to_writer:
+            out["collated_to_writer"] = to_writer
         out["timed_step"] = "map+allgather" if exchanging else "map_only"
         out["config"]["batches_in_flight"] = in_flight
         if col_result:

@@ -119,6 +119,7 @@ SYMBOLS = {
     "hgx_comm_create": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, P(VP), P(VP)]),
     "hgx_comm_destroy": (None, [VP]),
     "hgx_liftover_exchange": (C.c_int, [VP, VP, C.c_int64, VP, C.c_size_t, VP, P(C.c_size_t), P(VP)]),
+    "hgx_liftover_gather": (C.c_int, [VP, VP, C.c_int, C.c_int64, VP, C.c_size_t, C.c_int, VP, P(C.c_size_t), P(VP)]),
     "hgx_liftover_convert_multi": (C.c_int, [P(VP), C.c_int, C.c_int, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                              P(VP), P(C.c_size_t), P(VP)]),
     "hgx_liftover_kernel_times": (C.c_int, [VP, P(VP)]),

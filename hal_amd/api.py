@@ -628,12 +628,23 @@ class LiftoverPlan:
             raise HgxError(take_error(err))
         return nbytes.value
 
-    def wire_blob(self, first_query=0, dst=None):
+    def gather(self, comm, root, first_query, gathered, slot_bytes, bed_only=False):
+        """hgx_liftover_gather: this rank's records of the last run to rank `root` only (RCCL send / recv from the library, ordered
+        on the current stream).  gathered: comm.n_ranks * slot_bytes on the root, one slot on the others.  Returns this rank's bytes."""
+        import torch
+        err, nbytes = C.c_void_p(), C.c_size_t()
+        if lib.hgx_liftover_gather(self._p, comm._c, root, first_query, gathered.data_ptr(), slot_bytes, 1 if bed_only else 0,
+                                   torch.cuda.current_stream().cuda_stream, C.byref(nbytes), C.byref(err)) != 0:
+            raise HgxError(take_error(err))
+        return nbytes.value
+
+    def wire_blob(self, first_query=0, dst=None, bed_only=False):
         """The last run's records as one self-describing uint8 tensor for the multi-GPU exchange (hgx_liftover_wire_blob;
         hal_amd.shard.decode_blob reads it): (blob, format) with format 12 or 20 bytes per record.  dst: write into this uint8
-        device tensor (a slot of an exchange buffer) instead of a fresh one."""
+        device tensor (a slot of an exchange buffer) instead of a fresh one.  bed_only: the 8-byte form (no source coordinates: all a
+        writer of BED lines needs) when the batch fits it."""
         import torch
-        err, nbytes, fmt = C.c_void_p(), C.c_size_t(), C.c_int()
+        err, nbytes, fmt = C.c_void_p(), C.c_size_t(), C.c_int(8 if bed_only else 0)
         stream = torch.cuda.current_stream().cuda_stream
         t = dst if dst is not None else torch.empty(self.wire_capacity(), dtype=torch.uint8, device="cuda")
         if lib.hgx_liftover_wire_blob(self._p, t.data_ptr(), t.numel(), first_query, C.byref(nbytes), C.byref(fmt), stream, C.byref(err)) != 0:

@@ -23,6 +23,9 @@ typedef int (*GetUniqueIdFn)(UniqueId *);
 typedef int (*CommInitRankFn)(void **, int, UniqueId, int);
 typedef int (*AllGatherFn)(const void *, void *, size_t, int, void *, hipStream_t);
 typedef int (*CommDestroyFn)(void *);
+typedef int (*SendFn)(const void *, size_t, int, int, void *, hipStream_t);
+typedef int (*RecvFn)(void *, size_t, int, int, void *, hipStream_t);
+typedef int (*GroupFn)(void);
 typedef const char *(*GetErrorStringFn)(int);
 
 struct Rccl {
@@ -32,6 +35,9 @@ struct Rccl {
     AllGatherFn allGather = nullptr;
     CommDestroyFn commDestroy = nullptr;
     GetErrorStringFn getErrorString = nullptr;
+    SendFn send = nullptr;
+    RecvFn recv = nullptr;
+    GroupFn groupStart = nullptr, groupEnd = nullptr;
 };
 
 Rccl &rccl() {
@@ -57,6 +63,10 @@ Rccl &rccl() {
         r.allGather = (AllGatherFn)dlsym(r.lib, "ncclAllGather");
         r.commDestroy = (CommDestroyFn)dlsym(r.lib, "ncclCommDestroy");
         r.getErrorString = (GetErrorStringFn)dlsym(r.lib, "ncclGetErrorString");
+        r.send = (SendFn)dlsym(r.lib, "ncclSend"); // (hgx_liftover_gather; checked there)
+        r.recv = (RecvFn)dlsym(r.lib, "ncclRecv");
+        r.groupStart = (GroupFn)dlsym(r.lib, "ncclGroupStart");
+        r.groupEnd = (GroupFn)dlsym(r.lib, "ncclGroupEnd");
         if (!r.getUniqueId || !r.commInitRank || !r.allGather || !r.commDestroy)
             failure = "librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy";
     });
@@ -139,6 +149,43 @@ void hgx_comm_destroy(hgx_comm *c) {
     delete c;
 }
 
+// this rank's blob of the plan's last run into `mine` (a slot of slot_bytes); on failure the slot's header says so and `failure`
+// why — the caller still takes part in its collective
+static void buildSlot(hgx_liftover_plan *p, unsigned char *mine, size_t slot_bytes, int64_t first_query, int bed_only, void *hip_stream,
+                      size_t &wrote, std::string &failure) {
+    size_t need = 0;
+    wrote = 0;
+    // (the buffers rotate: the slot may hold a complete blob of an earlier batch.  Its header is cleared first, so that whatever
+    // goes wrong below the other ranks cannot take stale records for this batch's: a slot without the magic is not a blob)
+    (void)hipMemsetAsync(mine, 0, 32, (hipStream_t)hip_stream);
+    bool tooSmall = false;
+    try {
+        need = hgx::liftoverPlanWireBlob(p, nullptr, 0, first_query, nullptr, hip_stream);
+        if (need <= slot_bytes) {
+            int fmt = bed_only ? 8 : 0;
+            wrote = hgx::liftoverPlanWireBlob(p, mine, slot_bytes, first_query, &fmt, hip_stream);
+        } else {
+            tooSmall = true;
+            failure = "this rank's records need " + std::to_string(need) + " bytes, the slot has " + std::to_string(slot_bytes);
+        }
+    } catch (std::exception &e) { // a plan with a batch in flight, a HIP error while the blob was made, no memory for its staging
+        failure = std::string("no blob from this rank: ") + e.what();
+    }
+    if (!failure.empty()) {
+        // the slot's header says so to the other ranks: format 0; n_queries 0 = the slot was too small, and the bytes the blob
+        // would have needed stand in the record count; n_queries 1 = no blob for another reason (a batch in flight, a HIP error)
+        struct {
+            char magic[4];
+            uint32_t format;
+            int64_t firstQuery;
+            uint64_t nq, nrec;
+        } h = {{'H', 'G', 'X', 'W'}, 0u, first_query, tooSmall ? 0ull : 1ull, (uint64_t)need};
+        // (best effort: when even this copy fails the slot keeps its cleared header — the collective is still posted)
+        if (hipMemcpyAsync(mine, &h, sizeof h, hipMemcpyHostToDevice, (hipStream_t)hip_stream) == hipSuccess)
+            (void)hipStreamSynchronize((hipStream_t)hip_stream); // (h lives on this stack frame)
+    }
+}
+
 int hgx_liftover_exchange(hgx_liftover_plan *p, hgx_comm *c, int64_t first_query, void *d_gathered, size_t slot_bytes, void *hip_stream,
                           size_t *my_bytes, char **err) {
     try {
@@ -149,42 +196,56 @@ int hgx_liftover_exchange(hgx_liftover_plan *p, hgx_comm *c, int64_t first_query
         // (argument errors above are the caller's on every rank alike; from here on this rank takes part in the collective
         // whatever happens to its own blob — the other ranks are waiting in theirs)
         unsigned char *mine = (unsigned char *)d_gathered + (size_t)c->rank * slot_bytes;
-        size_t need = 0, wrote = 0;
+        size_t wrote = 0;
         std::string failure;
-        // (the buffers rotate: the slot may hold a complete blob of an earlier batch.  Its header is cleared first, so that whatever
-        // goes wrong below the other ranks cannot take stale records for this batch's: a slot without the magic is not a blob)
-        (void)hipMemsetAsync(mine, 0, 32, (hipStream_t)hip_stream);
-        bool tooSmall = false;
-        try {
-            need = hgx::liftoverPlanWireBlob(p, nullptr, 0, first_query, nullptr, hip_stream);
-            if (need <= slot_bytes)
-                wrote = hgx::liftoverPlanWireBlob(p, mine, slot_bytes, first_query, nullptr, hip_stream);
-            else {
-                tooSmall = true;
-                failure = "hgx_liftover_exchange: this rank's records need " + std::to_string(need) + " bytes, the slot has " +
-                          std::to_string(slot_bytes);
-            }
-        } catch (std::exception &e) { // a plan with a batch in flight, a HIP error while the blob was made, no memory for its staging
-            failure = std::string("hgx_liftover_exchange: no blob from this rank: ") + e.what();
-        }
-        if (!failure.empty()) {
-            // the slot's header says so to the other ranks: format 0; n_queries 0 = the slot was too small, and the bytes the blob
-            // would have needed stand in the record count; n_queries 1 = no blob for another reason (a batch in flight, a HIP error)
-            struct {
-                char magic[4];
-                uint32_t format;
-                int64_t firstQuery;
-                uint64_t nq, nrec;
-            } h = {{'H', 'G', 'X', 'W'}, 0u, first_query, tooSmall ? 0ull : 1ull, (uint64_t)need};
-            // (best effort: when even this copy fails the slot keeps whatever it held — the collective is still posted)
-            if (hipMemcpyAsync(mine, &h, sizeof h, hipMemcpyHostToDevice, (hipStream_t)hip_stream) == hipSuccess)
-                (void)hipStreamSynchronize((hipStream_t)hip_stream); // (h lives on this stack frame)
-        }
+        buildSlot(p, mine, slot_bytes, first_query, 0, hip_stream, wrote, failure);
         check(rccl().allGather(mine, d_gathered, slot_bytes, /*ncclUint8*/ 1, c->comm, (hipStream_t)hip_stream), "ncclAllGather");
         if (my_bytes)
             *my_bytes = wrote;
         if (!failure.empty())
-            throw std::runtime_error(failure + " (the exchange was carried out; the slot's header says so to the other ranks)");
+            throw std::runtime_error("hgx_liftover_exchange: " + failure + " (the exchange was carried out; the slot's header says so to the other ranks)");
+        return HGX_OK;
+    } catch (std::exception &e) {
+        setErr(err, e.what());
+        return HGX_ERR;
+    }
+}
+
+int hgx_liftover_gather(hgx_liftover_plan *p, hgx_comm *c, int root, int64_t first_query, void *d_gathered, size_t slot_bytes, int bed_only,
+                        void *hip_stream, size_t *my_bytes, char **err) {
+    try {
+        if (!p || !c || !d_gathered)
+            throw std::runtime_error("hgx_liftover_gather: null argument");
+        if (slot_bytes < 64 || slot_bytes % 8)
+            throw std::runtime_error("hgx_liftover_gather: the slot size must be a multiple of 8 and at least 64 bytes");
+        if (root < 0 || root >= c->nRanks)
+            throw std::runtime_error("hgx_liftover_gather: no such root rank");
+        Rccl &R = rccl();
+        if (c->nRanks > 1 && (!R.send || !R.recv || !R.groupStart || !R.groupEnd))
+            throw std::runtime_error("librccl.so lacks ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd");
+        const bool isRoot = c->rank == root;
+        unsigned char *mine = (unsigned char *)d_gathered + (isRoot ? (size_t)c->rank * slot_bytes : 0);
+        size_t wrote = 0;
+        std::string failure;
+        buildSlot(p, mine, slot_bytes, first_query, bed_only, hip_stream, wrote, failure);
+        if (c->nRanks > 1) {
+            check(R.groupStart(), "ncclGroupStart");
+            int rc = 0;
+            if (isRoot) {
+                for (int r = 0; r < c->nRanks && rc == 0; ++r)
+                    if (r != root)
+                        rc = R.recv((unsigned char *)d_gathered + (size_t)r * slot_bytes, slot_bytes, /*ncclUint8*/ 1, r, c->comm, (hipStream_t)hip_stream);
+            } else {
+                rc = R.send(mine, slot_bytes, /*ncclUint8*/ 1, root, c->comm, (hipStream_t)hip_stream);
+            }
+            const int rcEnd = R.groupEnd();
+            check(rc, isRoot ? "ncclRecv" : "ncclSend");
+            check(rcEnd, "ncclGroupEnd");
+        }
+        if (my_bytes)
+            *my_bytes = wrote;
+        if (!failure.empty())
+            throw std::runtime_error("hgx_liftover_gather: " + failure + " (the transfer was carried out; the slot's header says so to the root)");
         return HGX_OK;
     } catch (std::exception &e) {
         setErr(err, e.what());

@@ -1092,6 +1092,20 @@ static __global__ void __launch_bounds__(256) k_wire12_records(const hgx_record 
         o[2] = (uint32_t)len | ((uint32_t)r.tgt_seq << 22) | (sc << 29) | ((uint32_t)r.tgt_reversed << 31);
     }
 }
+// the 8-byte form for a receiver that only prints BED lines (halLiftover's output has no source coordinates: liftover/impl/
+// halLiftover.cpp:94-106): tgt_start as uint32 and the third word of the 12-byte form; same limits, same flag
+static __global__ void __launch_bounds__(256) k_wire8_records(const hgx_record *__restrict__ in, uint32_t n, uint32_t *__restrict__ out,
+                                                              unsigned int *bad) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const hgx_record r = in[i];
+        const int64_t len = r.tgt_end - r.tgt_start;
+        const uint32_t sc = r.strand == '+' ? 0u : r.strand == '-' ? 1u : r.strand == '.' ? 2u : 3u;
+        if (len < 0 || len >= (1 << 22) || (uint64_t)r.tgt_start >> 32 || (uint32_t)r.tgt_seq >= 128u || sc == 3u || r.tgt_reversed > 1)
+            *bad = 1;
+        out[2 * (size_t)i] = (uint32_t)r.tgt_start;
+        out[2 * (size_t)i + 1] = (uint32_t)len | ((uint32_t)r.tgt_seq << 22) | (sc << 29) | ((uint32_t)r.tgt_reversed << 31);
+    }
+}
 static __global__ void __launch_bounds__(256) k_wire12_counts(const uint32_t *__restrict__ nOut, uint32_t nq, uint32_t nqPadded,
                                                               uint16_t *__restrict__ out, unsigned int *bad) {
     for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nqPadded; q += gridDim.x * blockDim.x) {

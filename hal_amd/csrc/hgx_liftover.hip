@@ -2162,6 +2162,7 @@ size_t liftoverPlanWireBlob(hgx_liftover_plan *p, void *dDst, size_t capacity, i
         throw std::runtime_error("hgx_liftover_wire_blob: destination too small");
     unsigned char *dst = (unsigned char *)dDst;
     int fmt = 12;
+    const bool bedOnly = format && *format == 8; // the caller asks for the 8-byte form (no source coordinates: BED lines only)
     {
         p->wireFlag.ensure(4);
         if (!p->wireFlagHost)
@@ -2170,13 +2171,18 @@ size_t liftoverPlanWireBlob(hgx_liftover_plan *p, void *dDst, size_t capacity, i
         if (nq)
             hipLaunchKernelGGL(k_wire12_counts, dim3(GRID), dim3(256), 0, s, (const uint32_t *)p->nOut.p, (uint32_t)nq, (uint32_t)(countsBytes / 2),
                                (uint16_t *)(dst + 32), (unsigned int *)p->wireFlag.p);
-        if (nrec)
+        if (nrec && bedOnly)
+            hipLaunchKernelGGL(k_wire8_records, dim3(GRID), dim3(256), 0, s, (const hgx_record *)p->outRecords.p, (uint32_t)nrec,
+                               (uint32_t *)(dst + 32 + countsBytes), (unsigned int *)p->wireFlag.p);
+        else if (nrec)
             hipLaunchKernelGGL(k_wire12_records, dim3(GRID), dim3(256), 0, s, (const hgx_record *)p->outRecords.p, (uint32_t)nrec,
                                (uint32_t *)(dst + 32 + countsBytes), (unsigned int *)p->wireFlag.p);
         HIP_OK(hipMemcpyAsync(p->wireFlagHost, p->wireFlag.p, 4, hipMemcpyDeviceToHost, s));
         HIP_OK(hipStreamSynchronize(s)); // the one synchronisation of the call: does the narrow form hold this batch?
         if (*p->wireFlagHost)
             fmt = fits20 ? 20 : 40;
+        else if (bedOnly)
+            fmt = 8;
     }
     if (forced && forced[0] == '4')
         fmt = 40;
@@ -2190,7 +2196,7 @@ size_t liftoverPlanWireBlob(hgx_liftover_plan *p, void *dDst, size_t capacity, i
     hipLaunchKernelGGL(k_wire_header, dim3(1), dim3(1), 0, s, header, (WireHeader *)dst); // (stream ordered: no further wait)
     if (format)
         *format = fmt;
-    return fmt == 12 ? need12 : fmt == 20 ? need20 : need40;
+    return fmt == 8 ? 32 + countsBytes + 8 * nrec : fmt == 12 ? need12 : fmt == 20 ? need20 : need40;
 }
 
 std::string liftoverPlanKernelTimes(hgx_liftover_plan *p) {

@@ -122,7 +122,16 @@ def encode_blob(recs, num_queries, first_query=0, fmt=None):
                            (seq < 128) & (code < 3) & (rev <= 1)).all()) and bool(num_queries == 0 or (counts < 65536).all())
     if fmt is None:
         fmt = 12 if fits else 20
-    if fmt == 12:
+    if fmt == 8:  # (the 12-byte form without the source start: all a writer of BED lines needs)
+        assert fits, "fields do not fit the 8-byte form"
+        c16 = torch.zeros((2 * num_queries + 7) // 8 * 4, dtype=torch.int16, device=dev)
+        c16[:num_queries] = counts.to(torch.int32).to(torch.int16)
+        w = torch.empty((n, 2), dtype=torch.int64, device=dev)
+        w[:, 0] = ts
+        w[:, 1] = (te - ts) | (seq << 22) | (code << 29) | (rev << 31)
+        body = torch.cat([c16.view(torch.uint8), (w & 0xFFFFFFFF).to(torch.int32).view(torch.uint8).view(-1) if n else
+                          torch.empty(0, dtype=torch.uint8, device=dev)])
+    elif fmt == 12:
         assert fits, "fields do not fit the 12-byte form"
         c16 = torch.zeros((2 * num_queries + 7) // 8 * 4, dtype=torch.int16, device=dev)
         c16[:num_queries] = counts.to(torch.int32).to(torch.int16)  # (uint16 bit pattern)
@@ -152,11 +161,14 @@ def decode_blob(blob):
     if fmt == 40:
         recs = body[:RECORD_BYTES * nrec].view(nrec, RECORD_BYTES).clone()
         return offset_query_index(recs, first_query), first_query, nq
-    if fmt != 12:
+    if fmt not in (8, 12):
         raise ValueError("unknown wire format %d" % fmt)
     cbytes = (2 * nq + 7) // 8 * 8
     counts = body[:2 * nq].contiguous().view(torch.int16).to(torch.int64) & 0xFFFF
-    w = (body[cbytes:cbytes + 12 * nrec].contiguous().view(torch.int32).view(nrec, 3).to(torch.int64)) & 0xFFFFFFFF
+    words = fmt // 4
+    w = (body[cbytes:cbytes + fmt * nrec].contiguous().view(torch.int32).view(nrec, words).to(torch.int64)) & 0xFFFFFFFF
+    if fmt == 8:  # (no source start on the wire: -1 in the record)
+        w = torch.stack([w[:, 0], torch.full_like(w[:, 0], -1), w[:, 1]], dim=1)
     out = torch.zeros((nrec, 5), dtype=torch.int64, device=dev)
     out[:, 0] = torch.repeat_interleave(torch.arange(nq, dtype=torch.int64, device=dev), counts) + first_query
     out[:, 1] = w[:, 0]
@@ -280,9 +292,13 @@ class SlotExchange:
     gloo on CPU for the tests).  submit() starts the exchange of the plan's last run, wait() hands out the oldest buffer under
     way (three rotate, so the mapping of the next batches overlaps the exchange); slots(buf) views the ranks' blobs."""
 
-    def __init__(self, world, rank, slot_bytes, device, backend="torch", comm=None):
+    def __init__(self, world, rank, slot_bytes, device, backend="torch", comm=None, root=None, bed_only=False):
+        """root: None — every rank gets every rank's blob (one all-gather); a rank — only that rank does (the writer's collation:
+        a rank sends its slot once instead of receiving all the others'; hgx_liftover_gather / torch.distributed.gather), the
+        other ranks' buffers keep their own slot only.  bed_only: blobs in the 8-byte form (no source coordinates)."""
         self.world, self.rank, self.slot = world, rank, (int(slot_bytes) + 7) // 8 * 8
         self.backend, self.comm = backend, comm
+        self.root, self.bed_only = root, bed_only
         self._bufs = [torch.zeros(world * self.slot, dtype=torch.uint8, device=device) for _ in range(3)]
         self._turn, self._inflight = 0, []
         self.last_bytes, self.last_format = 0, None
@@ -300,7 +316,10 @@ class SlotExchange:
         self._turn += 1
         work = None
         if self.backend == "c_abi":
-            self.last_bytes = plan.exchange(self.comm, first_query, buf, self.slot)
+            if self.root is None:
+                self.last_bytes = plan.exchange(self.comm, first_query, buf, self.slot)
+            else:
+                self.last_bytes = plan.gather(self.comm, self.root, first_query, buf, self.slot, bed_only=self.bed_only)
             if buf.device.type == "cuda":  # (the library queues its all-gather on the current stream: an event marks its end)
                 work = torch.cuda.Event()
                 work.record()
@@ -314,9 +333,12 @@ class SlotExchange:
             else:
                 if plan.wire_capacity() > self.slot:
                     raise ValueError("this rank's records may need %d bytes, the slot has %d" % (plan.wire_capacity(), self.slot))
-                b, self.last_format = plan.wire_blob(first_query, dst=mine)
+                b, self.last_format = plan.wire_blob(first_query, dst=mine, bed_only=self.bed_only)
                 self.last_bytes = int(b.numel())
-            if buf.device.type == "cuda":
+            if self.root is not None:  # to the writer only
+                parts = list(buf.view(self.world, self.slot).unbind(0)) if self.rank == self.root else None
+                work = dist.gather(mine.clone(), gather_list=parts, dst=self.root, async_op=True)
+            elif buf.device.type == "cuda":
                 work = dist.all_gather_into_tensor(buf, mine, async_op=True)
             else:
                 parts = list(buf.view(self.world, self.slot).unbind(0))
@@ -346,7 +368,9 @@ class SlotExchange:
         return out
 
     def slots(self, buf):
-        """the ranks' blobs (each trimmed to what its header says it holds), in rank order"""
+        """the ranks' blobs (each trimmed to what its header says it holds), in rank order (with a root: on the root only)"""
+        if self.root is not None and self.rank != self.root:
+            raise ValueError("the blobs were gathered on rank %d" % self.root)
         out = []
         for r in range(self.world):
             s = buf[r * self.slot:(r + 1) * self.slot]
@@ -365,6 +389,6 @@ def blob_bytes(slot):
         if nq == 0:
             raise ValueError("a rank's records did not fit its slot (it needed %d bytes)" % nrec)
         raise ValueError("a rank had no blob for this batch (its own call reports the cause: a batch in flight, a HIP error)")
-    if fmt == 12:
-        return 32 + (2 * nq + 7) // 8 * 8 + 12 * nrec
+    if fmt in (8, 12):
+        return 32 + (2 * nq + 7) // 8 * 8 + fmt * nrec
     return 32 + (20 if fmt == 20 else 40) * nrec

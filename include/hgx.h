@@ -268,6 +268,9 @@ int hgx_liftover_copy_records_packed(const hgx_liftover_plan *p, void *d_dst, si
  *   format 12: uint16 record count per interval (padded to 8 bytes), then 12 bytes per record — tgt_start and src_start
  *              as uint32, (tgt_end - tgt_start) | tgt_seq << 22 | strand code << 29 | tgt_reversed << 31 (strand code
  *              0 '+', 1 '-', 2 '.'); the query index follows from the counts and first_query;
+ *   format 8:  the same counts, then 8 bytes per record — tgt_start and the third word of format 12, no source coordinate:
+ *              all a receiver needs that only prints BED lines (liftover/impl/halLiftover.cpp:94-106).  Written only when
+ *              the caller sets *format to 8 before the call, under format 12's conditions (else 20 / 40 as below);
  *   format 20: the records of hgx_liftover_copy_records_packed (query relative to first_query);
  *   format 40: hgx_record rows as they are (query relative to first_query).
  * Format 12 is used when every field fits (lengths < 2^22, positions < 2^32, < 128 target sequences, < 65536 records per
@@ -295,6 +298,13 @@ int hgx_comm_create(const unsigned char *id128, int rank, int n_ranks, int devic
 void hgx_comm_destroy(hgx_comm *c);
 int hgx_liftover_exchange(hgx_liftover_plan *p, hgx_comm *c, int64_t first_query, void *d_gathered, size_t slot_bytes, void *hip_stream,
                           size_t *my_bytes, char **err);
+/* The collation a writer needs: every rank's blob in rank `root`'s buffer only (ncclSend / ncclRecv in one group; a rank sends
+ * its slot once instead of receiving every other rank's — with N ranks an all-gather moves N times the batch's records into
+ * every GPU, this moves them once into one).  d_gathered: n_ranks slots on the root, one slot (the rank's own, slot 0) on the
+ * others.  bed_only: the blobs in the 8-byte form when they fit it (hgx_liftover_wire_blob).  Failures as
+ * hgx_liftover_exchange: the rank still takes part. */
+int hgx_liftover_gather(hgx_liftover_plan *p, hgx_comm *c, int root, int64_t first_query, void *d_gathered, size_t slot_bytes,
+                        int bed_only, void *hip_stream, size_t *my_bytes, char **err);
 
 
 /* Text-level drop-in for Liftover::convert (liftover/inc/halLiftover.h:25-28): BED text in, BED text

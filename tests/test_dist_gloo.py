@@ -221,6 +221,27 @@ def _slot_worker(rank, world, port, result):
         ok = False
     except ValueError:
         pass
+    # the writer's collation: every rank's blob on rank 0 only (torch.distributed.gather; hgx_liftover_gather from the library),
+    # in the 8-byte form — what a writer of BED lines needs: everything but the source start
+    blob8 = encode_blob(mine, nq, first_query=bounds[rank], fmt=8)
+    gx = SlotExchange(world, rank, slot, "cpu", backend="torch", root=0, bed_only=True)
+    want8 = whole.view(torch.int64).view(-1, 5).clone()
+    want8[:, 3] = -1
+    for _ in range(4):
+        gx.submit(blob=blob8)
+        buf = gx.wait()
+        if rank == 0:
+            parts = gx.slots(buf)
+            ok = ok and [p.numel() for p in parts] == [32 + (2 * (bounds[r + 1] - bounds[r]) + 7) // 8 * 8 + 8 * int(z["shard%d" % r].shape[0])
+                                                       for r in range(world)]
+            got8 = torch.cat([decode_blob(p)[0] for p in parts], dim=0).view(torch.int64).view(-1, 5)
+            ok = ok and bool(torch.equal(got8, want8))
+        else:
+            try:
+                gx.slots(buf)
+                ok = False
+            except ValueError:
+                pass
     result[rank] = ok
     dist.barrier()
     dist.destroy_process_group()

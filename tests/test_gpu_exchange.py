@@ -30,6 +30,7 @@ def test_exchange_on_a_one_rank_rccl_group(hal, tmp_path):
     comm = hal.Comm(hal.Comm.unique_id(), 0, 1, 0)
     ptr, nrec = plan.run(gs, ge, st)
     direct = plan.records_to_tensor(ptr, nrec).clone()
+    pristine = direct.clone()
     slot = (plan.wire_capacity() + 7) // 8 * 8
     ex = shard.SlotExchange(1, 0, slot, "cuda", backend="c_abi", comm=comm)
     for first_query in (0, 1 << 33):  # a shard's global offset travels in the header
@@ -42,6 +43,21 @@ def test_exchange_on_a_one_rank_rccl_group(hal, tmp_path):
         assert (fq, nq) == (first_query, 3000)
         want = shard.offset_query_index(direct, first_query)
         assert torch.equal(recs.cpu(), want.cpu())
+    # the writer's collation (hgx_liftover_gather: send / recv to the root; here the root is the only rank) in the 8-byte form:
+    # the device writes the bytes the torch encoder writes, and they decode to the records without their source start
+    gx = shard.SlotExchange(1, 0, slot, "cuda", backend="c_abi", comm=comm, root=0, bed_only=True)
+    gx.submit(plan, first_query=12345)
+    buf = gx.wait()
+    torch.cuda.synchronize()
+    (blob8,) = gx.slots(buf)
+    assert blob8.numel() == gx.last_bytes == 32 + (2 * 3000 + 7) // 8 * 8 + 8 * nrec
+    assert torch.equal(blob8.cpu(), shard.encode_blob(pristine.cpu(), 3000, first_query=12345, fmt=8))
+    recs8, fq, nq = shard.decode_blob(blob8)
+    want8 = shard.offset_query_index(pristine.clone(), 12345).cpu().contiguous().view(torch.int64).view(-1, 5)
+    want8[:, 3] = -1
+    assert (fq, nq) == (12345, 3000) and torch.equal(recs8.cpu().contiguous().view(torch.int64).view(-1, 5), want8)
+    b8, fmt8 = plan.wire_blob(first_query=0, bed_only=True)
+    assert fmt8 == 8 and b8.numel() == blob8.numel()
     # a slot that is too small: the collective is still carried out, the call reports it, the slot says so to the others
     small = shard.SlotExchange(1, 0, 64, "cuda", backend="c_abi", comm=comm)
     with pytest.raises(hal.HgxError, match="need"):
@@ -72,5 +88,12 @@ def test_slot_exchange_over_torch_distributed(hal, tmp_path):
         torch.cuda.synchronize()
         recs, fq, nq = shard.decode_blob(ex.slots(buf)[0])
         assert (fq, nq) == (77, 2000) and torch.equal(recs.cpu(), shard.offset_query_index(direct, 77).cpu())
+        # gather to the writer rank over torch.distributed (dist.gather)
+        gx = shard.SlotExchange(1, 0, plan.wire_capacity(), "cuda", backend="torch", root=0, bed_only=True)
+        gx.submit(plan, first_query=5)
+        buf = gx.wait()
+        torch.cuda.synchronize()
+        recs8, fq, nq = shard.decode_blob(gx.slots(buf)[0])
+        assert (fq, nq, gx.last_format) == (5, 2000, 8) and recs8.shape == recs.shape
     finally:
         dist.destroy_process_group()
