@@ -30,7 +30,8 @@ def test_sweeps_own_bytes_on_a_three_genome_tree(hal):
     word = 1  # three genomes: an 8-bit genome set per base
     want = word * al.genome_length(root) + al.num_bottom_segments(root) * (8.0 + 4.0 * len(kids)) + sum(16.0 * al.num_top_segments(c) for c in kids)
     if len(kids) == 2:  # (leaves carry constants: no child track is read)
-        want += 24.0 * al.num_top_segments(ref) + 4.0 * al.genome_length(ref) + word * al.genome_length(ref) + 8.0 * al.genome_length(ref)
+        # (down: TopRec + the parent's BotRec, the depth written as a byte, the root's track read; out: the byte read, int32 written)
+        want += 24.0 * al.num_top_segments(ref) + 1.0 * al.genome_length(ref) + word * al.genome_length(ref) + 5.0 * al.genome_length(ref)
         assert bench.sweep_design_bytes(al, ref) == want
 
 
