@@ -15,7 +15,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 ALIGNMENTS = [(3, 5, 2, 150), (8, 6, 1, 180), (21, 5, 3, 120), ("randgen", 0, 0, 0)]
 EXPORTS = [({}, []), (dict(max_block_len=4, keep_empty_ref_blocks=True), ["--maxBlockLen", "4", "--keepEmptyRefBlocks"]),
            (dict(no_dupes=True, only_sequence_names=True), ["--noDupes", "--onlySequenceNames"]),
-           (dict(unique=True), ["--unique"]),                       # the column-by-column path: visit cache replayed on the host
+           (dict(unique=True), ["--unique"]),                       # which columns are walked / written comes from the device (heads 2, 3)
+           (dict(unique=True, max_ref_gap=5), ["--unique", "--maxRefGap", "5"]),  # the column-by-column path: visit caches replayed on the host
            (dict(print_tree=True), ["--printTree"]),                # the same path with the block's tree
            (dict(print_tree=True, no_dupes=True, max_block_len=9), ["--printTree", "--noDupes", "--maxBlockLen", "9"]),
            (dict(max_ref_gap=9), ["--maxRefGap", "9"]),             # the iterator with its stack of inserted / deleted ranges
