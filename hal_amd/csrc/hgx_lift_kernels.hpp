@@ -445,11 +445,13 @@ __device__ __forceinline__ void lift_wave_emit(const ComposedRec<C> *__restrict_
             const int span = (int)__builtin_amdgcn_readlane((int)wave_incl_scan<LiftMax>(inGroup ? (uint32_t)(rel + 1) : 0u), 63);
             const uint32_t oB = (uint32_t)__shfl((int)b, owner);
             uint32_t rank = 0;
+            // (one exchange per partner: a lane that is not in such a group shows the largest coordinate, which is in front of nobody —
+            // with paralogs an interval's first base lies in twenty records and this loop was most of the kernel)
+            const C key = inGroup ? tLo : LiftCoord<C>::MAXV;
             for (int jj = 0; jj < span; ++jj) {
                 const int partner = (int)lo + jj;
-                const int pGroup = __shfl((int)inGroup, partner & 63);
-                const C pT = wave_pull<C>(tLo, partner & 63);
-                if (inGroup && (uint32_t)jj < oB && partner < 64 && pGroup && pT < tLo)
+                const C pT = wave_pull<C>(key, partner & 63);
+                if (inGroup && (uint32_t)jj < oB && partner < 64 && pT < tLo)
                     ++rank;
             }
             if (inGroup)
