@@ -1,5 +1,6 @@
 // extern "C" boundary of libhgx (include/hgx.h).  No exception crosses it.
 #include "../../include/hgx.h"
+#include "hgx_textmem.hpp"
 #include "hgx_columns_host.hpp"
 #include "hgx_liftover_host.hpp"
 #include <cstdlib>
@@ -625,7 +626,7 @@ static int convertOver(hgx_alignment *const *handles, int n_handles, int src, co
         if (!text)
             rc = HGX_ERR;
     } else {
-        free(text);
+        hgx::textFree(text);
     }
     return rc;
 }
@@ -716,7 +717,7 @@ int hgx_column_rows(hgx_alignment *h, int ref, int64_t first, int64_t count, con
 namespace {
 class MallocBuf : public std::streambuf {
   public:
-    ~MallocBuf() override { free(_p); }
+    ~MallocBuf() override { hgx::textFree(_p); }
     // NUL-terminated; the caller owns it (hgx_free)
     bool release(char **out, size_t *len) {
         if (!reserve(_n + 1))
@@ -759,7 +760,17 @@ class MallocBuf : public std::streambuf {
         size_t cap = _cap ? _cap : (size_t)1 << 16;
         while (cap < need)
             cap += cap < ((size_t)1 << 28) ? cap : ((size_t)1 << 28);
-        char *q = (char *)realloc(_p, cap);
+        // (hgx_textmem.hpp: a text of a megabyte or more lives in a mapping advised as huge pages and grows by mremap)
+        char *q;
+        if (_p && !hgx::textOwns(_p) && cap >= ((size_t)1 << 20)) { // outgrows malloc: moved over
+            q = (char *)hgx::textAlloc(cap);
+            if (q) {
+                memcpy(q, _p, _n);
+                free(_p);
+            }
+        } else {
+            q = (char *)hgx::textRealloc(_p, cap);
+        }
         if (!q)
             return false;
         _p = q;
@@ -1015,7 +1026,7 @@ int hgx_save_image(const hgx_alignment *h, const char *path, char **err) {
 }
 
 void hgx_free(void *p) {
-    free(p);
+    hgx::textFree(p); // (the library's large texts are mappings: hgx_textmem.hpp; everything else is malloc's)
 }
 
 const char *hgx_version(void) {

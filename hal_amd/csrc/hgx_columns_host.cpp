@@ -1061,6 +1061,13 @@ namespace {
 struct TextBuffer {
     char *data = nullptr;
     size_t len = 0, cap = 0;
+    TextBuffer() = default;
+    TextBuffer(const TextBuffer &) = delete;
+    TextBuffer &operator=(const TextBuffer &) = delete;
+    TextBuffer(TextBuffer &&o) noexcept : data(o.data), len(o.len), cap(o.cap) {
+        o.data = nullptr;
+        o.len = o.cap = 0;
+    }
     ~TextBuffer() { free(data); }
     char *room(size_t n) {
         if (len + n > cap) {
@@ -1108,7 +1115,28 @@ void MafExport::RunMachine::flush(const PRow *current) {
         nt = std::max(1u, std::min(nt ? nt : 1u, 16u));
         if (nb < 256)
             nt = 1;
-        std::vector<TextBuffer> text(nt);
+        // (the rendering threads' buffers are kept from batch to batch: thirty megabytes of fresh pages per batch were as many page
+        // faults again as the text's own)
+        struct BufferPool {
+            std::mutex mu;
+            std::vector<std::unique_ptr<std::vector<TextBuffer>>> idle;
+        };
+        static BufferPool *pool = new BufferPool;
+        std::unique_ptr<std::vector<TextBuffer>> held;
+        {
+            std::lock_guard<std::mutex> lock(pool->mu);
+            if (!pool->idle.empty()) {
+                held = std::move(pool->idle.back());
+                pool->idle.pop_back();
+            }
+        }
+        if (!held)
+            held.reset(new std::vector<TextBuffer>());
+        if (held->size() < nt)
+            held->resize(nt);
+        std::vector<TextBuffer> &text = *held;
+        for (TextBuffer &t : text)
+            t.len = 0;
         auto render = [&](unsigned t) {
             TextBuffer &buf = text[t];
             struct RowOut {
@@ -1247,8 +1275,11 @@ void MafExport::RunMachine::flush(const PRow *current) {
             for (std::thread &x : th)
                 x.join();
         }
-        for (const TextBuffer &t : text)
-            out->write(t.data, (std::streamsize)t.len);
+        for (unsigned t = 0; t < nt; ++t)
+            out->write(text[t].data, (std::streamsize)text[t].len);
+        std::lock_guard<std::mutex> lock(pool->mu);
+        if (pool->idle.size() < 4)
+            pool->idle.push_back(std::move(held));
     });
 }
 

@@ -1,3 +1,4 @@
+#include "hgx_textmem.hpp"
 #include "hgx_liftover_host.hpp"
 #include <algorithm>
 #include <cerrno>
@@ -385,12 +386,12 @@ void Liftover::convert(hgx_alignment *al, int srcGenome, std::istream *in, int t
     } catch (...) { // what was lifted before the failing line has been written by then in the reference, too
         if (lifted)
             out->write(lifted, (std::streamsize)n);
-        free(lifted);
+        textFree(lifted);
         throw;
     }
     if (lifted)
         out->write(lifted, (std::streamsize)n);
-    free(lifted);
+    textFree(lifted); // (hgx_textmem.hpp: the parallel path's text is a mapping, the general path's malloc's: it tells them apart)
 }
 
 void Liftover::convertBuffer(hgx_alignment *al, int srcGenome, const char *text, size_t len, int tgtGenome, char **outText, size_t *outLen, int bedType,

@@ -14,6 +14,7 @@
 // first malformed line ends the conversion with the reference's message after the lines before it have been written.
 // Anything else — BED12 lines, PSL output, files that mix column counts (the reference's line object then inherits fields from
 // earlier lines) — returns false and takes the general path of hgx_liftover_host.cpp.
+#include "hgx_textmem.hpp"
 #include "hgx_liftover_host.hpp"
 #include <algorithm>
 #include <atomic>
@@ -524,9 +525,10 @@ bool liftoverTextFast(hgx_alignment *const *als, int nAls, int srcGenome, const 
         C.firstLine = total; // (reused: the chunk's place in the output)
         total += C.out.size();
     }
-    // the output buffer is handed to the caller as it is (malloc, untouched until the chunks copy themselves in: the
-    // first touch of its pages is spread over the threads as well)
-    char *buf = (char *)malloc(total + 1);
+    // the output buffer is handed to the caller as it is (hgx_textmem.hpp: a mapping advised as huge pages, or the block the last
+    // call's text was released from), untouched until the chunks copy themselves in: the first touch of its pages is spread over
+    // the threads as well
+    char *buf = (char *)textAlloc(total + 1);
     if (!buf)
         throw std::runtime_error("out of memory");
     buf[total] = '\0';

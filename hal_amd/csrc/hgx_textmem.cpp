@@ -1,0 +1,140 @@
+#include "hgx_textmem.hpp"
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <sys/mman.h>
+
+namespace hgx {
+
+namespace {
+constexpr size_t kMapFrom = (size_t)1 << 20;   // smaller blocks come from malloc
+constexpr size_t kKeepBytes = (size_t)1 << 30; // released blocks kept for reuse: at most this much, in at most two blocks
+struct TextMem {
+    std::mutex mu;
+    std::map<const void *, size_t> live; // mapped blocks handed out: their mapped length
+    std::map<const void *, size_t> kept; // released, still mapped
+    size_t keptBytes = 0;
+};
+TextMem &mem() {
+    static TextMem *m = new TextMem; // (never destroyed: texts may be released from static destructors)
+    return *m;
+}
+size_t pages(size_t bytes) {
+    return (bytes + 4095) & ~(size_t)4095;
+}
+void *mapFresh(size_t len) {
+    void *p = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (p == MAP_FAILED)
+        return nullptr;
+    (void)madvise(p, len, MADV_HUGEPAGE); // (advice: the 2 MB extents inside the block fault in as one page each)
+    return p;
+}
+} // namespace
+
+void *textAlloc(size_t bytes) {
+    if (bytes < kMapFrom) {
+        // (small texts: malloc's; told apart from the mapped ones by the registry)
+        return malloc(bytes ? bytes : 1);
+    }
+    const size_t len = pages(bytes);
+    TextMem &M = mem();
+    {
+        std::lock_guard<std::mutex> lock(M.mu);
+        // a kept block that holds the text without being several times its size
+        const void *best = nullptr;
+        size_t bestLen = 0;
+        for (auto &kv : M.kept)
+            if (kv.second >= len && kv.second <= 4 * len + ((size_t)16 << 20) && (!best || kv.second < bestLen)) {
+                best = kv.first;
+                bestLen = kv.second;
+            }
+        if (best) {
+            M.kept.erase(best);
+            M.keptBytes -= bestLen;
+            M.live[best] = bestLen;
+            return const_cast<void *>(best);
+        }
+    }
+    void *p = mapFresh(len);
+    if (!p)
+        return nullptr;
+    std::lock_guard<std::mutex> lock(M.mu);
+    M.live[p] = len;
+    return p;
+}
+
+void *textRealloc(void *p, size_t bytes) {
+    if (!p)
+        return textAlloc(bytes);
+    TextMem &M = mem();
+    size_t have = 0;
+    {
+        std::lock_guard<std::mutex> lock(M.mu);
+        auto it = M.live.find(p);
+        if (it != M.live.end())
+            have = it->second;
+    }
+    if (!have) // malloc's (a caller whose text outgrows malloc moves it over itself: the size of a malloc block is not known here)
+        return realloc(p, bytes ? bytes : 1);
+    const size_t len = pages(bytes);
+    if (len <= have)
+        return p;
+    void *q = mremap(p, have, len, MREMAP_MAYMOVE);
+    if (q == MAP_FAILED)
+        return nullptr;
+    (void)madvise(q, len, MADV_HUGEPAGE);
+    std::lock_guard<std::mutex> lock(M.mu);
+    M.live.erase(p);
+    M.live[q] = len;
+    return q;
+}
+
+bool textOwns(const void *p) {
+    if (!p)
+        return false;
+    TextMem &M = mem();
+    std::lock_guard<std::mutex> lock(M.mu);
+    return M.live.count(p) != 0;
+}
+
+void textFree(void *p) {
+    if (!p)
+        return;
+    TextMem &M = mem();
+    size_t len = 0;
+    bool keep = false;
+    {
+        std::lock_guard<std::mutex> lock(M.mu);
+        auto it = M.live.find(p);
+        if (it == M.live.end()) {
+            len = 0;
+        } else {
+            len = it->second;
+            M.live.erase(it);
+            keep = M.kept.size() < 2 && M.keptBytes + len <= kKeepBytes;
+            if (keep) {
+                M.kept[p] = len;
+                M.keptBytes += len;
+            }
+        }
+    }
+    if (!len)
+        free(p); // malloc's
+    else if (!keep)
+        (void)munmap(p, len);
+}
+
+void textTrim() {
+    TextMem &M = mem();
+    std::map<const void *, size_t> drop;
+    {
+        std::lock_guard<std::mutex> lock(M.mu);
+        drop.swap(M.kept);
+        M.keptBytes = 0;
+    }
+    for (auto &kv : drop)
+        (void)munmap(const_cast<void *>(kv.first), kv.second);
+}
+
+} // namespace hgx
