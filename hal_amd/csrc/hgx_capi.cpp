@@ -715,8 +715,15 @@ int hgx_column_rows(hgx_alignment *h, int ref, int64_t first, int64_t count, con
 // remapping, not copying) and is handed to the caller as it stands.  (std::ostringstream + str() + a copy into malloc'd memory
 // moved the 264 MB of an 8 M-column MAF four times.)
 namespace {
-class MallocBuf : public std::streambuf {
+class MallocBuf : public std::streambuf, public hgx::BulkSink {
   public:
+    char *room(size_t n) override { // (hgx::BulkSink)
+        if (!reserve(_n + n + 1))
+            return nullptr;
+        char *p = _p + _n;
+        _n += n;
+        return p;
+    }
     ~MallocBuf() override { hgx::textFree(_p); }
     // NUL-terminated; the caller owns it (hgx_free)
     bool release(char **out, size_t *len) {

@@ -801,15 +801,18 @@ struct MafExport::RunMachine {
         int64_t refIndex;
     };
     struct EventLog {
-        int64_t k; // columns
-        uint32_t firstPair;
+        int64_t k;       // columns
+        const PRow *rows; // the bases of the event's first column, sorted the way the column map holds them
+        uint32_t firstIdx, nRows; // rowEnt[firstIdx + r]: the entry of the block that base r was given to
     };
     struct Batch {
         std::vector<BlockLog> blocks;
         std::vector<int32_t> entRank;
         std::vector<EventLog> events;
-        std::vector<const PRow *> pairs; // per event and entry of the block: the base the entry was given at the event's first column
-        std::vector<std::shared_ptr<Chunk>> chunks; // (what the pairs point into)
+        // (per event only which entry each BASE went to — a dozen words —, not a pointer per ENTRY of the block: the rendering
+        // threads turn it round; the walk is the one thread everything waits for)
+        std::vector<uint32_t> rowEnt;
+        std::vector<std::shared_ptr<Chunk>> chunks; // (what the events' rows point into)
         std::vector<std::unique_ptr<PRow[]>> extra;
     };
     MafExport &M;
@@ -824,6 +827,9 @@ struct MafExport::RunMachine {
     std::shared_ptr<Chunk> chunk;
     BlockLog cur{};
     size_t appendCount = 0, numBlocks = 0;
+    bool entsLogged = false; // the entries' ranks as they are stand in this batch's log (at lastFirstEnt): the next block points there too
+    uint32_t lastFirstEnt = 0;
+    size_t refHint = 0;
 
     RunMachine(MafExport &m, std::ostream &o, int refRank_) : M(m), os(o), img(m._al->img), refRank(refRank_), batch(new Batch) {
         size_t ranks = 0;
@@ -922,11 +928,14 @@ struct MafExport::RunMachine {
     void initBlock(const PRow *rows, size_t n, int64_t refPos) {
         MAF_TICK(1);
         size_t w = 0; // resetEntries
+        bool changed = false;
         for (size_t i = 0; i < ents.size(); ++i) {
             Ent &e = ents[i];
             if (e.start == NULL_INDEX) {
-                if (e.lastUsed > 10)
+                if (e.lastUsed > 10) {
+                    changed = true;
                     continue; // unused for more than 10 consecutive blocks: dropped
+                }
                 ++e.lastUsed;
             } else {
                 e.lastUsed = 0;
@@ -934,21 +943,28 @@ struct MafExport::RunMachine {
             e.start = NULL_INDEX;
             e.rev = false;
             e.length = 0;
-            ents[w++] = e;
+            if (w != i)
+                ents[w] = e;
+            ++w;
         }
-        ents.resize(w);
+        if (w != ents.size())
+            ents.resize(w);
         size_t oi = 0, ei = 0;
         for (const KeyRec &k : keys) {
             while (ei < ents.size() && ents[ei].rank < k.rank)
                 ++ei;
             if (oi == n || rows[oi].rank != k.rank) { // a key without bases: an empty entry for it, if it has none
-                if (ei == ents.size() || ents[ei].rank != k.rank)
+                if (ei == ents.size() || ents[ei].rank != k.rank) {
                     ents.insert(ents.begin() + (std::ptrdiff_t)ei, newEnt(k));
+                    changed = true;
+                }
                 continue;
             }
             for (; oi < n && rows[oi].rank == k.rank; ++oi, ++ei) {
-                if (ei == ents.size() || ents[ei].rank != k.rank)
+                if (ei == ents.size() || ents[ei].rank != k.rank) {
                     ents.insert(ents.begin() + (std::ptrdiff_t)ei, newEnt(k));
+                    changed = true;
+                }
                 setFromRow(ents[ei], rows[oi]);
             }
         }
@@ -957,17 +973,31 @@ struct MafExport::RunMachine {
         g_mafTicks[9] += n;
         g_mafTicks[10] += keys.size();
 #endif
-        cur.firstEnt = (uint32_t)batch->entRank.size();
+        // the entries' ranks: logged once per change of the set (most blocks have the entries of the block before)
+        if (changed || !entsLogged) {
+            lastFirstEnt = (uint32_t)batch->entRank.size();
+            batch->entRank.resize(lastFirstEnt + ents.size());
+            int32_t *o = batch->entRank.data() + lastFirstEnt;
+            for (size_t i = 0; i < ents.size(); ++i)
+                o[i] = ents[i].rank;
+            entsLogged = true;
+        }
+        cur.firstEnt = lastFirstEnt;
         cur.numEnts = (uint32_t)ents.size();
         cur.firstEvent = (uint32_t)batch->events.size();
         cur.numEvents = 0;
-        for (const Ent &e : ents)
-            batch->entRank.push_back(e.rank);
-        size_t r = 0;
-        while (r < ents.size() && ents[r].rank < refRank)
-            ++r;
-        if (r == ents.size() || ents[r].rank != refRank)
+        size_t r = refHint; // (where the reference's entry was in the block before)
+        if (r >= ents.size() || ents[r].rank != refRank) {
             r = 0;
+            while (r < ents.size() && ents[r].rank < refRank)
+                ++r;
+            if (r == ents.size() || ents[r].rank != refRank)
+                r = 0;
+        } else {
+            while (r > 0 && ents[r - 1].rank == refRank) // (several entries of the sequence: the first one)
+                --r;
+        }
+        refHint = r;
         cur.refEnt = ents.empty() ? -1 : (int32_t)r;
         cur.refIndex = !ents.empty() && ents[r].rank == refRank ? refPos : NULL_INDEX;
     }
@@ -1020,26 +1050,26 @@ struct MafExport::RunMachine {
             initBlock(rows, n, refPos);
         }
         MAF_TICK(3);
-        const size_t firstPair = batch->pairs.size();
-        batch->pairs.resize(firstPair + ents.size(), nullptr);
-        const PRow **pairs = batch->pairs.data() + firstPair;
+        const size_t firstIdx = batch->rowEnt.size();
+        batch->rowEnt.resize(firstIdx + n);
+        uint32_t *idx = batch->rowEnt.data() + firstIdx;
         int64_t k = left;
         size_t ei = 0;
         for (size_t i = 0; i < n; ++i) { // the pairing appendColumn performs
             while (ents[ei].rank != rows[i].rank)
                 ++ei;
-            pairs[ei] = &rows[i];
+            idx[i] = (uint32_t)ei;
             k = std::min(k, 1 + std::max<int64_t>(0, M._maxBlockLength - (ents[ei].length + 1)));
             k = std::min(k, 1 + rows[i].limit);
             ++ei;
         }
-        for (size_t j = 0; j < ents.size(); ++j)
-            if (const PRow *p = pairs[j]) {
-                if (ents[j].start == NULL_INDEX)
-                    setFromRow(ents[j], *p);
-                ents[j].length += k;
-            }
-        batch->events.push_back(EventLog{k, (uint32_t)firstPair});
+        for (size_t i = 0; i < n; ++i) {
+            Ent &e = ents[idx[i]];
+            if (e.start == NULL_INDEX)
+                setFromRow(e, rows[i]);
+            e.length += k;
+        }
+        batch->events.push_back(EventLog{k, rows, (uint32_t)firstIdx, (uint32_t)n});
         appendCount += (size_t)k;
         return k;
     }
@@ -1081,12 +1111,22 @@ struct TextBuffer {
 };
 } // namespace
 
+static int renderThreads() { // hal2maf's rendering threads per batch (HGX_MAF_RENDER_THREADS; the walk is one thread beside them)
+    static const int n = getenv("HGX_MAF_RENDER_THREADS") ? std::max(1, atoi(getenv("HGX_MAF_RENDER_THREADS"))) : 32;
+    return n;
+}
+static double g_mafRenderWait = 0; // (HGX_MAF_TIMING: how long the walk stood waiting for the batch before to be rendered)
 void MafExport::RunMachine::flush(const PRow *current) {
-    M.waitPendingWrite();
+    {
+        const auto tw = std::chrono::steady_clock::now();
+        M.waitPendingWrite();
+        g_mafRenderWait += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
+    }
     if (batch->blocks.empty())
         return;
     std::shared_ptr<Batch> work(batch.release());
     batch.reset(new Batch);
+    entsLogged = false;
     if (chunk)
         batch->chunks.push_back(chunk); // (still being walked)
     if (!work->extra.empty() && work->extra.back().get() == current) { // (made by advance for the block to come: no event of this batch points to it)
@@ -1112,7 +1152,7 @@ void MafExport::RunMachine::flush(const PRow *current) {
         static const PairTable fwd2(fwd, false), rc2(rc, true);
         const size_t nb = work->blocks.size();
         unsigned nt = std::thread::hardware_concurrency();
-        nt = std::max(1u, std::min(nt ? nt : 1u, 16u));
+        nt = std::max(1u, std::min(nt ? nt : 1u, (unsigned)renderThreads()));
         if (nb < 256)
             nt = 1;
         // (the rendering threads' buffers are kept from batch to batch: thirty megabytes of fresh pages per batch were as many page
@@ -1146,6 +1186,7 @@ void MafExport::RunMachine::flush(const PRow *current) {
             };
             std::vector<RowOut> rows;
             std::vector<Entry::Seg> segs;
+            std::vector<const PRow *> given;
             for (size_t b = nb * t / nt; b < nb * (t + 1) / nt; ++b) {
                 const BlockLog &B = work->blocks[b];
                 const EventLog *ev = work->events.data() + B.firstEvent;
@@ -1154,12 +1195,19 @@ void MafExport::RunMachine::flush(const PRow *current) {
                 int64_t columns = 0;
                 for (uint32_t e = 0; e < B.numEvents; ++e)
                     columns += ev[e].k;
+                // which base every entry was given at every event (the walk logs the other direction)
+                given.assign((size_t)B.numEvents * B.numEnts, nullptr);
+                for (uint32_t e = 0; e < B.numEvents; ++e) {
+                    const uint32_t *idx = work->rowEnt.data() + ev[e].firstIdx;
+                    for (uint32_t r = 0; r < ev[e].nRows; ++r)
+                        given[(size_t)e * B.numEnts + idx[r]] = ev[e].rows + r;
+                }
                 // appendColumn / updateEntry (halMafBlock.cpp:114-138, 370-395) for every entry, the row kept as runs
                 for (uint32_t j = 0; j < B.numEnts; ++j) {
                     RowOut r{NULL_INDEX, 0, (uint32_t)segs.size(), 0, false};
                     const int64_t srcLength = (*ranks)[(size_t)work->entRank[B.firstEnt + j]].srcLength;
                     for (uint32_t e = 0; e < B.numEvents; ++e) {
-                        const PRow *p = work->pairs[ev[e].firstPair + j];
+                        const PRow *p = given[(size_t)e * B.numEnts + j];
                         const int64_t k = ev[e].k;
                         const uint8_t kind = !p ? 0 : (p->rev ? 2 : 1);
                         if (p) {
@@ -1275,8 +1323,26 @@ void MafExport::RunMachine::flush(const PRow *current) {
             for (std::thread &x : th)
                 x.join();
         }
+        // the parts into the output: side by side where the stream's buffer gives room for all of them at once
+        size_t total = 0;
         for (unsigned t = 0; t < nt; ++t)
-            out->write(text[t].data, (std::streamsize)text[t].len);
+            total += text[t].len;
+        char *dst = nullptr;
+        if (BulkSink *sink = dynamic_cast<BulkSink *>(out->rdbuf()))
+            dst = nt > 1 && total >= (1u << 20) ? sink->room(total) : nullptr;
+        if (dst) {
+            std::vector<std::thread> th;
+            size_t at = 0;
+            for (unsigned t = 0; t < nt; ++t) {
+                th.emplace_back([&text, dst, at, t]() { memcpy(dst + at, text[t].data, text[t].len); });
+                at += text[t].len;
+            }
+            for (std::thread &x : th)
+                x.join();
+        } else {
+            for (unsigned t = 0; t < nt; ++t)
+                out->write(text[t].data, (std::streamsize)text[t].len);
+        }
         std::lock_guard<std::mutex> lock(pool->mu);
         if (pool->idle.size() < 4)
             pool->idle.push_back(std::move(held));
@@ -1416,7 +1482,9 @@ void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alig
         if (getenv("HGX_MAF_TIMING"))
             std::cerr << "[hgx maf] columns " << length << " heads " << numHeads << " blocks " << numBlocks << " state machine + waits "
                       << std::chrono::duration<double>(std::chrono::steady_clock::now() - tStart).count() << " s, of which waiting for the device "
-                      << waitSeconds << " s (fetches " << fetchSeconds << " s, device " << stats.rows_ms + stats.depth_ms << " ms)" << std::endl;
+                      << waitSeconds << " s (fetches " << fetchSeconds << " s, device " << stats.rows_ms + stats.depth_ms << " ms), for the rendering of the batch before "
+                      << g_mafRenderWait << " s" << std::endl;
+        g_mafRenderWait = 0;
     }
     waitPendingWrite();
     mafStream.flush();

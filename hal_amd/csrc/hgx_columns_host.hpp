@@ -12,6 +12,14 @@
 
 namespace hgx {
 
+// A stream buffer that can give room for a stretch of text at once (the C ABI's output buffer, hgx_capi.cpp): hal2maf's rendering
+// threads copy their parts of a batch into it side by side instead of one after the other through ostream::write.
+struct BulkSink {
+    virtual char *room(size_t n) = 0; // n bytes at the end of the text, counted as written; null: no room (write them the usual way)
+    virtual ~BulkSink() {}
+};
+
+
 // halAlignmentDepth: writes the wig text of printGenome.  sequence = -1: all sequences of the genome.
 void alignmentDepth(std::ostream &os, hgx_alignment *h, int genome, int sequence, const std::set<int> &targetSet, int64_t start,
                     int64_t length, int64_t step, bool countDupes, bool noAncestors, ColumnStats *stats = nullptr,
