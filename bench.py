@@ -10,7 +10,9 @@ A "step" = one pass of the device-resident liftover over the whole interval batc
 classify against the merged whole-path table, per-interval overlap breaking + merging + ordering, totals, record
 compaction.  With --gpus N every rank lifts its own 1 M-interval shard against a replicated image (weak scaling,
 no collective on the mapping path); collating every rank's records on every rank with an all-gather (RCCL) is
-measured beside as `collated`, or inside the timed step with --exchange-in-step 1.
+measured beside as `collated` (and the gather to one writer rank as `collated_to_writer`), or inside the timed step with
+--exchange-in-step 1.  Those two legs run last, under a watchdog: their collectives have not met a multi-GPU node yet, and a hang or
+an error there must not cost the line.
 
 Prints one JSON line (rank 0).  `roofline` is for the kernel with the largest device time; `cpu_baseline` times the
 oracle (bit-identical CPU restatement of the reference, oracle/) on a bounded sample of the same workload.
@@ -458,8 +460,9 @@ def main():
                                 "on every rank, which the links bound (%.1f MB per rank and step)" % (wire["bytes"] / 1e6)}
 
     # ---- N ranks without an exchange in the step: the same steps with every rank's records collated on every rank ----
-    collated = None
-    if synced and not exchanging and world > 1:
+    # (these two legs carry collectives that no multi-GPU node has run yet: they are made at the very end, under a watchdog, so that
+    # whatever happens to them the line with everything else is printed — see the end of main)
+    def leg_collated():
         def step_collated():
             plan.run(d_gs, d_ge, d_st)
             exchange.wait()
@@ -478,7 +481,7 @@ def main():
         dist.barrier()
         tc = torch.tensor([time.perf_counter() - t0c], dtype=torch.float64, device=dev)
         dist.all_reduce(tc, op=dist.ReduceOp.MAX)
-        collated = {"value": world * nq * args.steps / float(tc.item()), "unit": "intervals/s", "ms_per_step": 1e3 * float(tc.item()) / args.steps,
+        return {"value": world * nq * args.steps / float(tc.item()), "unit": "intervals/s", "ms_per_step": 1e3 * float(tc.item()) / args.steps,
                     "wire_format_bytes_per_record": wire["format"], "wire_MB_per_rank_and_step": wire["bytes"] / 1e6,
                     "what": "the same steps (one plan per rank) each followed by one all-gather of every rank's records of the batch to every "
                             "rank (%s), overlapped with the next batches: bound by the links, not by the kernels; not part of `value`"
@@ -486,8 +489,7 @@ def main():
 
     # ---- the same steps with every rank's records gathered on rank 0 only, in the 8-byte form: what a writer of the BED file needs
     # (a rank sends its blob once; nobody receives N of them) ----
-    to_writer = None
-    if synced and (world > 1 or args.exchange_selftest):
+    def leg_to_writer():
         wx = shard.SlotExchange(world, rank, exchange.slot, dev, backend=args.exchange, comm=exchange.comm, root=0, bed_only=True)
 
         def step_to_writer():
@@ -507,13 +509,14 @@ def main():
         dist.barrier()
         tw = torch.tensor([time.perf_counter() - t0w], dtype=torch.float64, device=dev)
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-        to_writer = {"value": world * nq * args.steps / float(tw.item()), "unit": "intervals/s", "ms_per_step": 1e3 * float(tw.item()) / args.steps,
+        res = {"value": world * nq * args.steps / float(tw.item()), "unit": "intervals/s", "ms_per_step": 1e3 * float(tw.item()) / args.steps,
                      "wire_format_bytes_per_record": wx.last_format, "wire_MB_per_rank_and_step": wx.last_bytes / 1e6,
                      "what": "the same steps (one plan per rank) each followed by a gather of the ranks' records of the batch to rank 0 only "
                              "(%s), 8 bytes a record (no source coordinates: what a writer of BED lines needs), overlapped with the next batches; "
                              "not part of `value`" % ("hgx_liftover_gather: RCCL send / recv from the library" if args.exchange == "c_abi"
                                                       else "torch.distributed.gather")}
         del wx
+        return res
 
     # ---- sustained: the same step for a couple of seconds (a region long enough for outside observers: rocm-smi, the driver) ----
     sustained = None
@@ -806,14 +809,6 @@ def main():
                                        "kernels when the batches rotate past the Infinity Cache")
         if mapping_only:
             out["mapping_only"] = mapping_only
-        if collated:
-            out["collated"] = collated
-            # BASELINE config 4 names the all-gatherv as part of its workload: its number is the collated one, quoted beside `value`
-            out["config4_as_stated"] = {"value": collated["value"], "unit": "intervals/s", "ms_per_step": collated["ms_per_step"],
-                                        "what": "`collated`: every step's records gathered on every rank (RCCL all-gather of wire blobs); "
-                                                "`value` is the same steps without it"}
-        if to_writer:
-            out["collated_to_writer"] = to_writer
         out["timed_step"] = "map+allgather" if exchanging else "map_only"
         out["config"]["batches_in_flight"] = in_flight
         if col_result:
@@ -1014,9 +1009,42 @@ def main():
                                    "parity_with_gpu": gpu_text == text}
             if multi:
                 out["cpu_baseline"]["all_cores"] = multi
-        result_line = json.dumps(out)
     else:
-        result_line = None
+        out = None
+    # ---- the collated legs, last and under a watchdog: a collective that hangs or fails here costs these legs, not the line ----
+    want_collated = synced and not exchanging and world > 1
+    want_writer = synced and (world > 1 or bool(args.exchange_selftest))
+    if want_collated or want_writer:
+        import threading
+        finished = threading.Event()
+
+        def give_up():
+            if finished.wait(180.0):
+                return
+            if out is not None:
+                out["collated_legs"] = "timed out after 180 s: not measured"
+                sys.stdout.flush()
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        threading.Thread(target=give_up, daemon=True).start()
+        legs = {}
+        try:
+            if want_collated:
+                legs["collated"] = leg_collated()
+            if want_writer:
+                legs["collated_to_writer"] = leg_to_writer()
+        except Exception as e:  # (every rank fails alike on a call that is not there; a hang is the watchdog's)
+            legs["collated_legs_error"] = "%s: %s" % (type(e).__name__, e)
+        finished.set()
+        if out is not None:
+            for k, v in legs.items():
+                out[k] = v
+            if "collated" in legs:
+                # BASELINE config 4 names the all-gatherv as part of its workload: its number is the collated one, quoted beside `value`
+                out["config4_as_stated"] = {"value": legs["collated"]["value"], "unit": "intervals/s", "ms_per_step": legs["collated"]["ms_per_step"],
+                                            "what": "`collated`: every step's records gathered on every rank (RCCL all-gather of wire blobs); "
+                                                    "`value` is the same steps without it"}
+    result_line = json.dumps(out) if out is not None else None
     if synced:
         dist.destroy_process_group()
     # the JSON line is the last thing on stdout: whatever C libraries have buffered (RCCL prints its version banner through
