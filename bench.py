@@ -918,7 +918,7 @@ def main():
             out["end_to_end"] = {"what": "hgx_liftover_convert = Liftover::convert: BED6 text of the batch in host memory -> lifted BED text "
                                          "in host memory (tokenise, H2D, kernels, D2H, render; PCIe inclusive, never `value`); best of 3",
                                  "value": nq / best_t, "unit": "intervals/s", "seconds": best_t, "lines_in": nq, "lines_out": out_lines,
-                                 "bytes_in": len(bed), "bytes_out": out_bytes, "host_threads": min(32, os.cpu_count() or 1)}
+                                 "bytes_in": len(bed), "bytes_out": out_bytes, "host_threads": min(64, os.cpu_count() or 1)}
         if args.features and want_maf:
             # the other entry points of the path, each as a number: halGetBlocksInTargetRange (a browser's call: latency per call and
             # ranges per second when a call carries many), hal2maf --unique (what hal2mafMP.py runs every slice with), --maxRefGap,

@@ -16,6 +16,9 @@
 // earlier lines) — returns false and takes the general path of hgx_liftover_host.cpp.
 #include "hgx_textmem.hpp"
 #include "hgx_liftover_host.hpp"
+#include <mutex>
+#include <functional>
+#include <condition_variable>
 #include <algorithm>
 #include <atomic>
 #include <charconv>
@@ -275,12 +278,73 @@ void renderChunk(Chunk &C, const hgx_record *recs, size_t nRecs, const GenomeTab
     out.resize(used);
 }
 
+// The threads of the text path's phases are kept (a call has three phases of a few milliseconds each: thirty-one threads made and
+// joined per phase were a fifth of the call).  One job at a time: a caller that finds the pool at work makes threads of its own.
+struct TextPool {
+    std::mutex jobMu, mu;
+    std::condition_variable wake, done;
+    std::vector<std::thread> workers;
+    const std::function<void()> *work = nullptr;
+    unsigned generation = 0, want = 0, running = 0;
+    void worker(unsigned idx) {
+        unsigned seen = 0;
+        for (;;) {
+            const std::function<void()> *w = nullptr;
+            {
+                std::unique_lock<std::mutex> lock(mu);
+                wake.wait(lock, [&] { return generation != seen; });
+                seen = generation;
+                if (idx < want)
+                    w = work;
+            }
+            if (!w)
+                continue;
+            (*w)();
+            std::lock_guard<std::mutex> lock(mu);
+            if (--running == 0)
+                done.notify_all();
+        }
+    }
+    // work() on `threads` threads, this one among them; false: the pool is busy (nothing was run)
+    bool run(unsigned threads, const std::function<void()> &w) {
+        std::unique_lock<std::mutex> job(jobMu, std::try_to_lock);
+        if (!job.owns_lock())
+            return false;
+        if (threads > 1) {
+            std::lock_guard<std::mutex> lock(mu);
+            while (workers.size() + 1 < threads) {
+                const unsigned idx = (unsigned)workers.size();
+                workers.emplace_back([this, idx] { worker(idx); });
+                workers.back().detach();
+            }
+            work = &w;
+            want = threads - 1;
+            running = want;
+            ++generation;
+        }
+        if (threads > 1)
+            wake.notify_all();
+        w();
+        if (threads > 1) {
+            std::unique_lock<std::mutex> lock(mu);
+            done.wait(lock, [&] { return running == 0; });
+        }
+        return true;
+    }
+};
+TextPool &textPool() {
+    static TextPool *p = new TextPool; // (never destroyed: its threads wait for work until the process ends)
+    return *p;
+}
+
 template <typename F> void forEachChunk(std::vector<Chunk> &chunks, unsigned threads, F f) {
     std::atomic<size_t> next{0};
-    auto work = [&]() {
+    const std::function<void()> work = [&]() {
         for (size_t i; (i = next.fetch_add(1)) < chunks.size();)
             f(chunks[i]);
     };
+    if (textPool().run(threads, work))
+        return;
     std::vector<std::thread> pool;
     for (unsigned t = 1; t < threads; ++t)
         pool.emplace_back(work);
@@ -310,7 +374,8 @@ bool liftoverTextFast(hgx_alignment *const *als, int nAls, int srcGenome, const 
     };
     const auto t0 = now();
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const unsigned threads = (unsigned)std::min<size_t>(std::min(hw, 32u), len / (1u << 18) + 1);
+    static const unsigned maxThreads = getenv("HGX_TEXT_THREADS") ? (unsigned)std::max(1, atoi(getenv("HGX_TEXT_THREADS"))) : 64u;
+    const unsigned threads = (unsigned)std::min<size_t>(std::min(hw, maxThreads), len / (1u << 18) + 1);
     // chunks: about four per thread, cut behind a newline; no chunk larger than 16 MB of text, so that a device batch (whole
     // chunks, at most batchLines intervals: below) stays bounded on inputs of any size
     std::vector<Chunk> chunks;
@@ -431,12 +496,15 @@ bool liftoverTextFast(hgx_alignment *const *als, int nAls, int srcGenome, const 
             }
         auto forMine = [&](auto f) {
             std::atomic<size_t> next{0};
-            auto work = [&]() {
+            const std::function<void()> work = [&]() {
                 for (size_t i; (i = next.fetch_add(1)) < mine.size();)
                     f(*mine[i]);
             };
+            const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, mine.size()));
+            if (textPool().run(nt, work))
+                return;
             std::vector<std::thread> pool;
-            for (unsigned t = 1; t < threads && t < mine.size(); ++t)
+            for (unsigned t = 1; t < nt; ++t)
                 pool.emplace_back(work);
             work();
             for (std::thread &t : pool)
