@@ -257,6 +257,11 @@ struct hgx_alignment {
         size_t capR = 0;
         void *dS = nullptr, *dE = nullptr, *dT = nullptr;
         size_t capD = 0;
+        // (the 8-byte form of the records for a caller that prints BED lines: device words, pinned words and offsets, a flag)
+        void *dPacked = nullptr, *dFlag = nullptr;
+        uint32_t *packed = nullptr, *first = nullptr;
+        unsigned int *flagHost = nullptr;
+        size_t capP = 0, capF = 0;
     } stage;
     ~hgx_alignment();
 };

@@ -33,8 +33,16 @@ void liftoverBatchHostRaw(hgx_alignment *h, int src, int tgt, size_t n, const hg
 // end -1) ...
 void liftoverStageQueries(hgx_alignment *h, size_t n, int64_t **gs, int64_t **ge, uint8_t **strand);
 // ... and the run over what was written into them: *recs (pinned, owned by the alignment, valid until the next staged run)
+// packed (optional): a caller that only prints BED lines takes the records in the 8-byte form of the wire (hgx.h: format 8: tgt_start,
+// length | tgt_seq << 22 | strand code << 29 | reversed << 31) with the first record of every interval — 30 MB across PCIe for a
+// million intervals instead of 130 — whenever the batch fits that form and the plan writes its records densely with their offsets (the
+// single-pass path); then *recs is null and packed->words is not.
+struct PackedRecords {
+    const uint32_t *words = nullptr; // two per record
+    const uint32_t *first = nullptr; // n + 1 entries: interval q's records are [first[q], first[q + 1])
+};
 void liftoverBatchStaged(hgx_alignment *h, int src, int tgt, size_t n, const hgx_liftover_opts &opts, const hgx_record **recs, size_t *nRecs,
-                         hgx_liftover_stats *stats);
+                         hgx_liftover_stats *stats, PackedRecords *packed = nullptr);
 // the table of the whole path src -> dst with dupes (hgx_device.hpp: ComposedUp, through), built on first use; null when the
 // pair cannot have one
 const ComposedUp *wholePathTable(hgx_alignment *h, int src, int dst, int coalescenceLimit);

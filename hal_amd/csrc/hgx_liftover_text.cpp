@@ -210,22 +210,69 @@ void parseChunk(Chunk &C, int forcedType, const std::unordered_map<std::string, 
     }
 }
 
+// what a line needs of a record, from the record itself or from its 8-byte form (liftoverBatchStaged: PackedRecords)
+struct RecView {
+    int64_t tgt_start, tgt_end;
+    int32_t tgt_seq;
+    char strand;
+};
+struct RecCursor {
+    const hgx_record *r = nullptr, *rEnd = nullptr; // the records as they are, sorted by query ...
+    const uint32_t *words = nullptr, *first = nullptr; // ... or packed, with every interval's first record
+    size_t at = 0, end = 0;
+    void seek(int64_t query) {
+        if (words) {
+            at = first[query];
+            end = first[query + 1];
+        }
+    }
+    bool next(int64_t query, RecView &v) {
+        if (words) {
+            if (at == end)
+                return false;
+            const uint32_t a = words[2 * at], b = words[2 * at + 1];
+            ++at;
+            v.tgt_start = (int64_t)a;
+            v.tgt_end = (int64_t)a + (int64_t)(b & ((1u << 22) - 1u));
+            v.tgt_seq = (int32_t)((b >> 22) & 127u);
+            v.strand = "+-."[(b >> 29) & 3u];
+            return true;
+        }
+        if (r == rEnd || r->query != query)
+            return false;
+        v.tgt_start = r->tgt_start;
+        v.tgt_end = r->tgt_end;
+        v.tgt_seq = r->tgt_seq;
+        v.strand = r->strand;
+        ++r;
+        return true;
+    }
+};
+
 // BedLine::write (halBedLine.cpp:104-151) with what BlockLiftover::liftInterval and Liftover::cleanResults substitute
-void renderChunk(Chunk &C, const hgx_record *recs, size_t nRecs, const GenomeTables &T) {
+void renderChunk(Chunk &C, const hgx_record *recs, size_t nRecs, const PackedRecords &packed, const GenomeTables &T) {
     if (C.numQueries == 0)
         return;
-    // the chunk's records: queries [firstQuery, firstQuery + numQueries), the records are sorted by query
-    const hgx_record *r = std::lower_bound(recs, recs + nRecs, (int64_t)C.firstQuery, [](const hgx_record &a, int64_t q) { return a.query < q; });
-    const hgx_record *rEnd = recs + nRecs;
+    RecCursor cur;
+    if (packed.words) {
+        cur.words = packed.words;
+        cur.first = packed.first;
+    } else {
+        // the chunk's records: queries [firstQuery, firstQuery + numQueries), the records are sorted by query
+        cur.r = std::lower_bound(recs, recs + nRecs, (int64_t)C.firstQuery, [](const hgx_record &a, int64_t q) { return a.query < q; });
+        cur.rEnd = recs + nRecs;
+    }
     const int bt = C.bedType;
     std::string &out = C.out;
     size_t used = 0;
     out.resize(1 << 16);
+    RecView rec{};
     for (const Line &L : C.lines) {
         if (L.query < 0)
             continue;
         const bool thick = bt > 6 && (L.thickStart != 0 || L.thickEnd != 0);
-        for (; r < rEnd && r->query == L.query; ++r) {
+        cur.seek(L.query);
+        for (const RecView *r = &rec; cur.next(L.query, rec);) {
             const std::string &chrom = T.seqs[(size_t)r->tgt_seq].name;
             const size_t need = chrom.size() + L.len + 200;
             if (out.size() - used < need)
@@ -528,6 +575,7 @@ bool liftoverTextFast(hgx_alignment *const *als, int nAls, int srcGenome, const 
         });
         const auto r1 = now();
         std::vector<const hgx_record *> recs((size_t)nAls, nullptr);
+        std::vector<PackedRecords> packedRecs((size_t)nAls);
         std::vector<size_t> nRecs((size_t)nAls, 0);
         std::vector<hgx_liftover_stats> devStats((size_t)nAls);
         std::vector<std::string> devError((size_t)nAls);
@@ -537,7 +585,7 @@ bool liftoverTextFast(hgx_alignment *const *als, int nAls, int srcGenome, const 
                     return;
                 try {
                     liftoverBatchStaged(als[d], srcGenome, tgtGenome, grp[(size_t)d]->numQueries, opts, &recs[(size_t)d], &nRecs[(size_t)d],
-                                        &devStats[(size_t)d]);
+                                        &devStats[(size_t)d], &packedRecs[(size_t)d]);
                 } catch (std::exception &e) {
                     devError[(size_t)d] = e.what();
                 }
@@ -574,7 +622,7 @@ bool liftoverTextFast(hgx_alignment *const *als, int nAls, int srcGenome, const 
         const auto r2 = now();
         forMine([&](Chunk &C) {
             if (C.numQueries && devError[(size_t)C.device].empty())
-                renderChunk(C, recs[(size_t)C.device], nRecs[(size_t)C.device], T);
+                renderChunk(C, recs[(size_t)C.device], nRecs[(size_t)C.device], packedRecs[(size_t)C.device], T);
             std::vector<Line>().swap(C.lines); // (the tokens of a rendered chunk are not needed any more)
         });
         const auto r3 = now();
