@@ -139,11 +139,16 @@ void MafExport::buildRanks() {
         order[i] = (int)i;
     std::sort(order.begin(), order.end(), [&](int a, int b) { return img.genomes[(size_t)a].name < img.genomes[(size_t)b].name; });
     _rank.assign(img.genomes.size(), std::vector<int>());
+    _rankGenome.clear();
+    _rankSeq.clear();
     int r = 0;
     for (int g : order) {
         _rank[(size_t)g].resize(img.genomes[(size_t)g].seqs.size());
-        for (size_t s = 0; s < img.genomes[(size_t)g].seqs.size(); ++s)
+        for (size_t s = 0; s < img.genomes[(size_t)g].seqs.size(); ++s) {
             _rank[(size_t)g][s] = r++;
+            _rankGenome.push_back(g);
+            _rankSeq.push_back((int)s);
+        }
     }
 }
 
@@ -762,18 +767,19 @@ struct MafTick {
     explicit MafTick(int s) : slot(s), t0(__builtin_ia32_rdtsc()) {}
     ~MafTick() { g_mafTicks[slot] += __builtin_ia32_rdtsc() - t0; }
 };
+#ifdef HGX_HOST_TICKS // (two rdtsc a scope: the walk's phases are a few hundred ticks a column)
 #define MAF_TICK(slot) MafTick mafTick##slot(slot)
 #else
 #define MAF_TICK(slot)
 #endif
+#else
+#define MAF_TICK(slot)
+#endif
 struct MafExport::RunMachine {
-    struct PRow { // a base of a column: what the walk and the renderers need of it
-        int64_t pos;      // genome coordinate
-        int64_t seqStart; // of its sequence
-        int64_t limit;    // columns the row can go on inside its sequence
-        int32_t rank, genome, seq;
-        uint32_t ord : 31; // its place in the column as the walk delivers it (the order of a sequence's bases in the column map)
-        uint32_t rev : 1;
+    struct PRow { // a base of a column: what the walk and the renderers need of it, sixteen bytes
+        int64_t key;  // 2 * (its place in its sequence, counted on its strand: an entry's start) + (reverse strand)
+        int32_t rank; // of its sequence (genome, sequence, the sequence's start and length: RankInfo)
+        uint32_t ord; // its place in the column as the walk delivers it (the order of a sequence's bases in the column map)
     };
     struct Chunk { // one device batch: which columns are heads, the heads' rows (sorted the way the column map holds them)
         int64_t done = 0, n = 0;
@@ -782,18 +788,9 @@ struct MafExport::RunMachine {
         std::vector<PRow> rows;
         double seconds = 0;
     };
-    struct Ent {
-        int32_t rank, genome, seq;
-        bool rev;
-        short lastUsed;
-        int64_t start, length, srcLength;
-    };
-    struct KeyRec {
-        int32_t rank, genome, seq;
-    };
     struct RankInfo {
-        int64_t nameId = -1, srcLength = 0;
-        int32_t genome = 0;
+        int64_t nameId = -1, srcLength = 0, seqStart = 0;
+        int32_t genome = 0, seq = 0;
     };
     struct BlockLog {
         uint32_t firstEnt, numEnts, firstEvent, numEvents;
@@ -812,6 +809,7 @@ struct MafExport::RunMachine {
         // (per event only which entry each BASE went to — a dozen words —, not a pointer per ENTRY of the block: the rendering
         // threads turn it round; the walk is the one thread everything waits for)
         std::vector<uint32_t> rowEnt;
+        size_t numIdx = 0; // (rowEnt is grown ahead of the walk; its first numIdx words are the log)
         std::vector<std::shared_ptr<Chunk>> chunks; // (what the events' rows point into)
         std::vector<std::unique_ptr<PRow[]>> extra;
     };
@@ -819,8 +817,18 @@ struct MafExport::RunMachine {
     std::ostream &os;
     const Image &img;
     int refRank; // the rank of the reference sequence of the column a block begins with (the column-by-column path sets it per column)
-    std::vector<Ent> ents;
-    std::vector<KeyRec> keys; // the column map's keys, the ones without bases in the current column among them
+    // The block's entries (MafBlock::_entries), sorted by the rank of their sequence, as the four things the walk asks of them,
+    // each in an array of its own.  Nothing is written into an entry when a block begins (resetEntries, halMafBlock.cpp:36-82,
+    // visits every entry): an entry says which block gave it a base last (elast), and what it holds — where its next base has to
+    // be, how long it is — counts only while that is the block being made.  Its age, the reference's _lastUsed, is how far that
+    // block lies back: "unused for more than ten blocks in a row" is block - elast >= 13 at the beginning of a block.
+    std::vector<int32_t> erank;
+    std::vector<int64_t> elast; // the block that gave the entry a base last (an entry made for a block that gave it none: the block before)
+    std::vector<int64_t> enext; // the key (PRow::key) its next base must have: 2 * (start + length) + strand
+    std::vector<int64_t> elen;  // its length
+    std::vector<int64_t> esrc;  // the length of its sequence
+    int64_t block = -1;         // the block being made, counted from 0 (-1: the entries are the ones the constructor found)
+    std::vector<int32_t> keys; // the column map's keys (ranks), the ones without bases in the current column among them
     std::vector<uint8_t> inKeys;
     std::shared_ptr<std::vector<RankInfo>> rankInfo;
     std::unique_ptr<Batch> batch;
@@ -839,34 +847,47 @@ struct MafExport::RunMachine {
         inKeys.assign(ranks, 0);
         for (auto &kv : M._entries) { // the block the other paths (and the sequence before) left
             const Entry &e = *kv.second;
-            ents.push_back(Ent{kv.first.rank, kv.first.genome, kv.first.seq, e.strand == '-', e.lastUsed, e.start, e.length, e.srcLength});
-            info(KeyRec{kv.first.rank, kv.first.genome, kv.first.seq});
+            esrc.push_back(info(kv.first.rank).srcLength);
+            erank.push_back(kv.first.rank);
+            const bool used = e.start != NULL_INDEX;
+            elast.push_back(used ? -1 : -2 - (int64_t)e.lastUsed);
+            enext.push_back(used ? ((e.start + e.length) << 1) | (e.strand == '-' ? 1 : 0) : 0);
+            elen.push_back(used ? e.length : 0);
             delete kv.second;
         }
         M._entries.clear();
         M._reference = nullptr;
     }
     ~RunMachine() { // the entries go back to the block the other paths (and the next sequence) go on with
-        for (const Ent &x : ents) {
+        for (size_t i = 0; i < erank.size(); ++i) {
+            const RankInfo &ri = (*rankInfo)[(size_t)erank[i]];
             Entry *e = new Entry;
-            e->genome = x.genome;
-            e->nameId = (uint32_t)(*rankInfo)[(size_t)x.rank].nameId;
+            e->genome = ri.genome;
+            e->nameId = (uint32_t)ri.nameId;
             e->name = M._names[e->nameId];
-            e->start = x.start;
-            e->length = x.length;
-            e->srcLength = x.srcLength;
-            e->strand = x.rev ? '-' : '+';
-            e->lastUsed = x.lastUsed;
-            M._entries.insert(M._entries.end(), Entries::value_type(Key{x.rank, x.genome, x.seq}, e));
+            e->srcLength = ri.srcLength;
+            if (elast[i] == block) {
+                e->length = elen[i];
+                e->start = (enext[i] >> 1) - elen[i];
+                e->strand = (enext[i] & 1) ? '-' : '+';
+                e->lastUsed = 0; // (whatever it was: the next block's resetEntries sets it to 0)
+            } else {
+                e->start = NULL_INDEX;
+                e->length = 0;
+                e->strand = '+';
+                e->lastUsed = (short)(block - 1 - elast[i]);
+            }
+            M._entries.insert(M._entries.end(), Entries::value_type(Key{erank[i], ri.genome, ri.seq}, e));
         }
         M._reference = nullptr; // (the next block begins with resetEntries)
         M._refIndex = NULL_INDEX;
     }
-    const RankInfo &info(const KeyRec &k) {
-        RankInfo &ri = (*rankInfo)[(size_t)k.rank];
+    const RankInfo &info(int32_t rank) {
+        RankInfo &ri = (*rankInfo)[(size_t)rank];
         if (ri.nameId < 0) { // initEntry's name (halMafBlock.cpp:84-112)
-            const GenomeTables &G = img.genomes[(size_t)k.genome];
-            const SeqInfo &S = G.seqs[(size_t)k.seq];
+            const int genome = M._rankGenome[(size_t)rank], seq = M._rankSeq[(size_t)rank];
+            const GenomeTables &G = img.genomes[(size_t)genome];
+            const SeqInfo &S = G.seqs[(size_t)seq];
             const std::string name = M._ucscNames ? G.name + "." + S.name : S.name;
             auto it = M._nameIds.find(name);
             if (it == M._nameIds.end()) {
@@ -875,28 +896,27 @@ struct MafExport::RunMachine {
             }
             ri.nameId = it->second;
             ri.srcLength = S.length;
-            ri.genome = k.genome;
+            ri.seqStart = S.start;
+            ri.genome = genome;
+            ri.seq = seq;
         }
         return ri;
     }
-    Ent newEnt(const KeyRec &k) { return Ent{k.rank, k.genome, k.seq, false, 0, NULL_INDEX, 0, info(k).srcLength}; }
     // device rows -> PRows, every column's sorted by rank (stable): done by the thread that fetches, beside the walk
     static void describe(const Image &img, const std::vector<std::vector<int>> &rank, PRow &p, int genome, int64_t pos, bool rev, uint32_t ord) {
         const GenomeTables &G = img.genomes[(size_t)genome];
         const int s = G.seqs.size() == 1 ? 0 : G.seqIndexBySite(pos);
         const SeqInfo &S = G.seqs[(size_t)s];
-        p.pos = pos;
-        p.seqStart = S.start;
-        p.limit = rev ? pos - S.start : S.start + S.length - 1 - pos;
+        const int64_t at = pos - S.start;
+        p.key = rev ? ((S.length - 1 - at) << 1) | 1 : at << 1; // initEntry with a base (halMafBlock.cpp:84-112): start and strand
         p.rank = rank[(size_t)genome][(size_t)s];
-        p.genome = genome;
-        p.seq = s;
         p.ord = ord;
-        p.rev = rev ? 1 : 0;
     }
     // by sequence, a sequence's bases in the walk's order (a handful of rows: insertion sort)
     static void sortColumn(PRow *r, size_t n) {
         for (size_t i = 1; i < n; ++i) {
+            if (r[i - 1].rank < r[i].rank || (r[i - 1].rank == r[i].rank && r[i - 1].ord <= r[i].ord))
+                continue;
             const PRow x = r[i];
             size_t j = i;
             for (; j > 0 && (r[j - 1].rank > x.rank || (r[j - 1].rank == x.rank && r[j - 1].ord > x.ord)); --j)
@@ -910,124 +930,121 @@ struct MafExport::RunMachine {
                 continue;
             inKeys[(size_t)rows[i].rank] = 1;
             size_t ki = 0;
-            while (ki < keys.size() && keys[ki].rank < rows[i].rank)
+            while (ki < keys.size() && keys[ki] < rows[i].rank)
                 ++ki;
-            keys.insert(keys.begin() + (std::ptrdiff_t)ki, KeyRec{rows[i].rank, rows[i].genome, rows[i].seq});
+            keys.insert(keys.begin() + (std::ptrdiff_t)ki, rows[i].rank);
         }
     }
     void defragment(const PRow *rows, size_t n) { // ColumnIterator::defragment (halColumnIterator.cpp:193-208): keys without bases go
-        for (const KeyRec &k : keys)
-            inKeys[(size_t)k.rank] = 0;
+        for (const int32_t k : keys)
+            inKeys[(size_t)k] = 0;
         keys.clear();
         for (size_t i = 0; i < n; ++i)
             if (i == 0 || rows[i].rank != rows[i - 1].rank) {
-                keys.push_back(KeyRec{rows[i].rank, rows[i].genome, rows[i].seq});
+                keys.push_back(rows[i].rank);
                 inKeys[(size_t)rows[i].rank] = 1;
             }
     }
-    void initBlock(const PRow *rows, size_t n, int64_t refPos) {
+    void insertEntry(size_t at, int32_t rank) { // an empty entry for the sequence (initEntry without a base)
+        esrc.insert(esrc.begin() + (std::ptrdiff_t)at, info(rank).srcLength);
+        erank.insert(erank.begin() + (std::ptrdiff_t)at, rank);
+        elast.insert(elast.begin() + (std::ptrdiff_t)at, block - 1);
+        enext.insert(enext.begin() + (std::ptrdiff_t)at, 0);
+        elen.insert(elen.begin() + (std::ptrdiff_t)at, 0);
+    }
+    uint32_t *idxRoom(size_t n) { // where the pairing of the next n bases is logged
+        Batch &b = *batch;
+        if (b.numIdx + n > b.rowEnt.size())
+            b.rowEnt.resize(std::max(b.rowEnt.size() * 2, b.numIdx + n + 4096));
+        return b.rowEnt.data() + b.numIdx;
+    }
+    // MafBlock::initBlock (halMafBlock.cpp:294-367) after resetEntries (:36-82); idx[i]: the entry base i is given to
+    void initBlock(const PRow *rows, size_t n, int64_t refPos, uint32_t *idx) {
         MAF_TICK(1);
-        size_t w = 0; // resetEntries
-        bool changed = false;
-        for (size_t i = 0; i < ents.size(); ++i) {
-            Ent &e = ents[i];
-            if (e.start == NULL_INDEX) {
-                if (e.lastUsed > 10) {
-                    changed = true;
-                    continue; // unused for more than 10 consecutive blocks: dropped
-                }
-                ++e.lastUsed;
-            } else {
-                e.lastUsed = 0;
-            }
-            e.start = NULL_INDEX;
-            e.rev = false;
-            e.length = 0;
-            if (w != i)
-                ents[w] = e;
+        ++block;
+        size_t ne = erank.size(), w = 0;
+        for (size_t i = 0; i < ne; ++i) { // resetEntries: an entry unused for more than 10 blocks in a row is dropped
+            if (block - elast[i] >= 13)
+                continue;
+            erank[w] = erank[i];
+            elast[w] = elast[i]; // (no entry holds anything of the block to come)
+            esrc[w] = esrc[i];
             ++w;
         }
-        if (w != ents.size())
-            ents.resize(w);
+        bool changed = w != ne;
+        if (changed) {
+            erank.resize(w);
+            elast.resize(w);
+            enext.resize(w);
+            elen.resize(w);
+            esrc.resize(w);
+        }
         size_t oi = 0, ei = 0;
-        for (const KeyRec &k : keys) {
-            while (ei < ents.size() && ents[ei].rank < k.rank)
+        for (const int32_t k : keys) {
+            while (ei < erank.size() && erank[ei] < k)
                 ++ei;
-            if (oi == n || rows[oi].rank != k.rank) { // a key without bases: an empty entry for it, if it has none
-                if (ei == ents.size() || ents[ei].rank != k.rank) {
-                    ents.insert(ents.begin() + (std::ptrdiff_t)ei, newEnt(k));
+            if (oi == n || rows[oi].rank != k) { // a key without bases: an empty entry for it, if it has none
+                if (ei == erank.size() || erank[ei] != k) {
+                    insertEntry(ei, k);
                     changed = true;
                 }
                 continue;
             }
-            for (; oi < n && rows[oi].rank == k.rank; ++oi, ++ei) {
-                if (ei == ents.size() || ents[ei].rank != k.rank) {
-                    ents.insert(ents.begin() + (std::ptrdiff_t)ei, newEnt(k));
+            for (; oi < n && rows[oi].rank == k; ++oi, ++ei) {
+                if (ei == erank.size() || erank[ei] != k) {
+                    insertEntry(ei, k);
                     changed = true;
                 }
-                setFromRow(ents[ei], rows[oi]);
+                idx[oi] = (uint32_t)ei;
             }
         }
+        ne = erank.size();
 #ifdef HGX_HOST_PROFILE
-        g_mafTicks[8] += ents.size();
+        g_mafTicks[8] += ne;
         g_mafTicks[9] += n;
         g_mafTicks[10] += keys.size();
 #endif
         // the entries' ranks: logged once per change of the set (most blocks have the entries of the block before)
         if (changed || !entsLogged) {
             lastFirstEnt = (uint32_t)batch->entRank.size();
-            batch->entRank.resize(lastFirstEnt + ents.size());
-            int32_t *o = batch->entRank.data() + lastFirstEnt;
-            for (size_t i = 0; i < ents.size(); ++i)
-                o[i] = ents[i].rank;
+            batch->entRank.insert(batch->entRank.end(), erank.begin(), erank.end());
             entsLogged = true;
         }
         cur.firstEnt = lastFirstEnt;
-        cur.numEnts = (uint32_t)ents.size();
+        cur.numEnts = (uint32_t)ne;
         cur.firstEvent = (uint32_t)batch->events.size();
         cur.numEvents = 0;
         size_t r = refHint; // (where the reference's entry was in the block before)
-        if (r >= ents.size() || ents[r].rank != refRank) {
+        if (r >= ne || erank[r] != refRank) {
             r = 0;
-            while (r < ents.size() && ents[r].rank < refRank)
+            while (r < ne && erank[r] < refRank)
                 ++r;
-            if (r == ents.size() || ents[r].rank != refRank)
+            if (r == ne || erank[r] != refRank)
                 r = 0;
         } else {
-            while (r > 0 && ents[r - 1].rank == refRank) // (several entries of the sequence: the first one)
+            while (r > 0 && erank[r - 1] == refRank) // (several entries of the sequence: the first one)
                 --r;
         }
         refHint = r;
-        cur.refEnt = ents.empty() ? -1 : (int32_t)r;
-        cur.refIndex = !ents.empty() && ents[r].rank == refRank ? refPos : NULL_INDEX;
+        cur.refEnt = ne == 0 ? -1 : (int32_t)r;
+        cur.refIndex = ne != 0 && erank[r] == refRank ? refPos : NULL_INDEX;
     }
-    static void setFromRow(Ent &e, const PRow &row) { // initEntry with a base
-        e.start = row.pos - row.seqStart;
-        e.length = 0;
-        e.rev = row.rev != 0;
-        if (row.rev)
-            e.start = e.srcLength - 1 - e.start;
-    }
-    bool canAppend(const PRow *rows, size_t n) const {
+    // MafBlock::canAppendColumn (halMafBlock.cpp:401-450) with appendColumn's pairing (:370-395): the i-th base of a sequence
+    // goes with the i-th entry of the sequence; an entry that has bases goes on only where it ended, on its strand, below the length limit
+    bool pair(const PRow *rows, size_t n, uint32_t *idx) const {
         MAF_TICK(2);
+        const size_t ne = erank.size();
+        const int32_t *er = erank.data();
         size_t ei = 0;
         for (size_t i = 0; i < n; ++i) {
-            const PRow &row = rows[i];
-            while (ei < ents.size() && ents[ei].rank != row.rank)
+            const int32_t rank = rows[i].rank;
+            while (ei < ne && er[ei] < rank)
                 ++ei;
-            if (ei == ents.size())
+            if (ei == ne || er[ei] != rank)
                 return false;
-            const Ent &entry = ents[ei];
-            if (entry.start != NULL_INDEX) {
-                if (entry.length >= M._maxBlockLength || (entry.length > 0 && entry.rev != (row.rev != 0)))
-                    return false;
-                int64_t pos = row.pos - row.seqStart;
-                if (row.rev)
-                    pos = entry.srcLength - 1 - pos;
-                if (pos - entry.start != entry.length)
-                    return false;
-            }
-            ++ei;
+            if (elast[ei] == block && (elen[ei] >= M._maxBlockLength || enext[ei] != rows[i].key))
+                return false;
+            idx[i] = (uint32_t)ei++;
         }
         return true;
     }
@@ -1039,45 +1056,52 @@ struct MafExport::RunMachine {
     // through MafExport::convertSequence's loop body (halMafExport.cpp:60-79); returns how many columns were placed: as many
     // as fit before a block-length limit (canAppendColumn: length >= maxLength breaks) or the end of a row's sequence
     int64_t place(const PRow *rows, size_t n, int64_t left, int64_t refPos) {
+        uint32_t *idx = idxRoom(n);
         if (appendCount == 0) {
-            initBlock(rows, n, refPos);
-        } else if (!canAppend(rows, n)) {
+            initBlock(rows, n, refPos, idx);
+        } else if (!pair(rows, n, idx)) {
             endBlock();
             if (numBlocks++ % 1000 == 0)
                 defragment(rows, n);
-            if (batch->blocks.size() >= 32768)
+            if (batch->blocks.size() >= 32768) {
                 flush(rows);
-            initBlock(rows, n, refPos);
+                idx = idxRoom(n);
+            }
+            initBlock(rows, n, refPos, idx);
         }
         MAF_TICK(3);
-        const size_t firstIdx = batch->rowEnt.size();
-        batch->rowEnt.resize(firstIdx + n);
-        uint32_t *idx = batch->rowEnt.data() + firstIdx;
+        const int64_t maxLength = M._maxBlockLength;
         int64_t k = left;
-        size_t ei = 0;
-        for (size_t i = 0; i < n; ++i) { // the pairing appendColumn performs
-            while (ents[ei].rank != rows[i].rank)
-                ++ei;
-            idx[i] = (uint32_t)ei;
-            k = std::min(k, 1 + std::max<int64_t>(0, M._maxBlockLength - (ents[ei].length + 1)));
-            k = std::min(k, 1 + rows[i].limit);
-            ++ei;
-        }
         for (size_t i = 0; i < n; ++i) {
-            Ent &e = ents[idx[i]];
-            if (e.start == NULL_INDEX)
-                setFromRow(e, rows[i]);
-            e.length += k;
+            const uint32_t e = idx[i];
+            const int64_t length = elast[e] == block ? elen[e] : 0;
+            k = std::min(k, 1 + std::max<int64_t>(0, maxLength - (length + 1)));
+            k = std::min(k, esrc[e] - (rows[i].key >> 1)); // (the columns the base can go on inside its sequence, itself among them)
         }
-        batch->events.push_back(EventLog{k, rows, (uint32_t)firstIdx, (uint32_t)n});
+        for (size_t i = 0; i < n; ++i) { // appendColumn, k columns at once
+            const uint32_t e = idx[i];
+            if (elast[e] != block) {
+                elast[e] = block;
+                elen[e] = 0;
+                enext[e] = rows[i].key;
+            }
+            elen[e] += k;
+            enext[e] += 2 * k;
+        }
+        batch->events.push_back(EventLog{k, rows, (uint32_t)batch->numIdx, (uint32_t)n});
+        batch->numIdx += n;
         appendCount += (size_t)k;
         return k;
     }
     // the bases k columns on (a column that has to go through the per-column logic in the middle of a run)
     const PRow *advance(const PRow *rows, size_t n, int64_t k) {
         std::unique_ptr<PRow[]> next(new PRow[n]);
-        for (size_t i = 0; i < n; ++i)
-            describe(img, M._rank, next[i], rows[i].genome, rows[i].pos + (rows[i].rev ? -k : k), rows[i].rev != 0, rows[i].ord);
+        for (size_t i = 0; i < n; ++i) { // (k bases on along its strand: that may be the genome's next sequence)
+            const RankInfo &ri = info(rows[i].rank);
+            const bool rev = (rows[i].key & 1) != 0;
+            const int64_t q = rows[i].key >> 1, pos = ri.seqStart + (rev ? ri.srcLength - 1 - q : q);
+            describe(img, M._rank, next[i], ri.genome, pos + (rev ? -k : k), rev, rows[i].ord);
+        }
         sortColumn(next.get(), n);
         batch->extra.push_back(std::move(next));
         return batch->extra.back().get();
@@ -1205,21 +1229,20 @@ void MafExport::RunMachine::flush(const PRow *current) {
                 // appendColumn / updateEntry (halMafBlock.cpp:114-138, 370-395) for every entry, the row kept as runs
                 for (uint32_t j = 0; j < B.numEnts; ++j) {
                     RowOut r{NULL_INDEX, 0, (uint32_t)segs.size(), 0, false};
-                    const int64_t srcLength = (*ranks)[(size_t)work->entRank[B.firstEnt + j]].srcLength;
+                    const RankInfo &ri = (*ranks)[(size_t)work->entRank[B.firstEnt + j]];
                     for (uint32_t e = 0; e < B.numEvents; ++e) {
                         const PRow *p = given[(size_t)e * B.numEnts + j];
                         const int64_t k = ev[e].k;
-                        const uint8_t kind = !p ? 0 : (p->rev ? 2 : 1);
+                        const uint8_t kind = !p ? 0 : ((p->key & 1) ? 2 : 1);
                         if (p) {
                             if (r.start == NULL_INDEX) {
-                                r.start = p->pos - p->seqStart;
-                                r.rev = p->rev != 0;
-                                if (p->rev)
-                                    r.start = srcLength - 1 - r.start;
+                                r.start = p->key >> 1;
+                                r.rev = (p->key & 1) != 0;
                             }
                             r.length += k;
                         }
-                        const int64_t pos = p ? p->pos : 0;
+                        // (the base's genome coordinate: the packed DNA is read there)
+                        const int64_t pos = !p ? 0 : ri.seqStart + ((p->key & 1) ? ri.srcLength - 1 - (p->key >> 1) : p->key >> 1);
                         if (segs.size() > r.firstSeg) {
                             Entry::Seg &l = segs.back();
                             if (l.kind == kind && (int64_t)l.n + k < INT32_MAX &&
@@ -1428,16 +1451,30 @@ void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alig
     };
     double fetchSeconds = 0, waitSeconds = 0;
     size_t numHeads = 0, numBlocks = 0;
+    std::deque<std::shared_ptr<Chunk>> ahead;
+#ifdef HGX_HOST_PROFILE
+    if (mafReplayFile() && getenv("HGX_MAF_REPLAY_AHEAD")) // (the walk by itself: every batch is there before it begins)
+        for (int64_t done = 0; done < length; done += ahead.back()->n)
+            ahead.push_back(fetch(done));
+#endif
     const auto tStart = std::chrono::steady_clock::now();
     {
         RunMachine R(*this, mafStream, _rank[(size_t)genome][(size_t)seq]);
-        std::future<std::shared_ptr<Chunk>> next = std::async(std::launch::async, fetch, (int64_t)0);
+        std::future<std::shared_ptr<Chunk>> next;
+        if (ahead.empty())
+            next = std::async(std::launch::async, fetch, (int64_t)0);
         for (int64_t done = 0; done < length;) {
             const auto tw = std::chrono::steady_clock::now();
-            std::shared_ptr<Chunk> c = next.get();
+            std::shared_ptr<Chunk> c;
+            if (!ahead.empty()) {
+                c = ahead.front();
+                ahead.pop_front();
+            } else {
+                c = next.get();
+            }
             waitSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
             const int64_t n = c->n;
-            if (done + n < length)
+            if (done + n < length && ahead.empty())
                 next = std::async(std::launch::async, fetch, done + n);
             fetchSeconds += c->seconds;
             numHeads += c->headOff.size() - 1;

@@ -114,6 +114,7 @@ class MafExport {
     int64_t _refIndex = NULL_INDEX;
     hgx_alignment *_al = nullptr;
     std::vector<std::vector<int>> _rank; // [genome][sequence] -> order of ColumnIterator::SequenceLess
+    std::vector<int> _rankGenome, _rankSeq; // and back
     void buildRanks();
     Key keyOf(int genome, int64_t pos) const;
     void resetEntries();

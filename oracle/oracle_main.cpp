@@ -339,10 +339,16 @@ static int cmdColumnRows(int argc, char **argv) {
     std::vector<std::string> pos;
     i64 maxInsertLength = 0;
     bool noDupes = false, noAncestors = false, unique = false;
+    std::string batches;
+    i64 chunk = 1 << 21;
     for (int i = 0; i < argc; ++i) {
         std::string a = argv[i];
         if (a == "--maxRefGap")
             maxInsertLength = atoll(argv[++i]);
+        else if (a == "--batches") // the columns as a recording of device batches instead of text (below)
+            batches = argv[++i];
+        else if (a == "--chunk")
+            chunk = atoll(argv[++i]);
         else if (a == "--noDupes")
             noDupes = true;
         else if (a == "--noAncestors")
@@ -361,6 +367,71 @@ static int cmdColumnRows(int argc, char **argv) {
     if (ref < 0) {
         std::cerr << "genome not found" << std::endl;
         return 1;
+    }
+    if (!batches.empty()) {
+        // A profiling aid for hal2maf's host side on a machine without a GPU: the plain export's columns (no --unique, no
+        // --maxRefGap) in the layout the library's profiling build records its device batches in (hal_amd/csrc/hgx_columns_host.cpp:
+        // HGX_MAF_DUMP / HGX_MAF_REPLAY; make hostprof-lib) — per chunk of columns {first column, columns, heads + 1, rows}, a byte
+        // per column (1: the column does not continue the one before base by base), the heads' row offsets, the heads' rows
+        // {position, genome, reversed} in the column map's order.
+        if (unique || maxInsertLength != 0)
+            throw std::runtime_error("--batches: the plain export's columns only");
+        struct Row {
+            i64 pos;
+            int32_t genome;
+            uint8_t rev;
+            char base;
+            uint8_t pad[2];
+        };
+        static_assert(sizeof(Row) == 16, "ColumnRowHost");
+        std::ofstream out(batches, std::ios::binary);
+        std::vector<uint8_t> head;
+        std::vector<uint32_t> headOff(1, 0);
+        std::vector<Row> rows, prev, cur;
+        i64 done = 0, total = 0;
+        auto flushChunk = [&]() {
+            const uint64_t hd[4] = {(uint64_t)done, (uint64_t)head.size(), headOff.size(), rows.size()};
+            out.write((const char *)hd, 32);
+            out.write((const char *)head.data(), (std::streamsize)head.size());
+            out.write((const char *)headOff.data(), (std::streamsize)(4 * headOff.size()));
+            out.write((const char *)rows.data(), (std::streamsize)(16 * rows.size()));
+            done += (i64)head.size();
+            head.clear();
+            headOff.assign(1, 0);
+            rows.clear();
+        };
+        for (const Sequence &Sq : al.genomes[(size_t)ref].seqs) { // (an export of its own per sequence, as hal2maf makes them)
+            if (Sq.length == 0)
+                continue;
+            ColumnIterator col(&al, ref, nullptr, Sq.start, Sq.start + Sq.length - 1, noDupes, noAncestors, false, false, 0);
+            done = 0;
+            prev.clear();
+            for (;;) {
+                cur.clear();
+                for (auto &kv : col.colMap)
+                    for (const Dna &d : kv.second)
+                        cur.push_back(Row{d.pos, (int32_t)d.g, (uint8_t)(d.rev ? 1 : 0), 'N', {0, 0}});
+                bool continues = !head.empty() && cur.size() == prev.size();
+                for (size_t i = 0; continues && i < cur.size(); ++i)
+                    continues = cur[i].genome == prev[i].genome && cur[i].rev == prev[i].rev && cur[i].pos == prev[i].pos + (cur[i].rev ? -1 : 1);
+                head.push_back(continues ? 0 : 1);
+                if (!continues) {
+                    rows.insert(rows.end(), cur.begin(), cur.end());
+                    headOff.push_back((uint32_t)rows.size());
+                }
+                prev.swap(cur);
+                if ((i64)head.size() == chunk)
+                    flushChunk();
+                if (col.lastColumn())
+                    break;
+                col.toRight();
+            }
+            if (!head.empty())
+                flushChunk();
+            total += done;
+        }
+        std::cerr << "columns " << total << std::endl;
+        return 0;
     }
     const Sequence &S = al.genomes[(size_t)ref].seqs[0];
     ColumnIterator col(&al, ref, nullptr, S.start, S.start + S.length - 1, noDupes, noAncestors, false, unique, maxInsertLength);
