@@ -819,15 +819,19 @@ struct MafExport::RunMachine {
     int refRank; // the rank of the reference sequence of the column a block begins with (the column-by-column path sets it per column)
     // The block's entries (MafBlock::_entries), sorted by the rank of their sequence, as the four things the walk asks of them,
     // each in an array of its own.  Nothing is written into an entry when a block begins (resetEntries, halMafBlock.cpp:36-82,
-    // visits every entry): an entry says which block gave it a base last (elast), and what it holds — where its next base has to
+    // visits every entry): an entry says which block gave it a base last, and what it holds — where its next base has to
     // be, how long it is — counts only while that is the block being made.  Its age, the reference's _lastUsed, is how far that
-    // block lies back: "unused for more than ten blocks in a row" is block - elast >= 13 at the beginning of a block.
+    // block lies back: "unused for more than ten blocks in a row" is block - last >= 13 at the beginning of a block.
+    struct Ent {
+        int64_t next; // the key (PRow::key) its next base must have: 2 * (start + length) + strand
+        int64_t len;  // its length
+        int64_t src;  // the length of its sequence
+    };
     std::vector<int32_t> erank;
-    std::vector<int64_t> elast; // the block that gave the entry a base last (an entry made for a block that gave it none: the block before)
-    std::vector<int64_t> enext; // the key (PRow::key) its next base must have: 2 * (start + length) + strand
-    std::vector<int64_t> elen;  // its length
-    std::vector<int64_t> esrc;  // the length of its sequence
-    int64_t block = -1;         // the block being made, counted from 0 (-1: the entries are the ones the constructor found)
+    std::vector<int32_t> elast; // the block that gave the entry a base last (an entry made for a block that gave it none: the block before)
+    std::vector<Ent> ent;
+    std::vector<int32_t> firstOf;
+    int32_t block = -1; // the block being made, counted from 0 (-1: the entries are the ones the constructor found)
     std::vector<int32_t> keys; // the column map's keys (ranks), the ones without bases in the current column among them
     std::vector<uint8_t> inKeys;
     std::shared_ptr<std::vector<RankInfo>> rankInfo;
@@ -845,18 +849,18 @@ struct MafExport::RunMachine {
             ranks += r.size();
         rankInfo = std::make_shared<std::vector<RankInfo>>(ranks);
         inKeys.assign(ranks, 0);
+        firstOf.assign(ranks, -1);
         for (auto &kv : M._entries) { // the block the other paths (and the sequence before) left
             const Entry &e = *kv.second;
-            esrc.push_back(info(kv.first.rank).srcLength);
             erank.push_back(kv.first.rank);
             const bool used = e.start != NULL_INDEX;
-            elast.push_back(used ? -1 : -2 - (int64_t)e.lastUsed);
-            enext.push_back(used ? ((e.start + e.length) << 1) | (e.strand == '-' ? 1 : 0) : 0);
-            elen.push_back(used ? e.length : 0);
+            elast.push_back(used ? -1 : -2 - (int32_t)e.lastUsed);
+            ent.push_back(Ent{used ? ((e.start + e.length) << 1) | (e.strand == '-' ? 1 : 0) : 0, used ? e.length : 0, info(kv.first.rank).srcLength});
             delete kv.second;
         }
         M._entries.clear();
         M._reference = nullptr;
+        indexEntries();
     }
     ~RunMachine() { // the entries go back to the block the other paths (and the next sequence) go on with
         for (size_t i = 0; i < erank.size(); ++i) {
@@ -867,9 +871,9 @@ struct MafExport::RunMachine {
             e->name = M._names[e->nameId];
             e->srcLength = ri.srcLength;
             if (elast[i] == block) {
-                e->length = elen[i];
-                e->start = (enext[i] >> 1) - elen[i];
-                e->strand = (enext[i] & 1) ? '-' : '+';
+                e->length = ent[i].len;
+                e->start = (ent[i].next >> 1) - ent[i].len;
+                e->strand = (ent[i].next & 1) ? '-' : '+';
                 e->lastUsed = 0; // (whatever it was: the next block's resetEntries sets it to 0)
             } else {
                 e->start = NULL_INDEX;
@@ -926,7 +930,7 @@ struct MafExport::RunMachine {
     }
     void addKeys(const PRow *rows, size_t n) {
         for (size_t i = 0; i < n; ++i) {
-            if (inKeys[(size_t)rows[i].rank])
+            if ((i > 0 && rows[i].rank == rows[i - 1].rank) || inKeys[(size_t)rows[i].rank])
                 continue;
             inKeys[(size_t)rows[i].rank] = 1;
             size_t ki = 0;
@@ -946,11 +950,16 @@ struct MafExport::RunMachine {
             }
     }
     void insertEntry(size_t at, int32_t rank) { // an empty entry for the sequence (initEntry without a base)
-        esrc.insert(esrc.begin() + (std::ptrdiff_t)at, info(rank).srcLength);
         erank.insert(erank.begin() + (std::ptrdiff_t)at, rank);
         elast.insert(elast.begin() + (std::ptrdiff_t)at, block - 1);
-        enext.insert(enext.begin() + (std::ptrdiff_t)at, 0);
-        elen.insert(elen.begin() + (std::ptrdiff_t)at, 0);
+        ent.insert(ent.begin() + (std::ptrdiff_t)at, Ent{0, 0, info(rank).srcLength});
+        indexEntries();
+    }
+    void indexEntries() { // firstOf[rank]: the first entry of the sequence (of a sequence without entries: anything)
+        const size_t ne = erank.size();
+        for (size_t i = 0; i < ne; ++i)
+            if (i == 0 || erank[i] != erank[i - 1])
+                firstOf[(size_t)erank[i]] = (int32_t)i;
     }
     uint32_t *idxRoom(size_t n) { // where the pairing of the next n bases is logged
         Batch &b = *batch;
@@ -958,45 +967,57 @@ struct MafExport::RunMachine {
             b.rowEnt.resize(std::max(b.rowEnt.size() * 2, b.numIdx + n + 4096));
         return b.rowEnt.data() + b.numIdx;
     }
-    // MafBlock::initBlock (halMafBlock.cpp:294-367) after resetEntries (:36-82); idx[i]: the entry base i is given to
-    void initBlock(const PRow *rows, size_t n, int64_t refPos, uint32_t *idx) {
+    // MafBlock::initBlock (halMafBlock.cpp:294-367) after resetEntries (:36-82); idx[i]: the entry base i is given to; room: the
+    // columns the bases can go on inside their sequences
+    void initBlock(const PRow *rows, size_t n, int64_t refPos, uint32_t *idx, int64_t &room) {
         MAF_TICK(1);
         ++block;
-        size_t ne = erank.size(), w = 0;
-        for (size_t i = 0; i < ne; ++i) { // resetEntries: an entry unused for more than 10 blocks in a row is dropped
-            if (block - elast[i] >= 13)
-                continue;
-            erank[w] = erank[i];
-            elast[w] = elast[i]; // (no entry holds anything of the block to come)
-            esrc[w] = esrc[i];
-            ++w;
-        }
-        bool changed = w != ne;
-        if (changed) {
+        size_t ne = erank.size();
+        if (block == INT32_MAX)
+            throw std::runtime_error("hal2maf: more than 2^31 blocks in one export");
+        int32_t oldest = block;
+        for (size_t i = 0; i < ne; ++i)
+            oldest = std::min(oldest, elast[i]);
+        bool changed = false;
+        if (block - oldest >= 13) { // resetEntries: an entry unused for more than 10 blocks in a row is dropped
+            size_t w = 0;
+            for (size_t i = 0; i < ne; ++i) {
+                if (block - elast[i] >= 13)
+                    continue;
+                erank[w] = erank[i];
+                elast[w] = elast[i];
+                ent[w] = ent[i];
+                ++w;
+            }
             erank.resize(w);
             elast.resize(w);
-            enext.resize(w);
-            elen.resize(w);
-            esrc.resize(w);
+            ent.resize(w);
+            changed = true;
         }
-        size_t oi = 0, ei = 0;
+        if (changed)
+            indexEntries();
+        // every key of the column map — the sequences of this column's bases are among them — has an entry at least (the ones
+        // made here come first: a later one would move the entries the bases have been given)
         for (const int32_t k : keys) {
-            while (ei < erank.size() && erank[ei] < k)
-                ++ei;
-            if (oi == n || rows[oi].rank != k) { // a key without bases: an empty entry for it, if it has none
-                if (ei == erank.size() || erank[ei] != k) {
-                    insertEntry(ei, k);
-                    changed = true;
-                }
-                continue;
+            const size_t at = (uint32_t)firstOf[(size_t)k];
+            if (at >= erank.size() || erank[at] != k) {
+                insertEntry((size_t)(std::lower_bound(erank.begin(), erank.end(), k) - erank.begin()), k);
+                changed = true;
             }
-            for (; oi < n && rows[oi].rank == k; ++oi, ++ei) {
-                if (ei == erank.size() || erank[ei] != k) {
-                    insertEntry(ei, k);
-                    changed = true;
-                }
-                idx[oi] = (uint32_t)ei;
+        }
+        // the i-th base of a sequence goes with the sequence's i-th entry; entries that are missing are made behind the ones it has
+        size_t ei = 0;
+        int32_t rank = -1;
+        for (size_t i = 0; i < n; ++i) {
+            if (rows[i].rank != rank) {
+                rank = rows[i].rank;
+                ei = (uint32_t)firstOf[(size_t)rank];
+            } else if (++ei == erank.size() || erank[ei] != rank) {
+                insertEntry(ei, rank);
+                changed = true;
             }
+            idx[i] = (uint32_t)ei;
+            room = std::min(room, ent[ei].src - (rows[i].key >> 1));
         }
         ne = erank.size();
 #ifdef HGX_HOST_PROFILE
@@ -1031,21 +1052,36 @@ struct MafExport::RunMachine {
     }
     // MafBlock::canAppendColumn (halMafBlock.cpp:401-450) with appendColumn's pairing (:370-395): the i-th base of a sequence
     // goes with the i-th entry of the sequence; an entry that has bases goes on only where it ended, on its strand, below the length limit
-    bool pair(const PRow *rows, size_t n, uint32_t *idx) const {
+    bool pair(const PRow *rows, size_t n, uint32_t *idx, int64_t &room) const {
         MAF_TICK(2);
         const size_t ne = erank.size();
         const int32_t *er = erank.data();
+        const Ent *en = ent.data();
+        const int32_t *el = elast.data(), blk = block;
+        const int64_t maxLength = M._maxBlockLength;
+        int64_t most = room;
         size_t ei = 0;
+        int32_t rank = -1;
         for (size_t i = 0; i < n; ++i) {
-            const int32_t rank = rows[i].rank;
-            while (ei < ne && er[ei] < rank)
+            if (rows[i].rank != rank) {
+                rank = rows[i].rank;
+                ei = (uint32_t)firstOf[(size_t)rank];
+            } else {
                 ++ei;
-            if (ei == ne || er[ei] != rank)
+            }
+            if (ei >= ne || er[ei] != rank)
                 return false;
-            if (elast[ei] == block && (elen[ei] >= M._maxBlockLength || enext[ei] != rows[i].key))
-                return false;
-            idx[i] = (uint32_t)ei++;
+            const Ent &e = en[ei];
+            const int64_t key = rows[i].key;
+            if (el[ei] == blk) {
+                if (e.len >= maxLength || e.next != key)
+                    return false;
+                most = std::min(most, maxLength - e.len); // (appendColumn up to the length limit)
+            }
+            most = std::min(most, e.src - (key >> 1)); // (the columns the base can go on inside its sequence, itself among them)
+            idx[i] = (uint32_t)ei;
         }
+        room = most;
         return true;
     }
     void endBlock() {
@@ -1057,9 +1093,11 @@ struct MafExport::RunMachine {
     // as fit before a block-length limit (canAppendColumn: length >= maxLength breaks) or the end of a row's sequence
     int64_t place(const PRow *rows, size_t n, int64_t left, int64_t refPos) {
         uint32_t *idx = idxRoom(n);
+        // (an entry without bases takes one column at least; a column without bases limits nothing)
+        int64_t k = n == 0 ? left : std::min(left, std::max<int64_t>(1, M._maxBlockLength));
         if (appendCount == 0) {
-            initBlock(rows, n, refPos, idx);
-        } else if (!pair(rows, n, idx)) {
+            initBlock(rows, n, refPos, idx, k);
+        } else if (!pair(rows, n, idx, k)) {
             endBlock();
             if (numBlocks++ % 1000 == 0)
                 defragment(rows, n);
@@ -1067,26 +1105,21 @@ struct MafExport::RunMachine {
                 flush(rows);
                 idx = idxRoom(n);
             }
-            initBlock(rows, n, refPos, idx);
+            initBlock(rows, n, refPos, idx, k);
         }
         MAF_TICK(3);
-        const int64_t maxLength = M._maxBlockLength;
-        int64_t k = left;
-        for (size_t i = 0; i < n; ++i) {
-            const uint32_t e = idx[i];
-            const int64_t length = elast[e] == block ? elen[e] : 0;
-            k = std::min(k, 1 + std::max<int64_t>(0, maxLength - (length + 1)));
-            k = std::min(k, esrc[e] - (rows[i].key >> 1)); // (the columns the base can go on inside its sequence, itself among them)
-        }
+        Ent *en = ent.data();
+        int32_t *el = elast.data();
+        const int32_t blk = block;
         for (size_t i = 0; i < n; ++i) { // appendColumn, k columns at once
-            const uint32_t e = idx[i];
-            if (elast[e] != block) {
-                elast[e] = block;
-                elen[e] = 0;
-                enext[e] = rows[i].key;
+            Ent &e = en[idx[i]];
+            if (el[idx[i]] != blk) {
+                el[idx[i]] = blk;
+                e.len = 0;
+                e.next = rows[i].key;
             }
-            elen[e] += k;
-            enext[e] += 2 * k;
+            e.len += k;
+            e.next += 2 * k;
         }
         batch->events.push_back(EventLog{k, rows, (uint32_t)batch->numIdx, (uint32_t)n});
         batch->numIdx += n;
@@ -1495,9 +1528,22 @@ void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alig
                     ++i;
                     continue;
                 }
-                int64_t left = 1;
-                while (i + left < n && !c->head[(size_t)(i + left)])
-                    ++left;
+                int64_t left = 1; // (the columns up to the next head, eight bytes of the marks at a time)
+                {
+                    const uint8_t *hp = c->head.data();
+                    int64_t at = i + 1;
+                    for (; at + 8 <= n; at += 8) {
+                        uint64_t w;
+                        memcpy(&w, hp + at, 8);
+                        if (w) {
+                            at += __builtin_ctzll(w) >> 3;
+                            break;
+                        }
+                    }
+                    while (at < n && !hp[at])
+                        ++at;
+                    left = at - i;
+                }
                 int64_t col = i;
                 for (;;) {
                     R.addKeys(rows, nr);
