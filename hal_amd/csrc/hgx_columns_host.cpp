@@ -12,6 +12,8 @@
 #include <climits>
 #include <thread>
 #include <cstring>
+#include <condition_variable>
+#include <mutex>
 
 namespace hgx {
 
@@ -785,7 +787,7 @@ struct MafExport::RunMachine {
         int64_t done = 0, n = 0;
         std::vector<uint8_t> head;
         std::vector<uint32_t> headOff;
-        std::vector<PRow> rows;
+        std::unique_ptr<PRow[]> rows;
         double seconds = 0;
     };
     struct RankInfo {
@@ -1413,12 +1415,20 @@ void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alig
     const int64_t first = startPosition + G.seqs[(size_t)seq].start;
     if (const char *e = getenv("HGX_MAF_CHUNK")) // (columns per device batch: tests cross batch ends with it)
         chunkColumns = (size_t)std::max<long long>(1, atoll(e));
-    // (the next batch is walked by the device, copied and sorted while the state machine goes through this one)
-    auto fetch = [&](int64_t done) {
-        std::shared_ptr<Chunk> c(new Chunk);
+    // The batches come through two stages beside the walk: the device stage (the column kernels, the copies to the host: one call at
+    // a time, the next one begun as soon as this one is back, up to a few batches ahead of the walk) and the stage that describes and
+    // sorts a batch's rows for the walk (several threads a batch, beside the device stage of the batch behind it).
+    struct Raw {
+        std::shared_ptr<Chunk> c;
+        std::vector<ColumnRowHost> headRows;
+    };
+    auto deviceStage = [&](int64_t done) {
+        std::unique_ptr<Raw> raw(new Raw);
+        raw->c.reset(new Chunk);
+        Chunk *c = raw->c.get();
+        std::vector<ColumnRowHost> &headRows = raw->headRows;
         c->done = done;
         c->n = std::min<int64_t>((int64_t)chunkColumns, length - done);
-        std::vector<ColumnRowHost> headRows;
         const auto t0 = std::chrono::steady_clock::now();
         bool have = false;
 #ifdef HGX_HOST_PROFILE
@@ -1462,53 +1472,123 @@ void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alig
                 c->n = (int64_t)chunkColumns;
             }
         }
-        c->rows.resize(headRows.size());
+        c->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return raw;
+    };
+    auto describeStage = [this, alignment](std::shared_ptr<Raw> raw) {
+        const auto t0 = std::chrono::steady_clock::now();
+        Chunk *c = raw->c.get();
+        const std::vector<ColumnRowHost> &headRows = raw->headRows;
+        c->rows.reset(new PRow[headRows.size() ? headRows.size() : 1]); // (first touched by the threads that fill it)
         const size_t heads = c->headOff.size() - 1;
         auto convert = [&](size_t h0, size_t h1) {
             for (size_t h = h0; h < h1; ++h) {
                 for (size_t i = c->headOff[h]; i < c->headOff[h + 1]; ++i)
                     RunMachine::describe(alignment->img, _rank, c->rows[i], headRows[i].genome, headRows[i].pos, headRows[i].rev != 0,
                                          (uint32_t)(i - c->headOff[h]));
-                RunMachine::sortColumn(c->rows.data() + c->headOff[h], c->headOff[h + 1] - c->headOff[h]);
+                RunMachine::sortColumn(c->rows.get() + c->headOff[h], c->headOff[h + 1] - c->headOff[h]);
             }
         };
-        const size_t parts = heads >= 4096 ? 4 : 1;
+        const size_t parts = heads >= 32768 ? 8 : heads >= 4096 ? 4 : 1;
         std::vector<std::thread> helpers;
         for (size_t t = 1; t < parts; ++t)
             helpers.emplace_back(convert, heads * t / parts, heads * (t + 1) / parts);
         convert(0, heads / parts);
         for (std::thread &t : helpers)
             t.join();
-        c->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        return c;
+        c->seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return raw->c;
+    };
+    // the batches in flight, in order; the thread of the device stage keeps at most `ahead` of them beyond the one being walked
+    struct Pipe {
+        std::mutex mu;
+        std::condition_variable cv;
+        std::deque<std::future<std::shared_ptr<Chunk>>> ready;
+        size_t taken = 0, made = 0;
+        bool stop = false, done = false;
+        std::exception_ptr error;
+    } pipe;
+    size_t ahead = 4; // (batches made and not yet taken by the walk)
+#ifdef HGX_HOST_PROFILE
+    const bool wholeAhead = mafReplayFile() && getenv("HGX_MAF_REPLAY_AHEAD"); // (the walk by itself: every batch is there before it begins)
+    if (wholeAhead)
+        ahead = (size_t)-1;
+#endif
+    std::thread deviceThread([&]() {
+        try {
+            for (int64_t done = 0; done < length;) {
+                {
+                    std::unique_lock<std::mutex> lock(pipe.mu);
+                    pipe.cv.wait(lock, [&]() { return pipe.stop || pipe.made - pipe.taken < ahead; });
+                    if (pipe.stop)
+                        break;
+                }
+                std::shared_ptr<Raw> raw(deviceStage(done).release());
+                done += raw->c->n;
+                std::future<std::shared_ptr<Chunk>> f = std::async(std::launch::async, describeStage, raw);
+                std::lock_guard<std::mutex> lock(pipe.mu);
+                pipe.ready.push_back(std::move(f));
+                ++pipe.made;
+                pipe.cv.notify_all();
+            }
+        } catch (...) {
+            std::lock_guard<std::mutex> lock(pipe.mu);
+            pipe.error = std::current_exception();
+        }
+        std::lock_guard<std::mutex> lock(pipe.mu);
+        pipe.done = true;
+        pipe.cv.notify_all();
+    });
+    struct Join { // (whatever ends the walk ends the device stage's thread too)
+        Pipe &p;
+        std::thread &t;
+        ~Join() {
+            {
+                std::lock_guard<std::mutex> lock(p.mu);
+                p.stop = true;
+                p.cv.notify_all();
+            }
+            t.join();
+            for (auto &f : p.ready) // (stages still describing their batch)
+                if (f.valid())
+                    f.wait();
+        }
+    } join{pipe, deviceThread};
+    auto nextChunk = [&]() {
+        std::future<std::shared_ptr<Chunk>> f;
+        {
+            std::unique_lock<std::mutex> lock(pipe.mu);
+            pipe.cv.wait(lock, [&]() { return !pipe.ready.empty() || pipe.done; });
+            if (pipe.ready.empty()) {
+                if (pipe.error)
+                    std::rethrow_exception(pipe.error);
+                throw std::runtime_error("hal2maf: the batches ended before the columns did");
+            }
+            f = std::move(pipe.ready.front());
+            pipe.ready.pop_front();
+            ++pipe.taken;
+            pipe.cv.notify_all();
+        }
+        return f.get();
     };
     double fetchSeconds = 0, waitSeconds = 0;
     size_t numHeads = 0, numBlocks = 0;
-    std::deque<std::shared_ptr<Chunk>> ahead;
 #ifdef HGX_HOST_PROFILE
-    if (mafReplayFile() && getenv("HGX_MAF_REPLAY_AHEAD")) // (the walk by itself: every batch is there before it begins)
-        for (int64_t done = 0; done < length; done += ahead.back()->n)
-            ahead.push_back(fetch(done));
+    if (wholeAhead) {
+        std::unique_lock<std::mutex> lock(pipe.mu);
+        pipe.cv.wait(lock, [&]() { return pipe.done; });
+        for (auto &f : pipe.ready)
+            f.wait();
+    }
 #endif
     const auto tStart = std::chrono::steady_clock::now();
     {
         RunMachine R(*this, mafStream, _rank[(size_t)genome][(size_t)seq]);
-        std::future<std::shared_ptr<Chunk>> next;
-        if (ahead.empty())
-            next = std::async(std::launch::async, fetch, (int64_t)0);
         for (int64_t done = 0; done < length;) {
             const auto tw = std::chrono::steady_clock::now();
-            std::shared_ptr<Chunk> c;
-            if (!ahead.empty()) {
-                c = ahead.front();
-                ahead.pop_front();
-            } else {
-                c = next.get();
-            }
+            std::shared_ptr<Chunk> c = nextChunk();
             waitSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
             const int64_t n = c->n;
-            if (done + n < length && ahead.empty())
-                next = std::async(std::launch::async, fetch, done + n);
             fetchSeconds += c->seconds;
             numHeads += c->headOff.size() - 1;
             R.chunk = c;
@@ -1520,7 +1600,7 @@ void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alig
                     continue;
                 }
                 // head column i: its rows come from the device; the columns up to the next head continue it
-                const PRow *rows = c->rows.data() + c->headOff[hk];
+                const PRow *rows = c->rows.get() + c->headOff[hk];
                 const size_t nr = c->headOff[hk + 1] - c->headOff[hk];
                 ++hk;
                 if (c->head[(size_t)i] == 3) { // --unique: walked, not written (a reference base left of the range): its sequences stay
