@@ -72,3 +72,18 @@ def test_global_export_where_an_abandoned_walk_lies_under_a_paralogy_cycle(oracl
     env = dict(os.environ, HGX_LIB_PATH=lib, HGX_MAF_REPLAY=os.path.join(GOLD, "maf_global_batches.bin"))
     out = subprocess.run([sys.executable, "-c", GLOBAL_SCRIPT], env=env, check=True, stdout=subprocess.PIPE).stdout.decode()
     assert out.strip().splitlines()[-1].startswith("global same"), out
+
+
+def test_oracle_written_batches_through_the_host_state_machine(oracle_bin):
+    """The plain export's host side over batches the ORACLE writes (hal_oracle columns --batches: which columns are heads, the
+    heads' rows, cut into chunks of 1 .. 2^21 columns so that blocks, runs and sequences cross batch ends): random alignments with
+    several sequences a genome, every genome as the reference, --noDupes / --noAncestors / --maxBlockLen / --keepEmptyRefBlocks /
+    --onlySequenceNames; the text must be the oracle's (profiles/scripts/r04_cpu_maf_soak.py; profiles/r04y_cpu_maf_soak.txt has
+    the long runs)."""
+    lib = os.path.join(ROOT, "hal_amd", "libhgx_hostprof.so")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "hal_amd", "csrc"), "all", "hostprof-lib"])
+    assert os.path.exists(lib)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "scripts", "r04_cpu_maf_soak.py"), "7000", "12"],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT).stdout.decode()
+    last = out.strip().splitlines()[-1].split()
+    assert last[:2] == ["alignments", "12"] and int(last[3]) >= 60 and last[4:] == ["different", "0"], out
