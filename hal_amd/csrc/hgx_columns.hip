@@ -10,6 +10,7 @@
 #include <cstring>
 #include <functional>
 #include <memory>
+#include <mutex>
 #include <set>
 
 namespace hgx {
@@ -615,9 +616,110 @@ static uint32_t deviceScan(const uint32_t *in, uint32_t n, uint32_t *out, uint32
     return total;
 }
 
+// ---- page-locked host blocks for the large copies (hgx_columns_engine.hpp) ----
+namespace {
+struct HostBlockHeader { // in front of every block
+    size_t capacity; // bytes behind the header
+    uint32_t pinned; // hipHostMalloc'ed (else malloc'ed)
+    uint32_t magic;
+    char pad[48];
+};
+static_assert(sizeof(HostBlockHeader) == 64, "blocks stay 64-byte aligned");
+const uint32_t HOST_BLOCK_MAGIC = 0x48474258u;
+const size_t HOST_BLOCK_SMALL = (size_t)1 << 20, HOST_BLOCK_KEEP = 12, HOST_BLOCK_KEEP_BYTES = (size_t)4 << 30;
+struct HostBlockPool {
+    std::mutex mu;
+    std::vector<HostBlockHeader *> idle;
+    size_t idleBytes = 0;
+    bool noDevice = false; // (hipHostMalloc said so once: not asked again)
+};
+HostBlockPool &hostBlockPool() {
+    static HostBlockPool *pool = new HostBlockPool; // (never destroyed: blocks may be given back while the process ends)
+    return *pool;
+}
+} // namespace
+
+void *hostBlockTake(size_t bytes) {
+    if (bytes == 0)
+        bytes = 1;
+    HostBlockHeader *hd = nullptr;
+    if (bytes >= HOST_BLOCK_SMALL) {
+        HostBlockPool &pool = hostBlockPool();
+        bool tryPinned;
+        {
+            std::lock_guard<std::mutex> lock(pool.mu);
+            size_t best = pool.idle.size();
+            for (size_t i = 0; i < pool.idle.size(); ++i) // the smallest kept block that holds it (and is not four times too large)
+                if (pool.idle[i]->capacity >= bytes && pool.idle[i]->capacity / 4 <= bytes &&
+                    (best == pool.idle.size() || pool.idle[i]->capacity < pool.idle[best]->capacity))
+                    best = i;
+            if (best != pool.idle.size()) {
+                hd = pool.idle[best];
+                pool.idle.erase(pool.idle.begin() + (std::ptrdiff_t)best);
+                pool.idleBytes -= hd->capacity;
+                return hd + 1;
+            }
+            tryPinned = !pool.noDevice;
+        }
+        const size_t capacity = (bytes + bytes / 8 + ((size_t)4 << 20) - 1) & ~(((size_t)4 << 20) - 1); // (an eighth of slack, 4 MiB steps)
+        if (tryPinned) {
+            void *p = nullptr;
+            const hipError_t e = hipHostMalloc(&p, capacity + sizeof(HostBlockHeader), hipHostMallocPortable);
+            if (e == hipSuccess && p) {
+                hd = static_cast<HostBlockHeader *>(p);
+                hd->capacity = capacity;
+                hd->pinned = 1;
+                hd->magic = HOST_BLOCK_MAGIC;
+                return hd + 1;
+            }
+            (void)hipGetLastError();
+            if (e == hipErrorNoDevice || e == hipErrorInsufficientDriver || e == hipErrorNotInitialized || e == hipErrorInvalidDevice) {
+                std::lock_guard<std::mutex> lock(pool.mu);
+                pool.noDevice = true;
+            }
+        }
+        hd = static_cast<HostBlockHeader *>(aligned_alloc(64, (capacity + sizeof(HostBlockHeader) + 63) & ~(size_t)63));
+        if (!hd)
+            throw std::bad_alloc();
+        hd->capacity = capacity;
+        hd->pinned = 0;
+        hd->magic = HOST_BLOCK_MAGIC;
+        return hd + 1;
+    }
+    hd = static_cast<HostBlockHeader *>(aligned_alloc(64, (bytes + sizeof(HostBlockHeader) + 63) & ~(size_t)63));
+    if (!hd)
+        throw std::bad_alloc();
+    hd->capacity = bytes;
+    hd->pinned = 0;
+    hd->magic = HOST_BLOCK_MAGIC;
+    return hd + 1;
+}
+
+void hostBlockGive(void *p) noexcept {
+    if (!p)
+        return;
+    HostBlockHeader *hd = static_cast<HostBlockHeader *>(p) - 1;
+    if (hd->magic != HOST_BLOCK_MAGIC)
+        std::abort(); // (not one of ours: nothing sensible to do)
+    if (hd->capacity >= HOST_BLOCK_SMALL) {
+        HostBlockPool &pool = hostBlockPool();
+        std::lock_guard<std::mutex> lock(pool.mu);
+        if (pool.idle.size() < HOST_BLOCK_KEEP && pool.idleBytes + hd->capacity <= HOST_BLOCK_KEEP_BYTES) {
+            pool.idle.push_back(hd);
+            pool.idleBytes += hd->capacity;
+            return;
+        }
+    }
+    hd->magic = 0;
+    if (hd->pinned)
+        (void)hipHostFree(hd);
+    else
+        free(hd);
+}
+
 void columnsHeadRowsHost(hgx_alignment *h, int ref, int64_t first, int64_t count, const ColumnOptions &opt, bool withDna,
-                         std::vector<uint8_t> &head, std::vector<uint32_t> &headOffset, std::vector<ColumnRowHost> &headRows,
-                         ColumnStats *stats, int64_t uniqueFirst) {
+                         std::vector<uint8_t> &head, std::vector<uint32_t> &headOffset, HeadRows &headRows, ColumnStats *stats,
+                         int64_t uniqueFirst) {
     if (!h->dev)
         throw std::runtime_error("alignment was opened without a device (device = -1); the column engine needs the HIP path");
     HIP_OK(hipSetDevice(h->dev->device));
@@ -677,8 +779,13 @@ void columnsHeadRowsHost(hgx_alignment *h, int ref, int64_t first, int64_t count
         throw std::runtime_error("column walk exceeded the frame stack (more than 64 pending branches for one base)");
     head.resize(n);
     HIP_OK(hipMemcpy(head.data(), dHead.p, n, hipMemcpyDeviceToHost));
-    std::unique_ptr<uint32_t[]> headCnt(new uint32_t[n]); // (written by the copy: no need to clear it first)
-    HIP_OK(hipMemcpy(headCnt.get(), dHeadCnt.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    struct Counts { // (a page-locked block, written by the copy: no need to clear it first)
+        uint32_t *p;
+        explicit Counts(size_t n) : p(static_cast<uint32_t *>(hostBlockTake(n * 4))) {}
+        ~Counts() { hostBlockGive(p); }
+        uint32_t operator[](size_t i) const { return p[i]; }
+    } headCnt(n);
+    HIP_OK(hipMemcpy(headCnt.p, dHeadCnt.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     headRows.resize(totalHeadRows);
     if (totalHeadRows)
         HIP_OK(hipMemcpy(headRows.data(), dOut.p, (size_t)totalHeadRows * sizeof(ColumnRow), hipMemcpyDeviceToHost));

@@ -2,8 +2,10 @@
 #pragma once
 #include "../../include/hgx.h"
 #include "hgx_device.hpp"
+#include <new>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace hgx {
@@ -16,10 +18,32 @@ struct ColumnRowHost { // mirrors ColumnRow of hgx_column_kernels.hpp
     uint8_t _pad[2];
 };
 
+// Host memory the device's large copies land in: page-locked blocks (hipHostMalloc) kept in a small pool.  A copy into pageable
+// memory goes through the runtime's staging buffers at a fraction of the link's rate, and a fresh vector of a batch's rows is
+// cleared and page-faulted before it is overwritten: a config-3 export moves half a gigabyte of rows this way.  Requests below a
+// megabyte, and every request where there is no device (the profiling build's replay), are ordinary memory.
+void *hostBlockTake(size_t bytes); // never null (std::bad_alloc)
+void hostBlockGive(void *p) noexcept;
+template <class T> struct HostBlockAllocator {
+    typedef T value_type;
+    HostBlockAllocator() = default;
+    template <class U> HostBlockAllocator(const HostBlockAllocator<U> &) {}
+    T *allocate(size_t n) { return static_cast<T *>(hostBlockTake(n * sizeof(T))); }
+    void deallocate(T *p, size_t) noexcept { hostBlockGive(p); }
+    template <class U> void construct(U *p) { ::new (static_cast<void *>(p)) U; } // (not cleared: a copy fills it)
+    template <class U, class A0, class... A> void construct(U *p, A0 &&a0, A &&...a) {
+        ::new (static_cast<void *>(p)) U(std::forward<A0>(a0), std::forward<A>(a)...);
+    }
+    template <class U> bool operator==(const HostBlockAllocator<U> &) const { return true; }
+    template <class U> bool operator!=(const HostBlockAllocator<U> &) const { return false; }
+};
+
 struct ColumnOptions {
     bool noDupes = false, noAncestors = false, onlyOrthologs = false;
     std::vector<int> targets; // genome ids; empty = everything (halColumnIterator.cpp:45-51)
 };
+
+typedef std::vector<ColumnRowHost, HostBlockAllocator<ColumnRowHost>> HeadRows; // the heads' rows of a batch of columns
 
 // thrown by columnsHeadRowsHost when a chunk of columns holds 2^32 rows or more (its offsets are 32-bit): the caller halves
 // the chunk and asks again
@@ -69,7 +93,7 @@ void columnsGapRowsHost(hgx_alignment *h, int ref, const std::vector<GapAskHost>
 // head[c] == 3: walked but not written (its rows are returned: their sequences become keys of the column map); a written
 // column is a head or a continuation of the written column before it, as above.
 void columnsHeadRowsHost(hgx_alignment *h, int ref, int64_t first, int64_t count, const ColumnOptions &opt, bool withDna,
-                         std::vector<uint8_t> &head, std::vector<uint32_t> &headOffset, std::vector<ColumnRowHost> &headRows,
-                         ColumnStats *stats, int64_t uniqueFirst = -1);
+                         std::vector<uint8_t> &head, std::vector<uint32_t> &headOffset, HeadRows &headRows, ColumnStats *stats,
+                         int64_t uniqueFirst = -1);
 
 } // namespace hgx

@@ -1420,13 +1420,13 @@ void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alig
     // sorts a batch's rows for the walk (several threads a batch, beside the device stage of the batch behind it).
     struct Raw {
         std::shared_ptr<Chunk> c;
-        std::vector<ColumnRowHost> headRows;
+        HeadRows headRows;
     };
     auto deviceStage = [&](int64_t done) {
         std::unique_ptr<Raw> raw(new Raw);
         raw->c.reset(new Chunk);
         Chunk *c = raw->c.get();
-        std::vector<ColumnRowHost> &headRows = raw->headRows;
+        HeadRows &headRows = raw->headRows;
         c->done = done;
         c->n = std::min<int64_t>((int64_t)chunkColumns, length - done);
         const auto t0 = std::chrono::steady_clock::now();
@@ -1478,7 +1478,7 @@ void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alig
     auto describeStage = [this, alignment](std::shared_ptr<Raw> raw) {
         const auto t0 = std::chrono::steady_clock::now();
         Chunk *c = raw->c.get();
-        const std::vector<ColumnRowHost> &headRows = raw->headRows;
+        const HeadRows &headRows = raw->headRows;
         c->rows.reset(new PRow[headRows.size() ? headRows.size() : 1]); // (first touched by the threads that fill it)
         const size_t heads = c->headOff.size() - 1;
         auto convert = [&](size_t h0, size_t h1) {
@@ -1837,7 +1837,8 @@ void MafExport::convertSequence(std::ostream &mafStream, hgx_alignment *alignmen
         size_t numHeads = 0;
         std::vector<uint8_t> head;
         std::vector<uint32_t> headOff;
-        std::vector<ColumnRowHost> headRows, curRows;
+        HeadRows headRows;
+        std::vector<ColumnRowHost> curRows;
         struct Pair {
             Entry *e;
             ColumnRowHost *row; // null: entry gets a gap
