@@ -787,7 +787,10 @@ struct MafExport::RunMachine {
         int64_t done = 0, n = 0;
         std::vector<uint8_t> head;
         std::vector<uint32_t> headOff;
-        std::unique_ptr<PRow[]> rows;
+        struct GiveBack {
+            void operator()(PRow *p) const { hostBlockGive(p); }
+        };
+        std::unique_ptr<PRow[], GiveBack> rows; // (a block of the pool the device's copies use: touched before, not paged in again)
         double seconds = 0;
     };
     struct RankInfo {
@@ -814,7 +817,44 @@ struct MafExport::RunMachine {
         size_t numIdx = 0; // (rowEnt is grown ahead of the walk; its first numIdx words are the log)
         std::vector<std::shared_ptr<Chunk>> chunks; // (what the events' rows point into)
         std::vector<std::unique_ptr<PRow[]>> extra;
+        void reset() { // (the arrays keep their memory)
+            blocks.clear();
+            entRank.clear();
+            events.clear();
+            numIdx = 0;
+            chunks.clear();
+            extra.clear();
+        }
     };
+    // A batch's log is tens of megabytes written once by the walk: taken fresh, every page of it is a fault in the one thread
+    // everything waits for.  Rendered batches come back here and are written over.
+    struct BatchPool {
+        std::mutex mu;
+        std::vector<std::unique_ptr<Batch>> idle;
+    };
+    static BatchPool &batchPool() {
+        static BatchPool *pool = new BatchPool;
+        return *pool;
+    }
+    static std::unique_ptr<Batch> takeBatch() {
+        BatchPool &pool = batchPool();
+        {
+            std::lock_guard<std::mutex> lock(pool.mu);
+            if (!pool.idle.empty()) {
+                std::unique_ptr<Batch> b = std::move(pool.idle.back());
+                pool.idle.pop_back();
+                return b;
+            }
+        }
+        return std::unique_ptr<Batch>(new Batch);
+    }
+    static void giveBatch(std::unique_ptr<Batch> b) {
+        b->reset();
+        BatchPool &pool = batchPool();
+        std::lock_guard<std::mutex> lock(pool.mu);
+        if (pool.idle.size() < 3)
+            pool.idle.push_back(std::move(b));
+    }
     MafExport &M;
     std::ostream &os;
     const Image &img;
@@ -845,7 +885,7 @@ struct MafExport::RunMachine {
     uint32_t lastFirstEnt = 0;
     size_t refHint = 0;
 
-    RunMachine(MafExport &m, std::ostream &o, int refRank_) : M(m), os(o), img(m._al->img), refRank(refRank_), batch(new Batch) {
+    RunMachine(MafExport &m, std::ostream &o, int refRank_) : M(m), os(o), img(m._al->img), refRank(refRank_), batch(takeBatch()) {
         size_t ranks = 0;
         for (const std::vector<int> &r : M._rank)
             ranks += r.size();
@@ -887,6 +927,8 @@ struct MafExport::RunMachine {
         }
         M._reference = nullptr; // (the next block begins with resetEntries)
         M._refIndex = NULL_INDEX;
+        if (batch)
+            giveBatch(std::move(batch));
     }
     const RankInfo &info(int32_t rank) {
         RankInfo &ri = (*rankInfo)[(size_t)rank];
@@ -1183,8 +1225,8 @@ void MafExport::RunMachine::flush(const PRow *current) {
     }
     if (batch->blocks.empty())
         return;
-    std::shared_ptr<Batch> work(batch.release());
-    batch.reset(new Batch);
+    std::shared_ptr<Batch> work(batch.release(), [](Batch *b) { giveBatch(std::unique_ptr<Batch>(b)); }); // (back to the pool when rendered)
+    batch = takeBatch();
     entsLogged = false;
     if (chunk)
         batch->chunks.push_back(chunk); // (still being walked)
@@ -1479,7 +1521,7 @@ void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alig
         const auto t0 = std::chrono::steady_clock::now();
         Chunk *c = raw->c.get();
         const HeadRows &headRows = raw->headRows;
-        c->rows.reset(new PRow[headRows.size() ? headRows.size() : 1]); // (first touched by the threads that fill it)
+        c->rows.reset(static_cast<PRow *>(hostBlockTake((headRows.size() ? headRows.size() : 1) * sizeof(PRow))));
         const size_t heads = c->headOff.size() - 1;
         auto convert = [&](size_t h0, size_t h1) {
             for (size_t h = h0; h < h1; ++h) {
