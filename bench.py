@@ -840,6 +840,21 @@ def main():
                                                    "(bench.py: sweep_design_bytes: the per-base genome-set tracks written and read once, the segment "
                                                    "records, the 4-byte depths).  traffic: k_sweep_up launches only; per-GPU figures when n_gpus > 1"}}
         if want_maf:
+            # halAlignmentDepth as the tool delivers it: the wig text of the whole genome in host memory (values over PCIe, the lines made
+            # by the host's threads)
+            try:
+                al.alignment_depth_bytes(src, length=min(al.genome_length(src), 2000000))
+                wruns = []
+                for _ in range(2):
+                    t0 = time.perf_counter()
+                    wbytes = al.alignment_depth_bytes(src)
+                    wruns.append(time.perf_counter() - t0)
+                out.setdefault("columns", {})["depth_wig"] = {"what": "hgx_alignment_depth end to end: wig text of %s's whole genome in host memory (PCIe inclusive); "
+                                                                      "the better of two" % src_name,
+                                                              "value": al.genome_length(src) / min(wruns), "unit": "columns/s", "seconds": min(wruns),
+                                                              "runs_seconds": wruns, "wig_bytes": wbytes}
+            except Exception as e:  # (a leg beside the line, not the line)
+                out.setdefault("columns", {})["depth_wig"] = {"error": str(e)[:300]}
             # BASELINE config 3: hal2maf --refGenome <leaf> --noAncestors, end to end (column kernels, row fetch, block state
             # machine, text rendering) over the first N reference columns
             ncols = min(args.maf_columns, al.genome_length(src))
@@ -906,6 +921,18 @@ def main():
                            "value": ncol4 / (ms4 * 1e-3), "unit": "columns/s", "columns": ncol4, "kernel_ms": ms4,
                            "mean_depth": float(d4.double().mean().item()),
                            "sweeps_own_bytes": sw4, "sweeps_own_GBs": sw4 / (ms4 * 1e-3) / 1e9, "sweeps_own_frac": sw4 / (ms4 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            # the same as the tool delivers it: wig text in host memory (values over PCIe, the lines made by the host's threads)
+            try:
+                al4.alignment_depth_bytes(s4, length=min(ncol4, 2000000))
+                wruns = []
+                for _ in range(2):
+                    t0 = time.perf_counter()
+                    wbytes = al4.alignment_depth_bytes(s4)
+                    wruns.append(time.perf_counter() - t0)
+                out["cfg5"]["wig"] = {"what": "hgx_alignment_depth end to end: the whole genome's wig text in host memory (PCIe inclusive); the better of two",
+                                      "value": ncol4 / min(wruns), "unit": "columns/s", "seconds": min(wruns), "runs_seconds": wruns, "wig_bytes": wbytes}
+            except Exception as e:  # (a leg beside the line, not the line)
+                out["cfg5"]["wig"] = {"error": str(e)[:300]}
             del al4, d4
         if args.text_path and world == 1 and not args.exchange_selftest:
             # Liftover::convert as halLiftover runs it: BED text in, BED text out (parse, H2D, kernels, D2H, format), PCIe inclusive

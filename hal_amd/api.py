@@ -300,6 +300,15 @@ class Alignment:
         finally:
             lib.hgx_free(out)
 
+    def alignment_depth_bytes(self, ref, ref_sequence=-1, start=0, length=0, step=1, count_dupes=False, no_ancestors=False):
+        """halAlignmentDepth end to end, the wig text left in library memory and released: returns its size (benchmark use)."""
+        out, n, err = C.c_void_p(), C.c_size_t(), C.c_void_p()
+        if lib.hgx_alignment_depth(self._h, ref, ref_sequence, start, length, step, 1 if count_dupes else 0, 1 if no_ancestors else 0,
+                                   None, 0, C.byref(out), C.byref(n), C.byref(err)) != 0:
+            raise HgxError(take_error(err))
+        lib.hgx_free(out)
+        return n.value
+
     def maf_export_bytes(self, ref, ref_sequence=-1, start=0, length=0, no_ancestors=False, max_block_len=1000, unique=False, max_ref_gap=0):
         """hal2maf end to end, the text left in library memory and released: returns its size (benchmark use)."""
         o = maf_opts(no_ancestors=no_ancestors, max_block_len=max_block_len, unique=unique, max_ref_gap=max_ref_gap)

@@ -1,6 +1,7 @@
 #include "hgx_columns_host.hpp"
 #include <functional>
 #include "hgx_liftover_host.hpp"
+#include "hgx_wig_text.hpp"
 #include <iostream>
 #include <algorithm>
 #include <atomic>
@@ -58,7 +59,13 @@ static void depthSequence(std::ostream &os, hgx_alignment *h, int genome, int se
     ColumnOptions opt;
     opt.noAncestors = noAncestors;
     opt.targets.assign(targetSet.begin(), targetSet.end());
-    std::vector<int32_t> vals((size_t)count);
+    // (a page-locked block the copies fill — hostBlockTake — not a vector cleared first: 0.9 GB for config 5's genome)
+    struct Values {
+        int32_t *p;
+        explicit Values(int64_t n) : p(static_cast<int32_t *>(hostBlockTake((size_t)std::max<int64_t>(n, 1) * 4))) {}
+        ~Values() { hostBlockGive(p); }
+        int32_t *data() const { return p; }
+    } vals(count);
     if (moreDevices && !moreDevices->empty() && count >= 2) {
         // columns are independent (api/impl/halColumnIterator.cpp:785-787): contiguous shares of the sampled columns, one per
         // device clone, scanned at the same time; the values land in their place of the one array
@@ -88,14 +95,9 @@ static void depthSequence(std::ostream &os, hgx_alignment *h, int genome, int se
     } else {
         columnsDepthHost(h, genome, start + S.start, count, step, countDupes ? 1 : 0, opt, vals.data(), stats);
     }
-    std::string buf;
-    buf.reserve((size_t)count * 3);
-    char tmp[16];
-    for (int64_t i = 0; i < count; ++i) {
-        int n = snprintf(tmp, sizeof tmp, "%d\n", vals[(size_t)i]);
-        buf.append(tmp, (size_t)n);
-    }
-    os << buf;
+    // the lines: sizes counted and lines written by many threads, into the output itself where the stream gives room (hgx_wig_text.hpp)
+    BulkSink *sink = dynamic_cast<BulkSink *>(os.rdbuf());
+    wigLines(os, vals.data(), count, [sink](size_t n) { return sink ? sink->room(n) : nullptr; });
 }
 
 void alignmentDepth(std::ostream &os, hgx_alignment *h, int genome, int sequence, const std::set<int> &targetSet, int64_t start,

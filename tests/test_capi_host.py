@@ -422,3 +422,12 @@ def test_randgen_cli_and_library_agree(hal, tmp_path):
     o.max_branch_length = 3.0
     hal.Alignment.random(o, device=-1).save(p2)
     assert open(p1, "rb").read() == open(p2, "rb").read()
+
+
+def test_wig_lines_are_snprintf_lines(tmp_path):
+    """halAlignmentDepth's text is made by many threads from the device's values (hal_amd/csrc/hgx_wig_text.hpp): the same bytes as
+    the reference's one `%d\\n` per column (alignmentDepth/halAlignmentDepth.cpp:246, 271, 305) for every digit count and sign."""
+    exe = str(tmp_path / "wig_text_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-I", os.path.join(ROOT, "hal_amd", "csrc"), "-o", exe,
+                           os.path.join(ROOT, "tests", "cpp", "wig_text_check.cpp")])
+    assert subprocess.run([exe], stdout=subprocess.PIPE, check=True).stdout.decode().strip() == "same"
