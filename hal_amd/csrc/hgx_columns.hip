@@ -5,10 +5,12 @@
 #include "hgx_scan_kernels.hpp"
 #include "hgx_columns_engine.hpp"
 #include "hgx_liftover_engine.hpp"
+#include "hgx_wig_text.hpp"
 #include <hipcub/hipcub.hpp>
 #include <algorithm>
 #include <cstring>
 #include <functional>
+#include <future>
 #include <memory>
 #include <mutex>
 #include <set>
@@ -480,6 +482,33 @@ void columnsDepthHost(hgx_alignment *h, int ref, int64_t first, int64_t count, i
         HIP_OK(hipMemcpy(out, d.p, (size_t)count * 4, hipMemcpyDeviceToHost));
 }
 
+void columnsDepthChunksHost(hgx_alignment *h, int ref, int64_t first, int64_t count, int64_t step, int mode, const ColumnOptions &opt,
+                            ColumnStats *stats, int64_t chunk, const std::function<void(const int32_t *, int64_t, int64_t)> &sink) {
+    if (!h->dev)
+        throw std::runtime_error("alignment was opened without a device (device = -1); the column engine needs the HIP path");
+    HIP_OK(hipSetDevice(h->dev->device));
+    if (count <= 0)
+        return;
+    if (chunk < 1)
+        chunk = 1;
+    Buf d((size_t)count * 4);
+    columnsDepthDevice(h, ref, first, count, step, mode, opt, (int32_t *)d.p, nullptr, stats, false);
+    // two page-locked blocks in turn: the copy of a chunk goes on while the chunk before is with the sink
+    struct Block {
+        int32_t *p = nullptr;
+        ~Block() { hostBlockGive(p); }
+    } block[2];
+    const size_t bytes = (size_t)std::min(chunk, count) * 4;
+    block[0].p = static_cast<int32_t *>(hostBlockTake(bytes));
+    if (count > chunk)
+        block[1].p = static_cast<int32_t *>(hostBlockTake(bytes));
+    int32_t *const buffer[2] = {block[0].p, block[1].p};
+    const int32_t *values = (const int32_t *)d.p;
+    handOffChunks(buffer, count, chunk,
+                  [values](int32_t *p, int64_t lo, int64_t n) { HIP_OK(hipMemcpy(p, values + lo, (size_t)n * 4, hipMemcpyDeviceToHost)); },
+                  sink);
+}
+
 void columnsRowsHost(hgx_alignment *h, int ref, int64_t first, int64_t count, const ColumnOptions &opt, bool withDna,
                      std::vector<uint64_t> &rowOffset, std::vector<ColumnRowHost> &rows, ColumnStats *stats) {
     static_assert(sizeof(ColumnRowHost) == sizeof(ColumnRow), "row layouts must match");
@@ -626,7 +655,10 @@ struct HostBlockHeader { // in front of every block
 };
 static_assert(sizeof(HostBlockHeader) == 64, "blocks stay 64-byte aligned");
 const uint32_t HOST_BLOCK_MAGIC = 0x48474258u;
-const size_t HOST_BLOCK_SMALL = (size_t)1 << 20, HOST_BLOCK_KEEP = 12, HOST_BLOCK_KEEP_BYTES = (size_t)4 << 30;
+// (locking pages costs about as much as copying them once through pageable memory: it pays for blocks that are used again, and a
+// block of a genome's length is not)
+const size_t HOST_BLOCK_SMALL = (size_t)1 << 20, HOST_BLOCK_PIN_MAX = (size_t)256 << 20, HOST_BLOCK_KEEP = 12,
+             HOST_BLOCK_KEEP_BYTES = (size_t)1 << 30;
 struct HostBlockPool {
     std::mutex mu;
     std::vector<HostBlockHeader *> idle;
@@ -659,7 +691,7 @@ void *hostBlockTake(size_t bytes) {
                 pool.idleBytes -= hd->capacity;
                 return hd + 1;
             }
-            tryPinned = !pool.noDevice;
+            tryPinned = !pool.noDevice && bytes <= HOST_BLOCK_PIN_MAX;
         }
         const size_t capacity = (bytes + bytes / 8 + ((size_t)4 << 20) - 1) & ~(((size_t)4 << 20) - 1); // (an eighth of slack, 4 MiB steps)
         if (tryPinned) {

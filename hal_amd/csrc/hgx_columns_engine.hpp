@@ -2,6 +2,7 @@
 #pragma once
 #include "../../include/hgx.h"
 #include "hgx_device.hpp"
+#include <functional>
 #include <new>
 #include <stdexcept>
 #include <string>
@@ -65,6 +66,11 @@ void columnsDepthHost(hgx_alignment *h, int ref, int64_t first, int64_t count, i
 // same, results left on the device (d_out: device int32[count]); stream = hipStream_t
 void columnsDepthDevice(hgx_alignment *h, int ref, int64_t first, int64_t count, int64_t step, int mode, const ColumnOptions &opt,
                         int32_t *d_out, void *stream, ColumnStats *stats, bool countDerefs = false, bool perBase = false);
+// the same values handed to `sink(values, index of the first, how many)` chunk by chunk, in order, from page-locked blocks of `chunk`
+// values: the copy of a chunk goes on while the sink has the chunk before (halAlignmentDepth's text: no array of a genome's length
+// on the host)
+void columnsDepthChunksHost(hgx_alignment *h, int ref, int64_t first, int64_t count, int64_t step, int mode, const ColumnOptions &opt,
+                            ColumnStats *stats, int64_t chunk, const std::function<void(const int32_t *, int64_t, int64_t)> &sink);
 // every reported base of columns [first, first+count), in the reference's ColumnMap insertion order;
 // rowOffset gets count+1 entries
 void columnsRowsHost(hgx_alignment *h, int ref, int64_t first, int64_t count, const ColumnOptions &opt, bool withDna,

@@ -59,14 +59,23 @@ static void depthSequence(std::ostream &os, hgx_alignment *h, int genome, int se
     ColumnOptions opt;
     opt.noAncestors = noAncestors;
     opt.targets.assign(targetSet.begin(), targetSet.end());
-    // (a page-locked block the copies fill — hostBlockTake — not a vector cleared first: 0.9 GB for config 5's genome)
+    // the lines: sizes counted and lines written by many threads, into the output itself where the stream gives room (hgx_wig_text.hpp)
+    BulkSink *sink = dynamic_cast<BulkSink *>(os.rdbuf());
+    auto lines = [&os, sink](const int32_t *v, int64_t n) { wigLines(os, v, n, [sink](size_t b) { return sink ? sink->room(b) : nullptr; }); };
+    if (!(moreDevices && !moreDevices->empty() && count >= 2)) {
+        // one device: the values come chunk by chunk (sixteen million of them) while the chunk before is made into lines
+        columnsDepthChunksHost(h, genome, start + S.start, count, step, countDupes ? 1 : 0, opt, stats, (int64_t)1 << 24,
+                               [&lines](const int32_t *v, int64_t, int64_t n) { lines(v, n); });
+        return;
+    }
+    // (a block the copies fill — hostBlockTake — not a vector cleared first)
     struct Values {
         int32_t *p;
         explicit Values(int64_t n) : p(static_cast<int32_t *>(hostBlockTake((size_t)std::max<int64_t>(n, 1) * 4))) {}
         ~Values() { hostBlockGive(p); }
         int32_t *data() const { return p; }
     } vals(count);
-    if (moreDevices && !moreDevices->empty() && count >= 2) {
+    {
         // columns are independent (api/impl/halColumnIterator.cpp:785-787): contiguous shares of the sampled columns, one per
         // device clone, scanned at the same time; the values land in their place of the one array
         std::vector<hgx_alignment *> hs{h};
@@ -92,12 +101,8 @@ static void depthSequence(std::ostream &os, hgx_alignment *h, int genome, int se
         for (const std::string &e : errors)
             if (!e.empty())
                 throw std::runtime_error(e);
-    } else {
-        columnsDepthHost(h, genome, start + S.start, count, step, countDupes ? 1 : 0, opt, vals.data(), stats);
     }
-    // the lines: sizes counted and lines written by many threads, into the output itself where the stream gives room (hgx_wig_text.hpp)
-    BulkSink *sink = dynamic_cast<BulkSink *>(os.rdbuf());
-    wigLines(os, vals.data(), count, [sink](size_t n) { return sink ? sink->room(n) : nullptr; });
+    lines(vals.data(), count);
 }
 
 void alignmentDepth(std::ostream &os, hgx_alignment *h, int genome, int sequence, const std::set<int> &targetSet, int64_t start,

@@ -7,6 +7,7 @@
 #include <charconv>
 #include <cstdint>
 #include <cstring>
+#include <future>
 #include <ostream>
 #include <string>
 #include <thread>
@@ -82,6 +83,24 @@ template <class Room> void wigLines(std::ostream &os, const int32_t *vals, int64
     spread(write);
     if (!own.empty())
         os.write(own.data(), (std::streamsize)own.size());
+}
+
+// count values in chunks through two buffers in turn: copy(buffer, first, n) fills a buffer with values [first, first + n),
+// sink(buffer, first, n) takes them — in order, one at a time, the copy of a chunk going on while the sink has the chunk before
+// (the device's copies into page-locked blocks beside the threads that make the lines: hgx_columns.hip, columnsDepthChunksHost).
+template <class Copy, class Sink> void handOffChunks(int32_t *const buffer[2], int64_t count, int64_t chunk, Copy copy, Sink sink) {
+    std::future<void> pending; // (waited for by its destructor too: nothing of the caller's is let go while a sink runs)
+    int turn = 0;
+    for (int64_t lo = 0; lo < count; lo += chunk, turn ^= 1) {
+        const int64_t n = std::min(chunk, count - lo);
+        int32_t *p = buffer[turn]; // (the sink that read this buffer last was waited for a round ago)
+        copy(p, lo, n);
+        if (pending.valid())
+            pending.get(); // (in order: a sink appends to the text where the one before stopped)
+        pending = std::async(std::launch::async, [&sink, p, lo, n]() { sink(p, lo, n); });
+    }
+    if (pending.valid())
+        pending.get();
 }
 
 } // namespace hgx

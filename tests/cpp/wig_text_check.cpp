@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <random>
 #include <sstream>
+#include <stdexcept>
 int main() {
     std::mt19937_64 rng(7);
     std::vector<int32_t> v;
@@ -21,6 +22,35 @@ int main() {
         if (buf != want || !os2.str().empty()) { printf("DIFFERENT (room, %u threads)\n", threads); return 1; }
     }
     for (int64_t n : {0, 1, 2, 65535, 65536, 65537}) { std::ostringstream os; hgx::wigLines(os, v.data(), n, [](size_t) { return (char *)nullptr; }); std::string w; for (int64_t i = 0; i < n; ++i) { int k = snprintf(tmp, sizeof tmp, "%d\n", v[i]); w.append(tmp, k); } if (os.str() != w) { printf("DIFFERENT n=%ld\n", (long)n); return 1; } }
+    // the chunks' hand-off (columnsDepthChunksHost's loop with a memcpy in the device copy's place): every value once, in order,
+    // whatever the chunk size; the text through it is the text at once; a sink's exception comes out
+    for (int64_t chunk : {1, 7, 4096, 65536, 1000000, 5000000}) {
+        const int64_t count = chunk == 1 ? 1000 : chunk == 7 ? 20000 : (int64_t)v.size();
+        std::vector<int32_t> a((size_t)std::min(chunk, count)), b((size_t)std::min(chunk, count));
+        int32_t *const buffer[2] = {a.data(), b.data()};
+        std::ostringstream os;
+        int64_t next = 0;
+        bool ordered = true;
+        hgx::handOffChunks(buffer, count, chunk, [&](int32_t *p, int64_t lo, int64_t n) { memcpy(p, v.data() + lo, (size_t)n * 4); },
+                           [&](const int32_t *p, int64_t lo, int64_t n) {
+                               ordered = ordered && lo == next;
+                               next = lo + n;
+                               hgx::wigLines(os, p, n, [](size_t) { return (char *)nullptr; }, 3);
+                           });
+        std::string w;
+        for (int64_t i = 0; i < count; ++i) { int k = snprintf(tmp, sizeof tmp, "%d\n", v[i]); w.append(tmp, k); }
+        if (!ordered || next != count || os.str() != w) { printf("DIFFERENT (chunks of %ld)\n", (long)chunk); return 1; }
+    }
+    {
+        std::vector<int32_t> a(10), b(10);
+        int32_t *const buffer[2] = {a.data(), b.data()};
+        bool caught = false;
+        try {
+            hgx::handOffChunks(buffer, 100, 10, [&](int32_t *p, int64_t lo, int64_t n) { memcpy(p, v.data() + lo, (size_t)n * 4); },
+                               [&](const int32_t *, int64_t lo, int64_t) { if (lo == 30) throw std::runtime_error("sink"); });
+        } catch (const std::runtime_error &) { caught = true; }
+        if (!caught) { printf("a sink's exception was lost\n"); return 1; }
+    }
     printf("same\n");
     return 0;
 }
