@@ -7,7 +7,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <exception>
 #include <sstream>
+#include <thread>
 #include <unordered_map>
 
 namespace hgx {
@@ -432,8 +434,47 @@ void Liftover::convertBuffer(hgx_alignment *al, int srcGenome, const char *text,
     hand();
 }
 
+#ifdef HGX_HOST_PROFILE
+// The profiling build (make hostprof-lib, not part of libhgx.so) can take the device's records from a file instead — HGX_LIFT_REPLAY:
+// hgx_record rows with the index of the interval counted over the whole conversion, as `hal_oracle liftover --records` writes them —
+// so that the host side of the general path (BED12 blocks, PSL, mixed column counts) runs against the oracle on a machine without a GPU.
+namespace {
+struct LiftReplay {
+    FILE *f = nullptr;
+    hgx_record next{};
+    bool have = false;
+    int64_t base = 0; // intervals of the batches before
+    LiftReplay() {
+        if (const char *p = getenv("HGX_LIFT_REPLAY"))
+            f = fopen(p, "rb");
+    }
+    void batch(size_t n, std::vector<hgx_record> &recs) {
+        recs.clear();
+        for (;;) {
+            if (!have)
+                have = fread(&next, sizeof next, 1, f) == 1;
+            if (!have || next.query >= base + (int64_t)n)
+                break;
+            if (next.query < base)
+                throw std::runtime_error("HGX_LIFT_REPLAY: the file does not continue with this batch");
+            recs.push_back(next);
+            recs.back().query -= base;
+            have = false;
+        }
+        base += (int64_t)n;
+    }
+};
+LiftReplay &liftReplay() {
+    static LiftReplay r;
+    return r;
+}
+} // namespace
+#endif
+
 void Liftover::convertGeneral(hgx_alignment *al, int srcGenome, std::istream *in, int tgtGenome, std::ostream *out, int bedType,
                               bool traverseDupes, bool outPSL, bool outPSLWithName, int coalescenceLimit) {
+    if (const char *e = getenv("HGX_BATCH_LINES")) // (intervals per device batch: tests cross batch ends with it)
+        batchLines = (size_t)std::max<long long>(1, atoll(e));
     _outPSL = outPSL || outPSLWithName; // halLiftoverMain.cpp:82-84
     _outPSLWithName = outPSLWithName;
     const GenomeTables &S = al->img.genomes[(size_t)srcGenome];
@@ -525,7 +566,12 @@ void Liftover::convertGeneral(hgx_alignment *al, int srcGenome, std::istream *in
             hgx_liftover_stats st{};
             try { // (BedScanner::scan wraps visitLine as well, halBedScanner.cpp:60-68: an error raised while lifting names a line — here
                   // the first line of the batch it was lifted in)
-                liftoverBatchHost(al, srcGenome, tgtGenome, ivs.size(), ivs.data(), opts, recs, &st);
+#ifdef HGX_HOST_PROFILE
+                if (liftReplay().f)
+                    liftReplay().batch(ivs.size(), recs);
+                else
+#endif
+                    liftoverBatchHost(al, srcGenome, tgtGenome, ivs.size(), ivs.data(), opts, recs, &st);
             } catch (std::runtime_error &e) {
                 throw std::runtime_error(std::string(e.what()) + " in input bed line " + std::to_string(batchFirstLine));
             }
@@ -538,91 +584,130 @@ void Liftover::convertGeneral(hgx_alignment *al, int srcGenome, std::istream *in
             lastStats.deferred_queries += st.deferred_queries;
             lastStats.walk_ms += st.walk_ms;
             lastStats.total_ms += st.total_ms;
-            size_t r = 0; // records are grouped by query in input order
-            std::string outBuf;
-            std::vector<BedLine> mapped, outLines;
-            for (const Job &job : jobs) {
-                const BedLine &src = job.line;
-                const size_t qEnd = job.firstQuery + job.numQueries;
-                const size_t r0 = r;
-                while (r < recs.size() && (size_t)recs[r].query < qEnd)
-                    ++r;
-                if (src.bedType <= 9) {
-                    for (size_t k = r0; k < r; ++k) {
-                        const hgx_record &rec = recs[k];
-                        // halBlockLiftover.cpp:82-105 (fields other than chrom/start/end/strand echo the input line);
-                        // Liftover::cleanResults, halLiftover.cpp:313-331: a set thick range becomes the lifted range
-                        const bool thick = src.bedType > 6 && (src.thickStart != 0 || src.thickEnd != 0);
-                        src.append(outBuf, T.seqs[(size_t)rec.tgt_seq].name, rec.tgt_start, rec.tgt_end, rec.strand,
-                                   thick ? rec.tgt_start : src.thickStart, thick ? rec.tgt_end : src.thickEnd);
-                    }
-                    if (outBuf.size() > (1u << 20)) {
-                        out->write(outBuf.data(), (std::streamsize)outBuf.size());
-                        outBuf.clear();
-                    }
-                    continue;
+            // The lines' records (grouped by query, in input order), then the lines themselves: what happens to a line's records —
+            // BlockLiftover's output lines, assignBlocksToIntervals, cleanResults, the PSL columns — depends on that line only, so
+            // the batch's lines are dealt to the host's threads in contiguous shares and the shares' texts written in order.
+            std::vector<size_t> jobRec(jobs.size() + 1);
+            {
+                size_t r = 0;
+                for (size_t j = 0; j < jobs.size(); ++j) {
+                    jobRec[j] = r;
+                    const size_t qEnd = jobs[j].firstQuery + jobs[j].numQueries;
+                    while (r < recs.size() && (size_t)recs[r].query < qEnd)
+                        ++r;
                 }
-                if (!outBuf.empty()) { // keep the order of the output when line types are mixed
-                    out->write(outBuf.data(), (std::streamsize)outBuf.size());
-                    outBuf.clear();
-                }
-                // BED12 / PSL: mapped blocks of all of the line's block intervals, stably sorted by source start
-                // (assignBlocksToIntervals' first step; per interval they already are)
-                _inStrand = src.strand;
-                mapped.clear();
-                outLines.clear();
-                for (size_t k = r0; k < r; ++k) {
-                    const hgx_record &rec = recs[k];
-                    mapped.push_back(src);
-                    BedLine &m = mapped.back();
-                    m.blocks.clear();
-                    m.chrName = T.seqs[(size_t)rec.tgt_seq].name;
-                    m.start = rec.tgt_start;
-                    m.end = rec.tgt_end;
-                    m.strand = rec.strand;
-                    m.srcStart = rec.src_start;
-                    if (_outPSL) {
-                        const SeqInfo &qs = S.seqs[(size_t)ivs[(size_t)rec.query].seq];
-                        const SeqInfo &ts = T.seqs[(size_t)rec.tgt_seq];
-                        m.psl.assign(1, PSLInfo());
-                        PSLInfo &p = m.psl[0];
-                        p.qSeqName = qs.name;
-                        p.qSeqSize = (uint64_t)qs.length;
-                        p.qStrand = src.strand == '-' ? '-' : '+'; // source pieces are flipped for '-' input (halBlockLiftover.cpp:64-70)
-                        p.qChromOffset = (uint64_t)qs.start;
-                        p.qEnd = (uint64_t)(m.srcStart + (m.end - m.start));
-                        p.tSeqSize = (uint64_t)ts.length;
-                        pslCounts(S, T, m.srcStart, m.start + ts.start, m.end - m.start, src.strand == '-', rec.tgt_reversed != 0, p);
-                    }
-                }
-                std::stable_sort(mapped.begin(), mapped.end(), [](const BedLine &a, const BedLine &b) { return a.srcStart < b.srcStart; });
-                if (!mapped.empty())
-                    assignBlocksToIntervals(mapped, outLines);
-                // cleanResults (halLiftover.cpp:313-355)
-                for (BedLine &b : outLines) {
-                    if (src.thickStart != 0 || src.thickEnd != 0) {
-                        b.thickStart = b.start;
-                        b.thickEnd = b.end;
-                    }
-                    if (_outPSL) {
-                        b.srcStart = INT64_MAX;
-                        b.psl[0].qEnd = 0;
-                        for (size_t k = 0; k < b.psl[0].qBlockStarts.size(); ++k) {
-                            b.srcStart = std::min(b.srcStart, b.psl[0].qBlockStarts[k]);
-                            b.psl[0].qEnd = std::max(b.psl[0].qEnd, (uint64_t)b.psl[0].qBlockStarts[k] + (uint64_t)b.blocks[k].length);
+                jobRec[jobs.size()] = r;
+            }
+            struct Share {
+                std::string text;
+                std::exception_ptr error; // (then `text` ends where the serial loop would have stopped writing)
+            };
+            unsigned nt = std::thread::hardware_concurrency();
+            nt = std::max(1u, std::min(nt ? nt : 1u, 32u));
+            nt = (unsigned)std::min<size_t>(nt, jobs.size() / 64 + 1);
+            std::vector<Share> shares(nt);
+            const bool outPSL = _outPSL, outPSLWithName = _outPSLWithName;
+            auto render = [&](unsigned t) {
+                Share &share = shares[t];
+                std::string &outBuf = share.text;
+                Liftover self; // (assignBlocksToIntervals and its helpers read the input line's strand from the object)
+                self._outPSL = outPSL;
+                self._outPSLWithName = outPSLWithName;
+                std::ostringstream pslText;
+                std::vector<BedLine> mapped, outLines;
+                try {
+                    for (size_t j = jobs.size() * t / nt; j < jobs.size() * (t + 1) / nt; ++j) {
+                        const BedLine &src = jobs[j].line;
+                        const size_t r0 = jobRec[j], r = jobRec[j + 1];
+                        if (src.bedType <= 9) {
+                            for (size_t k = r0; k < r; ++k) {
+                                const hgx_record &rec = recs[k];
+                                // halBlockLiftover.cpp:82-105 (fields other than chrom/start/end/strand echo the input line);
+                                // Liftover::cleanResults, halLiftover.cpp:313-331: a set thick range becomes the lifted range
+                                const bool thick = src.bedType > 6 && (src.thickStart != 0 || src.thickEnd != 0);
+                                src.append(outBuf, T.seqs[(size_t)rec.tgt_seq].name, rec.tgt_start, rec.tgt_end, rec.strand,
+                                           thick ? rec.tgt_start : src.thickStart, thick ? rec.tgt_end : src.thickEnd);
+                            }
+                            continue;
+                        }
+                        // BED12 / PSL: mapped blocks of all of the line's block intervals, stably sorted by source start
+                        // (assignBlocksToIntervals' first step; per interval they already are)
+                        self._inStrand = src.strand;
+                        mapped.clear();
+                        outLines.clear();
+                        for (size_t k = r0; k < r; ++k) {
+                            const hgx_record &rec = recs[k];
+                            mapped.push_back(src);
+                            BedLine &m = mapped.back();
+                            m.blocks.clear();
+                            m.chrName = T.seqs[(size_t)rec.tgt_seq].name;
+                            m.start = rec.tgt_start;
+                            m.end = rec.tgt_end;
+                            m.strand = rec.strand;
+                            m.srcStart = rec.src_start;
+                            if (outPSL) {
+                                const SeqInfo &qs = S.seqs[(size_t)ivs[(size_t)rec.query].seq];
+                                const SeqInfo &ts = T.seqs[(size_t)rec.tgt_seq];
+                                m.psl.assign(1, PSLInfo());
+                                PSLInfo &p = m.psl[0];
+                                p.qSeqName = qs.name;
+                                p.qSeqSize = (uint64_t)qs.length;
+                                p.qStrand = src.strand == '-' ? '-' : '+'; // source pieces are flipped for '-' input (halBlockLiftover.cpp:64-70)
+                                p.qChromOffset = (uint64_t)qs.start;
+                                p.qEnd = (uint64_t)(m.srcStart + (m.end - m.start));
+                                p.tSeqSize = (uint64_t)ts.length;
+                                pslCounts(S, T, m.srcStart, m.start + ts.start, m.end - m.start, src.strand == '-', rec.tgt_reversed != 0, p);
+                            }
+                        }
+                        std::stable_sort(mapped.begin(), mapped.end(), [](const BedLine &a, const BedLine &b) { return a.srcStart < b.srcStart; });
+                        if (!mapped.empty())
+                            self.assignBlocksToIntervals(mapped, outLines);
+                        // cleanResults (halLiftover.cpp:313-355)
+                        for (BedLine &b : outLines) {
+                            if (src.thickStart != 0 || src.thickEnd != 0) {
+                                b.thickStart = b.start;
+                                b.thickEnd = b.end;
+                            }
+                            if (outPSL) {
+                                b.srcStart = INT64_MAX;
+                                b.psl[0].qEnd = 0;
+                                for (size_t k = 0; k < b.psl[0].qBlockStarts.size(); ++k) {
+                                    b.srcStart = std::min(b.srcStart, b.psl[0].qBlockStarts[k]);
+                                    b.psl[0].qEnd = std::max(b.psl[0].qEnd, (uint64_t)b.psl[0].qBlockStarts[k] + (uint64_t)b.blocks[k].length);
+                                }
+                            }
+                        }
+                        std::stable_sort(outLines.begin(), outLines.end(), [](const BedLine &a, const BedLine &b) { return a.srcStart < b.srcStart; });
+                        for (const BedLine &b : outLines) {
+                            if (!outPSL) {
+                                b.append(outBuf, b.chrName, b.start, b.end, b.strand, b.thickStart, b.thickEnd); // (BedLine::write)
+                            } else {
+                                pslText.str(std::string());
+                                b.writePSL(pslText, outPSLWithName);
+                                outBuf += pslText.str();
+                            }
                         }
                     }
+                } catch (...) {
+                    share.error = std::current_exception();
                 }
-                std::stable_sort(outLines.begin(), outLines.end(), [](const BedLine &a, const BedLine &b) { return a.srcStart < b.srcStart; });
-                for (const BedLine &b : outLines) {
-                    if (!_outPSL)
-                        b.write(*out);
-                    else
-                        b.writePSL(*out, _outPSLWithName);
-                }
+            };
+            if (nt == 1) {
+                render(0);
+            } else {
+                std::vector<std::thread> threads;
+                for (unsigned t = 1; t < nt; ++t)
+                    threads.emplace_back(render, t);
+                render(0);
+                for (std::thread &th : threads)
+                    th.join();
             }
-            if (!outBuf.empty())
-                out->write(outBuf.data(), (std::streamsize)outBuf.size());
+            for (Share &share : shares) { // (what was written before a line that fails stays written, as in the reference's loop)
+                if (!share.text.empty())
+                    out->write(share.text.data(), (std::streamsize)share.text.size());
+                if (share.error)
+                    std::rethrow_exception(share.error);
+            }
         }
         if (!pendingError.empty()) {
             std::string e = pendingError;

@@ -309,6 +309,15 @@ void Liftover::liftInterval(std::list<BedLine> &mappedBedLines) {
     std::vector<MSegPtr> fragments;
     MSegSet emptySet;
     std::set<i64> queryCutSet, targetCutSet;
+    struct Record { // hgx_record
+        i64 query, tgtStart, tgtEnd, srcStart;
+        int32_t tgtSeq;
+        char strand;
+        u8 tgtReversed;
+        char pad[2];
+    };
+    static_assert(sizeof(Record) == 40, "hgx_record");
+    std::vector<Record> records;
     for (MSegSet::iterator i = mappedSegments.begin(); i != mappedSegments.end(); ++i) {
         extractSegment(i, emptySet, fragments, &mappedSegments, targetCutSet, queryCutSet);
         const Sequence *seq = (*i)->tgt.getSequence();
@@ -335,6 +344,14 @@ void Liftover::liftInterval(std::list<BedLine> &mappedBedLines) {
         }
         if (outPSL && !fragments.empty())
             readPSLInfo(fragments, out);
+        if (recordsOut)
+            records.push_back(Record{recordQuery, out._start, out._end, out._srcStart, (int32_t)(seq - (*i)->tgt.G().seqs.data()), out._strand,
+                                     (u8)((*i)->getReversed() ? 1 : 0), {0, 0}});
+    }
+    if (recordsOut) {
+        std::stable_sort(records.begin(), records.end(), [](const Record &a, const Record &b) { return a.srcStart < b.srcStart; });
+        recordsOut->write((const char *)records.data(), (std::streamsize)(records.size() * sizeof(Record)));
+        ++recordQuery;
     }
 }
 

@@ -61,6 +61,12 @@ struct Liftover {
     i64 lastIndex = 0;
     std::set<int> downwardPath;
     MSegSet mappedSegments;
+    // hal_oracle liftover --records: every lifted interval's output lines as the library's device hands them to its host side
+    // (include/hgx.h: hgx_record — the index of the interval among the lifted ones, target range, source start, target sequence,
+    // strand, the mapped piece's orientation; an interval's lines stably sorted by source start), for playing them back to the
+    // library's host code on a machine without a GPU (hal_amd/csrc/hgx_liftover_host.cpp, HGX_LIFT_REPLAY; make hostprof-lib)
+    std::ostream *recordsOut = nullptr;
+    i64 recordQuery = 0;
     // statistics for bench.py's cpu_baseline leg
     double mapSeconds = 0;
     size_t numIntervals = 0, numRecords = 0, numMappedPieces = 0;

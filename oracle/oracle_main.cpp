@@ -16,11 +16,13 @@ static int cmdLiftover(int argc, char **argv) {
     std::vector<std::string> pos;
     bool noDupes = false, stats = false, outPSL = false, outPSLWithName = false;
     int bedType = 0;
-    std::string coalName;
+    std::string coalName, recordsPath;
     for (int i = 0; i < argc; ++i) {
         std::string a = argv[i];
         if (a == "--noDupes")
             noDupes = true;
+        else if (a == "--records") // (oracle_liftover.hpp: recordsOut)
+            recordsPath = argv[++i];
         else if (a == "--coalescenceLimit")
             coalName = argv[++i];
         else if (a == "--stats")
@@ -57,8 +59,18 @@ static int cmdLiftover(int argc, char **argv) {
             return 1;
         }
     }
-    lo.convert(&al, src, &inBuf, tgt, &outBuf, bedType, !noDupes, coal, outPSL, outPSLWithName);
+    std::ofstream recordsFile;
+    if (!recordsPath.empty()) {
+        recordsFile.open(recordsPath, std::ios::binary);
+        lo.recordsOut = &recordsFile;
+    }
     std::ofstream out(pos[4]);
+    try {
+        lo.convert(&al, src, &inBuf, tgt, &outBuf, bedType, !noDupes, coal, outPSL, outPSLWithName);
+    } catch (...) { // (halLiftover writes as it goes: what was lifted before a malformed line is in the file)
+        out << outBuf.str();
+        throw;
+    }
     out << outBuf.str();
     if (stats)
         std::cout << "{\"intervals\": " << lo.numIntervals << ", \"records\": " << lo.numRecords

@@ -87,3 +87,15 @@ def test_oracle_written_batches_through_the_host_state_machine(oracle_bin):
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT).stdout.decode()
     last = out.strip().splitlines()[-1].split()
     assert last[:2] == ["alignments", "12"] and int(last[3]) >= 60 and last[4:] == ["different", "0"], out
+
+
+def test_oracle_written_records_through_the_general_liftover_path(oracle_bin):
+    """halLiftover's general path (BED12 blocks, PSL, mixed column counts, malformed lines: hal_amd/csrc/hgx_liftover_host.cpp,
+    Liftover::convertGeneral — a batch's lines dealt to the host's threads) over records the ORACLE writes (hal_oracle liftover
+    --records: every lifted interval's hgx_record rows), batches of 1 .. 4 M intervals; text and partial text before an error must be
+    the oracle's (profiles/scripts/r04_cpu_liftover_soak.py; profiles/r04y_cpu_liftover_soak.txt has the long run)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "hal_amd", "csrc"), "all", "hostprof-lib"])
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "scripts", "r04_cpu_liftover_soak.py"), "9000", "12"],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT).stdout.decode()
+    last = out.strip().splitlines()[-1].split()
+    assert last[:2] == ["alignments", "12"] and int(last[3]) >= 60 and last[4:] == ["different", "0"], out
