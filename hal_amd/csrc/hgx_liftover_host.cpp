@@ -491,77 +491,78 @@ void Liftover::convertGeneral(hgx_alignment *al, int srcGenome, std::istream *in
 
     if (in->bad())
         throw std::runtime_error("Error reading bed input stream");
-    auto skipWhiteSpaces = [](std::istream *s) { // halBedScanner.cpp:76-80
-        while (s->good() && std::isspace((char)s->peek()))
-            s->get();
+    // The scanner's loop (halBedScanner.cpp:40-61, 76-80: blank space skipped, a line read, parsed, visited) runs over the text in
+    // pieces cut behind line ends, a piece a thread: a line's BedLine depends on the lines before it only through the fields a shorter
+    // line leaves as they were (BedScanner keeps one BedLine), and of those only the strand is ever looked at — by lines of five
+    // columns or fewer, whose intervals are lifted on it.  So every piece is parsed from a fresh BedLine, and one pass in order hands
+    // the strand on, counts the lines, reports the skipped ones and stops at the first malformed one.
+    const std::string text((std::istreambuf_iterator<char>(*in)), std::istreambuf_iterator<char>());
+    struct Item {
+        BedLine line;
+        int seq = -1;          // source sequence; -1: the line is skipped
+        bool ownStrand = false; // the line has a strand column
+        int note = 0;          // skipped: 1 unknown sequence, 2 past the sequence's end, 3 no blocks
     };
-    BedLine bedLine; // persists across lines like BedScanner::_bedLine (fields of shorter lines are inherited)
-    std::string lineBuffer;
+    struct Piece {
+        size_t begin = 0, end = 0;
+        std::vector<Item> items;
+        std::string error; // the first malformed line's message (the piece's items end before it)
+    };
+    auto parsePiece = [&](Piece &pc) {
+        BedLine bedLine;
+        std::string lineBuffer;
+        size_t pos = pc.begin;
+        auto skipWhiteSpaces = [&]() {
+            while (pos < pc.end && std::isspace((unsigned char)text[pos]))
+                ++pos;
+        };
+        skipWhiteSpaces();
+        while (pos < pc.end) {
+            const char *nl = (const char *)memchr(text.data() + pos, '\n', pc.end - pos);
+            const size_t eol = nl ? (size_t)(nl - text.data()) : pc.end;
+            lineBuffer.assign(text, pos, eol - pos);
+            pos = nl ? eol + 1 : pc.end;
+            try {
+                bedLine.parse(lineBuffer, bedType);
+            } catch (std::runtime_error &e) {
+                pc.error = e.what();
+                return;
+            }
+            pc.items.emplace_back();
+            Item &it = pc.items.back();
+            it.ownStrand = bedLine.bedType > 5;
+            // Liftover::visitLine, halLiftover.cpp:46-70
+            if (_outPSL && bedLine.bedType < 12)
+                bedLine.expandToBed12(); // forcing to BED12 makes PSL code simpler
+            auto found = seqByName.find(bedLine.chrName);
+            if (found == seqByName.end()) {
+                it.note = 1;
+            } else if (bedLine.end > S.seqs[(size_t)found->second].length) {
+                it.note = 2;
+                it.seq = found->second; // (for the message; the line is skipped all the same)
+            } else if (bedLine.bedType > 9 && bedLine.blocks.empty()) {
+                it.note = 3;
+            } else {
+                it.seq = found->second;
+                if (bedLine.bedType > 9) // liftBlockIntervals, halLiftover.cpp:296-309: blocks sorted by start
+                    std::sort(bedLine.blocks.begin(), bedLine.blocks.end());
+            }
+            it.line = bedLine;
+            skipWhiteSpaces();
+        }
+    };
     size_t lineNumber = 0;
+    char strandBefore = BedLine().strand; // the scanner's BedLine as the lines so far left it
     std::string pendingError;
     struct Job {
-        BedLine line;
+        const BedLine *line;
         size_t firstQuery, numQueries;
     };
     std::vector<Job> jobs;
     std::vector<hgx_interval> ivs;
     std::vector<hgx_record> recs;
-    skipWhiteSpaces(in);
-    bool more = in->good();
-    while (more || !pendingError.empty()) {
-        jobs.clear();
-        ivs.clear();
-        const size_t batchFirstLine = lineNumber + 1;
-        while (more && ivs.size() < batchLines) {
-            ++lineNumber;
-            try {
-                std::getline(*in, lineBuffer);
-                bedLine.parse(lineBuffer, bedType);
-            } catch (std::runtime_error &e) {
-                pendingError = std::string(e.what()) + " in input bed line " + std::to_string(lineNumber);
-                more = false;
-                break;
-            }
-            // Liftover::visitLine, halLiftover.cpp:46-70
-            if (_outPSL && bedLine.bedType < 12)
-                bedLine.expandToBed12(); // forcing to BED12 makes PSL code simpler
-            auto it = seqByName.find(bedLine.chrName);
-            if (it == seqByName.end()) {
-                if (_missedSet.insert(bedLine.chrName).second)
-                    std::cerr << "Unable to find sequence " << bedLine.chrName << " in genome " << S.name << std::endl;
-            } else if (bedLine.end > S.seqs[(size_t)it->second].length) {
-                std::cerr << "Skipping interval with endpoint " << bedLine.end << "because sequence " << bedLine.chrName
-                          << " has length " << S.seqs[(size_t)it->second].length << std::endl;
-            } else if (bedLine.bedType > 9 && bedLine.blocks.empty()) {
-                std::cerr << "Skipping input line with 0 blocks" << std::endl;
-            } else {
-                Job job;
-                job.firstQuery = ivs.size();
-                hgx_interval q;
-                q.seq = it->second;
-                q.strand = bedLine.strand;
-                q._pad[0] = q._pad[1] = q._pad[2] = 0;
-                if (bedLine.bedType <= 9) {
-                    q.start = bedLine.start;
-                    q.end = bedLine.end;
-                    ivs.push_back(q);
-                } else {
-                    // liftBlockIntervals, halLiftover.cpp:296-309: blocks sorted by start, one lift per non-empty block
-                    std::sort(bedLine.blocks.begin(), bedLine.blocks.end());
-                    for (const BedBlock &b : bedLine.blocks) {
-                        q.start = b.start + bedLine.start;
-                        q.end = q.start + b.length;
-                        if (q.end > q.start)
-                            ivs.push_back(q);
-                    }
-                }
-                job.numQueries = ivs.size() - job.firstQuery;
-                job.line = bedLine;
-                jobs.push_back(std::move(job));
-            }
-            skipWhiteSpaces(in);
-            more = in->good();
-        }
+    size_t batchFirstLine = 1;
+    auto liftBatch = [&]() {
         if (!jobs.empty()) {
             hgx_liftover_stats st{};
             try { // (BedScanner::scan wraps visitLine as well, halBedScanner.cpp:60-68: an error raised while lifting names a line — here
@@ -617,7 +618,7 @@ void Liftover::convertGeneral(hgx_alignment *al, int srcGenome, std::istream *in
                 std::vector<BedLine> mapped, outLines;
                 try {
                     for (size_t j = jobs.size() * t / nt; j < jobs.size() * (t + 1) / nt; ++j) {
-                        const BedLine &src = jobs[j].line;
+                        const BedLine &src = *jobs[j].line;
                         const size_t r0 = jobRec[j], r = jobRec[j + 1];
                         if (src.bedType <= 9) {
                             for (size_t k = r0; k < r; ++k) {
@@ -709,12 +710,94 @@ void Liftover::convertGeneral(hgx_alignment *al, int srcGenome, std::istream *in
                     std::rethrow_exception(share.error);
             }
         }
-        if (!pendingError.empty()) {
-            std::string e = pendingError;
-            pendingError.clear();
-            throw std::runtime_error(e);
+        jobs.clear();
+        ivs.clear();
+    };
+    const size_t window = (size_t)64 << 20; // (of text at a time: its lines' BedLines are all in memory)
+    for (size_t w0 = 0; w0 < text.size() && pendingError.empty();) {
+        size_t w1 = std::min(text.size(), w0 + window);
+        if (w1 < text.size()) {
+            const char *nl = (const char *)memchr(text.data() + w1, '\n', text.size() - w1);
+            w1 = nl ? (size_t)(nl - text.data()) + 1 : text.size();
         }
+        unsigned np = std::thread::hardware_concurrency();
+        np = std::max(1u, std::min(np ? np : 1u, 32u));
+        static const size_t pieceBytes = getenv("HGX_PARSE_PIECE") ? (size_t)std::max(1, atoi(getenv("HGX_PARSE_PIECE"))) : 16384; // (tests: small pieces)
+        np = (unsigned)std::min<size_t>(np, (w1 - w0) / pieceBytes + 1);
+        std::vector<Piece> pieces(np);
+        for (unsigned k = 0; k < np; ++k) { // cut behind line ends
+            pieces[k].begin = k == 0 ? w0 : pieces[k - 1].end;
+            size_t e = k + 1 == np ? w1 : std::max(pieces[k].begin, w0 + (w1 - w0) * (k + 1) / np);
+            if (e < w1) {
+                const char *nl = (const char *)memchr(text.data() + e, '\n', w1 - e);
+                e = nl ? (size_t)(nl - text.data()) + 1 : w1;
+            }
+            pieces[k].end = e;
+        }
+        if (np == 1) {
+            parsePiece(pieces[0]);
+        } else {
+            std::vector<std::thread> threads;
+            for (unsigned k = 1; k < np; ++k)
+                threads.emplace_back([&, k]() { parsePiece(pieces[k]); });
+            parsePiece(pieces[0]);
+            for (std::thread &th : threads)
+                th.join();
+        }
+        // in order: line numbers, the strand handed on, the skipped lines' messages, batches of intervals, the first malformed line
+        for (Piece &pc : pieces) {
+            for (Item &it : pc.items) {
+                ++lineNumber;
+                BedLine &bl = it.line;
+                if (!it.ownStrand && !_outPSL)
+                    bl.strand = strandBefore; // (a line without a strand column is lifted on the strand the scanner's BedLine still holds)
+                strandBefore = bl.strand;
+                if (it.note == 1) {
+                    if (_missedSet.insert(bl.chrName).second)
+                        std::cerr << "Unable to find sequence " << bl.chrName << " in genome " << S.name << std::endl;
+                } else if (it.note == 2) {
+                    std::cerr << "Skipping interval with endpoint " << bl.end << "because sequence " << bl.chrName << " has length "
+                              << S.seqs[(size_t)it.seq].length << std::endl;
+                } else if (it.note == 3) {
+                    std::cerr << "Skipping input line with 0 blocks" << std::endl;
+                } else {
+                    if (jobs.empty())
+                        batchFirstLine = lineNumber;
+                    Job job;
+                    job.line = &bl;
+                    job.firstQuery = ivs.size();
+                    hgx_interval q;
+                    q.seq = it.seq;
+                    q.strand = bl.strand;
+                    q._pad[0] = q._pad[1] = q._pad[2] = 0;
+                    if (bl.bedType <= 9) {
+                        q.start = bl.start;
+                        q.end = bl.end;
+                        ivs.push_back(q);
+                    } else { // one lift per non-empty block
+                        for (const BedBlock &b : bl.blocks) {
+                            q.start = b.start + bl.start;
+                            q.end = q.start + b.length;
+                            if (q.end > q.start)
+                                ivs.push_back(q);
+                        }
+                    }
+                    job.numQueries = ivs.size() - job.firstQuery;
+                    jobs.push_back(job);
+                    if (ivs.size() >= batchLines)
+                        liftBatch();
+                }
+            }
+            if (!pc.error.empty()) {
+                pendingError = pc.error + " in input bed line " + std::to_string(lineNumber + 1);
+                break;
+            }
+        }
+        liftBatch(); // (the window's BedLines go with it)
+        w0 = w1;
     }
+    if (!pendingError.empty())
+        throw std::runtime_error(pendingError);
 }
 
 } // namespace hgx

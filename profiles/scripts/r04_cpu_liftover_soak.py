@@ -2,7 +2,8 @@
 Liftover::convertGeneral, the lines of a batch dealt to the host's threads — soaked on a machine WITHOUT a GPU: for random alignments
 (tests/halfix.py) and random BED inputs the oracle writes both the expected text and, with --records, every lifted interval's records as
 the device hands them to the host side; the profiling build of the library (make -C hal_amd/csrc hostprof-lib) plays the records back
-(HGX_LIFT_REPLAY, halLiftover --device -1, HGX_TEXT_GENERAL=1) with batches of 1 .. 4 M intervals, and the text must be the oracle's.
+(HGX_LIFT_REPLAY, halLiftover --device -1, HGX_TEXT_GENERAL=1) with batches of 1 .. 4 M intervals and the text parsed in pieces of 40
+bytes .. 16 KB a thread, and the text must be the oracle's.
 usage: python profiles/scripts/r04_cpu_liftover_soak.py [first seed] [alignments]"""
 import os, random, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -87,7 +88,7 @@ with tempfile.TemporaryDirectory() as tmp:
             r0 = subprocess.run([ORACLE, "liftover", img, src["name"], bed, tgt["name"], want, "--records", rec] + opts, stderr=subprocess.PIPE)
             batch = rng.choice(["1", "7", "100", "4000000"])
             r1 = subprocess.run([TOOL, "--device", "-1"] + opts + [img, src["name"], bed, tgt["name"], got],
-                                env=dict(os.environ, LD_PRELOAD=LIB, HGX_LIFT_REPLAY=rec, HGX_TEXT_GENERAL="1", HGX_BATCH_LINES=batch), stderr=subprocess.PIPE)
+                                env=dict(os.environ, LD_PRELOAD=LIB, HGX_LIFT_REPLAY=rec, HGX_TEXT_GENERAL="1", HGX_BATCH_LINES=batch, HGX_PARSE_PIECE=rng.choice(["40", "300", "16384"])), stderr=subprocess.PIPE)
             exports += 1
             a = open(want).read() if os.path.exists(want) else None
             b = open(got).read() if os.path.exists(got) else None
