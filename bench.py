@@ -1017,6 +1017,31 @@ def main():
                                                  "two handles of this one GPU, first %d columns" % ncm,
                                          "value": ncm / dt_m2, "unit": "columns/s", "seconds": dt_m2, "maf_bytes": nb_m, "handles": 2, "gpus": 1}
             del clones
+            try:
+                import numpy as np
+                if not want_maf:
+                    raise RuntimeError("skipped: the alignment was generated without DNA (--maf-columns 0)")
+                # halLiftover --outPSL of BED12 lines: the general path of Liftover::convert (a BedLine a line, blocks lifted one by one,
+                # assignBlocksToIntervals, PSL columns counted from both genomes' DNA on the host), parsed and rendered by the host's threads
+                npsl = 200000
+                rs = np.random.default_rng(11)
+                b12 = []
+                for i, (a0, l0) in enumerate(zip(sn[:npsl], ln[:npsl])):
+                    a0, l0 = int(a0), int(l0)
+                    cut = sorted(int(x) for x in rs.choice(np.arange(1, l0), size=3, replace=False))
+                    b12.append("%s\t%d\t%d\tn%d\t0\t%s\t%d\t%d\t0\t2\t%d,%d,\t0,%d," % (seq_name, a0, a0 + l0, i, "+-"[i & 1], a0, a0 + l0,
+                                                                                       cut[0], l0 - cut[1], cut[1]))
+                psl_in = ("\n".join(b12) + "\n").encode()
+                hal_amd.liftover_convert_bytes(al, src, ("\n".join(b12[:2000]) + "\n").encode(), tgt, out_psl=True)
+                t0 = time.perf_counter()
+                nb_psl, ln_psl = hal_amd.liftover_convert_bytes(al, src, psl_in, tgt, out_psl=True)
+                dt_psl = time.perf_counter() - t0
+                feats["liftover_psl"] = {"what": "hgx_liftover_convert --outPSL: %d BED12 lines of two blocks (the batch's first intervals) to PSL text in host "
+                                                 "memory: the general path of Liftover::convert (hgx_liftover_host.cpp), needs the alignment's DNA" % npsl,
+                                         "value": npsl / dt_psl, "unit": "lines/s", "seconds": dt_psl, "bytes_in": len(psl_in), "bytes_out": nb_psl,
+                                         "lines_out": ln_psl}
+            except Exception as e:  # (a leg beside the line, not the line)
+                feats["liftover_psl"] = {"error": str(e)[:300]}
             out["features"] = feats
         if args.cpu_sample > 0:
             sample = min(args.cpu_sample, nq)

@@ -439,12 +439,12 @@ def maf_export_multi(alignments, ref, ref_sequence=-1, start=0, length=0, slice_
         lib.hgx_free(out)
 
 
-def liftover_convert_bytes(alignment, src_genome, data, tgt_genome, bed_type=0, traverse_dupes=True, count_lines=True):
+def liftover_convert_bytes(alignment, src_genome, data, tgt_genome, bed_type=0, traverse_dupes=True, count_lines=True, out_psl=False):
     """hgx_liftover_convert on BED bytes, the output left in library memory and released: (bytes, lines) of it (benchmark use:
     no decoding of a hundred megabytes of text in Python)."""
     out, n, err = C.c_void_p(), C.c_size_t(), C.c_void_p()
-    rc = lib.hgx_liftover_convert(alignment._h, src_genome, data, len(data), tgt_genome, bed_type, 1 if traverse_dupes else 0, 0, 0, -1,
-                                  C.byref(out), C.byref(n), C.byref(err))
+    rc = lib.hgx_liftover_convert(alignment._h, src_genome, data, len(data), tgt_genome, bed_type, 1 if traverse_dupes else 0,
+                                  1 if out_psl else 0, 0, -1, C.byref(out), C.byref(n), C.byref(err))
     lines = C.string_at(out, n.value).count(b"\n") if (out.value and count_lines) else 0
     if out.value:
         lib.hgx_free(out)
