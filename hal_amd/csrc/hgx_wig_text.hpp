@@ -5,9 +5,11 @@
 #pragma once
 #include <algorithm>
 #include <charconv>
+#include <condition_variable>
 #include <cstdint>
 #include <cstring>
 #include <future>
+#include <mutex>
 #include <ostream>
 #include <string>
 #include <thread>
@@ -53,34 +55,65 @@ template <class Room> void wigLines(std::ostream &os, const int32_t *vals, int64
             n += (uint32_t)vals[i] < 10 ? 2 : wigLineLength(vals[i]);
         bytes[t + 1] = n;
     };
-    auto spread = [&](auto &&fn) {
-        if (nt == 1) {
-            fn(0u);
-            return;
-        }
-        std::vector<std::thread> th;
-        for (unsigned t = 1; t < nt; ++t)
-            th.emplace_back(fn, t);
-        fn(0u);
-        for (std::thread &x : th)
-            x.join();
-    };
-    spread(measure);
-    for (unsigned t = 0; t < nt; ++t)
-        bytes[t + 1] += bytes[t];
-    const size_t total = bytes[nt];
-    std::string own;
-    char *dst = room(total);
-    if (!dst) {
-        own.resize(total);
-        dst = &own[0];
-    }
+    char *dst = nullptr;
     auto write = [&](unsigned t) {
         char *o = dst + bytes[t];
         for (int64_t i = part(t); i < part(t + 1); ++i)
             o = wigLine(o, vals[i]);
     };
-    spread(write);
+    std::string own;
+    auto place = [&]() { // every part's place in the text, and the text's
+        for (unsigned t = 0; t < nt; ++t)
+            bytes[t + 1] += bytes[t];
+        dst = room(bytes[nt]);
+        if (!dst) {
+            own.resize(bytes[nt]);
+            dst = &own[0];
+        }
+    };
+    if (nt == 1) {
+        measure(0);
+        place();
+        write(0);
+    } else {
+        // the threads are made once: each counts its part, waits until all have and the places are known, writes its part
+        std::mutex mu;
+        std::condition_variable cv;
+        unsigned counted = 0;
+        bool placed = false, failed = false;
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; ++t)
+            th.emplace_back([&, t]() {
+                measure(t);
+                std::unique_lock<std::mutex> lock(mu);
+                ++counted;
+                cv.notify_all();
+                cv.wait(lock, [&]() { return placed || failed; });
+                lock.unlock();
+                if (!failed)
+                    write(t);
+            });
+        measure(0);
+        {
+            std::unique_lock<std::mutex> lock(mu);
+            cv.wait(lock, [&]() { return counted == nt - 1; });
+            try {
+                place();
+                placed = true;
+            } catch (...) { // (no memory for the text: the threads must not be left waiting)
+                failed = true;
+                cv.notify_all();
+                lock.unlock();
+                for (std::thread &x : th)
+                    x.join();
+                throw;
+            }
+            cv.notify_all();
+        }
+        write(0);
+        for (std::thread &x : th)
+            x.join();
+    }
     if (!own.empty())
         os.write(own.data(), (std::streamsize)own.size());
 }
