@@ -1,5 +1,6 @@
 #include "hgx_textmem.hpp"
 #include "hgx_liftover_host.hpp"
+#include "hgx_lift_replay.hpp"
 #include <algorithm>
 #include <cerrno>
 #include <charconv>
@@ -433,43 +434,6 @@ void Liftover::convertBuffer(hgx_alignment *al, int srcGenome, const char *text,
     }
     hand();
 }
-
-#ifdef HGX_HOST_PROFILE
-// The profiling build (make hostprof-lib, not part of libhgx.so) can take the device's records from a file instead — HGX_LIFT_REPLAY:
-// hgx_record rows with the index of the interval counted over the whole conversion, as `hal_oracle liftover --records` writes them —
-// so that the host side of the general path (BED12 blocks, PSL, mixed column counts) runs against the oracle on a machine without a GPU.
-namespace {
-struct LiftReplay {
-    FILE *f = nullptr;
-    hgx_record next{};
-    bool have = false;
-    int64_t base = 0; // intervals of the batches before
-    LiftReplay() {
-        if (const char *p = getenv("HGX_LIFT_REPLAY"))
-            f = fopen(p, "rb");
-    }
-    void batch(size_t n, std::vector<hgx_record> &recs) {
-        recs.clear();
-        for (;;) {
-            if (!have)
-                have = fread(&next, sizeof next, 1, f) == 1;
-            if (!have || next.query >= base + (int64_t)n)
-                break;
-            if (next.query < base)
-                throw std::runtime_error("HGX_LIFT_REPLAY: the file does not continue with this batch");
-            recs.push_back(next);
-            recs.back().query -= base;
-            have = false;
-        }
-        base += (int64_t)n;
-    }
-};
-LiftReplay &liftReplay() {
-    static LiftReplay r;
-    return r;
-}
-} // namespace
-#endif
 
 void Liftover::convertGeneral(hgx_alignment *al, int srcGenome, std::istream *in, int tgtGenome, std::ostream *out, int bedType,
                               bool traverseDupes, bool outPSL, bool outPSLWithName, int coalescenceLimit) {

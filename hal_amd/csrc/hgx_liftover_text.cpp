@@ -16,6 +16,7 @@
 // earlier lines) — returns false and takes the general path of hgx_liftover_host.cpp.
 #include "hgx_textmem.hpp"
 #include "hgx_liftover_host.hpp"
+#include "hgx_lift_replay.hpp"
 #include <mutex>
 #include <functional>
 #include <condition_variable>
@@ -536,6 +537,18 @@ bool liftoverTextFast(hgx_alignment *const *als, int nAls, int srcGenome, const 
         for (int d = 0; d < nAls; ++d)
             if (round < groups[(size_t)d].size() && groups[(size_t)d][round].firstChunk < limit) {
                 grp[(size_t)d] = &groups[(size_t)d][round];
+#ifdef HGX_HOST_PROFILE
+                static std::vector<int64_t> replayStarts, replayEnds; // (the profiling build's stand-ins for the plan's pinned staging)
+                static std::vector<uint8_t> replayStrands;
+                if (liftReplay().f && nAls == 1) {
+                    replayStarts.resize(grp[0]->numQueries + 1);
+                    replayEnds.resize(grp[0]->numQueries + 1);
+                    replayStrands.resize(grp[0]->numQueries + 1);
+                    gs[0] = replayStarts.data();
+                    ge[0] = replayEnds.data();
+                    st[0] = replayStrands.data();
+                } else
+#endif
                 if (grp[(size_t)d]->numQueries)
                     liftoverStageQueries(als[d], grp[(size_t)d]->numQueries, &gs[(size_t)d], &ge[(size_t)d], &st[(size_t)d]);
                 for (size_t i = grp[(size_t)d]->firstChunk; i < grp[(size_t)d]->endChunk; ++i)
@@ -584,6 +597,14 @@ bool liftoverTextFast(hgx_alignment *const *als, int nAls, int srcGenome, const 
                 if (!grp[(size_t)d] || !grp[(size_t)d]->numQueries)
                     return;
                 try {
+#ifdef HGX_HOST_PROFILE
+                    static std::vector<hgx_record> replayRecs;
+                    if (liftReplay().f && nAls == 1) {
+                        liftReplay().batch(grp[0]->numQueries, replayRecs);
+                        recs[0] = replayRecs.data();
+                        nRecs[0] = replayRecs.size();
+                    } else
+#endif
                     liftoverBatchStaged(als[d], srcGenome, tgtGenome, grp[(size_t)d]->numQueries, opts, &recs[(size_t)d], &nRecs[(size_t)d],
                                         &devStats[(size_t)d], &packedRecs[(size_t)d]);
                 } catch (std::exception &e) {

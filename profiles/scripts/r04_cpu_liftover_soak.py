@@ -1,4 +1,4 @@
-"""halLiftover's general path — BED12 blocks, PSL output, lines of mixed column counts, one BedLine at a time: hal_amd/csrc/hgx_liftover_host.cpp,
+"""halLiftover's host side — the parallel text path for inputs of one column count (hal_amd/csrc/hgx_liftover_text.cpp) and the general path — BED12 blocks, PSL output, lines of mixed column counts, one BedLine at a time: hal_amd/csrc/hgx_liftover_host.cpp,
 Liftover::convertGeneral, the lines of a batch dealt to the host's threads — soaked on a machine WITHOUT a GPU: for random alignments
 (tests/halfix.py) and random BED inputs the oracle writes both the expected text and, with --records, every lifted interval's records as
 the device hands them to the host side; the profiling build of the library (make -C hal_amd/csrc hostprof-lib) plays the records back
@@ -31,7 +31,8 @@ def bed_lines(rng, seqs, n, cols, extras):
         elif rng.random() < 0.02:
             b = length + rng.randint(1, 9)            # past the end: skipped
         strand = rng.choice("+-.") if cols != 12 else rng.choice("+-")
-        f = [name, str(a), str(b), "n%d" % i, str(rng.randint(0, 1000)), strand, str(a if rng.random() < 0.5 else 0),
+        odd = lambda v: rng.choice([" %d", "+%d", "%dx", "%d ", "0%d"]) % v if rng.random() < 0.03 else str(v)  # (read like operator>>)
+        f = [name, odd(a), odd(b), "n%d" % i, odd(rng.randint(0, 1000)), strand, str(a if rng.random() < 0.5 else 0),
              str(b if rng.random() < 0.5 else 0), rng.choice(["255,0,0", "7", "1,2", "3,4,5,"])]
         if cols == 12:
             nb = rng.randint(1, min(5, max(1, ln // 2)))
@@ -87,16 +88,20 @@ with tempfile.TemporaryDirectory() as tmp:
             open(bed, "w").write(text)
             r0 = subprocess.run([ORACLE, "liftover", img, src["name"], bed, tgt["name"], want, "--records", rec] + opts, stderr=subprocess.PIPE)
             batch = rng.choice(["1", "7", "100", "4000000"])
-            r1 = subprocess.run([TOOL, "--device", "-1"] + opts + [img, src["name"], bed, tgt["name"], got],
-                                env=dict(os.environ, LD_PRELOAD=LIB, HGX_LIFT_REPLAY=rec, HGX_TEXT_GENERAL="1", HGX_BATCH_LINES=batch, HGX_PARSE_PIECE=rng.choice(["40", "300", "16384"])), stderr=subprocess.PIPE)
+            env = dict(os.environ, LD_PRELOAD=LIB, HGX_LIFT_REPLAY=rec, HGX_BATCH_LINES=batch, HGX_PARSE_PIECE=rng.choice(["40", "300", "16384"]),
+                       HGX_TEXT_THREADS=rng.choice(["1", "3", "8"]))
+            if rng.random() < 0.5:  # (else: inputs of one column count, BED out, take the parallel text path of hgx_liftover_text.cpp)
+                env["HGX_TEXT_GENERAL"] = "1"
+            r1 = subprocess.run([TOOL, "--device", "-1"] + opts + [img, src["name"], bed, tgt["name"], got], env=env, stderr=subprocess.PIPE)
             exports += 1
             a = open(want).read() if os.path.exists(want) else None
             b = open(got).read() if os.path.exists(got) else None
             same = a == b and (r0.returncode == 0) == (r1.returncode == 0)
             if not same:
                 different += 1
-                print("DIFFERENT seed %d %s -> %s %s %s batch %s rc %d / %d\n  oracle: %s\n  library: %s" % (
-                    seed, src["name"], tgt["name"], shape, opts, batch, r0.returncode, r1.returncode, r0.stderr.decode()[-200:], r1.stderr.decode()[-200:]), flush=True)
+                print("DIFFERENT seed %d %s -> %s %s %s batch %s general %s rc %d / %d\n  oracle: %s\n  library: %s" % (
+                    seed, src["name"], tgt["name"], shape, opts, batch, env.get("HGX_TEXT_GENERAL"), r0.returncode, r1.returncode, r0.stderr.decode()[-200:],
+                    r1.stderr.decode()[-200:]), flush=True)
             for f in (want, got):
                 if os.path.exists(f):
                     os.remove(f)
