@@ -57,7 +57,8 @@ struct Chunk {
     bool general = false;         // a line the fast path does not handle
     int bedType = -1;             // column count of the chunk's lines
     std::vector<std::string> notes; // what the reference writes to stderr, in order
-    std::string out;
+    std::string out;             // its lines (only where they cannot be written into the output text directly)
+    size_t outBytes = 0, outAt = 0; // how long its lines are, where they stand in the output text
 };
 
 inline bool isBlank(char c) { // std::isspace in the "C" locale
@@ -250,8 +251,34 @@ struct RecCursor {
     }
 };
 
-// BedLine::write (halBedLine.cpp:104-151) with what BlockLiftover::liftInterval and Liftover::cleanResults substitute
-void renderChunk(Chunk &C, const hgx_record *recs, size_t nRecs, const PackedRecords &packed, const GenomeTables &T) {
+// BedLine::write (halBedLine.cpp:104-151) with what BlockLiftover::liftInterval and Liftover::cleanResults substitute.  One body
+// for two sinks: the lines are counted first, then written at their place in the one output text (the chunks' texts used to be
+// made apart and copied together: as many bytes moved again as rendered).
+struct CountSink {
+    size_t n = 0;
+    void bytes(const char *, size_t k) { n += k; }
+    void ch(char) { ++n; }
+    void num(int64_t v) { // what putInt writes
+        uint64_t u = v < 0 ? 0 - (uint64_t)v : (uint64_t)v;
+        size_t k = v < 0 ? 2 : 1;
+        for (uint64_t p = 10; u >= p; p *= 10) {
+            ++k;
+            if (p > UINT64_MAX / 10)
+                break;
+        }
+        n += k;
+    }
+};
+struct WriteSink {
+    char *w;
+    void bytes(const char *p, size_t k) {
+        memcpy(w, p, k);
+        w += k;
+    }
+    void ch(char c) { *w++ = c; }
+    void num(int64_t v) { w = putInt(w, v); }
+};
+template <class Sink> void emitChunk(const Chunk &C, const hgx_record *recs, size_t nRecs, const PackedRecords &packed, const GenomeTables &T, Sink &o) {
     if (C.numQueries == 0)
         return;
     RecCursor cur;
@@ -264,9 +291,6 @@ void renderChunk(Chunk &C, const hgx_record *recs, size_t nRecs, const PackedRec
         cur.rEnd = recs + nRecs;
     }
     const int bt = C.bedType;
-    std::string &out = C.out;
-    size_t used = 0;
-    out.resize(1 << 16);
     RecView rec{};
     for (const Line &L : C.lines) {
         if (L.query < 0)
@@ -275,55 +299,57 @@ void renderChunk(Chunk &C, const hgx_record *recs, size_t nRecs, const PackedRec
         cur.seek(L.query);
         for (const RecView *r = &rec; cur.next(L.query, rec);) {
             const std::string &chrom = T.seqs[(size_t)r->tgt_seq].name;
-            const size_t need = chrom.size() + L.len + 200;
-            if (out.size() - used < need)
-                out.resize(std::max(out.size() * 2, used + need));
-            char *w = &out[used];
-            memcpy(w, chrom.data(), chrom.size());
-            w += chrom.size();
-            *w++ = '\t';
-            w = putInt(w, r->tgt_start);
-            *w++ = '\t';
-            w = putInt(w, r->tgt_end);
+            o.bytes(chrom.data(), chrom.size());
+            o.ch('\t');
+            o.num(r->tgt_start);
+            o.ch('\t');
+            o.num(r->tgt_end);
             if (bt > 3) {
-                *w++ = '\t';
-                memcpy(w, L.text + L.nameOff, L.nameLen);
-                w += L.nameLen;
+                o.ch('\t');
+                o.bytes(L.text + L.nameOff, L.nameLen);
             }
             if (bt > 4) {
-                *w++ = '\t';
-                w = putInt(w, L.score);
+                o.ch('\t');
+                o.num(L.score);
             }
             if (bt > 5) {
-                *w++ = '\t';
-                *w++ = r->strand;
+                o.ch('\t');
+                o.ch(r->strand);
             }
             if (bt > 6) { // (bt == 7 never gets here)
-                *w++ = '\t';
-                w = putInt(w, thick ? r->tgt_start : L.thickStart);
+                o.ch('\t');
+                o.num(thick ? r->tgt_start : L.thickStart);
             }
             if (bt > 7) {
-                *w++ = '\t';
-                w = putInt(w, thick ? r->tgt_end : L.thickEnd);
+                o.ch('\t');
+                o.num(thick ? r->tgt_end : L.thickEnd);
             }
             if (bt > 8) {
-                *w++ = '\t';
-                w = putInt(w, L.r);
-                *w++ = ',';
-                w = putInt(w, L.g);
-                *w++ = ',';
-                w = putInt(w, L.b);
+                o.ch('\t');
+                o.num(L.r);
+                o.ch(',');
+                o.num(L.g);
+                o.ch(',');
+                o.num(L.b);
             }
             if (L.extraOff != NO_EXTRA) {
-                *w++ = '\t';
-                memcpy(w, L.text + L.extraOff, L.extraEnd - L.extraOff);
-                w += L.extraEnd - L.extraOff;
+                o.ch('\t');
+                o.bytes(L.text + L.extraOff, L.extraEnd - L.extraOff);
             }
-            *w++ = '\n';
-            used = (size_t)(w - out.data());
+            o.ch('\n');
         }
     }
-    out.resize(used);
+}
+size_t measureChunk(const Chunk &C, const hgx_record *recs, size_t nRecs, const PackedRecords &packed, const GenomeTables &T) {
+    CountSink n;
+    emitChunk(C, recs, nRecs, packed, T, n);
+    return n.n;
+}
+void renderChunk(const Chunk &C, const hgx_record *recs, size_t nRecs, const PackedRecords &packed, const GenomeTables &T, char *dst, size_t bytes) {
+    WriteSink w{dst};
+    emitChunk(C, recs, nRecs, packed, T, w);
+    if ((size_t)(w.w - dst) != bytes) // (the two sinks share one body: this cannot be; better loud than a text with a hole)
+        throw std::logic_error("hgx_liftover_text: a chunk's lines are not as long as they were counted");
 }
 
 // The threads of the text path's phases are kept (a call has three phases of a few milliseconds each: thirty-one threads made and
@@ -528,6 +554,12 @@ bool liftoverTextFast(hgx_alignment *const *als, int nAls, int srcGenome, const 
     // in front of it — other devices' later rounds — still are
     size_t limit = chunks.size();
     std::string devFailure;
+    const bool direct = nAls == 1 || rounds == 1;
+    struct Text { // the output text while it grows (handed to the caller at the end; released if something throws)
+        char *p = nullptr;
+        ~Text() { textFree(p); }
+    } lifted;
+    size_t total = 0;
     for (size_t round = 0; round < rounds; ++round) {
         const auto r0 = now();
         std::vector<int64_t *> gs((size_t)nAls, nullptr), ge((size_t)nAls, nullptr);
@@ -641,9 +673,31 @@ bool liftoverTextFast(hgx_alignment *const *als, int nAls, int srcGenome, const 
             stats.composed_records = devStats[(size_t)d].composed_records;
         }
         const auto r2 = now();
+        // the chunks' lines: counted, then written — at their place in the output text where that is known by now (one device, or
+        // one round: everything in front of a chunk has been counted), else into the chunk's own text, put together at the end
         forMine([&](Chunk &C) {
-            if (C.numQueries && devError[(size_t)C.device].empty())
-                renderChunk(C, recs[(size_t)C.device], nRecs[(size_t)C.device], packedRecs[(size_t)C.device], T);
+            const size_t d = (size_t)C.device;
+            C.outBytes = C.numQueries && devError[d].empty() ? measureChunk(C, recs[d], nRecs[d], packedRecs[d], T) : 0;
+        });
+        if (direct) {
+            size_t at = total;
+            for (Chunk *C : mine) { // (in input order: a device's share of the chunks is contiguous, the devices' shares follow each other)
+                C->outAt = at;
+                at += C->outBytes;
+            }
+            char *q = (char *)textRealloc(lifted.p, at + 1);
+            if (!q)
+                throw std::runtime_error("out of memory");
+            lifted.p = q;
+            total = at;
+        }
+        forMine([&](Chunk &C) {
+            const size_t d = (size_t)C.device;
+            if (C.outBytes) {
+                if (!direct)
+                    C.out.resize(C.outBytes);
+                renderChunk(C, recs[d], nRecs[d], packedRecs[d], T, direct ? lifted.p + C.outAt : &C.out[0], C.outBytes);
+            }
             std::vector<Line>().swap(C.lines); // (the tokens of a rendered chunk are not needed any more)
         });
         const auto r3 = now();
@@ -653,27 +707,39 @@ bool liftoverTextFast(hgx_alignment *const *als, int nAls, int srcGenome, const 
     }
     if (!devFailure.empty()) {
         error = devFailure; // (it lies in front of any malformed line, which ended the input)
+        if (direct)
+            total = chunks[limit].outAt; // (the failed group's chunks are empty; nothing behind them counts)
         for (size_t i = limit; i < chunks.size(); ++i)
             chunks[i].out.clear();
     }
     const auto t4 = now();
-    size_t total = 0;
-    for (Chunk &C : chunks) {
-        C.firstLine = total; // (reused: the chunk's place in the output)
-        total += C.out.size();
+    auto t5 = t4;
+    if (!direct) {
+        total = 0;
+        for (Chunk &C : chunks) {
+            C.outAt = total;
+            total += C.out.size();
+        }
+        // the output buffer is handed to the caller as it is (hgx_textmem.hpp: a mapping advised as huge pages, or the block the last
+        // call's text was released from), untouched until the chunks copy themselves in: the first touch of its pages is spread over
+        // the threads as well
+        lifted.p = (char *)textAlloc(total + 1);
+        if (!lifted.p)
+            throw std::runtime_error("out of memory");
+        t5 = now();
+        char *const dst = lifted.p;
+        forEachChunk(chunks, threads, [&](Chunk &C) {
+            if (!C.out.empty())
+                memcpy(dst + C.outAt, C.out.data(), C.out.size());
+        });
+    } else if (!lifted.p) {
+        lifted.p = (char *)textAlloc(1);
+        if (!lifted.p)
+            throw std::runtime_error("out of memory");
     }
-    // the output buffer is handed to the caller as it is (hgx_textmem.hpp: a mapping advised as huge pages, or the block the last
-    // call's text was released from), untouched until the chunks copy themselves in: the first touch of its pages is spread over
-    // the threads as well
-    char *buf = (char *)textAlloc(total + 1);
-    if (!buf)
-        throw std::runtime_error("out of memory");
+    char *buf = lifted.p;
+    lifted.p = nullptr;
     buf[total] = '\0';
-    const auto t5 = now();
-    forEachChunk(chunks, threads, [&](Chunk &C) {
-        if (!C.out.empty())
-            memcpy(buf + C.firstLine, C.out.data(), C.out.size());
-    });
     *outText = buf;
     *outLen = total;
     if (timing)
