@@ -27,7 +27,12 @@ void *mapFresh(size_t len) {
     void *p = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
     if (p == MAP_FAILED)
         return nullptr;
-    (void)madvise(p, len, MADV_HUGEPAGE); // (advice: the 2 MB extents inside the block fault in as one page each)
+    // (advice: the 2 MB extents inside the block fault in as one page each.  Where memory is fragmented and transparent_hugepage/defrag
+    // is "madvise", such a fault waits for the kernel to compact memory — seconds for a few hundred megabytes on a long-running VM:
+    // HGX_TEXT_HUGEPAGES=0 leaves the advice out)
+    static const bool advise = !(getenv("HGX_TEXT_HUGEPAGES") && atoi(getenv("HGX_TEXT_HUGEPAGES")) == 0);
+    if (advise)
+        (void)madvise(p, len, MADV_HUGEPAGE);
     return p;
 }
 } // namespace
