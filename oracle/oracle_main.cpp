@@ -386,8 +386,8 @@ static int cmdColumnRows(int argc, char **argv) {
         // HGX_MAF_DUMP / HGX_MAF_REPLAY; make hostprof-lib) — per chunk of columns {first column, columns, heads + 1, rows}, a byte
         // per column (1: the column does not continue the one before base by base), the heads' row offsets, the heads' rows
         // {position, genome, reversed} in the column map's order.
-        if (unique || maxInsertLength != 0)
-            throw std::runtime_error("--batches: the plain export's columns only");
+        if (maxInsertLength != 0)
+            throw std::runtime_error("--batches: not with --maxRefGap (those columns go one by one through the iterator's replay)");
         struct Row {
             i64 pos;
             int32_t genome;
@@ -397,50 +397,75 @@ static int cmdColumnRows(int argc, char **argv) {
         };
         static_assert(sizeof(Row) == 16, "ColumnRowHost");
         std::ofstream out(batches, std::ios::binary);
-        std::vector<uint8_t> head;
-        std::vector<uint32_t> headOff(1, 0);
-        std::vector<Row> rows, prev, cur;
-        i64 done = 0, total = 0;
-        auto flushChunk = [&]() {
-            const uint64_t hd[4] = {(uint64_t)done, (uint64_t)head.size(), headOff.size(), rows.size()};
-            out.write((const char *)hd, 32);
-            out.write((const char *)head.data(), (std::streamsize)head.size());
-            out.write((const char *)headOff.data(), (std::streamsize)(4 * headOff.size()));
-            out.write((const char *)rows.data(), (std::streamsize)(16 * rows.size()));
-            done += (i64)head.size();
-            head.clear();
-            headOff.assign(1, 0);
-            rows.clear();
-        };
+        i64 total = 0;
         for (const Sequence &Sq : al.genomes[(size_t)ref].seqs) { // (an export of its own per sequence, as hal2maf makes them)
             if (Sq.length == 0)
                 continue;
-            ColumnIterator col(&al, ref, nullptr, Sq.start, Sq.start + Sq.length - 1, noDupes, noAncestors, false, false, 0);
-            done = 0;
-            prev.clear();
+            // per column of the sequence: 0 continues the column before base by base, 1 a head, and with --unique 2 a column the
+            // iterator passes over (nextFreeIndex: its reference base was in an earlier column), 3 a column that is walked but not
+            // written (not canonical on the reference); heads and 3s have their rows
+            std::vector<uint8_t> head((size_t)Sq.length, unique ? 2 : 1);
+            std::vector<std::vector<Row>> rowsOf((size_t)Sq.length);
+            ColumnIterator col(&al, ref, nullptr, Sq.start, Sq.start + Sq.length - 1, noDupes, noAncestors, false, unique, 0);
+            i64 prevWritten = -2;
+            std::vector<Row> prev, cur;
             for (;;) {
                 cur.clear();
                 for (auto &kv : col.colMap)
                     for (const Dna &d : kv.second)
                         cur.push_back(Row{d.pos, (int32_t)d.g, (uint8_t)(d.rev ? 1 : 0), 'N', {0, 0}});
-                bool continues = !head.empty() && cur.size() == prev.size();
-                for (size_t i = 0; continues && i < cur.size(); ++i)
-                    continues = cur[i].genome == prev[i].genome && cur[i].rev == prev[i].rev && cur[i].pos == prev[i].pos + (cur[i].rev ? -1 : 1);
-                head.push_back(continues ? 0 : 1);
-                if (!continues) {
-                    rows.insert(rows.end(), cur.begin(), cur.end());
-                    headOff.push_back((uint32_t)rows.size());
+                const i64 c = col.refSequencePosition(); // (sequence relative)
+                if (c < 0 || c >= Sq.length)
+                    throw std::runtime_error("--batches: a column outside the sequence");
+                if (unique && !col.isCanonicalOnRef()) {
+                    head[(size_t)c] = 3;
+                    rowsOf[(size_t)c] = cur;
+                } else {
+                    bool continues = prevWritten == c - 1 && cur.size() == prev.size();
+                    for (size_t i = 0; continues && i < cur.size(); ++i)
+                        continues = cur[i].genome == prev[i].genome && cur[i].rev == prev[i].rev && cur[i].pos == prev[i].pos + (cur[i].rev ? -1 : 1);
+                    head[(size_t)c] = continues ? 0 : 1;
+                    if (!continues)
+                        rowsOf[(size_t)c] = cur;
+                    prevWritten = c;
+                    prev.swap(cur);
                 }
-                prev.swap(cur);
-                if ((i64)head.size() == chunk)
-                    flushChunk();
                 if (col.lastColumn())
                     break;
                 col.toRight();
             }
-            if (!head.empty())
-                flushChunk();
-            total += done;
+            for (i64 done = 0; done < Sq.length; done += chunk) { // the batches: the first written column of each is a head
+                const i64 n = std::min(chunk, Sq.length - done);
+                std::vector<uint32_t> headOff(1, 0);
+                std::vector<Row> rows;
+                std::vector<uint8_t> marks(head.begin() + done, head.begin() + done + n);
+                for (i64 i = 0; i < n; ++i) {
+                    if (marks[(size_t)i] == 0 && (i == 0 || (marks[(size_t)i - 1] != 0 && marks[(size_t)i - 1] != 1))) {
+                        // (a continuation at a batch's beginning: the device sees no column before it; its rows are the head's, advanced)
+                        marks[(size_t)i] = 1;
+                        i64 h = done + i;
+                        while (head[(size_t)h] == 0)
+                            --h;
+                        std::vector<Row> r = rowsOf[(size_t)h];
+                        for (Row &x : r)
+                            x.pos += (x.rev ? -1 : 1) * (done + i - h);
+                        rows.insert(rows.end(), r.begin(), r.end());
+                        headOff.push_back((uint32_t)rows.size());
+                        continue;
+                    }
+                    if (marks[(size_t)i] & 1) {
+                        const std::vector<Row> &r = rowsOf[(size_t)(done + i)];
+                        rows.insert(rows.end(), r.begin(), r.end());
+                        headOff.push_back((uint32_t)rows.size());
+                    }
+                }
+                const uint64_t hd[4] = {(uint64_t)done, (uint64_t)n, headOff.size(), rows.size()};
+                out.write((const char *)hd, 32);
+                out.write((const char *)marks.data(), (std::streamsize)marks.size());
+                out.write((const char *)headOff.data(), (std::streamsize)(4 * headOff.size()));
+                out.write((const char *)rows.data(), (std::streamsize)(16 * rows.size()));
+            }
+            total += Sq.length;
         }
         std::cerr << "columns " << total << std::endl;
         return 0;

@@ -1,7 +1,7 @@
 """hal2maf's host side (the block state machine on flat arrays, the log, the rendering threads: hal_amd/csrc/hgx_columns_host.cpp,
 RunMachine) soaked on a machine WITHOUT a GPU: for random alignments (tests/halfix.py, several sequences a genome) the oracle writes
 the plain export's columns in the layout of the library's recorded device batches (hal_oracle columns --batches: which columns are
-heads, the heads' rows) with small and odd chunk sizes, the profiling build of the library (make -C hal_amd/csrc hostprof-lib) plays
+heads, the heads' rows; with --unique: which columns the iterator passes over or walks without writing) with small and odd chunk sizes, the profiling build of the library (make -C hal_amd/csrc hostprof-lib) plays
 them back through hal2maf (HGX_MAF_REPLAY, --device -1), and the text must be the oracle's own hal2maf text.
 usage: python profiles/scripts/r04_cpu_maf_soak.py [first seed] [alignments]"""
 import os, random, subprocess, sys, tempfile
@@ -28,6 +28,8 @@ with tempfile.TemporaryDirectory() as tmp:
                     col.append("--noDupes")
                 if leaf and rng.random() < 0.5:
                     col.append("--noAncestors")
+                if rng.random() < 0.4:  # (which columns the iterator walks and writes: marks 2 and 3 of the batches)
+                    col.append("--unique")
                 if rng.random() < 0.5:
                     host += ["--maxBlockLen", str(rng.choice([1, 2, 5, 17, 100]))]
                 if rng.random() < 0.3:
