@@ -631,10 +631,31 @@ bool liftoverTextFast(hgx_alignment *const *als, int nAls, int srcGenome, const 
                 try {
 #ifdef HGX_HOST_PROFILE
                     static std::vector<hgx_record> replayRecs;
+                    static std::vector<uint32_t> replayWords, replayFirst;
                     if (liftReplay().f && nAls == 1) {
                         liftReplay().batch(grp[0]->numQueries, replayRecs);
                         recs[0] = replayRecs.data();
                         nRecs[0] = replayRecs.size();
+                        // HGX_REPLAY_PACKED: the records in the 8-byte form the device hands over when they fit it (start, length |
+                        // sequence << 22 | strand << 29, every interval's first record), so that this reading of them is covered too
+                        bool fits = getenv("HGX_REPLAY_PACKED") != nullptr;
+                        for (const hgx_record &r : replayRecs)
+                            fits = fits && r.tgt_start >= 0 && r.tgt_start < ((int64_t)1 << 32) && r.tgt_end - r.tgt_start < (1 << 22) && r.tgt_seq < 128;
+                        if (fits) {
+                            replayWords.assign(2 * replayRecs.size(), 0);
+                            replayFirst.assign(grp[0]->numQueries + 1, 0);
+                            for (size_t i = 0; i < replayRecs.size(); ++i) {
+                                const hgx_record &r = replayRecs[i];
+                                replayWords[2 * i] = (uint32_t)r.tgt_start;
+                                replayWords[2 * i + 1] = (uint32_t)(r.tgt_end - r.tgt_start) | ((uint32_t)r.tgt_seq << 22) |
+                                                         ((r.strand == '+' ? 0u : r.strand == '-' ? 1u : 2u) << 29);
+                                ++replayFirst[(size_t)r.query + 1];
+                            }
+                            for (size_t q = 0; q < grp[0]->numQueries; ++q)
+                                replayFirst[q + 1] += replayFirst[q];
+                            packedRecs[0].words = replayWords.data();
+                            packedRecs[0].first = replayFirst.data();
+                        }
                     } else
 #endif
                     liftoverBatchStaged(als[d], srcGenome, tgtGenome, grp[(size_t)d]->numQueries, opts, &recs[(size_t)d], &nRecs[(size_t)d],

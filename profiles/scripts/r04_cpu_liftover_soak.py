@@ -90,6 +90,8 @@ with tempfile.TemporaryDirectory() as tmp:
             batch = rng.choice(["1", "7", "100", "4000000"])
             env = dict(os.environ, LD_PRELOAD=LIB, HGX_LIFT_REPLAY=rec, HGX_BATCH_LINES=batch, HGX_PARSE_PIECE=rng.choice(["40", "300", "16384"]),
                        HGX_TEXT_THREADS=rng.choice(["1", "3", "8"]))
+            if rng.random() < 0.5:  # (the records in the device's 8-byte form, when they fit it)
+                env["HGX_REPLAY_PACKED"] = "1"
             if rng.random() < 0.5:  # (else: inputs of one column count, BED out, take the parallel text path of hgx_liftover_text.cpp)
                 env["HGX_TEXT_GENERAL"] = "1"
             r1 = subprocess.run([TOOL, "--device", "-1"] + opts + [img, src["name"], bed, tgt["name"], got], env=env, stderr=subprocess.PIPE)
