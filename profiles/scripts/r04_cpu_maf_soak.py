@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import halfix
 ORACLE = os.path.join(ROOT, "oracle", "_build", "hal_oracle")
 TOOL = os.path.join(ROOT, "hal_amd", "_build", "hal2maf")
-LIB = os.path.join(ROOT, "hal_amd", "libhgx_hostprof.so")
+LIB = os.environ.get("HGX_SOAK_PRELOAD", os.path.join(ROOT, "hal_amd", "libhgx_hostprof.so"))  # (e.g. a sanitizer build behind its runtime)
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 exports = different = 0
