@@ -843,9 +843,17 @@ struct MafExport::RunMachine {
         static BatchPool *pool = new BatchPool;
         return *pool;
     }
+    // HGX_MAF_BATCH_POOL=1: rendered batches' logs come back and are written over.  Off by default: on the GPU box a log that
+    // 32 rendering threads have just read lies in their caches, and the walk's stores into it wait for those lines one by one
+    // (place(): 429 -> 154 Mticks per config-3 export with fresh logs, profiles/r04y_gpu_maf_diag_pool.txt); on a VM whose page
+    // faults cost 2 us each the pool is the faster one.
+    static bool poolBatches() {
+        const char *e = getenv("HGX_MAF_BATCH_POOL");
+        return e && atoi(e) != 0;
+    }
     static std::unique_ptr<Batch> takeBatch() {
         BatchPool &pool = batchPool();
-        {
+        if (poolBatches()) {
             std::lock_guard<std::mutex> lock(pool.mu);
             if (!pool.idle.empty()) {
                 std::unique_ptr<Batch> b = std::move(pool.idle.back());
@@ -856,6 +864,8 @@ struct MafExport::RunMachine {
         return std::unique_ptr<Batch>(new Batch);
     }
     static void giveBatch(std::unique_ptr<Batch> b) {
+        if (!poolBatches())
+            return;
         b->reset();
         BatchPool &pool = batchPool();
         std::lock_guard<std::mutex> lock(pool.mu);
@@ -1220,9 +1230,15 @@ struct TextBuffer {
 } // namespace
 
 static int renderThreads() { // hal2maf's rendering threads per batch (HGX_MAF_RENDER_THREADS; the walk is one thread beside them)
-    static const int n = getenv("HGX_MAF_RENDER_THREADS") ? std::max(1, atoi(getenv("HGX_MAF_RENDER_THREADS"))) : 32;
-    return n;
+    const char *e = getenv("HGX_MAF_RENDER_THREADS"); // (read per batch: a process can try several settings)
+    return e ? std::max(1, atoi(e)) : 32;
 }
+static size_t describeThreads(size_t heads) { // the threads that describe and sort a device batch's rows (HGX_MAF_DESCRIBE_THREADS)
+    if (const char *e = getenv("HGX_MAF_DESCRIBE_THREADS"))
+        return (size_t)std::max(1, atoi(e));
+    return heads >= 32768 ? 8 : heads >= 4096 ? 4 : 1;
+}
+static double g_mafFlush = 0; // (HGX_MAF_TIMING: the walk's thread in flush(): names, hand-over, without the wait for the batch before)
 static double g_mafRenderWait = 0; // (HGX_MAF_TIMING: how long the walk stood waiting for the batch before to be rendered)
 void MafExport::RunMachine::flush(const PRow *current) {
     {
@@ -1232,6 +1248,11 @@ void MafExport::RunMachine::flush(const PRow *current) {
     }
     if (batch->blocks.empty())
         return;
+    const auto tFlush = std::chrono::steady_clock::now();
+    struct FlushTime {
+        std::chrono::steady_clock::time_point t0;
+        ~FlushTime() { g_mafFlush += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+    } flushTime{tFlush};
     std::shared_ptr<Batch> work(batch.release(), [](Batch *b) { giveBatch(std::unique_ptr<Batch>(b)); }); // (back to the pool when rendered)
     batch = takeBatch();
     entsLogged = false;
@@ -1538,7 +1559,7 @@ void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alig
                 RunMachine::sortColumn(c->rows.get() + c->headOff[h], c->headOff[h + 1] - c->headOff[h]);
             }
         };
-        const size_t parts = heads >= 32768 ? 8 : heads >= 4096 ? 4 : 1;
+        const size_t parts = describeThreads(heads);
         std::vector<std::thread> helpers;
         for (size_t t = 1; t < parts; ++t)
             helpers.emplace_back(convert, heads * t / parts, heads * (t + 1) / parts);
@@ -1557,7 +1578,7 @@ void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alig
         bool stop = false, done = false;
         std::exception_ptr error;
     } pipe;
-    size_t ahead = 4; // (batches made and not yet taken by the walk)
+    size_t ahead = getenv("HGX_MAF_AHEAD") ? (size_t)std::max(1, atoi(getenv("HGX_MAF_AHEAD"))) : 4; // (batches made and not yet taken by the walk)
 #ifdef HGX_HOST_PROFILE
     const bool wholeAhead = mafReplayFile() && getenv("HGX_MAF_REPLAY_AHEAD"); // (the walk by itself: every batch is there before it begins)
     if (wholeAhead)
@@ -1695,8 +1716,9 @@ void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alig
             std::cerr << "[hgx maf] columns " << length << " heads " << numHeads << " blocks " << numBlocks << " state machine + waits "
                       << std::chrono::duration<double>(std::chrono::steady_clock::now() - tStart).count() << " s, of which waiting for the device "
                       << waitSeconds << " s (fetches " << fetchSeconds << " s, device " << stats.rows_ms + stats.depth_ms << " ms), for the rendering of the batch before "
-                      << g_mafRenderWait << " s" << std::endl;
+                      << g_mafRenderWait << " s, handing batches over " << g_mafFlush << " s" << std::endl;
         g_mafRenderWait = 0;
+        g_mafFlush = 0;
     }
     waitPendingWrite();
     mafStream.flush();

@@ -1,8 +1,10 @@
 #include "hgx_textmem.hpp"
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <vector>
 #include <sys/mman.h>
 
 namespace hgx {
@@ -14,6 +16,7 @@ struct TextMem {
     std::mutex mu;
     std::map<const void *, size_t> live; // mapped blocks handed out: their mapped length
     std::map<const void *, size_t> kept; // released, still mapped
+    std::vector<const void *> keptOrder; // ... in the order they were released
     size_t keptBytes = 0;
 };
 TextMem &mem() {
@@ -56,6 +59,7 @@ void *textAlloc(size_t bytes) {
             }
         if (best) {
             M.kept.erase(best);
+            M.keptOrder.erase(std::find(M.keptOrder.begin(), M.keptOrder.end(), best));
             M.keptBytes -= bestLen;
             M.live[best] = bestLen;
             return const_cast<void *>(best);
@@ -108,26 +112,37 @@ void textFree(void *p) {
         return;
     TextMem &M = mem();
     size_t len = 0;
-    bool keep = false;
+    std::vector<std::pair<void *, size_t>> drop; // (unmapped outside the lock)
     {
         std::lock_guard<std::mutex> lock(M.mu);
         auto it = M.live.find(p);
-        if (it == M.live.end()) {
-            len = 0;
-        } else {
+        if (it != M.live.end()) {
             len = it->second;
             M.live.erase(it);
-            keep = M.kept.size() < 2 && M.keptBytes + len <= kKeepBytes;
-            if (keep) {
+            // the block just released is the likeliest size of the next text: it is kept, and older ones make room for it (kept
+            // in the order they were released: a full set of two small blocks used to turn every larger text away — a fresh
+            // mapping of 140 MB and its page faults per call)
+            if (len <= kKeepBytes) {
+                M.keptOrder.push_back(p);
                 M.kept[p] = len;
                 M.keptBytes += len;
+                while (M.keptOrder.size() > 2 || M.keptBytes > kKeepBytes) {
+                    const void *old = M.keptOrder.front();
+                    M.keptOrder.erase(M.keptOrder.begin());
+                    auto k = M.kept.find(old);
+                    M.keptBytes -= k->second;
+                    drop.emplace_back(const_cast<void *>(old), k->second);
+                    M.kept.erase(k);
+                }
+            } else {
+                drop.emplace_back(p, len);
             }
         }
     }
     if (!len)
         free(p); // malloc's
-    else if (!keep)
-        (void)munmap(p, len);
+    for (auto &d : drop)
+        (void)munmap(d.first, d.second);
 }
 
 void textTrim() {
@@ -136,6 +151,7 @@ void textTrim() {
     {
         std::lock_guard<std::mutex> lock(M.mu);
         drop.swap(M.kept);
+        M.keptOrder.clear();
         M.keptBytes = 0;
     }
     for (auto &kv : drop)
