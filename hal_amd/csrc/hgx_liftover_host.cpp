@@ -457,14 +457,15 @@ void Liftover::convertGeneral(hgx_alignment *al, int srcGenome, std::istream *in
         throw std::runtime_error("Error reading bed input stream");
     // The scanner's loop (halBedScanner.cpp:40-61, 76-80: blank space skipped, a line read, parsed, visited) runs over the text in
     // pieces cut behind line ends, a piece a thread: a line's BedLine depends on the lines before it only through the fields a shorter
-    // line leaves as they were (BedScanner keeps one BedLine), and of those only the strand is ever looked at — by lines of five
-    // columns or fewer, whose intervals are lifted on it.  So every piece is parsed from a fresh BedLine, and one pass in order hands
-    // the strand on, counts the lines, reports the skipped ones and stops at the first malformed one.
+    // line leaves as they were (BedScanner keeps one BedLine) — the strand a line of five columns or fewer is lifted on, the thick
+    // end that decides for a line of seven columns whether its thick start is the lifted one.  So every piece is parsed from a fresh
+    // BedLine, and one pass in order gives every line the fields it has no column for from the line before it (as they stand after
+    // that line), counts the lines, reports the skipped ones and stops at the first malformed one.
     const std::string text((std::istreambuf_iterator<char>(*in)), std::istreambuf_iterator<char>());
     struct Item {
         BedLine line;
         int seq = -1;          // source sequence; -1: the line is skipped
-        bool ownStrand = false; // the line has a strand column
+        int columns = 0;       // the line's own column count (BedLine::bedType as parse left it): the fields behind are the scanner's
         int note = 0;          // skipped: 1 unknown sequence, 2 past the sequence's end, 3 no blocks
     };
     struct Piece {
@@ -494,7 +495,7 @@ void Liftover::convertGeneral(hgx_alignment *al, int srcGenome, std::istream *in
             }
             pc.items.emplace_back();
             Item &it = pc.items.back();
-            it.ownStrand = bedLine.bedType > 5;
+            it.columns = bedLine.bedType;
             // Liftover::visitLine, halLiftover.cpp:46-70
             if (_outPSL && bedLine.bedType < 12)
                 bedLine.expandToBed12(); // forcing to BED12 makes PSL code simpler
@@ -516,7 +517,7 @@ void Liftover::convertGeneral(hgx_alignment *al, int srcGenome, std::istream *in
         }
     };
     size_t lineNumber = 0;
-    char strandBefore = BedLine().strand; // the scanner's BedLine as the lines so far left it
+    BedLine before; // the scanner's BedLine as the lines so far left it (the fields a shorter line keeps)
     std::string pendingError;
     struct Job {
         const BedLine *line;
@@ -713,9 +714,31 @@ void Liftover::convertGeneral(hgx_alignment *al, int srcGenome, std::istream *in
             for (Item &it : pc.items) {
                 ++lineNumber;
                 BedLine &bl = it.line;
-                if (!it.ownStrand && !_outPSL)
-                    bl.strand = strandBefore; // (a line without a strand column is lifted on the strand the scanner's BedLine still holds)
-                strandBefore = bl.strand;
+                if (!_outPSL) { // (with PSL output expandToBed12 has given the missing fields their defaults, in the scanner's BedLine too)
+                    if (it.columns <= 3)
+                        bl.name = before.name;
+                    if (it.columns <= 4)
+                        bl.score = before.score;
+                    if (it.columns <= 5)
+                        bl.strand = before.strand; // (such a line is lifted on the strand the scanner's BedLine still holds)
+                    if (it.columns <= 6)
+                        bl.thickStart = before.thickStart;
+                    if (it.columns <= 7)
+                        bl.thickEnd = before.thickEnd; // (a line of seven columns: a thick end left over decides whether its thick start is lifted)
+                    if (it.columns <= 8) {
+                        bl.itemR = before.itemR;
+                        bl.itemG = before.itemG;
+                        bl.itemB = before.itemB;
+                    }
+                }
+                before.name = bl.name;
+                before.score = bl.score;
+                before.strand = bl.strand;
+                before.thickStart = bl.thickStart;
+                before.thickEnd = bl.thickEnd;
+                before.itemR = bl.itemR;
+                before.itemG = bl.itemG;
+                before.itemB = bl.itemB;
                 if (it.note == 1) {
                     if (_missedSet.insert(bl.chrName).second)
                         std::cerr << "Unable to find sequence " << bl.chrName << " in genome " << S.name << std::endl;

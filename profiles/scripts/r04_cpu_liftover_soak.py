@@ -63,13 +63,16 @@ with tempfile.TemporaryDirectory() as tmp:
             seqs = [s for s in src["seqs"] if s[2] > 0]
             if not seqs:
                 continue
-            shape = rng.choice(["bed12", "bed12", "mixed", "uniform", "extras"])
+            shape = rng.choice(["bed12", "bed12", "mixed", "uniform", "extras", "thick"])
             opts, body = [], []
             if shape == "bed12":
                 body = bed_lines(rng, seqs, rng.choice([3, 80, 400]), 12, 0)
             elif shape == "mixed":  # (the reference's line object keeps the fields of longer lines before)
                 for _k in range(rng.randint(2, 4)):
-                    body += bed_lines(rng, seqs, rng.choice([5, 120]), rng.choice([3, 4, 5, 6, 8, 9, 12]), 0)
+                    body += bed_lines(rng, seqs, rng.choice([5, 120]), rng.choice([3, 4, 5, 6, 7, 8, 9, 12]), 0)
+            elif shape == "thick":  # (lines of seven columns take their thick end from the last longer line: it decides what their thick start becomes)
+                body = (bed_lines(rng, seqs, rng.choice([3, 150]), rng.choice([8, 9]), 0) + bed_lines(rng, seqs, rng.choice([0, 2, 150]), rng.choice([3, 4, 5, 6]), 0) +
+                        bed_lines(rng, seqs, rng.choice([5, 200]), 7, 0) + bed_lines(rng, seqs, rng.choice([0, 40]), rng.choice([3, 6, 8]), 0))
             elif shape == "uniform":
                 body = bed_lines(rng, seqs, rng.choice([10, 300]), rng.choice([3, 4, 5, 6, 7, 8, 9]), 0)
             else:
