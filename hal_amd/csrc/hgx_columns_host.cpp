@@ -1442,34 +1442,50 @@ void MafExport::RunMachine::flush(const PRow *current) {
                 buf.len += 1;
             }
         };
+        BulkSink *const sink = dynamic_cast<BulkSink *>(out->rdbuf());
         if (nt == 1) {
             render(0);
+            out->write(text[0].data, (std::streamsize)text[0].len);
         } else {
+            // the threads are made once a batch: each renders its share of the blocks, waits until all have and the output has given
+            // room for the batch's text at once, and copies its share there — side by side (else the shares are written one after
+            // the other by this thread)
+            std::mutex mu;
+            std::condition_variable cv;
+            unsigned rendered = 0;
+            bool placed = false;
+            char *dst = nullptr;
+            std::vector<size_t> at(nt, 0);
             std::vector<std::thread> th;
             for (unsigned t = 0; t < nt; ++t)
-                th.emplace_back(render, t);
-            for (std::thread &x : th)
-                x.join();
-        }
-        // the parts into the output: side by side where the stream's buffer gives room for all of them at once
-        size_t total = 0;
-        for (unsigned t = 0; t < nt; ++t)
-            total += text[t].len;
-        char *dst = nullptr;
-        if (BulkSink *sink = dynamic_cast<BulkSink *>(out->rdbuf()))
-            dst = nt > 1 && total >= (1u << 20) ? sink->room(total) : nullptr;
-        if (dst) {
-            std::vector<std::thread> th;
-            size_t at = 0;
-            for (unsigned t = 0; t < nt; ++t) {
-                th.emplace_back([&text, dst, at, t]() { memcpy(dst + at, text[t].data, text[t].len); });
-                at += text[t].len;
+                th.emplace_back([&, t]() {
+                    render(t);
+                    std::unique_lock<std::mutex> lock(mu);
+                    ++rendered;
+                    cv.notify_all();
+                    cv.wait(lock, [&]() { return placed; });
+                    lock.unlock();
+                    if (dst)
+                        memcpy(dst + at[t], text[t].data, text[t].len);
+                });
+            {
+                std::unique_lock<std::mutex> lock(mu);
+                cv.wait(lock, [&]() { return rendered == nt; });
+                size_t total = 0;
+                for (unsigned t = 0; t < nt; ++t) {
+                    at[t] = total;
+                    total += text[t].len;
+                }
+                if (sink && total >= (1u << 20))
+                    dst = sink->room(total);
+                placed = true;
+                cv.notify_all();
             }
             for (std::thread &x : th)
                 x.join();
-        } else {
-            for (unsigned t = 0; t < nt; ++t)
-                out->write(text[t].data, (std::streamsize)text[t].len);
+            if (!dst)
+                for (unsigned t = 0; t < nt; ++t)
+                    out->write(text[t].data, (std::streamsize)text[t].len);
         }
         std::lock_guard<std::mutex> lock(pool->mu);
         if (pool->idle.size() < 4)
@@ -1664,6 +1680,7 @@ void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alig
             R.chunk = c;
             R.batch->chunks.push_back(c);
             size_t hk = 0;
+            const size_t numChunkHeads = c->headOff.size() - 1;
             for (int64_t i = 0; i < n;) {
                 if (c->head[(size_t)i] == 2) { // --unique: a column the iterator does not walk (nextFreeIndex passes over it)
                     ++i;
@@ -1673,6 +1690,13 @@ void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alig
                 const PRow *rows = c->rows.get() + c->headOff[hk];
                 const size_t nr = c->headOff[hk + 1] - c->headOff[hk];
                 ++hk;
+                if (hk + 6 < numChunkHeads) { // (the rows were written by other cores a moment ago: asked for a few heads ahead of their use)
+                    const char *ahead = (const char *)(c->rows.get() + c->headOff[hk + 5]);
+                    __builtin_prefetch(ahead);
+                    __builtin_prefetch(ahead + 64);
+                    __builtin_prefetch(ahead + 128);
+                    __builtin_prefetch(ahead + 192);
+                }
                 if (c->head[(size_t)i] == 3) { // --unique: walked, not written (a reference base left of the range): its sequences stay
                     R.addKeys(rows, nr);       // behind as keys of the column map (halColumnIterator.cpp:822-826)
                     ++i;
