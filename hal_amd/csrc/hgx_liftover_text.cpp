@@ -106,6 +106,9 @@ inline char *putInt(char *p, int64_t v) {
 void parseChunk(Chunk &C, int forcedType, const std::unordered_map<std::string, int> &seqByName, const GenomeTables &S) {
     const char *p = C.begin;
     std::string key;
+    bool haveKey = false; // (key is the sequence name of the line before, found at keySeq)
+    std::unordered_map<std::string, int>::const_iterator keySeq = seqByName.end();
+    C.lines.reserve((size_t)(C.end - C.begin) / 32 + 16); // (a line of six columns is some forty bytes: the vector seldom has to move)
     while (true) {
         while (p < C.end && isBlank(*p)) // BedScanner::skipWhiteSpaces
             ++p;
@@ -190,8 +193,13 @@ void parseChunk(Chunk &C, int forcedType, const std::unordered_map<std::string, 
                 L.extraEnd = (uint32_t)((eol[-1] == '\t' ? eol - 1 : eol) - p);
             }
             // Liftover::visitLine (halLiftover.cpp:52-66)
-            key.assign(fb[0], fe[0]);
-            auto it = seqByName.find(key);
+            // (the lines of a file mostly name one sequence after the other: the name is looked up when it changes)
+            if (!haveKey || key.size() != (size_t)(fe[0] - fb[0]) || memcmp(key.data(), fb[0], key.size()) != 0) {
+                key.assign(fb[0], fe[0]);
+                keySeq = seqByName.find(key);
+                haveKey = true;
+            }
+            const auto it = keySeq;
             L.seq = -1;
             if (it == seqByName.end()) {
                 C.notes.push_back("?" + key);
