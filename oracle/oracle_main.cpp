@@ -351,7 +351,7 @@ static int cmdColumnRows(int argc, char **argv) {
     std::vector<std::string> pos;
     i64 maxInsertLength = 0;
     bool noDupes = false, noAncestors = false, unique = false;
-    std::string batches;
+    std::string batches, targetGenomes;
     i64 chunk = 1 << 21;
     for (int i = 0; i < argc; ++i) {
         std::string a = argv[i];
@@ -361,6 +361,8 @@ static int cmdColumnRows(int argc, char **argv) {
             batches = argv[++i];
         else if (a == "--chunk")
             chunk = atoll(argv[++i]);
+        else if (a == "--targetGenomes")
+            targetGenomes = argv[++i];
         else if (a == "--noDupes")
             noDupes = true;
         else if (a == "--noAncestors")
@@ -397,6 +399,17 @@ static int cmdColumnRows(int argc, char **argv) {
         };
         static_assert(sizeof(Row) == 16, "ColumnRowHost");
         std::ofstream out(batches, std::ios::binary);
+        std::set<int> targetSet; // hal2maf --targetGenomes (the reference is added by the iterator itself)
+        for (size_t a0 = 0; a0 < targetGenomes.size();) {
+            size_t b0 = targetGenomes.find(',', a0);
+            if (b0 == std::string::npos)
+                b0 = targetGenomes.size();
+            const int g = al.genomeByName(targetGenomes.substr(a0, b0 - a0));
+            if (g < 0)
+                throw std::runtime_error("--targetGenomes: genome not found");
+            targetSet.insert(g);
+            a0 = b0 + 1;
+        }
         i64 total = 0;
         for (const Sequence &Sq : al.genomes[(size_t)ref].seqs) { // (an export of its own per sequence, as hal2maf makes them)
             if (Sq.length == 0)
@@ -406,7 +419,7 @@ static int cmdColumnRows(int argc, char **argv) {
             // written (not canonical on the reference); heads and 3s have their rows
             std::vector<uint8_t> head((size_t)Sq.length, unique ? 2 : 1);
             std::vector<std::vector<Row>> rowsOf((size_t)Sq.length);
-            ColumnIterator col(&al, ref, nullptr, Sq.start, Sq.start + Sq.length - 1, noDupes, noAncestors, false, unique, 0);
+            ColumnIterator col(&al, ref, targetSet.empty() ? nullptr : &targetSet, Sq.start, Sq.start + Sq.length - 1, noDupes, noAncestors, false, unique, 0);
             i64 prevWritten = -2;
             std::vector<Row> prev, cur;
             for (;;) {

@@ -30,6 +30,8 @@ with tempfile.TemporaryDirectory() as tmp:
                     col.append("--noAncestors")
                 if rng.random() < 0.4:  # (which columns the iterator walks and writes: marks 2 and 3 of the batches)
                     col.append("--unique")
+                if rng.random() < 0.25 and len(al) > 2:  # (the columns' scope: the spanning tree of the targets and the reference)
+                    col += ["--targetGenomes", ",".join(g["name"] for g in rng.sample(al, rng.randint(1, min(3, len(al)))))]
                 if rng.random() < 0.5:
                     host += ["--maxBlockLen", str(rng.choice([1, 2, 5, 17, 100]))]
                 if rng.random() < 0.3:
