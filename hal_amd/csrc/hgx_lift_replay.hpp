@@ -6,8 +6,10 @@
 #pragma once
 #ifdef HGX_HOST_PROFILE
 #include "../../include/hgx.h"
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include <stdexcept>
 #include <vector>
 
@@ -36,6 +38,22 @@ struct LiftReplay {
             have = false;
         }
         base += (int64_t)n;
+    }
+    // the rows of the intervals [first, first + n) of the conversion, their indices counted from `first` (the parallel text path:
+    // its groups of chunks are lifted side by side, by several handles; one conversion a process)
+    std::vector<hgx_record> all;
+    std::once_flag loaded;
+    void range(int64_t first, size_t n, std::vector<hgx_record> &recs) {
+        std::call_once(loaded, [this]() {
+            hgx_record r;
+            while (fread(&r, sizeof r, 1, f) == 1)
+                all.push_back(r);
+        });
+        auto lo = std::lower_bound(all.begin(), all.end(), first, [](const hgx_record &a, int64_t q) { return a.query < q; });
+        auto hi = std::lower_bound(lo, all.end(), first + (int64_t)n, [](const hgx_record &a, int64_t q) { return a.query < q; });
+        recs.assign(lo, hi);
+        for (hgx_record &r : recs)
+            r.query -= first;
     }
 };
 inline LiftReplay &liftReplay() {

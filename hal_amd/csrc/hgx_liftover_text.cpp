@@ -578,15 +578,20 @@ bool liftoverTextFast(hgx_alignment *const *als, int nAls, int srcGenome, const 
             if (round < groups[(size_t)d].size() && groups[(size_t)d][round].firstChunk < limit) {
                 grp[(size_t)d] = &groups[(size_t)d][round];
 #ifdef HGX_HOST_PROFILE
-                static std::vector<int64_t> replayStarts, replayEnds; // (the profiling build's stand-ins for the plan's pinned staging)
-                static std::vector<uint8_t> replayStrands;
-                if (liftReplay().f && nAls == 1) {
-                    replayStarts.resize(grp[0]->numQueries + 1);
-                    replayEnds.resize(grp[0]->numQueries + 1);
-                    replayStrands.resize(grp[0]->numQueries + 1);
-                    gs[0] = replayStarts.data();
-                    ge[0] = replayEnds.data();
-                    st[0] = replayStrands.data();
+                static std::vector<std::vector<int64_t>> replayStarts, replayEnds; // (the profiling build's stand-ins for the plans' pinned staging)
+                static std::vector<std::vector<uint8_t>> replayStrands;
+                if (liftReplay().f) {
+                    if (replayStarts.size() < (size_t)nAls) {
+                        replayStarts.resize((size_t)nAls);
+                        replayEnds.resize((size_t)nAls);
+                        replayStrands.resize((size_t)nAls);
+                    }
+                    replayStarts[(size_t)d].resize(grp[(size_t)d]->numQueries + 1);
+                    replayEnds[(size_t)d].resize(grp[(size_t)d]->numQueries + 1);
+                    replayStrands[(size_t)d].resize(grp[(size_t)d]->numQueries + 1);
+                    gs[(size_t)d] = replayStarts[(size_t)d].data();
+                    ge[(size_t)d] = replayEnds[(size_t)d].data();
+                    st[(size_t)d] = replayStrands[(size_t)d].data();
                 } else
 #endif
                 if (grp[(size_t)d]->numQueries)
@@ -638,15 +643,19 @@ bool liftoverTextFast(hgx_alignment *const *als, int nAls, int srcGenome, const 
                     return;
                 try {
 #ifdef HGX_HOST_PROFILE
-                    static std::vector<hgx_record> replayRecs;
+                    static std::vector<std::vector<hgx_record>> replayRecsOf(64);
                     static std::vector<uint32_t> replayWords, replayFirst;
-                    if (liftReplay().f && nAls == 1) {
-                        liftReplay().batch(grp[0]->numQueries, replayRecs);
-                        recs[0] = replayRecs.data();
-                        nRecs[0] = replayRecs.size();
+                    if (liftReplay().f && nAls <= 64) {
+                        std::vector<hgx_record> &replayRecs = replayRecsOf[(size_t)d];
+                        int64_t before = 0; // the intervals of the chunks in front of the group, in input order
+                        for (size_t i = 0; i < grp[(size_t)d]->firstChunk; ++i)
+                            before += (int64_t)chunks[i].numQueries;
+                        liftReplay().range(before, grp[(size_t)d]->numQueries, replayRecs);
+                        recs[(size_t)d] = replayRecs.data();
+                        nRecs[(size_t)d] = replayRecs.size();
                         // HGX_REPLAY_PACKED: the records in the 8-byte form the device hands over when they fit it (start, length |
                         // sequence << 22 | strand << 29, every interval's first record), so that this reading of them is covered too
-                        bool fits = getenv("HGX_REPLAY_PACKED") != nullptr;
+                        bool fits = nAls == 1 && getenv("HGX_REPLAY_PACKED") != nullptr;
                         for (const hgx_record &r : replayRecs)
                             fits = fits && r.tgt_start >= 0 && r.tgt_start < ((int64_t)1 << 32) && r.tgt_end - r.tgt_start < (1 << 22) && r.tgt_seq < 128;
                         if (fits) {

@@ -97,7 +97,16 @@ with tempfile.TemporaryDirectory() as tmp:
                 env["HGX_REPLAY_PACKED"] = "1"
             if rng.random() < 0.5:  # (else: inputs of one column count, BED out, take the parallel text path of hgx_liftover_text.cpp)
                 env["HGX_TEXT_GENERAL"] = "1"
-            r1 = subprocess.run([TOOL, "--device", "-1"] + opts + [img, src["name"], bed, tgt["name"], got], env=env, stderr=subprocess.PIPE)
+            psl = any(o.startswith("--outPSL") for o in opts)
+            if not psl and shape in ("uniform", "extras") and rng.random() < 0.5:
+                # several handles (hgx_liftover_convert_multi: the lines shared out, one round or several, the shares' texts collated)
+                env2 = dict(env, HGX_LIB_PATH=LIB.split()[-1], LD_PRELOAD=" ".join(LIB.split()[:-1]))
+                env2.pop("HGX_REPLAY_PACKED", None)
+                env2.pop("HGX_TEXT_GENERAL", None)
+                r1 = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "scripts", "r04_cpu_liftover_multi.py"), img, src["name"], bed, tgt["name"], got,
+                                     str(rng.randint(2, 4))] + opts, env=env2, stderr=subprocess.PIPE)
+            else:
+                r1 = subprocess.run([TOOL, "--device", "-1"] + opts + [img, src["name"], bed, tgt["name"], got], env=env, stderr=subprocess.PIPE)
             exports += 1
             a = open(want).read() if os.path.exists(want) else None
             b = open(got).read() if os.path.exists(got) else None
