@@ -1231,7 +1231,9 @@ struct TextBuffer {
 
 static int renderThreads() { // hal2maf's rendering threads per batch (HGX_MAF_RENDER_THREADS; the walk is one thread beside them)
     const char *e = getenv("HGX_MAF_RENDER_THREADS"); // (read per batch: a process can try several settings)
-    return e ? std::max(1, atoi(e)) : 32;
+    // (48: with the walk at a half of its old time the rendering is what it waits for — config 3 in one process on the GPU box:
+    // 24 threads 0.67 s, 32 0.74-0.75, 48 0.63, 64 0.61, profiles/r04y_gpu_maf_diag_threads.txt; more threads also disturb the walk more)
+    return e ? std::max(1, atoi(e)) : 48;
 }
 static size_t describeThreads(size_t heads) { // the threads that describe and sort a device batch's rows (HGX_MAF_DESCRIBE_THREADS)
     if (const char *e = getenv("HGX_MAF_DESCRIBE_THREADS"))
