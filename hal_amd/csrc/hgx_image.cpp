@@ -80,7 +80,7 @@ void Image::validate() const {
             if (++steps > ng)
                 fail(genomes[(size_t)gi].name + ": parent links form a cycle");
     }
-    for (size_t gi = 0; gi < genomes.size(); ++gi) {
+    forEachGenome(genomes.size(), [&](size_t gi) {
         const GenomeTables &G = genomes[gi];
         if ((int64_t)G.tStart.size() != G.numTop + 1 || (int64_t)G.bStart.size() != G.numBot + 1)
             fail(G.name + ": start table size");
@@ -198,7 +198,7 @@ void Image::validate() const {
             fail(G.name + ": sequence lengths do not sum to the genome length");
         if (!G.seqs.empty() && ((G.numTop > 0 && topAt != G.numTop) || (G.numBot > 0 && botAt != G.numBot)))
             fail(G.name + ": segments outside every sequence");
-    }
+    });
 }
 
 // ---- HGX file ----

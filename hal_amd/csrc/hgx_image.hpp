@@ -11,12 +11,48 @@
 // A segment's length is next.start - start, so each start table carries one sentinel entry
 // (mmapTopSegment.h:78-80, mmapGenome.cpp:141).
 #pragma once
+#include <algorithm>
+#include <atomic>
+#include <exception>
+#include <thread>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
 #include <vector>
 
 namespace hgx {
+
+// fn(g) for every genome g < n on a few threads (a genome's tables are converted and checked on their own; what fn throws for the
+// genome with the smallest index comes out, as if the genomes had been gone through in order)
+template <class Fn> void forEachGenome(size_t n, Fn fn) {
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = (unsigned)std::min<size_t>(std::max(1u, std::min(nt ? nt : 1u, 16u)), n);
+    if (nt <= 1) {
+        for (size_t g = 0; g < n; ++g)
+            fn(g);
+        return;
+    }
+    std::vector<std::exception_ptr> failed(n);
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+        for (size_t g; (g = next.fetch_add(1)) < n;) {
+            try {
+                fn(g);
+            } catch (...) {
+                failed[g] = std::current_exception();
+            }
+        }
+    };
+    std::vector<std::thread> threads;
+    for (unsigned t = 1; t < nt; ++t)
+        threads.emplace_back(work);
+    work();
+    for (std::thread &t : threads)
+        t.join();
+    for (size_t g = 0; g < n; ++g)
+        if (failed[g])
+            std::rethrow_exception(failed[g]);
+}
 
 static const int64_t NULL_INDEX = -1; // api/impl/halCommon.cpp:18
 

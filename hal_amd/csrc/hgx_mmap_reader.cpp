@@ -150,7 +150,7 @@ Image readMmapHal(const std::string &path) {
         }
     }
     // segment tables
-    for (uint64_t g = 0; g < numGenomes; ++g) {
+    forEachGenome((size_t)numGenomes, [&](size_t g) {
         GenomeTables &G = img.genomes[g];
         const uint64_t nt = (uint64_t)G.numTop, nb = (uint64_t)G.numBot, nc = G.children.size();
         G.tStart.resize(nt + 1);
@@ -204,7 +204,7 @@ Image readMmapHal(const std::string &path) {
             G.tStart[nt] = G.totalLength;
         if (nb > 0 && G.bStart[nb] != G.totalLength)
             G.bStart[nb] = G.totalLength;
-    }
+    });
     return img;
 }
 
