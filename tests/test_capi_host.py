@@ -431,3 +431,14 @@ def test_wig_lines_are_snprintf_lines(tmp_path):
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-I", os.path.join(ROOT, "hal_amd", "csrc"), "-o", exe,
                            os.path.join(ROOT, "tests", "cpp", "wig_text_check.cpp")])
     assert subprocess.run([exe], stdout=subprocess.PIPE, check=True).stdout.decode().strip() == "same"
+
+
+def test_text_memory_keeps_the_block_released_last(tmp_path):
+    """hgx_textmem: the texts' mappings grow with their contents, and released blocks are kept most-recent-first (two small kept
+    blocks used to turn every larger text away: a fresh mapping and its page faults per call)."""
+    exe = str(tmp_path / "textmem_check")
+    src = os.path.join(ROOT, "hal_amd", "csrc")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-I", src, "-o", exe, os.path.join(ROOT, "tests", "cpp", "textmem_check.cpp"),
+                           os.path.join(src, "hgx_textmem.cpp")])
+    env = dict(os.environ, HGX_TEXT_HUGEPAGES="0")  # (no huge-page advice: a VM with fragmented memory stalls on it)
+    assert subprocess.run([exe], stdout=subprocess.PIPE, check=True, env=env).stdout.decode().strip() == "same"
