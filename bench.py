@@ -51,16 +51,15 @@ def make_queries(length, n, seed):
     return starts, lens, strand
 
 
-def cpu_baseline(al, src_name, tgt_name, starts, lens, strand, seq_name, sample, all_cores_sample=0):
+def cpu_baseline(al, src_name, tgt_name, starts, lens, strand, seq_name, sample, all_cores_sample=0, img=None):
     """Oracle (oracle/_build/hal_oracle) on the first `sample` intervals of this rank's batch, single thread; and, as a
     fairness row, `all_cores_sample` intervals split over one oracle process per host core (the reference's own way of
     scaling: a pool of processes, stats/halStats.py:16,38)."""
-    oracle = os.path.join(ROOT, "oracle", "_build", "hal_oracle")
-    if not os.path.exists(oracle):
-        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    oracle = oracle_bin()
     with tempfile.TemporaryDirectory() as tmp:
-        img = os.path.join(tmp, "bench.hgx")
-        al.save(img)
+        if img is None:
+            img = os.path.join(tmp, "bench.hgx")
+            al.save(img)
 
         def write_bed(path, lo, hi):
             with open(path, "w") as f:
@@ -95,6 +94,61 @@ def cpu_baseline(al, src_name, tgt_name, starts, lens, strand, seq_name, sample,
     return st, text, multi
 
 
+def oracle_bin():
+    oracle = os.path.join(ROOT, "oracle", "_build", "hal_oracle")
+    if not os.path.exists(oracle):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    return oracle
+
+
+def host_cpu_model():
+    try:
+        return [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        return ""
+
+
+def cpu_columns_baseline(img, kind, ref_name, seq_name, length, tmp, tag, all_cores_total=0, extra=()):
+    """The oracle's column loop — `maf`: MafExport::convertSequence (maf/impl/halMafExport.cpp:46-81), `depth`: printSequence
+    (alignmentDepth/halAlignmentDepth.cpp:215-308) — single-threaded over the reference's first `length` columns (the time of
+    the loop itself: image load and file writing are outside), its text for the parity gate, and, as the fairness row, one
+    process per host core over consecutive slices (the reference's own way to use more cores: hal2mafMP.py's slices)."""
+    oracle = oracle_bin()
+
+    def cmd(out, start, n):
+        c = [oracle, kind, img] + ([out] if kind == "maf" else [ref_name, out]) + (["--refGenome", ref_name] if kind == "maf" else [])
+        return c + list(extra) + ["--refSequence", seq_name, "--start", str(start), "--length", str(n), "--stats"]
+    out = os.path.join(tmp, "%s.%s" % (tag, kind))
+    st = json.loads(subprocess.run(cmd(out, 0, length), check=True, stdout=subprocess.PIPE).stdout.decode())
+    with open(out, "rb") as f:
+        text = f.read()
+    res = {"value": length / st["seconds"], "unit": "columns/s", "cores": 1, "kind": "port", "host_cpu": host_cpu_model(),
+           "sample": "the oracle's %s over the first %d columns of %s, the column loop's time only (image load and the file excluded)"
+                     % ("MafExport::convertSequence --noAncestors" if kind == "maf" else "halAlignmentDepth printSequence", length, ref_name),
+           "seconds": st["seconds"]}
+    cores = os.cpu_count() or 1
+    if all_cores_total > 0 and cores > 1:
+        per = max(1, all_cores_total // cores)
+        procs = [subprocess.Popen(cmd(os.path.join(tmp, "%s.%d.%s" % (tag, c, kind)), c * per, per), stdout=subprocess.PIPE) for c in range(cores)]
+        secs = [json.loads(pr.communicate()[0].decode())["seconds"] for pr in procs]
+        for c in range(cores):
+            try:
+                os.unlink(os.path.join(tmp, "%s.%d.%s" % (tag, c, kind)))
+            except OSError:
+                pass
+        res["all_cores"] = {"value": per * cores / max(secs), "unit": "columns/s", "cores": cores,
+                            "sample": "%d columns in slices of %d over %d oracle processes (the loop time of the slowest)" % (per * cores, per, cores)}
+    os.unlink(out)
+    return res, text
+
+
+def maf_prefix_matches(oracle_text, gpu_prefix):
+    """The export of a whole genome begins with the export of its first L columns, but for the slice's last block (it ends where the
+    slice does): the oracle's text up to its last block is held against the timed export's text."""
+    cut = oracle_text.rfind(b"\na")
+    return cut > 0 and len(gpu_prefix) >= cut and oracle_text[:cut] == gpu_prefix[:cut]
+
+
 def lib_sha16():
     import hashlib
     with open(os.path.join(ROOT, "hal_amd", "libhgx.so"), "rb") as f:
@@ -116,6 +170,68 @@ def kernel_sources_sha16():
     return h.hexdigest()[:16]
 
 
+_KERNEL_CODE = {}
+
+
+def kernel_code_sha16s(lib_path=None):
+    """{kernel name: hash of its machine code} for every hgx kernel of the library: the gfx950 code objects are taken out of
+    libhgx.so (llvm-objdump --offloading), and of every FUNC symbol hgx::k_* the bytes of its body are hashed — all instantiations
+    of a template under the template's name.  A PMC measurement of a kernel stays valid exactly as long as this stays the same:
+    host-side edits and edits to other kernels leave it alone (what the file-level hashes could not tell apart).  {} when the
+    tools are not there."""
+    import hashlib
+    import re
+    import shutil
+    import struct
+    lib_path = lib_path or os.path.join(ROOT, "hal_amd", "libhgx.so")
+    if lib_path in _KERNEL_CODE:
+        return _KERNEL_CODE[lib_path]
+    out = {}
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            copy = os.path.join(tmp, "lib.so")
+            shutil.copyfile(lib_path, copy)
+            subprocess.run([objdump, "--offloading", copy], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            per = {}
+            for name in sorted(os.listdir(tmp)):
+                if "amdgcn" not in name:
+                    continue
+                data = open(os.path.join(tmp, name), "rb").read()
+                if data[:4] != b"\x7fELF" or data[4] != 2:
+                    continue
+                shoff, = struct.unpack_from("<Q", data, 0x28)
+                shentsize, shnum, shstrndx = struct.unpack_from("<HHH", data, 0x3A)
+                secs = [struct.unpack_from("<IIQQQQIIQQ", data, shoff + i * shentsize) for i in range(shnum)]
+                for sec in secs:
+                    if sec[1] != 2:  # SHT_SYMTAB
+                        continue
+                    stroff = secs[sec[6]][4]
+                    for k in range(sec[5] // 24):
+                        st_name, st_info, _, st_shndx, st_value, st_size = struct.unpack_from("<IBBHQQ", data, sec[4] + 24 * k)
+                        if (st_info & 15) != 2 or st_size == 0 or st_shndx == 0 or st_shndx >= shnum:  # STT_FUNC with a body
+                            continue
+                        end = data.index(b"\0", stroff + st_name)
+                        sym = data[stroff + st_name:end].decode("ascii", "replace")
+                        m = re.match(r"_ZN3hgx(?:L|\d+_GLOBAL__N_1)?(\d+)(k_\w+)", sym)
+                        if not m:
+                            continue
+                        base = m.group(2)[:int(m.group(1))]
+                        host = secs[st_shndx]
+                        off = host[4] + (st_value - host[3])
+                        per.setdefault(base, {})[sym] = hashlib.sha256(data[off:off + st_size]).hexdigest()
+            for base, syms in per.items():
+                h = hashlib.sha256()
+                for sym in sorted(syms):
+                    h.update(sym.encode())
+                    h.update(syms[sym].encode())
+                out[base] = h.hexdigest()[:16]
+    except Exception:
+        out = {}
+    _KERNEL_CODE[lib_path] = out
+    return out
+
+
 def pmc_traffic(kernel, form="kernels"):
     """HBM bytes per launch of `kernel` from the PMC passes of profiles/scripts/r04_pmc.py (profiles/pmc_traffic.json; form
     "kernels": one batch repeated, "rotating": four batches in turn), or
@@ -127,8 +243,13 @@ def pmc_traffic(kernel, form="kernels"):
         d = json.load(open(path))
     except Exception:
         return None, "no profiles/pmc_traffic.json"
+    # (per kernel first: the hash of the kernel's own machine code as the PMC run recorded it — host-side commits and edits to other
+    # kernels do not void a measurement; then the whole library / all device sources, as files of earlier rounds have it)
+    recorded = d.get("kernel_code_sha16", {}).get(kernel)
+    if recorded is not None and recorded == kernel_code_sha16s().get(kernel):
+        return d.get(form, {}).get(kernel), d.get("source", "") + " [kernel code %s]" % recorded
     if d.get("libhgx_sha16") != lib_sha16() and d.get("kernel_sources_sha16") != kernel_sources_sha16():
-        return None, "profiles/pmc_traffic.json was measured on other device code (library %s); rerun profiles/scripts/r04_pmc.py" % d.get("libhgx_sha16")
+        return None, "profiles/pmc_traffic.json was measured on other code of %s (library %s); rerun profiles/scripts/r05_pmc.py" % (kernel, d.get("libhgx_sha16"))
     return d.get(form, {}).get(kernel), d.get("source", "")
 
 
@@ -207,6 +328,10 @@ def main():
     ap.add_argument("--target", default="Genome_2")
     ap.add_argument("--cpu-sample", type=int, default=300000, help="intervals timed on the CPU oracle (0 = skip)")
     ap.add_argument("--cpu-all-cores", type=int, default=1, help="also time the oracle sharded over every host core")
+    ap.add_argument("--cpu-columns", type=int, default=4000000,
+                    help="columns of the reference genome the oracle's hal2maf and halAlignmentDepth loops are timed on, beside the column "
+                         "legs (the parity gate of those legs is the same slice; 0 = skip)")
+    ap.add_argument("--cpu-columns-cfg5", type=int, default=1000000, help="the same for config 5's depth scan on the 50-genome alignment")
     ap.add_argument("--columns", type=int, default=1, help="also time the column-depth kernel over the whole source genome (0 = skip)")
     ap.add_argument("--maf-columns", type=int, default=8000000,
                     help="hal2maf (BASELINE config 3) over the first N reference columns, end to end to MAF text (0 = skip; one GPU only)")
@@ -219,8 +344,9 @@ def main():
     ap.add_argument("--in-flight", type=int, default=2, help="batches in flight on one GPU without an exchange: 2 (two plans, two streams) or 1")
     ap.add_argument("--sustained-seconds", type=float, default=2.0, help="extra leg: the same step repeated for about this long")
     ap.add_argument("--rotating", type=int, default=4,
-                    help="extra leg: this many DISTINCT batches (other seeds), each with a plan and output buffers of its own, taken in turn "
-                         "with two in flight — one rotation's working set (0.65 GB at 4) is past the 256 MiB Infinity Cache (0 = skip)")
+                    help="the timed loop takes this many DISTINCT batches (other seeds), each with a plan and output buffers of its own, in turn "
+                         "with two in flight — one rotation's working set (0.65 GB at 4) is past the 256 MiB Infinity Cache (0 or 1: one batch "
+                         "repeated, which stays in that cache; measured beside as `cached` otherwise)")
     ap.add_argument("--features", type=int, default=1,
                     help="extra legs for the other entry points of the path: halGetBlocksInTargetRange (ranges/s), hal2maf --unique, "
                          "--maxRefGap 100 and hgx_maf_export_multi over device clones (one GPU only)")
@@ -357,14 +483,28 @@ def main():
     # finishing general intervals) and the host's launch and wake-up times overlap the other batch.  `one_plan` reports the
     # same steps through one plan, batch after batch.  With an exchange every step carries a collective and one plan is used.
     in_flight = 1 if exchanging or args.in_flight <= 1 else 2
-    plans, streams, pending = [plan], [torch.cuda.current_stream()], [False, False]
+    # The timed loop takes K DISTINCT batches (other seeds), each with a plan — and so record, answer and count buffers — of its
+    # own, in turn, two in flight: a batch's inputs and buffers are touched again only after the K - 1 others have gone through
+    # (K = 4: 0.65 GB per rotation, past the 256 MiB Infinity Cache).  One batch passed through two plans again and again — what
+    # `value` was up to round 4 — has its whole working set in that cache; it is measured beside, as `cached`.
+    K = args.rotating if (in_flight == 2 and args.rotating > 1) else 1
+    plans, batches, streams = [plan], [(d_gs, d_ge, d_st)], [torch.cuda.current_stream()]
     if in_flight == 2:
-        plans.append(hal_amd.LiftoverPlan(al, src, tgt, max_queries=nq))
-        for _ in range(3):  # (the second plan's own change-over to the table, which is cached in the alignment by now)
-            plans[1].run(d_gs, d_ge, d_st)
-        plans[1].set_timing(0)
         streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-    counter = {"i": 0, "nrec": nrec}
+        for k in range(1, max(K, 2)):
+            if K > 1:
+                s_k, l_k, d_k = make_queries(length, nq, 5000 + 17 * k + 101 * rank)
+                batches.append(((s_k + seq_start).to(dev), (s_k + l_k - 1 + seq_start).to(dev), d_k.to(dev)))
+            else:
+                batches.append(batches[0])
+            pk = hal_amd.LiftoverPlan(al, src, tgt, max_queries=nq)
+            for _ in range(3):  # (the plan's own change-over to the table, which is cached in the alignment by now)
+                pk.run(*batches[k])
+            pk.set_timing(0)
+            plans.append(pk)
+    slots = len(plans)
+    pending, records = [False] * slots, [nrec] * slots
+    counter = {"i": 0}
 
     def step_one():
         ptr, nrec = plan.run(d_gs, d_ge, d_st)
@@ -376,22 +516,25 @@ def main():
 
     def finish(k):
         if pending[k]:
-            _, counter["nrec"] = plans[k].collect()
+            _, records[k] = plans[k].collect()
             pending[k] = False
 
     def step():
         if in_flight == 1:
-            return step_one()
-        k = counter["i"] & 1
+            records[0] = step_one()
+            return records[0]
+        i = counter["i"]
         counter["i"] += 1
+        k = i % slots
+        finish((i - 2) % slots)  # (two in flight: the batch two steps back is waited for)
         finish(k)
-        plans[k].submit(d_gs, d_ge, d_st, stream=streams[k])
+        plans[k].submit(*batches[k], stream=streams[i & 1])
         pending[k] = True
-        return counter["nrec"]
+        return records[k]
 
     def drain():
-        finish(0)
-        finish(1)
+        for k in range(slots):
+            finish(k)
 
     # settle (untimed): the first runs of a fresh process pay for lazy code-object loads and workspace growth, and a process
     # that starts while the previous GPU process is still being torn down sees extra host time per run for a second or two.
@@ -424,9 +567,9 @@ def main():
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        nrec = step()
+        step()
     drain()  # the batches still in flight belong to the timed region
-    nrec = counter["nrec"] if in_flight == 2 else nrec
+    nrec = sum(records) // slots  # (records of a step: the batches' mean)
     if exchanging:
         exchange.drain()  # the exchanges still under way belong to the timed region
     sync()
@@ -529,77 +672,36 @@ def main():
             drain()
         dt_s, _ = timed_steps(all_steps, 1, sync)
         sustained = {"steps": k, "seconds": dt_s, "value": nq * k / dt_s, "ms_per_step": 1e3 * dt_s / k, "in_flight": in_flight}
-    # ---- rotating: K distinct batches, a plan (and so output, answer and count buffers) each, taken in turn with two in flight.
-    # The timed loop above passes ONE batch through two plans again and again: its inputs, tables and even the records it writes
-    # (165 MB per plan) can stay in the 256 MiB Infinity Cache, and FETCH_SIZE counts what is served from there.  Here a batch
-    # and its buffers come round again only after K - 1 others have gone through (K = 4: 0.65 GB per rotation). ----
-    rotating = None
-    if args.rotating > 1 and in_flight == 2 and not exchanging:
-        K = args.rotating
-        r_plans, r_batches = [], []
-        for k in range(K):
-            s_k, l_k, d_k = make_queries(length, nq, 5000 + 17 * k + 101 * rank)
-            r_batches.append(((s_k + seq_start).to(dev), (s_k + l_k - 1 + seq_start).to(dev), d_k.to(dev)))
-            pk = hal_amd.LiftoverPlan(al, src, tgt, max_queries=nq)
-            for _ in range(3):
-                pk.run(*r_batches[k])
-            pk.set_timing(0)
-            r_plans.append(pk)
-        r_pending = [False] * K
-        r_records = [0] * K
+    # ---- cached: ONE batch through two plans again and again (`value` up to round 4): inputs, tables and even the records written
+    # (165 MB per plan) stay in the 256 MiB Infinity Cache, and FETCH_SIZE counts what is served from there ----
+    cached = None
+    if K > 1 and not exchanging:
+        plan_c = hal_amd.LiftoverPlan(al, src, tgt, max_queries=nq)
+        for _ in range(3):
+            plan_c.run(d_gs, d_ge, d_st)
+        plan_c.set_timing(0)
+        c_plans, c_pending = [plan, plan_c], [False, False]
 
-        def r_finish(k):
-            if r_pending[k]:
-                _, r_records[k] = r_plans[k].collect()
-                r_pending[k] = False
-
-        def r_loop(n_steps):
+        def c_loop(n_steps):
             for i in range(n_steps):
-                k = i % K
-                r_finish((i - 2) % K)  # (two in flight: the batch two steps back is waited for)
-                r_finish(k)
-                r_plans[k].submit(*r_batches[k], stream=streams[i & 1])
-                r_pending[k] = True
-            for k in range(K):
-                r_finish(k)
-        n_r = (max(args.steps, 4 * K) + K - 1) // K * K
-        r_loop(2 * K)
-        # (three times, all listed, the best one quoted: one run in five of this leg takes 1.7 ms per step instead of 0.09 on the
-        # test boxes, whichever kernels are built — a stall of ~85 ms somewhere under a collect, not a rate)
-        r_runs = [timed_steps(lambda: r_loop(n_r), 1, sync)[0] for _ in range(3)]
-        dt_r = min(r_runs)
-        # the kernels of these steps: every plan in turn, one batch at a time, HIP events around every launch, in the form the
-        # batches in flight are launched in
-        for pk in r_plans:
-            pk.set_workers(0)
-            pk.set_timing(2)
-        for i in range(n_r):
-            r_plans[i % K].run(*r_batches[i % K])
-        r_kt = {}
-        r_stats = r_plans[0].stats()
-        for pk in r_plans:
-            for kname, kv in pk.kernel_times().items():
-                acc = r_kt.setdefault(kname, {"ms": 0.0, "launches": 0, "top_derefs": 0, "bot_derefs": 0})
-                for f in acc:
-                    acc[f] += kv.get(f, 0)
-        r_bytes = plan_kernel_bytes(r_kt, dict(r_stats, records=sum(r_records) // K), n_r)
-        rotating = {"value": nq * n_r / dt_r, "unit": "intervals/s", "ms_per_step": 1e3 * dt_r / n_r, "runs_ms_per_step": [1e3 * t / n_r for t in r_runs],
-                    "steps": n_r, "batches": K,
-                    "batches_in_flight": 2, "records_per_step": sum(r_records) / K,
-                    "working_set_bytes_per_rotation": K * (17 * nq + 12 * nq + 4 * nq) + 40 * sum(r_records) + 16 * r_stats["composed_records"],
-                    "kernels_ms_per_step": {k: round(v["ms"] / n_r, 4) for k, v in sorted(r_kt.items())},
-                    "roofline_kernels": [
-                        {"kernel": k, "kernel_avg_ms": v["ms"] / max(1, v["launches"]), "algorithmic_bytes_per_launch": r_bytes.get(k, 0.0),
-                         "achieved": r_bytes.get(k, 0.0) / (v["ms"] / max(1, v["launches"]) * 1e-3) / 1e9 if v["ms"] > 0 else 0.0,
-                         "frac": r_bytes.get(k, 0.0) / (v["ms"] / max(1, v["launches"]) * 1e-3) / 1e9 / HBM_PEAK_GBS if v["ms"] > 0 else 0.0,
-                         "traffic": pmc_traffic(k, "rotating")[0]}
-                        for k, v in sorted(r_kt.items(), key=lambda kv: -kv[1]["ms"])],
-                    "what": "%d distinct 1 M-interval batches (other seeds), each with its own plan — its own record, answer and count buffers "
-                            "— taken in turn, two in flight on the two streams of `value`: a batch's inputs and buffers are touched again after "
-                            "the %d others, past the Infinity Cache; `value` repeats one batch (its working set fits the cache).  Kernel times: "
-                            "the same rotation one batch at a time with HIP events; traffic: the PMC passes over this form "
-                            "(profiles/scripts/r04_pmc.py --form rotating)" % (K, K - 1)}
-        del r_plans, r_batches
+                k = i & 1
+                if c_pending[k]:
+                    c_plans[k].collect()
+                    c_pending[k] = False
+                c_plans[k].submit(d_gs, d_ge, d_st, stream=streams[k])
+                c_pending[k] = True
+            for k in (0, 1):
+                if c_pending[k]:
+                    c_plans[k].collect()
+                    c_pending[k] = False
+        c_loop(10)
+        n_c = max(args.steps, 16)
+        c_runs = [timed_steps(lambda: c_loop(n_c), 1, sync)[0] for _ in range(3)]
+        cached = {"value": nq * n_c / min(c_runs), "unit": "intervals/s", "ms_per_step": 1e3 * min(c_runs) / n_c,
+                  "runs_ms_per_step": [1e3 * t / n_c for t in c_runs], "steps": n_c, "batches_in_flight": 2,
+                  "what": "ONE batch passed through two plans again and again, two in flight (the headline of rounds 2-4): the working set of a "
+                          "plan fits the 256 MiB Infinity Cache; `value` rotates %d distinct batches with buffers of their own" % K}
+        del plan_c, c_plans
 
     # ---- the same number of steps through ONE plan, batch after batch (what `value` was before batches were kept in flight) ----
     one_plan = None
@@ -626,15 +728,22 @@ def main():
 
     # ---- kernel times: the steps of the timed region again with HIP events around every launch (untimed) — through one plan, in
     # the form the batches in flight are launched in (no pass for the general intervals in front, see one_plan) ----
-    if in_flight == 2:
-        plan.set_workers(0)
-    plan.set_timing(2)
-    for _ in range(args.steps):
-        plan.run(d_gs, d_ge, d_st)
-    kt_total = plan.kernel_times()
+    n_kt = (max(args.steps, 4 * K) + K - 1) // K * K  # (every batch of the rotation as often as the others)
+    kt_total = {}
+    for pk in plans[:K]:
+        if in_flight == 2:
+            pk.set_workers(0)
+        pk.set_timing(2)
+    for i in range(n_kt):
+        plans[i % K].run(*batches[i % K])
+    for pk in plans[:K]:
+        for kname, kv in pk.kernel_times().items():
+            acc = kt_total.setdefault(kname, {"ms": 0.0, "launches": 0, "top_derefs": 0, "bot_derefs": 0})
+            for f in acc:
+                acc[f] += kv.get(f, 0)
+        pk.set_timing(1 if pk is plan else 0)
+        pk.set_workers(-1)
     kt_acc = {k: {"ms": v["ms"], "launches": v["launches"]} for k, v in kt_total.items()}
-    plan.set_timing(1)
-    plan.set_workers(-1)
 
     col_result = None
     if args.columns:
@@ -667,6 +776,7 @@ def main():
         col_result = (ncol, col_ms, gather_ms, depth_sum / ncol)
 
     if rank == 0:
+        kept = {}  # the beginnings of the timed column legs' texts, for their parity gates
         st = plan.stats()
         value = world * nq * args.steps / elapsed
         # ---- walk: the level-by-level kernels (HGX_COMPOSED_UP=0), the "per-query-interval graph chase" itself.  Its
@@ -699,7 +809,7 @@ def main():
         table_records = 0
         if st["composed_records"]:
             table_kernel = {3: "k_lift_merged", 2: "k_locate_through"}.get(st["composed_kind"], "k_locate_composed")
-            table_records = kt_total[table_kernel]["top_derefs"] // args.steps  # table records dereferenced per step
+            table_records = kt_total[table_kernel]["top_derefs"] // n_kt  # table records dereferenced per step
         wcounts = dict(top_derefs=wst["top_derefs"], bottom_derefs=wst["bottom_derefs"], source_pieces=wst["source_pieces"],
                        mapped_pieces=wst["mapped_pieces"])
         del walk_plan
@@ -708,13 +818,14 @@ def main():
         dom_name, dom_ms, dom_launches = dom[0], dom[1]["ms"], dom[1]["launches"]
         Q, T, B, R = st["queries"], wcounts["top_derefs"], wcounts["bottom_derefs"], st["records"]
         alg_walk = 24 * Q + 25 * T + 25 * B + 40 * R  # SURVEY 8(d), per step, by the reference's walk
-        kern_ms_total = sum(v["ms"] for v in kt_acc.values()) / args.steps
-        per_kernel_alg = plan_kernel_bytes(kt_total, st, args.steps)
-        own_bytes = sum(per_kernel_alg[k] * v["launches"] for k, v in kt_acc.items()) / args.steps  # what the timed kernels must move
+        kern_ms_total = sum(v["ms"] for v in kt_acc.values()) / n_kt
+        per_kernel_alg = plan_kernel_bytes(kt_total, dict(st, records=nrec), n_kt)  # (records: the batches' mean)
+        own_bytes = sum(per_kernel_alg[k] * v["launches"] for k, v in kt_acc.items()) / n_kt  # what the timed kernels must move
+        pmc_form = "rotating" if K > 1 else "kernels"
         dom_bytes_per_launch = per_kernel_alg.get(dom_name, 0.0)
         dom_avg_ms = dom_ms / max(1, dom_launches)
         achieved = dom_bytes_per_launch / (dom_avg_ms * 1e-3) / 1e9 if dom_avg_ms > 0 else 0.0
-        traffic, traffic_source = pmc_traffic(dom_name)
+        traffic, traffic_source = pmc_traffic(dom_name, pmc_form)
         # every timed kernel of the step priced the same way (the object above is the one that takes the most time)
         per_kernel_roofline = []
         for kname, kv in sorted(kt_acc.items(), key=lambda kv: -kv[1]["ms"]):
@@ -722,7 +833,7 @@ def main():
             k_bytes = per_kernel_alg.get(kname, 0.0)
             k_gbs = k_bytes / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms > 0 else 0.0
             per_kernel_roofline.append({"kernel": kname, "kernel_avg_ms": k_avg_ms, "algorithmic_bytes_per_launch": k_bytes,
-                                        "achieved": k_gbs, "frac": k_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic(kname)[0]})
+                                        "achieved": k_gbs, "frac": k_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic(kname, pmc_form)[0]})
         # measured device-copy rate on this GPU (read + write bytes of a 1 GiB device-to-device copy), SURVEY 8(d)
         cp_src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
         cp_dst = torch.empty_like(cp_src)
@@ -746,13 +857,13 @@ def main():
                                                                      "seed 2" if args.workload == "cfg2" else "seed 0", args.scale, nq,
                                                                      src_name, tgt_name),
                        "intervals_per_gpu": nq, "records_per_step": nrec_all, "parallelism": "query-shard x%d" % world,
-                       "regime": ("steady state: the timed steps are passes %d.. of this batch, through %s; the first plan's first pass "
+                       "regime": ("steady state: the timed steps are passes %d.. over the batches, through %s; the first plan's first pass "
                                   "(see `cold`) built its %s: %d records (%.0f MB) in %.1f ms on the device; %d table records "
                                   "dereferenced per step, %d of the %d intervals took the general (overlap-breaking) route; "
                                   "`walk` is the same batch without any table"
                                   % (passes_before_timing + 1,
-                                     "one plan" if in_flight == 1 else "two plans of the alignment with a batch each in flight on two streams "
-                                     "(hgx_liftover_submit / _collect; `one_plan`: the same steps batch after batch)",
+                                     "one plan" if in_flight == 1 else "%d plans of the alignment taken in turn, two batches in flight on two streams "
+                                     "(hgx_liftover_submit / _collect; `one_plan`: the same steps batch after batch through one plan)" % slots,
                                      kind_text.get(st["composed_kind"], "?"), st["composed_records"],
                                      st["composed_records"] * 16 / 1e6, st["composed_build_ms"], table_records, st["general_queries"], nq))
                        if st["composed_records"] else "level-by-level walk (k_up_chain)",
@@ -766,7 +877,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "measured_copy_GBs": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs,
-                         "kernel_avg_ms": dom_avg_ms, "kernel_launches_per_step": dom_launches / args.steps,
+                         "kernel_avg_ms": dom_avg_ms, "kernel_launches_per_step": dom_launches / n_kt,
                          "algorithmic_bytes_per_launch": dom_bytes_per_launch,
                          "kernels": per_kernel_roofline,
                          "whole_step": {"kernel_ms_per_step": kern_ms_total, "bytes_the_timed_kernels_must_move": own_bytes,
@@ -794,7 +905,7 @@ def main():
                              "one pass over the batch, wall clock with the device synchronised, in a process that has loaded its HIP code "
                              "objects on a 1 %-scale alignment before (a fresh process adds ~120 ms of module loading once)"},
             "walk": walk,
-            "kernels_ms_per_step": {k: round(v["ms"] / args.steps, 4) for k, v in sorted(kt_acc.items())},
+            "kernels_ms_per_step": {k: round(v["ms"] / n_kt, 4) for k, v in sorted(kt_acc.items())},
             "counts_per_step": {"queries": Q, "source_pieces": wcounts["source_pieces"], "top_derefs": T, "bottom_derefs": B,
                                 "mapped_pieces": wcounts["mapped_pieces"], "records": R, "deferred_queries": st["deferred_queries"],
                                 "general_queries": st["general_queries"], "table_records_dereferenced": table_records},
@@ -803,10 +914,13 @@ def main():
             out["sustained"] = sustained
         if one_plan:
             out["one_plan"] = one_plan
-        if rotating:
-            out["rotating"] = rotating
-            out["roofline"]["form"] = ("`value`'s: one batch repeated (kernel_avg_ms from that loop); rotating.roofline_kernels prices the same "
-                                       "kernels when the batches rotate past the Infinity Cache")
+        if cached:
+            out["cached"] = cached
+        out["roofline"]["form"] = (("`value`'s: %d distinct batches in turn, each with a plan and buffers of its own, two in flight (0.65 GB per "
+                                    "rotation at 4: past the Infinity Cache); kernel_avg_ms from the same rotation one batch at a time with HIP "
+                                    "events; traffic from the PMC passes over this form" % K) if K > 1 else "one batch repeated")
+        out["config"]["batches_rotating"] = K
+        out["config"]["working_set_bytes_per_rotation"] = K * (17 * nq + 12 * nq + 4 * nq) + 40 * sum(records[:K]) + 16 * st["composed_records"]
         if mapping_only:
             out["mapping_only"] = mapping_only
         out["timed_step"] = "map+allgather" if exchanging else "map_only"
@@ -845,10 +959,10 @@ def main():
             try:
                 al.alignment_depth_bytes(src, length=min(al.genome_length(src), 2000000))
                 wruns = []
-                for _ in range(2):
-                    t0 = time.perf_counter()
-                    wbytes = al.alignment_depth_bytes(src)
-                    wruns.append(time.perf_counter() - t0)
+                for _ in range(2):  # (the text's beginning is kept for the parity gate below: cpu_baseline; the call itself is timed)
+                    wbytes, wig_head, w_s = al.alignment_depth_bytes(src, prefix=4 * args.cpu_columns + 4096)
+                    wruns.append(w_s)
+                kept["wig_head"] = wig_head
                 out.setdefault("columns", {})["depth_wig"] = {"what": "hgx_alignment_depth end to end: wig text of %s's whole genome in host memory (PCIe inclusive); "
                                                                       "the better of two" % src_name,
                                                               "value": al.genome_length(src) / min(wruns), "unit": "columns/s", "seconds": min(wruns),
@@ -859,9 +973,9 @@ def main():
             # machine, text rendering) over the first N reference columns
             ncols = min(args.maf_columns, al.genome_length(src))
             al.maf_export_bytes(src, start=0, length=min(ncols, 200000), no_ancestors=True)  # (DNA upload, code objects)
-            t0 = time.perf_counter()
-            nbytes = al.maf_export_bytes(src, start=0, length=ncols, no_ancestors=True)
-            dt_m = time.perf_counter() - t0
+            nbytes, maf_head, dt_m = al.maf_export_bytes(src, start=0, length=ncols, no_ancestors=True, prefix=56 * args.cpu_columns + 65536)
+            if ncols > args.cpu_columns:
+                kept["maf_head"] = maf_head
             out.setdefault("columns", {})["hal2maf"] = {"metric": "MAF columns/sec (hal2maf --refGenome %s --noAncestors, end to end to MAF text in host memory)" % src_name,
                                                         "value": ncols / dt_m, "unit": "columns/s", "columns": ncols, "seconds": dt_m,
                                                         "maf_bytes": nbytes}
@@ -870,9 +984,9 @@ def main():
             ncols = al.genome_length(src)
             runs = []
             for _ in range(2):  # (the second export finds the text's memory and the rendering buffers of the first: both are listed)
-                t0 = time.perf_counter()
-                nbytes = al.maf_export_bytes(src, no_ancestors=True)
-                runs.append(time.perf_counter() - t0)
+                nbytes, maf_head, m_s = al.maf_export_bytes(src, no_ancestors=True, prefix=56 * args.cpu_columns + 65536)
+                runs.append(m_s)
+            kept["maf_head"] = maf_head  # (the text's beginning, for the parity gate: cpu_baseline below)
             dt_m = min(runs)
             out.setdefault("columns", {})["hal2maf_full"] = {"metric": "MAF columns/sec (hal2maf --refGenome %s --noAncestors over the whole genome, end to end to MAF text "
                                                         "in host memory; the better of two exports)" % src_name,
@@ -890,7 +1004,7 @@ def main():
                             streams=streams if in_flight == 2 else None)
             w["what"] = ("the timed configuration on int64-coordinate tables (HGX_FORCE_WIDE=1 copy of the same alignment: 32-byte table "
                          "records): same batch, same records")
-            w["records_match"] = w["records_per_step"] == nrec_all
+            w["records_match"] = w["records_per_step"] == st["records"]  # (the same batch: the rotation's first)
             w["ratio_to_int32_step"] = w["ms_per_step"] / (1e3 * elapsed / args.steps)
             if one_plan:
                 w["one_plan"]["ratio_to_int32"] = w["one_plan"]["ms_per_step"] / one_plan["ms_per_step"]
@@ -926,13 +1040,27 @@ def main():
                 al4.alignment_depth_bytes(s4, length=min(ncol4, 2000000))
                 wruns = []
                 for _ in range(2):
-                    t0 = time.perf_counter()
-                    wbytes = al4.alignment_depth_bytes(s4)
-                    wruns.append(time.perf_counter() - t0)
+                    wbytes, wig4_head, w_s = al4.alignment_depth_bytes(s4, prefix=4 * args.cpu_columns_cfg5 + 4096)
+                    wruns.append(w_s)
                 out["cfg5"]["wig"] = {"what": "hgx_alignment_depth end to end: the whole genome's wig text in host memory (PCIe inclusive); the better of two",
                                       "value": ncol4 / min(wruns), "unit": "columns/s", "seconds": min(wruns), "runs_seconds": wruns, "wig_bytes": wbytes}
             except Exception as e:  # (a leg beside the line, not the line)
                 out["cfg5"]["wig"] = {"error": str(e)[:300]}
+                wig4_head = None
+            if args.cpu_columns_cfg5 > 0 and args.cpu_sample > 0:
+                # the CPU figure beside config 5, and its parity gate: the oracle's halAlignmentDepth loop over the genome's first columns
+                try:
+                    with tempfile.TemporaryDirectory() as tmp4:
+                        img4 = os.path.join(tmp4, "cfg4.hgx")
+                        al4.save(img4)
+                        n5 = min(args.cpu_columns_cfg5, ncol4)
+                        base5, text5 = cpu_columns_baseline(img4, "depth", "Genome_44", al4.sequences(s4)[0][0], n5, tmp4, "cfg5",
+                                                            all_cores_total=4 * n5 if args.cpu_all_cores else 0)
+                    base5["parity_with_gpu"] = wig4_head is not None and wig4_head[:len(text5)] == text5
+                    base5["parity"] = "the oracle's wig of the first %d columns is the beginning of the timed call's text" % n5
+                    out["cfg5"]["cpu_baseline"] = base5
+                except Exception as e:
+                    out["cfg5"]["cpu_baseline"] = {"error": str(e)[:300]}
             del al4, d4
         if args.text_path and world == 1 and not args.exchange_selftest:
             # Liftover::convert as halLiftover runs it: BED text in, BED text out (parse, H2D, kernels, D2H, format), PCIe inclusive
@@ -1045,19 +1173,71 @@ def main():
             out["features"] = feats
         if args.cpu_sample > 0:
             sample = min(args.cpu_sample, nq)
+            cpu_tmp = tempfile.TemporaryDirectory()
+            img = os.path.join(cpu_tmp.name, "bench.hgx")
+            al.save(img)
             cst, text, multi = cpu_baseline(al, src_name, tgt_name, starts, lens, strand, seq_name, sample,
-                                            all_cores_sample=min(nq, 4 * sample) if args.cpu_all_cores else 0)
+                                            all_cores_sample=min(nq, 4 * sample) if args.cpu_all_cores else 0, img=img)
+            # ---- the CPU figures beside the column metric ("MAF columns/sec ... vs CPU ref"), each with the parity gate of the timed leg
+            # it stands beside: the oracle's loops over the reference genome's first --cpu-columns columns ----
+            ncc = min(args.cpu_columns, al.genome_length(src))
+            if ncc > 0 and "columns" in out:
+                try:
+                    based, textd = cpu_columns_baseline(img, "depth", src_name, seq_name, ncc, cpu_tmp.name, "cfg2d",
+                                                        all_cores_total=4 * ncc if args.cpu_all_cores else 0)
+                    if "wig_head" in kept:
+                        based["parity_with_gpu"] = kept["wig_head"][:len(textd)] == textd
+                        based["parity"] = "the oracle's wig of the first %d columns is the beginning of columns.depth_wig's timed text" % ncc
+                    else:  # (no wig leg in this run: the values of the depth kernel's leg)
+                        import numpy as np
+                        vals = al.columns_depth(src, 0, ncc)
+                        based["parity_with_gpu"] = bool(np.array_equal(np.array(textd.split(b"\n")[1:-1], dtype=np.int64), vals))
+                        based["parity"] = "the oracle's values of the first %d columns against hgx_columns_depth's" % ncc
+                    out["columns"]["cpu_baseline"] = based
+                except Exception as e:  # (a leg beside the line, not the line)
+                    out["columns"]["cpu_baseline"] = {"error": str(e)[:300]}
+                if want_maf:
+                    try:
+                        basem, textm = cpu_columns_baseline(img, "maf", src_name, seq_name, ncc, cpu_tmp.name, "cfg2m",
+                                                            all_cores_total=4 * ncc if args.cpu_all_cores else 0, extra=("--noAncestors",))
+                        basem["parity_with_gpu"] = "maf_head" in kept and maf_prefix_matches(textm, kept["maf_head"])
+                        basem["parity"] = ("the oracle's MAF of the first %d columns, up to its last block (a slice ends its last block where it ends), is "
+                                           "the beginning of the timed export's text" % ncc)
+                        basem["maf_bytes"] = len(textm)
+                        for leg in ("hal2maf_full", "hal2maf"):
+                            if leg in out["columns"]:
+                                out["columns"][leg]["cpu_baseline"] = basem
+                                break
+                    except Exception as e:
+                        out["columns"]["hal2maf_cpu_baseline"] = {"error": str(e)[:300]}
+            # ---- halGetBlocksInTargetRange on the CPU: the oracle's getBlocksInTargetRange, a call per range, the same ranges ----
+            if "features" in out and "blocks_in_target_range" in out["features"]:
+                try:
+                    rfile, ofile = os.path.join(cpu_tmp.name, "ranges.txt"), os.path.join(cpu_tmp.name, "viz.out")
+                    rr = [(int(a), int(a + b)) for a, b in zip(starts.numpy()[:100], lens.numpy()[:100])]
+                    with open(rfile, "w") as f:
+                        f.write("".join("%d %d\n" % r for r in rr))
+                    vst = json.loads(subprocess.run([oracle_bin(), "blockviz", img, tgt_name, src_name, seq_name, "--ranges", rfile, "--out", ofile,
+                                                     "--dupMode", "2", "--stats"], check=True, stdout=subprocess.PIPE).stdout.decode())
+                    want = open(ofile).read()
+                    got = al.blocks_in_target_ranges(tgt_name, src_name, seq_name, rr, dup_mode=2, adjacencies=True)
+                    got_text = "".join("# %d %d\n" % r + hal_amd.format_block_results(b, d) for r, (b, d) in zip(rr, got))
+                    out["features"]["blocks_in_target_range"]["cpu_baseline"] = {
+                        "median_us": None, "mean_us": 1e6 * vst["seconds"] / max(1, vst["ranges"]), "ranges_per_s": vst["ranges"] / vst["seconds"],
+                        "cores": 1, "kind": "port", "host_cpu": host_cpu_model(),
+                        "sample": "the oracle's getBlocksInTargetRange (blockViz/impl/halBlockViz.cpp:759-827), one call per range, the first %d "
+                                  "ranges of one_range_per_call" % len(rr),
+                        "parity_with_gpu": got_text == want}
+                except Exception as e:
+                    out["features"]["blocks_in_target_range"]["cpu_baseline"] = {"error": str(e)[:300]}
             # parity spot check of the timed configuration: GPU records of the sampled intervals vs the oracle's text
             ptr, n = plan.run(d_gs[:sample].contiguous(), d_ge[:sample].contiguous(), d_st[:sample].contiguous())
             import numpy as np
             recs = plan.records_to_tensor(ptr, n).cpu().numpy().view(hal_amd.RECORD_DTYPE).reshape(-1)
             tname = al.sequences(tgt)[0][0]
             gpu_text = "".join("%s\t%d\t%d\tq\t0\t%s\n" % (tname, r["tgt_start"], r["tgt_end"], r["strand"].decode()) for r in recs)
-            cpu_model = ""
-            try:
-                cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
-            except Exception:
-                pass
+            cpu_model = host_cpu_model()
+            cpu_tmp.cleanup()
             out["cpu_baseline"] = {"value": cst["intervals"] / cst["map_seconds"], "unit": "intervals/s", "cores": 1,
                                    "kind": "port", "host_cpu": cpu_model,
                                    "sample": "first %d intervals of rank 0's batch, oracle liftInterval+sort time only "

@@ -144,6 +144,7 @@ SYMBOLS = {
     "hgx_create_random": (C.c_int, [P(hgx_rand_opts), C.c_int, P(VP), P(VP)]),
     "hgx_save_image": (C.c_int, [VP, C.c_char_p, P(VP)]),
     "hgx_free": (None, [VP]),
+    "hgx_release_cached": (None, []),
     "hgx_version": (C.c_char_p, []),
 }
 

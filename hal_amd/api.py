@@ -1,5 +1,6 @@
 """Python mirror of the reference interfaces this library stands behind (argument names and meaning
 follow Liftover::convert, liftover/inc/halLiftover.h:25-28, and the Alignment/Genome getters)."""
+import time
 import ctypes as C
 from dataclasses import dataclass
 
@@ -300,23 +301,32 @@ class Alignment:
         finally:
             lib.hgx_free(out)
 
-    def alignment_depth_bytes(self, ref, ref_sequence=-1, start=0, length=0, step=1, count_dupes=False, no_ancestors=False):
-        """halAlignmentDepth end to end, the wig text left in library memory and released: returns its size (benchmark use)."""
+    def alignment_depth_bytes(self, ref, ref_sequence=-1, start=0, length=0, step=1, count_dupes=False, no_ancestors=False, prefix=0):
+        """halAlignmentDepth end to end, the wig text left in library memory and released: returns its size (benchmark use);
+        prefix > 0: (size, the text's first `prefix` bytes, seconds of the call itself) — what a parity check of a timed run looks at."""
         out, n, err = C.c_void_p(), C.c_size_t(), C.c_void_p()
+        t0 = time.perf_counter()
         if lib.hgx_alignment_depth(self._h, ref, ref_sequence, start, length, step, 1 if count_dupes else 0, 1 if no_ancestors else 0,
                                    None, 0, C.byref(out), C.byref(n), C.byref(err)) != 0:
             raise HgxError(take_error(err))
+        seconds = time.perf_counter() - t0
+        head = C.string_at(out, min(prefix, n.value)) if prefix > 0 and out.value else b""
         lib.hgx_free(out)
-        return n.value
+        return (n.value, head, seconds) if prefix > 0 else n.value
 
-    def maf_export_bytes(self, ref, ref_sequence=-1, start=0, length=0, no_ancestors=False, max_block_len=1000, unique=False, max_ref_gap=0):
-        """hal2maf end to end, the text left in library memory and released: returns its size (benchmark use)."""
+    def maf_export_bytes(self, ref, ref_sequence=-1, start=0, length=0, no_ancestors=False, max_block_len=1000, unique=False, max_ref_gap=0,
+                         prefix=0):
+        """hal2maf end to end, the text left in library memory and released: returns its size (benchmark use); prefix > 0: (size,
+        the text's first `prefix` bytes, seconds of the call itself)."""
         o = maf_opts(no_ancestors=no_ancestors, max_block_len=max_block_len, unique=unique, max_ref_gap=max_ref_gap)
         out, n, err = C.c_void_p(), C.c_size_t(), C.c_void_p()
+        t0 = time.perf_counter()
         if lib.hgx_maf_export(self._h, ref, ref_sequence, start, length, C.byref(o), None, 0, C.byref(out), C.byref(n), C.byref(err)) != 0:
             raise HgxError(take_error(err))
+        seconds = time.perf_counter() - t0
+        head = C.string_at(out, min(prefix, n.value)) if prefix > 0 and out.value else b""
         lib.hgx_free(out)
-        return n.value
+        return (n.value, head, seconds) if prefix > 0 else n.value
 
     def maf_export_global(self, no_dupes=False, no_ancestors=False, only_sequence_names=False, only_orthologs=False, max_block_len=1000,
                           print_tree=False):

@@ -834,6 +834,9 @@ static hgx_maf_opts mafOpts(const hgx_maf_opts *o) {
     const size_t first = offsetof(hgx_maf_opts, max_block_len) + sizeof(int64_t);
     if (o->struct_size < first)
         throw std::runtime_error("hgx_maf_opts.struct_size is not set (initialise the options with HGX_MAF_OPTS_INIT)");
+    if (o->struct_size > 4096 || o->struct_size % 4 != 0) // (a struct of a header to come is larger, not this large: garbage, or a caller built against hgx 0.1)
+        throw std::runtime_error("hgx_maf_opts.struct_size is implausible (" + std::to_string(o->struct_size) +
+                                 "): initialise the options with HGX_MAF_OPTS_INIT of this library's include/hgx.h");
     memcpy(&x, o, std::min<size_t>(o->struct_size, sizeof x));
     x.struct_size = (uint32_t)sizeof x;
     return x;
@@ -1042,8 +1045,12 @@ void hgx_free(void *p) {
     hgx::textFree(p); // (the library's large texts are mappings: hgx_textmem.hpp; everything else is malloc's)
 }
 
+void hgx_release_cached(void) {
+    hgx::textTrim();
+}
+
 const char *hgx_version(void) {
-    return "hgx 0.1 (HAL API 2.2 semantics; gfx950)";
+    return "hgx 0.2 (HAL API 2.2 semantics; gfx950)";
 }
 
 } // extern "C"

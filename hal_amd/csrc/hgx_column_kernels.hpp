@@ -689,8 +689,10 @@ static __global__ void __launch_bounds__(256) k_sweep_up(const BotRec<C> *__rest
             if (o >= len)
                 continue;
             // (the lane at the segment's end takes the segment's last V bases — some of them its neighbour's as well, which come out
-            // the same: element by element it was the one lane the other fifteen waited for)
-            if (o + V > len && len >= V)
+            // the same: element by element it was the one lane the other fifteen waited for.  Not when sums are added to what an
+            // earlier launch left (more than SWEEP_MAX_CHILDREN children, --countDupes): a base covered twice — by this lane and by
+            // the last lane of the round before, which has stored already — would get this launch's children added twice)
+            if (!(SUM && accumulate) && o + V > len && len >= V)
                 o = len - V;
             const bool whole = o + V <= len;
             SweepVec<M> v;

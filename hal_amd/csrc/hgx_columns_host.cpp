@@ -64,7 +64,11 @@ static void depthSequence(std::ostream &os, hgx_alignment *h, int genome, int se
     auto lines = [&os, sink](const int32_t *v, int64_t n) { wigLines(os, v, n, [sink](size_t b) { return sink ? sink->room(b) : nullptr; }); };
     if (!(moreDevices && !moreDevices->empty() && count >= 2)) {
         // one device: the values come chunk by chunk (sixteen million of them) while the chunk before is made into lines
-        columnsDepthChunksHost(h, genome, start + S.start, count, step, countDupes ? 1 : 0, opt, stats, (int64_t)1 << 24,
+        // (HGX_WIG_CHUNK: columns per chunk — the tests run genomes of a few thousand columns through several chunks)
+        int64_t chunk = (int64_t)1 << 24;
+        if (const char *e = getenv("HGX_WIG_CHUNK"))
+            chunk = std::max<int64_t>(1, atoll(e));
+        columnsDepthChunksHost(h, genome, start + S.start, count, step, countDupes ? 1 : 0, opt, stats, chunk,
                                [&lines](const int32_t *v, int64_t, int64_t n) { lines(v, n); });
         return;
     }

@@ -80,18 +80,25 @@ void Image::validate() const {
             if (++steps > ng)
                 fail(genomes[(size_t)gi].name + ": parent links form a cycle");
     }
-    forEachGenome(genomes.size(), [&](size_t gi) {
-        const GenomeTables &G = genomes[gi];
+    // the sizes of every genome's tables first, one after the other: the checks below run genome by genome on several threads
+    // and index into the parent's and the children's tables as well
+    for (int gi = 0; gi < ng; ++gi) {
+        const GenomeTables &G = genomes[(size_t)gi];
         if ((int64_t)G.tStart.size() != G.numTop + 1 || (int64_t)G.bStart.size() != G.numBot + 1)
             fail(G.name + ": start table size");
         if ((int64_t)G.tParent.size() != G.numTop || (int64_t)G.tParalogy.size() != G.numTop || (int64_t)G.tBotParse.size() != G.numTop ||
             (int64_t)G.tParentRev.size() != G.numTop || (int64_t)G.bTopParse.size() != G.numBot)
             fail(G.name + ": segment table size");
+        if (G.bChild.size() < G.children.size())
+            fail(G.name + ": child link table size");
         for (size_t k = 0; k < G.bChild.size(); ++k)
             if ((int64_t)G.bChild[k].size() != G.numBot || k >= G.bChildRev.size() || (int64_t)G.bChildRev[k].size() != G.numBot)
                 fail(G.name + ": child link table size");
         if (!G.dna.empty() && (int64_t)G.dna.size() != (G.totalLength + 1) / 2)
             fail(G.name + ": DNA is not (length + 1) / 2 bytes");
+    }
+    forEachGenome(genomes.size(), [&](size_t gi) {
+        const GenomeTables &G = genomes[gi];
         if (G.parent < 0)
             for (int64_t i = 0; i < G.numTop; ++i)
                 if (G.tParent[(size_t)i] != NULL_INDEX)

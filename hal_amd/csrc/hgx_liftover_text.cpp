@@ -18,6 +18,7 @@
 #include "hgx_liftover_host.hpp"
 #include "hgx_lift_replay.hpp"
 #include <mutex>
+#include <exception>
 #include <functional>
 #include <condition_variable>
 #include <algorithm>
@@ -368,6 +369,7 @@ struct TextPool {
     std::vector<std::thread> workers;
     const std::function<void()> *work = nullptr;
     unsigned generation = 0, want = 0, running = 0;
+    std::exception_ptr failure; // the first exception of a worker of the job under way
     void worker(unsigned idx) {
         unsigned seen = 0;
         for (;;) {
@@ -381,8 +383,15 @@ struct TextPool {
             }
             if (!w)
                 continue;
-            (*w)();
+            std::exception_ptr err;
+            try {
+                (*w)();
+            } catch (...) { // (handed to the caller of run: an exception that leaves a detached thread ends the process)
+                err = std::current_exception();
+            }
             std::lock_guard<std::mutex> lock(mu);
+            if (err && !failure)
+                failure = err;
             if (--running == 0)
                 done.notify_all();
         }
@@ -406,11 +415,23 @@ struct TextPool {
         }
         if (threads > 1)
             wake.notify_all();
-        w();
+        // (w and what it captured live on the caller's stack: whatever happens on this thread, the workers are waited for
+        // before run is left)
+        std::exception_ptr err;
+        try {
+            w();
+        } catch (...) {
+            err = std::current_exception();
+        }
         if (threads > 1) {
             std::unique_lock<std::mutex> lock(mu);
             done.wait(lock, [&] { return running == 0; });
+            if (!err)
+                err = failure;
+            failure = nullptr;
         }
+        if (err)
+            std::rethrow_exception(err);
         return true;
     }
 };
@@ -427,12 +448,29 @@ template <typename F> void forEachChunk(std::vector<Chunk> &chunks, unsigned thr
     };
     if (textPool().run(threads, work))
         return;
+    // (the pool is busy: threads of this call's own, joined whatever happens — an exception of one of them comes out here)
+    std::mutex errMu;
+    std::exception_ptr err;
+    const auto guarded = [&]() {
+        try {
+            work();
+        } catch (...) {
+            std::lock_guard<std::mutex> lock(errMu);
+            if (!err)
+                err = std::current_exception();
+        }
+    };
     std::vector<std::thread> pool;
-    for (unsigned t = 1; t < threads; ++t)
-        pool.emplace_back(work);
-    work();
+    try {
+        for (unsigned t = 1; t < threads; ++t)
+            pool.emplace_back(guarded);
+    } catch (...) { // (a thread could not be made: the ones there are do the work)
+    }
+    guarded();
     for (std::thread &t : pool)
         t.join();
+    if (err)
+        std::rethrow_exception(err);
 }
 
 } // namespace

@@ -26,6 +26,10 @@ TextMem &mem() {
 size_t pages(size_t bytes) {
     return (bytes + 4095) & ~(size_t)4095;
 }
+bool adviseHugePages() {
+    static const bool advise = !(getenv("HGX_TEXT_HUGEPAGES") && atoi(getenv("HGX_TEXT_HUGEPAGES")) == 0);
+    return advise;
+}
 void *mapFresh(size_t len) {
     void *p = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
     if (p == MAP_FAILED)
@@ -33,8 +37,7 @@ void *mapFresh(size_t len) {
     // (advice: the 2 MB extents inside the block fault in as one page each.  Where memory is fragmented and transparent_hugepage/defrag
     // is "madvise", such a fault waits for the kernel to compact memory — seconds for a few hundred megabytes on a long-running VM:
     // HGX_TEXT_HUGEPAGES=0 leaves the advice out)
-    static const bool advise = !(getenv("HGX_TEXT_HUGEPAGES") && atoi(getenv("HGX_TEXT_HUGEPAGES")) == 0);
-    if (advise)
+    if (adviseHugePages())
         (void)madvise(p, len, MADV_HUGEPAGE);
     return p;
 }
@@ -92,7 +95,8 @@ void *textRealloc(void *p, size_t bytes) {
     void *q = mremap(p, have, len, MREMAP_MAYMOVE);
     if (q == MAP_FAILED)
         return nullptr;
-    (void)madvise(q, len, MADV_HUGEPAGE);
+    if (adviseHugePages())
+        (void)madvise(q, len, MADV_HUGEPAGE);
     std::lock_guard<std::mutex> lock(M.mu);
     M.live.erase(p);
     M.live[q] = len;

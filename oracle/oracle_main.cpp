@@ -312,10 +312,17 @@ static int cmdBlockViz(int argc, char **argv) {
     std::vector<std::string> pos;
     bool doSeq = false, adj = true, tReversed = false;
     int dupMode = VIZ_QUERY_AND_TARGET_DUPS;
-    std::string coalName;
+    std::string coalName, rangesPath, outPath;
+    bool stats = false;
     for (int i = 0; i < argc; ++i) {
         std::string a = argv[i];
-        if (a == "--doSeq")
+        if (a == "--ranges")
+            rangesPath = argv[++i];
+        else if (a == "--out")
+            outPath = argv[++i];
+        else if (a == "--stats")
+            stats = true;
+        else if (a == "--doSeq")
             doSeq = true;
         else if (a == "--noAdj")
             adj = false;
@@ -327,6 +334,33 @@ static int cmdBlockViz(int argc, char **argv) {
             coalName = argv[++i];
         else
             pos.push_back(a);
+    }
+    if (!rangesPath.empty() && pos.size() == 4) {
+        // hal_oracle blockviz <img> <qSpecies> <tSpecies> <tChrom> --ranges <file of "tStart tEnd" lines> --out <file> [--stats]:
+        // one call per line (bench.py's CPU baseline beside features.blocks_in_target_range); every result behind a "# tStart tEnd" line
+        Alignment al = loadImage(pos[0]);
+        const int q = al.genomeByName(pos[1]), t = al.genomeByName(pos[2]);
+        const int coal = coalName.empty() ? -1 : al.genomeByName(coalName);
+        if (q < 0 || t < 0 || (!coalName.empty() && coal < 0)) {
+            std::cerr << "genome not found" << std::endl;
+            return 1;
+        }
+        std::ifstream in(rangesPath);
+        std::vector<std::pair<long long, long long>> ranges;
+        for (long long a, b; in >> a >> b;)
+            ranges.emplace_back(a, b);
+        std::ofstream out(outPath);
+        double seconds = 0;
+        for (auto &r : ranges) {
+            auto t0 = std::chrono::steady_clock::now();
+            VizResults res = getBlocksInTargetRange(al, q, t, pos[3], r.first, r.second, tReversed, doSeq, dupMode, adj, coal);
+            seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            out << "# " << r.first << " " << r.second << "\n";
+            printVizResults(out, res, doSeq);
+        }
+        if (stats)
+            std::cout << "{\"ranges\": " << ranges.size() << ", \"seconds\": " << seconds << "}" << std::endl;
+        return 0;
     }
     if (pos.size() != 6) {
         std::cerr << "usage: hal_oracle blockviz <img.hgx> <qSpecies> <tSpecies> <tChrom> <tStart> <tEnd>" << std::endl;

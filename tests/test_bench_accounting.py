@@ -38,3 +38,57 @@ def test_sweeps_own_bytes_on_a_three_genome_tree(hal):
 def test_device_source_identity_is_stable():
     a, b = bench.kernel_sources_sha16(), bench.kernel_sources_sha16()
     assert a == b and len(a) == 16
+
+
+def test_kernel_code_identity_per_kernel():
+    """the PMC traffic of a kernel is tied to the hash of that kernel's machine code in libhgx.so (bench.kernel_code_sha16s): every
+    timed kernel has one, two readings agree, and a recorded value voids exactly its own kernel"""
+    import json
+    import tempfile
+    ids = bench.kernel_code_sha16s()
+    for k in ("k_lift_classify", "k_lift_merged", "k_lift_totals", "k_up_chain", "k_sweep_up", "k_sweep_down", "k_finish_lds"):
+        assert len(ids.get(k, "")) == 16, k
+    bench._KERNEL_CODE.clear()
+    assert bench.kernel_code_sha16s() == ids
+    real = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    saved = open(real).read() if os.path.exists(real) else None
+    try:
+        with open(real, "w") as f:
+            json.dump({"libhgx_sha16": "x", "kernel_sources_sha16": "y", "source": "test",
+                       "kernel_code_sha16": {"k_lift_classify": ids["k_lift_classify"], "k_lift_merged": "0" * 16},
+                       "rotating": {"k_lift_classify": 1.0e8, "k_lift_merged": 2.0e8}}, f)
+        assert bench.pmc_traffic("k_lift_classify", "rotating")[0] == 1.0e8
+        assert bench.pmc_traffic("k_lift_merged", "rotating")[0] is None
+    finally:
+        if saved is None:
+            os.unlink(real)
+        else:
+            open(real, "w").write(saved)
+
+
+def test_cpu_column_baselines_and_their_parity_gates(hal, tmp_path):
+    """bench.py's CPU figures beside the column legs: the oracle's hal2maf / halAlignmentDepth loops over a genome's first columns,
+    timed, and the gates that hold a timed export's text against them — here the whole genome's text (the oracle's own) stands in
+    for the GPU's: the wig of a slice is the beginning of the genome's wig, the MAF of a slice, up to its last block, the
+    beginning of the genome's MAF; a text that differs anywhere before fails the gate."""
+    opts = hal.RandOptions(mean_degree=1.5, max_branch_length=3.0, min_genomes=2, max_genomes=10, min_segment_length=10, max_segment_length=60,
+                           min_segments=150, max_segments=300, seed=2, with_dna=True)
+    al = hal.Alignment.random(opts, device=-1)
+    img = str(tmp_path / "a.hgx")
+    al.save(img)
+    g = al.genome_id("Genome_9")
+    seq, _, n = al.sequences(g)[0]
+    for kind, extra in (("depth", ()), ("maf", ("--noAncestors",))):
+        whole, text_whole = bench.cpu_columns_baseline(img, kind, "Genome_9", seq, n, str(tmp_path), "w", extra=extra)
+        part, text_part = bench.cpu_columns_baseline(img, kind, "Genome_9", seq, n // 3, str(tmp_path), "p", all_cores_total=n // 2, extra=extra)
+        assert whole["value"] > 0 and part["cores"] == 1 and part["kind"] == "port"
+        assert part["all_cores"]["cores"] == (os.cpu_count() or 1) and part["all_cores"]["value"] > 0
+        if kind == "depth":
+            assert text_whole[:len(text_part)] == text_part and text_part.count(b"\n") == n // 3 + 1
+        else:
+            assert bench.maf_prefix_matches(text_part, text_whole[:len(text_part) + 100])
+            broken = bytearray(text_whole)
+            at = len(text_part) // 2
+            broken[at] = ord("X") if broken[at] != ord("X") else ord("Y")
+            assert not bench.maf_prefix_matches(text_part, bytes(broken))
+            assert not bench.maf_prefix_matches(text_part, text_whole[:len(text_part) // 2])
