@@ -988,10 +988,18 @@ def main():
                 runs.append(m_s)
             kept["maf_head"] = maf_head  # (the text's beginning, for the parity gate: cpu_baseline below)
             dt_m = min(runs)
+            try:
+                tracks = al.maf_tracks_info()
+            except Exception as e:
+                tracks = {"error": str(e)[:200]}
             out.setdefault("columns", {})["hal2maf_full"] = {"metric": "MAF columns/sec (hal2maf --refGenome %s --noAncestors over the whole genome, end to end to MAF text "
                                                         "in host memory; the better of two exports)" % src_name,
                                               "value": ncols / dt_m, "unit": "columns/s", "columns": ncols, "seconds": dt_m, "runs_seconds": runs,
-                                              "maf_bytes": nbytes}
+                                              "maf_bytes": nbytes,
+                                              "device_stage": dict(tracks, what="hgx_maf_tracks_info after the two exports (and the legs before them): the per-base "
+                                                                   "tracks the heads are taken from (hgx_maf_kernels.hpp) — built once (build_ms), every chunk's "
+                                                                   "kernels timed with HIP events (device_ms_served over columns_served); state says whether the "
+                                                                   "first chunk's heads were the column walk's (else the walk is used: round 4's stage)")}
         if args.wide and world == 1 and not args.exchange_selftest:
             # the reference's own coordinate width (hal_index_t = int64, api/inc/halDefs.h:34; what an alignment with a genome of
             # 2^31 bases or more — every mammalian one — runs on): the same alignment, batch and steps on int64 tables

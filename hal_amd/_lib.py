@@ -145,6 +145,7 @@ SYMBOLS = {
     "hgx_save_image": (C.c_int, [VP, C.c_char_p, P(VP)]),
     "hgx_free": (None, [VP]),
     "hgx_release_cached": (None, []),
+    "hgx_maf_tracks_info": (C.c_int, [VP, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "hgx_version": (C.c_char_p, []),
 }
 

@@ -328,6 +328,17 @@ class Alignment:
         lib.hgx_free(out)
         return (n.value, head, seconds) if prefix > 0 else n.value
 
+    def maf_tracks_info(self, drop=False):
+        """hal2maf's per-base tracks kept with this handle (hgx_maf_tracks_info): a dict; drop=True releases them afterwards"""
+        import json
+        out, err = C.c_void_p(), C.c_void_p()
+        if lib.hgx_maf_tracks_info(self._h, 1 if drop else 0, C.byref(out), C.byref(err)) != 0:
+            raise HgxError(take_error(err))
+        try:
+            return json.loads(C.string_at(out).decode())
+        finally:
+            lib.hgx_free(out)
+
     def maf_export_global(self, no_dupes=False, no_ancestors=False, only_sequence_names=False, only_orthologs=False, max_block_len=1000,
                           print_tree=False):
         """hal2maf --global (MafExport::convertEntireAlignment, maf/impl/halMafExport.cpp:90-153): every column of the alignment once"""

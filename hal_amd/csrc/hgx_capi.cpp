@@ -1045,6 +1045,21 @@ void hgx_free(void *p) {
     hgx::textFree(p); // (the library's large texts are mappings: hgx_textmem.hpp; everything else is malloc's)
 }
 
+int hgx_maf_tracks_info(hgx_alignment *h, int drop, char **json, char **err) {
+    HGX_TRY
+    if (!h || !json)
+        throw std::runtime_error("hgx_maf_tracks_info: null argument");
+    const std::string s = h->dev ? mafTracksInfo(h) : std::string("{\"tracks\": false}");
+    if (drop && h->dev)
+        mafTracksDrop(h);
+    *json = (char *)malloc(s.size() + 1);
+    if (!*json)
+        throw std::bad_alloc();
+    memcpy(*json, s.c_str(), s.size() + 1);
+    return HGX_OK;
+    HGX_CATCH
+}
+
 void hgx_release_cached(void) {
     hgx::textTrim();
 }

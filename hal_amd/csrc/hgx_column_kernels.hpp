@@ -10,6 +10,12 @@
 #include "hgx_device.hpp"
 #include <hip/hip_runtime.h>
 
+// (HGX_DEV: the walk and the row selection are plain functions of the tables; tests/cpp/maf_select_check.cpp compiles them for
+// the host — -DHGX_DEV="__host__ __device__" — and runs them there against each other)
+#ifndef HGX_DEV
+#define HGX_DEV __device__
+#endif
+
 namespace hgx {
 
 struct ColumnParams {
@@ -44,7 +50,7 @@ struct Frame {
     uint32_t meta; // kind | rev << 3 | genome << 4
 };
 
-__device__ __forceinline__ bool bit(const unsigned long long *m, int g) {
+HGX_DEV __forceinline__ bool bit(const unsigned long long *m, int g) {
     return (m[g >> 6] >> (g & 63)) & 1ull;
 }
 
@@ -58,16 +64,16 @@ template <typename C, bool STATS = false> struct ColumnWalker {
     // parent, child or paralog keeps the offset inside segments of equal length, so only the reference segment and the
     // segments a parse step lands in can end the run; remain = the fewest bases left (iteration order) in any of them.
     int64_t remain = 0;
-    __device__ ColumnWalker(const ColumnParams &p) : P(p) {
+    HGX_DEV ColumnWalker(const ColumnParams &p) : P(p) {
     }
-    __device__ __forceinline__ const TopRec<C> *top(int g) const {
+    HGX_DEV __forceinline__ const TopRec<C> *top(int g) const {
         return (const TopRec<C> *)P.desc[g].top;
     }
-    __device__ __forceinline__ const BotRec<C> *bot(int g) const {
+    HGX_DEV __forceinline__ const BotRec<C> *bot(int g) const {
         return (const BotRec<C> *)P.desc[g].bot;
     }
     // (keeping the most recently pushed frame in registers instead of on the scratch stack was measured 17 % slower)
-    __device__ __forceinline__ void push(uint32_t kind, int g, int32_t idx, int32_t so, bool rev, int32_t extra) {
+    HGX_DEV __forceinline__ void push(uint32_t kind, int g, int32_t idx, int32_t so, bool rev, int32_t extra) {
         if (sp >= COL_STACK) {
             overflow = true;
             return;
@@ -79,15 +85,15 @@ template <typename C, bool STATS = false> struct ColumnWalker {
         f.meta = kind | ((uint32_t)rev << 3) | ((uint32_t)g << 4);
         stack[sp++] = f;
     }
-    __device__ __forceinline__ Frame pop() {
+    HGX_DEV __forceinline__ Frame pop() {
         return stack[--sp];
     }
     // position of a base given its segment and iteration-order offset (halSegmentIterator.cpp:46-52)
-    template <typename REC> __device__ __forceinline__ int64_t posOf(const REC *segs, int32_t idx, int32_t so, bool rev) const {
+    template <typename REC> HGX_DEV __forceinline__ int64_t posOf(const REC *segs, int32_t idx, int32_t so, bool rev) const {
         return !rev ? (int64_t)segs[idx].start + so : (int64_t)segs[idx + 1].start - 1 - so;
     }
     // V: visitor with  void operator()(int genome, int64_t pos, bool rev)
-    template <typename V> __device__ __forceinline__ void insert(V &visit, int g, int64_t pos, bool rev) const {
+    template <typename V> HGX_DEV __forceinline__ void insert(V &visit, int g, int64_t pos, bool rev) const {
         // colMapInsert (halColumnIterator.cpp:802-812): noAncestors / targets filters
         if constexpr (VisitorWantsRaw<V>::value)
             visit.raw(g, pos);
@@ -96,7 +102,7 @@ template <typename C, bool STATS = false> struct ColumnWalker {
     }
 
     // index of the reference segment (top tiling, or bottom for a genome without one) holding position p
-    __device__ __forceinline__ int32_t locate(int64_t p) const {
+    HGX_DEV __forceinline__ int32_t locate(int64_t p) const {
         const GenomeDesc &RD = P.desc[P.ref];
         int64_t lo = 0, hi;
         if (RD.numTop > 0) {
@@ -122,11 +128,11 @@ template <typename C, bool STATS = false> struct ColumnWalker {
         }
         return (int32_t)lo;
     }
-    template <typename V> __device__ __forceinline__ void run(int64_t p, V &visit) {
+    template <typename V> HGX_DEV __forceinline__ void run(int64_t p, V &visit) {
         runAt(locate(p), p, visit);
     }
     // the walk of column p, which lies in reference segment seg
-    template <typename V> __device__ void runAt(int32_t seg, int64_t p, V &visit) {
+    template <typename V> HGX_DEV void runAt(int32_t seg, int64_t p, V &visit) {
         const int R = P.ref;
         const GenomeDesc &RD = P.desc[R];
         sp = 0;
@@ -352,7 +358,7 @@ struct RowVisitor {
     ColumnRow *dst;
     const GenomeDesc *desc;
     uint32_t n = 0;
-    __device__ __forceinline__ void operator()(int g, int64_t pos, bool rev) {
+    HGX_DEV __forceinline__ void operator()(int g, int64_t pos, bool rev) {
         ColumnRow r;
         r.pos = pos;
         r.genome = g;

@@ -2,12 +2,14 @@
 // hgx_maf_export (include/hgx.h).
 #include "hgx_column_kernels.hpp"
 #include "hgx_gap_kernels.hpp"
+#include "hgx_maf_kernels.hpp"
 #include "hgx_scan_kernels.hpp"
 #include "hgx_columns_engine.hpp"
 #include "hgx_liftover_engine.hpp"
 #include "hgx_wig_text.hpp"
 #include <hipcub/hipcub.hpp>
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <functional>
 #include <future>
@@ -241,18 +243,19 @@ static void sweepTracks(hgx_alignment *h, const std::vector<int> &postOrder, con
     }
 }
 
-static bool columnsDepthSweep(hgx_alignment *h, int ref, int64_t first, int64_t count, int64_t step, int mode, const ColumnOptions &opt,
-                              int32_t *d_out, hipStream_t s, ColumnStats *stats) {
-    const char *env = getenv("HGX_DEPTH_SWEEP");
-    if (count <= 0 || (env && env[0] == '0') || opt.noDupes || opt.onlyOrthologs)
-        return false;
-    const int64_t span = (count - 1) * step + 1;
-    if (span < (1 << 20) && !(env && env[0] == '1'))
-        return false;
-    const Image &img = h->img;
+// the walk's scope (halColumnIterator.cpp:45-51), the genomes whose bases are reported (:802-812), a post-order of the scope's tree
+// and the path from its top to the reference: what the tree sweeps go by
+struct SweepScope {
+    std::vector<char> inScope, counted;
+    int scopeRoot = -1;
+    std::vector<int> postOrder, path;
+};
+static SweepScope sweepScope(const Image &img, int ref, const ColumnOptions &opt) {
     const int ng = (int)img.genomes.size();
-    // the walk's scope (halColumnIterator.cpp:45-51) and the genomes whose bases are reported (:802-812)
-    std::vector<char> inScope((size_t)ng, 1), counted((size_t)ng, 1);
+    SweepScope sc;
+    sc.inScope.assign((size_t)ng, 1);
+    sc.counted.assign((size_t)ng, 1);
+    std::vector<char> &inScope = sc.inScope, &counted = sc.counted;
     int scopeRoot = img.root();
     if (!opt.targets.empty()) {
         std::set<int> tg(opt.targets.begin(), opt.targets.end());
@@ -278,8 +281,8 @@ static bool columnsDepthSweep(hgx_alignment *h, int ref, int64_t first, int64_t 
         for (int g = 0; g < ng; ++g)
             if (!img.genomes[(size_t)g].children.empty())
                 counted[(size_t)g] = 0;
-    // post-order of the scope's tree, the path to the reference, one bit per counted genome
-    std::vector<int> postOrder, stack{scopeRoot}, path;
+    // post-order of the scope's tree, the path to the reference
+    std::vector<int> &postOrder = sc.postOrder, &path = sc.path, stack{scopeRoot};
     while (!stack.empty()) { // reverse pre-order = a post-order
         const int g = stack.back();
         stack.pop_back();
@@ -295,6 +298,23 @@ static bool columnsDepthSweep(hgx_alignment *h, int ref, int64_t first, int64_t 
             break;
     }
     std::reverse(path.begin(), path.end());
+    sc.scopeRoot = scopeRoot;
+    return sc;
+}
+
+static bool columnsDepthSweep(hgx_alignment *h, int ref, int64_t first, int64_t count, int64_t step, int mode, const ColumnOptions &opt,
+                              int32_t *d_out, hipStream_t s, ColumnStats *stats) {
+    const char *env = getenv("HGX_DEPTH_SWEEP");
+    if (count <= 0 || (env && env[0] == '0') || opt.noDupes || opt.onlyOrthologs)
+        return false;
+    const int64_t span = (count - 1) * step + 1;
+    if (span < (1 << 20) && !(env && env[0] == '1'))
+        return false;
+    const Image &img = h->img;
+    const int ng = (int)img.genomes.size();
+    const SweepScope sc = sweepScope(img, ref, opt);
+    const std::vector<char> &inScope = sc.inScope, &counted = sc.counted;
+    const std::vector<int> &postOrder = sc.postOrder, &path = sc.path;
     const bool sum = mode != 0;
     int bits = 0;
     std::vector<int> bitOf((size_t)ng, -1); // a counted genome's number among the counted ones: post-order, so a subtree's are consecutive
@@ -749,9 +769,298 @@ void hostBlockGive(void *p) noexcept {
         free(hd);
 }
 
+// ---- hal2maf's device stage from piece closures (hgx_maf_kernels.hpp) ----
+// The per-base tracks of one (reference, scope, filters): S (the reported bases in the tree below every base: the depth sweeps with
+// sums), A of the reference (= the rows of every column), D / F (where a segment boundary lies between two neighbouring bases,
+// below a base / anywhere in its column).  Built once by sweeps over whole genomes, kept with the handle: an export's chunks, and
+// the slices of hgx_maf_export_multi, find them there.
+namespace {
+struct MafTracks {
+    enum : int { UNCHECKED = 0, CHECKED = 1, REFUSED = 2 };
+    std::atomic<int> state{UNCHECKED}; // the first chunk taken from the tracks is held against the column walk (columnsHeadRowsHost)
+    std::atomic<uint64_t> chunks{0};   // chunks served
+    std::atomic<uint64_t> deviceUs{0}, servedColumns{0}, servedHeads{0}, servedMarked{0}; // ... their kernels' time (HIP events), columns, heads
+    int ref = -1;
+    bool noAncestors = false;
+    std::vector<int> targets;
+    int device = -1;
+    std::vector<Buf> S, D, A, F;
+    Buf sPtrs;               // device: const int32_t *[genomes]
+    const uint8_t *Fref = nullptr;
+    const int32_t *Aref = nullptr; // null: every column has constRows rows
+    int32_t constRows = 0;
+    size_t bytes = 0;
+    double buildMs = 0;
+};
+} // namespace
+
+static bool mafSweepAllowed(const Image &img, const SweepScope &sc, int64_t exportColumns) {
+    const char *env = getenv("HGX_MAF_SWEEP");
+    if (env && env[0] == '0')
+        return false;
+    if (env && env[0] == '1')
+        return true;
+    // the sweeps touch every base of every genome in scope once; the walk they replace touches a column's tree per column
+    int64_t bases = 0;
+    for (int g : sc.postOrder)
+        bases += img.genomes[(size_t)g].totalLength;
+    return bases <= ((int64_t)4 << 20) || bases <= 32 * exportColumns;
+}
+
+template <typename C>
+static void mafBreakSweeps(hgx_alignment *h, const SweepScope &sc, const std::vector<char> &hasTrack, MafTracks &M, hipStream_t s) {
+    const Image &img = h->img;
+    const DeviceImage &D = *h->dev;
+    const int GRID = 4096;
+    for (int g : sc.postOrder) {
+        const GenomeTables &G = img.genomes[(size_t)g];
+        if (!hasTrack[(size_t)g])
+            continue;
+        const DeviceGenome &dg = D.genomes[(size_t)g];
+        std::vector<BreakChild> kids;
+        for (size_t k = 0; k < G.children.size(); ++k) {
+            const int c = G.children[k];
+            if (sc.inScope[(size_t)c] && hasTrack[(size_t)c]) // (a child without bottom segments in scope adds no boundary of its own)
+                kids.push_back(BreakChild{dg.childEnc[k], D.genomes[(size_t)c].top, (const uint8_t *)M.D[(size_t)c].p});
+        }
+        size_t at = 0;
+        do {
+            BreakChildren ch;
+            ch.n = (int)std::min<size_t>(SWEEP_MAX_CHILDREN, kids.size() - at);
+            for (int k = 0; k < ch.n; ++k)
+                ch.c[k] = kids[at + (size_t)k];
+            hipLaunchKernelGGL((k_break_up<C>), dim3(GRID), dim3(256), 0, s, (const BotRec<C> *)dg.bot, (int64_t)G.numBot, ch, at ? 1 : 0,
+                               (uint8_t *)M.D[(size_t)g].p);
+            at += SWEEP_MAX_CHILDREN;
+        } while (at < kids.size());
+    }
+    const int top = sc.path[0];
+    {
+        const GenomeTables &G = img.genomes[(size_t)top];
+        hipLaunchKernelGGL(k_break_top, dim3(GRID), dim3(256), 0, s, hasTrack[(size_t)top] ? (const uint8_t *)M.D[(size_t)top].p : (const uint8_t *)nullptr,
+                           (int64_t)G.totalLength, (uint8_t *)M.F[(size_t)top].p);
+        if (G.numTop > 0)
+            hipLaunchKernelGGL((k_break_top_starts<C>), dim3(GRID), dim3(256), 0, s, (const TopRec<C> *)D.genomes[(size_t)top].top, (int64_t)G.numTop,
+                               (uint8_t *)M.F[(size_t)top].p);
+    }
+    for (size_t i = 1; i < sc.path.size(); ++i) {
+        const int c = sc.path[i], p = sc.path[i - 1];
+        hipLaunchKernelGGL((k_break_down<C>), dim3(GRID), dim3(256), 0, s, (const TopRec<C> *)D.genomes[(size_t)c].top, (int64_t)img.genomes[(size_t)c].numTop,
+                           (const BotRec<C> *)D.genomes[(size_t)p].bot, (const uint8_t *)M.F[(size_t)p].p,
+                           hasTrack[(size_t)c] ? (const uint8_t *)M.D[(size_t)c].p : (const uint8_t *)nullptr, (uint8_t *)M.F[(size_t)c].p);
+    }
+}
+
+// the tracks of (ref, opt) — from the handle, or built now; null when the sweeps do not pay or do not fit
+static std::shared_ptr<MafTracks> mafTracksFor(hgx_alignment *h, int ref, const ColumnOptions &opt, int64_t exportColumns) {
+    if (opt.noDupes || opt.onlyOrthologs)
+        return nullptr; // (options that cut edges of the column's tree: the walk)
+    const Image &img = h->img;
+    const int ng = (int)img.genomes.size();
+    std::vector<int> tg(opt.targets.begin(), opt.targets.end());
+    std::sort(tg.begin(), tg.end());
+    tg.erase(std::unique(tg.begin(), tg.end()), tg.end());
+    std::lock_guard<std::mutex> lock(h->mafTracksMutex);
+    if (h->mafTracks) {
+        std::shared_ptr<MafTracks> have = std::static_pointer_cast<MafTracks>(h->mafTracks);
+        if (have->ref == ref && have->noAncestors == opt.noAncestors && have->targets == tg && have->device == h->dev->device) {
+            const char *env = getenv("HGX_MAF_SWEEP");
+            return env && env[0] == '0' ? nullptr : have;
+        }
+    }
+    const SweepScope sc = sweepScope(img, ref, opt);
+    if (!mafSweepAllowed(img, sc, exportColumns))
+        return nullptr;
+    h->mafTracks.reset(); // (one set of tracks a handle: the old one's memory first)
+    // a genome has tracks of its own when something in scope hangs under it
+    std::vector<char> hasTrack((size_t)ng, 0);
+    for (int g : sc.postOrder) {
+        const GenomeTables &G = img.genomes[(size_t)g];
+        if (G.numBot <= 0)
+            continue;
+        for (int c : G.children)
+            if (sc.inScope[(size_t)c] && img.genomes[(size_t)c].totalLength > 0 && img.genomes[(size_t)c].numTop > 0)
+                hasTrack[(size_t)g] = 1;
+    }
+    std::vector<SweepTrack> track((size_t)ng);
+    for (int g = 0; g < ng; ++g)
+        track[(size_t)g] = SweepTrack{2, 0, sc.counted[(size_t)g] ? 1ll : 0ll};
+    const size_t PAD = 8;
+    size_t need = 0;
+    for (int g : sc.postOrder)
+        if (hasTrack[(size_t)g])
+            need += (size_t)img.genomes[(size_t)g].totalLength * 5 + PAD;
+    const size_t aFrom = sc.path.size() == 1 ? 0 : 1;
+    for (size_t i = 0; i < sc.path.size(); ++i)
+        need += (size_t)img.genomes[(size_t)sc.path[i]].totalLength * (i >= aFrom ? 5 : 1) + PAD;
+    size_t freeB = 0, totalB = 0;
+    HIP_OK(hipMemGetInfo(&freeB, &totalB));
+    if (need + (1ull << 30) > freeB)
+        return nullptr;
+    std::shared_ptr<MafTracks> M(new MafTracks);
+    M->ref = ref;
+    M->noAncestors = opt.noAncestors;
+    M->targets = tg;
+    M->device = h->dev->device;
+    M->bytes = need;
+    M->S = std::vector<Buf>((size_t)ng);
+    M->D = std::vector<Buf>((size_t)ng);
+    M->A = std::vector<Buf>((size_t)ng);
+    M->F = std::vector<Buf>((size_t)ng);
+    hipStream_t s = nullptr;
+    for (int g : sc.postOrder)
+        if (hasTrack[(size_t)g]) {
+            const size_t len = (size_t)img.genomes[(size_t)g].totalLength;
+            M->S[(size_t)g].resize(len * 4);
+            M->D[(size_t)g].resize(len + PAD);
+            HIP_OK(hipMemsetAsync(M->D[(size_t)g].p, 0, len + PAD, s));
+        }
+    for (size_t i = 0; i < sc.path.size(); ++i) {
+        const size_t len = (size_t)img.genomes[(size_t)sc.path[i]].totalLength;
+        if (i >= aFrom)
+            M->A[(size_t)sc.path[i]].resize(std::max<size_t>(len, 1) * 4);
+        M->F[(size_t)sc.path[i]].resize(len + PAD);
+        HIP_OK(hipMemsetAsync(M->F[(size_t)sc.path[i]].p, 0, len + PAD, s));
+    }
+    Ev a, b;
+    HIP_OK(hipEventRecord(a.e, s));
+    if (h->dev->wide) {
+        sweepTracks<int64_t, true, int32_t>(h, sc.postOrder, sc.path, sc.inScope, track, hasTrack, M->S, M->A, s);
+        mafBreakSweeps<int64_t>(h, sc, hasTrack, *M, s);
+    } else {
+        sweepTracks<int32_t, true, int32_t>(h, sc.postOrder, sc.path, sc.inScope, track, hasTrack, M->S, M->A, s);
+        mafBreakSweeps<int32_t>(h, sc, hasTrack, *M, s);
+    }
+    HIP_OK(hipEventRecord(b.e, s));
+    std::vector<const int32_t *> ptrs((size_t)ng, nullptr);
+    for (int g = 0; g < ng; ++g)
+        if (hasTrack[(size_t)g])
+            ptrs[(size_t)g] = (const int32_t *)M->S[(size_t)g].p;
+    M->sPtrs.resize((size_t)ng * sizeof(void *));
+    HIP_OK(hipMemcpyAsync(M->sPtrs.p, ptrs.data(), (size_t)ng * sizeof(void *), hipMemcpyHostToDevice, s));
+    HIP_OK(hipStreamSynchronize(s));
+    float ms = 0;
+    HIP_OK(hipEventElapsedTime(&ms, a.e, b.e));
+    M->buildMs = ms;
+    M->Fref = (const uint8_t *)M->F[(size_t)ref].p;
+    // (the rows of a column: A of the reference — sweepTracks leaves it for every genome of the path below the top, and for the
+    // top itself when the reference is the top)
+    M->Aref = (const int32_t *)M->A[(size_t)ref].p;
+    M->constRows = sc.counted[(size_t)ref] ? 1 : 0;
+    if (!hasTrack[(size_t)ref] && sc.path.size() == 1)
+        M->Aref = nullptr; // (nothing in scope but the reference itself: k_sweep_top wrote the constant; no need to read it)
+    if (getenv("HGX_MAF_TIMING"))
+        fprintf(stderr, "[hgx] hal2maf tracks of genome %d: %.3f ms on the device, %.1f MB\n", ref, ms, (double)need / 1e6);
+    h->mafTracks = M;
+    return M;
+}
+
+std::string mafTracksInfo(hgx_alignment *h) {
+    std::lock_guard<std::mutex> lock(h->mafTracksMutex);
+    if (!h->mafTracks)
+        return "{\"tracks\": false}";
+    const MafTracks &T = *std::static_pointer_cast<MafTracks>(h->mafTracks);
+    char buf[512];
+    static const char *const states[] = {"unchecked", "checked against the column walk", "refused: the column walk is used"};
+    snprintf(buf, sizeof buf,
+             "{\"tracks\": true, \"reference\": %d, \"no_ancestors\": %s, \"targets\": %zu, \"build_ms\": %.4f, \"bytes\": %zu, \"state\": \"%s\", "
+             "\"chunks_served\": %llu, \"columns_served\": %llu, \"marked_columns\": %llu, \"heads\": %llu, \"device_ms_served\": %.3f}",
+             T.ref, T.noAncestors ? "true" : "false", T.targets.size(), T.buildMs, T.bytes, states[T.state.load()], (unsigned long long)T.chunks.load(),
+             (unsigned long long)T.servedColumns.load(), (unsigned long long)T.servedMarked.load(), (unsigned long long)T.servedHeads.load(),
+             (double)T.deviceUs.load() / 1e3);
+    return buf;
+}
+
+void mafTracksDrop(hgx_alignment *h) {
+    std::lock_guard<std::mutex> lock(h->mafTracksMutex);
+    h->mafTracks.reset();
+}
+
+namespace {
+struct MafSizesDoNotAddUp : std::runtime_error {
+    MafSizesDoNotAddUp() : std::runtime_error("hal2maf: a column's rows do not add up to its subtrees' sizes") {}
+};
+} // namespace
+
+// columnsHeadRowsHost from the tracks: the marked columns of the chunk, their rows by rank, the heads among them
+static void columnsHeadRowsSweep(hgx_alignment *h, MafTracks &T, int ref, int64_t first, int64_t count, const ColumnOptions &opt,
+                                 std::vector<uint8_t> &head, std::vector<uint32_t> &headOffset, HeadRows &headRows, ColumnStats *stats) {
+    const uint32_t n = (uint32_t)count;
+    const int GRID = 1024;
+    Buf dMark((size_t)n * 4), dRowsOf((size_t)n * 4), dMarkIdx(((size_t)n + 1) * 4), dRowOff(((size_t)n + 1) * 4), dSums(((size_t)n / SCAN_BLOCK + 2) * 4),
+        err(4), masks;
+    Ev e0, e1;
+    HIP_OK(hipEventRecord(e0.e, nullptr));
+    HIP_OK(hipMemset(err.p, 0, 4));
+    MafRowParams M;
+    M.P = makeParams(h, ref, first, count, 1, opt, (unsigned int *)err.p, masks);
+    hipLaunchKernelGGL(k_maf_marks, dim3(GRID), dim3(256), 0, nullptr, T.Fref, T.Aref, T.constRows, first, n, (uint32_t *)dMark.p, (uint32_t *)dRowsOf.p);
+    checkRowTotal((const uint32_t *)dRowsOf.p, n);
+    const uint32_t nCand = deviceScan((const uint32_t *)dMark.p, n, (uint32_t *)dMarkIdx.p, (uint32_t *)dSums.p);
+    const uint32_t totalRows = deviceScan((const uint32_t *)dRowsOf.p, n, (uint32_t *)dRowOff.p, (uint32_t *)dSums.p);
+    Buf dCandCol((size_t)nCand * 4), dCandRow(((size_t)nCand + 1) * 4), dRows(std::max<size_t>(totalRows, 1) * sizeof(ColumnRow));
+    hipLaunchKernelGGL(k_maf_list, dim3(GRID), dim3(256), 0, nullptr, (const uint32_t *)dMark.p, (const uint32_t *)dMarkIdx.p, (const uint32_t *)dRowOff.p, n,
+                       (uint32_t *)dCandCol.p, (uint32_t *)dCandRow.p);
+    HIP_OK(hipMemcpyAsync((uint32_t *)dCandRow.p + nCand, (const uint32_t *)dRowOff.p + n, 4, hipMemcpyDeviceToDevice, nullptr));
+    M.S = (const int32_t *const *)T.sPtrs.p;
+    M.candCol = (const uint32_t *)dCandCol.p;
+    M.candRow = (const uint32_t *)dCandRow.p;
+    M.nCand = nCand;
+    const int rowGrid = (int)std::min<int64_t>(COL_GRID, ((int64_t)nCand * (1 << MAF_LPC_LOG) + 255) / 256);
+    if (h->dev->wide)
+        hipLaunchKernelGGL((k_maf_rows<int64_t>), dim3(std::max(rowGrid, 1)), dim3(256), 0, nullptr, M, (ColumnRow *)dRows.p);
+    else
+        hipLaunchKernelGGL((k_maf_rows<int32_t>), dim3(std::max(rowGrid, 1)), dim3(256), 0, nullptr, M, (ColumnRow *)dRows.p);
+    Buf dIsHead((size_t)nCand * 4), dHeadCnt((size_t)nCand * 4), dHeadIdx(((size_t)nCand + 1) * 4), dHeadRowOff(((size_t)nCand + 1) * 4);
+    hipLaunchKernelGGL(k_maf_heads, dim3(GRID), dim3(256), 0, nullptr, (const uint32_t *)dCandCol.p, (const uint32_t *)dCandRow.p, (const ColumnRow *)dRows.p,
+                       nCand, (uint32_t *)dIsHead.p, (uint32_t *)dHeadCnt.p);
+    const uint32_t nHeads = deviceScan((const uint32_t *)dIsHead.p, nCand, (uint32_t *)dHeadIdx.p, (uint32_t *)dSums.p);
+    const uint32_t totalHeadRows = deviceScan((const uint32_t *)dHeadCnt.p, nCand, (uint32_t *)dHeadRowOff.p, (uint32_t *)dSums.p);
+    Buf dHead(n), dHeadOffset(((size_t)nHeads + 1) * 4), dOut(std::max<size_t>(totalHeadRows, 1) * sizeof(ColumnRow));
+    HIP_OK(hipMemsetAsync(dHead.p, 0, n, nullptr));
+    hipLaunchKernelGGL(k_maf_gather, dim3(std::max(rowGrid, 1)), dim3(256), 0, nullptr, (const uint32_t *)dCandCol.p, (const uint32_t *)dCandRow.p,
+                       (const ColumnRow *)dRows.p, nCand, (const uint32_t *)dIsHead.p, (const uint32_t *)dHeadIdx.p, (const uint32_t *)dHeadRowOff.p,
+                       (uint8_t *)dHead.p, (uint32_t *)dHeadOffset.p, (ColumnRow *)dOut.p);
+    HIP_OK(hipEventRecord(e1.e, nullptr));
+    unsigned int e = 0;
+    HIP_OK(hipMemcpy(&e, err.p, 4, hipMemcpyDeviceToHost));
+    if (e == 2)
+        throw MafSizesDoNotAddUp();
+    if (e)
+        throw std::runtime_error("column walk exceeded the frame stack (more than 64 pending branches for one base)");
+    head.resize(n);
+    HIP_OK(hipMemcpy(head.data(), dHead.p, n, hipMemcpyDeviceToHost));
+    headOffset.resize((size_t)nHeads + 1);
+    if (nHeads)
+        HIP_OK(hipMemcpy(headOffset.data(), dHeadOffset.p, (size_t)nHeads * 4, hipMemcpyDeviceToHost));
+    headOffset[nHeads] = totalHeadRows;
+    headRows.resize(totalHeadRows);
+    if (totalHeadRows)
+        HIP_OK(hipMemcpy(headRows.data(), dOut.p, (size_t)totalHeadRows * sizeof(ColumnRow), hipMemcpyDeviceToHost));
+    {
+        float ms = 0;
+        HIP_OK(hipEventElapsedTime(&ms, e0.e, e1.e));
+        T.deviceUs.fetch_add((uint64_t)(ms * 1e3));
+        T.servedColumns.fetch_add((uint64_t)count);
+        T.servedHeads.fetch_add(nHeads);
+        T.servedMarked.fetch_add(nCand);
+        if (stats) {
+            stats->rows_ms += ms;
+            stats->rows += totalRows;
+            stats->columns += (uint64_t)count;
+        }
+    }
+}
+
+// columnsHeadRowsHost by the column walk: every column's rows on the device (two walks of every column: count, emit), the heads
+// found by comparing neighbours, their rows gathered — the path of --unique, --noDupes and --onlyOrthologs, of exports too short for
+// the sweeps to pay, and what the sweeps' first chunk is held against
+static void columnsHeadRowsWalk(hgx_alignment *h, int ref, int64_t first, int64_t count, const ColumnOptions &opt, std::vector<uint8_t> &head,
+                                std::vector<uint32_t> &headOffset, HeadRows &headRows, ColumnStats *stats, int64_t uniqueFirst);
+
 void columnsHeadRowsHost(hgx_alignment *h, int ref, int64_t first, int64_t count, const ColumnOptions &opt, bool withDna,
                          std::vector<uint8_t> &head, std::vector<uint32_t> &headOffset, HeadRows &headRows, ColumnStats *stats,
-                         int64_t uniqueFirst) {
+                         int64_t uniqueFirst, int64_t exportColumns) {
     if (!h->dev)
         throw std::runtime_error("alignment was opened without a device (device = -1); the column engine needs the HIP path");
     HIP_OK(hipSetDevice(h->dev->device));
@@ -764,6 +1073,61 @@ void columnsHeadRowsHost(hgx_alignment *h, int ref, int64_t first, int64_t count
         return;
     if (count >= ((int64_t)1 << 31))
         throw std::runtime_error("column chunk too large");
+    if (uniqueFirst < 0) {
+        // the plain export: the heads from the per-base tracks (hgx_maf_kernels.hpp) where the sweeps behind them pay
+        if (std::shared_ptr<MafTracks> T = mafTracksFor(h, ref, opt, std::max(exportColumns, count))) {
+            const char *env = getenv("HGX_MAF_SWEEP");
+            const bool forced = env && env[0] == '1';
+            if (T->state.load() != MafTracks::REFUSED) {
+                bool good = true;
+                try {
+                    columnsHeadRowsSweep(h, *T, ref, first, count, opt, head, headOffset, headRows, stats);
+                } catch (const MafSizesDoNotAddUp &) {
+                    if (forced)
+                        throw; // (forced: the tests want to see it)
+                    good = false;
+                }
+                // The first chunk taken from a set of tracks is held against the column walk (a chunk of the export is walked once
+                // more: a fiftieth of config 3): tracks whose heads are not the walk's are not used again, and the walk's answer goes out.
+                if (good && T->state.load() == MafTracks::UNCHECKED) {
+                    std::vector<uint8_t> head2;
+                    std::vector<uint32_t> off2(1, 0);
+                    HeadRows rows2;
+                    columnsHeadRowsWalk(h, ref, first, count, opt, head2, off2, rows2, nullptr, -1);
+                    good = head2 == head && off2 == headOffset && rows2.size() == headRows.size() &&
+                           (rows2.empty() || memcmp(rows2.data(), headRows.data(), rows2.size() * sizeof(ColumnRowHost)) == 0);
+                    if (good) {
+                        T->state.store(MafTracks::CHECKED);
+                    } else {
+                        if (forced)
+                            throw std::runtime_error("hal2maf: the heads taken from the per-base tracks differ from the column walk's");
+                        head.swap(head2);
+                        headOffset.swap(off2);
+                        headRows.swap(rows2);
+                        T->state.store(MafTracks::REFUSED);
+                        fprintf(stderr, "[hgx] hal2maf: the heads taken from the per-base tracks differ from the column walk's; the walk is used\n");
+                        return;
+                    }
+                }
+                if (good) {
+                    T->chunks.fetch_add(1);
+                    return;
+                }
+                T->state.store(MafTracks::REFUSED);
+                head.clear();
+                headOffset.assign(1, 0);
+                headRows.clear();
+            }
+        }
+    }
+    columnsHeadRowsWalk(h, ref, first, count, opt, head, headOffset, headRows, stats, uniqueFirst);
+}
+
+static void columnsHeadRowsWalk(hgx_alignment *h, int ref, int64_t first, int64_t count, const ColumnOptions &opt, std::vector<uint8_t> &head,
+                                std::vector<uint32_t> &headOffset, HeadRows &headRows, ColumnStats *stats, int64_t uniqueFirst) {
+    head.clear();
+    headOffset.assign(1, 0);
+    headRows.clear();
     const uint32_t n = (uint32_t)count;
     Buf dCnt((size_t)n * 4), dOff(((size_t)n + 1) * 4), dSums(((size_t)n / SCAN_BLOCK + 2) * 4), err(4);
     Ev e0, e1;

@@ -100,6 +100,13 @@ void columnsGapRowsHost(hgx_alignment *h, int ref, const std::vector<GapAskHost>
 // column is a head or a continuation of the written column before it, as above.
 void columnsHeadRowsHost(hgx_alignment *h, int ref, int64_t first, int64_t count, const ColumnOptions &opt, bool withDna,
                          std::vector<uint8_t> &head, std::vector<uint32_t> &headOffset, HeadRows &headRows, ColumnStats *stats,
-                         int64_t uniqueFirst = -1);
+                         int64_t uniqueFirst = -1, int64_t exportColumns = 0);
+// (exportColumns: the columns of the whole export this chunk belongs to — the plain export takes its heads from per-base tracks
+// made by sweeps over whole genomes, hgx_maf_kernels.hpp, when the export is long enough for them to pay; HGX_MAF_SWEEP=1 / 0
+// forces / forbids them)
+
+// the per-base tracks kept with the handle for hal2maf (hgx_columns.hip: MafTracks), as a JSON object; and letting go of them
+std::string mafTracksInfo(hgx_alignment *h);
+void mafTracksDrop(hgx_alignment *h);
 
 } // namespace hgx

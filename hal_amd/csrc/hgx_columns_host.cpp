@@ -1545,7 +1545,7 @@ void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alig
         while (!have) { // (a chunk's row offsets are 32-bit: very wide alignments get smaller chunks)
             try {
                 columnsHeadRowsHost(alignment, genome, first + done, c->n, opt, true, c->head, c->headOff, headRows, &stats,
-                                    _unique ? first : (int64_t)-1);
+                                    _unique ? first : (int64_t)-1, length);
 #ifdef HGX_HOST_PROFILE
                 if (dump) {
                     const uint64_t hd[4] = {(uint64_t)done, (uint64_t)c->n, c->headOff.size(), headRows.size()};
@@ -2005,7 +2005,7 @@ void MafExport::convertSequence(std::ostream &mafStream, hgx_alignment *alignmen
             const auto tFetch0 = std::chrono::steady_clock::now();
             for (;;) { // (a chunk's row offsets are 32-bit: very wide alignments get smaller chunks)
                 try {
-                    columnsHeadRowsHost(alignment, genome, first + done, n, opt, true, head, headOff, headRows, &stats);
+                    columnsHeadRowsHost(alignment, genome, first + done, n, opt, true, head, headOff, headRows, &stats, -1, length);
                     break;
                 } catch (const ColumnChunkTooLarge &) {
                     if (n <= 1)

@@ -247,6 +247,10 @@ struct hgx_alignment {
     // calls alternate between, kept like the one above (creating a plan is a millisecond, a call's device work a tenth of it)
     CachedPlan vizPlans[2];
     std::mutex planMutex;
+    // hal2maf's per-base tracks of the last (reference, scope, filters) exported from this handle (hgx_columns.hip: MafTracks): the
+    // sweeps behind them cover whole genomes, and an export comes in chunks (and, sliced, in many exports)
+    std::shared_ptr<void> mafTracks;
+    std::mutex mafTracksMutex;
     // pinned host staging of the text path (Liftover::convert): genome coordinates and strands of a batch on the way in, its
     // records on the way out, and the device copy of the former; grown on demand, freed with the alignment
     struct Stage {

@@ -2257,6 +2257,7 @@ static void runHostArrays(hgx_liftover_plan *P, const std::vector<int64_t> &gs, 
 } // namespace hgx
 
 hgx_alignment::~hgx_alignment() {
+    mafTracks.reset(); // (device workspaces: back to the block cache before it is trimmed)
     if (stage.packed)
         (void)hipHostFree(stage.packed);
     if (stage.first)

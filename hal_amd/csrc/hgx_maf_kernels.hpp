@@ -1,0 +1,500 @@
+// hal2maf's device stage from piece closures (gfx950): the rows of the columns where the row STRUCTURE changes, and of no others.
+//
+// The reference walks the whole column tree again for every reference base (api/impl/halColumnIterator.cpp:246-355), and the
+// first version of this stage did the same on a lane per column: two walks (count, emit) of each of config 3's 54.7 M columns,
+// 5.7 GB of rows written to keep the 2.28 M that begin a run.  A column's rows are the rows of the column before it, each
+// advanced by one base on its strand, unless one of the segments the walk passes through ends between the two columns — and the
+// walk's segments are the top and bottom segments around every base of the column (parent, child and paralogy hops keep the
+// offset inside segments of equal length; a parse step changes the tiling, not the base).  So:
+//
+//   where runs begin      two sweeps over the tree, a byte per base, like the depth sweeps (hgx_column_kernels.hpp): bottom-up
+//                         D_x[q] = 1 when a segment boundary lies between bases q-1 and q of genome x anywhere in the tree below x
+//                         (x's own bottom segments, and the D of every top segment of every child that hangs under the bottom
+//                         segment, read in the child's orientation); top-down along the path from the top of the scope to the
+//                         reference F_x[q] = the same for the whole column of q (its topmost ancestor's D and the top segments'
+//                         boundaries on the way).  F of the reference marks a superset of the columns that begin a run;
+//   how many rows         the depth sweeps with sums (--countDupes without the -1): S_x[q] = the reported bases in the tree below
+//                         base q, A_ref[p] = S at p's topmost ancestor = the rows of column p;
+//   the rows              with every subtree's size known, the k-th row of a column — the reference's insertion order: the
+//                         reference base, its ancestors upwards, then what hangs off the path from the top down, the reference's
+//                         own paralogs and children last (recursiveUpdate's order, :246-355, :556-744) — is found by walking up
+//                         the path once and down ONE branch: no stack, no second pass, a lane per row (k_maf_rows);
+//   the heads             a marked column whose rows are its predecessor's advanced (adjacent segments mapped to adjacent
+//                         places) is dropped by comparing it with the marked column before it (k_maf_heads).
+#pragma once
+#include "hgx_column_kernels.hpp"
+
+namespace hgx {
+
+// ---- where runs begin ----
+struct BreakChild {
+    const int32_t *enc;   // the parent's child link array for this slot
+    const void *top;      // the child's TopRec table
+    const uint8_t *track; // the child's D (children without bottom segments in scope have none and are left out)
+};
+struct BreakChildren {
+    BreakChild c[SWEEP_MAX_CHILDREN];
+    int n;
+};
+// eight bases of a track as one unaligned word; `rev`: the bases at the mirrored place, back to front
+HGX_DEV __forceinline__ unsigned long long break_word(const uint8_t *p, bool rev) {
+    unsigned long long w;
+    __builtin_memcpy(&w, p, 8);
+    return rev ? __builtin_bswap64(w) : w;
+}
+// D of a bottom segment of `len` bases (at `start`): base o >= 1 of the segment has the boundary of the child's base pair
+// (o - 1, o) — forward: the child's D at tstart + o; reversed: the pair is (tstart + len - o, tstart + len - 1 - o), whose boundary
+// is D at tstart + len - o.  Base 0 begins the segment.  Sixteen lanes a segment, eight bases a lane; the lane at the segment's
+// end takes the last eight bases (OR is idempotent).  Tracks are allocated eight bytes longer than their genome.
+// (the body as a function of the thread's number and the number of threads: the kernel below, and the host-side check)
+template <typename C>
+HGX_DEV __forceinline__ void break_up_body(int64_t thread, int64_t threads, const BotRec<C> *__restrict__ bot, int64_t numBot, const BreakChildren &ch,
+                                           int accumulate, uint8_t *__restrict__ D) {
+    const int sub = (int)(thread & 15);
+    const int64_t groupsTotal = threads >> 4;
+    for (int64_t b = thread >> 4; b < numBot; b += groupsTotal) {
+        const int64_t start = (int64_t)bot[b].start, len = (int64_t)bot[b + 1].start - start;
+        for (int64_t o0 = 0; o0 < len; o0 += 128) {
+            int64_t o = o0 + (int64_t)sub * 8;
+            if (o >= len)
+                continue;
+            if (o + 8 > len && len >= 8)
+                o = len - 8;
+            const bool whole = o + 8 <= len;
+            unsigned long long v = 0;
+            if (accumulate) {
+                if (whole)
+                    __builtin_memcpy(&v, D + start + o, 8);
+                else
+                    for (int j = 0; j < 8 && o + j < len; ++j)
+                        v |= (unsigned long long)D[start + o + j] << (8 * j);
+            }
+            for (int k = 0; k < ch.n; ++k) {
+                const int32_t enc = ch.c[k].enc[b];
+                if (enc < 0)
+                    continue;
+                const TopRec<C> *top = (const TopRec<C> *)ch.c[k].top;
+                const int32_t t0 = enc >> 1;
+                int32_t t = t0;
+                do { // the slot's segment and its paralogy ring
+                    const TopRec<C> tr = top[t];
+                    const uint8_t *base = ch.c[k].track + (int64_t)tr.start;
+                    const bool rev = (tr.parentEnc & 1) != 0;
+                    if (whole) {
+                        v |= break_word(rev ? base + len - o - 7 : base + o, rev);
+                    } else {
+                        for (int j = 0; j < 8 && o + j < len; ++j)
+                            v |= (unsigned long long)base[rev ? len - o - j : o + j] << (8 * j);
+                    }
+                    t = tr.paralogy;
+                } while (t >= 0 && t != t0);
+            }
+            if (o == 0)
+                v |= 1ull;
+            v &= 0x0101010101010101ull;
+            if (whole) {
+                __builtin_memcpy(D + start + o, &v, 8);
+            } else {
+                for (int j = 0; j < 8 && o + j < len; ++j)
+                    D[start + o + j] = (uint8_t)(v >> (8 * j));
+            }
+        }
+    }
+}
+template <typename C>
+static __global__ void __launch_bounds__(256) k_break_up(const BotRec<C> *__restrict__ bot, int64_t numBot, BreakChildren ch, int accumulate,
+                                                         uint8_t *__restrict__ D) {
+    break_up_body<C>((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, bot, numBot, ch, accumulate, D);
+}
+// F of a genome on the path below the top of the scope: a top segment with a parent takes the parent's F (read in the parent's
+// orientation, as above); one without (an insertion) its own D; base 0 begins the segment.  pF: the parent's F; D: this genome's
+// own D, or null when nothing in scope hangs under it.
+template <typename C>
+HGX_DEV __forceinline__ void break_down_body(int64_t thread, int64_t threads, const TopRec<C> *__restrict__ top, int64_t numTop,
+                                             const BotRec<C> *__restrict__ pbot, const uint8_t *__restrict__ pF, const uint8_t *__restrict__ D,
+                                             uint8_t *__restrict__ F) {
+    const int sub = (int)(thread & 15);
+    const int64_t groupsTotal = threads >> 4;
+    for (int64_t t = thread >> 4; t < numTop; t += groupsTotal) {
+        const TopRec<C> tr = top[t];
+        const int64_t start = (int64_t)tr.start, len = (int64_t)top[t + 1].start - start;
+        const bool hasParent = tr.parentEnc >= 0, rev = (tr.parentEnc & 1) != 0;
+        const uint8_t *base = hasParent ? pF + (int64_t)pbot[tr.parentEnc >> 1].start : (D ? D + start : nullptr);
+        for (int64_t o0 = 0; o0 < len; o0 += 128) {
+            int64_t o = o0 + (int64_t)sub * 8;
+            if (o >= len)
+                continue;
+            if (o + 8 > len && len >= 8)
+                o = len - 8;
+            const bool whole = o + 8 <= len;
+            const bool r = hasParent && rev;
+            unsigned long long v = 0;
+            if (base) {
+                if (whole) {
+                    v = break_word(r ? base + len - o - 7 : base + o, r);
+                } else {
+                    for (int j = 0; j < 8 && o + j < len; ++j)
+                        v |= (unsigned long long)base[r ? len - o - j : o + j] << (8 * j);
+                }
+            }
+            if (o == 0)
+                v |= 1ull;
+            v &= 0x0101010101010101ull;
+            if (whole) {
+                __builtin_memcpy(F + start + o, &v, 8);
+            } else {
+                for (int j = 0; j < 8 && o + j < len; ++j)
+                    F[start + o + j] = (uint8_t)(v >> (8 * j));
+            }
+        }
+    }
+}
+template <typename C>
+static __global__ void __launch_bounds__(256) k_break_down(const TopRec<C> *__restrict__ top, int64_t numTop, const BotRec<C> *__restrict__ pbot,
+                                                           const uint8_t *__restrict__ pF, const uint8_t *__restrict__ D, uint8_t *__restrict__ F) {
+    break_down_body<C>((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, top, numTop, pbot, pF, D, F);
+}
+// F of the genome at the top of the scope: its own D, and where its top segments begin (it has some when the scope ends below the root)
+static __global__ void __launch_bounds__(256) k_break_top(const uint8_t *__restrict__ D, int64_t n, uint8_t *__restrict__ F) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        F[i] = D ? D[i] : 0;
+}
+template <typename C> static __global__ void __launch_bounds__(256) k_break_top_starts(const TopRec<C> *__restrict__ top, int64_t numTop, uint8_t *__restrict__ F) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < numTop; t += (int64_t)gridDim.x * blockDim.x)
+        F[(int64_t)top[t].start] = 1;
+}
+
+// ---- the marked columns of a chunk ----
+// mark[c] = 1 when column c of the chunk may begin a run (its F, or the chunk's first column); rowsOf[c] = its rows (A) then, else 0
+static __global__ void __launch_bounds__(256) k_maf_marks(const uint8_t *__restrict__ F, const int32_t *__restrict__ A, int32_t constRows, int64_t first,
+                                                          uint32_t n, uint32_t *__restrict__ mark, uint32_t *__restrict__ rowsOf) {
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
+        const bool m = c == 0 || F[first + c] != 0;
+        mark[c] = m ? 1u : 0u;
+        rowsOf[c] = m ? (uint32_t)(A ? A[first + c] : constRows) : 0u;
+    }
+}
+// the marked columns in order: their column, the offset of their rows (candRow[nCand] = all rows: written by the caller's scan)
+static __global__ void __launch_bounds__(256) k_maf_list(const uint32_t *__restrict__ mark, const uint32_t *__restrict__ markIdx,
+                                                         const uint32_t *__restrict__ rowOff, uint32_t n, uint32_t *__restrict__ candCol,
+                                                         uint32_t *__restrict__ candRow) {
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x)
+        if (mark[c]) {
+            candCol[markIdx[c]] = c;
+            candRow[markIdx[c]] = rowOff[c];
+        }
+}
+
+// ---- the rows of the marked columns: row k of a column by rank ----
+struct MafRowParams {
+    ColumnParams P;             // desc, ref, first (genome coordinate of the chunk's first column), noAncestors, the masks, error
+    const int32_t *const *S;    // per genome: the reported bases in the tree below each base (own base included), or null: a constant
+    const uint32_t *candCol;    // the marked columns (index in the chunk)
+    const uint32_t *candRow;    // [nCand + 1] offsets of their rows
+    uint32_t nCand;
+};
+static constexpr int MAF_LPC_LOG = 3; // lanes per marked column (config 3: 6.6 rows a column); a lane takes rows k, k + 8, ...
+
+template <typename C> struct MafSelect {
+    const ColumnParams &P;
+    const int32_t *const *S;
+    HGX_DEV MafSelect(const MafRowParams &p) : P(p.P), S(p.S) {
+    }
+    HGX_DEV __forceinline__ const TopRec<C> *top(int g) const {
+        return (const TopRec<C> *)P.desc[g].top;
+    }
+    HGX_DEV __forceinline__ const BotRec<C> *bot(int g) const {
+        return (const BotRec<C> *)P.desc[g].bot;
+    }
+    HGX_DEV __forceinline__ int32_t reported(int g) const { // colMapInsert's filters (halColumnIterator.cpp:802-812)
+        return (!P.noAncestors || P.desc[g].numChildren == 0) && bit(P.targetMask, g) ? 1 : 0;
+    }
+    HGX_DEV __forceinline__ int32_t sizeAt(int g, int64_t pos) const {
+        const int32_t *s = S[g];
+        return s ? s[pos] : reported(g);
+    }
+    template <typename REC> HGX_DEV __forceinline__ int64_t posOf(const REC *segs, int32_t idx, int32_t so, bool rev) const {
+        return !rev ? (int64_t)segs[idx].start + so : (int64_t)segs[idx + 1].start - 1 - so;
+    }
+    HGX_DEV __forceinline__ void emit(ColumnRow *dst, int g, int64_t pos, bool rev) const {
+        RowVisitor v;
+        v.dst = dst;
+        v.desc = P.desc;
+        v(g, pos, rev);
+    }
+    // index of the reference segment (top tiling, or bottom for a genome without one) holding position p
+    HGX_DEV __forceinline__ int32_t locate(int64_t p) const {
+        const GenomeDesc &RD = P.desc[P.ref];
+        int64_t lo = 0, hi = RD.numTop > 0 ? RD.numTop : RD.numBot;
+        while (hi - lo > 1) {
+            const int64_t mid = (lo + hi) >> 1;
+            const int64_t st = RD.numTop > 0 ? (int64_t)top(P.ref)[mid].start : (int64_t)bot(P.ref)[mid].start;
+            if (st <= p)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        return (int32_t)lo;
+    }
+    // Row l of what hangs under the bottom segment (g, j) at offset so (iteration order, strand rev) — the CHILD frames of
+    // updateParseDown / recursiveUpdate's bottom branch in slot order, `skip` left out (the path's own slot) — and on down:
+    // one branch per level.  A CHILD block is: the slot's segment's base, then every other member of its paralogy ring with what
+    // hangs under it, then what hangs under the slot's segment itself (updateChild pushes the parse-down first and the ring on
+    // top of it, :607-640; updateNextTopDup goes round the ring, each member's subtree before the next member, :642-681).
+    // Returns false when l lies behind everything here (l is then what is left).
+    HGX_DEV bool below(ColumnRow *dst, int g, int32_t j, int32_t so, bool rev, int skip, int64_t &l) const {
+        for (;;) {
+            const GenomeDesc &D = P.desc[g];
+            bool down = false;
+            for (int i = 0; i < D.numChildren && !down; ++i) {
+                if (i == skip)
+                    continue;
+                const int32_t enc = D.child[i][j];
+                const int cg = D.childGenome[i];
+                if (enc < 0 || !bit(P.scopeMask, cg))
+                    continue;
+                const TopRec<C> *CT = top(cg);
+                const int32_t t0 = enc >> 1;
+                const TopRec<C> c0 = CT[t0];
+                const bool rev0 = rev ^ ((enc & 1) != 0);
+                const int64_t pos0 = posOf(CT, t0, so, rev0);
+                const int32_t own = reported(cg);
+                const int64_t s0 = sizeAt(cg, pos0);
+                if (own) {
+                    if (l == 0) {
+                        emit(dst, cg, pos0, rev0);
+                        return true;
+                    }
+                    --l;
+                }
+                int32_t t = -1;
+                bool trev = false;
+                if (ringMember(dst, cg, CT, c0, t0, so, rev0, l, t, trev))
+                    return true;
+                if (t < 0) { // not in the ring's members: under the slot's segment itself?
+                    if (l < s0 - own) {
+                        t = t0;
+                        trev = rev0;
+                    } else {
+                        l -= s0 - own;
+                        continue;
+                    }
+                }
+                // parse down from top segment (cg, t) (updateParseDown, :711-744) and go on one level lower
+                const int32_t bp = CT[t].botParse;
+                if (bp < 0)
+                    return false;
+                const int64_t pos = posOf(CT, t, so, trev);
+                const BotRec<C> *B = bot(cg);
+                int32_t jj = bp;
+                while ((int64_t)B[jj + 1].start <= pos)
+                    ++jj;
+                so = !trev ? (int32_t)(pos - (int64_t)B[jj].start) : (int32_t)((int64_t)B[jj + 1].start - 1 - pos);
+                g = cg;
+                j = jj;
+                rev = trev;
+                skip = -1;
+                down = true;
+            }
+            if (!down)
+                return false;
+        }
+    }
+    // The members of the paralogy ring of top segment t0 (record c0) of genome g behind t0, in ring order, each with what hangs
+    // under it (updateNextTopDup).  Row l is a member's own base: emitted, true.  Row l lies under a member: t / trev name it and l
+    // is the row among what hangs under it.  Otherwise l is reduced by the members' sizes and t stays -1.
+    HGX_DEV __forceinline__ bool ringMember(ColumnRow *dst, int g, const TopRec<C> *T, const TopRec<C> &c0, int32_t t0, int32_t so, bool rev0,
+                                               int64_t &l, int32_t &t, bool &trev) const {
+        const int32_t own = reported(g);
+        TopRec<C> cur = c0;
+        bool crev = rev0;
+        while (cur.paralogy >= 0 && cur.paralogy != t0) {
+            const int32_t nxt = cur.paralogy;
+            const TopRec<C> nr = T[nxt];
+            const bool nrev = crev ^ ((nr.parentEnc & 1) != (cur.parentEnc & 1));
+            const int64_t npos = posOf(T, nxt, so, nrev);
+            const int64_t sz = sizeAt(g, npos);
+            if (l < sz) {
+                if (own) {
+                    if (l == 0) {
+                        emit(dst, g, npos, nrev);
+                        return true;
+                    }
+                    --l;
+                }
+                t = nxt;
+                trev = nrev;
+                return false;
+            }
+            l -= sz;
+            cur = nr;
+            crev = nrev;
+        }
+        return false;
+    }
+    // what hangs under top segment (g, t) at offset so: parse down, then `below`
+    HGX_DEV bool underTop(ColumnRow *dst, int g, int32_t t, int32_t so, bool rev, int64_t &l) const {
+        const TopRec<C> *T = top(g);
+        const int32_t bp = T[t].botParse;
+        if (bp < 0)
+            return false;
+        const int64_t pos = posOf(T, t, so, rev);
+        const BotRec<C> *B = bot(g);
+        int32_t j = bp;
+        while ((int64_t)B[j + 1].start <= pos)
+            ++j;
+        const int32_t so2 = !rev ? (int32_t)(pos - (int64_t)B[j].start) : (int32_t)((int64_t)B[j + 1].start - 1 - pos);
+        return below(dst, g, j, so2, rev, -1, l);
+    }
+    // row r of the column of reference position p (reference segment seg), `total` rows in all; false: the sizes do not add up
+    HGX_DEV bool row(ColumnRow *dst, int32_t seg, int64_t p, int64_t r, int64_t total) const {
+        int g = P.ref;
+        const GenomeDesc &RD = P.desc[g];
+        int64_t anc = 0; // reported bases among the reference base and the ancestors so far
+        if (RD.numTop <= 0) {
+            // the root as reference (recursiveUpdate's bottom branch, :302-353): its base, then every child
+            if (reported(g)) {
+                if (r == 0) {
+                    emit(dst, g, p, false);
+                    return true;
+                }
+                --r;
+            }
+            const BotRec<C> *B = bot(g);
+            return below(dst, g, seg, (int32_t)(p - (int64_t)B[seg].start), false, -1, r);
+        }
+        int32_t t = seg;
+        int32_t so = (int32_t)(p - (int64_t)top(g)[t].start);
+        bool rev = false;
+        if (reported(g)) {
+            if (r == 0) {
+                emit(dst, g, p, false);
+                return true;
+            }
+            anc = 1;
+        }
+        {
+            // what hangs under the reference base comes last (its parse-down frame lies at the bottom of the stack, :252-300)
+            const int64_t u0 = sizeAt(g, p);
+            const int64_t start0 = total - u0 + anc;
+            if (r >= start0) {
+                int64_t l = r - start0;
+                return underTop(dst, g, t, so, false, l);
+            }
+        }
+        for (;;) {
+            // updateParent (:556-605): the parent's base, then — after everything above it — the siblings under the same bottom
+            // segment and the other members of this top segment's paralogy ring
+            const TopRec<C> *T = top(g);
+            const TopRec<C> tr = T[t];
+            const GenomeDesc &D = P.desc[g];
+            if (tr.parentEnc < 0 || D.parent < 0 || !bit(P.scopeMask, D.parent))
+                return false;
+            const int pg = D.parent;
+            const GenomeDesc &PD = P.desc[pg];
+            const int32_t b = tr.parentEnc >> 1;
+            const bool brev = rev ^ ((tr.parentEnc & 1) != 0);
+            const BotRec<C> *B = bot(pg);
+            const int64_t apos = posOf(B, b, so, brev);
+            if (reported(pg)) {
+                if (r == anc) {
+                    emit(dst, pg, apos, brev);
+                    return true;
+                }
+                ++anc;
+            }
+            const int64_t start = total - sizeAt(pg, apos) + anc; // rows in front of what hangs off the path at this level
+            if (r >= start) {
+                int64_t l = r - start;
+                if (below(dst, pg, b, so, brev, D.slotInParent, l))
+                    return true;
+                int32_t mt = -1;
+                bool mrev = false;
+                if (ringMember(dst, g, T, tr, t, so, rev, l, mt, mrev))
+                    return true;
+                if (mt < 0)
+                    return false;
+                return underTop(dst, g, mt, so, mrev, l);
+            }
+            // updateParseUp (:683-709): the same base in the parent's top tiling
+            if (PD.parent < 0)
+                return false;
+            const int32_t tp = B[b].topParse;
+            if (tp < 0)
+                return false;
+            const TopRec<C> *PT = top(pg);
+            int32_t j = tp;
+            while ((int64_t)PT[j + 1].start <= apos)
+                ++j;
+            so = !brev ? (int32_t)(apos - (int64_t)PT[j].start) : (int32_t)((int64_t)PT[j + 1].start - 1 - apos);
+            g = pg;
+            t = j;
+            rev = brev;
+        }
+    }
+};
+
+template <typename C> static __global__ void __launch_bounds__(256) k_maf_rows(MafRowParams M, ColumnRow *__restrict__ rows) {
+    constexpr int LPC = 1 << MAF_LPC_LOG;
+    MafSelect<C> sel(M);
+    const int sub = (int)(threadIdx.x & (LPC - 1));
+    const int64_t groups = ((int64_t)gridDim.x * blockDim.x) >> MAF_LPC_LOG;
+    bool bad = false;
+    for (int64_t k = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> MAF_LPC_LOG; k < (int64_t)M.nCand; k += groups) {
+        const uint32_t a = M.candRow[k], n = M.candRow[k + 1] - a;
+        if ((uint32_t)sub >= n)
+            continue;
+        const int64_t p = M.P.first + (int64_t)M.candCol[k];
+        const int32_t seg = sel.locate(p);
+        for (uint32_t r = (uint32_t)sub; r < n; r += LPC)
+            if (!sel.row(rows + a + r, seg, p, (int64_t)r, (int64_t)n))
+                bad = true;
+    }
+    if (bad)
+        *M.P.error = 2;
+}
+
+// ---- which marked columns are heads ----
+// marked column k continues marked column k - 1 (no boundary lies between the two, so the columns in between are k - 1's
+// advanced) when it has the same rows, each d = candCol[k] - candCol[k - 1] bases further on its strand
+static __global__ void __launch_bounds__(256) k_maf_heads(const uint32_t *__restrict__ candCol, const uint32_t *__restrict__ candRow,
+                                                          const ColumnRow *__restrict__ rows, uint32_t nCand, uint32_t *__restrict__ isHead,
+                                                          uint32_t *__restrict__ headRows) {
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nCand; k += gridDim.x * blockDim.x) {
+        const uint32_t a = candRow[k], n = candRow[k + 1] - a;
+        bool head = k == 0;
+        if (!head) {
+            const uint32_t pa = candRow[k - 1];
+            const int64_t d = (int64_t)candCol[k] - (int64_t)candCol[k - 1];
+            head = a - pa != n;
+            for (uint32_t i = 0; i < n && !head; ++i) {
+                const ColumnRow r = rows[a + i], q = rows[pa + i];
+                head = r.genome != q.genome || r.rev != q.rev || r.pos != (q.rev ? q.pos - d : q.pos + d);
+            }
+        }
+        isHead[k] = head ? 1u : 0u;
+        headRows[k] = head ? n : 0u;
+    }
+}
+// the heads' rows packed, their offsets, and the per-column marks of the chunk (cleared by the caller)
+static __global__ void __launch_bounds__(256) k_maf_gather(const uint32_t *__restrict__ candCol, const uint32_t *__restrict__ candRow,
+                                                           const ColumnRow *__restrict__ rows, uint32_t nCand, const uint32_t *__restrict__ isHead,
+                                                           const uint32_t *__restrict__ headIdx, const uint32_t *__restrict__ headRowOff,
+                                                           uint8_t *__restrict__ head, uint32_t *__restrict__ headOffset, ColumnRow *__restrict__ out) {
+    constexpr int LPC = 1 << MAF_LPC_LOG;
+    const int sub = (int)(threadIdx.x & (LPC - 1));
+    const int64_t groups = ((int64_t)gridDim.x * blockDim.x) >> MAF_LPC_LOG;
+    for (int64_t k = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> MAF_LPC_LOG; k < (int64_t)nCand; k += groups) {
+        if (!isHead[k])
+            continue;
+        const uint32_t a = candRow[k], n = candRow[k + 1] - a, o = headRowOff[k];
+        if (sub == 0) {
+            head[candCol[k]] = 1;
+            headOffset[headIdx[k]] = o;
+        }
+        for (uint32_t i = (uint32_t)sub; i < n; i += LPC)
+            out[o + i] = rows[a + i];
+    }
+}
+
+} // namespace hgx

@@ -407,6 +407,12 @@ int hgx_maf_export_multi(hgx_alignment *const *handles, int n_handles, int ref_g
                          int64_t slice_size, const hgx_maf_opts *opts, const int32_t *targets, int32_t n_targets, char **out_text,
                          size_t *out_len, char **err);
 
+/* hal2maf's plain export takes the columns where rows begin and end from per-base tracks made by sweeps over whole genomes
+ * (hal_amd/csrc/hgx_maf_kernels.hpp) and keeps them with the handle for the export's chunks and for later exports of the same
+ * reference, scope and filters.  *json (release with hgx_free): {"tracks": bool, "build_ms", "bytes", "state": "unchecked" |
+ * "checked against the column walk" | "refused: ...", "chunks_served"}; drop != 0 releases the tracks' device memory afterwards. */
+int hgx_maf_tracks_info(hgx_alignment *h, int drop, char **json, char **err);
+
 /* ---- synthetic workloads: halRandGen (randgen/halRandGen.cpp) ---- */
 typedef struct hgx_rand_opts {
     double mean_degree, max_branch_length;

@@ -442,3 +442,33 @@ def test_text_memory_keeps_the_block_released_last(tmp_path):
                            os.path.join(src, "hgx_textmem.cpp")])
     env = dict(os.environ, HGX_TEXT_HUGEPAGES="0")  # (no huge-page advice: a VM with fragmented memory stalls on it)
     assert subprocess.run([exe], stdout=subprocess.PIPE, check=True, env=env).stdout.decode().strip() == "same"
+
+
+def test_maf_rows_by_rank_are_the_walks_rows(hal, tmp_path):
+    """hal2maf's device stage takes a column's rows from the sizes of the subtrees below every base, a lane a row, and the
+    columns that begin a run from per-base break tracks (hal_amd/csrc/hgx_maf_kernels.hpp).  The same functions compiled for the
+    host (tests/cpp/maf_select_check.cpp) against the column walk — the restatement of recursiveUpdate that every MAF golden of
+    the reference is reproduced through — on random alignments: every genome as reference, --noAncestors, target sets, a
+    polytomy of twelve children (more than one launch of the break sweep per genome), several sequences a genome, real data."""
+    import halfix
+    exe = str(tmp_path / "maf_select_check")
+    src = os.path.join(ROOT, "hal_amd", "csrc")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-host-only", "-x", "hip", "-O1", "-std=c++17", '-DHGX_DEV=__host__ __device__',
+                           "-Wno-unused-result", "-I", src, "-o", exe, os.path.join(ROOT, "tests", "cpp", "maf_select_check.cpp"),
+                           os.path.join(src, "hgx_image.cpp"), os.path.join(src, "hgx_mmap_reader.cpp"), os.path.join(src, "hgx_hdf5_reader.cpp"),
+                           "-ldl", "-lpthread"])
+    images = []
+    for seed in (2, 5):
+        o = hal.RandOptions(mean_degree=1.5, max_branch_length=3.0, min_genomes=2, max_genomes=10, min_segment_length=10, max_segment_length=60,
+                            min_segments=60, max_segments=160, seed=seed, with_dna=True)
+        images.append(str(tmp_path / ("r%d.hgx" % seed)))
+        hal.Alignment.random(o, device=-1).save(images[-1])
+    for seed in (1, 6):
+        images.append(str(tmp_path / ("m%d.hgx" % seed)))
+        halfix.write_hgx(images[-1], halfix.random_multiseq_alignment(seed, n_genomes=8, max_children=3, root_len=300))
+    images.append(str(tmp_path / "star.hgx"))
+    halfix.write_hgx(images[-1], halfix.random_multiseq_alignment(5, n_genomes=20, max_children=3, root_len=200, root_children=12))
+    images.append(os.path.join(ROOT, "tests", "golden", "ref_mmap", "small.mmap1.0.hal"))
+    out = subprocess.run([exe] + [i for i in images if os.path.exists(i)], stdout=subprocess.PIPE).stdout.decode()
+    assert out.strip().endswith("OK"), out[-2000:]
+    assert out.count("cases") >= 5

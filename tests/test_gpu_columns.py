@@ -227,27 +227,6 @@ def test_depth_by_tree_sweeps_vs_walk_and_oracle(hal, oracle_bin, tmp_path, seed
             _oracle(oracle_bin, "depth", img, tmp_path, name, "--refSequence", al.sequences(g)[0][0], "--start", "7", "--length", str(n // 2), "--step", "3")
 
 
-@pytest.mark.parametrize("chunk", [1, 97, 1000])
-def test_depth_wig_through_several_chunks(hal, oracle_bin, tmp_path, monkeypatch, chunk):
-    """hgx_alignment_depth hands its values to the line writers chunk by chunk through two page-locked blocks (sixteen million
-    columns a chunk: HGX_WIG_CHUNK sets it): genomes of a few thousand columns through 3 .. thousands of chunks — the device
-    copies, the hand-off and the lines in place — against the oracle's wig and the device values."""
-    al, img = _rand(hal, tmp_path, 6, dna=False, min_segments=120, max_segments=400)
-    monkeypatch.setenv("HGX_WIG_CHUNK", str(chunk))
-    for g in (al.num_genomes - 1, 0, 3):
-        n, name = al.genome_length(g), al.genome_name(g)
-        assert n > 3 * chunk
-        want = _oracle(oracle_bin, "depth", img, tmp_path, name)
-        assert al.alignment_depth(g) == want, (name, chunk)
-        vals = al.columns_depth(g, 0, n)
-        assert [int(x) for x in want.split("\n")[1:-1]] == vals.tolist()
-        assert al.alignment_depth(g, count_dupes=True) == _oracle(oracle_bin, "depth", img, tmp_path, name, "--countDupes"), (name, chunk)
-        if chunk > 1:
-            assert al.alignment_depth(g, 0, start=7, length=n // 2, step=3) == \
-                _oracle(oracle_bin, "depth", img, tmp_path, name, "--refSequence", al.sequences(g)[0][0], "--start", "7", "--length", str(n // 2),
-                        "--step", "3")
-
-
 def test_column_tools_over_device_clones(hal, oracle_bin, tmp_path):
     """hgx_alignment_depth_multi / hgx_maf_export_multi over three handles of one alignment (clones on the test box's one GPU: the
     sharing out, the threads and the collation are the code that runs with three GPUs): the depth text is the single handle's, the

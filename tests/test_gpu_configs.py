@@ -191,30 +191,6 @@ def test_config4_full_size_shard_through_the_three_plans(hal, cfg4_full):
     assert np.all(np.diff(recs["src_start"])[np.diff(q) == 0] >= 0)
 
 
-def test_config4_full_size_sample_vs_oracle(hal, oracle_bin, tmp_path, cfg4_full):
-    """The FULL-size 50-genome alignment against the oracle itself: the first 5 000 intervals of the shard's batch Genome_44 ->
-    Genome_2 (the default plan: merged table, general intervals, the LDS finishing kernels for the sets of more than 64 pieces),
-    then 1 500 of them without dupes, and halAlignmentDepth of a 100 k-column window."""
-    al = cfg4_full
-    src, tgt = al.genome_id("Genome_44"), al.genome_id("Genome_2")
-    seq_name, seq_start, length = al.sequences(src)[0]
-    assert al.num_genomes == 50 and length > 50_000_000
-    starts, lens, strand = make_queries(length, 1250000, 1234)
-    img = str(tmp_path / "cfg4.hgx")
-    al.save(img)
-    bed = _bed(seq_name, starts, lens, strand, 0, 5000)
-    got = hal.liftover_convert(al, src, bed, tgt)
-    assert got == oracle_liftover(oracle_bin, img, "Genome_44", "Genome_2", bed, tmp_path)
-    assert got.count("\n") > 10 * 5000
-    bed2 = _bed(seq_name, starts, lens, strand, 5000, 6500)
-    assert hal.liftover_convert(al, src, bed2, tgt, traverse_dupes=False) == \
-        oracle_liftover(oracle_bin, img, "Genome_44", "Genome_2", bed2, tmp_path, no_dupes=True)
-    a, ln = length // 2, 100000
-    wig = str(tmp_path / "o.wig")
-    subprocess.check_call([oracle_bin, "depth", img, "Genome_44", wig, "--refSequence", seq_name, "--start", str(a), "--length", str(ln)])
-    assert al.alignment_depth(src, 0, start=a, length=ln) == open(wig).read()
-
-
 def test_config5_full_size_depth_properties(hal, cfg4_full):
     """Whole-genome depth of Genome_44 on the 50-genome alignment: the run kernel and the per-column kernel agree on a 4 M-column
     window, the ranks' shards of the column range concatenate to the unsharded result (hal_amd.shard.shard_bounds), bounds."""

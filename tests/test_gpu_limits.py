@@ -84,48 +84,3 @@ def test_depth_sweeps_with_more_than_64_counted_genomes(hal, oracle_bin, tmp_pat
         assert al.alignment_depth(g) == _oracle(oracle_bin, "depth", img, tmp_path, name), name
         if leaf:
             assert al.alignment_depth(g, no_ancestors=True) == _oracle(oracle_bin, "depth", img, tmp_path, name, "--noAncestors"), name
-
-
-def test_count_dupes_sweep_over_a_polytomy_with_segment_tails(hal, oracle_bin, tmp_path, monkeypatch):
-    """--countDupes by the tree sweeps when a genome has more than eight children in scope (k_sweep_up runs once per eight and
-    adds to what the launch before left) and bottom segments whose length leaves one base past a round of lanes (33, 65, 97):
-    the lane at a segment's end must not add a launch's children twice to a base its neighbour of the round before has stored."""
-    import random
-    import numpy as np
-    rnd = random.Random(3)
-    lens = [33, 65, 33, 97, 1, 34, 65, 129, 2, 33]
-    starts = [sum(lens[:i]) for i in range(len(lens))]
-    total = sum(lens)
-    nkids = 12
-    genomes = [None] * (nkids + 1)
-    slots = []
-    for c in range(nkids):
-        tops, pos = [], 0
-        members = {}
-        order = list(range(len(lens))) + [rnd.randrange(len(lens)) for _ in range(4)]  # (every segment once, four of them twice)
-        rnd.shuffle(order)
-        for k, j in enumerate(order):
-            tops.append([pos, lens[j], j, rnd.random() < 0.4, -1])
-            members.setdefault(j, []).append(k)
-            pos += lens[j]
-        for j, ms in members.items():
-            if len(ms) > 1:
-                for a, b in zip(ms, ms[1:] + ms[:1]):
-                    tops[a][4] = b
-        genomes[c + 1] = halfix.simple_genome("L%d" % c, 0, [], pos, [tuple(t) for t in tops], [], seqname="L%d_chr" % c)
-        slots.append({j: (ms[-1], tops[ms[-1]][3]) for j, ms in members.items()})
-    bots = [(starts[j], lens[j], [slots[c][j] for c in range(nkids)]) for j in range(len(lens))]
-    genomes[0] = halfix.simple_genome("Root", -1, list(range(1, nkids + 1)), total, [], bots, seqname="Root_chr")
-    img = str(tmp_path / "poly.hgx")
-    halfix.write_hgx(img, genomes)
-    al = hal.Alignment.open(img, device=0)
-    for g in (0, 1, nkids):
-        name, n = al.genome_name(g), al.genome_length(g)
-        for kw in (dict(count_dupes=True), dict()):
-            monkeypatch.setenv("HGX_DEPTH_SWEEP", "1")
-            a = al.columns_depth(g, 0, n, **kw)
-            monkeypatch.setenv("HGX_DEPTH_SWEEP", "0")
-            assert np.array_equal(a, al.columns_depth(g, 0, n, **kw)), (name, kw)
-        monkeypatch.setenv("HGX_DEPTH_SWEEP", "1")
-        assert al.alignment_depth(g, count_dupes=True) == _oracle(oracle_bin, "depth", img, tmp_path, name, "--countDupes"), name
-        assert al.alignment_depth(g) == _oracle(oracle_bin, "depth", img, tmp_path, name), name

@@ -1,0 +1,248 @@
+"""Round 5's GPU tests, in a file of their own that sorts behind the others: hal2maf's device stage from per-base tracks
+(hal_amd/csrc/hgx_maf_kernels.hpp) forced on and held against the column walk and the oracle; the tree sweeps with sums over a
+polytomy; halAlignmentDepth's wig through several chunks; the full-size 50-genome alignment against the oracle itself."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import halfix
+from util import oracle_liftover
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import make_queries, workload_options  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _oracle(oracle_bin, cmd, img, tmp_path, *args):
+    out = str(tmp_path / ("o." + cmd))
+    if cmd == "maf":
+        subprocess.check_call([oracle_bin, "maf", img, out] + list(args))
+    else:
+        subprocess.check_call([oracle_bin, "depth", img, args[0], out] + list(args[1:]))
+    return open(out).read()
+
+
+def _rand(hal, tmp_path, seed, dna=True, **kw):
+    o = dict(mean_degree=1.5, max_branch_length=3.0, min_genomes=2, max_genomes=10, min_segment_length=10, max_segment_length=60,
+             min_segments=60, max_segments=160, seed=seed, with_dna=dna)
+    o.update(kw)
+    al = hal.Alignment.random(hal.RandOptions(**o), device=0)
+    img = str(tmp_path / ("c%d.hgx" % seed))
+    al.save(img)
+    return al, img
+
+
+def _both_ways(al, monkeypatch, *args, **kw):
+    """the export with the heads from the per-base tracks (forced: a difference from the walk in the first chunk, or sizes that do
+    not add up, raise) and by the column walk: the same text; the tracks were used and checked"""
+    monkeypatch.setenv("HGX_MAF_SWEEP", "1")
+    al.maf_tracks_info(drop=True)
+    a = al.maf_export(*args, **kw)
+    info = al.maf_tracks_info()
+    assert info["tracks"] and info["state"].startswith("checked") and info["chunks_served"] >= 1, info
+    monkeypatch.setenv("HGX_MAF_SWEEP", "0")
+    b = al.maf_export(*args, **kw)
+    monkeypatch.delenv("HGX_MAF_SWEEP")
+    assert a == b
+    return a
+
+
+# ---- hal2maf's heads from per-base tracks ----
+
+def test_maf_tracks_reference_goldens(hal, monkeypatch):
+    """the reference's own expected files (maf/tests/expected) through the tracks"""
+    al = hal.Alignment.random(hal.RandOptions.preset("small", seed=0), device=0)
+    assert _both_ways(al, monkeypatch, al.genome_id("Genome_0")) == open(os.path.join(GOLD, "ref_maf", "hal2mafSmallTest.maf")).read()
+    g2 = al.genome_id("Genome_2")
+    assert _both_ways(al, monkeypatch, g2, 0, start=1000, length=2000) == open(os.path.join(GOLD, "ref_maf", "hal2mafSeqPartTest.maf")).read()
+
+
+@pytest.mark.parametrize("seed", [2, 5, 6, 11])
+def test_maf_tracks_vs_walk_and_oracle(hal, oracle_bin, tmp_path, seed, monkeypatch):
+    """random alignments with inversions and paralogy rings: every genome as reference, --noAncestors on leaves, target sets,
+    ranges; device batches of 13 and 1000 columns (the tracks serve every chunk; marked columns at chunk ends)"""
+    al, img = _rand(hal, tmp_path, seed)
+    for chunk in ("13", "1000"):
+        monkeypatch.setenv("HGX_MAF_CHUNK", chunk)
+        for g in range(al.num_genomes):
+            n, name = al.genome_length(g), al.genome_name(g)
+            if n == 0 or (chunk == "13" and g % 3 != seed % 3):
+                continue
+            leaf = not al.genome_children(g)
+            others = [x for x in range(al.num_genomes) if x != g]
+            assert _both_ways(al, monkeypatch, g) == _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", name), (name, chunk)
+            if leaf:
+                assert _both_ways(al, monkeypatch, g, no_ancestors=True) == \
+                    _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", name, "--noAncestors"), (name, chunk)
+            tg = others[1:4]
+            assert _both_ways(al, monkeypatch, g, targets=tg) == \
+                _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", name, "--targetGenomes", ",".join(al.genome_name(x) for x in tg)), (name, chunk)
+            seq = al.sequences(g)[0][0]
+            assert _both_ways(al, monkeypatch, g, 0, start=n // 3, length=n // 2, max_block_len=50) == \
+                _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", name, "--refSequence", seq, "--start", str(n // 3), "--length", str(n // 2),
+                        "--maxBlockLen", "50"), (name, chunk)
+
+
+def test_maf_tracks_multiseq_and_star(hal, oracle_bin, tmp_path, monkeypatch):
+    """the independent generator's alignments (several sequences a genome, irregular segments, insertions, deletions) and a star of
+    twenty-four children under the root (three launches of the break sweep for the root)"""
+    cases = [("m1", halfix.random_multiseq_alignment(1, n_genomes=8, max_children=3, root_len=400)),
+             ("m6", halfix.random_multiseq_alignment(6, n_genomes=9, max_children=3, root_len=300)),
+             ("star", halfix.random_multiseq_alignment(5, n_genomes=41, max_children=3, root_len=300, root_children=24))]
+    for tag, genomes in cases:
+        img = str(tmp_path / (tag + ".hgx"))
+        halfix.write_hgx(img, genomes)
+        al = hal.Alignment.open(img, device=0)
+        refs = range(al.num_genomes) if tag != "star" else (0, 1, 7, 25, al.num_genomes - 1)
+        for g in refs:
+            if al.genome_length(g) == 0:
+                continue
+            name = al.genome_name(g)
+            assert _both_ways(al, monkeypatch, g) == _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", name), (tag, name)
+            if not al.genome_children(g):
+                assert _both_ways(al, monkeypatch, g, no_ancestors=True, only_sequence_names=True) == \
+                    _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", name, "--noAncestors", "--onlySequenceNames"), (tag, name)
+
+
+def test_maf_tracks_on_int64_tables_and_real_data(hal, oracle_bin, tmp_path, monkeypatch):
+    al, img = _rand(hal, tmp_path, 2)
+    monkeypatch.setenv("HGX_FORCE_WIDE", "1")
+    wide = al.clone_to_device(0)
+    monkeypatch.delenv("HGX_FORCE_WIDE")
+    for g in (al.num_genomes - 1, 0, 3):
+        name = al.genome_name(g)
+        assert _both_ways(wide, monkeypatch, g) == _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", name), name
+    mr = os.path.join(GOLD, "ref_hdf5", "mr.hal")
+    real = hal.Alignment.open(mr, device=0)
+    rimg = str(tmp_path / "mr.hgx")
+    real.save(rimg)
+    for g in range(real.num_genomes):
+        name = real.genome_name(g)
+        seq, _, n = real.sequences(g)[0]
+        ln = min(n, 300000)
+        assert _both_ways(real, monkeypatch, g, 0, start=n // 5, length=ln) == \
+            _oracle(oracle_bin, "maf", rimg, tmp_path, "--refGenome", name, "--refSequence", seq, "--start", str(n // 5), "--length", str(ln)), name
+
+
+def test_maf_tracks_at_full_size(hal, oracle_bin, tmp_path, monkeypatch):
+    """config 3's alignment at full size: 3 M columns by the tracks and by the walk (the same text), a 200 k-column slice of them
+    against the oracle, and the tracks kept with the handle serve the second export without being built again"""
+    al = hal.Alignment.random(workload_options(1.0, "cfg2", dna="fast"), device=0)
+    src = al.genome_id("Genome_9")
+    seq = al.sequences(src)[0][0]
+    a, ln = 11_000_000, 3_000_000
+    text = _both_ways(al, monkeypatch, src, 0, start=a, length=ln, no_ancestors=True)
+    assert text.count("\na") > ln // 200
+    built = al.maf_tracks_info()
+    img = str(tmp_path / "cfg2.hgx")
+    al.save(img)
+    monkeypatch.setenv("HGX_MAF_SWEEP", "1")
+    got = al.maf_export(src, 0, start=a + 1_000_000, length=200000, no_ancestors=True)
+    after = al.maf_tracks_info()
+    assert after["build_ms"] == built["build_ms"] and after["chunks_served"] > built["chunks_served"]
+    assert got == _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", "Genome_9", "--noAncestors", "--refSequence", seq, "--start",
+                          str(a + 1_000_000), "--length", "200000")
+
+
+# ---- the tree sweeps with sums over more than eight children ----
+
+def test_count_dupes_sweep_over_a_polytomy_with_segment_tails(hal, oracle_bin, tmp_path, monkeypatch):
+    """--countDupes by the tree sweeps when a genome has more than eight children in scope (k_sweep_up runs once per eight and
+    adds to what the launch before left) and bottom segments whose length leaves one base past a round of lanes (33, 65, 97):
+    the lane at a segment's end must not add a launch's children twice to a base its neighbour of the round before has stored."""
+    import random
+    rnd = random.Random(3)
+    lens = [33, 65, 33, 97, 1, 34, 65, 129, 2, 33]
+    starts = [sum(lens[:i]) for i in range(len(lens))]
+    total = sum(lens)
+    nkids = 12
+    genomes = [None] * (nkids + 1)
+    slots = []
+    for c in range(nkids):
+        tops, pos = [], 0
+        members = {}
+        order = list(range(len(lens))) + [rnd.randrange(len(lens)) for _ in range(4)]  # (every segment once, four of them twice)
+        rnd.shuffle(order)
+        for k, j in enumerate(order):
+            tops.append([pos, lens[j], j, rnd.random() < 0.4, -1])
+            members.setdefault(j, []).append(k)
+            pos += lens[j]
+        for j, ms in members.items():
+            if len(ms) > 1:
+                for a, b in zip(ms, ms[1:] + ms[:1]):
+                    tops[a][4] = b
+        genomes[c + 1] = halfix.simple_genome("L%d" % c, 0, [], pos, [tuple(t) for t in tops], [], seqname="L%d_chr" % c)
+        slots.append({j: (ms[-1], tops[ms[-1]][3]) for j, ms in members.items()})
+    bots = [(starts[j], lens[j], [slots[c][j] for c in range(nkids)]) for j in range(len(lens))]
+    genomes[0] = halfix.simple_genome("Root", -1, list(range(1, nkids + 1)), total, [], bots, seqname="Root_chr")
+    img = str(tmp_path / "poly.hgx")
+    halfix.write_hgx(img, genomes)
+    al = hal.Alignment.open(img, device=0)
+    for g in (0, 1, nkids):
+        name, n = al.genome_name(g), al.genome_length(g)
+        for kw in (dict(count_dupes=True), dict()):
+            monkeypatch.setenv("HGX_DEPTH_SWEEP", "1")
+            a = al.columns_depth(g, 0, n, **kw)
+            monkeypatch.setenv("HGX_DEPTH_SWEEP", "0")
+            assert np.array_equal(a, al.columns_depth(g, 0, n, **kw)), (name, kw)
+        monkeypatch.setenv("HGX_DEPTH_SWEEP", "1")
+        assert al.alignment_depth(g, count_dupes=True) == _oracle(oracle_bin, "depth", img, tmp_path, name, "--countDupes"), name
+        assert al.alignment_depth(g) == _oracle(oracle_bin, "depth", img, tmp_path, name), name
+        assert _both_ways(al, monkeypatch, g) == _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", name), name
+
+
+# ---- halAlignmentDepth's wig text chunk by chunk ----
+
+@pytest.mark.parametrize("chunk", [97, 1000, 4099])
+def test_depth_wig_through_several_chunks(hal, oracle_bin, tmp_path, monkeypatch, chunk):
+    """hgx_alignment_depth hands its values to the line writers chunk by chunk through two page-locked blocks (sixteen million
+    columns a chunk: HGX_WIG_CHUNK sets it): genomes of a few thousand columns through 3 .. a hundred chunks — the device copies,
+    the hand-off and the lines in place — against the oracle's wig and the device values."""
+    al, img = _rand(hal, tmp_path, 6, dna=False, min_segments=240, max_segments=400)
+    monkeypatch.setenv("HGX_WIG_CHUNK", str(chunk))
+    for g in (al.num_genomes - 1, 0, 3):
+        n, name = al.genome_length(g), al.genome_name(g)
+        assert n >= 2 * chunk
+        want = _oracle(oracle_bin, "depth", img, tmp_path, name)
+        assert al.alignment_depth(g) == want, (name, chunk)
+        vals = al.columns_depth(g, 0, n)
+        assert [int(x) for x in want.split("\n")[1:-1]] == vals.tolist()
+        assert al.alignment_depth(g, count_dupes=True) == _oracle(oracle_bin, "depth", img, tmp_path, name, "--countDupes"), (name, chunk)
+        assert al.alignment_depth(g, 0, start=7, length=n // 2, step=3) == \
+            _oracle(oracle_bin, "depth", img, tmp_path, name, "--refSequence", al.sequences(g)[0][0], "--start", "7", "--length", str(n // 2),
+                    "--step", "3")
+
+
+# ---- the full-size 50-genome alignment against the oracle itself ----
+
+def _bed(seq_name, starts, lens, strand, lo, hi):
+    return "".join("%s\t%d\t%d\tq\t0\t%s\n" % (seq_name, int(starts[i]), int(starts[i] + lens[i]), chr(int(strand[i]))) for i in range(lo, hi))
+
+
+def test_config4_full_size_sample_vs_oracle(hal, oracle_bin, tmp_path):
+    """The FULL-size 50-genome alignment against the oracle itself: the first 5 000 intervals of the shard's batch Genome_44 ->
+    Genome_2 (the default plan: merged table, general intervals, the LDS finishing kernels for the sets of more than 64 pieces),
+    then 1 500 of them without dupes, and halAlignmentDepth of a 100 k-column window."""
+    al = hal.Alignment.random(workload_options(1.0, "cfg4"), device=0)
+    src, tgt = al.genome_id("Genome_44"), al.genome_id("Genome_2")
+    seq_name, seq_start, length = al.sequences(src)[0]
+    assert al.num_genomes == 50 and length > 50_000_000
+    starts, lens, strand = make_queries(length, 1250000, 1234)
+    img = str(tmp_path / "cfg4.hgx")
+    al.save(img)
+    bed = _bed(seq_name, starts, lens, strand, 0, 5000)
+    got = hal.liftover_convert(al, src, bed, tgt)
+    assert got == oracle_liftover(oracle_bin, img, "Genome_44", "Genome_2", bed, tmp_path)
+    assert got.count("\n") > 10 * 5000
+    bed2 = _bed(seq_name, starts, lens, strand, 5000, 6500)
+    assert hal.liftover_convert(al, src, bed2, tgt, traverse_dupes=False) == \
+        oracle_liftover(oracle_bin, img, "Genome_44", "Genome_2", bed2, tmp_path, no_dupes=True)
+    a, ln = length // 2, 100000
+    wig = str(tmp_path / "o.wig")
+    subprocess.check_call([oracle_bin, "depth", img, "Genome_44", wig, "--refSequence", seq_name, "--start", str(a), "--length", str(ln)])
+    assert al.alignment_depth(src, 0, start=a, length=ln) == open(wig).read()
