@@ -798,6 +798,7 @@ struct MafExport::RunMachine {
         int64_t done = 0, n = 0;
         std::vector<uint8_t> head;
         std::vector<uint32_t> headOff;
+        std::vector<uint32_t> headCol; // (the walk over slices: the column of every head, so that a walk can begin in the middle of a chunk)
         struct GiveBack {
             void operator()(PRow *p) const { hostBlockGive(p); }
         };
@@ -891,6 +892,8 @@ struct MafExport::RunMachine {
         int64_t src;  // the length of its sequence
     };
     std::vector<int32_t> erank;
+    std::vector<uint8_t> ekey;  // the entry was made for a key of the column map and has not been given a base since (the walk over slices)
+    std::vector<int64_t> lastSeen; // per rank: the block (counted over the export) in which the sequence last had a base; INT64_MIN: not seen
     std::vector<int32_t> elast; // the block that gave the entry a base last (an entry made for a block that gave it none: the block before)
     std::vector<Ent> ent;
     std::vector<int32_t> firstOf;
@@ -905,6 +908,159 @@ struct MafExport::RunMachine {
     bool entsLogged = false; // the entries' ranks as they are stand in this batch's log (at lastFirstEnt): the next block points there too
     uint32_t lastFirstEnt = 0;
     size_t refHint = 0;
+    // ---- a walk over a SLICE of the export (convertSequenceRunsSliced) ----
+    // What decides where blocks begin, and so the whole log from a column on, is: the entries (their sequences, what the block being
+    // made has given them, how many blocks ago they were last given a base), the column map's keys, and the count of blocks so far
+    // (defragment runs at every thousandth).  A walk that begins cold some thousand blocks in front of its slice has all of that
+    // right when it reaches the slice — if it was told the right count.  It logs the blocks that BEGIN inside [logFrom, stopAt),
+    // and what it looked like when its first and its one-past-last block began is kept: the slice before must have ended as this
+    // one began (Snapshot equality), which makes this slice's log the sequential walk's by induction from the first slice.
+    struct Snapshot {
+        int64_t column = -1; // the reference position of the column the block begins with
+        size_t numBlocks = 0;
+        std::vector<int32_t> erank, age, keys;
+        std::vector<int64_t> next, len; // (of entries the block being made has given bases: age 0)
+        // what does not depend on the count of blocks the walk was told: the entries that bases made, and how many blocks ago every
+        // sequence was last seen (up to a thousand: the keys are a function of that and of the count)
+        std::vector<int32_t> bRank, bAge;
+        std::vector<std::pair<int32_t, int32_t>> seen;
+        bool operator==(const Snapshot &o) const {
+            return column == o.column && numBlocks == o.numBlocks && erank == o.erank && age == o.age && keys == o.keys && next == o.next && len == o.len;
+        }
+        bool sameButForTheCount(const Snapshot &o) const {
+            return column == o.column && bRank == o.bRank && bAge == o.bAge && next == o.next && len == o.len && seen == o.seen;
+        }
+    };
+    // How a slice's own count of blocks moves with the count it is told.  The count matters through defragment alone (the column map's
+    // keys are reset at the beginning of every block whose number is 1 above a multiple of a thousand), the keys matter through the
+    // entries initBlock makes for keys without one, and those through pair() alone: a sequence that turns up in the middle of a block
+    // finds such an entry (no break) or none (a break).  Every such look that decided a column is noted — the block it happened in, the
+    // block the sequence was last seen in — and keyEntryAt says what it would have found under another count: the next round's walks
+    // are told counts put right by that (countChangeUnderShift).  An ESTIMATE that saves rounds; what is accepted is decided by the
+    // states alone (Snapshot equality, walkSliced).
+    struct KeyUse {
+        int64_t seen, at; // blocks counted over the export as this walk was told (seen: INT64_MIN = not since this walk began)
+        bool found;       // the sequence had an entry (a key's)
+    };
+    std::vector<KeyUse> keyUses;
+    int64_t firstBlock = 0; // the count this walk began with
+    // When does a sequence last seen in block `seen` have an entry in block `at` although no base has made one (at >= seen + 13: the
+    // entry its bases made is dropped at the beginning of block seen + 13)?  initBlock makes one at the beginning of a block for every key
+    // of the column map without an entry; it lives twelve blocks and is made again while the sequence is still a key: made at c0 =
+    // seen + 13, c0 + 12, c0 + 24, ... as long as no reset has fallen behind `seen` — the first block behind `seen` that begins with a
+    // reset (block g begins with one when g - 1 is a multiple of a thousand) ends that; the last one made lives on for its twelve blocks.
+    // shift: the blocks' true numbers are these plus shift.  creation: the block the entry in place at `at` was made in.
+    static int64_t firstResetBehind(int64_t seen, int64_t shift) {
+        int64_t y = seen + shift; // g + shift - 1 for g = seen + 1: the smallest multiple of a thousand at or above it (and 0)
+        if (y < 0)
+            y = 0;
+        return (y + 999) / 1000 * 1000 - shift + 1;
+    }
+    static bool keyEntryAt(int64_t seen, int64_t at, int64_t shift, int64_t *creation = nullptr) {
+        const int64_t c0 = seen + 13;
+        if (at < c0)
+            return false;
+        const int64_t r1 = firstResetBehind(seen, shift);
+        if (r1 <= c0)
+            return false;
+        const int64_t made = r1 > at ? c0 + (at - c0) / 12 * 12 : c0 + (r1 - 1 - c0) / 12 * 12;
+        if (creation)
+            *creation = made;
+        return at <= made + 11;
+    }
+    // how many more blocks (fewer: negative) this walk would have counted had it been told a count `shift` higher, as far as the looks
+    // at keys' entries tell: one that found an entry and would find none is a block more, the other way round one fewer (what follows
+    // from that further on is left out: an estimate for the next round's counts, not a result)
+    int64_t countChangeUnderShift(int64_t shift) const {
+        int64_t change = 0;
+        for (const KeyUse &u : keyUses)
+            if (u.seen != INT64_MIN && keyEntryAt(u.seen, u.at, shift) != u.found)
+                change += u.found ? 1 : -1;
+        return change;
+    }
+    bool irregularKeys = false; // keys that no base of a block made (--unique: columns walked and not written): the model above does not hold
+    // everything the walk goes on from (not the log)
+    struct MachineState {
+        std::vector<int32_t> erank, elast, firstOf, keys;
+        std::vector<Ent> ent;
+        std::vector<uint8_t> inKeys, ekey;
+        std::vector<int64_t> lastSeen;
+        int32_t block = -1;
+        size_t appendCount = 0, numBlocks = 0;
+    };
+    MachineState saveState() const {
+        return MachineState{erank, elast, firstOf, keys, ent, inKeys, ekey, lastSeen, block, appendCount, numBlocks};
+    }
+    void restoreState(const MachineState &st) {
+        erank = st.erank;
+        elast = st.elast;
+        firstOf = st.firstOf;
+        keys = st.keys;
+        ent = st.ent;
+        inKeys = st.inKeys;
+        ekey = st.ekey;
+        lastSeen = st.lastSeen;
+        block = st.block;
+        appendCount = st.appendCount;
+        numBlocks = st.numBlocks;
+        refHint = 0;
+        entsLogged = false;
+    }
+    // the state in front of the head in whose columns the next slice's first block begins (kept from the first head at or behind the
+    // slice's end on): the next slice can be walked from it exactly, in the place of a cold run-up
+    MachineState preStop;
+    size_t preStopChunk = 0, preStopHead = 0, curChunkIndex = 0;
+    bool preStopValid = false;
+    bool owner = true;     // the constructor took the export's entries and the destructor hands them back
+    bool sliced = false;   // logs are kept (not rendered) and cut at the slice's ends
+    int64_t logFrom = INT64_MIN, stopAt = INT64_MAX;
+    bool logging = true, stopped = false, startPending = false;
+    Snapshot startSnap, endSnap;
+    size_t warmBlocks = 0; // blocks begun in front of the slice (the cold walk's run-up)
+    int64_t expectCount = -1; // >= 0: the count of blocks the slice's first block must begin at (else the walk stops there: miscounted)
+    bool miscounted = false;
+    bool emptySlice = false; // the first block at or behind the slice's beginning begins behind its end, at emptyAt
+    int64_t emptyAt = -1;
+    size_t numBlocksAtStart = 0;
+    struct LogMark {
+        size_t blocks, events, numIdx, entRank, extra;
+    } stopMark{};
+    Snapshot snapshot(int64_t column) const {
+        Snapshot sn;
+        sn.column = column;
+        sn.numBlocks = numBlocks;
+        sn.erank = erank;
+        sn.keys = keys;
+        sn.age.resize(erank.size());
+        for (size_t i = 0; i < erank.size(); ++i) {
+            sn.age[i] = block - elast[i];
+            if (elast[i] == block) {
+                sn.next.push_back(ent[i].next);
+                sn.len.push_back(ent[i].len);
+            }
+            if (!ekey[i]) {
+                sn.bRank.push_back(erank[i]);
+                sn.bAge.push_back(block - elast[i]);
+            }
+        }
+        for (size_t r = 0; r < lastSeen.size(); ++r)
+            if (lastSeen[r] != INT64_MIN && (int64_t)numBlocks - lastSeen[r] <= 1000)
+                sn.seen.emplace_back((int32_t)r, (int32_t)((int64_t)numBlocks - lastSeen[r]));
+        return sn;
+    }
+    // a walk that owns nothing of the export: cold (no entries, no keys), told the count of blocks in front of it
+    RunMachine(MafExport &m, std::ostream &o, int refRank_, std::shared_ptr<std::vector<RankInfo>> ranks, size_t numBlocks_)
+        : M(m), os(o), img(m._al->img), refRank(refRank_), rankInfo(std::move(ranks)), batch(new Batch), numBlocks(numBlocks_), owner(false), sliced(true) {
+        inKeys.assign(rankInfo->size(), 0);
+        firstOf.assign(rankInfo->size(), -1);
+        lastSeen.assign(rankInfo->size(), INT64_MIN);
+        firstBlock = (int64_t)numBlocks_;
+    }
+    // every sequence's name and length looked up now: walks on several threads only read them
+    void describeAllRanks() {
+        for (size_t r = 0; r < rankInfo->size(); ++r)
+            info((int32_t)r);
+    }
 
     RunMachine(MafExport &m, std::ostream &o, int refRank_) : M(m), os(o), img(m._al->img), refRank(refRank_), batch(takeBatch()) {
         size_t ranks = 0;
@@ -913,10 +1069,12 @@ struct MafExport::RunMachine {
         rankInfo = std::make_shared<std::vector<RankInfo>>(ranks);
         inKeys.assign(ranks, 0);
         firstOf.assign(ranks, -1);
+        lastSeen.assign(ranks, INT64_MIN);
         for (auto &kv : M._entries) { // the block the other paths (and the sequence before) left
             const Entry &e = *kv.second;
             erank.push_back(kv.first.rank);
             const bool used = e.start != NULL_INDEX;
+            ekey.push_back(0);
             elast.push_back(used ? -1 : -2 - (int32_t)e.lastUsed);
             ent.push_back(Ent{used ? ((e.start + e.length) << 1) | (e.strand == '-' ? 1 : 0) : 0, used ? e.length : 0, info(kv.first.rank).srcLength});
             delete kv.second;
@@ -926,6 +1084,8 @@ struct MafExport::RunMachine {
         indexEntries();
     }
     ~RunMachine() { // the entries go back to the block the other paths (and the next sequence) go on with
+        if (!owner)
+            return;
         for (size_t i = 0; i < erank.size(); ++i) {
             const RankInfo &ri = (*rankInfo)[(size_t)erank[i]];
             Entry *e = new Entry;
@@ -1014,8 +1174,9 @@ struct MafExport::RunMachine {
                 inKeys[(size_t)rows[i].rank] = 1;
             }
     }
-    void insertEntry(size_t at, int32_t rank) { // an empty entry for the sequence (initEntry without a base)
+    void insertEntry(size_t at, int32_t rank, bool forKey = false) { // an empty entry for the sequence (initEntry without a base)
         erank.insert(erank.begin() + (std::ptrdiff_t)at, rank);
+        ekey.insert(ekey.begin() + (std::ptrdiff_t)at, forKey ? 1 : 0);
         elast.insert(elast.begin() + (std::ptrdiff_t)at, block - 1);
         ent.insert(ent.begin() + (std::ptrdiff_t)at, Ent{0, 0, info(rank).srcLength});
         indexEntries();
@@ -1050,11 +1211,13 @@ struct MafExport::RunMachine {
                 if (block - elast[i] >= 13)
                     continue;
                 erank[w] = erank[i];
+                ekey[w] = ekey[i];
                 elast[w] = elast[i];
                 ent[w] = ent[i];
                 ++w;
             }
             erank.resize(w);
+            ekey.resize(w);
             elast.resize(w);
             ent.resize(w);
             changed = true;
@@ -1066,7 +1229,7 @@ struct MafExport::RunMachine {
         for (const int32_t k : keys) {
             const size_t at = (uint32_t)firstOf[(size_t)k];
             if (at >= erank.size() || erank[at] != k) {
-                insertEntry((size_t)(std::lower_bound(erank.begin(), erank.end(), k) - erank.begin()), k);
+                insertEntry((size_t)(std::lower_bound(erank.begin(), erank.end(), k) - erank.begin()), k, true);
                 changed = true;
             }
         }
@@ -1086,9 +1249,11 @@ struct MafExport::RunMachine {
         }
         ne = erank.size();
 #ifdef HGX_HOST_PROFILE
-        g_mafTicks[8] += ne;
-        g_mafTicks[9] += n;
-        g_mafTicks[10] += keys.size();
+        if (!sliced) { // (plain words: the walks over slices run side by side)
+            g_mafTicks[8] += ne;
+            g_mafTicks[9] += n;
+            g_mafTicks[10] += keys.size();
+        }
 #endif
         // the entries' ranks: logged once per change of the set (most blocks have the entries of the block before)
         if (changed || !entsLogged) {
@@ -1117,7 +1282,7 @@ struct MafExport::RunMachine {
     }
     // MafBlock::canAppendColumn (halMafBlock.cpp:401-450) with appendColumn's pairing (:370-395): the i-th base of a sequence
     // goes with the i-th entry of the sequence; an entry that has bases goes on only where it ended, on its strand, below the length limit
-    bool pair(const PRow *rows, size_t n, uint32_t *idx, int64_t &room) const {
+    bool pair(const PRow *rows, size_t n, uint32_t *idx, int64_t &room) {
         MAF_TICK(2);
         const size_t ne = erank.size();
         const int32_t *er = erank.data();
@@ -1127,27 +1292,56 @@ struct MafExport::RunMachine {
         int64_t most = room;
         size_t ei = 0;
         int32_t rank = -1;
+        // (a walk over a slice notes where the answer hangs on an entry made for a key of the column map — RunMachine::KeyUse — and
+        // only there: a sequence without an entry does not decide a column that cannot be appended anyway, nor does a key's entry)
+        const bool noting = sliced && logging;
+        const size_t notedFrom = keyUses.size();
+        int32_t missing = -1; // a sequence without an entry that a key's entry would serve: the answer is no; the rest is looked at to see whether that alone decides
         for (size_t i = 0; i < n; ++i) {
             if (rows[i].rank != rank) {
                 rank = rows[i].rank;
                 ei = (uint32_t)firstOf[(size_t)rank];
             } else {
+                if (rank == missing) { // (a second base of the sequence: one entry of a key's would not do either)
+                    keyUses.resize(notedFrom);
+                    return false;
+                }
                 ++ei;
             }
-            if (ei >= ne || er[ei] != rank)
+            if (ei >= ne || er[ei] != rank) {
+                if (noting && missing < 0 && (i == 0 || rows[i - 1].rank != rank) && mayBeKey(rank)) {
+                    missing = rank;
+                    continue;
+                }
+                keyUses.resize(notedFrom);
                 return false;
+            }
+            if (noting && ekey[ei] && (i == 0 || rows[i - 1].rank != rank))
+                keyUses.push_back(KeyUse{lastSeen[(size_t)rank], (int64_t)numBlocks, true}); // (kept if the column is appended)
             const Ent &e = en[ei];
             const int64_t key = rows[i].key;
             if (el[ei] == blk) {
-                if (e.len >= maxLength || e.next != key)
+                if (e.len >= maxLength || e.next != key) {
+                    keyUses.resize(notedFrom);
                     return false;
+                }
                 most = std::min(most, maxLength - e.len); // (appendColumn up to the length limit)
             }
             most = std::min(most, e.src - (key >> 1)); // (the columns the base can go on inside its sequence, itself among them)
             idx[i] = (uint32_t)ei;
         }
+        if (missing >= 0) { // nothing else stands against the column: with an entry for this sequence it would have been appended
+            keyUses.push_back(KeyUse{lastSeen[(size_t)missing], (int64_t)numBlocks, false});
+            return false;
+        }
         room = most;
         return true;
+    }
+    // could the sequence be a key of the column map for SOME count of blocks (it was seen within the last thousand blocks, or this walk
+    // does not reach back that far)?
+    bool mayBeKey(int32_t rank) const {
+        const int64_t seen = lastSeen[(size_t)rank], at = (int64_t)numBlocks;
+        return seen == INT64_MIN ? at - firstBlock <= 1000 : at - seen <= 1000;
     }
     void endBlock() {
         cur.numEvents = (uint32_t)batch->events.size() - cur.firstEvent;
@@ -1166,7 +1360,38 @@ struct MafExport::RunMachine {
             endBlock();
             if (numBlocks++ % 1000 == 0)
                 defragment(rows, n);
-            if (batch->blocks.size() >= 32768) {
+            if (sliced) {
+                if (!logging && refPos >= logFrom && refPos >= stopAt) {
+                    // (no block begins inside the slice: the block that began in front of it ends behind it)
+                    emptySlice = true;
+                    emptyAt = refPos;
+                    stopped = true;
+                    return 0;
+                }
+                if (!logging && refPos >= logFrom && expectCount >= 0 && (int64_t)numBlocks != expectCount) {
+                    // (the run-up held another number of blocks than it was reckoned with: the count it was told at its beginning is put
+                    // right by the difference and the run-up walked again — walkSliced)
+                    miscounted = true;
+                    stopped = true;
+                    return 0;
+                }
+                if (!logging && refPos >= logFrom) { // the slice's first block begins: the run-up's log goes
+                    std::vector<std::unique_ptr<PRow[]>> keep;
+                    if (!batch->extra.empty() && batch->extra.back().get() == rows)
+                        keep.push_back(std::move(batch->extra.back())); // (made by advance for this very column)
+                    batch->reset();
+                    batch->extra = std::move(keep);
+                    entsLogged = false;
+                    logging = true;
+                    startPending = true;
+                    idx = idxRoom(n);
+                } else if (logging && refPos >= stopAt && !stopped) { // the next slice's first block begins: nothing of it is kept
+                    stopMark = LogMark{batch->blocks.size(), batch->events.size(), batch->numIdx, batch->entRank.size(), batch->extra.size()};
+                    stopped = true;
+                } else if (!logging) {
+                    ++warmBlocks;
+                }
+            } else if (batch->blocks.size() >= 32768) {
                 flush(rows);
                 idx = idxRoom(n);
             }
@@ -1182,6 +1407,8 @@ struct MafExport::RunMachine {
                 el[idx[i]] = blk;
                 e.len = 0;
                 e.next = rows[i].key;
+                ekey[idx[i]] = 0;
+                lastSeen[(size_t)rows[i].rank] = (int64_t)numBlocks; // (the block being made, counted over the export)
             }
             e.len += k;
             e.next += 2 * k;
@@ -1189,7 +1416,90 @@ struct MafExport::RunMachine {
         batch->events.push_back(EventLog{k, rows, (uint32_t)batch->numIdx, (uint32_t)n});
         batch->numIdx += n;
         appendCount += (size_t)k;
+        if (startPending) {
+            startPending = false;
+            startSnap = snapshot(refPos);
+            numBlocksAtStart = numBlocks;
+        }
+        if (stopped && endSnap.column < 0) {
+            endSnap = snapshot(refPos);
+            // (what the block that begins here has logged goes: it is the next slice's)
+            batch->events.resize(stopMark.events);
+            batch->numIdx = stopMark.numIdx;
+            batch->entRank.resize(stopMark.entRank);
+            if (batch->extra.size() > stopMark.extra)
+                batch->extra.resize(stopMark.extra);
+        }
         return k;
+    }
+    // The walk over chunk c from its head number hk0 on: MafExport::convertSequence's loop (halMafExport.cpp:46-81) over the
+    // run-compressed columns — a head's rows come from the device, the columns up to the next head continue it base by base.
+    // Ends with the chunk, or (a slice's walk) where the next slice's first block has begun.
+    void walkChunk(const std::shared_ptr<Chunk> &c, size_t hk0, int64_t startPosition) {
+        chunk = c;
+        if (!sliced)
+            batch->chunks.push_back(c);
+        const int64_t n = c->n;
+        size_t hk = hk0;
+        const size_t numChunkHeads = c->headOff.size() - 1;
+        for (int64_t i = hk0 == 0 ? 0 : (int64_t)c->headCol[hk0]; i < n && !stopped;) {
+            if (c->head[(size_t)i] == 2) { // --unique: a column the iterator does not walk (nextFreeIndex passes over it)
+                ++i;
+                continue;
+            }
+            // head column i: its rows come from the device; the columns up to the next head continue it
+            if (sliced && logging && !stopped && startPosition + c->done + i >= stopAt) {
+                preStop = saveState(); // (the next slice's first block begins at this head or one of the next few)
+                preStopChunk = curChunkIndex;
+                preStopHead = hk;
+                preStopValid = true;
+            }
+            const PRow *rows = c->rows.get() + c->headOff[hk];
+            const size_t nr = c->headOff[hk + 1] - c->headOff[hk];
+            ++hk;
+            if (hk + 6 < numChunkHeads) { // (the rows were written by other cores a moment ago: asked for a few heads ahead of their use)
+                const char *ahead = (const char *)(c->rows.get() + c->headOff[hk + 5]);
+                __builtin_prefetch(ahead);
+                __builtin_prefetch(ahead + 64);
+                __builtin_prefetch(ahead + 128);
+                __builtin_prefetch(ahead + 192);
+            }
+            if (c->head[(size_t)i] == 3) { // --unique: walked, not written (a reference base left of the range): its sequences stay
+                addKeys(rows, nr);         // behind as keys of the column map (halColumnIterator.cpp:822-826)
+                for (size_t r = 0; r < nr; ++r)
+                    lastSeen[(size_t)rows[r].rank] = (int64_t)numBlocks;
+                irregularKeys = true;
+                ++i;
+                continue;
+            }
+            int64_t left = 1; // (the columns up to the next head, eight bytes of the marks at a time)
+            {
+                const uint8_t *hp = c->head.data();
+                int64_t at = i + 1;
+                for (; at + 8 <= n; at += 8) {
+                    uint64_t w;
+                    memcpy(&w, hp + at, 8);
+                    if (w) {
+                        at += __builtin_ctzll(w) >> 3;
+                        break;
+                    }
+                }
+                while (at < n && !hp[at])
+                    ++at;
+                left = at - i;
+            }
+            int64_t col = i;
+            for (;;) {
+                addKeys(rows, nr);
+                const int64_t k = place(rows, nr, left, startPosition + c->done + col);
+                left -= k;
+                col += k;
+                if (left == 0 || stopped)
+                    break;
+                rows = advance(rows, nr, k); // a block-length break or a sequence end: an ordinary column next
+            }
+            i = col;
+        }
     }
     // the bases k columns on (a column that has to go through the per-column logic in the middle of a run)
     const PRow *advance(const PRow *rows, size_t n, int64_t k) {
@@ -1239,6 +1549,12 @@ static int renderThreads() { // hal2maf's rendering threads per batch (HGX_MAF_R
     // 24 threads 0.67 s, 32 0.74-0.75, 48 0.63, 64 0.61, profiles/r04y_gpu_maf_diag_threads.txt; more threads also disturb the walk more)
     return e ? std::max(1, atoi(e)) : 48;
 }
+static int rendersInFlight() { // batches rendered at a time (HGX_MAF_RENDERS_IN_FLIGHT): their threads share the host's
+    const char *e = getenv("HGX_MAF_RENDERS_IN_FLIGHT");
+    if (e)
+        return std::max(1, atoi(e));
+    return std::thread::hardware_concurrency() >= 64 ? 4 : 2;
+}
 static size_t describeThreads(size_t heads) { // the threads that describe and sort a device batch's rows (HGX_MAF_DESCRIBE_THREADS)
     if (const char *e = getenv("HGX_MAF_DESCRIBE_THREADS"))
         return (size_t)std::max(1, atoi(e));
@@ -1248,8 +1564,15 @@ static double g_mafFlush = 0; // (HGX_MAF_TIMING: the walk's thread in flush(): 
 static double g_mafRenderWait = 0; // (HGX_MAF_TIMING: how long the walk stood waiting for the batch before to be rendered)
 void MafExport::RunMachine::flush(const PRow *current) {
     {
+        // (up to rendersInFlight() batches are being rendered at a time; a batch whose threads are done waits for its turn to write)
         const auto tw = std::chrono::steady_clock::now();
-        M.waitPendingWrite();
+        if (M._pendingWrite.valid())
+            M._pendingWrite.get();
+        const size_t inFlight = batch->blocks.empty() ? 0 : (size_t)rendersInFlight();
+        while (M._pendingWrites.size() > (inFlight ? inFlight - 1 : 0)) {
+            M._pendingWrites.front().get();
+            M._pendingWrites.pop_front();
+        }
         g_mafRenderWait += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
     }
     if (batch->blocks.empty())
@@ -1281,13 +1604,21 @@ void MafExport::RunMachine::flush(const PRow *current) {
     if (getenv("HGX_MAF_NO_RENDER"))
         return;
 #endif
-    M._pendingWrite = std::async(std::launch::async, [work, names, ranks, al, out, keepEmptyRefBlocks]() {
+    const size_t ticket = M._ticketsIssued++;
+    std::shared_ptr<WriteOrder> order = M._writeOrder;
+    M._pendingWrites.push_back(std::async(std::launch::async, [work, names, ranks, al, out, keepEmptyRefBlocks, ticket, order]() {
+        struct Turn { // (whatever happens to this batch, the batches behind it get their turn)
+            WriteOrder &o;
+            size_t t;
+            ~Turn() { o.done(t); }
+        } turn{*order, ticket};
         static const char fwd[17] = "acgtn\0\0\0ACGTN\0\0\0";
         static const char rc[17] = "tgcan\0\0\0TGCAN\0\0\0";
         static const PairTable fwd2(fwd, false), rc2(rc, true);
         const size_t nb = work->blocks.size();
         unsigned nt = std::thread::hardware_concurrency();
         nt = std::max(1u, std::min(nt ? nt : 1u, (unsigned)renderThreads()));
+        nt = std::max(1u, std::min(nt, (std::thread::hardware_concurrency() + (unsigned)rendersInFlight() - 1) / (unsigned)rendersInFlight()));
         if (nb < 256)
             nt = 1;
         // (the rendering threads' buffers are kept from batch to batch: thirty megabytes of fresh pages per batch were as many page
@@ -1451,6 +1782,7 @@ void MafExport::RunMachine::flush(const PRow *current) {
         BulkSink *const sink = dynamic_cast<BulkSink *>(out->rdbuf());
         if (nt == 1) {
             render(0);
+            order->wait(ticket);
             out->write(text[0].data, (std::streamsize)text[0].len);
         } else {
             // the threads are made once a batch: each renders its share of the blocks, waits until all have and the output has given
@@ -1477,6 +1809,7 @@ void MafExport::RunMachine::flush(const PRow *current) {
             {
                 std::unique_lock<std::mutex> lock(mu);
                 cv.wait(lock, [&]() { return rendered == nt; });
+                order->wait(ticket); // (the batches' texts in the batches' order)
                 size_t total = 0;
                 for (unsigned t = 0; t < nt; ++t) {
                     at[t] = total;
@@ -1494,9 +1827,297 @@ void MafExport::RunMachine::flush(const PRow *current) {
                     out->write(text[t].data, (std::streamsize)text[t].len);
         }
         std::lock_guard<std::mutex> lock(pool->mu);
-        if (pool->idle.size() < 4)
+        if (pool->idle.size() < 6)
             pool->idle.push_back(std::move(held));
-    });
+    }));
+}
+
+// MafBlock's state machine over slices of the export, side by side.  Where a block begins depends on the blocks before it only
+// through the entries (a memory of thirteen blocks), the column map's keys (since the last defragment) and the count of blocks
+// so far (defragment runs at every thousandth) — RunMachine::Snapshot.  Every slice but the first is walked cold from some
+// thousand heads in front of it, told the count of blocks in front of it as the round before found it (first round: nothing),
+// and logs the blocks that begin inside it; a slice's walk goes on until the next slice's first block has begun and keeps what it
+// looked like then.  When every slice began as the slice before it ended, the logs in order are the one-thread walk's, by
+// induction from the first slice (which begins with the export's own state).  Counts that moved, or a run-up that did not find
+// the state, cost another round for the slices behind; after a few rounds without agreement one thread walks the export.
+bool MafExport::walkSliced(std::ostream &mafStream, void *chunksPtr, int refRank, int64_t startPosition, size_t &numBlocksOut) {
+    typedef RunMachine::Chunk Chunk;
+    const std::vector<std::shared_ptr<Chunk>> &all = *static_cast<const std::vector<std::shared_ptr<Chunk>> *>(chunksPtr);
+    const size_t S = all.size();
+    if (S < 2)
+        return false;
+    const auto t0 = std::chrono::steady_clock::now();
+    RunMachine first(*this, mafStream, refRank); // (takes the export's entries; hands the last slice's back in the end)
+    first.describeAllRanks();
+    const RunMachine::MachineState initial = first.saveState();
+    std::shared_ptr<std::vector<RunMachine::RankInfo>> ranks = first.rankInfo;
+    // heads in front of every chunk; where a slice's run-up begins
+    std::vector<size_t> headBase(S + 1, 0);
+    for (size_t c = 0; c < S; ++c)
+        headBase[c + 1] = headBase[c] + (all[c]->headOff.size() - 1);
+    const size_t RUNUP = getenv("HGX_MAF_RUNUP") ? (size_t)std::max(1, atoi(getenv("HGX_MAF_RUNUP"))) : 4096;
+    auto seamOf = [&](size_t s) { return s < S ? startPosition + all[s]->done : INT64_MAX; };
+    struct Slice {
+        std::unique_ptr<RunMachine> R;
+        int64_t count = 0, runup = 0;  // blocks that began in the slice / in its run-up, as its last walk found them
+        int64_t toldCount = -1;        // the count its last walk was told at its run-up's beginning
+        int64_t shift = 0;             // how far the count its accepted walk was told was off (nothing it decided depended on it)
+        int64_t exactBase = -1;        // the count in front of it, once the slices before it are settled
+        int64_t guessBase = -1;        // ... or as the last round's walks let it be told
+        int64_t lastBase = -1;         // what its last cold walk was told
+        bool settledEmpty = false;     // no block begins in it
+        bool exactWalk = false;        // walked from the very state the slice before it stopped in
+        bool exactState = false;       // its machine's count and keys are the one-thread walk's (else: right but for them)
+        bool walked = false, reachedEnd = false;
+    };
+    std::vector<Slice> slice(S);
+    // the first slice: the export's own state, its log from the first column on
+    first.sliced = true;
+    first.stopAt = seamOf(1);
+    auto walkFrom = [&](RunMachine &R, size_t chunk, size_t head) {
+        for (size_t c = chunk; c < S && !R.stopped; ++c) {
+            R.curChunkIndex = c;
+            R.walkChunk(all[c], c == chunk ? head : 0, startPosition);
+        }
+        if (!R.stopped && R.appendCount > 0)
+            R.endBlock();
+    };
+    walkFrom(first, 0, 0);
+    slice[0].count = (int64_t)(first.stopped ? first.endSnap.numBlocks : first.numBlocks);
+    slice[0].reachedEnd = !first.stopped;
+    unsigned threads = std::thread::hardware_concurrency();
+    threads = std::max(1u, std::min(threads ? threads : 1u, 32u));
+    if (const char *e = getenv("HGX_MAF_WALK_THREADS"))
+        threads = (unsigned)std::max(1, atoi(e));
+    // the settled slices' logs go to the rendering threads in order as soon as they are settled (RunMachine::flush renders a few
+    // batches at a time beside whatever this thread does next: the following round's walks)
+    size_t flushedUpTo = 0, blocksFlushed = 0;
+    bool flushEnded = false;
+    auto flushSettled = [&](size_t upTo) {
+        for (; flushedUpTo < upTo && !flushEnded; ++flushedUpTo) {
+            const size_t s = flushedUpTo;
+            if (s > 0 && slice[s].settledEmpty)
+                continue;
+            RunMachine &R = s == 0 ? first : *slice[s].R;
+            flushEnded = slice[s].reachedEnd;
+            blocksFlushed += R.batch->blocks.size();
+            if (&R != &first) {
+                first.batch = std::move(R.batch);
+                R.batch.reset(new RunMachine::Batch);
+            }
+            first.sliced = false;
+            first.flush();
+            first.sliced = true;
+        }
+    };
+    std::vector<char> todo(S, 1);
+    todo[0] = 0;
+    bool settled = false;
+    int rounds = 0;
+    size_t frontier = 1, frontierPrev = 0; // the first slice that is not settled; the last slice in front of it with blocks of its own
+    slice[0].exactState = true;
+    for (; rounds < (int)S + 2 && !settled; ++rounds) {
+        std::atomic<size_t> next{1};
+        std::exception_ptr failure;
+        std::mutex failureMu;
+        // (a walk is told the blocks in front of its slice as the round before counted them: taken before the threads start — a
+        // round's walks write only their own slice's counts)
+        std::vector<int64_t> baseOf(S, 0);
+        for (size_t s = 1; s < S; ++s)
+            baseOf[s] = slice[s].exactBase >= 0 ? slice[s].exactBase : slice[s].guessBase >= 0 ? slice[s].guessBase : baseOf[s - 1] + slice[s - 1].count;
+        auto walkSlice = [&](size_t s) {
+            Slice &L = slice[s];
+            L.exactWalk = false;
+            if (s == frontier) {
+                // the first slice that is not settled: from the state the slice before it was in when it reached this one (put right
+                // for the count where that slice was told another) — the one-thread walk of this slice, whatever the others guess
+                const size_t q = frontierPrev;
+                const RunMachine &P = q == 0 ? first : *slice[q].R;
+                if (P.preStopValid) {
+                    const RunMachine::MachineState &st = P.preStop;
+                    L.R.reset(new RunMachine(*this, mafStream, refRank, ranks, st.numBlocks));
+                    RunMachine &R = *L.R;
+                    R.restoreState(st);
+                    R.logFrom = seamOf(s);
+                    R.stopAt = seamOf(s + 1);
+                    R.logging = false;
+                    walkFrom(R, P.preStopChunk, P.preStopHead);
+                    L.toldCount = (int64_t)st.numBlocks;
+                    L.walked = true;
+                    L.exactWalk = true;
+                    L.reachedEnd = !R.stopped;
+                    L.runup = 0;
+                    L.count = R.startSnap.column >= 0 ? (int64_t)((R.stopped ? R.endSnap.numBlocks : R.numBlocks) - R.numBlocksAtStart) : 0;
+                    return;
+                }
+            }
+            if (L.walked && !L.exactWalk && L.lastBase == baseOf[s])
+                return; // (told what it was told before: the same walk)
+            L.lastBase = baseOf[s];
+            const int64_t told = std::max<int64_t>(0, baseOf[s] - L.runup);
+            const size_t h0 = headBase[s] > RUNUP ? headBase[s] - RUNUP : 0;
+            const size_t c0 = (size_t)(std::upper_bound(headBase.begin(), headBase.begin() + (std::ptrdiff_t)S, h0) - headBase.begin()) - 1;
+            // (the run-up's own count of blocks is only known when it has been walked: up to three times, told the count put right by
+            // what the walk before found; the last one goes on whatever it finds)
+            int64_t tell = told;
+            size_t before = 0;
+            for (int attempt = 0;; ++attempt) {
+                L.R.reset(new RunMachine(*this, mafStream, refRank, ranks, (size_t)tell));
+                RunMachine &R = *L.R;
+                if (h0 == 0) { // (the run-up reaches the export's first column: the export's own state, not a cold one)
+                    R.restoreState(initial);
+                    R.numBlocks = 0;
+                }
+                R.logFrom = seamOf(s);
+                R.stopAt = seamOf(s + 1);
+                R.logging = false;
+                R.expectCount = h0 == 0 || attempt == 3 ? -1 : baseOf[s];
+                before = R.numBlocks;
+                walkFrom(R, c0, h0 - headBase[c0]);
+                if (!R.miscounted)
+                    break;
+                tell = std::max<int64_t>(0, tell + baseOf[s] - (int64_t)R.numBlocks);
+            }
+            RunMachine &R = *L.R;
+            L.toldCount = tell;
+            L.walked = true;
+            L.reachedEnd = !R.stopped;
+            if (R.startSnap.column >= 0) {
+                L.runup = (int64_t)(R.numBlocksAtStart - before);
+                L.count = (int64_t)((R.stopped ? R.endSnap.numBlocks : R.numBlocks) - R.numBlocksAtStart);
+            } else { // (no block begins inside the slice: the slice before runs through it)
+                L.runup = (int64_t)(R.numBlocks - before);
+                L.count = 0;
+            }
+        };
+        auto work = [&]() {
+            try {
+                for (size_t s; (s = next.fetch_add(1)) < S;)
+                    if (todo[s])
+                        walkSlice(s);
+            } catch (...) {
+                std::lock_guard<std::mutex> lock(failureMu);
+                if (!failure)
+                    failure = std::current_exception();
+            }
+        };
+        {
+            std::vector<std::thread> pool;
+            const unsigned nt = (unsigned)std::min<size_t>(threads, S - 1);
+            for (unsigned t = 1; t < nt; ++t)
+                pool.emplace_back(work);
+            work();
+            for (std::thread &t : pool)
+                t.join();
+        }
+        if (failure)
+            std::rethrow_exception(failure);
+        // does every slice begin as the one before it ended?  (a slice whose walk ran to the export's end has everything behind it)
+        settled = true;
+        std::fill(todo.begin(), todo.end(), 0);
+        bool ended = slice[0].reachedEnd;
+        const RunMachine *prev = &first;
+        size_t prevIndex = 0;               // the last slice in front that has blocks of its own
+        int64_t trueCount = slice[0].count; // the blocks in front of the slice's first block, for certain
+        bool prevKeysExact = true;          // the slice before was walked with that count and knew the keys it began with
+        for (size_t s = 1; s < S; ++s) {
+            if (ended) { // (nothing begins here: the slice in front ran through)
+                slice[s].count = 0;
+                continue;
+            }
+            RunMachine &R = *slice[s].R;
+            bool agrees = false, keysExact = false;
+            int64_t shift = 0;
+            if (R.emptySlice && prev->stopped && prev->endSnap.column == R.emptyAt) {
+                slice[s].count = 0; // (the block the slice in front ended with begins behind this slice: nothing of this one)
+                slice[s].shift = 0;
+                slice[s].settledEmpty = true;
+                continue;
+            }
+            slice[s].settledEmpty = false;
+            if (slice[s].exactWalk && R.startSnap.column >= 0 && prev->stopped && prev->endSnap.column == R.startSnap.column &&
+                (int64_t)R.startSnap.numBlocks == trueCount) {
+                agrees = keysExact = true; // (walked from the state the slice before was in: nothing to compare but that it did begin there)
+            } else if (R.startSnap.column >= 0 && prev->stopped) {
+                shift = trueCount - (int64_t)R.startSnap.numBlocks;
+                if (shift == 0 && prevKeysExact && prev->endSnap == R.startSnap) {
+                    agrees = keysExact = true; // the whole state, keys and count
+                }
+            }
+            if (!agrees) {
+                settled = false;
+                if (getenv("HGX_MAF_TIMING"))
+                    std::cerr << "[hgx maf]   round " << rounds << ": slice " << s << " does not begin as slice " << s - 1 << " ended (columns "
+                              << (prev->stopped ? prev->endSnap.column : -1) << " / " << R.startSnap.column << ", blocks " << trueCount << " / "
+                              << R.startSnap.numBlocks << ", entries " << (prev->stopped ? prev->endSnap.bRank.size() : 0) << " / " << R.startSnap.bRank.size()
+                              << ", sequences seen " << (prev->stopped ? prev->endSnap.seen.size() : 0) << " / " << R.startSnap.seen.size() << ", looks at keys' entries "
+                              << R.keyUses.size() << ")" << std::endl;
+                // this slice and the ones behind it again, told the counts as they are known now
+                for (size_t j = s; j < S; ++j)
+                    todo[j] = 1;
+                slice[s].exactBase = trueCount;
+                frontier = s;
+                frontierPrev = prevIndex;
+                // the counts in front of the slices behind, as well as they can be told now: every slice's count put right by what its looks
+                // at keys' entries say of the count it should have been told
+                {
+                    int64_t base = trueCount;
+                    for (size_t j = s; j + 1 < S; ++j) {
+                        const RunMachine &W = *slice[j].R;
+                        int64_t count = slice[j].count;
+                        if (W.startSnap.column >= 0)
+                            count += W.countChangeUnderShift(base - (int64_t)W.startSnap.numBlocks);
+                        base += count;
+                        slice[j + 1].guessBase = base;
+                    }
+                }
+                break;
+            }
+            slice[s].shift = shift;
+            slice[s].exactState = keysExact;
+            prevIndex = s;
+            trueCount += slice[s].count;
+            prevKeysExact = keysExact;
+            ended = slice[s].reachedEnd;
+            prev = &R;
+        }
+        flushSettled(settled ? S : frontier);
+    }
+    if (getenv("HGX_MAF_TIMING"))
+        std::cerr << "[hgx maf] the walk over " << S << " slices on " << threads << " threads: " << rounds << " round(s), "
+                  << (settled ? "settled" : "NOT settled") << " after " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << " s"
+                  << std::endl;
+    if (getenv("HGX_MAF_TIMING") && getenv("HGX_MAF_SLICE_COUNTS")) {
+        std::cerr << "[hgx maf]   slices' blocks (count off by):";
+        for (size_t s = 0; s < S; ++s)
+            std::cerr << " " << slice[s].count << "(" << slice[s].shift << (slice[s].exactWalk ? "x" : "") << ")";
+        std::cerr << std::endl;
+    }
+    if (!settled) {
+        // (cannot be: the first unsettled slice of every round is walked from the state the slice before it stopped in)
+        if (flushedUpTo > 0)
+            throw std::runtime_error("hal2maf: the walk over slices of the export did not settle");
+        first.restoreState(initial); // the export's entries as they were: one thread's walk follows
+        first.sliced = false;
+        first.batch->reset();
+        return false;
+    }
+    const RunMachine *last = &first;
+    for (size_t s = 1; s < S; ++s) {
+        if (slice[s].settledEmpty || !slice[s].R)
+            continue;
+        if (slice[s].R->startSnap.column < 0)
+            continue;
+        last = slice[s].R.get();
+        if (slice[s].reachedEnd)
+            break;
+    }
+    if (last != &first)
+        first.restoreState(last->saveState());
+    first.sliced = false;
+    const size_t blocks = blocksFlushed;
+    numBlocksOut = blocks ? blocks - 1 : 0; // (as the one-thread walk counts: blocks ended)
+    return true;
 }
 
 void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alignment, int genome, int seq, int64_t startPosition,
@@ -1507,6 +2128,13 @@ void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alig
     const int64_t first = startPosition + G.seqs[(size_t)seq].start;
     if (const char *e = getenv("HGX_MAF_CHUNK")) // (columns per device batch: tests cross batch ends with it)
         chunkColumns = (size_t)std::max<long long>(1, atoll(e));
+    // The walk over slices of the export, side by side (walkSliced): exports of sixteen million columns or more in eight chunks or
+    // more on a host of thirty-two threads or more; HGX_MAF_SLICED=1 / 0 forces / forbids it
+    const int64_t numChunksExpected = (length + (int64_t)chunkColumns - 1) / (int64_t)chunkColumns;
+    // (a round of walks takes one slice's time when every slice has a thread: hosts of 32 threads or more)
+    bool wantHeadCols = numChunksExpected >= 8 && numChunksExpected <= 512 && length >= ((int64_t)16 << 20) && std::thread::hardware_concurrency() >= 32;
+    if (const char *e = getenv("HGX_MAF_SLICED"))
+        wantHeadCols = atoi(e) != 0; // (1: whatever the export's size — with two batches or more; the tests and the soaks)
     // The batches come through two stages beside the walk: the device stage (the column kernels, the copies to the host: one call at
     // a time, the next one begun as soon as this one is back, up to a few batches ahead of the walk) and the stage that describes and
     // sorts a batch's rows for the walk (several threads a batch, beside the device stage of the batch behind it).
@@ -1567,12 +2195,18 @@ void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alig
         c->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         return raw;
     };
-    auto describeStage = [this, alignment](std::shared_ptr<Raw> raw) {
+    auto describeStage = [this, alignment, wantHeadCols](std::shared_ptr<Raw> raw) {
         const auto t0 = std::chrono::steady_clock::now();
         Chunk *c = raw->c.get();
         const HeadRows &headRows = raw->headRows;
         c->rows.reset(static_cast<PRow *>(hostBlockTake((headRows.size() ? headRows.size() : 1) * sizeof(PRow))));
         const size_t heads = c->headOff.size() - 1;
+        if (wantHeadCols) { // (the walk over slices begins in the middle of chunks)
+            c->headCol.reserve(heads);
+            for (int64_t i = 0; i < c->n; ++i)
+                if (c->head[(size_t)i] & 1)
+                    c->headCol.push_back((uint32_t)i);
+        }
         auto convert = [&](size_t h0, size_t h1) {
             for (size_t h = h0; h < h1; ++h) {
                 for (size_t i = c->headOff[h]; i < c->headOff[h + 1]; ++i)
@@ -1601,6 +2235,8 @@ void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alig
         std::exception_ptr error;
     } pipe;
     size_t ahead = getenv("HGX_MAF_AHEAD") ? (size_t)std::max(1, atoi(getenv("HGX_MAF_AHEAD"))) : 4; // (batches made and not yet taken by the walk)
+    if (wantHeadCols)
+        ahead = (size_t)-1; // (the walk over slices begins when every batch is there)
 #ifdef HGX_HOST_PROFILE
     const bool wholeAhead = mafReplayFile() && getenv("HGX_MAF_REPLAY_AHEAD"); // (the walk by itself: every batch is there before it begins)
     if (wholeAhead)
@@ -1674,68 +2310,38 @@ void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alig
     }
 #endif
     const auto tStart = std::chrono::steady_clock::now();
-    {
-        RunMachine R(*this, mafStream, _rank[(size_t)genome][(size_t)seq]);
+    std::vector<std::shared_ptr<Chunk>> all; // (the walk over slices: every batch, kept until the text is written)
+    bool slicedDone = false;
+    if (wantHeadCols) {
         for (int64_t done = 0; done < length;) {
             const auto tw = std::chrono::steady_clock::now();
             std::shared_ptr<Chunk> c = nextChunk();
             waitSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
-            const int64_t n = c->n;
             fetchSeconds += c->seconds;
             numHeads += c->headOff.size() - 1;
-            R.chunk = c;
-            R.batch->chunks.push_back(c);
-            size_t hk = 0;
-            const size_t numChunkHeads = c->headOff.size() - 1;
-            for (int64_t i = 0; i < n;) {
-                if (c->head[(size_t)i] == 2) { // --unique: a column the iterator does not walk (nextFreeIndex passes over it)
-                    ++i;
-                    continue;
-                }
-                // head column i: its rows come from the device; the columns up to the next head continue it
-                const PRow *rows = c->rows.get() + c->headOff[hk];
-                const size_t nr = c->headOff[hk + 1] - c->headOff[hk];
-                ++hk;
-                if (hk + 6 < numChunkHeads) { // (the rows were written by other cores a moment ago: asked for a few heads ahead of their use)
-                    const char *ahead = (const char *)(c->rows.get() + c->headOff[hk + 5]);
-                    __builtin_prefetch(ahead);
-                    __builtin_prefetch(ahead + 64);
-                    __builtin_prefetch(ahead + 128);
-                    __builtin_prefetch(ahead + 192);
-                }
-                if (c->head[(size_t)i] == 3) { // --unique: walked, not written (a reference base left of the range): its sequences stay
-                    R.addKeys(rows, nr);       // behind as keys of the column map (halColumnIterator.cpp:822-826)
-                    ++i;
-                    continue;
-                }
-                int64_t left = 1; // (the columns up to the next head, eight bytes of the marks at a time)
-                {
-                    const uint8_t *hp = c->head.data();
-                    int64_t at = i + 1;
-                    for (; at + 8 <= n; at += 8) {
-                        uint64_t w;
-                        memcpy(&w, hp + at, 8);
-                        if (w) {
-                            at += __builtin_ctzll(w) >> 3;
-                            break;
-                        }
-                    }
-                    while (at < n && !hp[at])
-                        ++at;
-                    left = at - i;
-                }
-                int64_t col = i;
-                for (;;) {
-                    R.addKeys(rows, nr);
-                    const int64_t k = R.place(rows, nr, left, startPosition + done + col);
-                    left -= k;
-                    col += k;
-                    if (left == 0)
-                        break;
-                    rows = R.advance(rows, nr, k); // a block-length break or a sequence end: an ordinary column next
-                }
-                i = col;
+            done += c->n;
+            all.push_back(std::move(c));
+        }
+        slicedDone = walkSliced(mafStream, &all, _rank[(size_t)genome][(size_t)seq], startPosition, numBlocks);
+        if (getenv("HGX_MAF_TIMING"))
+            std::cerr << "[hgx maf] columns " << length << " heads " << numHeads << " blocks " << numBlocks << ": the walk over " << all.size()
+                      << " slices " << (slicedDone ? "" : "did not settle; one thread's walk instead ") << "after "
+                      << std::chrono::duration<double>(std::chrono::steady_clock::now() - tStart).count() << " s, of which waiting for the device "
+                      << waitSeconds << " s (fetches " << fetchSeconds << " s, device " << stats.rows_ms + stats.depth_ms << " ms)" << std::endl;
+    }
+    if (!slicedDone) {
+        RunMachine R(*this, mafStream, _rank[(size_t)genome][(size_t)seq]);
+        size_t nextOfAll = 0;
+        for (int64_t done = 0; done < length;) {
+            const auto tw = std::chrono::steady_clock::now();
+            std::shared_ptr<Chunk> c = wantHeadCols ? all[nextOfAll++] : nextChunk();
+            waitSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
+            const int64_t n = c->n;
+            if (!wantHeadCols) {
+                fetchSeconds += c->seconds;
+                numHeads += c->headOff.size() - 1;
             }
+            R.walkChunk(c, 0, startPosition);
             done += n;
         }
         if (R.appendCount > 0)

@@ -5,6 +5,9 @@
 #pragma once
 #include "hgx_columns_engine.hpp"
 #include <deque>
+#include <condition_variable>
+#include <mutex>
+#include <memory>
 #include <future>
 #include <map>
 #include <ostream>
@@ -144,9 +147,47 @@ class MafExport {
     void snapshotBlock();
     void flushSnapshots(std::ostream &os);
     std::future<void> _pendingWrite;              // rendering + writing of the previous batch, running beside the state machine
+    // the run-compressed export renders several batches at a time (RunMachine::flush): every batch's threads make its text apart,
+    // then take their turn — by ticket, in the order of the batches — to be given room in the output and copy it there
+    struct WriteOrder {
+        std::mutex mu;
+        std::condition_variable cv;
+        size_t next = 0; // the ticket whose batch may write
+        void wait(size_t ticket) {
+            std::unique_lock<std::mutex> lock(mu);
+            cv.wait(lock, [&]() { return next == ticket; });
+        }
+        std::set<size_t> gone; // (batches that ended before their turn came: an exception)
+        void done(size_t ticket) {
+            std::lock_guard<std::mutex> lock(mu);
+            if (next == ticket) {
+                ++next;
+                while (gone.erase(next))
+                    ++next;
+            } else if (ticket > next) {
+                gone.insert(ticket);
+            }
+            cv.notify_all();
+        }
+    };
+    std::shared_ptr<WriteOrder> _writeOrder = std::make_shared<WriteOrder>();
+    size_t _ticketsIssued = 0;
+    std::deque<std::future<void>> _pendingWrites;
     void waitPendingWrite() {
         if (_pendingWrite.valid())
             _pendingWrite.get();
+        std::exception_ptr first;
+        while (!_pendingWrites.empty()) { // (every one is waited for, whatever the ones before threw)
+            try {
+                _pendingWrites.front().get();
+            } catch (...) {
+                if (!first)
+                    first = std::current_exception();
+            }
+            _pendingWrites.pop_front();
+        }
+        if (first)
+            std::rethrow_exception(first);
     }
     void appendRun(Entry *e, const ColumnRowHost *row, int64_t pos, int64_t n);
     // ---- the run-compressed export (hgx_columns_host.cpp: RunMachine): MafBlock's state on flat arrays ----
@@ -154,6 +195,9 @@ class MafExport {
     friend struct RunMachine;
     void convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alignment, int genome, int seq, int64_t startPosition, int64_t length,
                              const ColumnOptions &opt);
+    // the same walk over slices of the export side by side (hgx_columns_host.cpp); chunks: RunMachine::Chunk, every batch of the export;
+    // false: the slices' walks did not settle on one sequence of blocks — nothing was written, the caller walks with one thread
+    bool walkSliced(std::ostream &mafStream, void *chunks, int refRank, int64_t startPosition, size_t &numBlocks);
     // --maxRefGap > 0: the column iterator with its stack of inserted / deleted ranges (halColumnIterator.cpp:65-144, 357-405),
     // replayed over the columns and indel events the device returns (hgx_gap_kernels.hpp)
     void convertSequenceGapped(std::ostream &mafStream, hgx_alignment *alignment, int genome, int seq, int64_t first, int64_t last,

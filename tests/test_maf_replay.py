@@ -99,3 +99,23 @@ def test_oracle_written_records_through_the_general_liftover_path(oracle_bin):
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT).stdout.decode()
     last = out.strip().splitlines()[-1].split()
     assert last[:2] == ["alignments", "12"] and int(last[3]) >= 60 and last[4:] == ["different", "0"], out
+
+
+def test_walk_over_slices_of_the_export_is_the_one_thread_walk(oracle_bin):
+    """hal2maf's block state machine over slices of the export side by side (MafExport::walkSliced: cold run-ups, the count of
+    blocks told from round to round, slices accepted when they begin in the very state the slice before ended in, the first
+    unsettled slice walked from that state) on batches the oracle writes: exports of thousands of blocks (block-length limits of
+    1 .. 5: the column map's keys are reset at every thousandth block), genomes of several sequences that come and go, 5 .. 200
+    slices, run-ups of 3 .. 4096 heads, 1 / 3 / 8 threads, --unique / --targetGenomes / --noDupes; every text the oracle's, every
+    walk settled (profiles/scripts/r05_cpu_maf_sliced_soak.py; profiles/r05_cpu_maf_sliced_soak.txt has the long runs, and the
+    full-size config-3 export — 27 slices, 1.79 M blocks, 1.81 GB — is byte-identical too: profiles/r05_notes.md)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "hal_amd", "csrc"), "all", "hostprof-lib"])
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "scripts", "r05_cpu_maf_sliced_soak.py"), "500", "20"],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT).stdout.decode()
+    last = out.strip().splitlines()[-1].split()
+    assert last[:2] == ["alignments", "20"] and int(last[3]) >= 40 and last[4:8] == ["different", "0", "not", "settled"] and last[8] == "0", out
+    # and the earlier soak's shapes (chunks of 1 .. 2^21 columns, every option of the state machine) with the walk over slices forced
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "scripts", "r04_cpu_maf_soak.py"), "7100", "8"],
+                         env=dict(os.environ, HGX_MAF_SLICED="1", HGX_MAF_RUNUP="50"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT).stdout.decode()
+    last = out.strip().splitlines()[-1].split()
+    assert last[:2] == ["alignments", "8"] and last[4:] == ["different", "0"], out
