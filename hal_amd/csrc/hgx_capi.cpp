@@ -1049,7 +1049,8 @@ int hgx_maf_tracks_info(hgx_alignment *h, int drop, char **json, char **err) {
     HGX_TRY
     if (!h || !json)
         throw std::runtime_error("hgx_maf_tracks_info: null argument");
-    const std::string s = h->dev ? mafTracksInfo(h) : std::string("{\"tracks\": false}");
+    std::string s = h->dev ? mafTracksInfo(h) : std::string("{\"tracks\": false}");
+    s.insert(s.size() - 1, ", \"last_export\": " + mafLastExportInfo()); // (the host side of the last run-compressed export of this process)
     if (drop && h->dev)
         mafTracksDrop(h);
     *json = (char *)malloc(s.size() + 1);

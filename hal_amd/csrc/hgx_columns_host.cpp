@@ -1549,6 +1549,20 @@ static int renderThreads() { // hal2maf's rendering threads per batch (HGX_MAF_R
     // 24 threads 0.67 s, 32 0.74-0.75, 48 0.63, 64 0.61, profiles/r04y_gpu_maf_diag_threads.txt; more threads also disturb the walk more)
     return e ? std::max(1, atoi(e)) : 48;
 }
+namespace {
+struct LastExport { // the last run-compressed export of this process: who walked it and how long the parts took
+    std::mutex mu;
+    std::string json = "null";
+};
+LastExport &lastExport() {
+    static LastExport *l = new LastExport;
+    return *l;
+}
+} // namespace
+std::string mafLastExportInfo() {
+    std::lock_guard<std::mutex> lock(lastExport().mu);
+    return lastExport().json;
+}
 static int rendersInFlight() { // batches rendered at a time (HGX_MAF_RENDERS_IN_FLIGHT): their threads share the host's
     const char *e = getenv("HGX_MAF_RENDERS_IN_FLIGHT");
     if (e)
@@ -1840,7 +1854,8 @@ void MafExport::RunMachine::flush(const PRow *current) {
 // looked like then.  When every slice began as the slice before it ended, the logs in order are the one-thread walk's, by
 // induction from the first slice (which begins with the export's own state).  Counts that moved, or a run-up that did not find
 // the state, cost another round for the slices behind; after a few rounds without agreement one thread walks the export.
-bool MafExport::walkSliced(std::ostream &mafStream, void *chunksPtr, int refRank, int64_t startPosition, size_t &numBlocksOut) {
+bool MafExport::walkSliced(std::ostream &mafStream, void *chunksPtr, int refRank, int64_t startPosition, size_t &numBlocksOut, int *roundsOut,
+                           unsigned *threadsOut, double *secondsOut) {
     typedef RunMachine::Chunk Chunk;
     const std::vector<std::shared_ptr<Chunk>> &all = *static_cast<const std::vector<std::shared_ptr<Chunk>> *>(chunksPtr);
     const size_t S = all.size();
@@ -2087,6 +2102,12 @@ bool MafExport::walkSliced(std::ostream &mafStream, void *chunksPtr, int refRank
         std::cerr << "[hgx maf] the walk over " << S << " slices on " << threads << " threads: " << rounds << " round(s), "
                   << (settled ? "settled" : "NOT settled") << " after " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << " s"
                   << std::endl;
+    if (roundsOut)
+        *roundsOut = rounds;
+    if (threadsOut)
+        *threadsOut = (unsigned)std::min<size_t>(threads, S - 1);
+    if (secondsOut)
+        *secondsOut = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (getenv("HGX_MAF_TIMING") && getenv("HGX_MAF_SLICE_COUNTS")) {
         std::cerr << "[hgx maf]   slices' blocks (count off by):";
         for (size_t s = 0; s < S; ++s)
@@ -2312,6 +2333,9 @@ void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alig
     const auto tStart = std::chrono::steady_clock::now();
     std::vector<std::shared_ptr<Chunk>> all; // (the walk over slices: every batch, kept until the text is written)
     bool slicedDone = false;
+    int slicedRounds = 0;
+    unsigned slicedThreads = 0;
+    double slicedFetched = 0, slicedWalk = 0;
     if (wantHeadCols) {
         for (int64_t done = 0; done < length;) {
             const auto tw = std::chrono::steady_clock::now();
@@ -2322,7 +2346,8 @@ void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alig
             done += c->n;
             all.push_back(std::move(c));
         }
-        slicedDone = walkSliced(mafStream, &all, _rank[(size_t)genome][(size_t)seq], startPosition, numBlocks);
+        slicedFetched = std::chrono::duration<double>(std::chrono::steady_clock::now() - tStart).count();
+        slicedDone = walkSliced(mafStream, &all, _rank[(size_t)genome][(size_t)seq], startPosition, numBlocks, &slicedRounds, &slicedThreads, &slicedWalk);
         if (getenv("HGX_MAF_TIMING"))
             std::cerr << "[hgx maf] columns " << length << " heads " << numHeads << " blocks " << numBlocks << ": the walk over " << all.size()
                       << " slices " << (slicedDone ? "" : "did not settle; one thread's walk instead ") << "after "
@@ -2358,6 +2383,18 @@ void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alig
     }
     waitPendingWrite();
     mafStream.flush();
+    {
+        char buf[640];
+        snprintf(buf, sizeof buf,
+                 "{\"columns\": %lld, \"heads\": %zu, \"blocks\": %zu, \"batches\": %zu, \"walk\": \"%s\", \"slices\": %zu, \"rounds\": %d, "
+                 "\"walk_threads\": %u, \"seconds_until_the_batches_were_there\": %.4f, \"seconds_of_the_rounds\": %.4f, \"seconds\": %.4f, "
+                 "\"seconds_waiting_for_the_device\": %.4f, \"device_stage_seconds\": %.4f}",
+                 (long long)length, numHeads, numBlocks, wantHeadCols ? all.size() : (size_t)numChunksExpected,
+                 slicedDone ? "slices of the export side by side" : "one thread", slicedDone ? all.size() : (size_t)0, slicedRounds, slicedThreads,
+                 slicedFetched, slicedWalk, std::chrono::duration<double>(std::chrono::steady_clock::now() - tStart).count(), waitSeconds, fetchSeconds);
+        std::lock_guard<std::mutex> lock(lastExport().mu);
+        lastExport().json = buf;
+    }
 #ifdef HGX_HOST_PROFILE
     if (getenv("HGX_MAF_TIMING")) {
         static const char *what[] = {"", "initBlock", "canAppend", "pair + place"};

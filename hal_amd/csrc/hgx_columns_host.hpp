@@ -197,11 +197,15 @@ class MafExport {
                              const ColumnOptions &opt);
     // the same walk over slices of the export side by side (hgx_columns_host.cpp); chunks: RunMachine::Chunk, every batch of the export;
     // false: the slices' walks did not settle on one sequence of blocks — nothing was written, the caller walks with one thread
-    bool walkSliced(std::ostream &mafStream, void *chunks, int refRank, int64_t startPosition, size_t &numBlocks);
+    bool walkSliced(std::ostream &mafStream, void *chunks, int refRank, int64_t startPosition, size_t &numBlocks, int *rounds = nullptr,
+                    unsigned *threads = nullptr, double *seconds = nullptr);
     // --maxRefGap > 0: the column iterator with its stack of inserted / deleted ranges (halColumnIterator.cpp:65-144, 357-405),
     // replayed over the columns and indel events the device returns (hgx_gap_kernels.hpp)
     void convertSequenceGapped(std::ostream &mafStream, hgx_alignment *alignment, int genome, int seq, int64_t first, int64_t last,
                                const ColumnOptions &opt);
 };
+
+// the last run-compressed hal2maf export of this process, as a JSON object ("null" before the first): who walked it, how long the parts took
+std::string mafLastExportInfo();
 
 } // namespace hgx

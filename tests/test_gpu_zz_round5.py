@@ -149,6 +149,32 @@ def test_maf_tracks_at_full_size(hal, oracle_bin, tmp_path, monkeypatch):
                           str(a + 1_000_000), "--length", "200000")
 
 
+def test_maf_walk_over_slices_at_full_size(hal, oracle_bin, tmp_path, monkeypatch):
+    """the block state machine over slices of the export side by side (HGX_MAF_SLICED=1: whatever the host's size) on config 3's
+    alignment: 4 M columns in batches of 250 k (16 slices) give the one-thread walk's text, with and without --unique, and a
+    300 k-column stretch of it is the oracle's"""
+    al = hal.Alignment.random(workload_options(1.0, "cfg2", dna="fast"), device=0)
+    src = al.genome_id("Genome_9")
+    seq = al.sequences(src)[0][0]
+    a, ln = 23_000_000, 4_000_000
+    monkeypatch.setenv("HGX_MAF_CHUNK", "250000")
+    for kw in (dict(), dict(unique=True)):
+        monkeypatch.setenv("HGX_MAF_SLICED", "1")
+        sliced = al.maf_export(src, 0, start=a, length=ln, no_ancestors=True, **kw)
+        info = al.maf_tracks_info()["last_export"]
+        assert info["walk"].startswith("slices") and info["slices"] == 16 and info["rounds"] >= 1, info
+        monkeypatch.setenv("HGX_MAF_SLICED", "0")
+        assert sliced == al.maf_export(src, 0, start=a, length=ln, no_ancestors=True, **kw), kw
+        assert al.maf_tracks_info()["last_export"]["walk"] == "one thread"
+    img = str(tmp_path / "cfg2.hgx")
+    al.save(img)
+    monkeypatch.setenv("HGX_MAF_SLICED", "1")
+    monkeypatch.setenv("HGX_MAF_CHUNK", "20000")
+    got = al.maf_export(src, 0, start=a, length=300000, no_ancestors=True)
+    assert got == _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", "Genome_9", "--noAncestors", "--refSequence", seq, "--start", str(a),
+                          "--length", "300000")
+
+
 # ---- the tree sweeps with sums over more than eight children ----
 
 def test_count_dupes_sweep_over_a_polytomy_with_segment_tails(hal, oracle_bin, tmp_path, monkeypatch):
