@@ -1074,7 +1074,7 @@ def main():
             # Liftover::convert as halLiftover runs it: BED text in, BED text out (parse, H2D, kernels, D2H, format), PCIe inclusive
             sn, ln, tn = starts.numpy(), lens.numpy(), strand.numpy()
             bed = "".join("%s\t%d\t%d\tq\t0\t%s\n" % (seq_name, int(a), int(a + b), chr(int(c))) for a, b, c in zip(sn, ln, tn)).encode()
-            hal_amd.liftover_convert_bytes(al, src, bed[:bed.index(b"\n", 4000000) + 1], tgt)  # (code objects, plan, pinned buffers)
+            hal_amd.liftover_convert_bytes(al, src, bed[:bed.index(b"\n", min(4000000, len(bed) // 2)) + 1], tgt)  # (code objects, plan, pinned buffers)
             out_bytes, out_lines = hal_amd.liftover_convert_bytes(al, src, bed, tgt)
             best_t = None
             for _ in range(3):
