@@ -149,6 +149,72 @@ def maf_prefix_matches(oracle_text, gpu_prefix):
     return cut > 0 and len(gpu_prefix) >= cut and oracle_text[:cut] == gpu_prefix[:cut]
 
 
+def leg_hal2maf_full(args, local=0):
+    """BASELINE config 3 as stated — hal2maf --refGenome <leaf> --noAncestors over the WHOLE reference genome, end to end to MAF text in host
+    memory — with its device-stage report, its CPU figure and its parity gate.  Run by a process of its own (main: --leg hal2maf_full): the
+    export takes its heads from round 5's per-base tracks and walks its blocks over slices of the export, code whose first run on a GPU
+    is the driver's; whatever happens to it must not cost the line."""
+    import hal_amd
+    al = hal_amd.Alignment.random(workload_options(args.scale, "cfg2", dna="fast"), device=local)
+    src_name = "Genome_9"
+    src = al.genome_id(src_name)
+    seq_name = al.sequences(src)[0][0]
+    ncols = al.genome_length(src)
+    al.maf_export_bytes(src, start=0, length=min(ncols, 200000), no_ancestors=True)  # (DNA upload, code objects)
+    runs = []
+    for _ in range(2):  # (the second export finds the text's memory and the rendering buffers of the first: both are listed)
+        nbytes, maf_head, m_s = al.maf_export_bytes(src, no_ancestors=True, prefix=56 * args.cpu_columns + 65536)
+        runs.append(m_s)
+    dt_m = min(runs)
+    try:
+        tracks = al.maf_tracks_info()
+    except Exception as e:
+        tracks = {"error": str(e)[:200]}
+    leg = {"metric": "MAF columns/sec (hal2maf --refGenome %s --noAncestors over the whole genome, end to end to MAF text in host memory; the better "
+                     "of two exports)" % src_name,
+           "value": ncols / dt_m, "unit": "columns/s", "columns": ncols, "seconds": dt_m, "runs_seconds": runs, "maf_bytes": nbytes,
+           "process": "a child of bench.py (its own alignment, its own HIP context)",
+           "device_stage": dict(tracks, what="hgx_maf_tracks_info after the two exports: the per-base tracks the heads are taken from (hgx_maf_kernels.hpp) "
+                                             "— built once (build_ms), every chunk's kernels timed with HIP events (device_ms_served over "
+                                             "columns_served); state says whether the first chunk's heads were the column walk's (else the walk is "
+                                             "used: round 4's stage); last_export: the host side — who walked the blocks, rounds, seconds")}
+    ncc = min(args.cpu_columns, ncols)
+    if args.cpu_sample > 0 and ncc > 0:
+        try:
+            with tempfile.TemporaryDirectory() as tmp:
+                img = os.path.join(tmp, "bench.hgx")
+                al.save(img)
+                basem, textm = cpu_columns_baseline(img, "maf", src_name, seq_name, ncc, tmp, "cfg2m",
+                                                    all_cores_total=4 * ncc if args.cpu_all_cores else 0, extra=("--noAncestors",))
+            basem["parity_with_gpu"] = maf_prefix_matches(textm, maf_head)
+            basem["parity"] = ("the oracle's MAF of the first %d columns, up to its last block (a slice ends its last block where it ends), is the "
+                               "beginning of the timed export's text" % ncc)
+            basem["maf_bytes"] = len(textm)
+            leg["cpu_baseline"] = basem
+        except Exception as e:
+            leg["cpu_baseline"] = {"error": str(e)[:300]}
+    return leg
+
+
+def run_leg_in_child(name, args, env_extra=None, timeout=420.0):
+    """`python bench.py --leg <name>` in a process of its own; its JSON object, or {"error": ...}"""
+    prelude = os.environ.get("HGX_BENCH_PRELUDE", "")  # (the dry run without a GPU installs its fakes in the child too)
+    code = "import sys; sys.path.insert(0, %r)\n%s\nimport bench\nbench.main()" % (ROOT, prelude)
+    cmd = [sys.executable, "-c", code, "--leg", name, "--scale", str(args.scale), "--cpu-sample", str(args.cpu_sample), "--cpu-columns",
+           str(args.cpu_columns), "--cpu-all-cores", str(args.cpu_all_cores)]
+    try:
+        r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, **(env_extra or {})), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        return {"error": "the child did not finish within %.0f s" % timeout}
+    lines = [l for l in r.stdout.decode(errors="replace").strip().splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": "the child ended with code %d: %s" % (r.returncode, r.stderr.decode(errors="replace")[-400:])}
+    try:
+        return json.loads(lines[-1])
+    except Exception as e:
+        return {"error": "the child's line does not parse: %s" % e}
+
+
 def lib_sha16():
     import hashlib
     with open(os.path.join(ROOT, "hal_amd", "libhgx.so"), "rb") as f:
@@ -356,11 +422,15 @@ def main():
     ap.add_argument("--exchange-in-step", type=int, default=0,
                     help="N > 1: 1 = every timed step ends with the all-gather of all ranks' records (link-bound); 0 (default) = the ranks map "
                          "their shards as one GPU does and the collated form is measured beside")
+    ap.add_argument("--leg", default="", help="run ONE leg and print its JSON object (bench.py starts itself with this: hal2maf_full)")
     ap.add_argument("--exchange-selftest", type=int, default=0,
                     help="1: with one GPU, run the multi-GPU code path (wire blob, overlapped all-gatherv, collective settle exit) on a "
                          "one-rank RCCL group; the JSON line then says so in config.exchange")
     args = ap.parse_args()
 
+    if args.leg == "hal2maf_full":
+        print(json.dumps(leg_hal2maf_full(args)), flush=True)
+        return
     import torch
     import torch.distributed as dist
     import hal_amd
@@ -979,27 +1049,6 @@ def main():
             out.setdefault("columns", {})["hal2maf"] = {"metric": "MAF columns/sec (hal2maf --refGenome %s --noAncestors, end to end to MAF text in host memory)" % src_name,
                                                         "value": ncols / dt_m, "unit": "columns/s", "columns": ncols, "seconds": dt_m,
                                                         "maf_bytes": nbytes}
-        if want_maf and args.maf_full:
-            # BASELINE config 3 as stated: the full reference genome
-            ncols = al.genome_length(src)
-            runs = []
-            for _ in range(2):  # (the second export finds the text's memory and the rendering buffers of the first: both are listed)
-                nbytes, maf_head, m_s = al.maf_export_bytes(src, no_ancestors=True, prefix=56 * args.cpu_columns + 65536)
-                runs.append(m_s)
-            kept["maf_head"] = maf_head  # (the text's beginning, for the parity gate: cpu_baseline below)
-            dt_m = min(runs)
-            try:
-                tracks = al.maf_tracks_info()
-            except Exception as e:
-                tracks = {"error": str(e)[:200]}
-            out.setdefault("columns", {})["hal2maf_full"] = {"metric": "MAF columns/sec (hal2maf --refGenome %s --noAncestors over the whole genome, end to end to MAF text "
-                                                        "in host memory; the better of two exports)" % src_name,
-                                              "value": ncols / dt_m, "unit": "columns/s", "columns": ncols, "seconds": dt_m, "runs_seconds": runs,
-                                              "maf_bytes": nbytes,
-                                              "device_stage": dict(tracks, what="hgx_maf_tracks_info after the two exports (and the legs before them): the per-base "
-                                                                   "tracks the heads are taken from (hgx_maf_kernels.hpp) — built once (build_ms), every chunk's "
-                                                                   "kernels timed with HIP events (device_ms_served over columns_served); state says whether the "
-                                                                   "first chunk's heads were the column walk's (else the walk is used: round 4's stage)")}
         if args.wide and world == 1 and not args.exchange_selftest:
             # the reference's own coordinate width (hal_index_t = int64, api/inc/halDefs.h:34; what an alignment with a genome of
             # 2^31 bases or more — every mammalian one — runs on): the same alignment, batch and steps on int64 tables
@@ -1204,18 +1253,15 @@ def main():
                     out["columns"]["cpu_baseline"] = based
                 except Exception as e:  # (a leg beside the line, not the line)
                     out["columns"]["cpu_baseline"] = {"error": str(e)[:300]}
-                if want_maf:
-                    try:
-                        basem, textm = cpu_columns_baseline(img, "maf", src_name, seq_name, ncc, cpu_tmp.name, "cfg2m",
-                                                            all_cores_total=4 * ncc if args.cpu_all_cores else 0, extra=("--noAncestors",))
-                        basem["parity_with_gpu"] = "maf_head" in kept and maf_prefix_matches(textm, kept["maf_head"])
-                        basem["parity"] = ("the oracle's MAF of the first %d columns, up to its last block (a slice ends its last block where it ends), is "
-                                           "the beginning of the timed export's text" % ncc)
-                        basem["maf_bytes"] = len(textm)
-                        for leg in ("hal2maf_full", "hal2maf"):
-                            if leg in out["columns"]:
-                                out["columns"][leg]["cpu_baseline"] = basem
-                                break
+                if want_maf and "hal2maf" in out["columns"] and "maf_head" in kept:
+                    try:  # (the CPU figure beside the 8 M-column leg when the whole-genome leg is off; else that leg's child brings its own)
+                        if not args.maf_full:
+                            basem, textm = cpu_columns_baseline(img, "maf", src_name, seq_name, ncc, cpu_tmp.name, "cfg2m",
+                                                                all_cores_total=4 * ncc if args.cpu_all_cores else 0, extra=("--noAncestors",))
+                            basem["parity_with_gpu"] = maf_prefix_matches(textm, kept["maf_head"])
+                            basem["parity"] = ("the oracle's MAF of the first %d columns, up to its last block, is the beginning of the timed export's "
+                                               "text" % ncc)
+                            out["columns"]["hal2maf"]["cpu_baseline"] = basem
                     except Exception as e:
                         out["columns"]["hal2maf_cpu_baseline"] = {"error": str(e)[:300]}
             # ---- halGetBlocksInTargetRange on the CPU: the oracle's getBlocksInTargetRange, a call per range, the same ranges ----
@@ -1253,6 +1299,17 @@ def main():
                                    "parity_with_gpu": gpu_text == text}
             if multi:
                 out["cpu_baseline"]["all_cores"] = multi
+        if want_maf and args.maf_full:
+            # BASELINE config 3 as stated: hal2maf over the full reference genome — in a process of its own (leg_hal2maf_full), the last
+            # thing this rank does: the line above is complete whatever becomes of it.  Should it fail with round 5's device stage and
+            # walk, it is run once more with round 4's (HGX_MAF_SWEEP=0, HGX_MAF_SLICED=0) and both outcomes are in the line.
+            leg = run_leg_in_child("hal2maf_full", args)
+            if "error" in leg:
+                again = run_leg_in_child("hal2maf_full", args, env_extra={"HGX_MAF_SWEEP": "0", "HGX_MAF_SLICED": "0"})
+                again["first_attempt"] = leg["error"]
+                again["path"] = "the column walk and one thread's block state machine (HGX_MAF_SWEEP=0 HGX_MAF_SLICED=0) after the default path failed"
+                leg = again
+            out.setdefault("columns", {})["hal2maf_full"] = leg
     else:
         out = None
     # ---- the collated legs, last and under a watchdog: a collective that hangs or fails here costs these legs, not the line ----

@@ -800,11 +800,12 @@ static bool mafSweepAllowed(const Image &img, const SweepScope &sc, int64_t expo
         return false;
     if (env && env[0] == '1')
         return true;
-    // the sweeps touch every base of every genome in scope once; the walk they replace touches a column's tree per column
+    // the sweeps touch every base of every genome in scope once; the walk they replace touches a column's tree per column: exports of
+    // a million columns or more (as halAlignmentDepth's sweeps) that cover a thirty-second of the scope's bases or more
     int64_t bases = 0;
     for (int g : sc.postOrder)
         bases += img.genomes[(size_t)g].totalLength;
-    return bases <= ((int64_t)4 << 20) || bases <= 32 * exportColumns;
+    return exportColumns >= ((int64_t)1 << 20) && bases <= 32 * exportColumns;
 }
 
 template <typename C>

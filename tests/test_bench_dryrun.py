@@ -18,7 +18,8 @@ def test_bench_prints_its_line_with_every_leg(tmp_path):
             "sys.argv = ['bench.py', '--steps', '6', '--warmup', '2', '--scale', '0.002', '--queries', '3000', '--maf-columns', '20000',\n"
             "            '--cpu-sample', '500', '--cpu-columns', '20000', '--cpu-columns-cfg5', '5000', '--sustained-seconds', '0.05']\n"
             "bench.main()\n") % (ROOT, os.path.join(ROOT, "tests", "support"))
-    env = dict(os.environ, HGX_LIB_PATH=lib, HGX_COL_GRID="4", HGX_MAF_SWEEP="1")
+    prelude = "sys.path.insert(0, %r); import bench_fakes; bench_fakes.install()" % os.path.join(ROOT, "tests", "support")
+    env = dict(os.environ, HGX_LIB_PATH=lib, HGX_COL_GRID="4", HGX_MAF_SWEEP="1", HGX_BENCH_PRELUDE=prelude)  # (the child of the hal2maf_full leg too)
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 0, r.stderr.decode()[-4000:]
     line = r.stdout.decode().strip().splitlines()[-1]
@@ -34,6 +35,7 @@ def test_bench_prints_its_line_with_every_leg(tmp_path):
     assert cols["hal2maf_full"]["cpu_baseline"]["parity_with_gpu"] is True, cols["hal2maf_full"]["cpu_baseline"]
     assert cols["hal2maf_full"]["device_stage"]["state"].startswith("checked"), cols["hal2maf_full"]["device_stage"]
     assert cols["hal2maf_full"]["device_stage"]["last_export"]["walk"] in ("one thread", "slices of the export side by side")
+    assert cols["hal2maf_full"]["process"].startswith("a child")
     assert out["cfg5"]["cpu_baseline"]["parity_with_gpu"] is True, out["cfg5"]
     assert "all_cores" in cols["cpu_baseline"] and "all_cores" in out["cpu_baseline"]
     assert "blocks_in_target_range" in out["features"] and "cpu_baseline" in out["features"]["blocks_in_target_range"]
