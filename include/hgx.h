@@ -410,7 +410,9 @@ int hgx_maf_export_multi(hgx_alignment *const *handles, int n_handles, int ref_g
 /* hal2maf's plain export takes the columns where rows begin and end from per-base tracks made by sweeps over whole genomes
  * (hal_amd/csrc/hgx_maf_kernels.hpp) and keeps them with the handle for the export's chunks and for later exports of the same
  * reference, scope and filters.  *json (release with hgx_free): {"tracks": bool, "build_ms", "bytes", "state": "unchecked" |
- * "checked against the column walk" | "refused: ...", "chunks_served"}; drop != 0 releases the tracks' device memory afterwards. */
+ * "checked against the column walk" | "refused: ...", "chunks_served", ..., "last_export": the host side of this process's last
+ * run-compressed export (who walked its blocks — one thread, or slices of the export side by side —, rounds, seconds) or null};
+ * drop != 0 releases the tracks' device memory afterwards. */
 int hgx_maf_tracks_info(hgx_alignment *h, int drop, char **json, char **err);
 
 /* ---- synthetic workloads: halRandGen (randgen/halRandGen.cpp) ---- */
