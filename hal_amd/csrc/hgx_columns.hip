@@ -778,6 +778,8 @@ namespace {
 struct MafTracks {
     enum : int { UNCHECKED = 0, CHECKED = 1, REFUSED = 2 };
     std::atomic<int> state{UNCHECKED}; // the first chunk taken from the tracks is held against the column walk (columnsHeadRowsHost)
+    std::atomic<int> stateUnique{UNCHECKED}; // ... the first chunk of an export with --unique (the stretches of hgx_maf_kernels.hpp)
+    std::atomic<uint64_t> chunksUnique{0};
     std::atomic<uint64_t> chunks{0};   // chunks served
     std::atomic<uint64_t> deviceUs{0}, servedColumns{0}, servedHeads{0}, servedMarked{0}; // ... their kernels' time (HIP events), columns, heads
     int ref = -1;
@@ -961,12 +963,14 @@ std::string mafTracksInfo(hgx_alignment *h) {
     if (!h->mafTracks)
         return "{\"tracks\": false}";
     const MafTracks &T = *std::static_pointer_cast<MafTracks>(h->mafTracks);
-    char buf[512];
+    char buf[768];
     static const char *const states[] = {"unchecked", "checked against the column walk", "refused: the column walk is used"};
     snprintf(buf, sizeof buf,
              "{\"tracks\": true, \"reference\": %d, \"no_ancestors\": %s, \"targets\": %zu, \"build_ms\": %.4f, \"bytes\": %zu, \"state\": \"%s\", "
-             "\"chunks_served\": %llu, \"columns_served\": %llu, \"marked_columns\": %llu, \"heads\": %llu, \"device_ms_served\": %.3f}",
+             "\"chunks_served\": %llu, \"state_unique\": \"%s\", \"chunks_served_unique\": %llu, \"columns_served\": %llu, \"marked_columns\": %llu, "
+             "\"heads\": %llu, \"device_ms_served\": %.3f}",
              T.ref, T.noAncestors ? "true" : "false", T.targets.size(), T.buildMs, T.bytes, states[T.state.load()], (unsigned long long)T.chunks.load(),
+             states[T.stateUnique.load()], (unsigned long long)T.chunksUnique.load(),
              (unsigned long long)T.servedColumns.load(), (unsigned long long)T.servedMarked.load(), (unsigned long long)T.servedHeads.load(),
              (double)T.deviceUs.load() / 1e3);
     return buf;
@@ -981,11 +985,17 @@ namespace {
 struct MafSizesDoNotAddUp : std::runtime_error {
     MafSizesDoNotAddUp() : std::runtime_error("hal2maf: a column's rows do not add up to its subtrees' sizes") {}
 };
+struct MafUniqueNeedsTheWalk : std::runtime_error { // (this chunk only: a column with more reference copies than a lane holds)
+    MafUniqueNeedsTheWalk() : std::runtime_error("hal2maf --unique: a column's reference bases cannot be told from its rows") {}
+};
 } // namespace
 
 // columnsHeadRowsHost from the tracks: the marked columns of the chunk, their rows by rank, the heads among them
+// uniqueFirst >= 0 (--unique): the classes of the columns (passed over / walked for their keys / written) by stretches of the marked
+// columns' runs, in the format of the walk (marks 2 and 3)
 static void columnsHeadRowsSweep(hgx_alignment *h, MafTracks &T, int ref, int64_t first, int64_t count, const ColumnOptions &opt,
-                                 std::vector<uint8_t> &head, std::vector<uint32_t> &headOffset, HeadRows &headRows, ColumnStats *stats) {
+                                 std::vector<uint8_t> &head, std::vector<uint32_t> &headOffset, HeadRows &headRows, ColumnStats *stats,
+                                 int64_t uniqueFirst) {
     const uint32_t n = (uint32_t)count;
     const int GRID = 1024;
     Buf dMark((size_t)n * 4), dRowsOf((size_t)n * 4), dMarkIdx(((size_t)n + 1) * 4), dRowOff(((size_t)n + 1) * 4), dSums(((size_t)n / SCAN_BLOCK + 2) * 4),
@@ -1012,21 +1022,59 @@ static void columnsHeadRowsSweep(hgx_alignment *h, MafTracks &T, int ref, int64_
         hipLaunchKernelGGL((k_maf_rows<int64_t>), dim3(std::max(rowGrid, 1)), dim3(256), 0, nullptr, M, (ColumnRow *)dRows.p);
     else
         hipLaunchKernelGGL((k_maf_rows<int32_t>), dim3(std::max(rowGrid, 1)), dim3(256), 0, nullptr, M, (ColumnRow *)dRows.p);
-    Buf dIsHead((size_t)nCand * 4), dHeadCnt((size_t)nCand * 4), dHeadIdx(((size_t)nCand + 1) * 4), dHeadRowOff(((size_t)nCand + 1) * 4);
-    hipLaunchKernelGGL(k_maf_heads, dim3(GRID), dim3(256), 0, nullptr, (const uint32_t *)dCandCol.p, (const uint32_t *)dCandRow.p, (const ColumnRow *)dRows.p,
-                       nCand, (uint32_t *)dIsHead.p, (uint32_t *)dHeadCnt.p);
-    const uint32_t nHeads = deviceScan((const uint32_t *)dIsHead.p, nCand, (uint32_t *)dHeadIdx.p, (uint32_t *)dSums.p);
-    const uint32_t totalHeadRows = deviceScan((const uint32_t *)dHeadCnt.p, nCand, (uint32_t *)dHeadRowOff.p, (uint32_t *)dSums.p);
-    Buf dHead(n), dHeadOffset(((size_t)nHeads + 1) * 4), dOut(std::max<size_t>(totalHeadRows, 1) * sizeof(ColumnRow));
+    uint32_t nHeads = 0, totalHeadRows = 0;
+    Buf dHead(n), dHeadOffset, dOut;
     HIP_OK(hipMemsetAsync(dHead.p, 0, n, nullptr));
-    hipLaunchKernelGGL(k_maf_gather, dim3(std::max(rowGrid, 1)), dim3(256), 0, nullptr, (const uint32_t *)dCandCol.p, (const uint32_t *)dCandRow.p,
-                       (const ColumnRow *)dRows.p, nCand, (const uint32_t *)dIsHead.p, (const uint32_t *)dHeadIdx.p, (const uint32_t *)dHeadRowOff.p,
-                       (uint8_t *)dHead.p, (uint32_t *)dHeadOffset.p, (ColumnRow *)dOut.p);
+    if (uniqueFirst >= 0) {
+        if (uniqueFirst > first)
+            throw std::runtime_error("columnsHeadRowsHost: the range of --unique begins behind its columns");
+        UniqueParams U;
+        U.candCol = (const uint32_t *)dCandCol.p;
+        U.candRow = (const uint32_t *)dCandRow.p;
+        U.rows = (const ColumnRow *)dRows.p;
+        U.nCand = nCand;
+        U.n = n;
+        U.first = first;
+        U.f = uniqueFirst;
+        U.ref = ref;
+        U.error = (unsigned int *)err.p;
+        const int candGrid = (int)std::max<int64_t>(1, std::min<int64_t>(GRID, ((int64_t)nCand + 255) / 256));
+        Buf dSegCnt((size_t)nCand * 4), dSegOff(((size_t)nCand + 1) * 4);
+        hipLaunchKernelGGL(k_unique_count, dim3(candGrid), dim3(256), 0, nullptr, U, (uint32_t *)dSegCnt.p);
+        const uint32_t nSeg = deviceScan((const uint32_t *)dSegCnt.p, nCand, (uint32_t *)dSegOff.p, (uint32_t *)dSums.p);
+        Buf dSeg(std::max<size_t>(nSeg, 1) * sizeof(UniqueSeg)), dUnits(std::max<size_t>(nSeg, 1) * 4), dUnitRows(std::max<size_t>(nSeg, 1) * 4),
+            dUnitOff(((size_t)nSeg + 1) * 4), dUnitRowOff(((size_t)nSeg + 1) * 4), dSums2(((size_t)nSeg / SCAN_BLOCK + 2) * 4);
+        hipLaunchKernelGGL(k_unique_stretches, dim3(candGrid), dim3(256), 0, nullptr, U, (const uint32_t *)dSegOff.p, (UniqueSeg *)dSeg.p);
+        const int segGrid = (int)std::max<int64_t>(1, std::min<int64_t>(GRID, ((int64_t)nSeg + 255) / 256));
+        hipLaunchKernelGGL(k_unique_units, dim3(segGrid), dim3(256), 0, nullptr, U, (const UniqueSeg *)dSeg.p, nSeg, (uint32_t *)dUnits.p,
+                           (uint32_t *)dUnitRows.p);
+        checkRowTotal((const uint32_t *)dUnitRows.p, nSeg);
+        nHeads = deviceScan((const uint32_t *)dUnits.p, nSeg, (uint32_t *)dUnitOff.p, (uint32_t *)dSums2.p);
+        totalHeadRows = deviceScan((const uint32_t *)dUnitRows.p, nSeg, (uint32_t *)dUnitRowOff.p, (uint32_t *)dSums2.p);
+        dHeadOffset.resize(((size_t)nHeads + 1) * 4);
+        dOut.resize(std::max<size_t>(totalHeadRows, 1) * sizeof(ColumnRow));
+        hipLaunchKernelGGL(k_unique_gather, dim3(segGrid), dim3(256), 0, nullptr, U, M.P.desc, (const UniqueSeg *)dSeg.p, nSeg, (const uint32_t *)dUnits.p,
+                           (const uint32_t *)dUnitOff.p, (const uint32_t *)dUnitRowOff.p, (uint8_t *)dHead.p, (uint32_t *)dHeadOffset.p,
+                           (ColumnRow *)dOut.p);
+    } else {
+        Buf dIsHead((size_t)nCand * 4), dHeadCnt((size_t)nCand * 4), dHeadIdx(((size_t)nCand + 1) * 4), dHeadRowOff(((size_t)nCand + 1) * 4);
+        hipLaunchKernelGGL(k_maf_heads, dim3(GRID), dim3(256), 0, nullptr, (const uint32_t *)dCandCol.p, (const uint32_t *)dCandRow.p,
+                           (const ColumnRow *)dRows.p, nCand, (uint32_t *)dIsHead.p, (uint32_t *)dHeadCnt.p);
+        nHeads = deviceScan((const uint32_t *)dIsHead.p, nCand, (uint32_t *)dHeadIdx.p, (uint32_t *)dSums.p);
+        totalHeadRows = deviceScan((const uint32_t *)dHeadCnt.p, nCand, (uint32_t *)dHeadRowOff.p, (uint32_t *)dSums.p);
+        dHeadOffset.resize(((size_t)nHeads + 1) * 4);
+        dOut.resize(std::max<size_t>(totalHeadRows, 1) * sizeof(ColumnRow));
+        hipLaunchKernelGGL(k_maf_gather, dim3(std::max(rowGrid, 1)), dim3(256), 0, nullptr, (const uint32_t *)dCandCol.p, (const uint32_t *)dCandRow.p,
+                           (const ColumnRow *)dRows.p, nCand, (const uint32_t *)dIsHead.p, (const uint32_t *)dHeadIdx.p, (const uint32_t *)dHeadRowOff.p,
+                           (uint8_t *)dHead.p, (uint32_t *)dHeadOffset.p, (ColumnRow *)dOut.p);
+    }
     HIP_OK(hipEventRecord(e1.e, nullptr));
     unsigned int e = 0;
     HIP_OK(hipMemcpy(&e, err.p, 4, hipMemcpyDeviceToHost));
     if (e == 2)
         throw MafSizesDoNotAddUp();
+    if (e == 3)
+        throw MafUniqueNeedsTheWalk();
     if (e)
         throw std::runtime_error("column walk exceeded the frame stack (more than 64 pending branches for one base)");
     head.resize(n);
@@ -1054,8 +1102,8 @@ static void columnsHeadRowsSweep(hgx_alignment *h, MafTracks &T, int ref, int64_
 }
 
 // columnsHeadRowsHost by the column walk: every column's rows on the device (two walks of every column: count, emit), the heads
-// found by comparing neighbours, their rows gathered — the path of --unique, --noDupes and --onlyOrthologs, of exports too short for
-// the sweeps to pay, and what the sweeps' first chunk is held against
+// found by comparing neighbours, their rows gathered — the path of --noDupes and --onlyOrthologs, of exports too short for the sweeps
+// to pay, and what the sweeps' first chunk is held against
 static void columnsHeadRowsWalk(hgx_alignment *h, int ref, int64_t first, int64_t count, const ColumnOptions &opt, std::vector<uint8_t> &head,
                                 std::vector<uint32_t> &headOffset, HeadRows &headRows, ColumnStats *stats, int64_t uniqueFirst);
 
@@ -1074,51 +1122,56 @@ void columnsHeadRowsHost(hgx_alignment *h, int ref, int64_t first, int64_t count
         return;
     if (count >= ((int64_t)1 << 31))
         throw std::runtime_error("column chunk too large");
-    if (uniqueFirst < 0) {
-        // the plain export: the heads from the per-base tracks (hgx_maf_kernels.hpp) where the sweeps behind them pay
-        if (std::shared_ptr<MafTracks> T = mafTracksFor(h, ref, opt, std::max(exportColumns, count))) {
-            const char *env = getenv("HGX_MAF_SWEEP");
-            const bool forced = env && env[0] == '1';
-            if (T->state.load() != MafTracks::REFUSED) {
-                bool good = true;
-                try {
-                    columnsHeadRowsSweep(h, *T, ref, first, count, opt, head, headOffset, headRows, stats);
-                } catch (const MafSizesDoNotAddUp &) {
-                    if (forced)
-                        throw; // (forced: the tests want to see it)
-                    good = false;
-                }
-                // The first chunk taken from a set of tracks is held against the column walk (a chunk of the export is walked once
-                // more: a fiftieth of config 3): tracks whose heads are not the walk's are not used again, and the walk's answer goes out.
-                if (good && T->state.load() == MafTracks::UNCHECKED) {
-                    std::vector<uint8_t> head2;
-                    std::vector<uint32_t> off2(1, 0);
-                    HeadRows rows2;
-                    columnsHeadRowsWalk(h, ref, first, count, opt, head2, off2, rows2, nullptr, -1);
-                    good = head2 == head && off2 == headOffset && rows2.size() == headRows.size() &&
-                           (rows2.empty() || memcmp(rows2.data(), headRows.data(), rows2.size() * sizeof(ColumnRowHost)) == 0);
-                    if (good) {
-                        T->state.store(MafTracks::CHECKED);
-                    } else {
-                        if (forced)
-                            throw std::runtime_error("hal2maf: the heads taken from the per-base tracks differ from the column walk's");
-                        head.swap(head2);
-                        headOffset.swap(off2);
-                        headRows.swap(rows2);
-                        T->state.store(MafTracks::REFUSED);
-                        fprintf(stderr, "[hgx] hal2maf: the heads taken from the per-base tracks differ from the column walk's; the walk is used\n");
-                        return;
-                    }
-                }
+    // the heads from the per-base tracks (hgx_maf_kernels.hpp) where the sweeps behind them pay
+    if (std::shared_ptr<MafTracks> T = mafTracksFor(h, ref, opt, std::max(exportColumns, count))) {
+        const char *env = getenv("HGX_MAF_SWEEP");
+        const bool forced = env && env[0] == '1';
+        const bool unique = uniqueFirst >= 0;
+        std::atomic<int> &state = unique ? T->stateUnique : T->state;
+        // (--unique tells a column's reference bases from its rows: the reference has to be reported)
+        if (state.load() != MafTracks::REFUSED && !(unique && T->constRows == 0)) {
+            bool good = true, refuse = true;
+            try {
+                columnsHeadRowsSweep(h, *T, ref, first, count, opt, head, headOffset, headRows, stats, uniqueFirst);
+            } catch (const MafSizesDoNotAddUp &) {
+                if (forced)
+                    throw; // (forced: the tests want to see it)
+                good = false;
+            } catch (const MafUniqueNeedsTheWalk &) {
+                good = false;
+                refuse = false; // (this chunk by the walk; the next one may do without)
+            }
+            // The first chunk taken from a set of tracks is held against the column walk (a chunk of the export is walked once
+            // more: a fiftieth of config 3): tracks whose heads are not the walk's are not used again, and the walk's answer goes out.
+            if (good && state.load() == MafTracks::UNCHECKED) {
+                std::vector<uint8_t> head2;
+                std::vector<uint32_t> off2(1, 0);
+                HeadRows rows2;
+                columnsHeadRowsWalk(h, ref, first, count, opt, head2, off2, rows2, nullptr, uniqueFirst);
+                good = head2 == head && off2 == headOffset && rows2.size() == headRows.size() &&
+                       (rows2.empty() || memcmp(rows2.data(), headRows.data(), rows2.size() * sizeof(ColumnRowHost)) == 0);
                 if (good) {
-                    T->chunks.fetch_add(1);
+                    state.store(MafTracks::CHECKED);
+                } else {
+                    if (forced)
+                        throw std::runtime_error("hal2maf: the heads taken from the per-base tracks differ from the column walk's");
+                    head.swap(head2);
+                    headOffset.swap(off2);
+                    headRows.swap(rows2);
+                    state.store(MafTracks::REFUSED);
+                    fprintf(stderr, "[hgx] hal2maf: the heads taken from the per-base tracks differ from the column walk's; the walk is used\n");
                     return;
                 }
-                T->state.store(MafTracks::REFUSED);
-                head.clear();
-                headOffset.assign(1, 0);
-                headRows.clear();
             }
+            if (good) {
+                (unique ? T->chunksUnique : T->chunks).fetch_add(1);
+                return;
+            }
+            if (refuse)
+                state.store(MafTracks::REFUSED);
+            head.clear();
+            headOffset.assign(1, 0);
+            headRows.clear();
         }
     }
     columnsHeadRowsWalk(h, ref, first, count, opt, head, headOffset, headRows, stats, uniqueFirst);

@@ -497,4 +497,178 @@ static __global__ void __launch_bounds__(256) k_maf_gather(const uint32_t *__res
     }
 }
 
+// ---- hal2maf --unique from the marked columns' rows ----
+// Which columns the iterator's visit cache lets it walk, and which of them hal2maf writes, is a function of the column's REFERENCE
+// bases (hgx_column_kernels.hpp: k_column_unique_count has the derivation): with f the range's first column and R(p) the reference
+// bases of column p's walk, p is passed over when a base of R(p) lies in [f, p), is walked without being written when none does but
+// one lies left of f, and is written otherwise.  Inside a run the rows only move — forward rows with the column, reverse rows
+// against it — so the class of column h + j of the run that begins at marked column h changes where a reverse copy of the reference
+// base crosses it or a copy crosses f: a run falls into stretches of one class, found from the marked column's rows alone.
+struct UniqueSeg {
+    uint32_t col;  // first column of the stretch (in the chunk)
+    uint32_t len;  // its columns
+    uint32_t cand; // the marked column whose run it lies in
+    uint32_t j;    // col - that marked column
+    uint32_t cls;  // COL_SKIPPED / COL_WRITTEN / COL_KEYS_ONLY
+};
+static constexpr int UNIQUE_MAX_REF_ROWS = 32;
+struct UniqueParams {
+    const uint32_t *candCol, *candRow;
+    const ColumnRow *rows;
+    uint32_t nCand, n; // marked columns, columns of the chunk
+    int64_t first, f;  // genome coordinate of the chunk's first column, of the range's first column
+    int32_t ref;
+    unsigned int *error; // 3: a column with more reference bases than UNIQUE_MAX_REF_ROWS, or none (the reference is not reported)
+};
+// emit(j, len, cls) for every stretch of marked column k's run; false: the column's reference rows cannot be held
+template <typename F> HGX_DEV __forceinline__ bool unique_stretches(const UniqueParams &U, uint32_t k, F emit) {
+    const uint32_t a = U.candRow[k], nr = U.candRow[k + 1] - a;
+    const int64_t h = (int64_t)U.candCol[k], L = (int64_t)(k + 1 < U.nCand ? U.candCol[k + 1] : U.n) - h;
+    const int64_t p0 = U.first + h;
+    int64_t pos[UNIQUE_MAX_REF_ROWS];
+    bool rev[UNIQUE_MAX_REF_ROWS];
+    int m = 0;
+    bool self = false;
+    for (uint32_t i = 0; i < nr; ++i) {
+        const ColumnRow r = U.rows[a + i];
+        if (r.genome != U.ref)
+            continue;
+        if (r.pos == p0 && !r.rev) {
+            self = true; // (the column's own base: never left of itself)
+            continue;
+        }
+        if (m == UNIQUE_MAX_REF_ROWS)
+            return false;
+        pos[m] = r.pos;
+        rev[m] = r.rev != 0;
+        ++m;
+    }
+    if (!self)
+        return false; // (the reference's bases are not among the rows: a filter keeps them out)
+    int64_t j = 0;
+    int64_t start = 0;
+    uint32_t cur = 0;
+    bool have = false;
+    while (j < L) {
+        // the class of column h + j, and the first column behind it where a copy crosses the column or the range's beginning
+        const int64_t p = p0 + j;
+        bool inRange = false, left = false;
+        int64_t next = L;
+        for (int i = 0; i < m; ++i) {
+            const int64_t x = rev[i] ? pos[i] - j : pos[i] + j;
+            if (x < p) {
+                if (x >= U.f)
+                    inRange = true;
+                else
+                    left = true;
+            }
+            int64_t b;
+            if (!rev[i]) {
+                b = U.f - pos[i]; // from here on the copy lies at or behind f
+                if (b > j && b < next)
+                    next = b;
+            } else {
+                b = (pos[i] - p0) / 2 + 1; // from here on the copy lies left of the column (pos - j < p0 + j)
+                if (pos[i] >= p0 && b > j && b < next)
+                    next = b;
+                b = pos[i] - U.f + 1; // from here on the copy lies left of f
+                if (b > j && b < next)
+                    next = b;
+            }
+        }
+        const uint32_t cls = inRange ? COL_SKIPPED : left ? COL_KEYS_ONLY : COL_WRITTEN;
+        if (have && cls != cur) {
+            emit(start, j - start, cur);
+            start = j;
+        }
+        cur = cls;
+        have = true;
+        j = next;
+    }
+    if (have)
+        emit(start, L - start, cur);
+    return true;
+}
+static __global__ void __launch_bounds__(256) k_unique_count(UniqueParams U, uint32_t *__restrict__ segCount) {
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < U.nCand; k += gridDim.x * blockDim.x) {
+        uint32_t n = 0;
+        if (!unique_stretches(U, k, [&](int64_t, int64_t, uint32_t) { ++n; }))
+            *U.error = 3;
+        segCount[k] = n;
+    }
+}
+static __global__ void __launch_bounds__(256) k_unique_stretches(UniqueParams U, const uint32_t *__restrict__ segOff, UniqueSeg *__restrict__ seg) {
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < U.nCand; k += gridDim.x * blockDim.x) {
+        uint32_t at = segOff[k];
+        unique_stretches(U, k, [&](int64_t j, int64_t len, uint32_t cls) {
+            seg[at++] = UniqueSeg{(uint32_t)(U.candCol[k] + j), (uint32_t)len, k, (uint32_t)j, cls};
+        });
+    }
+}
+// a stretch's share of the output: a written stretch that begins a run of written columns ships its first column's rows (a head); a
+// stretch walked without being written ships every column's rows (their sequences become keys of the column map, column by column,
+// as the walk delivers them); units = entries of headOffset
+static __global__ void __launch_bounds__(256) k_unique_units(UniqueParams U, const UniqueSeg *__restrict__ seg, uint32_t nSeg, uint32_t *__restrict__ units,
+                                                             uint32_t *__restrict__ unitRows) {
+    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < nSeg; s += gridDim.x * blockDim.x) {
+        const UniqueSeg g = seg[s];
+        const uint32_t a = U.candRow[g.cand], nr = U.candRow[g.cand + 1] - a;
+        uint32_t u = 0;
+        if (g.cls == COL_KEYS_ONLY) {
+            u = g.len;
+        } else if (g.cls == COL_WRITTEN) {
+            bool head = g.col == 0 || g.j > 0 || s == 0 || seg[s - 1].cls != COL_WRITTEN;
+            if (!head) { // the marked column before, advanced by the distance (k_maf_heads' test)
+                const uint32_t k = g.cand, pa = U.candRow[k - 1];
+                const int64_t d = (int64_t)U.candCol[k] - (int64_t)U.candCol[k - 1];
+                head = a - pa != nr;
+                for (uint32_t i = 0; i < nr && !head; ++i) {
+                    const ColumnRow r = U.rows[a + i], q = U.rows[pa + i];
+                    head = r.genome != q.genome || r.rev != q.rev || r.pos != (q.rev ? q.pos - d : q.pos + d);
+                }
+            }
+            u = head ? 1 : 0;
+        }
+        units[s] = u;
+        unitRows[s] = u * nr;
+    }
+}
+// marks, offsets and rows of the chunk from the stretches (head: cleared by the caller)
+static __global__ void __launch_bounds__(256) k_unique_gather(UniqueParams U, const GenomeDesc *__restrict__ desc, const UniqueSeg *__restrict__ seg, uint32_t nSeg,
+                                                              const uint32_t *__restrict__ units, const uint32_t *__restrict__ unitOff,
+                                                              const uint32_t *__restrict__ rowOff, uint8_t *__restrict__ head,
+                                                              uint32_t *__restrict__ headOffset, ColumnRow *__restrict__ out) {
+    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < nSeg; s += gridDim.x * blockDim.x) {
+        const UniqueSeg g = seg[s];
+        const uint32_t a = U.candRow[g.cand], nr = U.candRow[g.cand + 1] - a;
+        if (g.cls == COL_SKIPPED) {
+            for (uint32_t t = 0; t < g.len; ++t)
+                head[g.col + t] = 2;
+            continue;
+        }
+        if (g.cls == COL_KEYS_ONLY)
+            for (uint32_t t = 0; t < g.len; ++t)
+                head[g.col + t] = 3;
+        const uint32_t u = units[s];
+        if (g.cls == COL_WRITTEN && u)
+            head[g.col] = 1;
+        for (uint32_t t = 0; t < u; ++t) {
+            const uint32_t o = rowOff[s] + t * nr;
+            headOffset[unitOff[s] + t] = o;
+            const int64_t shift = (int64_t)g.j + t;
+            for (uint32_t i = 0; i < nr; ++i) {
+                const ColumnRow r = U.rows[a + i];
+                if (shift == 0) {
+                    out[o + i] = r;
+                } else { // the same base `shift` columns on along its strand, read anew
+                    RowVisitor v;
+                    v.dst = out + o + i;
+                    v.desc = desc;
+                    v(r.genome, r.rev ? r.pos - shift : r.pos + shift, r.rev != 0);
+                }
+            }
+        }
+    }
+}
+
 } // namespace hgx

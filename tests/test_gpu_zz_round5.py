@@ -129,6 +129,61 @@ def test_maf_tracks_on_int64_tables_and_real_data(hal, oracle_bin, tmp_path, mon
             _oracle(oracle_bin, "maf", rimg, tmp_path, "--refGenome", name, "--refSequence", seq, "--start", str(n // 5), "--length", str(ln)), name
 
 
+def _unique_both_ways(al, monkeypatch, *args, **kw):
+    monkeypatch.setenv("HGX_MAF_SWEEP", "1")
+    al.maf_tracks_info(drop=True)
+    a = al.maf_export(*args, unique=True, **kw)
+    info = al.maf_tracks_info()
+    assert info["tracks"] and info["state_unique"].startswith("checked") and info["chunks_served_unique"] >= 1, info
+    monkeypatch.setenv("HGX_MAF_SWEEP", "0")
+    b = al.maf_export(*args, unique=True, **kw)
+    monkeypatch.delenv("HGX_MAF_SWEEP")
+    assert a == b
+    return a
+
+
+@pytest.mark.parametrize("seed", [0, 3, 4])
+def test_maf_tracks_unique(hal, oracle_bin, tmp_path, seed, monkeypatch):
+    """--unique from the marked columns' rows (the stretches of a run that are passed over, walked for their keys, written): several
+    sequences a genome (a sequence's range begins inside the genome: paralogs left of it), every genome as reference, whole
+    sequences and ranges, device batches of 13 columns and whole, --noAncestors, target sets"""
+    img = str(tmp_path / "ms.hgx")
+    halfix.write_hgx(img, halfix.random_multiseq_alignment(seed, n_genomes=6))
+    al = hal.Alignment.open(img, device=0)
+    n_bytes = 0
+    for chunk in (None, "13"):
+        if chunk:
+            monkeypatch.setenv("HGX_MAF_CHUNK", chunk)
+        for g in range(al.num_genomes):
+            nm = al.genome_name(g)
+            if al.genome_length(g) == 0:
+                continue
+            want = _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", nm, "--unique")
+            assert _unique_both_ways(al, monkeypatch, g) == want, (nm, chunk)
+            n_bytes += len(want)
+            if not al.genome_children(g):
+                assert _unique_both_ways(al, monkeypatch, g, no_ancestors=True) == \
+                    _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", nm, "--unique", "--noAncestors"), (nm, chunk)
+            tg = [x for x in range(al.num_genomes) if x != g][1:4]
+            assert _unique_both_ways(al, monkeypatch, g, targets=tg) == \
+                _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", nm, "--unique", "--targetGenomes",
+                        ",".join(al.genome_name(x) for x in tg)), (nm, chunk)
+            for si, (sname, _, slen) in enumerate(al.sequences(g)):
+                if slen < 4:
+                    continue
+                for a, ln in ((slen // 3, slen // 2), (1, slen - 1)):
+                    assert _unique_both_ways(al, monkeypatch, g, si, start=a, length=ln) == \
+                        _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", nm, "--refSequence", sname, "--start", str(a), "--length", str(ln),
+                                "--unique"), (nm, sname, a, ln, chunk)
+    assert n_bytes > 0
+    # the generator of the reference's own tests: inversions and paralogy rings inside one sequence
+    al2, img2 = _rand(hal, tmp_path, seed + 1)
+    monkeypatch.setenv("HGX_MAF_CHUNK", "50")
+    for g in range(al2.num_genomes):
+        nm = al2.genome_name(g)
+        assert _unique_both_ways(al2, monkeypatch, g) == _oracle(oracle_bin, "maf", img2, tmp_path, "--refGenome", nm, "--unique"), nm
+
+
 def test_maf_tracks_at_full_size(hal, oracle_bin, tmp_path, monkeypatch):
     """config 3's alignment at full size: 3 M columns by the tracks and by the walk (the same text), a 200 k-column slice of them
     against the oracle, and the tracks kept with the handle serve the second export without being built again"""
