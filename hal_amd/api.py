@@ -492,6 +492,13 @@ class Comm:
             raise HgxError(take_error(err))
         return bytes(buf)
 
+    def all_sizes(self, mine):
+        """hgx_comm_all_sizes: every rank's value in rank order (the writers' text sizes: where each one's text begins)"""
+        out, err = (C.c_uint64 * self.n_ranks)(), C.c_void_p()
+        if lib.hgx_comm_all_sizes(self._c, int(mine), out, C.byref(err)) != 0:
+            raise HgxError(take_error(err))
+        return list(out)
+
     def close(self):
         if self._c:
             lib.hgx_comm_destroy(self._c)
@@ -665,6 +672,16 @@ class LiftoverPlan:
         err, nbytes = C.c_void_p(), C.c_size_t()
         if lib.hgx_liftover_gather(self._p, comm._c, root, first_query, gathered.data_ptr(), slot_bytes, 1 if bed_only else 0,
                                    torch.cuda.current_stream().cuda_stream, C.byref(nbytes), C.byref(err)) != 0:
+            raise HgxError(take_error(err))
+        return nbytes.value
+
+    def gather_writers(self, comm, group_size, first_query, gathered, slot_bytes, bed_only=False):
+        """hgx_liftover_gather_writers: this rank's records of the last run to its group's writer (the first of group_size
+        consecutive ranks).  gathered: group_size * slot_bytes on a writer, one slot on the others.  Returns this rank's bytes."""
+        import torch
+        err, nbytes = C.c_void_p(), C.c_size_t()
+        if lib.hgx_liftover_gather_writers(self._p, comm._c, group_size, first_query, gathered.data_ptr(), slot_bytes, 1 if bed_only else 0,
+                                           torch.cuda.current_stream().cuda_stream, C.byref(nbytes), C.byref(err)) != 0:
             raise HgxError(take_error(err))
         return nbytes.value
 

@@ -2194,7 +2194,7 @@ void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alig
         while (!have) { // (a chunk's row offsets are 32-bit: very wide alignments get smaller chunks)
             try {
                 columnsHeadRowsHost(alignment, genome, first + done, c->n, opt, true, c->head, c->headOff, headRows, &stats,
-                                    _unique ? first : (int64_t)-1, length);
+                                    _unique ? first : (int64_t)-1, std::max(length, _exportHint));
 #ifdef HGX_HOST_PROFILE
                 if (dump) {
                     const uint64_t hd[4] = {(uint64_t)done, (uint64_t)c->n, c->headOff.size(), headRows.size()};
@@ -3472,6 +3472,9 @@ void mafExportSliced(std::ostream &os, const std::vector<hgx_alignment *> &handl
         if (inLength % size > 0)
             slices.push_back(Slice{s, start + (inLength / size) * size, inLength % size, "", ""});
     }
+    int64_t allColumns = 0;
+    for (const Slice &sl : slices)
+        allColumns += sl.length;
     std::atomic<size_t> next{0};
     auto work = [&](hgx_alignment *h) {
         for (size_t i; (i = next.fetch_add(1)) < slices.size();) {
@@ -3487,6 +3490,7 @@ void mafExportSliced(std::ostream &os, const std::vector<hgx_alignment *> &handl
                 me.setMaxBlockLength(cfg.maxBlockLength);
                 me.setMaxRefGap(cfg.maxRefGap);
                 me.setPrintTree(cfg.printTree);
+                me.setExportHint(allColumns / (int64_t)handles.size());
                 std::ostringstream text;
                 me.convertSequence(text, h, genome, sl.seq, sl.start, sl.length, targets);
                 sl.text = text.str();

@@ -43,6 +43,9 @@ class MafExport {
   public:
     // maf/inc/halMafExport.h:36-58
     void setNoDupes(bool v) { _noDupes = v; }
+    // the columns the handle serves in all (hgx_maf_export_multi's slices are exports of their own: the per-base tracks of
+    // hgx_maf_kernels.hpp are kept with the handle and pay over all of them)
+    void setExportHint(int64_t columns) { _exportHint = columns; }
     void setNoAncestors(bool v) { _noAncestors = v; }
     void setUcscNames(bool v) { _ucscNames = v; }
     void setAppend(bool v) { _append = v; }
@@ -107,6 +110,7 @@ class MafExport {
     typedef std::map<Key, std::vector<const ColumnRowHost *>> ColumnMap;
     bool _noDupes = false, _noAncestors = false, _ucscNames = true, _append = false, _onlyOrthologs = false, _keepEmptyRefBlocks = false,
          _unique = false, _printTree = false;
+    int64_t _exportHint = 0;
     Tree *_tree = nullptr;
     Tree *getTreeNode(int genome, int64_t pos, bool modifyEntries);
     void buildTreeR(int genome, int64_t bottomSegment, int64_t pos, Tree *node, bool modifyEntries);

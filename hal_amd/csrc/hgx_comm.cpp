@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <mutex>
 #include <stdexcept>
+#include <algorithm>
 #include <string>
 
 namespace {
@@ -211,30 +212,32 @@ int hgx_liftover_exchange(hgx_liftover_plan *p, hgx_comm *c, int64_t first_query
     }
 }
 
-int hgx_liftover_gather(hgx_liftover_plan *p, hgx_comm *c, int root, int64_t first_query, void *d_gathered, size_t slot_bytes, int bed_only,
-                        void *hip_stream, size_t *my_bytes, char **err) {
+// every rank of [first, last) sends its slot to `root` (one of them), whose buffer holds them at their distance from `first`
+static int gatherSlots(const char *who, hgx_liftover_plan *p, hgx_comm *c, int root, int first, int last, int64_t first_query, void *d_gathered,
+                       size_t slot_bytes, int bed_only, void *hip_stream, size_t *my_bytes, char **err) {
     try {
         if (!p || !c || !d_gathered)
-            throw std::runtime_error("hgx_liftover_gather: null argument");
+            throw std::runtime_error(std::string(who) + ": null argument");
         if (slot_bytes < 64 || slot_bytes % 8)
-            throw std::runtime_error("hgx_liftover_gather: the slot size must be a multiple of 8 and at least 64 bytes");
-        if (root < 0 || root >= c->nRanks)
-            throw std::runtime_error("hgx_liftover_gather: no such root rank");
+            throw std::runtime_error(std::string(who) + ": the slot size must be a multiple of 8 and at least 64 bytes");
+        if (root < first || root >= last || first < 0 || last > c->nRanks)
+            throw std::runtime_error(std::string(who) + ": no such root rank");
         Rccl &R = rccl();
-        if (c->nRanks > 1 && (!R.send || !R.recv || !R.groupStart || !R.groupEnd))
+        if (last - first > 1 && (!R.send || !R.recv || !R.groupStart || !R.groupEnd))
             throw std::runtime_error("librccl.so lacks ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd");
         const bool isRoot = c->rank == root;
-        unsigned char *mine = (unsigned char *)d_gathered + (isRoot ? (size_t)c->rank * slot_bytes : 0);
+        unsigned char *mine = (unsigned char *)d_gathered + (isRoot ? (size_t)(c->rank - first) * slot_bytes : 0);
         size_t wrote = 0;
         std::string failure;
         buildSlot(p, mine, slot_bytes, first_query, bed_only, hip_stream, wrote, failure);
-        if (c->nRanks > 1) {
+        if (last - first > 1) {
             check(R.groupStart(), "ncclGroupStart");
             int rc = 0;
             if (isRoot) {
-                for (int r = 0; r < c->nRanks && rc == 0; ++r)
+                for (int r = first; r < last && rc == 0; ++r)
                     if (r != root)
-                        rc = R.recv((unsigned char *)d_gathered + (size_t)r * slot_bytes, slot_bytes, /*ncclUint8*/ 1, r, c->comm, (hipStream_t)hip_stream);
+                        rc = R.recv((unsigned char *)d_gathered + (size_t)(r - first) * slot_bytes, slot_bytes, /*ncclUint8*/ 1, r, c->comm,
+                                    (hipStream_t)hip_stream);
             } else {
                 rc = R.send(mine, slot_bytes, /*ncclUint8*/ 1, root, c->comm, (hipStream_t)hip_stream);
             }
@@ -245,7 +248,54 @@ int hgx_liftover_gather(hgx_liftover_plan *p, hgx_comm *c, int root, int64_t fir
         if (my_bytes)
             *my_bytes = wrote;
         if (!failure.empty())
-            throw std::runtime_error("hgx_liftover_gather: " + failure + " (the transfer was carried out; the slot's header says so to the root)");
+            throw std::runtime_error(std::string(who) + ": " + failure + " (the transfer was carried out; the slot's header says so to the root)");
+        return HGX_OK;
+    } catch (std::exception &e) {
+        setErr(err, e.what());
+        return HGX_ERR;
+    }
+}
+
+int hgx_liftover_gather(hgx_liftover_plan *p, hgx_comm *c, int root, int64_t first_query, void *d_gathered, size_t slot_bytes, int bed_only,
+                        void *hip_stream, size_t *my_bytes, char **err) {
+    return gatherSlots("hgx_liftover_gather", p, c, root, 0, c ? c->nRanks : 0, first_query, d_gathered, slot_bytes, bed_only, hip_stream, my_bytes,
+                       err);
+}
+
+int hgx_liftover_gather_writers(hgx_liftover_plan *p, hgx_comm *c, int group_size, int64_t first_query, void *d_gathered, size_t slot_bytes,
+                                int bed_only, void *hip_stream, size_t *my_bytes, char **err) {
+    if (!c || group_size < 1) {
+        setErr(err, "hgx_liftover_gather_writers: null communicator or a group of less than one rank");
+        return HGX_ERR;
+    }
+    const int writer = c->rank - c->rank % group_size;
+    return gatherSlots("hgx_liftover_gather_writers", p, c, writer, writer, std::min(writer + group_size, c->nRanks), first_query, d_gathered,
+                       slot_bytes, bed_only, hip_stream, my_bytes, err);
+}
+
+int hgx_comm_all_sizes(hgx_comm *c, uint64_t mine, uint64_t *sizes, char **err) {
+    try {
+        if (!c || !sizes)
+            throw std::runtime_error("hgx_comm_all_sizes: null argument");
+        if (hipSetDevice(c->device) != hipSuccess)
+            throw std::runtime_error("hgx_comm_all_sizes: hipSetDevice failed");
+        void *d = nullptr;
+        if (hipMalloc(&d, (size_t)c->nRanks * 8) != hipSuccess)
+            throw std::runtime_error("hgx_comm_all_sizes: hipMalloc failed");
+        std::string failure;
+        try {
+            if (hipMemcpy((unsigned char *)d + (size_t)c->rank * 8, &mine, 8, hipMemcpyHostToDevice) != hipSuccess)
+                failure = "hipMemcpy failed"; // (the collective is still posted: the other ranks wait in theirs)
+            check(rccl().allGather((unsigned char *)d + (size_t)c->rank * 8, d, 8, /*ncclUint8*/ 1, c->comm, nullptr), "ncclAllGather");
+            if (hipStreamSynchronize(nullptr) != hipSuccess || hipMemcpy(sizes, d, (size_t)c->nRanks * 8, hipMemcpyDeviceToHost) != hipSuccess)
+                failure = "hipMemcpy failed";
+        } catch (...) {
+            (void)hipFree(d);
+            throw;
+        }
+        (void)hipFree(d);
+        if (!failure.empty())
+            throw std::runtime_error("hgx_comm_all_sizes: " + failure);
         return HGX_OK;
     } catch (std::exception &e) {
         setErr(err, e.what());

@@ -1,7 +1,8 @@
 """Multi-GPU host logic of the hot path: one process per GPU, contiguous shards of independent units (query
 intervals: liftover/impl/halLiftover.cpp:46-92 clears all per-line state; reference columns:
 api/impl/halColumnIterator.cpp:785-787), and the single exchange step that collates fixed-width output records
-(SURVEY 8(e)): an all-gather of per-rank counts, then an all-gather of payloads padded to the largest shard.
+(SURVEY 8(e)): an all-gather of per-rank counts, then an all-gather of payloads padded to the largest shard; for writers of text
+one gather to a root, or to several writers whose texts are placed by their sizes (SlotExchange(group=), text_placement).
 torch.distributed is the transport (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests)."""
 import torch
 import torch.distributed as dist
@@ -292,19 +293,28 @@ class SlotExchange:
     gloo on CPU for the tests).  submit() starts the exchange of the plan's last run, wait() hands out the oldest buffer under
     way (three rotate, so the mapping of the next batches overlaps the exchange); slots(buf) views the ranks' blobs."""
 
-    def __init__(self, world, rank, slot_bytes, device, backend="torch", comm=None, root=None, bed_only=False):
+    def __init__(self, world, rank, slot_bytes, device, backend="torch", comm=None, root=None, bed_only=False, group=None):
         """root: None — every rank gets every rank's blob (one all-gather); a rank — only that rank does (the writer's collation:
         a rank sends its slot once instead of receiving all the others'; hgx_liftover_gather / torch.distributed.gather), the
-        other ranks' buffers keep their own slot only.  bed_only: blobs in the 8-byte form (no source coordinates)."""
+        other ranks' buffers keep their own slot only.  group: several writers instead of one root — the ranks in groups of
+        `group` consecutive ranks, the first of a group receives the group's blobs (hgx_liftover_gather_writers / grouped
+        isend / irecv; buffers of `group` slots, rank r's at r - writer); what the writers do with them: text_placement below.
+        bed_only: blobs in the 8-byte form (no source coordinates)."""
         self.world, self.rank, self.slot = world, rank, (int(slot_bytes) + 7) // 8 * 8
         self.backend, self.comm = backend, comm
-        self.root, self.bed_only = root, bed_only
-        self._bufs = [torch.zeros(world * self.slot, dtype=torch.uint8, device=device) for _ in range(3)]
+        self.root, self.bed_only, self.group = root, bed_only, group
+        if group is not None:
+            if root is not None or group < 1:
+                raise ValueError("either one root or groups of at least one rank")
+            self.writer = writer_of(rank, group)
+            self.members = list(range(self.writer, min(self.writer + group, world)))
+        self._bufs = [torch.zeros((world if group is None else group) * self.slot, dtype=torch.uint8, device=device) for _ in range(3)]
         self._turn, self._inflight = 0, []
         self.last_bytes, self.last_format = 0, None
 
     def _mine(self, buf):
-        return buf[self.rank * self.slot:(self.rank + 1) * self.slot]
+        at = self.rank if self.group is None else 0  # (grouped: a writer is its group's first rank, the others keep one slot)
+        return buf[at * self.slot:(at + 1) * self.slot]
 
     def submit(self, plan=None, first_query=0, blob=None):
         """plan: a LiftoverPlan whose last run is exchanged; blob: a ready blob instead (CPU tests)"""
@@ -316,7 +326,9 @@ class SlotExchange:
         self._turn += 1
         work = None
         if self.backend == "c_abi":
-            if self.root is None:
+            if self.group is not None:
+                self.last_bytes = plan.gather_writers(self.comm, self.group, first_query, buf, self.slot, bed_only=self.bed_only)
+            elif self.root is None:
                 self.last_bytes = plan.exchange(self.comm, first_query, buf, self.slot)
             else:
                 self.last_bytes = plan.gather(self.comm, self.root, first_query, buf, self.slot, bed_only=self.bed_only)
@@ -335,7 +347,14 @@ class SlotExchange:
                     raise ValueError("this rank's records may need %d bytes, the slot has %d" % (plan.wire_capacity(), self.slot))
                 b, self.last_format = plan.wire_blob(first_query, dst=mine, bed_only=self.bed_only)
                 self.last_bytes = int(b.numel())
-            if self.root is not None:  # to the writer only
+            if self.group is not None:  # to the group's writer: the sends and receives of one batch posted together
+                if self.rank == self.writer:
+                    ops = [dist.P2POp(dist.irecv, buf[(r - self.writer) * self.slot:(r - self.writer + 1) * self.slot], r)
+                           for r in self.members[1:]]
+                else:
+                    ops = [dist.P2POp(dist.isend, mine.clone(), self.writer)]
+                work = dist.batch_isend_irecv(ops) if ops else None
+            elif self.root is not None:  # to the writer only
                 parts = list(buf.view(self.world, self.slot).unbind(0)) if self.rank == self.root else None
                 work = dist.gather(mine.clone(), gather_list=parts, dst=self.root, async_op=True)
             elif buf.device.type == "cuda":
@@ -357,6 +376,9 @@ class SlotExchange:
         if work is not None:
             if isinstance(work, torch.cuda.Event):  # (c_abi): readers on other streams must see the gathered slots
                 work.synchronize()
+            elif isinstance(work, list):
+                for w in work:
+                    w.wait()
             else:
                 work.wait()
         return buf
@@ -371,11 +393,42 @@ class SlotExchange:
         """the ranks' blobs (each trimmed to what its header says it holds), in rank order (with a root: on the root only)"""
         if self.root is not None and self.rank != self.root:
             raise ValueError("the blobs were gathered on rank %d" % self.root)
+        if self.group is not None and self.rank != self.writer:
+            raise ValueError("the group's blobs were gathered on rank %d" % self.writer)
         out = []
-        for r in range(self.world):
+        for r in range(self.world if self.group is None else len(self.members)):
             s = buf[r * self.slot:(r + 1) * self.slot]
             out.append(s[:blob_bytes(s)])
         return out
+
+
+def writer_of(rank, group):
+    """the first rank of `rank`'s group of `group` consecutive ranks: the group's writer"""
+    return rank - rank % group
+
+
+def text_placement(nbytes, device):
+    """Level two of the collation by several writers, and it moves no records: every rank tells the bytes of text it holds (0 on a
+    rank that is not a writer), and (offset, total) say where this rank's text belongs in the one output — the groups in rank
+    order are the input's order (shard_bounds), so the writers' texts one behind the other are the single writer's text."""
+    sizes = all_gather_counts(int(nbytes), device)
+    rank = dist.get_rank()
+    return sum(sizes[:rank]), sum(sizes)
+
+
+def write_text_at(path, offset, text, total=None):
+    """a writer's share of the output file, written where it belongs (the writers write side by side; the file ends at `total`)"""
+    import os
+    fd = os.open(path, os.O_WRONLY | os.O_CREAT, 0o644)
+    try:
+        if total is not None and os.fstat(fd).st_size != total:
+            os.ftruncate(fd, total)  # (never below what any writer writes: every share ends at or before `total`)
+        done = 0
+        view = memoryview(text)
+        while done < len(view):
+            done += os.pwrite(fd, view[done:], offset + done)
+    finally:
+        os.close(fd)
 
 
 def blob_bytes(slot):

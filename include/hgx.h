@@ -305,6 +305,19 @@ int hgx_liftover_exchange(hgx_liftover_plan *p, hgx_comm *c, int64_t first_query
  * hgx_liftover_exchange: the rank still takes part. */
 int hgx_liftover_gather(hgx_liftover_plan *p, hgx_comm *c, int root, int64_t first_query, void *d_gathered, size_t slot_bytes,
                         int bed_only, void *hip_stream, size_t *my_bytes, char **err);
+/* Several writers instead of one root — the collation hal2mafMP.py / a pool of halLiftover processes do through files
+ * (maf/hal2mafMP.py:176-190 concatenates the workers' outputs): the ranks are taken in groups of group_size consecutive ranks,
+ * the first rank of a group is its writer and receives the group's blobs (d_gathered: group_size slots on a writer, the slot of
+ * rank r at r - writer; one slot on the others).  A GPU's xGMI links are point to point, so the group_size - 1 blobs a writer
+ * receives arrive over as many links at once — the step takes one blob's time over one link whatever the group and the world; what
+ * the writers divide among themselves is the HOST work behind it (rendering and writing the lines of n_ranks / n_writers ranks
+ * each).  Level two moves no records: hgx_comm_all_sizes tells every writer the bytes of text the writers before it hold, i.e.
+ * where in the one output file its text belongs (rank-major order of the groups = input order), and the writers write side by
+ * side (pwrite).  All ranks of the communicator call both; failures as hgx_liftover_exchange. */
+int hgx_liftover_gather_writers(hgx_liftover_plan *p, hgx_comm *c, int group_size, int64_t first_query, void *d_gathered,
+                                size_t slot_bytes, int bed_only, void *hip_stream, size_t *my_bytes, char **err);
+/* every rank's `mine` in rank order on every rank (an all-gather of eight bytes a rank; blocking; sizes: n_ranks values on the host) */
+int hgx_comm_all_sizes(hgx_comm *c, uint64_t mine, uint64_t *sizes, char **err);
 
 
 /* Text-level drop-in for Liftover::convert (liftover/inc/halLiftover.h:25-28): BED text in, BED text

@@ -256,3 +256,96 @@ def test_one_collective_exchange_of_real_lifted_records_world2():
     result = mgr.dict()
     mp.spawn(_slot_worker, args=(2, port, result), nprocs=2, join=True)
     assert result[0] and result[1]
+
+
+def _lines(recs):
+    """BED-like lines of hgx_record rows (what a writer renders; names stand in as indices here)"""
+    r = recs.contiguous().view(torch.int64).view(-1, 5).numpy()
+    out = []
+    for q, ts, te, ss, tail in r:
+        out.append("q%d\tseq%d\t%d\t%d\t%s\n" % (q, tail & 0xFFFFFFFF, ts, te, chr((tail >> 32) & 0xFF)))
+    return "".join(out).encode()
+
+
+def _writers_worker(rank, world, port, group, path, result):
+    """Several writers (hal_amd.shard.SlotExchange(group=), text_placement, write_text_at) on the really-lifted records of
+    tests/golden/lifted_records.npz, as four ranks would lift them: four uneven shards of the 600 intervals, each rank's rows with
+    shard-relative query indices as a plan returns them."""
+    from hal_amd.shard import SlotExchange, text_placement, write_text_at, writer_of
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    z = np.load(os.path.join(GOLD, "lifted_records.npz"))
+    whole = torch.from_numpy(z["whole"].copy())
+    nq_all = int(z["bounds"][-1])
+    b1 = int(z["bounds"][1])
+    cuts = [0, b1 // 3, b1, b1 + 3, nq_all] if world == 4 else [shard_bounds(nq_all, world, r)[0] for r in range(world)] + [nq_all]
+    q = whole.view(torch.int64).view(-1, 5)[:, 0]
+
+    def shard(r):
+        rows = whole[(q >= cuts[r]) & (q < cuts[r + 1])].clone()
+        return offset_query_index(rows, -cuts[r]), cuts[r + 1] - cuts[r]
+
+    mine, nq = shard(rank)
+    ok = True
+    if world == 4 and group == 2:  # (the four shards are the golden's two, cut again: the device's own blobs decode to them)
+        two = [torch.from_numpy(z["shard%d" % k].copy()) for k in (0, 1)]
+        ok = int(z["bounds"][1]) == cuts[2] and bool(torch.equal(torch.cat([offset_query_index(shard(r)[0], cuts[r] - cuts[0 if r < 2 else 2])
+                                                                             for r in range(4)]), torch.cat(two)))
+    blob = encode_blob(mine, nq, first_query=cuts[rank])
+    slot = 16384
+    ex = SlotExchange(world, rank, slot, "cpu", backend="torch", group=group)
+    writer = writer_of(rank, group)
+    for step in range(4):  # a stream of batches, two in flight
+        ex.submit(blob=blob)
+        if step % 2 == 0:
+            ex.submit(blob=blob)
+        bufs = [ex.wait()] + ([ex.wait()] if step % 2 == 0 else [])
+        for buf in bufs:
+            if rank == writer:
+                parts = ex.slots(buf)
+                members = list(range(writer, min(writer + group, world)))
+                ok = ok and len(parts) == len(members)
+                decoded = torch.cat([decode_blob(p)[0] for p in parts], dim=0)
+                want = whole[(q >= cuts[members[0]]) & (q < cuts[members[-1] + 1])]
+                ok = ok and bool(torch.equal(decoded, want))  # the group's stretch of the unsharded lift, in its order
+                text = _lines(decoded)
+            else:
+                try:
+                    ex.slots(buf)
+                    ok = False
+                except ValueError:
+                    pass
+                text = b""
+            # level two: where the writers' texts go
+            offset, total = text_placement(len(text), torch.device("cpu"))
+            ok = ok and total == len(_lines(whole))
+            out = "%s.%d" % (path, step)
+            write_text_at(out, offset, text, total)
+            dist.barrier()
+            if rank == world - 1:
+                ok = ok and open(out, "rb").read() == _lines(whole)  # the single writer's file
+            dist.barrier()
+    result[rank] = ok
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _spawn_writers(world, group, tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mgr = mp.Manager()
+    result = mgr.dict()
+    mp.spawn(_writers_worker, args=(world, port, group, str(tmp_path / "out.bed"), result), nprocs=world, join=True)
+    assert all(result[r] for r in range(world)), dict(result)
+
+
+def test_two_writers_of_four_ranks_place_their_texts_world4(tmp_path):
+    _spawn_writers(4, 2, tmp_path)
+
+
+def test_writers_with_a_ragged_last_group_and_groups_of_one(tmp_path):
+    _spawn_writers(3, 2, tmp_path)  # groups {0, 1} and {2}
+    _spawn_writers(2, 1, tmp_path)  # every rank its own writer: no records move at all
