@@ -193,6 +193,31 @@ def leg_hal2maf_full(args, local=0):
             leg["cpu_baseline"] = basem
         except Exception as e:
             leg["cpu_baseline"] = {"error": str(e)[:300]}
+    # the line so far is out before round 5's second new device path runs (the parent reads the child's LAST line, whatever its end)
+    print(json.dumps(leg), flush=True)
+    try:
+        # --unique over the whole genome — what hal2mafMP.py runs every slice with: the columns' classes (passed over / walked for
+        # their keys / written) from the per-base tracks (hgx_maf_kernels.hpp: unique_stretches) against round 4's lane-a-column walk
+        al.maf_tracks_info(drop=True)
+        asked = os.environ.get("HGX_MAF_SWEEP")
+        n_t, head_t, s_t = al.maf_export_bytes(src, no_ancestors=True, unique=True, prefix=1 << 20)
+        n_t2, _, s_t2 = al.maf_export_bytes(src, no_ancestors=True, unique=True, prefix=1 << 20)
+        info = al.maf_tracks_info()
+        os.environ["HGX_MAF_SWEEP"] = "0"
+        n_w, head_w, s_w = al.maf_export_bytes(src, no_ancestors=True, unique=True, prefix=1 << 20)
+        if asked is None:
+            os.environ.pop("HGX_MAF_SWEEP", None)
+        else:
+            os.environ["HGX_MAF_SWEEP"] = asked
+        leg["unique"] = {"what": "the same export with --unique: heads and classes from the per-base tracks (the better of two) / by the column walk "
+                                 "(HGX_MAF_SWEEP=0)",
+                         "value": ncols / min(s_t, s_t2), "unit": "columns/s", "seconds": min(s_t, s_t2), "runs_seconds": [s_t, s_t2],
+                         "by_the_column_walk": {"value": ncols / s_w, "seconds": s_w},
+                         "same_text": n_t == n_w and n_t2 == n_w and head_t == head_w, "maf_bytes": n_t,
+                         "device_stage": {k: info.get(k) for k in ("state_unique", "chunks_served_unique", "build_ms", "device_ms_served",
+                                                                   "columns_served", "marked_columns")}}
+    except Exception as e:
+        leg["unique"] = {"error": str(e)[:300]}
     return leg
 
 
@@ -207,12 +232,15 @@ def run_leg_in_child(name, args, env_extra=None, timeout=420.0):
     except subprocess.TimeoutExpired:
         return {"error": "the child did not finish within %.0f s" % timeout}
     lines = [l for l in r.stdout.decode(errors="replace").strip().splitlines() if l.startswith("{")]
-    if r.returncode != 0 or not lines:
+    if not lines:
         return {"error": "the child ended with code %d: %s" % (r.returncode, r.stderr.decode(errors="replace")[-400:])}
     try:
-        return json.loads(lines[-1])
+        leg = json.loads(lines[-1])
     except Exception as e:
         return {"error": "the child's line does not parse: %s" % e}
+    if r.returncode != 0:  # (a leg prints its line as far as it has got before it goes on: what it had is kept, its end is told)
+        leg["child_ended_with"] = {"code": r.returncode, "stderr": r.stderr.decode(errors="replace")[-300:]}
+    return leg
 
 
 def lib_sha16():

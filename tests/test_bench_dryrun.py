@@ -36,6 +36,8 @@ def test_bench_prints_its_line_with_every_leg(tmp_path):
     assert cols["hal2maf_full"]["device_stage"]["state"].startswith("checked"), cols["hal2maf_full"]["device_stage"]
     assert cols["hal2maf_full"]["device_stage"]["last_export"]["walk"] in ("one thread", "slices of the export side by side")
     assert cols["hal2maf_full"]["process"].startswith("a child")
+    uniq = cols["hal2maf_full"]["unique"]
+    assert uniq["same_text"] is True and uniq["device_stage"]["state_unique"].startswith("checked"), uniq
     assert out["cfg5"]["cpu_baseline"]["parity_with_gpu"] is True, out["cfg5"]
     assert "all_cores" in cols["cpu_baseline"] and "all_cores" in out["cpu_baseline"]
     assert "blocks_in_target_range" in out["features"] and "cpu_baseline" in out["features"]["blocks_in_target_range"]
