@@ -202,6 +202,18 @@ def test_maf_tracks_at_full_size(hal, oracle_bin, tmp_path, monkeypatch):
     assert after["build_ms"] == built["build_ms"] and after["chunks_served"] > built["chunks_served"]
     assert got == _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", "Genome_9", "--noAncestors", "--refSequence", seq, "--start",
                           str(a + 1_000_000), "--length", "200000")
+    # --unique from the same tracks: the range begins inside the genome (copies of its bases left of it: columns walked for their
+    # keys only), the generator's paralogs inside it (columns passed over)
+    text_u = _unique_both_ways(al, monkeypatch, src, 0, start=a, length=ln, no_ancestors=True)
+    assert 0 < len(text_u) <= len(text)
+    monkeypatch.setenv("HGX_MAF_SWEEP", "1")
+    got_u = al.maf_export(src, 0, start=a + 1_000_000, length=200000, no_ancestors=True, unique=True)
+    assert got_u == _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", "Genome_9", "--noAncestors", "--unique", "--refSequence", seq,
+                            "--start", str(a + 1_000_000), "--length", "200000")
+    # ... and over the slices of hgx_maf_export_multi (an export each; the handle's tracks serve all of them)
+    multi = hal.maf_export_multi([al], src, 0, start=a, length=ln, slice_size=500000, no_ancestors=True, unique=True)
+    monkeypatch.setenv("HGX_MAF_SWEEP", "0")
+    assert multi == hal.maf_export_multi([al], src, 0, start=a, length=ln, slice_size=500000, no_ancestors=True, unique=True)
 
 
 def test_maf_walk_over_slices_at_full_size(hal, oracle_bin, tmp_path, monkeypatch):
