@@ -17,6 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # emulation too — profiles/r05_notes.md has that run — but takes a quarter of an hour)
 CASES = [
     "tests/test_gpu_zz_round5.py::test_maf_tracks_reference_goldens",
+    "tests/test_gpu_zz_round5.py::test_maf_tracks_unique_small",
     "tests/test_gpu_zz_round5.py::test_count_dupes_sweep_over_a_polytomy_with_segment_tails",
     "tests/test_gpu_zz_round5.py::test_depth_wig_through_several_chunks[97]",
     "tests/test_gpu_columns.py::test_reference_cli_goldens_hal2maf",

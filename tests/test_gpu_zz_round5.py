@@ -142,6 +142,28 @@ def _unique_both_ways(al, monkeypatch, *args, **kw):
     return a
 
 
+def test_maf_tracks_unique_small(hal, oracle_bin, tmp_path, monkeypatch):
+    """a small case of test_maf_tracks_unique (the CPU suite runs it on the host-side emulation, tests/test_cpu_emulation.py)"""
+    img = str(tmp_path / "ms.hgx")
+    halfix.write_hgx(img, halfix.random_multiseq_alignment(2, n_genomes=4, root_len=200))
+    al = hal.Alignment.open(img, device=0)
+    monkeypatch.setenv("HGX_MAF_CHUNK", "37")
+    n_bytes = 0
+    for g in range(al.num_genomes):
+        nm = al.genome_name(g)
+        if al.genome_length(g) == 0:
+            continue
+        want = _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", nm, "--unique")
+        assert _unique_both_ways(al, monkeypatch, g) == want, nm
+        n_bytes += len(want)
+        sname, _, slen = al.sequences(g)[-1]
+        if slen >= 4:
+            assert _unique_both_ways(al, monkeypatch, g, len(al.sequences(g)) - 1, start=1, length=slen - 1) == \
+                _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", nm, "--refSequence", sname, "--start", "1", "--length", str(slen - 1),
+                        "--unique"), (nm, sname)
+    assert n_bytes > 0
+
+
 @pytest.mark.parametrize("seed", [0, 3, 4])
 def test_maf_tracks_unique(hal, oracle_bin, tmp_path, seed, monkeypatch):
     """--unique from the marked columns' rows (the stretches of a run that are passed over, walked for their keys, written): several
