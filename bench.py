@@ -216,8 +216,30 @@ def leg_hal2maf_full(args, local=0):
                          "same_text": n_t == n_w and n_t2 == n_w and head_t == head_w, "maf_bytes": n_t,
                          "device_stage": {k: info.get(k) for k in ("state_unique", "chunks_served_unique", "build_ms", "device_ms_served",
                                                                    "columns_served", "marked_columns")}}
+        print(json.dumps(leg), flush=True)
+        # hal2mafMP.py's recipe over the whole genome: slices of a million columns, --unique, an export each, two handles of this GPU —
+        # the slices of a handle share its tracks
+        clones = [al, al.clone_to_device(local)]
+        al.maf_tracks_info(drop=True)
+        t0 = time.perf_counter()
+        nb_t = hal_amd.maf_export_multi(clones, src, 0, start=0, length=ncols, slice_size=1000000, no_ancestors=True, unique=True, size_only=True)
+        s_mt = time.perf_counter() - t0
+        infos = [c.maf_tracks_info() for c in clones]
+        os.environ["HGX_MAF_SWEEP"] = "0"
+        t0 = time.perf_counter()
+        nb_w = hal_amd.maf_export_multi(clones, src, 0, start=0, length=ncols, slice_size=1000000, no_ancestors=True, unique=True, size_only=True)
+        s_mw = time.perf_counter() - t0
+        if asked is None:
+            os.environ.pop("HGX_MAF_SWEEP", None)
+        else:
+            os.environ["HGX_MAF_SWEEP"] = asked
+        leg["unique"]["export_multi"] = {"what": "hgx_maf_export_multi over the whole genome: %d slices of 1 M columns, --unique, two handles of this one GPU; "
+                                                 "from each handle's tracks / by the column walk" % ((ncols + 999999) // 1000000),
+                                         "value": ncols / s_mt, "unit": "columns/s", "seconds": s_mt, "by_the_column_walk": {"value": ncols / s_mw, "seconds": s_mw},
+                                         "same_size": nb_t == nb_w, "maf_bytes": nb_t,
+                                         "tracks": [{k: i.get(k) for k in ("tracks", "state_unique", "chunks_served_unique", "build_ms")} for i in infos]}
     except Exception as e:
-        leg["unique"] = {"error": str(e)[:300]}
+        leg.setdefault("unique", {})["error"] = str(e)[:300]
     return leg
 
 

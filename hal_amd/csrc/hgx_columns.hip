@@ -802,12 +802,14 @@ static bool mafSweepAllowed(const Image &img, const SweepScope &sc, int64_t expo
         return false;
     if (env && env[0] == '1')
         return true;
-    // the sweeps touch every base of every genome in scope once; the walk they replace touches a column's tree per column: exports of
-    // a million columns or more (as halAlignmentDepth's sweeps) that cover a thirty-second of the scope's bases or more
+    // the sweeps touch every base of every genome in scope once (about 15 bytes a base: 5 ms for config 2's gigabase by round 4's
+    // depth sweeps); the walk they replace touches a column's tree per column (2.8 ns a column, round 4): even at about 500 bases of
+    // scope a column.  Exports of a million columns or more (as halAlignmentDepth's sweeps) with a fivefold margin on that (the
+    // stage's own times are not measured yet: profiles/r05_notes.md)
     int64_t bases = 0;
     for (int g : sc.postOrder)
         bases += img.genomes[(size_t)g].totalLength;
-    return exportColumns >= ((int64_t)1 << 20) && bases <= 32 * exportColumns;
+    return exportColumns >= ((int64_t)1 << 20) && bases <= 100 * exportColumns;
 }
 
 template <typename C>
