@@ -361,3 +361,31 @@ def test_config4_full_size_sample_vs_oracle(hal, oracle_bin, tmp_path):
     wig = str(tmp_path / "o.wig")
     subprocess.check_call([oracle_bin, "depth", img, "Genome_44", wig, "--refSequence", seq_name, "--start", str(a), "--length", str(ln)])
     assert al.alignment_depth(src, 0, start=a, length=ln) == open(wig).read()
+
+
+def test_writers_group_through_the_c_abi(hal, tmp_path):
+    """several writers (hgx_liftover_gather_writers; with the test box's one rank the group is the rank itself) and the sizes that
+    place their texts (hgx_comm_all_sizes): the writer's blob is the blob the root of hgx_liftover_gather gets"""
+    import torch
+    from hal_amd import shard
+    from test_gpu_exchange import _batch
+    from test_gpu_liftover import _rand_alignment
+    al, _ = _rand_alignment(hal, tmp_path, 2)
+    src, tgt, gs, ge, st = _batch(hal, al, 3000, 5)
+    plan = hal.LiftoverPlan(al, src, tgt, max_queries=3000)
+    comm = hal.Comm(hal.Comm.unique_id(), 0, 1, 0)
+    plan.run(gs, ge, st)
+    slot = (plan.wire_capacity() + 7) // 8 * 8
+    gx = shard.SlotExchange(1, 0, slot, "cuda", backend="c_abi", comm=comm, root=0, bed_only=True)
+    gx.submit(plan, first_query=12345)
+    (blob8,) = gx.slots(gx.wait())
+    torch.cuda.synchronize()
+    for group in (1, 2):
+        wx = shard.SlotExchange(1, 0, slot, "cuda", backend="c_abi", comm=comm, group=group, bed_only=True)
+        wx.submit(plan, first_query=12345)
+        buf = wx.wait()
+        torch.cuda.synchronize()
+        (blobw,) = wx.slots(buf)
+        assert wx.last_bytes == blobw.numel() and torch.equal(blobw.cpu(), blob8.cpu())
+    assert comm.all_sizes(123456789012) == [123456789012]
+    comm.close()
