@@ -170,10 +170,23 @@ def leg_hal2maf_full(args, local=0):
         tracks = al.maf_tracks_info()
     except Exception as e:
         tracks = {"error": str(e)[:200]}
+    # the same export by round 4's path (every column walked on the device, one thread's block state machine), for the comparison
+    round4 = None
+    if "HGX_MAF_SWEEP" not in os.environ and "HGX_MAF_SLICED" not in os.environ:
+        try:
+            os.environ["HGX_MAF_SWEEP"] = os.environ["HGX_MAF_SLICED"] = "0"
+            n4, head4, s4 = al.maf_export_bytes(src, no_ancestors=True, prefix=65536)
+            round4 = {"what": "HGX_MAF_SWEEP=0 HGX_MAF_SLICED=0: round 4's device stage and walk, one export after the two above", "seconds": s4,
+                      "value": ncols / s4, "same_size": n4 == nbytes, "same_beginning": head4 == maf_head[:65536]}
+        except Exception as e:
+            round4 = {"error": str(e)[:200]}
+        finally:
+            os.environ.pop("HGX_MAF_SWEEP", None)
+            os.environ.pop("HGX_MAF_SLICED", None)
     leg = {"metric": "MAF columns/sec (hal2maf --refGenome %s --noAncestors over the whole genome, end to end to MAF text in host memory; the better "
                      "of two exports)" % src_name,
            "value": ncols / dt_m, "unit": "columns/s", "columns": ncols, "seconds": dt_m, "runs_seconds": runs, "maf_bytes": nbytes,
-           "process": "a child of bench.py (its own alignment, its own HIP context)",
+           "process": "a child of bench.py (its own alignment, its own HIP context)", "by_round_4s_path": round4,
            "device_stage": dict(tracks, what="hgx_maf_tracks_info after the two exports: the per-base tracks the heads are taken from (hgx_maf_kernels.hpp) "
                                              "— built once (build_ms), every chunk's kernels timed with HIP events (device_ms_served over "
                                              "columns_served); state says whether the first chunk's heads were the column walk's (else the walk is "
