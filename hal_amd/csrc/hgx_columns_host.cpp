@@ -1854,24 +1854,85 @@ void MafExport::RunMachine::flush(const PRow *current) {
 // looked like then.  When every slice began as the slice before it ended, the logs in order are the one-thread walk's, by
 // induction from the first slice (which begins with the export's own state).  Counts that moved, or a run-up that did not find
 // the state, cost another round for the slices behind; after a few rounds without agreement one thread walks the export.
-bool MafExport::walkSliced(std::ostream &mafStream, void *chunksPtr, int refRank, int64_t startPosition, size_t &numBlocksOut, int *roundsOut,
+// The export's batches as they arrive from the device stage (convertSequenceRuns' feeding thread), for the walk over slices: the walk
+// begins with the first batches and takes the others in as they come, so that its rounds — and the rendering of the slices they
+// settle — run beside the device stage instead of behind it.
+struct MafExport::Arrivals {
+    typedef RunMachine::Chunk Chunk;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<std::shared_ptr<Chunk>> chunks; // (under mu: the vector grows)
+    std::vector<size_t> headBase{0};            // heads in front of every chunk that is there, and behind the last one
+    bool complete = false;                      // no more batches
+    std::exception_ptr error;                   // the feeding thread's
+    double completeAt = 0;                      // seconds after `since`
+    std::chrono::steady_clock::time_point since = std::chrono::steady_clock::now();
+    void push(std::shared_ptr<Chunk> c) {
+        std::lock_guard<std::mutex> lock(mu);
+        headBase.push_back(headBase.back() + (c->headOff.size() - 1));
+        chunks.push_back(std::move(c));
+        cv.notify_all();
+    }
+    void end(std::exception_ptr e = nullptr) {
+        std::lock_guard<std::mutex> lock(mu);
+        complete = true;
+        error = e;
+        completeAt = std::chrono::duration<double>(std::chrono::steady_clock::now() - since).count();
+        cv.notify_all();
+    }
+    // batch c, waited for; null: the export has fewer batches
+    std::shared_ptr<Chunk> get(size_t c) {
+        std::unique_lock<std::mutex> lock(mu);
+        cv.wait(lock, [&]() { return c < chunks.size() || complete; });
+        if (error)
+            std::rethrow_exception(error);
+        return c < chunks.size() ? chunks[c] : nullptr;
+    }
+    // the batches that are there (and whether they are all), once there are more than `have` or they are all
+    size_t waitMore(size_t have, bool &all) {
+        std::unique_lock<std::mutex> lock(mu);
+        cv.wait(lock, [&]() { return chunks.size() > have || complete; });
+        if (error)
+            std::rethrow_exception(error);
+        all = complete;
+        return chunks.size();
+    }
+    std::vector<size_t> headBases() {
+        std::lock_guard<std::mutex> lock(mu);
+        return headBase;
+    }
+    void waitComplete() {
+        std::unique_lock<std::mutex> lock(mu);
+        cv.wait(lock, [&]() { return complete; });
+        if (error)
+            std::rethrow_exception(error);
+    }
+};
+
+bool MafExport::walkSliced(std::ostream &mafStream, Arrivals &A, int refRank, int64_t startPosition, size_t &numBlocksOut, int *roundsOut,
                            unsigned *threadsOut, double *secondsOut) {
     typedef RunMachine::Chunk Chunk;
-    const std::vector<std::shared_ptr<Chunk>> &all = *static_cast<const std::vector<std::shared_ptr<Chunk>> *>(chunksPtr);
-    const size_t S = all.size();
-    if (S < 2)
-        return false;
+    // slices = batches.  `there`: the batches that have arrived; S: the slices in play — a slice's walk goes on into the batch behind
+    // it (until that slice's first block begins), so the last batch that is there is in play only when it is the export's last
+    bool complete = false;
+    size_t there = A.waitMore(1, complete);
+    if (there < 2)
+        return false; // (one batch: nothing to walk side by side)
+    size_t S = complete ? there : there - 1;
     const auto t0 = std::chrono::steady_clock::now();
     RunMachine first(*this, mafStream, refRank); // (takes the export's entries; hands the last slice's back in the end)
     first.describeAllRanks();
     const RunMachine::MachineState initial = first.saveState();
     std::shared_ptr<std::vector<RunMachine::RankInfo>> ranks = first.rankInfo;
     // heads in front of every chunk; where a slice's run-up begins
-    std::vector<size_t> headBase(S + 1, 0);
-    for (size_t c = 0; c < S; ++c)
-        headBase[c + 1] = headBase[c] + (all[c]->headOff.size() - 1);
+    std::vector<size_t> headBase = A.headBases();
     const size_t RUNUP = getenv("HGX_MAF_RUNUP") ? (size_t)std::max(1, atoi(getenv("HGX_MAF_RUNUP"))) : 4096;
-    auto seamOf = [&](size_t s) { return s < S ? startPosition + all[s]->done : INT64_MAX; };
+    // the first column of slice s (its batch is there, or the one before it is): a walk is told where the slice behind its own begins
+    auto seamOf = [&](size_t s) {
+        if (std::shared_ptr<Chunk> c = A.get(s))
+            return startPosition + c->done;
+        return (int64_t)INT64_MAX;
+    };
     struct Slice {
         std::unique_ptr<RunMachine> R;
         int64_t count = 0, runup = 0;  // blocks that began in the slice / in its run-up, as its last walk found them
@@ -1885,14 +1946,18 @@ bool MafExport::walkSliced(std::ostream &mafStream, void *chunksPtr, int refRank
         bool exactState = false;       // its machine's count and keys are the one-thread walk's (else: right but for them)
         bool walked = false, reachedEnd = false;
     };
-    std::vector<Slice> slice(S);
+    std::deque<Slice> slice(S); // (grows between rounds; a round's walks each touch their own)
     // the first slice: the export's own state, its log from the first column on
     first.sliced = true;
     first.stopAt = seamOf(1);
+    // (a walk that runs out of batches waits for the next one: only the export's end ends it)
     auto walkFrom = [&](RunMachine &R, size_t chunk, size_t head) {
-        for (size_t c = chunk; c < S && !R.stopped; ++c) {
+        for (size_t c = chunk; !R.stopped; ++c) {
+            std::shared_ptr<Chunk> ch = A.get(c);
+            if (!ch)
+                break;
             R.curChunkIndex = c;
-            R.walkChunk(all[c], c == chunk ? head : 0, startPosition);
+            R.walkChunk(ch, c == chunk ? head : 0, startPosition);
         }
         if (!R.stopped && R.appendCount > 0)
             R.endBlock();
@@ -1931,7 +1996,8 @@ bool MafExport::walkSliced(std::ostream &mafStream, void *chunksPtr, int refRank
     int rounds = 0;
     size_t frontier = 1, frontierPrev = 0; // the first slice that is not settled; the last slice in front of it with blocks of its own
     slice[0].exactState = true;
-    for (; rounds < (int)S + 2 && !settled; ++rounds) {
+    // (every round settles its frontier at least: the rounds are fewer than the slices plus the times new batches came into play)
+    for (; rounds < 100000 && !settled; ++rounds) {
         std::atomic<size_t> next{1};
         std::exception_ptr failure;
         std::mutex failureMu;
@@ -1971,7 +2037,7 @@ bool MafExport::walkSliced(std::ostream &mafStream, void *chunksPtr, int refRank
             L.lastBase = baseOf[s];
             const int64_t told = std::max<int64_t>(0, baseOf[s] - L.runup);
             const size_t h0 = headBase[s] > RUNUP ? headBase[s] - RUNUP : 0;
-            const size_t c0 = (size_t)(std::upper_bound(headBase.begin(), headBase.begin() + (std::ptrdiff_t)S, h0) - headBase.begin()) - 1;
+            const size_t c0 = (size_t)(std::upper_bound(headBase.begin(), headBase.begin() + (std::ptrdiff_t)s + 1, h0) - headBase.begin()) - 1;
             // (the run-up's own count of blocks is only known when it has been walked: up to three times, told the count put right by
             // what the walk before found; the last one goes on whatever it finds)
             int64_t tell = told;
@@ -2097,6 +2163,45 @@ bool MafExport::walkSliced(std::ostream &mafStream, void *chunksPtr, int refRank
             prev = &R;
         }
         flushSettled(settled ? S : frontier);
+        // the batches that arrived meanwhile come into play: behind the slices that are walked again, or — when every slice in play
+        // is settled and the export goes on — after waiting for the next one, its slice walked from the state the last one stopped in
+        {
+            // (a settled slice whose walk ran to the export's end — it waited for the batches — has everything behind it)
+            if (settled && (ended || (complete && S == there)))
+                break;
+            bool nowComplete = complete;
+            size_t nowThere = there;
+            if (settled)
+                nowThere = A.waitMore(there, nowComplete);
+            else
+                nowThere = A.waitMore(0, nowComplete); // (does not wait: something is there)
+            const size_t newS = nowComplete ? nowThere : nowThere - 1;
+            if (settled) {
+                // (S slices settled, more to come: the first new one is the frontier)
+                frontier = S;
+                frontierPrev = prevIndex;
+                settled = false;
+            }
+            if (newS > S) {
+                const size_t oldS = S;
+                slice.resize(newS);
+                todo.resize(newS, 1);
+                for (size_t j = oldS; j < newS; ++j)
+                    todo[j] = 1;
+                if (frontier == oldS)
+                    slice[oldS].exactBase = trueCount;
+                // (the count in front of the new slices, as far as it can be told: what is known of the slices in front of them)
+                int64_t base = slice[oldS - 1].exactBase >= 0 ? slice[oldS - 1].exactBase : slice[oldS - 1].guessBase >= 0 ? slice[oldS - 1].guessBase : 0;
+                base += slice[oldS - 1].count;
+                for (size_t j = oldS; j < newS; ++j)
+                    if (slice[j].exactBase < 0)
+                        slice[j].guessBase = base;
+                S = newS;
+            }
+            there = nowThere;
+            complete = nowComplete;
+            headBase = A.headBases();
+        }
     }
     if (getenv("HGX_MAF_TIMING"))
         std::cerr << "[hgx maf] the walk over " << S << " slices on " << threads << " threads: " << rounds << " round(s), "
@@ -2331,29 +2436,65 @@ void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alig
     }
 #endif
     const auto tStart = std::chrono::steady_clock::now();
-    std::vector<std::shared_ptr<Chunk>> all; // (the walk over slices: every batch, kept until the text is written)
+    Arrivals arrivals; // (the walk over slices: every batch, kept until the text is written)
     bool slicedDone = false;
     int slicedRounds = 0;
     unsigned slicedThreads = 0;
     double slicedFetched = 0, slicedWalk = 0;
     if (wantHeadCols) {
-        for (int64_t done = 0; done < length;) {
-            const auto tw = std::chrono::steady_clock::now();
-            std::shared_ptr<Chunk> c = nextChunk();
-            waitSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
-            fetchSeconds += c->seconds;
-            numHeads += c->headOff.size() - 1;
-            done += c->n;
-            all.push_back(std::move(c));
+        // the batches are handed to the walk as they arrive (a thread of its own takes them from the stages); the walk's rounds and
+        // the rendering of what they settle run beside the device stage
+        arrivals.since = tStart;
+        struct Feeder {
+            std::thread t;
+            ~Feeder() {
+                if (t.joinable())
+                    t.join();
+            }
+        } feeder;
+        const long feedDelayUs = getenv("HGX_MAF_FEED_DELAY_US") ? atol(getenv("HGX_MAF_FEED_DELAY_US")) : 0;
+        feeder.t = std::thread([&]() {
+            try {
+                for (int64_t done = 0; done < length;) {
+                    const auto tw = std::chrono::steady_clock::now();
+                    std::shared_ptr<Chunk> c = nextChunk();
+                    waitSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
+                    fetchSeconds += c->seconds;
+                    numHeads += c->headOff.size() - 1;
+                    done += c->n;
+                    if (feedDelayUs > 0) // (the tests: batches that arrive while the rounds run)
+                        std::this_thread::sleep_for(std::chrono::microseconds(feedDelayUs));
+                    arrivals.push(std::move(c));
+                }
+                arrivals.end();
+            } catch (...) {
+                arrivals.end(std::current_exception());
+            }
+        });
+        try {
+            slicedDone = walkSliced(mafStream, arrivals, _rank[(size_t)genome][(size_t)seq], startPosition, numBlocks, &slicedRounds, &slicedThreads,
+                                    &slicedWalk);
+        } catch (...) {
+            // (the feeding thread ends by itself: the device stage goes on to the export's end or to its own failure; Join below ends
+            // the device stage's thread when this frame is left, the feeder's nextChunk then throws and the feeder ends)
+            {
+                std::lock_guard<std::mutex> lock(pipe.mu);
+                pipe.stop = true;
+                pipe.cv.notify_all();
+            }
+            feeder.t.join();
+            throw;
         }
-        slicedFetched = std::chrono::duration<double>(std::chrono::steady_clock::now() - tStart).count();
-        slicedDone = walkSliced(mafStream, &all, _rank[(size_t)genome][(size_t)seq], startPosition, numBlocks, &slicedRounds, &slicedThreads, &slicedWalk);
+        feeder.t.join();
+        arrivals.waitComplete(); // (rethrows the feeding thread's failure)
+        slicedFetched = arrivals.completeAt;
         if (getenv("HGX_MAF_TIMING"))
-            std::cerr << "[hgx maf] columns " << length << " heads " << numHeads << " blocks " << numBlocks << ": the walk over " << all.size()
-                      << " slices " << (slicedDone ? "" : "did not settle; one thread's walk instead ") << "after "
-                      << std::chrono::duration<double>(std::chrono::steady_clock::now() - tStart).count() << " s, of which waiting for the device "
-                      << waitSeconds << " s (fetches " << fetchSeconds << " s, device " << stats.rows_ms + stats.depth_ms << " ms)" << std::endl;
+            std::cerr << "[hgx maf] columns " << length << " heads " << numHeads << " blocks " << numBlocks << ": the walk over " << arrivals.chunks.size()
+                      << " slices " << (slicedDone ? "" : "did not begin (one batch); one thread's walk instead ") << "after "
+                      << std::chrono::duration<double>(std::chrono::steady_clock::now() - tStart).count() << " s, the last batch there after "
+                      << slicedFetched << " s (fetches " << fetchSeconds << " s, device " << stats.rows_ms + stats.depth_ms << " ms)" << std::endl;
     }
+    const std::vector<std::shared_ptr<Chunk>> &all = arrivals.chunks; // (complete by now)
     if (!slicedDone) {
         RunMachine R(*this, mafStream, _rank[(size_t)genome][(size_t)seq]);
         size_t nextOfAll = 0;

@@ -199,9 +199,10 @@ class MafExport {
     friend struct RunMachine;
     void convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alignment, int genome, int seq, int64_t startPosition, int64_t length,
                              const ColumnOptions &opt);
-    // the same walk over slices of the export side by side (hgx_columns_host.cpp); chunks: RunMachine::Chunk, every batch of the export;
-    // false: the slices' walks did not settle on one sequence of blocks — nothing was written, the caller walks with one thread
-    bool walkSliced(std::ostream &mafStream, void *chunks, int refRank, int64_t startPosition, size_t &numBlocks, int *rounds = nullptr,
+    // the same walk over slices of the export side by side (hgx_columns_host.cpp); batches: the export's batches as they arrive (the walk
+    // begins when the first two are there); false: fewer than two batches — nothing was written, the caller walks with one thread
+    struct Arrivals;
+    bool walkSliced(std::ostream &mafStream, Arrivals &batches, int refRank, int64_t startPosition, size_t &numBlocks, int *rounds = nullptr,
                     unsigned *threads = nullptr, double *seconds = nullptr);
     // --maxRefGap > 0: the column iterator with its stack of inserted / deleted ranges (halColumnIterator.cpp:65-144, 357-405),
     // replayed over the columns and indel events the device returns (hgx_gap_kernels.hpp)
