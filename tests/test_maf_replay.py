@@ -112,6 +112,11 @@ def test_walk_over_slices_of_the_export_is_the_one_thread_walk(oracle_bin):
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT).stdout.decode()
     last = out.strip().splitlines()[-1].split()
     assert last[:2] == ["alignments", "20"] and int(last[3]) >= 40 and last[4:8] == ["different", "0", "not", "settled"] and last[8] == "0", out
+    # batches that arrive while the rounds run (MafExport::Arrivals: the walk takes them in as they come)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "scripts", "r05_cpu_maf_sliced_soak.py"), "520", "6"],
+                         env=dict(os.environ, HGX_MAF_FEED_DELAY_US="1500"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT).stdout.decode()
+    last = out.strip().splitlines()[-1].split()
+    assert last[:2] == ["alignments", "6"] and last[4:8] == ["different", "0", "not", "settled"] and last[8] == "0", out
     # and the earlier soak's shapes (chunks of 1 .. 2^21 columns, every option of the state machine) with the walk over slices forced
     out = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "scripts", "r04_cpu_maf_soak.py"), "7100", "8"],
                          env=dict(os.environ, HGX_MAF_SLICED="1", HGX_MAF_RUNUP="50"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT).stdout.decode()
