@@ -1039,11 +1039,20 @@ static void columnsHeadRowsSweep(hgx_alignment *h, MafTracks &T, int ref, int64_
         U.first = first;
         U.f = uniqueFirst;
         U.ref = ref;
+        U.maxRefRows = UNIQUE_MAX_REF_ROWS;
+        if (const char *e = getenv("HGX_MAF_UNIQUE_MAX_REF"))
+            U.maxRefRows = std::max(0, std::min(UNIQUE_MAX_REF_ROWS, atoi(e)));
         U.error = (unsigned int *)err.p;
         const int candGrid = (int)std::max<int64_t>(1, std::min<int64_t>(GRID, ((int64_t)nCand + 255) / 256));
         Buf dSegCnt((size_t)nCand * 4), dSegOff(((size_t)nCand + 1) * 4);
         hipLaunchKernelGGL(k_unique_count, dim3(candGrid), dim3(256), 0, nullptr, U, (uint32_t *)dSegCnt.p);
         const uint32_t nSeg = deviceScan((const uint32_t *)dSegCnt.p, nCand, (uint32_t *)dSegOff.p, (uint32_t *)dSums.p);
+        {
+            unsigned int early = 0; // (a column whose reference rows could not be held has no stretches: nothing to go on with)
+            HIP_OK(hipMemcpy(&early, err.p, 4, hipMemcpyDeviceToHost));
+            if (early == 3 || nSeg == 0)
+                throw MafUniqueNeedsTheWalk();
+        }
         Buf dSeg(std::max<size_t>(nSeg, 1) * sizeof(UniqueSeg)), dUnits(std::max<size_t>(nSeg, 1) * 4), dUnitRows(std::max<size_t>(nSeg, 1) * 4),
             dUnitOff(((size_t)nSeg + 1) * 4), dUnitRowOff(((size_t)nSeg + 1) * 4), dSums2(((size_t)nSeg / SCAN_BLOCK + 2) * 4);
         hipLaunchKernelGGL(k_unique_stretches, dim3(candGrid), dim3(256), 0, nullptr, U, (const uint32_t *)dSegOff.p, (UniqueSeg *)dSeg.p);

@@ -518,6 +518,7 @@ struct UniqueParams {
     uint32_t nCand, n; // marked columns, columns of the chunk
     int64_t first, f;  // genome coordinate of the chunk's first column, of the range's first column
     int32_t ref;
+    int32_t maxRefRows; // <= UNIQUE_MAX_REF_ROWS (the tests lower it: HGX_MAF_UNIQUE_MAX_REF)
     unsigned int *error; // 3: a column with more reference bases than UNIQUE_MAX_REF_ROWS, or none (the reference is not reported)
 };
 // emit(j, len, cls) for every stretch of marked column k's run; false: the column's reference rows cannot be held
@@ -537,7 +538,7 @@ template <typename F> HGX_DEV __forceinline__ bool unique_stretches(const Unique
             self = true; // (the column's own base: never left of itself)
             continue;
         }
-        if (m == UNIQUE_MAX_REF_ROWS)
+        if (m >= U.maxRefRows)
             return false;
         pos[m] = r.pos;
         rev[m] = r.rev != 0;

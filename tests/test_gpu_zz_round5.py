@@ -162,6 +162,14 @@ def test_maf_tracks_unique_small(hal, oracle_bin, tmp_path, monkeypatch):
                 _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", nm, "--refSequence", sname, "--start", "1", "--length", str(slen - 1),
                         "--unique"), (nm, sname)
     assert n_bytes > 0
+    # batches with a column of more reference copies than a lane holds go to the walk, the others are served (the limit lowered to
+    # none: every batch with a paralog of the reference)
+    monkeypatch.setenv("HGX_MAF_UNIQUE_MAX_REF", "0")
+    monkeypatch.setenv("HGX_MAF_SWEEP", "1")
+    for g in range(al.num_genomes):
+        if al.genome_length(g):
+            al.maf_tracks_info(drop=True)
+            assert al.maf_export(g, unique=True) == _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", al.genome_name(g), "--unique")
 
 
 @pytest.mark.parametrize("seed", [0, 3, 4])
