@@ -157,7 +157,7 @@ def test_maf_tracks_unique_small(hal, oracle_bin, tmp_path, monkeypatch):
         assert _unique_both_ways(al, monkeypatch, g) == want, nm
         n_bytes += len(want)
         sname, _, slen = al.sequences(g)[-1]
-        if slen >= 4:
+        if slen >= 4 and g == al.num_genomes - 1:
             assert _unique_both_ways(al, monkeypatch, g, len(al.sequences(g)) - 1, start=1, length=slen - 1) == \
                 _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", nm, "--refSequence", sname, "--start", "1", "--length", str(slen - 1),
                         "--unique"), (nm, sname)
@@ -166,7 +166,7 @@ def test_maf_tracks_unique_small(hal, oracle_bin, tmp_path, monkeypatch):
     # none: every batch with a paralog of the reference)
     monkeypatch.setenv("HGX_MAF_UNIQUE_MAX_REF", "0")
     monkeypatch.setenv("HGX_MAF_SWEEP", "1")
-    for g in range(al.num_genomes):
+    for g in (1, al.num_genomes - 1):
         if al.genome_length(g):
             al.maf_tracks_info(drop=True)
             assert al.maf_export(g, unique=True) == _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", al.genome_name(g), "--unique")
