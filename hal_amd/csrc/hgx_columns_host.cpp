@@ -1966,7 +1966,7 @@ bool MafExport::walkSliced(std::ostream &mafStream, Arrivals &A, int refRank, in
     slice[0].count = (int64_t)(first.stopped ? first.endSnap.numBlocks : first.numBlocks);
     slice[0].reachedEnd = !first.stopped;
     unsigned threads = std::thread::hardware_concurrency();
-    threads = std::max(1u, std::min(threads ? threads : 1u, 32u));
+    threads = std::max(1u, std::min(threads ? threads : 1u, threads >= 96 ? 64u : 32u));
     if (const char *e = getenv("HGX_MAF_WALK_THREADS"))
         threads = (unsigned)std::max(1, atoi(e));
     // the settled slices' logs go to the rendering threads in order as soon as they are settled (RunMachine::flush renders a few
@@ -2256,11 +2256,19 @@ void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alig
         chunkColumns = (size_t)std::max<long long>(1, atoll(e));
     // The walk over slices of the export, side by side (walkSliced): exports of sixteen million columns or more in eight chunks or
     // more on a host of thirty-two threads or more; HGX_MAF_SLICED=1 / 0 forces / forbids it
-    const int64_t numChunksExpected = (length + (int64_t)chunkColumns - 1) / (int64_t)chunkColumns;
+    int64_t numChunksExpected = (length + (int64_t)chunkColumns - 1) / (int64_t)chunkColumns;
     // (a round of walks takes one slice's time when every slice has a thread: hosts of 32 threads or more)
     bool wantHeadCols = numChunksExpected >= 8 && numChunksExpected <= 512 && length >= ((int64_t)16 << 20) && std::thread::hardware_concurrency() >= 32;
     if (const char *e = getenv("HGX_MAF_SLICED"))
         wantHeadCols = atoi(e) != 0; // (1: whatever the export's size — with two batches or more; the tests and the soaks)
+    // Slices are batches, and a round takes one slice's walk: where the host has a thread for each of twice as many slices, batches of
+    // half the columns halve the rounds' time (full-size config 3 on the CPU replay: 53 slices settle in 12-14 rounds where 27 take
+    // 9-10 — how far a round's guesses hold is a matter of columns, not of slices)
+    if (wantHeadCols && !getenv("HGX_MAF_CHUNK") && chunkColumns == ((size_t)1 << 21) && std::thread::hardware_concurrency() >= 96 &&
+        length >= ((int64_t)16 << 20)) {
+        chunkColumns = (size_t)1 << 20;
+        numChunksExpected = (length + (int64_t)chunkColumns - 1) / (int64_t)chunkColumns;
+    }
     // The batches come through two stages beside the walk: the device stage (the column kernels, the copies to the host: one call at
     // a time, the next one begun as soon as this one is back, up to a few batches ahead of the walk) and the stage that describes and
     // sorts a batch's rows for the walk (several threads a batch, beside the device stage of the batch behind it).
