@@ -431,6 +431,54 @@ def write_text_at(path, offset, text, total=None):
         os.close(fd)
 
 
+def line_shares(data, world):
+    """`world` contiguous byte ranges of a text, cut behind line ends, in order and covering it: rank r's share of the lines (a line
+    belongs to the share its first byte falls into; the shares' outputs one behind the other are the whole text's output, since a
+    line's lifting knows nothing of the other lines: liftover/impl/halLiftover.cpp:46-92)."""
+    n = len(data)
+    cuts = [0]
+    for r in range(1, world):
+        at = max(cuts[-1], (n * r) // world)
+        if at > 0 and at < n and data[at - 1:at] != b"\n":
+            nl = data.find(b"\n", at)
+            at = n if nl < 0 else nl + 1
+        cuts.append(at)
+    cuts.append(n)
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def convert_sharded(convert, data, out_path, device=None):
+    """One process per GPU, every rank a writer (groups of one: no records move): rank r converts its share of the input's lines
+    (`convert`: bytes -> bytes; hal_amd.liftover_convert on the rank's own handle), an all-gather of the texts' sizes places them
+    (text_placement), the ranks write side by side into `out_path`.  A rank whose share holds a malformed line behaves as the one
+    process does (halLiftoverMain.cpp:143-149: what was lifted before the line is written, then the error): the ranks before it write
+    everything, it writes what it had (the exception's partial_output), the ranks behind it nothing, and every rank raises.
+    Returns the output's size."""
+    device = device or torch.device("cpu")
+    world, rank = dist.get_world_size(), dist.get_rank()
+    lo, hi = line_shares(data, world)[rank]
+    failure = None
+    try:
+        text = convert(data[lo:hi])
+    except Exception as e:  # (the collectives below are still taken part in: the other ranks are waiting in theirs)
+        failure = e
+        text = getattr(e, "partial_output", b"") or b""
+    if isinstance(text, str):
+        text = text.encode()
+    failed = all_gather_counts(1 if failure is not None else 0, device)
+    first_bad = failed.index(1) if 1 in failed else world
+    if rank > first_bad:
+        text = b""
+    offset, total = text_placement(len(text), device)
+    write_text_at(out_path, offset, text, total)
+    dist.barrier()
+    if failure is not None and rank == first_bad:
+        raise failure
+    if first_bad < world:
+        raise RuntimeError("rank %d met a malformed line: the output ends with what was lifted before it" % first_bad)
+    return total
+
+
 def blob_bytes(slot):
     """length of the blob at the start of a slot, from its 32-byte header {"HGXW", u32 format, i64 first_query, u64 n_queries, u64 n_records}"""
     h = slot[:32].cpu().numpy().tobytes()

@@ -349,3 +349,66 @@ def test_two_writers_of_four_ranks_place_their_texts_world4(tmp_path):
 def test_writers_with_a_ragged_last_group_and_groups_of_one(tmp_path):
     _spawn_writers(3, 2, tmp_path)  # groups {0, 1} and {2}
     _spawn_writers(2, 1, tmp_path)  # every rank its own writer: no records move at all
+
+
+class _Malformed(Exception):
+    pass
+
+
+def _stand_in_convert(share):
+    """a line-by-line conversion with a data-dependent number of output lines; a line beginning with '!' is malformed: what came
+    before it is the exception's partial_output (the contract of hal_amd.liftover_convert)"""
+    out = []
+    for line in share.split(b"\n"):
+        if not line:
+            continue
+        if line.startswith(b"!"):
+            e = _Malformed("malformed: " + line.decode())
+            e.partial_output = b"".join(out)
+            raise e
+        for k in range(len(line) % 4):
+            out.append(line.upper() + b"\t%d\n" % k)
+    return b"".join(out)
+
+
+def _sharded_worker(rank, world, port, path, result):
+    from hal_amd.shard import convert_sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(5)
+    lines = [b"chr%d\t%d\t%d" % (rng.integers(1, 20), rng.integers(0, 10 ** 6), rng.integers(0, 10 ** 6)) + b"x" * int(rng.integers(0, 5))
+             for _ in range(997)]
+    ok = True
+    for tail in (b"\n", b""):  # (with and without a newline at the end of the input)
+        data = b"\n".join(lines) + tail
+        total = convert_sharded(_stand_in_convert, data, path)
+        want = _stand_in_convert(data)
+        ok = ok and total == len(want) and open(path, "rb").read() == want
+        dist.barrier()
+    # a malformed line in the middle share: the output ends with what was lifted before it, every rank raises
+    bad = list(lines)
+    bad[500] = b"!" + bad[500]
+    data = b"\n".join(bad) + b"\n"
+    try:
+        convert_sharded(_stand_in_convert, data, path + ".bad")
+        ok = False
+    except _Malformed:
+        ok = ok and rank == 1
+    except RuntimeError:
+        ok = ok and rank != 1
+    ok = ok and open(path + ".bad", "rb").read() == _stand_in_convert(b"\n".join(bad[:500]) + b"\n")
+    result[rank] = ok
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_every_rank_a_writer_of_its_share_of_the_lines_world3(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mgr = mp.Manager()
+    result = mgr.dict()
+    mp.spawn(_sharded_worker, args=(3, port, str(tmp_path / "out.bed"), result), nprocs=3, join=True)
+    assert all(result[r] for r in range(3)), dict(result)

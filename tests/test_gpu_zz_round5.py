@@ -397,3 +397,42 @@ def test_writers_group_through_the_c_abi(hal, tmp_path):
         assert wx.last_bytes == blobw.numel() and torch.equal(blobw.cpu(), blob8.cpu())
     assert comm.all_sizes(123456789012) == [123456789012]
     comm.close()
+
+
+def test_liftover_over_the_ranks_of_a_node_every_rank_a_writer(hal, oracle_bin, tmp_path):
+    """hal_amd.liftover_mp (one process per GPU, the ranks write their shares side by side) with the test box's one rank: the
+    file is halLiftover's; and through the launcher with two processes on this one GPU"""
+    import socket
+    import torch.distributed as dist
+    from hal_amd import liftover_mp
+    from test_gpu_liftover import _rand_alignment
+    al, img = _rand_alignment(hal, tmp_path, 2)
+    src, tgt = al.genome_id("Genome_9"), al.genome_id("Genome_2")
+    seq, _, n = al.sequences(src)[0]
+    rng = np.random.default_rng(9)
+    lines = []
+    for i in range(4000):
+        a = int(rng.integers(0, n - 300))
+        lines.append("%s\t%d\t%d\tn%d\t0\t%s" % (seq, a, a + int(rng.integers(1, 300)), i, "+-"[i & 1]))
+    bed = str(tmp_path / "in.bed")
+    open(bed, "w").write("\n".join(lines) + "\n")
+    want = hal.liftover_convert(al, src, open(bed).read(), tgt)
+    assert want == oracle_liftover(oracle_bin, img, "Genome_9", "Genome_2", open(bed).read(), tmp_path)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        out = str(tmp_path / "out1.bed")
+        assert liftover_mp.run(img, "Genome_9", bed, "Genome_2", out, device=0) == len(want.encode())
+        assert open(out).read() == want
+    finally:
+        dist.destroy_process_group()
+    out2 = str(tmp_path / "out2.bed")
+    env = dict(os.environ, HGX_MP_DEVICE="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), "-m", "hal_amd.liftover_mp", img, "Genome_9", bed, "Genome_2", out2],
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert open(out2).read() == want
