@@ -1,7 +1,7 @@
 """halLiftover over the GPUs of a node, one process per GPU and every process a writer:
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 -m hal_amd.liftover_mp \\
-        [--noDupes] [--outPSL] [--bedType T] <halFile> <srcGenome> <srcBed> <tgtGenome> <tgtBed>
+        <halFile> <srcGenome> <srcBed> <tgtGenome> <tgtBed> [--noDupes] [--outPSL] [--bedType T]
 
 The reference's way to use more hardware is a pool of halLiftover processes over pieces of the BED file whose outputs are put
 together afterwards (stats/halStats.py:16,38; maf/hal2mafMP.py:176-190 for hal2maf); here rank r lifts its share of the lines on

@@ -18,6 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = [
     "tests/test_gpu_zz_round5.py::test_maf_tracks_reference_goldens",
     "tests/test_gpu_zz_round5.py::test_maf_tracks_unique_small",
+    "tests/test_gpu_zz_round5.py::test_hal2maf_over_the_ranks_of_a_node_every_rank_a_writer",  # (1, 2 and 3 processes, for real)
     "tests/test_gpu_zz_round5.py::test_count_dupes_sweep_over_a_polytomy_with_segment_tails",
     "tests/test_gpu_zz_round5.py::test_depth_wig_through_several_chunks[97]",
     "tests/test_gpu_columns.py::test_reference_cli_goldens_hal2maf",

@@ -147,7 +147,7 @@ def test_maf_tracks_unique_small(hal, oracle_bin, tmp_path, monkeypatch):
     img = str(tmp_path / "ms.hgx")
     halfix.write_hgx(img, halfix.random_multiseq_alignment(2, n_genomes=4, root_len=200))
     al = hal.Alignment.open(img, device=0)
-    monkeypatch.setenv("HGX_MAF_CHUNK", "37")
+    monkeypatch.setenv("HGX_MAF_CHUNK", "150")
     n_bytes = 0
     for g in range(al.num_genomes):
         nm = al.genome_name(g)
@@ -436,3 +436,42 @@ def test_liftover_over_the_ranks_of_a_node_every_rank_a_writer(hal, oracle_bin, 
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     assert open(out2).read() == want
+
+
+def test_hal2maf_over_the_ranks_of_a_node_every_rank_a_writer(hal, tmp_path):
+    """hal_amd.maf_mp (hal2mafMP.py's slices, a contiguous run of them a rank, the ranks write side by side): the file is
+    hgx_maf_export_multi's with the same slice size — one rank in process, two and three processes through the launcher on this one
+    GPU; several sequences, --unique, a sub-range"""
+    import socket
+    import torch.distributed as dist
+    from hal_amd import maf_mp
+    img = str(tmp_path / "ms.hgx")
+    halfix.write_hgx(img, halfix.random_multiseq_alignment(4, n_genomes=6))
+    al = hal.Alignment.open(img, device=0)
+    ref = al.num_genomes - 1
+    name = al.genome_name(ref)
+    want_all = hal.maf_export_multi([al], ref, -1, slice_size=37, unique=True)
+    seq, _, slen = max(al.sequences(ref), key=lambda t: t[2])
+    si = [t[0] for t in al.sequences(ref)].index(seq)
+    want_part = hal.maf_export_multi([al], ref, si, start=3, length=slen - 5, slice_size=11, no_dupes=True)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        out = str(tmp_path / "one.maf")
+        assert maf_mp.run(img, out, ref_genome=name, slice_size=37, device=0, unique=True) == len(want_all.encode())
+        assert open(out).read() == want_all
+    finally:
+        dist.destroy_process_group()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for nproc, args, want in ((2, ["--refGenome", name, "--sliceSize", "37", "--unique"], want_all),
+                              (3, ["--refGenome", name, "--refSequence", seq, "--refStart", "3", "--length", str(slen - 5), "--sliceSize", "11", "--noDupes"],
+                               want_part)):
+        out = str(tmp_path / ("mp%d.maf" % nproc))
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+                            "--master-port", str(port), "-m", "hal_amd.maf_mp", img, out] + args,  # (the launcher takes what follows the module for its own until a positional)
+                           cwd=root, env=dict(os.environ, HGX_MP_DEVICE="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        assert open(out).read() == want, (nproc, args)
