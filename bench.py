@@ -1291,7 +1291,7 @@ def main():
             except Exception as e:  # (a leg beside the line, not the line)
                 feats["liftover_psl"] = {"error": str(e)[:300]}
             out["features"] = feats
-        if args.cpu_sample > 0:
+        if args.cpu_sample > 0 and world == 1:  # (the CPU baseline: rank 0 at N = 1 only — with more ranks the others would stand waiting)
             sample = min(args.cpu_sample, nq)
             cpu_tmp = tempfile.TemporaryDirectory()
             img = os.path.join(cpu_tmp.name, "bench.hgx")
