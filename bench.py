@@ -1058,6 +1058,28 @@ def main():
             out["mapping_only"] = mapping_only
         out["timed_step"] = "map+allgather" if exchanging else "map_only"
         out["config"]["batches_in_flight"] = in_flight
+        # The line as it stands is complete (metric, value, roofline); the legs below stand beside it.  Should one of them hang — a
+        # kernel that never ends, a child that cannot be reaped — the line is printed as far as it has got after a quarter of an hour
+        legs_done = None
+        if world == 1:
+            import threading
+            legs_done = threading.Event()
+
+            def line_anyway(line_so_far=out, done=legs_done):
+                if done.wait(900.0):
+                    return
+                for _ in range(5):
+                    try:
+                        snap = json.dumps(dict(line_so_far, secondary_legs="timed out after 900 s: the legs that had finished are here"))
+                        break
+                    except RuntimeError:  # (the main thread added a key meanwhile)
+                        time.sleep(0.05)
+                else:
+                    return
+                sys.stdout.flush()
+                print(snap, flush=True)
+                os._exit(0)
+            threading.Thread(target=line_anyway, daemon=True).start()
         if col_result:
             ncol, col_ms, gather_ms, mean_depth = col_result
             cst = al.columns_depth_stats(src, 0, ncol)
@@ -1373,6 +1395,8 @@ def main():
                 again["path"] = "the column walk and one thread's block state machine (HGX_MAF_SWEEP=0 HGX_MAF_SLICED=0) after the default path failed"
                 leg = again
             out.setdefault("columns", {})["hal2maf_full"] = leg
+        if legs_done is not None:
+            legs_done.set()
     else:
         out = None
     # ---- the collated legs, last and under a watchdog: a collective that hangs or fails here costs these legs, not the line ----
