@@ -256,7 +256,7 @@ def leg_hal2maf_full(args, local=0):
     return leg
 
 
-def run_leg_in_child(name, args, env_extra=None, timeout=420.0):
+def run_leg_in_child(name, args, env_extra=None, timeout=300.0):
     """`python bench.py --leg <name>` in a process of its own; its JSON object, or {"error": ...}"""
     prelude = os.environ.get("HGX_BENCH_PRELUDE", "")  # (the dry run without a GPU installs its fakes in the child too)
     code = "import sys; sys.path.insert(0, %r)\n%s\nimport bench\nbench.main()" % (ROOT, prelude)
