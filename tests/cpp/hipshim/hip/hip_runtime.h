@@ -186,7 +186,8 @@ using std::min;
 
 // ---- runtime ----
 inline hipError_t hipGetDeviceCount(int *n) {
-    *n = 1;
+    const char *e = getenv("HGX_EMULATED_DEVICES"); // (the dry run of bench.py with several ranks: every ordinal is the host)
+    *n = e ? std::max(1, atoi(e)) : 1;
     return hipSuccess;
 }
 inline hipError_t hipSetDevice(int) {

@@ -38,6 +38,10 @@ def install():
         return orig_to(self, *a, **k)
     torch.Tensor.to = to
 
+    import torch.distributed as dist
+    real_init = dist.init_process_group
+    dist.init_process_group = lambda backend=None, **k: real_init("gloo")  # (N ranks on CPU tensors: gloo in the place of RCCL)
+
     import hal_amd
 
     class FakePlan:
@@ -93,7 +97,15 @@ def install():
             return self._keep[:n * 40]
 
         def wire_capacity(self):
-            return 1 << 20
+            return 32 + 2 * self.nq + 8 + 12 * 3 * self.nq
+
+        def wire_blob(self, first_query=0, dst=None, bed_only=False):
+            from hal_amd import shard
+            blob = shard.encode_blob(self._keep.view(-1, 40), self.nq, first_query=first_query, fmt=8 if bed_only else None)
+            if dst is not None:
+                dst[:blob.numel()] = blob
+                blob = dst[:blob.numel()]
+            return blob, int(blob[4])
     hal_amd.LiftoverPlan = FakePlan
     hal_amd.liftover_convert_bytes = lambda al, src, data, tgt, **k: (3 * len(data), 3 * data.count(b"\n"))
     hal_amd.build_phases = lambda: [("a phase", 0.1)]

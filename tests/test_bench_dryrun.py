@@ -9,9 +9,48 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bench_prints_its_line_with_every_leg(tmp_path):
-    lib = str(tmp_path / "libhgx_cpu.so")
+import pytest
+
+
+@pytest.fixture(scope="module")
+def emulation_lib(tmp_path_factory):
+    lib = str(tmp_path_factory.mktemp("emu") / "libhgx_cpu.so")
     subprocess.check_call([os.path.join(ROOT, "tests", "cpp", "build_cpu_emulation.sh"), lib])
+    return lib
+
+
+def test_bench_with_three_ranks(emulation_lib, tmp_path):
+    """the N-rank control flow (python -m torch.distributed.run ... bench.py --gpus N): gloo in the place of RCCL, every ordinal of the
+    emulated device the host — barriers, the slowest rank's time, the rotating batches per rank, the collated legs under their
+    watchdog; ONE line from rank 0, without the CPU baselines (N = 1 only)"""
+    script = tmp_path / "bench_n.py"
+    script.write_text("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+                      "import bench_fakes; bench_fakes.install()\n"
+                      "import bench\n"
+                      "sys.argv = ['bench.py', '--gpus', '3', '--steps', '5', '--warmup', '2', '--scale', '0.002', '--queries', '2000',\n"
+                      "            '--sustained-seconds', '0.05', '--cpu-sample', '500']\n"
+                      "bench.main()\n" % (ROOT, os.path.join(ROOT, "tests", "support")))
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HGX_LIB_PATH=emulation_lib, HGX_COL_GRID="4", HGX_EMULATED_DEVICES="8")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(script)], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-4000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 3 and out["scaling"] == "weak" and out["steps"] == 5 and out["config"]["batches_rotating"] == 4
+    assert out["config"]["parallelism"] == "query-shard x3" and "roofline" in out and "cpu_baseline" not in out
+    for leg in ("collated", "collated_to_writer", "config4_as_stated"):
+        assert out[leg]["value"] > 0, leg
+    assert "collated_legs_error" not in out and "collated_legs" not in out
+
+
+def test_bench_prints_its_line_with_every_leg(emulation_lib, tmp_path):
+    lib = emulation_lib
     code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
             "import bench_fakes; bench_fakes.install()\n"
             "import bench\n"
