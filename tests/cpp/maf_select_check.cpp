@@ -84,6 +84,8 @@ void build(const Image &img, HostTables &H) {
     }
 }
 
+size_t g_uniqueRuns = 0, g_uniqueSplitRuns = 0, g_uniqueColumns[3] = {0, 0, 0}; // runs checked, runs of more than one stretch, columns by class
+
 struct Case {
     int ref;
     bool noAncestors;
@@ -249,6 +251,10 @@ size_t checkCase(const Image &img, const HostTables &H, const Case &cs, size_t &
     std::vector<ColumnRow> want(4096), got(4096), prev, prevMarked;
     int64_t prevMarkedCol = -1;
     size_t failures = 0;
+    // (for the check of --unique below: every column's rows, and which columns are marked)
+    std::vector<ColumnRow> allRows;
+    std::vector<size_t> rowsAt{0};
+    std::vector<char> isMarked;
     auto fail = [&](const char *what, int64_t p) {
         if (failures < 5)
             printf("  DIFFERENT (%s): reference %s, column %lld, noAncestors %d, %zu targets\n", what, img.genomes[(size_t)cs.ref].name.c_str(), (long long)p,
@@ -320,9 +326,84 @@ size_t checkCase(const Image &img, const HostTables &H, const Case &cs, size_t &
             prevMarkedCol = p;
         }
         prev.assign(want.begin(), want.begin() + rows);
+        allRows.insert(allRows.end(), want.begin(), want.begin() + rows);
+        rowsAt.push_back(allRows.size());
+        isMarked.push_back(mark ? 1 : 0);
     }
     if (walker.overflow || err)
         fail("walk overflow", -1);
+    // --unique (unique_stretches, what k_unique_count / k_unique_stretches run): for ranges that begin at several columns f — the
+    // range's first column is a batch's first column and so marked — the stretches of every run against the class of every column
+    // told from the column's own rows (hgx_column_kernels.hpp: k_column_unique_count's rule)
+    for (int64_t f : {(int64_t)0, n / 3, (2 * n) / 3, n - 1}) {
+        if (f < 0 || f >= n)
+            continue;
+        std::vector<uint32_t> candCol, candRow;
+        std::vector<ColumnRow> rows;
+        for (int64_t p = f; p < n; ++p)
+            if (p == f || isMarked[(size_t)p]) {
+                candCol.push_back((uint32_t)(p - f));
+                candRow.push_back((uint32_t)rows.size());
+                rows.insert(rows.end(), allRows.begin() + (std::ptrdiff_t)rowsAt[(size_t)p], allRows.begin() + (std::ptrdiff_t)rowsAt[(size_t)p + 1]);
+            }
+        candRow.push_back((uint32_t)rows.size());
+        unsigned int uerr = 0;
+        UniqueParams U;
+        U.candCol = candCol.data();
+        U.candRow = candRow.data();
+        U.rows = rows.data();
+        U.nCand = (uint32_t)candCol.size();
+        U.n = (uint32_t)(n - f);
+        U.first = f;
+        U.f = f;
+        U.ref = cs.ref;
+        U.maxRefRows = UNIQUE_MAX_REF_ROWS;
+        U.error = &uerr;
+        auto classOf = [&](int64_t p) { // the column's class from its own rows
+            bool inRange = false, left = false;
+            for (size_t i = rowsAt[(size_t)p]; i < rowsAt[(size_t)p + 1]; ++i) {
+                const ColumnRow &r = allRows[i];
+                if (r.genome == cs.ref && r.pos < p) {
+                    if (r.pos >= f)
+                        inRange = true;
+                    else
+                        left = true;
+                }
+            }
+            return inRange ? (uint32_t)COL_SKIPPED : left ? (uint32_t)COL_KEYS_ONLY : (uint32_t)COL_WRITTEN;
+        };
+        for (uint32_t k = 0; k < U.nCand; ++k) {
+            const int64_t h = candCol[k], L = (k + 1 < U.nCand ? (int64_t)candCol[k + 1] : (int64_t)U.n) - h;
+            int64_t covered = 0;
+            bool bad = false;
+            uint32_t last = 99;
+            const bool ok = unique_stretches(U, k, [&](int64_t j, int64_t len, uint32_t cls) {
+                if (j != covered || len <= 0 || cls == last)
+                    bad = true; // (the stretches tile the run, in order, and neighbours differ)
+                last = cls;
+                for (int64_t t = 0; t < len && j + t < L; ++t)
+                    if (classOf(f + h + j + t) != cls)
+                        bad = true;
+                if (j > 0)
+                    ++g_uniqueSplitRuns;
+                g_uniqueColumns[cls] += (size_t)len;
+                covered = j + len;
+            });
+            ++g_uniqueRuns;
+            if (!ok) { // (more reference copies than a lane holds: the batch goes to the walk — fine, but rare)
+                bool many = false;
+                size_t refs = 0;
+                for (uint32_t i = candRow[k]; i < candRow[k + 1]; ++i)
+                    refs += rows[i].genome == cs.ref;
+                many = refs > (size_t)UNIQUE_MAX_REF_ROWS;
+                if (!many)
+                    fail("--unique: the run's reference rows were refused", f + h);
+                continue;
+            }
+            if (bad || covered != L)
+                fail("--unique: the run's stretches are not the columns' classes", f + h);
+        }
+    }
     return failures;
 }
 } // namespace
@@ -360,6 +441,8 @@ int main(int argc, char **argv) {
         printf("FAILED: %zu differences\n", failures);
         return 1;
     }
+    printf("--unique: %zu runs (%zu breaks inside runs), columns passed over %zu, written %zu, walked for their keys %zu\n", g_uniqueRuns,
+           g_uniqueSplitRuns, g_uniqueColumns[0], g_uniqueColumns[1], g_uniqueColumns[2]);
     printf("OK\n");
     return 0;
 }

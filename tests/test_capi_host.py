@@ -449,7 +449,9 @@ def test_maf_rows_by_rank_are_the_walks_rows(hal, tmp_path):
     columns that begin a run from per-base break tracks (hal_amd/csrc/hgx_maf_kernels.hpp).  The same functions compiled for the
     host (tests/cpp/maf_select_check.cpp) against the column walk — the restatement of recursiveUpdate that every MAF golden of
     the reference is reproduced through — on random alignments: every genome as reference, --noAncestors, target sets, a
-    polytomy of twelve children (more than one launch of the break sweep per genome), several sequences a genome, real data."""
+    polytomy of twelve children (more than one launch of the break sweep per genome), several sequences a genome, real data.
+    And --unique: the stretches unique_stretches cuts every run into (ranges beginning at four columns of every genome) against
+    the class of every column told from its own rows."""
     import halfix
     exe = str(tmp_path / "maf_select_check")
     src = os.path.join(ROOT, "hal_amd", "csrc")
@@ -471,4 +473,4 @@ def test_maf_rows_by_rank_are_the_walks_rows(hal, tmp_path):
     images.append(os.path.join(ROOT, "tests", "golden", "ref_mmap", "small.mmap1.0.hal"))
     out = subprocess.run([exe] + [i for i in images if os.path.exists(i)], stdout=subprocess.PIPE).stdout.decode()
     assert out.strip().endswith("OK"), out[-2000:]
-    assert out.count("cases") >= 5
+    assert out.count("cases") >= 5 and "--unique:" in out
