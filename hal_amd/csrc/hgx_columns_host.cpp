@@ -2084,7 +2084,10 @@ bool MafExport::walkSliced(std::ostream &mafStream, Arrivals &A, int refRank, in
         };
         {
             std::vector<std::thread> pool;
-            const unsigned nt = (unsigned)std::min<size_t>(threads, S - 1);
+            size_t toWalk = 0;
+            for (size_t s = 1; s < S; ++s)
+                toWalk += todo[s] != 0;
+            const unsigned nt = (unsigned)std::min<size_t>(threads, std::max<size_t>(toWalk, 1)); // (a thread a slice that is walked)
             for (unsigned t = 1; t < nt; ++t)
                 pool.emplace_back(work);
             work();
