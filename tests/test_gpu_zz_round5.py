@@ -235,7 +235,7 @@ def test_maf_tracks_at_full_size(hal, oracle_bin, tmp_path, monkeypatch):
     # --unique from the same tracks: the range begins inside the genome (copies of its bases left of it: columns walked for their
     # keys only), the generator's paralogs inside it (columns passed over)
     text_u = _unique_both_ways(al, monkeypatch, src, 0, start=a, length=ln, no_ancestors=True)
-    assert 0 < len(text_u) <= len(text)
+    assert text_u.count("\na") > ln // 400  # (columns passed over cut blocks in two: no bound by the plain export's size)
     monkeypatch.setenv("HGX_MAF_SWEEP", "1")
     got_u = al.maf_export(src, 0, start=a + 1_000_000, length=200000, no_ancestors=True, unique=True)
     assert got_u == _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", "Genome_9", "--noAncestors", "--unique", "--refSequence", seq,
