@@ -973,8 +973,8 @@ struct MafExport::RunMachine {
     // from that further on is left out: an estimate for the next round's counts, not a result)
     int64_t countChangeUnderShift(int64_t shift) const {
         int64_t change = 0;
-        for (const KeyUse &u : keyUses)
-            if (u.seen != INT64_MIN && keyEntryAt(u.seen, u.at, shift) != u.found)
+        for (const KeyUse &u : keyUses) // (in the walk's order: a block more or fewer moves the numbers of the blocks behind it)
+            if (u.seen != INT64_MIN && keyEntryAt(u.seen, u.at, shift + change) != u.found)
                 change += u.found ? 1 : -1;
         return change;
     }
