@@ -1945,6 +1945,8 @@ bool MafExport::walkSliced(std::ostream &mafStream, Arrivals &A, int refRank, in
         bool exactWalk = false;        // walked from the very state the slice before it stopped in
         bool exactState = false;       // its machine's count and keys are the one-thread walk's (else: right but for them)
         bool walked = false, reachedEnd = false;
+        int64_t predictedCount = -1, predictedShift = 0; // (HGX_MAF_TIMING: what the count model said of this slice in the round before)
+        size_t predictedLooks = 0;
     };
     std::deque<Slice> slice(S); // (grows between rounds; a round's walks each touch their own)
     // the first slice: the export's own state, its log from the first column on
@@ -2151,12 +2153,20 @@ bool MafExport::walkSliced(std::ostream &mafStream, Arrivals &A, int refRank, in
                         int64_t count = slice[j].count;
                         if (W.startSnap.column >= 0)
                             count += W.countChangeUnderShift(base - (int64_t)W.startSnap.numBlocks);
+                        slice[j].predictedCount = count;
+                        slice[j].predictedShift = W.startSnap.column >= 0 ? base - (int64_t)W.startSnap.numBlocks : 0;
+                        slice[j].predictedLooks = W.keyUses.size();
                         base += count;
                         slice[j + 1].guessBase = base;
                     }
                 }
                 break;
             }
+            if (getenv("HGX_MAF_TIMING") && slice[s].predictedCount >= 0 && slice[s].predictedCount != slice[s].count)
+                std::cerr << "[hgx maf]   round " << rounds << ": slice " << s << " has " << slice[s].count << " blocks, the count model said "
+                          << slice[s].predictedCount << " (from a walk told a count off by " << slice[s].predictedShift << ", " << slice[s].predictedLooks
+                          << " looks at keys' entries)" << std::endl;
+            slice[s].predictedCount = -1;
             slice[s].shift = shift;
             slice[s].exactState = keysExact;
             prevIndex = s;
