@@ -2044,6 +2044,14 @@ bool MafExport::walkSliced(std::ostream &mafStream, Arrivals &A, int refRank, in
             // what the walk before found; the last one goes on whatever it finds)
             int64_t tell = told;
             size_t before = 0;
+            // (HGX_MAF_SLICE_DIFF: where this walk's blocks differ from the blocks the slice's walk before found, told another count)
+            std::vector<std::pair<int64_t, uint32_t>> blocksBefore;
+            int64_t countBefore = -1;
+            if (getenv("HGX_MAF_SLICE_DIFF") && L.R && L.R->startSnap.column >= 0) {
+                for (const RunMachine::BlockLog &b : L.R->batch->blocks)
+                    blocksBefore.emplace_back(b.refIndex, b.numEnts);
+                countBefore = (int64_t)L.R->numBlocksAtStart;
+            }
             for (int attempt = 0;; ++attempt) {
                 L.R.reset(new RunMachine(*this, mafStream, refRank, ranks, (size_t)tell));
                 RunMachine &R = *L.R;
@@ -2062,6 +2070,29 @@ bool MafExport::walkSliced(std::ostream &mafStream, Arrivals &A, int refRank, in
                 tell = std::max<int64_t>(0, tell + baseOf[s] - (int64_t)R.numBlocks);
             }
             RunMachine &R = *L.R;
+            if (countBefore >= 0 && R.startSnap.column >= 0) {
+                static std::mutex diffMu;
+                std::lock_guard<std::mutex> lock(diffMu);
+                const std::vector<RunMachine::BlockLog> &now = R.batch->blocks;
+                size_t i = 0, j = 0, shown = 0;
+                std::cerr << "[hgx maf]   slice " << s << ": blocks " << blocksBefore.size() << " when it began at count " << countBefore << ", " << now.size()
+                          << " at count " << R.numBlocksAtStart << std::endl;
+                while (i < blocksBefore.size() && j < now.size() && shown < 6) {
+                    if (blocksBefore[i].first == now[j].refIndex) {
+                        ++i;
+                        ++j;
+                        continue;
+                    }
+                    std::cerr << "[hgx maf]     before: block " << countBefore + (int64_t)i << " (" << (countBefore + (int64_t)i) % 1000 << " past a thousand) begins at column "
+                              << blocksBefore[i].first << " with " << blocksBefore[i].second << " entries; now: block " << R.numBlocksAtStart + j << " ("
+                              << (R.numBlocksAtStart + j) % 1000 << ") at " << now[j].refIndex << " with " << now[j].numEnts << std::endl;
+                    ++shown;
+                    if (blocksBefore[i].first < now[j].refIndex)
+                        ++i;
+                    else
+                        ++j;
+                }
+            }
             L.toldCount = tell;
             L.walked = true;
             L.reachedEnd = !R.stopped;
