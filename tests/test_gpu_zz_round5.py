@@ -18,6 +18,9 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
+# ---- helpers ----
+
+
 def _oracle(oracle_bin, cmd, img, tmp_path, *args):
     out = str(tmp_path / ("o." + cmd))
     if cmd == "maf":
@@ -52,7 +55,216 @@ def _both_ways(al, monkeypatch, *args, **kw):
     return a
 
 
-# ---- hal2maf's heads from per-base tracks ----
+def _unique_both_ways(al, monkeypatch, *args, **kw):
+    monkeypatch.setenv("HGX_MAF_SWEEP", "1")
+    al.maf_tracks_info(drop=True)
+    a = al.maf_export(*args, unique=True, **kw)
+    info = al.maf_tracks_info()
+    assert info["tracks"] and info["state_unique"].startswith("checked") and info["chunks_served_unique"] >= 1, info
+    monkeypatch.setenv("HGX_MAF_SWEEP", "0")
+    b = al.maf_export(*args, unique=True, **kw)
+    monkeypatch.delenv("HGX_MAF_SWEEP")
+    assert a == b
+    return a
+
+
+def _bed(seq_name, starts, lens, strand, lo, hi):
+    return "".join("%s\t%d\t%d\tq\t0\t%s\n" % (seq_name, int(starts[i]), int(starts[i] + lens[i]), chr(int(strand[i]))) for i in range(lo, hi))
+
+
+# ---- what the round-4 review asked for and no new device code is needed for: the sums' tail (ADVICE), the wig's chunks, config 4 at full size ----
+
+
+def test_count_dupes_sweep_over_a_polytomy_with_segment_tails(hal, oracle_bin, tmp_path, monkeypatch):
+    """--countDupes by the tree sweeps when a genome has more than eight children in scope (k_sweep_up runs once per eight and
+    adds to what the launch before left) and bottom segments whose length leaves one base past a round of lanes (33, 65, 97):
+    the lane at a segment's end must not add a launch's children twice to a base its neighbour of the round before has stored."""
+    import random
+    rnd = random.Random(3)
+    lens = [33, 65, 33, 97, 1, 34, 65, 129, 2, 33]
+    starts = [sum(lens[:i]) for i in range(len(lens))]
+    total = sum(lens)
+    nkids = 12
+    genomes = [None] * (nkids + 1)
+    slots = []
+    for c in range(nkids):
+        tops, pos = [], 0
+        members = {}
+        order = list(range(len(lens))) + [rnd.randrange(len(lens)) for _ in range(4)]  # (every segment once, four of them twice)
+        rnd.shuffle(order)
+        for k, j in enumerate(order):
+            tops.append([pos, lens[j], j, rnd.random() < 0.4, -1])
+            members.setdefault(j, []).append(k)
+            pos += lens[j]
+        for j, ms in members.items():
+            if len(ms) > 1:
+                for a, b in zip(ms, ms[1:] + ms[:1]):
+                    tops[a][4] = b
+        genomes[c + 1] = halfix.simple_genome("L%d" % c, 0, [], pos, [tuple(t) for t in tops], [], seqname="L%d_chr" % c)
+        slots.append({j: (ms[-1], tops[ms[-1]][3]) for j, ms in members.items()})
+    bots = [(starts[j], lens[j], [slots[c][j] for c in range(nkids)]) for j in range(len(lens))]
+    genomes[0] = halfix.simple_genome("Root", -1, list(range(1, nkids + 1)), total, [], bots, seqname="Root_chr")
+    img = str(tmp_path / "poly.hgx")
+    halfix.write_hgx(img, genomes)
+    al = hal.Alignment.open(img, device=0)
+    for g in (0, 1, nkids):
+        name, n = al.genome_name(g), al.genome_length(g)
+        for kw in (dict(count_dupes=True), dict()):
+            monkeypatch.setenv("HGX_DEPTH_SWEEP", "1")
+            a = al.columns_depth(g, 0, n, **kw)
+            monkeypatch.setenv("HGX_DEPTH_SWEEP", "0")
+            assert np.array_equal(a, al.columns_depth(g, 0, n, **kw)), (name, kw)
+        monkeypatch.setenv("HGX_DEPTH_SWEEP", "1")
+        assert al.alignment_depth(g, count_dupes=True) == _oracle(oracle_bin, "depth", img, tmp_path, name, "--countDupes"), name
+        assert al.alignment_depth(g) == _oracle(oracle_bin, "depth", img, tmp_path, name), name
+        assert _both_ways(al, monkeypatch, g) == _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", name), name
+
+
+@pytest.mark.parametrize("chunk", [97, 1000, 4099])
+def test_depth_wig_through_several_chunks(hal, oracle_bin, tmp_path, monkeypatch, chunk):
+    """hgx_alignment_depth hands its values to the line writers chunk by chunk through two page-locked blocks (sixteen million
+    columns a chunk: HGX_WIG_CHUNK sets it): genomes of a few thousand columns through 3 .. a hundred chunks — the device copies,
+    the hand-off and the lines in place — against the oracle's wig and the device values."""
+    al, img = _rand(hal, tmp_path, 6, dna=False, min_segments=240, max_segments=400)
+    monkeypatch.setenv("HGX_WIG_CHUNK", str(chunk))
+    for g in (al.num_genomes - 1, 0, 3):
+        n, name = al.genome_length(g), al.genome_name(g)
+        assert n >= 2 * chunk
+        want = _oracle(oracle_bin, "depth", img, tmp_path, name)
+        assert al.alignment_depth(g) == want, (name, chunk)
+        vals = al.columns_depth(g, 0, n)
+        assert [int(x) for x in want.split("\n")[1:-1]] == vals.tolist()
+        assert al.alignment_depth(g, count_dupes=True) == _oracle(oracle_bin, "depth", img, tmp_path, name, "--countDupes"), (name, chunk)
+        assert al.alignment_depth(g, 0, start=7, length=n // 2, step=3) == \
+            _oracle(oracle_bin, "depth", img, tmp_path, name, "--refSequence", al.sequences(g)[0][0], "--start", "7", "--length", str(n // 2),
+                    "--step", "3")
+
+
+def test_config4_full_size_sample_vs_oracle(hal, oracle_bin, tmp_path):
+    """The FULL-size 50-genome alignment against the oracle itself: the first 5 000 intervals of the shard's batch Genome_44 ->
+    Genome_2 (the default plan: merged table, general intervals, the LDS finishing kernels for the sets of more than 64 pieces),
+    then 1 500 of them without dupes, and halAlignmentDepth of a 100 k-column window."""
+    al = hal.Alignment.random(workload_options(1.0, "cfg4"), device=0)
+    src, tgt = al.genome_id("Genome_44"), al.genome_id("Genome_2")
+    seq_name, seq_start, length = al.sequences(src)[0]
+    assert al.num_genomes == 50 and length > 50_000_000
+    starts, lens, strand = make_queries(length, 1250000, 1234)
+    img = str(tmp_path / "cfg4.hgx")
+    al.save(img)
+    bed = _bed(seq_name, starts, lens, strand, 0, 5000)
+    got = hal.liftover_convert(al, src, bed, tgt)
+    assert got == oracle_liftover(oracle_bin, img, "Genome_44", "Genome_2", bed, tmp_path)
+    assert got.count("\n") > 10 * 5000
+    bed2 = _bed(seq_name, starts, lens, strand, 5000, 6500)
+    assert hal.liftover_convert(al, src, bed2, tgt, traverse_dupes=False) == \
+        oracle_liftover(oracle_bin, img, "Genome_44", "Genome_2", bed2, tmp_path, no_dupes=True)
+    a, ln = length // 2, 100000
+    wig = str(tmp_path / "o.wig")
+    subprocess.check_call([oracle_bin, "depth", img, "Genome_44", wig, "--refSequence", seq_name, "--start", str(a), "--length", str(ln)])
+    assert al.alignment_depth(src, 0, start=a, length=ln) == open(wig).read()
+
+
+# ---- several writers, the tools with one process per GPU ----
+
+
+def test_writers_group_through_the_c_abi(hal, tmp_path):
+    """several writers (hgx_liftover_gather_writers; with the test box's one rank the group is the rank itself) and the sizes that
+    place their texts (hgx_comm_all_sizes): the writer's blob is the blob the root of hgx_liftover_gather gets"""
+    import torch
+    from hal_amd import shard
+    from test_gpu_exchange import _batch
+    from test_gpu_liftover import _rand_alignment
+    al, _ = _rand_alignment(hal, tmp_path, 2)
+    src, tgt, gs, ge, st = _batch(hal, al, 3000, 5)
+    plan = hal.LiftoverPlan(al, src, tgt, max_queries=3000)
+    comm = hal.Comm(hal.Comm.unique_id(), 0, 1, 0)
+    plan.run(gs, ge, st)
+    slot = (plan.wire_capacity() + 7) // 8 * 8
+    gx = shard.SlotExchange(1, 0, slot, "cuda", backend="c_abi", comm=comm, root=0, bed_only=True)
+    gx.submit(plan, first_query=12345)
+    (blob8,) = gx.slots(gx.wait())
+    torch.cuda.synchronize()
+    for group in (1, 2):
+        wx = shard.SlotExchange(1, 0, slot, "cuda", backend="c_abi", comm=comm, group=group, bed_only=True)
+        wx.submit(plan, first_query=12345)
+        buf = wx.wait()
+        torch.cuda.synchronize()
+        (blobw,) = wx.slots(buf)
+        assert wx.last_bytes == blobw.numel() and torch.equal(blobw.cpu(), blob8.cpu())
+    assert comm.all_sizes(123456789012) == [123456789012]
+    comm.close()
+
+
+def test_liftover_over_the_ranks_of_a_node_every_rank_a_writer(hal, oracle_bin, tmp_path):
+    """hal_amd.liftover_mp (one process per GPU, the ranks write their shares side by side) with the test box's one rank: the
+    file is halLiftover's; and through the launcher with two processes on this one GPU"""
+    import socket
+    import torch.distributed as dist
+    from hal_amd import liftover_mp
+    from test_gpu_liftover import _rand_alignment
+    al, img = _rand_alignment(hal, tmp_path, 2)
+    src, tgt = al.genome_id("Genome_9"), al.genome_id("Genome_2")
+    seq, _, n = al.sequences(src)[0]
+    rng = np.random.default_rng(9)
+    lines = []
+    for i in range(4000):
+        a = int(rng.integers(0, n - 300))
+        lines.append("%s\t%d\t%d\tn%d\t0\t%s" % (seq, a, a + int(rng.integers(1, 300)), i, "+-"[i & 1]))
+    bed = str(tmp_path / "in.bed")
+    open(bed, "w").write("\n".join(lines) + "\n")
+    want = hal.liftover_convert(al, src, open(bed).read(), tgt)
+    assert want == oracle_liftover(oracle_bin, img, "Genome_9", "Genome_2", open(bed).read(), tmp_path)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        out = str(tmp_path / "out1.bed")
+        assert liftover_mp.run(img, "Genome_9", bed, "Genome_2", out, device=0) == len(want.encode())
+        assert open(out).read() == want
+    finally:
+        dist.destroy_process_group()
+    out2 = str(tmp_path / "out2.bed")
+    env = dict(os.environ, HGX_MP_DEVICE="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), "-m", "hal_amd.liftover_mp", img, "Genome_9", bed, "Genome_2", out2],
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert open(out2).read() == want
+
+
+# ---- hal2maf's block state machine over slices of the export (host code) ----
+
+
+def test_maf_walk_over_slices_at_full_size(hal, oracle_bin, tmp_path, monkeypatch):
+    """the block state machine over slices of the export side by side (HGX_MAF_SLICED=1: whatever the host's size) on config 3's
+    alignment: 4 M columns in batches of 250 k (16 slices) give the one-thread walk's text, with and without --unique, and a
+    300 k-column stretch of it is the oracle's"""
+    al = hal.Alignment.random(workload_options(1.0, "cfg2", dna="fast"), device=0)
+    src = al.genome_id("Genome_9")
+    seq = al.sequences(src)[0][0]
+    a, ln = 23_000_000, 4_000_000
+    monkeypatch.setenv("HGX_MAF_CHUNK", "250000")
+    for kw in (dict(), dict(unique=True)):
+        monkeypatch.setenv("HGX_MAF_SLICED", "1")
+        sliced = al.maf_export(src, 0, start=a, length=ln, no_ancestors=True, **kw)
+        info = al.maf_tracks_info()["last_export"]
+        assert info["walk"].startswith("slices") and info["slices"] == 16 and info["rounds"] >= 1, info
+        monkeypatch.setenv("HGX_MAF_SLICED", "0")
+        assert sliced == al.maf_export(src, 0, start=a, length=ln, no_ancestors=True, **kw), kw
+        assert al.maf_tracks_info()["last_export"]["walk"] == "one thread"
+    img = str(tmp_path / "cfg2.hgx")
+    al.save(img)
+    monkeypatch.setenv("HGX_MAF_SLICED", "1")
+    monkeypatch.setenv("HGX_MAF_CHUNK", "20000")
+    got = al.maf_export(src, 0, start=a, length=300000, no_ancestors=True)
+    assert got == _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", "Genome_9", "--noAncestors", "--refSequence", seq, "--start", str(a),
+                          "--length", "300000")
+
+
+# ---- hal2maf's heads from per-base tracks (round 5's device code: last, so that nothing above waits behind it) ----
+
 
 def test_maf_tracks_reference_goldens(hal, monkeypatch):
     """the reference's own expected files (maf/tests/expected) through the tracks"""
@@ -127,19 +339,6 @@ def test_maf_tracks_on_int64_tables_and_real_data(hal, oracle_bin, tmp_path, mon
         ln = min(n, 300000)
         assert _both_ways(real, monkeypatch, g, 0, start=n // 5, length=ln) == \
             _oracle(oracle_bin, "maf", rimg, tmp_path, "--refGenome", name, "--refSequence", seq, "--start", str(n // 5), "--length", str(ln)), name
-
-
-def _unique_both_ways(al, monkeypatch, *args, **kw):
-    monkeypatch.setenv("HGX_MAF_SWEEP", "1")
-    al.maf_tracks_info(drop=True)
-    a = al.maf_export(*args, unique=True, **kw)
-    info = al.maf_tracks_info()
-    assert info["tracks"] and info["state_unique"].startswith("checked") and info["chunks_served_unique"] >= 1, info
-    monkeypatch.setenv("HGX_MAF_SWEEP", "0")
-    b = al.maf_export(*args, unique=True, **kw)
-    monkeypatch.delenv("HGX_MAF_SWEEP")
-    assert a == b
-    return a
 
 
 def test_maf_tracks_unique_small(hal, oracle_bin, tmp_path, monkeypatch):
@@ -244,198 +443,6 @@ def test_maf_tracks_at_full_size(hal, oracle_bin, tmp_path, monkeypatch):
     multi = hal.maf_export_multi([al], src, 0, start=a, length=ln, slice_size=500000, no_ancestors=True, unique=True)
     monkeypatch.setenv("HGX_MAF_SWEEP", "0")
     assert multi == hal.maf_export_multi([al], src, 0, start=a, length=ln, slice_size=500000, no_ancestors=True, unique=True)
-
-
-def test_maf_walk_over_slices_at_full_size(hal, oracle_bin, tmp_path, monkeypatch):
-    """the block state machine over slices of the export side by side (HGX_MAF_SLICED=1: whatever the host's size) on config 3's
-    alignment: 4 M columns in batches of 250 k (16 slices) give the one-thread walk's text, with and without --unique, and a
-    300 k-column stretch of it is the oracle's"""
-    al = hal.Alignment.random(workload_options(1.0, "cfg2", dna="fast"), device=0)
-    src = al.genome_id("Genome_9")
-    seq = al.sequences(src)[0][0]
-    a, ln = 23_000_000, 4_000_000
-    monkeypatch.setenv("HGX_MAF_CHUNK", "250000")
-    for kw in (dict(), dict(unique=True)):
-        monkeypatch.setenv("HGX_MAF_SLICED", "1")
-        sliced = al.maf_export(src, 0, start=a, length=ln, no_ancestors=True, **kw)
-        info = al.maf_tracks_info()["last_export"]
-        assert info["walk"].startswith("slices") and info["slices"] == 16 and info["rounds"] >= 1, info
-        monkeypatch.setenv("HGX_MAF_SLICED", "0")
-        assert sliced == al.maf_export(src, 0, start=a, length=ln, no_ancestors=True, **kw), kw
-        assert al.maf_tracks_info()["last_export"]["walk"] == "one thread"
-    img = str(tmp_path / "cfg2.hgx")
-    al.save(img)
-    monkeypatch.setenv("HGX_MAF_SLICED", "1")
-    monkeypatch.setenv("HGX_MAF_CHUNK", "20000")
-    got = al.maf_export(src, 0, start=a, length=300000, no_ancestors=True)
-    assert got == _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", "Genome_9", "--noAncestors", "--refSequence", seq, "--start", str(a),
-                          "--length", "300000")
-
-
-# ---- the tree sweeps with sums over more than eight children ----
-
-def test_count_dupes_sweep_over_a_polytomy_with_segment_tails(hal, oracle_bin, tmp_path, monkeypatch):
-    """--countDupes by the tree sweeps when a genome has more than eight children in scope (k_sweep_up runs once per eight and
-    adds to what the launch before left) and bottom segments whose length leaves one base past a round of lanes (33, 65, 97):
-    the lane at a segment's end must not add a launch's children twice to a base its neighbour of the round before has stored."""
-    import random
-    rnd = random.Random(3)
-    lens = [33, 65, 33, 97, 1, 34, 65, 129, 2, 33]
-    starts = [sum(lens[:i]) for i in range(len(lens))]
-    total = sum(lens)
-    nkids = 12
-    genomes = [None] * (nkids + 1)
-    slots = []
-    for c in range(nkids):
-        tops, pos = [], 0
-        members = {}
-        order = list(range(len(lens))) + [rnd.randrange(len(lens)) for _ in range(4)]  # (every segment once, four of them twice)
-        rnd.shuffle(order)
-        for k, j in enumerate(order):
-            tops.append([pos, lens[j], j, rnd.random() < 0.4, -1])
-            members.setdefault(j, []).append(k)
-            pos += lens[j]
-        for j, ms in members.items():
-            if len(ms) > 1:
-                for a, b in zip(ms, ms[1:] + ms[:1]):
-                    tops[a][4] = b
-        genomes[c + 1] = halfix.simple_genome("L%d" % c, 0, [], pos, [tuple(t) for t in tops], [], seqname="L%d_chr" % c)
-        slots.append({j: (ms[-1], tops[ms[-1]][3]) for j, ms in members.items()})
-    bots = [(starts[j], lens[j], [slots[c][j] for c in range(nkids)]) for j in range(len(lens))]
-    genomes[0] = halfix.simple_genome("Root", -1, list(range(1, nkids + 1)), total, [], bots, seqname="Root_chr")
-    img = str(tmp_path / "poly.hgx")
-    halfix.write_hgx(img, genomes)
-    al = hal.Alignment.open(img, device=0)
-    for g in (0, 1, nkids):
-        name, n = al.genome_name(g), al.genome_length(g)
-        for kw in (dict(count_dupes=True), dict()):
-            monkeypatch.setenv("HGX_DEPTH_SWEEP", "1")
-            a = al.columns_depth(g, 0, n, **kw)
-            monkeypatch.setenv("HGX_DEPTH_SWEEP", "0")
-            assert np.array_equal(a, al.columns_depth(g, 0, n, **kw)), (name, kw)
-        monkeypatch.setenv("HGX_DEPTH_SWEEP", "1")
-        assert al.alignment_depth(g, count_dupes=True) == _oracle(oracle_bin, "depth", img, tmp_path, name, "--countDupes"), name
-        assert al.alignment_depth(g) == _oracle(oracle_bin, "depth", img, tmp_path, name), name
-        assert _both_ways(al, monkeypatch, g) == _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", name), name
-
-
-# ---- halAlignmentDepth's wig text chunk by chunk ----
-
-@pytest.mark.parametrize("chunk", [97, 1000, 4099])
-def test_depth_wig_through_several_chunks(hal, oracle_bin, tmp_path, monkeypatch, chunk):
-    """hgx_alignment_depth hands its values to the line writers chunk by chunk through two page-locked blocks (sixteen million
-    columns a chunk: HGX_WIG_CHUNK sets it): genomes of a few thousand columns through 3 .. a hundred chunks — the device copies,
-    the hand-off and the lines in place — against the oracle's wig and the device values."""
-    al, img = _rand(hal, tmp_path, 6, dna=False, min_segments=240, max_segments=400)
-    monkeypatch.setenv("HGX_WIG_CHUNK", str(chunk))
-    for g in (al.num_genomes - 1, 0, 3):
-        n, name = al.genome_length(g), al.genome_name(g)
-        assert n >= 2 * chunk
-        want = _oracle(oracle_bin, "depth", img, tmp_path, name)
-        assert al.alignment_depth(g) == want, (name, chunk)
-        vals = al.columns_depth(g, 0, n)
-        assert [int(x) for x in want.split("\n")[1:-1]] == vals.tolist()
-        assert al.alignment_depth(g, count_dupes=True) == _oracle(oracle_bin, "depth", img, tmp_path, name, "--countDupes"), (name, chunk)
-        assert al.alignment_depth(g, 0, start=7, length=n // 2, step=3) == \
-            _oracle(oracle_bin, "depth", img, tmp_path, name, "--refSequence", al.sequences(g)[0][0], "--start", "7", "--length", str(n // 2),
-                    "--step", "3")
-
-
-# ---- the full-size 50-genome alignment against the oracle itself ----
-
-def _bed(seq_name, starts, lens, strand, lo, hi):
-    return "".join("%s\t%d\t%d\tq\t0\t%s\n" % (seq_name, int(starts[i]), int(starts[i] + lens[i]), chr(int(strand[i]))) for i in range(lo, hi))
-
-
-def test_config4_full_size_sample_vs_oracle(hal, oracle_bin, tmp_path):
-    """The FULL-size 50-genome alignment against the oracle itself: the first 5 000 intervals of the shard's batch Genome_44 ->
-    Genome_2 (the default plan: merged table, general intervals, the LDS finishing kernels for the sets of more than 64 pieces),
-    then 1 500 of them without dupes, and halAlignmentDepth of a 100 k-column window."""
-    al = hal.Alignment.random(workload_options(1.0, "cfg4"), device=0)
-    src, tgt = al.genome_id("Genome_44"), al.genome_id("Genome_2")
-    seq_name, seq_start, length = al.sequences(src)[0]
-    assert al.num_genomes == 50 and length > 50_000_000
-    starts, lens, strand = make_queries(length, 1250000, 1234)
-    img = str(tmp_path / "cfg4.hgx")
-    al.save(img)
-    bed = _bed(seq_name, starts, lens, strand, 0, 5000)
-    got = hal.liftover_convert(al, src, bed, tgt)
-    assert got == oracle_liftover(oracle_bin, img, "Genome_44", "Genome_2", bed, tmp_path)
-    assert got.count("\n") > 10 * 5000
-    bed2 = _bed(seq_name, starts, lens, strand, 5000, 6500)
-    assert hal.liftover_convert(al, src, bed2, tgt, traverse_dupes=False) == \
-        oracle_liftover(oracle_bin, img, "Genome_44", "Genome_2", bed2, tmp_path, no_dupes=True)
-    a, ln = length // 2, 100000
-    wig = str(tmp_path / "o.wig")
-    subprocess.check_call([oracle_bin, "depth", img, "Genome_44", wig, "--refSequence", seq_name, "--start", str(a), "--length", str(ln)])
-    assert al.alignment_depth(src, 0, start=a, length=ln) == open(wig).read()
-
-
-def test_writers_group_through_the_c_abi(hal, tmp_path):
-    """several writers (hgx_liftover_gather_writers; with the test box's one rank the group is the rank itself) and the sizes that
-    place their texts (hgx_comm_all_sizes): the writer's blob is the blob the root of hgx_liftover_gather gets"""
-    import torch
-    from hal_amd import shard
-    from test_gpu_exchange import _batch
-    from test_gpu_liftover import _rand_alignment
-    al, _ = _rand_alignment(hal, tmp_path, 2)
-    src, tgt, gs, ge, st = _batch(hal, al, 3000, 5)
-    plan = hal.LiftoverPlan(al, src, tgt, max_queries=3000)
-    comm = hal.Comm(hal.Comm.unique_id(), 0, 1, 0)
-    plan.run(gs, ge, st)
-    slot = (plan.wire_capacity() + 7) // 8 * 8
-    gx = shard.SlotExchange(1, 0, slot, "cuda", backend="c_abi", comm=comm, root=0, bed_only=True)
-    gx.submit(plan, first_query=12345)
-    (blob8,) = gx.slots(gx.wait())
-    torch.cuda.synchronize()
-    for group in (1, 2):
-        wx = shard.SlotExchange(1, 0, slot, "cuda", backend="c_abi", comm=comm, group=group, bed_only=True)
-        wx.submit(plan, first_query=12345)
-        buf = wx.wait()
-        torch.cuda.synchronize()
-        (blobw,) = wx.slots(buf)
-        assert wx.last_bytes == blobw.numel() and torch.equal(blobw.cpu(), blob8.cpu())
-    assert comm.all_sizes(123456789012) == [123456789012]
-    comm.close()
-
-
-def test_liftover_over_the_ranks_of_a_node_every_rank_a_writer(hal, oracle_bin, tmp_path):
-    """hal_amd.liftover_mp (one process per GPU, the ranks write their shares side by side) with the test box's one rank: the
-    file is halLiftover's; and through the launcher with two processes on this one GPU"""
-    import socket
-    import torch.distributed as dist
-    from hal_amd import liftover_mp
-    from test_gpu_liftover import _rand_alignment
-    al, img = _rand_alignment(hal, tmp_path, 2)
-    src, tgt = al.genome_id("Genome_9"), al.genome_id("Genome_2")
-    seq, _, n = al.sequences(src)[0]
-    rng = np.random.default_rng(9)
-    lines = []
-    for i in range(4000):
-        a = int(rng.integers(0, n - 300))
-        lines.append("%s\t%d\t%d\tn%d\t0\t%s" % (seq, a, a + int(rng.integers(1, 300)), i, "+-"[i & 1]))
-    bed = str(tmp_path / "in.bed")
-    open(bed, "w").write("\n".join(lines) + "\n")
-    want = hal.liftover_convert(al, src, open(bed).read(), tgt)
-    assert want == oracle_liftover(oracle_bin, img, "Genome_9", "Genome_2", open(bed).read(), tmp_path)
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
-    try:
-        out = str(tmp_path / "out1.bed")
-        assert liftover_mp.run(img, "Genome_9", bed, "Genome_2", out, device=0) == len(want.encode())
-        assert open(out).read() == want
-    finally:
-        dist.destroy_process_group()
-    out2 = str(tmp_path / "out2.bed")
-    env = dict(os.environ, HGX_MP_DEVICE="0")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), "-m", "hal_amd.liftover_mp", img, "Genome_9", bed, "Genome_2", out2],
-                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    assert r.returncode == 0, r.stderr.decode()[-2000:]
-    assert open(out2).read() == want
 
 
 def test_hal2maf_over_the_ranks_of_a_node_every_rank_a_writer(hal, tmp_path):
