@@ -75,7 +75,7 @@ def cpu_baseline(al, src_name, tgt_name, starts, lens, strand, seq_name, sample,
         with open(os.path.join(tmp, "out.bed")) as f:
             text = f.read()
         multi = None
-        cores = os.cpu_count() or 1
+        cores = oracle_pool_size(img)
         if all_cores_sample > 0 and cores > 1:
             per = all_cores_sample // cores
             procs = []
@@ -92,6 +92,54 @@ def cpu_baseline(al, src_name, tgt_name, starts, lens, strand, seq_name, sample,
             multi = {"value": per * cores / max(secs), "unit": "intervals/s", "cores": cores,
                      "sample": "%d intervals over %d oracle processes (mapping time of the slowest process)" % (per * cores, cores)}
     return st, text, multi
+
+
+_T_BENCH = time.time()
+
+
+def _mark(what):
+    """a line of progress on stderr: seconds since the start, memory available (a leg that takes the box down is the last one named)"""
+    avail = ""
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                avail = ", %.0f GB of memory available" % (int(line.split()[1]) / 1048576.0)
+    except OSError:
+        pass
+    sys.stderr.write("[bench +%.1f s%s] %s\n" % (time.time() - _T_BENCH, avail, what))
+    sys.stderr.flush()
+
+
+def oracle_pool_size(img_path):
+    """How many oracle processes may run side by side.  Every one of them loads the whole image into memory of its own (1.1 GB for
+    config 2's alignment with its DNA, several GB for the 50-genome one): one per host core of a 256-thread box is hundreds of GB,
+    and a box driven out of memory dies without a word (profiles/r06_notes.md: every lost GPU box of round 5 and the first of
+    round 6 were running these pools).  The pool is what fits a quarter of the memory that is free now — MemAvailable, and the
+    cgroup's own limit where there is one — at 1.3 times the image's size a process, never more than the cores or 64."""
+    cores = os.cpu_count() or 1
+    try:
+        per = int(1.3 * os.path.getsize(img_path)) + (256 << 20)
+    except OSError:
+        per = 4 << 30
+    avail = None
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                avail = int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    for lim, use in (("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory.current"),
+                     ("/sys/fs/cgroup/memory/memory.limit_in_bytes", "/sys/fs/cgroup/memory/memory.usage_in_bytes")):
+        try:
+            m = open(lim).read().strip()
+            if m != "max":
+                left = int(m) - int(open(use).read().strip())
+                avail = left if avail is None else min(avail, left)
+        except (OSError, ValueError):
+            pass
+    if avail is None:
+        avail = 16 << 30
+    return max(1, min(cores, 64, int(0.25 * avail // per)))
 
 
 def oracle_bin():
@@ -126,7 +174,7 @@ def cpu_columns_baseline(img, kind, ref_name, seq_name, length, tmp, tag, all_co
            "sample": "the oracle's %s over the first %d columns of %s, the column loop's time only (image load and the file excluded)"
                      % ("MafExport::convertSequence --noAncestors" if kind == "maf" else "halAlignmentDepth printSequence", length, ref_name),
            "seconds": st["seconds"]}
-    cores = os.cpu_count() or 1
+    cores = oracle_pool_size(img)
     if all_cores_total > 0 and cores > 1:
         per = max(1, all_cores_total // cores)
         procs = [subprocess.Popen(cmd(os.path.join(tmp, "%s.%d.%s" % (tag, c, kind)), c * per, per), stdout=subprocess.PIPE) for c in range(cores)]
@@ -256,12 +304,16 @@ def leg_hal2maf_full(args, local=0):
     return leg
 
 
+def leg_child_command():
+    """this file, run by this interpreter (nothing from the environment enters the child's code; the dry run without a GPU replaces
+    this function from its own script: tests/support/bench_fakes.py)"""
+    return [sys.executable, os.path.join(ROOT, "bench.py")]
+
+
 def run_leg_in_child(name, args, env_extra=None, timeout=300.0):
     """`python bench.py --leg <name>` in a process of its own; its JSON object, or {"error": ...}"""
-    prelude = os.environ.get("HGX_BENCH_PRELUDE", "")  # (the dry run without a GPU installs its fakes in the child too)
-    code = "import sys; sys.path.insert(0, %r)\n%s\nimport bench\nbench.main()" % (ROOT, prelude)
-    cmd = [sys.executable, "-c", code, "--leg", name, "--scale", str(args.scale), "--cpu-sample", str(args.cpu_sample), "--cpu-columns",
-           str(args.cpu_columns), "--cpu-all-cores", str(args.cpu_all_cores)]
+    cmd = leg_child_command() + ["--leg", name, "--scale", str(args.scale), "--cpu-sample", str(args.cpu_sample), "--cpu-columns",
+                                 str(args.cpu_columns), "--cpu-all-cores", str(args.cpu_all_cores)]
     try:
         r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, **(env_extra or {})), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
     except subprocess.TimeoutExpired:
@@ -534,6 +586,7 @@ def main():
     d_ge = (starts + lens - 1 + seq_start).to(dev)
     d_st = strand.to(dev)
 
+    _mark("cold")
     # ---- cold: a fresh plan with the default policy, one pass over the batch (whatever the policy does on its first
     # batch — here it builds the table of the whole path and its merged form — is inside the time).  The process has run the
     # same code once before on a 1 %-scale alignment, so the one-time loading of HIP code objects (≈120 ms in a fresh
@@ -718,6 +771,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    _mark("with an exchange in the step")
     # ---- with an exchange in the step: the same steps without it (what the ranks map when nobody collates) ----
     mapping_only = None
     if exchanging:
@@ -735,6 +789,7 @@ def main():
                                 "shards are independent, so this is what the ranks map; `value` includes collating every rank's records "
                                 "on every rank, which the links bound (%.1f MB per rank and step)" % (wire["bytes"] / 1e6)}
 
+    _mark("N ranks without an exchange in the step")
     # ---- N ranks without an exchange in the step: the same steps with every rank's records collated on every rank ----
     # (these two legs carry collectives that no multi-GPU node has run yet: they are made at the very end, under a watchdog, so that
     # whatever happens to them the line with everything else is printed — see the end of main)
@@ -763,6 +818,7 @@ def main():
                             "rank (%s), overlapped with the next batches: bound by the links, not by the kernels; not part of `value`"
                             % ("hgx_liftover_exchange: RCCL from the library" if args.exchange == "c_abi" else "torch.distributed")}
 
+    _mark("the same steps with every rank's records gathered on rank 0")
     # ---- the same steps with every rank's records gathered on rank 0 only, in the 8-byte form: what a writer of the BED file needs
     # (a rank sends its blob once; nobody receives N of them) ----
     def leg_to_writer():
@@ -794,6 +850,7 @@ def main():
         del wx
         return res
 
+    _mark("sustained")
     # ---- sustained: the same step for a couple of seconds (a region long enough for outside observers: rocm-smi, the driver) ----
     sustained = None
     if args.sustained_seconds > 0 and not exchanging:
@@ -805,6 +862,7 @@ def main():
             drain()
         dt_s, _ = timed_steps(all_steps, 1, sync)
         sustained = {"steps": k, "seconds": dt_s, "value": nq * k / dt_s, "ms_per_step": 1e3 * dt_s / k, "in_flight": in_flight}
+    _mark("cached")
     # ---- cached: ONE batch through two plans again and again (`value` up to round 4): inputs, tables and even the records written
     # (165 MB per plan) stay in the 256 MiB Infinity Cache, and FETCH_SIZE counts what is served from there ----
     cached = None
@@ -836,6 +894,7 @@ def main():
                           "plan fits the 256 MiB Infinity Cache; `value` rotates %d distinct batches with buffers of their own" % K}
         del plan_c, c_plans
 
+    _mark("the same number of steps through ONE plan, batch after batch")
     # ---- the same number of steps through ONE plan, batch after batch (what `value` was before batches were kept in flight) ----
     one_plan = None
     if in_flight == 2:
@@ -859,6 +918,7 @@ def main():
             for k, v in sorted(kt_one.items(), key=lambda kv: -kv[1]["ms"])]
         plan.set_timing(1)
 
+    _mark("kernel times")
     # ---- kernel times: the steps of the timed region again with HIP events around every launch (untimed) — through one plan, in
     # the form the batches in flight are launched in (no pass for the general intervals in front, see one_plan) ----
     n_kt = (max(args.steps, 4 * K) + K - 1) // K * K  # (every batch of the rotation as often as the others)
@@ -912,6 +972,7 @@ def main():
         kept = {}  # the beginnings of the timed column legs' texts, for their parity gates
         st = plan.stats()
         value = world * nq * args.steps / elapsed
+        _mark("walk")
         # ---- walk: the level-by-level kernels (HGX_COMPOSED_UP=0), the "per-query-interval graph chase" itself.  Its
         # dereference counts are also the SURVEY 8(d) figure of the batch: algorithmic bytes are a property of the input,
         # counted by the reference's own walk, whatever the timed plan reads instead. ----
@@ -1108,6 +1169,7 @@ def main():
                                                    "piece that reaches it (50-genome alignments).  sweeps_own_*: what the two sweeps themselves must move "
                                                    "(bench.py: sweep_design_bytes: the per-base genome-set tracks written and read once, the segment "
                                                    "records, the 4-byte depths).  traffic: k_sweep_up launches only; per-GPU figures when n_gpus > 1"}}
+        _mark("hal2maf over the first columns")
         if want_maf:
             # halAlignmentDepth as the tool delivers it: the wig text of the whole genome in host memory (values over PCIe, the lines made
             # by the host's threads)
@@ -1134,6 +1196,7 @@ def main():
             out.setdefault("columns", {})["hal2maf"] = {"metric": "MAF columns/sec (hal2maf --refGenome %s --noAncestors, end to end to MAF text in host memory)" % src_name,
                                                         "value": ncols / dt_m, "unit": "columns/s", "columns": ncols, "seconds": dt_m,
                                                         "maf_bytes": nbytes}
+        _mark("wide: int64 tables")
         if args.wide and world == 1 and not args.exchange_selftest:
             # the reference's own coordinate width (hal_index_t = int64, api/inc/halDefs.h:34; what an alignment with a genome of
             # 2^31 bases or more — every mammalian one — runs on): the same alignment, batch and steps on int64 tables
@@ -1152,6 +1215,7 @@ def main():
                 w["one_plan"]["ratio_to_int32"] = w["one_plan"]["ms_per_step"] / one_plan["ms_per_step"]
             out["wide"] = w
             del alw
+        _mark("configs 4 and 5 on the 50-genome alignment")
         if args.cfg4 and world == 1 and not args.exchange_selftest and args.workload == "cfg2":
             # BASELINE configs 4 and 5 on this GPU: one GPU's 1.25 M-interval shard of the 10 M intervals Genome_44 -> Genome_2 on the
             # 50-genome alignment, and the whole-genome depth scan of Genome_44
@@ -1189,6 +1253,7 @@ def main():
             except Exception as e:  # (a leg beside the line, not the line)
                 out["cfg5"]["wig"] = {"error": str(e)[:300]}
                 wig4_head = None
+            _mark("config 5: the oracle's depth loop (cpu_baseline)")
             if args.cpu_columns_cfg5 > 0 and args.cpu_sample > 0:
                 # the CPU figure beside config 5, and its parity gate: the oracle's halAlignmentDepth loop over the genome's first columns
                 try:
@@ -1204,6 +1269,7 @@ def main():
                 except Exception as e:
                     out["cfg5"]["cpu_baseline"] = {"error": str(e)[:300]}
             del al4, d4
+        _mark("the text path")
         if args.text_path and world == 1 and not args.exchange_selftest:
             # Liftover::convert as halLiftover runs it: BED text in, BED text out (parse, H2D, kernels, D2H, format), PCIe inclusive
             sn, ln, tn = starts.numpy(), lens.numpy(), strand.numpy()
@@ -1220,6 +1286,7 @@ def main():
                                          "in host memory (tokenise, H2D, kernels, D2H, render; PCIe inclusive, never `value`); best of 3",
                                  "value": nq / best_t, "unit": "intervals/s", "seconds": best_t, "lines_in": nq, "lines_out": out_lines,
                                  "bytes_in": len(bed), "bytes_out": out_bytes, "host_threads": min(64, os.cpu_count() or 1)}
+        _mark("features")
         if args.features and want_maf:
             # the other entry points of the path, each as a number: halGetBlocksInTargetRange (a browser's call: latency per call and
             # ranges per second when a call carries many), hal2maf --unique (what hal2mafMP.py runs every slice with), --maxRefGap,
@@ -1320,6 +1387,7 @@ def main():
             al.save(img)
             cst, text, multi = cpu_baseline(al, src_name, tgt_name, starts, lens, strand, seq_name, sample,
                                             all_cores_sample=min(nq, 4 * sample) if args.cpu_all_cores else 0, img=img)
+            _mark("the CPU figures beside the column metric")
             # ---- the CPU figures beside the column metric ("MAF columns/sec ... vs CPU ref"), each with the parity gate of the timed leg
             # it stands beside: the oracle's loops over the reference genome's first --cpu-columns columns ----
             ncc = min(args.cpu_columns, al.genome_length(src))
@@ -1349,6 +1417,7 @@ def main():
                             out["columns"]["hal2maf"]["cpu_baseline"] = basem
                     except Exception as e:
                         out["columns"]["hal2maf_cpu_baseline"] = {"error": str(e)[:300]}
+            _mark("halGetBlocksInTargetRange on the CPU")
             # ---- halGetBlocksInTargetRange on the CPU: the oracle's getBlocksInTargetRange, a call per range, the same ranges ----
             if "features" in out and "blocks_in_target_range" in out["features"]:
                 try:
@@ -1384,6 +1453,7 @@ def main():
                                    "parity_with_gpu": gpu_text == text}
             if multi:
                 out["cpu_baseline"]["all_cores"] = multi
+        _mark("config 3 in a child process")
         if want_maf and args.maf_full:
             # BASELINE config 3 as stated: hal2maf over the full reference genome — in a process of its own (leg_hal2maf_full), the last
             # thing this rank does: the line above is complete whatever becomes of it.  Should it fail with round 5's device stage and
@@ -1399,6 +1469,7 @@ def main():
             legs_done.set()
     else:
         out = None
+    _mark("the collated legs, last and under a watchdog")
     # ---- the collated legs, last and under a watchdog: a collective that hangs or fails here costs these legs, not the line ----
     want_collated = synced and not exchanging and world > 1
     want_writer = synced and (world > 1 or bool(args.exchange_selftest))

@@ -7,6 +7,7 @@
 #include <atomic>
 #include <sstream>
 #include <chrono>
+#include <ctime>
 #include <climits>
 #include <cstdlib>
 #include <charconv>
@@ -1584,8 +1585,9 @@ void MafExport::RunMachine::flush(const PRow *current) {
             M._pendingWrite.get();
         const size_t inFlight = batch->blocks.empty() ? 0 : (size_t)rendersInFlight();
         while (M._pendingWrites.size() > (inFlight ? inFlight - 1 : 0)) {
-            M._pendingWrites.front().get();
+            std::future<void> f = std::move(M._pendingWrites.front()); // (out of the deque first: get() may throw, and an invalid future must not stay behind)
             M._pendingWrites.pop_front();
+            f.get();
         }
         g_mafRenderWait += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
     }
@@ -2104,11 +2106,28 @@ bool MafExport::walkSliced(std::ostream &mafStream, Arrivals &A, int refRank, in
                 L.count = 0;
             }
         };
+        const bool timing = getenv("HGX_MAF_TIMING") != nullptr;
+        const auto tRound = std::chrono::steady_clock::now();
+        std::vector<double> sliceWall(timing ? S : 0, 0.0), sliceCpu(timing ? S : 0, 0.0);
+        auto threadCpu = []() {
+            timespec ts;
+            clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+            return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+        };
         auto work = [&]() {
             try {
                 for (size_t s; (s = next.fetch_add(1)) < S;)
-                    if (todo[s])
+                    if (todo[s]) {
+                        if (!timing) {
+                            walkSlice(s);
+                            continue;
+                        }
+                        const auto w0 = std::chrono::steady_clock::now();
+                        const double c0 = threadCpu();
                         walkSlice(s);
+                        sliceCpu[s] = threadCpu() - c0;
+                        sliceWall[s] = std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+                    }
             } catch (...) {
                 std::lock_guard<std::mutex> lock(failureMu);
                 if (!failure)
@@ -2129,6 +2148,24 @@ bool MafExport::walkSliced(std::ostream &mafStream, Arrivals &A, int refRank, in
         }
         if (failure)
             std::rethrow_exception(failure);
+        if (timing) { // (who the round waited for: the longest walk, and whether its thread was running all that time)
+            size_t walked = 0, longest = 0;
+            double sumWall = 0, sumCpu = 0;
+            for (size_t s = 1; s < S; ++s)
+                if (sliceWall[s] > 0) {
+                    ++walked;
+                    sumWall += sliceWall[s];
+                    sumCpu += sliceCpu[s];
+                    if (sliceWall[s] > sliceWall[longest])
+                        longest = s;
+                }
+            std::cerr << "[hgx maf]   round " << rounds << ": " << walked << " walk(s) of " << S << " slices in "
+                      << std::chrono::duration<double>(std::chrono::steady_clock::now() - tRound).count() << " s (begun "
+                      << std::chrono::duration<double>(tRound - t0).count() << " s in); a walk " << (walked ? sumWall / (double)walked : 0.0) << " s on average, of which on a core "
+                      << (walked ? sumCpu / (double)walked : 0.0) << " s; the longest (slice " << longest << ") " << sliceWall[longest] << " s, on a core " << sliceCpu[longest] << " s"
+                      << std::endl;
+        }
+        const auto tCheck = std::chrono::steady_clock::now();
         // does every slice begin as the one before it ended?  (a slice whose walk ran to the export's end has everything behind it)
         settled = true;
         std::fill(todo.begin(), todo.end(), 0);
@@ -2206,7 +2243,12 @@ bool MafExport::walkSliced(std::ostream &mafStream, Arrivals &A, int refRank, in
             ended = slice[s].reachedEnd;
             prev = &R;
         }
+        const auto tFlushSettled = std::chrono::steady_clock::now();
         flushSettled(settled ? S : frontier);
+        if (timing)
+            std::cerr << "[hgx maf]   round " << rounds << ": comparing the slices' ends " << std::chrono::duration<double>(tFlushSettled - tCheck).count()
+                      << " s, handing the settled ones to the renderers " << std::chrono::duration<double>(std::chrono::steady_clock::now() - tFlushSettled).count() << " s"
+                      << std::endl;
         // the batches that arrived meanwhile come into play: behind the slices that are walked again, or — when every slice in play
         // is settled and the export goes on — after waiting for the next one, its slice walked from the state the last one stopped in
         {
@@ -2535,6 +2577,12 @@ void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alig
                 pipe.cv.notify_all();
             }
             feeder.t.join();
+            // the batches settled so far are being rendered from rows that `arrivals` and the slices' machines keep alive: no thread of
+            // theirs may outlive this frame (their own failures are secondary to the one on its way out)
+            try {
+                waitPendingWrite();
+            } catch (...) {
+            }
             throw;
         }
         feeder.t.join();

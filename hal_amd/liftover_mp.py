@@ -69,7 +69,9 @@ def main(argv=None):
     try:
         run(a.halFile, a.srcGenome, a.srcBed, a.tgtGenome, a.tgtBed, no_dupes=a.noDupes, out_psl=a.outPSL, bed_type=a.bedType)
     except Exception as e:
-        sys.stderr.write("hal exception caught: %s\n" % e)
+        from hal_amd import shard
+        if not isinstance(e, shard.PeerFailed):  # (the rank that met the line prints the one message, numbered in the whole file)
+            sys.stderr.write("hal exception caught: %s\n" % e)
         return 1
     finally:
         dist.destroy_process_group()

@@ -4,6 +4,7 @@ api/impl/halColumnIterator.cpp:785-787), and the single exchange step that colla
 (SURVEY 8(e)): an all-gather of per-rank counts, then an all-gather of payloads padded to the largest shard; for writers of text
 one gather to a root, or to several writers whose texts are placed by their sizes (SlotExchange(group=), text_placement).
 torch.distributed is the transport (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests)."""
+import re
 import torch
 import torch.distributed as dist
 
@@ -473,10 +474,34 @@ def convert_sharded(convert, data, out_path, device=None):
     write_text_at(out_path, offset, text, total)
     dist.barrier()
     if failure is not None and rank == first_bad:
-        raise failure
+        raise renumbered(failure, data[:lo])
     if first_bad < world:
-        raise RuntimeError("rank %d met a malformed line: the output ends with what was lifted before it" % first_bad)
+        raise PeerFailed("rank %d met a malformed line: the output ends with what was lifted before it" % first_bad)
     return total
+
+
+class PeerFailed(RuntimeError):
+    """another rank's share held the malformed line: that rank reports it (the one process prints one message)"""
+
+
+_BED_LINE_SUFFIX = re.compile(r"( in input bed line )(\d+)$")
+
+
+def renumbered(failure, before):
+    """The library numbers the lines of the text it was given; a rank's share begins inside the file.  The reference's scanner counts
+    the lines it reads, and skips white space between them (liftover/impl/halBedScanner.cpp:47-59): the share's number plus the
+    lines of `before` (the input in front of the share) that are not blank."""
+    msg = str(failure)
+    m = _BED_LINE_SUFFIX.search(msg)
+    if not m or not before:
+        return failure
+    ahead = sum(1 for ln in before.split(b"\n") if ln.strip())
+    if ahead == 0:
+        return failure
+    out = type(failure)(msg[:m.start()] + m.group(1) + str(int(m.group(2)) + ahead))
+    for k, v in getattr(failure, "__dict__", {}).items():
+        setattr(out, k, v)
+    return out
 
 
 def blob_bytes(slot):

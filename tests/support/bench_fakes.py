@@ -10,6 +10,16 @@ import numpy as np
 import torch
 
 
+def install_leg_child(bench):
+    """the child process of a leg (bench.run_leg_in_child) installs these fakes too: the dry run's own script says so — bench.py takes
+    nothing of the kind from its environment"""
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\nimport bench_fakes; bench_fakes.install()\nimport bench\nbench.main()"
+            % (bench.ROOT, here))
+    bench.leg_child_command = lambda: [sys.executable, "-c", code]
+
+
 def install():
     real_device = torch.device
     cpu = real_device("cpu")

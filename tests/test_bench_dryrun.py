@@ -54,11 +54,11 @@ def test_bench_prints_its_line_with_every_leg(emulation_lib, tmp_path):
     code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
             "import bench_fakes; bench_fakes.install()\n"
             "import bench\n"
+            "bench_fakes.install_leg_child(bench)\n"
             "sys.argv = ['bench.py', '--steps', '6', '--warmup', '2', '--scale', '0.002', '--queries', '3000', '--maf-columns', '20000',\n"
             "            '--cpu-sample', '500', '--cpu-columns', '20000', '--cpu-columns-cfg5', '5000', '--sustained-seconds', '0.05']\n"
             "bench.main()\n") % (ROOT, os.path.join(ROOT, "tests", "support"))
-    prelude = "sys.path.insert(0, %r); import bench_fakes; bench_fakes.install()" % os.path.join(ROOT, "tests", "support")
-    env = dict(os.environ, HGX_LIB_PATH=lib, HGX_COL_GRID="4", HGX_MAF_SWEEP="1", HGX_BENCH_PRELUDE=prelude)  # (the child of the hal2maf_full leg too)
+    env = dict(os.environ, HGX_LIB_PATH=lib, HGX_COL_GRID="4", HGX_MAF_SWEEP="1")
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 0, r.stderr.decode()[-4000:]
     line = r.stdout.decode().strip().splitlines()[-1]

@@ -359,11 +359,13 @@ def _stand_in_convert(share):
     """a line-by-line conversion with a data-dependent number of output lines; a line beginning with '!' is malformed: what came
     before it is the exception's partial_output (the contract of hal_amd.liftover_convert)"""
     out = []
+    n_read = 0  # (the library numbers the lines of the text it is given, blank ones not counted: halBedScanner.cpp:47-59)
     for line in share.split(b"\n"):
-        if not line:
+        if not line.strip():
             continue
+        n_read += 1
         if line.startswith(b"!"):
-            e = _Malformed("malformed: " + line.decode())
+            e = _Malformed("malformed: " + line.decode() + " in input bed line %d" % n_read)
             e.partial_output = b"".join(out)
             raise e
         for k in range(len(line) % 4):
@@ -389,15 +391,22 @@ def _sharded_worker(rank, world, port, path, result):
     # a malformed line in the middle share: the output ends with what was lifted before it, every rank raises
     bad = list(lines)
     bad[500] = b"!" + bad[500]
+    bad.insert(10, b"")  # (a blank line in the first rank's share: read over, not counted)
+    bad.insert(300, b"  ")
     data = b"\n".join(bad) + b"\n"
     try:
         convert_sharded(_stand_in_convert, data, path + ".bad")
         ok = False
-    except _Malformed:
-        ok = ok and rank == 1
+    except _Malformed as e:
+        # the message is the one process's: the line's number in the whole file, not in the rank's share
+        ok = ok and rank == 1 and str(e).endswith(" in input bed line 501") and e.partial_output is not None
+        try:
+            _stand_in_convert(data)
+        except _Malformed as whole:
+            ok = ok and str(whole) == str(e)
     except RuntimeError:
         ok = ok and rank != 1
-    ok = ok and open(path + ".bad", "rb").read() == _stand_in_convert(b"\n".join(bad[:500]) + b"\n")
+    ok = ok and open(path + ".bad", "rb").read() == _stand_in_convert(b"\n".join(bad[:502]) + b"\n")
     result[rank] = ok
     dist.barrier()
     dist.destroy_process_group()
