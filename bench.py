@@ -115,8 +115,7 @@ def oracle_pool_size(img_path):
     config 2's alignment with its DNA, several GB for the 50-genome one): one per host core of a 256-thread box is hundreds of GB,
     and a box driven out of memory dies without a word (profiles/r06_notes.md: every lost GPU box of round 5 and the first of
     round 6 were running these pools).  The pool is what fits a quarter of the memory that is free now — MemAvailable, and the
-    cgroup's own limit where there is one — at 1.3 times the image's size a process, never more than the cores or 64."""
-    cores = os.cpu_count() or 1
+    cgroup's own limit where there is one — at 1.3 times the image's size a process, never more than the CPUs the process may keep busy (host_cpus) or 64."""
     try:
         per = int(1.3 * os.path.getsize(img_path)) + (256 << 20)
     except OSError:
@@ -139,7 +138,30 @@ def oracle_pool_size(img_path):
             pass
     if avail is None:
         avail = 16 << 30
-    return max(1, min(cores, 64, int(0.25 * avail // per)))
+    return max(1, min(host_cpus(), 64, int(0.25 * avail // per)))
+
+
+def host_cpus():
+    """the CPUs this process may keep busy: os.cpu_count() cut to its affinity mask and to the cgroup's CPU quota (the GPU boxes'
+    containers: 256 hardware threads under cpu.max = "1600000 100000", i.e. 16 — more processes than that only take turns)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(p))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                n = min(n, max(1, -(-q // p)))
+        except (OSError, ValueError):
+            pass
+    return n
 
 
 def oracle_bin():
@@ -1285,7 +1307,7 @@ def main():
             out["end_to_end"] = {"what": "hgx_liftover_convert = Liftover::convert: BED6 text of the batch in host memory -> lifted BED text "
                                          "in host memory (tokenise, H2D, kernels, D2H, render; PCIe inclusive, never `value`); best of 3",
                                  "value": nq / best_t, "unit": "intervals/s", "seconds": best_t, "lines_in": nq, "lines_out": out_lines,
-                                 "bytes_in": len(bed), "bytes_out": out_bytes, "host_threads": min(64, os.cpu_count() or 1)}
+                                 "bytes_in": len(bed), "bytes_out": out_bytes, "host_threads": min(64, host_cpus())}
         _mark("features")
         if args.features and want_maf:
             # the other entry points of the path, each as a number: halGetBlocksInTargetRange (a browser's call: latency per call and

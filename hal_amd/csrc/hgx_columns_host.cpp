@@ -607,7 +607,7 @@ void MafExport::flushSnapshots(std::ostream &os) {
     static const char rc[17] = "tgcan\0\0\0TGCAN\0\0\0";
     static const PairTable fwd2(fwd, false), rc2(rc, true);
     const size_t nb = _snapBlocks.size();
-    unsigned nt = std::thread::hardware_concurrency();
+    unsigned nt = hostThreads();
     nt = std::max(1u, std::min(nt ? nt : 1u, 16u));
     if (nb < 256)
         nt = 1;
@@ -1568,13 +1568,26 @@ static int rendersInFlight() { // batches rendered at a time (HGX_MAF_RENDERS_IN
     const char *e = getenv("HGX_MAF_RENDERS_IN_FLIGHT");
     if (e)
         return std::max(1, atoi(e));
-    return std::thread::hardware_concurrency() >= 64 ? 4 : 2;
+    return hostThreads() >= 64 ? 4 : 2;
 }
 static size_t describeThreads(size_t heads) { // the threads that describe and sort a device batch's rows (HGX_MAF_DESCRIBE_THREADS)
     if (const char *e = getenv("HGX_MAF_DESCRIBE_THREADS"))
         return (size_t)std::max(1, atoi(e));
     return heads >= 32768 ? 8 : heads >= 4096 ? 4 : 1;
 }
+// (HGX_MAF_TIMING: the CPU time the export's stages used, summed over their threads — what a host with a CPU quota has to pay for)
+static std::atomic<long long> g_cpuWalkNs{0}, g_cpuRenderNs{0}, g_cpuCopyNs{0}, g_cpuDescribeNs{0}, g_cpuDeviceNs{0};
+struct CpuScope {
+    std::atomic<long long> &to;
+    long long t0;
+    static long long now() {
+        timespec ts;
+        clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+        return (long long)ts.tv_sec * 1000000000ll + ts.tv_nsec;
+    }
+    explicit CpuScope(std::atomic<long long> &a) : to(a), t0(now()) {}
+    ~CpuScope() { to.fetch_add(now() - t0, std::memory_order_relaxed); }
+};
 static double g_mafFlush = 0; // (HGX_MAF_TIMING: the walk's thread in flush(): names, hand-over, without the wait for the batch before)
 static double g_mafRenderWait = 0; // (HGX_MAF_TIMING: how long the walk stood waiting for the batch before to be rendered)
 void MafExport::RunMachine::flush(const PRow *current) {
@@ -1632,9 +1645,9 @@ void MafExport::RunMachine::flush(const PRow *current) {
         static const char rc[17] = "tgcan\0\0\0TGCAN\0\0\0";
         static const PairTable fwd2(fwd, false), rc2(rc, true);
         const size_t nb = work->blocks.size();
-        unsigned nt = std::thread::hardware_concurrency();
+        unsigned nt = hostThreads();
         nt = std::max(1u, std::min(nt ? nt : 1u, (unsigned)renderThreads()));
-        nt = std::max(1u, std::min(nt, (std::thread::hardware_concurrency() + (unsigned)rendersInFlight() - 1) / (unsigned)rendersInFlight()));
+        nt = std::max(1u, std::min(nt, (hostThreads() + (unsigned)rendersInFlight() - 1) / (unsigned)rendersInFlight()));
         if (nb < 256)
             nt = 1;
         // (the rendering threads' buffers are kept from batch to batch: thirty megabytes of fresh pages per batch were as many page
@@ -1797,7 +1810,10 @@ void MafExport::RunMachine::flush(const PRow *current) {
         };
         BulkSink *const sink = dynamic_cast<BulkSink *>(out->rdbuf());
         if (nt == 1) {
-            render(0);
+            {
+                CpuScope cpu(g_cpuRenderNs);
+                render(0);
+            }
             order->wait(ticket);
             out->write(text[0].data, (std::streamsize)text[0].len);
         } else {
@@ -1813,12 +1829,16 @@ void MafExport::RunMachine::flush(const PRow *current) {
             std::vector<std::thread> th;
             for (unsigned t = 0; t < nt; ++t)
                 th.emplace_back([&, t]() {
-                    render(t);
+                    {
+                        CpuScope cpu(g_cpuRenderNs);
+                        render(t);
+                    }
                     std::unique_lock<std::mutex> lock(mu);
                     ++rendered;
                     cv.notify_all();
                     cv.wait(lock, [&]() { return placed; });
                     lock.unlock();
+                    CpuScope cpu(g_cpuCopyNs);
                     if (dst)
                         memcpy(dst + at[t], text[t].data, text[t].len);
                 });
@@ -1966,10 +1986,13 @@ bool MafExport::walkSliced(std::ostream &mafStream, Arrivals &A, int refRank, in
         if (!R.stopped && R.appendCount > 0)
             R.endBlock();
     };
-    walkFrom(first, 0, 0);
+    {
+        CpuScope cpu(g_cpuWalkNs);
+        walkFrom(first, 0, 0);
+    }
     slice[0].count = (int64_t)(first.stopped ? first.endSnap.numBlocks : first.numBlocks);
     slice[0].reachedEnd = !first.stopped;
-    unsigned threads = std::thread::hardware_concurrency();
+    unsigned threads = hostThreads();
     threads = std::max(1u, std::min(threads ? threads : 1u, threads >= 96 ? 64u : 32u));
     if (const char *e = getenv("HGX_MAF_WALK_THREADS"))
         threads = (unsigned)std::max(1, atoi(e));
@@ -2115,6 +2138,7 @@ bool MafExport::walkSliced(std::ostream &mafStream, Arrivals &A, int refRank, in
             return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
         };
         auto work = [&]() {
+            CpuScope cpu(g_cpuWalkNs);
             try {
                 for (size_t s; (s = next.fetch_add(1)) < S;)
                     if (todo[s]) {
@@ -2344,13 +2368,13 @@ void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alig
     // more on a host of thirty-two threads or more; HGX_MAF_SLICED=1 / 0 forces / forbids it
     int64_t numChunksExpected = (length + (int64_t)chunkColumns - 1) / (int64_t)chunkColumns;
     // (a round of walks takes one slice's time when every slice has a thread: hosts of 32 threads or more)
-    bool wantHeadCols = numChunksExpected >= 8 && numChunksExpected <= 512 && length >= ((int64_t)16 << 20) && std::thread::hardware_concurrency() >= 32;
+    bool wantHeadCols = numChunksExpected >= 8 && numChunksExpected <= 512 && length >= ((int64_t)16 << 20) && hostThreads() >= 8;
     if (const char *e = getenv("HGX_MAF_SLICED"))
         wantHeadCols = atoi(e) != 0; // (1: whatever the export's size — with two batches or more; the tests and the soaks)
     // Slices are batches, and a round takes one slice's walk: where the host has a thread for each of twice as many slices, batches of
     // half the columns halve the rounds' time (full-size config 3 on the CPU replay: 53 slices settle in 12-14 rounds where 27 take
     // 9-10 — how far a round's guesses hold is a matter of columns, not of slices)
-    if (wantHeadCols && !getenv("HGX_MAF_CHUNK") && chunkColumns == ((size_t)1 << 21) && std::thread::hardware_concurrency() >= 96 &&
+    if (wantHeadCols && !getenv("HGX_MAF_CHUNK") && chunkColumns == ((size_t)1 << 21) && hostThreads() >= 96 &&
         length >= ((int64_t)16 << 20)) {
         chunkColumns = (size_t)1 << 20;
         numChunksExpected = (length + (int64_t)chunkColumns - 1) / (int64_t)chunkColumns;
@@ -2363,6 +2387,7 @@ void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alig
         HeadRows headRows;
     };
     auto deviceStage = [&](int64_t done) {
+        CpuScope cpu(g_cpuDeviceNs);
         std::unique_ptr<Raw> raw(new Raw);
         raw->c.reset(new Chunk);
         Chunk *c = raw->c.get();
@@ -2416,6 +2441,7 @@ void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alig
         return raw;
     };
     auto describeStage = [this, alignment, wantHeadCols](std::shared_ptr<Raw> raw) {
+        CpuScope cpuAll(g_cpuDescribeNs);
         const auto t0 = std::chrono::steady_clock::now();
         Chunk *c = raw->c.get();
         const HeadRows &headRows = raw->headRows;
@@ -2428,6 +2454,7 @@ void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alig
                     c->headCol.push_back((uint32_t)i);
         }
         auto convert = [&](size_t h0, size_t h1) {
+            std::unique_ptr<CpuScope> cpu(h0 > 0 ? new CpuScope(g_cpuDescribeNs) : nullptr); // (the helpers' threads; the first share runs under cpuAll)
             for (size_t h = h0; h < h1; ++h) {
                 for (size_t i = c->headOff[h]; i < c->headOff[h + 1]; ++i)
                     RunMachine::describe(alignment->img, _rank, c->rows[i], headRows[i].genome, headRows[i].pos, headRows[i].rev != 0,
@@ -2607,7 +2634,10 @@ void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alig
                 fetchSeconds += c->seconds;
                 numHeads += c->headOff.size() - 1;
             }
-            R.walkChunk(c, 0, startPosition);
+            {
+                CpuScope cpu(g_cpuWalkNs);
+                R.walkChunk(c, 0, startPosition);
+            }
             done += n;
         }
         if (R.appendCount > 0)
@@ -2624,6 +2654,19 @@ void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alig
     }
     waitPendingWrite();
     mafStream.flush();
+    if (getenv("HGX_MAF_TIMING")) {
+        std::cerr << "[hgx maf] CPU seconds of the export's stages (all their threads; " << hostThreads() << " host threads to go by): device stage's thread "
+                  << 1e-9 * (double)g_cpuDeviceNs.exchange(0) << ", describing and sorting rows " << 1e-9 * (double)g_cpuDescribeNs.exchange(0) << ", walks "
+                  << 1e-9 * (double)g_cpuWalkNs.exchange(0) << ", rendering " << 1e-9 * (double)g_cpuRenderNs.exchange(0) << ", copying the text into place "
+                  << 1e-9 * (double)g_cpuCopyNs.exchange(0) << "; the export took " << std::chrono::duration<double>(std::chrono::steady_clock::now() - tStart).count()
+                  << " s" << std::endl;
+    } else {
+        g_cpuDeviceNs = 0;
+        g_cpuDescribeNs = 0;
+        g_cpuWalkNs = 0;
+        g_cpuRenderNs = 0;
+        g_cpuCopyNs = 0;
+    }
     {
         char buf[640];
         snprintf(buf, sizeof buf,

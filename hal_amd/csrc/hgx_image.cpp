@@ -7,6 +7,7 @@
 
 namespace hgx {
 
+
 // api/impl/halCommon.cpp:224-235: a,c,g,t,n -> 0..4, upper case +8, everything else 'n'
 const uint8_t dnaPackMap[256] = {
     4, 4, 4, 4, 4,  4, 4, 4, 4, 4, 4,  4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4,  4, 4,

@@ -19,13 +19,14 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+#include "hgx_host_threads.hpp"
 
 namespace hgx {
 
 // fn(g) for every genome g < n on a few threads (a genome's tables are converted and checked on their own; what fn throws for the
 // genome with the smallest index comes out, as if the genomes had been gone through in order)
 template <class Fn> void forEachGenome(size_t n, Fn fn) {
-    unsigned nt = std::thread::hardware_concurrency();
+    unsigned nt = hostThreads();
     nt = (unsigned)std::min<size_t>(std::max(1u, std::min(nt ? nt : 1u, 16u)), n);
     if (nt <= 1) {
         for (size_t g = 0; g < n; ++g)

@@ -14,6 +14,7 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include "hgx_host_threads.hpp"
 
 namespace hgx {
 
@@ -44,7 +45,7 @@ inline char *wigLine(char *o, int32_t v) {
 template <class Room> void wigLines(std::ostream &os, const int32_t *vals, int64_t count, Room room, unsigned maxThreads = 64) {
     if (count <= 0)
         return;
-    unsigned nt = std::thread::hardware_concurrency();
+    unsigned nt = hostThreads();
     nt = std::max(1u, std::min(nt ? nt : 1u, maxThreads));
     nt = (unsigned)std::min<int64_t>(nt, (count + 65535) / 65536); // (a thread per 64 k lines at least)
     std::vector<size_t> bytes(nt + 1, 0);
