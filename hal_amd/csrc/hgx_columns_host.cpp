@@ -809,6 +809,9 @@ struct MafExport::RunMachine {
     struct RankInfo {
         int64_t nameId = -1, srcLength = 0, seqStart = 0;
         int32_t genome = 0, seq = 0;
+        // what every row of the sequence's begins with and what stands between its strand and its bases ("s\t<name>\t", "\t<length of
+        // the sequence>\t": halMafBlock.cpp:499-520 prints them field by field), made once when the sequence is first met
+        std::string rowHead, rowTail;
     };
     struct BlockLog {
         uint32_t firstEnt, numEnts, firstEvent, numEvents;
@@ -1125,6 +1128,8 @@ struct MafExport::RunMachine {
                 M._names.push_back(name);
             }
             ri.nameId = it->second;
+            ri.rowHead = "s\t" + name + "\t";
+            ri.rowTail = "\t" + std::to_string(S.length) + "\t";
             ri.srcLength = S.length;
             ri.seqStart = S.start;
             ri.genome = genome;
@@ -1520,6 +1525,42 @@ struct MafExport::RunMachine {
     void flush(const PRow *current = nullptr);
 };
 
+// a row's start and length as decimal text, two digits at a time (std::to_chars was a sixth of the rendering threads' time)
+static inline char *mafNumber(char *o, int64_t v) {
+    static const struct Pairs {
+        char d[200];
+        Pairs() {
+            for (int i = 0; i < 100; ++i) {
+                d[2 * i] = (char)('0' + i / 10);
+                d[2 * i + 1] = (char)('0' + i % 10);
+            }
+        }
+    } pairs;
+    uint64_t u = (uint64_t)v;
+    if (v < 0) {
+        *o++ = '-';
+        u = 0 - u;
+    }
+    char tmp[24];
+    int n = 0;
+    while (u >= 100) {
+        const uint64_t q = u / 100;
+        const unsigned r = (unsigned)(u - q * 100);
+        tmp[n++] = pairs.d[2 * r + 1];
+        tmp[n++] = pairs.d[2 * r];
+        u = q;
+    }
+    if (u >= 10) {
+        tmp[n++] = pairs.d[2 * u + 1];
+        tmp[n++] = pairs.d[2 * u];
+    } else {
+        tmp[n++] = (char)('0' + u);
+    }
+    while (n > 0)
+        *o++ = tmp[--n];
+    return o;
+}
+
 namespace {
 struct TextBuffer {
     char *data = nullptr;
@@ -1682,27 +1723,59 @@ void MafExport::RunMachine::flush(const PRow *current) {
             std::vector<RowOut> rows;
             std::vector<Entry::Seg> segs;
             std::vector<const PRow *> given;
+            // A block lists every entry the walk still remembered (MafBlock keeps an entry for thirteen blocks after its last base:
+            // 29 entries a block on config 3) and gives bases to six or seven of them: only those are rows of the text.  stamp[j] == b + 1:
+            // entry j was given a base in block b and is number slot[j] among them.
+            std::vector<uint32_t> stamp, slot, touched;
+            const std::vector<uint8_t> *dnaOf = nullptr;
             for (size_t b = nb * t / nt; b < nb * (t + 1) / nt; ++b) {
                 const BlockLog &B = work->blocks[b];
                 const EventLog *ev = work->events.data() + B.firstEvent;
                 rows.clear();
                 segs.clear();
+                touched.clear();
                 int64_t columns = 0;
                 for (uint32_t e = 0; e < B.numEvents; ++e)
                     columns += ev[e].k;
-                // which base every entry was given at every event (the walk logs the other direction)
-                given.assign((size_t)B.numEvents * B.numEnts, nullptr);
+                if (stamp.size() < B.numEnts) {
+                    stamp.resize(B.numEnts, 0);
+                    slot.resize(B.numEnts, 0);
+                }
+                const uint32_t mark = (uint32_t)(b - nb * t / nt) + 1;
                 for (uint32_t e = 0; e < B.numEvents; ++e) {
                     const uint32_t *idx = work->rowEnt.data() + ev[e].firstIdx;
                     for (uint32_t r = 0; r < ev[e].nRows; ++r)
-                        given[(size_t)e * B.numEnts + idx[r]] = ev[e].rows + r;
+                        if (stamp[idx[r]] != mark) {
+                            stamp[idx[r]] = mark;
+                            touched.push_back(idx[r]);
+                        }
                 }
-                // appendColumn / updateEntry (halMafBlock.cpp:114-138, 370-395) for every entry, the row kept as runs
-                for (uint32_t j = 0; j < B.numEnts; ++j) {
+                // (the text's order is the entries' order)
+                for (size_t i = 1; i < touched.size(); ++i) {
+                    const uint32_t x = touched[i];
+                    size_t j = i;
+                    for (; j > 0 && touched[j - 1] > x; --j)
+                        touched[j] = touched[j - 1];
+                    touched[j] = x;
+                }
+                const size_t nT = touched.size();
+                for (size_t i = 0; i < nT; ++i)
+                    slot[touched[i]] = (uint32_t)i;
+                // which base every such entry was given at every event (the walk logs the other direction)
+                given.assign((size_t)B.numEvents * nT, nullptr);
+                for (uint32_t e = 0; e < B.numEvents; ++e) {
+                    const uint32_t *idx = work->rowEnt.data() + ev[e].firstIdx;
+                    for (uint32_t r = 0; r < ev[e].nRows; ++r)
+                        given[(size_t)e * nT + slot[idx[r]]] = ev[e].rows + r;
+                }
+                // appendColumn / updateEntry (halMafBlock.cpp:114-138, 370-395) for every entry that was given a base, the row kept as
+                // runs; rows[i] belongs to entry touched[i]
+                for (size_t i = 0; i < nT; ++i) {
                     RowOut r{NULL_INDEX, 0, (uint32_t)segs.size(), 0, false};
-                    const RankInfo &ri = (*ranks)[(size_t)work->entRank[B.firstEnt + j]];
+                    const RankInfo &ri = (*ranks)[(size_t)work->entRank[B.firstEnt + touched[i]]];
+                    dnaOf = &al->img.genomes[(size_t)ri.genome].dna;
                     for (uint32_t e = 0; e < B.numEvents; ++e) {
-                        const PRow *p = given[(size_t)e * B.numEnts + j];
+                        const PRow *p = given[(size_t)e * nT + i];
                         const int64_t k = ev[e].k;
                         const uint8_t kind = !p ? 0 : ((p->key & 1) ? 2 : 1);
                         if (p) {
@@ -1722,6 +1795,10 @@ void MafExport::RunMachine::flush(const PRow *current) {
                                 continue;
                             }
                         }
+                        // (the packed bases lie anywhere in fifty megabytes a genome: asked for now, they are there when the row is
+                        // written — the rows' misses overlap instead of following one another)
+                        if (kind && !dnaOf->empty())
+                            __builtin_prefetch(dnaOf->data() + (pos >> 1));
                         for (int64_t left = k, at = pos; left > 0;) { // (a run longer than 2^31 - 1 columns is split)
                             const int64_t m = std::min<int64_t>(left, INT32_MAX - 1);
                             segs.push_back(Entry::Seg{at, (int32_t)m, kind});
@@ -1734,29 +1811,24 @@ void MafExport::RunMachine::flush(const PRow *current) {
                 }
                 if (B.refEnt < 0)
                     continue;
-                if (!keepEmptyRefBlocks && rows[(size_t)B.refEnt].start == NULL_INDEX)
+                const uint32_t ref = (uint32_t)B.refEnt;
+                const bool refGiven = stamp[ref] == mark; // (else the reference's row is all gaps)
+                if (!keepEmptyRefBlocks && !refGiven)
                     continue; // referenceIsAllGaps (halMafExport.cpp:70, 85)
                 // MafBlock's operator<< (halMafBlock.cpp:499-520): the reference row first, then the entries that have a start
-                auto row = [&](uint32_t j, int64_t start) {
-                    const RowOut &r = rows[j];
+                auto row = [&](const RowOut &r, uint32_t j, int64_t start) {
                     const RankInfo &ri = (*ranks)[(size_t)work->entRank[B.firstEnt + j]];
-                    const std::string &nm = *(*names)[(size_t)ri.nameId];
-                    char *o = buf.room(nm.size() + 96 + (size_t)columns);
+                    char *o = buf.room(ri.rowHead.size() + ri.rowTail.size() + 64 + (size_t)columns);
                     char *const o0 = o;
-                    auto num = [&](int64_t v) { o = std::to_chars(o, o + 24, v).ptr; };
-                    *o++ = 's';
+                    memcpy(o, ri.rowHead.data(), ri.rowHead.size());
+                    o += ri.rowHead.size();
+                    o = mafNumber(o, start);
                     *o++ = '\t';
-                    memcpy(o, nm.data(), nm.size());
-                    o += nm.size();
-                    *o++ = '\t';
-                    num(start);
-                    *o++ = '\t';
-                    num(r.length);
+                    o = mafNumber(o, r.length);
                     *o++ = '\t';
                     *o++ = r.rev ? '-' : '+';
-                    *o++ = '\t';
-                    num(ri.srcLength);
-                    *o++ = '\t';
+                    memcpy(o, ri.rowTail.data(), ri.rowTail.size());
+                    o += ri.rowTail.size();
                     const std::vector<uint8_t> &d = al->img.genomes[(size_t)ri.genome].dna;
                     const uint8_t *pk = d.data();
                     for (uint32_t g = 0; g < r.numSegs; ++g) {
@@ -1794,16 +1866,23 @@ void MafExport::RunMachine::flush(const PRow *current) {
                 };
                 memcpy(buf.room(2), "a\n", 2);
                 buf.len += 2;
-                const uint32_t ref = (uint32_t)B.refEnt;
-                if (rows[ref].start == NULL_INDEX) {
-                    if (B.refIndex != NULL_INDEX)
-                        row(ref, B.refIndex);
+                if (!refGiven) {
+                    if (B.refIndex != NULL_INDEX) { // (a row of gaps, as long as the block)
+                        RowOut gaps{NULL_INDEX, 0, (uint32_t)segs.size(), 0, false};
+                        for (int64_t left = columns; left > 0;) {
+                            const int64_t m = std::min<int64_t>(left, INT32_MAX - 1);
+                            segs.push_back(Entry::Seg{0, (int32_t)m, 0});
+                            left -= m;
+                        }
+                        gaps.numSegs = (uint32_t)segs.size() - gaps.firstSeg;
+                        row(gaps, ref, B.refIndex);
+                    }
                 } else {
-                    row(ref, rows[ref].start);
+                    row(rows[slot[ref]], ref, rows[slot[ref]].start);
                 }
-                for (uint32_t j = 0; j < B.numEnts; ++j)
-                    if (rows[j].start != NULL_INDEX && j != ref)
-                        row(j, rows[j].start);
+                for (size_t i = 0; i < nT; ++i)
+                    if (touched[i] != ref)
+                        row(rows[i], touched[i], rows[i].start);
                 *buf.room(1) = '\n';
                 buf.len += 1;
             }
