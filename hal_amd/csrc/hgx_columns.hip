@@ -3,6 +3,7 @@
 #include "hgx_column_kernels.hpp"
 #include "hgx_gap_kernels.hpp"
 #include "hgx_maf_kernels.hpp"
+#include "hgx_maf_render_kernels.hpp"
 #include "hgx_scan_kernels.hpp"
 #include "hgx_columns_engine.hpp"
 #include "hgx_liftover_engine.hpp"
@@ -1274,6 +1275,132 @@ static void columnsHeadRowsWalk(hgx_alignment *h, int ref, int64_t first, int64_
         stats->rows += totalRows;
         stats->columns += (uint64_t)count;
     }
+}
+
+
+// ---- hal2maf's text on the device (hgx_maf_render_kernels.hpp) ----
+namespace {
+// streams of the rendering calls: a call takes one and gives it back (made without the null stream's implicit waits: the device
+// stage's launches on the null stream and a batch's rendering have nothing to wait for in each other)
+struct RenderStreams {
+    std::mutex mu;
+    std::vector<std::pair<int, hipStream_t>> idle;
+};
+RenderStreams &renderStreams() {
+    static RenderStreams *r = new RenderStreams; // (never destroyed: the runtime may be gone by then)
+    return *r;
+}
+struct RenderStream {
+    int device;
+    hipStream_t s = nullptr;
+    explicit RenderStream(int dev) : device(dev) {
+        RenderStreams &R = renderStreams();
+        {
+            std::lock_guard<std::mutex> lock(R.mu);
+            for (size_t i = 0; i < R.idle.size(); ++i)
+                if (R.idle[i].first == dev) {
+                    s = R.idle[i].second;
+                    R.idle.erase(R.idle.begin() + (std::ptrdiff_t)i);
+                    return;
+                }
+        }
+        HIP_OK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    }
+    ~RenderStream() {
+        RenderStreams &R = renderStreams();
+        std::lock_guard<std::mutex> lock(R.mu);
+        R.idle.emplace_back(device, s);
+    }
+};
+} // namespace
+
+bool mafRenderDevice(hgx_alignment *h, const MafRenderInput &in, char *&text, size_t &bytes) {
+    text = nullptr;
+    bytes = 0;
+    if (!h->dev || in.numBlocks == 0 || in.numBlocks >= (1ull << 31) || in.slots >= (1ull << 31) || in.numRows >= (1ull << 32) ||
+        in.numRowEnt >= (1ull << 32) || in.numEvents >= (1ull << 32))
+        return false;
+    HIP_OK(hipSetDevice(h->dev->device));
+    if (h->dev->dna.empty() && !h->img.genomes.empty()) {
+        bool any = false;
+        for (const GenomeTables &G : h->img.genomes)
+            any = any || !G.dna.empty();
+        if (any)
+            return false; // (the bases are not on the device: the export's device stage puts them there; a caller without one renders itself)
+    }
+    RenderStream stream(h->dev->device);
+    hipStream_t s = stream.s;
+    const uint32_t nb = (uint32_t)in.numBlocks;
+    auto up = [&](Buf &b, const void *src, size_t n) {
+        b.resize(std::max<size_t>(n, 16));
+        if (n)
+            HIP_OK(hipMemcpyAsync(b.p, src, n, hipMemcpyHostToDevice, s));
+    };
+    Buf dBlocks, dEntRank, dEvents, dRowEnt, dRows, dRanks, dChars;
+    up(dBlocks, in.blocks, in.numBlocks * sizeof(MafRenderBlock));
+    up(dEntRank, in.entRank, in.numEntRank * 4);
+    up(dEvents, in.events, in.numEvents * sizeof(MafRenderEvent));
+    up(dRowEnt, in.rowEnt, in.numRowEnt * 4);
+    up(dRows, in.rows, in.numRows * sizeof(MafRenderRow));
+    up(dRanks, in.ranks, in.numRanks * sizeof(MafRenderRank));
+    up(dChars, in.chars, in.numChars);
+    Buf dLen((size_t)nb * 4), dOff(((size_t)nb + 1) * 4), dSums(((size_t)nb / SCAN_BLOCK + 2) * 4), dRowOff(std::max<size_t>(in.slots, 1) * 4),
+        dSlotBlock(std::max<size_t>(in.slots, 1) * 4), dCtl(16);
+    HIP_OK(hipMemsetAsync(dCtl.p, 0, 16, s));
+    MafRenderParams P;
+    P.blocks = (const MafRenderBlock *)dBlocks.p;
+    P.entRank = (const int32_t *)dEntRank.p;
+    P.events = (const MafRenderEvent *)dEvents.p;
+    P.rowEnt = (const uint32_t *)dRowEnt.p;
+    P.rows = (const MafRenderRow *)dRows.p;
+    P.ranks = (const MafRenderRank *)dRanks.p;
+    P.chars = (const char *)dChars.p;
+    P.desc = h->dev->desc;
+    P.numBlocks = nb;
+    P.slots = (uint32_t)in.slots;
+    P.keepEmptyRefBlocks = in.keepEmptyRefBlocks ? 1 : 0;
+    P.blockLen = (uint32_t *)dLen.p;
+    P.blockOff = (const uint32_t *)dOff.p;
+    P.rowOff = (uint32_t *)dRowOff.p;
+    P.slotBlock = (uint32_t *)dSlotBlock.p;
+    P.total = (unsigned long long *)dCtl.p;
+    P.error = (unsigned int *)((char *)dCtl.p + 8);
+    P.text = nullptr;
+    const int gridB = (int)std::max<int64_t>(1, std::min<int64_t>(COL_GRID, ((int64_t)nb + 255) / 256));
+    hipLaunchKernelGGL(k_maf_render_sizes, dim3(gridB), dim3(256), 0, s, P);
+    {
+        const uint32_t tiles = (nb + SCAN_BLOCK - 1) / SCAN_BLOCK;
+        hipLaunchKernelGGL(k_scan_block_sums, dim3(tiles), dim3(256), 0, s, (const uint32_t *)dLen.p, nb, (uint32_t *)dSums.p);
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, (uint32_t *)dSums.p, tiles, (uint32_t *)dOff.p + nb);
+        hipLaunchKernelGGL(k_scan_apply, dim3(tiles), dim3(256), 0, s, (const uint32_t *)dLen.p, nb, (const uint32_t *)dSums.p, (uint32_t *)dOff.p);
+    }
+    struct {
+        unsigned long long total;
+        unsigned int error, pad;
+    } ctl{0, 0, 0};
+    HIP_OK(hipMemcpyAsync(&ctl, dCtl.p, 16, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    if (ctl.error || ctl.total >= (1ull << 32))
+        return false; // (offsets of 32 bits: a batch of four gigabytes of text is the rendering threads')
+    bytes = (size_t)ctl.total;
+    if (bytes == 0) {
+        text = static_cast<char *>(hostBlockTake(1));
+        return true;
+    }
+    Buf dText(bytes);
+    P.text = (char *)dText.p;
+    const int gridS = (int)std::max<int64_t>(1, std::min<int64_t>(2 * COL_GRID, ((int64_t)in.slots + 255) / 256));
+    hipLaunchKernelGGL(k_maf_render_rows, dim3(gridS), dim3(256), 0, s, P);
+    char *host = static_cast<char *>(hostBlockTake(bytes));
+    hipError_t e = hipMemcpyAsync(host, dText.p, bytes, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+        hostBlockGive(host);
+        throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e) + " while a batch's MAF text was rendered on the device");
+    }
+    text = host;
+    return true;
 }
 
 } // namespace hgx

@@ -105,6 +105,49 @@ void columnsHeadRowsHost(hgx_alignment *h, int ref, int64_t first, int64_t count
 // made by sweeps over whole genomes, hgx_maf_kernels.hpp, when the export is long enough for them to pay; HGX_MAF_SWEEP=1 / 0
 // forces / forbids them)
 
+// hal2maf's text on the device (hgx_maf_render_kernels.hpp): the walk's log of a batch of blocks — every array in host memory, in the
+// layouts of that header — becomes the batch's MAF text, which comes back in a page-locked block (hostBlockGive it).  false: not on
+// this handle or at this size (no device, the bases not on it, a batch of four gigabytes of text): the caller renders it itself.
+struct MafRenderBlock { // RunMachine::BlockLog + where the block's entries' slots begin
+    uint32_t firstEnt, numEnts, firstEvent, numEvents;
+    int32_t refEnt;
+    uint32_t slotBase;
+    int64_t refIndex;
+};
+struct MafRenderEvent { // RunMachine::EventLog with the rows' place in the batch's packed rows
+    int64_t k;
+    uint32_t rowsOff, firstIdx, nRows, _pad;
+};
+struct MafRenderRow { // RunMachine::PRow
+    int64_t key;
+    int32_t rank;
+    uint32_t ord;
+};
+struct MafRenderRank { // RunMachine::RankInfo: the sequence of a rank, and the two pieces of text every row of it carries
+    int64_t seqStart, srcLength;
+    int32_t genome;
+    uint32_t headOff, headLen, tailOff, tailLen, _pad;
+};
+struct MafRenderInput {
+    const MafRenderBlock *blocks = nullptr;
+    size_t numBlocks = 0;
+    const int32_t *entRank = nullptr;
+    size_t numEntRank = 0;
+    const MafRenderEvent *events = nullptr;
+    size_t numEvents = 0;
+    const uint32_t *rowEnt = nullptr;
+    size_t numRowEnt = 0;
+    const MafRenderRow *rows = nullptr;
+    size_t numRows = 0;
+    const MafRenderRank *ranks = nullptr;
+    size_t numRanks = 0;
+    const char *chars = nullptr;
+    size_t numChars = 0;
+    size_t slots = 0; // the blocks' entries, counted block by block (MafRenderBlock::slotBase)
+    bool keepEmptyRefBlocks = false;
+};
+bool mafRenderDevice(hgx_alignment *h, const MafRenderInput &in, char *&text, size_t &bytes);
+
 // the per-base tracks kept with the handle for hal2maf (hgx_columns.hip: MafTracks), as a JSON object; and letting go of them
 std::string mafTracksInfo(hgx_alignment *h);
 void mafTracksDrop(hgx_alignment *h);

@@ -1523,6 +1523,8 @@ struct MafExport::RunMachine {
     // hands the batch to the rendering threads (beside the walk: the previous batch is waited for first); current: the column
     // the next block begins with
     void flush(const PRow *current = nullptr);
+    static bool renderOnDevice(const Batch &work, const std::vector<RankInfo> &ranks, const hgx_alignment *al, bool keepEmptyRefBlocks, char *&text,
+                               size_t &bytes);
 };
 
 // a row's start and length as decimal text, two digits at a time (std::to_chars was a sixth of the rendering threads' time)
@@ -1605,11 +1607,14 @@ std::string mafLastExportInfo() {
     std::lock_guard<std::mutex> lock(lastExport().mu);
     return lastExport().json;
 }
+static bool deviceRenderWanted();
 static int rendersInFlight() { // batches rendered at a time (HGX_MAF_RENDERS_IN_FLIGHT): their threads share the host's
     const char *e = getenv("HGX_MAF_RENDERS_IN_FLIGHT");
     if (e)
         return std::max(1, atoi(e));
-    return hostThreads() >= 64 ? 4 : 2;
+    // (four where the host has the threads — and wherever the text is rendered on the device: a batch's task then waits for
+    // the device most of its time, and config 3 on the GPU box's 16 CPUs went from 0.30-0.35 s to 0.26-0.30 s with four)
+    return hostThreads() >= 64 || deviceRenderWanted() ? 4 : 2;
 }
 static size_t describeThreads(size_t heads) { // the threads that describe and sort a device batch's rows (HGX_MAF_DESCRIBE_THREADS)
     if (const char *e = getenv("HGX_MAF_DESCRIBE_THREADS"))
@@ -1631,6 +1636,89 @@ struct CpuScope {
 };
 static double g_mafFlush = 0; // (HGX_MAF_TIMING: the walk's thread in flush(): names, hand-over, without the wait for the batch before)
 static double g_mafRenderWait = 0; // (HGX_MAF_TIMING: how long the walk stood waiting for the batch before to be rendered)
+static bool deviceRenderWanted() { // HGX_MAF_DEVICE_RENDER=0: the rendering threads whatever the handle
+    const char *e = getenv("HGX_MAF_DEVICE_RENDER");
+    return !(e && e[0] == '0');
+}
+static size_t deviceRenderMinBlocks() { // (a handful of blocks is not worth the copies; the tests send every batch: HGX_MAF_DEVICE_RENDER_MIN_BLOCKS=1)
+    const char *e = getenv("HGX_MAF_DEVICE_RENDER_MIN_BLOCKS");
+    return e ? (size_t)std::max(1, atoi(e)) : 64;
+}
+// A batch's log in the layouts of hgx_maf_render_kernels.hpp, in one page-locked block, and the call (hgx_columns.hip:
+// mafRenderDevice).  false: the device did not take it (the rendering threads do).
+bool MafExport::RunMachine::renderOnDevice(const Batch &work, const std::vector<RankInfo> &ranks, const hgx_alignment *al, bool keepEmptyRefBlocks,
+                                           char *&text, size_t &bytes) {
+    static_assert(sizeof(PRow) == sizeof(MafRenderRow), "PRow is what the device reads");
+    const size_t nb = work.blocks.size(), ne = work.events.size();
+    size_t numRows = 0, slots = 0;
+    for (const EventLog &e : work.events)
+        numRows += e.nRows;
+    for (const BlockLog &b : work.blocks)
+        slots += b.numEnts;
+    if (numRows >= (1ull << 32) || slots >= (1ull << 31) || work.numIdx >= (1ull << 32))
+        return false;
+    // the sequences the batch's entries belong to (only those: the walk goes on looking others up while this batch is rendered)
+    std::vector<MafRenderRank> table(ranks.size());
+    memset(table.data(), 0, table.size() * sizeof(MafRenderRank));
+    std::string chars;
+    for (int32_t r : work.entRank) {
+        MafRenderRank &T = table[(size_t)r];
+        if (T.headLen)
+            continue;
+        const RankInfo &ri = ranks[(size_t)r];
+        T.seqStart = ri.seqStart;
+        T.srcLength = ri.srcLength;
+        T.genome = ri.genome;
+        T.headOff = (uint32_t)chars.size();
+        T.headLen = (uint32_t)ri.rowHead.size();
+        chars += ri.rowHead;
+        T.tailOff = (uint32_t)chars.size();
+        T.tailLen = (uint32_t)ri.rowTail.size();
+        chars += ri.rowTail;
+    }
+    auto pad = [](size_t n) { return (n + 63) & ~(size_t)63; };
+    const size_t oBlocks = 0, oEvents = oBlocks + pad(nb * sizeof(MafRenderBlock)), oRows = oEvents + pad(ne * sizeof(MafRenderEvent)),
+                 total = oRows + pad(numRows * sizeof(MafRenderRow));
+    struct Block {
+        char *p;
+        ~Block() { hostBlockGive(p); }
+    } stage{static_cast<char *>(hostBlockTake(std::max<size_t>(total, 64)))};
+    MafRenderBlock *blocks = reinterpret_cast<MafRenderBlock *>(stage.p + oBlocks);
+    MafRenderEvent *events = reinterpret_cast<MafRenderEvent *>(stage.p + oEvents);
+    MafRenderRow *rows = reinterpret_cast<MafRenderRow *>(stage.p + oRows);
+    uint32_t slot = 0;
+    for (size_t b = 0; b < nb; ++b) {
+        const BlockLog &B = work.blocks[b];
+        blocks[b] = MafRenderBlock{B.firstEnt, B.numEnts, B.firstEvent, B.numEvents, B.refEnt, slot, B.refIndex};
+        slot += B.numEnts;
+    }
+    uint32_t at = 0;
+    for (size_t e = 0; e < ne; ++e) {
+        const EventLog &E = work.events[e];
+        events[e] = MafRenderEvent{E.k, at, E.firstIdx, E.nRows, 0};
+        memcpy(rows + at, E.rows, (size_t)E.nRows * sizeof(PRow));
+        at += E.nRows;
+    }
+    MafRenderInput in;
+    in.blocks = blocks;
+    in.numBlocks = nb;
+    in.entRank = work.entRank.data();
+    in.numEntRank = work.entRank.size();
+    in.events = events;
+    in.numEvents = ne;
+    in.rowEnt = work.rowEnt.data();
+    in.numRowEnt = work.numIdx;
+    in.rows = rows;
+    in.numRows = numRows;
+    in.ranks = table.data();
+    in.numRanks = table.size();
+    in.chars = chars.data();
+    in.numChars = chars.size();
+    in.slots = slots;
+    in.keepEmptyRefBlocks = keepEmptyRefBlocks;
+    return mafRenderDevice(const_cast<hgx_alignment *>(al), in, text, bytes);
+}
+
 void MafExport::RunMachine::flush(const PRow *current) {
     {
         // (up to rendersInFlight() batches are being rendered at a time; a batch whose threads are done waits for its turn to write)
@@ -1691,6 +1779,44 @@ void MafExport::RunMachine::flush(const PRow *current) {
         nt = std::max(1u, std::min(nt, (hostThreads() + (unsigned)rendersInFlight() - 1) / (unsigned)rendersInFlight()));
         if (nb < 256)
             nt = 1;
+        BulkSink *const sink = dynamic_cast<BulkSink *>(out->rdbuf());
+        // The text on the device where there is one (hgx_maf_render_kernels.hpp): the log goes over as it is, the text comes back
+        if (nb >= deviceRenderMinBlocks() && al->dev && deviceRenderWanted()) {
+            char *text = nullptr;
+            size_t bytes = 0;
+            bool made = false;
+            {
+                CpuScope cpu(g_cpuRenderNs);
+                made = renderOnDevice(*work, *ranks, al, keepEmptyRefBlocks, text, bytes);
+            }
+            if (made) {
+                struct Give {
+                    char *p;
+                    ~Give() { hostBlockGive(p); }
+                } give{text};
+                order->wait(ticket); // (the batches' texts in the batches' order)
+                char *dst = sink && bytes >= (1u << 20) ? sink->room(bytes) : nullptr;
+                if (!dst) {
+                    out->write(text, (std::streamsize)bytes);
+                } else {
+                    // (copied into place by a few threads: one thread's copy of a batch's thirty megabytes into fresh pages is ten
+                    // milliseconds the next batch's text waits for)
+                    const unsigned parts = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(nt, 8u), bytes >> 22));
+                    auto copy = [&](unsigned t) {
+                        CpuScope cpu(g_cpuCopyNs);
+                        const size_t a = bytes * t / parts, b = bytes * (t + 1) / parts;
+                        memcpy(dst + a, text + a, b - a);
+                    };
+                    std::vector<std::thread> th;
+                    for (unsigned t = 1; t < parts; ++t)
+                        th.emplace_back(copy, t);
+                    copy(0);
+                    for (std::thread &x : th)
+                        x.join();
+                }
+                return;
+            }
+        }
         // (the rendering threads' buffers are kept from batch to batch: thirty megabytes of fresh pages per batch were as many page
         // faults again as the text's own)
         struct BufferPool {
@@ -1887,7 +2013,6 @@ void MafExport::RunMachine::flush(const PRow *current) {
                 buf.len += 1;
             }
         };
-        BulkSink *const sink = dynamic_cast<BulkSink *>(out->rdbuf());
         if (nt == 1) {
             {
                 CpuScope cpu(g_cpuRenderNs);
@@ -2453,7 +2578,7 @@ void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alig
     // Slices are batches, and a round takes one slice's walk: where the host has a thread for each of twice as many slices, batches of
     // half the columns halve the rounds' time (full-size config 3 on the CPU replay: 53 slices settle in 12-14 rounds where 27 take
     // 9-10 — how far a round's guesses hold is a matter of columns, not of slices)
-    if (wantHeadCols && !getenv("HGX_MAF_CHUNK") && chunkColumns == ((size_t)1 << 21) && hostThreads() >= 96 &&
+    if (wantHeadCols && !getenv("HGX_MAF_CHUNK") && chunkColumns == ((size_t)1 << 21) && hostThreads() >= 16 &&
         length >= ((int64_t)16 << 20)) {
         chunkColumns = (size_t)1 << 20;
         numChunksExpected = (length + (int64_t)chunkColumns - 1) / (int64_t)chunkColumns;

@@ -55,6 +55,8 @@ struct State {
     std::vector<unsigned long long> slots;
     const std::function<void()> *body = nullptr;
     unsigned long long launches = 0, fiberLaunches = 0;
+    unsigned long long syncGeneration = 0;
+    unsigned syncArrived = 0;
 };
 inline State &state() {
     static thread_local State s;
@@ -83,6 +85,7 @@ inline void runBlockWithFibers(unsigned threads) {
             S.stacks.emplace_back(new char[STACK]);
     }
     S.slots.assign(threads, 0);
+    S.syncArrived = 0;
     for (unsigned t = 0; t < threads; ++t) {
         getcontext(&S.ctx[t]);
         S.ctx[t].uc_stack.ss_sp = S.stacks[t].get();
@@ -150,8 +153,27 @@ template <class F> void launch(dim3 grid, dim3 block, F &&f) {
 #define gridDim (hipshim::state().gDim)
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) hipshim::launch((grid), (block), [&]() { kernel(__VA_ARGS__); })
 
+// (a barrier of the whole block: a fiber stays in it until every fiber of the block that is still running has come to one — the
+// wavefront operations below hand over too, a round each, and must not let the other wavefronts' threads through their barrier)
 inline void __syncthreads() {
-    hipshim::barrier();
+    hipshim::State &S = hipshim::state();
+    if (!S.fibers)
+        throw hipshim::NeedFibers();
+    const unsigned long long gen = S.syncGeneration;
+    ++S.syncArrived;
+    for (;;) {
+        unsigned alive = 0;
+        for (unsigned t = 0; t < S.bDim.x; ++t)
+            alive += S.done[t] ? 0u : 1u;
+        if (S.syncGeneration != gen)
+            break;
+        if (S.syncArrived >= alive) {
+            S.syncArrived = 0;
+            ++S.syncGeneration;
+            break;
+        }
+        hipshim::barrier();
+    }
 }
 template <typename T> inline T __shfl_down(T v, int delta, int width = 64) {
     hipshim::State &S = hipshim::state();
@@ -169,6 +191,53 @@ template <typename T> inline T __shfl_down(T v, int delta, int width = 64) {
         memcpy(&out, &S.slots[from], sizeof(T));
     hipshim::barrier();
     return out;
+}
+// (the other wavefront operations the column engine uses, the same way: through the block's slots between two barriers; a
+// wavefront is 64 consecutive threads of the block)
+template <typename T, typename Pick> inline T hipshim_exchange(T v, Pick pick) {
+    hipshim::State &S = hipshim::state();
+    if (!S.fibers)
+        throw hipshim::NeedFibers();
+    static_assert(sizeof(T) <= 8, "hipshim: shuffles of up to eight bytes");
+    unsigned long long raw = 0;
+    memcpy(&raw, &v, sizeof(T));
+    const unsigned me = S.current;
+    S.slots[me] = raw;
+    hipshim::barrier();
+    const long long from = pick(me);
+    T out = v;
+    if (from >= 0 && (unsigned long long)from < S.bDim.x && ((unsigned)from >> 6) == (me >> 6))
+        memcpy(&out, &S.slots[(size_t)from], sizeof(T));
+    hipshim::barrier();
+    return out;
+}
+template <typename T> inline T __shfl_up(T v, int delta, int width = 64) {
+    return hipshim_exchange(v, [&](unsigned me) { return (int)(me & 63u) % width >= delta ? (long long)me - delta : -1ll; });
+}
+template <typename T> inline T __shfl(T v, int lane, int width = 64) {
+    return hipshim_exchange(v, [&](unsigned me) { return (long long)((me & ~63u) + ((me & 63u) / (unsigned)width) * (unsigned)width + (unsigned)lane % (unsigned)width); });
+}
+inline unsigned long long __ballot(int predicate) {
+    hipshim::State &S = hipshim::state();
+    if (!S.fibers)
+        throw hipshim::NeedFibers();
+    const unsigned me = S.current;
+    S.slots[me] = predicate ? 1ull : 0ull;
+    hipshim::barrier();
+    unsigned long long mask = 0;
+    const unsigned w0 = me & ~63u;
+    for (unsigned l = 0; l < 64 && w0 + l < S.bDim.x; ++l)
+        if (S.slots[w0 + l])
+            mask |= 1ull << l;
+    hipshim::barrier();
+    return mask;
+}
+#define __HIP_MEMORY_SCOPE_AGENT 0
+template <typename T> inline T __hip_atomic_load(const T *p, int, int) {
+    return *p;
+}
+template <typename T> inline void __hip_atomic_store(T *p, T v, int, int) {
+    *p = v;
 }
 inline int __popc(unsigned v) {
     return __builtin_popcount(v);
@@ -237,6 +306,18 @@ inline hipError_t hipMemsetAsync(void *p, int v, size_t bytes, hipStream_t) {
 inline hipError_t hipMemGetInfo(size_t *freeB, size_t *totalB) {
     *freeB = (size_t)48 << 30;
     *totalB = (size_t)64 << 30;
+    return hipSuccess;
+}
+enum { hipStreamDefault = 0, hipStreamNonBlocking = 1 };
+inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { // (every stream is the one thread of the emulation)
+    *s = nullptr;
+    return hipSuccess;
+}
+inline hipError_t hipStreamCreate(hipStream_t *s) {
+    *s = nullptr;
+    return hipSuccess;
+}
+inline hipError_t hipStreamDestroy(hipStream_t) {
     return hipSuccess;
 }
 inline hipError_t hipStreamSynchronize(hipStream_t) {
