@@ -1278,6 +1278,375 @@ static void columnsHeadRowsWalk(hgx_alignment *h, int ref, int64_t first, int64_
 }
 
 
+// ---- the batches of an export as a stream (hgx_maf_kernels.hpp: a chunk in one pass) ----
+// columnsHeadRowsSweep makes a chunk with seventeen launches, six counts read back in between and three blocking copies into
+// pageable memory, and hands the host rows it has to describe and sort.  Here a chunk is three launches on a stream of its own — the
+// marked columns listed by a one-pass scan, their rows, the heads among them picked, described and sorted and written straight into
+// page-locked host memory — one copy of the head marks, and ONE wait for the host; the next chunk's launches are queued before this
+// one is waited for.  Plain exports (no --unique: its stretches keep the launches above).
+namespace {
+// Host memory the stream's kernels write (heads' offsets, columns and rows): page-locked whatever its size — hostBlockTake hands out
+// ordinary memory below a megabyte and when locking fails, which a copy can live with and a kernel's store cannot.  One allocation a
+// stream, carved up; a released one is kept for the next stream (hgx_maf_export_multi opens one per slice).
+struct PinnedArena {
+    char *p = nullptr;
+    size_t capacity = 0;
+};
+struct PinnedArenas {
+    std::mutex mu;
+    std::vector<PinnedArena> idle;
+};
+PinnedArenas &pinnedArenas() {
+    static PinnedArenas *a = new PinnedArenas;
+    return *a;
+}
+PinnedArena pinnedArenaTake(size_t bytes) { // p == nullptr: no page-locked memory to be had
+    PinnedArenas &A = pinnedArenas();
+    {
+        std::lock_guard<std::mutex> lock(A.mu);
+        for (size_t i = 0; i < A.idle.size(); ++i)
+            if (A.idle[i].capacity >= bytes && A.idle[i].capacity / 4 <= bytes) {
+                PinnedArena a = A.idle[i];
+                A.idle.erase(A.idle.begin() + (std::ptrdiff_t)i);
+                return a;
+            }
+    }
+    PinnedArena a;
+    a.capacity = (bytes + (bytes >> 3) + ((size_t)1 << 16) - 1) & ~(((size_t)1 << 16) - 1);
+    void *p = nullptr;
+    if (hipHostMalloc(&p, a.capacity, hipHostMallocPortable) != hipSuccess || !p) {
+        (void)hipGetLastError();
+        return PinnedArena();
+    }
+    a.p = static_cast<char *>(p);
+    return a;
+}
+void pinnedArenaGive(PinnedArena a) {
+    if (!a.p)
+        return;
+    PinnedArenas &A = pinnedArenas();
+    {
+        std::lock_guard<std::mutex> lock(A.mu);
+        if (A.idle.size() < 3) {
+            A.idle.push_back(a);
+            return;
+        }
+    }
+    (void)hipHostFree(a.p);
+}
+static void describeHostRow(const Image &img, const std::vector<int32_t> &rankBase, const ColumnRowHost &r, MafChunkRow &out, uint32_t ord) {
+    const GenomeTables &G = img.genomes[(size_t)r.genome];
+    const int s = G.seqs.size() == 1 ? 0 : G.seqIndexBySite(r.pos);
+    const SeqInfo &S = G.seqs[(size_t)s];
+    const int64_t at = r.pos - S.start;
+    out.key = r.rev ? ((S.length - 1 - at) << 1) | 1 : at << 1;
+    out.rank = rankBase[(size_t)r.genome] + s;
+    out.ord = ord;
+}
+} // namespace
+
+struct MafChunkStream {
+    static const int SLOTS = 2;
+    hgx_alignment *h = nullptr;
+    std::shared_ptr<MafTracks> T;
+    int ref = 0;
+    ColumnOptions opt;
+    std::vector<int32_t> rankBase;
+    bool forced = false;
+    Buf masks, dRankBase;
+    ColumnParams P;
+    hipStream_t s = nullptr;
+    ColumnStats *stats = nullptr;
+    uint32_t maxChunk = 0, headRoom = 0;
+    uint64_t rowsRoom = 0, outRoom = 0;
+    size_t tiles1 = 0, tiles2 = 0;
+    struct Slot {
+        Buf candCol, candRow, rows, head, ctl; // ctl: MafChunkCtl (64 bytes), then the two scans' tiles
+        Buf headOff, headCol, out;             // what k_maf_heads_out writes and k_maf_ship sends to the host
+        struct Host {
+            void *p = nullptr;
+        } hHead, hHeadOff, hHeadCol, hOut, hCtl; // (pieces of the stream's page-locked arena)
+        Ev e0, e1;
+        int64_t first = 0, count = 0;
+        bool busy = false;
+    } slot[SLOTS];
+    uint64_t submitted = 0, collected = 0;
+    PinnedArena arena;
+    ~MafChunkStream() {
+        if (s) {
+            (void)hipStreamSynchronize(s); // (nothing of ours is queued when the buffers go back to the cache)
+            (void)hipStreamDestroy(s);
+        }
+        pinnedArenaGive(arena);
+    }
+};
+
+static bool mafStreamWanted() {
+    const char *e = getenv("HGX_MAF_STREAM");
+    return !(e && e[0] == '0');
+}
+
+MafChunkStream *mafChunkStreamOpen(hgx_alignment *h, int ref, const ColumnOptions &opt, const std::vector<int32_t> &rankBase, int64_t maxChunk,
+                                   int64_t exportColumns, ColumnStats *stats) {
+    if (!h->dev || !mafStreamWanted() || maxChunk <= 0 || maxChunk >= (int64_t)LB_COUNT_MAX || rankBase.size() != h->img.genomes.size())
+        return nullptr;
+    HIP_OK(hipSetDevice(h->dev->device));
+    ensureDeviceDna(h->img, *h->dev);
+    std::shared_ptr<MafTracks> T = mafTracksFor(h, ref, opt, exportColumns);
+    if (!T || T->state.load() == MafTracks::REFUSED)
+        return nullptr;
+    std::unique_ptr<MafChunkStream> M(new MafChunkStream);
+    M->h = h;
+    M->T = T;
+    M->ref = ref;
+    M->opt = opt;
+    M->rankBase = rankBase;
+    M->stats = stats;
+    const char *env = getenv("HGX_MAF_SWEEP");
+    M->forced = env && env[0] == '1';
+    const uint32_t n = (uint32_t)maxChunk;
+    M->maxChunk = n;
+    // room: eight rows a column of the chunk for the marked columns' rows on the device; on the host two head rows a column and a
+    // head every second column — config 3 needs 0.5, 0.29 and 0.04 of a column; a chunk that needs more is the walk's (Collect: false)
+    M->rowsRoom = std::max<uint64_t>(8ull * n, 1u << 20);
+    M->outRoom = std::max<uint64_t>(2ull * n, 1u << 16);
+    M->headRoom = std::max<uint32_t>(n / 2 + 1, 1u << 12);
+    if (const char *e = getenv("HGX_MAF_STREAM_ROOM")) { // (the tests: chunks that do not fit)
+        M->outRoom = std::max<uint64_t>(1, (uint64_t)atoll(e));
+        M->headRoom = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(M->outRoom, M->headRoom));
+    }
+    M->tiles1 = (size_t)(n + MAF_MARK_TILE - 1) / MAF_MARK_TILE + 1;
+    M->tiles2 = (size_t)(n + 255) / 256 + 1;
+    M->P = makeParams(h, ref, 0, 1, 1, opt, nullptr, M->masks);
+    M->dRankBase.resize(rankBase.size() * 4);
+    HIP_OK(hipMemcpy(M->dRankBase.p, rankBase.data(), rankBase.size() * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipStreamCreateWithFlags(&M->s, hipStreamNonBlocking));
+    auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t bHead = pad((size_t)n + 8), bOff = pad(((size_t)M->headRoom + 1) * 4), bOut = pad((size_t)M->outRoom * sizeof(MafChunkRow)), bCtl = 256,
+                 perSlot = bHead + 2 * bOff + bOut + bCtl;
+    M->arena = pinnedArenaTake(perSlot * MafChunkStream::SLOTS);
+    if (!M->arena.p)
+        return nullptr; // (no page-locked memory: the launches that copy)
+    char *at = M->arena.p;
+    for (MafChunkStream::Slot &S : M->slot) {
+        S.candCol.resize((size_t)n * 4);
+        S.candRow.resize(((size_t)n + 1) * 4);
+        S.rows.resize((size_t)M->rowsRoom * sizeof(ColumnRow));
+        S.head.resize((size_t)n + 8);
+        S.ctl.resize(64 + (M->tiles1 + M->tiles2) * 8);
+        S.headOff.resize(((size_t)M->headRoom + 1) * 4);
+        S.headCol.resize(((size_t)M->headRoom + 1) * 4);
+        S.out.resize((size_t)M->outRoom * sizeof(MafChunkRow));
+        S.hHead.p = at;
+        S.hHeadOff.p = at + bHead;
+        S.hHeadCol.p = at + bHead + bOff;
+        S.hOut.p = at + bHead + 2 * bOff;
+        S.hCtl.p = at + bHead + 2 * bOff + bOut;
+        at += perSlot;
+    }
+    return M.release();
+}
+
+void mafChunkStreamClose(MafChunkStream *M) {
+    delete M;
+}
+
+size_t mafChunkStreamInFlight(const MafChunkStream *M) {
+    return (size_t)(M->submitted - M->collected);
+}
+
+void mafChunkStreamSubmit(MafChunkStream *M, int64_t first, int64_t count) {
+    if (count <= 0 || count > (int64_t)M->maxChunk || M->submitted - M->collected >= (uint64_t)MafChunkStream::SLOTS)
+        throw std::runtime_error("mafChunkStreamSubmit: no slot for the chunk");
+    const GenomeTables &R = M->h->img.genomes[(size_t)M->ref];
+    if (first < 0 || first + count > R.totalLength)
+        throw std::runtime_error("column range out of bounds for genome " + R.name);
+    HIP_OK(hipSetDevice(M->h->dev->device));
+    MafChunkStream::Slot &S = M->slot[M->submitted % MafChunkStream::SLOTS];
+    const uint32_t n = (uint32_t)count;
+    S.first = first;
+    S.count = count;
+    S.busy = true;
+    hipStream_t s = M->s;
+    MafChunkCtl *ctl = (MafChunkCtl *)S.ctl.p;
+    unsigned long long *tiles1 = (unsigned long long *)((char *)S.ctl.p + 64), *tiles2 = tiles1 + M->tiles1;
+    const MafTracks &T = *M->T;
+    HIP_OK(hipEventRecord(S.e0.e, s));
+    HIP_OK(hipMemsetAsync(S.ctl.p, 0, 64 + (M->tiles1 + M->tiles2) * 8, s));
+    const uint32_t nt1 = (n + MAF_MARK_TILE - 1) / MAF_MARK_TILE;
+    hipLaunchKernelGGL(k_maf_mark_list, dim3(nt1), dim3(256), 0, s, T.Fref, T.Aref, T.constRows, first, n, ctl, tiles1, (uint32_t *)S.candCol.p,
+                       (uint32_t *)S.candRow.p, (uint8_t *)S.head.p);
+    MafRowParams R2;
+    R2.P = M->P;
+    R2.P.first = first;
+    R2.P.count = count;
+    R2.S = (const int32_t *const *)T.sPtrs.p;
+    R2.candCol = (const uint32_t *)S.candCol.p;
+    R2.candRow = (const uint32_t *)S.candRow.p;
+    R2.nCand = 0;
+    const int rowGrid = (int)std::max<int64_t>(1, std::min<int64_t>(COL_GRID, ((int64_t)n * (1 << MAF_LPC_LOG) / 4 + 255) / 256));
+    if (M->h->dev->wide)
+        hipLaunchKernelGGL((k_maf_rows_ctl<int64_t>), dim3(rowGrid), dim3(256), 0, s, R2, ctl, (unsigned long long)M->rowsRoom, (ColumnRow *)S.rows.p);
+    else
+        hipLaunchKernelGGL((k_maf_rows_ctl<int32_t>), dim3(rowGrid), dim3(256), 0, s, R2, ctl, (unsigned long long)M->rowsRoom, (ColumnRow *)S.rows.p);
+    const uint32_t nt2 = (n + 255) / 256;
+    hipLaunchKernelGGL(k_maf_heads_out, dim3(nt2), dim3(256), 0, s, (const uint32_t *)S.candCol.p, (const uint32_t *)S.candRow.p, (const ColumnRow *)S.rows.p, ctl,
+                       tiles2, M->h->dev->desc, (const int32_t *)M->dRankBase.p, M->headRoom, (unsigned long long)M->outRoom, (uint8_t *)S.head.p,
+                       (uint32_t *)S.headOff.p, (uint32_t *)S.headCol.p, (MafHeadRow *)S.out.p);
+    hipLaunchKernelGGL(k_maf_ship, dim3(512), dim3(256), 0, s, ctl, (const uint32_t *)S.headOff.p, (const uint32_t *)S.headCol.p, (const MafHeadRow *)S.out.p,
+                       (uint32_t *)S.hHeadOff.p, (uint32_t *)S.hHeadCol.p, (MafHeadRow *)S.hOut.p);
+    HIP_OK(hipMemcpyAsync(S.hHead.p, S.head.p, n, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipMemcpyAsync(S.hCtl.p, S.ctl.p, 64, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipEventRecord(S.e1.e, s));
+    ++M->submitted;
+}
+
+// the chunk's heads by the column walk, described and sorted as the stream's are: what a chunk of the stream is held against
+static void mafWalkChunk(MafChunkStream *M, int64_t first, int64_t count, std::vector<uint8_t> &head, std::vector<uint32_t> &off, std::vector<MafChunkRow> &rows) {
+    HeadRows raw;
+    columnsHeadRowsWalk(M->h, M->ref, first, count, M->opt, head, off, raw, nullptr, -1);
+    rows.resize(raw.size());
+    for (size_t hI = 0; hI + 1 < off.size(); ++hI) {
+        const uint32_t a = off[hI], b = off[hI + 1];
+        for (uint32_t i = a; i < b; ++i)
+            describeHostRow(M->h->img, M->rankBase, raw[i], rows[i], i - a);
+        std::stable_sort(rows.begin() + a, rows.begin() + b, [](const MafChunkRow &x, const MafChunkRow &y) { return x.rank < y.rank; });
+    }
+}
+
+bool mafChunkStreamCollect(MafChunkStream *M, MafChunkOut &out) {
+    if (M->collected >= M->submitted)
+        throw std::runtime_error("mafChunkStreamCollect: nothing was submitted");
+    HIP_OK(hipSetDevice(M->h->dev->device));
+    MafChunkStream::Slot &S = M->slot[M->collected % MafChunkStream::SLOTS];
+    ++M->collected;
+    HIP_OK(hipEventSynchronize(S.e1.e));
+    S.busy = false;
+    MafChunkCtl ctl;
+    memcpy(&ctl, S.hCtl.p, sizeof ctl);
+    MafTracks &T = *M->T;
+    if (ctl.error == 2) {
+        if (M->forced)
+            throw MafSizesDoNotAddUp();
+        T.state.store(MafTracks::REFUSED);
+        return false;
+    }
+    if (ctl.error == 1)
+        throw std::runtime_error("column walk exceeded the frame stack (more than 64 pending branches for one base)");
+    if (ctl.error)
+        return false; // (no room, or 2^32 rows: this chunk and what follows by the launches that size their buffers as they go)
+    const uint32_t n = (uint32_t)S.count, nHeads = ctl.nHeads;
+    const uint64_t total = ctl.totalHeadRows;
+    out.n = S.count;
+    out.head.assign((const uint8_t *)S.hHead.p, (const uint8_t *)S.hHead.p + n);
+    out.headOff.assign((const uint32_t *)S.hHeadOff.p, (const uint32_t *)S.hHeadOff.p + nHeads);
+    out.headOff.push_back((uint32_t)total);
+    out.headCol.assign((const uint32_t *)S.hHeadCol.p, (const uint32_t *)S.hHeadCol.p + nHeads);
+    out.numRows = (size_t)total;
+    out.rows = static_cast<MafChunkRow *>(hostBlockTake(std::max<size_t>((size_t)total, 1) * sizeof(MafChunkRow)));
+    memcpy(out.rows, S.hOut.p, (size_t)total * sizeof(MafChunkRow));
+    float ms = 0;
+    HIP_OK(hipEventElapsedTime(&ms, S.e0.e, S.e1.e));
+    T.deviceUs.fetch_add((uint64_t)(ms * 1e3));
+    T.servedColumns.fetch_add((uint64_t)S.count);
+    T.servedHeads.fetch_add(nHeads);
+    T.servedMarked.fetch_add(ctl.nCand);
+    if (M->stats) {
+        M->stats->rows_ms += ms;
+        M->stats->rows += ctl.totalRows;
+        M->stats->columns += (uint64_t)S.count;
+    }
+    // The first chunk taken from a set of tracks is held against the column walk whole; of every eighth chunk behind it a stretch of
+    // 32 k columns somewhere inside it (a structure the first chunk does not hold — an insertion, a ring, a reversed tail — would be
+    // wrong without a word otherwise: ADVICE r05).  Tracks that differ are not used again; this chunk and the rest are the walk's.
+    const uint64_t index = M->collected - 1;
+    const bool whole = T.state.load() == MafTracks::UNCHECKED;
+    if (whole || (index % 8 == 7 && n > 65536)) {
+        int64_t a = 0, len = n;
+        if (!whole) {
+            len = 32768;
+            a = (int64_t)((index * 2654435761ull) % (uint64_t)(n - len));
+        }
+        std::vector<uint8_t> head2;
+        std::vector<uint32_t> off2(1, 0);
+        std::vector<MafChunkRow> rows2;
+        mafWalkChunk(M, S.first + a, len, head2, off2, rows2);
+        bool good = true;
+        size_t hI = 0; // heads of the chunk in front of column a
+        for (int64_t c = 0; c < a; ++c)
+            hI += out.head[(size_t)c] & 1;
+        size_t h2 = 0;
+        const MafChunkRow *mine = static_cast<const MafChunkRow *>(out.rows);
+        for (int64_t c = 0; c < len && good; ++c) {
+            const bool isHead = (out.head[(size_t)(a + c)] & 1) != 0, isHead2 = (head2[(size_t)c] & 1) != 0;
+            if (c == 0 && !whole) { // (the walk's stretch begins with a head whatever lies in front of it)
+                if (isHead) {
+                    const uint32_t x = out.headOff[hI], y = out.headOff[hI + 1], x2 = off2[0], y2 = off2[1];
+                    good = y - x == y2 - x2 && memcmp(mine + x, rows2.data() + x2, (size_t)(y - x) * sizeof(MafChunkRow)) == 0;
+                    ++hI;
+                }
+                ++h2;
+                continue;
+            }
+            if (isHead != isHead2) {
+                good = false;
+                break;
+            }
+            if (isHead) {
+                const uint32_t x = out.headOff[hI], y = out.headOff[hI + 1], x2 = off2[h2], y2 = off2[h2 + 1];
+                good = y - x == y2 - x2 && memcmp(mine + x, rows2.data() + x2, (size_t)(y - x) * sizeof(MafChunkRow)) == 0 &&
+                       out.headCol[hI] == (uint32_t)(a + c);
+                ++hI;
+                ++h2;
+            }
+        }
+        if (!good && getenv("HGX_MAF_STREAM_DEBUG")) {
+            size_t nh = 0, nh2 = 0;
+            for (uint8_t x : out.head)
+                nh += x & 1;
+            for (uint8_t x : head2)
+                nh2 += x & 1;
+            fprintf(stderr, "[hgx] stream check: chunk of %u columns at %lld, stretch %lld + %lld: heads %zu (ctl %u, marked %u, rows %llu, head rows %llu) / walk's %zu, rows %zu / %zu\n", n,
+                    (long long)S.first, (long long)a, (long long)len, nh, nHeads, ctl.nCand, (unsigned long long)ctl.totalRows, (unsigned long long)total, nh2,
+                    (size_t)total, rows2.size());
+            size_t i2 = 0, i1 = 0;
+            for (int64_t c = 0; c < len; ++c) {
+                const bool h1 = out.head[(size_t)(a + c)] & 1, h2b = head2[(size_t)c] & 1;
+                if (h1 != h2b) {
+                    fprintf(stderr, "[hgx]   column %lld: head %d / %d\n", (long long)c, (int)h1, (int)h2b);
+                    break;
+                }
+                if (h1) {
+                    const uint32_t x = out.headOff[i1], y = out.headOff[i1 + 1], x2 = off2[i2], y2 = off2[i2 + 1];
+                    if (y - x != y2 - x2 || memcmp(mine + x, rows2.data() + x2, (size_t)(y - x) * sizeof(MafChunkRow)) != 0 || out.headCol[i1] != (uint32_t)(a + c)) {
+                        fprintf(stderr, "[hgx]   head %zu at column %lld (headCol %u): rows %u / %u, offsets %u / %u\n", i1, (long long)c, out.headCol[i1], y - x, y2 - x2, x, x2);
+                        for (uint32_t q = 0; q < std::max(y - x, y2 - x2) && q < 12; ++q)
+                            fprintf(stderr, "[hgx]     row %u: key %lld rank %d ord %u / key %lld rank %d ord %u\n", q, q < y - x ? (long long)mine[x + q].key : -1ll,
+                                    q < y - x ? mine[x + q].rank : -1, q < y - x ? mine[x + q].ord : 0u, q < y2 - x2 ? (long long)rows2[x2 + q].key : -1ll,
+                                    q < y2 - x2 ? rows2[x2 + q].rank : -1, q < y2 - x2 ? rows2[x2 + q].ord : 0u);
+                        break;
+                    }
+                    ++i1;
+                    ++i2;
+                }
+            }
+        }
+        if (!good) {
+            hostBlockGive(out.rows);
+            out.rows = nullptr;
+            if (M->forced)
+                throw std::runtime_error("hal2maf: the heads taken from the per-base tracks differ from the column walk's");
+            T.state.store(MafTracks::REFUSED);
+            fprintf(stderr, "[hgx] hal2maf: the heads taken from the per-base tracks differ from the column walk's; the walk is used\n");
+            return false;
+        }
+        if (whole)
+            T.state.store(MafTracks::CHECKED);
+    }
+    T.chunks.fetch_add(1);
+    return true;
+}
+
 // ---- hal2maf's text on the device (hgx_maf_render_kernels.hpp) ----
 namespace {
 // streams of the rendering calls: a call takes one and gives it back (made without the null stream's implicit waits: the device
@@ -1367,6 +1736,9 @@ bool mafRenderDevice(hgx_alignment *h, const MafRenderInput &in, char *&text, si
     P.error = (unsigned int *)((char *)dCtl.p + 8);
     P.text = nullptr;
     const int gridB = (int)std::max<int64_t>(1, std::min<int64_t>(COL_GRID, ((int64_t)nb + 255) / 256));
+    const int gridS0 = (int)std::max<int64_t>(1, std::min<int64_t>(2 * COL_GRID, ((int64_t)in.slots + 255) / 256));
+    hipLaunchKernelGGL(k_maf_render_blocks, dim3(gridB), dim3(256), 0, s, P);
+    hipLaunchKernelGGL(k_maf_render_rowlen, dim3(gridS0), dim3(256), 0, s, P);
     hipLaunchKernelGGL(k_maf_render_sizes, dim3(gridB), dim3(256), 0, s, P);
     {
         const uint32_t tiles = (nb + SCAN_BLOCK - 1) / SCAN_BLOCK;

@@ -105,6 +105,31 @@ void columnsHeadRowsHost(hgx_alignment *h, int ref, int64_t first, int64_t count
 // made by sweeps over whole genomes, hgx_maf_kernels.hpp, when the export is long enough for them to pay; HGX_MAF_SWEEP=1 / 0
 // forces / forbids them)
 
+// The batches of a plain hal2maf export as a stream (hgx_columns.hip: MafChunkStream): chunks are submitted ahead and collected in
+// order; a chunk comes back as the walk wants it — the head marks, the heads' columns and row offsets, their rows described (key,
+// rank of the sequence) and sorted the way the column map holds them.  rankBase[g]: the rank of genome g's first sequence.  Open:
+// null when the export is not one for the per-base tracks (then columnsHeadRowsHost serves it).  Collect: false when the chunk has to
+// be made by columnsHeadRowsHost after all (no room, 2^32 rows, tracks that differ from the walk) — it and everything behind it.
+struct MafChunkRow { // = RunMachine::PRow of hgx_columns_host.cpp
+    int64_t key;
+    int32_t rank;
+    uint32_t ord;
+};
+struct MafChunkOut {
+    int64_t n = 0;
+    std::vector<uint8_t> head;
+    std::vector<uint32_t> headOff, headCol;
+    MafChunkRow *rows = nullptr; // a page-locked block (hostBlockGive it)
+    size_t numRows = 0;
+};
+struct MafChunkStream;
+MafChunkStream *mafChunkStreamOpen(hgx_alignment *h, int ref, const ColumnOptions &opt, const std::vector<int32_t> &rankBase, int64_t maxChunk,
+                                   int64_t exportColumns, ColumnStats *stats);
+void mafChunkStreamSubmit(MafChunkStream *M, int64_t first, int64_t count);
+bool mafChunkStreamCollect(MafChunkStream *M, MafChunkOut &out);
+size_t mafChunkStreamInFlight(const MafChunkStream *M);
+void mafChunkStreamClose(MafChunkStream *M);
+
 // hal2maf's text on the device (hgx_maf_render_kernels.hpp): the walk's log of a batch of blocks — every array in host memory, in the
 // layouts of that header — becomes the batch's MAF text, which comes back in a page-locked block (hostBlockGive it).  false: not on
 // this handle or at this size (no device, the bases not on it, a batch of four gigabytes of text): the caller renders it itself.

@@ -2693,14 +2693,64 @@ void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alig
     if (wholeAhead)
         ahead = (size_t)-1;
 #endif
+    // The plain export's batches as a stream where the per-base tracks serve it (hgx_columns.hip: MafChunkStream): three launches
+    // and one wait a batch, the next batch queued before this one is waited for, the rows described and sorted on the device.  A
+    // batch the stream does not deliver (no room, tracks that differ from the walk) and every batch behind it come by deviceStage.
+    struct StreamCloser {
+        void operator()(MafChunkStream *m) const { mafChunkStreamClose(m); }
+    };
+    std::unique_ptr<MafChunkStream, StreamCloser> chunkStream;
+    bool streamAllowed = !_unique && alignment->dev != nullptr;
+#ifdef HGX_HOST_PROFILE
+    if (mafReplayFile() || mafDumpFile())
+        streamAllowed = false; // (the recordings hold the device's rows as they were)
+#endif
     std::thread deviceThread([&]() {
         try {
+            int64_t nextSubmit = 0;
+            if (streamAllowed) {
+                std::vector<int32_t> rankBase(_rank.size(), 0);
+                for (size_t g = 0; g < _rank.size(); ++g)
+                    rankBase[g] = _rank[g].empty() ? 0 : _rank[g][0];
+                chunkStream.reset(mafChunkStreamOpen(alignment, genome, opt, rankBase, (int64_t)chunkColumns, std::max(length, _exportHint), &stats));
+            }
             for (int64_t done = 0; done < length;) {
                 {
                     std::unique_lock<std::mutex> lock(pipe.mu);
                     pipe.cv.wait(lock, [&]() { return pipe.stop || pipe.made - pipe.taken < ahead; });
                     if (pipe.stop)
                         break;
+                }
+                if (chunkStream) {
+                    CpuScope cpu(g_cpuDeviceNs);
+                    const auto t0 = std::chrono::steady_clock::now();
+                    while (nextSubmit < length && mafChunkStreamInFlight(chunkStream.get()) < 2) {
+                        const int64_t n = std::min<int64_t>((int64_t)chunkColumns, length - nextSubmit);
+                        mafChunkStreamSubmit(chunkStream.get(), first + nextSubmit, n);
+                        nextSubmit += n;
+                    }
+                    MafChunkOut o;
+                    if (mafChunkStreamCollect(chunkStream.get(), o)) {
+                        static_assert(sizeof(PRow) == sizeof(MafChunkRow), "the stream's rows are the walk's");
+                        std::shared_ptr<Chunk> c(new Chunk);
+                        c->done = done;
+                        c->n = o.n;
+                        c->head.swap(o.head);
+                        c->headOff.swap(o.headOff);
+                        if (wantHeadCols)
+                            c->headCol.swap(o.headCol);
+                        c->rows.reset(reinterpret_cast<PRow *>(o.rows));
+                        c->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                        done += c->n;
+                        std::promise<std::shared_ptr<Chunk>> ready;
+                        ready.set_value(c);
+                        std::lock_guard<std::mutex> lock(pipe.mu);
+                        pipe.ready.push_back(ready.get_future());
+                        ++pipe.made;
+                        pipe.cv.notify_all();
+                        continue;
+                    }
+                    chunkStream.reset(); // (waits for what it had queued; this batch and the rest by deviceStage)
                 }
                 std::shared_ptr<Raw> raw(deviceStage(done).release());
                 done += raw->c->n;

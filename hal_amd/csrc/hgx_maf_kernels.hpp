@@ -23,6 +23,7 @@
 //                         places) is dropped by comparing it with the marked column before it (k_maf_heads).
 #pragma once
 #include "hgx_column_kernels.hpp"
+#include "hgx_scan_kernels.hpp"
 
 namespace hgx {
 
@@ -434,13 +435,13 @@ template <typename C> struct MafSelect {
     }
 };
 
-template <typename C> static __global__ void __launch_bounds__(256) k_maf_rows(MafRowParams M, ColumnRow *__restrict__ rows) {
+template <typename C> HGX_DEV __forceinline__ void maf_rows_body(const MafRowParams &M, uint32_t nCand, ColumnRow *__restrict__ rows) {
     constexpr int LPC = 1 << MAF_LPC_LOG;
     MafSelect<C> sel(M);
     const int sub = (int)(threadIdx.x & (LPC - 1));
     const int64_t groups = ((int64_t)gridDim.x * blockDim.x) >> MAF_LPC_LOG;
     bool bad = false;
-    for (int64_t k = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> MAF_LPC_LOG; k < (int64_t)M.nCand; k += groups) {
+    for (int64_t k = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> MAF_LPC_LOG; k < (int64_t)nCand; k += groups) {
         const uint32_t a = M.candRow[k], n = M.candRow[k + 1] - a;
         if ((uint32_t)sub >= n)
             continue;
@@ -452,6 +453,228 @@ template <typename C> static __global__ void __launch_bounds__(256) k_maf_rows(M
     }
     if (bad)
         *M.P.error = 2;
+}
+template <typename C> static __global__ void __launch_bounds__(256) k_maf_rows(MafRowParams M, ColumnRow *__restrict__ rows) {
+    maf_rows_body<C>(M, M.nCand, rows);
+}
+
+// ---- a chunk in one pass: no count on the host between the launches ----
+// What the chunk's launches tell each other (and, at the chunk's end, the host) lies in device memory, cleared before the chunk.
+struct MafChunkCtl {
+    unsigned int ticket[4]; // the tiles' numbers of the chunk's one-pass scans (hgx_scan_kernels.hpp)
+    unsigned int nCand, nHeads, error, _pad; // error: 1 frame stack, 2 sizes, 3 --unique needs the walk (as P.error), MAF_ERR_* below
+    unsigned long long totalRows, totalHeadRows;
+};
+static constexpr unsigned MAF_ERR_TOO_MANY_ROWS = 4, MAF_ERR_ROWS_ROOM = 5, MAF_ERR_OUT_ROOM = 6;
+static constexpr uint32_t MAF_MARK_TILE = 2048; // columns a tile of k_maf_mark_list (256 threads, eight columns each)
+
+// k_maf_marks, both scans and k_maf_list in one launch: the marked columns of the chunk in order, the offsets of their rows, their
+// number and their rows' number (ctl), and the chunk's head marks cleared.  grid = tiles of MAF_MARK_TILE columns.
+static __global__ void __launch_bounds__(256) k_maf_mark_list(const uint8_t *__restrict__ F, const int32_t *__restrict__ A, int32_t constRows, int64_t first,
+                                                              uint32_t n, MafChunkCtl *ctl, unsigned long long *tiles, uint32_t *__restrict__ candCol,
+                                                              uint32_t *__restrict__ candRow, uint8_t *__restrict__ head) {
+    const unsigned tile = lb_take_tile(&ctl->ticket[0]);
+    const unsigned numTiles = (n + MAF_MARK_TILE - 1) / MAF_MARK_TILE;
+    if (tile >= numTiles)
+        return;
+    const uint32_t c0 = tile * MAF_MARK_TILE + threadIdx.x * 8;
+    uint32_t rowsOf[8];
+    unsigned marks = 0;
+    unsigned long long cnt = 0, w = 0;
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t c = c0 + (uint32_t)j;
+        rowsOf[j] = 0;
+        if (c < n && (c == 0 || F[first + c] != 0)) {
+            marks |= 1u << j;
+            rowsOf[j] = (uint32_t)(A ? A[first + c] : constRows);
+            ++cnt;
+            w += rowsOf[j];
+        }
+        if (c < n)
+            head[c] = 0;
+    }
+    const LbResult r = lb_scan_tile(tile, cnt, w, tiles);
+    unsigned long long idx = r.exC, off = r.exW;
+    for (int j = 0; j < 8; ++j)
+        if (marks & (1u << j)) {
+            candCol[idx] = c0 + (uint32_t)j;
+            candRow[idx] = (uint32_t)off;
+            ++idx;
+            off += rowsOf[j];
+        }
+    if (tile == numTiles - 1 && threadIdx.x == 0) { // (the last tile's sums are the chunk's)
+        const unsigned long long nc = r.baseC + r.tileC, nr = r.baseW + r.tileW;
+        ctl->nCand = (unsigned int)nc;
+        ctl->totalRows = nr;
+        candRow[nc] = (uint32_t)nr;
+        if (nr >= (1ull << 32))
+            ctl->error = MAF_ERR_TOO_MANY_ROWS;
+    }
+}
+// k_maf_rows with the marked columns' number taken from ctl; rowsRoom: the rows `rows` holds
+template <typename C> static __global__ void __launch_bounds__(256) k_maf_rows_ctl(MafRowParams M, MafChunkCtl *ctl, unsigned long long rowsRoom,
+                                                                                  ColumnRow *__restrict__ rows) {
+    if (ctl->error >= MAF_ERR_TOO_MANY_ROWS)
+        return;
+    if (ctl->totalRows > rowsRoom) { // (every thread sees the same two numbers: nobody writes)
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+            ctl->error = MAF_ERR_ROWS_ROOM;
+        return;
+    }
+    M.P.error = &ctl->error;
+    maf_rows_body<C>(M, ctl->nCand, rows);
+}
+
+// What the walk wants of a row (RunMachine::PRow, hgx_columns_host.cpp; MafRenderRow): the key of its base in its sequence on its
+// strand, the rank of its sequence — initEntry with a base (halMafBlock.cpp:84-112) and SequenceLess (halColumnIterator.h:45-50),
+// which the host's threads used to work out row by row (describe).  rankBase[g]: the rank of genome g's first sequence (a genome's
+// sequences have consecutive ranks).
+HGX_DEV __forceinline__ void maf_describe(const GenomeDesc *__restrict__ desc, const int32_t *__restrict__ rankBase, const ColumnRow &r, int64_t &key,
+                                          int32_t &rank) {
+    const GenomeDesc &G = desc[r.genome];
+    int32_t s = 0;
+    if (G.numSeq > 1) { // the sequence that holds the base (Genome::getSequenceBySite)
+        int32_t lo = 0, hi = G.numSeq;
+        while (hi - lo > 1) {
+            const int32_t mid = (lo + hi) >> 1;
+            if (G.seqStart[mid] <= r.pos)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        s = lo;
+    }
+    const int64_t at = r.pos - G.seqStart[s], len = G.seqStart[s + 1] - G.seqStart[s];
+    key = r.rev ? ((len - 1 - at) << 1) | 1 : at << 1;
+    rank = rankBase[r.genome] + s;
+}
+// what a wavefront's lanes wrote to LDS is read by its other lanes behind this point
+__device__ __forceinline__ void maf_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+struct MafHeadRow { // = RunMachine::PRow
+    int64_t key;
+    int32_t rank;
+    uint32_t ord;
+};
+// k_maf_heads, both scans and k_maf_gather in one launch, and the rows as the walk wants them: which marked columns begin a run
+// (compared with the marked column before them), the heads' marks, columns and row offsets, their rows described and sorted the way
+// the column map holds them (by sequence, a sequence's bases in the walk's order).  head: device memory; headOff, headCol, out: where
+// the host reads them (page-locked host memory, written from here).  grid: tiles of 256 marked columns, as many as the chunk could need.
+static constexpr int MAF_SORT_CACHE = 32; // a column's ranks kept in LDS while its rows are placed (longer columns: worked out again)
+static __global__ void __launch_bounds__(256) k_maf_heads_out(const uint32_t *__restrict__ candCol, const uint32_t *__restrict__ candRow,
+                                                              const ColumnRow *__restrict__ rows, MafChunkCtl *ctl, unsigned long long *tiles,
+                                                              const GenomeDesc *__restrict__ desc, const int32_t *__restrict__ rankBase, uint32_t headRoom,
+                                                              unsigned long long outRoom, uint8_t *__restrict__ head, uint32_t *__restrict__ headOff,
+                                                              uint32_t *__restrict__ headCol, MafHeadRow *__restrict__ out) {
+    __shared__ uint32_t sA[256], sN[256], sO[256];
+    __shared__ int32_t sRank[32][MAF_SORT_CACHE];
+    const unsigned tile = lb_take_tile(&ctl->ticket[1]);
+    if (ctl->error)
+        return;
+    const uint32_t nCand = ctl->nCand;
+    const unsigned numTiles = nCand ? (nCand + 255) / 256 : 1;
+    if (tile >= numTiles)
+        return;
+    const uint32_t k = tile * 256 + threadIdx.x;
+    uint32_t a = 0, n = 0;
+    bool isHead = false;
+    if (k < nCand) {
+        a = candRow[k];
+        n = candRow[k + 1] - a;
+        isHead = k == 0;
+        if (!isHead) { // the marked column before, advanced by the distance (k_maf_heads)
+            const uint32_t pa = candRow[k - 1];
+            const int64_t d = (int64_t)candCol[k] - (int64_t)candCol[k - 1];
+            isHead = a - pa != n;
+            for (uint32_t i = 0; i < n && !isHead; ++i) {
+                const ColumnRow r = rows[a + i], q = rows[pa + i];
+                isHead = r.genome != q.genome || r.rev != q.rev || r.pos != (q.rev ? q.pos - d : q.pos + d);
+            }
+        }
+    }
+    const LbResult r = lb_scan_tile(tile, isHead ? 1u : 0u, isHead ? n : 0u, tiles);
+    const bool room = r.baseC + r.tileC <= headRoom && r.baseW + r.tileW <= outRoom && r.baseW + r.tileW < (1ull << 32);
+    if (tile == numTiles - 1 && threadIdx.x == 0) {
+        ctl->nHeads = (unsigned int)(r.baseC + r.tileC);
+        ctl->totalHeadRows = r.baseW + r.tileW;
+        if (!room)
+            ctl->error = MAF_ERR_OUT_ROOM;
+    }
+    if (!room) { // (the tiles behind this one find no room either; the ones in front have written what nobody will read)
+        if (threadIdx.x == 0)
+            ctl->error = MAF_ERR_OUT_ROOM;
+        return;
+    }
+    sA[threadIdx.x] = a;
+    sN[threadIdx.x] = isHead ? n : 0;
+    sO[threadIdx.x] = (uint32_t)r.exW;
+    if (isHead) {
+        head[candCol[k]] = 1;
+        headOff[r.exC] = (uint32_t)r.exW;
+        headCol[r.exC] = candCol[k];
+    }
+    __syncthreads();
+    // the rows: eight lanes a head, a lane a row at a time — its place among the column's rows is the number of rows that sort in
+    // front of it (by rank, then by the walk's order)
+    const int sub = (int)(threadIdx.x & 7), grp = (int)(threadIdx.x >> 3);
+    for (int c = grp; c < 256; c += 32) {
+        const uint32_t hn = sN[c];
+        if (hn == 0)
+            continue; // (the group's lanes agree)
+        const uint32_t ha = sA[c], ho = sO[c];
+        const bool cached = hn <= (uint32_t)MAF_SORT_CACHE;
+        if (cached)
+            for (uint32_t i = (uint32_t)sub; i < hn; i += 8) {
+                int64_t key;
+                int32_t rank;
+                maf_describe(desc, rankBase, rows[ha + i], key, rank);
+                sRank[grp][i] = rank;
+            }
+        // (the eight lanes of a group are lanes of one wavefront: what they wrote to LDS is there when they read it behind this point
+        // only after a barrier of the wavefront — the groups of a workgroup walk the same number of heads apart from the last round, so a
+        // workgroup barrier would not do; the wavefront's own is enough)
+        maf_wave_sync();
+        for (uint32_t i = (uint32_t)sub; i < hn; i += 8) {
+            int64_t key;
+            int32_t rank;
+            maf_describe(desc, rankBase, rows[ha + i], key, rank);
+            uint32_t place = 0;
+            for (uint32_t j = 0; j < hn; ++j) {
+                int32_t rj;
+                if (cached) {
+                    rj = sRank[grp][j];
+                } else {
+                    int64_t kj;
+                    maf_describe(desc, rankBase, rows[ha + j], kj, rj);
+                }
+                place += (rj < rank || (rj == rank && j < i)) ? 1u : 0u;
+            }
+            out[ho + place] = MafHeadRow{key, rank, i};
+        }
+        maf_wave_sync();
+    }
+}
+
+// What k_maf_heads_out left in HBM goes to the host's page-locked memory from here, by the counts in ctl: consecutive lanes write
+// consecutive sixteen bytes — a wavefront's store is a kilobyte the link takes in one piece (the heads' rows written to the host
+// row by row, each at its sorted place, took three times the launch this and the one above take together).
+static __global__ void __launch_bounds__(256) k_maf_ship(const MafChunkCtl *ctl, const uint32_t *__restrict__ headOff, const uint32_t *__restrict__ headCol,
+                                                         const MafHeadRow *__restrict__ out, uint32_t *__restrict__ hostHeadOff,
+                                                         uint32_t *__restrict__ hostHeadCol, MafHeadRow *__restrict__ hostOut) {
+    if (ctl->error)
+        return;
+    const uint32_t nHeads = ctl->nHeads;
+    const unsigned long long rows = ctl->totalHeadRows;
+    const unsigned long long threads = (unsigned long long)gridDim.x * blockDim.x, me = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (unsigned long long i = me; i < rows; i += threads)
+        hostOut[i] = out[i];
+    for (unsigned long long i = me; i < nHeads; i += threads) {
+        hostHeadOff[i] = headOff[i];
+        hostHeadCol[i] = headCol[i];
+    }
 }
 
 // ---- which marked columns are heads ----

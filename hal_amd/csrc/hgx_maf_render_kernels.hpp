@@ -7,9 +7,10 @@
 // use sixteen CPUs that is half a second whatever the threads, and the rows' bases lie anywhere in the packed DNA (a cache miss a
 // row).  Here the log goes to the device as it is (a few megabytes a batch) and two kernels make the text:
 //
-//   k_maf_render_sizes   a lane a block: which of the block's remembered entries were given a base (only those are rows), every
-//                        row's length in characters (its sequence's name and length are text per sequence, its start and length
-//                        are counted in digits), the rows' places in the block (the reference's row first), the block's length;
+//   k_maf_render_blocks / _rowlen / _sizes   whose slot every remembered entry of every block is; a lane an entry: was it given a
+//                        base (only those are rows), its row's length in characters (its sequence's name and length are text per
+//                        sequence, its start and length are counted in digits); a lane a block: the rows' places in the block (the
+//                        reference's row first), the block's length;
 //   (exclusive scan of the blocks' lengths: the blocks' places in the batch's text)
 //   k_maf_render_rows    a lane a remembered entry: a row's lane writes "s <name> <start> <length> <strand> <sequence length>
 //                        <bases>" — a run of bases from the packed DNA (reverse strand: leftwards, complemented: halCommon.h:45-75,
@@ -80,47 +81,87 @@ HGX_DEV __forceinline__ bool maf_row_fields(const MafRenderParams &P, const MafR
     return start >= 0;
 }
 
-// (the body as a function of the block: the kernel below, and the host-side emulation's loop)
+// ---- sizes: three small launches, the middle one a lane per remembered ENTRY (a lane per block going through the block's 29
+// entries one after the other was a millisecond a batch: 34 k lanes on a device that holds half a million) ----
+// a lane a block: whose slots these are, the block's columns
+static __global__ void __launch_bounds__(256) k_maf_render_blocks(MafRenderParams P) {
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < P.numBlocks; b += gridDim.x * blockDim.x) {
+        const MafRenderBlock B = P.blocks[b];
+        for (uint32_t j = 0; j < B.numEnts; ++j)
+            P.slotBlock[B.slotBase + j] = b;
+    }
+}
+// a lane an entry of a block: the length of its row (rowOff[s], for the moment), 0: it has none
+HGX_DEV __forceinline__ void maf_render_rowlen_body(const MafRenderParams &P, uint32_t s) {
+    const uint32_t b = P.slotBlock[s];
+    const MafRenderBlock B = P.blocks[b];
+    const uint32_t j = s - B.slotBase;
+    const MafRenderEvent *ev = P.events + B.firstEvent;
+    int64_t start, length;
+    bool rev;
+    bool given = maf_row_fields(P, B, j, start, length, rev);
+    if (!given && B.refEnt >= 0 && j == (uint32_t)B.refEnt && B.refIndex != -1 && P.keepEmptyRefBlocks) { // (a row of gaps, as long as the block)
+        given = true;
+        start = B.refIndex;
+        length = 0;
+    }
+    uint32_t len = 0;
+    if (given) {
+        uint64_t columns = 0;
+        for (uint32_t e = 0; e < B.numEvents; ++e)
+            columns += (uint64_t)ev[e].k;
+        const MafRenderRank R = P.ranks[P.entRank[B.firstEnt + j]];
+        const uint64_t n = (uint64_t)R.headLen + maf_digits((uint64_t)start) + 1 + maf_digits((uint64_t)length) + 2 + R.tailLen + columns + 1;
+        if (n >= 0x7FFFFFFFull)
+            *P.error = 1;
+        else
+            len = (uint32_t)n;
+    }
+    P.rowOff[s] = len;
+}
+static __global__ void __launch_bounds__(256) k_maf_render_rowlen(MafRenderParams P) {
+    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < P.slots; s += gridDim.x * blockDim.x)
+        maf_render_rowlen_body(P, s);
+}
+// a lane a block: the rows' places in the block — MafBlock's operator<< (halMafBlock.cpp:499-520): the reference's row first, then
+// the entries that have a start — and the block's length; a block whose reference was given no base is not written unless empty
+// reference blocks are kept (referenceIsAllGaps, halMafExport.cpp:70, 85)
 HGX_DEV __forceinline__ void maf_render_sizes_body(const MafRenderParams &P, uint32_t b) {
     const MafRenderBlock B = P.blocks[b];
-    const MafRenderEvent *ev = P.events + B.firstEvent;
-    uint64_t columns = 0;
-    for (uint32_t e = 0; e < B.numEvents; ++e)
-        columns += (uint64_t)ev[e].k;
-    for (uint32_t j = 0; j < B.numEnts; ++j) {
-        P.slotBlock[B.slotBase + j] = b;
-        P.rowOff[B.slotBase + j] = MAF_NO_ROW;
-    }
     uint64_t off = 0;
+    bool written = false;
     if (B.refEnt >= 0) {
         const uint32_t ref = (uint32_t)B.refEnt;
         int64_t start, length;
         bool rev;
-        const bool refGiven = maf_row_fields(P, B, ref, start, length, rev);
-        if (P.keepEmptyRefBlocks || refGiven) { // referenceIsAllGaps (halMafExport.cpp:70, 85)
+        written = P.keepEmptyRefBlocks || maf_row_fields(P, B, ref, start, length, rev);
+        if (written) {
             off = 2; // "a\n"
-            auto rowLen = [&](uint32_t j, int64_t st, int64_t ln) {
-                const MafRenderRank R = P.ranks[P.entRank[B.firstEnt + j]];
-                return (uint64_t)R.headLen + maf_digits((uint64_t)st) + 1 + maf_digits((uint64_t)ln) + 2 + R.tailLen + columns + 1;
-            };
-            // MafBlock's operator<< (halMafBlock.cpp:499-520): the reference's row first, then the entries that have a start
-            if (refGiven) {
+            const uint32_t refLen = P.rowOff[B.slotBase + ref];
+            if (refLen) {
                 P.rowOff[B.slotBase + ref] = (uint32_t)off;
-                off += rowLen(ref, start, length);
-            } else if (B.refIndex != -1) { // (a row of gaps, as long as the block)
-                P.rowOff[B.slotBase + ref] = (uint32_t)off;
-                off += rowLen(ref, B.refIndex, 0);
+                off += refLen;
+            } else {
+                P.rowOff[B.slotBase + ref] = MAF_NO_ROW;
             }
             for (uint32_t j = 0; j < B.numEnts; ++j) {
-                if (j == ref || !maf_row_fields(P, B, j, start, length, rev))
+                if (j == ref)
                     continue;
-                if (off < 0xFFFFFFF0ull)
+                const uint32_t len = P.rowOff[B.slotBase + j];
+                if (len && off < 0xFFFFFFF0ull) {
                     P.rowOff[B.slotBase + j] = (uint32_t)off;
-                off += rowLen(j, start, length);
+                    off += len;
+                } else {
+                    P.rowOff[B.slotBase + j] = MAF_NO_ROW;
+                    off += len;
+                }
             }
             off += 1; // the empty line behind the block
         }
     }
+    if (!written)
+        for (uint32_t j = 0; j < B.numEnts; ++j)
+            P.rowOff[B.slotBase + j] = MAF_NO_ROW;
     if (off >= 0xFFFFFFF0ull) {
         *P.error = 1;
         off = 0;

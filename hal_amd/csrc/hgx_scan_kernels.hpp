@@ -108,6 +108,8 @@ HGX_SCAN_DEV __forceinline__ void lb_store(unsigned long long *p, unsigned long 
 // the tile of this workgroup (every thread gets it); call once, first thing in the kernel
 HGX_SCAN_DEV __forceinline__ unsigned lb_take_tile(unsigned int *ticket) {
     __shared__ unsigned sTile;
+    __syncthreads(); // (the last call's readers are done with the word; and the host-side emulation, which runs a kernel again from
+                     // its first barrier on, meets one before the ticket is taken)
     if (threadIdx.x == 0)
         sTile = atomicAdd(ticket, 1u);
     __syncthreads();
