@@ -17,6 +17,7 @@ from .api import (  # noqa: F401
     liftover_convert,
     liftover_convert_bytes,
     liftover_convert_multi,
+    liftover_render_blobs,
     alignment_depth_multi,
     maf_export_multi,
     RECORD_DTYPE,

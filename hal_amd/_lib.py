@@ -120,6 +120,7 @@ SYMBOLS = {
     "hgx_comm_destroy": (None, [VP]),
     "hgx_liftover_exchange": (C.c_int, [VP, VP, C.c_int64, VP, C.c_size_t, VP, P(C.c_size_t), P(VP)]),
     "hgx_liftover_gather": (C.c_int, [VP, VP, C.c_int, C.c_int64, VP, C.c_size_t, C.c_int, VP, P(C.c_size_t), P(VP)]),
+    "hgx_liftover_render_blobs": (C.c_int, [VP, C.c_int, C.c_int, C.c_char_p, C.c_size_t, C.c_int, P(VP), P(C.c_size_t), C.c_int, P(VP), P(C.c_size_t), P(VP)]),
     "hgx_liftover_gather_writers": (C.c_int, [VP, VP, C.c_int, C.c_int64, VP, C.c_size_t, C.c_int, VP, P(C.c_size_t), P(VP)]),
     "hgx_comm_all_sizes": (C.c_int, [VP, C.c_uint64, P(C.c_uint64), P(VP)]),
     "hgx_liftover_convert_multi": (C.c_int, [P(VP), C.c_int, C.c_int, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -404,6 +404,26 @@ def liftover_convert(alignment, src_genome, bed_text, tgt_genome, bed_type=0, tr
     return text
 
 
+def liftover_render_blobs(alignment, src_genome, tgt_genome, bed_text, blobs, bed_type=0):
+    """hgx_liftover_render_blobs: the lifted BED text of the intervals a writer's wire blobs hold (blobs: bytes-like objects or uint8
+    tensors on the host, in the order of the group's ranks; bed_text: the group's input lines, in order).  Needs no device."""
+    data = bed_text.encode() if isinstance(bed_text, str) else bytes(bed_text)
+    raw = [bytes(b.cpu().numpy().tobytes()) if hasattr(b, "cpu") else bytes(b) for b in blobs]
+    keep = [C.create_string_buffer(r, len(r)) for r in raw]
+    ptrs = (C.c_void_p * len(keep))(*[C.cast(k, C.c_void_p) for k in keep])
+    sizes = (C.c_size_t * len(keep))(*[len(r) for r in raw])
+    out, n, err = C.c_void_p(), C.c_size_t(), C.c_void_p()
+    rc = lib.hgx_liftover_render_blobs(alignment._h, src_genome, tgt_genome, data, len(data), bed_type, ptrs, sizes, len(keep), C.byref(out),
+                                       C.byref(n), C.byref(err))
+    if rc != 0:
+        raise HgxError(take_error(err))
+    try:
+        return C.string_at(out, n.value)
+    finally:
+        if out.value:
+            lib.hgx_free(out)
+
+
 def liftover_convert_multi(alignments, src_genome, bed_text, tgt_genome, bed_type=0, traverse_dupes=True, out_psl=False,
                            out_psl_with_name=False, coalescence_limit=-1):
     """hgx_liftover_convert_multi: Liftover::convert over several device clones of one alignment (Alignment.clone_to_device),

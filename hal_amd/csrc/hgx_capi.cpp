@@ -575,6 +575,21 @@ int hgx_liftover_convert(hgx_alignment *h, int src, const char *bed_text, size_t
                        err);
 }
 
+int hgx_liftover_render_blobs(hgx_alignment *h, int src, int tgt, const char *src_bed, size_t src_len, int bed_type, const void *const *blobs,
+                              const size_t *blob_bytes, int n_blobs, char **out_text, size_t *out_len, char **err) {
+    try {
+        if (!h || !out_text || !out_len || (src_len && !src_bed) || n_blobs < 0 || (n_blobs && (!blobs || !blob_bytes)))
+            throw std::runtime_error("hgx_liftover_render_blobs: null argument");
+        if (!genomeOf(h, src) || !genomeOf(h, tgt))
+            throw std::runtime_error("hgx_liftover_render_blobs: genome id out of range");
+        liftoverRenderBlobs(h, src, tgt, src_bed ? src_bed : "", src_len, bed_type, blobs, blob_bytes, n_blobs, out_text, out_len);
+        return HGX_OK;
+    } catch (std::exception &e) {
+        setErr(err, e.what());
+        return HGX_ERR;
+    }
+}
+
 int hgx_liftover_convert_multi(hgx_alignment *const *handles, int n_handles, int src, const char *bed_text, size_t bed_len, int tgt, int bed_type,
                                int traverse_dupes, int out_psl, int out_psl_with_name, int coalescence_limit, char **out_text, size_t *out_len,
                                char **err) {

@@ -82,6 +82,9 @@ class Liftover {
 
 // hgx_liftover_text.cpp; false: not an input for the fast path (nothing was done)
 // als: one handle per device (hgx_clone_to_device); the lines are dealt to them in contiguous shares
+// the BED lines of the intervals a writer's wire blobs hold (hgx_liftover_text.cpp)
+void liftoverRenderBlobs(hgx_alignment *al, int srcGenome, int tgtGenome, const char *text, size_t len, int bedType, const void *const *blobs,
+                         const size_t *blobBytes, int nBlobs, char **outText, size_t *outLen);
 bool liftoverTextFast(hgx_alignment *const *als, int nAls, int srcGenome, const char *text, size_t len, int tgtGenome, int bedType,
                       bool traverseDupes, int coalescenceLimit, char **outText, size_t *outLen, std::string &error,
                       std::set<std::string> &missedSet, hgx_liftover_stats &stats, size_t batchLines);

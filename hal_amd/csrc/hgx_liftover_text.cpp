@@ -825,4 +825,157 @@ bool liftoverTextFast(hgx_alignment *const *als, int nAls, int srcGenome, const 
     return true;
 }
 
+
+// What a writer does with the blobs of its group (hgx_liftover_gather_writers leaves them in its buffer): the BED lines of the
+// intervals they hold, rendered as hgx_liftover_convert renders them.  text: the input lines the blobs' intervals came from, in
+// order — blob i answers the next n_queries(i) lines that are intervals (lines of sequences the source genome does not have are
+// not, as in the conversion itself).  The fast path's BED forms only (no blocks).
+void liftoverRenderBlobs(hgx_alignment *al, int srcGenome, int tgtGenome, const char *text, size_t len, int bedType, const void *const *blobs,
+                         const size_t *blobBytes, int nBlobs, char **outText, size_t *outLen) {
+    *outText = nullptr;
+    *outLen = 0;
+    if (bedType > 9 || bedType == 7 || bedType < 0)
+        throw std::runtime_error("hgx_liftover_render_blobs: BED3 to BED9 lines only");
+    const GenomeTables &S = al->img.genomes[(size_t)srcGenome], &T = al->img.genomes[(size_t)tgtGenome];
+    std::unordered_map<std::string, int> seqByName;
+    for (size_t i = 0; i < S.seqs.size(); ++i)
+        seqByName.emplace(S.seqs[i].name, (int)i);
+    // the records of all blobs as rows, their query numbers counted over the whole text
+    std::vector<hgx_record> recs;
+    size_t nqBlobs = 0;
+    for (int b = 0; b < nBlobs; ++b) {
+        const unsigned char *p = static_cast<const unsigned char *>(blobs[b]);
+        const size_t have = blobBytes[b];
+        if (!p || have < 32 || memcmp(p, "HGXW", 4) != 0)
+            throw std::runtime_error("hgx_liftover_render_blobs: slot " + std::to_string(b) + " does not hold a wire blob");
+        uint32_t fmt;
+        uint64_t nq, nrec;
+        memcpy(&fmt, p + 4, 4);
+        memcpy(&nq, p + 16, 8);
+        memcpy(&nrec, p + 24, 8);
+        const unsigned char *body = p + 32;
+        if (fmt == 0)
+            throw std::runtime_error("hgx_liftover_render_blobs: the rank of slot " + std::to_string(b) + " had no blob for the batch");
+        const size_t cbytes = fmt == 8 || fmt == 12 ? (2 * (size_t)nq + 7) / 8 * 8 : 0;
+        if (fmt != 8 && fmt != 12 && fmt != 20 && fmt != 40)
+            throw std::runtime_error("hgx_liftover_render_blobs: unknown wire format " + std::to_string(fmt));
+        if (have < 32 + cbytes + (size_t)fmt * (size_t)nrec)
+            throw std::runtime_error("hgx_liftover_render_blobs: slot " + std::to_string(b) + " is shorter than its blob");
+        const size_t base = recs.size();
+        recs.resize(base + (size_t)nrec);
+        if (fmt == 8 || fmt == 12) {
+            const size_t words = fmt / 4;
+            size_t at = 0;
+            for (uint64_t q = 0; q < nq; ++q) {
+                uint16_t c;
+                memcpy(&c, body + 2 * q, 2);
+                for (uint16_t k = 0; k < c; ++k, ++at) {
+                    if (at >= nrec)
+                        throw std::runtime_error("hgx_liftover_render_blobs: a blob's counts hold more records than the blob");
+                    uint32_t w[3];
+                    memcpy(w, body + cbytes + at * fmt, fmt);
+                    const uint32_t tail = w[words - 1];
+                    hgx_record &r = recs[base + at];
+                    memset(&r, 0, sizeof r);
+                    r.query = (int64_t)(nqBlobs + q);
+                    r.tgt_start = (int64_t)w[0];
+                    r.tgt_end = r.tgt_start + (int64_t)(tail & ((1u << 22) - 1u));
+                    r.src_start = fmt == 12 ? (int64_t)w[1] : -1;
+                    r.tgt_seq = (int32_t)((tail >> 22) & 127u);
+                    r.strand = "+-."[(tail >> 29) & 3u];
+                    r.tgt_reversed = (uint8_t)(tail >> 31);
+                }
+            }
+            if (at != nrec)
+                throw std::runtime_error("hgx_liftover_render_blobs: a blob's counts do not add up to its records");
+        } else if (fmt == 20) {
+            for (uint64_t i = 0; i < nrec; ++i) {
+                int32_t w[5];
+                memcpy(w, body + 20 * i, 20);
+                hgx_record &r = recs[base + i];
+                memset(&r, 0, sizeof r);
+                r.query = (int64_t)nqBlobs + w[0];
+                r.tgt_start = w[1];
+                r.tgt_end = w[2];
+                r.src_start = w[3];
+                r.tgt_seq = (int32_t)(((uint32_t)w[4] >> 16) & 0xFFFFu);
+                r.strand = (char)(((uint32_t)w[4] >> 8) & 0xFFu);
+                r.tgt_reversed = (uint8_t)((uint32_t)w[4] & 0xFFu);
+            }
+        } else {
+            memcpy(recs.data() + base, body, 40 * (size_t)nrec);
+            for (uint64_t i = 0; i < nrec; ++i)
+                recs[base + i].query += (int64_t)nqBlobs;
+        }
+        nqBlobs += (size_t)nq;
+    }
+    for (size_t i = 1; i < recs.size(); ++i)
+        if (recs[i].query < recs[i - 1].query)
+            throw std::runtime_error("hgx_liftover_render_blobs: a blob's records are not in the order of its intervals");
+    for (const hgx_record &r : recs)
+        if (r.tgt_seq < 0 || (size_t)r.tgt_seq >= T.seqs.size())
+            throw std::runtime_error("hgx_liftover_render_blobs: a record names a sequence the target genome does not have");
+    // the lines, parsed the way the conversion parses them
+    const unsigned threads = (unsigned)std::min<size_t>(std::min(std::max(1u, hostThreads()), 64u), len / (1u << 18) + 1);
+    std::vector<Chunk> chunks;
+    {
+        const size_t want = std::max<size_t>((size_t)threads * 4, len / ((size_t)16 << 20) + 1), per = len / want + 1;
+        const char *p = text, *end = text + len;
+        while (p < end) {
+            const char *q = p + per < end ? p + per : end;
+            if (q < end) {
+                const char *nl = (const char *)memchr(q, '\n', (size_t)(end - q));
+                q = nl ? nl + 1 : end;
+            }
+            Chunk c;
+            c.begin = p;
+            c.end = q;
+            chunks.push_back(std::move(c));
+            p = q;
+        }
+    }
+    forEachChunk(chunks, threads, [&](Chunk &C) { parseChunk(C, bedType, seqByName, S); });
+    int bt = -1;
+    size_t nq = 0;
+    for (Chunk &C : chunks) {
+        if (C.general)
+            throw std::runtime_error("hgx_liftover_render_blobs: lines with blocks are not this entry point's");
+        if (!C.error.empty())
+            throw std::runtime_error(C.error);
+        if (C.bedType >= 0) {
+            if (bt >= 0 && C.bedType != bt)
+                throw std::runtime_error("hgx_liftover_render_blobs: lines of different numbers of columns");
+            bt = C.bedType;
+        }
+    }
+    for (Chunk &C : chunks) {
+        C.bedType = bt;
+        C.firstQuery = nq;
+        size_t q = nq;
+        for (Line &L : C.lines)
+            L.query = L.seq < 0 ? -1 : (int64_t)q++;
+        nq += C.numQueries;
+    }
+    if (nq != nqBlobs)
+        throw std::runtime_error("hgx_liftover_render_blobs: the text holds " + std::to_string(nq) + " intervals, the blobs answer " + std::to_string(nqBlobs));
+    const PackedRecords none;
+    size_t total = 0;
+    forEachChunk(chunks, threads, [&](Chunk &C) { C.outBytes = measureChunk(C, recs.data(), recs.size(), none, T); });
+    for (Chunk &C : chunks) {
+        C.outAt = total;
+        total += C.outBytes;
+    }
+    char *out = static_cast<char *>(textAlloc(std::max<size_t>(total, 1)));
+    if (!out)
+        throw std::bad_alloc();
+    try {
+        forEachChunk(chunks, threads, [&](Chunk &C) { renderChunk(C, recs.data(), recs.size(), none, T, out + C.outAt, C.outBytes); });
+    } catch (...) {
+        textFree(out);
+        throw;
+    }
+    *outText = out;
+    *outLen = total;
+}
+
 } // namespace hgx

@@ -318,6 +318,15 @@ int hgx_liftover_gather_writers(hgx_liftover_plan *p, hgx_comm *c, int group_siz
                                 size_t slot_bytes, int bed_only, void *hip_stream, size_t *my_bytes, char **err);
 /* every rank's `mine` in rank order on every rank (an all-gather of eight bytes a rank; blocking; sizes: n_ranks values on the host) */
 int hgx_comm_all_sizes(hgx_comm *c, uint64_t mine, uint64_t *sizes, char **err);
+/* What a writer does with its group's blobs once they are in host memory: the lifted BED text of the intervals they hold — the
+ * lines BedLine::write prints (liftover/impl/halBedLine.cpp:104-151) with what BlockLiftover::liftInterval and
+ * Liftover::cleanResults put into them, exactly as hgx_liftover_convert renders them.  src_bed: the input lines of the group's
+ * ranks, in order (blob i answers the next n_queries(i) lines that are intervals of the source genome; lines of sequences it does
+ * not have are passed over, as in the conversion); blobs[i] / blob_bytes[i]: slot i as hgx_liftover_gather_writers /
+ * hgx_liftover_gather / hgx_liftover_exchange left it (any wire format), copied to the host.  BED3..BED9 lines (bed_type 0 = auto);
+ * no device is needed.  *out_text is released with hgx_free. */
+int hgx_liftover_render_blobs(hgx_alignment *h, int src_genome, int tgt_genome, const char *src_bed, size_t src_len, int bed_type,
+                              const void *const *blobs, const size_t *blob_bytes, int n_blobs, char **out_text, size_t *out_len, char **err);
 
 
 /* Text-level drop-in for Liftover::convert (liftover/inc/halLiftover.h:25-28): BED text in, BED text

@@ -346,6 +346,88 @@ def test_two_writers_of_four_ranks_place_their_texts_world4(tmp_path):
     _spawn_writers(4, 2, tmp_path)
 
 
+def _golden_lift_inputs():
+    """the alignment and the BED lines tests/golden/make_lifted_records.py lifted (same options, same seeds; no device needed)"""
+    import hal_amd
+    opts = hal_amd.RandOptions(mean_degree=1.5, max_branch_length=3.0, min_genomes=2, max_genomes=10, min_segment_length=10, max_segment_length=60,
+                               min_segments=200, max_segments=600, seed=2, with_dna=False)
+    al = hal_amd.Alignment.random(opts, device=-1)
+    src, tgt = al.genome_id("Genome_9"), al.genome_id("Genome_2")
+    name, _, length = al.sequences(src)[0]
+    g = torch.Generator().manual_seed(3)
+    starts = torch.randint(0, length - 400, (600,), generator=g)
+    lens = torch.randint(1, 400, (600,), generator=g)
+    lines = ["%s\t%d\t%d\tiv%d\t%d\t%s\n" % (name, int(starts[i]), int(starts[i] + lens[i]), i, i % 1000, "+-."[i % 3]) for i in range(600)]
+    return al, src, tgt, lines
+
+
+def _library_writers_worker(rank, world, port, group, path, img, want, result):
+    """the writers' text made INSIDE the library (hgx_liftover_render_blobs: VERDICT r05 next 9): four ranks' blobs of the really
+    lifted records, two writers, each renders its group's slots from the group's input lines; side by side they write halLiftover's
+    file (the oracle's, made by the test's parent)"""
+    import hal_amd
+    from hal_amd.shard import SlotExchange, text_placement, write_text_at, writer_of
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    al, src, tgt, lines = _golden_lift_inputs()
+    z = np.load(os.path.join(GOLD, "lifted_records.npz"))
+    whole = torch.from_numpy(z["whole"].copy())
+    b1 = int(z["bounds"][1])
+    cuts = [0, b1 // 3, b1, b1 + 3, 600]
+    q = whole.view(torch.int64).view(-1, 5)[:, 0]
+    rows = offset_query_index(whole[(q >= cuts[rank]) & (q < cuts[rank + 1])].clone(), -cuts[rank])
+    ok = True
+    for fmt in (None, 8, 40):  # (the 12-byte form by default, the writers' 8-byte form, raw rows)
+        blob = encode_blob(rows, cuts[rank + 1] - cuts[rank], first_query=cuts[rank], fmt=fmt)
+        ex = SlotExchange(world, rank, 65536, "cpu", backend="torch", group=group)
+        ex.submit(blob=blob)
+        buf = ex.wait()
+        writer = writer_of(rank, group)
+        text = b""
+        if rank == writer:
+            members = list(range(writer, min(writer + group, world)))
+            bed = "".join(lines[cuts[members[0]]:cuts[members[-1] + 1]])
+            text = hal_amd.liftover_render_blobs(al, src, tgt, bed, ex.slots(buf))
+        offset, total = text_placement(len(text), torch.device("cpu"))
+        out = "%s.%s" % (path, fmt)
+        write_text_at(out, offset, text, total)
+        dist.barrier()
+        if rank == 0:
+            ok = ok and open(out, "rb").read() == want
+        dist.barrier()
+    if rank == 0:  # what does not fit is refused with a message, not rendered
+        try:
+            hal_amd.liftover_render_blobs(al, src, tgt, "".join(lines[:10]), [encode_blob(rows, cuts[1], first_query=0)])
+            ok = False
+        except hal_amd.HgxError as e:
+            ok = ok and "intervals" in str(e)
+    result[rank] = ok
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_writers_render_their_groups_blobs_inside_the_library_world4(oracle_bin, tmp_path):
+    import subprocess
+    al, src, tgt, lines = _golden_lift_inputs()
+    img = str(tmp_path / "al.hgx")
+    al.save(img)
+    bed = str(tmp_path / "in.bed")
+    open(bed, "w").write("".join(lines))
+    out = str(tmp_path / "want.bed")
+    subprocess.check_call([oracle_bin, "liftover", img, "Genome_9", bed, "Genome_2", out])
+    want = open(out, "rb").read()
+    assert want.count(b"\n") == 2186  # (the golden's records, one line each)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mgr = mp.Manager()
+    result = mgr.dict()
+    mp.spawn(_library_writers_worker, args=(4, port, 2, str(tmp_path / "out.bed"), img, want, result), nprocs=4, join=True)
+    assert all(result[r] for r in range(4)), dict(result)
+
+
 def test_writers_with_a_ragged_last_group_and_groups_of_one(tmp_path):
     _spawn_writers(3, 2, tmp_path)  # groups {0, 1} and {2}
     _spawn_writers(2, 1, tmp_path)  # every rank its own writer: no records move at all
