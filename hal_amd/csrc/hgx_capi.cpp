@@ -1078,6 +1078,7 @@ int hgx_maf_tracks_info(hgx_alignment *h, int drop, char **json, char **err) {
 
 void hgx_release_cached(void) {
     hgx::textTrim();
+    hgx::columnsReleaseCached();
 }
 
 const char *hgx_version(void) {

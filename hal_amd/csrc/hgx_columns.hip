@@ -803,10 +803,12 @@ static bool mafSweepAllowed(const Image &img, const SweepScope &sc, int64_t expo
         return false;
     if (env && env[0] == '1')
         return true;
-    // the sweeps touch every base of every genome in scope once (about 15 bytes a base: 5 ms for config 2's gigabase by round 4's
-    // depth sweeps); the walk they replace touches a column's tree per column (2.8 ns a column, round 4): even at about 500 bases of
-    // scope a column.  Exports of a million columns or more (as halAlignmentDepth's sweeps) with a fivefold margin on that (the
-    // stage's own times are not measured yet: profiles/r05_notes.md)
+    // Measured on the MI355X (profiles/r06_notes.md, config 2's alignment): the sweeps that build the tracks touch every base of every
+    // genome in scope once — 6.4 ms for a gigabase of scope; a batch of a million columns then costs 0.8 ms of kernels (k_maf_mark_list,
+    // k_maf_rows_ctl, k_maf_heads_out, k_maf_ship) where the walk's launches cost 2.8 (k_column_depth, k_column_rows twice over every
+    // column, k_column_heads, k_gather_head_rows): the tracks pay from about 300 bases of scope a column down.  The rule keeps a
+    // threefold margin on that and leaves exports below a million columns to the walk (a first batch held against the walk, the
+    // buffers of a stream: fixed costs of a few milliseconds).
     int64_t bases = 0;
     for (int g : sc.postOrder)
         bases += img.genomes[(size_t)g].totalLength;
@@ -877,7 +879,6 @@ static std::shared_ptr<MafTracks> mafTracksFor(hgx_alignment *h, int ref, const 
     const SweepScope sc = sweepScope(img, ref, opt);
     if (!mafSweepAllowed(img, sc, exportColumns))
         return nullptr;
-    h->mafTracks.reset(); // (one set of tracks a handle: the old one's memory first)
     // a genome has tracks of its own when something in scope hangs under it
     std::vector<char> hasTrack((size_t)ng, 0);
     for (int g : sc.postOrder) {
@@ -901,8 +902,11 @@ static std::shared_ptr<MafTracks> mafTracksFor(hgx_alignment *h, int ref, const 
         need += (size_t)img.genomes[(size_t)sc.path[i]].totalLength * (i >= aFrom ? 5 : 1) + PAD;
     size_t freeB = 0, totalB = 0;
     HIP_OK(hipMemGetInfo(&freeB, &totalB));
-    if (need + (1ull << 30) > freeB)
+    // (one set of tracks a handle: the old one's memory counts as free — and is given up only when the new set fits: ADVICE r05)
+    const size_t oldBytes = h->mafTracks ? std::static_pointer_cast<MafTracks>(h->mafTracks)->bytes : 0;
+    if (need + (1ull << 30) > freeB + oldBytes)
         return nullptr;
+    h->mafTracks.reset();
     std::shared_ptr<MafTracks> M(new MafTracks);
     M->ref = ref;
     M->noAncestors = opt.noAncestors;
@@ -1645,6 +1649,35 @@ bool mafChunkStreamCollect(MafChunkStream *M, MafChunkOut &out) {
     }
     T.chunks.fetch_add(1);
     return true;
+}
+
+// what the column engine keeps between calls and nobody is using: the stream's page-locked arenas, the page-locked host blocks
+// (hgx_release_cached; a handle's per-base tracks go with hgx_maf_tracks_info(drop) or with the handle)
+void columnsReleaseCached() {
+    {
+        PinnedArenas &A = pinnedArenas();
+        std::vector<PinnedArena> idle;
+        {
+            std::lock_guard<std::mutex> lock(A.mu);
+            idle.swap(A.idle);
+        }
+        for (PinnedArena &a : idle)
+            (void)hipHostFree(a.p);
+    }
+    HostBlockPool &pool = hostBlockPool();
+    std::vector<HostBlockHeader *> idle;
+    {
+        std::lock_guard<std::mutex> lock(pool.mu);
+        idle.swap(pool.idle);
+        pool.idleBytes = 0;
+    }
+    for (HostBlockHeader *hd : idle) {
+        hd->magic = 0;
+        if (hd->pinned)
+            (void)hipHostFree(hd);
+        else
+            free(hd);
+    }
 }
 
 // ---- hal2maf's text on the device (hgx_maf_render_kernels.hpp) ----

@@ -173,6 +173,8 @@ struct MafRenderInput {
 };
 bool mafRenderDevice(hgx_alignment *h, const MafRenderInput &in, char *&text, size_t &bytes);
 
+void columnsReleaseCached(); // idle page-locked memory of the column engine back to the system (hgx_release_cached)
+
 // the per-base tracks kept with the handle for hal2maf (hgx_columns.hip: MafTracks), as a JSON object; and letting go of them
 std::string mafTracksInfo(hgx_alignment *h);
 void mafTracksDrop(hgx_alignment *h);

@@ -50,4 +50,24 @@ inline unsigned hostThreads() {
     return threads;
 }
 
+// For a phase of a few milliseconds: a quota is an amount of CPU time per period (1.6 CPU-seconds per 100 ms on the GPU boxes), not a
+// number of threads — 64 threads for 6 ms spend a quarter of a period's allowance and finish in a third of the time 16 take
+// (hgx_liftover_convert of a million lines on the box: 6.3 ms with 64 threads, 11.1 with 16: profiles/r06_notes.md).  Up to four
+// times the quota's CPUs, the hardware and the affinity mask permitting; work that goes on for tenths of a second keeps to hostThreads().
+inline unsigned hostBurstThreads() {
+    static const unsigned threads = []() {
+        if (getenv("HGX_HOST_THREADS"))
+            return hostThreads();
+        unsigned n = std::thread::hardware_concurrency();
+        if (n == 0)
+            n = 1;
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0)
+            n = std::min(n, (unsigned)CPU_COUNT(&set));
+        return std::max(hostThreads(), std::min(n, 4u * hostThreads()));
+    }();
+    return threads;
+}
+
 } // namespace hgx

@@ -568,7 +568,7 @@ void Liftover::convertGeneral(hgx_alignment *al, int srcGenome, std::istream *in
                 std::string text;
                 std::exception_ptr error; // (then `text` ends where the serial loop would have stopped writing)
             };
-            unsigned nt = hostThreads();
+            unsigned nt = hostBurstThreads();
             nt = std::max(1u, std::min(nt ? nt : 1u, 32u));
             nt = (unsigned)std::min<size_t>(nt, jobs.size() / 64 + 1);
             std::vector<Share> shares(nt);
@@ -685,7 +685,7 @@ void Liftover::convertGeneral(hgx_alignment *al, int srcGenome, std::istream *in
             const char *nl = (const char *)memchr(text.data() + w1, '\n', text.size() - w1);
             w1 = nl ? (size_t)(nl - text.data()) + 1 : text.size();
         }
-        unsigned np = hostThreads();
+        unsigned np = hostBurstThreads();
         np = std::max(1u, std::min(np ? np : 1u, 32u));
         static const size_t pieceBytes = getenv("HGX_PARSE_PIECE") ? (size_t)std::max(1, atoi(getenv("HGX_PARSE_PIECE"))) : 16384; // (tests: small pieces)
         np = (unsigned)std::min<size_t>(np, (w1 - w0) / pieceBytes + 1);

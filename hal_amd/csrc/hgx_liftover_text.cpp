@@ -493,7 +493,7 @@ bool liftoverTextFast(hgx_alignment *const *als, int nAls, int srcGenome, const 
         return std::chrono::duration<double, std::milli>(b - a).count();
     };
     const auto t0 = now();
-    const unsigned hw = std::max(1u, hostThreads());
+    const unsigned hw = std::max(1u, hostBurstThreads()); // (three phases of a few milliseconds a call)
     static const unsigned maxThreads = getenv("HGX_TEXT_THREADS") ? (unsigned)std::max(1, atoi(getenv("HGX_TEXT_THREADS"))) : 64u;
     const unsigned threads = (unsigned)std::min<size_t>(std::min(hw, maxThreads), len / (1u << 18) + 1);
     // chunks: about four per thread, cut behind a newline; no chunk larger than 16 MB of text, so that a device batch (whole

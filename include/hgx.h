@@ -450,8 +450,10 @@ int hgx_create_random(const hgx_rand_opts *opts, int device, hgx_alignment **out
 int hgx_save_image(const hgx_alignment *h, const char *path, char **err);
 
 void hgx_free(void *p);
-/* The library keeps up to two released large texts (MAF, BED, wig: a gigabyte at most) and its device workspaces mapped for the
- * next call; a long-lived embedder gives them back with this (nothing in use is touched). */
+/* The library keeps up to two released large texts (MAF, BED, wig: a gigabyte at most) and the page-locked host memory of its
+ * copies for the next call; a long-lived embedder gives them back with this (nothing in use is touched).  A handle's own device
+ * memory — its tables, and the per-base tracks hal2maf builds for a reference genome: five bytes a base of every genome in scope —
+ * stays with the handle: hgx_maf_tracks_info(h, 1, ...) lets go of the tracks, hgx_close of everything. */
 void hgx_release_cached(void);
 /* "hgx <major>.<minor> (...)".  ABI history: 0.2 — hgx_maf_opts begins with struct_size (callers built against 0.1 must be
  * rebuilt: every field moved by four bytes, and an options struct without struct_size is refused), hgx_release_cached. */
