@@ -1048,6 +1048,8 @@ static void columnsHeadRowsSweep(hgx_alignment *h, MafTracks &T, int ref, int64_
         if (const char *e = getenv("HGX_MAF_UNIQUE_MAX_REF"))
             U.maxRefRows = std::max(0, std::min(UNIQUE_MAX_REF_ROWS, atoi(e)));
         U.error = (unsigned int *)err.p;
+        // (the chunk that is held against the column walk keeps the walk's form: every such column's rows)
+        U.collapseKeysOnly = T.stateUnique.load() == MafTracks::CHECKED && !(getenv("HGX_MAF_UNIQUE_COLLAPSE") && getenv("HGX_MAF_UNIQUE_COLLAPSE")[0] == '0') ? 1 : 0;
         const int candGrid = (int)std::max<int64_t>(1, std::min<int64_t>(GRID, ((int64_t)nCand + 255) / 256));
         Buf dSegCnt((size_t)nCand * 4), dSegOff(((size_t)nCand + 1) * 4);
         hipLaunchKernelGGL(k_unique_count, dim3(candGrid), dim3(256), 0, nullptr, U, (uint32_t *)dSegCnt.p);

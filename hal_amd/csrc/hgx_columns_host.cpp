@@ -2,6 +2,7 @@
 #include <functional>
 #include "hgx_liftover_host.hpp"
 #include "hgx_wig_text.hpp"
+#include "hgx_textmem.hpp"
 #include <iostream>
 #include <algorithm>
 #include <atomic>
@@ -4013,6 +4014,51 @@ void mafExportSliced(std::ostream &os, const std::vector<hgx_alignment *> &handl
     int64_t allColumns = 0;
     for (const Slice &sl : slices)
         allColumns += sl.length;
+    // A slice's text grows in memory of the text allocator (huge pages, mremap: hgx_textmem.hpp) where the rendering can be given room
+    // for a batch at once (BulkSink); it used to grow in a std::ostringstream, be copied out of it, and be copied once more line by line
+    // to drop the header — three passes over seventeen megabytes a slice, more than the export itself took.
+    struct SliceText : std::streambuf, BulkSink {
+        char *p = nullptr;
+        size_t n = 0, cap = 0;
+        ~SliceText() override { textFree(p); }
+        bool reserve(size_t need) {
+            if (need <= cap)
+                return true;
+            size_t c = cap ? cap : (size_t)1 << 20;
+            while (c < need)
+                c += c < ((size_t)1 << 28) ? c : ((size_t)1 << 28);
+            char *q = static_cast<char *>(textRealloc(p, c));
+            if (!q)
+                return false;
+            p = q;
+            cap = c;
+            return true;
+        }
+        char *room(size_t k) override {
+            if (!reserve(n + k))
+                return nullptr;
+            char *q = p + n;
+            n += k;
+            return q;
+        }
+        std::streamsize xsputn(const char *src, std::streamsize k) override {
+            if (k <= 0)
+                return 0;
+            char *q = room((size_t)k);
+            if (!q)
+                return 0;
+            memcpy(q, src, (size_t)k);
+            return k;
+        }
+        int_type overflow(int_type c) override {
+            if (traits_type::eq_int_type(c, traits_type::eof()))
+                return traits_type::not_eof(c);
+            const char ch = traits_type::to_char_type(c);
+            return xsputn(&ch, 1) == 1 ? c : traits_type::eof();
+        }
+    };
+    std::vector<std::unique_ptr<SliceText>> texts(slices.size());
+    std::vector<size_t> skip(slices.size(), 0); // concatenateSlices (hal2mafMP.py:176-190): of every slice but the first the lines that start with '#' are dropped
     std::atomic<size_t> next{0};
     auto work = [&](hgx_alignment *h) {
         for (size_t i; (i = next.fetch_add(1)) < slices.size();) {
@@ -4029,20 +4075,23 @@ void mafExportSliced(std::ostream &os, const std::vector<hgx_alignment *> &handl
                 me.setMaxRefGap(cfg.maxRefGap);
                 me.setPrintTree(cfg.printTree);
                 me.setExportHint(allColumns / (int64_t)handles.size());
-                std::ostringstream text;
+                texts[i].reset(new SliceText);
+                std::ostream text(texts[i].get());
                 me.convertSequence(text, h, genome, sl.seq, sl.start, sl.length, targets);
-                sl.text = text.str();
-                if (i != 0) { // concatenateSlices (hal2mafMP.py:176-190): of every slice but the first the lines that start with '#' are dropped
-                    std::string kept;
-                    kept.reserve(sl.text.size());
-                    for (size_t a = 0; a < sl.text.size();) {
-                        size_t b = sl.text.find('\n', a);
-                        b = b == std::string::npos ? sl.text.size() : b + 1;
-                        if (sl.text[a] != '#')
-                            kept.append(sl.text, a, b - a);
-                        a = b;
+                text.flush();
+                if (!text.good())
+                    throw std::runtime_error("out of memory for a slice's text");
+                if (i != 0) {
+                    // (a MAF text's '#' lines are its header: every other line begins with 'a', 's' or is empty — halMafBlock.cpp:499-520 —
+                    // so the lines to drop are the ones the text begins with)
+                    const char *p = texts[i]->p;
+                    const size_t n = texts[i]->n;
+                    size_t a = 0;
+                    while (a < n && p[a] == '#') {
+                        const void *nl = memchr(p + a, '\n', n - a);
+                        a = nl ? (size_t)((const char *)nl - p) + 1 : n;
                     }
-                    sl.text.swap(kept);
+                    skip[i] = a;
                 }
             } catch (std::exception &e) {
                 sl.error = e.what();
@@ -4058,8 +4107,35 @@ void mafExportSliced(std::ostream &os, const std::vector<hgx_alignment *> &handl
     for (const Slice &sl : slices)
         if (!sl.error.empty())
             throw std::runtime_error(sl.error);
-    for (const Slice &sl : slices)
-        os.write(sl.text.data(), (std::streamsize)sl.text.size());
+    // the slices' texts into the output: side by side where it gives room for all of them at once
+    size_t total = 0;
+    std::vector<size_t> at(slices.size(), 0);
+    for (size_t i = 0; i < slices.size(); ++i) {
+        at[i] = total;
+        total += texts[i] ? texts[i]->n - skip[i] : 0;
+    }
+    BulkSink *const sink = dynamic_cast<BulkSink *>(os.rdbuf());
+    char *dst = sink && total >= ((size_t)1 << 20) ? sink->room(total) : nullptr;
+    if (!dst) {
+        for (size_t i = 0; i < slices.size(); ++i)
+            if (texts[i])
+                os.write(texts[i]->p + skip[i], (std::streamsize)(texts[i]->n - skip[i]));
+        return;
+    }
+    std::atomic<size_t> nextCopy{0};
+    auto copy = [&]() {
+        for (size_t i; (i = nextCopy.fetch_add(1)) < slices.size();)
+            if (texts[i]) {
+                memcpy(dst + at[i], texts[i]->p + skip[i], texts[i]->n - skip[i]);
+                texts[i].reset(); // (its pages go back while the others are copied)
+            }
+    };
+    std::vector<std::thread> copiers;
+    for (unsigned t = 1; t < std::min<unsigned>(8u, std::max(1u, hostThreads())) && t < slices.size(); ++t)
+        copiers.emplace_back(copy);
+    copy();
+    for (std::thread &t : copiers)
+        t.join();
 }
 
 // maf/impl/halMafBed.cpp:24-52 driven by BedScanner::scan (liftover/impl/halBedScanner.cpp:40-61)

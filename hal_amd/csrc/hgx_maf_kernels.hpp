@@ -742,6 +742,13 @@ struct UniqueParams {
     int64_t first, f;  // genome coordinate of the chunk's first column, of the range's first column
     int32_t ref;
     int32_t maxRefRows; // <= UNIQUE_MAX_REF_ROWS (the tests lower it: HGX_MAF_UNIQUE_MAX_REF)
+    // 1: a stretch that is walked for its keys ships its FIRST column's rows only and marks the columns behind it as passed over.  What
+    // such a column does to the walk — its sequences become keys of the column map and count as seen in the block being made
+    // (RunMachine::walkChunk) — is the same for every column of the stretch: inside a run the rows only move, and a run ends where a
+    // sequence does (a segment boundary).  A slice deep inside a genome has such a column for every copy left of it: a fifth of
+    // hgx_maf_export_multi's columns, each with all its rows.  0: every column's rows, as the column walk ships them (the chunk
+    // that is held against the walk).
+    int32_t collapseKeysOnly;
     unsigned int *error; // 3: a column with more reference bases than UNIQUE_MAX_REF_ROWS, or none (the reference is not reported)
 };
 // emit(j, len, cls) for every stretch of marked column k's run; false: the column's reference rows cannot be held
@@ -839,7 +846,7 @@ static __global__ void __launch_bounds__(256) k_unique_units(UniqueParams U, con
         const uint32_t a = U.candRow[g.cand], nr = U.candRow[g.cand + 1] - a;
         uint32_t u = 0;
         if (g.cls == COL_KEYS_ONLY) {
-            u = g.len;
+            u = U.collapseKeysOnly ? 1u : g.len;
         } else if (g.cls == COL_WRITTEN) {
             bool head = g.col == 0 || g.j > 0 || s == 0 || seg[s - 1].cls != COL_WRITTEN;
             if (!head) { // the marked column before, advanced by the distance (k_maf_heads' test)
@@ -872,7 +879,7 @@ static __global__ void __launch_bounds__(256) k_unique_gather(UniqueParams U, co
         }
         if (g.cls == COL_KEYS_ONLY)
             for (uint32_t t = 0; t < g.len; ++t)
-                head[g.col + t] = 3;
+                head[g.col + t] = U.collapseKeysOnly && t > 0 ? 2 : 3;
         const uint32_t u = units[s];
         if (g.cls == COL_WRITTEN && u)
             head[g.col] = 1;
