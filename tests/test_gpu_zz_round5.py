@@ -482,3 +482,62 @@ def test_hal2maf_over_the_ranks_of_a_node_every_rank_a_writer(hal, tmp_path):
                            cwd=root, env=dict(os.environ, HGX_MP_DEVICE="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         assert open(out).read() == want, (nproc, args)
+
+
+# ---- round 6: the batches as a stream, the text rendered on the device, a writer's blobs rendered in the library ----
+
+
+def test_maf_stream_and_device_render_against_the_host_paths(hal, oracle_bin, tmp_path, monkeypatch):
+    """the plain export three ways — batches as a stream + text rendered on the device (the defaults), the launches that copy
+    (HGX_MAF_STREAM=0) + the host's rendering threads (HGX_MAF_DEVICE_RENDER=0), and a stream whose buffers have no room for its
+    batches (it hands them to the other launches) — give the oracle's text; chunks of 777 columns so that every path crosses batch
+    ends and the stream's eighth batches are held against the walk"""
+    al, img = _rand(hal, tmp_path, 4, min_segments=300, max_segments=500)
+    monkeypatch.setenv("HGX_MAF_SWEEP", "1")
+    monkeypatch.setenv("HGX_MAF_DEVICE_RENDER_MIN_BLOCKS", "1")
+    for g in (al.num_genomes - 1, 0):
+        name = al.genome_name(g)
+        want = _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", name)
+        for chunk in ("777", "100000"):
+            monkeypatch.setenv("HGX_MAF_CHUNK", chunk)
+            al.maf_tracks_info(drop=True)
+            assert al.maf_export(g) == want, (name, chunk, "stream + device render")
+            served = al.maf_tracks_info()["chunks_served"]
+            assert served >= 1
+            monkeypatch.setenv("HGX_MAF_STREAM", "0")
+            monkeypatch.setenv("HGX_MAF_DEVICE_RENDER", "0")
+            assert al.maf_export(g) == want, (name, chunk, "copying launches + rendering threads")
+            monkeypatch.delenv("HGX_MAF_STREAM")
+            monkeypatch.delenv("HGX_MAF_DEVICE_RENDER")
+            monkeypatch.setenv("HGX_MAF_STREAM_ROOM", "3")  # (three rows of room: no batch fits)
+            assert al.maf_export(g) == want, (name, chunk, "a stream without room")
+            monkeypatch.delenv("HGX_MAF_STREAM_ROOM")
+    monkeypatch.delenv("HGX_MAF_CHUNK")
+
+
+def test_a_writers_blobs_rendered_in_the_library(hal, oracle_bin, tmp_path):
+    """hgx_liftover_render_blobs on the device's own wire blobs (12-byte and 8-byte forms, two shards as two ranks would lift them):
+    the text is hgx_liftover_convert's, which is the oracle's"""
+    from test_gpu_liftover import _rand_alignment
+    import torch
+    al, img = _rand_alignment(hal, tmp_path, 2)
+    src, tgt = al.genome_id("Genome_9"), al.genome_id("Genome_2")
+    seq, ss, n = al.sequences(src)[0]
+    rng = np.random.default_rng(11)
+    starts = rng.integers(0, n - 300, 3000)
+    lens = rng.integers(1, 300, 3000)
+    lines = ["%s\t%d\t%d\tn%d\t%d\t%s\n" % (seq, starts[i], starts[i] + lens[i], i, i % 7, "+-."[i % 3]) for i in range(3000)]
+    want = hal.liftover_convert(al, src, "".join(lines), tgt)
+    assert want == oracle_liftover(oracle_bin, img, "Genome_9", "Genome_2", "".join(lines), tmp_path)
+    gs = torch.tensor(starts + ss, dtype=torch.int64, device="cuda")
+    ge = torch.tensor(starts + lens - 1 + ss, dtype=torch.int64, device="cuda")
+    st = torch.tensor([ord("+-."[i % 3]) for i in range(3000)], dtype=torch.uint8, device="cuda")
+    plan = hal.LiftoverPlan(al, src, tgt, max_queries=3000)
+    for bed_only in (False, True):
+        blobs = []
+        for lo, hi in ((0, 1100), (1100, 3000)):
+            plan.run(gs[lo:hi].contiguous(), ge[lo:hi].contiguous(), st[lo:hi].contiguous())
+            blob, fmt = plan.wire_blob(first_query=lo, bed_only=bed_only)
+            assert fmt == (8 if bed_only else 12)
+            blobs.append(blob.cpu())
+        assert hal.liftover_render_blobs(al, src, tgt, "".join(lines), blobs).decode() == want
