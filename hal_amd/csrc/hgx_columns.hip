@@ -789,6 +789,8 @@ struct MafTracks {
     int device = -1;
     std::vector<Buf> S, D, A, F;
     Buf sPtrs;               // device: const int32_t *[genomes]
+    Buf refLocate;           // coarse position -> segment table of the reference's tiling (k_maf_locate_table)
+    int refLocateShift = 0;
     const uint8_t *Fref = nullptr;
     const int32_t *Aref = nullptr; // null: every column has constRows rows
     int32_t constRows = 0;
@@ -941,6 +943,34 @@ static std::shared_ptr<MafTracks> mafTracksFor(hgx_alignment *h, int ref, const 
         sweepTracks<int32_t, true, int32_t>(h, sc.postOrder, sc.path, sc.inScope, track, hasTrack, M->S, M->A, s);
         mafBreakSweeps<int32_t>(h, sc, hasTrack, *M, s);
     }
+    { // where a column's walk begins: the reference segment of its base, from a table of a bucket per four segments
+        const GenomeTables &R = img.genomes[(size_t)ref];
+        const int64_t nseg = R.numTop > 0 ? R.numTop : R.numBot;
+        if (nseg > 0 && R.totalLength > 0) {
+            int64_t buckets = 1;
+            while (buckets < nseg / 4 && buckets < ((int64_t)1 << 22))
+                buckets <<= 1;
+            int shift = 0;
+            while (((R.totalLength - 1) >> shift) >= buckets)
+                ++shift;
+            const int64_t nb = ((R.totalLength - 1) >> shift) + 1;
+            M->refLocate.resize(((size_t)nb + 1) * 4);
+            M->refLocateShift = shift;
+            const DeviceGenome &dg = h->dev->genomes[(size_t)ref];
+            const int grid = (int)std::min<int64_t>(4096, (nb + 256) / 256);
+            if (R.numTop > 0) {
+                if (h->dev->wide)
+                    hipLaunchKernelGGL((k_maf_locate_table<TopRec<int64_t>>), dim3(grid), dim3(256), 0, s, (const TopRec<int64_t> *)dg.top, nseg, shift, (uint32_t)nb, (int32_t *)M->refLocate.p);
+                else
+                    hipLaunchKernelGGL((k_maf_locate_table<TopRec<int32_t>>), dim3(grid), dim3(256), 0, s, (const TopRec<int32_t> *)dg.top, nseg, shift, (uint32_t)nb, (int32_t *)M->refLocate.p);
+            } else {
+                if (h->dev->wide)
+                    hipLaunchKernelGGL((k_maf_locate_table<BotRec<int64_t>>), dim3(grid), dim3(256), 0, s, (const BotRec<int64_t> *)dg.bot, nseg, shift, (uint32_t)nb, (int32_t *)M->refLocate.p);
+                else
+                    hipLaunchKernelGGL((k_maf_locate_table<BotRec<int32_t>>), dim3(grid), dim3(256), 0, s, (const BotRec<int32_t> *)dg.bot, nseg, shift, (uint32_t)nb, (int32_t *)M->refLocate.p);
+            }
+        }
+    }
     HIP_OK(hipEventRecord(b.e, s));
     std::vector<const int32_t *> ptrs((size_t)ng, nullptr);
     for (int g = 0; g < ng; ++g)
@@ -1021,6 +1051,8 @@ static void columnsHeadRowsSweep(hgx_alignment *h, MafTracks &T, int ref, int64_
                        (uint32_t *)dCandCol.p, (uint32_t *)dCandRow.p);
     HIP_OK(hipMemcpyAsync((uint32_t *)dCandRow.p + nCand, (const uint32_t *)dRowOff.p + n, 4, hipMemcpyDeviceToDevice, nullptr));
     M.S = (const int32_t *const *)T.sPtrs.p;
+    M.refLocate = (const int32_t *)T.refLocate.p;
+    M.refLocateShift = T.refLocateShift;
     M.candCol = (const uint32_t *)dCandCol.p;
     M.candRow = (const uint32_t *)dCandRow.p;
     M.nCand = nCand;
@@ -1352,7 +1384,7 @@ static void describeHostRow(const Image &img, const std::vector<int32_t> &rankBa
 } // namespace
 
 struct MafChunkStream {
-    static const int SLOTS = 2;
+    static const int SLOTS = 3; // (a stream each: the launches of consecutive batches are short of lanes and latency-bound — they run beside each other)
     hgx_alignment *h = nullptr;
     std::shared_ptr<MafTracks> T;
     int ref = 0;
@@ -1361,7 +1393,7 @@ struct MafChunkStream {
     bool forced = false;
     Buf masks, dRankBase;
     ColumnParams P;
-    hipStream_t s = nullptr;
+    hipStream_t streams[SLOTS] = {nullptr, nullptr, nullptr};
     ColumnStats *stats = nullptr;
     uint32_t maxChunk = 0, headRoom = 0;
     uint64_t rowsRoom = 0, outRoom = 0;
@@ -1379,10 +1411,11 @@ struct MafChunkStream {
     uint64_t submitted = 0, collected = 0;
     PinnedArena arena;
     ~MafChunkStream() {
-        if (s) {
-            (void)hipStreamSynchronize(s); // (nothing of ours is queued when the buffers go back to the cache)
-            (void)hipStreamDestroy(s);
-        }
+        for (hipStream_t s : streams)
+            if (s) {
+                (void)hipStreamSynchronize(s); // (nothing of ours is queued when the buffers go back to the cache)
+                (void)hipStreamDestroy(s);
+            }
         pinnedArenaGive(arena);
     }
 };
@@ -1426,7 +1459,8 @@ MafChunkStream *mafChunkStreamOpen(hgx_alignment *h, int ref, const ColumnOption
     M->P = makeParams(h, ref, 0, 1, 1, opt, nullptr, M->masks);
     M->dRankBase.resize(rankBase.size() * 4);
     HIP_OK(hipMemcpy(M->dRankBase.p, rankBase.data(), rankBase.size() * 4, hipMemcpyHostToDevice));
-    HIP_OK(hipStreamCreateWithFlags(&M->s, hipStreamNonBlocking));
+    for (hipStream_t &st : M->streams)
+        HIP_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t bHead = pad((size_t)n + 8), bOff = pad(((size_t)M->headRoom + 1) * 4), bOut = pad((size_t)M->outRoom * sizeof(MafChunkRow)), bCtl = 256,
                  perSlot = bHead + 2 * bOff + bOut + bCtl;
@@ -1473,7 +1507,7 @@ void mafChunkStreamSubmit(MafChunkStream *M, int64_t first, int64_t count) {
     S.first = first;
     S.count = count;
     S.busy = true;
-    hipStream_t s = M->s;
+    hipStream_t s = M->streams[M->submitted % MafChunkStream::SLOTS];
     MafChunkCtl *ctl = (MafChunkCtl *)S.ctl.p;
     unsigned long long *tiles1 = (unsigned long long *)((char *)S.ctl.p + 64), *tiles2 = tiles1 + M->tiles1;
     const MafTracks &T = *M->T;
@@ -1487,6 +1521,8 @@ void mafChunkStreamSubmit(MafChunkStream *M, int64_t first, int64_t count) {
     R2.P.first = first;
     R2.P.count = count;
     R2.S = (const int32_t *const *)T.sPtrs.p;
+    R2.refLocate = (const int32_t *)T.refLocate.p;
+    R2.refLocateShift = T.refLocateShift;
     R2.candCol = (const uint32_t *)S.candCol.p;
     R2.candRow = (const uint32_t *)S.candRow.p;
     R2.nCand = 0;
@@ -1495,7 +1531,7 @@ void mafChunkStreamSubmit(MafChunkStream *M, int64_t first, int64_t count) {
         hipLaunchKernelGGL((k_maf_rows_ctl<int64_t>), dim3(rowGrid), dim3(256), 0, s, R2, ctl, (unsigned long long)M->rowsRoom, (ColumnRow *)S.rows.p);
     else
         hipLaunchKernelGGL((k_maf_rows_ctl<int32_t>), dim3(rowGrid), dim3(256), 0, s, R2, ctl, (unsigned long long)M->rowsRoom, (ColumnRow *)S.rows.p);
-    const uint32_t nt2 = (n + 255) / 256;
+    const uint32_t nt2 = std::min<uint32_t>((n + 255) / 256, 1024u);
     hipLaunchKernelGGL(k_maf_heads_out, dim3(nt2), dim3(256), 0, s, (const uint32_t *)S.candCol.p, (const uint32_t *)S.candRow.p, (const ColumnRow *)S.rows.p, ctl,
                        tiles2, M->h->dev->desc, (const int32_t *)M->dRankBase.p, M->headRoom, (unsigned long long)M->outRoom, (uint8_t *)S.head.p,
                        (uint32_t *)S.headOff.p, (uint32_t *)S.headCol.p, (MafHeadRow *)S.out.p);

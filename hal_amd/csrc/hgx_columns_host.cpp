@@ -2725,7 +2725,7 @@ void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alig
                 if (chunkStream) {
                     CpuScope cpu(g_cpuDeviceNs);
                     const auto t0 = std::chrono::steady_clock::now();
-                    while (nextSubmit < length && mafChunkStreamInFlight(chunkStream.get()) < 2) {
+                    while (nextSubmit < length && mafChunkStreamInFlight(chunkStream.get()) < 3) {
                         const int64_t n = std::min<int64_t>((int64_t)chunkColumns, length - nextSubmit);
                         mafChunkStreamSubmit(chunkStream.get(), first + nextSubmit, n);
                         nextSubmit += n;

@@ -165,6 +165,27 @@ template <typename C> static __global__ void __launch_bounds__(256) k_break_top_
         F[(int64_t)top[t].start] = 1;
 }
 
+// the coarse table MafSelect::locate starts from: out[b] = the segment that holds position b << shift (b < nb), out[nb] = the last segment
+template <typename REC> static __global__ void __launch_bounds__(256) k_maf_locate_table(const REC *__restrict__ segs, int64_t nseg, int shift, uint32_t nb,
+                                                                                         int32_t *__restrict__ out) {
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b <= nb; b += gridDim.x * blockDim.x) {
+        if (b == nb) {
+            out[b] = (int32_t)(nseg - 1);
+            continue;
+        }
+        const int64_t pos = (int64_t)b << shift;
+        int64_t lo = 0, hi = nseg; // the last segment that begins at or before pos
+        while (hi - lo > 1) {
+            const int64_t mid = (lo + hi) >> 1;
+            if ((int64_t)segs[mid].start <= pos)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        out[b] = (int32_t)lo;
+    }
+}
+
 // ---- the marked columns of a chunk ----
 // mark[c] = 1 when column c of the chunk may begin a run (its F, or the chunk's first column); rowsOf[c] = its rows (A) then, else 0
 static __global__ void __launch_bounds__(256) k_maf_marks(const uint8_t *__restrict__ F, const int32_t *__restrict__ A, int32_t constRows, int64_t first,
@@ -193,13 +214,19 @@ struct MafRowParams {
     const uint32_t *candCol;    // the marked columns (index in the chunk)
     const uint32_t *candRow;    // [nCand + 1] offsets of their rows
     uint32_t nCand;
+    // coarse position -> segment table of the reference's tiling (k_maf_locate_table), or null: refLocate[b] = the segment that holds
+    // position b << refLocateShift, one entry more for the last segment
+    const int32_t *refLocate;
+    int32_t refLocateShift;
 };
 static constexpr int MAF_LPC_LOG = 3; // lanes per marked column (config 3: 6.6 rows a column); a lane takes rows k, k + 8, ...
 
 template <typename C> struct MafSelect {
     const ColumnParams &P;
     const int32_t *const *S;
-    HGX_DEV MafSelect(const MafRowParams &p) : P(p.P), S(p.S) {
+    const int32_t *refLocate;
+    int32_t refLocateShift;
+    HGX_DEV MafSelect(const MafRowParams &p) : P(p.P), S(p.S), refLocate(p.refLocate), refLocateShift(p.refLocateShift) {
     }
     HGX_DEV __forceinline__ const TopRec<C> *top(int g) const {
         return (const TopRec<C> *)P.desc[g].top;
@@ -227,6 +254,11 @@ template <typename C> struct MafSelect {
     HGX_DEV __forceinline__ int32_t locate(int64_t p) const {
         const GenomeDesc &RD = P.desc[P.ref];
         int64_t lo = 0, hi = RD.numTop > 0 ? RD.numTop : RD.numBot;
+        if (refLocate) { // (twenty dependent loads of the search over a million segments down to three or four)
+            const int64_t b = p >> refLocateShift;
+            lo = refLocate[b];
+            hi = (int64_t)refLocate[b + 1] + 1;
+        }
         while (hi - lo > 1) {
             const int64_t mid = (lo + hi) >> 1;
             const int64_t st = RD.numTop > 0 ? (int64_t)top(P.ref)[mid].start : (int64_t)bot(P.ref)[mid].start;
@@ -562,7 +594,7 @@ struct MafHeadRow { // = RunMachine::PRow
 // k_maf_heads, both scans and k_maf_gather in one launch, and the rows as the walk wants them: which marked columns begin a run
 // (compared with the marked column before them), the heads' marks, columns and row offsets, their rows described and sorted the way
 // the column map holds them (by sequence, a sequence's bases in the walk's order).  head: device memory; headOff, headCol, out: where
-// the host reads them (page-locked host memory, written from here).  grid: tiles of 256 marked columns, as many as the chunk could need.
+// k_maf_ship takes them to the host.  Tiles of 256 marked columns, taken by ticket.
 static constexpr int MAF_SORT_CACHE = 32; // a column's ranks kept in LDS while its rows are placed (longer columns: worked out again)
 static __global__ void __launch_bounds__(256) k_maf_heads_out(const uint32_t *__restrict__ candCol, const uint32_t *__restrict__ candRow,
                                                               const ColumnRow *__restrict__ rows, MafChunkCtl *ctl, unsigned long long *tiles,
@@ -571,6 +603,7 @@ static __global__ void __launch_bounds__(256) k_maf_heads_out(const uint32_t *__
                                                               uint32_t *__restrict__ headCol, MafHeadRow *__restrict__ out) {
     __shared__ uint32_t sA[256], sN[256], sO[256];
     __shared__ int32_t sRank[32][MAF_SORT_CACHE];
+  for (;;) { // (a workgroup takes tiles until there are none left: the grid need not know how many marked columns the chunk has)
     const unsigned tile = lb_take_tile(&ctl->ticket[1]);
     if (ctl->error)
         return;
@@ -656,6 +689,7 @@ static __global__ void __launch_bounds__(256) k_maf_heads_out(const uint32_t *__
         }
         maf_wave_sync();
     }
+  }
 }
 
 // What k_maf_heads_out left in HBM goes to the host's page-locked memory from here, by the counts in ctl: consecutive lanes write

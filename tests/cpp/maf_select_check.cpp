@@ -245,6 +245,8 @@ size_t checkCase(const Image &img, const HostTables &H, const Case &cs, size_t &
     M.candCol = nullptr;
     M.candRow = nullptr;
     M.nCand = 0;
+    M.refLocate = nullptr; // (the search over all of the reference's segments)
+    M.refLocateShift = 0;
     MafSelect<C> sel(M);
     ColumnWalker<C> walker(P);
     const int64_t n = img.genomes[(size_t)cs.ref].totalLength;
