@@ -1395,12 +1395,15 @@ struct MafChunkStream {
     ColumnParams P;
     hipStream_t streams[SLOTS] = {nullptr, nullptr, nullptr};
     ColumnStats *stats = nullptr;
-    uint32_t maxChunk = 0, headRoom = 0;
+    uint32_t maxChunk = 0, headRoom = 0, segRoom = 0;
     uint64_t rowsRoom = 0, outRoom = 0;
     size_t tiles1 = 0, tiles2 = 0;
+    int64_t uniqueFirst = -1; // >= 0: hal2maf --unique over a range that begins there (the stretches of hgx_maf_kernels.hpp)
     struct Slot {
         Buf candCol, candRow, rows, head, ctl; // ctl: MafChunkCtl (64 bytes), then the two scans' tiles
         Buf headOff, headCol, out;             // what k_maf_heads_out writes and k_maf_ship sends to the host
+        Buf seg;                               // --unique: the batch's stretches
+        bool collapsed = false;                // --unique: the stretches walked for their keys shipped as one column each
         struct Host {
             void *p = nullptr;
         } hHead, hHeadOff, hHeadCol, hOut, hCtl; // (pieces of the stream's page-locked arena)
@@ -1426,14 +1429,17 @@ static bool mafStreamWanted() {
 }
 
 MafChunkStream *mafChunkStreamOpen(hgx_alignment *h, int ref, const ColumnOptions &opt, const std::vector<int32_t> &rankBase, int64_t maxChunk,
-                                   int64_t exportColumns, ColumnStats *stats) {
+                                   int64_t exportColumns, ColumnStats *stats, int64_t uniqueFirst) {
     if (!h->dev || !mafStreamWanted() || maxChunk <= 0 || maxChunk >= (int64_t)LB_COUNT_MAX || rankBase.size() != h->img.genomes.size())
         return nullptr;
     HIP_OK(hipSetDevice(h->dev->device));
     ensureDeviceDna(h->img, *h->dev);
     std::shared_ptr<MafTracks> T = mafTracksFor(h, ref, opt, exportColumns);
-    if (!T || T->state.load() == MafTracks::REFUSED)
+    const bool unique = uniqueFirst >= 0;
+    if (!T || (unique ? T->stateUnique : T->state).load() == MafTracks::REFUSED)
         return nullptr;
+    if (unique && T->constRows == 0)
+        return nullptr; // (--unique tells a column's reference bases from its rows: the reference has to be reported)
     std::unique_ptr<MafChunkStream> M(new MafChunkStream);
     M->h = h;
     M->T = T;
@@ -1441,6 +1447,7 @@ MafChunkStream *mafChunkStreamOpen(hgx_alignment *h, int ref, const ColumnOption
     M->opt = opt;
     M->rankBase = rankBase;
     M->stats = stats;
+    M->uniqueFirst = uniqueFirst;
     const char *env = getenv("HGX_MAF_SWEEP");
     M->forced = env && env[0] == '1';
     const uint32_t n = (uint32_t)maxChunk;
@@ -1455,7 +1462,10 @@ MafChunkStream *mafChunkStreamOpen(hgx_alignment *h, int ref, const ColumnOption
         M->headRoom = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(M->outRoom, M->headRoom));
     }
     M->tiles1 = (size_t)(n + MAF_MARK_TILE - 1) / MAF_MARK_TILE + 1;
-    M->tiles2 = (size_t)(n + 255) / 256 + 1;
+    M->tiles2 = (size_t)(n + 255) / 256 + 1; // (a scan over the marked columns — two of them with --unique —, one over the stretches: as many tiles each at most... see segRoom)
+    M->segRoom = unique ? (uint32_t)std::min<uint64_t>(LB_COUNT_MAX - 1, 2ull * n + 1024) : 0; // (a run falls into a few stretches; more: the other launches)
+    if (unique)
+        M->tiles2 = (size_t)(M->segRoom + 255) / 256 + 1;
     M->P = makeParams(h, ref, 0, 1, 1, opt, nullptr, M->masks);
     M->dRankBase.resize(rankBase.size() * 4);
     HIP_OK(hipMemcpy(M->dRankBase.p, rankBase.data(), rankBase.size() * 4, hipMemcpyHostToDevice));
@@ -1473,7 +1483,9 @@ MafChunkStream *mafChunkStreamOpen(hgx_alignment *h, int ref, const ColumnOption
         S.candRow.resize(((size_t)n + 1) * 4);
         S.rows.resize((size_t)M->rowsRoom * sizeof(ColumnRow));
         S.head.resize((size_t)n + 8);
-        S.ctl.resize(64 + (M->tiles1 + M->tiles2) * 8);
+        S.ctl.resize(64 + (M->tiles1 + 3 * M->tiles2) * 8);
+        if (unique)
+            S.seg.resize((size_t)M->segRoom * sizeof(UniqueSeg));
         S.headOff.resize(((size_t)M->headRoom + 1) * 4);
         S.headCol.resize(((size_t)M->headRoom + 1) * 4);
         S.out.resize((size_t)M->outRoom * sizeof(MafChunkRow));
@@ -1512,7 +1524,7 @@ void mafChunkStreamSubmit(MafChunkStream *M, int64_t first, int64_t count) {
     unsigned long long *tiles1 = (unsigned long long *)((char *)S.ctl.p + 64), *tiles2 = tiles1 + M->tiles1;
     const MafTracks &T = *M->T;
     HIP_OK(hipEventRecord(S.e0.e, s));
-    HIP_OK(hipMemsetAsync(S.ctl.p, 0, 64 + (M->tiles1 + M->tiles2) * 8, s));
+    HIP_OK(hipMemsetAsync(S.ctl.p, 0, 64 + (M->tiles1 + 3 * M->tiles2) * 8, s));
     const uint32_t nt1 = (n + MAF_MARK_TILE - 1) / MAF_MARK_TILE;
     hipLaunchKernelGGL(k_maf_mark_list, dim3(nt1), dim3(256), 0, s, T.Fref, T.Aref, T.constRows, first, n, ctl, tiles1, (uint32_t *)S.candCol.p,
                        (uint32_t *)S.candRow.p, (uint8_t *)S.head.p);
@@ -1532,9 +1544,38 @@ void mafChunkStreamSubmit(MafChunkStream *M, int64_t first, int64_t count) {
     else
         hipLaunchKernelGGL((k_maf_rows_ctl<int32_t>), dim3(rowGrid), dim3(256), 0, s, R2, ctl, (unsigned long long)M->rowsRoom, (ColumnRow *)S.rows.p);
     const uint32_t nt2 = std::min<uint32_t>((n + 255) / 256, 1024u);
-    hipLaunchKernelGGL(k_maf_heads_out, dim3(nt2), dim3(256), 0, s, (const uint32_t *)S.candCol.p, (const uint32_t *)S.candRow.p, (const ColumnRow *)S.rows.p, ctl,
-                       tiles2, M->h->dev->desc, (const int32_t *)M->dRankBase.p, M->headRoom, (unsigned long long)M->outRoom, (uint8_t *)S.head.p,
-                       (uint32_t *)S.headOff.p, (uint32_t *)S.headCol.p, (MafHeadRow *)S.out.p);
+    if (M->uniqueFirst >= 0) {
+        if (M->uniqueFirst > first)
+            throw std::runtime_error("columnsHeadRowsHost: the range of --unique begins behind its columns");
+        UniqueParams U;
+        U.candCol = (const uint32_t *)S.candCol.p;
+        U.candRow = (const uint32_t *)S.candRow.p;
+        U.rows = (const ColumnRow *)S.rows.p;
+        U.nCand = 0;
+        U.n = n;
+        U.first = first;
+        U.f = M->uniqueFirst;
+        U.ref = M->ref;
+        U.maxRefRows = UNIQUE_MAX_REF_ROWS;
+        if (const char *e = getenv("HGX_MAF_UNIQUE_MAX_REF"))
+            U.maxRefRows = std::max(0, std::min(UNIQUE_MAX_REF_ROWS, atoi(e)));
+        U.error = &ctl->error;
+        // (the batches that are held against the column walk — the first of a set of tracks, every eighth behind it — keep the walk's
+        // form: every column of a stretch that is walked for its keys)
+        const bool checked = M->T->stateUnique.load() == MafTracks::CHECKED && M->submitted % 8 != 7;
+        S.collapsed = checked && !(getenv("HGX_MAF_UNIQUE_COLLAPSE") && getenv("HGX_MAF_UNIQUE_COLLAPSE")[0] == '0');
+        U.collapseKeysOnly = S.collapsed ? 1 : 0;
+        unsigned long long *tiles3 = tiles2 + M->tiles2, *tiles4 = tiles3 + M->tiles2;
+        hipLaunchKernelGGL(k_unique_stretch_list, dim3(nt2), dim3(256), 0, s, U, ctl, tiles3, (UniqueSeg *)S.seg.p, M->segRoom);
+        const uint32_t nt3 = std::min<uint32_t>((M->segRoom + 255) / 256, 1024u);
+        hipLaunchKernelGGL(k_unique_out, dim3(nt3), dim3(256), 0, s, U, ctl, tiles4, (const UniqueSeg *)S.seg.p, M->h->dev->desc, (const int32_t *)M->dRankBase.p,
+                           M->headRoom, (unsigned long long)M->outRoom, (uint8_t *)S.head.p, (uint32_t *)S.headOff.p, (uint32_t *)S.headCol.p,
+                           (MafHeadRow *)S.out.p);
+    } else {
+        hipLaunchKernelGGL(k_maf_heads_out, dim3(nt2), dim3(256), 0, s, (const uint32_t *)S.candCol.p, (const uint32_t *)S.candRow.p, (const ColumnRow *)S.rows.p,
+                           ctl, tiles2, M->h->dev->desc, (const int32_t *)M->dRankBase.p, M->headRoom, (unsigned long long)M->outRoom, (uint8_t *)S.head.p,
+                           (uint32_t *)S.headOff.p, (uint32_t *)S.headCol.p, (MafHeadRow *)S.out.p);
+    }
     hipLaunchKernelGGL(k_maf_ship, dim3(512), dim3(256), 0, s, ctl, (const uint32_t *)S.headOff.p, (const uint32_t *)S.headCol.p, (const MafHeadRow *)S.out.p,
                        (uint32_t *)S.hHeadOff.p, (uint32_t *)S.hHeadCol.p, (MafHeadRow *)S.hOut.p);
     HIP_OK(hipMemcpyAsync(S.hHead.p, S.head.p, n, hipMemcpyDeviceToHost, s));
@@ -1546,7 +1587,7 @@ void mafChunkStreamSubmit(MafChunkStream *M, int64_t first, int64_t count) {
 // the chunk's heads by the column walk, described and sorted as the stream's are: what a chunk of the stream is held against
 static void mafWalkChunk(MafChunkStream *M, int64_t first, int64_t count, std::vector<uint8_t> &head, std::vector<uint32_t> &off, std::vector<MafChunkRow> &rows) {
     HeadRows raw;
-    columnsHeadRowsWalk(M->h, M->ref, first, count, M->opt, head, off, raw, nullptr, -1);
+    columnsHeadRowsWalk(M->h, M->ref, first, count, M->opt, head, off, raw, nullptr, M->uniqueFirst);
     rows.resize(raw.size());
     for (size_t hI = 0; hI + 1 < off.size(); ++hI) {
         const uint32_t a = off[hI], b = off[hI + 1];
@@ -1567,10 +1608,12 @@ bool mafChunkStreamCollect(MafChunkStream *M, MafChunkOut &out) {
     MafChunkCtl ctl;
     memcpy(&ctl, S.hCtl.p, sizeof ctl);
     MafTracks &T = *M->T;
+    const bool unique = M->uniqueFirst >= 0;
+    std::atomic<int> &state = unique ? T.stateUnique : T.state;
     if (ctl.error == 2) {
         if (M->forced)
             throw MafSizesDoNotAddUp();
-        T.state.store(MafTracks::REFUSED);
+        state.store(MafTracks::REFUSED);
         return false;
     }
     if (ctl.error == 1)
@@ -1602,8 +1645,8 @@ bool mafChunkStreamCollect(MafChunkStream *M, MafChunkOut &out) {
     // 32 k columns somewhere inside it (a structure the first chunk does not hold — an insertion, a ring, a reversed tail — would be
     // wrong without a word otherwise: ADVICE r05).  Tracks that differ are not used again; this chunk and the rest are the walk's.
     const uint64_t index = M->collected - 1;
-    const bool whole = T.state.load() == MafTracks::UNCHECKED;
-    if (whole || (index % 8 == 7 && n > 65536)) {
+    const bool whole = state.load() == MafTracks::UNCHECKED;
+    if (whole || (index % 8 == 7 && n > 65536 && !S.collapsed)) {
         int64_t a = 0, len = n;
         if (!whole) {
             len = 32768;
@@ -1620,8 +1663,8 @@ bool mafChunkStreamCollect(MafChunkStream *M, MafChunkOut &out) {
         size_t h2 = 0;
         const MafChunkRow *mine = static_cast<const MafChunkRow *>(out.rows);
         for (int64_t c = 0; c < len && good; ++c) {
-            const bool isHead = (out.head[(size_t)(a + c)] & 1) != 0, isHead2 = (head2[(size_t)c] & 1) != 0;
-            if (c == 0 && !whole) { // (the walk's stretch begins with a head whatever lies in front of it)
+            const bool isHead = (out.head[(size_t)(a + c)] & 1) != 0;
+            if (c == 0 && !whole && head2[0] == 1) { // (the walk's stretch begins with a head whatever lies in front of it)
                 if (isHead) {
                     const uint32_t x = out.headOff[hI], y = out.headOff[hI + 1], x2 = off2[0], y2 = off2[1];
                     good = y - x == y2 - x2 && memcmp(mine + x, rows2.data() + x2, (size_t)(y - x) * sizeof(MafChunkRow)) == 0;
@@ -1630,7 +1673,7 @@ bool mafChunkStreamCollect(MafChunkStream *M, MafChunkOut &out) {
                 ++h2;
                 continue;
             }
-            if (isHead != isHead2) {
+            if (out.head[(size_t)(a + c)] != head2[(size_t)c]) {
                 good = false;
                 break;
             }
@@ -1678,14 +1721,14 @@ bool mafChunkStreamCollect(MafChunkStream *M, MafChunkOut &out) {
             out.rows = nullptr;
             if (M->forced)
                 throw std::runtime_error("hal2maf: the heads taken from the per-base tracks differ from the column walk's");
-            T.state.store(MafTracks::REFUSED);
+            state.store(MafTracks::REFUSED);
             fprintf(stderr, "[hgx] hal2maf: the heads taken from the per-base tracks differ from the column walk's; the walk is used\n");
             return false;
         }
         if (whole)
-            T.state.store(MafTracks::CHECKED);
+            state.store(MafTracks::CHECKED);
     }
-    T.chunks.fetch_add(1);
+    (unique ? T.chunksUnique : T.chunks).fetch_add(1);
     return true;
 }
 

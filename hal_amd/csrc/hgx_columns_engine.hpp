@@ -124,7 +124,8 @@ struct MafChunkOut {
 };
 struct MafChunkStream;
 MafChunkStream *mafChunkStreamOpen(hgx_alignment *h, int ref, const ColumnOptions &opt, const std::vector<int32_t> &rankBase, int64_t maxChunk,
-                                   int64_t exportColumns, ColumnStats *stats);
+                                   int64_t exportColumns, ColumnStats *stats, int64_t uniqueFirst = -1);
+// (uniqueFirst >= 0: hal2maf --unique over a range that begins at that genome coordinate — marks 2 and 3 as columnsHeadRowsHost's)
 void mafChunkStreamSubmit(MafChunkStream *M, int64_t first, int64_t count);
 bool mafChunkStreamCollect(MafChunkStream *M, MafChunkOut &out);
 size_t mafChunkStreamInFlight(const MafChunkStream *M);

@@ -2701,7 +2701,7 @@ void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alig
         void operator()(MafChunkStream *m) const { mafChunkStreamClose(m); }
     };
     std::unique_ptr<MafChunkStream, StreamCloser> chunkStream;
-    bool streamAllowed = !_unique && alignment->dev != nullptr;
+    bool streamAllowed = alignment->dev != nullptr;
 #ifdef HGX_HOST_PROFILE
     if (mafReplayFile() || mafDumpFile())
         streamAllowed = false; // (the recordings hold the device's rows as they were)
@@ -2713,7 +2713,8 @@ void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alig
                 std::vector<int32_t> rankBase(_rank.size(), 0);
                 for (size_t g = 0; g < _rank.size(); ++g)
                     rankBase[g] = _rank[g].empty() ? 0 : _rank[g][0];
-                chunkStream.reset(mafChunkStreamOpen(alignment, genome, opt, rankBase, (int64_t)chunkColumns, std::max(length, _exportHint), &stats));
+                chunkStream.reset(mafChunkStreamOpen(alignment, genome, opt, rankBase, (int64_t)chunkColumns, std::max(length, _exportHint), &stats,
+                                                     _unique ? first : (int64_t)-1));
             }
             for (int64_t done = 0; done < length;) {
                 {
@@ -4098,9 +4099,17 @@ void mafExportSliced(std::ostream &os, const std::vector<hgx_alignment *> &handl
             }
         }
     };
+    // A slice is an export of a batch or two: its device stage, its walk and its rendering follow one another with nothing to run
+    // beside them.  A few slices at a time a handle fill each other's waits (HGX_MAF_MULTI_PER_HANDLE; the engine's shared state — the
+    // handle's tracks, the caches of device and page-locked memory, the rendering streams — is behind mutexes, a slice's buffers are its own).
+    size_t perHandle = 3; // (55 slices of config 3 over two handles on the box: 0.42 s one at a time, 0.30 two, 0.26 three)
+    if (const char *e = getenv("HGX_MAF_MULTI_PER_HANDLE"))
+        perHandle = (size_t)std::max(1, atoi(e));
     std::vector<std::thread> pool;
-    for (size_t d = 1; d < handles.size(); ++d)
-        pool.emplace_back(work, handles[d]);
+    for (size_t d = 0; d < handles.size(); ++d)
+        for (size_t k = 0; k < perHandle; ++k)
+            if (d + k > 0 && pool.size() + 1 < slices.size())
+                pool.emplace_back(work, handles[d]);
     work(handles[0]);
     for (std::thread &t : pool)
         t.join();

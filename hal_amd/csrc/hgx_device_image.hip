@@ -245,6 +245,8 @@ static void uploadDescs(const Image &img, DeviceImage &D) {
 }
 
 void ensureDeviceDna(const Image &img, DeviceImage &D) {
+    static std::mutex mu; // (several exports at a time on one handle: hgx_maf_export_multi's slices)
+    std::lock_guard<std::mutex> lock(mu);
     if (!D.dna.empty())
         return;
     HIP_OK(hipSetDevice(D.device));

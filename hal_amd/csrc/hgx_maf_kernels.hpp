@@ -494,7 +494,7 @@ template <typename C> static __global__ void __launch_bounds__(256) k_maf_rows(M
 // What the chunk's launches tell each other (and, at the chunk's end, the host) lies in device memory, cleared before the chunk.
 struct MafChunkCtl {
     unsigned int ticket[4]; // the tiles' numbers of the chunk's one-pass scans (hgx_scan_kernels.hpp)
-    unsigned int nCand, nHeads, error, _pad; // error: 1 frame stack, 2 sizes, 3 --unique needs the walk (as P.error), MAF_ERR_* below
+    unsigned int nCand, nHeads, error, nSeg; // error: 1 frame stack, 2 sizes, 3 --unique needs the walk (as P.error), MAF_ERR_* below; nSeg: --unique's stretches
     unsigned long long totalRows, totalHeadRows;
 };
 static constexpr unsigned MAF_ERR_TOO_MANY_ROWS = 4, MAF_ERR_ROWS_ROOM = 5, MAF_ERR_OUT_ROOM = 6;
@@ -604,8 +604,9 @@ static __global__ void __launch_bounds__(256) k_maf_heads_out(const uint32_t *__
     __shared__ uint32_t sA[256], sN[256], sO[256];
     __shared__ int32_t sRank[32][MAF_SORT_CACHE];
   for (;;) { // (a workgroup takes tiles until there are none left: the grid need not know how many marked columns the chunk has)
-    const unsigned tile = lb_take_tile(&ctl->ticket[1]);
-    if (ctl->error)
+    unsigned failed;
+    const unsigned tile = lb_take_tile(&ctl->ticket[1], &ctl->error, failed);
+    if (failed)
         return;
     const uint32_t nCand = ctl->nCand;
     const unsigned numTiles = nCand ? (nCand + 255) / 256 : 1;
@@ -931,6 +932,150 @@ static __global__ void __launch_bounds__(256) k_unique_gather(UniqueParams U, co
                     v.desc = desc;
                     v(r.genome, r.rev ? r.pos - shift : r.pos + shift, r.rev != 0);
                 }
+            }
+        }
+    }
+}
+
+
+// ---- --unique in the stream: the stretches listed and the units shipped in one launch each ----
+// k_unique_count, the scan and k_unique_stretches: a lane a marked column counts its run's stretches, the tiles' counts are scanned in
+// the same launch, the lane goes through its run again and writes them.  (U.nCand, U.error: taken from ctl here.)
+static __global__ void __launch_bounds__(256) k_unique_stretch_list(UniqueParams U, MafChunkCtl *ctl, unsigned long long *tiles, UniqueSeg *__restrict__ seg,
+                                                                    uint32_t segRoom) {
+    for (;;) {
+        unsigned failed;
+        const unsigned tile = lb_take_tile(&ctl->ticket[2], &ctl->error, failed);
+        if (failed)
+            return;
+        U.nCand = ctl->nCand;
+        U.error = &ctl->error;
+        const unsigned numTiles = U.nCand ? (U.nCand + 255) / 256 : 1;
+        if (tile >= numTiles)
+            return;
+        const uint32_t k = tile * 256 + threadIdx.x;
+        uint32_t cnt = 0;
+        bool bad = false;
+        if (k < U.nCand)
+            bad = !unique_stretches(U, k, [&](int64_t, int64_t, uint32_t) { ++cnt; });
+        if (bad)
+            cnt = 0;
+        const LbResult r = lb_scan_tile(tile, cnt, 0, tiles);
+        const bool room = r.baseC + r.tileC <= segRoom;
+        if (bad)
+            ctl->error = 3; // (a column whose reference rows a lane cannot hold: this batch is the walk's)
+        if (tile == numTiles - 1 && threadIdx.x == 0)
+            ctl->nSeg = (unsigned int)(r.baseC + r.tileC);
+        if (!room) {
+            if (threadIdx.x == 0)
+                ctl->error = MAF_ERR_OUT_ROOM;
+            return;
+        }
+        if (k < U.nCand && !bad) {
+            uint32_t at = (uint32_t)r.exC;
+            unique_stretches(U, k, [&](int64_t j, int64_t len, uint32_t cls) {
+                seg[at++] = UniqueSeg{(uint32_t)(U.candCol[k] + j), (uint32_t)len, k, (uint32_t)j, cls};
+            });
+        }
+    }
+}
+// k_unique_units, both scans and k_unique_gather, the rows as the walk wants them (k_maf_heads_out's form): a lane a stretch — its
+// units (a written stretch that begins a run of written columns: its first column; a stretch walked for its keys: every column, or
+// the first one only: UniqueParams::collapseKeysOnly), the marks of its columns, its units' columns, row offsets and rows, every row
+// moved along its strand to the unit's column, described and sorted.
+static constexpr int UNIQUE_SORT_ROWS = 24; // a unit's ranks kept by its lane (longer columns: worked out again)
+static __global__ void __launch_bounds__(256) k_unique_out(UniqueParams U, MafChunkCtl *ctl, unsigned long long *tiles, const UniqueSeg *__restrict__ seg,
+                                                           const GenomeDesc *__restrict__ desc, const int32_t *__restrict__ rankBase, uint32_t headRoom,
+                                                           unsigned long long outRoom, uint8_t *__restrict__ head, uint32_t *__restrict__ headOff,
+                                                           uint32_t *__restrict__ headCol, MafHeadRow *__restrict__ out) {
+    for (;;) {
+        unsigned failed;
+        const unsigned tile = lb_take_tile(&ctl->ticket[3], &ctl->error, failed);
+        if (failed)
+            return;
+        const uint32_t nSeg = ctl->nSeg;
+        const unsigned numTiles = nSeg ? (nSeg + 255) / 256 : 1;
+        if (tile >= numTiles)
+            return;
+        const uint32_t s = tile * 256 + threadIdx.x;
+        UniqueSeg g{0, 0, 0, 0, COL_SKIPPED};
+        uint32_t a = 0, nr = 0, u = 0;
+        if (s < nSeg) {
+            g = seg[s];
+            a = U.candRow[g.cand];
+            nr = U.candRow[g.cand + 1] - a;
+            if (g.cls == COL_KEYS_ONLY) {
+                u = U.collapseKeysOnly ? 1u : g.len;
+            } else if (g.cls == COL_WRITTEN) {
+                bool isHead = g.col == 0 || g.j > 0 || s == 0 || seg[s - 1].cls != COL_WRITTEN;
+                if (!isHead) { // the marked column before, advanced by the distance (k_maf_heads' test)
+                    const uint32_t k = g.cand, pa = U.candRow[k - 1];
+                    const int64_t d = (int64_t)U.candCol[k] - (int64_t)U.candCol[k - 1];
+                    isHead = a - pa != nr;
+                    for (uint32_t i = 0; i < nr && !isHead; ++i) {
+                        const ColumnRow r = U.rows[a + i], q = U.rows[pa + i];
+                        isHead = r.genome != q.genome || r.rev != q.rev || r.pos != (q.rev ? q.pos - d : q.pos + d);
+                    }
+                }
+                u = isHead ? 1 : 0;
+            }
+        }
+        const LbResult r = lb_scan_tile(tile, u, (unsigned long long)u * nr, tiles);
+        const bool room = r.baseC + r.tileC <= headRoom && r.baseW + r.tileW <= outRoom && r.baseW + r.tileW < (1ull << 32);
+        if (tile == numTiles - 1 && threadIdx.x == 0) {
+            ctl->nHeads = (unsigned int)(r.baseC + r.tileC);
+            ctl->totalHeadRows = r.baseW + r.tileW;
+        }
+        if (!room) {
+            if (threadIdx.x == 0)
+                ctl->error = MAF_ERR_OUT_ROOM;
+            return;
+        }
+        if (s >= nSeg)
+            continue;
+        if (g.cls == COL_SKIPPED) {
+            for (uint32_t t = 0; t < g.len; ++t)
+                head[g.col + t] = 2;
+            continue;
+        }
+        if (g.cls == COL_KEYS_ONLY)
+            for (uint32_t t = 0; t < g.len; ++t)
+                head[g.col + t] = U.collapseKeysOnly && t > 0 ? 2 : 3;
+        if (g.cls == COL_WRITTEN && u)
+            head[g.col] = 1;
+        for (uint32_t t = 0; t < u; ++t) {
+            const uint32_t unit = (uint32_t)r.exC + t, o = (uint32_t)r.exW + t * nr;
+            headOff[unit] = o;
+            headCol[unit] = g.col + t;
+            const int64_t shift = (int64_t)g.j + t; // the same bases `shift` columns on along their strands
+            int32_t rk[UNIQUE_SORT_ROWS];
+            const bool cached = nr <= (uint32_t)UNIQUE_SORT_ROWS;
+            auto moved = [&](uint32_t i) {
+                ColumnRow x = U.rows[a + i];
+                x.pos = x.rev ? x.pos - shift : x.pos + shift;
+                return x;
+            };
+            if (cached)
+                for (uint32_t i = 0; i < nr; ++i) {
+                    int64_t key;
+                    maf_describe(desc, rankBase, moved(i), key, rk[i]);
+                }
+            for (uint32_t i = 0; i < nr; ++i) {
+                int64_t key;
+                int32_t rank;
+                maf_describe(desc, rankBase, moved(i), key, rank);
+                uint32_t place = 0;
+                for (uint32_t j = 0; j < nr; ++j) {
+                    int32_t rj;
+                    if (cached) {
+                        rj = rk[j];
+                    } else {
+                        int64_t kj;
+                        maf_describe(desc, rankBase, moved(j), kj, rj);
+                    }
+                    place += (rj < rank || (rj == rank && j < i)) ? 1u : 0u;
+                }
+                out[o + place] = MafHeadRow{key, rank, i};
             }
         }
     }

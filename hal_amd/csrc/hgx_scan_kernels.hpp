@@ -115,6 +115,19 @@ HGX_SCAN_DEV __forceinline__ unsigned lb_take_tile(unsigned int *ticket) {
     __syncthreads();
     return sTile;
 }
+// the same, and a word every thread of the workgroup must see the same value of (an error flag other workgroups may set while this
+// one looks at it: threads that read it for themselves could part ways in front of a barrier)
+HGX_SCAN_DEV __forceinline__ unsigned lb_take_tile(unsigned int *ticket, const unsigned int *word, unsigned &value) {
+    __shared__ unsigned sTile2, sWord;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        sTile2 = atomicAdd(ticket, 1u);
+        sWord = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    value = sWord;
+    return sTile2;
+}
 // A workgroup of 256 threads: thread t brings the sums (c, w) of its own items; it gets back the sums of everything in front of its
 // items in the whole launch (exC, exW), and every thread the tile's own totals and the totals in front of the tile.
 struct LbResult {
