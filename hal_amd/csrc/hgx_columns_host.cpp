@@ -2701,7 +2701,9 @@ void MafExport::convertSequenceRuns(std::ostream &mafStream, hgx_alignment *alig
         void operator()(MafChunkStream *m) const { mafChunkStreamClose(m); }
     };
     std::unique_ptr<MafChunkStream, StreamCloser> chunkStream;
-    bool streamAllowed = alignment->dev != nullptr;
+    // (an export of one batch has nothing to queue ahead, and a stream's buffers, streams and page-locked arena are set up per export:
+    // hgx_maf_export_multi's million-column slices went from 0.26 to 0.82 s with a stream each)
+    bool streamAllowed = alignment->dev != nullptr && length > (int64_t)chunkColumns;
 #ifdef HGX_HOST_PROFILE
     if (mafReplayFile() || mafDumpFile())
         streamAllowed = false; // (the recordings hold the device's rows as they were)
