@@ -7,6 +7,7 @@
 // boundaries.  The walk order is the reference's (updateParent, then paralogs, then the parse-down subtree;
 // :246-355, :556-744) so that rows come out in ColumnMap insertion order for the MAF writer.
 #pragma once
+#include "hgx_scan_kernels.hpp"
 #include "hgx_device.hpp"
 #include <hip/hip_runtime.h>
 
@@ -840,6 +841,61 @@ static __global__ void __launch_bounds__(256) k_sweep_out(const AT *__restrict__
                                                           int32_t *__restrict__ out, int accumulate) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
         out[i] = (accumulate ? out[i] : 0) + (int32_t)A[first + i * step] - sub;
+}
+
+
+// ---- halAlignmentDepth's lines on the device ----
+// "%d\n" per column (alignmentDepth/halAlignmentDepth.cpp:246, 271, 305).  The host's threads counted and wrote a quarter of a
+// billion lines in 40 ms beside a scan of 12; here a lane takes eight values, the lines' lengths cross the tiles by the one-pass
+// scan (hgx_scan_kernels.hpp), the lane writes its lines where they belong.  ctl: {ticket, unused, total bytes (64 bits)}.
+struct WigCtl {
+    unsigned int ticket, _pad;
+    unsigned long long bytes;
+};
+static constexpr uint32_t WIG_TILE = 2048;
+static __global__ void __launch_bounds__(256) k_wig_text(const int32_t *__restrict__ vals, uint32_t n, WigCtl *ctl, unsigned long long *tiles,
+                                                         char *__restrict__ text) {
+    const unsigned tile = lb_take_tile(&ctl->ticket);
+    const unsigned numTiles = (n + WIG_TILE - 1) / WIG_TILE;
+    if (tile >= numTiles)
+        return;
+    const uint32_t i0 = tile * WIG_TILE + threadIdx.x * 8;
+    int32_t v[8];
+    uint32_t len[8];
+    unsigned long long w = 0;
+    for (int j = 0; j < 8; ++j) {
+        len[j] = 0;
+        v[j] = 0;
+        if (i0 + (uint32_t)j < n) {
+            v[j] = vals[i0 + j];
+            uint32_t u = v[j] < 0 ? 0u - (uint32_t)v[j] : (uint32_t)v[j];
+            uint32_t k = v[j] < 0 ? 3 : 2; // a digit and the newline (and the sign)
+            while (u >= 10) {
+                u /= 10;
+                ++k;
+            }
+            len[j] = k;
+            w += k;
+        }
+    }
+    const LbResult r = lb_scan_tile(tile, 0, w, tiles);
+    char *o = text + r.exW;
+    for (int j = 0; j < 8; ++j) {
+        if (!len[j])
+            continue;
+        uint32_t u = v[j] < 0 ? 0u - (uint32_t)v[j] : (uint32_t)v[j];
+        if (v[j] < 0)
+            *o++ = '-';
+        const uint32_t digits = len[j] - (v[j] < 0 ? 2u : 1u);
+        for (uint32_t d = digits; d > 0; --d) {
+            o[d - 1] = (char)('0' + u % 10);
+            u /= 10;
+        }
+        o += digits;
+        *o++ = '\n';
+    }
+    if (tile == numTiles - 1 && threadIdx.x == 0)
+        ctl->bytes = r.baseW + r.tileW;
 }
 
 } // namespace hgx

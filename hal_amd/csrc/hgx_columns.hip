@@ -530,6 +530,69 @@ void columnsDepthChunksHost(hgx_alignment *h, int ref, int64_t first, int64_t co
                   sink);
 }
 
+// halAlignmentDepth's lines made on the device (k_wig_text): the values never leave it; the text of a chunk of values comes to a
+// page-locked block while the next chunk's is made, and goes to `sink` in order.
+void columnsDepthTextChunksHost(hgx_alignment *h, int ref, int64_t first, int64_t count, int64_t step, int mode, const ColumnOptions &opt,
+                                ColumnStats *stats, int64_t chunk, const std::function<void(const char *, size_t)> &sink) {
+    if (!h->dev)
+        throw std::runtime_error("alignment was opened without a device (device = -1); the column engine needs the HIP path");
+    HIP_OK(hipSetDevice(h->dev->device));
+    if (count <= 0)
+        return;
+    chunk = std::max<int64_t>(1, std::min<int64_t>(chunk, (int64_t)1 << 26)); // (a chunk's lines: 12 bytes each at most, offsets below 2^38)
+    Buf d((size_t)count * 4);
+    columnsDepthDevice(h, ref, first, count, step, mode, opt, (int32_t *)d.p, nullptr, stats, false);
+    HIP_OK(hipDeviceSynchronize());
+    const int32_t *values = (const int32_t *)d.p;
+    struct Side {
+        hipStream_t s = nullptr;
+        Buf text, ctl; // ctl: WigCtl (16 bytes), then the scan's tiles
+        int64_t lo = 0, n = 0;
+        ~Side() {
+            if (s) {
+                (void)hipStreamSynchronize(s);
+                (void)hipStreamDestroy(s);
+            }
+        }
+    } side[2];
+    const size_t tiles = (size_t)((std::min(chunk, count) + WIG_TILE - 1) / WIG_TILE) + 1;
+    const int64_t numChunks = (count + chunk - 1) / chunk;
+    for (int k = 0; k < 2 && k < numChunks; ++k) {
+        HIP_OK(hipStreamCreateWithFlags(&side[k].s, hipStreamNonBlocking));
+        side[k].text.resize((size_t)std::min(chunk, count) * 12);
+        side[k].ctl.resize(16 + tiles * 8);
+    }
+    auto launch = [&](int64_t c) {
+        Side &S = side[c & 1];
+        S.lo = c * chunk;
+        S.n = std::min(chunk, count - S.lo);
+        HIP_OK(hipMemsetAsync(S.ctl.p, 0, 16 + tiles * 8, S.s));
+        const uint32_t nt = (uint32_t)((S.n + WIG_TILE - 1) / WIG_TILE);
+        hipLaunchKernelGGL(k_wig_text, dim3(nt), dim3(256), 0, S.s, values + S.lo, (uint32_t)S.n, (WigCtl *)S.ctl.p, (unsigned long long *)((char *)S.ctl.p + 16),
+                           (char *)S.text.p);
+    };
+    auto finish = [&](int64_t c) {
+        Side &S = side[c & 1];
+        WigCtl ctl{0, 0, 0};
+        HIP_OK(hipMemcpyAsync(&ctl, S.ctl.p, sizeof ctl, hipMemcpyDeviceToHost, S.s));
+        HIP_OK(hipStreamSynchronize(S.s));
+        const size_t bytes = (size_t)ctl.bytes;
+        struct Block {
+            char *p;
+            ~Block() { hostBlockGive(p); }
+        } block{static_cast<char *>(hostBlockTake(std::max<size_t>(bytes, 1)))};
+        HIP_OK(hipMemcpyAsync(block.p, S.text.p, bytes, hipMemcpyDeviceToHost, S.s));
+        HIP_OK(hipStreamSynchronize(S.s));
+        sink(block.p, bytes);
+    };
+    for (int64_t c = 0; c < numChunks; ++c) {
+        launch(c);
+        if (c > 0)
+            finish(c - 1);
+    }
+    finish(numChunks - 1);
+}
+
 void columnsRowsHost(hgx_alignment *h, int ref, int64_t first, int64_t count, const ColumnOptions &opt, bool withDna,
                      std::vector<uint64_t> &rowOffset, std::vector<ColumnRowHost> &rows, ColumnStats *stats) {
     static_assert(sizeof(ColumnRowHost) == sizeof(ColumnRow), "row layouts must match");

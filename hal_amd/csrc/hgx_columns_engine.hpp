@@ -71,6 +71,10 @@ void columnsDepthDevice(hgx_alignment *h, int ref, int64_t first, int64_t count,
 // on the host)
 void columnsDepthChunksHost(hgx_alignment *h, int ref, int64_t first, int64_t count, int64_t step, int mode, const ColumnOptions &opt,
                             ColumnStats *stats, int64_t chunk, const std::function<void(const int32_t *, int64_t, int64_t)> &sink);
+// the same values as halAlignmentDepth's lines ("%d\n" each), made on the device (k_wig_text) and handed to `sink(text, bytes)` chunk by
+// chunk, in order
+void columnsDepthTextChunksHost(hgx_alignment *h, int ref, int64_t first, int64_t count, int64_t step, int mode, const ColumnOptions &opt,
+                                ColumnStats *stats, int64_t chunk, const std::function<void(const char *, size_t)> &sink);
 // every reported base of columns [first, first+count), in the reference's ColumnMap insertion order;
 // rowOffset gets count+1 entries
 void columnsRowsHost(hgx_alignment *h, int ref, int64_t first, int64_t count, const ColumnOptions &opt, bool withDna,

@@ -70,6 +70,26 @@ static void depthSequence(std::ostream &os, hgx_alignment *h, int genome, int se
         int64_t chunk = (int64_t)1 << 24;
         if (const char *e = getenv("HGX_WIG_CHUNK"))
             chunk = std::max<int64_t>(1, atoll(e));
+        // the lines made on the device where there is one (k_wig_text; HGX_WIG_DEVICE_TEXT=0: the host's threads): a chunk's text comes
+        // back instead of its values, and is copied into the output by a few threads while the next chunk's is made
+        if (h->dev && !(getenv("HGX_WIG_DEVICE_TEXT") && getenv("HGX_WIG_DEVICE_TEXT")[0] == '0')) {
+            columnsDepthTextChunksHost(h, genome, start + S.start, count, step, countDupes ? 1 : 0, opt, stats, chunk, [&os, sink](const char *text, size_t bytes) {
+                char *dst = sink && bytes >= ((size_t)1 << 20) ? sink->room(bytes) : nullptr;
+                if (!dst) {
+                    os.write(text, (std::streamsize)bytes);
+                    return;
+                }
+                const unsigned parts = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(hostThreads(), 8u), bytes >> 22));
+                std::vector<std::thread> th;
+                auto copy = [&](unsigned t) { memcpy(dst + bytes * t / parts, text + bytes * t / parts, bytes * (t + 1) / parts - bytes * t / parts); };
+                for (unsigned t = 1; t < parts; ++t)
+                    th.emplace_back(copy, t);
+                copy(0);
+                for (std::thread &x : th)
+                    x.join();
+            });
+            return;
+        }
         columnsDepthChunksHost(h, genome, start + S.start, count, step, countDupes ? 1 : 0, opt, stats, chunk,
                                [&lines](const int32_t *v, int64_t, int64_t n) { lines(v, n); });
         return;
