@@ -632,6 +632,7 @@ static constexpr int SWEEP_MAX_CHILDREN = 8;
 struct SweepChildren {
     SweepChild c[SWEEP_MAX_CHILDREN];
     int n;
+    int noRing; // --noDupes: a child slot's segment without its paralogy ring (updateNextTopDup is not run: halColumnIterator.cpp:642-681)
 };
 // sixteen lanes per bottom segment — four segments' dependent loads (segment bounds, child link, child record, ring links) are
 // in flight per wavefront instead of one —, and every lane moves 8 bytes of consecutive bases of the track (16 of 64-bit sets) as one
@@ -702,6 +703,66 @@ static __global__ void __launch_bounds__(256) k_sweep_up(const BotRec<C> *__rest
             if (!(SUM && accumulate) && o + V > len && len >= V)
                 o = len - V;
             const bool whole = o + V <= len;
+            if constexpr (sizeof(M) == 1 && !SUM) {
+                // byte-wide sets (a genome with at most eight counted genomes below it — most genomes of a large tree, and the launches
+                // most of the sweep's time went to): the lane's eight bases as ONE 64-bit word from the load to the store — a child's
+                // bases in the other orientation by a byte swap, its place in the parent's numbering by one masked shift of all eight
+                // (round 6; element by element the kernel held 108 VGPRs, four wavefronts a SIMD, for arithmetic a few 64-bit
+                // operations do).  A child's word is a byte as well: its subtree is part of this genome's.
+                const unsigned long long ones = 0x0101010101010101ull;
+                unsigned long long pv = ones * (unsigned long long)(uint8_t)own;
+                if (accumulate) {
+                    if (whole) {
+                        pv = sweep_load<unsigned long long>(S + start + o);
+                    } else {
+                        pv = 0;
+#pragma nounroll
+                        for (int j = 0; j < 8 && o + j < len; ++j) // (a segment of fewer than eight bases: rare, and not worth registers)
+                            pv |= (unsigned long long)(uint8_t)S[start + o + j] << (8 * j);
+                    }
+                }
+                for (int k = 0; k < ch.n; ++k) {
+                    const int32_t enc = ch.c[k].enc[b];
+                    if (enc < 0)
+                        continue;
+                    const uint8_t *T = (const uint8_t *)ch.c[k].track;
+                    if (!T) {
+                        pv |= ones * (unsigned long long)(uint8_t)ch.c[k].constant;
+                        continue;
+                    }
+                    const TopRec<C> *top = (const TopRec<C> *)ch.c[k].top;
+                    const int shift = ch.c[k].shift;
+                    const unsigned long long keep = ones * (unsigned long long)(0xFFu >> shift);
+                    const int32_t t0 = enc >> 1;
+                    int32_t t = t0;
+                    do {
+                        const TopRec<C> tr = top[t];
+                        const uint8_t *base = T + (int64_t)tr.start;
+                        const bool rev = (tr.parentEnc & 1) != 0;
+                        unsigned long long x;
+                        if (whole) {
+                            x = sweep_load<unsigned long long>(base + (rev ? len - o - 8 : o));
+                            if (rev)
+                                x = __builtin_bswap64(x);
+                        } else {
+                            x = 0;
+#pragma nounroll
+                            for (int j = 0; j < 8 && o + j < len; ++j)
+                                x |= (unsigned long long)base[rev ? len - 1 - o - j : o + j] << (8 * j);
+                        }
+                        pv |= (x & keep) << shift;
+                        t = ch.noRing ? -1 : tr.paralogy;
+                    } while (t >= 0 && t != t0);
+                }
+                if (whole) {
+                    sweep_store(S + start + o, pv);
+                } else {
+#pragma nounroll
+                    for (int j = 0; j < 8 && o + j < len; ++j)
+                        S[start + o + j] = (M)(pv >> (8 * j));
+                }
+                continue;
+            }
             SweepVec<M> v;
             if (accumulate && whole) { // (more than SWEEP_MAX_CHILDREN children: several launches)
                 v = sweep_load<SweepVec<M>>(S + start + o);
@@ -748,7 +809,7 @@ static __global__ void __launch_bounds__(256) k_sweep_up(const BotRec<C> *__rest
                         for (int j = 0; j < V; ++j)
                             v.e[j] = track_join<M, SUM>(v.e[j], (M)ch.c[k].constant);
                     }
-                    t = tr.paralogy;
+                    t = ch.noRing ? -1 : tr.paralogy;
                 } while (t >= 0 && t != t0);
             }
             if (whole) {
@@ -787,7 +848,7 @@ template <bool SUM> __device__ __forceinline__ int32_t track_size_at(const void 
 template <typename C, typename M, bool SUM, typename AT>
 static __global__ void __launch_bounds__(256) k_sweep_down(const TopRec<C> *__restrict__ top, int64_t numTop, const BotRec<C> *__restrict__ pbot,
                                                            const AT *__restrict__ pA, const M *__restrict__ pS, const void *__restrict__ S, int sLog,
-                                                           int32_t ownSize, AT *__restrict__ A) {
+                                                           int32_t ownSize, AT *__restrict__ A, const int32_t *__restrict__ pEnc = nullptr) {
     constexpr int V = sizeof(AT) == 1 ? 8 : 4; // bases per lane and round: an 8- or 16-byte word of A
     struct AVec {
         AT e[V];
@@ -800,7 +861,9 @@ static __global__ void __launch_bounds__(256) k_sweep_down(const TopRec<C> *__re
     for (int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; t < numTop; t += groupsTotal) {
         const TopRec<C> tr = top[t];
         const int64_t start = (int64_t)tr.start, len = (int64_t)top[t + 1].start - start;
-        const bool hasParent = tr.parentEnc >= 0, rev = (tr.parentEnc & 1) != 0;
+        // (pEnc — --noDupes: the parent's links to this genome: only the segment a parent's slot names goes up, mmapTopSegment.cpp:30-40;
+        // the others' columns end with them, as an insertion's)
+        const bool hasParent = tr.parentEnc >= 0 && (!pEnc || (int64_t)(pEnc[tr.parentEnc >> 1] >> 1) == t), rev = (tr.parentEnc & 1) != 0;
         const int64_t pstart = hasParent ? (int64_t)pbot[tr.parentEnc >> 1].start : 0;
         for (int64_t o_ = (int64_t)sub * V; o_ < len; o_ += 16 * V) {
             const int64_t o = o_ + V > len && len >= V ? len - V : o_; // (the last lane: the segment's last V bases, as in k_sweep_up)

@@ -160,10 +160,20 @@ struct SweepTrack {
 template <typename C, bool SUM, typename AT>
 static void sweepTracks(hgx_alignment *h, const std::vector<int> &postOrder, const std::vector<int> &path, const std::vector<char> &inScope,
                         const std::vector<SweepTrack> &track, const std::vector<char> &hasTrack, std::vector<Buf> &S, std::vector<Buf> &A,
-                        hipStream_t s) {
+                        hipStream_t s, bool noDupes = false) {
     const Image &img = h->img;
     const DeviceImage &D = *h->dev;
     const int GRID = 4096;
+    // (--noDupes: the parent's links to a genome of the path, by which k_sweep_down tells the segment that goes up)
+    auto linksTo = [&](int p, int c) -> const int32_t * {
+        if (!noDupes)
+            return nullptr;
+        const GenomeTables &P = img.genomes[(size_t)p];
+        for (size_t k = 0; k < P.children.size(); ++k)
+            if (P.children[k] == c)
+                return D.genomes[(size_t)p].childEnc[k];
+        return nullptr;
+    };
     for (int g : postOrder) {
         const GenomeTables &G = img.genomes[(size_t)g];
         const DeviceGenome &dg = D.genomes[(size_t)g];
@@ -182,6 +192,7 @@ static void sweepTracks(hgx_alignment *h, const std::vector<int> &postOrder, con
         }
         for (size_t at = 0; at < kids.size(); at += SWEEP_MAX_CHILDREN) {
             SweepChildren ch;
+            ch.noRing = noDupes ? 1 : 0;
             ch.n = (int)std::min<size_t>(SWEEP_MAX_CHILDREN, kids.size() - at);
             for (int k = 0; k < ch.n; ++k)
                 ch.c[k] = kids[at + (size_t)k];
@@ -228,7 +239,7 @@ static void sweepTracks(hgx_alignment *h, const std::vector<int> &postOrder, con
     hipLaunchKernelGGL((k_sweep_down<C, M, SUM, AT>), dim3(GRID), dim3(256), 0, s, (const TopRec<C> *)D.genomes[(size_t)c].top,               \
                        (int64_t)img.genomes[(size_t)c].numTop, (const BotRec<C> *)D.genomes[(size_t)p].bot,                                   \
                        i == 1 ? (const AT *)nullptr : (const AT *)A[(size_t)p].p, i == 1 ? (const M *)S[(size_t)p].p : (const M *)nullptr, Sc,  \
-                       track[(size_t)c].wlog, sizeOfOwn(c), (AT *)A[(size_t)c].p)
+                       track[(size_t)c].wlog, sizeOfOwn(c), (AT *)A[(size_t)c].p, linksTo(p, c))
         const int pl = track[(size_t)p].wlog;
         if (SUM)
             HGX_DOWN(int32_t);
@@ -847,7 +858,7 @@ struct MafTracks {
     std::atomic<uint64_t> chunks{0};   // chunks served
     std::atomic<uint64_t> deviceUs{0}, servedColumns{0}, servedHeads{0}, servedMarked{0}; // ... their kernels' time (HIP events), columns, heads
     int ref = -1;
-    bool noAncestors = false;
+    bool noAncestors = false, noDupes = false;
     std::vector<int> targets;
     int device = -1;
     std::vector<Buf> S, D, A, F;
@@ -899,6 +910,7 @@ static void mafBreakSweeps(hgx_alignment *h, const SweepScope &sc, const std::ve
         size_t at = 0;
         do {
             BreakChildren ch;
+            ch.noRing = M.noDupes ? 1 : 0;
             ch.n = (int)std::min<size_t>(SWEEP_MAX_CHILDREN, kids.size() - at);
             for (int k = 0; k < ch.n; ++k)
                 ch.c[k] = kids[at + (size_t)k];
@@ -918,16 +930,25 @@ static void mafBreakSweeps(hgx_alignment *h, const SweepScope &sc, const std::ve
     }
     for (size_t i = 1; i < sc.path.size(); ++i) {
         const int c = sc.path[i], p = sc.path[i - 1];
+        const int32_t *pEnc = nullptr; // (--noDupes: the parent's links to the path's genome)
+        if (M.noDupes) {
+            const GenomeTables &P = img.genomes[(size_t)p];
+            for (size_t k = 0; k < P.children.size(); ++k)
+                if (P.children[k] == c)
+                    pEnc = D.genomes[(size_t)p].childEnc[k];
+        }
         hipLaunchKernelGGL((k_break_down<C>), dim3(GRID), dim3(256), 0, s, (const TopRec<C> *)D.genomes[(size_t)c].top, (int64_t)img.genomes[(size_t)c].numTop,
                            (const BotRec<C> *)D.genomes[(size_t)p].bot, (const uint8_t *)M.F[(size_t)p].p,
-                           hasTrack[(size_t)c] ? (const uint8_t *)M.D[(size_t)c].p : (const uint8_t *)nullptr, (uint8_t *)M.F[(size_t)c].p);
+                           hasTrack[(size_t)c] ? (const uint8_t *)M.D[(size_t)c].p : (const uint8_t *)nullptr, (uint8_t *)M.F[(size_t)c].p, pEnc);
     }
 }
 
 // the tracks of (ref, opt) — from the handle, or built now; null when the sweeps do not pay or do not fit
 static std::shared_ptr<MafTracks> mafTracksFor(hgx_alignment *h, int ref, const ColumnOptions &opt, int64_t exportColumns) {
-    if (opt.noDupes || opt.onlyOrthologs)
-        return nullptr; // (options that cut edges of the column's tree: the walk)
+    if (opt.onlyOrthologs)
+        return nullptr; // (the paralogs of the path's own segments left out, the children's kept: the walk)
+    // (--noDupes cuts the same edges everywhere — no ring is followed, only the segment a parent's slot names goes up: the sweeps and the
+    // row selection take it as a flag)
     const Image &img = h->img;
     const int ng = (int)img.genomes.size();
     std::vector<int> tg(opt.targets.begin(), opt.targets.end());
@@ -936,7 +957,7 @@ static std::shared_ptr<MafTracks> mafTracksFor(hgx_alignment *h, int ref, const 
     std::lock_guard<std::mutex> lock(h->mafTracksMutex);
     if (h->mafTracks) {
         std::shared_ptr<MafTracks> have = std::static_pointer_cast<MafTracks>(h->mafTracks);
-        if (have->ref == ref && have->noAncestors == opt.noAncestors && have->targets == tg && have->device == h->dev->device) {
+        if (have->ref == ref && have->noAncestors == opt.noAncestors && have->noDupes == opt.noDupes && have->targets == tg && have->device == h->dev->device) {
             const char *env = getenv("HGX_MAF_SWEEP");
             return env && env[0] == '0' ? nullptr : have;
         }
@@ -975,6 +996,7 @@ static std::shared_ptr<MafTracks> mafTracksFor(hgx_alignment *h, int ref, const 
     std::shared_ptr<MafTracks> M(new MafTracks);
     M->ref = ref;
     M->noAncestors = opt.noAncestors;
+    M->noDupes = opt.noDupes;
     M->targets = tg;
     M->device = h->dev->device;
     M->bytes = need;
@@ -1000,10 +1022,10 @@ static std::shared_ptr<MafTracks> mafTracksFor(hgx_alignment *h, int ref, const 
     Ev a, b;
     HIP_OK(hipEventRecord(a.e, s));
     if (h->dev->wide) {
-        sweepTracks<int64_t, true, int32_t>(h, sc.postOrder, sc.path, sc.inScope, track, hasTrack, M->S, M->A, s);
+        sweepTracks<int64_t, true, int32_t>(h, sc.postOrder, sc.path, sc.inScope, track, hasTrack, M->S, M->A, s, opt.noDupes);
         mafBreakSweeps<int64_t>(h, sc, hasTrack, *M, s);
     } else {
-        sweepTracks<int32_t, true, int32_t>(h, sc.postOrder, sc.path, sc.inScope, track, hasTrack, M->S, M->A, s);
+        sweepTracks<int32_t, true, int32_t>(h, sc.postOrder, sc.path, sc.inScope, track, hasTrack, M->S, M->A, s, opt.noDupes);
         mafBreakSweeps<int32_t>(h, sc, hasTrack, *M, s);
     }
     { // where a column's walk begins: the reference segment of its base, from a table of a bucket per four segments

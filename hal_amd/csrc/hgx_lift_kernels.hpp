@@ -113,6 +113,21 @@ template <typename C> struct alignas(16) LiftAsk {
 // all of them is a queue of same-address atomics at the memory side, 15 ns each).  k_lift_classify's workers take the lists, its
 // tiles leave the intervals of the mask alone.  waveExtra / groupExtra: see k_lift_classify.
 static constexpr uint32_t LIFT_LISTS = 64, LIFT_LIST_PITCH = 16; // (counters 128 bytes apart)
+// the rule of the list for one interval, from the interval and the bucket bits alone (k_lift_general_list's, two dependent loads):
+// the scouts of k_lift_classify find their intervals with it and the tiles tell by it which intervals are not theirs — the same
+// function of the same words on both sides, so nothing has to pass between them
+__device__ __forceinline__ bool lift_listed(int64_t gs, int64_t ge, int64_t genomeLength, const uint32_t *__restrict__ bits, int shift,
+                                            int64_t window) {
+    const bool valid = ge >= gs && gs >= 0 && gs < genomeLength;
+    if (!valid)
+        return false;
+    const int64_t b0 = gs >> shift, nbk = ((ge < genomeLength ? ge : genomeLength - 1) >> shift) - b0 + 1;
+    if (ge - gs >= window || nbk > 32)
+        return true;
+    const uint64_t both = ((uint64_t)bits[(b0 >> 5) + 1] << 32) | bits[b0 >> 5];
+    return (((uint32_t)(both >> (b0 & 31))) & (nbk >= 32 ? 0xFFFFFFFFu : ((1u << nbk) - 1u))) != 0;
+}
+static constexpr uint32_t LIFT_SCOUT_ROUND = 1024; // intervals a scout workgroup looks at before it finishes what it found among them
 static __global__ void __launch_bounds__(256) k_lift_general_list(const int64_t *__restrict__ gStart, const int64_t *__restrict__ gEnd, uint32_t nq,
                                                                   int64_t genomeLength, const uint32_t *__restrict__ bits, int shift, int64_t window,
                                                                   unsigned long long *__restrict__ mask, uint32_t *__restrict__ list, uint32_t listCap,
@@ -205,7 +220,9 @@ static __global__ void __launch_bounds__(256, MINW) k_lift_classify(const int64_
                                                               uint32_t workers, uint32_t *__restrict__ waveExtra,
                                                               const unsigned long long *__restrict__ workMask, const uint32_t *__restrict__ workList,
                                                               uint32_t workListCap, const unsigned long long *__restrict__ workCounts,
-                                                              unsigned long long *__restrict__ groupExtra) {
+                                                              unsigned long long *__restrict__ groupExtra, uint32_t scoutShare,
+                                                              const uint32_t *__restrict__ flagBits, uint32_t mLast, uint32_t *__restrict__ otherWaveExtra,
+                                                              unsigned long long *__restrict__ otherGroupExtra) {
     __shared__ C sDAll[INLINE ? 4 : 1][INLINE ? 128 : 1];
     __shared__ uint8_t sOwnAll[INLINE ? 4 : 1][INLINE ? 64 : 1];
     __shared__ LiftAsk<C> sAsk[4][64];
@@ -215,6 +232,90 @@ static __global__ void __launch_bounds__(256, MINW) k_lift_classify(const int64_
     uint32_t generalSeen = 0, used = 0, generalLines = 0;
     const uint32_t nTiles = (nq + (uint32_t)LIFT_TILE - 1) >> LIFT_TILE_SHIFT;
     LIFT_PROF_DECL;
+    if (INLINE && blockIdx.x < workers && scoutShare != 0) {
+        // ---- a scout (round 6): a worker that finds its general intervals itself.  The workgroups in front of the grid each look at
+        // a share of the batch — the interval's two ends and two words of the bucket bits, lift_listed: four intervals a thread, their
+        // loads issued together —, put what they find in a list in LDS and finish it, a wavefront an interval, round-robin.  No
+        // launch in front (k_lift_general_list's pass over the batch cost what the tail it removed did, and more once batches
+        // overlap: DESIGN 4.0.2, 4.0.3), nothing passed between workgroups: a scout takes an interval exactly when the tile's own
+        // scan calls it general for a flag or its length (the same test on both sides).  Every general interval of the batch is
+        // under way three microseconds into the launch.
+        uint32_t *sList = (uint32_t *)&sAnswer[0][0]; // (1024 words: LIFT_SCOUT_ROUND)
+        __shared__ uint32_t sListN;
+        const uint32_t lo = blockIdx.x * scoutShare, hi = lo + scoutShare < nq ? lo + scoutShare : nq;
+        for (uint32_t base = lo; base < hi; base += LIFT_SCOUT_ROUND) { // (usually one round: the host sizes the shares for it)
+            if (threadIdx.x == 0)
+                sListN = 0;
+            __syncthreads();
+            uint32_t sq[4];
+            int64_t sgs[4], sge[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                sq[u] = base + (uint32_t)u * 256u + threadIdx.x;
+                sgs[u] = 0;
+                sge[u] = -1;
+                if (sq[u] < hi) {
+                    sgs[u] = gStart[sq[u]];
+                    sge[u] = gEnd[sq[u]];
+                }
+            }
+            bool mine[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                mine[u] = lift_listed(sgs[u], sge[u], genomeLength, flagBits, shift, window);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned long long m = __ballot(mine[u]);
+                if (m) {
+                    uint32_t at = 0;
+                    if (lane == 0)
+                        at = atomicAdd(&sListN, (uint32_t)__popcll(m));
+                    at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+                    if (mine[u])
+                        sList[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = sq[u];
+                }
+            }
+            __syncthreads();
+            const uint32_t nWork = sListN;
+            for (uint32_t i = (uint32_t)w; i < nWork; i += 4u) {
+                const uint32_t oq = (uint32_t)__builtin_amdgcn_readfirstlane((int)sList[i]);
+                const int64_t os = gStart[oq], oe = gEnd[oq];
+                {   // the tile's own question, put to the interval's first 64 merged records at once: is it general for a flag or for its
+                    // length, with a record?  Only then is it the scout's (the bits say "may be": a quarter of the listed are not)
+                    const C gsC = (C)os, geC = (C)(oe < genomeLength ? oe : genomeLength - 1);
+                    const uint32_t k0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)coarse[os >> shift]);
+                    const uint32_t idx = k0 + (uint32_t)lane < mLast ? k0 + (uint32_t)lane : mLast;
+                    const ComposedRec<C> r = recs[idx];
+                    const bool ov = r.sLo <= geC && r.sLo + r.len - 1 >= gsC;
+                    const bool take = __ballot(ov) != 0 && (oe - os >= window || __ballot(ov && ((r.mEncF >> 1) & 1u) != 0) != 0);
+                    if (!take)
+                        continue;
+                }
+                int nl = 0;
+                uint32_t gbase = 0;
+                const int rc = general_interval<C>(lane, GT, oq, os, oe, strand[oq], sDAll[w], sOwnAll[w], used, nl, gbase LIFT_PROF_ARG);
+                if (lane == 0) {
+                    if (rc == 0)
+                        lateList[atomicAdd(lateCount, 1ull)] = oq;
+                    kb[oq] = make_uint2(0u, KB_GENERAL);
+                    offset[oq] = gbase;
+                    nOut[oq] = (uint32_t)nl;
+                    if (nl > 0) {
+                        atomicAdd(&waveExtra[oq >> 6], (uint32_t)nl);
+                        atomicAdd(&groupExtra[oq >> (6 + LIFT_TILE_SHIFT)], (unsigned long long)nl);
+                    }
+                }
+                generalSeen += lane == 0 ? 1u : 0u;
+                generalLines += lane == 0 ? (uint32_t)nl : 0u;
+            }
+            __syncthreads();
+        }
+        stat_add(&kstat[0], used);
+        stat_add(&kstat[1], generalSeen);
+        stat_add(&kstatStore[1], generalLines);
+        stat_add(&GT.counters[CNT_DSTAT0 + STAT_MAPPED], used);
+        return;
+    }
     if (INLINE && blockIdx.x < workers) {
         // ---- a worker: the general intervals k_lift_general_list found, a wavefront each, dealt round-robin.  The workgroups in
         // front of the grid do this, so the general intervals of the whole batch are under way when the launch begins and not when
@@ -306,8 +407,11 @@ static __global__ void __launch_bounds__(256, MINW) k_lift_classify(const int64_
         // interval more than that saves: profiles/r02k_notes.md.)
         const bool general = valid && (cnt > 0 || (ans.y & 2u)) && ((ans.y & 3u) != 0 || ge - gs >= window);
         // (with workers: the intervals they take — every one with a flagged record among its own, and then some — are theirs
-        // to answer; what is left for the tile is an interval with more records than the scan holds, which is listed)
-        const bool theirs = INLINE && workers != 0 && q < nq && ((workMask[q >> 6] >> lane) & 1ull) != 0;
+        // to answer; what is left for the tile is an interval with more records than the scan holds, which is listed.  Scouts take
+        // exactly the general intervals with a record and a flag or the window's length: what the tile has just found out itself —
+        // a test by the bucket bits here, two more gathers an interval, cost the launch ten microseconds)
+        const bool theirs = INLINE && workers != 0 && q < nq &&
+                            (scoutShare != 0 ? general && cnt > 0 && ((ans.y & 1u) != 0 || ge - gs >= window) : ((workMask[q >> 6] >> lane) & 1ull) != 0);
         if (q < nq && !theirs)
             kb[q] = general ? make_uint2(0u, KB_GENERAL) : cnt ? make_uint2(ans.z, ans.w - ans.z + 1u) : make_uint2(0u, 0u);
         generalSeen += general && !theirs ? 1u : 0u;
@@ -347,6 +451,13 @@ static __global__ void __launch_bounds__(256, MINW) k_lift_classify(const int64_
         const uint32_t waveLines = wave_total(cnt);
         if (lane == 0)
             waveTotal[tile * 4u + (uint32_t)w] = waveLines;
+        // (scouts: the words the next batch's scouts add to — the other set of two — are cleared by this batch's tiles)
+        if (INLINE && otherWaveExtra) {
+            if (lane == 0)
+                otherWaveExtra[tile * 4u + (uint32_t)w] = 0;
+            if ((tile & 63u) == 0 && threadIdx.x == 0)
+                otherGroupExtra[tile >> 6] = 0;
+        }
         LIFT_PROF(2) // general intervals done
         LIFT_PROF(3)
     }

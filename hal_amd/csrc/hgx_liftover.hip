@@ -279,7 +279,7 @@ struct hgx_liftover_plan {
     DevBuf fr[6][6], mp[2][6], counters, perQuery, offset, cursor, nOut, outOffset, blockSums, total, grouped, outRecords,
         deferredList, needCap, bigSlot, scratch, bigRecords, classLists, classCounts;
     // single-pass path over the merged table (hgx_lift_kernels.hpp)
-    DevBuf liftKb, liftStatus, liftWorkMask, liftWorkCounts;
+    DevBuf liftKb, liftStatus, liftWorkMask, liftWorkCounts, liftExtraAlt;
     int liftLaunches = 0;        // launches of the last single-pass run that keep statistics
     bool liftWaveFinish = true;
     // hgx_liftover_submit / _collect: a batch whose launches are queued (1) or that has been run to the end already (2)
@@ -299,6 +299,11 @@ struct hgx_liftover_plan {
     uint32_t liftWorkers = 0;    // workgroups of k_lift_classify that go for the general intervals first (from the last run's count)
     unsigned long long liftLastQueries = 0;
     int liftWorkersWanted = -1;  // hgx_liftover_plan_set_workers
+    // scouts (k_lift_classify): two sets of the words the general intervals' lines are counted in — {liftStatus's, liftExtraAlt} —, a
+    // batch counts in one and its tiles clear the other for the batch behind it.  liftExtraDirty[k]: the tiles set k may hold
+    // counts for (0: zero throughout); liftExtraSet: the set the next scout batch counts in
+    size_t liftExtraDirty[2] = {0, 0};
+    int liftExtraSet = 0;
     // scratch of the single-pass runs for intervals that outgrow the LDS finishing kernel (k_finish_big without a host
     // synchronisation in between): liftBigSlots slices for liftBigCap pieces each, grown when a run needed more
     uint32_t liftBigSlots = 0;
@@ -380,6 +385,7 @@ struct hgx_liftover_plan {
         // [lines k_lift_classify's workers add per 64 intervals | the same per group of 64 tiles | lines per 64 intervals | lines per group]
         liftGroupsCap = std::max(liftGroupsCap, (nq + 64 * LIFT_TILE - 1) / (64 * LIFT_TILE));
         liftStatus.ensure(32 * liftTilesCap + 16 * liftGroupsCap + 16);
+        liftExtraAlt.ensure(16 * liftTilesCap + 8 * liftGroupsCap + 16);
         liftWorkMask.ensure(8 * ((nq + 63) / 64 + 1));
         liftWorkCounts.ensure(8 * LIFT_LISTS * LIFT_LIST_PITCH);
     }
@@ -473,6 +479,8 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
         HIP_OK(hipMemsetAsync(P.liftStatus.p, 0, P.liftStatus.n, s));
         HIP_OK(hipMemsetAsync(generalCount, 0, 32, s));
         HIP_OK(hipMemsetAsync(P.liftWorkCounts.p, 0, P.liftWorkCounts.n, s));
+        HIP_OK(hipMemsetAsync(P.liftExtraAlt.p, 0, P.liftExtraAlt.n, s));
+        P.liftExtraDirty[0] = P.liftExtraDirty[1] = 0;
     }
     const bool events = P.timer.mode != 0; // (walk_ms / total_ms of the statistics need three event records per run)
     if (events)
@@ -505,7 +513,44 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
     unsigned long long *workCounts = (unsigned long long *)P.liftWorkCounts.p;
     if (workers && (size_t)workListCap * LIFT_LISTS > 2 * (size_t)nq + 2)
         workers = 0; // (a batch of a few hundred intervals: no room for 64 lists, and nothing to gain)
-    if (workers) {
+    // scouts (round 6): the workers find their intervals themselves (HGX_LIFT_SCOUT=0: k_lift_general_list's pass in front, round
+    // 3's form).  A share is a round of LIFT_SCOUT_ROUND intervals where the batch allows, so that a scout's intervals are all
+    // under way behind one look.  Measured at config 2 (profiles/r06w_scout_diag.txt), a batch by itself: 0.1068 ms against 0.1078
+    // with the pass and 0.1153 inline (k_lift_classify 0.0435 / 0.0365 + 0.0104 / 0.0527).  Batches launched and left still go
+    // inline: with two in flight the step is the sum of the launches' bodies (0.0846 ms), and the scouts' look at the batch is work
+    // added to it (0.0889)
+    const bool scoutsAllowed = !(getenv("HGX_LIFT_SCOUT") && getenv("HGX_LIFT_SCOUT")[0] == '0');
+    uint32_t scoutShare = 0;
+    uint32_t *otherWaveExtra = nullptr;
+    unsigned long long *otherGroupExtra = nullptr;
+    if (workers && scoutsAllowed) {
+        workers = std::min<uint32_t>(4096u, std::max<uint32_t>(workers, (nq + LIFT_SCOUT_ROUND - 1) / LIFT_SCOUT_ROUND));
+        scoutShare = (((nq + workers - 1) / workers) + 255u) & ~255u;
+        workers = (nq + scoutShare - 1) / scoutShare;
+        const int k = P.liftExtraSet;
+        uint32_t *altWave = (uint32_t *)P.liftExtraAlt.p;
+        unsigned long long *altGroup = (unsigned long long *)(altWave + 4 * P.liftTilesCap);
+        if (P.liftExtraDirty[k]) { // (the batch that should have cleared it was a shorter one, or not a scout batch)
+            if (k == 0) {
+                HIP_OK(hipMemsetAsync(waveExtra, 0, 16 * P.liftTilesCap + 8 * P.liftGroupsCap, s));
+            } else {
+                HIP_OK(hipMemsetAsync(altWave, 0, 16 * P.liftTilesCap + 8 * P.liftGroupsCap, s));
+            }
+        }
+        otherWaveExtra = k == 0 ? altWave : waveExtra;
+        otherGroupExtra = k == 0 ? altGroup : groupExtra;
+        if (k == 1) {
+            waveExtra = altWave;
+            groupExtra = altGroup;
+        }
+        P.liftExtraDirty[k] = nTiles;
+        if (P.liftExtraDirty[1 - k] <= nTiles)
+            P.liftExtraDirty[1 - k] = 0;
+        P.liftExtraSet = 1 - k;
+    } else if (workers) {
+        P.liftExtraDirty[0] = std::max(P.liftExtraDirty[0], (size_t)nTiles); // (k_lift_general_list clears what this batch counts in, and no more)
+    }
+    if (workers && !scoutShare) {
         P.timer.begin("k_lift_general_list", s);
         hipLaunchKernelGGL(k_lift_general_list, dim3((nq + 511) / 512), dim3(256), 0, s, dS, dE, nq, srcLength, (const uint32_t *)T.mFlagBits, T.mShift,
                            T.mWindow, (unsigned long long *)P.liftWorkMask.p, workList, workListCap, workCounts, waveExtra, groupExtra);
@@ -517,7 +562,8 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
                        srcLength, (const uint32_t *)T.mBuckets, T.mShift, T.mWindow, (const ComposedRec<C> *)T.mRecs, (uint2 *)P.liftKb.p, GT,\
                        kstat(), cnt + CNT_DSTAT0 + STAT_LAUNCH0 + 2 * storeLaunch, (uint32_t *)P.offset.p, (uint32_t *)P.nOut.p,              \
                        (uint32_t *)lateList, lateCount, waveTotal, workers, waveExtra, (const unsigned long long *)P.liftWorkMask.p,         \
-                       (const uint32_t *)workList, workListCap, (const unsigned long long *)workCounts, groupExtra)
+                       (const uint32_t *)workList, workListCap, (const unsigned long long *)workCounts, groupExtra, scoutShare,                \
+                       (const uint32_t *)T.mFlagBits, (uint32_t)(T.mNum + LIFT_SENTINELS - 1), otherWaveExtra, otherGroupExtra)
     if (!waveFinish) {
         HGX_CLASSIFY(false, 1);
     } else if constexpr (sizeof(C) == 8) {

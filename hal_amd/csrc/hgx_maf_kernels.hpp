@@ -36,6 +36,7 @@ struct BreakChild {
 struct BreakChildren {
     BreakChild c[SWEEP_MAX_CHILDREN];
     int n;
+    int noRing; // --noDupes (SweepChildren::noRing)
 };
 // eight bases of a track as one unaligned word; `rev`: the bases at the mirrored place, back to front
 HGX_DEV __forceinline__ unsigned long long break_word(const uint8_t *p, bool rev) {
@@ -87,7 +88,7 @@ HGX_DEV __forceinline__ void break_up_body(int64_t thread, int64_t threads, cons
                         for (int j = 0; j < 8 && o + j < len; ++j)
                             v |= (unsigned long long)base[rev ? len - o - j : o + j] << (8 * j);
                     }
-                    t = tr.paralogy;
+                    t = ch.noRing ? -1 : tr.paralogy;
                 } while (t >= 0 && t != t0);
             }
             if (o == 0)
@@ -113,13 +114,14 @@ static __global__ void __launch_bounds__(256) k_break_up(const BotRec<C> *__rest
 template <typename C>
 HGX_DEV __forceinline__ void break_down_body(int64_t thread, int64_t threads, const TopRec<C> *__restrict__ top, int64_t numTop,
                                              const BotRec<C> *__restrict__ pbot, const uint8_t *__restrict__ pF, const uint8_t *__restrict__ D,
-                                             uint8_t *__restrict__ F) {
+                                             uint8_t *__restrict__ F, const int32_t *__restrict__ pEnc = nullptr) {
     const int sub = (int)(thread & 15);
     const int64_t groupsTotal = threads >> 4;
     for (int64_t t = thread >> 4; t < numTop; t += groupsTotal) {
         const TopRec<C> tr = top[t];
         const int64_t start = (int64_t)tr.start, len = (int64_t)top[t + 1].start - start;
-        const bool hasParent = tr.parentEnc >= 0, rev = (tr.parentEnc & 1) != 0;
+        // (pEnc — --noDupes: only the segment the parent's slot names has a parent: k_sweep_down)
+        const bool hasParent = tr.parentEnc >= 0 && (!pEnc || (int64_t)(pEnc[tr.parentEnc >> 1] >> 1) == t), rev = (tr.parentEnc & 1) != 0;
         const uint8_t *base = hasParent ? pF + (int64_t)pbot[tr.parentEnc >> 1].start : (D ? D + start : nullptr);
         for (int64_t o0 = 0; o0 < len; o0 += 128) {
             int64_t o = o0 + (int64_t)sub * 8;
@@ -152,8 +154,9 @@ HGX_DEV __forceinline__ void break_down_body(int64_t thread, int64_t threads, co
 }
 template <typename C>
 static __global__ void __launch_bounds__(256) k_break_down(const TopRec<C> *__restrict__ top, int64_t numTop, const BotRec<C> *__restrict__ pbot,
-                                                           const uint8_t *__restrict__ pF, const uint8_t *__restrict__ D, uint8_t *__restrict__ F) {
-    break_down_body<C>((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, top, numTop, pbot, pF, D, F);
+                                                           const uint8_t *__restrict__ pF, const uint8_t *__restrict__ D, uint8_t *__restrict__ F,
+                                                           const int32_t *__restrict__ pEnc) {
+    break_down_body<C>((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, top, numTop, pbot, pF, D, F, pEnc);
 }
 // F of the genome at the top of the scope: its own D, and where its top segments begin (it has some when the scope ends below the root)
 static __global__ void __launch_bounds__(256) k_break_top(const uint8_t *__restrict__ D, int64_t n, uint8_t *__restrict__ F) {
@@ -338,6 +341,8 @@ template <typename C> struct MafSelect {
     // is the row among what hangs under it.  Otherwise l is reduced by the members' sizes and t stays -1.
     HGX_DEV __forceinline__ bool ringMember(ColumnRow *dst, int g, const TopRec<C> *T, const TopRec<C> &c0, int32_t t0, int32_t so, bool rev0,
                                                int64_t &l, int32_t &t, bool &trev) const {
+        if (P.noDupes)
+            return false; // (--noDupes: a ring's other members are in no column)
         const int32_t own = reported(g);
         TopRec<C> cur = c0;
         bool crev = rev0;
@@ -426,6 +431,8 @@ template <typename C> struct MafSelect {
             const int pg = D.parent;
             const GenomeDesc &PD = P.desc[pg];
             const int32_t b = tr.parentEnc >> 1;
+            if (P.noDupes && (PD.child[D.slotInParent][b] >> 1) != t)
+                return false; // (--noDupes: only the segment the parent's slot names goes up — the column has no row up there)
             const bool brev = rev ^ ((tr.parentEnc & 1) != 0);
             const BotRec<C> *B = bot(pg);
             const int64_t apos = posOf(B, b, so, brev);

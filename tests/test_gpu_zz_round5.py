@@ -300,6 +300,38 @@ def test_maf_tracks_vs_walk_and_oracle(hal, oracle_bin, tmp_path, seed, monkeypa
                         "--maxBlockLen", "50"), (name, chunk)
 
 
+@pytest.mark.parametrize("seed", [2, 11])
+def test_maf_tracks_no_dupes(hal, oracle_bin, tmp_path, seed, monkeypatch):
+    """--noDupes through the tracks (round 6): no paralogy ring is followed and only the segment a parent's slot names goes up
+    (halColumnIterator.cpp:560, 645) — the sweeps, the break sweeps and the row selection take the option as a flag; with --unique,
+    target sets and ranges, against the column walk and the oracle"""
+    al, img = _rand(hal, tmp_path, seed)
+    for chunk in ("97", "5000"):
+        monkeypatch.setenv("HGX_MAF_CHUNK", chunk)
+        for g in range(al.num_genomes):
+            n, name = al.genome_length(g), al.genome_name(g)
+            if n == 0 or (chunk == "97" and g % 3 != seed % 3):
+                continue
+            others = [x for x in range(al.num_genomes) if x != g]
+            assert _both_ways(al, monkeypatch, g, no_dupes=True) == _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", name, "--noDupes"), (name, chunk)
+            assert _unique_both_ways(al, monkeypatch, g, no_dupes=True) == \
+                _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", name, "--noDupes", "--unique"), (name, chunk)
+            tg = others[1:4]
+            seq = al.sequences(g)[0][0]
+            assert _both_ways(al, monkeypatch, g, 0, start=n // 3, length=n // 2, max_block_len=50, targets=tg, no_dupes=True) == \
+                _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", name, "--refSequence", seq, "--start", str(n // 3), "--length", str(n // 2),
+                        "--maxBlockLen", "50", "--noDupes", "--targetGenomes", ",".join(al.genome_name(x) for x in tg)), (name, chunk)
+    star = halfix.random_multiseq_alignment(5, n_genomes=41, max_children=3, root_len=300, root_children=24)
+    simg = str(tmp_path / "star.hgx")
+    halfix.write_hgx(simg, star)
+    sal = hal.Alignment.open(simg, device=0)
+    monkeypatch.delenv("HGX_MAF_CHUNK")
+    for g in (0, 7, sal.num_genomes - 1):
+        if sal.genome_length(g):
+            assert _both_ways(sal, monkeypatch, g, no_dupes=True) == \
+                _oracle(oracle_bin, "maf", simg, tmp_path, "--refGenome", sal.genome_name(g), "--noDupes"), g
+
+
 def test_maf_tracks_multiseq_and_star(hal, oracle_bin, tmp_path, monkeypatch):
     """the independent generator's alignments (several sequences a genome, irregular segments, insertions, deletions) and a star of
     twenty-four children under the root (three launches of the break sweep for the root)"""
