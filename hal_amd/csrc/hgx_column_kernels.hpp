@@ -643,7 +643,10 @@ struct SweepChildren {
 #define HGX_SWEEP_LPS_LOG(V) ((V) >= 8 ? 3 : 4)
 #endif
 template <typename M> struct SweepVec {
-    static constexpr int N = sizeof(M) >= 8 ? 2 : 8 / (int)sizeof(M);
+    // (sixteen bytes a lane for 32- and 64-bit words — round 6: the sweeps are bound by the instructions a lane spends beside its
+    // loads, and twice the bytes a lane are half of those a byte: --countDupes at config 2 4.78 -> 3.95 ms; with 16-bit sets the
+    // eight elements cost registers instead, 56 -> 76 VGPRs, and the root's launch got slower)
+    static constexpr int N = sizeof(M) >= 8 ? 2 : sizeof(M) >= 4 ? 4 : 8 / (int)sizeof(M);
     M e[N];
 };
 template <typename T, int N> struct SweepElems {
@@ -659,7 +662,7 @@ template <typename T> __device__ __forceinline__ void sweep_store(void *p, const
 }
 // the bases o .. o + V - 1 of a parent segment of `len` bases under child segment `tr`, from the child's track T (words of MC)
 template <typename C, typename M, typename MC, bool SUM>
-__device__ __forceinline__ void sweep_join_child(SweepVec<M> &v, const MC *__restrict__ T, const TopRec<C> &tr, int64_t len, int64_t o, bool whole,
+__device__ __forceinline__ void sweep_join_child(SweepVec<M> &v, const MC *__restrict__ T, const TopRec<C> &tr, C len, C o, bool whole,
                                                  int shift) {
     constexpr int V = SweepVec<M>::N;
     const MC *base = T + (int64_t)tr.start;
@@ -691,9 +694,12 @@ static __global__ void __launch_bounds__(256) k_sweep_up(const BotRec<C> *__rest
     const int sub = (int)(threadIdx.x & (LPS - 1));
     const int64_t groupsTotal = ((int64_t)gridDim.x * blockDim.x) >> LPS_LOG;
     for (int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> LPS_LOG; b < numBot; b += groupsTotal) {
-        const int64_t start = (int64_t)bot[b].start, len = (int64_t)bot[b + 1].start - start;
-        for (int64_t o0 = 0; o0 < len; o0 += LPS * V) {
-            int64_t o = o0 + (int64_t)sub * V; // this lane's bases: o .. o + V - 1
+        // (offsets inside a segment in the tables' own width — with 32-bit tables a lane's address arithmetic is 32-bit: the sweeps
+        // are bound by the instructions a lane spends on its few bytes, round 6)
+        const int64_t start = (int64_t)bot[b].start;
+        const C len = (C)(bot[b + 1].start - bot[b].start);
+        for (C o0 = 0; o0 < len; o0 += LPS * V) {
+            C o = o0 + (C)(sub * V); // this lane's bases: o .. o + V - 1
             if (o >= len)
                 continue;
             // (the lane at the segment's end takes the segment's last V bases — some of them its neighbour's as well, which come out
@@ -703,66 +709,6 @@ static __global__ void __launch_bounds__(256) k_sweep_up(const BotRec<C> *__rest
             if (!(SUM && accumulate) && o + V > len && len >= V)
                 o = len - V;
             const bool whole = o + V <= len;
-            if constexpr (sizeof(M) == 1 && !SUM) {
-                // byte-wide sets (a genome with at most eight counted genomes below it — most genomes of a large tree, and the launches
-                // most of the sweep's time went to): the lane's eight bases as ONE 64-bit word from the load to the store — a child's
-                // bases in the other orientation by a byte swap, its place in the parent's numbering by one masked shift of all eight
-                // (round 6; element by element the kernel held 108 VGPRs, four wavefronts a SIMD, for arithmetic a few 64-bit
-                // operations do).  A child's word is a byte as well: its subtree is part of this genome's.
-                const unsigned long long ones = 0x0101010101010101ull;
-                unsigned long long pv = ones * (unsigned long long)(uint8_t)own;
-                if (accumulate) {
-                    if (whole) {
-                        pv = sweep_load<unsigned long long>(S + start + o);
-                    } else {
-                        pv = 0;
-#pragma nounroll
-                        for (int j = 0; j < 8 && o + j < len; ++j) // (a segment of fewer than eight bases: rare, and not worth registers)
-                            pv |= (unsigned long long)(uint8_t)S[start + o + j] << (8 * j);
-                    }
-                }
-                for (int k = 0; k < ch.n; ++k) {
-                    const int32_t enc = ch.c[k].enc[b];
-                    if (enc < 0)
-                        continue;
-                    const uint8_t *T = (const uint8_t *)ch.c[k].track;
-                    if (!T) {
-                        pv |= ones * (unsigned long long)(uint8_t)ch.c[k].constant;
-                        continue;
-                    }
-                    const TopRec<C> *top = (const TopRec<C> *)ch.c[k].top;
-                    const int shift = ch.c[k].shift;
-                    const unsigned long long keep = ones * (unsigned long long)(0xFFu >> shift);
-                    const int32_t t0 = enc >> 1;
-                    int32_t t = t0;
-                    do {
-                        const TopRec<C> tr = top[t];
-                        const uint8_t *base = T + (int64_t)tr.start;
-                        const bool rev = (tr.parentEnc & 1) != 0;
-                        unsigned long long x;
-                        if (whole) {
-                            x = sweep_load<unsigned long long>(base + (rev ? len - o - 8 : o));
-                            if (rev)
-                                x = __builtin_bswap64(x);
-                        } else {
-                            x = 0;
-#pragma nounroll
-                            for (int j = 0; j < 8 && o + j < len; ++j)
-                                x |= (unsigned long long)base[rev ? len - 1 - o - j : o + j] << (8 * j);
-                        }
-                        pv |= (x & keep) << shift;
-                        t = ch.noRing ? -1 : tr.paralogy;
-                    } while (t >= 0 && t != t0);
-                }
-                if (whole) {
-                    sweep_store(S + start + o, pv);
-                } else {
-#pragma nounroll
-                    for (int j = 0; j < 8 && o + j < len; ++j)
-                        S[start + o + j] = (M)(pv >> (8 * j));
-                }
-                continue;
-            }
             SweepVec<M> v;
             if (accumulate && whole) { // (more than SWEEP_MAX_CHILDREN children: several launches)
                 v = sweep_load<SweepVec<M>>(S + start + o);
@@ -823,6 +769,146 @@ static __global__ void __launch_bounds__(256) k_sweep_up(const BotRec<C> *__rest
         }
     }
 }
+// k_sweep_up for byte-wide sets (a genome with at most eight counted genomes below it: most genomes of a large tree), round 6.
+// What the launch waits for is not bytes: a wavefront's round — the segments' bounds and links, the children's records, their
+// tracks, the store — is a few memory round trips whatever it moves (loads and stores are counted by one in-order counter on
+// this hardware: 3.6 us a round, measured on the launch that only stores), and a round moved eight segments of 64 bases.  So a
+// round moves more: U segments a lane group, their loads asked for together level by level, and sixteen bases a lane — a
+// segment of up to 128 bases in one trip.  (Asking for the NEXT round's links and records beside this round's tracks, a
+// pipeline over rounds, changed nothing: profiles/r06x_*.)  A lane's sixteen bases are two 64-bit words from the load to the
+// store: a child in the other orientation by byte swaps, its place in the parent's numbering by a masked shift.
+struct SweepW2 {
+    unsigned long long a, b;
+};
+template <typename O> __device__ __forceinline__ SweepW2 sweep_bytes16(const uint8_t *__restrict__ base, bool rev, O len, O o, bool whole) {
+    SweepW2 x;
+    if (whole) {
+        x = sweep_load<SweepW2>(base + (rev ? len - o - 16 : o));
+        if (rev) {
+            const unsigned long long t = __builtin_bswap64(x.a);
+            x.a = __builtin_bswap64(x.b);
+            x.b = t;
+        }
+    } else {
+        x.a = x.b = 0;
+#pragma nounroll
+        for (int j = 0; j < 16 && o + j < len; ++j) {
+            const unsigned long long v = (unsigned long long)base[rev ? len - 1 - o - j : o + j] << (8 * (j & 7));
+            if (j < 8)
+                x.a |= v;
+            else
+                x.b |= v;
+        }
+    }
+    return x;
+}
+// a segment of a lane group's round (its fields as scalars and U of them by name, not as arrays: indexed arrays of them the
+// compiler kept in LDS)
+template <typename C> struct SweepSeg {
+    C start, len, o; // (offsets in the tables' own width: with 32-bit tables the address arithmetic of a lane is 32-bit)
+    bool act, whole;
+    SweepW2 pv, x;
+    int32_t enc;
+    TopRec<C> tr;
+};
+#define HGX_SEGS(X) X(s0) X(s1)
+template <typename C, int U>
+static __global__ void __launch_bounds__(256) k_sweep_up_bytes(const BotRec<C> *__restrict__ bot, int64_t numBot, SweepChildren ch, uint8_t own,
+                                                               int accumulate, uint8_t *__restrict__ S) {
+    static_assert(U == 2, "HGX_SEGS names the segments");
+    const int sub = (int)(threadIdx.x & 7);
+    const int64_t G = ((int64_t)gridDim.x * blockDim.x) >> 3;
+    const unsigned long long ones = 0x0101010101010101ull;
+    const int nKids = ch.n, noRing = ch.noRing;
+    for (int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; b < numBot; b += (int64_t)U * G) {
+        SweepSeg<C> s0, s1;
+        const int64_t b_s0 = b, b_s1 = b + G;
+#define X(s)                                                                                                                                 \
+    s.start = s.len = 0;                                                                                                                     \
+    if (b_##s < numBot) {                                                                                                                    \
+        s.start = bot[b_##s].start;                                                                                                          \
+        s.len = (C)(bot[b_##s + 1].start - s.start);                                                                                         \
+    }
+        HGX_SEGS(X)
+#undef X
+        const C maxLen = s0.len > s1.len ? s0.len : s1.len;
+        for (C o0 = 0; o0 < maxLen; o0 += 128) {
+#define X(s)                                                                                                                                 \
+    s.o = o0 + (C)(sub * 16);                                                                                                                \
+    s.act = s.o < s.len;                                                                                                                     \
+    if (s.act && s.o + 16 > s.len && s.len >= 16)                                                                                            \
+        s.o = s.len - 16; /* (the lane at the segment's end takes its last sixteen bases: unions may be made twice) */                      \
+    s.whole = s.o + 16 <= s.len;                                                                                                             \
+    s.pv.a = s.pv.b = ones * (unsigned long long)own;                                                                                        \
+    if (accumulate && s.act)                                                                                                                 \
+        s.pv = sweep_bytes16<C>(S + (int64_t)s.start, false, s.len, s.o, s.whole);
+            HGX_SEGS(X)
+#undef X
+            for (int k = 0; k < nKids; ++k) {
+                const int32_t *encs = ch.c[k].enc;
+                const uint8_t *T = (const uint8_t *)ch.c[k].track;
+                const TopRec<C> *top = (const TopRec<C> *)ch.c[k].top;
+                const int shift = ch.c[k].shift;
+                const unsigned long long keep = ones * (unsigned long long)(0xFFu >> shift), cst = ones * (unsigned long long)(uint8_t)ch.c[k].constant;
+#define X(s) s.enc = s.act ? encs[b_##s] : -1;
+                HGX_SEGS(X)
+#undef X
+                if (!T) { // (a child without a track: the same set on every base below it)
+#define X(s)                                                                                                                                 \
+    if (s.enc >= 0) {                                                                                                                        \
+        s.pv.a |= cst;                                                                                                                       \
+        s.pv.b |= cst;                                                                                                                       \
+    }
+                    HGX_SEGS(X)
+#undef X
+                    continue;
+                }
+#define X(s)                                                                                                                                 \
+    s.tr.start = 0;                                                                                                                          \
+    s.tr.parentEnc = 0;                                                                                                                      \
+    s.tr.paralogy = -1;                                                                                                                      \
+    if (s.enc >= 0)                                                                                                                          \
+        s.tr = top[s.enc >> 1];
+                HGX_SEGS(X)
+#undef X
+#define X(s)                                                                                                                                 \
+    s.x.a = s.x.b = 0;                                                                                                                       \
+    if (s.enc >= 0)                                                                                                                          \
+        s.x = sweep_bytes16<C>(T + (int64_t)s.tr.start, (s.tr.parentEnc & 1) != 0, s.len, s.o, s.whole);
+                HGX_SEGS(X)
+#undef X
+                // (behind the slot's segment the rest of its paralogy ring — updateNextTopDup, halColumnIterator.cpp:642-681: rare, link by link)
+#define X(s)                                                                                                                                 \
+    s.pv.a |= (s.x.a & keep) << shift;                                                                                                       \
+    s.pv.b |= (s.x.b & keep) << shift;                                                                                                       \
+    if (s.enc >= 0 && !noRing && s.tr.paralogy >= 0) {                                                                                       \
+        const int32_t t0 = s.enc >> 1;                                                                                                       \
+        for (int32_t t = s.tr.paralogy; t >= 0 && t != t0;) {                                                                                \
+            const TopRec<C> r = top[t];                                                                                                      \
+            const SweepW2 y = sweep_bytes16<C>(T + (int64_t)r.start, (r.parentEnc & 1) != 0, s.len, s.o, s.whole);                           \
+            s.pv.a |= (y.a & keep) << shift;                                                                                                 \
+            s.pv.b |= (y.b & keep) << shift;                                                                                                 \
+            t = r.paralogy;                                                                                                                  \
+        }                                                                                                                                    \
+    }
+                HGX_SEGS(X)
+#undef X
+            }
+#define X(s)                                                                                                                                 \
+    if (s.act) {                                                                                                                             \
+        if (s.whole) {                                                                                                                       \
+            sweep_store(S + (int64_t)s.start + s.o, s.pv);                                                                                   \
+        } else {                                                                                                                             \
+            _Pragma("nounroll") for (int j = 0; j < 16 && s.o + j < s.len; ++j)                                                              \
+                S[(int64_t)s.start + s.o + j] = (uint8_t)((j < 8 ? s.pv.a : s.pv.b) >> (8 * (j & 7)));                                      \
+        }                                                                                                                                    \
+    }
+            HGX_SEGS(X)
+#undef X
+        }
+    }
+}
+#undef HGX_SEGS
 template <typename M, bool SUM> __device__ __forceinline__ int32_t track_size(M v) {
     return SUM ? (int32_t)v : (int32_t)__popcll((unsigned long long)v);
 }
@@ -860,13 +946,14 @@ static __global__ void __launch_bounds__(256) k_sweep_down(const TopRec<C> *__re
     const int64_t groupsTotal = ((int64_t)gridDim.x * blockDim.x) >> 4;
     for (int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; t < numTop; t += groupsTotal) {
         const TopRec<C> tr = top[t];
-        const int64_t start = (int64_t)tr.start, len = (int64_t)top[t + 1].start - start;
+        const int64_t start = (int64_t)tr.start;
+        const C len = (C)(top[t + 1].start - tr.start); // (offsets inside a segment in the tables' own width: k_sweep_up)
         // (pEnc — --noDupes: the parent's links to this genome: only the segment a parent's slot names goes up, mmapTopSegment.cpp:30-40;
         // the others' columns end with them, as an insertion's)
         const bool hasParent = tr.parentEnc >= 0 && (!pEnc || (int64_t)(pEnc[tr.parentEnc >> 1] >> 1) == t), rev = (tr.parentEnc & 1) != 0;
         const int64_t pstart = hasParent ? (int64_t)pbot[tr.parentEnc >> 1].start : 0;
-        for (int64_t o_ = (int64_t)sub * V; o_ < len; o_ += 16 * V) {
-            const int64_t o = o_ + V > len && len >= V ? len - V : o_; // (the last lane: the segment's last V bases, as in k_sweep_up)
+        for (C o_ = (C)(sub * V); o_ < len; o_ += 16 * V) {
+            const C o = o_ + V > len && len >= V ? len - V : o_; // (the last lane: the segment's last V bases, as in k_sweep_up)
             AVec a;
             if (o + V <= len && hasParent) {
                 const int64_t pp = pstart + (rev ? len - o - V : o); // the V parent bases, in the parent's order
@@ -887,6 +974,34 @@ static __global__ void __launch_bounds__(256) k_sweep_down(const TopRec<C> *__re
                     const int64_t pp = pstart + (rev ? len - 1 - o - j : o + j);
                     A[start + o + j] = hasParent ? (pS ? (AT)track_size<M, SUM>(pS[pp]) : pA[pp])
                                                  : (AT)(S ? track_size_at<SUM>(S, start + o + j, sLog) : ownSize);
+                }
+            }
+        }
+    }
+}
+// k_sweep_down where depths are bytes and come from the parent's depths (every step of the path but the first): a copy of sixteen
+// bases a lane as two 64-bit words, a segment in the other orientation by byte swaps (round 6: k_sweep_up_bytes has the why)
+template <typename C>
+static __global__ void __launch_bounds__(256) k_sweep_down_bytes(const TopRec<C> *__restrict__ top, int64_t numTop, const BotRec<C> *__restrict__ pbot,
+                                                                 const uint8_t *__restrict__ pA, const void *__restrict__ S, int sLog, int32_t ownSize,
+                                                                 uint8_t *__restrict__ A, const int32_t *__restrict__ pEnc) {
+    const int sub = (int)(threadIdx.x & 7);
+    const int64_t groupsTotal = ((int64_t)gridDim.x * blockDim.x) >> 3;
+    for (int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; t < numTop; t += groupsTotal) {
+        const TopRec<C> tr = top[t];
+        const int64_t start = (int64_t)tr.start;
+        const C len = (C)(top[t + 1].start - tr.start);
+        const bool hasParent = tr.parentEnc >= 0 && (!pEnc || (int64_t)(pEnc[tr.parentEnc >> 1] >> 1) == t), rev = (tr.parentEnc & 1) != 0;
+        const int64_t pstart = hasParent ? (int64_t)pbot[tr.parentEnc >> 1].start : 0;
+        for (C o_ = (C)(sub * 16); o_ < len; o_ += 128) {
+            const C o = o_ + 16 > len && len >= 16 ? len - 16 : o_;
+            if (o + 16 <= len && hasParent) {
+                sweep_store(A + start + o, sweep_bytes16<C>(pA + pstart, rev, len, o, true));
+            } else { // (the end of a short segment, or a segment without a parent — an insertion: its own set's size)
+#pragma nounroll
+                for (int j = 0; j < 16 && o + j < len; ++j) {
+                    const int64_t pp = pstart + (rev ? len - 1 - o - j : o + j);
+                    A[start + o + j] = hasParent ? pA[pp] : (uint8_t)(S ? track_size_at<false>(S, start + o + j, sLog) : ownSize);
                 }
             }
         }

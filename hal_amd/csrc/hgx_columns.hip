@@ -163,7 +163,7 @@ static void sweepTracks(hgx_alignment *h, const std::vector<int> &postOrder, con
                         hipStream_t s, bool noDupes = false) {
     const Image &img = h->img;
     const DeviceImage &D = *h->dev;
-    const int GRID = 4096;
+    const int GRID = getenv("HGX_SWEEP_GRID") ? std::max(256, atoi(getenv("HGX_SWEEP_GRID"))) : 4096;
     // (--noDupes: the parent's links to a genome of the path, by which k_sweep_down tells the segment that goes up)
     auto linksTo = [&](int p, int c) -> const int32_t * {
         if (!noDupes)
@@ -201,6 +201,9 @@ static void sweepTracks(hgx_alignment *h, const std::vector<int> &postOrder, con
                        at ? 1 : 0, (M *)S[(size_t)g].p)
             if (SUM)
                 HGX_UP(int32_t);
+            else if (tg.wlog == 0 && !(getenv("HGX_SWEEP_AHEAD") && getenv("HGX_SWEEP_AHEAD")[0] == '0'))
+                hipLaunchKernelGGL((k_sweep_up_bytes<C, 2>), dim3(GRID), dim3(256), 0, s, (const BotRec<C> *)dg.bot, (int64_t)G.numBot, ch, (uint8_t)tg.own,
+                                   at ? 1 : 0, (uint8_t *)S[(size_t)g].p);
             else if (tg.wlog == 0)
                 HGX_UP(uint8_t);
             else if (tg.wlog == 1)
@@ -243,6 +246,10 @@ static void sweepTracks(hgx_alignment *h, const std::vector<int> &postOrder, con
         const int pl = track[(size_t)p].wlog;
         if (SUM)
             HGX_DOWN(int32_t);
+        else if (i > 1 && sizeof(AT) == 1 && !(getenv("HGX_SWEEP_AHEAD") && getenv("HGX_SWEEP_AHEAD")[0] == '0'))
+            hipLaunchKernelGGL((k_sweep_down_bytes<C>), dim3(GRID), dim3(256), 0, s, (const TopRec<C> *)D.genomes[(size_t)c].top,
+                               (int64_t)img.genomes[(size_t)c].numTop, (const BotRec<C> *)D.genomes[(size_t)p].bot, (const uint8_t *)A[(size_t)p].p, Sc,
+                               track[(size_t)c].wlog, sizeOfOwn(c), (uint8_t *)A[(size_t)c].p, linksTo(p, c));
         else if (i > 1 || pl == 0) // (the parent's track is read by the first step only)
             HGX_DOWN(uint8_t);
         else if (pl == 1)
