@@ -923,9 +923,10 @@ def main():
         dt_1, _ = timed_steps(step_one, args.steps, sync)
         one_plan = {"ms_per_step": 1e3 * dt_1 / args.steps, "value": nq * args.steps / dt_1, "unit": "intervals/s", "steps": args.steps,
                     "what": "hgx_liftover_run_device, one plan: every batch waited for before the next one is launched.  A batch that "
-                            "runs by itself has its general intervals found by a pass of its own (k_lift_general_list) and finished by "
-                            "workgroups at the head of k_lift_classify's grid (hgx_liftover_plan_set_workers, the default); the batches "
-                            "kept in flight for `value` overlap their launches' tails and are spared that pass"}
+                            "runs by itself has its general intervals found and finished by workgroups at the head of k_lift_classify's "
+                            "grid — scouts: each looks at a share of the batch and finishes what it finds (round 6; HGX_LIFT_SCOUT=0: "
+                            "round 3's pass in front, k_lift_general_list); the batches kept in flight for `value` overlap their "
+                            "launches' tails and are spared the look"}
         # the kernels of these steps (HIP events around every launch, a loop of its own)
         plan.set_timing(2)
         for _ in range(args.steps):

@@ -7,6 +7,7 @@
 // boundaries.  The walk order is the reference's (updateParent, then paralogs, then the parse-down subtree;
 // :246-355, :556-744) so that rows come out in ColumnMap insertion order for the MAF writer.
 #pragma once
+#include <type_traits>
 #include "hgx_scan_kernels.hpp"
 #include "hgx_device.hpp"
 #include <hip/hip_runtime.h>
@@ -683,10 +684,14 @@ __device__ __forceinline__ void sweep_join_child(SweepVec<M> &v, const MC *__res
             }
     }
 }
-template <typename C, typename M, bool SUM>
+// OUT: what is stored — the sets themselves (M), or, for the genome at the top of a depth request's scope, their sizes as bytes
+// (round 6: nobody reads that genome's sets but to count them — k_sweep_top, the first step of k_sweep_down —, and with 64-bit sets
+// they are eight bytes a base written and read again where one is enough; not with `accumulate`: a later launch adds to the sets)
+template <typename C, typename M, bool SUM, typename OUT = M>
 static __global__ void __launch_bounds__(256) k_sweep_up(const BotRec<C> *__restrict__ bot, int64_t numBot, SweepChildren ch, M own, int accumulate,
-                                                         M *__restrict__ S) {
+                                                         OUT *__restrict__ S) {
     constexpr int V = SweepVec<M>::N;
+    constexpr bool SIZES = !std::is_same<OUT, M>::value;
     // (lanes per segment: a round of them covers 64 bases or more — eight lanes with byte-wide sets, so that eight segments'
     // chains of dependent loads are in flight per wavefront)
     constexpr int LPS_LOG = HGX_SWEEP_LPS_LOG(V);
@@ -710,7 +715,11 @@ static __global__ void __launch_bounds__(256) k_sweep_up(const BotRec<C> *__rest
                 o = len - V;
             const bool whole = o + V <= len;
             SweepVec<M> v;
-            if (accumulate && whole) { // (more than SWEEP_MAX_CHILDREN children: several launches)
+            if constexpr (SIZES) {
+#pragma unroll
+                for (int j = 0; j < V; ++j)
+                    v.e[j] = own;
+            } else if (accumulate && whole) { // (more than SWEEP_MAX_CHILDREN children: several launches)
                 v = sweep_load<SweepVec<M>>(S + start + o);
             } else {
 #pragma unroll
@@ -758,7 +767,20 @@ static __global__ void __launch_bounds__(256) k_sweep_up(const BotRec<C> *__rest
                     t = ch.noRing ? -1 : tr.paralogy;
                 } while (t >= 0 && t != t0);
             }
-            if (whole) {
+            if constexpr (SIZES) {
+                SweepElems<OUT, V> w;
+#pragma unroll
+                for (int j = 0; j < V; ++j)
+                    w.e[j] = (OUT)(SUM ? (long long)v.e[j] : (long long)__popcll((unsigned long long)v.e[j]));
+                if (whole) {
+                    sweep_store(S + start + o, w);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < V; ++j)
+                        if (o + j < len)
+                            S[start + o + j] = w.e[j];
+                }
+            } else if (whole) {
                 sweep_store(S + start + o, v);
             } else {
 #pragma unroll
@@ -812,7 +834,14 @@ template <typename C> struct SweepSeg {
     TopRec<C> tr;
 };
 #define HGX_SEGS(X) X(s0) X(s1)
-template <typename C, int U>
+// per-byte population counts of eight bytes at once
+__device__ __forceinline__ unsigned long long sweep_popcount_bytes(unsigned long long x) {
+    x = x - ((x >> 1) & 0x5555555555555555ull);
+    x = (x & 0x3333333333333333ull) + ((x >> 2) & 0x3333333333333333ull);
+    return (x + (x >> 4)) & 0x0F0F0F0F0F0F0F0Full;
+}
+// SIZES: the sets' sizes are stored, not the sets (the genome at the top of a depth request's scope: k_sweep_up's OUT)
+template <typename C, int U, bool SIZES = false>
 static __global__ void __launch_bounds__(256) k_sweep_up_bytes(const BotRec<C> *__restrict__ bot, int64_t numBot, SweepChildren ch, uint8_t own,
                                                                int accumulate, uint8_t *__restrict__ S) {
     static_assert(U == 2, "HGX_SEGS names the segments");
@@ -896,6 +925,10 @@ static __global__ void __launch_bounds__(256) k_sweep_up_bytes(const BotRec<C> *
             }
 #define X(s)                                                                                                                                 \
     if (s.act) {                                                                                                                             \
+        if (SIZES) {                                                                                                                         \
+            s.pv.a = sweep_popcount_bytes(s.pv.a);                                                                                           \
+            s.pv.b = sweep_popcount_bytes(s.pv.b);                                                                                           \
+        }                                                                                                                                    \
         if (s.whole) {                                                                                                                       \
             sweep_store(S + (int64_t)s.start + s.o, s.pv);                                                                                   \
         } else {                                                                                                                             \

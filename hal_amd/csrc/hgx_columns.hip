@@ -160,10 +160,12 @@ struct SweepTrack {
 template <typename C, bool SUM, typename AT>
 static void sweepTracks(hgx_alignment *h, const std::vector<int> &postOrder, const std::vector<int> &path, const std::vector<char> &inScope,
                         const std::vector<SweepTrack> &track, const std::vector<char> &hasTrack, std::vector<Buf> &S, std::vector<Buf> &A,
-                        hipStream_t s, bool noDupes = false) {
+                        hipStream_t s, bool noDupes = false, bool topSizes = false) {
+    // topSizes (halAlignmentDepth, genome sets): the genome at the top of the scope stores its sets' SIZES, as bytes, in A — nobody
+    // reads its sets but to count them (the caller has made sure its children go in one launch, and given it no S)
     const Image &img = h->img;
     const DeviceImage &D = *h->dev;
-    const int GRID = getenv("HGX_SWEEP_GRID") ? std::max(256, atoi(getenv("HGX_SWEEP_GRID"))) : 4096;
+    const int GRID = getenv("HGX_SWEEP_GRID") ? std::max(256, atoi(getenv("HGX_SWEEP_GRID"))) : 8192; // (4096: 2-3 % slower, profiles/r06x_*)
     // (--noDupes: the parent's links to a genome of the path, by which k_sweep_down tells the segment that goes up)
     auto linksTo = [&](int p, int c) -> const int32_t * {
         if (!noDupes)
@@ -199,7 +201,22 @@ static void sweepTracks(hgx_alignment *h, const std::vector<int> &postOrder, con
 #define HGX_UP(M)                                                                                                                            \
     hipLaunchKernelGGL((k_sweep_up<C, M, SUM>), dim3(GRID), dim3(256), 0, s, (const BotRec<C> *)dg.bot, (int64_t)G.numBot, ch, (M)tg.own,     \
                        at ? 1 : 0, (M *)S[(size_t)g].p)
-            if (SUM)
+#define HGX_UP_SIZES(M)                                                                                                                      \
+    hipLaunchKernelGGL((k_sweep_up<C, M, false, uint8_t>), dim3(GRID), dim3(256), 0, s, (const BotRec<C> *)dg.bot, (int64_t)G.numBot, ch,    \
+                       (M)tg.own, 0, (uint8_t *)A[(size_t)g].p)
+            if (!SUM && topSizes && g == path[0]) {
+                if (kids.size() > SWEEP_MAX_CHILDREN || sizeof(AT) != 1)
+                    throw std::runtime_error("internal: sizes at the top of the scope are one launch's");
+                if (tg.wlog == 0)
+                    hipLaunchKernelGGL((k_sweep_up_bytes<C, 2, true>), dim3(GRID), dim3(256), 0, s, (const BotRec<C> *)dg.bot, (int64_t)G.numBot, ch,
+                                       (uint8_t)tg.own, 0, (uint8_t *)A[(size_t)g].p);
+                else if (tg.wlog == 1)
+                    HGX_UP_SIZES(uint16_t);
+                else if (tg.wlog == 2)
+                    HGX_UP_SIZES(uint32_t);
+                else
+                    HGX_UP_SIZES(unsigned long long);
+            } else if (SUM)
                 HGX_UP(int32_t);
             else if (tg.wlog == 0 && !(getenv("HGX_SWEEP_AHEAD") && getenv("HGX_SWEEP_AHEAD")[0] == '0'))
                 hipLaunchKernelGGL((k_sweep_up_bytes<C, 2>), dim3(GRID), dim3(256), 0, s, (const BotRec<C> *)dg.bot, (int64_t)G.numBot, ch, (uint8_t)tg.own,
@@ -213,12 +230,14 @@ static void sweepTracks(hgx_alignment *h, const std::vector<int> &postOrder, con
             else
                 HGX_UP(unsigned long long);
 #undef HGX_UP
+#undef HGX_UP_SIZES
         }
     }
     // top-down along the path from the top of the scope to the reference (the top's own A is the size of its S: read from S)
     auto sizeOfOwn = [&](int g) { return SUM ? (int32_t)track[(size_t)g].own : (int32_t)__builtin_popcountll((unsigned long long)track[(size_t)g].own); };
     const int top = path[0];
-    if (path.size() == 1) {
+    const bool topDone = !SUM && topSizes && hasTrack[(size_t)top]; // (A of the top is there already)
+    if (path.size() == 1 && !topDone) {
         const void *St = hasTrack[(size_t)top] ? S[(size_t)top].p : nullptr;
         const int64_t n = (int64_t)img.genomes[(size_t)top].totalLength;
         const SweepTrack &tt = track[(size_t)top];
@@ -246,7 +265,7 @@ static void sweepTracks(hgx_alignment *h, const std::vector<int> &postOrder, con
         const int pl = track[(size_t)p].wlog;
         if (SUM)
             HGX_DOWN(int32_t);
-        else if (i > 1 && sizeof(AT) == 1 && !(getenv("HGX_SWEEP_AHEAD") && getenv("HGX_SWEEP_AHEAD")[0] == '0'))
+        else if ((i > 1 || topDone) && sizeof(AT) == 1 && (topDone || !(getenv("HGX_SWEEP_AHEAD") && getenv("HGX_SWEEP_AHEAD")[0] == '0')))
             hipLaunchKernelGGL((k_sweep_down_bytes<C>), dim3(GRID), dim3(256), 0, s, (const TopRec<C> *)D.genomes[(size_t)c].top,
                                (int64_t)img.genomes[(size_t)c].numTop, (const BotRec<C> *)D.genomes[(size_t)p].bot, (const uint8_t *)A[(size_t)p].p, Sc,
                                track[(size_t)c].wlog, sizeOfOwn(c), (uint8_t *)A[(size_t)c].p, linksTo(p, c));
@@ -392,13 +411,23 @@ static bool columnsDepthSweep(hgx_alignment *h, int ref, int64_t first, int64_t 
             if (inScope[(size_t)c] && img.genomes[(size_t)c].totalLength > 0 && img.genomes[(size_t)c].numTop > 0)
                 hasTrack[(size_t)g] = 1;
     }
+    // the genome at the top of the scope keeps the sizes of its sets, not the sets (sweepTracks: topSizes) — when its children go in
+    // one launch and the sets are counted once (one group)
+    bool topSizes = false;
+    if (!sum && groups == 1 && hasTrack[(size_t)path[0]] && !(getenv("HGX_SWEEP_TOP_SIZES") && getenv("HGX_SWEEP_TOP_SIZES")[0] == '0')) {
+        size_t kids = 0;
+        for (int c : img.genomes[(size_t)path[0]].children)
+            if (inScope[(size_t)c] && img.genomes[(size_t)c].totalLength > 0 && img.genomes[(size_t)c].numTop > 0)
+                ++kids;
+        topSizes = kids <= (size_t)SWEEP_MAX_CHILDREN;
+    }
     size_t need = 0;
     for (int g : postOrder)
-        if (hasTrack[(size_t)g])
+        if (hasTrack[(size_t)g] && !(topSizes && g == path[0]))
             need += (size_t)img.genomes[(size_t)g].totalLength << track[(size_t)g].wlog;
     // (a depth along the path is a byte when genome sets are counted: at most 64 of them a group)
     const size_t depthBytes = sum ? 4 : 1;
-    for (size_t i = path.size() == 1 ? 0 : 1; i < path.size(); ++i)
+    for (size_t i = path.size() == 1 || topSizes ? 0 : 1; i < path.size(); ++i)
         need += (size_t)img.genomes[(size_t)path[i]].totalLength * depthBytes;
     size_t freeB = 0, totalB = 0;
     HIP_OK(hipMemGetInfo(&freeB, &totalB));
@@ -406,9 +435,9 @@ static bool columnsDepthSweep(hgx_alignment *h, int ref, int64_t first, int64_t 
         return false;
     std::vector<Buf> S((size_t)ng), A((size_t)ng);
     for (int g : postOrder)
-        if (hasTrack[(size_t)g])
+        if (hasTrack[(size_t)g] && !(topSizes && g == path[0]))
             S[(size_t)g].resize((size_t)img.genomes[(size_t)g].totalLength << track[(size_t)g].wlog);
-    for (size_t i = path.size() == 1 ? 0 : 1; i < path.size(); ++i)
+    for (size_t i = path.size() == 1 || topSizes ? 0 : 1; i < path.size(); ++i)
         A[(size_t)path[i]].resize((size_t)img.genomes[(size_t)path[i]].totalLength * depthBytes);
     Ev a, b;
     HIP_OK(hipEventRecord(a.e, s));
@@ -419,12 +448,12 @@ static bool columnsDepthSweep(hgx_alignment *h, int ref, int64_t first, int64_t 
         if (sum)
             sweepTracks<int64_t, true, int32_t>(h, postOrder, path, inScope, track, hasTrack, S, A, s);
         else
-            sweepTracks<int64_t, false, uint8_t>(h, postOrder, path, inScope, track, hasTrack, S, A, s);
+            sweepTracks<int64_t, false, uint8_t>(h, postOrder, path, inScope, track, hasTrack, S, A, s, false, topSizes);
     } else {
         if (sum)
             sweepTracks<int32_t, true, int32_t>(h, postOrder, path, inScope, track, hasTrack, S, A, s);
         else
-            sweepTracks<int32_t, false, uint8_t>(h, postOrder, path, inScope, track, hasTrack, S, A, s);
+            sweepTracks<int32_t, false, uint8_t>(h, postOrder, path, inScope, track, hasTrack, S, A, s, false, topSizes);
     }
     if (sum)
         hipLaunchKernelGGL(k_sweep_out<int32_t>, dim3(2048), dim3(256), 0, s, (const int32_t *)A[(size_t)ref].p, first, count, step,

@@ -524,7 +524,10 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
     uint32_t *otherWaveExtra = nullptr;
     unsigned long long *otherGroupExtra = nullptr;
     if (workers && scoutsAllowed) {
-        workers = std::min<uint32_t>(4096u, std::max<uint32_t>(workers, (nq + LIFT_SCOUT_ROUND - 1) / LIFT_SCOUT_ROUND));
+        uint32_t most = 4096u; // (HGX_LIFT_SCOUT_MAX: fewer, so that a scout's share takes several rounds — the tests' way to those)
+        if (const char *e = getenv("HGX_LIFT_SCOUT_MAX"))
+            most = (uint32_t)std::max(1, atoi(e));
+        workers = std::min<uint32_t>(most, std::max<uint32_t>(workers, (nq + LIFT_SCOUT_ROUND - 1) / LIFT_SCOUT_ROUND));
         scoutShare = (((nq + workers - 1) / workers) + 255u) & ~255u;
         workers = (nq + scoutShare - 1) / scoutShare;
         const int k = P.liftExtraSet;

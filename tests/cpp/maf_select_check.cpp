@@ -213,6 +213,7 @@ size_t checkCase(const Image &img, const HostTables &H, const Case &cs, size_t &
         size_t at = 0;
         do {
             BreakChildren ch;
+            ch.noRing = 0;
             ch.n = (int)std::min<size_t>(SWEEP_MAX_CHILDREN, kids.size() - at);
             for (int k = 0; k < ch.n; ++k)
                 ch.c[k] = kids[at + (size_t)k];

@@ -135,13 +135,21 @@ def test_general_intervals_by_worker_workgroups(hal, monkeypatch):
     plan = hal.LiftoverPlan(al, src, tgt, max_queries=n)
     want = run(plan)
     assert plan.stats()["composed_kind"] == 3 and plan.stats()["general_queries"] > 0
-    for workers in ("3", "64", "1024"):
-        monkeypatch.setenv("HGX_LIFT_WORKERS", workers)
-        plan = hal.LiftoverPlan(al, src, tgt, max_queries=n)
-        got = run(plan)
-        assert plan.stats()["general_queries"] > 0
-        for a, b in zip(got, want):
-            assert torch.equal(a, b), workers
+    # (round 6: the workers find their intervals themselves — "scouts", the default; HGX_LIFT_SCOUT=0: round 3's form, a pass over the
+    # batch in front that lists them; HGX_LIFT_SCOUT_MAX: few scouts, whose shares take several rounds)
+    for scout, most in (("1", None), ("0", None), ("1", "5")):
+        monkeypatch.setenv("HGX_LIFT_SCOUT", scout)
+        if most:
+            monkeypatch.setenv("HGX_LIFT_SCOUT_MAX", most)
+        for workers in ("3", "64", "1024"):
+            monkeypatch.setenv("HGX_LIFT_WORKERS", workers)
+            plan = hal.LiftoverPlan(al, src, tgt, max_queries=n)
+            got = run(plan)
+            assert plan.stats()["general_queries"] > 0
+            for a, b in zip(got, want):
+                assert torch.equal(a, b), (scout, most, workers)
+    monkeypatch.delenv("HGX_LIFT_SCOUT")
+    monkeypatch.delenv("HGX_LIFT_SCOUT_MAX")
     monkeypatch.delenv("HGX_LIFT_WORKERS")
     plan = hal.LiftoverPlan(al, src, tgt, max_queries=n)
     for _ in range(3):  # (the first run has no count to go by; the later ones do)
