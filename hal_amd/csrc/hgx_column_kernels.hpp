@@ -1055,6 +1055,34 @@ static __global__ void __launch_bounds__(256) k_sweep_out(const AT *__restrict__
 }
 
 
+// k_sweep_out for byte depths and consecutive columns (step 1, a first pass: nothing to add to): sixteen columns a lane — one
+// 16-byte load, four 16-byte stores (round 6: a column a lane was 370 us for the 224 M columns of config 5, 1.1 GB at 3 TB/s)
+static __global__ void __launch_bounds__(256) k_sweep_out_bytes(const uint8_t *__restrict__ A, int64_t first, int64_t count, int32_t sub,
+                                                                int32_t *__restrict__ out) {
+    const int64_t chunks = (count + 15) >> 4;
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < chunks; c += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = c << 4;
+        if (i + 16 <= count) {
+            const SweepW2 x = sweep_load<SweepW2>(A + first + i);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t w = (uint32_t)((q < 2 ? x.a : x.b) >> (32 * (q & 1)));
+                struct {
+                    int32_t x, y, z, w;
+                } o;
+                o.x = (int32_t)(w & 0xFFu) - sub;
+                o.y = (int32_t)((w >> 8) & 0xFFu) - sub;
+                o.z = (int32_t)((w >> 16) & 0xFFu) - sub;
+                o.w = (int32_t)(w >> 24) - sub;
+                sweep_store(out + i + 4 * q, o);
+            }
+        } else {
+            for (int64_t j = i; j < count; ++j)
+                out[j] = (int32_t)A[first + j] - sub;
+        }
+    }
+}
+
 // ---- halAlignmentDepth's lines on the device ----
 // "%d\n" per column (alignmentDepth/halAlignmentDepth.cpp:246, 271, 305).  The host's threads counted and wrote a quarter of a
 // billion lines in 40 ms beside a scan of 12; here a lane takes eight values, the lines' lengths cross the tiles by the one-pass

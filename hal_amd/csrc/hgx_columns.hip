@@ -157,6 +157,12 @@ struct SweepTrack {
     int wlog = 0, lo = 0;
     long long own = 0;
 };
+// workgroups of a sweep launch (4096: 2-3 % slower, profiles/r06x_*; HGX_SWEEP_GRID: experiments, and the host-side emulation of the
+// tests, whose launches are loops over the grid's threads)
+static int sweepGrid() {
+    const char *e = getenv("HGX_SWEEP_GRID");
+    return e ? std::max(1, atoi(e)) : 8192;
+}
 template <typename C, bool SUM, typename AT>
 static void sweepTracks(hgx_alignment *h, const std::vector<int> &postOrder, const std::vector<int> &path, const std::vector<char> &inScope,
                         const std::vector<SweepTrack> &track, const std::vector<char> &hasTrack, std::vector<Buf> &S, std::vector<Buf> &A,
@@ -165,7 +171,7 @@ static void sweepTracks(hgx_alignment *h, const std::vector<int> &postOrder, con
     // reads its sets but to count them (the caller has made sure its children go in one launch, and given it no S)
     const Image &img = h->img;
     const DeviceImage &D = *h->dev;
-    const int GRID = getenv("HGX_SWEEP_GRID") ? std::max(256, atoi(getenv("HGX_SWEEP_GRID"))) : 8192; // (4096: 2-3 % slower, profiles/r06x_*)
+    const int GRID = sweepGrid();
     // (--noDupes: the parent's links to a genome of the path, by which k_sweep_down tells the segment that goes up)
     auto linksTo = [&](int p, int c) -> const int32_t * {
         if (!noDupes)
@@ -458,6 +464,8 @@ static bool columnsDepthSweep(hgx_alignment *h, int ref, int64_t first, int64_t 
     if (sum)
         hipLaunchKernelGGL(k_sweep_out<int32_t>, dim3(2048), dim3(256), 0, s, (const int32_t *)A[(size_t)ref].p, first, count, step,
                            mode == 2 || group > 0 ? 0 : 1, d_out, group > 0 ? 1 : 0);
+    else if (step == 1 && group == 0 && count >= 4096)
+        hipLaunchKernelGGL(k_sweep_out_bytes, dim3(std::min(4096, sweepGrid())), dim3(256), 0, s, (const uint8_t *)A[(size_t)ref].p, first, count, mode == 2 ? 0 : 1, d_out);
     else
         hipLaunchKernelGGL(k_sweep_out<uint8_t>, dim3(2048), dim3(256), 0, s, (const uint8_t *)A[(size_t)ref].p, first, count, step,
                            mode == 2 || group > 0 ? 0 : 1, d_out, group > 0 ? 1 : 0);

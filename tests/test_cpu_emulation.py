@@ -37,7 +37,7 @@ def emulation_lib(tmp_path_factory):
 
 
 def test_column_engine_on_the_host_side_emulation(emulation_lib):
-    env = dict(os.environ, HGX_LIB_PATH=emulation_lib, HGX_COL_GRID="4")
+    env = dict(os.environ, HGX_LIB_PATH=emulation_lib, HGX_COL_GRID="4", HGX_SWEEP_GRID="16")
     env.pop("HGX_MAF_SWEEP", None)
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + CASES, cwd=ROOT, env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT)

@@ -113,6 +113,60 @@ def test_config2_full_batch_through_the_three_plans(hal, cfg2_full):
     assert np.all((recs["tgt_end"] - recs["tgt_start"]) <= lens.numpy()[q])
 
 
+def test_config2_full_batch_scouts_list_and_inline(hal, cfg2_full, monkeypatch):
+    """round 6: the 1 M-interval batch through a plan whose general intervals are finished by scouts (the default for a batch that
+    runs by itself, from the second run on), by round 3's listed workers (HGX_LIFT_SCOUT=0) and inline (no workers): the same bytes;
+    and through two plans with a batch each in flight (inline there)."""
+    import torch
+    al = cfg2_full
+    src, tgt = al.genome_id("Genome_9"), al.genome_id("Genome_2")
+    _, seq_start, length = al.sequences(src)[0]
+    nq = 1000000
+    batches = []
+    for seed in (1234, 77):
+        starts, lens, strand = make_queries(length, nq, seed)
+        batches.append(((starts + seq_start).cuda(), (starts + lens - 1 + seq_start).cuda(), strand.cuda()))
+
+    def three_runs(plan):
+        out = None
+        for k in range(3):  # (the first run has no count of general intervals to go by: the later ones take the workers)
+            out = []
+            for b in batches:
+                ptr, nrec = plan.run(*b)
+                out.append(plan.records_to_tensor(ptr, nrec).cpu())
+        return out
+
+    inline = hal.LiftoverPlan(al, src, tgt, max_queries=nq)
+    inline.set_workers(0)
+    want = three_runs(inline)
+    assert inline.stats()["general_queries"] > 500
+    for scout in ("1", "0"):
+        monkeypatch.setenv("HGX_LIFT_SCOUT", scout)
+        plan = hal.LiftoverPlan(al, src, tgt, max_queries=nq)
+        got = three_runs(plan)
+        for a, b in zip(got, want):
+            assert torch.equal(a, b), scout
+    monkeypatch.delenv("HGX_LIFT_SCOUT")
+    plans = [hal.LiftoverPlan(al, src, tgt, max_queries=nq) for _ in range(2)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for p in plans:
+        for b in batches:
+            p.run(*b)
+    pending = [None, None]  # (the batch a plan has in flight)
+    for i in range(6):
+        k = i & 1
+        if pending[k] is not None:
+            ptr, nrec = plans[k].collect()
+            with torch.cuda.stream(streams[k]):
+                assert torch.equal(plans[k].records_to_tensor(ptr, nrec).cpu(), want[pending[k]]), i
+        pending[k] = (i >> 1) & 1
+        plans[k].submit(*batches[pending[k]], stream=streams[k])
+    for k in (0, 1):
+        ptr, nrec = plans[k].collect()
+        with torch.cuda.stream(streams[k]):
+            assert torch.equal(plans[k].records_to_tensor(ptr, nrec).cpu(), want[pending[k]])
+
+
 def test_config3_full_size_maf_properties(hal, cfg2_full):
     """hal2maf --refGenome Genome_9 --noAncestors over 3 M columns of the full-size alignment: every reference base is in exactly
     one block (the reference rows tile the range), rows of a block have equal text length, and the export of the range equals

@@ -471,6 +471,13 @@ def test_maf_tracks_at_full_size(hal, oracle_bin, tmp_path, monkeypatch):
     got_u = al.maf_export(src, 0, start=a + 1_000_000, length=200000, no_ancestors=True, unique=True)
     assert got_u == _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", "Genome_9", "--noAncestors", "--unique", "--refSequence", seq,
                             "--start", str(a + 1_000_000), "--length", "200000")
+    # --noDupes through the tracks (round 6; another set of tracks: the option is part of what they were built for)
+    text_n = _both_ways(al, monkeypatch, src, 0, start=a, length=1_000_000, no_ancestors=True, no_dupes=True)
+    assert text_n.count("\na") > 1000
+    monkeypatch.setenv("HGX_MAF_SWEEP", "1")
+    got_n = al.maf_export(src, 0, start=a + 500_000, length=100000, no_ancestors=True, no_dupes=True)
+    assert got_n == _oracle(oracle_bin, "maf", img, tmp_path, "--refGenome", "Genome_9", "--noAncestors", "--noDupes", "--refSequence", seq,
+                            "--start", str(a + 500_000), "--length", "100000")
     # ... and over the slices of hgx_maf_export_multi (an export each; the handle's tracks serve all of them)
     multi = hal.maf_export_multi([al], src, 0, start=a, length=ln, slice_size=500000, no_ancestors=True, unique=True)
     monkeypatch.setenv("HGX_MAF_SWEEP", "0")
