@@ -559,11 +559,15 @@ __device__ __forceinline__ void lift_wave_emit(const ComposedRec<C> *__restrict_
             // (one exchange per partner: a lane that is not in such a group shows the largest coordinate, which is in front of nobody —
             // with paralogs an interval's first base lies in twenty records and this loop was most of the kernel)
             const C key = inGroup ? tLo : LiftCoord<C>::MAXV;
-            for (int jj = 0; jj < span; ++jj) {
-                const int partner = (int)lo + jj;
-                const C pT = wave_pull<C>(key, partner & 63);
-                if (inGroup && (uint32_t)jj < oB && partner < 64 && pT < tLo)
-                    ++rank;
+            // (four partners a trip, their exchanges asked for together: one after the other every partner cost an LDS round trip —
+            // twenty of them a round on the 50-genome alignment, most of the kernel there)
+            for (int jj = 0; jj < span; jj += 4) {
+                const int p0 = (int)lo + jj, p1 = p0 + 1, p2 = p0 + 2, p3 = p0 + 3;
+                const C t0 = wave_pull<C>(key, p0 & 63), t1 = wave_pull<C>(key, p1 & 63), t2 = wave_pull<C>(key, p2 & 63), t3 = wave_pull<C>(key, p3 & 63);
+                if (inGroup) {
+                    rank += ((uint32_t)jj < oB && p0 < 64 && t0 < tLo ? 1u : 0u) + ((uint32_t)(jj + 1) < oB && p1 < 64 && t1 < tLo ? 1u : 0u) +
+                            ((uint32_t)(jj + 2) < oB && p2 < 64 && t2 < tLo ? 1u : 0u) + ((uint32_t)(jj + 3) < oB && p3 < 64 && t3 < tLo ? 1u : 0u);
+                }
             }
             if (inGroup)
                 pos = rank;
