@@ -505,7 +505,8 @@ template <typename C>
 __device__ __forceinline__ void lift_wave_emit(const ComposedRec<C> *__restrict__ recs, uint8_t *sStrip, const LiftIv<C> *sIv,
                                                const uint32_t *sOff, const int lane, const uint32_t b, const uint32_t p,
                                                const uint32_t totalSlots, const uint32_t firstQuery, const int64_t *__restrict__ tSeqStart,
-                                               const int64_t ss0, const bool oneSeq, hgx_record *__restrict__ out) {
+                                               const int64_t ss0, const bool oneSeq, hgx_record *__restrict__ out,
+                                               unsigned long long *sStage = nullptr) {
     const unsigned long long below = (1ull << lane) - 1ull;
     uint32_t windowBase = 0;
     bool haveWindow = false;
@@ -572,10 +573,29 @@ __device__ __forceinline__ void lift_wave_emit(const ComposedRec<C> *__restrict_
             if (inGroup)
                 pos = rank;
         }
+        // (sStage — HGX_LIFT_STAGED: a round's records are one span of the output — it is dense in input order — unless a general interval's
+        // lines lie between them: staged in LDS at their places and stored as the span it is, 8 bytes a lane and 512 a store,
+        // instead of 40-byte records 40 bytes apart.  sOff[64]: where the wavefront's lines end)
+        bool staged = false;
+        uint32_t roundStart = 0;
+        if (sStage) {
+            const unsigned long long st = __ballot(started);
+            const int qa = st ? __ffsll((long long)st) - 1 : 0;
+            roundStart = sOff[qa];
+            staged = em != 0 && sOff[qb] - roundStart == (uint32_t)__popcll(em);
+        }
         if (emit) {
             const uint32_t seq = r.mEncF >> 8;
             const int64_t ss = oneSeq ? ss0 : tSeqStart[seq];
             const uint32_t rev = trev ^ iv.minus();
+            if (staged) {
+                unsigned long long *w = sStage + (size_t)(oOff + pos - roundStart) * 5;
+                w[0] = (unsigned long long)(firstQuery + (uint32_t)owner);
+                w[1] = (unsigned long long)((int64_t)tLo - ss);
+                w[2] = (unsigned long long)((int64_t)tLo + n - ss);
+                w[3] = (unsigned long long)(int64_t)c;
+                w[4] = (unsigned long long)seq | ((unsigned long long)(uint8_t)(iv.dot() ? '.' : (rev ? '-' : '+')) << 32) | ((unsigned long long)rev << 40);
+            } else {
             hgx_record rec;
             rec.query = (int64_t)(firstQuery + (uint32_t)owner);
             rec.tgt_start = (int64_t)tLo - ss;
@@ -586,6 +606,15 @@ __device__ __forceinline__ void lift_wave_emit(const ComposedRec<C> *__restrict_
             rec.tgt_reversed = (uint8_t)rev;
             rec._pad[0] = rec._pad[1] = 0;
             out[oOff + pos] = rec;
+            }
+        }
+        if (staged) { // (wave-uniform)
+            wave_lds_fence();
+            const uint32_t words = (uint32_t)__popcll(em) * 5u;
+            unsigned long long *dst = (unsigned long long *)(out + roundStart);
+            for (uint32_t i = (uint32_t)lane; i < words; i += 64u)
+                dst[i] = sStage[i];
+            wave_lds_fence();
         }
         base = nextBase;
     }
@@ -603,10 +632,11 @@ static __global__ void __launch_bounds__(256, MINW) k_lift_merged(const int64_t 
                                                             const hgx_record *__restrict__ genRecords, hgx_record *__restrict__ out,
                                                             uint32_t outCap, const uint32_t *__restrict__ nOut, uint32_t *__restrict__ outOffset,
                                                             const uint32_t *__restrict__ waveTotal, const uint32_t *__restrict__ waveExtra,
-                                                            const unsigned long long *__restrict__ groupTotal, uint32_t nTiles) {
+                                                            const unsigned long long *__restrict__ groupTotal, uint32_t nTiles, int stagedStores) {
     __shared__ __attribute__((aligned(16))) uint8_t sStripAll[4][LIFT_STRIP];
     __shared__ LiftIv<C> sIvAll[4][64];
-    __shared__ uint32_t sOffAll[4][64];
+    __shared__ uint32_t sOffAll[4][65];
+    __shared__ unsigned long long sStageAll[4][64 * 5];
     __shared__ uint32_t sWaveTotal[4], sFront[4];
     const int lane = lane_id(), w = (int)(threadIdx.x >> 6);
     const int64_t ss0 = tSeqStart[0];
@@ -667,8 +697,10 @@ static __global__ void __launch_bounds__(256, MINW) k_lift_merged(const int64_t 
             // ---- the lines, at their final place ----
             const uint32_t lineOff = (uint32_t)tileBase + wavePrefix + (inclLines - cnt);
             sOffAll[w][lane] = lineOff; // (made visible to the wave by the fences in front of lift_wave_emit's first scatter)
+            if (lane == 63)
+                sOffAll[w][64] = lineOff + cnt;
             lift_wave_emit(recs, sStripAll[w], sIvAll[w], sOffAll[w], lane, b, p, totalSlots, tile * (uint32_t)LIFT_TILE + (uint32_t)(w << 6),
-                           tSeqStart, ss0, oneSeq, out);
+                           tSeqStart, ss0, oneSeq, out, stagedStores ? sStageAll[w] : nullptr);
             LIFT_PROF(2) // lines stored
             // general intervals: their records were made by the general path; copied in as 8-byte words
             unsigned long long gm = __ballot(general && cnt > 0);

@@ -660,13 +660,14 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
                        groupTotal, cap, (uint32_t *)P.total.p, cnt, generalCount, waveFinish ? restCount : (unsigned long long *)nullptr, workCounts,
                        storeLaunch, P.pinnedDev + CNT_SLOTS + 1);
     P.timer.end(s);
+    const int stagedStores = getenv("HGX_LIFT_STAGED") && getenv("HGX_LIFT_STAGED")[0] == '1' ? 1 : 0;
     P.timer.begin("k_lift_merged", s, launch);
 #define HGX_LIFT(W)                                                                                                                          \
     hipLaunchKernelGGL((k_lift_merged<C, W>), dim3(std::min<uint32_t>((uint32_t)P.liftGrid, nTiles)), dim3(256), 0, s, dS, dE, dStrand, nq,     \
                        (const uint2 *)P.liftKb.p, (const ComposedRec<C> *)T.mRecs, (const int64_t *)TG.seqStart, (int)TG.numSeq,             \
                        (const uint32_t *)P.offset.p, (const hgx_record *)P.grouped.p, (hgx_record *)P.outRecords.p, cap,                     \
                        (const uint32_t *)P.nOut.p, (uint32_t *)P.outOffset.p, waveTotal, workers ? (const uint32_t *)waveExtra : nullptr, groupTotal, \
-                       nTiles)
+                       nTiles, stagedStores)
     if (P.liftMinWaves == 8)
         HGX_LIFT(8);
     else
