@@ -660,7 +660,10 @@ static void runMergedOnce(hgx_liftover_plan &P, size_t n, const int64_t *dS, con
                        groupTotal, cap, (uint32_t *)P.total.p, cnt, generalCount, waveFinish ? restCount : (unsigned long long *)nullptr, workCounts,
                        storeLaunch, P.pinnedDev + CNT_SLOTS + 1);
     P.timer.end(s);
-    const int stagedStores = getenv("HGX_LIFT_STAGED") && getenv("HGX_LIFT_STAGED")[0] == '1' ? 1 : 0;
+    // a round's records staged in LDS and stored as the one span of the output they are (lift_wave_emit) — HGX_LIFT_STAGED=0: every
+    // record stored by its lane, 40 bytes 40 bytes apart (before round 6's last day; config 4's launch 0.50 -> 0.377 ms, its step 0.84 ->
+    // 0.71 ms; config 2's 0.053 -> 0.049 ms: profiles/r06ac_staged_stores.txt)
+    const int stagedStores = getenv("HGX_LIFT_STAGED") && getenv("HGX_LIFT_STAGED")[0] == '0' ? 0 : 1;
     P.timer.begin("k_lift_merged", s, launch);
 #define HGX_LIFT(W)                                                                                                                          \
     hipLaunchKernelGGL((k_lift_merged<C, W>), dim3(std::min<uint32_t>((uint32_t)P.liftGrid, nTiles)), dim3(256), 0, s, dS, dE, dStrand, nq,     \
