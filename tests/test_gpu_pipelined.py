@@ -155,3 +155,22 @@ def test_general_intervals_by_worker_workgroups(hal, monkeypatch):
     for _ in range(3):  # (the first run has no count to go by; the later ones do)
         for a, b in zip(run(plan), want):
             assert torch.equal(a, b)
+    # batches of changing sizes through one plan: the two sets of words the scouts count in alternate by batch, and a batch's tiles
+    # clear the other set only as far as the batch goes — a longer batch behind a shorter one finds words the plan has to clear
+    sizes = (70000, 20000, 70000, 33000, 17000, 70000)
+
+    def run_sizes(p):
+        out = []
+        for k, m in enumerate(sizes):
+            gs, ge, st = batches[k % 2]
+            ptr, nrec = p.run(gs[:m].contiguous(), ge[:m].contiguous(), st[:m].contiguous())
+            out.append(p.records_to_tensor(ptr, nrec).cpu())
+        return out
+
+    inline = hal.LiftoverPlan(al, src, tgt, max_queries=n)
+    inline.set_workers(0)
+    want_sizes = run_sizes(inline)
+    plan = hal.LiftoverPlan(al, src, tgt, max_queries=n)
+    run(plan)
+    for a, b in zip(run_sizes(plan), want_sizes):
+        assert torch.equal(a, b)
