@@ -942,6 +942,218 @@ static __global__ void __launch_bounds__(256) k_sweep_up_bytes(const BotRec<C> *
     }
 }
 #undef HGX_SEGS
+// ---- k_sweep_up_bytes' form for sets of 2, 4 and 8 bytes (round 6) ----
+// A lane's sixteen bytes are N = 16 / W bases of W-byte sets in two 64-bit words; a child's track has words of CW <= W bytes: its
+// N elements are loaded as N * CW bytes, turned round when the child lies the other way, widened to W bytes and moved to the child's
+// place in the parent's numbering by one masked shift.  8 * W lanes a segment (128 bases a round whatever the width), two segments
+// a lane group.
+template <int CW> __device__ __forceinline__ unsigned long long sweep_reverse_elems64(unsigned long long x) { // the 8 / CW elements of a word, back to front
+    if (CW == 8)
+        return x;
+    if (CW == 4)
+        return (x >> 32) | (x << 32);
+    x = __builtin_bswap64(x);
+    if (CW == 2)
+        x = ((x & 0xFF00FF00FF00FF00ull) >> 8) | ((x & 0x00FF00FF00FF00FFull) << 8);
+    return x;
+}
+template <int W> __device__ __forceinline__ unsigned long long sweep_replicate(unsigned long long v) { // a W-byte value in every W bytes of a word
+    return W == 1 ? 0x0101010101010101ull * (v & 0xFFull) : W == 2 ? 0x0001000100010001ull * (v & 0xFFFFull) : W == 4 ? 0x0000000100000001ull * (v & 0xFFFFFFFFull) : v;
+}
+// the N elements of a child's track (words of CW bytes; ts: the child segment's start) under the parent's bases o .. o + N - 1, in
+// the parent's order, widened to W bytes
+template <int W, int CW, typename O>
+__device__ __forceinline__ SweepW2 sweep_fetch_words(const uint8_t *__restrict__ T, int64_t ts, bool rev, O len, O o, bool whole) {
+    constexpr int N = 16 / W, CB = N * CW; // bases a lane; the child's bytes under them
+    SweepW2 x;
+    x.a = x.b = 0;
+    if (!whole) {
+#pragma nounroll
+        for (int j = 0; j < N && o + j < len; ++j) {
+            const int64_t at = (ts + (rev ? (int64_t)len - 1 - o - j : (int64_t)o + j)) * CW;
+            unsigned long long e = 0;
+            __builtin_memcpy(&e, T + at, CW);
+            if (j < N / 2)
+                x.a |= W == 8 ? e : e << ((8 * W * j) & 63);
+            else
+                x.b |= W == 8 ? e : e << ((8 * W * (j - N / 2)) & 63);
+        }
+        return x;
+    }
+    const uint8_t *at = T + (ts + (rev ? (int64_t)len - o - N : (int64_t)o)) * CW;
+    if (CB == 16) { // (CW == W: the child's words are the parent's)
+        x = sweep_load<SweepW2>(at);
+        if (rev) {
+            const unsigned long long t = sweep_reverse_elems64<CW>(x.a);
+            x.a = sweep_reverse_elems64<CW>(x.b);
+            x.b = t;
+        }
+        return x;
+    }
+    unsigned long long c = 0; // the child's N elements, CB <= 8 bytes
+    __builtin_memcpy(&c, at, CB);
+    if (rev) {
+        c = sweep_reverse_elems64<CW>(c);
+        c >>= 8 * (8 - CB); // (the elements were at the word's low end: turned round they are at its high end)
+    }
+    const unsigned long long em = CW == 8 ? ~0ull : ((1ull << (8 * CW)) - 1ull);
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const unsigned long long e = (c >> (8 * CW * j)) & em;
+        if (j < N / 2)
+            x.a |= e << ((8 * W * j) & 63);
+        else
+            x.b |= e << ((8 * W * (j - N / 2)) & 63);
+    }
+    return x;
+}
+template <int W> __device__ __forceinline__ unsigned long long sweep_shift_words(unsigned long long x, int shift) {
+    if (W == 8)
+        return x << shift;
+    const unsigned long long all = W == 1 ? 0xFFull : W == 2 ? 0xFFFFull : 0xFFFFFFFFull;
+    return (x & sweep_replicate<W>(all >> shift)) << shift;
+}
+// the sizes of a lane's N sets as N bytes (the low N bytes of the result)
+template <int W> __device__ __forceinline__ unsigned long long sweep_sizes_words(const SweepW2 &v) {
+    if (W == 8)
+        return (unsigned long long)__popcll(v.a) | ((unsigned long long)__popcll(v.b) << 8);
+    if (W == 4)
+        return (unsigned long long)__popc((unsigned)v.a) | ((unsigned long long)__popc((unsigned)(v.a >> 32)) << 8) |
+               ((unsigned long long)__popc((unsigned)v.b) << 16) | ((unsigned long long)__popc((unsigned)(v.b >> 32)) << 24);
+    // W == 2: per-byte counts, pairs of them added, the four 16-bit sums of a word packed into four bytes
+    unsigned long long r = 0;
+    const unsigned long long w[2] = {v.a, v.b};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        unsigned long long t = sweep_popcount_bytes(w[h]);
+        t = (t + (t >> 8)) & 0x00FF00FF00FF00FFull;
+        t = (t | (t >> 8)) & 0x0000FFFF0000FFFFull;
+        t = (t | (t >> 16)) & 0x00000000FFFFFFFFull;
+        r |= t << (32 * h);
+    }
+    return r;
+}
+template <typename C, int W, bool SIZES>
+static __global__ void __launch_bounds__(256) k_sweep_up_words(const BotRec<C> *__restrict__ bot, int64_t numBot, SweepChildren ch, unsigned long long own,
+                                                               int accumulate, uint8_t *__restrict__ S) {
+    static_assert(W == 2 || W == 4 || W == 8, "byte-wide sets: k_sweep_up_bytes");
+    constexpr int N = 16 / W;                      // bases a lane
+    constexpr int LPS_LOG = W == 2 ? 4 : W == 4 ? 5 : 6; // lanes a segment: 128 bases a round
+    constexpr int LPS = 1 << LPS_LOG;
+    const int sub = (int)(threadIdx.x & (LPS - 1));
+    const int64_t G = ((int64_t)gridDim.x * blockDim.x) >> LPS_LOG;
+    const int nKids = ch.n, noRing = ch.noRing;
+    const unsigned long long ownAll = sweep_replicate<W>(own);
+#define HGX_SEGS(X) X(s0) X(s1)
+    for (int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> LPS_LOG; b < numBot; b += 2 * G) {
+        SweepSeg<C> s0, s1;
+        const int64_t b_s0 = b, b_s1 = b + G;
+#define X(s)                                                                                                                                 \
+    s.start = s.len = 0;                                                                                                                     \
+    if (b_##s < numBot) {                                                                                                                    \
+        s.start = bot[b_##s].start;                                                                                                          \
+        s.len = (C)(bot[b_##s + 1].start - s.start);                                                                                         \
+    }
+        HGX_SEGS(X)
+#undef X
+        const C maxLen = s0.len > s1.len ? s0.len : s1.len;
+        for (C o0 = 0; o0 < maxLen; o0 += LPS * N) {
+#define X(s)                                                                                                                                 \
+    s.o = o0 + (C)(sub * N);                                                                                                                 \
+    s.act = s.o < s.len;                                                                                                                     \
+    if (s.act && s.o + N > s.len && s.len >= N)                                                                                              \
+        s.o = s.len - N; /* (the lane at the segment's end takes its last N bases: unions may be made twice) */                             \
+    s.whole = s.o + N <= s.len;                                                                                                              \
+    s.pv.a = s.pv.b = ownAll;                                                                                                                \
+    if (accumulate && s.act)                                                                                                                 \
+        s.pv = sweep_fetch_words<W, W, C>(S, (int64_t)s.start, false, s.len, s.o, s.whole);
+            HGX_SEGS(X)
+#undef X
+            for (int k = 0; k < nKids; ++k) {
+                const int32_t *encs = ch.c[k].enc;
+                const uint8_t *T = (const uint8_t *)ch.c[k].track;
+                const TopRec<C> *top = (const TopRec<C> *)ch.c[k].top;
+                const int shift = ch.c[k].shift, wlog = ch.c[k].wlog;
+                const unsigned long long cst = sweep_replicate<W>((unsigned long long)ch.c[k].constant);
+#define X(s) s.enc = s.act ? encs[b_##s] : -1;
+                HGX_SEGS(X)
+#undef X
+                if (!T) { // (a child without a track: the same set on every base below it)
+#define X(s)                                                                                                                                 \
+    if (s.enc >= 0) {                                                                                                                        \
+        s.pv.a |= cst;                                                                                                                       \
+        s.pv.b |= cst;                                                                                                                       \
+    }
+                    HGX_SEGS(X)
+#undef X
+                    continue;
+                }
+#define X(s)                                                                                                                                 \
+    s.tr.start = 0;                                                                                                                          \
+    s.tr.parentEnc = 0;                                                                                                                      \
+    s.tr.paralogy = -1;                                                                                                                      \
+    if (s.enc >= 0)                                                                                                                          \
+        s.tr = top[s.enc >> 1];
+                HGX_SEGS(X)
+#undef X
+                // a child's words are as wide as the parent's or narrower (its subtree is part of the parent's)
+#define HGX_FETCH(s, TR)                                                                                                                     \
+    (wlog == 0 ? sweep_fetch_words<W, 1, C>(T, (int64_t)(TR).start, ((TR).parentEnc & 1) != 0, s.len, s.o, s.whole)                          \
+     : wlog == 1 || W == 2 ? sweep_fetch_words<W, 2, C>(T, (int64_t)(TR).start, ((TR).parentEnc & 1) != 0, s.len, s.o, s.whole)             \
+     : wlog == 2 || W == 4 ? sweep_fetch_words<W, (W >= 4 ? 4 : W), C>(T, (int64_t)(TR).start, ((TR).parentEnc & 1) != 0, s.len, s.o, s.whole) \
+                           : sweep_fetch_words<W, W, C>(T, (int64_t)(TR).start, ((TR).parentEnc & 1) != 0, s.len, s.o, s.whole))
+#define X(s)                                                                                                                                 \
+    s.x.a = s.x.b = 0;                                                                                                                       \
+    if (s.enc >= 0)                                                                                                                          \
+        s.x = HGX_FETCH(s, s.tr);
+                HGX_SEGS(X)
+#undef X
+                // (behind the slot's segment the rest of its paralogy ring — updateNextTopDup, halColumnIterator.cpp:642-681: rare, link by link)
+#define X(s)                                                                                                                                 \
+    s.pv.a |= sweep_shift_words<W>(s.x.a, shift);                                                                                            \
+    s.pv.b |= sweep_shift_words<W>(s.x.b, shift);                                                                                            \
+    if (s.enc >= 0 && !noRing && s.tr.paralogy >= 0) {                                                                                       \
+        const int32_t t0 = s.enc >> 1;                                                                                                       \
+        for (int32_t t = s.tr.paralogy; t >= 0 && t != t0;) {                                                                                \
+            const TopRec<C> r = top[t];                                                                                                      \
+            const SweepW2 y = HGX_FETCH(s, r);                                                                                               \
+            s.pv.a |= sweep_shift_words<W>(y.a, shift);                                                                                      \
+            s.pv.b |= sweep_shift_words<W>(y.b, shift);                                                                                      \
+            t = r.paralogy;                                                                                                                  \
+        }                                                                                                                                    \
+    }
+                HGX_SEGS(X)
+#undef X
+#undef HGX_FETCH
+            }
+#define X(s)                                                                                                                                 \
+    if (s.act) {                                                                                                                             \
+        if (SIZES) {                                                                                                                         \
+            const unsigned long long z = sweep_sizes_words<W>(s.pv);                                                                         \
+            uint8_t *dst = S + (int64_t)s.start + s.o;                                                                                       \
+            if (s.whole) {                                                                                                                   \
+                __builtin_memcpy(dst, &z, N);                                                                                                \
+            } else {                                                                                                                         \
+                _Pragma("nounroll") for (int j = 0; j < N && s.o + j < s.len; ++j) dst[j] = (uint8_t)(z >> (8 * j));                         \
+            }                                                                                                                                \
+        } else {                                                                                                                             \
+            uint8_t *dst = S + ((int64_t)s.start + s.o) * W;                                                                                 \
+            if (s.whole) {                                                                                                                   \
+                sweep_store(dst, s.pv);                                                                                                      \
+            } else {                                                                                                                         \
+                _Pragma("nounroll") for (int j = 0; j < N && s.o + j < s.len; ++j) {                                                         \
+                    const unsigned long long e = W == 8 ? (j == 0 ? s.pv.a : s.pv.b) : ((j < N / 2 ? s.pv.a : s.pv.b) >> (8 * W * (j < N / 2 ? j : j - N / 2))); \
+                    __builtin_memcpy(dst + (size_t)j * W, &e, W);                                                                            \
+                }                                                                                                                            \
+            }                                                                                                                                \
+        }                                                                                                                                    \
+    }
+            HGX_SEGS(X)
+#undef X
+        }
+    }
+#undef HGX_SEGS
+}
 template <typename M, bool SUM> __device__ __forceinline__ int32_t track_size(M v) {
     return SUM ? (int32_t)v : (int32_t)__popcll((unsigned long long)v);
 }

@@ -172,6 +172,9 @@ static void sweepTracks(hgx_alignment *h, const std::vector<int> &postOrder, con
     const Image &img = h->img;
     const DeviceImage &D = *h->dev;
     const int GRID = sweepGrid();
+    // (k_sweep_up_words for the sets of 2, 4 and 8 bytes: HGX_SWEEP_WORDS=0 keeps the generic kernel, element by element)
+    const bool words = !SUM && !(getenv("HGX_SWEEP_WORDS") && getenv("HGX_SWEEP_WORDS")[0] == '0') &&
+                       !(getenv("HGX_SWEEP_AHEAD") && getenv("HGX_SWEEP_AHEAD")[0] == '0');
     // (--noDupes: the parent's links to a genome of the path, by which k_sweep_down tells the segment that goes up)
     auto linksTo = [&](int p, int c) -> const int32_t * {
         if (!noDupes)
@@ -213,15 +216,24 @@ static void sweepTracks(hgx_alignment *h, const std::vector<int> &postOrder, con
             if (!SUM && topSizes && g == path[0]) {
                 if (kids.size() > SWEEP_MAX_CHILDREN || sizeof(AT) != 1)
                     throw std::runtime_error("internal: sizes at the top of the scope are one launch's");
+#define HGX_UP_WORDS(W, SIZES, OUT)                                                                                                          \
+    hipLaunchKernelGGL((k_sweep_up_words<C, W, SIZES>), dim3(GRID), dim3(256), 0, s, (const BotRec<C> *)dg.bot, (int64_t)G.numBot, ch,        \
+                       (unsigned long long)tg.own, at ? 1 : 0, (uint8_t *)(OUT))
                 if (tg.wlog == 0)
                     hipLaunchKernelGGL((k_sweep_up_bytes<C, 2, true>), dim3(GRID), dim3(256), 0, s, (const BotRec<C> *)dg.bot, (int64_t)G.numBot, ch,
                                        (uint8_t)tg.own, 0, (uint8_t *)A[(size_t)g].p);
-                else if (tg.wlog == 1)
+                else if (!words && tg.wlog == 1)
                     HGX_UP_SIZES(uint16_t);
-                else if (tg.wlog == 2)
+                else if (!words && tg.wlog == 2)
                     HGX_UP_SIZES(uint32_t);
-                else
+                else if (!words)
                     HGX_UP_SIZES(unsigned long long);
+                else if (tg.wlog == 1)
+                    HGX_UP_WORDS(2, true, A[(size_t)g].p);
+                else if (tg.wlog == 2)
+                    HGX_UP_WORDS(4, true, A[(size_t)g].p);
+                else
+                    HGX_UP_WORDS(8, true, A[(size_t)g].p);
             } else if (SUM)
                 HGX_UP(int32_t);
             else if (tg.wlog == 0 && !(getenv("HGX_SWEEP_AHEAD") && getenv("HGX_SWEEP_AHEAD")[0] == '0'))
@@ -229,6 +241,12 @@ static void sweepTracks(hgx_alignment *h, const std::vector<int> &postOrder, con
                                    at ? 1 : 0, (uint8_t *)S[(size_t)g].p);
             else if (tg.wlog == 0)
                 HGX_UP(uint8_t);
+            else if (words && tg.wlog == 1)
+                HGX_UP_WORDS(2, false, S[(size_t)g].p);
+            else if (words && tg.wlog == 2)
+                HGX_UP_WORDS(4, false, S[(size_t)g].p);
+            else if (words)
+                HGX_UP_WORDS(8, false, S[(size_t)g].p);
             else if (tg.wlog == 1)
                 HGX_UP(uint16_t);
             else if (tg.wlog == 2)
@@ -237,6 +255,7 @@ static void sweepTracks(hgx_alignment *h, const std::vector<int> &postOrder, con
                 HGX_UP(unsigned long long);
 #undef HGX_UP
 #undef HGX_UP_SIZES
+#undef HGX_UP_WORDS
         }
     }
     // top-down along the path from the top of the scope to the reference (the top's own A is the size of its S: read from S)
