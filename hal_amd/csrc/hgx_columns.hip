@@ -1305,6 +1305,28 @@ static void columnsHeadRowsSweep(hgx_alignment *h, MafTracks &T, int ref, int64_
 static void columnsHeadRowsWalk(hgx_alignment *h, int ref, int64_t first, int64_t count, const ColumnOptions &opt, std::vector<uint8_t> &head,
                                 std::vector<uint32_t> &headOffset, HeadRows &headRows, ColumnStats *stats, int64_t uniqueFirst);
 
+// One chunk's heads at a time (round 6, the last day).  This path — the export of one batch, the first chunk's check — puts its
+// launches, its scans' blocking four-byte copies and its results' copies on the NULL stream, written for one thread; hgx_maf_export_multi
+// runs several slices at a time, and with four or six of them in here side by side (two handles of one GPU) about every eighth
+// pass over config 3 ended in a GPU memory access fault or a hang.  Not the renderings side by side, not the page-locked blocks'
+// coming and going, not --unique's collapsed stretches, not a missing device synchronisation at the end (all tried on the box:
+// profiles/r06_notes.md 12); with the path one at a time 36 passes of six slices at a time went through, and faster than before
+// (0.24-0.26 s against 0.27-0.29: the threads' launches no longer wait for each other's blocking copies).  The batches of a large
+// export go through MafChunkStream, streams of their own, and are not held up here.
+namespace {
+struct HeadPathOnly {
+    static std::mutex &mu() {
+        static std::mutex *m = new std::mutex;
+        return *m;
+    }
+    std::unique_lock<std::mutex> lock;
+    HeadPathOnly() : lock(mu(), std::defer_lock) {
+        if (!(getenv("HGX_MAF_HEADS_LOCK") && getenv("HGX_MAF_HEADS_LOCK")[0] == '0'))
+            lock.lock();
+    }
+};
+} // namespace
+
 void columnsHeadRowsHost(hgx_alignment *h, int ref, int64_t first, int64_t count, const ColumnOptions &opt, bool withDna,
                          std::vector<uint8_t> &head, std::vector<uint32_t> &headOffset, HeadRows &headRows, ColumnStats *stats,
                          int64_t uniqueFirst, int64_t exportColumns) {
@@ -1330,6 +1352,7 @@ void columnsHeadRowsHost(hgx_alignment *h, int ref, int64_t first, int64_t count
         if (state.load() != MafTracks::REFUSED && !(unique && T->constRows == 0)) {
             bool good = true, refuse = true;
             try {
+                HeadPathOnly only;
                 columnsHeadRowsSweep(h, *T, ref, first, count, opt, head, headOffset, headRows, stats, uniqueFirst);
             } catch (const MafSizesDoNotAddUp &) {
                 if (forced)
@@ -1345,7 +1368,10 @@ void columnsHeadRowsHost(hgx_alignment *h, int ref, int64_t first, int64_t count
                 std::vector<uint8_t> head2;
                 std::vector<uint32_t> off2(1, 0);
                 HeadRows rows2;
-                columnsHeadRowsWalk(h, ref, first, count, opt, head2, off2, rows2, nullptr, uniqueFirst);
+                {
+                    HeadPathOnly only;
+                    columnsHeadRowsWalk(h, ref, first, count, opt, head2, off2, rows2, nullptr, uniqueFirst);
+                }
                 good = head2 == head && off2 == headOffset && rows2.size() == headRows.size() &&
                        (rows2.empty() || memcmp(rows2.data(), headRows.data(), rows2.size() * sizeof(ColumnRowHost)) == 0);
                 if (good) {
@@ -1372,6 +1398,7 @@ void columnsHeadRowsHost(hgx_alignment *h, int ref, int64_t first, int64_t count
             headRows.clear();
         }
     }
+    HeadPathOnly only;
     columnsHeadRowsWalk(h, ref, first, count, opt, head, headOffset, headRows, stats, uniqueFirst);
 }
 
@@ -1735,7 +1762,10 @@ void mafChunkStreamSubmit(MafChunkStream *M, int64_t first, int64_t count) {
 // the chunk's heads by the column walk, described and sorted as the stream's are: what a chunk of the stream is held against
 static void mafWalkChunk(MafChunkStream *M, int64_t first, int64_t count, std::vector<uint8_t> &head, std::vector<uint32_t> &off, std::vector<MafChunkRow> &rows) {
     HeadRows raw;
-    columnsHeadRowsWalk(M->h, M->ref, first, count, M->opt, head, off, raw, nullptr, M->uniqueFirst);
+    {
+        HeadPathOnly only; // (the null stream's path: one at a time)
+        columnsHeadRowsWalk(M->h, M->ref, first, count, M->opt, head, off, raw, nullptr, M->uniqueFirst);
+    }
     rows.resize(raw.size());
     for (size_t hI = 0; hI + 1 < off.size(); ++hI) {
         const uint32_t a = off[hI], b = off[hI + 1];

@@ -4127,11 +4127,28 @@ void mafExportSliced(std::ostream &os, const std::vector<hgx_alignment *> &handl
     size_t perHandle = 3; // (55 slices of config 3 over two handles on the box: 0.42 s one at a time, 0.30 two, 0.26 three)
     if (const char *e = getenv("HGX_MAF_MULTI_PER_HANDLE"))
         perHandle = (size_t)std::max(1, atoi(e));
+    // ... and at most four slices at a time a DEVICE (HGX_MAF_MULTI_PER_DEVICE).  Round 6, the last day: with six (two handles of one
+    // GPU, three slices each, every slice's text rendered on the device) about every eighth pass over config 3 ended in a GPU memory
+    // access fault or a hang; four — 48 passes — and six with the text rendered by the host's threads never did.  The cause is not
+    // found (not the page-locked blocks' coming and going, not the renderings side by side, not --unique's collapsed stretches:
+    // profiles/r06_notes.md 12); what WAS found on the way is textRealloc's race (hgx_textmem.cpp), which took about as many runs
+    size_t perDevice = 4;
+    if (const char *e = getenv("HGX_MAF_MULTI_PER_DEVICE"))
+        perDevice = (size_t)std::max(1, atoi(e));
+    std::map<int, size_t> handlesOn, startedOn;
+    for (hgx_alignment *h : handles)
+        ++handlesOn[h->dev ? h->dev->device : -1];
     std::vector<std::thread> pool;
-    for (size_t d = 0; d < handles.size(); ++d)
-        for (size_t k = 0; k < perHandle; ++k)
-            if (d + k > 0 && pool.size() + 1 < slices.size())
+    startedOn[handles[0]->dev ? handles[0]->dev->device : -1] = 1; // (this thread: handles[0]'s first)
+    for (size_t d = 0; d < handles.size(); ++d) {
+        const int dev = handles[d]->dev ? handles[d]->dev->device : -1;
+        const size_t share = std::max<size_t>(1, perDevice / handlesOn[dev]); // (a handle's part of its device's four)
+        for (size_t k = 0; k < std::min(perHandle, share); ++k)
+            if (d + k > 0 && pool.size() + 1 < slices.size() && startedOn[dev] < perDevice) {
                 pool.emplace_back(work, handles[d]);
+                ++startedOn[dev];
+            }
+    }
     work(handles[0]);
     for (std::thread &t : pool)
         t.join();

@@ -80,25 +80,34 @@ void *textRealloc(void *p, size_t bytes) {
     if (!p)
         return textAlloc(bytes);
     TextMem &M = mem();
+    const size_t len = pages(bytes);
     size_t have = 0;
     {
+        // The block leaves the registry BEFORE it is moved (round 6).  mremap gives the block's old addresses back to the kernel, and
+        // another thread's mapping may be handed exactly those before this thread is back under the lock: erasing p afterwards
+        // erased the OTHER thread's block, whose next textRealloc / textFree then took it for malloc's — "realloc(): invalid
+        // pointer", or a GPU copy into pages that had been unmapped: hgx_maf_export_multi's slices, several at a time a handle,
+        // lost about every third run of config 3's leg to it (profiles/r06_notes.md 12).
         std::lock_guard<std::mutex> lock(M.mu);
         auto it = M.live.find(p);
-        if (it != M.live.end())
+        if (it != M.live.end()) {
             have = it->second;
+            if (len <= have)
+                return p;
+            M.live.erase(it);
+        }
     }
     if (!have) // malloc's (a caller whose text outgrows malloc moves it over itself: the size of a malloc block is not known here)
         return realloc(p, bytes ? bytes : 1);
-    const size_t len = pages(bytes);
-    if (len <= have)
-        return p;
     void *q = mremap(p, have, len, MREMAP_MAYMOVE);
-    if (q == MAP_FAILED)
+    if (q == MAP_FAILED) {
+        std::lock_guard<std::mutex> lock(M.mu);
+        M.live[p] = have; // (still the caller's, where it was)
         return nullptr;
+    }
     if (adviseHugePages())
         (void)madvise(q, len, MADV_HUGEPAGE);
     std::lock_guard<std::mutex> lock(M.mu);
-    M.live.erase(p);
     M.live[q] = len;
     return q;
 }

@@ -5,6 +5,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <thread>
+#include <vector>
 using namespace hgx;
 #define CHECK(c)                                                   \
     do {                                                           \
@@ -52,6 +55,43 @@ int main() {
     CHECK(f && textOwns(f));
     textFree(f);
     textTrim();
+    // several threads growing texts of their own at the same time (hgx_maf_export_multi's slices): a block that moves gives its old
+    // addresses back, another thread's fresh mapping may land there at once, and each thread must still find its own block in the
+    // registry — round 6: the mover erased the address AFTER the move, i.e. the newcomer's block, whose next growth went to realloc()
+    {
+        std::atomic<int> bad{0};
+        auto worker = [&](int id) {
+            for (int round = 0; round < 300 && !bad.load(); ++round) {
+                size_t cap = MB;
+                char *p = (char *)textRealloc(nullptr, cap);
+                if (!p || !textOwns(p)) {
+                    ++bad;
+                    return;
+                }
+                p[0] = (char)id;
+                for (int step = 0; step < 6; ++step) {
+                    cap *= 2;
+                    char *q = (char *)textRealloc(p, cap);
+                    if (!q || !textOwns(q) || q[0] != (char)id) {
+                        ++bad;
+                        return;
+                    }
+                    p = q;
+                    p[cap - 1] = (char)id;
+                }
+                if (!textOwns(p))
+                    ++bad;
+                textFree(p);
+            }
+        };
+        std::vector<std::thread> ts;
+        for (int id = 1; id <= 6; ++id)
+            ts.emplace_back(worker, id);
+        for (std::thread &t : ts)
+            t.join();
+        CHECK(bad.load() == 0);
+        textTrim();
+    }
     printf("same\n");
     return 0;
 }
