@@ -1033,10 +1033,17 @@ template <int W> __device__ __forceinline__ unsigned long long sweep_sizes_words
     }
     return r;
 }
-template <typename C, int W, bool SIZES>
+// two 32-bit sums side by side in a word, added without a carry between them
+__device__ __forceinline__ unsigned long long sweep_add32x2(unsigned long long a, unsigned long long b) {
+    return (unsigned long long)((uint32_t)a + (uint32_t)b) | ((unsigned long long)((uint32_t)(a >> 32) + (uint32_t)(b >> 32)) << 32);
+}
+// SUM (W = 4): the words are counts of bases, joined by adding (--countDupes, hal2maf's tracks): a child's words are counts too, a child
+// without a track adds its constant once for the slot's segment and once for every other member of its paralogy ring
+template <typename C, int W, bool SIZES, bool SUM = false>
 static __global__ void __launch_bounds__(256) k_sweep_up_words(const BotRec<C> *__restrict__ bot, int64_t numBot, SweepChildren ch, unsigned long long own,
                                                                int accumulate, uint8_t *__restrict__ S) {
     static_assert(W == 2 || W == 4 || W == 8, "byte-wide sets: k_sweep_up_bytes");
+    static_assert(!SUM || (W == 4 && !SIZES), "sums are 32-bit counts");
     constexpr int N = 16 / W;                      // bases a lane
     constexpr int LPS_LOG = W == 2 ? 4 : W == 4 ? 5 : 6; // lanes a segment: 128 bases a round
     constexpr int LPS = 1 << LPS_LOG;
@@ -1061,8 +1068,9 @@ static __global__ void __launch_bounds__(256) k_sweep_up_words(const BotRec<C> *
 #define X(s)                                                                                                                                 \
     s.o = o0 + (C)(sub * N);                                                                                                                 \
     s.act = s.o < s.len;                                                                                                                     \
-    if (s.act && s.o + N > s.len && s.len >= N)                                                                                              \
-        s.o = s.len - N; /* (the lane at the segment's end takes its last N bases: unions may be made twice) */                             \
+    if (s.act && !(SUM && accumulate) && s.o + N > s.len && s.len >= N)                                                                      \
+        s.o = s.len - N; /* (the lane at the segment's end takes its last N bases: unions may be made twice — sums added to what an      \
+                            earlier launch left may not: k_sweep_up) */                                                                     \
     s.whole = s.o + N <= s.len;                                                                                                              \
     s.pv.a = s.pv.b = ownAll;                                                                                                                \
     if (accumulate && s.act)                                                                                                                 \
@@ -1078,7 +1086,7 @@ static __global__ void __launch_bounds__(256) k_sweep_up_words(const BotRec<C> *
 #define X(s) s.enc = s.act ? encs[b_##s] : -1;
                 HGX_SEGS(X)
 #undef X
-                if (!T) { // (a child without a track: the same set on every base below it)
+                if (!T && !SUM) { // (a child without a track: the same set on every base below it)
 #define X(s)                                                                                                                                 \
     if (s.enc >= 0) {                                                                                                                        \
         s.pv.a |= cst;                                                                                                                       \
@@ -1104,21 +1112,39 @@ static __global__ void __launch_bounds__(256) k_sweep_up_words(const BotRec<C> *
                            : sweep_fetch_words<W, W, C>(T, (int64_t)(TR).start, ((TR).parentEnc & 1) != 0, s.len, s.o, s.whole))
 #define X(s)                                                                                                                                 \
     s.x.a = s.x.b = 0;                                                                                                                       \
-    if (s.enc >= 0)                                                                                                                          \
-        s.x = HGX_FETCH(s, s.tr);
+    if (s.enc >= 0) {                                                                                                                        \
+        if (SUM && !T)                                                                                                                       \
+            s.x.a = s.x.b = cst;                                                                                                             \
+        else                                                                                                                                 \
+            s.x = HGX_FETCH(s, s.tr);                                                                                                        \
+    }
                 HGX_SEGS(X)
 #undef X
                 // (behind the slot's segment the rest of its paralogy ring — updateNextTopDup, halColumnIterator.cpp:642-681: rare, link by link)
 #define X(s)                                                                                                                                 \
-    s.pv.a |= sweep_shift_words<W>(s.x.a, shift);                                                                                            \
-    s.pv.b |= sweep_shift_words<W>(s.x.b, shift);                                                                                            \
+    if (SUM) {                                                                                                                               \
+        s.pv.a = sweep_add32x2(s.pv.a, s.x.a);                                                                                               \
+        s.pv.b = sweep_add32x2(s.pv.b, s.x.b);                                                                                               \
+    } else {                                                                                                                                 \
+        s.pv.a |= sweep_shift_words<W>(s.x.a, shift);                                                                                        \
+        s.pv.b |= sweep_shift_words<W>(s.x.b, shift);                                                                                        \
+    }                                                                                                                                        \
     if (s.enc >= 0 && !noRing && s.tr.paralogy >= 0) {                                                                                       \
         const int32_t t0 = s.enc >> 1;                                                                                                       \
         for (int32_t t = s.tr.paralogy; t >= 0 && t != t0;) {                                                                                \
             const TopRec<C> r = top[t];                                                                                                      \
-            const SweepW2 y = HGX_FETCH(s, r);                                                                                               \
-            s.pv.a |= sweep_shift_words<W>(y.a, shift);                                                                                      \
-            s.pv.b |= sweep_shift_words<W>(y.b, shift);                                                                                      \
+            SweepW2 y;                                                                                                                       \
+            if (SUM && !T)                                                                                                                   \
+                y.a = y.b = cst;                                                                                                             \
+            else                                                                                                                             \
+                y = HGX_FETCH(s, r);                                                                                                         \
+            if (SUM) {                                                                                                                       \
+                s.pv.a = sweep_add32x2(s.pv.a, y.a);                                                                                         \
+                s.pv.b = sweep_add32x2(s.pv.b, y.b);                                                                                         \
+            } else {                                                                                                                         \
+                s.pv.a |= sweep_shift_words<W>(y.a, shift);                                                                                  \
+                s.pv.b |= sweep_shift_words<W>(y.b, shift);                                                                                  \
+            }                                                                                                                                \
             t = r.paralogy;                                                                                                                  \
         }                                                                                                                                    \
     }

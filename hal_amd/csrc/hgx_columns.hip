@@ -173,8 +173,9 @@ static void sweepTracks(hgx_alignment *h, const std::vector<int> &postOrder, con
     const DeviceImage &D = *h->dev;
     const int GRID = sweepGrid();
     // (k_sweep_up_words for the sets of 2, 4 and 8 bytes: HGX_SWEEP_WORDS=0 keeps the generic kernel, element by element)
-    const bool words = !SUM && !(getenv("HGX_SWEEP_WORDS") && getenv("HGX_SWEEP_WORDS")[0] == '0') &&
-                       !(getenv("HGX_SWEEP_AHEAD") && getenv("HGX_SWEEP_AHEAD")[0] == '0');
+    const bool wordsAsked = !(getenv("HGX_SWEEP_WORDS") && getenv("HGX_SWEEP_WORDS")[0] == '0') &&
+                            !(getenv("HGX_SWEEP_AHEAD") && getenv("HGX_SWEEP_AHEAD")[0] == '0');
+    const bool words = !SUM && wordsAsked, wordsSum = SUM && wordsAsked;
     // (--noDupes: the parent's links to a genome of the path, by which k_sweep_down tells the segment that goes up)
     auto linksTo = [&](int p, int c) -> const int32_t * {
         if (!noDupes)
@@ -234,7 +235,10 @@ static void sweepTracks(hgx_alignment *h, const std::vector<int> &postOrder, con
                     HGX_UP_WORDS(4, true, A[(size_t)g].p);
                 else
                     HGX_UP_WORDS(8, true, A[(size_t)g].p);
-            } else if (SUM)
+            } else if (SUM && wordsSum)
+                hipLaunchKernelGGL((k_sweep_up_words<C, 4, false, true>), dim3(GRID), dim3(256), 0, s, (const BotRec<C> *)dg.bot, (int64_t)G.numBot, ch,
+                                   (unsigned long long)(uint32_t)tg.own, at ? 1 : 0, (uint8_t *)S[(size_t)g].p);
+            else if (SUM)
                 HGX_UP(int32_t);
             else if (tg.wlog == 0 && !(getenv("HGX_SWEEP_AHEAD") && getenv("HGX_SWEEP_AHEAD")[0] == '0'))
                 hipLaunchKernelGGL((k_sweep_up_bytes<C, 2>), dim3(GRID), dim3(256), 0, s, (const BotRec<C> *)dg.bot, (int64_t)G.numBot, ch, (uint8_t)tg.own,
