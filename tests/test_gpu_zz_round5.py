@@ -484,6 +484,28 @@ def test_maf_tracks_at_full_size(hal, oracle_bin, tmp_path, monkeypatch):
     assert multi == hal.maf_export_multi([al], src, 0, start=a, length=ln, slice_size=500000, no_ancestors=True, unique=True)
 
 
+def test_export_multi_again_and_again(hal):
+    """hgx_maf_export_multi's slices run several at a time (four a device): texts that grow by mremap side by side (textRealloc's
+    registry: round 6 found a moving block's old address erased after another thread had been handed it) and the null-stream path of
+    a one-batch export's heads, which is entered one chunk at a time.  Twelve passes over a genome of 5 M columns in slices of 100 k,
+    two handles of this GPU: the same text every time, and the text of one slice at a time a handle."""
+    al = hal.Alignment.random(workload_options(0.1, "cfg2", dna="fast"), device=0)
+    src = al.genome_id("Genome_9")
+    n = al.genome_length(src)
+    clones = [al, al.clone_to_device(0)]
+    os.environ["HGX_MAF_MULTI_PER_HANDLE"] = "1"
+    try:
+        want = hal.maf_export_multi([al], src, 0, start=0, length=n, slice_size=100000, no_ancestors=True, unique=True)
+    finally:
+        del os.environ["HGX_MAF_MULTI_PER_HANDLE"]
+    assert want.count("\na") > n // 400
+    for rep in range(12):
+        if rep % 3 == 0:  # (the tracks built again, by the first slices of a pass, side by side on the two handles)
+            for c in clones:
+                c.maf_tracks_info(drop=True)
+        assert hal.maf_export_multi(clones, src, 0, start=0, length=n, slice_size=100000, no_ancestors=True, unique=True) == want, rep
+
+
 def test_hal2maf_over_the_ranks_of_a_node_every_rank_a_writer(hal, tmp_path):
     """hal_amd.maf_mp (hal2mafMP.py's slices, a contiguous run of them a rank, the ranks write side by side): the file is
     hgx_maf_export_multi's with the same slice size — one rank in process, two and three processes through the launcher on this one
