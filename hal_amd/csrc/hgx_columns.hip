@@ -1215,6 +1215,12 @@ static void columnsHeadRowsSweep(hgx_alignment *h, MafTracks &T, int ref, int64_
         hipLaunchKernelGGL((k_maf_rows<int32_t>), dim3(std::max(rowGrid, 1)), dim3(256), 0, nullptr, M, (ColumnRow *)dRows.p);
     uint32_t nHeads = 0, totalHeadRows = 0;
     Buf dHead(n), dHeadOffset, dOut;
+    // (The blocks of both branches below live to the end of the function — round 6, the last day.  They were the branches' own, and a
+    // branch ends with a LAUNCH: its blocks went back to the device cache while k_unique_gather / k_maf_gather were still reading them,
+    // and another thread — a slice of hgx_maf_export_multi beside this one, asking for blocks of exactly these sizes — got them and
+    // wrote into them: wild offsets, a GPU memory access fault every few passes.  One thread alone never saw it: its own next use of such
+    // a block is queued behind the kernel.  A block is released behind a blocking copy, never behind a launch.)
+    Buf dSegCnt, dSegOff, dSeg, dUnits, dUnitRows, dUnitOff, dUnitRowOff, dSums2, dIsHead, dHeadCnt, dHeadIdx, dHeadRowOff;
     HIP_OK(hipMemsetAsync(dHead.p, 0, n, nullptr));
     if (uniqueFirst >= 0) {
         if (uniqueFirst > first)
@@ -1235,7 +1241,8 @@ static void columnsHeadRowsSweep(hgx_alignment *h, MafTracks &T, int ref, int64_
         // (the chunk that is held against the column walk keeps the walk's form: every such column's rows)
         U.collapseKeysOnly = T.stateUnique.load() == MafTracks::CHECKED && !(getenv("HGX_MAF_UNIQUE_COLLAPSE") && getenv("HGX_MAF_UNIQUE_COLLAPSE")[0] == '0') ? 1 : 0;
         const int candGrid = (int)std::max<int64_t>(1, std::min<int64_t>(GRID, ((int64_t)nCand + 255) / 256));
-        Buf dSegCnt((size_t)nCand * 4), dSegOff(((size_t)nCand + 1) * 4);
+        dSegCnt.resize((size_t)nCand * 4);
+        dSegOff.resize(((size_t)nCand + 1) * 4);
         hipLaunchKernelGGL(k_unique_count, dim3(candGrid), dim3(256), 0, nullptr, U, (uint32_t *)dSegCnt.p);
         const uint32_t nSeg = deviceScan((const uint32_t *)dSegCnt.p, nCand, (uint32_t *)dSegOff.p, (uint32_t *)dSums.p);
         {
@@ -1244,8 +1251,12 @@ static void columnsHeadRowsSweep(hgx_alignment *h, MafTracks &T, int ref, int64_
             if (early == 3 || nSeg == 0)
                 throw MafUniqueNeedsTheWalk();
         }
-        Buf dSeg(std::max<size_t>(nSeg, 1) * sizeof(UniqueSeg)), dUnits(std::max<size_t>(nSeg, 1) * 4), dUnitRows(std::max<size_t>(nSeg, 1) * 4),
-            dUnitOff(((size_t)nSeg + 1) * 4), dUnitRowOff(((size_t)nSeg + 1) * 4), dSums2(((size_t)nSeg / SCAN_BLOCK + 2) * 4);
+        dSeg.resize(std::max<size_t>(nSeg, 1) * sizeof(UniqueSeg));
+        dUnits.resize(std::max<size_t>(nSeg, 1) * 4);
+        dUnitRows.resize(std::max<size_t>(nSeg, 1) * 4);
+        dUnitOff.resize(((size_t)nSeg + 1) * 4);
+        dUnitRowOff.resize(((size_t)nSeg + 1) * 4);
+        dSums2.resize(((size_t)nSeg / SCAN_BLOCK + 2) * 4);
         hipLaunchKernelGGL(k_unique_stretches, dim3(candGrid), dim3(256), 0, nullptr, U, (const uint32_t *)dSegOff.p, (UniqueSeg *)dSeg.p);
         const int segGrid = (int)std::max<int64_t>(1, std::min<int64_t>(GRID, ((int64_t)nSeg + 255) / 256));
         hipLaunchKernelGGL(k_unique_units, dim3(segGrid), dim3(256), 0, nullptr, U, (const UniqueSeg *)dSeg.p, nSeg, (uint32_t *)dUnits.p,
@@ -1259,7 +1270,10 @@ static void columnsHeadRowsSweep(hgx_alignment *h, MafTracks &T, int ref, int64_
                            (const uint32_t *)dUnitOff.p, (const uint32_t *)dUnitRowOff.p, (uint8_t *)dHead.p, (uint32_t *)dHeadOffset.p,
                            (ColumnRow *)dOut.p);
     } else {
-        Buf dIsHead((size_t)nCand * 4), dHeadCnt((size_t)nCand * 4), dHeadIdx(((size_t)nCand + 1) * 4), dHeadRowOff(((size_t)nCand + 1) * 4);
+        dIsHead.resize((size_t)nCand * 4);
+        dHeadCnt.resize((size_t)nCand * 4);
+        dHeadIdx.resize(((size_t)nCand + 1) * 4);
+        dHeadRowOff.resize(((size_t)nCand + 1) * 4);
         hipLaunchKernelGGL(k_maf_heads, dim3(GRID), dim3(256), 0, nullptr, (const uint32_t *)dCandCol.p, (const uint32_t *)dCandRow.p,
                            (const ColumnRow *)dRows.p, nCand, (uint32_t *)dIsHead.p, (uint32_t *)dHeadCnt.p);
         nHeads = deviceScan((const uint32_t *)dIsHead.p, nCand, (uint32_t *)dHeadIdx.p, (uint32_t *)dSums.p);
@@ -1310,12 +1324,13 @@ static void columnsHeadRowsWalk(hgx_alignment *h, int ref, int64_t first, int64_
                                 std::vector<uint32_t> &headOffset, HeadRows &headRows, ColumnStats *stats, int64_t uniqueFirst);
 
 // One chunk's heads at a time (round 6, the last day).  This path — the export of one batch, the first chunk's check — puts its
-// launches, its scans' blocking four-byte copies and its results' copies on the NULL stream, written for one thread; hgx_maf_export_multi
-// runs several slices at a time, and with four or six of them in here side by side (two handles of one GPU) about every eighth
-// pass over config 3 ended in a GPU memory access fault or a hang.  Not the renderings side by side, not the page-locked blocks'
-// coming and going, not --unique's collapsed stretches, not a missing device synchronisation at the end (all tried on the box:
-// profiles/r06_notes.md 12); with the path one at a time 36 passes of six slices at a time went through, and faster than before
-// (0.24-0.26 s against 0.27-0.29: the threads' launches no longer wait for each other's blocking copies).  The batches of a large
+// launches, its scans' blocking four-byte copies and its results' copies on the NULL stream and was written for one thread;
+// hgx_maf_export_multi runs several slices at a time.  With four or six of them in here side by side about every eighth pass over
+// config 3 ended in a GPU memory access fault or a hang; with the path one at a time none did, and the passes were no slower (the
+// threads no longer wait for each other's blocking copies).  The cause, found a few hours later (profiles/r06_notes.md 12):
+// columnsHeadRowsSweep released the blocks of its two branches behind a LAUNCH instead of behind a blocking copy, and a neighbour
+// asking for blocks of the same sizes got them while the kernel was still reading — mended there.  The lock stays: it costs nothing,
+// and the path's other assumptions of being alone on the null stream have only ever been tested with it.  The batches of a large
 // export go through MafChunkStream, streams of their own, and are not held up here.
 namespace {
 struct HeadPathOnly {

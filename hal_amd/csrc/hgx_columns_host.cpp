@@ -4127,11 +4127,10 @@ void mafExportSliced(std::ostream &os, const std::vector<hgx_alignment *> &handl
     size_t perHandle = 3; // (55 slices of config 3 over two handles on the box: 0.42 s one at a time, 0.30 two, 0.26 three)
     if (const char *e = getenv("HGX_MAF_MULTI_PER_HANDLE"))
         perHandle = (size_t)std::max(1, atoi(e));
-    // ... and at most four slices at a time a DEVICE (HGX_MAF_MULTI_PER_DEVICE).  Round 6, the last day: with six (two handles of one
-    // GPU, three slices each, every slice's text rendered on the device) about every eighth pass over config 3 ended in a GPU memory
-    // access fault or a hang; four — 48 passes — and six with the text rendered by the host's threads never did.  The cause is not
-    // found (not the page-locked blocks' coming and going, not the renderings side by side, not --unique's collapsed stretches:
-    // profiles/r06_notes.md 12); what WAS found on the way is textRealloc's race (hgx_textmem.cpp), which took about as many runs
+    // ... and at most four slices at a time a DEVICE (HGX_MAF_MULTI_PER_DEVICE): beyond that the slices' device stages and renderings
+    // only queue behind each other (0.25-0.27 s for config 3's 55 slices with four as with six).  (Round 6, the last day: about every
+    // third run of config 3's leg was lost in here — to textRealloc's race, hgx_textmem.cpp, and to device blocks released behind a
+    // launch in columnsHeadRowsSweep, hgx_columns.hip: profiles/r06_notes.md 12)
     size_t perDevice = 4;
     if (const char *e = getenv("HGX_MAF_MULTI_PER_DEVICE"))
         perDevice = (size_t)std::max(1, atoi(e));
